@@ -1,0 +1,210 @@
+"""Interned (integer-world) containers handed to the C-ABI: node SoA columns, pod-spec constants
+and lookup tables, and the scheduler profile.
+
+These are plain numpy holders -- plumbing between Python callers (tests, bench.py) and
+``include/ccsim.h``.  Column order everywhere: 0 = cpu (milli), 1 = memory, 2 = ephemeral-storage,
+3+k = scalar/extended resource k  (reference: vendor/k8s.io/kubernetes/pkg/scheduler/framework/types.go:940-950).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+MAX_SCALAR = 8
+MAX_RES = 3 + MAX_SCALAR
+MAX_TSC = 8
+
+# filter plugin bits, default order (apis/config/v1/default_plugins.go:30-58)
+F_UNSCHEDULABLE = 1 << 0
+F_NODENAME = 1 << 1
+F_TAINT = 1 << 2
+F_NODEAFFINITY = 1 << 3
+F_FIT = 1 << 4
+F_TOPOLOGYSPREAD = 1 << 5
+F_ALL = F_UNSCHEDULABLE | F_NODENAME | F_TAINT | F_NODEAFFINITY | F_FIT | F_TOPOLOGYSPREAD
+
+# reason slots of the terminal histogram
+R_UNSCHEDULABLE = 0
+R_NODENAME = 1
+R_NODEAFFINITY = 2
+R_TOO_MANY_PODS = 3
+R_RES0 = 4
+R_PTS_MISSING_LABEL = R_RES0 + MAX_RES
+R_PTS_SKEW = R_PTS_MISSING_LABEL + 1
+NREASON = R_PTS_SKEW + 1
+
+STOP_UNSCHEDULABLE = 0
+STOP_LIMIT = 1
+STOP_NO_NODES = 2
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+@dataclass
+class NodesSoA:
+    """Structure-of-arrays snapshot of NodeInfo (types.go:160-200) in canonical node order
+    (backend/cache/node_tree.go:119-143)."""
+
+    alloc: List[np.ndarray]  # [3 + n_scalar] int64[n]
+    alloc_pods: np.ndarray  # int32[n]
+    req: List[np.ndarray]  # [3 + n_scalar] int64[n]   Requested
+    nz_mcpu: np.ndarray  # int64[n]  NonZeroRequested.MilliCPU
+    nz_mem: np.ndarray  # int64[n]
+    pod_count: np.ndarray  # int32[n]  len(NodeInfo.Pods)
+    taintset_id: np.ndarray  # int32[n]
+    unschedulable: np.ndarray  # uint8[n]
+    label_cols: List[np.ndarray] = field(default_factory=list)  # int32[n] value ids, 0 = absent
+    # optional string side (never crosses the ABI)
+    names: Optional[List[str]] = None
+    scalar_names: List[str] = field(default_factory=list)
+
+    def __post_init__(self):
+        self.alloc = [_i64(a) for a in self.alloc]
+        self.req = [_i64(a) for a in self.req]
+        self.alloc_pods = _i32(self.alloc_pods)
+        self.nz_mcpu = _i64(self.nz_mcpu)
+        self.nz_mem = _i64(self.nz_mem)
+        self.pod_count = _i32(self.pod_count)
+        self.taintset_id = _i32(self.taintset_id)
+        self.unschedulable = _u8(self.unschedulable)
+        self.label_cols = [_i32(c) for c in self.label_cols]
+        assert len(self.alloc) == len(self.req) and len(self.alloc) >= 3
+
+    @property
+    def n(self) -> int:
+        return int(self.alloc_pods.shape[0])
+
+    @property
+    def n_scalar(self) -> int:
+        return len(self.alloc) - 3
+
+    def copy(self) -> "NodesSoA":
+        return NodesSoA(
+            alloc=[a.copy() for a in self.alloc],
+            alloc_pods=self.alloc_pods.copy(),
+            req=[a.copy() for a in self.req],
+            nz_mcpu=self.nz_mcpu.copy(),
+            nz_mem=self.nz_mem.copy(),
+            pod_count=self.pod_count.copy(),
+            taintset_id=self.taintset_id.copy(),
+            unschedulable=self.unschedulable.copy(),
+            label_cols=[c.copy() for c in self.label_cols],
+            names=self.names,
+            scalar_names=list(self.scalar_names),
+        )
+
+    def slice(self, lo: int, hi: int) -> "NodesSoA":
+        """Contiguous node-range shard [lo, hi) (multi-GPU partitioning)."""
+        s = slice(lo, hi)
+        return NodesSoA(
+            alloc=[a[s] for a in self.alloc],
+            alloc_pods=self.alloc_pods[s],
+            req=[a[s] for a in self.req],
+            nz_mcpu=self.nz_mcpu[s],
+            nz_mem=self.nz_mem[s],
+            pod_count=self.pod_count[s],
+            taintset_id=self.taintset_id[s],
+            unschedulable=self.unschedulable[s],
+            label_cols=[c[s] for c in self.label_cols],
+            names=self.names[lo:hi] if self.names else None,
+            scalar_names=list(self.scalar_names),
+        )
+
+
+# A requirement is (label column index, uint8 table over the column's value ids incl. 0 = absent)
+Requirement = Tuple[int, np.ndarray]
+
+
+@dataclass
+class SpreadConstraint:
+    """One topologySpreadConstraint after interning (podtopologyspread/common.go:42-56)."""
+
+    col: int
+    max_skew: int
+    min_domains: int = 1
+    hard: bool = True  # DoNotSchedule
+    self_match: bool = True
+    is_hostname: bool = False
+    n_domains: int = 0
+    node_match_count: Optional[np.ndarray] = None  # int32[n] existing matching pods per node
+    node_included: Optional[np.ndarray] = None  # uint8[n] node inclusion policies
+
+
+@dataclass
+class PodSpec:
+    """Pod-side constants precomputed on the host."""
+
+    req: np.ndarray  # int64[3 + n_scalar]
+    nz_mcpu: int
+    nz_mem: int
+    has_scalar_entries: bool = False
+    taint_filter_ok: np.ndarray = field(default_factory=lambda: np.ones(1, np.uint8))
+    taint_prefer_cnt: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
+    tolerates_unschedulable: bool = False
+    affinity_filter_active: bool = False
+    has_node_selector: bool = False
+    node_selector: List[Requirement] = field(default_factory=list)
+    has_required_terms: bool = False
+    required: List[List[Requirement]] = field(default_factory=list)
+    preferred: List[Tuple[int, List[Requirement]]] = field(default_factory=list)  # (weight, term)
+    spread: List[SpreadConstraint] = field(default_factory=list)
+
+    def __post_init__(self):
+        self.req = _i64(self.req)
+        self.taint_filter_ok = _u8(self.taint_filter_ok)
+        self.taint_prefer_cnt = _i32(self.taint_prefer_cnt)
+
+
+@dataclass
+class Profile:
+    """The scheduler profile: enabled filters, score weights, plugin args
+    (apis/config/v1/default_plugins.go:30-58, defaults.go:33-36,229-245)."""
+
+    filter_mask: int = F_ALL
+    w_taint: int = 3
+    w_nodeaffinity: int = 2
+    w_fit: int = 1
+    w_balanced: int = 1
+    w_topologyspread: int = 2
+    fit_res: Tuple[int, ...] = (0, 1)
+    fit_res_w: Tuple[int, ...] = (1, 1)
+    bal_res: Tuple[int, ...] = (0, 1)
+    percentage_of_nodes_to_score: int = 100  # 0 = adaptive (schedule_one.go:697-723)
+
+    @staticmethod
+    def default() -> "Profile":
+        return Profile()
+
+    @staticmethod
+    def fit_only() -> "Profile":
+        """BASELINE config 2: NodeResourcesFit Filter + LeastAllocated Score only."""
+        return Profile(filter_mask=F_FIT, w_taint=0, w_nodeaffinity=0, w_fit=1, w_balanced=0, w_topologyspread=0)
+
+
+@dataclass
+class RunResult:
+    placed: int
+    stop: int
+    per_node_count: np.ndarray
+    log: Optional[np.ndarray]
+    hist: np.ndarray  # int64[NREASON]
+    hist_taintset: np.ndarray  # int64[n_taintsets]
+    n_code_unschedulable: int
+    rounds: int = 0
+    evaluated_total: int = 0
+    last_evaluated: int = 0
+    last_feasible: int = 0
+    scans: int = 0
+    kernel_ns: int = 0

@@ -1,0 +1,113 @@
+"""Stop-reason / report formatting: Python mirror of the strings the reference produces.
+
+* FitError.Error                    vendor/k8s.io/kubernetes/pkg/scheduler/framework/types.go:787-836
+* DefaultPreemption PostFilter msg  .../plugins/defaultpreemption/default_preemption.go:131-141,257
+                                    .../framework/preemption/preemption.go:266-279
+* StopReason / getMainFailReason    pkg/framework/simulator.go:297-342, pkg/framework/report.go:100-109
+* parsePodsReview                   pkg/framework/report.go:146-180
+
+Inputs are the integer histograms returned through the C-ABI; strings live only here.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import model as M
+
+RES_NAMES = ["cpu", "memory", "ephemeral-storage"]
+
+REASON_TEXT = {
+    M.R_UNSCHEDULABLE: "node(s) were unschedulable",
+    M.R_NODENAME: "node(s) didn't match the requested node name",
+    M.R_NODEAFFINITY: "node(s) didn't match Pod's node affinity/selector",
+    M.R_TOO_MANY_PODS: "Too many pods",
+    M.R_PTS_MISSING_LABEL: "node(s) didn't match pod topology spread constraints (missing required label)",
+    M.R_PTS_SKEW: "node(s) didn't match pod topology spread constraints",
+}
+
+
+def _histogram_message(reasons: Dict[str, int]) -> str:
+    # types.go:820-829: "<count> <reason>" strings sorted lexicographically, joined by ", "
+    items = sorted(f"{v} {k}" for k, v in reasons.items() if v)
+    return ", ".join(items)
+
+
+def fit_error_message(
+    n_nodes: int,
+    hist: Sequence[int],
+    hist_taintset: Sequence[int],
+    n_code_unschedulable: int,
+    taint_reasons: Optional[Sequence[str]] = None,
+    scalar_names: Sequence[str] = (),
+    with_preemption: bool = True,
+) -> str:
+    """FitError.Error() for the terminal round, including the DefaultPreemption suffix."""
+    reasons: Dict[str, int] = {}
+    for slot, cnt in enumerate(hist):
+        cnt = int(cnt)
+        if not cnt:
+            continue
+        if slot in REASON_TEXT:
+            text = REASON_TEXT[slot]
+        elif M.R_RES0 <= slot < M.R_RES0 + M.MAX_RES:
+            c = slot - M.R_RES0
+            name = RES_NAMES[c] if c < 3 else (scalar_names[c - 3] if c - 3 < len(scalar_names) else f"scalar-{c - 3}")
+            text = f"Insufficient {name}"
+        else:
+            text = f"reason-{slot}"
+        reasons[text] = reasons.get(text, 0) + cnt
+    for ts, cnt in enumerate(hist_taintset):
+        cnt = int(cnt)
+        if not cnt:
+            continue
+        # taint_toleration.go:119: "node(s) had untolerated taint {key: value}" (first untolerated taint)
+        text = taint_reasons[ts] if taint_reasons is not None else f"node(s) had untolerated taint {{taintset-{ts}}}"
+        reasons[text] = reasons.get(text, 0) + cnt
+    msg = f"0/{n_nodes} nodes are available:"
+    body = _histogram_message(reasons)
+    if body:
+        msg += f" {body}."
+    if with_preemption:
+        # Nodes that failed with plain Unschedulable are dry-run candidates; the simulated pod has
+        # priority 0 like everything else, so each reports "No preemption victims found"; the rest are
+        # absent from the map -> "Preemption is not helpful for scheduling".
+        pre: Dict[str, int] = {}
+        if n_code_unschedulable:
+            pre["No preemption victims found for incoming pod"] = int(n_code_unschedulable)
+        if n_nodes - n_code_unschedulable > 0:
+            pre["Preemption is not helpful for scheduling"] = int(n_nodes - n_code_unschedulable)
+        pmsg = f"0/{n_nodes} nodes are available:"
+        pbody = _histogram_message(pre)
+        if pbody:
+            pmsg += f" {pbody}."
+        msg += " preemption: " + pmsg
+    return msg
+
+
+def stop_reason(result, n_nodes: int, max_limit: int, **kw) -> str:
+    """ClusterCapacity.Status.StopReason (simulator.go:301,331)."""
+    if result.stop == M.STOP_LIMIT:
+        return f"LimitReached: Maximum number of pods simulated: {max_limit}"
+    if result.stop == M.STOP_NO_NODES:
+        return "Unschedulable: no nodes available to schedule pods"
+    return "Unschedulable: " + fit_error_message(n_nodes, result.hist, result.hist_taintset, result.n_code_unschedulable, **kw)
+
+
+def main_fail_reason(message: str):
+    """report.go:100-109 getMainFailReason."""
+    first = message.split("\n")[0]
+    colon = first.index(":")
+    return {"failType": first[:colon], "failMessage": first[colon + 1 :].strip(" ")}
+
+
+def replicas_on_nodes(per_node_count: np.ndarray, names: Optional[List[str]] = None, log: Optional[np.ndarray] = None):
+    """report.go:146-180: per-node replica counts; first-placement order when a log is available."""
+    idx = np.nonzero(per_node_count)[0]
+    if log is not None and len(log):
+        _, first = np.unique(log, return_index=True)
+        order = log[np.sort(first)]
+    else:
+        order = idx
+    return [{"nodeName": names[i] if names else str(int(i)), "replicas": int(per_node_count[i])} for i in order]

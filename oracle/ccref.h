@@ -1,0 +1,185 @@
+/*
+ * ccref.h -- CPU ORACLE for the cluster-capacity placement path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C, sequential restatement of the reference's one-pod-at-a-time scheduling
+ * loop (kubernetes-sigs/cluster-capacity driving the vendored kube-scheduler v1.34.1).  It is
+ * NOT part of the product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it.  The product path (cluster-capacity_amd/csrc) never links or calls it.
+ *
+ * Parity status: the reference cannot be executed here (no Go toolchain) and none of its tests
+ * pins an instance count, so numeric parity is pinned only by the prose known answers of the
+ * reference's README (52 = 4x13, 52 = 2x26) and the FailType assertions of
+ * pkg/framework/simulator_test.go -- see tests/test_oracle_known_answers.py.  "parity unpinned"
+ * beyond those.
+ *
+ * Paths below are relative to the reference root; S/ = vendor/k8s.io/kubernetes/pkg/scheduler,
+ * P/ = S/framework/plugins.
+ *
+ * Strings never appear here: taints, tolerations, labels and selectors are interned by the
+ * caller (tests/objmodel.py mirrors the string-level matching rules for that step).
+ */
+#ifndef CCREF_H
+#define CCREF_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCREF_MAX_SCALAR 8
+#define CCREF_MAX_RES (3 + CCREF_MAX_SCALAR) /* resource "columns": 0 cpu(milli) 1 memory 2 ephemeral 3+k scalar k */
+#define CCREF_MAX_LABEL_COLS 32
+#define CCREF_MAX_TSC 8 /* topology spread constraints per pod */
+
+/* filter plugins, in the default profile's order (S/apis/config/v1/default_plugins.go:30-58) */
+enum {
+    CCREF_F_UNSCHEDULABLE = 1u << 0, /* P/nodeunschedulable */
+    CCREF_F_NODENAME = 1u << 1,      /* P/nodename (always passes: podgenerator clears Spec.NodeName) */
+    CCREF_F_TAINT = 1u << 2,         /* P/tainttoleration */
+    CCREF_F_NODEAFFINITY = 1u << 3,  /* P/nodeaffinity */
+    CCREF_F_FIT = 1u << 4,           /* P/noderesources/fit.go */
+    CCREF_F_TOPOLOGYSPREAD = 1u << 5 /* P/podtopologyspread */
+};
+
+/* reason slots of the terminal-round histogram (S/framework/types.go:787-836) */
+enum {
+    CCREF_R_UNSCHEDULABLE = 0, /* "node(s) were unschedulable" */
+    CCREF_R_NODENAME = 1,      /* "node(s) didn't match the requested node name" */
+    CCREF_R_NODEAFFINITY = 2,  /* "node(s) didn't match Pod's node affinity/selector" */
+    CCREF_R_TOO_MANY_PODS = 3, /* "Too many pods" */
+    CCREF_R_RES0 = 4,          /* + column: "Insufficient cpu|memory|ephemeral-storage|<scalar name>" */
+    CCREF_R_PTS_MISSING_LABEL = CCREF_R_RES0 + CCREF_MAX_RES, /* "node(s) didn't match pod topology spread constraints (missing required label)" */
+    CCREF_R_PTS_SKEW,                                         /* "node(s) didn't match pod topology spread constraints" */
+    CCREF_NREASON
+};
+
+enum { CCREF_STOP_UNSCHEDULABLE = 0, CCREF_STOP_LIMIT = 1, CCREF_STOP_NO_NODES = 2 };
+
+typedef struct {
+    int64_t n;
+    /* NodeInfo.Allocatable (S/framework/types.go:940-950) */
+    const int64_t *alloc[CCREF_MAX_RES]; /* [col][n]; unused cols may be NULL */
+    const int32_t *alloc_pods;
+    /* NodeInfo.Requested / NonZeroRequested / len(Pods): MUTATED by placements (types.go:409-428) */
+    int64_t *req[CCREF_MAX_RES];
+    int64_t *nz_mcpu, *nz_mem;
+    int32_t *pod_count;
+    int32_t n_scalar;
+    /* interned static attributes */
+    const int32_t *taintset_id;   /* distinct Spec.Taints list id */
+    const uint8_t *unschedulable; /* Spec.Unschedulable */
+    int32_t n_label_cols;
+    const int32_t *label_cols[CCREF_MAX_LABEL_COLS]; /* value id per node, 0 = label absent */
+} ccref_nodes;
+
+/* one matchExpression/matchField evaluated by table lookup on the node's value id for `col` */
+typedef struct {
+    int32_t col;
+    int32_t table_off; /* match iff req_tables[table_off + label_cols[col][node]] != 0 */
+} ccref_requirement;
+
+typedef struct {
+    int32_t first_req, n_req; /* AND over requirements; n_req==0 never matches (nodeaffinity.go:60-64) */
+    int32_t weight;           /* preferred terms only */
+} ccref_term;
+
+/* one topologySpreadConstraint (P/podtopologyspread/common.go:42-56) */
+typedef struct {
+    int32_t col;          /* label column of the topologyKey */
+    int32_t max_skew;     /* >=1 */
+    int32_t min_domains;  /* >=1 (nil -> 1) */
+    int32_t hard;         /* 1 = DoNotSchedule (filter), 0 = ScheduleAnyway (score) */
+    int32_t self_match;   /* 1 if the pod's own labels match the constraint's selector */
+    int32_t is_hostname;  /* topologyKey == kubernetes.io/hostname (scoring.go:214-215) */
+    int32_t n_domains;    /* number of value ids of `col` (ids are 1..n_domains) */
+    /* per-node count of EXISTING pods (same namespace, selector match) on the node, or NULL = 0;
+       simulated clones add self_match per placement */
+    const int32_t *node_match_count;
+    /* node inclusion policy (NodeAffinityPolicy=Honor, NodeTaintsPolicy=Ignore by default,
+       common.go:107-122): precomputed per node, NULL = all included */
+    const uint8_t *node_included;
+} ccref_spread_constraint;
+
+typedef struct {
+    /* fit.go:224-233 computePodResourceRequest; col order as above */
+    int64_t req[CCREF_MAX_RES];
+    int32_t has_scalar_entries; /* len(ScalarResources) != 0 even if all zero (fit.go:578-583) */
+    /* NonZero requests: resource_allocation.go:118-148 == types.go:700-734 Non0CPU/Non0Mem */
+    int64_t nz_mcpu, nz_mem;
+    /* TaintToleration per distinct taint set */
+    int32_t n_taintsets;
+    const uint8_t *taint_filter_ok;  /* 1 iff every NoSchedule/NoExecute taint is tolerated */
+    const int32_t *taint_prefer_cnt; /* # PreferNoSchedule taints not tolerated (taint_toleration.go:169-181) */
+    int32_t tolerates_unschedulable; /* node_unschedulable.go:141-147 */
+    /* NodeAffinity (P/nodeaffinity/node_affinity.go) */
+    int32_t affinity_filter_active; /* 0 = PreFilter returned Skip (:149-155) */
+    int32_t has_node_selector;      /* spec.nodeSelector != nil */
+    ccref_term node_selector;       /* AND of equalities */
+    int32_t has_required_terms;     /* requiredDuringScheduling... != nil */
+    int32_t n_required;             /* ORed; 0 terms => nothing matches */
+    const ccref_term *required;
+    int32_t n_preferred; /* 0 => PreScore Skip (:243-246) */
+    const ccref_term *preferred;
+    const ccref_requirement *reqs;
+    const uint8_t *req_tables;
+    /* PodTopologySpread */
+    int32_t n_spread;
+    ccref_spread_constraint spread[CCREF_MAX_TSC];
+} ccref_pod;
+
+typedef struct {
+    uint32_t filter_mask;
+    /* score plugin weights; 0 = plugin not enabled (default_plugins.go:38-50) */
+    int32_t w_taint, w_nodeaffinity, w_fit, w_balanced, w_topologyspread;
+    /* NodeResourcesFit scoringStrategy LeastAllocated resources (defaults.go:33-36) */
+    int32_t n_fit_res;
+    int32_t fit_res[CCREF_MAX_RES];
+    int64_t fit_res_w[CCREF_MAX_RES];
+    /* NodeResourcesBalancedAllocation resources (defaults.go:229-245) */
+    int32_t n_bal_res;
+    int32_t bal_res[CCREF_MAX_RES];
+    int32_t percentage_of_nodes_to_score; /* 0 = adaptive (schedule_one.go:697-723) */
+} ccref_profile;
+
+typedef struct {
+    int64_t placed;
+    int32_t stop; /* CCREF_STOP_* */
+    int32_t *per_node_count; /* caller-allocated [n], zeroed by ccref_run */
+    int32_t *log;            /* optional caller-allocated placement log (node idx per placement) */
+    int64_t log_cap;
+    int64_t hist[CCREF_NREASON]; /* terminal round only */
+    int64_t *hist_taintset;      /* optional caller-allocated [n_taintsets]: nodes rejected by TaintToleration */
+    int64_t n_code_unschedulable; /* nodes whose terminal status code is plain Unschedulable (preemption msg) */
+    int64_t rounds;
+    int64_t evaluated_total; /* sum over rounds of nodes the filters visited */
+    int32_t last_evaluated, last_feasible;
+} ccref_result;
+
+/* scheduler state that survives rounds (S/scheduler.go nextStartNodeIndex) */
+typedef struct {
+    int64_t next_start_node_index;
+} ccref_sched_state;
+
+/* One scheduling cycle (schedule_one.go:430-478 schedulePod + :967-984 assume).
+ * Returns the winning node index (and applies the placement), or -1 when no node fits, in which
+ * case res->hist etc. describe the FitError.  res may be NULL. */
+int64_t ccref_schedule_one(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *pod, ccref_sched_state *st,
+                           ccref_result *res);
+
+/* The simulator loop (pkg/framework/simulator.go:297-381): place clones until Unschedulable or
+ * max_limit placements (max_limit <= 0: unlimited). threads>1 evaluates the node loop with OpenMP
+ * (same results; mirrors Parallelism=16 for timing only). */
+int ccref_run(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *pod, int64_t max_limit, int threads,
+              ccref_result *res);
+
+/* plugin score unit functions, exported for the known-answer vectors */
+int64_t ccref_least_allocated(const int64_t *requested, const int64_t *allocatable, const int64_t *weights, int n);
+int64_t ccref_balanced_allocation(const int64_t *requested, const int64_t *allocatable, int n);
+void ccref_default_normalize(int64_t max_priority, int reverse, int64_t *scores, int64_t n);
+int32_t ccref_num_feasible_nodes_to_find(int32_t percentage, int32_t num_all_nodes);
+double ccref_go_log(double x); /* restatement of Go's math.Log (pure-Go path) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,325 @@
+"""ctypes binding of the CPU oracle (oracle/libccref.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It accepts duck-typed objects with the attribute names of cluster-capacity_amd/model.py
+(NodesSoA / PodSpec / Profile) but does not import the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_SCALAR = 8
+MAX_RES = 3 + MAX_SCALAR
+MAX_LABEL_COLS = 32
+MAX_TSC = 8
+NREASON = 4 + MAX_RES + 2
+
+_p64 = C.POINTER(C.c_int64)
+_p32 = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+class _Nodes(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("alloc", _p64 * MAX_RES),
+        ("alloc_pods", _p32),
+        ("req", _p64 * MAX_RES),
+        ("nz_mcpu", _p64),
+        ("nz_mem", _p64),
+        ("pod_count", _p32),
+        ("n_scalar", C.c_int32),
+        ("taintset_id", _p32),
+        ("unschedulable", _pu8),
+        ("n_label_cols", C.c_int32),
+        ("label_cols", _p32 * MAX_LABEL_COLS),
+    ]
+
+
+class _Req(C.Structure):
+    _fields_ = [("col", C.c_int32), ("table_off", C.c_int32)]
+
+
+class _Term(C.Structure):
+    _fields_ = [("first_req", C.c_int32), ("n_req", C.c_int32), ("weight", C.c_int32)]
+
+
+class _Spread(C.Structure):
+    _fields_ = [
+        ("col", C.c_int32),
+        ("max_skew", C.c_int32),
+        ("min_domains", C.c_int32),
+        ("hard", C.c_int32),
+        ("self_match", C.c_int32),
+        ("is_hostname", C.c_int32),
+        ("n_domains", C.c_int32),
+        ("node_match_count", _p32),
+        ("node_included", _pu8),
+    ]
+
+
+class _Pod(C.Structure):
+    _fields_ = [
+        ("req", C.c_int64 * MAX_RES),
+        ("has_scalar_entries", C.c_int32),
+        ("nz_mcpu", C.c_int64),
+        ("nz_mem", C.c_int64),
+        ("n_taintsets", C.c_int32),
+        ("taint_filter_ok", _pu8),
+        ("taint_prefer_cnt", _p32),
+        ("tolerates_unschedulable", C.c_int32),
+        ("affinity_filter_active", C.c_int32),
+        ("has_node_selector", C.c_int32),
+        ("node_selector", _Term),
+        ("has_required_terms", C.c_int32),
+        ("n_required", C.c_int32),
+        ("required", C.POINTER(_Term)),
+        ("n_preferred", C.c_int32),
+        ("preferred", C.POINTER(_Term)),
+        ("reqs", C.POINTER(_Req)),
+        ("req_tables", _pu8),
+        ("n_spread", C.c_int32),
+        ("spread", _Spread * MAX_TSC),
+    ]
+
+
+class _Profile(C.Structure):
+    _fields_ = [
+        ("filter_mask", C.c_uint32),
+        ("w_taint", C.c_int32),
+        ("w_nodeaffinity", C.c_int32),
+        ("w_fit", C.c_int32),
+        ("w_balanced", C.c_int32),
+        ("w_topologyspread", C.c_int32),
+        ("n_fit_res", C.c_int32),
+        ("fit_res", C.c_int32 * MAX_RES),
+        ("fit_res_w", C.c_int64 * MAX_RES),
+        ("n_bal_res", C.c_int32),
+        ("bal_res", C.c_int32 * MAX_RES),
+        ("percentage_of_nodes_to_score", C.c_int32),
+    ]
+
+
+class _Result(C.Structure):
+    _fields_ = [
+        ("placed", C.c_int64),
+        ("stop", C.c_int32),
+        ("per_node_count", _p32),
+        ("log", _p32),
+        ("log_cap", C.c_int64),
+        ("hist", C.c_int64 * NREASON),
+        ("hist_taintset", _p64),
+        ("n_code_unschedulable", C.c_int64),
+        ("rounds", C.c_int64),
+        ("evaluated_total", C.c_int64),
+        ("last_evaluated", C.c_int32),
+        ("last_feasible", C.c_int32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(HERE, "libccref.so")
+    src = [os.path.join(HERE, f) for f in ("ccref.c", "ccref.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", HERE, "-s", "libccref.so"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.ccref_run.restype = C.c_int
+        _lib.ccref_run.argtypes = [C.POINTER(_Profile), C.POINTER(_Nodes), C.POINTER(_Pod), C.c_int64, C.c_int, C.POINTER(_Result)]
+        _lib.ccref_least_allocated.restype = C.c_int64
+        _lib.ccref_least_allocated.argtypes = [_p64, _p64, _p64, C.c_int]
+        _lib.ccref_balanced_allocation.restype = C.c_int64
+        _lib.ccref_balanced_allocation.argtypes = [_p64, _p64, C.c_int]
+        _lib.ccref_default_normalize.restype = None
+        _lib.ccref_default_normalize.argtypes = [C.c_int64, C.c_int, _p64, C.c_int64]
+        _lib.ccref_num_feasible_nodes_to_find.restype = C.c_int32
+        _lib.ccref_num_feasible_nodes_to_find.argtypes = [C.c_int32, C.c_int32]
+        _lib.ccref_go_log.restype = C.c_double
+        _lib.ccref_go_log.argtypes = [C.c_double]
+    return _lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class _Marshal:
+    """Keeps numpy buffers alive while the C structs point into them."""
+
+    def __init__(self):
+        self.keep = []
+
+    def arr(self, a, dtype, t):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        self.keep.append(a)
+        return _ptr(a, t)
+
+    def nodes(self, nd) -> _Nodes:
+        """Marshal a (private, mutable) copy of the node columns."""
+        s = _Nodes()
+        s.n = nd.n
+        ncol = len(nd.alloc)
+        assert ncol <= MAX_RES
+        for c in range(ncol):
+            s.alloc[c] = self.arr(nd.alloc[c], np.int64, _p64)
+            s.req[c] = self.arr(np.array(nd.req[c], dtype=np.int64, copy=True), np.int64, _p64)
+        s.alloc_pods = self.arr(nd.alloc_pods, np.int32, _p32)
+        s.nz_mcpu = self.arr(np.array(nd.nz_mcpu, dtype=np.int64, copy=True), np.int64, _p64)
+        s.nz_mem = self.arr(np.array(nd.nz_mem, dtype=np.int64, copy=True), np.int64, _p64)
+        s.pod_count = self.arr(np.array(nd.pod_count, dtype=np.int32, copy=True), np.int32, _p32)
+        s.n_scalar = ncol - 3
+        s.taintset_id = self.arr(nd.taintset_id, np.int32, _p32)
+        s.unschedulable = self.arr(nd.unschedulable, np.uint8, _pu8)
+        assert len(nd.label_cols) <= MAX_LABEL_COLS
+        s.n_label_cols = len(nd.label_cols)
+        for i, col in enumerate(nd.label_cols):
+            s.label_cols[i] = self.arr(col, np.int32, _p32)
+        return s
+
+    def pod(self, pod) -> _Pod:
+        s = _Pod()
+        for c, v in enumerate(np.asarray(pod.req, dtype=np.int64)):
+            s.req[c] = int(v)
+        s.has_scalar_entries = int(bool(pod.has_scalar_entries))
+        s.nz_mcpu = int(pod.nz_mcpu)
+        s.nz_mem = int(pod.nz_mem)
+        s.n_taintsets = int(len(pod.taint_filter_ok))
+        s.taint_filter_ok = self.arr(pod.taint_filter_ok, np.uint8, _pu8)
+        s.taint_prefer_cnt = self.arr(pod.taint_prefer_cnt, np.int32, _p32)
+        s.tolerates_unschedulable = int(bool(pod.tolerates_unschedulable))
+        s.affinity_filter_active = int(bool(pod.affinity_filter_active))
+        # flatten requirement tables
+        reqs, tables, off = [], [], 0
+
+        def add_term(term_reqs, weight=0):
+            nonlocal off
+            first = len(reqs)
+            for col, table in term_reqs:
+                t = np.ascontiguousarray(table, dtype=np.uint8)
+                reqs.append((int(col), off))
+                tables.append(t)
+                off += t.shape[0]
+            return _Term(first, len(term_reqs), int(weight))
+
+        s.has_node_selector = int(bool(pod.has_node_selector))
+        s.node_selector = add_term(pod.node_selector)
+        s.has_required_terms = int(bool(pod.has_required_terms))
+        req_terms = [add_term(t) for t in pod.required]
+        pref_terms = [add_term(t, w) for (w, t) in pod.preferred]
+        s.n_required = len(req_terms)
+        s.n_preferred = len(pref_terms)
+        rt = (_Term * max(1, len(req_terms)))(*req_terms)
+        pt = (_Term * max(1, len(pref_terms)))(*pref_terms)
+        rq = (_Req * max(1, len(reqs)))(*[_Req(c, o) for c, o in reqs])
+        self.keep += [rt, pt, rq]
+        s.required = C.cast(rt, C.POINTER(_Term))
+        s.preferred = C.cast(pt, C.POINTER(_Term))
+        s.reqs = C.cast(rq, C.POINTER(_Req))
+        tab = np.concatenate(tables) if tables else np.zeros(1, np.uint8)
+        s.req_tables = self.arr(tab, np.uint8, _pu8)
+        spread = list(getattr(pod, "spread", []))
+        assert len(spread) <= MAX_TSC
+        s.n_spread = len(spread)
+        for i, k in enumerate(spread):
+            s.spread[i].col = int(k.col)
+            s.spread[i].max_skew = int(k.max_skew)
+            s.spread[i].min_domains = int(k.min_domains)
+            s.spread[i].hard = int(bool(k.hard))
+            s.spread[i].self_match = int(bool(k.self_match))
+            s.spread[i].is_hostname = int(bool(k.is_hostname))
+            s.spread[i].n_domains = int(k.n_domains)
+            if k.node_match_count is not None:
+                s.spread[i].node_match_count = self.arr(k.node_match_count, np.int32, _p32)
+            if k.node_included is not None:
+                s.spread[i].node_included = self.arr(k.node_included, np.uint8, _pu8)
+        return s
+
+    def profile(self, p) -> _Profile:
+        s = _Profile()
+        s.filter_mask = int(p.filter_mask)
+        s.w_taint, s.w_nodeaffinity, s.w_fit = int(p.w_taint), int(p.w_nodeaffinity), int(p.w_fit)
+        s.w_balanced, s.w_topologyspread = int(p.w_balanced), int(p.w_topologyspread)
+        s.n_fit_res = len(p.fit_res)
+        for i, (c, w) in enumerate(zip(p.fit_res, p.fit_res_w)):
+            s.fit_res[i] = int(c)
+            s.fit_res_w[i] = int(w)
+        s.n_bal_res = len(p.bal_res)
+        for i, c in enumerate(p.bal_res):
+            s.bal_res[i] = int(c)
+        s.percentage_of_nodes_to_score = int(p.percentage_of_nodes_to_score)
+        return s
+
+
+def run(profile, nodes, pod, max_limit: int = 0, threads: int = 1, want_log: bool = True, log_cap: int | None = None):
+    """Run the reference simulation loop on the CPU. `nodes` is not modified. Returns a namespace
+    with placed, stop, per_node_count, log, hist, hist_taintset, n_code_unschedulable, rounds, ...
+    plus `final_nodes` = the mutated dynamic columns."""
+    m = _Marshal()
+    cn, cp, cf = m.nodes(nodes), m.pod(pod), m.profile(profile)
+    res = _Result()
+    per_node = np.zeros(max(1, nodes.n), np.int32)
+    res.per_node_count = _ptr(per_node, _p32)
+    log = None
+    if want_log:
+        if log_cap is None:
+            log_cap = int(max_limit) if max_limit > 0 else int(np.minimum(np.asarray(nodes.alloc_pods, dtype=np.int64).sum(), 1 << 26))
+        log = np.full(max(1, log_cap), -1, np.int32)
+        res.log = _ptr(log, _p32)
+        res.log_cap = log.shape[0]
+    ht = np.zeros(max(1, len(pod.taint_filter_ok)), np.int64)
+    res.hist_taintset = _ptr(ht, _p64)
+    rc = lib().ccref_run(C.byref(cf), C.byref(cn), C.byref(cp), int(max_limit), int(threads), C.byref(res))
+    if rc != 0:
+        raise RuntimeError(f"ccref_run failed rc={rc}")
+    placed = int(res.placed)
+    return SimpleNamespace(
+        placed=placed,
+        stop=int(res.stop),
+        per_node_count=per_node[: nodes.n].copy(),
+        log=log[: min(placed, log.shape[0])].copy() if log is not None else None,
+        hist=np.array(list(res.hist), dtype=np.int64),
+        hist_taintset=ht.copy(),
+        n_code_unschedulable=int(res.n_code_unschedulable),
+        rounds=int(res.rounds),
+        evaluated_total=int(res.evaluated_total),
+        last_evaluated=int(res.last_evaluated),
+        last_feasible=int(res.last_feasible),
+    )
+
+
+def least_allocated(requested, allocatable, weights):
+    r, a, w = (np.ascontiguousarray(x, dtype=np.int64) for x in (requested, allocatable, weights))
+    return int(lib().ccref_least_allocated(_ptr(r, _p64), _ptr(a, _p64), _ptr(w, _p64), len(r)))
+
+
+def balanced_allocation(requested, allocatable):
+    r, a = (np.ascontiguousarray(x, dtype=np.int64) for x in (requested, allocatable))
+    return int(lib().ccref_balanced_allocation(_ptr(r, _p64), _ptr(a, _p64), len(r)))
+
+
+def default_normalize(max_priority, reverse, scores):
+    s = np.array(scores, dtype=np.int64)
+    lib().ccref_default_normalize(int(max_priority), int(bool(reverse)), _ptr(s, _p64), len(s))
+    return s.tolist()
+
+
+def num_feasible_nodes_to_find(percentage, n):
+    return int(lib().ccref_num_feasible_nodes_to_find(int(percentage), int(n)))
+
+
+def go_log(x):
+    return float(lib().ccref_go_log(float(x)))
