@@ -1,0 +1,41 @@
+"""Build recipe for libccsim.so (HIP, gfx950 only).  hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+SOURCES = ["ccsim_engine.hip"]
+DEPS = ["ccsim_kernels.h", os.path.join(ROOT, "include", "ccsim.h")]
+# -ffp-contract=off: the fp64 score arithmetic must match Go (no FMA fusion); no fast-math anywhere.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-result"]
+
+
+def lib_path() -> str:
+    return os.path.join(CSRC, "libccsim.so")
+
+
+def _stale(out: str) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in DEPS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_all(force: bool = False, verbose: bool = False) -> str:
+    out = lib_path()
+    if force or _stale(out):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_all(force=True, verbose=True))

@@ -1,0 +1,335 @@
+"""ctypes binding of libccsim.so (include/ccsim.h).  Plumbing only: marshals the numpy holders of
+model.py into the C structs and calls the HIP engine.  There is no CPU fallback: if the library or
+the GPU is missing, calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import build as _build
+from . import model as M
+
+MAX_RES = M.MAX_RES
+MAX_LABEL_COLS = 32
+NREASON = M.NREASON
+XCHG_WORDS = 8
+MODE_SEQUENTIAL, MODE_BATCHED = 0, 1
+MODES = {"sequential": MODE_SEQUENTIAL, "batched": MODE_BATCHED}
+
+_p64 = C.POINTER(C.c_int64)
+_p32 = C.POINTER(C.c_int32)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+class CConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
+                ("rounds_per_sync", C.c_int32), ("use_graph", C.c_int32)]
+
+
+class CNodes(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int64), ("global_offset", C.c_int64), ("n_global", C.c_int64), ("n_scalar", C.c_int32),
+        ("alloc", _p64 * MAX_RES), ("alloc_pods", _p32), ("req", _p64 * MAX_RES), ("nz_mcpu", _p64), ("nz_mem", _p64),
+        ("pod_count", _p32), ("taintset_id", _p32), ("unschedulable", _pu8), ("n_label_cols", C.c_int32),
+        ("label_cols", _p32 * MAX_LABEL_COLS),
+    ]
+
+
+class CReq(C.Structure):
+    _fields_ = [("col", C.c_int32), ("table_off", C.c_int32)]
+
+
+class CTerm(C.Structure):
+    _fields_ = [("first_req", C.c_int32), ("n_req", C.c_int32), ("weight", C.c_int32)]
+
+
+class CPod(C.Structure):
+    _fields_ = [
+        ("req", C.c_int64 * MAX_RES), ("has_scalar_entries", C.c_int32), ("nz_mcpu", C.c_int64), ("nz_mem", C.c_int64),
+        ("n_taintsets", C.c_int32), ("taint_filter_ok", _pu8), ("taint_prefer_cnt", _p32),
+        ("tolerates_unschedulable", C.c_int32), ("affinity_filter_active", C.c_int32), ("has_node_selector", C.c_int32),
+        ("node_selector", CTerm), ("has_required_terms", C.c_int32), ("n_required", C.c_int32),
+        ("required", C.POINTER(CTerm)), ("n_preferred", C.c_int32), ("preferred", C.POINTER(CTerm)),
+        ("n_reqs", C.c_int32), ("reqs", C.POINTER(CReq)), ("req_tables_len", C.c_int64), ("req_tables", _pu8),
+    ]
+
+
+class CProfile(C.Structure):
+    _fields_ = [
+        ("filter_mask", C.c_uint32), ("w_taint", C.c_int32), ("w_nodeaffinity", C.c_int32), ("w_fit", C.c_int32),
+        ("w_balanced", C.c_int32), ("w_topologyspread", C.c_int32), ("n_fit_res", C.c_int32),
+        ("fit_res", C.c_int32 * MAX_RES), ("fit_res_w", C.c_int64 * MAX_RES), ("n_bal_res", C.c_int32),
+        ("bal_res", C.c_int32 * MAX_RES), ("percentage_of_nodes_to_score", C.c_int32),
+    ]
+
+
+class CReport(C.Structure):
+    _fields_ = [
+        ("placed", C.c_int64), ("stop", C.c_int32), ("per_node_count", _p32), ("per_node_cap", C.c_int64),
+        ("log", _p32), ("log_cap", C.c_int64), ("log_len", C.c_int64), ("hist", C.c_int64 * NREASON),
+        ("hist_taintset", _p64), ("hist_taintset_cap", C.c_int32), ("n_code_unschedulable", C.c_int64),
+        ("rounds", C.c_int64), ("scans", C.c_int64), ("evaluated_total", C.c_int64), ("last_feasible", C.c_int32),
+        ("kernel_ns", C.c_int64), ("bytes_per_scan", C.c_int64),
+    ]
+
+
+class CCycle(C.Structure):
+    _fields_ = [("node", C.c_int64), ("evaluated_nodes", C.c_int32), ("feasible_nodes", C.c_int32)]
+
+
+# every symbol include/ccsim.h declares (checked by tests/test_abi.py without a GPU)
+SYMBOLS = {
+    "ccsim_abi_version": (C.c_int32, []),
+    "ccsim_create": (C.c_int, [C.POINTER(CConfig), C.POINTER(C.c_void_p)]),
+    "ccsim_destroy": (None, [C.c_void_p]),
+    "ccsim_last_error": (C.c_char_p, [C.c_void_p]),
+    "ccsim_load_nodes": (C.c_int, [C.c_void_p, C.POINTER(CNodes)]),
+    "ccsim_set_profile": (C.c_int, [C.c_void_p, C.POINTER(CProfile)]),
+    "ccsim_set_pod": (C.c_int, [C.c_void_p, C.POINTER(CPod)]),
+    "ccsim_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
+    "ccsim_schedule_one": (C.c_int, [C.c_void_p, C.POINTER(CCycle)]),
+    "ccsim_read_state": (C.c_int, [C.c_void_p, _p64, _p64, _p64, _p64, _p32]),
+    "ccsim_dist_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
+    "ccsim_dist_scan": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_decide": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "ccsim_dist_finish": (C.c_int, [C.c_void_p, C.POINTER(CReport)]),
+    "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load(build_if_missing: bool = True):
+    """dlopen libccsim.so and bind every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is None:
+        path = _build.lib_path()
+        if not os.path.exists(path):
+            if not build_if_missing:
+                raise FileNotFoundError(path)
+            _build.build_all()
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.ccsim_abi_version() != 1:
+            raise RuntimeError("libccsim ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class CcsimError(RuntimeError):
+    pass
+
+
+def marshal_nodes(nodes: M.NodesSoA, keep: list, global_offset: int = 0, n_global: Optional[int] = None) -> CNodes:
+    s = CNodes()
+    s.n_nodes = nodes.n
+    s.global_offset = int(global_offset)
+    s.n_global = int(n_global if n_global is not None else nodes.n)
+    s.n_scalar = nodes.n_scalar
+
+    def arr(a, dt, t):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return _ptr(a, t)
+
+    for c in range(len(nodes.alloc)):
+        s.alloc[c] = arr(nodes.alloc[c], np.int64, _p64)
+        s.req[c] = arr(nodes.req[c], np.int64, _p64)
+    s.alloc_pods = arr(nodes.alloc_pods, np.int32, _p32)
+    s.nz_mcpu = arr(nodes.nz_mcpu, np.int64, _p64)
+    s.nz_mem = arr(nodes.nz_mem, np.int64, _p64)
+    s.pod_count = arr(nodes.pod_count, np.int32, _p32)
+    s.taintset_id = arr(nodes.taintset_id, np.int32, _p32)
+    s.unschedulable = arr(nodes.unschedulable, np.uint8, _pu8)
+    assert len(nodes.label_cols) <= MAX_LABEL_COLS
+    s.n_label_cols = len(nodes.label_cols)
+    for i, col in enumerate(nodes.label_cols):
+        s.label_cols[i] = arr(col, np.int32, _p32)
+    return s
+
+
+def marshal_pod(pod: M.PodSpec, keep: list) -> CPod:
+    s = CPod()
+    for c, v in enumerate(np.asarray(pod.req, dtype=np.int64)):
+        s.req[c] = int(v)
+    s.has_scalar_entries = int(bool(pod.has_scalar_entries))
+    s.nz_mcpu, s.nz_mem = int(pod.nz_mcpu), int(pod.nz_mem)
+    ok = np.ascontiguousarray(pod.taint_filter_ok, dtype=np.uint8)
+    cnt = np.ascontiguousarray(pod.taint_prefer_cnt, dtype=np.int32)
+    keep += [ok, cnt]
+    s.n_taintsets = int(ok.shape[0])
+    s.taint_filter_ok = _ptr(ok, _pu8)
+    s.taint_prefer_cnt = _ptr(cnt, _p32)
+    s.tolerates_unschedulable = int(bool(pod.tolerates_unschedulable))
+    s.affinity_filter_active = int(bool(pod.affinity_filter_active))
+    reqs, tables, off = [], [], 0
+
+    def add_term(term_reqs, weight=0):
+        nonlocal off
+        first = len(reqs)
+        for col, table in term_reqs:
+            t = np.ascontiguousarray(table, dtype=np.uint8)
+            reqs.append(CReq(int(col), off))
+            tables.append(t)
+            off += int(t.shape[0])
+        return CTerm(first, len(term_reqs), int(weight))
+
+    s.has_node_selector = int(bool(pod.has_node_selector))
+    s.node_selector = add_term(pod.node_selector)
+    s.has_required_terms = int(bool(pod.has_required_terms))
+    rt = [add_term(t) for t in pod.required]
+    pt = [add_term(t, w) for (w, t) in pod.preferred]
+    s.n_required, s.n_preferred, s.n_reqs = len(rt), len(pt), len(reqs)
+    rta = (CTerm * max(1, len(rt)))(*rt)
+    pta = (CTerm * max(1, len(pt)))(*pt)
+    rqa = (CReq * max(1, len(reqs)))(*reqs)
+    tab = np.concatenate(tables) if tables else np.zeros(1, np.uint8)
+    keep += [rta, pta, rqa, tab]
+    s.required = C.cast(rta, C.POINTER(CTerm))
+    s.preferred = C.cast(pta, C.POINTER(CTerm))
+    s.reqs = C.cast(rqa, C.POINTER(CReq))
+    s.req_tables_len = int(tab.shape[0])
+    s.req_tables = _ptr(tab, _pu8)
+    if getattr(pod, "spread", None):
+        raise CcsimError("PodTopologySpread constraints are not supported by the HIP engine yet")
+    return s
+
+
+def marshal_profile(p: M.Profile) -> CProfile:
+    s = CProfile()
+    s.filter_mask = int(p.filter_mask)
+    s.w_taint, s.w_nodeaffinity, s.w_fit = int(p.w_taint), int(p.w_nodeaffinity), int(p.w_fit)
+    s.w_balanced, s.w_topologyspread = int(p.w_balanced), int(p.w_topologyspread)
+    s.n_fit_res = len(p.fit_res)
+    for i, (c, w) in enumerate(zip(p.fit_res, p.fit_res_w)):
+        s.fit_res[i], s.fit_res_w[i] = int(c), int(w)
+    s.n_bal_res = len(p.bal_res)
+    for i, c in enumerate(p.bal_res):
+        s.bal_res[i] = int(c)
+    s.percentage_of_nodes_to_score = int(p.percentage_of_nodes_to_score)
+    return s
+
+
+class Engine:
+    """One engine = one GPU's shard of the snapshot (ccsim_engine*)."""
+
+    def __init__(self, device: int = 0, stream: int = 0, rounds_per_sync: int = 0, use_graph: bool = True):
+        self.lib = load()
+        cfg = CConfig(1, int(device), C.c_void_p(stream) if stream else None, int(rounds_per_sync), int(use_graph))
+        h = C.c_void_p()
+        rc = self.lib.ccsim_create(C.byref(cfg), C.byref(h))
+        if rc != 0 or not h:
+            raise CcsimError(f"ccsim_create failed rc={rc} (is a HIP device visible?)")
+        self.h = h
+        self.n = 0
+        self.n_taintsets = 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ccsim_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.ccsim_last_error(self.h)
+            raise CcsimError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")
+
+    def load(self, nodes: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int = 0,
+             n_global: Optional[int] = None):
+        keep: list = []
+        self._chk(self.lib.ccsim_load_nodes(self.h, C.byref(marshal_nodes(nodes, keep, global_offset, n_global))), "ccsim_load_nodes")
+        self.n = nodes.n
+        self.set_profile(profile)
+        self.set_pod(pod)
+
+    def set_profile(self, profile: M.Profile):
+        self._chk(self.lib.ccsim_set_profile(self.h, C.byref(marshal_profile(profile))), "ccsim_set_profile")
+
+    def set_pod(self, pod: M.PodSpec):
+        keep: list = []
+        cp = marshal_pod(pod, keep)
+        self._chk(self.lib.ccsim_set_pod(self.h, C.byref(cp)), "ccsim_set_pod")
+        self.n_taintsets = int(cp.n_taintsets)
+
+    def _report(self, want_log: bool, log_cap: int):
+        rep = CReport()
+        per_node = np.zeros(max(1, self.n), np.int32)
+        rep.per_node_count = _ptr(per_node, _p32)
+        rep.per_node_cap = per_node.shape[0]
+        log = None
+        if want_log:
+            log = np.full(max(1, int(log_cap)), -1, np.int32)
+            rep.log = _ptr(log, _p32)
+            rep.log_cap = log.shape[0]
+        ht = np.zeros(max(1, self.n_taintsets), np.int64)
+        rep.hist_taintset = _ptr(ht, _p64)
+        rep.hist_taintset_cap = ht.shape[0]
+        return rep, per_node, log, ht
+
+    def _result(self, rep, per_node, log, ht) -> M.RunResult:
+        return M.RunResult(
+            placed=int(rep.placed), stop=int(rep.stop), per_node_count=per_node[: self.n].copy(),
+            log=log[: int(rep.log_len)].copy() if log is not None else None,
+            hist=np.array(list(rep.hist), dtype=np.int64), hist_taintset=ht.copy(),
+            n_code_unschedulable=int(rep.n_code_unschedulable), rounds=int(rep.rounds),
+            evaluated_total=int(rep.evaluated_total), last_feasible=int(rep.last_feasible), scans=int(rep.scans),
+            kernel_ns=int(rep.kernel_ns), bytes_per_scan=int(rep.bytes_per_scan),
+        )
+
+    def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None) -> M.RunResult:
+        if log_cap is None:
+            log_cap = max_limit if max_limit > 0 else 1 << 22
+        rep, per_node, log, ht = self._report(want_log, log_cap)
+        self._chk(self.lib.ccsim_run(self.h, int(max_limit), MODES[mode], C.byref(rep)), "ccsim_run")
+        return self._result(rep, per_node, log, ht)
+
+    def schedule_one(self):
+        cyc = CCycle()
+        self._chk(self.lib.ccsim_schedule_one(self.h, C.byref(cyc)), "ccsim_schedule_one")
+        return int(cyc.node), int(cyc.evaluated_nodes), int(cyc.feasible_nodes)
+
+    def read_state(self):
+        n = max(1, self.n)
+        out = [np.zeros(n, np.int64) for _ in range(4)] + [np.zeros(n, np.int32)]
+        self._chk(self.lib.ccsim_read_state(self.h, *[_ptr(a, _p64) for a in out[:4]], _ptr(out[4], _p32)), "ccsim_read_state")
+        return dict(req_mcpu=out[0][: self.n], req_mem=out[1][: self.n], nz_mcpu=out[2][: self.n], nz_mem=out[3][: self.n],
+                    pod_count=out[4][: self.n])
+
+    def time_scan(self, iters: int):
+        ns, by = C.c_int64(), C.c_int64()
+        self._chk(self.lib.ccsim_time_scan(self.h, int(iters), C.byref(ns), C.byref(by)), "ccsim_time_scan")
+        return int(ns.value), int(by.value)
+
+    # ---- distributed stepping (collective supplied by the caller, see dist.py) ----
+    def dist_begin(self, max_limit: int, mode: str, n_ranks: int, send_ptr: int, recv_ptr: int, log_cap: int = 0):
+        self._chk(self.lib.ccsim_dist_begin(self.h, int(max_limit), MODES[mode], int(n_ranks), C.c_void_p(send_ptr),
+                                            C.c_void_p(recv_ptr), int(log_cap)), "ccsim_dist_begin")
+
+    def dist_scan(self):
+        self._chk(self.lib.ccsim_dist_scan(self.h), "ccsim_dist_scan")
+
+    def dist_decide(self):
+        self._chk(self.lib.ccsim_dist_decide(self.h), "ccsim_dist_decide")
+
+    def dist_poll(self):
+        done, placed = C.c_int32(), C.c_int64()
+        self._chk(self.lib.ccsim_dist_poll(self.h, C.byref(done), C.byref(placed)), "ccsim_dist_poll")
+        return int(done.value), int(placed.value)
+
+    def dist_finish(self, want_log: bool = False, log_cap: int = 0) -> M.RunResult:
+        rep, per_node, log, ht = self._report(want_log, log_cap)
+        self._chk(self.lib.ccsim_dist_finish(self.h, C.byref(rep)), "ccsim_dist_finish")
+        return self._result(rep, per_node, log, ht)

@@ -1,0 +1,650 @@
+// ccsim_engine.hip -- host side of libccsim.so: owns the HBM-resident snapshot, launches the CDNA4
+// kernels of ccsim_kernels.h and implements the C ABI declared in include/ccsim.h.
+//
+// Replaces (reference, kubernetes-sigs/cluster-capacity):
+//   pkg/framework/simulator.go:356-381   ClusterCapacity.Run    -> ccsim_run
+//   S/schedule_one.go:430-478,967-984    schedulePod + assume   -> ccsim_schedule_one
+//   S/backend/cache/cache.go:194-288     UpdateSnapshot         -> ccsim_load_nodes (once; state then lives in HBM)
+// There is NO CPU fallback: every entry point fails loudly if HIP does.
+#include "ccsim_kernels.h"
+
+#include <errno.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ccsim.h"
+
+using namespace ccsim;
+
+struct ccsim_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int rounds_per_sync = 0;
+    int use_graph = 1;
+    std::string err;
+
+    // snapshot
+    bool have_nodes = false, have_profile = false, have_pod = false;
+    int64_t n = 0, n_pad = 0, global_offset = 0, n_global = 0;
+    int ncol = 3, n_label_cols = 0, n_taintsets = 1;
+    std::vector<void *> allocs; // everything hipMalloc'ed
+    DevCols cols{};
+    uint8_t *d_unsched = nullptr;
+    int32_t **d_label_cols = nullptr;
+    uint32_t *d_stat = nullptr;
+    uint8_t *d_sreason = nullptr;
+
+    // pod / profile
+    ccsim_profile prof{};
+    DevPod pod{};
+    std::vector<void *> pod_allocs;
+
+    // run state
+    DevState *d_state = nullptr;
+    DevState *h_state = nullptr; // pinned
+    Partial *d_partials = nullptr;
+    XRec *d_xsend = nullptr, *d_xrecv = nullptr; // distributed exchange (caller's or ours)
+    int n_ranks = 0;
+    int32_t *d_log = nullptr;
+    int64_t log_cap = 0;
+    unsigned long long *d_hist = nullptr, *d_hist_ts = nullptr, *d_hist_code = nullptr;
+    int grid = 0;
+    int64_t chunk = 0;
+    bool begun = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double kernel_ms = 0;
+    int64_t limit = 0;
+    int mode = 0;
+
+    // graph replay of rounds_per_sync x (k_scan, k_final)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_rounds = 0;
+};
+
+static int fail(ccsim_engine *e, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                                           \
+    do {                                                                                                          \
+        hipError_t _r = (call);                                                                                   \
+        if (_r != hipSuccess) return fail((e), -EIO, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(ccsim_engine *e, T **out, size_t count, std::vector<void *> &track, bool zero = true) {
+    void *p = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(e, hipMalloc(&p, bytes));
+    track.push_back(p);
+    if (zero) HIPCHK(e, hipMemsetAsync(p, 0, bytes, e->stream));
+    *out = (T *)p;
+    return 0;
+}
+
+template <typename T>
+static int upload(ccsim_engine *e, T **out, const T *src, size_t count, size_t padded, std::vector<void *> &track) {
+    int rc = dev_alloc(e, out, padded, track, true);
+    if (rc) return rc;
+    if (src && count) HIPCHK(e, hipMemcpyAsync(*out, src, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    return 0;
+}
+
+static void free_list(std::vector<void *> &v) {
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+static void drop_graph(ccsim_engine *e) {
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    e->graph_exec = nullptr;
+    e->graph = nullptr;
+    e->graph_rounds = 0;
+}
+
+extern "C" int32_t ccsim_abi_version(void) { return CCSIM_ABI_VERSION; }
+
+extern "C" const char *ccsim_last_error(const ccsim_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
+    if (!cfg || !out) return -EINVAL;
+    if (cfg->abi_version != CCSIM_ABI_VERSION) return -EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return -EIO;
+    ccsim_engine *e = new ccsim_engine();
+    e->device = cfg->device;
+    e->rounds_per_sync = cfg->rounds_per_sync;
+    e->use_graph = cfg->use_graph;
+    if (hipSetDevice(e->device) != hipSuccess) {
+        delete e;
+        return -EIO;
+    }
+    if (cfg->stream) {
+        e->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete e;
+            return -EIO;
+        }
+        e->own_stream = true;
+    }
+    if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&e->d_state, sizeof(DevState)) != hipSuccess ||
+        hipMalloc((void **)&e->d_partials, sizeof(Partial) * kMaxGrid) != hipSuccess ||
+        hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess) {
+        ccsim_destroy(e);
+        return -ENOMEM;
+    }
+    e->d_hist_code = e->d_hist + CCSIM_NREASON;
+    *out = e;
+    return 0;
+}
+
+extern "C" void ccsim_destroy(ccsim_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    drop_graph(e);
+    free_list(e->allocs);
+    free_list(e->pod_allocs);
+    if (e->d_state) (void)hipFree(e->d_state);
+    if (e->d_partials) (void)hipFree(e->d_partials);
+    if (e->d_hist) (void)hipFree(e->d_hist);
+    if (e->d_log) (void)hipFree(e->d_log);
+    if (e->h_state) (void)hipHostFree(e->h_state);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
+    if (!e || !nd) return -EINVAL;
+    if (nd->n_nodes < 0 || nd->n_scalar < 0 || nd->n_scalar > CCSIM_MAX_SCALAR || nd->n_label_cols < 0 ||
+        nd->n_label_cols > CCSIM_MAX_LABEL_COLS)
+        return fail(e, -EINVAL, "bad node snapshot dimensions");
+    if (nd->n_nodes > 0 && (!nd->alloc_pods || !nd->pod_count || !nd->nz_mcpu || !nd->nz_mem))
+        return fail(e, -EINVAL, "alloc_pods, pod_count, nz_mcpu and nz_mem are required");
+    if (nd->global_offset + nd->n_nodes > (1ll << kIdxBits) - 1) return fail(e, -EINVAL, "too many nodes");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    drop_graph(e);
+    free_list(e->allocs);
+    e->have_nodes = e->have_pod = e->begun = false;
+    e->n = nd->n_nodes;
+    e->n_pad = ((e->n + kTile - 1) / kTile) * kTile;
+    if (e->n_pad == 0) e->n_pad = kTile;
+    e->global_offset = nd->global_offset;
+    e->n_global = nd->n_global > 0 ? nd->n_global : nd->n_nodes;
+    e->ncol = 3 + nd->n_scalar;
+    e->n_label_cols = nd->n_label_cols;
+    DevCols c{};
+    c.n = e->n;
+    c.n_pad = e->n_pad;
+    c.global_offset = e->global_offset;
+    const size_t n = (size_t)e->n, np = (size_t)e->n_pad;
+    int rc;
+    for (int col = 0; col < e->ncol; col++) {
+        int64_t *a = nullptr, *r = nullptr;
+        if ((rc = upload(e, &a, nd->alloc[col], n, np, e->allocs))) return rc;
+        if ((rc = upload(e, &r, nd->req[col], n, np, e->allocs))) return rc;
+        c.alloc[col] = a;
+        c.req[col] = r;
+    }
+    int32_t *ap = nullptr, *pc = nullptr, *ts = nullptr, *plc = nullptr;
+    int64_t *z0 = nullptr, *z1 = nullptr;
+    if ((rc = upload(e, &ap, nd->alloc_pods, n, np, e->allocs))) return rc;
+    if ((rc = upload(e, &pc, nd->pod_count, n, np, e->allocs))) return rc;
+    if ((rc = upload(e, &z0, nd->nz_mcpu, n, np, e->allocs))) return rc;
+    if ((rc = upload(e, &z1, nd->nz_mem, n, np, e->allocs))) return rc;
+    if ((rc = upload(e, &ts, nd->taintset_id, n, np, e->allocs))) return rc;
+    if ((rc = upload(e, &e->d_unsched, nd->unschedulable, n, np, e->allocs))) return rc;
+    if ((rc = dev_alloc(e, &plc, np, e->allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_stat, np, e->allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_sreason, np, e->allocs))) return rc;
+    std::vector<int32_t *> lc((size_t)CCSIM_MAX_LABEL_COLS, nullptr);
+    for (int k = 0; k < nd->n_label_cols; k++)
+        if ((rc = upload(e, &lc[k], nd->label_cols[k], n, np, e->allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_label_cols, (size_t)CCSIM_MAX_LABEL_COLS, e->allocs))) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->d_label_cols, lc.data(), sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyHostToDevice,
+                             e->stream));
+    c.alloc_pods = ap;
+    c.pod_count = pc;
+    c.nz_mcpu = z0;
+    c.nz_mem = z1;
+    c.taintset_id = ts;
+    c.placed_cnt = plc;
+    c.stat = e->d_stat;
+    c.sreason = e->d_sreason;
+    e->cols = c;
+    HIPCHK(e, hipStreamSynchronize(e->stream)); // lc / caller arrays may go away after return
+    // launch geometry: one contiguous chunk of nodes per block, <= kMaxGrid blocks
+    int64_t tiles = e->n_pad / kTile;
+    e->grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    e->chunk = ((tiles + e->grid - 1) / e->grid) * kTile;
+    e->grid = (int)((e->n_pad + e->chunk - 1) / e->chunk);
+    e->have_nodes = true;
+    return 0;
+}
+
+extern "C" int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
+    if (!e || !p) return -EINVAL;
+    if (p->percentage_of_nodes_to_score != 100)
+        return fail(e, -ENOSYS, "this engine scores every node: percentageOfNodesToScore must be 100");
+    if (p->filter_mask & CCSIM_F_TOPOLOGYSPREAD || p->w_topologyspread)
+        ; // accepted: PodTopologySpread is a no-op (PreFilter/PreScore Skip) for pods without constraints
+    if (p->n_fit_res < 0 || p->n_fit_res > CCSIM_MAX_RES || p->n_bal_res < 0 || p->n_bal_res > CCSIM_MAX_RES)
+        return fail(e, -EINVAL, "bad resource list");
+    for (int i = 0; i < p->n_fit_res; i++) {
+        if (p->fit_res[i] != 0 && p->fit_res[i] != 1)
+            return fail(e, -ENOSYS, "LeastAllocated resources other than cpu/memory are not supported yet");
+        if (p->fit_res_w[i] < 1 || p->fit_res_w[i] > 100) return fail(e, -EINVAL, "resource weight out of [1,100]");
+    }
+    for (int i = 0; i < p->n_bal_res; i++)
+        if (p->bal_res[i] != 0 && p->bal_res[i] != 1)
+            return fail(e, -ENOSYS, "BalancedAllocation resources other than cpu/memory are not supported yet");
+    e->prof = *p;
+    e->have_profile = true;
+    e->have_pod = false;
+    drop_graph(e);
+    return 0;
+}
+
+extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
+    if (!e || !pod) return -EINVAL;
+    if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
+    if (pod->n_taintsets < 1 || !pod->taint_filter_ok || !pod->taint_prefer_cnt)
+        return fail(e, -EINVAL, "taint tables are required (n_taintsets >= 1)");
+    int64_t wsum = 0;
+    for (int t = 0; t < pod->n_preferred; t++) wsum += pod->preferred[t].weight;
+    if (wsum > (int64_t)kStatAffMask) return fail(e, -EINVAL, "sum of preferred term weights too large");
+    for (int t = 0; t < pod->n_taintsets; t++)
+        if (pod->taint_prefer_cnt[t] < 0 || pod->taint_prefer_cnt[t] > (int32_t)kStatCntMask)
+            return fail(e, -EINVAL, "taint_prefer_cnt out of range");
+    for (int c = 0; c < CCSIM_MAX_RES; c++) {
+        if (pod->req[c] < 0) return fail(e, -EINVAL, "negative request");
+        if (c >= e->ncol && pod->req[c] != 0) return fail(e, -EINVAL, "request for a resource column the snapshot lacks");
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    drop_graph(e);
+    free_list(e->pod_allocs);
+    e->have_pod = e->begun = false;
+    e->n_taintsets = pod->n_taintsets;
+
+    const ccsim_profile &pf = e->prof;
+    DevPod p{};
+    for (int c = 0; c < CCSIM_MAX_RES; c++) p.req[c] = pod->req[c];
+    p.nz_mcpu = pod->nz_mcpu;
+    p.nz_mem = pod->nz_mem;
+    p.ncol = e->ncol;
+    p.fit_enabled = (pf.filter_mask & CCSIM_F_FIT) ? 1 : 0;
+    p.all_zero_req = (pod->req[0] == 0 && pod->req[1] == 0 && pod->req[2] == 0 && !pod->has_scalar_entries) ? 1 : 0;
+    p.nx = 0;
+    for (int c = 2; c < e->ncol; c++)
+        if (pod->req[c] != 0) p.xcol[p.nx++] = c;
+    p.w_taint = pf.w_taint;
+    p.w_aff = pod->n_preferred > 0 ? pf.w_nodeaffinity : 0; // node_affinity.go:243-246 PreScore Skip
+    p.w_fit = pf.w_fit;
+    for (int i = 0; i < pf.n_fit_res; i++) {
+        if (pf.fit_res[i] == 0) { p.fit_cpu = 1; p.fit_w_cpu = pf.fit_res_w[i]; }
+        if (pf.fit_res[i] == 1) { p.fit_mem = 1; p.fit_w_mem = pf.fit_res_w[i]; }
+    }
+    bool best_effort = true; // balanced_allocation.go:66-79
+    for (int i = 0; i < pf.n_bal_res; i++) {
+        if (pf.bal_res[i] == 0) p.bal_cpu = 1;
+        if (pf.bal_res[i] == 1) p.bal_mem = 1;
+        if (pod->req[pf.bal_res[i]] != 0) best_effort = false;
+    }
+    p.w_bal = best_effort ? 0 : pf.w_balanced;
+    e->pod = p;
+
+    // tables for the static kernel
+    StaticArgs s{};
+    s.n = e->n;
+    s.n_pad = e->n_pad;
+    s.filter_mask = pf.filter_mask;
+    s.unschedulable = e->d_unsched;
+    s.taintset_id = e->cols.taintset_id;
+    s.tolerates_unschedulable = pod->tolerates_unschedulable;
+    s.affinity_filter_active = pod->affinity_filter_active;
+    s.has_node_selector = pod->has_node_selector;
+    s.has_required_terms = pod->has_required_terms;
+    s.n_required = pod->n_required;
+    s.n_preferred = p.w_aff ? pod->n_preferred : 0;
+    s.node_selector = DevTerm{pod->node_selector.first_req, pod->node_selector.n_req, 0};
+    s.label_cols = e->d_label_cols;
+    s.stat = e->d_stat;
+    s.sreason = e->d_sreason;
+    int rc;
+    uint8_t *d_ok = nullptr;
+    int32_t *d_cnt = nullptr;
+    if ((rc = upload(e, &d_ok, pod->taint_filter_ok, (size_t)pod->n_taintsets, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
+    std::vector<int32_t> cnt(pod->taint_prefer_cnt, pod->taint_prefer_cnt + pod->n_taintsets);
+    if (!pf.w_taint) std::fill(cnt.begin(), cnt.end(), 0); // plugin disabled: keep the normalization constant fixed
+    if ((rc = upload(e, &d_cnt, cnt.data(), cnt.size(), cnt.size(), e->pod_allocs))) return rc;
+    s.taint_filter_ok = d_ok;
+    s.taint_prefer_cnt = d_cnt;
+    std::vector<DevTerm> rq, pr;
+    for (int t = 0; t < pod->n_required; t++) rq.push_back(DevTerm{pod->required[t].first_req, pod->required[t].n_req, 0});
+    for (int t = 0; t < pod->n_preferred; t++)
+        pr.push_back(DevTerm{pod->preferred[t].first_req, pod->preferred[t].n_req, pod->preferred[t].weight});
+    std::vector<DevReq> reqs;
+    for (int i = 0; i < pod->n_reqs; i++) {
+        if (pod->reqs[i].col < 0 || pod->reqs[i].col >= e->n_label_cols) return fail(e, -EINVAL, "requirement column out of range");
+        reqs.push_back(DevReq{pod->reqs[i].col, pod->reqs[i].table_off});
+    }
+    DevTerm *d_rq = nullptr, *d_pr = nullptr;
+    DevReq *d_reqs = nullptr;
+    uint8_t *d_tab = nullptr;
+    if ((rc = upload(e, &d_rq, rq.data(), rq.size(), rq.size(), e->pod_allocs))) return rc;
+    if ((rc = upload(e, &d_pr, pr.data(), pr.size(), pr.size(), e->pod_allocs))) return rc;
+    if ((rc = upload(e, &d_reqs, reqs.data(), reqs.size(), reqs.size(), e->pod_allocs))) return rc;
+    if ((rc = upload(e, &d_tab, pod->req_tables, (size_t)pod->req_tables_len, (size_t)pod->req_tables_len, e->pod_allocs))) return rc;
+    s.required = d_rq;
+    s.preferred = d_pr;
+    s.reqs = d_reqs;
+    s.req_tables = d_tab;
+    if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
+    const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_static, dim3(blocks), dim3(kThreads), 0, e->stream, s);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream)); // host vectors above go out of scope
+    e->have_pod = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int launch_scan(ccsim_engine *e) {
+    ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk};
+    const int nx = e->pod.nx;
+    dim3 g(e->grid), b(kThreads);
+    if (nx == 0) hipLaunchKernelGGL(k_scan<0>, g, b, 0, e->stream, a);
+    else if (nx == 1) hipLaunchKernelGGL(k_scan<1>, g, b, 0, e->stream, a);
+    else if (nx == 2) hipLaunchKernelGGL(k_scan<2>, g, b, 0, e->stream, a);
+    else if (nx <= 4) hipLaunchKernelGGL(k_scan<4>, g, b, 0, e->stream, a);
+    else hipLaunchKernelGGL(k_scan<kMaxExtra>, g, b, 0, e->stream, a);
+    return 0;
+}
+
+static FinalArgs final_args(ccsim_engine *e) {
+    FinalArgs f{};
+    f.c = e->cols;
+    f.p = e->pod;
+    f.st = e->d_state;
+    f.partials = e->d_partials;
+    f.n_partials = e->grid;
+    f.xsend = e->d_xsend;
+    f.xrecv = e->d_xrecv;
+    f.n_ranks = e->n_ranks;
+    f.log = e->d_log;
+    return f;
+}
+
+static int launch_final(ccsim_engine *e) {
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kThreads), 0, e->stream, final_args(e));
+    return 0;
+}
+
+static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_cap) {
+    if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
+    if (mode != CCSIM_MODE_SEQUENTIAL) return fail(e, -ENOSYS, "mode %d not implemented", mode);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (log_cap != e->log_cap) {
+        if (e->d_log) HIPCHK(e, hipFree(e->d_log));
+        e->d_log = nullptr;
+        e->log_cap = 0;
+        drop_graph(e);
+        if (log_cap > 0) {
+            HIPCHK(e, hipMalloc((void **)&e->d_log, sizeof(int32_t) * (size_t)log_cap));
+            e->log_cap = log_cap;
+        }
+    }
+    DevState st{};
+    st.limit = max_limit;
+    st.winner = -1;
+    st.mode = mode;
+    st.log_cap = e->log_cap;
+    *e->h_state = st;
+    HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
+    e->kernel_ms = 0;
+    e->limit = max_limit;
+    e->mode = mode;
+    e->begun = true;
+    return 0;
+}
+
+static int read_state(ccsim_engine *e) {
+    HIPCHK(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+static int enqueue_rounds(ccsim_engine *e, int rounds) {
+    if (e->use_graph && e->n_ranks == 0) {
+        if (!e->graph_exec || e->graph_rounds != rounds) {
+            drop_graph(e);
+            HIPCHK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            for (int r = 0; r < rounds; r++) {
+                launch_scan(e);
+                launch_final(e);
+            }
+            HIPCHK(e, hipStreamEndCapture(e->stream, &e->graph));
+            HIPCHK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+            e->graph_rounds = rounds;
+        }
+        HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
+    } else {
+        for (int r = 0; r < rounds; r++) {
+            launch_scan(e);
+            launch_final(e);
+        }
+        HIPCHK(e, hipGetLastError());
+    }
+    return 0;
+}
+
+static int fill_report(ccsim_engine *e, ccsim_report *out) {
+    const DevState &st = *e->h_state;
+    out->placed = st.placed;
+    out->stop = e->n_global == 0 ? CCSIM_STOP_NO_NODES : (st.done == DONE_LIMIT ? CCSIM_STOP_LIMIT : CCSIM_STOP_UNSCHEDULABLE);
+    out->rounds = st.rounds;
+    out->scans = st.scans;
+    out->evaluated_total = st.rounds * e->n_global;
+    out->last_feasible = st.last_feasible;
+    out->kernel_ns = (int64_t)(e->kernel_ms * 1e6);
+    // algorithmic bytes per scan: the columns the active plugin set must read once per node
+    int64_t per_node = 4 /*static word*/ + 6 * 8 /*alloc,req,nz x cpu,mem*/ + 2 * 4 /*pods*/ + (int64_t)e->pod.nx * 16;
+    out->bytes_per_scan = per_node * e->n;
+    memset(out->hist, 0, sizeof(out->hist));
+    out->n_code_unschedulable = 0;
+    if (out->hist_taintset)
+        for (int i = 0; i < out->hist_taintset_cap; i++) out->hist_taintset[i] = 0;
+    if (out->per_node_count) {
+        if (out->per_node_cap < e->n) return fail(e, -EINVAL, "per_node_cap too small");
+        HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+    }
+    out->log_len = 0;
+    if (out->log && e->d_log) {
+        int64_t len = st.placed < e->log_cap ? st.placed : e->log_cap;
+        if (len > out->log_cap) len = out->log_cap;
+        if (len > 0) HIPCHK(e, hipMemcpyAsync(out->log, e->d_log, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, e->stream));
+        out->log_len = len;
+    }
+    if (st.done == DONE_UNSCHEDULABLE && e->n > 0) {
+        // terminal round: FitError diagnosis (types.go:787-836)
+        HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
+        HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
+        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code};
+        hipLaunchKernelGGL(k_hist, dim3((unsigned)((e->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, h);
+        HIPCHK(e, hipGetLastError());
+        std::vector<unsigned long long> hh(CCSIM_NREASON + 1), ht((size_t)e->n_taintsets);
+        HIPCHK(e, hipMemcpyAsync(hh.data(), e->d_hist, sizeof(unsigned long long) * hh.size(), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(ht.data(), e->d_hist_ts, sizeof(unsigned long long) * ht.size(), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        for (int i = 0; i < CCSIM_NREASON; i++) out->hist[i] = (int64_t)hh[i];
+        out->n_code_unschedulable = (int64_t)hh[CCSIM_NREASON];
+        if (out->hist_taintset)
+            for (int i = 0; i < e->n_taintsets && i < out->hist_taintset_cap; i++) out->hist_taintset[i] = (int64_t)ht[i];
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
+    if (!e || !out) return -EINVAL;
+    e->n_ranks = 0;
+    e->d_xsend = e->d_xrecv = nullptr;
+    int rc = begin_run(e, max_limit, mode, out->log ? out->log_cap : 0);
+    if (rc) return rc;
+    if (e->n == 0) { // schedule_one.go:438-440 ErrNoNodesAvailable
+        e->h_state->done = DONE_UNSCHEDULABLE;
+        return fill_report(e, out);
+    }
+    int rps = e->rounds_per_sync > 0 ? e->rounds_per_sync : 256;
+    for (;;) {
+        int rounds = rps;
+        if (max_limit > 0) {
+            // no point enqueuing far beyond the limit (each committed round needs >= 1 scan)
+            int64_t left = max_limit - e->h_state->placed + 2;
+            if (left < rounds) rounds = (int)(left < 1 ? 1 : left);
+            if (e->use_graph && rounds != rps) rounds = rps; // keep one graph shape; extra rounds are no-ops after done
+        }
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        if ((rc = enqueue_rounds(e, rounds))) return rc;
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        if ((rc = read_state(e))) return rc;
+        float ms = 0;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->kernel_ms += ms;
+        if (e->h_state->done) break;
+    }
+    return fill_report(e, out);
+}
+
+extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
+    if (!e || !out) return -EINVAL;
+    int rc;
+    if (!e->begun) {
+        e->n_ranks = 0;
+        if ((rc = begin_run(e, 0, CCSIM_MODE_SEQUENTIAL, 0))) return rc;
+    }
+    out->node = -1;
+    out->evaluated_nodes = (int32_t)e->n_global;
+    out->feasible_nodes = 0;
+    if (e->n == 0) return 0;
+    const int64_t rounds0 = e->h_state->rounds;
+    for (int tries = 0; tries < 4; tries++) {
+        launch_scan(e);
+        launch_final(e);
+        HIPCHK(e, hipGetLastError());
+        if ((rc = read_state(e))) return rc;
+        if (e->h_state->rounds != rounds0 || e->h_state->done) break;
+    }
+    if (e->h_state->rounds == rounds0) return fail(e, -EIO, "scheduling cycle did not converge");
+    if (e->h_state->done == DONE_UNSCHEDULABLE) {
+        // allow further cycles to be attempted (each returns FitError again)
+        e->h_state->done = DONE_RUNNING;
+        HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        return 0;
+    }
+    out->node = e->h_state->winner;
+    out->feasible_nodes = e->h_state->last_feasible;
+    return 0;
+}
+
+extern "C" int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req_mem, int64_t *nz_mcpu, int64_t *nz_mem,
+                                int32_t *pod_count) {
+    if (!e || !e->have_nodes) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t n = (size_t)e->n;
+    if (req_mcpu) HIPCHK(e, hipMemcpyAsync(req_mcpu, e->cols.req[0], 8 * n, hipMemcpyDeviceToHost, e->stream));
+    if (req_mem) HIPCHK(e, hipMemcpyAsync(req_mem, e->cols.req[1], 8 * n, hipMemcpyDeviceToHost, e->stream));
+    if (nz_mcpu) HIPCHK(e, hipMemcpyAsync(nz_mcpu, e->cols.nz_mcpu, 8 * n, hipMemcpyDeviceToHost, e->stream));
+    if (nz_mem) HIPCHK(e, hipMemcpyAsync(nz_mem, e->cols.nz_mem, 8 * n, hipMemcpyDeviceToHost, e->stream));
+    if (pod_count) HIPCHK(e, hipMemcpyAsync(pod_count, e->cols.pod_count, 4 * n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ---- measurement aid: time `iters` back-to-back launches of the dominant kernel (k_scan) with HIP
+// events on the engine's stream; state is not advanced (no k_final in between). -------------------
+extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan) {
+    if (!e || iters <= 0 || !total_ns) return -EINVAL;
+    int rc;
+    if (!e->begun && (rc = begin_run(e, 0, CCSIM_MODE_SEQUENTIAL, 0))) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    for (int i = 0; i < 3; i++) launch_scan(e);
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    for (int i = 0; i < iters; i++) launch_scan(e);
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipGetLastError());
+    float ms = 0;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    *total_ns = (int64_t)((double)ms * 1e6);
+    if (bytes_per_scan) {
+        int64_t per_node = 4 + 6 * 8 + 2 * 4 + (int64_t)e->pod.nx * 16;
+        *bytes_per_scan = per_node * e->n;
+    }
+    return 0;
+}
+
+// ---- distributed stepping (one rank per GPU; the collective itself is the caller's: RCCL through
+// torch.distributed on the same stream) -----------------------------------------------------------
+extern "C" int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, void *sendbuf,
+                                void *recvbuf, int64_t log_cap) {
+    if (!e || n_ranks < 1 || !sendbuf || !recvbuf) return -EINVAL;
+    e->n_ranks = n_ranks;
+    e->d_xsend = (XRec *)sendbuf;
+    e->d_xrecv = (XRec *)recvbuf;
+    return begin_run(e, max_limit, mode, log_cap);
+}
+
+extern "C" int ccsim_dist_scan(ccsim_engine *e) {
+    if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    launch_scan(e);
+    launch_final(e); // n_ranks > 0: publishes this shard's record into sendbuf
+    HIPCHK(e, hipGetLastError());
+    return 0;
+}
+
+extern "C" int ccsim_dist_decide(ccsim_engine *e) {
+    if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, final_args(e));
+    HIPCHK(e, hipGetLastError());
+    return 0;
+}
+
+extern "C" int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed) {
+    if (!e || !e->begun) return -EINVAL;
+    int rc = read_state(e);
+    if (rc) return rc;
+    if (done) *done = e->h_state->done;
+    if (placed) *placed = e->h_state->placed;
+    return 0;
+}
+
+extern "C" int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out) {
+    if (!e || !out || !e->begun) return -EINVAL;
+    int rc = read_state(e);
+    if (rc) return rc;
+    return fill_report(e, out);
+}

@@ -1,0 +1,541 @@
+// ccsim_kernels.h -- CDNA4 (gfx950) kernels of the batched placement engine.
+//
+// Integer / bitmask / fp64 work over structure-of-arrays node columns resident in HBM; no MFMA
+// (nothing here is a contraction).  Layout and launch shape are chosen for the memory system:
+//   * every column is a dense array in canonical node order, padded to a multiple of TILE nodes;
+//     a thread owns 2 consecutive nodes so int64 columns are read with 16-byte loads and int32
+//     columns with 8-byte loads: one 1 KiB / 512 B fully coalesced request per wave instruction;
+//   * a block owns one CONTIGUOUS chunk of nodes for the whole run, so the same XCD (block b ->
+//     XCD b % 8) re-reads the same lines every round and finds them in its own L2 / the MALL;
+//   * feasibility is a wave64 __ballot (popcount = feasible count), the argmax is a packed
+//     (score, position) 64-bit key reduced with DPP/shuffle max per wave, LDS across the 4 waves,
+//     one 16-byte partial record per block -- no atomics on the hot path;
+//   * cross-block agreement happens at kernel boundaries (cheaper than an in-kernel grid barrier
+//     on this chip): k_scan (grid) -> k_final (1 block: reduce partials, decide, commit).
+//
+// Reference arithmetic restated here (file:line under vendor/k8s.io/kubernetes/pkg/scheduler):
+//   fitsRequest                 framework/plugins/noderesources/fit.go:564-660
+//   leastRequestedScore         framework/plugins/noderesources/least_allocated.go:30-61
+//   balancedResourceScorer      framework/plugins/noderesources/balanced_allocation.go:146-180
+//   DefaultNormalizeScore       framework/plugins/helper/normalize_score.go:28-56
+//   weight & sum                framework/runtime/framework.go:1214-1238
+//   selectHost                  schedule_one.go:894-941 (canonical tie-break: lowest position)
+//   NodeInfo.update             framework/types.go:409-428
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ccsim {
+
+constexpr int kMaxRes = 11;
+constexpr int kMaxExtra = 9;       // ephemeral + 8 scalars
+constexpr int kThreads = 256;      // 4 waves
+constexpr int kNodesPerThread = 2; // 16-byte loads on int64 columns
+constexpr int kTile = kThreads * kNodesPerThread;
+constexpr int kMaxGrid = 1024;     // 4 blocks per CU
+constexpr int kIdxBits = 40;
+constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1;
+constexpr int kStatOkBit = 31, kStatCntShift = 20;
+constexpr uint32_t kStatAffMask = (1u << kStatCntShift) - 1, kStatCntMask = 0x7ffu;
+
+enum { DONE_RUNNING = 0, DONE_UNSCHEDULABLE = 1, DONE_LIMIT = 2 };
+
+// node columns (device pointers), passed by value
+struct DevCols {
+    const int64_t *alloc[kMaxRes];
+    int64_t *req[kMaxRes];
+    const int32_t *alloc_pods;
+    int32_t *pod_count;
+    int64_t *nz_mcpu, *nz_mem;
+    const uint32_t *stat;  // static word per node for the current pod spec
+    const uint8_t *sreason; // which static filter rejected the node (0 none 1 unschedulable 2 taint 3 affinity)
+    const int32_t *taintset_id;
+    int32_t *placed_cnt;   // simulated pods per node
+    int64_t n;             // real node count of this shard
+    int64_t n_pad;         // padded to kTile
+    int64_t global_offset; // canonical index of node 0 of this shard
+};
+
+// pod + profile constants, passed by value
+struct DevPod {
+    int64_t req[kMaxRes];
+    int64_t nz_mcpu, nz_mem;
+    int32_t fit_enabled;
+    int32_t all_zero_req; // fit.go:578-583 early return
+    int32_t nx;           // active extra columns (checked by the Fit filter)
+    int32_t xcol[kMaxExtra];
+    int32_t w_taint, w_aff, w_fit, w_bal;
+    int32_t fit_cpu, fit_mem; // resource present in the LeastAllocated list
+    int64_t fit_w_cpu, fit_w_mem;
+    int32_t bal_cpu, bal_mem; // resource present in the BalancedAllocation list
+    int32_t ncol;
+};
+
+struct DevState {
+    int64_t placed, limit, rounds, scans;
+    int64_t winner; // global index committed by the last decide (-1 none)
+    int32_t done, have_prev;
+    int32_t mt_a, ma_a; // normalization maxima the pending scan result was computed with
+    int32_t last_feasible, mode;
+    int64_t log_cap;
+};
+
+// per-block result of one scan: 16 bytes
+struct __attribute__((aligned(16))) Partial {
+    uint64_t key;   // ((total+1) << 40) | (2^40-1 - global index); 0 = no feasible node
+    uint32_t norm;  // (max prefer-count << 20) | max affinity-sum, over this block's feasible nodes
+    uint32_t nfeas;
+};
+
+// exchange record (int64[8], see CCSIM_XCHG_WORDS): every word combines with MAX except nfeas (sum)
+struct XRec {
+    int64_t key, mt, ma, nfeas, pad[4];
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// floor(num / cap) for 0 <= num <= 100 * cap, exact: fp64 estimate + integer fix-up (a 64-bit integer
+// divide is ~10x the instructions on CDNA; the estimate is off by at most one).
+__device__ __forceinline__ int64_t div_small_quotient(int64_t num, int64_t cap) {
+    int64_t q = (int64_t)((double)num / (double)cap);
+    int64_t r = num - q * cap;
+    if (r < 0) q -= 1;
+    else if (r >= cap) q += 1;
+    return q;
+}
+
+// least_allocated.go:52-61
+__device__ __forceinline__ int64_t least_requested_score(int64_t requested, int64_t capacity) {
+    if (capacity == 0) return 0;
+    if (requested > capacity) return 0;
+    return div_small_quotient((capacity - requested) * 100, capacity);
+}
+
+// Score pair for one node in a given dynamic state: returns LeastAllocated*w_fit + Balanced*w_bal.
+__device__ __forceinline__ int64_t dynamic_score(const DevPod &p, int64_t a_cpu, int64_t a_mem, int64_t r_cpu,
+                                                 int64_t r_mem, int64_t z_cpu, int64_t z_mem) {
+    int64_t total = 0;
+    if (p.w_fit) {
+        // resource_allocation.go:48-114 with useRequested=false: NonZeroRequested + non-zero pod request
+        int64_t node_score = 0, weight_sum = 0;
+        if (p.fit_cpu && a_cpu != 0) {
+            node_score += least_requested_score(z_cpu + p.nz_mcpu, a_cpu) * p.fit_w_cpu;
+            weight_sum += p.fit_w_cpu;
+        }
+        if (p.fit_mem && a_mem != 0) {
+            node_score += least_requested_score(z_mem + p.nz_mem, a_mem) * p.fit_w_mem;
+            weight_sum += p.fit_w_mem;
+        }
+        // weights are small positive ints; node_score <= 100 * weight_sum
+        int64_t s = weight_sum == 0 ? 0 : div_small_quotient(node_score, weight_sum);
+        total += s * p.w_fit;
+    }
+    if (p.w_bal) {
+        // balanced_allocation.go:146-180 with useRequested=true: Requested + raw pod request
+        double f0 = 0, f1 = 0;
+        int m = 0;
+        if (p.bal_cpu && a_cpu != 0) {
+            double f = (double)(r_cpu + p.req[0]) / (double)a_cpu;
+            f0 = f > 1 ? 1 : f;
+            m++;
+        }
+        if (p.bal_mem && a_mem != 0) {
+            double f = (double)(r_mem + p.req[1]) / (double)a_mem;
+            f = f > 1 ? 1 : f;
+            if (m == 0) f0 = f; else f1 = f;
+            m++;
+        }
+        double std = 0.0;
+        if (m == 2) std = fabs((f0 - f1) / 2);
+        total += (int64_t)((1 - std) * 100.0) * p.w_bal;
+    }
+    return total;
+}
+
+// NodeResourcesFit filter for the cpu/mem/pods part (fit.go:564-615); extras are checked by the caller.
+__device__ __forceinline__ bool fits_core(const DevPod &p, int64_t a_cpu, int64_t a_mem, int64_t r_cpu, int64_t r_mem,
+                                          int32_t a_pods, int32_t npods) {
+    if (!p.fit_enabled) return true;
+    bool ok = (int64_t)npods + 1 <= (int64_t)a_pods;
+    if (!p.all_zero_req) {
+        if (p.req[0] > 0 && p.req[0] > a_cpu - r_cpu) ok = false;
+        if (p.req[1] > 0 && p.req[1] > a_mem - r_mem) ok = false;
+    }
+    return ok;
+}
+
+// static (pod-spec dependent, state independent) part of the total:
+//   TaintToleration: DefaultNormalizeScore(100, reverse) ; NodeAffinity: DefaultNormalizeScore(100)
+__device__ __forceinline__ int64_t static_score(const DevPod &p, uint32_t c, uint32_t a, uint32_t mt, uint32_t ma) {
+    int64_t t = 0;
+    if (p.w_taint) t += (int64_t)(mt == 0 ? 100u : 100u - (100u * c) / mt) * p.w_taint;
+    if (p.w_aff) t += (int64_t)(ma == 0 ? 0u : (100u * a) / ma) * p.w_aff; // w_aff is 0 when PreScore skips
+    return t;
+}
+
+__device__ __forceinline__ uint64_t make_key(int64_t total, int64_t gidx) {
+    return ((uint64_t)(total + 1) << kIdxBits) | (kIdxMask - (uint64_t)gidx);
+}
+__device__ __forceinline__ int64_t key_index(uint64_t key) { return (int64_t)(kIdxMask - (key & kIdxMask)); }
+__device__ __forceinline__ int64_t key_score(uint64_t key) { return (int64_t)(key >> kIdxBits) - 1; }
+
+// ------------------------------------------------------------------------------------------------
+// k_scan: one full pods x nodes pass for the current pod spec: Filter (static bit + Fit), Score
+// (TaintToleration, NodeAffinity, LeastAllocated, BalancedAllocation), weighted sum, per-block argmax.
+// ------------------------------------------------------------------------------------------------
+struct ScanArgs {
+    DevCols c;
+    DevPod p;
+    const DevState *st;
+    Partial *partials;
+    int64_t chunk; // nodes per block (multiple of kTile)
+};
+
+template <int NX>
+__global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
+    const DevState st = *a.st;
+    if (st.done) return;
+    const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
+    const int tid = threadIdx.x;
+    const int64_t lo = (int64_t)blockIdx.x * a.chunk;
+    int64_t hi = lo + a.chunk;
+    if (hi > a.c.n_pad) hi = a.c.n_pad;
+
+    uint64_t best = 0;
+    uint32_t mt_b = 0, ma_b = 0, nfeas = 0;
+
+    for (int64_t base = lo; base < hi; base += kTile) {
+        const int64_t i0 = base + 2 * tid; // first of this thread's 2 nodes
+        const uint2 sw = *reinterpret_cast<const uint2 *>(a.c.stat + i0);
+        const longlong2 A0 = *reinterpret_cast<const longlong2 *>(a.c.alloc[0] + i0);
+        const longlong2 A1 = *reinterpret_cast<const longlong2 *>(a.c.alloc[1] + i0);
+        const longlong2 R0 = *reinterpret_cast<const longlong2 *>(a.c.req[0] + i0);
+        const longlong2 R1 = *reinterpret_cast<const longlong2 *>(a.c.req[1] + i0);
+        const longlong2 Z0 = *reinterpret_cast<const longlong2 *>(a.c.nz_mcpu + i0);
+        const longlong2 Z1 = *reinterpret_cast<const longlong2 *>(a.c.nz_mem + i0);
+        const int2 AP = *reinterpret_cast<const int2 *>(a.c.alloc_pods + i0);
+        const int2 NP = *reinterpret_cast<const int2 *>(a.c.pod_count + i0);
+        bool xok0 = true, xok1 = true;
+        if (NX > 0 && a.p.fit_enabled && !a.p.all_zero_req) {
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                if (x < a.p.nx) {
+                    const int col = a.p.xcol[x];
+                    const longlong2 XA = *reinterpret_cast<const longlong2 *>(a.c.alloc[col] + i0);
+                    const longlong2 XR = *reinterpret_cast<const longlong2 *>(a.c.req[col] + i0);
+                    const int64_t rq = a.p.req[col];
+                    if (rq > XA.x - XR.x) xok0 = false;
+                    if (rq > XA.y - XR.y) xok1 = false;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t w = k ? sw.y : sw.x;
+            const int64_t a_cpu = k ? A0.y : A0.x, a_mem = k ? A1.y : A1.x;
+            const int64_t r_cpu = k ? R0.y : R0.x, r_mem = k ? R1.y : R1.x;
+            const int64_t z_cpu = k ? Z0.y : Z0.x, z_mem = k ? Z1.y : Z1.x;
+            const int32_t a_pods = k ? AP.y : AP.x, npods = k ? NP.y : NP.x;
+            const bool feasible = (w >> kStatOkBit) && (k ? xok1 : xok0) &&
+                                  fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods);
+            const uint64_t mask = __ballot(feasible);
+            nfeas += (uint32_t)__popcll(mask); // identical in every lane of the wave
+            if (feasible) {
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                const int64_t total = static_score(a.p, cnt, aff, mt, ma) +
+                                      dynamic_score(a.p, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem);
+                const uint64_t key = make_key(total, a.c.global_offset + i0 + k);
+                best = key > best ? key : best;
+                mt_b = cnt > mt_b ? cnt : mt_b;
+                ma_b = aff > ma_b ? aff : ma_b;
+            }
+        }
+    }
+
+    // wave reduce, then LDS across the 4 waves
+    best = wave_max_u64(best);
+    mt_b = wave_max_u32(mt_b);
+    ma_b = wave_max_u32(ma_b);
+    __shared__ uint64_t s_key[kThreads / 64];
+    __shared__ uint32_t s_mt[kThreads / 64], s_ma[kThreads / 64], s_nf[kThreads / 64];
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) {
+        s_key[wave] = best;
+        s_mt[wave] = mt_b;
+        s_ma[wave] = ma_b;
+        s_nf[wave] = nfeas;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Partial out;
+        out.key = 0;
+        uint32_t m1 = 0, m2 = 0, nf = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; w++) {
+            out.key = s_key[w] > out.key ? s_key[w] : out.key;
+            m1 = s_mt[w] > m1 ? s_mt[w] : m1;
+            m2 = s_ma[w] > m2 ? s_ma[w] : m2;
+            nf += s_nf[w];
+        }
+        out.norm = (m1 << kStatCntShift) | m2;
+        out.nfeas = nf;
+        a.partials[blockIdx.x] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decide + commit (one thread): the sequential part of a scheduling cycle.
+//   schedule_one.go:448-463 (0 feasible -> FitError), selectHost :894-941, assume :967-984,
+//   simulator.go:297-312 (limit test after the append).
+// The pending scan was computed with (mt_a, ma_a); if the true maxima over the feasible set differ,
+// the scores were normalized with the wrong constants: fix the constants and rescan, commit nothing.
+// ------------------------------------------------------------------------------------------------
+struct FinalArgs {
+    DevCols c;
+    DevPod p;
+    DevState *st;
+    const Partial *partials;
+    int32_t n_partials;
+    XRec *xsend;       // distributed: local record out
+    const XRec *xrecv; // distributed: gathered records in
+    int32_t n_ranks;   // 0 = single GPU (decide from the local record)
+    int32_t *log;
+};
+
+__device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas) {
+    DevState st = *a.st;
+    st.winner = -1;
+    if (st.done) return;
+    st.scans += 1;
+    if (key == 0) {
+        st.done = DONE_UNSCHEDULABLE;
+        st.rounds += 1;
+        st.last_feasible = 0;
+    } else if ((int32_t)mt != st.mt_a || (int32_t)ma != st.ma_a) {
+        st.mt_a = (int32_t)mt;
+        st.ma_a = (int32_t)ma;
+    } else {
+        const int64_t g = key_index(key);
+        const int64_t i = g - a.c.global_offset;
+        if (i >= 0 && i < a.c.n) { // this shard owns the winner: NodeInfo.update (types.go:409-428)
+#pragma unroll 1
+            for (int col = 0; col < a.p.ncol; col++)
+                if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
+            a.c.nz_mcpu[i] += a.p.nz_mcpu;
+            a.c.nz_mem[i] += a.p.nz_mem;
+            a.c.pod_count[i] += 1;
+            a.c.placed_cnt[i] += 1;
+        }
+        if (a.log && st.placed < st.log_cap) a.log[st.placed] = (int32_t)g;
+        st.placed += 1;
+        st.rounds += 1;
+        st.winner = g;
+        st.last_feasible = (int32_t)nfeas;
+        if (st.limit > 0 && st.placed >= st.limit) st.done = DONE_LIMIT;
+    }
+    *a.st = st;
+}
+
+// k_final: one block.  Reduces the per-block partials of the scan that just finished, then either
+// decides + commits (single GPU) or publishes the shard's record for the cross-GPU exchange.
+__global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
+    if (a.st->done) return;
+    const int tid = threadIdx.x;
+    uint64_t key = 0;
+    uint32_t mt = 0, ma = 0;
+    int64_t nf = 0;
+    for (int i = tid; i < a.n_partials; i += kThreads) {
+        const Partial q = a.partials[i];
+        key = q.key > key ? q.key : key;
+        const uint32_t m1 = q.norm >> kStatCntShift, m2 = q.norm & kStatAffMask;
+        mt = m1 > mt ? m1 : mt;
+        ma = m2 > ma ? m2 : ma;
+        nf += q.nfeas;
+    }
+    key = wave_max_u64(key);
+    mt = wave_max_u32(mt);
+    ma = wave_max_u32(ma);
+    nf = wave_sum_i64(nf);
+    __shared__ uint64_t s_key[kThreads / 64];
+    __shared__ uint32_t s_mt[kThreads / 64], s_ma[kThreads / 64];
+    __shared__ int64_t s_nf[kThreads / 64];
+    if ((tid & 63) == 0) {
+        s_key[tid >> 6] = key;
+        s_mt[tid >> 6] = mt;
+        s_ma[tid >> 6] = ma;
+        s_nf[tid >> 6] = nf;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    key = 0, mt = 0, ma = 0, nf = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) {
+        key = s_key[w] > key ? s_key[w] : key;
+        mt = s_mt[w] > mt ? s_mt[w] : mt;
+        ma = s_ma[w] > ma ? s_ma[w] : ma;
+        nf += s_nf[w];
+    }
+    if (a.n_ranks > 0) {
+        XRec r;
+        r.key = (int64_t)key;
+        r.mt = mt;
+        r.ma = ma;
+        r.nfeas = nf;
+        r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0;
+        *a.xsend = r;
+        return;
+    }
+    decide_commit(a, key, mt, ma, nf);
+}
+
+// k_decide (distributed): every rank reduces the gathered records identically, so all ranks agree on
+// the winner; only the owning rank's columns change ("only the owning rank updates").
+__global__ void k_decide(FinalArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (a.st->done) return;
+    uint64_t key = 0;
+    uint32_t mt = 0, ma = 0;
+    int64_t nf = 0;
+    for (int r = 0; r < a.n_ranks; r++) {
+        const XRec q = a.xrecv[r];
+        key = (uint64_t)q.key > key ? (uint64_t)q.key : key;
+        mt = (uint32_t)q.mt > mt ? (uint32_t)q.mt : mt;
+        ma = (uint32_t)q.ma > ma ? (uint32_t)q.ma : ma;
+        nf += q.nfeas;
+    }
+    decide_commit(a, key, mt, ma, nf);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_static: once per pod spec.  NodeUnschedulable (node_unschedulable.go:133-150), TaintToleration
+// filter + PreferNoSchedule count via the taint-set table (taint_toleration.go:111-121,169-194),
+// NodeAffinity required match + preferred weight sum via requirement tables
+// (component-helpers nodeaffinity.go:84-150; node_affinity.go:206-285).
+// ------------------------------------------------------------------------------------------------
+struct DevTerm {
+    int32_t first_req, n_req, weight;
+};
+struct DevReq {
+    int32_t col, table_off;
+};
+struct StaticArgs {
+    int64_t n, n_pad;
+    uint32_t filter_mask;
+    const uint8_t *unschedulable;
+    const int32_t *taintset_id;
+    const uint8_t *taint_filter_ok;
+    const int32_t *taint_prefer_cnt;
+    int32_t tolerates_unschedulable;
+    int32_t affinity_filter_active, has_node_selector, has_required_terms, n_required, n_preferred;
+    DevTerm node_selector;
+    const DevTerm *required;
+    const DevTerm *preferred;
+    const DevReq *reqs;
+    const uint8_t *req_tables;
+    const int32_t *const *label_cols; // device array of column pointers
+    uint32_t *stat;
+    uint8_t *sreason;
+};
+
+__device__ __forceinline__ bool term_matches(const StaticArgs &a, const DevTerm &t, int64_t n, bool empty_matches) {
+    if (t.n_req == 0) return empty_matches;
+    for (int i = 0; i < t.n_req; i++) {
+        const DevReq r = a.reqs[t.first_req + i];
+        if (!a.req_tables[r.table_off + a.label_cols[r.col][n]]) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(kThreads) void k_static(StaticArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= a.n_pad) return;
+    if (n >= a.n) { // padding: never feasible
+        a.stat[n] = 0;
+        a.sreason[n] = 0xff;
+        return;
+    }
+    uint32_t reason = 0;
+    const int32_t ts = a.taintset_id ? a.taintset_id[n] : 0;
+    if ((a.filter_mask & 1u) && a.unschedulable && a.unschedulable[n] && !a.tolerates_unschedulable) reason = 1;
+    if (!reason && (a.filter_mask & 4u) && !a.taint_filter_ok[ts]) reason = 2;
+    if (!reason && (a.filter_mask & 8u) && a.affinity_filter_active) {
+        bool m = true;
+        if (a.has_node_selector) m = term_matches(a, a.node_selector, n, true);
+        if (m && a.has_required_terms) {
+            bool any = false;
+            for (int t = 0; t < a.n_required && !any; t++) any = term_matches(a, a.required[t], n, false);
+            m = any;
+        }
+        if (!m) reason = 3;
+    }
+    uint32_t cnt = (uint32_t)a.taint_prefer_cnt[ts];
+    uint32_t aff = 0;
+    for (int t = 0; t < a.n_preferred; t++)
+        if (term_matches(a, a.preferred[t], n, false)) aff += (uint32_t)a.preferred[t].weight;
+    a.stat[n] = ((reason == 0 ? 1u : 0u) << kStatOkBit) | ((cnt & kStatCntMask) << kStatCntShift) | (aff & kStatAffMask);
+    a.sreason[n] = (uint8_t)reason;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_hist: terminal round only.  Per-node failure reasons exactly as the filter chain reports them
+// (first failing plugin in order; NodeResourcesFit keeps ALL its insufficient resources,
+// fit.go:520-531), histogrammed for FitError.Error (types.go:787-836).
+//   hist[0] unschedulable, [1] nodename, [2] node affinity, [3] too many pods, [4+col] insufficient col,
+//   hist_code[0] = nodes whose status code is plain Unschedulable (preemption dry-run candidates).
+// ------------------------------------------------------------------------------------------------
+struct HistArgs {
+    DevCols c;
+    DevPod p;
+    unsigned long long *hist;      // [4 + kMaxRes + 2]
+    unsigned long long *hist_ts;   // [n_taintsets]
+    unsigned long long *hist_code; // [1]
+};
+
+__global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= a.c.n) return;
+    const uint8_t sr = a.c.sreason[n];
+    if (sr == 1) { atomicAdd(&a.hist[0], 1ull); return; }
+    if (sr == 2) { atomicAdd(&a.hist_ts[a.c.taintset_id ? a.c.taintset_id[n] : 0], 1ull); return; }
+    if (sr == 3) { atomicAdd(&a.hist[2], 1ull); return; }
+    if (!a.p.fit_enabled) return;
+    bool unresolvable = false, any = false;
+    if ((int64_t)a.c.pod_count[n] + 1 > (int64_t)a.c.alloc_pods[n]) { atomicAdd(&a.hist[3], 1ull); any = true; }
+    if (!a.p.all_zero_req) {
+        for (int col = 0; col < a.p.ncol; col++) {
+            const int64_t rq = a.p.req[col];
+            if (col < 3 ? !(rq > 0) : rq == 0) continue;
+            const int64_t al = a.c.alloc[col] ? a.c.alloc[col][n] : 0;
+            const int64_t us = a.c.req[col] ? a.c.req[col][n] : 0;
+            if (rq > al - us) {
+                atomicAdd(&a.hist[4 + col], 1ull);
+                any = true;
+                if (rq > al) unresolvable = true;
+            }
+        }
+    }
+    if (any && !unresolvable) atomicAdd(&a.hist_code[0], 1ull);
+}
+
+} // namespace ccsim

@@ -1,0 +1,69 @@
+"""Multi-GPU driver: one process per GPU, node-range shards, one RCCL collective per round.
+
+torch.distributed is plumbing here (process group + the collective over xGMI); the shard work is
+the HIP engine.  Protocol per placement round (include/ccsim.h "multi-GPU stepping"):
+
+    engine.dist_scan()                         # k_scan on the shard -> 64-byte record in `send`
+    dist.all_gather_into_tensor(recv, send)    # the max-loc exchange (packed key in word 0)
+    engine.dist_decide()                       # identical reduction on every rank; owner commits
+
+The engine enqueues on torch's current stream, so the collective is ordered with the kernels
+without any host synchronization; the host only syncs every `rounds_per_poll` rounds to read the
+done flag.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import capi
+from . import model as M
+
+
+def shard_bounds(n_global: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous ranges of the canonical node order: rank g owns [g*ceil(N/G), (g+1)*ceil(N/G))."""
+    per = -(-n_global // world)
+    lo = min(n_global, rank * per)
+    return lo, min(n_global, lo + per)
+
+
+class DistRunner:
+    """Drives one rank's engine; `collective(recv, send)` performs the all-gather."""
+
+    def __init__(self, engine, world: int, send, recv, collective, rounds_per_poll: int = 32):
+        self.engine, self.world, self.send, self.recv = engine, world, send, recv
+        self.collective = collective
+        self.rounds_per_poll = rounds_per_poll
+
+    def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0) -> M.RunResult:
+        e = self.engine
+        e.dist_begin(max_limit, mode, self.world, self.send.data_ptr(), self.recv.data_ptr(), log_cap if want_log else 0)
+        while True:
+            for _ in range(self.rounds_per_poll):
+                e.dist_scan()
+                self.collective(self.recv, self.send)
+                e.dist_decide()
+            done, _placed = e.dist_poll()
+            if done:
+                break
+        return e.dist_finish(want_log, log_cap)
+
+
+def make_torch_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int, n_global: int,
+                      device: int, rounds_per_poll: int = 32) -> DistRunner:
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(device)
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = capi.Engine(device=device, stream=stream, use_graph=False)
+    eng.load(nodes_shard, pod, profile, global_offset=global_offset, n_global=n_global)
+    world = dist.get_world_size()
+    send = torch.zeros(capi.XCHG_WORDS, dtype=torch.int64, device=f"cuda:{device}")
+    recv = torch.zeros(capi.XCHG_WORDS * world, dtype=torch.int64, device=f"cuda:{device}")
+
+    def collective(r, s):
+        dist.all_gather_into_tensor(r, s)
+
+    return DistRunner(eng, world, send, recv, collective, rounds_per_poll)

@@ -1,0 +1,229 @@
+/*
+ * ccsim.h -- C ABI of libccsim.so, the MI355X-native batched placement engine that replaces the
+ * sequential schedule-one-pod loop of kubernetes-sigs/cluster-capacity.
+ *
+ * This is the drop-in boundary: what a cgo shim in pkg/framework, a Python ctypes
+ * harness and the C++ CLI all bind.  Each entry point names the reference interface it replaces.
+ * Paths are relative to the reference root; S/ = vendor/k8s.io/kubernetes/pkg/scheduler,
+ * P/ = S/framework/plugins.
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch types; no exceptions cross the boundary.
+ *   - return value: 0 = OK; < 0 = error (-EINVAL bad argument, -ENOMEM, -EIO HIP failure, -ENOSYS
+ *     unsupported configuration).  ccsim_last_error() returns the text.
+ *   - the caller owns every input array; the library copies during the call and never retains a
+ *     caller pointer (cgo rule).  Output arrays are caller-allocated with explicit capacities.
+ *   - strings never cross the boundary: taints/labels/selectors are interned ids and small lookup
+ *     tables built by the host layer (cluster-capacity_amd/host).
+ *   - a handle is single-caller (the reference calls schedulePod strictly serially,
+ *     S/schedule_one.go:65); every entry point sets the HIP device itself.
+ *
+ * Resource "columns": 0 = cpu (milli), 1 = memory, 2 = ephemeral-storage, 3+k = scalar resource k
+ * (S/framework/types.go:940-950 Resource).
+ */
+#ifndef CCSIM_H
+#define CCSIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCSIM_ABI_VERSION 1
+#define CCSIM_MAX_SCALAR 8
+#define CCSIM_MAX_RES (3 + CCSIM_MAX_SCALAR)
+#define CCSIM_MAX_LABEL_COLS 32
+#define CCSIM_MAX_TSC 8
+
+/* filter plugins, default profile order (S/apis/config/v1/default_plugins.go:30-58) */
+enum {
+    CCSIM_F_UNSCHEDULABLE = 1u << 0,
+    CCSIM_F_NODENAME = 1u << 1,
+    CCSIM_F_TAINT = 1u << 2,
+    CCSIM_F_NODEAFFINITY = 1u << 3,
+    CCSIM_F_FIT = 1u << 4,
+    CCSIM_F_TOPOLOGYSPREAD = 1u << 5
+};
+
+/* reason slots of the terminal-round histogram (FitError.Error, S/framework/types.go:787-836) */
+enum {
+    CCSIM_R_UNSCHEDULABLE = 0,
+    CCSIM_R_NODENAME = 1,
+    CCSIM_R_NODEAFFINITY = 2,
+    CCSIM_R_TOO_MANY_PODS = 3,
+    CCSIM_R_RES0 = 4, /* + column */
+    CCSIM_R_PTS_MISSING_LABEL = CCSIM_R_RES0 + CCSIM_MAX_RES,
+    CCSIM_R_PTS_SKEW,
+    CCSIM_NREASON
+};
+
+enum { CCSIM_STOP_UNSCHEDULABLE = 0, CCSIM_STOP_LIMIT = 1, CCSIM_STOP_NO_NODES = 2 };
+
+/* ccsim_run modes */
+enum {
+    CCSIM_MODE_SEQUENTIAL = 0, /* one full pods x nodes scan per placement round (the literal reference loop) */
+    CCSIM_MODE_BATCHED = 1     /* exact level-batched resolution: many rounds per scan, identical placement sequence */
+};
+
+typedef struct ccsim_engine ccsim_engine;
+
+typedef struct {
+    int32_t abi_version; /* CCSIM_ABI_VERSION */
+    int32_t device;      /* HIP device ordinal */
+    void *stream;        /* hipStream_t to enqueue on, or NULL: the engine creates its own */
+    int32_t rounds_per_sync; /* placement rounds enqueued between host checks of the done flag; 0 = default */
+    int32_t use_graph;       /* replay rounds from a captured hipGraph (1) or launch eagerly (0) */
+} ccsim_config;
+
+/* Node snapshot, structure-of-arrays, canonical node order (S/backend/cache/node_tree.go:119-143).
+ * Replaces the []NodeInfo the reference's Cache.UpdateSnapshot hands to schedulePod
+ * (S/backend/cache/cache.go:194-288; NodeInfo: S/framework/types.go:160-200). */
+typedef struct {
+    int64_t n_nodes;       /* nodes in THIS shard */
+    int64_t global_offset; /* canonical index of this shard's first node (0 on one GPU) */
+    int64_t n_global;      /* nodes in the whole snapshot (== n_nodes on one GPU) */
+    int32_t n_scalar;
+    const int64_t *alloc[CCSIM_MAX_RES]; /* Allocatable per column, [n_nodes]; NULL = all zero */
+    const int32_t *alloc_pods;           /* Allocatable.AllowedPodNumber */
+    const int64_t *req[CCSIM_MAX_RES];   /* Requested per column */
+    const int64_t *nz_mcpu, *nz_mem;     /* NonZeroRequested */
+    const int32_t *pod_count;            /* len(NodeInfo.Pods) */
+    const int32_t *taintset_id;          /* id of the node's distinct Spec.Taints list */
+    const uint8_t *unschedulable;        /* Spec.Unschedulable */
+    int32_t n_label_cols;
+    const int32_t *label_cols[CCSIM_MAX_LABEL_COLS]; /* value id of label key k on each node; 0 = absent */
+} ccsim_nodes;
+
+/* one matchExpression / matchField, pre-evaluated by the host against every distinct value of the
+ * label column (AM/labels/selector.go:246-293 semantics incl. Gt/Lt ParseInt): a table lookup */
+typedef struct {
+    int32_t col;
+    int32_t table_off; /* matches iff req_tables[table_off + label_cols[col][node]] != 0 */
+} ccsim_requirement;
+
+typedef struct {
+    int32_t first_req, n_req; /* AND; n_req == 0 matches nothing (component-helpers nodeaffinity.go:60-64) */
+    int32_t weight;           /* preferred terms only */
+} ccsim_term;
+
+/* Pod-spec constants.  Replaces the per-cycle PreFilter/PreScore state of the plugins:
+ * fit.go:224-233 (computePodResourceRequest), resource_allocation.go:118-148,
+ * taint_toleration.go:111-121,146-153, node_affinity.go:147-197,241-258. */
+typedef struct {
+    int64_t req[CCSIM_MAX_RES];
+    int32_t has_scalar_entries; /* len(ScalarResources) != 0 (fit.go:578-583) */
+    int64_t nz_mcpu, nz_mem;    /* non-zero requests (100m / 200Mi container defaults applied) */
+    int32_t n_taintsets;
+    const uint8_t *taint_filter_ok;  /* [n_taintsets] every NoSchedule/NoExecute taint tolerated */
+    const int32_t *taint_prefer_cnt; /* [n_taintsets] untolerated PreferNoSchedule taints (<= 2047) */
+    int32_t tolerates_unschedulable;
+    int32_t affinity_filter_active; /* 0 = NodeAffinity PreFilter returned Skip */
+    int32_t has_node_selector;
+    ccsim_term node_selector;
+    int32_t has_required_terms;
+    int32_t n_required;
+    const ccsim_term *required;
+    int32_t n_preferred;
+    const ccsim_term *preferred; /* sum of weights must stay < 2^20 */
+    int32_t n_reqs;
+    const ccsim_requirement *reqs;
+    int64_t req_tables_len;
+    const uint8_t *req_tables;
+} ccsim_pod;
+
+/* Scheduler profile: which plugins run and their weights/args.  Replaces
+ * KubeSchedulerConfiguration.Profiles[0] (pkg/utils/utils.go:90-143; defaults
+ * S/apis/config/v1/default_plugins.go:30-58, defaults.go:33-36,229-245). */
+typedef struct {
+    uint32_t filter_mask;
+    int32_t w_taint, w_nodeaffinity, w_fit, w_balanced, w_topologyspread; /* 0 = score plugin disabled */
+    int32_t n_fit_res;
+    int32_t fit_res[CCSIM_MAX_RES];
+    int64_t fit_res_w[CCSIM_MAX_RES];
+    int32_t n_bal_res;
+    int32_t bal_res[CCSIM_MAX_RES];
+    int32_t percentage_of_nodes_to_score; /* this engine evaluates every node: must be 100 */
+} ccsim_profile;
+
+/* Result of ccsim_run.  Replaces ClusterCapacity.Status{Pods, StopReason}
+ * (pkg/framework/simulator.go:90-93) + the inputs of parsePodsReview (report.go:146-180). */
+typedef struct {
+    int64_t placed;
+    int32_t stop; /* CCSIM_STOP_* */
+    int32_t *per_node_count; /* caller-allocated [per_node_cap]: simulated pods per node of this shard */
+    int64_t per_node_cap;
+    int32_t *log; /* optional caller-allocated placement log: global node index per placement, in order */
+    int64_t log_cap;
+    int64_t log_len;
+    int64_t hist[CCSIM_NREASON]; /* terminal round: nodes per failure reason (this shard) */
+    int64_t *hist_taintset;      /* optional caller-allocated [hist_taintset_cap] */
+    int32_t hist_taintset_cap;
+    int64_t n_code_unschedulable; /* nodes whose terminal status is plain Unschedulable */
+    /* counters */
+    int64_t rounds;          /* scheduling cycles simulated (placements + the terminal one) */
+    int64_t scans;           /* full pods x nodes scan passes launched */
+    int64_t evaluated_total; /* (pod, node) evaluations the reference semantics imply = rounds * n */
+    int32_t last_feasible;   /* FeasibleNodes of the last cycle */
+    int64_t kernel_ns;       /* GPU time of the scan launches (HIP events on the engine's stream) */
+    int64_t bytes_per_scan;  /* algorithmic bytes one scan reads: n_nodes * sum of enabled column widths */
+} ccsim_report;
+
+/* Result of one scheduling cycle.  Replaces ScheduleResult (S/scheduler.go:154-164) as returned by
+ * Scheduler.SchedulePod (S/scheduler.go:88-91, S/schedule_one.go:430-478). */
+typedef struct {
+    int64_t node; /* global index of the suggested host, -1 = FitError */
+    int32_t evaluated_nodes;
+    int32_t feasible_nodes;
+} ccsim_cycle;
+
+int32_t ccsim_abi_version(void);
+
+/* framework.New / createScheduler (pkg/framework/simulator.go:107-158,383-431) */
+int ccsim_create(const ccsim_config *cfg, ccsim_engine **out);
+void ccsim_destroy(ccsim_engine *e); /* ClusterCapacity.Close (simulator.go:314-325) */
+const char *ccsim_last_error(const ccsim_engine *e);
+
+/* SyncWithClient's end product (simulator.go:176-295): the node snapshot, copied into HBM */
+int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nodes);
+int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *profile);
+/* the simulated pod (New(..., simulatedPod, ...) simulator.go:107): uploads tables, runs the static
+ * (unschedulable / taint / node-affinity) kernel once */
+int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod);
+
+/* ClusterCapacity.Run (simulator.go:356-381): place clones until Unschedulable or max_limit
+ * (<= 0: unlimited). */
+int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out);
+
+/* Scheduler.SchedulePod + assume for one pod (S/schedule_one.go:430-478,967-984). */
+int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out);
+
+/* Read back the dynamic node columns (NodeInfo.Requested etc.) of this shard; any pointer may be NULL. */
+int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req_mem, int64_t *nz_mcpu, int64_t *nz_mem,
+                     int32_t *pod_count);
+
+/* ---- multi-GPU stepping: one rank per GPU, node-range shards, ONE collective per round ----
+ * (no reference counterpart: the reference is one process).
+ * sendbuf / recvbuf are device buffers the caller owns (e.g. torch tensors): int64[CCSIM_XCHG_WORDS]
+ * and int64[n_ranks * CCSIM_XCHG_WORDS].  Per round every rank:
+ *     ccsim_dist_scan()    k_scan on the shard + reduce -> this rank's record in sendbuf
+ *     all-gather sendbuf -> recvbuf over RCCL/xGMI on the same stream (the max-loc exchange:
+ *                          record word 0 is the packed (score, position) key combined with MAX)
+ *     ccsim_dist_decide()  every rank reduces the gathered records identically; the rank that owns
+ *                          the winning node applies NodeInfo.update to its HBM columns
+ * ccsim_dist_poll() synchronizes and reads the done flag; call it every few rounds. */
+#define CCSIM_XCHG_WORDS 8
+int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, void *sendbuf, void *recvbuf,
+                     int64_t log_cap);
+int ccsim_dist_scan(ccsim_engine *e);
+int ccsim_dist_decide(ccsim_engine *e);
+int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed);
+int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out);
+
+/* Measurement aid (bench.py roofline): time `iters` back-to-back launches of the dominant kernel
+ * (the full pods x nodes scan) with HIP events on the engine's stream; simulation state is not advanced. */
+int ccsim_time_scan(ccsim_engine *e, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: libccsim.so builds for gfx950, loads, and exports every
+symbol include/ccsim.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+
+from cluster_capacity_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ccsim.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ccsim_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    build.build_all()
+    lib = capi.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert n in capi.SYMBOLS, f"{n} declared in ccsim.h but not bound in capi.py"
+        assert getattr(lib, n) is not None
+    assert set(capi.SYMBOLS) == set(names)
+    assert lib.ccsim_abi_version() == 1
+
+
+def test_struct_layouts_match_header_sizes():
+    # sizes computed by the C compiler for the same header must equal the ctypes mirrors
+    import subprocess, tempfile, ctypes
+    prog = r'''
+    #include <stdio.h>
+    #include "ccsim.h"
+    int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccsim_config), sizeof(ccsim_nodes), sizeof(ccsim_requirement),
+      sizeof(ccsim_term), sizeof(ccsim_pod), sizeof(ccsim_profile), sizeof(ccsim_report), sizeof(ccsim_cycle));return 0;}
+    '''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
+    mirrors = [capi.CConfig, capi.CNodes, capi.CReq, capi.CTerm, capi.CPod, capi.CProfile, capi.CReport, capi.CCycle]
+    assert sizes == [ctypes.sizeof(m) for m in mirrors]
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        return
+    import pytest
+    with pytest.raises(capi.CcsimError):
+        capi.Engine(device=0)
