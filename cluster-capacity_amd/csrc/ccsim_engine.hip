@@ -588,7 +588,8 @@ extern "C" int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req
 extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan) {
     if (!e || iters <= 0 || !total_ns) return -EINVAL;
     int rc;
-    if (!e->begun && (rc = begin_run(e, 0, CCSIM_MODE_SEQUENTIAL, 0))) return rc;
+    e->n_ranks = 0;
+    if ((rc = begin_run(e, 0, CCSIM_MODE_SEQUENTIAL, 0))) return rc; // fresh state: a finished run leaves done != 0
     HIPCHK(e, hipSetDevice(e->device));
     for (int i = 0; i < 3; i++) launch_scan(e);
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
