@@ -1,20 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- simulated pod placements/sec on a synthetic 1M-node snapshot (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode sequential|batched] [--nodes 1000000]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode batched|sequential] [--nodes 1000000]
 
-A "step" is one pass of the hot path over one batch of synthetic input: `--rounds` placement rounds
-of the cluster-capacity simulation loop (filter -> score -> select -> assume per placement) against
-the HBM-resident snapshot.  The snapshot is resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over one batch of synthetic input: one whole cluster-capacity
+simulation (filter -> score -> select -> assume per placement, pkg/framework/simulator.go:356-381)
+of `--limit` placements (0 = until the scheduler reports Unschedulable) against the HBM-resident
+snapshot.  The snapshot is resident in HBM before the timed region starts; every step first restores
+the dynamic node columns device-to-device (ccsim_reset_state, inside the timed region).
 
-N=1: the 1M-node default-plugin-set snapshot (BASELINE config "1M synthetic nodes", C4) on one GPU.
-N>1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- every rank holds its own
-1M-node shard of an N x 1M-node cluster (contiguous node ranges), one RCCL all-gather of a 64-byte
-(packed score/position key) record per round picks the global winner, only the owning rank updates.
+Workload (BASELINE config 4, "C4"): 1M synthetic nodes, default plugin set, examples/pod.yaml +
+toleration + preferred node affinity, percentageOfNodesToScore=100.  N=1: the whole snapshot on one
+GPU.  N>1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling -- the same 1M nodes
+sharded by contiguous node range, one RCCL all-gather of a 128-byte record per pass (the max-loc
+exchange), only owning ranks update their columns.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live on the dominant kernel (k_scan) with HIP
-events on the engine's stream; `cpu_baseline` is the C oracle (a port of the reference algorithm --
-the Go reference cannot be built here) timed on this box's host cores on a bounded sample.
+Modes (identical placement sequences, see tests/): `batched` resolves a whole score level (many
+placement rounds) per full pods x nodes pass; `sequential` is the literal one-round-per-pass loop.
+The headline `value` is the batched mode; a sequential sample is reported next to it in `config`.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live on the dominant kernel (the full pass:
+k_level / k_scan) with HIP events on the engine's stream; `cpu_baseline` is the C oracle (a port of
+the reference algorithm -- the Go reference cannot be built here) timed on this box's host cores on
+a bounded sample.
 """
 from __future__ import annotations
 
@@ -29,7 +37,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 ge.load_package()
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 from cluster_capacity_amd import capi, dist as ccdist, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -57,11 +65,13 @@ def cpu_baseline(nodes, pod, prof, rounds: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", default="sequential", choices=["sequential", "batched"])
-    ap.add_argument("--nodes", type=int, default=1_000_000, help="nodes per GPU")
-    ap.add_argument("--rounds", type=int, default=0, help="placement rounds per step (0 = mode default)")
+    ap.add_argument("--mode", default="batched", choices=["sequential", "batched"])
+    ap.add_argument("--nodes", type=int, default=1_000_000, help="nodes in the whole snapshot")
+    ap.add_argument("--limit", type=int, default=-1, help="placements per step (0 = until Unschedulable; "
+                    "-1 = mode default: 0 for batched, 2048 for sequential)")
+    ap.add_argument("--seq-rounds", type=int, default=2048, help="rounds of the sequential-mode sample (0 = skip)")
     ap.add_argument("--cpu-rounds", type=int, default=160)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -78,10 +88,10 @@ def main():
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    rounds = args.rounds or 2048
-    n_global = args.nodes * world
-    offset = rank * args.nodes
-    nodes, pod, prof = synth.make_config("C4", n_nodes=args.nodes, offset=offset)
+    limit = args.limit if args.limit >= 0 else (0 if args.mode == "batched" else 2048)
+    n_global = args.nodes
+    lo, hi = ccdist.shard_bounds(n_global, world, rank)
+    nodes, pod, prof = synth.make_config("C4", n_nodes=hi - lo, offset=lo)
 
     def barrier():
         if distributed:
@@ -89,21 +99,27 @@ def main():
         torch.cuda.synchronize()
 
     if distributed:
-        runner = ccdist.make_torch_runner(nodes, pod, prof, offset, n_global, local_rank)
+        runner = ccdist.make_torch_runner(nodes, pod, prof, lo, n_global, local_rank)
         eng = runner.engine
-        step = lambda: runner.run(max_limit=rounds, mode=args.mode)  # noqa: E731
+
+        def step(mode, lim):
+            eng.reset_state()
+            return runner.run(max_limit=lim, mode=mode)
     else:
         eng = capi.Engine(device=local_rank)
         eng.load(nodes, pod, prof)
-        step = lambda: eng.run(max_limit=rounds, mode=args.mode, want_log=False)  # noqa: E731
+
+        def step(mode, lim):
+            eng.reset_state()
+            return eng.run(max_limit=lim, mode=mode, want_log=False)
 
     for _ in range(args.warmup):
-        step()
+        step(args.mode, limit)
     barrier()
     t0 = time.perf_counter()
     placed = scans = 0
     for _ in range(args.steps):
-        r = step()
+        r = step(args.mode, limit)
         placed += r.placed
         scans += r.scans
     barrier()
@@ -113,9 +129,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel, measured live with HIP events on the engine's stream
-    scan_ns, bytes_per_scan = eng.time_scan(50)
-    scan_s = scan_ns / 50 / 1e9
+    # the literal one-round-per-pass loop on the same snapshot, for comparison (untimed by the driver)
+    seq = None
+    if args.mode == "batched" and args.seq_rounds > 0:
+        step("sequential", args.seq_rounds)
+        barrier()
+        s0 = time.perf_counter()
+        rs = step("sequential", args.seq_rounds)
+        barrier()
+        seq = rs.placed / (time.perf_counter() - s0)
+
+    # roofline of the dominant kernel (the full pods x nodes pass: k_level / k_scan): its average launch
+    # duration over one more step of the SAME workload, measured live with a HIP event pair around every
+    # launch on the engine's stream (cfg.time_passes; eager launches).  rocprofv3 --kernel-trace --stats of
+    # this command (profiles/) reports the same average.
+    if distributed:
+        pe, prun = eng, None
+        scan_ns, bytes_per_scan = eng.time_scan(50, mode=args.mode)
+        scan_s = scan_ns / 50 / 1e9
+        launches = 50
+    else:
+        pe = capi.Engine(device=local_rank, time_passes=True)
+        pe.load(nodes, pod, prof)
+        prun = pe.run(max_limit=limit, mode=args.mode, want_log=False)
+        launches = prun.scans
+        scan_s = prun.pass_kernel_ns / max(1, launches) / 1e9
+        bytes_per_scan = prun.bytes_per_scan
     achieved = bytes_per_scan / scan_s / 1e9
     out = {
         "metric": "simulated pod placements/sec at 1M nodes",
@@ -126,17 +165,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
         "config": {
-            "workload": f"{n_global}-node synthetic snapshot ({args.nodes}/GPU), default plugin set (C4), examples/pod.yaml "
-                        f"+ toleration + preferred node affinity, percentageOfNodesToScore=100",
+            "workload": f"{n_global}-node synthetic snapshot (C4: default plugin set, examples/pod.yaml + toleration + "
+                        f"preferred node affinity, percentageOfNodesToScore=100), "
+                        f"{'until Unschedulable' if limit == 0 else str(limit) + ' placements'} per step",
             "mode": args.mode,
-            "rounds_per_step": rounds,
-            "placements": placed,
-            "scans": scans,
+            "placements_per_step": placed // max(1, args.steps),
+            "passes_per_step": scans // max(1, args.steps),
+            "sequential_mode_placements_per_s": seq,
             "parallelism": f"node-shard x{world}",
         },
         "roofline": {
@@ -146,13 +186,15 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "k_scan",
+            "kernel": "k_level" if args.mode == "batched" else "k_scan",
             "bytes_per_launch": bytes_per_scan,
             "us_per_launch": scan_s * 1e6,
+            "launches_timed": launches,
         },
     }
     if rank == 0 and not args.no_cpu and not distributed:
-        out["cpu_baseline"] = cpu_baseline(nodes, pod, prof, args.cpu_rounds)
+        nodes_full = nodes if world == 1 else synth.make_config("C4", n_nodes=n_global)[0]
+        out["cpu_baseline"] = cpu_baseline(nodes_full, pod, prof, args.cpu_rounds)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -15,7 +15,7 @@ from . import model as M
 MAX_RES = M.MAX_RES
 MAX_LABEL_COLS = 32
 NREASON = M.NREASON
-XCHG_WORDS = 8
+XCHG_WORDS = 16
 MODE_SEQUENTIAL, MODE_BATCHED = 0, 1
 MODES = {"sequential": MODE_SEQUENTIAL, "batched": MODE_BATCHED}
 
@@ -26,7 +26,7 @@ _pu8 = C.POINTER(C.c_uint8)
 
 class CConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("stream", C.c_void_p),
-                ("rounds_per_sync", C.c_int32), ("use_graph", C.c_int32)]
+                ("rounds_per_sync", C.c_int32), ("use_graph", C.c_int32), ("time_passes", C.c_int32)]
 
 
 class CNodes(C.Structure):
@@ -72,7 +72,7 @@ class CReport(C.Structure):
         ("log", _p32), ("log_cap", C.c_int64), ("log_len", C.c_int64), ("hist", C.c_int64 * NREASON),
         ("hist_taintset", _p64), ("hist_taintset_cap", C.c_int32), ("n_code_unschedulable", C.c_int64),
         ("rounds", C.c_int64), ("scans", C.c_int64), ("evaluated_total", C.c_int64), ("last_feasible", C.c_int32),
-        ("kernel_ns", C.c_int64), ("bytes_per_scan", C.c_int64),
+        ("kernel_ns", C.c_int64), ("pass_kernel_ns", C.c_int64), ("bytes_per_scan", C.c_int64),
     ]
 
 
@@ -92,12 +92,13 @@ SYMBOLS = {
     "ccsim_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
     "ccsim_schedule_one": (C.c_int, [C.c_void_p, C.POINTER(CCycle)]),
     "ccsim_read_state": (C.c_int, [C.c_void_p, _p64, _p64, _p64, _p64, _p32]),
-    "ccsim_dist_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
+    "ccsim_dist_begin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),
     "ccsim_dist_scan": (C.c_int, [C.c_void_p]),
     "ccsim_dist_decide": (C.c_int, [C.c_void_p]),
     "ccsim_dist_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "ccsim_dist_finish": (C.c_int, [C.c_void_p, C.POINTER(CReport)]),
-    "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ccsim_reset_state": (C.c_int, [C.c_void_p]),
+    "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -112,6 +113,14 @@ def load(build_if_missing: bool = True):
             if not build_if_missing:
                 raise FileNotFoundError(path)
             _build.build_all()
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7.  Loading torch FIRST makes the
+        # loader resolve libccsim's libamdhip64.so.7 dependency to that same copy, so torch streams and
+        # tensors (multi-GPU path) and the engine share one runtime.  (Engine first, torch second loads two
+        # runtimes and torch then sees no GPU.)  C / cgo consumers simply get /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the export is missing
@@ -224,9 +233,12 @@ def marshal_profile(p: M.Profile) -> CProfile:
 class Engine:
     """One engine = one GPU's shard of the snapshot (ccsim_engine*)."""
 
-    def __init__(self, device: int = 0, stream: int = 0, rounds_per_sync: int = 0, use_graph: bool = True):
+    def __init__(self, device: int = 0, stream: int = 0, rounds_per_sync: int = 0, use_graph: bool = True,
+                 time_passes: bool = False):
         self.lib = load()
-        cfg = CConfig(1, int(device), C.c_void_p(stream) if stream else None, int(rounds_per_sync), int(use_graph))
+        # stream: a hipStream_t handle (e.g. torch.cuda.Stream().cuda_stream); 0/None = the engine creates its own
+        cfg = CConfig(1, int(device), C.c_void_p(stream) if stream else None, int(rounds_per_sync), int(use_graph),
+                      int(time_passes))
         h = C.c_void_p()
         rc = self.lib.ccsim_create(C.byref(cfg), C.byref(h))
         if rc != 0 or not h:
@@ -286,7 +298,7 @@ class Engine:
             hist=np.array(list(rep.hist), dtype=np.int64), hist_taintset=ht.copy(),
             n_code_unschedulable=int(rep.n_code_unschedulable), rounds=int(rep.rounds),
             evaluated_total=int(rep.evaluated_total), last_feasible=int(rep.last_feasible), scans=int(rep.scans),
-            kernel_ns=int(rep.kernel_ns), bytes_per_scan=int(rep.bytes_per_scan),
+            kernel_ns=int(rep.kernel_ns), pass_kernel_ns=int(rep.pass_kernel_ns), bytes_per_scan=int(rep.bytes_per_scan),
         )
 
     def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None) -> M.RunResult:
@@ -308,15 +320,18 @@ class Engine:
         return dict(req_mcpu=out[0][: self.n], req_mem=out[1][: self.n], nz_mcpu=out[2][: self.n], nz_mem=out[3][: self.n],
                     pod_count=out[4][: self.n])
 
-    def time_scan(self, iters: int):
+    def reset_state(self):
+        self._chk(self.lib.ccsim_reset_state(self.h), "ccsim_reset_state")
+
+    def time_scan(self, iters: int, mode: str = "sequential"):
         ns, by = C.c_int64(), C.c_int64()
-        self._chk(self.lib.ccsim_time_scan(self.h, int(iters), C.byref(ns), C.byref(by)), "ccsim_time_scan")
+        self._chk(self.lib.ccsim_time_scan(self.h, MODES[mode], int(iters), C.byref(ns), C.byref(by)), "ccsim_time_scan")
         return int(ns.value), int(by.value)
 
     # ---- distributed stepping (collective supplied by the caller, see dist.py) ----
-    def dist_begin(self, max_limit: int, mode: str, n_ranks: int, send_ptr: int, recv_ptr: int, log_cap: int = 0):
-        self._chk(self.lib.ccsim_dist_begin(self.h, int(max_limit), MODES[mode], int(n_ranks), C.c_void_p(send_ptr),
-                                            C.c_void_p(recv_ptr), int(log_cap)), "ccsim_dist_begin")
+    def dist_begin(self, max_limit: int, mode: str, n_ranks: int, rank: int, send_ptr: int, recv_ptr: int, log_cap: int = 0):
+        self._chk(self.lib.ccsim_dist_begin(self.h, int(max_limit), MODES[mode], int(n_ranks), int(rank),
+                                            C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(log_cap)), "ccsim_dist_begin")
 
     def dist_scan(self):
         self._chk(self.lib.ccsim_dist_scan(self.h), "ccsim_dist_scan")

@@ -7,6 +7,7 @@
 //   S/backend/cache/cache.go:194-288     UpdateSnapshot         -> ccsim_load_nodes (once; state then lives in HBM)
 // There is NO CPU fallback: every entry point fails loudly if HIP does.
 #include "ccsim_kernels.h"
+#include "ccsim_level.h"
 
 #include <errno.h>
 #include <stdarg.h>
@@ -26,6 +27,10 @@ struct ccsim_engine {
     bool own_stream = false;
     int rounds_per_sync = 0;
     int use_graph = 1;
+    int time_passes = 0;
+    std::vector<hipEvent_t> pass_events; // time_passes: one (start, stop) pair per full-pass launch of a batch
+    int pass_events_used = 0;
+    double pass_kernel_ms = 0;
     std::string err;
 
     // snapshot
@@ -55,6 +60,15 @@ struct ccsim_engine {
     unsigned long long *d_hist = nullptr, *d_hist_ts = nullptr, *d_hist_code = nullptr;
     int grid = 0;
     int64_t chunk = 0;
+    // batched mode (ccsim_level.h): its own launch geometry (chunk bounded by the LDS score cache)
+    int lvl_grid = 0;
+    int64_t lvl_chunk = 0;
+    LevelPartial *d_lpartials = nullptr;
+    int64_t *d_blockprefix = nullptr;
+    int rank = 0;
+    // pristine copies of the dynamic columns (ccsim_reset_state)
+    std::vector<std::pair<void *, void *>> backups; // (live, pristine)
+    std::vector<size_t> backup_bytes;
     bool begun = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0;
@@ -65,6 +79,7 @@ struct ccsim_engine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_rounds = 0;
+    int graph_mode = -1;
 };
 
 static int fail(ccsim_engine *e, int code, const char *fmt, ...) {
@@ -113,6 +128,7 @@ static void drop_graph(ccsim_engine *e) {
     e->graph_exec = nullptr;
     e->graph = nullptr;
     e->graph_rounds = 0;
+    e->graph_mode = -1;
 }
 
 extern "C" int32_t ccsim_abi_version(void) { return CCSIM_ABI_VERSION; }
@@ -128,6 +144,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     e->device = cfg->device;
     e->rounds_per_sync = cfg->rounds_per_sync;
     e->use_graph = cfg->use_graph;
+    e->time_passes = cfg->time_passes;
     if (hipSetDevice(e->device) != hipSuccess) {
         delete e;
         return -EIO;
@@ -166,6 +183,7 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->d_hist) (void)hipFree(e->d_hist);
     if (e->d_log) (void)hipFree(e->d_log);
     if (e->h_state) (void)hipHostFree(e->h_state);
+    for (hipEvent_t ev : e->pass_events) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -184,6 +202,8 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->allocs);
+    e->backups.clear();
+    e->backup_bytes.clear();
     e->have_nodes = e->have_pod = e->begun = false;
     e->n = nd->n_nodes;
     e->n_pad = ((e->n + kTile - 1) / kTile) * kTile;
@@ -231,12 +251,37 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     c.stat = e->d_stat;
     c.sreason = e->d_sreason;
     e->cols = c;
+    // pristine copies of everything a placement mutates (NodeInfo.Requested / NonZeroRequested / len(Pods))
+    {
+        auto keep = [&](void *live, size_t bytes) -> int {
+            void *p = nullptr;
+            HIPCHK(e, hipMalloc(&p, bytes));
+            e->allocs.push_back(p);
+            HIPCHK(e, hipMemcpyAsync(p, live, bytes, hipMemcpyDeviceToDevice, e->stream));
+            e->backups.emplace_back(live, p);
+            e->backup_bytes.push_back(bytes);
+            return 0;
+        };
+        for (int col = 0; col < e->ncol; col++)
+            if ((rc = keep(c.req[col], np * 8))) return rc;
+        if ((rc = keep(c.nz_mcpu, np * 8))) return rc;
+        if ((rc = keep(c.nz_mem, np * 8))) return rc;
+        if ((rc = keep(c.pod_count, np * 4))) return rc;
+    }
     HIPCHK(e, hipStreamSynchronize(e->stream)); // lc / caller arrays may go away after return
     // launch geometry: one contiguous chunk of nodes per block, <= kMaxGrid blocks
     int64_t tiles = e->n_pad / kTile;
     e->grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     e->chunk = ((tiles + e->grid - 1) / e->grid) * kTile;
     e->grid = (int)((e->n_pad + e->chunk - 1) / e->chunk);
+    // batched mode: up to 2048 blocks of one contiguous chunk each
+    int64_t ltiles = (tiles + 2047) / 2048;
+    if (ltiles < 1) ltiles = 1;
+    e->lvl_chunk = ltiles * kTile;
+    e->lvl_grid = (int)((e->n_pad + e->lvl_chunk - 1) / e->lvl_chunk);
+    if ((rc = dev_alloc(e, &e->d_lpartials, (size_t)e->lvl_grid, e->allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_blockprefix, (size_t)e->lvl_grid, e->allocs))) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
     e->have_nodes = true;
     return 0;
 }
@@ -400,9 +445,42 @@ static int launch_final(ccsim_engine *e) {
     return 0;
 }
 
+static int launch_level(ccsim_engine *e) {
+    LevelArgs a{e->cols, e->pod, e->d_state, e->d_lpartials, e->d_blockprefix, e->d_log, e->lvl_chunk};
+    const int nx = e->pod.nx;
+    dim3 g(e->lvl_grid), b(kThreads);
+    if (nx == 0) hipLaunchKernelGGL(k_level<0>, g, b, 0, e->stream, a);
+    else if (nx == 1) hipLaunchKernelGGL(k_level<1>, g, b, 0, e->stream, a);
+    else if (nx == 2) hipLaunchKernelGGL(k_level<2>, g, b, 0, e->stream, a);
+    else if (nx <= 4) hipLaunchKernelGGL(k_level<4>, g, b, 0, e->stream, a);
+    else hipLaunchKernelGGL(k_level<kMaxExtra>, g, b, 0, e->stream, a);
+    return 0;
+}
+
+static LevelFinalArgs level_final_args(ccsim_engine *e) {
+    LevelFinalArgs f{};
+    f.st = e->d_state;
+    f.partials = e->d_lpartials;
+    f.n_partials = e->lvl_grid;
+    f.blockprefix = e->d_blockprefix;
+    f.xsend = e->d_xsend;
+    f.xrecv = e->d_xrecv;
+    f.n_ranks = e->n_ranks;
+    f.rank = e->rank;
+    f.want_log = e->d_log ? 1 : 0;
+    return f;
+}
+
+static int launch_level_final(ccsim_engine *e) {
+    hipLaunchKernelGGL(k_level_final, dim3(1), dim3(kFinalThreads), 0, e->stream, level_final_args(e));
+    return 0;
+}
+
 static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_cap) {
     if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
-    if (mode != CCSIM_MODE_SEQUENTIAL) return fail(e, -ENOSYS, "mode %d not implemented", mode);
+    if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
+    if (mode == CCSIM_MODE_BATCHED && !e->pod.fit_enabled)
+        return fail(e, -ENOSYS, "batched mode needs the NodeResourcesFit filter (a run-down is bounded by the node's pod capacity)");
     HIPCHK(e, hipSetDevice(e->device));
     if (log_cap != e->log_cap) {
         if (e->d_log) HIPCHK(e, hipFree(e->d_log));
@@ -422,7 +500,11 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     *e->h_state = st;
     HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
+    if (e->d_log && e->n_ranks > 0) // shards fill disjoint positions of the global log: -1 = "not mine"
+        HIPCHK(e, hipMemsetAsync(e->d_log, 0xff, sizeof(int32_t) * (size_t)e->log_cap, e->stream));
     e->kernel_ms = 0;
+    e->pass_kernel_ms = 0;
+    e->pass_events_used = 0;
     e->limit = max_limit;
     e->mode = mode;
     e->begun = true;
@@ -435,25 +517,49 @@ static int read_state(ccsim_engine *e) {
     return 0;
 }
 
+static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block reduction/decision
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (e->time_passes && e->n_ranks == 0) { // measurement runs only: HIP events around the full-pass kernel
+        while ((int)e->pass_events.size() < e->pass_events_used + 2) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreate(&ev) != hipSuccess) break;
+            e->pass_events.push_back(ev);
+        }
+        if ((int)e->pass_events.size() >= e->pass_events_used + 2) {
+            t0 = e->pass_events[e->pass_events_used++];
+            t1 = e->pass_events[e->pass_events_used++];
+        }
+    }
+    if (t0) (void)hipEventRecord(t0, e->stream);
+    if (e->mode == CCSIM_MODE_BATCHED) launch_level(e);
+    else launch_scan(e);
+    if (t1) (void)hipEventRecord(t1, e->stream);
+    if (e->mode == CCSIM_MODE_BATCHED) launch_level_final(e);
+    else launch_final(e);
+}
+
+static void collect_pass_times(ccsim_engine *e) { // after a stream sync
+    for (int i = 0; i + 1 < e->pass_events_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->pass_events[i], e->pass_events[i + 1]) == hipSuccess) e->pass_kernel_ms += ms;
+    }
+    e->pass_events_used = 0;
+}
+
 static int enqueue_rounds(ccsim_engine *e, int rounds) {
-    if (e->use_graph && e->n_ranks == 0) {
-        if (!e->graph_exec || e->graph_rounds != rounds) {
+    if (e->use_graph && e->n_ranks == 0 && !e->time_passes) {
+        if (!e->graph_exec || e->graph_rounds != rounds || e->graph_mode != e->mode) {
             drop_graph(e);
             HIPCHK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            for (int r = 0; r < rounds; r++) {
-                launch_scan(e);
-                launch_final(e);
-            }
+            for (int r = 0; r < rounds; r++) launch_pass(e);
             HIPCHK(e, hipStreamEndCapture(e->stream, &e->graph));
             HIPCHK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
             e->graph_rounds = rounds;
+            e->graph_mode = e->mode;
         }
         HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
     } else {
-        for (int r = 0; r < rounds; r++) {
-            launch_scan(e);
-            launch_final(e);
-        }
+        for (int r = 0; r < rounds; r++) launch_pass(e);
         HIPCHK(e, hipGetLastError());
     }
     return 0;
@@ -468,6 +574,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     out->evaluated_total = st.rounds * e->n_global;
     out->last_feasible = st.last_feasible;
     out->kernel_ns = (int64_t)(e->kernel_ms * 1e6);
+    out->pass_kernel_ns = (int64_t)(e->pass_kernel_ms * 1e6);
     // algorithmic bytes per scan: the columns the active plugin set must read once per node
     int64_t per_node = 4 /*static word*/ + 6 * 8 /*alloc,req,nz x cpu,mem*/ + 2 * 4 /*pods*/ + (int64_t)e->pod.nx * 16;
     out->bytes_per_scan = per_node * e->n;
@@ -490,8 +597,10 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
         // terminal round: FitError diagnosis (types.go:787-836)
         HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
         HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
-        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code};
-        hipLaunchKernelGGL(k_hist, dim3((unsigned)((e->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, h);
+        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets};
+        int64_t hb = (e->n + kThreads - 1) / kThreads;
+        if (hb > 2048) hb = 2048;
+        hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
         HIPCHK(e, hipGetLastError());
         std::vector<unsigned long long> hh(CCSIM_NREASON + 1), ht((size_t)e->n_taintsets);
         HIPCHK(e, hipMemcpyAsync(hh.data(), e->d_hist, sizeof(unsigned long long) * hh.size(), hipMemcpyDeviceToHost, e->stream));
@@ -516,15 +625,16 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         e->h_state->done = DONE_UNSCHEDULABLE;
         return fill_report(e, out);
     }
-    int rps = e->rounds_per_sync > 0 ? e->rounds_per_sync : 256;
+    int rps = e->rounds_per_sync > 0 ? e->rounds_per_sync : (mode == CCSIM_MODE_BATCHED ? 64 : 256);
     for (;;) {
         int rounds = rps;
-        if (max_limit > 0) {
+        if (max_limit > 0 && mode == CCSIM_MODE_SEQUENTIAL) {
             // no point enqueuing far beyond the limit (each committed round needs >= 1 scan)
             int64_t left = max_limit - e->h_state->placed + 2;
             if (left < rounds) rounds = (int)(left < 1 ? 1 : left);
             if (e->use_graph && rounds != rps) rounds = rps; // keep one graph shape; extra rounds are no-ops after done
         }
+        const int64_t placed0 = e->h_state->placed;
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         if ((rc = enqueue_rounds(e, rounds))) return rc;
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -532,7 +642,10 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         float ms = 0;
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->kernel_ms += ms;
+        collect_pass_times(e);
         if (e->h_state->done) break;
+        // every pass either places a pod or (at most twice in a row) re-derives the normalization constants
+        if (rounds >= 8 && e->h_state->placed == placed0) return fail(e, -EIO, "simulation made no progress in %d passes", rounds);
     }
     return fill_report(e, out);
 }
@@ -585,15 +698,16 @@ extern "C" int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req
 
 // ---- measurement aid: time `iters` back-to-back launches of the dominant kernel (k_scan) with HIP
 // events on the engine's stream; state is not advanced (no k_final in between). -------------------
-extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan) {
+extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan) {
     if (!e || iters <= 0 || !total_ns) return -EINVAL;
     int rc;
     e->n_ranks = 0;
-    if ((rc = begin_run(e, 0, CCSIM_MODE_SEQUENTIAL, 0))) return rc; // fresh state: a finished run leaves done != 0
+    if ((rc = begin_run(e, 0, mode, 0))) return rc; // fresh state: a finished run leaves done != 0
     HIPCHK(e, hipSetDevice(e->device));
-    for (int i = 0; i < 3; i++) launch_scan(e);
+    const bool lvl = mode == CCSIM_MODE_BATCHED; // k_level with nothing planned: Filter + Score + plan, no commit
+    for (int i = 0; i < 3; i++) lvl ? launch_level(e) : launch_scan(e);
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    for (int i = 0; i < iters; i++) launch_scan(e);
+    for (int i = 0; i < iters; i++) lvl ? launch_level(e) : launch_scan(e);
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipGetLastError());
@@ -609,10 +723,11 @@ extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t iters, int64_t *total_ns
 
 // ---- distributed stepping (one rank per GPU; the collective itself is the caller's: RCCL through
 // torch.distributed on the same stream) -----------------------------------------------------------
-extern "C" int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, void *sendbuf,
-                                void *recvbuf, int64_t log_cap) {
-    if (!e || n_ranks < 1 || !sendbuf || !recvbuf) return -EINVAL;
+extern "C" int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, int32_t rank,
+                                void *sendbuf, void *recvbuf, int64_t log_cap) {
+    if (!e || n_ranks < 1 || rank < 0 || rank >= n_ranks || !sendbuf || !recvbuf) return -EINVAL;
     e->n_ranks = n_ranks;
+    e->rank = rank;
     e->d_xsend = (XRec *)sendbuf;
     e->d_xrecv = (XRec *)recvbuf;
     return begin_run(e, max_limit, mode, log_cap);
@@ -621,16 +736,30 @@ extern "C" int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode
 extern "C" int ccsim_dist_scan(ccsim_engine *e) {
     if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
-    launch_scan(e);
-    launch_final(e); // n_ranks > 0: publishes this shard's record into sendbuf
+    launch_pass(e); // n_ranks > 0: the one-block kernel publishes this shard's record into sendbuf
     HIPCHK(e, hipGetLastError());
     return 0;
 }
 
 extern "C" int ccsim_dist_decide(ccsim_engine *e) {
     if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, final_args(e));
+    if (e->mode == CCSIM_MODE_BATCHED)
+        hipLaunchKernelGGL(k_level_decide, dim3(1), dim3(64), 0, e->stream, level_final_args(e));
+    else
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, final_args(e));
     HIPCHK(e, hipGetLastError());
+    return 0;
+}
+
+// Restore NodeInfo.Requested / NonZeroRequested / len(Pods) to what ccsim_load_nodes uploaded (device-to-device
+// from the pristine copies kept in HBM): re-run the same snapshot without another host upload.
+extern "C" int ccsim_reset_state(ccsim_engine *e) {
+    if (!e || !e->have_nodes) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    for (size_t i = 0; i < e->backups.size(); i++)
+        HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
+    e->begun = false;
     return 0;
 }
 

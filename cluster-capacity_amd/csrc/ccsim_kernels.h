@@ -78,6 +78,15 @@ struct DevState {
     int32_t mt_a, ma_a; // normalization maxima the pending scan result was computed with
     int32_t last_feasible, mode;
     int64_t log_cap;
+    // CCSIM_MODE_BATCHED (ccsim_level.h): the level the next pass commits
+    int64_t lvl_M;           // TotalScore of the level
+    int64_t lvl_cut;         // commit only nodes with global index <= cut (normalization change inside the level)
+    int64_t lvl_remaining;   // placements still allowed (limit - placed at level start)
+    int64_t lvl_rank_prefix; // placements of this level that belong to lower-ranked shards
+    int32_t lvl_valid;       // 1 = the next pass commits level lvl_M
+    int32_t lvl_prefix;      // 1 = ordered commit (limit inside the level, or placement log wanted)
+    int32_t lvl_plan_only;   // 1 = the next pass only measures level lvl_M (no commit)
+    int32_t pad0;
 };
 
 // per-block result of one scan: 16 bytes
@@ -87,9 +96,13 @@ struct __attribute__((aligned(16))) Partial {
     uint32_t nfeas;
 };
 
-// exchange record (int64[8], see CCSIM_XCHG_WORDS): every word combines with MAX except nfeas (sum)
+// exchange record (int64[16], see CCSIM_XCHG_WORDS).  Sequential mode uses the first four words (key, mt,
+// ma combine with MAX, nfeas with SUM); batched mode adds the plan of the shard's own top level.
 struct XRec {
-    int64_t key, mt, ma, nfeas, pad[4];
+    int64_t key, mt, ma, nfeas;
+    int64_t c_mt, c_ma, committed, n_top;
+    int64_t T, e_mt, e_ma, cut_mt;
+    int64_t cut_ma, pad[3];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -397,12 +410,11 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         nf += s_nf[w];
     }
     if (a.n_ranks > 0) {
-        XRec r;
+        XRec r{};
         r.key = (int64_t)key;
         r.mt = mt;
         r.ma = ma;
         r.nfeas = nf;
-        r.pad[0] = r.pad[1] = r.pad[2] = r.pad[3] = 0;
         *a.xsend = r;
         return;
     }
@@ -510,32 +522,53 @@ struct HistArgs {
     unsigned long long *hist;      // [4 + kMaxRes + 2]
     unsigned long long *hist_ts;   // [n_taintsets]
     unsigned long long *hist_code; // [1]
+    int32_t n_taintsets;
 };
 
+constexpr int kHistSlots = 4 + kMaxRes + 2 + 1; // + the status-code counter
+constexpr int kHistTsLds = 1024;                // taint sets histogrammed in LDS (more fall back to global atomics)
+
 __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
-    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (n >= a.c.n) return;
-    const uint8_t sr = a.c.sreason[n];
-    if (sr == 1) { atomicAdd(&a.hist[0], 1ull); return; }
-    if (sr == 2) { atomicAdd(&a.hist_ts[a.c.taintset_id ? a.c.taintset_id[n] : 0], 1ull); return; }
-    if (sr == 3) { atomicAdd(&a.hist[2], 1ull); return; }
-    if (!a.p.fit_enabled) return;
-    bool unresolvable = false, any = false;
-    if ((int64_t)a.c.pod_count[n] + 1 > (int64_t)a.c.alloc_pods[n]) { atomicAdd(&a.hist[3], 1ull); any = true; }
-    if (!a.p.all_zero_req) {
-        for (int col = 0; col < a.p.ncol; col++) {
-            const int64_t rq = a.p.req[col];
-            if (col < 3 ? !(rq > 0) : rq == 0) continue;
-            const int64_t al = a.c.alloc[col] ? a.c.alloc[col][n] : 0;
-            const int64_t us = a.c.req[col] ? a.c.req[col][n] : 0;
-            if (rq > al - us) {
-                atomicAdd(&a.hist[4 + col], 1ull);
-                any = true;
-                if (rq > al) unresolvable = true;
+    // block-private histograms in LDS, one global atomic per non-empty bin per block: the terminal round
+    // typically puts ~all N nodes into one or two bins
+    __shared__ unsigned int sh[kHistSlots];
+    __shared__ unsigned int sh_ts[kHistTsLds];
+    for (int i = threadIdx.x; i < kHistSlots; i += kThreads) sh[i] = 0;
+    for (int i = threadIdx.x; i < kHistTsLds; i += kThreads) sh_ts[i] = 0;
+    __syncthreads();
+    for (int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x; n < a.c.n; n += (int64_t)gridDim.x * kThreads) {
+        const uint8_t sr = a.c.sreason[n];
+        if (sr == 1) { atomicAdd(&sh[0], 1u); continue; }
+        if (sr == 2) {
+            const int32_t ts = a.c.taintset_id ? a.c.taintset_id[n] : 0;
+            if (ts < kHistTsLds) atomicAdd(&sh_ts[ts], 1u); else atomicAdd(&a.hist_ts[ts], 1ull);
+            continue;
+        }
+        if (sr == 3) { atomicAdd(&sh[2], 1u); continue; }
+        if (!a.p.fit_enabled) continue;
+        bool unresolvable = false, any = false;
+        if ((int64_t)a.c.pod_count[n] + 1 > (int64_t)a.c.alloc_pods[n]) { atomicAdd(&sh[3], 1u); any = true; }
+        if (!a.p.all_zero_req) {
+            for (int col = 0; col < a.p.ncol; col++) {
+                const int64_t rq = a.p.req[col];
+                if (col < 3 ? !(rq > 0) : rq == 0) continue;
+                const int64_t al = a.c.alloc[col] ? a.c.alloc[col][n] : 0;
+                const int64_t us = a.c.req[col] ? a.c.req[col][n] : 0;
+                if (rq > al - us) {
+                    atomicAdd(&sh[4 + col], 1u);
+                    any = true;
+                    if (rq > al) unresolvable = true;
+                }
             }
         }
+        if (any && !unresolvable) atomicAdd(&sh[kHistSlots - 1], 1u);
     }
-    if (any && !unresolvable) atomicAdd(&a.hist_code[0], 1ull);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHistSlots - 1; i += kThreads)
+        if (sh[i]) atomicAdd(&a.hist[i], (unsigned long long)sh[i]);
+    if (threadIdx.x == 0 && sh[kHistSlots - 1]) atomicAdd(&a.hist_code[0], (unsigned long long)sh[kHistSlots - 1]);
+    for (int i = threadIdx.x; i < kHistTsLds && i < a.n_taintsets; i += kThreads)
+        if (sh_ts[i]) atomicAdd(&a.hist_ts[i], (unsigned long long)sh_ts[i]);
 }
 
 } // namespace ccsim

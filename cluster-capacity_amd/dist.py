@@ -1,11 +1,12 @@
 """Multi-GPU driver: one process per GPU, node-range shards, one RCCL collective per round.
 
 torch.distributed is plumbing here (process group + the collective over xGMI); the shard work is
-the HIP engine.  Protocol per placement round (include/ccsim.h "multi-GPU stepping"):
+the HIP engine.  Protocol per pass (include/ccsim.h "multi-GPU stepping"; a pass is one placement
+round in sequential mode and one whole score level -- many rounds -- in batched mode):
 
-    engine.dist_scan()                         # k_scan on the shard -> 64-byte record in `send`
+    engine.dist_scan()                         # full pass over the shard -> 128-byte record in `send`
     dist.all_gather_into_tensor(recv, send)    # the max-loc exchange (packed key in word 0)
-    engine.dist_decide()                       # identical reduction on every rank; owner commits
+    engine.dist_decide()                       # identical reduction on every rank; owners commit
 
 The engine enqueues on torch's current stream, so the collective is ordered with the kernels
 without any host synchronization; the host only syncs every `rounds_per_poll` rounds to read the
@@ -31,14 +32,15 @@ def shard_bounds(n_global: int, world: int, rank: int) -> Tuple[int, int]:
 class DistRunner:
     """Drives one rank's engine; `collective(recv, send)` performs the all-gather."""
 
-    def __init__(self, engine, world: int, send, recv, collective, rounds_per_poll: int = 32):
-        self.engine, self.world, self.send, self.recv = engine, world, send, recv
+    def __init__(self, engine, world: int, rank: int, send, recv, collective, rounds_per_poll: int = 32):
+        self.engine, self.world, self.rank, self.send, self.recv = engine, world, rank, send, recv
         self.collective = collective
         self.rounds_per_poll = rounds_per_poll
 
     def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0) -> M.RunResult:
         e = self.engine
-        e.dist_begin(max_limit, mode, self.world, self.send.data_ptr(), self.recv.data_ptr(), log_cap if want_log else 0)
+        e.dist_begin(max_limit, mode, self.world, self.rank, self.send.data_ptr(), self.recv.data_ptr(),
+                     log_cap if want_log else 0)
         while True:
             for _ in range(self.rounds_per_poll):
                 e.dist_scan()
@@ -56,8 +58,12 @@ def make_torch_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profil
     import torch.distributed as dist
 
     torch.cuda.set_device(device)
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = capi.Engine(device=device, stream=stream, use_graph=False)
+    # a real (non-default) torch stream: the engine enqueues on it and RCCL orders against it.  The legacy
+    # default stream has handle 0, which the C ABI reads as "create your own stream".
+    ts = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(ts)
+    eng = capi.Engine(device=device, stream=ts.cuda_stream, use_graph=False)
+    eng._torch_stream = ts  # keep it alive
     eng.load(nodes_shard, pod, profile, global_offset=global_offset, n_global=n_global)
     world = dist.get_world_size()
     send = torch.zeros(capi.XCHG_WORDS, dtype=torch.int64, device=f"cuda:{device}")
@@ -66,4 +72,12 @@ def make_torch_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profil
     def collective(r, s):
         dist.all_gather_into_tensor(r, s)
 
-    return DistRunner(eng, world, send, recv, collective, rounds_per_poll)
+    return DistRunner(eng, world, dist.get_rank(), send, recv, collective, rounds_per_poll)
+
+
+def merge_logs(logs) -> np.ndarray:
+    """Each shard's log holds the node index at the positions of ITS placements and -1 elsewhere."""
+    out = logs[0].copy()
+    for l in logs[1:]:
+        np.maximum(out, l, out=out)
+    return out

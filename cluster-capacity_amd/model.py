@@ -208,4 +208,5 @@ class RunResult:
     last_feasible: int = 0
     scans: int = 0
     kernel_ns: int = 0
+    pass_kernel_ns: int = 0
     bytes_per_scan: int = 0

@@ -73,6 +73,8 @@ typedef struct {
     void *stream;        /* hipStream_t to enqueue on, or NULL: the engine creates its own */
     int32_t rounds_per_sync; /* placement rounds enqueued between host checks of the done flag; 0 = default */
     int32_t use_graph;       /* replay rounds from a captured hipGraph (1) or launch eagerly (0) */
+    int32_t time_passes;     /* measurement runs: launch eagerly with a HIP event pair around every full-pass kernel
+                                (k_scan / k_level) and report their summed duration in ccsim_report.pass_kernel_ns */
 } ccsim_config;
 
 /* Node snapshot, structure-of-arrays, canonical node order (S/backend/cache/node_tree.go:119-143).
@@ -161,10 +163,11 @@ typedef struct {
     int64_t n_code_unschedulable; /* nodes whose terminal status is plain Unschedulable */
     /* counters */
     int64_t rounds;          /* scheduling cycles simulated (placements + the terminal one) */
-    int64_t scans;           /* full pods x nodes scan passes launched */
+    int64_t scans;           /* full pods x nodes passes executed (sequential: one per round; batched: one per level) */
     int64_t evaluated_total; /* (pod, node) evaluations the reference semantics imply = rounds * n */
     int32_t last_feasible;   /* FeasibleNodes of the last cycle */
-    int64_t kernel_ns;       /* GPU time of the scan launches (HIP events on the engine's stream) */
+    int64_t kernel_ns;       /* GPU time of all launches of the run (HIP events on the engine's stream) */
+    int64_t pass_kernel_ns;  /* cfg.time_passes: summed duration of the `scans` full-pass kernel launches alone */
     int64_t bytes_per_scan;  /* algorithmic bytes one scan reads: n_nodes * sum of enabled column widths */
 } ccsim_report;
 
@@ -204,24 +207,33 @@ int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req_mem, int64
 /* ---- multi-GPU stepping: one rank per GPU, node-range shards, ONE collective per round ----
  * (no reference counterpart: the reference is one process).
  * sendbuf / recvbuf are device buffers the caller owns (e.g. torch tensors): int64[CCSIM_XCHG_WORDS]
- * and int64[n_ranks * CCSIM_XCHG_WORDS].  Per round every rank:
- *     ccsim_dist_scan()    k_scan on the shard + reduce -> this rank's record in sendbuf
+ * and int64[n_ranks * CCSIM_XCHG_WORDS].  Per pass (sequential: one placement round; batched: one
+ * score level = many rounds) every rank:
+ *     ccsim_dist_scan()    full pass over the shard + reduce -> this rank's record in sendbuf
  *     all-gather sendbuf -> recvbuf over RCCL/xGMI on the same stream (the max-loc exchange:
  *                          record word 0 is the packed (score, position) key combined with MAX)
- *     ccsim_dist_decide()  every rank reduces the gathered records identically; the rank that owns
- *                          the winning node applies NodeInfo.update to its HBM columns
- * ccsim_dist_poll() synchronizes and reads the done flag; call it every few rounds. */
-#define CCSIM_XCHG_WORDS 8
-int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, void *sendbuf, void *recvbuf,
-                     int64_t log_cap);
+ *     ccsim_dist_decide()  every rank reduces the gathered records identically; only the rank that
+ *                          owns a winning node applies NodeInfo.update to its HBM columns
+ * ccsim_dist_poll() synchronizes and reads the done flag; call it every few passes.
+ * With a placement log each rank fills the positions of ITS placements in its own log copy and leaves
+ * -1 elsewhere: the element-wise maximum over ranks is the global log. */
+#define CCSIM_XCHG_WORDS 16
+int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, int32_t rank, void *sendbuf,
+                     void *recvbuf, int64_t log_cap);
 int ccsim_dist_scan(ccsim_engine *e);
 int ccsim_dist_decide(ccsim_engine *e);
 int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed);
 int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out);
 
-/* Measurement aid (bench.py roofline): time `iters` back-to-back launches of the dominant kernel
- * (the full pods x nodes scan) with HIP events on the engine's stream; simulation state is not advanced. */
-int ccsim_time_scan(ccsim_engine *e, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan);
+/* Restore the dynamic node columns (Requested / NonZeroRequested / pod count) to the loaded snapshot,
+ * device-to-device from pristine copies kept in HBM: the next ccsim_run starts from the same cluster
+ * (what a fresh framework.New + SyncWithClient would give, simulator.go:107-295) without a host upload. */
+int ccsim_reset_state(ccsim_engine *e);
+
+/* Measurement aid (bench.py roofline): time `iters` back-to-back launches of the dominant kernel of
+ * `mode` (the full pods x nodes pass: k_scan or k_level) with HIP events on the engine's stream;
+ * simulation state is not advanced. */
+int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan);
 
 #ifdef __cplusplus
 }

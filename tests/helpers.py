@@ -53,3 +53,36 @@ def readme_nodes(k=4):
 def examples_pod():
     """examples/pod.yaml: cpu 150m, memory 100Mi."""
     return simple_pod(150, 100 * MiB)
+
+
+def random_case(rng, n):
+    """Random snapshot + pod + profile exercising every plugin of the engine (shared by CPU and GPU tests)."""
+    a_cpu = rng.choice([1000, 2000, 4000, 8000], n)
+    a_mem = rng.choice([2, 4, 8, 16], n) * GiB
+    a_eph = rng.choice([0, 10, 50], n) * GiB
+    nodes = simple_nodes(a_cpu, a_mem, rng.integers(1, 12, n), req_mcpu=rng.integers(0, 900, n),
+                           req_mem=rng.integers(0, 3, n) * GiB // 2, pod_count=rng.integers(0, 4, n), alloc_eph=a_eph,
+                           taintset_id=rng.integers(0, 4, n), unschedulable=(rng.random(n) < 0.05),
+                           label_cols=[rng.integers(0, 5, n), rng.integers(0, 3, n)])
+    nodes.nz_mcpu = nodes.req[0] + rng.integers(0, 3, n) * 100  # existing pods without cpu requests
+    nodes.nz_mem = nodes.req[1] + rng.integers(0, 2, n) * 200 * MiB
+    t_in = lambda size, ids: np.isin(np.arange(size), ids).astype(np.uint8)
+    pod = M.PodSpec(
+        req=np.array([int(rng.choice([0, 100, 250, 500])), int(rng.choice([0, 256, 512])) * MiB, int(rng.choice([0, 0, 1])) * GiB]),
+        nz_mcpu=0, nz_mem=0,
+        taint_filter_ok=np.array([1, rng.integers(0, 2), 1, rng.integers(0, 2)], np.uint8),
+        taint_prefer_cnt=np.array([0, 0, rng.integers(0, 3), rng.integers(0, 3)], np.int32),
+        tolerates_unschedulable=bool(rng.integers(0, 2)),
+        affinity_filter_active=bool(rng.integers(0, 2)),
+        has_node_selector=bool(rng.integers(0, 2)), node_selector=[(1, t_in(3, [1, 2]))],
+        has_required_terms=bool(rng.integers(0, 2)),
+        required=[[(0, t_in(5, [1, 2, 3])), (1, t_in(3, [0, 1]))], [(0, t_in(5, [4]))], []],
+        preferred=[(int(rng.integers(1, 100)), [(0, t_in(5, [2]))]), (int(rng.integers(1, 100)), [(1, t_in(3, [2])), (0, t_in(5, [0, 2, 4]))])]
+        if rng.integers(0, 2) else [],
+    )
+    pod.nz_mcpu = int(pod.req[0]) or 100
+    pod.nz_mem = int(pod.req[1]) or 200 * MiB
+    prof = M.Profile(fit_res_w=(int(rng.integers(1, 4)), int(rng.integers(1, 4))),
+                     w_taint=int(rng.integers(0, 4)), w_nodeaffinity=int(rng.integers(0, 3)), w_fit=int(rng.integers(0, 3)),
+                     w_balanced=int(rng.integers(0, 2)))
+    return nodes, pod, prof

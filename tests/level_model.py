@@ -1,0 +1,178 @@
+"""Executable specification of CCSIM_MODE_BATCHED (cluster-capacity_amd/csrc/ccsim_level.h) in plain
+Python -- TEST INFRASTRUCTURE.  It mirrors the decision logic of k_level / level_decide (levels,
+run-downs, the normalization "cut", limit truncation) so that the exactness argument of the batched
+mode can be checked against the sequential oracle on the CPU, without a GPU.
+
+Arithmetic restated from the reference (S/ = vendor/k8s.io/kubernetes/pkg/scheduler):
+  fitsRequest            S/framework/plugins/noderesources/fit.go:564-660
+  LeastAllocated         S/framework/plugins/noderesources/least_allocated.go:30-61
+  BalancedAllocation     S/framework/plugins/noderesources/balanced_allocation.go:146-180
+  DefaultNormalizeScore  S/framework/plugins/helper/normalize_score.go:28-56
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F_UNSCHEDULABLE, F_TAINT, F_NODEAFFINITY, F_FIT = 1, 4, 8, 16
+
+
+def _term(nodes, reqs, n, empty_matches):
+    if not reqs:
+        return empty_matches
+    return all(table[nodes.label_cols[col][n]] for col, table in reqs)
+
+
+class LevelModel:
+    def __init__(self, prof, nodes, pod):
+        self.prof, self.nd, self.pod = prof, nodes, pod
+        N = nodes.n
+        self.N = N
+        self.ncol = len(nodes.alloc)
+        self.alloc = [a.astype(object) for a in nodes.alloc]
+        self.req = [np.array(r, dtype=object) for r in nodes.req]
+        self.z_cpu = np.array(nodes.nz_mcpu, dtype=object)
+        self.z_mem = np.array(nodes.nz_mem, dtype=object)
+        self.npods = [int(x) for x in nodes.pod_count]
+        self.a_pods = [int(x) for x in nodes.alloc_pods]
+        self.preq = [int(x) for x in pod.req] + [0] * (self.ncol - len(pod.req))
+        fm = prof.filter_mask
+        self.fit_on = bool(fm & F_FIT)
+        self.all_zero = self.preq[0] == 0 and self.preq[1] == 0 and self.preq[2] == 0 and not pod.has_scalar_entries
+        self.xcols = [c for c in range(2, self.ncol) if self.preq[c] != 0]
+        w_taint = prof.w_taint
+        self.w_aff = prof.w_nodeaffinity if pod.preferred else 0
+        self.w_taint = w_taint
+        best_effort = all(self.preq[c] == 0 for c in prof.bal_res)
+        self.w_bal = 0 if best_effort else prof.w_balanced
+        # static part (k_static)
+        self.ok, self.cnt, self.aff = [], [], []
+        for n in range(N):
+            ts = int(nodes.taintset_id[n])
+            ok = True
+            if (fm & F_UNSCHEDULABLE) and nodes.unschedulable[n] and not pod.tolerates_unschedulable:
+                ok = False
+            if ok and (fm & F_TAINT) and not pod.taint_filter_ok[ts]:
+                ok = False
+            if ok and (fm & F_NODEAFFINITY) and pod.affinity_filter_active:
+                m = True
+                if pod.has_node_selector:
+                    m = _term(nodes, pod.node_selector, n, True)
+                if m and pod.has_required_terms:
+                    m = any(_term(nodes, t, n, False) for t in pod.required)
+                ok = m
+            self.ok.append(ok)
+            self.cnt.append(int(pod.taint_prefer_cnt[ts]) if w_taint else 0)
+            self.aff.append(sum(w for (w, t) in pod.preferred if _term(nodes, t, n, False)) if self.w_aff else 0)
+
+    # ---- per-node functions on the current state ----
+    def feasible(self, n):
+        if not self.ok[n]:
+            return False
+        if not self.fit_on:
+            return True
+        if self.npods[n] + 1 > self.a_pods[n]:
+            return False
+        if not self.all_zero:
+            for c in (0, 1):
+                if self.preq[c] > 0 and self.preq[c] > self.alloc[c][n] - self.req[c][n]:
+                    return False
+            for c in self.xcols:
+                if self.preq[c] > self.alloc[c][n] - self.req[c][n]:
+                    return False
+        return True
+
+    def dyn(self, n):
+        p, t = self.prof, 0
+        if p.w_fit:
+            score = wsum = 0
+            for c, w in zip(p.fit_res, p.fit_res_w):
+                a = int(self.alloc[c][n])
+                if a == 0:
+                    continue
+                r = int(self.z_cpu[n] + self.pod.nz_mcpu) if c == 0 else int(self.z_mem[n] + self.pod.nz_mem)
+                s = 0 if r > a else ((a - r) * 100) // a
+                score += s * w
+                wsum += w
+            t += (score // wsum if wsum else 0) * p.w_fit
+        if self.w_bal:
+            fr = []
+            for c in p.bal_res:
+                a = int(self.alloc[c][n])
+                if a == 0:
+                    continue
+                f = float(int(self.req[c][n]) + self.preq[c]) / float(a)
+                fr.append(1.0 if f > 1 else f)
+            std = abs((fr[0] - fr[1]) / 2) if len(fr) == 2 else 0.0
+            t += int((1 - std) * 100.0) * self.w_bal
+        return t
+
+    def stat(self, n, mt, ma):
+        t = 0
+        if self.w_taint:
+            t += (100 if mt == 0 else 100 - (100 * self.cnt[n]) // mt) * self.w_taint
+        if self.w_aff:
+            t += (0 if ma == 0 else (100 * self.aff[n]) // ma) * self.w_aff
+        return t
+
+    def apply(self, n, sign=1):
+        for c in range(self.ncol):
+            self.req[c][n] += sign * self.preq[c]
+        self.z_cpu[n] += sign * self.pod.nz_mcpu
+        self.z_mem[n] += sign * self.pod.nz_mem
+        self.npods[n] += sign
+
+    def run_down(self, n, stat, M, jmax):
+        j = 0
+        while True:
+            self.apply(n)
+            j += 1
+            f = self.feasible(n)
+            s = stat + self.dyn(n) if f else -1
+            if not (f and s >= M and j < jmax):
+                return j, f
+
+    # ---- the batched loop (k_level + level_decide) ----
+    def run(self, limit=0):
+        placed, log, levels = 0, [], 0
+        per_node = np.zeros(self.N, np.int32)
+        while True:
+            feas = [n for n in range(self.N) if self.feasible(n)]
+            if not feas:
+                return dict(placed=placed, stop=0, log=np.array(log, np.int32), per_node_count=per_node, levels=levels)
+            mt = max(self.cnt[n] for n in feas)
+            ma = max(self.aff[n] for n in feas)
+            c_mt = sum(1 for n in feas if self.cnt[n] == mt)
+            c_ma = sum(1 for n in feas if self.aff[n] == ma)
+            sc = {n: self.stat(n, mt, ma) + self.dyn(n) for n in feas}
+            M = max(sc.values())
+            level = [n for n in feas if sc[n] == M]
+            # plan: full run-downs on scratch state
+            e_mt = e_ma = 0
+            cut_mt = cut_ma = -1
+            for n in level:
+                j, f = self.run_down(n, self.stat(n, mt, ma), M, 1 << 30)
+                for _ in range(j):
+                    self.apply(n, -1)
+                if not f:
+                    if mt > 0 and self.cnt[n] == mt:
+                        e_mt, cut_mt = e_mt + 1, max(cut_mt, n)
+                    if ma > 0 and self.aff[n] == ma:
+                        e_ma, cut_ma = e_ma + 1, max(cut_ma, n)
+            cut = 1 << 62
+            if mt > 0 and e_mt == c_mt:
+                cut = min(cut, cut_mt)
+            if ma > 0 and e_ma == c_ma:
+                cut = min(cut, cut_ma)
+            levels += 1
+            for n in level:
+                if n > cut:
+                    break
+                allowed = (limit - placed) if limit > 0 else (1 << 30)
+                if allowed <= 0:
+                    break
+                j, _ = self.run_down(n, self.stat(n, mt, ma), M, allowed)
+                placed += j
+                per_node[n] += j
+                log += [n] * j
+            if limit > 0 and placed >= limit:
+                return dict(placed=placed, stop=1, log=np.array(log, np.int32), per_node_count=per_node, levels=levels)

@@ -6,6 +6,7 @@ import helpers as H
 from cluster_capacity_amd import capi, model as M, report as R, synth
 
 pytestmark = pytest.mark.gpu
+MODES = ["sequential", "batched"]
 
 
 def _engine(nodes, pod, prof, **kw):
@@ -27,7 +28,7 @@ def _assert_same(got, ref, nodes, pod, check_log=True):
         assert R.stop_reason(got, nodes.n, 0) == R.stop_reason(ref, nodes.n, 0)
 
 
-@pytest.mark.parametrize("mode", ["sequential"])
+@pytest.mark.parametrize("mode", MODES)
 def test_ka1_test_prediction(ccref, mode):
     nodes, pod, prof = H.test_prediction_nodes(), H.test_prediction_pod(), M.Profile.default()
     e = _engine(nodes, pod, prof)
@@ -41,7 +42,7 @@ def test_ka1_test_prediction(ccref, mode):
                                        "preemption: 0/3 nodes are available: 3 No preemption victims found for incoming pod.")
 
 
-@pytest.mark.parametrize("mode", ["sequential"])
+@pytest.mark.parametrize("mode", MODES)
 def test_ka2_readme(ccref, mode):
     nodes, pod, prof = H.readme_nodes(4), H.examples_pod(), M.Profile.default()
     got = _engine(nodes, pod, prof).run(mode=mode)
@@ -49,7 +50,7 @@ def test_ka2_readme(ccref, mode):
     _assert_same(got, ccref.run(prof, nodes, pod), nodes, pod)
 
 
-@pytest.mark.parametrize("mode", ["sequential"])
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cfg,n,limit", [("C2", 1000, 0), ("C3", 1000, 0), ("C3", 4096, 700), ("C2", 5000, 300),
                                           ("C3", 777, 0), ("C3", 1, 0), ("C3", 513, 50)])
 def test_synthetic_vs_oracle(ccref, mode, cfg, n, limit):
@@ -67,43 +68,11 @@ def test_synthetic_vs_oracle(ccref, mode, cfg, n, limit):
     assert np.array_equal(st["pod_count"], nodes.pod_count + got.per_node_count)
 
 
-def _random_case(rng, n):
-    a_cpu = rng.choice([1000, 2000, 4000, 8000], n)
-    a_mem = rng.choice([2, 4, 8, 16], n) * H.GiB
-    a_eph = rng.choice([0, 10, 50], n) * H.GiB
-    nodes = H.simple_nodes(a_cpu, a_mem, rng.integers(1, 12, n), req_mcpu=rng.integers(0, 900, n),
-                           req_mem=rng.integers(0, 3, n) * H.GiB // 2, pod_count=rng.integers(0, 4, n), alloc_eph=a_eph,
-                           taintset_id=rng.integers(0, 4, n), unschedulable=(rng.random(n) < 0.05),
-                           label_cols=[rng.integers(0, 5, n), rng.integers(0, 3, n)])
-    nodes.nz_mcpu = nodes.req[0] + rng.integers(0, 3, n) * 100  # existing pods without cpu requests
-    nodes.nz_mem = nodes.req[1] + rng.integers(0, 2, n) * 200 * H.MiB
-    t_in = lambda size, ids: np.isin(np.arange(size), ids).astype(np.uint8)
-    pod = M.PodSpec(
-        req=np.array([int(rng.choice([0, 100, 250, 500])), int(rng.choice([0, 256, 512])) * H.MiB, int(rng.choice([0, 0, 1])) * H.GiB]),
-        nz_mcpu=0, nz_mem=0,
-        taint_filter_ok=np.array([1, rng.integers(0, 2), 1, rng.integers(0, 2)], np.uint8),
-        taint_prefer_cnt=np.array([0, 0, rng.integers(0, 3), rng.integers(0, 3)], np.int32),
-        tolerates_unschedulable=bool(rng.integers(0, 2)),
-        affinity_filter_active=bool(rng.integers(0, 2)),
-        has_node_selector=bool(rng.integers(0, 2)), node_selector=[(1, t_in(3, [1, 2]))],
-        has_required_terms=bool(rng.integers(0, 2)),
-        required=[[(0, t_in(5, [1, 2, 3])), (1, t_in(3, [0, 1]))], [(0, t_in(5, [4]))], []],
-        preferred=[(int(rng.integers(1, 100)), [(0, t_in(5, [2]))]), (int(rng.integers(1, 100)), [(1, t_in(3, [2])), (0, t_in(5, [0, 2, 4]))])]
-        if rng.integers(0, 2) else [],
-    )
-    pod.nz_mcpu = int(pod.req[0]) or 100
-    pod.nz_mem = int(pod.req[1]) or 200 * H.MiB
-    prof = M.Profile(fit_res_w=(int(rng.integers(1, 4)), int(rng.integers(1, 4))),
-                     w_taint=int(rng.integers(0, 4)), w_nodeaffinity=int(rng.integers(0, 3)), w_fit=int(rng.integers(0, 3)),
-                     w_balanced=int(rng.integers(0, 2)))
-    return nodes, pod, prof
-
-
-@pytest.mark.parametrize("mode", ["sequential"])
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("seed", range(12))
 def test_random_plugin_mix_vs_oracle(ccref, mode, seed):
     rng = np.random.default_rng(seed)
-    nodes, pod, prof = _random_case(rng, int(rng.integers(1, 1500)))
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 1500)))
     limit = int(rng.choice([0, 0, 37, 500]))
     ref = ccref.run(prof, nodes, pod, max_limit=limit)
     got = _engine(nodes, pod, prof).run(max_limit=limit, mode=mode)
@@ -155,3 +124,58 @@ def test_full_size_properties_1m_nodes():
     # greedy property of round 1: the first winner maximizes the (static) total score, lowest index on ties
     st = e.read_state()
     assert np.array_equal(st["pod_count"], nodes.pod_count + got.per_node_count)
+
+
+# ---- multi-shard protocol on ONE GPU: several engines own contiguous ranges of the snapshot and the
+# "all-gather" is a device copy; exercises k_final/k_level_final publishing and k_decide/k_level_decide.
+class _LocalShards:
+    def __init__(self, nodes, pod, prof, world):
+        import torch
+        from cluster_capacity_amd import dist as ccdist
+        self.torch, self.world = torch, world
+        self.ts = torch.cuda.Stream(device=0)  # handle 0 (the default stream) would mean "create your own"
+        torch.cuda.set_stream(self.ts)
+        stream = self.ts.cuda_stream
+        assert stream != 0
+        self.engines, self.send = [], []
+        self.recv = [torch.zeros(capi.XCHG_WORDS * world, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+        for r in range(world):
+            lo, hi = ccdist.shard_bounds(nodes.n, world, r)
+            e = capi.Engine(device=0, stream=stream, use_graph=False)
+            e.load(nodes.slice(lo, hi), pod, prof, global_offset=lo, n_global=nodes.n)
+            self.engines.append(e)
+            self.send.append(torch.zeros(capi.XCHG_WORDS, dtype=torch.int64, device="cuda:0"))
+
+    def run(self, limit, mode, log_cap):
+        from cluster_capacity_amd import dist as ccdist
+        W = self.world
+        for r, e in enumerate(self.engines):
+            e.dist_begin(limit, mode, W, r, self.send[r].data_ptr(), self.recv[r].data_ptr(), log_cap)
+        for _ in range(1_000_000):
+            for e in self.engines:
+                e.dist_scan()
+            gathered = self.torch.cat(self.send)
+            for r in range(W):
+                self.recv[r].copy_(gathered)
+            for e in self.engines:
+                e.dist_decide()
+            if all(e.dist_poll()[0] for e in self.engines):
+                break
+        res = [e.dist_finish(True, log_cap) for e in self.engines]
+        return res, ccdist.merge_logs([r.log for r in res])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("world,cfg,n,limit", [(2, "C3", 1500, 0), (3, "C3", 1100, 450), (2, "C2", 700, 0)])
+def test_sharded_protocol_matches_oracle(ccref, mode, world, cfg, n, limit):
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    if mode == "sequential" and ref.placed > 3000:
+        limit = 3000
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    res, log = _LocalShards(nodes, pod, prof, world).run(limit, mode, max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res)
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    assert np.array_equal(log[: ref.placed], ref.log)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)

@@ -1,0 +1,38 @@
+"""The exactness argument of CCSIM_MODE_BATCHED, checked on the CPU: the Python restatement of the
+level algorithm (tests/level_model.py, mirroring ccsim_level.h) must reproduce the sequential oracle's
+placement sequence -- same log, same per-node counts, same stop -- on the cases the GPU tests use."""
+import numpy as np
+import pytest
+
+import helpers as H
+from cluster_capacity_amd import model as M, synth
+from level_model import LevelModel
+
+
+def _check(ccref, nodes, pod, prof, limit):
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    got = LevelModel(prof, nodes, pod).run(limit)
+    assert got["placed"] == ref.placed and got["stop"] == ref.stop
+    assert np.array_equal(got["per_node_count"], ref.per_node_count)
+    assert np.array_equal(got["log"], ref.log)
+    return got
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_level_model_random_plugin_mix(ccref, seed):
+    rng = np.random.default_rng(seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 400)))
+    _check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 37, 500])))
+
+
+@pytest.mark.parametrize("cfg,n,limit", [("C2", 300, 0), ("C3", 300, 0), ("C3", 513, 700), ("C3", 1, 0)])
+def test_level_model_synthetic(ccref, cfg, n, limit):
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=1234 + n)
+    got = _check(ccref, nodes, pod, prof, limit)
+    assert got["levels"] <= got["placed"] + 1  # a level never holds less than one placement
+
+
+def test_level_model_known_answers(ccref):
+    _check(ccref, H.test_prediction_nodes(), H.test_prediction_pod(), M.Profile.default(), 0)
+    _check(ccref, H.test_prediction_nodes(), H.test_prediction_pod(), M.Profile.default(), 6)
+    _check(ccref, H.readme_nodes(4), H.examples_pod(), M.Profile.default(), 0)
