@@ -292,6 +292,9 @@ extern "C" int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
         return fail(e, -ENOSYS, "this engine scores every node: percentageOfNodesToScore must be 100");
     if (p->filter_mask & CCSIM_F_TOPOLOGYSPREAD || p->w_topologyspread)
         ; // accepted: PodTopologySpread is a no-op (PreFilter/PreScore Skip) for pods without constraints
+    if (!p->w_taint && !p->w_nodeaffinity && !p->w_fit && !p->w_balanced && !p->w_topologyspread)
+        return fail(e, -ENOSYS, "profiles without any Score plugin (numFeasibleNodesToFind = 1 with start-index rotation, "
+                                "schedule_one.go:619-621) are not supported");
     if (p->n_fit_res < 0 || p->n_fit_res > CCSIM_MAX_RES || p->n_bal_res < 0 || p->n_bal_res > CCSIM_MAX_RES)
         return fail(e, -EINVAL, "bad resource list");
     for (int i = 0; i < p->n_fit_res; i++) {
