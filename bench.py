@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--seq-rounds", type=int, default=2048, help="rounds of the sequential-mode sample (0 = skip)")
     ap.add_argument("--cpu-rounds", type=int, default=160)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch timing run (PMC collection runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,7 +144,9 @@ def main():
     # duration over one more step of the SAME workload, measured live with a HIP event pair around every
     # launch on the engine's stream (cfg.time_passes; eager launches).  rocprofv3 --kernel-trace --stats of
     # this command (profiles/) reports the same average.
-    if distributed:
+    if args.no_roofline:
+        launches, scan_s, bytes_per_scan = 0, float("nan"), r.bytes_per_scan
+    elif distributed:
         pe, prun = eng, None
         scan_ns, bytes_per_scan = eng.time_scan(50, mode=args.mode)
         scan_s = scan_ns / 50 / 1e9

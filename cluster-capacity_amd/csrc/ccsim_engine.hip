@@ -12,6 +12,7 @@
 #include <errno.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -274,8 +275,10 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     e->grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
     e->chunk = ((tiles + e->grid - 1) / e->grid) * kTile;
     e->grid = (int)((e->n_pad + e->chunk - 1) / e->chunk);
-    // batched mode: up to 2048 blocks of one contiguous chunk each
-    int64_t ltiles = (tiles + 2047) / 2048;
+    // batched mode: blocks of one contiguous chunk each; default target = 3 resident blocks per CU x 256 CUs
+    int64_t target = 768;
+    if (const char *g = getenv("CCSIM_LEVEL_GRID")) target = atoll(g) > 0 ? atoll(g) : target; // tuning knob
+    int64_t ltiles = (tiles + target - 1) / target;
     if (ltiles < 1) ltiles = 1;
     e->lvl_chunk = ltiles * kTile;
     e->lvl_grid = (int)((e->n_pad + e->lvl_chunk - 1) / e->lvl_chunk);

@@ -128,60 +128,93 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;
 }
 
-// floor(num / cap) for 0 <= num <= 100 * cap, exact: fp64 estimate + integer fix-up (a 64-bit integer
-// divide is ~10x the instructions on CDNA; the estimate is off by at most one).
-__device__ __forceinline__ int64_t div_small_quotient(int64_t num, int64_t cap) {
-    int64_t q = (int64_t)((double)num / (double)cap);
-    int64_t r = num - q * cap;
+// ---- exact scores without IEEE divides on the common path -------------------------------------------
+// A pass is as much VALU- as HBM-bound if every node pays five fp64 divisions (~40 instructions each on
+// CDNA: v_div_scale x2, v_rcp_f64, Newton FMAs, v_div_fmas, v_div_fixup).  Both scores divide by the
+// node's allocatable cpu / memory, so ONE refined reciprocal per resource (v_rcp_f64 + one Newton step,
+// relative error < 2^-45) serves all of them, and exactness is restored by construction:
+//   * LeastAllocated is an integer floor: estimate with the reciprocal, fix up with an exact int64 remainder;
+//   * BalancedAllocation truncates an fp64 value to an integer: the reciprocal-based value differs from the
+//     IEEE one by < 1e-10, so unless it lies within 1e-9 of an integer the truncation is the same; in that
+//     (probability ~2e-9) case the IEEE sequence is evaluated.
+__device__ __forceinline__ double refined_rcp(double d) {
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r0, 1.0);
+    return __builtin_fma(r0, e, r0);
+}
+
+struct NodeRcp {
+    double cpu, mem; // ~1/alloc_cpu, ~1/alloc_mem (0 when the resource is absent)
+};
+__device__ __forceinline__ NodeRcp make_rcp(int64_t a_cpu, int64_t a_mem) {
+    NodeRcp r;
+    r.cpu = a_cpu != 0 ? refined_rcp((double)a_cpu) : 0.0;
+    r.mem = a_mem != 0 ? refined_rcp((double)a_mem) : 0.0;
+    return r;
+}
+
+// floor(num / cap) for 0 <= num <= 100 * cap, exact: reciprocal estimate (off by at most one) + integer fix-up
+__device__ __forceinline__ int64_t div_small_quotient(int64_t num, int64_t cap, double rcp_cap) {
+    int64_t q = (int64_t)((double)num * rcp_cap);
+    const int64_t r = num - q * cap;
     if (r < 0) q -= 1;
     else if (r >= cap) q += 1;
     return q;
 }
 
 // least_allocated.go:52-61
-__device__ __forceinline__ int64_t least_requested_score(int64_t requested, int64_t capacity) {
+__device__ __forceinline__ int64_t least_requested_score(int64_t requested, int64_t capacity, double rcp_cap) {
     if (capacity == 0) return 0;
     if (requested > capacity) return 0;
-    return div_small_quotient((capacity - requested) * 100, capacity);
+    return div_small_quotient((capacity - requested) * 100, capacity, rcp_cap);
+}
+
+// balanced_allocation.go:146-180, the IEEE sequence exactly as the reference evaluates it (slow path)
+__device__ __noinline__ int64_t balanced_exact(int64_t x0, int64_t a0, int64_t x1, int64_t a1) {
+    double f0 = (double)x0 / (double)a0, f1 = (double)x1 / (double)a1;
+    f0 = f0 > 1 ? 1 : f0;
+    f1 = f1 > 1 ? 1 : f1;
+    const double std = fabs((f0 - f1) / 2);
+    return (int64_t)((1 - std) * 100.0);
 }
 
 // Score pair for one node in a given dynamic state: returns LeastAllocated*w_fit + Balanced*w_bal.
-__device__ __forceinline__ int64_t dynamic_score(const DevPod &p, int64_t a_cpu, int64_t a_mem, int64_t r_cpu,
+__device__ __forceinline__ int64_t dynamic_score(const DevPod &p, const NodeRcp &rc, int64_t a_cpu, int64_t a_mem, int64_t r_cpu,
                                                  int64_t r_mem, int64_t z_cpu, int64_t z_mem) {
     int64_t total = 0;
     if (p.w_fit) {
         // resource_allocation.go:48-114 with useRequested=false: NonZeroRequested + non-zero pod request
         int64_t node_score = 0, weight_sum = 0;
         if (p.fit_cpu && a_cpu != 0) {
-            node_score += least_requested_score(z_cpu + p.nz_mcpu, a_cpu) * p.fit_w_cpu;
+            node_score += least_requested_score(z_cpu + p.nz_mcpu, a_cpu, rc.cpu) * p.fit_w_cpu;
             weight_sum += p.fit_w_cpu;
         }
         if (p.fit_mem && a_mem != 0) {
-            node_score += least_requested_score(z_mem + p.nz_mem, a_mem) * p.fit_w_mem;
+            node_score += least_requested_score(z_mem + p.nz_mem, a_mem, rc.mem) * p.fit_w_mem;
             weight_sum += p.fit_w_mem;
         }
-        // weights are small positive ints; node_score <= 100 * weight_sum
-        int64_t s = weight_sum == 0 ? 0 : div_small_quotient(node_score, weight_sum);
+        // weights are small positive ints; 0 <= node_score <= 100 * weight_sum
+        int64_t s = 0;
+        if (weight_sum == 2) s = node_score >> 1;
+        else if (weight_sum == 1) s = node_score;
+        else if (weight_sum != 0) s = (int64_t)((uint32_t)node_score / (uint32_t)weight_sum);
         total += s * p.w_fit;
     }
     if (p.w_bal) {
         // balanced_allocation.go:146-180 with useRequested=true: Requested + raw pod request
-        double f0 = 0, f1 = 0;
-        int m = 0;
-        if (p.bal_cpu && a_cpu != 0) {
-            double f = (double)(r_cpu + p.req[0]) / (double)a_cpu;
-            f0 = f > 1 ? 1 : f;
-            m++;
+        const bool c = p.bal_cpu && a_cpu != 0, m = p.bal_mem && a_mem != 0;
+        int64_t score = 100; // fewer than two fractions: std = 0
+        if (c && m) {
+            const int64_t x0 = r_cpu + p.req[0], x1 = r_mem + p.req[1];
+            double f0 = (double)x0 * rc.cpu, f1 = (double)x1 * rc.mem;
+            f0 = f0 > 1 ? 1 : f0;
+            f1 = f1 > 1 ? 1 : f1;
+            const double y = (1 - fabs((f0 - f1) / 2)) * 100.0; // in [50, 100]
+            const double t = floor(y), fr = y - t;
+            if (fr > 1e-9 && fr < 1 - 1e-9) score = (int64_t)t;
+            else score = balanced_exact(x0, a_cpu, x1, a_mem);
         }
-        if (p.bal_mem && a_mem != 0) {
-            double f = (double)(r_mem + p.req[1]) / (double)a_mem;
-            f = f > 1 ? 1 : f;
-            if (m == 0) f0 = f; else f1 = f;
-            m++;
-        }
-        double std = 0.0;
-        if (m == 2) std = fabs((f0 - f1) / 2);
-        total += (int64_t)((1 - std) * 100.0) * p.w_bal;
+        total += score * p.w_bal;
     }
     return total;
 }
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             if (feasible) {
                 const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
                 const int64_t total = static_score(a.p, cnt, aff, mt, ma) +
-                                      dynamic_score(a.p, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem);
+                                      dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem);
                 const uint64_t key = make_key(total, a.c.global_offset + i0 + k);
                 best = key > best ? key : best;
                 mt_b = cnt > mt_b ? cnt : mt_b;

@@ -90,8 +90,12 @@ __device__ __forceinline__ void node_apply(const DevPod &p, NodeRegs<NX> &n, int
 }
 
 template <int NX>
+__device__ __forceinline__ int64_t node_score(const DevPod &p, const NodeRegs<NX> &n, int64_t stat, const NodeRcp &rc) {
+    return stat + dynamic_score(p, rc, n.a_cpu, n.a_mem, n.r_cpu, n.r_mem, n.z_cpu, n.z_mem);
+}
+template <int NX>
 __device__ __forceinline__ int64_t node_score(const DevPod &p, const NodeRegs<NX> &n, int64_t stat) {
-    return stat + dynamic_score(p, n.a_cpu, n.a_mem, n.r_cpu, n.r_mem, n.z_cpu, n.z_mem);
+    return node_score<NX>(p, n, stat, make_rcp(n.a_cpu, n.a_mem));
 }
 
 __device__ __forceinline__ int64_t bcast_i64(int64_t v, int src) { return __shfl(v, src, 64); }
@@ -133,13 +137,14 @@ __device__ __forceinline__ int32_t wave_run_down(const DevPod &p, const NodeRegs
     if (!__ballot(mine)) return 0;
     NodeRegs<NX> cur = n;
     bool running = mine;
+    const NodeRcp rc = make_rcp(n.a_cpu, n.a_mem); // allocatable never changes: one reciprocal pair per node
 #pragma unroll 1
     for (int it = 0; it < kSeqSteps && __ballot(running); it++) {
         if (running) {
             node_apply<NX>(p, cur, 1);
             my_j++;
             feas_after = node_feasible<NX>(p, cur);
-            running = feas_after && node_score<NX>(p, cur, stat) >= M;
+            running = feas_after && node_score<NX>(p, cur, stat, rc) >= M;
         }
     }
     uint64_t todo = __ballot(running);
@@ -148,13 +153,14 @@ __device__ __forceinline__ int32_t wave_run_down(const DevPod &p, const NodeRegs
         todo &= todo - 1;
         const NodeRegs<NX> base = bcast_node<NX>(cur, src);
         const int64_t bstat = bcast_i64(stat, src);
+        const NodeRcp brc = make_rcp(base.a_cpu, base.a_mem);
         int32_t j = 0;
         bool f_end = true;
         for (int32_t k0 = 0;; k0 += 64) {
             NodeRegs<NX> t = base;
             node_apply<NX>(p, t, (int64_t)k0 + lane + 1);
             const bool f = node_feasible<NX>(p, t);
-            const bool stop = !(f && node_score<NX>(p, t, bstat) >= M);
+            const bool stop = !(f && node_score<NX>(p, t, bstat, brc) >= M);
             const uint64_t sm = __ballot(stop);
             if (sm) {
                 const int first = __ffsll((unsigned long long)sm) - 1;
@@ -255,14 +261,70 @@ struct LevelArgs {
     int64_t chunk; // nodes per block (multiple of kTile)
 };
 
+// Level nodes are sparse (a few % of a tile) and a run-down costs hundreds of VALU instructions per step,
+// so they are COMPACTED: owners append their level nodes (registers + static score + index) to a block-wide
+// LDS work list in canonical order (ballot/popcount prefix), and the first lanes of the block take one
+// entry each -- the run-downs of a whole tile execute in a handful of densely packed waves instead of one
+// or two active lanes in every wave.  The worker lane also commits the node (closed-form update, stores)
+// and scores it in its new state; the owner skips it.
+constexpr int kListCap = kThreads; // entries per round (one per worker lane)
+
 template <int NX>
-__global__ __launch_bounds__(kThreads) void k_level(LevelArgs a) {
+struct LevelList { // structure-of-arrays in LDS: conflict-free per-lane access
+    int64_t f64[7 + 2 * NX][kListCap]; // a_cpu a_mem r_cpu r_mem z_cpu z_mem stat, xa[NX], xr[NX]
+    int64_t idx[kListCap];             // node index inside the shard
+    int32_t f32[3][kListCap];          // a_pods npods w
+};
+
+template <int NX>
+__device__ __forceinline__ void list_put(LevelList<NX> &L, int pos, const NodeRegs<NX> &n, int64_t stat, int64_t idx) {
+    L.f64[0][pos] = n.a_cpu, L.f64[1][pos] = n.a_mem, L.f64[2][pos] = n.r_cpu, L.f64[3][pos] = n.r_mem;
+    L.f64[4][pos] = n.z_cpu, L.f64[5][pos] = n.z_mem, L.f64[6][pos] = stat;
+#pragma unroll
+    for (int x = 0; x < NX; x++) L.f64[7 + x][pos] = n.xa[x], L.f64[7 + NX + x][pos] = n.xr[x];
+    L.idx[pos] = idx;
+    L.f32[0][pos] = n.a_pods, L.f32[1][pos] = n.npods, L.f32[2][pos] = (int32_t)n.w;
+}
+
+template <int NX>
+__device__ __forceinline__ void list_get(const LevelList<NX> &L, int pos, NodeRegs<NX> &n, int64_t &stat, int64_t &idx) {
+    n.a_cpu = L.f64[0][pos], n.a_mem = L.f64[1][pos], n.r_cpu = L.f64[2][pos], n.r_mem = L.f64[3][pos];
+    n.z_cpu = L.f64[4][pos], n.z_mem = L.f64[5][pos], stat = L.f64[6][pos];
+    n.xa[0] = n.xr[0] = 0;
+#pragma unroll
+    for (int x = 0; x < NX; x++) n.xa[x] = L.f64[7 + x][pos], n.xr[x] = L.f64[7 + NX + x][pos];
+    idx = L.idx[pos];
+    n.a_pods = L.f32[0][pos], n.npods = L.f32[1][pos], n.w = (uint32_t)L.f32[2][pos];
+}
+
+// running reduction state of one thread over the nodes it scored
+struct LevelAcc {
+    uint64_t best = 0;
+    int64_t top = -1; // maximum post-commit score seen by this thread and how many of its nodes hold it
+    uint32_t ntop = 0, mt = 0, ma = 0, cmt = 0, cma = 0, nfeas = 0;
+    __device__ __forceinline__ void add(int64_t score, int64_t gidx, uint32_t cnt, uint32_t aff) {
+        const uint64_t key = make_key(score, gidx);
+        best = key > best ? key : best;
+        nfeas++;
+        if (score > top) top = score, ntop = 1; else if (score == top) ntop++;
+        if (cnt > mt) mt = cnt, cmt = 1; else if (cnt == mt) cmt++;
+        if (aff > ma) ma = aff, cma = 1; else if (aff == ma) cma++;
+    }
+};
+
+#ifndef CCSIM_LEVEL_WAVES
+#define CCSIM_LEVEL_WAVES 3
+#endif
+template <int NX>
+__global__ __launch_bounds__(kThreads, CCSIM_LEVEL_WAVES) void k_level(LevelArgs a) {
     const DevState st = *a.st;
     if (st.done) return;
     constexpr int kWaves = kThreads / 64;
+    __shared__ LevelList<NX> s_list;
     __shared__ uint64_t s_key[kWaves];
     __shared__ uint32_t s_u[8][kWaves];
     __shared__ int64_t s_l[4][kWaves];
+    __shared__ int32_t s_cnt[2][kWaves]; // double-buffered by tile parity (no barrier between tiles when a tile has no level node)
 
     const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -271,123 +333,137 @@ __global__ __launch_bounds__(kThreads) void k_level(LevelArgs a) {
     if (hi > a.c.n_pad) hi = a.c.n_pad;
     const bool plan_only = st.lvl_plan_only != 0;
     const bool commit_on = st.lvl_valid != 0 && !plan_only;
+    const bool active = commit_on || plan_only;
     const bool ordered = commit_on && st.lvl_prefix != 0;
     const int64_t M = st.lvl_M;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
-    uint64_t best = 0;
-    int64_t top = -1; // this thread's maximum post-commit score and how many of its nodes hold it
-    uint32_t ntop = 0, mt_b = 0, ma_b = 0, cmt = 0, cma = 0, nfeas = 0;
+    LevelAcc acc;
     int64_t committed = 0;
     int64_t carry = ordered ? st.lvl_rank_prefix + a.blockprefix[blockIdx.x] : 0;
     int64_t T = 0, cut_mt = -1, cut_ma = -1; // plan pass
     uint32_t e_mt = 0, e_ma = 0;
 
-    for (int64_t base = lo; base < hi; base += kTile) {
+    int par = 0;
+    for (int64_t base = lo; base < hi; base += kTile, par ^= 1) {
         const int64_t i0 = base + 2 * tid;
         NodeRegs<NX> nd[2];
         load_pair<NX>(a.c, a.p, i0, nd);
-        bool feas[2], lvl[2], fend[2];
+        bool feas[2], lvl[2];
         int64_t sc[2], stat[2];
-        int32_t j[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const uint32_t cnt = (nd[k].w >> kStatCntShift) & kStatCntMask, aff = nd[k].w & kStatAffMask;
             stat[k] = static_score(a.p, cnt, aff, mt, ma);
             feas[k] = node_feasible<NX>(a.p, nd[k]);
             sc[k] = feas[k] ? node_score<NX>(a.p, nd[k], stat[k]) : -1;
-            lvl[k] = (commit_on || plan_only) && feas[k] && sc[k] == M;
+            lvl[k] = active && feas[k] && sc[k] == M && (a.c.global_offset + i0 + k) <= st.lvl_cut;
         }
-        if (commit_on || plan_only) { // block-uniform
-#pragma unroll
-            for (int k = 0; k < 2; k++) j[k] = wave_run_down<NX>(a.p, nd[k], stat[k], M, lvl[k], fend[k]);
-        }
-        if (plan_only) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (!lvl[k]) continue;
-                T += j[k];
-                if (!fend[k]) {
-                    const uint32_t cnt = (nd[k].w >> kStatCntShift) & kStatCntMask, aff = nd[k].w & kStatAffMask;
-                    const int64_t g = a.c.global_offset + i0 + k;
-                    if (mt > 0 && cnt == mt) e_mt++, cut_mt = g > cut_mt ? g : cut_mt;
-                    if (ma > 0 && aff == ma) e_ma++, cut_ma = g > cut_ma ? g : cut_ma;
-                }
-            }
-        } else if (commit_on) {
-            int64_t pos = 0;
-            if (ordered) { // exclusive position of this thread's first placement inside the level
-                const int64_t v = (lvl[0] ? j[0] : 0) + (lvl[1] ? j[1] : 0);
-                const int64_t incl = wave_incl_scan_i64(v);
-                if (lane == 63) s_l[0][wave] = incl;
-                __syncthreads();
-                int64_t before = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; w++) {
-                    if (w < wave) before += s_l[0][w];
-                    total += s_l[0][w];
-                }
-                __syncthreads();
-                pos = carry + before + incl - v;
-                carry += total;
-            }
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (!lvl[k]) continue;
-                const int64_t g = a.c.global_offset + i0 + k;
-                int64_t took = g <= st.lvl_cut ? j[k] : 0;
-                if (ordered) {
-                    int64_t allowed = st.lvl_remaining - pos;
-                    if (allowed < 0) allowed = 0;
-                    if (took > allowed) took = allowed;
-                }
-                if (took > 0) {
-                    node_apply<NX>(a.p, nd[k], took);
-                    store_dyn<NX>(a.c, a.p, i0 + k, nd[k], (int32_t)took);
-                    committed += took;
-                    feas[k] = node_feasible<NX>(a.p, nd[k]);
-                    sc[k] = feas[k] ? node_score<NX>(a.p, nd[k], stat[k]) : -1;
-                    if (ordered && a.log) {
-                        for (int64_t q = 0; q < took; q++) {
-                            const int64_t at = st.placed + pos + q;
-                            if (at < st.log_cap) a.log[at] = (int32_t)g;
-                        }
-                    }
-                }
-                pos += j[k];
-            }
-        }
-        // post-commit evaluation
+        // nodes that are not in the level keep their state: scored by their owner (before the worker phase, so
+        // that the pair's registers are dead while the work list is processed)
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const uint64_t mask = __ballot(feas[k]);
-            nfeas += (uint32_t)__popcll(mask); // wave-uniform
-            if (feas[k]) {
+            if (feas[k] && !lvl[k]) {
                 const uint32_t cnt = (nd[k].w >> kStatCntShift) & kStatCntMask, aff = nd[k].w & kStatAffMask;
-                const uint64_t key = make_key(sc[k], a.c.global_offset + i0 + k);
-                best = key > best ? key : best;
-                if (sc[k] > top) top = sc[k], ntop = 1; else if (sc[k] == top) ntop++;
-                if (cnt > mt_b) mt_b = cnt, cmt = 1; else if (cnt == mt_b) cmt++;
-                if (aff > ma_b) ma_b = aff, cma = 1; else if (aff == ma_b) cma++;
+                acc.add(sc[k], a.c.global_offset + i0 + k, cnt, aff);
+            }
+        }
+        if (active) { // block-uniform
+            // canonical-order position of this thread's level nodes in the block's work list
+            const uint64_t b0 = __ballot(lvl[0]), b1 = __ballot(lvl[1]);
+            if (lane == 0) s_cnt[par][wave] = __popcll(b0) + __popcll(b1);
+            __syncthreads();
+            int off = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask), total = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) {
+                if (w < wave) off += s_cnt[par][w];
+                total += s_cnt[par][w];
+            }
+            const int pos0 = off, pos1 = off + (lvl[0] ? 1 : 0);
+            for (int r0 = 0; r0 < total; r0 += kListCap) { // block-uniform; > 1 round only for dense levels
+                if (lvl[0] && pos0 >= r0 && pos0 < r0 + kListCap) list_put<NX>(s_list, pos0 - r0, nd[0], stat[0], i0);
+                if (lvl[1] && pos1 >= r0 && pos1 < r0 + kListCap) list_put<NX>(s_list, pos1 - r0, nd[1], stat[1], i0 + 1);
+                __syncthreads();
+                const int nwork = total - r0 < kListCap ? total - r0 : kListCap;
+                const bool mine = tid < nwork;
+                NodeRegs<NX> n;
+                int64_t nstat = 0, nidx = 0;
+                n.a_cpu = n.a_mem = n.r_cpu = n.r_mem = n.z_cpu = n.z_mem = 0, n.a_pods = n.npods = 0, n.w = 0;
+#pragma unroll
+                for (int x = 0; x < (NX > 0 ? NX : 1); x++) n.xa[x] = n.xr[x] = 0;
+                if (mine) list_get<NX>(s_list, tid, n, nstat, nidx);
+                bool fend = true;
+                int64_t j = 0;
+                if ((wave * 64) < nwork) j = wave_run_down<NX>(a.p, n, nstat, M, mine, fend); // wave-uniform
+                const int64_t g = a.c.global_offset + nidx;
+                const uint32_t cnt = (n.w >> kStatCntShift) & kStatCntMask, aff = n.w & kStatAffMask;
+                if (plan_only) {
+                    if (mine) {
+                        T += j;
+                        if (!fend) {
+                            if (mt > 0 && cnt == mt) e_mt++, cut_mt = g > cut_mt ? g : cut_mt;
+                            if (ma > 0 && aff == ma) e_ma++, cut_ma = g > cut_ma ? g : cut_ma;
+                        }
+                        acc.add(M, g, cnt, aff); // unchanged: still feasible at level M
+                    }
+                } else {
+                    int64_t took = j, pos = 0;
+                    if (ordered) { // position of this node's first placement inside the level
+                        const int64_t incl = wave_incl_scan_i64(j);
+                        __syncthreads(); // s_l reuse across rounds
+                        if (lane == 63) s_l[0][wave] = incl;
+                        __syncthreads();
+                        int64_t before = 0, tot = 0;
+#pragma unroll
+                        for (int w = 0; w < kWaves; w++) {
+                            if (w < wave) before += s_l[0][w];
+                            tot += s_l[0][w];
+                        }
+                        pos = carry + before + incl - j;
+                        carry += tot;
+                        int64_t allowed = st.lvl_remaining - pos;
+                        if (allowed < 0) allowed = 0;
+                        if (took > allowed) took = allowed;
+                    }
+                    if (mine) {
+                        if (took > 0) {
+                            node_apply<NX>(a.p, n, took);
+                            store_dyn<NX>(a.c, a.p, nidx, n, (int32_t)took);
+                            committed += took;
+                            if (ordered && a.log) {
+                                for (int64_t q = 0; q < took; q++) {
+                                    const int64_t at = st.placed + pos + q;
+                                    if (at < st.log_cap) a.log[at] = (int32_t)g;
+                                }
+                            }
+                        }
+                        if (node_feasible<NX>(a.p, n)) acc.add(node_score<NX>(a.p, n, nstat), g, cnt, aff);
+                    }
+                }
+                __syncthreads(); // the list is rewritten next round / next tile
             }
         }
     }
 
     // ---- block reduce ----
     {
-        const uint64_t wbest = wave_max_u64(best);
-        const int64_t wtop = wave_max_i64(top);
-        const uint32_t wmt = wave_max_u32(mt_b), wma = wave_max_u32(ma_b);
-        const uint32_t wntop = wave_sum_u32(top == wtop ? ntop : 0u);
-        const uint32_t wcmt = wave_sum_u32(mt_b == wmt ? cmt : 0u), wcma = wave_sum_u32(ma_b == wma ? cma : 0u);
-        T = wave_sum_i64(T);
+        const uint64_t wbest = wave_max_u64(acc.best);
+        const int64_t wtop = wave_max_i64(acc.top);
+        const uint32_t wmt = wave_max_u32(acc.mt), wma = wave_max_u32(acc.ma);
+        const uint32_t wntop = wave_sum_u32(acc.top == wtop ? acc.ntop : 0u);
+        const uint32_t wcmt = wave_sum_u32(acc.mt == wmt ? acc.cmt : 0u), wcma = wave_sum_u32(acc.ma == wma ? acc.cma : 0u);
+        const uint32_t wnf = wave_sum_u32(acc.nfeas);
         committed = wave_sum_i64(committed);
-        cut_mt = wave_max_i64(cut_mt);
-        cut_ma = wave_max_i64(cut_ma);
-        e_mt = wave_sum_u32(e_mt);
-        e_ma = wave_sum_u32(e_ma);
+        if (plan_only) { // block-uniform
+            T = wave_sum_i64(T);
+            cut_mt = wave_max_i64(cut_mt);
+            cut_ma = wave_max_i64(cut_ma);
+            e_mt = wave_sum_u32(e_mt);
+            e_ma = wave_sum_u32(e_ma);
+        }
         if (lane == 0) {
             s_key[wave] = wbest;
-            s_u[0][wave] = wmt, s_u[1][wave] = wma, s_u[2][wave] = wcmt, s_u[3][wave] = wcma, s_u[4][wave] = nfeas;
+            s_u[0][wave] = wmt, s_u[1][wave] = wma, s_u[2][wave] = wcmt, s_u[3][wave] = wcma, s_u[4][wave] = wnf;
             s_u[5][wave] = wntop, s_u[6][wave] = e_mt, s_u[7][wave] = e_ma;
             s_l[0][wave] = T, s_l[1][wave] = committed, s_l[2][wave] = cut_mt, s_l[3][wave] = cut_ma;
         }
@@ -488,7 +564,7 @@ struct LevelFinalArgs {
 // k_level_final: one block of kFinalThreads.  Reduces the per-block partials in ONE sweep (the block is
 // latency-bound: every thread reads at most a couple of 96-byte partials); on one GPU also decides.  After a
 // plan pass it leaves the exclusive per-block prefix of the level's placements in blockprefix[].
-constexpr int kFinalThreads = 1024;
+constexpr int kFinalThreads = 256;
 
 __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a) {
     if (a.st->done) return;
