@@ -32,14 +32,16 @@ def shard_bounds(n_global: int, world: int, rank: int) -> Tuple[int, int]:
 class DistRunner:
     """Drives one rank's engine; `collective(recv, send)` performs the all-gather."""
 
-    def __init__(self, engine, world: int, rank: int, send, recv, collective, rounds_per_poll: int = 32):
+    def __init__(self, engine, world: int, rank: int, send, recv, collective, rounds_per_poll: int = 32,
+                 buffer_arg=lambda t: t.data_ptr()):
         self.engine, self.world, self.rank, self.send, self.recv = engine, world, rank, send, recv
         self.collective = collective
         self.rounds_per_poll = rounds_per_poll
+        self.buffer_arg = buffer_arg  # how the engine wants the exchange buffers (the HIP engine: device pointers)
 
     def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0) -> M.RunResult:
         e = self.engine
-        e.dist_begin(max_limit, mode, self.world, self.rank, self.send.data_ptr(), self.recv.data_ptr(),
+        e.dist_begin(max_limit, mode, self.world, self.rank, self.buffer_arg(self.send), self.buffer_arg(self.recv),
                      log_cap if want_log else 0)
         while True:
             for _ in range(self.rounds_per_poll):

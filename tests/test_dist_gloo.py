@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo process groups drive cluster-capacity_amd/dist.DistRunner with
+one all-gather per pass.  The shard engine is a CPU stand-in (tests/cpu_shard_engine.py) because the HIP engine
+needs a GPU; the protocol, shard bounds, owner-only update and log are the product's."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["CC_ROOT"]); sys.path.insert(0, os.path.join(os.environ["CC_ROOT"], "tests"))
+sys.path.insert(0, os.path.join(os.environ["CC_ROOT"], "oracle"))
+import __graft_entry__ as ge; ge.load_package()
+import numpy as np, torch, torch.distributed as dist
+from cluster_capacity_amd import dist as ccdist, synth
+from cpu_shard_engine import CpuShardEngine
+import ccref_py
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, limit = int(os.environ["CC_N"]), int(os.environ["CC_LIMIT"])
+nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=31)
+lo, hi = ccdist.shard_bounds(n, world, rank)
+eng = CpuShardEngine(nodes.slice(lo, hi), pod, prof, lo, n)
+send = torch.zeros(16, dtype=torch.int64); recv = torch.zeros(16 * world, dtype=torch.int64)
+runner = ccdist.DistRunner(eng, world, rank, send, recv, lambda r, s: dist.all_gather_into_tensor(r, s), rounds_per_poll=8,
+                           buffer_arg=lambda t: t)  # the CPU stand-in takes the tensors themselves
+res = runner.run(max_limit=limit, mode="sequential", want_log=True, log_cap=limit)
+counts = [None] * world
+dist.all_gather_object(counts, res.per_node_count.tolist())
+if rank == 0:
+    ref = ccref_py.run(prof, nodes, pod, max_limit=limit)
+    ok = (res.placed == ref.placed and res.stop == ref.stop and sum(counts, []) == ref.per_node_count.tolist()
+          and res.log.tolist() == ref.log.tolist())
+    print("RESULT", json.dumps({"ok": bool(ok), "placed": res.placed}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,n,limit", [(2, 240, 150), (3, 100, 40)])
+def test_sharded_runner_over_gloo(tmp_path, world, n, limit):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, CC_ROOT=ROOT, CC_N=str(n), CC_LIMIT=str(limit), OMP_NUM_THREADS="1")
+    port = 29500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line and '"ok": true' in line[0], (out.stdout[-1000:], out.stderr[-1000:])
+
+
+def test_shard_bounds_cover_and_order():
+    from cluster_capacity_amd import dist as ccdist
+    for n in (0, 1, 7, 1000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            b = [ccdist.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def test_merge_logs():
+    from cluster_capacity_amd import dist as ccdist
+    a, b = np.array([3, -1, -1, 5], np.int32), np.array([-1, 9, 8, -1], np.int32)
+    assert ccdist.merge_logs([a, b]).tolist() == [3, 9, 8, 5]
