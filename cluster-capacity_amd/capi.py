@@ -46,6 +46,11 @@ class CTerm(C.Structure):
     _fields_ = [("first_req", C.c_int32), ("n_req", C.c_int32), ("weight", C.c_int32)]
 
 
+class CSpread(C.Structure):
+    _fields_ = [("col", C.c_int32), ("max_skew", C.c_int32), ("min_domains", C.c_int32), ("hard", C.c_int32),
+                ("self_match", C.c_int32), ("n_domains", C.c_int32), ("node_match_count", _p32), ("node_included", _pu8)]
+
+
 class CPod(C.Structure):
     _fields_ = [
         ("req", C.c_int64 * MAX_RES), ("has_scalar_entries", C.c_int32), ("nz_mcpu", C.c_int64), ("nz_mem", C.c_int64),
@@ -54,6 +59,7 @@ class CPod(C.Structure):
         ("node_selector", CTerm), ("has_required_terms", C.c_int32), ("n_required", C.c_int32),
         ("required", C.POINTER(CTerm)), ("n_preferred", C.c_int32), ("preferred", C.POINTER(CTerm)),
         ("n_reqs", C.c_int32), ("reqs", C.POINTER(CReq)), ("req_tables_len", C.c_int64), ("req_tables", _pu8),
+        ("n_spread", C.c_int32), ("spread", CSpread * M.MAX_TSC),
     ]
 
 
@@ -210,8 +216,22 @@ def marshal_pod(pod: M.PodSpec, keep: list) -> CPod:
     s.reqs = C.cast(rqa, C.POINTER(CReq))
     s.req_tables_len = int(tab.shape[0])
     s.req_tables = _ptr(tab, _pu8)
-    if getattr(pod, "spread", None):
-        raise CcsimError("PodTopologySpread constraints are not supported by the HIP engine yet")
+    spread = list(getattr(pod, "spread", None) or [])
+    if len(spread) > M.MAX_TSC:
+        raise CcsimError("too many topology spread constraints")
+    s.n_spread = len(spread)
+    for i, k in enumerate(spread):
+        c = s.spread[i]
+        c.col, c.max_skew, c.min_domains = int(k.col), int(k.max_skew), int(k.min_domains)
+        c.hard, c.self_match, c.n_domains = int(bool(k.hard)), int(bool(k.self_match)), int(k.n_domains)
+        if k.node_match_count is not None:
+            a = np.ascontiguousarray(k.node_match_count, dtype=np.int32)
+            keep.append(a)
+            c.node_match_count = _ptr(a, _p32)
+        if k.node_included is not None:
+            a = np.ascontiguousarray(k.node_included, dtype=np.uint8)
+            keep.append(a)
+            c.node_included = _ptr(a, _pu8)
     return s
 
 

@@ -48,6 +48,10 @@ struct ccsim_engine {
     // pod / profile
     ccsim_profile prof{};
     DevPod pod{};
+    DevPts pts{};
+    int32_t *d_pts_min_partials = nullptr;
+    std::vector<std::pair<int32_t *, int32_t *>> pts_tables; // (live, pristine) count tables
+    std::vector<size_t> pts_table_len;
     std::vector<void *> pod_allocs;
 
     // run state
@@ -415,20 +419,80 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     hipLaunchKernelGGL(k_static, dim3(blocks), dim3(kThreads), 0, e->stream, s);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream)); // host vectors above go out of scope
+
+    // hard topology spread constraints: count tables + eligibility, built once (filtering.go:235-308)
+    e->pts = DevPts{};
+    e->d_pts_min_partials = nullptr;
+    e->pts_tables.clear();
+    e->pts_table_len.clear();
+    if (pod->n_spread < 0 || pod->n_spread > CCSIM_MAX_TSC) return fail(e, -EINVAL, "n_spread out of range");
+    if (pod->n_spread > 0 && (pf.filter_mask & CCSIM_F_TOPOLOGYSPREAD)) {
+        PtsInitArgs pi{};
+        pi.n = e->n;
+        DevPts &pt = e->pts;
+        pt.n = pod->n_spread;
+        std::vector<int32_t *> d_present((size_t)pod->n_spread, nullptr);
+        for (int c = 0; c < pod->n_spread; c++) {
+            const ccsim_spread_constraint &k = pod->spread[c];
+            if (!k.hard) return fail(e, -ENOSYS, "ScheduleAnyway topology spread constraints (PodTopologySpread score) are not supported by the HIP engine yet");
+            if (k.col < 0 || k.col >= e->n_label_cols) return fail(e, -EINVAL, "spread constraint label column out of range");
+            if (k.max_skew < 1 || k.min_domains < 1 || k.n_domains < 0) return fail(e, -EINVAL, "bad spread constraint");
+            pt.max_skew[c] = k.max_skew, pt.min_domains[c] = k.min_domains, pt.self_match[c] = k.self_match ? 1 : 0;
+            std::vector<int32_t *> lc((size_t)CCSIM_MAX_LABEL_COLS, nullptr);
+            HIPCHK(e, hipMemcpy(lc.data(), e->d_label_cols, sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyDeviceToHost));
+            pt.label[c] = lc[k.col];
+            const size_t len = (size_t)k.n_domains + 1;
+            int32_t *tbl = nullptr, *tbl0 = nullptr, *ex = nullptr;
+            uint8_t *inc = nullptr;
+            if ((rc = dev_alloc(e, &tbl, len, e->pod_allocs))) return rc;
+            if ((rc = dev_alloc(e, &tbl0, len, e->pod_allocs))) return rc;
+            if ((rc = dev_alloc(e, &d_present[c], len, e->pod_allocs))) return rc;
+            if (k.node_match_count && (rc = upload(e, &ex, k.node_match_count, (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            if (k.node_included && (rc = upload(e, &inc, k.node_included, (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            pt.tbl[c] = tbl;
+            pi.existing[c] = ex, pi.included[c] = inc, pi.present[c] = d_present[c];
+            e->pts_tables.emplace_back(tbl, tbl0);
+            e->pts_table_len.push_back(len);
+        }
+        uint8_t *elig = nullptr;
+        if ((rc = dev_alloc(e, &elig, (size_t)e->n_pad, e->pod_allocs))) return rc;
+        pt.elig = elig;
+        pi.elig = elig;
+        pi.pts = pt;
+        if ((rc = dev_alloc(e, &e->d_pts_min_partials, (size_t)kMaxGrid * kMaxTsc, e->pod_allocs))) return rc;
+        if (e->n > 0) hipLaunchKernelGGL(k_pts_init, dim3((unsigned)((e->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, pi);
+        HIPCHK(e, hipGetLastError());
+        for (int c = 0; c < pod->n_spread; c++) {
+            const size_t len = e->pts_table_len[c];
+            std::vector<int32_t> pres(len);
+            HIPCHK(e, hipMemcpyAsync(pres.data(), d_present[c], len * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].second, e->pts_tables[c].first, len * 4, hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            int32_t np_ = 0;
+            for (size_t v = 1; v < len; v++) np_ += pres[v] != 0;
+            pt.n_present[c] = np_;
+        }
+    }
     e->have_pod = true;
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-static int launch_scan(ccsim_engine *e) {
-    ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk};
+template <bool PTS>
+static void launch_scan_t(ccsim_engine *e, const ScanArgs &a) {
     const int nx = e->pod.nx;
     dim3 g(e->grid), b(kThreads);
-    if (nx == 0) hipLaunchKernelGGL(k_scan<0>, g, b, 0, e->stream, a);
-    else if (nx == 1) hipLaunchKernelGGL(k_scan<1>, g, b, 0, e->stream, a);
-    else if (nx == 2) hipLaunchKernelGGL(k_scan<2>, g, b, 0, e->stream, a);
-    else if (nx <= 4) hipLaunchKernelGGL(k_scan<4>, g, b, 0, e->stream, a);
-    else hipLaunchKernelGGL(k_scan<kMaxExtra>, g, b, 0, e->stream, a);
+    if (nx == 0) hipLaunchKernelGGL((k_scan<0, PTS>), g, b, 0, e->stream, a);
+    else if (nx == 1) hipLaunchKernelGGL((k_scan<1, PTS>), g, b, 0, e->stream, a);
+    else if (nx == 2) hipLaunchKernelGGL((k_scan<2, PTS>), g, b, 0, e->stream, a);
+    else if (nx <= 4) hipLaunchKernelGGL((k_scan<4, PTS>), g, b, 0, e->stream, a);
+    else hipLaunchKernelGGL((k_scan<kMaxExtra, PTS>), g, b, 0, e->stream, a);
+}
+
+static int launch_scan(ccsim_engine *e) {
+    ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk, e->pts, e->d_pts_min_partials};
+    if (e->pts.n > 0) launch_scan_t<true>(e, a);
+    else launch_scan_t<false>(e, a);
     return 0;
 }
 
@@ -443,6 +507,8 @@ static FinalArgs final_args(ccsim_engine *e) {
     f.xrecv = e->d_xrecv;
     f.n_ranks = e->n_ranks;
     f.log = e->d_log;
+    f.pts = e->pts;
+    f.pts_min_partials = e->d_pts_min_partials;
     return f;
 }
 
@@ -485,6 +551,11 @@ static int launch_level_final(ccsim_engine *e) {
 static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_cap) {
     if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
     if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
+    if (e->pts.n > 0 && mode == CCSIM_MODE_BATCHED)
+        return fail(e, -ENOSYS, "batched mode is not valid with topology spread constraints (a placement changes the feasibility of "
+                                "other nodes): use CCSIM_MODE_SEQUENTIAL");
+    if (e->pts.n > 0 && e->n_ranks > 0)
+        return fail(e, -ENOSYS, "topology spread constraints are single-GPU only for now");
     if (mode == CCSIM_MODE_BATCHED && !e->pod.fit_enabled)
         return fail(e, -ENOSYS, "batched mode needs the NodeResourcesFit filter (a run-down is bounded by the node's pod capacity)");
     HIPCHK(e, hipSetDevice(e->device));
@@ -499,6 +570,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
         }
     }
     DevState st{};
+    for (int c = 0; c < kMaxTsc; c++) st.pts_min_a[c] = 0x7fffffff;
     st.limit = max_limit;
     st.winner = -1;
     st.mode = mode;
@@ -582,7 +654,8 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     out->kernel_ns = (int64_t)(e->kernel_ms * 1e6);
     out->pass_kernel_ns = (int64_t)(e->pass_kernel_ms * 1e6);
     // algorithmic bytes per scan: the columns the active plugin set must read once per node
-    int64_t per_node = 4 /*static word*/ + 6 * 8 /*alloc,req,nz x cpu,mem*/ + 2 * 4 /*pods*/ + (int64_t)e->pod.nx * 16;
+    int64_t per_node = 4 /*static word*/ + 6 * 8 /*alloc,req,nz x cpu,mem*/ + 2 * 4 /*pods*/ + (int64_t)e->pod.nx * 16 +
+                       (e->pts.n ? 1 + 4 * (int64_t)e->pts.n : 0) /*eligibility byte + topology value id per constraint*/;
     out->bytes_per_scan = per_node * e->n;
     memset(out->hist, 0, sizeof(out->hist));
     out->n_code_unschedulable = 0;
@@ -603,7 +676,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
         // terminal round: FitError diagnosis (types.go:787-836)
         HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
         HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
-        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets};
+        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state};
         int64_t hb = (e->n + kThreads - 1) / kThreads;
         if (hb > 2048) hb = 2048;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
@@ -668,7 +741,7 @@ extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
     out->feasible_nodes = 0;
     if (e->n == 0) return 0;
     const int64_t rounds0 = e->h_state->rounds;
-    for (int tries = 0; tries < 4; tries++) {
+    for (int tries = 0; tries < 8; tries++) {
         launch_scan(e);
         launch_final(e);
         HIPCHK(e, hipGetLastError());
@@ -765,6 +838,8 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
     for (size_t i = 0; i < e->backups.size(); i++)
         HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
+    for (size_t c = 0; c < e->pts_tables.size(); c++)
+        HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].first, e->pts_tables[c].second, e->pts_table_len[c] * 4, hipMemcpyDeviceToDevice, e->stream));
     e->begun = false;
     return 0;
 }

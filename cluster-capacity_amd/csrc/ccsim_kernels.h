@@ -29,6 +29,7 @@ namespace ccsim {
 
 constexpr int kMaxRes = 11;
 constexpr int kMaxExtra = 9;       // ephemeral + 8 scalars
+constexpr int kMaxTsc = 8;         // hard topology spread constraints per pod
 constexpr int kThreads = 256;      // 4 waves
 constexpr int kNodesPerThread = 2; // 16-byte loads on int64 columns
 constexpr int kTile = kThreads * kNodesPerThread;
@@ -71,7 +72,19 @@ struct DevPod {
     int32_t ncol;
 };
 
+// Hard PodTopologySpread constraints (P/podtopologyspread/filtering.go:235-356): TpValueToMatchNum lives as
+// one count table per constraint in HBM (L2-resident: #domains x 4 B), updated by the commit.
+struct DevPts {
+    int32_t n;
+    int32_t max_skew[kMaxTsc], min_domains[kMaxTsc], self_match[kMaxTsc];
+    int32_t n_present[kMaxTsc];   // len(TpValueToMatchNum[c]): domains holding >= 1 counted node (static)
+    const int32_t *label[kMaxTsc]; // topology value id per node (0 = key absent)
+    int32_t *tbl[kMaxTsc];         // match count per value id
+    const uint8_t *elig;           // per node: bit0 has all hard keys (filtering.go:267-270), bit 1+c counted for c (:274-277)
+};
+
 struct DevState {
+    int32_t pts_min_a[kMaxTsc]; // CriticalPaths[c][0].MatchNum the pending scan assumed (filtering.go:298-305)
     int64_t placed, limit, rounds, scans;
     int64_t winner; // global index committed by the last decide (-1 none)
     int32_t done, have_prev;
@@ -256,9 +269,11 @@ struct ScanArgs {
     const DevState *st;
     Partial *partials;
     int64_t chunk; // nodes per block (multiple of kTile)
+    DevPts pts;
+    int32_t *pts_min_partials; // [grid][kMaxTsc]: per-block minimum match count per constraint
 };
 
-template <int NX>
+template <int NX, bool PTS>
 __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     const DevState st = *a.st;
     if (st.done) return;
@@ -270,6 +285,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
 
     uint64_t best = 0;
     uint32_t mt_b = 0, ma_b = 0, nfeas = 0;
+    int32_t pmin[kMaxTsc];
+#pragma unroll
+    for (int c = 0; c < kMaxTsc; c++) pmin[c] = 0x7fffffff;
 
     for (int64_t base = lo; base < hi; base += kTile) {
         const int64_t i0 = base + 2 * tid; // first of this thread's 2 nodes
@@ -303,8 +321,23 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             const int64_t r_cpu = k ? R0.y : R0.x, r_mem = k ? R1.y : R1.x;
             const int64_t z_cpu = k ? Z0.y : Z0.x, z_mem = k ? Z1.y : Z1.x;
             const int32_t a_pods = k ? AP.y : AP.x, npods = k ? NP.y : NP.x;
-            const bool feasible = (w >> kStatOkBit) && (k ? xok1 : xok0) &&
-                                  fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods);
+            bool feasible = (w >> kStatOkBit) && (k ? xok1 : xok0) &&
+                            fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods);
+            if (PTS) { // PodTopologySpread.Filter (filtering.go:311-356) + the minimum for the next verification
+                const uint32_t eb = a.pts.elig[i0 + k];
+#pragma unroll
+                for (int c = 0; c < kMaxTsc; c++) {
+                    if (c >= a.pts.n) break;
+                    const int32_t v = a.pts.label[c][i0 + k];
+                    const int32_t m = v ? a.pts.tbl[c][v] : 0;
+                    if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u)) pmin[c] = m < pmin[c] ? m : pmin[c];
+                    if (!v) feasible = false; // missing required label
+                    else {
+                        const int64_t minm = a.pts.n_present[c] < a.pts.min_domains[c] ? 0 : (int64_t)st.pts_min_a[c];
+                        if ((int64_t)m + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) feasible = false;
+                    }
+                }
+            }
             const uint64_t mask = __ballot(feasible);
             nfeas += (uint32_t)__popcll(mask); // identical in every lane of the wave
             if (feasible) {
@@ -348,6 +381,25 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
         out.nfeas = nf;
         a.partials[blockIdx.x] = out;
     }
+    if (PTS) {
+        __shared__ int32_t s_pm[kThreads / 64][kMaxTsc];
+#pragma unroll
+        for (int c = 0; c < kMaxTsc; c++) {
+            int32_t v = pmin[c];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int32_t o = __shfl_xor(v, off, 64);
+                v = o < v ? o : v;
+            }
+            if (lane == 0) s_pm[wave][c] = v;
+        }
+        __syncthreads();
+        if (tid < kMaxTsc) {
+            int32_t v = s_pm[0][tid];
+            for (int w = 1; w < kThreads / 64; w++) v = s_pm[w][tid] < v ? s_pm[w][tid] : v;
+            a.pts_min_partials[(int64_t)blockIdx.x * kMaxTsc + tid] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -367,13 +419,23 @@ struct FinalArgs {
     const XRec *xrecv; // distributed: gathered records in
     int32_t n_ranks;   // 0 = single GPU (decide from the local record)
     int32_t *log;
+    DevPts pts;
+    const int32_t *pts_min_partials;
 };
 
-__device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas) {
+__device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas,
+                                              const int32_t *pts_min) {
     DevState st = *a.st;
     st.winner = -1;
     if (st.done) return;
     st.scans += 1;
+    bool pts_stale = false; // the scan filtered with an outdated global minimum (filtering.go:298-305): redo it
+    for (int c = 0; c < a.pts.n; c++)
+        if (pts_min[c] != st.pts_min_a[c]) st.pts_min_a[c] = pts_min[c], pts_stale = true;
+    if (pts_stale) {
+        *a.st = st;
+        return;
+    }
     if (key == 0) {
         st.done = DONE_UNSCHEDULABLE;
         st.rounds += 1;
@@ -392,6 +454,13 @@ __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, 
             a.c.nz_mem[i] += a.p.nz_mem;
             a.c.pod_count[i] += 1;
             a.c.placed_cnt[i] += 1;
+            if (a.pts.n) { // the clone now counts towards its domains (filtering.go:255-296 on the next cycle)
+                const uint32_t eb = a.pts.elig[i];
+                for (int c = 0; c < a.pts.n; c++) {
+                    const int32_t v = a.pts.label[c][i];
+                    if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.pts.self_match[c]) a.pts.tbl[c][v] += 1;
+                }
+            }
         }
         if (a.log && st.placed < st.log_cap) a.log[st.placed] = (int32_t)g;
         st.placed += 1;
@@ -442,6 +511,15 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         ma = s_ma[w] > ma ? s_ma[w] : ma;
         nf += s_nf[w];
     }
+    int32_t pts_min[kMaxTsc];
+    for (int c = 0; c < a.pts.n; c++) { // single thread: <= 1024 x 8 ints, only when spread constraints exist
+        int32_t v = 0x7fffffff;
+        for (int i = 0; i < a.n_partials; i++) {
+            const int32_t q = a.pts_min_partials[(int64_t)i * kMaxTsc + c];
+            v = q < v ? q : v;
+        }
+        pts_min[c] = v;
+    }
     if (a.n_ranks > 0) {
         XRec r{};
         r.key = (int64_t)key;
@@ -451,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         *a.xsend = r;
         return;
     }
-    decide_commit(a, key, mt, ma, nf);
+    decide_commit(a, key, mt, ma, nf, pts_min);
 }
 
 // k_decide (distributed): every rank reduces the gathered records identically, so all ranks agree on
@@ -469,7 +547,7 @@ __global__ void k_decide(FinalArgs a) {
         ma = (uint32_t)q.ma > ma ? (uint32_t)q.ma : ma;
         nf += q.nfeas;
     }
-    decide_commit(a, key, mt, ma, nf);
+    decide_commit(a, key, mt, ma, nf, nullptr); // spread constraints are single-GPU only for now (pts.n == 0)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,9 +634,12 @@ struct HistArgs {
     unsigned long long *hist_ts;   // [n_taintsets]
     unsigned long long *hist_code; // [1]
     int32_t n_taintsets;
+    DevPts pts;
+    const DevState *st;
 };
 
 constexpr int kHistSlots = 4 + kMaxRes + 2 + 1; // + the status-code counter
+constexpr int kHistPtsMissing = 4 + kMaxRes, kHistPtsSkew = 4 + kMaxRes + 1;
 constexpr int kHistTsLds = 1024;                // taint sets histogrammed in LDS (more fall back to global atomics)
 
 __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
@@ -578,10 +659,9 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
             continue;
         }
         if (sr == 3) { atomicAdd(&sh[2], 1u); continue; }
-        if (!a.p.fit_enabled) continue;
         bool unresolvable = false, any = false;
-        if ((int64_t)a.c.pod_count[n] + 1 > (int64_t)a.c.alloc_pods[n]) { atomicAdd(&sh[3], 1u); any = true; }
-        if (!a.p.all_zero_req) {
+        if (a.p.fit_enabled && (int64_t)a.c.pod_count[n] + 1 > (int64_t)a.c.alloc_pods[n]) { atomicAdd(&sh[3], 1u); any = true; }
+        if (a.p.fit_enabled && !a.p.all_zero_req) {
             for (int col = 0; col < a.p.ncol; col++) {
                 const int64_t rq = a.p.req[col];
                 if (col < 3 ? !(rq > 0) : rq == 0) continue;
@@ -594,7 +674,21 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
                 }
             }
         }
-        if (any && !unresolvable) atomicAdd(&sh[kHistSlots - 1], 1u);
+        if (any) {
+            if (!unresolvable) atomicAdd(&sh[kHistSlots - 1], 1u);
+            continue;
+        }
+        // PodTopologySpread comes after NodeResourcesFit in the filter order (first failing plugin reports)
+        for (int c = 0; c < a.pts.n; c++) {
+            const int32_t v = a.pts.label[c][n];
+            if (!v) { atomicAdd(&sh[kHistPtsMissing], 1u); break; } // UnschedulableAndUnresolvable
+            const int64_t minm = a.pts.n_present[c] < a.pts.min_domains[c] ? 0 : (int64_t)a.st->pts_min_a[c];
+            if ((int64_t)a.pts.tbl[c][v] + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) {
+                atomicAdd(&sh[kHistPtsSkew], 1u);
+                atomicAdd(&sh[kHistSlots - 1], 1u); // plain Unschedulable
+                break;
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kHistSlots - 1; i += kThreads)
@@ -602,6 +696,36 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
     if (threadIdx.x == 0 && sh[kHistSlots - 1]) atomicAdd(&a.hist_code[0], (unsigned long long)sh[kHistSlots - 1]);
     for (int i = threadIdx.x; i < kHistTsLds && i < a.n_taintsets; i += kThreads)
         if (sh_ts[i]) atomicAdd(&a.hist_ts[i], (unsigned long long)sh_ts[i]);
+}
+
+// k_pts_init: once per pod spec.  calPreFilterState (filtering.go:235-308) for the initial cluster: which nodes
+// count (all hard keys present; inclusion policies), the match count of every domain, which domains exist.
+struct PtsInitArgs {
+    int64_t n;
+    DevPts pts;
+    uint8_t *elig;                          // out
+    const int32_t *existing[kMaxTsc];       // pods already on the node matching the selector (NULL = 0)
+    const uint8_t *included[kMaxTsc];       // node inclusion policies (NULL = all)
+    int32_t *present[kMaxTsc];              // out: 1 for every value id holding >= 1 counted node
+};
+
+__global__ __launch_bounds__(kThreads) void k_pts_init(PtsInitArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= a.n) return;
+    bool all = true;
+    for (int c = 0; c < a.pts.n; c++) all = all && a.pts.label[c][n] != 0;
+    uint32_t eb = all ? 1u : 0u;
+    for (int c = 0; c < a.pts.n; c++) {
+        const bool inc = a.included[c] ? a.included[c][n] != 0 : true;
+        if (inc) eb |= 1u << (1 + c);
+        if (all && inc) {
+            const int32_t v = a.pts.label[c][n];
+            const int32_t ex = a.existing[c] ? a.existing[c][n] : 0;
+            if (ex) atomicAdd(&a.pts.tbl[c][v], ex);
+            a.present[c][v] = 1;
+        }
+    }
+    a.elig[n] = (uint8_t)eb;
 }
 
 } // namespace ccsim

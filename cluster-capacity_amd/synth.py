@@ -47,7 +47,7 @@ def zones_for(n: int) -> int:
     return 3 if n <= 10_000 else (16 if n <= 100_000 else 64)
 
 
-def make_nodes(n: int, seed: int = SEED, offset: int = 0, with_names: bool = False) -> M.NodesSoA:
+def make_nodes(n: int, seed: int = SEED, offset: int = 0, with_names: bool = False, n_total: int = 0) -> M.NodesSoA:
     """Nodes offset..offset+n-1 of the synthetic cluster (a shard is just a different offset)."""
     with np.errstate(over="ignore"):
         i = np.arange(offset, offset + n, dtype=np.int64)
@@ -70,10 +70,17 @@ def make_nodes(n: int, seed: int = SEED, offset: int = 0, with_names: bool = Fal
         alloc=[a_cpu, a_mem, a_eph], alloc_pods=np.full(n, 110, np.int32),
         req=[r_cpu, r_mem, z], nz_mcpu=r_cpu.copy(), nz_mem=r_mem.copy(), pod_count=pods,
         taintset_id=taintset, unschedulable=unsched,
-        label_cols=[(itype + 1).astype(np.int32)],  # column 0 = node.kubernetes.io/instance-type
+        # column 0 = node.kubernetes.io/instance-type, column 1 = topology.kubernetes.io/zone (zone = i mod Z)
+        label_cols=[(itype + 1).astype(np.int32), ((i % zones_for(n_total or (offset + n))) + 1).astype(np.int32)],
         names=names,
     )
     return nodes
+
+
+def zone_spread(n_nodes: int, max_skew: int = 1, min_domains: int = 1) -> M.SpreadConstraint:
+    """whenUnsatisfiable: DoNotSchedule on topology.kubernetes.io/zone, selector matching the clones themselves."""
+    return M.SpreadConstraint(col=1, max_skew=max_skew, min_domains=min_domains, hard=True, self_match=True,
+                              n_domains=zones_for(n_nodes))
 
 
 def examples_pod(tolerate_infra: bool = False, prefer_types: bool = False) -> M.PodSpec:

@@ -108,6 +108,21 @@ typedef struct {
     int32_t weight;           /* preferred terms only */
 } ccsim_term;
 
+/* One hard (whenUnsatisfiable: DoNotSchedule) topologySpreadConstraint after interning
+ * (P/podtopologyspread/common.go:42-56, filtering.go:235-356).  The engine keeps TpValueToMatchNum as a
+ * per-domain count table in HBM, updates it at every placement and evaluates the skew test in the scan.
+ * ScheduleAnyway (score-side) constraints are not supported by the HIP engine yet: -ENOSYS. */
+typedef struct {
+    int32_t col;         /* label column of the topologyKey (value id 0 = node lacks the key) */
+    int32_t max_skew;    /* >= 1 */
+    int32_t min_domains; /* >= 1 (nil -> 1) */
+    int32_t hard;        /* must be 1 */
+    int32_t self_match;  /* 1 if the pod's own labels match the constraint's selector (common.go:144-159) */
+    int32_t n_domains;   /* value ids of `col` are 1..n_domains */
+    const int32_t *node_match_count; /* [n_nodes] existing pods on the node matching the selector, NULL = 0 */
+    const uint8_t *node_included;    /* [n_nodes] node inclusion policies (common.go:107-122), NULL = all */
+} ccsim_spread_constraint;
+
 /* Pod-spec constants.  Replaces the per-cycle PreFilter/PreScore state of the plugins:
  * fit.go:224-233 (computePodResourceRequest), resource_allocation.go:118-148,
  * taint_toleration.go:111-121,146-153, node_affinity.go:147-197,241-258. */
@@ -131,6 +146,8 @@ typedef struct {
     const ccsim_requirement *reqs;
     int64_t req_tables_len;
     const uint8_t *req_tables;
+    int32_t n_spread; /* <= CCSIM_MAX_TSC */
+    ccsim_spread_constraint spread[CCSIM_MAX_TSC];
 } ccsim_pod;
 
 /* Scheduler profile: which plugins run and their weights/args.  Replaces

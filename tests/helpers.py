@@ -86,3 +86,21 @@ def random_case(rng, n):
                      w_taint=int(rng.integers(0, 4)), w_nodeaffinity=int(rng.integers(0, 3)), w_fit=int(rng.integers(0, 3)),
                      w_balanced=int(rng.integers(0, 2)))
     return nodes, pod, prof
+
+
+def random_spread(rng, nodes, n_constraints=None):
+    """Random hard topology spread constraints over the two label columns of random_case() snapshots
+    (value id 0 = key absent, which exercises the missing-label path)."""
+    n = nodes.n
+    cons = []
+    for col, ndom in ((1, 2), (0, 4)):
+        if n_constraints is not None and len(cons) >= n_constraints:
+            break
+        if rng.integers(0, 3) == 0 and n_constraints is None:
+            continue
+        cons.append(M.SpreadConstraint(
+            col=col, max_skew=int(rng.integers(1, 4)), min_domains=int(rng.integers(1, 4)), hard=True,
+            self_match=bool(rng.integers(0, 4) != 0), n_domains=ndom,
+            node_match_count=rng.integers(0, 3, n).astype(np.int32) if rng.integers(0, 2) else None,
+            node_included=(rng.random(n) < 0.9).astype(np.uint8) if rng.integers(0, 2) else None))
+    return cons

@@ -1,0 +1,113 @@
+"""PodTopologySpread hard constraints (P/podtopologyspread/filtering.go:235-356).
+CPU: hand-derived known answers pin the oracle's restatement.  GPU: the HIP filter (count tables in HBM,
+assume-and-verify global minimum) against the oracle, sequential mode."""
+import numpy as np
+import pytest
+
+import helpers as H
+from cluster_capacity_amd import capi, model as M, report as R, synth
+
+DEFAULT = M.Profile.default()
+
+
+def _zone_nodes(zone_ids, pods):
+    n = len(zone_ids)
+    return H.simple_nodes([10000] * n, [64 * H.GiB] * n, pods, label_cols=[np.array(zone_ids, np.int32)])
+
+
+def _pod(**kw):
+    p = H.simple_pod(100, 64 * H.MiB)
+    p.spread = [M.SpreadConstraint(col=0, hard=True, **kw)]
+    return p
+
+
+def test_ka_spread_max_skew_1(ccref):
+    # 3 zones x 1 node; node 0 holds 5 pods at most.  skew = count + 1 - min <= 1  =>  only minimum domains grow:
+    # 5/5/5, then zone 0 is full but still a domain (min stays 5): the others stop at 6.  17 = 5 + 6 + 6.
+    nodes = _zone_nodes([1, 2, 3], [5, 110, 110])
+    r = ccref.run(DEFAULT, nodes, _pod(max_skew=1, n_domains=3, self_match=True))
+    assert r.placed == 17 and r.per_node_count.tolist() == [5, 6, 6]
+    assert R.stop_reason(r, 3, 0).startswith(
+        "Unschedulable: 0/3 nodes are available: 1 Too many pods, 2 node(s) didn't match pod topology spread constraints.")
+
+
+def test_ka_spread_min_domains(ccref):
+    # 2 domains < minDomains 3  =>  the global minimum counts as 0 (filtering.go:56-69): each zone holds maxSkew = 2 pods
+    nodes = _zone_nodes([1, 2], [110, 110])
+    r = ccref.run(DEFAULT, nodes, _pod(max_skew=2, min_domains=3, n_domains=2, self_match=True))
+    assert r.placed == 4 and r.per_node_count.tolist() == [2, 2]
+
+
+def test_ka_spread_missing_label_and_no_self_match(ccref):
+    # node 2 lacks the topology key: never feasible (UnschedulableAndUnresolvable).  Without self-match the counts
+    # never move, so the constraint never binds and capacity (pods) is the limit.
+    nodes = _zone_nodes([1, 2, 0], [3, 4, 50])
+    r = ccref.run(DEFAULT, nodes, _pod(max_skew=1, n_domains=2, self_match=False))
+    assert r.placed == 7 and r.per_node_count.tolist() == [3, 4, 0]
+    msg = R.stop_reason(r, 3, 0)
+    assert "1 node(s) didn't match pod topology spread constraints (missing required label)" in msg and "2 Too many pods" in msg
+
+
+def test_ka_spread_existing_pods_count(ccref):
+    # zone 1 already runs 2 matching pods, zone 2 none: zone 2 must catch up first (2 pods), then they alternate
+    nodes = _zone_nodes([1, 2], [110, 110])
+    pod = _pod(max_skew=1, n_domains=2, self_match=True)
+    pod.spread[0].node_match_count = np.array([2, 0], np.int32)
+    r = ccref.run(DEFAULT, nodes, pod, max_limit=6)
+    assert r.log.tolist()[:2] == [1, 1] and sorted(r.log.tolist()[2:4]) == [0, 1] and r.per_node_count.tolist() == [2, 4]
+
+
+def _gpu_check(ccref, nodes, pod, prof, limit):
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    got = e.run(max_limit=limit, mode="sequential", log_cap=max(1, ref.placed))
+    assert got.placed == ref.placed and got.stop == ref.stop
+    assert np.array_equal(got.per_node_count, ref.per_node_count)
+    assert np.array_equal(got.log, ref.log)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist)
+        assert got.n_code_unschedulable == ref.n_code_unschedulable
+        assert R.stop_reason(got, nodes.n, 0) == R.stop_reason(ref, nodes.n, 0)
+    return e, got
+
+
+@pytest.mark.gpu
+def test_gpu_spread_known_answers(ccref):
+    _gpu_check(ccref, _zone_nodes([1, 2, 3], [5, 110, 110]), _pod(max_skew=1, n_domains=3, self_match=True), DEFAULT, 0)
+    _gpu_check(ccref, _zone_nodes([1, 2], [110, 110]), _pod(max_skew=2, min_domains=3, n_domains=2, self_match=True), DEFAULT, 0)
+    _gpu_check(ccref, _zone_nodes([1, 2, 0], [3, 4, 50]), _pod(max_skew=1, n_domains=2, self_match=False), DEFAULT, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,skew,limit", [(600, 1, 0), (2000, 2, 900), (3000, 5, 1500)])
+def test_gpu_spread_synthetic_zones(ccref, n, skew, limit):
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=21 + n)
+    pod.spread = [synth.zone_spread(n, max_skew=skew)]
+    e, got = _gpu_check(ccref, nodes, pod, prof, limit)
+    # the invariant the constraint enforces, on the final placement: zone counts within maxSkew of each other
+    # while every zone still had a feasible node (checked on the prefix where no zone was exhausted: the first Z*k pods)
+    zc = np.bincount(nodes.label_cols[1][got.log[: 3 * 10]], minlength=4)[1:]
+    assert zc.max() - zc.min() <= skew
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_gpu_spread_random(ccref, seed):
+    rng = np.random.default_rng(500 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 1200)))
+    pod.spread = H.random_spread(rng, nodes, n_constraints=int(rng.integers(1, 3)))
+    _gpu_check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 60])))
+
+
+@pytest.mark.gpu
+def test_gpu_spread_rejects_batched_and_soft():
+    nodes, pod, prof = synth.make_config("C3", n_nodes=300, seed=3)
+    pod.spread = [synth.zone_spread(300)]
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    with pytest.raises(capi.CcsimError):
+        e.run(mode="batched")
+    pod.spread[0].hard = False
+    with pytest.raises(capi.CcsimError):
+        capi.Engine(device=0).load(nodes, pod, prof)
