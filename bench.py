@@ -155,10 +155,20 @@ def main():
         pe = capi.Engine(device=local_rank, time_passes=True)
         pe.load(nodes, pod, prof)
         prun = pe.run(max_limit=limit, mode=args.mode, want_log=False)
-        launches = prun.scans
+        launches = prun.pass_launches  # every launch, as rocprofv3 counts them (incl. the few early-exit ones at the end)
         scan_s = prun.pass_kernel_ns / max(1, launches) / 1e9
         bytes_per_scan = prun.bytes_per_scan
     achieved = bytes_per_scan / scan_s / 1e9
+    kernel = "k_level" if args.mode == "batched" else "k_scan"
+    # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this same command
+    # (scripts_gpu_pmc.sh -> profiles/r01/pmc_traffic.json); bench.py cannot profile itself.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        if n_global == 1_000_000 and world == 1:
+            traffic = pmc["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "simulated pod placements/sec at 1M nodes",
         "value": placed / dt,
@@ -188,8 +198,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
-            "kernel": "k_level" if args.mode == "batched" else "k_scan",
+            "traffic": traffic,
+            "kernel": kernel,
             "bytes_per_launch": bytes_per_scan,
             "us_per_launch": scan_s * 1e6,
             "launches_timed": launches,

@@ -78,7 +78,7 @@ class CReport(C.Structure):
         ("log", _p32), ("log_cap", C.c_int64), ("log_len", C.c_int64), ("hist", C.c_int64 * NREASON),
         ("hist_taintset", _p64), ("hist_taintset_cap", C.c_int32), ("n_code_unschedulable", C.c_int64),
         ("rounds", C.c_int64), ("scans", C.c_int64), ("evaluated_total", C.c_int64), ("last_feasible", C.c_int32),
-        ("kernel_ns", C.c_int64), ("pass_kernel_ns", C.c_int64), ("bytes_per_scan", C.c_int64),
+        ("kernel_ns", C.c_int64), ("pass_kernel_ns", C.c_int64), ("pass_launches", C.c_int64), ("bytes_per_scan", C.c_int64),
     ]
 
 
@@ -318,7 +318,7 @@ class Engine:
             hist=np.array(list(rep.hist), dtype=np.int64), hist_taintset=ht.copy(),
             n_code_unschedulable=int(rep.n_code_unschedulable), rounds=int(rep.rounds),
             evaluated_total=int(rep.evaluated_total), last_feasible=int(rep.last_feasible), scans=int(rep.scans),
-            kernel_ns=int(rep.kernel_ns), pass_kernel_ns=int(rep.pass_kernel_ns), bytes_per_scan=int(rep.bytes_per_scan),
+            kernel_ns=int(rep.kernel_ns), pass_kernel_ns=int(rep.pass_kernel_ns), pass_launches=int(rep.pass_launches), bytes_per_scan=int(rep.bytes_per_scan),
         )
 
     def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None) -> M.RunResult:

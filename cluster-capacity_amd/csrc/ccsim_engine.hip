@@ -32,6 +32,7 @@ struct ccsim_engine {
     std::vector<hipEvent_t> pass_events; // time_passes: one (start, stop) pair per full-pass launch of a batch
     int pass_events_used = 0;
     double pass_kernel_ms = 0;
+    int64_t pass_launches = 0;
     std::string err;
 
     // snapshot
@@ -582,6 +583,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
         HIPCHK(e, hipMemsetAsync(e->d_log, 0xff, sizeof(int32_t) * (size_t)e->log_cap, e->stream));
     e->kernel_ms = 0;
     e->pass_kernel_ms = 0;
+    e->pass_launches = 0;
     e->pass_events_used = 0;
     e->limit = max_limit;
     e->mode = mode;
@@ -619,7 +621,7 @@ static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block redu
 static void collect_pass_times(ccsim_engine *e) { // after a stream sync
     for (int i = 0; i + 1 < e->pass_events_used; i += 2) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e->pass_events[i], e->pass_events[i + 1]) == hipSuccess) e->pass_kernel_ms += ms;
+        if (hipEventElapsedTime(&ms, e->pass_events[i], e->pass_events[i + 1]) == hipSuccess) e->pass_kernel_ms += ms, e->pass_launches++;
     }
     e->pass_events_used = 0;
 }
@@ -653,6 +655,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     out->last_feasible = st.last_feasible;
     out->kernel_ns = (int64_t)(e->kernel_ms * 1e6);
     out->pass_kernel_ns = (int64_t)(e->pass_kernel_ms * 1e6);
+    out->pass_launches = e->pass_launches;
     // algorithmic bytes per scan: the columns the active plugin set must read once per node
     int64_t per_node = 4 /*static word*/ + 6 * 8 /*alloc,req,nz x cpu,mem*/ + 2 * 4 /*pods*/ + (int64_t)e->pod.nx * 16 +
                        (e->pts.n ? 1 + 4 * (int64_t)e->pts.n : 0) /*eligibility byte + topology value id per constraint*/;

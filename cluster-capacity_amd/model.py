@@ -209,4 +209,5 @@ class RunResult:
     scans: int = 0
     kernel_ns: int = 0
     pass_kernel_ns: int = 0
+    pass_launches: int = 0
     bytes_per_scan: int = 0

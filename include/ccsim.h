@@ -184,7 +184,8 @@ typedef struct {
     int64_t evaluated_total; /* (pod, node) evaluations the reference semantics imply = rounds * n */
     int32_t last_feasible;   /* FeasibleNodes of the last cycle */
     int64_t kernel_ns;       /* GPU time of all launches of the run (HIP events on the engine's stream) */
-    int64_t pass_kernel_ns;  /* cfg.time_passes: summed duration of the `scans` full-pass kernel launches alone */
+    int64_t pass_kernel_ns;  /* cfg.time_passes: summed duration of the full-pass kernel launches alone ... */
+    int64_t pass_launches;   /* ... and how many were launched (incl. early-exit launches after the done flag) */
     int64_t bytes_per_scan;  /* algorithmic bytes one scan reads: n_nodes * sum of enabled column widths */
 } ccsim_report;
 
