@@ -51,6 +51,17 @@ class CSpread(C.Structure):
                 ("self_match", C.c_int32), ("n_domains", C.c_int32), ("node_match_count", _p32), ("node_included", _pu8)]
 
 
+class CIpa(C.Structure):
+    _fields_ = [
+        ("n_keys", C.c_int32), ("key_col", C.c_int32 * M.MAX_IPA_KEYS), ("key_ndom", C.c_int32 * M.MAX_IPA_KEYS),
+        ("n_aff_terms", C.c_int32), ("aff_key", C.c_int32 * M.MAX_IPA_TERMS), ("self_aff", C.c_int32), ("aff_existing", _p32),
+        ("n_anti_terms", C.c_int32), ("anti_key", C.c_int32 * M.MAX_IPA_TERMS), ("anti_self", C.c_int32 * M.MAX_IPA_TERMS),
+        ("anti_existing", _p32 * M.MAX_IPA_TERMS), ("exist_anti", _p32 * M.MAX_IPA_KEYS),
+        ("score_existing", _p64 * M.MAX_IPA_KEYS), ("score_self", C.c_int64 * M.MAX_IPA_KEYS), ("entries_existing", C.c_int64),
+        ("self_entries", C.c_int32 * M.MAX_IPA_KEYS),
+    ]
+
+
 class CPod(C.Structure):
     _fields_ = [
         ("req", C.c_int64 * MAX_RES), ("has_scalar_entries", C.c_int32), ("nz_mcpu", C.c_int64), ("nz_mem", C.c_int64),
@@ -59,14 +70,14 @@ class CPod(C.Structure):
         ("node_selector", CTerm), ("has_required_terms", C.c_int32), ("n_required", C.c_int32),
         ("required", C.POINTER(CTerm)), ("n_preferred", C.c_int32), ("preferred", C.POINTER(CTerm)),
         ("n_reqs", C.c_int32), ("reqs", C.POINTER(CReq)), ("req_tables_len", C.c_int64), ("req_tables", _pu8),
-        ("n_spread", C.c_int32), ("spread", CSpread * M.MAX_TSC),
+        ("n_spread", C.c_int32), ("spread", CSpread * M.MAX_TSC), ("has_ipa", C.c_int32), ("ipa", CIpa),
     ]
 
 
 class CProfile(C.Structure):
     _fields_ = [
         ("filter_mask", C.c_uint32), ("w_taint", C.c_int32), ("w_nodeaffinity", C.c_int32), ("w_fit", C.c_int32),
-        ("w_balanced", C.c_int32), ("w_topologyspread", C.c_int32), ("n_fit_res", C.c_int32),
+        ("w_balanced", C.c_int32), ("w_topologyspread", C.c_int32), ("w_interpodaffinity", C.c_int32), ("n_fit_res", C.c_int32),
         ("fit_res", C.c_int32 * MAX_RES), ("fit_res_w", C.c_int64 * MAX_RES), ("n_bal_res", C.c_int32),
         ("bal_res", C.c_int32 * MAX_RES), ("percentage_of_nodes_to_score", C.c_int32),
     ]
@@ -232,7 +243,44 @@ def marshal_pod(pod: M.PodSpec, keep: list) -> CPod:
             a = np.ascontiguousarray(k.node_included, dtype=np.uint8)
             keep.append(a)
             c.node_included = _ptr(a, _pu8)
+    ipa = getattr(pod, "ipa", None)
+    s.has_ipa = int(ipa is not None)
+    if ipa is not None:
+        _fill_ipa(s.ipa, ipa, keep)
     return s
+
+
+def _fill_ipa(c, ipa: M.InterPodAffinity, keep: list):
+    def arr(a, dt, t):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return _ptr(a, t)
+
+    if len(ipa.key_cols) > M.MAX_IPA_KEYS or max(len(ipa.aff_keys), len(ipa.anti_keys)) > M.MAX_IPA_TERMS:
+        raise CcsimError("too many inter-pod affinity keys / terms")
+    c.n_keys = len(ipa.key_cols)
+    for k, (col, nd) in enumerate(zip(ipa.key_cols, ipa.key_ndom)):
+        c.key_col[k], c.key_ndom[k] = int(col), int(nd)
+    c.n_aff_terms = len(ipa.aff_keys)
+    for t, k in enumerate(ipa.aff_keys):
+        c.aff_key[t] = int(k)
+    c.self_aff = int(bool(ipa.self_aff))
+    if ipa.aff_existing is not None:
+        c.aff_existing = arr(ipa.aff_existing, np.int32, _p32)
+    c.n_anti_terms = len(ipa.anti_keys)
+    for t, k in enumerate(ipa.anti_keys):
+        c.anti_key[t] = int(k)
+        c.anti_self[t] = int(bool(ipa.anti_self[t]))
+        if ipa.anti_existing and ipa.anti_existing[t] is not None:
+            c.anti_existing[t] = arr(ipa.anti_existing[t], np.int32, _p32)
+    for k in range(c.n_keys):
+        if ipa.exist_anti and ipa.exist_anti[k] is not None:
+            c.exist_anti[k] = arr(ipa.exist_anti[k], np.int32, _p32)
+        if ipa.score_existing and ipa.score_existing[k] is not None:
+            c.score_existing[k] = arr(ipa.score_existing[k], np.int64, _p64)
+        c.score_self[k] = int(ipa.score_self[k]) if ipa.score_self else 0
+        c.self_entries[k] = int(ipa.self_entries[k]) if ipa.self_entries else 0
+    c.entries_existing = int(ipa.entries_existing)
 
 
 def marshal_profile(p: M.Profile) -> CProfile:
@@ -240,6 +288,7 @@ def marshal_profile(p: M.Profile) -> CProfile:
     s.filter_mask = int(p.filter_mask)
     s.w_taint, s.w_nodeaffinity, s.w_fit = int(p.w_taint), int(p.w_nodeaffinity), int(p.w_fit)
     s.w_balanced, s.w_topologyspread = int(p.w_balanced), int(p.w_topologyspread)
+    s.w_interpodaffinity = int(p.w_interpodaffinity)
     s.n_fit_res = len(p.fit_res)
     for i, (c, w) in enumerate(zip(p.fit_res, p.fit_res_w)):
         s.fit_res[i], s.fit_res_w[i] = int(c), int(w)

@@ -10,6 +10,7 @@
 #include "ccsim_level.h"
 
 #include <errno.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -300,7 +301,7 @@ extern "C" int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
         return fail(e, -ENOSYS, "this engine scores every node: percentageOfNodesToScore must be 100");
     if (p->filter_mask & CCSIM_F_TOPOLOGYSPREAD || p->w_topologyspread)
         ; // accepted: PodTopologySpread is a no-op (PreFilter/PreScore Skip) for pods without constraints
-    if (!p->w_taint && !p->w_nodeaffinity && !p->w_fit && !p->w_balanced && !p->w_topologyspread)
+    if (!p->w_taint && !p->w_nodeaffinity && !p->w_fit && !p->w_balanced && !p->w_topologyspread && !p->w_interpodaffinity)
         return fail(e, -ENOSYS, "profiles without any Score plugin (numFeasibleNodesToFind = 1 with start-index rotation, "
                                 "schedule_one.go:619-621) are not supported");
     if (p->n_fit_res < 0 || p->n_fit_res > CCSIM_MAX_RES || p->n_bal_res < 0 || p->n_bal_res > CCSIM_MAX_RES)
@@ -479,21 +480,29 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// t0/t1 (measurement runs only): hipExtLaunchKernelGGL stamps the events at the start and end of THIS dispatch,
+// i.e. the kernel's own duration -- what rocprofv3 --kernel-trace reports.
+#define CCSIM_LAUNCH(kern, g, b, stream, t0, t1, arg)                                   \
+    do {                                                                                \
+        if (t0) hipExtLaunchKernelGGL(kern, g, b, 0, stream, t0, t1, 0, arg);           \
+        else hipLaunchKernelGGL(kern, g, b, 0, stream, arg);                            \
+    } while (0)
+
 template <bool PTS>
-static void launch_scan_t(ccsim_engine *e, const ScanArgs &a) {
+static void launch_scan_t(ccsim_engine *e, const ScanArgs &a, hipEvent_t t0, hipEvent_t t1) {
     const int nx = e->pod.nx;
     dim3 g(e->grid), b(kThreads);
-    if (nx == 0) hipLaunchKernelGGL((k_scan<0, PTS>), g, b, 0, e->stream, a);
-    else if (nx == 1) hipLaunchKernelGGL((k_scan<1, PTS>), g, b, 0, e->stream, a);
-    else if (nx == 2) hipLaunchKernelGGL((k_scan<2, PTS>), g, b, 0, e->stream, a);
-    else if (nx <= 4) hipLaunchKernelGGL((k_scan<4, PTS>), g, b, 0, e->stream, a);
-    else hipLaunchKernelGGL((k_scan<kMaxExtra, PTS>), g, b, 0, e->stream, a);
+    if (nx == 0) CCSIM_LAUNCH((k_scan<0, PTS>), g, b, e->stream, t0, t1, a);
+    else if (nx == 1) CCSIM_LAUNCH((k_scan<1, PTS>), g, b, e->stream, t0, t1, a);
+    else if (nx == 2) CCSIM_LAUNCH((k_scan<2, PTS>), g, b, e->stream, t0, t1, a);
+    else if (nx <= 4) CCSIM_LAUNCH((k_scan<4, PTS>), g, b, e->stream, t0, t1, a);
+    else CCSIM_LAUNCH((k_scan<kMaxExtra, PTS>), g, b, e->stream, t0, t1, a);
 }
 
-static int launch_scan(ccsim_engine *e) {
+static int launch_scan(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk, e->pts, e->d_pts_min_partials};
-    if (e->pts.n > 0) launch_scan_t<true>(e, a);
-    else launch_scan_t<false>(e, a);
+    if (e->pts.n > 0) launch_scan_t<true>(e, a, t0, t1);
+    else launch_scan_t<false>(e, a, t0, t1);
     return 0;
 }
 
@@ -518,15 +527,15 @@ static int launch_final(ccsim_engine *e) {
     return 0;
 }
 
-static int launch_level(ccsim_engine *e) {
+static int launch_level(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     LevelArgs a{e->cols, e->pod, e->d_state, e->d_lpartials, e->d_blockprefix, e->d_log, e->lvl_chunk};
     const int nx = e->pod.nx;
     dim3 g(e->lvl_grid), b(kThreads);
-    if (nx == 0) hipLaunchKernelGGL(k_level<0>, g, b, 0, e->stream, a);
-    else if (nx == 1) hipLaunchKernelGGL(k_level<1>, g, b, 0, e->stream, a);
-    else if (nx == 2) hipLaunchKernelGGL(k_level<2>, g, b, 0, e->stream, a);
-    else if (nx <= 4) hipLaunchKernelGGL(k_level<4>, g, b, 0, e->stream, a);
-    else hipLaunchKernelGGL(k_level<kMaxExtra>, g, b, 0, e->stream, a);
+    if (nx == 0) CCSIM_LAUNCH(k_level<0>, g, b, e->stream, t0, t1, a);
+    else if (nx == 1) CCSIM_LAUNCH(k_level<1>, g, b, e->stream, t0, t1, a);
+    else if (nx == 2) CCSIM_LAUNCH(k_level<2>, g, b, e->stream, t0, t1, a);
+    else if (nx <= 4) CCSIM_LAUNCH(k_level<4>, g, b, e->stream, t0, t1, a);
+    else CCSIM_LAUNCH(k_level<kMaxExtra>, g, b, e->stream, t0, t1, a);
     return 0;
 }
 
@@ -610,10 +619,8 @@ static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block redu
             t1 = e->pass_events[e->pass_events_used++];
         }
     }
-    if (t0) (void)hipEventRecord(t0, e->stream);
-    if (e->mode == CCSIM_MODE_BATCHED) launch_level(e);
-    else launch_scan(e);
-    if (t1) (void)hipEventRecord(t1, e->stream);
+    if (e->mode == CCSIM_MODE_BATCHED) launch_level(e, t0, t1);
+    else launch_scan(e, t0, t1);
     if (e->mode == CCSIM_MODE_BATCHED) launch_level_final(e);
     else launch_final(e);
 }

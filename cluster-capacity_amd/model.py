@@ -15,6 +15,8 @@ import numpy as np
 MAX_SCALAR = 8
 MAX_RES = 3 + MAX_SCALAR
 MAX_TSC = 8
+MAX_IPA_KEYS = 4
+MAX_IPA_TERMS = 8
 
 # filter plugin bits, default order (apis/config/v1/default_plugins.go:30-58)
 F_UNSCHEDULABLE = 1 << 0
@@ -23,7 +25,8 @@ F_TAINT = 1 << 2
 F_NODEAFFINITY = 1 << 3
 F_FIT = 1 << 4
 F_TOPOLOGYSPREAD = 1 << 5
-F_ALL = F_UNSCHEDULABLE | F_NODENAME | F_TAINT | F_NODEAFFINITY | F_FIT | F_TOPOLOGYSPREAD
+F_INTERPODAFFINITY = 1 << 6
+F_ALL = F_UNSCHEDULABLE | F_NODENAME | F_TAINT | F_NODEAFFINITY | F_FIT | F_TOPOLOGYSPREAD | F_INTERPODAFFINITY
 
 # reason slots of the terminal histogram
 R_UNSCHEDULABLE = 0
@@ -33,7 +36,10 @@ R_TOO_MANY_PODS = 3
 R_RES0 = 4
 R_PTS_MISSING_LABEL = R_RES0 + MAX_RES
 R_PTS_SKEW = R_PTS_MISSING_LABEL + 1
-NREASON = R_PTS_SKEW + 1
+R_IPA_AFFINITY = R_PTS_SKEW + 1
+R_IPA_ANTI = R_IPA_AFFINITY + 1
+R_IPA_EXISTING_ANTI = R_IPA_ANTI + 1
+NREASON = R_IPA_EXISTING_ANTI + 1
 
 STOP_UNSCHEDULABLE = 0
 STOP_LIMIT = 1
@@ -143,6 +149,28 @@ class SpreadConstraint:
 
 
 @dataclass
+class InterPodAffinity:
+    """InterPodAffinity after interning (interpodaffinity/filtering.go:204-432, scoring.go:81-290).  The
+    reference keys its maps by topology pair, so everything is per distinct topology KEY; `*_existing` are
+    per-node counts over the snapshot's pods (selectors/namespaces evaluated by the caller), `self`/`*_self`
+    describe what one simulated clone (identical to the incoming pod) adds."""
+
+    key_cols: List[int]
+    key_ndom: List[int]
+    aff_keys: List[int] = field(default_factory=list)  # required affinity terms -> key index
+    self_aff: bool = False  # the pod matches all of its own affinity terms
+    aff_existing: Optional[np.ndarray] = None  # int32[n] existing pods matching ALL affinity terms
+    anti_keys: List[int] = field(default_factory=list)  # required anti-affinity terms -> key index
+    anti_self: List[bool] = field(default_factory=list)
+    anti_existing: List[Optional[np.ndarray]] = field(default_factory=list)  # per term int32[n]
+    exist_anti: List[Optional[np.ndarray]] = field(default_factory=list)  # per key int32[n]
+    score_existing: List[Optional[np.ndarray]] = field(default_factory=list)  # per key int64[n]
+    score_self: List[int] = field(default_factory=list)  # per key
+    entries_existing: int = 0
+    self_entries: List[int] = field(default_factory=list)  # per key
+
+
+@dataclass
 class PodSpec:
     """Pod-side constants precomputed on the host."""
 
@@ -160,6 +188,7 @@ class PodSpec:
     required: List[List[Requirement]] = field(default_factory=list)
     preferred: List[Tuple[int, List[Requirement]]] = field(default_factory=list)  # (weight, term)
     spread: List[SpreadConstraint] = field(default_factory=list)
+    ipa: Optional[InterPodAffinity] = None
 
     def __post_init__(self):
         self.req = _i64(self.req)
@@ -178,6 +207,7 @@ class Profile:
     w_fit: int = 1
     w_balanced: int = 1
     w_topologyspread: int = 2
+    w_interpodaffinity: int = 2
     fit_res: Tuple[int, ...] = (0, 1)
     fit_res_w: Tuple[int, ...] = (1, 1)
     bal_res: Tuple[int, ...] = (0, 1)
@@ -190,7 +220,8 @@ class Profile:
     @staticmethod
     def fit_only() -> "Profile":
         """BASELINE config 2: NodeResourcesFit Filter + LeastAllocated Score only."""
-        return Profile(filter_mask=F_FIT, w_taint=0, w_nodeaffinity=0, w_fit=1, w_balanced=0, w_topologyspread=0)
+        return Profile(filter_mask=F_FIT, w_taint=0, w_nodeaffinity=0, w_fit=1, w_balanced=0, w_topologyspread=0,
+                       w_interpodaffinity=0)
 
 
 @dataclass

@@ -25,6 +25,10 @@ REASON_TEXT = {
     M.R_TOO_MANY_PODS: "Too many pods",
     M.R_PTS_MISSING_LABEL: "node(s) didn't match pod topology spread constraints (missing required label)",
     M.R_PTS_SKEW: "node(s) didn't match pod topology spread constraints",
+    # interpodaffinity/filtering.go:37-45
+    M.R_IPA_AFFINITY: "node(s) didn't match pod affinity rules",
+    M.R_IPA_ANTI: "node(s) didn't match pod anti-affinity rules",
+    M.R_IPA_EXISTING_ANTI: "node(s) didn't satisfy existing pods anti-affinity rules",
 }
 
 

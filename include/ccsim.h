@@ -34,6 +34,8 @@ extern "C" {
 #define CCSIM_MAX_RES (3 + CCSIM_MAX_SCALAR)
 #define CCSIM_MAX_LABEL_COLS 32
 #define CCSIM_MAX_TSC 8
+#define CCSIM_MAX_IPA_KEYS 4
+#define CCSIM_MAX_IPA_TERMS 8
 
 /* filter plugins, default profile order (S/apis/config/v1/default_plugins.go:30-58) */
 enum {
@@ -42,7 +44,8 @@ enum {
     CCSIM_F_TAINT = 1u << 2,
     CCSIM_F_NODEAFFINITY = 1u << 3,
     CCSIM_F_FIT = 1u << 4,
-    CCSIM_F_TOPOLOGYSPREAD = 1u << 5
+    CCSIM_F_TOPOLOGYSPREAD = 1u << 5,
+    CCSIM_F_INTERPODAFFINITY = 1u << 6
 };
 
 /* reason slots of the terminal-round histogram (FitError.Error, S/framework/types.go:787-836) */
@@ -54,6 +57,9 @@ enum {
     CCSIM_R_RES0 = 4, /* + column */
     CCSIM_R_PTS_MISSING_LABEL = CCSIM_R_RES0 + CCSIM_MAX_RES,
     CCSIM_R_PTS_SKEW,
+    CCSIM_R_IPA_AFFINITY,      /* "node(s) didn't match pod affinity rules" */
+    CCSIM_R_IPA_ANTI,          /* "node(s) didn't match pod anti-affinity rules" */
+    CCSIM_R_IPA_EXISTING_ANTI, /* "node(s) didn't satisfy existing pods anti-affinity rules" */
     CCSIM_NREASON
 };
 
@@ -123,6 +129,31 @@ typedef struct {
     const uint8_t *node_included;    /* [n_nodes] node inclusion policies (common.go:107-122), NULL = all */
 } ccsim_spread_constraint;
 
+/* InterPodAffinity in the integer world (P/interpodaffinity/{filtering.go:204-432, scoring.go:81-290}).  The
+ * reference keys its count / score maps by topology PAIR (key, value): terms sharing a topology key share
+ * entries, so everything is per distinct KEY.  The caller evaluates selectors / namespaces of the snapshot's pods
+ * once (strings) and hands over per-node counts; simulated clones are identical to the incoming pod, so what one
+ * clone adds is a per-pod constant (the "self" fields).  The engine keeps one table per key per map in HBM. */
+typedef struct {
+    int32_t n_keys;
+    int32_t key_col[CCSIM_MAX_IPA_KEYS];  /* label column of the topology key */
+    int32_t key_ndom[CCSIM_MAX_IPA_KEYS]; /* value ids 1..n */
+    int32_t n_aff_terms;                  /* REQUIRED affinity terms (an existing pod counts iff it matches ALL) */
+    int32_t aff_key[CCSIM_MAX_IPA_TERMS]; /* index into key_col */
+    int32_t self_aff;                     /* podMatchesAllAffinityTerms(own terms, own pod) */
+    const int32_t *aff_existing;          /* [n_nodes] existing pods matching all terms, NULL = 0 */
+    int32_t n_anti_terms;                 /* REQUIRED anti-affinity terms (counted per term) */
+    int32_t anti_key[CCSIM_MAX_IPA_TERMS];
+    int32_t anti_self[CCSIM_MAX_IPA_TERMS];
+    const int32_t *anti_existing[CCSIM_MAX_IPA_TERMS]; /* [n_nodes] existing pods matching term t, NULL = 0 */
+    const int32_t *exist_anti[CCSIM_MAX_IPA_KEYS];     /* [n_nodes] (existing pod, anti term) pairs with that key
+                                                          matching the incoming pod, NULL = 0 */
+    const int64_t *score_existing[CCSIM_MAX_IPA_KEYS]; /* [n_nodes] net weight put on the node's pair, NULL = 0 */
+    int64_t score_self[CCSIM_MAX_IPA_KEYS];            /* net weight one clone adds (both directions) */
+    int64_t entries_existing;                          /* processTerm hits among existing pods (0 hits -> Skip) */
+    int32_t self_entries[CCSIM_MAX_IPA_KEYS];          /* hits one clone adds on a node that has the key */
+} ccsim_ipa;
+
 /* Pod-spec constants.  Replaces the per-cycle PreFilter/PreScore state of the plugins:
  * fit.go:224-233 (computePodResourceRequest), resource_allocation.go:118-148,
  * taint_toleration.go:111-121,146-153, node_affinity.go:147-197,241-258. */
@@ -148,6 +179,8 @@ typedef struct {
     const uint8_t *req_tables;
     int32_t n_spread; /* <= CCSIM_MAX_TSC */
     ccsim_spread_constraint spread[CCSIM_MAX_TSC];
+    int32_t has_ipa; /* 0 = no inter-pod (anti)affinity anywhere (PreFilter / PreScore Skip) */
+    ccsim_ipa ipa;
 } ccsim_pod;
 
 /* Scheduler profile: which plugins run and their weights/args.  Replaces
@@ -156,6 +189,7 @@ typedef struct {
 typedef struct {
     uint32_t filter_mask;
     int32_t w_taint, w_nodeaffinity, w_fit, w_balanced, w_topologyspread; /* 0 = score plugin disabled */
+    int32_t w_interpodaffinity;
     int32_t n_fit_res;
     int32_t fit_res[CCSIM_MAX_RES];
     int64_t fit_res_w[CCSIM_MAX_RES];

@@ -121,7 +121,7 @@ int32_t ccref_num_feasible_nodes_to_find(int32_t percentage, int32_t num_all_nod
 }
 
 static int has_scoring(const ccref_profile *p) {
-    return p->w_taint || p->w_nodeaffinity || p->w_fit || p->w_balanced || p->w_topologyspread;
+    return p->w_taint || p->w_nodeaffinity || p->w_fit || p->w_balanced || p->w_topologyspread || p->w_interpodaffinity;
 }
 
 /* component-helpers nodeaffinity.go term.match: AND over requirements; empty term matches nothing */
@@ -224,6 +224,89 @@ static int pts_filter(const ccref_nodes *nd, const ccref_pod *pod, const pts_sta
 }
 
 /* ------------------------------------------------------------------------------------------
+ * InterPodAffinity PreFilter / PreScore state (P/interpodaffinity/filtering.go:204-309, scoring.go:128-221),
+ * rebuilt every cycle like the reference does.  Count/score maps are keyed by topology pair, i.e. per KEY.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t *aff[CCREF_MAX_IPA_KEYS], *anti[CCREF_MAX_IPA_KEYS], *exist[CCREF_MAX_IPA_KEYS], *score[CCREF_MAX_IPA_KEYS];
+    int64_t aff_total;   /* entries of affinityCounts (len == 0 enables the first-pod exception, filtering.go:396-405) */
+    int64_t exist_total; /* entries of existingAntiAffinityCounts */
+    int64_t entries;     /* processTerm hits of PreScore (0 -> Skip, scoring.go:199-201) */
+    int filter_active;   /* PreFilter did not return Skip (filtering.go:299-301) */
+} ipa_state;
+
+static void ipa_build(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, ipa_state *s) {
+    const ccref_ipa *a = &pod->ipa;
+    for (int k = 0; k < a->n_keys; k++) {
+        size_t len = sizeof(int64_t) * (size_t)(a->key_ndom[k] + 1);
+        memset(s->aff[k], 0, len);
+        memset(s->anti[k], 0, len);
+        memset(s->exist[k], 0, len);
+        memset(s->score[k], 0, len);
+    }
+    s->aff_total = s->exist_total = 0;
+    s->entries = a->entries_existing;
+    for (int64_t n = 0; n < nd->n; n++) {
+        const int64_t clones = placed[n]; /* every simulated clone is an existing pod of the next cycle */
+        /* incoming affinity terms: a pod counts only if it matches ALL terms, once per term (filtering.go:165-173) */
+        int64_t am = (a->aff_existing ? a->aff_existing[n] : 0) + (a->self_aff ? clones : 0);
+        if (a->n_aff_terms && am)
+            for (int t = 0; t < a->n_aff_terms; t++) {
+                int k = a->aff_key[t];
+                int32_t v = nd->label_cols[a->key_col[k]][n];
+                if (v) s->aff[k][v] += am, s->aff_total += am;
+            }
+        /* incoming anti-affinity terms, per term (filtering.go:177-184) */
+        for (int t = 0; t < a->n_anti_terms; t++) {
+            int64_t m = (a->anti_existing[t] ? a->anti_existing[t][n] : 0) + (a->anti_self[t] ? clones : 0);
+            int k = a->anti_key[t];
+            int32_t v = nd->label_cols[a->key_col[k]][n];
+            if (m && v) s->anti[k][v] += m;
+        }
+        /* existing pods' anti-affinity terms matching the incoming pod (filtering.go:204-232); a clone carries the
+           incoming pod's own terms */
+        for (int k = 0; k < a->n_keys; k++) {
+            int64_t m = a->exist_anti[k] ? a->exist_anti[k][n] : 0;
+            for (int t = 0; t < a->n_anti_terms; t++)
+                if (a->anti_key[t] == k && a->anti_self[t]) m += clones;
+            int32_t v = nd->label_cols[a->key_col[k]][n];
+            if (m && v) s->exist[k][v] += m, s->exist_total += m;
+            /* score map (scoring.go:81-125) */
+            int64_t w = (a->score_existing[k] ? a->score_existing[k][n] : 0) + clones * a->score_self[k];
+            if (v) {
+                s->score[k][v] += w;
+                s->entries += clones * a->self_entries[k];
+            }
+        }
+    }
+    s->filter_active = !(s->exist_total == 0 && a->n_aff_terms == 0 && a->n_anti_terms == 0);
+}
+
+/* filtering.go:352-432; returns 0 ok, 1 affinity (Unresolvable), 2 anti-affinity, 3 existing pods' anti-affinity */
+static int ipa_filter(const ccref_nodes *nd, const ccref_pod *pod, const ipa_state *s, int64_t n) {
+    const ccref_ipa *a = &pod->ipa;
+    int pods_exist = 1;
+    for (int t = 0; t < a->n_aff_terms; t++) { /* satisfyPodAffinity :382-408 */
+        int k = a->aff_key[t];
+        int32_t v = nd->label_cols[a->key_col[k]][n];
+        if (!v) return 1; /* all topology labels must exist on the node */
+        if (s->aff[k][v] <= 0) pods_exist = 0;
+    }
+    if (!pods_exist && !(s->aff_total == 0 && a->self_aff)) return 1;
+    for (int t = 0; t < a->n_anti_terms; t++) { /* satisfyPodAntiAffinity :367-379 */
+        int k = a->anti_key[t];
+        int32_t v = nd->label_cols[a->key_col[k]][n];
+        if (v && s->anti[k][v] > 0) return 2;
+    }
+    if (s->exist_total > 0) /* satisfyExistingPodsAntiAffinity :352-364 */
+        for (int k = 0; k < a->n_keys; k++) {
+            int32_t v = nd->label_cols[a->key_col[k]][n];
+            if (v && s->exist[k][v] > 0) return 3;
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Filter chain for one node: S/framework/runtime/framework.go:897-930 (short-circuit AND in the
  * configured order; first failing plugin sets the status).  Returns 0 if feasible, else a
  * negative code: -1 Unschedulable, -2 UnschedulableAndUnresolvable; *first_plugin receives the
@@ -233,10 +316,11 @@ typedef struct {
     uint32_t plugin;
     uint32_t fit_mask; /* bit0 Too many pods, bit 1+col Insufficient <col> */
     int pts_code;
+    int ipa_code;
 } fail_info;
 
 static int filter_node(const ccref_profile *prof, const ccref_nodes *nd, const ccref_pod *pod, const pts_state *pts,
-                       int64_t n, fail_info *fi) {
+                       const ipa_state *ipa, int64_t n, fail_info *fi) {
     uint32_t fm = prof->filter_mask;
     /* P/nodeunschedulable/node_unschedulable.go:133-150 */
     if ((fm & CCREF_F_UNSCHEDULABLE) && nd->unschedulable && nd->unschedulable[n] && !pod->tolerates_unschedulable) {
@@ -285,6 +369,15 @@ static int filter_node(const ccref_profile *prof, const ccref_nodes *nd, const c
         if (r) {
             fi->plugin = CCREF_F_TOPOLOGYSPREAD;
             fi->pts_code = r;
+            return r == 1 ? -2 : -1;
+        }
+    }
+    /* P/interpodaffinity/filtering.go:410-432 */
+    if ((fm & CCREF_F_INTERPODAFFINITY) && ipa && ipa->filter_active) {
+        int r = ipa_filter(nd, pod, ipa, n);
+        if (r) {
+            fi->plugin = CCREF_F_INTERPODAFFINITY;
+            fi->ipa_code = r;
             return r == 1 ? -2 : -1;
         }
     }
@@ -474,6 +567,7 @@ typedef struct {
     fail_info *fails;
     int32_t *placed;  /* simulated pods per node (== res->per_node_count) */
     pts_state pts;
+    ipa_state ipa;
     int threads;
 } workspace;
 
@@ -490,6 +584,13 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
         pts = &ws->pts;
     }
 
+    /* InterPodAffinity PreFilter + PreScore state */
+    const ipa_state *ipa = NULL;
+    if (pod->has_ipa) {
+        ipa_build(nd, pod, ws->placed, &ws->ipa);
+        ipa = &ws->ipa;
+    }
+
     int64_t nf = 0, visited = 0, failed = 0;
     const int64_t start = st->next_start_node_index;
     if (num_to_find >= N) {
@@ -497,8 +598,8 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
 #pragma omp parallel for schedule(static) num_threads(ws->threads) if (ws->threads > 1)
         for (int64_t i = 0; i < N; i++) {
             int64_t n = (start + i) % N;
-            fail_info fi = {0, 0, 0};
-            int r = filter_node(prof, nd, pod, pts, n, &fi);
+            fail_info fi = {0, 0, 0, 0};
+            int r = filter_node(prof, nd, pod, pts, ipa, n, &fi);
             ws->status[n] = (int8_t)r;
             if (r) ws->fails[n] = fi;
         }
@@ -513,8 +614,8 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
     } else {
         for (int64_t i = 0; i < N; i++) {
             int64_t n = (start + i) % N;
-            fail_info fi = {0, 0, 0};
-            int r = filter_node(prof, nd, pod, pts, n, &fi);
+            fail_info fi = {0, 0, 0, 0};
+            int r = filter_node(prof, nd, pod, pts, ipa, n, &fi);
             if (r == 0) {
                 if (nf == num_to_find) break; /* :655-662 the (K+1)-th feasible node cancels the search */
                 ws->feas[nf++] = n;
@@ -557,6 +658,9 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
                     break;
                 case CCREF_F_TOPOLOGYSPREAD:
                     res->hist[fi->pts_code == 1 ? CCREF_R_PTS_MISSING_LABEL : CCREF_R_PTS_SKEW]++;
+                    break;
+                case CCREF_F_INTERPODAFFINITY:
+                    res->hist[fi->ipa_code == 1 ? CCREF_R_IPA_AFFINITY : fi->ipa_code == 2 ? CCREF_R_IPA_ANTI : CCREF_R_IPA_EXISTING_ANTI]++;
                     break;
                 default: break;
                 }
@@ -602,6 +706,27 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
             pts_scores(nd, pod, ws->placed, ws->feas, nf, sc);
             for (int64_t i = 0; i < nf; i++) ws->total[i] += sc[i] * prof->w_topologyspread;
         }
+        /* InterPodAffinity Score + NormalizeScore (scoring.go:226-290); PreScore Skip without any term hit */
+        if (prof->w_interpodaffinity && ipa && ipa->entries > 0) {
+            const ccref_ipa *a = &pod->ipa;
+            int64_t mn = INT64_MAX, mx = INT64_MIN;
+            for (int64_t i = 0; i < nf; i++) {
+                int64_t v = 0;
+                for (int k = 0; k < a->n_keys; k++) {
+                    int32_t d = nd->label_cols[a->key_col[k]][ws->feas[i]];
+                    if (d) v += ipa->score[k][d];
+                }
+                sc[i] = v;
+                if (v > mx) mx = v;
+                if (v < mn) mn = v;
+            }
+            int64_t diff = mx - mn;
+            for (int64_t i = 0; i < nf; i++) {
+                double f = 0;
+                if (diff > 0) f = (double)MAX_NODE_SCORE * ((double)(sc[i] - mn) / (double)diff);
+                ws->total[i] += (int64_t)f * prof->w_interpodaffinity;
+            }
+        }
         /* NodeResourcesBalancedAllocation (balanced_allocation.go:100-115); Skip for best-effort */
         if (prof->w_balanced && !balanced_skipped(prof, pod)) {
 #pragma omp parallel for schedule(static) num_threads(ws->threads) if (ws->threads > 1)
@@ -639,6 +764,14 @@ static int ws_init(workspace *ws, const ccref_nodes *nd, const ccref_pod *pod, i
     for (int c = 0; c < pod->n_spread; c++)
         if (pod->spread[c].hard)
             ws->pts.match_num[c] = (int64_t *)malloc(sizeof(int64_t) * (size_t)(pod->spread[c].n_domains + 1));
+    if (pod->has_ipa)
+        for (int k = 0; k < pod->ipa.n_keys; k++) {
+            size_t len = sizeof(int64_t) * (size_t)(pod->ipa.key_ndom[k] + 1);
+            ws->ipa.aff[k] = (int64_t *)malloc(len);
+            ws->ipa.anti[k] = (int64_t *)malloc(len);
+            ws->ipa.exist[k] = (int64_t *)malloc(len);
+            ws->ipa.score[k] = (int64_t *)malloc(len);
+        }
     return ws->feas && ws->total && ws->scratch && ws->status && ws->fails ? 0 : -1;
 }
 
@@ -649,6 +782,12 @@ static void ws_free(workspace *ws) {
     free(ws->status);
     free(ws->fails);
     for (int c = 0; c < CCREF_MAX_TSC; c++) free(ws->pts.match_num[c]);
+    for (int k = 0; k < CCREF_MAX_IPA_KEYS; k++) {
+        free(ws->ipa.aff[k]);
+        free(ws->ipa.anti[k]);
+        free(ws->ipa.exist[k]);
+        free(ws->ipa.score[k]);
+    }
 }
 
 int64_t ccref_schedule_one(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *pod, ccref_sched_state *st,

@@ -30,6 +30,8 @@ extern "C" {
 #define CCREF_MAX_RES (3 + CCREF_MAX_SCALAR) /* resource "columns": 0 cpu(milli) 1 memory 2 ephemeral 3+k scalar k */
 #define CCREF_MAX_LABEL_COLS 32
 #define CCREF_MAX_TSC 8 /* topology spread constraints per pod */
+#define CCREF_MAX_IPA_KEYS 4  /* distinct topology keys of inter-pod (anti)affinity terms */
+#define CCREF_MAX_IPA_TERMS 8 /* required (anti)affinity terms of the incoming pod */
 
 /* filter plugins, in the default profile's order (S/apis/config/v1/default_plugins.go:30-58) */
 enum {
@@ -38,7 +40,8 @@ enum {
     CCREF_F_TAINT = 1u << 2,         /* P/tainttoleration */
     CCREF_F_NODEAFFINITY = 1u << 3,  /* P/nodeaffinity */
     CCREF_F_FIT = 1u << 4,           /* P/noderesources/fit.go */
-    CCREF_F_TOPOLOGYSPREAD = 1u << 5 /* P/podtopologyspread */
+    CCREF_F_TOPOLOGYSPREAD = 1u << 5, /* P/podtopologyspread */
+    CCREF_F_INTERPODAFFINITY = 1u << 6 /* P/interpodaffinity */
 };
 
 /* reason slots of the terminal-round histogram (S/framework/types.go:787-836) */
@@ -50,6 +53,9 @@ enum {
     CCREF_R_RES0 = 4,          /* + column: "Insufficient cpu|memory|ephemeral-storage|<scalar name>" */
     CCREF_R_PTS_MISSING_LABEL = CCREF_R_RES0 + CCREF_MAX_RES, /* "node(s) didn't match pod topology spread constraints (missing required label)" */
     CCREF_R_PTS_SKEW,                                         /* "node(s) didn't match pod topology spread constraints" */
+    CCREF_R_IPA_AFFINITY,      /* "node(s) didn't match pod affinity rules" (UnschedulableAndUnresolvable) */
+    CCREF_R_IPA_ANTI,          /* "node(s) didn't match pod anti-affinity rules" */
+    CCREF_R_IPA_EXISTING_ANTI, /* "node(s) didn't satisfy existing pods anti-affinity rules" */
     CCREF_NREASON
 };
 
@@ -100,6 +106,35 @@ typedef struct {
     const uint8_t *node_included;
 } ccref_spread_constraint;
 
+/* InterPodAffinity in the integer world (P/interpodaffinity/{filtering.go:204-432, scoring.go:81-290}).
+ * The reference keys its count/score maps by topology PAIR (key, value), so terms sharing a topology key share
+ * entries; hence everything here is per distinct KEY.  The caller evaluates label selectors / namespaces of
+ * existing pods once (strings) and hands over per-node counts; simulated clones are identical to the incoming
+ * pod, so what one clone adds is a per-pod constant ("self" fields). */
+typedef struct {
+    int32_t n_keys;
+    int32_t key_col[CCREF_MAX_IPA_KEYS];   /* label column of the topology key */
+    int32_t key_ndom[CCREF_MAX_IPA_KEYS];  /* value ids 1..n */
+    /* incoming pod's REQUIRED affinity terms (filtering.go:187-199: an existing pod counts only if it matches ALL terms) */
+    int32_t n_aff_terms;
+    int32_t aff_key[CCREF_MAX_IPA_TERMS];  /* index into key_col */
+    int32_t self_aff;                      /* podMatchesAllAffinityTerms(own terms, own pod) */
+    const int32_t *aff_existing;           /* [n] existing pods on the node matching all terms, NULL = 0 */
+    /* incoming pod's REQUIRED anti-affinity terms (counted per term) */
+    int32_t n_anti_terms;
+    int32_t anti_key[CCREF_MAX_IPA_TERMS];
+    int32_t anti_self[CCREF_MAX_IPA_TERMS];            /* the term's selector matches the pod itself */
+    const int32_t *anti_existing[CCREF_MAX_IPA_TERMS]; /* [n] existing pods matching term t, NULL = 0 */
+    /* existing pods' required anti-affinity terms that match the incoming pod, per topology key (filtering.go:204-232) */
+    const int32_t *exist_anti[CCREF_MAX_IPA_KEYS]; /* [n] (pod, term) pairs with that key on the node, NULL = 0 */
+    /* Score (scoring.go:81-125): net weight existing pods put on the node's (key, value) pair, what one clone adds,
+     * and how many processTerm hits exist (PreScore returns Skip without any, scoring.go:199-201) */
+    const int64_t *score_existing[CCREF_MAX_IPA_KEYS]; /* [n], NULL = 0 */
+    int64_t score_self[CCREF_MAX_IPA_KEYS];
+    int64_t entries_existing;                          /* hits among existing pods (node has the key) */
+    int32_t self_entries[CCREF_MAX_IPA_KEYS];          /* hits one clone adds on a node that has the key */
+} ccref_ipa;
+
 typedef struct {
     /* fit.go:224-233 computePodResourceRequest; col order as above */
     int64_t req[CCREF_MAX_RES];
@@ -125,12 +160,15 @@ typedef struct {
     /* PodTopologySpread */
     int32_t n_spread;
     ccref_spread_constraint spread[CCREF_MAX_TSC];
+    int32_t has_ipa; /* 0 = no inter-pod (anti)affinity anywhere: PreFilter and PreScore return Skip */
+    ccref_ipa ipa;
 } ccref_pod;
 
 typedef struct {
     uint32_t filter_mask;
     /* score plugin weights; 0 = plugin not enabled (default_plugins.go:38-50) */
     int32_t w_taint, w_nodeaffinity, w_fit, w_balanced, w_topologyspread;
+    int32_t w_interpodaffinity; /* default 2 */
     /* NodeResourcesFit scoringStrategy LeastAllocated resources (defaults.go:33-36) */
     int32_t n_fit_res;
     int32_t fit_res[CCREF_MAX_RES];

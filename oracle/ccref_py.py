@@ -18,7 +18,9 @@ MAX_SCALAR = 8
 MAX_RES = 3 + MAX_SCALAR
 MAX_LABEL_COLS = 32
 MAX_TSC = 8
-NREASON = 4 + MAX_RES + 2
+MAX_IPA_KEYS = 4
+MAX_IPA_TERMS = 8
+NREASON = 4 + MAX_RES + 2 + 3
 
 _p64 = C.POINTER(C.c_int64)
 _p32 = C.POINTER(C.c_int32)
@@ -64,6 +66,17 @@ class _Spread(C.Structure):
     ]
 
 
+class _Ipa(C.Structure):
+    _fields_ = [
+        ("n_keys", C.c_int32), ("key_col", C.c_int32 * MAX_IPA_KEYS), ("key_ndom", C.c_int32 * MAX_IPA_KEYS),
+        ("n_aff_terms", C.c_int32), ("aff_key", C.c_int32 * MAX_IPA_TERMS), ("self_aff", C.c_int32), ("aff_existing", _p32),
+        ("n_anti_terms", C.c_int32), ("anti_key", C.c_int32 * MAX_IPA_TERMS), ("anti_self", C.c_int32 * MAX_IPA_TERMS),
+        ("anti_existing", _p32 * MAX_IPA_TERMS), ("exist_anti", _p32 * MAX_IPA_KEYS),
+        ("score_existing", _p64 * MAX_IPA_KEYS), ("score_self", C.c_int64 * MAX_IPA_KEYS), ("entries_existing", C.c_int64),
+        ("self_entries", C.c_int32 * MAX_IPA_KEYS),
+    ]
+
+
 class _Pod(C.Structure):
     _fields_ = [
         ("req", C.c_int64 * MAX_RES),
@@ -86,6 +99,8 @@ class _Pod(C.Structure):
         ("req_tables", _pu8),
         ("n_spread", C.c_int32),
         ("spread", _Spread * MAX_TSC),
+        ("has_ipa", C.c_int32),
+        ("ipa", _Ipa),
     ]
 
 
@@ -97,6 +112,7 @@ class _Profile(C.Structure):
         ("w_fit", C.c_int32),
         ("w_balanced", C.c_int32),
         ("w_topologyspread", C.c_int32),
+        ("w_interpodaffinity", C.c_int32),
         ("n_fit_res", C.c_int32),
         ("fit_res", C.c_int32 * MAX_RES),
         ("fit_res_w", C.c_int64 * MAX_RES),
@@ -246,6 +262,10 @@ class _Marshal:
                 s.spread[i].node_match_count = self.arr(k.node_match_count, np.int32, _p32)
             if k.node_included is not None:
                 s.spread[i].node_included = self.arr(k.node_included, np.uint8, _pu8)
+        ipa = getattr(pod, "ipa", None)
+        s.has_ipa = int(ipa is not None)
+        if ipa is not None:
+            fill_ipa(s.ipa, ipa, self.arr)
         return s
 
     def profile(self, p) -> _Profile:
@@ -253,6 +273,7 @@ class _Marshal:
         s.filter_mask = int(p.filter_mask)
         s.w_taint, s.w_nodeaffinity, s.w_fit = int(p.w_taint), int(p.w_nodeaffinity), int(p.w_fit)
         s.w_balanced, s.w_topologyspread = int(p.w_balanced), int(p.w_topologyspread)
+        s.w_interpodaffinity = int(getattr(p, "w_interpodaffinity", 0))
         s.n_fit_res = len(p.fit_res)
         for i, (c, w) in enumerate(zip(p.fit_res, p.fit_res_w)):
             s.fit_res[i] = int(c)
@@ -262,6 +283,34 @@ class _Marshal:
             s.bal_res[i] = int(c)
         s.percentage_of_nodes_to_score = int(p.percentage_of_nodes_to_score)
         return s
+
+
+def fill_ipa(c, ipa, arr):
+    """Marshal a duck-typed InterPodAffinity description (cluster-capacity_amd/model.py InterPodAffinity) into a
+    C struct with the ccref_ipa / ccsim_ipa layout; `arr(a, dtype, ptr_type)` pins the numpy buffer."""
+    c.n_keys = len(ipa.key_cols)
+    for k, (col, nd) in enumerate(zip(ipa.key_cols, ipa.key_ndom)):
+        c.key_col[k], c.key_ndom[k] = int(col), int(nd)
+    c.n_aff_terms = len(ipa.aff_keys)
+    for t, k in enumerate(ipa.aff_keys):
+        c.aff_key[t] = int(k)
+    c.self_aff = int(bool(ipa.self_aff))
+    if ipa.aff_existing is not None:
+        c.aff_existing = arr(ipa.aff_existing, np.int32, _p32)
+    c.n_anti_terms = len(ipa.anti_keys)
+    for t, k in enumerate(ipa.anti_keys):
+        c.anti_key[t] = int(k)
+        c.anti_self[t] = int(bool(ipa.anti_self[t]))
+        if ipa.anti_existing and ipa.anti_existing[t] is not None:
+            c.anti_existing[t] = arr(ipa.anti_existing[t], np.int32, _p32)
+    for k in range(c.n_keys):
+        if ipa.exist_anti and ipa.exist_anti[k] is not None:
+            c.exist_anti[k] = arr(ipa.exist_anti[k], np.int32, _p32)
+        if ipa.score_existing and ipa.score_existing[k] is not None:
+            c.score_existing[k] = arr(ipa.score_existing[k], np.int64, _p64)
+        c.score_self[k] = int(ipa.score_self[k]) if ipa.score_self else 0
+        c.self_entries[k] = int(ipa.self_entries[k]) if ipa.self_entries else 0
+    c.entries_existing = int(ipa.entries_existing)
 
 
 def run(profile, nodes, pod, max_limit: int = 0, threads: int = 1, want_log: bool = True, log_cap: int | None = None):

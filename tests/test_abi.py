@@ -32,15 +32,15 @@ def test_struct_layouts_match_header_sizes():
     prog = r'''
     #include <stdio.h>
     #include "ccsim.h"
-    int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccsim_config), sizeof(ccsim_nodes), sizeof(ccsim_requirement),
+    int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccsim_config), sizeof(ccsim_nodes), sizeof(ccsim_requirement),
       sizeof(ccsim_term), sizeof(ccsim_pod), sizeof(ccsim_profile), sizeof(ccsim_report), sizeof(ccsim_cycle),
-      sizeof(ccsim_spread_constraint));return 0;}
+      sizeof(ccsim_spread_constraint), sizeof(ccsim_ipa));return 0;}
     '''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(prog)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
-    mirrors = [capi.CConfig, capi.CNodes, capi.CReq, capi.CTerm, capi.CPod, capi.CProfile, capi.CReport, capi.CCycle, capi.CSpread]
+    mirrors = [capi.CConfig, capi.CNodes, capi.CReq, capi.CTerm, capi.CPod, capi.CProfile, capi.CReport, capi.CCycle, capi.CSpread, capi.CIpa]
     assert sizes == [ctypes.sizeof(m) for m in mirrors]
 
 

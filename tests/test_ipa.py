@@ -1,0 +1,80 @@
+"""InterPodAffinity (P/interpodaffinity).  CPU: the reference's own behavioural fixtures
+(test/benchmark/pod_colocation_test.go -- SURVEY KA3 / KA4) and hand-derived answers pin the oracle.
+GPU: the HIP filter/score against the oracle."""
+import numpy as np
+import pytest
+
+import helpers as H
+from cluster_capacity_amd import capi, model as M, report as R
+
+
+def colocation_nodes(zones):
+    """pod_colocation_test.go:193-221 BuildTestNode(name, 1000m, 1000 B, 30 pods); one label column = topology id."""
+    n = len(zones)
+    return H.simple_nodes([1000] * n, [1000] * n, [30] * n, label_cols=[np.array(zones, np.int32)])
+
+
+def self_affinity_pod(n_domains):
+    """BuildTestPod("pod-affinity", 10m, 10 B) with label key=value and a REQUIRED pod-affinity term on the
+    topology key selecting key=value: the pod matches its own term.  Each clone's required term matches the
+    incoming pod -> HardPodAffinityWeight (1) per clone on the clone's topology pair (scoring.go:104-110)."""
+    p = H.simple_pod(10, 10)
+    p.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[n_domains], aff_keys=[0], self_aff=True,
+                               score_self=[1], self_entries=[1])
+    return p
+
+
+def test_ka3_colocation_single_node(ccref):
+    # pod_colocation_test.go:18-97: 3 nodes, hostname topology, Filter = InterPodAffinity only, limit 100.
+    # First pod: affinityCounts empty + self-match -> allowed everywhere (filtering.go:396-405); afterwards only the
+    # node holding the clones passes.  No Fit filter -> the 30-pod capacity never binds: 100 on ONE node.
+    prof = M.Profile(filter_mask=M.F_INTERPODAFFINITY)
+    r = ccref.run(prof, colocation_nodes([1, 2, 3]), self_affinity_pod(3), max_limit=100)
+    assert r.placed == 100 and r.stop == M.STOP_LIMIT
+    assert sorted(r.per_node_count.tolist()) == [0, 0, 100]  # the test's assertion: all pods on one node (:84-90)
+    assert r.per_node_count.tolist() == [100, 0, 0]          # canonical tie-break: lowest index
+
+
+def test_ka4_colocation_single_zone(ccref):
+    # pod_colocation_test.go:99-190: 9 nodes in 3 zones (custom topology key, so the node tree has one zone and the
+    # canonical order is by name: node1-1..node3-3), Filter = InterPodAffinity + NodeResourcesFit, limit 100.
+    # All pods land in the first pod's zone; 30 pods/node -> 90 = 30+30+30, then Unschedulable.
+    prof = M.Profile(filter_mask=M.F_INTERPODAFFINITY | M.F_FIT)
+    nodes = colocation_nodes([1, 1, 1, 2, 2, 2, 3, 3, 3])
+    r = ccref.run(prof, nodes, self_affinity_pod(3), max_limit=100)
+    assert r.placed == 90 and r.stop == M.STOP_UNSCHEDULABLE
+    assert r.per_node_count.tolist() == [30, 30, 30, 0, 0, 0, 0, 0, 0]  # one zone only (:181-187)
+    assert R.stop_reason(r, 9, 100).startswith(
+        "Unschedulable: 0/9 nodes are available: 3 Too many pods, 6 node(s) didn't match pod affinity rules.")
+
+
+def test_ipa_required_anti_affinity_on_hostname(ccref):
+    # required anti-affinity to its own label on the hostname key: one clone per node (config 5's pod shape)
+    nodes = colocation_nodes([1, 2, 3, 4])
+    p = H.simple_pod(10, 10)
+    p.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[4], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    r = ccref.run(M.Profile.default(), nodes, p)
+    assert r.placed == 4 and r.per_node_count.tolist() == [1, 1, 1, 1]
+    assert "4 node(s) didn't match pod anti-affinity rules" in R.stop_reason(r, 4, 0)
+
+
+def test_ipa_existing_pods_anti_affinity_and_missing_key(ccref):
+    # node 0: an existing pod has required anti-affinity (this key) matching the incoming pod -> whole domain blocked;
+    # node 3 lacks the topology key: anti-affinity cannot bind there, affinity is not required -> feasible.
+    nodes = H.simple_nodes([1000] * 4, [1000] * 4, [2] * 4, label_cols=[np.array([1, 1, 2, 0], np.int32)])
+    p = H.simple_pod(10, 10)
+    p.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[2], exist_anti=[np.array([1, 0, 0, 0], np.int32)])
+    r = ccref.run(M.Profile.default(), nodes, p)
+    assert r.per_node_count.tolist() == [0, 0, 2, 2]
+    assert "2 node(s) didn't satisfy existing pods anti-affinity rules" in R.stop_reason(r, 4, 0)
+
+
+def test_ipa_preferred_score_prefers_domain(ccref):
+    # existing pods put weight 5 on domain 2 (e.g. a preferred affinity term of the incoming pod matches them):
+    # normalized 100 there, 0 elsewhere, x weight 2 dominates the +-1 resource-score differences
+    nodes = colocation_nodes([1, 2, 3])
+    p = H.simple_pod(10, 10)
+    p.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[3], score_existing=[np.array([0, 5, 0], np.int64)],
+                               score_self=[0], self_entries=[0], entries_existing=1)
+    r = ccref.run(M.Profile.default(), nodes, p, max_limit=10)
+    assert r.per_node_count.tolist() == [0, 10, 0]
