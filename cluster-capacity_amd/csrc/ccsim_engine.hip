@@ -51,9 +51,15 @@ struct ccsim_engine {
     ccsim_profile prof{};
     DevPod pod{};
     DevPts pts{};
+    DevIpa ipa{};
+    int64_t *d_ipa_partials = nullptr;
+    int64_t ipa_aff_total0 = 0, ipa_exist_total0 = 0, ipa_entries0 = 0; // initial PreFilter / PreScore totals
+    int64_t ipa_aff_total_cur = 0, ipa_exist_total_cur = 0, ipa_entries_cur = 0; // ... after the runs so far
     int32_t *d_pts_min_partials = nullptr;
     std::vector<std::pair<int32_t *, int32_t *>> pts_tables; // (live, pristine) count tables
     std::vector<size_t> pts_table_len;
+    std::vector<std::pair<int64_t *, int64_t *>> ipa_tables; // (live, pristine)
+    std::vector<size_t> ipa_table_len;
     std::vector<void *> pod_allocs;
 
     // run state
@@ -475,6 +481,78 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             pt.n_present[c] = np_;
         }
     }
+    // InterPodAffinity: topology-pair tables per key, filled from the snapshot's pods (filtering.go:204-272, scoring.go:128-221)
+    e->ipa = DevIpa{};
+    e->d_ipa_partials = nullptr;
+    e->ipa_tables.clear();
+    e->ipa_table_len.clear();
+    e->ipa_aff_total0 = e->ipa_exist_total0 = e->ipa_entries0 = 0;
+    const bool ipa_filter_on = (pf.filter_mask & CCSIM_F_INTERPODAFFINITY) != 0;
+    if (pod->has_ipa && (ipa_filter_on || pf.w_interpodaffinity)) {
+        const ccsim_ipa &ip = pod->ipa;
+        if (ip.n_keys < 0 || ip.n_keys > CCSIM_MAX_IPA_KEYS || ip.n_aff_terms < 0 || ip.n_aff_terms > CCSIM_MAX_IPA_TERMS ||
+            ip.n_anti_terms < 0 || ip.n_anti_terms > CCSIM_MAX_IPA_TERMS)
+            return fail(e, -EINVAL, "bad inter-pod affinity dimensions");
+        DevIpa &d = e->ipa;
+        d.on = 1, d.filter_on = ipa_filter_on ? 1 : 0, d.w = pf.w_interpodaffinity;
+        d.n_keys = ip.n_keys, d.n_aff = ip.n_aff_terms, d.n_anti = ip.n_anti_terms, d.self_aff = ip.self_aff ? 1 : 0;
+        std::vector<int32_t *> lc((size_t)CCSIM_MAX_LABEL_COLS, nullptr);
+        HIPCHK(e, hipMemcpy(lc.data(), e->d_label_cols, sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyDeviceToHost));
+        IpaInitArgs ii{};
+        ii.n = e->n;
+        for (int t = 0; t < ip.n_aff_terms; t++) {
+            if (ip.aff_key[t] < 0 || ip.aff_key[t] >= ip.n_keys) return fail(e, -EINVAL, "affinity term key out of range");
+            d.aff_key[t] = ip.aff_key[t];
+            d.aff_terms_on_key[ip.aff_key[t]]++;
+        }
+        for (int t = 0; t < ip.n_anti_terms; t++) {
+            if (ip.anti_key[t] < 0 || ip.anti_key[t] >= ip.n_keys) return fail(e, -EINVAL, "anti-affinity term key out of range");
+            d.anti_key[t] = ip.anti_key[t];
+            if (ip.anti_self[t]) d.anti_self_on_key[ip.anti_key[t]]++;
+            int32_t *ex = nullptr;
+            if (ip.anti_existing[t] && (rc = upload(e, &ex, ip.anti_existing[t], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            ii.anti_existing[t] = ex;
+        }
+        int32_t *affex = nullptr;
+        if (ip.aff_existing && (rc = upload(e, &affex, ip.aff_existing, (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+        ii.aff_existing = affex;
+        for (int k = 0; k < ip.n_keys; k++) {
+            if (ip.key_col[k] < 0 || ip.key_col[k] >= e->n_label_cols || ip.key_ndom[k] < 0) return fail(e, -EINVAL, "bad inter-pod affinity key");
+            d.label[k] = lc[ip.key_col[k]];
+            d.score_self[k] = ip.score_self[k];
+            d.self_entries[k] = ip.self_entries[k];
+            const size_t len = (size_t)ip.key_ndom[k] + 1;
+            int64_t **tabs[4] = {&d.aff[k], &d.anti[k], &d.exist[k], &d.score[k]};
+            for (auto tp : tabs) {
+                int64_t *live = nullptr, *prist = nullptr;
+                if ((rc = dev_alloc(e, &live, len, e->pod_allocs))) return rc;
+                if ((rc = dev_alloc(e, &prist, len, e->pod_allocs))) return rc;
+                *tp = live;
+                e->ipa_tables.emplace_back(live, prist);
+                e->ipa_table_len.push_back(len);
+            }
+            int32_t *ea = nullptr;
+            int64_t *sx = nullptr;
+            if (ip.exist_anti[k] && (rc = upload(e, &ea, ip.exist_anti[k], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            if (ip.score_existing[k] && (rc = upload(e, &sx, ip.score_existing[k], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            ii.exist_anti[k] = ea, ii.score_existing[k] = sx;
+        }
+        unsigned long long *d_tot = nullptr;
+        if ((rc = dev_alloc(e, &d_tot, (size_t)2, e->pod_allocs))) return rc;
+        if ((rc = dev_alloc(e, &e->d_ipa_partials, (size_t)kMaxGrid * 2, e->pod_allocs))) return rc;
+        ii.ipa = d;
+        ii.totals = d_tot;
+        if (e->n > 0) hipLaunchKernelGGL(k_ipa_init, dim3((unsigned)((e->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, ii);
+        HIPCHK(e, hipGetLastError());
+        unsigned long long tot[2] = {0, 0};
+        HIPCHK(e, hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, e->stream));
+        for (size_t i = 0; i < e->ipa_tables.size(); i++)
+            HIPCHK(e, hipMemcpyAsync(e->ipa_tables[i].second, e->ipa_tables[i].first, e->ipa_table_len[i] * 8, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->ipa_aff_total0 = (int64_t)tot[0];
+        e->ipa_exist_total0 = (int64_t)tot[1];
+        e->ipa_entries0 = ip.entries_existing;
+    }
     e->have_pod = true;
     return 0;
 }
@@ -500,8 +578,8 @@ static void launch_scan_t(ccsim_engine *e, const ScanArgs &a, hipEvent_t t0, hip
 }
 
 static int launch_scan(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk, e->pts, e->d_pts_min_partials};
-    if (e->pts.n > 0) launch_scan_t<true>(e, a, t0, t1);
+    ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk, e->pts, e->d_pts_min_partials, e->ipa, e->d_ipa_partials};
+    if (e->pts.n > 0 || e->ipa.on) launch_scan_t<true>(e, a, t0, t1);
     else launch_scan_t<false>(e, a, t0, t1);
     return 0;
 }
@@ -519,6 +597,8 @@ static FinalArgs final_args(ccsim_engine *e) {
     f.log = e->d_log;
     f.pts = e->pts;
     f.pts_min_partials = e->d_pts_min_partials;
+    f.ipa = e->ipa;
+    f.ipa_partials = e->d_ipa_partials;
     return f;
 }
 
@@ -561,6 +641,8 @@ static int launch_level_final(ccsim_engine *e) {
 static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_cap) {
     if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
     if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
+    if (e->ipa.on && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
+        return fail(e, -ENOSYS, "inter-pod affinity couples nodes through topology pairs: sequential mode on one GPU only, for now");
     if (e->pts.n > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "batched mode is not valid with topology spread constraints (a placement changes the feasibility of "
                                 "other nodes): use CCSIM_MODE_SEQUENTIAL");
@@ -581,6 +663,10 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     }
     DevState st{};
     for (int c = 0; c < kMaxTsc; c++) st.pts_min_a[c] = 0x7fffffff;
+    if (!e->begun) { // a fresh snapshot state (load / reset); otherwise the run continues where the last one stopped
+        e->ipa_aff_total_cur = e->ipa_aff_total0, e->ipa_exist_total_cur = e->ipa_exist_total0, e->ipa_entries_cur = e->ipa_entries0;
+    }
+    st.ipa_aff_total = e->ipa_aff_total_cur, st.ipa_exist_total = e->ipa_exist_total_cur, st.ipa_entries = e->ipa_entries_cur;
     st.limit = max_limit;
     st.winner = -1;
     st.mode = mode;
@@ -603,6 +689,8 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
 static int read_state(ccsim_engine *e) {
     HIPCHK(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->ipa_aff_total_cur = e->h_state->ipa_aff_total, e->ipa_exist_total_cur = e->h_state->ipa_exist_total;
+    e->ipa_entries_cur = e->h_state->ipa_entries;
     return 0;
 }
 
@@ -665,7 +753,8 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     out->pass_launches = e->pass_launches;
     // algorithmic bytes per scan: the columns the active plugin set must read once per node
     int64_t per_node = 4 /*static word*/ + 6 * 8 /*alloc,req,nz x cpu,mem*/ + 2 * 4 /*pods*/ + (int64_t)e->pod.nx * 16 +
-                       (e->pts.n ? 1 + 4 * (int64_t)e->pts.n : 0) /*eligibility byte + topology value id per constraint*/;
+                       (e->pts.n ? 1 + 4 * (int64_t)e->pts.n : 0) /*eligibility byte + topology value id per constraint*/ +
+                       (e->ipa.on ? 4 * (int64_t)e->ipa.n_keys : 0) /*topology value id per inter-pod affinity key*/;
     out->bytes_per_scan = per_node * e->n;
     memset(out->hist, 0, sizeof(out->hist));
     out->n_code_unschedulable = 0;
@@ -686,7 +775,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
         // terminal round: FitError diagnosis (types.go:787-836)
         HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
         HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
-        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state};
+        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state, e->ipa};
         int64_t hb = (e->n + kThreads - 1) / kThreads;
         if (hb > 2048) hb = 2048;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
@@ -850,6 +939,8 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
     HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
     for (size_t c = 0; c < e->pts_tables.size(); c++)
         HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].first, e->pts_tables[c].second, e->pts_table_len[c] * 4, hipMemcpyDeviceToDevice, e->stream));
+    for (size_t c = 0; c < e->ipa_tables.size(); c++)
+        HIPCHK(e, hipMemcpyAsync(e->ipa_tables[c].first, e->ipa_tables[c].second, e->ipa_table_len[c] * 8, hipMemcpyDeviceToDevice, e->stream));
     e->begun = false;
     return 0;
 }

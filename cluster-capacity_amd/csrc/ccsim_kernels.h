@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits.h>
 
 namespace ccsim {
 
@@ -83,8 +84,25 @@ struct DevPts {
     const uint8_t *elig;           // per node: bit0 has all hard keys (filtering.go:267-270), bit 1+c counted for c (:274-277)
 };
 
+// InterPodAffinity (P/interpodaffinity/filtering.go:204-432, scoring.go:81-290): the topology-pair maps live as
+// one int64 table per distinct topology key in HBM, updated by the commit (a clone is an existing pod next cycle).
+constexpr int kMaxIpaKeys = 4, kMaxIpaTerms = 8;
+struct DevIpa {
+    int32_t on, filter_on, w; // plugin present; Filter enabled in the profile; score weight (0 = off)
+    int32_t n_keys, n_aff, n_anti, self_aff;
+    int32_t aff_key[kMaxIpaTerms], anti_key[kMaxIpaTerms];
+    int32_t aff_terms_on_key[kMaxIpaKeys];  // # required affinity terms using the key
+    int32_t anti_self_on_key[kMaxIpaKeys];  // # required anti-affinity terms using the key that match the pod itself
+    int32_t self_entries[kMaxIpaKeys];
+    int64_t score_self[kMaxIpaKeys];
+    const int32_t *label[kMaxIpaKeys];
+    int64_t *aff[kMaxIpaKeys], *anti[kMaxIpaKeys], *exist[kMaxIpaKeys], *score[kMaxIpaKeys];
+};
+
 struct DevState {
     int32_t pts_min_a[kMaxTsc]; // CriticalPaths[c][0].MatchNum the pending scan assumed (filtering.go:298-305)
+    int64_t ipa_aff_total, ipa_exist_total, ipa_entries; // len(affinityCounts), len(existingAntiAffinityCounts), PreScore hits
+    int64_t ipa_min_a, ipa_max_a;                        // NormalizeScore min / max the pending scan assumed (scoring.go:258-290)
     int64_t placed, limit, rounds, scans;
     int64_t winner; // global index committed by the last decide (-1 none)
     int32_t done, have_prev;
@@ -263,6 +281,48 @@ __device__ __forceinline__ int64_t key_score(uint64_t key) { return (int64_t)(ke
 // k_scan: one full pods x nodes pass for the current pod spec: Filter (static bit + Fit), Score
 // (TaintToleration, NodeAffinity, LeastAllocated, BalancedAllocation), weighted sum, per-block argmax.
 // ------------------------------------------------------------------------------------------------
+// InterPodAffinity.Filter (filtering.go:410-432): 0 ok, 1 affinity (Unresolvable), 2 anti-affinity, 3 existing pods' anti-affinity
+__device__ __forceinline__ int ipa_filter(const DevIpa &p, const DevState &st, int64_t i) {
+    if (st.ipa_exist_total == 0 && p.n_aff == 0 && p.n_anti == 0) return 0; // PreFilter Skip (filtering.go:299-301)
+    bool pods_exist = true;
+    for (int t = 0; t < p.n_aff; t++) { // satisfyPodAffinity :382-408
+        const int k = p.aff_key[t];
+        const int32_t v = p.label[k][i];
+        if (!v) return 1;
+        if (p.aff[k][v] <= 0) pods_exist = false;
+    }
+    if (!pods_exist && !(st.ipa_aff_total == 0 && p.self_aff)) return 1;
+    for (int t = 0; t < p.n_anti; t++) { // satisfyPodAntiAffinity :367-379
+        const int k = p.anti_key[t];
+        const int32_t v = p.label[k][i];
+        if (v && p.anti[k][v] > 0) return 2;
+    }
+    if (st.ipa_exist_total > 0) // satisfyExistingPodsAntiAffinity :352-364
+        for (int k = 0; k < p.n_keys; k++) {
+            const int32_t v = p.label[k][i];
+            if (v && p.exist[k][v] > 0) return 3;
+        }
+    return 0;
+}
+
+// InterPodAffinity.Score (scoring.go:226-247): sum of the node's topology pairs
+__device__ __forceinline__ int64_t ipa_raw_score(const DevIpa &p, int64_t i) {
+    int64_t s = 0;
+    for (int k = 0; k < p.n_keys; k++) {
+        const int32_t v = p.label[k][i];
+        if (v) s += p.score[k][v];
+    }
+    return s;
+}
+
+// NormalizeScore (scoring.go:258-290): fp64, truncated
+__device__ __forceinline__ int64_t ipa_normalize(int64_t raw, int64_t mn, int64_t mx) {
+    const int64_t diff = mx - mn;
+    double f = 0;
+    if (diff > 0) f = 100.0 * ((double)(raw - mn) / (double)diff);
+    return (int64_t)f;
+}
+
 struct ScanArgs {
     DevCols c;
     DevPod p;
@@ -271,8 +331,11 @@ struct ScanArgs {
     int64_t chunk; // nodes per block (multiple of kTile)
     DevPts pts;
     int32_t *pts_min_partials; // [grid][kMaxTsc]: per-block minimum match count per constraint
+    DevIpa ipa;
+    int64_t *ipa_partials;     // [grid][2]: per-block min / max raw InterPodAffinity score over feasible nodes
 };
 
+// PTS = the pod carries topology-coupled plugins (PodTopologySpread and / or InterPodAffinity)
 template <int NX, bool PTS>
 __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     const DevState st = *a.st;
@@ -288,6 +351,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     int32_t pmin[kMaxTsc];
 #pragma unroll
     for (int c = 0; c < kMaxTsc; c++) pmin[c] = 0x7fffffff;
+    int64_t ipa_mn = INT64_MAX, ipa_mx = INT64_MIN;
+    const bool ipa_scoring = PTS && a.ipa.on && a.ipa.w && st.ipa_entries > 0; // else PreScore Skip (scoring.go:199-201)
 
     for (int64_t base = lo; base < hi; base += kTile) {
         const int64_t i0 = base + 2 * tid; // first of this thread's 2 nodes
@@ -337,13 +402,20 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
                         if ((int64_t)m + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) feasible = false;
                     }
                 }
+                if (feasible && a.ipa.on && a.ipa.filter_on && ipa_filter(a.ipa, st, i0 + k)) feasible = false;
             }
             const uint64_t mask = __ballot(feasible);
             nfeas += (uint32_t)__popcll(mask); // identical in every lane of the wave
             if (feasible) {
                 const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-                const int64_t total = static_score(a.p, cnt, aff, mt, ma) +
-                                      dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem);
+                int64_t total = static_score(a.p, cnt, aff, mt, ma) +
+                                dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem);
+                if (ipa_scoring) {
+                    const int64_t raw = ipa_raw_score(a.ipa, i0 + k);
+                    ipa_mn = raw < ipa_mn ? raw : ipa_mn;
+                    ipa_mx = raw > ipa_mx ? raw : ipa_mx;
+                    total += ipa_normalize(raw, st.ipa_min_a, st.ipa_max_a) * a.ipa.w;
+                }
                 const uint64_t key = make_key(total, a.c.global_offset + i0 + k);
                 best = key > best ? key : best;
                 mt_b = cnt > mt_b ? cnt : mt_b;
@@ -394,10 +466,27 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             if (lane == 0) s_pm[wave][c] = v;
         }
         __syncthreads();
-        if (tid < kMaxTsc) {
+        if (tid < kMaxTsc && a.pts.n) {
             int32_t v = s_pm[0][tid];
             for (int w = 1; w < kThreads / 64; w++) v = s_pm[w][tid] < v ? s_pm[w][tid] : v;
             a.pts_min_partials[(int64_t)blockIdx.x * kMaxTsc + tid] = v;
+        }
+        if (a.ipa.on) {
+            __shared__ int64_t s_im[2][kThreads / 64];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int64_t o1 = __shfl_xor(ipa_mn, off, 64), o2 = __shfl_xor(ipa_mx, off, 64);
+                ipa_mn = o1 < ipa_mn ? o1 : ipa_mn;
+                ipa_mx = o2 > ipa_mx ? o2 : ipa_mx;
+            }
+            if (lane == 0) s_im[0][wave] = ipa_mn, s_im[1][wave] = ipa_mx;
+            __syncthreads();
+            if (tid == 0) {
+                int64_t mn = s_im[0][0], mx = s_im[1][0];
+                for (int w = 1; w < kThreads / 64; w++) mn = s_im[0][w] < mn ? s_im[0][w] : mn, mx = s_im[1][w] > mx ? s_im[1][w] : mx;
+                a.ipa_partials[2 * (int64_t)blockIdx.x] = mn;
+                a.ipa_partials[2 * (int64_t)blockIdx.x + 1] = mx;
+            }
         }
     }
 }
@@ -421,10 +510,12 @@ struct FinalArgs {
     int32_t *log;
     DevPts pts;
     const int32_t *pts_min_partials;
+    DevIpa ipa;
+    const int64_t *ipa_partials;
 };
 
 __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas,
-                                              const int32_t *pts_min) {
+                                              const int32_t *pts_min, int64_t ipa_mn = 0, int64_t ipa_mx = 0) {
     DevState st = *a.st;
     st.winner = -1;
     if (st.done) return;
@@ -443,6 +534,9 @@ __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, 
     } else if ((int32_t)mt != st.mt_a || (int32_t)ma != st.ma_a) {
         st.mt_a = (int32_t)mt;
         st.ma_a = (int32_t)ma;
+    } else if (a.ipa.on && a.ipa.w && st.ipa_entries > 0 && (ipa_mn != st.ipa_min_a || ipa_mx != st.ipa_max_a)) {
+        st.ipa_min_a = ipa_mn; // InterPodAffinity scores were normalized with stale min / max: rescan
+        st.ipa_max_a = ipa_mx;
     } else {
         const int64_t g = key_index(key);
         const int64_t i = g - a.c.global_offset;
@@ -459,6 +553,23 @@ __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, 
                 for (int c = 0; c < a.pts.n; c++) {
                     const int32_t v = a.pts.label[c][i];
                     if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.pts.self_match[c]) a.pts.tbl[c][v] += 1;
+                }
+            }
+            if (a.ipa.on) { // the clone is an existing pod of the next cycle (filtering.go:204-272, scoring.go:81-125)
+                for (int k = 0; k < a.ipa.n_keys; k++) {
+                    const int32_t v = a.ipa.label[k][i];
+                    if (!v) continue;
+                    if (a.ipa.self_aff && a.ipa.aff_terms_on_key[k]) {
+                        a.ipa.aff[k][v] += a.ipa.aff_terms_on_key[k];
+                        st.ipa_aff_total += a.ipa.aff_terms_on_key[k];
+                    }
+                    if (a.ipa.anti_self_on_key[k]) {
+                        a.ipa.anti[k][v] += a.ipa.anti_self_on_key[k];
+                        a.ipa.exist[k][v] += a.ipa.anti_self_on_key[k];
+                        st.ipa_exist_total += a.ipa.anti_self_on_key[k];
+                    }
+                    a.ipa.score[k][v] += a.ipa.score_self[k];
+                    st.ipa_entries += a.ipa.self_entries[k];
                 }
             }
         }
@@ -502,6 +613,38 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         s_nf[tid >> 6] = nf;
     }
     __syncthreads();
+    // topology-coupled plugins: global minimum match count per spread constraint, min / max InterPodAffinity score
+    __shared__ int32_t s_pm[kThreads / 64][kMaxTsc];
+    __shared__ int64_t s_im[2][kThreads / 64];
+    for (int c = 0; c < a.pts.n; c++) {
+        int32_t v = 0x7fffffff;
+        for (int i = tid; i < a.n_partials; i += kThreads) {
+            const int32_t q = a.pts_min_partials[(int64_t)i * kMaxTsc + c];
+            v = q < v ? q : v;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int32_t o = __shfl_xor(v, off, 64);
+            v = o < v ? o : v;
+        }
+        if ((tid & 63) == 0) s_pm[tid >> 6][c] = v;
+    }
+    if (a.ipa.on) {
+        int64_t mn = INT64_MAX, mx = INT64_MIN;
+        for (int i = tid; i < a.n_partials; i += kThreads) {
+            const int64_t q1 = a.ipa_partials[2 * (int64_t)i], q2 = a.ipa_partials[2 * (int64_t)i + 1];
+            mn = q1 < mn ? q1 : mn;
+            mx = q2 > mx ? q2 : mx;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int64_t o1 = __shfl_xor(mn, off, 64), o2 = __shfl_xor(mx, off, 64);
+            mn = o1 < mn ? o1 : mn;
+            mx = o2 > mx ? o2 : mx;
+        }
+        if ((tid & 63) == 0) s_im[0][tid >> 6] = mn, s_im[1][tid >> 6] = mx;
+    }
+    __syncthreads();
     if (tid != 0) return;
     key = 0, mt = 0, ma = 0, nf = 0;
 #pragma unroll
@@ -512,13 +655,18 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         nf += s_nf[w];
     }
     int32_t pts_min[kMaxTsc];
-    for (int c = 0; c < a.pts.n; c++) { // single thread: <= 1024 x 8 ints, only when spread constraints exist
-        int32_t v = 0x7fffffff;
-        for (int i = 0; i < a.n_partials; i++) {
-            const int32_t q = a.pts_min_partials[(int64_t)i * kMaxTsc + c];
-            v = q < v ? q : v;
-        }
+    for (int c = 0; c < a.pts.n; c++) {
+        int32_t v = s_pm[0][c];
+        for (int w = 1; w < kThreads / 64; w++) v = s_pm[w][c] < v ? s_pm[w][c] : v;
         pts_min[c] = v;
+    }
+    int64_t ipa_mn = 0, ipa_mx = 0;
+    if (a.ipa.on) {
+        ipa_mn = s_im[0][0], ipa_mx = s_im[1][0];
+        for (int w = 1; w < kThreads / 64; w++) {
+            ipa_mn = s_im[0][w] < ipa_mn ? s_im[0][w] : ipa_mn;
+            ipa_mx = s_im[1][w] > ipa_mx ? s_im[1][w] : ipa_mx;
+        }
     }
     if (a.n_ranks > 0) {
         XRec r{};
@@ -529,7 +677,7 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         *a.xsend = r;
         return;
     }
-    decide_commit(a, key, mt, ma, nf, pts_min);
+    decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx);
 }
 
 // k_decide (distributed): every rank reduces the gathered records identically, so all ranks agree on
@@ -636,9 +784,11 @@ struct HistArgs {
     int32_t n_taintsets;
     DevPts pts;
     const DevState *st;
+    DevIpa ipa;
 };
 
-constexpr int kHistSlots = 4 + kMaxRes + 2 + 1; // + the status-code counter
+constexpr int kHistSlots = 4 + kMaxRes + 2 + 3 + 1; // + the status-code counter
+constexpr int kHistIpa = 4 + kMaxRes + 2;          // affinity, anti-affinity, existing pods' anti-affinity
 constexpr int kHistPtsMissing = 4 + kMaxRes, kHistPtsSkew = 4 + kMaxRes + 1;
 constexpr int kHistTsLds = 1024;                // taint sets histogrammed in LDS (more fall back to global atomics)
 
@@ -679,15 +829,22 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
             continue;
         }
         // PodTopologySpread comes after NodeResourcesFit in the filter order (first failing plugin reports)
-        for (int c = 0; c < a.pts.n; c++) {
+        bool pts_failed = false;
+        for (int c = 0; c < a.pts.n && !pts_failed; c++) {
             const int32_t v = a.pts.label[c][n];
-            if (!v) { atomicAdd(&sh[kHistPtsMissing], 1u); break; } // UnschedulableAndUnresolvable
+            if (!v) { atomicAdd(&sh[kHistPtsMissing], 1u); pts_failed = true; break; } // UnschedulableAndUnresolvable
             const int64_t minm = a.pts.n_present[c] < a.pts.min_domains[c] ? 0 : (int64_t)a.st->pts_min_a[c];
             if ((int64_t)a.pts.tbl[c][v] + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) {
                 atomicAdd(&sh[kHistPtsSkew], 1u);
                 atomicAdd(&sh[kHistSlots - 1], 1u); // plain Unschedulable
-                break;
+                pts_failed = true;
             }
+        }
+        if (pts_failed || !a.ipa.on || !a.ipa.filter_on) continue;
+        const int code = ipa_filter(a.ipa, *a.st, n); // InterPodAffinity is the last filter of the default order
+        if (code) {
+            atomicAdd(&sh[kHistIpa + code - 1], 1u);
+            if (code != 1) atomicAdd(&sh[kHistSlots - 1], 1u); // anti-affinity failures are plain Unschedulable
         }
     }
     __syncthreads();
@@ -726,6 +883,49 @@ __global__ __launch_bounds__(kThreads) void k_pts_init(PtsInitArgs a) {
         }
     }
     a.elig[n] = (uint8_t)eb;
+}
+
+// k_ipa_init: once per pod spec.  PreFilter / PreScore maps of the initial cluster (existing pods only).
+struct IpaInitArgs {
+    int64_t n;
+    DevIpa ipa;
+    const int32_t *aff_existing;
+    const int32_t *anti_existing[kMaxIpaTerms];
+    const int32_t *exist_anti[kMaxIpaKeys];
+    const int64_t *score_existing[kMaxIpaKeys];
+    unsigned long long *totals; // [0] affinity entries, [1] existing anti-affinity entries
+};
+
+__global__ __launch_bounds__(kThreads) void k_ipa_init(IpaInitArgs a) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= a.n) return;
+    const int64_t am = a.aff_existing ? a.aff_existing[n] : 0;
+    if (am)
+        for (int t = 0; t < a.ipa.n_aff; t++) {
+            const int k = a.ipa.aff_key[t];
+            const int32_t v = a.ipa.label[k][n];
+            if (v) {
+                atomicAdd((unsigned long long *)&a.ipa.aff[k][v], (unsigned long long)am);
+                atomicAdd(&a.totals[0], (unsigned long long)am);
+            }
+        }
+    for (int t = 0; t < a.ipa.n_anti; t++) {
+        const int64_t m = a.anti_existing[t] ? a.anti_existing[t][n] : 0;
+        const int k = a.ipa.anti_key[t];
+        const int32_t v = a.ipa.label[k][n];
+        if (m && v) atomicAdd((unsigned long long *)&a.ipa.anti[k][v], (unsigned long long)m);
+    }
+    for (int k = 0; k < a.ipa.n_keys; k++) {
+        const int32_t v = a.ipa.label[k][n];
+        if (!v) continue;
+        const int64_t m = a.exist_anti[k] ? a.exist_anti[k][n] : 0;
+        if (m) {
+            atomicAdd((unsigned long long *)&a.ipa.exist[k][v], (unsigned long long)m);
+            atomicAdd(&a.totals[1], (unsigned long long)m);
+        }
+        const int64_t w = a.score_existing[k] ? a.score_existing[k][n] : 0;
+        if (w) atomicAdd((unsigned long long *)&a.ipa.score[k][v], (unsigned long long)w); // two's complement: negatives add up too
+    }
 }
 
 } // namespace ccsim

@@ -104,3 +104,27 @@ def random_spread(rng, nodes, n_constraints=None):
             node_match_count=rng.integers(0, 3, n).astype(np.int32) if rng.integers(0, 2) else None,
             node_included=(rng.random(n) < 0.9).astype(np.uint8) if rng.integers(0, 2) else None))
     return cons
+
+
+def random_ipa(rng, nodes):
+    """Random InterPodAffinity description over the two label columns of random_case() snapshots."""
+    n = nodes.n
+    keys, ndom = [1, 0], [2, 4]
+    sparse = lambda hi, p=0.1: (rng.integers(1, hi + 1, n) * (rng.random(n) < p)).astype(np.int32)
+    n_aff, n_anti = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    score_existing = [(rng.integers(-5, 6, n) * (rng.random(n) < 0.15)).astype(np.int64) if rng.integers(0, 2) else None
+                      for _ in keys]
+    entries = 0
+    for k, se in enumerate(score_existing):
+        if se is not None:
+            entries += int(np.count_nonzero(se[nodes.label_cols[keys[k]] != 0]))
+    score_self = [int(rng.integers(-2, 4)) if rng.integers(0, 2) else 0 for _ in keys]
+    return M.InterPodAffinity(
+        key_cols=keys, key_ndom=ndom,
+        aff_keys=[int(rng.integers(0, 2)) for _ in range(n_aff)], self_aff=bool(rng.integers(0, 2)),
+        aff_existing=sparse(2, 0.05) if rng.integers(0, 2) else None,
+        anti_keys=[int(rng.integers(0, 2)) for _ in range(n_anti)], anti_self=[bool(rng.integers(0, 2)) for _ in range(n_anti)],
+        anti_existing=[sparse(2, 0.03) if rng.integers(0, 2) else None for _ in range(n_anti)],
+        exist_anti=[sparse(2, 0.03) if rng.integers(0, 3) == 0 else None for _ in keys],
+        score_existing=score_existing, score_self=score_self, entries_existing=entries,
+        self_entries=[1 if w else int(rng.integers(0, 2)) for w in score_self])

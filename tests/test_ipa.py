@@ -78,3 +78,65 @@ def test_ipa_preferred_score_prefers_domain(ccref):
                                score_self=[0], self_entries=[0], entries_existing=1)
     r = ccref.run(M.Profile.default(), nodes, p, max_limit=10)
     assert r.per_node_count.tolist() == [0, 10, 0]
+
+
+def _gpu_check(ccref, nodes, pod, prof, limit):
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    got = e.run(max_limit=limit, mode="sequential", log_cap=max(1, ref.placed))
+    assert got.placed == ref.placed and got.stop == ref.stop
+    assert np.array_equal(got.per_node_count, ref.per_node_count)
+    assert np.array_equal(got.log, ref.log)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist)
+        assert got.n_code_unschedulable == ref.n_code_unschedulable
+        assert R.stop_reason(got, nodes.n, limit) == R.stop_reason(ref, nodes.n, limit)
+    return got
+
+
+@pytest.mark.gpu
+def test_gpu_ipa_reference_fixtures(ccref):
+    _gpu_check(ccref, colocation_nodes([1, 2, 3]), self_affinity_pod(3), M.Profile(filter_mask=M.F_INTERPODAFFINITY), 100)
+    got = _gpu_check(ccref, colocation_nodes([1, 1, 1, 2, 2, 2, 3, 3, 3]), self_affinity_pod(3),
+                     M.Profile(filter_mask=M.F_INTERPODAFFINITY | M.F_FIT), 100)
+    assert got.placed == 90 and got.per_node_count.tolist() == [30, 30, 30, 0, 0, 0, 0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_gpu_ipa_hand_cases(ccref):
+    p = H.simple_pod(10, 10)
+    p.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[4], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    _gpu_check(ccref, colocation_nodes([1, 2, 3, 4]), p, M.Profile.default(), 0)
+    nodes = H.simple_nodes([1000] * 4, [1000] * 4, [2] * 4, label_cols=[np.array([1, 1, 2, 0], np.int32)])
+    p = H.simple_pod(10, 10)
+    p.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[2], exist_anti=[np.array([1, 0, 0, 0], np.int32)])
+    _gpu_check(ccref, nodes, p, M.Profile.default(), 0)
+    p = H.simple_pod(10, 10)
+    p.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[3], score_existing=[np.array([0, 5, 0], np.int64)],
+                               score_self=[0], self_entries=[0], entries_existing=1)
+    _gpu_check(ccref, colocation_nodes([1, 2, 3]), p, M.Profile.default(), 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_ipa_random(ccref, seed):
+    rng = np.random.default_rng(900 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 1000)))
+    pod.ipa = H.random_ipa(rng, nodes)
+    if seed % 3 == 0:
+        pod.spread = H.random_spread(rng, nodes, n_constraints=1)
+    _gpu_check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 80])))
+
+
+@pytest.mark.gpu
+def test_gpu_ipa_hostname_anti_affinity_1000_nodes(ccref):
+    # config 5's pod shape: required anti-affinity to itself on kubernetes.io/hostname (one clone per node) + zone spread
+    from cluster_capacity_amd import synth
+    n = 1000
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=5)
+    nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))  # column 2 = hostname
+    pod.ipa = M.InterPodAffinity(key_cols=[2], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    pod.spread = [synth.zone_spread(n, max_skew=2)]
+    got = _gpu_check(ccref, nodes, pod, prof, 0)
+    assert got.per_node_count.max() == 1
