@@ -48,7 +48,8 @@ class CTerm(C.Structure):
 
 class CSpread(C.Structure):
     _fields_ = [("col", C.c_int32), ("max_skew", C.c_int32), ("min_domains", C.c_int32), ("hard", C.c_int32),
-                ("self_match", C.c_int32), ("n_domains", C.c_int32), ("node_match_count", _p32), ("node_included", _pu8)]
+                ("self_match", C.c_int32), ("n_domains", C.c_int32), ("node_match_count", _p32), ("node_included", _pu8),
+                ("is_hostname", C.c_int32)]
 
 
 class CIpa(C.Structure):
@@ -235,6 +236,7 @@ def marshal_pod(pod: M.PodSpec, keep: list) -> CPod:
         c = s.spread[i]
         c.col, c.max_skew, c.min_domains = int(k.col), int(k.max_skew), int(k.min_domains)
         c.hard, c.self_match, c.n_domains = int(bool(k.hard)), int(bool(k.self_match)), int(k.n_domains)
+        c.is_hostname = int(bool(k.is_hostname))
         if k.node_match_count is not None:
             a = np.ascontiguousarray(k.node_match_count, dtype=np.int32)
             keep.append(a)

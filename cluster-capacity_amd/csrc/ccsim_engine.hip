@@ -53,6 +53,9 @@ struct ccsim_engine {
     DevPts pts{};
     DevIpa ipa{};
     int64_t *d_ipa_partials = nullptr;
+    DevSoft soft{};
+    int64_t *d_soft_partials = nullptr;
+    std::vector<std::pair<int32_t *, size_t>> soft_flags; // epoch flag tables, cleared at the start of every run
     int64_t ipa_aff_total0 = 0, ipa_exist_total0 = 0, ipa_entries0 = 0; // initial PreFilter / PreScore totals
     int64_t ipa_aff_total_cur = 0, ipa_exist_total_cur = 0, ipa_entries_cur = 0; // ... after the runs so far
     int32_t *d_pts_min_partials = nullptr;
@@ -428,57 +431,86 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream)); // host vectors above go out of scope
 
-    // hard topology spread constraints: count tables + eligibility, built once (filtering.go:235-308)
+    // topology spread constraints: count tables + eligibility, built once.  hard -> Filter state
+    // (filtering.go:235-308), soft -> Score state (scoring.go:61-178)
     e->pts = DevPts{};
+    e->soft = DevSoft{};
     e->d_pts_min_partials = nullptr;
+    e->d_soft_partials = nullptr;
     e->pts_tables.clear();
     e->pts_table_len.clear();
+    e->soft_flags.clear();
     if (pod->n_spread < 0 || pod->n_spread > CCSIM_MAX_TSC) return fail(e, -EINVAL, "n_spread out of range");
-    if (pod->n_spread > 0 && (pf.filter_mask & CCSIM_F_TOPOLOGYSPREAD)) {
+    for (int pass = 0; pass < 2 && pod->n_spread > 0; pass++) { // pass 0: hard constraints, pass 1: soft constraints
+        const bool hard = pass == 0;
+        if (hard && !(pf.filter_mask & CCSIM_F_TOPOLOGYSPREAD)) continue;
+        if (!hard && !pf.w_topologyspread) continue;
+        std::vector<int> idx;
+        for (int c = 0; c < pod->n_spread; c++)
+            if ((pod->spread[c].hard != 0) == hard) idx.push_back(c);
+        if (idx.empty()) continue;
+        std::vector<int32_t *> lc((size_t)CCSIM_MAX_LABEL_COLS, nullptr);
+        HIPCHK(e, hipMemcpy(lc.data(), e->d_label_cols, sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyDeviceToHost));
         PtsInitArgs pi{};
         pi.n = e->n;
-        DevPts &pt = e->pts;
-        pt.n = pod->n_spread;
-        std::vector<int32_t *> d_present((size_t)pod->n_spread, nullptr);
-        for (int c = 0; c < pod->n_spread; c++) {
-            const ccsim_spread_constraint &k = pod->spread[c];
-            if (!k.hard) return fail(e, -ENOSYS, "ScheduleAnyway topology spread constraints (PodTopologySpread score) are not supported by the HIP engine yet");
+        DevPts pt{};
+        pt.n = (int32_t)idx.size();
+        std::vector<int32_t *> d_present(idx.size(), nullptr);
+        for (size_t j = 0; j < idx.size(); j++) {
+            const ccsim_spread_constraint &k = pod->spread[idx[j]];
             if (k.col < 0 || k.col >= e->n_label_cols) return fail(e, -EINVAL, "spread constraint label column out of range");
             if (k.max_skew < 1 || k.min_domains < 1 || k.n_domains < 0) return fail(e, -EINVAL, "bad spread constraint");
-            pt.max_skew[c] = k.max_skew, pt.min_domains[c] = k.min_domains, pt.self_match[c] = k.self_match ? 1 : 0;
-            std::vector<int32_t *> lc((size_t)CCSIM_MAX_LABEL_COLS, nullptr);
-            HIPCHK(e, hipMemcpy(lc.data(), e->d_label_cols, sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyDeviceToHost));
-            pt.label[c] = lc[k.col];
+            pt.max_skew[j] = k.max_skew, pt.min_domains[j] = k.min_domains, pt.self_match[j] = k.self_match ? 1 : 0;
+            pt.label[j] = lc[k.col];
             const size_t len = (size_t)k.n_domains + 1;
             int32_t *tbl = nullptr, *tbl0 = nullptr, *ex = nullptr;
             uint8_t *inc = nullptr;
             if ((rc = dev_alloc(e, &tbl, len, e->pod_allocs))) return rc;
             if ((rc = dev_alloc(e, &tbl0, len, e->pod_allocs))) return rc;
-            if ((rc = dev_alloc(e, &d_present[c], len, e->pod_allocs))) return rc;
+            if ((rc = dev_alloc(e, &d_present[j], len, e->pod_allocs))) return rc;
             if (k.node_match_count && (rc = upload(e, &ex, k.node_match_count, (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
             if (k.node_included && (rc = upload(e, &inc, k.node_included, (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
-            pt.tbl[c] = tbl;
-            pi.existing[c] = ex, pi.included[c] = inc, pi.present[c] = d_present[c];
+            pt.tbl[j] = tbl;
+            pi.existing[j] = ex, pi.included[j] = inc, pi.present[j] = d_present[j];
             e->pts_tables.emplace_back(tbl, tbl0);
             e->pts_table_len.push_back(len);
+            if (!hard) {
+                DevSoft &so = e->soft;
+                so.max_skew[j] = k.max_skew, so.self_match[j] = k.self_match ? 1 : 0, so.is_hostname[j] = k.is_hostname ? 1 : 0;
+                so.n_domains[j] = k.n_domains;
+                so.label[j] = lc[k.col], so.tbl[j] = tbl, so.existing[j] = ex;
+                int32_t *flag = nullptr;
+                if ((rc = dev_alloc(e, &flag, len, e->pod_allocs))) return rc;
+                so.flag[j] = flag;
+                e->soft_flags.emplace_back(flag, len);
+            }
         }
         uint8_t *elig = nullptr;
         if ((rc = dev_alloc(e, &elig, (size_t)e->n_pad, e->pod_allocs))) return rc;
         pt.elig = elig;
         pi.elig = elig;
         pi.pts = pt;
-        if ((rc = dev_alloc(e, &e->d_pts_min_partials, (size_t)kMaxGrid * kMaxTsc, e->pod_allocs))) return rc;
         if (e->n > 0) hipLaunchKernelGGL(k_pts_init, dim3((unsigned)((e->n + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, pi);
         HIPCHK(e, hipGetLastError());
-        for (int c = 0; c < pod->n_spread; c++) {
-            const size_t len = e->pts_table_len[c];
+        const size_t first = e->pts_tables.size() - idx.size();
+        for (size_t j = 0; j < idx.size(); j++) {
+            const size_t len = e->pts_table_len[first + j];
             std::vector<int32_t> pres(len);
-            HIPCHK(e, hipMemcpyAsync(pres.data(), d_present[c], len * 4, hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].second, e->pts_tables[c].first, len * 4, hipMemcpyDeviceToDevice, e->stream));
+            HIPCHK(e, hipMemcpyAsync(pres.data(), d_present[j], len * 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->pts_tables[first + j].second, e->pts_tables[first + j].first, len * 4, hipMemcpyDeviceToDevice, e->stream));
             HIPCHK(e, hipStreamSynchronize(e->stream));
             int32_t np_ = 0;
             for (size_t v = 1; v < len; v++) np_ += pres[v] != 0;
-            pt.n_present[c] = np_;
+            pt.n_present[j] = np_;
+        }
+        if (hard) {
+            e->pts = pt;
+            if ((rc = dev_alloc(e, &e->d_pts_min_partials, (size_t)kMaxGrid * kMaxTsc, e->pod_allocs))) return rc;
+        } else {
+            e->soft.n = pt.n, e->soft.w = pf.w_topologyspread, e->soft.elig = elig;
+            for (auto &b : e->backups)
+                if (b.first == (void *)e->cols.pod_count) e->soft.pod_count0 = (const int32_t *)b.second;
+            if ((rc = dev_alloc(e, &e->d_soft_partials, (size_t)kMaxGrid * 3, e->pod_allocs))) return rc;
         }
     }
     // InterPodAffinity: topology-pair tables per key, filled from the snapshot's pods (filtering.go:204-272, scoring.go:128-221)
@@ -578,8 +610,9 @@ static void launch_scan_t(ccsim_engine *e, const ScanArgs &a, hipEvent_t t0, hip
 }
 
 static int launch_scan(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk, e->pts, e->d_pts_min_partials, e->ipa, e->d_ipa_partials};
-    if (e->pts.n > 0 || e->ipa.on) launch_scan_t<true>(e, a, t0, t1);
+    ScanArgs a{e->cols, e->pod, e->d_state, e->d_partials, e->chunk, e->pts, e->d_pts_min_partials, e->ipa, e->d_ipa_partials,
+               e->soft, e->d_soft_partials};
+    if (e->pts.n > 0 || e->ipa.on || e->soft.n > 0) launch_scan_t<true>(e, a, t0, t1);
     else launch_scan_t<false>(e, a, t0, t1);
     return 0;
 }
@@ -599,6 +632,8 @@ static FinalArgs final_args(ccsim_engine *e) {
     f.pts_min_partials = e->d_pts_min_partials;
     f.ipa = e->ipa;
     f.ipa_partials = e->d_ipa_partials;
+    f.soft = e->soft;
+    f.soft_partials = e->d_soft_partials;
     return f;
 }
 
@@ -643,6 +678,9 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
     if (e->ipa.on && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
         return fail(e, -ENOSYS, "inter-pod affinity couples nodes through topology pairs: sequential mode on one GPU only, for now");
+    if (e->soft.n > 0 && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
+        return fail(e, -ENOSYS, "ScheduleAnyway topology spread constraints score every node against cluster-wide counts: "
+                                "sequential mode on one GPU only, for now");
     if (e->pts.n > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "batched mode is not valid with topology spread constraints (a placement changes the feasibility of "
                                 "other nodes): use CCSIM_MODE_SEQUENTIAL");
@@ -667,6 +705,9 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
         e->ipa_aff_total_cur = e->ipa_aff_total0, e->ipa_exist_total_cur = e->ipa_exist_total0, e->ipa_entries_cur = e->ipa_entries0;
     }
     st.ipa_aff_total = e->ipa_aff_total_cur, st.ipa_exist_total = e->ipa_exist_total_cur, st.ipa_entries = e->ipa_entries_cur;
+    for (int c = 0; c < kMaxTsc; c++) st.soft_size_a[c] = -1; // unknown: the first scan derives sizes and weights
+    st.soft_min_a = INT64_MAX, st.soft_max_a = 0;
+    for (auto &fl : e->soft_flags) HIPCHK(e, hipMemsetAsync(fl.first, 0, fl.second * 4, e->stream)); // epochs restart at 1
     st.limit = max_limit;
     st.winner = -1;
     st.mode = mode;
@@ -754,7 +795,8 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     // algorithmic bytes per scan: the columns the active plugin set must read once per node
     int64_t per_node = 4 /*static word*/ + 6 * 8 /*alloc,req,nz x cpu,mem*/ + 2 * 4 /*pods*/ + (int64_t)e->pod.nx * 16 +
                        (e->pts.n ? 1 + 4 * (int64_t)e->pts.n : 0) /*eligibility byte + topology value id per constraint*/ +
-                       (e->ipa.on ? 4 * (int64_t)e->ipa.n_keys : 0) /*topology value id per inter-pod affinity key*/;
+                       (e->ipa.on ? 4 * (int64_t)e->ipa.n_keys : 0) /*topology value id per inter-pod affinity key*/ +
+                       (e->soft.n ? 1 + 4 * (int64_t)e->soft.n : 0);
     out->bytes_per_scan = per_node * e->n;
     memset(out->hist, 0, sizeof(out->hist));
     out->n_code_unschedulable = 0;

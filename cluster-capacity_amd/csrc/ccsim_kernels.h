@@ -84,6 +84,20 @@ struct DevPts {
     const uint8_t *elig;           // per node: bit0 has all hard keys (filtering.go:267-270), bit 1+c counted for c (:274-277)
 };
 
+// Soft (ScheduleAnyway) PodTopologySpread constraints -> Score (P/podtopologyspread/scoring.go:61-265).
+// TopologyValueToPodCounts lives as one count table per constraint in HBM; which domains are "candidates" this
+// cycle (hold a feasible, non-ignored node) is recorded by the scan in an epoch-stamped flag table.
+struct DevSoft {
+    int32_t n, w; // soft constraints; plugin weight (0 = Score off)
+    int32_t max_skew[kMaxTsc], self_match[kMaxTsc], is_hostname[kMaxTsc], n_domains[kMaxTsc];
+    const int32_t *label[kMaxTsc];
+    int32_t *tbl[kMaxTsc];            // matching pods per domain, over counted nodes
+    int32_t *flag[kMaxTsc];           // epoch of the last scan that saw a feasible non-ignored node in the domain
+    const int32_t *existing[kMaxTsc]; // hostname constraints: matching pods already on the node (NULL = 0)
+    const int32_t *pod_count0;        // len(NodeInfo.Pods) of the loaded snapshot: pod_count - pod_count0 = clones on the node
+    const uint8_t *elig;              // per node: bit0 has all soft keys (scoring.go:84-88), bit 1+c counted for c
+};
+
 // InterPodAffinity (P/interpodaffinity/filtering.go:204-432, scoring.go:81-290): the topology-pair maps live as
 // one int64 table per distinct topology key in HBM, updated by the commit (a clone is an existing pod next cycle).
 constexpr int kMaxIpaKeys = 4, kMaxIpaTerms = 8;
@@ -103,6 +117,10 @@ struct DevState {
     int32_t pts_min_a[kMaxTsc]; // CriticalPaths[c][0].MatchNum the pending scan assumed (filtering.go:298-305)
     int64_t ipa_aff_total, ipa_exist_total, ipa_entries; // len(affinityCounts), len(existingAntiAffinityCounts), PreScore hits
     int64_t ipa_min_a, ipa_max_a;                        // NormalizeScore min / max the pending scan assumed (scoring.go:258-290)
+    // soft PodTopologySpread: what the pending scan assumed
+    int64_t soft_size_a[kMaxTsc]; // topoSize per constraint (hostname: feasible minus ignored nodes), scoring.go:96-113
+    double soft_w[kMaxTsc];       // TopologyNormalizingWeight = math.Log(size + 2)
+    int64_t soft_min_a, soft_max_a;
     int64_t placed, limit, rounds, scans;
     int64_t winner; // global index committed by the last decide (-1 none)
     int32_t done, have_prev;
@@ -281,6 +299,56 @@ __device__ __forceinline__ int64_t key_score(uint64_t key) { return (int64_t)(ke
 // k_scan: one full pods x nodes pass for the current pod spec: Filter (static bit + Fit), Score
 // (TaintToleration, NodeAffinity, LeastAllocated, BalancedAllocation), weighted sum, per-block argmax.
 // ------------------------------------------------------------------------------------------------
+// Go's math.Log (pure-Go path, go1.24 src/math/log.go = FreeBSD e_log.c): plain IEEE +,-,*,/ and frexp, so the
+// device result is bit-identical to the host oracle's (no fast-math, no FMA contraction).  scoring.go:294-296.
+__device__ __forceinline__ double go_log(double x) {
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01, L3 = 2.857142874366239149e-01,
+                 L4 = 2.222219843214978396e-01, L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                 L7 = 1.479819860511658591e-01;
+    int ki;
+    double f1 = frexp(x, &ki);
+    if (f1 < 0.70710678118654752440) {
+        f1 *= 2;
+        ki--;
+    }
+    const double f = f1 - 1;
+    const double k = (double)ki;
+    const double s = f / (2 + f);
+    const double s2 = s * s;
+    const double s4 = s2 * s2;
+    const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+// PodTopologySpread.Score (scoring.go:196-223) for a node that has all soft keys; also stamps the node's domains
+// as candidates of this scan.
+__device__ __forceinline__ int64_t soft_raw_score(const DevSoft &p, const DevState &st, const int32_t *pod_count, int64_t i,
+                                                 int32_t epoch) {
+    double score = 0;
+    for (int c = 0; c < p.n; c++) {
+        const int32_t v = p.label[c][i];
+        int64_t cnt;
+        if (p.is_hostname[c])
+            cnt = (int64_t)(p.existing[c] ? p.existing[c][i] : 0) + (p.self_match[c] ? pod_count[i] - p.pod_count0[i] : 0);
+        else {
+            cnt = p.tbl[c][v];
+            p.flag[c][v] = epoch;
+        }
+        score += (double)cnt * st.soft_w[c] + (double)(p.max_skew[c] - 1);
+    }
+    return (int64_t)round(score); // math.Round: half away from zero
+}
+
+// NormalizeScore (scoring.go:226-265)
+__device__ __forceinline__ int64_t soft_normalize(int64_t raw, int64_t mn, int64_t mx) {
+    if (mx == 0) return 100;
+    return 100 * (mx + mn - raw) / mx;
+}
+
 // InterPodAffinity.Filter (filtering.go:410-432): 0 ok, 1 affinity (Unresolvable), 2 anti-affinity, 3 existing pods' anti-affinity
 __device__ __forceinline__ int ipa_filter(const DevIpa &p, const DevState &st, int64_t i) {
     if (st.ipa_exist_total == 0 && p.n_aff == 0 && p.n_anti == 0) return 0; // PreFilter Skip (filtering.go:299-301)
@@ -333,6 +401,8 @@ struct ScanArgs {
     int32_t *pts_min_partials; // [grid][kMaxTsc]: per-block minimum match count per constraint
     DevIpa ipa;
     int64_t *ipa_partials;     // [grid][2]: per-block min / max raw InterPodAffinity score over feasible nodes
+    DevSoft soft;
+    int64_t *soft_partials;    // [grid][3]: feasible non-ignored nodes, min / max raw PodTopologySpread score
 };
 
 // PTS = the pod carries topology-coupled plugins (PodTopologySpread and / or InterPodAffinity)
@@ -351,6 +421,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     int32_t pmin[kMaxTsc];
 #pragma unroll
     for (int c = 0; c < kMaxTsc; c++) pmin[c] = 0x7fffffff;
+    int64_t soft_mn = INT64_MAX, soft_mx = 0, soft_cnt = 0; // maxScore starts at 0 (scoring.go:238)
+    const bool soft_scoring = PTS && a.soft.n > 0 && a.soft.w;
+    const int32_t epoch = (int32_t)(st.scans + 1);
     int64_t ipa_mn = INT64_MAX, ipa_mx = INT64_MIN;
     const bool ipa_scoring = PTS && a.ipa.on && a.ipa.w && st.ipa_entries > 0; // else PreScore Skip (scoring.go:199-201)
 
@@ -410,6 +483,15 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
                 const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
                 int64_t total = static_score(a.p, cnt, aff, mt, ma) +
                                 dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem);
+                if (soft_scoring) {
+                    if (a.soft.elig[i0 + k] & 1u) {
+                        const int64_t raw = soft_raw_score(a.soft, st, a.c.pod_count, i0 + k, epoch);
+                        soft_mn = raw < soft_mn ? raw : soft_mn;
+                        soft_mx = raw > soft_mx ? raw : soft_mx;
+                        soft_cnt++;
+                        total += soft_normalize(raw, st.soft_min_a, st.soft_max_a) * a.soft.w;
+                    } // ignored nodes score 0 (scoring.go:205-207, 254-257)
+                }
                 if (ipa_scoring) {
                     const int64_t raw = ipa_raw_score(a.ipa, i0 + k);
                     ipa_mn = raw < ipa_mn ? raw : ipa_mn;
@@ -471,6 +553,29 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             for (int w = 1; w < kThreads / 64; w++) v = s_pm[w][tid] < v ? s_pm[w][tid] : v;
             a.pts_min_partials[(int64_t)blockIdx.x * kMaxTsc + tid] = v;
         }
+        if (a.soft.n) {
+            __shared__ int64_t s_sm[3][kThreads / 64];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int64_t o1 = __shfl_xor(soft_mn, off, 64), o2 = __shfl_xor(soft_mx, off, 64);
+                soft_mn = o1 < soft_mn ? o1 : soft_mn;
+                soft_mx = o2 > soft_mx ? o2 : soft_mx;
+                soft_cnt += __shfl_xor(soft_cnt, off, 64);
+            }
+            if (lane == 0) s_sm[0][wave] = soft_cnt, s_sm[1][wave] = soft_mn, s_sm[2][wave] = soft_mx;
+            __syncthreads();
+            if (tid == 0) {
+                int64_t cn = 0, mn = INT64_MAX, mx = 0;
+                for (int w = 0; w < kThreads / 64; w++) {
+                    cn += s_sm[0][w];
+                    mn = s_sm[1][w] < mn ? s_sm[1][w] : mn;
+                    mx = s_sm[2][w] > mx ? s_sm[2][w] : mx;
+                }
+                a.soft_partials[3 * (int64_t)blockIdx.x] = cn;
+                a.soft_partials[3 * (int64_t)blockIdx.x + 1] = mn;
+                a.soft_partials[3 * (int64_t)blockIdx.x + 2] = mx;
+            }
+        }
         if (a.ipa.on) {
             __shared__ int64_t s_im[2][kThreads / 64];
 #pragma unroll
@@ -512,10 +617,18 @@ struct FinalArgs {
     const int32_t *pts_min_partials;
     DevIpa ipa;
     const int64_t *ipa_partials;
+    DevSoft soft;
+    const int64_t *soft_partials;
+};
+
+struct SoftAgg { // one scan's PodTopologySpread PreScore facts
+    int64_t size[kMaxTsc]; // candidate domains per constraint (hostname: feasible non-ignored nodes)
+    int64_t mn, mx;
 };
 
 __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas,
-                                              const int32_t *pts_min, int64_t ipa_mn = 0, int64_t ipa_mx = 0) {
+                                              const int32_t *pts_min, int64_t ipa_mn = 0, int64_t ipa_mx = 0,
+                                              const SoftAgg *soft = nullptr) {
     DevState st = *a.st;
     st.winner = -1;
     if (st.done) return;
@@ -534,6 +647,20 @@ __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, 
     } else if ((int32_t)mt != st.mt_a || (int32_t)ma != st.ma_a) {
         st.mt_a = (int32_t)mt;
         st.ma_a = (int32_t)ma;
+    } else if (soft && a.soft.w && [&] { // topology weights depend on the candidate-domain counts (scoring.go:96-113)
+                   bool stale = false;
+                   for (int c = 0; c < a.soft.n; c++)
+                       if (soft->size[c] != st.soft_size_a[c]) {
+                           st.soft_size_a[c] = soft->size[c];
+                           st.soft_w[c] = go_log((double)(soft->size[c] + 2));
+                           stale = true;
+                       }
+                   return stale;
+               }()) {
+        // rescan with the right weights
+    } else if (soft && a.soft.w && (soft->mn != st.soft_min_a || soft->mx != st.soft_max_a)) {
+        st.soft_min_a = soft->mn;
+        st.soft_max_a = soft->mx;
     } else if (a.ipa.on && a.ipa.w && st.ipa_entries > 0 && (ipa_mn != st.ipa_min_a || ipa_mx != st.ipa_max_a)) {
         st.ipa_min_a = ipa_mn; // InterPodAffinity scores were normalized with stale min / max: rescan
         st.ipa_max_a = ipa_mx;
@@ -553,6 +680,13 @@ __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, 
                 for (int c = 0; c < a.pts.n; c++) {
                     const int32_t v = a.pts.label[c][i];
                     if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.pts.self_match[c]) a.pts.tbl[c][v] += 1;
+                }
+            }
+            if (a.soft.n) { // scoring.go:147-178 on the next cycle
+                const uint32_t eb = a.soft.elig[i];
+                for (int c = 0; c < a.soft.n; c++) {
+                    const int32_t v = a.soft.label[c][i];
+                    if (v && !a.soft.is_hostname[c] && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.soft.self_match[c]) a.soft.tbl[c][v] += 1;
                 }
             }
             if (a.ipa.on) { // the clone is an existing pod of the next cycle (filtering.go:204-272, scoring.go:81-125)
@@ -644,6 +778,32 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         }
         if ((tid & 63) == 0) s_im[0][tid >> 6] = mn, s_im[1][tid >> 6] = mx;
     }
+    __shared__ int64_t s_sf[3 + kMaxTsc][kThreads / 64];
+    if (a.soft.n) {
+        const int32_t epoch = (int32_t)(a.st->scans + 1); // the scan that just finished stamped this value
+        int64_t cn = 0, mn = INT64_MAX, mx = 0;
+        for (int i = tid; i < a.n_partials; i += kThreads) {
+            cn += a.soft_partials[3 * (int64_t)i];
+            const int64_t q1 = a.soft_partials[3 * (int64_t)i + 1], q2 = a.soft_partials[3 * (int64_t)i + 2];
+            mn = q1 < mn ? q1 : mn;
+            mx = q2 > mx ? q2 : mx;
+        }
+        cn = wave_sum_i64(cn);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int64_t o1 = __shfl_xor(mn, off, 64), o2 = __shfl_xor(mx, off, 64);
+            mn = o1 < mn ? o1 : mn;
+            mx = o2 > mx ? o2 : mx;
+        }
+        if ((tid & 63) == 0) s_sf[0][tid >> 6] = cn, s_sf[1][tid >> 6] = mn, s_sf[2][tid >> 6] = mx;
+        for (int c = 0; c < a.soft.n; c++) { // candidate domains: value ids stamped by this scan
+            int64_t d = 0;
+            if (!a.soft.is_hostname[c])
+                for (int v = 1 + tid; v <= a.soft.n_domains[c]; v += kThreads) d += a.soft.flag[c][v] == epoch;
+            d = wave_sum_i64(d);
+            if ((tid & 63) == 0) s_sf[3 + c][tid >> 6] = d;
+        }
+    }
     __syncthreads();
     if (tid != 0) return;
     key = 0, mt = 0, ma = 0, nf = 0;
@@ -653,6 +813,21 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         mt = s_mt[w] > mt ? s_mt[w] : mt;
         ma = s_ma[w] > ma ? s_ma[w] : ma;
         nf += s_nf[w];
+    }
+    SoftAgg soft{};
+    if (a.soft.n) {
+        int64_t cn = 0;
+        soft.mn = INT64_MAX, soft.mx = 0;
+        for (int w = 0; w < kThreads / 64; w++) {
+            cn += s_sf[0][w];
+            soft.mn = s_sf[1][w] < soft.mn ? s_sf[1][w] : soft.mn;
+            soft.mx = s_sf[2][w] > soft.mx ? s_sf[2][w] : soft.mx;
+        }
+        for (int c = 0; c < a.soft.n; c++) {
+            int64_t d = 0;
+            for (int w = 0; w < kThreads / 64; w++) d += s_sf[3 + c][w];
+            soft.size[c] = a.soft.is_hostname[c] ? cn : d;
+        }
     }
     int32_t pts_min[kMaxTsc];
     for (int c = 0; c < a.pts.n; c++) {
@@ -677,7 +852,7 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         *a.xsend = r;
         return;
     }
-    decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx);
+    decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, a.soft.n ? &soft : nullptr);
 }
 
 // k_decide (distributed): every rank reduces the gathered records identically, so all ranks agree on

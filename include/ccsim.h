@@ -114,19 +114,19 @@ typedef struct {
     int32_t weight;           /* preferred terms only */
 } ccsim_term;
 
-/* One hard (whenUnsatisfiable: DoNotSchedule) topologySpreadConstraint after interning
- * (P/podtopologyspread/common.go:42-56, filtering.go:235-356).  The engine keeps TpValueToMatchNum as a
- * per-domain count table in HBM, updates it at every placement and evaluates the skew test in the scan.
- * ScheduleAnyway (score-side) constraints are not supported by the HIP engine yet: -ENOSYS. */
+/* One topologySpreadConstraint after interning (P/podtopologyspread/common.go:42-56).  hard = DoNotSchedule ->
+ * Filter (filtering.go:235-356); soft = ScheduleAnyway -> Score (scoring.go:61-265).  The engine keeps
+ * TpValueToMatchNum / TopologyPairToPodCounts as per-domain count tables in HBM, updated at every placement. */
 typedef struct {
     int32_t col;         /* label column of the topologyKey (value id 0 = node lacks the key) */
     int32_t max_skew;    /* >= 1 */
     int32_t min_domains; /* >= 1 (nil -> 1) */
-    int32_t hard;        /* must be 1 */
+    int32_t hard;        /* 1 = DoNotSchedule (filter), 0 = ScheduleAnyway (score) */
     int32_t self_match;  /* 1 if the pod's own labels match the constraint's selector (common.go:144-159) */
     int32_t n_domains;   /* value ids of `col` are 1..n_domains */
     const int32_t *node_match_count; /* [n_nodes] existing pods on the node matching the selector, NULL = 0 */
     const uint8_t *node_included;    /* [n_nodes] node inclusion policies (common.go:107-122), NULL = all */
+    int32_t is_hostname; /* topologyKey == kubernetes.io/hostname: scored per node, not per domain (scoring.go:214-215) */
 } ccsim_spread_constraint;
 
 /* InterPodAffinity in the integer world (P/interpodaffinity/{filtering.go:204-432, scoring.go:81-290}).  The

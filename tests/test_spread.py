@@ -109,5 +109,45 @@ def test_gpu_spread_rejects_batched_and_soft():
     with pytest.raises(capi.CcsimError):
         e.run(mode="batched")
     pod.spread[0].hard = False
+    e2 = capi.Engine(device=0)
+    e2.load(nodes, pod, prof)
     with pytest.raises(capi.CcsimError):
-        capi.Engine(device=0).load(nodes, pod, prof)
+        e2.run(mode="batched")
+
+
+# ---- ScheduleAnyway (soft) constraints -> Score (scoring.go:61-265) ----
+def test_ka_soft_spread_prefers_emptier_zone(ccref):
+    # 2 zones, one node each, identical; zone 1 already runs 3 matching pods.  Raw score = count * log(2 + 2) + 0:
+    # zone 1 -> round(3 * 1.386) = 4, zone 2 -> 0; normalized 100 * (4 + 0 - s) / 4 -> 0 vs 100, weight 2: node 1 wins
+    # until the counts (and the small resource-score differences) even out.
+    nodes = _zone_nodes([1, 2], [110, 110])
+    pod = H.simple_pod(100, 64 * H.MiB)
+    pod.spread = [M.SpreadConstraint(col=0, max_skew=1, hard=False, self_match=True, n_domains=2,
+                                     node_match_count=np.array([3, 0], np.int32))]
+    r = ccref.run(DEFAULT, nodes, pod, max_limit=3)
+    assert r.log.tolist() == [1, 1, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,limit,hostname", [(500, 300, False), (1500, 0, False), (700, 400, True)])
+def test_gpu_soft_spread_synthetic(ccref, n, limit, hostname):
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=40 + n)
+    pod.spread = [M.SpreadConstraint(col=1, max_skew=2, hard=False, self_match=True, n_domains=synth.zones_for(n))]
+    if hostname:
+        nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))
+        pod.spread.append(M.SpreadConstraint(col=2, max_skew=1, hard=False, self_match=True, is_hostname=True, n_domains=n))
+    _gpu_check(ccref, nodes, pod, prof, limit)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_soft_and_hard_spread_random(ccref, seed):
+    rng = np.random.default_rng(700 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 900)))
+    cons = H.random_spread(rng, nodes, n_constraints=2)
+    for k in cons:
+        k.hard = bool(rng.integers(0, 2))
+    if seed % 4 == 0:
+        cons[0].is_hostname, cons[0].hard = True, False  # scored per node instead of per domain
+    pod.spread = cons
+    _gpu_check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 70])))
