@@ -9,11 +9,13 @@ of `--limit` placements (0 = until the scheduler reports Unschedulable) against 
 snapshot.  The snapshot is resident in HBM before the timed region starts; every step first restores
 the dynamic node columns device-to-device (ccsim_reset_state, inside the timed region).
 
-Workload (BASELINE config 4, "C4"): 1M synthetic nodes, default plugin set, examples/pod.yaml +
-toleration + preferred node affinity, percentageOfNodesToScore=100.  N=1: the whole snapshot on one
-GPU.  N>1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling -- the same 1M nodes
-sharded by contiguous node range, one RCCL all-gather of a 128-byte record per pass (the max-loc
-exchange), only owning ranks update their columns.
+Workload (BASELINE config 4, "C4"): 1M synthetic nodes per GPU, default plugin set, examples/pod.yaml +
+toleration + preferred node affinity, percentageOfNodesToScore=100.  N=1: the 1M-node snapshot on one
+GPU.  N>1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- an N x 1M-node cluster
+sharded by contiguous node range (1M nodes per GPU), one RCCL all-gather of a 128-byte record per pass
+(the max-loc exchange), only owning ranks update their columns.  `--scaling strong` shards ONE 1M-node
+snapshot over the N GPUs instead (BASELINE config 4 literally); it is latency-bound by construction (the
+per-pass GPU work shrinks N-fold while the exchange does not), see DESIGN.md section 5.
 
 Modes (identical placement sequences, see tests/): `batched` resolves a whole score level (many
 placement rounds) per full pods x nodes pass; `sequential` is the literal one-round-per-pass loop.
@@ -68,7 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default="batched", choices=["sequential", "batched"])
-    ap.add_argument("--nodes", type=int, default=1_000_000, help="nodes in the whole snapshot")
+    ap.add_argument("--nodes", type=int, default=1_000_000, help="nodes per GPU (weak) / in the whole snapshot (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--limit", type=int, default=-1, help="placements per step (0 = until Unschedulable; "
                     "-1 = mode default: 0 for batched, 2048 for sequential)")
     ap.add_argument("--seq-rounds", type=int, default=2048, help="rounds of the sequential-mode sample (0 = skip)")
@@ -83,16 +86,16 @@ def main():
     import torch
 
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("CCSIM_FORCE_DIST") == "1"  # world == 1 over RCCL: a plumbing self-test
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     limit = args.limit if args.limit >= 0 else (0 if args.mode == "batched" else 2048)
-    n_global = args.nodes
+    n_global = args.nodes * world if args.scaling == "weak" else args.nodes
     lo, hi = ccdist.shard_bounds(n_global, world, rank)
-    nodes, pod, prof = synth.make_config("C4", n_nodes=hi - lo, offset=lo)
+    nodes, pod, prof = synth.make_config("C4", n_nodes=hi - lo, offset=lo, n_total=n_global)
 
     def barrier():
         if distributed:
@@ -165,7 +168,7 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-        if n_global == 1_000_000 and world == 1:
+        if hi - lo == 1_000_000:
             traffic = pmc["kernels"][kernel]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -178,12 +181,12 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
         "config": {
-            "workload": f"{n_global}-node synthetic snapshot (C4: default plugin set, examples/pod.yaml + toleration + "
+            "workload": f"{n_global}-node synthetic snapshot ({hi - lo} nodes/GPU; C4: default plugin set, examples/pod.yaml + toleration + "
                         f"preferred node affinity, percentageOfNodesToScore=100), "
                         f"{'until Unschedulable' if limit == 0 else str(limit) + ' placements'} per step",
             "mode": args.mode,

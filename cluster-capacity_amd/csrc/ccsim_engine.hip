@@ -748,6 +748,9 @@ static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block redu
             t1 = e->pass_events[e->pass_events_used++];
         }
     }
+    // the start stamp is taken when the packet is picked up, which may be while the predecessor still runs (barrier
+    // bit): drain the stream first so that t1 - t0 is this kernel alone, like rocprofv3's begin/end
+    if (t0) (void)hipStreamSynchronize(e->stream);
     if (e->mode == CCSIM_MODE_BATCHED) launch_level(e, t0, t1);
     else launch_scan(e, t0, t1);
     if (e->mode == CCSIM_MODE_BATCHED) launch_level_final(e);

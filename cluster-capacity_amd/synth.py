@@ -98,15 +98,16 @@ def examples_pod(tolerate_infra: bool = False, prefer_types: bool = False) -> M.
                      taint_filter_ok=ok, taint_prefer_cnt=cnt, preferred=preferred)
 
 
-def make_config(name: str, n_nodes: int | None = None, seed: int = SEED, offset: int = 0):
+def make_config(name: str, n_nodes: int | None = None, seed: int = SEED, offset: int = 0, n_total: int = 0):
     """BASELINE.json configs -> (nodes, pod, profile).
     C2: NodeResourcesFit only (Filter + LeastAllocated).  C3/C4: default plugin set, pod tolerates
     dedicated=infra and has preferred node affinity on instance type (weights 10, 40)."""
     name = name.upper()
     if name == "C2":
         n = n_nodes or 10_000
-        return make_nodes(n, seed, offset), examples_pod(), M.Profile.fit_only()
+        return make_nodes(n, seed, offset, n_total=n_total), examples_pod(), M.Profile.fit_only()
     if name in ("C3", "C4"):
         n = n_nodes or (100_000 if name == "C3" else 1_000_000)
-        return make_nodes(n, seed, offset), examples_pod(tolerate_infra=True, prefer_types=True), M.Profile.default()
+        return (make_nodes(n, seed, offset, n_total=n_total), examples_pod(tolerate_infra=True, prefer_types=True),
+                M.Profile.default())
     raise ValueError(name)
