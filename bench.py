@@ -21,10 +21,12 @@ Modes (identical placement sequences, see tests/): `batched` resolves a whole sc
 placement rounds) per full pods x nodes pass; `sequential` is the literal one-round-per-pass loop.
 The headline `value` is the batched mode; a sequential sample is reported next to it in `config`.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live on the dominant kernel (the full pass:
-k_level / k_scan) with HIP events on the engine's stream; `cpu_baseline` is the C oracle (a port of
-the reference algorithm -- the Go reference cannot be built here) timed on this box's host cores on
-a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` is measured live on the full pods x nodes pass (k_level_score in
+batched mode, k_scan in sequential mode: the kernel that streams every node column, 60 B/node) with HIP
+events on the engine's stream; the batched mode's other kernels (k_level_commit: sparse run-downs of the
+level's nodes off a 4-byte score cache, VALU/latency-bound; k_level_final: one block) are listed in
+profiles/.  `cpu_baseline` is the C oracle (a port of the reference algorithm -- the Go reference cannot
+be built here) timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
 
@@ -143,7 +145,7 @@ def main():
         barrier()
         seq = rs.placed / (time.perf_counter() - s0)
 
-    # roofline of the dominant kernel (the full pods x nodes pass: k_level / k_scan): its average launch
+    # roofline of the full pods x nodes pass (k_level_score / k_scan): its average launch
     # duration over one more step of the SAME workload, measured live with a HIP event pair around every
     # launch on the engine's stream (cfg.time_passes; eager launches).  rocprofv3 --kernel-trace --stats of
     # this command (profiles/) reports the same average.
@@ -162,7 +164,7 @@ def main():
         scan_s = prun.pass_kernel_ns / max(1, launches) / 1e9
         bytes_per_scan = prun.bytes_per_scan
     achieved = bytes_per_scan / scan_s / 1e9
-    kernel = "k_level" if args.mode == "batched" else "k_scan"
+    kernel = "k_level_score" if args.mode == "batched" else "k_scan"
     # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this same command
     # (scripts_gpu_pmc.sh -> profiles/r01/pmc_traffic.json); bench.py cannot profile itself.
     traffic = None

@@ -80,6 +80,8 @@ struct ccsim_engine {
     int lvl_grid = 0;
     int64_t lvl_chunk = 0;
     LevelPartial *d_lpartials = nullptr;
+    CommitPartial *d_cpartials = nullptr;
+    int32_t *d_cscore = nullptr;
     int64_t *d_blockprefix = nullptr;
     int rank = 0;
     // pristine copies of the dynamic columns (ccsim_reset_state)
@@ -297,8 +299,10 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     if (ltiles < 1) ltiles = 1;
     e->lvl_chunk = ltiles * kTile;
     e->lvl_grid = (int)((e->n_pad + e->lvl_chunk - 1) / e->lvl_chunk);
-    if ((rc = dev_alloc(e, &e->d_lpartials, (size_t)e->lvl_grid, e->allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_lpartials, (size_t)e->grid, e->allocs))) return rc;     // score pass: k_scan's geometry
+    if ((rc = dev_alloc(e, &e->d_cpartials, (size_t)e->lvl_grid, e->allocs))) return rc; // commit pass
     if ((rc = dev_alloc(e, &e->d_blockprefix, (size_t)e->lvl_grid, e->allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_cscore, np, e->allocs))) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->have_nodes = true;
     return 0;
@@ -642,15 +646,33 @@ static int launch_final(ccsim_engine *e) {
     return 0;
 }
 
-static int launch_level(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
-    LevelArgs a{e->cols, e->pod, e->d_state, e->d_lpartials, e->d_blockprefix, e->d_log, e->lvl_chunk};
+static LevelArgs level_args(ccsim_engine *e) {
+    return LevelArgs{e->cols, e->pod, e->d_state, e->d_lpartials, e->d_cpartials, e->d_blockprefix, e->d_cscore, e->d_log,
+                     e->chunk, e->lvl_chunk};
+}
+
+// the batched mode's full pods x nodes pass (k_level_score); t0/t1 as in launch_scan
+static int launch_level_score(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+    const LevelArgs a = level_args(e);
+    const int nx = e->pod.nx;
+    dim3 g(e->grid), b(kThreads);
+    if (nx == 0) CCSIM_LAUNCH(k_level_score<0>, g, b, e->stream, t0, t1, a);
+    else if (nx == 1) CCSIM_LAUNCH(k_level_score<1>, g, b, e->stream, t0, t1, a);
+    else if (nx == 2) CCSIM_LAUNCH(k_level_score<2>, g, b, e->stream, t0, t1, a);
+    else if (nx <= 4) CCSIM_LAUNCH(k_level_score<4>, g, b, e->stream, t0, t1, a);
+    else CCSIM_LAUNCH(k_level_score<kMaxExtra>, g, b, e->stream, t0, t1, a);
+    return 0;
+}
+
+static int launch_level_commit(ccsim_engine *e) {
+    const LevelArgs a = level_args(e);
     const int nx = e->pod.nx;
     dim3 g(e->lvl_grid), b(kThreads);
-    if (nx == 0) CCSIM_LAUNCH(k_level<0>, g, b, e->stream, t0, t1, a);
-    else if (nx == 1) CCSIM_LAUNCH(k_level<1>, g, b, e->stream, t0, t1, a);
-    else if (nx == 2) CCSIM_LAUNCH(k_level<2>, g, b, e->stream, t0, t1, a);
-    else if (nx <= 4) CCSIM_LAUNCH(k_level<4>, g, b, e->stream, t0, t1, a);
-    else CCSIM_LAUNCH(k_level<kMaxExtra>, g, b, e->stream, t0, t1, a);
+    if (nx == 0) hipLaunchKernelGGL(k_level_commit<0>, g, b, 0, e->stream, a);
+    else if (nx == 1) hipLaunchKernelGGL(k_level_commit<1>, g, b, 0, e->stream, a);
+    else if (nx == 2) hipLaunchKernelGGL(k_level_commit<2>, g, b, 0, e->stream, a);
+    else if (nx <= 4) hipLaunchKernelGGL(k_level_commit<4>, g, b, 0, e->stream, a);
+    else hipLaunchKernelGGL(k_level_commit<kMaxExtra>, g, b, 0, e->stream, a);
     return 0;
 }
 
@@ -658,7 +680,9 @@ static LevelFinalArgs level_final_args(ccsim_engine *e) {
     LevelFinalArgs f{};
     f.st = e->d_state;
     f.partials = e->d_lpartials;
-    f.n_partials = e->lvl_grid;
+    f.n_partials = e->grid;
+    f.cpartials = e->d_cpartials;
+    f.n_cpartials = e->lvl_grid;
     f.blockprefix = e->d_blockprefix;
     f.xsend = e->d_xsend;
     f.xrecv = e->d_xrecv;
@@ -751,8 +775,12 @@ static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block redu
     // the start stamp is taken when the packet is picked up, which may be while the predecessor still runs (barrier
     // bit): drain the stream first so that t1 - t0 is this kernel alone, like rocprofv3's begin/end
     if (t0) (void)hipStreamSynchronize(e->stream);
-    if (e->mode == CCSIM_MODE_BATCHED) launch_level(e, t0, t1);
-    else launch_scan(e, t0, t1);
+    if (e->mode == CCSIM_MODE_BATCHED) {
+        launch_level_commit(e); // the level found by the previous pass (sparse: reads the 4-byte score cache)
+        if (t0) (void)hipStreamSynchronize(e->stream);
+        launch_level_score(e, t0, t1);
+    } else
+        launch_scan(e, t0, t1);
     if (e->mode == CCSIM_MODE_BATCHED) launch_level_final(e);
     else launch_final(e);
 }
@@ -927,10 +955,10 @@ extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int
     e->n_ranks = 0;
     if ((rc = begin_run(e, 0, mode, 0))) return rc; // fresh state: a finished run leaves done != 0
     HIPCHK(e, hipSetDevice(e->device));
-    const bool lvl = mode == CCSIM_MODE_BATCHED; // k_level with nothing planned: Filter + Score + plan, no commit
-    for (int i = 0; i < 3; i++) lvl ? launch_level(e) : launch_scan(e);
+    const bool lvl = mode == CCSIM_MODE_BATCHED; // k_level_score: the batched mode's full pass
+    for (int i = 0; i < 3; i++) lvl ? launch_level_score(e) : launch_scan(e);
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    for (int i = 0; i < iters; i++) lvl ? launch_level(e) : launch_scan(e);
+    for (int i = 0; i < iters; i++) lvl ? launch_level_score(e) : launch_scan(e);
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipGetLastError());

@@ -132,6 +132,7 @@ struct DevState {
     int64_t lvl_cut;         // commit only nodes with global index <= cut (normalization change inside the level)
     int64_t lvl_remaining;   // placements still allowed (limit - placed at level start)
     int64_t lvl_rank_prefix; // placements of this level that belong to lower-ranked shards
+    int64_t lvl_c_mt, lvl_c_ma; // feasible holders of the normalization maxima when the level was found
     int32_t lvl_valid;       // 1 = the next pass commits level lvl_M
     int32_t lvl_prefix;      // 1 = ordered commit (limit inside the level, or placement log wanted)
     int32_t lvl_plan_only;   // 1 = the next pass only measures level lvl_M (no commit)

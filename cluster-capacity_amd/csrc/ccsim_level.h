@@ -40,18 +40,13 @@ namespace ccsim {
 
 constexpr int64_t kNoCut = (int64_t)1 << 62;
 
-// per-block result of one pass: 96 bytes
+// per-block result of the score pass: 32 bytes
 struct __attribute__((aligned(16))) LevelPartial {
-    uint64_t key;        // post-commit block max: ((score+1) << 40) | (2^40-1 - global idx); 0 = nothing feasible
-    uint32_t mt, ma;     // max prefer-count / affinity-sum over the block's post-commit feasible nodes
+    uint64_t key;        // block max: ((score+1) << 40) | (2^40-1 - global idx); 0 = nothing feasible
+    uint32_t mt, ma;     // max prefer-count / affinity-sum over the block's feasible nodes
     uint32_t c_mt, c_ma; // how many feasible nodes hold those block maxima
     uint32_t nfeas;
     uint32_t n_top;      // how many nodes hold the block's maximum score
-    uint32_t e_mt, e_ma; // plan pass: holders of st.mt_a / st.ma_a that their run-down exhausts
-    int64_t T;              // plan pass: placements of the block's nodes at level st.lvl_M
-    int64_t cut_mt, cut_ma; // plan pass: highest global index among those exhausted holders (-1 none)
-    int64_t committed;      // placements committed by this block in this pass
-    int64_t pad;
 };
 
 // one node in registers
@@ -126,7 +121,10 @@ __device__ __forceinline__ NodeRegs<NX> bcast_node(const NodeRegs<NX> &n, int sr
 //      l+1 further placements (closed form), and one __ballot finds the first placement after which the node
 //      is infeasible or scores < M: <= 2 steps for a 110-pod node instead of 110 dependent iterations.
 // Returns this lane's run-down length (0 if !mine) and whether its node is still feasible afterwards.
-constexpr int kSeqSteps = 6;
+#ifndef CCSIM_SEQ_STEPS
+#define CCSIM_SEQ_STEPS 6
+#endif
+constexpr int kSeqSteps = CCSIM_SEQ_STEPS;
 
 template <int NX>
 __device__ __forceinline__ int32_t wave_run_down(const DevPod &p, const NodeRegs<NX> &n, int64_t stat, int64_t M, bool mine,
@@ -251,56 +249,48 @@ __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v) {
     return v;
 }
 
+struct __attribute__((aligned(16))) CommitPartial { // per k_level_commit block: 48 bytes
+    int64_t committed;      // placements committed by this block in this pass
+    int64_t T;              // plan pass: placements of the block's nodes at level st.lvl_M
+    int64_t cut_mt, cut_ma; // plan pass: highest global index among exhausted holders of st.mt_a / st.ma_a (-1 none)
+    uint32_t e_mt, e_ma;    // plan pass: how many holders their run-down exhausts
+    int64_t pad;
+};
+
 struct LevelArgs {
     DevCols c;
     DevPod p;
     const DevState *st;
-    LevelPartial *partials;
-    const int64_t *blockprefix; // [grid] exclusive prefix of the planned level's per-block placements
+    LevelPartial *partials;     // k_level_score: one per block
+    CommitPartial *cpartials;   // k_level_commit: one per block
+    const int64_t *blockprefix; // [commit grid] exclusive prefix of the planned level's per-block placements
+    int32_t *cscore;            // TotalScore of every node under (mt_a, ma_a), -1 = infeasible: written by the score
+                                // pass, read by the commit pass to find the level without re-evaluating anything
     int32_t *log;
-    int64_t chunk; // nodes per block (multiple of kTile)
+    int64_t chunk;  // nodes per k_level_score block (multiple of kTile)
+    int64_t cchunk; // nodes per k_level_commit block
 };
 
-// Level nodes are sparse (a few % of a tile) and a run-down costs hundreds of VALU instructions per step,
-// so they are COMPACTED: owners append their level nodes (registers + static score + index) to a block-wide
-// LDS work list in canonical order (ballot/popcount prefix), and the first lanes of the block take one
-// entry each -- the run-downs of a whole tile execute in a handful of densely packed waves instead of one
-// or two active lanes in every wave.  The worker lane also commits the node (closed-form update, stores)
-// and scores it in its new state; the owner skips it.
-constexpr int kListCap = kThreads; // entries per round (one per worker lane)
-
+// single-node load (commit pass workers: sparse)
 template <int NX>
-struct LevelList { // structure-of-arrays in LDS: conflict-free per-lane access
-    int64_t f64[7 + 2 * NX][kListCap]; // a_cpu a_mem r_cpu r_mem z_cpu z_mem stat, xa[NX], xr[NX]
-    int64_t idx[kListCap];             // node index inside the shard
-    int32_t f32[3][kListCap];          // a_pods npods w
-};
-
-template <int NX>
-__device__ __forceinline__ void list_put(LevelList<NX> &L, int pos, const NodeRegs<NX> &n, int64_t stat, int64_t idx) {
-    L.f64[0][pos] = n.a_cpu, L.f64[1][pos] = n.a_mem, L.f64[2][pos] = n.r_cpu, L.f64[3][pos] = n.r_mem;
-    L.f64[4][pos] = n.z_cpu, L.f64[5][pos] = n.z_mem, L.f64[6][pos] = stat;
+__device__ __forceinline__ void load_one(const DevCols &c, const DevPod &p, int64_t i, NodeRegs<NX> &n) {
+    n.w = c.stat[i];
+    n.a_cpu = c.alloc[0][i], n.a_mem = c.alloc[1][i];
+    n.r_cpu = c.req[0][i], n.r_mem = c.req[1][i];
+    n.z_cpu = c.nz_mcpu[i], n.z_mem = c.nz_mem[i];
+    n.a_pods = c.alloc_pods[i], n.npods = c.pod_count[i];
 #pragma unroll
-    for (int x = 0; x < NX; x++) L.f64[7 + x][pos] = n.xa[x], L.f64[7 + NX + x][pos] = n.xr[x];
-    L.idx[pos] = idx;
-    L.f32[0][pos] = n.a_pods, L.f32[1][pos] = n.npods, L.f32[2][pos] = (int32_t)n.w;
-}
-
-template <int NX>
-__device__ __forceinline__ void list_get(const LevelList<NX> &L, int pos, NodeRegs<NX> &n, int64_t &stat, int64_t &idx) {
-    n.a_cpu = L.f64[0][pos], n.a_mem = L.f64[1][pos], n.r_cpu = L.f64[2][pos], n.r_mem = L.f64[3][pos];
-    n.z_cpu = L.f64[4][pos], n.z_mem = L.f64[5][pos], stat = L.f64[6][pos];
-    n.xa[0] = n.xr[0] = 0;
-#pragma unroll
-    for (int x = 0; x < NX; x++) n.xa[x] = L.f64[7 + x][pos], n.xr[x] = L.f64[7 + NX + x][pos];
-    idx = L.idx[pos];
-    n.a_pods = L.f32[0][pos], n.npods = L.f32[1][pos], n.w = (uint32_t)L.f32[2][pos];
+    for (int x = 0; x < (NX > 0 ? NX : 1); x++) {
+        const bool on = NX > 0 && x < p.nx;
+        n.xa[x] = on ? c.alloc[p.xcol[x]][i] : 0;
+        n.xr[x] = on ? c.req[p.xcol[x]][i] : 0;
+    }
 }
 
 // running reduction state of one thread over the nodes it scored
 struct LevelAcc {
     uint64_t best = 0;
-    int64_t top = -1; // maximum post-commit score seen by this thread and how many of its nodes hold it
+    int64_t top = -1; // maximum score seen by this thread and how many of its nodes hold it
     uint32_t ntop = 0, mt = 0, ma = 0, cmt = 0, cma = 0, nfeas = 0;
     __device__ __forceinline__ void add(int64_t score, int64_t gidx, uint32_t cnt, uint32_t aff) {
         const uint64_t key = make_key(score, gidx);
@@ -312,140 +302,44 @@ struct LevelAcc {
     }
 };
 
-#ifndef CCSIM_LEVEL_WAVES
-#define CCSIM_LEVEL_WAVES 3
-#endif
+// ------------------------------------------------------------------------------------------------
+// k_level_score: the full pods x nodes pass of the batched mode.  Filter + Score of every node (same arithmetic and
+// bytes as k_scan), the packed max key, the size of the top level, the normalization maxima with their holder
+// counts, the feasible count -- and one int32 per node: its TotalScore (the commit pass's index of the level).
+// No barriers, no LDS list: it runs at k_scan's occupancy.  HBM roofline: 60 B read (+ 4 B written) per node.
+// ------------------------------------------------------------------------------------------------
 template <int NX>
-__global__ __launch_bounds__(kThreads, CCSIM_LEVEL_WAVES) void k_level(LevelArgs a) {
+__global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
     const DevState st = *a.st;
-    if (st.done) return;
+    if (st.done || st.lvl_plan_only) return; // a plan pass moves nothing: the previous scores stand
     constexpr int kWaves = kThreads / 64;
-    __shared__ LevelList<NX> s_list;
     __shared__ uint64_t s_key[kWaves];
-    __shared__ uint32_t s_u[8][kWaves];
-    __shared__ int64_t s_l[4][kWaves];
-    __shared__ int32_t s_cnt[2][kWaves]; // double-buffered by tile parity (no barrier between tiles when a tile has no level node)
-
+    __shared__ uint32_t s_u[6][kWaves];
     const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t lo = (int64_t)blockIdx.x * a.chunk;
     int64_t hi = lo + a.chunk;
     if (hi > a.c.n_pad) hi = a.c.n_pad;
-    const bool plan_only = st.lvl_plan_only != 0;
-    const bool commit_on = st.lvl_valid != 0 && !plan_only;
-    const bool active = commit_on || plan_only;
-    const bool ordered = commit_on && st.lvl_prefix != 0;
-    const int64_t M = st.lvl_M;
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
     LevelAcc acc;
-    int64_t committed = 0;
-    int64_t carry = ordered ? st.lvl_rank_prefix + a.blockprefix[blockIdx.x] : 0;
-    int64_t T = 0, cut_mt = -1, cut_ma = -1; // plan pass
-    uint32_t e_mt = 0, e_ma = 0;
-
-    int par = 0;
-    for (int64_t base = lo; base < hi; base += kTile, par ^= 1) {
+    for (int64_t base = lo; base < hi; base += kTile) {
         const int64_t i0 = base + 2 * tid;
         NodeRegs<NX> nd[2];
         load_pair<NX>(a.c, a.p, i0, nd);
-        bool feas[2], lvl[2];
-        int64_t sc[2], stat[2];
+        int2 cs;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const uint32_t cnt = (nd[k].w >> kStatCntShift) & kStatCntMask, aff = nd[k].w & kStatAffMask;
-            stat[k] = static_score(a.p, cnt, aff, mt, ma);
-            feas[k] = node_feasible<NX>(a.p, nd[k]);
-            sc[k] = feas[k] ? node_score<NX>(a.p, nd[k], stat[k]) : -1;
-            lvl[k] = active && feas[k] && sc[k] == M && (a.c.global_offset + i0 + k) <= st.lvl_cut;
-        }
-        // nodes that are not in the level keep their state: scored by their owner (before the worker phase, so
-        // that the pair's registers are dead while the work list is processed)
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (feas[k] && !lvl[k]) {
+            int32_t sc = -1;
+            if (node_feasible<NX>(a.p, nd[k])) {
                 const uint32_t cnt = (nd[k].w >> kStatCntShift) & kStatCntMask, aff = nd[k].w & kStatAffMask;
-                acc.add(sc[k], a.c.global_offset + i0 + k, cnt, aff);
+                const int64_t s64 = node_score<NX>(a.p, nd[k], static_score(a.p, cnt, aff, mt, ma));
+                acc.add(s64, a.c.global_offset + i0 + k, cnt, aff);
+                sc = (int32_t)s64;
             }
+            (k ? cs.y : cs.x) = sc;
         }
-        if (active) { // block-uniform
-            // canonical-order position of this thread's level nodes in the block's work list
-            const uint64_t b0 = __ballot(lvl[0]), b1 = __ballot(lvl[1]);
-            if (lane == 0) s_cnt[par][wave] = __popcll(b0) + __popcll(b1);
-            __syncthreads();
-            int off = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask), total = 0;
-#pragma unroll
-            for (int w = 0; w < kWaves; w++) {
-                if (w < wave) off += s_cnt[par][w];
-                total += s_cnt[par][w];
-            }
-            const int pos0 = off, pos1 = off + (lvl[0] ? 1 : 0);
-            for (int r0 = 0; r0 < total; r0 += kListCap) { // block-uniform; > 1 round only for dense levels
-                if (lvl[0] && pos0 >= r0 && pos0 < r0 + kListCap) list_put<NX>(s_list, pos0 - r0, nd[0], stat[0], i0);
-                if (lvl[1] && pos1 >= r0 && pos1 < r0 + kListCap) list_put<NX>(s_list, pos1 - r0, nd[1], stat[1], i0 + 1);
-                __syncthreads();
-                const int nwork = total - r0 < kListCap ? total - r0 : kListCap;
-                const bool mine = tid < nwork;
-                NodeRegs<NX> n;
-                int64_t nstat = 0, nidx = 0;
-                n.a_cpu = n.a_mem = n.r_cpu = n.r_mem = n.z_cpu = n.z_mem = 0, n.a_pods = n.npods = 0, n.w = 0;
-#pragma unroll
-                for (int x = 0; x < (NX > 0 ? NX : 1); x++) n.xa[x] = n.xr[x] = 0;
-                if (mine) list_get<NX>(s_list, tid, n, nstat, nidx);
-                bool fend = true;
-                int64_t j = 0;
-                if ((wave * 64) < nwork) j = wave_run_down<NX>(a.p, n, nstat, M, mine, fend); // wave-uniform
-                const int64_t g = a.c.global_offset + nidx;
-                const uint32_t cnt = (n.w >> kStatCntShift) & kStatCntMask, aff = n.w & kStatAffMask;
-                if (plan_only) {
-                    if (mine) {
-                        T += j;
-                        if (!fend) {
-                            if (mt > 0 && cnt == mt) e_mt++, cut_mt = g > cut_mt ? g : cut_mt;
-                            if (ma > 0 && aff == ma) e_ma++, cut_ma = g > cut_ma ? g : cut_ma;
-                        }
-                        acc.add(M, g, cnt, aff); // unchanged: still feasible at level M
-                    }
-                } else {
-                    int64_t took = j, pos = 0;
-                    if (ordered) { // position of this node's first placement inside the level
-                        const int64_t incl = wave_incl_scan_i64(j);
-                        __syncthreads(); // s_l reuse across rounds
-                        if (lane == 63) s_l[0][wave] = incl;
-                        __syncthreads();
-                        int64_t before = 0, tot = 0;
-#pragma unroll
-                        for (int w = 0; w < kWaves; w++) {
-                            if (w < wave) before += s_l[0][w];
-                            tot += s_l[0][w];
-                        }
-                        pos = carry + before + incl - j;
-                        carry += tot;
-                        int64_t allowed = st.lvl_remaining - pos;
-                        if (allowed < 0) allowed = 0;
-                        if (took > allowed) took = allowed;
-                    }
-                    if (mine) {
-                        if (took > 0) {
-                            node_apply<NX>(a.p, n, took);
-                            store_dyn<NX>(a.c, a.p, nidx, n, (int32_t)took);
-                            committed += took;
-                            if (ordered && a.log) {
-                                for (int64_t q = 0; q < took; q++) {
-                                    const int64_t at = st.placed + pos + q;
-                                    if (at < st.log_cap) a.log[at] = (int32_t)g;
-                                }
-                            }
-                        }
-                        if (node_feasible<NX>(a.p, n)) acc.add(node_score<NX>(a.p, n, nstat), g, cnt, aff);
-                    }
-                }
-                __syncthreads(); // the list is rewritten next round / next tile
-            }
-        }
+        *reinterpret_cast<int2 *>(a.cscore + i0) = cs;
     }
-
-    // ---- block reduce ----
     {
         const uint64_t wbest = wave_max_u64(acc.best);
         const int64_t wtop = wave_max_i64(acc.top);
@@ -453,25 +347,14 @@ __global__ __launch_bounds__(kThreads, CCSIM_LEVEL_WAVES) void k_level(LevelArgs
         const uint32_t wntop = wave_sum_u32(acc.top == wtop ? acc.ntop : 0u);
         const uint32_t wcmt = wave_sum_u32(acc.mt == wmt ? acc.cmt : 0u), wcma = wave_sum_u32(acc.ma == wma ? acc.cma : 0u);
         const uint32_t wnf = wave_sum_u32(acc.nfeas);
-        committed = wave_sum_i64(committed);
-        if (plan_only) { // block-uniform
-            T = wave_sum_i64(T);
-            cut_mt = wave_max_i64(cut_mt);
-            cut_ma = wave_max_i64(cut_ma);
-            e_mt = wave_sum_u32(e_mt);
-            e_ma = wave_sum_u32(e_ma);
-        }
         if (lane == 0) {
             s_key[wave] = wbest;
-            s_u[0][wave] = wmt, s_u[1][wave] = wma, s_u[2][wave] = wcmt, s_u[3][wave] = wcma, s_u[4][wave] = wnf;
-            s_u[5][wave] = wntop, s_u[6][wave] = e_mt, s_u[7][wave] = e_ma;
-            s_l[0][wave] = T, s_l[1][wave] = committed, s_l[2][wave] = cut_mt, s_l[3][wave] = cut_ma;
+            s_u[0][wave] = wmt, s_u[1][wave] = wma, s_u[2][wave] = wcmt, s_u[3][wave] = wcma, s_u[4][wave] = wnf, s_u[5][wave] = wntop;
         }
     }
     __syncthreads();
     if (tid == 0) {
         LevelPartial out{};
-        out.cut_mt = out.cut_ma = -1;
 #pragma unroll
         for (int w = 0; w < kWaves; w++) {
             const uint64_t kw = s_key[w];
@@ -481,13 +364,171 @@ __global__ __launch_bounds__(kThreads, CCSIM_LEVEL_WAVES) void k_level(LevelArgs
             if (s_u[0][w] > out.mt) out.mt = s_u[0][w], out.c_mt = s_u[2][w]; else if (s_u[0][w] == out.mt) out.c_mt += s_u[2][w];
             if (s_u[1][w] > out.ma) out.ma = s_u[1][w], out.c_ma = s_u[3][w]; else if (s_u[1][w] == out.ma) out.c_ma += s_u[3][w];
             out.nfeas += s_u[4][w];
-            out.e_mt += s_u[6][w], out.e_ma += s_u[7][w];
+        }
+        a.partials[blockIdx.x] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_level_commit: commits (or, in a plan pass, only measures) the level st.lvl_M.  Reads 4 B per node (the cached
+// TotalScore) to find the level; level nodes are sparse (a few % of a tile) and a run-down costs hundreds of VALU
+// instructions per step, so they are COMPACTED: owners append their level nodes' indices to a block-wide LDS work
+// list in canonical order (ballot/popcount prefix), and the first lanes of the block take one entry each, gather
+// the node's columns, run it down (wave_run_down) and rewrite its columns -- a tile's run-downs execute in one or
+// two densely packed waves.  Ordered commits (limit / log) add an exclusive scan of the run-down lengths.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGroupTiles = 4; // tiles compacted together: 2048 nodes, 8 KiB of LDS work list
+
+template <int NX>
+__global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
+    const DevState st = *a.st;
+    if (st.done) return;
+    const bool plan_only = st.lvl_plan_only != 0;
+    const bool commit_on = st.lvl_valid != 0 && !plan_only;
+    if (!plan_only && !commit_on) return; // nothing planned (first pass, or the constants just changed)
+    constexpr int kWaves = kThreads / 64;
+    __shared__ int32_t s_idx[kGroupTiles * kTile]; // work list: node index relative to the block's chunk, canonical order
+    __shared__ uint32_t s_u[2][kWaves];
+    __shared__ int64_t s_l[4][kWaves];
+    __shared__ int32_t s_cnt[kGroupTiles][kWaves];
+
+    const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t lo = (int64_t)blockIdx.x * a.cchunk;
+    int64_t hi = lo + a.cchunk;
+    if (hi > a.c.n_pad) hi = a.c.n_pad;
+    const bool ordered = commit_on && st.lvl_prefix != 0;
+    const int32_t M = (int32_t)st.lvl_M;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+    int64_t committed = 0;
+    int64_t carry = ordered ? st.lvl_rank_prefix + a.blockprefix[blockIdx.x] : 0;
+    int64_t T = 0, cut_mt = -1, cut_ma = -1; // plan pass
+    uint32_t e_mt = 0, e_ma = 0;
+
+    // Tiles are handled in groups of kGroupTiles: ONE compaction and ONE worker phase per group (the phases of a
+    // block are latency chains -- gather loads, dependent run-down steps -- so fewer, fuller phases win).
+    for (int64_t gbase = lo; gbase < hi; gbase += (int64_t)kGroupTiles * kTile) {
+        uint32_t flags = 0; // bit 2t / 2t+1: this thread's first / second node of tile t holds the level
+        int wcnt[kGroupTiles];
+#pragma unroll
+        for (int t = 0; t < kGroupTiles; t++) {
+            const int64_t base = gbase + (int64_t)t * kTile;
+            wcnt[t] = 0;
+            if (base < hi) { // block-uniform
+                const int64_t i0 = base + 2 * tid;
+                const int2 cs = *reinterpret_cast<const int2 *>(a.cscore + i0);
+                const bool l0 = cs.x == M && (a.c.global_offset + i0) <= st.lvl_cut;
+                const bool l1 = cs.y == M && (a.c.global_offset + i0 + 1) <= st.lvl_cut;
+                const uint64_t b0 = __ballot(l0), b1 = __ballot(l1);
+                flags |= (l0 ? 1u : 0u) << (2 * t) | (l1 ? 1u : 0u) << (2 * t + 1);
+                wcnt[t] = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask); // level nodes of lower lanes in this wave
+                if (lane == 0) s_cnt[t][wave] = __popcll(b0) + __popcll(b1);
+            } else if (lane == 0)
+                s_cnt[t][wave] = 0;
+        }
+        __syncthreads();
+        // canonical order: tile-major, then thread, then the thread's two nodes
+        int total = 0;
+#pragma unroll
+        for (int t = 0; t < kGroupTiles; t++) {
+            int off = total + wcnt[t];
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) {
+                if (w < wave) off += s_cnt[t][w];
+                total += s_cnt[t][w];
+            }
+            const int64_t i0 = gbase + (int64_t)t * kTile + 2 * tid;
+            if (flags & (1u << (2 * t))) s_idx[off] = (int32_t)(i0 - lo), off++;
+            if (flags & (1u << (2 * t + 1))) s_idx[off] = (int32_t)(i0 + 1 - lo);
+        }
+        __syncthreads();
+        for (int r0 = 0; r0 < total; r0 += kThreads) { // one entry per worker lane per round
+            const int nwork = total - r0 < kThreads ? total - r0 : kThreads;
+            const bool mine = tid < nwork;
+            NodeRegs<NX> n;
+            n.a_cpu = n.a_mem = n.r_cpu = n.r_mem = n.z_cpu = n.z_mem = 0, n.a_pods = n.npods = 0, n.w = 0;
+#pragma unroll
+            for (int x = 0; x < (NX > 0 ? NX : 1); x++) n.xa[x] = n.xr[x] = 0;
+            int64_t nidx = 0;
+            if (mine) {
+                nidx = lo + s_idx[r0 + tid];
+                load_one<NX>(a.c, a.p, nidx, n);
+            }
+            const uint32_t cnt = (n.w >> kStatCntShift) & kStatCntMask, aff = n.w & kStatAffMask;
+            const int64_t nstat = static_score(a.p, cnt, aff, mt, ma);
+            bool fend = true;
+            int64_t j = 0;
+            if ((wave * 64) < nwork) j = wave_run_down<NX>(a.p, n, nstat, M, mine, fend); // wave-uniform
+            const int64_t g = a.c.global_offset + nidx;
+            if (plan_only) {
+                if (mine) {
+                    T += j;
+                    if (!fend) {
+                        if (mt > 0 && cnt == mt) e_mt++, cut_mt = g > cut_mt ? g : cut_mt;
+                        if (ma > 0 && aff == ma) e_ma++, cut_ma = g > cut_ma ? g : cut_ma;
+                    }
+                }
+            } else {
+                int64_t took = j, pos = 0;
+                if (ordered) { // position of this node's first placement inside the level
+                    const int64_t incl = wave_incl_scan_i64(j);
+                    __syncthreads(); // s_l reuse across rounds
+                    if (lane == 63) s_l[0][wave] = incl;
+                    __syncthreads();
+                    int64_t before = 0, tot = 0;
+#pragma unroll
+                    for (int w = 0; w < kWaves; w++) {
+                        if (w < wave) before += s_l[0][w];
+                        tot += s_l[0][w];
+                    }
+                    pos = carry + before + incl - j;
+                    carry += tot;
+                    int64_t allowed = st.lvl_remaining - pos;
+                    if (allowed < 0) allowed = 0;
+                    if (took > allowed) took = allowed;
+                }
+                if (mine && took > 0) {
+                    node_apply<NX>(a.p, n, took);
+                    store_dyn<NX>(a.c, a.p, nidx, n, (int32_t)took);
+                    committed += took;
+                    if (ordered && a.log) {
+                        for (int64_t q = 0; q < took; q++) {
+                            const int64_t at = st.placed + pos + q;
+                            if (at < st.log_cap) a.log[at] = (int32_t)g;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads(); // the list and the counters are rewritten by the next group
+    }
+
+    committed = wave_sum_i64(committed);
+    if (plan_only) { // block-uniform
+        T = wave_sum_i64(T);
+        cut_mt = wave_max_i64(cut_mt);
+        cut_ma = wave_max_i64(cut_ma);
+        e_mt = wave_sum_u32(e_mt);
+        e_ma = wave_sum_u32(e_ma);
+    }
+    if (lane == 0) {
+        s_u[0][wave] = e_mt, s_u[1][wave] = e_ma;
+        s_l[0][wave] = T, s_l[1][wave] = committed, s_l[2][wave] = cut_mt, s_l[3][wave] = cut_ma;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        CommitPartial out{};
+        out.cut_mt = out.cut_ma = -1;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+            out.e_mt += s_u[0][w], out.e_ma += s_u[1][w];
             out.T += s_l[0][w];
             out.committed += s_l[1][w];
             out.cut_mt = s_l[2][w] > out.cut_mt ? s_l[2][w] : out.cut_mt;
             out.cut_ma = s_l[3][w] > out.cut_ma ? s_l[3][w] : out.cut_ma;
         }
-        a.partials[blockIdx.x] = out;
+        a.cpartials[blockIdx.x] = out;
     }
 }
 
@@ -510,8 +551,8 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
         st.lvl_plan_only = 0;
         st.lvl_valid = 1;
         int64_t cut = kNoCut;
-        if (st.mt_a > 0 && g.e_mt == (int64_t)g.c_mt && g.cut_mt < cut) cut = g.cut_mt;
-        if (st.ma_a > 0 && g.e_ma == (int64_t)g.c_ma && g.cut_ma < cut) cut = g.cut_ma;
+        if (st.mt_a > 0 && g.e_mt == st.lvl_c_mt && g.cut_mt < cut) cut = g.cut_mt; // every feasible holder exhausted
+        if (st.ma_a > 0 && g.e_ma == st.lvl_c_ma && g.cut_ma < cut) cut = g.cut_ma;
         st.lvl_cut = cut;
         st.lvl_remaining = st.limit > 0 ? st.limit - st.placed : kNoCut;
         st.lvl_prefix = (want_log || (st.limit > 0 && st.placed + g.T > st.limit)) ? 1 : 0;
@@ -537,6 +578,8 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
         return;
     }
     st.lvl_M = key_score(g.key);
+    st.lvl_c_mt = g.c_mt; // holder counts of the maxima, for the plan pass's "all holders exhausted?" test
+    st.lvl_c_ma = g.c_ma;
     st.lvl_cut = kNoCut;
     st.lvl_remaining = kNoCut;
     st.lvl_prefix = 0;
@@ -551,8 +594,10 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
 
 struct LevelFinalArgs {
     DevState *st;
-    const LevelPartial *partials;
+    const LevelPartial *partials; // score pass
     int32_t n_partials;
+    const CommitPartial *cpartials; // commit pass
+    int32_t n_cpartials;
     int64_t *blockprefix;
     XRec *xsend;       // distributed: this shard's record out
     const XRec *xrecv; // distributed: gathered records in
@@ -561,9 +606,9 @@ struct LevelFinalArgs {
     int32_t want_log;
 };
 
-// k_level_final: one block of kFinalThreads.  Reduces the per-block partials in ONE sweep (the block is
-// latency-bound: every thread reads at most a couple of 96-byte partials); on one GPU also decides.  After a
-// plan pass it leaves the exclusive per-block prefix of the level's placements in blockprefix[].
+// k_level_final: one block.  Reduces the per-block partials of the pass that just ran (commit partials: what was
+// committed or planned; score partials: the next level) in one sweep each; on one GPU also decides.  After a plan
+// pass it leaves the exclusive per-block prefix of the level's placements in blockprefix[].
 constexpr int kFinalThreads = 256;
 
 __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a) {
@@ -574,25 +619,31 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
     __shared__ int64_t s_l[8][kWaves];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool plan_pass = a.st->lvl_plan_only != 0;
+    const bool commit_ran = plan_pass || a.st->lvl_valid != 0; // else k_level_commit exited without writing partials
 
     uint64_t key = 0;
     uint32_t mt = 0, cmt = 0, ma = 0, cma = 0;
     int64_t nf = 0, committed = 0, T = 0, e_mt = 0, e_ma = 0, cut_mt = -1, cut_ma = -1, ntop = 0;
-    for (int i = tid; i < a.n_partials; i += kFinalThreads) {
-        const LevelPartial q = a.partials[i];
-        if (q.key) { // size of the top level: nodes holding the maximum score, over the blocks whose maximum it is
-            if (!key || key_score(q.key) > key_score(key)) ntop = q.n_top;
-            else if (key_score(q.key) == key_score(key)) ntop += q.n_top;
+    if (!plan_pass) // a plan pass skips the score pass: nothing moved, its partials are the previous pass's
+        for (int i = tid; i < a.n_partials; i += kFinalThreads) {
+            const LevelPartial q = a.partials[i];
+            if (q.key) { // size of the top level: nodes holding the maximum score, over the blocks whose maximum it is
+                if (!key || key_score(q.key) > key_score(key)) ntop = q.n_top;
+                else if (key_score(q.key) == key_score(key)) ntop += q.n_top;
+            }
+            key = q.key > key ? q.key : key;
+            if (q.mt > mt) mt = q.mt, cmt = q.c_mt; else if (q.mt == mt) cmt += q.c_mt;
+            if (q.ma > ma) ma = q.ma, cma = q.c_ma; else if (q.ma == ma) cma += q.c_ma;
+            nf += q.nfeas;
         }
-        key = q.key > key ? q.key : key;
-        if (q.mt > mt) mt = q.mt, cmt = q.c_mt; else if (q.mt == mt) cmt += q.c_mt;
-        if (q.ma > ma) ma = q.ma, cma = q.c_ma; else if (q.ma == ma) cma += q.c_ma;
-        nf += q.nfeas;
-        committed += q.committed;
-        T += q.T, e_mt += q.e_mt, e_ma += q.e_ma;
-        cut_mt = q.cut_mt > cut_mt ? q.cut_mt : cut_mt;
-        cut_ma = q.cut_ma > cut_ma ? q.cut_ma : cut_ma;
-    }
+    if (commit_ran)
+        for (int i = tid; i < a.n_cpartials; i += kFinalThreads) {
+            const CommitPartial q = a.cpartials[i];
+            committed += q.committed;
+            T += q.T, e_mt += q.e_mt, e_ma += q.e_ma;
+            cut_mt = q.cut_mt > cut_mt ? q.cut_mt : cut_mt;
+            cut_ma = q.cut_ma > cut_ma ? q.cut_ma : cut_ma;
+        }
     {
         const uint64_t wkey = wave_max_u64(key);
         const uint32_t wmt = wave_max_u32(mt), wma = wave_max_u32(ma);
@@ -638,13 +689,13 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
         }
     }
     if (!plan_pass) return; // block-uniform
-    // exclusive prefix over blocks (canonical node order == block order) of the level's placements
+    // exclusive prefix over commit blocks (canonical node order == block order) of the level's placements
     __syncthreads();
-    const int per = (a.n_partials + kFinalThreads - 1) / kFinalThreads;
-    const int b0 = tid * per < a.n_partials ? tid * per : a.n_partials;
-    const int b1 = (b0 + per < a.n_partials) ? b0 + per : a.n_partials;
+    const int per = (a.n_cpartials + kFinalThreads - 1) / kFinalThreads;
+    const int b0 = tid * per < a.n_cpartials ? tid * per : a.n_cpartials;
+    const int b1 = (b0 + per < a.n_cpartials) ? b0 + per : a.n_cpartials;
     int64_t mine = 0;
-    for (int i = b0; i < b1; i++) mine += a.partials[i].T;
+    for (int i = b0; i < b1; i++) mine += a.cpartials[i].T;
     const int64_t incl = wave_incl_scan_i64(mine);
     if (lane == 63) s_l[0][wave] = incl;
     __syncthreads();
@@ -652,7 +703,7 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
     for (int w = 0; w < wave; w++) run += s_l[0][w];
     for (int i = b0; i < b1; i++) {
         a.blockprefix[i] = run;
-        run += a.partials[i].T;
+        run += a.cpartials[i].T;
     }
 }
 
