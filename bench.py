@@ -149,20 +149,24 @@ def main():
     # duration over one more step of the SAME workload, measured live with a HIP event pair around every
     # launch on the engine's stream (cfg.time_passes; eager launches).  rocprofv3 --kernel-trace --stats of
     # this command (profiles/) reports the same average.
+    in_run_us = None
     if args.no_roofline:
         launches, scan_s, bytes_per_scan = 0, float("nan"), r.bytes_per_scan
-    elif distributed:
-        pe, prun = eng, None
-        scan_ns, bytes_per_scan = eng.time_scan(50, mode=args.mode)
-        scan_s = scan_ns / 50 / 1e9
-        launches = 50
     else:
-        pe = capi.Engine(device=local_rank, time_passes=True)
-        pe.load(nodes, pod, prof)
-        prun = pe.run(max_limit=limit, mode=args.mode, want_log=False)
-        launches = prun.pass_launches  # every launch, as rocprofv3 counts them (incl. the few early-exit ones at the end)
-        scan_s = prun.pass_kernel_ns / max(1, launches) / 1e9
-        bytes_per_scan = prun.bytes_per_scan
+        # (a) a train of back-to-back launches of the kernel on the freshly restored snapshot, one HIP event pair
+        #     around the train (no per-dispatch completion signals);
+        # (b) [1 GPU] one more run of the same workload with a stop stamp per dispatch (cfg.time_passes): the eager
+        #     launches and their signals add a few us of idle gap before each dispatch, so (b) is an upper bound.
+        eng.reset_state()
+        launches = 200
+        scan_ns, bytes_per_scan = eng.time_scan(launches, mode=args.mode)
+        scan_s = scan_ns / launches / 1e9
+        if not distributed:
+            pe = capi.Engine(device=local_rank, time_passes=True)
+            pe.load(nodes, pod, prof)
+            prun = pe.run(max_limit=limit, mode=args.mode, want_log=False)
+            in_run_us = prun.pass_kernel_ns / max(1, prun.pass_launches) / 1e3
+            pe.close()
     achieved = bytes_per_scan / scan_s / 1e9
     kernel = "k_level_score" if args.mode == "batched" else "k_scan"
     # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this same command
@@ -208,6 +212,7 @@ def main():
             "bytes_per_launch": bytes_per_scan,
             "us_per_launch": scan_s * 1e6,
             "launches_timed": launches,
+            "us_per_launch_stamped_in_run": in_run_us,
         },
     }
     if rank == 0 and not args.no_cpu and not distributed:

@@ -32,6 +32,7 @@ struct ccsim_engine {
     int time_passes = 0;
     std::vector<hipEvent_t> pass_events; // time_passes: one (start, stop) pair per full-pass launch of a batch
     int pass_events_used = 0;
+    int graph_events = 0; // events recorded by the captured graph (re-recorded at every replay)
     double pass_kernel_ms = 0;
     int64_t pass_launches = 0;
     std::string err;
@@ -594,11 +595,13 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// t0/t1 (measurement runs only): hipExtLaunchKernelGGL stamps the events at the start and end of THIS dispatch,
-// i.e. the kernel's own duration -- what rocprofv3 --kernel-trace reports.
+// t0/t1 (measurement runs only): hipExtLaunchKernelGGL stamps the events when THIS dispatch is picked up / has
+// finished.  The pick-up stamp can precede the predecessor's end (barrier bit), so durations are taken between the
+// STOP stamps of consecutive dispatches of the in-order stream: stop(kernel) - stop(predecessor) = the kernel's
+// duration plus the ~1.5 us kernel boundary -- without draining the stream (an idle gap changes clocks and caches).
 #define CCSIM_LAUNCH(kern, g, b, stream, t0, t1, arg)                                   \
     do {                                                                                \
-        if (t0) hipExtLaunchKernelGGL(kern, g, b, 0, stream, t0, t1, 0, arg);           \
+        if (t0 || t1) hipExtLaunchKernelGGL(kern, g, b, 0, stream, t0, t1, 0, arg);     \
         else hipLaunchKernelGGL(kern, g, b, 0, stream, arg);                            \
     } while (0)
 
@@ -664,15 +667,16 @@ static int launch_level_score(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent
     return 0;
 }
 
-static int launch_level_commit(ccsim_engine *e) {
+static int launch_level_commit(ccsim_engine *e, hipEvent_t t1 = nullptr) {
     const LevelArgs a = level_args(e);
     const int nx = e->pod.nx;
     dim3 g(e->lvl_grid), b(kThreads);
-    if (nx == 0) hipLaunchKernelGGL(k_level_commit<0>, g, b, 0, e->stream, a);
-    else if (nx == 1) hipLaunchKernelGGL(k_level_commit<1>, g, b, 0, e->stream, a);
-    else if (nx == 2) hipLaunchKernelGGL(k_level_commit<2>, g, b, 0, e->stream, a);
-    else if (nx <= 4) hipLaunchKernelGGL(k_level_commit<4>, g, b, 0, e->stream, a);
-    else hipLaunchKernelGGL(k_level_commit<kMaxExtra>, g, b, 0, e->stream, a);
+    hipEvent_t t0 = nullptr;
+    if (nx == 0) CCSIM_LAUNCH(k_level_commit<0>, g, b, e->stream, t0, t1, a);
+    else if (nx == 1) CCSIM_LAUNCH(k_level_commit<1>, g, b, e->stream, t0, t1, a);
+    else if (nx == 2) CCSIM_LAUNCH(k_level_commit<2>, g, b, e->stream, t0, t1, a);
+    else if (nx <= 4) CCSIM_LAUNCH(k_level_commit<4>, g, b, e->stream, t0, t1, a);
+    else CCSIM_LAUNCH(k_level_commit<kMaxExtra>, g, b, e->stream, t0, t1, a);
     return 0;
 }
 
@@ -696,6 +700,8 @@ static int launch_level_final(ccsim_engine *e) {
     hipLaunchKernelGGL(k_level_final, dim3(1), dim3(kFinalThreads), 0, e->stream, level_final_args(e));
     return 0;
 }
+
+
 
 static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_cap) {
     if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
@@ -760,35 +766,43 @@ static int read_state(ccsim_engine *e) {
 }
 
 static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block reduction/decision
+    // Measurement runs (eager): the full-pass kernel's duration is taken between the STOP stamps of two consecutive
+    // dispatches of the in-order stream (hipExtLaunchKernelGGL): an empty marker kernel right before it, and the
+    // kernel itself.  (A start stamp is taken at packet pick-up, possibly before the predecessor ends; a stamp on
+    // k_level_commit itself costs a multi-us flush of its dirty lines -- hence two markers, the first absorbs it.)
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (e->time_passes && e->n_ranks == 0) { // measurement runs only: HIP events around the full-pass kernel
-        while ((int)e->pass_events.size() < e->pass_events_used + 2) {
+    if (e->time_passes && e->n_ranks == 0) {
+        while ((int)e->pass_events.size() < e->pass_events_used + 3) {
             hipEvent_t ev = nullptr;
             if (hipEventCreate(&ev) != hipSuccess) break;
             e->pass_events.push_back(ev);
         }
-        if ((int)e->pass_events.size() >= e->pass_events_used + 2) {
+        if ((int)e->pass_events.size() >= e->pass_events_used + 3) {
+            hipEvent_t scratch = e->pass_events[e->pass_events_used++];
             t0 = e->pass_events[e->pass_events_used++];
             t1 = e->pass_events[e->pass_events_used++];
+            if (e->mode == CCSIM_MODE_BATCHED) launch_level_commit(e);
+            hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, scratch, 0, 0);
+            hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, t0, 0, 0);
+            if (e->mode == CCSIM_MODE_BATCHED) launch_level_score(e, nullptr, t1), launch_level_final(e);
+            else launch_scan(e, nullptr, t1), launch_final(e);
+            return;
         }
     }
-    // the start stamp is taken when the packet is picked up, which may be while the predecessor still runs (barrier
-    // bit): drain the stream first so that t1 - t0 is this kernel alone, like rocprofv3's begin/end
-    if (t0) (void)hipStreamSynchronize(e->stream);
     if (e->mode == CCSIM_MODE_BATCHED) {
         launch_level_commit(e); // the level found by the previous pass (sparse: reads the 4-byte score cache)
-        if (t0) (void)hipStreamSynchronize(e->stream);
-        launch_level_score(e, t0, t1);
-    } else
-        launch_scan(e, t0, t1);
-    if (e->mode == CCSIM_MODE_BATCHED) launch_level_final(e);
-    else launch_final(e);
+        launch_level_score(e);
+        launch_level_final(e);
+    } else {
+        launch_scan(e);
+        launch_final(e);
+    }
 }
 
 static void collect_pass_times(ccsim_engine *e) { // after a stream sync
-    for (int i = 0; i + 1 < e->pass_events_used; i += 2) {
+    for (int i = 0; i + 2 < e->pass_events_used; i += 3) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e->pass_events[i], e->pass_events[i + 1]) == hipSuccess) e->pass_kernel_ms += ms, e->pass_launches++;
+        if (hipEventElapsedTime(&ms, e->pass_events[i + 1], e->pass_events[i + 2]) == hipSuccess) e->pass_kernel_ms += ms, e->pass_launches++;
     }
     e->pass_events_used = 0;
 }
@@ -797,10 +811,12 @@ static int enqueue_rounds(ccsim_engine *e, int rounds) {
     if (e->use_graph && e->n_ranks == 0 && !e->time_passes) {
         if (!e->graph_exec || e->graph_rounds != rounds || e->graph_mode != e->mode) {
             drop_graph(e);
+            e->pass_events_used = 0;
             HIPCHK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             for (int r = 0; r < rounds; r++) launch_pass(e);
             HIPCHK(e, hipStreamEndCapture(e->stream, &e->graph));
             HIPCHK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+            e->graph_events = e->pass_events_used;
             e->graph_rounds = rounds;
             e->graph_mode = e->mode;
         }

@@ -1031,6 +1031,8 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
         if (sh_ts[i]) atomicAdd(&a.hist_ts[i], (unsigned long long)sh_ts[i]);
 }
 
+__global__ void k_noop(int) {} // measurement marker: its stop stamp = the end of the preceding dispatch + one boundary
+
 // k_pts_init: once per pod spec.  calPreFilterState (filtering.go:235-308) for the initial cluster: which nodes
 // count (all hard keys present; inclusion policies), the match count of every domain, which domains exist.
 struct PtsInitArgs {
