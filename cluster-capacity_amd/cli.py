@@ -1,0 +1,177 @@
+"""cluster-capacity CLI restated on top of the MI355X engine.
+
+    ./cluster-capacity --podspec pod.yaml --snapshot cluster.yaml [--snapshot more.json]
+           [--max-limit N] [--exclude-nodes a,b] [--verbose] [-o json|yaml]
+
+Flags mirror cmd/cluster-capacity/app/options/options.go:65-77.  There is no API server to talk to here, so
+`--kubeconfig` is replaced by `--snapshot`: files holding the Node and Pod objects `SyncWithClient` would list
+(pkg/framework/simulator.go:176-295) -- `kubectl get nodes,pods -A -o yaml` output, a `List`, or multi-document YAML.
+`--default-config` (a KubeSchedulerConfiguration) is not parsed: the default profile is used.
+
+Output formats mirror pkg/framework/report.go:235-317 (pretty / json / yaml).  The simulation itself runs on the
+GPU through the C ABI (capi.Engine); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import json
+import sys
+from typing import List, Optional
+
+import numpy as np
+import yaml
+
+from . import ingest, model as M, report as R
+
+
+def load_objects(paths: List[str]):
+    nodes, pods = [], []
+    for path in paths:
+        with open(path) as f:
+            docs = list(yaml.safe_load_all(f))  # YAML is a superset of JSON
+        for d in docs:
+            if not d:
+                continue
+            items = d["items"] if str(d.get("kind", "")).endswith("List") and "items" in d else [d]
+            for o in items:
+                if o.get("kind") == "Node":
+                    nodes.append(o)
+                elif o.get("kind") == "Pod":
+                    pods.append(o)
+    return nodes, pods
+
+
+def parse_pod_spec(path: str, scheduler_name: str = "default-scheduler") -> dict:
+    """options.go:79-147 ParseAPISpec (defaults only; API validation is the apiserver's job)."""
+    with open(path) as f:
+        pod = yaml.safe_load(f)
+    if not pod or pod.get("kind") != "Pod":
+        raise SystemExit("Failed to decode config file: not a Pod")
+    md = pod.setdefault("metadata", {})
+    md.setdefault("namespace", "default")
+    spec = pod.setdefault("spec", {})
+    spec.setdefault("schedulerName", scheduler_name)
+    spec.setdefault("dnsPolicy", "ClusterFirst")
+    spec.setdefault("restartPolicy", "Always")
+    for c in spec.get("containers") or []:
+        c.setdefault("terminationMessagePolicy", "FallbackToLogsOnError")
+    if not spec.get("containers"):
+        raise SystemExit("Invalid pod: spec.containers: Required value")
+    return pod
+
+
+def _fmt_quantity_milli(milli: int) -> str:
+    return f"{milli // 1000}" if milli % 1000 == 0 else f"{milli}m"
+
+
+def _fmt_quantity_binary(v: int) -> str:
+    for suf, mul in (("Ei", 2**60), ("Pi", 2**50), ("Ti", 2**40), ("Gi", 2**30), ("Mi", 2**20), ("Ki", 2**10)):
+        if v and v % mul == 0:
+            return f"{v // mul}{suf}"
+    return str(v)
+
+
+def pod_requirements(pod: dict) -> dict:
+    """report.go:111-144 getResourceRequest (containers only) + :182-194."""
+    cpu = mem = 0
+    scalars = {}
+    for c in pod["spec"].get("containers") or []:
+        for name, q in ((c.get("resources") or {}).get("requests") or {}).items():
+            if name == "cpu":
+                cpu += ingest.milli_value(q)
+            elif name == "memory":
+                mem += ingest.value(q)
+            elif ingest.is_scalar_resource(name):
+                scalars[name] = scalars.get(name, 0) + ingest.value(q)
+    return {"podName": pod["metadata"].get("name", ""),
+            "resources": {"primaryResources": {"cpu": _fmt_quantity_milli(cpu), "memory": _fmt_quantity_binary(mem),
+                                               "nvidia.com/gpu": "0"},
+                          "scalarResources": scalars or None},
+            "nodeSelectors": pod["spec"].get("nodeSelector")}
+
+
+def build_review(pod: dict, snap: ingest.Snapshot, result: M.RunResult, max_limit: int) -> dict:
+    """report.go:196-225 GetReport."""
+    stop = R.stop_reason(result, len(snap.names), max_limit, taint_reasons=snap.taint_reasons, scalar_names=snap.scalar_names)
+    replicas = R.replicas_on_nodes(result.per_node_count, snap.names, result.log)
+    return {
+        "spec": {"templates": [pod], "replicas": 0, "podRequirements": [pod_requirements(pod)]},
+        "status": {
+            "creationTimestamp": datetime.datetime.now(datetime.timezone.utc).isoformat(),
+            "replicas": int(result.placed),
+            "failReason": R.main_fail_reason(stop),
+            "pods": [{"podName": pod["metadata"].get("name", ""), "replicasOnNodes": replicas, "failSummary": None}],
+        },
+    }
+
+
+def pretty(review: dict, verbose: bool) -> str:
+    """report.go:235-283 clusterCapacityReviewPrettyPrint."""
+    out = []
+    if verbose:
+        for req in review["spec"]["podRequirements"]:
+            out.append(f"{req['podName']} pod requirements:")
+            out.append(f"\t- CPU: {req['resources']['primaryResources']['cpu']}")
+            out.append(f"\t- Memory: {req['resources']['primaryResources']['memory']}")
+            if req["resources"]["scalarResources"] is not None:
+                out.append(f"\t- ScalarResources: {req['resources']['scalarResources']}")
+            if req["nodeSelectors"] is not None:
+                out.append("\t- NodeSelector: " + ",".join(f"{k}={v}" for k, v in sorted(req["nodeSelectors"].items())))
+            out.append("")
+    for p in review["status"]["pods"]:
+        total = sum(r["replicas"] for r in p["replicasOnNodes"])
+        out.append(f"The cluster can schedule {total} instance(s) of the pod {p['podName']}." if verbose else f"{total}")
+    if verbose:
+        fr = review["status"]["failReason"]
+        out.append(f"\nTermination reason: {fr['failType']}: {fr['failMessage']}")
+        if review["status"]["replicas"] > 0:
+            out.append("\nPod distribution among nodes:")
+            for p in review["status"]["pods"]:
+                out.append(p["podName"])
+                for r in p["replicasOnNodes"]:
+                    out.append(f"\t- {r['nodeName']}: {r['replicas']} instance(s)")
+    return "\n".join(out) + "\n"
+
+
+def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, device: int = 0) -> M.RunResult:
+    from . import capi
+
+    coupled = bool(snap.pod.spread) or snap.pod.ipa is not None
+    mode = mode or ("sequential" if coupled else "batched")
+    eng = capi.Engine(device=device)
+    eng.load(snap.nodes, snap.pod, M.Profile.default())
+    cap = max_limit if max_limit > 0 else int(min(int(snap.nodes.alloc_pods.astype(np.int64).sum()), 1 << 26))
+    try:
+        return eng.run(max_limit=max_limit, mode=mode, want_log=True, log_cap=max(1, cap))
+    finally:
+        eng.close()
+
+
+def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
+    ap = argparse.ArgumentParser(prog="cluster-capacity", description="Cluster-capacity is used for simulating scheduling of one or multiple pods")
+    ap.add_argument("--podspec", required=True, help="Path to JSON or YAML file containing pod definition.")
+    ap.add_argument("--snapshot", action="append", required=True, help="File(s) with the cluster's Node and Pod objects (replaces --kubeconfig)")
+    ap.add_argument("--max-limit", type=int, default=0, help="Number of instances of pod to be scheduled after which analysis stops. By default unlimited.")
+    ap.add_argument("--exclude-nodes", default="", help="Exclude nodes to be scheduled")
+    ap.add_argument("--verbose", action="store_true", help="Verbose mode")
+    ap.add_argument("-o", "--output", default="", choices=["", "json", "yaml"], help="Output format. One of: json|yaml")
+    ap.add_argument("--mode", default=None, choices=["batched", "sequential"], help="engine mode (default: batched unless the pod couples nodes)")
+    args = ap.parse_args(argv)
+
+    pod = parse_pod_spec(args.podspec)
+    node_objs, pod_objs = load_objects(args.snapshot)
+    snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x])
+    result = simulate(snap, args.max_limit, args.mode)
+    review = build_review(pod, snap, result, args.max_limit)
+    if args.output == "json":
+        out.write(json.dumps(review) + "\n")
+    elif args.output == "yaml":
+        out.write(yaml.safe_dump(review, sort_keys=False))
+    else:
+        out.write(pretty(review, args.verbose))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

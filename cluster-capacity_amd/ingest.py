@@ -1,0 +1,462 @@
+"""Snapshot ingest: Kubernetes objects (parsed YAML/JSON dicts: Nodes, Pods, the pod spec to simulate) -> the
+interned integer world of model.py.  Host-side mirror of what the reference does with strings before and inside
+the scheduling loop; nothing here is on the hot path.
+
+Reference (paths relative to the reference root; S/ = vendor/k8s.io/kubernetes/pkg/scheduler):
+  which objects are copied          pkg/framework/simulator.go:176-295 (non-terminal pods, nodes minus --exclude-nodes)
+  Quantity.Value / MilliValue       vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go:813-834 (ceil)
+  pod requests                      vendor/k8s.io/component-helpers/resource/helpers.go:144-251 (sum containers, max init, + overhead)
+  NonZero requests                  S/framework/types.go:1095-1124 (100m / 200Mi per container without the request)
+  NodeInfo.AddPod                   S/framework/types.go:345-350,409-428
+  node order                        S/backend/cache/node_tree.go:119-143, component-helpers/node/topology/helpers.go:31-58
+  taints / tolerations              component-helpers/scheduling/corev1/helpers.go:63-101, api/core/v1/toleration.go:38-57
+  node selector requirements        apimachinery/pkg/labels/selector.go:246-293, component-helpers/.../nodeaffinity.go
+  label selectors                   apimachinery/pkg/apis/meta/v1/helpers.go:36-75
+  spread constraints                S/framework/plugins/podtopologyspread/common.go:42-159
+  inter-pod affinity terms          vendor/k8s.io/kube-scheduler/framework/types.go:379-384, S/framework/types.go:927-935
+"""
+from __future__ import annotations
+
+import math
+import re
+from fractions import Fraction
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import model as M
+
+DEFAULT_MILLI_CPU = 100  # S/util/pod_resources.go:28-31
+DEFAULT_MEMORY = 200 * 1024 * 1024
+HOSTNAME = "kubernetes.io/hostname"
+UNSCHED_TAINT = "node.kubernetes.io/unschedulable"
+
+_BIN = {"Ki": 2**10, "Mi": 2**20, "Gi": 2**30, "Ti": 2**40, "Pi": 2**50, "Ei": 2**60}
+_DEC = {"n": Fraction(1, 10**9), "u": Fraction(1, 10**6), "m": Fraction(1, 1000), "": 1, "k": 10**3, "M": 10**6,
+        "G": 10**9, "T": 10**12, "P": 10**15, "E": 10**18}
+_Q = re.compile(r"^([+-]?[0-9]*\.?[0-9]*)(?:([eE][+-]?[0-9]+)|(Ki|Mi|Gi|Ti|Pi|Ei|n|u|m|k|M|G|T|P|E)?)$")
+
+
+def parse_quantity(q) -> Fraction:
+    """resource.Quantity as an exact rational."""
+    if isinstance(q, (int, float)):
+        return Fraction(str(q))
+    m = _Q.match(str(q).strip())
+    if not m or m.group(1) in ("", "+", "-", "."):
+        raise ValueError(f"bad quantity {q!r}")
+    num = Fraction(m.group(1))
+    if m.group(2):
+        return num * Fraction(10) ** int(m.group(2)[1:])
+    suf = m.group(3) or ""
+    return num * (_BIN[suf] if suf in _BIN else _DEC[suf])
+
+
+def value(q) -> int:
+    """Quantity.Value(): rounded up to an integer (quantity.go:813-820)."""
+    return math.ceil(parse_quantity(q))
+
+
+def milli_value(q) -> int:
+    """Quantity.MilliValue(): rounded up to an integer number of thousandths (quantity.go:822-834)."""
+    return math.ceil(parse_quantity(q) * 1000)
+
+
+def _res(rl: Optional[dict], name: str) -> int:
+    if not rl or name not in rl:
+        return 0
+    return milli_value(rl[name]) if name == "cpu" else value(rl[name])
+
+
+def is_scalar_resource(name: str) -> bool:
+    """S/util/utils.go:140-143: extended / hugepages / prefixed native / attachable-volumes resources."""
+    if name in ("cpu", "memory", "ephemeral-storage", "pods"):
+        return False
+    return True
+
+
+def pod_requests(spec: dict, names: Sequence[str]):
+    """-> (requests per name, non-zero cpu, non-zero memory).  helpers.go:144-251 PodRequests + types.go:1095-1124."""
+    def container_req(c, n):
+        return _res((c.get("resources") or {}).get("requests"), n)
+
+    out = {}
+    for n in names:
+        total = sum(container_req(c, n) for c in spec.get("containers") or [])
+        for ic in spec.get("initContainers") or []:
+            total = max(total, container_req(ic, n))  # (restartable init containers are not modelled)
+        total += _res(spec.get("overhead"), n)
+        out[n] = total
+
+    def nz(n, default):
+        def one(c):
+            r = (c.get("resources") or {}).get("requests") or {}
+            return (milli_value(r[n]) if n == "cpu" else value(r[n])) if n in r else default
+        total = sum(one(c) for c in spec.get("containers") or [])
+        for ic in spec.get("initContainers") or []:
+            total = max(total, one(ic))
+        return total + _res(spec.get("overhead"), n)
+
+    return out, nz("cpu", DEFAULT_MILLI_CPU), nz("memory", DEFAULT_MEMORY)
+
+
+def zone_key(labels: dict) -> str:
+    zone = labels.get("failure-domain.beta.kubernetes.io/zone", labels.get("topology.kubernetes.io/zone", ""))
+    region = labels.get("failure-domain.beta.kubernetes.io/region", labels.get("topology.kubernetes.io/region", ""))
+    if not region and not zone:
+        return ""
+    return region + ":\x00:" + zone
+
+
+def canonical_node_order(nodes: List[dict]) -> List[dict]:
+    """node_tree.go:119-143: nodes arrive sorted by name (the fake tracker lists lexicographically,
+    client-go/testing/fixture.go:847-855), zones in first-seen order, then round robin across zones."""
+    zones: Dict[str, List[dict]] = {}
+    for n in sorted(nodes, key=lambda n: n["metadata"]["name"]):
+        zones.setdefault(zone_key(n["metadata"].get("labels") or {}), []).append(n)
+    out, i = [], 0
+    while len(out) < len(nodes):
+        for z in zones.values():
+            if i < len(z):
+                out.append(z[i])
+        i += 1
+    return out
+
+
+# ---- taints / tolerations -------------------------------------------------------------------------------------
+def tolerates(tol: dict, taint: dict) -> bool:
+    """toleration.go:38-57 ToleratesTaint."""
+    if tol.get("effect") and tol["effect"] != taint.get("effect"):
+        return False
+    if tol.get("key") and tol["key"] != taint.get("key"):
+        return False
+    op = tol.get("operator") or "Equal"
+    if op == "Exists":
+        return True
+    if op == "Equal":
+        return (tol.get("value") or "") == (taint.get("value") or "")
+    return False
+
+
+def taint_verdict(taints: List[dict], tolerations: List[dict]):
+    """-> (filter_ok, untolerated PreferNoSchedule count, first untolerated NoSchedule/NoExecute taint or None)."""
+    first = None
+    for t in taints:
+        if t.get("effect") in ("NoSchedule", "NoExecute") and not any(tolerates(x, t) for x in tolerations):
+            first = t
+            break
+    prefer_tols = [x for x in tolerations if not x.get("effect") or x.get("effect") == "PreferNoSchedule"]
+    cnt = sum(1 for t in taints if t.get("effect") == "PreferNoSchedule" and not any(tolerates(x, t) for x in prefer_tols))
+    return first is None, cnt, first
+
+
+# ---- selectors --------------------------------------------------------------------------------------------------
+def requirement_matches(key_present: bool, val: Optional[str], op: str, values: List[str]) -> bool:
+    """labels.Requirement.Matches (selector.go:246-293)."""
+    if op == "In":
+        return key_present and val in values
+    if op == "NotIn":
+        return not key_present or val not in values
+    if op == "Exists":
+        return key_present
+    if op == "DoesNotExist":
+        return not key_present
+    if op in ("Gt", "Lt"):
+        if not key_present or len(values) != 1:
+            return False
+        try:
+            a, b = int(val), int(values[0])
+        except (TypeError, ValueError):
+            return False
+        return a > b if op == "Gt" else a < b
+    return False
+
+
+def label_selector_matches(sel: Optional[dict], labels: dict) -> bool:
+    """metav1.LabelSelectorAsSelector: nil -> Nothing, {} -> Everything (helpers.go:36-75)."""
+    if sel is None:
+        return False
+    for k, v in (sel.get("matchLabels") or {}).items():
+        if labels.get(k) != v:
+            return False
+    for e in sel.get("matchExpressions") or []:
+        if not requirement_matches(e["key"] in labels, labels.get(e["key"]), e["operator"], e.get("values") or []):
+            return False
+    return True
+
+
+def selector_empty(sel: Optional[dict]) -> bool:
+    return sel is not None and not (sel.get("matchLabels") or {}) and not (sel.get("matchExpressions") or [])
+
+
+class Interner:
+    """label key -> column; label value -> id (0 = key absent).  Columns are created on demand."""
+
+    def __init__(self, nodes: List[dict]):
+        self.nodes = nodes
+        self.cols: Dict[str, int] = {}
+        self.values: List[List[str]] = []  # per column: value strings, index = id - 1
+        self.arrays: List[np.ndarray] = []
+
+    def col(self, key: str) -> int:
+        if key in self.cols:
+            return self.cols[key]
+        vals: Dict[str, int] = {}
+        ids = np.zeros(len(self.nodes), np.int32)
+        for i, n in enumerate(self.nodes):
+            lab = dict(n["metadata"].get("labels") or {})
+            if key == "metadata.name":
+                lab = {key: n["metadata"]["name"]}
+            if key in lab:
+                ids[i] = vals.setdefault(lab[key], len(vals) + 1)
+        self.cols[key] = len(self.arrays)
+        self.arrays.append(ids)
+        self.values.append(list(vals))
+        return self.cols[key]
+
+    def table(self, key: str, op: str, values: List[str]) -> "M.Requirement":
+        c = self.col(key)
+        t = np.zeros(len(self.values[c]) + 1, np.uint8)
+        t[0] = requirement_matches(False, None, op, values)
+        for i, v in enumerate(self.values[c]):
+            t[i + 1] = requirement_matches(True, v, op, values)
+        return (c, t)
+
+
+def _node_selector_term(it: Interner, term: dict) -> List["M.Requirement"]:
+    reqs = [it.table(e["key"], e["operator"], e.get("values") or []) for e in term.get("matchExpressions") or []]
+    for f in term.get("matchFields") or []:  # only metadata.name with In / NotIn (nodeaffinity.go:260-293)
+        reqs.append(it.table("metadata.name", f["operator"], f.get("values") or []))
+    return reqs
+
+
+# ---- the snapshot -----------------------------------------------------------------------------------------------
+class Snapshot:
+    """Everything the engine needs, plus the strings the report needs."""
+
+    def __init__(self, nodes: M.NodesSoA, pod: M.PodSpec, names: List[str], taint_reasons: List[str], scalar_names: List[str]):
+        self.nodes, self.pod, self.names, self.taint_reasons, self.scalar_names = nodes, pod, names, taint_reasons, scalar_names
+
+
+def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict) -> bool:
+    """AffinityTerm.Matches: namespace in the term's set (default: the owner's namespace) and selector matches."""
+    ns_set = term.get("namespaces") or []
+    pod_ns = pod["metadata"].get("namespace") or "default"
+    if term.get("namespaceSelector") is not None and not ns_set:
+        if selector_empty(term["namespaceSelector"]):
+            pass  # empty selector = all namespaces
+        else:
+            raise NotImplementedError("namespaceSelector needs Namespace objects")
+    elif not ns_set:
+        if pod_ns != term_owner_ns:
+            return False
+    elif pod_ns not in ns_set:
+        return False
+    return label_selector_matches(term.get("labelSelector"), pod["metadata"].get("labels") or {})
+
+
+def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, exclude_nodes: Sequence[str] = (),
+                   hard_pod_affinity_weight: int = 1) -> Snapshot:
+    """SyncWithClient (simulator.go:176-295) + every per-pod-spec precomputation, in integers."""
+    nodes = canonical_node_order([n for n in node_objs if n["metadata"]["name"] not in set(exclude_nodes)])
+    N = len(nodes)
+    names = [n["metadata"]["name"] for n in nodes]
+    index = {nm: i for i, nm in enumerate(names)}
+    spec = sim_pod.get("spec") or {}
+    sim_ns = sim_pod["metadata"].get("namespace") or "default"
+    sim_labels = sim_pod["metadata"].get("labels") or {}
+
+    # resources: cpu, memory, ephemeral-storage + every scalar resource the pod names
+    req_names = set()
+    for c in (spec.get("containers") or []) + (spec.get("initContainers") or []):
+        req_names |= set(((c.get("resources") or {}).get("requests") or {}).keys())
+    scalars = sorted(n for n in req_names if is_scalar_resource(n))[: M.MAX_SCALAR]
+    res_names = ["cpu", "memory", "ephemeral-storage"] + scalars
+    preq, nz_cpu, nz_mem = pod_requests(spec, res_names)
+
+    alloc = [np.zeros(N, np.int64) for _ in res_names]
+    alloc_pods = np.zeros(N, np.int32)
+    for i, n in enumerate(nodes):
+        a = (n.get("status") or {}).get("allocatable") or {}
+        for c, r in enumerate(res_names):
+            alloc[c][i] = _res(a, r)
+        alloc_pods[i] = value(a.get("pods", 0))
+    req = [np.zeros(N, np.int64) for _ in res_names]
+    nzc, nzm, pcount = np.zeros(N, np.int64), np.zeros(N, np.int64), np.zeros(N, np.int32)
+    live = []  # non-terminal pods bound to a kept node (simulator.go:193-200)
+    for p in pod_objs:
+        phase = (p.get("status") or {}).get("phase")
+        node = (p.get("spec") or {}).get("nodeName")
+        if phase in ("Succeeded", "Failed") or node not in index:
+            continue
+        live.append(p)
+        i = index[node]
+        r, c0, m0 = pod_requests(p["spec"], res_names)
+        for c, rn in enumerate(res_names):
+            req[c][i] += r[rn]
+        nzc[i] += c0
+        nzm[i] += m0
+        pcount[i] += 1
+
+    # taints -> distinct taint sets
+    tolerations = spec.get("tolerations") or []
+    sets: Dict[str, int] = {}
+    ts_id = np.zeros(N, np.int32)
+    ok, cnt, reasons = [], [], []
+    for i, n in enumerate(nodes):
+        taints = (n.get("spec") or {}).get("taints") or []
+        key = repr([(t.get("key"), t.get("value"), t.get("effect")) for t in taints])
+        if key not in sets:
+            sets[key] = len(sets)
+            f, c, first = taint_verdict(taints, tolerations)
+            ok.append(f)
+            cnt.append(c)
+            # taint_toleration.go:119
+            reasons.append("" if first is None else f"node(s) had untolerated taint {{{first.get('key')}: {first.get('value') or ''}}}")
+        ts_id[i] = sets[key]
+    unsched = np.array([1 if (n.get("spec") or {}).get("unschedulable") else 0 for n in nodes], np.uint8)
+    tol_unsched = any(tolerates(t, {"key": UNSCHED_TAINT, "effect": "NoSchedule"}) for t in tolerations)
+
+    # node affinity / node selector
+    it = Interner(nodes)
+    aff = (spec.get("affinity") or {}).get("nodeAffinity") or {}
+    node_selector = spec.get("nodeSelector")
+    required = (aff.get("requiredDuringSchedulingIgnoredDuringExecution") or {}).get("nodeSelectorTerms")
+    sel_reqs = [it.table(k, "In", [v]) for k, v in (node_selector or {}).items()]
+    req_terms = [_node_selector_term(it, t) for t in (required or [])]
+    pref = [(int(t["weight"]), _node_selector_term(it, t["preference"]))
+            for t in aff.get("preferredDuringSchedulingIgnoredDuringExecution") or []]
+    affinity_active = bool(node_selector) or required is not None
+
+    def node_matches_required(i: int) -> bool:  # RequiredNodeAffinity.Match, for the spread inclusion policy
+        def term_ok(reqs, empty):
+            return empty if not reqs else all(t[it.arrays[c][i]] for c, t in reqs)
+        if node_selector and not term_ok(sel_reqs, True):
+            return False
+        if required is not None and not any(term_ok(t, False) for t in req_terms):
+            return False
+        return True
+
+    pod = M.PodSpec(
+        req=np.array([preq[r] for r in res_names], np.int64), nz_mcpu=nz_cpu, nz_mem=nz_mem,
+        has_scalar_entries=bool(scalars), taint_filter_ok=np.array(ok, np.uint8), taint_prefer_cnt=np.array(cnt, np.int32),
+        tolerates_unschedulable=tol_unsched, affinity_filter_active=affinity_active,
+        has_node_selector=node_selector is not None and len(node_selector) > 0, node_selector=sel_reqs,
+        has_required_terms=required is not None, required=req_terms, preferred=pref)
+
+    # topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
+    included = np.array([node_matches_required(i) for i in range(N)], np.uint8) if affinity_active else None
+    for c in spec.get("topologySpreadConstraints") or []:
+        sel = c.get("labelSelector")
+        col = it.col(c["topologyKey"])
+
+        def matches(p):  # countPodsMatchSelector (common.go:144-159)
+            return (not selector_empty(sel) and (p["metadata"].get("namespace") or "default") == sim_ns
+                    and not p["metadata"].get("deletionTimestamp") and label_selector_matches(sel, p["metadata"].get("labels") or {}))
+        existing = np.zeros(N, np.int32)
+        for p in live:
+            if matches(p):
+                existing[index[p["spec"]["nodeName"]]] += 1
+        honor_aff = (c.get("nodeAffinityPolicy") or "Honor") == "Honor"
+        if (c.get("nodeTaintsPolicy") or "Ignore") == "Honor":
+            raise NotImplementedError("nodeTaintsPolicy: Honor")
+        pod.spread.append(M.SpreadConstraint(
+            col=col, max_skew=int(c["maxSkew"]), min_domains=int(c.get("minDomains") or 1),
+            hard=(c.get("whenUnsatisfiable") or "DoNotSchedule") == "DoNotSchedule",
+            self_match=not selector_empty(sel) and label_selector_matches(sel, sim_labels),
+            is_hostname=c["topologyKey"] == HOSTNAME, n_domains=len(it.values[col]),
+            node_match_count=existing if existing.any() else None, node_included=included if honor_aff else None))
+
+    # inter-pod affinity (filtering.go:204-432, scoring.go:81-125)
+    pa = (spec.get("affinity") or {}).get("podAffinity") or {}
+    paa = (spec.get("affinity") or {}).get("podAntiAffinity") or {}
+    r_aff = pa.get("requiredDuringSchedulingIgnoredDuringExecution") or []
+    r_anti = paa.get("requiredDuringSchedulingIgnoredDuringExecution") or []
+    p_aff = pa.get("preferredDuringSchedulingIgnoredDuringExecution") or []
+    p_anti = paa.get("preferredDuringSchedulingIgnoredDuringExecution") or []
+    others_have_terms = any(((p.get("spec") or {}).get("affinity") or {}).get(k) for p in live for k in ("podAffinity", "podAntiAffinity"))
+    if r_aff or r_anti or p_aff or p_anti or others_have_terms:
+        keys: List[str] = []
+
+        def kidx(k):
+            if k not in keys:
+                keys.append(k)
+            return keys.index(k)
+
+        sim_as_pod = {"metadata": {"namespace": sim_ns, "labels": sim_labels}}
+        ipa = M.InterPodAffinity(key_cols=[], key_ndom=[])
+        ipa.aff_keys = [kidx(t["topologyKey"]) for t in r_aff]
+        ipa.self_aff = bool(r_aff) and all(_term_matches_pod(t, sim_ns, sim_as_pod) for t in r_aff)
+        ipa.anti_keys = [kidx(t["topologyKey"]) for t in r_anti]
+        ipa.anti_self = [_term_matches_pod(t, sim_ns, sim_as_pod) for t in r_anti]
+        aff_existing = np.zeros(N, np.int32)
+        anti_existing = [np.zeros(N, np.int32) for _ in r_anti]
+        exist_anti: Dict[int, np.ndarray] = {}
+        score_existing: Dict[int, np.ndarray] = {}
+        entries = 0
+
+        def add_score(k, i, w):
+            nonlocal entries
+            col = it.col(keys[k])
+            if it.arrays[col][i]:
+                score_existing.setdefault(k, np.zeros(N, np.int64))[i] += w
+                entries += 1
+
+        for p in live:
+            i = index[p["spec"]["nodeName"]]
+            p_ns = p["metadata"].get("namespace") or "default"
+            if r_aff and all(_term_matches_pod(t, sim_ns, p) for t in r_aff):
+                aff_existing[i] += 1
+            for t_i, t in enumerate(r_anti):
+                if _term_matches_pod(t, sim_ns, p):
+                    anti_existing[t_i][i] += 1
+            e_aff = ((p["spec"].get("affinity") or {}).get("podAffinity") or {})
+            e_anti = ((p["spec"].get("affinity") or {}).get("podAntiAffinity") or {})
+            for t in e_anti.get("requiredDuringSchedulingIgnoredDuringExecution") or []:
+                if _term_matches_pod(t, p_ns, sim_as_pod):
+                    exist_anti.setdefault(kidx(t["topologyKey"]), np.zeros(N, np.int32))[i] += 1
+            # scoring.go:81-125 processExistingPod
+            for wt in p_aff:
+                if _term_matches_pod(wt["podAffinityTerm"], sim_ns, p):
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int(wt["weight"]))
+            for wt in p_anti:
+                if _term_matches_pod(wt["podAffinityTerm"], sim_ns, p):
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int(wt["weight"]))
+            if hard_pod_affinity_weight > 0:
+                for t in e_aff.get("requiredDuringSchedulingIgnoredDuringExecution") or []:
+                    if _term_matches_pod(t, p_ns, sim_as_pod):
+                        add_score(kidx(t["topologyKey"]), i, hard_pod_affinity_weight)
+            for wt in e_aff.get("preferredDuringSchedulingIgnoredDuringExecution") or []:
+                if _term_matches_pod(wt["podAffinityTerm"], p_ns, sim_as_pod):
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int(wt["weight"]))
+            for wt in e_anti.get("preferredDuringSchedulingIgnoredDuringExecution") or []:
+                if _term_matches_pod(wt["podAffinityTerm"], p_ns, sim_as_pod):
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int(wt["weight"]))
+        # what ONE clone adds (it is an existing pod of the next cycle, with the incoming pod's own terms)
+        K = len(keys)
+        score_self, self_entries = [0] * K, [0] * K
+        for wt, sign in [(w, 1) for w in p_aff] + [(w, -1) for w in p_anti]:
+            if _term_matches_pod(wt["podAffinityTerm"], sim_ns, sim_as_pod):  # both directions: incoming's term vs the
+                k = kidx(wt["podAffinityTerm"]["topologyKey"])              # clone, and the clone's term vs the incoming pod
+                score_self[k] += 2 * sign * int(wt["weight"])
+                self_entries[k] += 2
+        if hard_pod_affinity_weight > 0:
+            for t in r_aff:
+                if _term_matches_pod(t, sim_ns, sim_as_pod):
+                    k = kidx(t["topologyKey"])
+                    score_self[k] += hard_pod_affinity_weight
+                    self_entries[k] += 1
+        if len(keys) > M.MAX_IPA_KEYS:
+            raise NotImplementedError("more than %d distinct inter-pod affinity topology keys" % M.MAX_IPA_KEYS)
+        ipa.key_cols = [it.col(k) for k in keys]
+        ipa.key_ndom = [len(it.values[c]) for c in ipa.key_cols]
+        ipa.aff_existing = aff_existing if aff_existing.any() else None
+        ipa.anti_existing = [a if a.any() else None for a in anti_existing]
+        ipa.exist_anti = [exist_anti.get(k) for k in range(len(keys))]
+        ipa.score_existing = [score_existing.get(k) for k in range(len(keys))]
+        ipa.score_self, ipa.self_entries, ipa.entries_existing = score_self, self_entries, entries
+        pod.ipa = ipa
+
+    soa = M.NodesSoA(alloc=alloc, alloc_pods=alloc_pods, req=req, nz_mcpu=nzc, nz_mem=nzm, pod_count=pcount,
+                     taintset_id=ts_id, unschedulable=unsched, label_cols=[a for a in it.arrays] or [], names=names,
+                     scalar_names=scalars)
+    return Snapshot(soa, pod, names, reasons, scalars)
