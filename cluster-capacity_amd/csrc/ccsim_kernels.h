@@ -178,6 +178,17 @@ __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
     return v;
 }
 
+// ---- per-block partials ---------------------------------------------------------------------------------------
+// Per-block partial results are naturally aligned 8-byte words written and read with AGENT-scope relaxed atomics
+// (write-through sc1 stores, L1-bypassing sc1 loads): correct across a kernel boundary and also inside one launch
+// ("8-B agent atomics both sides", MI355X_MICROARCH.md).
+__device__ __forceinline__ void st_agent(uint64_t *p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- exact scores without IEEE divides on the common path -------------------------------------------
 // A pass is as much VALU- as HBM-bound if every node pays five fp64 divisions (~40 instructions each on
 // CDNA: v_div_scale x2, v_rcp_f64, Newton FMAs, v_div_fmas, v_div_fixup).  Both scores divide by the
@@ -392,19 +403,29 @@ __device__ __forceinline__ int64_t ipa_normalize(int64_t raw, int64_t mn, int64_
     return (int64_t)f;
 }
 
+// One argument block for the scan, the (fused or separate) final reduction and the distributed decide.
 struct ScanArgs {
     DevCols c;
     DevPod p;
-    const DevState *st;
-    Partial *partials;
-    int64_t chunk; // nodes per block (multiple of kTile)
+    DevState *st;
+    uint64_t *partials; // [grid][2]: packed max key ; norm | nfeas << 32   (struct Partial)
+    int64_t chunk;      // nodes per block (multiple of kTile)
     DevPts pts;
-    int32_t *pts_min_partials; // [grid][kMaxTsc]: per-block minimum match count per constraint
+    uint64_t *pts_min_partials; // [grid][kMaxTsc]: per-block minimum match count per constraint
     DevIpa ipa;
-    int64_t *ipa_partials;     // [grid][2]: per-block min / max raw InterPodAffinity score over feasible nodes
+    uint64_t *ipa_partials;     // [grid][2]: per-block min / max raw InterPodAffinity score over feasible nodes
     DevSoft soft;
-    int64_t *soft_partials;    // [grid][3]: feasible non-ignored nodes, min / max raw PodTopologySpread score
+    uint64_t *soft_partials;    // [grid][3]: feasible non-ignored nodes, min / max raw PodTopologySpread score
+    int32_t n_partials;         // = scan grid
+    unsigned *ticket;           // unused (a fused last-block reduction was measured SLOWER: inlining or calling the
+                                // reduction from k_scan costs the scan its registers / occupancy -- 44k -> 36k cycles/s)
+    XRec *xsend;                // distributed: this shard's record out
+    const XRec *xrecv;          // distributed: gathered records in
+    int32_t n_ranks;            // 0 = single GPU (decide from the local record)
+    int32_t *log;
 };
+
+template <class A> __device__ void final_body(const A &a);
 
 // PTS = the pod carries topology-coupled plugins (PodTopologySpread and / or InterPodAffinity)
 template <int NX, bool PTS>
@@ -534,7 +555,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
         }
         out.norm = (m1 << kStatCntShift) | m2;
         out.nfeas = nf;
-        a.partials[blockIdx.x] = out;
+        st_agent(a.partials + 2 * (int64_t)blockIdx.x, out.key);
+        st_agent(a.partials + 2 * (int64_t)blockIdx.x + 1, (uint64_t)out.norm | ((uint64_t)out.nfeas << 32));
     }
     if (PTS) {
         __shared__ int32_t s_pm[kThreads / 64][kMaxTsc];
@@ -552,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
         if (tid < kMaxTsc && a.pts.n) {
             int32_t v = s_pm[0][tid];
             for (int w = 1; w < kThreads / 64; w++) v = s_pm[w][tid] < v ? s_pm[w][tid] : v;
-            a.pts_min_partials[(int64_t)blockIdx.x * kMaxTsc + tid] = v;
+            st_agent(a.pts_min_partials + (int64_t)blockIdx.x * kMaxTsc + tid, (uint64_t)(int64_t)v);
         }
         if (a.soft.n) {
             __shared__ int64_t s_sm[3][kThreads / 64];
@@ -572,9 +594,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
                     mn = s_sm[1][w] < mn ? s_sm[1][w] : mn;
                     mx = s_sm[2][w] > mx ? s_sm[2][w] : mx;
                 }
-                a.soft_partials[3 * (int64_t)blockIdx.x] = cn;
-                a.soft_partials[3 * (int64_t)blockIdx.x + 1] = mn;
-                a.soft_partials[3 * (int64_t)blockIdx.x + 2] = mx;
+                st_agent(a.soft_partials + 3 * (int64_t)blockIdx.x, (uint64_t)cn);
+                st_agent(a.soft_partials + 3 * (int64_t)blockIdx.x + 1, (uint64_t)mn);
+                st_agent(a.soft_partials + 3 * (int64_t)blockIdx.x + 2, (uint64_t)mx);
             }
         }
         if (a.ipa.on) {
@@ -590,8 +612,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             if (tid == 0) {
                 int64_t mn = s_im[0][0], mx = s_im[1][0];
                 for (int w = 1; w < kThreads / 64; w++) mn = s_im[0][w] < mn ? s_im[0][w] : mn, mx = s_im[1][w] > mx ? s_im[1][w] : mx;
-                a.ipa_partials[2 * (int64_t)blockIdx.x] = mn;
-                a.ipa_partials[2 * (int64_t)blockIdx.x + 1] = mx;
+                st_agent(a.ipa_partials + 2 * (int64_t)blockIdx.x, (uint64_t)mn);
+                st_agent(a.ipa_partials + 2 * (int64_t)blockIdx.x + 1, (uint64_t)mx);
             }
         }
     }
@@ -604,30 +626,13 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
 // The pending scan was computed with (mt_a, ma_a); if the true maxima over the feasible set differ,
 // the scores were normalized with the wrong constants: fix the constants and rescan, commit nothing.
 // ------------------------------------------------------------------------------------------------
-struct FinalArgs {
-    DevCols c;
-    DevPod p;
-    DevState *st;
-    const Partial *partials;
-    int32_t n_partials;
-    XRec *xsend;       // distributed: local record out
-    const XRec *xrecv; // distributed: gathered records in
-    int32_t n_ranks;   // 0 = single GPU (decide from the local record)
-    int32_t *log;
-    DevPts pts;
-    const int32_t *pts_min_partials;
-    DevIpa ipa;
-    const int64_t *ipa_partials;
-    DevSoft soft;
-    const int64_t *soft_partials;
-};
-
 struct SoftAgg { // one scan's PodTopologySpread PreScore facts
     int64_t size[kMaxTsc]; // candidate domains per constraint (hostname: feasible non-ignored nodes)
     int64_t mn, mx;
 };
 
-__device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas,
+template <class A>
+__device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas,
                                               const int32_t *pts_min, int64_t ipa_mn = 0, int64_t ipa_mx = 0,
                                               const SoftAgg *soft = nullptr) {
     DevState st = *a.st;
@@ -720,19 +725,21 @@ __device__ __forceinline__ void decide_commit(const FinalArgs &a, uint64_t key, 
 
 // k_final: one block.  Reduces the per-block partials of the scan that just finished, then either
 // decides + commits (single GPU) or publishes the shard's record for the cross-GPU exchange.
-__global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
+template <class A>
+__device__ void final_body(const A &a) {
     if (a.st->done) return;
     const int tid = threadIdx.x;
     uint64_t key = 0;
     uint32_t mt = 0, ma = 0;
     int64_t nf = 0;
     for (int i = tid; i < a.n_partials; i += kThreads) {
-        const Partial q = a.partials[i];
-        key = q.key > key ? q.key : key;
-        const uint32_t m1 = q.norm >> kStatCntShift, m2 = q.norm & kStatAffMask;
+        const uint64_t qk = ld_agent(a.partials + 2 * (int64_t)i), qn = ld_agent(a.partials + 2 * (int64_t)i + 1);
+        key = qk > key ? qk : key;
+        const uint32_t norm = (uint32_t)qn;
+        const uint32_t m1 = norm >> kStatCntShift, m2 = norm & kStatAffMask;
         mt = m1 > mt ? m1 : mt;
         ma = m2 > ma ? m2 : ma;
-        nf += q.nfeas;
+        nf += (uint32_t)(qn >> 32);
     }
     key = wave_max_u64(key);
     mt = wave_max_u32(mt);
@@ -754,7 +761,7 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
     for (int c = 0; c < a.pts.n; c++) {
         int32_t v = 0x7fffffff;
         for (int i = tid; i < a.n_partials; i += kThreads) {
-            const int32_t q = a.pts_min_partials[(int64_t)i * kMaxTsc + c];
+            const int32_t q = (int32_t)(int64_t)ld_agent(a.pts_min_partials + (int64_t)i * kMaxTsc + c);
             v = q < v ? q : v;
         }
 #pragma unroll
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
     if (a.ipa.on) {
         int64_t mn = INT64_MAX, mx = INT64_MIN;
         for (int i = tid; i < a.n_partials; i += kThreads) {
-            const int64_t q1 = a.ipa_partials[2 * (int64_t)i], q2 = a.ipa_partials[2 * (int64_t)i + 1];
+            const int64_t q1 = (int64_t)ld_agent(a.ipa_partials + 2 * (int64_t)i), q2 = (int64_t)ld_agent(a.ipa_partials + 2 * (int64_t)i + 1);
             mn = q1 < mn ? q1 : mn;
             mx = q2 > mx ? q2 : mx;
         }
@@ -784,8 +791,8 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
         const int32_t epoch = (int32_t)(a.st->scans + 1); // the scan that just finished stamped this value
         int64_t cn = 0, mn = INT64_MAX, mx = 0;
         for (int i = tid; i < a.n_partials; i += kThreads) {
-            cn += a.soft_partials[3 * (int64_t)i];
-            const int64_t q1 = a.soft_partials[3 * (int64_t)i + 1], q2 = a.soft_partials[3 * (int64_t)i + 2];
+            cn += (int64_t)ld_agent(a.soft_partials + 3 * (int64_t)i);
+            const int64_t q1 = (int64_t)ld_agent(a.soft_partials + 3 * (int64_t)i + 1), q2 = (int64_t)ld_agent(a.soft_partials + 3 * (int64_t)i + 2);
             mn = q1 < mn ? q1 : mn;
             mx = q2 > mx ? q2 : mx;
         }
@@ -856,9 +863,12 @@ __global__ __launch_bounds__(kThreads) void k_final(FinalArgs a) {
     decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, a.soft.n ? &soft : nullptr);
 }
 
+// k_final: the same reduction + decision as a separate one-block launch (a.ticket == NULL in k_scan).
+__global__ __launch_bounds__(kThreads) void k_final(ScanArgs a) { final_body(a); }
+
 // k_decide (distributed): every rank reduces the gathered records identically, so all ranks agree on
 // the winner; only the owning rank's columns change ("only the owning rank updates").
-__global__ void k_decide(FinalArgs a) {
+__global__ void k_decide(ScanArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (a.st->done) return;
     uint64_t key = 0;
