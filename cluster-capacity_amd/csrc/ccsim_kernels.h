@@ -674,13 +674,18 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
         const int64_t g = key_index(key);
         const int64_t i = g - a.c.global_offset;
         if (i >= 0 && i < a.c.n) { // this shard owns the winner: NodeInfo.update (types.go:409-428)
+            // one thread, latency-bound: issue every load of the row before the first store
+            const int64_t r0 = a.c.req[0][i], r1 = a.c.req[1][i], z0 = a.c.nz_mcpu[i], z1 = a.c.nz_mem[i];
+            const int32_t pc = a.c.pod_count[i], pl = a.c.placed_cnt[i];
+            a.c.req[0][i] = r0 + a.p.req[0];
+            a.c.req[1][i] = r1 + a.p.req[1];
+            a.c.nz_mcpu[i] = z0 + a.p.nz_mcpu;
+            a.c.nz_mem[i] = z1 + a.p.nz_mem;
+            a.c.pod_count[i] = pc + 1;
+            a.c.placed_cnt[i] = pl + 1;
 #pragma unroll 1
-            for (int col = 0; col < a.p.ncol; col++)
+            for (int col = 2; col < a.p.ncol; col++)
                 if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
-            a.c.nz_mcpu[i] += a.p.nz_mcpu;
-            a.c.nz_mem[i] += a.p.nz_mem;
-            a.c.pod_count[i] += 1;
-            a.c.placed_cnt[i] += 1;
             if (a.pts.n) { // the clone now counts towards its domains (filtering.go:255-296 on the next cycle)
                 const uint32_t eb = a.pts.elig[i];
                 for (int c = 0; c < a.pts.n; c++) {
