@@ -179,3 +179,31 @@ def test_sharded_protocol_matches_oracle(ccref, mode, world, cfg, n, limit):
     assert np.array_equal(log[: ref.placed], ref.log)
     if ref.stop == M.STOP_UNSCHEDULABLE:
         assert np.array_equal(sum(r.hist for r in res), ref.hist)
+
+
+def test_full_size_batched_equals_sequential_1m_nodes():
+    """BASELINE full size: the two engine modes must produce the same placement sequence (the oracle is too slow
+    here; its equality with the sequential mode is established at the sizes above)."""
+    nodes, pod, prof = synth.make_config("C4", n_nodes=1_000_000)
+    L = 20_000
+    e = _engine(nodes, pod, prof)
+    seq = e.run(max_limit=L, mode="sequential", log_cap=L)
+    e.reset_state()
+    bat = e.run(max_limit=L, mode="batched", log_cap=L)
+    assert seq.placed == bat.placed == L and seq.stop == bat.stop == M.STOP_LIMIT
+    assert np.array_equal(seq.log, bat.log)
+    assert np.array_equal(seq.per_node_count, bat.per_node_count)
+    assert bat.scans < seq.scans / 50  # levels, not cycles
+    # exhaustive batched run: conservation and capacity properties at full size
+    e.reset_state()
+    full = e.run(max_limit=0, mode="batched", want_log=False)
+    assert full.stop == M.STOP_UNSCHEDULABLE and int(full.per_node_count.astype(np.int64).sum()) == full.placed
+    cnt = full.per_node_count.astype(np.int64)
+    assert (cnt * 150 <= nodes.alloc[0] - nodes.req[0]).all() and (cnt + nodes.pod_count <= nodes.alloc_pods).all()
+    ok = (nodes.unschedulable == 0) & (np.isin(nodes.taintset_id, [0, 1, 2, 3]))
+    # every node that can still take one more pod must be statically infeasible (none here: pod tolerates infra)
+    room = (cnt + 1) * 150 <= nodes.alloc[0] - nodes.req[0]
+    room &= (cnt + 1) * (100 << 20) <= nodes.alloc[1] - nodes.req[1]
+    room &= cnt + nodes.pod_count + 1 <= nodes.alloc_pods
+    assert not (room & ok).any()
+    assert full.hist[M.R_UNSCHEDULABLE] == int(nodes.unschedulable.sum())
