@@ -12,7 +12,7 @@ the dynamic node columns device-to-device (ccsim_reset_state, inside the timed r
 Workload (BASELINE config 4, "C4"): 1M synthetic nodes per GPU, default plugin set, examples/pod.yaml +
 toleration + preferred node affinity, percentageOfNodesToScore=100.  N=1: the 1M-node snapshot on one
 GPU.  N>1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- an N x 1M-node cluster
-sharded by contiguous node range (1M nodes per GPU), one RCCL all-gather of a 128-byte record per pass
+sharded by contiguous node range (1M nodes per GPU), one RCCL all-gather of a 256-byte record per pass
 (the max-loc exchange), only owning ranks update their columns.  `--scaling strong` shards ONE 1M-node
 snapshot over the N GPUs instead (BASELINE config 4 literally); it is latency-bound by construction (the
 per-pass GPU work shrinks N-fold while the exchange does not), see DESIGN.md section 5.

@@ -15,7 +15,7 @@ from . import model as M
 MAX_RES = M.MAX_RES
 MAX_LABEL_COLS = 32
 NREASON = M.NREASON
-XCHG_WORDS = 16
+XCHG_WORDS = 32
 MODE_SEQUENTIAL, MODE_BATCHED = 0, 1
 MODES = {"sequential": MODE_SEQUENTIAL, "batched": MODE_BATCHED}
 
@@ -115,6 +115,10 @@ SYMBOLS = {
     "ccsim_dist_decide": (C.c_int, [C.c_void_p]),
     "ccsim_dist_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "ccsim_dist_finish": (C.c_int, [C.c_void_p, C.POINTER(CReport)]),
+    "ccsim_dist_table_count": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_table": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32)]),
+    "ccsim_dist_tables_done": (C.c_int, [C.c_void_p]),
     "ccsim_reset_state": (C.c_int, [C.c_void_p]),
     "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
@@ -403,6 +407,18 @@ class Engine:
     def dist_begin(self, max_limit: int, mode: str, n_ranks: int, rank: int, send_ptr: int, recv_ptr: int, log_cap: int = 0):
         self._chk(self.lib.ccsim_dist_begin(self.h, int(max_limit), MODES[mode], int(n_ranks), int(rank),
                                             C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(log_cap)), "ccsim_dist_begin")
+
+    def dist_tables(self):
+        """[(device pointer, element count, element bytes, op)] of the replicated topology tables (op 0 SUM, 1 MAX)."""
+        out = []
+        for i in range(self.lib.ccsim_dist_table_count(self.h)):
+            ptr, n, eb, op = C.c_void_p(), C.c_int64(), C.c_int32(), C.c_int32()
+            self._chk(self.lib.ccsim_dist_table(self.h, i, C.byref(ptr), C.byref(n), C.byref(eb), C.byref(op)), "ccsim_dist_table")
+            out.append((int(ptr.value), int(n.value), int(eb.value), int(op.value)))
+        return out
+
+    def dist_tables_done(self):
+        self._chk(self.lib.ccsim_dist_tables_done(self.h), "ccsim_dist_tables_done")
 
     def dist_scan(self):
         self._chk(self.lib.ccsim_dist_scan(self.h), "ccsim_dist_scan")

@@ -57,6 +57,10 @@ struct ccsim_engine {
     DevSoft soft{};
     uint64_t *d_soft_partials = nullptr;
     std::vector<std::pair<int32_t *, size_t>> soft_flags; // epoch flag tables, cleared at the start of every run
+    struct DistTable { void *ptr; int64_t len; int32_t elem_bytes, op; };
+    std::vector<DistTable> dist_tables;   // replicated tables the caller all-reduces across ranks (ccsim_dist_table)
+    std::vector<int32_t *> pts_present;   // per hard constraint: domain-presence flags
+    unsigned long long *d_ipa_totals = nullptr; // [3] affinity entries, existing anti-affinity entries, PreScore hits
     int64_t ipa_aff_total0 = 0, ipa_exist_total0 = 0, ipa_entries0 = 0; // initial PreFilter / PreScore totals
     int64_t ipa_aff_total_cur = 0, ipa_exist_total_cur = 0, ipa_entries_cur = 0; // ... after the runs so far
     uint64_t *d_pts_min_partials = nullptr;
@@ -450,6 +454,9 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     e->pts_tables.clear();
     e->pts_table_len.clear();
     e->soft_flags.clear();
+    e->dist_tables.clear();
+    e->pts_present.clear();
+    e->d_ipa_totals = nullptr;
     if (pod->n_spread < 0 || pod->n_spread > CCSIM_MAX_TSC) return fail(e, -EINVAL, "n_spread out of range");
     for (int pass = 0; pass < 2 && pod->n_spread > 0; pass++) { // pass 0: hard constraints, pass 1: soft constraints
         const bool hard = pass == 0;
@@ -514,6 +521,11 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             pt.n_present[j] = np_;
         }
         if (hard) {
+            for (size_t j = 0; j < idx.size(); j++) {
+                e->dist_tables.push_back({pt.tbl[j], (int64_t)e->pts_table_len[first + j], 4, 0});
+                e->dist_tables.push_back({d_present[j], (int64_t)e->pts_table_len[first + j], 4, 1});
+                e->pts_present.push_back(d_present[j]);
+            }
             e->pts = pt;
             if ((rc = dev_alloc(e, &e->d_pts_min_partials, (size_t)kMaxGrid * kMaxTsc, e->pod_allocs))) return rc;
         } else {
@@ -580,7 +592,8 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             ii.exist_anti[k] = ea, ii.score_existing[k] = sx;
         }
         unsigned long long *d_tot = nullptr;
-        if ((rc = dev_alloc(e, &d_tot, (size_t)2, e->pod_allocs))) return rc;
+        if ((rc = dev_alloc(e, &d_tot, (size_t)3, e->pod_allocs))) return rc;
+        e->d_ipa_totals = d_tot;
         if ((rc = dev_alloc(e, &e->d_ipa_partials, (size_t)kMaxGrid * 2, e->pod_allocs))) return rc;
         ii.ipa = d;
         ii.totals = d_tot;
@@ -594,6 +607,10 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         e->ipa_aff_total0 = (int64_t)tot[0];
         e->ipa_exist_total0 = (int64_t)tot[1];
         e->ipa_entries0 = ip.entries_existing;
+        const unsigned long long ent = (unsigned long long)ip.entries_existing;
+        HIPCHK(e, hipMemcpy(d_tot + 2, &ent, sizeof ent, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < e->ipa_tables.size(); i++) e->dist_tables.push_back({e->ipa_tables[i].first, (int64_t)e->ipa_table_len[i], 8, 0});
+        e->dist_tables.push_back({d_tot, 3, 8, 0});
     }
     e->have_pod = true;
     return 0;
@@ -710,16 +727,14 @@ static int launch_level_final(ccsim_engine *e) {
 static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_cap) {
     if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
     if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
-    if (e->ipa.on && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
-        return fail(e, -ENOSYS, "inter-pod affinity couples nodes through topology pairs: sequential mode on one GPU only, for now");
+    if (e->ipa.on && mode == CCSIM_MODE_BATCHED)
+        return fail(e, -ENOSYS, "inter-pod affinity couples nodes through topology pairs: use CCSIM_MODE_SEQUENTIAL");
     if (e->soft.n > 0 && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
         return fail(e, -ENOSYS, "ScheduleAnyway topology spread constraints score every node against cluster-wide counts: "
                                 "sequential mode on one GPU only, for now");
     if (e->pts.n > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "batched mode is not valid with topology spread constraints (a placement changes the feasibility of "
                                 "other nodes): use CCSIM_MODE_SEQUENTIAL");
-    if (e->pts.n > 0 && e->n_ranks > 0)
-        return fail(e, -ENOSYS, "topology spread constraints are single-GPU only for now");
     if (mode == CCSIM_MODE_BATCHED && !e->pod.fit_enabled)
         return fail(e, -ENOSYS, "batched mode needs the NodeResourcesFit filter (a run-down is bounded by the node's pod capacity)");
     HIPCHK(e, hipSetDevice(e->device));
@@ -1020,6 +1035,41 @@ extern "C" int ccsim_dist_decide(ccsim_engine *e) {
     else
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, scan_args(e));
     HIPCHK(e, hipGetLastError());
+    return 0;
+}
+
+// ---- replicated topology tables across ranks (include/ccsim.h) ------------------------------------------------
+extern "C" int ccsim_dist_table_count(ccsim_engine *e) { return e && e->have_pod ? (int)e->dist_tables.size() : 0; }
+
+extern "C" int ccsim_dist_table(ccsim_engine *e, int32_t idx, void **ptr, int64_t *len, int32_t *elem_bytes, int32_t *op) {
+    if (!e || !e->have_pod || idx < 0 || idx >= (int)e->dist_tables.size() || !ptr || !len || !elem_bytes || !op) return -EINVAL;
+    const auto &t = e->dist_tables[(size_t)idx];
+    *ptr = t.ptr, *len = t.len, *elem_bytes = t.elem_bytes, *op = t.op;
+    return 0;
+}
+
+extern "C" int ccsim_dist_tables_done(ccsim_engine *e) {
+    if (!e || !e->have_pod) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (size_t c = 0; c < e->pts_tables.size(); c++) // the reduced tables are the new pristine state
+        HIPCHK(e, hipMemcpy(e->pts_tables[c].second, e->pts_tables[c].first, e->pts_table_len[c] * 4, hipMemcpyDeviceToDevice));
+    for (size_t c = 0; c < e->ipa_tables.size(); c++)
+        HIPCHK(e, hipMemcpy(e->ipa_tables[c].second, e->ipa_tables[c].first, e->ipa_table_len[c] * 8, hipMemcpyDeviceToDevice));
+    for (size_t j = 0; j < e->pts_present.size(); j++) { // len(TpValueToMatchNum[c]) over the whole cluster
+        const size_t len = e->pts_table_len[j];
+        std::vector<int32_t> pres(len);
+        HIPCHK(e, hipMemcpy(pres.data(), e->pts_present[j], len * 4, hipMemcpyDeviceToHost));
+        int32_t np_ = 0;
+        for (size_t v = 1; v < len; v++) np_ += pres[v] != 0;
+        e->pts.n_present[j] = np_;
+    }
+    if (e->d_ipa_totals) {
+        unsigned long long tot[3] = {0, 0, 0};
+        HIPCHK(e, hipMemcpy(tot, e->d_ipa_totals, sizeof tot, hipMemcpyDeviceToHost));
+        e->ipa_aff_total0 = (int64_t)tot[0], e->ipa_exist_total0 = (int64_t)tot[1], e->ipa_entries0 = (int64_t)tot[2];
+    }
+    e->begun = false;
     return 0;
 }
 

@@ -146,14 +146,23 @@ struct __attribute__((aligned(16))) Partial {
     uint32_t nfeas;
 };
 
-// exchange record (int64[16], see CCSIM_XCHG_WORDS).  Sequential mode uses the first four words (key, mt,
+// exchange record (int64[32], see CCSIM_XCHG_WORDS).  Sequential mode uses the first four words (key, mt,
 // ma combine with MAX, nfeas with SUM); batched mode adds the plan of the shard's own top level.
 struct XRec {
     int64_t key, mt, ma, nfeas;
     int64_t c_mt, c_ma, committed, n_top;
     int64_t T, e_mt, e_ma, cut_mt;
-    int64_t cut_ma, pad[3];
+    int64_t cut_ma;
+    // sequential mode, topology-coupled plugins: what the global verification needs, and the topology value ids of this
+    // shard's best node ("the winner's domain ids travel with it": every rank updates its replicated count tables)
+    int64_t pts_min[kMaxTsc];
+    int64_t ipa_mn, ipa_mx;
+    int64_t win_elig;   // PodTopologySpread eligibility bits of the node
+    int32_t win_pts_v[kMaxTsc];
+    int32_t win_ipa_v[4];
+    int64_t pad[2];
 };
+static_assert(sizeof(XRec) == 32 * 8, "XRec must be CCSIM_XCHG_WORDS int64");
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
@@ -626,6 +635,12 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
 // The pending scan was computed with (mt_a, ma_a); if the true maxima over the feasible set differ,
 // the scores were normalized with the wrong constants: fix the constants and rescan, commit nothing.
 // ------------------------------------------------------------------------------------------------
+struct WinnerTopo { // topology value ids of the winning node (from the owning rank's record in the sharded path)
+    uint32_t elig;
+    int32_t pts_v[kMaxTsc];
+    int32_t ipa_v[4];
+};
+
 struct SoftAgg { // one scan's PodTopologySpread PreScore facts
     int64_t size[kMaxTsc]; // candidate domains per constraint (hostname: feasible non-ignored nodes)
     int64_t mn, mx;
@@ -634,7 +649,7 @@ struct SoftAgg { // one scan's PodTopologySpread PreScore facts
 template <class A>
 __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas,
                                               const int32_t *pts_min, int64_t ipa_mn = 0, int64_t ipa_mx = 0,
-                                              const SoftAgg *soft = nullptr) {
+                                              const SoftAgg *soft = nullptr, const WinnerTopo *wt = nullptr) {
     DevState st = *a.st;
     st.winner = -1;
     if (st.done) return;
@@ -686,36 +701,39 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
 #pragma unroll 1
             for (int col = 2; col < a.p.ncol; col++)
                 if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
-            if (a.pts.n) { // the clone now counts towards its domains (filtering.go:255-296 on the next cycle)
-                const uint32_t eb = a.pts.elig[i];
-                for (int c = 0; c < a.pts.n; c++) {
-                    const int32_t v = a.pts.label[c][i];
-                    if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.pts.self_match[c]) a.pts.tbl[c][v] += 1;
-                }
+        }
+        // Replicated topology tables: EVERY rank applies the winner's contribution (the clone is an existing pod of the
+        // next cycle).  Single GPU: the ids are read from the node's own columns; sharded: from the owner's record.
+        const bool local = i >= 0 && i < a.c.n;
+        if (a.pts.n && (local || wt)) { // filtering.go:255-296 on the next cycle
+            const uint32_t eb = wt ? wt->elig : a.pts.elig[i];
+            for (int c = 0; c < a.pts.n; c++) {
+                const int32_t v = wt ? wt->pts_v[c] : a.pts.label[c][i];
+                if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.pts.self_match[c]) a.pts.tbl[c][v] += 1;
             }
-            if (a.soft.n) { // scoring.go:147-178 on the next cycle
-                const uint32_t eb = a.soft.elig[i];
-                for (int c = 0; c < a.soft.n; c++) {
-                    const int32_t v = a.soft.label[c][i];
-                    if (v && !a.soft.is_hostname[c] && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.soft.self_match[c]) a.soft.tbl[c][v] += 1;
-                }
+        }
+        if (a.soft.n && local) { // scoring.go:147-178 on the next cycle (single GPU only)
+            const uint32_t eb = a.soft.elig[i];
+            for (int c = 0; c < a.soft.n; c++) {
+                const int32_t v = a.soft.label[c][i];
+                if (v && !a.soft.is_hostname[c] && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.soft.self_match[c]) a.soft.tbl[c][v] += 1;
             }
-            if (a.ipa.on) { // the clone is an existing pod of the next cycle (filtering.go:204-272, scoring.go:81-125)
-                for (int k = 0; k < a.ipa.n_keys; k++) {
-                    const int32_t v = a.ipa.label[k][i];
-                    if (!v) continue;
-                    if (a.ipa.self_aff && a.ipa.aff_terms_on_key[k]) {
-                        a.ipa.aff[k][v] += a.ipa.aff_terms_on_key[k];
-                        st.ipa_aff_total += a.ipa.aff_terms_on_key[k];
-                    }
-                    if (a.ipa.anti_self_on_key[k]) {
-                        a.ipa.anti[k][v] += a.ipa.anti_self_on_key[k];
-                        a.ipa.exist[k][v] += a.ipa.anti_self_on_key[k];
-                        st.ipa_exist_total += a.ipa.anti_self_on_key[k];
-                    }
-                    a.ipa.score[k][v] += a.ipa.score_self[k];
-                    st.ipa_entries += a.ipa.self_entries[k];
+        }
+        if (a.ipa.on && (local || wt)) { // filtering.go:204-272, scoring.go:81-125
+            for (int k = 0; k < a.ipa.n_keys; k++) {
+                const int32_t v = wt ? wt->ipa_v[k] : a.ipa.label[k][i];
+                if (!v) continue;
+                if (a.ipa.self_aff && a.ipa.aff_terms_on_key[k]) {
+                    a.ipa.aff[k][v] += a.ipa.aff_terms_on_key[k];
+                    st.ipa_aff_total += a.ipa.aff_terms_on_key[k];
                 }
+                if (a.ipa.anti_self_on_key[k]) {
+                    a.ipa.anti[k][v] += a.ipa.anti_self_on_key[k];
+                    a.ipa.exist[k][v] += a.ipa.anti_self_on_key[k];
+                    st.ipa_exist_total += a.ipa.anti_self_on_key[k];
+                }
+                a.ipa.score[k][v] += a.ipa.score_self[k];
+                st.ipa_entries += a.ipa.self_entries[k];
             }
         }
         if (a.log && st.placed < st.log_cap) a.log[st.placed] = (int32_t)g;
@@ -856,12 +874,21 @@ __device__ void final_body(const A &a) {
             ipa_mx = s_im[1][w] > ipa_mx ? s_im[1][w] : ipa_mx;
         }
     }
-    if (a.n_ranks > 0) {
+    if (a.n_ranks > 0) { // publish this shard's record; k_decide finishes after the exchange
         XRec r{};
         r.key = (int64_t)key;
         r.mt = mt;
         r.ma = ma;
         r.nfeas = nf;
+        for (int c = 0; c < kMaxTsc; c++) r.pts_min[c] = c < a.pts.n ? pts_min[c] : 0x7fffffff;
+        r.ipa_mn = a.ipa.on ? ipa_mn : INT64_MAX;
+        r.ipa_mx = a.ipa.on ? ipa_mx : INT64_MIN;
+        if (key && (a.pts.n || a.ipa.on)) { // topology value ids of this shard's best node
+            const int64_t i = key_index(key) - a.c.global_offset;
+            r.win_elig = a.pts.n ? a.pts.elig[i] : 0;
+            for (int c = 0; c < a.pts.n; c++) r.win_pts_v[c] = a.pts.label[c][i];
+            for (int k = 0; k < a.ipa.n_keys; k++) r.win_ipa_v[k] = a.ipa.label[k][i];
+        }
         *a.xsend = r;
         return;
     }
@@ -878,15 +905,29 @@ __global__ void k_decide(ScanArgs a) {
     if (a.st->done) return;
     uint64_t key = 0;
     uint32_t mt = 0, ma = 0;
-    int64_t nf = 0;
+    int64_t nf = 0, ipa_mn = INT64_MAX, ipa_mx = INT64_MIN;
+    int32_t pts_min[kMaxTsc];
+    for (int c = 0; c < kMaxTsc; c++) pts_min[c] = 0x7fffffff;
+    int win = -1;
     for (int r = 0; r < a.n_ranks; r++) {
-        const XRec q = a.xrecv[r];
-        key = (uint64_t)q.key > key ? (uint64_t)q.key : key;
+        const XRec &q = a.xrecv[r];
+        if ((uint64_t)q.key > key) key = (uint64_t)q.key, win = r;
         mt = (uint32_t)q.mt > mt ? (uint32_t)q.mt : mt;
         ma = (uint32_t)q.ma > ma ? (uint32_t)q.ma : ma;
         nf += q.nfeas;
+        for (int c = 0; c < a.pts.n; c++) pts_min[c] = (int32_t)q.pts_min[c] < pts_min[c] ? (int32_t)q.pts_min[c] : pts_min[c];
+        ipa_mn = q.ipa_mn < ipa_mn ? q.ipa_mn : ipa_mn;
+        ipa_mx = q.ipa_mx > ipa_mx ? q.ipa_mx : ipa_mx;
     }
-    decide_commit(a, key, mt, ma, nf, nullptr); // spread constraints are single-GPU only for now (pts.n == 0)
+    WinnerTopo wt{};
+    const bool coupled = a.pts.n || a.ipa.on;
+    if (coupled && win >= 0) { // the winner's domain ids travel with its record
+        const XRec &q = a.xrecv[win];
+        wt.elig = (uint32_t)q.win_elig;
+        for (int c = 0; c < kMaxTsc; c++) wt.pts_v[c] = q.win_pts_v[c];
+        for (int k = 0; k < 4; k++) wt.ipa_v[k] = q.win_ipa_v[k];
+    }
+    decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, nullptr, coupled ? &wt : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

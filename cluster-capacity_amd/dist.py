@@ -29,6 +29,27 @@ def shard_bounds(n_global: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, min(n_global, lo + per)
 
 
+def shard_pod(pod: M.PodSpec, lo: int, hi: int) -> M.PodSpec:
+    """The pod spec for the shard [lo, hi): per-node side arrays (existing matching pods etc.) follow the nodes."""
+    import copy
+
+    p = copy.copy(pod)
+    cut = lambda a: None if a is None else a[lo:hi]  # noqa: E731
+    p.spread = [copy.copy(k) for k in pod.spread]
+    for k in p.spread:
+        k.node_match_count, k.node_included = cut(k.node_match_count), cut(k.node_included)
+    if pod.ipa is not None:
+        q = copy.copy(pod.ipa)
+        q.aff_existing = cut(q.aff_existing)
+        q.anti_existing = [cut(a) for a in q.anti_existing]
+        q.exist_anti = [cut(a) for a in q.exist_anti]
+        q.score_existing = [cut(a) for a in q.score_existing]
+        if lo > 0:
+            q.entries_existing = 0  # a cluster-wide count: contributed once (rank 0), then all-reduced
+        p.ipa = q
+    return p
+
+
 class DistRunner:
     """Drives one rank's engine; `collective(recv, send)` performs the all-gather."""
 
@@ -54,6 +75,32 @@ class DistRunner:
         return e.dist_finish(want_log, log_cap)
 
 
+class _DevArray:
+    """Zero-copy view of an engine table for torch (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, n: int, elem_bytes: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4" if elem_bytes == 4 else "<i8", "data": (ptr, False),
+                                         "version": 2}
+
+
+def table_tensors(engine, device: int):
+    """The engine's replicated topology tables as torch tensors sharing their memory, with the reduction each needs."""
+    import torch
+
+    return [(torch.as_tensor(_DevArray(p, n, eb), device=f"cuda:{device}"), "max" if op == 1 else "sum")
+            for (p, n, eb, op) in engine.dist_tables()]
+
+
+def sync_tables(engine, device: int):
+    """Topology-coupled plugins: every rank filled its count tables from its own nodes only -- all-reduce them
+    (RCCL) so that every rank holds the cluster-wide tables (include/ccsim.h ccsim_dist_table)."""
+    import torch.distributed as dist
+
+    for t, op in table_tensors(engine, device):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    engine.dist_tables_done()
+
+
 def make_torch_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int, n_global: int,
                       device: int, rounds_per_poll: int = 32) -> DistRunner:
     import torch
@@ -67,6 +114,8 @@ def make_torch_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profil
     eng = capi.Engine(device=device, stream=ts.cuda_stream, use_graph=False)
     eng._torch_stream = ts  # keep it alive
     eng.load(nodes_shard, pod, profile, global_offset=global_offset, n_global=n_global)
+    if eng.dist_tables():
+        sync_tables(eng, device)
     world = dist.get_world_size()
     send = torch.zeros(capi.XCHG_WORDS, dtype=torch.int64, device=f"cuda:{device}")
     recv = torch.zeros(capi.XCHG_WORDS * world, dtype=torch.int64, device=f"cuda:{device}")

@@ -269,13 +269,22 @@ int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req_mem, int64
  * ccsim_dist_poll() synchronizes and reads the done flag; call it every few passes.
  * With a placement log each rank fills the positions of ITS placements in its own log copy and leaves
  * -1 elsewhere: the element-wise maximum over ranks is the global log. */
-#define CCSIM_XCHG_WORDS 16
+#define CCSIM_XCHG_WORDS 32
 int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, int32_t rank, void *sendbuf,
                      void *recvbuf, int64_t log_cap);
 int ccsim_dist_scan(ccsim_engine *e);
 int ccsim_dist_decide(ccsim_engine *e);
 int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed);
 int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out);
+
+/* Topology-coupled plugins on several GPUs (hard PodTopologySpread constraints, InterPodAffinity): the per-domain
+ * count / score tables are replicated on every rank, but ccsim_set_pod can only fill them from the rank's own nodes.
+ * After ccsim_set_pod on every rank the caller all-reduces each table in place across ranks (table i:
+ * ccsim_dist_table -> device pointer, element count, element size 4 / 8, op 0 = SUM / 1 = MAX), then calls
+ * ccsim_dist_tables_done on every rank.  No-op for pods without such plugins (count 0). */
+int ccsim_dist_table_count(ccsim_engine *e);
+int ccsim_dist_table(ccsim_engine *e, int32_t idx, void **ptr, int64_t *len, int32_t *elem_bytes, int32_t *op);
+int ccsim_dist_tables_done(ccsim_engine *e);
 
 /* Restore the dynamic node columns (Requested / NonZeroRequested / pod count) to the loaded snapshot,
  * device-to-device from pristine copies kept in HBM: the next ccsim_run starts from the same cluster

@@ -142,9 +142,20 @@ class _LocalShards:
         for r in range(world):
             lo, hi = ccdist.shard_bounds(nodes.n, world, r)
             e = capi.Engine(device=0, stream=stream, use_graph=False)
-            e.load(nodes.slice(lo, hi), pod, prof, global_offset=lo, n_global=nodes.n)
+            e.load(nodes.slice(lo, hi), ccdist.shard_pod(pod, lo, hi), prof, global_offset=lo, n_global=nodes.n)
             self.engines.append(e)
             self.send.append(torch.zeros(capi.XCHG_WORDS, dtype=torch.int64, device="cuda:0"))
+        # replicated topology tables: the in-process stand-in for dist.all_reduce over the ranks
+        tabs = [ccdist.table_tensors(e, 0) for e in self.engines]
+        for j in range(len(tabs[0])):
+            stack = torch.stack([t[j][0] for t in tabs])
+            red = stack.max(0).values if tabs[0][j][1] == "max" else stack.sum(0)
+            for t in tabs:
+                t[j][0].copy_(red)
+        torch.cuda.synchronize()
+        for e in self.engines:
+            if tabs[0]:
+                e.dist_tables_done()
 
     def run(self, limit, mode, log_cap):
         from cluster_capacity_amd import dist as ccdist
@@ -207,3 +218,26 @@ def test_full_size_batched_equals_sequential_1m_nodes():
     room &= cnt + nodes.pod_count + 1 <= nodes.alloc_pods
     assert not (room & ok).any()
     assert full.hist[M.R_UNSCHEDULABLE] == int(nodes.unschedulable.sum())
+
+
+@pytest.mark.parametrize("world,seed", [(2, 0), (3, 1), (2, 2), (4, 3), (2, 4), (3, 5)])
+def test_sharded_protocol_with_topology_coupled_plugins(ccref, world, seed):
+    """Hard spread constraints + inter-pod affinity across shards: replicated count tables (all-reduced after
+    set_pod), global verification of the assumed minimum / min-max, the winner's domain ids travelling in the record."""
+    rng = np.random.default_rng(300 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(50, 900)))
+    pod.spread = H.random_spread(rng, nodes, n_constraints=int(rng.integers(0, 3)))
+    if seed % 2 == 0 or not pod.spread:
+        pod.ipa = H.random_ipa(rng, nodes)
+    limit = int(rng.choice([0, 60, 150]))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    if ref.placed > 1500:
+        limit = 1500
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    res, log = _LocalShards(nodes, pod, prof, world).run(limit, "sequential", max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res)
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    assert np.array_equal(log[: ref.placed], ref.log)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
+        assert sum(r.n_code_unschedulable for r in res) == ref.n_code_unschedulable
