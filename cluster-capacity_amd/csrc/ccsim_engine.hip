@@ -74,8 +74,6 @@ struct ccsim_engine {
     DevState *d_state = nullptr;
     DevState *h_state = nullptr; // pinned
     uint64_t *d_partials = nullptr; // [kMaxGrid][2]
-    unsigned *d_ticket = nullptr;   // fused final: arrival counter of the scan blocks
-    int fused_final = 1;
     XRec *d_xsend = nullptr, *d_xrecv = nullptr; // distributed exchange (caller's or ours)
     int n_ranks = 0;
     int32_t *d_log = nullptr;
@@ -170,7 +168,6 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     e->rounds_per_sync = cfg->rounds_per_sync;
     e->use_graph = cfg->use_graph;
     e->time_passes = cfg->time_passes;
-    if (const char *f = getenv("CCSIM_FUSED_FINAL")) e->fused_final = atoi(f); // tuning / fallback knob
     if (hipSetDevice(e->device) != hipSuccess) {
         delete e;
         return -EIO;
@@ -188,7 +185,6 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
         hipHostMalloc((void **)&e->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&e->d_state, sizeof(DevState)) != hipSuccess ||
         hipMalloc((void **)&e->d_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
-        hipMalloc((void **)&e->d_ticket, sizeof(unsigned)) != hipSuccess ||
         hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess) {
         ccsim_destroy(e);
         return -ENOMEM;
@@ -207,7 +203,6 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     free_list(e->pod_allocs);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_partials) (void)hipFree(e->d_partials);
-    if (e->d_ticket) (void)hipFree(e->d_ticket);
     if (e->d_hist) (void)hipFree(e->d_hist);
     if (e->d_log) (void)hipFree(e->d_log);
     if (e->h_state) (void)hipHostFree(e->h_state);
@@ -638,12 +633,6 @@ static void launch_scan_t(ccsim_engine *e, const ScanArgs &a, hipEvent_t t0, hip
     else CCSIM_LAUNCH((k_scan<kMaxExtra, PTS>), g, b, e->stream, t0, t1, a);
 }
 
-static bool scan_fused(const ccsim_engine *e) {
-    // the soft-spread candidate flags are plain stores of every block, read by the reduction: keep the kernel boundary
-    (void)e;
-    return false; // see ScanArgs::ticket
-}
-
 static ScanArgs scan_args(ccsim_engine *e) {
     ScanArgs a{};
     a.c = e->cols, a.p = e->pod, a.st = e->d_state, a.partials = e->d_partials, a.chunk = e->chunk;
@@ -651,22 +640,20 @@ static ScanArgs scan_args(ccsim_engine *e) {
     a.ipa = e->ipa, a.ipa_partials = e->d_ipa_partials;
     a.soft = e->soft, a.soft_partials = e->d_soft_partials;
     a.n_partials = e->grid;
-    a.ticket = scan_fused(e) ? e->d_ticket : nullptr;
     a.xsend = e->d_xsend, a.xrecv = e->d_xrecv, a.n_ranks = e->n_ranks;
     a.log = e->d_log;
     return a;
 }
 
-static int launch_scan(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, bool with_final = true) {
+static int launch_scan(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
     ScanArgs a = scan_args(e);
-    if (!with_final) a.ticket = nullptr; // ccsim_time_scan: the bare pass
     if (e->pts.n > 0 || e->ipa.on || e->soft.n > 0) launch_scan_t<true>(e, a, t0, t1);
     else launch_scan_t<false>(e, a, t0, t1);
     return 0;
 }
 
-static int launch_final(ccsim_engine *e) { // no-op when the scan's last block already did it
-    if (!scan_fused(e)) hipLaunchKernelGGL(k_final, dim3(1), dim3(kThreads), 0, e->stream, scan_args(e));
+static int launch_final(ccsim_engine *e) {
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kThreads), 0, e->stream, scan_args(e));
     return 0;
 }
 
@@ -764,7 +751,6 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     *e->h_state = st;
     HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
-    HIPCHK(e, hipMemsetAsync(e->d_ticket, 0, sizeof(unsigned), e->stream));
     if (e->d_log && e->n_ranks > 0) // shards fill disjoint positions of the global log: -1 = "not mine"
         HIPCHK(e, hipMemsetAsync(e->d_log, 0xff, sizeof(int32_t) * (size_t)e->log_cap, e->stream));
     e->kernel_ms = 0;
@@ -992,9 +978,9 @@ extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int
     if ((rc = begin_run(e, 0, mode, 0))) return rc; // fresh state: a finished run leaves done != 0
     HIPCHK(e, hipSetDevice(e->device));
     const bool lvl = mode == CCSIM_MODE_BATCHED; // k_level_score: the batched mode's full pass
-    for (int i = 0; i < 3; i++) lvl ? launch_level_score(e) : launch_scan(e, nullptr, nullptr, false);
+    for (int i = 0; i < 3; i++) lvl ? launch_level_score(e) : launch_scan(e);
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    for (int i = 0; i < iters; i++) lvl ? launch_level_score(e) : launch_scan(e, nullptr, nullptr, false);
+    for (int i = 0; i < iters; i++) lvl ? launch_level_score(e) : launch_scan(e);
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipGetLastError());

@@ -412,7 +412,7 @@ __device__ __forceinline__ int64_t ipa_normalize(int64_t raw, int64_t mn, int64_
     return (int64_t)f;
 }
 
-// One argument block for the scan, the (fused or separate) final reduction and the distributed decide.
+// One argument block for the scan, the one-block final reduction / decision and the distributed decide.
 struct ScanArgs {
     DevCols c;
     DevPod p;
@@ -425,9 +425,8 @@ struct ScanArgs {
     uint64_t *ipa_partials;     // [grid][2]: per-block min / max raw InterPodAffinity score over feasible nodes
     DevSoft soft;
     uint64_t *soft_partials;    // [grid][3]: feasible non-ignored nodes, min / max raw PodTopologySpread score
-    int32_t n_partials;         // = scan grid
-    unsigned *ticket;           // unused (a fused last-block reduction was measured SLOWER: inlining or calling the
-                                // reduction from k_scan costs the scan its registers / occupancy -- 44k -> 36k cycles/s)
+    int32_t n_partials;         // = scan grid (a fused last-block reduction inside k_scan was measured SLOWER:
+                                // inlined or called, it costs the scan its registers / occupancy -- 44k -> 36k cycles/s)
     XRec *xsend;                // distributed: this shard's record out
     const XRec *xrecv;          // distributed: gathered records in
     int32_t n_ranks;            // 0 = single GPU (decide from the local record)
@@ -895,7 +894,7 @@ __device__ void final_body(const A &a) {
     decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, a.soft.n ? &soft : nullptr);
 }
 
-// k_final: the same reduction + decision as a separate one-block launch (a.ticket == NULL in k_scan).
+// k_final: the one-block reduction + decision that follows every k_scan.
 __global__ __launch_bounds__(kThreads) void k_final(ScanArgs a) { final_body(a); }
 
 // k_decide (distributed): every rank reduces the gathered records identically, so all ranks agree on
