@@ -51,3 +51,32 @@ def test_no_gpu_fails_loudly():
     import pytest
     with pytest.raises(capi.CcsimError):
         capi.Engine(device=0)
+
+
+def _build_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "ccsim_demo")
+    csrc = os.path.join(ROOT, "cluster-capacity_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "ccsim_demo.c"), "-L", csrc, "-lccsim",
+                           f"-Wl,-rpath,{csrc}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_c_demo_compiles_against_the_header(tmp_path):
+    """include/ccsim.h is usable from plain C (what cgo sees) and links against libccsim.so."""
+    build.build_all()
+    _build_demo(tmp_path)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_c_demo_reproduces_readme_answer(tmp_path):
+    """The reference's README demo through the C ABI from a C program, no Python in the loop: 52 = 13 x 4."""
+    import subprocess
+    out = subprocess.run([_build_demo(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "The cluster can schedule 52 instance(s)" in out.stdout and "4 Insufficient cpu" in out.stdout
+    assert out.stdout.count("13 instance(s)") == 4
