@@ -170,7 +170,7 @@ def main():
     achieved = bytes_per_scan / scan_s / 1e9
     kernel = "k_level_score" if args.mode == "batched" else "k_scan"
     # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this same command
-    # (scripts_gpu_pmc.sh -> profiles/r01/pmc_traffic.json); bench.py cannot profile itself.
+    # (tools/gpu_pmc.sh -> profiles/r01/pmc_traffic.json); bench.py cannot profile itself.
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))

@@ -1,5 +1,5 @@
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import __graft_entry__ as ge; ge.load_package()
 import numpy as np
 from cluster_capacity_amd import capi, model as M, synth

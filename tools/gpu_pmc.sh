@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_gpu_pmc.sh <tag> "<counters set 1>" ["<counters set 2>" ...]   -- one rocprofv3 run per set
+# usage: tools/gpu_pmc.sh <tag> "<counters set 1>" ["<counters set 2>" ...]   -- one rocprofv3 run per set
 # (PMC runs use --kernel-trace only; never sys/hip/hsa trace domains).  Bounded, no stdin reads.
 tag=$1; shift
 exec < /dev/null
@@ -12,5 +12,5 @@ for set in "$@"; do
      python /root/repo/bench.py --steps 1 --warmup 0 --seq-rounds 0 --no-cpu --no-roofline $BENCH_EXTRA > /root/repo/gpurun_out/pmc_${tag}_$i.json 2> /root/repo/gpurun_out/pmc_${tag}_$i.err
   echo "set $i ($set): rc=$?"
   f=$(find /root/repo/gpurun_out/pmc_${tag}_$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python3 /root/repo/scripts_pmc_summary.py "$f"; else echo "no counter csv"; tail -3 /root/repo/gpurun_out/pmc_${tag}_$i.err; fi
+  if [ -n "$f" ]; then python3 /root/repo/tools/pmc_summary.py "$f"; else echo "no counter csv"; tail -3 /root/repo/gpurun_out/pmc_${tag}_$i.err; fi
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_gpu_prof.sh <tag> <bench args...>   (runs on the GPU box; everything bounded, no stdin reads)
+# usage: tools/gpu_prof.sh <tag> <bench args...>   (runs on the GPU box; everything bounded, no stdin reads)
 tag=$1; shift
 exec < /dev/null
 mkdir -p /root/repo/gpurun_out
