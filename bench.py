@@ -45,6 +45,7 @@ import numpy as np  # noqa: E402,F401
 from cluster_capacity_amd import capi, dist as ccdist, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+READ_PEAK_MEASURED_GBPS = 6420.0  # pure streaming read of the same 60 MB on the round-1 box (tools/hbm_peak.hip, profiles/r01/hbm_peak.txt)
 
 
 def cpu_baseline(nodes, pod, prof, rounds: int):
@@ -207,6 +208,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
+            "frac_of_measured_read_peak": achieved / READ_PEAK_MEASURED_GBPS,
             "traffic": traffic,
             "kernel": kernel,
             "bytes_per_launch": bytes_per_scan,

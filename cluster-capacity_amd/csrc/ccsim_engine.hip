@@ -294,7 +294,9 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipStreamSynchronize(e->stream)); // lc / caller arrays may go away after return
     // launch geometry: one contiguous chunk of nodes per block, <= kMaxGrid blocks
     int64_t tiles = e->n_pad / kTile;
-    e->grid = (int)(tiles < kMaxGrid ? tiles : kMaxGrid);
+    int64_t gcap = 1024; // 4 blocks per CU
+    if (const char *g = getenv("CCSIM_SCAN_GRID")) gcap = atoll(g) > 0 && atoll(g) <= kMaxGrid ? atoll(g) : gcap; // tuning knob
+    e->grid = (int)(tiles < gcap ? tiles : gcap);
     e->chunk = ((tiles + e->grid - 1) / e->grid) * kTile;
     e->grid = (int)((e->n_pad + e->chunk - 1) / e->chunk);
     // batched mode: blocks of one contiguous chunk each; default target = 3 resident blocks per CU x 256 CUs

@@ -34,7 +34,7 @@ constexpr int kMaxTsc = 8;         // hard topology spread constraints per pod
 constexpr int kThreads = 256;      // 4 waves
 constexpr int kNodesPerThread = 2; // 16-byte loads on int64 columns
 constexpr int kTile = kThreads * kNodesPerThread;
-constexpr int kMaxGrid = 1024;     // 4 blocks per CU
+constexpr int kMaxGrid = 2048;     // upper bound of the scan grid (partial arrays are sized for it)
 constexpr int kIdxBits = 40;
 constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1;
 constexpr int kStatOkBit = 31, kStatCntShift = 20;

@@ -1,0 +1,48 @@
+// hbm_peak.hip -- what a pure streaming read achieves on this box, for the roofline denominator beside the 8 TB/s
+// spec: a grid-stride 16-byte-per-lane read + xor reduction over (a) 60 MB, the working set of one full
+// pods x nodes pass (fits the 256 MB Infinity Cache, re-read every launch like k_scan does) and (b) 4 GB (HBM).
+//   hipcc --offload-arch=gfx950 -O3 tools/hbm_peak.hip -o /tmp/hbm_peak && /tmp/hbm_peak
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+__global__ __launch_bounds__(256) void k_read(const uint4 *p, size_t n16, uint32_t *out) {
+    uint4 acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        acc.x ^= v.x, acc.y ^= v.y, acc.z ^= v.z, acc.w ^= v.w;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *out = 1; // keep the loads
+}
+
+static double run(size_t bytes, int grid, int iters) {
+    void *p = nullptr;
+    uint32_t *out = nullptr;
+    hipMalloc(&p, bytes);
+    hipMalloc((void **)&out, 4);
+    hipMemset(p, 1, bytes);
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const uint4 *)p, bytes / 16, out);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, (const uint4 *)p, bytes / 16, out);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    hipFree(p), hipFree(out);
+    return (double)ms * 1e3 / iters; // us per launch
+}
+
+int main() {
+    const int grids[] = {1024, 2048, 4096};
+    for (int g : grids) {
+        const double us = run(60000000, g, 200);
+        printf("60 MB   grid %4d: %7.2f us/launch  %7.1f GB/s\n", g, us, 60000000 / us / 1e3);
+    }
+    for (int g : grids) {
+        const double us = run((size_t)4 << 30, g, 10);
+        printf("4 GiB   grid %4d: %7.2f us/launch  %7.1f GB/s\n", g, us, (double)((size_t)4 << 30) / us / 1e3);
+    }
+    return 0;
+}
