@@ -89,6 +89,11 @@ struct ccsim_engine {
     int32_t *d_cscore = nullptr;
     int64_t *d_blockprefix = nullptr;
     int rank = 0;
+    // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
+    int32_t *d_a32[2] = {nullptr, nullptr};
+    uint64_t node_mem_or = 0; // OR of every memory value of the snapshot (common power-of-two unit)
+    int64_t node_max_cpu = 0, node_max_mem = 0, node_max_pods = 0;
+    int narrow_allowed = 1;
     // pristine copies of the dynamic columns (ccsim_reset_state)
     std::vector<std::pair<void *, void *>> backups; // (live, pristine)
     std::vector<size_t> backup_bytes;
@@ -132,6 +137,9 @@ static int dev_alloc(ccsim_engine *e, T **out, size_t count, std::vector<void *>
     return 0;
 }
 
+struct ccsim_engine;
+static int build_narrow(ccsim_engine *e);
+
 template <typename T>
 static int upload(ccsim_engine *e, T **out, const T *src, size_t count, size_t padded, std::vector<void *> &track) {
     int rc = dev_alloc(e, out, padded, track, true);
@@ -168,6 +176,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     e->rounds_per_sync = cfg->rounds_per_sync;
     e->use_graph = cfg->use_graph;
     e->time_passes = cfg->time_passes;
+    if (const char *f = getenv("CCSIM_NARROW")) e->narrow_allowed = atoi(f); // A/B knob
     if (hipSetDevice(e->device) != hipSuccess) {
         delete e;
         return -EIO;
@@ -228,6 +237,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     e->backups.clear();
     e->backup_bytes.clear();
     e->have_nodes = e->have_pod = e->begun = false;
+    e->cols.narrow = 0;
     e->n = nd->n_nodes;
     e->n_pad = ((e->n + kTile - 1) / kTile) * kTile;
     if (e->n_pad == 0) e->n_pad = kTile;
@@ -273,6 +283,27 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     c.placed_cnt = plc;
     c.stat = e->d_stat;
     c.sreason = e->d_sreason;
+    // narrow mirrors: storage now, content at ccsim_set_pod (the unit also depends on the pod's requests)
+    {
+        int32_t *m[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < 6; k++)
+            if ((rc = dev_alloc(e, &m[k], np, e->allocs))) return rc;
+        e->d_a32[0] = m[0], e->d_a32[1] = m[1];
+        c.a32[0] = m[0], c.a32[1] = m[1], c.r32[0] = m[2], c.r32[1] = m[3], c.z32[0] = m[4], c.z32[1] = m[5];
+        c.narrow = 0, c.mem_shift = 0;
+        e->node_mem_or = 0, e->node_max_cpu = e->node_max_mem = e->node_max_pods = 0;
+        for (size_t i = 0; i < n; i++) {
+            const int64_t vc[3] = {nd->alloc[0] ? nd->alloc[0][i] : 0, nd->req[0] ? nd->req[0][i] : 0, nd->nz_mcpu[i]};
+            const int64_t vm[3] = {nd->alloc[1] ? nd->alloc[1][i] : 0, nd->req[1] ? nd->req[1][i] : 0, nd->nz_mem[i]};
+            for (int k = 0; k < 3; k++) {
+                if (vc[k] < 0 || vm[k] < 0) e->node_max_cpu = INT64_MAX; // negative values: never narrow
+                e->node_max_cpu = vc[k] > e->node_max_cpu ? vc[k] : e->node_max_cpu;
+                e->node_max_mem = vm[k] > e->node_max_mem ? vm[k] : e->node_max_mem;
+                e->node_mem_or |= (uint64_t)vm[k];
+            }
+            e->node_max_pods = nd->alloc_pods[i] > e->node_max_pods ? nd->alloc_pods[i] : e->node_max_pods;
+        }
+    }
     e->cols = c;
     // pristine copies of everything a placement mutates (NodeInfo.Requested / NonZeroRequested / len(Pods))
     {
@@ -609,7 +640,32 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         for (size_t i = 0; i < e->ipa_tables.size(); i++) e->dist_tables.push_back({e->ipa_tables[i].first, (int64_t)e->ipa_table_len[i], 8, 0});
         e->dist_tables.push_back({d_tot, 3, 8, 0});
     }
+    // Narrow mirrors: lossless iff every cpu value stays below 2^30 and every memory value is a multiple of the common
+    // power-of-two unit with (value >> unit) below 2^30, for the whole run (a node takes at most max_pods clones).
+    {
+        DevCols &c = e->cols;
+        c.narrow = 0, c.mem_shift = 0;
+        const uint64_t orv = e->node_mem_or | (uint64_t)pod->req[1] | (uint64_t)pod->nz_mem;
+        int sh = orv ? __builtin_ctzll(orv) : 0;
+        if (sh > 40) sh = 40;
+        const int64_t grow_c = (pod->req[0] > pod->nz_mcpu ? pod->req[0] : pod->nz_mcpu) * (e->node_max_pods + 1);
+        const int64_t grow_m = (pod->req[1] > pod->nz_mem ? pod->req[1] : pod->nz_mem) * (e->node_max_pods + 1);
+        const bool fits = e->node_max_cpu < (1ll << 30) && grow_c < (1ll << 30) && (e->node_max_mem >> sh) < (1ll << 30) &&
+                          (grow_m >> sh) < (1ll << 30);
+        if (e->narrow_allowed && e->pod.fit_enabled && e->pod.nx == 0 && fits && e->n > 0) {
+            c.narrow = 1, c.mem_shift = sh;
+            if ((rc = build_narrow(e))) return rc;
+        }
+    }
     e->have_pod = true;
+    return 0;
+}
+
+static int build_narrow(ccsim_engine *e) {
+    if (!e->cols.narrow) return 0;
+    const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_narrow_build, dim3(blocks), dim3(kThreads), 0, e->stream, e->cols, e->d_a32[0], e->d_a32[1]);
+    HIPCHK(e, hipGetLastError());
     return 0;
 }
 
@@ -628,7 +684,8 @@ template <bool PTS>
 static void launch_scan_t(ccsim_engine *e, const ScanArgs &a, hipEvent_t t0, hipEvent_t t1) {
     const int nx = e->pod.nx;
     dim3 g(e->grid), b(kThreads);
-    if (nx == 0) CCSIM_LAUNCH((k_scan<0, PTS>), g, b, e->stream, t0, t1, a);
+    if (nx == 0 && e->cols.narrow) CCSIM_LAUNCH((k_scan<0, PTS, true>), g, b, e->stream, t0, t1, a);
+    else if (nx == 0) CCSIM_LAUNCH((k_scan<0, PTS>), g, b, e->stream, t0, t1, a);
     else if (nx == 1) CCSIM_LAUNCH((k_scan<1, PTS>), g, b, e->stream, t0, t1, a);
     else if (nx == 2) CCSIM_LAUNCH((k_scan<2, PTS>), g, b, e->stream, t0, t1, a);
     else if (nx <= 4) CCSIM_LAUNCH((k_scan<4, PTS>), g, b, e->stream, t0, t1, a);
@@ -669,7 +726,8 @@ static int launch_level_score(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent
     const LevelArgs a = level_args(e);
     const int nx = e->pod.nx;
     dim3 g(e->grid), b(kThreads);
-    if (nx == 0) CCSIM_LAUNCH(k_level_score<0>, g, b, e->stream, t0, t1, a);
+    if (nx == 0 && e->cols.narrow) CCSIM_LAUNCH((k_level_score<0, true>), g, b, e->stream, t0, t1, a);
+    else if (nx == 0) CCSIM_LAUNCH(k_level_score<0>, g, b, e->stream, t0, t1, a);
     else if (nx == 1) CCSIM_LAUNCH(k_level_score<1>, g, b, e->stream, t0, t1, a);
     else if (nx == 2) CCSIM_LAUNCH(k_level_score<2>, g, b, e->stream, t0, t1, a);
     else if (nx <= 4) CCSIM_LAUNCH(k_level_score<4>, g, b, e->stream, t0, t1, a);
@@ -1073,6 +1131,10 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
         HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].first, e->pts_tables[c].second, e->pts_table_len[c] * 4, hipMemcpyDeviceToDevice, e->stream));
     for (size_t c = 0; c < e->ipa_tables.size(); c++)
         HIPCHK(e, hipMemcpyAsync(e->ipa_tables[c].first, e->ipa_tables[c].second, e->ipa_table_len[c] * 8, hipMemcpyDeviceToDevice, e->stream));
+    if (e->have_pod) {
+        int rc = build_narrow(e);
+        if (rc) return rc;
+    }
     e->begun = false;
     return 0;
 }

@@ -56,7 +56,48 @@ struct DevCols {
     int64_t n;             // real node count of this shard
     int64_t n_pad;         // padded to kTile
     int64_t global_offset; // canonical index of node 0 of this shard
+    // Narrow mirrors of the six int64 columns the full pass streams (lossless: enabled only when every cpu value
+    // stays < 2^31 and every memory value is a multiple of 2^mem_shift with value >> mem_shift < 2^31 for the whole
+    // run).  The full-pass kernels read 36 B per node instead of 60; every writer of the wide columns also updates
+    // the mirror.  Wide columns stay the canonical state (commit gathers, histogram, read-back, reset).
+    int32_t narrow, mem_shift;
+    const int32_t *a32[2]; // alloc cpu, alloc mem >> mem_shift
+    int32_t *r32[2];       // requested
+    int32_t *z32[2];       // non-zero requested
 };
+
+// the six streamed columns of a thread's node pair, widened back to the exact int64 values
+struct Cols6 {
+    longlong2 A0, A1, R0, R1, Z0, Z1;
+};
+template <bool NARROW>
+__device__ __forceinline__ Cols6 load_cols6(const DevCols &c, int64_t i0) {
+    Cols6 o;
+    if (NARROW) {
+        const int2 a0 = *reinterpret_cast<const int2 *>(c.a32[0] + i0), a1 = *reinterpret_cast<const int2 *>(c.a32[1] + i0);
+        const int2 r0 = *reinterpret_cast<const int2 *>(c.r32[0] + i0), r1 = *reinterpret_cast<const int2 *>(c.r32[1] + i0);
+        const int2 z0 = *reinterpret_cast<const int2 *>(c.z32[0] + i0), z1 = *reinterpret_cast<const int2 *>(c.z32[1] + i0);
+        const int sh = c.mem_shift;
+        o.A0 = {a0.x, a0.y}, o.R0 = {r0.x, r0.y}, o.Z0 = {z0.x, z0.y};
+        o.A1 = {(int64_t)a1.x << sh, (int64_t)a1.y << sh};
+        o.R1 = {(int64_t)r1.x << sh, (int64_t)r1.y << sh};
+        o.Z1 = {(int64_t)z1.x << sh, (int64_t)z1.y << sh};
+    } else {
+        o.A0 = *reinterpret_cast<const longlong2 *>(c.alloc[0] + i0);
+        o.A1 = *reinterpret_cast<const longlong2 *>(c.alloc[1] + i0);
+        o.R0 = *reinterpret_cast<const longlong2 *>(c.req[0] + i0);
+        o.R1 = *reinterpret_cast<const longlong2 *>(c.req[1] + i0);
+        o.Z0 = *reinterpret_cast<const longlong2 *>(c.nz_mcpu + i0);
+        o.Z1 = *reinterpret_cast<const longlong2 *>(c.nz_mem + i0);
+    }
+    return o;
+}
+// keep the mirror of one node's dynamic columns in step with the wide columns (sparse writers: commits)
+__device__ __forceinline__ void store_mirror(const DevCols &c, int64_t i, int64_t r_cpu, int64_t r_mem, int64_t z_cpu, int64_t z_mem) {
+    if (!c.narrow) return;
+    c.r32[0][i] = (int32_t)r_cpu, c.r32[1][i] = (int32_t)(r_mem >> c.mem_shift);
+    c.z32[0][i] = (int32_t)z_cpu, c.z32[1][i] = (int32_t)(z_mem >> c.mem_shift);
+}
 
 // pod + profile constants, passed by value
 struct DevPod {
@@ -289,6 +330,80 @@ __device__ __forceinline__ int64_t dynamic_score(const DevPod &p, const NodeRcp 
     return total;
 }
 
+// ---- NARROW arithmetic ---------------------------------------------------------------------------------------
+// With the narrow mirrors every operand is a non-negative integer below 2^30 (cpu in milli-cores, memory in units
+// of 2^mem_shift bytes).  Both scores are functions of RATIOS, which do not depend on the unit, so they are evaluated
+// directly on the 32-bit values, with f32 estimates made exact the same way as above:
+//   * LeastAllocated: floor((A - x) * 100 / A) from an f32 estimate (relative error < 2^-20, i.e. < 1e-4 absolute on a
+//     quotient <= 100) + an exact 64-bit remainder fix-up (the estimate is off by at most one);
+//   * BalancedAllocation: the f32 value of (1 - |f0 - f1| / 2) * 100 is within 5e-5 of the reference's fp64 value;
+//     unless it lies within 3e-4 of an integer the truncation is the same, otherwise the IEEE fp64 sequence is
+//     evaluated (scaling both operands of a division by 2^k does not change its correctly rounded quotient).
+struct NarrowPod {
+    int32_t req0, req1, nz0, nz1; // the pod's requests / non-zero requests in narrow units
+};
+__device__ __forceinline__ NarrowPod narrow_pod(const DevPod &p, int sh) {
+    return NarrowPod{(int32_t)p.req[0], (int32_t)(p.req[1] >> sh), (int32_t)p.nz_mcpu, (int32_t)(p.nz_mem >> sh)};
+}
+
+// floor(d * 100 / A) for 0 <= d <= A < 2^30, A > 0
+__device__ __forceinline__ uint32_t floor_ratio100(uint32_t d, uint32_t A) {
+    uint32_t q = (uint32_t)((float)d * (100.0f * __builtin_amdgcn_rcpf((float)A)));
+    const uint64_t num = (uint64_t)d * 100u, prod = (uint64_t)q * A;
+    if (prod > num) q -= 1;
+    else if (num - prod >= A) q += 1;
+    return q;
+}
+
+__device__ __forceinline__ bool fits_narrow(const DevPod &p, const NarrowPod &q, int32_t a0, int32_t a1, int32_t r0, int32_t r1,
+                                            int32_t a_pods, int32_t npods) { // fit.go:564-615
+    bool ok = (int64_t)npods + 1 <= (int64_t)a_pods;
+    if (!p.all_zero_req) {
+        if (q.req0 > 0 && q.req0 > a0 - r0) ok = false;
+        if (q.req1 > 0 && q.req1 > a1 - r1) ok = false;
+    }
+    return ok;
+}
+
+__device__ __forceinline__ int64_t dynamic_score_narrow(const DevPod &p, const NarrowPod &q, int32_t a0, int32_t a1, int32_t r0,
+                                                        int32_t r1, int32_t z0, int32_t z1) {
+    int64_t total = 0;
+    if (p.w_fit) { // least_allocated.go:30-61 on NonZeroRequested + the pod's non-zero request
+        uint32_t node_score = 0, weight_sum = 0;
+        if (p.fit_cpu && a0 != 0) {
+            const int32_t x = z0 + q.nz0;
+            node_score += (x > a0 ? 0u : floor_ratio100((uint32_t)(a0 - x), (uint32_t)a0)) * (uint32_t)p.fit_w_cpu;
+            weight_sum += (uint32_t)p.fit_w_cpu;
+        }
+        if (p.fit_mem && a1 != 0) {
+            const int32_t x = z1 + q.nz1;
+            node_score += (x > a1 ? 0u : floor_ratio100((uint32_t)(a1 - x), (uint32_t)a1)) * (uint32_t)p.fit_w_mem;
+            weight_sum += (uint32_t)p.fit_w_mem;
+        }
+        uint32_t s = 0;
+        if (weight_sum == 2) s = node_score >> 1;
+        else if (weight_sum == 1) s = node_score;
+        else if (weight_sum != 0) s = node_score / weight_sum;
+        total += (int64_t)s * p.w_fit;
+    }
+    if (p.w_bal) { // balanced_allocation.go:146-180 on Requested + the pod's raw request
+        const bool c = p.bal_cpu && a0 != 0, m = p.bal_mem && a1 != 0;
+        int64_t score = 100; // fewer than two fractions: std = 0
+        if (c && m) {
+            const int32_t x0 = r0 + q.req0, x1 = r1 + q.req1;
+            float f0 = (float)x0 * __builtin_amdgcn_rcpf((float)a0), f1 = (float)x1 * __builtin_amdgcn_rcpf((float)a1);
+            f0 = f0 > 1.0f ? 1.0f : f0;
+            f1 = f1 > 1.0f ? 1.0f : f1;
+            const float y = (1.0f - fabsf((f0 - f1) * 0.5f)) * 100.0f; // in [50, 100]
+            const float t = floorf(y), fr = y - t;
+            if (fr > 3e-4f && fr < 1.0f - 3e-4f) score = (int64_t)t;
+            else score = balanced_exact(x0, a0, x1, a1);
+        }
+        total += score * p.w_bal;
+    }
+    return total;
+}
+
 // NodeResourcesFit filter for the cpu/mem/pods part (fit.go:564-615); extras are checked by the caller.
 __device__ __forceinline__ bool fits_core(const DevPod &p, int64_t a_cpu, int64_t a_mem, int64_t r_cpu, int64_t r_mem,
                                           int32_t a_pods, int32_t npods) {
@@ -436,7 +551,7 @@ struct ScanArgs {
 template <class A> __device__ void final_body(const A &a);
 
 // PTS = the pod carries topology-coupled plugins (PodTopologySpread and / or InterPodAffinity)
-template <int NX, bool PTS>
+template <int NX, bool PTS, bool NARROW = false>
 __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     const DevState st = *a.st;
     if (st.done) return;
@@ -456,16 +571,22 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     const int32_t epoch = (int32_t)(st.scans + 1);
     int64_t ipa_mn = INT64_MAX, ipa_mx = INT64_MIN;
     const bool ipa_scoring = PTS && a.ipa.on && a.ipa.w && st.ipa_entries > 0; // else PreScore Skip (scoring.go:199-201)
+    const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
 
     for (int64_t base = lo; base < hi; base += kTile) {
         const int64_t i0 = base + 2 * tid; // first of this thread's 2 nodes
         const uint2 sw = *reinterpret_cast<const uint2 *>(a.c.stat + i0);
-        const longlong2 A0 = *reinterpret_cast<const longlong2 *>(a.c.alloc[0] + i0);
-        const longlong2 A1 = *reinterpret_cast<const longlong2 *>(a.c.alloc[1] + i0);
-        const longlong2 R0 = *reinterpret_cast<const longlong2 *>(a.c.req[0] + i0);
-        const longlong2 R1 = *reinterpret_cast<const longlong2 *>(a.c.req[1] + i0);
-        const longlong2 Z0 = *reinterpret_cast<const longlong2 *>(a.c.nz_mcpu + i0);
-        const longlong2 Z1 = *reinterpret_cast<const longlong2 *>(a.c.nz_mem + i0);
+        // NARROW: the 32-bit mirrors are used as they are (no widening); otherwise the int64 columns
+        int2 a0n{}, a1n{}, r0n{}, r1n{}, z0n{}, z1n{};
+        longlong2 A0{}, A1{}, R0{}, R1{}, Z0{}, Z1{};
+        if (NARROW) {
+            a0n = *reinterpret_cast<const int2 *>(a.c.a32[0] + i0), a1n = *reinterpret_cast<const int2 *>(a.c.a32[1] + i0);
+            r0n = *reinterpret_cast<const int2 *>(a.c.r32[0] + i0), r1n = *reinterpret_cast<const int2 *>(a.c.r32[1] + i0);
+            z0n = *reinterpret_cast<const int2 *>(a.c.z32[0] + i0), z1n = *reinterpret_cast<const int2 *>(a.c.z32[1] + i0);
+        } else {
+            const Cols6 c6 = load_cols6<false>(a.c, i0);
+            A0 = c6.A0, A1 = c6.A1, R0 = c6.R0, R1 = c6.R1, Z0 = c6.Z0, Z1 = c6.Z1;
+        }
         const int2 AP = *reinterpret_cast<const int2 *>(a.c.alloc_pods + i0);
         const int2 NP = *reinterpret_cast<const int2 *>(a.c.pod_count + i0);
         bool xok0 = true, xok1 = true;
@@ -489,8 +610,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             const int64_t r_cpu = k ? R0.y : R0.x, r_mem = k ? R1.y : R1.x;
             const int64_t z_cpu = k ? Z0.y : Z0.x, z_mem = k ? Z1.y : Z1.x;
             const int32_t a_pods = k ? AP.y : AP.x, npods = k ? NP.y : NP.x;
+            const int32_t na0 = k ? a0n.y : a0n.x, na1 = k ? a1n.y : a1n.x, nr0 = k ? r0n.y : r0n.x, nr1 = k ? r1n.y : r1n.x;
+            const int32_t nz0 = k ? z0n.y : z0n.x, nz1 = k ? z1n.y : z1n.x;
             bool feasible = (w >> kStatOkBit) && (k ? xok1 : xok0) &&
-                            fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods);
+                            (NARROW ? fits_narrow(a.p, npod, na0, na1, nr0, nr1, a_pods, npods)
+                                    : fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods));
             if (PTS) { // PodTopologySpread.Filter (filtering.go:311-356) + the minimum for the next verification
                 const uint32_t eb = a.pts.elig[i0 + k];
 #pragma unroll
@@ -512,7 +636,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             if (feasible) {
                 const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
                 int64_t total = static_score(a.p, cnt, aff, mt, ma) +
-                                dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem);
+                                (NARROW ? dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1)
+                                        : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem));
                 if (soft_scoring) {
                     if (a.soft.elig[i0 + k] & 1u) {
                         const int64_t raw = soft_raw_score(a.soft, st, a.c.pod_count, i0 + k, epoch);
@@ -697,6 +822,7 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
             a.c.nz_mem[i] = z1 + a.p.nz_mem;
             a.c.pod_count[i] = pc + 1;
             a.c.placed_cnt[i] = pl + 1;
+            store_mirror(a.c, i, r0 + a.p.req[0], r1 + a.p.req[1], z0 + a.p.nz_mcpu, z1 + a.p.nz_mem);
 #pragma unroll 1
             for (int col = 2; col < a.p.ncol; col++)
                 if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
@@ -1084,6 +1210,16 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
     if (threadIdx.x == 0 && sh[kHistSlots - 1]) atomicAdd(&a.hist_code[0], (unsigned long long)sh[kHistSlots - 1]);
     for (int i = threadIdx.x; i < kHistTsLds && i < a.n_taintsets; i += kThreads)
         if (sh_ts[i]) atomicAdd(&a.hist_ts[i], (unsigned long long)sh_ts[i]);
+}
+
+// k_narrow_build: (re)derive the narrow mirrors from the wide columns (per pod spec, and after a state reset)
+__global__ __launch_bounds__(kThreads) void k_narrow_build(DevCols c, int32_t *a32_cpu, int32_t *a32_mem) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= c.n_pad) return;
+    const int sh = c.mem_shift;
+    a32_cpu[n] = (int32_t)c.alloc[0][n], a32_mem[n] = (int32_t)(c.alloc[1][n] >> sh);
+    c.r32[0][n] = (int32_t)c.req[0][n], c.r32[1][n] = (int32_t)(c.req[1][n] >> sh);
+    c.z32[0][n] = (int32_t)c.nz_mcpu[n], c.z32[1][n] = (int32_t)(c.nz_mem[n] >> sh);
 }
 
 __global__ void k_noop(int) {} // measurement marker: its stop stamp = the end of the preceding dispatch + one boundary

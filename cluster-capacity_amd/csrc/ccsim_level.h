@@ -179,12 +179,8 @@ __device__ __forceinline__ int32_t wave_run_down(const DevPod &p, const NodeRegs
 template <int NX>
 __device__ __forceinline__ void load_pair(const DevCols &c, const DevPod &p, int64_t i0, NodeRegs<NX> (&nd)[2]) {
     const uint2 sw = *reinterpret_cast<const uint2 *>(c.stat + i0);
-    const longlong2 A0 = *reinterpret_cast<const longlong2 *>(c.alloc[0] + i0);
-    const longlong2 A1 = *reinterpret_cast<const longlong2 *>(c.alloc[1] + i0);
-    const longlong2 R0 = *reinterpret_cast<const longlong2 *>(c.req[0] + i0);
-    const longlong2 R1 = *reinterpret_cast<const longlong2 *>(c.req[1] + i0);
-    const longlong2 Z0 = *reinterpret_cast<const longlong2 *>(c.nz_mcpu + i0);
-    const longlong2 Z1 = *reinterpret_cast<const longlong2 *>(c.nz_mem + i0);
+    const Cols6 c6 = load_cols6<false>(c, i0);
+    const longlong2 A0 = c6.A0, A1 = c6.A1, R0 = c6.R0, R1 = c6.R1, Z0 = c6.Z0, Z1 = c6.Z1;
     const int2 AP = *reinterpret_cast<const int2 *>(c.alloc_pods + i0);
     const int2 NP = *reinterpret_cast<const int2 *>(c.pod_count + i0);
     nd[0].w = sw.x, nd[1].w = sw.y;
@@ -218,6 +214,7 @@ __device__ __forceinline__ void store_dyn(const DevCols &c, const DevPod &p, int
     c.nz_mem[i] = n.z_mem;
     c.pod_count[i] = n.npods;
     c.placed_cnt[i] += took;
+    store_mirror(c, i, n.r_cpu, n.r_mem, n.z_cpu, n.z_mem);
     if (NX > 0) {
 #pragma unroll
         for (int x = 0; x < NX; x++)
@@ -308,7 +305,7 @@ struct LevelAcc {
 // counts, the feasible count -- and one int32 per node: its TotalScore (the commit pass's index of the level).
 // No barriers, no LDS list: it runs at k_scan's occupancy.  HBM roofline: 60 B read (+ 4 B written) per node.
 // ------------------------------------------------------------------------------------------------
-template <int NX>
+template <int NX, bool NARROW = false>
 __global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
     const DevState st = *a.st;
     if (st.done || st.lvl_plan_only) return; // a plan pass moves nothing: the previous scores stand
@@ -322,8 +319,33 @@ __global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
     if (hi > a.c.n_pad) hi = a.c.n_pad;
 
     LevelAcc acc;
+    const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
     for (int64_t base = lo; base < hi; base += kTile) {
         const int64_t i0 = base + 2 * tid;
+        if (NARROW) { // 36 B per node, 32-bit arithmetic (ccsim_kernels.h "NARROW arithmetic")
+            const uint2 sw = *reinterpret_cast<const uint2 *>(a.c.stat + i0);
+            const int2 a0 = *reinterpret_cast<const int2 *>(a.c.a32[0] + i0), a1 = *reinterpret_cast<const int2 *>(a.c.a32[1] + i0);
+            const int2 r0 = *reinterpret_cast<const int2 *>(a.c.r32[0] + i0), r1 = *reinterpret_cast<const int2 *>(a.c.r32[1] + i0);
+            const int2 z0 = *reinterpret_cast<const int2 *>(a.c.z32[0] + i0), z1 = *reinterpret_cast<const int2 *>(a.c.z32[1] + i0);
+            const int2 AP = *reinterpret_cast<const int2 *>(a.c.alloc_pods + i0), NP = *reinterpret_cast<const int2 *>(a.c.pod_count + i0);
+            int2 cs;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t w = k ? sw.y : sw.x;
+                const int32_t na0 = k ? a0.y : a0.x, na1 = k ? a1.y : a1.x, nr0 = k ? r0.y : r0.x, nr1 = k ? r1.y : r1.x;
+                int32_t sc = -1;
+                if ((w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, k ? AP.y : AP.x, k ? NP.y : NP.x)) {
+                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                    const int64_t s64 = static_score(a.p, cnt, aff, mt, ma) +
+                                        dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, k ? z0.y : z0.x, k ? z1.y : z1.x);
+                    acc.add(s64, a.c.global_offset + i0 + k, cnt, aff);
+                    sc = (int32_t)s64;
+                }
+                (k ? cs.y : cs.x) = sc;
+            }
+            *reinterpret_cast<int2 *>(a.cscore + i0) = cs;
+            continue;
+        }
         NodeRegs<NX> nd[2];
         load_pair<NX>(a.c, a.p, i0, nd);
         int2 cs;

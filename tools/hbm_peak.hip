@@ -40,6 +40,11 @@ int main() {
         const double us = run(60000000, g, 200);
         printf("60 MB   grid %4d: %7.2f us/launch  %7.1f GB/s\n", g, us, 60000000 / us / 1e3);
     }
+    const size_t small[] = {4000000, 16000000, 36000000};
+    for (size_t b : small) { // how much of a 1M-node pass is fixed cost (launch, first-byte latency, tail)?
+        const double us = run(b, 1024, 300);
+        printf("%2zu MB   grid 1024: %7.2f us/launch  %7.1f GB/s\n", b / 1000000, us, (double)b / us / 1e3);
+    }
     for (int g : grids) {
         const double us = run((size_t)4 << 30, g, 10);
         printf("4 GiB   grid %4d: %7.2f us/launch  %7.1f GB/s\n", g, us, (double)((size_t)4 << 30) / us / 1e3);
