@@ -241,3 +241,23 @@ def test_sharded_protocol_with_topology_coupled_plugins(ccref, world, seed):
     if ref.stop == M.STOP_UNSCHEDULABLE:
         assert np.array_equal(sum(r.hist for r in res), ref.hist)
         assert sum(r.n_code_unschedulable for r in res) == ref.n_code_unschedulable
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("narrow", ["0", "1"])
+def test_wide_and_narrow_column_paths_agree_with_oracle(ccref, monkeypatch, mode, narrow):
+    """The full-pass kernels have two storage / arithmetic paths (int64 columns + fp64, int32 mirrors + f32 estimates);
+    both must reproduce the oracle.  CCSIM_NARROW=0 forces the wide path; odd byte counts force it naturally."""
+    monkeypatch.setenv("CCSIM_NARROW", narrow)
+    for cfg, n, seed, limit in (("C3", 3000, 91, 0), ("C2", 2000, 92, 1500)):
+        nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=seed)
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+        _assert_same(_engine(nodes, pod, prof).run(max_limit=limit, mode=mode), ref, nodes, pod)
+    # memory values with no common power-of-two unit and > 2^30 after the shift: the wide path even with CCSIM_NARROW=1
+    rng = np.random.default_rng(5)
+    n = 800
+    nodes = H.simple_nodes(rng.choice([4000, 8000, 64000], n), rng.integers(1 << 34, 1 << 38, n) | 1, np.full(n, 40),
+                           req_mcpu=rng.integers(0, 2000, n), req_mem=rng.integers(0, 1 << 33, n))
+    pod = H.simple_pod(137, (1 << 28) + 12345)
+    ref = ccref.run(M.Profile.default(), nodes, pod, max_limit=0)
+    _assert_same(_engine(nodes, pod, M.Profile.default()).run(mode=mode), ref, nodes, pod)
