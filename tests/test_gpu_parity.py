@@ -261,3 +261,47 @@ def test_wide_and_narrow_column_paths_agree_with_oracle(ccref, monkeypatch, mode
     pod = H.simple_pod(137, (1 << 28) + 12345)
     ref = ccref.run(M.Profile.default(), nodes, pod, max_limit=0)
     _assert_same(_engine(nodes, pod, M.Profile.default()).run(mode=mode), ref, nodes, pod)
+
+
+def _scalar_case(rng, n, n_scalar):
+    """Snapshots with extended resources (columns 3+): exercises the NX > 0 kernel variants and their reasons."""
+    base = H.simple_nodes(rng.choice([4000, 8000], n), rng.choice([8, 16], n) * H.GiB, rng.integers(5, 30, n),
+                          req_mcpu=rng.integers(0, 1000, n), alloc_eph=rng.choice([0, 20, 100], n) * H.GiB)
+    alloc = list(base.alloc) + [rng.integers(0, 9, n).astype(np.int64) for _ in range(n_scalar)]
+    req = list(base.req) + [np.minimum(rng.integers(0, 3, n), alloc[3 + k]).astype(np.int64) for k in range(n_scalar)]
+    nodes = M.NodesSoA(alloc=alloc, alloc_pods=base.alloc_pods, req=req, nz_mcpu=base.nz_mcpu, nz_mem=base.nz_mem,
+                       pod_count=base.pod_count, taintset_id=base.taintset_id, unschedulable=base.unschedulable,
+                       scalar_names=[f"example.com/dev{k}" for k in range(n_scalar)])
+    preq = [int(rng.choice([100, 250])), 256 * H.MiB, int(rng.choice([0, 1])) * H.GiB] + [int(rng.integers(0, 3)) for _ in range(n_scalar)]
+    pod = M.PodSpec(req=np.array(preq, np.int64), nz_mcpu=preq[0], nz_mem=preq[1], has_scalar_entries=True)
+    return nodes, pod
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n_scalar,seed", [(1, 0), (2, 1), (3, 2), (8, 3)])
+def test_scalar_resources_vs_oracle(ccref, mode, n_scalar, seed):
+    rng = np.random.default_rng(40 + seed)
+    nodes, pod = _scalar_case(rng, int(rng.integers(300, 1500)), n_scalar)
+    prof = M.Profile.default()
+    limit = int(rng.choice([0, 0, 200]))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    got = _engine(nodes, pod, prof).run(max_limit=limit, mode=mode)
+    _assert_same(got, ref, nodes, pod)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        msg = R.stop_reason(got, nodes.n, 0, scalar_names=nodes.scalar_names)
+        assert msg == R.stop_reason(ref, nodes.n, 0, scalar_names=nodes.scalar_names)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("prof", [
+    M.Profile(fit_res=(0,), fit_res_w=(3,), bal_res=(0, 1)),                       # LeastAllocated on cpu only
+    M.Profile(fit_res=(1,), fit_res_w=(1,), bal_res=(1,)),                         # one Balanced resource: std = 0
+    M.Profile(fit_res=(0, 1), fit_res_w=(2, 5), bal_res=(0,), w_balanced=3),       # uneven weights (weight sum 7)
+    M.Profile(filter_mask=M.F_FIT | M.F_TAINT, w_nodeaffinity=0, w_taint=1),       # filters partly disabled
+    M.Profile(filter_mask=M.F_FIT, w_taint=0, w_nodeaffinity=0, w_fit=0, w_balanced=1, w_topologyspread=0, w_interpodaffinity=0),
+], ids=["cpu-only", "one-balanced", "weights-2-5", "mask-fit-taint", "balanced-only"])
+def test_profile_variants_vs_oracle(ccref, mode, prof):
+    nodes, pod, _ = synth.make_config("C3", n_nodes=1500, seed=314)
+    for limit in (0, 333):
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+        _assert_same(_engine(nodes, pod, prof).run(max_limit=limit, mode=mode), ref, nodes, pod)

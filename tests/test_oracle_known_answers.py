@@ -98,3 +98,17 @@ def test_sampling_mode_b_same_final_distribution(ccref):
     assert a.placed == b.placed and np.array_equal(a.per_node_count, b.per_node_count)
     assert b.evaluated_total < a.evaluated_total  # sampling really visits fewer nodes
     assert not np.array_equal(a.log, b.log)       # ... and is order-dependent round by round
+
+
+def test_scalar_resource_known_answer(ccref):
+    # fit.go:617-657: extended resources bind like the native ones.  2 nodes with 2 and 5 "example.com/gpu", pod asks 2:
+    # 1 + 2 instances; cpu/memory/pods never bind.  Reason uses the resource's name (fit.go:640-647).
+    z = np.zeros(2, np.int64)
+    nodes = M.NodesSoA(alloc=[np.array([64000, 64000]), np.array([1 << 40, 1 << 40]), z, np.array([2, 5])], alloc_pods=np.array([110, 110]),
+                       req=[z, z, z, z], nz_mcpu=z, nz_mem=z, pod_count=np.zeros(2, np.int32), taintset_id=np.zeros(2, np.int32),
+                       unschedulable=np.zeros(2, np.uint8), scalar_names=["example.com/gpu"])
+    pod = M.PodSpec(req=np.array([100, 1 << 20, 0, 2]), nz_mcpu=100, nz_mem=1 << 20, has_scalar_entries=True)
+    r = ccref.run(DEFAULT, nodes, pod)
+    assert r.placed == 3 and r.per_node_count.tolist() == [1, 2]
+    assert R.stop_reason(r, 2, 0, scalar_names=nodes.scalar_names).startswith(
+        "Unschedulable: 0/2 nodes are available: 2 Insufficient example.com/gpu.")
