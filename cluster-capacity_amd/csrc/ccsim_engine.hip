@@ -74,6 +74,10 @@ struct ccsim_engine {
     DevState *d_state = nullptr;
     DevState *h_state = nullptr; // pinned
     uint64_t *d_partials = nullptr; // [kMaxGrid][2]
+    uint64_t *d_smp_partials = nullptr; // [kMaxGrid][2] sampled search (percentageOfNodesToScore < 100)
+    int64_t *d_smp_prefix = nullptr;    // [kMaxGrid]
+    int64_t smp_K = 0;                  // numFeasibleNodesToFind of the current run; 0 = every node is scored
+    int64_t smp_start_cur = 0;          // nextStartNodeIndex after the runs so far
     XRec *d_xsend = nullptr, *d_xrecv = nullptr; // distributed exchange (caller's or ours)
     int n_ranks = 0;
     int32_t *d_log = nullptr;
@@ -194,6 +198,8 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
         hipHostMalloc((void **)&e->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&e->d_state, sizeof(DevState)) != hipSuccess ||
         hipMalloc((void **)&e->d_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
+        hipMalloc((void **)&e->d_smp_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
+        hipMalloc((void **)&e->d_smp_prefix, sizeof(int64_t) * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess) {
         ccsim_destroy(e);
         return -ENOMEM;
@@ -212,6 +218,8 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     free_list(e->pod_allocs);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_partials) (void)hipFree(e->d_partials);
+    if (e->d_smp_partials) (void)hipFree(e->d_smp_partials);
+    if (e->d_smp_prefix) (void)hipFree(e->d_smp_prefix);
     if (e->d_hist) (void)hipFree(e->d_hist);
     if (e->d_log) (void)hipFree(e->d_log);
     if (e->h_state) (void)hipHostFree(e->h_state);
@@ -348,8 +356,8 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
 
 extern "C" int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
     if (!e || !p) return -EINVAL;
-    if (p->percentage_of_nodes_to_score != 100)
-        return fail(e, -ENOSYS, "this engine scores every node: percentageOfNodesToScore must be 100");
+    if (p->percentage_of_nodes_to_score < 0 || p->percentage_of_nodes_to_score > 100)
+        return fail(e, -EINVAL, "percentageOfNodesToScore out of [0,100]");
     if (p->filter_mask & CCSIM_F_TOPOLOGYSPREAD || p->w_topologyspread)
         ; // accepted: PodTopologySpread is a no-op (PreFilter/PreScore Skip) for pods without constraints
     if (!p->w_taint && !p->w_nodeaffinity && !p->w_fit && !p->w_balanced && !p->w_topologyspread && !p->w_interpodaffinity)
@@ -680,6 +688,29 @@ static int build_narrow(ccsim_engine *e) {
         else hipLaunchKernelGGL(kern, g, b, 0, stream, arg);                            \
     } while (0)
 
+// numFeasibleNodesToFind (schedule_one.go:697-723)
+static int64_t num_feasible_nodes_to_find(int32_t percentage, int64_t n_all) {
+    if (n_all < 100) return n_all;
+    if (percentage == 0) {
+        percentage = (int32_t)(50 - n_all / 125);
+        if (percentage < 5) percentage = 5;
+    }
+    const int64_t num = n_all * percentage / 100;
+    return num < 100 ? 100 : num;
+}
+
+// the two passes of a sampled cycle (wide columns only: the sampled search is not the throughput path)
+template <bool PTS, int SMP>
+static void launch_scan_smp(ccsim_engine *e, const ScanArgs &a) {
+    const int nx = e->pod.nx;
+    dim3 g(e->grid), b(kThreads);
+    if (nx == 0) hipLaunchKernelGGL((k_scan<0, PTS, false, SMP>), g, b, 0, e->stream, a);
+    else if (nx == 1) hipLaunchKernelGGL((k_scan<1, PTS, false, SMP>), g, b, 0, e->stream, a);
+    else if (nx == 2) hipLaunchKernelGGL((k_scan<2, PTS, false, SMP>), g, b, 0, e->stream, a);
+    else if (nx <= 4) hipLaunchKernelGGL((k_scan<4, PTS, false, SMP>), g, b, 0, e->stream, a);
+    else hipLaunchKernelGGL((k_scan<kMaxExtra, PTS, false, SMP>), g, b, 0, e->stream, a);
+}
+
 template <bool PTS>
 static void launch_scan_t(ccsim_engine *e, const ScanArgs &a, hipEvent_t t0, hipEvent_t t1) {
     const int nx = e->pod.nx;
@@ -701,6 +732,7 @@ static ScanArgs scan_args(ccsim_engine *e) {
     a.n_partials = e->grid;
     a.xsend = e->d_xsend, a.xrecv = e->d_xrecv, a.n_ranks = e->n_ranks;
     a.log = e->d_log;
+    a.smp_partials = e->d_smp_partials, a.smp_prefix = e->d_smp_prefix;
     return a;
 }
 
@@ -715,6 +747,22 @@ static int launch_final(ccsim_engine *e) {
     hipLaunchKernelGGL(k_final, dim3(1), dim3(kThreads), 0, e->stream, scan_args(e));
     return 0;
 }
+
+// one scheduling cycle attempt of the sequential mode: the scan(s) + the one-block reduction / decision
+static void launch_cycle(ccsim_engine *e) {
+    if (e->smp_K > 0) { // sampled search: count, prefix, score the first K feasible nodes of the visiting order
+        const ScanArgs a = scan_args(e);
+        const bool coupled = e->pts.n > 0 || e->ipa.on || e->soft.n > 0;
+        if (coupled) launch_scan_smp<true, 1>(e, a); else launch_scan_smp<false, 1>(e, a);
+        hipLaunchKernelGGL(k_smp_prefix, dim3(1), dim3(kThreads), 0, e->stream, a);
+        if (coupled) launch_scan_smp<true, 2>(e, a); else launch_scan_smp<false, 2>(e, a);
+        hipLaunchKernelGGL(k_final, dim3(1), dim3(kThreads), 0, e->stream, a);
+        return;
+    }
+    launch_scan(e);
+    launch_final(e);
+}
+
 
 static LevelArgs level_args(ccsim_engine *e) {
     return LevelArgs{e->cols, e->pod, e->d_state, e->d_lpartials, e->d_cpartials, e->d_blockprefix, e->d_cscore, e->d_log,
@@ -782,6 +830,13 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     if (e->pts.n > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "batched mode is not valid with topology spread constraints (a placement changes the feasibility of "
                                 "other nodes): use CCSIM_MODE_SEQUENTIAL");
+    const int64_t k_find = num_feasible_nodes_to_find(e->prof.percentage_of_nodes_to_score, e->n_global);
+    const int64_t smp_K = k_find < e->n_global ? k_find : 0;
+    if (smp_K > 0 && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
+        return fail(e, -ENOSYS, "percentageOfNodesToScore < 100 (here: the first %lld feasible nodes of %lld) makes the outcome depend on the "
+                                "visiting order: sequential mode on one GPU only", (long long)smp_K, (long long)e->n_global);
+    if (smp_K != e->smp_K) drop_graph(e);
+    e->smp_K = smp_K;
     if (mode == CCSIM_MODE_BATCHED && !e->pod.fit_enabled)
         return fail(e, -ENOSYS, "batched mode needs the NodeResourcesFit filter (a run-down is bounded by the node's pod capacity)");
     HIPCHK(e, hipSetDevice(e->device));
@@ -799,7 +854,10 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     for (int c = 0; c < kMaxTsc; c++) st.pts_min_a[c] = 0x7fffffff;
     if (!e->begun) { // a fresh snapshot state (load / reset); otherwise the run continues where the last one stopped
         e->ipa_aff_total_cur = e->ipa_aff_total0, e->ipa_exist_total_cur = e->ipa_exist_total0, e->ipa_entries_cur = e->ipa_entries0;
+        e->smp_start_cur = 0;
     }
+    st.smp_K = e->smp_K;
+    st.smp_start = e->smp_K > 0 ? e->smp_start_cur % (e->n_global > 0 ? e->n_global : 1) : 0;
     st.ipa_aff_total = e->ipa_aff_total_cur, st.ipa_exist_total = e->ipa_exist_total_cur, st.ipa_entries = e->ipa_entries_cur;
     for (int c = 0; c < kMaxTsc; c++) st.soft_size_a[c] = -1; // unknown: the first scan derives sizes and weights
     st.soft_min_a = INT64_MAX, st.soft_max_a = 0;
@@ -828,6 +886,7 @@ static int read_state(ccsim_engine *e) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     e->ipa_aff_total_cur = e->h_state->ipa_aff_total, e->ipa_exist_total_cur = e->h_state->ipa_exist_total;
     e->ipa_entries_cur = e->h_state->ipa_entries;
+    e->smp_start_cur = e->h_state->smp_start;
     return 0;
 }
 
@@ -837,6 +896,10 @@ static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block redu
     // kernel itself.  (A start stamp is taken at packet pick-up, possibly before the predecessor ends; a stamp on
     // k_level_commit itself costs a multi-us flush of its dirty lines -- hence two markers, the first absorbs it.)
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (e->smp_K > 0) {
+        launch_cycle(e);
+        return;
+    }
     if (e->time_passes && e->n_ranks == 0) {
         while ((int)e->pass_events.size() < e->pass_events_used + 3) {
             hipEvent_t ev = nullptr;
@@ -900,7 +963,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     out->stop = e->n_global == 0 ? CCSIM_STOP_NO_NODES : (st.done == DONE_LIMIT ? CCSIM_STOP_LIMIT : CCSIM_STOP_UNSCHEDULABLE);
     out->rounds = st.rounds;
     out->scans = st.scans;
-    out->evaluated_total = st.rounds * e->n_global;
+    out->evaluated_total = e->smp_K > 0 ? st.evaluated : st.rounds * e->n_global;
     out->last_feasible = st.last_feasible;
     out->kernel_ns = (int64_t)(e->kernel_ms * 1e6);
     out->pass_kernel_ns = (int64_t)(e->pass_kernel_ms * 1e6);
@@ -996,8 +1059,7 @@ extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
     if (e->n == 0) return 0;
     const int64_t rounds0 = e->h_state->rounds;
     for (int tries = 0; tries < 8; tries++) {
-        launch_scan(e);
-        launch_final(e);
+        launch_cycle(e);
         HIPCHK(e, hipGetLastError());
         if ((rc = read_state(e))) return rc;
         if (e->h_state->rounds != rounds0 || e->h_state->done) break;
@@ -1011,6 +1073,7 @@ extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
         return 0;
     }
     out->node = e->h_state->winner;
+    out->evaluated_nodes = e->smp_K > 0 ? e->h_state->last_evaluated : (int32_t)e->n_global;
     out->feasible_nodes = e->h_state->last_feasible;
     return 0;
 }

@@ -177,7 +177,14 @@ struct DevState {
     int32_t lvl_valid;       // 1 = the next pass commits level lvl_M
     int32_t lvl_prefix;      // 1 = ordered commit (limit inside the level, or placement log wanted)
     int32_t lvl_plan_only;   // 1 = the next pass only measures level lvl_M (no commit)
-    int32_t pad0;
+    int32_t last_evaluated;  // nodes the last cycle visited (sampled search; otherwise N)
+    // percentageOfNodesToScore < 100 (schedule_one.go:610-723): the sampled search of the sequential mode
+    int64_t smp_K;           // numFeasibleNodesToFind; 0 = every node is scored
+    int64_t smp_start;       // nextStartNodeIndex
+    int64_t smp_Fs;          // feasible nodes with index < smp_start (this cycle)
+    int64_t smp_Ftotal;      // feasible nodes of the whole snapshot (this cycle)
+    int64_t smp_stop;        // rotated position of the (K+1)-th feasible node = nodes visited; -1: all N were visited
+    int64_t evaluated;       // sum of visited nodes over the cycles
 };
 
 // per-block result of one scan: 16 bytes
@@ -462,7 +469,9 @@ __device__ __forceinline__ double go_log(double x) {
 
 // PodTopologySpread.Score (scoring.go:196-223) for a node that has all soft keys; also stamps the node's domains
 // as candidates of this scan.
-__device__ __forceinline__ int64_t soft_raw_score(const DevSoft &p, const DevState &st, const int32_t *pod_count, int64_t i,
+// `soft_w` points INTO the device-resident DevState (not a per-lane copy: indexing a local copy with the runtime
+// constraint number puts the whole 400-byte struct into scratch, for every lane of the scan)
+__device__ __forceinline__ int64_t soft_raw_score(const DevSoft &p, const double *soft_w, const int32_t *pod_count, int64_t i,
                                                  int32_t epoch) {
     double score = 0;
     for (int c = 0; c < p.n; c++) {
@@ -474,7 +483,7 @@ __device__ __forceinline__ int64_t soft_raw_score(const DevSoft &p, const DevSta
             cnt = p.tbl[c][v];
             p.flag[c][v] = epoch;
         }
-        score += (double)cnt * st.soft_w[c] + (double)(p.max_skew[c] - 1);
+        score += (double)cnt * soft_w[c] + (double)(p.max_skew[c] - 1);
     }
     return (int64_t)round(score); // math.Round: half away from zero
 }
@@ -546,15 +555,30 @@ struct ScanArgs {
     const XRec *xrecv;          // distributed: gathered records in
     int32_t n_ranks;            // 0 = single GPU (decide from the local record)
     int32_t *log;
+    uint64_t *smp_partials;     // [grid][2] sampled search: feasible nodes of the block ; those with index < smp_start
+    int64_t *smp_prefix;        // [grid] feasible nodes in the blocks before this one (index order)
 };
 
 template <class A> __device__ void final_body(const A &a);
 
 // PTS = the pod carries topology-coupled plugins (PodTopologySpread and / or InterPodAffinity)
-template <int NX, bool PTS, bool NARROW = false>
+// SMP = the sampled search (percentageOfNodesToScore < 100; findNodesThatPassFilters, schedule_one.go:610-680):
+//   0  every node is scored (the search visits all N nodes);
+//   1  counting pass: feasible nodes per block (and how many of them lie before nextStartNodeIndex);
+//   2  scoring pass: a feasible node is kept iff fewer than K feasible nodes precede it in the visiting order
+//      (start, start+1, ..., N-1, 0, ..., start-1).  Its rank in that order follows from the exclusive prefix F(i)
+//      of the feasibility bits in INDEX order: rank = F(i) - F(start) for i >= start, F(i) + F_total - F(start)
+//      otherwise -- block prefix (k_smp_prefix) + wave ballots, no sort.  The selectHost tie-break follows the
+//      feasible-list order, so the key carries the visiting position instead of the node index.
+template <int NX, bool PTS, bool NARROW = false, int SMP = 0>
 __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     const DevState st = *a.st;
     if (st.done) return;
+    const int64_t smp_S = st.smp_start, smp_N = a.c.n;
+    int64_t smp_carry = SMP == 2 ? a.smp_prefix[blockIdx.x] : 0; // feasible nodes before the current tile (index order)
+    uint32_t smp_cnt = 0, smp_before = 0;
+    int smp_par = 0;
+    __shared__ uint32_t s_smp[2][kThreads / 64];
     const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
     const int tid = threadIdx.x;
     const int64_t lo = (int64_t)blockIdx.x * a.chunk;
@@ -603,15 +627,14 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
                 }
             }
         }
+        bool fe[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const uint32_t w = k ? sw.y : sw.x;
             const int64_t a_cpu = k ? A0.y : A0.x, a_mem = k ? A1.y : A1.x;
             const int64_t r_cpu = k ? R0.y : R0.x, r_mem = k ? R1.y : R1.x;
-            const int64_t z_cpu = k ? Z0.y : Z0.x, z_mem = k ? Z1.y : Z1.x;
             const int32_t a_pods = k ? AP.y : AP.x, npods = k ? NP.y : NP.x;
             const int32_t na0 = k ? a0n.y : a0n.x, na1 = k ? a1n.y : a1n.x, nr0 = k ? r0n.y : r0n.x, nr1 = k ? r1n.y : r1n.x;
-            const int32_t nz0 = k ? z0n.y : z0n.x, nz1 = k ? z1n.y : z1n.x;
             bool feasible = (w >> kStatOkBit) && (k ? xok1 : xok0) &&
                             (NARROW ? fits_narrow(a.p, npod, na0, na1, nr0, nr1, a_pods, npods)
                                     : fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods));
@@ -631,6 +654,49 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
                 }
                 if (feasible && a.ipa.on && a.ipa.filter_on && ipa_filter(a.ipa, st, i0 + k)) feasible = false;
             }
+            fe[k] = feasible;
+        }
+        if (SMP == 1) { // counting pass: no scores
+            smp_cnt += (uint32_t)fe[0] + (uint32_t)fe[1];
+            smp_before += (uint32_t)(fe[0] && i0 < smp_S) + (uint32_t)(fe[1] && i0 + 1 < smp_S);
+            continue;
+        }
+        int64_t vpos[2] = {a.c.global_offset + i0, a.c.global_offset + i0 + 1}; // tie-break position of the node
+        if (SMP == 2) {
+            const uint64_t b0 = __ballot(fe[0]), b1 = __ballot(fe[1]);
+            const int lane_ = tid & 63, wave_ = tid >> 6;
+            const uint64_t lt = (1ull << lane_) - 1;
+            if (lane_ == 0) s_smp[smp_par][wave_] = (uint32_t)(__popcll(b0) + __popcll(b1));
+            __syncthreads(); // one barrier per tile: the two buffers alternate
+            uint32_t woff = 0, ttot = 0;
+#pragma unroll
+            for (int w_ = 0; w_ < kThreads / 64; w_++) {
+                const uint32_t c_ = s_smp[smp_par][w_];
+                woff += w_ < wave_ ? c_ : 0;
+                ttot += c_;
+            }
+            const int64_t F0 = smp_carry + woff + __popcll(b0 & lt) + __popcll(b1 & lt);
+            smp_carry += ttot;
+            smp_par ^= 1;
+            const int64_t f0 = fe[0];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int64_t gi = i0 + k, F = F0 + (k ? f0 : 0);
+                const int64_t rank = gi >= smp_S ? F - st.smp_Fs : F + st.smp_Ftotal - st.smp_Fs;
+                vpos[k] = gi >= smp_S ? gi - smp_S : gi + smp_N - smp_S;
+                if (fe[k] && rank == st.smp_K) a.st->smp_stop = vpos[k]; // the node that cancels the search (:655-662)
+                fe[k] = fe[k] && rank < st.smp_K;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t w = k ? sw.y : sw.x;
+            const int64_t a_cpu = k ? A0.y : A0.x, a_mem = k ? A1.y : A1.x;
+            const int64_t r_cpu = k ? R0.y : R0.x, r_mem = k ? R1.y : R1.x;
+            const int64_t z_cpu = k ? Z0.y : Z0.x, z_mem = k ? Z1.y : Z1.x;
+            const int32_t na0 = k ? a0n.y : a0n.x, na1 = k ? a1n.y : a1n.x, nr0 = k ? r0n.y : r0n.x, nr1 = k ? r1n.y : r1n.x;
+            const int32_t nz0 = k ? z0n.y : z0n.x, nz1 = k ? z1n.y : z1n.x;
+            const bool feasible = fe[k];
             const uint64_t mask = __ballot(feasible);
             nfeas += (uint32_t)__popcll(mask); // identical in every lane of the wave
             if (feasible) {
@@ -640,7 +706,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
                                         : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem));
                 if (soft_scoring) {
                     if (a.soft.elig[i0 + k] & 1u) {
-                        const int64_t raw = soft_raw_score(a.soft, st, a.c.pod_count, i0 + k, epoch);
+                        const int64_t raw = soft_raw_score(a.soft, a.st->soft_w, a.c.pod_count, i0 + k, epoch);
                         soft_mn = raw < soft_mn ? raw : soft_mn;
                         soft_mx = raw > soft_mx ? raw : soft_mx;
                         soft_cnt++;
@@ -653,7 +719,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
                     ipa_mx = raw > ipa_mx ? raw : ipa_mx;
                     total += ipa_normalize(raw, st.ipa_min_a, st.ipa_max_a) * a.ipa.w;
                 }
-                const uint64_t key = make_key(total, a.c.global_offset + i0 + k);
+                const uint64_t key = make_key(total, vpos[k]);
                 best = key > best ? key : best;
                 mt_b = cnt > mt_b ? cnt : mt_b;
                 ma_b = aff > ma_b ? aff : ma_b;
@@ -661,6 +727,19 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
         }
     }
 
+    if (SMP == 1) {
+        const int64_t c1 = wave_sum_i64(smp_cnt), c2 = wave_sum_i64(smp_before);
+        __shared__ int64_t s_c[2][kThreads / 64];
+        if ((tid & 63) == 0) s_c[0][tid >> 6] = c1, s_c[1][tid >> 6] = c2;
+        __syncthreads();
+        if (tid == 0) {
+            int64_t t1 = 0, t2 = 0;
+            for (int w = 0; w < kThreads / 64; w++) t1 += s_c[0][w], t2 += s_c[1][w];
+            st_agent(a.smp_partials + 2 * (int64_t)blockIdx.x, (uint64_t)t1);
+            st_agent(a.smp_partials + 2 * (int64_t)blockIdx.x + 1, (uint64_t)t2);
+        }
+        return;
+    }
     // wave reduce, then LDS across the 4 waves
     best = wave_max_u64(best);
     mt_b = wave_max_u32(mt_b);
@@ -752,6 +831,44 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     }
 }
 
+// k_smp_prefix: one block, between the counting and the scoring pass of a sampled cycle.  Exclusive prefix of the
+// per-block feasible counts (index order), the snapshot total and F(start).
+__global__ __launch_bounds__(kThreads) void k_smp_prefix(ScanArgs a) {
+    if (a.st->done) return;
+    const int tid = threadIdx.x, n = a.n_partials;
+    const int per = (n + kThreads - 1) / kThreads;
+    const int lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    int64_t s = 0, sb = 0;
+    for (int i = lo; i < hi; i++) s += (int64_t)ld_agent(a.smp_partials + 2 * (int64_t)i), sb += (int64_t)ld_agent(a.smp_partials + 2 * (int64_t)i + 1);
+    int64_t inc = s; // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t o = __shfl_up(inc, off, 64);
+        if ((tid & 63) >= off) inc += o;
+    }
+    sb = wave_sum_i64(sb);
+    __shared__ int64_t s_w[kThreads / 64], s_b[kThreads / 64];
+    if ((tid & 63) == 63) s_w[tid >> 6] = inc;
+    if ((tid & 63) == 0) s_b[tid >> 6] = sb;
+    __syncthreads();
+    int64_t woff = 0, total = 0, before = 0;
+    for (int w = 0; w < kThreads / 64; w++) {
+        woff += w < (tid >> 6) ? s_w[w] : 0;
+        total += s_w[w];
+        before += s_b[w];
+    }
+    int64_t run = woff + inc - s;
+    for (int i = lo; i < hi; i++) {
+        a.smp_prefix[i] = run;
+        run += (int64_t)ld_agent(a.smp_partials + 2 * (int64_t)i);
+    }
+    if (tid == 0) {
+        a.st->smp_Ftotal = total;
+        a.st->smp_Fs = before;
+        a.st->smp_stop = -1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // decide + commit (one thread): the sequential part of a scheduling cycle.
 //   schedule_one.go:448-463 (0 feasible -> FitError), selectHost :894-941, assume :967-984,
@@ -785,10 +902,15 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
         *a.st = st;
         return;
     }
+    const bool smp = st.smp_K > 0;
+    // a finished sampled cycle moves nextStartNodeIndex past the nodes it visited (schedule_one.go:538-539)
+    const bool smp_all = !smp || st.smp_Ftotal <= st.smp_K; // the search visited every node
     if (key == 0) {
         st.done = DONE_UNSCHEDULABLE;
         st.rounds += 1;
         st.last_feasible = 0;
+        st.last_evaluated = (int32_t)a.c.n; // no feasible node: every node was visited
+        st.evaluated += a.c.n;
     } else if ((int32_t)mt != st.mt_a || (int32_t)ma != st.ma_a) {
         st.mt_a = (int32_t)mt;
         st.ma_a = (int32_t)ma;
@@ -810,7 +932,16 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
         st.ipa_min_a = ipa_mn; // InterPodAffinity scores were normalized with stale min / max: rescan
         st.ipa_max_a = ipa_mx;
     } else {
-        const int64_t g = key_index(key);
+        int64_t g = key_index(key);
+        const int64_t visited = smp_all ? a.c.n : st.smp_stop;
+        if (smp) { // the key carries the visiting position
+            g += st.smp_start;
+            g = g >= a.c.n ? g - a.c.n : g;
+            st.smp_start += visited; // both terms are <= N
+            st.smp_start = st.smp_start >= a.c.n ? st.smp_start - a.c.n : st.smp_start;
+            st.evaluated += visited;
+        }
+        st.last_evaluated = (int32_t)visited;
         const int64_t i = g - a.c.global_offset;
         if (i >= 0 && i < a.c.n) { // this shard owns the winner: NodeInfo.update (types.go:409-428)
             // one thread, latency-bound: issue every load of the row before the first store

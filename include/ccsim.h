@@ -195,7 +195,12 @@ typedef struct {
     int64_t fit_res_w[CCSIM_MAX_RES];
     int32_t n_bal_res;
     int32_t bal_res[CCSIM_MAX_RES];
-    int32_t percentage_of_nodes_to_score; /* this engine evaluates every node: must be 100 */
+    /* KubeSchedulerConfiguration.percentageOfNodesToScore (schedule_one.go:697-723): 100 = every node is scored;
+     * 0 = adaptive (50 - N/125, at least 5 %); below 100 the search keeps the first numFeasibleNodesToFind
+     * feasible nodes of a rotating visiting order (schedule_one.go:610-680).  The sampled search is order-dependent:
+     * CCSIM_MODE_SEQUENTIAL on one GPU only (ccsim_run / ccsim_schedule_one); snapshots with fewer than 100 nodes
+     * are always searched completely. */
+    int32_t percentage_of_nodes_to_score;
 } ccsim_profile;
 
 /* Result of ccsim_run.  Replaces ClusterCapacity.Status{Pods, StopReason}

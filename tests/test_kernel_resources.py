@@ -1,0 +1,34 @@
+"""Build hygiene of the gfx950 kernels (no GPU needed: hipcc cross-compiles and reports per-kernel resources).
+
+A per-lane scratch frame in a streaming kernel is pure overhead (every lane first copies its frame to memory):
+the node-scan kernels must keep everything in registers; only the one-block decision kernels may hold their
+400-byte DevState working copy in scratch."""
+import os
+import shutil
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import kernel_resources as KR  # noqa: E402
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_streaming_kernels_use_no_scratch_and_do_not_spill():
+    rows = KR.collect()
+    scans = [k for k in rows if k.startswith(("k_scan<", "k_level_score<", "k_level_commit<"))]
+    assert len(scans) >= 30  # every NX / coupled / narrow / sampled variant was instantiated
+    for k in scans + ["k_level_final", "k_level_decide", "k_smp_prefix", "k_hist", "k_static"]:
+        assert rows[k]["ScratchSize"] == "0", (k, rows[k])
+        assert rows[k]["VGPRs Spill"] == "0", (k, rows[k])  # (SGPRs may spill into VGPR lanes: no memory traffic)
+    for k in ("k_final", "k_decide"):  # one working copy of DevState, nothing else (not the 1.7 KB argument block)
+        assert int(rows[k]["ScratchSize"]) <= 768, (k, rows[k])
+        assert rows[k]["VGPRs Spill"] == "0"
+    # the throughput kernels keep >= 4 waves per SIMD for the common shapes (no extended resources)
+    for k in ("k_scan<0,0,1,0>", "k_scan<0,0,0,0>", "k_level_score<0,1>", "k_level_score<0,0>", "k_level_commit<0>"):
+        assert int(rows[k]["Occupancy"]) >= 4, (k, rows[k])
+
+
+def test_kernel_name_demangling():
+    assert KR.demangle_kernel("_ZN5ccsim7k_finalENS_8ScanArgsE") == "k_final"
+    assert KR.demangle_kernel("_ZN5ccsim6k_scanILi0ELb0ELb1ELi2EEEvNS_8ScanArgsE") == "k_scan<0,0,1,2>"

@@ -1,0 +1,128 @@
+"""percentageOfNodesToScore < 100: the sampled search of findNodesThatPassFilters
+(vendor/k8s.io/kubernetes/pkg/scheduler/schedule_one.go:610-723): rotating start index, stop at the
+(K+1)-th feasible node, tie-break in feasible-list order.  HIP path (k_scan<SMP=1>, k_smp_prefix,
+k_scan<SMP=2>, k_final) against the oracle's literal visiting loop, cycle by cycle."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+import helpers as H
+from cluster_capacity_amd import capi, model as M, report as R, synth
+
+
+def _check(ccref, nodes, pod, prof, limit):
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    got = e.run(max_limit=limit, mode="sequential", log_cap=max(1, ref.placed))
+    assert got.placed == ref.placed and got.stop == ref.stop
+    assert np.array_equal(got.log, ref.log)
+    assert np.array_equal(got.per_node_count, ref.per_node_count)
+    assert got.evaluated_total == ref.evaluated_total  # the same nodes were visited, cycle by cycle
+    assert got.last_feasible == ref.last_feasible
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist)
+        assert got.n_code_unschedulable == ref.n_code_unschedulable
+        assert R.stop_reason(got, nodes.n, 0) == R.stop_reason(ref, nodes.n, 0)
+    return e, got, ref
+
+
+def _with_pct(prof, pct):
+    return dataclasses.replace(prof, percentage_of_nodes_to_score=pct)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,n,pct,limit", [("C3", 1000, 0, 0), ("C3", 1000, 0, 300), ("C2", 5000, 10, 400), ("C3", 300, 50, 0),
+                                             ("C3", 4096, 5, 0), ("C3", 777, 35, 0), ("C2", 2049, 0, 1000), ("C3", 100, 0, 0),
+                                             ("C3", 100_000, 0, 600)])
+def test_sampled_search_vs_oracle(ccref, cfg, n, pct, limit):
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, pct), limit)
+    k = ccref.num_feasible_nodes_to_find(pct, n)
+    if k < n:
+        assert got.evaluated_total < (got.placed + 1) * n  # the search really stopped early
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_sampled_search_random_plugin_mix(ccref, seed):
+    rng = np.random.default_rng(3000 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(100, 1500)))
+    prof = _with_pct(prof, int(rng.choice([0, 10, 35, 70, 99])))
+    _check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 37, 500])))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_sampled_search_with_topology_coupled_plugins(ccref, seed):
+    # PreFilter / PreScore state covers ALL nodes (filtering.go:235-308), Filter and Score only the sampled ones
+    rng = np.random.default_rng(3100 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(100, 900)))
+    if seed % 3 != 2:
+        cons = H.random_spread(rng, nodes, n_constraints=2)
+        for c in cons:
+            c.hard = bool(rng.integers(0, 2))
+        pod.spread = cons
+    if seed % 3 != 0:
+        pod.ipa = H.random_ipa(rng, nodes)
+    prof = _with_pct(prof, int(rng.choice([0, 20, 60])))
+    _check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 70])))
+
+
+@pytest.mark.gpu
+def test_sampled_search_scalar_resources(ccref):
+    from test_gpu_parity import _scalar_case
+    for n_scalar, seed in [(1, 0), (3, 1), (8, 2)]:
+        nodes, pod = _scalar_case(np.random.default_rng(3200 + seed), 1200, n_scalar)
+        _check(ccref, nodes, pod, _with_pct(M.Profile.default(), 0), 0)
+
+
+@pytest.mark.gpu
+def test_sampled_schedule_one_reports_visited_nodes(ccref):
+    n = 2000
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=11)
+    prof = _with_pct(prof, 0)
+    k = ccref.num_feasible_nodes_to_find(0, n)
+    ref = ccref.run(prof, nodes, pod, max_limit=150)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    total = 0
+    for r in range(150):
+        node, evaluated, feasible = e.schedule_one()
+        assert node == ref.log[r]
+        assert feasible == k and k <= evaluated < n
+        total += evaluated
+    assert total == ref.evaluated_total
+
+
+@pytest.mark.gpu
+def test_sampled_search_continues_across_runs(ccref):
+    # nextStartNodeIndex is scheduler state: two runs of 100 == one run of 200
+    nodes, pod, prof = synth.make_config("C3", n_nodes=1500, seed=12)
+    prof = _with_pct(prof, 0)
+    ref = ccref.run(prof, nodes, pod, max_limit=200)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    a = e.run(max_limit=100, mode="sequential", log_cap=100)
+    b = e.run(max_limit=100, mode="sequential", log_cap=100)
+    assert np.array_equal(np.concatenate([a.log, b.log]), ref.log)
+    e.reset_state()
+    c = e.run(max_limit=200, mode="sequential", log_cap=200)
+    assert np.array_equal(c.log, ref.log)
+
+
+@pytest.mark.gpu
+def test_sampled_search_is_sequential_single_gpu_only(ccref):
+    nodes, pod, prof = synth.make_config("C3", n_nodes=500, seed=13)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, _with_pct(prof, 0))
+    with pytest.raises(capi.CcsimError):
+        e.run(mode="batched")
+    # fewer than 100 nodes: every node is visited whatever the percentage (schedule_one.go:703-705): batched is valid
+    nodes, pod, prof = synth.make_config("C3", n_nodes=90, seed=14)
+    ref = ccref.run(_with_pct(prof, 0), nodes, pod)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, _with_pct(prof, 0))
+    got = e.run(mode="batched")
+    assert got.placed == ref.placed and np.array_equal(got.per_node_count, ref.per_node_count)
