@@ -134,13 +134,18 @@ def pretty(review: dict, verbose: bool) -> str:
     return "\n".join(out) + "\n"
 
 
-def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, device: int = 0) -> M.RunResult:
+def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, device: int = 0,
+             percentage_of_nodes_to_score: int = 100) -> M.RunResult:
     from . import capi
 
     coupled = bool(snap.pod.spread) or snap.pod.ipa is not None
-    mode = mode or ("sequential" if coupled else "batched")
+    # a sampled search (schedule_one.go:610-723) is order-dependent: the literal one-cycle-per-pass loop
+    sampled = percentage_of_nodes_to_score != 100 and snap.nodes.n >= 100
+    mode = mode or ("sequential" if coupled or sampled else "batched")
     eng = capi.Engine(device=device)
-    eng.load(snap.nodes, snap.pod, M.Profile.default())
+    prof = M.Profile.default()
+    prof.percentage_of_nodes_to_score = percentage_of_nodes_to_score
+    eng.load(snap.nodes, snap.pod, prof)
     cap = max_limit if max_limit > 0 else int(min(int(snap.nodes.alloc_pods.astype(np.int64).sum()), 1 << 26))
     try:
         return eng.run(max_limit=max_limit, mode=mode, want_log=True, log_cap=max(1, cap))
@@ -157,12 +162,15 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     ap.add_argument("--verbose", action="store_true", help="Verbose mode")
     ap.add_argument("-o", "--output", default="", choices=["", "json", "yaml"], help="Output format. One of: json|yaml")
     ap.add_argument("--mode", default=None, choices=["batched", "sequential"], help="engine mode (default: batched unless the pod couples nodes)")
+    ap.add_argument("--percentage-of-nodes-to-score", type=int, default=100,
+                    help="KubeSchedulerConfiguration.percentageOfNodesToScore: 100 scores every node (the final capacity and "
+                         "distribution do not depend on it for pods without topology constraints); 0 = the scheduler's adaptive default")
     args = ap.parse_args(argv)
 
     pod = parse_pod_spec(args.podspec)
     node_objs, pod_objs = load_objects(args.snapshot)
     snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x])
-    result = simulate(snap, args.max_limit, args.mode)
+    result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=args.percentage_of_nodes_to_score)
     review = build_review(pod, snap, result, args.max_limit)
     if args.output == "json":
         out.write(json.dumps(review) + "\n")

@@ -2,6 +2,7 @@
 # A/B: sequential + batched throughput of the in-tree library vs cluster-capacity_amd/csrc/libccsim_head.so
 exec < /dev/null
 cd /root/repo
+[ -f cluster-capacity_amd/csrc/libccsim_head.so ] || { echo "build the baseline library first: cluster-capacity_amd/csrc/libccsim_head.so"; exit 1; }
 mkdir -p gpurun_out
 run() {
 timeout 200 python - <<'PY'
