@@ -863,6 +863,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     st.soft_min_a = INT64_MAX, st.soft_max_a = 0;
     for (auto &fl : e->soft_flags) HIPCHK(e, hipMemsetAsync(fl.first, 0, fl.second * 4, e->stream)); // epochs restart at 1
     st.limit = max_limit;
+    st.lvl_full = 1; // no score cache yet
     st.winner = -1;
     st.mode = mode;
     st.log_cap = e->log_cap;

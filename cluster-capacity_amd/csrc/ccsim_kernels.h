@@ -178,6 +178,11 @@ struct DevState {
     int32_t lvl_prefix;      // 1 = ordered commit (limit inside the level, or placement log wanted)
     int32_t lvl_plan_only;   // 1 = the next pass only measures level lvl_M (no commit)
     int32_t last_evaluated;  // nodes the last cycle visited (sampled search; otherwise N)
+    // batched mode: the score cache (LevelArgs::cscore).  lvl_full = 1: it is invalid, the next pass is a full one
+    // (k_level_score); otherwise k_level_commit keeps it current and these counts track the feasible set:
+    int64_t cur_nfeas;       // feasible nodes of this shard
+    int64_t cur_c_mt, cur_c_ma; // this shard's feasible holders of the (global) normalization maxima mt_a / ma_a
+    int32_t lvl_full, pad1;
     // percentageOfNodesToScore < 100 (schedule_one.go:610-723): the sampled search of the sequential mode
     int64_t smp_K;           // numFeasibleNodesToFind; 0 = every node is scored
     int64_t smp_start;       // nextStartNodeIndex

@@ -246,13 +246,18 @@ __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v) {
     return v;
 }
 
-struct __attribute__((aligned(16))) CommitPartial { // per k_level_commit block: 48 bytes
+struct __attribute__((aligned(16))) CommitPartial { // per k_level_commit block: 64 bytes
     int64_t committed;      // placements committed by this block in this pass
     int64_t T;              // plan pass: placements of the block's nodes at level st.lvl_M
     int64_t cut_mt, cut_ma; // plan pass: highest global index among exhausted holders of st.mt_a / st.ma_a (-1 none)
     uint32_t e_mt, e_ma;    // plan pass: how many holders their run-down exhausts
-    int64_t pad;
+    // commit pass: the block's part of the NEXT level, from the score cache (unchanged nodes) and the re-scored level nodes
+    uint64_t key;           // block max ((score+1) << 40 | (2^40-1 - global idx)); 0 = nothing feasible
+    uint32_t n_top;         // nodes holding the block's maximum score
+    uint32_t x_nf;          // level nodes this commit left infeasible ...
+    uint32_t x_mt, x_ma;    // ... and how many of them held the normalization maxima st.mt_a / st.ma_a
 };
+static_assert(sizeof(CommitPartial) == 64, "CommitPartial layout");
 
 struct LevelArgs {
     DevCols c;
@@ -299,6 +304,18 @@ struct LevelAcc {
     }
 };
 
+// the commit pass's running reduction: maximum score, lowest index holding it, how many nodes hold it
+struct LevelTop {
+    uint64_t best = 0;
+    int64_t top = -1;
+    uint32_t ntop = 0;
+    __device__ __forceinline__ void add(int64_t score, int64_t gidx) {
+        const uint64_t key = make_key(score, gidx);
+        best = key > best ? key : best;
+        if (score > top) top = score, ntop = 1; else if (score == top) ntop++;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // k_level_score: the full pods x nodes pass of the batched mode.  Filter + Score of every node (same arithmetic and
 // bytes as k_scan), the packed max key, the size of the top level, the normalization maxima with their holder
@@ -308,7 +325,10 @@ struct LevelAcc {
 template <int NX, bool NARROW = false>
 __global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
     const DevState st = *a.st;
-    if (st.done || st.lvl_plan_only) return; // a plan pass moves nothing: the previous scores stand
+    // Runs only while the score cache is invalid (first pass of a run; the normalization constants moved).  Otherwise
+    // the commit pass keeps the cache current -- it re-scores exactly the nodes it changed -- and derives the next
+    // level from it: a placement changes one node, so re-reading the other 10^6 - |level| rows would be wasted traffic.
+    if (st.done || !st.lvl_full) return;
     constexpr int kWaves = kThreads / 64;
     __shared__ uint64_t s_key[kWaves];
     __shared__ uint32_t s_u[6][kWaves];
@@ -427,6 +447,8 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
     int64_t carry = ordered ? st.lvl_rank_prefix + a.blockprefix[blockIdx.x] : 0;
     int64_t T = 0, cut_mt = -1, cut_ma = -1; // plan pass
     uint32_t e_mt = 0, e_ma = 0;
+    LevelTop acc;                            // commit pass: the next level
+    uint32_t x_nf = 0, x_mt = 0, x_ma = 0;
 
     // Tiles are handled in groups of kGroupTiles: ONE compaction and ONE worker phase per group (the phases of a
     // block are latency chains -- gather loads, dependent run-down steps -- so fewer, fuller phases win).
@@ -444,6 +466,10 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
                 const bool l1 = cs.y == M && (a.c.global_offset + i0 + 1) <= st.lvl_cut;
                 const uint64_t b0 = __ballot(l0), b1 = __ballot(l1);
                 flags |= (l0 ? 1u : 0u) << (2 * t) | (l1 ? 1u : 0u) << (2 * t + 1);
+                if (!plan_only) { // nodes this pass does not touch keep their cached score
+                    if (!l0 && cs.x >= 0) acc.add(cs.x, a.c.global_offset + i0);
+                    if (!l1 && cs.y >= 0) acc.add(cs.y, a.c.global_offset + i0 + 1);
+                }
                 wcnt[t] = __popcll(b0 & lt_mask) + __popcll(b1 & lt_mask); // level nodes of lower lanes in this wave
                 if (lane == 0) s_cnt[t][wave] = __popcll(b0) + __popcll(b1);
             } else if (lane == 0)
@@ -521,6 +547,17 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
                         }
                     }
                 }
+                if (mine) { // re-score the node in the state it was left in: the cache stays exact
+                    const bool f = node_feasible<NX>(a.p, n);
+                    const int64_t s = f ? node_score<NX>(a.p, n, nstat) : -1;
+                    a.cscore[nidx] = (int32_t)s;
+                    if (f) acc.add(s, g);
+                    else {
+                        x_nf++;
+                        x_mt += cnt == mt ? 1u : 0u;
+                        x_ma += aff == ma ? 1u : 0u;
+                    }
+                }
             }
         }
         __syncthreads(); // the list and the counters are rewritten by the next group
@@ -534,6 +571,16 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
         e_mt = wave_sum_u32(e_mt);
         e_ma = wave_sum_u32(e_ma);
     }
+    __shared__ uint64_t s_k[kWaves];
+    __shared__ uint32_t s_x[4][kWaves];
+    if (!plan_only) {
+        const uint64_t wbest = wave_max_u64(acc.best);
+        const int64_t wtop = wave_max_i64(acc.top);
+        const uint32_t wntop = wave_sum_u32(acc.top == wtop ? acc.ntop : 0u);
+        x_nf = wave_sum_u32(x_nf), x_mt = wave_sum_u32(x_mt), x_ma = wave_sum_u32(x_ma);
+        if (lane == 0) s_k[wave] = wbest, s_x[0][wave] = wntop, s_x[1][wave] = x_nf, s_x[2][wave] = x_mt, s_x[3][wave] = x_ma;
+    } else if (lane == 0)
+        s_k[wave] = 0, s_x[0][wave] = s_x[1][wave] = s_x[2][wave] = s_x[3][wave] = 0;
     if (lane == 0) {
         s_u[0][wave] = e_mt, s_u[1][wave] = e_ma;
         s_l[0][wave] = T, s_l[1][wave] = committed, s_l[2][wave] = cut_mt, s_l[3][wave] = cut_ma;
@@ -544,6 +591,11 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
         out.cut_mt = out.cut_ma = -1;
 #pragma unroll
         for (int w = 0; w < kWaves; w++) {
+            const uint64_t kw = s_k[w];
+            if (kw && (!out.key || key_score(kw) > key_score(out.key))) out.n_top = s_x[0][w];
+            else if (kw && key_score(kw) == key_score(out.key)) out.n_top += s_x[0][w];
+            out.key = kw > out.key ? kw : out.key;
+            out.x_nf += s_x[1][w], out.x_mt += s_x[2][w], out.x_ma += s_x[3][w];
             out.e_mt += s_u[0][w], out.e_ma += s_u[1][w];
             out.T += s_l[0][w];
             out.committed += s_l[1][w];
@@ -580,6 +632,7 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
         st.lvl_prefix = (want_log || (st.limit > 0 && st.placed + g.T > st.limit)) ? 1 : 0;
         return;
     }
+    const bool incremental = !st.lvl_full; // g came from the score cache (commit pass), not from a full pass
     st.placed += g.committed;
     st.rounds += g.committed;
     st.lvl_valid = 0;
@@ -594,11 +647,17 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
         return;
     }
     st.last_feasible = (int32_t)g.nfeas;
+    if (incremental && ((st.mt_a > 0 && g.c_mt == 0) || (st.ma_a > 0 && g.c_ma == 0))) {
+        st.lvl_full = 1; // the last feasible holder of a normalization maximum is gone: every cached score is stale
+        return;
+    }
     if ((int32_t)g.mt != st.mt_a || (int32_t)g.ma != st.ma_a) { // scores above used stale constants: rescan
         st.mt_a = (int32_t)g.mt;
         st.ma_a = (int32_t)g.ma;
+        st.lvl_full = 1;
         return;
     }
+    st.lvl_full = 0;
     st.lvl_M = key_score(g.key);
     st.lvl_c_mt = g.c_mt; // holder counts of the maxima, for the plan pass's "all holders exhausted?" test
     st.lvl_c_ma = g.c_ma;
@@ -639,14 +698,17 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
     __shared__ uint64_t s_key[kWaves];
     __shared__ uint32_t s_u[4][kWaves];
     __shared__ int64_t s_l[8][kWaves];
+    __shared__ int64_t s_x[3][kWaves];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool plan_pass = a.st->lvl_plan_only != 0;
     const bool commit_ran = plan_pass || a.st->lvl_valid != 0; // else k_level_commit exited without writing partials
+    const bool full_pass = a.st->lvl_full != 0;                // k_level_score ran: the next level comes from its partials
 
     uint64_t key = 0;
     uint32_t mt = 0, cmt = 0, ma = 0, cma = 0;
     int64_t nf = 0, committed = 0, T = 0, e_mt = 0, e_ma = 0, cut_mt = -1, cut_ma = -1, ntop = 0;
-    if (!plan_pass) // a plan pass skips the score pass: nothing moved, its partials are the previous pass's
+    int64_t x_nf = 0, x_mt = 0, x_ma = 0;
+    if (full_pass)
         for (int i = tid; i < a.n_partials; i += kFinalThreads) {
             const LevelPartial q = a.partials[i];
             if (q.key) { // size of the top level: nodes holding the maximum score, over the blocks whose maximum it is
@@ -665,6 +727,14 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
             T += q.T, e_mt += q.e_mt, e_ma += q.e_ma;
             cut_mt = q.cut_mt > cut_mt ? q.cut_mt : cut_mt;
             cut_ma = q.cut_ma > cut_ma ? q.cut_ma : cut_ma;
+            if (!plan_pass && !full_pass) { // the next level, from the score cache
+                if (q.key) {
+                    if (!key || key_score(q.key) > key_score(key)) ntop = q.n_top;
+                    else if (key_score(q.key) == key_score(key)) ntop += q.n_top;
+                }
+                key = q.key > key ? q.key : key;
+                x_nf += q.x_nf, x_mt += q.x_mt, x_ma += q.x_ma;
+            }
         }
     {
         const uint64_t wkey = wave_max_u64(key);
@@ -674,6 +744,8 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
         nf = wave_sum_i64(nf), committed = wave_sum_i64(committed);
         T = wave_sum_i64(T), e_mt = wave_sum_i64(e_mt), e_ma = wave_sum_i64(e_ma);
         cut_mt = wave_max_i64(cut_mt), cut_ma = wave_max_i64(cut_ma);
+        x_nf = wave_sum_i64(x_nf), x_mt = wave_sum_i64(x_mt), x_ma = wave_sum_i64(x_ma);
+        if (lane == 0) s_x[0][wave] = x_nf, s_x[1][wave] = x_mt, s_x[2][wave] = x_ma;
         if (lane == 0) {
             s_key[wave] = wkey;
             s_u[0][wave] = wmt, s_u[1][wave] = wma, s_u[2][wave] = wcmt, s_u[3][wave] = wcma;
@@ -697,6 +769,17 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
             g.nfeas += s_l[0][w], g.committed += s_l[1][w], g.T += s_l[2][w], g.e_mt += s_l[3][w], g.e_ma += s_l[4][w];
             g.cut_mt = s_l[5][w] > g.cut_mt ? s_l[5][w] : g.cut_mt;
             g.cut_ma = s_l[6][w] > g.cut_ma ? s_l[6][w] : g.cut_ma;
+        }
+        if (!plan_pass && !full_pass) { // incremental pass: the maxima stand, their holders and the feasible count shrink
+            int64_t dn = 0, dt = 0, da = 0;
+            for (int w = 0; w < kWaves; w++) dn += s_x[0][w], dt += s_x[1][w], da += s_x[2][w];
+            g.mt = (uint32_t)a.st->mt_a, g.ma = (uint32_t)a.st->ma_a;
+            g.nfeas = a.st->cur_nfeas - dn;
+            g.c_mt = (uint32_t)(a.st->cur_c_mt - dt), g.c_ma = (uint32_t)(a.st->cur_c_ma - da);
+        }
+        if (!plan_pass) { // this shard's feasible count and holder counts after the pass
+            a.st->cur_nfeas = g.nfeas;
+            a.st->cur_c_mt = g.c_mt, a.st->cur_c_ma = g.c_ma;
         }
         if (a.n_ranks > 0) { // publish this shard's record; k_level_decide finishes after the exchange
             XRec r{};
@@ -757,6 +840,11 @@ __global__ void k_level_decide(LevelFinalArgs a) {
         if (q.key && key_score((uint64_t)q.key) == top) g.n_top += q.n_top;
     }
     const bool plan_pass = st.lvl_plan_only != 0;
+    if (!plan_pass && st.lvl_full) { // after a full pass: this shard's holder counts refer to the GLOBAL maxima
+        const XRec own = a.xrecv[a.rank];
+        if ((uint32_t)own.mt != g.mt) st.cur_c_mt = 0;
+        if ((uint32_t)own.ma != g.ma) st.cur_c_ma = 0;
+    }
     level_decide(st, g, a.want_log != 0);
     if (plan_pass) st.lvl_rank_prefix = before;
     *a.st = st;
