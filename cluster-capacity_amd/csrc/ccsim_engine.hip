@@ -788,7 +788,8 @@ static int launch_level_commit(ccsim_engine *e, hipEvent_t t1 = nullptr) {
     const int nx = e->pod.nx;
     dim3 g(e->lvl_grid), b(kThreads);
     hipEvent_t t0 = nullptr;
-    if (nx == 0) CCSIM_LAUNCH(k_level_commit<0>, g, b, e->stream, t0, t1, a);
+    if (nx == 0 && e->cols.narrow) CCSIM_LAUNCH((k_level_commit<0, true>), g, b, e->stream, t0, t1, a);
+    else if (nx == 0) CCSIM_LAUNCH(k_level_commit<0>, g, b, e->stream, t0, t1, a);
     else if (nx == 1) CCSIM_LAUNCH(k_level_commit<1>, g, b, e->stream, t0, t1, a);
     else if (nx == 2) CCSIM_LAUNCH(k_level_commit<2>, g, b, e->stream, t0, t1, a);
     else if (nx <= 4) CCSIM_LAUNCH(k_level_commit<4>, g, b, e->stream, t0, t1, a);

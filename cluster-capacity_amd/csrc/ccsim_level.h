@@ -112,6 +112,60 @@ __device__ __forceinline__ NodeRegs<NX> bcast_node(const NodeRegs<NX> &n, int sr
     return o;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One node of the commit pass behind a small common interface (nd_*), in two representations:
+//   NodeRegs<NX>  the int64 columns (any snapshot, NX extended resources);
+//   NodeNarrow    the 32-bit mirrors (DevCols::narrow: every value stays below 2^31 for the whole run, memory in the
+//                 common power-of-two unit; see "NARROW arithmetic" in ccsim_kernels.h).  A run-down step costs ~5x fewer
+//                 VALU instructions (no 64-bit multiply / divide emulation, no fp64), and the run-downs are what the
+//                 commit pass spends its time on.
+// ------------------------------------------------------------------------------------------------
+struct RunCtx {
+    const DevPod &p;
+    NarrowPod q; // the pod in narrow units (unused by NodeRegs)
+};
+
+struct NodeNarrow {
+    int32_t a0, a1, r0, r1, z0, z1, a_pods, npods;
+    uint32_t w;
+};
+struct NoRcp {};
+
+template <int NX> __device__ __forceinline__ bool nd_feasible(const RunCtx &cx, const NodeRegs<NX> &n) { return node_feasible<NX>(cx.p, n); }
+template <int NX> __device__ __forceinline__ void nd_apply(const RunCtx &cx, NodeRegs<NX> &n, int64_t k) { node_apply<NX>(cx.p, n, k); }
+template <int NX> __device__ __forceinline__ NodeRcp nd_rcp(const NodeRegs<NX> &n) { return make_rcp(n.a_cpu, n.a_mem); }
+template <int NX> __device__ __forceinline__ int64_t nd_score(const RunCtx &cx, const NodeRegs<NX> &n, int64_t stat, const NodeRcp &rc) {
+    return node_score<NX>(cx.p, n, stat, rc);
+}
+template <int NX> __device__ __forceinline__ NodeRegs<NX> nd_bcast(const NodeRegs<NX> &n, int src) { return bcast_node<NX>(n, src); }
+template <int NX> __device__ __forceinline__ int64_t nd_room(const NodeRegs<NX> &) { return (int64_t)1 << 40; } // int64: no clamp needed
+template <int NX> __device__ __forceinline__ uint32_t nd_word(const NodeRegs<NX> &n) { return n.w; }
+
+__device__ __forceinline__ bool nd_feasible(const RunCtx &cx, const NodeNarrow &n) {
+    return (n.w >> kStatOkBit) && fits_narrow(cx.p, cx.q, n.a0, n.a1, n.r0, n.r1, n.a_pods, n.npods);
+}
+__device__ __forceinline__ void nd_apply(const RunCtx &cx, NodeNarrow &n, int64_t k) {
+    const int32_t kk = (int32_t)k;
+    n.r0 += kk * cx.q.req0, n.r1 += kk * cx.q.req1;
+    n.z0 += kk * cx.q.nz0, n.z1 += kk * cx.q.nz1;
+    n.npods += kk;
+}
+__device__ __forceinline__ NoRcp nd_rcp(const NodeNarrow &) { return NoRcp{}; }
+__device__ __forceinline__ int64_t nd_score(const RunCtx &cx, const NodeNarrow &n, int64_t stat, const NoRcp &) {
+    return stat + dynamic_score_narrow(cx.p, cx.q, n.a0, n.a1, n.r0, n.r1, n.z0, n.z1);
+}
+__device__ __forceinline__ NodeNarrow nd_bcast(const NodeNarrow &n, int src) {
+    NodeNarrow o;
+    o.a0 = bcast_i32(n.a0, src), o.a1 = bcast_i32(n.a1, src), o.r0 = bcast_i32(n.r0, src), o.r1 = bcast_i32(n.r1, src);
+    o.z0 = bcast_i32(n.z0, src), o.z1 = bcast_i32(n.z1, src), o.a_pods = bcast_i32(n.a_pods, src), o.npods = bcast_i32(n.npods, src);
+    o.w = (uint32_t)bcast_i32((int32_t)n.w, src);
+    return o;
+}
+// Placements after which the node is certainly full (NodeResourcesFit pod count): the closed-form candidates of the
+// cooperative tail are clamped to it, so 32-bit state never leaves the range the narrow mode was validated for.
+__device__ __forceinline__ int64_t nd_room(const NodeNarrow &n) { return n.a_pods > n.npods ? (int64_t)(n.a_pods - n.npods) : 1; }
+__device__ __forceinline__ uint32_t nd_word(const NodeNarrow &n) { return n.w; }
+
 // Run-downs, two regimes.  Every lane of the wave must call this (wave-uniform control flow).
 // `mine` = this lane's node holds the level (feasible, score == M).
 //   1. kSeqSteps placements evaluated by the lane itself (all level lanes of the wave in parallel): most
@@ -126,39 +180,40 @@ __device__ __forceinline__ NodeRegs<NX> bcast_node(const NodeRegs<NX> &n, int sr
 #endif
 constexpr int kSeqSteps = CCSIM_SEQ_STEPS;
 
-template <int NX>
-__device__ __forceinline__ int32_t wave_run_down(const DevPod &p, const NodeRegs<NX> &n, int64_t stat, int64_t M, bool mine,
-                                                 bool &feas_after) {
+template <class Node>
+__device__ __forceinline__ int32_t wave_run_down(const RunCtx &cx, const Node &n, int64_t stat, int64_t M, bool mine, bool &feas_after) {
     const int lane = threadIdx.x & 63;
     int32_t my_j = 0;
     feas_after = true;
     if (!__ballot(mine)) return 0;
-    NodeRegs<NX> cur = n;
+    Node cur = n;
     bool running = mine;
-    const NodeRcp rc = make_rcp(n.a_cpu, n.a_mem); // allocatable never changes: one reciprocal pair per node
+    const auto rc = nd_rcp(n); // allocatable never changes: one reciprocal pair per node
 #pragma unroll 1
     for (int it = 0; it < kSeqSteps && __ballot(running); it++) {
         if (running) {
-            node_apply<NX>(p, cur, 1);
+            nd_apply(cx, cur, 1);
             my_j++;
-            feas_after = node_feasible<NX>(p, cur);
-            running = feas_after && node_score<NX>(p, cur, stat, rc) >= M;
+            feas_after = nd_feasible(cx, cur);
+            running = feas_after && nd_score(cx, cur, stat, rc) >= M;
         }
     }
     uint64_t todo = __ballot(running);
     while (todo) {
         const int src = __ffsll((unsigned long long)todo) - 1;
         todo &= todo - 1;
-        const NodeRegs<NX> base = bcast_node<NX>(cur, src);
+        const Node base = nd_bcast(cur, src);
         const int64_t bstat = bcast_i64(stat, src);
-        const NodeRcp brc = make_rcp(base.a_cpu, base.a_mem);
+        const auto brc = nd_rcp(base);
+        const int64_t room = nd_room(base); // after `room` more placements the node is full
         int32_t j = 0;
         bool f_end = true;
         for (int32_t k0 = 0;; k0 += 64) {
-            NodeRegs<NX> t = base;
-            node_apply<NX>(p, t, (int64_t)k0 + lane + 1);
-            const bool f = node_feasible<NX>(p, t);
-            const bool stop = !(f && node_score<NX>(p, t, bstat, brc) >= M);
+            Node t = base;
+            const int64_t k = (int64_t)k0 + lane + 1;
+            nd_apply(cx, t, k < room ? k : room);
+            const bool f = nd_feasible(cx, t); // (k >= room: the pod count alone makes it infeasible)
+            const bool stop = !(f && nd_score(cx, t, bstat, brc) >= M);
             const uint64_t sm = __ballot(stop);
             if (sm) {
                 const int first = __ffsll((unsigned long long)sm) - 1;
@@ -288,6 +343,35 @@ __device__ __forceinline__ void load_one(const DevCols &c, const DevPod &p, int6
         n.xr[x] = on ? c.req[p.xcol[x]][i] : 0;
     }
 }
+
+template <int NX> __device__ __forceinline__ void nd_load(const DevCols &c, const DevPod &p, int64_t i, NodeRegs<NX> &n) { load_one<NX>(c, p, i, n); }
+template <int NX> __device__ __forceinline__ void nd_store(const DevCols &c, const DevPod &p, int64_t i, const NodeRegs<NX> &n, int32_t took) {
+    store_dyn<NX>(c, p, i, n, took);
+}
+template <int NX> __device__ __forceinline__ void nd_zero(NodeRegs<NX> &n) {
+    n.a_cpu = n.a_mem = n.r_cpu = n.r_mem = n.z_cpu = n.z_mem = 0, n.a_pods = n.npods = 0, n.w = 0;
+#pragma unroll
+    for (int x = 0; x < (NX > 0 ? NX : 1); x++) n.xa[x] = n.xr[x] = 0;
+}
+__device__ __forceinline__ void nd_load(const DevCols &c, const DevPod &, int64_t i, NodeNarrow &n) { // 9 x 4-byte gathers
+    n.w = c.stat[i];
+    n.a0 = c.a32[0][i], n.a1 = c.a32[1][i];
+    n.r0 = c.r32[0][i], n.r1 = c.r32[1][i];
+    n.z0 = c.z32[0][i], n.z1 = c.z32[1][i];
+    n.a_pods = c.alloc_pods[i], n.npods = c.pod_count[i];
+}
+__device__ __forceinline__ void nd_store(const DevCols &c, const DevPod &, int64_t i, const NodeNarrow &n, int32_t took) {
+    const int sh = c.mem_shift; // the int64 columns stay authoritative (read_state, k_hist, the sequential mode): same values
+    c.req[0][i] = (int64_t)n.r0, c.req[1][i] = (int64_t)n.r1 << sh;
+    c.nz_mcpu[i] = (int64_t)n.z0, c.nz_mem[i] = (int64_t)n.z1 << sh;
+    c.r32[0][i] = n.r0, c.r32[1][i] = n.r1, c.z32[0][i] = n.z0, c.z32[1][i] = n.z1;
+    c.pod_count[i] = n.npods;
+    c.placed_cnt[i] += took;
+}
+__device__ __forceinline__ void nd_zero(NodeNarrow &n) { n.a0 = n.a1 = n.r0 = n.r1 = n.z0 = n.z1 = 0, n.a_pods = n.npods = 0, n.w = 0; }
+
+template <int NX, bool NARROW> struct CommitNode { using type = NodeRegs<NX>; };
+template <int NX> struct CommitNode<NX, true> { using type = NodeNarrow; };
 
 // running reduction state of one thread over the nodes it scored
 struct LevelAcc {
@@ -421,8 +505,10 @@ __global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kGroupTiles = 4; // tiles compacted together: 2048 nodes, 8 KiB of LDS work list
 
-template <int NX>
+template <int NX, bool NARROW = false>
 __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
+    using Node = typename CommitNode<NX, NARROW>::type;
+    const RunCtx cx{a.p, narrow_pod(a.p, a.c.mem_shift)};
     const DevState st = *a.st;
     if (st.done) return;
     const bool plan_only = st.lvl_plan_only != 0;
@@ -494,20 +580,19 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
         for (int r0 = 0; r0 < total; r0 += kThreads) { // one entry per worker lane per round
             const int nwork = total - r0 < kThreads ? total - r0 : kThreads;
             const bool mine = tid < nwork;
-            NodeRegs<NX> n;
-            n.a_cpu = n.a_mem = n.r_cpu = n.r_mem = n.z_cpu = n.z_mem = 0, n.a_pods = n.npods = 0, n.w = 0;
-#pragma unroll
-            for (int x = 0; x < (NX > 0 ? NX : 1); x++) n.xa[x] = n.xr[x] = 0;
+            Node n;
+            nd_zero(n);
             int64_t nidx = 0;
             if (mine) {
                 nidx = lo + s_idx[r0 + tid];
-                load_one<NX>(a.c, a.p, nidx, n);
+                nd_load(a.c, a.p, nidx, n);
             }
-            const uint32_t cnt = (n.w >> kStatCntShift) & kStatCntMask, aff = n.w & kStatAffMask;
+            const uint32_t nw = nd_word(n);
+            const uint32_t cnt = (nw >> kStatCntShift) & kStatCntMask, aff = nw & kStatAffMask;
             const int64_t nstat = static_score(a.p, cnt, aff, mt, ma);
             bool fend = true;
             int64_t j = 0;
-            if ((wave * 64) < nwork) j = wave_run_down<NX>(a.p, n, nstat, M, mine, fend); // wave-uniform
+            if ((wave * 64) < nwork) j = wave_run_down<Node>(cx, n, nstat, M, mine, fend); // wave-uniform
             const int64_t g = a.c.global_offset + nidx;
             if (plan_only) {
                 if (mine) {
@@ -537,8 +622,8 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
                     if (took > allowed) took = allowed;
                 }
                 if (mine && took > 0) {
-                    node_apply<NX>(a.p, n, took);
-                    store_dyn<NX>(a.c, a.p, nidx, n, (int32_t)took);
+                    nd_apply(cx, n, took);
+                    nd_store(a.c, a.p, nidx, n, (int32_t)took);
                     committed += took;
                     if (ordered && a.log) {
                         for (int64_t q = 0; q < took; q++) {
@@ -548,8 +633,8 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
                     }
                 }
                 if (mine) { // re-score the node in the state it was left in: the cache stays exact
-                    const bool f = node_feasible<NX>(a.p, n);
-                    const int64_t s = f ? node_score<NX>(a.p, n, nstat) : -1;
+                    const bool f = nd_feasible(cx, n);
+                    const int64_t s = f ? nd_score(cx, n, nstat, nd_rcp(n)) : -1;
                     a.cscore[nidx] = (int32_t)s;
                     if (f) acc.add(s, g);
                     else {
