@@ -770,6 +770,10 @@ struct LevelFinalArgs {
     int32_t n_ranks;   // 0 = single GPU
     int32_t rank;
     int32_t want_log;
+    // which kernels ran before this one in the pass.  The graph of a single-GPU run is 2 x [k_level_score, k_level_final]
+    // followed by R x [k_level_commit, k_level_final]: a pass whose kernels cannot do what the state asks for (a full
+    // pass is due inside the commit-only stretch, or nothing is due in a score-only pass) is a no-op.
+    int32_t commit_launched, score_launched;
 };
 
 // k_level_final: one block.  Reduces the per-block partials of the pass that just ran (commit partials: what was
@@ -779,6 +783,7 @@ constexpr int kFinalThreads = 256;
 
 __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a) {
     if (a.st->done) return;
+    if (a.st->lvl_full ? !a.score_launched : !a.commit_launched) return; // block-uniform: see LevelFinalArgs
     constexpr int kWaves = kFinalThreads / 64;
     __shared__ uint64_t s_key[kWaves];
     __shared__ uint32_t s_u[4][kWaves];
