@@ -95,6 +95,7 @@ struct ccsim_engine {
     int rank = 0;
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
+    bool rows_active = false; // the current batched run keeps its dynamic state in the commit rows (DevCols::rows)
     uint64_t node_mem_or = 0; // OR of every memory value of the snapshot (common power-of-two unit)
     int64_t node_max_cpu = 0, node_max_mem = 0, node_max_pods = 0;
     int narrow_allowed = 1;
@@ -297,6 +298,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
         for (int k = 0; k < 6; k++)
             if ((rc = dev_alloc(e, &m[k], np, e->allocs))) return rc;
         e->d_a32[0] = m[0], e->d_a32[1] = m[1];
+        if ((rc = dev_alloc(e, &c.rows, np * kRowWords, e->allocs))) return rc;
         c.a32[0] = m[0], c.a32[1] = m[1], c.r32[0] = m[2], c.r32[1] = m[3], c.z32[0] = m[4], c.z32[1] = m[5];
         c.narrow = 0, c.mem_shift = 0;
         e->node_mem_or = 0, e->node_max_cpu = e->node_max_mem = e->node_max_pods = 0;
@@ -814,6 +816,14 @@ static LevelFinalArgs level_final_args(ccsim_engine *e, bool commit_launched = t
     return f;
 }
 
+// commit rows -> columns: in front of every k_level_score launch (conditional on the full pass being due) and when a
+// batched run ends (unconditional)
+static void launch_rows_flush(ccsim_engine *e, bool only_if_full) {
+    if (!e->rows_active) return;
+    const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_rows_flush, dim3(blocks), dim3(kThreads), 0, e->stream, e->cols, (const DevState *)e->d_state, only_if_full ? 1 : 0);
+}
+
 static int launch_level_final(ccsim_engine *e, bool commit_launched = true, bool score_launched = true) {
     hipLaunchKernelGGL(k_level_final, dim3(1), dim3(kFinalThreads), 0, e->stream, level_final_args(e, commit_launched, score_launched));
     return 0;
@@ -881,6 +891,14 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     e->limit = max_limit;
     e->mode = mode;
     e->begun = true;
+    const bool rows = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0;
+    if (rows != e->rows_active) drop_graph(e);
+    e->rows_active = rows;
+    if (rows) {
+        const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(k_rows_build, dim3(blocks), dim3(kThreads), 0, e->stream, e->cols);
+        HIPCHK(e, hipGetLastError());
+    }
     return 0;
 }
 
@@ -916,13 +934,14 @@ static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block redu
             hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, scratch, 0, 0);
             hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, t0, 0, 0);
             if (e->mode == CCSIM_MODE_BATCHED) // the batched mode's dominant kernel is the commit pass
-                launch_level_commit(e, t1), launch_level_score(e), launch_level_final(e);
+                launch_level_commit(e, t1), launch_rows_flush(e, true), launch_level_score(e), launch_level_final(e);
             else launch_scan(e, nullptr, t1), launch_final(e);
             return;
         }
     }
     if (e->mode == CCSIM_MODE_BATCHED) {
         launch_level_commit(e); // the level found by the previous pass (sparse: reads the 4-byte score cache)
+        launch_rows_flush(e, true);
         launch_level_score(e);
         launch_level_final(e);
     } else {
@@ -949,7 +968,7 @@ static int enqueue_rounds(ccsim_engine *e, int rounds) {
                 // Full passes are rare (first pass; the normalization constants moved): two score-only passes at the head
                 // (stale constants found, then the real level), then commit-only passes.  If a full pass falls due inside
                 // the stretch, the rest of this replay is no-ops and the next replay starts with it.
-                for (int r = 0; r < 2; r++) launch_level_score(e), launch_level_final(e, false, true);
+                for (int r = 0; r < 2; r++) launch_rows_flush(e, true), launch_level_score(e), launch_level_final(e, false, true);
                 for (int r = 0; r < rounds; r++) launch_level_commit(e), launch_level_final(e, true, false);
             } else
                 for (int r = 0; r < rounds; r++) launch_pass(e);
@@ -1053,6 +1072,7 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         // every pass either places a pod or (at most twice in a row) re-derives the normalization constants
         if (rounds >= 8 && e->h_state->placed == placed0) return fail(e, -EIO, "simulation made no progress in %d passes", rounds);
     }
+    launch_rows_flush(e, false); // the columns are the state every other entry point reads
     return fill_report(e, out);
 }
 
@@ -1223,6 +1243,7 @@ extern "C" int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed) 
 
 extern "C" int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out) {
     if (!e || !out || !e->begun) return -EINVAL;
+    launch_rows_flush(e, false);
     int rc = read_state(e);
     if (rc) return rc;
     return fill_report(e, out);

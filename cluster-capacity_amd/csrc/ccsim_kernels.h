@@ -64,7 +64,14 @@ struct DevCols {
     const int32_t *a32[2]; // alloc cpu, alloc mem >> mem_shift
     int32_t *r32[2];       // requested
     int32_t *z32[2];       // non-zero requested
+    // Commit rows (batched mode on the narrow mirrors): one 64-byte row per node holding everything a run-down needs --
+    // a level node costs the commit pass one row read and half a row written instead of nine column gathers and eleven
+    // scattered stores (each a full cache line of traffic).  Rows are built at the start of a batched run and are the
+    // ONLY state k_level_commit<.., NARROW> touches; the columns are brought up to date (k_rows_flush) before a full pass
+    // reads them and when the run ends.   int32[16]: a0 a1 alloc_pods stat | r0 r1 z0 z1 | pods placed - - | - - - -
+    int32_t *rows;
 };
+constexpr int kRowWords = 16;
 
 // the six streamed columns of a thread's node pair, widened back to the exact int64 values
 struct Cols6 {
@@ -1356,6 +1363,32 @@ __global__ __launch_bounds__(kThreads) void k_narrow_build(DevCols c, int32_t *a
     a32_cpu[n] = (int32_t)c.alloc[0][n], a32_mem[n] = (int32_t)(c.alloc[1][n] >> sh);
     c.r32[0][n] = (int32_t)c.req[0][n], c.r32[1][n] = (int32_t)(c.req[1][n] >> sh);
     c.z32[0][n] = (int32_t)c.nz_mcpu[n], c.z32[1][n] = (int32_t)(c.nz_mem[n] >> sh);
+}
+
+// k_rows_build: start of a batched run on the narrow mirrors (columns -> commit rows)
+__global__ __launch_bounds__(kThreads) void k_rows_build(DevCols c) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= c.n_pad) return;
+    int4 *row = reinterpret_cast<int4 *>(c.rows + n * kRowWords);
+    row[0] = make_int4(c.a32[0][n], c.a32[1][n], c.alloc_pods[n], (int32_t)c.stat[n]);
+    row[1] = make_int4(c.r32[0][n], c.r32[1][n], c.z32[0][n], c.z32[1][n]);
+    row[2] = make_int4(c.pod_count[n], 0, 0, 0);
+}
+
+// k_rows_flush: commit rows -> columns (mirrors, int64 columns, pod counts).  `only_if_full`: the launch in front of a
+// k_level_score, which reads the mirrors -- it has work only when that full pass is due.
+__global__ __launch_bounds__(kThreads) void k_rows_flush(DevCols c, const DevState *st, int only_if_full) {
+    if (only_if_full && (st->done || !st->lvl_full)) return;
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= c.n_pad) return;
+    const int4 *row = reinterpret_cast<const int4 *>(c.rows + n * kRowWords);
+    const int4 d = row[1], q = row[2];
+    const int sh = c.mem_shift;
+    c.r32[0][n] = d.x, c.r32[1][n] = d.y, c.z32[0][n] = d.z, c.z32[1][n] = d.w;
+    c.req[0][n] = (int64_t)d.x, c.req[1][n] = (int64_t)d.y << sh;
+    c.nz_mcpu[n] = (int64_t)d.z, c.nz_mem[n] = (int64_t)d.w << sh;
+    c.pod_count[n] = q.x;
+    c.placed_cnt[n] = q.y;
 }
 
 __global__ void k_noop(int) {} // measurement marker: its stop stamp = the end of the preceding dispatch + one boundary

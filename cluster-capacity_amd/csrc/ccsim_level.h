@@ -128,6 +128,7 @@ struct RunCtx {
 struct NodeNarrow {
     int32_t a0, a1, r0, r1, z0, z1, a_pods, npods;
     uint32_t w;
+    int32_t placed; // pods this run has put on the node (travels in the commit row)
 };
 struct NoRcp {};
 
@@ -159,6 +160,7 @@ __device__ __forceinline__ NodeNarrow nd_bcast(const NodeNarrow &n, int src) {
     o.a0 = bcast_i32(n.a0, src), o.a1 = bcast_i32(n.a1, src), o.r0 = bcast_i32(n.r0, src), o.r1 = bcast_i32(n.r1, src);
     o.z0 = bcast_i32(n.z0, src), o.z1 = bcast_i32(n.z1, src), o.a_pods = bcast_i32(n.a_pods, src), o.npods = bcast_i32(n.npods, src);
     o.w = (uint32_t)bcast_i32((int32_t)n.w, src);
+    o.placed = 0;
     return o;
 }
 // Placements after which the node is certainly full (NodeResourcesFit pod count): the closed-form candidates of the
@@ -353,22 +355,21 @@ template <int NX> __device__ __forceinline__ void nd_zero(NodeRegs<NX> &n) {
 #pragma unroll
     for (int x = 0; x < (NX > 0 ? NX : 1); x++) n.xa[x] = n.xr[x] = 0;
 }
-__device__ __forceinline__ void nd_load(const DevCols &c, const DevPod &, int64_t i, NodeNarrow &n) { // 9 x 4-byte gathers
-    n.w = c.stat[i];
-    n.a0 = c.a32[0][i], n.a1 = c.a32[1][i];
-    n.r0 = c.r32[0][i], n.r1 = c.r32[1][i];
-    n.z0 = c.z32[0][i], n.z1 = c.z32[1][i];
-    n.a_pods = c.alloc_pods[i], n.npods = c.pod_count[i];
+__device__ __forceinline__ void nd_load(const DevCols &c, const DevPod &, int64_t i, NodeNarrow &n) { // one commit row: 48 bytes
+    const int4 *row = reinterpret_cast<const int4 *>(c.rows + i * kRowWords);
+    const int4 s = row[0], d = row[1], q = row[2];
+    n.a0 = s.x, n.a1 = s.y, n.a_pods = s.z, n.w = (uint32_t)s.w;
+    n.r0 = d.x, n.r1 = d.y, n.z0 = d.z, n.z1 = d.w;
+    n.npods = q.x, n.placed = q.y;
 }
 __device__ __forceinline__ void nd_store(const DevCols &c, const DevPod &, int64_t i, const NodeNarrow &n, int32_t took) {
-    const int sh = c.mem_shift; // the int64 columns stay authoritative (read_state, k_hist, the sequential mode): same values
-    c.req[0][i] = (int64_t)n.r0, c.req[1][i] = (int64_t)n.r1 << sh;
-    c.nz_mcpu[i] = (int64_t)n.z0, c.nz_mem[i] = (int64_t)n.z1 << sh;
-    c.r32[0][i] = n.r0, c.r32[1][i] = n.r1, c.z32[0][i] = n.z0, c.z32[1][i] = n.z1;
-    c.pod_count[i] = n.npods;
-    c.placed_cnt[i] += took;
+    int4 *row = reinterpret_cast<int4 *>(c.rows + i * kRowWords); // the columns follow at the next k_rows_flush
+    row[1] = make_int4(n.r0, n.r1, n.z0, n.z1);
+    row[2] = make_int4(n.npods, n.placed + took, 0, 0);
 }
-__device__ __forceinline__ void nd_zero(NodeNarrow &n) { n.a0 = n.a1 = n.r0 = n.r1 = n.z0 = n.z1 = 0, n.a_pods = n.npods = 0, n.w = 0; }
+__device__ __forceinline__ void nd_zero(NodeNarrow &n) {
+    n.a0 = n.a1 = n.r0 = n.r1 = n.z0 = n.z1 = 0, n.a_pods = n.npods = 0, n.w = 0, n.placed = 0;
+}
 
 template <int NX, bool NARROW> struct CommitNode { using type = NodeRegs<NX>; };
 template <int NX> struct CommitNode<NX, true> { using type = NodeNarrow; };
