@@ -21,11 +21,10 @@ Modes (identical placement sequences, see tests/): `batched` resolves a whole sc
 placement rounds) per full pods x nodes pass; `sequential` is the literal one-round-per-pass loop.
 The headline `value` is the batched mode; a sequential sample is reported next to it in `config`.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live on the full pods x nodes pass (k_level_score in
-batched mode, k_scan in sequential mode: the kernel that streams every node column, 60 B/node) with HIP
-events on the engine's stream; the batched mode's other kernels (k_level_commit: sparse run-downs of the
-level's nodes off a 4-byte score cache, VALU/latency-bound; k_level_final: one block) are listed in
-profiles/.  `cpu_baseline` is the C oracle (a port of the reference algorithm -- the Go reference cannot
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the engine's stream for the
+dominant kernel (batched: k_level_commit, the one launch per pass that commits a level off the score cache;
+sequential: k_scan) and, under `full_pass`, for the kernel that streams every node column (k_level_score /
+k_scan, 60 B/node); k_level_final (one block) is listed in profiles/.  `cpu_baseline` is the C oracle (a port of the reference algorithm -- the Go reference cannot
 be built here) timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
@@ -146,39 +145,56 @@ def main():
         barrier()
         seq = rs.placed / (time.perf_counter() - s0)
 
-    # roofline of the full pods x nodes pass (k_level_score / k_scan): its average launch
-    # duration over one more step of the SAME workload, measured live with a HIP event pair around every
-    # launch on the engine's stream (cfg.time_passes; eager launches).  rocprofv3 --kernel-trace --stats of
-    # this command (profiles/) reports the same average.
-    in_run_us = None
-    if args.no_roofline:
-        launches, scan_s, bytes_per_scan = 0, float("nan"), r.bytes_per_scan
-    else:
-        # (a) a train of back-to-back launches of the kernel on the freshly restored snapshot, one HIP event pair
-        #     around the train (no per-dispatch completion signals);
-        # (b) [1 GPU] one more run of the same workload with a stop stamp per dispatch (cfg.time_passes): the eager
-        #     launches and their signals add a few us of idle gap before each dispatch, so (b) is an upper bound.
-        eng.reset_state()
-        launches = 200
-        scan_ns, bytes_per_scan = eng.time_scan(launches, mode=args.mode)
-        scan_s = scan_ns / launches / 1e9
-        if not distributed:
-            pe = capi.Engine(device=local_rank, time_passes=True)
-            pe.load(nodes, pod, prof)
-            prun = pe.run(max_limit=limit, mode=args.mode, want_log=False)
-            in_run_us = prun.pass_kernel_ns / max(1, prun.pass_launches) / 1e3
-            pe.close()
-    achieved = bytes_per_scan / scan_s / 1e9
-    kernel = "k_level_score" if args.mode == "batched" else "k_scan"
-    # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this same command
-    # (tools/gpu_pmc.sh -> profiles/r01/pmc_traffic.json); bench.py cannot profile itself.
-    traffic = None
+    # Roofline.  The dominant kernel of the batched mode is k_level_commit (one launch per pass: reads the 4-byte score
+    # cache of every node, runs the level's nodes down on their commit rows, re-scores them, reduces the next level);
+    # of the sequential mode, k_scan.  Their average launch duration is measured live: one more run of the SAME workload
+    # on a second engine whose passes are launched eagerly with a stop stamp per dispatch on the engine's stream
+    # (cfg.time_passes -> hipExtLaunchKernelGGL events; rocprofv3 --kernel-trace --stats of this command, profiles/,
+    # reports the same average).  `achieved` uses SURVEY 8(d)'s algorithmic bytes: one pass = one evaluation of every
+    # (pod, node) pair = N x B_node, the full-scan definition -- what the pass would have to stream without the score
+    # cache; `traffic` is what it really moves (PMC).  The kernel that DOES stream every node column, the full pass
+    # k_level_score (first pass of a run and whenever the normalization constants move), is timed as a train of
+    # back-to-back launches on the freshly restored snapshot and reported next to it (`full_pass`).
+    kernel = "k_level_commit" if args.mode == "batched" else "k_scan"
+    pmc = {}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-        if hi - lo == 1_000_000:
-            traffic = pmc["kernels"][kernel]["hbm_bytes_per_launch"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["kernels"] if hi - lo == 1_000_000 else {}
     except (OSError, KeyError, ValueError):
         pass
+    roofline = None
+    if not args.no_roofline:
+        eng.reset_state()
+        train = 200
+        scan_ns, bytes_per_scan = eng.time_scan(train, mode=args.mode)
+        full_s = scan_ns / train / 1e9
+        full_kernel = "k_level_score" if args.mode == "batched" else "k_scan"
+        full_pass = {
+            "kernel": full_kernel, "achieved": bytes_per_scan / full_s / 1e9, "frac": bytes_per_scan / full_s / 1e9 / HBM_PEAK_GBPS,
+            "frac_of_measured_read_peak": bytes_per_scan / full_s / 1e9 / READ_PEAK_MEASURED_GBPS,
+            "us_per_launch": full_s * 1e6, "launches_timed": train, "bytes_per_launch": bytes_per_scan,
+            "traffic": pmc.get(full_kernel, {}).get("hbm_bytes_per_launch"),
+        }
+        pe = capi.Engine(device=local_rank, time_passes=True)  # this rank's shard as a stand-alone snapshot
+        pe.load(nodes, pod, prof)
+        prun = pe.run(max_limit=limit, mode=args.mode, want_log=False)
+        pe.close()
+        dom_s = prun.pass_kernel_ns / max(1, prun.pass_launches) / 1e9
+        achieved = bytes_per_scan / dom_s / 1e9
+        roofline = {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": pmc.get(kernel, {}).get("hbm_bytes_per_launch"),
+            "kernel": kernel,
+            "bytes_per_launch": bytes_per_scan,
+            "bytes_definition": "algorithmic, full-scan definition (SURVEY 8(d)): nodes x enabled column bytes per pass; "
+                                "`traffic` = HBM bytes the launch really moves (rocprofv3 PMC, profiles/r01/pmc_traffic.json)",
+            "us_per_launch": dom_s * 1e6,
+            "launches_timed": int(prun.pass_launches),
+            "full_pass": full_pass,
+        }
     out = {
         "metric": "simulated pod placements/sec at 1M nodes",
         "value": placed / dt,
@@ -201,21 +217,10 @@ def main():
             "passes_per_step": scans // max(1, args.steps),
             "sequential_mode_placements_per_s": seq,
             "parallelism": f"node-shard x{world}",
+            "arithmetic": "exact integer results (int64 columns); this snapshot's values fit the engine's lossless 32-bit mirrors, "
+                          "which the scan / level kernels then use",
         },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "frac_of_measured_read_peak": achieved / READ_PEAK_MEASURED_GBPS,
-            "traffic": traffic,
-            "kernel": kernel,
-            "bytes_per_launch": bytes_per_scan,
-            "us_per_launch": scan_s * 1e6,
-            "launches_timed": launches,
-            "us_per_launch_stamped_in_run": in_run_us,
-        },
+        "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu and not distributed:
         nodes_full = nodes if world == 1 else synth.make_config("C4", n_nodes=n_global)[0]

@@ -1079,7 +1079,8 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
 extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
     if (!e || !out) return -EINVAL;
     int rc;
-    if (!e->begun) {
+    if (!e->begun || e->h_state->done != DONE_RUNNING || e->mode != CCSIM_MODE_SEQUENTIAL || e->n_ranks != 0) {
+        // first cycle, or a ccsim_run has finished on this engine: a fresh run state on the current columns
         e->n_ranks = 0;
         if ((rc = begin_run(e, 0, CCSIM_MODE_SEQUENTIAL, 0))) return rc;
     }

@@ -305,3 +305,32 @@ def test_profile_variants_vs_oracle(ccref, mode, prof):
     for limit in (0, 333):
         ref = ccref.run(prof, nodes, pod, max_limit=limit)
         _assert_same(_engine(nodes, pod, prof).run(max_limit=limit, mode=mode), ref, nodes, pod)
+
+
+@pytest.mark.parametrize("narrow", ["0", "1"])
+def test_modes_interleave_on_one_engine(ccref, monkeypatch, narrow):
+    """One engine, one snapshot, runs continued in alternating modes: the batched mode keeps its state in commit rows and a
+    score cache, the sequential mode and ccsim_schedule_one in the columns -- every hand-over must be lossless."""
+    monkeypatch.setenv("CCSIM_NARROW", narrow)
+    nodes, pod, prof = synth.make_config("C3", n_nodes=3000, seed=31)
+    ref = ccref.run(prof, nodes, pod, max_limit=0)
+    e = _engine(nodes, pod, prof)
+    logs = []
+    a = e.run(max_limit=700, mode="batched", log_cap=700)
+    logs.append(a.log)
+    b = e.run(max_limit=300, mode="sequential", log_cap=300)
+    logs.append(b.log)
+    one = [e.schedule_one()[0] for _ in range(50)]
+    logs.append(np.array(one, np.int32))
+    c = e.run(max_limit=2000, mode="batched", log_cap=2000)
+    logs.append(c.log)
+    d = e.run(max_limit=0, mode="batched", log_cap=max(1, ref.placed))
+    logs.append(d.log)
+    got = np.concatenate(logs)
+    assert a.placed == 700 and b.placed == 300 and c.placed == 2000
+    assert len(got) == ref.placed and np.array_equal(got, ref.log)
+    assert d.stop == ref.stop and np.array_equal(d.hist, ref.hist)
+    st = e.read_state()
+    cnt = np.bincount(ref.log, minlength=nodes.n).astype(np.int64)
+    assert np.array_equal(st["req_mcpu"], nodes.req[0] + cnt * int(pod.req[0]))
+    assert np.array_equal(st["pod_count"], nodes.pod_count + cnt)

@@ -18,14 +18,14 @@ def test_streaming_kernels_use_no_scratch_and_do_not_spill():
     rows = KR.collect()
     scans = [k for k in rows if k.startswith(("k_scan<", "k_level_score<", "k_level_commit<"))]
     assert len(scans) >= 30  # every NX / coupled / narrow / sampled variant was instantiated
-    for k in scans + ["k_level_final", "k_level_decide", "k_smp_prefix", "k_hist", "k_static"]:
+    for k in scans + ["k_level_final", "k_level_decide", "k_smp_prefix", "k_hist", "k_static", "k_rows_build", "k_rows_flush"]:
         assert rows[k]["ScratchSize"] == "0", (k, rows[k])
         assert rows[k]["VGPRs Spill"] == "0", (k, rows[k])  # (SGPRs may spill into VGPR lanes: no memory traffic)
     for k in ("k_final", "k_decide"):  # one working copy of DevState, nothing else (not the 1.7 KB argument block)
         assert int(rows[k]["ScratchSize"]) <= 768, (k, rows[k])
         assert rows[k]["VGPRs Spill"] == "0"
     # the throughput kernels keep >= 4 waves per SIMD for the common shapes (no extended resources)
-    for k in ("k_scan<0,0,1,0>", "k_scan<0,0,0,0>", "k_level_score<0,1>", "k_level_score<0,0>", "k_level_commit<0>"):
+    for k in ("k_scan<0,0,1,0>", "k_scan<0,0,0,0>", "k_level_score<0,1>", "k_level_score<0,0>", "k_level_commit<0,1>", "k_level_commit<0,0>"):
         assert int(rows[k]["Occupancy"]) >= 4, (k, rows[k])
 
 

@@ -14,3 +14,6 @@ for set in "$@"; do
   f=$(find /root/repo/gpurun_out/pmc_${tag}_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 /root/repo/tools/pmc_summary.py "$f"; else echo "no counter csv"; tail -3 /root/repo/gpurun_out/pmc_${tag}_$i.err; fi
 done
+f1=$(find /root/repo/gpurun_out/pmc_${tag}_1 -name "*counter_collection.csv" | head -1)
+f2=$(find /root/repo/gpurun_out/pmc_${tag}_2 -name "*counter_collection.csv" | head -1)
+if [ -n "$f1" ] && [ -n "$f2" ]; then python3 /root/repo/tools/pmc_to_json.py "$f1" "$f2" > /root/repo/gpurun_out/pmc_traffic_${tag}.json; fi

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""rocprofv3 PMC passes (one counter_collection.csv per counter set) -> per-kernel HBM bytes per launch (JSON).
+
+    python tools/pmc_to_json.py <fetch.csv> <write.csv> > pmc_traffic.json
+
+hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md
+prescribes for gfx950 (128-byte requests are tallied as 64 B); the factor is calibrated for wide coalesced reads, so the
+figure of kernels dominated by sparse accesses (k_level_commit) is indicative."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def averages(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"ccsim::(k_\w+)", r["Kernel_Name"])
+        if not m:
+            continue
+        a = acc[m.group(1)][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+    return acc
+
+
+def main():
+    fetch, write = averages(sys.argv[1]), averages(sys.argv[2])
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 0])
+        w = write.get(k, {}).get("WRITE_SIZE", [0.0, 0])
+        if not f[1] or not w[1]:
+            continue
+        fk, wk = f[0] / f[1], w[0] / w[1]
+        out[k] = {"launches": f[1], "FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
+                  "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    json.dump({
+        "workload": "bench.py C4 1,000,000 nodes, 1 GPU, batched mode (one timed step)",
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_pmc.sh); hbm_bytes_per_launch = "
+                "(2*FETCH_SIZE + WRITE_SIZE) KB, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); averages over ALL "
+                "launches of the run incl. the no-op launches (passes after the done flag is set, score-only graph heads)",
+        "kernels": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
