@@ -785,11 +785,10 @@ static int launch_level_score(ccsim_engine *e, hipEvent_t t0 = nullptr, hipEvent
     return 0;
 }
 
-static int launch_level_commit(ccsim_engine *e, hipEvent_t t1 = nullptr) {
+static int launch_level_commit(ccsim_engine *e, hipEvent_t t1 = nullptr, hipEvent_t t0 = nullptr) {
     const LevelArgs a = level_args(e);
     const int nx = e->pod.nx;
     dim3 g(e->lvl_grid), b(kThreads);
-    hipEvent_t t0 = nullptr;
     if (nx == 0 && e->cols.narrow) CCSIM_LAUNCH((k_level_commit<0, true>), g, b, e->stream, t0, t1, a);
     else if (nx == 0) CCSIM_LAUNCH(k_level_commit<0>, g, b, e->stream, t0, t1, a);
     else if (nx == 1) CCSIM_LAUNCH(k_level_commit<1>, g, b, e->stream, t0, t1, a);
@@ -932,9 +931,10 @@ static void launch_pass(ccsim_engine *e) { // one scan pass + its one-block redu
             t0 = e->pass_events[e->pass_events_used++];
             t1 = e->pass_events[e->pass_events_used++];
             hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, scratch, 0, 0);
-            hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, t0, 0, 0);
-            if (e->mode == CCSIM_MODE_BATCHED) // the batched mode's dominant kernel is the commit pass
-                launch_level_commit(e, t1), launch_rows_flush(e, true), launch_level_score(e), launch_level_final(e);
+            if (e->mode != CCSIM_MODE_BATCHED) hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, t0, 0, 0);
+            else hipExtLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, e->stream, nullptr, nullptr, 0, 0);
+            if (e->mode == CCSIM_MODE_BATCHED) // the dominant kernel is the commit pass: its own start and stop stamps
+                launch_level_commit(e, t1, t0), launch_rows_flush(e, true), launch_level_score(e), launch_level_final(e);
             else launch_scan(e, nullptr, t1), launch_final(e);
             return;
         }

@@ -14,14 +14,16 @@ import sys
 
 
 def averages(path):
-    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0, 0.0]))
     for r in csv.DictReader(open(path)):
         m = re.search(r"ccsim::(k_\w+)", r["Kernel_Name"])
         if not m:
             continue
         a = acc[m.group(1)][r["Counter_Name"]]
-        a[0] += float(r["Counter_Value"])
+        v = float(r["Counter_Value"])
+        a[0] += v
         a[1] += 1
+        a[2] = max(a[2], v)
     return acc
 
 
@@ -29,18 +31,21 @@ def main():
     fetch, write = averages(sys.argv[1]), averages(sys.argv[2])
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        f = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 0])
-        w = write.get(k, {}).get("WRITE_SIZE", [0.0, 0])
+        f = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 0, 0.0])
+        w = write.get(k, {}).get("WRITE_SIZE", [0.0, 0, 0.0])
         if not f[1] or not w[1]:
             continue
         fk, wk = f[0] / f[1], w[0] / w[1]
         out[k] = {"launches": f[1], "FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
-                  "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+                  "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
+                  "hbm_bytes_largest_launch": int((2 * f[2] + w[2]) * 1024)}
     json.dump({
         "workload": "bench.py C4 1,000,000 nodes, 1 GPU, batched mode (one timed step)",
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_pmc.sh); hbm_bytes_per_launch = "
                 "(2*FETCH_SIZE + WRITE_SIZE) KB, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); averages over ALL "
-                "launches of the run incl. the no-op launches (passes after the done flag is set, score-only graph heads)",
+                "launches of the run incl. the no-op launches (passes after the done flag is set, score-only graph heads); "
+                "hbm_bytes_largest_launch = the same from the per-counter maxima: for kernels that mostly no-op (k_level_score, "
+                "k_rows_flush: ~3 real launches per run) it is the traffic of a real launch",
         "kernels": out}, sys.stdout, indent=1)
 
 
