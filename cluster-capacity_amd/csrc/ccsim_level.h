@@ -13,15 +13,20 @@
 //   * then the next node holding M (in index order) is run down, and so on          -> a "level";
 //   * when no node holds M any more the next level is the new maximum (< M).
 //
-// One k_level pass reads every node column once and
-//   (a) COMMITS the current level: every node holding M runs down independently and rewrites its own
-//       columns (no atomics, no cross-node traffic).  Run-downs are evaluated per lane for the first few
+// One pass = k_level_commit + k_level_final (one block):
+//   (a) k_level_commit COMMITS the current level: every node holding M runs down independently and rewrites its own
+//       state (no atomics, no cross-node traffic).  Run-downs are evaluated per lane for the first few
 //       placements and WAVE-COOPERATIVELY for long ones (wave_run_down below): <= kSeqSteps + 2 dependent
 //       steps for a 110-pod node instead of 110;
-//   (b) evaluates Filter + Score of every node in its post-commit state and reduces the next level
-//       (packed max key), the normalization maxima with their holder counts, and the feasible count.
-// k_level_final (one block) reduces the per-block partials and decides.  A level is committed blindly
-// unless something could end it early; then one extra PLAN pass (same kernel, no commit) measures it:
+//   (b) the same kernel RE-SCORES exactly the nodes it changed and stores the result in the per-node score cache
+//       (cscore, 4 B/node) -- a placement changes one node, every other cached score is still exact -- and reduces the
+//       NEXT level from the cache: packed max key, how many nodes hold it, how many nodes the commit left infeasible
+//       and how many of those held a normalization maximum;
+//   (c) k_level_final reduces the per-block partials, keeps the feasible / holder counts current and decides.
+// The full pods x nodes pass (k_level_score: Filter + Score of every node from its columns, same arithmetic and bytes
+// as k_scan) runs only while the cache is invalid: the first pass of a run, and when a normalization maximum loses its
+// last feasible holder.  A level is committed blindly unless something could end it early; then one extra PLAN pass
+// (k_level_commit, no commit) measures it:
 //   * the level could exhaust the last feasible holder of a normalization maximum (level size >= holder
 //     count): nodes after that holder ("cut") must be re-scored with new constants -> commit up to the cut;
 //   * --max-limit, or the caller wants the placement log: the commit becomes ORDERED (exclusive scan of
@@ -31,8 +36,8 @@
 // (tests/test_level_model.py proves the argument on the CPU against the oracle; tests/test_gpu_parity.py
 // checks this kernel).
 //
-// Roofline: HBM.  A pass reads every enabled column once (same algorithmic bytes as k_scan) and rewrites
-// only the columns of the nodes that took pods.
+// Roofline: the full pass is an HBM stream (60 B/node algorithmic); the commit pass is a latency chain inside one
+// dispatch that moves 4 B/node (the cache) + one 64-byte row per level node.
 #pragma once
 #include "ccsim_kernels.h"
 

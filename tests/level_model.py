@@ -176,3 +176,76 @@ class LevelModel:
                 log += [n] * j
             if limit > 0 and placed >= limit:
                 return dict(placed=placed, stop=1, log=np.array(log, np.int32), per_node_count=per_node, levels=levels)
+
+    # ---- the incremental pass structure (k_level_score only while the cache is invalid; otherwise k_level_commit
+    #      re-scores the nodes it changed and the next level comes from the score cache) ----
+    def run_incremental(self, limit=0):
+        """Mirrors the state machine of level_decide + k_level_commit's cache maintenance: cached TotalScore per node
+        (-1 infeasible) under the constants (mt, ma), running feasible / holder counts, a full pass only when a
+        normalization maximum lost its last feasible holder.  Returns also how many full passes were needed."""
+        placed, log, passes, full_passes = 0, [], 0, 0
+        per_node = np.zeros(self.N, np.int32)
+        cs = [-1] * self.N
+        full, mt, ma, nfeas, c_mt, c_ma = True, 0, 0, 0, 0, 0
+        while True:
+            passes += 1
+            if full:  # k_level_score: every node from its columns
+                full_passes += 1
+                feas = [n for n in range(self.N) if self.feasible(n)]
+                if not feas:
+                    return dict(placed=placed, stop=0, log=np.array(log, np.int32), per_node_count=per_node, levels=passes,
+                                full_passes=full_passes)
+                t_mt, t_ma = max(self.cnt[n] for n in feas), max(self.aff[n] for n in feas)
+                if (t_mt, t_ma) != (mt, ma):  # scores would use stale constants: adopt them, rescan
+                    mt, ma = t_mt, t_ma
+                    continue
+                cs = [self.stat(n, mt, ma) + self.dyn(n) if self.feasible(n) else -1 for n in range(self.N)]
+                nfeas = len(feas)
+                c_mt = sum(1 for n in feas if self.cnt[n] == mt)
+                c_ma = sum(1 for n in feas if self.aff[n] == ma)
+                full = False
+            M = max(cs)
+            if M < 0:
+                return dict(placed=placed, stop=0, log=np.array(log, np.int32), per_node_count=per_node, levels=passes,
+                            full_passes=full_passes)
+            level = [n for n in range(self.N) if cs[n] == M]
+            # plan (when the level could exhaust every holder of a maximum): where is the cut?
+            cut = 1 << 62
+            if (mt > 0 and len(level) >= c_mt) or (ma > 0 and len(level) >= c_ma) or limit > 0:
+                e_mt = e_ma = 0
+                cut_mt = cut_ma = -1
+                for n in level:
+                    j, f = self.run_down(n, self.stat(n, mt, ma), M, 1 << 30)
+                    for _ in range(j):
+                        self.apply(n, -1)
+                    if not f:
+                        if mt > 0 and self.cnt[n] == mt:
+                            e_mt, cut_mt = e_mt + 1, max(cut_mt, n)
+                        if ma > 0 and self.aff[n] == ma:
+                            e_ma, cut_ma = e_ma + 1, max(cut_ma, n)
+                if mt > 0 and e_mt == c_mt:
+                    cut = min(cut, cut_mt)
+                if ma > 0 and e_ma == c_ma:
+                    cut = min(cut, cut_ma)
+            # commit pass: run the level down, re-score exactly its nodes, count what became infeasible
+            for n in level:
+                if n > cut:
+                    break
+                allowed = (limit - placed) if limit > 0 else (1 << 30)
+                if allowed <= 0:
+                    break
+                j, _ = self.run_down(n, self.stat(n, mt, ma), M, allowed)
+                placed += j
+                per_node[n] += j
+                log += [n] * j
+                f = self.feasible(n)
+                cs[n] = self.stat(n, mt, ma) + self.dyn(n) if f else -1
+                if not f:
+                    nfeas -= 1
+                    c_mt -= self.cnt[n] == mt
+                    c_ma -= self.aff[n] == ma
+            if limit > 0 and placed >= limit:
+                return dict(placed=placed, stop=1, log=np.array(log, np.int32), per_node_count=per_node, levels=passes,
+                            full_passes=full_passes)
+            if nfeas > 0 and ((mt > 0 and c_mt == 0) or (ma > 0 and c_ma == 0)):
+                full = True  # every cached score used a maximum that no feasible node holds any more

@@ -36,3 +36,29 @@ def test_level_model_known_answers(ccref):
     _check(ccref, H.test_prediction_nodes(), H.test_prediction_pod(), M.Profile.default(), 0)
     _check(ccref, H.test_prediction_nodes(), H.test_prediction_pod(), M.Profile.default(), 6)
     _check(ccref, H.readme_nodes(4), H.examples_pod(), M.Profile.default(), 0)
+
+
+def _check_incremental(ccref, nodes, pod, prof, limit):
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    got = LevelModel(prof, nodes, pod).run_incremental(limit)
+    assert got["placed"] == ref.placed and got["stop"] == ref.stop
+    assert np.array_equal(got["per_node_count"], ref.per_node_count)
+    assert np.array_equal(got["log"], ref.log)
+    return got
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_incremental_score_cache_random_plugin_mix(ccref, seed):
+    """The score cache argument: after a level is committed only its own nodes have new scores, the feasible and holder
+    counts can be kept by subtraction, and a full pass is needed only when a maximum loses its last feasible holder."""
+    rng = np.random.default_rng(seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 400)))
+    got = _check_incremental(ccref, nodes, pod, prof, int(rng.choice([0, 0, 37, 500])))
+    assert got["full_passes"] <= 2 + 2 * 6  # first pass (+ its rescan), then at most one pair per distinct maximum
+
+
+@pytest.mark.parametrize("cfg,n,limit", [("C2", 300, 0), ("C3", 300, 0), ("C3", 513, 700), ("C3", 1, 0)])
+def test_incremental_score_cache_synthetic(ccref, cfg, n, limit):
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=1234 + n)
+    got = _check_incremental(ccref, nodes, pod, prof, limit)
+    assert got["full_passes"] < got["levels"] or got["levels"] <= 2
