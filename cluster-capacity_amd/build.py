@@ -38,5 +38,29 @@ def build_all(force: bool = False, verbose: bool = False) -> str:
     return out
 
 
+HOST = os.path.join(HERE, "host")
+HOST_SOURCES = ["main.cpp"]
+HOST_DEPS = ["value.hpp", "quantity.hpp", "snapshot.hpp", "report.hpp"]
+
+
+def host_path() -> str:
+    return os.path.join(HERE, "bin", "cluster-capacity-native")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The native (C++) host above the C ABI: ingest, CLI, report.  Loads libccsim.so at run time (dlopen)."""
+    out = host_path()
+    deps = [os.path.join(HOST, f) for f in HOST_SOURCES + HOST_DEPS] + [os.path.join(ROOT, "include", "ccsim.h")]
+    if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", out] + \
+              [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build_all(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

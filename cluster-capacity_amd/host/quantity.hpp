@@ -1,0 +1,118 @@
+// quantity.hpp -- resource.Quantity -> integers, exactly.
+//   Quantity.Value()       rounds up to an integer            (vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go:813-820)
+//   Quantity.MilliValue()  rounds up to an integer of 1/1000  (quantity.go:822-834)
+// Grammar (quantity.go:52-80): <signedNumber><suffix>, suffix = binarySI (Ki Mi Gi Ti Pi Ei) | decimalSI (n u m "" k M G T P E)
+// | decimalExponent (e<N> | E<N>).  Evaluated with 128-bit integers: mantissa * 10^e * 2^b, ceiling division for e < 0.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+namespace cchost {
+
+struct Quantity {
+    __int128 mant = 0; // signed decimal digits without the point
+    int exp10 = 0;     // value = mant * 10^exp10 * 2^exp2
+    int exp2 = 0;
+};
+
+inline Quantity parse_quantity(const std::string &text) {
+    size_t b = 0, e = text.size();
+    while (b < e && (text[b] == ' ' || text[b] == '\t')) b++;
+    while (e > b && (text[e - 1] == ' ' || text[e - 1] == '\t')) e--;
+    const std::string s = text.substr(b, e - b);
+    auto bad = [&]() -> std::runtime_error { return std::runtime_error("bad quantity '" + text + "'"); };
+    size_t i = 0;
+    bool neg = false;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) neg = s[i] == '-', i++;
+    Quantity q;
+    int digits = 0, frac = 0;
+    bool dot = false;
+    for (; i < s.size(); i++) {
+        const char c = s[i];
+        if (c >= '0' && c <= '9') {
+            if (q.mant > ((__int128)1 << 100)) throw bad();
+            q.mant = q.mant * 10 + (c - '0');
+            digits++;
+            if (dot) frac++;
+        } else if (c == '.' && !dot)
+            dot = true;
+        else
+            break;
+    }
+    if (digits == 0) throw bad();
+    q.exp10 = -frac;
+    const std::string suf = s.substr(i);
+    if (!suf.empty() && (suf[0] == 'e' || suf[0] == 'E')) {
+        size_t j = 1;
+        bool eneg = false;
+        if (j < suf.size() && (suf[j] == '+' || suf[j] == '-')) eneg = suf[j] == '-', j++;
+        if (j >= suf.size()) {
+            if (suf == "E") q.exp10 += 18; // the decimalSI suffix E (exa)
+            else throw bad();
+        } else {
+            int ex = 0;
+            for (; j < suf.size(); j++) {
+                if (suf[j] < '0' || suf[j] > '9' || ex > 1000) throw bad();
+                ex = ex * 10 + (suf[j] - '0');
+            }
+            q.exp10 += eneg ? -ex : ex;
+        }
+    } else if (suf == "Ki") q.exp2 = 10;
+    else if (suf == "Mi") q.exp2 = 20;
+    else if (suf == "Gi") q.exp2 = 30;
+    else if (suf == "Ti") q.exp2 = 40;
+    else if (suf == "Pi") q.exp2 = 50;
+    else if (suf == "Ei") q.exp2 = 60;
+    else if (suf == "n") q.exp10 -= 9;
+    else if (suf == "u") q.exp10 -= 6;
+    else if (suf == "m") q.exp10 -= 3;
+    else if (suf.empty()) ;
+    else if (suf == "k") q.exp10 += 3;
+    else if (suf == "M") q.exp10 += 6;
+    else if (suf == "G") q.exp10 += 9;
+    else if (suf == "T") q.exp10 += 12;
+    else if (suf == "P") q.exp10 += 15;
+    else throw bad();
+    if (neg) q.mant = -q.mant;
+    return q;
+}
+
+// ceil(q * 10^scale10), saturating at the int64 range
+inline int64_t quantity_ceil(const Quantity &q, int scale10) {
+    __int128 v = q.mant;
+    int e = q.exp10 + scale10;
+    const __int128 lim = (__int128)INT64_MAX;
+    for (int k = 0; k < q.exp2; k++) {
+        v *= 2;
+        if (v > lim * 1024 || v < -lim * 1024) return v > 0 ? INT64_MAX : INT64_MIN;
+    }
+    while (e > 0) {
+        v *= 10, e--;
+        if (v > lim * 1024 || v < -lim * 1024) return v > 0 ? INT64_MAX : INT64_MIN;
+    }
+    if (e < 0) {
+        __int128 d = 1;
+        bool huge = false;
+        for (int k = 0; k < -e; k++) {
+            d *= 10;
+            if (d > ((__int128)1 << 110)) {
+                huge = true;
+                break;
+            }
+        }
+        if (huge) v = v > 0 ? 1 : 0; // 0 < |x| < 1: ceil is 1 for positive, 0 for negative values
+        else {
+            const __int128 qd = v / d, r = v % d; // truncation toward zero
+            v = qd + ((r > 0) ? 1 : 0);
+        }
+    }
+    if (v > lim) return INT64_MAX;
+    if (v < -lim) return INT64_MIN;
+    return (int64_t)v;
+}
+
+inline int64_t quantity_value(const std::string &text) { return quantity_ceil(parse_quantity(text), 0); }
+inline int64_t quantity_milli_value(const std::string &text) { return quantity_ceil(parse_quantity(text), 3); }
+
+} // namespace cchost

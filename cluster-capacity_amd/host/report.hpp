@@ -1,0 +1,227 @@
+// report.hpp -- the strings the reference produces around the path, from the integer results of the C ABI.
+//   FitError.Error                    vendor/k8s.io/kubernetes/pkg/scheduler/framework/types.go:787-836
+//   DefaultPreemption PostFilter msg  .../plugins/defaultpreemption/default_preemption.go:131-141,257
+//                                     .../framework/preemption/preemption.go:266-279
+//   StopReason / getMainFailReason    pkg/framework/simulator.go:297-342, pkg/framework/report.go:100-109
+//   parsePodsReview / GetReport       pkg/framework/report.go:111-225
+//   clusterCapacityReviewPrettyPrint  pkg/framework/report.go:235-283
+#pragma once
+#include <algorithm>
+#include <ctime>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ccsim.h"
+#include "quantity.hpp"
+#include "snapshot.hpp"
+#include "value.hpp"
+
+namespace cchost {
+
+struct RunResult { // what ccsim_run hands back (host copies)
+    int64_t placed = 0;
+    int32_t stop = CCSIM_STOP_UNSCHEDULABLE;
+    std::vector<int32_t> per_node_count, log;
+    std::vector<int64_t> hist, hist_taintset;
+    int64_t n_code_unschedulable = 0;
+};
+
+inline std::string histogram_message(const std::map<std::string, int64_t> &reasons) {
+    // types.go:820-829: "<count> <reason>" strings sorted lexicographically, joined by ", "
+    std::vector<std::string> items;
+    for (const auto &kv : reasons)
+        if (kv.second) items.push_back(std::to_string(kv.second) + " " + kv.first);
+    std::sort(items.begin(), items.end());
+    std::string out;
+    for (size_t i = 0; i < items.size(); i++) out += (i ? ", " : "") + items[i];
+    return out;
+}
+
+inline const char *reason_text(int slot) {
+    switch (slot) {
+    case CCSIM_R_UNSCHEDULABLE: return "node(s) were unschedulable";
+    case CCSIM_R_NODENAME: return "node(s) didn't match the requested node name";
+    case CCSIM_R_NODEAFFINITY: return "node(s) didn't match Pod's node affinity/selector";
+    case CCSIM_R_TOO_MANY_PODS: return "Too many pods";
+    case CCSIM_R_PTS_MISSING_LABEL: return "node(s) didn't match pod topology spread constraints (missing required label)";
+    case CCSIM_R_PTS_SKEW: return "node(s) didn't match pod topology spread constraints";
+    case CCSIM_R_IPA_AFFINITY: return "node(s) didn't match pod affinity rules"; // interpodaffinity/filtering.go:37-45
+    case CCSIM_R_IPA_ANTI: return "node(s) didn't match pod anti-affinity rules";
+    case CCSIM_R_IPA_EXISTING_ANTI: return "node(s) didn't satisfy existing pods anti-affinity rules";
+    }
+    return nullptr;
+}
+
+// FitError.Error() for the terminal cycle, including the DefaultPreemption suffix
+inline std::string fit_error_message(int64_t n_nodes, const RunResult &r, const std::vector<std::string> &taint_reasons,
+                                     const std::vector<std::string> &scalar_names) {
+    static const char *res_names[3] = {"cpu", "memory", "ephemeral-storage"};
+    std::map<std::string, int64_t> reasons;
+    for (int slot = 0; slot < (int)r.hist.size(); slot++) {
+        if (!r.hist[(size_t)slot]) continue;
+        std::string text;
+        if (const char *t = reason_text(slot)) text = t;
+        else if (slot >= CCSIM_R_RES0 && slot < CCSIM_R_RES0 + CCSIM_MAX_RES) {
+            const int c = slot - CCSIM_R_RES0;
+            text = std::string("Insufficient ") + (c < 3 ? res_names[c] : (c - 3 < (int)scalar_names.size() ? scalar_names[(size_t)c - 3] : "scalar-" + std::to_string(c - 3)));
+        } else
+            text = "reason-" + std::to_string(slot);
+        reasons[text] += r.hist[(size_t)slot];
+    }
+    for (size_t ts = 0; ts < r.hist_taintset.size(); ts++)
+        if (r.hist_taintset[ts]) // taint_toleration.go:119: the first untolerated taint of the set
+            reasons[ts < taint_reasons.size() ? taint_reasons[ts] : "node(s) had untolerated taint {taintset-" + std::to_string(ts) + "}"] += r.hist_taintset[ts];
+    std::string msg = "0/" + std::to_string(n_nodes) + " nodes are available:";
+    const std::string body = histogram_message(reasons);
+    if (!body.empty()) msg += " " + body + ".";
+    // Nodes that failed with plain Unschedulable are dry-run candidates; the simulated pod has priority 0 like everything
+    // else, so each reports "No preemption victims found"; the rest are absent from the map.
+    std::map<std::string, int64_t> pre;
+    if (r.n_code_unschedulable) pre["No preemption victims found for incoming pod"] = r.n_code_unschedulable;
+    if (n_nodes - r.n_code_unschedulable > 0) pre["Preemption is not helpful for scheduling"] = n_nodes - r.n_code_unschedulable;
+    std::string pmsg = "0/" + std::to_string(n_nodes) + " nodes are available:";
+    const std::string pbody = histogram_message(pre);
+    if (!pbody.empty()) pmsg += " " + pbody + ".";
+    return msg + " preemption: " + pmsg;
+}
+
+// ClusterCapacity.Status.StopReason (simulator.go:301,331)
+inline std::string stop_reason(const RunResult &r, int64_t n_nodes, int64_t max_limit, const std::vector<std::string> &taint_reasons,
+                               const std::vector<std::string> &scalar_names) {
+    if (r.stop == CCSIM_STOP_LIMIT) return "LimitReached: Maximum number of pods simulated: " + std::to_string(max_limit);
+    if (r.stop == CCSIM_STOP_NO_NODES) return "Unschedulable: no nodes available to schedule pods";
+    return "Unschedulable: " + fit_error_message(n_nodes, r, taint_reasons, scalar_names);
+}
+
+// report.go:100-109 getMainFailReason
+inline Value main_fail_reason(const std::string &message) {
+    const std::string first = message.substr(0, message.find('\n'));
+    const size_t colon = first.find(':');
+    std::string rest = colon == std::string::npos ? "" : first.substr(colon + 1);
+    while (!rest.empty() && rest.front() == ' ') rest.erase(rest.begin());
+    while (!rest.empty() && rest.back() == ' ') rest.pop_back();
+    Value o = Value::object();
+    o.set("failType", Value::str(first.substr(0, colon))), o.set("failMessage", Value::str(rest));
+    return o;
+}
+
+// report.go:146-180: per-node replica counts, in first-placement order when the log is available
+inline Value replicas_on_nodes(const RunResult &r, const std::vector<std::string> &names) {
+    std::vector<size_t> order;
+    if (!r.log.empty()) {
+        std::vector<char> seen(r.per_node_count.size(), 0);
+        for (const int32_t g : r.log)
+            if (g >= 0 && (size_t)g < seen.size() && !seen[(size_t)g]) seen[(size_t)g] = 1, order.push_back((size_t)g);
+    } else
+        for (size_t i = 0; i < r.per_node_count.size(); i++)
+            if (r.per_node_count[i]) order.push_back(i);
+    Value a = Value::array();
+    for (const size_t i : order) {
+        Value o = Value::object();
+        o.set("nodeName", Value::str(i < names.size() ? names[i] : std::to_string(i))), o.set("replicas", Value::num(r.per_node_count[i]));
+        a.a.push_back(o);
+    }
+    return a;
+}
+
+inline std::string fmt_quantity_milli(int64_t milli) { return milli % 1000 == 0 ? std::to_string(milli / 1000) : std::to_string(milli) + "m"; }
+inline std::string fmt_quantity_binary(int64_t v) {
+    static const std::pair<const char *, int> suf[] = {{"Ei", 60}, {"Pi", 50}, {"Ti", 40}, {"Gi", 30}, {"Mi", 20}, {"Ki", 10}};
+    for (const auto &s : suf)
+        if (v && v % ((int64_t)1 << s.second) == 0) return std::to_string(v >> s.second) + s.first;
+    return std::to_string(v);
+}
+
+// report.go:111-144 getResourceRequest (containers only) + :182-194
+inline Value pod_requirements(const Value &pod) {
+    int64_t cpu = 0, mem = 0;
+    Value scalars = Value::object();
+    for (const auto &c : pod["spec"]["containers"].items())
+        for (const auto &kv : c["resources"]["requests"].fields()) {
+            if (kv.first == "cpu") cpu += quantity_milli_value(kv.second.text());
+            else if (kv.first == "memory") mem += quantity_value(kv.second.text());
+            else if (is_scalar_resource(kv.first)) scalars.set(kv.first, Value::num(scalars[kv.first].as_int() + quantity_value(kv.second.text())));
+        }
+    Value prim = Value::object();
+    prim.set("cpu", Value::str(fmt_quantity_milli(cpu))), prim.set("memory", Value::str(fmt_quantity_binary(mem))), prim.set("nvidia.com/gpu", Value::str("0"));
+    Value res = Value::object();
+    res.set("primaryResources", prim), res.set("scalarResources", scalars.o.empty() ? Value() : scalars);
+    Value o = Value::object();
+    o.set("podName", Value::str(pod["metadata"]["name"].text())), o.set("resources", res), o.set("nodeSelectors", pod["spec"]["nodeSelector"]);
+    return o;
+}
+
+inline std::string utc_now_iso() {
+    const std::time_t t = std::time(nullptr);
+    std::tm tm{};
+    gmtime_r(&t, &tm);
+    char buf[40];
+    std::strftime(buf, sizeof buf, "%Y-%m-%dT%H:%M:%S+00:00", &tm);
+    return buf;
+}
+
+// report.go:196-225 GetReport
+inline Value build_review(const Value &pod, const Snapshot &snap, const RunResult &r, int64_t max_limit) {
+    const std::string stop = stop_reason(r, (int64_t)snap.n(), max_limit, snap.taint_reasons, snap.scalar_names);
+    Value spec = Value::object();
+    Value templates = Value::array(), reqs = Value::array();
+    templates.a.push_back(pod), reqs.a.push_back(pod_requirements(pod));
+    spec.set("templates", templates), spec.set("replicas", Value::num(0)), spec.set("podRequirements", reqs);
+    Value p = Value::object();
+    p.set("podName", Value::str(pod["metadata"]["name"].text())), p.set("replicasOnNodes", replicas_on_nodes(r, snap.names)), p.set("failSummary", Value());
+    Value pods = Value::array();
+    pods.a.push_back(p);
+    Value status = Value::object();
+    status.set("creationTimestamp", Value::str(utc_now_iso())), status.set("replicas", Value::num(r.placed));
+    status.set("failReason", main_fail_reason(stop)), status.set("pods", pods);
+    Value review = Value::object();
+    review.set("spec", spec), review.set("status", status);
+    return review;
+}
+
+// report.go:235-283 clusterCapacityReviewPrettyPrint
+inline std::string pretty(const Value &review, bool verbose) {
+    std::string out;
+    auto line = [&](const std::string &s) { out += s + "\n"; };
+    if (verbose)
+        for (const auto &req : review["spec"]["podRequirements"].items()) {
+            line(req["podName"].text() + " pod requirements:");
+            line("\t- CPU: " + req["resources"]["primaryResources"]["cpu"].text());
+            line("\t- Memory: " + req["resources"]["primaryResources"]["memory"].text());
+            if (!req["resources"]["scalarResources"].is_null()) { // python prints the dict: {'name': value, ...}
+                std::string d = "{";
+                bool first = true;
+                for (const auto &kv : req["resources"]["scalarResources"].fields()) d += std::string(first ? "" : ", ") + "'" + kv.first + "': " + kv.second.text(), first = false;
+                line("\t- ScalarResources: " + d + "}");
+            }
+            if (!req["nodeSelectors"].is_null()) {
+                std::vector<std::pair<std::string, std::string>> kv;
+                for (const auto &f : req["nodeSelectors"].fields()) kv.emplace_back(f.first, f.second.text());
+                std::sort(kv.begin(), kv.end());
+                std::string s;
+                for (size_t i = 0; i < kv.size(); i++) s += (i ? "," : "") + kv[i].first + "=" + kv[i].second;
+                line("\t- NodeSelector: " + s);
+            }
+            line("");
+        }
+    for (const auto &p : review["status"]["pods"].items()) {
+        long long total = 0;
+        for (const auto &r : p["replicasOnNodes"].items()) total += r["replicas"].as_int();
+        line(verbose ? "The cluster can schedule " + std::to_string(total) + " instance(s) of the pod " + p["podName"].text() + "." : std::to_string(total));
+    }
+    if (verbose) {
+        const Value &fr = review["status"]["failReason"];
+        line("\nTermination reason: " + fr["failType"].text() + ": " + fr["failMessage"].text());
+        if (review["status"]["replicas"].as_int() > 0) {
+            line("\nPod distribution among nodes:");
+            for (const auto &p : review["status"]["pods"].items()) {
+                line(p["podName"].text());
+                for (const auto &r : p["replicasOnNodes"].items()) line("\t- " + r["nodeName"].text() + ": " + r["replicas"].text() + " instance(s)");
+            }
+        }
+    }
+    return out;
+}
+
+} // namespace cchost

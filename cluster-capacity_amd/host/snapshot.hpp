@@ -1,0 +1,635 @@
+// snapshot.hpp -- SyncWithClient (pkg/framework/simulator.go:176-295) and every per-pod-spec precomputation the scheduler
+// plugins do with strings, turned into the integer world of include/ccsim.h.  Nothing here is on the hot path.
+//
+// Reference (S/ = vendor/k8s.io/kubernetes/pkg/scheduler):
+//   which objects are copied          pkg/framework/simulator.go:176-295 (non-terminal pods, nodes minus --exclude-nodes)
+//   pod requests                      vendor/k8s.io/component-helpers/resource/helpers.go:144-251 (sum containers, max init, + overhead)
+//   NonZero requests                  S/framework/types.go:1095-1124 (100m / 200Mi per container without the request)
+//   NodeInfo.AddPod                   S/framework/types.go:345-350,409-428
+//   node order                        S/backend/cache/node_tree.go:119-143, component-helpers/node/topology/helpers.go:31-58
+//   taints / tolerations              component-helpers/scheduling/corev1/helpers.go:63-101, api/core/v1/toleration.go:38-57
+//   node selector requirements        apimachinery/pkg/labels/selector.go:246-293, component-helpers/.../nodeaffinity.go
+//   label selectors                   apimachinery/pkg/apis/meta/v1/helpers.go:36-75
+//   spread constraints                S/framework/plugins/podtopologyspread/common.go:42-159
+//   inter-pod affinity terms          vendor/k8s.io/kube-scheduler/framework/types.go:379-384, S/framework/types.go:927-935
+#pragma once
+#include <algorithm>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/ccsim.h"
+#include "quantity.hpp"
+#include "value.hpp"
+
+namespace cchost {
+
+constexpr int64_t kDefaultMilliCPU = 100; // S/util/pod_resources.go:28-31
+constexpr int64_t kDefaultMemory = 200ll * 1024 * 1024;
+static const char *const kHostname = "kubernetes.io/hostname";
+static const char *const kUnschedTaint = "node.kubernetes.io/unschedulable";
+
+struct Unsupported : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+inline int64_t res_of(const Value &rl, const std::string &name) { // a ResourceList entry, 0 when absent
+    if (!rl.truthy() || !rl.has(name)) return 0;
+    const std::string q = rl[name].text();
+    return name == "cpu" ? quantity_milli_value(q) : quantity_value(q);
+}
+
+// S/util/utils.go:140-143: extended / hugepages / prefixed native / attachable-volumes resources
+inline bool is_scalar_resource(const std::string &name) { return !(name == "cpu" || name == "memory" || name == "ephemeral-storage" || name == "pods"); }
+
+struct PodRequests {
+    std::vector<int64_t> req; // per resource name
+    int64_t nz_cpu = 0, nz_mem = 0;
+};
+
+// helpers.go:144-251 PodRequests + types.go:1095-1124 (restartable init containers are not modelled)
+inline PodRequests pod_requests(const Value &spec, const std::vector<std::string> &names) {
+    PodRequests out;
+    auto creq = [](const Value &c, const std::string &n) { return res_of(c["resources"]["requests"], n); };
+    for (const auto &n : names) {
+        int64_t total = 0;
+        for (const auto &c : spec["containers"].items()) total += creq(c, n);
+        for (const auto &ic : spec["initContainers"].items()) total = std::max(total, creq(ic, n));
+        total += res_of(spec["overhead"], n);
+        out.req.push_back(total);
+    }
+    auto nz = [&](const std::string &n, int64_t dflt) {
+        auto one = [&](const Value &c) {
+            const Value &r = c["resources"]["requests"];
+            return r.truthy() && r.has(n) ? res_of(r, n) : dflt;
+        };
+        int64_t total = 0;
+        for (const auto &c : spec["containers"].items()) total += one(c);
+        for (const auto &ic : spec["initContainers"].items()) total = std::max(total, one(ic));
+        return total + res_of(spec["overhead"], n);
+    };
+    out.nz_cpu = nz("cpu", kDefaultMilliCPU);
+    out.nz_mem = nz("memory", kDefaultMemory);
+    return out;
+}
+
+inline std::string label_or(const Value &labels, const char *a, const char *b) {
+    if (labels.has(a)) return labels[a].text();
+    if (labels.has(b)) return labels[b].text();
+    return "";
+}
+inline std::string zone_key(const Value &labels) { // component-helpers/node/topology/helpers.go:31-58
+    const std::string zone = label_or(labels, "failure-domain.beta.kubernetes.io/zone", "topology.kubernetes.io/zone");
+    const std::string region = label_or(labels, "failure-domain.beta.kubernetes.io/region", "topology.kubernetes.io/region");
+    if (region.empty() && zone.empty()) return "";
+    return region + std::string(":\0:", 3) + zone;
+}
+
+// node_tree.go:119-143: nodes arrive sorted by name (the fake tracker lists lexicographically,
+// client-go/testing/fixture.go:847-855), zones in first-seen order, then round robin across zones
+inline std::vector<const Value *> canonical_node_order(std::vector<const Value *> nodes) {
+    std::stable_sort(nodes.begin(), nodes.end(), [](const Value *a, const Value *b) { return (*a)["metadata"]["name"].text() < (*b)["metadata"]["name"].text(); });
+    std::vector<std::string> order;
+    std::map<std::string, std::vector<const Value *>> zones;
+    for (const Value *n : nodes) {
+        const std::string z = zone_key((*n)["metadata"]["labels"]);
+        if (!zones.count(z)) order.push_back(z);
+        zones[z].push_back(n);
+    }
+    std::vector<const Value *> out;
+    for (size_t i = 0; out.size() < nodes.size(); i++)
+        for (const auto &z : order)
+            if (i < zones[z].size()) out.push_back(zones[z][i]);
+    return out;
+}
+
+// toleration.go:38-57 ToleratesTaint
+inline bool tolerates(const Value &tol, const Value &taint) {
+    if (tol["effect"].truthy() && tol["effect"].text() != taint["effect"].text()) return false;
+    if (tol["key"].truthy() && tol["key"].text() != taint["key"].text()) return false;
+    const std::string op = tol["operator"].truthy() ? tol["operator"].text() : "Equal";
+    if (op == "Exists") return true;
+    if (op == "Equal") return tol["value"].text() == taint["value"].text();
+    return false;
+}
+
+struct TaintVerdict {
+    bool filter_ok;
+    int prefer_cnt;
+    const Value *first; // first untolerated NoSchedule / NoExecute taint
+};
+inline TaintVerdict taint_verdict(const Value &taints, const Value &tolerations) {
+    TaintVerdict v{true, 0, nullptr};
+    auto any_tol = [&](const Value &t, bool prefer_only) {
+        for (const auto &x : tolerations.items()) {
+            if (prefer_only && x["effect"].truthy() && x["effect"].text() != "PreferNoSchedule") continue;
+            if (tolerates(x, t)) return true;
+        }
+        return false;
+    };
+    for (const auto &t : taints.items()) {
+        const std::string e = t["effect"].text();
+        if ((e == "NoSchedule" || e == "NoExecute") && !any_tol(t, false)) {
+            v.first = &t, v.filter_ok = false;
+            break;
+        }
+    }
+    for (const auto &t : taints.items())
+        if (t["effect"].text() == "PreferNoSchedule" && !any_tol(t, true)) v.prefer_cnt++;
+    return v;
+}
+
+// labels.Requirement.Matches (selector.go:246-293)
+inline bool requirement_matches(bool key_present, const std::string &val, const std::string &op, const std::vector<std::string> &values) {
+    auto in = [&] { return std::find(values.begin(), values.end(), val) != values.end(); };
+    if (op == "In") return key_present && in();
+    if (op == "NotIn") return !key_present || !in();
+    if (op == "Exists") return key_present;
+    if (op == "DoesNotExist") return !key_present;
+    if (op == "Gt" || op == "Lt") {
+        if (!key_present || values.size() != 1) return false;
+        auto parse = [](const std::string &s, long long &out) { // strconv.ParseInt(s, 10, 64)
+            if (s.empty()) return false;
+            size_t i = (s[0] == '-' || s[0] == '+') ? 1 : 0;
+            if (i >= s.size()) return false;
+            for (size_t k = i; k < s.size(); k++)
+                if (s[k] < '0' || s[k] > '9') return false;
+            try {
+                out = std::stoll(s);
+            } catch (...) {
+                return false;
+            }
+            return true;
+        };
+        long long a, b;
+        if (!parse(val, a) || !parse(values[0], b)) return false;
+        return op == "Gt" ? a > b : a < b;
+    }
+    return false;
+}
+
+inline std::vector<std::string> string_list(const Value &v) {
+    std::vector<std::string> out;
+    for (const auto &x : v.items()) out.push_back(x.text());
+    return out;
+}
+
+// metav1.LabelSelectorAsSelector: nil -> Nothing, {} -> Everything (helpers.go:36-75)
+inline bool label_selector_matches(const Value &sel, const Value &labels) {
+    if (sel.is_null()) return false;
+    for (const auto &kv : sel["matchLabels"].fields())
+        if (!labels.has(kv.first) || labels[kv.first].text() != kv.second.text()) return false;
+    for (const auto &e : sel["matchExpressions"].items()) {
+        const std::string k = e["key"].text();
+        if (!requirement_matches(labels.has(k), labels[k].text(), e["operator"].text(), string_list(e["values"]))) return false;
+    }
+    return true;
+}
+inline bool selector_empty(const Value &sel) { return !sel.is_null() && !sel["matchLabels"].truthy() && !sel["matchExpressions"].truthy(); }
+
+struct Requirement {
+    int col;
+    std::vector<uint8_t> table; // matches iff table[value id of the node's label] != 0
+};
+using Term = std::vector<Requirement>;
+
+// label key -> column; label value -> id (0 = key absent).  Columns are created on demand.
+struct Interner {
+    const std::vector<const Value *> &nodes;
+    std::vector<std::string> keys;
+    std::vector<std::vector<std::string>> values; // per column: value strings, index = id - 1
+    std::vector<std::vector<int32_t>> arrays;
+    explicit Interner(const std::vector<const Value *> &n) : nodes(n) {}
+    int col(const std::string &key) {
+        for (size_t c = 0; c < keys.size(); c++)
+            if (keys[c] == key) return (int)c;
+        std::vector<std::string> vals;
+        std::map<std::string, int> ids;
+        std::vector<int32_t> arr(nodes.size(), 0);
+        for (size_t i = 0; i < nodes.size(); i++) {
+            const Value &md = (*nodes[i])["metadata"];
+            std::string v;
+            bool present;
+            if (key == "metadata.name") present = true, v = md["name"].text();
+            else present = md["labels"].has(key), v = md["labels"][key].text();
+            if (!present) continue;
+            auto it = ids.find(v);
+            if (it == ids.end()) {
+                vals.push_back(v);
+                it = ids.emplace(v, (int)vals.size()).first;
+            }
+            arr[i] = it->second;
+        }
+        keys.push_back(key), values.push_back(vals), arrays.push_back(arr);
+        return (int)keys.size() - 1;
+    }
+    Requirement table(const std::string &key, const std::string &op, const std::vector<std::string> &vals) {
+        const int c = col(key);
+        Requirement r{c, std::vector<uint8_t>(values[(size_t)c].size() + 1, 0)};
+        r.table[0] = requirement_matches(false, "", op, vals);
+        for (size_t i = 0; i < values[(size_t)c].size(); i++) r.table[i + 1] = requirement_matches(true, values[(size_t)c][i], op, vals);
+        return r;
+    }
+};
+
+inline Term node_selector_term(Interner &it, const Value &term) {
+    Term reqs;
+    for (const auto &e : term["matchExpressions"].items()) reqs.push_back(it.table(e["key"].text(), e["operator"].text(), string_list(e["values"])));
+    for (const auto &f : term["matchFields"].items()) // only metadata.name with In / NotIn (nodeaffinity.go:260-293)
+        reqs.push_back(it.table("metadata.name", f["operator"].text(), string_list(f["values"])));
+    return reqs;
+}
+
+struct Spread {
+    int col, max_skew, min_domains, n_domains;
+    bool hard, self_match, is_hostname;
+    std::vector<int32_t> node_match_count; // empty = none
+    bool use_included = false;             // node inclusion policy (nodeAffinityPolicy: Honor) -> Snapshot::included
+};
+
+struct Ipa {
+    std::vector<int> key_cols, key_ndom;
+    std::vector<int> aff_keys;
+    bool self_aff = false;
+    std::vector<int32_t> aff_existing; // empty = none
+    std::vector<int> anti_keys;
+    std::vector<int> anti_self;
+    std::vector<std::vector<int32_t>> anti_existing; // per term, empty = none
+    std::vector<std::vector<int32_t>> exist_anti;    // per key, empty = none
+    std::vector<std::vector<int64_t>> score_existing; // per key, empty = none
+    std::vector<int64_t> score_self;
+    std::vector<int32_t> self_entries;
+    int64_t entries_existing = 0;
+};
+
+struct Snapshot {
+    // nodes (canonical order)
+    std::vector<std::string> names, res_names, scalar_names, taint_reasons;
+    std::vector<std::vector<int64_t>> alloc, req;
+    std::vector<int32_t> alloc_pods, pod_count, taintset_id;
+    std::vector<int64_t> nz_mcpu, nz_mem;
+    std::vector<uint8_t> unschedulable;
+    std::vector<std::string> label_keys;
+    std::vector<std::vector<int32_t>> label_cols;
+    // the simulated pod
+    std::vector<int64_t> preq;
+    int64_t pod_nz_cpu = 0, pod_nz_mem = 0;
+    bool has_scalar_entries = false, tolerates_unschedulable = false, affinity_filter_active = false, has_node_selector = false,
+         has_required_terms = false;
+    std::vector<uint8_t> taint_filter_ok;
+    std::vector<int32_t> taint_prefer_cnt;
+    Term node_selector;
+    std::vector<Term> required;
+    std::vector<std::pair<int, Term>> preferred;
+    std::vector<Spread> spread;
+    std::vector<uint8_t> included; // RequiredNodeAffinity.Match per node (spread inclusion policy); empty = all
+    bool has_ipa = false;
+    Ipa ipa;
+    size_t n() const { return names.size(); }
+};
+
+// AffinityTerm.Matches: namespace in the term's set (default: the owner's namespace) and selector matches
+inline bool term_matches_pod(const Value &term, const std::string &owner_ns, const std::string &pod_ns, const Value &pod_labels) {
+    const std::vector<std::string> ns_set = string_list(term["namespaces"]);
+    if (!term["namespaceSelector"].is_null() && ns_set.empty()) {
+        if (!selector_empty(term["namespaceSelector"])) throw Unsupported("namespaceSelector needs Namespace objects");
+    } else if (ns_set.empty()) {
+        if (pod_ns != owner_ns) return false;
+    } else if (std::find(ns_set.begin(), ns_set.end(), pod_ns) == ns_set.end())
+        return false;
+    return label_selector_matches(term["labelSelector"], pod_labels);
+}
+inline std::string ns_of(const Value &obj) { return obj["metadata"]["namespace"].truthy() ? obj["metadata"]["namespace"].text() : "default"; }
+
+inline bool any_nonzero(const std::vector<int32_t> &v) {
+    for (auto x : v)
+        if (x) return true;
+    return false;
+}
+
+inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const Value &sim_pod,
+                               const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1) {
+    Snapshot s;
+    std::vector<const Value *> kept;
+    for (const auto &n : node_objs)
+        if (std::find(exclude_nodes.begin(), exclude_nodes.end(), n["metadata"]["name"].text()) == exclude_nodes.end()) kept.push_back(&n);
+    const std::vector<const Value *> nodes = canonical_node_order(kept);
+    const size_t N = nodes.size();
+    std::map<std::string, size_t> index;
+    for (size_t i = 0; i < N; i++) {
+        s.names.push_back((*nodes[i])["metadata"]["name"].text());
+        index[s.names.back()] = i;
+    }
+    const Value &spec = sim_pod["spec"];
+    const std::string sim_ns = ns_of(sim_pod);
+    const Value &sim_labels = sim_pod["metadata"]["labels"];
+
+    // resources: cpu, memory, ephemeral-storage + every scalar resource the pod names
+    std::set<std::string> req_names;
+    for (const char *list : {"containers", "initContainers"})
+        for (const auto &c : spec[list].items())
+            for (const auto &kv : c["resources"]["requests"].fields()) req_names.insert(kv.first);
+    for (const auto &n : req_names) // std::set iterates sorted
+        if (is_scalar_resource(n) && (int)s.scalar_names.size() < CCSIM_MAX_SCALAR) s.scalar_names.push_back(n);
+    s.res_names = {"cpu", "memory", "ephemeral-storage"};
+    s.res_names.insert(s.res_names.end(), s.scalar_names.begin(), s.scalar_names.end());
+    const size_t R = s.res_names.size();
+    const PodRequests pr = pod_requests(spec, s.res_names);
+    s.preq = pr.req, s.pod_nz_cpu = pr.nz_cpu, s.pod_nz_mem = pr.nz_mem;
+    s.has_scalar_entries = !s.scalar_names.empty();
+
+    s.alloc.assign(R, std::vector<int64_t>(N, 0));
+    s.req.assign(R, std::vector<int64_t>(N, 0));
+    s.alloc_pods.assign(N, 0), s.pod_count.assign(N, 0), s.nz_mcpu.assign(N, 0), s.nz_mem.assign(N, 0);
+    for (size_t i = 0; i < N; i++) {
+        const Value &a = (*nodes[i])["status"]["allocatable"];
+        for (size_t c = 0; c < R; c++) s.alloc[c][i] = res_of(a, s.res_names[c]);
+        s.alloc_pods[i] = a.has("pods") ? (int32_t)quantity_value(a["pods"].text()) : 0;
+    }
+    std::vector<const Value *> live; // non-terminal pods bound to a kept node (simulator.go:193-200)
+    std::vector<size_t> live_node;
+    for (const auto &p : pod_objs) {
+        const std::string phase = p["status"]["phase"].text();
+        const std::string node = p["spec"]["nodeName"].text();
+        if (phase == "Succeeded" || phase == "Failed" || !index.count(node)) continue;
+        const size_t i = index[node];
+        live.push_back(&p), live_node.push_back(i);
+        const PodRequests r = pod_requests(p["spec"], s.res_names);
+        for (size_t c = 0; c < R; c++) s.req[c][i] += r.req[c];
+        s.nz_mcpu[i] += r.nz_cpu, s.nz_mem[i] += r.nz_mem, s.pod_count[i] += 1;
+    }
+
+    // taints -> distinct taint sets
+    const Value &tolerations = spec["tolerations"];
+    std::map<std::string, int> sets;
+    s.taintset_id.assign(N, 0);
+    for (size_t i = 0; i < N; i++) {
+        const Value &taints = (*nodes[i])["spec"]["taints"];
+        std::string key;
+        for (const auto &t : taints.items()) key += t["key"].text() + '\x1f' + t["value"].text() + '\x1f' + t["effect"].text() + '\x1e';
+        auto it = sets.find(key);
+        if (it == sets.end()) {
+            it = sets.emplace(key, (int)sets.size()).first;
+            const TaintVerdict v = taint_verdict(taints, tolerations);
+            s.taint_filter_ok.push_back(v.filter_ok), s.taint_prefer_cnt.push_back(v.prefer_cnt);
+            // taint_toleration.go:119
+            s.taint_reasons.push_back(v.first ? "node(s) had untolerated taint {" + (*v.first)["key"].text() + ": " + (*v.first)["value"].text() + "}" : "");
+        }
+        s.taintset_id[i] = it->second;
+    }
+    s.unschedulable.assign(N, 0);
+    for (size_t i = 0; i < N; i++) s.unschedulable[i] = (*nodes[i])["spec"]["unschedulable"].truthy();
+    {
+        Value unsched = Value::object();
+        unsched.set("key", Value::str(kUnschedTaint)), unsched.set("effect", Value::str("NoSchedule"));
+        for (const auto &t : tolerations.items())
+            if (tolerates(t, unsched)) s.tolerates_unschedulable = true;
+    }
+
+    // node affinity / node selector
+    Interner it(nodes);
+    const Value &aff = spec["affinity"]["nodeAffinity"];
+    const Value &node_selector = spec["nodeSelector"];
+    const Value &req_aff = aff["requiredDuringSchedulingIgnoredDuringExecution"];
+    const Value &required = req_aff.truthy() ? req_aff["nodeSelectorTerms"] : Value::null_value();
+    for (const auto &kv : node_selector.fields()) s.node_selector.push_back(it.table(kv.first, "In", {kv.second.text()}));
+    for (const auto &t : required.items()) s.required.push_back(node_selector_term(it, t));
+    for (const auto &t : aff["preferredDuringSchedulingIgnoredDuringExecution"].items())
+        s.preferred.emplace_back((int)t["weight"].as_int(), node_selector_term(it, t["preference"]));
+    s.has_node_selector = node_selector.truthy();
+    s.has_required_terms = !required.is_null();
+    s.affinity_filter_active = s.has_node_selector || s.has_required_terms;
+
+    auto node_matches_required = [&](size_t i) { // RequiredNodeAffinity.Match, for the spread inclusion policy
+        auto term_ok = [&](const Term &reqs, bool empty) {
+            if (reqs.empty()) return empty;
+            for (const auto &r : reqs)
+                if (!r.table[(size_t)it.arrays[(size_t)r.col][i]]) return false;
+            return true;
+        };
+        if (s.has_node_selector && !term_ok(s.node_selector, true)) return false;
+        if (s.has_required_terms) {
+            bool any = false;
+            for (const auto &t : s.required) any = any || term_ok(t, false);
+            if (!any) return false;
+        }
+        return true;
+    };
+    if (s.affinity_filter_active) {
+        s.included.assign(N, 0);
+        for (size_t i = 0; i < N; i++) s.included[i] = node_matches_required(i);
+    }
+
+    // topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
+    for (const auto &c : spec["topologySpreadConstraints"].items()) {
+        const Value &sel = c["labelSelector"];
+        Spread k{};
+        k.col = it.col(c["topologyKey"].text());
+        std::vector<int32_t> existing(N, 0);
+        for (size_t p = 0; p < live.size(); p++) { // countPodsMatchSelector (common.go:144-159)
+            const Value &pod = *live[p];
+            if (!selector_empty(sel) && ns_of(pod) == sim_ns && !pod["metadata"]["deletionTimestamp"].truthy() && label_selector_matches(sel, pod["metadata"]["labels"]))
+                existing[live_node[p]] += 1;
+        }
+        const std::string aff_policy = c["nodeAffinityPolicy"].truthy() ? c["nodeAffinityPolicy"].text() : "Honor";
+        const std::string taint_policy = c["nodeTaintsPolicy"].truthy() ? c["nodeTaintsPolicy"].text() : "Ignore";
+        if (taint_policy == "Honor") throw Unsupported("nodeTaintsPolicy: Honor");
+        k.max_skew = (int)c["maxSkew"].as_int();
+        k.min_domains = c["minDomains"].truthy() ? (int)c["minDomains"].as_int() : 1;
+        k.hard = (c["whenUnsatisfiable"].truthy() ? c["whenUnsatisfiable"].text() : "DoNotSchedule") == "DoNotSchedule";
+        k.self_match = !selector_empty(sel) && label_selector_matches(sel, sim_labels);
+        k.is_hostname = c["topologyKey"].text() == kHostname;
+        k.n_domains = (int)it.values[(size_t)k.col].size();
+        if (any_nonzero(existing)) k.node_match_count = existing;
+        k.use_included = aff_policy == "Honor" && !s.included.empty();
+        s.spread.push_back(std::move(k));
+    }
+
+    // inter-pod affinity (filtering.go:204-432, scoring.go:81-125)
+    const Value &pa = spec["affinity"]["podAffinity"], &paa = spec["affinity"]["podAntiAffinity"];
+    const Value &r_aff = pa["requiredDuringSchedulingIgnoredDuringExecution"], &r_anti = paa["requiredDuringSchedulingIgnoredDuringExecution"];
+    const Value &p_aff = pa["preferredDuringSchedulingIgnoredDuringExecution"], &p_anti = paa["preferredDuringSchedulingIgnoredDuringExecution"];
+    bool others_have_terms = false;
+    for (const Value *p : live)
+        if ((*p)["spec"]["affinity"]["podAffinity"].truthy() || (*p)["spec"]["affinity"]["podAntiAffinity"].truthy()) others_have_terms = true;
+    if (r_aff.truthy() || r_anti.truthy() || p_aff.truthy() || p_anti.truthy() || others_have_terms) {
+        std::vector<std::string> keys;
+        auto kidx = [&](const std::string &k) {
+            for (size_t i = 0; i < keys.size(); i++)
+                if (keys[i] == k) return (int)i;
+            keys.push_back(k);
+            return (int)keys.size() - 1;
+        };
+        Ipa &ipa = s.ipa;
+        for (const auto &t : r_aff.items()) ipa.aff_keys.push_back(kidx(t["topologyKey"].text()));
+        ipa.self_aff = r_aff.truthy();
+        for (const auto &t : r_aff.items()) ipa.self_aff = ipa.self_aff && term_matches_pod(t, sim_ns, sim_ns, sim_labels);
+        for (const auto &t : r_anti.items()) {
+            ipa.anti_keys.push_back(kidx(t["topologyKey"].text()));
+            ipa.anti_self.push_back(term_matches_pod(t, sim_ns, sim_ns, sim_labels));
+        }
+        std::vector<int32_t> aff_existing(N, 0);
+        std::vector<std::vector<int32_t>> anti_existing(r_anti.items().size(), std::vector<int32_t>(N, 0));
+        std::map<int, std::vector<int32_t>> exist_anti;
+        std::map<int, std::vector<int64_t>> score_existing;
+        int64_t entries = 0;
+        auto add_score = [&](int k, size_t i, int64_t w) {
+            const int col = it.col(keys[(size_t)k]);
+            if (it.arrays[(size_t)col][i]) {
+                auto &v = score_existing[k];
+                if (v.empty()) v.assign(N, 0);
+                v[i] += w;
+                entries++;
+            }
+        };
+        for (size_t pi = 0; pi < live.size(); pi++) {
+            const Value &p = *live[pi];
+            const size_t i = live_node[pi];
+            const std::string p_ns = ns_of(p);
+            const Value &pl = p["metadata"]["labels"];
+            if (r_aff.truthy()) {
+                bool all = true;
+                for (const auto &t : r_aff.items()) all = all && term_matches_pod(t, sim_ns, p_ns, pl);
+                if (all) aff_existing[i] += 1;
+            }
+            for (size_t t = 0; t < r_anti.items().size(); t++)
+                if (term_matches_pod(r_anti.items()[t], sim_ns, p_ns, pl)) anti_existing[t][i] += 1;
+            const Value &e_aff = p["spec"]["affinity"]["podAffinity"], &e_anti = p["spec"]["affinity"]["podAntiAffinity"];
+            for (const auto &t : e_anti["requiredDuringSchedulingIgnoredDuringExecution"].items())
+                if (term_matches_pod(t, p_ns, sim_ns, sim_labels)) {
+                    auto &v = exist_anti[kidx(t["topologyKey"].text())];
+                    if (v.empty()) v.assign(N, 0);
+                    v[i] += 1;
+                }
+            // scoring.go:81-125 processExistingPod
+            for (const auto &wt : p_aff.items())
+                if (term_matches_pod(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
+            for (const auto &wt : p_anti.items())
+                if (term_matches_pod(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
+            if (hard_pod_affinity_weight > 0)
+                for (const auto &t : e_aff["requiredDuringSchedulingIgnoredDuringExecution"].items())
+                    if (term_matches_pod(t, p_ns, sim_ns, sim_labels)) add_score(kidx(t["topologyKey"].text()), i, hard_pod_affinity_weight);
+            for (const auto &wt : e_aff["preferredDuringSchedulingIgnoredDuringExecution"].items())
+                if (term_matches_pod(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
+            for (const auto &wt : e_anti["preferredDuringSchedulingIgnoredDuringExecution"].items())
+                if (term_matches_pod(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
+        }
+        // what ONE clone adds (it is an existing pod of the next cycle, with the incoming pod's own terms): both directions --
+        // the incoming pod's term vs the clone, and the clone's term vs the incoming pod
+        std::map<int, int64_t> score_self;
+        std::map<int, int32_t> self_entries;
+        auto self_term = [&](const Value &wt, int sign) {
+            if (term_matches_pod(wt["podAffinityTerm"], sim_ns, sim_ns, sim_labels)) {
+                const int k = kidx(wt["podAffinityTerm"]["topologyKey"].text());
+                score_self[k] += 2 * sign * wt["weight"].as_int();
+                self_entries[k] += 2;
+            }
+        };
+        for (const auto &wt : p_aff.items()) self_term(wt, 1);
+        for (const auto &wt : p_anti.items()) self_term(wt, -1);
+        if (hard_pod_affinity_weight > 0)
+            for (const auto &t : r_aff.items())
+                if (term_matches_pod(t, sim_ns, sim_ns, sim_labels)) {
+                    const int k = kidx(t["topologyKey"].text());
+                    score_self[k] += hard_pod_affinity_weight;
+                    self_entries[k] += 1;
+                }
+        if ((int)keys.size() > CCSIM_MAX_IPA_KEYS) throw Unsupported("more than " + std::to_string(CCSIM_MAX_IPA_KEYS) + " distinct inter-pod affinity topology keys");
+        if ((int)ipa.aff_keys.size() > CCSIM_MAX_IPA_TERMS || (int)ipa.anti_keys.size() > CCSIM_MAX_IPA_TERMS) throw Unsupported("too many inter-pod affinity terms");
+        for (const auto &k : keys) {
+            ipa.key_cols.push_back(it.col(k));
+            ipa.key_ndom.push_back((int)it.values[(size_t)ipa.key_cols.back()].size());
+        }
+        if (any_nonzero(aff_existing)) ipa.aff_existing = aff_existing;
+        for (auto &a : anti_existing) ipa.anti_existing.push_back(any_nonzero(a) ? a : std::vector<int32_t>());
+        for (int k = 0; k < (int)keys.size(); k++) {
+            ipa.exist_anti.push_back(exist_anti.count(k) ? exist_anti[k] : std::vector<int32_t>());
+            ipa.score_existing.push_back(score_existing.count(k) ? score_existing[k] : std::vector<int64_t>());
+            ipa.score_self.push_back(score_self.count(k) ? score_self[k] : 0);
+            ipa.self_entries.push_back(self_entries.count(k) ? self_entries[k] : 0);
+        }
+        ipa.entries_existing = entries;
+        s.has_ipa = true;
+    }
+    if ((int)s.spread.size() > CCSIM_MAX_TSC) throw Unsupported("too many topology spread constraints");
+    s.label_keys = it.keys;
+    s.label_cols = it.arrays;
+    if ((int)s.label_cols.size() > CCSIM_MAX_LABEL_COLS) throw Unsupported("too many distinct label keys in selectors");
+    return s;
+}
+
+// ---- the dump the CPU tests compare with the Python ingest (tests/test_native_host.py) -------------------------
+template <class T> inline Value int_array(const std::vector<T> &v) {
+    Value a = Value::array();
+    for (auto x : v) a.a.push_back(Value::num((long long)x));
+    return a;
+}
+inline Value term_json(const Term &t) {
+    Value a = Value::array();
+    for (const auto &r : t) {
+        Value o = Value::object();
+        o.set("col", Value::num(r.col)), o.set("table", int_array(r.table));
+        a.a.push_back(o);
+    }
+    return a;
+}
+inline Value snapshot_json(const Snapshot &s) {
+    Value o = Value::object();
+    auto strs = [](const std::vector<std::string> &v) {
+        Value a = Value::array();
+        for (auto &x : v) a.a.push_back(Value::str(x));
+        return a;
+    };
+    o.set("names", strs(s.names)), o.set("res_names", strs(s.res_names)), o.set("scalar_names", strs(s.scalar_names));
+    o.set("taint_reasons", strs(s.taint_reasons));
+    Value alloc = Value::array(), req = Value::array(), cols = Value::array();
+    for (auto &c : s.alloc) alloc.a.push_back(int_array(c));
+    for (auto &c : s.req) req.a.push_back(int_array(c));
+    for (auto &c : s.label_cols) cols.a.push_back(int_array(c));
+    o.set("alloc", alloc), o.set("req", req), o.set("label_cols", cols), o.set("label_keys", strs(s.label_keys));
+    o.set("alloc_pods", int_array(s.alloc_pods)), o.set("pod_count", int_array(s.pod_count)), o.set("taintset_id", int_array(s.taintset_id));
+    o.set("nz_mcpu", int_array(s.nz_mcpu)), o.set("nz_mem", int_array(s.nz_mem)), o.set("unschedulable", int_array(s.unschedulable));
+    Value p = Value::object();
+    p.set("req", int_array(s.preq)), p.set("nz_mcpu", Value::num(s.pod_nz_cpu)), p.set("nz_mem", Value::num(s.pod_nz_mem));
+    p.set("has_scalar_entries", Value::boolean(s.has_scalar_entries)), p.set("taint_filter_ok", int_array(s.taint_filter_ok));
+    p.set("taint_prefer_cnt", int_array(s.taint_prefer_cnt)), p.set("tolerates_unschedulable", Value::boolean(s.tolerates_unschedulable));
+    p.set("affinity_filter_active", Value::boolean(s.affinity_filter_active)), p.set("has_node_selector", Value::boolean(s.has_node_selector));
+    p.set("has_required_terms", Value::boolean(s.has_required_terms)), p.set("node_selector", term_json(s.node_selector));
+    Value rq = Value::array(), pf = Value::array(), sp = Value::array();
+    for (auto &t : s.required) rq.a.push_back(term_json(t));
+    for (auto &t : s.preferred) {
+        Value e = Value::object();
+        e.set("weight", Value::num(t.first)), e.set("term", term_json(t.second));
+        pf.a.push_back(e);
+    }
+    for (auto &k : s.spread) {
+        Value e = Value::object();
+        e.set("col", Value::num(k.col)), e.set("max_skew", Value::num(k.max_skew)), e.set("min_domains", Value::num(k.min_domains));
+        e.set("hard", Value::boolean(k.hard)), e.set("self_match", Value::boolean(k.self_match)), e.set("is_hostname", Value::boolean(k.is_hostname));
+        e.set("n_domains", Value::num(k.n_domains));
+        e.set("node_match_count", k.node_match_count.empty() ? Value() : int_array(k.node_match_count));
+        e.set("node_included", k.use_included ? int_array(s.included) : Value());
+        sp.a.push_back(e);
+    }
+    p.set("required", rq), p.set("preferred", pf), p.set("spread", sp);
+    if (s.has_ipa) {
+        const Ipa &a = s.ipa;
+        Value e = Value::object();
+        e.set("key_cols", int_array(a.key_cols)), e.set("key_ndom", int_array(a.key_ndom)), e.set("aff_keys", int_array(a.aff_keys));
+        e.set("self_aff", Value::boolean(a.self_aff)), e.set("aff_existing", a.aff_existing.empty() ? Value() : int_array(a.aff_existing));
+        e.set("anti_keys", int_array(a.anti_keys)), e.set("anti_self", int_array(a.anti_self));
+        Value ae = Value::array(), ea = Value::array(), se = Value::array();
+        for (auto &v : a.anti_existing) ae.a.push_back(v.empty() ? Value() : int_array(v));
+        for (auto &v : a.exist_anti) ea.a.push_back(v.empty() ? Value() : int_array(v));
+        for (auto &v : a.score_existing) se.a.push_back(v.empty() ? Value() : int_array(v));
+        e.set("anti_existing", ae), e.set("exist_anti", ea), e.set("score_existing", se);
+        e.set("score_self", int_array(a.score_self)), e.set("self_entries", int_array(a.self_entries)), e.set("entries_existing", Value::num(a.entries_existing));
+        p.set("ipa", e);
+    } else
+        p.set("ipa", Value());
+    o.set("pod", p);
+    return o;
+}
+
+} // namespace cchost

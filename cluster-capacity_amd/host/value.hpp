@@ -1,0 +1,715 @@
+// value.hpp -- the object model of the native host: Kubernetes objects as a JSON-like tree, read from JSON or from the
+// YAML subset kubectl emits (block mappings / sequences, flow [] {}, quoted and plain scalars, | and > block scalars,
+// multi-document streams), written as JSON or YAML.  No third-party parser: the image has none for C++.
+// Scalars keep their source text: a Quantity such as 0.5, "500m" or 1e3 is interpreted by quantity.hpp, exactly like
+// resource.ParseQuantity does with the JSON token (vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go).
+#pragma once
+#include <cctype>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace cchost {
+
+struct Value {
+    enum Type { Null, Bool, Num, Str, Arr, Obj } t = Null;
+    bool b = false;
+    std::string s; // Str: the string; Num: its source text
+    std::vector<Value> a;
+    std::vector<std::pair<std::string, Value>> o; // insertion order kept (label / selector order matters downstream)
+
+    static const Value &null_value() {
+        static const Value v;
+        return v;
+    }
+    static Value str(std::string x) {
+        Value v;
+        v.t = Str, v.s = std::move(x);
+        return v;
+    }
+    static Value num(long long x) {
+        Value v;
+        v.t = Num, v.s = std::to_string(x);
+        return v;
+    }
+    static Value boolean(bool x) {
+        Value v;
+        v.t = Bool, v.b = x;
+        return v;
+    }
+    static Value array() {
+        Value v;
+        v.t = Arr;
+        return v;
+    }
+    static Value object() {
+        Value v;
+        v.t = Obj;
+        return v;
+    }
+    bool is_null() const { return t == Null; }
+    bool has(const std::string &k) const {
+        if (t != Obj) return false;
+        for (auto &kv : o)
+            if (kv.first == k) return true;
+        return false;
+    }
+    // python's d.get(k): Null when absent (or when this is not a mapping)
+    const Value &operator[](const std::string &k) const {
+        if (t == Obj)
+            for (auto &kv : o)
+                if (kv.first == k) return kv.second;
+        return null_value();
+    }
+    Value &set(const std::string &k, Value v) {
+        if (t != Obj) t = Obj, o.clear();
+        for (auto &kv : o)
+            if (kv.first == k) return kv.second = std::move(v);
+        o.emplace_back(k, std::move(v));
+        return o.back().second;
+    }
+    // python truthiness: None, False, "", 0, [], {} are falsy
+    bool truthy() const {
+        switch (t) {
+        case Null: return false;
+        case Bool: return b;
+        case Num: return !(s == "0" || s == "0.0" || s.empty());
+        case Str: return !s.empty();
+        case Arr: return !a.empty();
+        case Obj: return !o.empty();
+        }
+        return false;
+    }
+    // text of a scalar ("" for null / containers); booleans as YAML/JSON spell them
+    std::string text() const {
+        if (t == Str || t == Num) return s;
+        if (t == Bool) return b ? "true" : "false";
+        return "";
+    }
+    long long as_int(long long dflt = 0) const {
+        if (t == Num || t == Str) {
+            try {
+                return std::stoll(s);
+            } catch (...) {
+                return dflt;
+            }
+        }
+        return dflt;
+    }
+    const std::vector<Value> &items() const {
+        static const std::vector<Value> empty;
+        return t == Arr ? a : empty;
+    }
+    const std::vector<std::pair<std::string, Value>> &fields() const {
+        static const std::vector<std::pair<std::string, Value>> empty;
+        return t == Obj ? o : empty;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ JSON
+class JsonParser {
+  public:
+    explicit JsonParser(const std::string &src) : s_(src) {}
+    Value parse_document() {
+        Value v = parse_value();
+        skip_ws();
+        if (i_ != s_.size()) fail("trailing characters");
+        return v;
+    }
+
+  private:
+    const std::string &s_;
+    size_t i_ = 0;
+    [[noreturn]] void fail(const char *what) const { throw std::runtime_error("JSON: " + std::string(what) + " at offset " + std::to_string(i_)); }
+    void skip_ws() {
+        while (i_ < s_.size() && (s_[i_] == ' ' || s_[i_] == '\t' || s_[i_] == '\n' || s_[i_] == '\r')) i_++;
+    }
+    static void put_utf8(std::string &out, unsigned cp) {
+        if (cp < 0x80) out += (char)cp;
+        else if (cp < 0x800) out += (char)(0xC0 | (cp >> 6)), out += (char)(0x80 | (cp & 0x3F));
+        else if (cp < 0x10000) out += (char)(0xE0 | (cp >> 12)), out += (char)(0x80 | ((cp >> 6) & 0x3F)), out += (char)(0x80 | (cp & 0x3F));
+        else out += (char)(0xF0 | (cp >> 18)), out += (char)(0x80 | ((cp >> 12) & 0x3F)), out += (char)(0x80 | ((cp >> 6) & 0x3F)), out += (char)(0x80 | (cp & 0x3F));
+    }
+    unsigned hex4() {
+        if (i_ + 4 > s_.size()) fail("bad \\u escape");
+        unsigned v = 0;
+        for (int k = 0; k < 4; k++) {
+            const char c = s_[i_++];
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= c - '0';
+            else if (c >= 'a' && c <= 'f') v |= c - 'a' + 10;
+            else if (c >= 'A' && c <= 'F') v |= c - 'A' + 10;
+            else fail("bad \\u escape");
+        }
+        return v;
+    }
+    std::string parse_string() {
+        std::string out;
+        i_++; // opening quote
+        while (true) {
+            if (i_ >= s_.size()) fail("unterminated string");
+            const char c = s_[i_++];
+            if (c == '"') return out;
+            if (c != '\\') {
+                out += c;
+                continue;
+            }
+            if (i_ >= s_.size()) fail("unterminated escape");
+            const char e = s_[i_++];
+            switch (e) {
+            case 'n': out += '\n'; break;
+            case 't': out += '\t'; break;
+            case 'r': out += '\r'; break;
+            case 'b': out += '\b'; break;
+            case 'f': out += '\f'; break;
+            case 'u': {
+                unsigned cp = hex4();
+                if (cp >= 0xD800 && cp < 0xDC00 && i_ + 1 < s_.size() && s_[i_] == '\\' && s_[i_ + 1] == 'u') {
+                    i_ += 2;
+                    const unsigned lo = hex4();
+                    cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                }
+                put_utf8(out, cp);
+                break;
+            }
+            default: out += e; // \" \\ \/
+            }
+        }
+    }
+    Value parse_value() {
+        skip_ws();
+        if (i_ >= s_.size()) fail("unexpected end");
+        const char c = s_[i_];
+        if (c == '{') {
+            Value v = Value::object();
+            i_++;
+            skip_ws();
+            if (i_ < s_.size() && s_[i_] == '}') return i_++, v;
+            while (true) {
+                skip_ws();
+                if (i_ >= s_.size() || s_[i_] != '"') fail("expected a key");
+                std::string k = parse_string();
+                skip_ws();
+                if (i_ >= s_.size() || s_[i_] != ':') fail("expected ':'");
+                i_++;
+                v.o.emplace_back(std::move(k), parse_value());
+                skip_ws();
+                if (i_ < s_.size() && s_[i_] == ',') {
+                    i_++;
+                    continue;
+                }
+                if (i_ < s_.size() && s_[i_] == '}') return i_++, v;
+                fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            Value v = Value::array();
+            i_++;
+            skip_ws();
+            if (i_ < s_.size() && s_[i_] == ']') return i_++, v;
+            while (true) {
+                v.a.push_back(parse_value());
+                skip_ws();
+                if (i_ < s_.size() && s_[i_] == ',') {
+                    i_++;
+                    continue;
+                }
+                if (i_ < s_.size() && s_[i_] == ']') return i_++, v;
+                fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') return Value::str(parse_string());
+        if (s_.compare(i_, 4, "true") == 0) return i_ += 4, Value::boolean(true);
+        if (s_.compare(i_, 5, "false") == 0) return i_ += 5, Value::boolean(false);
+        if (s_.compare(i_, 4, "null") == 0) return i_ += 4, Value();
+        const size_t j = i_;
+        while (i_ < s_.size() && (std::isdigit((unsigned char)s_[i_]) || s_[i_] == '-' || s_[i_] == '+' || s_[i_] == '.' || s_[i_] == 'e' || s_[i_] == 'E')) i_++;
+        if (j == i_) fail("unexpected character");
+        Value v;
+        v.t = Value::Num, v.s = s_.substr(j, i_ - j);
+        return v;
+    }
+};
+
+inline void json_escape(std::string &out, const std::string &s) {
+    out += '"';
+    for (const unsigned char c : s) {
+        switch (c) {
+        case '"': out += "\\\""; break;
+        case '\\': out += "\\\\"; break;
+        case '\n': out += "\\n"; break;
+        case '\t': out += "\\t"; break;
+        case '\r': out += "\\r"; break;
+        default:
+            if (c < 0x20) {
+                char buf[8];
+                std::snprintf(buf, sizeof buf, "\\u%04x", c);
+                out += buf;
+            } else
+                out += (char)c;
+        }
+    }
+    out += '"';
+}
+
+// compact JSON with ", " / ": " separators: byte-identical to python's json.dumps default
+inline void to_json(std::string &out, const Value &v) {
+    switch (v.t) {
+    case Value::Null: out += "null"; break;
+    case Value::Bool: out += v.b ? "true" : "false"; break;
+    case Value::Num: out += v.s; break;
+    case Value::Str: json_escape(out, v.s); break;
+    case Value::Arr:
+        out += '[';
+        for (size_t i = 0; i < v.a.size(); i++) {
+            if (i) out += ", ";
+            to_json(out, v.a[i]);
+        }
+        out += ']';
+        break;
+    case Value::Obj:
+        out += '{';
+        for (size_t i = 0; i < v.o.size(); i++) {
+            if (i) out += ", ";
+            json_escape(out, v.o[i].first);
+            out += ": ";
+            to_json(out, v.o[i].second);
+        }
+        out += '}';
+        break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ YAML (subset)
+class YamlParser {
+  public:
+    explicit YamlParser(const std::string &src) { split_lines(src); }
+    // every document of the stream (--- separators); empty documents are dropped
+    std::vector<Value> parse_stream() {
+        std::vector<Value> docs;
+        while (true) {
+            skip_blank();
+            if (pos_ >= lines_.size()) break;
+            if (is_doc_marker(lines_[pos_].text)) {
+                pos_++;
+                continue;
+            }
+            Value v = parse_node(lines_[pos_].indent);
+            if (!v.is_null()) docs.push_back(std::move(v));
+        }
+        return docs;
+    }
+
+  private:
+    struct Line {
+        int indent;
+        std::string text; // without indentation, trailing spaces and comments
+        std::string raw;  // the full line (block scalars)
+    };
+    std::vector<Line> lines_;
+    size_t pos_ = 0;
+
+    [[noreturn]] void fail(const std::string &what) const {
+        throw std::runtime_error("YAML: " + what + " near line " + std::to_string(pos_ + 1) + " (use JSON for input this subset cannot read)");
+    }
+    static bool is_doc_marker(const std::string &t) { return t == "---" || t.rfind("--- ", 0) == 0 || t == "..."; }
+    static std::string strip_comment(const std::string &t) {
+        bool sq = false, dq = false;
+        for (size_t i = 0; i < t.size(); i++) {
+            const char c = t[i];
+            if (c == '\'' && !dq) sq = !sq;
+            else if (c == '"' && !sq && (i == 0 || t[i - 1] != '\\')) dq = !dq;
+            else if (c == '#' && !sq && !dq && (i == 0 || t[i - 1] == ' ' || t[i - 1] == '\t')) return t.substr(0, i);
+        }
+        return t;
+    }
+    void split_lines(const std::string &src) {
+        size_t i = 0;
+        while (i <= src.size()) {
+            size_t j = src.find('\n', i);
+            if (j == std::string::npos) j = src.size();
+            std::string raw = src.substr(i, j - i);
+            if (!raw.empty() && raw.back() == '\r') raw.pop_back();
+            Line l;
+            l.raw = raw;
+            size_t k = 0;
+            while (k < raw.size() && raw[k] == ' ') k++;
+            l.indent = (int)k;
+            std::string t = strip_comment(raw.substr(k));
+            while (!t.empty() && (t.back() == ' ' || t.back() == '\t')) t.pop_back();
+            l.text = t;
+            lines_.push_back(std::move(l));
+            if (j == src.size()) break;
+            i = j + 1;
+        }
+    }
+    void skip_blank() {
+        while (pos_ < lines_.size() && lines_[pos_].text.empty()) pos_++;
+    }
+    static bool looks_like_number(const std::string &s) {
+        if (s.empty()) return false;
+        size_t i = (s[0] == '-' || s[0] == '+') ? 1 : 0;
+        if (i >= s.size()) return false;
+        bool digit = false, dot = false, exp = false;
+        for (; i < s.size(); i++) {
+            const char c = s[i];
+            if (std::isdigit((unsigned char)c)) digit = true;
+            else if (c == '.' && !dot && !exp) dot = true;
+            else if ((c == 'e' || c == 'E') && digit && !exp && dot) { // YAML 1.1 (PyYAML): a float needs the dot
+                exp = true;
+                if (i + 1 < s.size() && (s[i + 1] == '-' || s[i + 1] == '+')) i++;
+            } else
+                return false;
+        }
+        return digit;
+    }
+    static Value plain_scalar(const std::string &t) {
+        if (t.empty() || t == "~" || t == "null" || t == "Null" || t == "NULL") return Value();
+        if (t == "true" || t == "True" || t == "TRUE") return Value::boolean(true);
+        if (t == "false" || t == "False" || t == "FALSE") return Value::boolean(false);
+        if (looks_like_number(t)) {
+            Value v;
+            v.t = Value::Num, v.s = t;
+            return v;
+        }
+        return Value::str(t);
+    }
+    static std::string unquote_double(const std::string &t, size_t &i) { // t[i] == '"'
+        std::string json = "\"";
+        size_t j = i + 1;
+        for (; j < t.size(); j++) {
+            if (t[j] == '\\' && j + 1 < t.size()) {
+                json += t[j], json += t[j + 1], j++;
+                continue;
+            }
+            if (t[j] == '"') break;
+            json += t[j];
+        }
+        if (j >= t.size()) throw std::runtime_error("YAML: unterminated double-quoted scalar (multi-line quoted scalars are not supported)");
+        json += '"';
+        i = j + 1;
+        JsonParser p(json);
+        return p.parse_document().s;
+    }
+    static std::string unquote_single(const std::string &t, size_t &i) { // t[i] == '\''
+        std::string out;
+        size_t j = i + 1;
+        for (; j < t.size(); j++) {
+            if (t[j] == '\'') {
+                if (j + 1 < t.size() && t[j + 1] == '\'') {
+                    out += '\'', j++;
+                    continue;
+                }
+                break;
+            }
+            out += t[j];
+        }
+        if (j >= t.size()) throw std::runtime_error("YAML: unterminated single-quoted scalar");
+        i = j + 1;
+        return out;
+    }
+    // flow collections and scalars inside them
+    Value parse_flow(const std::string &t, size_t &i) {
+        auto ws = [&] {
+            while (i < t.size() && (t[i] == ' ' || t[i] == '\t')) i++;
+        };
+        ws();
+        if (i >= t.size()) return Value();
+        if (t[i] == '[') {
+            Value v = Value::array();
+            i++;
+            ws();
+            if (i < t.size() && t[i] == ']') return i++, v;
+            while (true) {
+                v.a.push_back(parse_flow(t, i));
+                ws();
+                if (i < t.size() && t[i] == ',') {
+                    i++;
+                    continue;
+                }
+                if (i < t.size() && t[i] == ']') return i++, v;
+                fail("multi-line flow sequence");
+            }
+        }
+        if (t[i] == '{') {
+            Value v = Value::object();
+            i++;
+            ws();
+            if (i < t.size() && t[i] == '}') return i++, v;
+            while (true) {
+                ws();
+                std::string k;
+                if (i < t.size() && t[i] == '"') k = unquote_double(t, i);
+                else if (i < t.size() && t[i] == '\'') k = unquote_single(t, i);
+                else {
+                    const size_t j = i;
+                    while (i < t.size() && t[i] != ':' && t[i] != ',' && t[i] != '}') i++;
+                    k = t.substr(j, i - j);
+                    while (!k.empty() && k.back() == ' ') k.pop_back();
+                }
+                ws();
+                if (i >= t.size() || t[i] != ':') fail("flow mapping without ':'");
+                i++;
+                v.o.emplace_back(k, parse_flow(t, i));
+                ws();
+                if (i < t.size() && t[i] == ',') {
+                    i++;
+                    continue;
+                }
+                if (i < t.size() && t[i] == '}') return i++, v;
+                fail("multi-line flow mapping");
+            }
+        }
+        if (t[i] == '"') return Value::str(unquote_double(t, i));
+        if (t[i] == '\'') return Value::str(unquote_single(t, i));
+        const size_t j = i;
+        while (i < t.size() && t[i] != ',' && t[i] != ']' && t[i] != '}') i++;
+        std::string s = t.substr(j, i - j);
+        while (!s.empty() && s.back() == ' ') s.pop_back();
+        return plain_scalar(s);
+    }
+    // a block scalar (| or >) whose header is on the line before pos_; parent_indent = indentation of the owning key
+    Value parse_block_scalar(char style, char chomp, int parent_indent) {
+        std::vector<std::string> body;
+        int indent = -1;
+        while (pos_ < lines_.size()) {
+            const Line &l = lines_[pos_];
+            const bool blank = l.raw.find_first_not_of(" \t") == std::string::npos;
+            if (!blank) {
+                size_t k = 0;
+                while (k < l.raw.size() && l.raw[k] == ' ') k++;
+                if ((int)k <= parent_indent) break;
+                if (indent < 0) indent = (int)k;
+                if ((int)k < indent) break;
+            }
+            body.push_back(blank ? "" : l.raw.substr((size_t)indent));
+            pos_++;
+        }
+        while (!body.empty() && body.back().empty()) body.pop_back();
+        std::string out;
+        for (size_t i = 0; i < body.size(); i++) {
+            out += body[i];
+            if (i + 1 < body.size()) out += (style == '|' || body[i].empty() || body[i + 1].empty()) ? "\n" : " ";
+        }
+        if (chomp != '-' && !body.empty()) out += '\n';
+        return Value::str(out);
+    }
+    // the value that follows "key:" or "- " on the same line (rest), or on the following lines
+    Value parse_inline_or_nested(const std::string &rest, int owner_indent, bool owner_is_seq_item) {
+        if (!rest.empty()) {
+            if (rest[0] == '|' || rest[0] == '>') {
+                const char chomp = rest.size() > 1 && (rest[1] == '-' || rest[1] == '+') ? rest[1] : ' ';
+                return parse_block_scalar(rest[0], chomp, owner_indent);
+            }
+            if (rest[0] == '[' || rest[0] == '{' || rest[0] == '"' || rest[0] == '\'') {
+                size_t i = 0;
+                Value v = parse_flow(rest, i);
+                return v;
+            }
+            if (rest[0] == '&' || rest[0] == '*' || rest[0] == '!') fail("anchors / aliases / tags");
+            // plain scalar, possibly continued on more-indented lines (kubectl folds long strings)
+            std::string s = rest;
+            while (pos_ < lines_.size()) {
+                const Line &l = lines_[pos_];
+                if (l.text.empty()) break;
+                if (l.indent <= owner_indent) break;
+                if (l.text[0] == '-' && (l.text.size() == 1 || l.text[1] == ' ')) break;
+                if (find_key_colon(l.text) != std::string::npos) break;
+                s += " " + l.text;
+                pos_++;
+            }
+            return plain_scalar(s);
+        }
+        skip_blank();
+        if (pos_ >= lines_.size()) return Value();
+        const Line &l = lines_[pos_];
+        if (is_doc_marker(l.text)) return Value();
+        const bool seq_here = l.text[0] == '-' && (l.text.size() == 1 || l.text[1] == ' ');
+        // a sequence may sit at the SAME indentation as its key ("containers:\n- name: x"), a mapping must be deeper
+        if (l.indent > owner_indent || (seq_here && l.indent == owner_indent && !owner_is_seq_item)) return parse_node(l.indent);
+        return Value();
+    }
+    // position of the ':' that ends a block-mapping key, npos if the line is not "key: ..."
+    static size_t find_key_colon(const std::string &t) {
+        bool sq = false, dq = false;
+        for (size_t i = 0; i < t.size(); i++) {
+            const char c = t[i];
+            if (c == '\'' && !dq) sq = !sq;
+            else if (c == '"' && !sq) dq = !dq;
+            else if (c == ':' && !sq && !dq && (i + 1 == t.size() || t[i + 1] == ' ')) return i;
+            else if (!sq && !dq && (c == '[' || c == '{') && i == 0) return std::string::npos;
+        }
+        return std::string::npos;
+    }
+    static std::string key_text(std::string k) {
+        while (!k.empty() && k.back() == ' ') k.pop_back();
+        if (k.size() >= 2 && k.front() == '"') {
+            size_t i = 0;
+            return unquote_double(k, i);
+        }
+        if (k.size() >= 2 && k.front() == '\'') {
+            size_t i = 0;
+            return unquote_single(k, i);
+        }
+        return k;
+    }
+    Value parse_node(int indent) {
+        skip_blank();
+        if (pos_ >= lines_.size()) return Value();
+        const std::string &first = lines_[pos_].text;
+        if (first[0] == '-' && (first.size() == 1 || first[1] == ' ')) return parse_sequence(indent);
+        if (find_key_colon(first) != std::string::npos) return parse_mapping(indent);
+        // a bare scalar document
+        std::string t = first;
+        pos_++;
+        size_t i = 0;
+        if (t[0] == '[' || t[0] == '{' || t[0] == '"' || t[0] == '\'') return parse_flow(t, i);
+        return plain_scalar(t);
+    }
+    Value parse_sequence(int indent) {
+        Value v = Value::array();
+        while (true) {
+            skip_blank();
+            if (pos_ >= lines_.size()) break;
+            Line &l = lines_[pos_];
+            if (l.indent != indent || is_doc_marker(l.text)) break;
+            if (!(l.text[0] == '-' && (l.text.size() == 1 || l.text[1] == ' '))) break;
+            std::string rest = l.text.size() > 1 ? l.text.substr(2) : "";
+            size_t lead = 0;
+            while (lead < rest.size() && rest[lead] == ' ') lead++;
+            rest = rest.substr(lead);
+            const int item_indent = indent + 2 + (int)lead; // where the item's content starts
+            if (!rest.empty() && find_key_colon(rest) != std::string::npos && rest[0] != '"' && rest[0] != '\'' && rest[0] != '[' && rest[0] != '{') {
+                // "- key: value": the item is a mapping whose first key sits on the dash line
+                l.text = rest, l.indent = item_indent;
+                v.a.push_back(parse_mapping(item_indent));
+            } else if (!rest.empty() && (rest[0] == '"' || rest[0] == '\'') && find_key_colon(rest) != std::string::npos) {
+                l.text = rest, l.indent = item_indent;
+                v.a.push_back(parse_mapping(item_indent));
+            } else {
+                pos_++;
+                v.a.push_back(parse_inline_or_nested(rest, indent, true));
+            }
+        }
+        return v;
+    }
+    Value parse_mapping(int indent) {
+        Value v = Value::object();
+        while (true) {
+            skip_blank();
+            if (pos_ >= lines_.size()) break;
+            const Line &l = lines_[pos_];
+            if (l.indent != indent || is_doc_marker(l.text)) break;
+            const size_t c = find_key_colon(l.text);
+            if (c == std::string::npos) break;
+            const std::string key = key_text(l.text.substr(0, c));
+            std::string rest = c + 1 < l.text.size() ? l.text.substr(c + 1) : "";
+            size_t lead = 0;
+            while (lead < rest.size() && rest[lead] == ' ') lead++;
+            rest = rest.substr(lead);
+            pos_++;
+            v.o.emplace_back(key, parse_inline_or_nested(rest, indent, false));
+        }
+        return v;
+    }
+};
+
+inline bool yaml_needs_quotes(const std::string &s) {
+    if (s.empty()) return true;
+    static const char *special[] = {"true", "false", "null", "True", "False", "Null", "yes", "no", "on", "off", "~", "Yes", "No", "y", "n"};
+    for (const char *w : special)
+        if (s == w) return true;
+    if (std::isdigit((unsigned char)s[0]) || s[0] == '-' || s[0] == '+' || s[0] == '.') {
+        bool numeric = true;
+        for (const char c : s)
+            if (!(std::isdigit((unsigned char)c) || c == '.' || c == '-' || c == '+' || c == 'e' || c == 'E' || c == '_' || c == ':')) numeric = false;
+        if (numeric) return true;
+    }
+    if (std::string("!&*-?|>'\"%@`#{}[],").find(s[0]) != std::string::npos && !(s[0] == '-' && s.size() > 1 && s[1] != ' ')) return true;
+    if (s.back() == ' ' || s.front() == ' ') return true;
+    for (size_t i = 0; i < s.size(); i++) {
+        const char c = s[i];
+        if (c == '\n' || c == '\t' || c == '"' || (unsigned char)c < 0x20) return true;
+        if (c == ':' && (i + 1 == s.size() || s[i + 1] == ' ')) return true;
+        if (c == '#' && i > 0 && s[i - 1] == ' ') return true;
+    }
+    return false;
+}
+
+// block-style YAML in the shape python's yaml.safe_dump(sort_keys=False) produces for these reviews
+inline void to_yaml(std::string &out, const Value &v, int indent = 0, bool in_seq_item = false) {
+    const std::string pad((size_t)indent, ' ');
+    auto scalar = [&](const Value &x) {
+        switch (x.t) {
+        case Value::Null: out += "null"; break;
+        case Value::Bool: out += x.b ? "true" : "false"; break;
+        case Value::Num: out += x.s; break;
+        case Value::Str:
+            if (yaml_needs_quotes(x.s)) {
+                out += '\'';
+                for (const char c : x.s) {
+                    if (c == '\'') out += "''";
+                    else out += c;
+                }
+                out += '\'';
+            } else
+                out += x.s;
+            break;
+        default: break;
+        }
+    };
+    if (v.t == Value::Obj) {
+        if (v.o.empty()) {
+            out += "{}\n";
+            return;
+        }
+        bool first = true;
+        for (auto &kv : v.o) {
+            if (!(first && in_seq_item)) out += pad;
+            first = false;
+            { Value k = Value::str(kv.first); scalar(k); }
+            out += ':';
+            const Value &c = kv.second;
+            if (c.t == Value::Obj && !c.o.empty()) out += '\n', to_yaml(out, c, indent + 2);
+            else if (c.t == Value::Arr && !c.a.empty()) out += '\n', to_yaml(out, c, indent);
+            else if (c.t == Value::Obj) out += " {}\n";
+            else if (c.t == Value::Arr) out += " []\n";
+            else out += ' ', scalar(c), out += '\n';
+        }
+        return;
+    }
+    if (v.t == Value::Arr) {
+        if (v.a.empty()) {
+            out += "[]\n";
+            return;
+        }
+        for (auto &c : v.a) {
+            out += pad + "- ";
+            if (c.t == Value::Obj && !c.o.empty()) to_yaml(out, c, indent + 2, true);
+            else if (c.t == Value::Arr && !c.a.empty()) to_yaml(out, c, indent + 2, true);
+            else if (c.t == Value::Obj) out += "{}\n";
+            else if (c.t == Value::Arr) out += "[]\n";
+            else scalar(c), out += '\n';
+        }
+        return;
+    }
+    scalar(v);
+    out += '\n';
+}
+
+// a file of objects: JSON (first non-blank character is { or [) or YAML stream
+inline std::vector<Value> parse_documents(const std::string &text) {
+    size_t i = 0;
+    while (i < text.size() && std::isspace((unsigned char)text[i])) i++;
+    if (i < text.size() && (text[i] == '{' || text[i] == '[')) {
+        JsonParser p(text);
+        return {p.parse_document()};
+    }
+    YamlParser y(text);
+    return y.parse_stream();
+}
+
+} // namespace cchost
