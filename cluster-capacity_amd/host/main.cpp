@@ -169,13 +169,14 @@ void marshal(const Snapshot &s, int percentage, Marshalled &m) {
     p.has_required_terms = s.has_required_terms;
     for (const auto &t : s.required) m.required.push_back(add_term(t, 0));
     for (const auto &t : s.preferred) m.preferred.push_back(add_term(t.second, t.first));
-    if (m.required.empty()) m.required.push_back(ccsim_term{});
+    const int32_t n_reqs = (int32_t)m.reqs.size();
+    if (m.required.empty()) m.required.push_back(ccsim_term{}); // (never dereferenced: the counts below stay 0)
     if (m.preferred.empty()) m.preferred.push_back(ccsim_term{});
     if (m.reqs.empty()) m.reqs.push_back(ccsim_requirement{});
     if (m.tables.empty()) m.tables.push_back(0);
     p.n_required = (int32_t)s.required.size(), p.required = m.required.data();
     p.n_preferred = (int32_t)s.preferred.size(), p.preferred = m.preferred.data();
-    p.n_reqs = (int32_t)(s.node_selector.size() ? m.reqs.size() : m.reqs.size()), p.reqs = m.reqs.data();
+    p.n_reqs = n_reqs, p.reqs = m.reqs.data();
     p.req_tables_len = (int64_t)m.tables.size(), p.req_tables = m.tables.data();
     p.n_spread = (int32_t)s.spread.size();
     for (size_t i = 0; i < s.spread.size(); i++) {
