@@ -317,6 +317,14 @@ int main(int argc, char **argv) {
             else if (a == "--device") device = std::stoi(need());
             else if (a == "--dump-snapshot") dump = need();
             else if (a == "--fake-result") fake = need();
+            else if (a == "--parse") { // test hook: the documents of a file, as JSON (one array)
+                Value all = Value::array();
+                for (const Value &d : parse_documents(read_file(need()))) all.a.push_back(d);
+                std::string out;
+                to_json(out, all);
+                std::cout << out << "\n";
+                return 0;
+            }
             else if (a == "--kubeconfig" || a == "--default-config") return usage(("not supported here: " + a + " (see --snapshot)").c_str());
             else return usage(("unknown flag " + a).c_str());
         } catch (const std::exception &e) {

@@ -242,3 +242,114 @@ def test_native_cli_end_to_end(native, tmp_path):
     ref = json.loads(buf.getvalue())
     got["status"].pop("creationTimestamp"), ref["status"].pop("creationTimestamp")
     assert got["status"] == ref["status"]
+
+
+KUBECTL_STYLE_YAML = """\
+# kubectl get nodes,pods -o yaml (abridged)
+apiVersion: v1
+items:
+- apiVersion: v1
+  kind: Node
+  metadata:
+    annotations:
+      kubectl.kubernetes.io/last-applied-configuration: |
+        {"apiVersion":"v1","kind":"Node","metadata":{"name":"n1"}}
+      note: >-
+        folded text
+        continues here
+      node.alpha.kubernetes.io/ttl: "0"
+      "quoted: key": 'it''s quoted'
+    creationTimestamp: "2025-01-01T00:00:00Z"
+    labels:
+      kubernetes.io/hostname: n1   # trailing comment
+      topology.kubernetes.io/zone: zone-a
+      numeric-looking: "123"
+      empty-value: ""
+    name: n1
+  spec:
+    taints:
+    - effect: NoSchedule
+      key: dedicated
+      value: infra
+    - {effect: PreferNoSchedule, key: maintenance}
+    podCIDRs: [10.0.0.0/24, "10.0.1.0/24"]
+    unschedulable: true
+  status:
+    allocatable:
+      cpu: 3920m
+      ephemeral-storage: "47093746742"
+      memory: 15842200Ki
+      pods: "110"
+      fractional: 0.5
+    capacity: {}
+    conditions: []
+    images:
+    -
+      names:
+      - registry.k8s.io/pause:3.9
+      sizeBytes: 322000
+- apiVersion: v1
+  kind: Pod
+  metadata: {name: p1, namespace: kube-system, labels: {app: dns}}
+  spec:
+    nodeName: n1
+    containers:
+    - name: c
+      args: ["--flag=a: b", '--x']
+      resources:
+        requests: {cpu: 100m, memory: 70Mi}
+      command:
+      - /bin/sh
+      - -c
+      - echo hello
+  status: {phase: Running}
+kind: List
+metadata:
+  resourceVersion: ""
+---
+kind: Pod
+metadata:
+  name: long-plain
+  description: this plain scalar is long enough that the emitter
+    wrapped it onto a second line
+spec:
+  nodeName: null
+  priority: 0
+  enableServiceLinks: false
+...
+"""
+
+
+def _stringify(v):
+    """PyYAML types -> the native model: numbers keep their text, everything else as is."""
+    if isinstance(v, dict):
+        return {str(k): _stringify(x) for k, x in v.items()}
+    if isinstance(v, list):
+        return [_stringify(x) for x in v]
+    if isinstance(v, bool) or v is None or isinstance(v, str):
+        return v
+    return v  # int / float: json round-trips them
+
+
+def test_native_yaml_reader_agrees_with_pyyaml_on_kubectl_style_input(native, tmp_path):
+    (tmp_path / "dump.yaml").write_text(KUBECTL_STYLE_YAML)
+    got = json.loads(_run(native, ["--parse", str(tmp_path / "dump.yaml")]))
+    ref = [_stringify(d) for d in yaml.safe_load_all(KUBECTL_STYLE_YAML) if d]
+    assert got == ref
+    # and the ingest of that file: one kept node with its quantities interpreted exactly
+    (tmp_path / "pod.yaml").write_text(EXAMPLES_POD)
+    d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "dump.yaml"), "--dump-snapshot", "-"]))
+    assert d["names"] == ["n1"] and d["alloc"][0] == [3920] and d["alloc"][1] == [15842200 * 1024] and d["alloc"][2] == [47093746742]
+    assert d["alloc_pods"] == [110] and d["req"][0] == [100] and d["req"][1] == [70 << 20] and d["unschedulable"] == [1]
+    assert d["taint_reasons"] == ["node(s) had untolerated taint {dedicated: infra}"] and d["pod"]["taint_prefer_cnt"] == [1]
+
+
+def test_native_quantity_arithmetic(native, tmp_path):
+    """quantity.go:813-834 through the native ingest: Value / MilliValue round UP, every suffix family."""
+    q = {"cpu": ["150m", "2", "0.1", "1500u", "100n", "1e-1", "2E0", "0.0005"], "memory": ["100Mi", "4Gi", "1e3", "1.5Ki", "100m", "4G", "1E", "0.5"]}
+    nodes = [node(f"n{i}", cpu=q["cpu"][i], mem=q["memory"][i]) for i in range(8)]
+    (tmp_path / "c.json").write_text(json.dumps({"kind": "List", "items": nodes}))
+    (tmp_path / "pod.yaml").write_text(EXAMPLES_POD)
+    d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
+    assert d["alloc"][0] == [ingest.milli_value(x) for x in q["cpu"]] == [150, 2000, 100, 2, 1, 100, 2000, 1]
+    assert d["alloc"][1] == [ingest.value(x) for x in q["memory"]] == [104857600, 4 << 30, 1000, 1536, 1, 4_000_000_000, 10**18, 1]
