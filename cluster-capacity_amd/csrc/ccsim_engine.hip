@@ -95,6 +95,8 @@ struct ccsim_engine {
     int rank = 0;
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
+    int dist_pass_in_window = 0;      // passes since the last ccsim_dist_begin / ccsim_dist_poll
+    bool dist_score_launched = true;  // whether the current sharded pass launched k_level_score
     bool rows_active = false; // the current batched run keeps its dynamic state in the commit rows (DevCols::rows)
     uint64_t node_mem_or = 0; // OR of every memory value of the snapshot (common power-of-two unit)
     int64_t node_max_cpu = 0, node_max_mem = 0, node_max_pods = 0;
@@ -1157,13 +1159,25 @@ extern "C" int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode
     e->rank = rank;
     e->d_xsend = (XRec *)sendbuf;
     e->d_xrecv = (XRec *)recvbuf;
+    e->dist_pass_in_window = 0;
     return begin_run(e, max_limit, mode, log_cap);
 }
 
 extern "C" int ccsim_dist_scan(ccsim_engine *e) {
     if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
-    launch_pass(e); // n_ranks > 0: the one-block kernel publishes this shard's record into sendbuf
+    if (e->mode == CCSIM_MODE_BATCHED) {
+        // Full passes are rare: only the first two passes after every ccsim_dist_begin / ccsim_dist_poll launch the flush +
+        // score kernels (stale constants found, then the real level); the others are commit-only.  A full pass that falls
+        // due in between turns the passes up to the next poll into no-ops ON EVERY RANK ALIKE (k_level_final and
+        // k_level_decide apply the same device-side test to the same replicated state), then runs.
+        e->dist_score_launched = e->dist_pass_in_window < 2;
+        e->dist_pass_in_window++;
+        launch_level_commit(e);
+        if (e->dist_score_launched) launch_rows_flush(e, true), launch_level_score(e);
+        launch_level_final(e, true, e->dist_score_launched); // publishes this shard's record into sendbuf
+    } else
+        launch_pass(e); // n_ranks > 0: the one-block kernel publishes this shard's record into sendbuf
     HIPCHK(e, hipGetLastError());
     return 0;
 }
@@ -1171,7 +1185,7 @@ extern "C" int ccsim_dist_scan(ccsim_engine *e) {
 extern "C" int ccsim_dist_decide(ccsim_engine *e) {
     if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
     if (e->mode == CCSIM_MODE_BATCHED)
-        hipLaunchKernelGGL(k_level_decide, dim3(1), dim3(64), 0, e->stream, level_final_args(e));
+        hipLaunchKernelGGL(k_level_decide, dim3(1), dim3(64), 0, e->stream, level_final_args(e, true, e->dist_score_launched));
     else
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, scan_args(e));
     HIPCHK(e, hipGetLastError());
@@ -1239,6 +1253,7 @@ extern "C" int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed) 
     if (rc) return rc;
     if (done) *done = e->h_state->done;
     if (placed) *placed = e->h_state->placed;
+    e->dist_pass_in_window = 0;
     return 0;
 }
 

@@ -915,6 +915,7 @@ __global__ void k_level_decide(LevelFinalArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     DevState st = *a.st;
     if (st.done) return;
+    if (st.lvl_full ? !a.score_launched : !a.commit_launched) return; // the pass was a no-op on every rank (LevelFinalArgs)
     LevelAgg g{};
     g.cut_mt = g.cut_ma = -1;
     int64_t before = 0;

@@ -271,7 +271,9 @@ int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req_mem, int64
  *                          record word 0 is the packed (score, position) key combined with MAX)
  *     ccsim_dist_decide()  every rank reduces the gathered records identically; only the rank that
  *                          owns a winning node applies NodeInfo.update to its HBM columns
- * ccsim_dist_poll() synchronizes and reads the done flag; call it every few passes.
+ * ccsim_dist_poll() synchronizes and reads the done flag; call it every few passes, after the SAME number of passes on
+ * every rank (the batched mode launches its rare full pass only in the first two passes after a begin / poll: a full
+ * pass that falls due in between makes the passes up to the next poll no-ops on all ranks alike).
  * With a placement log each rank fills the positions of ITS placements in its own log copy and leaves
  * -1 elsewhere: the element-wise maximum over ranks is the global log. */
 #define CCSIM_XCHG_WORDS 32

@@ -157,34 +157,36 @@ class _LocalShards:
             if tabs[0]:
                 e.dist_tables_done()
 
-    def run(self, limit, mode, log_cap):
+    def run(self, limit, mode, log_cap, poll_every=1):
         from cluster_capacity_amd import dist as ccdist
         W = self.world
         for r, e in enumerate(self.engines):
             e.dist_begin(limit, mode, W, r, self.send[r].data_ptr(), self.recv[r].data_ptr(), log_cap)
         for _ in range(1_000_000):
-            for e in self.engines:
-                e.dist_scan()
-            gathered = self.torch.cat(self.send)
-            for r in range(W):
-                self.recv[r].copy_(gathered)
-            for e in self.engines:
-                e.dist_decide()
-            if all(e.dist_poll()[0] for e in self.engines):
+            for _ in range(poll_every):  # (the batched mode launches its full pass only right after a poll)
+                for e in self.engines:
+                    e.dist_scan()
+                gathered = self.torch.cat(self.send)
+                for r in range(W):
+                    self.recv[r].copy_(gathered)
+                for e in self.engines:
+                    e.dist_decide()
+            if all([e.dist_poll()[0] for e in self.engines]):  # every rank polls (no short-circuit): same cadence everywhere
                 break
         res = [e.dist_finish(True, log_cap) for e in self.engines]
         return res, ccdist.merge_logs([r.log for r in res])
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("world,cfg,n,limit", [(2, "C3", 1500, 0), (3, "C3", 1100, 450), (2, "C2", 700, 0)])
-def test_sharded_protocol_matches_oracle(ccref, mode, world, cfg, n, limit):
+@pytest.mark.parametrize("world,cfg,n,limit,poll_every", [(2, "C3", 1500, 0, 1), (3, "C3", 1100, 450, 1), (2, "C2", 700, 0, 1),
+                                                          (2, "C3", 1500, 0, 8), (3, "C3", 1100, 450, 5), (4, "C3", 2100, 0, 32)])
+def test_sharded_protocol_matches_oracle(ccref, mode, world, cfg, n, limit, poll_every):
     nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
     ref = ccref.run(prof, nodes, pod, max_limit=limit)
     if mode == "sequential" and ref.placed > 3000:
         limit = 3000
         ref = ccref.run(prof, nodes, pod, max_limit=limit)
-    res, log = _LocalShards(nodes, pod, prof, world).run(limit, mode, max(1, ref.placed))
+    res, log = _LocalShards(nodes, pod, prof, world).run(limit, mode, max(1, ref.placed), poll_every)
     assert all(r.placed == ref.placed and r.stop == ref.stop for r in res)
     assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
     assert np.array_equal(log[: ref.placed], ref.log)
