@@ -79,8 +79,9 @@ typedef struct {
     void *stream;        /* hipStream_t to enqueue on, or NULL: the engine creates its own */
     int32_t rounds_per_sync; /* placement rounds enqueued between host checks of the done flag; 0 = default */
     int32_t use_graph;       /* replay rounds from a captured hipGraph (1) or launch eagerly (0) */
-    int32_t time_passes;     /* measurement runs: launch eagerly with a HIP event pair around every full-pass kernel
-                                (k_scan / k_level) and report their summed duration in ccsim_report.pass_kernel_ns */
+    int32_t time_passes;     /* measurement runs: launch eagerly with HIP event stamps on every launch of the pass's
+                                dominant kernel (sequential: k_scan; batched: k_level_commit) and report their summed
+                                duration in ccsim_report.pass_kernel_ns */
 } ccsim_config;
 
 /* Node snapshot, structure-of-arrays, canonical node order (S/backend/cache/node_tree.go:119-143).
@@ -219,11 +220,12 @@ typedef struct {
     int64_t n_code_unschedulable; /* nodes whose terminal status is plain Unschedulable */
     /* counters */
     int64_t rounds;          /* scheduling cycles simulated (placements + the terminal one) */
-    int64_t scans;           /* full pods x nodes passes executed (sequential: one per round; batched: one per level) */
+    int64_t scans;           /* passes executed (sequential: one full pods x nodes scan per attempt of a round; batched: one per
+                                score level -- a commit pass off the score cache, or the rare full pass) */
     int64_t evaluated_total; /* (pod, node) evaluations the reference semantics imply = rounds * n */
     int32_t last_feasible;   /* FeasibleNodes of the last cycle */
     int64_t kernel_ns;       /* GPU time of all launches of the run (HIP events on the engine's stream) */
-    int64_t pass_kernel_ns;  /* cfg.time_passes: summed duration of the full-pass kernel launches alone ... */
+    int64_t pass_kernel_ns;  /* cfg.time_passes: summed duration of the dominant kernel's launches alone ... */
     int64_t pass_launches;   /* ... and how many were launched (incl. early-exit launches after the done flag) */
     int64_t bytes_per_scan;  /* algorithmic bytes one scan reads: n_nodes * sum of enabled column widths */
 } ccsim_report;
@@ -299,7 +301,7 @@ int ccsim_dist_tables_done(ccsim_engine *e);
 int ccsim_reset_state(ccsim_engine *e);
 
 /* Measurement aid (bench.py roofline): time `iters` back-to-back launches of the dominant kernel of
- * `mode` (the full pods x nodes pass: k_scan or k_level) with HIP events on the engine's stream;
+ * `mode` (the full pods x nodes pass: k_scan or k_level_score) with HIP events on the engine's stream;
  * simulation state is not advanced. */
 int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan);
 
