@@ -6,8 +6,8 @@
 // Flags mirror cmd/cluster-capacity/app/options/options.go:65-77; Run / Report mirror pkg/framework/simulator.go:356-381
 // and pkg/framework/report.go.  There is no API server here, so --kubeconfig is replaced by --snapshot: files holding the
 // Node and Pod objects SyncWithClient would list (simulator.go:176-295) -- `kubectl get nodes,pods -A -o json` output, a
-// List, or a multi-document YAML stream.  --default-config (a KubeSchedulerConfiguration) is not parsed: the default
-// profile is used, with --percentage-of-nodes-to-score as its one knob.
+// List, or a multi-document YAML stream.  --default-config takes a KubeSchedulerConfiguration (profile.hpp: plugin sets,
+// weights, scoring resources, percentageOfNodesToScore); --percentage-of-nodes-to-score overrides its percentage.
 //
 // The simulation runs on the GPU through include/ccsim.h (libccsim.so, loaded at run time); there is NO CPU fallback: if
 // the library or the device is missing the command fails.  Test hooks (no GPU needed): --dump-snapshot prints the integer
@@ -23,6 +23,7 @@
 #include <iostream>
 #include <sstream>
 
+#include "profile.hpp"
 #include "report.hpp"
 #include "snapshot.hpp"
 
@@ -140,7 +141,7 @@ struct Marshalled {
     std::vector<ccsim_term> required, preferred;
 };
 
-void marshal(const Snapshot &s, int percentage, Marshalled &m) {
+void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
     const int64_t N = (int64_t)s.n();
     ccsim_nodes &n = m.nodes;
     n.n_nodes = N, n.global_offset = 0, n.n_global = N, n.n_scalar = (int32_t)s.scalar_names.size();
@@ -209,19 +210,14 @@ void marshal(const Snapshot &s, int percentage, Marshalled &m) {
         }
         c.entries_existing = a.entries_existing;
     }
-    // the default profile (apis/config/v1/default_plugins.go:30-58, defaults.go:33-36,229-245)
-    ccsim_profile &f = m.profile;
-    f.filter_mask = CCSIM_F_UNSCHEDULABLE | CCSIM_F_NODENAME | CCSIM_F_TAINT | CCSIM_F_NODEAFFINITY | CCSIM_F_FIT | CCSIM_F_TOPOLOGYSPREAD | CCSIM_F_INTERPODAFFINITY;
-    f.w_taint = 3, f.w_nodeaffinity = 2, f.w_fit = 1, f.w_balanced = 1, f.w_topologyspread = 2, f.w_interpodaffinity = 2;
-    f.n_fit_res = 2, f.fit_res[0] = 0, f.fit_res[1] = 1, f.fit_res_w[0] = 1, f.fit_res_w[1] = 1;
-    f.n_bal_res = 2, f.bal_res[0] = 0, f.bal_res[1] = 1;
-    f.percentage_of_nodes_to_score = percentage;
+    m.profile = prof.c;
 }
 
-RunResult simulate(const Snapshot &s, int64_t max_limit, const std::string &mode_flag, int percentage, int device) {
+RunResult simulate(const Snapshot &s, int64_t max_limit, const std::string &mode_flag, const HostProfile &prof, int device) {
     const Api api = load_api();
     Marshalled m;
-    marshal(s, percentage, m);
+    marshal(s, prof, m);
+    const int percentage = prof.c.percentage_of_nodes_to_score;
     ccsim_config cfg{};
     cfg.abi_version = CCSIM_ABI_VERSION, cfg.device = device, cfg.use_graph = 1;
     ccsim_engine *e = nullptr;
@@ -279,7 +275,8 @@ RunResult result_from_json(const Value &v) {
 
 int usage(const char *msg) {
     std::fprintf(stderr, "%s\nusage: cluster-capacity --podspec FILE --snapshot FILE [--snapshot FILE ...] [--max-limit N] [--exclude-nodes a,b]\n"
-                         "                        [--verbose] [-o json|yaml] [--mode batched|sequential] [--percentage-of-nodes-to-score P] [--device D]\n",
+                         "                        [--default-config FILE] [--verbose] [-o json|yaml] [--mode batched|sequential]\n"
+                         "                        [--percentage-of-nodes-to-score P] [--device D]\n",
                  msg);
     return 2;
 }
@@ -287,7 +284,8 @@ int usage(const char *msg) {
 } // namespace
 
 int main(int argc, char **argv) {
-    std::string podspec, output, mode, dump, fake;
+    std::string podspec, output, mode, dump, fake, sched_config;
+    bool dump_profile = false, pct_flag = false;
     std::vector<std::string> snapshots, exclude;
     int64_t max_limit = 0;
     int percentage = 100, device = 0;
@@ -313,7 +311,9 @@ int main(int argc, char **argv) {
             } else if (a == "--verbose") verbose = true;
             else if (a == "-o" || a == "--output") output = need();
             else if (a == "--mode") mode = need();
-            else if (a == "--percentage-of-nodes-to-score") percentage = std::stoi(need());
+            else if (a == "--percentage-of-nodes-to-score") percentage = std::stoi(need()), pct_flag = true;
+            else if (a == "--default-config") sched_config = need();
+            else if (a == "--dump-profile") dump_profile = true;
             else if (a == "--device") device = std::stoi(need());
             else if (a == "--dump-snapshot") dump = need();
             else if (a == "--fake-result") fake = need();
@@ -325,20 +325,35 @@ int main(int argc, char **argv) {
                 std::cout << out << "\n";
                 return 0;
             }
-            else if (a == "--kubeconfig" || a == "--default-config") return usage(("not supported here: " + a + " (see --snapshot)").c_str());
+            else if (a == "--kubeconfig") return usage("not supported here: --kubeconfig (see --snapshot)");
             else return usage(("unknown flag " + a).c_str());
         } catch (const std::exception &e) {
             return usage(e.what());
         }
     }
+    try { // --default-config: Path to JSON or YAML file containing scheduler configuration (options.go:73)
+        if (dump_profile) {
+            HostProfile hp = profile_from_config(sched_config.empty() ? Value() : parse_documents(read_file(sched_config)).at(0));
+            if (pct_flag) hp.c.percentage_of_nodes_to_score = percentage;
+            std::string out;
+            to_json(out, profile_json(hp));
+            std::cout << out << "\n";
+            return 0;
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "cluster-capacity: %s\n", e.what());
+        return 1;
+    }
     if (podspec.empty()) return usage("Pod spec file is missing"); // options.go / server.go:71-73
     if (snapshots.empty()) return usage("--snapshot is required");
     if (!output.empty() && output != "json" && output != "yaml") return usage("output format must be json or yaml");
     try {
+        HostProfile prof = profile_from_config(sched_config.empty() ? Value() : parse_documents(read_file(sched_config)).at(0));
+        if (pct_flag) prof.c.percentage_of_nodes_to_score = percentage;
         const Value pod = parse_pod_spec(podspec);
         std::vector<Value> node_objs, pod_objs;
         load_objects(snapshots, node_objs, pod_objs);
-        const Snapshot snap = build_snapshot(node_objs, pod_objs, pod, exclude);
+        const Snapshot snap = build_snapshot(node_objs, pod_objs, pod, exclude, prof.hard_pod_affinity_weight);
         if (!dump.empty()) {
             std::string out;
             to_json(out, snapshot_json(snap));
@@ -346,7 +361,7 @@ int main(int argc, char **argv) {
             else std::ofstream(dump) << out << "\n";
             return 0;
         }
-        const RunResult result = fake.empty() ? simulate(snap, max_limit, mode, percentage, device)
+        const RunResult result = fake.empty() ? simulate(snap, max_limit, mode, prof, device)
                                               : result_from_json(parse_documents(read_file(fake)).at(0));
         const Value review = build_review(pod, snap, result, max_limit);
         std::string out;

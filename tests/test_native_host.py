@@ -353,3 +353,98 @@ def test_native_quantity_arithmetic(native, tmp_path):
     d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
     assert d["alloc"][0] == [ingest.milli_value(x) for x in q["cpu"]] == [150, 2000, 100, 2, 1, 100, 2000, 1]
     assert d["alloc"][1] == [ingest.value(x) for x in q["memory"]] == [104857600, 4 << 30, 1000, 1536, 1, 4_000_000_000, 10**18, 1]
+
+
+SCHED_CONFIG = """\
+apiVersion: kubescheduler.config.k8s.io/v1
+kind: KubeSchedulerConfiguration
+percentageOfNodesToScore: 40
+profiles:
+- schedulerName: default-scheduler
+  plugins:
+    multiPoint:
+      enabled:
+      - name: TaintToleration
+        weight: 7
+      disabled:
+      - name: ImageLocality
+    filter:
+      disabled:
+      - name: NodeUnschedulable
+    score:
+      disabled:
+      - name: NodeResourcesBalancedAllocation
+      enabled:
+      - name: NodeAffinity
+      - name: PodTopologySpread
+        weight: 5
+  pluginConfig:
+  - name: NodeResourcesFit
+    args:
+      scoringStrategy:
+        type: LeastAllocated
+        resources:
+        - name: memory
+          weight: 3
+        - name: cpu
+          weight: 1
+  - name: InterPodAffinity
+    args:
+      hardPodAffinityWeight: 10
+"""
+
+
+def _profile(native, tmp_path, text=None, extra=()):
+    args = ["--dump-profile", *extra]
+    if text is not None:
+        (tmp_path / "sched.yaml").write_text(text)
+        args += ["--default-config", str(tmp_path / "sched.yaml")]
+    return json.loads(_run(native, args))
+
+
+def test_native_scheduler_config(native, tmp_path):
+    """--default-config (options.go:73): plugin sets, weights, scoring resources, percentageOfNodesToScore."""
+    d = _profile(native, tmp_path)
+    p = M.Profile.default()
+    assert d == {"filter_mask": p.filter_mask, "w_taint": 3, "w_nodeaffinity": 2, "w_fit": 1, "w_balanced": 1, "w_topologyspread": 2,
+                 "w_interpodaffinity": 2, "fit_res": [0, 1], "fit_res_w": [1, 1], "bal_res": [0, 1], "percentage_of_nodes_to_score": 100,
+                 "hard_pod_affinity_weight": 1}
+    d = _profile(native, tmp_path, SCHED_CONFIG)
+    assert d["filter_mask"] == M.F_ALL & ~M.F_UNSCHEDULABLE
+    assert (d["w_taint"], d["w_nodeaffinity"], d["w_fit"], d["w_balanced"], d["w_topologyspread"], d["w_interpodaffinity"]) == (7, 1, 1, 0, 5, 2)
+    assert d["fit_res"] == [1, 0] and d["fit_res_w"] == [3, 1] and d["bal_res"] == [0, 1]
+    assert d["percentage_of_nodes_to_score"] == 40 and d["hard_pod_affinity_weight"] == 10
+    assert _profile(native, tmp_path, SCHED_CONFIG, ["--percentage-of-nodes-to-score", "100"])["percentage_of_nodes_to_score"] == 100
+    fit_only = """{"kind": "KubeSchedulerConfiguration", "profiles": [{"percentageOfNodesToScore": 0, "plugins": {
+        "multiPoint": {"disabled": [{"name": "*"}], "enabled": [{"name": "NodeResourcesFit"}]}}}]}"""
+    d = _profile(native, tmp_path, fit_only)
+    q = M.Profile.fit_only()
+    assert d["filter_mask"] == q.filter_mask and d["w_fit"] == 1 and d["percentage_of_nodes_to_score"] == 0
+    assert all(d[k] == 0 for k in ("w_taint", "w_nodeaffinity", "w_balanced", "w_topologyspread", "w_interpodaffinity"))
+    for bad in ('{"profiles": [{"plugins": {"score": {"enabled": [{"name": "NoSuchPlugin"}]}}}]}',
+                '{"profiles": [{"pluginConfig": [{"name": "NodeResourcesFit", "args": {"scoringStrategy": {"type": "MostAllocated"}}}]}]}',
+                '{"percentageOfNodesToScore": 101}', '{"profiles": [{}, {}]}'):
+        (tmp_path / "bad.json").write_text(bad)
+        p = subprocess.run([native, "--dump-profile", "--default-config", str(tmp_path / "bad.json")], capture_output=True, text=True)
+        assert p.returncode == 1 and "scheduler config" in p.stderr
+
+
+@pytest.mark.gpu
+def test_native_scheduler_config_end_to_end(native, tmp_path, ccref):
+    """A non-default profile through the native host == the same profile through the Python host's engine binding."""
+    from cluster_capacity_amd import capi
+    nodes, pods, pod, exclude = CASES["taints-selectors"]()
+    nodes += [node(f"x{i}", cpu=["3", "5", "7"][i % 3], mem=["6Gi", "9Gi", "20Gi"][i % 3], labels={"disk": "ssd"}) for i in range(9)]
+    podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
+    (tmp_path / "sched.yaml").write_text(SCHED_CONFIG.replace("percentageOfNodesToScore: 40", "percentageOfNodesToScore: 100"))
+    rev = json.loads(_run(native, ["--podspec", podspec, "--snapshot", snaps[0], "--default-config", str(tmp_path / "sched.yaml"), "-o", "json"]))
+    snap = ingest.build_snapshot(*cli.load_objects(snaps), cli.parse_pod_spec(podspec), hard_pod_affinity_weight=10)
+    prof = M.Profile(filter_mask=M.F_ALL & ~M.F_UNSCHEDULABLE, w_taint=7, w_nodeaffinity=1, w_fit=1, w_balanced=0, w_topologyspread=5,
+                     w_interpodaffinity=2, fit_res=(1, 0), fit_res_w=(3, 1))
+    ref = ccref.run(prof, snap.nodes, snap.pod)
+    got = {r["nodeName"]: r["replicas"] for r in rev["status"]["pods"][0]["replicasOnNodes"]}
+    assert rev["status"]["replicas"] == ref.placed
+    assert got == {snap.names[i]: int(c) for i, c in enumerate(ref.per_node_count) if c}
+    order = [r["nodeName"] for r in rev["status"]["pods"][0]["replicasOnNodes"]]
+    _, first = np.unique(ref.log, return_index=True)
+    assert order == [snap.names[i] for i in ref.log[np.sort(first)]]  # first-placement order == the oracle's sequence
