@@ -40,7 +40,7 @@ def build_all(force: bool = False, verbose: bool = False) -> str:
 
 HOST = os.path.join(HERE, "host")
 HOST_SOURCES = ["main.cpp"]
-HOST_DEPS = ["value.hpp", "quantity.hpp", "snapshot.hpp", "report.hpp", "profile.hpp"]
+HOST_DEPS = ["value.hpp", "quantity.hpp", "snapshot.hpp", "report.hpp", "profile.hpp", "engine.hpp", "cluster_capacity.hpp"]
 
 
 def host_path() -> str:

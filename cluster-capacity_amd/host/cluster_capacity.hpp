@@ -1,0 +1,66 @@
+// cluster_capacity.hpp -- the reference's simulator object (pkg/framework/simulator.go) on the MI355X engine, same method
+// names, same order of use (cmd/cluster-capacity/app/server.go:163-183 runSimulator):
+//
+//     cc := framework.New(kubeSchedulerConfig, restConfig, simulatedPod, maxPods, excludeNodes)   simulator.go:107-158
+//     cc.SyncWithClient(client)    copy Nodes and non-terminal Pods into the simulator              :176-295
+//     cc.Run()                     schedule clones of the pod until Unschedulable / the limit       :356-381
+//     cc.Report()                  ClusterCapacityReview                                             :160-170, report.go:196-225
+//     cc.Close()                                                                                     :314-325
+//
+// Differences, on purpose: there is no API server, so SyncWithClient takes the listed objects themselves; the scheduling
+// loop is ccsim_run on the GPU (exact) instead of one fake-clientset round trip per pod; Status keeps the
+// per-node counts and the placement order instead of one *v1.Pod per clone.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+
+namespace cchost {
+
+class ClusterCapacity {
+  public:
+    struct Status { // simulator.go:90-93
+        RunResult Pods;         // which node every simulated pod landed on (counts + order)
+        std::string StopReason; // "LimitReached: ..." / "Unschedulable: <FitError>"
+    };
+    int device = 0;
+    std::string mode; // "" = batched unless the pod couples nodes or the search is sampled
+
+    static ClusterCapacity New(const HostProfile &kubeSchedulerConfig, Value simulatedPod, int64_t maxPods, std::vector<std::string> excludeNodes) {
+        ClusterCapacity c;
+        c.profile_ = kubeSchedulerConfig, c.pod_ = std::move(simulatedPod), c.max_simulated_ = maxPods, c.exclude_ = std::move(excludeNodes);
+        return c;
+    }
+    void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods) {
+        snap_ = build_snapshot(nodes, pods, pod_, exclude_, profile_.hard_pod_affinity_weight);
+        synced_ = true;
+    }
+    void Run() {
+        if (!synced_) throw std::runtime_error("ClusterCapacity.Run before SyncWithClient");
+        SetResult(simulate(snap_, max_simulated_, mode, profile_, device));
+    }
+    void SetResult(RunResult r) { // (test hook: a result that did not come from the engine)
+        status_.Pods = std::move(r);
+        status_.StopReason = stop_reason(status_.Pods, (int64_t)snap_.n(), max_simulated_, snap_.taint_reasons, snap_.scalar_names);
+        ran_ = true;
+    }
+    Value Report() const {
+        if (!ran_) throw std::runtime_error("ClusterCapacity.Report before Run");
+        return build_review(pod_, snap_, status_.Pods, max_simulated_);
+    }
+    const Status &GetStatus() const { return status_; }
+    const Snapshot &snapshot() const { return snap_; }
+    void Close() { synced_ = ran_ = false; }
+
+  private:
+    HostProfile profile_;
+    Value pod_;
+    int64_t max_simulated_ = 0;
+    std::vector<std::string> exclude_;
+    Snapshot snap_;
+    Status status_;
+    bool synced_ = false, ran_ = false;
+};
+
+} // namespace cchost

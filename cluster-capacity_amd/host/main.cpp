@@ -23,9 +23,7 @@
 #include <iostream>
 #include <sstream>
 
-#include "profile.hpp"
-#include "report.hpp"
-#include "snapshot.hpp"
+#include "cluster_capacity.hpp"
 
 using namespace cchost;
 
@@ -76,191 +74,6 @@ Value parse_pod_spec(const std::string &path) {
     }
     if (!pod["spec"]["containers"].truthy()) throw std::runtime_error("Invalid pod: spec.containers: Required value");
     return pod;
-}
-
-// ---- the engine, bound at run time (the same entry points the cgo shim of INTEGRATION.md binds) ---------------------------
-struct Api {
-    void *h = nullptr;
-    int32_t (*abi_version)() = nullptr;
-    int (*create)(const ccsim_config *, ccsim_engine **) = nullptr;
-    void (*destroy)(ccsim_engine *) = nullptr;
-    const char *(*last_error)(const ccsim_engine *) = nullptr;
-    int (*load_nodes)(ccsim_engine *, const ccsim_nodes *) = nullptr;
-    int (*set_profile)(ccsim_engine *, const ccsim_profile *) = nullptr;
-    int (*set_pod)(ccsim_engine *, const ccsim_pod *) = nullptr;
-    int (*run)(ccsim_engine *, int64_t, int32_t, ccsim_report *) = nullptr;
-};
-
-std::string exe_dir() {
-    char buf[PATH_MAX];
-    const ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1);
-    if (n <= 0) return ".";
-    buf[n] = 0;
-    std::string p(buf);
-    return p.substr(0, p.find_last_of('/'));
-}
-
-Api load_api() {
-    Api a;
-    std::vector<std::string> candidates;
-    if (const char *e = getenv("CCSIM_LIB")) candidates.push_back(e);
-    candidates.push_back(exe_dir() + "/../csrc/libccsim.so");
-    candidates.push_back(exe_dir() + "/libccsim.so");
-    candidates.push_back("libccsim.so");
-    std::string errs;
-    for (const auto &c : candidates) {
-        a.h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (a.h) break;
-        errs += std::string("\n  ") + dlerror();
-    }
-    if (!a.h) throw std::runtime_error("the MI355X engine (libccsim.so) could not be loaded; there is no CPU fallback:" + errs);
-    auto sym = [&](const char *name) {
-        void *p = dlsym(a.h, name);
-        if (!p) throw std::runtime_error(std::string("libccsim.so lacks ") + name);
-        return p;
-    };
-    a.abi_version = (int32_t(*)())sym("ccsim_abi_version");
-    a.create = (int (*)(const ccsim_config *, ccsim_engine **))sym("ccsim_create");
-    a.destroy = (void (*)(ccsim_engine *))sym("ccsim_destroy");
-    a.last_error = (const char *(*)(const ccsim_engine *))sym("ccsim_last_error");
-    a.load_nodes = (int (*)(ccsim_engine *, const ccsim_nodes *))sym("ccsim_load_nodes");
-    a.set_profile = (int (*)(ccsim_engine *, const ccsim_profile *))sym("ccsim_set_profile");
-    a.set_pod = (int (*)(ccsim_engine *, const ccsim_pod *))sym("ccsim_set_pod");
-    a.run = (int (*)(ccsim_engine *, int64_t, int32_t, ccsim_report *))sym("ccsim_run");
-    if (a.abi_version() != CCSIM_ABI_VERSION) throw std::runtime_error("libccsim ABI version mismatch");
-    return a;
-}
-
-// Snapshot -> the structs of include/ccsim.h (pointers into the snapshot and into `hold`)
-struct Marshalled {
-    ccsim_nodes nodes{};
-    ccsim_pod pod{};
-    ccsim_profile profile{};
-    std::vector<ccsim_requirement> reqs;
-    std::vector<uint8_t> tables;
-    std::vector<ccsim_term> required, preferred;
-};
-
-void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
-    const int64_t N = (int64_t)s.n();
-    ccsim_nodes &n = m.nodes;
-    n.n_nodes = N, n.global_offset = 0, n.n_global = N, n.n_scalar = (int32_t)s.scalar_names.size();
-    for (size_t c = 0; c < s.alloc.size(); c++) n.alloc[c] = s.alloc[c].data(), n.req[c] = s.req[c].data();
-    n.alloc_pods = s.alloc_pods.data(), n.nz_mcpu = s.nz_mcpu.data(), n.nz_mem = s.nz_mem.data(), n.pod_count = s.pod_count.data();
-    n.taintset_id = s.taintset_id.data(), n.unschedulable = s.unschedulable.data();
-    n.n_label_cols = (int32_t)s.label_cols.size();
-    for (size_t c = 0; c < s.label_cols.size(); c++) n.label_cols[c] = s.label_cols[c].data();
-
-    ccsim_pod &p = m.pod;
-    for (size_t c = 0; c < s.preq.size(); c++) p.req[c] = s.preq[c];
-    p.has_scalar_entries = s.has_scalar_entries, p.nz_mcpu = s.pod_nz_cpu, p.nz_mem = s.pod_nz_mem;
-    p.n_taintsets = (int32_t)s.taint_filter_ok.size();
-    p.taint_filter_ok = s.taint_filter_ok.data(), p.taint_prefer_cnt = s.taint_prefer_cnt.data();
-    p.tolerates_unschedulable = s.tolerates_unschedulable, p.affinity_filter_active = s.affinity_filter_active;
-    auto add_term = [&](const Term &t, int weight) {
-        ccsim_term ct{(int32_t)m.reqs.size(), (int32_t)t.size(), weight};
-        for (const auto &r : t) {
-            m.reqs.push_back(ccsim_requirement{r.col, (int32_t)m.tables.size()});
-            m.tables.insert(m.tables.end(), r.table.begin(), r.table.end());
-        }
-        return ct;
-    };
-    p.has_node_selector = s.has_node_selector;
-    p.node_selector = add_term(s.node_selector, 0);
-    p.has_required_terms = s.has_required_terms;
-    for (const auto &t : s.required) m.required.push_back(add_term(t, 0));
-    for (const auto &t : s.preferred) m.preferred.push_back(add_term(t.second, t.first));
-    const int32_t n_reqs = (int32_t)m.reqs.size();
-    if (m.required.empty()) m.required.push_back(ccsim_term{}); // (never dereferenced: the counts below stay 0)
-    if (m.preferred.empty()) m.preferred.push_back(ccsim_term{});
-    if (m.reqs.empty()) m.reqs.push_back(ccsim_requirement{});
-    if (m.tables.empty()) m.tables.push_back(0);
-    p.n_required = (int32_t)s.required.size(), p.required = m.required.data();
-    p.n_preferred = (int32_t)s.preferred.size(), p.preferred = m.preferred.data();
-    p.n_reqs = n_reqs, p.reqs = m.reqs.data();
-    p.req_tables_len = (int64_t)m.tables.size(), p.req_tables = m.tables.data();
-    p.n_spread = (int32_t)s.spread.size();
-    for (size_t i = 0; i < s.spread.size(); i++) {
-        const Spread &k = s.spread[i];
-        ccsim_spread_constraint &c = p.spread[i];
-        c.col = k.col, c.max_skew = k.max_skew, c.min_domains = k.min_domains, c.hard = k.hard, c.self_match = k.self_match;
-        c.n_domains = k.n_domains, c.is_hostname = k.is_hostname;
-        c.node_match_count = k.node_match_count.empty() ? nullptr : k.node_match_count.data();
-        c.node_included = k.use_included ? s.included.data() : nullptr;
-    }
-    p.has_ipa = s.has_ipa;
-    if (s.has_ipa) {
-        const Ipa &a = s.ipa;
-        ccsim_ipa &c = p.ipa;
-        c.n_keys = (int32_t)a.key_cols.size();
-        for (int k = 0; k < c.n_keys; k++) {
-            c.key_col[k] = a.key_cols[(size_t)k], c.key_ndom[k] = a.key_ndom[(size_t)k];
-            c.exist_anti[k] = a.exist_anti[(size_t)k].empty() ? nullptr : a.exist_anti[(size_t)k].data();
-            c.score_existing[k] = a.score_existing[(size_t)k].empty() ? nullptr : a.score_existing[(size_t)k].data();
-            c.score_self[k] = a.score_self[(size_t)k], c.self_entries[k] = a.self_entries[(size_t)k];
-        }
-        c.n_aff_terms = (int32_t)a.aff_keys.size();
-        for (size_t t = 0; t < a.aff_keys.size(); t++) c.aff_key[t] = a.aff_keys[t];
-        c.self_aff = a.self_aff;
-        c.aff_existing = a.aff_existing.empty() ? nullptr : a.aff_existing.data();
-        c.n_anti_terms = (int32_t)a.anti_keys.size();
-        for (size_t t = 0; t < a.anti_keys.size(); t++) {
-            c.anti_key[t] = a.anti_keys[t], c.anti_self[t] = a.anti_self[t];
-            c.anti_existing[t] = a.anti_existing[t].empty() ? nullptr : a.anti_existing[t].data();
-        }
-        c.entries_existing = a.entries_existing;
-    }
-    m.profile = prof.c;
-}
-
-RunResult simulate(const Snapshot &s, int64_t max_limit, const std::string &mode_flag, const HostProfile &prof, int device) {
-    const Api api = load_api();
-    Marshalled m;
-    marshal(s, prof, m);
-    const int percentage = prof.c.percentage_of_nodes_to_score;
-    ccsim_config cfg{};
-    cfg.abi_version = CCSIM_ABI_VERSION, cfg.device = device, cfg.use_graph = 1;
-    ccsim_engine *e = nullptr;
-    int rc = api.create(&cfg, &e);
-    if (rc != 0 || !e) throw std::runtime_error("ccsim_create failed rc=" + std::to_string(rc) + " (is a HIP device visible?)");
-    auto chk = [&](int r, const char *what) {
-        if (r != 0) {
-            const std::string msg = api.last_error(e) ? api.last_error(e) : "";
-            api.destroy(e);
-            throw std::runtime_error(std::string(what) + " failed rc=" + std::to_string(r) + ": " + msg);
-        }
-    };
-    chk(api.load_nodes(e, &m.nodes), "ccsim_load_nodes");
-    chk(api.set_profile(e, &m.profile), "ccsim_set_profile");
-    chk(api.set_pod(e, &m.pod), "ccsim_set_pod");
-    // a pod that couples nodes through topology domains, or a sampled search, is order-dependent: the literal loop
-    const bool coupled = !s.spread.empty() || s.has_ipa;
-    const bool sampled = percentage != 100 && s.n() >= 100;
-    const int32_t mode = mode_flag == "sequential" ? CCSIM_MODE_SEQUENTIAL : mode_flag == "batched" ? CCSIM_MODE_BATCHED
-                         : (coupled || sampled ? CCSIM_MODE_SEQUENTIAL : CCSIM_MODE_BATCHED);
-    int64_t cap = max_limit;
-    if (cap <= 0) {
-        cap = 0;
-        for (const auto x : s.alloc_pods) cap += x;
-        cap = std::min<int64_t>(cap, (int64_t)1 << 26);
-    }
-    cap = std::max<int64_t>(cap, 1);
-    RunResult r;
-    r.per_node_count.assign(std::max<size_t>(s.n(), 1), 0);
-    r.log.assign((size_t)cap, 0);
-    r.hist_taintset.assign(std::max<size_t>(s.taint_filter_ok.size(), 1), 0);
-    ccsim_report rep{};
-    rep.per_node_count = r.per_node_count.data(), rep.per_node_cap = (int64_t)r.per_node_count.size();
-    rep.log = r.log.data(), rep.log_cap = cap;
-    rep.hist_taintset = r.hist_taintset.data(), rep.hist_taintset_cap = (int32_t)r.hist_taintset.size();
-    chk(api.run(e, max_limit, mode, &rep), "ccsim_run");
-    api.destroy(e);
-    r.placed = rep.placed, r.stop = rep.stop, r.n_code_unschedulable = rep.n_code_unschedulable;
-    r.per_node_count.resize(s.n());
-    r.log.resize((size_t)std::min<int64_t>(rep.log_len, cap));
-    r.hist.assign(rep.hist, rep.hist + CCSIM_NREASON);
-    r.hist_taintset.resize(s.taint_filter_ok.size());
-    return r;
 }
 
 RunResult result_from_json(const Value &v) {
@@ -350,20 +163,23 @@ int main(int argc, char **argv) {
     try {
         HostProfile prof = profile_from_config(sched_config.empty() ? Value() : parse_documents(read_file(sched_config)).at(0));
         if (pct_flag) prof.c.percentage_of_nodes_to_score = percentage;
-        const Value pod = parse_pod_spec(podspec);
+        // runSimulator (cmd/cluster-capacity/app/server.go:163-183): New -> SyncWithClient -> Run -> Report
+        ClusterCapacity cc = ClusterCapacity::New(prof, parse_pod_spec(podspec), max_limit, exclude);
+        cc.device = device, cc.mode = mode;
         std::vector<Value> node_objs, pod_objs;
         load_objects(snapshots, node_objs, pod_objs);
-        const Snapshot snap = build_snapshot(node_objs, pod_objs, pod, exclude, prof.hard_pod_affinity_weight);
+        cc.SyncWithClient(node_objs, pod_objs);
         if (!dump.empty()) {
             std::string out;
-            to_json(out, snapshot_json(snap));
+            to_json(out, snapshot_json(cc.snapshot()));
             if (dump == "-") std::cout << out << "\n";
             else std::ofstream(dump) << out << "\n";
             return 0;
         }
-        const RunResult result = fake.empty() ? simulate(snap, max_limit, mode, prof, device)
-                                              : result_from_json(parse_documents(read_file(fake)).at(0));
-        const Value review = build_review(pod, snap, result, max_limit);
+        if (fake.empty()) cc.Run();
+        else cc.SetResult(result_from_json(parse_documents(read_file(fake)).at(0)));
+        const Value review = cc.Report();
+        cc.Close();
         std::string out;
         if (output == "json") to_json(out, review), out += "\n";
         else if (output == "yaml") to_yaml(out, review);
