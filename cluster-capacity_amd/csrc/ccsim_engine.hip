@@ -1072,7 +1072,11 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         collect_pass_times(e);
         if (e->h_state->done) break;
         // every pass either places a pod or (at most twice in a row) re-derives the normalization constants
-        if (rounds >= 8 && e->h_state->placed == placed0) return fail(e, -EIO, "simulation made no progress in %d passes", rounds);
+        if (rounds >= 8 && e->h_state->placed == placed0) {
+            launch_rows_flush(e, false); // leave the columns consistent with what was committed so far
+            (void)hipStreamSynchronize(e->stream);
+            return fail(e, -EIO, "simulation made no progress in %d passes", rounds);
+        }
     }
     launch_rows_flush(e, false); // the columns are the state every other entry point reads
     return fill_report(e, out);
