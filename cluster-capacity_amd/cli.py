@@ -6,7 +6,7 @@
 Flags mirror cmd/cluster-capacity/app/options/options.go:65-77.  There is no API server to talk to here, so
 `--kubeconfig` is replaced by `--snapshot`: files holding the Node and Pod objects `SyncWithClient` would list
 (pkg/framework/simulator.go:176-295) -- `kubectl get nodes,pods -A -o yaml` output, a `List`, or multi-document YAML.
-`--default-config` (a KubeSchedulerConfiguration) is not parsed: the default profile is used.
+`--default-config` takes a KubeSchedulerConfiguration (schedconfig.py: what the engine can express of it).
 
 Output formats mirror pkg/framework/report.go:235-317 (pretty / json / yaml).  The simulation itself runs on the
 GPU through the C ABI (capi.Engine); there is no CPU fallback.
@@ -22,7 +22,7 @@ from typing import List, Optional
 import numpy as np
 import yaml
 
-from . import ingest, model as M, report as R
+from . import ingest, model as M, report as R, schedconfig
 
 
 def load_objects(paths: List[str]):
@@ -135,7 +135,7 @@ def pretty(review: dict, verbose: bool) -> str:
 
 
 def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, device: int = 0,
-             percentage_of_nodes_to_score: int = 100) -> M.RunResult:
+             percentage_of_nodes_to_score: int = 100, profile: Optional[M.Profile] = None) -> M.RunResult:
     from . import capi
 
     coupled = bool(snap.pod.spread) or snap.pod.ipa is not None
@@ -143,7 +143,7 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
     sampled = percentage_of_nodes_to_score != 100 and snap.nodes.n >= 100
     mode = mode or ("sequential" if coupled or sampled else "batched")
     eng = capi.Engine(device=device)
-    prof = M.Profile.default()
+    prof = profile or M.Profile.default()
     prof.percentage_of_nodes_to_score = percentage_of_nodes_to_score
     eng.load(snap.nodes, snap.pod, prof)
     cap = max_limit if max_limit > 0 else int(min(int(snap.nodes.alloc_pods.astype(np.int64).sum()), 1 << 26))
@@ -162,15 +162,22 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     ap.add_argument("--verbose", action="store_true", help="Verbose mode")
     ap.add_argument("-o", "--output", default="", choices=["", "json", "yaml"], help="Output format. One of: json|yaml")
     ap.add_argument("--mode", default=None, choices=["batched", "sequential"], help="engine mode (default: batched unless the pod couples nodes)")
-    ap.add_argument("--percentage-of-nodes-to-score", type=int, default=100,
+    ap.add_argument("--default-config", default="", help="Path to JSON or YAML file containing scheduler configuration.")
+    ap.add_argument("--percentage-of-nodes-to-score", type=int, default=None,
                     help="KubeSchedulerConfiguration.percentageOfNodesToScore: 100 scores every node (the final capacity and "
                          "distribution do not depend on it for pods without topology constraints); 0 = the scheduler's adaptive default")
     args = ap.parse_args(argv)
 
+    cfg = None
+    if args.default_config:
+        with open(args.default_config) as f:
+            cfg = yaml.safe_load(f)
+    prof, hard_weight = schedconfig.profile_from_config(cfg)
+    pct = args.percentage_of_nodes_to_score if args.percentage_of_nodes_to_score is not None else prof.percentage_of_nodes_to_score
     pod = parse_pod_spec(args.podspec)
     node_objs, pod_objs = load_objects(args.snapshot)
-    snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x])
-    result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=args.percentage_of_nodes_to_score)
+    snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight)
+    result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=pct, profile=prof)
     review = build_review(pod, snap, result, args.max_limit)
     if args.output == "json":
         out.write(json.dumps(review) + "\n")

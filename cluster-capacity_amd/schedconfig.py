@@ -1,0 +1,137 @@
+"""KubeSchedulerConfiguration (--default-config, cmd/cluster-capacity/app/options/options.go:73, server.go:106-113)
+-> model.Profile.  Python mirror of cluster-capacity_amd/host/profile.hpp (same semantics, checked against it in
+tests/test_native_host.py): which of the engine's Filter plugins run, the Score plugins' weights, the resource lists of
+NodeResourcesFit (LeastAllocated) / NodeResourcesBalancedAllocation, percentageOfNodesToScore (global or per profile,
+schedule_one.go:702-708), InterPodAffinity's hardPodAffinityWeight.  Merge semantics follow the scheduler's
+(S/apis/config/v1/default_plugins.go:30-58,77-140; S/framework/runtime/framework.go:506-640): multiPoint applies to every
+extension point a plugin implements, `disabled: [{name: "*"}]` clears a point, a specific point overrides multiPoint, a
+Score plugin enabled without a weight gets 1."""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional, Tuple
+
+from . import model as M
+
+# name -> (filter bit, Profile weight field, default weight)
+PLUGINS = {
+    "NodeUnschedulable": (M.F_UNSCHEDULABLE, None, 0),
+    "NodeName": (M.F_NODENAME, None, 0),
+    "TaintToleration": (M.F_TAINT, "w_taint", 3),
+    "NodeAffinity": (M.F_NODEAFFINITY, "w_nodeaffinity", 2),
+    "NodeResourcesFit": (M.F_FIT, "w_fit", 1),
+    "NodeResourcesBalancedAllocation": (0, "w_balanced", 1),
+    "PodTopologySpread": (M.F_TOPOLOGYSPREAD, "w_topologyspread", 2),
+    "InterPodAffinity": (M.F_INTERPODAFFINITY, "w_interpodaffinity", 2),
+}
+# default plugins whose Filter / Score is a no-op for the pods this simulator accepts: accepted, ignored
+FOLDED_AWAY = {"SchedulingGates", "PrioritySort", "NodePorts", "VolumeRestrictions", "NodeVolumeLimits", "EBSLimits", "GCEPDLimits",
+               "AzureDiskLimits", "VolumeBinding", "VolumeZone", "DynamicResources", "DefaultPreemption", "ImageLocality",
+               "DefaultBinder", "ClusterCapacityBinder"}
+
+
+class ConfigError(ValueError):
+    pass
+
+
+def _column(name: str) -> int:
+    if name == "cpu":
+        return 0
+    if name == "memory":
+        return 1
+    raise ConfigError(f"scheduler config: scoring resource '{name}' is not supported by the engine (cpu and memory are)")
+
+
+def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
+    """-> (Profile, hardPodAffinityWeight)."""
+    p = dataclasses.asdict(M.Profile.default())
+    hard = 1
+    if not cfg:
+        return M.Profile(**p), hard
+    if cfg.get("kind") and cfg["kind"] != "KubeSchedulerConfiguration":
+        raise ConfigError("scheduler config: kind is not KubeSchedulerConfiguration")
+    if cfg.get("percentageOfNodesToScore") is not None:
+        p["percentage_of_nodes_to_score"] = int(cfg["percentageOfNodesToScore"])
+    profiles = cfg.get("profiles") or []
+    if len(profiles) > 1:
+        raise ConfigError("scheduler config: one profile only (the simulated pod is scheduled by Profiles[0])")
+    prof = (profiles[0] if profiles else None) or {}
+    if prof.get("percentageOfNodesToScore") is not None:
+        p["percentage_of_nodes_to_score"] = int(prof["percentageOfNodesToScore"])
+
+    def lookup(name):
+        if name in PLUGINS:
+            return PLUGINS[name]
+        if name in FOLDED_AWAY:
+            return None
+        raise ConfigError(f"scheduler config: unknown plugin '{name}'")
+
+    def set_filter(info, on):
+        if info[0]:
+            p["filter_mask"] = (p["filter_mask"] | info[0]) if on else (p["filter_mask"] & ~info[0])
+
+    def set_score(info, w):
+        if info[1]:
+            p[info[1]] = w
+
+    def apply(pset, do_filter, do_score, multipoint):
+        pset = pset or {}
+        for d in pset.get("disabled") or []:
+            name = d.get("name", "")
+            infos = list(PLUGINS.values()) if name == "*" else [lookup(name)]
+            for info in infos:
+                if info is None:
+                    continue
+                if do_filter:
+                    set_filter(info, False)
+                if do_score:
+                    set_score(info, 0)
+        for e in pset.get("enabled") or []:
+            info = lookup(e.get("name", ""))
+            if info is None:
+                continue
+            if do_filter:
+                set_filter(info, True)
+            if do_score and info[1]:
+                w = int(e.get("weight") or 0)
+                if w < 0 or w > 100 * 1000:
+                    raise ConfigError(f"scheduler config: bad weight for {e.get('name')}")
+                set_score(info, w if w > 0 else (info[2] if multipoint else 1))
+
+    plugins = prof.get("plugins") or {}
+    apply(plugins.get("multiPoint"), True, True, True)
+    apply(plugins.get("filter"), True, False, False)
+    apply(plugins.get("score"), False, True, False)
+
+    for pc in prof.get("pluginConfig") or []:
+        name, args = pc.get("name", ""), pc.get("args") or {}
+        if name == "NodeResourcesFit":
+            st = args.get("scoringStrategy") or {}
+            if st:
+                typ = st.get("type") or "LeastAllocated"
+                if typ != "LeastAllocated":
+                    raise ConfigError(f"scheduler config: NodeResourcesFit scoringStrategy {typ} is not implemented (LeastAllocated is)")
+                if st.get("resources"):
+                    p["fit_res"] = tuple(_column(r["name"]) for r in st["resources"])
+                    p["fit_res_w"] = tuple(int(r.get("weight") or 1) for r in st["resources"])
+            if args.get("ignoredResources") or args.get("ignoredResourceGroups"):
+                raise ConfigError("scheduler config: NodeResourcesFit ignoredResources are not implemented")
+        elif name == "NodeResourcesBalancedAllocation":
+            if args.get("resources"):
+                p["bal_res"] = tuple(_column(r["name"]) for r in args["resources"])
+        elif name == "InterPodAffinity":
+            if "hardPodAffinityWeight" in args:
+                hard = int(args["hardPodAffinityWeight"] or 0)
+            if args.get("ignorePreferredTermsOfExistingPods"):
+                raise ConfigError("scheduler config: ignorePreferredTermsOfExistingPods is not implemented")
+        elif name == "PodTopologySpread":
+            if args.get("defaultConstraints"):
+                raise ConfigError("scheduler config: PodTopologySpread defaultConstraints are not implemented")
+        elif name == "NodeAffinity":
+            if args.get("addedAffinity"):
+                raise ConfigError("scheduler config: NodeAffinity addedAffinity is not implemented")
+        elif name not in FOLDED_AWAY and name not in PLUGINS:
+            raise ConfigError(f"scheduler config: pluginConfig for unknown plugin '{name}'")
+    if not 0 <= p["percentage_of_nodes_to_score"] <= 100:
+        raise ConfigError("scheduler config: percentageOfNodesToScore out of [0,100] (validation.go:86-90)")
+    return M.Profile(**p), hard

@@ -448,3 +448,53 @@ def test_native_scheduler_config_end_to_end(native, tmp_path, ccref):
     order = [r["nodeName"] for r in rev["status"]["pods"][0]["replicasOnNodes"]]
     _, first = np.unique(ref.log, return_index=True)
     assert order == [snap.names[i] for i in ref.log[np.sort(first)]]  # first-placement order == the oracle's sequence
+
+
+def _py_profile_dump(cfg):
+    from cluster_capacity_amd import schedconfig
+    p, hard = schedconfig.profile_from_config(cfg)
+    return {"filter_mask": p.filter_mask, "w_taint": p.w_taint, "w_nodeaffinity": p.w_nodeaffinity, "w_fit": p.w_fit, "w_balanced": p.w_balanced,
+            "w_topologyspread": p.w_topologyspread, "w_interpodaffinity": p.w_interpodaffinity, "fit_res": list(p.fit_res),
+            "fit_res_w": list(p.fit_res_w), "bal_res": list(p.bal_res), "percentage_of_nodes_to_score": p.percentage_of_nodes_to_score,
+            "hard_pod_affinity_weight": hard}
+
+
+def test_scheduler_config_native_and_python_hosts_agree(native, tmp_path):
+    """Differential: random KubeSchedulerConfigurations through host/profile.hpp and schedconfig.py."""
+    from cluster_capacity_amd import schedconfig
+    assert _profile(native, tmp_path, SCHED_CONFIG) == _py_profile_dump(yaml.safe_load(SCHED_CONFIG))
+    names = list(schedconfig.PLUGINS) + ["ImageLocality", "VolumeBinding", "NodePorts"]
+    rng = np.random.default_rng(11)
+
+    def pset(with_weight):
+        out = {}
+        if rng.random() < 0.6:
+            out["disabled"] = [{"name": str(rng.choice(names + ["*"]))} for _ in range(int(rng.integers(0, 3)))]
+        if rng.random() < 0.7:
+            en = []
+            for _ in range(int(rng.integers(0, 4))):
+                e = {"name": str(rng.choice(names))}
+                if with_weight and rng.random() < 0.6:
+                    e["weight"] = int(rng.integers(0, 12))
+                en.append(e)
+            out["enabled"] = en
+        return out
+
+    for i in range(60):
+        prof = {"plugins": {k: pset(k != "filter") for k in ("multiPoint", "filter", "score") if rng.random() < 0.7}}
+        if rng.random() < 0.5:
+            prof["percentageOfNodesToScore"] = int(rng.integers(0, 101))
+        pc = []
+        if rng.random() < 0.5:
+            res = [{"name": str(n), "weight": int(rng.integers(1, 5))} for n in rng.permutation(["cpu", "memory"])[: int(rng.integers(1, 3))]]
+            pc.append({"name": "NodeResourcesFit", "args": {"scoringStrategy": {"type": "LeastAllocated", "resources": res}}})
+        if rng.random() < 0.4:
+            pc.append({"name": "NodeResourcesBalancedAllocation", "args": {"resources": [{"name": "memory", "weight": 1}, {"name": "cpu", "weight": 1}]}})
+        if rng.random() < 0.4:
+            pc.append({"name": "InterPodAffinity", "args": {"hardPodAffinityWeight": int(rng.integers(0, 20))}})
+        prof["pluginConfig"] = pc
+        cfg = {"apiVersion": "kubescheduler.config.k8s.io/v1", "kind": "KubeSchedulerConfiguration", "profiles": [prof]}
+        if rng.random() < 0.4:
+            cfg["percentageOfNodesToScore"] = int(rng.integers(0, 101))
+        text = yaml.safe_dump(cfg) if i % 2 else json.dumps(cfg)
+        assert _profile(native, tmp_path, text) == _py_profile_dump(cfg), cfg
