@@ -1,0 +1,182 @@
+/* abi_recorder.c -- TEST INFRASTRUCTURE.  A stand-in for libccsim.so that RECORDS what a host passes through the C ABI
+ * (include/ccsim.h) and schedules nothing: ccsim_run returns a canned, obviously artificial result (one pod on every
+ * node, LimitReached).  tests/test_native_host.py points the native host at it (CCSIM_LIB) to check, without a GPU, that
+ * the structs the C++ host marshals equal the ones the Python binding marshals from the same snapshot.
+ * The recording goes to the file named by $CCSIM_RECORD as JSON. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/ccsim.h"
+
+struct ccsim_engine {
+    FILE *f;
+    int64_t n;
+    int n_taintsets;
+    int first;
+};
+
+static void arr64(FILE *f, const char *k, const int64_t *p, int64_t n) {
+    fprintf(f, "\"%s\": ", k);
+    if (!p) { fprintf(f, "null"); return; }
+    fprintf(f, "[");
+    for (int64_t i = 0; i < n; i++) fprintf(f, "%s%lld", i ? ", " : "", (long long)p[i]);
+    fprintf(f, "]");
+}
+static void arr32(FILE *f, const char *k, const int32_t *p, int64_t n) {
+    fprintf(f, "\"%s\": ", k);
+    if (!p) { fprintf(f, "null"); return; }
+    fprintf(f, "[");
+    for (int64_t i = 0; i < n; i++) fprintf(f, "%s%d", i ? ", " : "", p[i]);
+    fprintf(f, "]");
+}
+static void arr8(FILE *f, const char *k, const uint8_t *p, int64_t n) {
+    fprintf(f, "\"%s\": ", k);
+    if (!p) { fprintf(f, "null"); return; }
+    fprintf(f, "[");
+    for (int64_t i = 0; i < n; i++) fprintf(f, "%s%d", i ? ", " : "", (int)p[i]);
+    fprintf(f, "]");
+}
+static void sep(ccsim_engine *e) { fprintf(e->f, e->first ? "" : ",\n"), e->first = 0; }
+
+int32_t ccsim_abi_version(void) { return CCSIM_ABI_VERSION; }
+const char *ccsim_last_error(const ccsim_engine *e) { (void)e; return "abi recorder"; }
+
+int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
+    const char *path = getenv("CCSIM_RECORD");
+    if (!path || !cfg || cfg->abi_version != CCSIM_ABI_VERSION) return -22;
+    ccsim_engine *e = (ccsim_engine *)calloc(1, sizeof *e);
+    e->f = fopen(path, "w");
+    if (!e->f) return -5;
+    e->first = 1;
+    fprintf(e->f, "{\n");
+    sep(e);
+    fprintf(e->f, "\"config\": {\"device\": %d, \"use_graph\": %d, \"time_passes\": %d, \"stream_is_null\": %d}", cfg->device, cfg->use_graph,
+            cfg->time_passes, cfg->stream == NULL);
+    *out = e;
+    return 0;
+}
+
+void ccsim_destroy(ccsim_engine *e) {
+    if (!e) return;
+    fprintf(e->f, "\n}\n");
+    fclose(e->f);
+    free(e);
+}
+
+int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *n) {
+    FILE *f = e->f;
+    e->n = n->n_nodes;
+    sep(e);
+    fprintf(f, "\"nodes\": {\"n_nodes\": %lld, \"global_offset\": %lld, \"n_global\": %lld, \"n_scalar\": %d, \"n_label_cols\": %d, ", (long long)n->n_nodes,
+            (long long)n->global_offset, (long long)n->n_global, n->n_scalar, n->n_label_cols);
+    fprintf(f, "\"alloc\": [");
+    for (int c = 0; c < 3 + n->n_scalar; c++) { fprintf(f, "%s{", c ? ", " : ""); arr64(f, "v", n->alloc[c], n->n_nodes); fprintf(f, "}"); }
+    fprintf(f, "], \"req\": [");
+    for (int c = 0; c < 3 + n->n_scalar; c++) { fprintf(f, "%s{", c ? ", " : ""); arr64(f, "v", n->req[c], n->n_nodes); fprintf(f, "}"); }
+    fprintf(f, "], \"label_cols\": [");
+    for (int c = 0; c < n->n_label_cols; c++) { fprintf(f, "%s{", c ? ", " : ""); arr32(f, "v", n->label_cols[c], n->n_nodes); fprintf(f, "}"); }
+    fprintf(f, "], ");
+    arr32(f, "alloc_pods", n->alloc_pods, n->n_nodes), fprintf(f, ", ");
+    arr64(f, "nz_mcpu", n->nz_mcpu, n->n_nodes), fprintf(f, ", ");
+    arr64(f, "nz_mem", n->nz_mem, n->n_nodes), fprintf(f, ", ");
+    arr32(f, "pod_count", n->pod_count, n->n_nodes), fprintf(f, ", ");
+    arr32(f, "taintset_id", n->taintset_id, n->n_nodes), fprintf(f, ", ");
+    arr8(f, "unschedulable", n->unschedulable, n->n_nodes);
+    fprintf(f, "}");
+    return 0;
+}
+
+int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
+    FILE *f = e->f;
+    sep(e);
+    fprintf(f, "\"profile\": {\"filter_mask\": %u, \"w\": [%d, %d, %d, %d, %d, %d], \"pct\": %d, ", p->filter_mask, p->w_taint, p->w_nodeaffinity, p->w_fit,
+            p->w_balanced, p->w_topologyspread, p->w_interpodaffinity, p->percentage_of_nodes_to_score);
+    arr32(f, "fit_res", p->fit_res, p->n_fit_res), fprintf(f, ", ");
+    arr64(f, "fit_res_w", p->fit_res_w, p->n_fit_res), fprintf(f, ", ");
+    arr32(f, "bal_res", p->bal_res, p->n_bal_res);
+    fprintf(f, "}");
+    return 0;
+}
+
+static void term(FILE *f, const ccsim_pod *p, const ccsim_term *t) { /* resolved: [weight, [[col, table...], ...]] */
+    fprintf(f, "[%d, [", t->weight);
+    for (int i = 0; i < t->n_req; i++) {
+        const ccsim_requirement *r = &p->reqs[t->first_req + i];
+        /* the table's length is not part of the ABI: it ends where the next requirement's begins (or at req_tables_len) */
+        int64_t end = p->req_tables_len;
+        for (int j = 0; j < p->n_reqs; j++)
+            if (p->reqs[j].table_off > r->table_off && p->reqs[j].table_off < end) end = p->reqs[j].table_off;
+        fprintf(f, "%s[%d", i ? ", " : "", r->col);
+        for (int64_t k = r->table_off; k < end; k++) fprintf(f, ", %d", (int)p->req_tables[k]);
+        fprintf(f, "]");
+    }
+    fprintf(f, "]]");
+}
+
+int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *p) {
+    FILE *f = e->f;
+    const int64_t N = e->n;
+    e->n_taintsets = p->n_taintsets;
+    sep(e);
+    fprintf(f, "\"pod\": {");
+    arr64(f, "req", p->req, CCSIM_MAX_RES);
+    fprintf(f, ", \"has_scalar_entries\": %d, \"nz_mcpu\": %lld, \"nz_mem\": %lld, \"tolerates_unschedulable\": %d, \"affinity_filter_active\": %d, "
+               "\"has_node_selector\": %d, \"has_required_terms\": %d, \"n_reqs\": %d, ",
+            p->has_scalar_entries, (long long)p->nz_mcpu, (long long)p->nz_mem, p->tolerates_unschedulable, p->affinity_filter_active, p->has_node_selector,
+            p->has_required_terms, p->n_reqs);
+    arr8(f, "taint_filter_ok", p->taint_filter_ok, p->n_taintsets), fprintf(f, ", ");
+    arr32(f, "taint_prefer_cnt", p->taint_prefer_cnt, p->n_taintsets);
+    fprintf(f, ", \"node_selector\": ");
+    term(f, p, &p->node_selector);
+    fprintf(f, ", \"required\": [");
+    for (int i = 0; i < p->n_required; i++) fprintf(f, "%s", i ? ", " : ""), term(f, p, &p->required[i]);
+    fprintf(f, "], \"preferred\": [");
+    for (int i = 0; i < p->n_preferred; i++) fprintf(f, "%s", i ? ", " : ""), term(f, p, &p->preferred[i]);
+    fprintf(f, "], \"spread\": [");
+    for (int i = 0; i < p->n_spread; i++) {
+        const ccsim_spread_constraint *c = &p->spread[i];
+        fprintf(f, "%s{\"k\": [%d, %d, %d, %d, %d, %d, %d], ", i ? ", " : "", c->col, c->max_skew, c->min_domains, c->hard, c->self_match, c->n_domains, c->is_hostname);
+        arr32(f, "node_match_count", c->node_match_count, N), fprintf(f, ", ");
+        arr8(f, "node_included", c->node_included, N);
+        fprintf(f, "}");
+    }
+    fprintf(f, "], \"has_ipa\": %d", p->has_ipa);
+    if (p->has_ipa) {
+        const ccsim_ipa *a = &p->ipa;
+        fprintf(f, ", \"ipa\": {\"self_aff\": %d, \"entries_existing\": %lld, ", a->self_aff, (long long)a->entries_existing);
+        arr32(f, "key_col", a->key_col, a->n_keys), fprintf(f, ", ");
+        arr32(f, "key_ndom", a->key_ndom, a->n_keys), fprintf(f, ", ");
+        arr32(f, "aff_key", a->aff_key, a->n_aff_terms), fprintf(f, ", ");
+        arr32(f, "anti_key", a->anti_key, a->n_anti_terms), fprintf(f, ", ");
+        arr32(f, "anti_self", a->anti_self, a->n_anti_terms), fprintf(f, ", ");
+        arr64(f, "score_self", a->score_self, a->n_keys), fprintf(f, ", ");
+        arr32(f, "self_entries", a->self_entries, a->n_keys), fprintf(f, ", ");
+        arr32(f, "aff_existing", a->aff_existing, N);
+        fprintf(f, ", \"anti_existing\": [");
+        for (int t = 0; t < a->n_anti_terms; t++) { fprintf(f, "%s{", t ? ", " : ""); arr32(f, "v", a->anti_existing[t], N); fprintf(f, "}"); }
+        fprintf(f, "], \"exist_anti\": [");
+        for (int k = 0; k < a->n_keys; k++) { fprintf(f, "%s{", k ? ", " : ""); arr32(f, "v", a->exist_anti[k], N); fprintf(f, "}"); }
+        fprintf(f, "], \"score_existing\": [");
+        for (int k = 0; k < a->n_keys; k++) { fprintf(f, "%s{", k ? ", " : ""); arr64(f, "v", a->score_existing[k], N); fprintf(f, "}"); }
+        fprintf(f, "]}");
+    }
+    fprintf(f, "}");
+    return 0;
+}
+
+int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
+    sep(e);
+    fprintf(e->f, "\"run\": {\"max_limit\": %lld, \"mode\": %d, \"per_node_cap\": %lld, \"log_cap\": %lld, \"hist_taintset_cap\": %d}", (long long)max_limit, mode,
+            (long long)out->per_node_cap, (long long)out->log_cap, out->hist_taintset_cap);
+    if (out->per_node_cap < e->n || (out->hist_taintset && out->hist_taintset_cap < e->n_taintsets)) return -22;
+    /* the canned result: one pod on every node, in index order */
+    out->placed = e->n, out->stop = CCSIM_STOP_LIMIT, out->log_len = 0;
+    for (int64_t i = 0; i < e->n; i++) {
+        out->per_node_count[i] = 1;
+        if (out->log && i < out->log_cap) out->log[i] = (int32_t)i, out->log_len = i + 1;
+    }
+    memset(out->hist, 0, sizeof out->hist);
+    out->n_code_unschedulable = 0;
+    return 0;
+}

@@ -498,3 +498,53 @@ def test_scheduler_config_native_and_python_hosts_agree(native, tmp_path):
             cfg["percentageOfNodesToScore"] = int(rng.integers(0, 101))
         text = yaml.safe_dump(cfg) if i % 2 else json.dumps(cfg)
         assert _profile(native, tmp_path, text) == _py_profile_dump(cfg), cfg
+
+
+@pytest.fixture(scope="module")
+def recorder(tmp_path_factory):
+    """tests/abi_recorder.c: records what a host passes through the C ABI and schedules nothing (test infrastructure)."""
+    out = tmp_path_factory.mktemp("rec") / "libabi_recorder.so"
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", str(out), os.path.join(here, "abi_recorder.c")])
+    return str(out)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_native_host_marshals_the_c_abi_like_the_python_binding(native, recorder, tmp_path, case):
+    """The same snapshot through main.cpp:marshal() and through capi.marshal_*: every struct field, pointer target and
+    requirement table that reaches ccsim_load_nodes / ccsim_set_profile / ccsim_set_pod must be identical."""
+    import ctypes as C
+    from cluster_capacity_amd import capi
+    nodes, pods, pod, exclude = CASES[case]()
+    podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
+    args = ["--podspec", podspec, "--snapshot", snaps[0], "--max-limit", "1000", "-o", "json"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
+    env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "native.json"))
+    p = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
+    assert p.returncode == 0, p.stderr
+    native_rec = json.load(open(tmp_path / "native.json"))
+    # the recorder's canned result came back through ccsim_report into the review
+    rev = json.loads(p.stdout)
+    snap = ingest.build_snapshot(*cli.load_objects(snaps), cli.parse_pod_spec(podspec), exclude)
+    assert rev["status"]["replicas"] == len(snap.names) and rev["status"]["failReason"]["failType"] == "LimitReached"
+    assert [r["nodeName"] for r in rev["status"]["pods"][0]["replicasOnNodes"]] == snap.names
+
+    lib = C.CDLL(recorder)
+    os.environ["CCSIM_RECORD"] = str(tmp_path / "python.json")
+    try:
+        cfg = capi.CConfig()
+        cfg.abi_version, cfg.use_graph = 1, 1
+        h = C.c_void_p()
+        assert lib.ccsim_create(C.byref(cfg), C.byref(h)) == 0
+        keep = []
+        assert lib.ccsim_load_nodes(h, C.byref(capi.marshal_nodes(snap.nodes, keep))) == 0
+        assert lib.ccsim_set_profile(h, C.byref(capi.marshal_profile(M.Profile.default()))) == 0
+        assert lib.ccsim_set_pod(h, C.byref(capi.marshal_pod(snap.pod, keep))) == 0
+        lib.ccsim_destroy(h)
+    finally:
+        os.environ.pop("CCSIM_RECORD")
+    python_rec = json.load(open(tmp_path / "python.json"))
+    for k in ("nodes", "profile", "pod"):
+        assert native_rec[k] == python_rec[k], k
+    assert native_rec["run"]["max_limit"] == 1000 and native_rec["run"]["log_cap"] == 1000 and native_rec["run"]["per_node_cap"] >= len(snap.names)
+    coupled = bool(snap.pod.spread) or snap.pod.ipa is not None
+    assert native_rec["run"]["mode"] == (0 if coupled else 1)  # order-dependent pods run the literal loop
