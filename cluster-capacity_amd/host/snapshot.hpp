@@ -442,7 +442,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         k.is_hostname = c["topologyKey"].text() == kHostname;
         k.n_domains = (int)it.values[(size_t)k.col].size();
         if (any_nonzero(existing)) k.node_match_count = existing;
-        k.use_included = aff_policy == "Honor" && !s.included.empty();
+        k.use_included = aff_policy == "Honor" && s.affinity_filter_active;
         s.spread.push_back(std::move(k));
     }
 

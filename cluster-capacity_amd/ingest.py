@@ -432,19 +432,21 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
                 if _term_matches_pod(wt["podAffinityTerm"], p_ns, sim_as_pod):
                     add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int(wt["weight"]))
         # what ONE clone adds (it is an existing pod of the next cycle, with the incoming pod's own terms)
-        K = len(keys)
-        score_self, self_entries = [0] * K, [0] * K
+        self_score: Dict[int, int] = {}   # (a term of the incoming pod may name a topology key no existing pod touched:
+        self_hits: Dict[int, int] = {}    #  kidx can still grow here)
         for wt, sign in [(w, 1) for w in p_aff] + [(w, -1) for w in p_anti]:
             if _term_matches_pod(wt["podAffinityTerm"], sim_ns, sim_as_pod):  # both directions: incoming's term vs the
                 k = kidx(wt["podAffinityTerm"]["topologyKey"])              # clone, and the clone's term vs the incoming pod
-                score_self[k] += 2 * sign * int(wt["weight"])
-                self_entries[k] += 2
+                self_score[k] = self_score.get(k, 0) + 2 * sign * int(wt["weight"])
+                self_hits[k] = self_hits.get(k, 0) + 2
         if hard_pod_affinity_weight > 0:
             for t in r_aff:
                 if _term_matches_pod(t, sim_ns, sim_as_pod):
                     k = kidx(t["topologyKey"])
-                    score_self[k] += hard_pod_affinity_weight
-                    self_entries[k] += 1
+                    self_score[k] = self_score.get(k, 0) + hard_pod_affinity_weight
+                    self_hits[k] = self_hits.get(k, 0) + 1
+        score_self = [self_score.get(k, 0) for k in range(len(keys))]
+        self_entries = [self_hits.get(k, 0) for k in range(len(keys))]
         if len(keys) > M.MAX_IPA_KEYS:
             raise NotImplementedError("more than %d distinct inter-pod affinity topology keys" % M.MAX_IPA_KEYS)
         ipa.key_cols = [it.col(k) for k in keys]

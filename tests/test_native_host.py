@@ -548,3 +548,163 @@ def test_native_host_marshals_the_c_abi_like_the_python_binding(native, recorder
     assert native_rec["run"]["max_limit"] == 1000 and native_rec["run"]["log_cap"] == 1000 and native_rec["run"]["per_node_cap"] >= len(snap.names)
     coupled = bool(snap.pod.spread) or snap.pod.ipa is not None
     assert native_rec["run"]["mode"] == (0 if coupled else 1)  # order-dependent pods run the literal loop
+
+
+def _random_objects(rng):
+    """A random cluster + pod spec drawing on every ingest feature (selectors, tolerations, affinities, constraints)."""
+    keys = ["disk", "gen", "team", "topology.kubernetes.io/zone", "kubernetes.io/hostname", "rack"]
+    vals = {"disk": ["ssd", "hdd", "nvme"], "gen": ["1", "2", "3", "10", "x"], "team": ["a", "b"], "rack": ["r1", "r2", "r3", "r4"]}
+    effects = ["NoSchedule", "PreferNoSchedule", "NoExecute"]
+    qty_cpu = ["250m", "1", "2", "0.5", "1500m", "4", "3.3", "100u"]
+    qty_mem = ["512Mi", "1Gi", "2G", "1500M", "3.5Gi", "1e9", "123456789", "64Ki"]
+
+    def rand_labels(i, extra=()):
+        lab = {}
+        for k in keys:
+            if k == "kubernetes.io/hostname":
+                if rng.random() < 0.9:
+                    lab[k] = f"n{i}"
+            elif k == "topology.kubernetes.io/zone":
+                if rng.random() < 0.85:
+                    lab[k] = f"z{int(rng.integers(0, 4))}"
+            elif rng.random() < 0.7:
+                lab[k] = str(rng.choice(vals[k]))
+        lab.update(extra)
+        return lab
+
+    def rand_selector():
+        r = rng.random()
+        if r < 0.15:
+            return None
+        if r < 0.3:
+            return {}
+        sel = {}
+        if rng.random() < 0.6:
+            sel["matchLabels"] = {"app": str(rng.choice(["web", "api", "db"]))}
+        if rng.random() < 0.5:
+            op = str(rng.choice(["In", "NotIn", "Exists", "DoesNotExist"]))
+            e = {"key": str(rng.choice(["app", "tier"])), "operator": op}
+            if op in ("In", "NotIn"):
+                e["values"] = [str(x) for x in rng.choice(["web", "api", "db", "frontend"], int(rng.integers(1, 3)), replace=False)]
+            sel["matchExpressions"] = [e]
+        return sel
+
+    def rand_node_term():
+        exprs = []
+        for _ in range(int(rng.integers(0, 3))):
+            k = str(rng.choice(["disk", "gen", "team", "rack"]))
+            op = str(rng.choice(["In", "NotIn", "Exists", "DoesNotExist", "Gt", "Lt"]))
+            e = {"key": k, "operator": op}
+            if op in ("In", "NotIn"):
+                e["values"] = [str(x) for x in rng.choice(vals[k], int(rng.integers(1, 3)), replace=False)]
+            elif op in ("Gt", "Lt"):
+                e["values"] = [str(int(rng.integers(0, 5)))]
+            exprs.append(e)
+        t = {"matchExpressions": exprs} if exprs or rng.random() < 0.5 else {}
+        if rng.random() < 0.2:
+            t["matchFields"] = [{"key": "metadata.name", "operator": str(rng.choice(["In", "NotIn"])), "values": [f"n{int(rng.integers(0, 12))}"]}]
+        return t
+
+    def rand_pod_term():
+        t = {"topologyKey": str(rng.choice(["topology.kubernetes.io/zone", "kubernetes.io/hostname", "rack"])), "labelSelector": rand_selector()}
+        r = rng.random()
+        if r < 0.2:
+            t["namespaces"] = [str(x) for x in rng.choice(["default", "other", "third"], int(rng.integers(1, 3)), replace=False)]
+        elif r < 0.3:
+            t["namespaceSelector"] = {}
+        return t
+
+    def rand_pod_affinity():
+        aff = {}
+        for kind in ("podAffinity", "podAntiAffinity"):
+            a = {}
+            if rng.random() < 0.35:
+                a["requiredDuringSchedulingIgnoredDuringExecution"] = [rand_pod_term() for _ in range(int(rng.integers(1, 3)))]
+            if rng.random() < 0.35:
+                a["preferredDuringSchedulingIgnoredDuringExecution"] = [{"weight": int(rng.integers(1, 100)), "podAffinityTerm": rand_pod_term()}
+                                                                        for _ in range(int(rng.integers(1, 3)))]
+            if a:
+                aff[kind] = a
+        return aff
+
+    n = int(rng.integers(1, 14))
+    nodes = []
+    for i in range(n):
+        taints = [{"key": str(rng.choice(["dedicated", "maintenance", "gpu"])), "value": str(rng.choice(["infra", "soon", ""])), "effect": str(rng.choice(effects))}
+                  for _ in range(int(rng.integers(0, 3)))]
+        nd = node(f"n{i}", cpu=str(rng.choice(qty_cpu)), mem=str(rng.choice(qty_mem)), pods=str(int(rng.integers(0, 20))), labels=rand_labels(i),
+                  taints=taints, unschedulable=bool(rng.random() < 0.1))
+        if rng.random() < 0.5:
+            nd["status"]["allocatable"]["example.com/gpu"] = str(int(rng.integers(0, 5)))
+        nodes.append(nd)
+    pods = []
+    for j in range(int(rng.integers(0, 25))):
+        p = running_pod(f"p{j}", f"n{int(rng.integers(0, n + 2))}", cpu=rng.choice([None, "100m", "1", "2500u"]), mem=rng.choice([None, "128Mi", "1G"]),
+                        labels={"app": str(rng.choice(["web", "api", "db"])), "tier": str(rng.choice(["frontend", "backend"]))},
+                        ns=str(rng.choice(["default", "other"])), phase=str(rng.choice(["Running", "Pending", "Succeeded", "Failed", "Running"])),
+                        affinity=rand_pod_affinity())
+        if rng.random() < 0.2:
+            p["spec"]["initContainers"] = [{"name": "i", "resources": {"requests": {"cpu": str(rng.choice(qty_cpu)), "example.com/gpu": "1"}}}]
+        if rng.random() < 0.15:
+            p["spec"]["overhead"] = {"cpu": "1m", "memory": "1Ki"}
+        if rng.random() < 0.1:
+            p["metadata"]["deletionTimestamp"] = "2025-01-01T00:00:00Z"
+        pods.append(p)
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["metadata"]["labels"] = {"app": str(rng.choice(["web", "api"])), "tier": "frontend"}
+    if rng.random() < 0.3:
+        pod["metadata"]["namespace"] = "other"
+    spec = pod["spec"]
+    if rng.random() < 0.4:
+        spec["containers"].append({"name": "x", "resources": {"requests": {"example.com/gpu": "1", "cpu": str(rng.choice(qty_cpu))}}})
+    if rng.random() < 0.3:
+        spec["containers"].append({"name": "besteffort"})
+    if rng.random() < 0.3:
+        spec["initContainers"] = [{"name": "i", "resources": {"requests": {"memory": str(rng.choice(qty_mem))}}}]
+    if rng.random() < 0.5:
+        spec["nodeSelector"] = {str(k): str(rng.choice(vals[k])) for k in rng.choice(["disk", "team", "rack"], int(rng.integers(1, 3)), replace=False)}
+    spec["tolerations"] = [{k: v for k, v in (("key", str(rng.choice(["dedicated", "maintenance", "", "node.kubernetes.io/unschedulable"]))),
+                                              ("operator", str(rng.choice(["Equal", "Exists", ""]))), ("value", str(rng.choice(["infra", "soon", ""]))),
+                                              ("effect", str(rng.choice(effects + [""])))) if v}
+                           for _ in range(int(rng.integers(0, 3)))]
+    aff = rand_pod_affinity()
+    na = {}
+    if rng.random() < 0.5:
+        na["requiredDuringSchedulingIgnoredDuringExecution"] = {"nodeSelectorTerms": [rand_node_term() for _ in range(int(rng.integers(0, 3)))]}
+    if rng.random() < 0.5:
+        na["preferredDuringSchedulingIgnoredDuringExecution"] = [{"weight": int(rng.integers(1, 100)), "preference": rand_node_term()}
+                                                                 for _ in range(int(rng.integers(1, 3)))]
+    if na:
+        aff["nodeAffinity"] = na
+    if aff:
+        spec["affinity"] = aff
+    if rng.random() < 0.5:
+        spec["topologySpreadConstraints"] = [
+            {k: v for k, v in (("maxSkew", int(rng.integers(1, 4))), ("minDomains", int(rng.integers(1, 4)) if rng.random() < 0.3 else None),
+                               ("topologyKey", str(rng.choice(["topology.kubernetes.io/zone", "kubernetes.io/hostname", "rack"]))),
+                               ("whenUnsatisfiable", str(rng.choice(["DoNotSchedule", "ScheduleAnyway"])) if rng.random() < 0.8 else None),
+                               ("nodeAffinityPolicy", str(rng.choice(["Honor", "Ignore"])) if rng.random() < 0.4 else None),
+                               ("labelSelector", rand_selector())) if v is not None or k == "labelSelector"}
+            for _ in range(int(rng.integers(1, 3)))]
+    exclude = [f"n{int(rng.integers(0, n))}"] if rng.random() < 0.3 else []
+    return nodes, pods, pod, exclude
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_native_ingest_random_differential(native, tmp_path, seed):
+    """Random clusters and pod specs through both ingests: same integer snapshot, or the same refusal."""
+    rng = np.random.default_rng(9000 + seed)
+    nodes, pods, pod, exclude = _random_objects(rng)
+    podspec, snaps = _write(tmp_path, "json" if seed % 2 else "yaml", nodes, pods, pod)
+    args = ["--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
+    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=60)
+    try:
+        ref = py_dump(ingest.build_snapshot(*cli.load_objects(snaps), cli.parse_pod_spec(podspec), exclude))
+    except NotImplementedError as e:  # both hosts refuse the same inputs (e.g. more topology keys than the engine holds)
+        assert p.returncode == 1 and str(e).split(" ")[-1] in p.stderr
+        return
+    assert p.returncode == 0, p.stderr
+    got = json.loads(p.stdout)
+    got.pop("label_keys")
+    for k in ref:
+        assert got[k] == ref[k], (k, seed)
