@@ -316,13 +316,23 @@ class YamlParser {
         throw std::runtime_error("YAML: " + what + " near line " + std::to_string(pos_ + 1) + " (use JSON for input this subset cannot read)");
     }
     static bool is_doc_marker(const std::string &t) { return t == "---" || t.rfind("--- ", 0) == 0 || t == "..."; }
+    // a quote character OPENS a quoted scalar only where a token can start (it's, q"x are plain words)
+    static bool opens_quote(const std::string &t, size_t i) { return i == 0 || t[i - 1] == ' ' || t[i - 1] == '\t' || t[i - 1] == '[' || t[i - 1] == '{' || t[i - 1] == ','; }
     static std::string strip_comment(const std::string &t) {
         bool sq = false, dq = false;
         for (size_t i = 0; i < t.size(); i++) {
             const char c = t[i];
-            if (c == '\'' && !dq) sq = !sq;
-            else if (c == '"' && !sq && (i == 0 || t[i - 1] != '\\')) dq = !dq;
-            else if (c == '#' && !sq && !dq && (i == 0 || t[i - 1] == ' ' || t[i - 1] == '\t')) return t.substr(0, i);
+            if (sq) {
+                if (c == '\'') {
+                    if (i + 1 < t.size() && t[i + 1] == '\'') i++; // '' is an escaped quote
+                    else sq = false;
+                }
+            } else if (dq) {
+                if (c == '\\') i++;
+                else if (c == '"') dq = false;
+            } else if (c == '\'' && opens_quote(t, i)) sq = true;
+            else if (c == '"' && opens_quote(t, i)) dq = true;
+            else if (c == '#' && (i == 0 || t[i - 1] == ' ' || t[i - 1] == '\t')) return t.substr(0, i);
         }
         return t;
     }
@@ -377,22 +387,68 @@ class YamlParser {
         }
         return Value::str(t);
     }
+    static void put_utf8(std::string &out, unsigned long cp) {
+        if (cp < 0x80) out += (char)cp;
+        else if (cp < 0x800) out += (char)(0xC0 | (cp >> 6)), out += (char)(0x80 | (cp & 0x3F));
+        else if (cp < 0x10000) out += (char)(0xE0 | (cp >> 12)), out += (char)(0x80 | ((cp >> 6) & 0x3F)), out += (char)(0x80 | (cp & 0x3F));
+        else out += (char)(0xF0 | (cp >> 18)), out += (char)(0x80 | ((cp >> 12) & 0x3F)), out += (char)(0x80 | ((cp >> 6) & 0x3F)), out += (char)(0x80 | (cp & 0x3F));
+    }
+    // YAML 1.1 double-quoted escapes (section 5.7): the JSON ones plus \xNN \UNNNNNNNN \0 \a \e \v \N \_ \L \P and "\ "
     static std::string unquote_double(const std::string &t, size_t &i) { // t[i] == '"'
-        std::string json = "\"";
+        std::string out;
         size_t j = i + 1;
         for (; j < t.size(); j++) {
-            if (t[j] == '\\' && j + 1 < t.size()) {
-                json += t[j], json += t[j + 1], j++;
+            const char c = t[j];
+            if (c == '"') break;
+            if (c != '\\' || j + 1 >= t.size()) {
+                out += c;
                 continue;
             }
-            if (t[j] == '"') break;
-            json += t[j];
+            const char e = t[++j];
+            auto hex = [&](int n) {
+                unsigned long v = 0;
+                for (int k = 0; k < n && j + 1 < t.size(); k++) {
+                    const char h = t[++j];
+                    v <<= 4;
+                    if (h >= '0' && h <= '9') v |= (unsigned long)(h - '0');
+                    else if (h >= 'a' && h <= 'f') v |= (unsigned long)(h - 'a' + 10);
+                    else if (h >= 'A' && h <= 'F') v |= (unsigned long)(h - 'A' + 10);
+                    else throw std::runtime_error("YAML: bad hex escape");
+                }
+                return v;
+            };
+            switch (e) {
+            case 'n': out += '\n'; break;
+            case 't': case '\t': out += '\t'; break;
+            case 'r': out += '\r'; break;
+            case 'b': out += '\b'; break;
+            case 'f': out += '\f'; break;
+            case 'v': out += '\v'; break;
+            case 'a': out += '\a'; break;
+            case 'e': out += '\x1b'; break;
+            case '0': out += '\0'; break;
+            case ' ': out += ' '; break;
+            case '_': put_utf8(out, 0xA0); break;
+            case 'N': put_utf8(out, 0x85); break;
+            case 'L': put_utf8(out, 0x2028); break;
+            case 'P': put_utf8(out, 0x2029); break;
+            case 'x': put_utf8(out, hex(2)); break;
+            case 'u': {
+                unsigned long cp = hex(4);
+                if (cp >= 0xD800 && cp < 0xDC00 && j + 2 < t.size() && t[j + 1] == '\\' && t[j + 2] == 'u') {
+                    j += 2;
+                    cp = 0x10000 + ((cp - 0xD800) << 10) + (hex(4) - 0xDC00);
+                }
+                put_utf8(out, cp);
+                break;
+            }
+            case 'U': put_utf8(out, hex(8)); break;
+            default: out += e; // \" \\ \/
+            }
         }
-        if (j >= t.size()) throw std::runtime_error("YAML: unterminated double-quoted scalar (multi-line quoted scalars are not supported)");
-        json += '"';
+        if (j >= t.size()) throw std::runtime_error("YAML: unterminated double-quoted scalar");
         i = j + 1;
-        JsonParser p(json);
-        return p.parse_document().s;
+        return out;
     }
     static std::string unquote_single(const std::string &t, size_t &i) { // t[i] == '\''
         std::string out;
@@ -471,6 +527,44 @@ class YamlParser {
         while (!s.empty() && s.back() == ' ') s.pop_back();
         return plain_scalar(s);
     }
+    static bool flow_balanced(const std::string &q) {
+        int depth = 0;
+        bool sq = false, dq = false;
+        for (size_t i = 0; i < q.size(); i++) {
+            const char c = q[i];
+            if (sq) {
+                if (c == '\'') {
+                    if (i + 1 < q.size() && q[i + 1] == '\'') i++; // '' is an escaped quote
+                    else sq = false;
+                }
+            } else if (dq) {
+                if (c == '\\') i++;
+                else if (c == '"') dq = false;
+            } else if (c == '\'' && opens_quote(q, i)) sq = true;
+            else if (c == '"' && opens_quote(q, i)) dq = true;
+            else if (c == '[' || c == '{') depth++;
+            else if (c == ']' || c == '}') depth--;
+        }
+        return depth <= 0 && !sq && !dq;
+    }
+    // does the quoted scalar that starts at q[0] end inside q?
+    static bool quoted_terminated(const std::string &q) {
+        const char quote = q[0];
+        for (size_t i = 1; i < q.size(); i++) {
+            if (quote == '"' && q[i] == '\\') {
+                i++;
+                continue;
+            }
+            if (q[i] == quote) {
+                if (quote == '\'' && i + 1 < q.size() && q[i + 1] == '\'') {
+                    i++;
+                    continue;
+                }
+                return true;
+            }
+        }
+        return false;
+    }
     // a block scalar (| or >) whose header is on the line before pos_; parent_indent = indentation of the owning key
     Value parse_block_scalar(char style, char chomp, int parent_indent) {
         std::vector<std::string> body;
@@ -504,9 +598,42 @@ class YamlParser {
                 const char chomp = rest.size() > 1 && (rest[1] == '-' || rest[1] == '+') ? rest[1] : ' ';
                 return parse_block_scalar(rest[0], chomp, owner_indent);
             }
-            if (rest[0] == '[' || rest[0] == '{' || rest[0] == '"' || rest[0] == '\'') {
+            if (rest[0] == '"' || rest[0] == '\'') {
+                // a quoted scalar may be folded over several lines: a line break is a space, an empty line a newline
+                std::string q = rest;
+                while (!quoted_terminated(q) && pos_ < lines_.size()) {
+                    const std::string &raw = lines_[pos_].raw;
+                    const size_t b = raw.find_first_not_of(" \t");
+                    while (!q.empty() && (q.back() == ' ' || q.back() == '\t')) q.pop_back();
+                    if (b == std::string::npos) q += "\x01"; // empty line (placeholder: resolved below)
+                    else {
+                        if (q.back() == '\x01' || (q.back() == '\\' && q[0] == '"')) { // after a newline / an escaped line break: no space
+                            if (q.back() == '\\') q.pop_back();
+                        } else
+                            q += ' ';
+                        size_t e = raw.size();
+                        while (e > b && (raw[e - 1] == ' ' || raw[e - 1] == '\t' || raw[e - 1] == '\r')) e--;
+                        q += raw.substr(b, e - b);
+                    }
+                    pos_++;
+                }
                 size_t i = 0;
-                Value v = parse_flow(rest, i);
+                Value v = parse_flow(q, i);
+                if (v.t == Value::Str)
+                    for (auto &c : v.s)
+                        if (c == '\x01') c = '\n';
+                return v;
+            }
+            if (rest[0] == '[' || rest[0] == '{') {
+                std::string q = rest; // a flow collection may continue on the following lines until its brackets balance
+                while (!flow_balanced(q) && pos_ < lines_.size()) {
+                    const std::string &raw = lines_[pos_].raw;
+                    const size_t b = raw.find_first_not_of(" \t");
+                    if (b != std::string::npos) q += " " + strip_comment(raw.substr(b));
+                    pos_++;
+                }
+                size_t i = 0;
+                Value v = parse_flow(q, i);
                 return v;
             }
             if (rest[0] == '&' || rest[0] == '*' || rest[0] == '!') fail("anchors / aliases / tags");
@@ -534,14 +661,22 @@ class YamlParser {
     }
     // position of the ':' that ends a block-mapping key, npos if the line is not "key: ..."
     static size_t find_key_colon(const std::string &t) {
-        bool sq = false, dq = false;
-        for (size_t i = 0; i < t.size(); i++) {
-            const char c = t[i];
-            if (c == '\'' && !dq) sq = !sq;
-            else if (c == '"' && !sq) dq = !dq;
-            else if (c == ':' && !sq && !dq && (i + 1 == t.size() || t[i + 1] == ' ')) return i;
-            else if (!sq && !dq && (c == '[' || c == '{') && i == 0) return std::string::npos;
+        if (t.empty() || t[0] == '[' || t[0] == '{') return std::string::npos;
+        size_t i = 0;
+        if (t[0] == '"') { // a quoted key: skip to its closing quote
+            for (i = 1; i < t.size() && t[i] != '"'; i++)
+                if (t[i] == '\\') i++;
+            i++;
+        } else if (t[0] == '\'') {
+            for (i = 1; i < t.size(); i++)
+                if (t[i] == '\'') {
+                    if (i + 1 < t.size() && t[i + 1] == '\'') i++;
+                    else break;
+                }
+            i++;
         }
+        for (; i < t.size(); i++)
+            if (t[i] == ':' && (i + 1 == t.size() || t[i + 1] == ' ')) return i;
         return std::string::npos;
     }
     static std::string key_text(std::string k) {
@@ -582,6 +717,11 @@ class YamlParser {
             while (lead < rest.size() && rest[lead] == ' ') lead++;
             rest = rest.substr(lead);
             const int item_indent = indent + 2 + (int)lead; // where the item's content starts
+            if (rest == "-" || rest.rfind("- ", 0) == 0) { // "- - x": the item is itself a sequence that starts on this line
+                l.text = rest, l.indent = item_indent;
+                v.a.push_back(parse_sequence(item_indent));
+                continue;
+            }
             if (!rest.empty() && find_key_colon(rest) != std::string::npos && rest[0] != '"' && rest[0] != '\'' && rest[0] != '[' && rest[0] != '{') {
                 // "- key: value": the item is a mapping whose first key sits on the dash line
                 l.text = rest, l.indent = item_indent;
@@ -705,8 +845,11 @@ inline std::vector<Value> parse_documents(const std::string &text) {
     size_t i = 0;
     while (i < text.size() && std::isspace((unsigned char)text[i])) i++;
     if (i < text.size() && (text[i] == '{' || text[i] == '[')) {
-        JsonParser p(text);
-        return {p.parse_document()};
+        try {
+            JsonParser p(text);
+            return {p.parse_document()};
+        } catch (const std::exception &) { // a YAML document in flow style
+        }
     }
     YamlParser y(text);
     return y.parse_stream();

@@ -708,3 +708,44 @@ def test_native_ingest_random_differential(native, tmp_path, seed):
     got.pop("label_keys")
     for k in ref:
         assert got[k] == ref[k], (k, seed)
+
+
+def test_native_yaml_reader_fuzz_against_pyyaml(native, tmp_path):
+    """Random block-style documents (what kubectl and PyYAML emit): tricky plain / quoted / folded scalars, escapes,
+    nested sequences, odd keys.  The native reader must build the same tree as PyYAML."""
+    import random
+    import string
+    rnd = random.Random(20250923)
+    alphabet = string.ascii_letters + string.digits + "  :#-_/.,'\"{}[]!&*?|>%@`=+~\\"
+
+    def rstr():
+        s = "".join(rnd.choice(alphabet) for _ in range(rnd.choice([0, 1, 3, 8, 20, 60, 150])))
+        if rnd.random() < 0.1:
+            s += "\n" + "".join(rnd.choice(alphabet) for _ in range(10))
+        if rnd.random() < 0.1:
+            s = "é✓ " + s
+        return s
+
+    def rkey():
+        return rnd.choice(["app", "kubernetes.io/name", "a b", "x:y", "123", "true", "é", 'q"uote', "it's"]) + str(rnd.randint(0, 99))
+
+    def rval(d=0):
+        r = rnd.random()
+        if d < 3 and r < 0.25:
+            return {rkey(): rval(d + 1) for _ in range(rnd.randint(0, 4))}
+        if d < 3 and r < 0.45:
+            return [rval(d + 1) for _ in range(rnd.randint(0, 4))]
+        if r < 0.55:
+            return rnd.randint(-5, 10**6)
+        if r < 0.6:
+            return rnd.choice([True, False, None])
+        if r < 0.65:
+            return rnd.choice(["true", "null", "123", "1e3", "0.5", "~", "yes", "- x", "a: b", "#c", " lead", "trail "])
+        return rstr()
+
+    for it in range(150):
+        docs = [{rkey(): rval() for _ in range(rnd.randint(1, 6))} for _ in range(rnd.choice([1, 1, 3]))]
+        text = yaml.safe_dump_all(docs, default_flow_style=False, width=rnd.choice([30, 80, 1000]), allow_unicode=rnd.choice([True, False]))
+        (tmp_path / "d.yaml").write_text(text)
+        got = json.loads(_run(native, ["--parse", str(tmp_path / "d.yaml")]))
+        assert got == [d for d in yaml.safe_load_all(text) if d], (it, text)
