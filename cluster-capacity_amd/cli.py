@@ -25,8 +25,9 @@ import yaml
 from . import ingest, model as M, report as R, schedconfig
 
 
-def load_objects(paths: List[str]):
-    nodes, pods = [], []
+def load_all(paths: List[str]):
+    """-> (nodes, pods, namespaces): what SyncWithClient lists (simulator.go:176-295)."""
+    nodes, pods, namespaces = [], [], []
     for path in paths:
         with open(path) as f:
             docs = list(yaml.safe_load_all(f))  # YAML is a superset of JSON
@@ -39,7 +40,13 @@ def load_objects(paths: List[str]):
                     nodes.append(o)
                 elif o.get("kind") == "Pod":
                     pods.append(o)
-    return nodes, pods
+                elif o.get("kind") == "Namespace":
+                    namespaces.append(o)
+    return nodes, pods, namespaces
+
+
+def load_objects(paths: List[str]):
+    return load_all(paths)[:2]
 
 
 def parse_pod_spec(path: str, scheduler_name: str = "default-scheduler") -> dict:
@@ -175,8 +182,9 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     prof, hard_weight = schedconfig.profile_from_config(cfg)
     pct = args.percentage_of_nodes_to_score if args.percentage_of_nodes_to_score is not None else prof.percentage_of_nodes_to_score
     pod = parse_pod_spec(args.podspec)
-    node_objs, pod_objs = load_objects(args.snapshot)
-    snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight)
+    node_objs, pod_objs, ns_objs = load_all(args.snapshot)
+    snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
+                                 namespace_objs=ns_objs)
     result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=pct, profile=prof)
     review = build_review(pod, snap, result, args.max_limit)
     if args.output == "json":

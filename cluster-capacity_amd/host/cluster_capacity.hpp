@@ -32,8 +32,8 @@ class ClusterCapacity {
         c.profile_ = kubeSchedulerConfig, c.pod_ = std::move(simulatedPod), c.max_simulated_ = maxPods, c.exclude_ = std::move(excludeNodes);
         return c;
     }
-    void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods) {
-        snap_ = build_snapshot(nodes, pods, pod_, exclude_, profile_.hard_pod_affinity_weight);
+    void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods, const std::vector<Value> &namespaces = {}) {
+        snap_ = build_snapshot(nodes, pods, pod_, exclude_, profile_.hard_pod_affinity_weight, namespaces);
         synced_ = true;
     }
     void Run() {

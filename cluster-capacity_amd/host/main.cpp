@@ -37,7 +37,7 @@ std::string read_file(const std::string &path) {
     return ss.str();
 }
 
-void load_objects(const std::vector<std::string> &paths, std::vector<Value> &nodes, std::vector<Value> &pods) {
+void load_objects(const std::vector<std::string> &paths, std::vector<Value> &nodes, std::vector<Value> &pods, std::vector<Value> &namespaces) {
     for (const auto &path : paths)
         for (const Value &d : parse_documents(read_file(path))) {
             if (!d.truthy()) continue;
@@ -47,6 +47,7 @@ void load_objects(const std::vector<std::string> &paths, std::vector<Value> &nod
             for (const Value &o : is_list ? d["items"].items() : one) {
                 if (o["kind"].text() == "Node") nodes.push_back(o);
                 else if (o["kind"].text() == "Pod") pods.push_back(o);
+                else if (o["kind"].text() == "Namespace") namespaces.push_back(o);
             }
         }
 }
@@ -166,9 +167,9 @@ int main(int argc, char **argv) {
         // runSimulator (cmd/cluster-capacity/app/server.go:163-183): New -> SyncWithClient -> Run -> Report
         ClusterCapacity cc = ClusterCapacity::New(prof, parse_pod_spec(podspec), max_limit, exclude);
         cc.device = device, cc.mode = mode;
-        std::vector<Value> node_objs, pod_objs;
-        load_objects(snapshots, node_objs, pod_objs);
-        cc.SyncWithClient(node_objs, pod_objs);
+        std::vector<Value> node_objs, pod_objs, ns_objs;
+        load_objects(snapshots, node_objs, pod_objs, ns_objs);
+        cc.SyncWithClient(node_objs, pod_objs, ns_objs);
         if (!dump.empty()) {
             std::string out;
             to_json(out, snapshot_json(cc.snapshot()));

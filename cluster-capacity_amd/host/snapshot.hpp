@@ -289,16 +289,22 @@ struct Snapshot {
     size_t n() const { return names.size(); }
 };
 
-// AffinityTerm.Matches: namespace in the term's set (default: the owner's namespace) and selector matches
-inline bool term_matches_pod(const Value &term, const std::string &owner_ns, const std::string &pod_ns, const Value &pod_labels) {
-    const std::vector<std::string> ns_set = string_list(term["namespaces"]);
-    if (!term["namespaceSelector"].is_null() && ns_set.empty()) {
-        if (!selector_empty(term["namespaceSelector"])) throw Unsupported("namespaceSelector needs Namespace objects");
-    } else if (ns_set.empty()) {
-        if (pod_ns != owner_ns) return false;
-    } else if (std::find(ns_set.begin(), ns_set.end(), pod_ns) == ns_set.end())
-        return false;
-    return label_selector_matches(term["labelSelector"], pod_labels);
+// AffinityTerm.Matches (S/framework/types.go:927-935): the pod's namespace is in the term's set, or its namespace's labels
+// match the term's namespaceSelector; then the label selector decides.  newAffinityTerm (:879-895): no namespaces and no
+// namespaceSelector -> the namespace of the pod that owns the term.  A namespace without a Namespace object in the snapshot
+// has no labels (as the scheduler's lister would report).
+using NamespaceLabels = std::map<std::string, Value>;
+inline bool term_matches_pod(const Value &term, const std::string &owner_ns, const std::string &pod_ns, const Value &pod_labels,
+                             const NamespaceLabels &ns_labels) {
+    std::vector<std::string> ns_set = string_list(term["namespaces"]);
+    const Value &ns_sel = term["namespaceSelector"];
+    if (ns_set.empty() && ns_sel.is_null()) ns_set.push_back(owner_ns);
+    bool in = std::find(ns_set.begin(), ns_set.end(), pod_ns) != ns_set.end();
+    if (!in && !ns_sel.is_null()) {
+        const auto it = ns_labels.find(pod_ns);
+        in = label_selector_matches(ns_sel, it == ns_labels.end() ? Value::null_value() : it->second);
+    }
+    return in && label_selector_matches(term["labelSelector"], pod_labels);
 }
 inline std::string ns_of(const Value &obj) { return obj["metadata"]["namespace"].truthy() ? obj["metadata"]["namespace"].text() : "default"; }
 
@@ -309,8 +315,14 @@ inline bool any_nonzero(const std::vector<int32_t> &v) {
 }
 
 inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const Value &sim_pod,
-                               const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1) {
+                               const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1,
+                               const std::vector<Value> &namespace_objs = {}) {
     Snapshot s;
+    NamespaceLabels ns_labels;
+    for (const auto &n : namespace_objs) ns_labels[n["metadata"]["name"].text()] = n["metadata"]["labels"];
+    auto tm = [&](const Value &term, const std::string &owner_ns, const std::string &pod_ns, const Value &pod_labels) {
+        return term_matches_pod(term, owner_ns, pod_ns, pod_labels, ns_labels);
+    };
     std::vector<const Value *> kept;
     for (const auto &n : node_objs)
         if (std::find(exclude_nodes.begin(), exclude_nodes.end(), n["metadata"]["name"].text()) == exclude_nodes.end()) kept.push_back(&n);
@@ -464,10 +476,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         Ipa &ipa = s.ipa;
         for (const auto &t : r_aff.items()) ipa.aff_keys.push_back(kidx(t["topologyKey"].text()));
         ipa.self_aff = r_aff.truthy();
-        for (const auto &t : r_aff.items()) ipa.self_aff = ipa.self_aff && term_matches_pod(t, sim_ns, sim_ns, sim_labels);
+        for (const auto &t : r_aff.items()) ipa.self_aff = ipa.self_aff && tm(t, sim_ns, sim_ns, sim_labels);
         for (const auto &t : r_anti.items()) {
             ipa.anti_keys.push_back(kidx(t["topologyKey"].text()));
-            ipa.anti_self.push_back(term_matches_pod(t, sim_ns, sim_ns, sim_labels));
+            ipa.anti_self.push_back(tm(t, sim_ns, sim_ns, sim_labels));
         }
         std::vector<int32_t> aff_existing(N, 0);
         std::vector<std::vector<int32_t>> anti_existing(r_anti.items().size(), std::vector<int32_t>(N, 0));
@@ -490,37 +502,37 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             const Value &pl = p["metadata"]["labels"];
             if (r_aff.truthy()) {
                 bool all = true;
-                for (const auto &t : r_aff.items()) all = all && term_matches_pod(t, sim_ns, p_ns, pl);
+                for (const auto &t : r_aff.items()) all = all && tm(t, sim_ns, p_ns, pl);
                 if (all) aff_existing[i] += 1;
             }
             for (size_t t = 0; t < r_anti.items().size(); t++)
-                if (term_matches_pod(r_anti.items()[t], sim_ns, p_ns, pl)) anti_existing[t][i] += 1;
+                if (tm(r_anti.items()[t], sim_ns, p_ns, pl)) anti_existing[t][i] += 1;
             const Value &e_aff = p["spec"]["affinity"]["podAffinity"], &e_anti = p["spec"]["affinity"]["podAntiAffinity"];
             for (const auto &t : e_anti["requiredDuringSchedulingIgnoredDuringExecution"].items())
-                if (term_matches_pod(t, p_ns, sim_ns, sim_labels)) {
+                if (tm(t, p_ns, sim_ns, sim_labels)) {
                     auto &v = exist_anti[kidx(t["topologyKey"].text())];
                     if (v.empty()) v.assign(N, 0);
                     v[i] += 1;
                 }
             // scoring.go:81-125 processExistingPod
             for (const auto &wt : p_aff.items())
-                if (term_matches_pod(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
             for (const auto &wt : p_anti.items())
-                if (term_matches_pod(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
             if (hard_pod_affinity_weight > 0)
                 for (const auto &t : e_aff["requiredDuringSchedulingIgnoredDuringExecution"].items())
-                    if (term_matches_pod(t, p_ns, sim_ns, sim_labels)) add_score(kidx(t["topologyKey"].text()), i, hard_pod_affinity_weight);
+                    if (tm(t, p_ns, sim_ns, sim_labels)) add_score(kidx(t["topologyKey"].text()), i, hard_pod_affinity_weight);
             for (const auto &wt : e_aff["preferredDuringSchedulingIgnoredDuringExecution"].items())
-                if (term_matches_pod(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
             for (const auto &wt : e_anti["preferredDuringSchedulingIgnoredDuringExecution"].items())
-                if (term_matches_pod(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
         }
         // what ONE clone adds (it is an existing pod of the next cycle, with the incoming pod's own terms): both directions --
         // the incoming pod's term vs the clone, and the clone's term vs the incoming pod
         std::map<int, int64_t> score_self;
         std::map<int, int32_t> self_entries;
         auto self_term = [&](const Value &wt, int sign) {
-            if (term_matches_pod(wt["podAffinityTerm"], sim_ns, sim_ns, sim_labels)) {
+            if (tm(wt["podAffinityTerm"], sim_ns, sim_ns, sim_labels)) {
                 const int k = kidx(wt["podAffinityTerm"]["topologyKey"].text());
                 score_self[k] += 2 * sign * wt["weight"].as_int();
                 self_entries[k] += 2;
@@ -530,7 +542,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         for (const auto &wt : p_anti.items()) self_term(wt, -1);
         if (hard_pod_affinity_weight > 0)
             for (const auto &t : r_aff.items())
-                if (term_matches_pod(t, sim_ns, sim_ns, sim_labels)) {
+                if (tm(t, sim_ns, sim_ns, sim_labels)) {
                     const int k = kidx(t["topologyKey"].text());
                     score_self[k] += hard_pod_affinity_weight;
                     self_entries[k] += 1;

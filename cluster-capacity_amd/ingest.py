@@ -237,26 +237,29 @@ class Snapshot:
         self.nodes, self.pod, self.names, self.taint_reasons, self.scalar_names = nodes, pod, names, taint_reasons, scalar_names
 
 
-def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict) -> bool:
-    """AffinityTerm.Matches: namespace in the term's set (default: the owner's namespace) and selector matches."""
-    ns_set = term.get("namespaces") or []
+def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict, ns_labels: Optional[Dict[str, dict]] = None) -> bool:
+    """AffinityTerm.Matches (S/framework/types.go:927-935): the pod's namespace is in the term's set, or its namespace's
+    labels match the term's namespaceSelector; then the label selector decides.  newAffinityTerm (:879-895): no namespaces
+    and no namespaceSelector -> the namespace of the pod that owns the term.  A namespace without a Namespace object in the
+    snapshot has no labels (as the scheduler's lister would report)."""
+    ns_set = list(term.get("namespaces") or [])
+    ns_sel = term.get("namespaceSelector")
+    if not ns_set and ns_sel is None:
+        ns_set = [term_owner_ns]
     pod_ns = pod["metadata"].get("namespace") or "default"
-    if term.get("namespaceSelector") is not None and not ns_set:
-        if selector_empty(term["namespaceSelector"]):
-            pass  # empty selector = all namespaces
-        else:
-            raise NotImplementedError("namespaceSelector needs Namespace objects")
-    elif not ns_set:
-        if pod_ns != term_owner_ns:
-            return False
-    elif pod_ns not in ns_set:
+    if pod_ns not in ns_set and not (ns_sel is not None and label_selector_matches(ns_sel, (ns_labels or {}).get(pod_ns, {}))):
         return False
     return label_selector_matches(term.get("labelSelector"), pod["metadata"].get("labels") or {})
 
 
 def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, exclude_nodes: Sequence[str] = (),
-                   hard_pod_affinity_weight: int = 1) -> Snapshot:
-    """SyncWithClient (simulator.go:176-295) + every per-pod-spec precomputation, in integers."""
+                   hard_pod_affinity_weight: int = 1, namespace_objs: Sequence[dict] = ()) -> Snapshot:
+    """SyncWithClient (simulator.go:176-295: namespaces, nodes, pods) + every per-pod-spec precomputation, in integers."""
+    ns_labels = {n["metadata"]["name"]: (n["metadata"].get("labels") or {}) for n in namespace_objs}
+
+    def tm(term, owner_ns, pod):
+        return _term_matches_pod(term, owner_ns, pod, ns_labels)
+
     nodes = canonical_node_order([n for n in node_objs if n["metadata"]["name"] not in set(exclude_nodes)])
     N = len(nodes)
     names = [n["metadata"]["name"] for n in nodes]
@@ -385,9 +388,9 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
         sim_as_pod = {"metadata": {"namespace": sim_ns, "labels": sim_labels}}
         ipa = M.InterPodAffinity(key_cols=[], key_ndom=[])
         ipa.aff_keys = [kidx(t["topologyKey"]) for t in r_aff]
-        ipa.self_aff = bool(r_aff) and all(_term_matches_pod(t, sim_ns, sim_as_pod) for t in r_aff)
+        ipa.self_aff = bool(r_aff) and all(tm(t, sim_ns, sim_as_pod) for t in r_aff)
         ipa.anti_keys = [kidx(t["topologyKey"]) for t in r_anti]
-        ipa.anti_self = [_term_matches_pod(t, sim_ns, sim_as_pod) for t in r_anti]
+        ipa.anti_self = [tm(t, sim_ns, sim_as_pod) for t in r_anti]
         aff_existing = np.zeros(N, np.int32)
         anti_existing = [np.zeros(N, np.int32) for _ in r_anti]
         exist_anti: Dict[int, np.ndarray] = {}
@@ -404,44 +407,44 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
         for p in live:
             i = index[p["spec"]["nodeName"]]
             p_ns = p["metadata"].get("namespace") or "default"
-            if r_aff and all(_term_matches_pod(t, sim_ns, p) for t in r_aff):
+            if r_aff and all(tm(t, sim_ns, p) for t in r_aff):
                 aff_existing[i] += 1
             for t_i, t in enumerate(r_anti):
-                if _term_matches_pod(t, sim_ns, p):
+                if tm(t, sim_ns, p):
                     anti_existing[t_i][i] += 1
             e_aff = ((p["spec"].get("affinity") or {}).get("podAffinity") or {})
             e_anti = ((p["spec"].get("affinity") or {}).get("podAntiAffinity") or {})
             for t in e_anti.get("requiredDuringSchedulingIgnoredDuringExecution") or []:
-                if _term_matches_pod(t, p_ns, sim_as_pod):
+                if tm(t, p_ns, sim_as_pod):
                     exist_anti.setdefault(kidx(t["topologyKey"]), np.zeros(N, np.int32))[i] += 1
             # scoring.go:81-125 processExistingPod
             for wt in p_aff:
-                if _term_matches_pod(wt["podAffinityTerm"], sim_ns, p):
+                if tm(wt["podAffinityTerm"], sim_ns, p):
                     add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int(wt["weight"]))
             for wt in p_anti:
-                if _term_matches_pod(wt["podAffinityTerm"], sim_ns, p):
+                if tm(wt["podAffinityTerm"], sim_ns, p):
                     add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int(wt["weight"]))
             if hard_pod_affinity_weight > 0:
                 for t in e_aff.get("requiredDuringSchedulingIgnoredDuringExecution") or []:
-                    if _term_matches_pod(t, p_ns, sim_as_pod):
+                    if tm(t, p_ns, sim_as_pod):
                         add_score(kidx(t["topologyKey"]), i, hard_pod_affinity_weight)
             for wt in e_aff.get("preferredDuringSchedulingIgnoredDuringExecution") or []:
-                if _term_matches_pod(wt["podAffinityTerm"], p_ns, sim_as_pod):
+                if tm(wt["podAffinityTerm"], p_ns, sim_as_pod):
                     add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int(wt["weight"]))
             for wt in e_anti.get("preferredDuringSchedulingIgnoredDuringExecution") or []:
-                if _term_matches_pod(wt["podAffinityTerm"], p_ns, sim_as_pod):
+                if tm(wt["podAffinityTerm"], p_ns, sim_as_pod):
                     add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int(wt["weight"]))
         # what ONE clone adds (it is an existing pod of the next cycle, with the incoming pod's own terms)
         self_score: Dict[int, int] = {}   # (a term of the incoming pod may name a topology key no existing pod touched:
         self_hits: Dict[int, int] = {}    #  kidx can still grow here)
         for wt, sign in [(w, 1) for w in p_aff] + [(w, -1) for w in p_anti]:
-            if _term_matches_pod(wt["podAffinityTerm"], sim_ns, sim_as_pod):  # both directions: incoming's term vs the
+            if tm(wt["podAffinityTerm"], sim_ns, sim_as_pod):  # both directions: incoming's term vs the
                 k = kidx(wt["podAffinityTerm"]["topologyKey"])              # clone, and the clone's term vs the incoming pod
                 self_score[k] = self_score.get(k, 0) + 2 * sign * int(wt["weight"])
                 self_hits[k] = self_hits.get(k, 0) + 2
         if hard_pod_affinity_weight > 0:
             for t in r_aff:
-                if _term_matches_pod(t, sim_ns, sim_as_pod):
+                if tm(t, sim_ns, sim_as_pod):
                     k = kidx(t["topologyKey"])
                     self_score[k] = self_score.get(k, 0) + hard_pod_affinity_weight
                     self_hits[k] = self_hits.get(k, 0) + 1

@@ -612,6 +612,10 @@ def _random_objects(rng):
             t["namespaces"] = [str(x) for x in rng.choice(["default", "other", "third"], int(rng.integers(1, 3)), replace=False)]
         elif r < 0.3:
             t["namespaceSelector"] = {}
+        elif r < 0.45:
+            t["namespaceSelector"] = {"matchLabels": {"team": str(rng.choice(["a", "b"]))}}
+            if rng.random() < 0.5:
+                t["namespaces"] = ["third"]
         return t
 
     def rand_pod_affinity():
@@ -687,6 +691,9 @@ def _random_objects(rng):
                                ("labelSelector", rand_selector())) if v is not None or k == "labelSelector"}
             for _ in range(int(rng.integers(1, 3)))]
     exclude = [f"n{int(rng.integers(0, n))}"] if rng.random() < 0.3 else []
+    # Namespace objects travel with the pods (simulator.go:177-185); "third" has none -> no labels
+    pods += [{"kind": "Namespace", "metadata": {"name": "default", "labels": {"team": "a", "kubernetes.io/metadata.name": "default"}}},
+             {"kind": "Namespace", "metadata": {"name": "other", "labels": {"team": str(rng.choice(["a", "b"]))}}}]
     return nodes, pods, pod, exclude
 
 
@@ -699,7 +706,8 @@ def test_native_ingest_random_differential(native, tmp_path, seed):
     args = ["--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
     p = subprocess.run([native] + args, capture_output=True, text=True, timeout=60)
     try:
-        ref = py_dump(ingest.build_snapshot(*cli.load_objects(snaps), cli.parse_pod_spec(podspec), exclude))
+        no, po, ns = cli.load_all(snaps)
+        ref = py_dump(ingest.build_snapshot(no, po, cli.parse_pod_spec(podspec), exclude, namespace_objs=ns))
     except NotImplementedError as e:  # both hosts refuse the same inputs (e.g. more topology keys than the engine holds)
         assert p.returncode == 1 and str(e).split(" ")[-1] in p.stderr
         return
@@ -749,3 +757,28 @@ def test_native_yaml_reader_fuzz_against_pyyaml(native, tmp_path):
         (tmp_path / "d.yaml").write_text(text)
         got = json.loads(_run(native, ["--parse", str(tmp_path / "d.yaml")]))
         assert got == [d for d in yaml.safe_load_all(text) if d], (it, text)
+
+
+def test_namespace_selector_known_answer(native, tmp_path):
+    """AffinityTerm.Matches (S/framework/types.go:927-935): namespaces UNION namespaceSelector, labels from the Namespace
+    objects of the snapshot; a term without either means the owner's namespace."""
+    nodes = [node("a"), node("b")]
+    ns = [{"kind": "Namespace", "metadata": {"name": n, "labels": {"team": t}}} for n, t in (("default", "x"), ("red", "r"), ("blue", "b"))]
+    pods = [running_pod("p-default", "a", labels={"app": "web"}, ns="default"), running_pod("p-red", "a", labels={"app": "web"}, ns="red"),
+            running_pod("p-blue", "b", labels={"app": "web"}, ns="blue"), running_pod("p-nolabel-ns", "b", labels={"app": "web"}, ns="ghost")]
+    sel = {"matchLabels": {"app": "web"}}
+    terms = [{"topologyKey": "kubernetes.io/hostname", "labelSelector": sel},                                                # own namespace only
+             {"topologyKey": "kubernetes.io/hostname", "labelSelector": sel, "namespaceSelector": {"matchLabels": {"team": "r"}}},  # red
+             {"topologyKey": "kubernetes.io/hostname", "labelSelector": sel, "namespaceSelector": {}},                           # every namespace
+             {"topologyKey": "kubernetes.io/hostname", "labelSelector": sel, "namespaces": ["blue"],
+              "namespaceSelector": {"matchLabels": {"team": "r"}}}]                                                             # blue UNION red
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["spec"]["affinity"] = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": terms}}
+    for n in nodes:
+        n["metadata"]["labels"]["kubernetes.io/hostname"] = n["metadata"]["name"]
+    snap = ingest.build_snapshot(nodes, pods, pod, namespace_objs=ns)
+    assert [a.tolist() if a is not None else None for a in snap.pod.ipa.anti_existing] == [[1, 0], [1, 0], [2, 2], [1, 1]]
+    (tmp_path / "c.json").write_text(json.dumps({"kind": "List", "items": nodes + pods + ns}))
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    got = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
+    assert got["pod"]["ipa"]["anti_existing"] == [[1, 0], [1, 0], [2, 2], [1, 1]]
