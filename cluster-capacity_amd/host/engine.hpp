@@ -122,7 +122,7 @@ inline void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
         c.col = k.col, c.max_skew = k.max_skew, c.min_domains = k.min_domains, c.hard = k.hard, c.self_match = k.self_match;
         c.n_domains = k.n_domains, c.is_hostname = k.is_hostname;
         c.node_match_count = k.node_match_count.empty() ? nullptr : k.node_match_count.data();
-        c.node_included = k.use_included ? s.included.data() : nullptr;
+        c.node_included = k.use_included ? k.node_included.data() : nullptr;
     }
     p.has_ipa = s.has_ipa;
     if (s.has_ipa) {

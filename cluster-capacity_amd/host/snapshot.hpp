@@ -245,7 +245,8 @@ struct Spread {
     int col, max_skew, min_domains, n_domains;
     bool hard, self_match, is_hostname;
     std::vector<int32_t> node_match_count; // empty = none
-    bool use_included = false;             // node inclusion policy (nodeAffinityPolicy: Honor) -> Snapshot::included
+    bool use_included = false;             // a node inclusion policy applies (common.go:107-122) -> node_included
+    std::vector<uint8_t> node_included;
 };
 
 struct Ipa {
@@ -444,9 +445,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             if (!selector_empty(sel) && ns_of(pod) == sim_ns && !pod["metadata"]["deletionTimestamp"].truthy() && label_selector_matches(sel, pod["metadata"]["labels"]))
                 existing[live_node[p]] += 1;
         }
+        // matchNodeInclusionPolicies (common.go:107-122): required node affinity / selector (default Honor) and the
+        // NoSchedule / NoExecute taints the pod does not tolerate (default Ignore)
         const std::string aff_policy = c["nodeAffinityPolicy"].truthy() ? c["nodeAffinityPolicy"].text() : "Honor";
         const std::string taint_policy = c["nodeTaintsPolicy"].truthy() ? c["nodeTaintsPolicy"].text() : "Ignore";
-        if (taint_policy == "Honor") throw Unsupported("nodeTaintsPolicy: Honor");
         k.max_skew = (int)c["maxSkew"].as_int();
         k.min_domains = c["minDomains"].truthy() ? (int)c["minDomains"].as_int() : 1;
         k.hard = (c["whenUnsatisfiable"].truthy() ? c["whenUnsatisfiable"].text() : "DoNotSchedule") == "DoNotSchedule";
@@ -454,7 +456,15 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         k.is_hostname = c["topologyKey"].text() == kHostname;
         k.n_domains = (int)it.values[(size_t)k.col].size();
         if (any_nonzero(existing)) k.node_match_count = existing;
-        k.use_included = aff_policy == "Honor" && s.affinity_filter_active;
+        const bool honor_aff = aff_policy == "Honor" && s.affinity_filter_active, honor_taints = taint_policy == "Honor";
+        k.use_included = honor_aff || honor_taints;
+        if (k.use_included) {
+            k.node_included.assign(N, 1);
+            for (size_t i = 0; i < N; i++) {
+                if (honor_aff && !s.included[i]) k.node_included[i] = 0;
+                if (honor_taints && !s.taint_filter_ok[(size_t)s.taintset_id[i]]) k.node_included[i] = 0;
+            }
+        }
         s.spread.push_back(std::move(k));
     }
 
@@ -621,7 +631,7 @@ inline Value snapshot_json(const Snapshot &s) {
         e.set("hard", Value::boolean(k.hard)), e.set("self_match", Value::boolean(k.self_match)), e.set("is_hostname", Value::boolean(k.is_hostname));
         e.set("n_domains", Value::num(k.n_domains));
         e.set("node_match_count", k.node_match_count.empty() ? Value() : int_array(k.node_match_count));
-        e.set("node_included", k.use_included ? int_array(s.included) : Value());
+        e.set("node_included", k.use_included ? int_array(k.node_included) : Value());
         sp.a.push_back(e);
     }
     p.set("required", rq), p.set("preferred", pf), p.set("spread", sp);

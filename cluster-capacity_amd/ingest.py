@@ -359,15 +359,22 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
         for p in live:
             if matches(p):
                 existing[index[p["spec"]["nodeName"]]] += 1
+        # matchNodeInclusionPolicies (common.go:107-122): required node affinity / selector (default Honor) and the
+        # NoSchedule / NoExecute taints the pod does not tolerate (default Ignore)
         honor_aff = (c.get("nodeAffinityPolicy") or "Honor") == "Honor"
-        if (c.get("nodeTaintsPolicy") or "Ignore") == "Honor":
-            raise NotImplementedError("nodeTaintsPolicy: Honor")
+        honor_taints = (c.get("nodeTaintsPolicy") or "Ignore") == "Honor"
+        inc = None
+        if honor_aff and included is not None:
+            inc = included.copy()
+        if honor_taints:
+            tol_ok = np.array(ok, np.uint8)[ts_id]
+            inc = tol_ok if inc is None else (inc & tol_ok)
         pod.spread.append(M.SpreadConstraint(
             col=col, max_skew=int(c["maxSkew"]), min_domains=int(c.get("minDomains") or 1),
             hard=(c.get("whenUnsatisfiable") or "DoNotSchedule") == "DoNotSchedule",
             self_match=not selector_empty(sel) and label_selector_matches(sel, sim_labels),
             is_hostname=c["topologyKey"] == HOSTNAME, n_domains=len(it.values[col]),
-            node_match_count=existing if existing.any() else None, node_included=included if honor_aff else None))
+            node_match_count=existing if existing.any() else None, node_included=inc))
 
     # inter-pod affinity (filtering.go:204-432, scoring.go:81-125)
     pa = (spec.get("affinity") or {}).get("podAffinity") or {}

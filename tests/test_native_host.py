@@ -688,6 +688,7 @@ def _random_objects(rng):
                                ("topologyKey", str(rng.choice(["topology.kubernetes.io/zone", "kubernetes.io/hostname", "rack"]))),
                                ("whenUnsatisfiable", str(rng.choice(["DoNotSchedule", "ScheduleAnyway"])) if rng.random() < 0.8 else None),
                                ("nodeAffinityPolicy", str(rng.choice(["Honor", "Ignore"])) if rng.random() < 0.4 else None),
+                               ("nodeTaintsPolicy", str(rng.choice(["Honor", "Ignore"])) if rng.random() < 0.4 else None),
                                ("labelSelector", rand_selector())) if v is not None or k == "labelSelector"}
             for _ in range(int(rng.integers(1, 3)))]
     exclude = [f"n{int(rng.integers(0, n))}"] if rng.random() < 0.3 else []
@@ -782,3 +783,26 @@ def test_namespace_selector_known_answer(native, tmp_path):
     (tmp_path / "pod.json").write_text(json.dumps(pod))
     got = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
     assert got["pod"]["ipa"]["anti_existing"] == [[1, 0], [1, 0], [2, 2], [1, 1]]
+
+
+def test_spread_node_inclusion_policies_known_answer(native, tmp_path):
+    """matchNodeInclusionPolicies (podtopologyspread/common.go:107-122): nodeAffinityPolicy (default Honor) and
+    nodeTaintsPolicy (default Ignore) decide which nodes count towards a constraint's domains."""
+    z = lambda v, **kw: dict({"topology.kubernetes.io/zone": v}, **kw)
+    nodes = [node("n0", labels=z("a", disk="ssd")), node("n1", labels=z("a", disk="hdd")),
+             node("n2", labels=z("b", disk="ssd"), taints=[{"key": "dedicated", "value": "infra", "effect": "NoSchedule"}]),
+             node("n3", labels=z("b", disk="ssd"), taints=[{"key": "soft", "effect": "PreferNoSchedule"}])]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["spec"]["nodeSelector"] = {"disk": "ssd"}
+    base = {"maxSkew": 1, "topologyKey": "topology.kubernetes.io/zone", "labelSelector": {"matchLabels": {"app": "guestbook"}}}
+    pod["spec"]["topologySpreadConstraints"] = [dict(base), dict(base, nodeAffinityPolicy="Ignore"), dict(base, nodeTaintsPolicy="Honor"),
+                                                dict(base, nodeAffinityPolicy="Ignore", nodeTaintsPolicy="Honor")]
+    want = [[1, 0, 1, 1], None, [1, 0, 0, 1], [1, 1, 0, 1]]  # canonical order n0 n2 n1 n3 -> reorder below
+    snap = ingest.build_snapshot(nodes, [], pod)
+    order = [snap.names.index(n) for n in ("n0", "n1", "n2", "n3")]
+    got_py = [None if k.node_included is None else [int(k.node_included[i]) for i in order] for k in snap.pod.spread]
+    assert got_py == want
+    (tmp_path / "c.json").write_text(json.dumps({"kind": "List", "items": nodes}))
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
+    assert [None if k["node_included"] is None else [k["node_included"][i] for i in order] for k in d["pod"]["spread"]] == want
