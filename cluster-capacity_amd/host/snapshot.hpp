@@ -436,7 +436,21 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
 
     // topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
     for (const auto &c : spec["topologySpreadConstraints"].items()) {
-        const Value &sel = c["labelSelector"];
+        // matchLabelKeys (common.go:95-105): the incoming pod's own values of these keys are ANDed into the selector
+        Value merged_sel = c["labelSelector"];
+        if (!merged_sel.is_null()) {
+            Value exprs = merged_sel["matchExpressions"].t == Value::Arr ? merged_sel["matchExpressions"] : Value::array();
+            bool any = false;
+            for (const auto &k : c["matchLabelKeys"].items())
+                if (sim_labels.has(k.text())) {
+                    Value e = Value::object(), vals = Value::array();
+                    vals.a.push_back(Value::str(sim_labels[k.text()].text()));
+                    e.set("key", Value::str(k.text())), e.set("operator", Value::str("In")), e.set("values", vals);
+                    exprs.a.push_back(e), any = true;
+                }
+            if (any) merged_sel.set("matchExpressions", exprs);
+        }
+        const Value &sel = merged_sel;
         Spread k{};
         k.col = it.col(c["topologyKey"].text());
         std::vector<int32_t> existing(N, 0);

@@ -350,6 +350,10 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
     included = np.array([node_matches_required(i) for i in range(N)], np.uint8) if affinity_active else None
     for c in spec.get("topologySpreadConstraints") or []:
         sel = c.get("labelSelector")
+        # matchLabelKeys (common.go:95-105): the incoming pod's own values of these keys are ANDed into the selector
+        merged = [{"key": k, "operator": "In", "values": [sim_labels[k]]} for k in c.get("matchLabelKeys") or [] if k in sim_labels]
+        if sel is not None and merged:
+            sel = {"matchLabels": dict(sel.get("matchLabels") or {}), "matchExpressions": list(sel.get("matchExpressions") or []) + merged}
         col = it.col(c["topologyKey"])
 
         def matches(p):  # countPodsMatchSelector (common.go:144-159)

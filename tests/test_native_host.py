@@ -689,6 +689,8 @@ def _random_objects(rng):
                                ("whenUnsatisfiable", str(rng.choice(["DoNotSchedule", "ScheduleAnyway"])) if rng.random() < 0.8 else None),
                                ("nodeAffinityPolicy", str(rng.choice(["Honor", "Ignore"])) if rng.random() < 0.4 else None),
                                ("nodeTaintsPolicy", str(rng.choice(["Honor", "Ignore"])) if rng.random() < 0.4 else None),
+                               ("matchLabelKeys", [str(x) for x in rng.choice(["app", "tier", "absent"], int(rng.integers(1, 3)), replace=False)]
+                                if rng.random() < 0.3 else None),
                                ("labelSelector", rand_selector())) if v is not None or k == "labelSelector"}
             for _ in range(int(rng.integers(1, 3)))]
     exclude = [f"n{int(rng.integers(0, n))}"] if rng.random() < 0.3 else []
@@ -806,3 +808,24 @@ def test_spread_node_inclusion_policies_known_answer(native, tmp_path):
     (tmp_path / "pod.json").write_text(json.dumps(pod))
     d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
     assert [None if k["node_included"] is None else [k["node_included"][i] for i in order] for k in d["pod"]["spread"]] == want
+
+
+def test_spread_match_label_keys_known_answer(native, tmp_path):
+    """matchLabelKeys (podtopologyspread/common.go:95-105): the incoming pod's values of the listed keys join the selector."""
+    nodes = [node("n0", labels={"topology.kubernetes.io/zone": "a"}), node("n1", labels={"topology.kubernetes.io/zone": "b"})]
+    pods = [running_pod("v1-a", "n0", labels={"app": "web", "rev": "1"}), running_pod("v2-a", "n0", labels={"app": "web", "rev": "2"}),
+            running_pod("v2-b", "n1", labels={"app": "web", "rev": "2"}), running_pod("other", "n1", labels={"app": "db", "rev": "2"})]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["metadata"]["labels"] = {"app": "web", "rev": "2"}
+    base = {"maxSkew": 1, "topologyKey": "topology.kubernetes.io/zone", "labelSelector": {"matchLabels": {"app": "web"}}}
+    pod["spec"]["topologySpreadConstraints"] = [dict(base), dict(base, matchLabelKeys=["rev"]), dict(base, matchLabelKeys=["absent"]),
+                                                {"maxSkew": 1, "topologyKey": "topology.kubernetes.io/zone", "labelSelector": {}, "matchLabelKeys": ["rev"]},
+                                                {"maxSkew": 1, "topologyKey": "topology.kubernetes.io/zone", "matchLabelKeys": ["rev"]}]
+    # web pods: 2 / 1; web AND rev=2: 1 / 1; key absent on the pod: unchanged; {} AND rev=2: 1 / 2 (db counts); nil selector stays Nothing
+    want = [([2, 1], True), ([1, 1], True), ([2, 1], True), ([1, 2], True), (None, False)]
+    snap = ingest.build_snapshot(nodes, pods, pod)
+    assert [(None if k.node_match_count is None else k.node_match_count.tolist(), bool(k.self_match)) for k in snap.pod.spread] == want
+    (tmp_path / "c.json").write_text(json.dumps({"kind": "List", "items": nodes + pods}))
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
+    assert [(k["node_match_count"], k["self_match"]) for k in d["pod"]["spread"]] == want
