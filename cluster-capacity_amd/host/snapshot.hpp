@@ -48,29 +48,39 @@ struct PodRequests {
     int64_t nz_cpu = 0, nz_mem = 0;
 };
 
-// helpers.go:144-251 PodRequests + types.go:1095-1124 (restartable init containers are not modelled)
+// IsSupportedPodLevelResource (component-helpers/resource/helpers.go): cpu, memory, hugepages-*
+inline bool pod_level_supported(const std::string &n) { return n == "cpu" || n == "memory" || n.rfind("hugepages-", 0) == 0; }
+
+// PodRequests for one resource (helpers.go:144-251): sum of the containers; restartable (sidecar) init containers add to the
+// sum; InitContainerUse(i) = the i-th init container + the sidecars before it, and the pod needs at least the largest of those;
+// pod-level requests (spec.resources) override the aggregate for the resources they may carry; + overhead.  `dflt` >= 0 stands in
+// for a container that does not name the resource (NonMissingContainerRequests, types.go:1095-1124).
+inline int64_t aggregate_request(const Value &spec, const std::string &name, int64_t dflt = -1) {
+    auto creq = [&](const Value &c) -> int64_t {
+        const Value &r = c["resources"]["requests"];
+        if (r.truthy() && r.has(name)) return res_of(r, name);
+        return dflt >= 0 ? dflt : 0;
+    };
+    int64_t total = 0, restartable = 0, init_max = 0;
+    for (const auto &c : spec["containers"].items()) total += creq(c);
+    for (const auto &ic : spec["initContainers"].items()) {
+        const int64_t r = creq(ic);
+        int64_t use;
+        if (ic["restartPolicy"].text() == "Always") total += r, restartable += r, use = restartable;
+        else use = r + restartable;
+        init_max = std::max(init_max, use);
+    }
+    total = std::max(total, init_max);
+    const Value &pod_level = spec["resources"]["requests"];
+    if (pod_level.truthy() && pod_level.has(name) && pod_level_supported(name)) total = res_of(pod_level, name);
+    return total + res_of(spec["overhead"], name);
+}
+
 inline PodRequests pod_requests(const Value &spec, const std::vector<std::string> &names) {
     PodRequests out;
-    auto creq = [](const Value &c, const std::string &n) { return res_of(c["resources"]["requests"], n); };
-    for (const auto &n : names) {
-        int64_t total = 0;
-        for (const auto &c : spec["containers"].items()) total += creq(c, n);
-        for (const auto &ic : spec["initContainers"].items()) total = std::max(total, creq(ic, n));
-        total += res_of(spec["overhead"], n);
-        out.req.push_back(total);
-    }
-    auto nz = [&](const std::string &n, int64_t dflt) {
-        auto one = [&](const Value &c) {
-            const Value &r = c["resources"]["requests"];
-            return r.truthy() && r.has(n) ? res_of(r, n) : dflt;
-        };
-        int64_t total = 0;
-        for (const auto &c : spec["containers"].items()) total += one(c);
-        for (const auto &ic : spec["initContainers"].items()) total = std::max(total, one(ic));
-        return total + res_of(spec["overhead"], n);
-    };
-    out.nz_cpu = nz("cpu", kDefaultMilliCPU);
-    out.nz_mem = nz("memory", kDefaultMemory);
+    for (const auto &n : names) out.req.push_back(aggregate_request(spec, n));
+    out.nz_cpu = aggregate_request(spec, "cpu", kDefaultMilliCPU);
+    out.nz_mem = aggregate_request(spec, "memory", kDefaultMemory);
     return out;
 }
 

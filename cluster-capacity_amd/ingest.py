@@ -74,29 +74,44 @@ def is_scalar_resource(name: str) -> bool:
     return True
 
 
+def _pod_level_supported(name: str) -> bool:
+    """IsSupportedPodLevelResource (component-helpers/resource/helpers.go): cpu, memory, hugepages-*."""
+    return name in ("cpu", "memory") or name.startswith("hugepages-")
+
+
+def _aggregate(spec: dict, name: str, default: Optional[int] = None) -> int:
+    """PodRequests for one resource (helpers.go:144-251): sum of the containers; restartable (sidecar) init containers add to
+    the sum; InitContainerUse(i) = the i-th init container + the sidecars before it, and the pod needs at least the largest
+    of those; pod-level requests (spec.resources) override the aggregate for the resources they may carry; + overhead.
+    `default` stands in for a container that does not name the resource (NonMissingContainerRequests, types.go:1095-1124)."""
+    def creq(c):
+        r = (c.get("resources") or {}).get("requests") or {}
+        if name in r:
+            return milli_value(r[name]) if name == "cpu" else value(r[name])
+        return default if default is not None else 0
+
+    total = sum(creq(c) for c in spec.get("containers") or [])
+    restartable = init_max = 0
+    for ic in spec.get("initContainers") or []:
+        r = creq(ic)
+        if ic.get("restartPolicy") == "Always":
+            total += r
+            restartable += r
+            use = restartable
+        else:
+            use = r + restartable
+        init_max = max(init_max, use)
+    total = max(total, init_max)
+    pod_level = (spec.get("resources") or {}).get("requests") or {}
+    if name in pod_level and _pod_level_supported(name):
+        total = _res(pod_level, name)
+    return total + _res(spec.get("overhead"), name)
+
+
 def pod_requests(spec: dict, names: Sequence[str]):
     """-> (requests per name, non-zero cpu, non-zero memory).  helpers.go:144-251 PodRequests + types.go:1095-1124."""
-    def container_req(c, n):
-        return _res((c.get("resources") or {}).get("requests"), n)
-
-    out = {}
-    for n in names:
-        total = sum(container_req(c, n) for c in spec.get("containers") or [])
-        for ic in spec.get("initContainers") or []:
-            total = max(total, container_req(ic, n))  # (restartable init containers are not modelled)
-        total += _res(spec.get("overhead"), n)
-        out[n] = total
-
-    def nz(n, default):
-        def one(c):
-            r = (c.get("resources") or {}).get("requests") or {}
-            return (milli_value(r[n]) if n == "cpu" else value(r[n])) if n in r else default
-        total = sum(one(c) for c in spec.get("containers") or [])
-        for ic in spec.get("initContainers") or []:
-            total = max(total, one(ic))
-        return total + _res(spec.get("overhead"), n)
-
-    return out, nz("cpu", DEFAULT_MILLI_CPU), nz("memory", DEFAULT_MEMORY)
+    out = {n: _aggregate(spec, n) for n in names}
+    return out, _aggregate(spec, "cpu", DEFAULT_MILLI_CPU), _aggregate(spec, "memory", DEFAULT_MEMORY)
 
 
 def zone_key(labels: dict) -> str:

@@ -649,6 +649,11 @@ def _random_objects(rng):
                         affinity=rand_pod_affinity())
         if rng.random() < 0.2:
             p["spec"]["initContainers"] = [{"name": "i", "resources": {"requests": {"cpu": str(rng.choice(qty_cpu)), "example.com/gpu": "1"}}}]
+        if rng.random() < 0.15:  # sidecars between ordinary init containers (KEP-753)
+            p["spec"]["initContainers"] = [dict({"name": f"i{k}", "resources": {"requests": {"cpu": str(rng.choice(qty_cpu))} if rng.random() < 0.7 else {}}},
+                                                **({"restartPolicy": "Always"} if rng.random() < 0.5 else {})) for k in range(int(rng.integers(1, 5)))]
+        if rng.random() < 0.1:
+            p["spec"]["resources"] = {"requests": {"cpu": str(rng.choice(qty_cpu)), "memory": str(rng.choice(qty_mem))}}
         if rng.random() < 0.15:
             p["spec"]["overhead"] = {"cpu": "1m", "memory": "1Ki"}
         if rng.random() < 0.1:
@@ -665,6 +670,11 @@ def _random_objects(rng):
         spec["containers"].append({"name": "besteffort"})
     if rng.random() < 0.3:
         spec["initContainers"] = [{"name": "i", "resources": {"requests": {"memory": str(rng.choice(qty_mem))}}}]
+    if rng.random() < 0.2:
+        spec["initContainers"] = [dict({"name": f"i{k}", "resources": {"requests": {"cpu": str(rng.choice(qty_cpu)), "memory": str(rng.choice(qty_mem))}}},
+                                       **({"restartPolicy": "Always"} if rng.random() < 0.5 else {})) for k in range(int(rng.integers(1, 4)))]
+    if rng.random() < 0.1:
+        spec["resources"] = {"requests": {"cpu": str(rng.choice(qty_cpu))}}
     if rng.random() < 0.5:
         spec["nodeSelector"] = {str(k): str(rng.choice(vals[k])) for k in rng.choice(["disk", "team", "rack"], int(rng.integers(1, 3)), replace=False)}
     spec["tolerations"] = [{k: v for k, v in (("key", str(rng.choice(["dedicated", "maintenance", "", "node.kubernetes.io/unschedulable"]))),
@@ -829,3 +839,25 @@ def test_spread_match_label_keys_known_answer(native, tmp_path):
     (tmp_path / "pod.json").write_text(json.dumps(pod))
     d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
     assert [(k["node_match_count"], k["self_match"]) for k in d["pod"]["spread"]] == want
+
+
+def test_sidecar_and_pod_level_requests_known_answer(native, tmp_path):
+    """PodRequests (component-helpers/resource/helpers.go:144-251, KEP-753): restartable init containers add to the sum,
+    InitContainerUse(i) = init container i + the sidecars before it, pod-level requests override, overhead on top."""
+    pod = yaml.safe_load(EXAMPLES_POD)
+    spec = pod["spec"]
+    spec["containers"] = [{"name": "c", "resources": {"requests": {"cpu": "1"}}}]
+    spec["initContainers"] = [{"name": "ic1", "resources": {"requests": {"cpu": "2"}}},
+                              {"name": "s1", "restartPolicy": "Always", "resources": {"requests": {"cpu": "500m"}}},
+                              {"name": "ic2", "resources": {"requests": {"cpu": "3"}}},
+                              {"name": "s2", "restartPolicy": "Always", "resources": {"requests": {"cpu": "250m"}}}]
+    spec["overhead"] = {"cpu": "10m"}
+    req, nzc, nzm = ingest.pod_requests(spec, ["cpu", "memory"])
+    assert req == {"cpu": 3510, "memory": 0} and nzc == 3510 and nzm == 600 * (1 << 20)
+    spec["resources"] = {"requests": {"cpu": "5", "example.com/gpu": "9"}}  # pod-level: cpu counts, extended resources do not
+    req, nzc, nzm = ingest.pod_requests(spec, ["cpu", "memory", "example.com/gpu"])
+    assert req == {"cpu": 5010, "memory": 0, "example.com/gpu": 0} and nzc == 5010
+    (tmp_path / "c.json").write_text(json.dumps({"kind": "List", "items": [node("n0")]}))
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
+    assert d["pod"]["req"][:2] == [5010, 0] and d["pod"]["nz_mcpu"] == 5010 and d["pod"]["nz_mem"] == 600 * (1 << 20)
