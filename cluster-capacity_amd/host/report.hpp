@@ -106,13 +106,17 @@ inline Value main_fail_reason(const std::string &message) {
     return o;
 }
 
-// report.go:146-180: per-node replica counts, in first-placement order when the log is available
+// report.go:146-180: per-node replica counts, in first-placement order when the log is available.  The log may be
+// capped below the number of placements (ccsim_report.log_cap): nodes first placed beyond the cap follow in canonical
+// node order, so the list always covers every node with a replica and sums to the headline count.
 inline Value replicas_on_nodes(const RunResult &r, const std::vector<std::string> &names) {
     std::vector<size_t> order;
     if (!r.log.empty()) {
         std::vector<char> seen(r.per_node_count.size(), 0);
         for (const int32_t g : r.log)
             if (g >= 0 && (size_t)g < seen.size() && !seen[(size_t)g]) seen[(size_t)g] = 1, order.push_back((size_t)g);
+        for (size_t i = 0; i < r.per_node_count.size(); i++)
+            if (r.per_node_count[i] && !seen[i]) order.push_back(i);
     } else
         for (size_t i = 0; i < r.per_node_count.size(); i++)
             if (r.per_node_count[i]) order.push_back(i);

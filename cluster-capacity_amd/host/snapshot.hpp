@@ -353,8 +353,13 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     for (const char *list : {"containers", "initContainers"})
         for (const auto &c : spec[list].items())
             for (const auto &kv : c["resources"]["requests"].fields()) req_names.insert(kv.first);
+    for (const auto &kv : spec["resources"]["requests"].fields()) req_names.insert(kv.first); // pod-level requests (hugepages-*)
+    for (const auto &kv : spec["overhead"].fields()) req_names.insert(kv.first);
     for (const auto &n : req_names) // std::set iterates sorted
-        if (is_scalar_resource(n) && (int)s.scalar_names.size() < CCSIM_MAX_SCALAR) s.scalar_names.push_back(n);
+        if (is_scalar_resource(n)) s.scalar_names.push_back(n);
+    if ((int)s.scalar_names.size() > CCSIM_MAX_SCALAR) // never drop a resource silently: the Fit filter would over-estimate
+        throw std::runtime_error("the pod names " + std::to_string(s.scalar_names.size()) + " scalar/extended resources; at most " +
+                                 std::to_string(CCSIM_MAX_SCALAR) + " are supported");
     s.res_names = {"cpu", "memory", "ephemeral-storage"};
     s.res_names.insert(s.res_names.end(), s.scalar_names.begin(), s.scalar_names.end());
     const size_t R = s.res_names.size();

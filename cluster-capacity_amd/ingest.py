@@ -287,7 +287,11 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
     req_names = set()
     for c in (spec.get("containers") or []) + (spec.get("initContainers") or []):
         req_names |= set(((c.get("resources") or {}).get("requests") or {}).keys())
-    scalars = sorted(n for n in req_names if is_scalar_resource(n))[: M.MAX_SCALAR]
+    req_names |= set(((spec.get("resources") or {}).get("requests") or {}).keys())  # pod-level requests (hugepages-*)
+    req_names |= set((spec.get("overhead") or {}).keys())
+    scalars = sorted(n for n in req_names if is_scalar_resource(n))
+    if len(scalars) > M.MAX_SCALAR:  # never drop a resource silently: the Fit filter would over-estimate the capacity
+        raise ValueError(f"the pod names {len(scalars)} scalar/extended resources; at most {M.MAX_SCALAR} are supported")
     res_names = ["cpu", "memory", "ephemeral-storage"] + scalars
     preq, nz_cpu, nz_mem = pod_requests(spec, res_names)
 

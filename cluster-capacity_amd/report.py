@@ -107,11 +107,15 @@ def main_fail_reason(message: str):
 
 
 def replicas_on_nodes(per_node_count: np.ndarray, names: Optional[List[str]] = None, log: Optional[np.ndarray] = None):
-    """report.go:146-180: per-node replica counts; first-placement order when a log is available."""
+    """report.go:146-180: per-node replica counts; first-placement order when a log is available.  The placement
+    log may be capped below the number of placements (ccsim_report.log_cap): nodes first placed beyond the cap follow
+    in canonical node order, so the list always covers every node with a replica and sums to the headline count."""
     idx = np.nonzero(per_node_count)[0]
     if log is not None and len(log):
         _, first = np.unique(log, return_index=True)
         order = log[np.sort(first)]
+        if len(order) < len(idx):
+            order = np.concatenate([order, np.setdiff1d(idx, order)])
     else:
         order = idx
     return [{"nodeName": names[i] if names else str(int(i)), "replicas": int(per_node_count[i])} for i in order]

@@ -108,7 +108,7 @@ def test_ingest_self_affinity_matches_reference_fixture(ccref):
                         {"topologyKey": "topology-domain", "labelSelector": {"matchLabels": {"key": "value"}}}]}}}}
     snap = ingest.build_snapshot(objs, [], sim)
     assert snap.pod.ipa.self_aff and snap.pod.ipa.score_self == [1] and snap.pod.ipa.self_entries == [1]
-    r = ccref.run(M.Profile(filter_mask=M.F_INTERPODAFFINITY | M.F_FIT), snap.nodes, snap.pod, max_limit=100)
+    r = ccref.run(M.Profile.default(), snap.nodes, snap.pod, max_limit=100)  # the fixture's profile keeps the MultiPoint defaults
     assert r.placed == 90 and r.per_node_count.tolist() == [30, 30, 30, 0, 0, 0, 0, 0, 0]
 
 
@@ -140,3 +140,12 @@ def test_cli_end_to_end_readme_demo(tmp_path):
     rev = json.loads(buf.getvalue())
     assert rev["status"]["replicas"] == 7 and rev["status"]["failReason"]["failType"] == "LimitReached"
     assert sum(r["replicas"] for r in rev["status"]["pods"][0]["replicasOnNodes"]) == 7
+
+
+def test_replicas_on_nodes_with_a_capped_log():
+    # ccsim_report.log_cap < placed (1M nodes x 110 pods exceeds the 2^26 cap): nodes first placed beyond the cap must
+    # still be listed, so that the pretty-printer's headline (the sum of the list) equals status.replicas
+    per_node = np.array([2, 3, 0, 1], np.int32)
+    got = R.replicas_on_nodes(per_node, ["a", "b", "c", "d"], np.array([1, 1], np.int32))  # log cut after two placements
+    assert [g["nodeName"] for g in got] == ["b", "a", "d"]
+    assert sum(g["replicas"] for g in got) == int(per_node.sum())

@@ -25,21 +25,36 @@ def self_affinity_pod(n_domains):
 
 
 def test_ka3_colocation_single_node(ccref):
-    # pod_colocation_test.go:18-97: 3 nodes, hostname topology, Filter = InterPodAffinity only, limit 100.
+    # pod_colocation_test.go:18-97: 3 nodes, hostname topology, limit 100.  The fixture sets only
+    # Profiles[0].Plugins.Filter.Enabled = [InterPodAffinity] (:49-53); the MultiPoint defaults still contribute every
+    # default Filter plugin behind it (expandMultiPointPlugins, S/framework/runtime/framework.go:539-624 -- the merge
+    # cluster_capacity_amd/schedconfig.py implements), so NodeResourcesFit is ON.
     # First pod: affinityCounts empty + self-match -> allowed everywhere (filtering.go:396-405); afterwards only the
-    # node holding the clones passes.  No Fit filter -> the 30-pod capacity never binds: 100 on ONE node.
+    # node holding the clones passes InterPodAffinity; its 30-pod capacity binds: 30 on ONE node, then Unschedulable.
+    prof = M.Profile.default()
+    r = ccref.run(prof, colocation_nodes([1, 2, 3]), self_affinity_pod(3), max_limit=100)
+    assert r.placed == 30 and r.stop == M.STOP_UNSCHEDULABLE
+    assert sorted(r.per_node_count.tolist()) == [0, 0, 30]  # the test's assertion: all pods on one node (:84-90)
+    assert r.per_node_count.tolist() == [30, 0, 0]          # canonical tie-break: lowest index
+    assert R.stop_reason(r, 3, 100).startswith(
+        "Unschedulable: 0/3 nodes are available: 1 Too many pods, 2 node(s) didn't match pod affinity rules.")
+
+
+def test_hand_case_interpodaffinity_as_the_only_filter(ccref):
+    # NOT a reference fixture: a profile whose ONLY filter is InterPodAffinity (MultiPoint defaults disabled).  No Fit
+    # filter -> the 30-pod capacity never binds: the limit of 100 is reached on one node.
     prof = M.Profile(filter_mask=M.F_INTERPODAFFINITY)
     r = ccref.run(prof, colocation_nodes([1, 2, 3]), self_affinity_pod(3), max_limit=100)
     assert r.placed == 100 and r.stop == M.STOP_LIMIT
-    assert sorted(r.per_node_count.tolist()) == [0, 0, 100]  # the test's assertion: all pods on one node (:84-90)
-    assert r.per_node_count.tolist() == [100, 0, 0]          # canonical tie-break: lowest index
+    assert r.per_node_count.tolist() == [100, 0, 0]
 
 
 def test_ka4_colocation_single_zone(ccref):
     # pod_colocation_test.go:99-190: 9 nodes in 3 zones (custom topology key, so the node tree has one zone and the
-    # canonical order is by name: node1-1..node3-3), Filter = InterPodAffinity + NodeResourcesFit, limit 100.
+    # canonical order is by name: node1-1..node3-3), Filter.Enabled = [InterPodAffinity, NodeResourcesFit] in front of
+    # the MultiPoint defaults (see KA3), limit 100.
     # All pods land in the first pod's zone; 30 pods/node -> 90 = 30+30+30, then Unschedulable.
-    prof = M.Profile(filter_mask=M.F_INTERPODAFFINITY | M.F_FIT)
+    prof = M.Profile.default()
     nodes = colocation_nodes([1, 1, 1, 2, 2, 2, 3, 3, 3])
     r = ccref.run(prof, nodes, self_affinity_pod(3), max_limit=100)
     assert r.placed == 90 and r.stop == M.STOP_UNSCHEDULABLE
@@ -97,10 +112,15 @@ def _gpu_check(ccref, nodes, pod, prof, limit):
 
 @pytest.mark.gpu
 def test_gpu_ipa_reference_fixtures(ccref):
-    _gpu_check(ccref, colocation_nodes([1, 2, 3]), self_affinity_pod(3), M.Profile(filter_mask=M.F_INTERPODAFFINITY), 100)
-    got = _gpu_check(ccref, colocation_nodes([1, 1, 1, 2, 2, 2, 3, 3, 3]), self_affinity_pod(3),
-                     M.Profile(filter_mask=M.F_INTERPODAFFINITY | M.F_FIT), 100)
+    # the fixtures' real profile: Filter.Enabled entries in front of the MultiPoint defaults (see test_ka3_*)
+    got = _gpu_check(ccref, colocation_nodes([1, 2, 3]), self_affinity_pod(3), M.Profile.default(), 100)
+    assert got.placed == 30 and got.per_node_count.tolist() == [30, 0, 0]
+    got = _gpu_check(ccref, colocation_nodes([1, 1, 1, 2, 2, 2, 3, 3, 3]), self_affinity_pod(3), M.Profile.default(), 100)
     assert got.placed == 90 and got.per_node_count.tolist() == [30, 30, 30, 0, 0, 0, 0, 0, 0]
+    # hand cases (not reference fixtures): InterPodAffinity as the only filter / with NodeResourcesFit only
+    _gpu_check(ccref, colocation_nodes([1, 2, 3]), self_affinity_pod(3), M.Profile(filter_mask=M.F_INTERPODAFFINITY), 100)
+    _gpu_check(ccref, colocation_nodes([1, 1, 1, 2, 2, 2, 3, 3, 3]), self_affinity_pod(3),
+               M.Profile(filter_mask=M.F_INTERPODAFFINITY | M.F_FIT), 100)
 
 
 @pytest.mark.gpu
