@@ -121,6 +121,7 @@ SYMBOLS = {
     "ccsim_dist_tables_done": (C.c_int, [C.c_void_p]),
     "ccsim_reset_state": (C.c_int, [C.c_void_p]),
     "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ccsim_debug_persist_prof": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -402,6 +403,15 @@ class Engine:
         ns, by = C.c_int64(), C.c_int64()
         self._chk(self.lib.ccsim_time_scan(self.h, MODES[mode], int(iters), C.byref(ns), C.byref(by)), "ccsim_time_scan")
         return int(ns.value), int(by.value)
+
+    def persist_prof(self):
+        """Phase breakdown of the last persistent batched launch (ccsim_debug_persist_prof), in microseconds."""
+        out = (C.c_int64 * 8)()
+        self._chk(self.lib.ccsim_debug_persist_prof(self.h, out), "ccsim_debug_persist_prof")
+        names = ["scan_list", "plan", "apply", "block_reduce", "grid_reduce", "rescore"]
+        d = {k: out[i] / 100.0 for i, k in enumerate(names)}
+        d["levels"] = int(out[6])
+        return d
 
     # ---- distributed stepping (collective supplied by the caller, see dist.py) ----
     def dist_begin(self, max_limit: int, mode: str, n_ranks: int, rank: int, send_ptr: int, recv_ptr: int, log_cap: int = 0):

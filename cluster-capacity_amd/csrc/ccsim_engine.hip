@@ -8,6 +8,7 @@
 // There is NO CPU fallback: every entry point fails loudly if HIP does.
 #include "ccsim_kernels.h"
 #include "ccsim_level.h"
+#include "ccsim_persist.h"
 
 #include <errno.h>
 #include <hip/hip_ext.h>
@@ -93,6 +94,12 @@ struct ccsim_engine {
     int32_t *d_cscore = nullptr;
     int64_t *d_blockprefix = nullptr;
     int rank = 0;
+    // persistent batched run (ccsim_persist.h)
+    PersistSync *d_psync = nullptr;
+    int n_cus = 0;
+    int persist_allowed = 1;
+    int64_t node_max_podcount = 0; // largest len(NodeInfo.Pods) of the snapshot
+    int persist_run = 0; // K of the current batched run's persistent launch, 0 = multi-kernel path
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
     int dist_pass_in_window = 0;      // passes since the last ccsim_dist_begin / ccsim_dist_poll
@@ -146,6 +153,7 @@ static int dev_alloc(ccsim_engine *e, T **out, size_t count, std::vector<void *>
 
 struct ccsim_engine;
 static int build_narrow(ccsim_engine *e);
+static int persist_k(const ccsim_engine *e);
 
 template <typename T>
 static int upload(ccsim_engine *e, T **out, const T *src, size_t count, size_t padded, std::vector<void *> &track) {
@@ -184,6 +192,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     e->use_graph = cfg->use_graph;
     e->time_passes = cfg->time_passes;
     if (const char *f = getenv("CCSIM_NARROW")) e->narrow_allowed = atoi(f); // A/B knob
+    if (const char *f = getenv("CCSIM_PERSIST")) e->persist_allowed = atoi(f); // A/B knob: 0 = multi-kernel batched mode
     if (hipSetDevice(e->device) != hipSuccess) {
         delete e;
         return -EIO;
@@ -203,9 +212,14 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
         hipMalloc((void **)&e->d_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_smp_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_smp_prefix, sizeof(int64_t) * kMaxGrid) != hipSuccess ||
-        hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess) {
+        hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess ||
+        hipMalloc((void **)&e->d_psync, sizeof(PersistSync)) != hipSuccess) {
         ccsim_destroy(e);
         return -ENOMEM;
+    }
+    {
+        hipDeviceProp_t prop;
+        e->n_cus = hipGetDeviceProperties(&prop, e->device) == hipSuccess ? prop.multiProcessorCount : 0;
     }
     e->d_hist_code = e->d_hist + CCSIM_NREASON;
     *out = e;
@@ -224,6 +238,7 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->d_smp_partials) (void)hipFree(e->d_smp_partials);
     if (e->d_smp_prefix) (void)hipFree(e->d_smp_prefix);
     if (e->d_hist) (void)hipFree(e->d_hist);
+    if (e->d_psync) (void)hipFree(e->d_psync);
     if (e->d_log) (void)hipFree(e->d_log);
     if (e->h_state) (void)hipHostFree(e->h_state);
     for (hipEvent_t ev : e->pass_events) (void)hipEventDestroy(ev);
@@ -303,7 +318,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
         if ((rc = dev_alloc(e, &c.rows, np * kRowWords, e->allocs))) return rc;
         c.a32[0] = m[0], c.a32[1] = m[1], c.r32[0] = m[2], c.r32[1] = m[3], c.z32[0] = m[4], c.z32[1] = m[5];
         c.narrow = 0, c.mem_shift = 0;
-        e->node_mem_or = 0, e->node_max_cpu = e->node_max_mem = e->node_max_pods = 0;
+        e->node_mem_or = 0, e->node_max_cpu = e->node_max_mem = e->node_max_pods = e->node_max_podcount = 0;
         for (size_t i = 0; i < n; i++) {
             const int64_t vc[3] = {nd->alloc[0] ? nd->alloc[0][i] : 0, nd->req[0] ? nd->req[0][i] : 0, nd->nz_mcpu[i]};
             const int64_t vm[3] = {nd->alloc[1] ? nd->alloc[1][i] : 0, nd->req[1] ? nd->req[1][i] : 0, nd->nz_mem[i]};
@@ -314,6 +329,8 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
                 e->node_mem_or |= (uint64_t)vm[k];
             }
             e->node_max_pods = nd->alloc_pods[i] > e->node_max_pods ? nd->alloc_pods[i] : e->node_max_pods;
+            e->node_max_podcount = nd->pod_count[i] > e->node_max_podcount ? nd->pod_count[i] : e->node_max_podcount;
+            if (nd->alloc_pods[i] < 0 || nd->pod_count[i] < 0) e->node_max_podcount = INT64_MAX; // never packed into 16 bits
         }
     }
     e->cols = c;
@@ -892,7 +909,8 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     e->limit = max_limit;
     e->mode = mode;
     e->begun = true;
-    const bool rows = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0;
+    e->persist_run = (mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes) ? persist_k(e) : 0;
+    const bool rows = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !e->persist_run;
     if (rows != e->rows_active) drop_graph(e);
     e->rows_active = rows;
     if (rows) {
@@ -1042,6 +1060,48 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     return 0;
 }
 
+// The persistent form of the batched mode (ccsim_persist.h): narrow mirrors, one 1024-thread workgroup per CU with up to
+// 4096 nodes each in LDS, scores and pod counts in 16 bits.  Everything else takes the multi-kernel path.
+static int persist_k(const ccsim_engine *e) {
+    if (!e->persist_allowed || !e->cols.narrow || e->pod.nx != 0 || e->n_ranks != 0 || e->n_cus <= 0 || e->n <= 0) return 0;
+    if (e->node_max_pods > 65535 || e->node_max_podcount > 65535) return 0;
+    const int64_t max_total = 100ll * ((int64_t)e->pod.w_taint + e->pod.w_aff + e->pod.w_fit + e->pod.w_bal);
+    if (max_total >= 65535) return 0;
+    const int cus = e->n_cus < kPMaxGrid ? e->n_cus : kPMaxGrid;
+    for (int k : {1, 2, 4})
+        if ((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads) <= cus) return k;
+    return 0;
+}
+
+static int run_persist(ccsim_engine *e, int k) {
+    PersistArgs a{};
+    const DevCols &c = e->cols;
+    a.c = PersistCols{{c.a32[0], c.a32[1]}, {c.r32[0], c.r32[1]}, {c.z32[0], c.z32[1]}, c.alloc_pods, c.pod_count, c.placed_cnt, c.stat,
+                      {c.req[0], c.req[1]}, c.nz_mcpu, c.nz_mem, c.n_pad, c.global_offset, c.mem_shift};
+    a.p = e->pod, a.st = e->d_state, a.sync = e->d_psync, a.log = e->d_log, a.want_log = e->d_log ? 1 : 0;
+    a.max_syncs = 1 << 20;
+    a.seq_steps = kSeqSteps;
+    if (const char *f = getenv("CCSIM_SEQ_STEPS")) a.seq_steps = atoi(f) > 0 ? atoi(f) : kSeqSteps; // tuning knob
+    const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
+    for (int launch = 0; launch < 64; launch++) {
+        HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync), e->stream));
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        if (k == 1) hipLaunchKernelGGL(k_level_persist<1>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
+        else if (k == 2) hipLaunchKernelGGL(k_level_persist<2>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
+        else hipLaunchKernelGGL(k_level_persist<4>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        int rc = read_state(e);
+        if (rc) return rc;
+        float ms = 0;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->kernel_ms += ms, e->pass_kernel_ms += ms, e->pass_launches += 1;
+        if (e->h_state->done == DONE_ERROR) return fail(e, -EIO, "persistent level kernel: grid barrier timed out (a workgroup was not resident)");
+        if (e->h_state->done) return 0;
+    }
+    return fail(e, -EIO, "persistent level kernel did not finish");
+}
+
 extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
     if (!e || !out) return -EINVAL;
     e->n_ranks = 0;
@@ -1050,6 +1110,10 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
     if (rc) return rc;
     if (e->n == 0) { // schedule_one.go:438-440 ErrNoNodesAvailable
         e->h_state->done = DONE_UNSCHEDULABLE;
+        return fill_report(e, out);
+    }
+    if (e->persist_run) { // begin_run chose the persistent form of the batched mode
+        if ((rc = run_persist(e, e->persist_run))) return rc;
         return fill_report(e, out);
     }
     int rps = e->rounds_per_sync > 0 ? e->rounds_per_sync : (mode == CCSIM_MODE_BATCHED ? 64 : 256);
@@ -1248,6 +1312,14 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
         if (rc) return rc;
     }
     e->begun = false;
+    return 0;
+}
+
+// measurement aid: s_memtime ticks (100 MHz) workgroup 0 of the last persistent launch spent per phase
+extern "C" int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out8) {
+    if (!e || !out8) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpy(out8, e->d_psync->prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

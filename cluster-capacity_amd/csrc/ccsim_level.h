@@ -188,7 +188,8 @@ __device__ __forceinline__ uint32_t nd_word(const NodeNarrow &n) { return n.w; }
 constexpr int kSeqSteps = CCSIM_SEQ_STEPS;
 
 template <class Node>
-__device__ __forceinline__ int32_t wave_run_down(const RunCtx &cx, const Node &n, int64_t stat, int64_t M, bool mine, bool &feas_after) {
+__device__ __forceinline__ int32_t wave_run_down(const RunCtx &cx, const Node &n, int64_t stat, int64_t M, bool mine, bool &feas_after,
+                                                 int seq_steps = kSeqSteps) {
     const int lane = threadIdx.x & 63;
     int32_t my_j = 0;
     feas_after = true;
@@ -197,7 +198,7 @@ __device__ __forceinline__ int32_t wave_run_down(const RunCtx &cx, const Node &n
     bool running = mine;
     const auto rc = nd_rcp(n); // allocatable never changes: one reciprocal pair per node
 #pragma unroll 1
-    for (int it = 0; it < kSeqSteps && __ballot(running); it++) {
+    for (int it = 0; it < seq_steps && __ballot(running); it++) {
         if (running) {
             nd_apply(cx, cur, 1);
             my_j++;

@@ -1,0 +1,562 @@
+// ccsim_persist.h -- CCSIM_MODE_BATCHED as ONE persistent launch: the whole level-batched run (ccsim_level.h explains
+// why levels are exact) inside a single kernel whose workgroups keep their nodes in LDS for the whole run.
+//
+// Why: the multi-kernel form pays, per score level, one commit dispatch (a latency chain of ~18 us at 1M nodes:
+// launch, dense read of the 4-byte score cache, compaction barriers, row gather from HBM, run-down, store) plus a
+// one-block decision kernel (~7 us) plus two dispatch boundaries.  Nothing in a level needs HBM: a level touches a
+// few per cent of the nodes and the decision needs five numbers.  So:
+//   * one 1024-thread workgroup per CU, K x 1024 nodes per workgroup, the node state (36 B per node in the narrow
+//     units of ccsim_kernels.h + a 2-byte work-list slot) resident in the CU's 160 KiB of LDS: 256 CUs x 4096 nodes =
+//     1 048 576 nodes per GPU -- the BASELINE 1M-node snapshot exactly fits one MI355X;
+//   * per level every workgroup scans the 16-bit scores of its own nodes (LDS), compacts the level's nodes into an LDS
+//     work list, its first waves run them down (wave_run_down, ccsim_level.h) and re-score them, and the block
+//     contributes <= 5 packed 64-bit words to a grid-wide reduction;
+//   * the grid-wide reduction doubles as the grid barrier (grid_reduce below): relaxed agent-scope atomics into
+//     8 group-sharded slots, hierarchical arrival counters, one generation word to poll -- no fences, because the only
+//     data that crosses workgroups are those atomically updated words ("8-B agent atomics both sides",
+//     MI355X_MICROARCH.md), and no zeroing, because max-words carry a generation tag and add-words are cumulative;
+//   * every workgroup runs the same decision state machine on the same reduced numbers (replicated, like the ranks of
+//     the sharded protocol), so nothing is broadcast.
+// HBM is read once when the run starts (36 B per node) and written once when it ends; in between the kernel is bound
+// by the grid-barrier latency (tools/barrier_bench.hip) plus the run-down arithmetic of the level.
+//
+// Exactness.  The FAST path commits a level blindly and validates afterwards: if the level exhausted every feasible
+// holder of a normalization maximum (P/helper/normalize_score.go:28-56) or crossed --max-limit, the whole level is
+// rolled back (integer adds undone from the per-node `took`) and redone on the ORDERED path: plan (run-down lengths,
+// exhausted holders, highest exhausted index = the cut) -> grid reduce + per-block prefix -> commit the nodes up to the
+// cut in canonical order with positions (limit clamp, placement log) -> grid reduce.  With a placement log every level
+// takes the ordered path.  Results are identical to the multi-kernel batched mode and to the sequential mode.
+#pragma once
+#include "ccsim_level.h"
+
+namespace ccsim {
+
+constexpr int kPThreads = 1024;
+constexpr int kPWaves = kPThreads / 64;
+constexpr int kPGroups = 8;        // arrival / slot sharding (one group per XCD when dispatch is round-robin)
+constexpr int kPMaxGrid = 1024;
+constexpr uint32_t kScInf = 0xffffu; // 16-bit score: infeasible
+constexpr int kTagShift = 40;        // max-words: generation tag above a 40-bit payload
+constexpr int DONE_ERROR = 3;
+
+struct PersistSync { // global memory; zeroed by the host before every launch
+    unsigned long long slot[2][kPGroups][8]; // [parity][group][word]; words 0,3,4: tagged max; 1,2,5,6,7: cumulative add
+    unsigned int garrive[kPGroups][16];      // cumulative arrivals per group (one 64-byte line each)
+    unsigned int top[16];                    // cumulative group completions
+    unsigned int gen[16];                    // generations released so far
+    unsigned int err[16];
+    unsigned int blockT[kPMaxGrid];          // ordered path: planned placements per workgroup
+    unsigned long long prof[8];              // workgroup 0: s_memtime ticks per phase (scan+list, plan, apply, block reduce, grid reduce, rescore) + levels
+};
+
+// the columns the persistent kernel touches (a slim argument block: the full DevCols would sit in ~90 SGPRs)
+struct PersistCols {
+    const int32_t *a32[2];
+    int32_t *r32[2], *z32[2];
+    const int32_t *alloc_pods;
+    int32_t *pod_count, *placed_cnt;
+    const uint32_t *stat;
+    int64_t *req[2], *nz_mcpu, *nz_mem;
+    int64_t n_pad, global_offset;
+    int32_t mem_shift;
+};
+
+struct PersistArgs {
+    PersistCols c;
+    DevPod p;
+    DevState *st;
+    PersistSync *sync;
+    int32_t *log;
+    int32_t want_log;
+    int32_t max_syncs; // generations per launch (the host relaunches an unfinished run: state lives in the columns)
+    int32_t seq_steps; // run-down placements a lane evaluates itself before the wave-cooperative tail (ccsim_level.h)
+};
+
+template <int K>
+struct PersistLds {
+    int32_t a0[K * kPThreads], a1[K * kPThreads];
+    int32_t r0[K * kPThreads], r1[K * kPThreads], z0[K * kPThreads], z1[K * kPThreads];
+    uint32_t pods[K * kPThreads]; // allocatable pods << 16 | pods on the node
+    uint32_t ws[K * kPThreads];   // bit31 static filters passed | bit30 holds max prefer-count | bit29 holds max affinity sum | static score
+    uint32_t sct[K * kPThreads];  // low 16: TotalScore (kScInf infeasible) | high 16: placements of the pending level (took)
+    uint16_t list[K * kPThreads]; // work list of the level (local node ids)
+};
+
+__device__ __forceinline__ unsigned p_ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long p_ld_u64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Grid-wide reduction + barrier.  Thread 0 has put this workgroup's contribution into s_v[0..7] (LDS; zero = nothing to
+// add); on return s_red[0..7] (LDS) holds the grid-wide result: words 0, 3, 4 combine with MAX (payload < 2^40), the
+// others with ADD.  One generation = one call by every workgroup of the grid.
+struct GridCtx {
+    PersistSync *s;
+    unsigned gen_no;             // generations completed
+    unsigned gsize, ngroups, g;  // this workgroup's group
+    unsigned long long prev[2];  // wave 0: cumulative value of this lane's (group, word) at the last read, per parity
+    unsigned long long *s_v;     // LDS [8] in
+    unsigned long long *s_red;   // LDS [8] out
+    int *s_err;                  // LDS
+};
+
+__device__ __forceinline__ bool is_max_word(int w) { return w == 0 || w == 3 || w == 4; }
+
+// a value every lane holds identically (read from LDS): tell the compiler, so that it lives in SGPRs
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void grid_reduce(GridCtx &gc) {
+    PersistSync *s = gc.s;
+    const unsigned par = gc.gen_no & 1u;
+    if (threadIdx.x == 0) {
+        const unsigned long long tag = (unsigned long long)(gc.gen_no + 1) << kTagShift;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const unsigned long long x = gc.s_v[w];
+            if (x == 0) continue;
+            if (is_max_word(w)) __hip_atomic_fetch_max(&s->slot[par][gc.g][w], tag | x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(&s->slot[par][gc.g][w], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gc.s_v[w] = 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // contributions performed before the arrival is counted
+        const unsigned a = __hip_atomic_fetch_add(&s->garrive[gc.g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a + 1 == gc.gsize * (gc.gen_no + 1)) {
+            const unsigned t = __hip_atomic_fetch_add(&s->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 == gc.ngroups * (gc.gen_no + 1))
+                __hip_atomic_store(&s->gen[0], gc.gen_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int spins = 0;
+        while (p_ld_u32(&s->gen[0]) < gc.gen_no + 1) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22) || ((spins & 1023) == 0 && p_ld_u32(&s->err[0]))) { // bounded: a lost workgroup must not hang the GPU
+                __hip_atomic_store(&s->err[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *gc.s_err = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) { // wave 0: lane = group * 8 + word
+        const int g = threadIdx.x >> 3, w = threadIdx.x & 7;
+        const unsigned long long cur = (unsigned)g < gc.ngroups ? p_ld_u64(&s->slot[par][g][w]) : 0ull;
+        unsigned long long val;
+        if (is_max_word(w)) val = (cur >> kTagShift) == (unsigned long long)(gc.gen_no + 1) ? (cur & ((1ull << kTagShift) - 1)) : 0ull;
+        else val = cur - gc.prev[par], gc.prev[par] = cur;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_xor(val, off, 64);
+            val = is_max_word(w) ? (o > val ? o : val) : val + o;
+        }
+        if (threadIdx.x < 8) gc.s_red[threadIdx.x] = val;
+    }
+    __syncthreads();
+    gc.gen_no += 1;
+}
+
+template <int K>
+__device__ __forceinline__ NodeNarrow p_load_node(const PersistLds<K> &L, int li) {
+    NodeNarrow n;
+    n.a0 = L.a0[li], n.a1 = L.a1[li], n.r0 = L.r0[li], n.r1 = L.r1[li], n.z0 = L.z0[li], n.z1 = L.z1[li];
+    const uint32_t pd = L.pods[li];
+    n.a_pods = (int32_t)(pd >> 16), n.npods = (int32_t)(pd & 0xffffu);
+    n.w = L.ws[li];
+    n.placed = 0;
+    return n;
+}
+template <int K>
+__device__ __forceinline__ void p_store_dyn(PersistLds<K> &L, int li, const NodeNarrow &n) {
+    L.r0[li] = n.r0, L.r1[li] = n.r1, L.z0[li] = n.z0, L.z1[li] = n.z1;
+    L.pods[li] = ((uint32_t)n.a_pods << 16) | (uint32_t)n.npods;
+}
+
+struct PBlockRed { // per-wave partials of a block reduction
+    unsigned long long mx[3][kPWaves]; // max-words 0, 3, 4
+    unsigned long long ad[2][kPWaves]; // add-words 1, 2
+};
+
+template <int K>
+__global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
+    __shared__ PersistLds<K> L;
+    __shared__ PBlockRed R;
+    __shared__ unsigned long long s_v[8], s_red[8];
+    __shared__ int s_err, s_n;
+    __shared__ int s_cnt[K][kPWaves], s_off[K][kPWaves];
+    __shared__ long long s_scan[kPWaves];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t base = (int64_t)blockIdx.x * K * kPThreads; // first node of this workgroup (shard-local index)
+    const RunCtx cx{a.p, narrow_pod(a.p, a.c.mem_shift)};
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+
+    // (no local copy of the 450-byte DevState: it would live in scratch)
+    if (a.st->done) return;
+    const int64_t log_cap = a.st->log_cap;
+    GridCtx gc;
+    gc.s = a.sync, gc.gen_no = 0, gc.ngroups = gridDim.x < (unsigned)kPGroups ? gridDim.x : (unsigned)kPGroups;
+    gc.g = blockIdx.x % gc.ngroups;
+    gc.gsize = gridDim.x / gc.ngroups + (gc.g < gridDim.x % gc.ngroups ? 1u : 0u);
+    gc.prev[0] = gc.prev[1] = 0, gc.s_v = s_v, gc.s_red = s_red, gc.s_err = &s_err;
+    if (tid == 0) s_err = 0, s_n = 0;
+    if (tid < 8) s_v[tid] = 0;
+
+    // ---- load: narrow mirrors -> LDS (the only bulk HBM read of the run) -------------------------------------
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int li = k * kPThreads + tid;
+        const int64_t i = base + li;
+        const bool in = i < a.c.n_pad;
+        L.a0[li] = in ? a.c.a32[0][i] : 0, L.a1[li] = in ? a.c.a32[1][i] : 0;
+        L.r0[li] = in ? a.c.r32[0][i] : 0, L.r1[li] = in ? a.c.r32[1][i] : 0;
+        L.z0[li] = in ? a.c.z32[0][i] : 0, L.z1[li] = in ? a.c.z32[1][i] : 0;
+        L.pods[li] = in ? (((uint32_t)a.c.alloc_pods[i] << 16) | ((uint32_t)a.c.pod_count[i] & 0xffffu)) : 0u;
+        L.ws[li] = 0, L.sct[li] = kScInf;
+    }
+    __syncthreads();
+
+    // replicated run state (identical in every thread of every workgroup)
+    int64_t placed = a.st->placed, rounds = a.st->rounds, scans = a.st->scans;
+    const int64_t limit = a.st->limit;
+    const bool want_log = a.want_log != 0;
+    uint32_t mt = 0, ma = 0;
+    int64_t c_mt = 0, c_ma = 0, nfeas = 0;
+    int32_t M = 0, last_feasible = a.st->last_feasible;
+    int done = 0;
+    bool rescore = true, ordered = want_log;
+    unsigned long long pf[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
+#define PTICK(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } while (0)
+
+    while (!done && (int)gc.gen_no < a.max_syncs) {
+        if (rescore) {
+            // ---- normalization maxima over the feasible set, then every node's TotalScore --------------------
+            uint32_t lmt = 0, lma = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int li = k * kPThreads + tid;
+                const int64_t i = base + li;
+                const uint32_t w = i < a.c.n_pad ? a.c.stat[i] : 0u;
+                NodeNarrow n = p_load_node<K>(L, li);
+                n.w = w;
+                L.ws[li] = w; // raw static word until the scores are written below
+                if (nd_feasible(cx, n)) {
+                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                    lmt = cnt > lmt ? cnt : lmt, lma = aff > lma ? aff : lma;
+                }
+            }
+            lmt = wave_max_u32(lmt), lma = wave_max_u32(lma);
+            if (lane == 0) R.mx[0][wave] = lmt, R.mx[1][wave] = lma;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long m0 = 0, m1 = 0;
+                for (int w = 0; w < kPWaves; w++) m0 = R.mx[0][w] > m0 ? R.mx[0][w] : m0, m1 = R.mx[1][w] > m1 ? R.mx[1][w] : m1;
+                s_v[0] = m0, s_v[3] = m1; // 0 contributes nothing, and 0 is the neutral result
+            }
+            grid_reduce(gc);
+            if (uni32(s_err)) break;
+            mt = (uint32_t)uni64(s_red[0]), ma = (uint32_t)uni64(s_red[3]);
+            uint32_t lmax = 0, lnf = 0, lcmt = 0, lcma = 0; // lmax: score + 1
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int li = k * kPThreads + tid;
+                NodeNarrow n = p_load_node<K>(L, li);
+                const uint32_t w = n.w;
+                uint32_t sc = kScInf, wsv = w & (1u << kStatOkBit);
+                if (nd_feasible(cx, n)) {
+                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                    const int64_t nstat = static_score(a.p, cnt, aff, mt, ma);
+                    sc = (uint32_t)(nstat + dynamic_score_narrow(a.p, cx.q, n.a0, n.a1, n.r0, n.r1, n.z0, n.z1));
+                    lmax = sc + 1 > lmax ? sc + 1 : lmax;
+                    lnf++, lcmt += cnt == mt, lcma += aff == ma;
+                    wsv |= (cnt == mt ? 1u << 30 : 0u) | (aff == ma ? 1u << 29 : 0u) | (uint32_t)nstat;
+                } // (a node the Fit filter rejects never becomes feasible again: placements only add pods)
+                L.ws[li] = wsv;
+                L.sct[li] = sc;
+            }
+            lmax = wave_max_u32(lmax);
+            lnf = wave_sum_u32(lnf), lcmt = wave_sum_u32(lcmt), lcma = wave_sum_u32(lcma);
+            if (lane == 0) R.mx[0][wave] = lmax, R.ad[0][wave] = (unsigned long long)lnf | ((unsigned long long)lcmt << 32), R.ad[1][wave] = lcma;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long v0 = 0, v1 = 0, v2 = 0;
+                for (int w = 0; w < kPWaves; w++) v0 = R.mx[0][w] > v0 ? R.mx[0][w] : v0, v1 += R.ad[0][w], v2 += R.ad[1][w];
+                s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
+            }
+            grid_reduce(gc);
+            if (uni32(s_err)) break;
+            scans += 1;
+            nfeas = (int64_t)(uni64(s_red[1]) & 0xffffffffull), c_mt = (int64_t)(uni64(s_red[1]) >> 32), c_ma = (int64_t)uni64(s_red[2]);
+            if (uni64(s_red[0]) == 0) { // schedule_one.go:448-454: no feasible node
+                done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0;
+                break;
+            }
+            M = (int32_t)uni64(s_red[0]) - 1;
+            last_feasible = (int32_t)nfeas;
+            rescore = false;
+            ordered = want_log;
+            PTICK(5);
+            continue;
+        }
+
+        // ---- one level: nodes with TotalScore == M -------------------------------------------------------------
+        // (a) every thread looks at its own K scores; level nodes go to the work list
+        uint32_t mymax = 0; // score + 1 over the nodes this level leaves alone
+        int wtot = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t sc = L.sct[k * kPThreads + tid] & 0xffffu;
+            const bool lv = sc == (uint32_t)M;
+            if (!lv && sc != kScInf) mymax = sc + 1 > mymax ? sc + 1 : mymax;
+            const int c = __popcll(__ballot(lv));
+            wtot += c;
+            if (ordered && lane == 0) s_cnt[k][wave] = c;
+        }
+        if (!ordered) { // any order will do: one LDS atomic per wave
+            int wbase = 0;
+            if (lane == 0 && wtot) wbase = atomicAdd(&s_n, wtot);
+            wbase = __shfl(wbase, 0, 64);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const bool lv = (L.sct[k * kPThreads + tid] & 0xffffu) == (uint32_t)M;
+                const uint64_t b = __ballot(lv);
+                if (lv) L.list[wbase + __popcll(b & lt_mask)] = (uint16_t)(k * kPThreads + tid);
+                wbase += __popcll(b);
+            }
+            __syncthreads();
+        } else { // canonical order (k-major, then thread): exclusive scan of the K x 16 wave counts by wave 0
+            __syncthreads();
+            if (wave == 0) {
+                int run = 0;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const int c = lane < kPWaves ? s_cnt[k][lane] : 0;
+                    int inc = c;
+#pragma unroll
+                    for (int off = 1; off < kPWaves; off <<= 1) {
+                        const int o = __shfl_up(inc, off, 64);
+                        if (lane >= off) inc += o;
+                    }
+                    if (lane < kPWaves) s_off[k][lane] = run + inc - c;
+                    run += __shfl(inc, kPWaves - 1, 64);
+                }
+                if (lane == 0) s_n = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const bool lv = (L.sct[k * kPThreads + tid] & 0xffffu) == (uint32_t)M;
+                const uint64_t b = __ballot(lv);
+                if (lv) L.list[s_off[k][wave] + __popcll(b & lt_mask)] = (uint16_t)(k * kPThreads + tid);
+            }
+            __syncthreads();
+        }
+        const int total = uni32(s_n);
+        PTICK(0);
+
+        // (b) PLAN: every level node's run-down length -> the high half of its score word
+        {
+            uint32_t T = 0, e_mt = 0, e_ma = 0;
+            int64_t cmt = 0, cma = 0; // global index + 1 of the highest exhausted holder
+#pragma unroll 1
+            for (int r0 = 0; r0 < total; r0 += kPThreads) {
+                const int nwork = total - r0 < kPThreads ? total - r0 : kPThreads;
+                const bool mine = tid < nwork;
+                NodeNarrow n;
+                nd_zero(n);
+                int li = 0;
+                if (mine) li = L.list[r0 + tid], n = p_load_node<K>(L, li);
+                bool fend = true;
+                int32_t j = 0;
+                if (wave * 64 < nwork) j = wave_run_down<NodeNarrow>(cx, n, (int64_t)(n.w & 0xffffu), (int64_t)M, mine, fend, a.seq_steps);
+                if (mine) {
+                    L.sct[li] = (uint32_t)M | ((uint32_t)j << 16);
+                    if (ordered) {
+                        T += (uint32_t)j;
+                        if (!fend) {
+                            const int64_t gi = a.c.global_offset + base + li + 1;
+                            if (mt > 0 && (n.w >> 30 & 1u)) e_mt++, cmt = gi > cmt ? gi : cmt;
+                            if (ma > 0 && (n.w >> 29 & 1u)) e_ma++, cma = gi > cma ? gi : cma;
+                        }
+                    }
+                }
+            }
+            if (ordered) {
+                T = wave_sum_u32(T), e_mt = wave_sum_u32(e_mt), e_ma = wave_sum_u32(e_ma);
+                cmt = wave_max_i64(cmt), cma = wave_max_i64(cma);
+                if (lane == 0) {
+                    R.ad[0][wave] = (unsigned long long)T | ((unsigned long long)e_mt << 32), R.ad[1][wave] = e_ma;
+                    R.mx[1][wave] = (unsigned long long)cmt, R.mx[2][wave] = (unsigned long long)cma;
+                }
+            }
+        }
+        PTICK(1);
+        int64_t cut = kNoCut, remaining = kNoCut, prefix_b = 0;
+        if (ordered) {
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                for (int w = 0; w < kPWaves; w++) {
+                    v1 += R.ad[0][w], v2 += R.ad[1][w];
+                    v3 = R.mx[1][w] > v3 ? R.mx[1][w] : v3, v4 = R.mx[2][w] > v4 ? R.mx[2][w] : v4;
+                }
+                s_v[1] = v1, s_v[2] = v2, s_v[3] = v3, s_v[4] = v4;
+                __hip_atomic_store(&a.sync->blockT[blockIdx.x], (unsigned)(v1 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            grid_reduce(gc); // (its s_waitcnt covers the blockT store)
+            if (uni32(s_err)) break;
+            const int64_t ge_mt = (int64_t)(uni64(s_red[1]) >> 32), ge_ma = (int64_t)uni64(s_red[2]);
+            if (mt > 0 && ge_mt == c_mt && (int64_t)uni64(s_red[3]) - 1 < cut) cut = (int64_t)uni64(s_red[3]) - 1; // every feasible holder exhausted
+            if (ma > 0 && ge_ma == c_ma && (int64_t)uni64(s_red[4]) - 1 < cut) cut = (int64_t)uni64(s_red[4]) - 1;
+            remaining = limit > 0 ? limit - placed : kNoCut;
+            // placements of this level that belong to lower workgroups (canonical order == workgroup order)
+            long long pb = 0;
+            for (int b = tid; b < (int)blockIdx.x; b += kPThreads) pb += (long long)p_ld_u32(&a.sync->blockT[b]);
+            pb = wave_sum_i64(pb);
+            if (lane == 0) s_scan[wave] = pb;
+            __syncthreads();
+            for (int w = 0; w < kPWaves; w++) prefix_b += (int64_t)uni64((unsigned long long)s_scan[w]);
+        } else
+            __syncthreads(); // the run-down lengths are in LDS
+
+        // (c) APPLY: rewrite the level's nodes, re-score them
+        uint32_t committed = 0, x_nf = 0, x_mt = 0, x_ma = 0;
+        int64_t carry = prefix_b;
+#pragma unroll 1
+        for (int r0 = 0; r0 < total; r0 += kPThreads) {
+            const int nwork = total - r0 < kPThreads ? total - r0 : kPThreads;
+            const bool mine = tid < nwork;
+            int li = 0;
+            int32_t took = 0;
+            if (mine) li = L.list[r0 + tid], took = (int32_t)(L.sct[li] >> 16);
+            if (ordered) {
+                const int32_t j = took;
+                const int64_t incl = wave_incl_scan_i64(j);
+                __syncthreads(); // s_scan reuse across rounds
+                if (lane == 63) s_scan[wave] = incl;
+                __syncthreads();
+                int64_t before = 0, tot = 0;
+#pragma unroll
+                for (int w = 0; w < kPWaves; w++) {
+                    if (w < wave) before += s_scan[w];
+                    tot += s_scan[w];
+                }
+                const int64_t pos = carry + before + incl - j;
+                carry += tot;
+                const int64_t gi = a.c.global_offset + base + li;
+                int64_t allowed = remaining - pos;
+                allowed = allowed < 0 ? 0 : allowed;
+                took = (mine && gi <= cut) ? (int32_t)(j < allowed ? j : allowed) : 0;
+                if (a.log && took > 0)
+                    for (int32_t q = 0; q < took; q++) {
+                        const int64_t at = placed + pos + q;
+                        if (at < log_cap) a.log[at] = (int32_t)gi;
+                    }
+            }
+            if (mine) {
+                NodeNarrow n = p_load_node<K>(L, li);
+                if (took > 0) nd_apply(cx, n, took), p_store_dyn<K>(L, li, n);
+                const bool f = nd_feasible(cx, n);
+                const uint32_t s = f ? (uint32_t)nd_score(cx, n, (int64_t)(n.w & 0xffffu), NoRcp{}) : kScInf;
+                L.sct[li] = s | ((uint32_t)took << 16);
+                committed += (uint32_t)took;
+                if (f) mymax = s + 1 > mymax ? s + 1 : mymax;
+                else x_nf++, x_mt += n.w >> 30 & 1u, x_ma += n.w >> 29 & 1u;
+            }
+        }
+        PTICK(2);
+        // (d) block reduction -> grid reduction
+        mymax = wave_max_u32(mymax);
+        if (wave * 64 < total) committed = wave_sum_u32(committed), x_nf = wave_sum_u32(x_nf), x_mt = wave_sum_u32(x_mt), x_ma = wave_sum_u32(x_ma);
+        if (lane == 0) {
+            R.mx[0][wave] = mymax;
+            R.ad[0][wave] = (unsigned long long)committed | ((unsigned long long)x_nf << 32);
+            R.ad[1][wave] = (unsigned long long)x_mt | ((unsigned long long)x_ma << 32);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long v0 = 0, v1 = 0, v2 = 0;
+            for (int w = 0; w < kPWaves; w++) v0 = R.mx[0][w] > v0 ? R.mx[0][w] : v0, v1 += R.ad[0][w], v2 += R.ad[1][w];
+            s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
+            s_n = 0; // next level's list (every thread read `total` before the barrier above)
+        }
+        PTICK(3);
+        grid_reduce(gc);
+        PTICK(4);
+        pf[6] += 1;
+        if (uni32(s_err)) break;
+        const int64_t g_committed = (int64_t)(uni64(s_red[1]) & 0xffffffffull), g_xnf = (int64_t)(uni64(s_red[1]) >> 32);
+        const int64_t g_xmt = (int64_t)(uni64(s_red[2]) & 0xffffffffull), g_xma = (int64_t)(uni64(s_red[2]) >> 32);
+        const uint32_t g_next = (uint32_t)uni64(s_red[0]);
+
+        if (!ordered) {
+            // validate the blind commit: did it exhaust every holder of a normalization maximum, or cross the limit?
+            const bool cut_event = (mt > 0 && g_xmt == c_mt) || (ma > 0 && g_xma == c_ma);
+            const bool over = limit > 0 && placed + g_committed > limit;
+            if (cut_event || over) { // undo the whole level, redo it in canonical order
+#pragma unroll 1
+                for (int r0 = 0; r0 < total; r0 += kPThreads)
+                    if (r0 + tid < total) {
+                        const int li = L.list[r0 + tid];
+                        const int32_t tk = (int32_t)(L.sct[li] >> 16);
+                        NodeNarrow n = p_load_node<K>(L, li);
+                        nd_apply(cx, n, -(int64_t)tk);
+                        p_store_dyn<K>(L, li, n);
+                        L.sct[li] = (uint32_t)M;
+                    }
+                __syncthreads();
+                ordered = true;
+                continue;
+            }
+        }
+        placed += g_committed, rounds += g_committed;
+        nfeas -= g_xnf, c_mt -= g_xmt, c_ma -= g_xma;
+        scans += 1;
+        if (limit > 0 && placed >= limit) { // simulator.go:297-312: tested after the append
+            done = DONE_LIMIT;
+            break;
+        }
+        if (ordered && cut != kNoCut) { // a normalization maximum lost its last feasible holder: new constants
+            rescore = true;
+            ordered = want_log;
+            continue;
+        }
+        ordered = want_log;
+        if (g_next == 0) {
+            done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0;
+            break;
+        }
+        last_feasible = (int32_t)nfeas;
+        M = (int32_t)g_next - 1;
+    }
+
+    // ---- write the node state back: mirrors, int64 columns, pod counts, per-node result -----------------------------
+    __syncthreads();
+    const int sh = a.c.mem_shift;
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        const int li = k * kPThreads + tid;
+        const int64_t i = base + li;
+        if (i >= a.c.n_pad) continue;
+        const int32_t r0 = L.r0[li], r1 = L.r1[li], z0 = L.z0[li], z1 = L.z1[li];
+        const int32_t np = (int32_t)(L.pods[li] & 0xffffu), np0 = a.c.pod_count[i];
+        a.c.r32[0][i] = r0, a.c.r32[1][i] = r1, a.c.z32[0][i] = z0, a.c.z32[1][i] = z1;
+        a.c.req[0][i] = (int64_t)r0, a.c.req[1][i] = (int64_t)r1 << sh;
+        a.c.nz_mcpu[i] = (int64_t)z0, a.c.nz_mem[i] = (int64_t)z1 << sh;
+        a.c.pod_count[i] = np;
+        a.c.placed_cnt[i] += np - np0;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 7; i++) a.sync->prof[i] = pf[i];
+        DevState *st = a.st;
+        st->placed = placed, st->rounds = rounds, st->scans = scans;
+        st->done = s_err ? DONE_ERROR : done;
+        st->mt_a = (int32_t)mt, st->ma_a = (int32_t)ma;
+        st->last_feasible = last_feasible;
+        st->lvl_full = 1, st->lvl_valid = 0, st->lvl_plan_only = 0; // the multi-kernel path's score cache knows nothing of this run
+        st->winner = -1;
+    }
+}
+
+} // namespace ccsim

@@ -305,6 +305,11 @@ int ccsim_reset_state(ccsim_engine *e);
  * simulation state is not advanced. */
 int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan);
 
+/* Measurement aid: where the last persistent batched launch (csrc/ccsim_persist.h) spent its time.
+ * out8: 10 ns ticks of workgroup 0 in [0] level scan + work list, [1] run-down planning, [2] commit + re-score,
+ * [3] block reduction, [4] grid-wide reduce + barrier, [5] full re-score phases; [6] = levels; [7] unused. */
+int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+"""The persistent form of the batched mode (csrc/ccsim_persist.h: one launch, node state resident in LDS, grid-wide
+reduce + barrier per score level) against the oracle and against the multi-kernel batched mode (CCSIM_PERSIST=0).
+
+The rest of the GPU suite runs the batched mode with its default (persistent where the snapshot qualifies) and mostly
+WITH a placement log, i.e. on the ordered path; here the blind fast path (no log), its roll-back cases (limit crossed
+inside a level, a normalization maximum losing its last feasible holder) and the fallback conditions are pinned."""
+import numpy as np
+import pytest
+
+import helpers as H
+from cluster_capacity_amd import capi, model as M, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(nodes, pod, prof, limit, want_log, **kw):
+    e = capi.Engine(device=0, **kw)
+    e.load(nodes, pod, prof)
+    r = e.run(max_limit=limit, mode="batched", want_log=want_log, log_cap=None if want_log else 0)
+    st = e.read_state()
+    e.close()
+    return r, st
+
+
+def _same(got, ref, check_log):
+    assert got.placed == ref.placed and got.stop == ref.stop
+    assert np.array_equal(got.per_node_count, ref.per_node_count)
+    if check_log:
+        assert np.array_equal(got.log, ref.log)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist) and got.n_code_unschedulable == ref.n_code_unschedulable
+
+
+@pytest.mark.parametrize("persist", ["1", "0"])
+@pytest.mark.parametrize("cfg,n,limit", [("C3", 4096, 0), ("C3", 4096, 700), ("C2", 5000, 300), ("C3", 777, 0), ("C3", 513, 50),
+                                          ("C3", 20_000, 12_345), ("C2", 3000, 0), ("C3", 1, 0)])
+def test_fast_path_without_log_vs_oracle(ccref, monkeypatch, persist, cfg, n, limit):
+    monkeypatch.setenv("CCSIM_PERSIST", persist)
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=4321 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    got, st = _run(nodes, pod, prof, limit, want_log=False)
+    _same(got, ref, check_log=False)
+    cnt = ref.per_node_count.astype(np.int64)
+    assert np.array_equal(st["req_mcpu"], nodes.req[0] + cnt * int(pod.req[0]))
+    assert np.array_equal(st["req_mem"], nodes.req[1] + cnt * int(pod.req[1]))
+    assert np.array_equal(st["nz_mcpu"], nodes.nz_mcpu + cnt * pod.nz_mcpu)
+    assert np.array_equal(st["pod_count"], nodes.pod_count + ref.per_node_count)
+    got, _ = _run(nodes, pod, prof, limit, want_log=True)  # ordered path
+    _same(got, ref, check_log=True)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_plugin_mix_fast_and_ordered_paths(ccref, seed):
+    """Taints / preferred affinity with few holders: normalization maxima lose their last feasible holder inside a level
+    (roll-back + ordered redo with a cut), limits fall inside levels."""
+    rng = np.random.default_rng(7000 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 3000)))
+    limit = int(rng.choice([0, 0, 37, 500]))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    for want_log in (False, True):
+        got, _ = _run(nodes, pod, prof, limit, want_log)
+        _same(got, ref, check_log=want_log)
+
+
+def test_continued_runs_and_mode_switches(ccref):
+    """The persistent launch starts from the columns and writes them back: runs continue across launches and modes."""
+    nodes, pod, prof = synth.make_config("C3", n_nodes=6000, seed=99)
+    ref = ccref.run(prof, nodes, pod, max_limit=0, threads=8)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    a = e.run(max_limit=1000, mode="batched", want_log=False, log_cap=0)
+    b = e.run(max_limit=200, mode="sequential", log_cap=200)
+    c = e.run(max_limit=5000, mode="batched", log_cap=5000)
+    d = e.run(max_limit=0, mode="batched", want_log=False, log_cap=0)
+    assert (a.placed, b.placed, c.placed) == (1000, 200, 5000) and a.placed + b.placed + c.placed + d.placed == ref.placed
+    assert np.array_equal(b.log, ref.log[1000:1200]) and np.array_equal(c.log, ref.log[1200:6200])
+    total = a.per_node_count + b.per_node_count + c.per_node_count + d.per_node_count
+    assert np.array_equal(total, ref.per_node_count) and d.stop == ref.stop and np.array_equal(d.hist, ref.hist)
+    e.close()
+
+
+def test_large_snapshot_4_nodes_per_thread(ccref):
+    """> 512k nodes: 4 nodes per thread (the 1M-node BASELINE shape); oracle prefix + closed-form exhaustive vector."""
+    nodes, pod, prof = synth.make_config("C4", n_nodes=600_000, seed=5)
+    ref = ccref.run(prof, nodes, pod, max_limit=400, threads=8)
+    for want_log in (True, False):
+        got, _ = _run(nodes, pod, prof, 400, want_log)
+        _same(got, ref, check_log=want_log)
+    full, _ = _run(nodes, pod, prof, 0, False)
+    free_c, free_m = nodes.alloc[0] - nodes.req[0], nodes.alloc[1] - nodes.req[1]
+    cap = np.minimum(np.minimum(free_c // 150, free_m // (100 << 20)), (nodes.alloc_pods - nodes.pod_count).astype(np.int64)).clip(0)
+    cap = np.where(nodes.unschedulable == 0, cap, 0)
+    assert full.placed == int(cap.sum()) and np.array_equal(full.per_node_count.astype(np.int64), cap)
+
+
+def test_fallback_when_the_snapshot_does_not_qualify(ccref):
+    """Extended resources (NX > 0) and odd memory values (no narrow mirrors) take the multi-kernel path: same answers."""
+    rng = np.random.default_rng(11)
+    n = 900
+    nodes = H.simple_nodes(rng.choice([4000, 8000, 64000], n), rng.integers(1 << 34, 1 << 38, n) | 1, np.full(n, 40),
+                           req_mcpu=rng.integers(0, 2000, n), req_mem=rng.integers(0, 1 << 33, n))
+    pod = H.simple_pod(137, (1 << 28) + 12345)
+    ref = ccref.run(M.Profile.default(), nodes, pod, max_limit=0)
+    got, _ = _run(nodes, pod, M.Profile.default(), 0, False)
+    _same(got, ref, check_log=False)
