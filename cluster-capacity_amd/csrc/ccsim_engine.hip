@@ -1068,7 +1068,7 @@ static int persist_k(const ccsim_engine *e) {
     const int64_t max_total = 100ll * ((int64_t)e->pod.w_taint + e->pod.w_aff + e->pod.w_fit + e->pod.w_bal);
     if (max_total >= 65535) return 0;
     const int cus = e->n_cus < kPMaxGrid ? e->n_cus : kPMaxGrid;
-    for (int k : {1, 2, 4})
+    for (int k : {1, 2, 4, 8})
         if ((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads) <= cus) return k;
     return 0;
 }
@@ -1080,15 +1080,19 @@ static int run_persist(ccsim_engine *e, int k) {
                       {c.req[0], c.req[1]}, c.nz_mcpu, c.nz_mem, c.n_pad, c.global_offset, c.mem_shift};
     a.p = e->pod, a.st = e->d_state, a.sync = e->d_psync, a.log = e->d_log, a.want_log = e->d_log ? 1 : 0;
     a.max_syncs = 1 << 20;
-    a.seq_steps = kSeqSteps;
+    a.seq_steps = 8;
     if (const char *f = getenv("CCSIM_SEQ_STEPS")) a.seq_steps = atoi(f) > 0 ? atoi(f) : kSeqSteps; // tuning knob
+    a.level_batch = 16;
+    if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
+    if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
     for (int launch = 0; launch < 64; launch++) {
         HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync), e->stream));
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         if (k == 1) hipLaunchKernelGGL(k_level_persist<1>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
         else if (k == 2) hipLaunchKernelGGL(k_level_persist<2>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
-        else hipLaunchKernelGGL(k_level_persist<4>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
+        else if (k == 4) hipLaunchKernelGGL(k_level_persist<4>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
+        else hipLaunchKernelGGL(k_level_persist<8>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
         int rc = read_state(e);

@@ -225,26 +225,66 @@ struct XRec {
 static_assert(sizeof(XRec) == 32 * 8, "XRec must be CCSIM_XCHG_WORDS int64");
 
 // ------------------------------------------------------------------------------------------------
+// Wave-wide reductions on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 / :31 across
+// the four rows -- the gfx9 sequence LLVM's atomic optimizer emits): six VALU steps, result in lane 63, broadcast with
+// v_readlane.  The ds_bpermute form (__shfl_xor) costs one LDS round trip (~100 cycles) per step and the steps are
+// dependent: in the latency-bound kernels (one-block decisions, the persistent level kernel) that was microseconds.
+#define CCSIM_DPP_STEP32(v, ident, op, ctrl, rmask)                                                   \
+    {                                                                                                  \
+        const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp((int)(ident), (int)(v), ctrl, rmask, 0xf, false); \
+        v = op(v, o_);                                                                                \
+    }
+__device__ __forceinline__ uint32_t op_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t op_add_u32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    CCSIM_DPP_STEP32(v, 0u, op_max_u32, 0x111, 0xf) CCSIM_DPP_STEP32(v, 0u, op_max_u32, 0x112, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_max_u32, 0x114, 0xf) CCSIM_DPP_STEP32(v, 0u, op_max_u32, 0x118, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_max_u32, 0x142, 0xa) CCSIM_DPP_STEP32(v, 0u, op_max_u32, 0x143, 0xc)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v) {
+    CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x111, 0xf) CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x112, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x114, 0xf) CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x118, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x142, 0xa) CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x143, 0xc)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit values travel as two DPP moves per step; the combine is a full 64-bit operation
+__device__ __forceinline__ uint64_t dpp_move_u64(uint64_t ident, uint64_t v, const int ctrl_sel) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const uint32_t ilo = (uint32_t)ident, ihi = (uint32_t)(ident >> 32);
+    switch (ctrl_sel) { // (the control word must be an immediate)
+    case 0: lo = __builtin_amdgcn_update_dpp((int)ilo, (int)lo, 0x111, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp((int)ihi, (int)hi, 0x111, 0xf, 0xf, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp((int)ilo, (int)lo, 0x112, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp((int)ihi, (int)hi, 0x112, 0xf, 0xf, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp((int)ilo, (int)lo, 0x114, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp((int)ihi, (int)hi, 0x114, 0xf, 0xf, false); break;
+    case 3: lo = __builtin_amdgcn_update_dpp((int)ilo, (int)lo, 0x118, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp((int)ihi, (int)hi, 0x118, 0xf, 0xf, false); break;
+    case 4: lo = __builtin_amdgcn_update_dpp((int)ilo, (int)lo, 0x142, 0xa, 0xf, false), hi = __builtin_amdgcn_update_dpp((int)ihi, (int)hi, 0x142, 0xa, 0xf, false); break;
+    default: lo = __builtin_amdgcn_update_dpp((int)ilo, (int)lo, 0x143, 0xc, 0xf, false), hi = __builtin_amdgcn_update_dpp((int)ihi, (int)hi, 0x143, 0xc, 0xf, false); break;
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t bcast63_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint64_t o = __shfl_xor(v, off, 64);
+    for (int s = 0; s < 6; s++) {
+        const uint64_t o = dpp_move_u64(0ull, v, s);
         v = o > v ? o : v;
     }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint32_t o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    return bcast63_u64(v);
 }
 __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+    uint64_t u = (uint64_t)v;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int s = 0; s < 6; s++) u += dpp_move_u64(0ull, u, s);
+    return (int64_t)bcast63_u64(u);
+}
+// value of lane `src` (wave-uniform index) in every lane: v_readlane, not an LDS permute
+__device__ __forceinline__ int32_t lane_bcast_i32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int64_t lane_bcast_i64(int64_t v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // ---- per-block partials ---------------------------------------------------------------------------------------

@@ -98,8 +98,9 @@ __device__ __forceinline__ int64_t node_score(const DevPod &p, const NodeRegs<NX
     return node_score<NX>(p, n, stat, make_rcp(n.a_cpu, n.a_mem));
 }
 
-__device__ __forceinline__ int64_t bcast_i64(int64_t v, int src) { return __shfl(v, src, 64); }
-__device__ __forceinline__ int32_t bcast_i32(int32_t v, int src) { return __shfl(v, src, 64); }
+// (src is wave-uniform at every call site: the lowest set bit of a ballot)
+__device__ __forceinline__ int64_t bcast_i64(int64_t v, int src) { return lane_bcast_i64(v, src); }
+__device__ __forceinline__ int32_t bcast_i32(int32_t v, int src) { return lane_bcast_i32(v, src); }
 
 template <int NX>
 __device__ __forceinline__ NodeRegs<NX> bcast_node(const NodeRegs<NX> &n, int src) {
@@ -285,19 +286,10 @@ __device__ __forceinline__ void store_dyn(const DevCols &c, const DevPod &p, int
     }
 }
 
-__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int64_t o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) { // (values >= -1 at every call site: biased to unsigned)
+    return (int64_t)(wave_max_u64((uint64_t)(v + 1))) - 1;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_sum_u32_dpp(v); }
 // inclusive prefix sum across the 64 lanes of a wave
 __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v) {
     const int lane = threadIdx.x & 63;

@@ -31,7 +31,7 @@
 
 namespace ccsim {
 
-constexpr int kPThreads = 1024;
+constexpr int kPThreads = 512; // 8 waves = 2 per SIMD: a 256-VGPR budget (the run-down's working set spills at 128)
 constexpr int kPWaves = kPThreads / 64;
 constexpr int kPGroups = 8;        // arrival / slot sharding (one group per XCD when dispatch is round-robin)
 constexpr int kPMaxGrid = 1024;
@@ -70,6 +70,8 @@ struct PersistArgs {
     int32_t want_log;
     int32_t max_syncs; // generations per launch (the host relaunches an unfinished run: state lives in the columns)
     int32_t seq_steps; // run-down placements a lane evaluates itself before the wave-cooperative tail (ccsim_level.h)
+    int32_t level_batch; // fast path: score levels resolved per grid-wide sync (>= 1)
+    int32_t prof;        // measurement runs: per-phase s_memrealtime stamps (each stamp costs a few hundred ns)
 };
 
 template <int K>
@@ -140,21 +142,95 @@ __device__ __forceinline__ void grid_reduce(GridCtx &gc) {
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64) { // wave 0: lane = group * 8 + word
-        const int g = threadIdx.x >> 3, w = threadIdx.x & 7;
+    if (threadIdx.x < 64) { // wave 0: lane = word * 8 + group; the 8 groups of a word are reduced on the DPP network
+        const int w = threadIdx.x >> 3, g = threadIdx.x & 7;
         const unsigned long long cur = (unsigned)g < gc.ngroups ? p_ld_u64(&s->slot[par][g][w]) : 0ull;
         unsigned long long val;
         if (is_max_word(w)) val = (cur >> kTagShift) == (unsigned long long)(gc.gen_no + 1) ? (cur & ((1ull << kTagShift) - 1)) : 0ull;
         else val = cur - gc.prev[par], gc.prev[par] = cur;
 #pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            const unsigned long long o = __shfl_xor(val, off, 64);
+        for (int st = 0; st < 3; st++) { // row_shr 1, 2, 4: lane w*8+7 ends up with the combination of its 8 lanes
+            const unsigned long long o = dpp_move_u64(0ull, val, st);
             val = is_max_word(w) ? (o > val ? o : val) : val + o;
         }
-        if (threadIdx.x < 8) gc.s_red[threadIdx.x] = val;
+        if (g == 7) gc.s_red[w] = val;
     }
     __syncthreads();
     gc.gen_no += 1;
+}
+
+// wave_run_down for long run-downs (several levels per sync): the lane-sequential prefix as in ccsim_level.h, then the
+// nodes still running are finished FOUR AT A TIME -- each 16-lane row of the wave takes one node, lane r of the row
+// evaluates the node after k0 + r + 1 further placements (closed form), one ballot per round finds every row's first stop.
+// The 64-candidates-per-node form of ccsim_level.h spends a whole wave on a node that needs 10-30 more placements.
+__device__ __forceinline__ NodeNarrow nd_shfl(const NodeNarrow &n, int src) { // per-lane source: LDS permutes, independent of one another
+    NodeNarrow o;
+    o.a0 = __shfl(n.a0, src, 64), o.a1 = __shfl(n.a1, src, 64), o.r0 = __shfl(n.r0, src, 64), o.r1 = __shfl(n.r1, src, 64);
+    o.z0 = __shfl(n.z0, src, 64), o.z1 = __shfl(n.z1, src, 64), o.a_pods = __shfl(n.a_pods, src, 64), o.npods = __shfl(n.npods, src, 64);
+    o.w = (uint32_t)__shfl((int32_t)n.w, src, 64);
+    o.placed = 0;
+    return o;
+}
+
+__device__ __forceinline__ int32_t wave_run_down_rows(const RunCtx &cx, const NodeNarrow &n, int32_t stat, int32_t M, bool mine, bool &feas_after,
+                                                      int seq_steps) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, rl = lane & 15;
+    int32_t my_j = 0;
+    feas_after = true;
+    if (!__ballot(mine)) return 0;
+    NodeNarrow cur = n;
+    bool running = mine;
+#pragma unroll 1
+    for (int it = 0; it < seq_steps && __ballot(running); it++) {
+        if (running) {
+            nd_apply(cx, cur, 1);
+            my_j++;
+            feas_after = nd_feasible(cx, cur);
+            running = feas_after && nd_score(cx, cur, (int64_t)stat, NoRcp{}) >= (int64_t)M;
+        }
+    }
+    uint64_t todo = __ballot(running);
+#pragma unroll 1
+    while (todo) {
+        int src = -1; // the node of this lane's row: the row-th lowest lane still running
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int b = todo ? __ffsll((unsigned long long)todo) - 1 : -1;
+            if (row == g) src = b;
+            if (todo) todo &= todo - 1;
+        }
+        const bool active = src >= 0;
+        const NodeNarrow base = nd_shfl(cur, active ? src : 0);
+        const int32_t bstat = __shfl(stat, active ? src : 0, 64);
+        const int32_t room = (int32_t)nd_room(base); // after `room` more placements the node is full
+        int32_t j = 0;
+        bool f_end = true, row_done = !active;
+#pragma unroll 1
+        for (int32_t k0 = 0;; k0 += 16) {
+            NodeNarrow t = base;
+            const int32_t k = k0 + rl + 1;
+            nd_apply(cx, t, k < room ? k : room);
+            const bool f = nd_feasible(cx, t); // (k >= room: the pod count alone makes it infeasible)
+            const bool stop = !(f && nd_score(cx, t, (int64_t)bstat, NoRcp{}) >= (int64_t)M);
+            const uint64_t sm = __ballot(stop), fm = __ballot(f);
+            const uint32_t seg = (uint32_t)(sm >> (row * 16)) & 0xffffu;
+            if (!row_done && seg) {
+                const int first = __ffs((int)seg) - 1;
+                j = k0 + first + 1;
+                f_end = (fm >> (row * 16 + first)) & 1ull;
+                row_done = true;
+            }
+            if (!__ballot(!row_done) || k0 > (1 << 20)) break; // (a run-down is bounded by the node's pod capacity)
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) { // hand each row's result to the lane that owns the node
+            const int sg = __builtin_amdgcn_readlane(src, g * 16);
+            const int32_t jg = __builtin_amdgcn_readlane(j, g * 16);
+            const int fg = __builtin_amdgcn_readlane((int)f_end, g * 16);
+            if (sg >= 0 && lane == sg) my_j += jg, feas_after = fg != 0;
+        }
+    }
+    return my_j;
 }
 
 template <int K>
@@ -171,6 +247,15 @@ template <int K>
 __device__ __forceinline__ void p_store_dyn(PersistLds<K> &L, int li, const NodeNarrow &n) {
     L.r0[li] = n.r0, L.r1[li] = n.r1, L.z0[li] = n.z0, L.z1[li] = n.z1;
     L.pods[li] = ((uint32_t)n.a_pods << 16) | (uint32_t)n.npods;
+}
+
+// wave 0 combines the per-wave partials of a block reduction (one LDS read per lane + log2(waves) shuffles; a loop in
+// thread 0 was a chain of 16 dependent LDS reads per word: 1.6 us per level)
+__device__ __forceinline__ unsigned long long comb_max(const unsigned long long *arr) {
+    return wave_max_u64((threadIdx.x & 63) < kPWaves ? arr[threadIdx.x & 63] : 0ull);
+}
+__device__ __forceinline__ unsigned long long comb_add(const unsigned long long *arr) {
+    return (unsigned long long)wave_sum_i64((int64_t)((threadIdx.x & 63) < kPWaves ? arr[threadIdx.x & 63] : 0ull));
 }
 
 struct PBlockRed { // per-wave partials of a block reduction
@@ -226,8 +311,10 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
     int32_t M = 0, last_feasible = a.st->last_feasible;
     int done = 0;
     bool rescore = true, ordered = want_log;
+    int kb = a.level_batch; // levels the fast path resolves per sync: halved when a batch had to be rolled back, doubled after a clean one
+    int64_t last_k = 1, last_xmt = 0, last_xma = 0; // the last clean pass: levels resolved, holders of the normalization maxima it exhausted
     unsigned long long pf[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
-#define PTICK(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#define PTICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     while (!done && (int)gc.gen_no < a.max_syncs) {
         if (rescore) {
@@ -249,10 +336,9 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             lmt = wave_max_u32(lmt), lma = wave_max_u32(lma);
             if (lane == 0) R.mx[0][wave] = lmt, R.mx[1][wave] = lma;
             __syncthreads();
-            if (tid == 0) {
-                unsigned long long m0 = 0, m1 = 0;
-                for (int w = 0; w < kPWaves; w++) m0 = R.mx[0][w] > m0 ? R.mx[0][w] : m0, m1 = R.mx[1][w] > m1 ? R.mx[1][w] : m1;
-                s_v[0] = m0, s_v[3] = m1; // 0 contributes nothing, and 0 is the neutral result
+            if (wave == 0) {
+                const unsigned long long m0 = comb_max(R.mx[0]), m1 = comb_max(R.mx[1]);
+                if (lane == 0) s_v[0] = m0, s_v[3] = m1; // 0 contributes nothing, and 0 is the neutral result
             }
             grid_reduce(gc);
             if (uni32(s_err)) break;
@@ -279,10 +365,9 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             lnf = wave_sum_u32(lnf), lcmt = wave_sum_u32(lcmt), lcma = wave_sum_u32(lcma);
             if (lane == 0) R.mx[0][wave] = lmax, R.ad[0][wave] = (unsigned long long)lnf | ((unsigned long long)lcmt << 32), R.ad[1][wave] = lcma;
             __syncthreads();
-            if (tid == 0) {
-                unsigned long long v0 = 0, v1 = 0, v2 = 0;
-                for (int w = 0; w < kPWaves; w++) v0 = R.mx[0][w] > v0 ? R.mx[0][w] : v0, v1 += R.ad[0][w], v2 += R.ad[1][w];
-                s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
+            if (wave == 0) {
+                const unsigned long long v0 = comb_max(R.mx[0]), v1 = comb_add(R.ad[0]), v2 = comb_add(R.ad[1]);
+                if (lane == 0) s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
             }
             grid_reduce(gc);
             if (uni32(s_err)) break;
@@ -302,12 +387,30 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
 
         // ---- one level: nodes with TotalScore == M -------------------------------------------------------------
         // (a) every thread looks at its own K scores; level nodes go to the work list
-        uint32_t mymax = 0; // score + 1 over the nodes this level leaves alone
+        // The fast path resolves the levels M .. Lo in one go: every node scoring >= Lo runs down until it scores < Lo --
+        // for a single node that is exactly the sequence of its run-downs at the levels in between (a run-down continues
+        // while the score stays >= the level, a node below the level waits for its own), and without a log or a limit the
+        // interleaving across nodes is unobservable; a normalization event or a crossed limit inside the batch is caught
+        // by the validation below and the batch is redone level by level.
+        // A batch that exhausts the last feasible holder of a normalization maximum is rolled back: do not try one when, at
+        // the rate of the last pass, the holders would run out within twice its span (a heuristic for speed only -- the
+        // validation below decides)
+        int kcap = kb;
+        if (mt > 0 && last_xmt > 0) {
+            const int64_t lv = c_mt * last_k / last_xmt / 2;
+            kcap = lv < kcap ? (lv < 1 ? 1 : (int)lv) : kcap;
+        }
+        if (ma > 0 && last_xma > 0) {
+            const int64_t lv = c_ma * last_k / last_xma / 2;
+            kcap = lv < kcap ? (lv < 1 ? 1 : (int)lv) : kcap;
+        }
+        const int32_t Lo = ordered ? M : (M - (kcap - 1) > 0 ? M - (kcap - 1) : 0);
+        uint32_t mymax = 0; // score + 1 over the nodes this pass leaves alone
         int wtot = 0;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const uint32_t sc = L.sct[k * kPThreads + tid] & 0xffffu;
-            const bool lv = sc == (uint32_t)M;
+            const bool lv = sc >= (uint32_t)Lo && sc != kScInf;
             if (!lv && sc != kScInf) mymax = sc + 1 > mymax ? sc + 1 : mymax;
             const int c = __popcll(__ballot(lv));
             wtot += c;
@@ -316,10 +419,11 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
         if (!ordered) { // any order will do: one LDS atomic per wave
             int wbase = 0;
             if (lane == 0 && wtot) wbase = atomicAdd(&s_n, wtot);
-            wbase = __shfl(wbase, 0, 64);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const bool lv = (L.sct[k * kPThreads + tid] & 0xffffu) == (uint32_t)M;
+                const uint32_t sc = L.sct[k * kPThreads + tid] & 0xffffu;
+                const bool lv = sc >= (uint32_t)Lo && sc != kScInf;
                 const uint64_t b = __ballot(lv);
                 if (lv) L.list[wbase + __popcll(b & lt_mask)] = (uint16_t)(k * kPThreads + tid);
                 wbase += __popcll(b);
@@ -346,7 +450,8 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const bool lv = (L.sct[k * kPThreads + tid] & 0xffffu) == (uint32_t)M;
+                const uint32_t sc = L.sct[k * kPThreads + tid] & 0xffffu;
+                const bool lv = sc >= (uint32_t)Lo && sc != kScInf; // (ordered: Lo == M, the maximum)
                 const uint64_t b = __ballot(lv);
                 if (lv) L.list[s_off[k][wave] + __popcll(b & lt_mask)] = (uint16_t)(k * kPThreads + tid);
             }
@@ -362,16 +467,17 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
 #pragma unroll 1
             for (int r0 = 0; r0 < total; r0 += kPThreads) {
                 const int nwork = total - r0 < kPThreads ? total - r0 : kPThreads;
-                const bool mine = tid < nwork;
+                const int e = lane * kPWaves + wave; // entries dealt round-robin to the waves: every SIMD gets its share of run-downs
+                const bool mine = e < nwork;
                 NodeNarrow n;
                 nd_zero(n);
                 int li = 0;
-                if (mine) li = L.list[r0 + tid], n = p_load_node<K>(L, li);
+                if (mine) li = L.list[r0 + e], n = p_load_node<K>(L, li);
                 bool fend = true;
                 int32_t j = 0;
-                if (wave * 64 < nwork) j = wave_run_down<NodeNarrow>(cx, n, (int64_t)(n.w & 0xffffu), (int64_t)M, mine, fend, a.seq_steps);
+                if (wave < nwork) j = wave_run_down_rows(cx, n, (int32_t)(n.w & 0xffffu), Lo, mine, fend, a.seq_steps);
                 if (mine) {
-                    L.sct[li] = (uint32_t)M | ((uint32_t)j << 16);
+                    L.sct[li] = (L.sct[li] & 0xffffu) | ((uint32_t)j << 16);
                     if (ordered) {
                         T += (uint32_t)j;
                         if (!fend) {
@@ -395,14 +501,12 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
         int64_t cut = kNoCut, remaining = kNoCut, prefix_b = 0;
         if (ordered) {
             __syncthreads();
-            if (tid == 0) {
-                unsigned long long v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-                for (int w = 0; w < kPWaves; w++) {
-                    v1 += R.ad[0][w], v2 += R.ad[1][w];
-                    v3 = R.mx[1][w] > v3 ? R.mx[1][w] : v3, v4 = R.mx[2][w] > v4 ? R.mx[2][w] : v4;
+            if (wave == 0) {
+                const unsigned long long v1 = comb_add(R.ad[0]), v2 = comb_add(R.ad[1]), v3 = comb_max(R.mx[1]), v4 = comb_max(R.mx[2]);
+                if (lane == 0) {
+                    s_v[1] = v1, s_v[2] = v2, s_v[3] = v3, s_v[4] = v4;
+                    __hip_atomic_store(&a.sync->blockT[blockIdx.x], (unsigned)(v1 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                s_v[1] = v1, s_v[2] = v2, s_v[3] = v3, s_v[4] = v4;
-                __hip_atomic_store(&a.sync->blockT[blockIdx.x], (unsigned)(v1 & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             grid_reduce(gc); // (its s_waitcnt covers the blockT store)
             if (uni32(s_err)) break;
@@ -475,11 +579,12 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             R.ad[1][wave] = (unsigned long long)x_mt | ((unsigned long long)x_ma << 32);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned long long v0 = 0, v1 = 0, v2 = 0;
-            for (int w = 0; w < kPWaves; w++) v0 = R.mx[0][w] > v0 ? R.mx[0][w] : v0, v1 += R.ad[0][w], v2 += R.ad[1][w];
-            s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
-            s_n = 0; // next level's list (every thread read `total` before the barrier above)
+        if (wave == 0) {
+            const unsigned long long v0 = comb_max(R.mx[0]), v1 = comb_add(R.ad[0]), v2 = comb_add(R.ad[1]);
+            if (lane == 0) {
+                s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
+                s_n = 0; // next level's list (every thread read `total` before the barrier above)
+            }
         }
         PTICK(3);
         grid_reduce(gc);
@@ -503,14 +608,17 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                         NodeNarrow n = p_load_node<K>(L, li);
                         nd_apply(cx, n, -(int64_t)tk);
                         p_store_dyn<K>(L, li, n);
-                        L.sct[li] = (uint32_t)M;
+                        L.sct[li] = (uint32_t)nd_score(cx, n, (int64_t)(n.w & 0xffffu), NoRcp{}); // (it was feasible: it took pods)
                     }
                 __syncthreads();
-                ordered = true;
+                if (Lo < M) kb = (M - Lo + 1) >> 1; // a batch: retry with half the levels, still blind (the event is somewhere inside)
+                else ordered = true;                // one level: redo it in canonical order
                 continue;
             }
         }
         placed += g_committed, rounds += g_committed;
+        if (!ordered) kb = 2 * kb < a.level_batch ? 2 * kb : a.level_batch;
+        last_k = M - Lo + 1, last_xmt = g_xmt, last_xma = g_xma;
         nfeas -= g_xnf, c_mt -= g_xmt, c_ma -= g_xma;
         scans += 1;
         if (limit > 0 && placed >= limit) { // simulator.go:297-312: tested after the append
