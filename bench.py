@@ -9,22 +9,23 @@ of `--limit` placements (0 = until the scheduler reports Unschedulable) against 
 snapshot.  The snapshot is resident in HBM before the timed region starts; every step first restores
 the dynamic node columns device-to-device (ccsim_reset_state, inside the timed region).
 
-Workload (BASELINE config 4, "C4"): 1M synthetic nodes per GPU, default plugin set, examples/pod.yaml +
+Workload (BASELINE config 4, "C4"): 1M synthetic nodes, default plugin set, examples/pod.yaml +
 toleration + preferred node affinity, percentageOfNodesToScore=100.  N=1: the 1M-node snapshot on one
-GPU.  N>1 (launched by torch.distributed.run, one rank per GPU): WEAK scaling -- an N x 1M-node cluster
-sharded by contiguous node range (1M nodes per GPU), one RCCL all-gather of a 256-byte record per pass
-(the max-loc exchange), only owning ranks update their columns.  `--scaling strong` shards ONE 1M-node
-snapshot over the N GPUs instead (BASELINE config 4 literally); it is latency-bound by construction (the
-per-pass GPU work shrinks N-fold while the exchange does not), see DESIGN.md section 5.
+GPU.  N>1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling by default -- the SAME
+1M-node snapshot sharded by contiguous node range over the N GPUs (BASELINE config 4 literally), one RCCL
+all-gather of a 256-byte record per pass (the max-loc exchange), only owning ranks update their columns.
+It is latency-bound by construction (the per-pass GPU work shrinks N-fold while the exchange does not) and
+one GPU holds the whole snapshot in LDS, so sharding buys capacity, not speed.
+`--scaling weak` makes it an N x 1M-node cluster (1M nodes per GPU) instead.
 
 Modes (identical placement sequences, see tests/): `batched` resolves a whole score level (many
 placement rounds) per full pods x nodes pass; `sequential` is the literal one-round-per-pass loop.
 The headline `value` is the batched mode; a sequential sample is reported next to it in `config`.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the engine's stream for the
-dominant kernel (batched: k_level_commit, the one launch per pass that commits a level off the score cache;
-sequential: k_scan) and, under `full_pass`, for the kernel that streams every node column (k_level_score /
-k_scan, 60 B/node); k_level_final (one block) is listed in profiles/.  `cpu_baseline` is the C oracle (a port of the reference algorithm -- the Go reference cannot
+dominant kernel (batched: k_level_persist, the ONE persistent launch of a simulation; sequential: k_scan) as a
+physical HBM rate (PMC bytes / duration), with the sync-latency model that actually bounds it, and, under
+`full_pass`, for the kernel that streams every node column (k_level_score / k_scan).  `cpu_baseline` is the C oracle (a port of the reference algorithm -- the Go reference cannot
 be built here) timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
@@ -47,16 +48,27 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 READ_PEAK_MEASURED_GBPS = 6420.0  # pure streaming read of the same 60 MB on the round-1 box (tools/hbm_peak.hip, profiles/r01/hbm_peak.txt)
 
 
-def cpu_baseline(nodes, pod, prof, rounds: int):
-    """Oracle (port of the reference algorithm) on the host cores, bounded sample."""
+def lib_sha16() -> str:
+    import hashlib
+    from cluster_capacity_amd import build as b
+
+    return hashlib.sha256(open(b.lib_path(), "rb").read()).hexdigest()[:16]
+
+
+def cpu_baseline(nodes, pod, prof, rounds: int, engine_log):
+    """Oracle (port of the reference algorithm) on the host cores, bounded sample.  Its placement log must equal the
+    engine's first `rounds` placements (the checker checks the thing measured before the number is printed)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ccref_py
 
     threads = min(16, os.cpu_count() or 1)  # reference default Parallelism = 16
     t0 = time.perf_counter()
-    r = ccref_py.run(prof, nodes, pod, max_limit=rounds, threads=threads, want_log=False)
+    r = ccref_py.run(prof, nodes, pod, max_limit=rounds, threads=threads, want_log=True)
     dt = time.perf_counter() - t0
+    if engine_log is not None:
+        assert np.array_equal(np.asarray(r.log[: r.placed]), np.asarray(engine_log[: r.placed])), "engine and oracle placement logs differ"
     return {
+        "log_equals_engine_prefix": engine_log is not None,
         "value": r.placed / dt,
         "unit": "placements/s",
         "cores": threads,
@@ -73,7 +85,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default="batched", choices=["sequential", "batched"])
     ap.add_argument("--nodes", type=int, default=1_000_000, help="nodes per GPU (weak) / in the whole snapshot (strong)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong = ONE --nodes snapshot sharded over the N GPUs (BASELINE config 4 literally); weak = N x --nodes")
+    ap.add_argument("--no-variants", action="store_true", help="skip the multi-kernel / wide-path comparison runs")
     ap.add_argument("--limit", type=int, default=-1, help="placements per step (0 = until Unschedulable; "
                     "-1 = mode default: 0 for batched, 2048 for sequential)")
     ap.add_argument("--seq-rounds", type=int, default=2048, help="rounds of the sequential-mode sample (0 = skip)")
@@ -145,57 +159,93 @@ def main():
         barrier()
         seq = rs.placed / (time.perf_counter() - s0)
 
-    # Roofline.  The dominant kernel of the batched mode is k_level_commit (one launch per pass: reads the 4-byte score
-    # cache of every node, runs the level's nodes down on their commit rows, re-scores them, reduces the next level);
-    # of the sequential mode, k_scan.  Their average launch duration is measured live: one more run of the SAME workload
-    # on a second engine whose passes are launched eagerly with a stop stamp per dispatch on the engine's stream
-    # (cfg.time_passes -> hipExtLaunchKernelGGL events; rocprofv3 --kernel-trace --stats of this command, profiles/,
-    # reports the same average).  `achieved` uses SURVEY 8(d)'s algorithmic bytes: one pass = one evaluation of every
-    # (pod, node) pair = N x B_node, the full-scan definition -- what the pass would have to stream without the score
-    # cache; `traffic` is what it really moves (PMC).  The kernel that DOES stream every node column, the full pass
-    # k_level_score (first pass of a run and whenever the normalization constants move), is timed as a train of
-    # back-to-back launches on the freshly restored snapshot and reported next to it (`full_pass`).
-    kernel = "k_level_commit" if args.mode == "batched" else "k_scan"
-    pmc = {}
+    # Roofline.  The dominant kernel of the batched mode is the persistent level kernel k_level_persist (csrc/ccsim_persist.h:
+    # one launch per simulation; it reads the narrow node columns once, keeps them in LDS, and writes the state back at
+    # the end), of the sequential mode k_scan.  Duration: HIP events around the launch on the engine's stream
+    # (ccsim_report.kernel_ns of the LAST timed step; rocprofv3 --kernel-trace --stats of this command, profiles/r02/,
+    # reports the same average).  `achieved` = HBM bytes the launch really moves (rocprofv3 PMC, profiles/r02/pmc_traffic.json,
+    # accepted only if it was collected with THIS libccsim.so) / duration: a physical rate.  The persistent kernel is not
+    # HBM-bound -- it is bound by its grid-wide syncs (syncs x (barrier latency + the run-downs of the slowest workgroup)) --
+    # so the fraction is small by design; `sync_bound` carries that model.  The work the reference semantics imply
+    # (every placement round evaluates every node) is reported separately under `algorithmic`, never as GB/s.
+    # The kernels that DO stream every node column per launch (k_level_score, the multi-kernel batched mode's full pass /
+    # k_scan, the sequential mode's pass) are timed as a train of back-to-back launches on the freshly restored snapshot
+    # and reported under `full_pass` with both the algorithmic (60 B/node) and the physical (narrow mirrors) byte counts.
+    persistent = args.mode == "batched" and not distributed and os.environ.get("CCSIM_PERSIST", "1") != "0"
+    kernel = "k_level_persist" if persistent else ("k_level_commit" if args.mode == "batched" else "k_scan")
+    sha = lib_sha16()
+    pmc, pmc_note = {}, "no profiles/r02/pmc_traffic.json for this workload"
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["kernels"] if hi - lo == 1_000_000 else {}
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")))
+        if hi - lo != 1_000_000:
+            pmc_note = "PMC traffic was collected at 1,000,000 nodes per GPU"
+        elif pj.get("lib_sha16") != sha:
+            pmc_note = f"stale: collected with libccsim.so {pj.get('lib_sha16')}, this run uses {sha}"
+        else:
+            pmc, pmc_note = pj["kernels"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so (profiles/r02/pmc_traffic.json)"
     except (OSError, KeyError, ValueError):
         pass
     roofline = None
-    if not args.no_roofline:
+    if not args.no_roofline and not distributed:
         eng.reset_state()
         train = 200
         scan_ns, bytes_per_scan = eng.time_scan(train, mode=args.mode)
         full_s = scan_ns / train / 1e9
         full_kernel = "k_level_score" if args.mode == "batched" else "k_scan"
+        n_here = hi - lo
+        phys = n_here * (36 + (4 if args.mode == "batched" else 0))  # int32 mirrors (24 B) + stat, alloc_pods, pod_count (12 B) [+ the 4-byte score cache written]
         full_pass = {
-            "kernel": full_kernel, "achieved": bytes_per_scan / full_s / 1e9, "frac": bytes_per_scan / full_s / 1e9 / HBM_PEAK_GBPS,
-            "frac_of_measured_read_peak": bytes_per_scan / full_s / 1e9 / READ_PEAK_MEASURED_GBPS,
-            "us_per_launch": full_s * 1e6, "launches_timed": train, "bytes_per_launch": bytes_per_scan,
-            # most k_level_score launches of a profiled run are no-op graph heads: the largest launch is a real one
+            "kernel": full_kernel, "us_per_launch": full_s * 1e6, "launches_timed": train,
+            "bytes_algorithmic": bytes_per_scan, "achieved_algorithmic": bytes_per_scan / full_s / 1e9,
+            "frac_algorithmic": bytes_per_scan / full_s / 1e9 / HBM_PEAK_GBPS,
+            "bytes_physical": phys, "achieved": phys / full_s / 1e9, "frac": phys / full_s / 1e9 / HBM_PEAK_GBPS,
+            "frac_of_measured_read_peak": phys / full_s / 1e9 / READ_PEAK_MEASURED_GBPS,
             "traffic": pmc.get(full_kernel, {}).get("hbm_bytes_largest_launch" if args.mode == "batched" else "hbm_bytes_per_launch"),
         }
-        pe = capi.Engine(device=local_rank, time_passes=True)  # this rank's shard as a stand-alone snapshot
-        pe.load(nodes, pod, prof)
-        prun = pe.run(max_limit=limit, mode=args.mode, want_log=False)
-        pe.close()
-        dom_s = prun.pass_kernel_ns / max(1, prun.pass_launches) / 1e9
-        achieved = bytes_per_scan / dom_s / 1e9
+        launches = max(1, r.pass_launches) if persistent else max(1, r.scans)
+        dom_s = r.kernel_ns / 1e9 / (launches if persistent else 1)
+        traffic = pmc.get(kernel, {}).get("hbm_bytes_per_launch")
+        # without counters: what the kernel is written to move -- 36 B/node read at the start, 4 B/node (static word) per
+        # re-score phase, 68 B/node written + 8 B/node read at the end (mirrors 16, int64 columns 32, pod counts 4+4, result 4+4)
+        model_bytes = n_here * (36 + 4 * 4 + 76)
+        moved = traffic if traffic else model_bytes
         roofline = {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc.get(kernel, {}).get("hbm_bytes_per_launch"),
-            "kernel": kernel,
-            "bytes_per_launch": bytes_per_scan,
-            "bytes_definition": "algorithmic, full-scan definition (SURVEY 8(d)): nodes x enabled column bytes per pass; "
-                                "`traffic` = HBM bytes the launch really moves (rocprofv3 PMC, profiles/r01/pmc_traffic.json)",
-            "us_per_launch": dom_s * 1e6,
-            "launches_timed": int(prun.pass_launches),
+            "bound": "hbm", "kernel": kernel,
+            "achieved": moved / dom_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": moved / dom_s / 1e9 / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": pmc_note, "bytes_per_launch": moved,
+            "bytes_definition": "HBM bytes one launch moves (PMC when available, else the kernel's designed traffic): a physical rate",
+            "us_per_launch": dom_s * 1e6, "launches_timed": int(launches),
+            "sync_bound": {
+                "what": "the persistent kernel is bound by grid-wide sync latency, not HBM: one reduce+barrier per resolved batch of score levels",
+                "syncs_per_launch": int(r.scans), "us_per_sync": dom_s * 1e6 / max(1, r.scans),
+                "barrier_floor_us": 2.6,  # tools/barrier_bench.hip on this chip: arrive + release + poll, nothing published (profiles/r02/barrier_bench.txt)
+            } if persistent else None,
+            "algorithmic": {
+                "definition": "SURVEY 8(d): every placement round evaluates every node = rounds x nodes x 60 B; the level-batched engine "
+                              "does not do that work (an algorithmic speed-up, not bandwidth)",
+                "full_scan_bytes_per_step": int(r.rounds) * n_here * 60,
+                "algorithmic_speedup_vs_bytes_moved": int(r.rounds) * n_here * 60 / max(1, moved),
+            },
             "full_pass": full_pass,
         }
+    variants = {}
+    if args.mode == "batched" and not distributed and not args.no_variants:
+        # the same step on the other code paths of the batched mode (untimed by the driver): the multi-kernel form
+        # (one commit + one decision dispatch per level) and the wide path (int64 columns, fp64 arithmetic)
+        for name, env in (("multi_kernel_ms_per_step", {"CCSIM_PERSIST": "0"}), ("wide_path_ms_per_step", {"CCSIM_NARROW": "0"})):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            ve = capi.Engine(device=local_rank)
+            ve.load(nodes, pod, prof)
+            ve.reset_state(); ve.run(max_limit=limit, mode="batched", want_log=False)
+            torch.cuda.synchronize()
+            v0 = time.perf_counter()
+            ve.reset_state(); vr = ve.run(max_limit=limit, mode="batched", want_log=False)
+            variants[name] = (time.perf_counter() - v0) * 1e3
+            assert vr.placed == r.placed, (name, vr.placed, r.placed)
+            ve.close()
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     out = {
         "metric": "simulated pod placements/sec at 1M nodes",
         "value": placed / dt,
@@ -207,7 +257,7 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "int64",
+        "dtype": "int32",
         "data": "synthetic",
         "config": {
             "workload": f"{n_global}-node synthetic snapshot ({hi - lo} nodes/GPU; C4: default plugin set, examples/pod.yaml + toleration + "
@@ -218,14 +268,18 @@ def main():
             "passes_per_step": scans // max(1, args.steps),
             "sequential_mode_placements_per_s": seq,
             "parallelism": f"node-shard x{world}",
-            "arithmetic": "exact integer results (int64 columns); this snapshot's values fit the engine's lossless 32-bit mirrors, "
-                          "which the scan / level kernels then use",
+            "arithmetic": "exact integer results: the canonical state is int64 columns; this snapshot's values fit the engine's lossless "
+                          "32-bit mirrors (validated per pod spec), which the timed kernels compute in (int32 / f32 estimates with exact "
+                          "fix-ups); `wide_path_ms_per_step` is the same step on the int64 / fp64 path",
+            **variants,
         },
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu and not distributed:
         nodes_full = nodes if world == 1 else synth.make_config("C4", n_nodes=n_global)[0]
-        out["cpu_baseline"] = cpu_baseline(nodes_full, pod, prof, args.cpu_rounds)
+        eng.reset_state()
+        head = eng.run(max_limit=args.cpu_rounds, mode=args.mode, want_log=True, log_cap=args.cpu_rounds)
+        out["cpu_baseline"] = cpu_baseline(nodes_full, pod, prof, args.cpu_rounds, head.log)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

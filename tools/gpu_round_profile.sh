@@ -1,0 +1,17 @@
+#!/bin/bash
+# round-end evidence: the bench line, rocprofv3 kernel stats of the same command, PMC traffic (separate passes), the
+# barrier micro-benchmark.  Everything lands in gpurun_out/r02/ ; copy what is to be judged into profiles/r02/.
+exec < /dev/null
+cd /root/repo
+O=/root/repo/gpurun_out/r02
+mkdir -p $O
+timeout 60 tools/barrier_bench.bin 2000 2>&1 | tee $O/barrier_bench.txt
+timeout 400 python bench.py > $O/bench_1M.json 2> $O/bench_1M.err; tail -c 400 $O/bench_1M.json; echo
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/ks
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python /root/repo/bench.py --no-cpu --no-variants --seq-rounds 0 > $O/bench_1M_under_rocprofv3.json 2> $O/ks.err
+f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_1M_kernel_stats.csv && cut -c1-200 $O/bench_1M_kernel_stats.csv | head -12
+cd /root/repo
+bash tools/gpu_pmc.sh r02 "FETCH_SIZE" "WRITE_SIZE" 2>&1 | tail -12
+cp gpurun_out/pmc_traffic_r02.json $O/pmc_traffic.json 2>/dev/null
+rm -rf $O/ks gpurun_out/pmc_r02_1 gpurun_out/pmc_r02_2

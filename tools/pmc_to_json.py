@@ -39,7 +39,10 @@ def main():
         out[k] = {"launches": f[1], "FETCH_SIZE_KB_avg": round(fk, 1), "WRITE_SIZE_KB_avg": round(wk, 1),
                   "hbm_bytes_per_launch": int((2 * fk + wk) * 1024),
                   "hbm_bytes_largest_launch": int((2 * f[2] + w[2]) * 1024)}
+    import hashlib, os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cluster-capacity_amd", "csrc", "libccsim.so")
     json.dump({
+        "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],  # bench.py refuses traffic collected with another build
         "workload": "bench.py C4 1,000,000 nodes, 1 GPU, batched mode (one timed step)",
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_pmc.sh); hbm_bytes_per_launch = "
                 "(2*FETCH_SIZE + WRITE_SIZE) KB, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); averages over ALL "
