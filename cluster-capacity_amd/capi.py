@@ -91,12 +91,15 @@ class CReport(C.Structure):
         ("hist_taintset", _p64), ("hist_taintset_cap", C.c_int32), ("n_code_unschedulable", C.c_int64),
         ("rounds", C.c_int64), ("scans", C.c_int64), ("evaluated_total", C.c_int64), ("last_feasible", C.c_int32),
         ("kernel_ns", C.c_int64), ("pass_kernel_ns", C.c_int64), ("pass_launches", C.c_int64), ("bytes_per_scan", C.c_int64),
+        ("per_spec_count", _p32), ("per_spec_cap", C.c_int32), ("stop_spec", C.c_int32),
     ]
 
 
 class CCycle(C.Structure):
     _fields_ = [("node", C.c_int64), ("evaluated_nodes", C.c_int32), ("feasible_nodes", C.c_int32)]
 
+
+ABI_VERSION = 2  # CCSIM_ABI_VERSION of include/ccsim.h
 
 # every symbol include/ccsim.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = {
@@ -107,6 +110,8 @@ SYMBOLS = {
     "ccsim_load_nodes": (C.c_int, [C.c_void_p, C.POINTER(CNodes)]),
     "ccsim_set_profile": (C.c_int, [C.c_void_p, C.POINTER(CProfile)]),
     "ccsim_set_pod": (C.c_int, [C.c_void_p, C.POINTER(CPod)]),
+    "ccsim_set_pods": (C.c_int, [C.c_void_p, C.POINTER(CPod), C.c_int32]),
+    "ccsim_schedule_pod": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(CCycle)]),
     "ccsim_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
     "ccsim_schedule_one": (C.c_int, [C.c_void_p, C.POINTER(CCycle)]),
     "ccsim_read_state": (C.c_int, [C.c_void_p, _p64, _p64, _p64, _p64, _p32]),
@@ -149,7 +154,7 @@ def load(build_if_missing: bool = True):
             fn = getattr(lib, name)  # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.ccsim_abi_version() != 1:
+        if lib.ccsim_abi_version() != ABI_VERSION:
             raise RuntimeError("libccsim ABI version mismatch")
         _lib = lib
     return _lib
@@ -313,7 +318,7 @@ class Engine:
                  time_passes: bool = False):
         self.lib = load()
         # stream: a hipStream_t handle (e.g. torch.cuda.Stream().cuda_stream); 0/None = the engine creates its own
-        cfg = CConfig(1, int(device), C.c_void_p(stream) if stream else None, int(rounds_per_sync), int(use_graph),
+        cfg = CConfig(ABI_VERSION, int(device), C.c_void_p(stream) if stream else None, int(rounds_per_sync), int(use_graph),
                       int(time_passes))
         h = C.c_void_p()
         rc = self.lib.ccsim_create(C.byref(cfg), C.byref(h))
@@ -322,6 +327,7 @@ class Engine:
         self.h = h
         self.n = 0
         self.n_taintsets = 1
+        self.n_pods = 1
 
     def close(self):
         if getattr(self, "h", None):
@@ -335,13 +341,17 @@ class Engine:
             msg = self.lib.ccsim_last_error(self.h)
             raise CcsimError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")
 
-    def load(self, nodes: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int = 0,
+    def load(self, nodes: M.NodesSoA, pod, profile: M.Profile, global_offset: int = 0,
              n_global: Optional[int] = None):
+        """`pod`: one M.PodSpec, or a list of them (cycled round-robin: ccsim_set_pods)."""
         keep: list = []
         self._chk(self.lib.ccsim_load_nodes(self.h, C.byref(marshal_nodes(nodes, keep, global_offset, n_global))), "ccsim_load_nodes")
         self.n = nodes.n
         self.set_profile(profile)
-        self.set_pod(pod)
+        if isinstance(pod, (list, tuple)):
+            self.set_pods(pod)
+        else:
+            self.set_pod(pod)
 
     def set_profile(self, profile: M.Profile):
         self._chk(self.lib.ccsim_set_profile(self.h, C.byref(marshal_profile(profile))), "ccsim_set_profile")
@@ -351,6 +361,21 @@ class Engine:
         cp = marshal_pod(pod, keep)
         self._chk(self.lib.ccsim_set_pod(self.h, C.byref(cp)), "ccsim_set_pod")
         self.n_taintsets = int(cp.n_taintsets)
+
+    def set_pods(self, pods):
+        """Several pod specs, cycled round-robin by run() (include/ccsim.h ccsim_set_pods)."""
+        keep: list = []
+        arr = (CPod * len(pods))()
+        for i, p in enumerate(pods):
+            arr[i] = marshal_pod(p, keep)
+        self._chk(self.lib.ccsim_set_pods(self.h, arr, len(pods)), "ccsim_set_pods")
+        self.n_taintsets = max(int(a.n_taintsets) for a in arr)
+        self.n_pods = len(pods)
+
+    def schedule_pod(self, pod_idx: int):
+        cyc = CCycle()
+        self._chk(self.lib.ccsim_schedule_pod(self.h, int(pod_idx), C.byref(cyc)), "ccsim_schedule_pod")
+        return int(cyc.node), int(cyc.evaluated_nodes), int(cyc.feasible_nodes)
 
     def _report(self, want_log: bool, log_cap: int):
         rep = CReport()
@@ -365,6 +390,10 @@ class Engine:
         ht = np.zeros(max(1, self.n_taintsets), np.int64)
         rep.hist_taintset = _ptr(ht, _p64)
         rep.hist_taintset_cap = ht.shape[0]
+        self._per_spec = np.zeros(max(1, self.n_pods), np.int32)
+        rep.per_spec_count = _ptr(self._per_spec, _p32)
+        rep.per_spec_cap = self._per_spec.shape[0]
+        rep.stop_spec = -1
         return rep, per_node, log, ht
 
     def _result(self, rep, per_node, log, ht) -> M.RunResult:
@@ -375,6 +404,7 @@ class Engine:
             n_code_unschedulable=int(rep.n_code_unschedulable), rounds=int(rep.rounds),
             evaluated_total=int(rep.evaluated_total), last_feasible=int(rep.last_feasible), scans=int(rep.scans),
             kernel_ns=int(rep.kernel_ns), pass_kernel_ns=int(rep.pass_kernel_ns), pass_launches=int(rep.pass_launches), bytes_per_scan=int(rep.bytes_per_scan),
+            per_spec_count=self._per_spec[: self.n_pods].copy(), stop_spec=int(rep.stop_spec),
         )
 
     def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None) -> M.RunResult:

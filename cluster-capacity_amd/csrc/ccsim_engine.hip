@@ -9,6 +9,7 @@
 #include "ccsim_kernels.h"
 #include "ccsim_level.h"
 #include "ccsim_persist.h"
+#include "ccsim_multi.h"
 
 #include <errno.h>
 #include <hip/hip_ext.h>
@@ -17,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -46,6 +48,9 @@ struct ccsim_engine {
     DevCols cols{};
     uint8_t *d_unsched = nullptr;
     int32_t **d_label_cols = nullptr;
+    std::vector<std::vector<int32_t>> h_label_cols; // host copies (ccsim_set_pods derives per-spec tables from them)
+    std::vector<int32_t *> dev_label_ptrs;
+    std::vector<int32_t> label_col_max; // largest value id per label column
     uint32_t *d_stat = nullptr;
     uint8_t *d_sreason = nullptr;
 
@@ -100,6 +105,24 @@ struct ccsim_engine {
     int persist_allowed = 1;
     int64_t node_max_podcount = 0; // largest len(NodeInfo.Pods) of the snapshot
     int persist_run = 0; // K of the current batched run's persistent launch, 0 = multi-kernel path
+    // several pod specs cycled round-robin (ccsim_multi.h)
+    bool multi = false;
+    int n_pods = 0, n_cls = 0, m_blocks = 0, multi_window = kMWindowMax, max_taintsets = 1;
+    std::vector<void *> multi_allocs;
+    std::vector<MPod> h_mpods;
+    std::vector<int> cls_taintsets; // taint sets of each static class (the FitError histogram of the failing pod)
+    MPod *d_mpods = nullptr;
+    MState *d_mstate = nullptr, *h_mstate = nullptr;
+    uint32_t *d_stat_cls = nullptr;
+    uint8_t *d_sreason_cls = nullptr, *d_present_pool = nullptr, *d_inc_pool = nullptr;
+    int32_t *d_tbl_pool = nullptr, *d_tbl_pool0 = nullptr, *d_per_spec = nullptr;
+    size_t tbl_len = 0, anti_words = 0;
+    uint32_t *d_anti_bits = nullptr, *d_anti_bits0 = nullptr;
+    MPartial *d_mpartials = nullptr;
+    MCand *d_mcands = nullptr;
+    const int32_t *tsc_label[kMTsc] = {nullptr, nullptr};
+    DevPod multi_prof{};
+    int32_t multi_next = 0; // spec of the next cycle (continues across runs; ccsim_reset_state rewinds it)
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
     int dist_pass_in_window = 0;      // passes since the last ccsim_dist_begin / ccsim_dist_poll
@@ -233,6 +256,8 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     drop_graph(e);
     free_list(e->allocs);
     free_list(e->pod_allocs);
+    free_list(e->multi_allocs);
+    if (e->h_mstate) (void)hipHostFree(e->h_mstate);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_partials) (void)hipFree(e->d_partials);
     if (e->d_smp_partials) (void)hipFree(e->d_smp_partials);
@@ -263,6 +288,8 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     e->backups.clear();
     e->backup_bytes.clear();
     e->have_nodes = e->have_pod = e->begun = false;
+    e->multi = false;
+    free_list(e->multi_allocs);
     e->cols.narrow = 0;
     e->n = nd->n_nodes;
     e->n_pad = ((e->n + kTile - 1) / kTile) * kTile;
@@ -296,8 +323,16 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     if ((rc = dev_alloc(e, &e->d_stat, np, e->allocs))) return rc;
     if ((rc = dev_alloc(e, &e->d_sreason, np, e->allocs))) return rc;
     std::vector<int32_t *> lc((size_t)CCSIM_MAX_LABEL_COLS, nullptr);
-    for (int k = 0; k < nd->n_label_cols; k++)
+    e->h_label_cols.assign((size_t)nd->n_label_cols, {});
+    for (int k = 0; k < nd->n_label_cols; k++) {
         if ((rc = upload(e, &lc[k], nd->label_cols[k], n, np, e->allocs))) return rc;
+        if (nd->label_cols[k]) e->h_label_cols[(size_t)k].assign(nd->label_cols[k], nd->label_cols[k] + n);
+        else e->h_label_cols[(size_t)k].assign(n, 0);
+    }
+    e->dev_label_ptrs = lc;
+    e->label_col_max.assign((size_t)nd->n_label_cols, 0);
+    for (int k = 0; k < nd->n_label_cols; k++)
+        for (int32_t v : e->h_label_cols[(size_t)k]) e->label_col_max[(size_t)k] = v > e->label_col_max[(size_t)k] ? v : e->label_col_max[(size_t)k];
     if ((rc = dev_alloc(e, &e->d_label_cols, (size_t)CCSIM_MAX_LABEL_COLS, e->allocs))) return rc;
     HIPCHK(e, hipMemcpyAsync(e->d_label_cols, lc.data(), sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyHostToDevice,
                              e->stream));
@@ -397,32 +432,70 @@ extern "C" int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
     e->prof = *p;
     e->have_profile = true;
     e->have_pod = false;
+    e->multi = false;
     drop_graph(e);
     return 0;
 }
 
-extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
-    if (!e || !pod) return -EINVAL;
-    if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
-    if (pod->n_taintsets < 1 || !pod->taint_filter_ok || !pod->taint_prefer_cnt)
-        return fail(e, -EINVAL, "taint tables are required (n_taintsets >= 1)");
-    int64_t wsum = 0;
-    for (int t = 0; t < pod->n_preferred; t++) wsum += pod->preferred[t].weight;
-    if (wsum > (int64_t)kStatAffMask) return fail(e, -EINVAL, "sum of preferred term weights too large");
-    for (int t = 0; t < pod->n_taintsets; t++)
-        if (pod->taint_prefer_cnt[t] < 0 || pod->taint_prefer_cnt[t] > (int32_t)kStatCntMask)
-            return fail(e, -EINVAL, "taint_prefer_cnt out of range");
-    for (int c = 0; c < CCSIM_MAX_RES; c++) {
-        if (pod->req[c] < 0) return fail(e, -EINVAL, "negative request");
-        if (c >= e->ncol && pod->req[c] != 0) return fail(e, -EINVAL, "request for a resource column the snapshot lacks");
+// The static (pod-spec dependent, state independent) kernel for one pod spec: uploads the taint-set / requirement tables,
+// runs k_static into `stat` / `sreason` ([n_pad] each).  Shared by ccsim_set_pod and ccsim_set_pods (one run per class).
+static int static_pass(ccsim_engine *e, const ccsim_pod *pod, bool score_preferred, uint32_t *stat, uint8_t *sreason, std::vector<void *> &track) {
+    const ccsim_profile &pf = e->prof;
+    StaticArgs s{};
+    s.n = e->n;
+    s.n_pad = e->n_pad;
+    s.filter_mask = pf.filter_mask;
+    s.unschedulable = e->d_unsched;
+    s.taintset_id = e->cols.taintset_id;
+    s.tolerates_unschedulable = pod->tolerates_unschedulable;
+    s.affinity_filter_active = pod->affinity_filter_active;
+    s.has_node_selector = pod->has_node_selector;
+    s.has_required_terms = pod->has_required_terms;
+    s.n_required = pod->n_required;
+    s.n_preferred = score_preferred ? pod->n_preferred : 0;
+    s.node_selector = DevTerm{pod->node_selector.first_req, pod->node_selector.n_req, 0};
+    s.label_cols = e->d_label_cols;
+    s.stat = stat;
+    s.sreason = sreason;
+    int rc;
+    uint8_t *d_ok = nullptr;
+    int32_t *d_cnt = nullptr;
+    if ((rc = upload(e, &d_ok, pod->taint_filter_ok, (size_t)pod->n_taintsets, (size_t)pod->n_taintsets, track))) return rc;
+    std::vector<int32_t> cnt(pod->taint_prefer_cnt, pod->taint_prefer_cnt + pod->n_taintsets);
+    if (!pf.w_taint) std::fill(cnt.begin(), cnt.end(), 0); // plugin disabled: keep the normalization constant fixed
+    if ((rc = upload(e, &d_cnt, cnt.data(), cnt.size(), cnt.size(), track))) return rc;
+    s.taint_filter_ok = d_ok;
+    s.taint_prefer_cnt = d_cnt;
+    std::vector<DevTerm> rq, pr;
+    for (int t = 0; t < pod->n_required; t++) rq.push_back(DevTerm{pod->required[t].first_req, pod->required[t].n_req, 0});
+    for (int t = 0; t < pod->n_preferred; t++)
+        pr.push_back(DevTerm{pod->preferred[t].first_req, pod->preferred[t].n_req, pod->preferred[t].weight});
+    std::vector<DevReq> reqs;
+    for (int i = 0; i < pod->n_reqs; i++) {
+        if (pod->reqs[i].col < 0 || pod->reqs[i].col >= e->n_label_cols) return fail(e, -EINVAL, "requirement column out of range");
+        reqs.push_back(DevReq{pod->reqs[i].col, pod->reqs[i].table_off});
     }
-    HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    drop_graph(e);
-    free_list(e->pod_allocs);
-    e->have_pod = e->begun = false;
-    e->n_taintsets = pod->n_taintsets;
+    DevTerm *d_rq = nullptr, *d_pr = nullptr;
+    DevReq *d_reqs = nullptr;
+    uint8_t *d_tab = nullptr;
+    if ((rc = upload(e, &d_rq, rq.data(), rq.size(), rq.size(), track))) return rc;
+    if ((rc = upload(e, &d_pr, pr.data(), pr.size(), pr.size(), track))) return rc;
+    if ((rc = upload(e, &d_reqs, reqs.data(), reqs.size(), reqs.size(), track))) return rc;
+    if ((rc = upload(e, &d_tab, pod->req_tables, (size_t)pod->req_tables_len, (size_t)pod->req_tables_len, track))) return rc;
+    s.required = d_rq;
+    s.preferred = d_pr;
+    s.reqs = d_reqs;
+    s.req_tables = d_tab;
+    const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_static, dim3(blocks), dim3(kThreads), 0, e->stream, s);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream)); // host vectors above go out of scope
+    return 0;
+}
 
+// pod + profile constants of the scan kernels (fit.go:224-233, resource_allocation.go:118-148, node_affinity.go:243-246,
+// balanced_allocation.go:66-79)
+static DevPod make_devpod(const ccsim_engine *e, const ccsim_pod *pod) {
     const ccsim_profile &pf = e->prof;
     DevPod p{};
     for (int c = 0; c < CCSIM_MAX_RES; c++) p.req[c] = pod->req[c];
@@ -448,59 +521,45 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         if (pod->req[pf.bal_res[i]] != 0) best_effort = false;
     }
     p.w_bal = best_effort ? 0 : pf.w_balanced;
+    return p;
+}
+
+static int validate_pod(ccsim_engine *e, const ccsim_pod *pod) {
+    if (int vrc = validate_pod(e, pod)) return vrc;
+    return 0;
+}
+
+extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
+    if (!e || !pod) return -EINVAL;
+    if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
+    if (pod->n_taintsets < 1 || !pod->taint_filter_ok || !pod->taint_prefer_cnt)
+        return fail(e, -EINVAL, "taint tables are required (n_taintsets >= 1)");
+    int64_t wsum = 0;
+    for (int t = 0; t < pod->n_preferred; t++) wsum += pod->preferred[t].weight;
+    if (wsum > (int64_t)kStatAffMask) return fail(e, -EINVAL, "sum of preferred term weights too large");
+    for (int t = 0; t < pod->n_taintsets; t++)
+        if (pod->taint_prefer_cnt[t] < 0 || pod->taint_prefer_cnt[t] > (int32_t)kStatCntMask)
+            return fail(e, -EINVAL, "taint_prefer_cnt out of range");
+    for (int c = 0; c < CCSIM_MAX_RES; c++) {
+        if (pod->req[c] < 0) return fail(e, -EINVAL, "negative request");
+        if (c >= e->ncol && pod->req[c] != 0) return fail(e, -EINVAL, "request for a resource column the snapshot lacks");
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    drop_graph(e);
+    free_list(e->pod_allocs);
+    free_list(e->multi_allocs);
+    e->multi = false;
+    e->have_pod = e->begun = false;
+    e->n_taintsets = pod->n_taintsets;
+
+    const ccsim_profile &pf = e->prof;
+    DevPod p = make_devpod(e, pod);
     e->pod = p;
 
-    // tables for the static kernel
-    StaticArgs s{};
-    s.n = e->n;
-    s.n_pad = e->n_pad;
-    s.filter_mask = pf.filter_mask;
-    s.unschedulable = e->d_unsched;
-    s.taintset_id = e->cols.taintset_id;
-    s.tolerates_unschedulable = pod->tolerates_unschedulable;
-    s.affinity_filter_active = pod->affinity_filter_active;
-    s.has_node_selector = pod->has_node_selector;
-    s.has_required_terms = pod->has_required_terms;
-    s.n_required = pod->n_required;
-    s.n_preferred = p.w_aff ? pod->n_preferred : 0;
-    s.node_selector = DevTerm{pod->node_selector.first_req, pod->node_selector.n_req, 0};
-    s.label_cols = e->d_label_cols;
-    s.stat = e->d_stat;
-    s.sreason = e->d_sreason;
     int rc;
-    uint8_t *d_ok = nullptr;
-    int32_t *d_cnt = nullptr;
-    if ((rc = upload(e, &d_ok, pod->taint_filter_ok, (size_t)pod->n_taintsets, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
-    std::vector<int32_t> cnt(pod->taint_prefer_cnt, pod->taint_prefer_cnt + pod->n_taintsets);
-    if (!pf.w_taint) std::fill(cnt.begin(), cnt.end(), 0); // plugin disabled: keep the normalization constant fixed
-    if ((rc = upload(e, &d_cnt, cnt.data(), cnt.size(), cnt.size(), e->pod_allocs))) return rc;
-    s.taint_filter_ok = d_ok;
-    s.taint_prefer_cnt = d_cnt;
-    std::vector<DevTerm> rq, pr;
-    for (int t = 0; t < pod->n_required; t++) rq.push_back(DevTerm{pod->required[t].first_req, pod->required[t].n_req, 0});
-    for (int t = 0; t < pod->n_preferred; t++)
-        pr.push_back(DevTerm{pod->preferred[t].first_req, pod->preferred[t].n_req, pod->preferred[t].weight});
-    std::vector<DevReq> reqs;
-    for (int i = 0; i < pod->n_reqs; i++) {
-        if (pod->reqs[i].col < 0 || pod->reqs[i].col >= e->n_label_cols) return fail(e, -EINVAL, "requirement column out of range");
-        reqs.push_back(DevReq{pod->reqs[i].col, pod->reqs[i].table_off});
-    }
-    DevTerm *d_rq = nullptr, *d_pr = nullptr;
-    DevReq *d_reqs = nullptr;
-    uint8_t *d_tab = nullptr;
-    if ((rc = upload(e, &d_rq, rq.data(), rq.size(), rq.size(), e->pod_allocs))) return rc;
-    if ((rc = upload(e, &d_pr, pr.data(), pr.size(), pr.size(), e->pod_allocs))) return rc;
-    if ((rc = upload(e, &d_reqs, reqs.data(), reqs.size(), reqs.size(), e->pod_allocs))) return rc;
-    if ((rc = upload(e, &d_tab, pod->req_tables, (size_t)pod->req_tables_len, (size_t)pod->req_tables_len, e->pod_allocs))) return rc;
-    s.required = d_rq;
-    s.preferred = d_pr;
-    s.reqs = d_reqs;
-    s.req_tables = d_tab;
+    if ((rc = static_pass(e, pod, p.w_aff != 0, e->d_stat, e->d_sreason, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
-    const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(k_static, dim3(blocks), dim3(kThreads), 0, e->stream, s);
-    HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream)); // host vectors above go out of scope
 
     // topology spread constraints: count tables + eligibility, built once.  hard -> Filter state
     // (filtering.go:235-308), soft -> Score state (scoring.go:61-178)
@@ -1106,8 +1165,12 @@ static int run_persist(ccsim_engine *e, int k) {
     return fail(e, -EIO, "persistent level kernel did not finish");
 }
 
+static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out);
+
 extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
     if (!e || !out) return -EINVAL;
+    out->stop_spec = -1;
+    if (e->multi) return run_multi(e, max_limit, out);
     e->n_ranks = 0;
     e->d_xsend = e->d_xrecv = nullptr;
     int rc = begin_run(e, max_limit, mode, out->log ? out->log_cap : 0);
@@ -1315,6 +1378,11 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
         int rc = build_narrow(e);
         if (rc) return rc;
     }
+    if (e->multi) { // the specs' own plugin state: spread count tables, anti-affinity bitmap, the round-robin position
+        HIPCHK(e, hipMemcpyAsync(e->d_tbl_pool, e->d_tbl_pool0, e->tbl_len * 4, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_anti_bits, e->d_anti_bits0, e->anti_words * 4, hipMemcpyDeviceToDevice, e->stream));
+        e->multi_next = 0;
+    }
     e->begun = false;
     return 0;
 }
@@ -1343,4 +1411,396 @@ extern "C" int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out) {
     int rc = read_state(e);
     if (rc) return rc;
     return fill_report(e, out);
+}
+
+// ================================================================================================================
+// Several pod specs cycled round-robin (include/ccsim.h ccsim_set_pods; kernels in ccsim_multi.h)
+// ================================================================================================================
+static std::string static_class_key(const ccsim_engine *e, const ccsim_pod *pod, bool score_preferred) {
+    std::string k;
+    auto put = [&](const void *p, size_t n) { k.append((const char *)p, n); };
+    auto puti = [&](int64_t v) { put(&v, sizeof v); };
+    puti(pod->n_taintsets);
+    put(pod->taint_filter_ok, (size_t)pod->n_taintsets);
+    if (e->prof.w_taint) put(pod->taint_prefer_cnt, sizeof(int32_t) * (size_t)pod->n_taintsets);
+    puti(pod->tolerates_unschedulable), puti(pod->affinity_filter_active), puti(pod->has_node_selector), puti(pod->has_required_terms);
+    auto put_term = [&](const ccsim_term &t, bool weight) {
+        puti(t.n_req);
+        if (weight) puti(t.weight);
+        for (int i = 0; i < t.n_req; i++) {
+            const ccsim_requirement &r = pod->reqs[t.first_req + i];
+            puti(r.col);
+            // the requirement's verdict table: one byte per value id of the column
+            const int32_t mx = r.col >= 0 && r.col < (int)e->label_col_max.size() ? e->label_col_max[(size_t)r.col] : 0;
+            put(pod->req_tables + r.table_off, (size_t)mx + 1);
+        }
+    };
+    if (pod->has_node_selector) put_term(pod->node_selector, false);
+    puti(pod->n_required);
+    for (int t = 0; t < pod->n_required; t++) put_term(pod->required[t], false);
+    puti(score_preferred ? pod->n_preferred : 0);
+    if (score_preferred)
+        for (int t = 0; t < pod->n_preferred; t++) put_term(pod->preferred[t], true);
+    return k;
+}
+
+extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_pods) {
+    if (!e || !pods || n_pods < 1) return -EINVAL;
+    if (n_pods == 1) return ccsim_set_pod(e, &pods[0]);
+    if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
+    const ccsim_profile &pf = e->prof;
+    if (e->n_global != e->n || e->global_offset != 0) return fail(e, -ENOSYS, "several pod specs: one GPU only");
+    if (num_feasible_nodes_to_find(pf.percentage_of_nodes_to_score, e->n_global) < e->n_global)
+        return fail(e, -ENOSYS, "several pod specs: percentageOfNodesToScore must be 100 (every node is scored)");
+    if (!(pf.filter_mask & CCSIM_F_FIT)) return fail(e, -ENOSYS, "several pod specs need the NodeResourcesFit filter");
+    int rc;
+    for (int p = 0; p < n_pods; p++)
+        if ((rc = validate_pod(e, &pods[p]))) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    drop_graph(e);
+    free_list(e->pod_allocs);
+    free_list(e->multi_allocs);
+    e->multi = false;
+    e->have_pod = e->begun = false;
+    e->pts = DevPts{}, e->soft = DevSoft{}, e->ipa = DevIpa{};
+    e->pts_tables.clear(), e->pts_table_len.clear(), e->ipa_tables.clear(), e->ipa_table_len.clear(), e->soft_flags.clear();
+    e->dist_tables.clear(), e->pts_present.clear();
+    const size_t N = (size_t)e->n, NP = (size_t)e->n_pad;
+
+    // ---- what P > 1 supports (include/ccsim.h) -------------------------------------------------------------------
+    uint64_t mem_or = e->node_mem_or;
+    int64_t grow_c = 0, grow_m = 0;
+    int slot_col[kMTsc] = {-1, -1};
+    const bool pts_on = (pf.filter_mask & CCSIM_F_TOPOLOGYSPREAD) != 0, ipa_on = (pf.filter_mask & CCSIM_F_INTERPODAFFINITY) != 0;
+    for (int p = 0; p < n_pods; p++) {
+        const ccsim_pod &q = pods[p];
+        for (int c = 2; c < CCSIM_MAX_RES; c++)
+            if (q.req[c] != 0) return fail(e, -ENOSYS, "several pod specs: requests beyond cpu / memory (spec %d)", p);
+        if (q.has_scalar_entries) return fail(e, -ENOSYS, "several pod specs: scalar resource entries (spec %d)", p);
+        mem_or |= (uint64_t)q.req[1] | (uint64_t)q.nz_mem;
+        const int64_t gc = q.req[0] > q.nz_mcpu ? q.req[0] : q.nz_mcpu, gm = q.req[1] > q.nz_mem ? q.req[1] : q.nz_mem;
+        grow_c = gc > grow_c ? gc : grow_c, grow_m = gm > grow_m ? gm : grow_m;
+        int hard = 0;
+        for (int c = 0; c < q.n_spread; c++) {
+            const ccsim_spread_constraint &k = q.spread[c];
+            if (!k.hard) {
+                if (pf.w_topologyspread) return fail(e, -ENOSYS, "several pod specs: ScheduleAnyway spread constraints (spec %d)", p);
+                continue;
+            }
+            if (!pts_on) continue;
+            if (++hard > kMTsc) return fail(e, -ENOSYS, "several pod specs: more than %d DoNotSchedule constraints (spec %d)", kMTsc, p);
+            if (k.col < 0 || k.col >= e->n_label_cols || k.max_skew < 1 || k.min_domains < 1) return fail(e, -EINVAL, "bad spread constraint (spec %d)", p);
+            if (k.n_domains < 0 || k.n_domains > kMDomMax - 1) return fail(e, -ENOSYS, "several pod specs: spread constraints over more than %d domains (spec %d)", kMDomMax - 1, p);
+            int sl = slot_col[0] == k.col ? 0 : (slot_col[1] == k.col ? 1 : -1);
+            if (sl < 0) {
+                sl = slot_col[0] < 0 ? 0 : (slot_col[1] < 0 ? 1 : -1);
+                if (sl < 0) return fail(e, -ENOSYS, "several pod specs: spread constraints over more than two topology keys in total");
+                slot_col[sl] = k.col;
+            }
+        }
+        if (q.has_ipa && (ipa_on || pf.w_interpodaffinity)) {
+            const ccsim_ipa &a = q.ipa;
+            bool okk = a.n_keys == 1 && a.n_aff_terms == 0 && a.n_anti_terms >= 1 && !a.aff_existing && a.entries_existing == 0 &&
+                       a.score_self[0] == 0 && a.self_entries[0] == 0 && !a.score_existing[0] && !a.exist_anti[0] && a.key_col[0] >= 0 &&
+                       a.key_col[0] < e->n_label_cols;
+            for (int t = 0; okk && t < a.n_anti_terms; t++) okk = a.anti_key[t] == 0 && a.anti_self[t] != 0;
+            if (okk) { // the key must put every node into its own domain (kubernetes.io/hostname)
+                const std::vector<int32_t> &col = e->h_label_cols[(size_t)a.key_col[0]];
+                for (size_t i = 0; okk && i < N; i++) okk = col[i] == (int32_t)(i + 1);
+            }
+            if (!okk) return fail(e, -ENOSYS, "several pod specs: inter-pod affinity other than required anti-affinity of a spec to its own clones on a "
+                                              "one-node-per-domain key (spec %d)", p);
+            if (!ipa_on) return fail(e, -ENOSYS, "several pod specs: inter-pod affinity with its Filter disabled (spec %d)", p);
+        }
+    }
+    int sh = mem_or ? __builtin_ctzll(mem_or) : 0;
+    if (sh > 40) sh = 40;
+    const bool fits = e->node_max_cpu < (1ll << 30) && grow_c * (e->node_max_pods + 1) < (1ll << 30) && (e->node_max_mem >> sh) < (1ll << 30) &&
+                      ((grow_m * (e->node_max_pods + 1)) >> sh) < (1ll << 30);
+    if (!fits || N == 0) return fail(e, -ENOSYS, "several pod specs need the lossless 32-bit mirrors (cpu < 2^30 milli, memory a multiple of a common power-of-two unit)");
+    e->cols.narrow = 1, e->cols.mem_shift = sh;
+    if ((rc = build_narrow(e))) return rc;
+
+    // ---- static classes: one k_static run per distinct (tolerations, selectors, terms) ---------------------------
+    std::map<std::string, int> cls_of;
+    std::vector<int> pod_cls((size_t)n_pods), cls_rep;
+    for (int p = 0; p < n_pods; p++) {
+        const bool pref = pods[p].n_preferred > 0 && pf.w_nodeaffinity;
+        auto it = cls_of.emplace(static_class_key(e, &pods[p], pref), (int)cls_of.size());
+        if (it.second) cls_rep.push_back(p);
+        pod_cls[(size_t)p] = it.first->second;
+    }
+    e->n_cls = (int)cls_rep.size();
+    if ((rc = dev_alloc(e, &e->d_stat_cls, NP * (size_t)e->n_cls, e->multi_allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_sreason_cls, NP * (size_t)e->n_cls, e->multi_allocs))) return rc;
+    e->cls_taintsets.assign((size_t)e->n_cls, 1);
+    e->max_taintsets = 1;
+    for (int c = 0; c < e->n_cls; c++) {
+        const ccsim_pod &q = pods[cls_rep[(size_t)c]];
+        if ((rc = static_pass(e, &q, q.n_preferred > 0 && pf.w_nodeaffinity, e->d_stat_cls + NP * (size_t)c, e->d_sreason_cls + NP * (size_t)c, e->pod_allocs))) return rc;
+        free_list(e->pod_allocs); // (static_pass synchronizes: its tables are no longer needed)
+        e->cls_taintsets[(size_t)c] = q.n_taintsets;
+        e->max_taintsets = q.n_taintsets > e->max_taintsets ? q.n_taintsets : e->max_taintsets;
+    }
+    if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)e->max_taintsets, e->multi_allocs))) return rc;
+
+    // ---- per-spec plugin state: spread count tables (+ which domains hold a counted node), inclusion arrays, anti-affinity bits
+    std::vector<MPod> mp((size_t)n_pods);
+    std::vector<int32_t> tbl;
+    std::vector<uint8_t> present;
+    std::vector<const uint8_t *> inc_ptrs; // distinct inclusion arrays, by pointer (callers share one array per selector)
+    std::map<const uint8_t *, int> inc_id;
+    e->anti_words = (size_t)n_pods * (NP / 32);
+    std::vector<uint32_t> bits;
+    bool any_anti = false;
+    for (int p = 0; p < n_pods; p++) {
+        const ccsim_pod &q = pods[p];
+        MPod &m = mp[(size_t)p];
+        m = MPod{};
+        m.req0 = (int32_t)q.req[0], m.req1 = (int32_t)(q.req[1] >> sh), m.nz0 = (int32_t)q.nz_mcpu, m.nz1 = (int32_t)(q.nz_mem >> sh);
+        m.req_wide[0] = q.req[0], m.req_wide[1] = q.req[1], m.nz_wide[0] = q.nz_mcpu, m.nz_wide[1] = q.nz_mem;
+        m.cls = pod_cls[(size_t)p];
+        const DevPod dp = make_devpod(e, &q);
+        m.all_zero_req = dp.all_zero_req, m.w_bal = dp.w_bal, m.w_aff = dp.w_aff;
+        // hard constraints; a node is counted iff it carries ALL the spec's hard keys and passes the inclusion policies
+        std::vector<int> hard;
+        for (int c = 0; c < q.n_spread && pts_on; c++)
+            if (q.spread[c].hard) hard.push_back(c);
+        m.n_tsc = (int32_t)hard.size();
+        for (size_t j = 0; j < hard.size(); j++) {
+            const ccsim_spread_constraint &k = q.spread[hard[j]];
+            m.tsc_slot[j] = slot_col[0] == k.col ? 0 : 1;
+            m.tsc_max_skew[j] = k.max_skew, m.tsc_min_dom[j] = k.min_domains, m.tsc_self[j] = k.self_match ? 1 : 0, m.tsc_ndom[j] = k.n_domains;
+            m.tsc_tbl[j] = (int32_t)tbl.size();
+            m.tsc_inc[j] = -1;
+            if (k.node_included) {
+                auto it = inc_id.emplace(k.node_included, (int)inc_ptrs.size());
+                if (it.second) inc_ptrs.push_back(k.node_included);
+                m.tsc_inc[j] = it.first->second;
+            }
+            tbl.resize(tbl.size() + (size_t)k.n_domains + 1, 0);
+            present.resize(tbl.size(), 0);
+        }
+        for (size_t j = 0; j < hard.size(); j++) {
+            const ccsim_spread_constraint &k = q.spread[hard[j]];
+            const std::vector<int32_t> &col = e->h_label_cols[(size_t)k.col];
+            int32_t np_ = 0;
+            for (size_t i = 0; i < N; i++) {
+                bool all = true;
+                for (size_t j2 = 0; j2 < hard.size() && all; j2++) all = e->h_label_cols[(size_t)q.spread[hard[j2]].col][i] != 0;
+                if (!all || (k.node_included && !k.node_included[i])) continue;
+                const int32_t v = col[i];
+                if (v < 0 || v > k.n_domains) return fail(e, -EINVAL, "topology value id out of range (spec %d)", p);
+                if (!present[(size_t)m.tsc_tbl[j] + (size_t)v]) present[(size_t)m.tsc_tbl[j] + (size_t)v] = 1, np_++;
+                if (k.node_match_count) tbl[(size_t)m.tsc_tbl[j] + (size_t)v] += k.node_match_count[i];
+            }
+            m.tsc_npresent[j] = np_;
+        }
+        if (q.has_ipa && ipa_on) {
+            m.anti = 1;
+            any_anti = true;
+            if (bits.empty()) bits.assign(e->anti_words, 0u);
+            uint32_t *row = bits.data() + (size_t)p * (NP / 32);
+            const ccsim_ipa &a = q.ipa;
+            for (size_t i = 0; i < N; i++) {
+                bool hit = false;
+                for (int t = 0; t < a.n_anti_terms && !hit; t++) hit = a.anti_existing[t] && a.anti_existing[t][i] > 0;
+                if (hit) row[i >> 5] |= 1u << (i & 31);
+            }
+        }
+    }
+    if (tbl.empty()) tbl.push_back(0), present.push_back(0);
+    e->tbl_len = tbl.size();
+    if ((rc = upload(e, &e->d_tbl_pool, tbl.data(), tbl.size(), tbl.size(), e->multi_allocs))) return rc;
+    if ((rc = upload(e, &e->d_tbl_pool0, tbl.data(), tbl.size(), tbl.size(), e->multi_allocs))) return rc;
+    if ((rc = upload(e, &e->d_present_pool, present.data(), present.size(), present.size(), e->multi_allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_inc_pool, NP * (inc_ptrs.empty() ? 1 : inc_ptrs.size()), e->multi_allocs))) return rc;
+    for (size_t i = 0; i < inc_ptrs.size(); i++)
+        HIPCHK(e, hipMemcpyAsync(e->d_inc_pool + NP * i, inc_ptrs[i], N, hipMemcpyHostToDevice, e->stream));
+    if (!any_anti) e->anti_words = 1;
+    if ((rc = upload(e, &e->d_anti_bits, bits.empty() ? nullptr : bits.data(), bits.size(), e->anti_words, e->multi_allocs))) return rc;
+    if ((rc = upload(e, &e->d_anti_bits0, bits.empty() ? nullptr : bits.data(), bits.size(), e->anti_words, e->multi_allocs))) return rc;
+    if ((rc = upload(e, &e->d_mpods, mp.data(), mp.size(), mp.size(), e->multi_allocs))) return rc;
+    e->h_mpods = mp;
+    e->m_blocks = (int)((e->n_pad + kMBlockNodes - 1) / kMBlockNodes);
+    if ((rc = dev_alloc(e, &e->d_mpartials, (size_t)kMWindowMax * (size_t)e->m_blocks, e->multi_allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_mcands, (size_t)kMWindowMax, e->multi_allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_per_spec, (size_t)n_pods, e->multi_allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_mstate, (size_t)1, e->multi_allocs))) return rc;
+    if (!e->h_mstate) HIPCHK(e, hipHostMalloc((void **)&e->h_mstate, sizeof(MState), hipHostMallocDefault));
+    for (int sl = 0; sl < kMTsc; sl++) e->tsc_label[sl] = slot_col[sl] >= 0 ? e->dev_label_ptrs[(size_t)slot_col[sl]] : nullptr;
+    e->multi_prof = make_devpod(e, &pods[0]); // profile-level constants; the per-pod switches come from MPod
+    e->multi_window = kMWindowMax;
+    if (const char *f = getenv("CCSIM_MULTI_WINDOW")) e->multi_window = atoi(f) >= 1 && atoi(f) <= kMWindowMax ? atoi(f) : kMWindowMax; // tuning knob
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->n_pods = n_pods;
+    e->multi_next = 0;
+    e->multi = true;
+    e->have_pod = true;
+    return 0;
+}
+
+static MultiArgs multi_args(ccsim_engine *e) {
+    MultiArgs a{};
+    const DevCols &c = e->cols;
+    a.c = PersistCols{{c.a32[0], c.a32[1]}, {c.r32[0], c.r32[1]}, {c.z32[0], c.z32[1]}, c.alloc_pods, c.pod_count, c.placed_cnt, c.stat,
+                      {c.req[0], c.req[1]}, c.nz_mcpu, c.nz_mem, c.n_pad, c.global_offset, c.mem_shift};
+    a.prof = e->multi_prof, a.st = e->d_mstate, a.pods = e->d_mpods, a.n_pods = e->n_pods;
+    a.stat_cls = e->d_stat_cls, a.n_pad = e->n_pad;
+    a.tsc_label[0] = e->tsc_label[0], a.tsc_label[1] = e->tsc_label[1];
+    a.tbl_pool = e->d_tbl_pool, a.present_pool = e->d_present_pool, a.inc_pool = e->d_inc_pool, a.anti_bits = e->d_anti_bits;
+    a.partials = e->d_mpartials, a.n_blocks = e->m_blocks, a.cands = e->d_mcands, a.log = e->d_log, a.per_spec = e->d_per_spec;
+    a.window = e->multi_window < e->n_pods ? e->multi_window : e->n_pods;
+    return a;
+}
+
+static void launch_multi_window(ccsim_engine *e, const MultiArgs &a) {
+    const int chunks = (a.window + kMPodChunk - 1) / kMPodChunk;
+    hipLaunchKernelGGL(k_multi_scan, dim3((unsigned)e->m_blocks, (unsigned)chunks), dim3(kThreads), 0, e->stream, a);
+    hipLaunchKernelGGL(k_multi_select, dim3((unsigned)a.window), dim3(64), 0, e->stream, a);
+    hipLaunchKernelGGL(k_multi_commit, dim3(1), dim3(64), 0, e->stream, a);
+}
+
+// begin a multi-spec run (or one cycle: single_pod >= 0) on the current columns
+static int begin_multi(ccsim_engine *e, int64_t max_limit, int64_t log_cap, int32_t single_pod) {
+    HIPCHK(e, hipSetDevice(e->device));
+    if (log_cap != e->log_cap) {
+        if (e->d_log) HIPCHK(e, hipFree(e->d_log));
+        e->d_log = nullptr, e->log_cap = 0;
+        drop_graph(e);
+        if (log_cap > 0) {
+            HIPCHK(e, hipMalloc((void **)&e->d_log, sizeof(int32_t) * (size_t)log_cap));
+            e->log_cap = log_cap;
+        }
+    }
+    MState st{};
+    st.limit = max_limit, st.single_pod = single_pod, st.stop_spec = -1, st.winner = -1, st.log_cap = e->log_cap;
+    st.next_pod = single_pod >= 0 ? single_pod : e->multi_next;
+    int64_t wn = e->multi_window < e->n_pods ? e->multi_window : e->n_pods;
+    if (max_limit > 0 && max_limit < wn) wn = max_limit;
+    if (single_pod >= 0) wn = 1;
+    st.win_n = (int32_t)wn;
+    *e->h_mstate = st;
+    HIPCHK(e, hipMemcpyAsync(e->d_mstate, e->h_mstate, sizeof(MState), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_per_spec, 0, sizeof(int32_t) * (size_t)e->n_pods, e->stream));
+    e->kernel_ms = 0, e->pass_kernel_ms = 0, e->pass_launches = 0;
+    e->begun = false; // (the single-spec run state knows nothing of this run)
+    return 0;
+}
+
+static int read_mstate(ccsim_engine *e) {
+    HIPCHK(e, hipMemcpyAsync(e->h_mstate, e->d_mstate, sizeof(MState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out) {
+    int rc = begin_multi(e, max_limit, out->log ? out->log_cap : 0, -1);
+    if (rc) return rc;
+    const MultiArgs a = multi_args(e);
+    const int per_sync = e->rounds_per_sync > 0 ? e->rounds_per_sync : 16;
+    int idle = 0;
+    for (;;) {
+        const int64_t placed0 = e->h_mstate->placed;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        if (e->use_graph) {
+            if (!e->graph_exec || e->graph_mode != 100 || e->graph_rounds != per_sync) {
+                drop_graph(e);
+                HIPCHK(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+                for (int w = 0; w < per_sync; w++) launch_multi_window(e, a);
+                HIPCHK(e, hipStreamEndCapture(e->stream, &e->graph));
+                HIPCHK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+                e->graph_mode = 100, e->graph_rounds = per_sync;
+            }
+            HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
+        } else
+            for (int w = 0; w < per_sync; w++) launch_multi_window(e, a);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        if ((rc = read_mstate(e))) return rc;
+        float ms = 0;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->kernel_ms += ms;
+        if (e->h_mstate->done) break;
+        idle = e->h_mstate->placed == placed0 ? idle + 1 : 0;
+        if (idle >= 4) return fail(e, -EIO, "multi-spec simulation made no progress in %d windows", 4 * per_sync);
+    }
+    const MState &st = *e->h_mstate;
+    e->multi_next = st.next_pod;
+    out->placed = st.placed;
+    out->stop = st.done == DONE_LIMIT ? CCSIM_STOP_LIMIT : CCSIM_STOP_UNSCHEDULABLE;
+    out->stop_spec = st.stop_spec;
+    out->rounds = st.rounds;
+    out->scans = st.windows;
+    out->evaluated_total = st.rounds * e->n_global;
+    out->last_feasible = st.last_feasible;
+    out->kernel_ns = (int64_t)(e->kernel_ms * 1e6);
+    out->pass_kernel_ns = 0, out->pass_launches = st.stops; // windows that ended early (the exact validation declined to go on)
+    out->bytes_per_scan = (int64_t)(36 + 4) * e->n; // per window: the narrow columns once + one static word per (pod, node) of the window
+    memset(out->hist, 0, sizeof(out->hist));
+    out->n_code_unschedulable = 0;
+    if (out->hist_taintset)
+        for (int i = 0; i < out->hist_taintset_cap; i++) out->hist_taintset[i] = 0;
+    if (out->per_node_count) {
+        if (out->per_node_cap < e->n) return fail(e, -EINVAL, "per_node_cap too small");
+        HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (out->per_spec_count) {
+        if (out->per_spec_cap < e->n_pods) return fail(e, -EINVAL, "per_spec_cap too small");
+        HIPCHK(e, hipMemcpyAsync(out->per_spec_count, e->d_per_spec, sizeof(int32_t) * (size_t)e->n_pods, hipMemcpyDeviceToHost, e->stream));
+    }
+    out->log_len = 0;
+    if (out->log && e->d_log) {
+        int64_t len = st.placed < e->log_cap ? st.placed : e->log_cap;
+        if (len > out->log_cap) len = out->log_cap;
+        if (len > 0) HIPCHK(e, hipMemcpyAsync(out->log, e->d_log, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, e->stream));
+        out->log_len = len;
+    }
+    if (st.done == DONE_UNSCHEDULABLE && st.stop_spec >= 0) { // the failing pod's FitError (types.go:787-836)
+        HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
+        HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->max_taintsets, e->stream));
+        MultiHistArgs h{};
+        h.m = a, h.pod = st.stop_spec, h.sreason_cls = e->d_sreason_cls, h.taintset_id = e->cols.taintset_id;
+        h.alloc[0] = e->cols.alloc[0], h.alloc[1] = e->cols.alloc[1], h.n = e->n;
+        h.hist = e->d_hist, h.hist_ts = e->d_hist_ts, h.hist_code = e->d_hist_code;
+        int64_t hb = (e->n + kThreads - 1) / kThreads;
+        if (hb > 1024) hb = 1024;
+        hipLaunchKernelGGL(k_multi_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
+        HIPCHK(e, hipGetLastError());
+        std::vector<unsigned long long> hh(CCSIM_NREASON + 1), ht((size_t)e->max_taintsets);
+        HIPCHK(e, hipMemcpyAsync(hh.data(), e->d_hist, sizeof(unsigned long long) * hh.size(), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(ht.data(), e->d_hist_ts, sizeof(unsigned long long) * ht.size(), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        for (int i = 0; i < CCSIM_NREASON; i++) out->hist[i] = (int64_t)hh[i];
+        out->n_code_unschedulable = (int64_t)hh[CCSIM_NREASON];
+        const int nts = e->cls_taintsets[(size_t)e->h_mpods[(size_t)st.stop_spec].cls];
+        if (out->hist_taintset)
+            for (int i = 0; i < nts && i < out->hist_taintset_cap; i++) out->hist_taintset[i] = (int64_t)ht[i];
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int ccsim_schedule_pod(ccsim_engine *e, int32_t pod_idx, ccsim_cycle *out) {
+    if (!e || !out) return -EINVAL;
+    if (!e->multi) return pod_idx == 0 ? ccsim_schedule_one(e, out) : fail(e, -EINVAL, "one pod spec is set: pod_idx must be 0");
+    if (pod_idx < 0 || pod_idx >= e->n_pods) return fail(e, -EINVAL, "pod_idx out of range");
+    // (per-node / per-spec result counters restart: this is one cycle at the SchedulePod seam, not a run)
+    int rc = begin_multi(e, 0, 0, pod_idx);
+    if (rc) return rc;
+    const MultiArgs a = multi_args(e);
+    out->node = -1, out->evaluated_nodes = (int32_t)e->n_global, out->feasible_nodes = 0;
+    for (int tries = 0; tries < 8; tries++) {
+        launch_multi_window(e, a);
+        HIPCHK(e, hipGetLastError());
+        if ((rc = read_mstate(e))) return rc;
+        if (e->h_mstate->done) break;
+    }
+    if (!e->h_mstate->done) return fail(e, -EIO, "scheduling cycle did not converge");
+    if (e->h_mstate->done == DONE_UNSCHEDULABLE) return 0; // FitError: node stays -1
+    out->node = e->h_mstate->winner;
+    out->feasible_nodes = e->h_mstate->last_feasible;
+    return 0;
 }

@@ -242,3 +242,5 @@ class RunResult:
     pass_kernel_ns: int = 0
     pass_launches: int = 0
     bytes_per_scan: int = 0
+    per_spec_count: Optional[np.ndarray] = None  # several pod specs: placements per spec
+    stop_spec: int = -1                          # ... and the spec whose pod was Unschedulable

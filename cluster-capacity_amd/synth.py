@@ -98,6 +98,52 @@ def examples_pod(tolerate_infra: bool = False, prefer_types: bool = False) -> M.
                      taint_filter_ok=ok, taint_prefer_cnt=cnt, preferred=preferred)
 
 
+POOLS = 8  # node-pool label values (config 5's second nodeSelector key)
+
+
+def make_c5(n_nodes: int = 100_000, n_specs: int = 1024, seed: int = SEED):
+    """BASELINE config 5: nodes of the synthetic cluster + `n_specs` pod specs in genpod shape
+    (pkg/client/nspod.go:34-126: one container, request == limit): cpu in [50m, 2000m], memory in [64Mi, 8Gi], 25 % with a
+    2-key nodeSelector (instance type + node pool), every spec with a DoNotSchedule zone spread over its own label
+    (maxSkew 1-5, nodeAffinityPolicy Honor: only nodes matching the selector are counted) and required anti-affinity to
+    its own label on kubernetes.io/hostname.  Returns (nodes, [PodSpec], profile); pods are cycled round-robin."""
+    nodes = make_nodes(n_nodes, seed)
+    with np.errstate(over="ignore"):
+        i = np.arange(n_nodes, dtype=np.int64)
+        pool = (_uniform(seed, i, 11) * POOLS).astype(np.int32).clip(0, POOLS - 1) + 1
+    nodes.label_cols = list(nodes.label_cols) + [pool, (i + 1).astype(np.int32)]  # col 2 = node pool, col 3 = kubernetes.io/hostname
+    Z = zones_for(n_nodes)
+    ok = np.array([1, 0, 1, 0], np.uint8)   # no tolerations: dedicated=infra:NoSchedule rejects
+    cnt = np.array([0, 0, 1, 1], np.int32)  # maintenance=soon:PreferNoSchedule is not tolerated either
+    with np.errstate(over="ignore"):
+        p = np.arange(n_specs, dtype=np.int64)
+        u = [_uniform(seed ^ 0x5EC5, p, k) for k in range(6)]
+    included = {}
+    pods = []
+    for j in range(n_specs):
+        cpu = 50 * (1 + int(u[0][j] * 40))                      # 50m .. 2000m
+        mem = 64 * MiB * (1 + int(u[1][j] * 128))               # 64Mi .. 8Gi
+        kw = {}
+        inc = None
+        if u[2][j] < 0.25:
+            t, q = int(u[3][j] * len(INSTANCE_TYPES)) % len(INSTANCE_TYPES), int(u[4][j] * POOLS) % POOLS
+            tt = np.zeros(len(INSTANCE_TYPES) + 1, np.uint8)
+            tt[t + 1] = 1
+            tq = np.zeros(POOLS + 1, np.uint8)
+            tq[q + 1] = 1
+            kw = dict(affinity_filter_active=True, has_node_selector=True, node_selector=[(0, tt), (2, tq)])
+            if (t, q) not in included:  # one array per distinct selector (the engine dedups inclusion arrays by pointer)
+                included[(t, q)] = ((nodes.label_cols[0] == t + 1) & (pool == q + 1)).astype(np.uint8)
+            inc = included[(t, q)]
+        spread = [M.SpreadConstraint(col=1, max_skew=1 + int(u[5][j] * 5) % 5, min_domains=1, hard=True, self_match=True,
+                                     n_domains=Z, node_included=inc)]
+        ipa = M.InterPodAffinity(key_cols=[3], key_ndom=[n_nodes], anti_keys=[0], anti_self=[True], anti_existing=[None],
+                                 exist_anti=[None], score_existing=[None], score_self=[0], self_entries=[0])
+        pods.append(M.PodSpec(req=np.array([cpu, mem, 0], np.int64), nz_mcpu=cpu, nz_mem=mem, taint_filter_ok=ok,
+                              taint_prefer_cnt=cnt, spread=spread, ipa=ipa, **kw))
+    return nodes, pods, M.Profile.default()
+
+
 def make_config(name: str, n_nodes: int | None = None, seed: int = SEED, offset: int = 0, n_total: int = 0):
     """BASELINE.json configs -> (nodes, pod, profile).
     C2: NodeResourcesFit only (Filter + LeastAllocated).  C3/C4: default plugin set, pod tolerates

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCSIM_ABI_VERSION 1
+#define CCSIM_ABI_VERSION 2
 #define CCSIM_MAX_SCALAR 8
 #define CCSIM_MAX_RES (3 + CCSIM_MAX_SCALAR)
 #define CCSIM_MAX_LABEL_COLS 32
@@ -228,6 +228,10 @@ typedef struct {
     int64_t pass_kernel_ns;  /* cfg.time_passes: summed duration of the dominant kernel's launches alone ... */
     int64_t pass_launches;   /* ... and how many were launched (incl. early-exit launches after the done flag) */
     int64_t bytes_per_scan;  /* algorithmic bytes one scan reads: n_nodes * sum of enabled column widths */
+    /* several pod specs (ccsim_set_pods): */
+    int32_t *per_spec_count; /* optional caller-allocated [per_spec_cap]: placements per pod spec */
+    int32_t per_spec_cap;
+    int32_t stop_spec;       /* the spec whose pod was Unschedulable (hist describes ITS FitError), -1 otherwise */
 } ccsim_report;
 
 /* Result of one scheduling cycle.  Replaces ScheduleResult (S/scheduler.go:154-164) as returned by
@@ -252,8 +256,24 @@ int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *profile);
  * (unschedulable / taint / node-affinity) kernel once */
 int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod);
 
+/* Several pod specs against one snapshot (BASELINE.json configs[4]: "100k nodes x 1024 genpod pod specs").  The
+ * reference simulates ONE template (New(..., simulatedPod, ...) simulator.go:107); with P specs the same loop
+ * (simulator.go:297-381) takes the next pod ROUND-ROBIN: placement i is a clone of spec i mod P, every cycle is the
+ * reference's schedulePod for that pod against everything placed so far, and the run ends like the reference's -- at the
+ * first pod reported Unschedulable (ccsim_report.stop_spec) or at max_limit.  ccsim_set_pods(e, pods, 1) == ccsim_set_pod.
+ * With P > 1, ccsim_run evaluates WINDOWS of consecutive pods against the HBM-resident node columns in one pass (each
+ * node's columns are read once per window and shared by the window's pods) and commits them in order with an exact
+ * validation of every pod's choice against the placements of the pods before it (csrc/ccsim_multi.h).
+ * What P > 1 supports: the Filter/Score plugins of ccsim_set_pod except ScheduleAnyway spread constraints; at most two
+ * DoNotSchedule constraints per spec (<= 62 domains each) over at most two label columns in total; inter-pod
+ * affinity only as REQUIRED ANTI-affinity of a spec to its own clones on a one-node-per-domain key (kubernetes.io/hostname);
+ * no selector of one spec may match the clones of another (the caller's labels are disjoint).  Anything else: -ENOSYS. */
+int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_pods);
+/* Scheduler.SchedulePod + assume for one pod of spec pod_idx (the B2 seam with several templates) */
+int ccsim_schedule_pod(ccsim_engine *e, int32_t pod_idx, ccsim_cycle *out);
+
 /* ClusterCapacity.Run (simulator.go:356-381): place clones until Unschedulable or max_limit
- * (<= 0: unlimited). */
+ * (<= 0: unlimited).  After ccsim_set_pods with P > 1 the specs are cycled round-robin (`mode` is ignored). */
 int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out);
 
 /* Scheduler.SchedulePod + assume for one pod (S/schedule_one.go:430-478,967-984). */

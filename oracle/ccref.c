@@ -837,3 +837,70 @@ int ccref_run(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *po
     ws_free(&ws);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Several pod specs against one snapshot (BASELINE.json configs[4]: "100k nodes x 1024 genpod pod specs").
+ * The reference simulates ONE template (pkg/framework/simulator.go:107); this is the same loop
+ * (simulator.go:297-381: createNextPod -> schedule -> postBindHook) with the next pod taken from P
+ * specs ROUND-ROBIN: placement i is a clone of spec i mod P, every cycle is the reference's
+ * schedulePod for that pod against everything placed so far, and the run ends like the reference's:
+ * at the first pod the scheduler reports Unschedulable, or at max_limit placements.
+ *
+ * What a clone contributes to the plugin state of LATER cycles is per spec, exactly as in the
+ * single-spec loop: placed[p][n] = clones of spec p on node n feeds spec p's own selectors
+ * (self_match / anti_self / self_aff of ITS pod struct).  Callers must not hand over specs whose
+ * selectors match the clones of another spec (the harness generates disjoint labels; config 5's
+ * pods select their own label only).
+ * ------------------------------------------------------------------------------------------ */
+int ccref_run_multi(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *pods, int32_t n_pods, int64_t max_limit,
+                    int threads, ccref_multi_result *res) {
+    res->placed = 0;
+    res->rounds = 0;
+    res->stop_spec = -1;
+    memset(res->hist, 0, sizeof(res->hist));
+    res->n_code_unschedulable = 0;
+    if (n_pods <= 0) return -1;
+    if (nodes->n == 0) {
+        res->stop = CCREF_STOP_NO_NODES;
+        return 0;
+    }
+    const size_t N = (size_t)nodes->n;
+    int32_t *placed = (int32_t *)calloc(N * (size_t)n_pods, sizeof(int32_t)); /* clones of spec p on node n */
+    if (!placed) return -1;
+    if (res->per_node_count) memset(res->per_node_count, 0, sizeof(int32_t) * N);
+    if (res->per_spec_count) memset(res->per_spec_count, 0, sizeof(int32_t) * (size_t)n_pods);
+    ccref_sched_state st = {0};
+    ccref_result one;
+    int rc = 0;
+    for (;;) {
+        const int32_t p = (int32_t)(res->placed % n_pods);
+        workspace ws;
+        if (ws_init(&ws, nodes, &pods[p], placed + (size_t)p * N, threads)) {
+            rc = -1;
+            break;
+        }
+        memset(&one, 0, sizeof one);
+        one.hist_taintset = res->hist_taintset;
+        res->rounds++;
+        const int64_t w = schedule_one_ws(prof, nodes, &pods[p], &st, &one, &ws);
+        ws_free(&ws);
+        if (w < 0) {
+            res->stop = CCREF_STOP_UNSCHEDULABLE;
+            res->stop_spec = p;
+            memcpy(res->hist, one.hist, sizeof(res->hist));
+            res->n_code_unschedulable = one.n_code_unschedulable;
+            break;
+        }
+        if (res->log && res->placed < res->log_cap) res->log[res->placed] = (int32_t)w;
+        if (res->per_node_count) res->per_node_count[w] += 1;
+        if (res->per_spec_count) res->per_spec_count[p] += 1;
+        res->placed++;
+        if (max_limit > 0 && res->placed >= max_limit) {
+            res->stop = CCREF_STOP_LIMIT;
+            break;
+        }
+    }
+    free(placed);
+    return rc;
+}
+

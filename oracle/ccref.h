@@ -210,6 +210,23 @@ int64_t ccref_schedule_one(const ccref_profile *prof, ccref_nodes *nodes, const 
 int ccref_run(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *pod, int64_t max_limit, int threads,
               ccref_result *res);
 
+/* Several pod specs cycled round-robin against one snapshot (BASELINE.json configs[4]); see ccref.c. */
+typedef struct {
+    int64_t placed;
+    int32_t stop;      /* CCREF_STOP_* */
+    int32_t stop_spec; /* the spec whose pod was Unschedulable, -1 otherwise */
+    int32_t *per_node_count; /* optional caller-allocated [n]: simulated pods per node (all specs) */
+    int32_t *per_spec_count; /* optional caller-allocated [n_pods] */
+    int32_t *log;            /* optional: node index per placement (placement i is spec i mod n_pods) */
+    int64_t log_cap;
+    int64_t hist[CCREF_NREASON]; /* terminal cycle (the failing pod) */
+    int64_t *hist_taintset;      /* optional caller-allocated [n_taintsets of the failing pod] */
+    int64_t n_code_unschedulable;
+    int64_t rounds;
+} ccref_multi_result;
+int ccref_run_multi(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *pods, int32_t n_pods, int64_t max_limit,
+                    int threads, ccref_multi_result *res);
+
 /* plugin score unit functions, exported for the known-answer vectors */
 int64_t ccref_least_allocated(const int64_t *requested, const int64_t *allocatable, const int64_t *weights, int n);
 int64_t ccref_balanced_allocation(const int64_t *requested, const int64_t *allocatable, int n);

@@ -350,6 +350,51 @@ def run(profile, nodes, pod, max_limit: int = 0, threads: int = 1, want_log: boo
     )
 
 
+class _MultiResult(C.Structure):
+    _fields_ = [
+        ("placed", C.c_int64),
+        ("stop", C.c_int32),
+        ("stop_spec", C.c_int32),
+        ("per_node_count", _p32),
+        ("per_spec_count", _p32),
+        ("log", _p32),
+        ("log_cap", C.c_int64),
+        ("hist", C.c_int64 * NREASON),
+        ("hist_taintset", _p64),
+        ("n_code_unschedulable", C.c_int64),
+        ("rounds", C.c_int64),
+    ]
+
+
+def run_multi(profile, nodes, pods, max_limit: int = 0, threads: int = 1, log_cap: int | None = None):
+    """Several pod specs cycled round-robin (ccref_run_multi): placement i is a clone of spec i mod len(pods)."""
+    m = _Marshal()
+    cn, cf = m.nodes(nodes), m.profile(profile)
+    arr = (_Pod * len(pods))()
+    for i, p in enumerate(pods):
+        arr[i] = m.pod(p)
+    res = _MultiResult()
+    per_node = np.zeros(max(1, nodes.n), np.int32)
+    per_spec = np.zeros(len(pods), np.int32)
+    res.per_node_count, res.per_spec_count = _ptr(per_node, _p32), _ptr(per_spec, _p32)
+    if log_cap is None:
+        log_cap = int(max_limit) if max_limit > 0 else int(np.minimum(np.asarray(nodes.alloc_pods, dtype=np.int64).sum(), 1 << 26))
+    log = np.full(max(1, log_cap), -1, np.int32)
+    res.log, res.log_cap = _ptr(log, _p32), log.shape[0]
+    ht = np.zeros(max(1, max(len(p.taint_filter_ok) for p in pods)), np.int64)
+    res.hist_taintset = _ptr(ht, _p64)
+    fn = lib().ccref_run_multi
+    fn.restype = C.c_int
+    rc = fn(C.byref(cf), C.byref(cn), arr, len(pods), C.c_int64(int(max_limit)), int(threads), C.byref(res))
+    if rc != 0:
+        raise RuntimeError(f"ccref_run_multi failed rc={rc}")
+    placed = int(res.placed)
+    return SimpleNamespace(placed=placed, stop=int(res.stop), stop_spec=int(res.stop_spec), per_node_count=per_node[: nodes.n].copy(),
+                           per_spec_count=per_spec.copy(), log=log[: min(placed, log.shape[0])].copy(),
+                           hist=np.array(list(res.hist), dtype=np.int64), hist_taintset=ht.copy(),
+                           n_code_unschedulable=int(res.n_code_unschedulable), rounds=int(res.rounds))
+
+
 def least_allocated(requested, allocatable, weights):
     r, a, w = (np.ascontiguousarray(x, dtype=np.int64) for x in (requested, allocatable, weights))
     return int(lib().ccref_least_allocated(_ptr(r, _p64), _ptr(a, _p64), _ptr(w, _p64), len(r)))

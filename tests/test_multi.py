@@ -1,0 +1,158 @@
+"""Several pod specs cycled round-robin (BASELINE config 5): ccsim_set_pods / ccsim_run / ccsim_schedule_pod against the
+oracle's round-robin loop (oracle/ccref.c ccref_run_multi: one reference scheduling cycle per pod, in order).
+
+The engine resolves WINDOWS of consecutive pods per pass and validates every pod's choice against the placements of the
+pods before it (csrc/ccsim_multi.h); the result must not depend on the window size."""
+import numpy as np
+import pytest
+
+import helpers as H
+from cluster_capacity_amd import capi, model as M, synth
+
+
+def random_specs(rng, nodes, n_specs):
+    """Config-5-shaped specs over random_case()-style nodes (label columns: 0 = 'type' (0..4), 1 = 'zone' (0..2, 0 = key
+    absent), 2 = hostname), with per-spec variety: tolerations, selectors, preferred terms, existing matching pods."""
+    n = nodes.n
+    t_in = lambda size, ids: np.isin(np.arange(size), ids).astype(np.uint8)
+    sel_cache = {}
+    pods = []
+    for j in range(n_specs):
+        cpu, mem = int(rng.choice([50, 100, 250, 500, 900])), int(rng.choice([64, 128, 512, 1024])) * H.MiB
+        kw = {}
+        inc = None
+        if rng.random() < 0.4:
+            ids = tuple(sorted(rng.choice(5, size=int(rng.integers(1, 4)), replace=False).tolist()))
+            kw = dict(affinity_filter_active=True, has_node_selector=True, node_selector=[(0, t_in(5, list(ids)))])
+            if ids not in sel_cache:
+                sel_cache[ids] = np.isin(nodes.label_cols[0], list(ids)).astype(np.uint8)
+            inc = sel_cache[ids]
+        if rng.random() < 0.3:
+            kw["preferred"] = [(int(rng.integers(1, 50)), [(0, t_in(5, [int(rng.integers(0, 5))]))])]
+        ok = np.array([1, rng.integers(0, 2), 1, rng.integers(0, 2)], np.uint8)
+        cnt = np.array([0, 0, rng.integers(0, 3), rng.integers(0, 3)], np.int32)
+        spread = []
+        if rng.random() < 0.8:
+            spread.append(M.SpreadConstraint(col=1, max_skew=int(rng.integers(1, 4)), min_domains=int(rng.integers(1, 3)), hard=True,
+                                             self_match=bool(rng.random() < 0.9), n_domains=2, node_included=inc,
+                                             node_match_count=rng.integers(0, 2, n).astype(np.int32) if rng.random() < 0.3 else None))
+        if rng.random() < 0.2:
+            spread.append(M.SpreadConstraint(col=0, max_skew=int(rng.integers(1, 6)), min_domains=1, hard=True, self_match=True, n_domains=4,
+                                             node_included=inc))
+        ipa = None
+        if rng.random() < 0.7:
+            ex = (rng.random(n) < 0.05).astype(np.int32) if rng.random() < 0.3 else None
+            ipa = M.InterPodAffinity(key_cols=[2], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[ex], exist_anti=[None],
+                                     score_existing=[None], score_self=[0], self_entries=[0])
+        pods.append(M.PodSpec(req=np.array([cpu, mem, 0], np.int64), nz_mcpu=cpu, nz_mem=mem, taint_filter_ok=ok, taint_prefer_cnt=cnt,
+                              tolerates_unschedulable=bool(rng.random() < 0.2), spread=spread, ipa=ipa, **kw))
+    return pods
+
+
+def random_multi_case(rng, n, n_specs):
+    nodes = H.simple_nodes(rng.choice([2000, 4000, 8000, 16000], n), rng.choice([4, 8, 16, 32], n) * H.GiB, rng.integers(3, 30, n),
+                           req_mcpu=rng.integers(0, 20, n) * 50, req_mem=rng.integers(0, 8, n) * 256 * H.MiB, pod_count=rng.integers(0, 3, n),
+                           taintset_id=rng.integers(0, 4, n), unschedulable=(rng.random(n) < 0.03),
+                           label_cols=[rng.integers(0, 5, n), rng.integers(0, 3, n), np.arange(1, n + 1)])
+    return nodes, random_specs(rng, nodes, n_specs), M.Profile.default()
+
+
+def _same(got, ref):
+    assert got.placed == ref.placed and got.stop == ref.stop and got.stop_spec == ref.stop_spec
+    assert np.array_equal(got.log, ref.log)
+    assert np.array_equal(got.per_node_count, ref.per_node_count)
+    assert np.array_equal(got.per_spec_count, ref.per_spec_count)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist) and got.n_code_unschedulable == ref.n_code_unschedulable
+        assert np.array_equal(got.hist_taintset[: len(ref.hist_taintset)], ref.hist_taintset[: len(got.hist_taintset)])
+
+
+def test_oracle_round_robin_with_one_spec_is_the_single_spec_loop(ccref):
+    nodes, pod, prof = synth.make_config("C3", n_nodes=300, seed=3)
+    a, b = ccref.run(prof, nodes, pod, max_limit=0), ccref.run_multi(prof, nodes, [pod], max_limit=0)
+    assert a.placed == b.placed and np.array_equal(a.log, b.log) and np.array_equal(a.hist, b.hist) and b.stop_spec == 0
+
+
+def test_oracle_two_specs_hand_case(ccref):
+    # 2 nodes x (1000m, 1 GiB, 10 pods); spec A 300m with hostname anti-affinity to itself, spec B 200m without.
+    # A B A B ... : A takes each node once (cycles 0 and 2), its third pod (cycle 4) finds both nodes taken -> Unschedulable.
+    nodes = H.simple_nodes([1000, 1000], [H.GiB, H.GiB], [10, 10], label_cols=[np.array([1, 2], np.int32)])
+    a = H.simple_pod(300, 64 * H.MiB)
+    a.ipa = M.InterPodAffinity(key_cols=[0], key_ndom=[2], anti_keys=[0], anti_self=[True], anti_existing=[None], exist_anti=[None],
+                               score_existing=[None], score_self=[0], self_entries=[0])
+    b = H.simple_pod(200, 64 * H.MiB)
+    r = ccref.run_multi(M.Profile.default(), nodes, [a, b], max_limit=0)
+    assert r.placed == 4 and r.stop == M.STOP_UNSCHEDULABLE and r.stop_spec == 0
+    assert r.per_spec_count.tolist() == [2, 2] and sorted(r.log[[0, 2]].tolist()) == [0, 1]
+    assert r.hist[M.R_IPA_ANTI] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", ["1", "7", "64"])
+@pytest.mark.parametrize("seed", range(10))
+def test_random_specs_vs_oracle(ccref, monkeypatch, window, seed):
+    monkeypatch.setenv("CCSIM_MULTI_WINDOW", window)
+    rng = np.random.default_rng(5000 + seed)
+    nodes, pods, prof = random_multi_case(rng, int(rng.integers(20, 700)), int(rng.integers(2, 80)))
+    limit = int(rng.choice([0, 0, 0, 150]))
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=limit)
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    got = e.run(max_limit=limit, log_cap=max(1, ref.placed))
+    _same(got, ref)
+    e.reset_state()  # the specs' own state (spread tables, anti-affinity bits, round-robin position) is restored too
+    _same(e.run(max_limit=limit, log_cap=max(1, ref.placed)), ref)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_c5_shape_10k_nodes_1024_specs_vs_oracle(ccref):
+    nodes, pods, prof = synth.make_c5(10_000, 1024)
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=6000, threads=8)
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    got = e.run(max_limit=6000, log_cap=6000)
+    _same(got, ref)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_c5_shape_whole_run_small(ccref):
+    nodes, pods, prof = synth.make_c5(3000, 96)
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=0, threads=8)
+    assert ref.stop == M.STOP_UNSCHEDULABLE
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    _same(e.run(max_limit=0, log_cap=max(1, ref.placed)), ref)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_schedule_pod_cycle_by_cycle(ccref):
+    rng = np.random.default_rng(77)
+    nodes, pods, prof = random_multi_case(rng, 400, 12)
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=300)
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    for i in range(ref.placed):
+        node, evaluated, feasible = e.schedule_pod(i % len(pods))
+        assert node == ref.log[i] and evaluated == nodes.n and feasible > 0
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert e.schedule_pod(ref.stop_spec)[0] == -1
+    e.close()
+
+
+@pytest.mark.gpu
+def test_unsupported_multi_spec_shapes_are_rejected():
+    nodes, pods, prof = synth.make_c5(600, 4)
+    e = capi.Engine(device=0)
+    soft = synth.make_c5(600, 4)[1]
+    soft[1].spread = [M.SpreadConstraint(col=1, max_skew=1, hard=False, n_domains=3)]
+    with pytest.raises(capi.CcsimError, match="ScheduleAnyway"):
+        e.load(nodes, soft, prof)
+    aff = synth.make_c5(600, 4)[1]
+    aff[2].ipa = M.InterPodAffinity(key_cols=[1], key_ndom=[3], aff_keys=[0], self_aff=True, score_self=[1], self_entries=[1])
+    with pytest.raises(capi.CcsimError, match="inter-pod affinity"):
+        e.load(nodes, aff, prof)
+    e.load(nodes, pods, M.Profile.default())  # and the supported shape loads
+    e.close()
