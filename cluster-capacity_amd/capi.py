@@ -127,6 +127,7 @@ SYMBOLS = {
     "ccsim_reset_state": (C.c_int, [C.c_void_p]),
     "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ccsim_debug_persist_prof": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ccsim_debug_multi_stops": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -433,6 +434,11 @@ class Engine:
         ns, by = C.c_int64(), C.c_int64()
         self._chk(self.lib.ccsim_time_scan(self.h, MODES[mode], int(iters), C.byref(ns), C.byref(by)), "ccsim_time_scan")
         return int(ns.value), int(by.value)
+
+    def multi_stops(self):
+        out = (C.c_int64 * 8)()
+        self._chk(self.lib.ccsim_debug_multi_stops(self.h, out), "ccsim_debug_multi_stops")
+        return [int(x) for x in out]
 
     def persist_prof(self):
         """Phase breakdown of the last persistent batched launch (ccsim_debug_persist_prof), in microseconds."""

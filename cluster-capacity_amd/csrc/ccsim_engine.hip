@@ -1659,7 +1659,8 @@ static void launch_multi_window(ccsim_engine *e, const MultiArgs &a) {
     const int chunks = (a.window + kMPodChunk - 1) / kMPodChunk;
     hipLaunchKernelGGL(k_multi_scan, dim3((unsigned)e->m_blocks, (unsigned)chunks), dim3(kThreads), 0, e->stream, a);
     hipLaunchKernelGGL(k_multi_select, dim3((unsigned)a.window), dim3(64), 0, e->stream, a);
-    hipLaunchKernelGGL(k_multi_commit, dim3(1), dim3(64), 0, e->stream, a);
+    hipLaunchKernelGGL(k_multi_commit_par, dim3(1), dim3(kMParThreads), 0, e->stream, a); // one of the two commits has the window
+    hipLaunchKernelGGL(k_multi_commit, dim3(1), dim3(64), 0, e->stream, a);           // (MState::seq_windows)
 }
 
 // begin a multi-spec run (or one cycle: single_pod >= 0) on the current columns
@@ -1676,6 +1677,7 @@ static int begin_multi(ccsim_engine *e, int64_t max_limit, int64_t log_cap, int3
     }
     MState st{};
     st.limit = max_limit, st.single_pod = single_pod, st.stop_spec = -1, st.winner = -1, st.log_cap = e->log_cap;
+    if (const char *f = getenv("CCSIM_MULTI_SEQ")) st.seq_windows = atoi(f) ? 1 << 30 : 0; // tuning knob: always the in-order commit
     st.next_pod = single_pod >= 0 ? single_pod : e->multi_next;
     int64_t wn = e->multi_window < e->n_pods ? e->multi_window : e->n_pods;
     if (max_limit > 0 && max_limit < wn) wn = max_limit;
@@ -1780,6 +1782,15 @@ static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out) {
             for (int i = 0; i < nts && i < out->hist_taintset_cap; i++) out->hist_taintset[i] = (int64_t)ht[i];
     }
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// measurement aid: why the windows of the last multi-spec run ended (k_multi_commit stop reasons 0..7)
+extern "C" int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out8) {
+    if (!e || !out8 || !e->h_mstate) return -EINVAL;
+    for (int i = 0; i < 8; i++) out8[i] = e->h_mstate->stop_count[i];
+    if (getenv("CCSIM_MULTI_PROF"))
+        for (int i = 0; i < 8; i++) out8[i] = e->h_mstate->prof[i];
     return 0;
 }
 

@@ -479,8 +479,10 @@ __device__ __forceinline__ bool fits_core(const DevPod &p, int64_t a_cpu, int64_
 //   TaintToleration: DefaultNormalizeScore(100, reverse) ; NodeAffinity: DefaultNormalizeScore(100)
 __device__ __forceinline__ int64_t static_score(const DevPod &p, uint32_t c, uint32_t a, uint32_t mt, uint32_t ma) {
     int64_t t = 0;
-    if (p.w_taint) t += (int64_t)(mt == 0 ? 100u : 100u - (100u * c) / mt) * p.w_taint;
-    if (p.w_aff) t += (int64_t)(ma == 0 ? 0u : (100u * a) / ma) * p.w_aff; // w_aff is 0 when PreScore skips
+    // (c == 0 / a == 0 short-cut the runtime division -- ~30 VALU instructions -- for the common node without
+    // PreferNoSchedule taints / matching preferred terms; same values)
+    if (p.w_taint) t += (int64_t)(mt == 0 || c == 0 ? 100u : 100u - (100u * c) / mt) * p.w_taint;
+    if (p.w_aff) t += (int64_t)(ma == 0 || a == 0 ? 0u : (100u * a) / ma) * p.w_aff; // w_aff is 0 when PreScore skips
     return t;
 }
 

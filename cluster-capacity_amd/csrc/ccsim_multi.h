@@ -29,9 +29,9 @@
 namespace ccsim {
 
 constexpr int kMWindowMax = 64;   // pods per window (= lanes of the commit wave holding per-pod rows)
-constexpr int kMPodChunk = 8;     // pods per scan workgroup
-constexpr int kMNodesPerThread = 8;
-constexpr int kMBlockNodes = kThreads * kMNodesPerThread; // 2048
+constexpr int kMPodChunk = 4;     // pods per scan workgroup
+constexpr int kMNodesPerThread = 4;
+constexpr int kMBlockNodes = kThreads * kMNodesPerThread; // 1024
 constexpr int kMTopK = 8;
 constexpr int kMTouched = 64;     // touched nodes a window can hold (one per lane)
 constexpr int kMTsc = 2;          // hard spread constraints per spec
@@ -53,6 +53,8 @@ struct MPod { // one pod spec (device array of P)
 
 struct MState {
     int64_t placed, limit, rounds, windows, stops;
+    int64_t stop_count[8]; // windows ended by reason (k_multi_commit): diagnostics
+    int64_t prof[8];       // k_multi_commit: 10 ns ticks in [0] prologue, [1] touched-node evaluation, [2] candidate walk, [3] new touched node, [4] commit, [5] epilogue; [6] new touched nodes, [7] third-key loads
     int32_t done, stop_spec;
     int32_t next_pod;   // spec of the next cycle
     int32_t win_n;      // pods the pending window covers
@@ -60,15 +62,20 @@ struct MState {
     int32_t last_feasible, last_evaluated;
     int64_t winner;
     int64_t log_cap;
+    int32_t seq_windows; // > 0: the in-order commit (k_multi_commit) handles the next windows, else the assign + verify one
+    int32_t epoch, committed_epoch; // k_multi_select bumps epoch once per window; the commit kernel that takes the window records it
+    int32_t pad_;
 };
 
 struct MPartial { // per (pod of the window, scan workgroup)
-    uint64_t key1, key2; // best two nodes of the workgroup's 2048 for the pod: ((score+1) << 40) | ~index ; 0 = none
+    uint64_t key1, key2; // best two nodes of the workgroup's nodes for the pod: ((score+1) << 40) | ~index ; 0 = none
+    uint64_t key3;       // the third best: never a candidate, only the BOUND on what the workgroup hides once its two are touched
     uint32_t nfeas, mt, ma, c_mt, c_ma, pad;
 };
 
 struct MCand { // per pod of the window, after k_multi_select
     uint64_t key[kMTopK];
+    uint64_t bound; // the best key NOT in the list (0 = the list holds every feasible node's workgroup-best-two)
     int32_t n, nfeas;
     uint32_t mt, ma, c_mt, c_ma;
 };
@@ -107,6 +114,19 @@ __device__ __forceinline__ int m_pts_check(const MPod &q, int c, int32_t v, int3
     return (int64_t)match + q.tsc_self[c] - mm > (int64_t)q.tsc_max_skew[c] ? 2 : 0;
 }
 
+// A staged (LDS) table entry carries its domain's presence: absent domains (no counted node: excluded from the minimum,
+// match count 0) hold kMAbsent.  (m_tbl_min over the GLOBAL presence array is a chain of dependent loads: it ran once per
+// scan workgroup and once per commit lane and dominated both kernels.)
+constexpr int32_t kMAbsent = 0x40000000;
+__device__ __forceinline__ int32_t m_stage(int32_t count, uint8_t present) { return present ? count : kMAbsent; }
+__device__ __forceinline__ int32_t m_count(int32_t staged) { return staged & (kMAbsent - 1); }
+__device__ __forceinline__ int32_t m_staged_min(const int32_t *staged, int ndom) {
+    int32_t m = 0x7fffffff;
+    for (int v = 1; v <= ndom; v++)
+        if (staged[v] < kMAbsent) m = staged[v] < m ? staged[v] : m;
+    return m;
+}
+
 // minimum match count over the domains holding a counted node (CriticalPaths[c][0], filtering.go:298-305)
 __device__ __forceinline__ int32_t m_tbl_min(const int32_t *tbl, const uint8_t *present, int ndom) {
     int32_t m = 0x7fffffff;
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void k_multi_scan(MultiArgs a) {
 
     __shared__ int32_t s_tbl[kMPodChunk][kMTsc][kMDomMax + 1];
     __shared__ int32_t s_min[kMPodChunk][kMTsc];
-    __shared__ uint64_t s_k[2][kThreads / 64];
+    __shared__ uint64_t s_k[3][kThreads / 64];
     __shared__ uint32_t s_u[5][kThreads / 64];
     // stage the chunk's spread tables; one lane per (pod, constraint) derives the minimum over present domains
     for (int i = tid; i < kMPodChunk * kMTsc * (kMDomMax + 1); i += kThreads) {
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void k_multi_scan(MultiArgs a) {
         int32_t x = 0;
         if (jj < jn) {
             const MPod &q = a.pods[(st.next_pod + j0 + jj) % a.n_pods];
-            if (c < q.n_tsc && v <= q.tsc_ndom[c]) x = a.tbl_pool[q.tsc_tbl[c] + v];
+            if (c < q.n_tsc && v <= q.tsc_ndom[c]) x = m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]);
         }
         s_tbl[jj][c][v] = x;
     }
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void k_multi_scan(MultiArgs a) {
         int32_t m = 0x7fffffff;
         if (jj < jn) {
             const MPod &q = a.pods[(st.next_pod + j0 + jj) % a.n_pods];
-            if (c < q.n_tsc) m = m_tbl_min(&s_tbl[jj][c][0], a.present_pool + q.tsc_tbl[c], q.tsc_ndom[c]);
+            if (c < q.n_tsc) m = m_staged_min(&s_tbl[jj][c][0], q.tsc_ndom[c]);
         }
         s_min[jj][c] = m;
     }
@@ -168,51 +188,75 @@ __global__ __launch_bounds__(kThreads) void k_multi_scan(MultiArgs a) {
         lv1[k] = in && a.tsc_label[1] ? a.tsc_label[1][i] : 0;
     }
 
-#pragma unroll 1
-    for (int jj = 0; jj < jn; jj++) {
+    // the chunk's per-(pod, node) words -- static word of the pod's class, the pod's anti-affinity bits -- for ALL its pods
+    // first, every load in flight together: the evaluation loop below then never waits for memory
+    uint32_t wv[kMPodChunk][kMNodesPerThread], bv[kMPodChunk][kMNodesPerThread];
+#pragma unroll
+    for (int jj = 0; jj < kMPodChunk; jj++) {
+        const bool on = jj < jn;
+        const int pi = (st.next_pod + j0 + (on ? jj : 0)) % a.n_pods;
+        const int32_t cls = a.pods[pi].cls, anti = a.pods[pi].anti;
+        const uint32_t *stat = a.stat_cls + (int64_t)cls * a.n_pad;
+        const uint32_t *bits = a.anti_bits + (int64_t)pi * (a.n_pad / 32);
+#pragma unroll
+        for (int k = 0; k < kMNodesPerThread; k++) {
+            const int64_t i = base + k * kThreads + tid;
+            const bool in = on && i < a.c.n_pad;
+            wv[jj][k] = in ? stat[i] : 0u;
+            bv[jj][k] = in && anti ? bits[i >> 5] : 0u;
+        }
+    }
+
+#pragma unroll
+    for (int jj = 0; jj < kMPodChunk; jj++) {
+        if (jj >= jn) break;
         const int pi = (st.next_pod + j0 + jj) % a.n_pods;
         const MPod q = a.pods[pi];
         const DevPod p = m_devpod(a.prof, q);
         const NarrowPod nq{q.req0, q.req1, q.nz0, q.nz1};
         const uint32_t mt = (uint32_t)q.mt_a, ma = (uint32_t)q.ma_a;
-        const uint32_t *stat = a.stat_cls + (int64_t)q.cls * a.n_pad;
-        const uint32_t *bits = q.anti ? a.anti_bits + (int64_t)pi * (a.n_pad / 32) : nullptr;
-        uint64_t k1 = 0, k2 = 0;
+        uint64_t k1 = 0, k2 = 0, k3 = 0;
         uint32_t nf = 0, mtb = 0, mab = 0, cmt = 0, cma = 0;
 #pragma unroll
         for (int k = 0; k < kMNodesPerThread; k++) {
             const int64_t i = base + k * kThreads + tid;
-            if (i >= a.c.n_pad) continue;
-            const uint32_t w = stat[i];
+            const uint32_t w = wv[jj][k];
             bool ok = (w >> kStatOkBit) && fits_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], ap[k], np[k]);
-            if (ok && bits) ok = !((bits[i >> 5] >> (i & 31)) & 1u); // satisfyPodAntiAffinity / existing pods' anti-affinity (filtering.go:352-379)
-            for (int c = 0; c < q.n_tsc && ok; c++) {
-                const int32_t v = q.tsc_slot[c] ? lv1[k] : lv0[k];
-                ok = m_pts_check(q, c, v, s_tbl[jj][c][v < 0 || v > kMDomMax ? 0 : v], s_min[jj][c]) == 0;
-            }
+            ok = ok && !((bv[jj][k] >> (i & 31)) & 1u); // satisfyPodAntiAffinity / existing pods' anti-affinity (filtering.go:352-379)
+#pragma unroll
+            for (int c = 0; c < kMTsc; c++) // (constant indices: a runtime-indexed copy of the pod would live in scratch)
+                if (c < q.n_tsc && ok) {
+                    const int32_t v = q.tsc_slot[c] ? lv1[k] : lv0[k];
+                    ok = m_pts_check(q, c, v, m_count(s_tbl[jj][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[jj][c]) == 0;
+                }
             if (!ok) continue;
             const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
             const int64_t total = static_score(p, cnt, aff, mt, ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k]);
             const uint64_t key = make_key(total, a.c.global_offset + i);
-            if (key > k1) k2 = k1, k1 = key; else if (key > k2) k2 = key;
+            if (key > k1) k3 = k2, k2 = k1, k1 = key; else if (key > k2) k3 = k2, k2 = key; else if (key > k3) k3 = key;
             nf++;
             if (cnt > mtb) mtb = cnt, cmt = 1; else if (cnt == mtb) cmt++;
             if (aff > mab) mab = aff, cma = 1; else if (aff == mab) cma++;
         }
-        // workgroup top-2: wave maxima of k1, then of max(k2, the lanes' k1 that lost)
+        // workgroup top-3 (keys are unique: exactly one lane holds a wave maximum): best, second, third over the wave, then
+        // merged across the 4 waves by thread 0
         const uint64_t w1 = wave_max_u64(k1);
-        const uint64_t w2 = wave_max_u64(k1 == w1 ? k2 : k1); // (keys are unique: exactly one lane holds w1)
+        const bool h1 = k1 == w1 && w1 != 0;
+        const uint64_t x2 = h1 ? k2 : k1, y2 = h1 ? k3 : k2; // this lane's best two once the wave's best is removed
+        const uint64_t w2 = wave_max_u64(x2);
+        const bool h2 = x2 == w2 && w2 != 0;
+        const uint64_t w3 = wave_max_u64(h2 ? y2 : x2);
         const uint32_t wmt = wave_max_u32(mtb), wma = wave_max_u32(mab);
         const uint32_t wcmt = wave_sum_u32(mtb == wmt ? cmt : 0u), wcma = wave_sum_u32(mab == wma ? cma : 0u), wnf = wave_sum_u32(nf);
         __syncthreads(); // (s_k / s_u reuse across pods)
-        if (lane == 0) s_k[0][wave] = w1, s_k[1][wave] = w2, s_u[0][wave] = wnf, s_u[1][wave] = wmt, s_u[2][wave] = wma, s_u[3][wave] = wcmt, s_u[4][wave] = wcma;
+        if (lane == 0) s_k[0][wave] = w1, s_k[1][wave] = w2, s_k[2][wave] = w3, s_u[0][wave] = wnf, s_u[1][wave] = wmt, s_u[2][wave] = wma, s_u[3][wave] = wcmt, s_u[4][wave] = wcma;
         __syncthreads();
         if (tid == 0) {
             MPartial o{};
             for (int x = 0; x < kThreads / 64; x++) {
-                for (int h = 0; h < 2; h++) {
+                for (int h = 0; h < 3; h++) {
                     const uint64_t key = s_k[h][x];
-                    if (key > o.key1) o.key2 = o.key1, o.key1 = key; else if (key > o.key2) o.key2 = key;
+                    if (key > o.key1) o.key3 = o.key2, o.key2 = o.key1, o.key1 = key; else if (key > o.key2) o.key3 = o.key2, o.key2 = key; else if (key > o.key3) o.key3 = key;
                 }
                 o.nfeas += s_u[0][x];
                 if (s_u[1][x] > o.mt) o.mt = s_u[1][x], o.c_mt = s_u[3][x]; else if (s_u[1][x] == o.mt) o.c_mt += s_u[3][x];
@@ -235,6 +279,7 @@ __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
 #pragma unroll
     for (int k = 0; k < kMTopK; k++) best[k] = 0;
     uint32_t nf = 0, mt = 0, ma = 0, cmt = 0, cma = 0;
+    uint64_t dropped = 0; // the best key this lane saw and does not keep (it may still be the wave's (K+1)-th)
     // every lane keeps the sorted top-K of its share, then K rounds of wave max + pop
     for (int b = lane; b < a.n_blocks; b += 64) {
         const MPartial q = pp[b];
@@ -243,6 +288,7 @@ __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
 #pragma unroll
             for (int k = 0; k < kMTopK; k++)
                 if (key > best[k]) { const uint64_t t = best[k]; best[k] = key; key = t; }
+            dropped = key > dropped ? key : dropped;
         }
         nf += q.nfeas;
         if (q.mt > mt) mt = q.mt, cmt = q.c_mt; else if (q.mt == mt) cmt += q.c_mt;
@@ -263,9 +309,13 @@ __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
             best[kMTopK - 1] = 0;
         }
     }
+    // what the list does not hold: the lanes' remaining (and dropped) candidates; the workgroups' hidden nodes are bounded
+    // per workgroup (MPartial::key3) when the commit needs them
+    const uint64_t rest = wave_max_u64(best[0] > dropped ? best[0] : dropped);
     if (lane == 0) {
-        out.n = n, out.nfeas = (int32_t)wnf, out.mt = wmt, out.ma = wma, out.c_mt = wcmt, out.c_ma = wcma;
+        out.n = n, out.nfeas = (int32_t)wnf, out.mt = wmt, out.ma = wma, out.c_mt = wcmt, out.c_ma = wcma, out.bound = rest;
         a.cands[j] = out;
+        if (j == 0) a.st->epoch = st.epoch + 1; // this window's candidates exist: exactly one commit kernel may consume them
     }
 }
 
@@ -274,40 +324,58 @@ __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
     MState st = *a.st;
-    if (st.done) return;
+    if (st.done || st.seq_windows <= 0 || st.committed_epoch == st.epoch) return; // (k_multi_commit_par had this window)
+    st.seq_windows -= 1, st.committed_epoch = st.epoch;
     const int lane = threadIdx.x;
     const int W = st.win_n;
+    __shared__ MPod s_pod[kMWindowMax];
+    __shared__ MCand s_cd[kMWindowMax];
+    __shared__ int32_t s_tbl[kMWindowMax][kMTsc][kMDomMax + 1]; // the pods' spread tables (their own clones only: fixed until their turn)
+    __shared__ int32_t s_min[kMWindowMax][kMTsc];
     __shared__ uint32_t s_w[kMTouched][kMWindowMax];  // static word of touched node t for pod j
     __shared__ uint8_t s_f[kMTouched][kMWindowMax];   // bit0 anti-affinity hit, bit 1+c counted for spread constraint c
-    __shared__ int32_t s_min[kMWindowMax][kMTsc];
 
-    // lane j: pod j of the window -- the minimum of its spread tables (its own clones only: fixed during the window)
+    unsigned long long pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf7 = 0, t_prev = __builtin_amdgcn_s_memrealtime();
+#define MTICK(v) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); v += t_now - t_prev; t_prev = t_now; } while (0)
+    // everything the in-order loop needs about the window's pods -> LDS, all loads in flight together
+    if (lane < W) s_pod[lane] = a.pods[(st.next_pod + lane) % a.n_pods], s_cd[lane] = a.cands[lane];
+    __syncthreads();
+    for (int i = lane; i < W * kMTsc * (kMDomMax + 1); i += 64) {
+        const int j = i / (kMTsc * (kMDomMax + 1)), c = (i / (kMDomMax + 1)) % kMTsc, v = i % (kMDomMax + 1);
+        const MPod &q = s_pod[j];
+        s_tbl[j][c][v] = (c < q.n_tsc && v <= q.tsc_ndom[c]) ? m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]) : 0;
+    }
+    __syncthreads();
     if (lane < W) {
-        const MPod &q = a.pods[(st.next_pod + lane) % a.n_pods];
+        const MPod &q = s_pod[lane];
         for (int c = 0; c < kMTsc; c++)
-            s_min[lane][c] = c < q.n_tsc ? m_tbl_min(a.tbl_pool + q.tsc_tbl[c], a.present_pool + q.tsc_tbl[c], q.tsc_ndom[c]) : 0;
+            s_min[lane][c] = c < q.n_tsc ? m_staged_min(&s_tbl[lane][c][0], q.tsc_ndom[c]) : 0;
     }
     __syncthreads();
 
+    MTICK(pf0);
     // lane t: touched node t
     int64_t t_idx = -1; // shard-local index
     int32_t ta0 = 0, ta1 = 0, tr0 = 0, tr1 = 0, tz0 = 0, tz1 = 0, tap = 0, tnp = 0, tl0 = 0, tl1 = 0, tplaced = 0;
     int nt = 0;
     int committed = 0;
     int stop_reason = 0; // 0 window complete
+    int64_t my_node = -1; // lane j: where pod j of the window went
+    uint32_t my_f = 0;
+    int32_t my_l0 = 0, my_l1 = 0;
+    DevPod p = a.prof;   // profile constants once; the three per-pod switches are set per pod (a per-pod COPY lived in scratch)
 
 #pragma unroll 1
     for (int j = 0; j < W; j++) {
         const int pi = (st.next_pod + j) % a.n_pods;
-        const MPod q = a.pods[pi];
-        const MCand cd = a.cands[j];
+        const MPod &q = s_pod[j];
+        const MCand &cd = s_cd[j];
         // an assumed normalization maximum was wrong: the pod's scores are invalid -- fix it, end the window here
         if ((int32_t)cd.mt != q.mt_a || (int32_t)cd.ma != q.ma_a) {
-            if (lane == 0) a.pods[pi].mt_a = (int32_t)cd.mt, a.pods[pi].ma_a = (int32_t)cd.ma;
             // (the later pods of the window get their maxima fixed too, so that one window repairs a whole cycle of specs)
-            for (int jj = j + 1 + lane; jj < W; jj += 64) {
+            for (int jj = j + lane; jj < W; jj += 64) {
                 const int pj = (st.next_pod + jj) % a.n_pods;
-                a.pods[pj].mt_a = (int32_t)a.cands[jj].mt, a.pods[pj].ma_a = (int32_t)a.cands[jj].ma;
+                a.pods[pj].mt_a = (int32_t)s_cd[jj].mt, a.pods[pj].ma_a = (int32_t)s_cd[jj].ma;
             }
             stop_reason = 1;
             break;
@@ -317,12 +385,18 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
             stop_reason = 2;
             break;
         }
-        // a maximum whose feasible holders could all be among the touched nodes may have moved
-        if ((cd.mt > 0 && (int)cd.c_mt <= nt) || (cd.ma > 0 && q.w_aff && (int)cd.c_ma <= nt)) {
-            stop_reason = 3;
-            break;
+        // a normalization maximum can only move if EVERY feasible holder lost its room, and only touched nodes changed: as
+        // long as the scan counted more holders than there are touched nodes holding the maximum, an untouched one remains
+        {
+            const uint32_t w = lane < nt ? s_w[lane][j] : 0u;
+            const int th_mt = __popcll(__ballot(lane < nt && ((w >> kStatCntShift) & kStatCntMask) == cd.mt));
+            const int th_ma = __popcll(__ballot(lane < nt && (w & kStatAffMask) == cd.ma));
+            if ((cd.mt > 0 && (int)cd.c_mt <= th_mt) || (cd.ma > 0 && q.w_aff && (int)cd.c_ma <= th_ma)) {
+                stop_reason = 3;
+                break;
+            }
         }
-        const DevPod p = m_devpod(a.prof, q);
+        p.all_zero_req = q.all_zero_req, p.w_bal = q.w_bal, p.w_aff = q.w_aff;
         const NarrowPod nq{q.req0, q.req1, q.nz0, q.nz1};
         // touched nodes, re-evaluated for this pod in their current state
         uint64_t tkey = 0;
@@ -330,10 +404,12 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
             const uint32_t w = s_w[lane][j];
             const uint32_t f = s_f[lane][j];
             bool ok = (w >> kStatOkBit) && fits_narrow(p, nq, ta0, ta1, tr0, tr1, tap, tnp) && !(f & 1u);
-            for (int c = 0; c < q.n_tsc && ok; c++) {
-                const int32_t v = q.tsc_slot[c] ? tl1 : tl0;
-                ok = m_pts_check(q, c, v, v ? a.tbl_pool[q.tsc_tbl[c] + v] : 0, s_min[j][c]) == 0;
-            }
+#pragma unroll
+            for (int c = 0; c < kMTsc; c++)
+                if (c < q.n_tsc && ok) {
+                    const int32_t v = q.tsc_slot[c] ? tl1 : tl0;
+                    ok = m_pts_check(q, c, v, m_count(s_tbl[j][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[j][c]) == 0;
+                }
             if (ok) {
                 const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
                 const int64_t total = static_score(p, cnt, aff, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, ta0, ta1, tr0, tr1, tz0, tz1);
@@ -341,28 +417,47 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
             }
         }
         tkey = wave_max_u64(tkey);
-        // first untouched entry of the candidate list; two skipped entries of one scan workgroup hide that workgroup's third
-        uint64_t ukey = 0;
-        bool unknown = false;
+        MTICK(pf1);
+        // The best UNTOUCHED node: the first untouched entry of the candidate list.  What the list cannot show is BOUNDED:
+        // a scan workgroup whose best two are both touched hides nodes no better than its third key; a list that ran out
+        // hides nothing better than the best key left out of it.  The winner must beat every such bound, else the window ends.
+        uint64_t ukey = 0, bound = 0;
         {
-            int64_t skipped_blk[2] = {-1, -1};
+            int64_t sb0 = -1, sb1 = -1, sb2 = -1; // workgroups of the skipped (touched) entries, and how many each
+            int sc0 = 0, sc1 = 0, sc2 = 0;
+            bool overflow = false;
             int k = 0;
             for (; k < cd.n; k++) {
                 const int64_t li = key_index(cd.key[k]) - a.c.global_offset;
                 const bool touched = __ballot(lane < nt && t_idx == li) != 0;
-                if (!touched) { ukey = cd.key[k]; break; }
+                if (!touched) {
+                    ukey = cd.key[k];
+                    break;
+                }
                 const int64_t blk = li / kMBlockNodes;
-                if (blk == skipped_blk[0] || blk == skipped_blk[1]) { unknown = true; break; }
-                if (skipped_blk[0] < 0) skipped_blk[0] = blk; else if (skipped_blk[1] < 0) skipped_blk[1] = blk; else { unknown = true; break; }
+                int cnt2;
+                if (blk == sb0) cnt2 = ++sc0;
+                else if (blk == sb1) cnt2 = ++sc1;
+                else if (blk == sb2) cnt2 = ++sc2;
+                else if (sb0 < 0) sb0 = blk, cnt2 = sc0 = 1;
+                else if (sb1 < 0) sb1 = blk, cnt2 = sc1 = 1;
+                else if (sb2 < 0) sb2 = blk, cnt2 = sc2 = 1;
+                else { overflow = true; break; }
+                if (cnt2 == 2) { // both recorded nodes of that workgroup are touched: its hidden nodes are bounded by its third key
+                    const uint64_t k3 = a.partials[(int64_t)j * a.n_blocks + blk].key3;
+                    bound = k3 > bound ? k3 : bound;
+                    pf7++;
+                }
             }
-            // the list ran out while feasible untouched nodes may exist beyond it
-            if (!unknown && !ukey && k >= cd.n && cd.nfeas > cd.n) unknown = true;
+            if (overflow) bound = ~0ull;
+            else if (!ukey && cd.bound > bound) bound = cd.bound; // the list ran out
         }
-        if (unknown) {
+        MTICK(pf2);
+        const uint64_t win = tkey > ukey ? tkey : ukey;
+        if (bound && win < bound) { // (keys are unique: win == bound cannot happen)
             stop_reason = 4;
             break;
         }
-        const uint64_t win = tkey > ukey ? tkey : ukey;
         if (!win) { // every feasible node of the scan is touched and none of them fits any more: let the next scan say so
             stop_reason = 5;
             break;
@@ -378,16 +473,15 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
             // lane l < W gathers the node's static word / anti-affinity bit / inclusion bits for pod l of the window
             if (lane < W) {
                 const int pl = (st.next_pod + lane) % a.n_pods;
-                const MPod &ql = a.pods[pl];
+                const MPod &ql = s_pod[lane];
                 s_w[slot][lane] = a.stat_cls[(int64_t)ql.cls * a.n_pad + li];
                 uint32_t f = 0;
                 if (ql.anti) f |= (a.anti_bits[(int64_t)pl * (a.n_pad / 32) + (li >> 5)] >> (li & 31)) & 1u;
+                bool all = true; // counted iff the node has ALL the pod's hard keys and passes the inclusion policies (filtering.go:267-277)
+                for (int c2 = 0; c2 < ql.n_tsc; c2++) all = all && (ql.tsc_slot[c2] ? a.tsc_label[1][li] : a.tsc_label[0][li]) != 0;
                 for (int c = 0; c < ql.n_tsc; c++) {
-                    const int32_t v = ql.tsc_slot[c] ? a.tsc_label[1][li] : a.tsc_label[0][li];
-                    bool all = true; // counted iff the node has ALL the pod's hard keys and passes the inclusion policies (filtering.go:267-277)
-                    for (int c2 = 0; c2 < ql.n_tsc; c2++) all = all && (ql.tsc_slot[c2] ? a.tsc_label[1][li] : a.tsc_label[0][li]) != 0;
                     const bool inc = ql.tsc_inc[c] < 0 || a.inc_pool[(int64_t)ql.tsc_inc[c] * a.n_pad + li] != 0;
-                    if (v && all && inc) f |= 2u << c;
+                    if (all && inc) f |= 2u << c;
                 }
                 s_f[slot][lane] = (uint8_t)f;
             }
@@ -399,22 +493,23 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
                 tplaced = 0;
             }
             __syncthreads(); // (one wave: orders the LDS rows before the next pod reads them)
+            pf6++;
+            MTICK(pf3);
         }
-        // NodeInfo.update (types.go:409-428) on the winner's lane; the pod's own plugin state
+        // NodeInfo.update (types.go:409-428) on the winner's lane.  The pod's own plugin state (spread tables, anti-affinity
+        // bit, per-spec count) is only read again in a LATER window: lane j applies it after the loop, all pods in parallel
+        // (a read-modify-write per pod inside the loop cost a memory round trip per pod).
         if (lane == slot) {
             tr0 += q.req0, tr1 += q.req1, tz0 += q.nz0, tz1 += q.nz1, tnp += 1, tplaced += 1;
-            const uint32_t f = s_f[slot][j];
-            for (int c = 0; c < q.n_tsc; c++)
-                if (((f >> (1 + c)) & 1u) && q.tsc_self[c]) a.tbl_pool[q.tsc_tbl[c] + (q.tsc_slot[c] ? tl1 : tl0)] += 1;
-            if (q.anti) {
-                atomicOr(&a.anti_bits[(int64_t)pi * (a.n_pad / 32) + (li >> 5)], 1u << (li & 31));
-                s_f[slot][j] |= 1u;
-            }
             const int64_t at = st.placed + committed;
             if (a.log && at < st.log_cap) a.log[at] = (int32_t)g;
-            a.per_spec[pi] += 1;
+        }
+        {
+            const int32_t wl0 = __builtin_amdgcn_readlane(tl0, slot), wl1 = __builtin_amdgcn_readlane(tl1, slot);
+            if (lane == j) my_node = li, my_f = s_f[slot][j], my_l0 = wl0, my_l1 = wl1;
         }
         committed++;
+        MTICK(pf4);
         st.winner = g;
         st.last_feasible = cd.nfeas;
         if (st.limit > 0 && st.placed + committed >= st.limit) {
@@ -422,6 +517,16 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
             stop_reason = 7;
             break;
         }
+    }
+    // the committed pods' own plugin state: lane j = pod j
+    if (lane < committed && my_node >= 0) {
+        const int pi = (st.next_pod + lane) % a.n_pods;
+        const MPod &q = s_pod[lane];
+#pragma unroll
+        for (int c = 0; c < kMTsc; c++) // filtering.go:255-296 on the next cycle of this spec
+            if (c < q.n_tsc && ((my_f >> (1 + c)) & 1u) && q.tsc_self[c]) a.tbl_pool[q.tsc_tbl[c] + (q.tsc_slot[c] ? my_l1 : my_l0)] += 1;
+        if (q.anti) atomicOr(&a.anti_bits[(int64_t)pi * (a.n_pad / 32) + (my_node >> 5)], 1u << (my_node & 31));
+        a.per_spec[pi] += 1;
     }
     // touched nodes -> columns (mirrors, int64 columns, pod counts, per-node result)
     if (lane < nt && tplaced > 0) {
@@ -443,6 +548,283 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
         st.win_n = (int32_t)(wn < 0 ? 0 : wn);
         if (st.single_pod >= 0 && committed) st.done = st.done ? st.done : DONE_LIMIT; // one cycle asked for, one done
         *a.st = st;
+        a.st->stop_count[stop_reason & 7] += 1;
+        MTICK(pf5);
+        a.st->prof[0] += pf0, a.st->prof[1] += pf1, a.st->prof[2] += pf2, a.st->prof[3] += pf3, a.st->prof[4] += pf4, a.st->prof[5] += pf5, a.st->prof[6] += pf6, a.st->prof[7] += pf7; // (indexed in memory: a runtime index into the register copy would put it in scratch)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_multi_commit_par: the window's commit when pods rarely share nodes (config 5: 1024 different pods, every one of
+// them lands on a node no other pod of the window chose -- measured: 99 879 new nodes per 100 000 pods).  ASSIGN, then
+// VERIFY, then APPLY:
+//   A  (one wave, in order, ~20 instructions per pod) pod j takes the first entry of its candidate list that no earlier
+//      pod of the window took, under the same bounds as k_multi_commit (hidden third keys, exhausted list);
+//   B  (all threads, every pair t < j in parallel) the nodes taken by earlier pods are the only nodes whose state differs
+//      from what the scan saw -- each carries exactly one more pod -- so pod j's choice is right iff none of them, in
+//      that state, beats its candidate for pod j (exact filter + score of pod j on node w_t + pod_t), and its
+//      normalization maxima still have an untouched holder.  The first pod that fails ends the window: it is re-scanned
+//      against the committed state, as pod 0 of the next window (which never fails).  When windows keep ending early the
+//      in-order commit takes over for a while (st.seq_windows);
+//   C  (lane j = pod j) NodeInfo.update on the distinct winners, the pods' own spread tables / anti-affinity bits.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kMParThreads = 1024;
+__global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) {
+    __shared__ MState s_st;
+    __shared__ MPod s_pod[kMWindowMax];
+    __shared__ MCand s_cd[kMWindowMax];
+    __shared__ int32_t s_tbl[kMWindowMax][kMTsc][kMDomMax + 1];
+    __shared__ int32_t s_min[kMWindowMax][kMTsc];
+    __shared__ int64_t s_win[kMWindowMax];   // shard-local node index pod j was assigned
+    __shared__ uint64_t s_wkey[kMWindowMax]; // ... and its key
+    __shared__ int32_t s_node[kMWindowMax][10]; // the winners' columns as the scan saw them: a0 a1 r0 r1 z0 z1 alloc_pods pods l0 l1
+    __shared__ int s_wa, s_fail, s_reason, s_unsched;
+    __shared__ int s_th_mt[kMWindowMax], s_th_ma[kMWindowMax];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
+#define PT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); tp[i] += t_now - t_prev; t_prev = t_now; } while (0)
+    if (tid == 0) s_st = *a.st;
+    __syncthreads();
+    if (s_st.done || s_st.seq_windows > 0 || s_st.committed_epoch == s_st.epoch) return;
+    const int W = s_st.win_n;
+    const int32_t next_pod = s_st.next_pod;
+    if (tid < W) s_pod[tid] = a.pods[(next_pod + tid) % a.n_pods], s_cd[tid] = a.cands[tid], s_th_mt[tid] = 0, s_th_ma[tid] = 0;
+    if (tid == 0) s_wa = W, s_fail = W, s_reason = 0, s_unsched = -1;
+    __syncthreads();
+    PT(0);
+    { // the pods' spread tables: 4 threads per pod, only the entries that exist, all loads in flight together (a flat
+      // loop over 64 x 2 x 64 slots was 32 dependent memory round trips per thread: 48 us per window)
+        const int j = tid >> 2, qd = tid & 3;
+        if (j < W) {
+            const MPod &q = s_pod[j];
+#pragma unroll
+            for (int c = 0; c < kMTsc; c++) {
+                int32_t x[(kMDomMax + 1) / 4];
+#pragma unroll
+                for (int i = 0; i < (kMDomMax + 1) / 4; i++) {
+                    const int v = qd + 4 * i;
+                    x[i] = (c < q.n_tsc && v <= q.tsc_ndom[c]) ? m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]) : 0;
+                }
+#pragma unroll
+                for (int i = 0; i < (kMDomMax + 1) / 4; i++) s_tbl[j][c][qd + 4 * i] = x[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < W) {
+        const MPod &q = s_pod[tid];
+        for (int c = 0; c < kMTsc; c++)
+            s_min[tid][c] = c < q.n_tsc ? m_staged_min(&s_tbl[tid][c][0], q.tsc_ndom[c]) : 0;
+    }
+    __syncthreads();
+
+    PT(1);
+    // ---- A: assignment.  Pod j takes the first entry of its list that no EARLIER pod of the window took.  Lane j = pod j.
+    // Every lane checks its current candidate against the lower lanes' current picks (W v_readlane steps, no memory) and
+    // moves on if it is taken; repeated until nobody moves.  This reaches the in-order result: a lane only abandons a node
+    // that a LOWER lane holds, and the lowest holder of a node never moves, so a node once taken stays taken for every
+    // higher lane -- candidates only move forward, at most K steps each; one or two rounds when conflicts are rare.
+    if (wave == 0) {
+        const int j = lane;
+        const bool live = j < W;
+        int stop = 0; // why this pod cannot be assigned (0 = it can)
+        int k = 0;
+        uint64_t bound = 0;
+        int64_t sb0 = -1, sb1 = -1, sb2 = -1;
+        int sc0 = 0, sc1 = 0, sc2 = 0;
+        const MCand &cd = s_cd[live ? j : 0]; // (indexed in LDS: a register copy with a runtime index would live in scratch)
+        if (live) {
+            const MPod &q = s_pod[j];
+            if ((int32_t)cd.mt != q.mt_a || (int32_t)cd.ma != q.ma_a) stop = 1; // an assumed normalization maximum was wrong
+            else if (cd.nfeas == 0) stop = 2;                                     // Unschedulable -- if the pods before it stand
+        }
+        int64_t pick = live && !stop && cd.n > 0 ? key_index(cd.key[0]) - a.c.global_offset : -1;
+#pragma unroll 1
+        for (int round = 0; round < kMTopK * kMWindowMax + 2; round++) {
+            bool taken = false;
+#pragma unroll 1
+            for (int t = 0; t + 1 < W; t++) { // lane t's pick, broadcast: is my candidate held by a lower lane?
+                const int64_t pt = lane_bcast_i64(pick, t);
+                taken = taken || (t < j && pick >= 0 && pt == pick);
+            }
+            if (taken) { // move on: remember the scan workgroup of the entry skipped
+                const int64_t blk = pick / kMBlockNodes;
+                int cnt2 = 0;
+                if (blk == sb0) cnt2 = ++sc0;
+                else if (blk == sb1) cnt2 = ++sc1;
+                else if (blk == sb2) cnt2 = ++sc2;
+                else if (sb0 < 0) sb0 = blk, cnt2 = sc0 = 1;
+                else if (sb1 < 0) sb1 = blk, cnt2 = sc1 = 1;
+                else if (sb2 < 0) sb2 = blk, cnt2 = sc2 = 1;
+                else bound = ~0ull;
+                if (cnt2 == 2) { // both recorded nodes of that scan workgroup are taken: what it hides is bounded by its third key
+                    const uint64_t k3 = a.partials[(int64_t)j * a.n_blocks + blk].key3;
+                    bound = k3 > bound ? k3 : bound;
+                }
+                k++;
+                pick = k < cd.n ? key_index(cd.key[k < kMTopK ? k : 0]) - a.c.global_offset : -1;
+            }
+            if (!__ballot(taken)) break;
+        }
+        uint64_t ukey = 0;
+        if (live && !stop) {
+            if (k >= cd.n) { // the list ran out
+                if (cd.bound > bound) bound = cd.bound;
+                stop = 5;
+            } else {
+                ukey = cd.key[k < kMTopK ? k : 0];
+                if (bound && ukey < bound) stop = 4; // what the list hides may beat the candidate: the next scan will know
+            }
+        }
+        const uint64_t stopped = __ballot(live && stop != 0);
+        const int wa = stopped ? __ffsll((unsigned long long)stopped) - 1 : W;
+        if (lane < wa) s_win[lane] = pick, s_wkey[lane] = ukey;
+        const int reason = stopped ? __builtin_amdgcn_readlane(stop, wa < 64 ? wa : 0) : 0;
+        if (stop == 1 && live) { // repair every wrong maximum of the window at once (one window fixes a whole cycle of specs)
+            const int pj = (next_pod + j) % a.n_pods;
+            a.pods[pj].mt_a = (int32_t)cd.mt, a.pods[pj].ma_a = (int32_t)cd.ma;
+        }
+        if (lane == 0) s_wa = wa, s_reason = reason, s_unsched = reason == 2 ? wa : -1;
+    }
+    __syncthreads();
+    PT(2);
+    const int wa = s_wa;
+    // the winners' columns (as the scan saw them: nobody wrote since)
+    for (int i = tid; i < wa * 10; i += kMParThreads) {
+        const int j = i / 10, f = i % 10;
+        const int64_t n = s_win[j];
+        int32_t v;
+        switch (f) {
+        case 0: v = a.c.a32[0][n]; break;
+        case 1: v = a.c.a32[1][n]; break;
+        case 2: v = a.c.r32[0][n]; break;
+        case 3: v = a.c.r32[1][n]; break;
+        case 4: v = a.c.z32[0][n]; break;
+        case 5: v = a.c.z32[1][n]; break;
+        case 6: v = a.c.alloc_pods[n]; break;
+        case 7: v = a.c.pod_count[n]; break;
+        case 8: v = a.tsc_label[0] ? a.tsc_label[0][n] : 0; break;
+        default: v = a.tsc_label[1] ? a.tsc_label[1][n] : 0; break;
+        }
+        s_node[j][f] = v;
+    }
+    __syncthreads();
+
+    PT(3);
+    // ---- B: verification, every pair (t < j) in parallel: 16 threads per pod, each 4 earlier pods; the per-pair words are
+    // loaded first, all in flight together
+    {
+        const int j = tid >> 4, tq = tid & 15;
+        const bool pod_on = j < wa;
+        DevPod p = a.prof;
+        uint32_t wv[4], bv[4];
+        const MPod &q = s_pod[pod_on ? j : 0];
+        const MCand &cd = s_cd[pod_on ? j : 0];
+        const uint32_t *stat = a.stat_cls + (int64_t)q.cls * a.n_pad;
+        const uint32_t *bits = q.anti ? a.anti_bits + (int64_t)((next_pod + j) % a.n_pods) * (a.n_pad / 32) : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int t = tq + 16 * i;
+            const bool on = pod_on && t < j;
+            const int64_t n = on ? s_win[t] : 0;
+            wv[i] = on ? stat[n] : 0u;
+            bv[i] = on && bits ? bits[n >> 5] : 0u;
+        }
+        int th_mt = 0, th_ma = 0;
+        bool beaten = false;
+        p.all_zero_req = q.all_zero_req, p.w_bal = q.w_bal, p.w_aff = q.w_aff;
+        const NarrowPod nq{q.req0, q.req1, q.nz0, q.nz1};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int t = tq + 16 * i;
+            if (!(pod_on && t < j)) continue;
+            const int64_t n = s_win[t];
+            const uint32_t w = wv[i];
+            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+            th_mt += cnt == cd.mt, th_ma += aff == cd.ma;
+            bool ok = (w >> kStatOkBit) && !((bv[i] >> (n & 31)) & 1u);
+            if (!ok) continue;
+            const MPod &qt = s_pod[t];
+            // node w_t after pod t's placement (NodeInfo.update, types.go:409-428)
+            const int32_t a0 = s_node[t][0], a1 = s_node[t][1], r0 = s_node[t][2] + qt.req0, r1 = s_node[t][3] + qt.req1;
+            const int32_t z0 = s_node[t][4] + qt.nz0, z1 = s_node[t][5] + qt.nz1, ap = s_node[t][6], np = s_node[t][7] + 1;
+            ok = fits_narrow(p, nq, a0, a1, r0, r1, ap, np);
+#pragma unroll
+            for (int c = 0; c < kMTsc; c++)
+                if (c < q.n_tsc && ok) {
+                    const int32_t v = q.tsc_slot[c] ? s_node[t][9] : s_node[t][8];
+                    ok = m_pts_check(q, c, v, m_count(s_tbl[j][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[j][c]) == 0;
+                }
+            if (!ok) continue;
+            const int64_t total = static_score(p, cnt, aff, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1);
+            beaten = beaten || make_key(total, a.c.global_offset + n) > s_wkey[j]; // pod j prefers a node an earlier pod took
+        }
+        if (pod_on) {
+            if (th_mt) atomicAdd(&s_th_mt[j], th_mt);
+            if (th_ma) atomicAdd(&s_th_ma[j], th_ma);
+            if (beaten) atomicMin(&s_fail, j);
+        }
+    }
+    __syncthreads();
+    if (tid < wa) { // a normalization maximum may have moved if every holder the scan counted is among the taken nodes
+        const MPod &q = s_pod[tid];
+        const MCand &cd = s_cd[tid];
+        if ((cd.mt > 0 && (int)cd.c_mt <= s_th_mt[tid]) || (cd.ma > 0 && q.w_aff && (int)cd.c_ma <= s_th_ma[tid])) atomicMin(&s_fail, tid);
+    }
+    __syncthreads();
+    PT(4);
+    const int fail = s_fail;
+    const int ok_n = fail < wa ? fail : wa; // pods 0 .. ok_n-1 stand
+
+    // ---- C: apply (thread j = pod j; the winners are distinct nodes) ------------------------------------------------
+    if (tid < ok_n) {
+        const int j = tid, pi = (next_pod + j) % a.n_pods;
+        const MPod &q = s_pod[j];
+        const int64_t n = s_win[j];
+        const int sh = a.c.mem_shift;
+        const int32_t r0 = s_node[j][2] + q.req0, r1 = s_node[j][3] + q.req1, z0 = s_node[j][4] + q.nz0, z1 = s_node[j][5] + q.nz1;
+        a.c.r32[0][n] = r0, a.c.r32[1][n] = r1, a.c.z32[0][n] = z0, a.c.z32[1][n] = z1;
+        a.c.req[0][n] = (int64_t)r0, a.c.req[1][n] = (int64_t)r1 << sh;
+        a.c.nz_mcpu[n] = (int64_t)z0, a.c.nz_mem[n] = (int64_t)z1 << sh;
+        a.c.pod_count[n] = s_node[j][7] + 1;
+        a.c.placed_cnt[n] += 1;
+        bool all = true; // counted iff the node has ALL the pod's hard keys and passes the inclusion policies (filtering.go:267-277)
+#pragma unroll
+        for (int c = 0; c < kMTsc; c++)
+            if (c < q.n_tsc) all = all && (q.tsc_slot[c] ? s_node[j][9] : s_node[j][8]) != 0;
+#pragma unroll
+        for (int c = 0; c < kMTsc; c++)
+            if (c < q.n_tsc && all && q.tsc_self[c] && (q.tsc_inc[c] < 0 || a.inc_pool[(int64_t)q.tsc_inc[c] * a.n_pad + n] != 0))
+                a.tbl_pool[q.tsc_tbl[c] + (q.tsc_slot[c] ? s_node[j][9] : s_node[j][8])] += 1;
+        if (q.anti) atomicOr(&a.anti_bits[(int64_t)pi * (a.n_pad / 32) + (n >> 5)], 1u << (n & 31));
+        a.per_spec[pi] += 1;
+        const int64_t at = s_st.placed + j;
+        if (a.log && at < s_st.log_cap) a.log[at] = (int32_t)(a.c.global_offset + n);
+    }
+    if (tid == 0) {
+        MState st = s_st;
+        st.committed_epoch = st.epoch;
+        int reason = fail < wa ? 3 : s_reason; // 3: a pod preferred a taken node / a maximum may have moved
+        if (ok_n > 0) st.winner = a.c.global_offset + s_win[ok_n - 1], st.last_feasible = s_cd[ok_n - 1].nfeas;
+        st.placed += ok_n, st.rounds += ok_n;
+        if (fail >= wa && s_unsched == wa) { // the pod after the last assigned one is Unschedulable, and everything before it stands
+            st.done = DONE_UNSCHEDULABLE, st.stop_spec = (next_pod + wa) % a.n_pods, st.rounds += 1, st.last_feasible = 0, st.winner = -1;
+            reason = 2;
+        }
+        if (st.limit > 0 && st.placed >= st.limit) st.done = st.done ? st.done : DONE_LIMIT, reason = reason ? reason : 7;
+        st.windows += 1, st.stops += reason != 0 && reason != 7 && reason != 2;
+        st.next_pod = st.single_pod >= 0 ? st.next_pod : (int32_t)((st.next_pod + ok_n) % a.n_pods);
+        // windows that keep ending early because pods prefer taken nodes: the in-order commit handles that regime
+        if (reason == 3 && ok_n < 4 && W >= 16) st.seq_windows = 4;
+        int64_t wn = a.window < a.n_pods ? a.window : a.n_pods;
+        if (st.limit > 0 && st.limit - st.placed < wn) wn = st.limit - st.placed;
+        if (st.single_pod >= 0) wn = st.done || ok_n ? 0 : 1;
+        st.win_n = (int32_t)(wn < 0 ? 0 : wn);
+        if (st.single_pod >= 0 && ok_n) st.done = st.done ? st.done : DONE_LIMIT;
+        *a.st = st;
+        a.st->stop_count[reason & 7] += 1;
+        PT(5);
+        for (int i = 0; i < 6; i++) a.st->prof[i] += tp[i];
     }
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 exec < /dev/null
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_c5 -o c5 -- python /root/repo/tools/c5_shaped.py 2>&1 | grep "C5-shaped"
-f=$(find /root/repo/gpurun_out/prof_c5 -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cut -c1-150 "$f" | head -8
+cd /root/repo
+mkdir -p gpurun_out
+timeout 300 python -m pytest tests/test_multi.py -m gpu -x -q 2>&1 | tail -3
+timeout 600 python tools/bench_c5.py 100000 1024 100000 1,16,64 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bench_c5.txt
