@@ -416,19 +416,14 @@ extern "C" int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
         return fail(e, -EINVAL, "percentageOfNodesToScore out of [0,100]");
     if (p->filter_mask & CCSIM_F_TOPOLOGYSPREAD || p->w_topologyspread)
         ; // accepted: PodTopologySpread is a no-op (PreFilter/PreScore Skip) for pods without constraints
-    if (!p->w_taint && !p->w_nodeaffinity && !p->w_fit && !p->w_balanced && !p->w_topologyspread && !p->w_interpodaffinity)
-        return fail(e, -ENOSYS, "profiles without any Score plugin (numFeasibleNodesToFind = 1 with start-index rotation, "
-                                "schedule_one.go:619-621) are not supported");
     if (p->n_fit_res < 0 || p->n_fit_res > CCSIM_MAX_RES || p->n_bal_res < 0 || p->n_bal_res > CCSIM_MAX_RES)
         return fail(e, -EINVAL, "bad resource list");
     for (int i = 0; i < p->n_fit_res; i++) {
-        if (p->fit_res[i] != 0 && p->fit_res[i] != 1)
-            return fail(e, -ENOSYS, "LeastAllocated resources other than cpu/memory are not supported yet");
+        if (p->fit_res[i] < 0 || p->fit_res[i] >= CCSIM_MAX_RES) return fail(e, -EINVAL, "LeastAllocated resource column out of range");
         if (p->fit_res_w[i] < 1 || p->fit_res_w[i] > 100) return fail(e, -EINVAL, "resource weight out of [1,100]");
     }
     for (int i = 0; i < p->n_bal_res; i++)
-        if (p->bal_res[i] != 0 && p->bal_res[i] != 1)
-            return fail(e, -ENOSYS, "BalancedAllocation resources other than cpu/memory are not supported yet");
+        if (p->bal_res[i] < 0 || p->bal_res[i] >= CCSIM_MAX_RES) return fail(e, -EINVAL, "BalancedAllocation resource column out of range");
     e->prof = *p;
     e->have_profile = true;
     e->have_pod = false;
@@ -504,9 +499,22 @@ static DevPod make_devpod(const ccsim_engine *e, const ccsim_pod *pod) {
     p.ncol = e->ncol;
     p.fit_enabled = (pf.filter_mask & CCSIM_F_FIT) ? 1 : 0;
     p.all_zero_req = (pod->req[0] == 0 && pod->req[1] == 0 && pod->req[2] == 0 && !pod->has_scalar_entries) ? 1 : 0;
+    // resource lists beyond cpu / memory: the general evaluation.  A scalar column the pod does not request is bypassed
+    // (resource_allocation.go:97-99); ephemeral-storage always takes part (:105-106), so it needs a slot even without a request
+    bool list_eph = false;
+    for (int i = 0; i < pf.n_fit_res; i++) {
+        p.gen_score |= pf.fit_res[i] >= 2;
+        list_eph |= pf.fit_res[i] == 2 && pf.w_fit;
+        p.fit_col[p.n_fit] = pf.fit_res[i], p.fit_w[p.n_fit++] = pf.fit_res_w[i];
+    }
+    for (int i = 0; i < pf.n_bal_res; i++) {
+        p.gen_score |= pf.bal_res[i] >= 2;
+        list_eph |= pf.bal_res[i] == 2 && pf.w_balanced;
+        p.bal_col[p.n_bal++] = pf.bal_res[i];
+    }
     p.nx = 0;
     for (int c = 2; c < e->ncol; c++)
-        if (pod->req[c] != 0) p.xcol[p.nx++] = c;
+        if (pod->req[c] != 0 || (c == 2 && p.gen_score && list_eph)) p.xcol[p.nx++] = c;
     p.w_taint = pf.w_taint;
     p.w_aff = pod->n_preferred > 0 ? pf.w_nodeaffinity : 0; // node_affinity.go:243-246 PreScore Skip
     p.w_fit = pf.w_fit;
@@ -768,6 +776,10 @@ static int build_narrow(ccsim_engine *e) {
         else hipLaunchKernelGGL(kern, g, b, 0, stream, arg);                            \
     } while (0)
 
+static bool profile_has_scoring(const ccsim_profile &p) { // fwk.HasScorePlugins() (schedule_one.go:619-621)
+    return p.w_taint || p.w_nodeaffinity || p.w_fit || p.w_balanced || p.w_topologyspread || p.w_interpodaffinity;
+}
+
 // numFeasibleNodesToFind (schedule_one.go:697-723)
 static int64_t num_feasible_nodes_to_find(int32_t percentage, int64_t n_all) {
     if (n_all < 100) return n_all;
@@ -919,7 +931,9 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     if (e->pts.n > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "batched mode is not valid with topology spread constraints (a placement changes the feasibility of "
                                 "other nodes): use CCSIM_MODE_SEQUENTIAL");
-    const int64_t k_find = num_feasible_nodes_to_find(e->prof.percentage_of_nodes_to_score, e->n_global);
+    // a profile without any Score plugin keeps ONE feasible node per cycle (schedule_one.go:619-621: numNodesToFind = 1): the
+    // sampled search with K = 1 -- the first feasible node of the rotating visiting order wins, the search stops at the second
+    const int64_t k_find = profile_has_scoring(e->prof) ? num_feasible_nodes_to_find(e->prof.percentage_of_nodes_to_score, e->n_global) : 1;
     const int64_t smp_K = k_find < e->n_global ? k_find : 0;
     if (smp_K > 0 && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
         return fail(e, -ENOSYS, "percentageOfNodesToScore < 100 (here: the first %lld feasible nodes of %lld) makes the outcome depend on the "
@@ -1450,8 +1464,8 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
     const ccsim_profile &pf = e->prof;
     if (e->n_global != e->n || e->global_offset != 0) return fail(e, -ENOSYS, "several pod specs: one GPU only");
-    if (num_feasible_nodes_to_find(pf.percentage_of_nodes_to_score, e->n_global) < e->n_global)
-        return fail(e, -ENOSYS, "several pod specs: percentageOfNodesToScore must be 100 (every node is scored)");
+    if (num_feasible_nodes_to_find(pf.percentage_of_nodes_to_score, e->n_global) < e->n_global || !profile_has_scoring(pf))
+        return fail(e, -ENOSYS, "several pod specs: percentageOfNodesToScore must be 100 (every node is scored) and the profile needs a Score plugin");
     if (!(pf.filter_mask & CCSIM_F_FIT)) return fail(e, -ENOSYS, "several pod specs need the NodeResourcesFit filter");
     int rc;
     for (int p = 0; p < n_pods; p++)
@@ -1631,6 +1645,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     if (!e->h_mstate) HIPCHK(e, hipHostMalloc((void **)&e->h_mstate, sizeof(MState), hipHostMallocDefault));
     for (int sl = 0; sl < kMTsc; sl++) e->tsc_label[sl] = slot_col[sl] >= 0 ? e->dev_label_ptrs[(size_t)slot_col[sl]] : nullptr;
     e->multi_prof = make_devpod(e, &pods[0]); // profile-level constants; the per-pod switches come from MPod
+    if (e->multi_prof.gen_score) return fail(e, -ENOSYS, "several pod specs: scoring resource lists beyond cpu / memory");
     e->multi_window = kMWindowMax;
     if (const char *f = getenv("CCSIM_MULTI_WINDOW")) e->multi_window = atoi(f) >= 1 && atoi(f) <= kMWindowMax ? atoi(f) : kMWindowMax; // tuning knob
     HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -119,6 +119,13 @@ struct DevPod {
     int64_t fit_w_cpu, fit_w_mem;
     int32_t bal_cpu, bal_mem; // resource present in the BalancedAllocation list
     int32_t ncol;
+    // Resource lists beyond cpu / memory (ephemeral-storage, scalar resources: resource_allocation.go:97-110) take the
+    // general evaluation (dynamic_score_gen, int64 columns only).  A column >= 2 is read through the extra-column slot
+    // (xcol) that holds it; a scalar the pod does not request has no slot: bypassed, as the reference does.
+    int32_t gen_score;
+    int32_t n_fit, fit_col[kMaxRes];
+    int64_t fit_w[kMaxRes];
+    int32_t n_bal, bal_col[kMaxRes];
 };
 
 // Hard PodTopologySpread constraints (P/podtopologyspread/filtering.go:235-356): TpValueToMatchNum lives as
@@ -385,6 +392,68 @@ __device__ __forceinline__ int64_t dynamic_score(const DevPod &p, const NodeRcp 
             else score = balanced_exact(x0, a_cpu, x1, a_mem);
         }
         total += score * p.w_bal;
+    }
+    return total;
+}
+
+// The general form of both scores: any resource list (least_allocated.go:30-61, balanced_allocation.go:146-180 incl. the
+// population standard deviation of MORE than two fractions: IEEE divide / multiply / add / sqrt in the reference's order,
+// no contraction).  xa / xr: allocatable / requested of the extra-column slots p.xcol[0..nx).
+template <int NX>
+__device__ __forceinline__ bool gen_resource(const DevPod &p, int col, bool nonzero, int64_t a_cpu, int64_t a_mem, int64_t r_cpu, int64_t r_mem,
+                                             int64_t z_cpu, int64_t z_mem, const int64_t *xa, const int64_t *xr, int64_t &alloc, int64_t &req) {
+    alloc = 0, req = 0;
+    if (col == 0) alloc = a_cpu, req = nonzero ? z_cpu + p.nz_mcpu : r_cpu + p.req[0];
+    else if (col == 1) alloc = a_mem, req = nonzero ? z_mem + p.nz_mem : r_mem + p.req[1];
+    else {
+#pragma unroll
+        for (int x = 0; x < (NX > 0 ? NX : 1); x++)
+            if (NX > 0 && x < p.nx && p.xcol[x] == col) alloc = xa[x], req = xr[x] + p.req[col];
+    }
+    return alloc != 0; // resource_allocation.go:66-69: an absent resource does not take part
+}
+
+template <int NX>
+__device__ __forceinline__ int64_t dynamic_score_gen(const DevPod &p, int64_t a_cpu, int64_t a_mem, int64_t r_cpu, int64_t r_mem, int64_t z_cpu,
+                                                  int64_t z_mem, const int64_t *xa, const int64_t *xr) {
+    int64_t total = 0;
+    if (p.w_fit) {
+        int64_t node_score = 0, weight_sum = 0;
+        for (int i = 0; i < p.n_fit; i++) {
+            int64_t alloc, req;
+            if (!gen_resource<NX>(p, p.fit_col[i], true, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xa, xr, alloc, req)) continue;
+            node_score += (req > alloc ? 0 : ((alloc - req) * 100) / alloc) * p.fit_w[i];
+            weight_sum += p.fit_w[i];
+        }
+        total += (weight_sum ? node_score / weight_sum : 0) * p.w_fit;
+    }
+    if (p.w_bal) {
+        double f0 = 0, f1 = 0, sum_f = 0; // (no per-lane array of fractions: it would be a scratch frame; the > 2 branch recomputes them)
+        int m = 0;
+        for (int i = 0; i < p.n_bal; i++) {
+            int64_t alloc, req;
+            if (!gen_resource<NX>(p, p.bal_col[i], false, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xa, xr, alloc, req)) continue;
+            double f = (double)req / (double)alloc;
+            f = f > 1 ? 1 : f;
+            sum_f += f;
+            if (m == 0) f0 = f; else if (m == 1) f1 = f;
+            m++;
+        }
+        double std = 0;
+        if (m == 2) std = fabs((f0 - f1) / 2);
+        else if (m > 2) {
+            const double mean = sum_f / (double)m;
+            double sum = 0;
+            for (int i = 0; i < p.n_bal; i++) {
+                int64_t alloc, req;
+                if (!gen_resource<NX>(p, p.bal_col[i], false, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xa, xr, alloc, req)) continue;
+                double f = (double)req / (double)alloc;
+                f = f > 1 ? 1 : f;
+                sum = sum + (f - mean) * (f - mean);
+            }
+            std = sqrt(sum / (double)m);
+        }
+        total += (int64_t)((1 - std) * 100.0) * p.w_bal;
     }
     return total;
 }
@@ -668,16 +737,21 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
         const int2 AP = *reinterpret_cast<const int2 *>(a.c.alloc_pods + i0);
         const int2 NP = *reinterpret_cast<const int2 *>(a.c.pod_count + i0);
         bool xok0 = true, xok1 = true;
-        if (NX > 0 && a.p.fit_enabled && !a.p.all_zero_req) {
+        int64_t xa0[NX > 0 ? NX : 1], xr0[NX > 0 ? NX : 1], xa1[NX > 0 ? NX : 1], xr1[NX > 0 ? NX : 1]; // the pair's extra columns
+        if (NX > 0) {
 #pragma unroll
             for (int x = 0; x < NX; x++) {
+                xa0[x] = xr0[x] = xa1[x] = xr1[x] = 0;
                 if (x < a.p.nx) {
                     const int col = a.p.xcol[x];
                     const longlong2 XA = *reinterpret_cast<const longlong2 *>(a.c.alloc[col] + i0);
                     const longlong2 XR = *reinterpret_cast<const longlong2 *>(a.c.req[col] + i0);
+                    xa0[x] = XA.x, xr0[x] = XR.x, xa1[x] = XA.y, xr1[x] = XR.y;
                     const int64_t rq = a.p.req[col];
-                    if (rq > XA.x - XR.x) xok0 = false;
-                    if (rq > XA.y - XR.y) xok1 = false;
+                    if (a.p.fit_enabled && !a.p.all_zero_req && rq > 0) { // (a slot held only for scoring carries no request: fit.go:585-615 checks requested resources)
+                        if (rq > XA.x - XR.x) xok0 = false;
+                        if (rq > XA.y - XR.y) xok1 = false;
+                    }
                 }
             }
         }
@@ -751,13 +825,18 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             const int32_t na0 = k ? a0n.y : a0n.x, na1 = k ? a1n.y : a1n.x, nr0 = k ? r0n.y : r0n.x, nr1 = k ? r1n.y : r1n.x;
             const int32_t nz0 = k ? z0n.y : z0n.x, nz1 = k ? z1n.y : z1n.x;
             const bool feasible = fe[k];
+            int64_t xak[NX > 0 ? NX : 1], xrk[NX > 0 ? NX : 1]; // (element-wise select: a pointer select would put the arrays in scratch)
+#pragma unroll
+            for (int x = 0; x < (NX > 0 ? NX : 1); x++) xak[x] = k ? xa1[x] : xa0[x], xrk[x] = k ? xr1[x] : xr0[x];
             const uint64_t mask = __ballot(feasible);
             nfeas += (uint32_t)__popcll(mask); // identical in every lane of the wave
             if (feasible) {
                 const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
                 int64_t total = static_score(a.p, cnt, aff, mt, ma) +
                                 (NARROW ? dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1)
-                                        : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem));
+                                        : (NX > 0 && a.p.gen_score
+                                               ? dynamic_score_gen<NX>(a.p, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xak, xrk)
+                                               : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem)));
                 if (soft_scoring) {
                     if (a.soft.elig[i0 + k] & 1u) {
                         const int64_t raw = soft_raw_score(a.soft, a.st->soft_w, a.c.pod_count, i0 + k, epoch);

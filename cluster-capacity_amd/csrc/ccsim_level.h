@@ -69,7 +69,7 @@ __device__ __forceinline__ bool node_feasible(const DevPod &p, const NodeRegs<NX
     if (NX > 0 && p.fit_enabled && !p.all_zero_req) {
 #pragma unroll
         for (int x = 0; x < NX; x++)
-            if (x < p.nx && p.req[p.xcol[x]] > n.xa[x] - n.xr[x]) ok = false;
+            if (x < p.nx && p.req[p.xcol[x]] > 0 && p.req[p.xcol[x]] > n.xa[x] - n.xr[x]) ok = false; // (a slot held only for scoring carries no request)
     }
     return ok;
 }
@@ -91,6 +91,7 @@ __device__ __forceinline__ void node_apply(const DevPod &p, NodeRegs<NX> &n, int
 
 template <int NX>
 __device__ __forceinline__ int64_t node_score(const DevPod &p, const NodeRegs<NX> &n, int64_t stat, const NodeRcp &rc) {
+    if (NX > 0 && p.gen_score) return stat + dynamic_score_gen<NX>(p, n.a_cpu, n.a_mem, n.r_cpu, n.r_mem, n.z_cpu, n.z_mem, n.xa, n.xr);
     return stat + dynamic_score(p, rc, n.a_cpu, n.a_mem, n.r_cpu, n.r_mem, n.z_cpu, n.z_mem);
 }
 template <int NX>

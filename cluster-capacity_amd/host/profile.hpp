@@ -63,7 +63,10 @@ inline bool folded_away(const std::string &n) {
 inline int resource_column(const std::string &name) {
     if (name == "cpu") return 0;
     if (name == "memory") return 1;
-    throw std::runtime_error("scheduler config: scoring resource '" + name + "' is not supported by the engine (cpu and memory are)");
+    if (name == "ephemeral-storage") return 2;
+    // (the engine scores scalar resources too -- columns 3+ of the ABI -- but a config names them before the snapshot's
+    // scalar columns exist: not wired through this host)
+    throw std::runtime_error("scheduler config: scoring resource '" + name + "' is not supported by this host (cpu, memory and ephemeral-storage are)");
 }
 
 inline HostProfile profile_from_config(const Value &cfg) {

@@ -39,7 +39,11 @@ def _column(name: str) -> int:
         return 0
     if name == "memory":
         return 1
-    raise ConfigError(f"scheduler config: scoring resource '{name}' is not supported by the engine (cpu and memory are)")
+    if name == "ephemeral-storage":
+        return 2
+    # (the engine scores scalar resources too -- columns 3+ of the ABI -- but a config names them before the snapshot's
+    # scalar columns exist: not wired through this host)
+    raise ConfigError(f"scheduler config: scoring resource '{name}' is not supported by this host (cpu, memory and ephemeral-storage are)")
 
 
 def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:

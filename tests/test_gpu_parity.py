@@ -336,3 +336,34 @@ def test_modes_interleave_on_one_engine(ccref, monkeypatch, narrow):
     cnt = np.bincount(ref.log, minlength=nodes.n).astype(np.int64)
     assert np.array_equal(st["req_mcpu"], nodes.req[0] + cnt * int(pod.req[0]))
     assert np.array_equal(st["pod_count"], nodes.pod_count + cnt)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("fit_res,fit_w,bal_res,n_scalar", [
+    ((0, 1, 2), (1, 1, 1), (0, 1, 2), 0),        # ephemeral-storage in both lists: three fractions -> math.Sqrt branch
+    ((0, 2), (3, 2), (1, 2), 0),                 # two resources, one of them ephemeral-storage
+    ((0, 1, 3, 4), (1, 1, 2, 1), (0, 1, 3, 4), 2),  # scalar resources: requested ones take part, others are bypassed
+    ((3,), (1,), (0, 1, 2, 3), 1),               # LeastAllocated on a scalar only; four fractions
+], ids=["eph-3way", "eph-2way", "scalars", "scalar-only-fit"])
+def test_scoring_resource_lists_beyond_cpu_and_memory(ccref, mode, fit_res, fit_w, bal_res, n_scalar):
+    """resource_allocation.go:97-110: ephemeral-storage and requested scalar resources take part in LeastAllocated and in
+    BalancedAllocation (population standard deviation of > 2 fractions, balanced_allocation.go:168-174)."""
+    rng = np.random.default_rng(sum(fit_res) * 31 + n_scalar)
+    for seed in range(3):
+        n = int(rng.integers(200, 1200))
+        if n_scalar:
+            nodes, pod = _scalar_case(rng, n, n_scalar)
+            if seed == 1:
+                pod.req[3] = 0  # a scalar in the list that THIS pod does not request: bypassed
+        else:
+            base = H.simple_nodes(rng.choice([4000, 8000, 16000], n), rng.choice([8, 16, 32], n) * H.GiB, rng.integers(5, 40, n),
+                                  req_mcpu=rng.integers(0, 20, n) * 100, req_mem=rng.integers(0, 8, n) * H.GiB // 2,
+                                  alloc_eph=rng.choice([0, 20, 50, 100], n) * H.GiB)
+            base.req[2] = (rng.integers(0, 10, n) * H.GiB).astype(np.int64)
+            nodes = base
+            pod = H.simple_pod(int(rng.choice([100, 250, 500])), int(rng.choice([128, 512])) * H.MiB, eph=int(rng.choice([0, 1, 2])) * H.GiB)
+        prof = M.Profile(fit_res=fit_res, fit_res_w=fit_w, bal_res=bal_res, w_balanced=2)
+        limit = int(rng.choice([0, 150]))
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+        got = _engine(nodes, pod, prof).run(max_limit=limit, mode=mode)
+        _assert_same(got, ref, nodes, pod)

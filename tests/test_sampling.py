@@ -126,3 +126,22 @@ def test_sampled_search_is_sequential_single_gpu_only(ccref):
     e.load(nodes, pod, _with_pct(prof, 0))
     got = e.run(mode="batched")
     assert got.placed == ref.placed and np.array_equal(got.per_node_count, ref.per_node_count)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,n,limit", [("C3", 1000, 0), ("C3", 50, 0), ("C2", 3000, 700), ("C3", 4097, 2500)])
+def test_profile_without_score_plugins_keeps_the_first_feasible_node(ccref, cfg, n, limit):
+    """schedule_one.go:619-621: no Score plugin -> numNodesToFind = 1, for every snapshot size: the first feasible node of the
+    rotating visiting order is bound, the search stops at the second feasible node, nextStartNodeIndex moves past it."""
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=5 + n)
+    prof = dataclasses.replace(prof, w_taint=0, w_nodeaffinity=0, w_fit=0, w_balanced=0, w_topologyspread=0, w_interpodaffinity=0)
+    e, got, ref = _check(ccref, nodes, pod, prof, limit)
+    if limit == 0:
+        assert got.placed > n  # the rotation spreads clones round the cluster instead of filling node 0 first
+    e.close()
+    # ... and at the SchedulePod seam, cycle by cycle
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    for i in range(min(200, ref.placed)):
+        assert e.schedule_one()[0] == ref.log[i]
+    e.close()
