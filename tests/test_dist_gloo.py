@@ -28,23 +28,38 @@ eng = CpuShardEngine(nodes.slice(lo, hi), pod, prof, lo, n)
 send = torch.zeros(16, dtype=torch.int64); recv = torch.zeros(16 * world, dtype=torch.int64)
 runner = ccdist.DistRunner(eng, world, rank, send, recv, lambda r, s: dist.all_gather_into_tensor(r, s), rounds_per_poll=8,
                            buffer_arg=lambda t: t)  # the CPU stand-in takes the tensors themselves
-res = runner.run(max_limit=limit, mode="sequential", want_log=True, log_cap=limit)
+mode = os.environ.get("CC_MODE", "sequential")
+want_log = os.environ.get("CC_LOG", "1") == "1"
+res = runner.run(max_limit=limit, mode=mode, want_log=want_log, log_cap=(limit or 100000) if want_log else 0)
 counts = [None] * world
 dist.all_gather_object(counts, res.per_node_count.tolist())
 if rank == 0:
     ref = ccref_py.run(prof, nodes, pod, max_limit=limit)
-    ok = (res.placed == ref.placed and res.stop == ref.stop and sum(counts, []) == ref.per_node_count.tolist()
-          and res.log.tolist() == ref.log.tolist())
+    logs = [None] * world
+else:
+    logs = None
+if want_log:  # every rank holds the positions of ITS placements, -1 elsewhere: the element-wise maximum is the global log
+    dist.gather_object(res.log.tolist(), logs, dst=0)
+if rank == 0:
+    log_ok = True
+    if want_log:
+        merged = ccdist.merge_logs([np.array(l, np.int32) for l in logs])
+        log_ok = merged[: ref.placed].tolist() == ref.log.tolist()
+    ok = (res.placed == ref.placed and res.stop == ref.stop and sum(counts, []) == ref.per_node_count.tolist() and log_ok)
     print("RESULT", json.dumps({"ok": bool(ok), "placed": res.placed}))
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,n,limit", [(2, 240, 150), (3, 100, 40)])
-def test_sharded_runner_over_gloo(tmp_path, world, n, limit):
+@pytest.mark.parametrize("world,n,limit,mode,log", [(2, 240, 150, "sequential", 1), (3, 100, 40, "sequential", 1),
+                                                    (2, 300, 0, "batched", 0), (3, 200, 0, "batched", 1), (2, 260, 700, "batched", 0),
+                                                    (3, 150, 333, "batched", 1)])
+def test_sharded_runner_over_gloo(tmp_path, world, n, limit, mode, log):
+    """Sequential: one exchange per placement.  Batched: one exchange per score level (level / plan / cut protocol of
+    ccsim_level.h across ranks), blind and ordered commits, limits falling inside a level, the placement log merged over ranks."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, CC_ROOT=ROOT, CC_N=str(n), CC_LIMIT=str(limit), OMP_NUM_THREADS="1")
+    env = dict(os.environ, CC_ROOT=ROOT, CC_N=str(n), CC_LIMIT=str(limit), CC_MODE=mode, CC_LOG=str(log), OMP_NUM_THREADS="1")
     port = 29500 + (os.getpid() % 2000) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]

@@ -75,7 +75,38 @@ def main():
     n.label_cols.append(np.arange(1, n.n + 1, dtype=np.int32))
     p.spread = [synth.zone_spread(n.n, max_skew=2)]
     p.ipa = M.InterPodAffinity(key_cols=[2], key_ndom=[n.n], anti_keys=[0], anti_self=[True], anti_existing=[None])
-    row("C5-shaped: zone DoNotSchedule spread + hostname anti-affinity, 2048 cycles", n, p, f, 2048, 200, ["sequential"])
+    row("C5-shaped (ONE spec): zone DoNotSchedule spread + hostname anti-affinity, 2048 cycles", n, p, f, 2048, 200, ["sequential"])
+    c5(100_000, 1024, 200_000)
+
+
+def c5(n_nodes, n_specs, limit):
+    """BASELINE config 5 proper: n_specs genpod-shaped pod specs cycled round-robin (ccsim_set_pods), parity gate on the
+    oracle's first cycles, algorithmic bytes per placement = N x B_node / pods sharing a pass."""
+    nodes, pods, prof = synth.make_c5(n_nodes, n_specs)
+    threads = min(16, os.cpu_count() or 1)
+    cycles = 300
+    t0 = time.perf_counter()
+    ref = ccref_py.run_multi(prof, nodes, pods, max_limit=cycles, threads=threads)
+    t_cpu = time.perf_counter() - t0
+    eng = capi.Engine(device=0)
+    eng.load(nodes, pods, prof)
+    head = eng.run(max_limit=cycles, log_cap=cycles)
+    assert np.array_equal(head.log, ref.log) and np.array_equal(head.per_spec_count, ref.per_spec_count), "C5 parity gate"
+
+    def run():
+        eng.reset_state()
+        return eng.run(max_limit=limit, want_log=False, log_cap=0)
+
+    run()
+    dt, r = timed(run)
+    eng.close()
+    pods_per_pass = r.placed / max(1, r.scans)
+    print(f"| C5: {n_specs} genpod-shaped specs round-robin (zone DoNotSchedule spread + hostname anti-affinity to their own label), "
+          f"{limit:,} placements | {n_nodes:,} | oracle OMP x{threads} {ref.placed / t_cpu:,.0f}/s (first {cycles} cycles) | "
+          f"GPU windows of <= 64 pods: {r.placed:,} placements in {dt * 1e3:.1f} ms = {r.placed / dt:,.0f}/s ({r.scans} passes, "
+          f"{pods_per_pass:.1f} pods per pass, {r.pass_launches} passes ended early by the exact validation) | "
+          f"algorithmic bytes per placement = N x 92 B / pods per pass = {n_nodes * 92 / pods_per_pass / 1e3:,.0f} KB "
+          f"(one cycle per pass: {n_nodes * 92 / 1e6:.1f} MB) |")
 
 
 if __name__ == "__main__":
