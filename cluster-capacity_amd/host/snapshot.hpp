@@ -76,11 +76,27 @@ inline int64_t aggregate_request(const Value &spec, const std::string &name, int
     return total + res_of(spec["overhead"], name);
 }
 
+// does the pod's aggregated ResourceList hold `name` at all (some container, init container or the pod level names it)?
+inline bool named_anywhere(const Value &spec, const std::string &name) {
+    for (const char *list : {"containers", "initContainers"})
+        for (const auto &c : spec[list].items())
+            if (c["resources"]["requests"].truthy() && c["resources"]["requests"].has(name)) return true;
+    const Value &pod_level = spec["resources"]["requests"];
+    return pod_level.truthy() && pod_level.has(name) && pod_level_supported(name);
+}
+
+// types.go:700-734, 1095-1124: without pod-level requests every container lacking cpu / memory counts 100m / 200Mi; WITH
+// pod-level requests (spec.resources.requests non-empty) a default is used only for a resource nobody names
 inline PodRequests pod_requests(const Value &spec, const std::vector<std::string> &names) {
     PodRequests out;
     for (const auto &n : names) out.req.push_back(aggregate_request(spec, n));
-    out.nz_cpu = aggregate_request(spec, "cpu", kDefaultMilliCPU);
-    out.nz_mem = aggregate_request(spec, "memory", kDefaultMemory);
+    const Value &pod_level = spec["resources"]["requests"];
+    const bool pod_level_set = pod_level.truthy() && !pod_level.fields().empty();
+    auto non_zero = [&](const std::string &name, int64_t dflt) {
+        return aggregate_request(spec, name, !pod_level_set || !named_anywhere(spec, name) ? dflt : -1);
+    };
+    out.nz_cpu = non_zero("cpu", kDefaultMilliCPU);
+    out.nz_mem = non_zero("memory", kDefaultMemory);
     return out;
 }
 

@@ -108,10 +108,25 @@ def _aggregate(spec: dict, name: str, default: Optional[int] = None) -> int:
     return total + _res(spec.get("overhead"), name)
 
 
+def _named_anywhere(spec: dict, name: str) -> bool:
+    """Does the pod's aggregated ResourceList hold `name` at all (some container, init container or the pod level names it)?"""
+    for c in (spec.get("containers") or []) + (spec.get("initContainers") or []):
+        if name in ((c.get("resources") or {}).get("requests") or {}):
+            return True
+    return name in ((spec.get("resources") or {}).get("requests") or {}) and _pod_level_supported(name)
+
+
 def pod_requests(spec: dict, names: Sequence[str]):
-    """-> (requests per name, non-zero cpu, non-zero memory).  helpers.go:144-251 PodRequests + types.go:1095-1124."""
+    """-> (requests per name, non-zero cpu, non-zero memory).  helpers.go:144-251 PodRequests + types.go:700-734, 1095-1124:
+    without pod-level requests every container lacking cpu / memory counts 100m / 200Mi; WITH pod-level requests
+    (spec.resources.requests non-empty) a default is used only for a resource that neither a container nor the pod level names."""
     out = {n: _aggregate(spec, n) for n in names}
-    return out, _aggregate(spec, "cpu", DEFAULT_MILLI_CPU), _aggregate(spec, "memory", DEFAULT_MEMORY)
+    pod_level_set = bool((spec.get("resources") or {}).get("requests"))
+
+    def non_zero(name, dflt):
+        return _aggregate(spec, name, dflt if not pod_level_set or not _named_anywhere(spec, name) else None)
+
+    return out, non_zero("cpu", DEFAULT_MILLI_CPU), non_zero("memory", DEFAULT_MEMORY)
 
 
 def zone_key(labels: dict) -> str:

@@ -149,3 +149,19 @@ def test_replicas_on_nodes_with_a_capped_log():
     got = R.replicas_on_nodes(per_node, ["a", "b", "c", "d"], np.array([1, 1], np.int32))  # log cut after two placements
     assert [g["nodeName"] for g in got] == ["b", "a", "d"]
     assert sum(g["replicas"] for g in got) == int(per_node.sum())
+
+
+def test_non_zero_requests_with_pod_level_resources():
+    # types.go:1095-1124: pod-level memory is set, so the 100m / 200Mi defaults apply only to a resource that NOBODY names.
+    # containers [cpu 500m, -]: cpu is named by a container -> no per-container default: Non0CPU = 500m (not 600m);
+    # memory comes from the pod level: 1Gi
+    spec = {"resources": {"requests": {"memory": "1Gi"}},
+            "containers": [{"resources": {"requests": {"cpu": "500m"}}}, {"resources": {}}]}
+    req, nz_cpu, nz_mem = ingest.pod_requests(spec, ["cpu", "memory"])
+    assert (req["cpu"], req["memory"], nz_cpu, nz_mem) == (500, 1 << 30, 500, 1 << 30)
+    # nobody names cpu: the default stands in for every container
+    spec = {"resources": {"requests": {"memory": "1Gi"}}, "containers": [{"resources": {}}, {"resources": {}}]}
+    assert ingest.pod_requests(spec, ["cpu", "memory"])[1:] == (200, 1 << 30)
+    # no pod-level requests: per-container defaults as ever
+    spec = {"containers": [{"resources": {"requests": {"cpu": "500m"}}}, {"resources": {}}]}
+    assert ingest.pod_requests(spec, ["cpu", "memory"])[1:] == (600, 2 * 200 * 1024 * 1024)

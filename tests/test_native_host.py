@@ -532,7 +532,7 @@ def test_native_host_marshals_the_c_abi_like_the_python_binding(native, recorder
     os.environ["CCSIM_RECORD"] = str(tmp_path / "python.json")
     try:
         cfg = capi.CConfig()
-        cfg.abi_version, cfg.use_graph = 1, 1
+        cfg.abi_version, cfg.use_graph = capi.ABI_VERSION, 1
         h = C.c_void_p()
         assert lib.ccsim_create(C.byref(cfg), C.byref(h)) == 0
         keep = []
