@@ -180,11 +180,19 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         with open(args.default_config) as f:
             cfg = yaml.safe_load(f)
     prof, hard_weight = schedconfig.profile_from_config(cfg)
-    pct = args.percentage_of_nodes_to_score if args.percentage_of_nodes_to_score is not None else prof.percentage_of_nodes_to_score
     pod = parse_pod_spec(args.podspec)
     node_objs, pod_objs, ns_objs = load_all(args.snapshot)
     snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
                                  namespace_objs=ns_objs)
+    if args.percentage_of_nodes_to_score is not None:
+        pct = args.percentage_of_nodes_to_score
+    elif schedconfig.sets_percentage(cfg):
+        pct = prof.percentage_of_nodes_to_score
+    else:
+        # left unset: the reference's default is 0 = adaptive sampling (defaults.go:106-129).  The final capacity and distribution
+        # do not depend on it when nothing observes the ORDER of the placements (no --max-limit, no topology-coupled plugin): then
+        # every node is scored (the fast batched mode); otherwise the reference's default applies
+        pct = 0 if (args.max_limit > 0 or snap.pod.spread or snap.pod.ipa is not None) else 100
     result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=pct, profile=prof)
     review = build_review(pod, snap, result, args.max_limit)
     if args.output == "json":

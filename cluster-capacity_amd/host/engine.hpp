@@ -152,8 +152,14 @@ inline void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
 inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::string &mode_flag, const HostProfile &prof, int device) {
     const Api api = load_api();
     Marshalled m;
-    marshal(s, prof, m);
-    const int percentage = prof.c.percentage_of_nodes_to_score;
+    // percentageOfNodesToScore left unset: the reference's default is 0 = adaptive sampling (defaults.go:106-129).  The final
+    // capacity and distribution do not depend on it when nothing observes the ORDER of the placements (no --max-limit, no
+    // topology-coupled plugin): then every node is scored (the fast batched mode).  Otherwise the reference's default applies,
+    // so that the result is a legal outcome of the reference's default configuration.
+    HostProfile prof_eff = prof;
+    if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = (max_limit > 0 || !s.spread.empty() || s.has_ipa) ? 0 : 100;
+    const int percentage = prof_eff.c.percentage_of_nodes_to_score;
+    marshal(s, prof_eff, m);
     ccsim_config cfg{};
     cfg.abi_version = CCSIM_ABI_VERSION, cfg.device = device, cfg.use_graph = 1;
     ccsim_engine *e = nullptr;

@@ -148,7 +148,7 @@ int main(int argc, char **argv) {
     try { // --default-config: Path to JSON or YAML file containing scheduler configuration (options.go:73)
         if (dump_profile) {
             HostProfile hp = profile_from_config(sched_config.empty() ? Value() : parse_documents(read_file(sched_config)).at(0));
-            if (pct_flag) hp.c.percentage_of_nodes_to_score = percentage;
+            if (pct_flag) hp.c.percentage_of_nodes_to_score = percentage, hp.percentage_set = true;
             std::string out;
             to_json(out, profile_json(hp));
             std::cout << out << "\n";
@@ -163,7 +163,7 @@ int main(int argc, char **argv) {
     if (!output.empty() && output != "json" && output != "yaml") return usage("output format must be json or yaml");
     try {
         HostProfile prof = profile_from_config(sched_config.empty() ? Value() : parse_documents(read_file(sched_config)).at(0));
-        if (pct_flag) prof.c.percentage_of_nodes_to_score = percentage;
+        if (pct_flag) prof.c.percentage_of_nodes_to_score = percentage, prof.percentage_set = true;
         // runSimulator (cmd/cluster-capacity/app/server.go:163-183): New -> SyncWithClient -> Run -> Report
         ClusterCapacity cc = ClusterCapacity::New(prof, parse_pod_spec(podspec), max_limit, exclude);
         cc.device = device, cc.mode = mode;

@@ -18,6 +18,7 @@ namespace cchost {
 struct HostProfile {
     ccsim_profile c{};
     int hard_pod_affinity_weight = 1; // InterPodAffinityArgs (defaults.go:229-231), used by the ingest
+    bool percentage_set = false;      // percentageOfNodesToScore came from the config file / the command line (else: see simulate())
 };
 
 inline HostProfile default_profile() {
@@ -73,11 +74,13 @@ inline HostProfile profile_from_config(const Value &cfg) {
     HostProfile p = default_profile();
     if (cfg.is_null()) return p;
     if (cfg["kind"].truthy() && cfg["kind"].text() != "KubeSchedulerConfiguration") throw std::runtime_error("scheduler config: kind is not KubeSchedulerConfiguration");
-    if (cfg.has("percentageOfNodesToScore") && !cfg["percentageOfNodesToScore"].is_null()) p.c.percentage_of_nodes_to_score = (int32_t)cfg["percentageOfNodesToScore"].as_int();
+    if (cfg.has("percentageOfNodesToScore") && !cfg["percentageOfNodesToScore"].is_null())
+        p.c.percentage_of_nodes_to_score = (int32_t)cfg["percentageOfNodesToScore"].as_int(), p.percentage_set = true;
     const Value &profiles = cfg["profiles"];
     if (profiles.items().size() > 1) throw std::runtime_error("scheduler config: one profile only (the simulated pod is scheduled by Profiles[0], pkg/utils/utils.go:103-108)");
     const Value &prof = profiles.items().empty() ? Value::null_value() : profiles.items()[0];
-    if (prof.has("percentageOfNodesToScore") && !prof["percentageOfNodesToScore"].is_null()) p.c.percentage_of_nodes_to_score = (int32_t)prof["percentageOfNodesToScore"].as_int();
+    if (prof.has("percentageOfNodesToScore") && !prof["percentageOfNodesToScore"].is_null())
+        p.c.percentage_of_nodes_to_score = (int32_t)prof["percentageOfNodesToScore"].as_int(), p.percentage_set = true;
 
     auto lookup = [&](const std::string &name) -> const PluginInfo * {
         auto it = plugin_table().find(name);

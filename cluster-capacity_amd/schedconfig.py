@@ -46,6 +46,14 @@ def _column(name: str) -> int:
     raise ConfigError(f"scheduler config: scoring resource '{name}' is not supported by this host (cpu, memory and ephemeral-storage are)")
 
 
+def sets_percentage(cfg: Optional[dict]) -> bool:
+    """Does the configuration file name percentageOfNodesToScore (globally or in Profiles[0])?"""
+    if not cfg:
+        return False
+    profs = cfg.get("profiles") or [{}]
+    return cfg.get("percentageOfNodesToScore") is not None or (profs[0] or {}).get("percentageOfNodesToScore") is not None
+
+
 def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
     """-> (Profile, hardPodAffinityWeight)."""
     p = dataclasses.asdict(M.Profile.default())
