@@ -15,3 +15,7 @@ cd /root/repo
 bash tools/gpu_pmc.sh r02 "FETCH_SIZE" "WRITE_SIZE" 2>&1 | tail -12
 cp gpurun_out/pmc_traffic_r02.json $O/pmc_traffic.json 2>/dev/null
 rm -rf $O/ks gpurun_out/pmc_r02_1 gpurun_out/pmc_r02_2
+# config 5 (1024 pod specs): throughput line + per-kernel time
+timeout 300 python tools/bench_c5.py 100000 1024 200000 64 2>&1 | grep -v amdgpu.ids | tee $O/bench_c5.txt | cut -c1-300
+bash tools/gpu_c5_prof.sh > /dev/null 2>&1; cp gpurun_out/c5_kernel_stats.csv $O/c5_kernel_stats.csv 2>/dev/null
+timeout 120 python tools/persist_prof.py 1000000 8 1,16 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-250
