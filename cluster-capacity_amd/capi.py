@@ -72,6 +72,7 @@ class CPod(C.Structure):
         ("required", C.POINTER(CTerm)), ("n_preferred", C.c_int32), ("preferred", C.POINTER(CTerm)),
         ("n_reqs", C.c_int32), ("reqs", C.POINTER(CReq)), ("req_tables_len", C.c_int64), ("req_tables", _pu8),
         ("n_spread", C.c_int32), ("spread", CSpread * M.MAX_TSC), ("has_ipa", C.c_int32), ("ipa", CIpa),
+        ("has_host_ports", C.c_int32), ("host_ports_conflict", _pu8), ("image_score", _pu8),
     ]
 
 
@@ -80,7 +81,7 @@ class CProfile(C.Structure):
         ("filter_mask", C.c_uint32), ("w_taint", C.c_int32), ("w_nodeaffinity", C.c_int32), ("w_fit", C.c_int32),
         ("w_balanced", C.c_int32), ("w_topologyspread", C.c_int32), ("w_interpodaffinity", C.c_int32), ("n_fit_res", C.c_int32),
         ("fit_res", C.c_int32 * MAX_RES), ("fit_res_w", C.c_int64 * MAX_RES), ("n_bal_res", C.c_int32),
-        ("bal_res", C.c_int32 * MAX_RES), ("percentage_of_nodes_to_score", C.c_int32),
+        ("bal_res", C.c_int32 * MAX_RES), ("percentage_of_nodes_to_score", C.c_int32), ("w_imagelocality", C.c_int32),
     ]
 
 
@@ -99,7 +100,7 @@ class CCycle(C.Structure):
     _fields_ = [("node", C.c_int64), ("evaluated_nodes", C.c_int32), ("feasible_nodes", C.c_int32)]
 
 
-ABI_VERSION = 2  # CCSIM_ABI_VERSION of include/ccsim.h
+ABI_VERSION = 3  # CCSIM_ABI_VERSION of include/ccsim.h
 
 # every symbol include/ccsim.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = {
@@ -260,6 +261,13 @@ def marshal_pod(pod: M.PodSpec, keep: list) -> CPod:
     s.has_ipa = int(ipa is not None)
     if ipa is not None:
         _fill_ipa(s.ipa, ipa, keep)
+    s.has_host_ports = int(bool(getattr(pod, "has_host_ports", False)))
+    for name in ("host_ports_conflict", "image_score"):
+        a = getattr(pod, name, None)
+        if a is not None:
+            a = np.ascontiguousarray(a, dtype=np.uint8)
+            keep.append(a)
+            setattr(s, name, _ptr(a, _pu8))
     return s
 
 
@@ -309,6 +317,7 @@ def marshal_profile(p: M.Profile) -> CProfile:
     for i, c in enumerate(p.bal_res):
         s.bal_res[i] = int(c)
     s.percentage_of_nodes_to_score = int(p.percentage_of_nodes_to_score)
+    s.w_imagelocality = int(p.w_imagelocality)
     return s
 
 

@@ -53,6 +53,8 @@ struct ccsim_engine {
     std::vector<int32_t> label_col_max; // largest value id per label column
     uint32_t *d_stat = nullptr;
     uint8_t *d_sreason = nullptr;
+    const int32_t *d_alloc_pods_real = nullptr; // Allocatable.AllowedPodNumber as loaded (cols.alloc_pods may be a pod's clamped copy)
+    bool ports_on = false;                      // NodePorts active for the current pod (ccsim_set_pod)
 
     // pod / profile
     ccsim_profile prof{};
@@ -337,6 +339,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipMemcpyAsync(e->d_label_cols, lc.data(), sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyHostToDevice,
                              e->stream));
     c.alloc_pods = ap;
+    e->d_alloc_pods_real = ap, e->ports_on = false;
     c.pod_count = pc;
     c.nz_mcpu = z0;
     c.nz_mem = z1;
@@ -453,6 +456,16 @@ static int static_pass(ccsim_engine *e, const ccsim_pod *pod, bool score_preferr
     s.stat = stat;
     s.sreason = sreason;
     int rc;
+    if ((pf.filter_mask & CCSIM_F_NODEPORTS) && pod->has_host_ports && pod->host_ports_conflict) {
+        uint8_t *d_pc = nullptr;
+        if ((rc = upload(e, &d_pc, pod->host_ports_conflict, (size_t)e->n, (size_t)e->n_pad, track))) return rc;
+        s.ports_conflict = d_pc;
+    }
+    if (pf.w_imagelocality && pod->image_score) {
+        uint8_t *d_img = nullptr;
+        if ((rc = upload(e, &d_img, pod->image_score, (size_t)e->n, (size_t)e->n_pad, track))) return rc;
+        s.image_score = d_img;
+    }
     uint8_t *d_ok = nullptr;
     int32_t *d_cnt = nullptr;
     if ((rc = upload(e, &d_ok, pod->taint_filter_ok, (size_t)pod->n_taintsets, (size_t)pod->n_taintsets, track))) return rc;
@@ -518,6 +531,7 @@ static DevPod make_devpod(const ccsim_engine *e, const ccsim_pod *pod) {
     p.w_taint = pf.w_taint;
     p.w_aff = pod->n_preferred > 0 ? pf.w_nodeaffinity : 0; // node_affinity.go:243-246 PreScore Skip
     p.w_fit = pf.w_fit;
+    p.w_img = pod->image_score ? pf.w_imagelocality : 0; // no image of the pod on any node: the plugin scores 0 everywhere
     for (int i = 0; i < pf.n_fit_res; i++) {
         if (pf.fit_res[i] == 0) { p.fit_cpu = 1; p.fit_w_cpu = pf.fit_res_w[i]; }
         if (pf.fit_res[i] == 1) { p.fit_mem = 1; p.fit_w_mem = pf.fit_res_w[i]; }
@@ -532,14 +546,8 @@ static DevPod make_devpod(const ccsim_engine *e, const ccsim_pod *pod) {
     return p;
 }
 
+// argument checks shared by ccsim_set_pod and ccsim_set_pods (ranges the packed static word / the columns can hold)
 static int validate_pod(ccsim_engine *e, const ccsim_pod *pod) {
-    if (int vrc = validate_pod(e, pod)) return vrc;
-    return 0;
-}
-
-extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
-    if (!e || !pod) return -EINVAL;
-    if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
     if (pod->n_taintsets < 1 || !pod->taint_filter_ok || !pod->taint_prefer_cnt)
         return fail(e, -EINVAL, "taint tables are required (n_taintsets >= 1)");
     int64_t wsum = 0;
@@ -552,6 +560,18 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         if (pod->req[c] < 0) return fail(e, -EINVAL, "negative request");
         if (c >= e->ncol && pod->req[c] != 0) return fail(e, -EINVAL, "request for a resource column the snapshot lacks");
     }
+    if (pod->image_score)
+        for (int64_t i = 0; i < e->n; i++)
+            if (pod->image_score[i] > 100) return fail(e, -EINVAL, "image_score out of [0,100]");
+    if (pod->has_host_ports && (e->prof.filter_mask & CCSIM_F_NODEPORTS) && !(e->prof.filter_mask & CCSIM_F_FIT))
+        return fail(e, -ENOSYS, "NodePorts needs the NodeResourcesFit filter (one clone per node is kept as a pod-capacity clamp)");
+    return 0;
+}
+
+extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
+    if (!e || !pod) return -EINVAL;
+    if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
+    if (int vrc = validate_pod(e, pod)) return vrc;
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
@@ -566,6 +586,21 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     e->pod = p;
 
     int rc;
+    // NodePorts: every clone holds the pod's host ports, so a node takes at most one -- kept as a clamped copy of the
+    // allocatable pod count (k_ports_clamp), which every Fit evaluation of every mode already tests
+    e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = false;
+    if ((pf.filter_mask & CCSIM_F_NODEPORTS) && pod->has_host_ports) {
+        int32_t *eff = nullptr;
+        const int32_t *pc0 = nullptr;
+        for (auto &b : e->backups)
+            if (b.first == (void *)e->cols.pod_count) pc0 = (const int32_t *)b.second;
+        if (!pc0) return fail(e, -EIO, "pristine pod counts missing");
+        if ((rc = dev_alloc(e, &eff, (size_t)e->n_pad, e->pod_allocs))) return rc;
+        hipLaunchKernelGGL(k_ports_clamp, dim3((unsigned)((e->n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, eff,
+                           e->d_alloc_pods_real, pc0, e->n_pad);
+        HIPCHK(e, hipGetLastError());
+        e->cols.alloc_pods = eff, e->ports_on = true;
+    }
     if ((rc = static_pass(e, pod, p.w_aff != 0, e->d_stat, e->d_sreason, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
 
@@ -777,7 +812,7 @@ static int build_narrow(ccsim_engine *e) {
     } while (0)
 
 static bool profile_has_scoring(const ccsim_profile &p) { // fwk.HasScorePlugins() (schedule_one.go:619-621)
-    return p.w_taint || p.w_nodeaffinity || p.w_fit || p.w_balanced || p.w_topologyspread || p.w_interpodaffinity;
+    return p.w_taint || p.w_nodeaffinity || p.w_fit || p.w_balanced || p.w_topologyspread || p.w_interpodaffinity || p.w_imagelocality;
 }
 
 // numFeasibleNodesToFind (schedule_one.go:697-723)
@@ -1115,7 +1150,8 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
         // terminal round: FitError diagnosis (types.go:787-836)
         HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
         HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
-        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state, e->ipa};
+        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state, e->ipa,
+                   e->ports_on ? 1 : 0, e->d_alloc_pods_real};
         int64_t hb = (e->n + kThreads - 1) / kThreads;
         if (hb > 2048) hb = 2048;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
@@ -1138,7 +1174,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
 static int persist_k(const ccsim_engine *e) {
     if (!e->persist_allowed || !e->cols.narrow || e->pod.nx != 0 || e->n_ranks != 0 || e->n_cus <= 0 || e->n <= 0) return 0;
     if (e->node_max_pods > 65535 || e->node_max_podcount > 65535) return 0;
-    const int64_t max_total = 100ll * ((int64_t)e->pod.w_taint + e->pod.w_aff + e->pod.w_fit + e->pod.w_bal);
+    const int64_t max_total = 100ll * ((int64_t)e->pod.w_taint + e->pod.w_aff + e->pod.w_fit + e->pod.w_bal + e->pod.w_img);
     if (max_total >= 65535) return 0;
     const int cus = e->n_cus < kPMaxGrid ? e->n_cus : kPMaxGrid;
     for (int k : {1, 2, 4, 8})
@@ -1478,6 +1514,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     e->multi = false;
     e->have_pod = e->begun = false;
     e->pts = DevPts{}, e->soft = DevSoft{}, e->ipa = DevIpa{};
+    e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = false;
     e->pts_tables.clear(), e->pts_table_len.clear(), e->ipa_tables.clear(), e->ipa_table_len.clear(), e->soft_flags.clear();
     e->dist_tables.clear(), e->pts_present.clear();
     const size_t N = (size_t)e->n, NP = (size_t)e->n_pad;
@@ -1492,6 +1529,8 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
         for (int c = 2; c < CCSIM_MAX_RES; c++)
             if (q.req[c] != 0) return fail(e, -ENOSYS, "several pod specs: requests beyond cpu / memory (spec %d)", p);
         if (q.has_scalar_entries) return fail(e, -ENOSYS, "several pod specs: scalar resource entries (spec %d)", p);
+        if (q.has_host_ports && (pf.filter_mask & CCSIM_F_NODEPORTS)) return fail(e, -ENOSYS, "several pod specs: host ports (spec %d)", p);
+        if (q.image_score && pf.w_imagelocality) return fail(e, -ENOSYS, "several pod specs: ImageLocality scores (spec %d)", p);
         mem_or |= (uint64_t)q.req[1] | (uint64_t)q.nz_mem;
         const int64_t gc = q.req[0] > q.nz_mcpu ? q.req[0] : q.nz_mcpu, gm = q.req[1] > q.nz_mem ? q.req[1] : q.nz_mem;
         grow_c = gc > grow_c ? gc : grow_c, grow_m = gm > grow_m ? gm : grow_m;

@@ -37,8 +37,10 @@ constexpr int kTile = kThreads * kNodesPerThread;
 constexpr int kMaxGrid = 2048;     // upper bound of the scan grid (partial arrays are sized for it)
 constexpr int kIdxBits = 40;
 constexpr uint64_t kIdxMask = (1ull << kIdxBits) - 1;
-constexpr int kStatOkBit = 31, kStatCntShift = 20;
-constexpr uint32_t kStatAffMask = (1u << kStatCntShift) - 1, kStatCntMask = 0x7ffu;
+// the packed static word of a node for the current pod spec (k_static): bit 31 static filters passed | bits 30..20
+// untolerated PreferNoSchedule taints | bits 19..13 ImageLocality score (0..100) | bits 12..0 sum of matching preferred weights
+constexpr int kStatOkBit = 31, kStatCntShift = 20, kStatImgShift = 13;
+constexpr uint32_t kStatAffMask = (1u << kStatImgShift) - 1, kStatCntMask = 0x7ffu, kStatImgMask = 0x7fu;
 
 enum { DONE_RUNNING = 0, DONE_UNSCHEDULABLE = 1, DONE_LIMIT = 2 };
 
@@ -115,6 +117,7 @@ struct DevPod {
     int32_t nx;           // active extra columns (checked by the Fit filter)
     int32_t xcol[kMaxExtra];
     int32_t w_taint, w_aff, w_fit, w_bal;
+    int32_t w_img;            // ImageLocality weight (0 when the pod's images are on no node: the plugin scores 0 everywhere)
     int32_t fit_cpu, fit_mem; // resource present in the LeastAllocated list
     int64_t fit_w_cpu, fit_w_mem;
     int32_t bal_cpu, bal_mem; // resource present in the BalancedAllocation list
@@ -546,8 +549,9 @@ __device__ __forceinline__ bool fits_core(const DevPod &p, int64_t a_cpu, int64_
 
 // static (pod-spec dependent, state independent) part of the total:
 //   TaintToleration: DefaultNormalizeScore(100, reverse) ; NodeAffinity: DefaultNormalizeScore(100)
-__device__ __forceinline__ int64_t static_score(const DevPod &p, uint32_t c, uint32_t a, uint32_t mt, uint32_t ma) {
-    int64_t t = 0;
+//   ImageLocality: the node's score as it is (image_locality.go:54-66: no NormalizeScore)
+__device__ __forceinline__ int64_t static_score(const DevPod &p, uint32_t c, uint32_t a, uint32_t img, uint32_t mt, uint32_t ma) {
+    int64_t t = (int64_t)(img * (uint32_t)p.w_img);
     // (c == 0 / a == 0 short-cut the runtime division -- ~30 VALU instructions -- for the common node without
     // PreferNoSchedule taints / matching preferred terms; same values)
     if (p.w_taint) t += (int64_t)(mt == 0 || c == 0 ? 100u : 100u - (100u * c) / mt) * p.w_taint;
@@ -831,8 +835,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             const uint64_t mask = __ballot(feasible);
             nfeas += (uint32_t)__popcll(mask); // identical in every lane of the wave
             if (feasible) {
-                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-                int64_t total = static_score(a.p, cnt, aff, mt, ma) +
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                int64_t total = static_score(a.p, cnt, aff, img, mt, ma) +
                                 (NARROW ? dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1)
                                         : (NX > 0 && a.p.gen_score
                                                ? dynamic_score_gen<NX>(a.p, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xak, xrk)
@@ -1346,6 +1350,8 @@ struct StaticArgs {
     const DevReq *reqs;
     const uint8_t *req_tables;
     const int32_t *const *label_cols; // device array of column pointers
+    const uint8_t *ports_conflict;    // NodePorts: an existing pod of the node holds a conflicting host port (NULL: plugin off / none)
+    const uint8_t *image_score;       // ImageLocality score per node, 0..100 (NULL: 0)
     uint32_t *stat;
     uint8_t *sreason;
 };
@@ -1381,11 +1387,16 @@ __global__ __launch_bounds__(kThreads) void k_static(StaticArgs a) {
         }
         if (!m) reason = 3;
     }
+    // NodePorts runs after NodeAffinity and before NodeResourcesFit (default_plugins.go:34-40); the ports of the clones
+    // placed during the run are the engine's business (one clone per node: the clamped pod capacity, ccsim_set_pod)
+    if (!reason && a.ports_conflict && a.ports_conflict[n]) reason = 4;
     uint32_t cnt = (uint32_t)a.taint_prefer_cnt[ts];
     uint32_t aff = 0;
     for (int t = 0; t < a.n_preferred; t++)
         if (term_matches(a, a.preferred[t], n, false)) aff += (uint32_t)a.preferred[t].weight;
-    a.stat[n] = ((reason == 0 ? 1u : 0u) << kStatOkBit) | ((cnt & kStatCntMask) << kStatCntShift) | (aff & kStatAffMask);
+    const uint32_t img = a.image_score ? (uint32_t)a.image_score[n] : 0u;
+    a.stat[n] = ((reason == 0 ? 1u : 0u) << kStatOkBit) | ((cnt & kStatCntMask) << kStatCntShift) | ((img & kStatImgMask) << kStatImgShift) |
+                (aff & kStatAffMask);
     a.sreason[n] = (uint8_t)reason;
 }
 
@@ -1393,7 +1404,7 @@ __global__ __launch_bounds__(kThreads) void k_static(StaticArgs a) {
 // k_hist: terminal round only.  Per-node failure reasons exactly as the filter chain reports them
 // (first failing plugin in order; NodeResourcesFit keeps ALL its insufficient resources,
 // fit.go:520-531), histogrammed for FitError.Error (types.go:787-836).
-//   hist[0] unschedulable, [1] nodename, [2] node affinity, [3] too many pods, [4+col] insufficient col,
+//   hist[0] unschedulable, [1] nodename, [2] node affinity, [3] too many pods, [4+col] insufficient col, ... [kHistNodePorts],
 //   hist_code[0] = nodes whose status code is plain Unschedulable (preemption dry-run candidates).
 // ------------------------------------------------------------------------------------------------
 struct HistArgs {
@@ -1406,9 +1417,12 @@ struct HistArgs {
     DevPts pts;
     const DevState *st;
     DevIpa ipa;
+    int32_t ports_on;               // NodePorts active for this pod: a node that took a clone has no free ports
+    const int32_t *alloc_pods_real; // Allocatable.AllowedPodNumber (c.alloc_pods is the clamped copy while ports_on)
 };
 
-constexpr int kHistSlots = 4 + kMaxRes + 2 + 3 + 1; // + the status-code counter
+constexpr int kHistSlots = 4 + kMaxRes + 2 + 3 + 1 + 1; // + NodePorts + the status-code counter
+constexpr int kHistNodePorts = 4 + kMaxRes + 2 + 3;
 constexpr int kHistIpa = 4 + kMaxRes + 2;          // affinity, anti-affinity, existing pods' anti-affinity
 constexpr int kHistPtsMissing = 4 + kMaxRes, kHistPtsSkew = 4 + kMaxRes + 1;
 constexpr int kHistTsLds = 1024;                // taint sets histogrammed in LDS (more fall back to global atomics)
@@ -1430,8 +1444,13 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
             continue;
         }
         if (sr == 3) { atomicAdd(&sh[2], 1u); continue; }
+        if (sr == 4 || (a.ports_on && a.c.placed_cnt[n] > 0)) { // node_ports.go:148-162: plain Unschedulable, before NodeResourcesFit
+            atomicAdd(&sh[kHistNodePorts], 1u);
+            atomicAdd(&sh[kHistSlots - 1], 1u);
+            continue;
+        }
         bool unresolvable = false, any = false;
-        if (a.p.fit_enabled && (int64_t)a.c.pod_count[n] + 1 > (int64_t)a.c.alloc_pods[n]) { atomicAdd(&sh[3], 1u); any = true; }
+        if (a.p.fit_enabled && (int64_t)a.c.pod_count[n] + 1 > (int64_t)a.alloc_pods_real[n]) { atomicAdd(&sh[3], 1u); any = true; }
         if (a.p.fit_enabled && !a.p.all_zero_req) {
             for (int col = 0; col < a.p.ncol; col++) {
                 const int64_t rq = a.p.req[col];
@@ -1474,6 +1493,16 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
     if (threadIdx.x == 0 && sh[kHistSlots - 1]) atomicAdd(&a.hist_code[0], (unsigned long long)sh[kHistSlots - 1]);
     for (int i = threadIdx.x; i < kHistTsLds && i < a.n_taintsets; i += kThreads)
         if (sh_ts[i]) atomicAdd(&a.hist_ts[i], (unsigned long long)sh_ts[i]);
+}
+
+// k_ports_clamp: NodePorts for a pod with host ports -- every clone holds the same ports, so a node takes at most one
+// (NodeInfo.updateUsedPorts, S/framework/types.go:431-439; fitsPorts, node_ports.go:164-176).  The engine folds that into
+// the pod-count test every Fit evaluation already makes: allowed pods = min(real, pods of the snapshot + 1).
+__global__ __launch_bounds__(kThreads) void k_ports_clamp(int32_t *eff, const int32_t *real, const int32_t *pod_count0, int64_t n_pad) {
+    const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (n >= n_pad) return;
+    const int64_t one_more = (int64_t)pod_count0[n] + 1;
+    eff[n] = (int32_t)(one_more < (int64_t)real[n] ? one_more : (int64_t)real[n]);
 }
 
 // k_narrow_build: (re)derive the narrow mirrors from the wide columns (per pod spec, and after a state reset)

@@ -439,8 +439,8 @@ __global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
                 const int32_t na0 = k ? a0.y : a0.x, na1 = k ? a1.y : a1.x, nr0 = k ? r0.y : r0.x, nr1 = k ? r1.y : r1.x;
                 int32_t sc = -1;
                 if ((w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, k ? AP.y : AP.x, k ? NP.y : NP.x)) {
-                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-                    const int64_t s64 = static_score(a.p, cnt, aff, mt, ma) +
+                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                    const int64_t s64 = static_score(a.p, cnt, aff, img, mt, ma) +
                                         dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, k ? z0.y : z0.x, k ? z1.y : z1.x);
                     acc.add(s64, a.c.global_offset + i0 + k, cnt, aff);
                     sc = (int32_t)s64;
@@ -457,8 +457,8 @@ __global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
         for (int k = 0; k < 2; k++) {
             int32_t sc = -1;
             if (node_feasible<NX>(a.p, nd[k])) {
-                const uint32_t cnt = (nd[k].w >> kStatCntShift) & kStatCntMask, aff = nd[k].w & kStatAffMask;
-                const int64_t s64 = node_score<NX>(a.p, nd[k], static_score(a.p, cnt, aff, mt, ma));
+                const uint32_t cnt = (nd[k].w >> kStatCntShift) & kStatCntMask, aff = nd[k].w & kStatAffMask, img = (nd[k].w >> kStatImgShift) & kStatImgMask;
+                const int64_t s64 = node_score<NX>(a.p, nd[k], static_score(a.p, cnt, aff, img, mt, ma));
                 acc.add(s64, a.c.global_offset + i0 + k, cnt, aff);
                 sc = (int32_t)s64;
             }
@@ -588,8 +588,8 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
                 nd_load(a.c, a.p, nidx, n);
             }
             const uint32_t nw = nd_word(n);
-            const uint32_t cnt = (nw >> kStatCntShift) & kStatCntMask, aff = nw & kStatAffMask;
-            const int64_t nstat = static_score(a.p, cnt, aff, mt, ma);
+            const uint32_t cnt = (nw >> kStatCntShift) & kStatCntMask, aff = nw & kStatAffMask, img = (nw >> kStatImgShift) & kStatImgMask;
+            const int64_t nstat = static_score(a.p, cnt, aff, img, mt, ma);
             bool fend = true;
             int64_t j = 0;
             if ((wave * 64) < nwork) j = wave_run_down<Node>(cx, n, nstat, M, mine, fend); // wave-uniform

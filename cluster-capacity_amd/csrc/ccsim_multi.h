@@ -230,8 +230,8 @@ __global__ __launch_bounds__(kThreads) void k_multi_scan(MultiArgs a) {
                     ok = m_pts_check(q, c, v, m_count(s_tbl[jj][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[jj][c]) == 0;
                 }
             if (!ok) continue;
-            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-            const int64_t total = static_score(p, cnt, aff, mt, ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k]);
+            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+            const int64_t total = static_score(p, cnt, aff, img, mt, ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k]);
             const uint64_t key = make_key(total, a.c.global_offset + i);
             if (key > k1) k3 = k2, k2 = k1, k1 = key; else if (key > k2) k3 = k2, k2 = key; else if (key > k3) k3 = key;
             nf++;
@@ -411,8 +411,8 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
                     ok = m_pts_check(q, c, v, m_count(s_tbl[j][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[j][c]) == 0;
                 }
             if (ok) {
-                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-                const int64_t total = static_score(p, cnt, aff, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, ta0, ta1, tr0, tr1, tz0, tz1);
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                const int64_t total = static_score(p, cnt, aff, img, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, ta0, ta1, tr0, tr1, tz0, tz1);
                 tkey = make_key(total, a.c.global_offset + t_idx);
             }
         }
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
             if (!(pod_on && t < j)) continue;
             const int64_t n = s_win[t];
             const uint32_t w = wv[i];
-            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
             th_mt += cnt == cd.mt, th_ma += aff == cd.ma;
             bool ok = (w >> kStatOkBit) && !((bv[i] >> (n & 31)) & 1u);
             if (!ok) continue;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
                     ok = m_pts_check(q, c, v, m_count(s_tbl[j][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[j][c]) == 0;
                 }
             if (!ok) continue;
-            const int64_t total = static_score(p, cnt, aff, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1);
+            const int64_t total = static_score(p, cnt, aff, img, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1);
             beaten = beaten || make_key(total, a.c.global_offset + n) > s_wkey[j]; // pod j prefers a node an earlier pod took
         }
         if (pod_on) {

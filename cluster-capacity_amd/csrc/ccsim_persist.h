@@ -351,8 +351,8 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                 const uint32_t w = n.w;
                 uint32_t sc = kScInf, wsv = w & (1u << kStatOkBit);
                 if (nd_feasible(cx, n)) {
-                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-                    const int64_t nstat = static_score(a.p, cnt, aff, mt, ma);
+                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                    const int64_t nstat = static_score(a.p, cnt, aff, img, mt, ma);
                     sc = (uint32_t)(nstat + dynamic_score_narrow(a.p, cx.q, n.a0, n.a1, n.r0, n.r1, n.z0, n.z1));
                     lmax = sc + 1 > lmax ? sc + 1 : lmax;
                     lnf++, lcmt += cnt == mt, lcma += aff == ma;

@@ -146,6 +146,9 @@ inline void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
         }
         c.entries_existing = a.entries_existing;
     }
+    p.has_host_ports = s.has_host_ports;
+    p.host_ports_conflict = s.host_ports_conflict.empty() ? nullptr : s.host_ports_conflict.data();
+    p.image_score = s.image_score.empty() ? nullptr : s.image_score.data();
     m.profile = prof.c;
 }
 

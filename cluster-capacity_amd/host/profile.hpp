@@ -24,8 +24,9 @@ struct HostProfile {
 inline HostProfile default_profile() {
     HostProfile p;
     ccsim_profile &f = p.c;
-    f.filter_mask = CCSIM_F_UNSCHEDULABLE | CCSIM_F_NODENAME | CCSIM_F_TAINT | CCSIM_F_NODEAFFINITY | CCSIM_F_FIT | CCSIM_F_TOPOLOGYSPREAD | CCSIM_F_INTERPODAFFINITY;
-    f.w_taint = 3, f.w_nodeaffinity = 2, f.w_fit = 1, f.w_balanced = 1, f.w_topologyspread = 2, f.w_interpodaffinity = 2;
+    f.filter_mask = CCSIM_F_UNSCHEDULABLE | CCSIM_F_NODENAME | CCSIM_F_TAINT | CCSIM_F_NODEAFFINITY | CCSIM_F_FIT | CCSIM_F_TOPOLOGYSPREAD | CCSIM_F_INTERPODAFFINITY |
+                    CCSIM_F_NODEPORTS;
+    f.w_taint = 3, f.w_nodeaffinity = 2, f.w_fit = 1, f.w_balanced = 1, f.w_topologyspread = 2, f.w_interpodaffinity = 2, f.w_imagelocality = 1;
     f.n_fit_res = 2, f.fit_res[0] = 0, f.fit_res[1] = 1, f.fit_res_w[0] = 1, f.fit_res_w[1] = 1;
     f.n_bal_res = 2, f.bal_res[0] = 0, f.bal_res[1] = 1;
     f.percentage_of_nodes_to_score = 100; // this host's default: the order-independent full search
@@ -48,14 +49,17 @@ inline const std::map<std::string, PluginInfo> &plugin_table() {
         {"NodeResourcesBalancedAllocation", {0, &ccsim_profile::w_balanced, 1}},
         {"PodTopologySpread", {CCSIM_F_TOPOLOGYSPREAD, &ccsim_profile::w_topologyspread, 2}},
         {"InterPodAffinity", {CCSIM_F_INTERPODAFFINITY, &ccsim_profile::w_interpodaffinity, 2}},
+        {"NodePorts", {CCSIM_F_NODEPORTS, nullptr, 0}},
+        {"ImageLocality", {0, &ccsim_profile::w_imagelocality, 1}},
     };
     return t;
 }
 // default plugins whose Filter / Score is a no-op for the pods this simulator accepts: accepted, ignored
+// (pods that would activate a volume / DRA plugin are refused at ingest)
 inline bool folded_away(const std::string &n) {
-    static const char *names[] = {"SchedulingGates", "PrioritySort", "NodePorts", "VolumeRestrictions", "NodeVolumeLimits", "EBSLimits",
+    static const char *names[] = {"SchedulingGates", "PrioritySort", "VolumeRestrictions", "NodeVolumeLimits", "EBSLimits",
                                   "GCEPDLimits", "AzureDiskLimits", "VolumeBinding", "VolumeZone", "DynamicResources", "DefaultPreemption",
-                                  "ImageLocality", "DefaultBinder", "ClusterCapacityBinder"};
+                                  "DefaultBinder", "ClusterCapacityBinder"};
     for (const char *x : names)
         if (n == x) return true;
     return false;
@@ -174,6 +178,7 @@ inline Value profile_json(const HostProfile &p) {
     o.set("filter_mask", Value::num(f.filter_mask));
     o.set("w_taint", Value::num(f.w_taint)), o.set("w_nodeaffinity", Value::num(f.w_nodeaffinity)), o.set("w_fit", Value::num(f.w_fit));
     o.set("w_balanced", Value::num(f.w_balanced)), o.set("w_topologyspread", Value::num(f.w_topologyspread)), o.set("w_interpodaffinity", Value::num(f.w_interpodaffinity));
+    o.set("w_imagelocality", Value::num(f.w_imagelocality));
     Value fr = Value::array(), fw = Value::array(), br = Value::array();
     for (int i = 0; i < f.n_fit_res; i++) fr.a.push_back(Value::num(f.fit_res[i])), fw.a.push_back(Value::num(f.fit_res_w[i]));
     for (int i = 0; i < f.n_bal_res; i++) br.a.push_back(Value::num(f.bal_res[i]));

@@ -49,6 +49,7 @@ inline const char *reason_text(int slot) {
     case CCSIM_R_IPA_AFFINITY: return "node(s) didn't match pod affinity rules"; // interpodaffinity/filtering.go:37-45
     case CCSIM_R_IPA_ANTI: return "node(s) didn't match pod anti-affinity rules";
     case CCSIM_R_IPA_EXISTING_ANTI: return "node(s) didn't satisfy existing pods anti-affinity rules";
+    case CCSIM_R_NODEPORTS: return "node(s) didn't have free ports for the requested pod ports"; // nodeports/node_ports.go:39
     }
     return nullptr;
 }

@@ -313,8 +313,58 @@ struct Snapshot {
     std::vector<uint8_t> included; // RequiredNodeAffinity.Match per node (spread inclusion policy); empty = all
     bool has_ipa = false;
     Ipa ipa;
+    bool has_host_ports = false;              // NodePorts: util.GetHostPorts(pod) is not empty
+    std::vector<uint8_t> host_ports_conflict; // per node: an existing pod holds a conflicting port; empty = none does
+    std::vector<uint8_t> image_score;         // ImageLocality score per node (0..100); empty = no image of the pod anywhere
     size_t n() const { return names.size(); }
 };
+
+// ---- host ports (NodePorts) --------------------------------------------------------------------------------------
+struct HostPort {
+    std::string ip, protocol;
+    int64_t port;
+};
+// util.GetHostPorts (S/util/utils.go:175-210): hostPort > 0 of the restartable init containers and of the containers,
+// sanitized as HostPortInfo does ("" -> 0.0.0.0 / TCP, kube-scheduler/framework/types.go:530-538)
+inline std::vector<HostPort> host_ports(const Value &spec) {
+    std::vector<HostPort> out;
+    auto take = [&](const Value &c) {
+        for (const auto &p : c["ports"].items()) {
+            const int64_t hp = p["hostPort"].truthy() ? p["hostPort"].as_int() : 0;
+            if (hp > 0) out.push_back({p["hostIP"].truthy() ? p["hostIP"].text() : "0.0.0.0", p["protocol"].truthy() ? p["protocol"].text() : "TCP", hp});
+        }
+    };
+    for (const auto &c : spec["initContainers"].items())
+        if (c["restartPolicy"].text() == "Always") take(c);
+    for (const auto &c : spec["containers"].items()) take(c);
+    return out;
+}
+// fitsPorts (node_ports.go:164-176) over HostPortInfo.CheckConflict (types.go:499-528): 0.0.0.0 conflicts with every ip
+inline bool ports_conflict(const std::vector<HostPort> &want, const std::vector<HostPort> &used) {
+    for (const auto &w : want)
+        for (const auto &u : used)
+            if (u.protocol == w.protocol && u.port == w.port && (w.ip == "0.0.0.0" || u.ip == "0.0.0.0" || u.ip == w.ip)) return true;
+    return false;
+}
+
+// ---- image locality (P/imagelocality/image_locality.go:54-127) ---------------------------------------------------
+inline std::string normalized_image_name(const std::string &name) { // :122-127
+    const size_t colon = name.rfind(':'), slash = name.rfind('/');
+    const long long ci = colon == std::string::npos ? -1 : (long long)colon, si = slash == std::string::npos ? -1 : (long long)slash;
+    return ci <= si ? name + ":latest" : name;
+}
+// calculatePriority(sumImageScores) :84-115; scaledImageScore is fp64: int64(float64(Size) * (NumNodes / total))
+inline int64_t image_locality_score(const std::vector<std::pair<int64_t, int64_t>> &sizes_and_spread, int64_t total_nodes, int64_t n_containers) {
+    const int64_t mb = 1024 * 1024, lo = 23 * mb, hi = 1000 * mb * n_containers;
+    int64_t sum = 0;
+    for (const auto &x : sizes_and_spread) {
+        const double spread = (double)x.second / (double)total_nodes;
+        const double scaled = (double)x.first * spread;
+        sum += (int64_t)scaled;
+    }
+    sum = sum < lo ? lo : (sum > hi ? hi : sum);
+    return 100 * (sum - lo) / (hi - lo);
+}
 
 // AffinityTerm.Matches (S/framework/types.go:927-935): the pod's namespace is in the term's set, or its namespace's labels
 // match the term's namespaceSelector; then the label selector decides.  newAffinityTerm (:879-895): no namespaces and no
@@ -464,6 +514,58 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         s.included.assign(N, 0);
         for (size_t i = 0; i < N; i++) s.included[i] = node_matches_required(i);
     }
+
+    // NodePorts: which nodes' existing pods already hold one of the pod's host ports
+    {
+        const std::vector<HostPort> want = host_ports(spec);
+        if (!want.empty()) {
+            s.has_host_ports = true;
+            std::vector<std::vector<HostPort>> used(N);
+            for (size_t j = 0; j < live.size(); j++)
+                for (const auto &hp : host_ports((*live[j])["spec"])) used[live_node[j]].push_back(hp);
+            std::vector<uint8_t> conflict(N, 0);
+            bool any = false;
+            for (size_t i = 0; i < N; i++) conflict[i] = !used[i].empty() && ports_conflict(want, used[i]), any = any || conflict[i];
+            if (any) s.host_ports_conflict = conflict;
+        }
+    }
+    // ImageLocality: the scheduler cache's image states (cache.go:680-703): Size = what the FIRST node added (nodes arrive
+    // sorted by name) reports for the image name, NumNodes = nodes listing the name
+    {
+        std::vector<size_t> by_name(N);
+        for (size_t i = 0; i < N; i++) by_name[i] = i;
+        std::sort(by_name.begin(), by_name.end(), [&](size_t a, size_t b) { return s.names[a] < s.names[b]; });
+        std::map<std::string, int64_t> size;
+        std::map<std::string, std::set<size_t>> holders;
+        for (size_t i : by_name)
+            for (const auto &img : (*nodes[i])["status"]["images"].items())
+                for (const auto &nm : img["names"].items()) {
+                    size.emplace(nm.text(), img["sizeBytes"].truthy() ? img["sizeBytes"].as_int() : 0);
+                    holders[nm.text()].insert(i);
+                }
+        std::vector<std::string> wanted;
+        for (const char *list : {"initContainers", "containers"})
+            for (const auto &c : spec[list].items()) wanted.push_back(normalized_image_name(c["image"].text()));
+        bool any = false;
+        for (const auto &w : wanted) any = any || holders.count(w);
+        if (any) {
+            s.image_score.assign(N, 0);
+            for (size_t i = 0; i < N; i++) {
+                std::vector<std::pair<int64_t, int64_t>> present;
+                for (const auto &w : wanted) {
+                    const auto h = holders.find(w);
+                    if (h != holders.end() && h->second.count(i)) present.emplace_back(size[w], (int64_t)h->second.size());
+                }
+                s.image_score[i] = (uint8_t)image_locality_score(present, (int64_t)N, (int64_t)wanted.size());
+            }
+        }
+    }
+    // volume-backed plugins (VolumeBinding / VolumeZone / VolumeRestrictions / NodeVolumeLimits / DynamicResources) have no
+    // integer form here: a pod that would activate them is refused instead of silently ignoring the constraint
+    for (const auto &v : spec["volumes"].items())
+        for (const char *kind : {"persistentVolumeClaim", "ephemeral", "gcePersistentDisk", "awsElasticBlockStore", "rbd", "iscsi", "csi"})
+            if (!v[kind].is_null()) throw std::runtime_error("pod volume '" + v["name"].text() + "' of kind " + kind + ": the volume plugins are not modelled");
+    if (spec["resourceClaims"].truthy()) throw std::runtime_error("spec.resourceClaims: the DynamicResources plugin is not modelled");
 
     // topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
     for (const auto &c : spec["topologySpreadConstraints"].items()) {
@@ -695,6 +797,9 @@ inline Value snapshot_json(const Snapshot &s) {
         p.set("ipa", e);
     } else
         p.set("ipa", Value());
+    p.set("has_host_ports", Value::boolean(s.has_host_ports));
+    p.set("host_ports_conflict", s.host_ports_conflict.empty() ? Value() : int_array(s.host_ports_conflict));
+    p.set("image_score", s.image_score.empty() ? Value() : int_array(s.image_score));
     o.set("pod", p);
     return o;
 }

@@ -14,6 +14,8 @@ Reference (paths relative to the reference root; S/ = vendor/k8s.io/kubernetes/p
   label selectors                   apimachinery/pkg/apis/meta/v1/helpers.go:36-75
   spread constraints                S/framework/plugins/podtopologyspread/common.go:42-159
   inter-pod affinity terms          vendor/k8s.io/kube-scheduler/framework/types.go:379-384, S/framework/types.go:927-935
+  host ports                        S/util/utils.go:175-210 GetHostPorts, kube-scheduler/framework/types.go:455-538 HostPortInfo
+  image states                      S/backend/cache/cache.go:680-703, S/framework/plugins/imagelocality/image_locality.go:54-127
 """
 from __future__ import annotations
 
@@ -177,6 +179,75 @@ def taint_verdict(taints: List[dict], tolerations: List[dict]):
     prefer_tols = [x for x in tolerations if not x.get("effect") or x.get("effect") == "PreferNoSchedule"]
     cnt = sum(1 for t in taints if t.get("effect") == "PreferNoSchedule" and not any(tolerates(x, t) for x in prefer_tols))
     return first is None, cnt, first
+
+
+# ---- host ports (NodePorts) -------------------------------------------------------------------------------------
+def host_ports(spec: dict):
+    """util.GetHostPorts (S/util/utils.go:175-210): ports with hostPort > 0 of the restartable init containers and of the
+    containers -> [(hostIP, protocol, hostPort)], sanitized as HostPortInfo does ("" -> 0.0.0.0 / TCP, types.go:530-538)."""
+    out = []
+    cs = [c for c in spec.get("initContainers") or [] if c.get("restartPolicy") == "Always"] + list(spec.get("containers") or [])
+    for c in cs:
+        for p in c.get("ports") or []:
+            hp = int(p.get("hostPort") or 0)
+            if hp > 0:
+                out.append((p.get("hostIP") or "0.0.0.0", p.get("protocol") or "TCP", hp))
+    return out
+
+
+def ports_conflict(want, used) -> bool:
+    """fitsPorts (node_ports.go:164-176) over HostPortInfo.CheckConflict (types.go:499-528); `used` = set of sanitized
+    (ip, protocol, port) held by the node's pods.  0.0.0.0 conflicts with every ip on the same (protocol, port)."""
+    for ip, proto, port in want:
+        for uip, uproto, uport in used:
+            if (uproto, uport) == (proto, port) and (ip == "0.0.0.0" or uip == "0.0.0.0" or uip == ip):
+                return True
+    return False
+
+
+# ---- image locality ---------------------------------------------------------------------------------------------
+_MB = 1024 * 1024
+
+
+def normalized_image_name(name: str) -> str:
+    """image_locality.go:122-127: append :latest when the last path component carries no tag."""
+    return name + ":latest" if name.rfind(":") <= name.rfind("/") else name
+
+
+def image_locality_score(sizes_and_spread, total_nodes: int, n_containers: int) -> int:
+    """calculatePriority(sumImageScores) (image_locality.go:84-115); `sizes_and_spread` = (Size, NumNodes) of the pod's
+    container images present on the node.  scaledImageScore is fp64: int64(float64(Size) * (NumNodes / total))."""
+    total = 0
+    for size, num_nodes in sizes_and_spread:
+        total += int(float(size) * (float(num_nodes) / float(total_nodes)))
+    lo, hi = 23 * _MB, 1000 * _MB * n_containers
+    total = lo if total < lo else (hi if total > hi else total)
+    q = 100 * (total - lo)
+    d = hi - lo
+    return int(abs(q) // abs(d)) * (1 if (q >= 0) == (d > 0) else -1)  # Go integer division truncates toward zero
+
+
+def image_scores(nodes: List[dict], spec: dict) -> Optional[np.ndarray]:
+    """Per-node ImageLocality score (uint8) or None when none of the pod's images is on any node.  The image states are
+    the scheduler cache's (cache.go:680-703): Size = what the FIRST node added (nodes arrive sorted by name) reports for
+    that image name, NumNodes = nodes listing the name."""
+    by_name = sorted(range(len(nodes)), key=lambda i: nodes[i]["metadata"]["name"])
+    size: Dict[str, int] = {}
+    holders: Dict[str, set] = {}
+    for i in by_name:
+        for img in (nodes[i].get("status") or {}).get("images") or []:
+            for nm in img.get("names") or []:
+                size.setdefault(nm, int(img.get("sizeBytes") or 0))
+                holders.setdefault(nm, set()).add(i)
+    cs = list(spec.get("initContainers") or []) + list(spec.get("containers") or [])
+    wanted = [normalized_image_name(c.get("image") or "") for c in cs]
+    if not any(w in holders for w in wanted):
+        return None
+    out = np.zeros(len(nodes), np.uint8)
+    for i in range(len(nodes)):
+        present = [(size[w], len(holders[w])) for w in wanted if w in holders and i in holders[w]]
+        out[i] = image_locality_score(present, len(nodes), len(cs))
+    return out
 
 
 # ---- selectors --------------------------------------------------------------------------------------------------
@@ -379,6 +450,28 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
         tolerates_unschedulable=tol_unsched, affinity_filter_active=affinity_active,
         has_node_selector=node_selector is not None and len(node_selector) > 0, node_selector=sel_reqs,
         has_required_terms=required is not None, required=req_terms, preferred=pref)
+
+    # NodePorts: which nodes' existing pods already hold one of the pod's host ports
+    want = host_ports(spec)
+    if want:
+        pod.has_host_ports = True
+        used: Dict[int, set] = {}
+        for p in live:
+            hp = host_ports(p["spec"])
+            if hp:
+                used.setdefault(index[p["spec"]["nodeName"]], set()).update(hp)
+        conflict = np.array([1 if i in used and ports_conflict(want, used[i]) else 0 for i in range(N)], np.uint8)
+        pod.host_ports_conflict = conflict if conflict.any() else None
+    # ImageLocality: per-node score from node.status.images
+    pod.image_score = image_scores(nodes, spec)
+    # volume-backed plugins (VolumeBinding / VolumeZone / VolumeRestrictions / NodeVolumeLimits / DynamicResources) have no
+    # integer form here: a pod that would activate them is refused instead of silently ignoring the constraint
+    for v in spec.get("volumes") or []:
+        for kind in ("persistentVolumeClaim", "ephemeral", "gcePersistentDisk", "awsElasticBlockStore", "rbd", "iscsi", "csi"):
+            if v.get(kind) is not None:
+                raise NotImplementedError(f"pod volume {v.get('name')!r} of kind {kind}: the volume plugins are not modelled")
+    if spec.get("resourceClaims"):
+        raise NotImplementedError("spec.resourceClaims: the DynamicResources plugin is not modelled")
 
     # topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
     included = np.array([node_matches_required(i) for i in range(N)], np.uint8) if affinity_active else None

@@ -26,7 +26,9 @@ F_NODEAFFINITY = 1 << 3
 F_FIT = 1 << 4
 F_TOPOLOGYSPREAD = 1 << 5
 F_INTERPODAFFINITY = 1 << 6
-F_ALL = F_UNSCHEDULABLE | F_NODENAME | F_TAINT | F_NODEAFFINITY | F_FIT | F_TOPOLOGYSPREAD | F_INTERPODAFFINITY
+F_NODEPORTS = 1 << 7  # runs between NodeAffinity and NodeResourcesFit (the bit order is not the plugin order)
+F_ALL = (F_UNSCHEDULABLE | F_NODENAME | F_TAINT | F_NODEAFFINITY | F_FIT | F_TOPOLOGYSPREAD | F_INTERPODAFFINITY
+         | F_NODEPORTS)
 
 # reason slots of the terminal histogram
 R_UNSCHEDULABLE = 0
@@ -39,7 +41,8 @@ R_PTS_SKEW = R_PTS_MISSING_LABEL + 1
 R_IPA_AFFINITY = R_PTS_SKEW + 1
 R_IPA_ANTI = R_IPA_AFFINITY + 1
 R_IPA_EXISTING_ANTI = R_IPA_ANTI + 1
-NREASON = R_IPA_EXISTING_ANTI + 1
+R_NODEPORTS = R_IPA_EXISTING_ANTI + 1
+NREASON = R_NODEPORTS + 1
 
 STOP_UNSCHEDULABLE = 0
 STOP_LIMIT = 1
@@ -189,11 +192,21 @@ class PodSpec:
     preferred: List[Tuple[int, List[Requirement]]] = field(default_factory=list)  # (weight, term)
     spread: List[SpreadConstraint] = field(default_factory=list)
     ipa: Optional[InterPodAffinity] = None
+    # NodePorts (plugins/nodeports/node_ports.go:67-176): the pod asks for host ports; which nodes' EXISTING pods
+    # already hold a conflicting one (uint8[n]; clones conflict with one another by construction)
+    has_host_ports: bool = False
+    host_ports_conflict: Optional[np.ndarray] = None
+    # ImageLocality (plugins/imagelocality/image_locality.go:54-115): per-node score 0..100, uint8[n]; None = 0
+    image_score: Optional[np.ndarray] = None
 
     def __post_init__(self):
         self.req = _i64(self.req)
         self.taint_filter_ok = _u8(self.taint_filter_ok)
         self.taint_prefer_cnt = _i32(self.taint_prefer_cnt)
+        if self.host_ports_conflict is not None:
+            self.host_ports_conflict = _u8(self.host_ports_conflict)
+        if self.image_score is not None:
+            self.image_score = _u8(self.image_score)
 
 
 @dataclass
@@ -212,6 +225,7 @@ class Profile:
     fit_res_w: Tuple[int, ...] = (1, 1)
     bal_res: Tuple[int, ...] = (0, 1)
     percentage_of_nodes_to_score: int = 100  # 0 = adaptive (schedule_one.go:697-723)
+    w_imagelocality: int = 1
 
     @staticmethod
     def default() -> "Profile":
@@ -221,7 +235,7 @@ class Profile:
     def fit_only() -> "Profile":
         """BASELINE config 2: NodeResourcesFit Filter + LeastAllocated Score only."""
         return Profile(filter_mask=F_FIT, w_taint=0, w_nodeaffinity=0, w_fit=1, w_balanced=0, w_topologyspread=0,
-                       w_interpodaffinity=0)
+                       w_interpodaffinity=0, w_imagelocality=0)
 
 
 @dataclass

@@ -29,6 +29,7 @@ REASON_TEXT = {
     M.R_IPA_AFFINITY: "node(s) didn't match pod affinity rules",
     M.R_IPA_ANTI: "node(s) didn't match pod anti-affinity rules",
     M.R_IPA_EXISTING_ANTI: "node(s) didn't satisfy existing pods anti-affinity rules",
+    M.R_NODEPORTS: "node(s) didn't have free ports for the requested pod ports",  # nodeports/node_ports.go:39
 }
 
 

@@ -23,10 +23,13 @@ PLUGINS = {
     "NodeResourcesBalancedAllocation": (0, "w_balanced", 1),
     "PodTopologySpread": (M.F_TOPOLOGYSPREAD, "w_topologyspread", 2),
     "InterPodAffinity": (M.F_INTERPODAFFINITY, "w_interpodaffinity", 2),
+    "NodePorts": (M.F_NODEPORTS, None, 0),
+    "ImageLocality": (0, "w_imagelocality", 1),
 }
 # default plugins whose Filter / Score is a no-op for the pods this simulator accepts: accepted, ignored
-FOLDED_AWAY = {"SchedulingGates", "PrioritySort", "NodePorts", "VolumeRestrictions", "NodeVolumeLimits", "EBSLimits", "GCEPDLimits",
-               "AzureDiskLimits", "VolumeBinding", "VolumeZone", "DynamicResources", "DefaultPreemption", "ImageLocality",
+# (pods that would activate a volume / DRA plugin are refused at ingest)
+FOLDED_AWAY = {"SchedulingGates", "PrioritySort", "VolumeRestrictions", "NodeVolumeLimits", "EBSLimits", "GCEPDLimits",
+               "AzureDiskLimits", "VolumeBinding", "VolumeZone", "DynamicResources", "DefaultPreemption",
                "DefaultBinder", "ClusterCapacityBinder"}
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCSIM_ABI_VERSION 2
+#define CCSIM_ABI_VERSION 3
 #define CCSIM_MAX_SCALAR 8
 #define CCSIM_MAX_RES (3 + CCSIM_MAX_SCALAR)
 #define CCSIM_MAX_LABEL_COLS 32
@@ -45,7 +45,8 @@ enum {
     CCSIM_F_NODEAFFINITY = 1u << 3,
     CCSIM_F_FIT = 1u << 4,
     CCSIM_F_TOPOLOGYSPREAD = 1u << 5,
-    CCSIM_F_INTERPODAFFINITY = 1u << 6
+    CCSIM_F_INTERPODAFFINITY = 1u << 6,
+    CCSIM_F_NODEPORTS = 1u << 7 /* P/nodeports; runs between NodeAffinity and NodeResourcesFit (the bit order is not the plugin order) */
 };
 
 /* reason slots of the terminal-round histogram (FitError.Error, S/framework/types.go:787-836) */
@@ -60,6 +61,7 @@ enum {
     CCSIM_R_IPA_AFFINITY,      /* "node(s) didn't match pod affinity rules" */
     CCSIM_R_IPA_ANTI,          /* "node(s) didn't match pod anti-affinity rules" */
     CCSIM_R_IPA_EXISTING_ANTI, /* "node(s) didn't satisfy existing pods anti-affinity rules" */
+    CCSIM_R_NODEPORTS,         /* "node(s) didn't have free ports for the requested pod ports" (P/nodeports/node_ports.go:39) */
     CCSIM_NREASON
 };
 
@@ -173,7 +175,7 @@ typedef struct {
     int32_t n_required;
     const ccsim_term *required;
     int32_t n_preferred;
-    const ccsim_term *preferred; /* sum of weights must stay < 2^20 */
+    const ccsim_term *preferred; /* sum of weights must stay < 2^13 (the packed static word) */
     int32_t n_reqs;
     const ccsim_requirement *reqs;
     int64_t req_tables_len;
@@ -182,6 +184,17 @@ typedef struct {
     ccsim_spread_constraint spread[CCSIM_MAX_TSC];
     int32_t has_ipa; /* 0 = no inter-pod (anti)affinity anywhere (PreFilter / PreScore Skip) */
     ccsim_ipa ipa;
+    /* NodePorts (P/nodeports/node_ports.go:67-76 PreFilter, :148-176 Filter).  has_host_ports: the pod asks for at least
+     * one host port (util.GetHostPorts, S/util/utils.go:175-210; 0 = PreFilter Skip).  host_ports_conflict[n] = 1 iff a
+     * port held by an EXISTING pod of node n conflicts with one of them (HostPortInfo.CheckConflict,
+     * kube-scheduler/framework/types.go:499-528: ip / protocol strings, evaluated by the caller).  A clone holds the
+     * same ports as the next one, so a node takes at most one (NodeInfo.updateUsedPorts, S/framework/types.go:431-439):
+     * the engine keeps UsedPorts as one more resource column (allocatable 1). */
+    int32_t has_host_ports;
+    const uint8_t *host_ports_conflict; /* [n_nodes], NULL = no existing pod conflicts */
+    /* ImageLocality (P/imagelocality/image_locality.go:54-115): the node's score 0..100 for the pod's container images
+     * (sizes x spread over the snapshot's nodes: strings, evaluated by the caller); folded into the static word. */
+    const uint8_t *image_score; /* [n_nodes], NULL = 0 */
 } ccsim_pod;
 
 /* Scheduler profile: which plugins run and their weights/args.  Replaces
@@ -202,6 +215,7 @@ typedef struct {
      * CCSIM_MODE_SEQUENTIAL on one GPU only (ccsim_run / ccsim_schedule_one); snapshots with fewer than 100 nodes
      * are always searched completely. */
     int32_t percentage_of_nodes_to_score;
+    int32_t w_imagelocality; /* default 1 (default_plugins.go:49); 0 = disabled.  No NormalizeScore. */
 } ccsim_profile;
 
 /* Result of ccsim_run.  Replaces ClusterCapacity.Status{Pods, StopReason}

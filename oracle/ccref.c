@@ -120,8 +120,26 @@ int32_t ccref_num_feasible_nodes_to_find(int32_t percentage, int32_t num_all_nod
     return num;
 }
 
+/* P/imagelocality/image_locality.go:84-115: calculatePriority(sumImageScores(...), numContainers) */
+int64_t ccref_image_locality_score(const int64_t *size, const int32_t *num_nodes, int n_present, int32_t total_nodes,
+                                   int n_containers) {
+    const int64_t mb = 1024 * 1024, min_threshold = 23 * mb, max_container_threshold = 1000 * mb;
+    int64_t sum = 0;
+    for (int i = 0; i < n_present; i++) { /* scaledImageScore :105-108 */
+        double spread = (double)num_nodes[i] / (double)total_nodes;
+        sum += (int64_t)((double)size[i] * spread);
+    }
+    int64_t max_threshold = max_container_threshold * (int64_t)n_containers;
+    if (sum < min_threshold)
+        sum = min_threshold;
+    else if (sum > max_threshold)
+        sum = max_threshold;
+    return MAX_NODE_SCORE * (sum - min_threshold) / (max_threshold - min_threshold);
+}
+
 static int has_scoring(const ccref_profile *p) {
-    return p->w_taint || p->w_nodeaffinity || p->w_fit || p->w_balanced || p->w_topologyspread || p->w_interpodaffinity;
+    return p->w_taint || p->w_nodeaffinity || p->w_fit || p->w_balanced || p->w_topologyspread || p->w_interpodaffinity ||
+           p->w_imagelocality;
 }
 
 /* component-helpers nodeaffinity.go term.match: AND over requirements; empty term matches nothing */
@@ -320,7 +338,7 @@ typedef struct {
 } fail_info;
 
 static int filter_node(const ccref_profile *prof, const ccref_nodes *nd, const ccref_pod *pod, const pts_state *pts,
-                       const ipa_state *ipa, int64_t n, fail_info *fi) {
+                       const ipa_state *ipa, const int32_t *placed, int64_t n, fail_info *fi) {
     uint32_t fm = prof->filter_mask;
     /* P/nodeunschedulable/node_unschedulable.go:133-150 */
     if ((fm & CCREF_F_UNSCHEDULABLE) && nd->unschedulable && nd->unschedulable[n] && !pod->tolerates_unschedulable) {
@@ -337,6 +355,13 @@ static int filter_node(const ccref_profile *prof, const ccref_nodes *nd, const c
     if ((fm & CCREF_F_NODEAFFINITY) && pod->affinity_filter_active && !required_affinity_matches(nd, pod, n)) {
         fi->plugin = CCREF_F_NODEAFFINITY;
         return -2;
+    }
+    /* P/nodeports/node_ports.go:148-176 (PreFilter Skip for pods without host ports :67-76): the node's UsedPorts are
+     * those of its existing pods plus those of the clones placed on it */
+    if ((fm & CCREF_F_NODEPORTS) && pod->has_host_ports &&
+        ((pod->host_ports_conflict && pod->host_ports_conflict[n]) || (placed && placed[n] > 0))) {
+        fi->plugin = CCREF_F_NODEPORTS;
+        return -1;
     }
     /* P/noderesources/fit.go:564-660 fitsRequest: ALL insufficient resources are kept */
     if (fm & CCREF_F_FIT) {
@@ -599,7 +624,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
         for (int64_t i = 0; i < N; i++) {
             int64_t n = (start + i) % N;
             fail_info fi = {0, 0, 0, 0};
-            int r = filter_node(prof, nd, pod, pts, ipa, n, &fi);
+            int r = filter_node(prof, nd, pod, pts, ipa, ws->placed, n, &fi);
             ws->status[n] = (int8_t)r;
             if (r) ws->fails[n] = fi;
         }
@@ -615,7 +640,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
         for (int64_t i = 0; i < N; i++) {
             int64_t n = (start + i) % N;
             fail_info fi = {0, 0, 0, 0};
-            int r = filter_node(prof, nd, pod, pts, ipa, n, &fi);
+            int r = filter_node(prof, nd, pod, pts, ipa, ws->placed, n, &fi);
             if (r == 0) {
                 if (nf == num_to_find) break; /* :655-662 the (K+1)-th feasible node cancels the search */
                 ws->feas[nf++] = n;
@@ -651,6 +676,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
                     if (res->hist_taintset) res->hist_taintset[nd->taintset_id[n]]++;
                     break;
                 case CCREF_F_NODEAFFINITY: res->hist[CCREF_R_NODEAFFINITY]++; break;
+                case CCREF_F_NODEPORTS: res->hist[CCREF_R_NODEPORTS]++; break;
                 case CCREF_F_FIT:
                     if (fi->fit_mask & 1u) res->hist[CCREF_R_TOO_MANY_PODS]++;
                     for (int c = 0; c < CCREF_MAX_RES; c++)
@@ -733,6 +759,9 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
             for (int64_t i = 0; i < nf; i++)
                 ws->total[i] += balanced_score(prof, nd, pod, ws->feas[i]) * prof->w_balanced;
         }
+        /* ImageLocality (image_locality.go:54-66): no PreScore, no NormalizeScore */
+        if (prof->w_imagelocality && pod->image_score)
+            for (int64_t i = 0; i < nf; i++) ws->total[i] += (int64_t)pod->image_score[ws->feas[i]] * prof->w_imagelocality;
         /* selectHost, canonical tie-break: first maximum in feasible-list order */
         int64_t best = 0;
         for (int64_t i = 1; i < nf; i++)

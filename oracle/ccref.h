@@ -41,7 +41,8 @@ enum {
     CCREF_F_NODEAFFINITY = 1u << 3,  /* P/nodeaffinity */
     CCREF_F_FIT = 1u << 4,           /* P/noderesources/fit.go */
     CCREF_F_TOPOLOGYSPREAD = 1u << 5, /* P/podtopologyspread */
-    CCREF_F_INTERPODAFFINITY = 1u << 6 /* P/interpodaffinity */
+    CCREF_F_INTERPODAFFINITY = 1u << 6, /* P/interpodaffinity */
+    CCREF_F_NODEPORTS = 1u << 7 /* P/nodeports (runs between NodeAffinity and NodeResourcesFit, default_plugins.go:34-40) */
 };
 
 /* reason slots of the terminal-round histogram (S/framework/types.go:787-836) */
@@ -56,6 +57,7 @@ enum {
     CCREF_R_IPA_AFFINITY,      /* "node(s) didn't match pod affinity rules" (UnschedulableAndUnresolvable) */
     CCREF_R_IPA_ANTI,          /* "node(s) didn't match pod anti-affinity rules" */
     CCREF_R_IPA_EXISTING_ANTI, /* "node(s) didn't satisfy existing pods anti-affinity rules" */
+    CCREF_R_NODEPORTS,         /* "node(s) didn't have free ports for the requested pod ports" (P/nodeports/node_ports.go:39) */
     CCREF_NREASON
 };
 
@@ -162,6 +164,17 @@ typedef struct {
     ccref_spread_constraint spread[CCREF_MAX_TSC];
     int32_t has_ipa; /* 0 = no inter-pod (anti)affinity anywhere: PreFilter and PreScore return Skip */
     ccref_ipa ipa;
+    /* NodePorts (P/nodeports/node_ports.go:67-76,148-176).  has_host_ports = len(util.GetHostPorts(pod)) != 0
+     * (S/util/utils.go:175-210: hostPort > 0 of containers and restartable init containers; 0 => PreFilter Skip).
+     * host_ports_conflict[n] = 1 iff a port an EXISTING pod of node n holds conflicts with one of the pod's
+     * (HostPortInfo.CheckConflict, kube-scheduler/framework/types.go:499-528 -- ip / protocol strings: evaluated by the
+     * caller).  A simulated clone holds the same ports, so a node that took one clone conflicts with the next
+     * (NodeInfo.updateUsedPorts, S/framework/types.go:431-439). */
+    int32_t has_host_ports;
+    const uint8_t *host_ports_conflict; /* [n], NULL = none */
+    /* ImageLocality (P/imagelocality/image_locality.go:54-115): the node's score 0..100 for this pod's images -- image
+     * names are strings, so the caller evaluates ccref_image_locality_score per node.  NULL = 0 everywhere. */
+    const uint8_t *image_score; /* [n] */
 } ccref_pod;
 
 typedef struct {
@@ -177,6 +190,7 @@ typedef struct {
     int32_t n_bal_res;
     int32_t bal_res[CCREF_MAX_RES];
     int32_t percentage_of_nodes_to_score; /* 0 = adaptive (schedule_one.go:697-723) */
+    int32_t w_imagelocality; /* default 1 (default_plugins.go:49); no NormalizeScore */
 } ccref_profile;
 
 typedef struct {
@@ -233,6 +247,10 @@ int64_t ccref_balanced_allocation(const int64_t *requested, const int64_t *alloc
 void ccref_default_normalize(int64_t max_priority, int reverse, int64_t *scores, int64_t n);
 int32_t ccref_num_feasible_nodes_to_find(int32_t percentage, int32_t num_all_nodes);
 double ccref_go_log(double x); /* restatement of Go's math.Log (pure-Go path) */
+/* ImageLocality score of one node (image_locality.go:54-115): size[i] / num_nodes[i] = ImageStateSummary of the i-th
+ * pod container (incl. init containers) whose image the node holds; n_containers = len(InitContainers) + len(Containers) */
+int64_t ccref_image_locality_score(const int64_t *size, const int32_t *num_nodes, int n_present, int32_t total_nodes,
+                                   int n_containers);
 
 #ifdef __cplusplus
 }

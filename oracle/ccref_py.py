@@ -20,7 +20,8 @@ MAX_LABEL_COLS = 32
 MAX_TSC = 8
 MAX_IPA_KEYS = 4
 MAX_IPA_TERMS = 8
-NREASON = 4 + MAX_RES + 2 + 3
+NREASON = 4 + MAX_RES + 2 + 3 + 1
+R_NODEPORTS = NREASON - 1
 
 _p64 = C.POINTER(C.c_int64)
 _p32 = C.POINTER(C.c_int32)
@@ -101,6 +102,9 @@ class _Pod(C.Structure):
         ("spread", _Spread * MAX_TSC),
         ("has_ipa", C.c_int32),
         ("ipa", _Ipa),
+        ("has_host_ports", C.c_int32),
+        ("host_ports_conflict", _pu8),
+        ("image_score", _pu8),
     ]
 
 
@@ -119,6 +123,7 @@ class _Profile(C.Structure):
         ("n_bal_res", C.c_int32),
         ("bal_res", C.c_int32 * MAX_RES),
         ("percentage_of_nodes_to_score", C.c_int32),
+        ("w_imagelocality", C.c_int32),
     ]
 
 
@@ -166,6 +171,8 @@ def lib():
         _lib.ccref_num_feasible_nodes_to_find.argtypes = [C.c_int32, C.c_int32]
         _lib.ccref_go_log.restype = C.c_double
         _lib.ccref_go_log.argtypes = [C.c_double]
+        _lib.ccref_image_locality_score.restype = C.c_int64
+        _lib.ccref_image_locality_score.argtypes = [_p64, _p32, C.c_int, C.c_int32, C.c_int]
     return _lib
 
 
@@ -266,6 +273,11 @@ class _Marshal:
         s.has_ipa = int(ipa is not None)
         if ipa is not None:
             fill_ipa(s.ipa, ipa, self.arr)
+        s.has_host_ports = int(bool(getattr(pod, "has_host_ports", False)))
+        if getattr(pod, "host_ports_conflict", None) is not None:
+            s.host_ports_conflict = self.arr(pod.host_ports_conflict, np.uint8, _pu8)
+        if getattr(pod, "image_score", None) is not None:
+            s.image_score = self.arr(pod.image_score, np.uint8, _pu8)
         return s
 
     def profile(self, p) -> _Profile:
@@ -282,6 +294,7 @@ class _Marshal:
         for i, c in enumerate(p.bal_res):
             s.bal_res[i] = int(c)
         s.percentage_of_nodes_to_score = int(p.percentage_of_nodes_to_score)
+        s.w_imagelocality = int(getattr(p, "w_imagelocality", 0))
         return s
 
 
@@ -417,3 +430,9 @@ def num_feasible_nodes_to_find(percentage, n):
 
 def go_log(x):
     return float(lib().ccref_go_log(float(x)))
+
+
+def image_locality_score(sizes, num_nodes, total_nodes, n_containers):
+    """ImageLocality score of one node: sizes / num_nodes of the pod's container images the node holds."""
+    sz, nn = np.ascontiguousarray(sizes, dtype=np.int64), np.ascontiguousarray(num_nodes, dtype=np.int32)
+    return int(lib().ccref_image_locality_score(_ptr(sz, _p64), _ptr(nn, _p32), len(sz), int(total_nodes), int(n_containers)))

@@ -90,8 +90,8 @@ int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *n) {
 int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
     FILE *f = e->f;
     sep(e);
-    fprintf(f, "\"profile\": {\"filter_mask\": %u, \"w\": [%d, %d, %d, %d, %d, %d], \"pct\": %d, ", p->filter_mask, p->w_taint, p->w_nodeaffinity, p->w_fit,
-            p->w_balanced, p->w_topologyspread, p->w_interpodaffinity, p->percentage_of_nodes_to_score);
+    fprintf(f, "\"profile\": {\"filter_mask\": %u, \"w\": [%d, %d, %d, %d, %d, %d, %d], \"pct\": %d, ", p->filter_mask, p->w_taint, p->w_nodeaffinity, p->w_fit,
+            p->w_balanced, p->w_topologyspread, p->w_interpodaffinity, p->w_imagelocality, p->percentage_of_nodes_to_score);
     arr32(f, "fit_res", p->fit_res, p->n_fit_res), fprintf(f, ", ");
     arr64(f, "fit_res_w", p->fit_res_w, p->n_fit_res), fprintf(f, ", ");
     arr32(f, "bal_res", p->bal_res, p->n_bal_res);
@@ -161,6 +161,9 @@ int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *p) {
         for (int k = 0; k < a->n_keys; k++) { fprintf(f, "%s{", k ? ", " : ""); arr64(f, "v", a->score_existing[k], N); fprintf(f, "}"); }
         fprintf(f, "]}");
     }
+    fprintf(f, ", \"has_host_ports\": %d, ", p->has_host_ports);
+    arr8(f, "host_ports_conflict", p->host_ports_conflict, N), fprintf(f, ", ");
+    arr8(f, "image_score", p->image_score, N);
     fprintf(f, "}");
     return 0;
 }

@@ -11,6 +11,7 @@ CASES = {
     "c2_n1000": ("synth", "C2", 1000, 11, 0), "c3_n1000": ("synth", "C3", 1000, 12, 0), "c3_n4096_l700": ("synth", "C3", 4096, 13, 700),
     "c3_n1": ("synth", "C3", 1, 14, 0), "c3_n513_l50": ("synth", "C3", 513, 15, 50),
     **{f"random_{s}": ("random", s) for s in range(8)},
+    **{f"random_ports_images_{s}": ("random_pi", s) for s in range(4)},
 }
 
 
@@ -23,8 +24,10 @@ def build(name):
     if spec[0] == "synth":
         nodes, pod, prof = synth.make_config(spec[1], n_nodes=spec[2], seed=spec[3])
         return nodes, pod, prof, spec[4]
-    rng = np.random.default_rng(1000 + spec[1])
+    rng = np.random.default_rng((1000 if spec[0] == "random" else 2000) + spec[1])
     nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 1200)))
+    if spec[0] == "random_pi":
+        nodes, pod, prof = H.with_ports_and_images(rng, nodes, pod, prof)
     return nodes, pod, prof, int(rng.choice([0, 0, 37, 500]))
 
 

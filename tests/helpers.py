@@ -88,6 +88,21 @@ def random_case(rng, n):
     return nodes, pod, prof
 
 
+def with_ports_and_images(rng, nodes, pod, prof):
+    """Random host-port conflicts / ImageLocality scores on top of a random_case() (kept apart: the golden vectors of the
+    plain cases depend on random_case()'s random stream)."""
+    n = nodes.n
+    if rng.integers(0, 3):
+        pod.has_host_ports = True
+        pod.host_ports_conflict = (rng.random(n) < 0.2).astype(np.uint8) if rng.integers(0, 2) else None
+    if rng.integers(0, 3):
+        pod.image_score = (rng.integers(0, 101, n) * (rng.random(n) < 0.5)).astype(np.uint8)
+    prof.w_imagelocality = int(rng.integers(0, 3))
+    if rng.integers(0, 4) == 0:
+        prof.filter_mask &= ~M.F_NODEPORTS
+    return nodes, pod, prof
+
+
 def random_spread(rng, nodes, n_constraints=None):
     """Random hard topology spread constraints over the two label columns of random_case() snapshots
     (value id 0 = key absent, which exercises the missing-label path)."""

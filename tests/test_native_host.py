@@ -47,7 +47,8 @@ def py_dump(snap):
                 "spread": [{"col": int(k.col), "max_skew": int(k.max_skew), "min_domains": int(k.min_domains), "hard": bool(k.hard),
                             "self_match": bool(k.self_match), "is_hostname": bool(k.is_hostname), "n_domains": int(k.n_domains),
                             "node_match_count": lst(k.node_match_count), "node_included": lst(k.node_included)} for k in p.spread],
-                "ipa": ipa}}
+                "ipa": ipa, "has_host_ports": bool(p.has_host_ports), "host_ports_conflict": lst(p.host_ports_conflict),
+                "image_score": lst(p.image_score)}}
 
 
 def rich_cluster():
@@ -124,6 +125,24 @@ def rich_pod():
     return pod
 
 
+def ports_images_case():
+    """Host ports (a conflict on one node through 0.0.0.0, none through another ip / protocol) and node images."""
+    mb = 1024 * 1024
+    nodes = [node(f"w{i}") for i in range(5)]
+    nodes[0]["status"]["images"] = [{"names": ["gcr.io/40:latest", "gcr.io/40@sha256:abc"], "sizeBytes": 40 * mb}]
+    nodes[1]["status"]["images"] = [{"names": ["gcr.io/250:latest"], "sizeBytes": 250 * mb}, {"names": ["gcr.io/40:latest"], "sizeBytes": 41 * mb}]
+    nodes[2]["status"]["images"] = [{"names": ["gcr.io/2000"], "sizeBytes": 2000 * mb}]
+    pods = [running_pod("holder", "w3"), running_pod("other-ip", "w4"), running_pod("udp", "w2")]
+    pods[0]["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": 8080}]
+    pods[1]["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": 8080, "hostIP": "10.0.0.9"}]
+    pods[2]["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": 8080, "protocol": "UDP"}]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["spec"]["containers"][0]["image"] = "gcr.io/40"
+    pod["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": 8080, "hostIP": "10.0.0.1"}]
+    pod["spec"]["containers"].append({"name": "big", "image": "gcr.io/250:latest"})
+    return nodes, pods, pod, []
+
+
 CASES = {
     "readme": lambda: ([node(f"kube-node-{i}", cpu="2", mem="4G") for i in range(1, 5)], [], yaml.safe_load(EXAMPLES_POD), []),
     "taints-selectors": lambda: (
@@ -134,6 +153,7 @@ CASES = {
          running_pod("elsewhere", "zzz", cpu="1")],
         dict(yaml.safe_load(EXAMPLES_POD), spec=dict(yaml.safe_load(EXAMPLES_POD)["spec"], nodeSelector={"disk": "ssd"})), ["b"]),
     "rich": lambda: (*rich_cluster(), rich_pod(), ["n04"]),
+    "ports-images": lambda: ports_images_case(),
 }
 
 
@@ -408,8 +428,8 @@ def test_native_scheduler_config(native, tmp_path):
     d = _profile(native, tmp_path)
     p = M.Profile.default()
     assert d == {"filter_mask": p.filter_mask, "w_taint": 3, "w_nodeaffinity": 2, "w_fit": 1, "w_balanced": 1, "w_topologyspread": 2,
-                 "w_interpodaffinity": 2, "fit_res": [0, 1], "fit_res_w": [1, 1], "bal_res": [0, 1], "percentage_of_nodes_to_score": 100,
-                 "hard_pod_affinity_weight": 1}
+                 "w_interpodaffinity": 2, "w_imagelocality": 1, "fit_res": [0, 1], "fit_res_w": [1, 1], "bal_res": [0, 1],
+                 "percentage_of_nodes_to_score": 100, "hard_pod_affinity_weight": 1}
     d = _profile(native, tmp_path, SCHED_CONFIG)
     assert d["filter_mask"] == M.F_ALL & ~M.F_UNSCHEDULABLE
     assert (d["w_taint"], d["w_nodeaffinity"], d["w_fit"], d["w_balanced"], d["w_topologyspread"], d["w_interpodaffinity"]) == (7, 1, 1, 0, 5, 2)
@@ -455,7 +475,8 @@ def _py_profile_dump(cfg):
     from cluster_capacity_amd import schedconfig
     p, hard = schedconfig.profile_from_config(cfg)
     return {"filter_mask": p.filter_mask, "w_taint": p.w_taint, "w_nodeaffinity": p.w_nodeaffinity, "w_fit": p.w_fit, "w_balanced": p.w_balanced,
-            "w_topologyspread": p.w_topologyspread, "w_interpodaffinity": p.w_interpodaffinity, "fit_res": list(p.fit_res),
+            "w_topologyspread": p.w_topologyspread, "w_interpodaffinity": p.w_interpodaffinity, "w_imagelocality": p.w_imagelocality,
+            "fit_res": list(p.fit_res),
             "fit_res_w": list(p.fit_res_w), "bal_res": list(p.bal_res), "percentage_of_nodes_to_score": p.percentage_of_nodes_to_score,
             "hard_pod_affinity_weight": hard}
 
@@ -710,6 +731,29 @@ def _random_objects(rng):
     # Namespace objects travel with the pods (simulator.go:177-185); "third" has none -> no labels
     pods += [{"kind": "Namespace", "metadata": {"name": "default", "labels": {"team": "a", "kubernetes.io/metadata.name": "default"}}},
              {"kind": "Namespace", "metadata": {"name": "other", "labels": {"team": str(rng.choice(["a", "b"]))}}}]
+    # host ports (NodePorts) and node images (ImageLocality)
+    def rand_ports():
+        return [{k: v for k, v in (("containerPort", 80), ("hostPort", int(rng.choice([0, 8080, 8080, 9090]))),
+                                   ("protocol", str(rng.choice(["TCP", "UDP", ""]))), ("hostIP", str(rng.choice(["", "0.0.0.0", "10.0.0.1", "10.0.0.2"])))) if v != ""}
+                for _ in range(int(rng.integers(1, 3)))]
+    for p in pods:
+        if p.get("kind") == "Pod" and rng.random() < 0.3:
+            p["spec"]["containers"][0]["ports"] = rand_ports()
+    if rng.random() < 0.5:
+        spec["containers"][int(rng.integers(0, len(spec["containers"])))]["ports"] = rand_ports()
+    if rng.random() < 0.2 and spec.get("initContainers"):
+        spec["initContainers"][0]["ports"] = rand_ports()
+    images = ["gcr.io/google-samples/gb-frontend:v4", "registry.k8s.io/pause", "registry.k8s.io/pause:latest", "localhost:5000/app", "busybox"]
+    for c in spec["containers"][1:] + (spec.get("initContainers") or []):
+        if rng.random() < 0.7:
+            c["image"] = str(rng.choice(images))
+    for nd in nodes:
+        if rng.random() < 0.6:
+            nd["status"]["images"] = [{"names": [str(x) for x in rng.choice(images + ["busybox:latest", "localhost:5000/app:latest"], int(rng.integers(1, 3)), replace=False)],
+                                       "sizeBytes": int(rng.choice([5_000_000, 120_000_000, 900_000_000, 2_500_000_000]))}
+                                      for _ in range(int(rng.integers(1, 4)))]
+    if rng.random() < 0.05:
+        spec["volumes"] = [{"name": "data", "persistentVolumeClaim": {"claimName": "pvc"}}]
     return nodes, pods, pod, exclude
 
 

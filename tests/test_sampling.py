@@ -134,7 +134,7 @@ def test_profile_without_score_plugins_keeps_the_first_feasible_node(ccref, cfg,
     """schedule_one.go:619-621: no Score plugin -> numNodesToFind = 1, for every snapshot size: the first feasible node of the
     rotating visiting order is bound, the search stops at the second feasible node, nextStartNodeIndex moves past it."""
     nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=5 + n)
-    prof = dataclasses.replace(prof, w_taint=0, w_nodeaffinity=0, w_fit=0, w_balanced=0, w_topologyspread=0, w_interpodaffinity=0)
+    prof = dataclasses.replace(prof, w_taint=0, w_nodeaffinity=0, w_fit=0, w_balanced=0, w_topologyspread=0, w_interpodaffinity=0, w_imagelocality=0)
     e, got, ref = _check(ccref, nodes, pod, prof, limit)
     if limit == 0:
         assert got.placed > n  # the rotation spreads clones round the cluster instead of filling node 0 first
