@@ -125,6 +125,10 @@ SYMBOLS = {
     "ccsim_dist_table": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),
     "ccsim_dist_tables_done": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_unique_id": (C.c_int, [_pu8]),
+    "ccsim_dist_comm_init": (C.c_int, [C.c_void_p, _pu8, C.c_int32, C.c_int32]),
+    "ccsim_dist_sync_tables": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
     "ccsim_reset_state": (C.c_int, [C.c_void_p]),
     "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ccsim_debug_persist_prof": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
@@ -168,6 +172,18 @@ def _ptr(a, t):
 
 class CcsimError(RuntimeError):
     pass
+
+
+DIST_ID_BYTES = 128
+
+
+def dist_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0; hand the bytes to every rank, e.g. torch.distributed.broadcast_object_list)."""
+    buf = (C.c_uint8 * DIST_ID_BYTES)()
+    rc = load().ccsim_dist_unique_id(buf)
+    if rc != 0:
+        raise CcsimError(f"ccsim_dist_unique_id failed rc={rc} (librccl.so.1 not loadable?)")
+    return bytes(buf)
 
 
 def marshal_nodes(nodes: M.NodesSoA, keep: list, global_offset: int = 0, n_global: Optional[int] = None) -> CNodes:
@@ -485,6 +501,19 @@ class Engine:
         done, placed = C.c_int32(), C.c_int64()
         self._chk(self.lib.ccsim_dist_poll(self.h, C.byref(done), C.byref(placed)), "ccsim_dist_poll")
         return int(done.value), int(placed.value)
+
+    # ---- ... or the whole sharded run inside the library, over its own RCCL communicator ----
+    def dist_comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
+        buf = (C.c_uint8 * DIST_ID_BYTES).from_buffer_copy(unique_id)
+        self._chk(self.lib.ccsim_dist_comm_init(self.h, buf, int(n_ranks), int(rank)), "ccsim_dist_comm_init")
+
+    def dist_sync_tables(self):
+        self._chk(self.lib.ccsim_dist_sync_tables(self.h), "ccsim_dist_sync_tables")
+
+    def dist_run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0) -> M.RunResult:
+        rep, per_node, log, ht = self._report(want_log, log_cap)
+        self._chk(self.lib.ccsim_dist_run(self.h, int(max_limit), MODES[mode], C.byref(rep)), "ccsim_dist_run")
+        return self._result(rep, per_node, log, ht)
 
     def dist_finish(self, want_log: bool = False, log_cap: int = 0) -> M.RunResult:
         rep, per_node, log, ht = self._report(want_log, log_cap)

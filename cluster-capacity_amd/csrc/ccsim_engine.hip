@@ -11,6 +11,7 @@
 #include "ccsim_persist.h"
 #include "ccsim_multi.h"
 
+#include <dlfcn.h>
 #include <errno.h>
 #include <hip/hip_ext.h>
 #include <stdarg.h>
@@ -88,6 +89,11 @@ struct ccsim_engine {
     int64_t smp_start_cur = 0;          // nextStartNodeIndex after the runs so far
     XRec *d_xsend = nullptr, *d_xrecv = nullptr; // distributed exchange (caller's or ours)
     int n_ranks = 0;
+    // the engine's own RCCL communicator (ccsim_dist_comm_init) and exchange buffers: ccsim_dist_run drives the whole
+    // sharded run -- scan, all-gather, decide -- from C++
+    void *rccl_comm = nullptr;
+    int comm_ranks = 0, comm_rank = 0;
+    XRec *d_own_send = nullptr, *d_own_recv = nullptr;
     int32_t *d_log = nullptr;
     int64_t log_cap = 0;
     unsigned long long *d_hist = nullptr, *d_hist_ts = nullptr, *d_hist_code = nullptr;
@@ -202,6 +208,8 @@ static void drop_graph(ccsim_engine *e) {
     e->graph_mode = -1;
 }
 
+static void dist_comm_release(ccsim_engine *e);
+
 extern "C" int32_t ccsim_abi_version(void) { return CCSIM_ABI_VERSION; }
 
 extern "C" const char *ccsim_last_error(const ccsim_engine *e) { return e ? e->err.c_str() : "null engine"; }
@@ -268,6 +276,7 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->d_psync) (void)hipFree(e->d_psync);
     if (e->d_log) (void)hipFree(e->d_log);
     if (e->h_state) (void)hipHostFree(e->h_state);
+    dist_comm_release(e);
     for (hipEvent_t ev : e->pass_events) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1191,7 +1200,7 @@ static int run_persist(ccsim_engine *e, int k) {
     a.max_syncs = 1 << 20;
     a.seq_steps = 8;
     if (const char *f = getenv("CCSIM_SEQ_STEPS")) a.seq_steps = atoi(f) > 0 ? atoi(f) : kSeqSteps; // tuning knob
-    a.level_batch = 16;
+    a.level_batch = 32; // measured on the C4 snapshot (profiles/r02/persist_phase_profile.txt): 1 -> 7.96 ms, 16 -> 1.90 ms, 32 -> 1.65 ms per run
     if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
@@ -1461,6 +1470,134 @@ extern "C" int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out) {
     int rc = read_state(e);
     if (rc) return rc;
     return fill_report(e, out);
+}
+
+// ================================================================================================================
+// The sharded run driven from C++ over the engine's own RCCL communicator (include/ccsim.h "multi-GPU, driven by the
+// library").  RCCL is bound at run time (dlopen): libccsim.so has no link-time dependency on it and single-GPU users
+// never load it.  In a process that already holds an RCCL (torch ships one) the same library is reused (same SONAME).
+// ================================================================================================================
+namespace {
+struct CcNcclId { char internal[CCSIM_DIST_ID_BYTES]; }; // ncclUniqueId (rccl.h:40-43)
+struct RcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(CcNcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, CcNcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+constexpr int kNcclInt32 = 2, kNcclInt64 = 4, kNcclSum = 0, kNcclMax = 2; // rccl.h:448-463
+
+RcclApi &rccl() {
+    static RcclApi a;
+    if (a.h || !a.err.empty()) return a;
+    const char *names[] = {getenv("CCSIM_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        a.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (a.h) break;
+    }
+    if (!a.h) {
+        a.err = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+        return a;
+    }
+    auto sym = [&](const char *n) -> void * {
+        void *p = dlsym(a.h, n);
+        if (!p && a.err.empty()) a.err = std::string("librccl lacks ") + n;
+        return p;
+    };
+    a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+    a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+    if (!a.err.empty()) a.h = nullptr;
+    return a;
+}
+} // namespace
+
+#define RCCLCHK(e, call)                                                                                  \
+    do {                                                                                                  \
+        const int rccl_rc_ = (call);                                                                      \
+        if (rccl_rc_ != 0) return fail(e, -EIO, "RCCL: %s failed: %s", #call, rccl().GetErrorString(rccl_rc_)); \
+    } while (0)
+
+static void dist_comm_release(ccsim_engine *e) {
+    if (e->rccl_comm && rccl().h) (void)rccl().CommDestroy(e->rccl_comm);
+    e->rccl_comm = nullptr;
+    if (e->d_own_send) (void)hipFree(e->d_own_send);
+    if (e->d_own_recv) (void)hipFree(e->d_own_recv);
+    e->d_own_send = e->d_own_recv = nullptr;
+}
+
+extern "C" int ccsim_dist_unique_id(uint8_t *id_out) {
+    if (!id_out) return -EINVAL;
+    RcclApi &r = rccl();
+    if (!r.h) return -EIO;
+    CcNcclId id;
+    if (r.GetUniqueId(&id) != 0) return -EIO;
+    memcpy(id_out, id.internal, CCSIM_DIST_ID_BYTES);
+    return 0;
+}
+
+extern "C" int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id_bytes, int32_t n_ranks, int32_t rank) {
+    if (!e || !id_bytes || n_ranks < 1 || rank < 0 || rank >= n_ranks) return -EINVAL;
+    RcclApi &r = rccl();
+    if (!r.h) return fail(e, -EIO, "%s", r.err.c_str());
+    HIPCHK(e, hipSetDevice(e->device));
+    dist_comm_release(e);
+    CcNcclId id;
+    memcpy(id.internal, id_bytes, CCSIM_DIST_ID_BYTES);
+    RCCLCHK(e, r.CommInitRank(&e->rccl_comm, n_ranks, id, rank));
+    e->comm_ranks = n_ranks, e->comm_rank = rank;
+    HIPCHK(e, hipMalloc((void **)&e->d_own_send, sizeof(XRec)));
+    HIPCHK(e, hipMalloc((void **)&e->d_own_recv, sizeof(XRec) * (size_t)n_ranks));
+    HIPCHK(e, hipMemset(e->d_own_send, 0, sizeof(XRec)));
+    HIPCHK(e, hipMemset(e->d_own_recv, 0, sizeof(XRec) * (size_t)n_ranks));
+    return 0;
+}
+
+extern "C" int ccsim_dist_sync_tables(ccsim_engine *e) {
+    if (!e || !e->have_pod) return -EINVAL;
+    if (!e->rccl_comm) return fail(e, -EINVAL, "ccsim_dist_comm_init first");
+    if (e->dist_tables.empty()) return 0;
+    HIPCHK(e, hipSetDevice(e->device));
+    for (const auto &t : e->dist_tables)
+        RCCLCHK(e, rccl().AllReduce(t.ptr, t.ptr, (size_t)t.len, t.elem_bytes == 8 ? kNcclInt64 : kNcclInt32, t.op == 1 ? kNcclMax : kNcclSum,
+                                    e->rccl_comm, e->stream));
+    return ccsim_dist_tables_done(e);
+}
+
+extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
+    if (!e || !out) return -EINVAL;
+    if (!e->rccl_comm) return fail(e, -EINVAL, "ccsim_dist_comm_init first");
+    static_assert(sizeof(XRec) == CCSIM_XCHG_WORDS * 8, "exchange record size");
+    int rc = ccsim_dist_begin(e, max_limit, mode, e->comm_ranks, e->comm_rank, e->d_own_send, e->d_own_recv, out->log ? out->log_cap : 0);
+    if (rc) return rc;
+    int per_poll = 32;
+    if (const char *f = getenv("CCSIM_DIST_POLL")) per_poll = atoi(f) > 0 ? atoi(f) : per_poll; // tuning knob (the SAME value on every rank)
+    int64_t last_placed = -1;
+    int idle = 0;
+    for (;;) {
+        for (int p = 0; p < per_poll; p++) {
+            if ((rc = ccsim_dist_scan(e))) return rc;
+            // the max-loc exchange: one 256-byte record per rank, on the engine's stream (ordered with the kernels, no host sync)
+            RCCLCHK(e, rccl().AllGather(e->d_own_send, e->d_own_recv, CCSIM_XCHG_WORDS, kNcclInt64, e->rccl_comm, e->stream));
+            if ((rc = ccsim_dist_decide(e))) return rc;
+        }
+        int32_t done = 0;
+        int64_t placed = 0;
+        if ((rc = ccsim_dist_poll(e, &done, &placed))) return rc;
+        if (done) break;
+        idle = placed == last_placed ? idle + 1 : 0; // (identical on every rank: the state is replicated)
+        last_placed = placed;
+        if (idle >= 64) return fail(e, -EIO, "sharded simulation made no progress in %d passes", 64 * per_poll);
+    }
+    return ccsim_dist_finish(e, out);
 }
 
 // ================================================================================================================

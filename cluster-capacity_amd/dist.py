@@ -1,5 +1,12 @@
 """Multi-GPU driver: one process per GPU, node-range shards, one RCCL collective per round.
 
+Two drivers of the same protocol (include/ccsim.h):
+  * LibraryRunner (default on GPUs): the whole sharded run inside libccsim.so -- ccsim_dist_run enqueues scan ->
+    ncclAllGather -> decide from C++ on the engine's stream, over the engine's own RCCL communicator; torch.distributed only
+    carries the 128-byte ncclUniqueId to the ranks (and the bench's barriers).
+  * DistRunner: the stepwise entry points with a caller-supplied collective (torch.distributed all_gather; the gloo CPU
+    tests use it with a stand-in engine; CCSIM_DIST_DRIVER=python selects it on GPUs for A/B runs).
+
 torch.distributed is plumbing here (process group + the collective over xGMI); the shard work is
 the HIP engine.  Protocol per pass (include/ccsim.h "multi-GPU stepping"; a pass is one placement
 round in sequential mode and one whole score level -- many rounds -- in batched mode):
@@ -102,11 +109,44 @@ def sync_tables(engine, device: int):
     engine.dist_tables_done()
 
 
-def make_torch_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int, n_global: int,
-                      device: int, rounds_per_poll: int = 32) -> DistRunner:
+class LibraryRunner:
+    """The sharded run driven inside libccsim.so (ccsim_dist_run) over the engine's own RCCL communicator."""
+
+    def __init__(self, engine, world: int, rank: int):
+        self.engine, self.world, self.rank = engine, world, rank
+
+    def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0) -> M.RunResult:
+        return self.engine.dist_run(max_limit, mode, want_log, log_cap)
+
+
+def make_library_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int, n_global: int,
+                        device: int) -> LibraryRunner:
+    """One rank of a torch.distributed job: load the shard, rendezvous the engine's RCCL communicator (rank 0's
+    ncclUniqueId travels through torch.distributed), all-reduce the replicated topology tables inside the library."""
     import torch
     import torch.distributed as dist
 
+    torch.cuda.set_device(device)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    eng = capi.Engine(device=device, use_graph=False)
+    eng.load(nodes_shard, pod, profile, global_offset=global_offset, n_global=n_global)
+    ids = [capi.dist_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    eng.dist_comm_init(ids[0], world, rank)
+    if eng.dist_tables():
+        eng.dist_sync_tables()
+    return LibraryRunner(eng, world, rank)
+
+
+def make_torch_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int, n_global: int,
+                      device: int, rounds_per_poll: int = 32):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    if os.environ.get("CCSIM_DIST_DRIVER", "library") != "python":
+        return make_library_runner(nodes_shard, pod, profile, global_offset, n_global, device)
     torch.cuda.set_device(device)
     # a real (non-default) torch stream: the engine enqueues on it and RCCL orders against it.  The legacy
     # default stream has handle 0, which the C ABI reads as "create your own stream".

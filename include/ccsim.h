@@ -320,6 +320,23 @@ int ccsim_dist_decide(ccsim_engine *e);
 int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed);
 int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out);
 
+/* ---- multi-GPU, driven by the library: the same protocol with the loop and the collective inside libccsim.so ----
+ * The engine owns an RCCL communicator (librccl.so.1 is bound with dlopen the first time one of these is called: no
+ * link-time dependency) and its exchange buffers; ccsim_dist_run enqueues scan -> ncclAllGather (256 B per rank over
+ * xGMI, on the engine's stream) -> decide for 32 passes per host poll, until every rank's replicated state says done.
+ * Rendezvous is the caller's: rank 0 calls ccsim_dist_unique_id and distributes the 128 bytes by any means (the Python
+ * host: torch.distributed.broadcast_object_list; a cgo host: whatever the job launcher offers), then every rank calls
+ * ccsim_dist_comm_init (collective) after ccsim_load_nodes of ITS shard.  ccsim_dist_sync_tables replaces the caller-side
+ * all-reduce of ccsim_dist_table (collective; call it after every ccsim_set_pod). */
+#define CCSIM_DIST_ID_BYTES 128
+int ccsim_dist_unique_id(uint8_t *id_out /* [CCSIM_DIST_ID_BYTES] */);
+int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id /* [CCSIM_DIST_ID_BYTES] */, int32_t n_ranks, int32_t rank);
+int ccsim_dist_sync_tables(ccsim_engine *e);
+/* ClusterCapacity.Run on the sharded snapshot: every rank calls it with the same max_limit / mode; out describes THIS
+ * shard (per_node_count, hist) plus the global totals (placed, stop, rounds); with a log each rank fills its own
+ * placements (-1 elsewhere), as ccsim_dist_finish does. */
+int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out);
+
 /* Topology-coupled plugins on several GPUs (hard PodTopologySpread constraints, InterPodAffinity): the per-domain
  * count / score tables are replicated on every rank, but ccsim_set_pod can only fill them from the rank's own nodes.
  * After ccsim_set_pod on every rank the caller all-reduces each table in place across ranks (table i:
