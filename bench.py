@@ -107,6 +107,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:  # CCSIM_FORCE_DIST=1 without a launcher: a one-rank job on this GPU
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29513")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     limit = args.limit if args.limit >= 0 else (0 if args.mode == "batched" else 2048)
     n_global = args.nodes * world if args.scaling == "weak" else args.nodes

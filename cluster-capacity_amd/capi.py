@@ -142,7 +142,7 @@ def load(build_if_missing: bool = True):
     """dlopen libccsim.so and bind every declared symbol (raises if one is missing)."""
     global _lib
     if _lib is None:
-        path = _build.lib_path()
+        path = os.environ.get("CCSIM_LIB") or _build.lib_path()  # CCSIM_LIB: another build of the same ABI (A/B timing runs)
         if not os.path.exists(path):
             if not build_if_missing:
                 raise FileNotFoundError(path)

@@ -436,6 +436,8 @@ extern "C" int ccsim_set_profile(ccsim_engine *e, const ccsim_profile *p) {
     }
     for (int i = 0; i < p->n_bal_res; i++)
         if (p->bal_res[i] < 0 || p->bal_res[i] >= CCSIM_MAX_RES) return fail(e, -EINVAL, "BalancedAllocation resource column out of range");
+    for (int32_t w : {p->w_taint, p->w_nodeaffinity, p->w_fit, p->w_balanced, p->w_topologyspread, p->w_interpodaffinity, p->w_imagelocality})
+        if (w < 0 || w > 1000000) return fail(e, -EINVAL, "plugin weight out of [0, 1000000]");
     e->prof = *p;
     e->have_profile = true;
     e->have_pod = false;
@@ -1200,7 +1202,7 @@ static int run_persist(ccsim_engine *e, int k) {
     a.max_syncs = 1 << 20;
     a.seq_steps = 8;
     if (const char *f = getenv("CCSIM_SEQ_STEPS")) a.seq_steps = atoi(f) > 0 ? atoi(f) : kSeqSteps; // tuning knob
-    a.level_batch = 32; // measured on the C4 snapshot (profiles/r02/persist_phase_profile.txt): 1 -> 7.96 ms, 16 -> 1.90 ms, 32 -> 1.65 ms per run
+    a.level_batch = 64; // measured on the C4 snapshot (profiles/r02/persist_phase_profile.txt): 1 -> 7.96 ms, 16 -> 1.97 ms, 32 -> 1.66 ms, 64 -> 1.57 ms, 128 -> 1.64 ms per run
     if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
@@ -1682,6 +1684,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
             if (++hard > kMTsc) return fail(e, -ENOSYS, "several pod specs: more than %d DoNotSchedule constraints (spec %d)", kMTsc, p);
             if (k.col < 0 || k.col >= e->n_label_cols || k.max_skew < 1 || k.min_domains < 1) return fail(e, -EINVAL, "bad spread constraint (spec %d)", p);
             if (k.n_domains < 0 || k.n_domains > kMDomMax - 1) return fail(e, -ENOSYS, "several pod specs: spread constraints over more than %d domains (spec %d)", kMDomMax - 1, p);
+            if (e->label_col_max[(size_t)k.col] > k.n_domains) return fail(e, -EINVAL, "spread constraint: label column holds value ids above n_domains (spec %d)", p);
             int sl = slot_col[0] == k.col ? 0 : (slot_col[1] == k.col ? 1 : -1);
             if (sl < 0) {
                 sl = slot_col[0] < 0 ? 0 : (slot_col[1] < 0 ? 1 : -1);
@@ -1822,6 +1825,8 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     for (int sl = 0; sl < kMTsc; sl++) e->tsc_label[sl] = slot_col[sl] >= 0 ? e->dev_label_ptrs[(size_t)slot_col[sl]] : nullptr;
     e->multi_prof = make_devpod(e, &pods[0]); // profile-level constants; the per-pod switches come from MPod
     if (e->multi_prof.gen_score) return fail(e, -ENOSYS, "several pod specs: scoring resource lists beyond cpu / memory");
+    if (100ll * ((int64_t)pf.w_taint + pf.w_nodeaffinity + pf.w_fit + pf.w_balanced + pf.w_imagelocality) >= (1ll << 21))
+        return fail(e, -ENOSYS, "several pod specs: plugin weights too large for the scan's packed 32-bit keys");
     e->multi_window = kMWindowMax;
     if (const char *f = getenv("CCSIM_MULTI_WINDOW")) e->multi_window = atoi(f) >= 1 && atoi(f) <= kMWindowMax ? atoi(f) : kMWindowMax; // tuning knob
     HIPCHK(e, hipStreamSynchronize(e->stream));

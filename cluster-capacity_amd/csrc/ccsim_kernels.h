@@ -461,6 +461,27 @@ __device__ __forceinline__ int64_t dynamic_score_gen(const DevPod &p, int64_t a_
     return total;
 }
 
+// a value every lane holds identically: tell the compiler, so that it lives in an SGPR
+__device__ __forceinline__ int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// floor(100 * c / m) for c <= m, 0 < m < 2^13 (DefaultNormalizeScore, normalize_score.go:28-56) without a runtime division per
+// node: m is a normalization maximum, uniform over the launch, so the magic below is loop-invariant (hoisted by the compiler).
+// floor(n / m) == mulhi(n, ceil(2^32 / m)) whenever n * m < 2^32 (Granlund-Montgomery: the error term n (M m - 2^32) / (m 2^32)
+// stays below 1 / m); with n = 100 c <= 100 m that holds for m <= 6553.  (c > m only happens under a stale ASSUMED maximum,
+// whose pass is thrown away by the verification that follows.)
+// The magic is derived with an fp64 division, not an integer one: it has no trap, so the compiler may hoist it out of loops and
+// conditionals (an integer division by a value it cannot prove non-zero stays where it is -- measured: 63 VALU instructions
+// per evaluation).  For 2 <= m < 2^13 the fp64 quotient 2^32 / m truncates to floor(2^32 / m) exactly (a non-integral
+// quotient is at least 2^-13 away from the next integer, the rounding error is below 2^-20), so magic >= ceil(2^32 / m) and
+// magic * m - 2^32 <= m: the exactness bound above.
+__device__ __forceinline__ uint32_t div_magic(uint32_t m) { return (uint32_t)(4294967296.0 / (double)(m < 2u ? 2u : m)) + 1u; }
+__device__ __forceinline__ uint32_t norm100(uint32_t c, uint32_t m, uint32_t magic) {
+    const uint32_t n = __umul24(100u, c); // (c < 2^13)
+    if (m > 6553u) return n / m; // (uniform; beyond the exactness bound)
+    return m == 1u ? n : __umulhi(n, magic);
+}
+__device__ __forceinline__ uint32_t norm100(uint32_t c, uint32_t m) { return norm100(c, m, div_magic(m)); }
+
 // ---- NARROW arithmetic ---------------------------------------------------------------------------------------
 // With the narrow mirrors every operand is a non-negative integer below 2^30 (cpu in milli-cores, memory in units
 // of 2^mem_shift bytes).  Both scores are functions of RATIOS, which do not depend on the unit, so they are evaluated
@@ -480,9 +501,12 @@ __device__ __forceinline__ NarrowPod narrow_pod(const DevPod &p, int sh) {
 // floor(d * 100 / A) for 0 <= d <= A < 2^30, A > 0
 __device__ __forceinline__ uint32_t floor_ratio100(uint32_t d, uint32_t A) {
     uint32_t q = (uint32_t)((float)d * (100.0f * __builtin_amdgcn_rcpf((float)A)));
-    const uint64_t num = (uint64_t)d * 100u, prod = (uint64_t)q * A;
-    if (prod > num) q -= 1;
-    else if (num - prod >= A) q += 1;
+    // the estimate is off by at most one, so the remainder 100 d - q A lies in [-A, 2A): below 2^31 in magnitude, hence exact
+    // in wrapping 32-bit arithmetic (no 64-bit products).  (Skipping the fix-up for estimates far from an integer was tried:
+    // the extra compare-and-branch cost more than the two multiplies it saves -- persistent run 1.33 -> 1.38 ms.)
+    const int32_t r = (int32_t)(d * 100u - q * A);
+    if (r < 0) q -= 1;
+    else if (r >= (int32_t)A) q += 1;
     return q;
 }
 
@@ -496,43 +520,50 @@ __device__ __forceinline__ bool fits_narrow(const DevPod &p, const NarrowPod &q,
     return ok;
 }
 
+// Straight-line form: every decision that depends on the NODE is a select, every decision that depends on the pod / profile
+// alone is a uniform branch (the first form mixed the two and spent more instructions on exec-mask bookkeeping and a
+// per-lane generic division by the weight sum than on the scores: 117 VALU + 119 SALU per evaluation).
 __device__ __forceinline__ int64_t dynamic_score_narrow(const DevPod &p, const NarrowPod &q, int32_t a0, int32_t a1, int32_t r0,
                                                         int32_t r1, int32_t z0, int32_t z1) {
-    int64_t total = 0;
+    uint32_t total = 0;
+    const bool has0 = a0 != 0, has1 = a1 != 0; // resource_allocation.go:66-69: an absent resource does not take part
     if (p.w_fit) { // least_allocated.go:30-61 on NonZeroRequested + the pod's non-zero request
-        uint32_t node_score = 0, weight_sum = 0;
-        if (p.fit_cpu && a0 != 0) {
+        uint32_t s0 = 0, s1 = 0;
+        if (p.fit_cpu) {
             const int32_t x = z0 + q.nz0;
-            node_score += (x > a0 ? 0u : floor_ratio100((uint32_t)(a0 - x), (uint32_t)a0)) * (uint32_t)p.fit_w_cpu;
-            weight_sum += (uint32_t)p.fit_w_cpu;
+            const uint32_t v = floor_ratio100((uint32_t)(a0 - x), (uint32_t)a0); // (garbage when x > a0 or a0 == 0: selected away)
+            s0 = has0 && x <= a0 ? v : 0u;
         }
-        if (p.fit_mem && a1 != 0) {
+        if (p.fit_mem) {
             const int32_t x = z1 + q.nz1;
-            node_score += (x > a1 ? 0u : floor_ratio100((uint32_t)(a1 - x), (uint32_t)a1)) * (uint32_t)p.fit_w_mem;
-            weight_sum += (uint32_t)p.fit_w_mem;
+            const uint32_t v = floor_ratio100((uint32_t)(a1 - x), (uint32_t)a1);
+            s1 = has1 && x <= a1 ? v : 0u;
         }
-        uint32_t s = 0;
-        if (weight_sum == 2) s = node_score >> 1;
-        else if (weight_sum == 1) s = node_score;
-        else if (weight_sum != 0) s = node_score / weight_sum;
-        total += (int64_t)s * p.w_fit;
+        const uint32_t w0 = p.fit_cpu ? (uint32_t)p.fit_w_cpu : 0u, w1 = p.fit_mem ? (uint32_t)p.fit_w_mem : 0u, W = w0 + w1; // uniform
+        // sum(s_i w_i) / sum(w_i) over the resources the node has: both -> the uniform weight sum W (weights <= 100 each: the
+        // numerator stays below 2^15, so mulhi with ceil(2^32 / W) is the exact quotient); one -> that resource's score; none -> 0
+        const uint32_t num = __umul24(s0, w0) + __umul24(s1, w1); // (24-bit multiplies issue at full rate; scores <= 100, weights <= 100)
+        const uint32_t both = W == 2u ? num >> 1 : (W <= 1u ? num : __umulhi(num, div_magic(W)));
+        const bool c = has0 && w0 != 0, m = has1 && w1 != 0;
+        const uint32_t s = c && m ? both : (c ? s0 : (m ? s1 : 0u));
+        total += __umul24(s, (uint32_t)p.w_fit); // (plugin weights are validated <= 10^6 < 2^24 by ccsim_set_profile)
     }
     if (p.w_bal) { // balanced_allocation.go:146-180 on Requested + the pod's raw request
-        const bool c = p.bal_cpu && a0 != 0, m = p.bal_mem && a1 != 0;
-        int64_t score = 100; // fewer than two fractions: std = 0
-        if (c && m) {
+        uint32_t score = 100; // fewer than two fractions: std = 0
+        if (p.bal_cpu && p.bal_mem) {
             const int32_t x0 = r0 + q.req0, x1 = r1 + q.req1;
             float f0 = (float)x0 * __builtin_amdgcn_rcpf((float)a0), f1 = (float)x1 * __builtin_amdgcn_rcpf((float)a1);
             f0 = f0 > 1.0f ? 1.0f : f0;
             f1 = f1 > 1.0f ? 1.0f : f1;
             const float y = (1.0f - fabsf((f0 - f1) * 0.5f)) * 100.0f; // in [50, 100]
             const float t = floorf(y), fr = y - t;
-            if (fr > 3e-4f && fr < 1.0f - 3e-4f) score = (int64_t)t;
-            else score = balanced_exact(x0, a0, x1, a1);
+            uint32_t two = (uint32_t)t;
+            if (has0 && has1 && !(fr > 3e-4f && fr < 1.0f - 3e-4f)) two = (uint32_t)balanced_exact(x0, a0, x1, a1); // (rare: a skipped branch)
+            score = has0 && has1 ? two : 100u;
         }
-        total += score * p.w_bal;
+        total += __umul24(score, (uint32_t)p.w_bal);
     }
-    return total;
+    return (int64_t)total;
 }
 
 // NodeResourcesFit filter for the cpu/mem/pods part (fit.go:564-615); extras are checked by the caller.
@@ -550,13 +581,15 @@ __device__ __forceinline__ bool fits_core(const DevPod &p, int64_t a_cpu, int64_
 // static (pod-spec dependent, state independent) part of the total:
 //   TaintToleration: DefaultNormalizeScore(100, reverse) ; NodeAffinity: DefaultNormalizeScore(100)
 //   ImageLocality: the node's score as it is (image_locality.go:54-66: no NormalizeScore)
+__device__ __forceinline__ int64_t static_score(const DevPod &p, uint32_t c, uint32_t a, uint32_t img, uint32_t mt, uint32_t ma, uint32_t magic_t,
+                                                uint32_t magic_a) {
+    uint32_t t = __umul24(img, (uint32_t)p.w_img); // (scores <= 100, weights <= 10^6: 24-bit multiplies, full rate)
+    if (p.w_taint) t += __umul24(mt == 0 ? 100u : 100u - norm100(c, mt, magic_t), (uint32_t)p.w_taint);
+    if (p.w_aff) t += __umul24(ma == 0 ? 0u : norm100(a, ma, magic_a), (uint32_t)p.w_aff); // w_aff is 0 when PreScore skips
+    return (int64_t)t;
+}
 __device__ __forceinline__ int64_t static_score(const DevPod &p, uint32_t c, uint32_t a, uint32_t img, uint32_t mt, uint32_t ma) {
-    int64_t t = (int64_t)(img * (uint32_t)p.w_img);
-    // (c == 0 / a == 0 short-cut the runtime division -- ~30 VALU instructions -- for the common node without
-    // PreferNoSchedule taints / matching preferred terms; same values)
-    if (p.w_taint) t += (int64_t)(mt == 0 || c == 0 ? 100u : 100u - (100u * c) / mt) * p.w_taint;
-    if (p.w_aff) t += (int64_t)(ma == 0 || a == 0 ? 0u : (100u * a) / ma) * p.w_aff; // w_aff is 0 when PreScore skips
-    return t;
+    return static_score(p, c, a, img, mt, ma, div_magic(mt), div_magic(ma));
 }
 
 __device__ __forceinline__ uint64_t make_key(int64_t total, int64_t gidx) {

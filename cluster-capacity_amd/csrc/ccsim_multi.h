@@ -29,7 +29,12 @@
 namespace ccsim {
 
 constexpr int kMWindowMax = 64;   // pods per window (= lanes of the commit wave holding per-pod rows)
-constexpr int kMPodChunk = 4;     // pods per scan workgroup
+#ifndef CCSIM_MPOD_CHUNK
+#define CCSIM_MPOD_CHUNK 8 // (build-time knob for A/B runs)
+#endif
+constexpr int kMPodChunk = CCSIM_MPOD_CHUNK; // pods per scan workgroup ...
+constexpr int kMPodSub = 2;                  // ... whose per-node words are held in registers at a time
+static_assert(kMPodChunk % kMPodSub == 0, "pods per scan workgroup: a multiple of kMPodSub");
 constexpr int kMNodesPerThread = 4;
 constexpr int kMBlockNodes = kThreads * kMNodesPerThread; // 1024
 constexpr int kMTopK = 8;
@@ -70,7 +75,9 @@ struct MState {
 struct MPartial { // per (pod of the window, scan workgroup)
     uint64_t key1, key2; // best two nodes of the workgroup's nodes for the pod: ((score+1) << 40) | ~index ; 0 = none
     uint64_t key3;       // the third best: never a candidate, only the BOUND on what the workgroup hides once its two are touched
-    uint32_t nfeas, mt, ma, c_mt, c_ma, pad;
+    uint32_t nfeas, mt, ma; // feasible nodes; the true normalization maxima over them
+    uint32_t c_mt, c_ma;    // nodes holding the pod's ASSUMED maxima (== the true holders whenever the assumption stands)
+    uint32_t pad;
 };
 
 struct MCand { // per pod of the window, after k_multi_select
@@ -137,27 +144,83 @@ __device__ __forceinline__ int32_t m_tbl_min(const int32_t *tbl, const uint8_t *
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_multi_scan: grid (node workgroups, pod chunks).
+// Measured (rocprofv3, C5 100k x 1024, profiles/r02/c5_kernel_stats.csv): the first form of this kernel -- 4 pods per
+// workgroup; tables staged, THEN node columns loaded, THEN the pods' per-node words, then per pod a descriptor load and a
+// two-barrier reduction -- took 65 us per window: a chain of dependent global round trips per workgroup at 4 waves per
+// SIMD, not arithmetic (6.4 M evaluations are ~10 us of VALU work).  This form keeps every load in flight early: node
+// columns and the first pods' words are issued before the staging barriers, the pod descriptors come from LDS, the words of
+// pod j + kMPodSub are fetched into the registers pod j just released, and the per-pod reductions meet at ONE barrier.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_multi_scan(MultiArgs a) {
-    const MState st = *a.st;
-    if (st.done) return;
+__global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
+    const int32_t done = a.st->done, win_n = a.st->win_n, next_pod = a.st->next_pod; // (not the whole MState: it would sit in ~60 SGPRs)
+    if (done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = blockIdx.y * kMPodChunk;
-    if (j0 >= st.win_n) return;
-    const int jn = st.win_n - j0 < kMPodChunk ? st.win_n - j0 : kMPodChunk;
+    if (j0 >= win_n) return;
+    const int jn = win_n - j0 < kMPodChunk ? win_n - j0 : kMPodChunk;
     const int64_t base = (int64_t)blockIdx.x * kMBlockNodes;
 
+    __shared__ MPod s_pod[kMPodChunk];
     __shared__ int32_t s_tbl[kMPodChunk][kMTsc][kMDomMax + 1];
     __shared__ int32_t s_min[kMPodChunk][kMTsc];
-    __shared__ uint64_t s_k[3][kThreads / 64];
-    __shared__ uint32_t s_u[5][kThreads / 64];
-    // stage the chunk's spread tables; one lane per (pod, constraint) derives the minimum over present domains
+    __shared__ uint32_t s_k[kMPodChunk][3][kThreads / 64];
+    __shared__ uint32_t s_u[kMPodChunk][5][kThreads / 64];
+
+    // (1) this thread's nodes: narrow columns -> registers, once for all pods of the chunk (independent of everything below)
+    int32_t a0[kMNodesPerThread], a1[kMNodesPerThread], r0[kMNodesPerThread], r1[kMNodesPerThread], z0[kMNodesPerThread], z1[kMNodesPerThread];
+    int32_t room[kMNodesPerThread]; // 1 = the node still has room for one more pod (fit.go:567-576: the same test for every pod)
+    uint32_t lv[kMNodesPerThread]; // the node's value ids of the two spread label columns, one byte each (ids <= kMDomMax - 1)
+#pragma unroll
+    for (int k = 0; k < kMNodesPerThread; k++) {
+        const int64_t i = base + k * kThreads + tid;
+        const bool in = i < a.c.n_pad;
+        a0[k] = in ? a.c.a32[0][i] : 0, a1[k] = in ? a.c.a32[1][i] : 0;
+        r0[k] = in ? a.c.r32[0][i] : 0, r1[k] = in ? a.c.r32[1][i] : 0;
+        z0[k] = in ? a.c.z32[0][i] : 0, z1[k] = in ? a.c.z32[1][i] : 0;
+        room[k] = in && (int64_t)a.c.pod_count[i] + 1 <= (int64_t)a.c.alloc_pods[i] ? 1 : 0;
+        const uint32_t l0 = in && a.tsc_label[0] ? (uint32_t)a.tsc_label[0][i] : 0u, l1 = in && a.tsc_label[1] ? (uint32_t)a.tsc_label[1][i] : 0u;
+        lv[k] = (l0 & (uint32_t)kMDomMax) | ((l1 & (uint32_t)kMDomMax) << 8);
+    }
+
+    // (2) the per-(pod, node) words -- static word of the pod's class, the pod's anti-affinity bits -- of the first kMPodSub
+    // pods; slot jj % kMPodSub is refilled with pod jj + kMPodSub's words as soon as pod jj has been evaluated
+    uint32_t wv[kMPodSub][kMNodesPerThread], bv[kMPodSub][kMNodesPerThread];
+    auto fetch_words = [&](int slot, int jj) {
+        const bool on = jj < jn;
+        const int pi = (next_pod + j0 + (on ? jj : 0)) % a.n_pods;
+        const int32_t cls = a.pods[pi].cls, anti = a.pods[pi].anti; // (uniform address: scalar loads)
+        const uint32_t *stat = a.stat_cls + (int64_t)cls * a.n_pad;
+        const uint32_t *bits = a.anti_bits + (int64_t)pi * (a.n_pad / 32);
+#pragma unroll
+        for (int k = 0; k < kMNodesPerThread; k++) {
+            const int64_t i = base + k * kThreads + tid;
+            const bool in = on && i < a.c.n_pad;
+            wv[slot][k] = in ? stat[i] : 0u;
+            bv[slot][k] = in && anti ? bits[i >> 5] : 0u;
+        }
+    };
+#pragma unroll
+    for (int jj = 0; jj < kMPodSub; jj++) fetch_words(jj, jj);
+
+    // (3) the chunk's pod descriptors -> LDS, then their spread tables; one lane per (pod, constraint) derives the minimum
+    // over present domains
+    {
+        constexpr int kWords = (int)(sizeof(MPod) / 4);
+        int32_t *dst = reinterpret_cast<int32_t *>(&s_pod[0]);
+        for (int i = tid; i < kMPodChunk * kWords; i += kThreads) {
+            const int jj = i / kWords, w = i % kWords;
+            const int pi = (next_pod + j0 + (jj < jn ? jj : 0)) % a.n_pods;
+            dst[i] = reinterpret_cast<const int32_t *>(&a.pods[pi])[w];
+        }
+    }
+    __syncthreads();
     for (int i = tid; i < kMPodChunk * kMTsc * (kMDomMax + 1); i += kThreads) {
         const int jj = i / (kMTsc * (kMDomMax + 1)), c = (i / (kMDomMax + 1)) % kMTsc, v = i % (kMDomMax + 1);
         int32_t x = 0;
         if (jj < jn) {
-            const MPod &q = a.pods[(st.next_pod + j0 + jj) % a.n_pods];
+            const MPod &q = s_pod[jj];
             if (c < q.n_tsc && v <= q.tsc_ndom[c]) x = m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]);
+            if (c < q.n_tsc && v == 0) x = kMAbsent - 1; // value id 0 = the node lacks the topology key (filtering.go:328-332): above every limit
         }
         s_tbl[jj][c][v] = x;
     }
@@ -166,104 +229,101 @@ __global__ __launch_bounds__(kThreads) void k_multi_scan(MultiArgs a) {
         const int jj = tid / kMTsc, c = tid % kMTsc;
         int32_t m = 0x7fffffff;
         if (jj < jn) {
-            const MPod &q = a.pods[(st.next_pod + j0 + jj) % a.n_pods];
+            const MPod &q = s_pod[jj];
             if (c < q.n_tsc) m = m_staged_min(&s_tbl[jj][c][0], q.tsc_ndom[c]);
         }
         s_min[jj][c] = m;
     }
     __syncthreads();
 
-    // this thread's 8 nodes: narrow columns -> registers, once for all pods of the chunk
-    int32_t a0[kMNodesPerThread], a1[kMNodesPerThread], r0[kMNodesPerThread], r1[kMNodesPerThread], z0[kMNodesPerThread], z1[kMNodesPerThread];
-    int32_t ap[kMNodesPerThread], np[kMNodesPerThread], lv0[kMNodesPerThread], lv1[kMNodesPerThread];
+    // Inside a workgroup a node is its 10-bit local index and a TotalScore fits 21 bits (checked by ccsim_set_pods), so the
+    // running top three are 32-bit keys ((score + 1) << 10 | 1023 - local index: same order as the global 64-bit keys);
+    // thread jj widens pod jj's three survivors at the end.
+    static_assert(kMBlockNodes == 1024, "local node index: 10 bits");
+#pragma unroll 1
+    for (int sub = 0; sub < kMPodChunk; sub += kMPodSub) { // (a runtime loop: the fully unrolled chunk did not fit the instruction cache)
+        if (sub >= jn) break;
 #pragma unroll
-    for (int k = 0; k < kMNodesPerThread; k++) {
-        const int64_t i = base + k * kThreads + tid;
-        const bool in = i < a.c.n_pad;
-        a0[k] = in ? a.c.a32[0][i] : 0, a1[k] = in ? a.c.a32[1][i] : 0;
-        r0[k] = in ? a.c.r32[0][i] : 0, r1[k] = in ? a.c.r32[1][i] : 0;
-        z0[k] = in ? a.c.z32[0][i] : 0, z1[k] = in ? a.c.z32[1][i] : 0;
-        ap[k] = in ? a.c.alloc_pods[i] : 0, np[k] = in ? a.c.pod_count[i] : 0;
-        lv0[k] = in && a.tsc_label[0] ? a.tsc_label[0][i] : 0;
-        lv1[k] = in && a.tsc_label[1] ? a.tsc_label[1][i] : 0;
-    }
-
-    // the chunk's per-(pod, node) words -- static word of the pod's class, the pod's anti-affinity bits -- for ALL its pods
-    // first, every load in flight together: the evaluation loop below then never waits for memory
-    uint32_t wv[kMPodChunk][kMNodesPerThread], bv[kMPodChunk][kMNodesPerThread];
+        for (int slot = 0; slot < kMPodSub; slot++) {
+            const int jj = sub + slot;
+            if (jj >= jn) break;
+            const MPod &q = s_pod[jj];
+            DevPod p = a.prof;
+            p.all_zero_req = uni32(q.all_zero_req), p.w_bal = uni32(q.w_bal), p.w_aff = uni32(q.w_aff);
+            const NarrowPod nq{uni32(q.req0), uni32(q.req1), uni32(q.nz0), uni32(q.nz1)}; // (uniform values: kept in SGPRs)
+            // everything that depends on the pod alone, once per pod: the normalization divisors' magics, and per spread
+            // constraint the largest domain count the skew test lets through -- (match + self - min > maxSkew) <=> match > lim
+            // (filtering.go:311-356; min counts as 0 while fewer than minDomains domains exist, :56-69); an unused slot passes all
+            const uint32_t mt = (uint32_t)uni32(q.mt_a), ma = (uint32_t)uni32(q.ma_a);
+            const uint32_t Mt = (uint32_t)uni32((int)div_magic(mt)), Ma = (uint32_t)uni32((int)div_magic(ma));
+            const int32_t n_tsc = uni32(q.n_tsc);
+            int32_t lim[kMTsc];
+            bool sl[kMTsc];
 #pragma unroll
-    for (int jj = 0; jj < kMPodChunk; jj++) {
-        const bool on = jj < jn;
-        const int pi = (st.next_pod + j0 + (on ? jj : 0)) % a.n_pods;
-        const int32_t cls = a.pods[pi].cls, anti = a.pods[pi].anti;
-        const uint32_t *stat = a.stat_cls + (int64_t)cls * a.n_pad;
-        const uint32_t *bits = a.anti_bits + (int64_t)pi * (a.n_pad / 32);
-#pragma unroll
-        for (int k = 0; k < kMNodesPerThread; k++) {
-            const int64_t i = base + k * kThreads + tid;
-            const bool in = on && i < a.c.n_pad;
-            wv[jj][k] = in ? stat[i] : 0u;
-            bv[jj][k] = in && anti ? bits[i >> 5] : 0u;
-        }
-    }
-
-#pragma unroll
-    for (int jj = 0; jj < kMPodChunk; jj++) {
-        if (jj >= jn) break;
-        const int pi = (st.next_pod + j0 + jj) % a.n_pods;
-        const MPod q = a.pods[pi];
-        const DevPod p = m_devpod(a.prof, q);
-        const NarrowPod nq{q.req0, q.req1, q.nz0, q.nz1};
-        const uint32_t mt = (uint32_t)q.mt_a, ma = (uint32_t)q.ma_a;
-        uint64_t k1 = 0, k2 = 0, k3 = 0;
-        uint32_t nf = 0, mtb = 0, mab = 0, cmt = 0, cma = 0;
-#pragma unroll
-        for (int k = 0; k < kMNodesPerThread; k++) {
-            const int64_t i = base + k * kThreads + tid;
-            const uint32_t w = wv[jj][k];
-            bool ok = (w >> kStatOkBit) && fits_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], ap[k], np[k]);
-            ok = ok && !((bv[jj][k] >> (i & 31)) & 1u); // satisfyPodAntiAffinity / existing pods' anti-affinity (filtering.go:352-379)
-#pragma unroll
-            for (int c = 0; c < kMTsc; c++) // (constant indices: a runtime-indexed copy of the pod would live in scratch)
-                if (c < q.n_tsc && ok) {
-                    const int32_t v = q.tsc_slot[c] ? lv1[k] : lv0[k];
-                    ok = m_pts_check(q, c, v, m_count(s_tbl[jj][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[jj][c]) == 0;
-                }
-            if (!ok) continue;
-            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
-            const int64_t total = static_score(p, cnt, aff, img, mt, ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k]);
-            const uint64_t key = make_key(total, a.c.global_offset + i);
-            if (key > k1) k3 = k2, k2 = k1, k1 = key; else if (key > k2) k3 = k2, k2 = key; else if (key > k3) k3 = key;
-            nf++;
-            if (cnt > mtb) mtb = cnt, cmt = 1; else if (cnt == mtb) cmt++;
-            if (aff > mab) mab = aff, cma = 1; else if (aff == mab) cma++;
-        }
-        // workgroup top-3 (keys are unique: exactly one lane holds a wave maximum): best, second, third over the wave, then
-        // merged across the 4 waves by thread 0
-        const uint64_t w1 = wave_max_u64(k1);
-        const bool h1 = k1 == w1 && w1 != 0;
-        const uint64_t x2 = h1 ? k2 : k1, y2 = h1 ? k3 : k2; // this lane's best two once the wave's best is removed
-        const uint64_t w2 = wave_max_u64(x2);
-        const bool h2 = x2 == w2 && w2 != 0;
-        const uint64_t w3 = wave_max_u64(h2 ? y2 : x2);
-        const uint32_t wmt = wave_max_u32(mtb), wma = wave_max_u32(mab);
-        const uint32_t wcmt = wave_sum_u32(mtb == wmt ? cmt : 0u), wcma = wave_sum_u32(mab == wma ? cma : 0u), wnf = wave_sum_u32(nf);
-        __syncthreads(); // (s_k / s_u reuse across pods)
-        if (lane == 0) s_k[0][wave] = w1, s_k[1][wave] = w2, s_k[2][wave] = w3, s_u[0][wave] = wnf, s_u[1][wave] = wmt, s_u[2][wave] = wma, s_u[3][wave] = wcmt, s_u[4][wave] = wcma;
-        __syncthreads();
-        if (tid == 0) {
-            MPartial o{};
-            for (int x = 0; x < kThreads / 64; x++) {
-                for (int h = 0; h < 3; h++) {
-                    const uint64_t key = s_k[h][x];
-                    if (key > o.key1) o.key3 = o.key2, o.key2 = o.key1, o.key1 = key; else if (key > o.key2) o.key3 = o.key2, o.key2 = key; else if (key > o.key3) o.key3 = key;
-                }
-                o.nfeas += s_u[0][x];
-                if (s_u[1][x] > o.mt) o.mt = s_u[1][x], o.c_mt = s_u[3][x]; else if (s_u[1][x] == o.mt) o.c_mt += s_u[3][x];
-                if (s_u[2][x] > o.ma) o.ma = s_u[2][x], o.c_ma = s_u[4][x]; else if (s_u[2][x] == o.ma) o.c_ma += s_u[4][x];
+            for (int c = 0; c < kMTsc; c++) {
+                const int32_t mm = q.tsc_npresent[c] < q.tsc_min_dom[c] ? 0 : s_min[jj][c];
+                lim[c] = uni32(c < n_tsc ? q.tsc_max_skew[c] + mm - q.tsc_self[c] : 0x7fffffff);
+                sl[c] = uni32(q.tsc_slot[c]) != 0;
             }
-            a.partials[(int64_t)(j0 + jj) * a.n_blocks + blockIdx.x] = o;
+            const uint32_t my_bit = (uint32_t)(tid & 31); // (the workgroup's first node and k * kThreads are multiples of 32)
+            uint32_t k1 = 0, k2 = 0, k3 = 0;
+            uint32_t mtb = 0, mab = 0;
+            uint32_t acc = 0; // three 10-bit counters: feasible nodes | holders of the assumed taint maximum << 10 | of the affinity one << 20
+#pragma unroll
+            for (int k = 0; k < kMNodesPerThread; k++) {
+                const uint32_t w = wv[slot][k];
+                bool ok = (w >> kStatOkBit) && fits_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], room[k], 0);
+                ok = ok && !((bv[slot][k] >> my_bit) & 1u); // satisfyPodAntiAffinity / existing pods' anti-affinity (filtering.go:352-379)
+#pragma unroll
+                for (int c = 0; c < kMTsc; c++) { // PodTopologySpread.Filter: one LDS read and one compare per constraint
+                    const uint32_t v = (sl[c] ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax; // (ids are validated <= kMDomMax - 1)
+                    ok = ok && m_count(s_tbl[jj][c][v]) <= lim[c];
+                }
+                if (!ok) continue;
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                const uint32_t total = (uint32_t)(static_score(p, cnt, aff, img, mt, ma, Mt, Ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k]));
+                const uint32_t key = ((total + 1u) << 10) | (1023u - (uint32_t)(k * kThreads + tid));
+                if (key > k1) k3 = k2, k2 = k1, k1 = key; else if (key > k2) k3 = k2, k2 = key; else if (key > k3) k3 = key;
+                // the true maxima over the feasible set, and how many nodes hold the ASSUMED ones (only read when the two agree)
+                mtb = cnt > mtb ? cnt : mtb, mab = aff > mab ? aff : mab;
+                acc += 1u | ((uint32_t)(cnt == mt) << 10) | ((uint32_t)(aff == ma) << 20);
+            }
+            if (sub + kMPodSub < kMPodChunk) fetch_words(slot, jj + kMPodSub); // the slot is free: pod jj + kMPodSub's words, consumed kMPodSub pods later
+            // wave top-3 (keys are unique: exactly one lane holds a wave maximum): best, second, third over the wave
+            const uint32_t w1 = wave_max_u32(k1);
+            const bool h1 = k1 == w1 && w1 != 0;
+            const uint32_t x2 = h1 ? k2 : k1, y2 = h1 ? k3 : k2; // this lane's best two once the wave's best is removed
+            const uint32_t w2 = wave_max_u32(x2);
+            const bool h2 = x2 == w2 && w2 != 0;
+            const uint32_t w3 = wave_max_u32(h2 ? y2 : x2);
+            const uint32_t wmt = wave_max_u32(mtb), wma = wave_max_u32(mab);
+            // (counts per wave <= 256: three 10-bit fields in one reduction)
+            const uint32_t packed = wave_sum_u32(acc);
+            const uint32_t wnf = packed & 1023u, wcmt = (packed >> 10) & 1023u, wcma = packed >> 20;
+            if (lane == 0)
+                s_k[jj][0][wave] = w1, s_k[jj][1][wave] = w2, s_k[jj][2][wave] = w3, s_u[jj][0][wave] = wnf, s_u[jj][1][wave] = wmt,
+                s_u[jj][2][wave] = wma, s_u[jj][3][wave] = wcmt, s_u[jj][4][wave] = wcma;
         }
+    }
+    __syncthreads();
+    if (tid < jn) { // thread jj merges pod jj's four wave results and widens the keys
+        const int jj = tid;
+        uint32_t b1 = 0, b2 = 0, b3 = 0;
+        MPartial o{};
+        for (int x = 0; x < kThreads / 64; x++) {
+            for (int h = 0; h < 3; h++) {
+                const uint32_t key = s_k[jj][h][x];
+                if (key > b1) b3 = b2, b2 = b1, b1 = key; else if (key > b2) b3 = b2, b2 = key; else if (key > b3) b3 = key;
+            }
+            o.nfeas += s_u[jj][0][x];
+            o.mt = s_u[jj][1][x] > o.mt ? s_u[jj][1][x] : o.mt, o.ma = s_u[jj][2][x] > o.ma ? s_u[jj][2][x] : o.ma;
+            o.c_mt += s_u[jj][3][x], o.c_ma += s_u[jj][4][x]; // holders of the ASSUMED maxima
+        }
+        auto widen = [&](uint32_t key) -> uint64_t {
+            return key ? make_key((int64_t)(key >> 10) - 1, a.c.global_offset + base + (int64_t)(1023u - (key & 1023u))) : 0ull;
+        };
+        o.key1 = widen(b1), o.key2 = widen(b2), o.key3 = widen(b3);
+        a.partials[(int64_t)(j0 + jj) * a.n_blocks + blockIdx.x] = o;
     }
 }
 
@@ -291,11 +351,11 @@ __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
             dropped = key > dropped ? key : dropped;
         }
         nf += q.nfeas;
-        if (q.mt > mt) mt = q.mt, cmt = q.c_mt; else if (q.mt == mt) cmt += q.c_mt;
-        if (q.ma > ma) ma = q.ma, cma = q.c_ma; else if (q.ma == ma) cma += q.c_ma;
+        mt = q.mt > mt ? q.mt : mt, ma = q.ma > ma ? q.ma : ma;
+        cmt += q.c_mt, cma += q.c_ma; // holders of the pod's ASSUMED maxima (meaningful iff they are the true ones: checked by the commit)
     }
     const uint32_t wmt = wave_max_u32(mt), wma = wave_max_u32(ma);
-    const uint32_t wcmt = wave_sum_u32(mt == wmt ? cmt : 0u), wcma = wave_sum_u32(ma == wma ? cma : 0u), wnf = wave_sum_u32(nf);
+    const uint32_t wcmt = wave_sum_u32(cmt), wcma = wave_sum_u32(cma), wnf = wave_sum_u32(nf);
     MCand out{};
     int n = 0;
 #pragma unroll 1

@@ -109,7 +109,6 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
-__device__ __forceinline__ int uni32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ void grid_reduce(GridCtx &gc) {
     PersistSync *s = gc.s;
