@@ -49,6 +49,20 @@ def load_objects(paths: List[str]):
     return load_all(paths)[:2]
 
 
+def load_kind(paths: List[str], kind: str):
+    """Every object of one kind in the snapshot files (lists are flattened)."""
+    out = []
+    for path in paths:
+        with open(path) as f:
+            docs = list(yaml.safe_load_all(f))
+        for d in docs:
+            if not d:
+                continue
+            items = d["items"] if str(d.get("kind", "")).endswith("List") and "items" in d else [d]
+            out += [o for o in items if o.get("kind") == kind]
+    return out
+
+
 def parse_pod_spec(path: str, scheduler_name: str = "default-scheduler") -> dict:
     """options.go:79-147 ParseAPISpec (defaults only; API validation is the apiserver's job)."""
     with open(path) as f:
@@ -162,7 +176,9 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
 
 def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     ap = argparse.ArgumentParser(prog="cluster-capacity", description="Cluster-capacity is used for simulating scheduling of one or multiple pods")
-    ap.add_argument("--podspec", required=True, help="Path to JSON or YAML file containing pod definition.")
+    ap.add_argument("--podspec", default="", help="Path to JSON or YAML file containing pod definition.")
+    ap.add_argument("--genpod", default="", metavar="NAMESPACE",
+                    help="cmd/genpod: print the pod the namespace's LimitRanges / node-selector annotation describe (objects from --snapshot)")
     ap.add_argument("--snapshot", action="append", required=True, help="File(s) with the cluster's Node and Pod objects (replaces --kubeconfig)")
     ap.add_argument("--max-limit", type=int, default=0, help="Number of instances of pod to be scheduled after which analysis stops. By default unlimited.")
     ap.add_argument("--exclude-nodes", default="", help="Exclude nodes to be scheduled")
@@ -174,6 +190,17 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
                     help="KubeSchedulerConfiguration.percentageOfNodesToScore: 100 scores every node (the final capacity and "
                          "distribution do not depend on it for pods without topology constraints); 0 = the scheduler's adaptive default")
     args = ap.parse_args(argv)
+    if args.genpod:
+        from . import genpod
+        try:
+            pod = genpod.namespace_pod(args.genpod, load_kind(args.snapshot, "Namespace"), load_kind(args.snapshot, "LimitRange"))
+        except genpod.GenpodError as e:
+            sys.stderr.write(f"Error: {e}\n")
+            return 1
+        out.write(json.dumps(pod) + "\n" if args.output == "json" else yaml.safe_dump(pod, sort_keys=False))
+        return 0
+    if not args.podspec:
+        ap.error("Pod spec file is missing")
 
     cfg = None
     if args.default_config:

@@ -24,6 +24,7 @@
 #include <sstream>
 
 #include "cluster_capacity.hpp"
+#include "genpod.hpp"
 
 using namespace cchost;
 
@@ -35,6 +36,21 @@ std::string read_file(const std::string &path) {
     std::ostringstream ss;
     ss << f.rdbuf();
     return ss.str();
+}
+
+// every object of one kind in the snapshot files (lists are flattened)
+std::vector<Value> load_kind(const std::vector<std::string> &paths, const std::string &want) {
+    std::vector<Value> out;
+    for (const auto &path : paths)
+        for (const Value &d : parse_documents(read_file(path))) {
+            if (!d.truthy()) continue;
+            const std::string kind = d["kind"].text();
+            const bool is_list = kind.size() >= 4 && kind.compare(kind.size() - 4, 4, "List") == 0 && d.has("items");
+            std::vector<Value> one{d};
+            for (const Value &o : is_list ? d["items"].items() : one)
+                if (o["kind"].text() == want) out.push_back(o);
+        }
+    return out;
 }
 
 void load_objects(const std::vector<std::string> &paths, std::vector<Value> &nodes, std::vector<Value> &pods, std::vector<Value> &namespaces) {
@@ -90,7 +106,8 @@ RunResult result_from_json(const Value &v) {
 int usage(const char *msg) {
     std::fprintf(stderr, "%s\nusage: cluster-capacity --podspec FILE --snapshot FILE [--snapshot FILE ...] [--max-limit N] [--exclude-nodes a,b]\n"
                          "                        [--default-config FILE] [--verbose] [-o json|yaml] [--mode batched|sequential]\n"
-                         "                        [--percentage-of-nodes-to-score P] [--device D]\n",
+                         "                        [--percentage-of-nodes-to-score P] [--device D]\n"
+                         "       cluster-capacity --genpod NAMESPACE --snapshot FILE [--snapshot FILE ...] [-o json|yaml]\n",
                  msg);
     return 2;
 }
@@ -98,7 +115,7 @@ int usage(const char *msg) {
 } // namespace
 
 int main(int argc, char **argv) {
-    std::string podspec, output, mode, dump, fake, sched_config;
+    std::string podspec, output, mode, dump, fake, sched_config, genpod_ns;
     bool dump_profile = false, pct_flag = false;
     std::vector<std::string> snapshots, exclude;
     int64_t max_limit = 0;
@@ -128,6 +145,7 @@ int main(int argc, char **argv) {
             else if (a == "--percentage-of-nodes-to-score") percentage = std::stoi(need()), pct_flag = true;
             else if (a == "--default-config") sched_config = need();
             else if (a == "--dump-profile") dump_profile = true;
+            else if (a == "--genpod") genpod_ns = need(); // cmd/genpod: the pod a namespace's LimitRanges / annotations describe
             else if (a == "--device") device = std::stoi(need());
             else if (a == "--dump-snapshot") dump = need();
             else if (a == "--fake-result") fake = need();
@@ -157,6 +175,21 @@ int main(int argc, char **argv) {
     } catch (const std::exception &e) {
         std::fprintf(stderr, "cluster-capacity: %s\n", e.what());
         return 1;
+    }
+    if (!genpod_ns.empty()) { // genpod --namespace NS [--output json|yaml] (cmd/genpod/app/server.go:36-104); objects from --snapshot
+        if (snapshots.empty()) return usage("--snapshot is required");
+        if (!output.empty() && output != "json" && output != "yaml") return usage(("Output format " + output + " not recognized: only json and yaml are allowed").c_str());
+        try {
+            const Value pod = namespace_pod(genpod_ns, load_kind(snapshots, "Namespace"), load_kind(snapshots, "LimitRange"));
+            std::string out;
+            if (output == "json") to_json(out, pod), out += "\n";
+            else to_yaml(out, pod); // PrintPod (pkg/utils/utils.go:47-71): yaml unless json is asked for
+            std::cout << out;
+            return 0;
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "Error: %s\n", e.what());
+            return 1;
+        }
     }
     if (podspec.empty()) return usage("Pod spec file is missing"); // options.go / server.go:71-73
     if (snapshots.empty()) return usage("--snapshot is required");

@@ -908,3 +908,65 @@ def test_sidecar_and_pod_level_requests_known_answer(native, tmp_path):
     (tmp_path / "pod.json").write_text(json.dumps(pod))
     d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"]))
     assert d["pod"]["req"][:2] == [5010, 0] and d["pod"]["nz_mcpu"] == 5010 and d["pod"]["nz_mem"] == 600 * (1 << 20)
+
+
+# ---- genpod (cmd/genpod, pkg/client/nspod.go:34-126) --------------------------------------------------------------------
+def _genpod_objects(rng=None):
+    ns = [{"kind": "Namespace", "metadata": {"name": "limited", "annotations": {"openshift.io/node-selector": "region=primary, disk = ssd"}}},
+          {"kind": "Namespace", "metadata": {"name": "open"}},
+          {"kind": "Namespace", "metadata": {"name": "zero", "annotations": {"openshift.io/node-selector": ""}}},
+          {"kind": "Namespace", "metadata": {"name": "broken", "annotations": {"openshift.io/node-selector": "a=b=c"}}}]
+    lrs = [{"kind": "LimitRange", "metadata": {"name": "a", "namespace": "limited"}, "spec": {"limits": [
+                {"type": "Pod", "max": {"cpu": "2", "memory": "1Gi"}}, {"type": "Container", "max": {"cpu": "100m"}},
+                {"type": "Pod", "max": {"cpu": "1500m", "nvdia.com/gpu": "1"}}]}},
+           {"kind": "LimitRange", "metadata": {"name": "b", "namespace": "limited"}, "spec": {"limits": [{"type": "Pod", "max": {"memory": "900Mi", "cpu": "1.5"}}]}},
+           {"kind": "LimitRange", "metadata": {"name": "z", "namespace": "zero"}, "spec": {"limits": [{"type": "Pod", "max": {"cpu": "0", "memory": "0"}}]}},
+           {"kind": "LimitRange", "metadata": {"name": "o", "namespace": "other"}, "spec": {"limits": [{"type": "Pod", "max": {"cpu": "1"}}]}}]
+    return ns, lrs
+
+
+def test_genpod_known_answers():
+    """By hand from nspod.go: minimum of the Pod-type maxima per resource (1500m < 2, the later equal 1.5 does not replace it:
+    Cmp == 1 is strict; 900Mi < 1Gi), limits == requests, the node selector from the annotation; all-zero limits leave the
+    container without resources; a namespace without LimitRanges yields the bare stub."""
+    from cluster_capacity_amd import genpod
+    ns, lrs = _genpod_objects()
+    pod = genpod.namespace_pod("limited", ns, lrs)
+    c = pod["spec"]["containers"][0]
+    assert c["resources"]["limits"] == c["resources"]["requests"] == {"memory": "900Mi", "cpu": "1500m", "nvdia.com/gpu": "1"}
+    assert pod["spec"]["nodeSelector"] == {"region": "primary", "disk": "ssd"}
+    assert (pod["metadata"]["name"], pod["metadata"]["namespace"], c["image"], c["imagePullPolicy"]) == \
+        ("cluster-capacity-stub-container", "limited", "gcr.io/google_containers/pause:2.0", "Always")
+    assert pod["spec"]["restartPolicy"] == "OnFailure" and pod["spec"]["dnsPolicy"] == "Default"
+    assert "resources" not in genpod.namespace_pod("zero", ns, lrs)["spec"]["containers"][0]
+    assert genpod.namespace_pod("zero", ns, lrs)["spec"]["nodeSelector"] == {}
+    bare = genpod.namespace_pod("open", ns, lrs)
+    assert "resources" not in bare["spec"]["containers"][0] and "nodeSelector" not in bare["spec"]
+    with pytest.raises(genpod.GenpodError, match="Namespace missing not found"):
+        genpod.namespace_pod("missing", ns, lrs)
+    with pytest.raises(genpod.GenpodError, match="Unable to parse openshift.io/node-selector"):
+        genpod.namespace_pod("broken", ns, lrs)
+
+
+@pytest.mark.parametrize("fmt", ["json", "yaml"])
+def test_native_genpod_equals_python_genpod(native, tmp_path, fmt):
+    from cluster_capacity_amd import genpod
+    ns, lrs = _genpod_objects()
+    (tmp_path / "objs.yaml").write_text(yaml.safe_dump({"kind": "List", "items": ns + lrs}))
+    load = json.loads if fmt == "json" else yaml.safe_load
+    for name in ("limited", "open", "zero"):
+        got = load(_run(native, ["--genpod", name, "--snapshot", str(tmp_path / "objs.yaml"), "-o", fmt]))
+        assert got == genpod.namespace_pod(name, ns, lrs), name
+        buf = __import__("io").StringIO()
+        assert cli.main(["--genpod", name, "--snapshot", str(tmp_path / "objs.yaml"), "-o", fmt], out=buf) == 0
+        assert load(buf.getvalue()) == got
+    for name, msg in (("missing", "Namespace missing not found"), ("broken", "Unable to parse openshift.io/node-selector")):
+        p = subprocess.run([native, "--genpod", name, "--snapshot", str(tmp_path / "objs.yaml")], capture_output=True, text=True)
+        assert p.returncode == 1 and msg in p.stderr
+    # the generated pod is a valid --podspec for the simulator's ingest (both hosts): README-style nodes labelled for the selector
+    nodes = [node(f"n{i}", labels={"region": "primary", "disk": "ssd" if i % 2 else "hdd"}) for i in range(4)]
+    nodes[0]["status"]["allocatable"]["nvdia.com/gpu"] = "2"
+    (tmp_path / "nodes.json").write_text(json.dumps({"kind": "List", "items": nodes}))
+    (tmp_path / "pod.yaml").write_text(_run(native, ["--genpod", "limited", "--snapshot", str(tmp_path / "objs.yaml")]))
+    d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "nodes.json"), "--dump-snapshot", "-"]))
+    assert d["pod"]["req"][:2] == [1500, 900 * 1024 * 1024] and d["scalar_names"] == ["nvdia.com/gpu"] and d["pod"]["has_node_selector"]
