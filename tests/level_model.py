@@ -249,3 +249,91 @@ class LevelModel:
                             full_passes=full_passes)
             if nfeas > 0 and ((mt > 0 and c_mt == 0) or (ma > 0 and c_ma == 0)):
                 full = True  # every cached score used a maximum that no feasible node holds any more
+
+    # ---- the persistent kernel's fast path (ccsim_persist.h): several score levels per grid-wide sync, committed blindly,
+    #      validated afterwards, rolled back and redone with fewer levels (down to ONE level in canonical order) ----
+    def run_persistent(self, limit=0, level_batch=8):
+        """Mirrors k_level_persist without a placement log.  Per sync: every feasible node scoring >= Lo = M - kb + 1 runs down
+        until it scores < Lo (or stops fitting) -- for one node exactly the sequence of its run-downs at the levels in between,
+        and without a log or a limit the interleaving across nodes is unobservable.  If that exhausted every feasible holder
+        of a normalization maximum, or crossed the limit, the whole batch is undone and retried with half the levels; a single
+        level that still trips is redone ORDERED (plan, cut, canonical commit: run()'s level step).  Returns the counters a
+        log-less run reports (placed, per-node counts, stop) + how many syncs / roll-backs it took."""
+        placed, syncs, rollbacks = 0, 0, 0
+        per_node = np.zeros(self.N, np.int32)
+        kb = level_batch
+        rescore = True
+        mt = ma = c_mt = c_ma = 0
+        while True:
+            feas = [n for n in range(self.N) if self.feasible(n)]
+            if not feas:
+                return dict(placed=placed, stop=0, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks)
+            if rescore:  # exact maxima over the feasible set (one extra grid reduce), then every node's TotalScore
+                mt, ma = max(self.cnt[n] for n in feas), max(self.aff[n] for n in feas)
+                rescore = False
+            c_mt = sum(1 for n in feas if self.cnt[n] == mt)
+            c_ma = sum(1 for n in feas if self.aff[n] == ma)
+            sc = {n: self.stat(n, mt, ma) + self.dyn(n) for n in feas}
+            M = max(sc.values())
+            ordered = False
+            while True:  # one sync (retried with fewer levels after a roll-back)
+                syncs += 1
+                Lo = M if ordered else max(M - (kb - 1), 0)
+                work = [n for n in feas if sc[n] >= Lo]
+                if ordered:  # the level step of run(): plan, cut, canonical order, limit clamp
+                    e_mt = e_ma = 0
+                    cut_mt = cut_ma = -1
+                    for n in work:
+                        j, f = self.run_down(n, self.stat(n, mt, ma), M, 1 << 30)
+                        for _ in range(j):
+                            self.apply(n, -1)
+                        if not f:
+                            if mt > 0 and self.cnt[n] == mt:
+                                e_mt, cut_mt = e_mt + 1, max(cut_mt, n)
+                            if ma > 0 and self.aff[n] == ma:
+                                e_ma, cut_ma = e_ma + 1, max(cut_ma, n)
+                    cut = 1 << 62
+                    if mt > 0 and e_mt == c_mt:
+                        cut = min(cut, cut_mt)
+                    if ma > 0 and e_ma == c_ma:
+                        cut = min(cut, cut_ma)
+                    for n in work:
+                        if n > cut:
+                            break
+                        allowed = (limit - placed) if limit > 0 else (1 << 30)
+                        if allowed <= 0:
+                            break
+                        j, _ = self.run_down(n, self.stat(n, mt, ma), M, allowed)
+                        placed += j
+                        per_node[n] += j
+                    if limit > 0 and placed >= limit:
+                        return dict(placed=placed, stop=1, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks)
+                    rescore = cut != 1 << 62  # a maximum lost its last feasible holder: new constants
+                    break
+                took, x_mt, x_ma = {}, 0, 0
+                for n in work:  # blind: any order
+                    j, f = self.run_down(n, self.stat(n, mt, ma), Lo, 1 << 30)
+                    took[n] = j
+                    if not f:
+                        x_mt += self.cnt[n] == mt
+                        x_ma += self.aff[n] == ma
+                total = sum(took.values())
+                cut_event = (mt > 0 and x_mt == c_mt) or (ma > 0 and x_ma == c_ma)
+                over = limit > 0 and placed + total > limit
+                if cut_event or over:  # undo the whole batch
+                    rollbacks += 1
+                    for n, j in took.items():
+                        for _ in range(j):
+                            self.apply(n, -1)
+                    if Lo < M:
+                        kb = (M - Lo + 1) >> 1
+                    else:
+                        ordered = True
+                    continue
+                placed += total
+                for n, j in took.items():
+                    per_node[n] += j
+                kb = min(2 * kb, level_batch)
+                if limit > 0 and placed >= limit:
+                    return dict(placed=placed, stop=1, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks)
+                break

@@ -62,3 +62,31 @@ def test_incremental_score_cache_synthetic(ccref, cfg, n, limit):
     nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=1234 + n)
     got = _check_incremental(ccref, nodes, pod, prof, limit)
     assert got["full_passes"] < got["levels"] or got["levels"] <= 2
+
+
+def _check_persistent(ccref, nodes, pod, prof, limit, batch):
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, want_log=False)
+    got = LevelModel(prof, nodes, pod).run_persistent(limit, batch)
+    assert got["placed"] == ref.placed and got["stop"] == ref.stop
+    assert np.array_equal(got["per_node_count"], ref.per_node_count)
+    return got
+
+
+@pytest.mark.parametrize("batch", [1, 4, 64])
+@pytest.mark.parametrize("seed", range(12))
+def test_persistent_level_batches_random_plugin_mix(ccref, seed, batch):
+    """The persistent kernel's argument (ccsim_persist.h): several score levels per sync committed blindly + validation +
+    roll-back give the sequential oracle's totals, per-node counts and stop -- incl. limits falling inside a batch and
+    normalization maxima losing their last feasible holder inside one."""
+    rng = np.random.default_rng(seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 400)))
+    _check_persistent(ccref, nodes, pod, prof, int(rng.choice([0, 0, 37, 500])), batch)
+
+
+def test_persistent_level_batches_save_syncs_and_roll_back(ccref):
+    nodes, pod, prof = synth.make_config("C3", n_nodes=513, seed=1747)
+    one = _check_persistent(ccref, nodes, pod, prof, 0, 1)
+    many = _check_persistent(ccref, nodes, pod, prof, 0, 64)
+    assert many["syncs"] < one["syncs"] / 4
+    limited = _check_persistent(ccref, nodes, pod, prof, 700, 64)  # the limit falls inside a batch: rolled back, halved, ...
+    assert limited["rollbacks"] >= 1 and limited["placed"] == 700
