@@ -112,17 +112,31 @@ def pod_requirements(pod: dict) -> dict:
             "nodeSelectors": pod["spec"].get("nodeSelector")}
 
 
-def build_review(pod: dict, snap: ingest.Snapshot, result: M.RunResult, max_limit: int) -> dict:
-    """report.go:196-225 GetReport."""
-    stop = R.stop_reason(result, len(snap.names), max_limit, taint_reasons=snap.taint_reasons, scalar_names=snap.scalar_names)
-    replicas = R.replicas_on_nodes(result.per_node_count, snap.names, result.log)
+def build_review(pod, snap: ingest.Snapshot, result: M.RunResult, max_limit: int) -> dict:
+    """report.go:196-225 GetReport.  `pod`: the template or the list of templates; scheduled pod i is a clone of template
+    i mod P (parsePodsReview, report.go:146-171), which is exactly the order the engine cycles them in."""
+    pods = list(pod) if isinstance(pod, (list, tuple)) else [pod]
+    P = len(pods)
+    failing = result.stop_spec if P > 1 and result.stop_spec >= 0 else 0  # the FitError describes the template that did not fit
+    stop = R.stop_reason(result, len(snap.names), max_limit, taint_reasons=snap.taint_reasons_all[failing], scalar_names=snap.scalar_names)
+    if P == 1:
+        per_template = [R.replicas_on_nodes(result.per_node_count, snap.names, result.log)]
+    else:
+        if result.log is None or len(result.log) < result.placed:
+            raise SystemExit("several templates: the placement log does not cover the run (raise the log capacity)")
+        per_template = []
+        for t in range(P):
+            log_t = np.asarray(result.log[t::P])
+            cnt = np.bincount(log_t, minlength=len(snap.names)).astype(np.int32) if len(log_t) else np.zeros(len(snap.names), np.int32)
+            per_template.append(R.replicas_on_nodes(cnt, snap.names, log_t))
     return {
-        "spec": {"templates": [pod], "replicas": 0, "podRequirements": [pod_requirements(pod)]},
+        "spec": {"templates": pods, "replicas": 0, "podRequirements": [pod_requirements(p) for p in pods]},
         "status": {
             "creationTimestamp": datetime.datetime.now(datetime.timezone.utc).isoformat(),
             "replicas": int(result.placed),
             "failReason": R.main_fail_reason(stop),
-            "pods": [{"podName": pod["metadata"].get("name", ""), "replicasOnNodes": replicas, "failSummary": None}],
+            "pods": [{"podName": p["metadata"].get("name", ""), "replicasOnNodes": per_template[t], "failSummary": None}
+                     for t, p in enumerate(pods)],
         },
     }
 
@@ -166,7 +180,8 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
     eng = capi.Engine(device=device)
     prof = profile or M.Profile.default()
     prof.percentage_of_nodes_to_score = percentage_of_nodes_to_score
-    eng.load(snap.nodes, snap.pod, prof)
+    # several templates: ccsim_set_pods, cycled round-robin by ccsim_run (windows of pods x nodes; `mode` does not apply)
+    eng.load(snap.nodes, snap.pods if len(snap.pods) > 1 else snap.pod, prof)
     cap = max_limit if max_limit > 0 else int(min(int(snap.nodes.alloc_pods.astype(np.int64).sum()), 1 << 26))
     try:
         return eng.run(max_limit=max_limit, mode=mode, want_log=True, log_cap=max(1, cap))
@@ -176,7 +191,9 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
 
 def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     ap = argparse.ArgumentParser(prog="cluster-capacity", description="Cluster-capacity is used for simulating scheduling of one or multiple pods")
-    ap.add_argument("--podspec", default="", help="Path to JSON or YAML file containing pod definition.")
+    ap.add_argument("--podspec", action="append", default=[],
+                    help="Path to JSON or YAML file containing pod definition.  Repeatable: the templates are cycled round-robin "
+                         "(scheduled pod i is a clone of template i mod P, as the reference's report layer counts them)")
     ap.add_argument("--genpod", default="", metavar="NAMESPACE",
                     help="cmd/genpod: print the pod the namespace's LimitRanges / node-selector annotation describe (objects from --snapshot)")
     ap.add_argument("--snapshot", action="append", required=True, help="File(s) with the cluster's Node and Pod objects (replaces --kubeconfig)")
@@ -207,7 +224,8 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         with open(args.default_config) as f:
             cfg = yaml.safe_load(f)
     prof, hard_weight = schedconfig.profile_from_config(cfg)
-    pod = parse_pod_spec(args.podspec)
+    pods = [parse_pod_spec(p) for p in args.podspec]
+    pod = pods if len(pods) > 1 else pods[0]
     node_objs, pod_objs, ns_objs = load_all(args.snapshot)
     snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
                                  namespace_objs=ns_objs)
@@ -219,7 +237,8 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         # left unset: the reference's default is 0 = adaptive sampling (defaults.go:106-129).  The final capacity and distribution
         # do not depend on it when nothing observes the ORDER of the placements (no --max-limit, no topology-coupled plugin): then
         # every node is scored (the fast batched mode); otherwise the reference's default applies
-        pct = 0 if (args.max_limit > 0 or snap.pod.spread or snap.pod.ipa is not None) else 100
+        # (several templates are always searched completely: the engine's windows need every node scored)
+        pct = 0 if len(pods) == 1 and (args.max_limit > 0 or snap.pod.spread or snap.pod.ipa is not None) else 100
     result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=pct, profile=prof)
     review = build_review(pod, snap, result, args.max_limit)
     if args.output == "json":

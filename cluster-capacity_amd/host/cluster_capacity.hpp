@@ -28,12 +28,16 @@ class ClusterCapacity {
     std::string mode; // "" = batched unless the pod couples nodes or the search is sampled
 
     static ClusterCapacity New(const HostProfile &kubeSchedulerConfig, Value simulatedPod, int64_t maxPods, std::vector<std::string> excludeNodes) {
+        return New(kubeSchedulerConfig, std::vector<Value>{std::move(simulatedPod)}, maxPods, std::move(excludeNodes));
+    }
+    // several templates: scheduled pod i is a clone of template i mod P (what the reference's report layer assumes, report.go:146-171)
+    static ClusterCapacity New(const HostProfile &kubeSchedulerConfig, std::vector<Value> simulatedPods, int64_t maxPods, std::vector<std::string> excludeNodes) {
         ClusterCapacity c;
-        c.profile_ = kubeSchedulerConfig, c.pod_ = std::move(simulatedPod), c.max_simulated_ = maxPods, c.exclude_ = std::move(excludeNodes);
+        c.profile_ = kubeSchedulerConfig, c.pods_ = std::move(simulatedPods), c.max_simulated_ = maxPods, c.exclude_ = std::move(excludeNodes);
         return c;
     }
     void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods, const std::vector<Value> &namespaces = {}) {
-        snap_ = build_snapshot(nodes, pods, pod_, exclude_, profile_.hard_pod_affinity_weight, namespaces);
+        snap_ = build_snapshot(nodes, pods, pods_, exclude_, profile_.hard_pod_affinity_weight, namespaces);
         synced_ = true;
     }
     void Run() {
@@ -42,12 +46,13 @@ class ClusterCapacity {
     }
     void SetResult(RunResult r) { // (test hook: a result that did not come from the engine)
         status_.Pods = std::move(r);
-        status_.StopReason = stop_reason(status_.Pods, (int64_t)snap_.n(), max_simulated_, snap_.taint_reasons, snap_.scalar_names);
+        const size_t failing = pods_.size() > 1 && status_.Pods.stop_spec >= 0 ? (size_t)status_.Pods.stop_spec : 0;
+        status_.StopReason = stop_reason(status_.Pods, (int64_t)snap_.n(), max_simulated_, snap_.side(failing).taint_reasons, snap_.scalar_names);
         ran_ = true;
     }
     Value Report() const {
         if (!ran_) throw std::runtime_error("ClusterCapacity.Report before Run");
-        return build_review(pod_, snap_, status_.Pods, max_simulated_);
+        return build_review(pods_, snap_, status_.Pods, max_simulated_);
     }
     const Status &GetStatus() const { return status_; }
     const Snapshot &snapshot() const { return snap_; }
@@ -55,7 +60,7 @@ class ClusterCapacity {
 
   private:
     HostProfile profile_;
-    Value pod_;
+    std::vector<Value> pods_;
     int64_t max_simulated_ = 0;
     std::vector<std::string> exclude_;
     Snapshot snap_;

@@ -24,6 +24,7 @@ struct Api {
     int (*load_nodes)(ccsim_engine *, const ccsim_nodes *) = nullptr;
     int (*set_profile)(ccsim_engine *, const ccsim_profile *) = nullptr;
     int (*set_pod)(ccsim_engine *, const ccsim_pod *) = nullptr;
+    int (*set_pods)(ccsim_engine *, const ccsim_pod *, int32_t) = nullptr;
     int (*run)(ccsim_engine *, int64_t, int32_t, ccsim_report *) = nullptr;
 };
 
@@ -62,20 +63,27 @@ inline Api load_api() {
     a.load_nodes = (int (*)(ccsim_engine *, const ccsim_nodes *))sym("ccsim_load_nodes");
     a.set_profile = (int (*)(ccsim_engine *, const ccsim_profile *))sym("ccsim_set_profile");
     a.set_pod = (int (*)(ccsim_engine *, const ccsim_pod *))sym("ccsim_set_pod");
+    a.set_pods = (int (*)(ccsim_engine *, const ccsim_pod *, int32_t))sym("ccsim_set_pods");
     a.run = (int (*)(ccsim_engine *, int64_t, int32_t, ccsim_report *))sym("ccsim_run");
     if (a.abi_version() != CCSIM_ABI_VERSION) throw std::runtime_error("libccsim ABI version mismatch");
     return a;
 }
 
 // Snapshot -> the structs of include/ccsim.h (pointers into the snapshot and into `hold`)
-struct Marshalled {
-    ccsim_nodes nodes{};
+struct MarshalledPod { // one template: the struct + the arrays it points into
     ccsim_pod pod{};
-    ccsim_profile profile{};
     std::vector<ccsim_requirement> reqs;
     std::vector<uint8_t> tables;
     std::vector<ccsim_term> required, preferred;
 };
+struct Marshalled {
+    ccsim_nodes nodes{};
+    ccsim_profile profile{};
+    std::vector<MarshalledPod> pods; // one per template (sized before the structs are filled: they point into themselves)
+    std::vector<ccsim_pod> pod_array; // contiguous copies for ccsim_set_pods
+};
+
+inline void marshal_pod(const PodSide &s, MarshalledPod &m);
 
 inline void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
     const int64_t N = (int64_t)s.n();
@@ -86,7 +94,14 @@ inline void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
     n.taintset_id = s.taintset_id.data(), n.unschedulable = s.unschedulable.data();
     n.n_label_cols = (int32_t)s.label_cols.size();
     for (size_t c = 0; c < s.label_cols.size(); c++) n.label_cols[c] = s.label_cols[c].data();
+    m.pods.resize(s.n_templates());
+    for (size_t t = 0; t < s.n_templates(); t++) marshal_pod(s.side(t), m.pods[t]);
+    m.pod_array.clear();
+    for (const auto &mp : m.pods) m.pod_array.push_back(mp.pod); // (the pointers inside stay valid: they point into m.pods[t])
+    m.profile = prof.c;
+}
 
+inline void marshal_pod(const PodSide &s, MarshalledPod &m) {
     ccsim_pod &p = m.pod;
     for (size_t c = 0; c < s.preq.size(); c++) p.req[c] = s.preq[c];
     p.has_scalar_entries = s.has_scalar_entries, p.nz_mcpu = s.pod_nz_cpu, p.nz_mem = s.pod_nz_mem;
@@ -149,7 +164,6 @@ inline void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
     p.has_host_ports = s.has_host_ports;
     p.host_ports_conflict = s.host_ports_conflict.empty() ? nullptr : s.host_ports_conflict.data();
     p.image_score = s.image_score.empty() ? nullptr : s.image_score.data();
-    m.profile = prof.c;
 }
 
 inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::string &mode_flag, const HostProfile &prof, int device) {
@@ -160,7 +174,8 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     // topology-coupled plugin): then every node is scored (the fast batched mode).  Otherwise the reference's default applies,
     // so that the result is a legal outcome of the reference's default configuration.
     HostProfile prof_eff = prof;
-    if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = (max_limit > 0 || !s.spread.empty() || s.has_ipa) ? 0 : 100;
+    // (several templates are always searched completely: the engine's windows of pods x nodes need every node scored)
+    if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = (s.n_templates() == 1 && (max_limit > 0 || !s.spread.empty() || s.has_ipa)) ? 0 : 100;
     const int percentage = prof_eff.c.percentage_of_nodes_to_score;
     marshal(s, prof_eff, m);
     ccsim_config cfg{};
@@ -177,7 +192,8 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     };
     chk(api.load_nodes(e, &m.nodes), "ccsim_load_nodes");
     chk(api.set_profile(e, &m.profile), "ccsim_set_profile");
-    chk(api.set_pod(e, &m.pod), "ccsim_set_pod");
+    if (s.n_templates() == 1) chk(api.set_pod(e, &m.pod_array[0]), "ccsim_set_pod");
+    else chk(api.set_pods(e, m.pod_array.data(), (int32_t)m.pod_array.size()), "ccsim_set_pods"); // cycled round-robin by ccsim_run
     // a pod that couples nodes through topology domains, or a sampled search, is order-dependent: the literal loop
     const bool coupled = !s.spread.empty() || s.has_ipa;
     const bool sampled = percentage != 100 && s.n() >= 100;
@@ -194,13 +210,15 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     r.per_node_count.assign(std::max<size_t>(s.n(), 1), 0);
     r.log.assign((size_t)cap, 0);
     r.hist_taintset.assign(std::max<size_t>(s.taint_filter_ok.size(), 1), 0);
+    r.per_spec_count.assign(s.n_templates(), 0);
     ccsim_report rep{};
+    rep.per_spec_count = r.per_spec_count.data(), rep.per_spec_cap = (int32_t)r.per_spec_count.size(), rep.stop_spec = -1;
     rep.per_node_count = r.per_node_count.data(), rep.per_node_cap = (int64_t)r.per_node_count.size();
     rep.log = r.log.data(), rep.log_cap = cap;
     rep.hist_taintset = r.hist_taintset.data(), rep.hist_taintset_cap = (int32_t)r.hist_taintset.size();
     chk(api.run(e, max_limit, mode, &rep), "ccsim_run");
     api.destroy(e);
-    r.placed = rep.placed, r.stop = rep.stop, r.n_code_unschedulable = rep.n_code_unschedulable;
+    r.placed = rep.placed, r.stop = rep.stop, r.n_code_unschedulable = rep.n_code_unschedulable, r.stop_spec = rep.stop_spec;
     r.per_node_count.resize(s.n());
     r.log.resize((size_t)std::min<int64_t>(rep.log_len, cap));
     r.hist.assign(rep.hist, rep.hist + CCSIM_NREASON);

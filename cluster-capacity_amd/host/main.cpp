@@ -104,7 +104,7 @@ RunResult result_from_json(const Value &v) {
 }
 
 int usage(const char *msg) {
-    std::fprintf(stderr, "%s\nusage: cluster-capacity --podspec FILE --snapshot FILE [--snapshot FILE ...] [--max-limit N] [--exclude-nodes a,b]\n"
+    std::fprintf(stderr, "%s\nusage: cluster-capacity --podspec FILE [--podspec FILE ...] --snapshot FILE [--snapshot FILE ...] [--max-limit N] [--exclude-nodes a,b]\n"
                          "                        [--default-config FILE] [--verbose] [-o json|yaml] [--mode batched|sequential]\n"
                          "                        [--percentage-of-nodes-to-score P] [--device D]\n"
                          "       cluster-capacity --genpod NAMESPACE --snapshot FILE [--snapshot FILE ...] [-o json|yaml]\n",
@@ -115,7 +115,8 @@ int usage(const char *msg) {
 } // namespace
 
 int main(int argc, char **argv) {
-    std::string podspec, output, mode, dump, fake, sched_config, genpod_ns;
+    std::string output, mode, dump, fake, sched_config, genpod_ns;
+    std::vector<std::string> podspecs; // repeatable: the templates are cycled round-robin
     bool dump_profile = false, pct_flag = false;
     std::vector<std::string> snapshots, exclude;
     int64_t max_limit = 0;
@@ -132,7 +133,7 @@ int main(int argc, char **argv) {
             return argv[++i];
         };
         try {
-            if (a == "--podspec") podspec = need();
+            if (a == "--podspec") podspecs.push_back(need());
             else if (a == "--snapshot") snapshots.push_back(need());
             else if (a == "--max-limit") max_limit = std::stoll(need());
             else if (a == "--exclude-nodes") {
@@ -191,14 +192,16 @@ int main(int argc, char **argv) {
             return 1;
         }
     }
-    if (podspec.empty()) return usage("Pod spec file is missing"); // options.go / server.go:71-73
+    if (podspecs.empty()) return usage("Pod spec file is missing"); // options.go / server.go:71-73
     if (snapshots.empty()) return usage("--snapshot is required");
     if (!output.empty() && output != "json" && output != "yaml") return usage("output format must be json or yaml");
     try {
         HostProfile prof = profile_from_config(sched_config.empty() ? Value() : parse_documents(read_file(sched_config)).at(0));
         if (pct_flag) prof.c.percentage_of_nodes_to_score = percentage, prof.percentage_set = true;
         // runSimulator (cmd/cluster-capacity/app/server.go:163-183): New -> SyncWithClient -> Run -> Report
-        ClusterCapacity cc = ClusterCapacity::New(prof, parse_pod_spec(podspec), max_limit, exclude);
+        std::vector<Value> templates;
+        for (const auto &p : podspecs) templates.push_back(parse_pod_spec(p));
+        ClusterCapacity cc = ClusterCapacity::New(prof, templates, max_limit, exclude);
         cc.device = device, cc.mode = mode;
         std::vector<Value> node_objs, pod_objs, ns_objs;
         load_objects(snapshots, node_objs, pod_objs, ns_objs);

@@ -25,6 +25,8 @@ struct RunResult { // what ccsim_run hands back (host copies)
     std::vector<int32_t> per_node_count, log;
     std::vector<int64_t> hist, hist_taintset;
     int64_t n_code_unschedulable = 0;
+    std::vector<int32_t> per_spec_count; // several templates: placements per template ...
+    int32_t stop_spec = -1;              // ... and the template whose pod was Unschedulable
 };
 
 inline std::string histogram_message(const std::map<std::string, int64_t> &reasons) {
@@ -166,23 +168,40 @@ inline std::string utc_now_iso() {
     return buf;
 }
 
-// report.go:196-225 GetReport
-inline Value build_review(const Value &pod, const Snapshot &snap, const RunResult &r, int64_t max_limit) {
-    const std::string stop = stop_reason(r, (int64_t)snap.n(), max_limit, snap.taint_reasons, snap.scalar_names);
+// report.go:196-225 GetReport.  Scheduled pod i is a clone of template i mod P (parsePodsReview, report.go:146-171): exactly
+// the order the engine cycles the templates in.
+inline Value build_review(const std::vector<Value> &templates_in, const Snapshot &snap, const RunResult &r, int64_t max_limit) {
+    const size_t P = templates_in.size();
+    const size_t failing = P > 1 && r.stop_spec >= 0 ? (size_t)r.stop_spec : 0; // the FitError describes the template that did not fit
+    const std::string stop = stop_reason(r, (int64_t)snap.n(), max_limit, snap.side(failing).taint_reasons, snap.scalar_names);
     Value spec = Value::object();
     Value templates = Value::array(), reqs = Value::array();
-    templates.a.push_back(pod), reqs.a.push_back(pod_requirements(pod));
+    for (const auto &pod : templates_in) templates.a.push_back(pod), reqs.a.push_back(pod_requirements(pod));
     spec.set("templates", templates), spec.set("replicas", Value::num(0)), spec.set("podRequirements", reqs);
-    Value p = Value::object();
-    p.set("podName", Value::str(pod["metadata"]["name"].text())), p.set("replicasOnNodes", replicas_on_nodes(r, snap.names)), p.set("failSummary", Value());
+    if (P > 1 && (int64_t)r.log.size() < r.placed) throw std::runtime_error("several templates: the placement log does not cover the run");
     Value pods = Value::array();
-    pods.a.push_back(p);
+    for (size_t t = 0; t < P; t++) {
+        Value p = Value::object();
+        p.set("podName", Value::str(templates_in[t]["metadata"]["name"].text()));
+        if (P == 1) p.set("replicasOnNodes", replicas_on_nodes(r, snap.names));
+        else { // this template's clones: log entries t, t + P, t + 2P, ...
+            RunResult rt;
+            rt.per_node_count.assign(snap.n(), 0);
+            for (size_t i = t; i < r.log.size(); i += P) rt.log.push_back(r.log[i]), rt.per_node_count[(size_t)r.log[i]] += 1;
+            p.set("replicasOnNodes", replicas_on_nodes(rt, snap.names));
+        }
+        p.set("failSummary", Value());
+        pods.a.push_back(p);
+    }
     Value status = Value::object();
     status.set("creationTimestamp", Value::str(utc_now_iso())), status.set("replicas", Value::num(r.placed));
     status.set("failReason", main_fail_reason(stop)), status.set("pods", pods);
     Value review = Value::object();
     review.set("spec", spec), review.set("status", status);
     return review;
+}
+inline Value build_review(const Value &pod, const Snapshot &snap, const RunResult &r, int64_t max_limit) {
+    return build_review(std::vector<Value>{pod}, snap, r, max_limit);
 }
 
 // report.go:235-283 clusterCapacityReviewPrettyPrint

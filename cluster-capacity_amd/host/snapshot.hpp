@@ -290,22 +290,16 @@ struct Ipa {
     int64_t entries_existing = 0;
 };
 
-struct Snapshot {
-    // nodes (canonical order)
-    std::vector<std::string> names, res_names, scalar_names, taint_reasons;
-    std::vector<std::vector<int64_t>> alloc, req;
-    std::vector<int32_t> alloc_pods, pod_count, taintset_id;
-    std::vector<int64_t> nz_mcpu, nz_mem;
-    std::vector<uint8_t> unschedulable;
-    std::vector<std::string> label_keys;
-    std::vector<std::vector<int32_t>> label_cols;
-    // the simulated pod
+// What ONE template (simulated pod spec) contributes: requests, the verdict of its tolerations on every distinct taint set,
+// selector / affinity terms as requirement tables over the shared label columns, spread constraints, inter-pod terms, ports, images.
+struct PodSide {
     std::vector<int64_t> preq;
     int64_t pod_nz_cpu = 0, pod_nz_mem = 0;
     bool has_scalar_entries = false, tolerates_unschedulable = false, affinity_filter_active = false, has_node_selector = false,
          has_required_terms = false;
     std::vector<uint8_t> taint_filter_ok;
     std::vector<int32_t> taint_prefer_cnt;
+    std::vector<std::string> taint_reasons; // per taint set: the FitError text of its first untolerated taint
     Term node_selector;
     std::vector<Term> required;
     std::vector<std::pair<int, Term>> preferred;
@@ -316,7 +310,23 @@ struct Snapshot {
     bool has_host_ports = false;              // NodePorts: util.GetHostPorts(pod) is not empty
     std::vector<uint8_t> host_ports_conflict; // per node: an existing pod holds a conflicting port; empty = none does
     std::vector<uint8_t> image_score;         // ImageLocality score per node (0..100); empty = no image of the pod anywhere
+};
+
+// The snapshot: node columns shared by every template + the first template (as base class: the single-template code reads
+// s.preq, s.spread, ... as before) + the further templates of a `--podspec a --podspec b ...` run (`more`).
+struct Snapshot : PodSide {
+    // nodes (canonical order)
+    std::vector<std::string> names, res_names, scalar_names;
+    std::vector<std::vector<int64_t>> alloc, req;
+    std::vector<int32_t> alloc_pods, pod_count, taintset_id;
+    std::vector<int64_t> nz_mcpu, nz_mem;
+    std::vector<uint8_t> unschedulable;
+    std::vector<std::string> label_keys;
+    std::vector<std::vector<int32_t>> label_cols;
+    std::vector<PodSide> more; // templates 1 .. P-1
     size_t n() const { return names.size(); }
+    size_t n_templates() const { return 1 + more.size(); }
+    const PodSide &side(size_t t) const { return t == 0 ? static_cast<const PodSide &>(*this) : more[t - 1]; }
 };
 
 // ---- host ports (NodePorts) --------------------------------------------------------------------------------------
@@ -391,10 +401,11 @@ inline bool any_nonzero(const std::vector<int32_t> &v) {
     return false;
 }
 
-inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const Value &sim_pod,
+inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const std::vector<Value> &sim_pods,
                                const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1,
                                const std::vector<Value> &namespace_objs = {}) {
-    Snapshot s;
+    if (sim_pods.empty()) throw std::runtime_error("no pod spec");
+    Snapshot S;
     NamespaceLabels ns_labels;
     for (const auto &n : namespace_objs) ns_labels[n["metadata"]["name"].text()] = n["metadata"]["labels"];
     auto tm = [&](const Value &term, const std::string &owner_ns, const std::string &pod_ns, const Value &pod_labels) {
@@ -407,39 +418,35 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     const size_t N = nodes.size();
     std::map<std::string, size_t> index;
     for (size_t i = 0; i < N; i++) {
-        s.names.push_back((*nodes[i])["metadata"]["name"].text());
-        index[s.names.back()] = i;
+        S.names.push_back((*nodes[i])["metadata"]["name"].text());
+        index[S.names.back()] = i;
     }
-    const Value &spec = sim_pod["spec"];
-    const std::string sim_ns = ns_of(sim_pod);
-    const Value &sim_labels = sim_pod["metadata"]["labels"];
-
-    // resources: cpu, memory, ephemeral-storage + every scalar resource the pod names
+    // resources: cpu, memory, ephemeral-storage + every scalar resource a template names
     std::set<std::string> req_names;
-    for (const char *list : {"containers", "initContainers"})
-        for (const auto &c : spec[list].items())
-            for (const auto &kv : c["resources"]["requests"].fields()) req_names.insert(kv.first);
-    for (const auto &kv : spec["resources"]["requests"].fields()) req_names.insert(kv.first); // pod-level requests (hugepages-*)
-    for (const auto &kv : spec["overhead"].fields()) req_names.insert(kv.first);
+    for (const Value &sp : sim_pods) {
+        const Value &spec = sp["spec"];
+        for (const char *list : {"containers", "initContainers"})
+            for (const auto &c : spec[list].items())
+                for (const auto &kv : c["resources"]["requests"].fields()) req_names.insert(kv.first);
+        for (const auto &kv : spec["resources"]["requests"].fields()) req_names.insert(kv.first); // pod-level requests (hugepages-*)
+        for (const auto &kv : spec["overhead"].fields()) req_names.insert(kv.first);
+    }
     for (const auto &n : req_names) // std::set iterates sorted
-        if (is_scalar_resource(n)) s.scalar_names.push_back(n);
-    if ((int)s.scalar_names.size() > CCSIM_MAX_SCALAR) // never drop a resource silently: the Fit filter would over-estimate
-        throw std::runtime_error("the pod names " + std::to_string(s.scalar_names.size()) + " scalar/extended resources; at most " +
+        if (is_scalar_resource(n)) S.scalar_names.push_back(n);
+    if ((int)S.scalar_names.size() > CCSIM_MAX_SCALAR) // never drop a resource silently: the Fit filter would over-estimate
+        throw std::runtime_error("the pod names " + std::to_string(S.scalar_names.size()) + " scalar/extended resources; at most " +
                                  std::to_string(CCSIM_MAX_SCALAR) + " are supported");
-    s.res_names = {"cpu", "memory", "ephemeral-storage"};
-    s.res_names.insert(s.res_names.end(), s.scalar_names.begin(), s.scalar_names.end());
-    const size_t R = s.res_names.size();
-    const PodRequests pr = pod_requests(spec, s.res_names);
-    s.preq = pr.req, s.pod_nz_cpu = pr.nz_cpu, s.pod_nz_mem = pr.nz_mem;
-    s.has_scalar_entries = !s.scalar_names.empty();
+    S.res_names = {"cpu", "memory", "ephemeral-storage"};
+    S.res_names.insert(S.res_names.end(), S.scalar_names.begin(), S.scalar_names.end());
+    const size_t R = S.res_names.size();
 
-    s.alloc.assign(R, std::vector<int64_t>(N, 0));
-    s.req.assign(R, std::vector<int64_t>(N, 0));
-    s.alloc_pods.assign(N, 0), s.pod_count.assign(N, 0), s.nz_mcpu.assign(N, 0), s.nz_mem.assign(N, 0);
+    S.alloc.assign(R, std::vector<int64_t>(N, 0));
+    S.req.assign(R, std::vector<int64_t>(N, 0));
+    S.alloc_pods.assign(N, 0), S.pod_count.assign(N, 0), S.nz_mcpu.assign(N, 0), S.nz_mem.assign(N, 0);
     for (size_t i = 0; i < N; i++) {
         const Value &a = (*nodes[i])["status"]["allocatable"];
-        for (size_t c = 0; c < R; c++) s.alloc[c][i] = res_of(a, s.res_names[c]);
-        s.alloc_pods[i] = a.has("pods") ? (int32_t)quantity_value(a["pods"].text()) : 0;
+        for (size_t c = 0; c < R; c++) S.alloc[c][i] = res_of(a, S.res_names[c]);
+        S.alloc_pods[i] = a.has("pods") ? (int32_t)quantity_value(a["pods"].text()) : 0;
     }
     std::vector<const Value *> live; // non-terminal pods bound to a kept node (simulator.go:193-200)
     std::vector<size_t> live_node;
@@ -449,15 +456,15 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         if (phase == "Succeeded" || phase == "Failed" || !index.count(node)) continue;
         const size_t i = index[node];
         live.push_back(&p), live_node.push_back(i);
-        const PodRequests r = pod_requests(p["spec"], s.res_names);
-        for (size_t c = 0; c < R; c++) s.req[c][i] += r.req[c];
-        s.nz_mcpu[i] += r.nz_cpu, s.nz_mem[i] += r.nz_mem, s.pod_count[i] += 1;
+        const PodRequests r = pod_requests(p["spec"], S.res_names);
+        for (size_t c = 0; c < R; c++) S.req[c][i] += r.req[c];
+        S.nz_mcpu[i] += r.nz_cpu, S.nz_mem[i] += r.nz_mem, S.pod_count[i] += 1;
     }
 
-    // taints -> distinct taint sets
-    const Value &tolerations = spec["tolerations"];
+    // taints -> distinct taint sets (per node); what a template's tolerations make of each set is the template's business
     std::map<std::string, int> sets;
-    s.taintset_id.assign(N, 0);
+    std::vector<const Value *> set_taints;
+    S.taintset_id.assign(N, 0);
     for (size_t i = 0; i < N; i++) {
         const Value &taints = (*nodes[i])["spec"]["taints"];
         std::string key;
@@ -465,15 +472,33 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         auto it = sets.find(key);
         if (it == sets.end()) {
             it = sets.emplace(key, (int)sets.size()).first;
-            const TaintVerdict v = taint_verdict(taints, tolerations);
-            s.taint_filter_ok.push_back(v.filter_ok), s.taint_prefer_cnt.push_back(v.prefer_cnt);
-            // taint_toleration.go:119
-            s.taint_reasons.push_back(v.first ? "node(s) had untolerated taint {" + (*v.first)["key"].text() + ": " + (*v.first)["value"].text() + "}" : "");
+            set_taints.push_back(&taints);
         }
-        s.taintset_id[i] = it->second;
+        S.taintset_id[i] = it->second;
     }
-    s.unschedulable.assign(N, 0);
-    for (size_t i = 0; i < N; i++) s.unschedulable[i] = (*nodes[i])["spec"]["unschedulable"].truthy();
+    S.unschedulable.assign(N, 0);
+    for (size_t i = 0; i < N; i++) S.unschedulable[i] = (*nodes[i])["spec"]["unschedulable"].truthy();
+    Interner it(nodes); // shared by the templates: a label column per key any of them touches
+
+    auto template_side = [&](const Value &sim_pod, PodSide &s) {
+    const Value &spec = sim_pod["spec"];
+    const std::string sim_ns = ns_of(sim_pod);
+    const Value &sim_labels = sim_pod["metadata"]["labels"];
+    const PodRequests pr = pod_requests(spec, S.res_names);
+    s.preq = pr.req, s.pod_nz_cpu = pr.nz_cpu, s.pod_nz_mem = pr.nz_mem;
+    for (const auto &n : S.scalar_names) { // len(ScalarResources) != 0: the template itself names a scalar resource
+        bool named = spec["resources"]["requests"].has(n) || spec["overhead"].has(n);
+        for (const char *list : {"containers", "initContainers"})
+            for (const auto &c : spec[list].items()) named = named || c["resources"]["requests"].has(n);
+        s.has_scalar_entries = s.has_scalar_entries || named;
+    }
+    const Value &tolerations = spec["tolerations"];
+    for (const Value *taints : set_taints) {
+        const TaintVerdict v = taint_verdict(*taints, tolerations);
+        s.taint_filter_ok.push_back(v.filter_ok), s.taint_prefer_cnt.push_back(v.prefer_cnt);
+        // taint_toleration.go:119
+        s.taint_reasons.push_back(v.first ? "node(s) had untolerated taint {" + (*v.first)["key"].text() + ": " + (*v.first)["value"].text() + "}" : "");
+    }
     {
         Value unsched = Value::object();
         unsched.set("key", Value::str(kUnschedTaint)), unsched.set("effect", Value::str("NoSchedule"));
@@ -482,7 +507,6 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     }
 
     // node affinity / node selector
-    Interner it(nodes);
     const Value &aff = spec["affinity"]["nodeAffinity"];
     const Value &node_selector = spec["nodeSelector"];
     const Value &req_aff = aff["requiredDuringSchedulingIgnoredDuringExecution"];
@@ -534,7 +558,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     {
         std::vector<size_t> by_name(N);
         for (size_t i = 0; i < N; i++) by_name[i] = i;
-        std::sort(by_name.begin(), by_name.end(), [&](size_t a, size_t b) { return s.names[a] < s.names[b]; });
+        std::sort(by_name.begin(), by_name.end(), [&](size_t a, size_t b) { return S.names[a] < S.names[b]; });
         std::map<std::string, int64_t> size;
         std::map<std::string, std::set<size_t>> holders;
         for (size_t i : by_name)
@@ -609,7 +633,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             k.node_included.assign(N, 1);
             for (size_t i = 0; i < N; i++) {
                 if (honor_aff && !s.included[i]) k.node_included[i] = 0;
-                if (honor_taints && !s.taint_filter_ok[(size_t)s.taintset_id[i]]) k.node_included[i] = 0;
+                if (honor_taints && !s.taint_filter_ok[(size_t)S.taintset_id[i]]) k.node_included[i] = 0;
             }
         }
         s.spread.push_back(std::move(k));
@@ -722,10 +746,40 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         s.has_ipa = true;
     }
     if ((int)s.spread.size() > CCSIM_MAX_TSC) throw Unsupported("too many topology spread constraints");
-    s.label_keys = it.keys;
-    s.label_cols = it.arrays;
-    if ((int)s.label_cols.size() > CCSIM_MAX_LABEL_COLS) throw Unsupported("too many distinct label keys in selectors");
-    return s;
+    }; // template_side
+
+    template_side(sim_pods[0], S);
+    for (size_t t = 1; t < sim_pods.size(); t++) {
+        S.more.emplace_back();
+        template_side(sim_pods[t], S.more.back());
+    }
+    S.label_keys = it.keys;
+    S.label_cols = it.arrays;
+    if ((int)S.label_cols.size() > CCSIM_MAX_LABEL_COLS) throw Unsupported("too many distinct label keys in selectors");
+    // several templates: what a clone contributes to the plugin state of later cycles is kept per template (the engine's
+    // ccsim_set_pods contract): no selector of one template may match the clones of another
+    if (sim_pods.size() > 1)
+        for (size_t a = 0; a < sim_pods.size(); a++) {
+            std::vector<const Value *> sels;
+            const Value &spec = sim_pods[a]["spec"];
+            for (const auto &c : spec["topologySpreadConstraints"].items()) sels.push_back(&c["labelSelector"]);
+            for (const char *kind : {"podAffinity", "podAntiAffinity"}) {
+                const Value &k = spec["affinity"][kind];
+                for (const auto &t : k["requiredDuringSchedulingIgnoredDuringExecution"].items()) sels.push_back(&t["labelSelector"]);
+                for (const auto &t : k["preferredDuringSchedulingIgnoredDuringExecution"].items()) sels.push_back(&t["podAffinityTerm"]["labelSelector"]);
+            }
+            for (size_t b = 0; b < sim_pods.size(); b++)
+                for (const Value *sel : sels)
+                    if (b != a && !sel->is_null() && !selector_empty(*sel) && label_selector_matches(*sel, sim_pods[b]["metadata"]["labels"]))
+                        throw Unsupported("several templates: a selector of template " + std::to_string(a) + " matches the labels of template " + std::to_string(b));
+        }
+    return S;
+}
+
+inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const Value &sim_pod,
+                               const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1,
+                               const std::vector<Value> &namespace_objs = {}) {
+    return build_snapshot(node_objs, pod_objs, std::vector<Value>{sim_pod}, exclude_nodes, hard_pod_affinity_weight, namespace_objs);
 }
 
 // ---- the dump the CPU tests compare with the Python ingest (tests/test_native_host.py) -------------------------
@@ -743,22 +797,7 @@ inline Value term_json(const Term &t) {
     }
     return a;
 }
-inline Value snapshot_json(const Snapshot &s) {
-    Value o = Value::object();
-    auto strs = [](const std::vector<std::string> &v) {
-        Value a = Value::array();
-        for (auto &x : v) a.a.push_back(Value::str(x));
-        return a;
-    };
-    o.set("names", strs(s.names)), o.set("res_names", strs(s.res_names)), o.set("scalar_names", strs(s.scalar_names));
-    o.set("taint_reasons", strs(s.taint_reasons));
-    Value alloc = Value::array(), req = Value::array(), cols = Value::array();
-    for (auto &c : s.alloc) alloc.a.push_back(int_array(c));
-    for (auto &c : s.req) req.a.push_back(int_array(c));
-    for (auto &c : s.label_cols) cols.a.push_back(int_array(c));
-    o.set("alloc", alloc), o.set("req", req), o.set("label_cols", cols), o.set("label_keys", strs(s.label_keys));
-    o.set("alloc_pods", int_array(s.alloc_pods)), o.set("pod_count", int_array(s.pod_count)), o.set("taintset_id", int_array(s.taintset_id));
-    o.set("nz_mcpu", int_array(s.nz_mcpu)), o.set("nz_mem", int_array(s.nz_mem)), o.set("unschedulable", int_array(s.unschedulable));
+inline Value pod_side_json(const PodSide &s) {
     Value p = Value::object();
     p.set("req", int_array(s.preq)), p.set("nz_mcpu", Value::num(s.pod_nz_cpu)), p.set("nz_mem", Value::num(s.pod_nz_mem));
     p.set("has_scalar_entries", Value::boolean(s.has_scalar_entries)), p.set("taint_filter_ok", int_array(s.taint_filter_ok));
@@ -800,7 +839,30 @@ inline Value snapshot_json(const Snapshot &s) {
     p.set("has_host_ports", Value::boolean(s.has_host_ports));
     p.set("host_ports_conflict", s.host_ports_conflict.empty() ? Value() : int_array(s.host_ports_conflict));
     p.set("image_score", s.image_score.empty() ? Value() : int_array(s.image_score));
-    o.set("pod", p);
+    return p;
+}
+inline Value snapshot_json(const Snapshot &s) {
+    Value o = Value::object();
+    auto strs = [](const std::vector<std::string> &v) {
+        Value a = Value::array();
+        for (auto &x : v) a.a.push_back(Value::str(x));
+        return a;
+    };
+    o.set("names", strs(s.names)), o.set("res_names", strs(s.res_names)), o.set("scalar_names", strs(s.scalar_names));
+    o.set("taint_reasons", strs(s.taint_reasons));
+    Value alloc = Value::array(), req = Value::array(), cols = Value::array();
+    for (auto &c : s.alloc) alloc.a.push_back(int_array(c));
+    for (auto &c : s.req) req.a.push_back(int_array(c));
+    for (auto &c : s.label_cols) cols.a.push_back(int_array(c));
+    o.set("alloc", alloc), o.set("req", req), o.set("label_cols", cols), o.set("label_keys", strs(s.label_keys));
+    o.set("alloc_pods", int_array(s.alloc_pods)), o.set("pod_count", int_array(s.pod_count)), o.set("taintset_id", int_array(s.taintset_id));
+    o.set("nz_mcpu", int_array(s.nz_mcpu)), o.set("nz_mem", int_array(s.nz_mem)), o.set("unschedulable", int_array(s.unschedulable));
+    o.set("pod", pod_side_json(s));
+    if (!s.more.empty()) { // templates 1 .. P-1
+        Value more = Value::array();
+        for (const auto &m : s.more) more.a.push_back(pod_side_json(m));
+        o.set("more_pods", more);
+    }
     return o;
 }
 

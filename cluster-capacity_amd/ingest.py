@@ -118,6 +118,14 @@ def _named_anywhere(spec: dict, name: str) -> bool:
     return name in ((spec.get("resources") or {}).get("requests") or {}) and _pod_level_supported(name)
 
 
+def _named_anywhere_any(spec: dict, name: str) -> bool:
+    """Does the template's own ResourceList hold `name` (container, init container, pod level or overhead)?"""
+    for c in (spec.get("containers") or []) + (spec.get("initContainers") or []):
+        if name in ((c.get("resources") or {}).get("requests") or {}):
+            return True
+    return name in ((spec.get("resources") or {}).get("requests") or {}) or name in (spec.get("overhead") or {})
+
+
 def pod_requests(spec: dict, names: Sequence[str]):
     """-> (requests per name, non-zero cpu, non-zero memory).  helpers.go:144-251 PodRequests + types.go:700-734, 1095-1124:
     without pod-level requests every container lacking cpu / memory counts 100m / 200Mi; WITH pod-level requests
@@ -332,10 +340,14 @@ def _node_selector_term(it: Interner, term: dict) -> List["M.Requirement"]:
 
 # ---- the snapshot -----------------------------------------------------------------------------------------------
 class Snapshot:
-    """Everything the engine needs, plus the strings the report needs."""
+    """Everything the engine needs, plus the strings the report needs.  With several templates (`--podspec` repeated: the
+    reference's report layer takes pod i as a clone of template i mod P, report.go:146-171) `pod` / `taint_reasons` describe
+    the first one and `pods` / `taint_reasons_all` all of them; the node columns (incl. the label columns every template's
+    selectors and topology keys touch) are shared."""
 
     def __init__(self, nodes: M.NodesSoA, pod: M.PodSpec, names: List[str], taint_reasons: List[str], scalar_names: List[str]):
         self.nodes, self.pod, self.names, self.taint_reasons, self.scalar_names = nodes, pod, names, taint_reasons, scalar_names
+        self.pods, self.taint_reasons_all = [pod], [taint_reasons]
 
 
 def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict, ns_labels: Optional[Dict[str, dict]] = None) -> bool:
@@ -353,33 +365,30 @@ def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict, ns_labels: Opti
     return label_selector_matches(term.get("labelSelector"), pod["metadata"].get("labels") or {})
 
 
-def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, exclude_nodes: Sequence[str] = (),
+def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude_nodes: Sequence[str] = (),
                    hard_pod_affinity_weight: int = 1, namespace_objs: Sequence[dict] = ()) -> Snapshot:
-    """SyncWithClient (simulator.go:176-295: namespaces, nodes, pods) + every per-pod-spec precomputation, in integers."""
+    """SyncWithClient (simulator.go:176-295: namespaces, nodes, pods) + every per-pod-spec precomputation, in integers.
+    `sim_pod`: the template, or a list of templates (cycled round-robin by the simulation)."""
+    sim_pods = list(sim_pod) if isinstance(sim_pod, (list, tuple)) else [sim_pod]
     ns_labels = {n["metadata"]["name"]: (n["metadata"].get("labels") or {}) for n in namespace_objs}
-
-    def tm(term, owner_ns, pod):
-        return _term_matches_pod(term, owner_ns, pod, ns_labels)
 
     nodes = canonical_node_order([n for n in node_objs if n["metadata"]["name"] not in set(exclude_nodes)])
     N = len(nodes)
     names = [n["metadata"]["name"] for n in nodes]
     index = {nm: i for i, nm in enumerate(names)}
-    spec = sim_pod.get("spec") or {}
-    sim_ns = sim_pod["metadata"].get("namespace") or "default"
-    sim_labels = sim_pod["metadata"].get("labels") or {}
 
-    # resources: cpu, memory, ephemeral-storage + every scalar resource the pod names
+    # resources: cpu, memory, ephemeral-storage + every scalar resource a template names
     req_names = set()
-    for c in (spec.get("containers") or []) + (spec.get("initContainers") or []):
-        req_names |= set(((c.get("resources") or {}).get("requests") or {}).keys())
-    req_names |= set(((spec.get("resources") or {}).get("requests") or {}).keys())  # pod-level requests (hugepages-*)
-    req_names |= set((spec.get("overhead") or {}).keys())
+    for sp in sim_pods:
+        spec = sp.get("spec") or {}
+        for c in (spec.get("containers") or []) + (spec.get("initContainers") or []):
+            req_names |= set(((c.get("resources") or {}).get("requests") or {}).keys())
+        req_names |= set(((spec.get("resources") or {}).get("requests") or {}).keys())  # pod-level requests (hugepages-*)
+        req_names |= set((spec.get("overhead") or {}).keys())
     scalars = sorted(n for n in req_names if is_scalar_resource(n))
     if len(scalars) > M.MAX_SCALAR:  # never drop a resource silently: the Fit filter would over-estimate the capacity
         raise ValueError(f"the pod names {len(scalars)} scalar/extended resources; at most {M.MAX_SCALAR} are supported")
     res_names = ["cpu", "memory", "ephemeral-storage"] + scalars
-    preq, nz_cpu, nz_mem = pod_requests(spec, res_names)
 
     alloc = [np.zeros(N, np.int64) for _ in res_names]
     alloc_pods = np.zeros(N, np.int32)
@@ -405,27 +414,77 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
         nzm[i] += m0
         pcount[i] += 1
 
-    # taints -> distinct taint sets
-    tolerations = spec.get("tolerations") or []
+    # taints -> distinct taint sets (per node); what a template's tolerations make of each set is the template's business
     sets: Dict[str, int] = {}
+    set_taints: List[List[dict]] = []
     ts_id = np.zeros(N, np.int32)
-    ok, cnt, reasons = [], [], []
     for i, n in enumerate(nodes):
         taints = (n.get("spec") or {}).get("taints") or []
         key = repr([(t.get("key"), t.get("value"), t.get("effect")) for t in taints])
         if key not in sets:
             sets[key] = len(sets)
-            f, c, first = taint_verdict(taints, tolerations)
-            ok.append(f)
-            cnt.append(c)
-            # taint_toleration.go:119
-            reasons.append("" if first is None else f"node(s) had untolerated taint {{{first.get('key')}: {first.get('value') or ''}}}")
+            set_taints.append(taints)
         ts_id[i] = sets[key]
     unsched = np.array([1 if (n.get("spec") or {}).get("unschedulable") else 0 for n in nodes], np.uint8)
+    it = Interner(nodes)  # shared by the templates: a label column per key any of them touches
+
+    ctx = dict(nodes=nodes, N=N, index=index, live=live, ns_labels=ns_labels, res_names=res_names, scalars=scalars, set_taints=set_taints,
+               ts_id=ts_id, it=it, hard_pod_affinity_weight=hard_pod_affinity_weight)
+    sides = [_template_side(ctx, sp) for sp in sim_pods]
+    soa = M.NodesSoA(alloc=alloc, alloc_pods=alloc_pods, req=req, nz_mcpu=nzc, nz_mem=nzm, pod_count=pcount,
+                     taintset_id=ts_id, unschedulable=unsched, label_cols=[a for a in it.arrays] or [], names=names,
+                     scalar_names=scalars)
+    snap = Snapshot(soa, sides[0][0], names, sides[0][1], scalars)
+    snap.pods, snap.taint_reasons_all = [p for p, _ in sides], [r for _, r in sides]
+    if len(sides) > 1:
+        _check_templates_disjoint(sim_pods)
+    return snap
+
+
+def _check_templates_disjoint(sim_pods: List[dict]):
+    """Several templates: what a clone contributes to the plugin state of later cycles is kept per template (the engine's
+    ccsim_set_pods contract, include/ccsim.h): no selector of one template may match the clones of another."""
+    for a_i, a in enumerate(sim_pods):
+        spec = a.get("spec") or {}
+        sels = [c.get("labelSelector") for c in spec.get("topologySpreadConstraints") or []]
+        aff = spec.get("affinity") or {}
+        for kind in ("podAffinity", "podAntiAffinity"):
+            k = aff.get(kind) or {}
+            sels += [t.get("labelSelector") for t in k.get("requiredDuringSchedulingIgnoredDuringExecution") or []]
+            sels += [(t.get("podAffinityTerm") or {}).get("labelSelector") for t in k.get("preferredDuringSchedulingIgnoredDuringExecution") or []]
+        for b_i, b in enumerate(sim_pods):
+            if b_i == a_i:
+                continue
+            for sel in sels:
+                if sel is not None and not selector_empty(sel) and label_selector_matches(sel, b["metadata"].get("labels") or {}):
+                    raise NotImplementedError(f"several templates: a selector of template {a_i} matches the labels of template {b_i}")
+
+
+def _template_side(ctx: dict, sim_pod: dict):
+    """Everything one template contributes: -> (PodSpec, reason string per taint set)."""
+    nodes, N, index, live, ns_labels, res_names, scalars = (ctx[k] for k in ("nodes", "N", "index", "live", "ns_labels", "res_names", "scalars"))
+    ts_id, it, hard_pod_affinity_weight = ctx["ts_id"], ctx["it"], ctx["hard_pod_affinity_weight"]
+
+    def tm(term, owner_ns, pod):
+        return _term_matches_pod(term, owner_ns, pod, ns_labels)
+
+    spec = sim_pod.get("spec") or {}
+    sim_ns = sim_pod["metadata"].get("namespace") or "default"
+    sim_labels = sim_pod["metadata"].get("labels") or {}
+    preq, nz_cpu, nz_mem = pod_requests(spec, res_names)
+    own_scalars = [n for n in scalars if _named_anywhere_any(spec, n)]
+
+    tolerations = spec.get("tolerations") or []
+    ok, cnt, reasons = [], [], []
+    for taints in ctx["set_taints"]:
+        f, c, first = taint_verdict(taints, tolerations)
+        ok.append(f)
+        cnt.append(c)
+        # taint_toleration.go:119
+        reasons.append("" if first is None else f"node(s) had untolerated taint {{{first.get('key')}: {first.get('value') or ''}}}")
     tol_unsched = any(tolerates(t, {"key": UNSCHED_TAINT, "effect": "NoSchedule"}) for t in tolerations)
 
     # node affinity / node selector
-    it = Interner(nodes)
     aff = (spec.get("affinity") or {}).get("nodeAffinity") or {}
     node_selector = spec.get("nodeSelector")
     required = (aff.get("requiredDuringSchedulingIgnoredDuringExecution") or {}).get("nodeSelectorTerms")
@@ -446,7 +505,7 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
 
     pod = M.PodSpec(
         req=np.array([preq[r] for r in res_names], np.int64), nz_mcpu=nz_cpu, nz_mem=nz_mem,
-        has_scalar_entries=bool(scalars), taint_filter_ok=np.array(ok, np.uint8), taint_prefer_cnt=np.array(cnt, np.int32),
+        has_scalar_entries=bool(own_scalars), taint_filter_ok=np.array(ok, np.uint8), taint_prefer_cnt=np.array(cnt, np.int32),
         tolerates_unschedulable=tol_unsched, affinity_filter_active=affinity_active,
         has_node_selector=node_selector is not None and len(node_selector) > 0, node_selector=sel_reqs,
         has_required_terms=required is not None, required=req_terms, preferred=pref)
@@ -598,8 +657,4 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod: dict, e
         ipa.score_existing = [score_existing.get(k) for k in range(len(keys))]
         ipa.score_self, ipa.self_entries, ipa.entries_existing = score_self, self_entries, entries
         pod.ipa = ipa
-
-    soa = M.NodesSoA(alloc=alloc, alloc_pods=alloc_pods, req=req, nz_mcpu=nzc, nz_mem=nzm, pod_count=pcount,
-                     taintset_id=ts_id, unschedulable=unsched, label_cols=[a for a in it.arrays] or [], names=names,
-                     scalar_names=scalars)
-    return Snapshot(soa, pod, names, reasons, scalars)
+    return pod, reasons

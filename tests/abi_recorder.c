@@ -114,12 +114,33 @@ static void term(FILE *f, const ccsim_pod *p, const ccsim_term *t) { /* resolved
     fprintf(f, "]]");
 }
 
+static void record_pod(ccsim_engine *e, const ccsim_pod *p);
+
 int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *p) {
-    FILE *f = e->f;
-    const int64_t N = e->n;
     e->n_taintsets = p->n_taintsets;
     sep(e);
-    fprintf(f, "\"pod\": {");
+    fprintf(e->f, "\"pod\": ");
+    record_pod(e, p);
+    return 0;
+}
+
+/* several templates, cycled round-robin by ccsim_run */
+int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_pods) {
+    e->n_taintsets = pods[0].n_taintsets;
+    sep(e);
+    fprintf(e->f, "\"pods\": [");
+    for (int32_t i = 0; i < n_pods; i++) {
+        if (i) fprintf(e->f, ", ");
+        record_pod(e, &pods[i]);
+    }
+    fprintf(e->f, "]");
+    return 0;
+}
+
+static void record_pod(ccsim_engine *e, const ccsim_pod *p) {
+    FILE *f = e->f;
+    const int64_t N = e->n;
+    fprintf(f, "{");
     arr64(f, "req", p->req, CCSIM_MAX_RES);
     fprintf(f, ", \"has_scalar_entries\": %d, \"nz_mcpu\": %lld, \"nz_mem\": %lld, \"tolerates_unschedulable\": %d, \"affinity_filter_active\": %d, "
                "\"has_node_selector\": %d, \"has_required_terms\": %d, \"n_reqs\": %d, ",
@@ -165,7 +186,6 @@ int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *p) {
     arr8(f, "host_ports_conflict", p->host_ports_conflict, N), fprintf(f, ", ");
     arr8(f, "image_score", p->image_score, N);
     fprintf(f, "}");
-    return 0;
 }
 
 int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {

@@ -19,9 +19,7 @@ def native():
     return B.build_host()
 
 
-def py_dump(snap):
-    """The structure snapshot_json() of host/snapshot.hpp emits, from the Python Snapshot."""
-    n, p = snap.nodes, snap.pod
+def _pod_dump(p):
     lst = lambda a: None if a is None else [int(x) for x in a]
     term = lambda t: [{"col": int(c), "table": lst(tab)} for c, tab in t]
     ipa = None
@@ -32,23 +30,33 @@ def py_dump(snap):
                "anti_existing": [lst(x) for x in a.anti_existing], "exist_anti": [lst(x) for x in a.exist_anti],
                "score_existing": [lst(x) for x in a.score_existing], "score_self": lst(a.score_self), "self_entries": lst(a.self_entries),
                "entries_existing": int(a.entries_existing)}
-    return {
+    return {"req": lst(p.req), "nz_mcpu": int(p.nz_mcpu), "nz_mem": int(p.nz_mem), "has_scalar_entries": bool(p.has_scalar_entries),
+            "taint_filter_ok": lst(p.taint_filter_ok), "taint_prefer_cnt": lst(p.taint_prefer_cnt),
+            "tolerates_unschedulable": bool(p.tolerates_unschedulable), "affinity_filter_active": bool(p.affinity_filter_active),
+            "has_node_selector": bool(p.has_node_selector), "has_required_terms": bool(p.has_required_terms),
+            "node_selector": term(p.node_selector), "required": [term(t) for t in p.required],
+            "preferred": [{"weight": int(w), "term": term(t)} for w, t in p.preferred],
+            "spread": [{"col": int(k.col), "max_skew": int(k.max_skew), "min_domains": int(k.min_domains), "hard": bool(k.hard),
+                        "self_match": bool(k.self_match), "is_hostname": bool(k.is_hostname), "n_domains": int(k.n_domains),
+                        "node_match_count": lst(k.node_match_count), "node_included": lst(k.node_included)} for k in p.spread],
+            "ipa": ipa, "has_host_ports": bool(p.has_host_ports), "host_ports_conflict": lst(p.host_ports_conflict),
+            "image_score": lst(p.image_score)}
+
+
+def py_dump(snap):
+    """The structure snapshot_json() of host/snapshot.hpp emits, from the Python Snapshot."""
+    n = snap.nodes
+    lst = lambda a: None if a is None else [int(x) for x in a]
+    d = {
         "names": list(snap.names), "res_names": ["cpu", "memory", "ephemeral-storage"] + list(snap.scalar_names),
         "scalar_names": list(snap.scalar_names), "taint_reasons": list(snap.taint_reasons),
         "alloc": [lst(c) for c in n.alloc], "req": [lst(c) for c in n.req], "label_cols": [lst(c) for c in n.label_cols],
         "alloc_pods": lst(n.alloc_pods), "pod_count": lst(n.pod_count), "taintset_id": lst(n.taintset_id),
         "nz_mcpu": lst(n.nz_mcpu), "nz_mem": lst(n.nz_mem), "unschedulable": lst(n.unschedulable),
-        "pod": {"req": lst(p.req), "nz_mcpu": int(p.nz_mcpu), "nz_mem": int(p.nz_mem), "has_scalar_entries": bool(p.has_scalar_entries),
-                "taint_filter_ok": lst(p.taint_filter_ok), "taint_prefer_cnt": lst(p.taint_prefer_cnt),
-                "tolerates_unschedulable": bool(p.tolerates_unschedulable), "affinity_filter_active": bool(p.affinity_filter_active),
-                "has_node_selector": bool(p.has_node_selector), "has_required_terms": bool(p.has_required_terms),
-                "node_selector": term(p.node_selector), "required": [term(t) for t in p.required],
-                "preferred": [{"weight": int(w), "term": term(t)} for w, t in p.preferred],
-                "spread": [{"col": int(k.col), "max_skew": int(k.max_skew), "min_domains": int(k.min_domains), "hard": bool(k.hard),
-                            "self_match": bool(k.self_match), "is_hostname": bool(k.is_hostname), "n_domains": int(k.n_domains),
-                            "node_match_count": lst(k.node_match_count), "node_included": lst(k.node_included)} for k in p.spread],
-                "ipa": ipa, "has_host_ports": bool(p.has_host_ports), "host_ports_conflict": lst(p.host_ports_conflict),
-                "image_score": lst(p.image_score)}}
+        "pod": _pod_dump(snap.pod)}
+    if len(snap.pods) > 1:
+        d["more_pods"] = [_pod_dump(p) for p in snap.pods[1:]]
+    return d
 
 
 def rich_cluster():
@@ -970,3 +978,137 @@ def test_native_genpod_equals_python_genpod(native, tmp_path, fmt):
     (tmp_path / "pod.yaml").write_text(_run(native, ["--genpod", "limited", "--snapshot", str(tmp_path / "objs.yaml")]))
     d = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "nodes.json"), "--dump-snapshot", "-"]))
     assert d["pod"]["req"][:2] == [1500, 900 * 1024 * 1024] and d["scalar_names"] == ["nvdia.com/gpu"] and d["pod"]["has_node_selector"]
+
+
+# ---- several templates (--podspec repeated): scheduled pod i is a clone of template i mod P (report.go:146-171) -------
+def _templates_case(n_nodes=12):
+    """Config-5-shaped templates (zone DoNotSchedule spread + required hostname anti-affinity to their own label, one with a
+    node selector) over a small zoned cluster with one existing pod per template label."""
+    nodes = [node(f"m{i:02d}", cpu="4", mem="8Gi", pods="6", labels={"topology.kubernetes.io/zone": f"z{i % 3}", "kubernetes.io/hostname": f"m{i:02d}",
+                                                                     "disk": "ssd" if i % 2 else "hdd"}) for i in range(n_nodes)]
+    pods = [running_pod("old-a", "m01", cpu="500m", mem="256Mi", labels={"app": "t0"}), running_pod("old-b", "m05", cpu="1", labels={"app": "t1"})]
+    templates = []
+    for t, (cpu, mem) in enumerate([("500m", "512Mi"), ("1", "1Gi"), ("250m", "256Mi")]):
+        p = yaml.safe_load(EXAMPLES_POD)
+        p["metadata"]["name"], p["metadata"]["labels"] = f"tmpl-{t}", {"app": f"t{t}"}
+        p["spec"]["containers"][0]["resources"] = {"requests": {"cpu": cpu, "memory": mem}}
+        sel = {"matchLabels": {"app": f"t{t}"}}
+        p["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1 + t, "topologyKey": "topology.kubernetes.io/zone", "whenUnsatisfiable": "DoNotSchedule", "labelSelector": sel}]
+        p["spec"]["affinity"] = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [{"topologyKey": "kubernetes.io/hostname", "labelSelector": sel}]}}
+        if t == 1:
+            p["spec"]["nodeSelector"] = {"disk": "ssd"}
+        templates.append(p)
+    return nodes, pods, templates
+
+
+def _write_templates(tmp_path, nodes, pods, templates):
+    (tmp_path / "cluster.json").write_text(json.dumps({"kind": "List", "items": nodes + pods}))
+    paths = []
+    for t, p in enumerate(templates):
+        (tmp_path / f"t{t}.yaml").write_text(yaml.safe_dump(json.loads(json.dumps(p))))  # (a deep copy: no YAML anchors for shared sub-dicts)
+        paths.append(str(tmp_path / f"t{t}.yaml"))
+    return str(tmp_path / "cluster.json"), paths
+
+
+def test_several_templates_ingest_abi_and_report_agree(native, recorder, tmp_path):
+    import ctypes as C
+    from cluster_capacity_amd import capi
+    nodes, pods, templates = _templates_case()
+    cluster, paths = _write_templates(tmp_path, nodes, pods, templates)
+    flags = [x for p in paths for x in ("--podspec", p)] + ["--snapshot", cluster]
+    # (1) the integer snapshot: shared node columns, one pod side per template
+    got = json.loads(_run(native, flags + ["--dump-snapshot", "-"]))
+    pypods = [cli.parse_pod_spec(p) for p in paths]
+    snap = ingest.build_snapshot(*cli.load_objects([cluster]), pypods)
+    ref = py_dump(snap)
+    got.pop("label_keys")
+    assert got.keys() == ref.keys() and len(got["more_pods"]) == 2
+    for k in ref:
+        assert got[k] == ref[k], k
+    assert got["pod"]["spread"][0]["col"] == got["more_pods"][0]["spread"][0]["col"]  # one zone column for all templates
+    assert [p["has_node_selector"] for p in [got["pod"]] + got["more_pods"]] == [False, True, False]
+    # (2) what reaches ccsim_set_pods is identical from both hosts
+    env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "native.json"))
+    p = subprocess.run([native] + flags + ["--max-limit", "12", "-o", "json"], capture_output=True, text=True, env=env, timeout=60)
+    assert p.returncode == 0, p.stderr
+    native_rec = json.load(open(tmp_path / "native.json"))
+    lib = C.CDLL(recorder)
+    os.environ["CCSIM_RECORD"] = str(tmp_path / "python.json")
+    try:
+        cfg = capi.CConfig()
+        cfg.abi_version, cfg.use_graph = capi.ABI_VERSION, 1
+        h = C.c_void_p()
+        assert lib.ccsim_create(C.byref(cfg), C.byref(h)) == 0
+        keep = []
+        assert lib.ccsim_load_nodes(h, C.byref(capi.marshal_nodes(snap.nodes, keep))) == 0
+        assert lib.ccsim_set_profile(h, C.byref(capi.marshal_profile(M.Profile.default()))) == 0  # several templates: searched completely
+        arr = (capi.CPod * 3)(*[capi.marshal_pod(q, keep) for q in snap.pods])
+        assert lib.ccsim_set_pods(h, arr, 3) == 0
+        lib.ccsim_destroy(h)
+    finally:
+        os.environ.pop("CCSIM_RECORD")
+    python_rec = json.load(open(tmp_path / "python.json"))
+    for k in ("nodes", "profile", "pods"):
+        assert native_rec[k] == python_rec[k], k
+    # (3) the review: the recorder's canned log (node i at position i) split round-robin over the templates
+    rev = json.loads(p.stdout)
+    assert [q["podName"] for q in rev["status"]["pods"]] == ["tmpl-0", "tmpl-1", "tmpl-2"] and len(rev["spec"]["templates"]) == 3
+    for t in range(3):
+        assert [r["nodeName"] for r in rev["status"]["pods"][t]["replicasOnNodes"]] == snap.names[t::3]
+    res = M.RunResult(placed=12, stop=M.STOP_LIMIT, per_node_count=np.ones(12, np.int32), log=np.arange(12, dtype=np.int32),
+                      hist=np.zeros(M.NREASON, np.int64), hist_taintset=np.zeros(1, np.int64), n_code_unschedulable=0)
+    pyrev = cli.build_review(pypods, snap, res, 12)
+    assert pyrev["status"]["pods"] == rev["status"]["pods"] and pyrev["status"]["failReason"] == rev["status"]["failReason"]
+    pretty = subprocess.run([native] + flags + ["--max-limit", "12", "--verbose"], capture_output=True, text=True, env=env, timeout=60).stdout
+    assert pretty == cli.pretty(pyrev, True)
+    # (4) templates whose selectors match one another's clones are refused by both hosts
+    templates[1]["metadata"]["labels"] = {"app": "t0"}
+    cluster, paths = _write_templates(tmp_path, nodes, pods, templates)
+    bad = subprocess.run([native] + [x for q in paths for x in ("--podspec", q)] + ["--snapshot", cluster, "--dump-snapshot", "-"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "several templates" in bad.stderr
+    with pytest.raises(NotImplementedError, match="several templates"):
+        ingest.build_snapshot(*cli.load_objects([cluster]), [cli.parse_pod_spec(q) for q in paths])
+
+
+def test_several_templates_oracle_round_robin(ccref):
+    """The ingest's pod sides drive the oracle's round-robin loop (ccref_run_multi): per-template counts from the log match
+    what parsePodsReview would report, every template's clones respect ITS spread constraint and anti-affinity."""
+    nodes, pods, templates = _templates_case()
+    snap = ingest.build_snapshot(nodes, pods, templates)
+    r = ccref.run_multi(M.Profile.default(), snap.nodes, snap.pods)
+    assert r.stop == M.STOP_UNSCHEDULABLE and r.placed == int(r.per_spec_count.sum()) > 6
+    zone = snap.nodes.label_cols[snap.pods[0].spread[0].col]
+    for t in range(3):
+        mine = r.log[t::3]
+        assert len(mine) == r.per_spec_count[t] and len(set(mine.tolist())) == len(mine)  # hostname anti-affinity: one clone per node
+        if t == 1:
+            assert all(nodes_i % 2 == 1 for nodes_i in [int(snap.names[i][1:]) for i in mine])  # disk=ssd nodes only
+    rev = cli.build_review(templates, snap, M.RunResult(placed=r.placed, stop=r.stop, per_node_count=r.per_node_count, log=r.log, hist=r.hist,
+                                                        hist_taintset=r.hist_taintset, n_code_unschedulable=r.n_code_unschedulable,
+                                                        stop_spec=r.stop_spec), 0)
+    assert [sum(x["replicas"] for x in q["replicasOnNodes"]) for q in rev["status"]["pods"]] == r.per_spec_count.tolist()
+    assert rev["status"]["replicas"] == r.placed and rev["status"]["failReason"]["failType"] == "Unschedulable"
+
+
+@pytest.mark.gpu
+def test_several_templates_cli_end_to_end_both_hosts(ccref, native, tmp_path):
+    """--podspec a --podspec b --podspec c through the C++ host, the C ABI (ccsim_set_pods) and the HIP engine == the Python host
+    == the oracle's round-robin loop."""
+    import io
+    nodes, pods, templates = _templates_case(n_nodes=30)
+    cluster, paths = _write_templates(tmp_path, nodes, pods, templates)
+    flags = [x for p in paths for x in ("--podspec", p)] + ["--snapshot", cluster]
+    got = json.loads(_run(native, flags + ["-o", "json"]))
+    buf = io.StringIO()
+    assert cli.main(flags + ["-o", "json"], out=buf) == 0
+    ref = json.loads(buf.getvalue())
+    got["status"].pop("creationTimestamp"), ref["status"].pop("creationTimestamp")
+    assert got["status"] == ref["status"]
+    snap = ingest.build_snapshot(nodes, pods, [cli.parse_pod_spec(p) for p in paths])
+    r = ccref.run_multi(M.Profile.default(), snap.nodes, snap.pods)
+    assert got["status"]["replicas"] == r.placed
+    assert [sum(x["replicas"] for x in q["replicasOnNodes"]) for q in got["status"]["pods"]] == r.per_spec_count.tolist()
+    for t in range(3):  # first-placement order per template == the oracle's sequence
+        assert [x["nodeName"] for x in got["status"]["pods"][t]["replicasOnNodes"]] == [snap.names[i] for i in r.log[t::3]]
+    txt = _run(native, flags + ["--verbose", "--max-limit", "7"])
+    assert "Termination reason: LimitReached: Maximum number of pods simulated: 7" in txt and txt.count("The cluster can schedule") == 3
