@@ -170,6 +170,10 @@ def test_gpu_image_scores_on_the_c3_snapshot(ccref):
         e.load(nodes, pod, prof)
         _same(e.run(max_limit=3000, mode=mode, log_cap=3000), ref)
         e.close()
+    # the whole run until Unschedulable on the blind fast path, at a size the oracle finishes in seconds (the 20k-node full run
+    # costs the CPU oracle two minutes: 1.1 M cycles x 20k nodes)
+    nodes, pod, prof = synth.make_config("C3", n_nodes=1500, seed=98)
+    pod.image_score = (rng.integers(0, 101, nodes.n) * (rng.random(nodes.n) < 0.3)).astype(np.uint8)
     ref = ccref.run(prof, nodes, pod, threads=8, want_log=False)
     e = capi.Engine(device=0)
     e.load(nodes, pod, prof)
