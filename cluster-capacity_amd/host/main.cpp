@@ -31,41 +31,56 @@ using namespace cchost;
 namespace {
 
 std::string read_file(const std::string &path) {
-    std::ifstream f(path, std::ios::binary);
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
     if (!f) throw std::runtime_error("cannot open " + path);
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    return ss.str();
+    const std::streamoff size = f.tellg();
+    if (size < 0) { // not seekable (a pipe): stream it
+        std::ostringstream ss;
+        f.clear(), ss << f.rdbuf();
+        return ss.str();
+    }
+    std::string text((size_t)size, '\0');
+    f.seekg(0);
+    f.read(text.data(), size);
+    return text;
 }
 
-// every object of one kind in the snapshot files (lists are flattened)
-std::vector<Value> load_kind(const std::vector<std::string> &paths, const std::string &want) {
-    std::vector<Value> out;
-    for (const auto &path : paths)
-        for (const Value &d : parse_documents(read_file(path))) {
+// Every object of the snapshot files goes to `sink` exactly once, MOVED out of the parsed documents (a kubectl dump of a large
+// cluster is hundreds of MB: copying the documents, as the first version did, cost more than parsing them); lists are flattened.
+template <class Sink> void for_each_object(const std::vector<std::string> &paths, Sink sink) {
+    for (const auto &path : paths) {
+        std::vector<Value> docs = parse_documents(read_file(path));
+        for (Value &d : docs) {
             if (!d.truthy()) continue;
             const std::string kind = d["kind"].text();
             const bool is_list = kind.size() >= 4 && kind.compare(kind.size() - 4, 4, "List") == 0 && d.has("items");
-            std::vector<Value> one{d};
-            for (const Value &o : is_list ? d["items"].items() : one)
-                if (o["kind"].text() == want) out.push_back(o);
+            if (!is_list) {
+                sink(std::move(d));
+                continue;
+            }
+            for (auto &kv : d.o)
+                if (kv.first == "items")
+                    for (Value &o : kv.second.a) sink(std::move(o));
         }
+    }
+}
+
+// every object of one kind in the snapshot files
+std::vector<Value> load_kind(const std::vector<std::string> &paths, const std::string &want) {
+    std::vector<Value> out;
+    for_each_object(paths, [&](Value &&o) {
+        if (o["kind"].text() == want) out.push_back(std::move(o));
+    });
     return out;
 }
 
 void load_objects(const std::vector<std::string> &paths, std::vector<Value> &nodes, std::vector<Value> &pods, std::vector<Value> &namespaces) {
-    for (const auto &path : paths)
-        for (const Value &d : parse_documents(read_file(path))) {
-            if (!d.truthy()) continue;
-            const std::string kind = d["kind"].text();
-            const bool is_list = kind.size() >= 4 && kind.compare(kind.size() - 4, 4, "List") == 0 && d.has("items");
-            std::vector<Value> one{d};
-            for (const Value &o : is_list ? d["items"].items() : one) {
-                if (o["kind"].text() == "Node") nodes.push_back(o);
-                else if (o["kind"].text() == "Pod") pods.push_back(o);
-                else if (o["kind"].text() == "Namespace") namespaces.push_back(o);
-            }
-        }
+    for_each_object(paths, [&](Value &&o) {
+        const std::string kind = o["kind"].text();
+        if (kind == "Node") nodes.push_back(std::move(o));
+        else if (kind == "Pod") pods.push_back(std::move(o));
+        else if (kind == "Namespace") namespaces.push_back(std::move(o));
+    });
 }
 
 // options.go:79-147 ParseAPISpec (defaults only; API validation is the apiserver's job)

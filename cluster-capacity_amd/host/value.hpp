@@ -187,7 +187,7 @@ class JsonParser {
             Value v = Value::object();
             i_++;
             skip_ws();
-            if (i_ < s_.size() && s_[i_] == '}') return i_++, v;
+            if (i_ < s_.size() && s_[i_] == '}') { i_++; return v; } // (not `return i_++, v`: a comma expression is no candidate for the implicit move and deep-copies v)
             while (true) {
                 skip_ws();
                 if (i_ >= s_.size() || s_[i_] != '"') fail("expected a key");
@@ -201,7 +201,7 @@ class JsonParser {
                     i_++;
                     continue;
                 }
-                if (i_ < s_.size() && s_[i_] == '}') return i_++, v;
+                if (i_ < s_.size() && s_[i_] == '}') { i_++; return v; } // (not `return i_++, v`: a comma expression is no candidate for the implicit move and deep-copies v)
                 fail("expected ',' or '}'");
             }
         }
@@ -209,7 +209,7 @@ class JsonParser {
             Value v = Value::array();
             i_++;
             skip_ws();
-            if (i_ < s_.size() && s_[i_] == ']') return i_++, v;
+            if (i_ < s_.size() && s_[i_] == ']') { i_++; return v; } // (not `return i_++, v`: a comma expression is no candidate for the implicit move and deep-copies v)
             while (true) {
                 v.a.push_back(parse_value());
                 skip_ws();
@@ -217,7 +217,7 @@ class JsonParser {
                     i_++;
                     continue;
                 }
-                if (i_ < s_.size() && s_[i_] == ']') return i_++, v;
+                if (i_ < s_.size() && s_[i_] == ']') { i_++; return v; } // (not `return i_++, v`: a comma expression is no candidate for the implicit move and deep-copies v)
                 fail("expected ',' or ']'");
             }
         }
@@ -478,7 +478,7 @@ class YamlParser {
             Value v = Value::array();
             i++;
             ws();
-            if (i < t.size() && t[i] == ']') return i++, v;
+            if (i < t.size() && t[i] == ']') { i++; return v; }
             while (true) {
                 v.a.push_back(parse_flow(t, i));
                 ws();
@@ -486,7 +486,7 @@ class YamlParser {
                     i++;
                     continue;
                 }
-                if (i < t.size() && t[i] == ']') return i++, v;
+                if (i < t.size() && t[i] == ']') { i++; return v; }
                 fail("multi-line flow sequence");
             }
         }
@@ -494,7 +494,7 @@ class YamlParser {
             Value v = Value::object();
             i++;
             ws();
-            if (i < t.size() && t[i] == '}') return i++, v;
+            if (i < t.size() && t[i] == '}') { i++; return v; }
             while (true) {
                 ws();
                 std::string k;
@@ -515,7 +515,7 @@ class YamlParser {
                     i++;
                     continue;
                 }
-                if (i < t.size() && t[i] == '}') return i++, v;
+                if (i < t.size() && t[i] == '}') { i++; return v; }
                 fail("multi-line flow mapping");
             }
         }
@@ -847,7 +847,9 @@ inline std::vector<Value> parse_documents(const std::string &text) {
     if (i < text.size() && (text[i] == '{' || text[i] == '[')) {
         try {
             JsonParser p(text);
-            return {p.parse_document()};
+            std::vector<Value> one;
+            one.push_back(p.parse_document()); // (moved: a braced list would copy the whole document)
+            return one;
         } catch (const std::exception &) { // a YAML document in flow style
         }
     }
