@@ -1,0 +1,36 @@
+"""The exactness argument of the several-pod-specs path (csrc/ccsim_multi.h), checked on the CPU: the Python restatement of the
+window algorithm (tests/window_model.py: scan against S0, candidate lists with hidden-node bounds, in-order commit or
+assign + verify) must reproduce the oracle's round-robin loop -- same log, same stop, same failing spec -- whatever the window
+size, the tile size and the commit variant."""
+import numpy as np
+import pytest
+
+from cluster_capacity_amd import model as M
+from test_multi import random_multi_case
+from window_model import WindowModel
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+@pytest.mark.parametrize("window,tile", [(1, 16), (5, 4), (64, 16), (64, 2)])
+@pytest.mark.parametrize("seed", range(10))
+def test_window_model_vs_oracle(ccref, seed, window, tile, parallel):
+    rng = np.random.default_rng(600 + seed)
+    nodes, pods, prof = random_multi_case(rng, int(rng.integers(20, 200)), int(rng.integers(2, 24)))
+    limit = int(rng.choice([0, 0, 37]))
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=limit)
+    got = WindowModel(prof, nodes, pods, tile=tile, topk=8 if tile > 2 else 3, window=window).run(limit, parallel=parallel)
+    assert got["placed"] == ref.placed and got["stop"] == ref.stop and got["stop_spec"] == ref.stop_spec
+    assert np.array_equal(got["log"], ref.log)
+
+
+def test_windows_end_early_and_still_match(ccref):
+    """Small tiles and a short candidate list force the bounds to end windows early (hidden nodes, exhausted lists): the result
+    still equals the oracle's, only the number of windows grows."""
+    rng = np.random.default_rng(4242)
+    nodes, pods, prof = random_multi_case(rng, 60, 12)
+    ref = ccref.run_multi(prof, nodes, pods)
+    wide = WindowModel(prof, nodes, pods, tile=16, topk=8, window=64).run(0)
+    tight = WindowModel(prof, nodes, pods, tile=2, topk=2, window=64).run(0)
+    for got in (wide, tight):
+        assert got["placed"] == ref.placed and np.array_equal(got["log"], ref.log)
+    assert tight["windows"] >= wide["windows"]
