@@ -91,7 +91,9 @@ def main():
     ap.add_argument("--limit", type=int, default=-1, help="placements per step (0 = until Unschedulable; "
                     "-1 = mode default: 0 for batched, 2048 for sequential)")
     ap.add_argument("--seq-rounds", type=int, default=2048, help="rounds of the sequential-mode sample (0 = skip)")
-    ap.add_argument("--cpu-rounds", type=int, default=160)
+    ap.add_argument("--cpu-rounds", type=int, default=1600,
+                    help="placement rounds of the CPU baseline sample (the oracle scans every node per round: ~9 ms per round at 1M nodes "
+                         "on 16 threads, so ~15 s); its placement log must equal the engine's first --cpu-rounds placements")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch timing run (PMC collection runs)")
     args = ap.parse_args()
