@@ -55,6 +55,12 @@ def lib_sha16() -> str:
     return hashlib.sha256(open(b.lib_path(), "rb").read()).hexdigest()[:16]
 
 
+def src_sha16() -> str:
+    from cluster_capacity_amd import build as b
+
+    return b.source_sha16()
+
+
 def cpu_baseline(nodes, pod, prof, rounds: int, engine_log):
     """Oracle (port of the reference algorithm) on the host cores, bounded sample.  Its placement log must equal the
     engine's first `rounds` placements (the checker checks the thing measured before the number is printed)."""
@@ -184,8 +190,8 @@ def main():
         pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")))
         if hi - lo != 1_000_000:
             pmc_note = "PMC traffic was collected at 1,000,000 nodes per GPU"
-        elif pj.get("lib_sha16") != sha:
-            pmc_note = f"stale: collected with libccsim.so {pj.get('lib_sha16')}, this run uses {sha}"
+        elif pj.get("lib_sha16") != sha and pj.get("src_sha16") != src_sha16():  # (the binary embeds its build path: the sources decide)
+            pmc_note = f"stale: collected with libccsim.so {pj.get('lib_sha16')} / sources {pj.get('src_sha16')}, this run uses {sha} / {src_sha16()}"
         else:
             pmc, pmc_note = pj["kernels"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so (profiles/r02/pmc_traffic.json)"
     except (OSError, KeyError, ValueError):

@@ -18,6 +18,18 @@ def lib_path() -> str:
     return os.path.join(CSRC, "libccsim.so")
 
 
+def source_sha16() -> str:
+    """Hash of everything libccsim.so is built from (sources, the ABI header, the flags).  The binary itself embeds the path of
+    the build directory, so the same sources built elsewhere give another file hash: measurement files are stamped with both."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + [d if os.path.isabs(d) else os.path.join(CSRC, d) for d in DEPS]:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _stale(out: str) -> bool:
     if not os.path.exists(out):
         return True

@@ -9,6 +9,7 @@ figure of kernels dominated by sparse accesses (k_level_commit) is indicative.""
 import collections
 import csv
 import json
+import os
 import re
 import sys
 
@@ -27,6 +28,17 @@ def averages(path):
     return acc
 
 
+def _source_sha16():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as ge
+
+    ge.load_package()
+    from cluster_capacity_amd import build as b
+
+    return b.source_sha16()
+
+
 def main():
     fetch, write = averages(sys.argv[1]), averages(sys.argv[2])
     out = {}
@@ -43,6 +55,7 @@ def main():
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cluster-capacity_amd", "csrc", "libccsim.so")
     json.dump({
         "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16],  # bench.py refuses traffic collected with another build
+        "src_sha16": _source_sha16(),  # ... where "build" means the sources + flags (the binary embeds its build directory)
         "workload": "bench.py C4 1,000,000 nodes, 1 GPU, batched mode (one timed step)",
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_pmc.sh); hbm_bytes_per_launch = "
                 "(2*FETCH_SIZE + WRITE_SIZE) KB, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); averages over ALL "
