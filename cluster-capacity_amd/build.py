@@ -66,7 +66,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", out] + \
-              [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-ldl"]
+              [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -25,6 +25,8 @@ class ClusterCapacity {
         std::string StopReason; // "LimitReached: ..." / "Unschedulable: <FitError>"
     };
     int device = 0;
+    int gpus = 1;               // > 1 (or force_sharded): node-range shards over the GPUs of this box, RCCL exchange per pass
+    bool force_sharded = false; // the sharded path with ONE rank (plumbing test on a one-GPU box)
     std::string mode; // "" = batched unless the pod couples nodes or the search is sampled
 
     static ClusterCapacity New(const HostProfile &kubeSchedulerConfig, Value simulatedPod, int64_t maxPods, std::vector<std::string> excludeNodes) {
@@ -42,7 +44,8 @@ class ClusterCapacity {
     }
     void Run() {
         if (!synced_) throw std::runtime_error("ClusterCapacity.Run before SyncWithClient");
-        SetResult(simulate(snap_, max_simulated_, mode, profile_, device));
+        if (gpus > 1 || force_sharded) SetResult(simulate_sharded(snap_, max_simulated_, mode, profile_, gpus));
+        else SetResult(simulate(snap_, max_simulated_, mode, profile_, device));
     }
     void SetResult(RunResult r) { // (test hook: a result that did not come from the engine)
         status_.Pods = std::move(r);

@@ -5,8 +5,10 @@
 #include <unistd.h>
 
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "profile.hpp"
@@ -26,6 +28,11 @@ struct Api {
     int (*set_pod)(ccsim_engine *, const ccsim_pod *) = nullptr;
     int (*set_pods)(ccsim_engine *, const ccsim_pod *, int32_t) = nullptr;
     int (*run)(ccsim_engine *, int64_t, int32_t, ccsim_report *) = nullptr;
+    // the sharded run driven inside the library over its own RCCL communicator (include/ccsim.h)
+    int (*dist_unique_id)(uint8_t *) = nullptr;
+    int (*dist_comm_init)(ccsim_engine *, const uint8_t *, int32_t, int32_t) = nullptr;
+    int (*dist_sync_tables)(ccsim_engine *) = nullptr;
+    int (*dist_run)(ccsim_engine *, int64_t, int32_t, ccsim_report *) = nullptr;
 };
 
 inline std::string exe_dir() {
@@ -65,6 +72,10 @@ inline Api load_api() {
     a.set_pod = (int (*)(ccsim_engine *, const ccsim_pod *))sym("ccsim_set_pod");
     a.set_pods = (int (*)(ccsim_engine *, const ccsim_pod *, int32_t))sym("ccsim_set_pods");
     a.run = (int (*)(ccsim_engine *, int64_t, int32_t, ccsim_report *))sym("ccsim_run");
+    a.dist_unique_id = (int (*)(uint8_t *))dlsym(a.h, "ccsim_dist_unique_id"); // (optional: only --gpus N > 1 needs them)
+    a.dist_comm_init = (int (*)(ccsim_engine *, const uint8_t *, int32_t, int32_t))dlsym(a.h, "ccsim_dist_comm_init");
+    a.dist_sync_tables = (int (*)(ccsim_engine *))dlsym(a.h, "ccsim_dist_sync_tables");
+    a.dist_run = (int (*)(ccsim_engine *, int64_t, int32_t, ccsim_report *))dlsym(a.h, "ccsim_dist_run");
     if (a.abi_version() != CCSIM_ABI_VERSION) throw std::runtime_error("libccsim ABI version mismatch");
     return a;
 }
@@ -226,5 +237,111 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     return r;
 }
 
+
+// ---- the snapshot sharded over the GPUs of one box (north star: "the node array shards across the 8 MI355X of one box with a
+// single RCCL max-loc exchange per placement round"): one thread and one engine per GPU, contiguous ranges of the canonical
+// node order, the whole run inside the library (ccsim_dist_run: scan -> ncclAllGather of 256 B per rank -> decide).  Results are
+// merged as the protocol defines them: totals are replicated, per-node counts concatenate, histograms add, every rank fills the
+// log positions of ITS placements (-1 elsewhere): the element-wise maximum is the log.
+inline RunResult simulate_sharded(const Snapshot &s, int64_t max_limit, const std::string &mode_flag, const HostProfile &prof, int n_gpus) {
+    const Api api = load_api();
+    if (!api.dist_unique_id || !api.dist_comm_init || !api.dist_sync_tables || !api.dist_run) throw std::runtime_error("libccsim.so lacks the ccsim_dist_* entry points");
+    if (s.n_templates() != 1) throw std::runtime_error("several templates run on one GPU (ccsim_set_pods)");
+    if (n_gpus < 1) throw std::runtime_error("--gpus must be >= 1");
+    HostProfile prof_eff = prof;
+    prof_eff.c.percentage_of_nodes_to_score = 100; // the sampled search is single-GPU (its outcome depends on one visiting order)
+    Marshalled m;
+    marshal(s, prof_eff, m);
+    const int64_t N = (int64_t)s.n(), per = (N + n_gpus - 1) / n_gpus;
+    const bool coupled = !s.spread.empty() || s.has_ipa;
+    const int32_t mode = mode_flag == "sequential" ? CCSIM_MODE_SEQUENTIAL : mode_flag == "batched" ? CCSIM_MODE_BATCHED
+                         : (coupled ? CCSIM_MODE_SEQUENTIAL : CCSIM_MODE_BATCHED);
+    int64_t cap = max_limit;
+    if (cap <= 0) {
+        cap = 0;
+        for (const auto x : s.alloc_pods) cap += x;
+        cap = std::min<int64_t>(cap, (int64_t)1 << 26);
+    }
+    cap = std::max<int64_t>(cap, 1);
+    uint8_t id[CCSIM_DIST_ID_BYTES];
+    if (api.dist_unique_id(id) != 0) throw std::runtime_error("ccsim_dist_unique_id failed (librccl.so.1 not loadable?)");
+
+    struct Rank {
+        RunResult r;
+        ccsim_report rep{};
+        std::string err;
+    };
+    std::vector<Rank> ranks((size_t)n_gpus);
+    auto work = [&](int g) {
+        Rank &k = ranks[(size_t)g];
+        const int64_t lo = std::min<int64_t>(N, g * per), hi = std::min<int64_t>(N, lo + per);
+        ccsim_nodes nn = m.nodes;
+        nn.n_nodes = hi - lo, nn.global_offset = lo, nn.n_global = N;
+        auto off = [&](auto *&p) { if (p) p += lo; };
+        for (int c = 0; c < CCSIM_MAX_RES; c++) off(nn.alloc[c]), off(nn.req[c]);
+        off(nn.alloc_pods), off(nn.nz_mcpu), off(nn.nz_mem), off(nn.pod_count), off(nn.taintset_id), off(nn.unschedulable);
+        for (int c = 0; c < nn.n_label_cols; c++) off(nn.label_cols[c]);
+        ccsim_pod pp = m.pod_array[0]; // per-node side arrays follow the nodes
+        for (int c = 0; c < pp.n_spread; c++) off(pp.spread[c].node_match_count), off(pp.spread[c].node_included);
+        if (pp.has_ipa) {
+            off(pp.ipa.aff_existing);
+            for (int t = 0; t < pp.ipa.n_anti_terms; t++) off(pp.ipa.anti_existing[t]);
+            for (int q = 0; q < pp.ipa.n_keys; q++) off(pp.ipa.exist_anti[q]), off(pp.ipa.score_existing[q]);
+            if (lo > 0) pp.ipa.entries_existing = 0; // a cluster-wide count: contributed once, then all-reduced
+        }
+        off(pp.host_ports_conflict), off(pp.image_score);
+        ccsim_config cfg{};
+        cfg.abi_version = CCSIM_ABI_VERSION, cfg.device = g, cfg.use_graph = 0;
+        ccsim_engine *e = nullptr;
+        int rc = api.create(&cfg, &e);
+        if (rc != 0 || !e) {
+            k.err = "ccsim_create failed on device " + std::to_string(g) + " rc=" + std::to_string(rc);
+            return;
+        }
+        auto chk = [&](int r, const char *what) {
+            if (r != 0 && k.err.empty()) k.err = std::string(what) + " failed on device " + std::to_string(g) + " rc=" + std::to_string(r) + ": " + (api.last_error(e) ? api.last_error(e) : "");
+            return r == 0;
+        };
+        k.r.per_node_count.assign((size_t)std::max<int64_t>(hi - lo, 1), 0);
+        k.r.log.assign((size_t)cap, -1);
+        k.r.hist_taintset.assign(std::max<size_t>(s.taint_filter_ok.size(), 1), 0);
+        k.rep.per_node_count = k.r.per_node_count.data(), k.rep.per_node_cap = (int64_t)k.r.per_node_count.size();
+        k.rep.log = k.r.log.data(), k.rep.log_cap = cap;
+        k.rep.hist_taintset = k.r.hist_taintset.data(), k.rep.hist_taintset_cap = (int32_t)k.r.hist_taintset.size();
+        // (every rank reaches the collectives -- comm_init, sync_tables, dist_run -- or none does: failures before them are local)
+        if (chk(api.load_nodes(e, &nn), "ccsim_load_nodes") && chk(api.set_profile(e, &m.profile), "ccsim_set_profile") && chk(api.set_pod(e, &pp), "ccsim_set_pod") &&
+            chk(api.dist_comm_init(e, id, n_gpus, g), "ccsim_dist_comm_init") && chk(api.dist_sync_tables(e), "ccsim_dist_sync_tables"))
+            chk(api.dist_run(e, max_limit, mode, &k.rep), "ccsim_dist_run");
+        api.destroy(e);
+    };
+    // RCCL announces itself on stdout (version banner): keep the report's stream clean -- stdout points to stderr while it runs
+    std::fflush(stdout);
+    const int saved_stdout = dup(1);
+    if (saved_stdout >= 0) dup2(2, 1);
+    std::vector<std::thread> threads;
+    for (int g = 1; g < n_gpus; g++) threads.emplace_back(work, g);
+    work(0);
+    for (auto &t : threads) t.join();
+    std::fflush(stdout);
+    if (saved_stdout >= 0) dup2(saved_stdout, 1), close(saved_stdout);
+    for (const auto &k : ranks)
+        if (!k.err.empty()) throw std::runtime_error(k.err);
+    RunResult r;
+    r.placed = ranks[0].rep.placed, r.stop = ranks[0].rep.stop;
+    r.hist.assign((size_t)CCSIM_NREASON, 0);
+    r.hist_taintset.assign(s.taint_filter_ok.size(), 0);
+    const int64_t log_len = std::min<int64_t>(r.placed, cap);
+    r.log.assign((size_t)log_len, -1);
+    for (int g = 0; g < n_gpus; g++) {
+        const Rank &k = ranks[(size_t)g];
+        const int64_t lo = std::min<int64_t>(N, g * per), hi = std::min<int64_t>(N, lo + per);
+        r.per_node_count.insert(r.per_node_count.end(), k.r.per_node_count.begin(), k.r.per_node_count.begin() + (hi - lo));
+        for (int i = 0; i < CCSIM_NREASON; i++) r.hist[(size_t)i] += k.rep.hist[i];
+        for (size_t i = 0; i < r.hist_taintset.size(); i++) r.hist_taintset[i] += k.r.hist_taintset[i];
+        r.n_code_unschedulable += k.rep.n_code_unschedulable;
+        for (int64_t i = 0; i < log_len; i++) r.log[(size_t)i] = std::max(r.log[(size_t)i], k.r.log[(size_t)i]);
+    }
+    return r;
+}
 
 } // namespace cchost

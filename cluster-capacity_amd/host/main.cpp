@@ -121,7 +121,7 @@ RunResult result_from_json(const Value &v) {
 int usage(const char *msg) {
     std::fprintf(stderr, "%s\nusage: cluster-capacity --podspec FILE [--podspec FILE ...] --snapshot FILE [--snapshot FILE ...] [--max-limit N] [--exclude-nodes a,b]\n"
                          "                        [--default-config FILE] [--verbose] [-o json|yaml] [--mode batched|sequential]\n"
-                         "                        [--percentage-of-nodes-to-score P] [--device D]\n"
+                         "                        [--percentage-of-nodes-to-score P] [--device D] [--gpus N]\n"
                          "       cluster-capacity --genpod NAMESPACE --snapshot FILE [--snapshot FILE ...] [-o json|yaml]\n",
                  msg);
     return 2;
@@ -135,7 +135,8 @@ int main(int argc, char **argv) {
     bool dump_profile = false, pct_flag = false;
     std::vector<std::string> snapshots, exclude;
     int64_t max_limit = 0;
-    int percentage = 100, device = 0;
+    int percentage = 100, device = 0, gpus = 1;
+    bool force_sharded = false;
     bool verbose = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i], val;
@@ -163,6 +164,8 @@ int main(int argc, char **argv) {
             else if (a == "--dump-profile") dump_profile = true;
             else if (a == "--genpod") genpod_ns = need(); // cmd/genpod: the pod a namespace's LimitRanges / annotations describe
             else if (a == "--device") device = std::stoi(need());
+            else if (a == "--gpus") gpus = std::stoi(need()); // node-range shards over GPUs 0 .. N-1 of this box
+            else if (a == "--force-sharded") force_sharded = true; // (test hook: the sharded path with one rank)
             else if (a == "--dump-snapshot") dump = need();
             else if (a == "--fake-result") fake = need();
             else if (a == "--parse") { // test hook: the documents of a file, as JSON (one array)
@@ -217,7 +220,7 @@ int main(int argc, char **argv) {
         std::vector<Value> templates;
         for (const auto &p : podspecs) templates.push_back(parse_pod_spec(p));
         ClusterCapacity cc = ClusterCapacity::New(prof, templates, max_limit, exclude);
-        cc.device = device, cc.mode = mode;
+        cc.device = device, cc.mode = mode, cc.gpus = gpus, cc.force_sharded = force_sharded;
         std::vector<Value> node_objs, pod_objs, ns_objs;
         load_objects(snapshots, node_objs, pod_objs, ns_objs);
         cc.SyncWithClient(node_objs, pod_objs, ns_objs);

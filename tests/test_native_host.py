@@ -1112,3 +1112,27 @@ def test_several_templates_cli_end_to_end_both_hosts(ccref, native, tmp_path):
         assert [x["nodeName"] for x in got["status"]["pods"][t]["replicasOnNodes"]] == [snap.names[i] for i in r.log[t::3]]
     txt = _run(native, flags + ["--verbose", "--max-limit", "7"])
     assert "Termination reason: LimitReached: Maximum number of pods simulated: 7" in txt and txt.count("The cluster can schedule") == 3
+
+
+# ---- --gpus N: the snapshot sharded over the GPUs of one box, the run driven inside libccsim.so over RCCL ------------------
+def test_native_sharded_run_fails_loudly_without_gpus(native, tmp_path):
+    nodes, pods, pod, _ = CASES["readme"]()
+    podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1")
+    p = subprocess.run([native, "--podspec", podspec, "--snapshot", snaps[0], "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 1 and ("ccsim_create failed on device" in p.stderr or "ccsim_dist_unique_id failed" in p.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["readme", "taints-selectors", "ports-images"])
+def test_native_sharded_path_with_one_rank_equals_the_plain_run(native, tmp_path, case):
+    """--force-sharded: node-range shard [0, N), one thread, one RCCL rank: shard views of the marshalled arrays, ccsim_dist_comm_init /
+    sync_tables / dist_run and the merge of the per-rank reports must give the review of the plain single-GPU run."""
+    nodes, pods, pod, exclude = CASES[case]()
+    podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
+    args = ["--podspec", podspec, "--snapshot", snaps[0], "-o", "json"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
+    for extra in ([], ["--max-limit", "9"]):
+        plain = json.loads(_run(native, args + extra))
+        shard = json.loads(_run(native, args + extra + ["--force-sharded"]))
+        plain["status"].pop("creationTimestamp"), shard["status"].pop("creationTimestamp")
+        assert shard["status"] == plain["status"], (case, extra)
