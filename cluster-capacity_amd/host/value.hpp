@@ -150,13 +150,13 @@ class JsonParser {
         std::string out;
         i_++; // opening quote
         while (true) {
+            // the run up to the next quote or escape in one append (kubectl dumps are almost all plain characters)
+            const size_t from = i_;
+            while (i_ < s_.size() && s_[i_] != '"' && s_[i_] != '\\') i_++;
+            if (i_ > from) out.append(s_, from, i_ - from);
             if (i_ >= s_.size()) fail("unterminated string");
             const char c = s_[i_++];
             if (c == '"') return out;
-            if (c != '\\') {
-                out += c;
-                continue;
-            }
             if (i_ >= s_.size()) fail("unterminated escape");
             const char e = s_[i_++];
             switch (e) {
