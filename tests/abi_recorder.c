@@ -2,7 +2,10 @@
  * (include/ccsim.h) and schedules nothing: ccsim_run returns a canned, obviously artificial result (one pod on every
  * node, LimitReached).  tests/test_native_host.py points the native host at it (CCSIM_LIB) to check, without a GPU, that
  * the structs the C++ host marshals equal the ones the Python binding marshals from the same snapshot.
- * The recording goes to the file named by $CCSIM_RECORD as JSON. */
+ * The recording goes to the file named by $CCSIM_RECORD as JSON; with $CCSIM_RECORD_PER_DEVICE set, engine d writes
+ * "$CCSIM_RECORD.d" (the sharded host path creates one engine per device, concurrently).
+ * The ccsim_dist_* driver entry points are recorded the same way: ccsim_dist_run returns a canned sharded result (one pod on
+ * every node of the shard, global placement i = global node i, logged by the rank that owns the node, -1 elsewhere). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,6 +17,8 @@ struct ccsim_engine {
     int64_t n;
     int n_taintsets;
     int first;
+    int64_t global_offset, n_global;
+    int world, rank;
 };
 
 static void arr64(FILE *f, const char *k, const int64_t *p, int64_t n) {
@@ -46,7 +51,10 @@ int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     const char *path = getenv("CCSIM_RECORD");
     if (!path || !cfg || cfg->abi_version != CCSIM_ABI_VERSION) return -22;
     ccsim_engine *e = (ccsim_engine *)calloc(1, sizeof *e);
-    e->f = fopen(path, "w");
+    char full[4096];
+    if (getenv("CCSIM_RECORD_PER_DEVICE")) snprintf(full, sizeof full, "%s.%d", path, cfg->device);
+    else snprintf(full, sizeof full, "%s", path);
+    e->f = fopen(full, "w");
     if (!e->f) return -5;
     e->first = 1;
     fprintf(e->f, "{\n");
@@ -66,7 +74,7 @@ void ccsim_destroy(ccsim_engine *e) {
 
 int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *n) {
     FILE *f = e->f;
-    e->n = n->n_nodes;
+    e->n = n->n_nodes, e->global_offset = n->global_offset, e->n_global = n->n_global;
     sep(e);
     fprintf(f, "\"nodes\": {\"n_nodes\": %lld, \"global_offset\": %lld, \"n_global\": %lld, \"n_scalar\": %d, \"n_label_cols\": %d, ", (long long)n->n_nodes,
             (long long)n->global_offset, (long long)n->n_global, n->n_scalar, n->n_label_cols);
@@ -201,5 +209,47 @@ int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *ou
     }
     memset(out->hist, 0, sizeof out->hist);
     out->n_code_unschedulable = 0;
+    return 0;
+}
+
+/* ---- the library-driven multi-GPU entry points ---- */
+int ccsim_dist_unique_id(uint8_t *id_out) {
+    for (int i = 0; i < CCSIM_DIST_ID_BYTES; i++) id_out[i] = (uint8_t)(i * 7 + 3);
+    return 0;
+}
+
+int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id, int32_t n_ranks, int32_t rank) {
+    int id_ok = 1;
+    for (int i = 0; i < CCSIM_DIST_ID_BYTES; i++) id_ok &= id[i] == (uint8_t)(i * 7 + 3);
+    e->world = n_ranks, e->rank = rank;
+    sep(e);
+    fprintf(e->f, "\"dist_comm_init\": {\"n_ranks\": %d, \"rank\": %d, \"id_ok\": %d}", n_ranks, rank, id_ok);
+    return id_ok ? 0 : -22;
+}
+
+int ccsim_dist_sync_tables(ccsim_engine *e) {
+    sep(e);
+    fprintf(e->f, "\"dist_sync_tables\": %d", e->world);
+    return e->world > 0 ? 0 : -22;
+}
+
+int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
+    sep(e);
+    fprintf(e->f, "\"dist_run\": {\"max_limit\": %lld, \"mode\": %d, \"per_node_cap\": %lld, \"log_cap\": %lld, \"hist_taintset_cap\": %d}", (long long)max_limit, mode,
+            (long long)out->per_node_cap, (long long)out->log_cap, out->hist_taintset_cap);
+    if (e->world <= 0 || out->per_node_cap < e->n || (out->hist_taintset && out->hist_taintset_cap < e->n_taintsets)) return -22;
+    out->placed = e->n_global, out->stop = CCSIM_STOP_UNSCHEDULABLE, out->log_len = 0;
+    for (int64_t i = 0; i < e->n; i++) out->per_node_count[i] = 1;
+    if (out->log)
+        for (int64_t g = 0; g < e->n_global && g < out->log_cap; g++) {
+            const int mine = g >= e->global_offset && g < e->global_offset + e->n;
+            out->log[g] = mine ? (int32_t)g : -1, out->log_len = g + 1;
+        }
+    /* FitError pieces of THIS shard: every node of the shard under one reason, the first taint set */
+    memset(out->hist, 0, sizeof out->hist);
+    out->hist[CCSIM_R_TOO_MANY_PODS] = e->n;
+    if (out->hist_taintset)
+        for (int i = 0; i < e->n_taintsets; i++) out->hist_taintset[i] = i == 0 ? e->rank + 1 : 0;
+    out->n_code_unschedulable = e->rank == 0 ? 1 : 0;
     return 0;
 }

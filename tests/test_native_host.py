@@ -1136,3 +1136,107 @@ def test_native_sharded_path_with_one_rank_equals_the_plain_run(native, tmp_path
         shard = json.loads(_run(native, args + extra + ["--force-sharded"]))
         plain["status"].pop("creationTimestamp"), shard["status"].pop("creationTimestamp")
         assert shard["status"] == plain["status"], (case, extra)
+
+
+def _slice_nodes(rec, lo, hi):
+    """What rank [lo, hi) of a node-range sharding must pass to ccsim_load_nodes, from the unsharded record."""
+    out = {}
+    for k, v in rec.items():
+        if k in ("alloc", "req", "label_cols"):
+            out[k] = [{"v": None if c["v"] is None else c["v"][lo:hi]} for c in v]
+        elif isinstance(v, list):
+            out[k] = v[lo:hi]
+        else:
+            out[k] = v
+    out["n_nodes"], out["global_offset"], out["n_global"] = hi - lo, lo, rec["n_nodes"]
+    return out
+
+
+def _slice_pod(rec, lo, hi):
+    """... and to ccsim_set_pod: per-node side arrays follow the nodes, everything else is replicated; the cluster-wide
+    entries_existing count is contributed by rank 0 only (ccsim_dist_sync_tables sums it)."""
+    out = json.loads(json.dumps(rec))
+    sl = lambda v: None if v is None else v[lo:hi]
+    for c in out["spread"]:
+        c["node_match_count"], c["node_included"] = sl(c["node_match_count"]), sl(c["node_included"])
+    if out["has_ipa"]:
+        a = out["ipa"]
+        a["aff_existing"] = sl(a["aff_existing"])
+        for k in ("anti_existing", "exist_anti", "score_existing"):
+            a[k] = [{"v": sl(c["v"])} for c in a[k]]
+        if lo > 0:
+            a["entries_existing"] = 0
+    out["host_ports_conflict"], out["image_score"] = sl(out["host_ports_conflict"]), sl(out["image_score"])
+    return out
+
+
+def _sharded_records(native, recorder, tmp_path, objs, n_gpus):
+    """Run the native host against the recorder, unsharded and with --gpus n_gpus; check each rank's record against the slices of
+    the unsharded one.  Returns (stdout of the sharded run, n, podspec, snaps), or None when the host refuses the input."""
+    nodes, pods, pod, exclude = objs
+    podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
+    args = ["--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["-o", "json"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
+    env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "plain.json"))
+    p = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
+    if p.returncode != 0:
+        return None
+    plain = json.load(open(tmp_path / "plain.json"))
+    env = dict(env, CCSIM_RECORD=str(tmp_path / "shard.json"), CCSIM_RECORD_PER_DEVICE="1")
+    p = subprocess.run([native] + args + ["--gpus", str(n_gpus)], capture_output=True, text=True, env=env, timeout=60)
+    assert p.returncode == 0, p.stderr
+    n = plain["nodes"]["n_nodes"]
+    per = -(-n // n_gpus)
+    for g in range(n_gpus):
+        rec = json.load(open(f"{tmp_path}/shard.json.{g}"))
+        lo, hi = min(n, g * per), min(n, g * per + per)
+        assert rec["config"]["device"] == g
+        assert rec["nodes"] == _slice_nodes(plain["nodes"], lo, hi), (g, "nodes")
+        assert rec["pod"] == _slice_pod(plain["pod"], lo, hi), (g, "pod")
+        assert rec["profile"] == dict(plain["profile"], pct=100)
+        assert rec["dist_comm_init"] == {"n_ranks": n_gpus, "rank": g, "id_ok": 1} and rec["dist_sync_tables"] == n_gpus
+        assert rec["dist_run"]["max_limit"] == 0 and rec["dist_run"]["mode"] == plain["run"]["mode"] and rec["dist_run"]["per_node_cap"] >= hi - lo
+        assert "run" not in rec
+    return p.stdout, n, podspec, snaps
+
+
+@pytest.mark.parametrize("n_gpus", [2, 3])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_native_sharded_host_side_views_threads_and_merge(native, recorder, tmp_path, case, n_gpus):
+    """--gpus N without a GPU: tests/abi_recorder.c stands in for libccsim.so.  Every rank's thread must hand the library exactly the
+    [lo, hi) slice of the arrays the unsharded host marshals (uneven last shard included), go through comm_init / sync_tables /
+    dist_run with the same unique id, and the merge of the per-rank reports (per-node counts concatenated, logs by element-wise
+    maximum, FitError histograms summed) must give the review of the recorder's canned global result."""
+    objs = CASES[case]()
+    exclude = objs[3]
+    stdout, n, podspec, snaps = _sharded_records(native, recorder, tmp_path, objs, n_gpus)
+    # the merged review: placement i on node i, one per node; the FitError of the canned result
+    pypod = cli.parse_pod_spec(podspec)
+    snap = ingest.build_snapshot(*cli.load_objects(snaps), pypod, exclude)
+    hist = np.zeros(M.NREASON, np.int64)
+    hist[M.R_TOO_MANY_PODS] = n
+    ht = np.zeros(len(snap.taint_reasons), np.int64)
+    if len(ht):
+        ht[0] = n_gpus * (n_gpus + 1) // 2
+    res = M.RunResult(placed=n, stop=M.STOP_UNSCHEDULABLE, per_node_count=np.ones(n, np.int32), log=np.arange(n, dtype=np.int32), hist=hist,
+                      hist_taintset=ht, n_code_unschedulable=1)
+    want = cli.build_review(pypod, snap, res, 0)
+    got = json.loads(stdout)
+    got["status"].pop("creationTimestamp"), want["status"].pop("creationTimestamp", None)
+    assert got["status"] == json.loads(json.dumps(want["status"]))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_native_sharded_host_side_views_random_clusters(native, recorder, tmp_path, seed):
+    """The same slicing check over the random clusters / pod specs of the ingest fuzz (spread constraints, inter-pod affinity with
+    existing pods, host ports, images), 2 .. 5 shards, more shards than nodes included."""
+    rng = np.random.default_rng(9000 + seed)
+    objs = _random_objects(rng)
+    got = _sharded_records(native, recorder, tmp_path, objs, 2 + seed % 4)
+    try:
+        podspec, snaps = _write(tmp_path, "json", *objs[:3])
+        no, po, ns = cli.load_all(snaps)
+        ingest.build_snapshot(no, po, cli.parse_pod_spec(podspec), objs[3], namespace_objs=ns)
+    except NotImplementedError:
+        assert got is None  # refused by both hosts (volumes, more topology keys than the engine holds, ...)
+        return
+    assert got is not None
