@@ -22,7 +22,7 @@ from typing import List, Optional
 import numpy as np
 import yaml
 
-from . import ingest, model as M, report as R, schedconfig
+from . import ingest, model as M, preemption, report as R, schedconfig
 
 
 def load_all(paths: List[str]):
@@ -112,13 +112,22 @@ def pod_requirements(pod: dict) -> dict:
             "nodeSelectors": pod["spec"].get("nodeSelector")}
 
 
-def build_review(pod, snap: ingest.Snapshot, result: M.RunResult, max_limit: int) -> dict:
+def build_review(pod, snap: ingest.Snapshot, result: M.RunResult, max_limit: int, filter_mask: int = M.F_ALL) -> dict:
     """report.go:196-225 GetReport.  `pod`: the template or the list of templates; scheduled pod i is a clone of template
     i mod P (parsePodsReview, report.go:146-171), which is exactly the order the engine cycles them in."""
     pods = list(pod) if isinstance(pod, (list, tuple)) else [pod]
     P = len(pods)
     failing = result.stop_spec if P > 1 and result.stop_spec >= 0 else 0  # the FitError describes the template that did not fit
-    stop = R.stop_reason(result, len(snap.names), max_limit, taint_reasons=snap.taint_reasons_all[failing], scalar_names=snap.scalar_names)
+    outcome = None
+    if result.stop == M.STOP_UNSCHEDULABLE:  # the PostFilter of the terminal cycle: DefaultPreemption's dry run (message tail only)
+        mixed = len({(p.preempt.priority if p.preempt else 0) for p in snap.pods}) > 1  # clones of one template below another's priority
+        outcome = preemption.dry_run(snap.nodes, snap.pods[failing], result.per_node_count, result.n_code_unschedulable, filter_mask, P, mixed)
+        if outcome.kind == "unmodelled":
+            print("warning: nodes hold pods of lower priority than the simulated pod and its filters are topology-coupled (or several "
+                  "templates run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims",
+                  file=sys.stderr)
+    stop = R.stop_reason(result, len(snap.names), max_limit, taint_reasons=snap.taint_reasons_all[failing], scalar_names=snap.scalar_names,
+                         preemption=outcome)
     if P == 1:
         per_template = [R.replicas_on_nodes(result.per_node_count, snap.names, result.log)]
     else:
@@ -240,7 +249,7 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         # (several templates are always searched completely: the engine's windows need every node scored)
         pct = 0 if len(pods) == 1 and (args.max_limit > 0 or snap.pod.spread or snap.pod.ipa is not None) else 100
     result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=pct, profile=prof)
-    review = build_review(pod, snap, result, args.max_limit)
+    review = build_review(pod, snap, result, args.max_limit, prof.filter_mask)
     if args.output == "json":
         out.write(json.dumps(review) + "\n")
     elif args.output == "yaml":

@@ -523,6 +523,29 @@ def _template_side(ctx: dict, sim_pod: dict):
         pod.host_ports_conflict = conflict if conflict.any() else None
     # ImageLocality: per-node score from node.status.images
     pod.image_score = image_scores(nodes, spec)
+    # DefaultPreemption dry run (report only): what removing every lower-priority pod of a node would free
+    # (corev1helpers.PodPriority: spec.priority, 0 when unset; default_preemption.go:392-396)
+    prio = int(spec.get("priority") or 0)
+    pre = M.PreemptionSide(priority=prio, never=spec.get("preemptionPolicy") == "Never")
+    victims = [p for p in live if int(p["spec"].get("priority") or 0) < prio]
+    if victims:
+        pre.victim_count = np.zeros(N, np.int32)
+        pre.victim_req = [np.zeros(N, np.int64) for _ in res_names]
+        for p in victims:
+            i = index[p["spec"]["nodeName"]]
+            r, _, _ = pod_requests(p["spec"], res_names)
+            pre.victim_count[i] += 1
+            for c, rn in enumerate(res_names):
+                pre.victim_req[c][i] += r[rn]
+        if want:
+            vic = set(map(id, victims))
+            rest: Dict[int, set] = {}
+            for p in live:
+                hp = host_ports(p["spec"]) if id(p) not in vic else None
+                if hp:
+                    rest.setdefault(index[p["spec"]["nodeName"]], set()).update(hp)
+            pre.ports_conflict_rest = np.array([1 if i in rest and ports_conflict(want, rest[i]) else 0 for i in range(N)], np.uint8)
+    pod.preempt = pre
     # volume-backed plugins (VolumeBinding / VolumeZone / VolumeRestrictions / NodeVolumeLimits / DynamicResources) have no
     # integer form here: a pod that would activate them is refused instead of silently ignoring the constraint
     for v in spec.get("volumes") or []:

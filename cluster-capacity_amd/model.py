@@ -174,6 +174,21 @@ class InterPodAffinity:
 
 
 @dataclass
+class PreemptionSide:
+    """What the DefaultPreemption dry run of the terminal cycle needs (HOST ONLY: it never crosses the C ABI; the dry run
+    decides the "preemption: ..." part of the FitError message, not a placement).  A victim is an existing pod whose
+    priority is lower than the template's (defaultpreemption/default_preemption.go:392-396); clones share the template's
+    priority and are never victims."""
+
+    priority: int = 0
+    never: bool = False  # spec.preemptionPolicy == Never (default_preemption.go:355-357)
+    victim_count: Optional[np.ndarray] = None  # int32[n]; None = no node holds a victim
+    victim_req: List[np.ndarray] = field(default_factory=list)  # per resource column int64[n]: what the victims request
+    # NodePorts with the victims gone: does a REMAINING existing pod of the node hold a conflicting host port (uint8[n])
+    ports_conflict_rest: Optional[np.ndarray] = None
+
+
+@dataclass
 class PodSpec:
     """Pod-side constants precomputed on the host."""
 
@@ -198,6 +213,7 @@ class PodSpec:
     host_ports_conflict: Optional[np.ndarray] = None
     # ImageLocality (plugins/imagelocality/image_locality.go:54-115): per-node score 0..100, uint8[n]; None = 0
     image_score: Optional[np.ndarray] = None
+    preempt: Optional[PreemptionSide] = None  # host only, see PreemptionSide
 
     def __post_init__(self):
         self.req = _i64(self.req)

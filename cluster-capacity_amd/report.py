@@ -39,16 +39,7 @@ def _histogram_message(reasons: Dict[str, int]) -> str:
     return ", ".join(items)
 
 
-def fit_error_message(
-    n_nodes: int,
-    hist: Sequence[int],
-    hist_taintset: Sequence[int],
-    n_code_unschedulable: int,
-    taint_reasons: Optional[Sequence[str]] = None,
-    scalar_names: Sequence[str] = (),
-    with_preemption: bool = True,
-) -> str:
-    """FitError.Error() for the terminal round, including the DefaultPreemption suffix."""
+def _reason_histogram(hist, hist_taintset, taint_reasons, scalar_names) -> Dict[str, int]:
     reasons: Dict[str, int] = {}
     for slot, cnt in enumerate(hist):
         cnt = int(cnt)
@@ -70,25 +61,43 @@ def fit_error_message(
         # taint_toleration.go:119: "node(s) had untolerated taint {key: value}" (first untolerated taint)
         text = taint_reasons[ts] if taint_reasons is not None else f"node(s) had untolerated taint {{taintset-{ts}}}"
         reasons[text] = reasons.get(text, 0) + cnt
+    return reasons
+
+
+def fit_error_message(
+    n_nodes: int,
+    hist: Sequence[int],
+    hist_taintset: Sequence[int],
+    n_code_unschedulable: int,
+    taint_reasons: Optional[Sequence[str]] = None,
+    scalar_names: Sequence[str] = (),
+    with_preemption: bool = True,
+    preemption=None,
+) -> str:
+    """FitError.Error() for the terminal round, including the DefaultPreemption tail.  `preemption`: the outcome of the dry
+    run (preemption.Outcome); None = no node holds a pod of lower priority than the simulated one."""
     msg = f"0/{n_nodes} nodes are available:"
-    body = _histogram_message(reasons)
+    body = _histogram_message(_reason_histogram(hist, hist_taintset, taint_reasons, scalar_names))
     if body:
         msg += f" {body}."
-    if with_preemption:
-        # Nodes that failed with plain Unschedulable are dry-run candidates; the simulated pod has
-        # priority 0 like everything else, so each reports "No preemption victims found"; the rest are
-        # absent from the map -> "Preemption is not helpful for scheduling".
-        pre: Dict[str, int] = {}
-        if n_code_unschedulable:
-            pre["No preemption victims found for incoming pod"] = int(n_code_unschedulable)
-        if n_nodes - n_code_unschedulable > 0:
-            pre["Preemption is not helpful for scheduling"] = int(n_nodes - n_code_unschedulable)
-        pmsg = f"0/{n_nodes} nodes are available:"
-        pbody = _histogram_message(pre)
-        if pbody:
-            pmsg += f" {pbody}."
-        msg += " preemption: " + pmsg
-    return msg
+    if not with_preemption or (preemption is not None and preemption.kind == "nominated"):
+        return msg  # a candidate node was found: PostFilter returns Success with an empty message (preemption.go:281-303)
+    if preemption is not None and preemption.kind == "never":
+        return msg + " preemption: not eligible due to preemptionPolicy=Never."  # default_preemption.go:355-357
+    # Nodes that failed with plain Unschedulable are dry-run candidates: without a lower-priority pod on them each reports
+    # "No preemption victims found"; with victims that do not help, the filter status after their removal; the rest are
+    # absent from the map -> "Preemption is not helpful for scheduling".
+    no_victims = int(n_code_unschedulable) if preemption is None else preemption.no_victims
+    pre = {} if preemption is None else _reason_histogram(preemption.hist, (), None, scalar_names)
+    if no_victims:
+        pre["No preemption victims found for incoming pod"] = no_victims
+    if n_nodes - n_code_unschedulable > 0:
+        pre["Preemption is not helpful for scheduling"] = int(n_nodes - n_code_unschedulable)
+    pmsg = f"0/{n_nodes} nodes are available:"
+    pbody = _histogram_message(pre)
+    if pbody:
+        pmsg += f" {pbody}."
+    return msg + " preemption: " + pmsg
 
 
 def stop_reason(result, n_nodes: int, max_limit: int, **kw) -> str:

@@ -933,3 +933,79 @@ int ccref_run_multi(const ccref_profile *prof, ccref_nodes *nodes, const ccref_p
     return rc;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * DefaultPreemption dry run of the terminal cycle (see ccref.h).  Preempt: preemption.go:234-303; findCandidates :306-331
+ * (potential nodes = status code Unschedulable, NodesForStatusCode); DryRunPreemption :741-794; SelectVictimsOnNode:
+ * default_preemption.go:217-310 (remove every lower-priority pod :245-252, none -> :255-257, Filter again :265-267).
+ * ------------------------------------------------------------------------------------------ */
+static void add_reasons(const fail_info *fi, int64_t *hist) {
+    switch (fi->plugin) {
+    case CCREF_F_NODEPORTS: hist[CCREF_R_NODEPORTS]++; break;
+    case CCREF_F_FIT:
+        if (fi->fit_mask & 1u) hist[CCREF_R_TOO_MANY_PODS]++;
+        for (int c = 0; c < CCREF_MAX_RES; c++)
+            if (fi->fit_mask & (1u << (1 + c))) hist[CCREF_R_RES0 + c]++;
+        break;
+    default: break; /* the plugins before NodePorts do not look at the node's pods: they passed before, they pass again */
+    }
+}
+
+int ccref_preemption_dry_run(const ccref_profile *prof, const ccref_nodes *nodes, const ccref_pod *pod, const int32_t *placed,
+                             const ccref_victims *victims, ccref_preemption *out) {
+    const int64_t N = nodes->n;
+    const int ncol = 3 + nodes->n_scalar;
+    memset(out, 0, sizeof *out);
+    int any_victim = 0;
+    if (victims && victims->victim_count)
+        for (int64_t n = 0; n < N; n++) any_victim |= victims->victim_count[n] > 0;
+    int coupled = 0;
+    if (prof->filter_mask & CCREF_F_TOPOLOGYSPREAD)
+        for (int i = 0; i < pod->n_spread; i++) coupled |= pod->spread[i].hard != 0;
+    if ((prof->filter_mask & CCREF_F_INTERPODAFFINITY) && pod->has_ipa) {
+        coupled |= pod->ipa.n_aff_terms > 0 || pod->ipa.n_anti_terms > 0;
+        for (int k = 0; k < pod->ipa.n_keys; k++) coupled |= pod->ipa.exist_anti[k] != NULL;
+    }
+    (void)any_victim;
+    if (coupled) return -38; /* (even the terminal status codes would need those plugins' state) */
+
+    /* the terminal NodeInfo: Requested and len(Pods) after the clones (types.go:409-428) */
+    ccref_nodes t = *nodes;
+    int64_t *cols[CCREF_MAX_RES] = {0};
+    for (int c = 0; c < ncol; c++) {
+        cols[c] = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+        for (int64_t n = 0; n < N; n++) cols[c][n] = (nodes->req[c] ? nodes->req[c][n] : 0) + (int64_t)placed[n] * pod->req[c];
+        t.req[c] = cols[c];
+    }
+    int32_t *pc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    for (int64_t n = 0; n < N; n++) pc[n] = nodes->pod_count[n] + placed[n];
+    t.pod_count = pc;
+    ccref_pod without = *pod; /* the node's used ports once the victims are gone */
+    without.host_ports_conflict = victims ? victims->ports_conflict_rest : NULL;
+
+    for (int64_t n = 0; n < N; n++) {
+        fail_info fi = {0, 0, 0, 0};
+        const int code = filter_node(prof, &t, pod, NULL, NULL, placed, n, &fi);
+        if (code != -1) { /* (0 cannot happen at a terminal cycle; counted as not helpful if the caller asks anyway) */
+            out->not_helpful++;
+            continue;
+        }
+        const int32_t vc = victims && victims->victim_count ? victims->victim_count[n] : 0;
+        if (vc == 0) {
+            out->no_victims++;
+            continue;
+        }
+        for (int c = 0; c < ncol; c++)
+            if (victims->victim_req[c]) cols[c][n] -= victims->victim_req[c][n];
+        pc[n] -= vc;
+        fail_info fj = {0, 0, 0, 0};
+        if (filter_node(prof, &t, &without, NULL, NULL, placed, n, &fj) == 0) out->nominated = 1;
+        else add_reasons(&fj, out->hist);
+        for (int c = 0; c < ncol; c++)
+            if (victims->victim_req[c]) cols[c][n] += victims->victim_req[c][n];
+        pc[n] += vc;
+    }
+    for (int c = 0; c < ncol; c++) free(cols[c]);
+    free(pc);
+    return 0;
+}

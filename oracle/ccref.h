@@ -252,6 +252,30 @@ double ccref_go_log(double x); /* restatement of Go's math.Log (pure-Go path) */
 int64_t ccref_image_locality_score(const int64_t *size, const int32_t *num_nodes, int n_present, int32_t total_nodes,
                                    int n_containers);
 
+/* DefaultPreemption's dry run for the terminal cycle (S/framework/preemption/preemption.go:234-303,741-794;
+ * P/defaultpreemption/default_preemption.go:217-310 SelectVictimsOnNode) -- it decides the tail of the FitError message,
+ * never a placement (the reference stops on the Unschedulable condition either way, pkg/framework/simulator.go:327-342).
+ * `nodes` is the snapshot as loaded, `placed` the clones per node at the terminal cycle (the terminal NodeInfo is rebuilt
+ * here).  A victim is an existing pod of lower priority than the incoming one (default_preemption.go:392-396); strings and
+ * priorities are the caller's, so the caller hands over per node: how many victims, what they request per column, and
+ * whether a REMAINING pod still holds a conflicting host port.  Every node whose filter status is plain Unschedulable is
+ * tried: no victims -> no_victims++; all victims removed and the Filter plugins run again -> feasible: nominated = 1
+ * (PostFilter returns Success, empty message), else the failing plugin's reasons go to hist.  Other nodes: not_helpful++.
+ * Pods with topology-coupled filters (hard spread constraints, inter-pod affinity) are refused with -38 when a victim exists:
+ * removing a pod would change those plugins' PreFilter state (RunPreFilterExtensionRemovePod), which is not restated. */
+typedef struct {
+    const int32_t *victim_count;              /* [n], NULL = no victims anywhere */
+    const int64_t *victim_req[CCREF_MAX_RES]; /* [n] per column, NULL = 0 */
+    const uint8_t *ports_conflict_rest;       /* [n], NULL = none */
+} ccref_victims;
+typedef struct {
+    int32_t nominated;
+    int64_t hist[CCREF_NREASON];
+    int64_t no_victims, not_helpful;
+} ccref_preemption;
+int ccref_preemption_dry_run(const ccref_profile *prof, const ccref_nodes *nodes, const ccref_pod *pod, const int32_t *placed,
+                             const ccref_victims *victims, ccref_preemption *out);
+
 #ifdef __cplusplus
 }
 #endif

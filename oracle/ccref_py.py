@@ -436,3 +436,38 @@ def image_locality_score(sizes, num_nodes, total_nodes, n_containers):
     """ImageLocality score of one node: sizes / num_nodes of the pod's container images the node holds."""
     sz, nn = np.ascontiguousarray(sizes, dtype=np.int64), np.ascontiguousarray(num_nodes, dtype=np.int32)
     return int(lib().ccref_image_locality_score(_ptr(sz, _p64), _ptr(nn, _p32), len(sz), int(total_nodes), int(n_containers)))
+
+
+class _Victims(C.Structure):
+    _fields_ = [("victim_count", _p32), ("victim_req", _p64 * MAX_RES), ("ports_conflict_rest", _pu8)]
+
+
+class _Preemption(C.Structure):
+    _fields_ = [("nominated", C.c_int32), ("hist", C.c_int64 * NREASON), ("no_victims", C.c_int64), ("not_helpful", C.c_int64)]
+
+
+def preemption_dry_run(profile, nodes, pod, placed, victim_count=None, victim_req=(), ports_conflict_rest=None):
+    """DefaultPreemption's dry run of the terminal cycle (ccref_preemption_dry_run): `nodes` as loaded, `placed` = clones
+    per node.  -> namespace(nominated, hist, no_victims, not_helpful); raises NotImplementedError for topology-coupled filters."""
+    m = _Marshal()
+    cn, cp, cf = m.nodes(nodes), m.pod(pod), m.profile(profile)
+    v = _Victims()
+    keep = [np.ascontiguousarray(placed, dtype=np.int32)]
+    if victim_count is not None:
+        keep.append(np.ascontiguousarray(victim_count, dtype=np.int32))
+        v.victim_count = _ptr(keep[-1], _p32)
+        for c, a in enumerate(victim_req):
+            keep.append(np.ascontiguousarray(a, dtype=np.int64))
+            v.victim_req[c] = _ptr(keep[-1], _p64)
+    if ports_conflict_rest is not None:
+        keep.append(np.ascontiguousarray(ports_conflict_rest, dtype=np.uint8))
+        v.ports_conflict_rest = _ptr(keep[-1], _pu8)
+    out = _Preemption()
+    lib().ccref_preemption_dry_run.restype = C.c_int
+    rc = lib().ccref_preemption_dry_run(C.byref(cf), C.byref(cn), C.byref(cp), _ptr(keep[0], _p32), C.byref(v), C.byref(out))
+    if rc == -38:
+        raise NotImplementedError("preemption dry run with topology-coupled filters")
+    if rc != 0:
+        raise RuntimeError(f"ccref_preemption_dry_run failed rc={rc}")
+    return SimpleNamespace(nominated=bool(out.nominated), hist=np.array(list(out.hist), dtype=np.int64), no_victims=int(out.no_victims),
+                           not_helpful=int(out.not_helpful))

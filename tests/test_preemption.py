@@ -1,0 +1,198 @@
+"""DefaultPreemption's dry run of the terminal cycle: the tail of the FitError message.
+
+Reference: P/defaultpreemption/default_preemption.go:131-141 (prefix), :217-310 (SelectVictimsOnNode), :355-357
+(preemptionPolicy), :392-396 (a victim has lower priority); S/framework/preemption/preemption.go:234-303 (Preempt), :306-331
+(potential nodes), :741-794 (DryRunPreemption); S/framework/types.go:787-836 (FitError.Error).  The reference vendors the
+plugin's unit tests but none goes through cluster-capacity's stop condition, so the known answers below are derived by hand
+from those lines ("parity unpinned").  CPU only: the dry run is host code -- the Python host and the C++ host against the
+oracle's restatement (ccref_preemption_dry_run) and against each other."""
+import copy
+import json
+import subprocess
+
+import numpy as np
+import pytest
+import yaml
+
+import helpers as H
+from cluster_capacity_amd import cli, ingest, model as M, preemption, report as R
+from test_native_host import EXAMPLES_POD, _write, node, running_pod
+
+NO_VICTIMS = "No preemption victims found for incoming pod"
+NOT_HELPFUL = "Preemption is not helpful for scheduling"
+
+
+def _cluster():
+    """3 nodes of 1 cpu / 4G / 110 pods.  a: a 500m pod of priority -10 (the classic overprovisioning placeholder);
+    b: a 500m pod of priority 0;  c: a 10m pod of priority -10 and a 490m pod of priority 0."""
+    nodes = [node(n, cpu="1", mem="4G") for n in "abc"]
+    pods = [running_pod("placeholder", "a", cpu="500m", mem="10Mi"), running_pod("app", "b", cpu="500m", mem="10Mi"),
+            running_pod("tiny", "c", cpu="10m", mem="10Mi"), running_pod("app2", "c", cpu="490m", mem="10Mi")]
+    pods[0]["spec"]["priority"] = -10
+    pods[2]["spec"]["priority"] = -10
+    return nodes, pods
+
+
+def _template(cpu, **spec):
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["spec"]["containers"][0]["resources"] = {"requests": {"cpu": cpu, "memory": "10Mi"}}
+    pod["spec"].update(spec)
+    return pod
+
+
+def _message(ccref, nodes, pods, pod, prof=None):
+    prof = prof or M.Profile.default()
+    snap = ingest.build_snapshot(nodes, pods, pod)
+    r = ccref.run(prof, snap.nodes, snap.pod)
+    review = cli.build_review(pod, snap, r, 0, prof.filter_mask)
+    return snap, r, review["status"]["failReason"]["failMessage"]
+
+
+def test_known_answers(ccref):
+    nodes, pods = _cluster()
+    # 300m clones: one per node (500m used + 300m <= 1000m < + 600m); then every node is short of cpu.  The placeholder on a
+    # frees 500m: 300 + 300 <= 1000 -> a is a candidate -> DefaultPreemption nominates it, PostFilterMsg is empty
+    snap, r, msg = _message(ccref, nodes, pods, _template("300m"))
+    assert snap.pod.preempt.victim_count.tolist() == [1, 0, 1] and snap.pod.preempt.victim_req[0].tolist() == [500, 0, 10]
+    assert r.placed == 3 and msg == "0/3 nodes are available: 3 Insufficient cpu."
+    # 450m clones: one per node; a without its placeholder: 450 + 450 <= 1000 -> candidate again
+    assert _message(ccref, nodes, pods, _template("450m"))[2] == "0/3 nodes are available: 3 Insufficient cpu."
+    # 600m clones: none fits anywhere (500 + 600 > 1000): a is a candidate from the start (0 + 600 <= 1000)
+    assert _message(ccref, nodes, pods, _template("600m"))[1].placed == 0
+    assert _message(ccref, nodes, pods, _template("600m"))[2] == "0/3 nodes are available: 3 Insufficient cpu."
+    # ... without the placeholder on a the only victim is c's 10m pod: 490 + 600 > 1000 still -> no candidate
+    snap, r, msg = _message(ccref, nodes, pods[1:], _template("600m"))
+    assert msg == ("0/3 nodes are available: 3 Insufficient cpu. preemption: 0/3 nodes are available: "
+                   f"1 Insufficient cpu, 2 {NO_VICTIMS}.")
+    # a pod of higher priority than everything: b's and c's pods are victims too -> candidates
+    assert _message(ccref, nodes, pods[1:], _template("600m", priority=100))[2] == "0/3 nodes are available: 3 Insufficient cpu."
+    # preemptionPolicy: Never (default_preemption.go:355-357)
+    assert _message(ccref, nodes, pods, _template("300m", preemptionPolicy="Never"))[2] == (
+        "0/3 nodes are available: 3 Insufficient cpu. preemption: not eligible due to preemptionPolicy=Never.")
+    # no victims anywhere: the round-1 form
+    for p in pods:
+        p["spec"].pop("priority", None)
+    assert _message(ccref, nodes, pods, _template("300m"))[2] == (
+        f"0/3 nodes are available: 3 Insufficient cpu. preemption: 0/3 nodes are available: 3 {NO_VICTIMS}.")
+
+
+def test_unresolvable_nodes_are_not_tried(ccref):
+    """A node that failed UnschedulableAndUnresolvable (here: a NoSchedule taint; a request beyond the node's allocatable,
+    fit.go:605-607) is no dry-run node even when it holds victims."""
+    nodes, pods = _cluster()
+    nodes[0]["spec"]["taints"] = [{"key": "dedicated", "value": "x", "effect": "NoSchedule"}]
+    snap, r, msg = _message(ccref, nodes, pods, _template("600m"))
+    assert r.placed == 0 and r.n_code_unschedulable == 2
+    assert msg == ("0/3 nodes are available: 1 node(s) had untolerated taint {dedicated: x}, 2 Insufficient cpu. "
+                   f"preemption: 0/3 nodes are available: 1 Insufficient cpu, 1 {NO_VICTIMS}, 1 {NOT_HELPFUL}.")  # sorted as strings, types.go:820-829
+    nodes, pods = _cluster()
+    snap, r, msg = _message(ccref, nodes, pods, _template("1100m"))  # more than any node's allocatable
+    assert r.n_code_unschedulable == 0
+    assert msg == f"0/3 nodes are available: 3 Insufficient cpu. preemption: 0/3 nodes are available: 3 {NOT_HELPFUL}."
+
+
+def test_too_many_pods_and_host_ports(ccref):
+    """The pod-count limit and NodePorts are part of the second Filter run: a victim frees its pod slot and its host ports."""
+    nodes = [node(n, cpu="1", mem="4G", pods="2") for n in "ab"]
+    pods = [running_pod(f"p{i}", "ab"[i // 2], cpu="10m", mem="1Mi") for i in range(4)]
+    pods[0]["spec"]["priority"] = -1
+    assert _message(ccref, nodes, pods, _template("100m"))[2] == "0/2 nodes are available: 2 Too many pods."  # a: slot freed
+    pods[0]["spec"]["priority"] = 0
+    assert _message(ccref, nodes, pods, _template("100m"))[2].endswith(f"2 {NO_VICTIMS}.")
+    # host ports: the template wants 8080; a's port holder is a victim, b's is not
+    nodes = [node(n, cpu="1", mem="4G") for n in "ab"]
+    pods = [running_pod("ha", "a", cpu="10m", mem="1Mi"), running_pod("hb", "b", cpu="10m", mem="1Mi")]
+    for p in pods:
+        p["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": 8080}]
+    pods[0]["spec"]["priority"] = -5
+    tpl = _template("100m")
+    tpl["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": 8080}]
+    snap, r, msg = _message(ccref, nodes, pods, tpl)
+    assert r.placed == 0 and snap.pod.preempt.ports_conflict_rest.tolist() == [0, 1]
+    assert msg == "0/2 nodes are available: 2 node(s) didn't have free ports for the requested pod ports."
+    # ... and when the victim is not the port holder: the second run fails on NodePorts again
+    pods.append(running_pod("lowprio", "a", cpu="10m", mem="1Mi"))
+    pods[0]["spec"]["priority"], pods[2]["spec"]["priority"] = 0, -5
+    assert _message(ccref, nodes, pods, tpl)[2] == (
+        "0/2 nodes are available: 2 node(s) didn't have free ports for the requested pod ports. preemption: 0/2 nodes are available: "
+        f"1 {NO_VICTIMS}, 1 node(s) didn't have free ports for the requested pod ports.")
+
+
+def test_topology_coupled_filters_are_flagged_not_guessed(ccref, capsys):
+    nodes, pods = _cluster()
+    for i, n in enumerate(nodes):
+        n["metadata"]["labels"] = {"kubernetes.io/hostname": n["metadata"]["name"], "zone": f"z{i}"}
+    tpl = _template("300m")
+    tpl["metadata"]["labels"] = {"app": "x"}
+    tpl["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule",
+                                                 "labelSelector": {"matchLabels": {"app": "x"}}}]
+    snap, r, msg = _message(ccref, nodes, pods, tpl)
+    assert "preemption dry run is not modelled" in capsys.readouterr().err
+    assert msg.endswith(f"preemption: 0/3 nodes are available: 3 {NO_VICTIMS}.")
+    # without victims nothing needs modelling: no warning
+    for p in pods:
+        p["spec"].pop("priority", None)
+    _message(ccref, nodes, pods, tpl)
+    assert capsys.readouterr().err == ""
+
+
+def _random_victims(rng, nodes):
+    """A consistent random split of every node's existing pods into victims and others (counts and requests)."""
+    n = nodes.n
+    vc = np.minimum(rng.integers(0, 3, n), nodes.pod_count).astype(np.int32) * (rng.random(n) < 0.5)
+    vreq = [np.where(vc > 0, (nodes.req[c] * rng.random(n)).astype(np.int64), 0) for c in range(len(nodes.req))]
+    return vc.astype(np.int32), vreq
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_host_dry_run_equals_oracle_restatement(ccref, seed):
+    """Random snapshots, pods, profiles and victim splits: the host's vectorised dry run over the victim-bearing nodes against
+    the oracle's literal loop over every node (filter chain run twice per potential node)."""
+    rng = np.random.default_rng(8800 + seed)
+    nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, int(rng.integers(5, 400))))
+    r = ccref.run(prof, nodes, pod)
+    assert r.stop == M.STOP_UNSCHEDULABLE
+    vc, vreq = _random_victims(rng, nodes)
+    rest = (rng.random(nodes.n) < 0.3).astype(np.uint8) if pod.has_host_ports and seed % 2 else None
+    pod.preempt = M.PreemptionSide(priority=1, victim_count=vc if vc.any() else None, victim_req=vreq, ports_conflict_rest=rest)
+    ref = ccref.preemption_dry_run(prof, nodes, pod, r.per_node_count, vc, vreq, rest)
+    assert ref.no_victims + ref.not_helpful + (0 if ref.nominated else int(ref.hist.sum() > 0)) >= 0
+    assert ref.not_helpful == nodes.n - r.n_code_unschedulable  # the oracle's two views of "plain Unschedulable" agree
+    got = preemption.dry_run(nodes, pod, r.per_node_count, r.n_code_unschedulable, prof.filter_mask)
+    assert (got.kind == "nominated") == ref.nominated, seed
+    if not ref.nominated:
+        assert got.kind == "none" and got.no_victims == ref.no_victims and got.not_helpful == ref.not_helpful
+        assert np.array_equal(got.hist, ref.hist), seed
+
+
+def test_random_cases_cover_both_outcomes(ccref):
+    kinds = set()
+    for seed in range(60):
+        rng = np.random.default_rng(8800 + seed)
+        nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, int(rng.integers(5, 400))))
+        r = ccref.run(prof, nodes, pod)
+        vc, vreq = _random_victims(rng, nodes)
+        rest = (rng.random(nodes.n) < 0.3).astype(np.uint8) if pod.has_host_ports and seed % 2 else None
+        ref = ccref.preemption_dry_run(prof, nodes, pod, r.per_node_count, vc, vreq, rest)
+        kinds.add((ref.nominated, bool(ref.hist.sum())))
+    assert (True, False) in kinds and (False, True) in kinds and len(kinds) >= 3
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_host_dry_run_without_the_fit_plugin(ccref, seed):
+    """NodeResourcesFit disabled in the profile: only NodePorts ends the run (one clone per node), and only the ports count in
+    the second Filter run -- a node that took a clone keeps conflicting whatever is removed."""
+    rng = np.random.default_rng(8900 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(5, 200)))
+    prof.filter_mask &= ~M.F_FIT
+    pod.has_host_ports, pod.host_ports_conflict = True, (rng.random(nodes.n) < 0.4).astype(np.uint8)
+    r = ccref.run(prof, nodes, pod, max_limit=10 * nodes.n)
+    assert r.stop == M.STOP_UNSCHEDULABLE and r.placed <= nodes.n
+    vc, vreq = _random_victims(rng, nodes)
+    rest = (pod.host_ports_conflict * (rng.random(nodes.n) < 0.5)).astype(np.uint8)
+    pod.preempt = M.PreemptionSide(priority=1, victim_count=vc if vc.any() else None, victim_req=vreq, ports_conflict_rest=rest)
+    ref = ccref.preemption_dry_run(prof, nodes, pod, r.per_node_count, vc, vreq, rest)
+    got = preemption.dry_run(nodes, pod, r.per_node_count, r.n_code_unschedulable, prof.filter_mask)
+    assert (got.kind == "nominated") == ref.nominated
+    if not ref.nominated:
+        assert got.no_victims == ref.no_victims and np.array_equal(got.hist, ref.hist) and ref.hist.sum() == ref.hist[M.R_NODEPORTS]
