@@ -49,13 +49,12 @@ class ClusterCapacity {
     }
     void SetResult(RunResult r) { // (test hook: a result that did not come from the engine)
         status_.Pods = std::move(r);
-        const size_t failing = pods_.size() > 1 && status_.Pods.stop_spec >= 0 ? (size_t)status_.Pods.stop_spec : 0;
-        status_.StopReason = stop_reason(status_.Pods, (int64_t)snap_.n(), max_simulated_, snap_.side(failing).taint_reasons, snap_.scalar_names);
+        status_.StopReason = terminal_stop_reason(snap_, status_.Pods, max_simulated_, profile_.c.filter_mask, /*warn=*/true);
         ran_ = true;
     }
     Value Report() const {
         if (!ran_) throw std::runtime_error("ClusterCapacity.Report before Run");
-        return build_review(pods_, snap_, status_.Pods, max_simulated_);
+        return build_review(pods_, snap_, status_.Pods, max_simulated_, profile_.c.filter_mask);
     }
     const Status &GetStatus() const { return status_; }
     const Snapshot &snapshot() const { return snap_; }

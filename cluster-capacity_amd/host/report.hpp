@@ -7,12 +7,14 @@
 //   clusterCapacityReviewPrettyPrint  pkg/framework/report.go:235-283
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <ctime>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/ccsim.h"
+#include "preemption.hpp"
 #include "quantity.hpp"
 #include "snapshot.hpp"
 #include "value.hpp"
@@ -56,13 +58,12 @@ inline const char *reason_text(int slot) {
     return nullptr;
 }
 
-// FitError.Error() for the terminal cycle, including the DefaultPreemption suffix
-inline std::string fit_error_message(int64_t n_nodes, const RunResult &r, const std::vector<std::string> &taint_reasons,
-                                     const std::vector<std::string> &scalar_names) {
+inline std::map<std::string, int64_t> reason_histogram(const std::vector<int64_t> &hist, const std::vector<int64_t> &hist_taintset,
+                                                       const std::vector<std::string> &taint_reasons, const std::vector<std::string> &scalar_names) {
     static const char *res_names[3] = {"cpu", "memory", "ephemeral-storage"};
     std::map<std::string, int64_t> reasons;
-    for (int slot = 0; slot < (int)r.hist.size(); slot++) {
-        if (!r.hist[(size_t)slot]) continue;
+    for (int slot = 0; slot < (int)hist.size(); slot++) {
+        if (!hist[(size_t)slot]) continue;
         std::string text;
         if (const char *t = reason_text(slot)) text = t;
         else if (slot >= CCSIM_R_RES0 && slot < CCSIM_R_RES0 + CCSIM_MAX_RES) {
@@ -70,31 +71,56 @@ inline std::string fit_error_message(int64_t n_nodes, const RunResult &r, const 
             text = std::string("Insufficient ") + (c < 3 ? res_names[c] : (c - 3 < (int)scalar_names.size() ? scalar_names[(size_t)c - 3] : "scalar-" + std::to_string(c - 3)));
         } else
             text = "reason-" + std::to_string(slot);
-        reasons[text] += r.hist[(size_t)slot];
+        reasons[text] += hist[(size_t)slot];
     }
-    for (size_t ts = 0; ts < r.hist_taintset.size(); ts++)
-        if (r.hist_taintset[ts]) // taint_toleration.go:119: the first untolerated taint of the set
-            reasons[ts < taint_reasons.size() ? taint_reasons[ts] : "node(s) had untolerated taint {taintset-" + std::to_string(ts) + "}"] += r.hist_taintset[ts];
+    for (size_t ts = 0; ts < hist_taintset.size(); ts++)
+        if (hist_taintset[ts]) // taint_toleration.go:119: the first untolerated taint of the set
+            reasons[ts < taint_reasons.size() ? taint_reasons[ts] : "node(s) had untolerated taint {taintset-" + std::to_string(ts) + "}"] += hist_taintset[ts];
+    return reasons;
+}
+
+// FitError.Error() for the terminal cycle, including the DefaultPreemption tail.  `pre`: the outcome of the dry run
+// (preemption.hpp); nullptr = no node holds a pod of lower priority than the simulated one.
+inline std::string fit_error_message(int64_t n_nodes, const RunResult &r, const std::vector<std::string> &taint_reasons,
+                                     const std::vector<std::string> &scalar_names, const PreemptionOutcome *pre = nullptr) {
     std::string msg = "0/" + std::to_string(n_nodes) + " nodes are available:";
-    const std::string body = histogram_message(reasons);
+    const std::string body = histogram_message(reason_histogram(r.hist, r.hist_taintset, taint_reasons, scalar_names));
     if (!body.empty()) msg += " " + body + ".";
-    // Nodes that failed with plain Unschedulable are dry-run candidates; the simulated pod has priority 0 like everything
-    // else, so each reports "No preemption victims found"; the rest are absent from the map.
-    std::map<std::string, int64_t> pre;
-    if (r.n_code_unschedulable) pre["No preemption victims found for incoming pod"] = r.n_code_unschedulable;
-    if (n_nodes - r.n_code_unschedulable > 0) pre["Preemption is not helpful for scheduling"] = n_nodes - r.n_code_unschedulable;
+    if (pre && pre->kind == PreemptionOutcome::Nominated) return msg; // a candidate: PostFilter Success, empty message (preemption.go:281-303)
+    if (pre && pre->kind == PreemptionOutcome::Never) return msg + " preemption: not eligible due to preemptionPolicy=Never."; // default_preemption.go:355-357
+    // Nodes that failed with plain Unschedulable are dry-run nodes: without a lower-priority pod each reports "No preemption
+    // victims found"; with victims that do not help, the filter status after their removal; the rest are absent from the map.
+    std::map<std::string, int64_t> h;
+    if (pre) h = reason_histogram(pre->hist, {}, {}, scalar_names);
+    const int64_t no_victims = pre ? pre->no_victims : r.n_code_unschedulable;
+    if (no_victims) h["No preemption victims found for incoming pod"] = no_victims;
+    if (n_nodes - r.n_code_unschedulable > 0) h["Preemption is not helpful for scheduling"] = n_nodes - r.n_code_unschedulable;
     std::string pmsg = "0/" + std::to_string(n_nodes) + " nodes are available:";
-    const std::string pbody = histogram_message(pre);
+    const std::string pbody = histogram_message(h);
     if (!pbody.empty()) pmsg += " " + pbody + ".";
     return msg + " preemption: " + pmsg;
 }
 
 // ClusterCapacity.Status.StopReason (simulator.go:301,331)
 inline std::string stop_reason(const RunResult &r, int64_t n_nodes, int64_t max_limit, const std::vector<std::string> &taint_reasons,
-                               const std::vector<std::string> &scalar_names) {
+                               const std::vector<std::string> &scalar_names, const PreemptionOutcome *pre = nullptr) {
     if (r.stop == CCSIM_STOP_LIMIT) return "LimitReached: Maximum number of pods simulated: " + std::to_string(max_limit);
     if (r.stop == CCSIM_STOP_NO_NODES) return "Unschedulable: no nodes available to schedule pods";
-    return "Unschedulable: " + fit_error_message(n_nodes, r, taint_reasons, scalar_names);
+    return "Unschedulable: " + fit_error_message(n_nodes, r, taint_reasons, scalar_names, pre);
+}
+
+// The PostFilter of the terminal cycle for a finished run: StopReason with DefaultPreemption's dry run folded in.
+inline std::string terminal_stop_reason(const Snapshot &snap, const RunResult &r, int64_t max_limit, uint32_t filter_mask, bool warn = false) {
+    const size_t P = snap.n_templates();
+    const size_t failing = P > 1 && r.stop_spec >= 0 ? (size_t)r.stop_spec : 0; // the FitError describes the template that did not fit
+    if (r.stop != CCSIM_STOP_UNSCHEDULABLE) return stop_reason(r, (int64_t)snap.n(), max_limit, snap.side(failing).taint_reasons, snap.scalar_names);
+    bool mixed = false; // clones of one template below another template's priority
+    for (size_t t = 1; t < P; t++) mixed = mixed || snap.side(t).priority != snap.side(0).priority;
+    const PreemptionOutcome pre = preemption_dry_run(snap, snap.side(failing), r.per_node_count, r.n_code_unschedulable, filter_mask, P, mixed);
+    if (warn && pre.kind == PreemptionOutcome::Unmodelled)
+        std::fprintf(stderr, "warning: nodes hold pods of lower priority than the simulated pod and its filters are topology-coupled (or several "
+                             "templates run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims\n");
+    return stop_reason(r, (int64_t)snap.n(), max_limit, snap.side(failing).taint_reasons, snap.scalar_names, &pre);
 }
 
 // report.go:100-109 getMainFailReason
@@ -170,10 +196,10 @@ inline std::string utc_now_iso() {
 
 // report.go:196-225 GetReport.  Scheduled pod i is a clone of template i mod P (parsePodsReview, report.go:146-171): exactly
 // the order the engine cycles the templates in.
-inline Value build_review(const std::vector<Value> &templates_in, const Snapshot &snap, const RunResult &r, int64_t max_limit) {
+inline Value build_review(const std::vector<Value> &templates_in, const Snapshot &snap, const RunResult &r, int64_t max_limit,
+                          uint32_t filter_mask = ~0u) {
     const size_t P = templates_in.size();
-    const size_t failing = P > 1 && r.stop_spec >= 0 ? (size_t)r.stop_spec : 0; // the FitError describes the template that did not fit
-    const std::string stop = stop_reason(r, (int64_t)snap.n(), max_limit, snap.side(failing).taint_reasons, snap.scalar_names);
+    const std::string stop = terminal_stop_reason(snap, r, max_limit, filter_mask);
     Value spec = Value::object();
     Value templates = Value::array(), reqs = Value::array();
     for (const auto &pod : templates_in) templates.a.push_back(pod), reqs.a.push_back(pod_requirements(pod));
@@ -200,8 +226,8 @@ inline Value build_review(const std::vector<Value> &templates_in, const Snapshot
     review.set("spec", spec), review.set("status", status);
     return review;
 }
-inline Value build_review(const Value &pod, const Snapshot &snap, const RunResult &r, int64_t max_limit) {
-    return build_review(std::vector<Value>{pod}, snap, r, max_limit);
+inline Value build_review(const Value &pod, const Snapshot &snap, const RunResult &r, int64_t max_limit, uint32_t filter_mask = ~0u) {
+    return build_review(std::vector<Value>{pod}, snap, r, max_limit, filter_mask);
 }
 
 // report.go:235-283 clusterCapacityReviewPrettyPrint

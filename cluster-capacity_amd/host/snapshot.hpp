@@ -310,6 +310,13 @@ struct PodSide {
     bool has_host_ports = false;              // NodePorts: util.GetHostPorts(pod) is not empty
     std::vector<uint8_t> host_ports_conflict; // per node: an existing pod holds a conflicting port; empty = none does
     std::vector<uint8_t> image_score;         // ImageLocality score per node (0..100); empty = no image of the pod anywhere
+    // DefaultPreemption's dry run of the terminal cycle (HOST ONLY, never crosses the C ABI; preemption.hpp): a victim is an
+    // existing pod of lower priority than the template (default_preemption.go:392-396)
+    int64_t priority = 0;
+    bool preempt_never = false;                   // spec.preemptionPolicy == Never
+    std::vector<int32_t> victim_count;            // per node; empty = no node holds a victim
+    std::vector<std::vector<int64_t>> victim_req; // per resource column, per node
+    std::vector<uint8_t> ports_conflict_rest;     // a REMAINING pod of the node holds a conflicting host port; empty = not evaluated
 };
 
 // The snapshot: node columns shared by every template + the first template (as base class: the single-template code reads
@@ -551,6 +558,31 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             bool any = false;
             for (size_t i = 0; i < N; i++) conflict[i] = !used[i].empty() && ports_conflict(want, used[i]), any = any || conflict[i];
             if (any) s.host_ports_conflict = conflict;
+        }
+        // DefaultPreemption dry run (report only): what removing every lower-priority pod of a node would free
+        // (corev1helpers.PodPriority: spec.priority, 0 when unset)
+        s.priority = spec["priority"].as_int(0);
+        s.preempt_never = spec["preemptionPolicy"].text() == "Never";
+        std::vector<uint8_t> is_victim(live.size(), 0);
+        bool any_victim = false;
+        for (size_t j = 0; j < live.size(); j++) is_victim[j] = (*live[j])["spec"]["priority"].as_int(0) < s.priority, any_victim = any_victim || is_victim[j];
+        if (any_victim) {
+            s.victim_count.assign(N, 0);
+            s.victim_req.assign(S.res_names.size(), std::vector<int64_t>(N, 0));
+            for (size_t j = 0; j < live.size(); j++) {
+                if (!is_victim[j]) continue;
+                const PodRequests r = pod_requests((*live[j])["spec"], S.res_names);
+                s.victim_count[live_node[j]] += 1;
+                for (size_t c = 0; c < r.req.size(); c++) s.victim_req[c][live_node[j]] += r.req[c];
+            }
+            if (!want.empty()) {
+                std::vector<std::vector<HostPort>> rest(N);
+                for (size_t j = 0; j < live.size(); j++)
+                    if (!is_victim[j])
+                        for (const auto &hp : host_ports((*live[j])["spec"])) rest[live_node[j]].push_back(hp);
+                s.ports_conflict_rest.assign(N, 0);
+                for (size_t i = 0; i < N; i++) s.ports_conflict_rest[i] = !rest[i].empty() && ports_conflict(want, rest[i]);
+            }
         }
     }
     // ImageLocality: the scheduler cache's image states (cache.go:680-703): Size = what the FIRST node added (nodes arrive
@@ -839,6 +871,14 @@ inline Value pod_side_json(const PodSide &s) {
     p.set("has_host_ports", Value::boolean(s.has_host_ports));
     p.set("host_ports_conflict", s.host_ports_conflict.empty() ? Value() : int_array(s.host_ports_conflict));
     p.set("image_score", s.image_score.empty() ? Value() : int_array(s.image_score));
+    Value pre = Value::object();
+    pre.set("priority", Value::num(s.priority)), pre.set("never", Value::boolean(s.preempt_never));
+    pre.set("victim_count", s.victim_count.empty() ? Value() : int_array(s.victim_count));
+    Value vr = Value::array();
+    for (auto &v : s.victim_req) vr.a.push_back(int_array(v));
+    pre.set("victim_req", vr);
+    pre.set("ports_conflict_rest", s.ports_conflict_rest.empty() ? Value() : int_array(s.ports_conflict_rest));
+    p.set("preempt", pre);
     return p;
 }
 inline Value snapshot_json(const Snapshot &s) {

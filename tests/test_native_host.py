@@ -40,7 +40,9 @@ def _pod_dump(p):
                         "self_match": bool(k.self_match), "is_hostname": bool(k.is_hostname), "n_domains": int(k.n_domains),
                         "node_match_count": lst(k.node_match_count), "node_included": lst(k.node_included)} for k in p.spread],
             "ipa": ipa, "has_host_ports": bool(p.has_host_ports), "host_ports_conflict": lst(p.host_ports_conflict),
-            "image_score": lst(p.image_score)}
+            "image_score": lst(p.image_score),
+            "preempt": {"priority": p.preempt.priority, "never": p.preempt.never, "victim_count": lst(p.preempt.victim_count),
+                        "victim_req": [lst(v) for v in p.preempt.victim_req], "ports_conflict_rest": lst(p.preempt.ports_conflict_rest)}}
 
 
 def py_dump(snap):
@@ -762,6 +764,14 @@ def _random_objects(rng):
                                       for _ in range(int(rng.integers(1, 4)))]
     if rng.random() < 0.05:
         spec["volumes"] = [{"name": "data", "persistentVolumeClaim": {"claimName": "pvc"}}]
+    # priorities (DefaultPreemption's dry run: existing pods below the template's priority are victims)
+    for p in pods:
+        if p.get("kind") == "Pod" and rng.random() < 0.4:
+            p["spec"]["priority"] = int(rng.choice([-10, 0, 5, 1000]))
+    if rng.random() < 0.5:
+        spec["priority"] = int(rng.choice([0, 5, 100]))
+    if rng.random() < 0.1:
+        spec["preemptionPolicy"] = str(rng.choice(["Never", "PreemptLowerPriority"]))
     return nodes, pods, pod, exclude
 
 
