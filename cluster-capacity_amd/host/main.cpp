@@ -13,9 +13,13 @@
 // the library or the device is missing the command fails.  Test hooks (no GPU needed): --dump-snapshot prints the integer
 // snapshot the ingest produced, --fake-result renders the report for a result read from a file.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <climits>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,11 +49,43 @@ std::string read_file(const std::string &path) {
     return text;
 }
 
+// A snapshot file as text without copying it: regular files are mapped (a dump of a large cluster is hundreds of MB to GBs;
+// zero-filling a string of that size and copying the page cache into it costs as much as scanning it), anything else is read.
+class FileText {
+  public:
+    explicit FileText(const std::string &path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *p = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p != MAP_FAILED) {
+                ::madvise(p, (size_t)st.st_size, MADV_SEQUENTIAL);
+                map_ = p, len_ = (size_t)st.st_size;
+            }
+        }
+        ::close(fd);
+        if (!map_) owned_ = read_file(path);
+    }
+    ~FileText() {
+        if (map_) ::munmap(map_, len_);
+    }
+    FileText(const FileText &) = delete;
+    FileText &operator=(const FileText &) = delete;
+    std::string_view view() const { return map_ ? std::string_view((const char *)map_, len_) : std::string_view(owned_); }
+
+  private:
+    void *map_ = nullptr;
+    size_t len_ = 0;
+    std::string owned_;
+};
+
 // Every object of the snapshot files goes to `sink` exactly once, MOVED out of the parsed documents (a kubectl dump of a large
 // cluster is hundreds of MB: copying the documents, as the first version did, cost more than parsing them); lists are flattened.
-template <class Sink> void for_each_object(const std::vector<std::string> &paths, Sink sink) {
+template <class Sink> void for_each_object(const std::vector<std::string> &paths, Sink sink, const std::vector<std::string> *wanted_images = nullptr) {
     for (const auto &path : paths) {
-        std::vector<Value> docs = parse_documents(read_file(path));
+        const FileText file(path);
+        std::vector<Value> docs = parse_documents(file.view(), /*prune_cluster_objects=*/true, wanted_images);
         for (Value &d : docs) {
             if (!d.truthy()) continue;
             const std::string kind = d["kind"].text();
@@ -74,13 +110,19 @@ std::vector<Value> load_kind(const std::vector<std::string> &paths, const std::s
     return out;
 }
 
-void load_objects(const std::vector<std::string> &paths, std::vector<Value> &nodes, std::vector<Value> &pods, std::vector<Value> &namespaces) {
+// `templates`: the simulated pods -- the Nodes' status.images entries are kept only for the images their containers name
+void load_objects(const std::vector<std::string> &paths, const std::vector<Value> &templates, std::vector<Value> &nodes, std::vector<Value> &pods,
+                  std::vector<Value> &namespaces) {
+    std::vector<std::string> wanted;
+    for (const auto &t : templates)
+        for (const char *list : {"initContainers", "containers"})
+            for (const auto &c : t["spec"][list].items()) wanted.push_back(normalized_image_name(c["image"].text()));
     for_each_object(paths, [&](Value &&o) {
         const std::string kind = o["kind"].text();
         if (kind == "Node") nodes.push_back(std::move(o));
         else if (kind == "Pod") pods.push_back(std::move(o));
         else if (kind == "Namespace") namespaces.push_back(std::move(o));
-    });
+    }, &wanted);
 }
 
 // options.go:79-147 ParseAPISpec (defaults only; API validation is the apiserver's job)
@@ -221,26 +263,43 @@ int main(int argc, char **argv) {
         for (const auto &p : podspecs) templates.push_back(parse_pod_spec(p));
         ClusterCapacity cc = ClusterCapacity::New(prof, templates, max_limit, exclude);
         cc.device = device, cc.mode = mode, cc.gpus = gpus, cc.force_sharded = force_sharded;
+        // CCHOST_TIMING=1: wall time of the host phases on stderr (read + parse, intern + integer snapshot, engine run, report)
+        const bool timing = std::getenv("CCHOST_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
+            const auto t1 = now();
+            if (timing) std::fprintf(stderr, "[timing] %-28s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        };
+        auto t0 = now();
         std::vector<Value> node_objs, pod_objs, ns_objs;
-        load_objects(snapshots, node_objs, pod_objs, ns_objs);
+        load_objects(snapshots, templates, node_objs, pod_objs, ns_objs);
+        lap("read + parse objects", t0);
         cc.SyncWithClient(node_objs, pod_objs, ns_objs);
+        lap("intern + integer snapshot", t0);
         if (!dump.empty()) {
             std::string out;
             to_json(out, snapshot_json(cc.snapshot()));
             if (dump == "-") std::cout << out << "\n";
             else std::ofstream(dump) << out << "\n";
-            return 0;
+            lap("dump snapshot", t0);
+            std::cout.flush(), std::fflush(nullptr);
+            std::_Exit(0); // (see the end of main)
         }
         if (fake.empty()) cc.Run();
         else cc.SetResult(result_from_json(parse_documents(read_file(fake)).at(0)));
+        lap("marshal + engine run", t0);
         const Value review = cc.Report();
+        lap("report", t0);
         cc.Close();
         std::string out;
         if (output == "json") to_json(out, review), out += "\n";
         else if (output == "yaml") to_yaml(out, review);
         else out = pretty(review, verbose);
         std::cout << out;
-        return 0;
+        // the object trees of a large dump take longer to free() node by node than the OS takes to reclaim the pages
+        std::cout.flush(), std::fflush(nullptr);
+        std::_Exit(0);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "cluster-capacity: %s\n", e.what());
         return 1;

@@ -588,6 +588,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     // ImageLocality: the scheduler cache's image states (cache.go:680-703): Size = what the FIRST node added (nodes arrive
     // sorted by name) reports for the image name, NumNodes = nodes listing the name
     {
+        // (only the images the template names are looked at: a cluster dump carries tens of image names per node)
+        std::vector<std::string> wanted;
+        for (const char *list : {"initContainers", "containers"})
+            for (const auto &c : spec[list].items()) wanted.push_back(normalized_image_name(c["image"].text()));
         std::vector<size_t> by_name(N);
         for (size_t i = 0; i < N; i++) by_name[i] = i;
         std::sort(by_name.begin(), by_name.end(), [&](size_t a, size_t b) { return S.names[a] < S.names[b]; });
@@ -596,12 +600,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         for (size_t i : by_name)
             for (const auto &img : (*nodes[i])["status"]["images"].items())
                 for (const auto &nm : img["names"].items()) {
-                    size.emplace(nm.text(), img["sizeBytes"].truthy() ? img["sizeBytes"].as_int() : 0);
-                    holders[nm.text()].insert(i);
+                    if (nm.t != Value::Str || std::find(wanted.begin(), wanted.end(), nm.s) == wanted.end()) continue;
+                    size.emplace(nm.s, img["sizeBytes"].truthy() ? img["sizeBytes"].as_int() : 0);
+                    holders[nm.s].insert(i);
                 }
-        std::vector<std::string> wanted;
-        for (const char *list : {"initContainers", "containers"})
-            for (const auto &c : spec[list].items()) wanted.push_back(normalized_image_name(c["image"].text()));
         bool any = false;
         for (const auto &w : wanted) any = any || holders.count(w);
         if (any) {

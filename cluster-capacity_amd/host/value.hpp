@@ -4,11 +4,15 @@
 // Scalars keep their source text: a Quantity such as 0.5, "500m" or 1e3 is interpreted by quantity.hpp, exactly like
 // resource.ParseQuantity does with the JSON token (vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go).
 #pragma once
+#include <algorithm>
 #include <cctype>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <initializer_list>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <utility>
 #include <vector>
 
@@ -51,17 +55,21 @@ struct Value {
         return v;
     }
     bool is_null() const { return t == Null; }
-    bool has(const std::string &k) const {
+    bool has(const std::string &k) const { return has(k.data(), k.size()); }
+    bool has(const char *k) const { return has(k, std::strlen(k)); }
+    bool has(const char *k, size_t len) const {
         if (t != Obj) return false;
         for (auto &kv : o)
-            if (kv.first == k) return true;
+            if (kv.first.size() == len && std::memcmp(kv.first.data(), k, len) == 0) return true;
         return false;
     }
     // python's d.get(k): Null when absent (or when this is not a mapping)
-    const Value &operator[](const std::string &k) const {
+    const Value &operator[](const std::string &k) const { return get(k.data(), k.size()); }
+    const Value &operator[](const char *k) const { return get(k, std::strlen(k)); } // (no temporary std::string per lookup)
+    const Value &get(const char *k, size_t len) const {
         if (t == Obj)
             for (auto &kv : o)
-                if (kv.first == k) return kv.second;
+                if (kv.first.size() == len && std::memcmp(kv.first.data(), k, len) == 0) return kv.second;
         return null_value();
     }
     Value &set(const std::string &k, Value v) {
@@ -110,19 +118,111 @@ struct Value {
 };
 
 // ------------------------------------------------------------------------------------------------ JSON
+// `prune_cluster_objects`: the document is a kubectl dump of cluster objects (Nodes, Pods, Namespaces, ... or Lists of them)
+// and only the fields the ingest reads are materialised; the rest is skipped without building it -- metadata.managedFields /
+// ownerReferences / finalizers / annotations (kept for Namespaces: genpod reads them), every status field except phase /
+// allocatable / images, the spec fields and container fields no scheduler plugin of this host looks at (volumes, env, probes,
+// mounts, ...).  On real dumps that is most of the bytes (managedFields, last-applied-configuration, conditions, container
+// statuses).  Templates (--podspec) are never read this way: they are echoed into the report as they came.
 class JsonParser {
   public:
-    explicit JsonParser(const std::string &src) : s_(src) {}
+    explicit JsonParser(std::string_view src, bool prune_cluster_objects = false, const std::vector<std::string> *wanted_images = nullptr)
+        : s_(src), prune_(prune_cluster_objects), wanted_images_(wanted_images) {}
     Value parse_document() {
-        Value v = parse_value();
+        Value v = parse_value(prune_ ? Item : NoCtx);
         skip_ws();
         if (i_ != s_.size()) fail("trailing characters");
         return v;
     }
 
   private:
-    const std::string &s_;
+    const std::string_view s_; // (a view: the host maps large dumps instead of copying them into a string)
+    const bool prune_;
+    // status.images of a Node: only entries naming one of these images are kept (ImageLocality looks at the images the template's
+    // containers name, a node lists tens); nullptr = keep every entry
+    const std::vector<std::string> *wanted_images_;
     size_t i_ = 0;
+    enum Ctx { NoCtx, Item, Items, Metadata, Status, Spec, Containers, Container, Images };
+    std::string kind_; // of the item being parsed ("" until its "kind" member was seen)
+    static bool one_of(const std::string &k, std::initializer_list<const char *> names) {
+        for (const char *n : names)
+            if (k == n) return true;
+        return false;
+    }
+    // -> the context of member `k` of an object in context `c`, or -1 to skip the member
+    int member_ctx(Ctx c, const std::string &k) const {
+        switch (c) {
+        case Item:
+            if (k == "items") return Items; // a List: its elements are objects again
+            if (k == "metadata") return Metadata;
+            if (k == "status") return Status;
+            if (k == "spec") return Spec;
+            return NoCtx;
+        case Metadata:
+            if (one_of(k, {"managedFields", "ownerReferences", "finalizers"})) return -1;
+            if (k == "annotations" && !kind_.empty() && kind_ != "Namespace") return -1;
+            return NoCtx;
+        case Status:
+            if (k == "images") return wanted_images_ ? (wanted_images_->empty() ? -1 : (int)Images) : (int)NoCtx;
+            return one_of(k, {"phase", "allocatable"}) ? NoCtx : -1;
+        case Spec:
+            if (one_of(k, {"containers", "initContainers"})) return Containers;
+            if (one_of(k, {"volumes", "securityContext", "imagePullSecrets", "dnsConfig", "hostAliases", "readinessGates", "tolerations", "ephemeralContainers"})) return -1;
+            return NoCtx;
+        case Container:
+            return one_of(k, {"env", "envFrom", "volumeMounts", "volumeDevices", "livenessProbe", "readinessProbe", "startupProbe", "lifecycle", "securityContext",
+                              "command", "args"}) ? -1 : NoCtx;
+        default: return NoCtx;
+        }
+    }
+    void skip_string() { // at the opening quote
+        i_++;
+        while (true) {
+            const void *q = std::memchr(s_.data() + i_, '"', s_.size() - i_);
+            if (!q) fail("unterminated string");
+            const size_t at = (size_t)((const char *)q - s_.data());
+            size_t back = 0;
+            while (at - back > i_ && s_[at - back - 1] == '\\') back++;
+            i_ = at + 1;
+            if (back % 2 == 0) return; // the quote is not escaped
+        }
+    }
+    // one entry of a Node's status.images, before it is parsed: can it name a wanted image?  The entry's text is searched for
+    // the quoted name; an entry containing a backslash (an escape could spell the name differently) is kept to be safe.
+    bool image_entry_is_wanted() {
+        skip_ws();
+        const size_t from = i_;
+        skip_value();
+        const size_t to = i_;
+        i_ = from;
+        if (std::memchr(s_.data() + from, '\\', to - from)) return true;
+        for (const auto &w : *wanted_images_) {
+            const std::string quoted = '"' + w + '"';
+            if (to - from >= quoted.size() && std::search(s_.begin() + (long)from, s_.begin() + (long)to, quoted.begin(), quoted.end()) != s_.begin() + (long)to) return true;
+        }
+        return false;
+    }
+    void skip_value() { // no tree is built; brackets are balanced, their kinds are not cross-checked
+        skip_ws();
+        if (i_ >= s_.size()) fail("unexpected end");
+        char c = s_[i_];
+        if (c == '"') return skip_string();
+        if (c == '{' || c == '[') {
+            int depth = 0;
+            while (i_ < s_.size()) {
+                c = s_[i_];
+                if (c == '"') {
+                    skip_string();
+                    continue;
+                }
+                i_++;
+                if (c == '{' || c == '[') depth++;
+                else if ((c == '}' || c == ']') && --depth == 0) return;
+            }
+            fail("unterminated container");
+        }
+        while (i_ < s_.size() && s_[i_] != ',' && s_[i_] != '}' && s_[i_] != ']' && s_[i_] != ' ' && s_[i_] != '\n' && s_[i_] != '\r' && s_[i_] != '\t') i_++;
+    }
     [[noreturn]] void fail(const char *what) const { throw std::runtime_error("JSON: " + std::string(what) + " at offset " + std::to_string(i_)); }
     void skip_ws() {
         while (i_ < s_.size() && (s_[i_] == ' ' || s_[i_] == '\t' || s_[i_] == '\n' || s_[i_] == '\r')) i_++;
@@ -153,7 +253,7 @@ class JsonParser {
             // the run up to the next quote or escape in one append (kubectl dumps are almost all plain characters)
             const size_t from = i_;
             while (i_ < s_.size() && s_[i_] != '"' && s_[i_] != '\\') i_++;
-            if (i_ > from) out.append(s_, from, i_ - from);
+            if (i_ > from) out.append(s_.data() + from, i_ - from);
             if (i_ >= s_.size()) fail("unterminated string");
             const char c = s_[i_++];
             if (c == '"') return out;
@@ -179,12 +279,13 @@ class JsonParser {
             }
         }
     }
-    Value parse_value() {
+    Value parse_value(Ctx ctx = NoCtx) {
         skip_ws();
         if (i_ >= s_.size()) fail("unexpected end");
         const char c = s_[i_];
         if (c == '{') {
             Value v = Value::object();
+            if (ctx == Item) kind_.clear();
             i_++;
             skip_ws();
             if (i_ < s_.size() && s_[i_] == '}') { i_++; return v; } // (not `return i_++, v`: a comma expression is no candidate for the implicit move and deep-copies v)
@@ -195,7 +296,12 @@ class JsonParser {
                 skip_ws();
                 if (i_ >= s_.size() || s_[i_] != ':') fail("expected ':'");
                 i_++;
-                v.o.emplace_back(std::move(k), parse_value());
+                const int sub = ctx == NoCtx ? (int)NoCtx : member_ctx(ctx, k);
+                if (sub < 0) skip_value();
+                else {
+                    v.o.emplace_back(std::move(k), parse_value((Ctx)sub));
+                    if (ctx == Item && v.o.back().first == "kind") kind_ = v.o.back().second.text();
+                }
                 skip_ws();
                 if (i_ < s_.size() && s_[i_] == ',') {
                     i_++;
@@ -210,8 +316,10 @@ class JsonParser {
             i_++;
             skip_ws();
             if (i_ < s_.size() && s_[i_] == ']') { i_++; return v; } // (not `return i_++, v`: a comma expression is no candidate for the implicit move and deep-copies v)
+            const Ctx elem = ctx == Items ? Item : ctx == Containers ? Container : NoCtx;
             while (true) {
-                v.a.push_back(parse_value());
+                if (ctx == Images && !image_entry_is_wanted()) skip_value();
+                else v.a.push_back(parse_value(elem));
                 skip_ws();
                 if (i_ < s_.size() && s_[i_] == ',') {
                     i_++;
@@ -229,7 +337,7 @@ class JsonParser {
         while (i_ < s_.size() && (std::isdigit((unsigned char)s_[i_]) || s_[i_] == '-' || s_[i_] == '+' || s_[i_] == '.' || s_[i_] == 'e' || s_[i_] == 'E')) i_++;
         if (j == i_) fail("unexpected character");
         Value v;
-        v.t = Value::Num, v.s = s_.substr(j, i_ - j);
+        v.t = Value::Num, v.s.assign(s_.data() + j, i_ - j);
         return v;
     }
 };
@@ -841,19 +949,19 @@ inline void to_yaml(std::string &out, const Value &v, int indent = 0, bool in_se
 }
 
 // a file of objects: JSON (first non-blank character is { or [) or YAML stream
-inline std::vector<Value> parse_documents(const std::string &text) {
+inline std::vector<Value> parse_documents(std::string_view text, bool prune_cluster_objects = false, const std::vector<std::string> *wanted_images = nullptr) {
     size_t i = 0;
     while (i < text.size() && std::isspace((unsigned char)text[i])) i++;
     if (i < text.size() && (text[i] == '{' || text[i] == '[')) {
         try {
-            JsonParser p(text);
+            JsonParser p(text, prune_cluster_objects, wanted_images);
             std::vector<Value> one;
             one.push_back(p.parse_document()); // (moved: a braced list would copy the whole document)
             return one;
         } catch (const std::exception &) { // a YAML document in flow style
         }
     }
-    YamlParser y(text);
+    YamlParser y{std::string(text)};
     return y.parse_stream();
 }
 

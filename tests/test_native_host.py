@@ -1250,3 +1250,69 @@ def test_native_sharded_host_side_views_random_clusters(native, recorder, tmp_pa
         assert got is None  # refused by both hosts (volumes, more topology keys than the engine holds, ...)
         return
     assert got is not None
+
+
+# ---- pruned parsing of cluster dumps (host/value.hpp JsonParser, prune_cluster_objects) -------------------------------------------
+def _decorate(obj, rng):
+    """What a real `kubectl get -o json` carries around the fields the ingest reads -- all of it must be skipped without a trace."""
+    o = json.loads(json.dumps(obj))
+    tricky = 'a "quoted" \\ back\\\\slash } ] { [ , : é \n end"'
+    md = o.setdefault("metadata", {})
+    md["managedFields"] = [{"manager": "kubelet", "operation": "Update", "fieldsType": "FieldsV1", "time": "2025-01-01T00:00:00Z",
+                            "fieldsV1": {"f:metadata": {"f:labels": {".": {}, 'f:k"ey': {}}}, "f:status": {"f:conditions": {'k:{"type":"Ready"}': {".": {}}}}}}]
+    md["ownerReferences"] = [{"apiVersion": "apps/v1", "kind": "ReplicaSet", "name": "rs", "uid": "1-2-3", "controller": True}]
+    md["finalizers"] = ["x/y"]
+    md["uid"], md["resourceVersion"], md["creationTimestamp"] = "u-1", "12345", "2025-01-01T00:00:00Z"
+    if o.get("kind") != "Namespace":
+        md["annotations"] = {"kubectl.kubernetes.io/last-applied-configuration": json.dumps(obj) + tricky, "note": tricky}
+    st = o.setdefault("status", {})
+    st["conditions"] = [{"type": "Ready", "status": "True", "message": tricky, "lastTransitionTime": None}]
+    st["addresses"] = [{"type": "InternalIP", "address": "10.0.0.1"}]
+    st["nodeInfo"] = {"kubeletVersion": "v1.34.0", "nested": {"deep": [[1, 2, {"x": [tricky]}], -1.5e3, True, None]}}
+    st["capacity"] = {"cpu": "9999", "memory": "9999Gi", "pods": "9999"}
+    st["containerStatuses"] = [{"name": "c", "ready": True, "state": {"running": {"startedAt": "2025-01-01T00:00:00Z"}}, "imageID": "sha256:" + "0" * 64}]
+    sp = o.setdefault("spec", {})
+    if o.get("kind") == "Pod":
+        sp["volumes"] = [{"name": "data", "persistentVolumeClaim": {"claimName": "pvc"}}, {"name": "kube-api-access", "projected": {"sources": [{"serviceAccountToken": {"path": "token"}}]}}]
+        sp["tolerations"] = [{"key": "node.kubernetes.io/not-ready", "operator": "Exists", "effect": "NoExecute", "tolerationSeconds": 300}]
+        sp["securityContext"], sp["imagePullSecrets"] = {"runAsUser": 1000}, [{"name": "regcred"}]
+        for c in (sp.get("containers") or []) + (sp.get("initContainers") or []):
+            c["env"] = [{"name": "A", "value": tricky}, {"name": "B", "valueFrom": {"fieldRef": {"fieldPath": "metadata.name"}}}]
+            c["volumeMounts"] = [{"name": "data", "mountPath": "/data"}]
+            c["livenessProbe"] = {"httpGet": {"path": "/healthz", "port": 8080}}
+            c["command"], c["args"] = ["sh", "-c", tricky], ["--flag={}"]
+            c["securityContext"] = {"capabilities": {"drop": ["ALL"]}}
+    if rng.random() < 0.5:  # member order as other producers emit it: kind after metadata
+        o = {k: o[k] for k in sorted(o, key=lambda k: (k == "kind", k == "apiVersion"))}
+    return o
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_pruned_parse_of_decorated_dumps_gives_the_same_snapshot(native, tmp_path, case):
+    nodes, pods, pod, exclude = CASES[case]()
+    rng = np.random.default_rng(1)
+    outs = []
+    for name, deco in (("plain", False), ("decorated", True)):
+        d = tmp_path / name
+        d.mkdir()
+        ns = [{"kind": "Namespace", "apiVersion": "v1", "metadata": {"name": "default", "labels": {"team": "a"}, "annotations": {"openshift.io/node-selector": "disk=ssd"}}}]
+        objs = [dict(o, kind=o.get("kind") or k) for k, lst in (("Node", nodes), ("Pod", pods), ("Namespace", ns)) for o in lst]
+        if deco:
+            objs = [_decorate(o, rng) for o in objs]
+        (d / "cluster.json").write_text(json.dumps({"kind": "List", "apiVersion": "v1", "metadata": {"resourceVersion": ""}, "items": objs}, indent=2 if deco else None))
+        (d / "pod.json").write_text(json.dumps(pod))
+        args = ["--podspec", str(d / "pod.json"), "--snapshot", str(d / "cluster.json"), "--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
+        outs.append(_run(native, args))
+        # genpod reads Namespace annotations: they survive the pruning whatever the member order
+        g = yaml.safe_load(_run(native, ["--genpod", "default", "--snapshot", str(d / "cluster.json")]))
+        assert g["spec"]["nodeSelector"] == {"disk": "ssd"}
+    assert outs[0] == outs[1]
+
+
+def test_pruned_parse_still_rejects_broken_json(native, tmp_path):
+    (tmp_path / "pod.json").write_text(EXAMPLES_POD)
+    for text in ('{"kind": "List", "items": [{"kind": "Node", "metadata": {"name": "n", "managedFields": [{"a": "unterminated}]}}]}',
+                 '{"kind": "Node", "metadata": {"name": "n"}, "status": {"conditions": [1, 2'):
+        (tmp_path / "c.json").write_text(text)
+        p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"], capture_output=True, text=True, timeout=30)
+        assert p.returncode != 0
