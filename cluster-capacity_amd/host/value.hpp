@@ -4,13 +4,19 @@
 // Scalars keep their source text: a Quantity such as 0.5, "500m" or 1e3 is interpreted by quantity.hpp, exactly like
 // resource.ParseQuantity does with the JSON token (vendor/k8s.io/apimachinery/pkg/api/resource/quantity.go).
 #pragma once
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <algorithm>
+#include <array>
 #include <cctype>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <initializer_list>
 #include <stdexcept>
+#include <thread>
+#include <cstdlib>
 #include <string>
 #include <string_view>
 #include <utility>
@@ -55,6 +61,14 @@ struct Value {
         return v;
     }
     bool is_null() const { return t == Null; }
+    // the member's value, or nullptr when absent (or when this is not a mapping): one scan where has() + [] take two
+    const Value *find(const char *k, size_t len) const {
+        if (t == Obj)
+            for (auto &kv : o)
+                if (kv.first.size() == len && std::memcmp(kv.first.data(), k, len) == 0) return &kv.second;
+        return nullptr;
+    }
+    const Value *find(const std::string &k) const { return find(k.data(), k.size()); }
     bool has(const std::string &k) const { return has(k.data(), k.size()); }
     bool has(const char *k) const { return has(k, std::strlen(k)); }
     bool has(const char *k, size_t len) const {
@@ -176,16 +190,17 @@ class JsonParser {
         }
     }
     void skip_string() { // at the opening quote
-        i_++;
-        while (true) {
-            const void *q = std::memchr(s_.data() + i_, '"', s_.size() - i_);
-            if (!q) fail("unterminated string");
-            const size_t at = (size_t)((const char *)q - s_.data());
-            size_t back = 0;
-            while (at - back > i_ && s_[at - back - 1] == '\\') back++;
-            i_ = at + 1;
-            if (back % 2 == 0) return; // the quote is not escaped
+        const char *p = s_.data() + i_ + 1, *const e = s_.data() + s_.size();
+        while (p < e) {
+            const char c = *p++;
+            if (c == '"') {
+                i_ = (size_t)(p - s_.data());
+                return;
+            }
+            if (c == '\\') p++; // whatever is escaped, it does not end the string
         }
+        i_ = s_.size();
+        fail("unterminated string");
     }
     // one entry of a Node's status.images, before it is parsed: can it name a wanted image?  The entry's text is searched for
     // the quoted name; an entry containing a backslash (an escape could spell the name differently) is kept to be safe.
@@ -202,25 +217,133 @@ class JsonParser {
         }
         return false;
     }
+    // The "items" of a List with many elements (a cluster dump): one cheap pass finds where each element starts and ends, then
+    // the elements are parsed by several threads, each with a parser of its own over its elements' text.  At the first '[' + ws.
+    // -> false (nothing consumed) when the list is small or one thread is asked for (CCHOST_THREADS=1).
+    bool parse_items_in_parallel(Value &v) {
+        unsigned threads = std::thread::hardware_concurrency();
+        if (const char *e = std::getenv("CCHOST_THREADS")) threads = (unsigned)std::atoi(e);
+        threads = std::min(threads, 32u);
+        size_t min_bytes = 8u << 20; // below this the threads cost more than they save (CCHOST_PARALLEL_MIN_BYTES: tests set 0)
+        if (const char *e = std::getenv("CCHOST_PARALLEL_MIN_BYTES")) min_bytes = (size_t)std::atoll(e);
+        if (threads < 2 || s_.size() - i_ < min_bytes) return false;
+        const size_t start = i_;
+        std::vector<std::pair<size_t, size_t>> spans;
+        while (true) {
+            skip_ws();
+            const size_t from = i_;
+            skip_value();
+            spans.emplace_back(from, i_);
+            skip_ws();
+            if (i_ < s_.size() && s_[i_] == ',') {
+                i_++;
+                continue;
+            }
+            if (i_ < s_.size() && s_[i_] == ']') {
+                i_++;
+                break;
+            }
+            fail("expected ',' or ']'");
+        }
+        if (spans.size() < 4 * threads) {
+            i_ = start;
+            return false;
+        }
+        const size_t end = i_;
+        v.a.resize(spans.size());
+        std::vector<std::string> errors(threads);
+        std::vector<std::thread> pool;
+        // contiguous blocks of roughly equal TEXT size (objects of a dump differ in size by kind: Nodes first, then Pods)
+        std::vector<size_t> cut(threads + 1, spans.size());
+        cut[0] = 0;
+        const size_t total = spans.back().second - spans.front().first;
+        for (size_t k = 0, t = 1; k < spans.size() && t < threads; k++)
+            if (spans[k].first - spans.front().first >= total * t / threads) cut[t++] = k;
+        for (unsigned t = 0; t < threads; t++)
+            pool.emplace_back([&, t] {
+                try {
+                    for (size_t k = cut[t]; k < cut[t + 1]; k++) {
+                        JsonParser p(s_.substr(spans[k].first, spans[k].second - spans[k].first), prune_, wanted_images_);
+                        v.a[k] = p.parse_value(Item);
+                    }
+                } catch (const std::exception &e) {
+                    errors[t] = e.what();
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (const auto &e : errors)
+            if (!e.empty()) throw std::runtime_error(e);
+        i_ = end;
+        return true;
+    }
+    // Skipping a container without building it is the floor of the pruned parse (and of the pass that finds the elements'
+    // boundaries for the parallel parse), so it works on 64-byte blocks: byte masks of quotes / backslashes / brackets, the
+    // in-string mask as the prefix parity of the quote mask, brackets counted outside strings.  A block that contains a backslash
+    // is walked byte by byte (escapes are rare outside a few long annotation strings).
+    void skip_container() { // at '{' or '['
+        const char *const base = s_.data(), *const e = base + s_.size();
+        const char *p = base + i_;
+        int depth = 0;
+        bool in_string = false;
+        auto bytewise = [&](const char *stop) -> bool { // -> true when the container closed (i_ set)
+            while (p < stop) {
+                const char c = *p++;
+                if (in_string) {
+                    if (c == '\\') p++; // (may step past `stop`: the escaped byte is skipped wherever it lies)
+                    else if (c == '"') in_string = false;
+                } else if (c == '"') in_string = true;
+                else if (c == '{' || c == '[') depth++;
+                else if ((c == '}' || c == ']') && --depth == 0) {
+                    i_ = (size_t)(p - base);
+                    return true;
+                }
+            }
+            return false;
+        };
+#if defined(__SSE2__)
+        const __m128i vq = _mm_set1_epi8('"'), vb = _mm_set1_epi8('\\'), vo = _mm_set1_epi8('{'), vc = _mm_set1_epi8('}'), v20 = _mm_set1_epi8(0x20);
+        while (e - p >= 64) {
+            uint64_t q = 0, bs = 0, op = 0, cl = 0;
+            for (int k = 0; k < 4; k++) {
+                const __m128i x = _mm_loadu_si128((const __m128i *)(p + 16 * k));
+                const __m128i y = _mm_or_si128(x, v20); // '[' -> '{', ']' -> '}' (no other byte maps onto them)
+                q |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vq)) << (16 * k);
+                bs |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vb)) << (16 * k);
+                op |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(y, vo)) << (16 * k);
+                cl |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(y, vc)) << (16 * k);
+            }
+            if (bs) {
+                if (bytewise(p + 64)) return;
+                continue;
+            }
+            uint64_t m = q; // bit i: an odd number of quotes in bytes 0..i
+            m ^= m << 1, m ^= m << 2, m ^= m << 4, m ^= m << 8, m ^= m << 16, m ^= m << 32;
+            if (in_string) m = ~m; // bit i: inside a string after byte i
+            in_string = (m >> 63) & 1;
+            op &= ~m, cl &= ~m;
+            if (!cl) depth += __builtin_popcountll(op);
+            else
+                for (uint64_t both = op | cl; both; both &= both - 1) {
+                    const int at = __builtin_ctzll(both);
+                    if ((op >> at) & 1) depth++;
+                    else if (--depth == 0) {
+                        i_ = (size_t)(p - base) + (size_t)at + 1;
+                        return;
+                    }
+                }
+            p += 64;
+        }
+#endif
+        if (bytewise(e)) return;
+        i_ = s_.size();
+        fail("unterminated container");
+    }
     void skip_value() { // no tree is built; brackets are balanced, their kinds are not cross-checked
         skip_ws();
         if (i_ >= s_.size()) fail("unexpected end");
-        char c = s_[i_];
+        const char c = s_[i_];
         if (c == '"') return skip_string();
-        if (c == '{' || c == '[') {
-            int depth = 0;
-            while (i_ < s_.size()) {
-                c = s_[i_];
-                if (c == '"') {
-                    skip_string();
-                    continue;
-                }
-                i_++;
-                if (c == '{' || c == '[') depth++;
-                else if ((c == '}' || c == ']') && --depth == 0) return;
-            }
-            fail("unterminated container");
-        }
+        if (c == '{' || c == '[') return skip_container();
         while (i_ < s_.size() && s_[i_] != ',' && s_[i_] != '}' && s_[i_] != ']' && s_[i_] != ' ' && s_[i_] != '\n' && s_[i_] != '\r' && s_[i_] != '\t') i_++;
     }
     [[noreturn]] void fail(const char *what) const { throw std::runtime_error("JSON: " + std::string(what) + " at offset " + std::to_string(i_)); }
@@ -317,6 +440,7 @@ class JsonParser {
             skip_ws();
             if (i_ < s_.size() && s_[i_] == ']') { i_++; return v; } // (not `return i_++, v`: a comma expression is no candidate for the implicit move and deep-copies v)
             const Ctx elem = ctx == Items ? Item : ctx == Containers ? Container : NoCtx;
+            if (ctx == Items && parse_items_in_parallel(v)) return v;
             while (true) {
                 if (ctx == Images && !image_entry_is_wanted()) skip_value();
                 else v.a.push_back(parse_value(elem));

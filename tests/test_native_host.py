@@ -1282,15 +1282,33 @@ def _decorate(obj, rng):
             c["livenessProbe"] = {"httpGet": {"path": "/healthz", "port": 8080}}
             c["command"], c["args"] = ["sh", "-c", tricky], ["--flag={}"]
             c["securityContext"] = {"capabilities": {"drop": ["ALL"]}}
+    # random junk of random shape and length in skipped places: the skipper works on 64-byte blocks, so strings, escapes and
+    # brackets must be met at every alignment, across block boundaries, and in blocks with and without a backslash
+    def junk(depth=0):
+        r = rng.random()
+        if depth > 3 or r < 0.35:
+            n = int(rng.integers(0, 150))
+            alphabet = ['a', 'b', ' ', '"', '\\', '{', '}', '[', ']', ',', ':', '\n', 'é', '\t', '/']
+            return "".join(rng.choice(alphabet, n, p=[.3, .2, .1, .06, .06, .04, .04, .04, .04, .03, .03, .02, .02, .01, .01]))
+        if r < 0.5:
+            return [None, True, -1.5e3, 0, int(rng.integers(0, 1 << 40))][int(rng.integers(0, 5))]
+        if r < 0.75:
+            return [junk(depth + 1) for _ in range(int(rng.integers(0, 5)))]
+        return {junk(9) or f"k{i}": junk(depth + 1) for i in range(int(rng.integers(0, 5)))}
+    md["managedFields"].append(junk())
+    st["junk"], st["moreJunk"] = junk(), junk()
+    if o.get("kind") != "Namespace":
+        md["annotations"]["junk"] = junk(9)
     if rng.random() < 0.5:  # member order as other producers emit it: kind after metadata
         o = {k: o[k] for k in sorted(o, key=lambda k: (k == "kind", k == "apiVersion"))}
     return o
 
 
+@pytest.mark.parametrize("seed", range(6))
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_pruned_parse_of_decorated_dumps_gives_the_same_snapshot(native, tmp_path, case):
+def test_pruned_parse_of_decorated_dumps_gives_the_same_snapshot(native, tmp_path, case, seed):
     nodes, pods, pod, exclude = CASES[case]()
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(seed)
     outs = []
     for name, deco in (("plain", False), ("decorated", True)):
         d = tmp_path / name
@@ -1299,10 +1317,17 @@ def test_pruned_parse_of_decorated_dumps_gives_the_same_snapshot(native, tmp_pat
         objs = [dict(o, kind=o.get("kind") or k) for k, lst in (("Node", nodes), ("Pod", pods), ("Namespace", ns)) for o in lst]
         if deco:
             objs = [_decorate(o, rng) for o in objs]
-        (d / "cluster.json").write_text(json.dumps({"kind": "List", "apiVersion": "v1", "metadata": {"resourceVersion": ""}, "items": objs}, indent=2 if deco else None))
+        text = json.dumps({"kind": "List", "apiVersion": "v1", "metadata": {"resourceVersion": ""}, "items": objs}, indent=2 if deco else None,
+                          ensure_ascii=bool(rng.integers(0, 2)))
+        assert json.loads(text)["items"] == objs
+        (d / "cluster.json").write_text(text)
         (d / "pod.json").write_text(json.dumps(pod))
         args = ["--podspec", str(d / "pod.json"), "--snapshot", str(d / "cluster.json"), "--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
         outs.append(_run(native, args))
+        if deco:  # ... and the same through the parallel parse of the List's items (off for small files unless asked for)
+            env = dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS=str(2 + seed % 3))
+            par = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
+            assert par.returncode == 0 and par.stdout == outs[-1], par.stderr
         # genpod reads Namespace annotations: they survive the pruning whatever the member order
         g = yaml.safe_load(_run(native, ["--genpod", "default", "--snapshot", str(d / "cluster.json")]))
         assert g["spec"]["nodeSelector"] == {"disk": "ssd"}
@@ -1314,5 +1339,14 @@ def test_pruned_parse_still_rejects_broken_json(native, tmp_path):
     for text in ('{"kind": "List", "items": [{"kind": "Node", "metadata": {"name": "n", "managedFields": [{"a": "unterminated}]}}]}',
                  '{"kind": "Node", "metadata": {"name": "n"}, "status": {"conditions": [1, 2'):
         (tmp_path / "c.json").write_text(text)
-        p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"], capture_output=True, text=True, timeout=30)
-        assert p.returncode != 0
+        for env in (None, dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS="2")):
+            p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"], capture_output=True, text=True,
+                               timeout=30, env=env)
+            assert p.returncode != 0
+    # an error inside an element must surface from the worker threads too
+    items = [{"kind": "Node", "metadata": {"name": f"n{i}"}, "status": {"allocatable": {"cpu": "1", "pods": "1"}}} for i in range(40)]
+    text = json.dumps({"kind": "List", "items": items}).replace('"n17"', '"n17" oops')
+    (tmp_path / "c.json").write_text(text)
+    p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"], capture_output=True, text=True,
+                       timeout=30, env=dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS="4"))
+    assert p.returncode != 0 and "cluster-capacity:" in p.stderr
