@@ -25,7 +25,7 @@ HEADER = os.path.join(ROOT, "cluster-capacity_amd", "csrc", "ccsim_kernels.h")
 WANTED = [("struct", "DevPod", 0), ("func", "refined_rcp", 0), ("struct", "NodeRcp", 0), ("func", "make_rcp", 0), ("func", "div_small_quotient", 0),
           ("func", "least_requested_score", 0), ("func", "balanced_exact", 0), ("func", "dynamic_score", 0), ("func", "div_magic", 0), ("func", "norm100", 0),
           ("func", "norm100", 1), ("struct", "NarrowPod", 0), ("func", "floor_ratio100", 0), ("func", "dynamic_score_narrow", 0), ("func", "static_score", 0),
-          ("func", "static_score", 1)]
+          ("func", "static_score", 1), ("func", "go_log", 0)]
 
 
 def _extract(text, kind, name, occurrence):
@@ -54,6 +54,7 @@ HARNESS = r"""
 extern "C" {
 int64_t ccref_least_allocated(const int64_t *requested, const int64_t *allocatable, const int64_t *weights, int n);
 int64_t ccref_balanced_allocation(const int64_t *requested, const int64_t *allocatable, int n);
+double ccref_go_log(double x);
 }
 #define __device__
 #define __forceinline__ inline
@@ -199,6 +200,17 @@ int main() {
         if (p.w_taint) want += (int64_t)(mt == 0 ? 100 : 100 - 100 * (int64_t)c / mt) * p.w_taint;
         if (p.w_aff) want += (int64_t)(ma == 0 ? 0 : 100 * (int64_t)a / ma) * p.w_aff;
         CHECK(static_score(p, c, a, img, mt, ma) == want, "static c=%u a=%u img=%u mt=%u ma=%u", c, a, img, mt, ma);
+    }
+    // (g) Go's math.Log as the device restates it (PodTopologySpread weights, scoring.go:294-296: log(size + 2)) against the oracle's
+    // restatement, bit for bit: every argument a cluster of up to 4M domains / nodes can produce, and random doubles
+    for (int64_t k = 2; k <= 4000002; k++, n_checked++) {
+        const double a = go_log((double)k), b = ccref_go_log((double)k);
+        CHECK(std::memcmp(&a, &b, 8) == 0 && std::fabs(a - std::log((double)k)) <= 4.5e-16 * a, "go_log(%lld)", (long long)k);
+    }
+    for (int it = 0; it < 2000000; it++, n_checked++) {
+        const double x = std::ldexp(1.0 + (double)rnd_below((int64_t)1 << 52) / 4503599627370496.0, (int)rnd_below(80) - 20);
+        const double a = go_log(x), b = ccref_go_log(x);
+        CHECK(std::memcmp(&a, &b, 8) == 0, "go_log(%a)", x);
     }
     std::printf("checked %ld failures %ld\n", n_checked, failures);
     return failures ? 1 : 0;
