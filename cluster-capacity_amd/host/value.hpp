@@ -1082,7 +1082,8 @@ inline std::vector<Value> parse_documents(std::string_view text, bool prune_clus
             std::vector<Value> one;
             one.push_back(p.parse_document()); // (moved: a braced list would copy the whole document)
             return one;
-        } catch (const std::exception &) { // a YAML document in flow style
+        } catch (const std::exception &) { // a YAML document in flow style?
+            if (text.size() > (32u << 20)) throw; // (not at this size: a broken multi-hundred-MB JSON dump should say where it is broken)
         }
     }
     YamlParser y{std::string(text)};
