@@ -126,7 +126,8 @@ def make_library_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Prof
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(device)
+    if torch.cuda.is_available():  # (absent only under the CPU tests, where an ABI recorder stands in for libccsim.so)
+        torch.cuda.set_device(device)
     world, rank = dist.get_world_size(), dist.get_rank()
     eng = capi.Engine(device=device, use_graph=False)
     eng.load(nodes_shard, pod, profile, global_offset=global_offset, n_global=n_global)

@@ -253,3 +253,31 @@ int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_repor
     out->n_code_unschedulable = e->rank == 0 ? 1 : 0;
     return 0;
 }
+
+/* ---- the rest of the ABI, so that the Python binding (capi.load binds EVERY declared symbol) can run on this library:
+ * entry points this stand-in has no use for answer -ENOSYS ---- */
+int ccsim_schedule_pod(ccsim_engine *e, int32_t pod_idx, ccsim_cycle *out) { (void)e, (void)pod_idx, (void)out; return -38; }
+int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) { (void)e, (void)out; return -38; }
+int ccsim_read_state(ccsim_engine *e, int64_t *a, int64_t *b, int64_t *c, int64_t *d, int32_t *f) { (void)e, (void)a, (void)b, (void)c, (void)d, (void)f; return -38; }
+int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, int32_t rank, void *s, void *r, int64_t log_cap) {
+    (void)e, (void)max_limit, (void)mode, (void)n_ranks, (void)rank, (void)s, (void)r, (void)log_cap;
+    return -38;
+}
+int ccsim_dist_scan(ccsim_engine *e) { (void)e; return -38; }
+int ccsim_dist_decide(ccsim_engine *e) { (void)e; return -38; }
+int ccsim_dist_poll(ccsim_engine *e, int32_t *done, int64_t *placed) { (void)e, (void)done, (void)placed; return -38; }
+int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out) { (void)e, (void)out; return -38; }
+/* one replicated table is announced, so that hosts which ask "are there tables?" go on to ccsim_dist_sync_tables */
+int ccsim_dist_table_count(ccsim_engine *e) { (void)e; return 1; }
+int ccsim_dist_table(ccsim_engine *e, int32_t idx, void **ptr, int64_t *len, int32_t *elem_bytes, int32_t *op) {
+    static int64_t dummy[1];
+    (void)e;
+    if (idx != 0) return -22;
+    *ptr = dummy, *len = 1, *elem_bytes = 8, *op = 0;
+    return 0;
+}
+int ccsim_dist_tables_done(ccsim_engine *e) { (void)e; return 0; }
+int ccsim_reset_state(ccsim_engine *e) { (void)e; return -38; }
+int ccsim_time_scan(ccsim_engine *e, int32_t a, int32_t b, int64_t *c, int64_t *d) { (void)e, (void)a, (void)b, (void)c, (void)d; return -38; }
+int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
+int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }

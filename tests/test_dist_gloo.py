@@ -82,3 +82,89 @@ def test_merge_logs():
     from cluster_capacity_amd import dist as ccdist
     a, b = np.array([3, -1, -1, 5], np.int32), np.array([-1, 9, 8, -1], np.int32)
     assert ccdist.merge_logs([a, b]).tolist() == [3, 9, 8, 5]
+
+
+# ---- the library-driven path (dist.make_library_runner -> ccsim_dist_comm_init / sync_tables / dist_run) over gloo --------------
+LIB_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["CC_ROOT"]); sys.path.insert(0, os.path.join(os.environ["CC_ROOT"], "tests"))
+import __graft_entry__ as ge; ge.load_package()
+import numpy as np, torch, torch.distributed as dist
+from cluster_capacity_amd import dist as ccdist, model as M
+import helpers as H
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(int(os.environ["CC_SEED"]))
+nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, int(os.environ["CC_N"])))
+pod.spread = H.random_spread(rng, nodes, n_constraints=2)
+pod.ipa = H.random_ipa(rng, nodes)
+n = nodes.n
+lo, hi = ccdist.shard_bounds(n, world, rank)
+runner = ccdist.make_library_runner(nodes.slice(lo, hi), ccdist.shard_pod(pod, lo, hi), prof, lo, n, device=rank)
+res = runner.run(max_limit=0, mode="sequential", want_log=True, log_cap=n)
+logs, counts = [None] * world, [None] * world
+dist.all_gather_object(logs, res.log.tolist())
+dist.all_gather_object(counts, res.per_node_count.tolist())
+runner.engine.close()
+if rank == 0:
+    merged = ccdist.merge_logs([np.array(l, np.int32) for l in logs])
+    ok = merged.tolist() == list(range(n)) and sum(counts, []) == [1] * n and res.placed == n
+    print("RESULT", json.dumps({"ok": bool(ok)}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,n,seed", [(2, 37, 1), (3, 50, 2)])
+def test_library_driven_runner_over_gloo(tmp_path, world, n, seed):
+    """The product's Python path for N > 1 with the loop inside the library: shard bounds, shard_pod, the unique id travelling
+    through torch.distributed, comm_init / sync_tables / dist_run on every rank, the log merge.  tests/abi_recorder.c stands in
+    for libccsim.so (CCSIM_LIB): each rank's record must hold exactly its slice of what the unsharded binding marshals."""
+    import ctypes as C
+    import json
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from cluster_capacity_amd import capi
+    from test_native_host import _slice_nodes, _slice_pod
+
+    rec = tmp_path / "libabi_recorder.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", str(rec), os.path.join(ROOT, "tests", "abi_recorder.c")])
+    script = tmp_path / "worker.py"
+    script.write_text(LIB_WORKER)
+    env = dict(os.environ, CC_ROOT=ROOT, CC_N=str(n), CC_SEED=str(seed), OMP_NUM_THREADS="1", CCSIM_LIB=str(rec), CCSIM_RECORD=str(tmp_path / "shard.json"),
+               CCSIM_RECORD_PER_DEVICE="1")
+    port = 31500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line and '"ok": true' in line[0], (out.stdout[-1000:], out.stderr[-1000:])
+    # the unsharded marshalling of the same case, recorded through the same library
+    rng = np.random.default_rng(seed)
+    nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, n))
+    pod.spread = H.random_spread(rng, nodes, n_constraints=2)
+    pod.ipa = H.random_ipa(rng, nodes)
+    lib = C.CDLL(str(rec))
+    os.environ["CCSIM_RECORD"] = str(tmp_path / "plain.json")
+    os.environ.pop("CCSIM_RECORD_PER_DEVICE", None)
+    try:
+        cfg = capi.CConfig()
+        cfg.abi_version = capi.ABI_VERSION
+        h = C.c_void_p()
+        assert lib.ccsim_create(C.byref(cfg), C.byref(h)) == 0
+        keep = []
+        assert lib.ccsim_load_nodes(h, C.byref(capi.marshal_nodes(nodes, keep))) == 0
+        assert lib.ccsim_set_profile(h, C.byref(capi.marshal_profile(prof))) == 0
+        assert lib.ccsim_set_pod(h, C.byref(capi.marshal_pod(pod, keep))) == 0
+        lib.ccsim_destroy(h)
+    finally:
+        os.environ.pop("CCSIM_RECORD")
+    plain = json.load(open(tmp_path / "plain.json"))
+    per = -(-n // world)
+    for g in range(world):
+        r = json.load(open(f"{tmp_path}/shard.json.{g}"))
+        lo, hi = min(n, g * per), min(n, g * per + per)
+        assert r["nodes"] == _slice_nodes(plain["nodes"], lo, hi) and r["pod"] == _slice_pod(plain["pod"], lo, hi) and r["profile"] == plain["profile"], g
+        assert r["dist_comm_init"] == {"n_ranks": world, "rank": g, "id_ok": 1} and r["dist_sync_tables"] == world
+        assert r["dist_run"]["mode"] == 0 and r["dist_run"]["log_cap"] == n
