@@ -15,6 +15,8 @@
 #pragma once
 #include <algorithm>
 #include <map>
+#include <thread>
+#include <unordered_map>
 #include <set>
 #include <string>
 #include <vector>
@@ -137,19 +139,54 @@ inline std::string zone_key(const Value &labels) { // component-helpers/node/top
 // node_tree.go:119-143: nodes arrive sorted by name (the fake tracker lists lexicographically,
 // client-go/testing/fixture.go:847-855), zones in first-seen order, then round robin across zones
 inline std::vector<const Value *> canonical_node_order(std::vector<const Value *> nodes) {
-    std::stable_sort(nodes.begin(), nodes.end(), [](const Value *a, const Value *b) { return (*a)["metadata"]["name"].text() < (*b)["metadata"]["name"].text(); });
-    std::vector<std::string> order;
-    std::map<std::string, std::vector<const Value *>> zones;
+    // (sorted through pointers to the name strings: a comparator that looks the name up and copies it, as the first version did,
+    // costs more than the rest of the node pass at 100k nodes)
+    static const std::string no_name;
+    std::vector<std::pair<const std::string *, const Value *>> by_name;
+    by_name.reserve(nodes.size());
     for (const Value *n : nodes) {
-        const std::string z = zone_key((*n)["metadata"]["labels"]);
-        if (!zones.count(z)) order.push_back(z);
-        zones[z].push_back(n);
+        const Value &nm = (*n)["metadata"]["name"];
+        by_name.emplace_back(nm.t == Value::Str || nm.t == Value::Num ? &nm.s : &no_name, n);
+    }
+    std::stable_sort(by_name.begin(), by_name.end(), [](const auto &a, const auto &b) { return *a.first < *b.first; });
+    std::unordered_map<std::string, size_t> zone_of; // zone key -> position in first-seen order
+    std::vector<std::vector<const Value *>> zones;
+    for (const auto &kv : by_name) {
+        const auto at = zone_of.emplace(zone_key((*kv.second)["metadata"]["labels"]), zones.size());
+        if (at.second) zones.emplace_back();
+        zones[at.first->second].push_back(kv.second);
     }
     std::vector<const Value *> out;
+    out.reserve(nodes.size());
     for (size_t i = 0; out.size() < nodes.size(); i++)
-        for (const auto &z : order)
-            if (i < zones[z].size()) out.push_back(zones[z][i]);
+        for (const auto &z : zones)
+            if (i < z.size()) out.push_back(z[i]);
     return out;
+}
+
+// fn(k) for k in [0, n) on several threads (CCHOST_THREADS, default one per core, at most 32; small n: the calling thread).  An
+// exception ends the thread's chunk; the one from the smallest k -- the one a serial loop would have raised -- is rethrown.
+template <class Fn> inline void parallel_for(size_t n, Fn fn) {
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("CCHOST_THREADS")) threads = (unsigned)std::atoi(e);
+    threads = n < 4096 ? 1u : std::max(1u, std::min(threads, 32u));
+    std::vector<std::pair<size_t, std::string>> errors(threads, {n, ""});
+    auto work = [&](unsigned t) {
+        for (size_t k = n * t / threads; k < n * (t + 1) / threads; k++) {
+            try {
+                fn(k);
+            } catch (const std::exception &e) {
+                errors[t] = {k, e.what()};
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    const auto first = std::min_element(errors.begin(), errors.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    if (first->first < n) throw std::runtime_error(first->second);
 }
 
 // toleration.go:38-57 ToleratesTaint
@@ -445,7 +482,8 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         if (std::find(exclude_nodes.begin(), exclude_nodes.end(), n["metadata"]["name"].text()) == exclude_nodes.end()) kept.push_back(&n);
     const std::vector<const Value *> nodes = canonical_node_order(kept);
     const size_t N = nodes.size();
-    std::map<std::string, size_t> index;
+    std::unordered_map<std::string, size_t> index; // node name -> position (hundreds of thousands of pod -> node lookups)
+    index.reserve(nodes.size() * 2);
     for (size_t i = 0; i < N; i++) {
         S.names.push_back((*nodes[i])["metadata"]["name"].text());
         index[S.names.back()] = i;
@@ -472,22 +510,45 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     S.alloc.assign(R, std::vector<int64_t>(N, 0));
     S.req.assign(R, std::vector<int64_t>(N, 0));
     S.alloc_pods.assign(N, 0), S.pod_count.assign(N, 0), S.nz_mcpu.assign(N, 0), S.nz_mem.assign(N, 0);
-    for (size_t i = 0; i < N; i++) {
+    parallel_for(N, [&](size_t i) {
         const Value &a = (*nodes[i])["status"]["allocatable"];
         for (size_t c = 0; c < R; c++) S.alloc[c][i] = res_of(a, S.res_names[c]);
         S.alloc_pods[i] = a.has("pods") ? (int32_t)quantity_value(a["pods"].text()) : 0;
-    }
+    });
     std::vector<const Value *> live; // non-terminal pods bound to a kept node (simulator.go:193-200)
     std::vector<size_t> live_node;
-    for (const auto &p : pod_objs) {
-        const std::string phase = p["status"]["phase"].text();
-        const std::string node = p["spec"]["nodeName"].text();
-        if (phase == "Succeeded" || phase == "Failed" || !index.count(node)) continue;
-        const size_t i = index[node];
-        live.push_back(&p), live_node.push_back(i);
-        const PodRequests r = pod_requests(p["spec"], S.res_names);
-        for (size_t c = 0; c < R; c++) S.req[c][i] += r.req[c];
-        S.nz_mcpu[i] += r.nz_cpu, S.nz_mem[i] += r.nz_mem, S.pod_count[i] += 1;
+    std::vector<int64_t> live_prio; // spec.priority of the live pods (who is a victim depends on the template: DefaultPreemption)
+    bool live_has_terms = false;    // some live pod carries inter-pod (anti)affinity terms
+    {
+        // Walking every pod's object tree (phase, node name, the containers' request quantities) is memory-latency bound and
+        // independent per pod: it runs on several threads into flat per-pod records; folding the records into the node columns
+        // (and the `live` list, in pod order) is a cheap serial pass, so the result does not depend on the thread count.
+        const size_t P = pod_objs.size(), W = R + 2;
+        std::vector<int64_t> rec(P * W);
+        std::vector<int64_t> pod_node(P, -1), prio(P, 0);
+        std::vector<uint8_t> terms(P, 0);
+        parallel_for(P, [&](size_t k) {
+            const Value &p = pod_objs[k];
+            const std::string phase = p["status"]["phase"].text();
+            if (phase == "Succeeded" || phase == "Failed") return;
+            const auto at = index.find(p["spec"]["nodeName"].text());
+            if (at == index.end()) return;
+            const PodRequests r = pod_requests(p["spec"], S.res_names);
+            for (size_t c = 0; c < R; c++) rec[k * W + c] = r.req[c];
+            rec[k * W + R] = r.nz_cpu, rec[k * W + R + 1] = r.nz_mem;
+            prio[k] = p["spec"]["priority"].as_int(0); // corev1helpers.PodPriority
+            const Value &aff = p["spec"]["affinity"];
+            terms[k] = aff["podAffinity"].truthy() || aff["podAntiAffinity"].truthy();
+            pod_node[k] = (int64_t)at->second;
+        });
+        for (size_t k = 0; k < P; k++) {
+            if (pod_node[k] < 0) continue;
+            const size_t i = (size_t)pod_node[k];
+            live.push_back(&pod_objs[k]), live_node.push_back(i);
+            live_prio.push_back(prio[k]), live_has_terms = live_has_terms || terms[k];
+            for (size_t c = 0; c < R; c++) S.req[c][i] += rec[k * W + c];
+            S.nz_mcpu[i] += rec[k * W + R], S.nz_mem[i] += rec[k * W + R + 1], S.pod_count[i] += 1;
+        }
     }
 
     // taints -> distinct taint sets (per node); what a template's tolerations make of each set is the template's business
@@ -587,7 +648,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         s.preempt_never = spec["preemptionPolicy"].text() == "Never";
         std::vector<uint8_t> is_victim(live.size(), 0);
         bool any_victim = false;
-        for (size_t j = 0; j < live.size(); j++) is_victim[j] = (*live[j])["spec"]["priority"].as_int(0) < s.priority, any_victim = any_victim || is_victim[j];
+        for (size_t j = 0; j < live.size(); j++) is_victim[j] = live_prio[j] < s.priority, any_victim = any_victim || is_victim[j];
         if (any_victim) {
             s.victim_count.assign(N, 0);
             s.victim_req.assign(S.res_names.size(), std::vector<int64_t>(N, 0));
@@ -614,8 +675,12 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         std::vector<std::string> wanted;
         for (const char *list : {"initContainers", "containers"})
             for (const auto &c : spec[list].items()) wanted.push_back(normalized_image_name(c["image"].text()));
-        std::vector<size_t> by_name(N);
-        for (size_t i = 0; i < N; i++) by_name[i] = i;
+        bool present = false; // no node lists an image of the template (the usual case): nothing to sort, nothing to score
+        for (size_t i = 0; i < N && !present; i++)
+            for (const auto &img : (*nodes[i])["status"]["images"].items())
+                for (const auto &nm : img["names"].items()) present = present || (nm.t == Value::Str && std::find(wanted.begin(), wanted.end(), nm.s) != wanted.end());
+        std::vector<size_t> by_name(present ? N : 0);
+        for (size_t i = 0; i < by_name.size(); i++) by_name[i] = i;
         std::sort(by_name.begin(), by_name.end(), [&](size_t a, size_t b) { return S.names[a] < S.names[b]; });
         std::map<std::string, int64_t> size;
         std::map<std::string, std::set<size_t>> holders;
@@ -699,9 +764,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     const Value &pa = spec["affinity"]["podAffinity"], &paa = spec["affinity"]["podAntiAffinity"];
     const Value &r_aff = pa["requiredDuringSchedulingIgnoredDuringExecution"], &r_anti = paa["requiredDuringSchedulingIgnoredDuringExecution"];
     const Value &p_aff = pa["preferredDuringSchedulingIgnoredDuringExecution"], &p_anti = paa["preferredDuringSchedulingIgnoredDuringExecution"];
-    bool others_have_terms = false;
-    for (const Value *p : live)
-        if ((*p)["spec"]["affinity"]["podAffinity"].truthy() || (*p)["spec"]["affinity"]["podAntiAffinity"].truthy()) others_have_terms = true;
+    const bool others_have_terms = live_has_terms;
     if (r_aff.truthy() || r_anti.truthy() || p_aff.truthy() || p_anti.truthy() || others_have_terms) {
         std::vector<std::string> keys;
         auto kidx = [&](const std::string &k) {

@@ -89,6 +89,6 @@ with tempfile.TemporaryDirectory() as d:
     ms = [float(l.split()[-2]) for l in phases.splitlines() if l.startswith("[timing]")]
     before_engine = (ms[0] + ms[1]) / 1e3  # what the CLI does before ccsim_load_nodes; the dump is this script's way of stopping there
     print(f"{N} Nodes + {P} Pods{' (kubectl-realistic objects)' if REAL else ''}, {size:.0f} MB of JSON: read + parse + intern + integer snapshot in "
-          f"{before_engine:.2f} s = {size / before_engine:.0f} MB/s (process incl. the snapshot dump: {best:.2f} s; {os.cpu_count()} host cores: the List's items are "
-          f"parsed by up to that many threads, the rest is one thread)")
+          f"{before_engine:.2f} s = {size / before_engine:.0f} MB/s (process incl. the snapshot dump: {best:.2f} s; {os.cpu_count()} host cores: the List's items, the per-pod and the per-node walks run on up to "
+          f"that many threads)")
     print(phases, end="")
