@@ -169,7 +169,9 @@ inline std::vector<const Value *> canonical_node_order(std::vector<const Value *
 template <class Fn> inline void parallel_for(size_t n, Fn fn) {
     unsigned threads = std::thread::hardware_concurrency();
     if (const char *e = std::getenv("CCHOST_THREADS")) threads = (unsigned)std::atoi(e);
-    threads = n < 4096 ? 1u : std::max(1u, std::min(threads, 32u));
+    size_t min_items = 4096; // (CCHOST_PARALLEL_MIN_ITEMS: tests set 0 to run small inputs through the threads)
+    if (const char *e = std::getenv("CCHOST_PARALLEL_MIN_ITEMS")) min_items = (size_t)std::atoll(e);
+    threads = n < min_items || n == 0 ? 1u : std::max(1u, std::min(threads, 32u));
     std::vector<std::pair<size_t, std::string>> errors(threads, {n, ""});
     auto work = [&](unsigned t) {
         for (size_t k = n * t / threads; k < n * (t + 1) / threads; k++) {

@@ -782,7 +782,9 @@ def test_native_ingest_random_differential(native, tmp_path, seed):
     nodes, pods, pod, exclude = _random_objects(rng)
     podspec, snaps = _write(tmp_path, "json" if seed % 2 else "yaml", nodes, pods, pod)
     args = ["--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
-    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=60)
+    # every third case through the host's worker threads (parallel parse of the List's items, parallel per-pod / per-node walks)
+    env = dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_PARALLEL_MIN_ITEMS="0", CCHOST_THREADS=str(2 + seed % 4)) if seed % 3 == 0 else None
+    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=60, env=env)
     try:
         no, po, ns = cli.load_all(snaps)
         ref = py_dump(ingest.build_snapshot(no, po, cli.parse_pod_spec(podspec), exclude, namespace_objs=ns))
@@ -1325,7 +1327,7 @@ def test_pruned_parse_of_decorated_dumps_gives_the_same_snapshot(native, tmp_pat
         args = ["--podspec", str(d / "pod.json"), "--snapshot", str(d / "cluster.json"), "--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
         outs.append(_run(native, args))
         if deco:  # ... and the same through the parallel parse of the List's items (off for small files unless asked for)
-            env = dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS=str(2 + seed % 3))
+            env = dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_PARALLEL_MIN_ITEMS="0", CCHOST_THREADS=str(2 + seed % 3))
             par = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
             assert par.returncode == 0 and par.stdout == outs[-1], par.stderr
         # genpod reads Namespace annotations: they survive the pruning whatever the member order
