@@ -52,7 +52,7 @@ def build_all(force: bool = False, verbose: bool = False) -> str:
 
 HOST = os.path.join(HERE, "host")
 HOST_SOURCES = ["main.cpp"]
-HOST_DEPS = ["value.hpp", "quantity.hpp", "snapshot.hpp", "report.hpp", "profile.hpp", "engine.hpp", "cluster_capacity.hpp"]
+HOST_DEPS = sorted(f for f in os.listdir(HOST) if f.endswith(".hpp"))  # every header of the host: a stale binary is a silent lie
 
 
 def host_path() -> str:

@@ -123,8 +123,8 @@ def build_review(pod, snap: ingest.Snapshot, result: M.RunResult, max_limit: int
         mixed = len({(p.preempt.priority if p.preempt else 0) for p in snap.pods}) > 1  # clones of one template below another's priority
         outcome = preemption.dry_run(snap.nodes, snap.pods[failing], result.per_node_count, result.n_code_unschedulable, filter_mask, P, mixed)
         if outcome.kind == "unmodelled":
-            print("warning: nodes hold pods of lower priority than the simulated pod and its filters are topology-coupled (or several "
-                  "templates run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims",
+            print("warning: a lower-priority pod takes part in a topology-coupled filter of the simulated pod (or several templates "
+                  "run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims",
                   file=sys.stderr)
     stop = R.stop_reason(result, len(snap.names), max_limit, taint_reasons=snap.taint_reasons_all[failing], scalar_names=snap.scalar_names,
                          preemption=outcome)

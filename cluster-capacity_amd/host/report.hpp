@@ -118,8 +118,8 @@ inline std::string terminal_stop_reason(const Snapshot &snap, const RunResult &r
     for (size_t t = 1; t < P; t++) mixed = mixed || snap.side(t).priority != snap.side(0).priority;
     const PreemptionOutcome pre = preemption_dry_run(snap, snap.side(failing), r.per_node_count, r.n_code_unschedulable, filter_mask, P, mixed);
     if (warn && pre.kind == PreemptionOutcome::Unmodelled)
-        std::fprintf(stderr, "warning: nodes hold pods of lower priority than the simulated pod and its filters are topology-coupled (or several "
-                             "templates run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims\n");
+        std::fprintf(stderr, "warning: a lower-priority pod takes part in a topology-coupled filter of the simulated pod (or several templates "
+                             "run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims\n");
     return stop_reason(r, (int64_t)snap.n(), max_limit, snap.side(failing).taint_reasons, snap.scalar_names, &pre);
 }
 

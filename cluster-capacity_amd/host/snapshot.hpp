@@ -378,6 +378,9 @@ struct PodSide {
     std::vector<int32_t> victim_count;            // per node; empty = no node holds a victim
     std::vector<std::vector<int64_t>> victim_req; // per resource column, per node
     std::vector<uint8_t> ports_conflict_rest;     // a REMAINING pod of the node holds a conflicting host port; empty = not evaluated
+    // a victim of the node takes part in the PreFilter state of a topology-coupled filter of the template (removing it would
+    // change that state: not modelled by the dry run); empty = no such node
+    std::vector<uint8_t> victim_interacts;
 };
 
 // The snapshot: node columns shared by every template + the first template (as base class: the single-template code reads
@@ -631,6 +634,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         for (size_t i = 0; i < N; i++) s.included[i] = node_matches_required(i);
     }
 
+    // (DefaultPreemption dry run) which live pods are victims of this template, and on which nodes a victim takes part in the
+    // PreFilter state of one of the template's topology-coupled FILTERS: it matches a hard spread selector or a required
+    // (anti)affinity term, or carries an anti-affinity term matching the template
+    std::vector<uint8_t> is_victim(live.size(), 0), interacts(N, 0);
     // NodePorts: which nodes' existing pods already hold one of the pod's host ports
     {
         const std::vector<HostPort> want = host_ports(spec);
@@ -648,7 +655,6 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         // (corev1helpers.PodPriority: spec.priority, 0 when unset)
         s.priority = spec["priority"].as_int(0);
         s.preempt_never = spec["preemptionPolicy"].text() == "Never";
-        std::vector<uint8_t> is_victim(live.size(), 0);
         bool any_victim = false;
         for (size_t j = 0; j < live.size(); j++) is_victim[j] = live_prio[j] < s.priority, any_victim = any_victim || is_victim[j];
         if (any_victim) {
@@ -736,8 +742,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         std::vector<int32_t> existing(N, 0);
         for (size_t p = 0; p < live.size(); p++) { // countPodsMatchSelector (common.go:144-159)
             const Value &pod = *live[p];
-            if (!selector_empty(sel) && ns_of(pod) == sim_ns && !pod["metadata"]["deletionTimestamp"].truthy() && label_selector_matches(sel, pod["metadata"]["labels"]))
+            if (!selector_empty(sel) && ns_of(pod) == sim_ns && !pod["metadata"]["deletionTimestamp"].truthy() && label_selector_matches(sel, pod["metadata"]["labels"])) {
                 existing[live_node[p]] += 1;
+                if (is_victim[p] && (c["whenUnsatisfiable"].truthy() ? c["whenUnsatisfiable"].text() : "DoNotSchedule") == "DoNotSchedule") interacts[live_node[p]] = 1;
+            }
         }
         // matchNodeInclusionPolicies (common.go:107-122): required node affinity / selector (default Honor) and the
         // NoSchedule / NoExecute taints the pod does not tolerate (default Ignore)
@@ -805,16 +813,17 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             if (r_aff.truthy()) {
                 bool all = true;
                 for (const auto &t : r_aff.items()) all = all && tm(t, sim_ns, p_ns, pl);
-                if (all) aff_existing[i] += 1;
+                if (all) aff_existing[i] += 1, interacts[i] |= is_victim[pi];
             }
             for (size_t t = 0; t < r_anti.items().size(); t++)
-                if (tm(r_anti.items()[t], sim_ns, p_ns, pl)) anti_existing[t][i] += 1;
+                if (tm(r_anti.items()[t], sim_ns, p_ns, pl)) anti_existing[t][i] += 1, interacts[i] |= is_victim[pi];
             const Value &e_aff = p["spec"]["affinity"]["podAffinity"], &e_anti = p["spec"]["affinity"]["podAntiAffinity"];
             for (const auto &t : e_anti["requiredDuringSchedulingIgnoredDuringExecution"].items())
                 if (tm(t, p_ns, sim_ns, sim_labels)) {
                     auto &v = exist_anti[kidx(t["topologyKey"].text())];
                     if (v.empty()) v.assign(N, 0);
                     v[i] += 1;
+                    interacts[i] |= is_victim[pi];
                 }
             // scoring.go:81-125 processExistingPod
             for (const auto &wt : p_aff.items())
@@ -867,6 +876,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         s.has_ipa = true;
     }
     if ((int)s.spread.size() > CCSIM_MAX_TSC) throw Unsupported("too many topology spread constraints");
+    if (std::find(interacts.begin(), interacts.end(), (uint8_t)1) != interacts.end()) s.victim_interacts = interacts;
     }; // template_side
 
     template_side(sim_pods[0], S);
@@ -967,6 +977,7 @@ inline Value pod_side_json(const PodSide &s) {
     for (auto &v : s.victim_req) vr.a.push_back(int_array(v));
     pre.set("victim_req", vr);
     pre.set("ports_conflict_rest", s.ports_conflict_rest.empty() ? Value() : int_array(s.ports_conflict_rest));
+    pre.set("victim_interacts", s.victim_interacts.empty() ? Value() : int_array(s.victim_interacts));
     p.set("preempt", pre);
     return p;
 }

@@ -528,6 +528,10 @@ def _template_side(ctx: dict, sim_pod: dict):
     prio = int(spec.get("priority") or 0)
     pre = M.PreemptionSide(priority=prio, never=spec.get("preemptionPolicy") == "Never")
     victims = [p for p in live if int(p["spec"].get("priority") or 0) < prio]
+    victim_ids = {id(p) for p in victims}
+    # nodes with a victim whose removal would change the PreFilter state of a topology-coupled FILTER of this template (it
+    # matches a hard spread selector or a required (anti)affinity term, or carries an anti-affinity term matching the template)
+    interacts = np.zeros(N, np.uint8)
     if victims:
         pre.victim_count = np.zeros(N, np.int32)
         pre.victim_req = [np.zeros(N, np.int64) for _ in res_names]
@@ -569,9 +573,12 @@ def _template_side(ctx: dict, sim_pod: dict):
             return (not selector_empty(sel) and (p["metadata"].get("namespace") or "default") == sim_ns
                     and not p["metadata"].get("deletionTimestamp") and label_selector_matches(sel, p["metadata"].get("labels") or {}))
         existing = np.zeros(N, np.int32)
+        is_hard = (c.get("whenUnsatisfiable") or "DoNotSchedule") == "DoNotSchedule"
         for p in live:
             if matches(p):
                 existing[index[p["spec"]["nodeName"]]] += 1
+                if is_hard and id(p) in victim_ids:
+                    interacts[index[p["spec"]["nodeName"]]] = 1
         # matchNodeInclusionPolicies (common.go:107-122): required node affinity / selector (default Honor) and the
         # NoSchedule / NoExecute taints the pod does not tolerate (default Ignore)
         honor_aff = (c.get("nodeAffinityPolicy") or "Honor") == "Honor"
@@ -627,16 +634,20 @@ def _template_side(ctx: dict, sim_pod: dict):
         for p in live:
             i = index[p["spec"]["nodeName"]]
             p_ns = p["metadata"].get("namespace") or "default"
+            vic = id(p) in victim_ids
             if r_aff and all(tm(t, sim_ns, p) for t in r_aff):
                 aff_existing[i] += 1
+                interacts[i] |= vic
             for t_i, t in enumerate(r_anti):
                 if tm(t, sim_ns, p):
                     anti_existing[t_i][i] += 1
+                    interacts[i] |= vic
             e_aff = ((p["spec"].get("affinity") or {}).get("podAffinity") or {})
             e_anti = ((p["spec"].get("affinity") or {}).get("podAntiAffinity") or {})
             for t in e_anti.get("requiredDuringSchedulingIgnoredDuringExecution") or []:
                 if tm(t, p_ns, sim_as_pod):
                     exist_anti.setdefault(kidx(t["topologyKey"]), np.zeros(N, np.int32))[i] += 1
+                    interacts[i] |= vic
             # scoring.go:81-125 processExistingPod
             for wt in p_aff:
                 if tm(wt["podAffinityTerm"], sim_ns, p):
@@ -680,4 +691,5 @@ def _template_side(ctx: dict, sim_pod: dict):
         ipa.score_existing = [score_existing.get(k) for k in range(len(keys))]
         ipa.score_self, ipa.self_entries, ipa.entries_existing = score_self, self_entries, entries
         pod.ipa = ipa
+    pre.victim_interacts = interacts if interacts.any() else None
     return pod, reasons

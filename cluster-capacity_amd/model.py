@@ -186,6 +186,10 @@ class PreemptionSide:
     victim_req: List[np.ndarray] = field(default_factory=list)  # per resource column int64[n]: what the victims request
     # NodePorts with the victims gone: does a REMAINING existing pod of the node hold a conflicting host port (uint8[n])
     ports_conflict_rest: Optional[np.ndarray] = None
+    # uint8[n]: a victim of the node takes part in the PreFilter state of one of the template's topology-coupled FILTERS (matches a
+    # hard spread selector / a required (anti)affinity term, or carries an anti-affinity term that matches the template): removing
+    # it would change that state (RunPreFilterExtensionRemovePod) -- such nodes are not modelled by the dry run.  None = no such node
+    victim_interacts: Optional[np.ndarray] = None
 
 
 @dataclass

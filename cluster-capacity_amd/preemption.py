@@ -19,10 +19,14 @@ and the candidate cap of the dry run (default_preemption.go:186-205) do not matt
 the tail is empty, with none every potential node was visited.
 
 Clones have the template's priority, so only pods of the snapshot can be victims (ingest: PreemptionSide).  Removing a victim
-changes the node's Requested, pod count and used host ports; with topology-coupled FILTERS in play (hard spread constraints,
-required inter-pod (anti)affinity, existing pods' anti-affinity) it would also change the plugins' PreFilter state
-(RunPreFilterExtensionRemovePod) -- that case is not modelled: kind = "unmodelled", the caller says so and keeps the
-no-victims form of the message.
+changes the node's Requested, pod count and used host ports.  With topology-coupled FILTERS in play (hard spread constraints,
+required inter-pod (anti)affinity, existing pods' anti-affinity) the second Filter run also evaluates those plugins against the
+cycle's PreFilter state, which the removal changes only through victims that take part in it (RunPreFilterExtensionRemovePod:
+the victim matches a hard spread selector or a required (anti)affinity term of the template, or carries an anti-affinity term
+matching it).  The usual victim -- a placeholder pod with labels of its own -- does not: then the state is the terminal cycle's,
+rebuilt here from the snapshot and the clone counts (CoupledState below: podtopologyspread/filtering.go:235-356,
+interpodaffinity/filtering.go:204-432, as oracle/ccref.c states them), and the dry run is exact.  A potential node whose victims
+DO take part is not modelled: kind = "unmodelled", the caller says so and keeps the no-victims form of the message.
 """
 from __future__ import annotations
 
@@ -67,13 +71,94 @@ def static_ok(nodes: M.NodesSoA, pod: M.PodSpec, idx: np.ndarray, filter_mask: i
     return ok
 
 
-def _coupled_filters(pod: M.PodSpec, filter_mask: int) -> bool:
-    if filter_mask & M.F_TOPOLOGYSPREAD and any(c.hard for c in pod.spread):
-        return True
-    a = pod.ipa
-    if filter_mask & M.F_INTERPODAFFINITY and a is not None and (a.aff_keys or a.anti_keys or any(x is not None for x in a.exist_anti)):
-        return True
-    return False
+MAXINT32 = 2147483647
+
+
+class CoupledState:
+    """The PreFilter state of PodTopologySpread (hard constraints) and InterPodAffinity at the terminal cycle: per-domain tables over
+    ALL nodes from the snapshot's per-node counts and the clones per node (a clone is an existing pod of the next cycle)."""
+
+    def __init__(self, nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, filter_mask: int):
+        self.nodes, self.pod = nodes, pod
+        n = nodes.n
+        clones = np.asarray(per_node_count, np.int64)[:n]
+        self.hard = [c for c in pod.spread if c.hard] if filter_mask & M.F_TOPOLOGYSPREAD else []
+        hard_keys = np.ones(n, bool)
+        for c in self.hard:
+            hard_keys &= nodes.label_cols[c.col] != 0
+        self.match, self.min_eff = [], []
+        for c in self.hard:  # pts_prefilter: TpValueToMatchNum over the counted nodes, the global minimum (0 below minDomains)
+            dom = nodes.label_cols[c.col].astype(np.int64)
+            counted = hard_keys & (np.ones(n, bool) if c.node_included is None else c.node_included != 0)
+            val = (np.zeros(n, np.int64) if c.node_match_count is None else c.node_match_count.astype(np.int64)) + (clones if c.self_match else 0)
+            size = int(dom.max()) + 1 if n else 1
+            tab = np.bincount(dom[counted], weights=val[counted], minlength=size).astype(np.int64)
+            present = np.bincount(dom[counted], minlength=size) > 0
+            self.match.append(tab)
+            mn = int(tab[present].min()) if present.any() else MAXINT32
+            self.min_eff.append(0 if int(present.sum()) < c.min_domains else mn)
+        a = self.ipa = pod.ipa if (filter_mask & M.F_INTERPODAFFINITY) else None
+        self.ipa_active = False
+        if a is not None:  # ipa_build: the count maps per topology key
+            K = len(a.key_cols)
+            doms = [nodes.label_cols[col].astype(np.int64) for col in a.key_cols]
+            size = [int(d.max()) + 1 if n else 1 for d in doms]
+            z = np.zeros(n, np.int64)
+            self.aff = [np.zeros(size[k], np.int64) for k in range(K)]
+            self.anti = [np.zeros(size[k], np.int64) for k in range(K)]
+            self.exist = [np.zeros(size[k], np.int64) for k in range(K)]
+            am = (z if a.aff_existing is None else a.aff_existing.astype(np.int64)) + (clones if a.self_aff else 0)
+            self.aff_total = 0
+            for k in a.aff_keys:
+                has = doms[k] != 0
+                self.aff[k] += np.bincount(doms[k][has], weights=am[has], minlength=size[k]).astype(np.int64)
+                self.aff_total += int(am[has].sum())
+            for t, k in enumerate(a.anti_keys):
+                m = (z if a.anti_existing[t] is None else a.anti_existing[t].astype(np.int64)) + (clones if a.anti_self[t] else 0)
+                has = doms[k] != 0
+                self.anti[k] += np.bincount(doms[k][has], weights=m[has], minlength=size[k]).astype(np.int64)
+            self.exist_total = 0
+            for k in range(K):
+                m = (z if a.exist_anti[k] is None else a.exist_anti[k].astype(np.int64)) + clones * sum(1 for t, kk in enumerate(a.anti_keys) if kk == k and a.anti_self[t])
+                has = doms[k] != 0
+                self.exist[k] += np.bincount(doms[k][has], weights=m[has], minlength=size[k]).astype(np.int64)
+                self.exist_total += int(m[has].sum())
+            self.doms = doms
+            self.ipa_active = not (self.exist_total == 0 and not a.aff_keys and not a.anti_keys)
+
+    @property
+    def active(self) -> bool:
+        return bool(self.hard) or self.ipa_active
+
+    def verdict(self, i: int):
+        """The coupled filters on node i -> None (passes) or (reason slot, unresolvable)."""
+        for c, tab, mn in zip(self.hard, self.match, self.min_eff):  # pts_filter
+            v = int(self.nodes.label_cols[c.col][i])
+            if v == 0:
+                return M.R_PTS_MISSING_LABEL, True
+            if int(tab[v]) + (1 if c.self_match else 0) - mn > c.max_skew:
+                return M.R_PTS_SKEW, False
+        if self.ipa_active:  # ipa_filter
+            a = self.ipa
+            pods_exist = True
+            for k in a.aff_keys:
+                v = int(self.doms[k][i])
+                if v == 0:
+                    return M.R_IPA_AFFINITY, True
+                if self.aff[k][v] <= 0:
+                    pods_exist = False
+            if not pods_exist and not (self.aff_total == 0 and a.self_aff):
+                return M.R_IPA_AFFINITY, True
+            for k in a.anti_keys:
+                v = int(self.doms[k][i])
+                if v and self.anti[k][v] > 0:
+                    return M.R_IPA_ANTI, False
+            if self.exist_total > 0:
+                for k in range(len(a.key_cols)):
+                    v = int(self.doms[k][i])
+                    if v and self.exist[k][v] > 0:
+                        return M.R_IPA_EXISTING_ANTI, False
+        return None
 
 
 def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedulable: int, filter_mask: int = M.F_ALL,
@@ -92,7 +177,7 @@ def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedula
         return out
     if pre.victim_count is None or not pre.victim_count.any():
         return out
-    if n_templates > 1 or _coupled_filters(pod, filter_mask):
+    if n_templates > 1:
         out.kind = "unmodelled"
         return out
     idx = np.nonzero(pre.victim_count)[0]
@@ -127,14 +212,24 @@ def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedula
         conflict_rest = cnt > 0
         if pre.ports_conflict_rest is not None:
             conflict_rest = conflict_rest | (pre.ports_conflict_rest[idx] != 0)
+    # the coupled filters run after NodePorts / Fit, against the terminal cycle's PreFilter state (unchanged by the removal of
+    # victims that take no part in it): one verdict per victim-bearing node
+    coupled = CoupledState(nodes, pod, per_node_count, filter_mask)
+    verdicts = [coupled.verdict(int(i)) for i in idx] if coupled.active else [None] * len(idx)
+    c_fail = np.array([v is not None for v in verdicts], bool)
+    c_unres = np.array([v is not None and v[1] for v in verdicts], bool)
     # the terminal cycle's status code of these nodes: plain Unschedulable = a dry-run node
     term_req = [nodes.req[c][idx] + cnt * int(pod.req[c]) for c in range(ncol)]
     term_pods = nodes.pod_count[idx].astype(np.int64) + cnt
     m0, beyond0 = fit(term_req, term_pods)
-    potential = sok & (conflict_now | ((m0 != 0) & ~beyond0))
+    local_fail = conflict_now | (m0 != 0)
+    potential = sok & np.where(local_fail, conflict_now | ~beyond0, c_fail & ~c_unres)
+    if coupled.active and pre.victim_interacts is not None and (potential & (pre.victim_interacts[idx] != 0)).any():
+        out.kind = "unmodelled"
+        return out
     # ... with the victims gone
     m1, _ = fit([term_req[c] - pre.victim_req[c][idx] for c in range(ncol)], term_pods - pre.victim_count[idx])
-    fits = potential & ~conflict_rest & (m1 == 0)
+    fits = potential & ~conflict_rest & (m1 == 0) & ~c_fail
     if fits.any():
         out.kind = "nominated"
         return out
@@ -144,4 +239,6 @@ def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedula
     out.hist[M.R_TOO_MANY_PODS] = int((still & ((m1 & 1) != 0)).sum())
     for c in range(ncol):
         out.hist[M.R_RES0 + c] = int((still & ((m1 >> (1 + c)) & 1 != 0)).sum())
+    for j in np.nonzero(still & (m1 == 0))[0]:  # node-locally fine now: the coupled filter's reason (the first failing plugin's)
+        out.hist[verdicts[j][0]] += 1
     return out

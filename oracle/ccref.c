@@ -947,6 +947,10 @@ static void add_reasons(const fail_info *fi, int64_t *hist) {
         for (int c = 0; c < CCREF_MAX_RES; c++)
             if (fi->fit_mask & (1u << (1 + c))) hist[CCREF_R_RES0 + c]++;
         break;
+    case CCREF_F_TOPOLOGYSPREAD: hist[fi->pts_code == 1 ? CCREF_R_PTS_MISSING_LABEL : CCREF_R_PTS_SKEW]++; break;
+    case CCREF_F_INTERPODAFFINITY:
+        hist[fi->ipa_code == 1 ? CCREF_R_IPA_AFFINITY : fi->ipa_code == 2 ? CCREF_R_IPA_ANTI : CCREF_R_IPA_EXISTING_ANTI]++;
+        break;
     default: break; /* the plugins before NodePorts do not look at the node's pods: they passed before, they pass again */
     }
 }
@@ -956,18 +960,6 @@ int ccref_preemption_dry_run(const ccref_profile *prof, const ccref_nodes *nodes
     const int64_t N = nodes->n;
     const int ncol = 3 + nodes->n_scalar;
     memset(out, 0, sizeof *out);
-    int any_victim = 0;
-    if (victims && victims->victim_count)
-        for (int64_t n = 0; n < N; n++) any_victim |= victims->victim_count[n] > 0;
-    int coupled = 0;
-    if (prof->filter_mask & CCREF_F_TOPOLOGYSPREAD)
-        for (int i = 0; i < pod->n_spread; i++) coupled |= pod->spread[i].hard != 0;
-    if ((prof->filter_mask & CCREF_F_INTERPODAFFINITY) && pod->has_ipa) {
-        coupled |= pod->ipa.n_aff_terms > 0 || pod->ipa.n_anti_terms > 0;
-        for (int k = 0; k < pod->ipa.n_keys; k++) coupled |= pod->ipa.exist_anti[k] != NULL;
-    }
-    (void)any_victim;
-    if (coupled) return -38; /* (even the terminal status codes would need those plugins' state) */
 
     /* the terminal NodeInfo: Requested and len(Pods) after the clones (types.go:409-428) */
     ccref_nodes t = *nodes;
@@ -983,9 +975,28 @@ int ccref_preemption_dry_run(const ccref_profile *prof, const ccref_nodes *nodes
     ccref_pod without = *pod; /* the node's used ports once the victims are gone */
     without.host_ports_conflict = victims ? victims->ports_conflict_rest : NULL;
 
+    /* the cycle's PreFilter state of the topology-coupled plugins, as schedule_one_ws builds it (the second Filter run of the dry
+     * run reads this state; removing a victim that takes no part in it leaves it as it is) */
+    workspace ws;
+    int32_t *placed_rw = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    memcpy(placed_rw, placed, sizeof(int32_t) * (size_t)N);
+    if (ws_init(&ws, &t, pod, placed_rw, 1)) return -12;
+    const pts_state *pts = NULL;
+    if ((prof->filter_mask & CCREF_F_TOPOLOGYSPREAD) && has_hard_spread(pod)) {
+        pts_prefilter(&t, pod, placed_rw, &ws.pts);
+        pts = &ws.pts;
+    }
+    const ipa_state *ipa = NULL;
+    if (pod->has_ipa) {
+        ipa_build(&t, pod, placed_rw, &ws.ipa);
+        ipa = &ws.ipa;
+    }
+    const int coupled = pts != NULL || (ipa != NULL && (prof->filter_mask & CCREF_F_INTERPODAFFINITY) && ipa->filter_active);
+
+    int rc = 0;
     for (int64_t n = 0; n < N; n++) {
         fail_info fi = {0, 0, 0, 0};
-        const int code = filter_node(prof, &t, pod, NULL, NULL, placed, n, &fi);
+        const int code = filter_node(prof, &t, pod, pts, ipa, placed, n, &fi);
         if (code != -1) { /* (0 cannot happen at a terminal cycle; counted as not helpful if the caller asks anyway) */
             out->not_helpful++;
             continue;
@@ -995,17 +1006,23 @@ int ccref_preemption_dry_run(const ccref_profile *prof, const ccref_nodes *nodes
             out->no_victims++;
             continue;
         }
+        if (coupled && victims->victim_interacts && victims->victim_interacts[n]) {
+            rc = -38; /* RunPreFilterExtensionRemovePod would change the coupled state: not restated */
+            break;
+        }
         for (int c = 0; c < ncol; c++)
             if (victims->victim_req[c]) cols[c][n] -= victims->victim_req[c][n];
         pc[n] -= vc;
         fail_info fj = {0, 0, 0, 0};
-        if (filter_node(prof, &t, &without, NULL, NULL, placed, n, &fj) == 0) out->nominated = 1;
+        if (filter_node(prof, &t, &without, pts, ipa, placed, n, &fj) == 0) out->nominated = 1;
         else add_reasons(&fj, out->hist);
         for (int c = 0; c < ncol; c++)
             if (victims->victim_req[c]) cols[c][n] += victims->victim_req[c][n];
         pc[n] += vc;
     }
+    ws_free(&ws);
+    free(placed_rw);
     for (int c = 0; c < ncol; c++) free(cols[c]);
     free(pc);
-    return 0;
+    return rc;
 }

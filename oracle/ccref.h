@@ -261,12 +261,16 @@ int64_t ccref_image_locality_score(const int64_t *size, const int32_t *num_nodes
  * whether a REMAINING pod still holds a conflicting host port.  Every node whose filter status is plain Unschedulable is
  * tried: no victims -> no_victims++; all victims removed and the Filter plugins run again -> feasible: nominated = 1
  * (PostFilter returns Success, empty message), else the failing plugin's reasons go to hist.  Other nodes: not_helpful++.
- * Pods with topology-coupled filters (hard spread constraints, inter-pod affinity) are refused with -38 when a victim exists:
- * removing a pod would change those plugins' PreFilter state (RunPreFilterExtensionRemovePod), which is not restated. */
+ * Topology-coupled filters (hard spread constraints, inter-pod affinity) are evaluated in the second run against the cycle's
+ * PreFilter state, which is the terminal cycle's as long as the removed victims take no part in it; a potential node whose victims
+ * do (victim_interacts) is refused with -38: RunPreFilterExtensionRemovePod is not restated. */
 typedef struct {
     const int32_t *victim_count;              /* [n], NULL = no victims anywhere */
     const int64_t *victim_req[CCREF_MAX_RES]; /* [n] per column, NULL = 0 */
     const uint8_t *ports_conflict_rest;       /* [n], NULL = none */
+    /* [n], NULL = none: a victim of the node takes part in the PreFilter state of a topology-coupled filter of the pod (matches a
+     * hard spread selector / a required (anti)affinity term, or carries an anti-affinity term matching the pod) */
+    const uint8_t *victim_interacts;
 } ccref_victims;
 typedef struct {
     int32_t nominated;

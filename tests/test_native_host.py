@@ -42,7 +42,8 @@ def _pod_dump(p):
             "ipa": ipa, "has_host_ports": bool(p.has_host_ports), "host_ports_conflict": lst(p.host_ports_conflict),
             "image_score": lst(p.image_score),
             "preempt": {"priority": p.preempt.priority, "never": p.preempt.never, "victim_count": lst(p.preempt.victim_count),
-                        "victim_req": [lst(v) for v in p.preempt.victim_req], "ports_conflict_rest": lst(p.preempt.ports_conflict_rest)}}
+                        "victim_req": [lst(v) for v in p.preempt.victim_req], "ports_conflict_rest": lst(p.preempt.ports_conflict_rest),
+                        "victim_interacts": lst(p.preempt.victim_interacts)}}
 
 
 def py_dump(snap):

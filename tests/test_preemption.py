@@ -118,7 +118,7 @@ def test_too_many_pods_and_host_ports(ccref):
         f"1 {NO_VICTIMS}, 1 node(s) didn't have free ports for the requested pod ports.")
 
 
-def test_topology_coupled_filters_are_flagged_not_guessed(ccref, capsys):
+def _zoned_cluster():
     nodes, pods = _cluster()
     for i, n in enumerate(nodes):
         n["metadata"]["labels"] = {"kubernetes.io/hostname": n["metadata"]["name"], "zone": f"z{i}"}
@@ -126,9 +126,36 @@ def test_topology_coupled_filters_are_flagged_not_guessed(ccref, capsys):
     tpl["metadata"]["labels"] = {"app": "x"}
     tpl["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule",
                                                  "labelSelector": {"matchLabels": {"app": "x"}}}]
+    return nodes, pods, tpl
+
+
+def test_topology_coupled_template_with_bystander_victims(ccref, capsys):
+    """A hard zone spread on the template; the low-priority pods carry other labels, so removing them leaves the spread state alone:
+    the second Filter run is Fit + the spread filter against the terminal counts.  One clone per node (500m + 300m), counts 1/1/1;
+    a without its 500m placeholder: 300 + 300 <= 1000, skew 1 + 1 - 1 = 1 <= maxSkew -> a candidate, no tail."""
+    nodes, pods, tpl = _zoned_cluster()
     snap, r, msg = _message(ccref, nodes, pods, tpl)
+    assert r.placed == 3 and snap.pod.preempt.victim_interacts is None and capsys.readouterr().err == ""
+    assert msg == "0/3 nodes are available: 3 Insufficient cpu."
+    # the same with a zone that is already ahead: an existing app=x pod of normal priority next to the placeholder on a.  a takes no
+    # clone (skew), b and c one each; terminal: a fails the spread filter (2 - 1 > 1 ... after its Fit passes), b and c are short of cpu.
+    # Dry run: a is a potential node (skew is plain Unschedulable) WITH a victim; without the placeholder Fit still passes and the
+    # spread filter still says no -> its reason; c's 10m victim does not help -> Insufficient cpu; b has no victim.
+    pods.append(running_pod("ahead", "a", cpu="10m", mem="1Mi", labels={"app": "x"}))
+    pods.append(running_pod("ahead2", "a", cpu="10m", mem="1Mi", labels={"app": "x"}))
+    snap, r, msg = _message(ccref, nodes, pods, tpl)
+    assert r.log.tolist() == [1, 2] and r.hist[M.R_PTS_SKEW] == 1 and r.hist[M.R_RES0] == 2
+    assert msg == ("0/3 nodes are available: 1 node(s) didn't match pod topology spread constraints, 2 Insufficient cpu. preemption: 0/3 nodes are "
+                   f"available: 1 Insufficient cpu, 1 {NO_VICTIMS}, 1 node(s) didn't match pod topology spread constraints.")
+
+
+def test_victims_that_take_part_in_the_coupled_state_are_flagged_not_guessed(ccref, capsys):
+    nodes, pods, tpl = _zoned_cluster()
+    pods[0]["metadata"]["labels"] = {"app": "x"}  # the placeholder on a now counts for the template's spread constraint
+    snap, r, msg = _message(ccref, nodes, pods, tpl)
+    assert snap.pod.preempt.victim_interacts.tolist() == [1, 0, 0]
     assert "preemption dry run is not modelled" in capsys.readouterr().err
-    assert msg.endswith(f"preemption: 0/3 nodes are available: 3 {NO_VICTIMS}.")
+    assert msg.endswith(f"preemption: 0/3 nodes are available: {r.n_code_unschedulable} {NO_VICTIMS}.")
     # without victims nothing needs modelling: no warning
     for p in pods:
         p["spec"].pop("priority", None)
@@ -163,6 +190,54 @@ def test_host_dry_run_equals_oracle_restatement(ccref, seed):
     if not ref.nominated:
         assert got.kind == "none" and got.no_victims == ref.no_victims and got.not_helpful == ref.not_helpful
         assert np.array_equal(got.hist, ref.hist), seed
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_host_dry_run_with_coupled_filters_equals_oracle_restatement(ccref, seed):
+    """Hard spread constraints and inter-pod (anti)affinity on the template, victims that take no part in their state (and, for some
+    seeds, a few that do: both sides must refuse exactly then)."""
+    rng = np.random.default_rng(8700 + seed)
+    nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, int(rng.integers(5, 300))))
+    if seed % 3 != 2:
+        pod.spread = H.random_spread(rng, nodes, n_constraints=2)
+    if seed % 3 != 0:
+        pod.ipa = H.random_ipa(rng, nodes)
+    r = ccref.run(prof, nodes, pod, max_limit=5000)
+    assert r.stop == M.STOP_UNSCHEDULABLE
+    vc, vreq = _random_victims(rng, nodes)
+    rest = (rng.random(nodes.n) < 0.3).astype(np.uint8) if pod.has_host_ports and seed % 2 else None
+    inter = ((rng.random(nodes.n) < 0.02) & (vc > 0)).astype(np.uint8) if seed % 4 == 0 else None
+    pod.preempt = M.PreemptionSide(priority=1, victim_count=vc if vc.any() else None, victim_req=vreq, ports_conflict_rest=rest, victim_interacts=inter)
+    got = preemption.dry_run(nodes, pod, r.per_node_count, r.n_code_unschedulable, prof.filter_mask)
+    try:
+        ref = ccref.preemption_dry_run(prof, nodes, pod, r.per_node_count, vc, vreq, rest, inter)
+    except NotImplementedError:
+        assert got.kind == "unmodelled", seed
+        return
+    assert ref.not_helpful == nodes.n - r.n_code_unschedulable
+    assert got.kind != "unmodelled" and (got.kind == "nominated") == ref.nominated, seed
+    if not ref.nominated:
+        assert got.no_victims == ref.no_victims and np.array_equal(got.hist, ref.hist), seed
+
+
+def test_coupled_random_cases_cover_the_outcomes(ccref):
+    seen = set()
+    for seed in range(80):
+        rng = np.random.default_rng(8700 + seed)
+        nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, int(rng.integers(5, 300))))
+        if seed % 3 != 2:
+            pod.spread = H.random_spread(rng, nodes, n_constraints=2)
+        if seed % 3 != 0:
+            pod.ipa = H.random_ipa(rng, nodes)
+        r = ccref.run(prof, nodes, pod, max_limit=5000)
+        vc, vreq = _random_victims(rng, nodes)
+        rest = (rng.random(nodes.n) < 0.3).astype(np.uint8) if pod.has_host_ports and seed % 2 else None
+        inter = ((rng.random(nodes.n) < 0.02) & (vc > 0)).astype(np.uint8) if seed % 4 == 0 else None
+        pod.preempt = M.PreemptionSide(priority=1, victim_count=vc if vc.any() else None, victim_req=vreq, ports_conflict_rest=rest, victim_interacts=inter)
+        got = preemption.dry_run(nodes, pod, r.per_node_count, r.n_code_unschedulable, prof.filter_mask)
+        coupled_reasons = int(got.hist[M.R_PTS_MISSING_LABEL:M.R_IPA_EXISTING_ANTI + 1].sum())
+        seen.add((got.kind, coupled_reasons > 0))
+    assert ("nominated", False) in seen and ("none", True) in seen and ("none", False) in seen and ("unmodelled", False) in seen, seen
 
 
 def test_random_cases_cover_both_outcomes(ccref):
@@ -250,14 +325,21 @@ def test_native_host_random_clusters(ccref, native, tmp_path, seed, capsys):
     assert ("not modelled" in err) == ("not modelled" in capsys.readouterr().err)
 
 
-def _random_uncoupled(rng):
-    """Small clusters whose template has no topology-coupled filter: taints, selectors, pod limits, host ports, priorities."""
+def _random_uncoupled(rng, coupled=False):
+    """Small clusters: taints, selectors, pod limits, host ports, priorities.  `coupled`: the template also carries a hard zone spread
+    and / or a required hostname anti-affinity against its own label, and some existing pods wear that label too (as victims they
+    take part in the coupled state: not modelled; as bystanders they leave it alone)."""
     n = int(rng.integers(2, 10))
     nodes = []
     for i in range(n):
         taints = [{"key": "dedicated", "value": "x", "effect": "NoSchedule"}] if rng.random() < 0.2 else []
+        labels = {"disk": str(rng.choice(["ssd", "hdd"]))}
+        if coupled:
+            labels.update({"kubernetes.io/hostname": f"n{i}", "zone": f"z{int(rng.integers(0, 3))}"})
+            if rng.random() < 0.1:
+                del labels["zone"]
         nodes.append(node(f"n{i}", cpu=str(rng.choice(["500m", "1", "2"])), mem="4Gi", pods=str(int(rng.integers(1, 6))),
-                          labels={"disk": str(rng.choice(["ssd", "hdd"]))}, taints=taints, unschedulable=bool(rng.random() < 0.1)))
+                          labels=labels, taints=taints, unschedulable=bool(rng.random() < 0.1)))
     pods = []
     for j in range(int(rng.integers(0, 3 * n))):
         p = running_pod(f"p{j}", f"n{int(rng.integers(0, n))}", cpu=str(rng.choice(["10m", "200m", "400m"])), mem="16Mi")
@@ -265,8 +347,19 @@ def _random_uncoupled(rng):
             p["spec"]["priority"] = int(rng.choice([-10, -1, 0, 7]))
         if rng.random() < 0.3:
             p["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": int(rng.choice([8080, 9090]))}]
+        if coupled:
+            p["metadata"]["labels"] = {"app": str(rng.choice(["x", "y", "y", "y"]))}
         pods.append(p)
     pod = _template(str(rng.choice(["100m", "300m", "450m", "1500m"])))
+    if coupled:
+        pod["metadata"]["labels"] = {"app": "x"}
+        kind = int(rng.integers(0, 3))
+        if kind != 1:
+            pod["spec"]["topologySpreadConstraints"] = [{"maxSkew": int(rng.integers(1, 3)), "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule",
+                                                         "labelSelector": {"matchLabels": {"app": "x"}}}]
+        if kind != 0:
+            pod["spec"]["affinity"] = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
+                {"topologyKey": "kubernetes.io/hostname", "labelSelector": {"matchLabels": {"app": "x"}}}]}}
     if rng.random() < 0.4:
         pod["spec"]["priority"] = int(rng.choice([0, 5, 100]))
     if rng.random() < 0.4:
@@ -289,6 +382,33 @@ def test_three_way_on_random_uncoupled_clusters(ccref, native, tmp_path, seed):
     r = ccref.run(M.Profile.default(), snap.nodes, snap.pod)
     pre = snap.pod.preempt
     ref = ccref.preemption_dry_run(M.Profile.default(), snap.nodes, snap.pod, r.per_node_count, pre.victim_count, pre.victim_req, pre.ports_conflict_rest)
+    tail = want["failMessage"].split(" preemption: ")
+    assert (len(tail) == 1) == ref.nominated
+    if not ref.nominated:
+        pre_hist = R._reason_histogram(ref.hist, (), None, snap.scalar_names)
+        for text, cnt in list(pre_hist.items()) + [(NO_VICTIMS, ref.no_victims), (NOT_HELPFUL, ref.not_helpful)]:
+            assert (f"{cnt} {text}" in tail[1]) == (cnt > 0), (seed, text)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_three_way_on_random_coupled_clusters(ccref, native, tmp_path, seed, capsys):
+    """... and with a hard zone spread / hostname anti-affinity on the template: both hosts agree, flag the same cases, and where they
+    model the dry run they agree with the oracle."""
+    rng = np.random.default_rng(9950 + seed)
+    nodes, pods, pod = _random_uncoupled(rng, coupled=True)
+    want, got, err = _both_hosts(ccref, native, tmp_path, nodes, pods, pod)
+    py_flagged = "not modelled" in capsys.readouterr().err
+    assert got == want and ("not modelled" in err) == py_flagged, seed
+    snap = ingest.build_snapshot(nodes, pods, pod)
+    r = ccref.run(M.Profile.default(), snap.nodes, snap.pod)
+    pre = snap.pod.preempt
+    try:
+        ref = ccref.preemption_dry_run(M.Profile.default(), snap.nodes, snap.pod, r.per_node_count, pre.victim_count, pre.victim_req, pre.ports_conflict_rest,
+                                       pre.victim_interacts)
+    except NotImplementedError:
+        assert py_flagged, seed
+        return
+    assert not py_flagged, seed
     tail = want["failMessage"].split(" preemption: ")
     assert (len(tail) == 1) == ref.nominated
     if not ref.nominated:
