@@ -89,8 +89,17 @@ def _find(rel, pattern):
     return m.group(1), text.count("\n", 0, m.start(1)) + 1
 
 
+def plugin_order():
+    """The default MultiPoint plugin list, in order (apis/config/v1/default_plugins.go getDefaultPlugins): Filter plugins run in this
+    order and the first failing one decides a node's reasons and status code."""
+    rel = S + "/apis/config/v1/default_plugins.go"
+    text = open(os.path.join(REF, rel)).read()
+    body = text[text.index("func getDefaultPlugins()"):text.index("applyFeatureGates(plugins)")]
+    return {"value": re.findall(r"\{Name: names\.(\w+)", body), "file": rel, "line": text.count("\n", 0, text.index("func getDefaultPlugins()")) + 1}
+
+
 def collect():
-    out = {}
+    out = {"plugins.multipoint_order": plugin_order()}
     for table, conv in ((STRINGS, str), (CODES, str), (NUMBERS, lambda e: int(eval(e, {"__builtins__": {}})))):
         for name, (rel, pattern) in table.items():
             value, line = _find(rel, pattern)

@@ -169,3 +169,45 @@ def test_oracle_status_codes(ccref, kind, slot):
     assert V["code.fit_default"] == "Unschedulable" and r.hist[M.R_TOO_MANY_PODS] == 1
     assert r.n_code_unschedulable == 1 + int(node1_resolvable), kind
     assert V["code.preemption_no_victims"] == "UnschedulableAndUnresolvable"
+
+
+# ---- filter order: the first failing plugin decides the reasons (framework.go:897-930), in the order of the default plugin list ----
+_FILTERS = {"NodeUnschedulable": "unschedulable", "TaintToleration": "taint", "NodeAffinity": "nodeaffinity", "NodePorts": "nodeports",
+            "NodeResourcesFit": "fit_default", "PodTopologySpread": "pts_skew", "InterPodAffinity": "ipa_anti"}
+_SLOT = {"unschedulable": M.R_UNSCHEDULABLE, "taint": None, "nodeaffinity": M.R_NODEAFFINITY, "nodeports": M.R_NODEPORTS, "fit_default": M.R_RES0,
+         "pts_skew": M.R_PTS_SKEW, "ipa_anti": M.R_IPA_ANTI}
+
+
+def _apply(kind, nodes, pod):
+    """The mutation of _one_node_failing(kind) on an existing (nodes, pod): node 1 additionally fails `kind`."""
+    n2, p2 = _one_node_failing(kind)
+    if kind == "unschedulable":
+        nodes.unschedulable = n2.unschedulable
+    elif kind == "taint":
+        nodes.taintset_id = n2.taintset_id
+    elif kind == "nodeaffinity":
+        pod.affinity_filter_active, pod.has_node_selector, pod.node_selector = True, True, p2.node_selector
+    elif kind == "nodeports":
+        pod.has_host_ports, pod.host_ports_conflict = True, p2.host_ports_conflict
+    elif kind == "fit_default":
+        nodes.req[0][1] = 950
+    elif kind == "pts_skew":
+        pod.spread = p2.spread
+    elif kind == "ipa_anti":
+        pod.ipa = p2.ipa
+
+
+def test_oracle_filter_order_is_the_default_plugin_order(ccref):
+    order = [p for p in V["plugins.multipoint_order"] if p in _FILTERS]
+    assert order == ["NodeUnschedulable", "TaintToleration", "NodeAffinity", "NodePorts", "NodeResourcesFit", "PodTopologySpread", "InterPodAffinity"]
+    for i, first in enumerate(order):
+        for second in order[i + 1:]:
+            a, b = _FILTERS[first], _FILTERS[second]
+            nodes, pod = _one_node_failing(a)
+            _apply(b, nodes, pod)
+            r = ccref.run(M.Profile.default(), nodes, pod)
+            # node 1 fails both plugins: only the earlier one's reason is recorded for it
+            got_a = r.hist_taintset[1] if _SLOT[a] is None else r.hist[_SLOT[a]]
+            got_b = r.hist_taintset[1] if _SLOT[b] is None else r.hist[_SLOT[b]]
+            # (node 0 took the one clone: with host ports in play ITS reason is NodePorts too, whichever role NodePorts has in the pair)
+            assert r.placed == 1 and got_a == (2 if a == "nodeports" else 1) and got_b == (1 if b == "nodeports" else 0), (first, second, r.hist.tolist())
