@@ -10,7 +10,11 @@
  * pins an instance count, so numeric parity is pinned only by the prose known answers of the
  * reference's README (52 = 4x13, 52 = 2x26) and the FailType assertions of
  * pkg/framework/simulator_test.go -- see tests/test_oracle_known_answers.py.  "parity unpinned"
- * beyond those.
+ * beyond those for the loop as a whole.  What can be anchored on the reference's SOURCES without running Go is: the unit arithmetic
+ * (ccref_least_allocated, ccref_balanced_allocation, ccref_default_normalize, ccref_num_feasible_nodes_to_find,
+ * ccref_image_locality_score) equals the output of a mechanical line-by-line transliteration of the reference's own Go functions
+ * (tests/golden/reference_vectors.json, tests/test_reference_vectors.py); every message string, status code, default and the
+ * filter order equal what the sources say (tests/golden/reference_pins.json, tests/test_reference_pins.py).
  *
  * Paths below are relative to the reference root; S/ = vendor/k8s.io/kubernetes/pkg/scheduler,
  * P/ = S/framework/plugins.

@@ -1,0 +1,221 @@
+"""Regenerates tests/golden/reference_vectors.json: input/output vectors of the reference's OWN arithmetic, obtained by executing a
+mechanical transliteration of its Go source text.
+
+    python tests/golden/make_reference_vectors.py
+
+The reference is Go and there is no Go toolchain in the build image, so it cannot be run as a whole.  Its scoring arithmetic,
+however, lives in a handful of small pure functions written in a subset of Go that maps line by line onto Python: int64 / float64
+arithmetic, if / else, for-range loops, append, math.Abs / math.Sqrt.  This script reads those functions out of /root/reference
+(file + line recorded), rewrites them token by token (rules below: no understanding of what the code does is involved, and none
+is injected), executes the result on adversarial + random inputs, and writes inputs and outputs to the fixture.
+tests/test_reference_vectors.py then holds the oracle's unit functions (oracle/ccref.c) against the fixture.  Where Python and Go
+semantics differ the rules say so: integer division truncates in Go (godiv), int64(float) truncates (goint), and the functions
+that divide integers are listed (INT_DIV) -- `/` between float64 operands is Python's `/`.  math.Log is NOT covered: Go's amd64
+implementation is its own (the oracle restates it; no other implementation of that polynomial exists here to execute).
+
+Functions: leastRequestedScore + the closure of leastResourceScorer (noderesources/least_allocated.go), balancedResourceScorer
+(noderesources/balanced_allocation.go), DefaultNormalizeScore (helper/normalize_score.go), numFeasibleNodesToFind (schedule_one.go),
+calculatePriority + scaledImageScore (imagelocality/image_locality.go), scoreForCount (podtopologyspread/scoring.go)."""
+import json
+import math
+import os
+import random
+import re
+import types
+
+REF = os.environ.get("CC_REFERENCE", "/root/reference")
+S = "vendor/k8s.io/kubernetes/pkg/scheduler"
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = {k: v["value"] for k, v in json.load(open(os.path.join(HERE, "reference_pins.json"))).items()}
+
+# (name, file, the line that starts the body to cut, parameter names, does `/` divide integers?)
+FUNCS = [
+    ("leastRequestedScore", S + "/framework/plugins/noderesources/least_allocated.go", "func leastRequestedScore(requested, capacity int64) int64 {", ["requested", "capacity"], True),
+    ("leastResourceScorer_closure", S + "/framework/plugins/noderesources/least_allocated.go", "\treturn func(requested, allocable []int64) int64 {", ["requested", "allocable", "resources"], True),
+    ("balancedResourceScorer", S + "/framework/plugins/noderesources/balanced_allocation.go", "func balancedResourceScorer(requested, allocable []int64) int64 {", ["requested", "allocable"], False),
+    ("DefaultNormalizeScore", S + "/framework/plugins/helper/normalize_score.go",
+     "func DefaultNormalizeScore(maxPriority int64, reverse bool, scores framework.NodeScoreList) *fwk.Status {", ["maxPriority", "reverse", "scores"], True),
+    ("numFeasibleNodesToFind", S + "/schedule_one.go",
+     "func (sched *Scheduler) numFeasibleNodesToFind(percentageOfNodesToScore *int32, numAllNodes int32) (numNodes int32) {", ["sched", "percentageOfNodesToScore", "numAllNodes"], True),
+    ("calculatePriority", S + "/framework/plugins/imagelocality/image_locality.go", "func calculatePriority(sumScores int64, numContainers int) int64 {", ["sumScores", "numContainers"], True),
+    ("scaledImageScore", S + "/framework/plugins/imagelocality/image_locality.go", "func scaledImageScore(imageState *fwk.ImageStateSummary, totalNumNodes int) int64 {",
+     ["imageState", "totalNumNodes"], False),
+    ("scoreForCount", S + "/framework/plugins/podtopologyspread/scoring.go", "func scoreForCount(cnt int64, maxSkew int32, tpWeight float64) float64 {", ["cnt", "maxSkew", "tpWeight"], False),
+]
+
+
+def cut(rel, start_line):
+    """The body of the function / closure whose first line is `start_line`: up to the brace that closes it."""
+    lines = open(os.path.join(REF, rel)).read().split("\n")
+    at = lines.index(start_line)
+    depth, body = 0, []
+    for ln in lines[at:]:
+        depth += ln.count("{") - ln.count("}")
+        body.append(ln)
+        if depth == 0:
+            break
+    return at + 1, body
+
+
+def transliterate(name, params, body, int_div):
+    """Go subset -> Python, one line at a time.  Indentation follows the braces."""
+    out = [f"def {name}({', '.join(params)}):"]
+    depth = 1
+    for raw in body[1:-1]:
+        ln = raw.strip()
+        if not ln or ln.startswith("//"):
+            continue
+        # closing braces (with else) first
+        if ln.startswith("}"):
+            depth -= 1
+            ln = ln[1:].strip()
+            if not ln:
+                continue
+            if ln.startswith("else if ") and ln.endswith("{"):
+                ln = "elif " + ln[len("else if "):-1].strip() + ":"
+            elif ln == "else {":
+                ln = "else:"
+            else:
+                raise SystemExit(f"{name}: cannot transliterate {raw!r}")
+            out.append("    " * depth + expr(ln, int_div))
+            depth += 1
+            continue
+        opens = ln.endswith("{")
+        if opens:
+            ln = ln[:-1].strip()
+            m = re.fullmatch(r"for (\w+) := range (\w+)", ln)
+            m2 = re.fullmatch(r"for _, (\w+) := range (\w+)", ln)
+            if m:
+                ln = f"for {m.group(1)} in range(len({m.group(2)})):"
+            elif m2:
+                ln = f"for {m2.group(1)} in {m2.group(2)}:"
+            elif ln.startswith("if "):
+                ln = "if " + ln[3:] + ":"
+            else:
+                raise SystemExit(f"{name}: cannot transliterate {raw!r}")
+        else:
+            m = re.fullmatch(r"var (\w+), (\w+) (int64|float64)", ln)
+            if m:
+                ln = f"{m.group(1)} = {m.group(2)} = 0"
+            elif re.fullmatch(r"var (\w+) \[\]float64", ln):
+                ln = re.sub(r"var (\w+) \[\]float64", r"\1 = []", ln)
+            elif re.fullmatch(r"var (\w+) (int64|int32|float64)", ln):
+                ln = re.sub(r"var (\w+) (int64|int32|float64)", r"\1 = 0", ln)
+            ln = ln.replace(":=", "=")
+            m = re.fullmatch(r"(\w+) = append\((\w+), (.+)\)", ln)
+            if m and m.group(1) == m.group(2):
+                ln = f"{m.group(1)} = {m.group(1)} + [{m.group(3)}]"
+            if ln == "return nil":
+                ln = "return None"
+        out.append("    " * depth + expr(ln, int_div))
+        if opens:
+            depth += 1
+    return "\n".join(out) + "\n"
+
+
+def expr(ln, int_div):
+    ln = ln.replace("framework.MaxNodeScore", "MaxNodeScore").replace("math.Abs(", "abs(").replace("math.Sqrt(", "math.sqrt(")
+    ln = re.sub(r"\bfloat64\(", "float(", ln)
+    ln = re.sub(r"\bint64\(", "goint(", ln)
+    ln = re.sub(r"\bint32\((\d+)\)", r"\1", ln)
+    ln = ln.replace("scores[i].Score", "scores[i]").replace("resources[i].Weight", "resources[i]")
+    ln = ln.replace("percentageOfNodesToScore != nil", "percentageOfNodesToScore is not None").replace("*percentageOfNodesToScore", "percentageOfNodesToScore")
+    ln = ln.replace("true", "True").replace("false", "False") if re.search(r"\b(true|false)\b", ln) else ln
+    if int_div and "/" in ln:
+        # a / b between integers: Go truncates toward zero.  Only the shapes that occur: `X / name` and `X / number`, at the top level of
+        # a statement `lhs = A / B`, `return A / B` or `lhs = A - B/C`
+        m = re.fullmatch(r"(\s*(?:return |\w+ = ))(.+) / (\w+|\([^()]*\))", ln)
+        m2 = re.fullmatch(r"(\s*\w+ = )(\w+) - (\w+)/(\d+)", ln)
+        if m2:
+            ln = f"{m2.group(1)}{m2.group(2)} - godiv({m2.group(3)}, {m2.group(4)})"
+        elif m:
+            ln = f"{m.group(1)}godiv({m.group(2)}, {m.group(3)})"
+        else:
+            raise SystemExit(f"integer division of an unexpected shape: {ln!r}")
+    return ln
+
+
+def godiv(a, b):
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def goint(x):
+    return int(x)  # int() truncates toward zero, like Go's conversion (the values here are far inside int64)
+
+
+def build():
+    env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"],
+           "minThreshold": PINS["image.min_threshold_mb"] * PINS["image.mb"], "maxContainerThreshold": PINS["image.max_container_threshold_mb"] * PINS["image.mb"],
+           "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"]}
+    sources = {}
+    for name, rel, start, params, int_div in FUNCS:
+        line, body = cut(rel, start)
+        py = transliterate(name, params, body, int_div)
+        exec(py, env)
+        sources[name] = {"file": rel, "line": line, "go": "\n".join(body), "python": py}
+    return env, sources
+
+
+def vectors(env):
+    rnd = random.Random(20260923)
+    v = {}
+    near = lambda cap, scale: max(0, min(cap, (rnd.randint(0, scale) * cap) // scale + rnd.randint(-2, 2)))
+    caps = lambda: rnd.choice([0, 1, 7, 1000, 4000, 15890, 64 << 30, (1 << 40) + 12345, rnd.randint(1, 1 << 45)])
+    # leastResourceScorer over 1..4 resources (weights as the config allows them: 1..100)
+    rows = []
+    for _ in range(1500):
+        n = rnd.randint(1, 4)
+        al = [caps() for _ in range(n)]
+        rq = [rnd.choice([near(a, 100), rnd.randint(0, a + a // 3 + 1), 0, a]) for a in al]
+        w = [rnd.randint(1, 100) if rnd.random() < 0.5 else 1 for _ in range(n)]
+        rows.append([rq, al, w, env["leastResourceScorer_closure"](rq, al, w)])
+    v["leastResourceScorer"] = rows
+    rows = []
+    for _ in range(2500):
+        n = rnd.choice([1, 2, 2, 2, 3, 4, 5])
+        al = [caps() for _ in range(n)]
+        rq = [rnd.choice([near(a, 200), rnd.randint(0, a + a // 3 + 1), 0, a]) for a in al]
+        if n == 2 and rnd.random() < 0.3 and al[0]:
+            al[1] = al[0]
+            rq[1] = near(al[0], 200)
+        rows.append([rq, al, env["balancedResourceScorer"](rq, al)])
+    v["balancedResourceScorer"] = rows
+    rows = []
+    for _ in range(500):
+        n = rnd.randint(0, 12)
+        top = rnd.choice([0, 1, 3, 100, 8191, 1 << 20])
+        sc = [rnd.randint(0, top) for _ in range(n)]
+        for reverse in (False, True):
+            out = list(sc)
+            env["DefaultNormalizeScore"](100, reverse, out)
+            rows.append([sc, reverse, out])
+    v["DefaultNormalizeScore"] = rows
+    rows = []
+    for n in list(range(0, 300)) + [rnd.randint(300, 2_000_000) for _ in range(400)] + [5000, 5625, 5750, 6000, 100000, 1000000]:
+        for pct in (None, 0, 1, 5, 10, 35, 50, 99, 100):
+            sched = types.SimpleNamespace(percentageOfNodesToScore=0)
+            rows.append([pct if pct is not None else -1, n, env["numFeasibleNodesToFind"](sched, pct, n)])
+    v["numFeasibleNodesToFind"] = rows
+    rows = []
+    mb = PINS["image.mb"]
+    for _ in range(1200):
+        k = rnd.randint(0, 4)
+        total = rnd.randint(1, 5000)
+        sizes = [rnd.choice([rnd.randint(0, 3000 * mb), 23 * mb, 1000 * mb, 40 * mb]) for _ in range(k)]
+        nn = [rnd.randint(1, total) for _ in range(k)]
+        ncont = rnd.randint(max(1, k), 6)
+        s = sum(env["scaledImageScore"](types.SimpleNamespace(NumNodes=a, Size=b), total) for a, b in zip(nn, sizes))
+        rows.append([sizes, nn, total, ncont, env["calculatePriority"](s, ncont)])
+    v["imageLocality"] = rows
+    return v
+
+
+if __name__ == "__main__":
+    env, sources = build()
+    out = {"sources": sources, "vectors": vectors(env)}
+    path = os.path.join(HERE, "reference_vectors.json")
+    json.dump(out, open(path, "w"), separators=(",", ":"))
+    print({k: len(r) for k, r in out["vectors"].items()}, "->", path, os.path.getsize(path) // 1024, "KB")
+    for name, s in sources.items():
+        print(f"--- {name} ({s['file']}:{s['line']})\n{s['python']}")

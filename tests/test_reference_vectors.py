@@ -1,0 +1,60 @@
+"""The oracle's unit arithmetic against the reference's OWN arithmetic: tests/golden/reference_vectors.json holds inputs and outputs
+obtained by executing a mechanical, line-by-line transliteration of the reference's Go functions (leastRequestedScore and the
+leastResourceScorer closure, balancedResourceScorer, DefaultNormalizeScore, numFeasibleNodesToFind, calculatePriority,
+scaledImageScore) -- tests/golden/make_reference_vectors.py, which records the Go text, its file and line, and the Python it became.
+No Go toolchain exists in the build image; this is as close as the oracle can get to "checked against outputs of the reference"
+for its scoring arithmetic.  Not covered: math.Log (Go's own implementation; the oracle restates it) and everything that is control
+flow over scheduler state rather than arithmetic."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+VEC = FIX["vectors"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_fixture_is_what_the_reference_sources_give():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_reference_vectors", os.path.join(ROOT, "tests", "golden", "make_reference_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    env, sources = mod.build()
+    assert sources == FIX["sources"]          # the Go text (and so its transliteration) is still what the fixture was made from
+    assert mod.vectors(env) == VEC
+
+
+def test_transliterations_are_line_by_line():
+    """Audit aid: every non-blank, non-comment Go line of a function became exactly one Python line (or a brace)."""
+    for name, s in FIX["sources"].items():
+        go = [l.strip() for l in s["go"].split("\n")[1:-1] if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
+        py = [l for l in s["python"].split("\n")[1:] if l.strip()]
+        assert len(go) == len(py), name
+
+
+def test_least_allocated(ccref):
+    for rq, al, w, want in VEC["leastResourceScorer"]:
+        assert ccref.least_allocated(rq, al, w) == want, (rq, al, w)
+
+
+def test_balanced_allocation(ccref):
+    for rq, al, want in VEC["balancedResourceScorer"]:
+        assert ccref.balanced_allocation(rq, al) == want, (rq, al)
+
+
+def test_default_normalize(ccref):
+    for sc, reverse, want in VEC["DefaultNormalizeScore"]:
+        assert list(ccref.default_normalize(100, reverse, sc)) == want, (sc, reverse)
+
+
+def test_num_feasible_nodes_to_find(ccref):
+    for pct, n, want in VEC["numFeasibleNodesToFind"]:
+        # (-1: the profile leaves percentageOfNodesToScore unset and the global value, 0 = adaptive, applies)
+        assert ccref.num_feasible_nodes_to_find(max(pct, 0), n) == want, (pct, n)
+
+
+def test_image_locality(ccref):
+    for sizes, nn, total, ncont, want in VEC["imageLocality"]:
+        assert ccref.image_locality_score(sizes, nn, total, ncont) == want, (sizes, nn, total, ncont)
