@@ -486,6 +486,42 @@ static int has_hard_spread(const ccref_pod *pod) {
     return 0;
 }
 
+/* PodTopologySpread.NormalizeScore (P/podtopologyspread/scoring.go:226-265): `ignored` = the node is in IgnoredNodes (NULL: none) */
+void ccref_pts_normalize(int64_t *scores, const uint8_t *ignored, int64_t n) {
+    int64_t min_score = INT64_MAX, max_score = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (ignored && ignored[i]) continue;
+        if (scores[i] < min_score) min_score = scores[i];
+        if (scores[i] > max_score) max_score = scores[i];
+    }
+    for (int64_t i = 0; i < n; i++) {
+        if (ignored && ignored[i]) {
+            scores[i] = 0;
+            continue;
+        }
+        if (max_score == 0) {
+            scores[i] = MAX_NODE_SCORE;
+            continue;
+        }
+        scores[i] = MAX_NODE_SCORE * (max_score + min_score - scores[i]) / max_score;
+    }
+}
+
+/* InterPodAffinity.NormalizeScore (P/interpodaffinity/scoring.go:259-290) */
+void ccref_ipa_normalize(int64_t *scores, int64_t n) {
+    int64_t mn = INT64_MAX, mx = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        if (scores[i] > mx) mx = scores[i];
+        if (scores[i] < mn) mn = scores[i];
+    }
+    const int64_t diff = mx - mn;
+    for (int64_t i = 0; i < n; i++) {
+        double f = 0;
+        if (diff > 0) f = (double)MAX_NODE_SCORE * ((double)(scores[i] - mn) / (double)diff);
+        scores[i] = (int64_t)f;
+    }
+}
+
 /* P/podtopologyspread/scoring.go:61-265 PreScore + Score + NormalizeScore over the feasible list */
 static void pts_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas,
                        int64_t nf, int64_t *out) {
@@ -555,24 +591,7 @@ static void pts_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_
         }
         out[i] = (int64_t)go_round(score);
     }
-    /* NormalizeScore :226-265 */
-    int64_t min_score = INT64_MAX, max_score = 0;
-    for (int64_t i = 0; i < nf; i++) {
-        if (ignored[i]) continue;
-        if (out[i] < min_score) min_score = out[i];
-        if (out[i] > max_score) max_score = out[i];
-    }
-    for (int64_t i = 0; i < nf; i++) {
-        if (ignored[i]) {
-            out[i] = 0;
-            continue;
-        }
-        if (max_score == 0) {
-            out[i] = MAX_NODE_SCORE;
-            continue;
-        }
-        out[i] = MAX_NODE_SCORE * (max_score + min_score - out[i]) / max_score;
-    }
+    ccref_pts_normalize(out, ignored, nf);
     for (int c = 0; c < pod->n_spread; c++) free(cnt[c]);
     free(ignored);
 }
@@ -735,7 +754,6 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
         /* InterPodAffinity Score + NormalizeScore (scoring.go:226-290); PreScore Skip without any term hit */
         if (prof->w_interpodaffinity && ipa && ipa->entries > 0) {
             const ccref_ipa *a = &pod->ipa;
-            int64_t mn = INT64_MAX, mx = INT64_MIN;
             for (int64_t i = 0; i < nf; i++) {
                 int64_t v = 0;
                 for (int k = 0; k < a->n_keys; k++) {
@@ -743,15 +761,9 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
                     if (d) v += ipa->score[k][d];
                 }
                 sc[i] = v;
-                if (v > mx) mx = v;
-                if (v < mn) mn = v;
             }
-            int64_t diff = mx - mn;
-            for (int64_t i = 0; i < nf; i++) {
-                double f = 0;
-                if (diff > 0) f = (double)MAX_NODE_SCORE * ((double)(sc[i] - mn) / (double)diff);
-                ws->total[i] += (int64_t)f * prof->w_interpodaffinity;
-            }
+            ccref_ipa_normalize(sc, nf);
+            for (int64_t i = 0; i < nf; i++) ws->total[i] += sc[i] * prof->w_interpodaffinity;
         }
         /* NodeResourcesBalancedAllocation (balanced_allocation.go:100-115); Skip for best-effort */
         if (prof->w_balanced && !balanced_skipped(prof, pod)) {

@@ -12,7 +12,7 @@
  * pkg/framework/simulator_test.go -- see tests/test_oracle_known_answers.py.  "parity unpinned"
  * beyond those for the loop as a whole.  What can be anchored on the reference's SOURCES without running Go is: the unit arithmetic
  * (ccref_least_allocated, ccref_balanced_allocation, ccref_default_normalize, ccref_num_feasible_nodes_to_find,
- * ccref_image_locality_score) equals the output of a mechanical line-by-line transliteration of the reference's own Go functions
+ * ccref_image_locality_score, ccref_pts_normalize, ccref_ipa_normalize) equals the output of a mechanical line-by-line transliteration of the reference's own Go functions
  * (tests/golden/reference_vectors.json, tests/test_reference_vectors.py); every message string, status code, default and the
  * filter order equal what the sources say (tests/golden/reference_pins.json, tests/test_reference_pins.py).
  *
@@ -251,6 +251,10 @@ int64_t ccref_balanced_allocation(const int64_t *requested, const int64_t *alloc
 void ccref_default_normalize(int64_t max_priority, int reverse, int64_t *scores, int64_t n);
 int32_t ccref_num_feasible_nodes_to_find(int32_t percentage, int32_t num_all_nodes);
 double ccref_go_log(double x); /* restatement of Go's math.Log (pure-Go path) */
+/* the NormalizeScore steps of PodTopologySpread (scoring.go:226-265; ignored: in IgnoredNodes, NULL = none) and InterPodAffinity
+ * (scoring.go:259-290), in place */
+void ccref_pts_normalize(int64_t *scores, const uint8_t *ignored, int64_t n);
+void ccref_ipa_normalize(int64_t *scores, int64_t n);
 /* ImageLocality score of one node (image_locality.go:54-115): size[i] / num_nodes[i] = ImageStateSummary of the i-th
  * pod container (incl. init containers) whose image the node holds; n_containers = len(InitContainers) + len(Containers) */
 int64_t ccref_image_locality_score(const int64_t *size, const int32_t *num_nodes, int n_present, int32_t total_nodes,

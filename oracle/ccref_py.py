@@ -428,6 +428,23 @@ def num_feasible_nodes_to_find(percentage, n):
     return int(lib().ccref_num_feasible_nodes_to_find(int(percentage), int(n)))
 
 
+def pts_normalize(scores, ignored=None):
+    s = np.array(scores, dtype=np.int64)
+    ig = None if ignored is None else np.ascontiguousarray(ignored, dtype=np.uint8)
+    fn = lib().ccref_pts_normalize
+    fn.restype, fn.argtypes = None, [_p64, _pu8, C.c_int64]
+    fn(_ptr(s, _p64), None if ig is None else _ptr(ig, _pu8), len(s))
+    return s.tolist()
+
+
+def ipa_normalize(scores):
+    s = np.array(scores, dtype=np.int64)
+    fn = lib().ccref_ipa_normalize
+    fn.restype, fn.argtypes = None, [_p64, C.c_int64]
+    fn(_ptr(s, _p64), len(s))
+    return s.tolist()
+
+
 def go_log(x):
     return float(lib().ccref_go_log(float(x)))
 

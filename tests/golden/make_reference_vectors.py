@@ -41,7 +41,20 @@ FUNCS = [
     ("scaledImageScore", S + "/framework/plugins/imagelocality/image_locality.go", "func scaledImageScore(imageState *fwk.ImageStateSummary, totalNumNodes int) int64 {",
      ["imageState", "totalNumNodes"], False),
     ("scoreForCount", S + "/framework/plugins/podtopologyspread/scoring.go", "func scoreForCount(cnt int64, maxSkew int32, tpWeight float64) float64 {", ["cnt", "maxSkew", "tpWeight"], False),
+    # the two plugin NormalizeScore methods: the lines that fetch the cycle state (getPreScoreState ... return nil) are dropped (DROP),
+    # `s.IgnoredNodes.Has(score.Name)` reads the `ignored` argument, `len(s.topologyScore) == 0` is the caller's business
+    ("ptsNormalizeScore", S + "/framework/plugins/podtopologyspread/scoring.go",
+     "func (pl *PodTopologySpread) NormalizeScore(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, scores framework.NodeScoreList) *fwk.Status {",
+     ["scores", "ignored"], True),
+    ("ipaNormalizeScore", S + "/framework/plugins/interpodaffinity/scoring.go",
+     "func (pl *InterPodAffinity) NormalizeScore(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, scores framework.NodeScoreList) *fwk.Status {",
+     ["scores"], False),
 ]
+# statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
+DROP = {
+    "ptsNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if s == nil {", "return nil", "}"],
+    "ipaNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if len(s.topologyScore) == 0 {", "return nil", "}"],
+}
 
 
 def cut(rel, start_line):
@@ -61,7 +74,15 @@ def transliterate(name, params, body, int_div):
     """Go subset -> Python, one line at a time.  Indentation follows the braces."""
     out = [f"def {name}({', '.join(params)}):"]
     depth = 1
-    for raw in body[1:-1]:
+    inner = body[1:-1]
+    drop = list(DROP.get(name, []))
+    while drop:  # the dropped statements are the first non-blank lines of the body, in this order
+        while not inner[0].strip() or inner[0].strip().startswith("//"):
+            inner = inner[1:]
+        if inner[0].strip() != drop[0]:
+            raise SystemExit(f"{name}: expected {drop[0]!r}, found {inner[0]!r}")
+        inner, drop = inner[1:], drop[1:]
+    for raw in inner:
         ln = raw.strip()
         if not ln or ln.startswith("//"):
             continue
@@ -85,7 +106,10 @@ def transliterate(name, params, body, int_div):
             ln = ln[:-1].strip()
             m = re.fullmatch(r"for (\w+) := range (\w+)", ln)
             m2 = re.fullmatch(r"for _, (\w+) := range (\w+)", ln)
-            if m:
+            m3 = re.fullmatch(r"for (\w+), (\w+) := range (\w+)", ln)
+            if m3 and m3.group(1) != "_":
+                ln = f"for {m3.group(1)}, {m3.group(2)} in enumerate({m3.group(3)}):"
+            elif m:
                 ln = f"for {m.group(1)} in range(len({m.group(2)})):"
             elif m2:
                 ln = f"for {m2.group(1)} in {m2.group(2)}:"
@@ -99,6 +123,8 @@ def transliterate(name, params, body, int_div):
                 ln = f"{m.group(1)} = {m.group(2)} = 0"
             elif re.fullmatch(r"var (\w+) \[\]float64", ln):
                 ln = re.sub(r"var (\w+) \[\]float64", r"\1 = []", ln)
+            elif re.fullmatch(r"var (\w+) int64 = (.+)", ln):
+                ln = re.sub(r"var (\w+) int64 = (.+)", r"\1 = \2", ln)
             elif re.fullmatch(r"var (\w+) (int64|int32|float64)", ln):
                 ln = re.sub(r"var (\w+) (int64|int32|float64)", r"\1 = 0", ln)
             ln = ln.replace(":=", "=")
@@ -119,12 +145,14 @@ def expr(ln, int_div):
     ln = re.sub(r"\bint64\(", "goint(", ln)
     ln = re.sub(r"\bint32\((\d+)\)", r"\1", ln)
     ln = ln.replace("scores[i].Score", "scores[i]").replace("resources[i].Weight", "resources[i]")
+    ln = ln.replace("s.IgnoredNodes.Has(score.Name)", "ignored[i]").replace("score.Score", "score").replace("math.MaxInt64", "MaxInt64").replace("math.MinInt64", "MinInt64")
+    ln = re.sub(r"^(\s*)(\w+) = float\(0\)$", r"\1\2 = 0.0", ln)
     ln = ln.replace("percentageOfNodesToScore != nil", "percentageOfNodesToScore is not None").replace("*percentageOfNodesToScore", "percentageOfNodesToScore")
     ln = ln.replace("true", "True").replace("false", "False") if re.search(r"\b(true|false)\b", ln) else ln
     if int_div and "/" in ln:
         # a / b between integers: Go truncates toward zero.  Only the shapes that occur: `X / name` and `X / number`, at the top level of
         # a statement `lhs = A / B`, `return A / B` or `lhs = A - B/C`
-        m = re.fullmatch(r"(\s*(?:return |\w+ = ))(.+) / (\w+|\([^()]*\))", ln)
+        m = re.fullmatch(r"(\s*(?:return |[\w\[\]]+ = ))(.+) / (\w+|\([^()]*\))", ln)
         m2 = re.fullmatch(r"(\s*\w+ = )(\w+) - (\w+)/(\d+)", ln)
         if m2:
             ln = f"{m2.group(1)}{m2.group(2)} - godiv({m2.group(3)}, {m2.group(4)})"
@@ -145,7 +173,8 @@ def goint(x):
 
 
 def build():
-    env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"],
+    env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"], "MaxInt64": (1 << 63) - 1, "MinInt64": -(1 << 63),
+           "invalidScore": -1,
            "minThreshold": PINS["image.min_threshold_mb"] * PINS["image.mb"], "maxContainerThreshold": PINS["image.max_container_threshold_mb"] * PINS["image.mb"],
            "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"]}
     sources = {}
@@ -208,6 +237,25 @@ def vectors(env):
         s = sum(env["scaledImageScore"](types.SimpleNamespace(NumNodes=a, Size=b), total) for a, b in zip(nn, sizes))
         rows.append([sizes, nn, total, ncont, env["calculatePriority"](s, ncont)])
     v["imageLocality"] = rows
+    rows = []
+    for _ in range(1200):
+        n = rnd.randint(0, 10)
+        top = rnd.choice([0, 1, 5, 100, 5000, 1 << 30])
+        sc = [rnd.randint(0, top) for _ in range(n)]
+        ig = [rnd.random() < 0.2 for _ in range(n)]
+        out = list(sc)
+        env["ptsNormalizeScore"](out, ig)
+        rows.append([sc, [int(x) for x in ig], out])
+    v["ptsNormalizeScore"] = rows
+    rows = []
+    for _ in range(1200):
+        n = rnd.randint(1, 10)
+        lo = rnd.choice([0, -50, -100000, 7])
+        sc = [lo + rnd.randint(0, rnd.choice([0, 1, 3, 100, 99999])) for _ in range(n)]
+        out = list(sc)
+        env["ipaNormalizeScore"](out)
+        rows.append([sc, out])
+    v["ipaNormalizeScore"] = rows
     return v
 
 
