@@ -52,7 +52,7 @@ def _go_round(x: float) -> int:  # C round(): half away from zero
 
 
 class CoupledWindowModel:
-    def __init__(self, prof, nodes, pod, go_log, window=64):
+    def __init__(self, prof, nodes, pod, go_log, window=64, every_node_scored=True):
         self.prof, self.nd, self.pod, self.go_log, self.W = prof, nodes, pod, go_log, window
         N = self.N = nodes.n
         fm = self.fm = prof.filter_mask
@@ -64,7 +64,7 @@ class CoupledWindowModel:
         self.clones = [0] * N
         self.preq = [int(x) for x in pod.req]
         self.all_zero = not any(self.preq[c] > 0 for c in range(3)) and not pod.has_scalar_entries
-        assert prof.percentage_of_nodes_to_score == 100 or N < 100
+        assert not every_node_scored or prof.percentage_of_nodes_to_score == 100 or N < 100  # (the window argument needs every node scored)
         assert any((prof.w_taint, prof.w_nodeaffinity, prof.w_fit, prof.w_balanced, prof.w_topologyspread, prof.w_interpodaffinity, prof.w_imagelocality))
         # ---- static per node ----
         self.ok, self.cnt, self.aff = [], [], []
