@@ -157,6 +157,7 @@ RunResult result_from_json(const Value &v) {
     for (const auto &x : v["log"].items()) r.log.push_back((int32_t)x.as_int());
     for (const auto &x : v["hist"].items()) r.hist.push_back(x.as_int());
     for (const auto &x : v["hist_taintset"].items()) r.hist_taintset.push_back(x.as_int());
+    if (v.has("stop_spec")) r.stop_spec = (int32_t)v["stop_spec"].as_int(); // several templates: the one whose pod did not fit
     return r;
 }
 

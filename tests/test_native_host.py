@@ -1353,3 +1353,34 @@ def test_pruned_parse_still_rejects_broken_json(native, tmp_path):
     p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"], capture_output=True, text=True,
                        timeout=30, env=dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS="4"))
     assert p.returncode != 0 and "cluster-capacity:" in p.stderr
+
+
+def test_several_templates_unschedulable_stop_names_the_failing_template(native, tmp_path, capsys):
+    """The FitError of a several-templates run describes the template whose pod did not fit (its taint reasons, its preemption side);
+    templates of different priority -> clones of one could be victims of another: both hosts flag the dry run as not modelled."""
+    nodes, pods, templates = _templates_case()
+    nodes[0]["spec"]["taints"] = [{"key": "dedicated", "value": "x", "effect": "NoSchedule"}]
+    templates[1]["spec"]["tolerations"] = [{"key": "dedicated", "operator": "Exists"}]
+    templates[2]["spec"]["priority"] = 10
+    cluster, paths = _write_templates(tmp_path, nodes, pods, templates)
+    pypods = [cli.parse_pod_spec(p) for p in paths]
+    snap = ingest.build_snapshot(*cli.load_objects([cluster]), pypods)
+    n = len(snap.names)
+    hist = np.zeros(M.NREASON, np.int64)
+    hist[M.R_RES0] = n - 1
+    for failing in (0, 1, 2):
+        ht = np.zeros(len(snap.taint_reasons_all[failing]), np.int64)
+        ts = int(snap.nodes.taintset_id[snap.names.index(nodes[0]["metadata"]["name"])])
+        ht[ts] = 0 if failing == 1 else 1
+        res = M.RunResult(placed=6, stop=M.STOP_UNSCHEDULABLE, per_node_count=np.bincount([0, 1, 2, 3, 4, 5], minlength=n).astype(np.int32),
+                          log=np.arange(6, dtype=np.int32), hist=hist, hist_taintset=ht, n_code_unschedulable=n - 1, stop_spec=failing)
+        (tmp_path / "result.json").write_text(json.dumps({
+            "placed": res.placed, "stop": res.stop, "n_code_unschedulable": res.n_code_unschedulable, "per_node_count": res.per_node_count.tolist(),
+            "log": res.log.tolist(), "hist": res.hist.tolist(), "hist_taintset": res.hist_taintset.tolist(), "stop_spec": failing}))
+        p = subprocess.run([native] + [x for q in paths for x in ("--podspec", q)] + ["--snapshot", cluster, "--fake-result", str(tmp_path / "result.json"), "-o", "json"],
+                           capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        want = cli.build_review(pypods, snap, res, 0)
+        assert json.loads(p.stdout)["status"]["failReason"] == want["status"]["failReason"], failing
+        assert ("not modelled" in p.stderr) and ("not modelled" in capsys.readouterr().err)
+        assert ("untolerated taint {dedicated: x}" in want["status"]["failReason"]["failMessage"]) == (failing != 1)
