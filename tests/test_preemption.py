@@ -426,3 +426,25 @@ def test_random_uncoupled_clusters_cover_the_outcomes(ccref):
         o = preemption.dry_run(snap.nodes, snap.pod, r.per_node_count, r.n_code_unschedulable)
         kinds.add((o.kind, bool(o.hist.sum()), snap.pod.preempt.victim_count is not None))
     assert ("nominated", False, True) in kinds and ("none", True, True) in kinds and ("none", False, True) in kinds and ("none", False, False) in kinds
+
+
+# ---- end to end on the GPU: objects -> host -> C ABI -> HIP engine -> the message ---------------------------------------------------
+@pytest.mark.gpu
+def test_cli_end_to_end_both_hosts(native, tmp_path):
+    """The hand-derived answers of test_known_answers with the real engine underneath: the placeholder on a is a candidate (no tail);
+    without it c's 10m pod does not help (tail with its reason); preemptionPolicy=Never."""
+    import io
+    nodes, pods = _cluster()
+    cases = [("300m", {}, pods, "0/3 nodes are available: 3 Insufficient cpu."),
+             ("600m", {}, pods[1:], f"0/3 nodes are available: 3 Insufficient cpu. preemption: 0/3 nodes are available: 1 Insufficient cpu, 2 {NO_VICTIMS}."),
+             ("300m", {"preemptionPolicy": "Never"}, pods, "0/3 nodes are available: 3 Insufficient cpu. preemption: not eligible due to preemptionPolicy=Never.")]
+    for k, (cpu, spec, keep, want) in enumerate(cases):
+        d = tmp_path / str(k)
+        d.mkdir()
+        podspec, snaps = _write(d, "json", nodes, keep, _template(cpu, **spec))
+        p = subprocess.run([native, "--podspec", podspec, "--snapshot", snaps[0], "-o", "json"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        assert json.loads(p.stdout)["status"]["failReason"] == {"failType": "Unschedulable", "failMessage": want}
+        buf = io.StringIO()
+        assert cli.main(["--podspec", podspec, "--snapshot", snaps[0], "-o", "json"], out=buf) == 0
+        assert json.loads(buf.getvalue())["status"]["failReason"]["failMessage"] == want
