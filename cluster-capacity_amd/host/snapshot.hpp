@@ -43,7 +43,43 @@ inline int64_t res_of(const Value &rl, const std::string &name) { // a ResourceL
 }
 
 // S/util/utils.go:140-143: extended / hugepages / prefixed native / attachable-volumes resources
-inline bool is_scalar_resource(const std::string &name) { return !(name == "cpu" || name == "memory" || name == "ephemeral-storage" || name == "pods"); }
+// validation.IsQualifiedName (apimachinery/pkg/util/validation/validation.go:29-70): [dns-1123-subdomain "/"] name; the name is at
+// most 63 characters of [-A-Za-z0-9_.] starting and ending alphanumeric, the prefix at most 253 of lower-case labels joined by dots
+inline bool is_qualified_name(const std::string &value) {
+    auto alnum = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9'); };
+    auto lower_alnum = [](char c) { return (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9'); };
+    const size_t slash = value.find('/');
+    std::string name = value;
+    if (slash != std::string::npos) {
+        if (value.find('/', slash + 1) != std::string::npos) return false;
+        const std::string prefix = value.substr(0, slash);
+        name = value.substr(slash + 1);
+        if (prefix.empty() || prefix.size() > 253) return false;
+        size_t at = 0; // labels [a-z0-9]([-a-z0-9]*[a-z0-9])? joined by '.'
+        while (true) {
+            const size_t dot = prefix.find('.', at);
+            const std::string label = prefix.substr(at, dot == std::string::npos ? std::string::npos : dot - at);
+            if (label.empty() || !lower_alnum(label.front()) || !lower_alnum(label.back())) return false;
+            for (const char c : label)
+                if (!(lower_alnum(c) || c == '-')) return false;
+            if (dot == std::string::npos) break;
+            at = dot + 1;
+        }
+    }
+    if (name.empty() || name.size() > 63 || !alnum(name.front()) || !alnum(name.back())) return false;
+    for (const char c : name)
+        if (!(alnum(c) || c == '-' || c == '_' || c == '.')) return false;
+    return true;
+}
+// schedutil.IsScalarResourceName (S/util/utils.go:140-143) = extended || hugepages-* || *kubernetes.io/* || attachable-volumes-*
+// (pkg/apis/core/v1/helper/helpers.go:36-66,133-135).  Anything else that is not cpu / memory / ephemeral-storage is DROPPED by the
+// scheduler's Resource.Add, e.g. an unqualified "foo" or a "requests."-prefixed name.
+inline bool is_scalar_resource(const std::string &name) {
+    const bool prefixed_native = name.find("kubernetes.io/") != std::string::npos;
+    const bool native = name.find('/') == std::string::npos || prefixed_native;
+    const bool extended = !native && name.rfind("requests.", 0) != 0 && is_qualified_name("requests." + name);
+    return extended || name.rfind("hugepages-", 0) == 0 || prefixed_native || name.rfind("attachable-volumes-", 0) == 0;
+}
 
 struct PodRequests {
     std::vector<int64_t> req; // per resource name

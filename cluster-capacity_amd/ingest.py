@@ -69,11 +69,33 @@ def _res(rl: Optional[dict], name: str) -> int:
     return milli_value(rl[name]) if name == "cpu" else value(rl[name])
 
 
-def is_scalar_resource(name: str) -> bool:
-    """S/util/utils.go:140-143: extended / hugepages / prefixed native / attachable-volumes resources."""
-    if name in ("cpu", "memory", "ephemeral-storage", "pods"):
+_QNAME = re.compile(r"([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9]")  # apimachinery/pkg/util/validation/validation.go:29-35
+_DNS1123_LABEL = r"[a-z0-9]([-a-z0-9]*[a-z0-9])?"                   # :176
+_DNS1123_SUBDOMAIN = re.compile(_DNS1123_LABEL + r"(\." + _DNS1123_LABEL + r")*")  # :205
+
+
+def is_qualified_name(value: str) -> bool:
+    """validation.IsQualifiedName (apimachinery/pkg/util/validation/validation.go:41-70): [dns-subdomain "/"] name, name <= 63 chars."""
+    parts = value.split("/")
+    if len(parts) == 1:
+        name = parts[0]
+    elif len(parts) == 2:
+        prefix, name = parts
+        if not prefix or len(prefix) > 253 or not _DNS1123_SUBDOMAIN.fullmatch(prefix):
+            return False
+    else:
         return False
-    return True
+    return 0 < len(name) <= 63 and _QNAME.fullmatch(name) is not None
+
+
+def is_scalar_resource(name: str) -> bool:
+    """schedutil.IsScalarResourceName (S/util/utils.go:140-143) = extended || hugepages-* || *kubernetes.io/* || attachable-volumes-*
+    (pkg/apis/core/v1/helper/helpers.go:36-66,133-135).  Anything else that is not cpu / memory / ephemeral-storage is DROPPED by
+    the scheduler's Resource.Add (S/framework/types.go), e.g. an unqualified "foo" or a "requests."-prefixed name."""
+    prefixed_native = "kubernetes.io/" in name
+    native = "/" not in name or prefixed_native
+    extended = not native and not name.startswith("requests.") and is_qualified_name("requests." + name)
+    return extended or name.startswith("hugepages-") or prefixed_native or name.startswith("attachable-volumes-")
 
 
 def _pod_level_supported(name: str) -> bool:

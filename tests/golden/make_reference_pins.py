@@ -36,6 +36,13 @@ STRINGS = {
     "preemption.not_helpful": (S + "/framework/preemption/preemption.go", r'"(Preemption is not helpful for scheduling)"'),
     "preemption.never": (P + "/defaultpreemption/default_preemption.go", r'"(not eligible due to preemptionPolicy=Never\.)"'),
     "preemption.prefix": (P + "/defaultpreemption/default_preemption.go", r'"(preemption: )"\+msg'),
+    "resource.prefix_native": ("vendor/k8s.io/api/core/v1/types.go", r'ResourceDefaultNamespacePrefix = "([^"]+)"'),
+    "resource.prefix_hugepages": ("vendor/k8s.io/api/core/v1/types.go", r'ResourceHugePagesPrefix = "([^"]+)"'),
+    "resource.prefix_attachable": ("vendor/k8s.io/api/core/v1/types.go", r'ResourceAttachableVolumesPrefix = "([^"]+)"'),
+    "resource.prefix_requests": ("vendor/k8s.io/api/core/v1/types.go", r'DefaultResourceRequestsPrefix = "([^"]+)"'),
+    "qname.char": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const qnameCharFmt string = "([^"]+)"'),
+    "qname.ext_char": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const qnameExtCharFmt string = "([^"]+)"'),
+    "qname.dns1123_label": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const dns1123LabelFmt string = "([^"]+)"'),
     "stop.limit_format": ("pkg/framework/simulator.go", r'fmt\.Sprintf\("(LimitReached: Maximum number of pods simulated: %v)"'),
     "report.headline_format": ("pkg/framework/report.go", r'fmt\.Printf\("(The cluster can schedule %v instance\(s\) of the pod %v\.)\\n"'),
     "report.termination_format": ("pkg/framework/report.go", r'fmt\.Printf\("\\n(Termination reason: %v: %v)\\n"'),
@@ -74,6 +81,8 @@ NUMBERS = {
     "search.min_feasible_percentage": (S + "/schedule_one.go", r'\n\tminFeasibleNodesPercentageToFind = (\d+)'),
     "default.percentage_of_nodes_to_score": (S + "/apis/config/types.go", r'\n\tDefaultPercentageOfNodesToScore = (\d+)'),
     "default.hard_pod_affinity_weight": (S + "/apis/config/v1/defaults.go", r'obj\.HardPodAffinityWeight = ptr\.To\[int32\]\((\d+)\)'),
+    "qname.max_length": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const qualifiedNameMaxLength int = (\d+)'),
+    "qname.dns1123_subdomain_max_length": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const DNS1123SubdomainMaxLength int = (\d+)'),
     "score.max_node_score": (S + "/framework/interface.go", r'MaxNodeScore int64 = (\d+)'),
     "image.mb": (P + "/imagelocality/image_locality.go", r'\n\tmb\s+int64 = ([\d \*]+)'),
     "image.min_threshold_mb": (P + "/imagelocality/image_locality.go", r'minThreshold\s+int64 = (\d+) \* mb'),

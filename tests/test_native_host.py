@@ -701,6 +701,11 @@ def _random_objects(rng):
     spec = pod["spec"]
     if rng.random() < 0.4:
         spec["containers"].append({"name": "x", "resources": {"requests": {"example.com/gpu": "1", "cpu": str(rng.choice(qty_cpu))}}})
+    if rng.random() < 0.3:  # resource names the scheduler drops (not scalar by schedutil.IsScalarResourceName) next to ones it keeps
+        weird = ["foo", "storage", "requests.example.com/x", "example.com/Bad Name", "a/b/c", "Example.com/x", "kubernetes.io/batch", "attachable-volumes-csi-x",
+                 "example.com/" + "n" * 63, "example.com/" + "n" * 64, "x.kubernetes.io/y", "hugepages-1Gi"]
+        spec["containers"][0].setdefault("resources", {}).setdefault("requests", {}).update(
+            {str(k): "1" for k in rng.choice(weird, int(rng.integers(1, 4)), replace=False)})
     if rng.random() < 0.3:
         spec["containers"].append({"name": "besteffort"})
     if rng.random() < 0.3:

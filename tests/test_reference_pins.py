@@ -211,3 +211,24 @@ def test_oracle_filter_order_is_the_default_plugin_order(ccref):
             got_b = r.hist_taintset[1] if _SLOT[b] is None else r.hist[_SLOT[b]]
             # (node 0 took the one clone: with host ports in play ITS reason is NodePorts too, whichever role NodePorts has in the pair)
             assert r.placed == 1 and got_a == (2 if a == "nodeports" else 1) and got_b == (1 if b == "nodeports" else 0), (first, second, r.hist.tolist())
+
+
+def test_scalar_resource_names():
+    """schedutil.IsScalarResourceName (S/util/utils.go:140-143 over pkg/apis/core/v1/helper/helpers.go:36-66,133-135 and
+    validation.IsQualifiedName): which request names become resource columns and which the scheduler drops.  The prefixes and the
+    qualified-name pieces come from the sources; the verdicts below follow from reading those functions."""
+    assert ingest._QNAME.pattern == "(" + V["qname.char"] + V["qname.ext_char"] + "*)?" + V["qname.char"]
+    assert ingest._DNS1123_LABEL == V["qname.dns1123_label"] and V["qname.max_length"] == 63 and V["qname.dns1123_subdomain_max_length"] == 253
+    assert (V["resource.prefix_native"], V["resource.prefix_hugepages"], V["resource.prefix_attachable"], V["resource.prefix_requests"]) == (
+        "kubernetes.io/", "hugepages-", "attachable-volumes-", "requests.")
+    src = open(os.path.join(ROOT, "cluster-capacity_amd", "host", "snapshot.hpp")).read() + open(os.path.join(ROOT, "cluster-capacity_amd", "ingest.py")).read()
+    for key in ("resource.prefix_native", "resource.prefix_hugepages", "resource.prefix_attachable", "resource.prefix_requests"):
+        assert src.count('"%s"' % V[key]) >= 2, key  # both hosts spell the prefix exactly
+    yes = ["nvidia.com/gpu", "example.com/gpu", "hugepages-2Mi", "hugepages-1Gi", "kubernetes.io/batch", "x.kubernetes.io/y", "attachable-volumes-csi-x",
+           "example.com/" + "n" * 63, "a-b.c/d_e.f", "requests.kubernetes.io/x"]
+    no = ["cpu", "memory", "pods", "ephemeral-storage", "storage", "foo", "requests.example.com/x", "example.com/Bad Name", "a/b/c", "Example.com/x", "example.com/",
+          "/x", "example.com/" + "n" * 64, "example..com/x", "-a.com/x", "example.com/-x", "example.com/x-"]
+    for n in yes:
+        assert ingest.is_scalar_resource(n), n
+    for n in no:
+        assert not ingest.is_scalar_resource(n), n
