@@ -294,12 +294,20 @@ def requirement_matches(key_present: bool, val: Optional[str], op: str, values: 
     if op in ("Gt", "Lt"):
         if not key_present or len(values) != 1:
             return False
-        try:
-            a, b = int(val), int(values[0])
-        except (TypeError, ValueError):
+        a, b = go_parse_int(val), go_parse_int(values[0])
+        if a is None or b is None:
             return False
         return a > b if op == "Gt" else a < b
     return False
+
+
+def go_parse_int(text) -> Optional[int]:
+    """strconv.ParseInt(text, 10, 64) as labels.Requirement.Matches uses it (apimachinery/pkg/labels/selector.go:264-289): an optional
+    sign and decimal digits, nothing else (Python's int() would also take "1_0", " 5" or "٣"), inside int64; None = the error case."""
+    if not isinstance(text, str) or not re.fullmatch(r"[+-]?[0-9]+", text):
+        return None
+    v = int(text)
+    return v if -(1 << 63) <= v < (1 << 63) else None
 
 
 def label_selector_matches(sel: Optional[dict], labels: dict) -> bool:

@@ -588,7 +588,10 @@ def test_native_host_marshals_the_c_abi_like_the_python_binding(native, recorder
 def _random_objects(rng):
     """A random cluster + pod spec drawing on every ingest feature (selectors, tolerations, affinities, constraints)."""
     keys = ["disk", "gen", "team", "topology.kubernetes.io/zone", "kubernetes.io/hostname", "rack"]
-    vals = {"disk": ["ssd", "hdd", "nvme"], "gen": ["1", "2", "3", "10", "x"], "team": ["a", "b"], "rack": ["r1", "r2", "r3", "r4"]}
+    # "gen" is compared numerically by Gt / Lt: values strconv.ParseInt takes ("+3", "-1", "007") and values it refuses although Python's int() or
+    # std::stoll would not ("1_0", "3x", beyond int64)
+    vals = {"disk": ["ssd", "hdd", "nvme"], "gen": ["1", "2", "3", "10", "x", "+3", "-1", "007", "1_0", "3x", "99999999999999999999"], "team": ["a", "b"],
+            "rack": ["r1", "r2", "r3", "r4"]}
     effects = ["NoSchedule", "PreferNoSchedule", "NoExecute"]
     qty_cpu = ["250m", "1", "2", "0.5", "1500m", "4", "3.3", "100u"]
     qty_mem = ["512Mi", "1Gi", "2G", "1500M", "3.5Gi", "1e9", "123456789", "64Ki"]
@@ -633,7 +636,7 @@ def _random_objects(rng):
             if op in ("In", "NotIn"):
                 e["values"] = [str(x) for x in rng.choice(vals[k], int(rng.integers(1, 3)), replace=False)]
             elif op in ("Gt", "Lt"):
-                e["values"] = [str(int(rng.integers(0, 5)))]
+                e["values"] = [str(rng.choice([str(int(rng.integers(0, 5))), "+2", "1_0", "-5", "9223372036854775808", "2.0"], p=[.7, .06, .06, .06, .06, .06]))]
             exprs.append(e)
         t = {"matchExpressions": exprs} if exprs or rng.random() < 0.5 else {}
         if rng.random() < 0.2:

@@ -232,3 +232,14 @@ def test_scalar_resource_names():
         assert ingest.is_scalar_resource(n), n
     for n in no:
         assert not ingest.is_scalar_resource(n), n
+
+
+def test_numeric_label_comparison_parses_integers_like_go():
+    """labels.Requirement.Matches, Gt / Lt (apimachinery/pkg/labels/selector.go:264-289): strconv.ParseInt(value, 10, 64) on both sides; a
+    value it refuses makes the requirement false.  Python's int() is more generous ("1_0", " 5", beyond int64): go_parse_int is not."""
+    f = ingest.go_parse_int
+    assert [f(x) for x in ("7", "+7", "-7", "007", "0", str((1 << 63) - 1), str(-(1 << 63)))] == [7, 7, -7, 7, 0, (1 << 63) - 1, -(1 << 63)]
+    assert [f(x) for x in ("1_0", " 5", "5 ", "", "+", "3x", "2.0", "0x10", str(1 << 63), "٣", None)] == [None] * 11
+    m = ingest.requirement_matches
+    assert m(True, "10", "Gt", ["9"]) and not m(True, "1_0", "Gt", ["9"]) and not m(True, "10", "Gt", ["9", "8"]) and not m(False, None, "Lt", ["9"])
+    assert m(True, "-2", "Lt", ["+1"]) and not m(True, "10", "Gt", ["9223372036854775808"])
