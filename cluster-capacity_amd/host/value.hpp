@@ -132,6 +132,44 @@ struct Value {
 };
 
 // ------------------------------------------------------------------------------------------------ JSON
+// Which members of a cluster object (a kubectl dump's Node / Pod / Namespace ...) the ingest reads; shared by the JSON and the YAML
+// reader.  A context says where in the object a container is; member_ctx gives the context of member `k`, or -1 = skip it.
+namespace prune {
+enum Ctx { NoCtx, Item, Items, Metadata, Status, Spec, Containers, Container, Images };
+inline bool one_of(const std::string &k, std::initializer_list<const char *> names) {
+    for (const char *n : names)
+        if (k == n) return true;
+    return false;
+}
+// `kind`: of the item being parsed ("" until its "kind" member was seen); images_filtered / images_none: status.images is filtered
+// by the template's image names / dropped altogether (no template names an image)
+inline int member_ctx(Ctx c, const std::string &k, const std::string &kind, bool images_filtered, bool images_none) {
+    switch (c) {
+    case Item:
+        if (k == "items") return Items; // a List: its elements are objects again
+        if (k == "metadata") return Metadata;
+        if (k == "status") return Status;
+        if (k == "spec") return Spec;
+        return NoCtx;
+    case Metadata:
+        if (one_of(k, {"managedFields", "ownerReferences", "finalizers"})) return -1;
+        if (k == "annotations" && !kind.empty() && kind != "Namespace") return -1;
+        return NoCtx;
+    case Status:
+        if (k == "images") return images_filtered ? (images_none ? -1 : (int)Images) : (int)NoCtx;
+        return one_of(k, {"phase", "allocatable"}) ? NoCtx : -1;
+    case Spec:
+        if (one_of(k, {"containers", "initContainers"})) return Containers;
+        if (one_of(k, {"volumes", "securityContext", "imagePullSecrets", "dnsConfig", "hostAliases", "readinessGates", "tolerations", "ephemeralContainers"})) return -1;
+        return NoCtx;
+    case Container:
+        return one_of(k, {"env", "envFrom", "volumeMounts", "volumeDevices", "livenessProbe", "readinessProbe", "startupProbe", "lifecycle", "securityContext",
+                          "command", "args"}) ? -1 : NoCtx;
+    default: return NoCtx;
+    }
+}
+} // namespace prune
+
 // `prune_cluster_objects`: the document is a kubectl dump of cluster objects (Nodes, Pods, Namespaces, ... or Lists of them)
 // and only the fields the ingest reads are materialised; the rest is skipped without building it -- metadata.managedFields /
 // ownerReferences / finalizers / annotations (kept for Namespaces: genpod reads them), every status field except phase /
@@ -156,39 +194,11 @@ class JsonParser {
     // containers name, a node lists tens); nullptr = keep every entry
     const std::vector<std::string> *wanted_images_;
     size_t i_ = 0;
-    enum Ctx { NoCtx, Item, Items, Metadata, Status, Spec, Containers, Container, Images };
+    using Ctx = prune::Ctx;
+    static constexpr Ctx NoCtx = prune::NoCtx, Item = prune::Item, Items = prune::Items, Containers = prune::Containers, Container = prune::Container,
+                         Images = prune::Images;
     std::string kind_; // of the item being parsed ("" until its "kind" member was seen)
-    static bool one_of(const std::string &k, std::initializer_list<const char *> names) {
-        for (const char *n : names)
-            if (k == n) return true;
-        return false;
-    }
-    // -> the context of member `k` of an object in context `c`, or -1 to skip the member
-    int member_ctx(Ctx c, const std::string &k) const {
-        switch (c) {
-        case Item:
-            if (k == "items") return Items; // a List: its elements are objects again
-            if (k == "metadata") return Metadata;
-            if (k == "status") return Status;
-            if (k == "spec") return Spec;
-            return NoCtx;
-        case Metadata:
-            if (one_of(k, {"managedFields", "ownerReferences", "finalizers"})) return -1;
-            if (k == "annotations" && !kind_.empty() && kind_ != "Namespace") return -1;
-            return NoCtx;
-        case Status:
-            if (k == "images") return wanted_images_ ? (wanted_images_->empty() ? -1 : (int)Images) : (int)NoCtx;
-            return one_of(k, {"phase", "allocatable"}) ? NoCtx : -1;
-        case Spec:
-            if (one_of(k, {"containers", "initContainers"})) return Containers;
-            if (one_of(k, {"volumes", "securityContext", "imagePullSecrets", "dnsConfig", "hostAliases", "readinessGates", "tolerations", "ephemeralContainers"})) return -1;
-            return NoCtx;
-        case Container:
-            return one_of(k, {"env", "envFrom", "volumeMounts", "volumeDevices", "livenessProbe", "readinessProbe", "startupProbe", "lifecycle", "securityContext",
-                              "command", "args"}) ? -1 : NoCtx;
-        default: return NoCtx;
-        }
-    }
+    int member_ctx(Ctx c, const std::string &k) const { return prune::member_ctx(c, k, kind_, wanted_images_ != nullptr, wanted_images_ && wanted_images_->empty()); }
     void skip_string() { // at the opening quote
         const char *p = s_.data() + i_ + 1, *const e = s_.data() + s_.size();
         while (p < e) {
@@ -518,7 +528,11 @@ inline void to_json(std::string &out, const Value &v) {
 // ------------------------------------------------------------------------------------------------ YAML (subset)
 class YamlParser {
   public:
-    explicit YamlParser(const std::string &src) { split_lines(src); }
+    // prune_cluster_objects / images: as for JsonParser (members the ingest does not read are skipped by indentation, never built;
+    // status.images is dropped when no template names an image -- entries are not filtered one by one here)
+    explicit YamlParser(const std::string &src, bool prune_cluster_objects = false, bool images_none = false) : prune_(prune_cluster_objects), images_none_(images_none) {
+        split_lines(src);
+    }
     // every document of the stream (--- separators); empty documents are dropped
     std::vector<Value> parse_stream() {
         std::vector<Value> docs;
@@ -529,6 +543,7 @@ class YamlParser {
                 pos_++;
                 continue;
             }
+            next_ctx_ = prune_ ? prune::Item : prune::NoCtx;
             Value v = parse_node(lines_[pos_].indent);
             if (!v.is_null()) docs.push_back(std::move(v));
         }
@@ -923,6 +938,29 @@ class YamlParser {
         }
         return k;
     }
+    const bool prune_, images_none_;
+    prune::Ctx next_ctx_ = prune::NoCtx; // the context of the next container parse_mapping / parse_sequence opens (consumed there)
+    std::string kind_;
+    prune::Ctx take_ctx() {
+        const prune::Ctx c = next_ctx_;
+        next_ctx_ = prune::NoCtx;
+        return c;
+    }
+    // a skipped member: everything more indented than its key, plus -- for a key with nothing after the colon -- the sequence items
+    // that sit at the key's own indentation ("key:\n- a\n- b")
+    void skip_member(int key_indent, bool rest_empty) {
+        while (pos_ < lines_.size()) {
+            const Line &l = lines_[pos_];
+            if (l.text.empty()) {
+                pos_++;
+                continue;
+            }
+            if (is_doc_marker(l.text)) break;
+            const bool item_here = rest_empty && l.indent == key_indent && l.text[0] == '-' && (l.text.size() == 1 || l.text[1] == ' ');
+            if (l.indent > key_indent || item_here) pos_++;
+            else break;
+        }
+    }
     Value parse_node(int indent) {
         skip_blank();
         if (pos_ >= lines_.size()) return Value();
@@ -938,12 +976,15 @@ class YamlParser {
     }
     Value parse_sequence(int indent) {
         Value v = Value::array();
+        const prune::Ctx ctx = take_ctx();
+        const prune::Ctx elem = ctx == prune::Items ? prune::Item : ctx == prune::Containers ? prune::Container : prune::NoCtx;
         while (true) {
             skip_blank();
             if (pos_ >= lines_.size()) break;
             Line &l = lines_[pos_];
             if (l.indent != indent || is_doc_marker(l.text)) break;
             if (!(l.text[0] == '-' && (l.text.size() == 1 || l.text[1] == ' '))) break;
+            next_ctx_ = elem;
             std::string rest = l.text.size() > 1 ? l.text.substr(2) : "";
             size_t lead = 0;
             while (lead < rest.size() && rest[lead] == ' ') lead++;
@@ -966,10 +1007,13 @@ class YamlParser {
                 v.a.push_back(parse_inline_or_nested(rest, indent, true));
             }
         }
+        next_ctx_ = prune::NoCtx;
         return v;
     }
     Value parse_mapping(int indent) {
         Value v = Value::object();
+        const prune::Ctx ctx = take_ctx();
+        if (ctx == prune::Item) kind_.clear();
         while (true) {
             skip_blank();
             if (pos_ >= lines_.size()) break;
@@ -983,7 +1027,15 @@ class YamlParser {
             while (lead < rest.size() && rest[lead] == ' ') lead++;
             rest = rest.substr(lead);
             pos_++;
+            const int sub = ctx == prune::NoCtx ? (int)prune::NoCtx : prune::member_ctx(ctx, key, kind_, true, images_none_);
+            if (sub < 0) {
+                skip_member(indent, rest.empty());
+                continue;
+            }
+            next_ctx_ = sub == prune::Images ? prune::NoCtx : (prune::Ctx)sub; // (image entries are not filtered here)
             v.o.emplace_back(key, parse_inline_or_nested(rest, indent, false));
+            next_ctx_ = prune::NoCtx; // (a scalar value opened no container)
+            if (ctx == prune::Item && key == "kind") kind_ = v.o.back().second.text();
         }
         return v;
     }
@@ -1086,7 +1138,7 @@ inline std::vector<Value> parse_documents(std::string_view text, bool prune_clus
             if (text.size() > (32u << 20)) throw; // (not at this size: a broken multi-hundred-MB JSON dump should say where it is broken)
         }
     }
-    YamlParser y{std::string(text)};
+    YamlParser y{std::string(text), prune_cluster_objects, wanted_images != nullptr && wanted_images->empty()};
     return y.parse_stream();
 }
 

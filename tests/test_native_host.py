@@ -1339,6 +1339,11 @@ def test_pruned_parse_of_decorated_dumps_gives_the_same_snapshot(native, tmp_pat
             env = dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_PARALLEL_MIN_ITEMS="0", CCHOST_THREADS=str(2 + seed % 3))
             par = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
             assert par.returncode == 0 and par.stdout == outs[-1], par.stderr
+        if deco:  # ... and as YAML (block style as kubectl / PyYAML emit it, long strings folded, quoted where needed): pruned by indentation
+            (d / "cluster.yaml").write_text(yaml.safe_dump({"kind": "List", "apiVersion": "v1", "items": objs}, default_flow_style=False, width=int(rng.choice([60, 80, 1000]))))
+            assert yaml.safe_load(open(d / "cluster.yaml"))["items"] == objs
+            yargs = ["--podspec", str(d / "pod.json"), "--snapshot", str(d / "cluster.yaml"), "--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
+            assert _run(native, yargs) == outs[0]
         # genpod reads Namespace annotations: they survive the pruning whatever the member order
         g = yaml.safe_load(_run(native, ["--genpod", "default", "--snapshot", str(d / "cluster.json")]))
         assert g["spec"]["nodeSelector"] == {"disk": "ssd"}
