@@ -16,6 +16,8 @@ from __future__ import annotations
 import argparse
 import datetime
 import json
+import math
+from fractions import Fraction
 import sys
 from typing import List, Optional
 
@@ -82,31 +84,23 @@ def parse_pod_spec(path: str, scheduler_name: str = "default-scheduler") -> dict
     return pod
 
 
-def _fmt_quantity_milli(milli: int) -> str:
-    return f"{milli // 1000}" if milli % 1000 == 0 else f"{milli}m"
-
-
-def _fmt_quantity_binary(v: int) -> str:
-    for suf, mul in (("Ei", 2**60), ("Pi", 2**50), ("Ti", 2**40), ("Gi", 2**30), ("Mi", 2**20), ("Ki", 2**10)):
-        if v and v % mul == 0:
-            return f"{v // mul}{suf}"
-    return str(v)
-
-
 def pod_requirements(pod: dict) -> dict:
-    """report.go:111-144 getResourceRequest (containers only) + :182-194."""
-    cpu = mem = 0
+    """report.go:111-144 getResourceRequest (containers only) + :182-194.  cpu and memory are sums of Quantities printed by
+    Quantity.String(): the container's quantity is the receiver of Add (`rQuantity.Add(sum so far)`), so the sum carries the Format
+    of the LAST container that names the resource with a non-zero amount (quantity.go:600-613), starting from DecimalSI (cpu) /
+    BinarySI (memory): `memory: 512M` prints as 512M, `512Mi` as 512Mi, 1Gi + 512Mi as 1536Mi."""
+    total = {"cpu": (Fraction(0), "DecimalSI"), "memory": (Fraction(0), "BinarySI")}
     scalars = {}
     for c in pod["spec"].get("containers") or []:
         for name, q in ((c.get("resources") or {}).get("requests") or {}).items():
-            if name == "cpu":
-                cpu += ingest.milli_value(q)
-            elif name == "memory":
-                mem += ingest.value(q)
+            if name in total:
+                v = Fraction(math.ceil(ingest.parse_quantity(q) * 10**9), 10**9)
+                acc_v, acc_fmt = total[name]
+                total[name] = (v + acc_v, ingest.quantity_format(q) if v != 0 else acc_fmt)
             elif ingest.is_scalar_resource(name):
                 scalars[name] = scalars.get(name, 0) + ingest.value(q)
     return {"podName": pod["metadata"].get("name", ""),
-            "resources": {"primaryResources": {"cpu": _fmt_quantity_milli(cpu), "memory": _fmt_quantity_binary(mem),
+            "resources": {"primaryResources": {"cpu": ingest.quantity_canonical(*total["cpu"]), "memory": ingest.quantity_canonical(*total["memory"]),
                                                "nvidia.com/gpu": "0"},
                           "scalarResources": scalars or None},
             "nodeSelectors": pod["spec"].get("nodeSelector")}

@@ -112,6 +112,64 @@ inline int64_t quantity_ceil(const Quantity &q, int scale10) {
     return (int64_t)v;
 }
 
+// ---- Quantity.String(), for the report's podRequirements (report.go:111-144 sums Quantities and prints them) ----------------
+enum class QuantityFormat { DecimalSI, BinarySI, DecimalExponent };
+// the Format a parsed Quantity carries (quantity.go:283-384 -> suffix.go interpret)
+inline QuantityFormat quantity_format(const std::string &text) {
+    size_t e = text.size();
+    while (e > 0 && (text[e - 1] == ' ' || text[e - 1] == '\t')) e--;
+    if (e >= 2 && text[e - 1] == 'i' && std::string("KMGTPE").find(text[e - 2]) != std::string::npos) return QuantityFormat::BinarySI;
+    for (size_t i = 0; i < e; i++)
+        if ((text[i] == 'e' || text[i] == 'E') && i + 1 < e) return QuantityFormat::DecimalExponent; // (a trailing E alone is exa)
+    return QuantityFormat::DecimalSI;
+}
+// the value in nano units, rounded up (ParseQuantity keeps nine decimal places, rounding up); non-negative quantities only
+inline __int128 quantity_nano(const Quantity &q) {
+    __int128 v = q.mant;
+    for (int k = 0; k < q.exp2; k++) v *= 2;
+    int e = q.exp10 + 9;
+    while (e > 0) v *= 10, e--;
+    if (e < 0) {
+        __int128 d = 1;
+        for (int k = 0; k < -e && d < ((__int128)1 << 120); k++) d *= 10;
+        v = v / d + (v % d > 0 ? 1 : 0);
+    }
+    return v;
+}
+inline std::string int128_text(__int128 v) {
+    if (v == 0) return "0";
+    std::string s;
+    for (; v > 0; v /= 10) s.insert(s.begin(), (char)('0' + (int)(v % 10)));
+    return s;
+}
+// quantity.go:424-461 CanonicalizeBytes; amount.go:257-293; math.go:262-287: BinarySI prints an integer >= 1024 as <n><Ki|Mi|..> with
+// every factor of 1024 removed and falls back to DecimalSI below 1024 or for a fractional value; the decimal forms print
+// mantissa x 10^exponent with the trailing zeros removed and the exponent lowered to a multiple of 3 (12000 -> 12k, 1.5 -> 1500m)
+inline std::string quantity_canonical(__int128 nano, QuantityFormat fmt) {
+    if (nano == 0) return "0";
+    const __int128 G = 1000000000;
+    if (fmt == QuantityFormat::BinarySI) {
+        if (nano < 1024 * G || nano % G != 0) fmt = QuantityFormat::DecimalSI;
+        else {
+            static const char *suf[] = {"", "Ki", "Mi", "Gi", "Ti", "Pi", "Ei"};
+            __int128 m = nano / G;
+            int t = 0;
+            while (m >= 1024 && m % 1024 == 0 && t < 6) m /= 1024, t++;
+            return int128_text(m) + suf[t];
+        }
+    }
+    __int128 m = nano;
+    int e = -9;
+    while (m >= 10 && m % 10 == 0) m /= 10, e++;
+    switch (e % 3) { // (C++ and Go agree: the remainder keeps the sign of the dividend)
+    case 1: case -2: m *= 10, e -= 1; break;
+    case 2: case -1: m *= 100, e -= 2; break;
+    }
+    if (fmt == QuantityFormat::DecimalExponent) return int128_text(m) + (e ? "e" + std::to_string(e) : "");
+    static const char *dec[] = {"n", "u", "m", "", "k", "M", "G", "T", "P", "E"};
+    return int128_text(m) + (e >= -9 && e <= 18 ? dec[(e + 9) / 3] : "");
+}
+
 inline int64_t quantity_value(const std::string &text) { return quantity_ceil(parse_quantity(text), 0); }
 inline int64_t quantity_milli_value(const std::string &text) { return quantity_ceil(parse_quantity(text), 3); }
 

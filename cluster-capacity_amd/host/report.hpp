@@ -167,17 +167,26 @@ inline std::string fmt_quantity_binary(int64_t v) {
 }
 
 // report.go:111-144 getResourceRequest (containers only) + :182-194
+// cpu and memory are sums of Quantities printed by Quantity.String(): the container's quantity is the receiver of Add
+// (`rQuantity.Add(sum so far)`), so the sum carries the Format of the LAST container that names the resource with a non-zero amount
+// (quantity.go:600-613), starting from DecimalSI (cpu) / BinarySI (memory): `memory: 512M` prints as 512M, 1Gi + 512Mi as 1536Mi.
 inline Value pod_requirements(const Value &pod) {
-    int64_t cpu = 0, mem = 0;
+    __int128 cpu = 0, mem = 0; // nano units
+    QuantityFormat cpu_fmt = QuantityFormat::DecimalSI, mem_fmt = QuantityFormat::BinarySI;
     Value scalars = Value::object();
     for (const auto &c : pod["spec"]["containers"].items())
         for (const auto &kv : c["resources"]["requests"].fields()) {
-            if (kv.first == "cpu") cpu += quantity_milli_value(kv.second.text());
-            else if (kv.first == "memory") mem += quantity_value(kv.second.text());
-            else if (is_scalar_resource(kv.first)) scalars.set(kv.first, Value::num(scalars[kv.first].as_int() + quantity_value(kv.second.text())));
+            if (kv.first == "cpu" || kv.first == "memory") {
+                const __int128 v = quantity_nano(parse_quantity(kv.second.text()));
+                __int128 &acc = kv.first == "cpu" ? cpu : mem;
+                QuantityFormat &fmt = kv.first == "cpu" ? cpu_fmt : mem_fmt;
+                if (v != 0) fmt = quantity_format(kv.second.text());
+                acc += v;
+            } else if (is_scalar_resource(kv.first))
+                scalars.set(kv.first, Value::num(scalars[kv.first].as_int() + quantity_value(kv.second.text())));
         }
     Value prim = Value::object();
-    prim.set("cpu", Value::str(fmt_quantity_milli(cpu))), prim.set("memory", Value::str(fmt_quantity_binary(mem))), prim.set("nvidia.com/gpu", Value::str("0"));
+    prim.set("cpu", Value::str(quantity_canonical(cpu, cpu_fmt))), prim.set("memory", Value::str(quantity_canonical(mem, mem_fmt))), prim.set("nvidia.com/gpu", Value::str("0"));
     Value res = Value::object();
     res.set("primaryResources", prim), res.set("scalarResources", scalars.o.empty() ? Value() : scalars);
     Value o = Value::object();

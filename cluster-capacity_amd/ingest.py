@@ -53,6 +53,47 @@ def parse_quantity(q) -> Fraction:
     return num * (_BIN[suf] if suf in _BIN else _DEC[suf])
 
 
+def quantity_format(q) -> str:
+    """The Format a parsed Quantity carries (quantity.go:283-384 ParseQuantity -> suffix.go interpret): binary suffix -> BinarySI,
+    e / E exponent -> DecimalExponent, anything else -> DecimalSI."""
+    m = _Q.match(str(q).strip())
+    if m and m.group(2):
+        return "DecimalExponent"
+    return "BinarySI" if m and (m.group(3) or "") in _BIN else "DecimalSI"
+
+
+_DEC_SUFFIX = {-9: "n", -6: "u", -3: "m", 0: "", 3: "k", 6: "M", 9: "G", 12: "T", 15: "P", 18: "E"}
+
+
+def quantity_canonical(v: Fraction, fmt: str) -> str:
+    """Quantity.String() for a non-negative value (quantity.go:424-461 CanonicalizeBytes; amount.go:257-293; math.go:262-287):
+    BinarySI prints an integer >= 1024 as <n><Ki|Mi|..> with every factor of 1024 removed, and falls back to DecimalSI below 1024
+    or for a fractional value; the decimal forms print mantissa x 10^exponent with the trailing zeros removed and the exponent
+    lowered to a multiple of 3 (12000 -> 12k, 1200 -> 1200, 1.5 -> 1500m).  Values are kept to the nano, rounded up, as
+    ParseQuantity does."""
+    n = math.ceil(v * 10**9)  # nano units
+    if n == 0:
+        return "0"
+    if fmt == "BinarySI":
+        if n < 1024 * 10**9 or n % 10**9:
+            fmt = "DecimalSI"
+        else:
+            m, t = n // 10**9, 0
+            while m >= 1024 and m % 1024 == 0:
+                m, t = m // 1024, t + 1
+            return f"{m}{['', 'Ki', 'Mi', 'Gi', 'Ti', 'Pi', 'Ei'][t]}"
+    m, e = n, -9
+    while m >= 10 and m % 10 == 0:
+        m, e = m // 10, e + 1
+    if e % 3 == 1:  # (Go's remainder keeps the sign of the dividend: 1 and -2 are Python's 1; 2 and -1 are Python's 2)
+        m, e = m * 10, e - 1
+    elif e % 3 == 2:
+        m, e = m * 100, e - 2
+    if fmt == "DecimalExponent":
+        return f"{m}e{e}" if e else f"{m}"
+    return f"{m}{_DEC_SUFFIX.get(e, '')}"
+
+
 def value(q) -> int:
     """Quantity.Value(): rounded up to an integer (quantity.go:813-820)."""
     return math.ceil(parse_quantity(q))

@@ -1397,3 +1397,55 @@ def test_several_templates_unschedulable_stop_names_the_failing_template(native,
         assert json.loads(p.stdout)["status"]["failReason"] == want["status"]["failReason"], failing
         assert ("not modelled" in p.stderr) and ("not modelled" in capsys.readouterr().err)
         assert ("untolerated taint {dedicated: x}" in want["status"]["failReason"]["failMessage"]) == (failing != 1)
+
+
+# ---- podRequirements: sums of Quantities printed by Quantity.String() -----------------------------------------------------------------
+def _requirements(native, tmp_path, cpu, mem):
+    pod = yaml.safe_load(EXAMPLES_POD)
+    k = max(len(cpu), len(mem))
+    cpu, mem = list(cpu) + [None] * (k - len(cpu)), list(mem) + [None] * (k - len(mem))
+    pod["spec"]["containers"] = [{"name": f"c{i}", "resources": {"requests": {k: v for k, v in (("cpu", c), ("memory", m)) if v is not None}}}
+                                 for i, (c, m) in enumerate(zip(cpu, mem))]
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    (tmp_path / "cluster.json").write_text(json.dumps({"kind": "List", "items": [dict(node("n1"), kind="Node")]}))
+    (tmp_path / "result.json").write_text(json.dumps({"placed": 0, "stop": M.STOP_LIMIT, "n_code_unschedulable": 0, "per_node_count": [0], "log": [],
+                                                      "hist": [0] * M.NREASON, "hist_taintset": [0]}))
+    out = json.loads(_run(native, ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "cluster.json"), "--fake-result", str(tmp_path / "result.json"),
+                                   "--max-limit", "1", "-o", "json"]))
+    got = out["spec"]["podRequirements"][0]["resources"]["primaryResources"]
+    want = cli.pod_requirements(cli.parse_pod_spec(str(tmp_path / "pod.json")))["resources"]["primaryResources"]
+    assert got == want, (cpu, mem)
+    return got["cpu"], got["memory"]
+
+
+def test_pod_requirements_print_quantities_like_the_reference(native, tmp_path):
+    """report.go:111-144 + Quantity.String() (quantity.go:424-461,600-613; amount.go:257-293), derived by hand from those lines:
+    the sum takes the format of the last non-zero addend; BinarySI removes factors of 1024 and falls back to decimal below 1024 or
+    for fractions; the decimal forms strip trailing zeros and lower the exponent to a multiple of three."""
+    f = lambda cpu, mem: _requirements(native, tmp_path, cpu, mem)
+    assert f(["150m"], ["100Mi"]) == ("150m", "100Mi")
+    assert f(["1", "500m"], ["1Gi", "512Mi"]) == ("1500m", "1536Mi")
+    assert f(["2"], ["512M"]) == ("2", "512M")                      # a decimal memory request stays decimal
+    assert f(["12000"], ["1G", "1Gi"]) == ("12k", "2073741824")     # 1e9 + 2^30 in BinarySI: no factor of 1024 left
+    assert f(["0.1"], ["500"]) == ("100m", "500")
+    assert f(["1e3"], ["1.5Gi"]) == ("1e3", "1536Mi")
+    assert f(["100m", "1e3"], ["0.5"]) == ("1000100e-3", "500m")
+    assert f(["1500u"], ["1000Ki"]) == ("1500u", "1000Ki")
+    assert f(["0", None], [None, "128974848"]) == ("0", "128974848")
+    assert f(["1Gi"], ["1Gi", "0"]) == ("1Gi", "1Gi")               # a zero addend leaves the format alone
+    assert f([None], [None]) == ("0", "0")
+
+
+def test_pod_requirements_random_quantities(native, tmp_path):
+    rng = np.random.default_rng(31)
+    sufs = ["", "m", "u", "n", "k", "M", "G", "Ki", "Mi", "Gi", "e3", "e-3", "E2"]
+    def q():
+        if rng.random() < 0.15:
+            return None
+        num = str(int(rng.integers(0, 5000))) if rng.random() < 0.6 else f"{rng.integers(0, 500)}.{rng.integers(0, 1000):03d}"
+        return num + str(rng.choice(sufs))
+    for k in range(60):
+        n = int(rng.integers(1, 4))
+        d = tmp_path / str(k)
+        d.mkdir()
+        _requirements(native, d, [q() for _ in range(n)], [q() for _ in range(n)])
