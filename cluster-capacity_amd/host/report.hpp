@@ -158,14 +158,6 @@ inline Value replicas_on_nodes(const RunResult &r, const std::vector<std::string
     return a;
 }
 
-inline std::string fmt_quantity_milli(int64_t milli) { return milli % 1000 == 0 ? std::to_string(milli / 1000) : std::to_string(milli) + "m"; }
-inline std::string fmt_quantity_binary(int64_t v) {
-    static const std::pair<const char *, int> suf[] = {{"Ei", 60}, {"Pi", 50}, {"Ti", 40}, {"Gi", 30}, {"Mi", 20}, {"Ki", 10}};
-    for (const auto &s : suf)
-        if (v && v % ((int64_t)1 << s.second) == 0) return std::to_string(v >> s.second) + s.first;
-    return std::to_string(v);
-}
-
 // report.go:111-144 getResourceRequest (containers only) + :182-194
 // cpu and memory are sums of Quantities printed by Quantity.String(): the container's quantity is the receiver of Add
 // (`rQuantity.Add(sum so far)`), so the sum carries the Format of the LAST container that names the resource with a non-zero amount
