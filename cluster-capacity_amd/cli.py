@@ -153,7 +153,8 @@ def pretty(review: dict, verbose: bool) -> str:
             out.append(f"\t- CPU: {req['resources']['primaryResources']['cpu']}")
             out.append(f"\t- Memory: {req['resources']['primaryResources']['memory']}")
             if req["resources"]["scalarResources"] is not None:
-                out.append(f"\t- ScalarResources: {req['resources']['scalarResources']}")
+                # fmt's %v of a map[v1.ResourceName]int64: map[key:value key:value], keys sorted (report.go:244-246)
+                out.append("\t- ScalarResources: map[" + " ".join(f"{k}:{v}" for k, v in sorted(req["resources"]["scalarResources"].items())) + "]")
             if req["nodeSelectors"] is not None:
                 out.append("\t- NodeSelector: " + ",".join(f"{k}={v}" for k, v in sorted(req["nodeSelectors"].items())))
             out.append("")

@@ -240,11 +240,13 @@ inline std::string pretty(const Value &review, bool verbose) {
             line(req["podName"].text() + " pod requirements:");
             line("\t- CPU: " + req["resources"]["primaryResources"]["cpu"].text());
             line("\t- Memory: " + req["resources"]["primaryResources"]["memory"].text());
-            if (!req["resources"]["scalarResources"].is_null()) { // python prints the dict: {'name': value, ...}
-                std::string d = "{";
-                bool first = true;
-                for (const auto &kv : req["resources"]["scalarResources"].fields()) d += std::string(first ? "" : ", ") + "'" + kv.first + "': " + kv.second.text(), first = false;
-                line("\t- ScalarResources: " + d + "}");
+            if (!req["resources"]["scalarResources"].is_null()) { // fmt's %v of a map[v1.ResourceName]int64: map[key:value key:value], keys sorted
+                std::vector<std::pair<std::string, std::string>> kv;
+                for (const auto &f : req["resources"]["scalarResources"].fields()) kv.emplace_back(f.first, f.second.text());
+                std::sort(kv.begin(), kv.end());
+                std::string d;
+                for (size_t i = 0; i < kv.size(); i++) d += (i ? " " : "") + kv[i].first + ":" + kv[i].second;
+                line("\t- ScalarResources: map[" + d + "]");
             }
             if (!req["nodeSelectors"].is_null()) {
                 std::vector<std::pair<std::string, std::string>> kv;

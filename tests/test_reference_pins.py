@@ -243,3 +243,16 @@ def test_numeric_label_comparison_parses_integers_like_go():
     m = ingest.requirement_matches
     assert m(True, "10", "Gt", ["9"]) and not m(True, "1_0", "Gt", ["9"]) and not m(True, "10", "Gt", ["9", "8"]) and not m(False, None, "Lt", ["9"])
     assert m(True, "-2", "Lt", ["+1"]) and not m(True, "10", "Gt", ["9223372036854775808"])
+
+
+def test_verbose_requirements_block_follows_the_reference_format():
+    """report.go:236-252: `%v` of the ScalarResources map prints Go's map syntax with sorted keys; the node selector prints as
+    labels.SelectorFromSet(...).String() (sorted k=v pairs joined by commas)."""
+    review = {"spec": {"podRequirements": [{"podName": "p", "resources": {"primaryResources": {"cpu": "150m", "memory": "100Mi"},
+                                                                          "scalarResources": {"hugepages-2Mi": 2097152, "example.com/gpu": 1}},
+                                            "nodeSelectors": {"zone": "a", "disk": "ssd"}}]},
+              "status": {"replicas": 0, "failReason": {"failType": "T", "failMessage": "m"}, "pods": [{"podName": "p", "replicasOnNodes": []}]}}
+    out = cli.pretty(review, True)
+    assert "\t- ScalarResources: map[example.com/gpu:1 hugepages-2Mi:2097152]\n" in out
+    assert "\t- NodeSelector: disk=ssd,zone=a\n" in out
+    assert "\t- CPU: 150m\n\t- Memory: 100Mi\n" in out
