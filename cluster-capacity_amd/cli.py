@@ -135,7 +135,8 @@ def build_review(pod, snap: ingest.Snapshot, result: M.RunResult, max_limit: int
     return {
         "spec": {"templates": pods, "replicas": 0, "podRequirements": [pod_requirements(p) for p in pods]},
         "status": {
-            "creationTimestamp": datetime.datetime.now(datetime.timezone.utc).isoformat(),
+            # time.Time marshals as RFC 3339 with "Z" for UTC (report.go:56, getReviewStatus :214-221)
+            "creationTimestamp": datetime.datetime.now(datetime.timezone.utc).isoformat().replace("+00:00", "Z"),
             "replicas": int(result.placed),
             "failReason": R.main_fail_reason(stop),
             "pods": [{"podName": p["metadata"].get("name", ""), "replicasOnNodes": per_template[t], "failSummary": None}

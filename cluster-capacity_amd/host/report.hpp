@@ -191,7 +191,7 @@ inline std::string utc_now_iso() {
     std::tm tm{};
     gmtime_r(&t, &tm);
     char buf[40];
-    std::strftime(buf, sizeof buf, "%Y-%m-%dT%H:%M:%S+00:00", &tm);
+    std::strftime(buf, sizeof buf, "%Y-%m-%dT%H:%M:%SZ", &tm); // time.Time marshals as RFC 3339 with "Z" for UTC
     return buf;
 }
 
