@@ -101,7 +101,7 @@ def pod_requirements(pod: dict) -> dict:
                 scalars[name] = scalars.get(name, 0) + ingest.value(q)
     return {"podName": pod["metadata"].get("name", ""),
             "resources": {"primaryResources": {"cpu": ingest.quantity_canonical(*total["cpu"]), "memory": ingest.quantity_canonical(*total["memory"]),
-                                               "nvidia.com/gpu": "0"},
+                                               "nvdia.com/gpu": "0"},  # sic: ResourceNvidiaGPU = "nvdia.com/gpu" (report.go:34)
                           "scalarResources": scalars or None},
             "nodeSelectors": pod["spec"].get("nodeSelector")}
 
@@ -219,7 +219,7 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         except genpod.GenpodError as e:
             sys.stderr.write(f"Error: {e}\n")
             return 1
-        out.write(json.dumps(pod) + "\n" if args.output == "json" else yaml.safe_dump(pod, sort_keys=False))
+        out.write(json.dumps(pod) + "\n" if args.output == "json" else yaml.safe_dump(pod, sort_keys=True))  # the YAML serializer goes through JSON: keys sorted
         return 0
     if not args.podspec:
         ap.error("Pod spec file is missing")
@@ -249,7 +249,7 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     if args.output == "json":
         out.write(json.dumps(review) + "\n")
     elif args.output == "yaml":
-        out.write(yaml.safe_dump(review, sort_keys=False))
+        out.write(yaml.safe_dump(review, sort_keys=True))  # sigs.k8s.io/yaml marshals through JSON: keys sorted (report.go:296-303)
     else:
         out.write(pretty(review, args.verbose))
     return 0

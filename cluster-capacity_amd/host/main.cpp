@@ -245,7 +245,7 @@ int main(int argc, char **argv) {
             const Value pod = namespace_pod(genpod_ns, load_kind(snapshots, "Namespace"), load_kind(snapshots, "LimitRange"));
             std::string out;
             if (output == "json") to_json(out, pod), out += "\n";
-            else to_yaml(out, pod); // PrintPod (pkg/utils/utils.go:47-71): yaml unless json is asked for
+            else to_yaml(out, sorted_keys(pod)); // PrintPod (pkg/utils/utils.go:47-71): yaml unless json is asked for
             std::cout << out;
             return 0;
         } catch (const std::exception &e) {
@@ -296,7 +296,7 @@ int main(int argc, char **argv) {
         cc.Close();
         std::string out;
         if (output == "json") to_json(out, review), out += "\n";
-        else if (output == "yaml") to_yaml(out, review);
+        else if (output == "yaml") to_yaml(out, sorted_keys(review));
         else out = pretty(review, verbose);
         std::cout << out;
         // the object trees of a large dump take longer to free() node by node than the OS takes to reclaim the pages

@@ -178,7 +178,7 @@ inline Value pod_requirements(const Value &pod) {
                 scalars.set(kv.first, Value::num(scalars[kv.first].as_int() + quantity_value(kv.second.text())));
         }
     Value prim = Value::object();
-    prim.set("cpu", Value::str(quantity_canonical(cpu, cpu_fmt))), prim.set("memory", Value::str(quantity_canonical(mem, mem_fmt))), prim.set("nvidia.com/gpu", Value::str("0"));
+    prim.set("cpu", Value::str(quantity_canonical(cpu, cpu_fmt))), prim.set("memory", Value::str(quantity_canonical(mem, mem_fmt))), prim.set("nvdia.com/gpu", Value::str("0")); // sic: ResourceNvidiaGPU = "nvdia.com/gpu" (report.go:34)
     Value res = Value::object();
     res.set("primaryResources", prim), res.set("scalarResources", scalars.o.empty() ? Value() : scalars);
     Value o = Value::object();

@@ -1064,6 +1064,15 @@ inline bool yaml_needs_quotes(const std::string &s) {
 }
 
 // block-style YAML in the shape python's yaml.safe_dump(sort_keys=False) produces for these reviews
+// the same tree with every mapping's members in key order: what a YAML document looks like after sigs.k8s.io/yaml marshalled it
+// through JSON (the reference's -o yaml, report.go:296-303, and its PrintPod)
+inline Value sorted_keys(Value v) {
+    for (auto &x : v.a) x = sorted_keys(std::move(x));
+    for (auto &kv : v.o) kv.second = sorted_keys(std::move(kv.second));
+    std::stable_sort(v.o.begin(), v.o.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    return v;
+}
+
 inline void to_yaml(std::string &out, const Value &v, int indent = 0, bool in_seq_item = false) {
     const std::string pad((size_t)indent, ' ');
     auto scalar = [&](const Value &x) {

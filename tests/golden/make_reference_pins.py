@@ -43,6 +43,7 @@ STRINGS = {
     "qname.char": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const qnameCharFmt string = "([^"]+)"'),
     "qname.ext_char": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const qnameExtCharFmt string = "([^"]+)"'),
     "qname.dns1123_label": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const dns1123LabelFmt string = "([^"]+)"'),
+    "report.gpu_resource_name": ("pkg/framework/report.go", r'ResourceNvidiaGPU v1\.ResourceName = "([^"]+)"'),
     "stop.limit_format": ("pkg/framework/simulator.go", r'fmt\.Sprintf\("(LimitReached: Maximum number of pods simulated: %v)"'),
     "report.headline_format": ("pkg/framework/report.go", r'fmt\.Printf\("(The cluster can schedule %v instance\(s\) of the pod %v\.)\\n"'),
     "report.termination_format": ("pkg/framework/report.go", r'fmt\.Printf\("\\n(Termination reason: %v: %v)\\n"'),

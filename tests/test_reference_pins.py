@@ -256,3 +256,20 @@ def test_verbose_requirements_block_follows_the_reference_format():
     assert "\t- ScalarResources: map[example.com/gpu:1 hugepages-2Mi:2097152]\n" in out
     assert "\t- NodeSelector: disk=ssd,zone=a\n" in out
     assert "\t- CPU: 150m\n\t- Memory: 100Mi\n" in out
+
+
+def test_report_keeps_the_references_resource_key_and_yaml_key_order(tmp_path):
+    """report.go:34 spells the third primary resource "nvdia.com/gpu" (sic) -- a consumer of the JSON sees that key; -o yaml goes through
+    sigs.k8s.io/yaml, i.e. through JSON: every mapping's keys come out sorted (report.go:296-303)."""
+    assert V["report.gpu_resource_name"] == "nvdia.com/gpu"
+    import io
+    import yaml
+    from test_ingest_cli import EXAMPLES_POD
+    pod = yaml.safe_load(EXAMPLES_POD)
+    assert set(cli.pod_requirements(pod)["resources"]["primaryResources"]) == {"cpu", "memory", V["report.gpu_resource_name"]}
+    src = open(os.path.join(ROOT, "cluster-capacity_amd", "host", "report.hpp")).read()
+    assert 'prim.set("%s"' % V["report.gpu_resource_name"] in src
+    text = yaml.safe_dump({"status": {"replicas": 1, "pods": []}, "spec": {"templates": [], "replicas": 0}}, sort_keys=True)
+    assert text.index("spec:") < text.index("status:")
+    assert "sort_keys=True" in open(os.path.join(ROOT, "cluster-capacity_amd", "cli.py")).read() and "sorted_keys(review)" in open(
+        os.path.join(ROOT, "cluster-capacity_amd", "host", "main.cpp")).read()
