@@ -112,7 +112,7 @@ std::vector<Value> load_kind(const std::vector<std::string> &paths, const std::s
 
 // `templates`: the simulated pods -- the Nodes' status.images entries are kept only for the images their containers name
 void load_objects(const std::vector<std::string> &paths, const std::vector<Value> &templates, std::vector<Value> &nodes, std::vector<Value> &pods,
-                  std::vector<Value> &namespaces) {
+                  std::vector<Value> &namespaces, std::vector<Value> &services) {
     std::vector<std::string> wanted;
     for (const auto &t : templates)
         for (const char *list : {"initContainers", "containers"})
@@ -122,6 +122,7 @@ void load_objects(const std::vector<std::string> &paths, const std::vector<Value
         if (kind == "Node") nodes.push_back(std::move(o));
         else if (kind == "Pod") pods.push_back(std::move(o));
         else if (kind == "Namespace") namespaces.push_back(std::move(o));
+        else if (kind == "Service") services.push_back(std::move(o));
     }, &wanted);
 }
 
@@ -273,9 +274,17 @@ int main(int argc, char **argv) {
             t0 = t1;
         };
         auto t0 = now();
-        std::vector<Value> node_objs, pod_objs, ns_objs;
-        load_objects(snapshots, templates, node_objs, pod_objs, ns_objs);
+        std::vector<Value> node_objs, pod_objs, ns_objs, svc_objs;
+        load_objects(snapshots, templates, node_objs, pod_objs, ns_objs, svc_objs);
         lap("read + parse objects", t0);
+        if (prof.c.w_topologyspread)
+            for (const auto &t : templates)
+                if (default_spreading_applies(t, svc_objs)) {
+                    std::fprintf(stderr, "warning: a Service selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system "
+                                         "default spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; it is not modelled -- the "
+                                         "order of the placements (and so a --max-limit result) may differ, the total does not\n");
+                    break;
+                }
         cc.SyncWithClient(node_objs, pod_objs, ns_objs);
         lap("intern + integer snapshot", t0);
         if (!dump.empty()) {

@@ -502,6 +502,25 @@ inline bool term_matches_pod(const Value &term, const std::string &owner_ns, con
 }
 inline std::string ns_of(const Value &obj) { return obj["metadata"]["namespace"].truthy() ? obj["metadata"]["namespace"].text() : "default"; }
 
+// Would PodTopologySpread's SYSTEM DEFAULT constraints apply to the template (P/podtopologyspread/plugin.go:48-59, common.go:61-74)?
+// They do for a pod WITHOUT constraints of its own when helper.DefaultSelector is not empty: the merged selectors of the Services of
+// the pod's namespace that select it (helper/spread.go:37-116; the template has no controller owner).  Not modelled: callers warn.
+inline bool default_spreading_applies(const Value &sim_pod, const std::vector<Value> &services) {
+    if (sim_pod["spec"]["topologySpreadConstraints"].truthy()) return false;
+    const std::string ns = ns_of(sim_pod);
+    const Value &labels = sim_pod["metadata"]["labels"];
+    for (const auto &svc : services) {
+        if (ns_of(svc) != ns) continue;
+        const Value &sel = svc["spec"]["selector"];
+        if (sel.t != Value::Obj || sel.o.empty()) continue; // a nil selector matches nothing; an empty one adds nothing to the merge
+        bool all = true;
+        for (const auto &kv : sel.o) all = all && labels.has(kv.first) && labels[kv.first].text() == kv.second.text();
+        if (all) return true;
+    }
+    return false;
+}
+
+
 inline bool any_nonzero(const std::vector<int32_t> &v) {
     for (auto x : v)
         if (x) return true;

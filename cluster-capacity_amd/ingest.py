@@ -410,6 +410,25 @@ def _node_selector_term(it: Interner, term: dict) -> List["M.Requirement"]:
 
 
 # ---- the snapshot -----------------------------------------------------------------------------------------------
+def default_spreading_applies(sim_pod: dict, service_objs: Sequence[dict]) -> bool:
+    """Would PodTopologySpread's SYSTEM DEFAULT constraints apply to the template (P/podtopologyspread/plugin.go:48-59,
+    common.go:61-74)?  They do for a pod WITHOUT constraints of its own when helper.DefaultSelector is not empty: the merged selectors of
+    the Services of the pod's namespace that select it (helper/spread.go:37-116; the template has no controller owner).  The hosts do
+    not model those two ScheduleAnyway constraints (they score with requireAllTopologies = false): callers warn."""
+    spec = sim_pod.get("spec") or {}
+    if spec.get("topologySpreadConstraints"):
+        return False
+    ns = sim_pod["metadata"].get("namespace") or "default"
+    labels = sim_pod["metadata"].get("labels") or {}
+    for svc in service_objs:
+        if (svc["metadata"].get("namespace") or "default") != ns:
+            continue
+        sel = (svc.get("spec") or {}).get("selector")
+        if sel and all(labels.get(k) == v for k, v in sel.items()):  # a nil selector matches nothing; an empty one adds nothing to the merge
+            return True
+    return False
+
+
 class Snapshot:
     """Everything the engine needs, plus the strings the report needs.  With several templates (`--podspec` repeated: the
     reference's report layer takes pod i as a clone of template i mod P, report.go:146-171) `pod` / `taint_reasons` describe

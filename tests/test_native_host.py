@@ -1449,3 +1449,29 @@ def test_pod_requirements_random_quantities(native, tmp_path):
         d = tmp_path / str(k)
         d.mkdir()
         _requirements(native, d, [q() for _ in range(n)], [q() for _ in range(n)])
+
+
+def test_system_default_spreading_is_flagged_by_both_hosts(native, tmp_path, capsys):
+    """PodTopologySpread's system defaults (plugin.go:48-59) apply to a pod without constraints that a Service of its namespace selects
+    (helper/spread.go:37-116): not modelled -> both hosts say so; no Service / another namespace / own constraints -> silence."""
+    nodes, pods, pod, _ = CASES["readme"]()
+    svc = lambda ns, sel: {"kind": "Service", "apiVersion": "v1", "metadata": {"name": "s", "namespace": ns}, "spec": {"selector": sel}}
+    cases = [([svc("default", {"app": "guestbook"})], True), ([svc("default", {"app": "guestbook", "tier": "frontend"})], True),
+             ([svc("other", {"app": "guestbook"})], False), ([svc("default", {"app": "nope"})], False), ([svc("default", {})], False),
+             ([svc("default", None)], False), ([], False)]
+    (tmp_path / "result.json").write_text(json.dumps({"placed": 0, "stop": M.STOP_LIMIT, "n_code_unschedulable": 0, "per_node_count": [0] * len(nodes), "log": [],
+                                                      "hist": [0] * M.NREASON, "hist_taintset": [0]}))
+    for k, (services, expect) in enumerate(cases):
+        for own in (False, True):
+            d = tmp_path / f"{k}{int(own)}"
+            d.mkdir()
+            tpl = json.loads(json.dumps(pod))
+            if own:
+                tpl["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": "guestbook"}}}]
+            (d / "cluster.json").write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + services}))
+            (d / "pod.json").write_text(json.dumps(tpl))
+            p = subprocess.run([native, "--podspec", str(d / "pod.json"), "--snapshot", str(d / "cluster.json"), "--fake-result", str(tmp_path / "result.json"), "--max-limit", "1"],
+                               capture_output=True, text=True, timeout=60)
+            assert p.returncode == 0, p.stderr
+            assert ("system default spreading" in p.stderr) == (expect and not own), (k, own, p.stderr)
+            assert ingest.default_spreading_applies(cli.parse_pod_spec(str(d / "pod.json")), cli.load_kind([str(d / "cluster.json")], "Service")) == (expect and not own)
