@@ -122,7 +122,7 @@ void load_objects(const std::vector<std::string> &paths, const std::vector<Value
         if (kind == "Node") nodes.push_back(std::move(o));
         else if (kind == "Pod") pods.push_back(std::move(o));
         else if (kind == "Namespace") namespaces.push_back(std::move(o));
-        else if (kind == "Service") services.push_back(std::move(o));
+        else if (kind == "Service" || kind == "ReplicationController" || kind == "ReplicaSet" || kind == "StatefulSet") services.push_back(std::move(o));
     }, &wanted);
 }
 
@@ -279,8 +279,8 @@ int main(int argc, char **argv) {
         lap("read + parse objects", t0);
         if (prof.c.w_topologyspread)
             for (const auto &t : templates)
-                if (default_spreading_applies(t, svc_objs)) {
-                    std::fprintf(stderr, "warning: a Service selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system "
+                if (default_spreading_applies(t, svc_objs, svc_objs)) { // (Services and controllers share the list: told apart by kind)
+                    std::fprintf(stderr, "warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system "
                                          "default spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; it is not modelled -- the "
                                          "order of the placements (and so a --max-limit result) may differ, the total does not\n");
                     break;

@@ -505,17 +505,30 @@ inline std::string ns_of(const Value &obj) { return obj["metadata"]["namespace"]
 // Would PodTopologySpread's SYSTEM DEFAULT constraints apply to the template (P/podtopologyspread/plugin.go:48-59, common.go:61-74)?
 // They do for a pod WITHOUT constraints of its own when helper.DefaultSelector is not empty: the merged selectors of the Services of
 // the pod's namespace that select it (helper/spread.go:37-116; the template has no controller owner).  Not modelled: callers warn.
-inline bool default_spreading_applies(const Value &sim_pod, const std::vector<Value> &services) {
+inline bool default_spreading_applies(const Value &sim_pod, const std::vector<Value> &services, const std::vector<Value> &owners = {}) {
     if (sim_pod["spec"]["topologySpreadConstraints"].truthy()) return false;
     const std::string ns = ns_of(sim_pod);
     const Value &labels = sim_pod["metadata"]["labels"];
     for (const auto &svc : services) {
-        if (ns_of(svc) != ns) continue;
+        if (svc["kind"].text() != "Service" || ns_of(svc) != ns) continue;
         const Value &sel = svc["spec"]["selector"];
         if (sel.t != Value::Obj || sel.o.empty()) continue; // a nil selector matches nothing; an empty one adds nothing to the merge
         bool all = true;
         for (const auto &kv : sel.o) all = all && labels.has(kv.first) && labels[kv.first].text() == kv.second.text();
         if (all) return true;
+    }
+    // ... or the selector of the template's controller (a pod spec copied from a live pod carries its ownerReferences): a
+    // ReplicationController's map selector, a ReplicaSet's / StatefulSet's label selector (spread.go:55-90)
+    for (const auto &ref : sim_pod["metadata"]["ownerReferences"].items()) {
+        if (!ref["controller"].truthy()) continue;
+        const std::string kind = ref["kind"].text(), api = ref["apiVersion"].text();
+        for (const auto &o : owners) {
+            if (o["kind"].text() != kind || o["metadata"]["name"].text() != ref["name"].text() || ns_of(o) != ns) continue;
+            const Value &sel = o["spec"]["selector"];
+            if (kind == "ReplicationController" && (api.empty() || api == "v1")) return sel.truthy();
+            if ((kind == "ReplicaSet" || kind == "StatefulSet") && api.rfind("apps/", 0) == 0) return sel["matchLabels"].truthy() || sel["matchExpressions"].truthy();
+        }
+        break; // (GetControllerOf: the first reference marked controller)
     }
     return false;
 }

@@ -410,7 +410,7 @@ def _node_selector_term(it: Interner, term: dict) -> List["M.Requirement"]:
 
 
 # ---- the snapshot -----------------------------------------------------------------------------------------------
-def default_spreading_applies(sim_pod: dict, service_objs: Sequence[dict]) -> bool:
+def default_spreading_applies(sim_pod: dict, service_objs: Sequence[dict], owner_objs: Sequence[dict] = ()) -> bool:
     """Would PodTopologySpread's SYSTEM DEFAULT constraints apply to the template (P/podtopologyspread/plugin.go:48-59,
     common.go:61-74)?  They do for a pod WITHOUT constraints of its own when helper.DefaultSelector is not empty: the merged selectors of
     the Services of the pod's namespace that select it (helper/spread.go:37-116; the template has no controller owner).  The hosts do
@@ -426,6 +426,20 @@ def default_spreading_applies(sim_pod: dict, service_objs: Sequence[dict]) -> bo
         sel = (svc.get("spec") or {}).get("selector")
         if sel and all(labels.get(k) == v for k, v in sel.items()):  # a nil selector matches nothing; an empty one adds nothing to the merge
             return True
+    # ... or the selector of the template's controller (a pod spec copied from a live pod carries its ownerReferences): a
+    # ReplicationController's map selector, a ReplicaSet's / StatefulSet's label selector (spread.go:55-90)
+    for ref in sim_pod["metadata"].get("ownerReferences") or []:
+        if not ref.get("controller"):
+            continue
+        for o in owner_objs:
+            if (o.get("kind"), o["metadata"].get("name"), o["metadata"].get("namespace") or "default") != (ref.get("kind"), ref.get("name"), ns):
+                continue
+            sel = (o.get("spec") or {}).get("selector") or {}
+            if ref.get("kind") == "ReplicationController" and (ref.get("apiVersion") or "v1") == "v1":
+                return bool(sel)
+            if ref.get("kind") in ("ReplicaSet", "StatefulSet") and str(ref.get("apiVersion") or "").startswith("apps/"):
+                return bool(sel.get("matchLabels") or sel.get("matchExpressions"))
+        break  # (GetControllerOf: the first reference marked controller)
     return False
 
 

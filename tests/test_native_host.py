@@ -1456,7 +1456,11 @@ def test_system_default_spreading_is_flagged_by_both_hosts(native, tmp_path, cap
     (helper/spread.go:37-116): not modelled -> both hosts say so; no Service / another namespace / own constraints -> silence."""
     nodes, pods, pod, _ = CASES["readme"]()
     svc = lambda ns, sel: {"kind": "Service", "apiVersion": "v1", "metadata": {"name": "s", "namespace": ns}, "spec": {"selector": sel}}
+    rs = lambda ns, sel: {"kind": "ReplicaSet", "apiVersion": "apps/v1", "metadata": {"name": "web-abc", "namespace": ns}, "spec": {"selector": sel}}
+    owned = {"ownerReferences": [{"apiVersion": "apps/v1", "kind": "ReplicaSet", "name": "web-abc", "controller": True}]}
     cases = [([svc("default", {"app": "guestbook"})], True), ([svc("default", {"app": "guestbook", "tier": "frontend"})], True),
+             ([rs("default", {"matchLabels": {"app": "guestbook"}}), owned], True), ([rs("other", {"matchLabels": {"app": "guestbook"}}), owned], False),
+             ([rs("default", {}), owned], False), ([rs("default", {"matchLabels": {"app": "guestbook"}})], False),
              ([svc("other", {"app": "guestbook"})], False), ([svc("default", {"app": "nope"})], False), ([svc("default", {})], False),
              ([svc("default", None)], False), ([], False)]
     (tmp_path / "result.json").write_text(json.dumps({"placed": 0, "stop": M.STOP_LIMIT, "n_code_unschedulable": 0, "per_node_count": [0] * len(nodes), "log": [],
@@ -1466,12 +1470,17 @@ def test_system_default_spreading_is_flagged_by_both_hosts(native, tmp_path, cap
             d = tmp_path / f"{k}{int(own)}"
             d.mkdir()
             tpl = json.loads(json.dumps(pod))
+            objs = [o for o in services if "kind" in o]
+            for o in services:
+                if "kind" not in o:  # template metadata (owner references) rides along in the case list
+                    tpl["metadata"].update(json.loads(json.dumps(o)))
             if own:
                 tpl["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": {"matchLabels": {"app": "guestbook"}}}]
-            (d / "cluster.json").write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + services}))
+            (d / "cluster.json").write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + objs}))
             (d / "pod.json").write_text(json.dumps(tpl))
             p = subprocess.run([native, "--podspec", str(d / "pod.json"), "--snapshot", str(d / "cluster.json"), "--fake-result", str(tmp_path / "result.json"), "--max-limit", "1"],
                                capture_output=True, text=True, timeout=60)
             assert p.returncode == 0, p.stderr
             assert ("system default spreading" in p.stderr) == (expect and not own), (k, own, p.stderr)
-            assert ingest.default_spreading_applies(cli.parse_pod_spec(str(d / "pod.json")), cli.load_kind([str(d / "cluster.json")], "Service")) == (expect and not own)
+            owners = [o for kind in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in cli.load_kind([str(d / "cluster.json")], kind)]
+            assert ingest.default_spreading_applies(cli.parse_pod_spec(str(d / "pod.json")), cli.load_kind([str(d / "cluster.json")], "Service"), owners) == (expect and not own)
