@@ -233,7 +233,7 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     pod = pods if len(pods) > 1 else pods[0]
     node_objs, pod_objs, ns_objs = load_all(args.snapshot)
     owners = [o for k in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in load_kind(args.snapshot, k)]
-    if prof.w_topologyspread and any(ingest.default_spreading_applies(p, load_kind(args.snapshot, "Service"), owners) for p in pods):
+    if prof.w_topologyspread and getattr(prof, "system_default_spreading", True) and any(ingest.default_spreading_applies(p, load_kind(args.snapshot, "Service"), owners) for p in pods):
         print("warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system default "
               "spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; it is not modelled -- the order of the "
               "placements (and so a --max-limit result) may differ, the total does not", file=sys.stderr)

@@ -277,7 +277,7 @@ int main(int argc, char **argv) {
         std::vector<Value> node_objs, pod_objs, ns_objs, svc_objs;
         load_objects(snapshots, templates, node_objs, pod_objs, ns_objs, svc_objs);
         lap("read + parse objects", t0);
-        if (prof.c.w_topologyspread)
+        if (prof.c.w_topologyspread && prof.system_default_spreading)
             for (const auto &t : templates)
                 if (default_spreading_applies(t, svc_objs, svc_objs)) { // (Services and controllers share the list: told apart by kind)
                     std::fprintf(stderr, "warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system "

@@ -19,6 +19,7 @@ struct HostProfile {
     ccsim_profile c{};
     int hard_pod_affinity_weight = 1; // InterPodAffinityArgs (defaults.go:229-231), used by the ingest
     bool percentage_set = false;      // percentageOfNodesToScore came from the config file / the command line (else: see simulate())
+    bool system_default_spreading = true; // PodTopologySpreadArgs.defaultingType System (the default); List with no constraints turns it off
 };
 
 inline HostProfile default_profile() {
@@ -162,6 +163,7 @@ inline HostProfile profile_from_config(const Value &cfg) {
             if (args["ignorePreferredTermsOfExistingPods"].truthy()) throw std::runtime_error("scheduler config: ignorePreferredTermsOfExistingPods is not implemented");
         } else if (name == "PodTopologySpread") {
             if (args["defaultConstraints"].truthy()) throw std::runtime_error("scheduler config: PodTopologySpread defaultConstraints are not implemented (defaultingType System needs Services / ReplicaSets)");
+            if (args["defaultingType"].text() == "List") p.system_default_spreading = false; // (an empty list: no default constraints at all, plugin.go:105-113)
         } else if (name == "NodeAffinity") {
             if (args["addedAffinity"].truthy()) throw std::runtime_error("scheduler config: NodeAffinity addedAffinity is not implemented");
         } else if (!folded_away(name) && !plugin_table().count(name))

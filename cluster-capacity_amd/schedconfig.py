@@ -61,8 +61,14 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
     """-> (Profile, hardPodAffinityWeight)."""
     p = dataclasses.asdict(M.Profile.default())
     hard = 1
+    system_default_spreading = True  # PodTopologySpreadArgs.defaultingType System (the default)
+
+    def done():
+        out = M.Profile(**p)
+        out.system_default_spreading = system_default_spreading  # host-side note (not an ABI field): see ingest.default_spreading_applies
+        return out, hard
     if not cfg:
-        return M.Profile(**p), hard
+        return done()
     if cfg.get("kind") and cfg["kind"] != "KubeSchedulerConfiguration":
         raise ConfigError("scheduler config: kind is not KubeSchedulerConfiguration")
     if cfg.get("percentageOfNodesToScore") is not None:
@@ -142,6 +148,8 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
         elif name == "PodTopologySpread":
             if args.get("defaultConstraints"):
                 raise ConfigError("scheduler config: PodTopologySpread defaultConstraints are not implemented")
+            if args.get("defaultingType") == "List":  # an empty list: no default constraints at all (plugin.go:105-113)
+                system_default_spreading = False
         elif name == "NodeAffinity":
             if args.get("addedAffinity"):
                 raise ConfigError("scheduler config: NodeAffinity addedAffinity is not implemented")
@@ -149,4 +157,4 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
             raise ConfigError(f"scheduler config: pluginConfig for unknown plugin '{name}'")
     if not 0 <= p["percentage_of_nodes_to_score"] <= 100:
         raise ConfigError("scheduler config: percentageOfNodesToScore out of [0,100] (validation.go:86-90)")
-    return M.Profile(**p), hard
+    return done()
