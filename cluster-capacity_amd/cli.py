@@ -233,12 +233,14 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     pod = pods if len(pods) > 1 else pods[0]
     node_objs, pod_objs, ns_objs = load_all(args.snapshot)
     owners = [o for k in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in load_kind(args.snapshot, k)]
-    if prof.w_topologyspread and getattr(prof, "system_default_spreading", True) and any(ingest.default_spreading_applies(p, load_kind(args.snapshot, "Service"), owners) for p in pods):
-        print("warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system default "
-              "spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; it is not modelled -- the order of the "
-              "placements (and so a --max-limit result) may differ, the total does not", file=sys.stderr)
+    services = load_kind(args.snapshot, "Service")
     snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
-                                 namespace_objs=ns_objs)
+                                 namespace_objs=ns_objs, service_objs=services, owner_objs=owners,
+                                 system_default_spreading=bool(prof.w_topologyspread) and getattr(prof, "system_default_spreading", True))
+    if snap.default_spreading_unmodelled:
+        print("warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system default "
+              "spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; some node lacks one of the two labels (or several templates run): "
+              "not modelled -- the order of the placements (and so a --max-limit result) may differ, the total does not", file=sys.stderr)
     if args.percentage_of_nodes_to_score is not None:
         pct = args.percentage_of_nodes_to_score
     elif schedconfig.sets_percentage(cfg):

@@ -38,8 +38,11 @@ class ClusterCapacity {
         c.profile_ = kubeSchedulerConfig, c.pods_ = std::move(simulatedPods), c.max_simulated_ = maxPods, c.exclude_ = std::move(excludeNodes);
         return c;
     }
-    void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods, const std::vector<Value> &namespaces = {}) {
-        snap_ = build_snapshot(nodes, pods, pods_, exclude_, profile_.hard_pod_affinity_weight, namespaces);
+    // spreading_objs: the Services and controllers of the dump (PodTopologySpread's system default constraints)
+    void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods, const std::vector<Value> &namespaces = {},
+                        const std::vector<Value> &spreading_objs = {}) {
+        snap_ = build_snapshot(nodes, pods, pods_, exclude_, profile_.hard_pod_affinity_weight, namespaces, spreading_objs,
+                               profile_.c.w_topologyspread != 0 && profile_.system_default_spreading);
         synced_ = true;
     }
     void Run() {

@@ -277,15 +277,11 @@ int main(int argc, char **argv) {
         std::vector<Value> node_objs, pod_objs, ns_objs, svc_objs;
         load_objects(snapshots, templates, node_objs, pod_objs, ns_objs, svc_objs);
         lap("read + parse objects", t0);
-        if (prof.c.w_topologyspread && prof.system_default_spreading)
-            for (const auto &t : templates)
-                if (default_spreading_applies(t, svc_objs, svc_objs)) { // (Services and controllers share the list: told apart by kind)
-                    std::fprintf(stderr, "warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system "
-                                         "default spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; it is not modelled -- the "
-                                         "order of the placements (and so a --max-limit result) may differ, the total does not\n");
-                    break;
-                }
-        cc.SyncWithClient(node_objs, pod_objs, ns_objs);
+        cc.SyncWithClient(node_objs, pod_objs, ns_objs, svc_objs);
+        if (cc.snapshot().default_spreading_unmodelled)
+            std::fprintf(stderr, "warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's "
+                                 "system default spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; some node lacks one of the "
+                                 "two labels (or several templates run): not modelled -- the order of the placements (and so a --max-limit result) may differ, the total does not\n");
         lap("intern + integer snapshot", t0);
         if (!dump.empty()) {
             std::string out;

@@ -431,6 +431,7 @@ struct Snapshot : PodSide {
     std::vector<std::string> label_keys;
     std::vector<std::vector<int32_t>> label_cols;
     std::vector<PodSide> more; // templates 1 .. P-1
+    bool default_spreading_unmodelled = false; // system default spreading applies but a node lacks the hostname / zone label
     size_t n() const { return names.size(); }
     size_t n_templates() const { return 1 + more.size(); }
     const PodSide &side(size_t t) const { return t == 0 ? static_cast<const PodSide &>(*this) : more[t - 1]; }
@@ -502,35 +503,58 @@ inline bool term_matches_pod(const Value &term, const std::string &owner_ns, con
 }
 inline std::string ns_of(const Value &obj) { return obj["metadata"]["namespace"].truthy() ? obj["metadata"]["namespace"].text() : "default"; }
 
-// Would PodTopologySpread's SYSTEM DEFAULT constraints apply to the template (P/podtopologyspread/plugin.go:48-59, common.go:61-74)?
-// They do for a pod WITHOUT constraints of its own when helper.DefaultSelector is not empty: the merged selectors of the Services of
-// the pod's namespace that select it (helper/spread.go:37-116; the template has no controller owner).  Not modelled: callers warn.
-inline bool default_spreading_applies(const Value &sim_pod, const std::vector<Value> &services, const std::vector<Value> &owners = {}) {
-    if (sim_pod["spec"]["topologySpreadConstraints"].truthy()) return false;
+static const char *const kZone = "topology.kubernetes.io/zone";
+
+// helper.DefaultSelector (P/helper/spread.go:37-116) as a LabelSelector value, Null when it is empty: the merged selectors of the Services
+// of the pod's namespace that select it, plus the selector of the pod's controller (a pod spec copied from a live pod carries its
+// ownerReferences): a ReplicationController's map, a ReplicaSet's / StatefulSet's label selector.  `objs`: Services and controllers.
+inline Value default_selector(const Value &sim_pod, const std::vector<Value> &objs) {
     const std::string ns = ns_of(sim_pod);
     const Value &labels = sim_pod["metadata"]["labels"];
-    for (const auto &svc : services) {
+    Value merged = Value::object(), exprs = Value::array();
+    for (const auto &svc : objs) {
         if (svc["kind"].text() != "Service" || ns_of(svc) != ns) continue;
         const Value &sel = svc["spec"]["selector"];
-        if (sel.t != Value::Obj || sel.o.empty()) continue; // a nil selector matches nothing; an empty one adds nothing to the merge
+        if (sel.t != Value::Obj) continue; // a nil selector matches nothing (spread.go:105-108)
         bool all = true;
         for (const auto &kv : sel.o) all = all && labels.has(kv.first) && labels[kv.first].text() == kv.second.text();
-        if (all) return true;
+        if (all)
+            for (const auto &kv : sel.o) merged.set(kv.first, kv.second);
     }
-    // ... or the selector of the template's controller (a pod spec copied from a live pod carries its ownerReferences): a
-    // ReplicationController's map selector, a ReplicaSet's / StatefulSet's label selector (spread.go:55-90)
     for (const auto &ref : sim_pod["metadata"]["ownerReferences"].items()) {
         if (!ref["controller"].truthy()) continue;
         const std::string kind = ref["kind"].text(), api = ref["apiVersion"].text();
-        for (const auto &o : owners) {
+        for (const auto &o : objs) {
             if (o["kind"].text() != kind || o["metadata"]["name"].text() != ref["name"].text() || ns_of(o) != ns) continue;
             const Value &sel = o["spec"]["selector"];
-            if (kind == "ReplicationController" && (api.empty() || api == "v1")) return sel.truthy();
-            if ((kind == "ReplicaSet" || kind == "StatefulSet") && api.rfind("apps/", 0) == 0) return sel["matchLabels"].truthy() || sel["matchExpressions"].truthy();
+            if (kind == "ReplicationController" && (api.empty() || api == "v1")) {
+                for (const auto &kv : sel.fields()) merged.set(kv.first, kv.second);
+            } else if ((kind == "ReplicaSet" || kind == "StatefulSet") && api.rfind("apps/", 0) == 0) {
+                for (const auto &kv : sel["matchLabels"].fields()) merged.set(kv.first, kv.second);
+                for (const auto &e : sel["matchExpressions"].items()) exprs.a.push_back(e);
+            }
         }
         break; // (GetControllerOf: the first reference marked controller)
     }
-    return false;
+    if (merged.o.empty() && exprs.a.empty()) return Value();
+    Value out = Value::object();
+    out.set("matchLabels", merged), out.set("matchExpressions", exprs);
+    return out;
+}
+
+// PodTopologySpread's SYSTEM DEFAULT constraints for a pod WITHOUT constraints of its own (P/podtopologyspread/plugin.go:48-59,
+// common.go:61-74): hostname maxSkew 3 and zone maxSkew 5, ScheduleAnyway, selector = helper.DefaultSelector; empty when that is empty
+inline Value system_default_constraints(const Value &sim_pod, const std::vector<Value> &objs) {
+    Value out = Value::array();
+    if (sim_pod["spec"]["topologySpreadConstraints"].truthy()) return out;
+    const Value sel = default_selector(sim_pod, objs);
+    if (sel.is_null()) return out;
+    for (const auto &kv : {std::pair<const char *, int>{kHostname, 3}, std::pair<const char *, int>{kZone, 5}}) {
+        Value c = Value::object();
+        c.set("maxSkew", Value::num(kv.second)), c.set("topologyKey", Value::str(kv.first)), c.set("whenUnsatisfiable", Value::str("ScheduleAnyway")), c.set("labelSelector", sel);
+        out.a.push_back(c);
+    }
+    return out;
 }
 
 
@@ -542,7 +566,8 @@ inline bool any_nonzero(const std::vector<int32_t> &v) {
 
 inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const std::vector<Value> &sim_pods,
                                const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1,
-                               const std::vector<Value> &namespace_objs = {}) {
+                               const std::vector<Value> &namespace_objs = {}, const std::vector<Value> &spreading_objs = {}, bool system_default_spreading = true) {
+    // spreading_objs: the Services and controllers (ReplicationController / ReplicaSet / StatefulSet) of the dump: helper.DefaultSelector
     if (sim_pods.empty()) throw std::runtime_error("no pod spec");
     Snapshot S;
     NamespaceLabels ns_labels;
@@ -789,7 +814,21 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     if (spec["resourceClaims"].truthy()) throw std::runtime_error("spec.resourceClaims: the DynamicResources plugin is not modelled");
 
     // topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
-    for (const auto &c : spec["topologySpreadConstraints"].items()) {
+    // System default spreading (a Service / the controller selects the template).  The plugin scores these with requireAllTopologies =
+    // false (scoring.go:61-115: a node without the key counts under the empty value instead of being ignored); when EVERY node carries
+    // both keys the two readings coincide and the constraints are exactly two more soft constraints of the pod -- otherwise they are
+    // left out and the caller is told (Snapshot::default_spreading_unmodelled)
+    Value constraints = spec["topologySpreadConstraints"].t == Value::Arr ? spec["topologySpreadConstraints"] : Value::array();
+    if (constraints.a.empty() && system_default_spreading) {
+        const Value defaults = system_default_constraints(sim_pod, spreading_objs);
+        if (!defaults.a.empty()) {
+            bool all = sim_pods.size() == 1; // (several templates: the engine keeps each template's spread state apart, a shared selector would couple them)
+            for (size_t i = 0; i < N && all; i++) all = (*nodes[i])["metadata"]["labels"].has(kHostname) && (*nodes[i])["metadata"]["labels"].has(kZone);
+            if (all) constraints = defaults;
+            else S.default_spreading_unmodelled = true;
+        }
+    }
+    for (const auto &c : constraints.items()) {
         // matchLabelKeys (common.go:95-105): the incoming pod's own values of these keys are ANDed into the selector
         Value merged_sel = c["labelSelector"];
         if (!merged_sel.is_null()) {
@@ -977,8 +1016,8 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
 
 inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const Value &sim_pod,
                                const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1,
-                               const std::vector<Value> &namespace_objs = {}) {
-    return build_snapshot(node_objs, pod_objs, std::vector<Value>{sim_pod}, exclude_nodes, hard_pod_affinity_weight, namespace_objs);
+                               const std::vector<Value> &namespace_objs = {}, const std::vector<Value> &spreading_objs = {}, bool system_default_spreading = true) {
+    return build_snapshot(node_objs, pod_objs, std::vector<Value>{sim_pod}, exclude_nodes, hard_pod_affinity_weight, namespace_objs, spreading_objs, system_default_spreading);
 }
 
 // ---- the dump the CPU tests compare with the Python ingest (tests/test_native_host.py) -------------------------

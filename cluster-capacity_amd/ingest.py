@@ -410,24 +410,23 @@ def _node_selector_term(it: Interner, term: dict) -> List["M.Requirement"]:
 
 
 # ---- the snapshot -----------------------------------------------------------------------------------------------
-def default_spreading_applies(sim_pod: dict, service_objs: Sequence[dict], owner_objs: Sequence[dict] = ()) -> bool:
-    """Would PodTopologySpread's SYSTEM DEFAULT constraints apply to the template (P/podtopologyspread/plugin.go:48-59,
-    common.go:61-74)?  They do for a pod WITHOUT constraints of its own when helper.DefaultSelector is not empty: the merged selectors of
-    the Services of the pod's namespace that select it (helper/spread.go:37-116; the template has no controller owner).  The hosts do
-    not model those two ScheduleAnyway constraints (they score with requireAllTopologies = false): callers warn."""
-    spec = sim_pod.get("spec") or {}
-    if spec.get("topologySpreadConstraints"):
-        return False
+ZONE = "topology.kubernetes.io/zone"
+
+
+def default_selector(sim_pod: dict, service_objs: Sequence[dict], owner_objs: Sequence[dict] = ()) -> Optional[dict]:
+    """helper.DefaultSelector (P/helper/spread.go:37-116) as a LabelSelector dict, None when it is empty: the merged selectors of the
+    Services of the pod's namespace that select it, plus the selector of the pod's controller (a pod spec copied from a live pod
+    carries its ownerReferences): a ReplicationController's map, a ReplicaSet's / StatefulSet's label selector."""
     ns = sim_pod["metadata"].get("namespace") or "default"
     labels = sim_pod["metadata"].get("labels") or {}
+    merged: Dict[str, str] = {}
     for svc in service_objs:
         if (svc["metadata"].get("namespace") or "default") != ns:
             continue
         sel = (svc.get("spec") or {}).get("selector")
-        if sel and all(labels.get(k) == v for k, v in sel.items()):  # a nil selector matches nothing; an empty one adds nothing to the merge
-            return True
-    # ... or the selector of the template's controller (a pod spec copied from a live pod carries its ownerReferences): a
-    # ReplicationController's map selector, a ReplicaSet's / StatefulSet's label selector (spread.go:55-90)
+        if sel is not None and all(labels.get(k) == v for k, v in sel.items()):  # a nil selector matches nothing (spread.go:105-108)
+            merged.update(sel)
+    exprs: List[dict] = []
     for ref in sim_pod["metadata"].get("ownerReferences") or []:
         if not ref.get("controller"):
             continue
@@ -436,11 +435,30 @@ def default_spreading_applies(sim_pod: dict, service_objs: Sequence[dict], owner
                 continue
             sel = (o.get("spec") or {}).get("selector") or {}
             if ref.get("kind") == "ReplicationController" and (ref.get("apiVersion") or "v1") == "v1":
-                return bool(sel)
-            if ref.get("kind") in ("ReplicaSet", "StatefulSet") and str(ref.get("apiVersion") or "").startswith("apps/"):
-                return bool(sel.get("matchLabels") or sel.get("matchExpressions"))
+                merged.update(sel)
+            elif ref.get("kind") in ("ReplicaSet", "StatefulSet") and str(ref.get("apiVersion") or "").startswith("apps/"):
+                merged.update(sel.get("matchLabels") or {})  # (selector.Add of the requirements: an equality per matchLabels entry)
+                exprs += list(sel.get("matchExpressions") or [])
         break  # (GetControllerOf: the first reference marked controller)
-    return False
+    if not merged and not exprs:
+        return None
+    return {"matchLabels": merged, "matchExpressions": exprs}
+
+
+def system_default_constraints(sim_pod: dict, service_objs: Sequence[dict], owner_objs: Sequence[dict] = ()) -> List[dict]:
+    """PodTopologySpread's SYSTEM DEFAULT constraints for a pod WITHOUT constraints of its own (P/podtopologyspread/plugin.go:48-59,
+    common.go:61-74): hostname maxSkew 3 and zone maxSkew 5, ScheduleAnyway, selector = helper.DefaultSelector; [] when that is empty."""
+    if (sim_pod.get("spec") or {}).get("topologySpreadConstraints"):
+        return []
+    sel = default_selector(sim_pod, service_objs, owner_objs)
+    if sel is None:
+        return []
+    return [{"maxSkew": 3, "topologyKey": HOSTNAME, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": sel},
+            {"maxSkew": 5, "topologyKey": ZONE, "whenUnsatisfiable": "ScheduleAnyway", "labelSelector": sel}]
+
+
+def default_spreading_applies(sim_pod: dict, service_objs: Sequence[dict], owner_objs: Sequence[dict] = ()) -> bool:
+    return bool(system_default_constraints(sim_pod, service_objs, owner_objs))
 
 
 class Snapshot:
@@ -452,6 +470,7 @@ class Snapshot:
     def __init__(self, nodes: M.NodesSoA, pod: M.PodSpec, names: List[str], taint_reasons: List[str], scalar_names: List[str]):
         self.nodes, self.pod, self.names, self.taint_reasons, self.scalar_names = nodes, pod, names, taint_reasons, scalar_names
         self.pods, self.taint_reasons_all = [pod], [taint_reasons]
+        self.default_spreading_unmodelled = False  # system default spreading applies but a node lacks the hostname / zone label (or several templates run)
 
 
 def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict, ns_labels: Optional[Dict[str, dict]] = None) -> bool:
@@ -470,7 +489,8 @@ def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict, ns_labels: Opti
 
 
 def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude_nodes: Sequence[str] = (),
-                   hard_pod_affinity_weight: int = 1, namespace_objs: Sequence[dict] = ()) -> Snapshot:
+                   hard_pod_affinity_weight: int = 1, namespace_objs: Sequence[dict] = (), service_objs: Sequence[dict] = (),
+                   owner_objs: Sequence[dict] = (), system_default_spreading: bool = True) -> Snapshot:
     """SyncWithClient (simulator.go:176-295: namespaces, nodes, pods) + every per-pod-spec precomputation, in integers.
     `sim_pod`: the template, or a list of templates (cycled round-robin by the simulation)."""
     sim_pods = list(sim_pod) if isinstance(sim_pod, (list, tuple)) else [sim_pod]
@@ -533,12 +553,14 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
     it = Interner(nodes)  # shared by the templates: a label column per key any of them touches
 
     ctx = dict(nodes=nodes, N=N, index=index, live=live, ns_labels=ns_labels, res_names=res_names, scalars=scalars, set_taints=set_taints,
-               ts_id=ts_id, it=it, hard_pod_affinity_weight=hard_pod_affinity_weight)
+               ts_id=ts_id, it=it, hard_pod_affinity_weight=hard_pod_affinity_weight,
+               default_spreading=(service_objs, owner_objs) if system_default_spreading else None, n_templates=len(sim_pods))
     sides = [_template_side(ctx, sp) for sp in sim_pods]
     soa = M.NodesSoA(alloc=alloc, alloc_pods=alloc_pods, req=req, nz_mcpu=nzc, nz_mem=nzm, pod_count=pcount,
                      taintset_id=ts_id, unschedulable=unsched, label_cols=[a for a in it.arrays] or [], names=names,
                      scalar_names=scalars)
     snap = Snapshot(soa, sides[0][0], names, sides[0][1], scalars)
+    snap.default_spreading_unmodelled = bool(ctx.get("default_spreading_unmodelled"))
     snap.pods, snap.taint_reasons_all = [p for p, _ in sides], [r for _, r in sides]
     if len(sides) > 1:
         _check_templates_disjoint(sim_pods)
@@ -665,7 +687,20 @@ def _template_side(ctx: dict, sim_pod: dict):
 
     # topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
     included = np.array([node_matches_required(i) for i in range(N)], np.uint8) if affinity_active else None
-    for c in spec.get("topologySpreadConstraints") or []:
+    constraints = list(spec.get("topologySpreadConstraints") or [])
+    if not constraints and ctx.get("default_spreading") is not None:
+        # System default spreading (a Service / the controller selects the template).  The plugin scores these with
+        # requireAllTopologies = false (scoring.go:61-115: a node without the key counts under the empty value instead of being
+        # ignored); when EVERY node carries both keys the two readings coincide and the constraints are exactly two more soft
+        # constraints of the pod -- otherwise they are left out and the caller is told (pod.default_spreading_unmodelled)
+        defaults = system_default_constraints(sim_pod, *ctx["default_spreading"])
+        if defaults:
+            # (several templates: the engine keeps each template's spread state apart, a shared Service selector would couple them)
+            if ctx["n_templates"] == 1 and all(HOSTNAME in (n["metadata"].get("labels") or {}) and ZONE in (n["metadata"].get("labels") or {}) for n in nodes):
+                constraints = defaults
+            else:
+                ctx["default_spreading_unmodelled"] = True
+    for c in constraints:
         sel = c.get("labelSelector")
         # matchLabelKeys (common.go:95-105): the incoming pod's own values of these keys are ANDed into the selector
         merged = [{"key": k, "operator": "In", "values": [sim_labels[k]]} for k in c.get("matchLabelKeys") or [] if k in sim_labels]

@@ -1484,3 +1484,36 @@ def test_system_default_spreading_is_flagged_by_both_hosts(native, tmp_path, cap
             assert ("system default spreading" in p.stderr) == (expect and not own), (k, own, p.stderr)
             owners = [o for kind in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in cli.load_kind([str(d / "cluster.json")], kind)]
             assert ingest.default_spreading_applies(cli.parse_pod_spec(str(d / "pod.json")), cli.load_kind([str(d / "cluster.json")], "Service"), owners) == (expect and not own)
+
+
+def test_system_default_spreading_becomes_two_soft_constraints_when_every_node_is_labelled(native, tmp_path, ccref):
+    """Every node carries kubernetes.io/hostname and topology.kubernetes.io/zone: requireAllTopologies = false and = true read the same
+    (scoring.go:61-115), so the system defaults are exactly two ScheduleAnyway constraints of the pod with the merged Service selector.
+    Both ingests must build the same snapshot; the total equals the run without the Service, the order of the placements need not."""
+    nodes = [node(f"n{i}", cpu="2", mem="4G", labels={"kubernetes.io/hostname": f"n{i}", "topology.kubernetes.io/zone": f"z{i % 3}"}) for i in range(9)]
+    pods = [running_pod(f"p{j}", f"n{j % 4}", cpu="100m", mem="64Mi", labels={"app": "guestbook", "tier": "frontend" if j % 2 else "backend"}) for j in range(7)]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    svcs = [{"kind": "Service", "apiVersion": "v1", "metadata": {"name": "fe", "namespace": "default"}, "spec": {"selector": {"app": "guestbook"}}},
+            {"kind": "Service", "apiVersion": "v1", "metadata": {"name": "fe2", "namespace": "default"}, "spec": {"selector": {"tier": "frontend"}}},
+            {"kind": "Service", "apiVersion": "v1", "metadata": {"name": "other", "namespace": "default"}, "spec": {"selector": {"app": "db"}}}]
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    outs = {}
+    for name, objs in (("with", svcs), ("without", [])):
+        path = tmp_path / f"{name}.json"
+        path.write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + [dict(p, kind="Pod") for p in pods] + objs}))
+        p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(path), "--dump-snapshot", "-"], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0 and p.stderr == "", p.stderr
+        got = json.loads(p.stdout)
+        got.pop("label_keys")
+        no, po, ns = cli.load_all([str(path)])
+        snap = ingest.build_snapshot(no, po, cli.parse_pod_spec(str(tmp_path / "pod.json")), namespace_objs=ns, service_objs=cli.load_kind([str(path)], "Service"))
+        ref = py_dump(snap)
+        for k in ref:
+            assert got[k] == ref[k], (name, k)
+        outs[name] = snap
+    a, b = outs["with"].pod, outs["without"].pod
+    assert not b.spread and [(c.max_skew, c.hard, c.is_hostname, c.self_match) for c in a.spread] == [(3, False, True, True), (5, False, False, True)]
+    # the merged selector app=guestbook,tier=frontend: p1, p3, p5 match -> on n1, n3, n1
+    assert a.spread[0].node_match_count.tolist() == [0, 2, 0, 1, 0, 0, 0, 0, 0]
+    ra, rb = ccref.run(M.Profile.default(), outs["with"].nodes, a), ccref.run(M.Profile.default(), outs["without"].nodes, b)
+    assert ra.placed == rb.placed and ra.per_node_count.tolist() == rb.per_node_count.tolist() and ra.log.tolist() != rb.log.tolist()
