@@ -9,6 +9,8 @@ LimitRanges; here they come from the same `--snapshot` files as the nodes (kubec
     apimachinery labels.ConvertSelectorToLabelsMap labels.go:159-183)."""
 from __future__ import annotations
 
+import math
+from fractions import Fraction
 from typing import List
 
 from . import ingest
@@ -55,7 +57,9 @@ def namespace_pod(namespace: str, namespace_objs: List[dict], limit_range_objs: 
                 if r not in best or ingest.parse_quantity(best[r]) > ingest.parse_quantity(amount):
                     best[r] = amount
     if any(ingest.parse_quantity(q) != 0 for q in best.values()):
-        pod["spec"]["containers"][0]["resources"] = {"limits": dict(best), "requests": dict(best)}
+        # (the serializer prints the Quantity, not the text it was read from: "0.5" leaves as "500m", "1024Mi" as "1Gi")
+        canon = {r: ingest.quantity_canonical(Fraction(math.ceil(ingest.parse_quantity(q) * 10**9), 10**9), ingest.quantity_format(q)) for r, q in best.items()}
+        pod["spec"]["containers"][0]["resources"] = {"limits": dict(canon), "requests": dict(canon)}
     ann = ns["metadata"].get("annotations") or {}
     if "openshift.io/node-selector" in ann:
         try:

@@ -80,7 +80,9 @@ inline Value namespace_pod(const std::string &ns_name, const std::vector<Value> 
         for (const char *r : kResources) {
             auto it = best.find(r);
             if (it == best.end()) continue;
-            limits.set(r, Value::str(it->second)), requests.set(r, Value::str(it->second));
+            // (the serializer prints the Quantity, not the text it was read from: "0.5" leaves as "500m", "1024Mi" as "1Gi")
+            const std::string canon = quantity_canonical(quantity_nano(parse_quantity(it->second)), quantity_format(it->second));
+            limits.set(r, Value::str(canon)), requests.set(r, Value::str(canon));
         }
         res.set("limits", limits), res.set("requests", requests);
         container.set("resources", res);

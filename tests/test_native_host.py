@@ -1517,3 +1517,15 @@ def test_system_default_spreading_becomes_two_soft_constraints_when_every_node_i
     assert a.spread[0].node_match_count.tolist() == [0, 2, 0, 1, 0, 0, 0, 0, 0]
     ra, rb = ccref.run(M.Profile.default(), outs["with"].nodes, a), ccref.run(M.Profile.default(), outs["without"].nodes, b)
     assert ra.placed == rb.placed and ra.per_node_count.tolist() == rb.per_node_count.tolist() and ra.log.tolist() != rb.log.tolist()
+
+
+def test_genpod_prints_quantities_canonically(native, tmp_path):
+    """The stub pod leaves through the serializer, which prints Quantity.String(), not the text the LimitRange carried."""
+    from cluster_capacity_amd import genpod
+    ns = [{"kind": "Namespace", "metadata": {"name": "q"}}]
+    lrs = [{"kind": "LimitRange", "metadata": {"name": "l", "namespace": "q"}, "spec": {"limits": [{"type": "Pod", "max": {"cpu": "0.5", "memory": "1024Mi", "nvdia.com/gpu": "2e0"}}]}}]
+    want = {"cpu": "500m", "memory": "1Gi", "nvdia.com/gpu": "2"}
+    assert genpod.namespace_pod("q", ns, lrs)["spec"]["containers"][0]["resources"]["requests"] == want
+    (tmp_path / "ns.json").write_text(json.dumps({"kind": "List", "items": ns + lrs}))
+    out = json.loads(_run(native, ["--genpod", "q", "--snapshot", str(tmp_path / "ns.json"), "-o", "json"]))
+    assert out["spec"]["containers"][0]["resources"] == {"limits": want, "requests": want}
