@@ -27,9 +27,9 @@ import yaml
 from . import ingest, model as M, preemption, report as R, schedconfig
 
 
-def load_all(paths: List[str]):
-    """-> (nodes, pods, namespaces): what SyncWithClient lists (simulator.go:176-295)."""
-    nodes, pods, namespaces = [], [], []
+def load_by_kind(paths: List[str]) -> dict:
+    """Every object of the snapshot files, by kind (lists are flattened; one pass over the files)."""
+    out: dict = {}
     for path in paths:
         with open(path) as f:
             docs = list(yaml.safe_load_all(f))  # YAML is a superset of JSON
@@ -38,13 +38,14 @@ def load_all(paths: List[str]):
                 continue
             items = d["items"] if str(d.get("kind", "")).endswith("List") and "items" in d else [d]
             for o in items:
-                if o.get("kind") == "Node":
-                    nodes.append(o)
-                elif o.get("kind") == "Pod":
-                    pods.append(o)
-                elif o.get("kind") == "Namespace":
-                    namespaces.append(o)
-    return nodes, pods, namespaces
+                out.setdefault(o.get("kind"), []).append(o)
+    return out
+
+
+def load_all(paths: List[str]):
+    """-> (nodes, pods, namespaces): what SyncWithClient lists (simulator.go:176-295)."""
+    by = load_by_kind(paths)
+    return by.get("Node", []), by.get("Pod", []), by.get("Namespace", [])
 
 
 def load_objects(paths: List[str]):
@@ -231,9 +232,10 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     prof, hard_weight = schedconfig.profile_from_config(cfg)
     pods = [parse_pod_spec(p) for p in args.podspec]
     pod = pods if len(pods) > 1 else pods[0]
-    node_objs, pod_objs, ns_objs = load_all(args.snapshot)
-    owners = [o for k in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in load_kind(args.snapshot, k)]
-    services = load_kind(args.snapshot, "Service")
+    by = load_by_kind(args.snapshot)
+    node_objs, pod_objs, ns_objs = by.get("Node", []), by.get("Pod", []), by.get("Namespace", [])
+    owners = [o for k in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in by.get(k, [])]
+    services = by.get("Service", [])
     snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
                                  namespace_objs=ns_objs, service_objs=services, owner_objs=owners,
                                  system_default_spreading=bool(prof.w_topologyspread) and getattr(prof, "system_default_spreading", True))
