@@ -200,6 +200,9 @@ int main(int argc, char **argv) {
                 std::stringstream ss(need());
                 for (std::string x; std::getline(ss, x, ',');)
                     if (!x.empty()) exclude.push_back(x);
+            } else if (a == "--help" || a == "-h") {
+                usage("Cluster-capacity is used for simulating scheduling of one or multiple pods"); // (the reference's command description, cmd/cluster-capacity/app/server.go:56)
+                return 0;
             } else if (a == "--verbose") verbose = true;
             else if (a == "-o" || a == "--output") output = need();
             else if (a == "--mode") mode = need();
