@@ -44,6 +44,12 @@ STRINGS = {
     "qname.ext_char": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const qnameExtCharFmt string = "([^"]+)"'),
     "qname.dns1123_label": ("vendor/k8s.io/apimachinery/pkg/util/validation/validation.go", r'const dns1123LabelFmt string = "([^"]+)"'),
     "report.gpu_resource_name": ("pkg/framework/report.go", r'ResourceNvidiaGPU v1\.ResourceName = "([^"]+)"'),
+    "toleration.op_exists": ("vendor/k8s.io/api/core/v1/types.go", r'TolerationOpExists TolerationOperator = "([^"]+)"'),
+    "toleration.op_equal": ("vendor/k8s.io/api/core/v1/types.go", r'TolerationOpEqual\s+TolerationOperator = "([^"]+)"'),
+    "label.zone": ("vendor/k8s.io/api/core/v1/well_known_labels.go", r'LabelTopologyZone\s+= "([^"]+)"'),
+    "label.region": ("vendor/k8s.io/api/core/v1/well_known_labels.go", r'LabelTopologyRegion = "([^"]+)"'),
+    "label.zone_beta": ("vendor/k8s.io/api/core/v1/well_known_labels.go", r'LabelFailureDomainBetaZone\s+= "([^"]+)"'),
+    "label.region_beta": ("vendor/k8s.io/api/core/v1/well_known_labels.go", r'LabelFailureDomainBetaRegion = "([^"]+)"'),
     "stop.limit_format": ("pkg/framework/simulator.go", r'fmt\.Sprintf\("(LimitReached: Maximum number of pods simulated: %v)"'),
     "report.headline_format": ("pkg/framework/report.go", r'fmt\.Printf\("(The cluster can schedule %v instance\(s\) of the pod %v\.)\\n"'),
     "report.termination_format": ("pkg/framework/report.go", r'fmt\.Printf\("\\n(Termination reason: %v: %v)\\n"'),

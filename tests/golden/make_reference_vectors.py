@@ -50,6 +50,12 @@ FUNCS = [
      "func (pl *InterPodAffinity) NormalizeScore(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, scores framework.NodeScoreList) *fwk.Status {",
      ["scores"], False),
 ]
+# string-level helpers the ingests mirror: toleration matching, the zone key of the node tree, image name normalisation
+FUNCS += [
+    ("ToleratesTaint", "vendor/k8s.io/api/core/v1/toleration.go", "func (t *Toleration) ToleratesTaint(taint *Taint) bool {", ["t", "taint"], False),
+    ("GetZoneKey", "vendor/k8s.io/component-helpers/node/topology/helpers.go", "func GetZoneKey(node *v1.Node) string {", ["node"], False),
+    ("normalizedImageName", S + "/framework/plugins/imagelocality/image_locality.go", "func normalizedImageName(name string) string {", ["name"], False),
+]
 # statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
 DROP = {
     "ptsNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if s == nil {", "return nil", "}"],
@@ -82,13 +88,32 @@ def transliterate(name, params, body, int_div):
         if inner[0].strip() != drop[0]:
             raise SystemExit(f"{name}: expected {drop[0]!r}, found {inner[0]!r}")
         inner, drop = inner[1:], drop[1:]
+    switches = []  # depth of every open `switch`: its cases become an if / elif chain on _sw
     for raw in inner:
         ln = raw.strip()
         if not ln or ln.startswith("//"):
             continue
+        m = re.fullmatch(r"switch (.+) \{", ln)
+        if m:
+            out.append("    " * depth + "_sw = " + expr(m.group(1), int_div))
+            switches.append([depth, True])
+            depth += 1
+            continue
+        if switches and (re.fullmatch(r"case (.+):", ln) or ln == "default:"):
+            d, first = switches[-1]
+            if ln == "default:":
+                out.append("    " * d + "else:")
+            else:
+                vals = ", ".join(expr(v.strip(), int_div) for v in ln[5:-1].split(","))
+                out.append("    " * d + ("if" if first else "elif") + f" _sw in ({vals},):")
+                switches[-1][1] = False
+            depth = d + 1
+            continue
         # closing braces (with else) first
         if ln.startswith("}"):
             depth -= 1
+            if switches and depth == switches[-1][0]:
+                switches.pop()
             ln = ln[1:].strip()
             if not ln:
                 continue
@@ -127,6 +152,13 @@ def transliterate(name, params, body, int_div):
                 ln = re.sub(r"var (\w+) int64 = (.+)", r"\1 = \2", ln)
             elif re.fullmatch(r"var (\w+) (int64|int32|float64)", ln):
                 ln = re.sub(r"var (\w+) (int64|int32|float64)", r"\1 = 0", ln)
+            m = re.fullmatch(r"(\w+), ok := (\w+)\[(.+)\]", ln)
+            m2 = re.fullmatch(r"(\w+), _ = (\w+)\[(.+)\]", ln)
+            if m:   # the two-value map lookup: the zero value ("") when the key is absent
+                out.append("    " * depth + f"ok = {expr(m.group(3), int_div)} in {m.group(2)}")
+                ln = f"{m.group(1)} = {m.group(2)}.get({m.group(3)}, \"\")"
+            elif m2:
+                ln = f"{m2.group(1)} = {m2.group(2)}.get({m2.group(3)}, \"\")"
             ln = ln.replace(":=", "=")
             m = re.fullmatch(r"(\w+) = append\((\w+), (.+)\)", ln)
             if m and m.group(1) == m.group(2):
@@ -149,6 +181,12 @@ def expr(ln, int_div):
     ln = re.sub(r"^(\s*)(\w+) = float\(0\)$", r"\1\2 = 0.0", ln)
     ln = ln.replace("percentageOfNodesToScore != nil", "percentageOfNodesToScore is not None").replace("*percentageOfNodesToScore", "percentageOfNodesToScore")
     ln = ln.replace("true", "True").replace("false", "False") if re.search(r"\b(true|false)\b", ln) else ln
+    ln = re.sub(r"strings\.LastIndex\((\w+), (\"[^\"]*\")\)", r"\1.rfind(\2)", ln)
+    ln = ln.replace(" && ", " and ").replace(" || ", " or ")
+    ln = re.sub(r"!(\w)", r"not \1", ln)
+    ln = re.sub(r"\bnil\b", "None", ln)
+    ln = ln.replace("v1.LabelFailureDomainBetaZone", "LabelFailureDomainBetaZone").replace("v1.LabelTopologyZone", "LabelTopologyZone")
+    ln = ln.replace("v1.LabelFailureDomainBetaRegion", "LabelFailureDomainBetaRegion").replace("v1.LabelTopologyRegion", "LabelTopologyRegion")
     if int_div and "/" in ln:
         # a / b between integers: Go truncates toward zero.  Only the shapes that occur: `X / name` and `X / number`, at the top level of
         # a statement `lhs = A / B`, `return A / B` or `lhs = A - B/C`
@@ -174,7 +212,9 @@ def goint(x):
 
 def build():
     env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"], "MaxInt64": (1 << 63) - 1, "MinInt64": -(1 << 63),
-           "invalidScore": -1,
+           "invalidScore": -1, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
+           "LabelFailureDomainBetaZone": PINS["label.zone_beta"], "LabelTopologyZone": PINS["label.zone"],
+           "LabelFailureDomainBetaRegion": PINS["label.region_beta"], "LabelTopologyRegion": PINS["label.region"],
            "minThreshold": PINS["image.min_threshold_mb"] * PINS["image.mb"], "maxContainerThreshold": PINS["image.max_container_threshold_mb"] * PINS["image.mb"],
            "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"]}
     sources = {}
@@ -256,6 +296,21 @@ def vectors(env):
         env["ipaNormalizeScore"](out)
         rows.append([sc, out])
     v["ipaNormalizeScore"] = rows
+    rows = []
+    keys, vals_, effs, ops = ["", "dedicated", "gpu"], ["", "infra", "x"], ["", "NoSchedule", "PreferNoSchedule", "NoExecute"], ["", "Equal", "Exists", "Bogus"]
+    for _ in range(1500):
+        tol = {"Key": rnd.choice(keys), "Value": rnd.choice(vals_), "Effect": rnd.choice(effs), "Operator": rnd.choice(ops)}
+        taint = {"Key": rnd.choice(keys[1:]), "Value": rnd.choice(vals_), "Effect": rnd.choice(effs[1:])}
+        rows.append([tol, taint, env["ToleratesTaint"](types.SimpleNamespace(**tol), types.SimpleNamespace(**taint))])
+    v["ToleratesTaint"] = rows
+    rows = []
+    lk = [PINS["label.zone_beta"], PINS["label.zone"], PINS["label.region_beta"], PINS["label.region"], "other"]
+    for _ in range(600):
+        labels = None if rnd.random() < 0.05 else {k: rnd.choice(["", "a", "b:c"]) for k in lk if rnd.random() < 0.5}
+        rows.append([labels, env["GetZoneKey"](types.SimpleNamespace(Labels=labels))])
+    v["GetZoneKey"] = rows
+    names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
+    v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
     return v
 
 

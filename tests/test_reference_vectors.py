@@ -32,7 +32,8 @@ def test_transliterations_are_line_by_line():
         go = [l.strip() for l in s["go"].split("\n")[1:-1] if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
         dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
-        assert len(go) - dropped == len(py), name
+        two_value_lookups = sum(", ok := " in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
+        assert len(go) - dropped + two_value_lookups == len(py), name
 
 
 def test_least_allocated(ccref):
@@ -69,3 +70,26 @@ def test_pts_normalize(ccref):
 def test_ipa_normalize(ccref):
     for sc, want in VEC["ipaNormalizeScore"]:
         assert ccref.ipa_normalize(sc) == want, sc
+
+
+# ---- string-level helpers the ingests mirror ------------------------------------------------------------------------------------
+def test_toleration_matching():
+    from cluster_capacity_amd import ingest
+    for tol, taint, want in VEC["ToleratesTaint"]:
+        t = {k.lower(): v for k, v in tol.items() if v != ""}      # (an object as kubectl prints it: empty fields are absent)
+        x = {k.lower(): v for k, v in taint.items() if v != ""}
+        assert ingest.tolerates(t, x) == want, (tol, taint)
+        full = {k.lower(): v for k, v in tol.items()}               # ... and with the empty strings spelt out
+        assert ingest.tolerates(full, {k.lower(): v for k, v in taint.items()}) == want, (tol, taint)
+
+
+def test_zone_key():
+    from cluster_capacity_amd import ingest
+    for labels, want in VEC["GetZoneKey"]:
+        assert ingest.zone_key(labels or {}) == want, labels
+
+
+def test_normalized_image_name():
+    from cluster_capacity_amd import ingest
+    for name, want in VEC["normalizedImageName"]:
+        assert ingest.normalized_image_name(name) == want, name
