@@ -55,6 +55,10 @@ FUNCS += [
     ("ToleratesTaint", "vendor/k8s.io/api/core/v1/toleration.go", "func (t *Toleration) ToleratesTaint(taint *Taint) bool {", ["t", "taint"], False),
     ("GetZoneKey", "vendor/k8s.io/component-helpers/node/topology/helpers.go", "func GetZoneKey(node *v1.Node) string {", ["node"], False),
     ("normalizedImageName", S + "/framework/plugins/imagelocality/image_locality.go", "func normalizedImageName(name string) string {", ["name"], False),
+    # label / node-selector requirements (NodeAffinity, nodeSelector, label selectors): In NotIn Exists DoesNotExist Gt Lt.  strconv.ParseInt is
+    # Go's standard library (not in the tree): parse_int below stands in for it; the klog lines are dropped
+    ("requirementHasValue", "vendor/k8s.io/apimachinery/pkg/labels/selector.go", "func (r *Requirement) hasValue(value string) bool {", ["r", "value"], False),
+    ("requirementMatches", "vendor/k8s.io/apimachinery/pkg/labels/selector.go", "func (r *Requirement) Matches(ls Labels) bool {", ["r", "ls"], False),
 ]
 # statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
 DROP = {
@@ -129,8 +133,8 @@ def transliterate(name, params, body, int_div):
         opens = ln.endswith("{")
         if opens:
             ln = ln[:-1].strip()
-            m = re.fullmatch(r"for (\w+) := range (\w+)", ln)
-            m2 = re.fullmatch(r"for _, (\w+) := range (\w+)", ln)
+            m = re.fullmatch(r"for (\w+) := range ([\w.]+)", ln)
+            m2 = re.fullmatch(r"for _, (\w+) := range ([\w.]+)", ln)
             m3 = re.fullmatch(r"for (\w+), (\w+) := range (\w+)", ln)
             if m3 and m3.group(1) != "_":
                 ln = f"for {m3.group(1)}, {m3.group(2)} in enumerate({m3.group(3)}):"
@@ -152,6 +156,15 @@ def transliterate(name, params, body, int_div):
                 ln = re.sub(r"var (\w+) int64 = (.+)", r"\1 = \2", ln)
             elif re.fullmatch(r"var (\w+) (int64|int32|float64)", ln):
                 ln = re.sub(r"var (\w+) (int64|int32|float64)", r"\1 = 0", ln)
+            if ln.startswith("klog."):
+                ln = "pass"
+            ml = re.fullmatch(r"(\w+), (\w+) := ls\.Lookup\((.+)\)", ln)
+            mp = re.fullmatch(r"(\w+), err :?= strconv\.ParseInt\((.+), 10, 64\)", ln)
+            if ml:  # Labels.Lookup: (value, present)
+                out.append("    " * depth + f"{ml.group(2)} = {ml.group(3)} in ls")
+                ln = f"{ml.group(1)} = ls.get({ml.group(3)}, \"\")"
+            elif mp:
+                ln = f"{mp.group(1)}, err = parse_int({mp.group(2)})"
             m = re.fullmatch(r"(\w+), ok := (\w+)\[(.+)\]", ln)
             m2 = re.fullmatch(r"(\w+), _ = (\w+)\[(.+)\]", ln)
             if m:   # the two-value map lookup: the zero value ("") when the key is absent
@@ -182,8 +195,11 @@ def expr(ln, int_div):
     ln = ln.replace("percentageOfNodesToScore != nil", "percentageOfNodesToScore is not None").replace("*percentageOfNodesToScore", "percentageOfNodesToScore")
     ln = ln.replace("true", "True").replace("false", "False") if re.search(r"\b(true|false)\b", ln) else ln
     ln = re.sub(r"strings\.LastIndex\((\w+), (\"[^\"]*\")\)", r"\1.rfind(\2)", ln)
+    ln = re.sub(r"\br\.hasValue\((\w+)\)", r"requirementHasValue(r, \1)", ln)
+    ln = re.sub(r"\bls\.Has\(([\w.]+)\)", r"(\1 in ls)", ln)
+    ln = re.sub(r"\bselection\.(\w+)", r"SEL_\1", ln)
     ln = ln.replace(" && ", " and ").replace(" || ", " or ")
-    ln = re.sub(r"!(\w)", r"not \1", ln)
+    ln = re.sub(r"!(?=[\w(])", "not ", ln)  # (logical not; != is left alone)
     ln = re.sub(r"\bnil\b", "None", ln)
     ln = ln.replace("v1.LabelFailureDomainBetaZone", "LabelFailureDomainBetaZone").replace("v1.LabelTopologyZone", "LabelTopologyZone")
     ln = ln.replace("v1.LabelFailureDomainBetaRegion", "LabelFailureDomainBetaRegion").replace("v1.LabelTopologyRegion", "LabelTopologyRegion")
@@ -201,6 +217,18 @@ def expr(ln, int_div):
     return ln
 
 
+SELECTION = {"DoesNotExist": "!", "Equals": "=", "DoubleEquals": "==", "In": "in", "NotEquals": "!=", "NotIn": "notin", "Exists": "exists", "GreaterThan": "gt",
+             "LessThan": "lt"}  # apimachinery/pkg/selection/operator.go:23-33 (checked against the file in build())
+
+
+def parse_int(text):
+    """strconv.ParseInt(text, 10, 64): (value, nil) or (0, error).  Go's standard library is not part of the reference tree; this is its
+    documented contract: an optional sign, decimal digits, inside int64."""
+    if re.fullmatch(r"[+-]?[0-9]+", text) and -(1 << 63) <= int(text) < (1 << 63):
+        return int(text), None
+    return 0, "error"
+
+
 def godiv(a, b):
     q = abs(a) // abs(b)
     return q if (a >= 0) == (b >= 0) else -q
@@ -212,11 +240,14 @@ def goint(x):
 
 def build():
     env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"], "MaxInt64": (1 << 63) - 1, "MinInt64": -(1 << 63),
-           "invalidScore": -1, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
+           "invalidScore": -1, "parse_int": parse_int, **{"SEL_" + k: v for k, v in SELECTION.items()}, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
            "LabelFailureDomainBetaZone": PINS["label.zone_beta"], "LabelTopologyZone": PINS["label.zone"],
            "LabelFailureDomainBetaRegion": PINS["label.region_beta"], "LabelTopologyRegion": PINS["label.region"],
            "minThreshold": PINS["image.min_threshold_mb"] * PINS["image.mb"], "maxContainerThreshold": PINS["image.max_container_threshold_mb"] * PINS["image.mb"],
            "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"]}
+    op_src = open(os.path.join(REF, "vendor/k8s.io/apimachinery/pkg/selection/operator.go")).read()
+    for k, v in SELECTION.items():
+        assert re.search(r"\b%s\s+Operator = \"%s\"" % (k, re.escape(v)), op_src), k
     sources = {}
     for name, rel, start, params, int_div in FUNCS:
         line, body = cut(rel, start)
@@ -309,6 +340,15 @@ def vectors(env):
         labels = None if rnd.random() < 0.05 else {k: rnd.choice(["", "a", "b:c"]) for k in lk if rnd.random() < 0.5}
         rows.append([labels, env["GetZoneKey"](types.SimpleNamespace(Labels=labels))])
     v["GetZoneKey"] = rows
+    rows = []
+    label_vals = ["", "a", "b", "3", "10", "-2", "+7", "1_0", "x3", "99999999999999999999"]
+    for _ in range(3000):
+        op = rnd.choice(list(SELECTION.values()))
+        vals = [rnd.choice(label_vals) for _ in range(rnd.choice([0, 1, 1, 2, 3]))]
+        ls = {k: rnd.choice(label_vals) for k in ("k", "other") if rnd.random() < 0.7}
+        r = types.SimpleNamespace(key="k", operator=op, strValues=vals)
+        rows.append([op, vals, ls, env["requirementMatches"](r, ls)])
+    v["requirementMatches"] = rows
     names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
     v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
     return v

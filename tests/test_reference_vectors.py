@@ -32,7 +32,7 @@ def test_transliterations_are_line_by_line():
         go = [l.strip() for l in s["go"].split("\n")[1:-1] if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
         dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
-        two_value_lookups = sum(", ok := " in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
+        two_value_lookups = sum(", ok := " in l or ":= ls.Lookup(" in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
         assert len(go) - dropped + two_value_lookups == len(py), name
 
 
@@ -93,3 +93,18 @@ def test_normalized_image_name():
     from cluster_capacity_amd import ingest
     for name, want in VEC["normalizedImageName"]:
         assert ingest.normalized_image_name(name) == want, name
+
+
+def test_requirement_matching():
+    """labels.Requirement.Matches (apimachinery/pkg/labels/selector.go:246-293) behind nodeSelector / node affinity / label selectors.  The
+    operators a NodeSelectorRequirement or LabelSelectorRequirement can name map onto selection operators
+    (component-helpers/scheduling/corev1/nodeaffinity nodeSelectorRequirementsAsSelector, metav1 LabelSelectorAsSelector)."""
+    from cluster_capacity_amd import ingest
+    name = {"in": "In", "notin": "NotIn", "exists": "Exists", "!": "DoesNotExist", "gt": "Gt", "lt": "Lt"}
+    checked = 0
+    for op, vals, ls, want in VEC["requirementMatches"]:
+        if op not in name:
+            continue  # =, ==, != only arise from selector STRINGS, which no object of this path carries
+        assert ingest.requirement_matches("k" in ls, ls.get("k"), name[op], vals) == want, (op, vals, ls)
+        checked += 1
+    assert checked > 1500
