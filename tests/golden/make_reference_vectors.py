@@ -15,7 +15,8 @@ implementation is its own (the oracle restates it; no other implementation of th
 
 Functions: leastRequestedScore + the closure of leastResourceScorer (noderesources/least_allocated.go), balancedResourceScorer
 (noderesources/balanced_allocation.go), DefaultNormalizeScore (helper/normalize_score.go), numFeasibleNodesToFind (schedule_one.go),
-calculatePriority + scaledImageScore (imagelocality/image_locality.go), scoreForCount (podtopologyspread/scoring.go)."""
+calculatePriority + scaledImageScore (imagelocality/image_locality.go), scoreForCount (podtopologyspread/scoring.go); and the string-level
+helpers of FUNCS' second block (toleration / taint verdicts, zone key, image names, label requirements)."""
 import json
 import math
 import os
@@ -59,6 +60,20 @@ FUNCS += [
     # Go's standard library (not in the tree): parse_int below stands in for it; the klog lines are dropped
     ("requirementHasValue", "vendor/k8s.io/apimachinery/pkg/labels/selector.go", "func (r *Requirement) hasValue(value string) bool {", ["r", "value"], False),
     ("requirementMatches", "vendor/k8s.io/apimachinery/pkg/labels/selector.go", "func (r *Requirement) Matches(ls Labels) bool {", ["r", "ls"], False),
+    # the TaintToleration plugin's verdicts: the Filter's first untolerated NoSchedule / NoExecute taint, the Score's count of untolerated
+    # PreferNoSchedule taints over the tolerations PreScore keeps
+    ("TolerationsTolerateTaint", "vendor/k8s.io/component-helpers/scheduling/corev1/helpers.go",
+     "func TolerationsTolerateTaint(tolerations []v1.Toleration, taint *v1.Taint) bool {", ["tolerations", "taint"], False),
+    ("getFilteredTaints", "vendor/k8s.io/component-helpers/scheduling/corev1/helpers.go",
+     "func getFilteredTaints(taints []v1.Taint, inclusionFilter taintsFilterFunc) []v1.Taint {", ["taints", "inclusionFilter"], False),
+    ("FindMatchingUntoleratedTaint", "vendor/k8s.io/component-helpers/scheduling/corev1/helpers.go",
+     "func FindMatchingUntoleratedTaint(taints []v1.Taint, tolerations []v1.Toleration, inclusionFilter taintsFilterFunc) (v1.Taint, bool) {",
+     ["taints", "tolerations", "inclusionFilter"], False),
+    ("DoNotScheduleTaintsFilter_closure", S + "/framework/plugins/helper/taint.go", "\treturn func(t *v1.Taint) bool {", ["t"], False),
+    ("getAllTolerationPreferNoSchedule", S + "/framework/plugins/tainttoleration/taint_toleration.go",
+     "func getAllTolerationPreferNoSchedule(tolerations []v1.Toleration) (tolerationList []v1.Toleration) {", ["tolerations"], False),
+    ("countIntolerableTaintsPreferNoSchedule", S + "/framework/plugins/tainttoleration/taint_toleration.go",
+     "func countIntolerableTaintsPreferNoSchedule(taints []v1.Taint, tolerations []v1.Toleration) (intolerableTaints int) {", ["taints", "tolerations"], False),
 ]
 # statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
 DROP = {
@@ -85,6 +100,9 @@ def transliterate(name, params, body, int_div):
     out = [f"def {name}({', '.join(params)}):"]
     depth = 1
     inner = body[1:-1]
+    named = re.search(r"\) \((\w+) (\[\])?[\w.]+\) \{$", body[0])  # a named result: starts at its zero value, a bare `return` returns it
+    if named:
+        out.append("    " + named.group(1) + (" = []" if named.group(2) else " = 0"))
     drop = list(DROP.get(name, []))
     while drop:  # the dropped statements are the first non-blank lines of the body, in this order
         while not inner[0].strip() or inner[0].strip().startswith("//"):
@@ -178,6 +196,9 @@ def transliterate(name, params, body, int_div):
                 ln = f"{m.group(1)} = {m.group(1)} + [{m.group(3)}]"
             if ln == "return nil":
                 ln = "return None"
+            if ln == "return" and named:
+                ln = "return " + named.group(1)
+            ln = re.sub(r"^(\w+)\+\+$", r"\1 += 1", ln)
         out.append("    " * depth + expr(ln, int_div))
         if opens:
             depth += 1
@@ -198,7 +219,11 @@ def expr(ln, int_div):
     ln = re.sub(r"\br\.hasValue\((\w+)\)", r"requirementHasValue(r, \1)", ln)
     ln = re.sub(r"\bls\.Has\(([\w.]+)\)", r"(\1 in ls)", ln)
     ln = re.sub(r"\bselection\.(\w+)", r"SEL_\1", ln)
+    ln = re.sub(r"\b(\w+)\[i\]\.ToleratesTaint\((\w+)\)", r"ToleratesTaint(\1[i], \2)", ln)
+    ln = ln.replace("v1helper.TolerationsTolerateTaint(", "TolerationsTolerateTaint(").replace("[]v1.Taint{}", "[]").replace("v1.Taint{}", "None")
+    ln = re.sub(r"\bv1\.TaintEffect(\w+)", r"TaintEffect\1", ln)
     ln = ln.replace(" && ", " and ").replace(" || ", " or ")
+    ln = re.sub(r"(?<![&\w])&(?=\w)", "", ln)  # &taint: the address of the loop variable, read only
     ln = re.sub(r"!(?=[\w(])", "not ", ln)  # (logical not; != is left alone)
     ln = re.sub(r"\bnil\b", "None", ln)
     ln = ln.replace("v1.LabelFailureDomainBetaZone", "LabelFailureDomainBetaZone").replace("v1.LabelTopologyZone", "LabelTopologyZone")
@@ -221,6 +246,9 @@ SELECTION = {"DoesNotExist": "!", "Equals": "=", "DoubleEquals": "==", "In": "in
              "LessThan": "lt"}  # apimachinery/pkg/selection/operator.go:23-33 (checked against the file in build())
 
 
+TAINT_EFFECTS = {"NoSchedule": "NoSchedule", "PreferNoSchedule": "PreferNoSchedule", "NoExecute": "NoExecute"}  # api/core/v1/types.go (checked in build())
+
+
 def parse_int(text):
     """strconv.ParseInt(text, 10, 64): (value, nil) or (0, error).  Go's standard library is not part of the reference tree; this is its
     documented contract: an optional sign, decimal digits, inside int64."""
@@ -240,7 +268,7 @@ def goint(x):
 
 def build():
     env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"], "MaxInt64": (1 << 63) - 1, "MinInt64": -(1 << 63),
-           "invalidScore": -1, "parse_int": parse_int, **{"SEL_" + k: v for k, v in SELECTION.items()}, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
+           "invalidScore": -1, "parse_int": parse_int, **{"TaintEffect" + k: v for k, v in TAINT_EFFECTS.items()}, **{"SEL_" + k: v for k, v in SELECTION.items()}, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
            "LabelFailureDomainBetaZone": PINS["label.zone_beta"], "LabelTopologyZone": PINS["label.zone"],
            "LabelFailureDomainBetaRegion": PINS["label.region_beta"], "LabelTopologyRegion": PINS["label.region"],
            "minThreshold": PINS["image.min_threshold_mb"] * PINS["image.mb"], "maxContainerThreshold": PINS["image.max_container_threshold_mb"] * PINS["image.mb"],
@@ -248,6 +276,9 @@ def build():
     op_src = open(os.path.join(REF, "vendor/k8s.io/apimachinery/pkg/selection/operator.go")).read()
     for k, v in SELECTION.items():
         assert re.search(r"\b%s\s+Operator = \"%s\"" % (k, re.escape(v)), op_src), k
+    types_src = open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read()
+    for k, v in TAINT_EFFECTS.items():
+        assert re.search(r"\bTaintEffect%s TaintEffect = \"%s\"" % (k, v), types_src), k
     sources = {}
     for name, rel, start, params, int_div in FUNCS:
         line, body = cut(rel, start)
@@ -349,6 +380,17 @@ def vectors(env):
         r = types.SimpleNamespace(key="k", operator=op, strValues=vals)
         rows.append([op, vals, ls, env["requirementMatches"](r, ls)])
     v["requirementMatches"] = rows
+    rows = []
+    keep = env["DoNotScheduleTaintsFilter_closure"]
+    for _ in range(1500):
+        mk = lambda d: types.SimpleNamespace(**d)
+        taints = [{"Key": rnd.choice(keys[1:]), "Value": rnd.choice(vals_), "Effect": rnd.choice(effs[1:])} for _ in range(rnd.choice([0, 1, 2, 3, 5]))]
+        tols = [{"Key": rnd.choice(keys), "Value": rnd.choice(vals_), "Effect": rnd.choice(effs), "Operator": rnd.choice(ops[:3])} for _ in range(rnd.choice([0, 0, 1, 2, 4]))]
+        tt, tl = [mk(d) for d in taints], [mk(d) for d in tols]
+        taint, found = env["FindMatchingUntoleratedTaint"](tt, tl, keep)
+        cnt = env["countIntolerableTaintsPreferNoSchedule"](tt, env["getAllTolerationPreferNoSchedule"](tl))
+        rows.append([taints, tols, found, tt.index(taint) if found else -1, cnt])
+    v["taintVerdict"] = rows
     names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
     v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
     return v

@@ -7,6 +7,7 @@ for its scoring arithmetic.  Not covered: math.Log (Go's own implementation; the
 flow over scheduler state rather than arithmetic."""
 import json
 import os
+import re
 
 import pytest
 
@@ -33,7 +34,8 @@ def test_transliterations_are_line_by_line():
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
         dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
         two_value_lookups = sum(", ok := " in l or ":= ls.Lookup(" in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
-        assert len(go) - dropped + two_value_lookups == len(py), name
+        named_result = 1 if re.search(r"\) \(\w+ [\[\]\w.]+\) \{$", s["go"].split("\n")[0]) else 0  # `(n int)`: one line that sets its zero value
+        assert len(go) - dropped + two_value_lookups + named_result == len(py), name
 
 
 def test_least_allocated(ccref):
@@ -81,6 +83,18 @@ def test_toleration_matching():
         assert ingest.tolerates(t, x) == want, (tol, taint)
         full = {k.lower(): v for k, v in tol.items()}               # ... and with the empty strings spelt out
         assert ingest.tolerates(full, {k.lower(): v for k, v in taint.items()}) == want, (tol, taint)
+
+
+def test_taint_verdicts():
+    """The TaintToleration Filter (first untolerated NoSchedule / NoExecute taint: helpers.go:78-101 under taint.go:23-28) and Score
+    (untolerated PreferNoSchedule taints over the tolerations PreScore keeps: taint_toleration.go:135-181)."""
+    from cluster_capacity_amd import ingest
+    low = lambda d: {k.lower(): v for k, v in d.items() if v != ""}
+    for taints, tols, found, at, cnt in VEC["taintVerdict"]:
+        ok, n, first = ingest.taint_verdict([low(t) for t in taints], [low(t) for t in tols])
+        assert ok == (not found) and n == cnt, (taints, tols)
+        if found:
+            assert first == low(taints[at]), (taints, tols)
 
 
 def test_zone_key():
