@@ -56,7 +56,8 @@ HOST_DEPS = sorted(f for f in os.listdir(HOST) if f.endswith(".hpp"))  # every h
 
 
 def host_path() -> str:
-    return os.path.join(HERE, "bin", "cluster-capacity-native")
+    san = os.environ.get("CCHOST_SANITIZE")  # e.g. "address,undefined" or "thread": a second binary, for tests/ under the sanitizers
+    return os.path.join(HERE, "bin", "cluster-capacity-native" + ("-" + san.replace(",", "-") if san else ""))
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
@@ -65,7 +66,9 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     deps = [os.path.join(HOST, f) for f in HOST_SOURCES + HOST_DEPS] + [os.path.join(ROOT, "include", "ccsim.h")]
     if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", out] + \
+        san = os.environ.get("CCHOST_SANITIZE")
+        opt = ["-O1", "-g", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all", "-fsanitize=" + san] if san else ["-O2"]
+        cmd = [os.environ.get("CXX", "g++")] + opt + ["-std=c++17", "-Wall", "-Wextra", "-o", out] + \
               [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd))

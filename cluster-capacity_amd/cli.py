@@ -230,15 +230,21 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         with open(args.default_config) as f:
             cfg = yaml.safe_load(f)
     prof, hard_weight = schedconfig.profile_from_config(cfg)
-    pods = [parse_pod_spec(p) for p in args.podspec]
-    pod = pods if len(pods) > 1 else pods[0]
-    by = load_by_kind(args.snapshot)
-    node_objs, pod_objs, ns_objs = by.get("Node", []), by.get("Pod", []), by.get("Namespace", [])
-    owners = [o for k in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in by.get(k, [])]
-    services = by.get("Service", [])
-    snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
-                                 namespace_objs=ns_objs, service_objs=services, owner_objs=owners,
-                                 system_default_spreading=bool(prof.w_topologyspread) and getattr(prof, "system_default_spreading", True))
+    try:
+        pods = [parse_pod_spec(p) for p in args.podspec]
+        pod = pods if len(pods) > 1 else pods[0]
+        by = load_by_kind(args.snapshot)
+        node_objs, pod_objs, ns_objs = by.get("Node", []), by.get("Pod", []), by.get("Namespace", [])
+        owners = [o for k in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in by.get(k, [])]
+        services = by.get("Service", [])
+        snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
+                                     namespace_objs=ns_objs, service_objs=services, owner_objs=owners,
+                                     system_default_spreading=bool(prof.w_topologyspread) and getattr(prof, "system_default_spreading", True))
+    except (TypeError, AttributeError, KeyError, OverflowError) as e:
+        # the objects are walked as plain dicts / lists: a string where a mapping belongs (a decode error in the reference, which reads
+        # into typed structs) or a sum beyond int64 surfaces as one of these -- refused, like the native host refuses it
+        sys.stderr.write(f"cluster-capacity: malformed object: {type(e).__name__}: {e}\n")
+        return 1
     if snap.default_spreading_unmodelled:
         print("warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system default "
               "spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; some node lacks one of the two labels (or several templates run): "

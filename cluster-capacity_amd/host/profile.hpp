@@ -80,12 +80,12 @@ inline HostProfile profile_from_config(const Value &cfg) {
     if (cfg.is_null()) return p;
     if (cfg["kind"].truthy() && cfg["kind"].text() != "KubeSchedulerConfiguration") throw std::runtime_error("scheduler config: kind is not KubeSchedulerConfiguration");
     if (cfg.has("percentageOfNodesToScore") && !cfg["percentageOfNodesToScore"].is_null())
-        p.c.percentage_of_nodes_to_score = (int32_t)cfg["percentageOfNodesToScore"].as_int(), p.percentage_set = true;
+        p.c.percentage_of_nodes_to_score = cfg["percentageOfNodesToScore"].as_int32(), p.percentage_set = true;
     const Value &profiles = cfg["profiles"];
     if (profiles.items().size() > 1) throw std::runtime_error("scheduler config: one profile only (the simulated pod is scheduled by Profiles[0], pkg/utils/utils.go:103-108)");
     const Value &prof = profiles.items().empty() ? Value::null_value() : profiles.items()[0];
     if (prof.has("percentageOfNodesToScore") && !prof["percentageOfNodesToScore"].is_null())
-        p.c.percentage_of_nodes_to_score = (int32_t)prof["percentageOfNodesToScore"].as_int(), p.percentage_set = true;
+        p.c.percentage_of_nodes_to_score = prof["percentageOfNodesToScore"].as_int32(), p.percentage_set = true;
 
     auto lookup = [&](const std::string &name) -> const PluginInfo * {
         auto it = plugin_table().find(name);
@@ -119,7 +119,7 @@ inline HostProfile profile_from_config(const Value &cfg) {
             if (!i) continue;
             if (do_filter) set_filter(*i, true);
             if (do_score && i->weight) {
-                const int w = (int)e["weight"].as_int();
+                const int w = e["weight"].as_int32();
                 if (w < 0 || w > 100 * 1000) throw std::runtime_error("scheduler config: bad weight for " + e["name"].text());
                 // multiPoint: an unset weight keeps the plugin's default; a Score entry without weight gets 1 (defaults.go:120-131)
                 set_score(*i, w > 0 ? w : (multipoint ? i->default_weight : 1));
@@ -159,7 +159,7 @@ inline HostProfile profile_from_config(const Value &cfg) {
                 }
             }
         } else if (name == "InterPodAffinity") {
-            if (args.has("hardPodAffinityWeight")) p.hard_pod_affinity_weight = (int)args["hardPodAffinityWeight"].as_int();
+            if (args.has("hardPodAffinityWeight")) p.hard_pod_affinity_weight = args["hardPodAffinityWeight"].as_int32();
             if (args["ignorePreferredTermsOfExistingPods"].truthy()) throw std::runtime_error("scheduler config: ignorePreferredTermsOfExistingPods is not implemented");
         } else if (name == "PodTopologySpread") {
             if (args["defaultConstraints"].truthy()) throw std::runtime_error("scheduler config: PodTopologySpread defaultConstraints are not implemented (defaultingType System needs Services / ReplicaSets)");

@@ -170,7 +170,19 @@ inline std::string quantity_canonical(__int128 nano, QuantityFormat fmt) {
     return int128_text(m) + (e >= -9 && e <= 18 ? dec[(e + 9) / 3] : "");
 }
 
-inline int64_t quantity_value(const std::string &text) { return quantity_ceil(parse_quantity(text), 0); }
-inline int64_t quantity_milli_value(const std::string &text) { return quantity_ceil(parse_quantity(text), 3); }
+// The snapshot's integers: a single quantity is refused beyond 2^60 (1Ei -- no node holds that, and Quantity itself leaves int64 just
+// above), sums are formed with add64, which refuses to leave int64: never a silent wrap-around.
+inline int64_t quantity_in_range(int64_t v, const std::string &text) {
+    constexpr int64_t lim = (int64_t)1 << 60;
+    if (v > lim || v < -lim) throw std::runtime_error("quantity '" + text + "' is out of range (beyond 2^60)");
+    return v;
+}
+inline int64_t add64(int64_t a, int64_t b) {
+    int64_t r;
+    if (__builtin_add_overflow(a, b, &r)) throw std::runtime_error("resource quantities sum beyond int64");
+    return r;
+}
+inline int64_t quantity_value(const std::string &text) { return quantity_in_range(quantity_ceil(parse_quantity(text), 0), text); }
+inline int64_t quantity_milli_value(const std::string &text) { return quantity_in_range(quantity_ceil(parse_quantity(text), 3), text); }
 
 } // namespace cchost

@@ -100,18 +100,18 @@ inline int64_t aggregate_request(const Value &spec, const std::string &name, int
         return dflt >= 0 ? dflt : 0;
     };
     int64_t total = 0, restartable = 0, init_max = 0;
-    for (const auto &c : spec["containers"].items()) total += creq(c);
+    for (const auto &c : spec["containers"].items()) total = add64(total, creq(c));
     for (const auto &ic : spec["initContainers"].items()) {
         const int64_t r = creq(ic);
         int64_t use;
-        if (ic["restartPolicy"].text() == "Always") total += r, restartable += r, use = restartable;
-        else use = r + restartable;
+        if (ic["restartPolicy"].text() == "Always") total = add64(total, r), restartable = add64(restartable, r), use = restartable;
+        else use = add64(r, restartable);
         init_max = std::max(init_max, use);
     }
     total = std::max(total, init_max);
     const Value &pod_level = spec["resources"]["requests"];
     if (pod_level.truthy() && pod_level.has(name) && pod_level_supported(name)) total = res_of(pod_level, name);
-    return total + res_of(spec["overhead"], name);
+    return add64(total, res_of(spec["overhead"], name));
 }
 
 // does the pod's aggregated ResourceList hold `name` at all (some container, init container or the pod level names it)?
@@ -140,12 +140,12 @@ inline PodRequests pod_requests(const Value &spec, const std::vector<std::string
             for (size_t k = 0; any && k < names.size(); k++)
                 if (const Value *q = r.find(names[k])) {
                     const int64_t v = names[k] == "cpu" ? quantity_milli_value(q->text()) : quantity_value(q->text());
-                    out.req[k] += v;
-                    if (names[k] == "cpu") has_cpu = true, out.nz_cpu += v;
-                    else if (names[k] == "memory") has_mem = true, out.nz_mem += v;
+                    out.req[k] = add64(out.req[k], v);
+                    if (names[k] == "cpu") has_cpu = true, out.nz_cpu = add64(out.nz_cpu, v);
+                    else if (names[k] == "memory") has_mem = true, out.nz_mem = add64(out.nz_mem, v);
                 }
-            if (!has_cpu) out.nz_cpu += kDefaultMilliCPU;
-            if (!has_mem) out.nz_mem += kDefaultMemory;
+            if (!has_cpu) out.nz_cpu = add64(out.nz_cpu, kDefaultMilliCPU);
+            if (!has_mem) out.nz_mem = add64(out.nz_mem, kDefaultMemory);
         }
         return out;
     }
@@ -448,7 +448,7 @@ inline std::vector<HostPort> host_ports(const Value &spec) {
     std::vector<HostPort> out;
     auto take = [&](const Value &c) {
         for (const auto &p : c["ports"].items()) {
-            const int64_t hp = p["hostPort"].truthy() ? p["hostPort"].as_int() : 0;
+            const int64_t hp = p["hostPort"].as_int32();
             if (hp > 0) out.push_back({p["hostIP"].truthy() ? p["hostIP"].text() : "0.0.0.0", p["protocol"].truthy() ? p["protocol"].text() : "TCP", hp});
         }
     };
@@ -611,7 +611,9 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     parallel_for(N, [&](size_t i) {
         const Value &a = (*nodes[i])["status"]["allocatable"];
         for (size_t c = 0; c < R; c++) S.alloc[c][i] = res_of(a, S.res_names[c]);
-        S.alloc_pods[i] = a.has("pods") ? (int32_t)quantity_value(a["pods"].text()) : 0;
+        const int64_t ap = a.has("pods") ? quantity_value(a["pods"].text()) : 0;
+        if (ap > INT32_MAX || ap < 0) throw std::runtime_error("node " + (*nodes[i])["metadata"]["name"].text() + ": allocatable pods " + a["pods"].text() + " is out of range");
+        S.alloc_pods[i] = (int32_t)ap;
     });
     std::vector<const Value *> live; // non-terminal pods bound to a kept node (simulator.go:193-200)
     std::vector<size_t> live_node;
@@ -634,7 +636,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             const PodRequests r = pod_requests(p["spec"], S.res_names);
             for (size_t c = 0; c < R; c++) rec[k * W + c] = r.req[c];
             rec[k * W + R] = r.nz_cpu, rec[k * W + R + 1] = r.nz_mem;
-            prio[k] = p["spec"]["priority"].as_int(0); // corev1helpers.PodPriority
+            prio[k] = p["spec"]["priority"].as_int32(0); // corev1helpers.PodPriority
             const Value &aff = p["spec"]["affinity"];
             terms[k] = aff["podAffinity"].truthy() || aff["podAntiAffinity"].truthy();
             pod_node[k] = (int64_t)at->second;
@@ -644,8 +646,8 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             const size_t i = (size_t)pod_node[k];
             live.push_back(&pod_objs[k]), live_node.push_back(i);
             live_prio.push_back(prio[k]), live_has_terms = live_has_terms || terms[k];
-            for (size_t c = 0; c < R; c++) S.req[c][i] += rec[k * W + c];
-            S.nz_mcpu[i] += rec[k * W + R], S.nz_mem[i] += rec[k * W + R + 1], S.pod_count[i] += 1;
+            for (size_t c = 0; c < R; c++) S.req[c][i] = add64(S.req[c][i], rec[k * W + c]);
+            S.nz_mcpu[i] = add64(S.nz_mcpu[i], rec[k * W + R]), S.nz_mem[i] = add64(S.nz_mem[i], rec[k * W + R + 1]), S.pod_count[i] += 1;
         }
     }
 
@@ -702,7 +704,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     for (const auto &kv : node_selector.fields()) s.node_selector.push_back(it.table(kv.first, "In", {kv.second.text()}));
     for (const auto &t : required.items()) s.required.push_back(node_selector_term(it, t));
     for (const auto &t : aff["preferredDuringSchedulingIgnoredDuringExecution"].items())
-        s.preferred.emplace_back((int)t["weight"].as_int(), node_selector_term(it, t["preference"]));
+        s.preferred.emplace_back(t["weight"].as_int32(), node_selector_term(it, t["preference"]));
     s.has_node_selector = node_selector.truthy();
     s.has_required_terms = !required.is_null();
     s.affinity_filter_active = s.has_node_selector || s.has_required_terms;
@@ -746,7 +748,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         }
         // DefaultPreemption dry run (report only): what removing every lower-priority pod of a node would free
         // (corev1helpers.PodPriority: spec.priority, 0 when unset)
-        s.priority = spec["priority"].as_int(0);
+        s.priority = spec["priority"].as_int32(0);
         s.preempt_never = spec["preemptionPolicy"].text() == "Never";
         bool any_victim = false;
         for (size_t j = 0; j < live.size(); j++) is_victim[j] = live_prio[j] < s.priority, any_victim = any_victim || is_victim[j];
@@ -757,7 +759,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
                 if (!is_victim[j]) continue;
                 const PodRequests r = pod_requests((*live[j])["spec"], S.res_names);
                 s.victim_count[live_node[j]] += 1;
-                for (size_t c = 0; c < r.req.size(); c++) s.victim_req[c][live_node[j]] += r.req[c];
+                for (size_t c = 0; c < r.req.size(); c++) s.victim_req[c][live_node[j]] = add64(s.victim_req[c][live_node[j]], r.req[c]);
             }
             if (!want.empty()) {
                 std::vector<std::vector<HostPort>> rest(N);
@@ -858,8 +860,8 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         // NoSchedule / NoExecute taints the pod does not tolerate (default Ignore)
         const std::string aff_policy = c["nodeAffinityPolicy"].truthy() ? c["nodeAffinityPolicy"].text() : "Honor";
         const std::string taint_policy = c["nodeTaintsPolicy"].truthy() ? c["nodeTaintsPolicy"].text() : "Ignore";
-        k.max_skew = (int)c["maxSkew"].as_int();
-        k.min_domains = c["minDomains"].truthy() ? (int)c["minDomains"].as_int() : 1;
+        k.max_skew = c["maxSkew"].as_int32();
+        k.min_domains = c["minDomains"].truthy() ? c["minDomains"].as_int32() : 1;
         k.hard = (c["whenUnsatisfiable"].truthy() ? c["whenUnsatisfiable"].text() : "DoNotSchedule") == "DoNotSchedule";
         k.self_match = !selector_empty(sel) && label_selector_matches(sel, sim_labels);
         k.is_hostname = c["topologyKey"].text() == kHostname;
@@ -934,16 +936,16 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
                 }
             // scoring.go:81-125 processExistingPod
             for (const auto &wt : p_aff.items())
-                if (tm(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int32());
             for (const auto &wt : p_anti.items())
-                if (tm(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], sim_ns, p_ns, pl)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int32());
             if (hard_pod_affinity_weight > 0)
                 for (const auto &t : e_aff["requiredDuringSchedulingIgnoredDuringExecution"].items())
                     if (tm(t, p_ns, sim_ns, sim_labels)) add_score(kidx(t["topologyKey"].text()), i, hard_pod_affinity_weight);
             for (const auto &wt : e_aff["preferredDuringSchedulingIgnoredDuringExecution"].items())
-                if (tm(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, wt["weight"].as_int32());
             for (const auto &wt : e_anti["preferredDuringSchedulingIgnoredDuringExecution"].items())
-                if (tm(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int());
+                if (tm(wt["podAffinityTerm"], p_ns, sim_ns, sim_labels)) add_score(kidx(wt["podAffinityTerm"]["topologyKey"].text()), i, -wt["weight"].as_int32());
         }
         // what ONE clone adds (it is an existing pod of the next cycle, with the incoming pod's own terms): both directions --
         // the incoming pod's term vs the clone, and the clone's term vs the incoming pod
@@ -952,7 +954,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         auto self_term = [&](const Value &wt, int sign) {
             if (tm(wt["podAffinityTerm"], sim_ns, sim_ns, sim_labels)) {
                 const int k = kidx(wt["podAffinityTerm"]["topologyKey"].text());
-                score_self[k] += 2 * sign * wt["weight"].as_int();
+                score_self[k] += 2 * sign * wt["weight"].as_int32();
                 self_entries[k] += 2;
             }
         };

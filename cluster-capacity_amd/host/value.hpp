@@ -61,8 +61,19 @@ struct Value {
         return v;
     }
     bool is_null() const { return t == Null; }
-    // the member's value, or nullptr when absent (or when this is not a mapping): one scan where has() + [] take two
+    // The reference decodes objects into typed structs: a string where a mapping belongs is a decode error there, never "absent".
+    // Same here, at the accessor: null is the zero value (absent), any other kind than the one asked for is refused.
+    const char *kind_name() const {
+        static const char *const names[] = {"null", "a boolean", "a number", "a string", "a list", "a mapping"};
+        return names[t];
+    }
+    [[noreturn]] void wrong_kind(const char *wanted) const { throw std::runtime_error(std::string("malformed object: expected ") + wanted + ", found " + kind_name()); }
+    void want_mapping() const {
+        if (t != Obj && t != Null) wrong_kind("a mapping");
+    }
+    // the member's value, or nullptr when absent (or when this is null): one scan where has() + [] take two
     const Value *find(const char *k, size_t len) const {
+        want_mapping();
         if (t == Obj)
             for (auto &kv : o)
                 if (kv.first.size() == len && std::memcmp(kv.first.data(), k, len) == 0) return &kv.second;
@@ -72,15 +83,17 @@ struct Value {
     bool has(const std::string &k) const { return has(k.data(), k.size()); }
     bool has(const char *k) const { return has(k, std::strlen(k)); }
     bool has(const char *k, size_t len) const {
+        want_mapping();
         if (t != Obj) return false;
         for (auto &kv : o)
             if (kv.first.size() == len && std::memcmp(kv.first.data(), k, len) == 0) return true;
         return false;
     }
-    // python's d.get(k): Null when absent (or when this is not a mapping)
+    // python's (d or {}).get(k): Null when absent (or when this is null)
     const Value &operator[](const std::string &k) const { return get(k.data(), k.size()); }
     const Value &operator[](const char *k) const { return get(k, std::strlen(k)); } // (no temporary std::string per lookup)
     const Value &get(const char *k, size_t len) const {
+        want_mapping();
         if (t == Obj)
             for (auto &kv : o)
                 if (kv.first.size() == len && std::memcmp(kv.first.data(), k, len) == 0) return kv.second;
@@ -105,28 +118,38 @@ struct Value {
         }
         return false;
     }
-    // text of a scalar ("" for null / containers); booleans as YAML/JSON spell them
+    // text of a scalar ("" for null); booleans as YAML/JSON spell them
     std::string text() const {
         if (t == Str || t == Num) return s;
         if (t == Bool) return b ? "true" : "false";
+        if (t != Null) wrong_kind("a scalar");
         return "";
     }
+    // an integer field: null = absent (dflt); a number (or its text) that is not a plain decimal integer, or another kind, is refused --
+    // the reference's decoder does not turn "1Gi", 5.5 or [] into an int32 either
     long long as_int(long long dflt = 0) const {
-        if (t == Num || t == Str) {
-            try {
-                return std::stoll(s);
-            } catch (...) {
-                return dflt;
-            }
-        }
-        return dflt;
+        if (t == Null) return dflt;
+        if (t != Num && t != Str) wrong_kind("an integer");
+        size_t i = (!s.empty() && (s[0] == '-' || s[0] == '+')) ? 1 : 0;
+        bool ok = i < s.size() && s.size() - i <= 18;
+        for (size_t k = i; ok && k < s.size(); k++) ok = s[k] >= '0' && s[k] <= '9';
+        if (!ok) throw std::runtime_error("malformed object: expected an integer, found '" + s + "'");
+        return std::stoll(s);
+    }
+    // ... of an int32 field (weights, maxSkew, minDomains, priority, hostPort)
+    int32_t as_int32(int32_t dflt = 0) const {
+        const long long v = as_int(dflt);
+        if (v > INT32_MAX || v < INT32_MIN) throw std::runtime_error("malformed object: " + s + " does not fit an int32 field");
+        return (int32_t)v;
     }
     const std::vector<Value> &items() const {
         static const std::vector<Value> empty;
+        if (t != Arr && t != Null) wrong_kind("a list");
         return t == Arr ? a : empty;
     }
     const std::vector<std::pair<std::string, Value>> &fields() const {
         static const std::vector<std::pair<std::string, Value>> empty;
+        want_mapping();
         return t == Obj ? o : empty;
     }
 };

@@ -94,14 +94,22 @@ def quantity_canonical(v: Fraction, fmt: str) -> str:
     return f"{m}{_DEC_SUFFIX.get(e, '')}"
 
 
+def _in_range(v: int, q) -> int:
+    """The snapshot's integers: a single quantity is refused beyond 2^60 (1Ei -- no node holds that); sums that leave int64 are refused
+    when they are stored (numpy raises OverflowError): never a silent wrap-around."""
+    if abs(v) > 1 << 60:
+        raise ValueError(f"quantity '{str(q).strip()}' is out of range (beyond 2^60)")
+    return v
+
+
 def value(q) -> int:
     """Quantity.Value(): rounded up to an integer (quantity.go:813-820)."""
-    return math.ceil(parse_quantity(q))
+    return _in_range(math.ceil(parse_quantity(q)), q)
 
 
 def milli_value(q) -> int:
     """Quantity.MilliValue(): rounded up to an integer number of thousandths (quantity.go:822-834)."""
-    return math.ceil(parse_quantity(q) * 1000)
+    return _in_range(math.ceil(parse_quantity(q) * 1000), q)
 
 
 def _res(rl: Optional[dict], name: str) -> int:
@@ -260,7 +268,7 @@ def host_ports(spec: dict):
     cs = [c for c in spec.get("initContainers") or [] if c.get("restartPolicy") == "Always"] + list(spec.get("containers") or [])
     for c in cs:
         for p in c.get("ports") or []:
-            hp = int(p.get("hostPort") or 0)
+            hp = int32_field(p.get("hostPort"))
             if hp > 0:
                 out.append((p.get("hostIP") or "0.0.0.0", p.get("protocol") or "TCP", hp))
     return out
@@ -340,6 +348,19 @@ def requirement_matches(key_present: bool, val: Optional[str], op: str, values: 
             return False
         return a > b if op == "Gt" else a < b
     return False
+
+
+def int32_field(x, default: int = 0) -> int:
+    """An int32 field of an object (weights, maxSkew, minDomains, priority, hostPort): None = absent; anything that is not a plain integer
+    inside int32 is refused, as the reference's decoder refuses it (and as host/value.hpp as_int32 does)."""
+    if x is None:
+        return default
+    if isinstance(x, bool) or not isinstance(x, (int, str)) or (isinstance(x, str) and not re.fullmatch(r"[+-]?[0-9]{1,18}", x)):
+        raise ValueError(f"malformed object: expected an integer, found {x!r}")
+    v = int(x)
+    if not -(1 << 31) <= v < (1 << 31):
+        raise ValueError(f"malformed object: {v} does not fit an int32 field")
+    return v
 
 
 def go_parse_int(text) -> Optional[int]:
@@ -520,7 +541,10 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
         a = (n.get("status") or {}).get("allocatable") or {}
         for c, r in enumerate(res_names):
             alloc[c][i] = _res(a, r)
-        alloc_pods[i] = value(a.get("pods", 0))
+        ap = value(a.get("pods", 0))
+        if not 0 <= ap <= 2**31 - 1:
+            raise ValueError(f"node {(n.get('metadata') or {}).get('name', '')}: allocatable pods {a.get('pods')} is out of range")
+        alloc_pods[i] = ap
     req = [np.zeros(N, np.int64) for _ in res_names]
     nzc, nzm, pcount = np.zeros(N, np.int64), np.zeros(N, np.int64), np.zeros(N, np.int32)
     live = []  # non-terminal pods bound to a kept node (simulator.go:193-200)
@@ -533,9 +557,9 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
         i = index[node]
         r, c0, m0 = pod_requests(p["spec"], res_names)
         for c, rn in enumerate(res_names):
-            req[c][i] += r[rn]
-        nzc[i] += c0
-        nzm[i] += m0
+            req[c][i] = int(req[c][i]) + r[rn]  # (Python integers: a sum beyond int64 raises OverflowError at the store, numpy's += would wrap)
+        nzc[i] = int(nzc[i]) + c0
+        nzm[i] = int(nzm[i]) + m0
         pcount[i] += 1
 
     # taints -> distinct taint sets (per node); what a template's tolerations make of each set is the template's business
@@ -616,7 +640,7 @@ def _template_side(ctx: dict, sim_pod: dict):
     required = (aff.get("requiredDuringSchedulingIgnoredDuringExecution") or {}).get("nodeSelectorTerms")
     sel_reqs = [it.table(k, "In", [v]) for k, v in (node_selector or {}).items()]
     req_terms = [_node_selector_term(it, t) for t in (required or [])]
-    pref = [(int(t["weight"]), _node_selector_term(it, t["preference"]))
+    pref = [(int32_field(t.get("weight")), _node_selector_term(it, t["preference"]))
             for t in aff.get("preferredDuringSchedulingIgnoredDuringExecution") or []]
     affinity_active = bool(node_selector) or required is not None
 
@@ -651,9 +675,9 @@ def _template_side(ctx: dict, sim_pod: dict):
     pod.image_score = image_scores(nodes, spec)
     # DefaultPreemption dry run (report only): what removing every lower-priority pod of a node would free
     # (corev1helpers.PodPriority: spec.priority, 0 when unset; default_preemption.go:392-396)
-    prio = int(spec.get("priority") or 0)
+    prio = int32_field(spec.get("priority"))
     pre = M.PreemptionSide(priority=prio, never=spec.get("preemptionPolicy") == "Never")
-    victims = [p for p in live if int(p["spec"].get("priority") or 0) < prio]
+    victims = [p for p in live if int32_field(p["spec"].get("priority")) < prio]
     victim_ids = {id(p) for p in victims}
     # nodes with a victim whose removal would change the PreFilter state of a topology-coupled FILTER of this template (it
     # matches a hard spread selector or a required (anti)affinity term, or carries an anti-affinity term matching the template)
@@ -729,7 +753,7 @@ def _template_side(ctx: dict, sim_pod: dict):
             tol_ok = np.array(ok, np.uint8)[ts_id]
             inc = tol_ok if inc is None else (inc & tol_ok)
         pod.spread.append(M.SpreadConstraint(
-            col=col, max_skew=int(c["maxSkew"]), min_domains=int(c.get("minDomains") or 1),
+            col=col, max_skew=int32_field(c.get("maxSkew")), min_domains=int32_field(c.get("minDomains") or None, 1),
             hard=(c.get("whenUnsatisfiable") or "DoNotSchedule") == "DoNotSchedule",
             self_match=not selector_empty(sel) and label_selector_matches(sel, sim_labels),
             is_hostname=c["topologyKey"] == HOSTNAME, n_domains=len(it.values[col]),
@@ -790,27 +814,27 @@ def _template_side(ctx: dict, sim_pod: dict):
             # scoring.go:81-125 processExistingPod
             for wt in p_aff:
                 if tm(wt["podAffinityTerm"], sim_ns, p):
-                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int(wt["weight"]))
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int32_field(wt.get("weight")))
             for wt in p_anti:
                 if tm(wt["podAffinityTerm"], sim_ns, p):
-                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int(wt["weight"]))
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int32_field(wt.get("weight")))
             if hard_pod_affinity_weight > 0:
                 for t in e_aff.get("requiredDuringSchedulingIgnoredDuringExecution") or []:
                     if tm(t, p_ns, sim_as_pod):
                         add_score(kidx(t["topologyKey"]), i, hard_pod_affinity_weight)
             for wt in e_aff.get("preferredDuringSchedulingIgnoredDuringExecution") or []:
                 if tm(wt["podAffinityTerm"], p_ns, sim_as_pod):
-                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int(wt["weight"]))
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, int32_field(wt.get("weight")))
             for wt in e_anti.get("preferredDuringSchedulingIgnoredDuringExecution") or []:
                 if tm(wt["podAffinityTerm"], p_ns, sim_as_pod):
-                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int(wt["weight"]))
+                    add_score(kidx(wt["podAffinityTerm"]["topologyKey"]), i, -int32_field(wt.get("weight")))
         # what ONE clone adds (it is an existing pod of the next cycle, with the incoming pod's own terms)
         self_score: Dict[int, int] = {}   # (a term of the incoming pod may name a topology key no existing pod touched:
         self_hits: Dict[int, int] = {}    #  kidx can still grow here)
         for wt, sign in [(w, 1) for w in p_aff] + [(w, -1) for w in p_anti]:
             if tm(wt["podAffinityTerm"], sim_ns, sim_as_pod):  # both directions: incoming's term vs the
                 k = kidx(wt["podAffinityTerm"]["topologyKey"])              # clone, and the clone's term vs the incoming pod
-                self_score[k] = self_score.get(k, 0) + 2 * sign * int(wt["weight"])
+                self_score[k] = self_score.get(k, 0) + 2 * sign * int32_field(wt.get("weight"))
                 self_hits[k] = self_hits.get(k, 0) + 2
         if hard_pod_affinity_weight > 0:
             for t in r_aff:

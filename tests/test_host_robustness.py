@@ -1,0 +1,220 @@
+"""The native host (the product's ingest + CLI, cluster-capacity_amd/host/) against damaged input: it must refuse cleanly -- exit code 1 and a
+message -- never crash, never wrap an integer around, never read a string as "absent".  The reference decodes objects into typed structs
+(a string where a mapping belongs is a decode error there); value.hpp's accessors refuse the same way, for every member the ingest reads
+(what it never looks at -- pruned members, the template's labels when no selector refers to them -- is not validated).
+
+Run the same tests (and tests/test_native_host.py) with the host built under the sanitizers:
+
+    CCHOST_SANITIZE=address,undefined ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_host_robustness.py tests/test_native_host.py -m "not gpu"
+    CCHOST_SANITIZE=thread python -m pytest tests/test_native_host.py -m "not gpu"
+
+(build.build_host() then builds bin/cluster-capacity-native-<sanitizers> with -fno-sanitize-recover: any report is a non-zero exit the
+tests below see as a failure.)"""
+import copy
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+import yaml
+
+from cluster_capacity_amd import build as B, cli, ingest
+from test_native_host import _random_objects, py_dump
+
+
+@pytest.fixture(scope="module")
+def native():
+    return B.build_host()
+
+
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")  # (the host leaves through _Exit: nothing is freed on purpose)
+TOKENS = [b"{", b"}", b"[", b"]", b":", b",", b'"', b"\\", b"\n", b"  ", b"- ", b"null", b"-", b"1e999", b"\x00", b"\xff", b"\t", b"#", b"|", b">", b"&a", b"*a",
+          b"---\n", b"'", b"\\u12", b"\\ud800", b"9" * 40, b"0.5m", b"Ki"]
+JUNK = [None, True, 0, -1, 1.5, "", "x", "1Gi", [], {}, [1], ["a"], {"a": "b"}, [{}], [[]], {"matchLabels": 3}, "9" * 30, 1 << 70, [None], {"": ""}]
+
+
+def _damage_bytes(rng, b):
+    b = bytearray(b)
+    for _ in range(rng.choice([1, 1, 2, 3, 8])):
+        if not b:
+            break
+        k, i = rng.randrange(6), rng.randrange(len(b))
+        if k == 0:
+            b[i] = rng.randrange(256)
+        elif k == 1:
+            del b[i:i + rng.choice([1, 1, 2, 16, 200])]
+        elif k == 2:
+            b[i:i] = rng.choice(TOKENS)
+        elif k == 3:
+            b = b[:i]
+        elif k == 4:
+            j = rng.randrange(len(b))
+            b[i:i] = b[j:j + rng.choice([1, 8, 64])]
+        else:
+            b[i] ^= 1 << rng.randrange(8)
+    return bytes(b)
+
+
+def _paths(o, acc, pre=()):
+    for k, v in (o.items() if isinstance(o, dict) else enumerate(o) if isinstance(o, list) else ()):
+        acc.append(pre + (k,))
+        _paths(v, acc, pre + (k,))
+
+
+def _damage_structure(rng, obj):
+    """Another kind of value at a random place of the object: a string where a mapping belongs, a list where a number does, a member gone."""
+    for _ in range(rng.choice([1, 1, 2, 4])):
+        acc = []
+        _paths(obj, acc)
+        if not acc:
+            return
+        p = rng.choice(acc)
+        o = obj
+        for k in p[:-1]:
+            o = o[k]
+        r = rng.random()
+        if r < 0.7:
+            o[p[-1]] = copy.deepcopy(rng.choice(JUNK))
+        elif r < 0.85 and isinstance(o, dict):
+            del o[p[-1]]
+        elif isinstance(o, dict):
+            o[rng.choice(["", "spec", "metadata", "labels", "name", "x"])] = copy.deepcopy(rng.choice(JUNK))
+
+
+def _run(native, tmp_path, cluster: bytes, pod: bytes, fmt, threads=False):
+    (tmp_path / f"c.{fmt}").write_bytes(cluster)
+    (tmp_path / f"p.{fmt}").write_bytes(pod)
+    env = dict(ENV, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_PARALLEL_MIN_ITEMS="0") if threads else ENV
+    return subprocess.run([native, "--podspec", str(tmp_path / f"p.{fmt}"), "--snapshot", str(tmp_path / f"c.{fmt}"), "--dump-snapshot", "-"], capture_output=True, env=env,
+                          timeout=120)
+
+
+def _clean(p):
+    return p.returncode in (0, 1) and b"Sanitizer" not in p.stderr and b"runtime error:" not in p.stderr and (p.returncode == 0 or p.stderr.strip())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_damaged_bytes_are_refused_cleanly(native, tmp_path, seed):
+    rng = random.Random(4100 + seed)
+    for it in range(12):
+        nodes, pods, pod, _ = _random_objects(np.random.default_rng(rng.randrange(1 << 30)))
+        fmt = rng.choice(["json", "yaml"])
+        if fmt == "json":
+            cl, pd = json.dumps({"kind": "List", "items": nodes + pods}).encode(), json.dumps(pod).encode()
+        else:
+            cl, pd = yaml.safe_dump_all(nodes + pods).encode(), yaml.safe_dump(pod).encode()
+        which = rng.randrange(3)
+        cl = cl if which == 1 else _damage_bytes(rng, cl)
+        pd = pd if which == 0 else _damage_bytes(rng, pd)
+        p = _run(native, tmp_path, cl, pd, fmt, threads=rng.random() < 0.3)
+        assert _clean(p), (seed, it, p.returncode, p.stderr[-400:])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_objects_of_the_wrong_shape_are_refused_or_read_alike(native, tmp_path, seed):
+    """...and where both hosts take the damaged object (a member gone is a zero value), they read the same snapshot."""
+    rng = random.Random(5200 + seed)
+    both = 0
+    for it in range(14):
+        nodes, pods, pod, _ = _random_objects(np.random.default_rng(rng.randrange(1 << 30)))
+        nodes, pods, pod = copy.deepcopy(nodes), copy.deepcopy(pods), copy.deepcopy(pod)
+        _damage_structure(rng, pod if rng.randrange(3) == 0 or not (nodes + pods) else rng.choice(nodes + pods))
+        p = _run(native, tmp_path, json.dumps({"kind": "List", "items": nodes + pods}).encode(), json.dumps(pod).encode(), "json")
+        assert _clean(p), (seed, it, p.returncode, p.stderr[-400:])
+        if p.returncode:
+            continue
+        try:
+            no, po, ns = cli.load_all([str(tmp_path / "c.json")])
+            ref = py_dump(ingest.build_snapshot(no, po, cli.parse_pod_spec(str(tmp_path / "p.json")), [], namespace_objs=ns))
+        except BaseException:  # the Python mirror walks plain dicts: it trips over shapes the native host reads as zero values
+            continue
+        got = json.loads(p.stdout)
+        for k in ref:
+            assert got[k] == ref[k], (seed, it, k)
+        both += 1
+    assert both >= 2
+
+
+def _case(tmp_path, native, pod_patch=None, node_patch=None, n_pods=0):
+    node = {"kind": "Node", "metadata": {"name": "n0", "labels": {"kubernetes.io/hostname": "n0"}}, "status": {"allocatable": {"cpu": "4", "memory": "8Gi", "pods": "110"}}}
+    pod = {"kind": "Pod", "metadata": {"name": "p", "namespace": "default"}, "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": "100m", "memory": "64Mi"}}}]}}
+    (node_patch or (lambda n: None))(node)
+    (pod_patch or (lambda p: None))(pod)
+    existing = [dict(copy.deepcopy(pod), metadata={"name": f"e{i}", "namespace": "default"}, spec=dict(copy.deepcopy(pod["spec"]), nodeName="n0"), status={"phase": "Running"})
+                for i in range(n_pods)]
+    p = _run(native, tmp_path, json.dumps({"kind": "List", "items": [node] + existing}).encode(), json.dumps(pod).encode(), "json")
+    try:
+        no, po, ns = cli.load_all([str(tmp_path / "c.json")])
+        ingest.build_snapshot(no, po, cli.parse_pod_spec(str(tmp_path / "p.json")), [], namespace_objs=ns)
+        py = None
+    except (ValueError, TypeError, AttributeError, KeyError, OverflowError, NotImplementedError) as e:
+        py = str(e)
+    return p, py
+
+
+def test_quantities_and_integers_out_of_range_are_refused_by_both_hosts(native, tmp_path):
+    def big_request(pod):
+        pod["spec"]["containers"][0]["resources"]["requests"]["memory"] = 1 << 70
+    p, py = _case(tmp_path, native, pod_patch=big_request)
+    assert p.returncode == 1 and b"out of range (beyond 2^60)" in p.stderr and "out of range (beyond 2^60)" in py
+    # the largest suffix still reads (1E = 10^18 < 2^60); the sum of nine pods of that size leaves int64: refused, not wrapped around
+
+    def exa(pod):
+        pod["spec"]["containers"][0]["resources"]["requests"]["memory"] = "1E"
+    p, py = _case(tmp_path, native, pod_patch=exa)
+    assert p.returncode == 0 and py is None
+    p, py = _case(tmp_path, native, pod_patch=exa, n_pods=10)
+    assert p.returncode == 1 and b"sum beyond int64" in p.stderr and py is not None
+
+    def pods_2_40(node):
+        node["status"]["allocatable"]["pods"] = str(1 << 40)
+    p, py = _case(tmp_path, native, node_patch=pods_2_40)
+    assert p.returncode == 1 and b"allocatable pods" in p.stderr and "allocatable pods" in py
+
+    def port(pod):
+        pod["spec"]["containers"][0]["ports"] = [{"containerPort": 80, "hostPort": 1 << 70}]
+    p, py = _case(tmp_path, native, pod_patch=port)
+    assert p.returncode == 1 and b"expected an integer" in p.stderr and "malformed object" in py
+
+    def skew(pod):
+        pod["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1 << 40, "topologyKey": "kubernetes.io/hostname", "whenUnsatisfiable": "DoNotSchedule", "labelSelector": {}}]
+    p, py = _case(tmp_path, native, pod_patch=skew)
+    assert p.returncode == 1 and b"does not fit an int32" in p.stderr and "does not fit an int32" in py
+
+    def weight(pod):
+        pod["spec"]["affinity"] = {"nodeAffinity": {"preferredDuringSchedulingIgnoredDuringExecution": [{"weight": "1Gi", "preference": {"matchExpressions": []}}]}}
+    p, py = _case(tmp_path, native, pod_patch=weight)
+    assert p.returncode == 1 and b"expected an integer, found '1Gi'" in p.stderr and "expected an integer" in py
+
+
+@pytest.mark.parametrize("where,junk,message", [
+    (("spec", "containers"), "x", b"expected a list, found a string"),
+    (("spec",), "x", b"expected a mapping, found a string"),
+    (("spec", "nodeSelector"), ["a"], b"expected a mapping, found a list"),
+    (("spec", "containers", 0, "resources"), 3, b"expected a mapping, found a number"),
+    (("spec", "tolerations"), {"key": "a"}, b"expected a list, found a mapping"),
+    (("spec", "containers", 0, "resources", "requests", "cpu"), ["1"], b"expected a scalar, found a list"),
+])
+def test_a_value_of_the_wrong_kind_is_a_decode_error_not_an_absent_field(native, tmp_path, where, junk, message):
+    def patch(pod):
+        o = pod
+        for k in where[:-1]:
+            o = o[k]
+        o[where[-1]] = junk
+    p, py = _case(tmp_path, native, pod_patch=patch)
+    assert p.returncode == 1 and message in p.stderr, p.stderr
+    assert py is not None  # (the Python mirror trips over the same value)
+    # null, on the other hand, is the zero value -- absent -- as in the reference's decoder
+    p, py = _case(tmp_path, native, pod_patch=lambda pod: pod["spec"].update(nodeSelector=None, tolerations=None, affinity=None))
+    assert p.returncode == 0 and py is None
+
+
+def test_python_cli_refuses_a_malformed_object_cleanly(tmp_path, capsys):
+    node = {"kind": "Node", "metadata": {"name": "n0"}, "status": {"allocatable": {"cpu": "4", "memory": "8Gi", "pods": "110"}}}
+    pod = {"kind": "Pod", "metadata": {"name": "p"}, "spec": {"containers": "x"}}
+    (tmp_path / "c.json").write_text(json.dumps(node))
+    (tmp_path / "p.json").write_text(json.dumps(pod))
+    assert cli.main(["--podspec", str(tmp_path / "p.json"), "--snapshot", str(tmp_path / "c.json")]) == 1
+    assert "malformed object" in capsys.readouterr().err
