@@ -80,3 +80,48 @@ def test_c_demo_reproduces_readme_answer(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "The cluster can schedule 52 instance(s)" in out.stdout and "4 Insufficient cpu" in out.stdout
     assert out.stdout.count("13 instance(s)") == 4
+
+
+def _header_structs():
+    """struct name -> member names, read out of include/ccsim.h."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ccsim.h")).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for body, name in re.findall(r"typedef struct \{(.*?)\}\s*(ccsim_\w+);", text, re.S):
+        members = set()
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                for part in decl.split(","):
+                    m = re.search(r"(\w+)\s*(?:\[[^\]]*\])*\s*$", part.strip())
+                    if m:
+                        members.add(m.group(1))
+        out[name] = members
+    return out
+
+
+def test_integration_md_go_binding_names_what_the_header_declares():
+    """INTEGRATION.md's cgo binding cannot be compiled here (no Go toolchain): at least every C identifier, and every struct member it
+    touches through a `var c C.ccsim_x` / `c := C.ccsim_x{...}` value, must exist in include/ccsim.h."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    header = open(os.path.join(ROOT, "include", "ccsim.h")).read()
+    structs = _header_structs()
+    assert {"ccsim_config", "ccsim_nodes", "ccsim_pod", "ccsim_profile", "ccsim_report"} <= structs.keys()
+    blocks = re.findall(r"```go\n(.*?)```", md, re.S)
+    assert blocks
+    checked = 0
+    for ident in set(re.findall(r"\bC\.((?:ccsim|CCSIM)_\w+)", "\n".join(blocks))):
+        assert re.search(r"\b%s\b" % ident, header), ident
+    for block in blocks:
+        for func in re.split(r"\nfunc ", block):
+            for var, struct in re.findall(r"\b(\w+) :?= C\.(ccsim_\w+)\{", func) + re.findall(r"\bvar (\w+) C\.(ccsim_\w+)\b", func):
+                if struct not in structs:
+                    continue
+                used = set(re.findall(r"\b%s\.(\w+)" % var, func))
+                lit = re.search(r"\b%s :?= C\.%s\{(.*?)\}\n" % (var, struct), func, re.S)
+                if lit:
+                    used |= set(re.findall(r"(\w+):", lit.group(1)))
+                for member in used:
+                    assert member in structs[struct], (struct, member)
+                    checked += 1
+    assert checked > 40
