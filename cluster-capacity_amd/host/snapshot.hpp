@@ -799,12 +799,12 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         if (any) {
             s.image_score.assign(N, 0);
             for (size_t i = 0; i < N; i++) {
-                std::vector<std::pair<int64_t, int64_t>> present;
+                std::vector<std::pair<int64_t, int64_t>> held; // (size, number of nodes holding it) of the template's images on node i
                 for (const auto &w : wanted) {
                     const auto h = holders.find(w);
-                    if (h != holders.end() && h->second.count(i)) present.emplace_back(size[w], (int64_t)h->second.size());
+                    if (h != holders.end() && h->second.count(i)) held.emplace_back(size[w], (int64_t)h->second.size());
                 }
-                s.image_score[i] = (uint8_t)image_locality_score(present, (int64_t)N, (int64_t)wanted.size());
+                s.image_score[i] = (uint8_t)image_locality_score(held, (int64_t)N, (int64_t)wanted.size());
             }
         }
     }
@@ -820,7 +820,8 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     // false (scoring.go:61-115: a node without the key counts under the empty value instead of being ignored); when EVERY node carries
     // both keys the two readings coincide and the constraints are exactly two more soft constraints of the pod -- otherwise they are
     // left out and the caller is told (Snapshot::default_spreading_unmodelled)
-    Value constraints = spec["topologySpreadConstraints"].t == Value::Arr ? spec["topologySpreadConstraints"] : Value::array();
+    Value constraints = Value::array();
+    constraints.a = spec["topologySpreadConstraints"].items(); // (null = none; any other kind than a list is refused)
     if (constraints.a.empty() && system_default_spreading) {
         const Value defaults = system_default_constraints(sim_pod, spreading_objs);
         if (!defaults.a.empty()) {
