@@ -199,6 +199,20 @@ inline int member_ctx(Ctx c, const std::string &k, const std::string &kind, bool
 // allocatable / images, the spec fields and container fields no scheduler plugin of this host looks at (volumes, env, probes,
 // mounts, ...).  On real dumps that is most of the bytes (managedFields, last-applied-configuration, conditions, container
 // statuses).  Templates (--podspec) are never read this way: they are echoed into the report as they came.
+// Nesting bound of both readers (encoding/json gives up at 10000 levels; 2000 here, safe for the sanitizer builds' larger frames too -- no
+// object of this path nests deeper than a few dozen):
+// recursion depth is input-controlled, the stack is not.
+struct DepthGuard {
+    int &d;
+    DepthGuard(int &depth, int limit) : d(depth) {
+        if (++d > limit) {
+            --d;
+            throw std::runtime_error("exceeded max nesting depth " + std::to_string(limit));
+        }
+    }
+    ~DepthGuard() { --d; }
+};
+
 class JsonParser {
   public:
     explicit JsonParser(std::string_view src, bool prune_cluster_objects = false, const std::vector<std::string> *wanted_images = nullptr)
@@ -435,7 +449,9 @@ class JsonParser {
             }
         }
     }
+    int depth_ = 0;
     Value parse_value(Ctx ctx = NoCtx) {
+        DepthGuard guard(depth_, 2000);
         skip_ws();
         if (i_ >= s_.size()) fail("unexpected end");
         const char c = s_[i_];
@@ -738,7 +754,9 @@ class YamlParser {
         return out;
     }
     // flow collections and scalars inside them
+    int depth_ = 0;
     Value parse_flow(const std::string &t, size_t &i) {
+        DepthGuard guard(depth_, 2000);
         auto ws = [&] {
             while (i < t.size() && (t[i] == ' ' || t[i] == '\t')) i++;
         };
@@ -985,6 +1003,7 @@ class YamlParser {
         }
     }
     Value parse_node(int indent) {
+        DepthGuard guard(depth_, 2000);
         skip_blank();
         if (pos_ >= lines_.size()) return Value();
         const std::string &first = lines_[pos_].text;

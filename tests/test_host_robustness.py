@@ -218,3 +218,30 @@ def test_python_cli_refuses_a_malformed_object_cleanly(tmp_path, capsys):
     (tmp_path / "p.json").write_text(json.dumps(pod))
     assert cli.main(["--podspec", str(tmp_path / "p.json"), "--snapshot", str(tmp_path / "c.json")]) == 1
     assert "malformed object" in capsys.readouterr().err
+
+
+@pytest.mark.parametrize("fmt,text", [
+    ("json", "[" * 1_000_000),
+    ("json", '{"a":' * 1_000_000),
+    ("json", '{"kind":"List","items":[{"kind":"Node","metadata":{"labels":' + '{"a":' * 500_000),
+    ("yaml", "".join(" " * i + "a:\n" for i in range(3000))),
+    ("yaml", "".join(" " * i + "-\n" for i in range(3000))),
+    ("yaml", "a: " + "[" * 200_000),
+])
+def test_nesting_depth_is_bounded(native, tmp_path, fmt, text):
+    """The readers recurse; the depth is the input's to choose, the stack is not (encoding/json stops at 10000 levels, the hosts at 2000)."""
+    pod = {"kind": "Pod", "metadata": {"name": "p"}, "spec": {"containers": [{"name": "c"}]}}
+    p = _run(native, tmp_path, text.encode(), json.dumps(pod).encode(), fmt) if fmt == "json" else None
+    if fmt == "yaml":
+        (tmp_path / "p.json").write_text(json.dumps(pod))
+        (tmp_path / "c.yaml").write_text(text)
+        p = subprocess.run([native, "--podspec", str(tmp_path / "p.json"), "--snapshot", str(tmp_path / "c.yaml"), "--dump-snapshot", "-"], capture_output=True, env=ENV, timeout=120)
+    assert p.returncode == 1 and b"exceeded max nesting depth" in p.stderr, (p.returncode, p.stderr[-300:])
+
+
+def test_deep_but_legal_nesting_is_read_and_skipped_members_do_not_count(native, tmp_path):
+    pod = {"kind": "Pod", "metadata": {"name": "p"}, "spec": {"containers": [{"name": "c"}]}}
+    node = '{"kind":"Node","metadata":{"name":"n","annotations":' + '{"a":' * 1900 + "1" + "}" * 1900 + ',"managedFields":' + '[{"a":' * 100_000 + "1" + "}]" * 100_000 + "}}"
+    p = _run(native, tmp_path, node.encode(), json.dumps(pod).encode(), "json")  # (managedFields is pruned: skipped without recursion)
+    assert p.returncode == 0, p.stderr[-300:]
+    assert json.loads(p.stdout)["names"] == ["n"]
