@@ -1179,18 +1179,25 @@ inline void to_yaml(std::string &out, const Value &v, int indent = 0, bool in_se
 inline std::vector<Value> parse_documents(std::string_view text, bool prune_cluster_objects = false, const std::vector<std::string> *wanted_images = nullptr) {
     size_t i = 0;
     while (i < text.size() && std::isspace((unsigned char)text[i])) i++;
+    std::string json_error;
     if (i < text.size() && (text[i] == '{' || text[i] == '[')) {
         try {
             JsonParser p(text, prune_cluster_objects, wanted_images);
             std::vector<Value> one;
             one.push_back(p.parse_document()); // (moved: a braced list would copy the whole document)
             return one;
-        } catch (const std::exception &) { // a YAML document in flow style?
+        } catch (const std::exception &e) { // a YAML document in flow style?
             if (text.size() > (32u << 20)) throw; // (not at this size: a broken multi-hundred-MB JSON dump should say where it is broken)
+            json_error = e.what();
         }
     }
-    YamlParser y{std::string(text), prune_cluster_objects, wanted_images != nullptr && wanted_images->empty()};
-    return y.parse_stream();
+    try {
+        YamlParser y{std::string(text), prune_cluster_objects, wanted_images != nullptr && wanted_images->empty()};
+        return y.parse_stream();
+    } catch (const std::exception &e) {
+        if (json_error.empty()) throw;
+        throw std::runtime_error(json_error + " (and not YAML either: " + e.what() + ")"); // it began like JSON: say where THAT reading broke
+    }
 }
 
 } // namespace cchost
