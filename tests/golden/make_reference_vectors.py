@@ -16,7 +16,8 @@ implementation is its own (the oracle restates it; no other implementation of th
 Functions: leastRequestedScore + the closure of leastResourceScorer (noderesources/least_allocated.go), balancedResourceScorer
 (noderesources/balanced_allocation.go), DefaultNormalizeScore (helper/normalize_score.go), numFeasibleNodesToFind (schedule_one.go),
 calculatePriority + scaledImageScore (imagelocality/image_locality.go), scoreForCount (podtopologyspread/scoring.go); and the string-level
-helpers of FUNCS' second block (toleration / taint verdicts, zone key, image names, label requirements)."""
+helpers of FUNCS' second block (toleration / taint verdicts, zone key, image names, label requirements) and fitsRequest (noderesources/fit.go),
+run on Python objects that carry the Go method surface (GoNodeInfo, GoResource, GoPodRequest below)."""
 import json
 import math
 import os
@@ -72,10 +73,16 @@ FUNCS += [
     ("DoNotScheduleTaintsFilter_closure", S + "/framework/plugins/helper/taint.go", "\treturn func(t *v1.Taint) bool {", ["t"], False),
     ("getAllTolerationPreferNoSchedule", S + "/framework/plugins/tainttoleration/taint_toleration.go",
      "func getAllTolerationPreferNoSchedule(tolerations []v1.Toleration) (tolerationList []v1.Toleration) {", ["tolerations"], False),
+    # the NodeResourcesFit filter itself.  nodeInfo / podRequest are Python objects with the Go method surface (GetAllocatable().GetMilliCPU() ...);
+    # Go ranges over the scalar map in random order, here sorted (the reasons of scalars are compared as a set)
+    ("fitsRequest", S + "/framework/plugins/noderesources/fit.go",
+     "func fitsRequest(podRequest *preFilterState, nodeInfo fwk.NodeInfo, ignoredExtendedResources, ignoredResourceGroups sets.Set[string], opts ResourceRequestsOptions) []InsufficientResource {",
+     ["podRequest", "nodeInfo", "ignoredExtendedResources", "ignoredResourceGroups", "opts"], False),
     ("countIntolerableTaintsPreferNoSchedule", S + "/framework/plugins/tainttoleration/taint_toleration.go",
      "func countIntolerableTaintsPreferNoSchedule(taints []v1.Taint, tolerations []v1.Toleration) (intolerableTaints int) {", ["taints", "tolerations"], False),
 ]
 # statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
+JOINED = {}
 DROP = {
     "ptsNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if s == nil {", "return nil", "}"],
     "ipaNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if len(s.topologyScore) == 0 {", "return nil", "}"],
@@ -110,6 +117,31 @@ def transliterate(name, params, body, int_div):
         if inner[0].strip() != drop[0]:
             raise SystemExit(f"{name}: expected {drop[0]!r}, found {inner[0]!r}")
         inner, drop = inner[1:], drop[1:]
+    # a condition continued after && / ||, and a composite literal spread over several lines, become one line each (JOINED counts the
+    # absorbed lines for the line-by-line audit)
+    merged, k = [], 0
+    while k < len(inner):
+        ln = inner[k].rstrip()
+        while ln.endswith("&&") or ln.endswith("||"):
+            k += 1
+            ln = ln + " " + inner[k].strip()
+            JOINED[name] = JOINED.get(name, 0) + 1
+        if ln.endswith("InsufficientResource{"):
+            fields = []
+            k += 1
+            while inner[k].strip() != "})":
+                f = inner[k].strip()
+                m = re.fullmatch(r"(\w+):\s+(.+),", f)
+                if not m:
+                    raise SystemExit(f"{name}: composite literal field {f!r}")
+                fields.append(f"{m.group(1)}={m.group(2)}")
+                JOINED[name] = JOINED.get(name, 0) + 1
+                k += 1
+            JOINED[name] = JOINED.get(name, 0) + 1  # the closing line
+            ln = ln[: -len("InsufficientResource{")] + "dict(" + ", ".join(fields) + "))"
+        merged.append(ln)
+        k += 1
+    inner = merged
     switches = []  # depth of every open `switch`: its cases become an if / elif chain on _sw
     for raw in inner:
         ln = raw.strip()
@@ -154,7 +186,10 @@ def transliterate(name, params, body, int_div):
             m = re.fullmatch(r"for (\w+) := range ([\w.]+)", ln)
             m2 = re.fullmatch(r"for _, (\w+) := range ([\w.]+)", ln)
             m3 = re.fullmatch(r"for (\w+), (\w+) := range (\w+)", ln)
-            if m3 and m3.group(1) != "_":
+            m4 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+\.ScalarResources)", ln)
+            if m4:  # a map: Go's order is random, sorted here
+                ln = f"for {m4.group(1)}, {m4.group(2)} in sorted({m4.group(3)}.items()):"
+            elif m3 and m3.group(1) != "_":
                 ln = f"for {m3.group(1)}, {m3.group(2)} in enumerate({m3.group(3)}):"
             elif m:
                 ln = f"for {m.group(1)} in range(len({m.group(2)})):"
@@ -176,6 +211,11 @@ def transliterate(name, params, body, int_div):
                 ln = re.sub(r"var (\w+) (int64|int32|float64)", r"\1 = 0", ln)
             if ln.startswith("klog."):
                 ln = "pass"
+            ln = re.sub(r"^var (\w+) string$", r'\1 = ""', ln)
+            ln = re.sub(r"make\(\[\]\w+, 0, \d+\)", "[]", ln)
+            mk = re.fullmatch(r"_, (\w+) := (.+)\[(\w+)\]", ln)
+            if mk:  # presence only
+                ln = f"{mk.group(1)} = {mk.group(3)} in {mk.group(2)}"
             ml = re.fullmatch(r"(\w+), (\w+) := ls\.Lookup\((.+)\)", ln)
             mp = re.fullmatch(r"(\w+), err :?= strconv\.ParseInt\((.+), 10, 64\)", ln)
             if ml:  # Labels.Lookup: (value, present)
@@ -222,6 +262,10 @@ def expr(ln, int_div):
     ln = re.sub(r"\b(\w+)\[i\]\.ToleratesTaint\((\w+)\)", r"ToleratesTaint(\1[i], \2)", ln)
     ln = ln.replace("v1helper.TolerationsTolerateTaint(", "TolerationsTolerateTaint(").replace("[]v1.Taint{}", "[]").replace("v1.Taint{}", "None")
     ln = re.sub(r"\bv1\.TaintEffect(\w+)", r"TaintEffect\1", ln)
+    ln = re.sub(r"\bv1\.Resource(Pods|CPU|Memory|EphemeralStorage)\b", r"Resource\1", ln).replace("v1helper.IsExtendedResourceName(", "IsExtendedResourceName(")
+    ln = re.sub(r'fmt\.Sprintf\("([^"%]*)%v", (\w+)\)', r'("\1%s" % \2)', ln)
+    ln = re.sub(r'strings\.Split\(string\((\w+)\), ("[^"]*")\)', r"\1.split(\2)", ln)
+    ln = re.sub(r"\bstring\((\w+)\)", r"str(\1)", ln)
     ln = ln.replace(" && ", " and ").replace(" || ", " or ")
     ln = re.sub(r"(?<![&\w])&(?=\w)", "", ln)  # &taint: the address of the loop variable, read only
     ln = re.sub(r"!(?=[\w(])", "not ", ln)  # (logical not; != is left alone)
@@ -246,7 +290,49 @@ SELECTION = {"DoesNotExist": "!", "Equals": "=", "DoubleEquals": "==", "In": "in
              "LessThan": "lt"}  # apimachinery/pkg/selection/operator.go:23-33 (checked against the file in build())
 
 
+RESOURCE_NAMES = {"Pods": "pods", "CPU": "cpu", "Memory": "memory", "EphemeralStorage": "ephemeral-storage"}  # api/core/v1/types.go (checked in build())
 TAINT_EFFECTS = {"NoSchedule": "NoSchedule", "PreferNoSchedule": "PreferNoSchedule", "NoExecute": "NoExecute"}  # api/core/v1/types.go (checked in build())
+
+
+class GoMap(dict):
+    """map[K]int64: a missing key reads as 0."""
+    def __missing__(self, k):
+        return 0
+
+
+class GoResource:
+    """framework.Resource behind its getters (S/framework/types.go)."""
+    def __init__(self, cpu=0, mem=0, eph=0, pods=0, scalars=None):
+        self.cpu, self.mem, self.eph, self.pods, self.scalars = cpu, mem, eph, pods, GoMap(scalars or {})
+
+    def GetMilliCPU(self): return self.cpu
+    def GetMemory(self): return self.mem
+    def GetEphemeralStorage(self): return self.eph
+    def GetAllowedPodNumber(self): return self.pods
+    def GetScalarResources(self): return self.scalars
+
+
+class GoNodeInfo:
+    def __init__(self, alloc, requested, n_pods):
+        self.alloc, self.requested, self.pods = alloc, requested, [None] * n_pods
+
+    def GetAllocatable(self): return self.alloc
+    def GetRequested(self): return self.requested
+    def GetPods(self): return self.pods
+
+
+class GoPodRequest:
+    """preFilterState (fit.go:100-108): the embedded Resource's fields + the DRA mapping (nil without the feature)."""
+    def __init__(self, cpu, mem, eph, scalars):
+        self.MilliCPU, self.Memory, self.EphemeralStorage, self.ScalarResources, self.resourceToDeviceClass = cpu, mem, eph, GoMap(scalars), None
+
+    def GetEphemeralStorage(self): return self.EphemeralStorage
+
+
+class GoNilSet:
+    """a nil sets.Set[string]."""
+    def Len(self): return 0
+    def Has(self, k): return False
 
 
 def parse_int(text):
@@ -268,7 +354,9 @@ def goint(x):
 
 def build():
     env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"], "MaxInt64": (1 << 63) - 1, "MinInt64": -(1 << 63),
-           "invalidScore": -1, "parse_int": parse_int, **{"TaintEffect" + k: v for k, v in TAINT_EFFECTS.items()}, **{"SEL_" + k: v for k, v in SELECTION.items()}, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
+           "invalidScore": -1, "parse_int": parse_int, **{"Resource" + k: v for k, v in RESOURCE_NAMES.items()},
+           # (guards only the ignored-resource sets, which Fits passes as nil: fit.go:560-562)
+           "IsExtendedResourceName": lambda n: "/" in n, **{"TaintEffect" + k: v for k, v in TAINT_EFFECTS.items()}, **{"SEL_" + k: v for k, v in SELECTION.items()}, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
            "LabelFailureDomainBetaZone": PINS["label.zone_beta"], "LabelTopologyZone": PINS["label.zone"],
            "LabelFailureDomainBetaRegion": PINS["label.region_beta"], "LabelTopologyRegion": PINS["label.region"],
            "minThreshold": PINS["image.min_threshold_mb"] * PINS["image.mb"], "maxContainerThreshold": PINS["image.max_container_threshold_mb"] * PINS["image.mb"],
@@ -279,12 +367,17 @@ def build():
     types_src = open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read()
     for k, v in TAINT_EFFECTS.items():
         assert re.search(r"\bTaintEffect%s TaintEffect = \"%s\"" % (k, v), types_src), k
+    for k, v in RESOURCE_NAMES.items():
+        assert re.search(r"\bResource%s ResourceName = \"%s\"" % (k, v), types_src), k
     sources = {}
+    JOINED.clear()
     for name, rel, start, params, int_div in FUNCS:
         line, body = cut(rel, start)
         py = transliterate(name, params, body, int_div)
         exec(py, env)
         sources[name] = {"file": rel, "line": line, "go": "\n".join(body), "python": py}
+        if JOINED.get(name):
+            sources[name]["joined"] = JOINED[name]
     return env, sources
 
 
@@ -391,6 +484,22 @@ def vectors(env):
         cnt = env["countIntolerableTaintsPreferNoSchedule"](tt, env["getAllTolerationPreferNoSchedule"](tl))
         rows.append([taints, tols, found, tt.index(taint) if found else -1, cnt])
     v["taintVerdict"] = rows
+    rows = []
+    scal = ["example.com/gpu", "hugepages-2Mi", "vendor.io/fpga"]
+    opts = types.SimpleNamespace(EnableDRAExtendedResource=False)
+    for _ in range(1500):
+        pod = {"cpu": rnd.choice([0, 0, 1, 100, 250, 4000]), "mem": rnd.choice([0, 0, 1, 64 << 20, 1 << 30]), "eph": rnd.choice([0, 0, 0, 1 << 20, 5 << 30]),
+               "scalars": {k: rnd.choice([0, 1, 1, 2, 8]) for k in scal if rnd.random() < 0.35}}
+        alloc = {"cpu": rnd.choice([0, 100, 4000, 4000, 64000, 64000]), "mem": rnd.choice([0, 64 << 20, 8 << 30, 8 << 30, 64 << 30]), "eph": rnd.choice([0, 1 << 20, 100 << 30, 100 << 30]),
+                 "pods": rnd.choice([0, 1, 3, 110, 110]), "scalars": {k: rnd.choice([0, 1, 2, 8, 8]) for k in scal if rnd.random() < 0.7}}
+        edge = lambda a, p: max(0, a - max(0, p + rnd.choice([-1, 0, 0, 1, 5, -5]))) if rnd.random() < 0.7 else rnd.randint(0, a) if a else 0
+        req = {"cpu": edge(alloc["cpu"], pod["cpu"]), "mem": edge(alloc["mem"], pod["mem"]), "eph": edge(alloc["eph"], pod["eph"]),
+               "scalars": {k: edge(v, pod["scalars"].get(k, 0)) for k, v in alloc["scalars"].items() if rnd.random() < 0.8}}
+        n_pods = max(0, alloc["pods"] - rnd.choice([0, 1, 1, 2, 50]))
+        node = GoNodeInfo(GoResource(alloc["cpu"], alloc["mem"], alloc["eph"], alloc["pods"], alloc["scalars"]), GoResource(req["cpu"], req["mem"], req["eph"], 0, req["scalars"]), n_pods)
+        out = env["fitsRequest"](GoPodRequest(pod["cpu"], pod["mem"], pod["eph"], pod["scalars"]), node, GoNilSet(), GoNilSet(), opts)
+        rows.append([alloc, req, n_pods, pod, [[r["Reason"], bool(r.get("Unresolvable", False))] for r in out]])
+    v["fitsRequest"] = rows
     names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
     v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
     return v
