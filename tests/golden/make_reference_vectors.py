@@ -16,7 +16,8 @@ implementation is its own (the oracle restates it; no other implementation of th
 Functions: leastRequestedScore + the closure of leastResourceScorer (noderesources/least_allocated.go), balancedResourceScorer
 (noderesources/balanced_allocation.go), DefaultNormalizeScore (helper/normalize_score.go), numFeasibleNodesToFind (schedule_one.go),
 calculatePriority + scaledImageScore (imagelocality/image_locality.go), scoreForCount (podtopologyspread/scoring.go); and the string-level
-helpers of FUNCS' second block (toleration / taint verdicts, zone key, image names, label requirements) and fitsRequest (noderesources/fit.go),
+helpers of FUNCS' second block (toleration / taint verdicts, zone key, image names, label requirements), fitsRequest (noderesources/fit.go) and
+InterPodAffinity's Filter with its three satisfy* functions (interpodaffinity/filtering.go),
 run on Python objects that carry the Go method surface (GoNodeInfo, GoResource, GoPodRequest below)."""
 import json
 import math
@@ -78,6 +79,11 @@ FUNCS += [
     ("fitsRequest", S + "/framework/plugins/noderesources/fit.go",
      "func fitsRequest(podRequest *preFilterState, nodeInfo fwk.NodeInfo, ignoredExtendedResources, ignoredResourceGroups sets.Set[string], opts ResourceRequestsOptions) []InsufficientResource {",
      ["podRequest", "nodeInfo", "ignoredExtendedResources", "ignoredResourceGroups", "opts"], False),
+    # InterPodAffinity's Filter over the three count maps PreFilter built (the maps themselves are put together by the harness)
+    ("satisfyExistingPodsAntiAffinity", S + "/framework/plugins/interpodaffinity/filtering.go", "func satisfyExistingPodsAntiAffinity(state *preFilterState, nodeInfo fwk.NodeInfo) bool {", ["state", "nodeInfo"], False),
+    ("satisfyPodAntiAffinity", S + "/framework/plugins/interpodaffinity/filtering.go", "func satisfyPodAntiAffinity(state *preFilterState, nodeInfo fwk.NodeInfo) bool {", ["state", "nodeInfo"], False),
+    ("satisfyPodAffinity", S + "/framework/plugins/interpodaffinity/filtering.go", "func satisfyPodAffinity(state *preFilterState, nodeInfo fwk.NodeInfo) bool {", ["state", "nodeInfo"], False),
+    ("ipaFilter", S + "/framework/plugins/interpodaffinity/filtering.go", "func (pl *InterPodAffinity) Filter(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) *fwk.Status {", ["state", "nodeInfo"], False),
     ("countIntolerableTaintsPreferNoSchedule", S + "/framework/plugins/tainttoleration/taint_toleration.go",
      "func countIntolerableTaintsPreferNoSchedule(taints []v1.Taint, tolerations []v1.Toleration) (intolerableTaints int) {", ["taints", "tolerations"], False),
 ]
@@ -85,6 +91,7 @@ FUNCS += [
 JOINED = {}
 DROP = {
     "ptsNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if s == nil {", "return nil", "}"],
+    "ipaFilter": ["state, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
     "ipaNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if len(s.topologyScore) == 0 {", "return nil", "}"],
 }
 
@@ -184,7 +191,7 @@ def transliterate(name, params, body, int_div):
         if opens:
             ln = ln[:-1].strip()
             m = re.fullmatch(r"for (\w+) := range ([\w.]+)", ln)
-            m2 = re.fullmatch(r"for _, (\w+) := range ([\w.]+)", ln)
+            m2 = re.fullmatch(r"for _, (\w+) := range ([\w.]+(?:\(\))?)", ln)
             m3 = re.fullmatch(r"for (\w+), (\w+) := range (\w+)", ln)
             m4 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+\.ScalarResources)", ln)
             if m4:  # a map: Go's order is random, sorted here
@@ -195,6 +202,14 @@ def transliterate(name, params, body, int_div):
                 ln = f"for {m.group(1)} in range(len({m.group(2)})):"
             elif m2:
                 ln = f"for {m2.group(1)} in {m2.group(2)}:"
+            elif re.fullmatch(r"if (\w+), ok := (.+)\[([\w.]+)\]; ok", ln):  # if with an init statement: the lookup, then the test
+                mi = re.fullmatch(r"if (\w+), ok := (.+)\[([\w.]+)\]; ok", ln)
+                out.append("    " * depth + f"ok = {mi.group(3)} in {mi.group(2)}")
+                out.append("    " * depth + f"{mi.group(1)} = {mi.group(2)}.get({mi.group(3)}, \"\")")
+                ln = "if ok:"
+            elif re.fullmatch(r"for (\w+), (\w+) := range ([\w.()]+\.Labels)", ln):
+                ml = re.fullmatch(r"for (\w+), (\w+) := range ([\w.()]+\.Labels)", ln)
+                ln = f"for {ml.group(1)}, {ml.group(2)} in sorted({ml.group(3)}.items()):"
             elif ln.startswith("if "):
                 ln = "if " + ln[3:] + ":"
             else:
@@ -261,6 +276,8 @@ def expr(ln, int_div):
     ln = re.sub(r"\bselection\.(\w+)", r"SEL_\1", ln)
     ln = re.sub(r"\b(\w+)\[i\]\.ToleratesTaint\((\w+)\)", r"ToleratesTaint(\1[i], \2)", ln)
     ln = ln.replace("v1helper.TolerationsTolerateTaint(", "TolerationsTolerateTaint(").replace("[]v1.Taint{}", "[]").replace("v1.Taint{}", "None")
+    ln = re.sub(r"topologyPair\{key: ([\w.]+), value: (\w+)\}", r"(\1, \2)", ln)
+    ln = re.sub(r"fwk\.NewStatus\(fwk\.(\w+), (\w+)\)", r'["\1", \2]', ln)
     ln = re.sub(r"\bv1\.TaintEffect(\w+)", r"TaintEffect\1", ln)
     ln = re.sub(r"\bv1\.Resource(Pods|CPU|Memory|EphemeralStorage)\b", r"Resource\1", ln).replace("v1helper.IsExtendedResourceName(", "IsExtendedResourceName(")
     ln = re.sub(r'fmt\.Sprintf\("([^"%]*)%v", (\w+)\)', r'("\1%s" % \2)', ln)
@@ -354,7 +371,10 @@ def goint(x):
 
 def build():
     env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"], "MaxInt64": (1 << 63) - 1, "MinInt64": -(1 << 63),
-           "invalidScore": -1, "parse_int": parse_int, **{"Resource" + k: v for k, v in RESOURCE_NAMES.items()},
+           "invalidScore": -1, "parse_int": parse_int, "ErrReasonAffinityRulesNotMatch": PINS["reason.ipa_affinity"],
+           "ErrReasonAntiAffinityRulesNotMatch": PINS["reason.ipa_anti"], "ErrReasonExistingAntiAffinityRulesNotMatch": PINS["reason.ipa_existing_anti"],
+           # podMatchesAllAffinityTerms (filtering.go): does the incoming pod match its own required affinity terms -- an input of the harness
+           "podMatchesAllAffinityTerms": lambda terms, pod: len(terms) > 0 and pod.self_aff, **{"Resource" + k: v for k, v in RESOURCE_NAMES.items()},
            # (guards only the ignored-resource sets, which Fits passes as nil: fit.go:560-562)
            "IsExtendedResourceName": lambda n: "/" in n, **{"TaintEffect" + k: v for k, v in TAINT_EFFECTS.items()}, **{"SEL_" + k: v for k, v in SELECTION.items()}, "TolerationOpEqual": PINS["toleration.op_equal"], "TolerationOpExists": PINS["toleration.op_exists"],
            "LabelFailureDomainBetaZone": PINS["label.zone_beta"], "LabelTopologyZone": PINS["label.zone"],
@@ -500,6 +520,36 @@ def vectors(env):
         out = env["fitsRequest"](GoPodRequest(pod["cpu"], pod["mem"], pod["eph"], pod["scalars"]), node, GoNilSet(), GoNilSet(), opts)
         rows.append([alloc, req, n_pods, pod, [[r["Reason"], bool(r.get("Unresolvable", False))] for r in out]])
     v["fitsRequest"] = rows
+    rows = []
+    for _ in range(900):
+        # four nodes over two topology keys; per node: existing pods matching ALL the incoming pod's affinity terms, per anti-affinity term the
+        # existing pods it matches, per key the existing pods' own anti-affinity terms that match the incoming pod.  The three count maps are put
+        # together the way updateWithAffinityTerms / updateWithAntiAffinityTerms do (types.go: one increment per term whose key the node carries)
+        labels = [{k: v for k, v in (("zone", rnd.choice(["a", "a", "b", None])), ("host", rnd.choice([f"h{i}", f"h{i}", None]))) if v is not None} for i in range(4)]
+        aff_terms = [rnd.choice(["zone", "host"]) for _ in range(rnd.choice([0, 0, 1, 1, 2]))]
+        anti_terms = [rnd.choice(["zone", "host"]) for _ in range(rnd.choice([0, 0, 1, 2]))]
+        self_aff = rnd.random() < 0.5
+        aff_existing = [rnd.choice([0, 0, 0, 1, 2]) if aff_terms else 0 for _ in range(4)]
+        anti_existing = [[rnd.choice([0, 0, 0, 1]) for _ in range(4)] for _ in anti_terms]
+        exist_anti = {k: [rnd.choice([0, 0, 0, 0, 1]) for _ in range(4)] for k in ("zone", "host") if rnd.random() < 0.4}
+        aff, anti, exist = GoMap(), GoMap(), GoMap()
+        for i, lb in enumerate(labels):
+            for k in aff_terms:
+                if k in lb and aff_existing[i]:
+                    aff[(k, lb[k])] += aff_existing[i]
+            for t, k in enumerate(anti_terms):
+                if k in lb and anti_existing[t][i]:
+                    anti[(k, lb[k])] += anti_existing[t][i]
+            for k, cnt in exist_anti.items():
+                if k in lb and cnt[i]:
+                    exist[(k, lb[k])] += cnt[i]
+        term = lambda k: types.SimpleNamespace(TopologyKey=k)
+        pod_info = types.SimpleNamespace(GetRequiredAffinityTerms=lambda a=[term(k) for k in aff_terms]: a, GetRequiredAntiAffinityTerms=lambda a=[term(k) for k in anti_terms]: a,
+                                         GetPod=lambda: types.SimpleNamespace(self_aff=self_aff))
+        state = types.SimpleNamespace(podInfo=pod_info, affinityCounts=aff, antiAffinityCounts=anti, existingAntiAffinityCounts=exist)
+        out = [env["ipaFilter"](state, types.SimpleNamespace(Node=lambda lb=lb: types.SimpleNamespace(Labels=lb))) for lb in labels]
+        rows.append([labels, aff_terms, self_aff, aff_existing, anti_terms, anti_existing, exist_anti, out])
+    v["ipaFilter"] = rows
     names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
     v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
     return v

@@ -32,8 +32,9 @@ def test_transliterations_are_line_by_line():
     for name, s in FIX["sources"].items():
         go = [l.strip() for l in s["go"].split("\n")[1:-1] if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
-        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
+        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
         two_value_lookups = sum(", ok := " in l or ":= ls.Lookup(" in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
+        two_value_lookups += sum(l.startswith("if ") and ", ok := " in l for l in go)  # `if v, ok := m[k]; ok {`: the lookup's two lines, then the test
         named_result = 1 if re.search(r"\) \(\w+ [\[\]\w.]+\) \{$", s["go"].split("\n")[0]) else 0  # `(n int)`: one line that sets its zero value
         joined = s.get("joined", 0)  # lines absorbed into the one before: a condition continued after && / ||, a composite literal's fields
         assert len(go) - dropped + two_value_lookups + named_result - joined == len(py), name
@@ -120,6 +121,41 @@ def test_fits_request(ccref):
         got = R._reason_histogram(r.hist, (), None, names)
         assert got == {text: 1 for text, _ in want}, (alloc, req, n_pods, pod, got)
         assert r.n_code_unschedulable == (0 if any(u for _, u in want) else 1), (alloc, req, n_pods, pod)
+
+
+def test_inter_pod_affinity_filter(ccref):
+    """InterPodAffinity's Filter (filtering.go:352-432: satisfyPodAffinity incl. the first-pod exception, satisfyPodAntiAffinity,
+    satisfyExistingPodsAntiAffinity, their order and status codes) against the oracle, node by node: the other three nodes are made
+    unschedulable (they still hold their pods, so the count maps are the cluster's) and the verdict is read from a one-cycle run."""
+    import numpy as np
+    from cluster_capacity_amd import model as M, report as R
+    prof = M.Profile.default()
+    zone_id, key_idx = {"a": 1, "b": 2}, {"zone": 0, "host": 1}
+    checked = 0
+    for labels, aff_terms, self_aff, aff_existing, anti_terms, anti_existing, exist_anti, want in VEC["ipaFilter"]:
+        cols = [np.array([zone_id.get(lb.get("zone"), 0) for lb in labels], np.int32), np.array([i + 1 if "host" in lb else 0 for i, lb in enumerate(labels)], np.int32)]
+        arr = lambda x: np.array(x, np.int32) if any(x) else None
+        ipa = M.InterPodAffinity(key_cols=[0, 1], key_ndom=[2, 4], aff_keys=[key_idx[k] for k in aff_terms], self_aff=self_aff, aff_existing=arr(aff_existing),
+                                 anti_keys=[key_idx[k] for k in anti_terms], anti_self=[False] * len(anti_terms), anti_existing=[arr(x) for x in anti_existing],
+                                 exist_anti=[arr(exist_anti[k]) if k in exist_anti else None for k in ("zone", "host")], score_existing=[None, None], score_self=[0, 0],
+                                 entries_existing=0, self_entries=[0, 0])
+        pod = M.PodSpec(req=np.array([100, 1 << 20, 0], np.int64), nz_mcpu=100, nz_mem=1 << 20, ipa=ipa)
+        for i in range(4):
+            unsched = np.ones(4, np.uint8)
+            unsched[i] = 0
+            z = np.zeros(4, np.int64)
+            nodes = M.NodesSoA(alloc=[z + 8000, z + (8 << 30), z.copy()], alloc_pods=np.full(4, 110, np.int32), req=[z.copy(), z.copy(), z.copy()], nz_mcpu=z.copy(), nz_mem=z.copy(),
+                               pod_count=np.zeros(4, np.int32), taintset_id=np.zeros(4, np.int32), unschedulable=unsched, label_cols=[c.copy() for c in cols], names=[f"n{j}" for j in range(4)])
+            r = ccref.run(prof, nodes, pod, max_limit=1)
+            if want[i] is None:
+                assert r.placed == 1 and list(r.log[:1]) == [i], (labels, aff_terms, anti_terms, i)
+            else:
+                code, text = want[i]
+                got = R._reason_histogram(r.hist, (), None, [])
+                assert r.placed == 0 and got.get(text) == 1 and sum(got.values()) == 4, (labels, aff_terms, self_aff, aff_existing, anti_terms, anti_existing, exist_anti, i, got)
+                assert r.n_code_unschedulable == (1 if code == "Unschedulable" else 0), (code, i)
+            checked += 1
+    assert checked == 3600
 
 
 def test_zone_key():
