@@ -17,7 +17,8 @@ Functions: leastRequestedScore + the closure of leastResourceScorer (noderesourc
 (noderesources/balanced_allocation.go), DefaultNormalizeScore (helper/normalize_score.go), numFeasibleNodesToFind (schedule_one.go),
 calculatePriority + scaledImageScore (imagelocality/image_locality.go), scoreForCount (podtopologyspread/scoring.go); and the string-level
 helpers of FUNCS' second block (toleration / taint verdicts, zone key, image names, label requirements), fitsRequest (noderesources/fit.go) and
-InterPodAffinity's Filter with its three satisfy* functions (interpodaffinity/filtering.go),
+InterPodAffinity's Filter with its three satisfy* functions (interpodaffinity/filtering.go), PodTopologySpread's Filter with minMatchNum
+(podtopologyspread/filtering.go),
 run on Python objects that carry the Go method surface (GoNodeInfo, GoResource, GoPodRequest below)."""
 import json
 import math
@@ -79,6 +80,10 @@ FUNCS += [
     ("fitsRequest", S + "/framework/plugins/noderesources/fit.go",
      "func fitsRequest(podRequest *preFilterState, nodeInfo fwk.NodeInfo, ignoredExtendedResources, ignoredResourceGroups sets.Set[string], opts ResourceRequestsOptions) []InsufficientResource {",
      ["podRequest", "nodeInfo", "ignoredExtendedResources", "ignoredResourceGroups", "opts"], False),
+    # PodTopologySpread's Filter over the per-constraint domain counts PreFilter built (TpValueToMatchNum and the critical paths are put together by the
+    # harness; the local `minMatchNum` shadows the method's name in Python, hence the prefixed function name)
+    ("preFilterState_minMatchNum", S + "/framework/plugins/podtopologyspread/filtering.go", "func (s *preFilterState) minMatchNum(constraintID int, minDomains int32) (int, error) {", ["s", "constraintID", "minDomains"], False),
+    ("ptsFilter", S + "/framework/plugins/podtopologyspread/filtering.go", "func (pl *PodTopologySpread) Filter(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) *fwk.Status {", ["s", "node", "pod"], False),
     # InterPodAffinity's Filter over the three count maps PreFilter built (the maps themselves are put together by the harness)
     ("satisfyExistingPodsAntiAffinity", S + "/framework/plugins/interpodaffinity/filtering.go", "func satisfyExistingPodsAntiAffinity(state *preFilterState, nodeInfo fwk.NodeInfo) bool {", ["state", "nodeInfo"], False),
     ("satisfyPodAntiAffinity", S + "/framework/plugins/interpodaffinity/filtering.go", "func satisfyPodAntiAffinity(state *preFilterState, nodeInfo fwk.NodeInfo) bool {", ["state", "nodeInfo"], False),
@@ -91,6 +96,7 @@ FUNCS += [
 JOINED = {}
 DROP = {
     "ptsNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if s == nil {", "return nil", "}"],
+    "ptsFilter": ["node := nodeInfo.Node()", "s, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
     "ipaFilter": ["state, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
     "ipaNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if len(s.topologyScore) == 0 {", "return nil", "}"],
 }
@@ -192,7 +198,7 @@ def transliterate(name, params, body, int_div):
             ln = ln[:-1].strip()
             m = re.fullmatch(r"for (\w+) := range ([\w.]+)", ln)
             m2 = re.fullmatch(r"for _, (\w+) := range ([\w.]+(?:\(\))?)", ln)
-            m3 = re.fullmatch(r"for (\w+), (\w+) := range (\w+)", ln)
+            m3 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+)", ln)
             m4 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+\.ScalarResources)", ln)
             if m4:  # a map: Go's order is random, sorted here
                 ln = f"for {m4.group(1)}, {m4.group(2)} in sorted({m4.group(3)}.items()):"
@@ -224,7 +230,7 @@ def transliterate(name, params, body, int_div):
                 ln = re.sub(r"var (\w+) int64 = (.+)", r"\1 = \2", ln)
             elif re.fullmatch(r"var (\w+) (int64|int32|float64)", ln):
                 ln = re.sub(r"var (\w+) (int64|int32|float64)", r"\1 = 0", ln)
-            if ln.startswith("klog."):
+            if ln.startswith("klog.") or ln.startswith("logger"):
                 ln = "pass"
             ln = re.sub(r"^var (\w+) string$", r'\1 = ""', ln)
             ln = re.sub(r"make\(\[\]\w+, 0, \d+\)", "[]", ln)
@@ -238,7 +244,7 @@ def transliterate(name, params, body, int_div):
                 ln = f"{ml.group(1)} = ls.get({ml.group(3)}, \"\")"
             elif mp:
                 ln = f"{mp.group(1)}, err = parse_int({mp.group(2)})"
-            m = re.fullmatch(r"(\w+), ok := (\w+)\[(.+)\]", ln)
+            m = re.fullmatch(r"(\w+), ok := ([\w.]+)\[(.+)\]", ln)
             m2 = re.fullmatch(r"(\w+), _ = (\w+)\[(.+)\]", ln)
             if m:   # the two-value map lookup: the zero value ("") when the key is absent
                 out.append("    " * depth + f"ok = {expr(m.group(3), int_div)} in {m.group(2)}")
@@ -276,6 +282,7 @@ def expr(ln, int_div):
     ln = re.sub(r"\bselection\.(\w+)", r"SEL_\1", ln)
     ln = re.sub(r"\b(\w+)\[i\]\.ToleratesTaint\((\w+)\)", r"ToleratesTaint(\1[i], \2)", ln)
     ln = ln.replace("v1helper.TolerationsTolerateTaint(", "TolerationsTolerateTaint(").replace("[]v1.Taint{}", "[]").replace("v1.Taint{}", "None")
+    ln = ln.replace("s.minMatchNum(", "preFilterState_minMatchNum(s, ").replace("labels.Set(", "(")
     ln = re.sub(r"topologyPair\{key: ([\w.]+), value: (\w+)\}", r"(\1, \2)", ln)
     ln = re.sub(r"fwk\.NewStatus\(fwk\.(\w+), (\w+)\)", r'["\1", \2]', ln)
     ln = re.sub(r"\bv1\.TaintEffect(\w+)", r"TaintEffect\1", ln)
@@ -372,6 +379,7 @@ def goint(x):
 def build():
     env = {"math": math, "godiv": godiv, "goint": goint, "MaxNodeScore": PINS["score.max_node_score"], "MaxInt64": (1 << 63) - 1, "MinInt64": -(1 << 63),
            "invalidScore": -1, "parse_int": parse_int, "ErrReasonAffinityRulesNotMatch": PINS["reason.ipa_affinity"],
+           "ErrReasonConstraintsNotMatch": PINS["reason.pts_skew"], "ErrReasonNodeLabelNotMatch": PINS["reason.pts_skew"] + PINS["reason.pts_missing_label_suffix"],
            "ErrReasonAntiAffinityRulesNotMatch": PINS["reason.ipa_anti"], "ErrReasonExistingAntiAffinityRulesNotMatch": PINS["reason.ipa_existing_anti"],
            # podMatchesAllAffinityTerms (filtering.go): does the incoming pod match its own required affinity terms -- an input of the harness
            "podMatchesAllAffinityTerms": lambda terms, pod: len(terms) > 0 and pod.self_aff, **{"Resource" + k: v for k, v in RESOURCE_NAMES.items()},
@@ -550,6 +558,26 @@ def vectors(env):
         out = [env["ipaFilter"](state, types.SimpleNamespace(Node=lambda lb=lb: types.SimpleNamespace(Labels=lb))) for lb in labels]
         rows.append([labels, aff_terms, self_aff, aff_existing, anti_terms, anti_existing, exist_anti, out])
     v["ipaFilter"] = rows
+    rows = []
+    for _ in range(900):
+        # four nodes, one or two DoNotSchedule constraints; per node and constraint the existing matching pods.  TpValueToMatchNum[i] sums them per value over
+        # the nodes that carry EVERY constraint's key (calPreFilterState, filtering.go:262-296), the critical path's minimum is the smallest of its values
+        # (math.MaxInt32 for no domain: newCriticalPaths)
+        labels = [{k: v for k, v in (("zone", rnd.choice(["a", "a", "b", "c", None])), ("host", rnd.choice([f"h{i}", f"h{i}", f"h{i}", None]))) if v is not None} for i in range(4)]
+        cons = [{"key": k, "maxSkew": rnd.choice([1, 1, 2, 3]), "minDomains": rnd.choice([1, 1, 2, 4, 5]), "selfMatch": rnd.random() < 0.7, "counts": [rnd.choice([0, 0, 1, 2, 3]) for _ in range(4)]}
+                for k in rnd.choice([["zone"], ["host"], ["zone", "host"], ["host", "zone"], ["zone", "zone"]])]
+        tp = [GoMap() for _ in cons]
+        for i, lb in enumerate(labels):
+            if all(c["key"] in lb for c in cons):
+                for j, c in enumerate(cons):
+                    tp[j][lb[c["key"]]] += c["counts"][i]  # (a counted node's domain exists even with 0 matching pods)
+        paths = [[types.SimpleNamespace(MatchNum=min(m.values()) if m else (1 << 31) - 1)] for m in tp]
+        state = types.SimpleNamespace(Constraints=[types.SimpleNamespace(TopologyKey=c["key"], MaxSkew=c["maxSkew"], MinDomains=c["minDomains"],
+                                                                         Selector=types.SimpleNamespace(Matches=lambda _l, m=c["selfMatch"]: m)) for c in cons],
+                                      TpValueToMatchNum=tp, CriticalPaths=paths)
+        out = [env["ptsFilter"](state, types.SimpleNamespace(Labels=lb), types.SimpleNamespace(Labels={})) for lb in labels]
+        rows.append([labels, cons, out])
+    v["ptsFilter"] = rows
     names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
     v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
     return v

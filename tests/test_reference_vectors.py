@@ -32,7 +32,7 @@ def test_transliterations_are_line_by_line():
     for name, s in FIX["sources"].items():
         go = [l.strip() for l in s["go"].split("\n")[1:-1] if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
-        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
+        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 4 if name == "ptsFilter" else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
         two_value_lookups = sum(", ok := " in l or ":= ls.Lookup(" in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
         two_value_lookups += sum(l.startswith("if ") and ", ok := " in l for l in go)  # `if v, ok := m[k]; ok {`: the lookup's two lines, then the test
         named_result = 1 if re.search(r"\) \(\w+ [\[\]\w.]+\) \{$", s["go"].split("\n")[0]) else 0  # `(n int)`: one line that sets its zero value
@@ -153,6 +153,37 @@ def test_inter_pod_affinity_filter(ccref):
                 code, text = want[i]
                 got = R._reason_histogram(r.hist, (), None, [])
                 assert r.placed == 0 and got.get(text) == 1 and sum(got.values()) == 4, (labels, aff_terms, self_aff, aff_existing, anti_terms, anti_existing, exist_anti, i, got)
+                assert r.n_code_unschedulable == (1 if code == "Unschedulable" else 0), (code, i)
+            checked += 1
+    assert checked == 3600
+
+
+def test_pod_topology_spread_filter(ccref):
+    """PodTopologySpread's Filter (filtering.go:311-356) with minMatchNum (:56-69: the global minimum reads 0 below minDomains) against the oracle,
+    node by node as in test_inter_pod_affinity_filter: missing label -> UnschedulableAndUnresolvable, skew above maxSkew -> Unschedulable."""
+    import numpy as np
+    from cluster_capacity_amd import model as M, report as R
+    prof = M.Profile.default()
+    zone_id = {"a": 1, "b": 2, "c": 3}
+    checked = 0
+    for labels, cons, want in VEC["ptsFilter"]:
+        cols = [np.array([zone_id.get(lb.get("zone"), 0) for lb in labels], np.int32), np.array([i + 1 if "host" in lb else 0 for i, lb in enumerate(labels)], np.int32)]
+        spread = [M.SpreadConstraint(col=0 if c["key"] == "zone" else 1, max_skew=c["maxSkew"], min_domains=c["minDomains"], hard=True, self_match=c["selfMatch"],
+                                     is_hostname=c["key"] == "host", n_domains=3 if c["key"] == "zone" else 4, node_match_count=np.array(c["counts"], np.int32)) for c in cons]
+        pod = M.PodSpec(req=np.array([100, 1 << 20, 0], np.int64), nz_mcpu=100, nz_mem=1 << 20, spread=spread)
+        for i in range(4):
+            unsched = np.ones(4, np.uint8)
+            unsched[i] = 0
+            z = np.zeros(4, np.int64)
+            nodes = M.NodesSoA(alloc=[z + 8000, z + (8 << 30), z.copy()], alloc_pods=np.full(4, 110, np.int32), req=[z.copy(), z.copy(), z.copy()], nz_mcpu=z.copy(), nz_mem=z.copy(),
+                               pod_count=np.zeros(4, np.int32), taintset_id=np.zeros(4, np.int32), unschedulable=unsched, label_cols=[c.copy() for c in cols], names=[f"n{j}" for j in range(4)])
+            r = ccref.run(prof, nodes, pod, max_limit=1)
+            if want[i] is None:
+                assert r.placed == 1 and list(r.log[:1]) == [i], (labels, cons, i)
+            else:
+                code, text = want[i]
+                got = R._reason_histogram(r.hist, (), None, [])
+                assert r.placed == 0 and got.get(text) == 1 and sum(got.values()) == 4, (labels, cons, i, got)
                 assert r.n_code_unschedulable == (1 if code == "Unschedulable" else 0), (code, i)
             checked += 1
     assert checked == 3600
