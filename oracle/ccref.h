@@ -12,7 +12,9 @@
  * pkg/framework/simulator_test.go -- see tests/test_oracle_known_answers.py.  "parity unpinned"
  * beyond those for the loop as a whole.  What can be anchored on the reference's SOURCES without running Go is: the unit arithmetic
  * (ccref_least_allocated, ccref_balanced_allocation, ccref_default_normalize, ccref_num_feasible_nodes_to_find,
- * ccref_image_locality_score, ccref_pts_normalize, ccref_ipa_normalize) equals the output of a mechanical line-by-line transliteration of the reference's own Go functions
+ * ccref_image_locality_score, ccref_pts_normalize, ccref_ipa_normalize) and three filters as the loop applies them -- NodeResourcesFit's fitsRequest (reason
+ * set + the Unresolvable status rule), PodTopologySpread's Filter with minMatchNum, InterPodAffinity's Filter with its satisfy* functions, each checked node by
+ * node through ccref_run -- equal the output of a mechanical line-by-line transliteration of the reference's own Go functions
  * (tests/golden/reference_vectors.json, tests/test_reference_vectors.py); every message string, status code, default and the
  * filter order equal what the sources say (tests/golden/reference_pins.json, tests/test_reference_pins.py).
  *
