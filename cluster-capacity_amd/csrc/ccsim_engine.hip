@@ -19,8 +19,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <time.h>
 #include <vector>
 
 #include "../../include/ccsim.h"
@@ -1493,17 +1499,36 @@ struct RcclApi {
 };
 constexpr int kNcclInt32 = 2, kNcclInt64 = 4, kNcclSum = 0, kNcclMax = 2; // rccl.h:448-463
 
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static bool dist_debug() {
+    static const bool on = getenv("CCSIM_DIST_DEBUG") && *getenv("CCSIM_DIST_DEBUG") && *getenv("CCSIM_DIST_DEBUG") != '0';
+    return on;
+}
+
 RcclApi &rccl() {
     static RcclApi a;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (a.h || !a.err.empty()) return a;
+    const double t0 = now_s();
+    // an RCCL the process already maps wins (torch ships one under the same SONAME): RTLD_NOLOAD probes without loading
     const char *names[] = {getenv("CCSIM_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    std::string last;
     for (const char *n : names) {
         if (!n || !*n) continue;
         a.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (a.h) break;
+        const char *m = dlerror(); // (one call: dlerror() clears the message it returns)
+        last = m ? m : "?";
+        if (n == names[0]) break; // an explicit CCSIM_RCCL_LIB that cannot be loaded is an error, not a hint
     }
     if (!a.h) {
-        a.err = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+        a.err = "librccl.so.1 could not be loaded: " + last;
+        if (dist_debug()) fprintf(stderr, "[ccsim dist] %s\n", a.err.c_str());
         return a;
     }
     auto sym = [&](const char *n) -> void * {
@@ -1518,7 +1543,40 @@ RcclApi &rccl() {
     a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
     if (!a.err.empty()) a.h = nullptr;
+    if (dist_debug()) fprintf(stderr, "[ccsim dist] librccl bound in %.2f s%s%s\n", now_s() - t0, a.err.empty() ? "" : ": ", a.err.c_str());
     return a;
+}
+
+// ncclCommInitRank blocks until every rank has arrived and gives no way to bound that; a rank that never comes (or a
+// first touch of a 500 MB library on a cold box) must end as an error with a text, not as a process that never returns.
+// The call runs on a helper thread; the caller waits CCSIM_RCCL_INIT_TIMEOUT_S (default 900) and then gives up (the helper
+// is abandoned: it holds only heap state of its own).
+struct CommInitJob {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int rc = 0;
+    void *comm = nullptr;
+};
+static int comm_init_bounded(RcclApi &r, int device, int n_ranks, const CcNcclId &id, int rank, void **comm_out, double *waited) {
+    auto job = std::make_shared<CommInitJob>();
+    std::thread([job, &r, device, n_ranks, id, rank]() {
+        int rc = (int)hipSetDevice(device);
+        void *c = nullptr;
+        if (rc == 0) rc = r.CommInitRank(&c, n_ranks, id, rank);
+        std::lock_guard<std::mutex> lk(job->mu);
+        job->rc = rc, job->comm = c, job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    double limit = 900;
+    if (const char *t = getenv("CCSIM_RCCL_INIT_TIMEOUT_S")) limit = atof(t) > 0 ? atof(t) : limit;
+    const double t0 = now_s();
+    std::unique_lock<std::mutex> lk(job->mu);
+    const bool ok = job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; });
+    *waited = now_s() - t0;
+    if (!ok) return -ETIMEDOUT;
+    *comm_out = job->comm;
+    return job->rc;
 }
 } // namespace
 
@@ -1554,7 +1612,12 @@ extern "C" int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id_bytes, in
     dist_comm_release(e);
     CcNcclId id;
     memcpy(id.internal, id_bytes, CCSIM_DIST_ID_BYTES);
-    RCCLCHK(e, r.CommInitRank(&e->rccl_comm, n_ranks, id, rank));
+    double waited = 0;
+    const int irc = comm_init_bounded(r, e->device, n_ranks, id, rank, &e->rccl_comm, &waited);
+    if (dist_debug()) fprintf(stderr, "[ccsim dist] ncclCommInitRank(rank %d of %d, device %d) returned %d after %.2f s\n", rank, n_ranks, e->device, irc, waited);
+    if (irc == -ETIMEDOUT)
+        return fail(e, -EIO, "RCCL: ncclCommInitRank(rank %d of %d) did not return within %.0f s (CCSIM_RCCL_INIT_TIMEOUT_S); a rank is missing or librccl is stuck", rank, n_ranks, waited);
+    if (irc != 0) return fail(e, -EIO, "RCCL: ncclCommInitRank failed: %s", r.GetErrorString(irc));
     e->comm_ranks = n_ranks, e->comm_rank = rank;
     HIPCHK(e, hipMalloc((void **)&e->d_own_send, sizeof(XRec)));
     HIPCHK(e, hipMalloc((void **)&e->d_own_recv, sizeof(XRec) * (size_t)n_ranks));

@@ -29,7 +29,26 @@ def _have_gpu() -> bool:
         return False
 
 
+# Run order of the files (with the driver's `-x`, a plumbing test that sorts early must not be able to take
+# the kernel parity evidence down with it).  Kernel parity against the oracle first, through the C ABI in-process; then the
+# configs / goldens; the in-process RCCL communicator; last whatever starts child processes (C demo, the native host, its
+# one-rank RCCL path on a cold box).  Files not named keep their alphabetical order between the two groups.
+_ORDER_FIRST = ["test_gpu_parity.py", "test_persist.py", "test_sampling.py", "test_spread.py", "test_ipa.py", "test_coupled.py", "test_multi.py",
+                "test_ports_images.py", "test_golden.py", "test_baseline_configs.py", "test_kernel_resources.py"]
+_ORDER_LAST = ["test_dist_rccl.py", "test_abi.py", "test_preemption.py", "test_ingest_cli.py", "test_host_robustness.py", "test_native_host.py"]
+
+
+def _file_rank(item) -> int:
+    name = os.path.basename(str(item.fspath))
+    if name in _ORDER_FIRST:
+        return _ORDER_FIRST.index(name)
+    if name in _ORDER_LAST:
+        return 1000 + _ORDER_LAST.index(name)
+    return 500
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_file_rank)  # (stable: the order inside a file, and among unnamed files, is pytest's)
     # `pytest tests` on a host without a HIP device: skip the gpu-marked tests instead of failing them one by one.
     # With an explicit `-m gpu` nothing is skipped: on a GPU box a missing device / library must fail loudly.
     gpu_items = [it for it in items if it.get_closest_marker("gpu")]

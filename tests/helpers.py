@@ -143,3 +143,10 @@ def random_ipa(rng, nodes):
         exist_anti=[sparse(2, 0.03) if rng.integers(0, 3) == 0 else None for _ in keys],
         score_existing=score_existing, score_self=score_self, entries_existing=entries,
         self_entries=[1 if w else int(rng.integers(0, 2)) for w in score_self])
+
+
+# Child processes started by the tests (native host, C demo): a fresh GPU box pages the HIP runtime, libccsim's code objects and --
+# on the sharded path -- a 570 MB librccl in from a cold image, which has taken more than a minute (GPUTEST r02).  The limit only
+# has to catch a real hang (ccsim_dist_comm_init bounds its own wait and reports): generous, one knob.
+SUBPROC_TIMEOUT = int(__import__("os").environ.get("CCSIM_TEST_SUBPROC_TIMEOUT", "600"))
+

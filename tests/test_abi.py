@@ -71,12 +71,14 @@ def test_c_demo_compiles_against_the_header(tmp_path):
 
 import pytest  # noqa: E402
 
+from helpers import SUBPROC_TIMEOUT  # noqa: E402
+
 
 @pytest.mark.gpu
 def test_c_demo_reproduces_readme_answer(tmp_path):
     """The reference's README demo through the C ABI from a C program, no Python in the loop: 52 = 13 x 4."""
     import subprocess
-    out = subprocess.run([_build_demo(tmp_path)], capture_output=True, text=True, timeout=120)
+    out = subprocess.run([_build_demo(tmp_path)], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "The cluster can schedule 52 instance(s)" in out.stdout and "4 Insufficient cpu" in out.stdout
     assert out.stdout.count("13 instance(s)") == 4

@@ -15,6 +15,22 @@ def test_unique_id_without_a_gpu():
     assert len(a) == len(b) == capi.DIST_ID_BYTES and a != b
 
 
+def test_unloadable_rccl_is_an_error_not_a_crash():
+    """with librccl not loadable the entry points return -EIO (the message built from ONE dlerror() call), they do not
+    segfault.  A child process: the binding is cached per process."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as ge; ge.load_package()\n"
+            "from cluster_capacity_amd import capi\n"
+            "try:\n    capi.dist_unique_id()\nexcept capi.CcsimError as ex:\n    print('REFUSED', ex)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=H.SUBPROC_TIMEOUT,
+                       env=dict(os.environ, CCSIM_RCCL_LIB="/nonexistent/librccl.so.1", CCSIM_DIST_DEBUG="1"))
+    assert p.returncode == 0 and "REFUSED" in p.stdout, (p.returncode, p.stdout, p.stderr)
+    assert "could not be loaded" in p.stderr and "/nonexistent/librccl.so.1" in p.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,cfg,n,limit", [("sequential", "C3", 1500, 700), ("batched", "C3", 1500, 0), ("batched", "C3", 20_000, 12_345),
                                               ("batched", "C2", 3000, 0)])

@@ -8,6 +8,8 @@ import subprocess
 
 import numpy as np
 import pytest
+
+from helpers import SUBPROC_TIMEOUT
 import yaml
 
 from cluster_capacity_amd import build as B, cli, ingest, model as M
@@ -180,7 +182,7 @@ def _write(tmp_path, fmt, nodes, pods, pod):
 
 
 def _run(native, args):
-    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=60)
+    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
     assert p.returncode == 0, p.stderr
     return p.stdout
 
@@ -247,7 +249,7 @@ def test_native_host_fails_loudly_without_the_engine(native, tmp_path):
     nodes, pods, pod, _ = CASES["readme"]()
     podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
     env = dict(os.environ, CCSIM_LIB="/nonexistent/libccsim.so", HIP_VISIBLE_DEVICES="-1")
-    p = subprocess.run([native, "--podspec", podspec, "--snapshot", snaps[0]], capture_output=True, text=True, env=env, timeout=120)
+    p = subprocess.run([native, "--podspec", podspec, "--snapshot", snaps[0]], capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
     assert p.returncode != 0 and ("no CPU fallback" in p.stderr or "ccsim_create failed" in p.stderr)
     p = subprocess.run([native, "--snapshot", snaps[0]], capture_output=True, text=True)
     assert p.returncode == 2 and "Pod spec file is missing" in p.stderr
@@ -552,7 +554,7 @@ def test_native_host_marshals_the_c_abi_like_the_python_binding(native, recorder
     podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
     args = ["--podspec", podspec, "--snapshot", snaps[0], "--max-limit", "1000", "-o", "json"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
     env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "native.json"))
-    p = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
+    p = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
     assert p.returncode == 0, p.stderr
     native_rec = json.load(open(tmp_path / "native.json"))
     # the recorder's canned result came back through ccsim_report into the review
@@ -793,7 +795,7 @@ def test_native_ingest_random_differential(native, tmp_path, seed):
     args = ["--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["--dump-snapshot", "-"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
     # every third case through the host's worker threads (parallel parse of the List's items, parallel per-pod / per-node walks)
     env = dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_PARALLEL_MIN_ITEMS="0", CCHOST_THREADS=str(2 + seed % 4)) if seed % 3 == 0 else None
-    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=60, env=env)
+    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=SUBPROC_TIMEOUT, env=env)
     try:
         no, po, ns = cli.load_all(snaps)
         ref = py_dump(ingest.build_snapshot(no, po, cli.parse_pod_spec(podspec), exclude, namespace_objs=ns))
@@ -1050,7 +1052,7 @@ def test_several_templates_ingest_abi_and_report_agree(native, recorder, tmp_pat
     assert [p["has_node_selector"] for p in [got["pod"]] + got["more_pods"]] == [False, True, False]
     # (2) what reaches ccsim_set_pods is identical from both hosts
     env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "native.json"))
-    p = subprocess.run([native] + flags + ["--max-limit", "12", "-o", "json"], capture_output=True, text=True, env=env, timeout=60)
+    p = subprocess.run([native] + flags + ["--max-limit", "12", "-o", "json"], capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
     assert p.returncode == 0, p.stderr
     native_rec = json.load(open(tmp_path / "native.json"))
     lib = C.CDLL(recorder)
@@ -1080,7 +1082,7 @@ def test_several_templates_ingest_abi_and_report_agree(native, recorder, tmp_pat
                       hist=np.zeros(M.NREASON, np.int64), hist_taintset=np.zeros(1, np.int64), n_code_unschedulable=0)
     pyrev = cli.build_review(pypods, snap, res, 12)
     assert pyrev["status"]["pods"] == rev["status"]["pods"] and pyrev["status"]["failReason"] == rev["status"]["failReason"]
-    pretty = subprocess.run([native] + flags + ["--max-limit", "12", "--verbose"], capture_output=True, text=True, env=env, timeout=60).stdout
+    pretty = subprocess.run([native] + flags + ["--max-limit", "12", "--verbose"], capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT).stdout
     assert pretty == cli.pretty(pyrev, True)
     # (4) templates whose selectors match one another's clones are refused by both hosts
     templates[1]["metadata"]["labels"] = {"app": "t0"}
@@ -1140,7 +1142,7 @@ def test_native_sharded_run_fails_loudly_without_gpus(native, tmp_path):
     nodes, pods, pod, _ = CASES["readme"]()
     podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1")
-    p = subprocess.run([native, "--podspec", podspec, "--snapshot", snaps[0], "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    p = subprocess.run([native, "--podspec", podspec, "--snapshot", snaps[0], "--gpus", "2"], capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
     assert p.returncode == 1 and ("ccsim_create failed on device" in p.stderr or "ccsim_dist_unique_id failed" in p.stderr)
 
 
@@ -1198,12 +1200,12 @@ def _sharded_records(native, recorder, tmp_path, objs, n_gpus):
     podspec, snaps = _write(tmp_path, "json", nodes, pods, pod)
     args = ["--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["-o", "json"] + (["--exclude-nodes", ",".join(exclude)] if exclude else [])
     env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "plain.json"))
-    p = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
+    p = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
     if p.returncode != 0:
         return None
     plain = json.load(open(tmp_path / "plain.json"))
     env = dict(env, CCSIM_RECORD=str(tmp_path / "shard.json"), CCSIM_RECORD_PER_DEVICE="1")
-    p = subprocess.run([native] + args + ["--gpus", str(n_gpus)], capture_output=True, text=True, env=env, timeout=60)
+    p = subprocess.run([native] + args + ["--gpus", str(n_gpus)], capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
     assert p.returncode == 0, p.stderr
     n = plain["nodes"]["n_nodes"]
     per = -(-n // n_gpus)
@@ -1337,7 +1339,7 @@ def test_pruned_parse_of_decorated_dumps_gives_the_same_snapshot(native, tmp_pat
         outs.append(_run(native, args))
         if deco:  # ... and the same through the parallel parse of the List's items (off for small files unless asked for)
             env = dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_PARALLEL_MIN_ITEMS="0", CCHOST_THREADS=str(2 + seed % 3))
-            par = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=60)
+            par = subprocess.run([native] + args, capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
             assert par.returncode == 0 and par.stdout == outs[-1], par.stderr
         if deco:  # ... and as YAML (block style as kubectl / PyYAML emit it, long strings folded, quoted where needed): pruned by indentation
             (d / "cluster.yaml").write_text(yaml.safe_dump({"kind": "List", "apiVersion": "v1", "items": objs}, default_flow_style=False, width=int(rng.choice([60, 80, 1000]))))
@@ -1357,14 +1359,14 @@ def test_pruned_parse_still_rejects_broken_json(native, tmp_path):
         (tmp_path / "c.json").write_text(text)
         for env in (None, dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS="2")):
             p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"], capture_output=True, text=True,
-                               timeout=30, env=env)
+                               timeout=SUBPROC_TIMEOUT, env=env)
             assert p.returncode != 0
     # an error inside an element must surface from the worker threads too
     items = [{"kind": "Node", "metadata": {"name": f"n{i}"}, "status": {"allocatable": {"cpu": "1", "pods": "1"}}} for i in range(40)]
     text = json.dumps({"kind": "List", "items": items}).replace('"n17"', '"n17" oops')
     (tmp_path / "c.json").write_text(text)
     p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(tmp_path / "c.json"), "--dump-snapshot", "-"], capture_output=True, text=True,
-                       timeout=30, env=dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS="4"))
+                       timeout=SUBPROC_TIMEOUT, env=dict(os.environ, CCHOST_PARALLEL_MIN_BYTES="0", CCHOST_THREADS="4"))
     assert p.returncode != 0 and "cluster-capacity:" in p.stderr
 
 
@@ -1391,7 +1393,7 @@ def test_several_templates_unschedulable_stop_names_the_failing_template(native,
             "placed": res.placed, "stop": res.stop, "n_code_unschedulable": res.n_code_unschedulable, "per_node_count": res.per_node_count.tolist(),
             "log": res.log.tolist(), "hist": res.hist.tolist(), "hist_taintset": res.hist_taintset.tolist(), "stop_spec": failing}))
         p = subprocess.run([native] + [x for q in paths for x in ("--podspec", q)] + ["--snapshot", cluster, "--fake-result", str(tmp_path / "result.json"), "-o", "json"],
-                           capture_output=True, text=True, timeout=60)
+                           capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
         assert p.returncode == 0, p.stderr
         want = cli.build_review(pypods, snap, res, 0)
         assert json.loads(p.stdout)["status"]["failReason"] == want["status"]["failReason"], failing
@@ -1479,7 +1481,7 @@ def test_system_default_spreading_is_flagged_by_both_hosts(native, tmp_path, cap
             (d / "cluster.json").write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + objs}))
             (d / "pod.json").write_text(json.dumps(tpl))
             p = subprocess.run([native, "--podspec", str(d / "pod.json"), "--snapshot", str(d / "cluster.json"), "--fake-result", str(tmp_path / "result.json"), "--max-limit", "1"],
-                               capture_output=True, text=True, timeout=60)
+                               capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
             assert p.returncode == 0, p.stderr
             assert ("system default spreading" in p.stderr) == (expect and not own), (k, own, p.stderr)
             owners = [o for kind in ("ReplicationController", "ReplicaSet", "StatefulSet") for o in cli.load_kind([str(d / "cluster.json")], kind)]
@@ -1501,7 +1503,7 @@ def test_system_default_spreading_becomes_two_soft_constraints_when_every_node_i
     for name, objs in (("with", svcs), ("without", [])):
         path = tmp_path / f"{name}.json"
         path.write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + [dict(p, kind="Pod") for p in pods] + objs}))
-        p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(path), "--dump-snapshot", "-"], capture_output=True, text=True, timeout=60)
+        p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(path), "--dump-snapshot", "-"], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
         assert p.returncode == 0 and p.stderr == "", p.stderr
         got = json.loads(p.stdout)
         got.pop("label_keys")

@@ -8,6 +8,8 @@ import json
 
 import numpy as np
 import pytest
+
+from helpers import SUBPROC_TIMEOUT
 import yaml
 
 import helpers as H
@@ -226,6 +228,6 @@ def test_gpu_cli_ports_images_both_hosts(tmp_path):
     txt = buf.getvalue()
     assert "The cluster can schedule 4 instance(s) of the pod small-pod." in txt
     assert "5 node(s) didn't have free ports for the requested pod ports" in txt
-    p = subprocess.run([B.build_host()] + args, capture_output=True, text=True, timeout=120)
+    p = subprocess.run([B.build_host()] + args, capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
     assert p.returncode == 0, p.stderr
     assert p.stdout == txt

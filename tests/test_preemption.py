@@ -12,6 +12,8 @@ import subprocess
 
 import numpy as np
 import pytest
+
+from helpers import SUBPROC_TIMEOUT
 import yaml
 
 import helpers as H
@@ -293,7 +295,7 @@ def _both_hosts(ccref, native, tmp_path, nodes, pods, pod, exclude=()):
     args = ["--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["--fake-result", str(tmp_path / "result.json"), "--max-limit", "3000", "-o", "json"]
     if exclude:
         args += ["--exclude-nodes", ",".join(exclude)]
-    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=60)
+    p = subprocess.run([native] + args, capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
     assert p.returncode == 0, p.stderr
     want = cli.build_review(pypod, snap, r, 3000)["status"]["failReason"]
     return want, json.loads(p.stdout)["status"]["failReason"], p.stderr
