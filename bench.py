@@ -61,9 +61,11 @@ def src_sha16() -> str:
     return b.source_sha16()
 
 
-def cpu_baseline(nodes, pod, prof, rounds: int, engine_log):
+def cpu_baseline(nodes, pod, prof, rounds: int, engine_log, blind_counts=None):
     """Oracle (port of the reference algorithm) on the host cores, bounded sample.  Its placement log must equal the
-    engine's first `rounds` placements (the checker checks the thing measured before the number is printed)."""
+    engine's first `rounds` placements on the ORDERED path, and its per-node counts must equal what the BLIND path -- the
+    path the timed steps take: no log, 64-level batches, validate / roll back -- leaves when the same limit cuts a level
+    (the checker checks the thing measured before the number is printed)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ccref_py
 
@@ -73,8 +75,11 @@ def cpu_baseline(nodes, pod, prof, rounds: int, engine_log):
     dt = time.perf_counter() - t0
     if engine_log is not None:
         assert np.array_equal(np.asarray(r.log[: r.placed]), np.asarray(engine_log[: r.placed])), "engine and oracle placement logs differ"
+    if blind_counts is not None:
+        assert np.array_equal(np.asarray(r.per_node_count), np.asarray(blind_counts)), "blind (timed) path and oracle per-node counts differ"
     return {
         "log_equals_engine_prefix": engine_log is not None,
+        "timed_path_per_node_counts_equal_oracle_at_limit": blind_counts is not None,
         "value": r.placed / dt,
         "unit": "placements/s",
         "cores": threads,
@@ -207,8 +212,7 @@ def main():
         phys = n_here * (36 + (4 if args.mode == "batched" else 0))  # int32 mirrors (24 B) + stat, alloc_pods, pod_count (12 B) [+ the 4-byte score cache written]
         full_pass = {
             "kernel": full_kernel, "us_per_launch": full_s * 1e6, "launches_timed": train,
-            "bytes_algorithmic": bytes_per_scan, "achieved_algorithmic": bytes_per_scan / full_s / 1e9,
-            "frac_algorithmic": bytes_per_scan / full_s / 1e9 / HBM_PEAK_GBPS,
+            "bytes_algorithmic_not_moved": bytes_per_scan,  # SURVEY 8(d)'s 60 B/node of int64 columns: what the reference semantics read, NOT what this kernel moves
             "bytes_physical": phys, "achieved": phys / full_s / 1e9, "frac": phys / full_s / 1e9 / HBM_PEAK_GBPS,
             "frac_of_measured_read_peak": phys / full_s / 1e9 / READ_PEAK_MEASURED_GBPS,
             "traffic": pmc.get(full_kernel, {}).get("hbm_bytes_largest_launch" if args.mode == "batched" else "hbm_bytes_per_launch"),
@@ -221,7 +225,8 @@ def main():
         model_bytes = n_here * (36 + 4 * 4 + 76)
         moved = traffic if traffic else model_bytes
         roofline = {
-            "bound": "hbm", "kernel": kernel,
+            # (the contract's vocabulary is hbm | mfma; neither bounds this kernel -- VERDICT r2: say what does)
+            "bound": "sync-latency" if persistent else "hbm", "kernel": kernel,
             "achieved": moved / dom_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": moved / dom_s / 1e9 / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": pmc_note, "bytes_per_launch": moved,
             "bytes_definition": "HBM bytes one launch moves (PMC when available, else the kernel's designed traffic): a physical rate",
@@ -254,6 +259,7 @@ def main():
             ve.reset_state(); vr = ve.run(max_limit=limit, mode="batched", want_log=False)
             variants[name] = (time.perf_counter() - v0) * 1e3
             assert vr.placed == r.placed, (name, vr.placed, r.placed)
+            assert np.array_equal(vr.per_node_count, r.per_node_count), name  # the whole observable of an unlogged run
             ve.close()
             for k, v in old.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
@@ -290,7 +296,15 @@ def main():
         nodes_full = nodes if world == 1 else synth.make_config("C4", n_nodes=n_global)[0]
         eng.reset_state()
         head = eng.run(max_limit=args.cpu_rounds, mode=args.mode, want_log=True, log_cap=args.cpu_rounds)
-        out["cpu_baseline"] = cpu_baseline(nodes_full, pod, prof, args.cpu_rounds, head.log)
+        # the path the timed steps took (want_log=False: blind multi-level batches), cut by the same limit INSIDE a score level:
+        # validation must roll the batch back and redo it in canonical order -- the per-node vector is the observable
+        eng.reset_state()
+        blind = eng.run(max_limit=args.cpu_rounds, mode=args.mode, want_log=False)
+        assert blind.placed == head.placed, (blind.placed, head.placed)
+        out["cpu_baseline"] = cpu_baseline(nodes_full, pod, prof, args.cpu_rounds, head.log, blind.per_node_count)
+        out["timed_path_check"] = {
+            "what": "the blind path (no log) run with --max-limit inside a score level; per-node counts equal the oracle's at the same limit",
+            "limit": args.cpu_rounds, "placed": int(blind.placed), "passes": int(blind.scans), "ordered_path_passes": int(head.scans)}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
