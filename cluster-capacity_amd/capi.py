@@ -133,6 +133,7 @@ SYMBOLS = {
     "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ccsim_debug_persist_prof": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_multi_stops": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ccsim_debug_coupled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -464,6 +465,12 @@ class Engine:
         out = (C.c_int64 * 8)()
         self._chk(self.lib.ccsim_debug_multi_stops(self.h, out), "ccsim_debug_multi_stops")
         return [int(x) for x in out]
+
+    def coupled_info(self):
+        """How the last run of one template with topology-coupled plugins was resolved (ccsim_debug_coupled)."""
+        out = (C.c_int64 * 8)()
+        self._chk(self.lib.ccsim_debug_coupled(self.h, out), "ccsim_debug_coupled")
+        return {"plan": bool(out[0]), "windows": int(out[1]), "fell_back": bool(out[2]), "window": int(out[3]), "list_len": int(out[4])}
 
     def persist_prof(self):
         """Phase breakdown of the last persistent batched launch (ccsim_debug_persist_prof), in microseconds."""

@@ -1,0 +1,949 @@
+// ccsim_coupled.h -- ONE template with topology-coupled plugins (PodTopologySpread, InterPodAffinity), resolved in exact
+// WINDOWS of placements per node pass instead of one pass per placement.
+//
+// The reference recomputes, every scheduling cycle, calPreFilterState over all nodes (P/podtopologyspread/filtering.go:235-308),
+// the inter-pod affinity maps (P/interpodaffinity/filtering.go:204-309) and both plugins' scores
+// (P/podtopologyspread/scoring.go:118-265, P/interpodaffinity/scoring.go:128-290).  The sequential mode of this engine does
+// the same with one k_scan + one k_final per placement: 2 launches and ~20 us per pod whatever the node count.
+//
+// The argument (tests/coupled_model.py is its executable form, checked placement by placement against the oracle on the CPU;
+// `device_plan=True` there is exactly the variant implemented here).  For one template a node's verdict and TotalScore split
+// into a NODE-LOCAL part A(n) -- static filters, NodePorts clamp, NodeResourcesFit, and the TaintToleration / NodeAffinity /
+// ImageLocality / LeastAllocated / BalancedAllocation scores under assumed normalization maxima -- that changes only when a
+// clone lands on n, and a COUPLED part that reads per-domain tables at the node's own topology values plus cycle-wide scalars.
+// Nodes that agree on everything the coupled part reads form a CLASS: same topology value for every key shared by several
+// nodes; same table ENTRIES for every key whose values are unique per node (kubernetes.io/hostname: the "domain" is the node
+// and its entries are node state).  Inside a class every node untouched since the pass has the same coupled verdict and raw
+// scores in every later cycle, so the class's best node is the head of its member list sorted by (A desc, index asc).
+// One pass therefore serves a window of W cycles:
+//   k_cw_scan    every node: local feasibility, A(n), the class tuple -> exact class table (hash + full-tuple check);
+//                per class: members, TaintToleration / NodeAffinity maxima
+//   k_cw_top     per block of 1024 nodes: the L best members of every class (L rounds of LDS atomic-max), holders of the
+//                class maxima
+//   k_cw_merge   per class: the L best members over all blocks
+//   k_cw_decide  ONE workgroup, the cycle loop in ONE wave (no barriers inside a cycle): shared-key tables, class records and
+//                the touched nodes live in LDS; per cycle the hard constraints' minima, every candidate's coupled verdict, the
+//                feasible / candidate-domain counts behind the PodTopologySpread weights, raw-score min / max, totals, argmax,
+//                commit (NodeInfo.update S/framework/types.go:409-428 + table updates).
+// Whatever the window cannot know ends it BEFORE the cycle in question (the next pass starts from the exact state): a class
+// whose next head is not among the L members kept; normalization maxima that differ from the ones A was computed with; the
+// last node at the minimum of a hard constraint over a unique key taken.  What the mode cannot represent at all (more than
+// kCwMaxClasses classes, a tuple beyond kCwTuple components, two tuples with one hash, an entry beyond int32) sets
+// DevState::cw_fallback and the run continues in the one-pass-per-placement loop -- an optimisation with an exact fallback,
+// never a different answer.
+#pragma once
+#include "ccsim_kernels.h"
+
+namespace ccsim {
+
+constexpr int kCwTuple = 16;        // int32 components of a class tuple
+constexpr int kCwMaxClasses = 256;  // classes per window
+constexpr int kCwSlots = 1024;      // global open-addressing class table (power of two)
+constexpr int kCwBlockSlots = 256;  // per-block LDS class table of the scan (power of two)
+constexpr int kCwMaxList = 32;      // L
+constexpr int kCwMaxWindow = 256;   // W
+constexpr int kCwThreads = 256, kCwPerThread = 4, kCwTile = kCwThreads * kCwPerThread;
+constexpr int kCwMaxKeys = 4096;    // k_cw_merge stages blocks x L keys of one class in LDS (32 KiB)
+constexpr int kCwLdsI32 = 6144;     // k_cw_decide: int32 words of shared-key tables (hard / soft counts, presence flags, candidate bitmaps)
+constexpr int kCwLdsI64 = 3072;     // ... int64 words (four InterPodAffinity tables per shared key)
+constexpr int kCwCtlClasses = 0, kCwCtlGiveUp = 1;
+
+// Where each plugin input sits in the class tuple, and where its table lives in the decide kernel's LDS (host-built per pod spec).
+struct CwPlan {
+    int32_t n_comp;
+    int32_t h_comp[kMaxTsc], h_unique[kMaxTsc], h_off[kMaxTsc], h_len[kMaxTsc], h_pres[kMaxTsc]; // hard constraint c
+    int32_t s_comp[kMaxTsc], s_off[kMaxTsc], s_len[kMaxTsc], s_bm[kMaxTsc];                      // soft constraint c (hostname: per node)
+    int32_t k_comp[kMaxIpaKeys], k_unique[kMaxIpaKeys], k_off[kMaxIpaKeys], k_len[kMaxIpaKeys];   // InterPodAffinity key k
+    int32_t i32_words, i64_words;
+    int32_t window, list_len;
+    const int32_t *h_present[kMaxTsc]; // domain-presence flags of hard constraint c (k_pts_init)
+};
+
+struct __attribute__((aligned(16))) CwClass {
+    int32_t tuple[kCwTuple];
+    uint32_t nf;     // node-feasible members
+    uint32_t mt, ma; // max PreferNoSchedule count / preferred-affinity sum over them
+    uint32_t ht, ha; // how many members hold those maxima
+    uint32_t id;     // dense class number (claim order)
+    uint32_t pad[2];
+};
+
+struct CwWork {
+    unsigned long long *keys; // [kCwSlots] tuple hash of the class in the slot, 0 = empty
+    uint32_t *ready;          // [kCwSlots] the claimant has written the tuple
+    CwClass *cls;             // [kCwSlots]
+    uint32_t *ctl;            // [16]
+    int32_t *slot_of_id;      // [kCwMaxClasses]
+    int32_t *node_slot;       // [n_pad] class slot of a node-feasible node, -1 otherwise
+    int32_t *node_A;          // [n_pad] its node-local score
+    unsigned long long *top;  // [blocks][kCwMaxClasses][L]
+    unsigned long long *lists; // [kCwMaxClasses][L]
+    unsigned long long *umin; // [blocks][kMaxTsc] unique-key hard constraints: (minimum << 32) | counted nodes at the minimum
+    int32_t n_blocks;
+};
+
+__device__ __forceinline__ uint64_t cw_hash(const int32_t *t, int n) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int i = 0; i < kCwTuple; i++)
+        if (i < n) {
+            h ^= (uint64_t)(uint32_t)t[i] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+            h *= 0xff51afd7ed558ccdull;
+            h ^= h >> 33;
+        }
+    return h ? h : 1ull;
+}
+
+__device__ __forceinline__ uint32_t ld_u32_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct CwScanArgs {
+    DevCols c;
+    DevPod p;
+    const DevState *st;
+    DevPts pts;
+    DevSoft soft;
+    DevIpa ipa;
+    CwPlan plan;
+    CwWork w;
+};
+
+// int64 table entry -> tuple component; beyond int32 the windowed mode gives up (exactly, not approximately)
+__device__ __forceinline__ int32_t cw_narrow_entry(int64_t v, uint32_t *giveup) {
+    if (v > 0x3fffffffll || v < -0x3fffffffll) {
+        __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    return (int32_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_cw_scan: one block = kCwTile consecutive nodes.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int NX, bool NARROW>
+__global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
+    const DevState &st = *a.st;
+    if (st.done || st.cw_fallback) return;
+    __shared__ unsigned long long b_key[kCwBlockSlots];
+    __shared__ int32_t b_tuple[kCwBlockSlots][kCwTuple];
+    __shared__ uint32_t b_nf[kCwBlockSlots], b_mt[kCwBlockSlots], b_ma[kCwBlockSlots];
+    __shared__ int32_t b_gslot[kCwBlockSlots];
+    __shared__ uint32_t b_um[kMaxTsc], b_uc[kMaxTsc];
+    const int tid = threadIdx.x;
+    for (int s = tid; s < kCwBlockSlots; s += kCwThreads) b_key[s] = 0, b_nf[s] = 0, b_mt[s] = 0, b_ma[s] = 0, b_gslot[s] = -1;
+    if (tid < kMaxTsc) b_um[tid] = 0x7fffffffu, b_uc[tid] = 0;
+    __syncthreads();
+    const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
+    const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
+    const int ncomp = a.plan.n_comp;
+    uint32_t *giveup = a.w.ctl + kCwCtlGiveUp;
+    int lslot[kCwPerThread];
+    int32_t lA[kCwPerThread];
+
+#pragma unroll 1
+    for (int j = 0; j < kCwPerThread; j++) {
+        const int64_t i = (int64_t)blockIdx.x * kCwTile + (int64_t)j * kCwThreads + tid;
+        lslot[j] = -1, lA[j] = 0;
+        bool feas = false;
+        int32_t tup[kCwTuple];
+#pragma unroll
+        for (int q = 0; q < kCwTuple; q++) tup[q] = 0;
+        uint32_t cnt = 0, aff = 0;
+        if (i < a.c.n) {
+            const uint32_t w = a.c.stat[i];
+            const uint32_t eb = a.pts.n ? a.pts.elig[i] : 1u;
+            // unique-key hard constraints: the minimum over the counted nodes (filtering.go:298-305), whatever their feasibility
+            for (int c = 0; c < a.pts.n; c++)
+                if (a.plan.h_unique[c]) {
+                    const int32_t v = a.pts.label[c][i];
+                    if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u)) {
+                        const uint32_t m = (uint32_t)a.pts.tbl[c][v];
+                        const uint32_t old = atomicMin(&b_um[c], m);
+                        (void)old;
+                    }
+                }
+            feas = (w >> kStatOkBit) != 0;
+            int64_t a_cpu = 0, a_mem = 0, r_cpu = 0, r_mem = 0, z_cpu = 0, z_mem = 0;
+            int32_t na0 = 0, na1 = 0, nr0 = 0, nr1 = 0, nz0 = 0, nz1 = 0;
+            const int32_t a_pods = a.c.alloc_pods[i], npods = a.c.pod_count[i];
+            int64_t xa[NX > 0 ? NX : 1], xr[NX > 0 ? NX : 1];
+            if (NARROW) {
+                na0 = a.c.a32[0][i], na1 = a.c.a32[1][i], nr0 = a.c.r32[0][i], nr1 = a.c.r32[1][i], nz0 = a.c.z32[0][i], nz1 = a.c.z32[1][i];
+                feas = feas && fits_narrow(a.p, npod, na0, na1, nr0, nr1, a_pods, npods);
+            } else {
+                a_cpu = a.c.alloc[0][i], a_mem = a.c.alloc[1][i], r_cpu = a.c.req[0][i], r_mem = a.c.req[1][i];
+                z_cpu = a.c.nz_mcpu[i], z_mem = a.c.nz_mem[i];
+                feas = feas && fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods);
+#pragma unroll
+                for (int x = 0; x < (NX > 0 ? NX : 1); x++) {
+                    xa[x] = xr[x] = 0;
+                    if (NX > 0 && x < a.p.nx) {
+                        const int col = a.p.xcol[x];
+                        xa[x] = a.c.alloc[col][i], xr[x] = a.c.req[col][i];
+                        const int64_t rq = a.p.req[col];
+                        if (a.p.fit_enabled && !a.p.all_zero_req && rq > 0 && rq > xa[x] - xr[x]) feas = false;
+                    }
+                }
+            }
+            // a node without one of the hard constraints' keys never passes PodTopologySpread (filtering.go:325-329): no class
+            if (a.pts.n && !(eb & 1u)) feas = false;
+            if (feas) {
+                cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                const uint32_t img = (w >> kStatImgShift) & kStatImgMask;
+                const int64_t A = static_score(a.p, cnt, aff, img, mt, ma) +
+                                  (NARROW ? dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1)
+                                          : (NX > 0 && a.p.gen_score ? dynamic_score_gen<NX>(a.p, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xa, xr)
+                                                                     : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem)));
+                lA[j] = (int32_t)A;
+                // ---- the class tuple: everything the coupled plugins read of this node
+                for (int c = 0; c < a.pts.n; c++) {
+                    const int32_t v = a.pts.label[c][i];
+                    tup[a.plan.h_comp[c]] = a.plan.h_unique[c] ? ((v ? 1 : 0) | (v ? a.pts.tbl[c][v] << 1 : 0)) : v;
+                }
+                for (int c = 0; c < a.soft.n; c++) {
+                    const int32_t v = a.soft.label[c][i];
+                    int32_t t = v;
+                    if (a.soft.is_hostname[c]) {
+                        const int32_t ct = (a.soft.existing[c] ? a.soft.existing[c][i] : 0) + (a.soft.self_match[c] ? npods - a.soft.pod_count0[i] : 0);
+                        t = (v ? 1 : 0) | (ct << 1);
+                    }
+                    tup[a.plan.s_comp[c]] = t;
+                }
+                if (a.ipa.on)
+                    for (int k = 0; k < a.ipa.n_keys; k++) {
+                        const int32_t v = a.ipa.label[k][i];
+                        const int q = a.plan.k_comp[k];
+                        if (!a.plan.k_unique[k]) tup[q] = v;
+                        else {
+                            tup[q] = v ? 1 : 0;
+                            tup[q + 1] = v ? cw_narrow_entry(a.ipa.aff[k][v], giveup) : 0;
+                            tup[q + 2] = v ? cw_narrow_entry(a.ipa.anti[k][v], giveup) : 0;
+                            tup[q + 3] = v ? cw_narrow_entry(a.ipa.exist[k][v], giveup) : 0;
+                            tup[q + 4] = v ? cw_narrow_entry(a.ipa.score[k][v], giveup) : 0;
+                        }
+                    }
+            }
+        }
+        // ---- block-local class table (LDS): one global atomic per (block, class) instead of one per node
+        bool mine = false;
+        int s = -1;
+        if (feas) {
+            const uint64_t h = cw_hash(tup, ncomp);
+            s = (int)(h & (kCwBlockSlots - 1));
+            int probes = 0;
+            for (;;) {
+                const unsigned long long old = atomicCAS(&b_key[s], 0ull, (unsigned long long)h);
+                if (old == 0ull) {
+                    mine = true;
+#pragma unroll
+                    for (int q = 0; q < kCwTuple; q++) b_tuple[s][q] = tup[q];
+                    break;
+                }
+                if (old == h) break;
+                s = (s + 1) & (kCwBlockSlots - 1);
+                if (++probes >= kCwBlockSlots) {
+                    __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // more classes in one block than the table holds
+                    s = -1;
+                    break;
+                }
+            }
+            if (s >= 0) atomicAdd(&b_nf[s], 1u), atomicMax(&b_mt[s], cnt), atomicMax(&b_ma[s], aff);
+        }
+        __syncthreads();
+        if (s >= 0 && !mine) { // same hash: the tuples must be the same tuple
+            bool same = true;
+#pragma unroll
+            for (int q = 0; q < kCwTuple; q++) same = same && b_tuple[s][q] == tup[q];
+            if (!same) __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lslot[j] = s;
+    }
+    // how many counted nodes of this block sit at the block's minimum (second sweep over the same entries: L2 hits)
+    bool any_unique = false;
+    for (int c = 0; c < a.pts.n; c++) any_unique = any_unique || a.plan.h_unique[c];
+    if (any_unique) {
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < kCwPerThread; j++) {
+            const int64_t i = (int64_t)blockIdx.x * kCwTile + (int64_t)j * kCwThreads + tid;
+            if (i >= a.c.n) continue;
+            const uint32_t eb = a.pts.elig[i];
+            for (int c = 0; c < a.pts.n; c++)
+                if (a.plan.h_unique[c]) {
+                    const int32_t v = a.pts.label[c][i];
+                    if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && (uint32_t)a.pts.tbl[c][v] == b_um[c]) atomicAdd(&b_uc[c], 1u);
+                }
+        }
+    }
+    __syncthreads();
+    if (tid < kMaxTsc) a.w.umin[(int64_t)blockIdx.x * kMaxTsc + tid] = ((unsigned long long)b_um[tid] << 32) | b_uc[tid];
+
+    // ---- block table -> global table.  Phase a: claim / find (no waiting); phase b: wait for foreign claimants, compare tuples
+    int gs[(kCwBlockSlots + kCwThreads - 1) / kCwThreads];
+    bool foreign[(kCwBlockSlots + kCwThreads - 1) / kCwThreads];
+#pragma unroll
+    for (int r = 0; r < (kCwBlockSlots + kCwThreads - 1) / kCwThreads; r++) {
+        const int s = r * kCwThreads + tid;
+        gs[r] = -1, foreign[r] = false;
+        if (s >= kCwBlockSlots || b_key[s] == 0ull) continue;
+        const unsigned long long h = b_key[s];
+        int g = (int)(h & (kCwSlots - 1)), probes = 0;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&a.w.keys[g], 0ull, h);
+            if (old == 0ull) {
+                const uint32_t id = atomicAdd(&a.w.ctl[kCwCtlClasses], 1u);
+                if (id >= (uint32_t)kCwMaxClasses) __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else {
+#pragma unroll
+                    for (int q = 0; q < kCwTuple; q++) a.w.cls[g].tuple[q] = b_tuple[s][q];
+                    a.w.cls[g].id = id;
+                    a.w.slot_of_id[id] = g;
+                }
+                __hip_atomic_store(&a.w.ready[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            if (old == h) {
+                foreign[r] = true;
+                break;
+            }
+            g = (g + 1) & (kCwSlots - 1);
+            if (++probes >= kCwSlots) {
+                __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g = -1;
+                break;
+            }
+        }
+        gs[r] = g;
+        if (g >= 0) {
+            atomicAdd(&a.w.cls[g].nf, b_nf[s]);
+            atomicMax(&a.w.cls[g].mt, b_mt[s]);
+            atomicMax(&a.w.cls[g].ma, b_ma[s]);
+        }
+        b_gslot[s] = g;
+    }
+#pragma unroll
+    for (int r = 0; r < (kCwBlockSlots + kCwThreads - 1) / kCwThreads; r++) {
+        const int s = r * kCwThreads + tid;
+        if (!foreign[r] || gs[r] < 0) continue;
+        int spins = 0;
+        while (!ld_u32_agent(&a.w.ready[gs[r]]) && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+        bool same = spins < (1 << 20);
+        if (same && !__hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            for (int q = 0; q < kCwTuple; q++) same = same && a.w.cls[gs[r]].tuple[q] == b_tuple[s][q];
+        if (!same) __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kCwPerThread; j++) {
+        const int64_t i = (int64_t)blockIdx.x * kCwTile + (int64_t)j * kCwThreads + tid;
+        if (i < a.c.n_pad) {
+            a.w.node_slot[i] = lslot[j] >= 0 ? b_gslot[lslot[j]] : -1;
+            a.w.node_A[i] = lA[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_cw_top: per block of kCwTile nodes, the L best members of every class: round r publishes, per class, the best key not
+// yet taken (one LDS atomic-max per live node), its owner retires.  Also counts the holders of the class maxima.
+// ------------------------------------------------------------------------------------------------------------------------
+struct CwTopArgs {
+    DevCols c;
+    const DevState *st;
+    CwWork w;
+    int32_t list_len;
+};
+
+__global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
+    if (a.st->done || a.st->cw_fallback) return;
+    if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    __shared__ unsigned long long cand[kCwMaxClasses];
+    __shared__ uint32_t l_mt[kCwMaxClasses], l_ma[kCwMaxClasses], l_ht[kCwMaxClasses], l_ha[kCwMaxClasses];
+    __shared__ int s_live;
+    const int tid = threadIdx.x;
+    const int C = (int)a.w.ctl[kCwCtlClasses];
+    for (int id = tid; id < C; id += kCwThreads) {
+        const CwClass &k = a.w.cls[a.w.slot_of_id[id]];
+        l_mt[id] = k.mt, l_ma[id] = k.ma, l_ht[id] = 0, l_ha[id] = 0;
+    }
+    __syncthreads();
+    int id_[kCwPerThread];
+    uint64_t key_[kCwPerThread];
+#pragma unroll
+    for (int j = 0; j < kCwPerThread; j++) {
+        const int64_t i = (int64_t)blockIdx.x * kCwTile + (int64_t)j * kCwThreads + tid;
+        id_[j] = -1, key_[j] = 0;
+        if (i < a.c.n) {
+            const int32_t slot = a.w.node_slot[i];
+            if (slot >= 0) {
+                id_[j] = (int)a.w.cls[slot].id;
+                key_[j] = make_key((int64_t)a.w.node_A[i], a.c.global_offset + i);
+                const uint32_t w = a.c.stat[i];
+                if (((w >> kStatCntShift) & kStatCntMask) == l_mt[id_[j]]) atomicAdd(&l_ht[id_[j]], 1u);
+                if ((w & kStatAffMask) == l_ma[id_[j]]) atomicAdd(&l_ha[id_[j]], 1u);
+            }
+        }
+    }
+    unsigned long long *out = a.w.top + (size_t)blockIdx.x * kCwMaxClasses * a.list_len;
+#pragma unroll 1
+    for (int r = 0; r < a.list_len; r++) {
+        for (int id = tid; id < C; id += kCwThreads) cand[id] = 0ull;
+        if (tid == 0) s_live = 0;
+        __syncthreads();
+        bool live = false;
+#pragma unroll
+        for (int j = 0; j < kCwPerThread; j++)
+            if (id_[j] >= 0) atomicMax(&cand[id_[j]], (unsigned long long)key_[j]), live = true;
+        if (live) s_live = 1;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kCwPerThread; j++)
+            if (id_[j] >= 0 && cand[id_[j]] == key_[j]) id_[j] = -1; // (keys are unique: they carry the node index)
+        for (int id = tid; id < C; id += kCwThreads) out[(size_t)id * a.list_len + r] = cand[id];
+        const bool any = s_live != 0;
+        __syncthreads();
+        if (!any) { // nothing left in this block: the remaining ranks are empty
+            for (int q = (r + 1) * kCwThreads + tid; q < a.list_len * kCwThreads; q += kCwThreads) {
+                const int rr = q / kCwThreads;
+                for (int id = q % kCwThreads; id < C; id += kCwThreads) out[(size_t)id * a.list_len + rr] = 0ull;
+            }
+            break;
+        }
+    }
+    for (int id = tid; id < C; id += kCwThreads) {
+        CwClass &k = a.w.cls[a.w.slot_of_id[id]];
+        if (l_ht[id]) atomicAdd(&k.ht, l_ht[id]);
+        if (l_ha[id]) atomicAdd(&k.ha, l_ha[id]);
+    }
+}
+
+// k_cw_merge: block id = class id.  The blocks' lists are sorted, so the class's L best are found by L rounds over the
+// blocks' current heads (staged in LDS).
+__global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a) {
+    if (a.st->done || a.st->cw_fallback) return;
+    if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const int C = (int)a.w.ctl[kCwCtlClasses], id = blockIdx.x, L = a.list_len, nb = a.w.n_blocks;
+    if (id >= C) return;
+    __shared__ unsigned long long s_k[kCwMaxKeys];
+    __shared__ uint8_t s_head[kCwMaxKeys];
+    __shared__ unsigned long long s_w[kCwThreads / 64];
+    const int tid = threadIdx.x;
+    for (int q = tid; q < nb * L; q += kCwThreads) {
+        const int b = q / L, r = q % L;
+        s_k[q] = a.w.top[((size_t)b * kCwMaxClasses + id) * L + r];
+    }
+    for (int b = tid; b < nb; b += kCwThreads) s_head[b] = 0;
+    __syncthreads();
+    for (int r = 0; r < L; r++) {
+        unsigned long long best = 0;
+        for (int b = tid; b < nb; b += kCwThreads) {
+            const int hd = s_head[b];
+            const unsigned long long k = hd < L ? s_k[b * L + hd] : 0ull;
+            best = k > best ? k : best;
+        }
+        best = wave_max_u64(best);
+        if ((tid & 63) == 0) s_w[tid >> 6] = best;
+        __syncthreads();
+        unsigned long long K = 0;
+#pragma unroll
+        for (int w = 0; w < kCwThreads / 64; w++) K = s_w[w] > K ? s_w[w] : K;
+        if (K)
+            for (int b = tid; b < nb; b += kCwThreads) {
+                const int hd = s_head[b];
+                if (hd < L && s_k[b * L + hd] == K) s_head[b] = (uint8_t)(hd + 1);
+            }
+        if (tid == 0) a.w.lists[(size_t)id * L + r] = K;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_cw_decide: the window's cycles.
+// ------------------------------------------------------------------------------------------------------------------------
+struct CwDecideArgs {
+    DevCols c;
+    DevPod p;
+    DevState *st;
+    DevPts pts;
+    DevSoft soft;
+    DevIpa ipa;
+    CwPlan plan;
+    CwWork w;
+    int32_t *log;
+};
+
+constexpr int kCwCand = kCwMaxClasses + kCwMaxWindow;
+
+struct CwLds {
+    int32_t i32[kCwLdsI32];
+    long long i64[kCwLdsI64];
+    int32_t c_tuple[kCwMaxClasses][kCwTuple];
+    uint32_t c_nf[kCwMaxClasses], c_mt[kCwMaxClasses], c_ma[kCwMaxClasses], c_ht[kCwMaxClasses], c_ha[kCwMaxClasses];
+    int32_t c_head[kCwMaxClasses], c_len[kCwMaxClasses];
+    unsigned long long c_key[kCwMaxClasses]; // the head's (A, index) key, 0 = list exhausted
+    int32_t t_tuple[kCwMaxWindow][kCwTuple];
+    long long t_gidx[kCwMaxWindow];
+    int32_t t_A[kCwMaxWindow];
+    uint32_t t_feas[kCwMaxWindow], t_cnt[kCwMaxWindow], t_aff[kCwMaxWindow], t_took[kCwMaxWindow], t_elig[kCwMaxWindow];
+    long long e_rp[kCwCand], e_ri[kCwCand]; // per candidate: raw PodTopologySpread / InterPodAffinity score
+    uint32_t e_fl[kCwCand];                 // bit0 feasible, bit1 has all soft keys
+    // per-constraint scalars of the cycle loop (runtime-indexed: registers would become a scratch frame)
+    int32_t mn[kMaxTsc], u_min[kMaxTsc];
+    uint32_t u_cnt[kMaxTsc];
+    double soft_w[kMaxTsc];
+    long long soft_size[kMaxTsc];
+};
+
+// one candidate's coupled verdict against the tables (minima of the hard constraints in L.mn)
+__device__ __forceinline__ bool cw_coupled_ok(const CwDecideArgs &a, const CwLds &L, const int32_t *t, int64_t aff_total, int64_t exist_total) {
+    for (int c = 0; c < a.pts.n; c++) { // PodTopologySpread.Filter (filtering.go:311-356)
+        const int32_t tv = t[a.plan.h_comp[c]];
+        int32_t v, m;
+        if (a.plan.h_unique[c]) v = tv & 1, m = tv >> 1;
+        else v = tv, m = v ? L.i32[a.plan.h_off[c] + v] : 0;
+        if (!v) return false;
+        const int64_t minm = a.pts.n_present[c] < a.pts.min_domains[c] ? 0 : (int64_t)L.mn[c];
+        if ((int64_t)m + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) return false;
+    }
+    if (a.ipa.on && a.ipa.filter_on && !(exist_total == 0 && a.ipa.n_aff == 0 && a.ipa.n_anti == 0)) { // filtering.go:410-432
+        bool pods_exist = true;
+        for (int q = 0; q < a.ipa.n_aff; q++) {
+            const int k = a.ipa.aff_key[q];
+            const int c0 = a.plan.k_comp[k];
+            const int32_t v = a.plan.k_unique[k] ? t[c0] : t[c0];
+            if (!v) return false;
+            const int64_t cntv = a.plan.k_unique[k] ? (int64_t)t[c0 + 1] : L.i64[a.plan.k_off[k] + v];
+            if (cntv <= 0) pods_exist = false;
+        }
+        if (!pods_exist && !(aff_total == 0 && a.ipa.self_aff)) return false;
+        for (int q = 0; q < a.ipa.n_anti; q++) {
+            const int k = a.ipa.anti_key[q];
+            const int c0 = a.plan.k_comp[k];
+            const int32_t v = t[c0];
+            const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 2] : L.i64[a.plan.k_off[k] + a.plan.k_len[k] + v]);
+            if (cntv > 0) return false;
+        }
+        if (exist_total > 0)
+            for (int k = 0; k < a.ipa.n_keys; k++) {
+                const int c0 = a.plan.k_comp[k];
+                const int32_t v = t[c0];
+                const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 3] : L.i64[a.plan.k_off[k] + 2 * a.plan.k_len[k] + v]);
+                if (cntv > 0) return false;
+            }
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool cw_soft_keys(const CwDecideArgs &a, const int32_t *t) {
+    bool all = true;
+    for (int c = 0; c < a.soft.n; c++) {
+        const int32_t tv = t[a.plan.s_comp[c]];
+        all = all && (a.soft.is_hostname[c] ? (tv & 1) : tv) != 0;
+    }
+    return all;
+}
+
+// (the argument block is read through a pointer: its arrays are indexed with runtime constraint numbers, which on a by-value
+// kernel argument means a 2.5 KB scratch copy per lane; from memory they are scalar loads)
+__global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__restrict__ ap) {
+    const CwDecideArgs &a = *ap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
+    CwLds &L = *reinterpret_cast<CwLds *>(cw_lds_raw);
+    DevState &S = *a.st;
+    if (S.done || S.cw_fallback) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int LL = a.plan.list_len, W = a.plan.window;
+    const bool giveup = __hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const int C = giveup ? 0 : (int)a.w.ctl[kCwCtlClasses];
+
+    // ---- prologue (all threads): class records, list heads, shared-key tables -> LDS
+    if (!giveup) {
+        for (int q = tid; q < C * kCwTuple; q += kCwThreads) {
+            const int id = q / kCwTuple;
+            L.c_tuple[id][q % kCwTuple] = a.w.cls[a.w.slot_of_id[id]].tuple[q % kCwTuple];
+        }
+        for (int id = tid; id < C; id += kCwThreads) {
+            const CwClass &k = a.w.cls[a.w.slot_of_id[id]];
+            L.c_nf[id] = k.nf, L.c_mt[id] = k.mt, L.c_ma[id] = k.ma, L.c_ht[id] = k.ht, L.c_ha[id] = k.ha;
+            L.c_head[id] = 0;
+            int len = 0;
+            for (int r = 0; r < LL; r++) len += a.w.lists[(size_t)id * LL + r] != 0ull;
+            L.c_len[id] = len;
+            L.c_key[id] = a.w.lists[(size_t)id * LL];
+        }
+        for (int c = 0; c < a.pts.n; c++)
+            if (!a.plan.h_unique[c])
+                for (int v = tid; v < a.plan.h_len[c]; v += kCwThreads) {
+                    L.i32[a.plan.h_off[c] + v] = a.pts.tbl[c][v];
+                    L.i32[a.plan.h_pres[c] + v] = v ? a.plan.h_present[c][v] : 0;
+                }
+        for (int c = 0; c < a.soft.n; c++)
+            if (!a.soft.is_hostname[c])
+                for (int v = tid; v < a.plan.s_len[c]; v += kCwThreads) L.i32[a.plan.s_off[c] + v] = a.soft.tbl[c][v];
+        if (a.ipa.on)
+            for (int k = 0; k < a.ipa.n_keys; k++)
+                if (!a.plan.k_unique[k]) {
+                    const int len = a.plan.k_len[k];
+                    for (int v = tid; v < len; v += kCwThreads) {
+                        L.i64[a.plan.k_off[k] + v] = a.ipa.aff[k][v];
+                        L.i64[a.plan.k_off[k] + len + v] = a.ipa.anti[k][v];
+                        L.i64[a.plan.k_off[k] + 2 * len + v] = a.ipa.exist[k][v];
+                        L.i64[a.plan.k_off[k] + 3 * len + v] = a.ipa.score[k][v];
+                    }
+                }
+    }
+    __syncthreads();
+
+    int nt = 0; // touched nodes of this window (wave 0's copy is the one that counts)
+    if (tid < 64) {
+        // ================= the cycle loop: wave 0 only, no block barriers =================
+        int64_t placed = S.placed, rounds = S.rounds;
+        const int64_t limit = S.limit, log_cap = S.log_cap;
+        int64_t aff_total = S.ipa_aff_total, exist_total = S.ipa_exist_total, entries = S.ipa_entries;
+        const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
+        int done = 0, last_feasible = S.last_feasible;
+        bool stale_maxima = false;
+        uint32_t new_mt = mt_a, new_ma = ma_a;
+        // unique-key hard constraints: (minimum, counted nodes at it) from the pass
+        if (lane < kMaxTsc) L.u_min[lane] = 0x7fffffff, L.u_cnt[lane] = 0, L.mn[lane] = 0x7fffffff, L.soft_w[lane] = 0, L.soft_size[lane] = -1;
+        for (int c = 0; c < a.pts.n; c++)
+            if (a.plan.h_unique[c]) {
+                uint32_t m = 0x7fffffffu;
+                for (int b = lane; b < a.w.n_blocks; b += 64) {
+                    const uint32_t q = (uint32_t)(a.w.umin[(int64_t)b * kMaxTsc + c] >> 32);
+                    m = q < m ? q : m;
+                }
+                m = 0x7fffffffu - wave_max_u32(0x7fffffffu - m);
+                uint32_t n_at = 0;
+                for (int b = lane; b < a.w.n_blocks; b += 64) {
+                    const unsigned long long q = a.w.umin[(int64_t)b * kMaxTsc + c];
+                    if ((uint32_t)(q >> 32) == m) n_at += (uint32_t)q;
+                }
+                n_at = wave_sum_u32_dpp(n_at);
+                if (lane == 0) L.u_min[c] = (int32_t)m, L.u_cnt[c] = n_at;
+            }
+        bool end_window = giveup;
+        int cycles = 0;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+
+#pragma unroll 1
+        while (!end_window && !done && cycles < W) {
+            // ---- minima of the hard constraints (filtering.go:298-305)
+            for (int c = 0; c < a.pts.n; c++) {
+                int32_t mc;
+                if (a.plan.h_unique[c]) mc = L.u_min[c];
+                else {
+                    uint32_t m = 0x7fffffffu;
+                    for (int v = 1 + lane; v < a.plan.h_len[c]; v += 64)
+                        if (L.i32[a.plan.h_pres[c] + v]) {
+                            const uint32_t q = (uint32_t)L.i32[a.plan.h_off[c] + v];
+                            m = q < m ? q : m;
+                        }
+                    mc = (int32_t)(0x7fffffffu - wave_max_u32(0x7fffffffu - m));
+                }
+                if (lane == 0) L.mn[c] = mc;
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            const int ncand = C + nt;
+            // ---- stage 1: every candidate's verdict; feasible count, ignored count, maxima, candidate domains
+            for (int c = 0; c < a.soft.n; c++)
+                if (!a.soft.is_hostname[c])
+                    for (int q = lane; q < (a.plan.s_len[c] + 31) / 32; q += 64) L.i32[a.plan.s_bm[c] + q] = 0;
+            uint32_t nf = 0, nign = 0, mt_now = 0, ma_now = 0;
+            bool unknown = false, need_head = false;
+            for (int base = 0; base < ncand; base += 64) {
+                const int q = base + lane;
+                uint32_t fl = 0;
+                if (q < ncand) {
+                    const bool is_cls = q < C;
+                    const int32_t *t = is_cls ? L.c_tuple[q] : L.t_tuple[q - C];
+                    const bool node_ok = is_cls ? L.c_nf[q] > 0 : L.t_feas[q - C] != 0;
+                    if (node_ok && cw_coupled_ok(a, L, t, aff_total, exist_total)) {
+                        const bool sk = cw_soft_keys(a, t);
+                        fl = 1u | (sk ? 2u : 0u);
+                        const uint32_t members = is_cls ? L.c_nf[q] : 1u;
+                        nf += members;
+                        if (!sk) nign += members;
+                        const uint32_t cm = is_cls ? L.c_mt[q] : L.t_cnt[q - C], ca = is_cls ? L.c_ma[q] : L.t_aff[q - C];
+                        mt_now = cm > mt_now ? cm : mt_now, ma_now = ca > ma_now ? ca : ma_now;
+                        if (is_cls && (L.c_ht[q] == 0 || L.c_ha[q] == 0)) unknown = true; // the class's own maximum lost its last holder
+                        if (is_cls && L.c_key[q] == 0ull) need_head = true;                 // its next head is not among the members kept
+                        if (sk)
+                            for (int c = 0; c < a.soft.n; c++)
+                                if (!a.soft.is_hostname[c]) {
+                                    const int32_t v = t[a.plan.s_comp[c]];
+                                    atomicOr((unsigned int *)&L.i32[a.plan.s_bm[c] + (v >> 5)], 1u << (v & 31));
+                                }
+                    }
+                    L.e_fl[q] = fl;
+                }
+            }
+            nf = wave_sum_u32_dpp(nf), nign = wave_sum_u32_dpp(nign);
+            mt_now = wave_max_u32(mt_now), ma_now = wave_max_u32(ma_now);
+            unknown = __ballot(unknown) != 0ull, need_head = __ballot(need_head) != 0ull;
+            if (nf == 0) {
+                if (cycles == 0) { // the pass saw every node: schedule_one.go:448-454
+                    done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0;
+                }
+                break; // else: nothing feasible among what the window knows -- the next pass decides
+            }
+            if (cycles == 0 && (mt_now != mt_a || ma_now != ma_a)) { // A was computed under other maxima: redo the pass
+                stale_maxima = true, new_mt = mt_now, new_ma = ma_now;
+                break;
+            }
+            if (cycles > 0 && (unknown || need_head || mt_now != mt_a || ma_now != ma_a)) break;
+            // ---- stage 2: PodTopologySpread weights (scoring.go:96-113,294-296), raw scores, their min / max
+            const bool soft_on = a.soft.n > 0 && a.soft.w;
+            const bool ipa_on = a.ipa.on && a.ipa.w && entries > 0; // else PreScore Skip (scoring.go:199-201)
+            if (soft_on)
+                for (int c = 0; c < a.soft.n; c++) {
+                    int64_t sz;
+                    if (a.soft.is_hostname[c]) sz = (int64_t)nf - (int64_t)nign;
+                    else {
+                        uint32_t bits = 0;
+                        for (int q = lane; q < (a.plan.s_len[c] + 31) / 32; q += 64) bits += (uint32_t)__popc((unsigned)L.i32[a.plan.s_bm[c] + q]);
+                        sz = wave_sum_u32_dpp(bits);
+                    }
+                    if (sz != L.soft_size[c] && lane == 0) L.soft_size[c] = sz, L.soft_w[c] = go_log((double)(sz + 2));
+                }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            int64_t p_mn = INT64_MAX, p_mx = 0, i_mn = INT64_MAX, i_mx = INT64_MIN;
+            if (soft_on || ipa_on)
+                for (int base = 0; base < ncand; base += 64) {
+                    const int q = base + lane;
+                    if (q < ncand && (L.e_fl[q] & 1u)) {
+                        const int32_t *t = q < C ? L.c_tuple[q] : L.t_tuple[q - C];
+                        if (soft_on && (L.e_fl[q] & 2u)) { // scoring.go:196-223
+                            double sc = 0;
+                            for (int c = 0; c < a.soft.n; c++) {
+                                const int32_t tv = t[a.plan.s_comp[c]];
+                                const int64_t ct = a.soft.is_hostname[c] ? (int64_t)(tv >> 1) : (int64_t)L.i32[a.plan.s_off[c] + tv];
+                                sc += (double)ct * L.soft_w[c] + (double)(a.soft.max_skew[c] - 1);
+                            }
+                            const int64_t raw = (int64_t)round(sc);
+                            L.e_rp[q] = raw;
+                            p_mn = raw < p_mn ? raw : p_mn, p_mx = raw > p_mx ? raw : p_mx;
+                        }
+                        if (ipa_on) { // scoring.go:226-247
+                            int64_t raw = 0;
+                            for (int k = 0; k < a.ipa.n_keys; k++) {
+                                const int c0 = a.plan.k_comp[k];
+                                const int32_t v = t[c0];
+                                if (v) raw += a.plan.k_unique[k] ? (int64_t)t[c0 + 4] : L.i64[a.plan.k_off[k] + 3 * a.plan.k_len[k] + v];
+                            }
+                            L.e_ri[q] = raw;
+                            i_mn = raw < i_mn ? raw : i_mn, i_mx = raw > i_mx ? raw : i_mx;
+                        }
+                    }
+                }
+            if (soft_on) {
+                p_mn = INT64_MAX - (int64_t)wave_max_u64((uint64_t)(INT64_MAX - p_mn)); // (values >= 0)
+                p_mx = (int64_t)wave_max_u64((uint64_t)p_mx);
+            }
+            if (ipa_on) { // signed: bias to unsigned order
+                i_mn = (int64_t)(~wave_max_u64(~((uint64_t)i_mn ^ 0x8000000000000000ull)) ^ 0x8000000000000000ull);
+                i_mx = (int64_t)(wave_max_u64((uint64_t)i_mx ^ 0x8000000000000000ull) ^ 0x8000000000000000ull);
+            }
+            // ---- stage 3: totals, argmax (selectHost, schedule_one.go:894-941: lowest index among the maxima)
+            uint64_t best = 0;
+            int best_q = -1;
+            for (int base = 0; base < ncand; base += 64) {
+                const int q = base + lane;
+                if (q < ncand && (L.e_fl[q] & 1u)) {
+                    const uint64_t hk = q < C ? L.c_key[q] : 0ull;
+                    int64_t total = q < C ? key_score(hk) : (int64_t)L.t_A[q - C];
+                    const int64_t gi = q < C ? key_index(hk) : (int64_t)L.t_gidx[q - C];
+                    if (soft_on && (L.e_fl[q] & 2u)) total += soft_normalize(L.e_rp[q], p_mn, p_mx) * a.soft.w; // ignored nodes score 0
+                    if (ipa_on) total += ipa_normalize(L.e_ri[q], i_mn, i_mx) * a.ipa.w;
+                    const uint64_t key = make_key(total, gi);
+                    if (key > best) best = key, best_q = q;
+                }
+            }
+            const uint64_t wbest = wave_max_u64(best);
+            const uint64_t owner = __ballot(best == wbest && best_q >= 0);
+            const int wl = __ffsll((unsigned long long)owner) - 1;
+            const int wq = __builtin_amdgcn_readlane(best_q, wl);
+            const int64_t g = key_index(wbest);
+            // ---- commit (every lane holds the same wq / g; lane 0 writes)
+            int ti; // the winner's touched record
+            if (wq < C) {
+                ti = nt;
+                const int64_t i = g - a.c.global_offset;
+                if (lane < kCwTuple) L.t_tuple[ti][lane] = L.c_tuple[wq][lane];
+                if (lane == 0) {
+                    const uint32_t w = a.c.stat[i];
+                    L.t_gidx[ti] = g;
+                    L.t_cnt[ti] = (w >> kStatCntShift) & kStatCntMask, L.t_aff[ti] = w & kStatAffMask;
+                    L.t_took[ti] = 0;
+                    L.t_elig[ti] = (a.pts.n ? (uint32_t)a.pts.elig[i] : 0u) | ((a.soft.n ? (uint32_t)a.soft.elig[i] : 0u) << 16);
+                    L.c_nf[wq] -= 1;
+                    L.c_ht[wq] -= L.t_cnt[ti] == L.c_mt[wq] ? 1u : 0u;
+                    L.c_ha[wq] -= L.t_aff[ti] == L.c_ma[wq] ? 1u : 0u;
+                    const int hd = L.c_head[wq] + 1;
+                    L.c_head[wq] = hd;
+                    L.c_key[wq] = hd < LL ? a.w.lists[(size_t)wq * LL + hd] : 0ull;
+                }
+                nt += 1;
+            } else
+                ti = wq - C;
+            __builtin_amdgcn_s_waitcnt(0); // (LDS writes of lane 0 above are read by every lane below)
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t el = L.t_elig[ti];
+            // the clone is an existing pod of the next cycle: tables, the node's own entries, totals
+            for (int c = 0; c < a.pts.n; c++) { // filtering.go:255-296
+                const int q = a.plan.h_comp[c];
+                const int32_t tv = L.t_tuple[ti][q];
+                const bool counted = (el & 1u) && ((el >> (1 + c)) & 1u) && a.pts.self_match[c];
+                if (a.plan.h_unique[c]) {
+                    if (counted && (tv & 1)) {
+                        if ((tv >> 1) == L.u_min[c]) { // the winner leaves the minimum
+                            const uint32_t left = L.u_cnt[c] - 1;
+                            if (lane == 0) L.u_cnt[c] = left;
+                            if (left == 0) end_window = true; // the new minimum takes a pass over the nodes
+                        }
+                        if (lane == 0) L.t_tuple[ti][q] = tv + 2;
+                    }
+                } else if (counted && tv && lane == 0)
+                    L.i32[a.plan.h_off[c] + tv] += 1;
+            }
+            for (int c = 0; c < a.soft.n; c++) { // scoring.go:147-178
+                const int q = a.plan.s_comp[c];
+                const int32_t tv = L.t_tuple[ti][q];
+                const uint32_t se = el >> 16;
+                if (a.soft.is_hostname[c]) {
+                    if (a.soft.self_match[c] && lane == 0) L.t_tuple[ti][q] = tv + 2;
+                } else if (tv && (se & 1u) && ((se >> (1 + c)) & 1u) && a.soft.self_match[c] && lane == 0)
+                    L.i32[a.plan.s_off[c] + tv] += 1;
+            }
+            if (a.ipa.on)
+                for (int k = 0; k < a.ipa.n_keys; k++) { // filtering.go:204-272, scoring.go:81-125
+                    const int q = a.plan.k_comp[k];
+                    const int32_t v = L.t_tuple[ti][q];
+                    if (!v) continue;
+                    const int64_t d_aff = a.ipa.self_aff && a.ipa.aff_terms_on_key[k] ? a.ipa.aff_terms_on_key[k] : 0;
+                    const int64_t d_anti = a.ipa.anti_self_on_key[k];
+                    aff_total += d_aff, exist_total += d_anti, entries += a.ipa.self_entries[k];
+                    if (lane == 0) {
+                        if (a.plan.k_unique[k]) {
+                            L.t_tuple[ti][q + 1] += (int32_t)d_aff, L.t_tuple[ti][q + 2] += (int32_t)d_anti, L.t_tuple[ti][q + 3] += (int32_t)d_anti;
+                            L.t_tuple[ti][q + 4] += (int32_t)a.ipa.score_self[k];
+                        } else {
+                            const int len = a.plan.k_len[k], o = a.plan.k_off[k];
+                            L.i64[o + v] += d_aff, L.i64[o + len + v] += d_anti, L.i64[o + 2 * len + v] += d_anti, L.i64[o + 3 * len + v] += a.ipa.score_self[k];
+                        }
+                    }
+                }
+            // NodeInfo.update (types.go:409-428) on the columns + the node's new local verdict and score
+            if (lane == 0) {
+                const int64_t i = g - a.c.global_offset;
+                const int64_t a_cpu = a.c.alloc[0][i], a_mem = a.c.alloc[1][i];
+                const int64_t r0 = a.c.req[0][i] + a.p.req[0], r1 = a.c.req[1][i] + a.p.req[1];
+                const int64_t z0 = a.c.nz_mcpu[i] + a.p.nz_mcpu, z1 = a.c.nz_mem[i] + a.p.nz_mem;
+                const int32_t pc = a.c.pod_count[i] + 1, pl = a.c.placed_cnt[i] + 1, a_pods = a.c.alloc_pods[i];
+                const uint32_t w = a.c.stat[i];
+                int64_t xa[kMaxExtra], xr[kMaxExtra];
+                bool ok = fits_core(a.p, a_cpu, a_mem, r0, r1, a_pods, pc);
+#pragma unroll
+                for (int x = 0; x < kMaxExtra; x++) {
+                    xa[x] = xr[x] = 0;
+                    if (x < a.p.nx) {
+                        const int col = a.p.xcol[x];
+                        xa[x] = a.c.alloc[col][i], xr[x] = a.c.req[col][i] + a.p.req[col];
+                        const int64_t rq = a.p.req[col];
+                        if (a.p.fit_enabled && !a.p.all_zero_req && rq > 0 && rq > xa[x] - xr[x]) ok = false;
+                    }
+                }
+                a.c.req[0][i] = r0, a.c.req[1][i] = r1, a.c.nz_mcpu[i] = z0, a.c.nz_mem[i] = z1;
+                a.c.pod_count[i] = pc, a.c.placed_cnt[i] = pl;
+                store_mirror(a.c, i, r0, r1, z0, z1);
+#pragma unroll 1
+                for (int col = 2; col < a.p.ncol; col++)
+                    if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                L.t_feas[ti] = ok ? 1u : 0u;
+                L.t_A[ti] = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) +
+                                      (a.p.gen_score ? dynamic_score_gen<kMaxExtra>(a.p, a_cpu, a_mem, r0, r1, z0, z1, xa, xr)
+                                                     : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r0, r1, z0, z1)));
+                L.t_took[ti] += 1;
+                if (a.log && placed < log_cap) a.log[placed] = (int32_t)g;
+            }
+            placed += 1, rounds += 1, cycles += 1;
+            last_feasible = (int32_t)nf;
+            if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312: tested after the append
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- the window is over: run state back to the device struct (lane 0)
+        if (lane == 0) {
+            S.placed = placed, S.rounds = rounds, S.scans += 1;
+            S.ipa_aff_total = aff_total, S.ipa_exist_total = exist_total, S.ipa_entries = entries;
+            S.last_feasible = last_feasible;
+            S.winner = -1;
+            if (stale_maxima) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
+            if (giveup) S.cw_fallback = 1;
+            for (int c = 0; c < a.pts.n; c++) S.pts_min_a[c] = L.mn[c]; // (the terminal histogram reads it: k_hist)
+            S.cw_windows += 1;
+            S.done = done;
+        }
+    }
+    __syncthreads();
+    __shared__ int s_nt;
+    if (tid == 0) s_nt = nt;
+    __syncthreads();
+    nt = s_nt;
+    // ---- epilogue (all threads): tables back to HBM -- they are the canonical state every other path reads
+    if (!giveup) {
+        for (int c = 0; c < a.pts.n; c++)
+            if (!a.plan.h_unique[c])
+                for (int v = 1 + tid; v < a.plan.h_len[c]; v += kCwThreads) a.pts.tbl[c][v] = L.i32[a.plan.h_off[c] + v];
+        for (int c = 0; c < a.soft.n; c++)
+            if (!a.soft.is_hostname[c])
+                for (int v = 1 + tid; v < a.plan.s_len[c]; v += kCwThreads) a.soft.tbl[c][v] = L.i32[a.plan.s_off[c] + v];
+        if (a.ipa.on)
+            for (int k = 0; k < a.ipa.n_keys; k++)
+                if (!a.plan.k_unique[k]) {
+                    const int len = a.plan.k_len[k];
+                    for (int v = 1 + tid; v < len; v += kCwThreads) {
+                        a.ipa.aff[k][v] = L.i64[a.plan.k_off[k] + v];
+                        a.ipa.anti[k][v] = L.i64[a.plan.k_off[k] + len + v];
+                        a.ipa.exist[k][v] = L.i64[a.plan.k_off[k] + 2 * len + v];
+                        a.ipa.score[k][v] = L.i64[a.plan.k_off[k] + 3 * len + v];
+                    }
+                }
+        // unique keys: the touched nodes' own entries
+        for (int ti = tid; ti < nt; ti += kCwThreads) {
+            const int64_t i = L.t_gidx[ti] - a.c.global_offset;
+            for (int c = 0; c < a.pts.n; c++)
+                if (a.plan.h_unique[c]) {
+                    const int32_t v = a.pts.label[c][i], tv = L.t_tuple[ti][a.plan.h_comp[c]];
+                    if (v) a.pts.tbl[c][v] = tv >> 1;
+                }
+            if (a.ipa.on)
+                for (int k = 0; k < a.ipa.n_keys; k++)
+                    if (a.plan.k_unique[k]) {
+                        const int32_t v = a.ipa.label[k][i];
+                        const int q = a.plan.k_comp[k];
+                        if (v) {
+                            a.ipa.aff[k][v] = L.t_tuple[ti][q + 1], a.ipa.anti[k][v] = L.t_tuple[ti][q + 2];
+                            a.ipa.exist[k][v] = L.t_tuple[ti][q + 3], a.ipa.score[k][v] = L.t_tuple[ti][q + 4];
+                        }
+                    }
+        }
+    }
+    // ---- leave the class table empty for the next pass
+    const int Cused = (int)a.w.ctl[kCwCtlClasses] < kCwMaxClasses ? (int)a.w.ctl[kCwCtlClasses] : kCwMaxClasses;
+    __syncthreads();
+    if (!giveup)
+        for (int id = tid; id < Cused; id += kCwThreads) {
+            const int g = a.w.slot_of_id[id];
+            a.w.keys[g] = 0ull, a.w.ready[g] = 0u;
+            CwClass &k = a.w.cls[g];
+            k.nf = k.mt = k.ma = k.ht = k.ha = 0u;
+        }
+    __syncthreads();
+    if (tid == 0 && !giveup) a.w.ctl[kCwCtlClasses] = 0u;
+}
+
+} // namespace ccsim

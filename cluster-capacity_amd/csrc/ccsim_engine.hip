@@ -10,6 +10,7 @@
 #include "ccsim_level.h"
 #include "ccsim_persist.h"
 #include "ccsim_multi.h"
+#include "ccsim_coupled.h"
 
 #include <dlfcn.h>
 #include <errno.h>
@@ -137,6 +138,18 @@ struct ccsim_engine {
     const int32_t *tsc_label[kMTsc] = {nullptr, nullptr};
     DevPod multi_prof{};
     int32_t multi_next = 0; // spec of the next cycle (continues across runs; ccsim_reset_state rewinds it)
+    // windowed mode for one template with topology-coupled plugins (ccsim_coupled.h)
+    std::vector<int> pts_col, soft_col, ipa_col; // label column of every hard / soft constraint / inter-pod affinity key
+    std::vector<int32_t *> soft_present;         // (unused by the kernels; keeps the soft pass symmetrical with the hard one)
+    bool cw_ok = false;                          // the current pod spec has a windowed plan
+    std::string cw_why;                          // ... or why not
+    CwPlan cw_plan{};
+    CwWork cw_work{};
+    void *d_cw_args = nullptr;                   // CwDecideArgs of the current run, in device memory
+    void *cw_zero_base = nullptr;                // class table + control words: one allocation, zeroed when a run starts
+    size_t cw_zero_bytes = 0;
+    int cw_allowed = 1;
+    bool cw_run = false;                         // the current run takes the windowed path
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
     int dist_pass_in_window = 0;      // passes since the last ccsim_dist_begin / ccsim_dist_poll
@@ -190,6 +203,7 @@ static int dev_alloc(ccsim_engine *e, T **out, size_t count, std::vector<void *>
 
 struct ccsim_engine;
 static int build_narrow(ccsim_engine *e);
+static int cw_make_plan(ccsim_engine *e);
 static int persist_k(const ccsim_engine *e);
 
 template <typename T>
@@ -232,6 +246,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     e->time_passes = cfg->time_passes;
     if (const char *f = getenv("CCSIM_NARROW")) e->narrow_allowed = atoi(f); // A/B knob
     if (const char *f = getenv("CCSIM_PERSIST")) e->persist_allowed = atoi(f); // A/B knob: 0 = multi-kernel batched mode
+    if (const char *f = getenv("CCSIM_CW")) e->cw_allowed = atoi(f);           // A/B knob: 0 = coupled plugins one pass per placement
     if (hipSetDevice(e->device) != hipSuccess) {
         delete e;
         return -EIO;
@@ -632,6 +647,8 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     e->soft_flags.clear();
     e->dist_tables.clear();
     e->pts_present.clear();
+    e->pts_col.clear(), e->soft_col.clear(), e->ipa_col.clear();
+    e->cw_ok = false, e->cw_why = "no topology-coupled plugin";
     e->d_ipa_totals = nullptr;
     if (pod->n_spread < 0 || pod->n_spread > CCSIM_MAX_TSC) return fail(e, -EINVAL, "n_spread out of range");
     for (int pass = 0; pass < 2 && pod->n_spread > 0; pass++) { // pass 0: hard constraints, pass 1: soft constraints
@@ -655,6 +672,7 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             if (k.max_skew < 1 || k.min_domains < 1 || k.n_domains < 0) return fail(e, -EINVAL, "bad spread constraint");
             pt.max_skew[j] = k.max_skew, pt.min_domains[j] = k.min_domains, pt.self_match[j] = k.self_match ? 1 : 0;
             pt.label[j] = lc[k.col];
+            (hard ? e->pts_col : e->soft_col).push_back(k.col);
             const size_t len = (size_t)k.n_domains + 1;
             int32_t *tbl = nullptr, *tbl0 = nullptr, *ex = nullptr;
             uint8_t *inc = nullptr;
@@ -749,6 +767,7 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         for (int k = 0; k < ip.n_keys; k++) {
             if (ip.key_col[k] < 0 || ip.key_col[k] >= e->n_label_cols || ip.key_ndom[k] < 0) return fail(e, -EINVAL, "bad inter-pod affinity key");
             d.label[k] = lc[ip.key_col[k]];
+            e->ipa_col.push_back(ip.key_col[k]);
             d.score_self[k] = ip.score_self[k];
             d.self_entries[k] = ip.self_entries[k];
             const size_t len = (size_t)ip.key_ndom[k] + 1;
@@ -805,7 +824,87 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             if ((rc = build_narrow(e))) return rc;
         }
     }
+    if ((rc = cw_make_plan(e))) return rc;
     e->have_pod = true;
+    return 0;
+}
+
+// ---- windowed mode for topology-coupled plugins: the plan of the current pod spec (ccsim_coupled.h) -----------------
+// Which keys are unique per node (their "domain" is the node: table entries become class-tuple components), where every
+// component sits, which shared-key tables the decide kernel keeps in LDS; the work buffers.  Anything that does not fit
+// leaves cw_ok false with the reason: the one-pass-per-placement loop then runs, as before.
+static int cw_make_plan(ccsim_engine *e) {
+    e->cw_ok = false;
+    const bool coupled = e->pts.n > 0 || e->soft.n > 0 || e->ipa.on;
+    if (!coupled) return 0;
+    auto no = [&](const char *why) { e->cw_why = why; return 0; };
+    if (!e->cw_allowed) return no("disabled (CCSIM_CW=0)");
+    if (e->n <= 0) return no("empty snapshot");
+    auto unique = [&](int col) {
+        const std::vector<int32_t> &v = e->h_label_cols[(size_t)col];
+        std::vector<uint8_t> seen((size_t)e->label_col_max[(size_t)col] + 1, 0);
+        for (int32_t x : v)
+            if (x) {
+                if (seen[(size_t)x]) return false;
+                seen[(size_t)x] = 1;
+            }
+        return true;
+    };
+    CwPlan pl{};
+    int comp = 0, i32 = 0, i64 = 0;
+    for (int c = 0; c < e->pts.n; c++) {
+        const int len = (int)e->pts_table_len[(size_t)c];
+        pl.h_comp[c] = comp++, pl.h_unique[c] = unique(e->pts_col[(size_t)c]) ? 1 : 0, pl.h_len[c] = len;
+        pl.h_present[c] = e->pts_present[(size_t)c];
+        if (!pl.h_unique[c]) pl.h_off[c] = i32, pl.h_pres[c] = i32 + len, i32 += 2 * len;
+    }
+    const size_t soft_first = e->pts_tables.size() - (size_t)e->soft.n; // (soft tables follow the hard ones)
+    for (int c = 0; c < e->soft.n; c++) {
+        const int len = (int)e->pts_table_len[soft_first + (size_t)c];
+        pl.s_comp[c] = comp++, pl.s_len[c] = len;
+        if (!e->soft.is_hostname[c]) pl.s_off[c] = i32, pl.s_bm[c] = i32 + len, i32 += len + (len + 31) / 32;
+    }
+    if (e->ipa.on)
+        for (int k = 0; k < e->ipa.n_keys; k++) {
+            const int len = (int)e->ipa_table_len[(size_t)k * 4];
+            pl.k_unique[k] = unique(e->ipa_col[(size_t)k]) ? 1 : 0, pl.k_len[k] = len;
+            pl.k_comp[k] = comp, comp += pl.k_unique[k] ? 5 : 1;
+            if (!pl.k_unique[k]) pl.k_off[k] = i64, i64 += 4 * len;
+        }
+    if (comp > kCwTuple) return no("more plugin inputs per node than a class tuple holds");
+    if (i32 > kCwLdsI32 || i64 > kCwLdsI64) return no("shared-key tables exceed the decide kernel's LDS budget");
+    pl.n_comp = comp, pl.i32_words = i32, pl.i64_words = i64;
+    pl.window = 64, pl.list_len = 16;
+    if (const char *f = getenv("CCSIM_CW_WINDOW")) pl.window = atoi(f); // tuning / test knobs
+    if (const char *f = getenv("CCSIM_CW_LIST")) pl.list_len = atoi(f);
+    pl.window = pl.window < 1 ? 1 : (pl.window > kCwMaxWindow ? kCwMaxWindow : pl.window);
+    pl.list_len = pl.list_len < 1 ? 1 : (pl.list_len > kCwMaxList ? kCwMaxList : pl.list_len);
+    const int64_t blocks = (e->n_pad + kCwTile - 1) / kCwTile;
+    while (pl.list_len > 1 && blocks * pl.list_len > kCwMaxKeys) pl.list_len >>= 1;
+    if (blocks * pl.list_len > kCwMaxKeys) return no("snapshot too large for the class-list merge");
+    if (e->global_offset != 0 || e->n_global != e->n) return no("sharded snapshot");
+    // work buffers: [keys | ready | ctl | classes] zeroed per run, the rest written before it is read
+    CwWork w{};
+    w.n_blocks = (int)blocks;
+    const size_t zb = sizeof(unsigned long long) * kCwSlots + sizeof(uint32_t) * kCwSlots + sizeof(uint32_t) * 16 + sizeof(CwClass) * kCwSlots;
+    unsigned char *base = nullptr;
+    int rc;
+    if ((rc = dev_alloc(e, &base, zb, e->pod_allocs))) return rc;
+    w.keys = (unsigned long long *)base;
+    w.ready = (uint32_t *)(base + sizeof(unsigned long long) * kCwSlots);
+    w.ctl = w.ready + kCwSlots;
+    w.cls = (CwClass *)(w.ctl + 16);
+    e->cw_zero_base = base, e->cw_zero_bytes = zb;
+    if ((rc = dev_alloc(e, &w.slot_of_id, (size_t)kCwMaxClasses, e->pod_allocs))) return rc;
+    if ((rc = dev_alloc(e, &w.node_slot, (size_t)e->n_pad, e->pod_allocs))) return rc;
+    if ((rc = dev_alloc(e, &w.node_A, (size_t)e->n_pad, e->pod_allocs))) return rc;
+    if ((rc = dev_alloc(e, &w.top, (size_t)blocks * kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs, false))) return rc;
+    if ((rc = dev_alloc(e, &w.lists, (size_t)kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs))) return rc;
+    if ((rc = dev_alloc(e, &w.umin, (size_t)blocks * kMaxTsc, e->pod_allocs))) return rc;
+    unsigned char *argbuf = nullptr;
+    if ((rc = dev_alloc(e, &argbuf, sizeof(CwDecideArgs), e->pod_allocs))) return rc;
+    e->d_cw_args = argbuf;
+    e->cw_plan = pl, e->cw_work = w, e->cw_ok = true, e->cw_why.clear();
     return 0;
 }
 
@@ -1035,6 +1134,9 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     e->mode = mode;
     e->begun = true;
     e->persist_run = (mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes) ? persist_k(e) : 0;
+    // topology-coupled plugins of one template: windows of placements per pass when every node is scored (ccsim_coupled.h)
+    e->cw_run = mode == CCSIM_MODE_SEQUENTIAL && e->cw_ok && e->n_ranks == 0 && e->smp_K == 0 && !e->time_passes && e->n > 0;
+    if (e->cw_run) HIPCHK(e, hipMemsetAsync(e->cw_zero_base, 0, e->cw_zero_bytes, e->stream));
     const bool rows = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !e->persist_run;
     if (rows != e->rows_active) drop_graph(e);
     e->rows_active = rows;
@@ -1234,6 +1336,49 @@ static int run_persist(ccsim_engine *e, int k) {
 
 static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out);
 
+// ---- one template with topology-coupled plugins, in windows (ccsim_coupled.h): pass -> class lists -> up to W cycles ----
+static void launch_cw_window(ccsim_engine *e) {
+    const CwScanArgs sa{e->cols, e->pod, e->d_state, e->pts, e->soft, e->ipa, e->cw_plan, e->cw_work};
+    const dim3 g((unsigned)e->cw_work.n_blocks), b(kCwThreads);
+    if (e->pod.nx == 0 && e->cols.narrow) hipLaunchKernelGGL((k_cw_scan<0, true>), g, b, 0, e->stream, sa);
+    else if (e->pod.nx == 0) hipLaunchKernelGGL((k_cw_scan<0, false>), g, b, 0, e->stream, sa);
+    else hipLaunchKernelGGL((k_cw_scan<kMaxExtra, false>), g, b, 0, e->stream, sa);
+    const CwTopArgs ta{e->cols, e->d_state, e->cw_work, e->cw_plan.list_len};
+    hipLaunchKernelGGL(k_cw_top, g, b, 0, e->stream, ta);
+    hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), b, 0, e->stream, ta);
+    hipLaunchKernelGGL(k_cw_decide, dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
+}
+
+static int run_cw(ccsim_engine *e) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+        attr_set = true;
+    }
+    // the decide kernel reads its argument block from memory (pointers and constants of this run)
+    const CwDecideArgs da{e->cols, e->pod, e->d_state, e->pts, e->soft, e->ipa, e->cw_plan, e->cw_work, e->d_log};
+    HIPCHK(e, hipMemcpyAsync(e->d_cw_args, &da, sizeof da, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream)); // (`da` is a stack object)
+    int per_sync = 8; // windows enqueued per host poll (a finished run turns the rest into no-ops)
+    if (const char *f = getenv("CCSIM_CW_PER_SYNC")) per_sync = atoi(f) > 0 ? atoi(f) : per_sync;
+    int idle = 0;
+    for (;;) {
+        const int64_t placed0 = e->h_state->placed;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        for (int w = 0; w < per_sync; w++) launch_cw_window(e);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        int rc = read_state(e);
+        if (rc) return rc;
+        float ms = 0;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->kernel_ms += ms;
+        if (e->h_state->done || e->h_state->cw_fallback) return 0;
+        idle = e->h_state->placed == placed0 ? idle + 1 : 0; // (a window places >= 1 pod unless it only corrected the assumed maxima)
+        if (idle >= 4) return fail(e, -EIO, "windowed simulation made no progress in %d windows", 4 * per_sync);
+    }
+}
+
 extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
     if (!e || !out) return -EINVAL;
     out->stop_spec = -1;
@@ -1249,6 +1394,11 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
     if (e->persist_run) { // begin_run chose the persistent form of the batched mode
         if ((rc = run_persist(e, e->persist_run))) return rc;
         return fill_report(e, out);
+    }
+    if (e->cw_run) { // begin_run chose the windowed form for the coupled plugins
+        if ((rc = run_cw(e))) return rc;
+        if (e->h_state->done) return fill_report(e, out);
+        // (cw_fallback: the windowed mode cannot represent this run -- the one-pass-per-placement loop below continues it)
     }
     int rps = e->rounds_per_sync > 0 ? e->rounds_per_sync : (mode == CCSIM_MODE_BATCHED ? 64 : 256);
     for (;;) {
@@ -2045,6 +2195,15 @@ static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out) {
 }
 
 // measurement aid: why the windows of the last multi-spec run ended (k_multi_commit stop reasons 0..7)
+extern "C" int ccsim_debug_coupled(ccsim_engine *e, int64_t *out8) {
+    if (!e || !out8) return -EINVAL;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    out8[0] = e->have_pod && e->cw_ok ? 1 : 0;
+    if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback;
+    out8[3] = e->cw_ok ? e->cw_plan.window : 0, out8[4] = e->cw_ok ? e->cw_plan.list_len : 0;
+    return 0;
+}
+
 extern "C" int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out8) {
     if (!e || !out8 || !e->h_mstate) return -EINVAL;
     for (int i = 0; i < 8; i++) out8[i] = e->h_mstate->stop_count[i];

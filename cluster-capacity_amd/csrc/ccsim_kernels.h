@@ -207,6 +207,9 @@ struct DevState {
     int64_t smp_Ftotal;      // feasible nodes of the whole snapshot (this cycle)
     int64_t smp_stop;        // rotated position of the (K+1)-th feasible node = nodes visited; -1: all N were visited
     int64_t evaluated;       // sum of visited nodes over the cycles
+    // windowed mode for topology-coupled plugins (ccsim_coupled.h)
+    int32_t cw_fallback;     // 1 = the windowed mode gave up on this run: the one-pass-per-placement loop continues from the current state
+    int32_t cw_windows;      // windows resolved so far
 };
 
 // per-block result of one scan: 16 bytes

@@ -366,6 +366,12 @@ int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out8);
  * (0 complete, 1 a normalization maximum was re-derived, 2 Unschedulable, 3 too few holders of a maximum left untouched,
  * 4 the candidate bounds could not prove the choice, 5 every candidate touched and full, 6 touched-node table full, 7 limit). */
 int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out8);
+/* ... and how the last run of ONE template with topology-coupled plugins (PodTopologySpread, InterPodAffinity) was resolved
+ * (csrc/ccsim_coupled.h: windows of placements per node pass): out8[0] = 1 if the pod spec has a windowed plan, [1] = windows
+ * of the last run, [2] = 1 if that run fell back to one pass per placement (more classes / plugin inputs than the mode
+ * represents), [3] = window length W, [4] = class-list length L.  Knobs (read by ccsim_set_pod): CCSIM_CW=0 disables the
+ * mode, CCSIM_CW_WINDOW, CCSIM_CW_LIST. */
+int ccsim_debug_coupled(ccsim_engine *e, int64_t *out8);
 
 #ifdef __cplusplus
 }

@@ -281,3 +281,4 @@ int ccsim_reset_state(ccsim_engine *e) { (void)e; return -38; }
 int ccsim_time_scan(ccsim_engine *e, int32_t a, int32_t b, int64_t *c, int64_t *d) { (void)e, (void)a, (void)b, (void)c, (void)d; return -38; }
 int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
+int ccsim_debug_coupled(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }

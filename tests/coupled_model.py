@@ -52,8 +52,14 @@ def _go_round(x: float) -> int:  # C round(): half away from zero
 
 
 class CoupledWindowModel:
-    def __init__(self, prof, nodes, pod, go_log, window=64, every_node_scored=True):
+    def __init__(self, prof, nodes, pod, go_log, window=64, every_node_scored=True, device_plan=False, list_len=None):
+        """device_plan: the three simplifications the HIP port (csrc/ccsim_coupled.h) makes, so that they are checked against the
+        oracle here first -- (1) the class key carries no `counted` bit (nothing an untouched node's verdict or score reads);
+        (2) a class keeps only its `list_len` best members: a cycle that would need an unknown head ends the window; (3) the
+        minimum of a hard constraint over a unique-per-node key is not recomputed from N table entries per cycle: the scan's
+        (minimum, nodes at the minimum) pair is tracked, and the window ends when the last node at the minimum is taken."""
         self.prof, self.nd, self.pod, self.go_log, self.W = prof, nodes, pod, go_log, window
+        self.device_plan, self.L = device_plan, (list_len if list_len else window)
         N = self.N = nodes.n
         fm = self.fm = prof.filter_mask
         self.ncol = len(nodes.alloc)
@@ -265,7 +271,10 @@ class CoupledWindowModel:
             v = self.sdom[i][n]
             if i in self.hard:
                 counted = self.hard_keys[n] and bool(self.sincl[i][n])
-                key.append(("h", v != 0, counted, T["hard"][i].get(v, 0)) if self.s_unique[i] else ("h", v, counted))
+                if self.device_plan:
+                    key.append(("h", v != 0, T["hard"][i].get(v, 0)) if self.s_unique[i] else ("h", v))
+                else:
+                    key.append(("h", v != 0, counted, T["hard"][i].get(v, 0)) if self.s_unique[i] else ("h", v, counted))
             elif i in self.soft:
                 if c.is_hostname:
                     key.append(("s", v != 0, self.sexist[i][n] + (self.clones[n] if c.self_match else 0)))
@@ -357,7 +366,7 @@ class CoupledWindowModel:
                 c["nf"] += 1
             for c in classes.values():
                 c["all"].sort()
-                c["list"] = c["all"][: self.W]
+                c["list"] = c["all"][: (self.L if self.device_plan else self.W)]
                 members = [n for _, n in c["all"]]
                 c["mt"], c["ma"] = max(self.cnt[n] for n in members), max(self.aff[n] for n in members)
                 c["ht"], c["ha"] = sum(self.cnt[n] == c["mt"] for n in members), sum(self.aff[n] == c["ma"] for n in members)
@@ -367,9 +376,22 @@ class CoupledWindowModel:
             stats["classes_max"] = max(stats["classes_max"], len(classes))
             touched = []  # nodes that received a clone in this window
             done = 0
+            umin = {}  # device plan: unique-key hard constraints -> [minimum, counted nodes at the minimum] as the scan saw them
+            if self.device_plan:
+                for i in self.hard:
+                    if self.s_unique[i]:
+                        vals = list(T["hard"][i].values())
+                        mn = min(vals) if vals else MAXINT32
+                        umin[i] = [mn, sum(v == mn for v in vals)]
+            end_window = False
             # ===== decide: up to W cycles from (class heads, class counters, touched nodes, tables) only =====
-            while done < self.W:
+            while done < self.W and not end_window:
                 minima = self.hard_minima(T)
+                for i, (mn, _) in umin.items():  # (the tracked value IS the minimum while a node at it remains)
+                    assert minima[i] == (0 if self.n_dom[i] < self.spread[i].min_domains else mn)
+                if self.device_plan and done > 0 and any(c["nf"] > 0 and c["head"] >= len(c["list"]) for c in classes.values()):
+                    stats["cut_by_list"] = stats.get("cut_by_list", 0) + 1
+                    break  # a class's next head is not among the members the scan kept
                 cand = []  # (node, class or None)
                 for c in classes.values():
                     if c["nf"] > 0:
@@ -424,6 +446,11 @@ class CoupledWindowModel:
                     if best is None or total > best[0] or (total == best[0] and n < best[1]):
                         best = (total, n, c)
                 _, w, c = best
+                for i in umin:  # the winner leaves the minimum of a unique-key hard constraint
+                    if self.hard_keys[w] and self.sincl[i][w] and self.spread[i].self_match and T["hard"][i].get(self.sdom[i][w], 0) == umin[i][0]:
+                        umin[i][1] -= 1
+                        if umin[i][1] == 0:
+                            end_window = True  # the new minimum is not known without a pass over the nodes
                 log.append(w)
                 if c is not None:  # the head of a class leaves it
                     c["head"] += 1

@@ -1,0 +1,161 @@
+"""The windowed mode for ONE template with topology-coupled plugins (csrc/ccsim_coupled.h: k_cw_scan / k_cw_top / k_cw_merge /
+k_cw_decide) against the oracle's literal one-cycle-at-a-time loop, placement by placement: the generators of tests/test_spread.py,
+tests/test_ipa.py and tests/test_coupled_model.py, with windows of 1 ... 64 cycles and class lists of 1 ... 16 members; the
+fallback to one pass per placement when the mode cannot represent a run; and that the windowed path is the one that ran.
+(The argument itself is checked on the CPU: tests/coupled_model.py `device_plan=True`, tests/test_coupled_model.py.)"""
+import numpy as np
+import pytest
+
+import helpers as H
+from cluster_capacity_amd import capi, model as M, report as R, synth
+from test_coupled_model import coupled_case
+
+WINDOWS = [(1, 1), (7, 2), (64, 16)]
+
+
+def _run(ccref, nodes, pod, prof, limit, monkeypatch, window, list_len, expect_plan=True, mode="sequential"):
+    monkeypatch.setenv("CCSIM_CW_WINDOW", str(window))
+    monkeypatch.setenv("CCSIM_CW_LIST", str(list_len))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    got = e.run(max_limit=limit, mode=mode, log_cap=max(1, ref.placed))
+    info = e.coupled_info()
+    where = (window, list_len, info, got.placed, ref.placed)
+    n = min(len(got.log), len(ref.log))
+    first = next((i for i in range(n) if got.log[i] != ref.log[i]), None)
+    assert first is None, ("first differing placement", first, got.log[max(0, first - 2): first + 3].tolist(), ref.log[max(0, first - 2): first + 3].tolist(), where)
+    assert got.placed == ref.placed and got.stop == ref.stop, where
+    assert np.array_equal(got.per_node_count, ref.per_node_count), where
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist), (got.hist, ref.hist, where)
+        assert got.n_code_unschedulable == ref.n_code_unschedulable
+        assert R.stop_reason(got, nodes.n, limit) == R.stop_reason(ref, nodes.n, limit)
+    if expect_plan:
+        assert info["plan"] and info["windows"] > 0 and not info["fell_back"], where
+    e.close()
+    return got, info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,list_len", WINDOWS)
+@pytest.mark.parametrize("seed", range(10))
+def test_hard_spread_random(ccref, monkeypatch, seed, window, list_len):
+    rng = np.random.default_rng(500 + seed)  # (the cases of tests/test_spread.py::test_gpu_spread_random)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 1200)))
+    pod.spread = H.random_spread(rng, nodes, n_constraints=int(rng.integers(1, 3)))
+    _run(ccref, nodes, pod, prof, int(rng.choice([0, 0, 60])), monkeypatch, window, list_len)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,list_len", WINDOWS)
+@pytest.mark.parametrize("seed", range(12))
+def test_soft_and_hard_spread_random(ccref, monkeypatch, seed, window, list_len):
+    rng = np.random.default_rng(700 + seed)  # (tests/test_spread.py::test_gpu_soft_and_hard_spread_random)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 900)))
+    cons = H.random_spread(rng, nodes, n_constraints=2)
+    for k in cons:
+        k.hard = bool(rng.integers(0, 2))
+    if seed % 4 == 0:
+        cons[0].is_hostname, cons[0].hard = True, False
+    pod.spread = cons
+    _run(ccref, nodes, pod, prof, int(rng.choice([0, 0, 70])), monkeypatch, window, list_len)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,list_len", WINDOWS)
+@pytest.mark.parametrize("seed", range(16))
+def test_ipa_random(ccref, monkeypatch, seed, window, list_len):
+    rng = np.random.default_rng(900 + seed)  # (tests/test_ipa.py::test_gpu_ipa_random)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 1000)))
+    pod.ipa = H.random_ipa(rng, nodes)
+    if seed % 3 == 0:
+        pod.spread = H.random_spread(rng, nodes, n_constraints=1)
+    _run(ccref, nodes, pod, prof, int(rng.choice([0, 0, 80])), monkeypatch, window, list_len)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,list_len", [(1, 1), (5, 3), (64, 16), (64, 4)])
+@pytest.mark.parametrize("seed", range(30))
+def test_coupled_cases_with_unique_keys(ccref, monkeypatch, seed, window, list_len):
+    """tests/test_coupled_model.py's generator: hard / soft constraints and inter-pod terms over shared keys AND over a unique-per-node
+    key (hostname), existing pods' counts, missing labels, node inclusion, minDomains, host ports, images; every third case roomy
+    (nodes take many clones: several windows, touched nodes that win again)."""
+    rng = np.random.default_rng(7100 + seed)
+    nodes, pod, prof = coupled_case(rng, int(rng.integers(12, 700)), roomy=seed % 3 == 0)
+    limit = 1500 if seed % 3 == 0 else int(rng.choice([0, 0, 29]))
+    coupled = bool(pod.spread) or pod.ipa is not None
+    _run(ccref, nodes, pod, prof, limit, monkeypatch, window, list_len, expect_plan=coupled)
+
+
+@pytest.mark.gpu
+def test_reference_fixtures_and_hand_cases(ccref, monkeypatch):
+    from test_ipa import colocation_nodes, self_affinity_pod
+    got, _ = _run(ccref, colocation_nodes([1, 2, 3]), self_affinity_pod(3), M.Profile.default(), 100, monkeypatch, 64, 16)
+    assert got.placed == 30 and got.per_node_count.tolist() == [30, 0, 0]  # pod_colocation_test.go:18-97 (KA3)
+    got, _ = _run(ccref, colocation_nodes([1, 1, 1, 2, 2, 2, 3, 3, 3]), self_affinity_pod(3), M.Profile.default(), 100, monkeypatch, 64, 16)
+    assert got.placed == 90 and got.per_node_count.tolist() == [30, 30, 30, 0, 0, 0, 0, 0, 0]  # :99-190 (KA4)
+    from test_spread import _pod, _zone_nodes
+    for w in (1, 64):
+        _run(ccref, _zone_nodes([1, 2, 3], [5, 110, 110]), _pod(max_skew=1, n_domains=3, self_match=True), M.Profile.default(), 0, monkeypatch, w, 16)
+        _run(ccref, _zone_nodes([1, 2], [110, 110]), _pod(max_skew=2, min_domains=3, n_domains=2, self_match=True), M.Profile.default(), 0, monkeypatch, w, 16)
+        _run(ccref, _zone_nodes([1, 2, 0], [3, 4, 50]), _pod(max_skew=1, n_domains=2, self_match=False), M.Profile.default(), 0, monkeypatch, w, 16)
+
+
+def c5_single_template(n, zones=None, seed=5):
+    """BASELINE config 5's pod shape as ONE template: DoNotSchedule zone spread (maxSkew 1) + required hostname anti-affinity against
+    its own clones, on a C3-style snapshot."""
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=seed)
+    nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))  # hostname
+    pod.ipa = M.InterPodAffinity(key_cols=[len(nodes.label_cols) - 1], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    pod.spread = [synth.zone_spread(n, max_skew=1)]
+    return nodes, pod, prof
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1000, 20_000])
+def test_c5_shape_single_template_windows_do_the_work(ccref, monkeypatch, n):
+    nodes, pod, prof = c5_single_template(n)
+    got, info = _run(ccref, nodes, pod, prof, 0 if n <= 1000 else 3000, monkeypatch, 64, 16)
+    assert got.per_node_count.max() == 1
+    assert info["windows"] * 16 < got.placed, info  # far fewer node passes than placements: the windows did the work
+
+
+@pytest.mark.gpu
+def test_falls_back_exactly_when_the_classes_do_not_fit(ccref, monkeypatch):
+    """More classes than the windowed mode represents (a soft hostname constraint over nodes with many different existing counts x
+    zones): DevState::cw_fallback, the run continues one pass per placement -- same answer."""
+    rng = np.random.default_rng(11)
+    n = 3000
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=77)
+    nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))
+    pod.spread = [M.SpreadConstraint(col=len(nodes.label_cols) - 1, max_skew=1, hard=False, self_match=True, is_hostname=True, n_domains=n,
+                                     node_match_count=rng.integers(0, 400, n).astype(np.int32)),
+                  M.SpreadConstraint(col=1, max_skew=2, hard=False, self_match=True, n_domains=synth.zones_for(n))]
+    got, info = _run(ccref, nodes, pod, prof, 150, monkeypatch, 64, 16, expect_plan=False)
+    assert info["plan"] and info["fell_back"], info
+
+
+@pytest.mark.gpu
+def test_disabled_by_knob_and_unaffected_modes(ccref, monkeypatch):
+    nodes, pod, prof = c5_single_template(600)
+    monkeypatch.setenv("CCSIM_CW", "0")
+    got, info = _run(ccref, nodes, pod, prof, 200, monkeypatch, 64, 16, expect_plan=False)
+    assert not info["plan"] and got.scans >= got.placed  # one pass per placement
+    monkeypatch.delenv("CCSIM_CW")
+    # continued runs: a windowed run, then more placements on the same engine, then a reset
+    ref = ccref.run(prof, nodes, pod, max_limit=300)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    a = e.run(max_limit=100, mode="sequential", log_cap=100)
+    b = e.run(max_limit=200, mode="sequential", log_cap=200)
+    assert np.array_equal(np.concatenate([a.log, b.log]), ref.log[:300]) and e.coupled_info()["windows"] > 0
+    e.reset_state()
+    c = e.run(max_limit=300, mode="sequential", log_cap=300)
+    assert np.array_equal(c.log, ref.log)
+    # the SchedulePod seam keeps stepping one cycle at a time on the state the windows left
+    e.reset_state()
+    e.run(max_limit=50, mode="sequential")
+    for i in range(50, 60):
+        assert e.schedule_one()[0] == ref.log[i]
+    e.close()

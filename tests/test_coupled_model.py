@@ -72,6 +72,20 @@ def test_coupled_window_model_long_runs(ccref, seed, window):
     assert (stop == "Unschedulable") == (ref.stop == M.STOP_UNSCHEDULABLE)
 
 
+@pytest.mark.parametrize("window,list_len", [(1, 1), (7, 2), (64, 8), (64, 64)])
+@pytest.mark.parametrize("seed", range(40))
+def test_device_plan_vs_oracle(ccref, seed, window, list_len):
+    """The simplifications of the HIP port (no `counted` bit in the class key, truncated class lists, tracked minimum of a
+    unique-key hard constraint): same log as the oracle."""
+    rng = np.random.default_rng(7100 + seed)
+    nodes, pod, prof = coupled_case(rng, int(rng.integers(12, 160)), roomy=seed % 3 == 0)
+    limit = 1500 if seed % 3 == 0 else int(rng.choice([0, 0, 29])) or 4000
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    log, stop, scans, stats = CoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=window, device_plan=True, list_len=list_len).run(limit)
+    assert log == ref.log.tolist(), (seed, window, list_len)
+    assert (stop == "Unschedulable") == (ref.stop == M.STOP_UNSCHEDULABLE)
+
+
 def test_zone_spread_with_hostname_anti_affinity(ccref):
     """The config-5 pod shape as ONE template: DoNotSchedule zone spread (maxSkew 1) + required hostname anti-affinity against its
     own clones.  One clone per node, zones filled evenly: 16 zones x heterogeneous nodes -> the classes are the zones (times the
