@@ -468,9 +468,14 @@ class Engine:
 
     def coupled_info(self):
         """How the last run of one template with topology-coupled plugins was resolved (ccsim_debug_coupled)."""
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 16)()
         self._chk(self.lib.ccsim_debug_coupled(self.h, out), "ccsim_debug_coupled")
-        return {"plan": bool(out[0]), "windows": int(out[1]), "fell_back": bool(out[2]), "window": int(out[3]), "list_len": int(out[4])}
+        d = {"plan": bool(out[0]), "windows": int(out[1]), "fell_back": bool(out[2]), "window": int(out[3]), "list_len": int(out[4])}
+        if out[15]:  # CCSIM_CW_PROF=1: microseconds per cycle of the deciding wave, by phase
+            names = ["stage", "setup", "verdicts", "raw_scores", "argmax", "commit", "write_back"]
+            d["prof_us_per_cycle"] = {k: round(out[8 + i] / 100.0 / out[15], 3) for i, k in enumerate(names)}
+            d["cycles"] = int(out[15])
+        return d
 
     def persist_prof(self):
         """Phase breakdown of the last persistent batched launch (ccsim_debug_persist_prof), in microseconds."""

@@ -44,8 +44,8 @@ constexpr int kCwMaxList = 32;      // L
 constexpr int kCwMaxWindow = 256;   // W
 constexpr int kCwThreads = 256, kCwPerThread = 4, kCwTile = kCwThreads * kCwPerThread;
 constexpr int kCwMaxKeys = 4096;    // k_cw_merge stages blocks x L keys of one class in LDS (32 KiB)
-constexpr int kCwLdsI32 = 6144;     // k_cw_decide: int32 words of shared-key tables (hard / soft counts, presence flags, candidate bitmaps)
-constexpr int kCwLdsI64 = 3072;     // ... int64 words (four InterPodAffinity tables per shared key)
+constexpr int kCwLdsI32 = 4096;     // k_cw_decide: int32 words of shared-key tables (hard / soft counts, presence flags, candidate bitmaps)
+constexpr int kCwLdsI64 = 2048;     // ... int64 words (four InterPodAffinity tables per shared key)
 constexpr int kCwCtlClasses = 0, kCwCtlGiveUp = 1;
 
 // Where each plugin input sits in the class tuple, and where its table lives in the decide kernel's LDS (host-built per pod spec).
@@ -76,6 +76,8 @@ struct CwWork {
     int32_t *slot_of_id;      // [kCwMaxClasses]
     int32_t *node_slot;       // [n_pad] class slot of a node-feasible node, -1 otherwise
     int32_t *node_A;          // [n_pad] its node-local score
+    int32_t *node_A1;         // [n_pad] ... after ONE more clone of the template (-1: the node could not take a second one)
+    unsigned long long *prof; // [16] k_cw_decide: 10 ns ticks per phase (measurement runs)
     unsigned long long *top;  // [blocks][kCwMaxClasses][L]
     unsigned long long *lists; // [kCwMaxClasses][L]
     unsigned long long *umin; // [blocks][kMaxTsc] unique-key hard constraints: (minimum << 32) | counted nodes at the minimum
@@ -137,12 +139,12 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
     const int ncomp = a.plan.n_comp;
     uint32_t *giveup = a.w.ctl + kCwCtlGiveUp;
     int lslot[kCwPerThread];
-    int32_t lA[kCwPerThread];
+    int32_t lA[kCwPerThread], lA1[kCwPerThread];
 
 #pragma unroll 1
     for (int j = 0; j < kCwPerThread; j++) {
         const int64_t i = (int64_t)blockIdx.x * kCwTile + (int64_t)j * kCwThreads + tid;
-        lslot[j] = -1, lA[j] = 0;
+        lslot[j] = -1, lA[j] = 0, lA1[j] = -1;
         bool feas = false;
         int32_t tup[kCwTuple];
 #pragma unroll
@@ -194,6 +196,31 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
                                           : (NX > 0 && a.p.gen_score ? dynamic_score_gen<NX>(a.p, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xa, xr)
                                                                      : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem)));
                 lA[j] = (int32_t)A;
+                // the node after one more clone (NodeInfo.update, types.go:409-428): what the window needs of a node it has placed on
+                {
+                    bool f1;
+                    int64_t A1;
+                    if (NARROW) {
+                        f1 = fits_narrow(a.p, npod, na0, na1, nr0 + npod.req0, nr1 + npod.req1, a_pods, npods + 1);
+                        A1 = dynamic_score_narrow(a.p, npod, na0, na1, nr0 + npod.req0, nr1 + npod.req1, nz0 + npod.nz0, nz1 + npod.nz1);
+                    } else {
+                        const int64_t q0 = r_cpu + a.p.req[0], q1 = r_mem + a.p.req[1], y0 = z_cpu + a.p.nz_mcpu, y1 = z_mem + a.p.nz_mem;
+                        f1 = fits_core(a.p, a_cpu, a_mem, q0, q1, a_pods, npods + 1);
+                        int64_t xr1[NX > 0 ? NX : 1];
+#pragma unroll
+                        for (int x = 0; x < (NX > 0 ? NX : 1); x++) {
+                            xr1[x] = 0;
+                            if (NX > 0 && x < a.p.nx) {
+                                const int64_t rq = a.p.req[a.p.xcol[x]];
+                                xr1[x] = xr[x] + rq;
+                                if (a.p.fit_enabled && !a.p.all_zero_req && rq > 0 && rq > xa[x] - xr1[x]) f1 = false;
+                            }
+                        }
+                        A1 = NX > 0 && a.p.gen_score ? dynamic_score_gen<NX>(a.p, a_cpu, a_mem, q0, q1, y0, y1, xa, xr1)
+                                                     : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, q0, q1, y0, y1);
+                    }
+                    lA1[j] = f1 ? (int32_t)(A1 + static_score(a.p, cnt, aff, img, mt, ma)) : -1;
+                }
                 // ---- the class tuple: everything the coupled plugins read of this node
                 for (int c = 0; c < a.pts.n; c++) {
                     const int32_t v = a.pts.label[c][i];
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
         if (i < a.c.n_pad) {
             a.w.node_slot[i] = lslot[j] >= 0 ? b_gslot[lslot[j]] : -1;
             a.w.node_A[i] = lA[j];
+            a.w.node_A1[i] = lA1[j];
         }
     }
 }
@@ -472,18 +500,26 @@ struct CwDecideArgs {
 };
 
 constexpr int kCwCand = kCwMaxClasses + kCwMaxWindow;
+constexpr int kCwListLds = 2048; // class-list entries (classes x L) whose node facts the decide kernel stages in LDS
 
 struct CwLds {
     int32_t i32[kCwLdsI32];
     long long i64[kCwLdsI64];
     int32_t c_tuple[kCwMaxClasses][kCwTuple];
     uint32_t c_nf[kCwMaxClasses], c_mt[kCwMaxClasses], c_ma[kCwMaxClasses], c_ht[kCwMaxClasses], c_ha[kCwMaxClasses];
-    int32_t c_head[kCwMaxClasses], c_len[kCwMaxClasses];
+    int32_t c_head[kCwMaxClasses];
     unsigned long long c_key[kCwMaxClasses]; // the head's (A, index) key, 0 = list exhausted
+    // node facts of every list entry (staged by all threads before the cycles start: a winner costs no trip to HBM)
+    unsigned long long li_key[kCwListLds];
+    uint32_t li_stat[kCwListLds], li_elig[kCwListLds];
+    int32_t li_A1[kCwListLds];
+    // nodes that received a clone in this window.  `alive` lists the ones that may still win (a node that is full, or whose own
+    // clone blocks it through a required anti-affinity term, never comes back: the counts only grow)
     int32_t t_tuple[kCwMaxWindow][kCwTuple];
     long long t_gidx[kCwMaxWindow];
     int32_t t_A[kCwMaxWindow];
-    uint32_t t_feas[kCwMaxWindow], t_cnt[kCwMaxWindow], t_aff[kCwMaxWindow], t_took[kCwMaxWindow], t_elig[kCwMaxWindow];
+    uint32_t t_cnt[kCwMaxWindow], t_aff[kCwMaxWindow], t_took[kCwMaxWindow], t_elig[kCwMaxWindow];
+    int32_t alive[kCwMaxWindow];
     long long e_rp[kCwCand], e_ri[kCwCand]; // per candidate: raw PodTopologySpread / InterPodAffinity score
     uint32_t e_fl[kCwCand];                 // bit0 feasible, bit1 has all soft keys
     // per-constraint scalars of the cycle loop (runtime-indexed: registers would become a scratch frame)
@@ -491,46 +527,56 @@ struct CwLds {
     uint32_t u_cnt[kMaxTsc];
     double soft_w[kMaxTsc];
     long long soft_size[kMaxTsc];
+    int32_t s_nt;
 };
 
-// one candidate's coupled verdict against the tables (minima of the hard constraints in L.mn)
-__device__ __forceinline__ bool cw_coupled_ok(const CwDecideArgs &a, const CwLds &L, const int32_t *t, int64_t aff_total, int64_t exist_total) {
+// LDS traffic inside one wave needs no barrier, only the data back: wait for the LDS / scalar counters, not for HBM stores
+__device__ __forceinline__ void cw_lds_sync() {
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_wave_barrier();
+}
+
+// one candidate's coupled verdict against the tables (minima of the hard constraints in L.mn).
+// `*dead`: the failure is permanent (required anti-affinity against pods that are there to stay: the counts only grow).
+__device__ __forceinline__ bool cw_coupled_ok(const CwDecideArgs &a, const CwLds &L, const int32_t *t, int64_t aff_total, int64_t exist_total,
+                                              bool *dead) {
+    bool ok = true;
     for (int c = 0; c < a.pts.n; c++) { // PodTopologySpread.Filter (filtering.go:311-356)
         const int32_t tv = t[a.plan.h_comp[c]];
         int32_t v, m;
         if (a.plan.h_unique[c]) v = tv & 1, m = tv >> 1;
         else v = tv, m = v ? L.i32[a.plan.h_off[c] + v] : 0;
-        if (!v) return false;
+        if (!v) ok = false;
         const int64_t minm = a.pts.n_present[c] < a.pts.min_domains[c] ? 0 : (int64_t)L.mn[c];
-        if ((int64_t)m + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) return false;
+        if ((int64_t)m + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) ok = false;
     }
     if (a.ipa.on && a.ipa.filter_on && !(exist_total == 0 && a.ipa.n_aff == 0 && a.ipa.n_anti == 0)) { // filtering.go:410-432
-        bool pods_exist = true;
+        bool pods_exist = true, aff_ok = true;
         for (int q = 0; q < a.ipa.n_aff; q++) {
             const int k = a.ipa.aff_key[q];
             const int c0 = a.plan.k_comp[k];
-            const int32_t v = a.plan.k_unique[k] ? t[c0] : t[c0];
-            if (!v) return false;
-            const int64_t cntv = a.plan.k_unique[k] ? (int64_t)t[c0 + 1] : L.i64[a.plan.k_off[k] + v];
+            const int32_t v = t[c0];
+            if (!v) aff_ok = false;
+            const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 1] : L.i64[a.plan.k_off[k] + v]);
             if (cntv <= 0) pods_exist = false;
         }
-        if (!pods_exist && !(aff_total == 0 && a.ipa.self_aff)) return false;
+        if (!aff_ok || (!pods_exist && !(aff_total == 0 && a.ipa.self_aff))) ok = false;
         for (int q = 0; q < a.ipa.n_anti; q++) {
             const int k = a.ipa.anti_key[q];
             const int c0 = a.plan.k_comp[k];
             const int32_t v = t[c0];
             const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 2] : L.i64[a.plan.k_off[k] + a.plan.k_len[k] + v]);
-            if (cntv > 0) return false;
+            if (cntv > 0) ok = false, *dead = true;
         }
         if (exist_total > 0)
             for (int k = 0; k < a.ipa.n_keys; k++) {
                 const int c0 = a.plan.k_comp[k];
                 const int32_t v = t[c0];
                 const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 3] : L.i64[a.plan.k_off[k] + 2 * a.plan.k_len[k] + v]);
-                if (cntv > 0) return false;
+                if (cntv > 0) ok = false, *dead = true;
             }
     }
-    return true;
+    return ok;
 }
 
 __device__ __forceinline__ bool cw_soft_keys(const CwDecideArgs &a, const int32_t *t) {
@@ -540,6 +586,33 @@ __device__ __forceinline__ bool cw_soft_keys(const CwDecideArgs &a, const int32_
         all = all && (a.soft.is_hostname[c] ? (tv & 1) : tv) != 0;
     }
     return all;
+}
+
+// the local verdict and score of node i after `k` clones were added to what its columns hold (the window applies its
+// placements to the columns when it ends)
+__device__ __forceinline__ int32_t cw_local_after(const CwDecideArgs &a, int64_t i, int64_t k, uint32_t mt_a, uint32_t ma_a) {
+    const int64_t a_cpu = a.c.alloc[0][i], a_mem = a.c.alloc[1][i];
+    const int64_t r0 = a.c.req[0][i] + k * a.p.req[0], r1 = a.c.req[1][i] + k * a.p.req[1];
+    const int64_t z0 = a.c.nz_mcpu[i] + k * a.p.nz_mcpu, z1 = a.c.nz_mem[i] + k * a.p.nz_mem;
+    const int32_t pc = a.c.pod_count[i] + (int32_t)k, a_pods = a.c.alloc_pods[i];
+    const uint32_t w = a.c.stat[i];
+    int64_t xa[kMaxExtra], xr[kMaxExtra];
+    bool ok = fits_core(a.p, a_cpu, a_mem, r0, r1, a_pods, pc);
+#pragma unroll
+    for (int x = 0; x < kMaxExtra; x++) {
+        xa[x] = xr[x] = 0;
+        if (x < a.p.nx) {
+            const int col = a.p.xcol[x];
+            xa[x] = a.c.alloc[col][i], xr[x] = a.c.req[col][i] + k * a.p.req[col];
+            const int64_t rq = a.p.req[col];
+            if (a.p.fit_enabled && !a.p.all_zero_req && rq > 0 && rq > xa[x] - xr[x]) ok = false;
+        }
+    }
+    if (!ok) return -1;
+    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+    return (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) +
+                     (a.p.gen_score ? dynamic_score_gen<kMaxExtra>(a.p, a_cpu, a_mem, r0, r1, z0, z1, xa, xr)
+                                    : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r0, r1, z0, z1)));
 }
 
 // (the argument block is read through a pointer: its arrays are indexed with runtime constraint numbers, which on a by-value
@@ -554,8 +627,12 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
     const int LL = a.plan.list_len, W = a.plan.window;
     const bool giveup = __hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     const int C = giveup ? 0 : (int)a.w.ctl[kCwCtlClasses];
+    const bool staged = C * LL <= kCwListLds; // else list entries are read from HBM when they are needed
+    unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(), pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool prof = a.w.prof != nullptr;
+#define CW_TICK(i) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
-    // ---- prologue (all threads): class records, list heads, shared-key tables -> LDS
+    // ---- prologue (all threads): class records, list entries with their nodes' facts, shared-key tables -> LDS
     if (!giveup) {
         for (int q = tid; q < C * kCwTuple; q += kCwThreads) {
             const int id = q / kCwTuple;
@@ -565,11 +642,19 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             const CwClass &k = a.w.cls[a.w.slot_of_id[id]];
             L.c_nf[id] = k.nf, L.c_mt[id] = k.mt, L.c_ma[id] = k.ma, L.c_ht[id] = k.ht, L.c_ha[id] = k.ha;
             L.c_head[id] = 0;
-            int len = 0;
-            for (int r = 0; r < LL; r++) len += a.w.lists[(size_t)id * LL + r] != 0ull;
-            L.c_len[id] = len;
             L.c_key[id] = a.w.lists[(size_t)id * LL];
         }
+        if (staged)
+            for (int q = tid; q < C * LL; q += kCwThreads) {
+                const unsigned long long key = a.w.lists[q];
+                L.li_key[q] = key;
+                if (key) {
+                    const int64_t i = key_index(key) - a.c.global_offset;
+                    L.li_stat[q] = a.c.stat[i];
+                    L.li_elig[q] = (a.pts.n ? (uint32_t)a.pts.elig[i] : 0u) | ((a.soft.n ? (uint32_t)a.soft.elig[i] : 0u) << 16);
+                    L.li_A1[q] = a.w.node_A1[i];
+                }
+            }
         for (int c = 0; c < a.pts.n; c++)
             if (!a.plan.h_unique[c])
                 for (int v = tid; v < a.plan.h_len[c]; v += kCwThreads) {
@@ -591,11 +676,13 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                     }
                 }
     }
+    if (tid == 0) L.s_nt = 0;
     __syncthreads();
 
-    int nt = 0; // touched nodes of this window (wave 0's copy is the one that counts)
     if (tid < 64) {
         // ================= the cycle loop: wave 0 only, no block barriers =================
+        CW_TICK(0);
+        int nt = 0, na = 0; // touched nodes ; how many of them may still win
         int64_t placed = S.placed, rounds = S.rounds;
         const int64_t limit = S.limit, log_cap = S.log_cap;
         int64_t aff_total = S.ipa_aff_total, exist_total = S.ipa_exist_total, entries = S.ipa_entries;
@@ -623,8 +710,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             }
         bool end_window = giveup;
         int cycles = 0;
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        cw_lds_sync();
+        CW_TICK(1);
 
 #pragma unroll 1
         while (!end_window && !done && cycles < W) {
@@ -643,13 +730,12 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                 }
                 if (lane == 0) L.mn[c] = mc;
             }
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            const int ncand = C + nt;
-            // ---- stage 1: every candidate's verdict; feasible count, ignored count, maxima, candidate domains
             for (int c = 0; c < a.soft.n; c++)
                 if (!a.soft.is_hostname[c])
                     for (int q = lane; q < (a.plan.s_len[c] + 31) / 32; q += 64) L.i32[a.plan.s_bm[c] + q] = 0;
+            cw_lds_sync();
+            const int ncand = C + na;
+            // ---- stage 1: every candidate's verdict; feasible count, ignored count, maxima, candidate domains
             uint32_t nf = 0, nign = 0, mt_now = 0, ma_now = 0;
             bool unknown = false, need_head = false;
             for (int base = 0; base < ncand; base += 64) {
@@ -657,15 +743,17 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                 uint32_t fl = 0;
                 if (q < ncand) {
                     const bool is_cls = q < C;
-                    const int32_t *t = is_cls ? L.c_tuple[q] : L.t_tuple[q - C];
-                    const bool node_ok = is_cls ? L.c_nf[q] > 0 : L.t_feas[q - C] != 0;
-                    if (node_ok && cw_coupled_ok(a, L, t, aff_total, exist_total)) {
+                    const int ti = is_cls ? 0 : L.alive[q - C];
+                    const int32_t *t = is_cls ? L.c_tuple[q] : L.t_tuple[ti];
+                    const bool node_ok = is_cls ? L.c_nf[q] > 0 : true;
+                    bool dead = false;
+                    if (node_ok && cw_coupled_ok(a, L, t, aff_total, exist_total, &dead)) {
                         const bool sk = cw_soft_keys(a, t);
                         fl = 1u | (sk ? 2u : 0u);
                         const uint32_t members = is_cls ? L.c_nf[q] : 1u;
                         nf += members;
                         if (!sk) nign += members;
-                        const uint32_t cm = is_cls ? L.c_mt[q] : L.t_cnt[q - C], ca = is_cls ? L.c_ma[q] : L.t_aff[q - C];
+                        const uint32_t cm = is_cls ? L.c_mt[q] : L.t_cnt[ti], ca = is_cls ? L.c_ma[q] : L.t_aff[ti];
                         mt_now = cm > mt_now ? cm : mt_now, ma_now = ca > ma_now ? ca : ma_now;
                         if (is_cls && (L.c_ht[q] == 0 || L.c_ha[q] == 0)) unknown = true; // the class's own maximum lost its last holder
                         if (is_cls && L.c_key[q] == 0ull) need_head = true;                 // its next head is not among the members kept
@@ -682,6 +770,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             nf = wave_sum_u32_dpp(nf), nign = wave_sum_u32_dpp(nign);
             mt_now = wave_max_u32(mt_now), ma_now = wave_max_u32(ma_now);
             unknown = __ballot(unknown) != 0ull, need_head = __ballot(need_head) != 0ull;
+            CW_TICK(2);
             if (nf == 0) {
                 if (cycles == 0) { // the pass saw every node: schedule_one.go:448-454
                     done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0;
@@ -696,25 +785,25 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             // ---- stage 2: PodTopologySpread weights (scoring.go:96-113,294-296), raw scores, their min / max
             const bool soft_on = a.soft.n > 0 && a.soft.w;
             const bool ipa_on = a.ipa.on && a.ipa.w && entries > 0; // else PreScore Skip (scoring.go:199-201)
-            if (soft_on)
-                for (int c = 0; c < a.soft.n; c++) {
-                    int64_t sz;
-                    if (a.soft.is_hostname[c]) sz = (int64_t)nf - (int64_t)nign;
-                    else {
-                        uint32_t bits = 0;
-                        for (int q = lane; q < (a.plan.s_len[c] + 31) / 32; q += 64) bits += (uint32_t)__popc((unsigned)L.i32[a.plan.s_bm[c] + q]);
-                        sz = wave_sum_u32_dpp(bits);
-                    }
-                    if (sz != L.soft_size[c] && lane == 0) L.soft_size[c] = sz, L.soft_w[c] = go_log((double)(sz + 2));
-                }
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
             int64_t p_mn = INT64_MAX, p_mx = 0, i_mn = INT64_MAX, i_mx = INT64_MIN;
-            if (soft_on || ipa_on)
+            if (soft_on || ipa_on) {
+                cw_lds_sync(); // (the candidate bitmaps and flags above)
+                if (soft_on)
+                    for (int c = 0; c < a.soft.n; c++) {
+                        int64_t sz;
+                        if (a.soft.is_hostname[c]) sz = (int64_t)nf - (int64_t)nign;
+                        else {
+                            uint32_t bits = 0;
+                            for (int q = lane; q < (a.plan.s_len[c] + 31) / 32; q += 64) bits += (uint32_t)__popc((unsigned)L.i32[a.plan.s_bm[c] + q]);
+                            sz = wave_sum_u32_dpp(bits);
+                        }
+                        if (sz != L.soft_size[c] && lane == 0) L.soft_size[c] = sz, L.soft_w[c] = go_log((double)(sz + 2));
+                    }
+                cw_lds_sync();
                 for (int base = 0; base < ncand; base += 64) {
                     const int q = base + lane;
                     if (q < ncand && (L.e_fl[q] & 1u)) {
-                        const int32_t *t = q < C ? L.c_tuple[q] : L.t_tuple[q - C];
+                        const int32_t *t = q < C ? L.c_tuple[q] : L.t_tuple[L.alive[q - C]];
                         if (soft_on && (L.e_fl[q] & 2u)) { // scoring.go:196-223
                             double sc = 0;
                             for (int c = 0; c < a.soft.n; c++) {
@@ -738,14 +827,16 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                         }
                     }
                 }
-            if (soft_on) {
-                p_mn = INT64_MAX - (int64_t)wave_max_u64((uint64_t)(INT64_MAX - p_mn)); // (values >= 0)
-                p_mx = (int64_t)wave_max_u64((uint64_t)p_mx);
+                if (soft_on) {
+                    p_mn = INT64_MAX - (int64_t)wave_max_u64((uint64_t)(INT64_MAX - p_mn)); // (values >= 0)
+                    p_mx = (int64_t)wave_max_u64((uint64_t)p_mx);
+                }
+                if (ipa_on) { // signed: bias to unsigned order
+                    i_mn = (int64_t)(~wave_max_u64(~((uint64_t)i_mn ^ 0x8000000000000000ull)) ^ 0x8000000000000000ull);
+                    i_mx = (int64_t)(wave_max_u64((uint64_t)i_mx ^ 0x8000000000000000ull) ^ 0x8000000000000000ull);
+                }
             }
-            if (ipa_on) { // signed: bias to unsigned order
-                i_mn = (int64_t)(~wave_max_u64(~((uint64_t)i_mn ^ 0x8000000000000000ull)) ^ 0x8000000000000000ull);
-                i_mx = (int64_t)(wave_max_u64((uint64_t)i_mx ^ 0x8000000000000000ull) ^ 0x8000000000000000ull);
-            }
+            CW_TICK(3);
             // ---- stage 3: totals, argmax (selectHost, schedule_one.go:894-941: lowest index among the maxima)
             uint64_t best = 0;
             int best_q = -1;
@@ -753,8 +844,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                 const int q = base + lane;
                 if (q < ncand && (L.e_fl[q] & 1u)) {
                     const uint64_t hk = q < C ? L.c_key[q] : 0ull;
-                    int64_t total = q < C ? key_score(hk) : (int64_t)L.t_A[q - C];
-                    const int64_t gi = q < C ? key_index(hk) : (int64_t)L.t_gidx[q - C];
+                    const int ti = q < C ? 0 : L.alive[q - C];
+                    int64_t total = q < C ? key_score(hk) : (int64_t)L.t_A[ti];
+                    const int64_t gi = q < C ? key_index(hk) : (int64_t)L.t_gidx[ti];
                     if (soft_on && (L.e_fl[q] & 2u)) total += soft_normalize(L.e_rp[q], p_mn, p_mx) * a.soft.w; // ignored nodes score 0
                     if (ipa_on) total += ipa_normalize(L.e_ri[q], i_mn, i_mx) * a.ipa.w;
                     const uint64_t key = make_key(total, gi);
@@ -766,30 +858,37 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             const int wl = __ffsll((unsigned long long)owner) - 1;
             const int wq = __builtin_amdgcn_readlane(best_q, wl);
             const int64_t g = key_index(wbest);
+            CW_TICK(4);
             // ---- commit (every lane holds the same wq / g; lane 0 writes)
             int ti; // the winner's touched record
+            int32_t A_next; // its local score after this clone, -1 = it takes no further clone
             if (wq < C) {
                 ti = nt;
-                const int64_t i = g - a.c.global_offset;
+                const int hd0 = L.c_head[wq], e0 = wq * LL + hd0;
+                uint32_t w, el;
+                if (staged) w = L.li_stat[e0], el = L.li_elig[e0], A_next = L.li_A1[e0];
+                else {
+                    const int64_t i = g - a.c.global_offset;
+                    w = a.c.stat[i], A_next = a.w.node_A1[i];
+                    el = (a.pts.n ? (uint32_t)a.pts.elig[i] : 0u) | ((a.soft.n ? (uint32_t)a.soft.elig[i] : 0u) << 16);
+                }
                 if (lane < kCwTuple) L.t_tuple[ti][lane] = L.c_tuple[wq][lane];
                 if (lane == 0) {
-                    const uint32_t w = a.c.stat[i];
-                    L.t_gidx[ti] = g;
-                    L.t_cnt[ti] = (w >> kStatCntShift) & kStatCntMask, L.t_aff[ti] = w & kStatAffMask;
-                    L.t_took[ti] = 0;
-                    L.t_elig[ti] = (a.pts.n ? (uint32_t)a.pts.elig[i] : 0u) | ((a.soft.n ? (uint32_t)a.soft.elig[i] : 0u) << 16);
+                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                    L.t_gidx[ti] = g, L.t_cnt[ti] = cnt, L.t_aff[ti] = aff, L.t_took[ti] = 0, L.t_elig[ti] = el;
                     L.c_nf[wq] -= 1;
-                    L.c_ht[wq] -= L.t_cnt[ti] == L.c_mt[wq] ? 1u : 0u;
-                    L.c_ha[wq] -= L.t_aff[ti] == L.c_ma[wq] ? 1u : 0u;
-                    const int hd = L.c_head[wq] + 1;
+                    L.c_ht[wq] -= cnt == L.c_mt[wq] ? 1u : 0u;
+                    L.c_ha[wq] -= aff == L.c_ma[wq] ? 1u : 0u;
+                    const int hd = hd0 + 1;
                     L.c_head[wq] = hd;
-                    L.c_key[wq] = hd < LL ? a.w.lists[(size_t)wq * LL + hd] : 0ull;
+                    L.c_key[wq] = hd < LL ? (staged ? L.li_key[e0 + 1] : a.w.lists[(size_t)wq * LL + hd]) : 0ull;
                 }
                 nt += 1;
-            } else
-                ti = wq - C;
-            __builtin_amdgcn_s_waitcnt(0); // (LDS writes of lane 0 above are read by every lane below)
-            __builtin_amdgcn_wave_barrier();
+            } else {
+                ti = L.alive[wq - C];
+                A_next = cw_local_after(a, g - a.c.global_offset, (int64_t)L.t_took[ti] + 1, mt_a, ma_a); // (a node winning again: one trip to its columns)
+            }
+            cw_lds_sync();
             const uint32_t el = L.t_elig[ti];
             // the clone is an existing pod of the next cycle: tables, the node's own entries, totals
             for (int c = 0; c < a.pts.n; c++) { // filtering.go:255-296
@@ -835,45 +934,30 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                         }
                     }
                 }
-            // NodeInfo.update (types.go:409-428) on the columns + the node's new local verdict and score
             if (lane == 0) {
-                const int64_t i = g - a.c.global_offset;
-                const int64_t a_cpu = a.c.alloc[0][i], a_mem = a.c.alloc[1][i];
-                const int64_t r0 = a.c.req[0][i] + a.p.req[0], r1 = a.c.req[1][i] + a.p.req[1];
-                const int64_t z0 = a.c.nz_mcpu[i] + a.p.nz_mcpu, z1 = a.c.nz_mem[i] + a.p.nz_mem;
-                const int32_t pc = a.c.pod_count[i] + 1, pl = a.c.placed_cnt[i] + 1, a_pods = a.c.alloc_pods[i];
-                const uint32_t w = a.c.stat[i];
-                int64_t xa[kMaxExtra], xr[kMaxExtra];
-                bool ok = fits_core(a.p, a_cpu, a_mem, r0, r1, a_pods, pc);
-#pragma unroll
-                for (int x = 0; x < kMaxExtra; x++) {
-                    xa[x] = xr[x] = 0;
-                    if (x < a.p.nx) {
-                        const int col = a.p.xcol[x];
-                        xa[x] = a.c.alloc[col][i], xr[x] = a.c.req[col][i] + a.p.req[col];
-                        const int64_t rq = a.p.req[col];
-                        if (a.p.fit_enabled && !a.p.all_zero_req && rq > 0 && rq > xa[x] - xr[x]) ok = false;
-                    }
-                }
-                a.c.req[0][i] = r0, a.c.req[1][i] = r1, a.c.nz_mcpu[i] = z0, a.c.nz_mem[i] = z1;
-                a.c.pod_count[i] = pc, a.c.placed_cnt[i] = pl;
-                store_mirror(a.c, i, r0, r1, z0, z1);
-#pragma unroll 1
-                for (int col = 2; col < a.p.ncol; col++)
-                    if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
-                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
-                L.t_feas[ti] = ok ? 1u : 0u;
-                L.t_A[ti] = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) +
-                                      (a.p.gen_score ? dynamic_score_gen<kMaxExtra>(a.p, a_cpu, a_mem, r0, r1, z0, z1, xa, xr)
-                                                     : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r0, r1, z0, z1)));
+                L.t_A[ti] = A_next;
                 L.t_took[ti] += 1;
                 if (a.log && placed < log_cap) a.log[placed] = (int32_t)g;
+            }
+            cw_lds_sync();
+            // does the node stay a candidate?  Full, or blocked for good by its own clone (required anti-affinity): no.
+            {
+                bool dead = A_next < 0;
+                if (!dead) (void)cw_coupled_ok(a, L, L.t_tuple[ti], aff_total, exist_total, &dead);
+                const bool was_alive = wq >= C;
+                if (!dead && !was_alive) {
+                    if (lane == 0) L.alive[na] = ti;
+                    na += 1;
+                } else if (dead && was_alive) { // remove: the last alive entry takes its place
+                    if (lane == 0) L.alive[wq - C] = L.alive[na - 1];
+                    na -= 1;
+                }
             }
             placed += 1, rounds += 1, cycles += 1;
             last_feasible = (int32_t)nf;
             if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312: tested after the append
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
+            cw_lds_sync();
+            CW_TICK(5);
         }
         // ---- the window is over: run state back to the device struct (lane 0)
         if (lane == 0) {
@@ -886,15 +970,43 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             for (int c = 0; c < a.pts.n; c++) S.pts_min_a[c] = L.mn[c]; // (the terminal histogram reads it: k_hist)
             S.cw_windows += 1;
             S.done = done;
+            L.s_nt = nt;
+            if (prof) pf[7] += (unsigned long long)cycles;
         }
     }
     __syncthreads();
-    __shared__ int s_nt;
-    if (tid == 0) s_nt = nt;
-    __syncthreads();
-    nt = s_nt;
-    // ---- epilogue (all threads): tables back to HBM -- they are the canonical state every other path reads
+    const int nt = L.s_nt;
+    // ---- epilogue (all threads): the window's placements onto the columns (NodeInfo.update, types.go:409-428) and the tables
+    // back to HBM -- they are the canonical state every other path reads
     if (!giveup) {
+        for (int ti = tid; ti < nt; ti += kCwThreads) {
+            const int64_t i = L.t_gidx[ti] - a.c.global_offset;
+            const int64_t k = (int64_t)L.t_took[ti];
+            const int64_t r0 = a.c.req[0][i] + k * a.p.req[0], r1 = a.c.req[1][i] + k * a.p.req[1];
+            const int64_t z0 = a.c.nz_mcpu[i] + k * a.p.nz_mcpu, z1 = a.c.nz_mem[i] + k * a.p.nz_mem;
+            a.c.req[0][i] = r0, a.c.req[1][i] = r1, a.c.nz_mcpu[i] = z0, a.c.nz_mem[i] = z1;
+            a.c.pod_count[i] += (int32_t)k, a.c.placed_cnt[i] += (int32_t)k;
+            store_mirror(a.c, i, r0, r1, z0, z1);
+#pragma unroll 1
+            for (int col = 2; col < a.p.ncol; col++)
+                if (a.p.req[col] != 0) a.c.req[col][i] += k * a.p.req[col];
+            // unique keys: the node's own table entries
+            for (int c = 0; c < a.pts.n; c++)
+                if (a.plan.h_unique[c]) {
+                    const int32_t v = a.pts.label[c][i], tv = L.t_tuple[ti][a.plan.h_comp[c]];
+                    if (v) a.pts.tbl[c][v] = tv >> 1;
+                }
+            if (a.ipa.on)
+                for (int kk = 0; kk < a.ipa.n_keys; kk++)
+                    if (a.plan.k_unique[kk]) {
+                        const int32_t v = a.ipa.label[kk][i];
+                        const int q = a.plan.k_comp[kk];
+                        if (v) {
+                            a.ipa.aff[kk][v] = L.t_tuple[ti][q + 1], a.ipa.anti[kk][v] = L.t_tuple[ti][q + 2];
+                            a.ipa.exist[kk][v] = L.t_tuple[ti][q + 3], a.ipa.score[kk][v] = L.t_tuple[ti][q + 4];
+                        }
+                    }
+        }
         for (int c = 0; c < a.pts.n; c++)
             if (!a.plan.h_unique[c])
                 for (int v = 1 + tid; v < a.plan.h_len[c]; v += kCwThreads) a.pts.tbl[c][v] = L.i32[a.plan.h_off[c] + v];
@@ -912,25 +1024,6 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                         a.ipa.score[k][v] = L.i64[a.plan.k_off[k] + 3 * len + v];
                     }
                 }
-        // unique keys: the touched nodes' own entries
-        for (int ti = tid; ti < nt; ti += kCwThreads) {
-            const int64_t i = L.t_gidx[ti] - a.c.global_offset;
-            for (int c = 0; c < a.pts.n; c++)
-                if (a.plan.h_unique[c]) {
-                    const int32_t v = a.pts.label[c][i], tv = L.t_tuple[ti][a.plan.h_comp[c]];
-                    if (v) a.pts.tbl[c][v] = tv >> 1;
-                }
-            if (a.ipa.on)
-                for (int k = 0; k < a.ipa.n_keys; k++)
-                    if (a.plan.k_unique[k]) {
-                        const int32_t v = a.ipa.label[k][i];
-                        const int q = a.plan.k_comp[k];
-                        if (v) {
-                            a.ipa.aff[k][v] = L.t_tuple[ti][q + 1], a.ipa.anti[k][v] = L.t_tuple[ti][q + 2];
-                            a.ipa.exist[k][v] = L.t_tuple[ti][q + 3], a.ipa.score[k][v] = L.t_tuple[ti][q + 4];
-                        }
-                    }
-        }
     }
     // ---- leave the class table empty for the next pass
     const int Cused = (int)a.w.ctl[kCwCtlClasses] < kCwMaxClasses ? (int)a.w.ctl[kCwCtlClasses] : kCwMaxClasses;
@@ -944,6 +1037,11 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
         }
     __syncthreads();
     if (tid == 0 && !giveup) a.w.ctl[kCwCtlClasses] = 0u;
+    if (tid == 0 && prof) {
+        pf[6] += __builtin_amdgcn_s_memrealtime() - t_prev;
+        for (int i = 0; i < 8; i++) a.w.prof[i] += pf[i];
+    }
+#undef CW_TICK
 }
 
 } // namespace ccsim

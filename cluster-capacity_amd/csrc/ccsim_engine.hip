@@ -898,6 +898,8 @@ static int cw_make_plan(ccsim_engine *e) {
     if ((rc = dev_alloc(e, &w.slot_of_id, (size_t)kCwMaxClasses, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &w.node_slot, (size_t)e->n_pad, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &w.node_A, (size_t)e->n_pad, e->pod_allocs))) return rc;
+    if ((rc = dev_alloc(e, &w.node_A1, (size_t)e->n_pad, e->pod_allocs))) return rc;
+    if (getenv("CCSIM_CW_PROF") && atoi(getenv("CCSIM_CW_PROF")) && (rc = dev_alloc(e, &w.prof, (size_t)16, e->pod_allocs))) return rc; // measurement runs
     if ((rc = dev_alloc(e, &w.top, (size_t)blocks * kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs, false))) return rc;
     if ((rc = dev_alloc(e, &w.lists, (size_t)kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &w.umin, (size_t)blocks * kMaxTsc, e->pod_allocs))) return rc;
@@ -1350,7 +1352,9 @@ static void launch_cw_window(ccsim_engine *e) {
 }
 
 static int run_cw(ccsim_engine *e) {
+    static_assert(sizeof(CwLds) <= 160 * 1024, "k_cw_decide's LDS image must fit one CU");
     static bool attr_set = false;
+    if (e->cw_work.prof) HIPCHK(e, hipMemsetAsync(e->cw_work.prof, 0, 16 * sizeof(unsigned long long), e->stream));
     if (!attr_set) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         attr_set = true;
@@ -2197,7 +2201,12 @@ static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out) {
 // measurement aid: why the windows of the last multi-spec run ended (k_multi_commit stop reasons 0..7)
 extern "C" int ccsim_debug_coupled(ccsim_engine *e, int64_t *out8) {
     if (!e || !out8) return -EINVAL;
-    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (int i = 0; i < 16; i++) out8[i] = 0;
+    if (e->cw_ok && e->cw_work.prof) { // CCSIM_CW_PROF=1: 10 ns ticks of the decide kernel's wave 0 per phase, summed over the last run
+        HIPCHK(e, hipSetDevice(e->device));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipMemcpy(out8 + 8, e->cw_work.prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));
+    }
     out8[0] = e->have_pod && e->cw_ok ? 1 : 0;
     if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback;
     out8[3] = e->cw_ok ? e->cw_plan.window : 0, out8[4] = e->cw_ok ? e->cw_plan.list_len : 0;

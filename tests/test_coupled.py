@@ -84,7 +84,9 @@ def test_coupled_cases_with_unique_keys(ccref, monkeypatch, seed, window, list_l
     rng = np.random.default_rng(7100 + seed)
     nodes, pod, prof = coupled_case(rng, int(rng.integers(12, 700)), roomy=seed % 3 == 0)
     limit = 1500 if seed % 3 == 0 else int(rng.choice([0, 0, 29]))
-    coupled = bool(pod.spread) or pod.ipa is not None
+    coupled = bool((any(c.hard for c in pod.spread) and prof.filter_mask & M.F_TOPOLOGYSPREAD) or
+                   (any(not c.hard for c in pod.spread) and prof.w_topologyspread) or
+                   (pod.ipa is not None and (prof.filter_mask & M.F_INTERPODAFFINITY or prof.w_interpodaffinity)))  # (what the engine activates)
     _run(ccref, nodes, pod, prof, limit, monkeypatch, window, list_len, expect_plan=coupled)
 
 
