@@ -36,7 +36,9 @@
 
 namespace ccsim {
 
-constexpr int kCwTuple = 16;        // int32 components of a class tuple
+constexpr int kCwTuple = 20;        // int32 components of a class tuple, at FIXED positions (registers in the scan, not a scratch frame):
+                                    // hard constraint c -> c (c < 4); soft c -> 4 + c; inter-pod key 0 -> 8..12, 1 -> 13..17, 2 -> 18, 3 -> 19
+constexpr int kCwMaxCons = 4, kCwKeyPos0 = 8, kCwKeyPos1 = 13, kCwKeyPos2 = 18, kCwKeyPos3 = 19;
 constexpr int kCwMaxClasses = 256;  // classes per window
 constexpr int kCwSlots = 1024;      // global open-addressing class table (power of two)
 constexpr int kCwBlockSlots = 256;  // per-block LDS class table of the scan (power of two)
@@ -136,17 +138,18 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
     __syncthreads();
     const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
     const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
-    const int ncomp = a.plan.n_comp;
     uint32_t *giveup = a.w.ctl + kCwCtlGiveUp;
     int lslot[kCwPerThread];
     int32_t lA[kCwPerThread], lA1[kCwPerThread];
 
-#pragma unroll 1
+    int32_t tup4[kCwPerThread][kCwTuple]; // (the four nodes of a thread are worked on together: their loads overlap)
+    bool mine4[kCwPerThread];
+#pragma unroll
     for (int j = 0; j < kCwPerThread; j++) {
         const int64_t i = (int64_t)blockIdx.x * kCwTile + (int64_t)j * kCwThreads + tid;
         lslot[j] = -1, lA[j] = 0, lA1[j] = -1;
         bool feas = false;
-        int32_t tup[kCwTuple];
+        int32_t(&tup)[kCwTuple] = tup4[j];
 #pragma unroll
         for (int q = 0; q < kCwTuple; q++) tup[q] = 0;
         uint32_t cnt = 0, aff = 0;
@@ -221,40 +224,48 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
                     }
                     lA1[j] = f1 ? (int32_t)(A1 + static_score(a.p, cnt, aff, img, mt, ma)) : -1;
                 }
-                // ---- the class tuple: everything the coupled plugins read of this node
-                for (int c = 0; c < a.pts.n; c++) {
-                    const int32_t v = a.pts.label[c][i];
-                    tup[a.plan.h_comp[c]] = a.plan.h_unique[c] ? ((v ? 1 : 0) | (v ? a.pts.tbl[c][v] << 1 : 0)) : v;
-                }
-                for (int c = 0; c < a.soft.n; c++) {
-                    const int32_t v = a.soft.label[c][i];
-                    int32_t t = v;
-                    if (a.soft.is_hostname[c]) {
-                        const int32_t ct = (a.soft.existing[c] ? a.soft.existing[c][i] : 0) + (a.soft.self_match[c] ? npods - a.soft.pod_count0[i] : 0);
-                        t = (v ? 1 : 0) | (ct << 1);
+                // ---- the class tuple: everything the coupled plugins read of this node (compile-time positions)
+#pragma unroll
+                for (int c = 0; c < kCwMaxCons; c++)
+                    if (c < a.pts.n) {
+                        const int32_t v = a.pts.label[c][i];
+                        tup[c] = a.plan.h_unique[c] ? ((v ? 1 : 0) | (v ? a.pts.tbl[c][v] << 1 : 0)) : v;
                     }
-                    tup[a.plan.s_comp[c]] = t;
-                }
-                if (a.ipa.on)
-                    for (int k = 0; k < a.ipa.n_keys; k++) {
-                        const int32_t v = a.ipa.label[k][i];
-                        const int q = a.plan.k_comp[k];
-                        if (!a.plan.k_unique[k]) tup[q] = v;
-                        else {
-                            tup[q] = v ? 1 : 0;
-                            tup[q + 1] = v ? cw_narrow_entry(a.ipa.aff[k][v], giveup) : 0;
-                            tup[q + 2] = v ? cw_narrow_entry(a.ipa.anti[k][v], giveup) : 0;
-                            tup[q + 3] = v ? cw_narrow_entry(a.ipa.exist[k][v], giveup) : 0;
-                            tup[q + 4] = v ? cw_narrow_entry(a.ipa.score[k][v], giveup) : 0;
+#pragma unroll
+                for (int c = 0; c < kCwMaxCons; c++)
+                    if (c < a.soft.n) {
+                        const int32_t v = a.soft.label[c][i];
+                        int32_t t = v;
+                        if (a.soft.is_hostname[c]) {
+                            const int32_t ct = (a.soft.existing[c] ? a.soft.existing[c][i] : 0) + (a.soft.self_match[c] ? npods - a.soft.pod_count0[i] : 0);
+                            t = (v ? 1 : 0) | (ct << 1);
                         }
+                        tup[kCwMaxCons + c] = t;
                     }
+                if (a.ipa.on) {
+#pragma unroll
+                    for (int k = 0; k < kMaxIpaKeys; k++)
+                        if (k < a.ipa.n_keys) {
+                            const int32_t v = a.ipa.label[k][i];
+                            constexpr int kPos[4] = {kCwKeyPos0, kCwKeyPos1, kCwKeyPos2, kCwKeyPos3};
+                            const int q = kPos[k];
+                            if (k >= 2 || !a.plan.k_unique[k]) tup[q] = v; // (a unique key beyond the second: no plan, see cw_make_plan)
+                            else {
+                                tup[q] = v ? 1 : 0;
+                                tup[q + 1] = v ? cw_narrow_entry(a.ipa.aff[k][v], giveup) : 0;
+                                tup[q + 2] = v ? cw_narrow_entry(a.ipa.anti[k][v], giveup) : 0;
+                                tup[q + 3] = v ? cw_narrow_entry(a.ipa.exist[k][v], giveup) : 0;
+                                tup[q + 4] = v ? cw_narrow_entry(a.ipa.score[k][v], giveup) : 0;
+                            }
+                        }
+                }
             }
         }
         // ---- block-local class table (LDS): one global atomic per (block, class) instead of one per node
         bool mine = false;
         int s = -1;
         if (feas) {
-            const uint64_t h = cw_hash(tup, ncomp);
+            const uint64_t h = cw_hash(tup, kCwTuple);
             s = (int)(h & (kCwBlockSlots - 1));
             int probes = 0;
             for (;;) {
@@ -275,15 +286,17 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
             }
             if (s >= 0) atomicAdd(&b_nf[s], 1u), atomicMax(&b_mt[s], cnt), atomicMax(&b_ma[s], aff);
         }
-        __syncthreads();
-        if (s >= 0 && !mine) { // same hash: the tuples must be the same tuple
+        lslot[j] = s, mine4[j] = mine;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kCwPerThread; j++)
+        if (lslot[j] >= 0 && !mine4[j]) { // same hash: the tuples must be the same tuple
             bool same = true;
 #pragma unroll
-            for (int q = 0; q < kCwTuple; q++) same = same && b_tuple[s][q] == tup[q];
+            for (int q = 0; q < kCwTuple; q++) same = same && b_tuple[lslot[j]][q] == tup4[j][q];
             if (!same) __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        lslot[j] = s;
-    }
     // how many counted nodes of this block sit at the block's minimum (second sweep over the same entries: L2 hits)
     bool any_unique = false;
     for (int c = 0; c < a.pts.n; c++) any_unique = any_unique || a.plan.h_unique[c];
@@ -384,9 +397,8 @@ struct CwTopArgs {
 __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
     if (a.st->done || a.st->cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    __shared__ unsigned long long cand[kCwMaxClasses];
+    __shared__ unsigned long long cand[2][kCwMaxClasses];
     __shared__ uint32_t l_mt[kCwMaxClasses], l_ma[kCwMaxClasses], l_ht[kCwMaxClasses], l_ha[kCwMaxClasses];
-    __shared__ int s_live;
     const int tid = threadIdx.x;
     const int C = (int)a.w.ctl[kCwCtlClasses];
     for (int id = tid; id < C; id += kCwThreads) {
@@ -412,30 +424,20 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
         }
     }
     unsigned long long *out = a.w.top + (size_t)blockIdx.x * kCwMaxClasses * a.list_len;
+    for (int id = tid; id < C; id += kCwThreads) cand[0][id] = 0ull, cand[1][id] = 0ull;
+    __syncthreads();
 #pragma unroll 1
-    for (int r = 0; r < a.list_len; r++) {
-        for (int id = tid; id < C; id += kCwThreads) cand[id] = 0ull;
-        if (tid == 0) s_live = 0;
-        __syncthreads();
-        bool live = false;
+    for (int r = 0; r < a.list_len; r++) { // two barriers per round: the other buffer is cleared while this one is read
+        const int pb = r & 1;
 #pragma unroll
         for (int j = 0; j < kCwPerThread; j++)
-            if (id_[j] >= 0) atomicMax(&cand[id_[j]], (unsigned long long)key_[j]), live = true;
-        if (live) s_live = 1;
+            if (id_[j] >= 0) atomicMax(&cand[pb][id_[j]], (unsigned long long)key_[j]);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kCwPerThread; j++)
-            if (id_[j] >= 0 && cand[id_[j]] == key_[j]) id_[j] = -1; // (keys are unique: they carry the node index)
-        for (int id = tid; id < C; id += kCwThreads) out[(size_t)id * a.list_len + r] = cand[id];
-        const bool any = s_live != 0;
+            if (id_[j] >= 0 && cand[pb][id_[j]] == key_[j]) id_[j] = -1; // (keys are unique: they carry the node index)
+        for (int id = tid; id < C; id += kCwThreads) out[(size_t)id * a.list_len + r] = cand[pb][id], cand[pb ^ 1][id] = 0ull;
         __syncthreads();
-        if (!any) { // nothing left in this block: the remaining ranks are empty
-            for (int q = (r + 1) * kCwThreads + tid; q < a.list_len * kCwThreads; q += kCwThreads) {
-                const int rr = q / kCwThreads;
-                for (int id = q % kCwThreads; id < C; id += kCwThreads) out[(size_t)id * a.list_len + rr] = 0ull;
-            }
-            break;
-        }
     }
     for (int id = tid; id < C; id += kCwThreads) {
         CwClass &k = a.w.cls[a.w.slot_of_id[id]];
@@ -444,44 +446,43 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
     }
 }
 
-// k_cw_merge: block id = class id.  The blocks' lists are sorted, so the class's L best are found by L rounds over the
-// blocks' current heads (staged in LDS).
-__global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a) {
+// k_cw_merge: block id = class id, ONE wave.  The blocks' lists are sorted, so the class's L best are found by L rounds over the
+// blocks' current heads (keys staged in LDS; a wave needs no block barrier).
+constexpr int kCwMergeThreads = 64;
+__global__ __launch_bounds__(kCwMergeThreads) void k_cw_merge(CwTopArgs a) {
     if (a.st->done || a.st->cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int C = (int)a.w.ctl[kCwCtlClasses], id = blockIdx.x, L = a.list_len, nb = a.w.n_blocks;
     if (id >= C) return;
     __shared__ unsigned long long s_k[kCwMaxKeys];
     __shared__ uint8_t s_head[kCwMaxKeys];
-    __shared__ unsigned long long s_w[kCwThreads / 64];
-    const int tid = threadIdx.x;
-    for (int q = tid; q < nb * L; q += kCwThreads) {
+    const int lane = threadIdx.x;
+    for (int q = lane; q < nb * L; q += kCwMergeThreads) {
         const int b = q / L, r = q % L;
         s_k[q] = a.w.top[((size_t)b * kCwMaxClasses + id) * L + r];
     }
-    for (int b = tid; b < nb; b += kCwThreads) s_head[b] = 0;
-    __syncthreads();
+    for (int b = lane; b < nb; b += kCwMergeThreads) s_head[b] = 0;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long mine = 0; // rank `lane` of the merged list ends up in lane `lane` (L <= 32)
     for (int r = 0; r < L; r++) {
         unsigned long long best = 0;
-        for (int b = tid; b < nb; b += kCwThreads) {
+        for (int b = lane; b < nb; b += kCwMergeThreads) {
             const int hd = s_head[b];
             const unsigned long long k = hd < L ? s_k[b * L + hd] : 0ull;
             best = k > best ? k : best;
         }
-        best = wave_max_u64(best);
-        if ((tid & 63) == 0) s_w[tid >> 6] = best;
-        __syncthreads();
-        unsigned long long K = 0;
-#pragma unroll
-        for (int w = 0; w < kCwThreads / 64; w++) K = s_w[w] > K ? s_w[w] : K;
+        const unsigned long long K = wave_max_u64(best);
         if (K)
-            for (int b = tid; b < nb; b += kCwThreads) {
+            for (int b = lane; b < nb; b += kCwMergeThreads) {
                 const int hd = s_head[b];
                 if (hd < L && s_k[b * L + hd] == K) s_head[b] = (uint8_t)(hd + 1);
             }
-        if (tid == 0) a.w.lists[(size_t)id * L + r] = K;
-        __syncthreads();
+        if (lane == r) mine = K;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
     }
+    if (lane < L) a.w.lists[(size_t)id * L + lane] = mine;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -536,55 +537,103 @@ __device__ __forceinline__ void cw_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// The plugin parameters the cycle loop reads, as a register image (every value is wave-uniform: SGPRs).  Read through the
+// argument pointer they were ~25 dependent scalar loads per candidate pass: 2 us of the first version's 4.6 us per cycle
+// (profiles/r03/bench_coupled.txt).  The bounds are compile-time so that every index is: <2,2,2> is the common pod (config 5's
+// shape has one hard constraint and one key), <4,4,4> everything else the plan admits.
+template <int MH, int MS, int MK>
+struct CwP {
+    int nh, ns, nk;
+    int h_comp[MH], h_unique[MH], h_off[MH], h_len[MH], h_pres[MH], h_skew[MH], h_self[MH], h_usemin[MH];
+    int s_comp[MS], s_off[MS], s_len[MS], s_bm[MS], s_host[MS], s_self[MS], s_skew[MS];
+    int k_comp[MK], k_unique[MK], k_off[MK], k_len[MK], k_aff[MK], k_anti[MK], k_daff[MK], k_danti[MK], k_dent[MK];
+    long long k_dscore[MK];
+    int soft_w, ipa_w, ipa_filter, ipa_any_term, self_aff;
+    __device__ __forceinline__ void load(const CwDecideArgs &a) {
+        nh = a.pts.n, ns = a.soft.n, nk = a.ipa.on ? a.ipa.n_keys : 0;
+#pragma unroll
+        for (int c = 0; c < MH; c++) {
+            const bool on = c < nh;
+            h_comp[c] = on ? a.plan.h_comp[c] : 0, h_unique[c] = on ? a.plan.h_unique[c] : 0, h_off[c] = on ? a.plan.h_off[c] : 0;
+            h_len[c] = on ? a.plan.h_len[c] : 0, h_pres[c] = on ? a.plan.h_pres[c] : 0;
+            h_skew[c] = on ? a.pts.max_skew[c] : 0, h_self[c] = on ? a.pts.self_match[c] : 0;
+            h_usemin[c] = on && !(a.pts.n_present[c] < a.pts.min_domains[c]) ? 1 : 0; // else the global minimum counts as 0 (filtering.go:56-69)
+        }
+#pragma unroll
+        for (int c = 0; c < MS; c++) {
+            const bool on = c < ns;
+            s_comp[c] = on ? a.plan.s_comp[c] : 0, s_off[c] = on ? a.plan.s_off[c] : 0, s_len[c] = on ? a.plan.s_len[c] : 0, s_bm[c] = on ? a.plan.s_bm[c] : 0;
+            s_host[c] = on ? a.soft.is_hostname[c] : 0, s_self[c] = on ? a.soft.self_match[c] : 0, s_skew[c] = on ? a.soft.max_skew[c] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < MK; k++) {
+            const bool on = k < nk;
+            k_comp[k] = on ? a.plan.k_comp[k] : 0, k_unique[k] = on ? a.plan.k_unique[k] : 0, k_off[k] = on ? a.plan.k_off[k] : 0, k_len[k] = on ? a.plan.k_len[k] : 0;
+            k_aff[k] = on ? a.ipa.aff_terms_on_key[k] : 0; // required affinity terms over this key (they all read the same pair)
+            int anti = 0;
+            for (int q = 0; on && q < a.ipa.n_anti; q++) anti += a.ipa.anti_key[q] == k;
+            k_anti[k] = anti;
+            k_daff[k] = on && a.ipa.self_aff ? a.ipa.aff_terms_on_key[k] : 0, k_danti[k] = on ? a.ipa.anti_self_on_key[k] : 0;
+            k_dent[k] = on ? a.ipa.self_entries[k] : 0, k_dscore[k] = on ? a.ipa.score_self[k] : 0;
+        }
+        soft_w = a.soft.n > 0 ? a.soft.w : 0, ipa_w = a.ipa.on ? a.ipa.w : 0, ipa_filter = a.ipa.on && a.ipa.filter_on;
+        ipa_any_term = a.ipa.on && (a.ipa.n_aff || a.ipa.n_anti), self_aff = a.ipa.on ? a.ipa.self_aff : 0;
+    }
+};
+
 // one candidate's coupled verdict against the tables (minima of the hard constraints in L.mn).
 // `*dead`: the failure is permanent (required anti-affinity against pods that are there to stay: the counts only grow).
-__device__ __forceinline__ bool cw_coupled_ok(const CwDecideArgs &a, const CwLds &L, const int32_t *t, int64_t aff_total, int64_t exist_total,
+template <int MH, int MS, int MK>
+__device__ __forceinline__ bool cw_coupled_ok(const CwP<MH, MS, MK> &P, const CwLds &L, const int32_t *t, int64_t aff_total, int64_t exist_total,
                                               bool *dead) {
     bool ok = true;
-    for (int c = 0; c < a.pts.n; c++) { // PodTopologySpread.Filter (filtering.go:311-356)
-        const int32_t tv = t[a.plan.h_comp[c]];
-        int32_t v, m;
-        if (a.plan.h_unique[c]) v = tv & 1, m = tv >> 1;
-        else v = tv, m = v ? L.i32[a.plan.h_off[c] + v] : 0;
-        if (!v) ok = false;
-        const int64_t minm = a.pts.n_present[c] < a.pts.min_domains[c] ? 0 : (int64_t)L.mn[c];
-        if ((int64_t)m + a.pts.self_match[c] - minm > (int64_t)a.pts.max_skew[c]) ok = false;
-    }
-    if (a.ipa.on && a.ipa.filter_on && !(exist_total == 0 && a.ipa.n_aff == 0 && a.ipa.n_anti == 0)) { // filtering.go:410-432
-        bool pods_exist = true, aff_ok = true;
-        for (int q = 0; q < a.ipa.n_aff; q++) {
-            const int k = a.ipa.aff_key[q];
-            const int c0 = a.plan.k_comp[k];
-            const int32_t v = t[c0];
-            if (!v) aff_ok = false;
-            const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 1] : L.i64[a.plan.k_off[k] + v]);
-            if (cntv <= 0) pods_exist = false;
+#pragma unroll
+    for (int c = 0; c < MH; c++)
+        if (c < P.nh) { // PodTopologySpread.Filter (filtering.go:311-356)
+            const int32_t tv = t[P.h_comp[c]];
+            int32_t v, m;
+            if (P.h_unique[c]) v = tv & 1, m = tv >> 1;
+            else v = tv, m = v ? L.i32[P.h_off[c] + v] : 0;
+            if (!v) ok = false;
+            const int64_t minm = P.h_usemin[c] ? (int64_t)L.mn[c] : 0;
+            if ((int64_t)m + P.h_self[c] - minm > (int64_t)P.h_skew[c]) ok = false;
         }
-        if (!aff_ok || (!pods_exist && !(aff_total == 0 && a.ipa.self_aff))) ok = false;
-        for (int q = 0; q < a.ipa.n_anti; q++) {
-            const int k = a.ipa.anti_key[q];
-            const int c0 = a.plan.k_comp[k];
-            const int32_t v = t[c0];
-            const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 2] : L.i64[a.plan.k_off[k] + a.plan.k_len[k] + v]);
-            if (cntv > 0) ok = false, *dead = true;
-        }
-        if (exist_total > 0)
-            for (int k = 0; k < a.ipa.n_keys; k++) {
-                const int c0 = a.plan.k_comp[k];
+    if (P.ipa_filter && !(exist_total == 0 && !P.ipa_any_term)) { // filtering.go:410-432
+        bool pods_exist = true, aff_ok = true, any_aff = false;
+#pragma unroll
+        for (int k = 0; k < MK; k++)
+            if (k < P.nk) {
+                const int c0 = P.k_comp[k];
                 const int32_t v = t[c0];
-                const int64_t cntv = !v ? 0 : (a.plan.k_unique[k] ? (int64_t)t[c0 + 3] : L.i64[a.plan.k_off[k] + 2 * a.plan.k_len[k] + v]);
-                if (cntv > 0) ok = false, *dead = true;
+                if (P.k_aff[k]) { // satisfyPodAffinity :382-408
+                    any_aff = true;
+                    if (!v) aff_ok = false;
+                    const int64_t cntv = !v ? 0 : (P.k_unique[k] ? (int64_t)t[c0 + 1] : L.i64[P.k_off[k] + v]);
+                    if (cntv <= 0) pods_exist = false;
+                }
+                if (P.k_anti[k]) { // satisfyPodAntiAffinity :367-379
+                    const int64_t cntv = !v ? 0 : (P.k_unique[k] ? (int64_t)t[c0 + 2] : L.i64[P.k_off[k] + P.k_len[k] + v]);
+                    if (cntv > 0) ok = false, *dead = true;
+                }
+                if (exist_total > 0) { // satisfyExistingPodsAntiAffinity :352-364
+                    const int64_t cntv = !v ? 0 : (P.k_unique[k] ? (int64_t)t[c0 + 3] : L.i64[P.k_off[k] + 2 * P.k_len[k] + v]);
+                    if (cntv > 0) ok = false, *dead = true;
+                }
             }
+        if (any_aff && (!aff_ok || (!pods_exist && !(aff_total == 0 && P.self_aff)))) ok = false;
     }
     return ok;
 }
 
-__device__ __forceinline__ bool cw_soft_keys(const CwDecideArgs &a, const int32_t *t) {
+template <int MH, int MS, int MK>
+__device__ __forceinline__ bool cw_soft_keys(const CwP<MH, MS, MK> &P, const int32_t *t) {
     bool all = true;
-    for (int c = 0; c < a.soft.n; c++) {
-        const int32_t tv = t[a.plan.s_comp[c]];
-        all = all && (a.soft.is_hostname[c] ? (tv & 1) : tv) != 0;
-    }
+#pragma unroll
+    for (int c = 0; c < MS; c++)
+        if (c < P.ns) {
+            const int32_t tv = t[P.s_comp[c]];
+            all = all && (P.s_host[c] ? (tv & 1) : tv) != 0;
+        }
     return all;
 }
 
@@ -617,6 +666,7 @@ __device__ __forceinline__ int32_t cw_local_after(const CwDecideArgs &a, int64_t
 
 // (the argument block is read through a pointer: its arrays are indexed with runtime constraint numbers, which on a by-value
 // kernel argument means a 2.5 KB scratch copy per lane; from memory they are scalar loads)
+template <int MH, int MS, int MK>
 __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__restrict__ ap) {
     const CwDecideArgs &a = *ap;
     extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
@@ -681,6 +731,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
 
     if (tid < 64) {
         // ================= the cycle loop: wave 0 only, no block barriers =================
+        CwP<MH, MS, MK> P;
+        P.load(a);
         CW_TICK(0);
         int nt = 0, na = 0; // touched nodes ; how many of them may still win
         int64_t placed = S.placed, rounds = S.rounds;
@@ -692,8 +744,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
         uint32_t new_mt = mt_a, new_ma = ma_a;
         // unique-key hard constraints: (minimum, counted nodes at it) from the pass
         if (lane < kMaxTsc) L.u_min[lane] = 0x7fffffff, L.u_cnt[lane] = 0, L.mn[lane] = 0x7fffffff, L.soft_w[lane] = 0, L.soft_size[lane] = -1;
-        for (int c = 0; c < a.pts.n; c++)
-            if (a.plan.h_unique[c]) {
+#pragma unroll
+        for (int c = 0; c < MH; c++)
+            if (c < P.nh && P.h_unique[c]) {
                 uint32_t m = 0x7fffffffu;
                 for (int b = lane; b < a.w.n_blocks; b += 64) {
                     const uint32_t q = (uint32_t)(a.w.umin[(int64_t)b * kMaxTsc + c] >> 32);
@@ -716,23 +769,26 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
 #pragma unroll 1
         while (!end_window && !done && cycles < W) {
             // ---- minima of the hard constraints (filtering.go:298-305)
-            for (int c = 0; c < a.pts.n; c++) {
-                int32_t mc;
-                if (a.plan.h_unique[c]) mc = L.u_min[c];
-                else {
-                    uint32_t m = 0x7fffffffu;
-                    for (int v = 1 + lane; v < a.plan.h_len[c]; v += 64)
-                        if (L.i32[a.plan.h_pres[c] + v]) {
-                            const uint32_t q = (uint32_t)L.i32[a.plan.h_off[c] + v];
-                            m = q < m ? q : m;
-                        }
-                    mc = (int32_t)(0x7fffffffu - wave_max_u32(0x7fffffffu - m));
+#pragma unroll
+            for (int c = 0; c < MH; c++)
+                if (c < P.nh) {
+                    int32_t mc;
+                    if (P.h_unique[c]) mc = L.u_min[c];
+                    else {
+                        uint32_t m = 0x7fffffffu;
+                        for (int v = 1 + lane; v < P.h_len[c]; v += 64)
+                            if (L.i32[P.h_pres[c] + v]) {
+                                const uint32_t q = (uint32_t)L.i32[P.h_off[c] + v];
+                                m = q < m ? q : m;
+                            }
+                        mc = (int32_t)(0x7fffffffu - wave_max_u32(0x7fffffffu - m));
+                    }
+                    if (lane == 0) L.mn[c] = mc;
                 }
-                if (lane == 0) L.mn[c] = mc;
-            }
-            for (int c = 0; c < a.soft.n; c++)
-                if (!a.soft.is_hostname[c])
-                    for (int q = lane; q < (a.plan.s_len[c] + 31) / 32; q += 64) L.i32[a.plan.s_bm[c] + q] = 0;
+#pragma unroll
+            for (int c = 0; c < MS; c++)
+                if (c < P.ns && !P.s_host[c] && P.soft_w)
+                    for (int q = lane; q < (P.s_len[c] + 31) / 32; q += 64) L.i32[P.s_bm[c] + q] = 0;
             cw_lds_sync();
             const int ncand = C + na;
             // ---- stage 1: every candidate's verdict; feasible count, ignored count, maxima, candidate domains
@@ -747,8 +803,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                     const int32_t *t = is_cls ? L.c_tuple[q] : L.t_tuple[ti];
                     const bool node_ok = is_cls ? L.c_nf[q] > 0 : true;
                     bool dead = false;
-                    if (node_ok && cw_coupled_ok(a, L, t, aff_total, exist_total, &dead)) {
-                        const bool sk = cw_soft_keys(a, t);
+                    if (node_ok && cw_coupled_ok(P, L, t, aff_total, exist_total, &dead)) {
+                        const bool sk = cw_soft_keys(P, t);
                         fl = 1u | (sk ? 2u : 0u);
                         const uint32_t members = is_cls ? L.c_nf[q] : 1u;
                         nf += members;
@@ -757,12 +813,14 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                         mt_now = cm > mt_now ? cm : mt_now, ma_now = ca > ma_now ? ca : ma_now;
                         if (is_cls && (L.c_ht[q] == 0 || L.c_ha[q] == 0)) unknown = true; // the class's own maximum lost its last holder
                         if (is_cls && L.c_key[q] == 0ull) need_head = true;                 // its next head is not among the members kept
-                        if (sk)
-                            for (int c = 0; c < a.soft.n; c++)
-                                if (!a.soft.is_hostname[c]) {
-                                    const int32_t v = t[a.plan.s_comp[c]];
-                                    atomicOr((unsigned int *)&L.i32[a.plan.s_bm[c] + (v >> 5)], 1u << (v & 31));
+                        if (sk && P.soft_w) {
+#pragma unroll
+                            for (int c = 0; c < MS; c++)
+                                if (c < P.ns && !P.s_host[c]) {
+                                    const int32_t v = t[P.s_comp[c]];
+                                    atomicOr((unsigned int *)&L.i32[P.s_bm[c] + (v >> 5)], 1u << (v & 31));
                                 }
+                        }
                     }
                     L.e_fl[q] = fl;
                 }
@@ -783,22 +841,25 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             }
             if (cycles > 0 && (unknown || need_head || mt_now != mt_a || ma_now != ma_a)) break;
             // ---- stage 2: PodTopologySpread weights (scoring.go:96-113,294-296), raw scores, their min / max
-            const bool soft_on = a.soft.n > 0 && a.soft.w;
-            const bool ipa_on = a.ipa.on && a.ipa.w && entries > 0; // else PreScore Skip (scoring.go:199-201)
+            const bool soft_on = P.ns > 0 && P.soft_w;
+            const bool ipa_on = P.nk > 0 && P.ipa_w && entries > 0; // else PreScore Skip (scoring.go:199-201)
             int64_t p_mn = INT64_MAX, p_mx = 0, i_mn = INT64_MAX, i_mx = INT64_MIN;
             if (soft_on || ipa_on) {
                 cw_lds_sync(); // (the candidate bitmaps and flags above)
-                if (soft_on)
-                    for (int c = 0; c < a.soft.n; c++) {
-                        int64_t sz;
-                        if (a.soft.is_hostname[c]) sz = (int64_t)nf - (int64_t)nign;
-                        else {
-                            uint32_t bits = 0;
-                            for (int q = lane; q < (a.plan.s_len[c] + 31) / 32; q += 64) bits += (uint32_t)__popc((unsigned)L.i32[a.plan.s_bm[c] + q]);
-                            sz = wave_sum_u32_dpp(bits);
+                if (soft_on) {
+#pragma unroll
+                    for (int c = 0; c < MS; c++)
+                        if (c < P.ns) {
+                            int64_t sz;
+                            if (P.s_host[c]) sz = (int64_t)nf - (int64_t)nign;
+                            else {
+                                uint32_t bits = 0;
+                                for (int q = lane; q < (P.s_len[c] + 31) / 32; q += 64) bits += (uint32_t)__popc((unsigned)L.i32[P.s_bm[c] + q]);
+                                sz = wave_sum_u32_dpp(bits);
+                            }
+                            if (sz != L.soft_size[c] && lane == 0) L.soft_size[c] = sz, L.soft_w[c] = go_log((double)(sz + 2));
                         }
-                        if (sz != L.soft_size[c] && lane == 0) L.soft_size[c] = sz, L.soft_w[c] = go_log((double)(sz + 2));
-                    }
+                }
                 cw_lds_sync();
                 for (int base = 0; base < ncand; base += 64) {
                     const int q = base + lane;
@@ -806,22 +867,26 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                         const int32_t *t = q < C ? L.c_tuple[q] : L.t_tuple[L.alive[q - C]];
                         if (soft_on && (L.e_fl[q] & 2u)) { // scoring.go:196-223
                             double sc = 0;
-                            for (int c = 0; c < a.soft.n; c++) {
-                                const int32_t tv = t[a.plan.s_comp[c]];
-                                const int64_t ct = a.soft.is_hostname[c] ? (int64_t)(tv >> 1) : (int64_t)L.i32[a.plan.s_off[c] + tv];
-                                sc += (double)ct * L.soft_w[c] + (double)(a.soft.max_skew[c] - 1);
-                            }
+#pragma unroll
+                            for (int c = 0; c < MS; c++)
+                                if (c < P.ns) {
+                                    const int32_t tv = t[P.s_comp[c]];
+                                    const int64_t ct = P.s_host[c] ? (int64_t)(tv >> 1) : (int64_t)L.i32[P.s_off[c] + tv];
+                                    sc += (double)ct * L.soft_w[c] + (double)(P.s_skew[c] - 1);
+                                }
                             const int64_t raw = (int64_t)round(sc);
                             L.e_rp[q] = raw;
                             p_mn = raw < p_mn ? raw : p_mn, p_mx = raw > p_mx ? raw : p_mx;
                         }
                         if (ipa_on) { // scoring.go:226-247
                             int64_t raw = 0;
-                            for (int k = 0; k < a.ipa.n_keys; k++) {
-                                const int c0 = a.plan.k_comp[k];
-                                const int32_t v = t[c0];
-                                if (v) raw += a.plan.k_unique[k] ? (int64_t)t[c0 + 4] : L.i64[a.plan.k_off[k] + 3 * a.plan.k_len[k] + v];
-                            }
+#pragma unroll
+                            for (int k = 0; k < MK; k++)
+                                if (k < P.nk) {
+                                    const int c0 = P.k_comp[k];
+                                    const int32_t v = t[c0];
+                                    if (v) raw += P.k_unique[k] ? (int64_t)t[c0 + 4] : L.i64[P.k_off[k] + 3 * P.k_len[k] + v];
+                                }
                             L.e_ri[q] = raw;
                             i_mn = raw < i_mn ? raw : i_mn, i_mx = raw > i_mx ? raw : i_mx;
                         }
@@ -847,8 +912,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                     const int ti = q < C ? 0 : L.alive[q - C];
                     int64_t total = q < C ? key_score(hk) : (int64_t)L.t_A[ti];
                     const int64_t gi = q < C ? key_index(hk) : (int64_t)L.t_gidx[ti];
-                    if (soft_on && (L.e_fl[q] & 2u)) total += soft_normalize(L.e_rp[q], p_mn, p_mx) * a.soft.w; // ignored nodes score 0
-                    if (ipa_on) total += ipa_normalize(L.e_ri[q], i_mn, i_mx) * a.ipa.w;
+                    if (soft_on && (L.e_fl[q] & 2u)) total += soft_normalize(L.e_rp[q], p_mn, p_mx) * P.soft_w; // ignored nodes score 0
+                    if (ipa_on) total += ipa_normalize(L.e_ri[q], i_mn, i_mx) * P.ipa_w;
                     const uint64_t key = make_key(total, gi);
                     if (key > best) best = key, best_q = q;
                 }
@@ -891,46 +956,51 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             cw_lds_sync();
             const uint32_t el = L.t_elig[ti];
             // the clone is an existing pod of the next cycle: tables, the node's own entries, totals
-            for (int c = 0; c < a.pts.n; c++) { // filtering.go:255-296
-                const int q = a.plan.h_comp[c];
-                const int32_t tv = L.t_tuple[ti][q];
-                const bool counted = (el & 1u) && ((el >> (1 + c)) & 1u) && a.pts.self_match[c];
-                if (a.plan.h_unique[c]) {
-                    if (counted && (tv & 1)) {
-                        if ((tv >> 1) == L.u_min[c]) { // the winner leaves the minimum
-                            const uint32_t left = L.u_cnt[c] - 1;
-                            if (lane == 0) L.u_cnt[c] = left;
-                            if (left == 0) end_window = true; // the new minimum takes a pass over the nodes
+#pragma unroll
+            for (int c = 0; c < MH; c++)
+                if (c < P.nh) { // filtering.go:255-296
+                    const int q = P.h_comp[c];
+                    const int32_t tv = L.t_tuple[ti][q];
+                    const bool counted = (el & 1u) && ((el >> (1 + c)) & 1u) && P.h_self[c];
+                    if (P.h_unique[c]) {
+                        if (counted && (tv & 1)) {
+                            if ((tv >> 1) == L.u_min[c]) { // the winner leaves the minimum
+                                const uint32_t left = L.u_cnt[c] - 1;
+                                if (lane == 0) L.u_cnt[c] = left;
+                                if (left == 0) end_window = true; // the new minimum takes a pass over the nodes
+                            }
+                            if (lane == 0) L.t_tuple[ti][q] = tv + 2;
                         }
-                        if (lane == 0) L.t_tuple[ti][q] = tv + 2;
-                    }
-                } else if (counted && tv && lane == 0)
-                    L.i32[a.plan.h_off[c] + tv] += 1;
-            }
-            for (int c = 0; c < a.soft.n; c++) { // scoring.go:147-178
-                const int q = a.plan.s_comp[c];
-                const int32_t tv = L.t_tuple[ti][q];
-                const uint32_t se = el >> 16;
-                if (a.soft.is_hostname[c]) {
-                    if (a.soft.self_match[c] && lane == 0) L.t_tuple[ti][q] = tv + 2;
-                } else if (tv && (se & 1u) && ((se >> (1 + c)) & 1u) && a.soft.self_match[c] && lane == 0)
-                    L.i32[a.plan.s_off[c] + tv] += 1;
-            }
-            if (a.ipa.on)
-                for (int k = 0; k < a.ipa.n_keys; k++) { // filtering.go:204-272, scoring.go:81-125
-                    const int q = a.plan.k_comp[k];
+                    } else if (counted && tv && lane == 0)
+                        L.i32[P.h_off[c] + tv] += 1;
+                }
+#pragma unroll
+            for (int c = 0; c < MS; c++)
+                if (c < P.ns) { // scoring.go:147-178
+                    const int q = P.s_comp[c];
+                    const int32_t tv = L.t_tuple[ti][q];
+                    const uint32_t se = el >> 16;
+                    if (P.s_host[c]) {
+                        if (P.s_self[c] && lane == 0) L.t_tuple[ti][q] = tv + 2;
+                    } else if (tv && (se & 1u) && ((se >> (1 + c)) & 1u) && P.s_self[c] && lane == 0)
+                        L.i32[P.s_off[c] + tv] += 1;
+                }
+#pragma unroll
+            for (int k = 0; k < MK; k++)
+                if (k < P.nk) { // filtering.go:204-272, scoring.go:81-125
+                    const int q = P.k_comp[k];
                     const int32_t v = L.t_tuple[ti][q];
-                    if (!v) continue;
-                    const int64_t d_aff = a.ipa.self_aff && a.ipa.aff_terms_on_key[k] ? a.ipa.aff_terms_on_key[k] : 0;
-                    const int64_t d_anti = a.ipa.anti_self_on_key[k];
-                    aff_total += d_aff, exist_total += d_anti, entries += a.ipa.self_entries[k];
-                    if (lane == 0) {
-                        if (a.plan.k_unique[k]) {
-                            L.t_tuple[ti][q + 1] += (int32_t)d_aff, L.t_tuple[ti][q + 2] += (int32_t)d_anti, L.t_tuple[ti][q + 3] += (int32_t)d_anti;
-                            L.t_tuple[ti][q + 4] += (int32_t)a.ipa.score_self[k];
-                        } else {
-                            const int len = a.plan.k_len[k], o = a.plan.k_off[k];
-                            L.i64[o + v] += d_aff, L.i64[o + len + v] += d_anti, L.i64[o + 2 * len + v] += d_anti, L.i64[o + 3 * len + v] += a.ipa.score_self[k];
+                    if (v) {
+                        const int64_t d_aff = P.k_daff[k], d_anti = P.k_danti[k];
+                        aff_total += d_aff, exist_total += d_anti, entries += P.k_dent[k];
+                        if (lane == 0) {
+                            if (P.k_unique[k]) {
+                                L.t_tuple[ti][q + 1] += (int32_t)d_aff, L.t_tuple[ti][q + 2] += (int32_t)d_anti, L.t_tuple[ti][q + 3] += (int32_t)d_anti;
+                                L.t_tuple[ti][q + 4] += (int32_t)P.k_dscore[k];
+                            } else {
+                                const int len = P.k_len[k], o = P.k_off[k];
+                                L.i64[o + v] += d_aff, L.i64[o + len + v] += d_anti, L.i64[o + 2 * len + v] += d_anti, L.i64[o + 3 * len + v] += P.k_dscore[k];
+                            }
                         }
                     }
                 }
@@ -943,7 +1013,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             // does the node stay a candidate?  Full, or blocked for good by its own clone (required anti-affinity): no.
             {
                 bool dead = A_next < 0;
-                if (!dead) (void)cw_coupled_ok(a, L, L.t_tuple[ti], aff_total, exist_total, &dead);
+                if (!dead) (void)cw_coupled_ok(P, L, L.t_tuple[ti], aff_total, exist_total, &dead);
                 const bool was_alive = wq >= C;
                 if (!dead && !was_alive) {
                     if (lane == 0) L.alive[na] = ti;
@@ -967,7 +1037,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             S.winner = -1;
             if (stale_maxima) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
             if (giveup) S.cw_fallback = 1;
-            for (int c = 0; c < a.pts.n; c++) S.pts_min_a[c] = L.mn[c]; // (the terminal histogram reads it: k_hist)
+            for (int c = 0; c < P.nh; c++) S.pts_min_a[c] = L.mn[c]; // (the terminal histogram reads it: k_hist)
             S.cw_windows += 1;
             S.done = done;
             L.s_nt = nt;

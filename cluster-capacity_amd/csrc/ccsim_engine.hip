@@ -851,29 +851,30 @@ static int cw_make_plan(ccsim_engine *e) {
         return true;
     };
     CwPlan pl{};
-    int comp = 0, i32 = 0, i64 = 0;
-    for (int c = 0; c < e->pts.n; c++) {
+    int i32 = 0, i64 = 0;
+    if (e->pts.n > kCwMaxCons || e->soft.n > kCwMaxCons) return no("more than four hard / four soft spread constraints");
+    for (int c = 0; c < e->pts.n; c++) { // tuple positions are fixed (ccsim_coupled.h kCwTuple)
         const int len = (int)e->pts_table_len[(size_t)c];
-        pl.h_comp[c] = comp++, pl.h_unique[c] = unique(e->pts_col[(size_t)c]) ? 1 : 0, pl.h_len[c] = len;
+        pl.h_comp[c] = c, pl.h_unique[c] = unique(e->pts_col[(size_t)c]) ? 1 : 0, pl.h_len[c] = len;
         pl.h_present[c] = e->pts_present[(size_t)c];
         if (!pl.h_unique[c]) pl.h_off[c] = i32, pl.h_pres[c] = i32 + len, i32 += 2 * len;
     }
     const size_t soft_first = e->pts_tables.size() - (size_t)e->soft.n; // (soft tables follow the hard ones)
     for (int c = 0; c < e->soft.n; c++) {
         const int len = (int)e->pts_table_len[soft_first + (size_t)c];
-        pl.s_comp[c] = comp++, pl.s_len[c] = len;
+        pl.s_comp[c] = kCwMaxCons + c, pl.s_len[c] = len;
         if (!e->soft.is_hostname[c]) pl.s_off[c] = i32, pl.s_bm[c] = i32 + len, i32 += len + (len + 31) / 32;
     }
     if (e->ipa.on)
         for (int k = 0; k < e->ipa.n_keys; k++) {
             const int len = (int)e->ipa_table_len[(size_t)k * 4];
-            pl.k_unique[k] = unique(e->ipa_col[(size_t)k]) ? 1 : 0, pl.k_len[k] = len;
-            pl.k_comp[k] = comp, comp += pl.k_unique[k] ? 5 : 1;
+            const int pos[4] = {kCwKeyPos0, kCwKeyPos1, kCwKeyPos2, kCwKeyPos3};
+            pl.k_unique[k] = unique(e->ipa_col[(size_t)k]) ? 1 : 0, pl.k_len[k] = len, pl.k_comp[k] = pos[k];
+            if (pl.k_unique[k] && k >= 2) return no("a unique-per-node topology key beyond the second inter-pod affinity key");
             if (!pl.k_unique[k]) pl.k_off[k] = i64, i64 += 4 * len;
         }
-    if (comp > kCwTuple) return no("more plugin inputs per node than a class tuple holds");
     if (i32 > kCwLdsI32 || i64 > kCwLdsI64) return no("shared-key tables exceed the decide kernel's LDS budget");
-    pl.n_comp = comp, pl.i32_words = i32, pl.i64_words = i64;
+    pl.n_comp = kCwTuple, pl.i32_words = i32, pl.i64_words = i64;
     pl.window = 64, pl.list_len = 16;
     if (const char *f = getenv("CCSIM_CW_WINDOW")) pl.window = atoi(f); // tuning / test knobs
     if (const char *f = getenv("CCSIM_CW_LIST")) pl.list_len = atoi(f);
@@ -1347,8 +1348,10 @@ static void launch_cw_window(ccsim_engine *e) {
     else hipLaunchKernelGGL((k_cw_scan<kMaxExtra, false>), g, b, 0, e->stream, sa);
     const CwTopArgs ta{e->cols, e->d_state, e->cw_work, e->cw_plan.list_len};
     hipLaunchKernelGGL(k_cw_top, g, b, 0, e->stream, ta);
-    hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), b, 0, e->stream, ta);
-    hipLaunchKernelGGL(k_cw_decide, dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
+    hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), dim3(kCwMergeThreads), 0, e->stream, ta);
+    const bool small = e->pts.n <= 2 && e->soft.n <= 2 && (!e->ipa.on || e->ipa.n_keys <= 2);
+    if (small) hipLaunchKernelGGL((k_cw_decide<2, 2, 2>), dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
+    else hipLaunchKernelGGL((k_cw_decide<4, 4, 4>), dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
 }
 
 static int run_cw(ccsim_engine *e) {
@@ -1356,7 +1359,8 @@ static int run_cw(ccsim_engine *e) {
     static bool attr_set = false;
     if (e->cw_work.prof) HIPCHK(e, hipMemsetAsync(e->cw_work.prof, 0, 16 * sizeof(unsigned long long), e->stream));
     if (!attr_set) {
-        HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         attr_set = true;
     }
     // the decide kernel reads its argument block from memory (pointers and constants of this run)
