@@ -150,6 +150,7 @@ struct ccsim_engine {
     size_t cw_zero_bytes = 0;
     int cw_allowed = 1;
     bool cw_run = false;                         // the current run takes the windowed path
+    bool cw_fast = false;                        // ... and may use the lane-per-candidate decide kernel (k_cw_decide_fast)
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
     int dist_pass_in_window = 0;      // passes since the last ccsim_dist_begin / ccsim_dist_poll
@@ -204,6 +205,7 @@ static int dev_alloc(ccsim_engine *e, T **out, size_t count, std::vector<void *>
 struct ccsim_engine;
 static int build_narrow(ccsim_engine *e);
 static int cw_make_plan(ccsim_engine *e);
+static bool label_col_unique(const ccsim_engine *e, int col);
 static int persist_k(const ccsim_engine *e);
 
 template <typename T>
@@ -748,15 +750,30 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         HIPCHK(e, hipMemcpy(lc.data(), e->d_label_cols, sizeof(int32_t *) * CCSIM_MAX_LABEL_COLS, hipMemcpyDeviceToHost));
         IpaInitArgs ii{};
         ii.n = e->n;
+        // The engine's own key order: keys whose values are unique per node first (the windowed mode keeps their table entries in
+        // the class tuple at fixed positions, ccsim_coupled.h).  Internal only -- and only on an unsharded snapshot: across ranks
+        // the order must be the same, and uniqueness inside a shard says nothing about the cluster.
+        int perm[CCSIM_MAX_IPA_KEYS], inv[CCSIM_MAX_IPA_KEYS]; // perm[new] = caller's index
+        {
+            int nn = 0;
+            const bool reorder = e->global_offset == 0 && e->n_global == e->n;
+            for (int pass = 0; pass < 2; pass++)
+                for (int k = 0; k < ip.n_keys; k++) {
+                    if (ip.key_col[k] < 0 || ip.key_col[k] >= e->n_label_cols || ip.key_ndom[k] < 0) return fail(e, -EINVAL, "bad inter-pod affinity key");
+                    const bool u = reorder && label_col_unique(e, ip.key_col[k]);
+                    if (u == (pass == 0)) perm[nn++] = k;
+                }
+            for (int k = 0; k < ip.n_keys; k++) inv[perm[k]] = k;
+        }
         for (int t = 0; t < ip.n_aff_terms; t++) {
             if (ip.aff_key[t] < 0 || ip.aff_key[t] >= ip.n_keys) return fail(e, -EINVAL, "affinity term key out of range");
-            d.aff_key[t] = ip.aff_key[t];
-            d.aff_terms_on_key[ip.aff_key[t]]++;
+            d.aff_key[t] = inv[ip.aff_key[t]];
+            d.aff_terms_on_key[inv[ip.aff_key[t]]]++;
         }
         for (int t = 0; t < ip.n_anti_terms; t++) {
             if (ip.anti_key[t] < 0 || ip.anti_key[t] >= ip.n_keys) return fail(e, -EINVAL, "anti-affinity term key out of range");
-            d.anti_key[t] = ip.anti_key[t];
-            if (ip.anti_self[t]) d.anti_self_on_key[ip.anti_key[t]]++;
+            d.anti_key[t] = inv[ip.anti_key[t]];
+            if (ip.anti_self[t]) d.anti_self_on_key[inv[ip.anti_key[t]]]++;
             int32_t *ex = nullptr;
             if (ip.anti_existing[t] && (rc = upload(e, &ex, ip.anti_existing[t], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
             ii.anti_existing[t] = ex;
@@ -765,12 +782,12 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         if (ip.aff_existing && (rc = upload(e, &affex, ip.aff_existing, (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
         ii.aff_existing = affex;
         for (int k = 0; k < ip.n_keys; k++) {
-            if (ip.key_col[k] < 0 || ip.key_col[k] >= e->n_label_cols || ip.key_ndom[k] < 0) return fail(e, -EINVAL, "bad inter-pod affinity key");
-            d.label[k] = lc[ip.key_col[k]];
-            e->ipa_col.push_back(ip.key_col[k]);
-            d.score_self[k] = ip.score_self[k];
-            d.self_entries[k] = ip.self_entries[k];
-            const size_t len = (size_t)ip.key_ndom[k] + 1;
+            const int o = perm[k]; // the caller's index of the engine's key k
+            d.label[k] = lc[ip.key_col[o]];
+            e->ipa_col.push_back(ip.key_col[o]);
+            d.score_self[k] = ip.score_self[o];
+            d.self_entries[k] = ip.self_entries[o];
+            const size_t len = (size_t)ip.key_ndom[o] + 1;
             int64_t **tabs[4] = {&d.aff[k], &d.anti[k], &d.exist[k], &d.score[k]};
             for (auto tp : tabs) {
                 int64_t *live = nullptr, *prist = nullptr;
@@ -782,8 +799,8 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             }
             int32_t *ea = nullptr;
             int64_t *sx = nullptr;
-            if (ip.exist_anti[k] && (rc = upload(e, &ea, ip.exist_anti[k], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
-            if (ip.score_existing[k] && (rc = upload(e, &sx, ip.score_existing[k], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            if (ip.exist_anti[o] && (rc = upload(e, &ea, ip.exist_anti[o], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            if (ip.score_existing[o] && (rc = upload(e, &sx, ip.score_existing[o], (size_t)e->n, (size_t)e->n_pad, e->pod_allocs))) return rc;
             ii.exist_anti[k] = ea, ii.score_existing[k] = sx;
         }
         unsigned long long *d_tot = nullptr;
@@ -833,6 +850,17 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
 // Which keys are unique per node (their "domain" is the node: table entries become class-tuple components), where every
 // component sits, which shared-key tables the decide kernel keeps in LDS; the work buffers.  Anything that does not fit
 // leaves cw_ok false with the reason: the one-pass-per-placement loop then runs, as before.
+static bool label_col_unique(const ccsim_engine *e, int col) { // every value of the key sits on at most one node (hostname-like)
+    const std::vector<int32_t> &v = e->h_label_cols[(size_t)col];
+    std::vector<uint8_t> seen((size_t)e->label_col_max[(size_t)col] + 1, 0);
+    for (int32_t x : v)
+        if (x) {
+            if (seen[(size_t)x]) return false;
+            seen[(size_t)x] = 1;
+        }
+    return true;
+}
+
 static int cw_make_plan(ccsim_engine *e) {
     e->cw_ok = false;
     const bool coupled = e->pts.n > 0 || e->soft.n > 0 || e->ipa.on;
@@ -840,16 +868,7 @@ static int cw_make_plan(ccsim_engine *e) {
     auto no = [&](const char *why) { e->cw_why = why; return 0; };
     if (!e->cw_allowed) return no("disabled (CCSIM_CW=0)");
     if (e->n <= 0) return no("empty snapshot");
-    auto unique = [&](int col) {
-        const std::vector<int32_t> &v = e->h_label_cols[(size_t)col];
-        std::vector<uint8_t> seen((size_t)e->label_col_max[(size_t)col] + 1, 0);
-        for (int32_t x : v)
-            if (x) {
-                if (seen[(size_t)x]) return false;
-                seen[(size_t)x] = 1;
-            }
-        return true;
-    };
+    auto unique = [&](int col) { return label_col_unique(e, col); };
     CwPlan pl{};
     int i32 = 0, i64 = 0;
     if (e->pts.n > kCwMaxCons || e->soft.n > kCwMaxCons) return no("more than four hard / four soft spread constraints");
@@ -908,6 +927,8 @@ static int cw_make_plan(ccsim_engine *e) {
     if ((rc = dev_alloc(e, &argbuf, sizeof(CwDecideArgs), e->pod_allocs))) return rc;
     e->d_cw_args = argbuf;
     e->cw_plan = pl, e->cw_work = w, e->cw_ok = true, e->cw_why.clear();
+    e->cw_fast = e->pts.n <= 2 && !(e->soft.n > 0 && e->soft.w) && (!e->ipa.on || e->ipa.n_keys <= 2);
+    if (const char *f = getenv("CCSIM_CW_FAST")) e->cw_fast = e->cw_fast && atoi(f) != 0; // A/B knob
     return 0;
 }
 
@@ -1349,6 +1370,8 @@ static void launch_cw_window(ccsim_engine *e) {
     const CwTopArgs ta{e->cols, e->d_state, e->cw_work, e->cw_plan.list_len};
     hipLaunchKernelGGL(k_cw_top, g, b, 0, e->stream, ta);
     hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), dim3(kCwMergeThreads), 0, e->stream, ta);
+    // lane = candidate form first (it declines, untouched, whatever it does not cover); the general form right behind it
+    if (e->cw_fast) hipLaunchKernelGGL(k_cw_decide_fast, dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
     const bool small = e->pts.n <= 2 && e->soft.n <= 2 && (!e->ipa.on || e->ipa.n_keys <= 2);
     if (small) hipLaunchKernelGGL((k_cw_decide<2, 2, 2>), dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
     else hipLaunchKernelGGL((k_cw_decide<4, 4, 4>), dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
@@ -1360,6 +1383,7 @@ static int run_cw(ccsim_engine *e) {
     if (e->cw_work.prof) HIPCHK(e, hipMemsetAsync(e->cw_work.prof, 0, 16 * sizeof(unsigned long long), e->stream));
     if (!attr_set) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         attr_set = true;
     }
