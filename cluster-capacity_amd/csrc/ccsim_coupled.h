@@ -529,6 +529,7 @@ struct CwLds {
     double soft_w[kMaxTsc];
     long long soft_size[kMaxTsc];
     int32_t s_nt;
+    unsigned long long pf[8]; // k_cw_decide_fast: phase ticks of a measurement run
 };
 
 // LDS traffic inside one wave needs no barrier, only the data back: wait for the LDS / scalar counters, not for HBM stores
@@ -684,6 +685,10 @@ __device__ __forceinline__ uint64_t rl64(uint64_t v, int src) {
 }
 __device__ __forceinline__ int32_t wave_min_i32_nonneg(int32_t v) { return (int32_t)(0x7fffffffu - wave_max_u32(0x7fffffffu - (uint32_t)v)); }
 
+// The shape of the pod is a template argument: NH hard constraints, bit c of HU = constraint c is over a unique-per-node key;
+// NK inter-pod keys, bit k of KU = key k is unique per node.  A runtime flag costs an SGPR and a branch in every cycle, and
+// the first (runtime-flag) form of this kernel spent a third of its instructions moving spilled SGPRs through VGPR lanes.
+template <int NH, int HU, int NK, int KU>
 __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArgs *__restrict__ ap) {
     const CwDecideArgs &a = *ap;
     extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
@@ -694,18 +699,19 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     const int tid = threadIdx.x, lane = tid & 63;
     const int LL = a.plan.list_len, W = a.plan.window < kCwMaxWindow ? a.plan.window : kCwMaxWindow;
     const int C = (int)a.w.ctl[kCwCtlClasses];
-    const int nh = a.pts.n, nk = a.ipa.on ? a.ipa.n_keys : 0;
+    constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
-    bool fits = C <= kCwFastClasses && C * LL <= kCwListLds && nh <= 2 && nk <= 2 && !(a.soft.n > 0 && a.soft.w);
-    for (int c = 0; c < nh && c < 2; c++) fits = fits && (a.plan.h_unique[c] || a.plan.h_len[c] <= 64);
-    if (nk > 0 && a.ipa.w) { // PreScore must skip for the whole window: no entries now, none added by a clone (scoring.go:199-201)
-        fits = fits && S.ipa_entries == 0;
-        for (int k = 0; k < nk && k < 2; k++) fits = fits && a.ipa.self_entries[k] == 0;
+    bool fits = C <= kCwFastClasses && C * LL <= kCwListLds;
+    if (NH > 0 && !HU0) fits = fits && a.plan.h_len[0] <= 64;
+    if (NH > 1 && !HU1) fits = fits && a.plan.h_len[1] <= 64;
+    if (NK > 0 && a.ipa.w) { // PreScore must skip for the whole window: no entries now, none added by a clone (scoring.go:199-201)
+        fits = fits && S.ipa_entries == 0 && a.ipa.self_entries[0] == 0;
+        if (NK > 1) fits = fits && a.ipa.self_entries[1] == 0;
     }
     if (!fits) return;
-    unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(), pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool prof = a.w.prof != nullptr;
-#define CW_TICK(i) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+    unsigned long long t_prev = prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define CW_TICK(i) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); if (lane == 0) L.pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     // ---- prologue (all threads): the node facts of every list entry -> LDS
     for (int q = tid; q < C * LL; q += kCwThreads) {
@@ -719,50 +725,49 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         }
     }
     if (tid == 0) L.s_nt = -1; // -1: the window was not taken
+    if (tid < 8) L.pf[tid] = 0;
     __syncthreads();
 
     if (tid < 64) {
-        // ---- uniform parameters (SGPRs)
-        const int h_unique0 = nh > 0 ? a.plan.h_unique[0] : 0, h_unique1 = nh > 1 ? a.plan.h_unique[1] : 0;
-        const int h_self0 = nh > 0 ? a.pts.self_match[0] : 0, h_self1 = nh > 1 ? a.pts.self_match[1] : 0;
-        const int h_skew0 = nh > 0 ? a.pts.max_skew[0] : 0, h_skew1 = nh > 1 ? a.pts.max_skew[1] : 0;
-        const int h_usemin0 = nh > 0 && !(a.pts.n_present[0] < a.pts.min_domains[0]), h_usemin1 = nh > 1 && !(a.pts.n_present[1] < a.pts.min_domains[1]);
-        const int k_unique0 = nk > 0 ? a.plan.k_unique[0] : 0, k_unique1 = nk > 1 ? a.plan.k_unique[1] : 0;
-        const int k_aff0 = nk > 0 ? a.ipa.aff_terms_on_key[0] : 0, k_aff1 = nk > 1 ? a.ipa.aff_terms_on_key[1] : 0;
+        // ---- uniform parameters (SGPRs; what the shape does not use is never loaded)
+        const int h_self0 = NH > 0 ? a.pts.self_match[0] : 0, h_self1 = NH > 1 ? a.pts.self_match[1] : 0;
+        const int h_skew0 = NH > 0 ? a.pts.max_skew[0] : 0, h_skew1 = NH > 1 ? a.pts.max_skew[1] : 0;
+        const bool h_usemin0 = NH > 0 && !(a.pts.n_present[0] < a.pts.min_domains[0]), h_usemin1 = NH > 1 && !(a.pts.n_present[1] < a.pts.min_domains[1]);
+        const int k_aff0 = NK > 0 ? a.ipa.aff_terms_on_key[0] : 0, k_aff1 = NK > 1 ? a.ipa.aff_terms_on_key[1] : 0;
         int k_anti0 = 0, k_anti1 = 0;
-        for (int q = 0; nk > 0 && q < a.ipa.n_anti; q++) k_anti0 += a.ipa.anti_key[q] == 0, k_anti1 += a.ipa.anti_key[q] == 1;
-        const int k_daff0 = nk > 0 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[0] : 0, k_daff1 = nk > 1 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[1] : 0;
-        const int k_danti0 = nk > 0 ? a.ipa.anti_self_on_key[0] : 0, k_danti1 = nk > 1 ? a.ipa.anti_self_on_key[1] : 0;
-        const bool ipa_filter = nk > 0 && a.ipa.filter_on, ipa_any_term = nk > 0 && (a.ipa.n_aff || a.ipa.n_anti), self_aff = nk > 0 && a.ipa.self_aff;
+        for (int q = 0; NK > 0 && q < a.ipa.n_anti; q++) k_anti0 += a.ipa.anti_key[q] == 0, k_anti1 += a.ipa.anti_key[q] == 1;
+        const int k_daff0 = NK > 0 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[0] : 0, k_daff1 = NK > 1 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[1] : 0;
+        const int k_danti0 = NK > 0 ? a.ipa.anti_self_on_key[0] : 0, k_danti1 = NK > 1 ? a.ipa.anti_self_on_key[1] : 0;
+        const int k_dent0 = NK > 0 ? a.ipa.self_entries[0] : 0, k_dent1 = NK > 1 ? a.ipa.self_entries[1] : 0;
+        const bool ipa_filter = NK > 0 && a.ipa.filter_on, ipa_any_term = NK > 0 && (a.ipa.n_aff || a.ipa.n_anti), self_aff = NK > 0 && a.ipa.self_aff;
         const bool any_aff = k_aff0 || k_aff1;
         const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
         const bool track = a.p.w_taint != 0 || a.p.w_aff != 0; // else every count / sum is 0 and the maxima cannot move
 
         // ---- lane = candidate: the class records into registers
-        const bool is_class_lane = lane < C;
         int32_t hv0 = 0, hv1 = 0, hc0 = 0, hc1 = 0, kv0 = 0, kv1 = 0, kf0 = 0, kf1 = 0, kn0 = 0, kn1 = 0, ke0 = 0, ke1 = 0;
         uint32_t nfm = 0, cmt = 0, cma = 0, cht = 0, cha = 0, el = 0;
         int32_t head = 0, tix = -1;
         uint64_t key = 0;
         bool is_cls = false, over = false;
-        if (is_class_lane) {
+        if (lane < C) {
             const CwClass &k = a.w.cls[a.w.slot_of_id[lane]];
             nfm = k.nf, cmt = k.mt, cma = k.ma, cht = k.ht, cha = k.ha, is_cls = true;
             key = L.li_key[lane * LL];
-            if (nh > 0) hv0 = k.tuple[0], hc0 = h_unique0 ? hv0 >> 1 : (hv0 ? a.pts.tbl[0][hv0] : 0);
-            if (nh > 1) hv1 = k.tuple[1], hc1 = h_unique1 ? hv1 >> 1 : (hv1 ? a.pts.tbl[1][hv1] : 0);
-            if (nk > 0) {
+            if (NH > 0) hv0 = k.tuple[0], hc0 = HU0 ? hv0 >> 1 : (hv0 ? a.pts.tbl[0][hv0] : 0);
+            if (NH > 1) hv1 = k.tuple[1], hc1 = HU1 ? hv1 >> 1 : (hv1 ? a.pts.tbl[1][hv1] : 0);
+            if (NK > 0) {
                 kv0 = k.tuple[kCwKeyPos0];
-                if (k_unique0) kf0 = k.tuple[kCwKeyPos0 + 1], kn0 = k.tuple[kCwKeyPos0 + 2], ke0 = k.tuple[kCwKeyPos0 + 3];
+                if (KU0) kf0 = k.tuple[kCwKeyPos0 + 1], kn0 = k.tuple[kCwKeyPos0 + 2], ke0 = k.tuple[kCwKeyPos0 + 3];
                 else if (kv0) {
                     const int64_t x = a.ipa.aff[0][kv0], y = a.ipa.anti[0][kv0], z = a.ipa.exist[0][kv0];
                     over = over || x > 0x3fffffff || y > 0x3fffffff || z > 0x3fffffff;
                     kf0 = (int32_t)x, kn0 = (int32_t)y, ke0 = (int32_t)z;
                 }
             }
-            if (nk > 1) {
+            if (NK > 1) {
                 kv1 = k.tuple[kCwKeyPos1];
-                if (k_unique1) kf1 = k.tuple[kCwKeyPos1 + 1], kn1 = k.tuple[kCwKeyPos1 + 2], ke1 = k.tuple[kCwKeyPos1 + 3];
+                if (KU1) kf1 = k.tuple[kCwKeyPos1 + 1], kn1 = k.tuple[kCwKeyPos1 + 2], ke1 = k.tuple[kCwKeyPos1 + 3];
                 else if (kv1) {
                     const int64_t x = a.ipa.aff[1][kv1], y = a.ipa.anti[1][kv1], z = a.ipa.exist[1][kv1];
                     over = over || x > 0x3fffffff || y > 0x3fffffff || z > 0x3fffffff;
@@ -773,76 +778,77 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         // lane = domain (shared-key hard constraints): count and presence, for the minimum
         int32_t dc0 = 0, dc1 = 0;
         bool dp0 = false, dp1 = false;
-        if (nh > 0 && !h_unique0 && lane >= 1 && lane < a.plan.h_len[0]) dc0 = a.pts.tbl[0][lane], dp0 = a.plan.h_present[0][lane] != 0;
-        if (nh > 1 && !h_unique1 && lane >= 1 && lane < a.plan.h_len[1]) dc1 = a.pts.tbl[1][lane], dp1 = a.plan.h_present[1][lane] != 0;
-        // unique-key hard constraints: (minimum, counted nodes at it) from the pass
-        int32_t um0 = 0x7fffffff, um1 = 0x7fffffff;
-        uint32_t uc0 = 0, uc1 = 0;
-        for (int c = 0; c < nh; c++)
-            if (c == 0 ? h_unique0 : h_unique1) {
-                uint32_t m = 0x7fffffffu;
-                for (int b = lane; b < a.w.n_blocks; b += 64) {
-                    const uint32_t q = (uint32_t)(a.w.umin[(int64_t)b * kMaxTsc + c] >> 32);
-                    m = q < m ? q : m;
+        if (NH > 0 && !HU0 && lane >= 1 && lane < a.plan.h_len[0]) dc0 = a.pts.tbl[0][lane], dp0 = a.plan.h_present[0][lane] != 0;
+        if (NH > 1 && !HU1 && lane >= 1 && lane < a.plan.h_len[1]) dc1 = a.pts.tbl[1][lane], dp1 = a.plan.h_present[1][lane] != 0;
+        // the minimum of a hard constraint and how many domains sit at it (filtering.go:298-305): counts only grow, so the minimum
+        // moves only when the last domain at it is taken -- shared keys: recomputed then (one DPP reduction); unique keys: the
+        // pass's (minimum, nodes at it), and the window ends when they run out
+        int32_t min0 = 0x7fffffff, min1 = 0x7fffffff;
+        uint32_t nmin0 = 0, nmin1 = 0;
+        bool remin0 = NH > 0 && !HU0, remin1 = NH > 1 && !HU1;
+        if ((NH > 0 && HU0) || (NH > 1 && HU1))
+            for (int c = 0; c < NH; c++)
+                if (c == 0 ? HU0 : HU1) {
+                    uint32_t m = 0x7fffffffu;
+                    for (int b = lane; b < a.w.n_blocks; b += 64) {
+                        const uint32_t q = (uint32_t)(a.w.umin[(int64_t)b * kMaxTsc + c] >> 32);
+                        m = q < m ? q : m;
+                    }
+                    m = 0x7fffffffu - wave_max_u32(0x7fffffffu - m);
+                    uint32_t n_at = 0;
+                    for (int b = lane; b < a.w.n_blocks; b += 64) {
+                        const unsigned long long q = a.w.umin[(int64_t)b * kMaxTsc + c];
+                        if ((uint32_t)(q >> 32) == m) n_at += (uint32_t)q;
+                    }
+                    n_at = wave_sum_u32_dpp(n_at);
+                    if (c == 0) min0 = (int32_t)m, nmin0 = n_at; else min1 = (int32_t)m, nmin1 = n_at;
                 }
-                m = 0x7fffffffu - wave_max_u32(0x7fffffffu - m);
-                uint32_t n_at = 0;
-                for (int b = lane; b < a.w.n_blocks; b += 64) {
-                    const unsigned long long q = a.w.umin[(int64_t)b * kMaxTsc + c];
-                    if ((uint32_t)(q >> 32) == m) n_at += (uint32_t)q;
-                }
-                n_at = wave_sum_u32_dpp(n_at);
-                if (c == 0) um0 = (int32_t)m, uc0 = n_at; else um1 = (int32_t)m, uc1 = n_at;
-            }
         if (__ballot(over) == 0ull) { // (else: an entry beyond int32 -- the general kernel's business)
             int ncand = C, nt = 0;
-            int64_t placed = S.placed, rounds = S.rounds;
-            const int64_t limit = S.limit, log_cap = S.log_cap;
+            int64_t placed = S.placed;
+            const int64_t placed0 = placed, limit = S.limit, log_cap = S.log_cap;
             int64_t aff_total = S.ipa_aff_total, exist_total = S.ipa_exist_total, entries = S.ipa_entries;
-            const int k_dent0 = nk > 0 ? a.ipa.self_entries[0] : 0, k_dent1 = nk > 1 ? a.ipa.self_entries[1] : 0;
-            int done = 0, last_feasible = S.last_feasible, cycles = 0;
-            bool stale_maxima = false, end_window = false;
-            uint32_t new_mt = mt_a, new_ma = ma_a;
-            int32_t min0 = 0x7fffffff, min1 = 0x7fffffff;
+            int done = 0, cycles = 0;
+            bool stale_maxima = false, end_window = false, unsched = false;
+            uint32_t new_mt = mt_a, new_ma = ma_a, lf = 0; // lf: this lane's share of the feasible count of the last cycle
             CW_TICK(0);
 #pragma unroll 1
             while (!end_window && !done && cycles < W && ncand < 64) {
-                // ---- minima (filtering.go:298-305)
-                if (nh > 0) min0 = h_unique0 ? um0 : wave_min_i32_nonneg(dp0 ? dc0 : 0x7fffffff);
-                if (nh > 1) min1 = h_unique1 ? um1 : wave_min_i32_nonneg(dp1 ? dc1 : 0x7fffffff);
+                if (NH > 0 && !HU0 && remin0) min0 = wave_min_i32_nonneg(dp0 ? dc0 : 0x7fffffff), nmin0 = (uint32_t)__popcll(__ballot(dp0 && dc0 == min0)), remin0 = false;
+                if (NH > 1 && !HU1 && remin1) min1 = wave_min_i32_nonneg(dp1 ? dc1 : 0x7fffffff), nmin1 = (uint32_t)__popcll(__ballot(dp1 && dc1 == min1)), remin1 = false;
                 // ---- verdicts (filtering.go:311-356, interpodaffinity/filtering.go:410-432)
                 bool ok = lane < ncand && nfm > 0;
-                if (nh > 0) {
-                    const int32_t v = h_unique0 ? (hv0 & 1) : hv0;
-                    ok = ok && v && (int64_t)hc0 + h_self0 - (h_usemin0 ? (int64_t)min0 : 0) <= (int64_t)h_skew0;
-                }
-                if (nh > 1) {
-                    const int32_t v = h_unique1 ? (hv1 & 1) : hv1;
-                    ok = ok && v && (int64_t)hc1 + h_self1 - (h_usemin1 ? (int64_t)min1 : 0) <= (int64_t)h_skew1;
-                }
-                if (ipa_filter && !(exist_total == 0 && !ipa_any_term)) {
-                    bool pods_exist = true, aff_ok = true;
-                    if (k_aff0) aff_ok = aff_ok && kv0, pods_exist = pods_exist && kv0 && kf0 > 0;
-                    if (k_aff1) aff_ok = aff_ok && kv1, pods_exist = pods_exist && kv1 && kf1 > 0;
-                    if (any_aff && (!aff_ok || (!pods_exist && !(aff_total == 0 && self_aff)))) ok = false;
+                if (NH > 0) ok = ok && (HU0 ? (hv0 & 1) : hv0) && hc0 + h_self0 - (h_usemin0 ? min0 : 0) <= h_skew0;
+                if (NH > 1) ok = ok && (HU1 ? (hv1 & 1) : hv1) && hc1 + h_self1 - (h_usemin1 ? min1 : 0) <= h_skew1;
+                if (NK > 0 && ipa_filter && !(exist_total == 0 && !ipa_any_term)) {
+                    if (any_aff) {
+                        bool pods_exist = true, aff_ok = true;
+                        if (k_aff0) aff_ok = aff_ok && kv0, pods_exist = pods_exist && kv0 && kf0 > 0;
+                        if (NK > 1 && k_aff1) aff_ok = aff_ok && kv1, pods_exist = pods_exist && kv1 && kf1 > 0;
+                        if (!aff_ok || (!pods_exist && !(aff_total == 0 && self_aff))) ok = false;
+                    }
                     if (k_anti0 && kv0 && kn0 > 0) ok = false;
-                    if (k_anti1 && kv1 && kn1 > 0) ok = false;
-                    if (exist_total > 0 && ((nk > 0 && kv0 && ke0 > 0) || (nk > 1 && kv1 && ke1 > 0))) ok = false;
+                    if (NK > 1 && k_anti1 && kv1 && kn1 > 0) ok = false;
+                    if (exist_total > 0 && ((kv0 && ke0 > 0) || (NK > 1 && kv1 && ke1 > 0))) ok = false;
                 }
-                const uint32_t nf = wave_sum_u32_dpp(ok ? nfm : 0u);
-                if (nf == 0) {
-                    if (cycles == 0) done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0; // schedule_one.go:448-454
+                if (__ballot(ok) == 0ull) {
+                    if (cycles == 0) unsched = true; // the pass saw every node: schedule_one.go:448-454
                     break;
                 }
-                if (track) {
-                    const uint32_t mt_now = wave_max_u32(ok ? cmt : 0u), ma_now = wave_max_u32(ok ? cma : 0u);
-                    if (cycles == 0 && (mt_now != mt_a || ma_now != ma_a)) { // A was computed under other maxima: redo the pass
-                        stale_maxima = true, new_mt = mt_now, new_ma = ma_now;
-                        break;
+                if (cycles == 0) {
+                    if (track) {
+                        const uint32_t mt_now = wave_max_u32(ok ? cmt : 0u), ma_now = wave_max_u32(ok ? cma : 0u);
+                        if (mt_now != mt_a || ma_now != ma_a) { // A was computed under other maxima: redo the pass
+                            stale_maxima = true, new_mt = mt_now, new_ma = ma_now;
+                            break;
+                        }
                     }
-                    if (cycles > 0 && (mt_now != mt_a || ma_now != ma_a || __ballot(ok && is_cls && (cht == 0 || cha == 0)))) break;
+                } else {
+                    // a class's next head is not among the members kept; the class's own maximum lost its last holder; the maxima moved
+                    if (__ballot(ok && is_cls && (key == 0ull || (track && (cht == 0 || cha == 0))))) break;
+                    if (track && (__ballot(ok && (cmt > mt_a || cma > ma_a)) || !__ballot(ok && cmt == mt_a) || !__ballot(ok && cma == ma_a))) break;
                 }
-                if (cycles > 0 && __ballot(ok && is_cls && key == 0ull)) break; // a class's next head is not among the members kept
+                lf = ok ? nfm : 0u;
                 CW_TICK(2);
                 // ---- argmax (selectHost, schedule_one.go:894-941): the key IS (A, lowest index first)
                 const uint64_t mykey = ok ? key : 0ull;
@@ -851,21 +857,23 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 const int64_t g = key_index(best);
                 CW_TICK(4);
                 // ---- commit: broadcasts from the winner's lane
-                const bool w_cls = rl32((int32_t)is_cls, wl) != 0;
-                const int32_t w_hv0 = rl32(hv0, wl), w_hv1 = rl32(hv1, wl), w_kv0 = rl32(kv0, wl), w_kv1 = rl32(kv1, wl);
-                const int32_t w_hc0 = rl32(hc0, wl), w_hc1 = rl32(hc1, wl); // (before this clone)
-                uint32_t w_el, w_cnt, w_aff;
+                const bool w_cls = wl < C;
+                const int32_t w_hv0 = NH > 0 ? rl32(hv0, wl) : 0, w_hv1 = NH > 1 ? rl32(hv1, wl) : 0, w_kv0 = NK > 0 ? rl32(kv0, wl) : 0, w_kv1 = NK > 1 ? rl32(kv1, wl) : 0;
+                const int32_t w_hc0 = NH > 0 ? rl32(hc0, wl) : 0, w_hc1 = NH > 1 ? rl32(hc1, wl) : 0; // (before this clone)
+                uint32_t w_el, w_cnt = 0, w_aff = 0;
                 int32_t A_next, w_tix;
                 if (w_cls) {
                     const int e0 = wl * LL + rl32(head, wl);
-                    const uint32_t w = L.li_stat[e0];
                     w_el = L.li_elig[e0], A_next = L.li_A1[e0];
-                    w_cnt = (w >> kStatCntShift) & kStatCntMask, w_aff = w & kStatAffMask;
+                    if (track) {
+                        const uint32_t w = L.li_stat[e0];
+                        w_cnt = (w >> kStatCntShift) & kStatCntMask, w_aff = w & kStatAffMask;
+                    }
                     w_tix = nt;
                     if (lane == wl) { // the class loses its head
-                        nfm -= 1, cht -= w_cnt == cmt ? 1u : 0u, cha -= w_aff == cma ? 1u : 0u;
-                        head += 1;
-                        key = head < LL ? L.li_key[wl * LL + head] : 0ull;
+                        nfm -= 1, head += 1;
+                        if (track) cht -= w_cnt == cmt ? 1u : 0u, cha -= w_aff == cma ? 1u : 0u;
+                        key = head < LL ? L.li_key[e0 + 1] : 0ull;
                     }
                     if (lane == 0) L.t_gidx[nt] = g, L.t_took[nt] = 1;
                     nt += 1;
@@ -877,54 +885,55 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     A_next = cw_local_after(a, g - a.c.global_offset, (int64_t)took, mt_a, ma_a); // (a node winning again: one trip to its columns)
                 }
                 // the clone is an existing pod of the next cycle (filtering.go:255-296, interpodaffinity/filtering.go:204-272)
-                const bool cnt0 = nh > 0 && (w_el & 1u) && ((w_el >> 1) & 1u) && h_self0, cnt1 = nh > 1 && (w_el & 1u) && ((w_el >> 2) & 1u) && h_self1;
                 int32_t n_hv0 = w_hv0, n_hc0 = w_hc0, n_hv1 = w_hv1, n_hc1 = w_hc1; // the winner's own components after the clone
-                if (cnt0) {
-                    if (h_unique0) {
+                if (NH > 0 && (w_el & 1u) && ((w_el >> 1) & 1u) && h_self0) {
+                    if (HU0) {
                         if (w_hv0 & 1) {
-                            if (w_hc0 == um0 && --uc0 == 0) end_window = true; // the last node at the minimum: the new one takes a pass
+                            if (w_hc0 == min0 && --nmin0 == 0) end_window = true; // the last node at the minimum: the new one takes a pass
                             n_hv0 = w_hv0 + 2, n_hc0 = w_hc0 + 1;
                         }
                     } else if (w_hv0) {
                         if (hv0 == w_hv0) hc0 += 1; // every candidate of the domain, the winner's class included
                         if (lane == w_hv0) dc0 += 1;
+                        if (w_hc0 == min0 && --nmin0 == 0) remin0 = true;
                         n_hc0 = w_hc0 + 1;
                     }
                 }
-                if (cnt1) {
-                    if (h_unique1) {
+                if (NH > 1 && (w_el & 1u) && ((w_el >> 2) & 1u) && h_self1) {
+                    if (HU1) {
                         if (w_hv1 & 1) {
-                            if (w_hc1 == um1 && --uc1 == 0) end_window = true;
+                            if (w_hc1 == min1 && --nmin1 == 0) end_window = true;
                             n_hv1 = w_hv1 + 2, n_hc1 = w_hc1 + 1;
                         }
                     } else if (w_hv1) {
                         if (hv1 == w_hv1) hc1 += 1;
                         if (lane == w_hv1) dc1 += 1;
+                        if (w_hc1 == min1 && --nmin1 == 0) remin1 = true;
                         n_hc1 = w_hc1 + 1;
                     }
                 }
-                int32_t n_kf0 = rl32(kf0, wl), n_kn0 = rl32(kn0, wl), n_ke0 = rl32(ke0, wl), n_kf1 = rl32(kf1, wl), n_kn1 = rl32(kn1, wl), n_ke1 = rl32(ke1, wl);
-                if (nk > 0 && w_kv0) {
-                    aff_total += k_daff0, exist_total += k_danti0, entries += k_dent0;
-                    if (k_unique0) n_kf0 += k_daff0, n_kn0 += k_danti0, n_ke0 += k_danti0;
-                    else {
-                        if (kv0 == w_kv0) kf0 += k_daff0, kn0 += k_danti0, ke0 += k_danti0;
+                int32_t n_kf0 = 0, n_kn0 = 0, n_ke0 = 0, n_kf1 = 0, n_kn1 = 0, n_ke1 = 0;
+                if (NK > 0) {
+                    n_kf0 = rl32(kf0, wl), n_kn0 = rl32(kn0, wl), n_ke0 = rl32(ke0, wl);
+                    if (w_kv0) {
+                        aff_total += k_daff0, exist_total += k_danti0, entries += k_dent0;
+                        if (!KU0 && kv0 == w_kv0) kf0 += k_daff0, kn0 += k_danti0, ke0 += k_danti0;
                         n_kf0 += k_daff0, n_kn0 += k_danti0, n_ke0 += k_danti0;
                     }
                 }
-                if (nk > 1 && w_kv1) {
-                    aff_total += k_daff1, exist_total += k_danti1, entries += k_dent1;
-                    if (k_unique1) n_kf1 += k_daff1, n_kn1 += k_danti1, n_ke1 += k_danti1;
-                    else {
-                        if (kv1 == w_kv1) kf1 += k_daff1, kn1 += k_danti1, ke1 += k_danti1;
+                if (NK > 1) {
+                    n_kf1 = rl32(kf1, wl), n_kn1 = rl32(kn1, wl), n_ke1 = rl32(ke1, wl);
+                    if (w_kv1) {
+                        aff_total += k_daff1, exist_total += k_danti1, entries += k_dent1;
+                        if (!KU1 && kv1 == w_kv1) kf1 += k_daff1, kn1 += k_danti1, ke1 += k_danti1;
                         n_kf1 += k_daff1, n_kn1 += k_danti1, n_ke1 += k_danti1;
                     }
                 }
                 // does the node stay a candidate?  Full, or blocked for good by a required anti-affinity term against what is there to stay: no
                 bool dead = A_next < 0;
-                if (ipa_filter) {
-                    if ((k_anti0 && w_kv0 && n_kn0 > 0) || (k_anti1 && w_kv1 && n_kn1 > 0)) dead = true;
-                    if (exist_total > 0 && ((nk > 0 && w_kv0 && n_ke0 > 0) || (nk > 1 && w_kv1 && n_ke1 > 0))) dead = true;
+                if (NK > 0 && ipa_filter) {
+                    if ((k_anti0 && w_kv0 && n_kn0 > 0) || (NK > 1 && k_anti1 && w_kv1 && n_kn1 > 0)) dead = true;
+                    if (exist_total > 0 && ((w_kv0 && n_ke0 > 0) || (NK > 1 && w_kv1 && n_ke1 > 0))) dead = true;
                 }
                 if (!dead) { // its lane: a new one behind the candidates, or the one it already has
                     const int tl = w_cls ? ncand : wl;
@@ -948,24 +957,25 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     ncand -= 1;
                 }
                 if (lane == 0 && a.log && placed < log_cap) a.log[placed] = (int32_t)g;
-                placed += 1, rounds += 1, cycles += 1;
-                last_feasible = (int32_t)nf;
+                placed += 1, cycles += 1;
                 if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312: tested after the append
                 cw_lds_sync();
                 CW_TICK(5);
             }
+            const uint32_t nf_last = wave_sum_u32_dpp(lf);
             if (lane == 0) {
-                S.placed = placed, S.rounds = rounds, S.scans += 1;
+                S.placed = placed, S.rounds += (placed - placed0) + (unsched ? 1 : 0), S.scans += 1;
                 S.ipa_aff_total = aff_total, S.ipa_exist_total = exist_total, S.ipa_entries = entries;
-                S.last_feasible = last_feasible;
+                if (unsched) S.last_feasible = 0;
+                else if (cycles > 0) S.last_feasible = (int32_t)nf_last;
                 S.winner = -1;
                 if (stale_maxima) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
-                if (nh > 0) S.pts_min_a[0] = min0; // (the terminal histogram reads them: k_hist)
-                if (nh > 1) S.pts_min_a[1] = min1;
+                if (NH > 0) S.pts_min_a[0] = min0; // (the terminal histogram reads them: k_hist)
+                if (NH > 1) S.pts_min_a[1] = min1;
                 S.cw_windows += 1;
-                S.done = done;
+                S.done = unsched ? DONE_UNSCHEDULABLE : done;
                 L.s_nt = nt;
-                if (prof) pf[7] += (unsigned long long)cycles;
+                if (prof) L.pf[7] += (unsigned long long)cycles;
             }
         }
     }
@@ -985,24 +995,23 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
 #pragma unroll 1
         for (int col = 2; col < a.p.ncol; col++)
             if (a.p.req[col] != 0) a.c.req[col][i] += k * a.p.req[col];
-        if (a.pts.n) {
+        if (NH > 0) {
             const uint32_t eb = a.pts.elig[i];
-            for (int c = 0; c < a.pts.n; c++) {
+            for (int c = 0; c < NH; c++) {
                 const int32_t v = a.pts.label[c][i];
                 if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.pts.self_match[c]) atomicAdd(&a.pts.tbl[c][v], (int32_t)k);
             }
         }
-        if (a.ipa.on)
-            for (int kk = 0; kk < a.ipa.n_keys; kk++) {
-                const int32_t v = a.ipa.label[kk][i];
-                if (!v) continue;
-                if (a.ipa.self_aff && a.ipa.aff_terms_on_key[kk]) atomicAdd((unsigned long long *)&a.ipa.aff[kk][v], (unsigned long long)(k * a.ipa.aff_terms_on_key[kk]));
-                if (a.ipa.anti_self_on_key[kk]) {
-                    atomicAdd((unsigned long long *)&a.ipa.anti[kk][v], (unsigned long long)(k * a.ipa.anti_self_on_key[kk]));
-                    atomicAdd((unsigned long long *)&a.ipa.exist[kk][v], (unsigned long long)(k * a.ipa.anti_self_on_key[kk]));
-                }
-                if (a.ipa.score_self[kk]) atomicAdd((unsigned long long *)&a.ipa.score[kk][v], (unsigned long long)(k * a.ipa.score_self[kk]));
+        for (int kk = 0; kk < NK; kk++) {
+            const int32_t v = a.ipa.label[kk][i];
+            if (!v) continue;
+            if (a.ipa.self_aff && a.ipa.aff_terms_on_key[kk]) atomicAdd((unsigned long long *)&a.ipa.aff[kk][v], (unsigned long long)(k * a.ipa.aff_terms_on_key[kk]));
+            if (a.ipa.anti_self_on_key[kk]) {
+                atomicAdd((unsigned long long *)&a.ipa.anti[kk][v], (unsigned long long)(k * a.ipa.anti_self_on_key[kk]));
+                atomicAdd((unsigned long long *)&a.ipa.exist[kk][v], (unsigned long long)(k * a.ipa.anti_self_on_key[kk]));
             }
+            if (a.ipa.score_self[kk]) atomicAdd((unsigned long long *)&a.ipa.score[kk][v], (unsigned long long)(k * a.ipa.score_self[kk]));
+        }
     }
     // ---- leave the class table empty for the next pass, and tell the general kernel that the window is done
     for (int id = tid; id < C; id += kCwThreads) {
@@ -1016,8 +1025,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         a.w.ctl[kCwCtlClasses] = 0u;
         __hip_atomic_store(a.w.ctl + kCwCtlFastDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prof) {
-            pf[6] += __builtin_amdgcn_s_memrealtime() - t_prev;
-            for (int i = 0; i < 8; i++) a.w.prof[i] += pf[i];
+            L.pf[6] += __builtin_amdgcn_s_memrealtime() - t_prev;
+            for (int i = 0; i < 8; i++) a.w.prof[i] += L.pf[i];
         }
     }
 #undef CW_TICK

@@ -1361,6 +1361,8 @@ static int run_persist(ccsim_engine *e, int k) {
 static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out);
 
 // ---- one template with topology-coupled plugins, in windows (ccsim_coupled.h): pass -> class lists -> up to W cycles ----
+// shapes with a lane-per-candidate decide kernel (NH hard constraints, HU unique-key mask, NK inter-pod keys, KU unique-key mask)
+#define CW_FAST_SHAPES(X) X(1, 0, 0, 0) X(1, 1, 0, 0) X(2, 0, 0, 0) X(0, 0, 1, 1) X(1, 0, 1, 1) X(2, 0, 1, 1) X(0, 0, 1, 0) X(1, 0, 1, 0)
 static void launch_cw_window(ccsim_engine *e) {
     const CwScanArgs sa{e->cols, e->pod, e->d_state, e->pts, e->soft, e->ipa, e->cw_plan, e->cw_work};
     const dim3 g((unsigned)e->cw_work.n_blocks), b(kCwThreads);
@@ -1371,7 +1373,18 @@ static void launch_cw_window(ccsim_engine *e) {
     hipLaunchKernelGGL(k_cw_top, g, b, 0, e->stream, ta);
     hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), dim3(kCwMergeThreads), 0, e->stream, ta);
     // lane = candidate form first (it declines, untouched, whatever it does not cover); the general form right behind it
-    if (e->cw_fast) hipLaunchKernelGGL(k_cw_decide_fast, dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
+    if (e->cw_fast) { // (the pod's shape picks the instantiation: bit c of HU / bit k of KU = unique-per-node key)
+        const int hu = (e->pts.n > 0 && e->cw_plan.h_unique[0] ? 1 : 0) | (e->pts.n > 1 && e->cw_plan.h_unique[1] ? 2 : 0);
+        const int nk = e->ipa.on ? e->ipa.n_keys : 0, ku = (nk > 0 && e->cw_plan.k_unique[0] ? 1 : 0) | (nk > 1 && e->cw_plan.k_unique[1] ? 2 : 0);
+        const CwDecideArgs *dp = (const CwDecideArgs *)e->d_cw_args;
+        const int shape = e->pts.n * 1000 + hu * 100 + nk * 10 + ku;
+        switch (shape) {
+#define CW_FAST_CASE(NH, HU, NK, KU) case NH * 1000 + HU * 100 + NK * 10 + KU: hipLaunchKernelGGL((k_cw_decide_fast<NH, HU, NK, KU>), dim3(1), b, sizeof(CwLds), e->stream, dp); break;
+            CW_FAST_SHAPES(CW_FAST_CASE)
+#undef CW_FAST_CASE
+        default: break; // no lane-per-candidate instantiation for this shape: the general kernel does every window
+        }
+    }
     const bool small = e->pts.n <= 2 && e->soft.n <= 2 && (!e->ipa.on || e->ipa.n_keys <= 2);
     if (small) hipLaunchKernelGGL((k_cw_decide<2, 2, 2>), dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
     else hipLaunchKernelGGL((k_cw_decide<4, 4, 4>), dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
@@ -1383,7 +1396,9 @@ static int run_cw(ccsim_engine *e) {
     if (e->cw_work.prof) HIPCHK(e, hipMemsetAsync(e->cw_work.prof, 0, 16 * sizeof(unsigned long long), e->stream));
     if (!attr_set) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
-        HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+#define CW_FAST_ATTR(NH, HU, NK, KU) HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast<NH, HU, NK, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+        CW_FAST_SHAPES(CW_FAST_ATTR)
+#undef CW_FAST_ATTR
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         attr_set = true;
     }
