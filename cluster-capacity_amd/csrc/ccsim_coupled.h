@@ -679,6 +679,12 @@ __device__ __forceinline__ int32_t cw_local_after(const CwDecideArgs &a, int64_t
 constexpr int kCwFastClasses = 48; // (the other lanes hold touched nodes that may still win)
 constexpr int kCwCtlFastDone = 2;
 
+// a value every lane holds identically but the compiler cannot know it (it came through a vector load): say so, or every
+// quantity derived from it -- loop counters, branch conditions -- is handled as divergent, with exec-mask bookkeeping
+__device__ __forceinline__ int64_t cw_uni64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ int32_t rl32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int src) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
@@ -697,19 +703,20 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     if (S.done || S.cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the general kernel records the fallback)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int LL = a.plan.list_len, W = a.plan.window < kCwMaxWindow ? a.plan.window : kCwMaxWindow;
-    const int C = (int)a.w.ctl[kCwCtlClasses];
+    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwMaxWindow ? a.plan.window : kCwMaxWindow);
+    const int C = uni32((int)a.w.ctl[kCwCtlClasses]);
     constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
     bool fits = C <= kCwFastClasses && C * LL <= kCwListLds;
     if (NH > 0 && !HU0) fits = fits && a.plan.h_len[0] <= 64;
+    // (uniform, and said so below: `fits` steers every thread of the block the same way)
     if (NH > 1 && !HU1) fits = fits && a.plan.h_len[1] <= 64;
     if (NK > 0 && a.ipa.w) { // PreScore must skip for the whole window: no entries now, none added by a clone (scoring.go:199-201)
         fits = fits && S.ipa_entries == 0 && a.ipa.self_entries[0] == 0;
         if (NK > 1) fits = fits && a.ipa.self_entries[1] == 0;
     }
-    if (!fits) return;
-    const bool prof = a.w.prof != nullptr;
+    if (!uni32(fits)) return;
+    const bool prof = uni32(a.w.prof != nullptr) != 0;
     unsigned long long t_prev = prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #define CW_TICK(i) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); if (lane == 0) L.pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
@@ -730,19 +737,20 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
 
     if (tid < 64) {
         // ---- uniform parameters (SGPRs; what the shape does not use is never loaded)
-        const int h_self0 = NH > 0 ? a.pts.self_match[0] : 0, h_self1 = NH > 1 ? a.pts.self_match[1] : 0;
-        const int h_skew0 = NH > 0 ? a.pts.max_skew[0] : 0, h_skew1 = NH > 1 ? a.pts.max_skew[1] : 0;
-        const bool h_usemin0 = NH > 0 && !(a.pts.n_present[0] < a.pts.min_domains[0]), h_usemin1 = NH > 1 && !(a.pts.n_present[1] < a.pts.min_domains[1]);
-        const int k_aff0 = NK > 0 ? a.ipa.aff_terms_on_key[0] : 0, k_aff1 = NK > 1 ? a.ipa.aff_terms_on_key[1] : 0;
+        const int h_self0 = uni32(NH > 0 ? a.pts.self_match[0] : 0), h_self1 = uni32(NH > 1 ? a.pts.self_match[1] : 0);
+        const int h_skew0 = uni32(NH > 0 ? a.pts.max_skew[0] : 0), h_skew1 = uni32(NH > 1 ? a.pts.max_skew[1] : 0);
+        const bool h_usemin0 = uni32(NH > 0 && !(a.pts.n_present[0] < a.pts.min_domains[0])) != 0, h_usemin1 = uni32(NH > 1 && !(a.pts.n_present[1] < a.pts.min_domains[1])) != 0;
+        const int k_aff0 = uni32(NK > 0 ? a.ipa.aff_terms_on_key[0] : 0), k_aff1 = uni32(NK > 1 ? a.ipa.aff_terms_on_key[1] : 0);
         int k_anti0 = 0, k_anti1 = 0;
-        for (int q = 0; NK > 0 && q < a.ipa.n_anti; q++) k_anti0 += a.ipa.anti_key[q] == 0, k_anti1 += a.ipa.anti_key[q] == 1;
-        const int k_daff0 = NK > 0 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[0] : 0, k_daff1 = NK > 1 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[1] : 0;
-        const int k_danti0 = NK > 0 ? a.ipa.anti_self_on_key[0] : 0, k_danti1 = NK > 1 ? a.ipa.anti_self_on_key[1] : 0;
-        const int k_dent0 = NK > 0 ? a.ipa.self_entries[0] : 0, k_dent1 = NK > 1 ? a.ipa.self_entries[1] : 0;
-        const bool ipa_filter = NK > 0 && a.ipa.filter_on, ipa_any_term = NK > 0 && (a.ipa.n_aff || a.ipa.n_anti), self_aff = NK > 0 && a.ipa.self_aff;
+        for (int q = 0; NK > 0 && q < uni32(a.ipa.n_anti); q++) k_anti0 += a.ipa.anti_key[q] == 0, k_anti1 += a.ipa.anti_key[q] == 1;
+        k_anti0 = uni32(k_anti0), k_anti1 = uni32(k_anti1);
+        const int k_daff0 = uni32(NK > 0 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[0] : 0), k_daff1 = uni32(NK > 1 && a.ipa.self_aff ? a.ipa.aff_terms_on_key[1] : 0);
+        const int k_danti0 = uni32(NK > 0 ? a.ipa.anti_self_on_key[0] : 0), k_danti1 = uni32(NK > 1 ? a.ipa.anti_self_on_key[1] : 0);
+        const int k_dent0 = uni32(NK > 0 ? a.ipa.self_entries[0] : 0), k_dent1 = uni32(NK > 1 ? a.ipa.self_entries[1] : 0);
+        const bool ipa_filter = uni32(NK > 0 && a.ipa.filter_on) != 0, ipa_any_term = uni32(NK > 0 && (a.ipa.n_aff || a.ipa.n_anti)) != 0, self_aff = uni32(NK > 0 && a.ipa.self_aff) != 0;
         const bool any_aff = k_aff0 || k_aff1;
-        const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
-        const bool track = a.p.w_taint != 0 || a.p.w_aff != 0; // else every count / sum is 0 and the maxima cannot move
+        const uint32_t mt_a = (uint32_t)uni32(S.mt_a), ma_a = (uint32_t)uni32(S.ma_a);
+        const bool track = uni32(a.p.w_taint != 0 || a.p.w_aff != 0) != 0; // else every count / sum is 0 and the maxima cannot move
 
         // ---- lane = candidate: the class records into registers
         int32_t hv0 = 0, hv1 = 0, hc0 = 0, hc1 = 0, kv0 = 0, kv1 = 0, kf0 = 0, kf1 = 0, kn0 = 0, kn1 = 0, ke0 = 0, ke1 = 0;
@@ -805,15 +813,18 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 }
         if (__ballot(over) == 0ull) { // (else: an entry beyond int32 -- the general kernel's business)
             int ncand = C, nt = 0;
-            int64_t placed = S.placed;
-            const int64_t placed0 = placed, limit = S.limit, log_cap = S.log_cap;
-            int64_t aff_total = S.ipa_aff_total, exist_total = S.ipa_exist_total, entries = S.ipa_entries;
+            int64_t placed = cw_uni64(S.placed);
+            const int64_t placed0 = placed, limit = cw_uni64(S.limit), log_cap = cw_uni64(S.log_cap);
+            int64_t aff_total = cw_uni64(S.ipa_aff_total), exist_total = cw_uni64(S.ipa_exist_total), entries = cw_uni64(S.ipa_entries);
             int done = 0, cycles = 0;
             bool stale_maxima = false, end_window = false, unsched = false;
             uint32_t new_mt = mt_a, new_ma = ma_a, lf = 0; // lf: this lane's share of the feasible count of the last cycle
             CW_TICK(0);
 #pragma unroll 1
-            while (!end_window && !done && cycles < W && ncand < 64) {
+            while (!uni32(end_window) && !done && cycles < W && ncand < 64) {
+                // (loop-carried scalars, re-asserted uniform: one v_readfirstlane each instead of divergent-loop bookkeeping)
+                ncand = uni32(ncand), nt = uni32(nt), nmin0 = (uint32_t)uni32((int)nmin0), nmin1 = (uint32_t)uni32((int)nmin1);
+                min0 = uni32(min0), min1 = uni32(min1), remin0 = uni32(remin0) != 0, remin1 = uni32(remin1) != 0;
                 if (NH > 0 && !HU0 && remin0) min0 = wave_min_i32_nonneg(dp0 ? dc0 : 0x7fffffff), nmin0 = (uint32_t)__popcll(__ballot(dp0 && dc0 == min0)), remin0 = false;
                 if (NH > 1 && !HU1 && remin1) min1 = wave_min_i32_nonneg(dp1 ? dc1 : 0x7fffffff), nmin1 = (uint32_t)__popcll(__ballot(dp1 && dc1 == min1)), remin1 = false;
                 // ---- verdicts (filtering.go:311-356, interpodaffinity/filtering.go:410-432)
@@ -864,9 +875,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 int32_t A_next, w_tix;
                 if (w_cls) {
                     const int e0 = wl * LL + rl32(head, wl);
-                    w_el = L.li_elig[e0], A_next = L.li_A1[e0];
+                    w_el = (uint32_t)uni32((int)L.li_elig[e0]), A_next = uni32(L.li_A1[e0]);
                     if (track) {
-                        const uint32_t w = L.li_stat[e0];
+                        const uint32_t w = (uint32_t)uni32((int)L.li_stat[e0]);
                         w_cnt = (w >> kStatCntShift) & kStatCntMask, w_aff = w & kStatAffMask;
                     }
                     w_tix = nt;
@@ -880,9 +891,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 } else {
                     w_el = (uint32_t)rl32((int32_t)el, wl), w_cnt = (uint32_t)rl32((int32_t)cmt, wl), w_aff = (uint32_t)rl32((int32_t)cma, wl);
                     w_tix = rl32(tix, wl);
-                    const uint32_t took = L.t_took[w_tix] + 1;
+                    const uint32_t took = (uint32_t)uni32((int)L.t_took[w_tix]) + 1;
                     if (lane == 0) L.t_took[w_tix] = took;
-                    A_next = cw_local_after(a, g - a.c.global_offset, (int64_t)took, mt_a, ma_a); // (a node winning again: one trip to its columns)
+                    A_next = uni32(cw_local_after(a, g - a.c.global_offset, (int64_t)took, mt_a, ma_a)); // (a node winning again: one trip to its columns)
                 }
                 // the clone is an existing pod of the next cycle (filtering.go:255-296, interpodaffinity/filtering.go:204-272)
                 int32_t n_hv0 = w_hv0, n_hc0 = w_hc0, n_hv1 = w_hv1, n_hc1 = w_hc1; // the winner's own components after the clone
@@ -1046,9 +1057,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
     }
     if (S.done || S.cw_fallback) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int LL = a.plan.list_len, W = a.plan.window;
+    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window);
     const bool giveup = __hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    const int C = giveup ? 0 : (int)a.w.ctl[kCwCtlClasses];
+    const int C = uni32(giveup ? 0 : (int)a.w.ctl[kCwCtlClasses]);
     const bool staged = C * LL <= kCwListLds; // else list entries are read from HBM when they are needed
     unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(), pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool prof = a.w.prof != nullptr;
@@ -1107,11 +1118,11 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
         P.load(a);
         CW_TICK(0);
         int nt = 0, na = 0; // touched nodes ; how many of them may still win
-        int64_t placed = S.placed, rounds = S.rounds;
-        const int64_t limit = S.limit, log_cap = S.log_cap;
-        int64_t aff_total = S.ipa_aff_total, exist_total = S.ipa_exist_total, entries = S.ipa_entries;
-        const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
-        int done = 0, last_feasible = S.last_feasible;
+        int64_t placed = cw_uni64(S.placed), rounds = cw_uni64(S.rounds);
+        const int64_t limit = cw_uni64(S.limit), log_cap = cw_uni64(S.log_cap);
+        int64_t aff_total = cw_uni64(S.ipa_aff_total), exist_total = cw_uni64(S.ipa_exist_total), entries = cw_uni64(S.ipa_entries);
+        const uint32_t mt_a = (uint32_t)uni32(S.mt_a), ma_a = (uint32_t)uni32(S.ma_a);
+        int done = 0, last_feasible = uni32(S.last_feasible);
         bool stale_maxima = false;
         uint32_t new_mt = mt_a, new_ma = ma_a;
         // unique-key hard constraints: (minimum, counted nodes at it) from the pass
@@ -1293,7 +1304,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
             const uint64_t wbest = wave_max_u64(best);
             const uint64_t owner = __ballot(best == wbest && best_q >= 0);
             const int wl = __ffsll((unsigned long long)owner) - 1;
-            const int wq = __builtin_amdgcn_readlane(best_q, wl);
+            const int wq = __builtin_amdgcn_readlane(best_q, uni32(wl));
             const int64_t g = key_index(wbest);
             CW_TICK(4);
             // ---- commit (every lane holds the same wq / g; lane 0 writes)
@@ -1303,7 +1314,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                 ti = nt;
                 const int hd0 = L.c_head[wq], e0 = wq * LL + hd0;
                 uint32_t w, el;
-                if (staged) w = L.li_stat[e0], el = L.li_elig[e0], A_next = L.li_A1[e0];
+                if (staged) w = (uint32_t)uni32((int)L.li_stat[e0]), el = (uint32_t)uni32((int)L.li_elig[e0]), A_next = uni32(L.li_A1[e0]);
                 else {
                     const int64_t i = g - a.c.global_offset;
                     w = a.c.stat[i], A_next = a.w.node_A1[i];
@@ -1322,11 +1333,11 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                 }
                 nt += 1;
             } else {
-                ti = L.alive[wq - C];
-                A_next = cw_local_after(a, g - a.c.global_offset, (int64_t)L.t_took[ti] + 1, mt_a, ma_a); // (a node winning again: one trip to its columns)
+                ti = uni32(L.alive[wq - C]);
+                A_next = uni32(cw_local_after(a, g - a.c.global_offset, (int64_t)uni32((int)L.t_took[ti]) + 1, mt_a, ma_a)); // (a node winning again: one trip to its columns)
             }
             cw_lds_sync();
-            const uint32_t el = L.t_elig[ti];
+            const uint32_t el = (uint32_t)uni32((int)L.t_elig[ti]);
             // the clone is an existing pod of the next cycle: tables, the node's own entries, totals
 #pragma unroll
             for (int c = 0; c < MH; c++)
