@@ -43,7 +43,8 @@ constexpr int kCwMaxClasses = 256;  // classes per window
 constexpr int kCwSlots = 1024;      // global open-addressing class table (power of two)
 constexpr int kCwBlockSlots = 256;  // per-block LDS class table of the scan (power of two)
 constexpr int kCwMaxList = 32;      // L
-constexpr int kCwMaxWindow = 256;   // W
+constexpr int kCwMaxWindow = 256;   // W of the general decide kernel (a touched node keeps its whole tuple in LDS)
+constexpr int kCwFastWindow = 1024; // W of the lane-per-candidate kernel (a touched node is (index, clones))
 constexpr int kCwThreads = 256, kCwPerThread = 4, kCwTile = kCwThreads * kCwPerThread;
 constexpr int kCwMaxKeys = 4096;    // k_cw_merge stages blocks x L keys of one class in LDS (32 KiB)
 constexpr int kCwLdsI32 = 4096;     // k_cw_decide: int32 words of shared-key tables (hard / soft counts, presence flags, candidate bitmaps)
@@ -465,23 +466,35 @@ __global__ __launch_bounds__(kCwMergeThreads) void k_cw_merge(CwTopArgs a) {
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     unsigned long long mine = 0; // rank `lane` of the merged list ends up in lane `lane` (L <= 32)
-    for (int r = 0; r < L; r++) {
-        unsigned long long best = 0;
-        for (int b = lane; b < nb; b += kCwMergeThreads) {
-            const int hd = s_head[b];
-            const unsigned long long k = hd < L ? s_k[b * L + hd] : 0ull;
-            best = k > best ? k : best;
+    if (nb <= 2 * kCwMergeThreads) { // the usual size: a lane keeps the current heads of its (at most two) blocks in registers
+        const int b0 = lane, b1 = lane + kCwMergeThreads;
+        int h0 = 0, h1 = 0;
+        unsigned long long k0 = b0 < nb ? s_k[b0 * L] : 0ull, k1 = b1 < nb ? s_k[b1 * L] : 0ull;
+        for (int r = 0; r < L; r++) {
+            const unsigned long long K = wave_max_u64(k0 > k1 ? k0 : k1);
+            if (lane == r) mine = K;
+            if (K == 0ull) break; // (wave-uniform)
+            if (k0 == K) h0 += 1, k0 = h0 < L ? s_k[b0 * L + h0] : 0ull;
+            else if (k1 == K) h1 += 1, k1 = h1 < L ? s_k[b1 * L + h1] : 0ull;
         }
-        const unsigned long long K = wave_max_u64(best);
-        if (K)
+    } else
+        for (int r = 0; r < L; r++) {
+            unsigned long long best = 0;
             for (int b = lane; b < nb; b += kCwMergeThreads) {
                 const int hd = s_head[b];
-                if (hd < L && s_k[b * L + hd] == K) s_head[b] = (uint8_t)(hd + 1);
+                const unsigned long long k = hd < L ? s_k[b * L + hd] : 0ull;
+                best = k > best ? k : best;
             }
-        if (lane == r) mine = K;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-    }
+            const unsigned long long K = wave_max_u64(best);
+            if (K)
+                for (int b = lane; b < nb; b += kCwMergeThreads) {
+                    const int hd = s_head[b];
+                    if (hd < L && s_k[b * L + hd] == K) s_head[b] = (uint8_t)(hd + 1);
+                }
+            if (lane == r) mine = K;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
     if (lane < L) a.w.lists[(size_t)id * L + lane] = mine;
 }
 
@@ -517,9 +530,9 @@ struct CwLds {
     // nodes that received a clone in this window.  `alive` lists the ones that may still win (a node that is full, or whose own
     // clone blocks it through a required anti-affinity term, never comes back: the counts only grow)
     int32_t t_tuple[kCwMaxWindow][kCwTuple];
-    long long t_gidx[kCwMaxWindow];
+    long long t_gidx[kCwFastWindow];
     int32_t t_A[kCwMaxWindow];
-    uint32_t t_cnt[kCwMaxWindow], t_aff[kCwMaxWindow], t_took[kCwMaxWindow], t_elig[kCwMaxWindow];
+    uint32_t t_cnt[kCwMaxWindow], t_aff[kCwMaxWindow], t_took[kCwFastWindow], t_elig[kCwMaxWindow];
     int32_t alive[kCwMaxWindow];
     long long e_rp[kCwCand], e_ri[kCwCand]; // per candidate: raw PodTopologySpread / InterPodAffinity score
     uint32_t e_fl[kCwCand];                 // bit0 feasible, bit1 has all soft keys
@@ -703,7 +716,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     if (S.done || S.cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the general kernel records the fallback)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwMaxWindow ? a.plan.window : kCwMaxWindow);
+    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
     const int C = uni32((int)a.w.ctl[kCwCtlClasses]);
     constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
@@ -970,9 +983,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 if (lane == 0 && a.log && placed < log_cap) a.log[placed] = (int32_t)g;
                 placed += 1, cycles += 1;
                 if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312: tested after the append
-                cw_lds_sync();
                 CW_TICK(5);
             }
+            cw_lds_sync();
             const uint32_t nf_last = wave_sum_u32_dpp(lf);
             if (lane == 0) {
                 S.placed = placed, S.rounds += (placed - placed0) + (unsched ? 1 : 0), S.scans += 1;
@@ -1057,7 +1070,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
     }
     if (S.done || S.cw_fallback) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window);
+    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwMaxWindow ? a.plan.window : kCwMaxWindow);
     const bool giveup = __hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     const int C = uni32(giveup ? 0 : (int)a.w.ctl[kCwCtlClasses]);
     const bool staged = C * LL <= kCwListLds; // else list entries are read from HBM when they are needed

@@ -897,7 +897,7 @@ static int cw_make_plan(ccsim_engine *e) {
     pl.window = 64, pl.list_len = 16;
     if (const char *f = getenv("CCSIM_CW_WINDOW")) pl.window = atoi(f); // tuning / test knobs
     if (const char *f = getenv("CCSIM_CW_LIST")) pl.list_len = atoi(f);
-    pl.window = pl.window < 1 ? 1 : (pl.window > kCwMaxWindow ? kCwMaxWindow : pl.window);
+    pl.window = pl.window < 1 ? 1 : (pl.window > kCwFastWindow ? kCwFastWindow : pl.window); // (the general decide kernel clamps to its own kCwMaxWindow)
     pl.list_len = pl.list_len < 1 ? 1 : (pl.list_len > kCwMaxList ? kCwMaxList : pl.list_len);
     const int64_t blocks = (e->n_pad + kCwTile - 1) / kCwTile;
     while (pl.list_len > 1 && blocks * pl.list_len > kCwMaxKeys) pl.list_len >>= 1;
