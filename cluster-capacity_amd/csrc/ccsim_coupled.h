@@ -450,21 +450,21 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
 // k_cw_merge: block id = class id, ONE wave.  The blocks' lists are sorted, so the class's L best are found by L rounds over the
 // blocks' current heads (keys staged in LDS; a wave needs no block barrier).
 constexpr int kCwMergeThreads = 64;
-__global__ __launch_bounds__(kCwMergeThreads) void k_cw_merge(CwTopArgs a) {
+__global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a) {
     if (a.st->done || a.st->cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int C = (int)a.w.ctl[kCwCtlClasses], id = blockIdx.x, L = a.list_len, nb = a.w.n_blocks;
     if (id >= C) return;
     __shared__ unsigned long long s_k[kCwMaxKeys];
     __shared__ uint8_t s_head[kCwMaxKeys];
-    const int lane = threadIdx.x;
-    for (int q = lane; q < nb * L; q += kCwMergeThreads) {
+    for (int q = threadIdx.x; q < nb * L; q += kCwThreads) { // staging: all four waves
         const int b = q / L, r = q % L;
         s_k[q] = a.w.top[((size_t)b * kCwMaxClasses + id) * L + r];
     }
-    for (int b = lane; b < nb; b += kCwMergeThreads) s_head[b] = 0;
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
+    for (int b = threadIdx.x; b < nb; b += kCwThreads) s_head[b] = 0;
+    __syncthreads();
+    if (threadIdx.x >= kCwMergeThreads) return; // the rounds: one wave, no block barrier
+    const int lane = threadIdx.x;
     unsigned long long mine = 0; // rank `lane` of the merged list ends up in lane `lane` (L <= 32)
     if (nb <= 2 * kCwMergeThreads) { // the usual size: a lane keeps the current heads of its (at most two) blocks in registers
         const int b0 = lane, b1 = lane + kCwMergeThreads;

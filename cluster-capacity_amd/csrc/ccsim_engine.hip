@@ -894,7 +894,7 @@ static int cw_make_plan(ccsim_engine *e) {
         }
     if (i32 > kCwLdsI32 || i64 > kCwLdsI64) return no("shared-key tables exceed the decide kernel's LDS budget");
     pl.n_comp = kCwTuple, pl.i32_words = i32, pl.i64_words = i64;
-    pl.window = 64, pl.list_len = 16;
+    pl.window = 512, pl.list_len = 32; // (profiles/r03/bench_coupled.txt: 64/16 -> 357k, 256/16 -> 537k, 512/32 -> 567k placements/s at 100k nodes)
     if (const char *f = getenv("CCSIM_CW_WINDOW")) pl.window = atoi(f); // tuning / test knobs
     if (const char *f = getenv("CCSIM_CW_LIST")) pl.list_len = atoi(f);
     pl.window = pl.window < 1 ? 1 : (pl.window > kCwFastWindow ? kCwFastWindow : pl.window); // (the general decide kernel clamps to its own kCwMaxWindow)
@@ -1371,7 +1371,7 @@ static void launch_cw_window(ccsim_engine *e) {
     else hipLaunchKernelGGL((k_cw_scan<kMaxExtra, false>), g, b, 0, e->stream, sa);
     const CwTopArgs ta{e->cols, e->d_state, e->cw_work, e->cw_plan.list_len};
     hipLaunchKernelGGL(k_cw_top, g, b, 0, e->stream, ta);
-    hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), dim3(kCwMergeThreads), 0, e->stream, ta);
+    hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), b, 0, e->stream, ta);
     // lane = candidate form first (it declines, untouched, whatever it does not cover); the general form right behind it
     if (e->cw_fast) { // (the pod's shape picks the instantiation: bit c of HU / bit k of KU = unique-per-node key)
         const int hu = (e->pts.n > 0 && e->cw_plan.h_unique[0] ? 1 : 0) | (e->pts.n > 1 && e->cw_plan.h_unique[1] ? 2 : 0);
