@@ -653,9 +653,7 @@ __device__ __forceinline__ bool cw_soft_keys(const CwP<MH, MS, MK> &P, const int
 
 // the local verdict and score of node i after `k` clones were added to what its columns hold (the window applies its
 // placements to the columns when it ends)
-// (not inlined: a rare path -- a touched node winning again -- whose 18 column values and fp64 scoring would otherwise set the register
-// budget and the control flow of the whole cycle loop)
-__device__ __noinline__ int32_t cw_local_after(const CwDecideArgs &a, int64_t i, int64_t k, uint32_t mt_a, uint32_t ma_a) {
+__device__ __forceinline__ int32_t cw_local_after(const CwDecideArgs &a, int64_t i, int64_t k, uint32_t mt_a, uint32_t ma_a) {
     const int64_t a_cpu = a.c.alloc[0][i], a_mem = a.c.alloc[1][i];
     const int64_t r0 = a.c.req[0][i] + k * a.p.req[0], r1 = a.c.req[1][i] + k * a.p.req[1];
     const int64_t z0 = a.c.nz_mcpu[i] + k * a.p.nz_mcpu, z1 = a.c.nz_mem[i] + k * a.p.nz_mem;
