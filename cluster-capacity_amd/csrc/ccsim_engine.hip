@@ -1142,6 +1142,14 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     for (auto &fl : e->soft_flags) HIPCHK(e, hipMemsetAsync(fl.first, 0, fl.second * 4, e->stream)); // epochs restart at 1
     st.limit = max_limit;
     st.lvl_full = 1; // no score cache yet
+    {   // several score levels per pass (blind, validated, rolled back if need be: ccsim_level.h) wherever the commit rows exist
+        const int persist = (mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes) ? persist_k(e) : 0;
+        const bool rows_now = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !persist;
+        int kb = 64; // (the persistent form's measured optimum, profiles/r02/persist_batch_sweep.txt; sharded: profiles/r03)
+        if (const char *f = getenv("CCSIM_LEVEL_BATCH")) kb = atoi(f) > 0 ? atoi(f) : 1; // tuning knob (the SAME value on every rank)
+        st.lvl_kb_max = rows_now && !e->time_passes ? kb : 1;
+        st.lvl_kb = st.lvl_kb_max;
+    }
     st.winner = -1;
     st.mode = mode;
     st.log_cap = e->log_cap;

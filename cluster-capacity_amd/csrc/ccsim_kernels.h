@@ -207,6 +207,13 @@ struct DevState {
     int64_t smp_Ftotal;      // feasible nodes of the whole snapshot (this cycle)
     int64_t smp_stop;        // rotated position of the (K+1)-th feasible node = nodes visited; -1: all N were visited
     int64_t evaluated;       // sum of visited nodes over the cycles
+    // multi-kernel batched mode: several score levels per pass, committed blindly and validated afterwards (ccsim_level.h)
+    int64_t lvl_Lo;          // the pending commit takes every node scoring >= lvl_Lo down to < lvl_Lo (== lvl_M: one level)
+    int64_t prev_nfeas, prev_c_mt, prev_c_ma; // this shard's counts before the pending blind batch (restored by a roll-back)
+    int32_t lvl_kb, lvl_kb_max; // levels per blind batch: now / at most (1 = the one-level-per-pass protocol)
+    int32_t lvl_blind;       // the commit of this pass is a blind batch: validate it before its placements count
+    int32_t lvl_rollback;    // the next pass undoes the batch of pass lvl_pass (a normalization maximum ran out of holders, or --max-limit was crossed inside it)
+    int32_t lvl_pass, pad2;  // stamp of the last committing pass (commit rows carry it next to the clones they took in it)
     // windowed mode for topology-coupled plugins (ccsim_coupled.h)
     int32_t cw_fallback;     // 1 = the windowed mode gave up on this run: the one-pass-per-placement loop continues from the current state
     int32_t cw_windows;      // windows resolved so far

@@ -346,7 +346,7 @@ __device__ __forceinline__ void load_one(const DevCols &c, const DevPod &p, int6
 }
 
 template <int NX> __device__ __forceinline__ void nd_load(const DevCols &c, const DevPod &p, int64_t i, NodeRegs<NX> &n) { load_one<NX>(c, p, i, n); }
-template <int NX> __device__ __forceinline__ void nd_store(const DevCols &c, const DevPod &p, int64_t i, const NodeRegs<NX> &n, int32_t took) {
+template <int NX> __device__ __forceinline__ void nd_store(const DevCols &c, const DevPod &p, int64_t i, const NodeRegs<NX> &n, int32_t took, int32_t = 0) {
     store_dyn<NX>(c, p, i, n, took);
 }
 template <int NX> __device__ __forceinline__ void nd_zero(NodeRegs<NX> &n) {
@@ -361,10 +361,10 @@ __device__ __forceinline__ void nd_load(const DevCols &c, const DevPod &, int64_
     n.r0 = d.x, n.r1 = d.y, n.z0 = d.z, n.z1 = d.w;
     n.npods = q.x, n.placed = q.y;
 }
-__device__ __forceinline__ void nd_store(const DevCols &c, const DevPod &, int64_t i, const NodeNarrow &n, int32_t took) {
+__device__ __forceinline__ void nd_store(const DevCols &c, const DevPod &, int64_t i, const NodeNarrow &n, int32_t took, int32_t pass = 0) {
     int4 *row = reinterpret_cast<int4 *>(c.rows + i * kRowWords); // the columns follow at the next k_rows_flush
     row[1] = make_int4(n.r0, n.r1, n.z0, n.z1);
-    row[2] = make_int4(n.npods, n.placed + took, 0, 0);
+    row[2] = make_int4(n.npods, n.placed + took, took, pass); // (clones of THIS pass + its stamp: what a roll-back of a blind batch undoes)
 }
 __device__ __forceinline__ void nd_zero(NodeNarrow &n) {
     n.a0 = n.a1 = n.r0 = n.r1 = n.z0 = n.z1 = 0, n.a_pods = n.npods = 0, n.w = 0, n.placed = 0;
@@ -511,6 +511,24 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
     const RunCtx cx{a.p, narrow_pod(a.p, a.c.mem_shift)};
     const DevState st = *a.st;
     if (st.done) return;
+    if (NARROW && st.lvl_rollback) { // undo the blind batch of pass lvl_pass: its clones off the rows, the cached scores back
+        const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
+        const int64_t lo = (int64_t)blockIdx.x * a.cchunk;
+        int64_t hi = lo + a.cchunk;
+        if (hi > a.c.n_pad) hi = a.c.n_pad;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const int4 q = reinterpret_cast<const int4 *>(a.c.rows + i * kRowWords)[2];
+            if (q.w != st.lvl_pass || q.z <= 0) continue;
+            typename CommitNode<NX, NARROW>::type n;
+            nd_load(a.c, a.p, i, n);
+            nd_apply(cx, n, -(int64_t)q.z);
+            nd_store(a.c, a.p, i, n, -q.z, 0);
+            const uint32_t nw = nd_word(n);
+            const uint32_t cnt = (nw >> kStatCntShift) & kStatCntMask, aff = nw & kStatAffMask, img = (nw >> kStatImgShift) & kStatImgMask;
+            a.cscore[i] = (int32_t)nd_score(cx, n, static_score(a.p, cnt, aff, img, mt, ma), nd_rcp(n)); // (it took clones: it was feasible)
+        }
+        return;
+    }
     const bool plan_only = st.lvl_plan_only != 0;
     const bool commit_on = st.lvl_valid != 0 && !plan_only;
     if (!plan_only && !commit_on) return; // nothing planned (first pass, or the constants just changed)
@@ -526,7 +544,11 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
     int64_t hi = lo + a.cchunk;
     if (hi > a.c.n_pad) hi = a.c.n_pad;
     const bool ordered = commit_on && st.lvl_prefix != 0;
-    const int32_t M = (int32_t)st.lvl_M;
+    // a blind batch takes the levels lvl_M .. lvl_Lo in one pass: every node scoring >= Lo runs down until it scores < Lo -- for a
+    // single node exactly its run-downs at the levels in between, and without a log or a limit the interleaving across nodes is
+    // unobservable (ccsim_persist.h has the argument; level_decide validates the batch afterwards).  One level: Lo == M.
+    const int32_t M = (int32_t)(commit_on && st.lvl_blind ? st.lvl_Lo : st.lvl_M);
+    const int32_t pass_stamp = st.lvl_pass + 1;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
 
     int64_t committed = 0;
@@ -548,8 +570,8 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
             if (base < hi) { // block-uniform
                 const int64_t i0 = base + 2 * tid;
                 const int2 cs = *reinterpret_cast<const int2 *>(a.cscore + i0);
-                const bool l0 = cs.x == M && (a.c.global_offset + i0) <= st.lvl_cut;
-                const bool l1 = cs.y == M && (a.c.global_offset + i0 + 1) <= st.lvl_cut;
+                const bool l0 = cs.x >= M && (a.c.global_offset + i0) <= st.lvl_cut; // (M is the maximum unless this is a batch: >= is == then)
+                const bool l1 = cs.y >= M && (a.c.global_offset + i0 + 1) <= st.lvl_cut;
                 const uint64_t b0 = __ballot(l0), b1 = __ballot(l1);
                 flags |= (l0 ? 1u : 0u) << (2 * t) | (l1 ? 1u : 0u) << (2 * t + 1);
                 if (!plan_only) { // nodes this pass does not touch keep their cached score
@@ -623,7 +645,7 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
                 }
                 if (mine && took > 0) {
                     nd_apply(cx, n, took);
-                    nd_store(a.c, a.p, nidx, n, (int32_t)took);
+                    nd_store(a.c, a.p, nidx, n, (int32_t)took, pass_stamp);
                     committed += took;
                     if (ordered && a.log) {
                         for (int64_t q = 0; q < took; q++) {
@@ -703,9 +725,36 @@ struct LevelAgg {
 
 // The sequential part of a level: simulator.go:297-312 limit test, schedule_one.go:448-454 FitError,
 // normalization-constant tracking, and how the next level is to be committed.
+__device__ __forceinline__ void level_issue(DevState &st, int64_t n_top, uint32_t mt, uint32_t c_mt, uint32_t ma, uint32_t c_ma, bool want_log, bool must_plan) {
+    // how the level st.lvl_M is to be committed
+    st.lvl_cut = kNoCut;
+    st.lvl_remaining = kNoCut;
+    st.lvl_prefix = 0;
+    st.lvl_rank_prefix = 0;
+    st.lvl_plan_only = 0, st.lvl_valid = 0, st.lvl_blind = 0;
+    st.lvl_Lo = st.lvl_M;
+    if (st.lvl_kb > 1 && !want_log) { // several levels, blind; validated by the next level_decide (roll-back + half the levels if it fails)
+        const int64_t lo = st.lvl_M - (st.lvl_kb - 1);
+        st.lvl_Lo = lo > 0 ? lo : 0;
+        st.lvl_blind = 1, st.lvl_valid = 1;
+        st.prev_nfeas = st.cur_nfeas, st.prev_c_mt = st.cur_c_mt, st.prev_c_ma = st.cur_c_ma;
+        return;
+    }
+    // Could anything end this level early?  The limit / the log need positions; a normalization maximum
+    // can only move if ALL its feasible holders are exhausted, i.e. the level has at least that many nodes.
+    const bool plan = must_plan || want_log || st.limit > 0 || (mt > 0 && n_top >= (int64_t)c_mt) || (ma > 0 && n_top >= (int64_t)c_ma);
+    if (plan) st.lvl_plan_only = 1;
+    else st.lvl_valid = 1;
+}
+
 __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bool want_log) {
     st.scans += 1;
     st.winner = -1;
+    if (st.lvl_rollback) { // the pass undid the batch: the same level again, fewer levels at once (one level: measured first)
+        st.lvl_rollback = 0;
+        level_issue(st, 0, (uint32_t)st.mt_a, (uint32_t)st.lvl_c_mt, (uint32_t)st.ma_a, (uint32_t)st.lvl_c_ma, want_log, st.lvl_kb <= 1);
+        return;
+    }
     if (st.lvl_plan_only) { // the pass measured level lvl_M (nothing moved): now commit it, carefully
         st.lvl_plan_only = 0;
         st.lvl_valid = 1;
@@ -718,9 +767,25 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
         return;
     }
     const bool incremental = !st.lvl_full; // g came from the score cache (commit pass), not from a full pass
+    if (incremental) st.lvl_pass += 1;     // (a commit pass ran: its rows carry this stamp)
+    if (incremental && st.lvl_blind) {
+        // validate the blind batch: did it exhaust every feasible holder of a normalization maximum (the nodes after that holder
+        // should have been re-scored first), or cross --max-limit (the prefix that fits is a matter of order)?
+        const bool cut_event = (st.mt_a > 0 && g.c_mt == 0) || (st.ma_a > 0 && g.c_ma == 0);
+        const bool over = st.limit > 0 && st.placed + g.committed > st.limit;
+        if (cut_event || over) {
+            st.lvl_rollback = 1, st.lvl_valid = 0, st.lvl_blind = 0;
+            const int64_t span = st.lvl_M - st.lvl_Lo + 1;
+            st.lvl_kb = span > 1 ? (int32_t)(span >> 1) : 1;
+            st.cur_nfeas = st.prev_nfeas, st.cur_c_mt = st.prev_c_mt, st.cur_c_ma = st.prev_c_ma;
+            return;
+        }
+        st.lvl_kb = 2 * st.lvl_kb < st.lvl_kb_max ? 2 * st.lvl_kb : st.lvl_kb_max;
+    } else if (incremental && st.lvl_kb < st.lvl_kb_max)
+        st.lvl_kb = 2 * st.lvl_kb < st.lvl_kb_max ? (st.lvl_kb < 1 ? 1 : 2 * st.lvl_kb) : st.lvl_kb_max; // (an ordered level went through: batches again)
     st.placed += g.committed;
     st.rounds += g.committed;
-    st.lvl_valid = 0;
+    st.lvl_valid = 0, st.lvl_blind = 0;
     if (st.limit > 0 && st.placed >= st.limit) {
         st.done = DONE_LIMIT;
         return;
@@ -746,16 +811,7 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
     st.lvl_M = key_score(g.key);
     st.lvl_c_mt = g.c_mt; // holder counts of the maxima, for the plan pass's "all holders exhausted?" test
     st.lvl_c_ma = g.c_ma;
-    st.lvl_cut = kNoCut;
-    st.lvl_remaining = kNoCut;
-    st.lvl_prefix = 0;
-    st.lvl_rank_prefix = 0;
-    // Could anything end this level early?  The limit / the log need positions; a normalization maximum
-    // can only move if ALL its feasible holders are exhausted, i.e. the level has at least that many nodes.
-    const bool plan = want_log || st.limit > 0 || (g.mt > 0 && g.n_top >= (int64_t)g.c_mt) ||
-                      (g.ma > 0 && g.n_top >= (int64_t)g.c_ma);
-    if (plan) st.lvl_plan_only = 1;
-    else st.lvl_valid = 1;
+    level_issue(st, g.n_top, g.mt, g.c_mt, g.ma, g.c_ma, want_log, false);
 }
 
 struct LevelFinalArgs {
@@ -784,6 +840,20 @@ constexpr int kFinalThreads = 256;
 __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a) {
     if (a.st->done) return;
     if (a.st->lvl_full ? !a.score_launched : !a.commit_launched) return; // block-uniform: see LevelFinalArgs
+    if (a.st->lvl_rollback) { // the commit kernel undid a blind batch: nothing to reduce
+        if (threadIdx.x == 0) {
+            if (a.n_ranks > 0) {
+                XRec r{};
+                *a.xsend = r; // (every rank decides the same way from its replicated state)
+            } else {
+                DevState st = *a.st;
+                LevelAgg g{};
+                level_decide(st, g, a.want_log != 0);
+                *a.st = st;
+            }
+        }
+        return;
+    }
     constexpr int kWaves = kFinalThreads / 64;
     __shared__ uint64_t s_key[kWaves];
     __shared__ uint32_t s_u[4][kWaves];
@@ -910,6 +980,12 @@ __global__ void k_level_decide(LevelFinalArgs a) {
     DevState st = *a.st;
     if (st.done) return;
     if (st.lvl_full ? !a.score_launched : !a.commit_launched) return; // the pass was a no-op on every rank (LevelFinalArgs)
+    if (st.lvl_rollback) {
+        LevelAgg g0{};
+        level_decide(st, g0, a.want_log != 0);
+        *a.st = st;
+        return;
+    }
     LevelAgg g{};
     g.cut_mt = g.cut_ma = -1;
     int64_t before = 0;

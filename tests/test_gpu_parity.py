@@ -173,8 +173,8 @@ class _LocalShards:
                     e.dist_decide()
             if all([e.dist_poll()[0] for e in self.engines]):  # every rank polls (no short-circuit): same cadence everywhere
                 break
-        res = [e.dist_finish(True, log_cap) for e in self.engines]
-        return res, ccdist.merge_logs([r.log for r in res])
+        res = [e.dist_finish(log_cap > 0, log_cap) for e in self.engines]
+        return res, (ccdist.merge_logs([r.log for r in res]) if log_cap > 0 else None)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -192,6 +192,41 @@ def test_sharded_protocol_matches_oracle(ccref, mode, world, cfg, n, limit, poll
     assert np.array_equal(log[: ref.placed], ref.log)
     if ref.stop == M.STOP_UNSCHEDULABLE:
         assert np.array_equal(sum(r.hist for r in res), ref.hist)
+
+
+@pytest.mark.parametrize("kb", ["1", "3", "64"])
+@pytest.mark.parametrize("world,cfg,n,limit,poll_every", [(2, "C3", 1500, 0, 1), (3, "C3", 1100, 450, 5), (2, "C2", 700, 0, 1), (4, "C3", 2100, 0, 32),
+                                                          (3, "C3", 4000, 2777, 8), (2, "C3", 6000, 0, 32)])
+def test_sharded_blind_level_batches_match_oracle(ccref, monkeypatch, kb, world, cfg, n, limit, poll_every):
+    """No placement log: the sharded batched mode commits up to CCSIM_LEVEL_BATCH score levels per exchange, blindly, and validates
+    afterwards (a normalization maximum out of holders, --max-limit crossed: roll back on every rank, half the levels, down to the
+    ordered one-level commit).  Totals, per-node counts and the terminal histogram are the observables."""
+    monkeypatch.setenv("CCSIM_LEVEL_BATCH", kb)
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    sh = _LocalShards(nodes, pod, prof, world)
+    res, _ = sh.run(limit, "batched", 0, poll_every)
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res)
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
+    if kb == "64" and limit == 0:
+        assert res[0].scans * 4 < _LocalShards(nodes, pod, prof, world).run(limit, "batched", max(1, ref.placed), poll_every)[0][0].scans  # far fewer exchanges than levels
+
+
+@pytest.mark.parametrize("world,seed", [(2, 0), (3, 1), (2, 2), (4, 3)])
+def test_sharded_blind_level_batches_random_plugin_mix(ccref, world, seed):
+    """Taints / preferred affinity with few holders: the roll-back cases, sharded."""
+    rng = np.random.default_rng(7600 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(200, 3000)))
+    prof.filter_mask |= M.F_FIT
+    for limit in (0, int(rng.choice([37, 500]))):
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+        res, _ = _LocalShards(nodes, pod, prof, world).run(limit, "batched", 0, 4)
+        assert all(r.placed == ref.placed and r.stop == ref.stop for r in res)
+        assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+        if ref.stop == M.STOP_UNSCHEDULABLE:
+            assert np.array_equal(sum(r.hist for r in res), ref.hist)
 
 
 def test_full_size_batched_equals_sequential_1m_nodes():

@@ -62,6 +62,22 @@ def test_random_plugin_mix_fast_and_ordered_paths(ccref, seed):
         _same(got, ref, check_log=want_log)
 
 
+@pytest.mark.parametrize("kb", ["1", "3", "64"])
+@pytest.mark.parametrize("seed", range(12))
+def test_multi_kernel_form_blind_level_batches(ccref, monkeypatch, seed, kb):
+    """The multi-kernel form (CCSIM_PERSIST=0; also every sharded run and every snapshot beyond the persistent form's LDS) resolves
+    several score levels per pass as well: blind commit on the rows, validation in the decision, roll-back by stamp."""
+    monkeypatch.setenv("CCSIM_PERSIST", "0")
+    monkeypatch.setenv("CCSIM_LEVEL_BATCH", kb)
+    rng = np.random.default_rng(7000 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 3000)))
+    limit = int(rng.choice([0, 0, 37, 500]))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    for want_log in (False, True):
+        got, _ = _run(nodes, pod, prof, limit, want_log)
+        _same(got, ref, check_log=want_log)
+
+
 def test_continued_runs_and_mode_switches(ccref):
     """The persistent launch starts from the columns and writes them back: runs continue across launches and modes."""
     nodes, pod, prof = synth.make_config("C3", n_nodes=6000, seed=99)
