@@ -1852,6 +1852,7 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
     if (const char *f = getenv("CCSIM_DIST_POLL")) per_poll = atoi(f) > 0 ? atoi(f) : per_poll; // tuning knob (the SAME value on every rank)
     int64_t last_placed = -1;
     int idle = 0;
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream)); // (kernel_ns of a sharded run: the whole pass train, exchanges included)
     for (;;) {
         for (int p = 0; p < per_poll; p++) {
             if ((rc = ccsim_dist_scan(e))) return rc;
@@ -1867,6 +1868,11 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
         last_placed = placed;
         if (idle >= 64) return fail(e, -EIO, "sharded simulation made no progress in %d passes", 64 * per_poll);
     }
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipEventSynchronize(e->ev1));
+    float ms = 0;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->kernel_ms = ms;
     return ccsim_dist_finish(e, out);
 }
 
