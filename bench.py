@@ -110,6 +110,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch timing run (PMC collection runs)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: RCCL announces itself on stdout (version banner, some of it at exit) -- everything but the line goes
+    # to stderr: fd 1 points at stderr for the run, the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -334,7 +339,8 @@ def main():
     elif rank == 0 and "cpu_baseline" not in out:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 
