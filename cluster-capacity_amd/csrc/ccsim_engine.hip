@@ -90,6 +90,9 @@ struct ccsim_engine {
     DevState *d_state = nullptr;
     DevState *h_state = nullptr; // pinned
     uint64_t *d_partials = nullptr; // [kMaxGrid][2]
+    DevState *d_state2 = nullptr;    // the fused sequential cycle (k_scan_fused) double-buffers state and partials by cycle parity
+    uint64_t *d_partials2 = nullptr;
+    int fused_allowed = 1;
     uint64_t *d_smp_partials = nullptr; // [kMaxGrid][2] sampled search (percentageOfNodesToScore < 100)
     int64_t *d_smp_prefix = nullptr;    // [kMaxGrid]
     int64_t smp_K = 0;                  // numFeasibleNodesToFind of the current run; 0 = every node is scored
@@ -249,6 +252,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     if (const char *f = getenv("CCSIM_NARROW")) e->narrow_allowed = atoi(f); // A/B knob
     if (const char *f = getenv("CCSIM_PERSIST")) e->persist_allowed = atoi(f); // A/B knob: 0 = multi-kernel batched mode
     if (const char *f = getenv("CCSIM_CW")) e->cw_allowed = atoi(f);           // A/B knob: 0 = coupled plugins one pass per placement
+    if (const char *f = getenv("CCSIM_FUSED")) e->fused_allowed = atoi(f);     // A/B knob: 0 = sequential cycle as k_scan + k_final
     if (hipSetDevice(e->device) != hipSuccess) {
         delete e;
         return -EIO;
@@ -266,6 +270,8 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
         hipHostMalloc((void **)&e->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&e->d_state, sizeof(DevState)) != hipSuccess ||
         hipMalloc((void **)&e->d_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
+        hipMalloc((void **)&e->d_state2, sizeof(DevState)) != hipSuccess ||
+        hipMalloc((void **)&e->d_partials2, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_smp_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_smp_prefix, sizeof(int64_t) * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess ||
@@ -293,6 +299,8 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->h_mstate) (void)hipHostFree(e->h_mstate);
     if (e->d_state) (void)hipFree(e->d_state);
     if (e->d_partials) (void)hipFree(e->d_partials);
+    if (e->d_state2) (void)hipFree(e->d_state2);
+    if (e->d_partials2) (void)hipFree(e->d_partials2);
     if (e->d_smp_partials) (void)hipFree(e->d_smp_partials);
     if (e->d_smp_prefix) (void)hipFree(e->d_smp_prefix);
     if (e->d_hist) (void)hipFree(e->d_hist);
@@ -1015,6 +1023,35 @@ static int launch_final(ccsim_engine *e) {
     return 0;
 }
 
+// the sequential cycle as one dispatch (k_scan_fused): no topology-coupled plugin, every node scored, one GPU
+static bool fused_ok(const ccsim_engine *e) {
+    return e->fused_allowed && e->mode == CCSIM_MODE_SEQUENTIAL && e->n_ranks == 0 && e->smp_K == 0 && !e->time_passes && e->pts.n == 0 &&
+           e->soft.n == 0 && !e->ipa.on;
+}
+static FusedArgs fused_args(ccsim_engine *e, int parity) {
+    FusedArgs a{};
+    a.c = e->cols, a.p = e->pod, a.st[0] = e->d_state, a.st[1] = e->d_state2, a.partials[0] = e->d_partials, a.partials[1] = e->d_partials2;
+    a.chunk = e->chunk, a.n_partials = e->grid, a.parity = parity, a.log = e->d_log;
+    return a;
+}
+static void launch_scan_fused(ccsim_engine *e, int parity) {
+    const FusedArgs a = fused_args(e, parity);
+    const int nx = e->pod.nx;
+    dim3 g(e->grid), b(kThreads);
+    if (nx == 0 && e->cols.narrow) hipLaunchKernelGGL((k_scan_fused<0, true>), g, b, 0, e->stream, a);
+    else if (nx == 0) hipLaunchKernelGGL((k_scan_fused<0, false>), g, b, 0, e->stream, a);
+    else if (nx == 1) hipLaunchKernelGGL((k_scan_fused<1, false>), g, b, 0, e->stream, a);
+    else if (nx == 2) hipLaunchKernelGGL((k_scan_fused<2, false>), g, b, 0, e->stream, a);
+    else if (nx <= 4) hipLaunchKernelGGL((k_scan_fused<4, false>), g, b, 0, e->stream, a);
+    else hipLaunchKernelGGL((k_scan_fused<kMaxExtra, false>), g, b, 0, e->stream, a);
+}
+// `rounds` cycles: an even number of fused launches (the state ends in the buffer the host reads) + the pending decision
+static void launch_fused_batch(ccsim_engine *e, int rounds) {
+    const int n = (rounds + 1) & ~1;
+    for (int r = 0; r < n; r++) launch_scan_fused(e, r & 1);
+    hipLaunchKernelGGL(k_final_fused, dim3(1), dim3(kThreads), 0, e->stream, fused_args(e, 0));
+}
+
 // one scheduling cycle attempt of the sequential mode: the scan(s) + the one-block reduction / decision
 static void launch_cycle(ccsim_engine *e) {
     if (e->smp_K > 0) { // sampled search: count, prefix, score the first K feasible nodes of the visiting order
@@ -1249,7 +1286,9 @@ static int enqueue_rounds(ccsim_engine *e, int rounds) {
                 // the stretch, the rest of this replay is no-ops and the next replay starts with it.
                 for (int r = 0; r < 2; r++) launch_rows_flush(e, true), launch_level_score(e), launch_level_final(e, false, true);
                 for (int r = 0; r < rounds; r++) launch_level_commit(e), launch_level_final(e, true, false);
-            } else
+            } else if (fused_ok(e))
+                launch_fused_batch(e, rounds);
+            else
                 for (int r = 0; r < rounds; r++) launch_pass(e);
             HIPCHK(e, hipStreamEndCapture(e->stream, &e->graph));
             HIPCHK(e, hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
@@ -1259,7 +1298,9 @@ static int enqueue_rounds(ccsim_engine *e, int rounds) {
         }
         HIPCHK(e, hipGraphLaunch(e->graph_exec, e->stream));
     } else {
-        for (int r = 0; r < rounds; r++) launch_pass(e);
+        if (fused_ok(e)) launch_fused_batch(e, rounds);
+        else
+            for (int r = 0; r < rounds; r++) launch_pass(e);
         HIPCHK(e, hipGetLastError());
     }
     return 0;

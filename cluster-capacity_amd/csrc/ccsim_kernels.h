@@ -1367,6 +1367,269 @@ __global__ void k_decide(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_scan_fused: the sequential mode's cycle as ONE dispatch (profiles without topology-coupled plugins, every node scored).
+// k_scan -> k_final spends ~40 % of a cycle on the one-block reduction + decision and the dispatch boundary in front of it
+// (10.2 us scan, ~7 us decision at 1M nodes, profiles/r02).  Here the decision of cycle t is the PROLOGUE of the scan of
+// cycle t + 1, replicated: every block reduces the <= 1024 partial records of the previous scan (L2-resident), runs the same
+// decision on the same numbers, and knows the winner.  No other block's data is touched: the thread that owns the winner
+// applies NodeInfo.update (types.go:409-428) to the values it has just loaded, stores them, and scores the node in its new
+// state -- a node's columns are read by exactly one thread of the grid, so there is nothing to race with.  State and partials
+// are double-buffered by cycle parity (a block still reading buffer t must not see block 0 writing the state of t + 1).
+// The last decision of a batch is made by k_final on the buffer the host reads.
+// ------------------------------------------------------------------------------------------------
+struct FusedArgs {
+    DevCols c;
+    DevPod p;
+    DevState *st[2];        // [parity]
+    uint64_t *partials[2];  // [parity][grid][2]
+    int64_t chunk;
+    int32_t n_partials, parity; // this launch READS st[parity] / partials[parity] and WRITES the other pair
+    int32_t *log;
+};
+
+// the decision of one cycle on the reduced record: a pure function of a few scalars of the state (no working copy of the 500-byte
+// DevState: as a local of every thread of the grid it is a scratch frame -- 96 MB of scratch traffic per launch at 1M nodes)
+struct FusedDecision {
+    int64_t winner, placed, rounds; // winner: global index or -1
+    int32_t mt_a, ma_a, done, last_feasible;
+    bool rescan;
+};
+__device__ __forceinline__ FusedDecision fused_decide(const DevState *s, uint64_t key, uint32_t mt, uint32_t ma, int64_t nfeas) {
+    FusedDecision d;
+    d.winner = -1, d.placed = s->placed, d.rounds = s->rounds, d.mt_a = s->mt_a, d.ma_a = s->ma_a, d.done = 0, d.last_feasible = s->last_feasible;
+    d.rescan = false;
+    if (key == 0) d.done = DONE_UNSCHEDULABLE, d.rounds += 1, d.last_feasible = 0; // schedule_one.go:448-454
+    else if ((int32_t)mt != d.mt_a || (int32_t)ma != d.ma_a) d.mt_a = (int32_t)mt, d.ma_a = (int32_t)ma, d.rescan = true; // stale maxima: this scan redoes it
+    else {
+        d.winner = key_index(key);
+        d.placed += 1, d.rounds += 1, d.last_feasible = (int32_t)nfeas;
+        const int64_t limit = s->limit;
+        if (limit > 0 && d.placed >= limit) d.done = DONE_LIMIT; // simulator.go:297-312
+    }
+    return d;
+}
+// (one thread) the state after the decision: everything else is carried over
+__device__ __forceinline__ void fused_store(DevState *out, const DevState *in, const FusedDecision &d, int32_t have_prev, int64_t n_nodes) {
+    if (out != in) *out = *in;
+    out->winner = d.winner, out->placed = d.placed, out->rounds = d.rounds, out->mt_a = d.mt_a, out->ma_a = d.ma_a, out->done = d.done;
+    out->last_feasible = d.last_feasible, out->have_prev = have_prev;
+    out->scans = in->scans + 1;
+    out->last_evaluated = (int32_t)n_nodes;
+}
+
+template <int NX, bool NARROW>
+__global__ __launch_bounds__(kThreads) void k_scan_fused(FusedArgs a) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ uint64_t s_key[kThreads / 64];
+    __shared__ uint32_t s_mt[kThreads / 64], s_ma[kThreads / 64], s_nf[kThreads / 64];
+    __shared__ int64_t s_nf64[kThreads / 64];
+    const DevState *sin = a.st[a.parity];
+    if (sin->done) { // the run ended in an earlier launch of this batch: carry the final state to the other buffer, do nothing else
+        if (blockIdx.x == 0 && tid == 0 && a.st[a.parity ^ 1]->done != sin->done) *a.st[a.parity ^ 1] = *sin;
+        return;
+    }
+    // ---- prologue: the previous scan's decision, in every block
+    FusedDecision d;
+    d.winner = -1, d.placed = sin->placed, d.rounds = sin->rounds, d.mt_a = sin->mt_a, d.ma_a = sin->ma_a, d.done = 0, d.last_feasible = sin->last_feasible;
+    d.rescan = false;
+    const bool have_prev = sin->have_prev != 0;
+    if (have_prev) {
+        uint64_t key = 0;
+        uint32_t mt = 0, ma = 0;
+        int64_t nf = 0;
+        const uint64_t *pin = a.partials[a.parity];
+        for (int i = tid; i < a.n_partials; i += kThreads) {
+            const uint64_t qk = ld_agent(pin + 2 * (int64_t)i), qn = ld_agent(pin + 2 * (int64_t)i + 1);
+            key = qk > key ? qk : key;
+            const uint32_t norm = (uint32_t)qn, m1 = norm >> kStatCntShift, m2 = norm & kStatAffMask;
+            mt = m1 > mt ? m1 : mt, ma = m2 > ma ? m2 : ma;
+            nf += (uint32_t)(qn >> 32);
+        }
+        key = wave_max_u64(key), mt = wave_max_u32(mt), ma = wave_max_u32(ma), nf = wave_sum_i64(nf);
+        if (lane == 0) s_key[wave] = key, s_mt[wave] = mt, s_ma[wave] = ma, s_nf64[wave] = nf;
+        __syncthreads();
+        key = 0, mt = 0, ma = 0, nf = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; w++) {
+            key = s_key[w] > key ? s_key[w] : key, mt = s_mt[w] > mt ? s_mt[w] : mt, ma = s_ma[w] > ma ? s_ma[w] : ma;
+            nf += s_nf64[w];
+        }
+        __syncthreads(); // (s_key / s_mt / s_ma are reused by the scan's own reduction below)
+        d = fused_decide(sin, key, mt, ma, nf);
+    }
+    const int64_t w_g = d.winner;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (w_g >= 0 && a.log && d.placed - 1 < sin->log_cap) a.log[d.placed - 1] = (int32_t)w_g;
+        DevState *out = a.st[a.parity ^ 1]; // (never the buffer this launch reads: a block that starts late must see what the others saw)
+        if (have_prev) fused_store(out, sin, d, 1, a.c.n);
+        else {
+            *out = *sin;
+            out->have_prev = 1, out->winner = -1;
+        }
+    }
+    if (d.done == DONE_UNSCHEDULABLE) return; // nothing to apply, nothing to scan for
+    // (DONE_LIMIT: the last winner is still to be applied by the thread that owns it -- one more pass, its partials unused)
+
+    const uint32_t mt = (uint32_t)d.mt_a, ma = (uint32_t)d.ma_a;
+    const int64_t lo = (int64_t)blockIdx.x * a.chunk;
+    int64_t hi = lo + a.chunk;
+    if (hi > a.c.n_pad) hi = a.c.n_pad;
+    const int64_t w_i = w_g - a.c.global_offset; // the winner's index in this shard (-1 - offset: none)
+    uint64_t best = 0;
+    uint32_t mt_b = 0, ma_b = 0, nfeas = 0;
+    const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
+    for (int64_t base = lo; base < hi; base += kTile) {
+        const int64_t i0 = base + 2 * tid;
+        const uint2 sw = *reinterpret_cast<const uint2 *>(a.c.stat + i0);
+        int2 a0n{}, a1n{}, r0n{}, r1n{}, z0n{}, z1n{};
+        longlong2 A0{}, A1{}, R0{}, R1{}, Z0{}, Z1{};
+        if (NARROW) {
+            a0n = *reinterpret_cast<const int2 *>(a.c.a32[0] + i0), a1n = *reinterpret_cast<const int2 *>(a.c.a32[1] + i0);
+            r0n = *reinterpret_cast<const int2 *>(a.c.r32[0] + i0), r1n = *reinterpret_cast<const int2 *>(a.c.r32[1] + i0);
+            z0n = *reinterpret_cast<const int2 *>(a.c.z32[0] + i0), z1n = *reinterpret_cast<const int2 *>(a.c.z32[1] + i0);
+        } else {
+            const Cols6 c6 = load_cols6<false>(a.c, i0);
+            A0 = c6.A0, A1 = c6.A1, R0 = c6.R0, R1 = c6.R1, Z0 = c6.Z0, Z1 = c6.Z1;
+        }
+        const int2 AP = *reinterpret_cast<const int2 *>(a.c.alloc_pods + i0);
+        int2 NP = *reinterpret_cast<const int2 *>(a.c.pod_count + i0);
+        int64_t xa0[NX > 0 ? NX : 1], xr0[NX > 0 ? NX : 1], xa1[NX > 0 ? NX : 1], xr1[NX > 0 ? NX : 1];
+        if (NX > 0) {
+#pragma unroll
+            for (int x = 0; x < NX; x++) {
+                xa0[x] = xr0[x] = xa1[x] = xr1[x] = 0;
+                if (x < a.p.nx) {
+                    const int col = a.p.xcol[x];
+                    const longlong2 XA = *reinterpret_cast<const longlong2 *>(a.c.alloc[col] + i0);
+                    const longlong2 XR = *reinterpret_cast<const longlong2 *>(a.c.req[col] + i0);
+                    xa0[x] = XA.x, xr0[x] = XR.x, xa1[x] = XA.y, xr1[x] = XR.y;
+                }
+            }
+        }
+        // ---- the winner of the previous cycle lives in this pair: NodeInfo.update on the loaded values, stored back
+        if (w_i == i0 || w_i == i0 + 1) {
+            const bool second = w_i == i0 + 1;
+            if (NARROW) { // the int64 columns are the canonical state: read-modify-write them too (this one thread)
+                const int64_t q0 = a.c.req[0][w_i] + a.p.req[0], q1 = a.c.req[1][w_i] + a.p.req[1];
+                const int64_t y0 = a.c.nz_mcpu[w_i] + a.p.nz_mcpu, y1 = a.c.nz_mem[w_i] + a.p.nz_mem;
+                a.c.req[0][w_i] = q0, a.c.req[1][w_i] = q1, a.c.nz_mcpu[w_i] = y0, a.c.nz_mem[w_i] = y1;
+                store_mirror(a.c, w_i, q0, q1, y0, y1);
+                (second ? r0n.y : r0n.x) += npod.req0, (second ? r1n.y : r1n.x) += npod.req1;
+                (second ? z0n.y : z0n.x) += npod.nz0, (second ? z1n.y : z1n.x) += npod.nz1;
+            } else {
+                (second ? R0.y : R0.x) += a.p.req[0], (second ? R1.y : R1.x) += a.p.req[1];
+                (second ? Z0.y : Z0.x) += a.p.nz_mcpu, (second ? Z1.y : Z1.x) += a.p.nz_mem;
+                a.c.req[0][w_i] = second ? R0.y : R0.x, a.c.req[1][w_i] = second ? R1.y : R1.x;
+                a.c.nz_mcpu[w_i] = second ? Z0.y : Z0.x, a.c.nz_mem[w_i] = second ? Z1.y : Z1.x;
+                store_mirror(a.c, w_i, second ? R0.y : R0.x, second ? R1.y : R1.x, second ? Z0.y : Z0.x, second ? Z1.y : Z1.x);
+            }
+            (second ? NP.y : NP.x) += 1;
+            a.c.pod_count[w_i] = second ? NP.y : NP.x;
+            a.c.placed_cnt[w_i] += 1;
+            if (NX > 0) {
+#pragma unroll
+                for (int x = 0; x < NX; x++)
+                    if (x < a.p.nx && a.p.req[a.p.xcol[x]] != 0) {
+                        (second ? xr1[x] : xr0[x]) += a.p.req[a.p.xcol[x]];
+                        a.c.req[a.p.xcol[x]][w_i] = second ? xr1[x] : xr0[x];
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t w = k ? sw.y : sw.x;
+            const int64_t a_cpu = k ? A0.y : A0.x, a_mem = k ? A1.y : A1.x, r_cpu = k ? R0.y : R0.x, r_mem = k ? R1.y : R1.x;
+            const int64_t z_cpu = k ? Z0.y : Z0.x, z_mem = k ? Z1.y : Z1.x;
+            const int32_t a_pods = k ? AP.y : AP.x, npods = k ? NP.y : NP.x;
+            const int32_t na0 = k ? a0n.y : a0n.x, na1 = k ? a1n.y : a1n.x, nr0 = k ? r0n.y : r0n.x, nr1 = k ? r1n.y : r1n.x;
+            const int32_t nz0 = k ? z0n.y : z0n.x, nz1 = k ? z1n.y : z1n.x;
+            bool feasible = (w >> kStatOkBit) && (NARROW ? fits_narrow(a.p, npod, na0, na1, nr0, nr1, a_pods, npods)
+                                                         : fits_core(a.p, a_cpu, a_mem, r_cpu, r_mem, a_pods, npods));
+            int64_t xak[NX > 0 ? NX : 1], xrk[NX > 0 ? NX : 1];
+#pragma unroll
+            for (int x = 0; x < (NX > 0 ? NX : 1); x++) {
+                xak[x] = k ? xa1[x] : xa0[x], xrk[x] = k ? xr1[x] : xr0[x];
+                if (NX > 0 && x < a.p.nx) {
+                    const int64_t rq = a.p.req[a.p.xcol[x]];
+                    if (a.p.fit_enabled && !a.p.all_zero_req && rq > 0 && rq > xak[x] - xrk[x]) feasible = false;
+                }
+            }
+            nfeas += (uint32_t)__popcll(__ballot(feasible));
+            if (feasible) {
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                const int64_t total = static_score(a.p, cnt, aff, img, mt, ma) +
+                                      (NARROW ? dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1)
+                                              : (NX > 0 && a.p.gen_score ? dynamic_score_gen<NX>(a.p, a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem, xak, xrk)
+                                                                         : dynamic_score(a.p, make_rcp(a_cpu, a_mem), a_cpu, a_mem, r_cpu, r_mem, z_cpu, z_mem)));
+                const uint64_t key = make_key(total, a.c.global_offset + i0 + k);
+                best = key > best ? key : best;
+                mt_b = cnt > mt_b ? cnt : mt_b, ma_b = aff > ma_b ? aff : ma_b;
+            }
+        }
+    }
+    best = wave_max_u64(best), mt_b = wave_max_u32(mt_b), ma_b = wave_max_u32(ma_b);
+    if (lane == 0) s_key[wave] = best, s_mt[wave] = mt_b, s_ma[wave] = ma_b, s_nf[wave] = nfeas;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t k = 0;
+        uint32_t m1 = 0, m2 = 0, nf = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; w++) {
+            k = s_key[w] > k ? s_key[w] : k, m1 = s_mt[w] > m1 ? s_mt[w] : m1, m2 = s_ma[w] > m2 ? s_ma[w] : m2;
+            nf += s_nf[w];
+        }
+        uint64_t *pout = a.partials[a.parity ^ 1];
+        st_agent(pout + 2 * (int64_t)blockIdx.x, k);
+        st_agent(pout + 2 * (int64_t)blockIdx.x + 1, (uint64_t)((m1 << kStatCntShift) | m2) | ((uint64_t)nf << 32));
+    }
+}
+
+// k_final_fused: the pending decision at the end of a batch of fused cycles (one block, buffer `parity` = the one the host reads):
+// reduce, decide, apply the winner to the columns -- afterwards nothing is pending (have_prev = 0).
+__global__ __launch_bounds__(kThreads) void k_final_fused(FusedArgs a) {
+    DevState *sp = a.st[a.parity];
+    if (sp->done || !sp->have_prev) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ uint64_t s_key[kThreads / 64];
+    __shared__ uint32_t s_mt[kThreads / 64], s_ma[kThreads / 64];
+    __shared__ int64_t s_nf64[kThreads / 64];
+    uint64_t key = 0;
+    uint32_t mt = 0, ma = 0;
+    int64_t nf = 0;
+    const uint64_t *pin = a.partials[a.parity];
+    for (int i = tid; i < a.n_partials; i += kThreads) {
+        const uint64_t qk = ld_agent(pin + 2 * (int64_t)i), qn = ld_agent(pin + 2 * (int64_t)i + 1);
+        key = qk > key ? qk : key;
+        const uint32_t norm = (uint32_t)qn, m1 = norm >> kStatCntShift, m2 = norm & kStatAffMask;
+        mt = m1 > mt ? m1 : mt, ma = m2 > ma ? m2 : ma;
+        nf += (uint32_t)(qn >> 32);
+    }
+    key = wave_max_u64(key), mt = wave_max_u32(mt), ma = wave_max_u32(ma), nf = wave_sum_i64(nf);
+    if (lane == 0) s_key[wave] = key, s_mt[wave] = mt, s_ma[wave] = ma, s_nf64[wave] = nf;
+    __syncthreads();
+    if (tid != 0) return;
+    key = 0, mt = 0, ma = 0, nf = 0;
+    for (int w = 0; w < kThreads / 64; w++) {
+        key = s_key[w] > key ? s_key[w] : key, mt = s_mt[w] > mt ? s_mt[w] : mt, ma = s_ma[w] > ma ? s_ma[w] : ma;
+        nf += s_nf64[w];
+    }
+    const FusedDecision d = fused_decide(sp, key, mt, ma, nf);
+    const int64_t i = d.winner - a.c.global_offset;
+    if (d.winner >= 0 && i >= 0 && i < a.c.n) { // NodeInfo.update (types.go:409-428)
+        const int64_t r0 = a.c.req[0][i] + a.p.req[0], r1 = a.c.req[1][i] + a.p.req[1];
+        const int64_t z0 = a.c.nz_mcpu[i] + a.p.nz_mcpu, z1 = a.c.nz_mem[i] + a.p.nz_mem;
+        a.c.req[0][i] = r0, a.c.req[1][i] = r1, a.c.nz_mcpu[i] = z0, a.c.nz_mem[i] = z1;
+        a.c.pod_count[i] += 1, a.c.placed_cnt[i] += 1;
+        store_mirror(a.c, i, r0, r1, z0, z1);
+#pragma unroll 1
+        for (int col = 2; col < a.p.ncol; col++)
+            if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
+        if (a.log && d.placed - 1 < sp->log_cap) a.log[d.placed - 1] = (int32_t)d.winner;
+    }
+    fused_store(sp, sp, d, 0, a.c.n);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_static: once per pod spec.  NodeUnschedulable (node_unschedulable.go:133-150), TaintToleration
 // filter + PreferNoSchedule count via the taint-set table (taint_toleration.go:111-121,169-194),
 // NodeAffinity required match + preferred weight sum via requirement tables
