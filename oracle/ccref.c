@@ -615,6 +615,20 @@ typedef struct {
     int threads;
 } workspace;
 
+/* RunScorePlugins' last block (S/framework/runtime/framework.go:1214-1238): plugin weight x normalized score, summed per node */
+void ccref_weigh(int64_t *total, const int64_t *scores, int64_t weight, int64_t n) {
+    for (int64_t i = 0; i < n; i++) total[i] += scores[i] * weight;
+}
+
+/* selectHost (S/schedule_one.go:894-941) under the canonical tie-break: the reference samples uniformly among the nodes
+ * of the maximum TotalScore; the FIRST of them in feasible-list order is the outcome chosen here */
+int64_t ccref_select_host(const int64_t *total, int64_t n) {
+    int64_t best = 0;
+    for (int64_t i = 1; i < n; i++)
+        if (total[i] > total[best]) best = i;
+    return best;
+}
+
 static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const ccref_pod *pod, ccref_sched_state *st,
                                ccref_result *res, workspace *ws) {
     const int64_t N = nd->n;
@@ -727,7 +741,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
             for (int64_t i = 0; i < nf; i++)
                 sc[i] = nd->taintset_id ? pod->taint_prefer_cnt[nd->taintset_id[ws->feas[i]]] : 0;
             ccref_default_normalize(MAX_NODE_SCORE, 1, sc, nf);
-            for (int64_t i = 0; i < nf; i++) ws->total[i] += sc[i] * prof->w_taint;
+            ccref_weigh(ws->total, sc, prof->w_taint, nf);
         }
         /* NodeAffinity Score + NormalizeScore (node_affinity.go:260-290); Skip without preferred terms */
         if (prof->w_nodeaffinity && pod->n_preferred > 0) {
@@ -739,7 +753,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
                 sc[i] = count;
             }
             ccref_default_normalize(MAX_NODE_SCORE, 0, sc, nf);
-            for (int64_t i = 0; i < nf; i++) ws->total[i] += sc[i] * prof->w_nodeaffinity;
+            ccref_weigh(ws->total, sc, prof->w_nodeaffinity, nf);
         }
         /* NodeResourcesFit LeastAllocated (fit.go:663-672); no normalization */
         if (prof->w_fit) {
@@ -749,7 +763,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
         /* PodTopologySpread soft constraints */
         if (prof->w_topologyspread && has_soft_spread(pod)) {
             pts_scores(nd, pod, ws->placed, ws->feas, nf, sc);
-            for (int64_t i = 0; i < nf; i++) ws->total[i] += sc[i] * prof->w_topologyspread;
+            ccref_weigh(ws->total, sc, prof->w_topologyspread, nf);
         }
         /* InterPodAffinity Score + NormalizeScore (scoring.go:226-290); PreScore Skip without any term hit */
         if (prof->w_interpodaffinity && ipa && ipa->entries > 0) {
@@ -763,7 +777,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
                 sc[i] = v;
             }
             ccref_ipa_normalize(sc, nf);
-            for (int64_t i = 0; i < nf; i++) ws->total[i] += sc[i] * prof->w_interpodaffinity;
+            ccref_weigh(ws->total, sc, prof->w_interpodaffinity, nf);
         }
         /* NodeResourcesBalancedAllocation (balanced_allocation.go:100-115); Skip for best-effort */
         if (prof->w_balanced && !balanced_skipped(prof, pod)) {
@@ -775,10 +789,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
         if (prof->w_imagelocality && pod->image_score)
             for (int64_t i = 0; i < nf; i++) ws->total[i] += (int64_t)pod->image_score[ws->feas[i]] * prof->w_imagelocality;
         /* selectHost, canonical tie-break: first maximum in feasible-list order */
-        int64_t best = 0;
-        for (int64_t i = 1; i < nf; i++)
-            if (ws->total[i] > ws->total[best]) best = i;
-        winner = ws->feas[best];
+        winner = ws->feas[ccref_select_host(ws->total, nf)];
     }
 
     /* assume -> NodeInfo.AddPod -> update (types.go:409-428) */
@@ -829,6 +840,39 @@ static void ws_free(workspace *ws) {
         free(ws->ipa.exist[k]);
         free(ws->ipa.score[k]);
     }
+}
+
+/* Test hooks (tests/test_reference_vectors.py): the PreFilter states of the two topology-coupled plugins for a cluster state, so that the
+ * counting loops above can be held against the reference's own (calPreFilterState; updateWithAffinityTerms / updateWithAntiAffinityTerms). */
+int ccref_unit_pts_prefilter(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, int c, int64_t *match_num, int64_t *min_match,
+                             int64_t *n_dom) {
+    if (c < 0 || c >= pod->n_spread || !pod->spread[c].hard) return -1;
+    pts_state s;
+    memset(&s, 0, sizeof s);
+    for (int j = 0; j < pod->n_spread; j++)
+        if (pod->spread[j].hard) s.match_num[j] = (int64_t *)malloc(sizeof(int64_t) * (size_t)(pod->spread[j].n_domains + 1));
+    pts_prefilter(nd, pod, placed, &s);
+    memcpy(match_num, s.match_num[c], sizeof(int64_t) * (size_t)(pod->spread[c].n_domains + 1));
+    *min_match = s.min_match[c], *n_dom = s.n_dom[c];
+    for (int j = 0; j < CCREF_MAX_TSC; j++) free(s.match_num[j]);
+    return 0;
+}
+
+int ccref_unit_ipa_build(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, int k, int64_t *aff, int64_t *anti, int64_t *exist,
+                         int64_t *score, int64_t *totals) {
+    if (!pod->has_ipa || k < 0 || k >= pod->ipa.n_keys) return -1;
+    ipa_state s;
+    memset(&s, 0, sizeof s);
+    for (int j = 0; j < pod->ipa.n_keys; j++) {
+        size_t len = sizeof(int64_t) * (size_t)(pod->ipa.key_ndom[j] + 1);
+        s.aff[j] = (int64_t *)malloc(len), s.anti[j] = (int64_t *)malloc(len), s.exist[j] = (int64_t *)malloc(len), s.score[j] = (int64_t *)malloc(len);
+    }
+    ipa_build(nd, pod, placed, &s);
+    size_t len = sizeof(int64_t) * (size_t)(pod->ipa.key_ndom[k] + 1);
+    memcpy(aff, s.aff[k], len), memcpy(anti, s.anti[k], len), memcpy(exist, s.exist[k], len), memcpy(score, s.score[k], len);
+    totals[0] = s.aff_total, totals[1] = s.exist_total, totals[2] = s.entries;
+    for (int j = 0; j < CCREF_MAX_IPA_KEYS; j++) free(s.aff[j]), free(s.anti[j]), free(s.exist[j]), free(s.score[j]);
+    return 0;
 }
 
 int64_t ccref_schedule_one(const ccref_profile *prof, ccref_nodes *nodes, const ccref_pod *pod, ccref_sched_state *st,

@@ -253,6 +253,15 @@ int64_t ccref_balanced_allocation(const int64_t *requested, const int64_t *alloc
 void ccref_default_normalize(int64_t max_priority, int reverse, int64_t *scores, int64_t n);
 int32_t ccref_num_feasible_nodes_to_find(int32_t percentage, int32_t num_all_nodes);
 double ccref_go_log(double x); /* restatement of Go's math.Log (pure-Go path) */
+/* RunScorePlugins' weight-and-sum block and selectHost under the canonical tie-break: the functions the cycle itself calls */
+void ccref_weigh(int64_t *total, const int64_t *scores, int64_t weight, int64_t n);
+int64_t ccref_select_host(const int64_t *total, int64_t n);
+/* test hooks: PodTopologySpread's / InterPodAffinity's PreFilter state of a cluster (match_num etc. hold n_domains + 1 entries; -1 = the domain is
+ * absent from TpValueToMatchNum; totals = len(affinityCounts) entries, existing anti-affinity entries, PreScore hits) */
+int ccref_unit_pts_prefilter(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, int c, int64_t *match_num, int64_t *min_match,
+                             int64_t *n_dom);
+int ccref_unit_ipa_build(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, int k, int64_t *aff, int64_t *anti, int64_t *exist,
+                         int64_t *score, int64_t *totals);
 /* the NormalizeScore steps of PodTopologySpread (scoring.go:226-265; ignored: in IgnoredNodes, NULL = none) and InterPodAffinity
  * (scoring.go:259-290), in place */
 void ccref_pts_normalize(int64_t *scores, const uint8_t *ignored, int64_t n);

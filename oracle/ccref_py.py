@@ -449,6 +449,60 @@ def go_log(x):
     return float(lib().ccref_go_log(float(x)))
 
 
+def weigh_and_select(scores_per_plugin, weights):
+    """The cycle's own ccref_weigh / ccref_select_host: per-node TotalScore and the canonical winner's list position."""
+    n = len(scores_per_plugin[0]) if scores_per_plugin else 0
+    total = np.zeros(max(1, n), np.int64)
+    L = lib()
+    L.ccref_weigh.restype, L.ccref_weigh.argtypes = None, [_p64, _p64, C.c_int64, C.c_int64]
+    L.ccref_select_host.restype, L.ccref_select_host.argtypes = C.c_int64, [_p64, C.c_int64]
+    for sc, w in zip(scores_per_plugin, weights):
+        a = np.ascontiguousarray(sc, dtype=np.int64)
+        L.ccref_weigh(_ptr(total, _p64), _ptr(a, _p64), int(w), n)
+    return total[:n].tolist(), int(L.ccref_select_host(_ptr(total, _p64), n))
+
+
+def select_host(totals):
+    t = np.ascontiguousarray(totals, dtype=np.int64)
+    L = lib()
+    L.ccref_select_host.restype, L.ccref_select_host.argtypes = C.c_int64, [_p64, C.c_int64]
+    return int(L.ccref_select_host(_ptr(t, _p64), len(t)))
+
+
+def unit_pts_prefilter(nodes, pod, placed=None):
+    """PodTopologySpread's PreFilter state of a cluster: per hard constraint (match_num per value id with -1 = absent, min_match, n_dom)."""
+    m = _Marshal()
+    cn, cp = m.nodes(nodes), m.pod(pod)
+    pl = np.zeros(max(1, nodes.n), np.int32) if placed is None else np.ascontiguousarray(placed, dtype=np.int32)
+    fn = lib().ccref_unit_pts_prefilter
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(_Nodes), C.POINTER(_Pod), _p32, C.c_int, _p64, _p64, _p64]
+    out = []
+    for c, k in enumerate(pod.spread):
+        if not k.hard:
+            out.append(None)
+            continue
+        mn = np.zeros(k.n_domains + 1, np.int64)
+        lo, nd = C.c_int64(), C.c_int64()
+        assert fn(C.byref(cn), C.byref(cp), _ptr(pl, _p32), c, _ptr(mn, _p64), C.byref(lo), C.byref(nd)) == 0
+        out.append((mn.tolist(), int(lo.value), int(nd.value)))
+    return out
+
+
+def unit_ipa_build(nodes, pod, placed=None):
+    """InterPodAffinity's PreFilter / PreScore maps of a cluster: per key (aff, anti, exist, score) per value id, and the totals."""
+    m = _Marshal()
+    cn, cp = m.nodes(nodes), m.pod(pod)
+    pl = np.zeros(max(1, nodes.n), np.int32) if placed is None else np.ascontiguousarray(placed, dtype=np.int32)
+    fn = lib().ccref_unit_ipa_build
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(_Nodes), C.POINTER(_Pod), _p32, C.c_int, _p64, _p64, _p64, _p64, _p64]
+    out, tot = [], np.zeros(3, np.int64)
+    for k, nd_ in enumerate(pod.ipa.key_ndom):
+        arrs = [np.zeros(nd_ + 1, np.int64) for _ in range(4)]
+        assert fn(C.byref(cn), C.byref(cp), _ptr(pl, _p32), k, *[_ptr(a, _p64) for a in arrs], _ptr(tot, _p64)) == 0
+        out.append([a.tolist() for a in arrs])
+    return out, tot.tolist()
+
+
 def image_locality_score(sizes, num_nodes, total_nodes, n_containers):
     """ImageLocality score of one node: sizes / num_nodes of the pod's container images the node holds."""
     sz, nn = np.ascontiguousarray(sizes, dtype=np.int64), np.ascontiguousarray(num_nodes, dtype=np.int32)

@@ -92,6 +92,53 @@ FUNCS += [
     ("countIntolerableTaintsPreferNoSchedule", S + "/framework/plugins/tainttoleration/taint_toleration.go",
      "func countIntolerableTaintsPreferNoSchedule(taints []v1.Taint, tolerations []v1.Toleration) (intolerableTaints int) {", ["taints", "tolerations"], False),
 ]
+# Round 3 -- the LOOP-LEVEL pieces the oracle restates by hand: the counting loop of PodTopologySpread's PreFilter, the
+# updates of InterPodAffinity's topology-pair maps, the weight-and-sum block of RunScorePlugins, selectHost, topologyNormalizingWeight.
+# Entries may carry a 6th element: {"nth": which occurrence of the start line, "block": the cut text is a statement block (a loop), not a function
+# body, "header": lines of the function header}.  A closure handed to the parallelizer (`processNode := func(n int) {`, `Until(ctx, len(nodes),
+# func(index int) {`) is cut as a function of its index; the harness calls it for 0..n-1 in order (the pieces write disjoint slots).
+I = S + "/framework/plugins/interpodaffinity/filtering.go"
+P = S + "/framework/plugins/podtopologyspread"
+FUNCS += [
+    ("topologyToMatchedTermCount_update", I, "func (m topologyToMatchedTermCount) update(node *v1.Node, tk string, value int64) {", ["m", "node", "tk", "value"], False),
+    ("updateWithAffinityTerms", I, "func (m topologyToMatchedTermCount) updateWithAffinityTerms(", ["m", "terms", "pod", "node", "value"], False, {"header": 2}),
+    ("updateWithAntiAffinityTerms", I, "func (m topologyToMatchedTermCount) updateWithAntiAffinityTerms(terms []fwk.AffinityTerm, pod *v1.Pod, nsLabels labels.Set, node *v1.Node, value int64) {",
+     ["m", "terms", "pod", "nsLabels", "node", "value"], False),
+    ("nodeLabelsMatchSpreadConstraints", P + "/common.go", "func nodeLabelsMatchSpreadConstraints(nodeLabels map[string]string, constraints []topologySpreadConstraint) bool {", ["nodeLabels", "constraints"], False),
+    ("countPodsMatchSelector", P + "/common.go", "func countPodsMatchSelector(podInfos []fwk.PodInfo, selector labels.Selector, ns string) int {", ["podInfos", "selector", "ns"], False),
+    ("matchNodeInclusionPolicies", P + "/common.go", "func (tsc *topologySpreadConstraint) matchNodeInclusionPolicies(pod *v1.Pod, node *v1.Node, require nodeaffinity.RequiredNodeAffinity) bool {",
+     ["tsc", "pod", "node", "require"], False),
+    ("criticalPaths_update", P + "/filtering.go", "func (p *criticalPaths) update(tpVal string, num int) {", ["p", "tpVal", "num"], False),
+    # calPreFilterState (filtering.go:235-308) in its three pieces: the per-node closure, the merge of the per-node counts, the critical paths
+    ("calPreFilterState_processNode", P + "/filtering.go", "\tprocessNode := func(n int) {", ["n", "pl", "pod", "allNodes", "constraints", "requiredNodeAffinity", "tpCountsByNode"], False),
+    ("calPreFilterState_merge", P + "/filtering.go", "\tfor _, tpCounts := range tpCountsByNode {", ["s", "tpCountsByNode"], False, {"block": True}),
+    ("calPreFilterState_minima", P + "/filtering.go", "\tfor i := 0; i < len(constraints); i++ {", ["s", "constraints"], False, {"block": True, "nth": 1}),
+    # RunScorePlugins' second parallel block: plugin weight x normalized score, summed per node (runtime/framework.go:1214-1238)
+    ("RunScorePlugins_weigh", S + "/framework/runtime/framework.go", "\tf.Parallelizer().Until(ctx, len(nodes), func(index int) {",
+     ["index", "f", "nodes", "plugins", "pluginToNodeScores", "allNodePluginScores", "errCh", "cancel"], False),
+    ("nodeScoreHeap_Less", S + "/schedule_one.go", "func (h nodeScoreHeap) Less(i, j int) bool { return h[i].TotalScore > h[j].TotalScore }", ["h", "i", "j"], False, {"oneline": True}),
+    ("selectHost", S + "/schedule_one.go", "func selectHost(nodeScoreList []framework.NodePluginScores, count int) (string, []framework.NodePluginScores, error) {", ["nodeScoreList", "count"], False),
+    ("topologyNormalizingWeight", P + "/scoring.go", "func topologyNormalizingWeight(size int) float64 {", ["size"], False),
+]
+# per-function textual substitutions applied to a Go statement before the general rules (method calls on receivers the harness models as plain
+# Python values; Go's value semantics where Python would alias)
+REWRITE = {
+    "topologyToMatchedTermCount_update": [(r"^delete\(m, pair\)$", "m.pop(pair, None)")],
+    "updateWithAffinityTerms": [(r"\bm\.update\(", "topologyToMatchedTermCount_update(m, ")],
+    "updateWithAntiAffinityTerms": [(r"\bm\.update\(", "topologyToMatchedTermCount_update(m, ")],
+    "criticalPaths_update": [(r"^p\[1\] = p\[0\]$", "p[1] = gocopy(p[0])")],  # an array element is a struct VALUE: assignment copies
+    "calPreFilterState_processNode": [(r"\bc\.matchNodeInclusionPolicies\(", "matchNodeInclusionPolicies(c, ")],
+    "calPreFilterState_minima": [(r"^s\.CriticalPaths\[i\]\.update\((.+)\)$", r"criticalPaths_update(s.CriticalPaths[i], \1)")],
+    "matchNodeInclusionPolicies": [(r"helper\.DoNotScheduleTaintsFilterFunc\(\)", "DoNotScheduleTaintsFilter_closure"), (r"v1helper\.FindMatchingUntoleratedTaint\(", "FindMatchingUntoleratedTaint("),
+                                   (r"v1\.NodeInclusionPolicyHonor", "NodeInclusionPolicyHonor")],
+    "RunScorePlugins_weigh": [(r"^err := fmt\.Errorf\(.*$", "err = 'invalid score'"), (r"^errCh\.SendErrorWithCancel\(err, cancel\)$", "errCh.append(err)"),
+                              (r"framework\.MinNodeScore", "MinNodeScore"), (r"nodeScoreList\[index\]\.Score", "nodeScoreList[index]"), (r"make\(\[\]framework\.PluginScore, len\(plugins\)\)", "[None] * len(plugins)")],
+    "selectHost": [(r"^var h nodeScoreHeap = nodeScoreList$", "h = GoHeap(nodeScoreList)"), (r"^heap\.Init\(&h\)$", "heap.Init(h)"), (r"heap\.Pop\(&h\)\.\(framework\.NodePluginScores\)", "heap.Pop(h)"),
+                   (r"make\(\[\]framework\.NodePluginScores, 0, count\)", "[]"), (r"^return \"\", nil, errEmptyPriorityList$", "return '', None, 'empty priorityList'"),
+                   (r"^return sortedNodeScoreList\[0\]\.Name, sortedNodeScoreList, nil$", "return sortedNodeScoreList[0].Name, sortedNodeScoreList, None"),
+                   (r"^sortedNodeScoreList = sortedNodeScoreList\[:count\]$", "sortedNodeScoreList = sortedNodeScoreList[:count]")],
+    "topologyNormalizingWeight": [(r"math\.Log\(", "go_math_log(")],
+}
 # statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
 JOINED = {}
 DROP = {
@@ -102,24 +149,32 @@ DROP = {
 }
 
 
-def cut(rel, start_line):
-    """The body of the function / closure whose first line is `start_line`: up to the brace that closes it."""
+def cut(rel, start_line, nth=0):
+    """The body of the function / closure / block whose first line is `start_line` (its `nth` occurrence): up to the brace that closes it."""
     lines = open(os.path.join(REF, rel)).read().split("\n")
-    at = lines.index(start_line)
-    depth, body = 0, []
+    at = -1
+    for _ in range(nth + 1):
+        at = lines.index(start_line, at + 1)
+    depth, body, opened = 0, [], False
     for ln in lines[at:]:
         depth += ln.count("{") - ln.count("}")
+        opened = opened or "{" in ln
         body.append(ln)
-        if depth == 0:
+        if opened and depth == 0:
             break
     return at + 1, body
 
 
-def transliterate(name, params, body, int_div):
+def transliterate(name, params, body, int_div, opts=None):
     """Go subset -> Python, one line at a time.  Indentation follows the braces."""
+    opts = opts or {}
     out = [f"def {name}({', '.join(params)}):"]
     depth = 1
-    inner = body[1:-1]
+    if opts.get("oneline"):  # `func ... { return X }`
+        return out[0] + "\n    " + expr(re.search(r"\{ (.+) \}$", body[0]).group(1), int_div) + "\n"
+    inner = body if opts.get("block") else body[opts.get("header", 1):-1]
+    if not opts.get("block") and body[-1].strip() not in ("}", "}, metrics.Score)"):
+        raise SystemExit(f"{name}: unexpected closing line {body[-1]!r}")
     named = re.search(r"\) \((\w+) (\[\])?[\w.]+\) \{$", body[0])  # a named result: starts at its zero value, a bare `return` returns it
     if named:
         out.append("    " + named.group(1) + (" = []" if named.group(2) else " = 0"))
@@ -139,6 +194,21 @@ def transliterate(name, params, body, int_div):
             k += 1
             ln = ln + " " + inner[k].strip()
             JOINED[name] = JOINED.get(name, 0) + 1
+        mlit = re.search(r"(\w+(?:\.\w+)?)\{$", ln)
+        if mlit and not ln.endswith("InsufficientResource{") and not ln.startswith(("if ", "for ", "} else", "switch ", "func ")) and " := func(" not in ln and not ln.endswith("func(index int) {"):
+            fields = []  # a struct literal spread over several lines -> GoStruct(field=..., ...)
+            k += 1
+            while inner[k].strip() not in ("}", "})"):
+                f = inner[k].strip()
+                m = re.fullmatch(r"(\w+):\s+(.+),", f)
+                if not m:
+                    raise SystemExit(f"{name}: composite literal field {f!r}")
+                fields.append(f"{m.group(1)}={m.group(2)}")
+                JOINED[name] = JOINED.get(name, 0) + 1
+                k += 1
+            if inner[k].strip() == "})":
+                JOINED[name] = JOINED.get(name, 0) + 1  # the closing line (a bare `}` is a brace like any other to the audit)
+            ln = ln[: mlit.start()] + "GoStruct(" + ", ".join(fields) + ")" + (")" if inner[k].strip() == "})" else "")
         if ln.endswith("InsufficientResource{"):
             fields = []
             k += 1
@@ -160,6 +230,8 @@ def transliterate(name, params, body, int_div):
         ln = raw.strip()
         if not ln or ln.startswith("//"):
             continue
+        for pat, rep in REWRITE.get(name, []):
+            ln = re.sub(pat, rep, ln)
         m = re.fullmatch(r"switch (.+) \{", ln)
         if m:
             out.append("    " * depth + "_sw = " + expr(m.group(1), int_div))
@@ -213,6 +285,30 @@ def transliterate(name, params, body, int_div):
                 out.append("    " * depth + f"ok = {mi.group(3)} in {mi.group(2)}")
                 out.append("    " * depth + f"{mi.group(1)} = {mi.group(2)}.get({mi.group(3)}, \"\")")
                 ln = "if ok:"
+            elif re.fullmatch(r"for (\w+) := 0; \1 < len\((\w+)\); \1\+\+", ln):  # the counting loop
+                mc = re.fullmatch(r"for (\w+) := 0; \1 < len\((\w+)\); \1\+\+", ln)
+                ln = f"for {mc.group(1)} in range(len({mc.group(2)})):"
+            elif re.fullmatch(r"for (\w+), (\w+) := range (s\.TpValueToMatchNum\[i\])", ln):  # a map: Go's order is random, sorted here
+                mc = re.fullmatch(r"for (\w+), (\w+) := range (s\.TpValueToMatchNum\[i\])", ln)
+                ln = f"for {mc.group(1)}, {mc.group(2)} in sorted({mc.group(3)}.items()):"
+            elif re.fullmatch(r"if _, (\w+) := ([\w.]+)\[([\w.]+)\]; !\1", ln):  # presence test with an init statement
+                mc = re.fullmatch(r"if _, (\w+) := ([\w.]+)\[([\w.]+)\]; !\1", ln)
+                out.append("    " * depth + f"{mc.group(1)} = {mc.group(3)} in {mc.group(2)}")
+                ln = f"if not {mc.group(1)}:"
+            elif re.fullmatch(r"if (\w+), _ := (.+); !\1", ln):  # `if match, _ := x.Match(node); !match {`
+                mc = re.fullmatch(r"if (\w+), _ := (.+); !\1", ln)
+                out.append("    " * depth + f"{mc.group(1)}, _ = {expr(mc.group(2), int_div)}")
+                ln = f"if not {mc.group(1)}:"
+            elif re.fullmatch(r"if _, (\w+) := (.+); \1", ln):  # `if _, untolerated := f(...); untolerated {`
+                mc = re.fullmatch(r"if _, (\w+) := (.+); \1", ln)
+                out.append("    " * depth + f"_, {mc.group(1)} = {expr(mc.group(2), int_div)}")
+                ln = f"if {mc.group(1)}:"
+            elif re.fullmatch(r"for (\w+) := (.+); ; \1 = \2", ln):  # `for x := f(); ; x = f() {`: f() before every iteration
+                mc = re.fullmatch(r"for (\w+) := (.+); ; \1 = \2", ln)
+                out.append("    " * depth + "while True:")
+                depth += 1
+                out.append("    " * depth + f"{mc.group(1)} = {expr(mc.group(2), int_div)}")
+                continue
             elif re.fullmatch(r"for (\w+), (\w+) := range ([\w.()]+\.Labels)", ln):
                 ml = re.fullmatch(r"for (\w+), (\w+) := range ([\w.()]+\.Labels)", ln)
                 ln = f"for {ml.group(1)}, {ml.group(2)} in sorted({ml.group(3)}.items()):"
@@ -234,6 +330,7 @@ def transliterate(name, params, body, int_div):
                 ln = "pass"
             ln = re.sub(r"^var (\w+) string$", r'\1 = ""', ln)
             ln = re.sub(r"make\(\[\]\w+, 0, \d+\)", "[]", ln)
+            ln = re.sub(r"make\(\[\]\w+, 0, len\(\w+\)\)", "[]", ln)
             mk = re.fullmatch(r"_, (\w+) := (.+)\[(\w+)\]", ln)
             if mk:  # presence only
                 ln = f"{mk.group(1)} = {mk.group(3)} in {mk.group(2)}"
@@ -259,7 +356,7 @@ def transliterate(name, params, body, int_div):
                 ln = "return None"
             if ln == "return" and named:
                 ln = "return " + named.group(1)
-            ln = re.sub(r"^(\w+)\+\+$", r"\1 += 1", ln)
+            ln = re.sub(r"^([\w.]+)\+\+$", r"\1 += 1", ln)
         out.append("    " * depth + expr(ln, int_div))
         if opens:
             depth += 1
@@ -359,6 +456,94 @@ class GoNilSet:
     def Has(self, k): return False
 
 
+class GoStruct(types.SimpleNamespace):
+    """A Go struct value: fields that were not set read as the zero value 0 (the numeric ones are the only ones read unset)."""
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return 0
+
+
+def gocopy(x):
+    import copy
+    return copy.copy(x)
+
+
+class GoHeap(list):
+    """nodeScoreHeap: a slice behind heap.Interface -- Len / Less / Swap / Push / Pop as schedule_one.go:949-963 has them (Less is the transliterated one)."""
+    less = None
+
+    def Len(self): return len(self)
+    def Less(self, i, j): return GoHeap.less(self, i, j)
+    def Swap(self, i, j): self[i], self[j] = self[j], self[i]
+    def Pop(self): return list.pop(self)
+
+
+class GoContainerHeap:
+    """container/heap of Go's standard library (not part of the reference tree): Init and Pop with the documented sift-down."""
+    @staticmethod
+    def _down(h, i0, n):
+        i = i0
+        while True:
+            j1 = 2 * i + 1
+            if j1 >= n or j1 < 0:
+                break
+            j = j1
+            j2 = j1 + 1
+            if j2 < n and h.Less(j2, j1):
+                j = j2
+            if not h.Less(j, i):
+                break
+            h.Swap(i, j)
+            i = j
+        return i > i0
+
+    @staticmethod
+    def Init(h):
+        n = h.Len()
+        for i in range(n // 2 - 1, -1, -1):
+            GoContainerHeap._down(h, i, n)
+
+    @staticmethod
+    def Pop(h):
+        n = h.Len() - 1
+        h.Swap(0, n)
+        GoContainerHeap._down(h, 0, n)
+        return h.Pop()
+
+
+class ScriptedRand:
+    """math/rand behind selectHost: Intn answers from a script (0 at the scripted call, 1 otherwise: 'keep the candidate')."""
+    def __init__(self, zero_at):
+        self.calls, self.zero_at = 0, zero_at
+
+    def Intn(self, n):
+        self.calls += 1
+        return 0 if self.calls == self.zero_at else 1
+
+
+def go_math_log(x):
+    """Go's math.Log, pure-Go path (src/math/log.go = FreeBSD e_log.c; not part of the reference tree): IEEE double +, -, *, / and frexp only, so this
+    restatement is bit-identical to it -- Python floats are IEEE doubles, and CPython fuses nothing."""
+    Ln2Hi, Ln2Lo = 6.93147180369123816490e-01, 1.90821492927058770002e-10
+    L1, L2, L3, L4 = 6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01
+    L5, L6, L7 = 1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01
+    f1, ki = math.frexp(x)
+    if f1 < math.sqrt(2) / 2:
+        f1 *= 2
+        ki -= 1
+    f = f1 - 1
+    k = float(ki)
+    s_ = f / (2 + f)
+    s2 = s_ * s_
+    s4 = s2 * s2
+    t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)))
+    t2 = s4 * (L2 + s4 * (L4 + s4 * L6))
+    R = t1 + t2
+    hfsq = 0.5 * f * f
+    return k * Ln2Hi - ((hfsq - (s_ * (hfsq + R) + k * Ln2Lo)) - f)
+
+
 def parse_int(text):
     """strconv.ParseInt(text, 10, 64): (value, nil) or (0, error).  Go's standard library is not part of the reference tree; this is its
     documented contract: an optional sign, decimal digits, inside int64."""
@@ -388,7 +573,15 @@ def build():
            "LabelFailureDomainBetaZone": PINS["label.zone_beta"], "LabelTopologyZone": PINS["label.zone"],
            "LabelFailureDomainBetaRegion": PINS["label.region_beta"], "LabelTopologyRegion": PINS["label.region"],
            "minThreshold": PINS["image.min_threshold_mb"] * PINS["image.mb"], "maxContainerThreshold": PINS["image.max_container_threshold_mb"] * PINS["image.mb"],
-           "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"]}
+           "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"],
+           # round 3: the loop-level pieces
+           "GoStruct": GoStruct, "gocopy": gocopy, "GoHeap": GoHeap, "heap": GoContainerHeap, "go_math_log": go_math_log, "MinNodeScore": 0, "NodeInclusionPolicyHonor": "Honor",
+           "newCriticalPaths": lambda: [GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1), GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1)]}
+    iface = open(os.path.join(REF, S, "framework/interface.go")).read()
+    assert re.search(r"MinNodeScore int64 = 0\b", iface) and re.search(r"MaxNodeScore int64 = %d\b" % PINS["score.max_node_score"], iface)
+    assert re.search(r'NodeInclusionPolicyHonor NodeInclusionPolicy = "Honor"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read())
+    ptsf = open(os.path.join(REF, S, "framework/plugins/podtopologyspread/filtering.go")).read()
+    assert "return &criticalPaths{{MatchNum: math.MaxInt32}, {MatchNum: math.MaxInt32}}" in ptsf  # newCriticalPaths, as the lambda above has it
     op_src = open(os.path.join(REF, "vendor/k8s.io/apimachinery/pkg/selection/operator.go")).read()
     for k, v in SELECTION.items():
         assert re.search(r"\b%s\s+Operator = \"%s\"" % (k, re.escape(v)), op_src), k
@@ -399,13 +592,19 @@ def build():
         assert re.search(r"\bResource%s ResourceName = \"%s\"" % (k, v), types_src), k
     sources = {}
     JOINED.clear()
-    for name, rel, start, params, int_div in FUNCS:
-        line, body = cut(rel, start)
-        py = transliterate(name, params, body, int_div)
+    for entry in FUNCS:
+        name, rel, start, params, int_div = entry[:5]
+        opts = entry[5] if len(entry) > 5 else {}
+        line, body = cut(rel, start.replace("\\t", "\t"), opts.get("nth", 0))
+        py = transliterate(name, params, body, int_div, opts)
         exec(py, env)
+        if name == "nodeScoreHeap_Less":
+            GoHeap.less = staticmethod(env[name])
         sources[name] = {"file": rel, "line": line, "go": "\n".join(body), "python": py}
         if JOINED.get(name):
             sources[name]["joined"] = JOINED[name]
+        if opts:
+            sources[name]["opts"] = opts
     return env, sources
 
 
@@ -578,6 +777,104 @@ def vectors(env):
         out = [env["ptsFilter"](state, types.SimpleNamespace(Labels=lb), types.SimpleNamespace(Labels={})) for lb in labels]
         rows.append([labels, cons, out])
     v["ptsFilter"] = rows
+    # ---- round 3: loop-level pieces ------------------------------------------------------------------------------------------------
+    # InterPodAffinity's topology-pair maps: every existing pod of every node goes through updateWithAffinityTerms (all of the incoming pod's
+    # affinity terms matched -> one increment per term) and updateWithAntiAffinityTerms (one increment per matched term), as PreFilter applies them
+    rows = []
+    for _ in range(700):
+        n_nodes = rnd.randint(1, 6)
+        labels = [{k: v for k, v in (("zone", rnd.choice(["a", "a", "b", "c", None])), ("host", rnd.choice([f"h{i}", f"h{i}", None]))) if v is not None} for i in range(n_nodes)]
+        aff_terms = [rnd.choice(["zone", "host"]) for _ in range(rnd.choice([0, 1, 1, 2, 3]))]
+        anti_terms = [rnd.choice(["zone", "host"]) for _ in range(rnd.choice([0, 1, 2, 3]))]
+        pods = [[[rnd.random() < 0.4, [rnd.random() < 0.35 for _ in anti_terms]] for _ in range(rnd.choice([0, 0, 1, 2, 4]))] for _ in range(n_nodes)]
+        aff, anti = GoMap(), GoMap()
+        a_terms = [types.SimpleNamespace(TopologyKey=k) for k in aff_terms]
+        n_terms = [types.SimpleNamespace(TopologyKey=k, Matches=lambda pod, ns, t=t: pod.anti[t]) for t, k in enumerate(anti_terms)]
+        for i, lb in enumerate(labels):
+            node = types.SimpleNamespace(Labels=lb)
+            for m_all, m_anti in pods[i]:
+                existing = types.SimpleNamespace(self_aff=m_all, anti=m_anti)
+                env["updateWithAffinityTerms"](aff, a_terms, existing, node, 1)
+                env["updateWithAntiAffinityTerms"](anti, n_terms, existing, None, node, 1)
+        # and the same pods removed again (value -1: the entries must disappear, not stay at 0)
+        aff2, anti2 = GoMap(aff), GoMap(anti)
+        for i, lb in enumerate(labels):
+            node = types.SimpleNamespace(Labels=lb)
+            for m_all, m_anti in pods[i]:
+                existing = types.SimpleNamespace(self_aff=m_all, anti=m_anti)
+                env["updateWithAffinityTerms"](aff2, a_terms, existing, node, -1)
+                env["updateWithAntiAffinityTerms"](anti2, n_terms, existing, None, node, -1)
+        assert not aff2 and not anti2
+        rows.append([labels, aff_terms, anti_terms, pods, sorted([list(k) + [c] for k, c in aff.items()]), sorted([list(k) + [c] for k, c in anti.items()])])
+    v["ipaCountMaps"] = rows
+    # PodTopologySpread's calPreFilterState: per-node closure, merge, critical paths -- nodes with / without the keys, node inclusion policies
+    # (required node affinity, untolerated NoSchedule taints), pods of other namespaces and terminating pods
+    rows = []
+    keep = env["DoNotScheduleTaintsFilter_closure"]
+    for _ in range(700):
+        n_nodes = rnd.randint(1, 7)
+        gate = rnd.random() < 0.7  # enableNodeInclusionPolicyInPodTopologySpread
+        keys = rnd.choice([["zone"], ["host"], ["zone", "host"], ["zone", "zone"]])
+        cons = [{"key": k, "affinityPolicy": rnd.choice(["Honor", "Honor", "Ignore"]), "taintsPolicy": rnd.choice(["Honor", "Ignore", "Ignore"]), "emptySelector": rnd.random() < 0.1} for k in keys]
+        nodes = []
+        for i in range(n_nodes):
+            lb = {k: v for k, v in (("zone", rnd.choice(["a", "a", "b", "c", None])), ("host", rnd.choice([f"h{i}", f"h{i}", f"h{i}", None]))) if v is not None}
+            taints = [{"Key": "dedicated", "Value": "infra", "Effect": rnd.choice(["NoSchedule", "PreferNoSchedule", "NoExecute"])}] if rnd.random() < 0.25 else []
+            pods = [{"ns": rnd.choice(["default", "default", "other"]), "terminating": rnd.random() < 0.15, "match": [rnd.random() < 0.6 for _ in cons]} for _ in range(rnd.choice([0, 1, 2, 3, 5]))]
+            nodes.append({"labels": lb, "taints": taints, "affinityMatch": rnd.random() < 0.8, "pods": pods})
+        tolerations = [{"Key": "dedicated", "Value": "infra", "Effect": "", "Operator": "Equal"}] if rnd.random() < 0.3 else []
+        mk = lambda d: types.SimpleNamespace(**d)
+        pod = types.SimpleNamespace(Namespace="default", Spec=types.SimpleNamespace(Tolerations=[mk(t) for t in tolerations]))
+        constraints = [GoStruct(TopologyKey=c["key"], NodeAffinityPolicy=c["affinityPolicy"], NodeTaintsPolicy=c["taintsPolicy"],
+                                Selector=types.SimpleNamespace(Empty=lambda e=c["emptySelector"]: e, Matches=lambda lbls, j=j: lbls["match"][j])) for j, c in enumerate(cons)]
+        all_nodes = []
+        for nd_ in nodes:
+            node = types.SimpleNamespace(Labels=nd_["labels"], Spec=types.SimpleNamespace(Taints=[mk(t) for t in nd_["taints"]]), affinityMatch=nd_["affinityMatch"])
+            infos = [types.SimpleNamespace(GetPod=lambda p=p: types.SimpleNamespace(DeletionTimestamp=("t" if p["terminating"] else None), Namespace=p["ns"], Labels={"match": p["match"]})) for p in nd_["pods"]]
+            all_nodes.append(types.SimpleNamespace(Node=lambda node=node: node, GetPods=lambda infos=infos: infos))
+        require = types.SimpleNamespace(Match=lambda node: (node.affinityMatch, None))
+        pl = types.SimpleNamespace(enableNodeInclusionPolicyInPodTopologySpread=gate)
+        by_node = [[] for _ in all_nodes]
+        for n in range(len(all_nodes)):  # parallelizer.Until(ctx, len(allNodes), processNode, ...): the pieces write disjoint slots
+            env["calPreFilterState_processNode"](n, pl, pod, all_nodes, constraints, require, by_node)
+        st = GoStruct(TpValueToMatchNum=[GoMap() for _ in constraints], CriticalPaths=[None] * len(constraints))
+        env["calPreFilterState_merge"](st, by_node)
+        env["calPreFilterState_minima"](st, constraints)
+        rows.append([gate, cons, nodes, tolerations, [[list(kv) for kv in sorted(m.items())] for m in st.TpValueToMatchNum], [p[0].MatchNum for p in st.CriticalPaths]])
+    v["calPreFilterState"] = rows
+    # RunScorePlugins: weight x normalized score per plugin, summed per node
+    rows = []
+    for _ in range(600):
+        n_nodes, n_pl = rnd.randint(1, 8), rnd.randint(1, 7)
+        weights = [rnd.choice([1, 1, 2, 3, 10000, 0]) for _ in range(n_pl)]
+        scores = [[rnd.randint(0, 100) for _ in range(n_nodes)] for _ in range(n_pl)]
+        plugins = [types.SimpleNamespace(Name=lambda j=j: f"p{j}") for j in range(n_pl)]
+        f = types.SimpleNamespace(scorePluginWeight={f"p{j}": w for j, w in enumerate(weights)})
+        nodes_ = [types.SimpleNamespace(Node=lambda i=i: types.SimpleNamespace(Name=f"n{i}")) for i in range(n_nodes)]
+        out, err = [None] * n_nodes, []
+        for i in range(n_nodes):
+            env["RunScorePlugins_weigh"](i, f, nodes_, plugins, {f"p{j}": scores[j] for j in range(n_pl)}, out, err, None)
+        assert not err
+        rows.append([weights, scores, [o.TotalScore for o in out]])
+    v["RunScorePlugins_weigh"] = rows
+    # selectHost: which node can it return?  The reservoir sampling is driven through every outcome (Intn scripted to pick the t-th node of the
+    # maximum in heap order); the canonical choice of this engine is the lowest list position among the possible winners
+    rows = []
+    for _ in range(500):
+        n_nodes = rnd.randint(2, 12)
+        top = rnd.choice([1, 3, 100, 700])
+        totals = [rnd.randint(0, top) for _ in range(n_nodes)]
+        possible = set()
+        for t in range(0, n_nodes + 1):
+            lst = [GoStruct(Name=f"n{i}", TotalScore=sc) for i, sc in enumerate(totals)]
+            env["rand"] = ScriptedRand(t)
+            name, _lst, err = env["selectHost"](lst, rnd.choice([1, 3, n_nodes]))
+            assert err is None
+            possible.add(int(name[1:]))
+        assert possible == {i for i, sc in enumerate(totals) if sc == max(totals)}  # (every node of the maximum, nothing else)
+        rows.append([totals, sorted(possible), min(possible)])
+    v["selectHost"] = rows
+    v["topologyNormalizingWeight"] = [[n, env["topologyNormalizingWeight"](n).hex()] for n in list(range(0, 4097)) + [10 ** 6, 2 ** 31 - 3]]
     names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
     v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
     return v
