@@ -1370,7 +1370,19 @@ static int persist_k(const ccsim_engine *e) {
     if (max_total >= 65535) return 0;
     const int cus = e->n_cus < kPMaxGrid ? e->n_cus : kPMaxGrid;
     for (int k : {1, 2, 4, 8})
-        if ((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads) <= cus) return k;
+        if ((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads) <= cus) {
+            // the hand-rolled grid barrier needs every workgroup resident at once: ask the runtime how many fit (LDS, registers), not
+            // just how many CUs there are; what it cannot know -- a CU mask, another tenant -- is caught by the barrier's
+            // bounded spin, after which ccsim_run continues on the multi-kernel path
+            static int per_cu[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+            if (per_cu[k] < 0) {
+                int nb = 0;
+                const void *fn = k == 1 ? (const void *)k_level_persist<1> : k == 2 ? (const void *)k_level_persist<2> : k == 4 ? (const void *)k_level_persist<4> : (const void *)k_level_persist<8>;
+                per_cu[k] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kPThreads, 0) == hipSuccess ? nb : 0;
+            }
+            const int64_t grid = (e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads);
+            return (int64_t)per_cu[k] * e->n_cus >= grid ? k : 0;
+        }
     return 0;
 }
 
@@ -1386,6 +1398,7 @@ static int run_persist(ccsim_engine *e, int k) {
     a.level_batch = 64; // measured on the C4 snapshot (profiles/r02/persist_phase_profile.txt): 1 -> 7.96 ms, 16 -> 1.97 ms, 32 -> 1.66 ms, 64 -> 1.57 ms, 128 -> 1.64 ms per run
     if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
+    if (const char *f = getenv("CCSIM_PERSIST_FAULT")) a.fault = atoi(f); // test knob: the lost-workgroup path (tests/test_persist.py)
     const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
     for (int launch = 0; launch < 64; launch++) {
         HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync), e->stream));
@@ -1401,7 +1414,10 @@ static int run_persist(ccsim_engine *e, int k) {
         float ms = 0;
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->kernel_ms += ms, e->pass_kernel_ms += ms, e->pass_launches += 1;
-        if (e->h_state->done == DONE_ERROR) return fail(e, -EIO, "persistent level kernel: grid barrier timed out (a workgroup was not resident)");
+        if (e->h_state->done == DONE_ERROR) { // nothing was written back (ccsim_persist.h): the caller redoes the run on the multi-kernel path
+            if (launch == 0) return -EAGAIN;
+            return fail(e, -EIO, "persistent level kernel: grid barrier timed out (a workgroup was not resident)");
+        }
         if (e->h_state->done) return 0;
     }
     return fail(e, -EIO, "persistent level kernel did not finish");
@@ -1488,8 +1504,14 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         return fill_report(e, out);
     }
     if (e->persist_run) { // begin_run chose the persistent form of the batched mode
-        if ((rc = run_persist(e, e->persist_run))) return rc;
-        return fill_report(e, out);
+        rc = run_persist(e, e->persist_run);
+        if (rc == -EAGAIN) { // its grid barrier could not be satisfied on this device right now: the multi-kernel form, from the untouched state
+            e->persist_allowed = 0;
+            if ((rc = begin_run(e, max_limit, mode, out->log ? out->log_cap : 0))) return rc;
+        } else {
+            if (rc) return rc;
+            return fill_report(e, out);
+        }
     }
     if (e->cw_run) { // begin_run chose the windowed form for the coupled plugins
         if ((rc = run_cw(e))) return rc;

@@ -5,7 +5,7 @@
 // launch, dense read of the 4-byte score cache, compaction barriers, row gather from HBM, run-down, store) plus a
 // one-block decision kernel (~7 us) plus two dispatch boundaries.  Nothing in a level needs HBM: a level touches a
 // few per cent of the nodes and the decision needs five numbers.  So:
-//   * one 1024-thread workgroup per CU, K x 1024 nodes per workgroup, the node state (36 B per node in the narrow
+//   * one 512-thread workgroup per CU, K x 512 nodes per workgroup (K <= 8), the node state (36 B per node in the narrow
 //     units of ccsim_kernels.h + a 2-byte work-list slot) resident in the CU's 160 KiB of LDS: 256 CUs x 4096 nodes =
 //     1 048 576 nodes per GPU -- the BASELINE 1M-node snapshot exactly fits one MI355X;
 //   * per level every workgroup scans the 16-bit scores of its own nodes (LDS), compacts the level's nodes into an LDS
@@ -72,6 +72,7 @@ struct PersistArgs {
     int32_t seq_steps; // run-down placements a lane evaluates itself before the wave-cooperative tail (ccsim_level.h)
     int32_t level_batch; // fast path: score levels resolved per grid-wide sync (>= 1)
     int32_t prof;        // measurement runs: per-phase s_memrealtime stamps (each stamp costs a few hundred ns)
+    int32_t fault;       // test knob (CCSIM_PERSIST_FAULT=1): workgroup 0 never arrives at the first barrier -- the lost-workgroup path
 };
 
 template <int K>
@@ -100,6 +101,7 @@ struct GridCtx {
     unsigned long long *s_v;     // LDS [8] in
     unsigned long long *s_red;   // LDS [8] out
     int *s_err;                  // LDS
+    int fault;                   // (test knob, see PersistArgs)
 };
 
 __device__ __forceinline__ bool is_max_word(int w) { return w == 0 || w == 3 || w == 4; }
@@ -124,7 +126,8 @@ __device__ __forceinline__ void grid_reduce(GridCtx &gc) {
             gc.s_v[w] = 0;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // contributions performed before the arrival is counted
-        const unsigned a = __hip_atomic_fetch_add(&s->garrive[gc.g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool lost = gc.fault && blockIdx.x == 0 && gc.gen_no == 0; // (injected: behaves like a workgroup that is not resident)
+        const unsigned a = lost ? 0xfffffff0u : __hip_atomic_fetch_add(&s->garrive[gc.g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a + 1 == gc.gsize * (gc.gen_no + 1)) {
             const unsigned t = __hip_atomic_fetch_add(&s->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (t + 1 == gc.ngroups * (gc.gen_no + 1))
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
     gc.s = a.sync, gc.gen_no = 0, gc.ngroups = gridDim.x < (unsigned)kPGroups ? gridDim.x : (unsigned)kPGroups;
     gc.g = blockIdx.x % gc.ngroups;
     gc.gsize = gridDim.x / gc.ngroups + (gc.g < gridDim.x % gc.ngroups ? 1u : 0u);
-    gc.prev[0] = gc.prev[1] = 0, gc.s_v = s_v, gc.s_red = s_red, gc.s_err = &s_err;
+    gc.prev[0] = gc.prev[1] = 0, gc.s_v = s_v, gc.s_red = s_red, gc.s_err = &s_err, gc.fault = a.fault;
     if (tid == 0) s_err = 0, s_n = 0;
     if (tid < 8) s_v[tid] = 0;
 
@@ -640,6 +643,14 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
 
     // ---- write the node state back: mirrors, int64 columns, pod counts, per-node result -----------------------------
     __syncthreads();
+    // A grid barrier that timed out (a workgroup was not resident: CU mask, a shared GPU) leaves this launch's levels half
+    // committed across the grid.  Nothing is written then: the columns still hold the state the launch started from, and the
+    // host continues on the multi-kernel path.  Every workgroup leaves the loop through the error flag -- the
+    // time-out sets it grid-wide -- so either all write or none does.
+    if (s_err || p_ld_u32(&a.sync->err[0])) {
+        if (blockIdx.x == 0 && tid == 0) a.st->done = DONE_ERROR;
+        return;
+    }
     const int sh = a.c.mem_shift;
 #pragma unroll 1
     for (int k = 0; k < K; k++) {

@@ -78,6 +78,18 @@ def test_multi_kernel_form_blind_level_batches(ccref, monkeypatch, seed, kb):
         _same(got, ref, check_log=want_log)
 
 
+def test_lost_workgroup_falls_back_to_the_multi_kernel_form(ccref, monkeypatch):
+    """A grid barrier that cannot complete (here injected: workgroup 0 never arrives -- what a CU mask or a co-tenant would cause): the
+    persistent launch writes nothing back, ccsim_run redoes the run on the multi-kernel path from the untouched state."""
+    monkeypatch.setenv("CCSIM_PERSIST_FAULT", "1")
+    nodes, pod, prof = synth.make_config("C3", n_nodes=3000, seed=17)
+    for limit, want_log in ((0, False), (700, True)):
+        ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+        got, st = _run(nodes, pod, prof, limit, want_log)
+        _same(got, ref, check_log=want_log)
+        assert np.array_equal(st["pod_count"], nodes.pod_count + ref.per_node_count)
+
+
 def test_continued_runs_and_mode_switches(ccref):
     """The persistent launch starts from the columns and writes them back: runs continue across launches and modes."""
     nodes, pod, prof = synth.make_config("C3", n_nodes=6000, seed=99)
