@@ -63,6 +63,7 @@ struct ccsim_engine {
     uint8_t *d_sreason = nullptr;
     const int32_t *d_alloc_pods_real = nullptr; // Allocatable.AllowedPodNumber as loaded (cols.alloc_pods may be a pod's clamped copy)
     bool ports_on = false;                      // NodePorts active for the current pod (ccsim_set_pod)
+    int32_t *d_ports_eff = nullptr, *d_ports_base = nullptr; // the clamped pod capacity and the pod counts it was built from (k_ports_clamp)
 
     // pod / profile
     ccsim_profile prof{};
@@ -631,17 +632,16 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     // NodePorts: every clone holds the pod's host ports, so a node takes at most one -- kept as a clamped copy of the
     // allocatable pod count (k_ports_clamp), which every Fit evaluation of every mode already tests
     e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = false;
+    e->d_ports_eff = e->d_ports_base = nullptr;
     if ((pf.filter_mask & CCSIM_F_NODEPORTS) && pod->has_host_ports) {
-        int32_t *eff = nullptr;
-        const int32_t *pc0 = nullptr;
-        for (auto &b : e->backups)
-            if (b.first == (void *)e->cols.pod_count) pc0 = (const int32_t *)b.second;
-        if (!pc0) return fail(e, -EIO, "pristine pod counts missing");
-        if ((rc = dev_alloc(e, &eff, (size_t)e->n_pad, e->pod_allocs))) return rc;
-        hipLaunchKernelGGL(k_ports_clamp, dim3((unsigned)((e->n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, eff,
-                           e->d_alloc_pods_real, pc0, e->n_pad);
+        // (against the pod counts as they are NOW -- a pod spec set after runs of other specs finds their clones on the nodes -- and
+        // rebuilt by ccsim_reset_state)
+        if ((rc = dev_alloc(e, &e->d_ports_eff, (size_t)e->n_pad, e->pod_allocs))) return rc;
+        if ((rc = dev_alloc(e, &e->d_ports_base, (size_t)e->n_pad, e->pod_allocs))) return rc;
+        hipLaunchKernelGGL(k_ports_clamp, dim3((unsigned)((e->n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, e->d_ports_eff,
+                           e->d_ports_base, e->d_alloc_pods_real, (const int32_t *)e->cols.pod_count, e->n_pad);
         HIPCHK(e, hipGetLastError());
-        e->cols.alloc_pods = eff, e->ports_on = true;
+        e->cols.alloc_pods = e->d_ports_eff, e->ports_on = true;
     }
     if ((rc = static_pass(e, pod, p.w_aff != 0, e->d_stat, e->d_sreason, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
@@ -1343,7 +1343,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
         HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
         HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
         HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state, e->ipa,
-                   e->ports_on ? 1 : 0, e->d_alloc_pods_real};
+                   e->ports_on ? 1 : 0, e->d_alloc_pods_real, e->d_ports_base};
         int64_t hb = (e->n + kThreads - 1) / kThreads;
         if (hb > 2048) hb = 2048;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
@@ -1712,6 +1712,11 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
     if (e->have_pod) {
         int rc = build_narrow(e);
         if (rc) return rc;
+        if (e->ports_on) { // the NodePorts clamp follows the restored pod counts
+            hipLaunchKernelGGL(k_ports_clamp, dim3((unsigned)((e->n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, e->d_ports_eff,
+                               e->d_ports_base, e->d_alloc_pods_real, (const int32_t *)e->cols.pod_count, e->n_pad);
+            HIPCHK(e, hipGetLastError());
+        }
     }
     if (e->multi) { // the specs' own plugin state: spread count tables, anti-affinity bitmap, the round-robin position
         HIPCHK(e, hipMemcpyAsync(e->d_tbl_pool, e->d_tbl_pool0, e->tbl_len * 4, hipMemcpyDeviceToDevice, e->stream));

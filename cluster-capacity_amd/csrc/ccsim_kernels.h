@@ -1725,6 +1725,7 @@ struct HistArgs {
     DevIpa ipa;
     int32_t ports_on;               // NodePorts active for this pod: a node that took a clone has no free ports
     const int32_t *alloc_pods_real; // Allocatable.AllowedPodNumber (c.alloc_pods is the clamped copy while ports_on)
+    const int32_t *ports_base;      // pods on the node when the clamp was built (k_ports_clamp): more than that = it holds a clone of this pod
 };
 
 constexpr int kHistSlots = 4 + kMaxRes + 2 + 3 + 1 + 1; // + NodePorts + the status-code counter
@@ -1750,7 +1751,7 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
             continue;
         }
         if (sr == 3) { atomicAdd(&sh[2], 1u); continue; }
-        if (sr == 4 || (a.ports_on && a.c.placed_cnt[n] > 0)) { // node_ports.go:148-162: plain Unschedulable, before NodeResourcesFit
+        if (sr == 4 || (a.ports_on && a.c.pod_count[n] > a.ports_base[n])) { // node_ports.go:148-162: plain Unschedulable, before NodeResourcesFit
             atomicAdd(&sh[kHistNodePorts], 1u);
             atomicAdd(&sh[kHistSlots - 1], 1u);
             continue;
@@ -1804,10 +1805,14 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
 // k_ports_clamp: NodePorts for a pod with host ports -- every clone holds the same ports, so a node takes at most one
 // (NodeInfo.updateUsedPorts, S/framework/types.go:431-439; fitsPorts, node_ports.go:164-176).  The engine folds that into
 // the pod-count test every Fit evaluation already makes: allowed pods = min(real, pods of the snapshot + 1).
-__global__ __launch_bounds__(kThreads) void k_ports_clamp(int32_t *eff, const int32_t *real, const int32_t *pod_count0, int64_t n_pad) {
+// `base` = the pods on the node when the clamp was built (ccsim_set_pod, ccsim_reset_state): none of them holds the ports of THIS pod (its
+// conflicts with the snapshot's pods are the static veto, clones of earlier pod specs carry other ports or none), so the node takes
+// exactly one clone more than that; a node whose pod count has passed `base` holds a clone with the conflicting ports (k_hist).
+__global__ __launch_bounds__(kThreads) void k_ports_clamp(int32_t *eff, int32_t *base, const int32_t *real, const int32_t *pod_count, int64_t n_pad) {
     const int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (n >= n_pad) return;
-    const int64_t one_more = (int64_t)pod_count0[n] + 1;
+    const int64_t one_more = (int64_t)pod_count[n] + 1;
+    base[n] = pod_count[n];
     eff[n] = (int32_t)(one_more < (int64_t)real[n] ? one_more : (int64_t)real[n]);
 }
 

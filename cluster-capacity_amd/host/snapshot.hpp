@@ -529,7 +529,7 @@ inline Value default_selector(const Value &sim_pod, const std::vector<Value> &ob
             const Value &sel = o["spec"]["selector"];
             if (kind == "ReplicationController" && (api.empty() || api == "v1")) {
                 for (const auto &kv : sel.fields()) merged.set(kv.first, kv.second);
-            } else if ((kind == "ReplicaSet" || kind == "StatefulSet") && api.rfind("apps/", 0) == 0) {
+            } else if ((kind == "ReplicaSet" || kind == "StatefulSet") && api == "apps/v1") {
                 for (const auto &kv : sel["matchLabels"].fields()) merged.set(kv.first, kv.second);
                 for (const auto &e : sel["matchExpressions"].items()) exprs.a.push_back(e);
             }

@@ -138,6 +138,7 @@ struct Value {
     }
     // ... of an int32 field (weights, maxSkew, minDomains, priority, hostPort)
     int32_t as_int32(int32_t dflt = 0) const {
+        if (t == Str) wrong_kind("an integer"); // a quoted "8080" is a string to the reference's typed decoder: refused there, refused here
         const long long v = as_int(dflt);
         if (v > INT32_MAX || v < INT32_MIN) throw std::runtime_error("malformed object: " + s + " does not fit an int32 field");
         return (int32_t)v;

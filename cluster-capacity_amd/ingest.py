@@ -355,7 +355,7 @@ def int32_field(x, default: int = 0) -> int:
     inside int32 is refused, as the reference's decoder refuses it (and as host/value.hpp as_int32 does)."""
     if x is None:
         return default
-    if isinstance(x, bool) or not isinstance(x, (int, str)) or (isinstance(x, str) and not re.fullmatch(r"[+-]?[0-9]{1,18}", x)):
+    if isinstance(x, bool) or not isinstance(x, int):  # (a quoted "8080" is a string to the reference's typed decoder: refused there, refused here)
         raise ValueError(f"malformed object: expected an integer, found {x!r}")
     v = int(x)
     if not -(1 << 31) <= v < (1 << 31):
@@ -457,7 +457,7 @@ def default_selector(sim_pod: dict, service_objs: Sequence[dict], owner_objs: Se
             sel = (o.get("spec") or {}).get("selector") or {}
             if ref.get("kind") == "ReplicationController" and (ref.get("apiVersion") or "v1") == "v1":
                 merged.update(sel)
-            elif ref.get("kind") in ("ReplicaSet", "StatefulSet") and str(ref.get("apiVersion") or "").startswith("apps/"):
+            elif ref.get("kind") in ("ReplicaSet", "StatefulSet") and ref.get("apiVersion") == "apps/v1":  # (helper/spread.go:31-32: the exact GroupVersionKind)
                 merged.update(sel.get("matchLabels") or {})  # (selector.Add of the requirements: an equality per matchLabels entry)
                 exprs += list(sel.get("matchExpressions") or [])
         break  # (GetControllerOf: the first reference marked controller)

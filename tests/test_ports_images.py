@@ -185,6 +185,45 @@ def test_gpu_image_scores_on_the_c3_snapshot(ccref):
 
 
 @pytest.mark.gpu
+def test_gpu_ports_pod_set_after_runs_of_another_pod(ccref):
+    """the NodePorts clamp is built from the pod counts as they are when the pod is set (clones of an earlier pod spec are
+    ordinary pods of the node), rebuilt on a reset, and a second run of the same ports pod finds the first run's clones in the way --
+    with the FitError histogram still summing to N."""
+    rng = np.random.default_rng(77)
+    nodes, pod_a, prof = H.random_case(rng, 800)
+    prof.filter_mask |= M.F_NODEPORTS | M.F_FIT
+    pod_b = H.simple_pod(100, 64 * H.MiB, has_host_ports=True, taint_filter_ok=pod_a.taint_filter_ok, taint_prefer_cnt=pod_a.taint_prefer_cnt)
+    def after(nd, pod, counts):  # NodeInfo.update (types.go:409-428) x the clones per node: the snapshot a run leaves behind
+        out = nd.copy()
+        c = counts.astype(np.int64)
+        out.req = [r + c * int(pod.req[k]) if k < len(pod.req) else r for k, r in enumerate(out.req)]
+        out.nz_mcpu, out.nz_mem = out.nz_mcpu + c * int(pod.nz_mcpu), out.nz_mem + c * int(pod.nz_mem)
+        out.pod_count = (out.pod_count + counts).astype(np.int32)
+        return out
+
+    ref_a = ccref.run(prof, nodes, pod_a, max_limit=300)
+    after_a = after(nodes, pod_a, ref_a.per_node_count)  # what the oracle sees as "existing pods" for B
+    ref_b = ccref.run(prof, after_a, pod_b, max_limit=0)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod_a, prof)
+    a = e.run(max_limit=300, mode="sequential", log_cap=300)
+    assert np.array_equal(a.log, ref_a.log)
+    e.set_pod(pod_b)  # no reset: A's clones stay on the nodes
+    b = e.run(max_limit=0, mode="sequential", log_cap=max(1, ref_b.placed))
+    _same(b, ref_b)
+    assert int(np.sum(b.hist)) + int(np.sum(b.hist_taintset)) >= nodes.n  # (NodeResourcesFit may give a node several reasons)
+    # a second run of B: every node that took a clone now fails NodePorts; nothing can be placed, and the reasons still cover every node
+    c = e.run(max_limit=0, mode="sequential", log_cap=1)
+    ref_c = ccref.run(prof, after(after_a, pod_b, ref_b.per_node_count), H.simple_pod(100, 64 * H.MiB, has_host_ports=True, taint_filter_ok=pod_a.taint_filter_ok, taint_prefer_cnt=pod_a.taint_prefer_cnt,
+                                                           host_ports_conflict=(ref_b.per_node_count > 0).astype(np.uint8)), max_limit=0)
+    assert c.placed == ref_c.placed == 0 and np.array_equal(c.hist, ref_c.hist) and np.array_equal(c.hist_taintset[: len(ref_c.hist_taintset)], ref_c.hist_taintset)
+    # after a reset B sees the pristine snapshot again
+    e.reset_state()
+    _same(e.run(max_limit=0, mode="batched", log_cap=1 << 20), ccref.run(prof, nodes, pod_b, max_limit=0))
+    e.close()
+
+
+@pytest.mark.gpu
 def test_gpu_ports_sharded_engines_and_switching_pods(ccref):
     """Two shards of one snapshot on one GPU (the multi-GPU protocol) with NodePorts; then the same engine takes a pod
     without host ports: the clamped pod capacity must be gone."""
