@@ -187,6 +187,9 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     HostProfile prof_eff = prof;
     // (several templates are always searched completely: the engine's windows of pods x nodes need every node scored)
     if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = (s.n_templates() == 1 && (max_limit > 0 || !s.spread.empty() || s.has_ipa)) ? 0 : 100;
+    if (!prof.percentage_set && s.n_templates() > 1 && max_limit > 0 && s.n() >= 100)
+        std::fprintf(stderr, "cluster-capacity: note: several templates are placed with every node scored (percentageOfNodesToScore 100); with --max-limit the placed "
+                             "set may differ from a run of the reference's default adaptive sampling\n");
     const int percentage = prof_eff.c.percentage_of_nodes_to_score;
     marshal(s, prof_eff, m);
     ccsim_config cfg{};
