@@ -196,7 +196,7 @@ def test_sharded_protocol_matches_oracle(ccref, mode, world, cfg, n, limit, poll
 
 @pytest.mark.parametrize("kb", ["1", "3", "64"])
 @pytest.mark.parametrize("world,cfg,n,limit,poll_every", [(2, "C3", 1500, 0, 1), (3, "C3", 1100, 450, 5), (2, "C2", 700, 0, 1), (4, "C3", 2100, 0, 32),
-                                                          (3, "C3", 4000, 2777, 8), (2, "C3", 6000, 0, 32)])
+                                                          (3, "C3", 4000, 2777, 8), (2, "C3", 2500, 0, 32)])
 def test_sharded_blind_level_batches_match_oracle(ccref, monkeypatch, kb, world, cfg, n, limit, poll_every):
     """No placement log: the sharded batched mode commits up to CCSIM_LEVEL_BATCH score levels per exchange, blindly, and validates
     afterwards (a normalization maximum out of holders, --max-limit crossed: roll back on every rank, half the levels, down to the
