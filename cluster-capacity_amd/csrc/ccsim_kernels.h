@@ -576,6 +576,70 @@ __device__ __forceinline__ int64_t dynamic_score_narrow(const DevPod &p, const N
     return (int64_t)total;
 }
 
+// ---- run-downs without looking at every placement ---------------------------------------------------------------------------------
+// A run-down (ccsim_level.h) puts clones on ONE node while the node stays feasible and its TotalScore stays >= Lo.  Large nodes
+// lose a score point only every few pods, and a batch of 64 levels lets them run for up to their whole pod capacity: evaluating
+// every intermediate state was most of the persistent kernel's planning phase.  This function returns a number of placements k
+// such that EVERY state 1 .. k is feasible and scores >= Lo -- so the run-down may start at state k -- from the real-valued form
+// of the score:
+//   * over the states in which nothing is clamped (cap below: the Fit filter still passes, NonZeroRequested has not passed the
+//     allocatable) LeastAllocated's per-resource value is linear in the number of clones, its weighted mean is linear, and
+//     BalancedAllocation's 100 - 50 |f0 - f1| is concave (the absolute value of a linear function, negated): the real-valued
+//     total S~(j) is CONCAVE in j.  A concave function that is >= T at 0 and at k is >= T everywhere in between;
+//   * the integer score differs from it by the floors only: each resource's floor and the floor of the weighted mean cost
+//     LeastAllocated less than 2 points, the truncation costs BalancedAllocation less than 1: S(j) > S~(j) - 2 w_fit - w_bal.
+// So with T = Lo + 2 w_fit + w_bal + 1/2 (the half point swallows the fp64 rounding of S~ itself: the operands are below 2^31),
+// S~(0) >= T and S~(k) >= T imply S(j) >= Lo for all 0 <= j <= k.  k is found by bisection (S~(j) >= T is monotone on [0, cap]
+// once S~(0) >= T).  Nothing about exactness rests on k being the LARGEST such value: the run-down continues from state k with
+// the exact integer arithmetic and stops where the reference would.  tests/test_device_arith.py checks the claim itself --
+// every skipped state feasible and >= Lo under the exact functions -- on the host.
+struct RunDownCoef {
+    double lin0, lin1, cb, wb, u0, v0, u1, v1;
+};
+__device__ __forceinline__ double rd_total(const RunDownCoef &k, int64_t j) { // S~(j), see run_down_safe_skip
+    const double x = (double)(j + 1);
+    double f0 = k.u0 + k.v0 * x, f1 = k.u1 + k.v1 * x;
+    f0 = f0 > 1 ? 1 : f0, f1 = f1 > 1 ? 1 : f1; // (only a resource the pod does not request can sit above 1: a constant)
+    return k.lin0 - k.lin1 * x + k.cb - k.wb * 50.0 * fabs(f0 - f1);
+}
+__device__ __forceinline__ int32_t run_down_safe_skip(const DevPod &p, const NarrowPod &q, int32_t a0, int32_t a1, int32_t r0, int32_t r1, int32_t z0,
+                                                      int32_t z1, int32_t a_pods, int32_t npods, int32_t stat, int32_t Lo) {
+    // cap: the states 1 .. cap can all take one more pod (fits_narrow) and clamp nothing
+    int64_t cap = (int64_t)a_pods - npods - 1;
+    if (!p.all_zero_req) {
+        if (q.req0 > 0) { const int64_t c = ((int64_t)a0 - r0) / q.req0 - 1; cap = c < cap ? c : cap; }
+        if (q.req1 > 0) { const int64_t c = ((int64_t)a1 - r1) / q.req1 - 1; cap = c < cap ? c : cap; }
+    }
+    const bool has0 = a0 != 0, has1 = a1 != 0;
+    // LeastAllocated: a resource whose NonZeroRequested (+ the pod) already exceeds the allocatable scores 0 from here on: a constant
+    const bool l0 = p.w_fit && p.fit_cpu && has0 && (int64_t)z0 + q.nz0 <= a0, l1 = p.w_fit && p.fit_mem && has1 && (int64_t)z1 + q.nz1 <= a1;
+    if (l0 && q.nz0 > 0) { const int64_t c = ((int64_t)a0 - z0) / q.nz0 - 1; cap = c < cap ? c : cap; }
+    if (l1 && q.nz1 > 0) { const int64_t c = ((int64_t)a1 - z1) / q.nz1 - 1; cap = c < cap ? c : cap; }
+    if (cap < 1) return 0;
+    const double w0 = p.w_fit && p.fit_cpu && has0 ? (double)p.fit_w_cpu : 0.0, w1 = p.w_fit && p.fit_mem && has1 ? (double)p.fit_w_mem : 0.0;
+    const double W = w0 + w1 > 0 ? w0 + w1 : 1.0;
+    const double k0 = l0 ? 100.0 / (double)a0 : 0.0, k1 = l1 ? 100.0 / (double)a1 : 0.0;
+    const bool bal = p.w_bal && p.bal_cpu && p.bal_mem && has0 && has1;
+    const double i0 = bal ? 1.0 / (double)a0 : 0.0, i1 = bal ? 1.0 / (double)a1 : 0.0;
+    const double T = (double)Lo + 2.0 * (double)p.w_fit + (double)p.w_bal + 0.5;
+    // the real-valued total of the node after j clones, as plain coefficients (no closure: it would be a scratch frame):
+    //   S~(j) = lin0 - lin1 (j + 1) + w_bal (100 - 50 |min(1, u0 + v0 (j + 1)) - min(1, u1 + v1 (j + 1))|)
+    const double fw = (double)p.w_fit / W;
+    const double lin0 = (double)stat + fw * (((double)a0 - (double)z0) * k0 * w0 + ((double)a1 - (double)z1) * k1 * w1);
+    const double lin1 = fw * ((double)q.nz0 * k0 * w0 + (double)q.nz1 * k1 * w1);
+    const double u0 = (double)r0 * i0, v0 = (double)q.req0 * i0, u1 = (double)r1 * i1, v1 = (double)q.req1 * i1, wb = bal ? (double)p.w_bal : 0.0;
+    const double cb = (double)p.w_bal * 100.0;
+    const RunDownCoef k{lin0, lin1, cb, wb, u0, v0, u1, v1};
+    if (!(rd_total(k, 0) >= T)) return 0;
+    int64_t lo = 0, hi = cap;
+    if (rd_total(k, hi) >= T) return (int32_t)hi;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rd_total(k, mid) >= T) lo = mid; else hi = mid;
+    }
+    return (int32_t)lo;
+}
+
 // NodeResourcesFit filter for the cpu/mem/pods part (fit.go:564-615); extras are checked by the caller.
 __device__ __forceinline__ bool fits_core(const DevPod &p, int64_t a_cpu, int64_t a_mem, int64_t r_cpu, int64_t r_mem,
                                           int32_t a_pods, int32_t npods) {

@@ -174,6 +174,11 @@ __device__ __forceinline__ NodeNarrow nd_bcast(const NodeNarrow &n, int src) {
 // cooperative tail are clamped to it, so 32-bit state never leaves the range the narrow mode was validated for.
 __device__ __forceinline__ int64_t nd_room(const NodeNarrow &n) { return n.a_pods > n.npods ? (int64_t)(n.a_pods - n.npods) : 1; }
 __device__ __forceinline__ uint32_t nd_word(const NodeNarrow &n) { return n.w; }
+// placements a run-down may take without evaluating the states in between (ccsim_kernels.h run_down_safe_skip; narrow form only)
+template <int NX> __device__ __forceinline__ int32_t nd_skip(const RunCtx &, const NodeRegs<NX> &, int64_t, int64_t) { return 0; }
+__device__ __forceinline__ int32_t nd_skip(const RunCtx &cx, const NodeNarrow &n, int64_t stat, int64_t M) {
+    return run_down_safe_skip(cx.p, cx.q, n.a0, n.a1, n.r0, n.r1, n.z0, n.z1, n.a_pods, n.npods, (int32_t)stat, (int32_t)M);
+}
 
 // Run-downs, two regimes.  Every lane of the wave must call this (wave-uniform control flow).
 // `mine` = this lane's node holds the level (feasible, score == M).
@@ -199,6 +204,10 @@ __device__ __forceinline__ int32_t wave_run_down(const RunCtx &cx, const Node &n
     Node cur = n;
     bool running = mine;
     const auto rc = nd_rcp(n); // allocatable never changes: one reciprocal pair per node
+    if (running) {
+        const int32_t k = nd_skip(cx, cur, stat, M);
+        if (k > 0) nd_apply(cx, cur, k), my_j = k;
+    }
 #pragma unroll 1
     for (int it = 0; it < seq_steps && __ballot(running); it++) {
         if (running) {

@@ -182,6 +182,10 @@ __device__ __forceinline__ int32_t wave_run_down_rows(const RunCtx &cx, const No
     if (!__ballot(mine)) return 0;
     NodeNarrow cur = n;
     bool running = mine;
+    if (running) { // the states that cannot end the run-down are not looked at (ccsim_kernels.h run_down_safe_skip)
+        const int32_t k = run_down_safe_skip(cx.p, cx.q, cur.a0, cur.a1, cur.r0, cur.r1, cur.z0, cur.z1, cur.a_pods, cur.npods, stat, M);
+        if (k > 0) nd_apply(cx, cur, k), my_j = k;
+    }
 #pragma unroll 1
     for (int it = 0; it < seq_steps && __ballot(running); it++) {
         if (running) {

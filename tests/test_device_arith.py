@@ -25,7 +25,7 @@ HEADER = os.path.join(ROOT, "cluster-capacity_amd", "csrc", "ccsim_kernels.h")
 WANTED = [("struct", "DevPod", 0), ("func", "refined_rcp", 0), ("struct", "NodeRcp", 0), ("func", "make_rcp", 0), ("func", "div_small_quotient", 0),
           ("func", "least_requested_score", 0), ("func", "balanced_exact", 0), ("func", "dynamic_score", 0), ("func", "div_magic", 0), ("func", "norm100", 0),
           ("func", "norm100", 1), ("struct", "NarrowPod", 0), ("func", "floor_ratio100", 0), ("func", "dynamic_score_narrow", 0), ("func", "static_score", 0),
-          ("func", "static_score", 1), ("func", "go_log", 0)]
+          ("func", "static_score", 1), ("func", "go_log", 0), ("func", "fits_narrow", 0), ("struct", "RunDownCoef", 0), ("func", "rd_total", 0), ("func", "run_down_safe_skip", 0)]
 
 
 def _extract(text, kind, name, occurrence):
@@ -212,6 +212,44 @@ int main() {
         const double a = go_log(x), b = ccref_go_log(x);
         CHECK(std::memcmp(&a, &b, 8) == 0, "go_log(%a)", x);
     }
+    // (h) run-downs that skip states: every state 1 .. k that run_down_safe_skip lets a run-down pass over must be feasible (the node
+    // takes one more pod) and score >= Lo under the EXACT functions above -- cluster-shaped nodes (cpu in milli-cores, memory in Mi
+    // units, tens to hundreds of pods), pods of every proportion, every threshold near the current score; the reciprocal perturbed
+    long skipped_states = 0, skips = 0;
+    for (g_ulp = -1; g_ulp <= 1; g_ulp++)
+        for (int it = 0; it < 400000; it++) {
+            DevPod p = random_pod();
+            p.fit_enabled = 1;
+            if (it % 4 == 0) p.w_fit = 1, p.w_bal = 1, p.fit_cpu = p.fit_mem = p.bal_cpu = p.bal_mem = 1, p.fit_w_cpu = p.fit_w_mem = 1; // the default profile
+            const int32_t a0 = (int32_t)(rnd_below(2) ? 1000 * (1 + rnd_below(128)) : 1 + rnd_below(1 << 20)), a1 = (int32_t)(rnd_below(2) ? 1024 * (1 + rnd_below(512)) : 1 + rnd_below(1 << 24));
+            NarrowPod q;
+            q.req0 = (int32_t)(rnd_below(6) == 0 ? 0 : 1 + rnd_below(a0 / 8 + 2)), q.req1 = (int32_t)(rnd_below(6) == 0 ? 0 : 1 + rnd_below(a1 / 8 + 2));
+            q.nz0 = q.req0 ? q.req0 : 100, q.nz1 = q.req1 ? q.req1 : 200;
+            p.all_zero_req = q.req0 == 0 && q.req1 == 0;
+            const int32_t r0 = (int32_t)rnd_below(a0 / 2 + 1), r1 = (int32_t)rnd_below(a1 / 2 + 1);
+            const int32_t z0 = r0 + (int32_t)(rnd_below(3) ? 0 : rnd_below(a0 / 3 + 1)), z1 = r1 + (int32_t)(rnd_below(3) ? 0 : rnd_below(a1 / 3 + 1)); // pods without requests raise NonZeroRequested only
+            const int32_t a_pods = (int32_t)(1 + rnd_below(rnd_below(2) ? 110 : 2000)), npods = (int32_t)rnd_below(a_pods);
+            const int32_t stat = (int32_t)rnd_below(600);
+            if (!fits_narrow(p, q, a0, a1, r0, r1, a_pods, npods)) continue;
+            const int64_t s0 = stat + dynamic_score_narrow(p, q, a0, a1, r0, r1, z0, z1);
+            const int32_t Lo = (int32_t)(s0 - rnd_below(rnd_below(2) ? 8 : 70)); // the node is in the list: it scores >= Lo now
+            if (Lo < 0) continue;
+            const int32_t k = run_down_safe_skip(p, q, a0, a1, r0, r1, z0, z1, a_pods, npods, stat, Lo);
+            n_checked++;
+            skips += k > 0;
+            for (int32_t j = 1; j <= k; j++, skipped_states++) {
+                const int32_t rr0 = r0 + j * q.req0, rr1 = r1 + j * q.req1, zz0 = z0 + j * q.nz0, zz1 = z1 + j * q.nz1;
+                const bool f = fits_narrow(p, q, a0, a1, rr0, rr1, a_pods, npods + j);
+                const int64_t sj = stat + dynamic_score_narrow(p, q, a0, a1, rr0, rr1, zz0, zz1);
+                CHECK(f && sj >= Lo, "skip k=%d j=%d feasible=%d score=%lld Lo=%d a=(%d,%d) r=(%d,%d) z=(%d,%d) q=(%d,%d,%d,%d) pods=%d/%d w=(%d,%d) fit=(%d,%d,%lld,%lld) bal=(%d,%d)", k, j,
+                      (int)f, (long long)sj, Lo, a0, a1, r0, r1, z0, z1, q.req0, q.req1, q.nz0, q.nz1, npods, a_pods, p.w_fit, p.w_bal, p.fit_cpu, p.fit_mem,
+                      (long long)p.fit_w_cpu, (long long)p.fit_w_mem, p.bal_cpu, p.bal_mem);
+                if (!(f && sj >= Lo)) break;
+            }
+        }
+    CHECK(skips > 100000 && skipped_states > 2000000, "the skip must be exercised: %ld skips, %ld states", skips, skipped_states);
+    n_checked += skipped_states;
+    std::printf("run-down skips: %ld, states passed over: %ld\n", skips, skipped_states);
     std::printf("checked %ld failures %ld\n", n_checked, failures);
     return failures ? 1 : 0;
 }
