@@ -1182,7 +1182,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     {   // several score levels per pass (blind, validated, rolled back if need be: ccsim_level.h) wherever the commit rows exist
         const int persist = (mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes) ? persist_k(e) : 0;
         const bool rows_now = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !persist;
-        int kb = 64; // (the persistent form's measured optimum, profiles/r02/persist_batch_sweep.txt; sharded: profiles/r03)
+        int kb = 384; // (profiles/r03/persist_batch_sweep.txt; the sharded protocol at one rank: 64 -> 3.30 ms, 256 -> 2.74, 384 -> 2.60, 512 -> 2.88 per C4 run)
         if (const char *f = getenv("CCSIM_LEVEL_BATCH")) kb = atoi(f) > 0 ? atoi(f) : 1; // tuning knob (the SAME value on every rank)
         st.lvl_kb_max = rows_now && !e->time_passes ? kb : 1;
         st.lvl_kb = st.lvl_kb_max;
@@ -1395,7 +1395,11 @@ static int run_persist(ccsim_engine *e, int k) {
     a.max_syncs = 1 << 20;
     a.seq_steps = 8;
     if (const char *f = getenv("CCSIM_SEQ_STEPS")) a.seq_steps = atoi(f) > 0 ? atoi(f) : kSeqSteps; // tuning knob
-    a.level_batch = 64; // measured on the C4 snapshot (profiles/r02/persist_phase_profile.txt): 1 -> 7.96 ms, 16 -> 1.97 ms, 32 -> 1.66 ms, 64 -> 1.57 ms, 128 -> 1.64 ms per run
+    // levels per blind batch, measured on the C4 snapshot.  Round 2 (every state of a run-down evaluated): 16 -> 1.97 ms, 64 -> 1.57, 128 -> 1.64.
+    // Round 3 (run_down_safe_skip: long run-downs cost a bisection): 64 -> 0.88 ms, 128 -> 0.85, 256 -> 0.96, 384 -> 0.555, 512 -> 0.77,
+    // >= 640 -> 0.68 (profiles/r03/persist_batch_sweep.txt; not monotone: what a batch costs depends on where the normalization
+    // maxima run out of holders inside it).  Any value gives the same results.
+    a.level_batch = 384;
     if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     if (const char *f = getenv("CCSIM_PERSIST_FAULT")) a.fault = atoi(f); // test knob: the lost-workgroup path (tests/test_persist.py)
