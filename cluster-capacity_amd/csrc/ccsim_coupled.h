@@ -707,42 +707,69 @@ __device__ __forceinline__ int32_t wave_min_i32_nonneg(int32_t v) { return (int3
 // The shape of the pod is a template argument: NH hard constraints, bit c of HU = constraint c is over a unique-per-node key;
 // NK inter-pod keys, bit k of KU = key k is unique per node.  A runtime flag costs an SGPR and a branch in every cycle, and
 // the first (runtime-flag) form of this kernel spent a third of its instructions moving spilled SGPRs through VGPR lanes.
-template <int NH, int HU, int NK, int KU>
+// PROF: phase ticks (s_memrealtime + an LDS add per phase) compiled in only for measurement runs (CCSIM_CW_PROF=1).
+//
+// What a cycle does NOT do (the second form of this loop; the first one is in profiles/r03/cw_kernel_stats.csv at 1.45 us):
+//  * no LDS round trip for the winner's facts: every class lane holds its list head's record (key, A after one more clone,
+//    count / sum / eligibility bits) in registers, the commit reads it with v_readlane, and the lane fetches its next head
+//    with a load that nothing waits for before the next cycle's argmax;
+//  * no per-cycle store: the placement log and the (node, clones) records of the epilogue are kept one per lane (lane = cycle
+//    mod 64) and written 64 at a time;
+//  * no 64-bit run counters: a window is <= 1024 cycles, so the loop counts in 32 bits against bounds computed once (limit,
+//    log capacity), and the inter-pod totals are (was zero, is positive) flags plus 32-bit deltas added to the state at the end;
+//  * the argmax is a 32-bit DPP maximum of the keys' high words (the score); the low words (lowest index first) are only
+//    reduced when several lanes share the score.
+struct CwFastLds {
+    uint4 ent[kCwListLds + 64];                 // class c, member m at c * (L + 1) + m: {key lo, key hi, A after one more clone, meta}; a zero key ends the list
+    unsigned long long rec[kCwFastWindow + 64]; // nodes that received clones in this window: index | clones << kIdxBits
+    int32_t s_nt;
+    unsigned long long pf[8];
+};
+static_assert(sizeof(CwFastLds) <= sizeof(CwLds), "both decide kernels are launched with sizeof(CwLds) of LDS");
+constexpr uint32_t kCwMetaStat = kStatAffMask | (kStatCntMask << kStatCntShift);
+// stat's count (TaintToleration) and sum (NodeAffinity) fields where they are; the node's eligibility bits in the image field
+__device__ __forceinline__ uint32_t cw_meta(uint32_t stat, uint32_t elig) { return (stat & kCwMetaStat) | ((elig & kStatImgMask) << kStatImgShift); }
+
+template <int NH, int HU, int NK, int KU, bool PROF>
 __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArgs *__restrict__ ap) {
     const CwDecideArgs &a = *ap;
     extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
-    CwLds &L = *reinterpret_cast<CwLds *>(cw_lds_raw);
+    CwFastLds &L = *reinterpret_cast<CwFastLds *>(cw_lds_raw);
     DevState &S = *a.st;
     if (S.done || S.cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the general kernel records the fallback)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
+    const int LL = uni32(a.plan.list_len), LS = LL + 1, W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
     const int C = uni32((int)a.w.ctl[kCwCtlClasses]);
     constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
     bool fits = C <= kCwFastClasses && C * LL <= kCwListLds;
     if (NH > 0 && !HU0) fits = fits && a.plan.h_len[0] <= 64;
-    // (uniform, and said so below: `fits` steers every thread of the block the same way)
     if (NH > 1 && !HU1) fits = fits && a.plan.h_len[1] <= 64;
     if (NK > 0 && a.ipa.w) { // PreScore must skip for the whole window: no entries now, none added by a clone (scoring.go:199-201)
         fits = fits && S.ipa_entries == 0 && a.ipa.self_entries[0] == 0;
         if (NK > 1) fits = fits && a.ipa.self_entries[1] == 0;
     }
+    for (int k = 0; k < NK; k++) // (what a clone adds per key, summed in 32 bits over <= 1024 cycles)
+        fits = fits && a.ipa.aff_terms_on_key[k] < (1 << 16) && a.ipa.anti_self_on_key[k] < (1 << 16) && a.ipa.self_entries[k] < (1 << 16);
     if (!uni32(fits)) return;
-    const bool prof = uni32(a.w.prof != nullptr) != 0;
-    unsigned long long t_prev = prof ? __builtin_amdgcn_s_memrealtime() : 0ull;
-#define CW_TICK(i) do { if (prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); if (lane == 0) L.pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+    unsigned long long t_prev = 0ull;
+    if (PROF) t_prev = __builtin_amdgcn_s_memrealtime();
+#define CW_TICK(i) do { if (PROF) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); if (lane == 0) L.pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     // ---- prologue (all threads): the node facts of every list entry -> LDS
-    for (int q = tid; q < C * LL; q += kCwThreads) {
-        const unsigned long long key = a.w.lists[q];
-        L.li_key[q] = key;
-        if (key) {
-            const int64_t i = key_index(key) - a.c.global_offset;
-            L.li_stat[q] = a.c.stat[i];
-            L.li_elig[q] = a.pts.n ? (uint32_t)a.pts.elig[i] : 0u;
-            L.li_A1[q] = a.w.node_A1[i];
+    for (int q = tid; q < C * LS; q += kCwThreads) {
+        const int c = q / LS, m = q - c * LS;
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (m < LL) {
+            const unsigned long long key = a.w.lists[c * LL + m];
+            if (key) {
+                const int64_t i = key_index(key) - a.c.global_offset;
+                r.x = (uint32_t)key, r.y = (uint32_t)(key >> 32), r.z = (uint32_t)a.w.node_A1[i];
+                r.w = cw_meta(a.c.stat[i], a.pts.n ? (uint32_t)a.pts.elig[i] : 0u);
+            }
         }
+        L.ent[q] = r;
     }
     if (tid == 0) L.s_nt = -1; // -1: the window was not taken
     if (tid < 8) L.pf[tid] = 0;
@@ -767,14 +794,17 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
 
         // ---- lane = candidate: the class records into registers
         int32_t hv0 = 0, hv1 = 0, hc0 = 0, hc1 = 0, kv0 = 0, kv1 = 0, kf0 = 0, kf1 = 0, kn0 = 0, kn1 = 0, ke0 = 0, ke1 = 0;
-        uint32_t nfm = 0, cmt = 0, cma = 0, cht = 0, cha = 0, el = 0;
-        int32_t head = 0, tix = -1;
+        uint32_t nfm = 0, cmt = 0, cma = 0, cht = 0, cha = 0;
+        int32_t head = 0, hA1 = 0; // class lanes: position in the list; the head's A after one more clone
+        uint32_t hmeta = 0, tk = 0; // the head's (class lanes) / the node's own (touched lanes) count, sum and eligibility bits; clones this window
         uint64_t key = 0;
-        bool is_cls = false, over = false;
-        if (lane < C) {
+        bool over = false;
+        const bool cls = lane < C;
+        if (cls) {
             const CwClass &k = a.w.cls[a.w.slot_of_id[lane]];
-            nfm = k.nf, cmt = k.mt, cma = k.ma, cht = k.ht, cha = k.ha, is_cls = true;
-            key = L.li_key[lane * LL];
+            nfm = k.nf, cmt = k.mt, cma = k.ma, cht = k.ht, cha = k.ha;
+            const uint4 r = L.ent[lane * LS];
+            key = ((uint64_t)r.y << 32) | r.x, hA1 = (int32_t)r.z, hmeta = r.w;
             if (NH > 0) hv0 = k.tuple[0], hc0 = HU0 ? hv0 >> 1 : (hv0 ? a.pts.tbl[0][hv0] : 0);
             if (NH > 1) hv1 = k.tuple[1], hc1 = HU1 ? hv1 >> 1 : (hv1 ? a.pts.tbl[1][hv1] : 0);
             if (NK > 0) {
@@ -825,88 +855,93 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     if (c == 0) min0 = (int32_t)m, nmin0 = n_at; else min1 = (int32_t)m, nmin1 = n_at;
                 }
         if (__ballot(over) == 0ull) { // (else: an entry beyond int32 -- the general kernel's business)
-            int ncand = C, nt = 0;
-            int64_t placed = cw_uni64(S.placed);
-            const int64_t placed0 = placed, limit = cw_uni64(S.limit), log_cap = cw_uni64(S.log_cap);
-            int64_t aff_total = cw_uni64(S.ipa_aff_total), exist_total = cw_uni64(S.ipa_exist_total), entries = cw_uni64(S.ipa_entries);
-            int done = 0, cycles = 0;
+            int ncand = C, nrec = 0, cycles = 0;
+            const int64_t placed0 = cw_uni64(S.placed), limit = cw_uni64(S.limit), log_cap = cw_uni64(S.log_cap);
+            int Wl = W; // cycles this window may run: the window, and what --max-limit leaves (simulator.go:297-312: tested after the append)
+            if (limit > 0 && limit - placed0 < (int64_t)Wl) Wl = (int)(limit - placed0);
+            int log_room = 0; // how many of them the placement log still takes
+            if (a.log != nullptr && log_cap > placed0) log_room = log_cap - placed0 < (int64_t)W ? (int)(log_cap - placed0) : W;
+            Wl = uni32(Wl), log_room = uni32(log_room);
+            // the inter-pod totals enter the verdicts only as (no matching pod anywhere) / (some existing pod has a term): flags,
+            // and what the clones add as 32-bit sums for the state
+            bool aff_zero = uni32(S.ipa_aff_total == 0) != 0, exist_pos = uni32(S.ipa_exist_total > 0) != 0;
+            int32_t d_aff = 0, d_exist = 0, d_ent = 0;
             bool stale_maxima = false, end_window = false, unsched = false;
             uint32_t new_mt = mt_a, new_ma = ma_a, lf = 0; // lf: this lane's share of the feasible count of the last cycle
+            int32_t mylog = 0;  // lane l: the winner of cycle (64 j + l), until the 64 are stored together
+            uint64_t myrec = 0; // lane l: record (64 j + l) of a node that left the candidates, likewise
             CW_TICK(0);
-#pragma unroll 1
-            while (!uni32(end_window) && !done && cycles < W && ncand < 64) {
-                // (loop-carried scalars, re-asserted uniform: one v_readfirstlane each instead of divergent-loop bookkeeping)
-                ncand = uni32(ncand), nt = uni32(nt), nmin0 = (uint32_t)uni32((int)nmin0), nmin1 = (uint32_t)uni32((int)nmin1);
-                min0 = uni32(min0), min1 = uni32(min1), remin0 = uni32(remin0) != 0, remin1 = uni32(remin1) != 0;
+            // One cycle's verdicts (filtering.go:311-356, interpodaffinity/filtering.go:410-432) on every lane; `&` / `|`: straight-line
+            // mask arithmetic.  The loop below is rotated -- verdicts of the NEXT cycle at the bottom, one exit -- so that every way
+            // out leaves the lane state where it is (with exits in mid-cycle the compiler copied all of it once per cycle).
+            auto verdicts = [&]() -> bool {
                 if (NH > 0 && !HU0 && remin0) min0 = wave_min_i32_nonneg(dp0 ? dc0 : 0x7fffffff), nmin0 = (uint32_t)__popcll(__ballot(dp0 && dc0 == min0)), remin0 = false;
                 if (NH > 1 && !HU1 && remin1) min1 = wave_min_i32_nonneg(dp1 ? dc1 : 0x7fffffff), nmin1 = (uint32_t)__popcll(__ballot(dp1 && dc1 == min1)), remin1 = false;
-                // ---- verdicts (filtering.go:311-356, interpodaffinity/filtering.go:410-432)
-                bool ok = lane < ncand && nfm > 0;
-                if (NH > 0) ok = ok && (HU0 ? (hv0 & 1) : hv0) && hc0 + h_self0 - (h_usemin0 ? min0 : 0) <= h_skew0;
-                if (NH > 1) ok = ok && (HU1 ? (hv1 & 1) : hv1) && hc1 + h_self1 - (h_usemin1 ? min1 : 0) <= h_skew1;
-                if (NK > 0 && ipa_filter && !(exist_total == 0 && !ipa_any_term)) {
+                bool ok = (lane < ncand) & (nfm > 0);
+                if (NH > 0) ok &= ((HU0 ? (hv0 & 1) : hv0) != 0) & (hc0 + h_self0 - (h_usemin0 ? min0 : 0) <= h_skew0);
+                if (NH > 1) ok &= ((HU1 ? (hv1 & 1) : hv1) != 0) & (hc1 + h_self1 - (h_usemin1 ? min1 : 0) <= h_skew1);
+                if (NK > 0 && ipa_filter && (exist_pos || ipa_any_term)) {
                     if (any_aff) {
                         bool pods_exist = true, aff_ok = true;
-                        if (k_aff0) aff_ok = aff_ok && kv0, pods_exist = pods_exist && kv0 && kf0 > 0;
-                        if (NK > 1 && k_aff1) aff_ok = aff_ok && kv1, pods_exist = pods_exist && kv1 && kf1 > 0;
-                        if (!aff_ok || (!pods_exist && !(aff_total == 0 && self_aff))) ok = false;
+                        if (k_aff0) aff_ok &= kv0 != 0, pods_exist &= (kv0 != 0) & (kf0 > 0);
+                        if (NK > 1 && k_aff1) aff_ok &= kv1 != 0, pods_exist &= (kv1 != 0) & (kf1 > 0);
+                        ok &= aff_ok & (pods_exist | (aff_zero && self_aff));
                     }
-                    if (k_anti0 && kv0 && kn0 > 0) ok = false;
-                    if (NK > 1 && k_anti1 && kv1 && kn1 > 0) ok = false;
-                    if (exist_total > 0 && ((kv0 && ke0 > 0) || (NK > 1 && kv1 && ke1 > 0))) ok = false;
-                }
-                if (__ballot(ok) == 0ull) {
-                    if (cycles == 0) unsched = true; // the pass saw every node: schedule_one.go:448-454
-                    break;
-                }
-                if (cycles == 0) {
-                    if (track) {
-                        const uint32_t mt_now = wave_max_u32(ok ? cmt : 0u), ma_now = wave_max_u32(ok ? cma : 0u);
-                        if (mt_now != mt_a || ma_now != ma_a) { // A was computed under other maxima: redo the pass
-                            stale_maxima = true, new_mt = mt_now, new_ma = ma_now;
-                            break;
-                        }
+                    if (k_anti0) ok &= !((kv0 != 0) & (kn0 > 0));
+                    if (NK > 1 && k_anti1) ok &= !((kv1 != 0) & (kn1 > 0));
+                    if (exist_pos) {
+                        ok &= !((kv0 != 0) & (ke0 > 0));
+                        if (NK > 1) ok &= !((kv1 != 0) & (ke1 > 0));
                     }
-                } else {
-                    // a class's next head is not among the members kept; the class's own maximum lost its last holder; the maxima moved
-                    if (__ballot(ok && is_cls && (key == 0ull || (track && (cht == 0 || cha == 0))))) break;
-                    if (track && (__ballot(ok && (cmt > mt_a || cma > ma_a)) || !__ballot(ok && cmt == mt_a) || !__ballot(ok && cma == ma_a))) break;
                 }
+                return ok;
+            };
+            bool ok = verdicts(), go = true;
+            if (__ballot(ok) == 0ull) unsched = true, go = false; // the pass saw every node: schedule_one.go:448-454
+            else if (track) {
+                const uint32_t mt_now = wave_max_u32(ok ? cmt : 0u), ma_now = wave_max_u32(ok ? cma : 0u);
+                if (mt_now != mt_a || ma_now != ma_a) stale_maxima = true, new_mt = mt_now, new_ma = ma_now, go = false; // A was computed under other maxima: redo the pass
+            }
+#pragma unroll 1
+            while (uni32(go)) {
+                // (loop-carried scalars, re-asserted uniform: one v_readfirstlane each instead of divergent-loop bookkeeping)
+                ncand = uni32(ncand), nrec = uni32(nrec), cycles = uni32(cycles), nmin0 = (uint32_t)uni32((int)nmin0), nmin1 = (uint32_t)uni32((int)nmin1);
+                min0 = uni32(min0), min1 = uni32(min1), remin0 = uni32(remin0) != 0, remin1 = uni32(remin1) != 0;
+                d_aff = uni32(d_aff), d_exist = uni32(d_exist), d_ent = uni32(d_ent), aff_zero = uni32(aff_zero) != 0, exist_pos = uni32(exist_pos) != 0;
                 lf = ok ? nfm : 0u;
                 CW_TICK(2);
-                // ---- argmax (selectHost, schedule_one.go:894-941): the key IS (A, lowest index first)
-                const uint64_t mykey = ok ? key : 0ull;
-                const uint64_t best = wave_max_u64(mykey);
-                const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(mykey == best)) - 1);
-                const int64_t g = key_index(best);
+                // ---- argmax (selectHost, schedule_one.go:894-941): the key IS (A, lowest index first); its high word carries A
+                const uint32_t khi = ok ? (uint32_t)(key >> 32) : 0u; // (> 0 on every feasible lane: make_key stores A + 1)
+                const uint32_t bhi = wave_max_u32(khi);
+                const bool top = ok & (khi == bhi);
+                unsigned long long tm = __ballot(top);
+                if (tm & (tm - 1ull)) { // several lanes share the score: the low words decide
+                    const uint32_t klo = top ? (uint32_t)key : 0u;
+                    const uint32_t blo = wave_max_u32(klo);
+                    tm = __ballot(top & (klo == blo));
+                }
+                const int wl = __builtin_amdgcn_readfirstlane(__ffsll(tm) - 1);
+                const int64_t g = key_index(rl64(key, wl));
                 CW_TICK(4);
                 // ---- commit: broadcasts from the winner's lane
                 const bool w_cls = wl < C;
                 const int32_t w_hv0 = NH > 0 ? rl32(hv0, wl) : 0, w_hv1 = NH > 1 ? rl32(hv1, wl) : 0, w_kv0 = NK > 0 ? rl32(kv0, wl) : 0, w_kv1 = NK > 1 ? rl32(kv1, wl) : 0;
                 const int32_t w_hc0 = NH > 0 ? rl32(hc0, wl) : 0, w_hc1 = NH > 1 ? rl32(hc1, wl) : 0; // (before this clone)
-                uint32_t w_el, w_cnt = 0, w_aff = 0;
-                int32_t A_next, w_tix;
+                const uint32_t w_meta = (uint32_t)rl32((int32_t)hmeta, wl);
+                const uint32_t w_el = (w_meta >> kStatImgShift) & kStatImgMask, w_cnt = (w_meta >> kStatCntShift) & kStatCntMask, w_aff = w_meta & kStatAffMask;
+                int32_t A_next;
+                uint32_t w_tk; // clones on the winner in this window, this one included
                 if (w_cls) {
-                    const int e0 = wl * LL + rl32(head, wl);
-                    w_el = (uint32_t)uni32((int)L.li_elig[e0]), A_next = uni32(L.li_A1[e0]);
-                    if (track) {
-                        const uint32_t w = (uint32_t)uni32((int)L.li_stat[e0]);
-                        w_cnt = (w >> kStatCntShift) & kStatCntMask, w_aff = w & kStatAffMask;
-                    }
-                    w_tix = nt;
-                    if (lane == wl) { // the class loses its head
+                    A_next = rl32(hA1, wl), w_tk = 1u;
+                    if (lane == wl) { // the class loses its head; the next one's record comes from LDS (nobody waits for it in this cycle)
                         nfm -= 1, head += 1;
                         if (track) cht -= w_cnt == cmt ? 1u : 0u, cha -= w_aff == cma ? 1u : 0u;
-                        key = head < LL ? L.li_key[e0 + 1] : 0ull;
+                        const uint4 r = L.ent[lane * LS + head]; // (member L of every class is the zero record)
+                        key = ((uint64_t)r.y << 32) | r.x, hA1 = (int32_t)r.z, hmeta = r.w;
                     }
-                    if (lane == 0) L.t_gidx[nt] = g, L.t_took[nt] = 1;
-                    nt += 1;
                 } else {
-                    w_el = (uint32_t)rl32((int32_t)el, wl), w_cnt = (uint32_t)rl32((int32_t)cmt, wl), w_aff = (uint32_t)rl32((int32_t)cma, wl);
-                    w_tix = rl32(tix, wl);
-                    const uint32_t took = (uint32_t)uni32((int)L.t_took[w_tix]) + 1;
-                    if (lane == 0) L.t_took[w_tix] = took;
-                    A_next = uni32(cw_local_after(a, g - a.c.global_offset, (int64_t)took, mt_a, ma_a)); // (a node winning again: one trip to its columns)
+                    w_tk = (uint32_t)rl32((int32_t)tk, wl) + 1u;
+                    A_next = uni32(cw_local_after(a, g - a.c.global_offset, (int64_t)w_tk, mt_a, ma_a)); // (a node winning again: one trip to its columns)
                 }
                 // the clone is an existing pod of the next cycle (filtering.go:255-296, interpodaffinity/filtering.go:204-272)
                 int32_t n_hv0 = w_hv0, n_hc0 = w_hc0, n_hv1 = w_hv1, n_hc1 = w_hc1; // the winner's own components after the clone
@@ -917,8 +952,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                             n_hv0 = w_hv0 + 2, n_hc0 = w_hc0 + 1;
                         }
                     } else if (w_hv0) {
-                        if (hv0 == w_hv0) hc0 += 1; // every candidate of the domain, the winner's class included
-                        if (lane == w_hv0) dc0 += 1;
+                        hc0 += hv0 == w_hv0 ? 1 : 0; // every candidate of the domain, the winner's class included
+                        dc0 += lane == w_hv0 ? 1 : 0;
                         if (w_hc0 == min0 && --nmin0 == 0) remin0 = true;
                         n_hc0 = w_hc0 + 1;
                     }
@@ -930,8 +965,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                             n_hv1 = w_hv1 + 2, n_hc1 = w_hc1 + 1;
                         }
                     } else if (w_hv1) {
-                        if (hv1 == w_hv1) hc1 += 1;
-                        if (lane == w_hv1) dc1 += 1;
+                        hc1 += hv1 == w_hv1 ? 1 : 0;
+                        dc1 += lane == w_hv1 ? 1 : 0;
                         if (w_hc1 == min1 && --nmin1 == 0) remin1 = true;
                         n_hc1 = w_hc1 + 1;
                     }
@@ -940,16 +975,24 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 if (NK > 0) {
                     n_kf0 = rl32(kf0, wl), n_kn0 = rl32(kn0, wl), n_ke0 = rl32(ke0, wl);
                     if (w_kv0) {
-                        aff_total += k_daff0, exist_total += k_danti0, entries += k_dent0;
-                        if (!KU0 && kv0 == w_kv0) kf0 += k_daff0, kn0 += k_danti0, ke0 += k_danti0;
+                        d_aff += k_daff0, d_exist += k_danti0, d_ent += k_dent0;
+                        aff_zero = aff_zero && k_daff0 == 0, exist_pos = exist_pos || k_danti0 != 0;
+                        if (!KU0) {
+                            const bool same = kv0 == w_kv0;
+                            kf0 += same ? k_daff0 : 0, kn0 += same ? k_danti0 : 0, ke0 += same ? k_danti0 : 0;
+                        }
                         n_kf0 += k_daff0, n_kn0 += k_danti0, n_ke0 += k_danti0;
                     }
                 }
                 if (NK > 1) {
                     n_kf1 = rl32(kf1, wl), n_kn1 = rl32(kn1, wl), n_ke1 = rl32(ke1, wl);
                     if (w_kv1) {
-                        aff_total += k_daff1, exist_total += k_danti1, entries += k_dent1;
-                        if (!KU1 && kv1 == w_kv1) kf1 += k_daff1, kn1 += k_danti1, ke1 += k_danti1;
+                        d_aff += k_daff1, d_exist += k_danti1, d_ent += k_dent1;
+                        aff_zero = aff_zero && k_daff1 == 0, exist_pos = exist_pos || k_danti1 != 0;
+                        if (!KU1) {
+                            const bool same = kv1 == w_kv1;
+                            kf1 += same ? k_daff1 : 0, kn1 += same ? k_danti1 : 0, ke1 += same ? k_danti1 : 0;
+                        }
                         n_kf1 += k_daff1, n_kn1 += k_danti1, n_ke1 += k_danti1;
                     }
                 }
@@ -957,39 +1000,67 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 bool dead = A_next < 0;
                 if (NK > 0 && ipa_filter) {
                     if ((k_anti0 && w_kv0 && n_kn0 > 0) || (NK > 1 && k_anti1 && w_kv1 && n_kn1 > 0)) dead = true;
-                    if (exist_total > 0 && ((w_kv0 && n_ke0 > 0) || (NK > 1 && w_kv1 && n_ke1 > 0))) dead = true;
+                    if (exist_pos && ((w_kv0 && n_ke0 > 0) || (NK > 1 && w_kv1 && n_ke1 > 0))) dead = true;
                 }
-                if (!dead) { // its lane: a new one behind the candidates, or the one it already has
-                    const int tl = w_cls ? ncand : wl;
-                    if (lane == tl) {
-                        hv0 = n_hv0, hc0 = n_hc0, hv1 = n_hv1, hc1 = n_hc1, kv0 = w_kv0, kv1 = w_kv1;
-                        kf0 = n_kf0, kn0 = n_kn0, ke0 = n_ke0, kf1 = n_kf1, kn1 = n_kn1, ke1 = n_ke1;
-                        nfm = 1, cmt = w_cnt, cma = w_aff, cht = cha = 1, el = w_el, head = 0, tix = w_tix, is_cls = false;
-                        key = make_key((int64_t)A_next, g);
-                    }
-                    if (w_cls) ncand += 1;
-                } else if (!w_cls) { // a touched node leaves: the last candidate lane takes its place
+                // (selects on every lane rather than branches: with the state rewritten on one side of a branch only, the compiler
+                // kept two copies of it and moved one into the other every cycle)
+                {   // it stays: its lane is a new one behind the candidates, or the one it already has
+                    const bool mine = !dead & (lane == (w_cls ? ncand : wl));
+                    if (NH > 0) hv0 = mine ? n_hv0 : hv0, hc0 = mine ? n_hc0 : hc0;
+                    if (NH > 1) hv1 = mine ? n_hv1 : hv1, hc1 = mine ? n_hc1 : hc1;
+                    if (NK > 0) kv0 = mine ? w_kv0 : kv0, kf0 = mine ? n_kf0 : kf0, kn0 = mine ? n_kn0 : kn0, ke0 = mine ? n_ke0 : ke0;
+                    if (NK > 1) kv1 = mine ? w_kv1 : kv1, kf1 = mine ? n_kf1 : kf1, kn1 = mine ? n_kn1 : kn1, ke1 = mine ? n_ke1 : ke1;
+                    nfm = mine ? 1u : nfm, cmt = mine ? w_cnt : cmt, cma = mine ? w_aff : cma, cht = mine ? 1u : cht, cha = mine ? 1u : cha;
+                    hmeta = mine ? w_meta : hmeta, tk = mine ? w_tk : tk;
+                    const uint64_t nkey = make_key((int64_t)(dead ? 0 : A_next), g);
+                    key = mine ? nkey : key;
+                    ncand += !dead && w_cls ? 1 : 0;
+                }
+                {   // it leaves (or never enters) the candidates: its (node, clones) record for the epilogue
+                    const uint64_t R = ((uint64_t)w_tk << kIdxBits) | (uint64_t)g;
+                    myrec = (dead & (lane == (nrec & 63))) ? R : myrec;
+                    nrec += dead ? 1 : 0;
+                    if (dead && (nrec & 63) == 0) L.rec[nrec - 64 + lane] = myrec;
+                }
+                if (dead && !w_cls) { // a touched node leaves: the last candidate lane takes its place
                     const int last = ncand - 1;
                     const int32_t m0 = rl32(hv0, last), m1 = rl32(hc0, last), m2 = rl32(hv1, last), m3 = rl32(hc1, last), m4 = rl32(kv0, last), m5 = rl32(kv1, last);
                     const int32_t m6 = rl32(kf0, last), m7 = rl32(kn0, last), m8 = rl32(ke0, last), m9 = rl32(kf1, last), m10 = rl32(kn1, last), m11 = rl32(ke1, last);
-                    const int32_t m12 = rl32((int32_t)cmt, last), m13 = rl32((int32_t)cma, last), m14 = rl32((int32_t)el, last), m15 = rl32(tix, last);
+                    const int32_t m12 = rl32((int32_t)cmt, last), m13 = rl32((int32_t)cma, last), m14 = rl32((int32_t)hmeta, last), m15 = rl32((int32_t)tk, last);
                     const uint64_t mk = rl64(key, last);
                     if (lane == wl) {
                         hv0 = m0, hc0 = m1, hv1 = m2, hc1 = m3, kv0 = m4, kv1 = m5, kf0 = m6, kn0 = m7, ke0 = m8, kf1 = m9, kn1 = m10, ke1 = m11;
-                        cmt = (uint32_t)m12, cma = (uint32_t)m13, el = (uint32_t)m14, tix = m15, key = mk; // (nfm = 1, holders = 1, not a class: as before)
+                        cmt = (uint32_t)m12, cma = (uint32_t)m13, hmeta = (uint32_t)m14, tk = (uint32_t)m15, key = mk; // (nfm = 1, holders = 1: as before)
                     }
                     ncand -= 1;
                 }
-                if (lane == 0 && a.log && placed < log_cap) a.log[placed] = (int32_t)g;
-                placed += 1, cycles += 1;
-                if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312: tested after the append
+                mylog = lane == (cycles & 63) ? (int32_t)g : mylog;
+                cycles += 1;
+                if ((cycles & 63) == 0 && cycles - 64 + lane < log_room) a.log[placed0 + (cycles - 64 + lane)] = mylog;
                 CW_TICK(5);
+                // ---- the next cycle: does it run in this window?
+                go = !end_window && cycles < Wl && ncand < 64;
+                if (go) {
+                    ok = verdicts();
+                    // nothing feasible (the next pass finds out why); a class's next head is not among the members kept; the
+                    // class's own maximum lost its last holder; the maxima moved
+                    uint64_t stop = __ballot(ok) == 0ull ? 1ull : 0ull;
+                    stop |= __ballot(ok & cls & ((key == 0ull) | (track & ((cht == 0) | (cha == 0)))));
+                    if (track) stop |= __ballot(ok & ((cmt > mt_a) | (cma > ma_a))) | (__ballot(ok & (cmt == mt_a)) == 0ull ? 1ull : 0ull) | (__ballot(ok & (cma == ma_a)) == 0ull ? 1ull : 0ull);
+                    go = stop == 0ull;
+                }
             }
             cw_lds_sync();
+            ncand = uni32(ncand), nrec = uni32(nrec), cycles = uni32(cycles);
+            // what the lanes still hold: the log's last partial group, the records' last partial group, the touched nodes that stayed
+            if (lane < (cycles & 63) && (cycles & ~63) + lane < log_room) a.log[placed0 + ((cycles & ~63) + lane)] = mylog;
+            if (lane < (nrec & 63)) L.rec[(nrec & ~63) + lane] = myrec;
+            if (lane >= C && lane < ncand) L.rec[nrec + (lane - C)] = ((uint64_t)tk << kIdxBits) | (uint64_t)key_index(key);
             const uint32_t nf_last = wave_sum_u32_dpp(lf);
             if (lane == 0) {
-                S.placed = placed, S.rounds += (placed - placed0) + (unsched ? 1 : 0), S.scans += 1;
-                S.ipa_aff_total = aff_total, S.ipa_exist_total = exist_total, S.ipa_entries = entries;
+                const int64_t placed = placed0 + cycles;
+                S.placed = placed, S.rounds += cycles + (unsched ? 1 : 0), S.scans += 1;
+                if (NK > 0) S.ipa_aff_total += d_aff, S.ipa_exist_total += d_exist, S.ipa_entries += d_ent;
                 if (unsched) S.last_feasible = 0;
                 else if (cycles > 0) S.last_feasible = (int32_t)nf_last;
                 S.winner = -1;
@@ -997,9 +1068,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 if (NH > 0) S.pts_min_a[0] = min0; // (the terminal histogram reads them: k_hist)
                 if (NH > 1) S.pts_min_a[1] = min1;
                 S.cw_windows += 1;
-                S.done = unsched ? DONE_UNSCHEDULABLE : done;
-                L.s_nt = nt;
-                if (prof) L.pf[7] += (unsigned long long)cycles;
+                S.done = unsched ? DONE_UNSCHEDULABLE : (limit > 0 && placed >= limit ? DONE_LIMIT : 0);
+                L.s_nt = nrec + (ncand - C);
+                if (PROF) L.pf[7] += (unsigned long long)cycles;
             }
         }
     }
@@ -1009,8 +1080,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     // ---- epilogue (all threads): everything a placement changes follows from (node, clones): columns (NodeInfo.update,
     // types.go:409-428) and table entries at the node's own topology values -- integer adds, in any order
     for (int ti = tid; ti < nt; ti += kCwThreads) {
-        const int64_t i = L.t_gidx[ti] - a.c.global_offset;
-        const int64_t k = (int64_t)L.t_took[ti];
+        const unsigned long long R = L.rec[ti];
+        const int64_t i = (int64_t)(R & kIdxMask) - a.c.global_offset;
+        const int64_t k = (int64_t)(R >> kIdxBits);
         const int64_t r0 = a.c.req[0][i] + k * a.p.req[0], r1 = a.c.req[1][i] + k * a.p.req[1];
         const int64_t z0 = a.c.nz_mcpu[i] + k * a.p.nz_mcpu, z1 = a.c.nz_mem[i] + k * a.p.nz_mem;
         a.c.req[0][i] = r0, a.c.req[1][i] = r1, a.c.nz_mcpu[i] = z0, a.c.nz_mem[i] = z1;
@@ -1048,7 +1120,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     if (tid == 0) {
         a.w.ctl[kCwCtlClasses] = 0u;
         __hip_atomic_store(a.w.ctl + kCwCtlFastDone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prof) {
+        if (PROF) {
             L.pf[6] += __builtin_amdgcn_s_memrealtime() - t_prev;
             for (int i = 0; i < 8; i++) a.w.prof[i] += L.pf[i];
         }

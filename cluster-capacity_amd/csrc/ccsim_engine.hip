@@ -1448,7 +1448,11 @@ static void launch_cw_window(ccsim_engine *e) {
         const CwDecideArgs *dp = (const CwDecideArgs *)e->d_cw_args;
         const int shape = e->pts.n * 1000 + hu * 100 + nk * 10 + ku;
         switch (shape) {
-#define CW_FAST_CASE(NH, HU, NK, KU) case NH * 1000 + HU * 100 + NK * 10 + KU: hipLaunchKernelGGL((k_cw_decide_fast<NH, HU, NK, KU>), dim3(1), b, sizeof(CwLds), e->stream, dp); break;
+#define CW_FAST_CASE(NH, HU, NK, KU)                                                                                             \
+    case NH * 1000 + HU * 100 + NK * 10 + KU:                                                                                    \
+        if (e->cw_work.prof) hipLaunchKernelGGL((k_cw_decide_fast<NH, HU, NK, KU, true>), dim3(1), b, sizeof(CwLds), e->stream, dp); \
+        else hipLaunchKernelGGL((k_cw_decide_fast<NH, HU, NK, KU, false>), dim3(1), b, sizeof(CwLds), e->stream, dp);             \
+        break;
             CW_FAST_SHAPES(CW_FAST_CASE)
 #undef CW_FAST_CASE
         default: break; // no lane-per-candidate instantiation for this shape: the general kernel does every window
@@ -1465,7 +1469,9 @@ static int run_cw(ccsim_engine *e) {
     if (e->cw_work.prof) HIPCHK(e, hipMemsetAsync(e->cw_work.prof, 0, 16 * sizeof(unsigned long long), e->stream));
     if (!attr_set) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
-#define CW_FAST_ATTR(NH, HU, NK, KU) HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast<NH, HU, NK, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+#define CW_FAST_ATTR(NH, HU, NK, KU)                                                                                                                          \
+    HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast<NH, HU, NK, KU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds))); \
+    HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast<NH, HU, NK, KU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         CW_FAST_SHAPES(CW_FAST_ATTR)
 #undef CW_FAST_ATTR
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
