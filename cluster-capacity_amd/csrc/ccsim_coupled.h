@@ -33,6 +33,7 @@
 // never a different answer.
 #pragma once
 #include "ccsim_kernels.h"
+#include <type_traits>
 
 namespace ccsim {
 
@@ -702,6 +703,8 @@ __device__ __forceinline__ int32_t rl32(int32_t v, int src) { return __builtin_a
 __device__ __forceinline__ uint64_t rl64(uint64_t v, int src) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
 }
+// v_writelane_b32: lane `lane` of `old` takes the uniform `value` (this clang has no builtin for it; the label names the LLVM intrinsic)
+extern "C" __device__ int cw_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane");
 __device__ __forceinline__ int32_t wave_min_i32_nonneg(int32_t v) { return (int32_t)(0x7fffffffu - wave_max_u32(0x7fffffffu - (uint32_t)v)); }
 
 // The shape of the pod is a template argument: NH hard constraints, bit c of HU = constraint c is over a unique-per-node key;
@@ -902,15 +905,12 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 const uint32_t mt_now = wave_max_u32(ok ? cmt : 0u), ma_now = wave_max_u32(ok ? cma : 0u);
                 if (mt_now != mt_a || ma_now != ma_a) stale_maxima = true, new_mt = mt_now, new_ma = ma_now, go = false; // A was computed under other maxima: redo the pass
             }
-#pragma unroll 1
-            while (uni32(go)) {
-                // (loop-carried scalars, re-asserted uniform: one v_readfirstlane each instead of divergent-loop bookkeeping)
-                ncand = uni32(ncand), nrec = uni32(nrec), cycles = uni32(cycles), nmin0 = (uint32_t)uni32((int)nmin0), nmin1 = (uint32_t)uni32((int)nmin1);
-                min0 = uni32(min0), min1 = uni32(min1), remin0 = uni32(remin0) != 0, remin1 = uni32(remin1) != 0;
-                d_aff = uni32(d_aff), d_exist = uni32(d_exist), d_ent = uni32(d_ent), aff_zero = uni32(aff_zero) != 0, exist_pos = uni32(exist_pos) != 0;
+            int wl = 0;    // the winner's lane
+            int64_t g = 0; // ... and node
+            // ---- argmax (selectHost, schedule_one.go:894-941): the key IS (A, lowest index first); its high word carries A
+            auto argmax = [&]() {
                 lf = ok ? nfm : 0u;
                 CW_TICK(2);
-                // ---- argmax (selectHost, schedule_one.go:894-941): the key IS (A, lowest index first); its high word carries A
                 const uint32_t khi = ok ? (uint32_t)(key >> 32) : 0u; // (> 0 on every feasible lane: make_key stores A + 1)
                 const uint32_t bhi = wave_max_u32(khi);
                 const bool top = ok & (khi == bhi);
@@ -920,11 +920,20 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     const uint32_t blo = wave_max_u32(klo);
                     tm = __ballot(top & (klo == blo));
                 }
-                const int wl = __builtin_amdgcn_readfirstlane(__ffsll(tm) - 1);
-                const int64_t g = key_index(rl64(key, wl));
+                wl = __builtin_amdgcn_readfirstlane(__ffsll(tm) - 1);
+                g = key_index(rl64(key, wl));
                 CW_TICK(4);
-                // ---- commit: broadcasts from the winner's lane
-                const bool w_cls = wl < C;
+            };
+            // (v_writelane: one lane of a register takes a uniform value -- no compare, no select)
+#define CW_PUT(var, val, at) var = (decltype(var))cw_writelane((int)(val), (at), (int)(var))
+#define CW_PUT64(var, val, at) var = ((uint64_t)(uint32_t)cw_writelane((int)(uint32_t)((val) >> 32), (at), (int)(uint32_t)((var) >> 32)) << 32) | (uint32_t)cw_writelane((int)(uint32_t)(val), (at), (int)(uint32_t)(var))
+            // ---- commit, for a winner that is a class's head (the tag says so) or a node that already received clones in this window.
+            // The class form is straight-line: what only happens on one side of a condition is done on both, to a place where it
+            // does no harm (lane 63 is no candidate while the loop runs; the next record slot is rewritten before it is stored).
+            // With the lane state rewritten on one side of a branch only, the compiler kept it under two names and copied one
+            // into the other every cycle.
+            auto commit = [&](auto w_cls_tag) {
+                constexpr bool w_cls = decltype(w_cls_tag)::value;
                 const int32_t w_hv0 = NH > 0 ? rl32(hv0, wl) : 0, w_hv1 = NH > 1 ? rl32(hv1, wl) : 0, w_kv0 = NK > 0 ? rl32(kv0, wl) : 0, w_kv1 = NK > 1 ? rl32(kv1, wl) : 0;
                 const int32_t w_hc0 = NH > 0 ? rl32(hc0, wl) : 0, w_hc1 = NH > 1 ? rl32(hc1, wl) : 0; // (before this clone)
                 const uint32_t w_meta = (uint32_t)rl32((int32_t)hmeta, wl);
@@ -945,56 +954,56 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 }
                 // the clone is an existing pod of the next cycle (filtering.go:255-296, interpodaffinity/filtering.go:204-272)
                 int32_t n_hv0 = w_hv0, n_hc0 = w_hc0, n_hv1 = w_hv1, n_hc1 = w_hc1; // the winner's own components after the clone
-                if (NH > 0 && (w_el & 1u) && ((w_el >> 1) & 1u) && h_self0) {
+                if (NH > 0) {
+                    const bool counts = (w_el & 1u) && ((w_el >> 1) & 1u) && h_self0 && (HU0 ? (w_hv0 & 1) : w_hv0) != 0;
+                    const bool at_min = counts && w_hc0 == min0;
+                    nmin0 -= at_min ? 1u : 0u;
                     if (HU0) {
-                        if (w_hv0 & 1) {
-                            if (w_hc0 == min0 && --nmin0 == 0) end_window = true; // the last node at the minimum: the new one takes a pass
-                            n_hv0 = w_hv0 + 2, n_hc0 = w_hc0 + 1;
-                        }
-                    } else if (w_hv0) {
-                        hc0 += hv0 == w_hv0 ? 1 : 0; // every candidate of the domain, the winner's class included
-                        dc0 += lane == w_hv0 ? 1 : 0;
-                        if (w_hc0 == min0 && --nmin0 == 0) remin0 = true;
-                        n_hc0 = w_hc0 + 1;
+                        end_window = end_window || (at_min && nmin0 == 0); // the last node at the minimum: the new one takes a pass
+                        n_hv0 += counts ? 2 : 0;
+                    } else {
+                        hc0 += (counts & (hv0 == w_hv0)) ? 1 : 0; // every candidate of the domain, the winner's class included
+                        dc0 += (counts & (lane == w_hv0)) ? 1 : 0;
+                        remin0 = remin0 || (at_min && nmin0 == 0);
                     }
+                    n_hc0 += counts ? 1 : 0;
                 }
-                if (NH > 1 && (w_el & 1u) && ((w_el >> 2) & 1u) && h_self1) {
+                if (NH > 1) {
+                    const bool counts = (w_el & 1u) && ((w_el >> 2) & 1u) && h_self1 && (HU1 ? (w_hv1 & 1) : w_hv1) != 0;
+                    const bool at_min = counts && w_hc1 == min1;
+                    nmin1 -= at_min ? 1u : 0u;
                     if (HU1) {
-                        if (w_hv1 & 1) {
-                            if (w_hc1 == min1 && --nmin1 == 0) end_window = true;
-                            n_hv1 = w_hv1 + 2, n_hc1 = w_hc1 + 1;
-                        }
-                    } else if (w_hv1) {
-                        hc1 += hv1 == w_hv1 ? 1 : 0;
-                        dc1 += lane == w_hv1 ? 1 : 0;
-                        if (w_hc1 == min1 && --nmin1 == 0) remin1 = true;
-                        n_hc1 = w_hc1 + 1;
+                        end_window = end_window || (at_min && nmin1 == 0);
+                        n_hv1 += counts ? 2 : 0;
+                    } else {
+                        hc1 += (counts & (hv1 == w_hv1)) ? 1 : 0;
+                        dc1 += (counts & (lane == w_hv1)) ? 1 : 0;
+                        remin1 = remin1 || (at_min && nmin1 == 0);
                     }
+                    n_hc1 += counts ? 1 : 0;
                 }
                 int32_t n_kf0 = 0, n_kn0 = 0, n_ke0 = 0, n_kf1 = 0, n_kn1 = 0, n_ke1 = 0;
                 if (NK > 0) {
-                    n_kf0 = rl32(kf0, wl), n_kn0 = rl32(kn0, wl), n_ke0 = rl32(ke0, wl);
-                    if (w_kv0) {
-                        d_aff += k_daff0, d_exist += k_danti0, d_ent += k_dent0;
-                        aff_zero = aff_zero && k_daff0 == 0, exist_pos = exist_pos || k_danti0 != 0;
-                        if (!KU0) {
-                            const bool same = kv0 == w_kv0;
-                            kf0 += same ? k_daff0 : 0, kn0 += same ? k_danti0 : 0, ke0 += same ? k_danti0 : 0;
-                        }
-                        n_kf0 += k_daff0, n_kn0 += k_danti0, n_ke0 += k_danti0;
+                    const int on = w_kv0 != 0 ? -1 : 0; // (the node has the key: its clone counts, there and on the totals)
+                    const int da = k_daff0 & on, dn = k_danti0 & on;
+                    d_aff += da, d_exist += dn, d_ent += k_dent0 & on;
+                    aff_zero = aff_zero && da == 0, exist_pos = exist_pos || dn != 0;
+                    if (!KU0) {
+                        const bool same = (kv0 == w_kv0) & (on != 0);
+                        kf0 += same ? da : 0, kn0 += same ? dn : 0, ke0 += same ? dn : 0;
                     }
+                    n_kf0 = rl32(kf0, wl) + (KU0 ? da : 0), n_kn0 = rl32(kn0, wl) + (KU0 ? dn : 0), n_ke0 = rl32(ke0, wl) + (KU0 ? dn : 0);
                 }
                 if (NK > 1) {
-                    n_kf1 = rl32(kf1, wl), n_kn1 = rl32(kn1, wl), n_ke1 = rl32(ke1, wl);
-                    if (w_kv1) {
-                        d_aff += k_daff1, d_exist += k_danti1, d_ent += k_dent1;
-                        aff_zero = aff_zero && k_daff1 == 0, exist_pos = exist_pos || k_danti1 != 0;
-                        if (!KU1) {
-                            const bool same = kv1 == w_kv1;
-                            kf1 += same ? k_daff1 : 0, kn1 += same ? k_danti1 : 0, ke1 += same ? k_danti1 : 0;
-                        }
-                        n_kf1 += k_daff1, n_kn1 += k_danti1, n_ke1 += k_danti1;
+                    const int on = w_kv1 != 0 ? -1 : 0;
+                    const int da = k_daff1 & on, dn = k_danti1 & on;
+                    d_aff += da, d_exist += dn, d_ent += k_dent1 & on;
+                    aff_zero = aff_zero && da == 0, exist_pos = exist_pos || dn != 0;
+                    if (!KU1) {
+                        const bool same = (kv1 == w_kv1) & (on != 0);
+                        kf1 += same ? da : 0, kn1 += same ? dn : 0, ke1 += same ? dn : 0;
                     }
+                    n_kf1 = rl32(kf1, wl) + (KU1 ? da : 0), n_kn1 = rl32(kn1, wl) + (KU1 ? dn : 0), n_ke1 = rl32(ke1, wl) + (KU1 ? dn : 0);
                 }
                 // does the node stay a candidate?  Full, or blocked for good by a required anti-affinity term against what is there to stay: no
                 bool dead = A_next < 0;
@@ -1002,54 +1011,86 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     if ((k_anti0 && w_kv0 && n_kn0 > 0) || (NK > 1 && k_anti1 && w_kv1 && n_kn1 > 0)) dead = true;
                     if (exist_pos && ((w_kv0 && n_ke0 > 0) || (NK > 1 && w_kv1 && n_ke1 > 0))) dead = true;
                 }
-                // (selects on every lane rather than branches: with the state rewritten on one side of a branch only, the compiler
-                // kept two copies of it and moved one into the other every cycle)
-                {   // it stays: its lane is a new one behind the candidates, or the one it already has
-                    const bool mine = !dead & (lane == (w_cls ? ncand : wl));
-                    if (NH > 0) hv0 = mine ? n_hv0 : hv0, hc0 = mine ? n_hc0 : hc0;
-                    if (NH > 1) hv1 = mine ? n_hv1 : hv1, hc1 = mine ? n_hc1 : hc1;
-                    if (NK > 0) kv0 = mine ? w_kv0 : kv0, kf0 = mine ? n_kf0 : kf0, kn0 = mine ? n_kn0 : kn0, ke0 = mine ? n_ke0 : ke0;
-                    if (NK > 1) kv1 = mine ? w_kv1 : kv1, kf1 = mine ? n_kf1 : kf1, kn1 = mine ? n_kn1 : kn1, ke1 = mine ? n_ke1 : ke1;
-                    nfm = mine ? 1u : nfm, cmt = mine ? w_cnt : cmt, cma = mine ? w_aff : cma, cht = mine ? 1u : cht, cha = mine ? 1u : cha;
-                    hmeta = mine ? w_meta : hmeta, tk = mine ? w_tk : tk;
+                const uint64_t R = ((uint64_t)w_tk << kIdxBits) | (uint64_t)g; // its (node, clones) record for the epilogue, if it leaves
+                if (w_cls) {
+                    // it stays: a new lane behind the candidates (it does not: lane 63)
+                    const int tl = dead ? 63 : ncand;
+                    if (NH > 0) { CW_PUT(hv0, n_hv0, tl); CW_PUT(hc0, n_hc0, tl); }
+                    if (NH > 1) { CW_PUT(hv1, n_hv1, tl); CW_PUT(hc1, n_hc1, tl); }
+                    if (NK > 0) { CW_PUT(kv0, w_kv0, tl); CW_PUT(kf0, n_kf0, tl); CW_PUT(kn0, n_kn0, tl); CW_PUT(ke0, n_ke0, tl); }
+                    if (NK > 1) { CW_PUT(kv1, w_kv1, tl); CW_PUT(kf1, n_kf1, tl); CW_PUT(kn1, n_kn1, tl); CW_PUT(ke1, n_ke1, tl); }
+                    CW_PUT(nfm, 1, tl); CW_PUT(cmt, w_cnt, tl); CW_PUT(cma, w_aff, tl); CW_PUT(cht, 1, tl); CW_PUT(cha, 1, tl);
+                    CW_PUT(hmeta, w_meta, tl); CW_PUT(tk, 1, tl);
                     const uint64_t nkey = make_key((int64_t)(dead ? 0 : A_next), g);
-                    key = mine ? nkey : key;
-                    ncand += !dead && w_cls ? 1 : 0;
-                }
-                {   // it leaves (or never enters) the candidates: its (node, clones) record for the epilogue
-                    const uint64_t R = ((uint64_t)w_tk << kIdxBits) | (uint64_t)g;
-                    myrec = (dead & (lane == (nrec & 63))) ? R : myrec;
+                    CW_PUT64(key, nkey, tl);
+                    ncand += dead ? 0 : 1;
+                    CW_PUT64(myrec, R, nrec & 63); // (kept if it left: the slot is the next record's otherwise)
                     nrec += dead ? 1 : 0;
                     if (dead && (nrec & 63) == 0) L.rec[nrec - 64 + lane] = myrec;
-                }
-                if (dead && !w_cls) { // a touched node leaves: the last candidate lane takes its place
+                } else if (!dead) { // it keeps the lane it has
+                    if (NH > 0) { CW_PUT(hv0, n_hv0, wl); CW_PUT(hc0, n_hc0, wl); }
+                    if (NH > 1) { CW_PUT(hv1, n_hv1, wl); CW_PUT(hc1, n_hc1, wl); }
+                    if (NK > 0) { CW_PUT(kf0, n_kf0, wl); CW_PUT(kn0, n_kn0, wl); CW_PUT(ke0, n_ke0, wl); }
+                    if (NK > 1) { CW_PUT(kf1, n_kf1, wl); CW_PUT(kn1, n_kn1, wl); CW_PUT(ke1, n_ke1, wl); }
+                    CW_PUT(tk, w_tk, wl);
+                    const uint64_t nkey = make_key((int64_t)A_next, g);
+                    CW_PUT64(key, nkey, wl);
+                } else { // a touched node leaves: its record, and the last candidate lane takes its place
+                    CW_PUT64(myrec, R, nrec & 63);
+                    nrec += 1;
+                    if ((nrec & 63) == 0) L.rec[nrec - 64 + lane] = myrec;
                     const int last = ncand - 1;
-                    const int32_t m0 = rl32(hv0, last), m1 = rl32(hc0, last), m2 = rl32(hv1, last), m3 = rl32(hc1, last), m4 = rl32(kv0, last), m5 = rl32(kv1, last);
-                    const int32_t m6 = rl32(kf0, last), m7 = rl32(kn0, last), m8 = rl32(ke0, last), m9 = rl32(kf1, last), m10 = rl32(kn1, last), m11 = rl32(ke1, last);
-                    const int32_t m12 = rl32((int32_t)cmt, last), m13 = rl32((int32_t)cma, last), m14 = rl32((int32_t)hmeta, last), m15 = rl32((int32_t)tk, last);
+                    if (NH > 0) { CW_PUT(hv0, rl32(hv0, last), wl); CW_PUT(hc0, rl32(hc0, last), wl); }
+                    if (NH > 1) { CW_PUT(hv1, rl32(hv1, last), wl); CW_PUT(hc1, rl32(hc1, last), wl); }
+                    if (NK > 0) { CW_PUT(kv0, rl32(kv0, last), wl); CW_PUT(kf0, rl32(kf0, last), wl); CW_PUT(kn0, rl32(kn0, last), wl); CW_PUT(ke0, rl32(ke0, last), wl); }
+                    if (NK > 1) { CW_PUT(kv1, rl32(kv1, last), wl); CW_PUT(kf1, rl32(kf1, last), wl); CW_PUT(kn1, rl32(kn1, last), wl); CW_PUT(ke1, rl32(ke1, last), wl); }
+                    CW_PUT(cmt, rl32((int32_t)cmt, last), wl); CW_PUT(cma, rl32((int32_t)cma, last), wl); // (nfm = 1, holders = 1: as before)
+                    CW_PUT(hmeta, rl32((int32_t)hmeta, last), wl); CW_PUT(tk, rl32((int32_t)tk, last), wl);
                     const uint64_t mk = rl64(key, last);
-                    if (lane == wl) {
-                        hv0 = m0, hc0 = m1, hv1 = m2, hc1 = m3, kv0 = m4, kv1 = m5, kf0 = m6, kn0 = m7, ke0 = m8, kf1 = m9, kn1 = m10, ke1 = m11;
-                        cmt = (uint32_t)m12, cma = (uint32_t)m13, hmeta = (uint32_t)m14, tk = (uint32_t)m15, key = mk; // (nfm = 1, holders = 1: as before)
-                    }
+                    CW_PUT64(key, mk, wl);
                     ncand -= 1;
                 }
-                mylog = lane == (cycles & 63) ? (int32_t)g : mylog;
+                CW_PUT(mylog, (int32_t)g, cycles & 63);
                 cycles += 1;
                 if ((cycles & 63) == 0 && cycles - 64 + lane < log_room) a.log[placed0 + (cycles - 64 + lane)] = mylog;
                 CW_TICK(5);
-                // ---- the next cycle: does it run in this window?
+            };
+            // ---- the next cycle: does it run in this window?
+            auto next_cycle = [&]() {
                 go = !end_window && cycles < Wl && ncand < 64;
                 if (go) {
                     ok = verdicts();
                     // nothing feasible (the next pass finds out why); a class's next head is not among the members kept; the
                     // class's own maximum lost its last holder; the maxima moved
-                    uint64_t stop = __ballot(ok) == 0ull ? 1ull : 0ull;
-                    stop |= __ballot(ok & cls & ((key == 0ull) | (track & ((cht == 0) | (cha == 0)))));
-                    if (track) stop |= __ballot(ok & ((cmt > mt_a) | (cma > ma_a))) | (__ballot(ok & (cmt == mt_a)) == 0ull ? 1ull : 0ull) | (__ballot(ok & (cma == ma_a)) == 0ull ? 1ull : 0ull);
-                    go = stop == 0ull;
+                    const uint64_t okm = __ballot(ok);
+                    bool stop = okm == 0ull;
+                    stop |= (__ballot(cls & ((key == 0ull) | (track & ((cht == 0) | (cha == 0))))) & okm) != 0ull;
+                    if (track) stop |= (int)((__ballot((cmt > mt_a) | (cma > ma_a)) & okm) != 0ull) | (int)((__ballot(cmt == mt_a) & okm) == 0ull) | (int)((__ballot(cma == ma_a) & okm) == 0ull);
+                    go = !stop;
                 }
+            };
+            // The hot loop runs while class heads win (every cycle of a pod whose clones exclude each other); a node winning AGAIN
+            // takes a trip to its columns (cw_local_after, with loops over the extra resources): kept out of the hot loop's body,
+            // whose register allocation it spoiled (SGPR spills reloaded in every cycle).
+            for (;;) {
+                bool again = false;
+                asm volatile("" ::: "memory"); // (keeps this header apart from the hot loop's: merged, they are one loop with the slow path inside)
+#pragma unroll 1
+                while (uni32(go)) {
+                    argmax();
+                    if (wl >= C) {
+                        again = true;
+                        break;
+                    }
+                    commit(std::true_type{});
+                    next_cycle();
+                }
+                if (!uni32(again)) break;
+                commit(std::false_type{});
+                next_cycle();
             }
+#undef CW_PUT
+#undef CW_PUT64
             cw_lds_sync();
             ncand = uni32(ncand), nrec = uni32(nrec), cycles = uni32(cycles);
             // what the lanes still hold: the log's last partial group, the records' last partial group, the touched nodes that stayed
