@@ -38,15 +38,51 @@ def _stale(out: str) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+class _BuildLock:
+    """One builder at a time per artefact, and nobody loads a file that is being written: processes that find the artefact stale
+    together (pytest-xdist workers on a fresh checkout) queue on the lock, the first one builds into a temporary name and renames
+    it into place, the others find it fresh.  (A worker once dlopen()ed a library another worker's compiler was still writing.)"""
+
+    def __init__(self, out: str):
+        self.path = out + ".lock"
+
+    def __enter__(self):
+        import fcntl
+
+        os.makedirs(os.path.dirname(self.path), exist_ok=True)
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
+def _run_into(cmd_without_out: list, out: str, verbose: bool) -> None:
+    tmp = "%s.tmp.%d" % (out, os.getpid())
+    cmd = cmd_without_out + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd_without_out + ["-o", out]))
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def build_all(force: bool = False, verbose: bool = False) -> str:
     out = lib_path()
     if force or _stale(out):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        extra = os.environ.get("CCSIM_EXTRA_FLAGS", "").split()
-        cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        with _BuildLock(out):
+            if force or _stale(out):
+                hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+                extra = os.environ.get("CCSIM_EXTRA_FLAGS", "").split()
+                _run_into([hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES], out, verbose)
     return out
 
 
@@ -64,15 +100,14 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     """The native (C++) host above the C ABI: ingest, CLI, report.  Loads libccsim.so at run time (dlopen)."""
     out = host_path()
     deps = [os.path.join(HOST, f) for f in HOST_SOURCES + HOST_DEPS] + [os.path.join(ROOT, "include", "ccsim.h")]
-    if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        san = os.environ.get("CCHOST_SANITIZE")
-        opt = ["-O1", "-g", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all", "-fsanitize=" + san] if san else ["-O2"]
-        cmd = [os.environ.get("CXX", "g++")] + opt + ["-std=c++17", "-Wall", "-Wextra", "-o", out] + \
-              [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-ldl", "-pthread"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    stale = lambda: not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+    if force or stale():
+        with _BuildLock(out):
+            if force or stale():
+                san = os.environ.get("CCHOST_SANITIZE")
+                opt = ["-O1", "-g", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all", "-fsanitize=" + san] if san else ["-O2"]
+                _run_into([os.environ.get("CXX", "g++")] + opt + ["-std=c++17", "-Wall", "-Wextra"] +
+                          [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-ldl", "-pthread"], out, verbose)
     return out
 
 

@@ -43,11 +43,11 @@ constexpr int kCwMaxCons = 4, kCwKeyPos0 = 8, kCwKeyPos1 = 13, kCwKeyPos2 = 18, 
 constexpr int kCwMaxClasses = 256;  // classes per window
 constexpr int kCwSlots = 1024;      // global open-addressing class table (power of two)
 constexpr int kCwBlockSlots = 256;  // per-block LDS class table of the scan (power of two)
-constexpr int kCwMaxList = 32;      // L
+constexpr int kCwMaxList = 64;      // L
 constexpr int kCwMaxWindow = 256;   // W of the general decide kernel (a touched node keeps its whole tuple in LDS)
 constexpr int kCwFastWindow = 1024; // W of the lane-per-candidate kernel (a touched node is (index, clones))
 constexpr int kCwThreads = 256, kCwPerThread = 4, kCwTile = kCwThreads * kCwPerThread;
-constexpr int kCwMaxKeys = 4096;    // k_cw_merge stages blocks x L keys of one class in LDS (32 KiB)
+constexpr int kCwMaxKeys = 6400;    // k_cw_merge stages blocks x L keys of one class in LDS (32 KiB)
 constexpr int kCwLdsI32 = 4096;     // k_cw_decide: int32 words of shared-key tables (hard / soft counts, presence flags, candidate bitmaps)
 constexpr int kCwLdsI64 = 2048;     // ... int64 words (four InterPodAffinity tables per shared key)
 constexpr int kCwCtlClasses = 0, kCwCtlGiveUp = 1;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a) {
     __syncthreads();
     if (threadIdx.x >= kCwMergeThreads) return; // the rounds: one wave, no block barrier
     const int lane = threadIdx.x;
-    unsigned long long mine = 0; // rank `lane` of the merged list ends up in lane `lane` (L <= 32)
+    unsigned long long mine = 0; // rank `lane` of the merged list ends up in lane `lane` (L <= 64)
     if (nb <= 2 * kCwMergeThreads) { // the usual size: a lane keeps the current heads of its (at most two) blocks in registers
         const int b0 = lane, b1 = lane + kCwMergeThreads;
         int h0 = 0, h1 = 0;
@@ -747,6 +747,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
     bool fits = C <= kCwFastClasses && C * LL <= kCwListLds;
+    if (NH > 0) fits = fits && a.pts.max_skew[0] <= (1 << 29);
+    if (NH > 1) fits = fits && a.pts.max_skew[1] <= (1 << 29);
     if (NH > 0 && !HU0) fits = fits && a.plan.h_len[0] <= 64;
     if (NH > 1 && !HU1) fits = fits && a.plan.h_len[1] <= 64;
     if (NK > 0 && a.ipa.w) { // PreScore must skip for the whole window: no entries now, none added by a clone (scoring.go:199-201)
@@ -829,6 +831,29 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 }
             }
         }
+        // What the verdicts need not test again in every cycle:
+        //  * a lane that is no candidate has nfm == 0 (lanes behind the candidates, lane 63 after a write that was not meant);
+        //  * a node without the topology key of a hard constraint carries a count no skew admits (filtering.go:326-330);
+        //  * a node without an inter-pod key has zero counts for it, and keeps them (a clone only counts where the key is);
+        //  * `nleft`: members of the class list not yet placed, the head included (1 on every other lane) -- the class is
+        //    exhausted when it reaches 0, known without waiting for the next head's record to arrive from LDS;
+        //  * without TaintToleration / NodeAffinity scores the holder counts stay 1.
+        constexpr int32_t kNoKey = 0x7fffffff, kCountCap = 1 << 30; // (counts and skews beyond 2^30 / 2^29: the general kernel's business)
+        if (NH > 0) over = over || hc0 >= kCountCap;
+        if (NH > 1) over = over || hc1 >= kCountCap;
+        if (NH > 0 && cls && (HU0 ? !(hv0 & 1) : hv0 == 0)) hc0 = kNoKey;
+        if (NH > 1 && cls && (HU1 ? !(hv1 & 1) : hv1 == 0)) hc1 = kNoKey;
+        // count + self - minimum <= maxSkew as count - min(minimum, 2^30) <= maxSkew - self: no overflow with kNoKey on the left, and
+        // with no domain present at all (minimum = MaxInt32: every node WITH the key passes, filtering.go:298-305) it still fails
+        const int32_t h_rhs0 = h_skew0 - h_self0, h_rhs1 = h_skew1 - h_self1;
+        if (NK > 0 && kv0 == 0) kf0 = kn0 = ke0 = 0;
+        if (NK > 1 && kv1 == 0) kf1 = kn1 = ke1 = 0;
+        uint32_t nleft = 1u;
+        if (cls) {
+            nleft = 0u;
+            for (int m = 0; m < LL; m++) nleft += L.ent[lane * LS + m].y != 0u ? 1u : 0u;
+        }
+        if (!track) cht = cha = 1u;
         // lane = domain (shared-key hard constraints): count and presence, for the minimum
         int32_t dc0 = 0, dc1 = 0;
         bool dp0 = false, dp1 = false;
@@ -880,21 +905,21 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
             auto verdicts = [&]() -> bool {
                 if (NH > 0 && !HU0 && remin0) min0 = wave_min_i32_nonneg(dp0 ? dc0 : 0x7fffffff), nmin0 = (uint32_t)__popcll(__ballot(dp0 && dc0 == min0)), remin0 = false;
                 if (NH > 1 && !HU1 && remin1) min1 = wave_min_i32_nonneg(dp1 ? dc1 : 0x7fffffff), nmin1 = (uint32_t)__popcll(__ballot(dp1 && dc1 == min1)), remin1 = false;
-                bool ok = (lane < ncand) & (nfm > 0);
-                if (NH > 0) ok &= ((HU0 ? (hv0 & 1) : hv0) != 0) & (hc0 + h_self0 - (h_usemin0 ? min0 : 0) <= h_skew0);
-                if (NH > 1) ok &= ((HU1 ? (hv1 & 1) : hv1) != 0) & (hc1 + h_self1 - (h_usemin1 ? min1 : 0) <= h_skew1);
+                bool ok = nfm > 0;
+                if (NH > 0) ok &= hc0 - (h_usemin0 ? (min0 < kCountCap ? min0 : kCountCap) : 0) <= h_rhs0;
+                if (NH > 1) ok &= hc1 - (h_usemin1 ? (min1 < kCountCap ? min1 : kCountCap) : 0) <= h_rhs1;
                 if (NK > 0 && ipa_filter && (exist_pos || ipa_any_term)) {
                     if (any_aff) {
                         bool pods_exist = true, aff_ok = true;
-                        if (k_aff0) aff_ok &= kv0 != 0, pods_exist &= (kv0 != 0) & (kf0 > 0);
-                        if (NK > 1 && k_aff1) aff_ok &= kv1 != 0, pods_exist &= (kv1 != 0) & (kf1 > 0);
+                        if (k_aff0) aff_ok &= kv0 != 0, pods_exist &= kf0 > 0;
+                        if (NK > 1 && k_aff1) aff_ok &= kv1 != 0, pods_exist &= kf1 > 0;
                         ok &= aff_ok & (pods_exist | (aff_zero && self_aff));
                     }
-                    if (k_anti0) ok &= !((kv0 != 0) & (kn0 > 0));
-                    if (NK > 1 && k_anti1) ok &= !((kv1 != 0) & (kn1 > 0));
+                    if (k_anti0) ok &= kn0 <= 0;
+                    if (NK > 1 && k_anti1) ok &= kn1 <= 0;
                     if (exist_pos) {
-                        ok &= !((kv0 != 0) & (ke0 > 0));
-                        if (NK > 1) ok &= !((kv1 != 0) & (ke1 > 0));
+                        ok &= ke0 <= 0;
+                        if (NK > 1) ok &= ke1 <= 0;
                     }
                 }
                 return ok;
@@ -943,7 +968,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 if (w_cls) {
                     A_next = rl32(hA1, wl), w_tk = 1u;
                     if (lane == wl) { // the class loses its head; the next one's record comes from LDS (nobody waits for it in this cycle)
-                        nfm -= 1, head += 1;
+                        nfm -= 1, head += 1, nleft -= 1;
                         if (track) cht -= w_cnt == cmt ? 1u : 0u, cha -= w_aff == cma ? 1u : 0u;
                         const uint4 r = L.ent[lane * LS + head]; // (member L of every class is the zero record)
                         key = ((uint64_t)r.y << 32) | r.x, hA1 = (int32_t)r.z, hmeta = r.w;
@@ -1019,7 +1044,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     if (NH > 1) { CW_PUT(hv1, n_hv1, tl); CW_PUT(hc1, n_hc1, tl); }
                     if (NK > 0) { CW_PUT(kv0, w_kv0, tl); CW_PUT(kf0, n_kf0, tl); CW_PUT(kn0, n_kn0, tl); CW_PUT(ke0, n_ke0, tl); }
                     if (NK > 1) { CW_PUT(kv1, w_kv1, tl); CW_PUT(kf1, n_kf1, tl); CW_PUT(kn1, n_kn1, tl); CW_PUT(ke1, n_ke1, tl); }
-                    CW_PUT(nfm, 1, tl); CW_PUT(cmt, w_cnt, tl); CW_PUT(cma, w_aff, tl); CW_PUT(cht, 1, tl); CW_PUT(cha, 1, tl);
+                    CW_PUT(nfm, dead ? 0 : 1, tl); CW_PUT(cmt, w_cnt, tl); CW_PUT(cma, w_aff, tl); CW_PUT(cht, 1, tl); CW_PUT(cha, 1, tl);
                     CW_PUT(hmeta, w_meta, tl); CW_PUT(tk, 1, tl);
                     const uint64_t nkey = make_key((int64_t)(dead ? 0 : A_next), g);
                     CW_PUT64(key, nkey, tl);
@@ -1048,6 +1073,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     CW_PUT(hmeta, rl32((int32_t)hmeta, last), wl); CW_PUT(tk, rl32((int32_t)tk, last), wl);
                     const uint64_t mk = rl64(key, last);
                     CW_PUT64(key, mk, wl);
+                    CW_PUT(nfm, 0, last); // (the vacated lane is no candidate)
                     ncand -= 1;
                 }
                 CW_PUT(mylog, (int32_t)g, cycles & 63);
@@ -1064,7 +1090,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     // class's own maximum lost its last holder; the maxima moved
                     const uint64_t okm = __ballot(ok);
                     bool stop = okm == 0ull;
-                    stop |= (__ballot(cls & ((key == 0ull) | (track & ((cht == 0) | (cha == 0))))) & okm) != 0ull;
+                    stop |= (__ballot(min(min(cht, cha), nleft) == 0u) & okm) != 0ull;
                     if (track) stop |= (int)((__ballot((cmt > mt_a) | (cma > ma_a)) & okm) != 0ull) | (int)((__ballot(cmt == mt_a) & okm) == 0ull) | (int)((__ballot(cma == ma_a) & okm) == 0ull);
                     go = !stop;
                 }

@@ -147,8 +147,25 @@ class _Result(C.Structure):
 def build(force: bool = False) -> str:
     so = os.path.join(HERE, "libccref.so")
     src = [os.path.join(HERE, f) for f in ("ccref.c", "ccref.h")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):
-        subprocess.check_call(["make", "-C", HERE, "-s", "libccref.so"])
+    stale = lambda: not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s))
+    if force or stale():
+        # one builder at a time, and the library appears under its name only when it is complete: pytest-xdist workers that find
+        # it stale together queue here, the first builds, the others find it fresh (none loads a file gcc is still writing)
+        import fcntl
+
+        with open(so + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or stale():
+                    tmp = "libccref.so.tmp.%d" % os.getpid()
+                    try:
+                        subprocess.check_call(["make", "-C", HERE, "-s", "-B", tmp, "OUT=" + tmp])
+                        os.replace(os.path.join(HERE, tmp), so)
+                    finally:
+                        if os.path.exists(os.path.join(HERE, tmp)):
+                            os.remove(os.path.join(HERE, tmp))
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return so
 
 
