@@ -83,6 +83,8 @@ struct CwWork {
     int32_t *node_A1;         // [n_pad] ... after ONE more clone of the template (-1: the node could not take a second one)
     unsigned long long *prof; // [16] k_cw_decide: 10 ns ticks per phase (measurement runs)
     unsigned long long *top;  // [blocks][kCwMaxClasses][L]
+    unsigned long long *top2; // [groups][kCwMaxClasses][L]: the lists of `merge_group` blocks merged (snapshots with more blocks than one merge stages)
+    int32_t merge_group;      // blocks one k_cw_merge workgroup merges (merge_group * L keys fit its LDS)
     unsigned long long *lists; // [kCwMaxClasses][L]
     unsigned long long *umin; // [blocks][kMaxTsc] unique-key hard constraints: (minimum << 32) | counted nodes at the minimum
     int32_t n_blocks;
@@ -448,19 +450,22 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
     }
 }
 
-// k_cw_merge: block id = class id, ONE wave.  The blocks' lists are sorted, so the class's L best are found by L rounds over the
-// blocks' current heads (keys staged in LDS; a wave needs no block barrier).
+// k_cw_merge: workgroup (class id, group g) merges the sorted lists of blocks [g * G, (g + 1) * G) of `src` into the class's L best
+// among them: L rounds over the lists' current heads (keys staged in LDS; the rounds are ONE wave, which needs no block barrier).
+// One launch when the snapshot's blocks fit one group (dst = the class lists); else two levels: groups -> CwWork::top2 -> lists
+// (G^2 blocks: 10 M nodes at L = 64).
 constexpr int kCwMergeThreads = 64;
-__global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a) {
+__global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a, const unsigned long long *__restrict__ src, int nb_all, int G, unsigned long long *__restrict__ dst) {
     if (a.st->done || a.st->cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    const int C = (int)a.w.ctl[kCwCtlClasses], id = blockIdx.x, L = a.list_len, nb = a.w.n_blocks;
+    const int C = (int)a.w.ctl[kCwCtlClasses], id = blockIdx.x, g = blockIdx.y, L = a.list_len;
     if (id >= C) return;
+    const int b_first = g * G, nb = (nb_all - b_first < G ? nb_all - b_first : G);
     __shared__ unsigned long long s_k[kCwMaxKeys];
     __shared__ uint8_t s_head[kCwMaxKeys];
     for (int q = threadIdx.x; q < nb * L; q += kCwThreads) { // staging: all four waves
         const int b = q / L, r = q % L;
-        s_k[q] = a.w.top[((size_t)b * kCwMaxClasses + id) * L + r];
+        s_k[q] = src[((size_t)(b_first + b) * kCwMaxClasses + id) * L + r];
     }
     for (int b = threadIdx.x; b < nb; b += kCwThreads) s_head[b] = 0;
     __syncthreads();
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
         }
-    if (lane < L) a.w.lists[(size_t)id * L + lane] = mine;
+    if (lane < L) dst[((size_t)g * kCwMaxClasses + id) * L + lane] = mine;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

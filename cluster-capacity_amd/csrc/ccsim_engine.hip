@@ -908,12 +908,16 @@ static int cw_make_plan(ccsim_engine *e) {
     pl.window = pl.window < 1 ? 1 : (pl.window > kCwFastWindow ? kCwFastWindow : pl.window); // (the general decide kernel clamps to its own kCwMaxWindow)
     pl.list_len = pl.list_len < 1 ? 1 : (pl.list_len > kCwMaxList ? kCwMaxList : pl.list_len);
     const int64_t blocks = (e->n_pad + kCwTile - 1) / kCwTile;
-    while (pl.list_len > 1 && blocks * pl.list_len > kCwMaxKeys) pl.list_len >>= 1;
-    if (blocks * pl.list_len > kCwMaxKeys) return no("snapshot too large for the class-list merge");
+    // the merge of the blocks' lists: one workgroup stages merge_group * L keys; more blocks than that take a second level
+    int64_t group = kCwMaxKeys / pl.list_len;
+    group = group > 2 * 64 ? 2 * 64 : group; // (a lane of the merging wave keeps the heads of two blocks in registers)
+    if (const char *f = getenv("CCSIM_CW_MERGE_GROUP")) group = atoi(f) >= 2 && atoi(f) < group ? atoi(f) : group; // test knob: two levels on small snapshots
+    while (pl.list_len > 1 && !getenv("CCSIM_CW_MERGE_GROUP") && (blocks + group - 1) / group > group) pl.list_len >>= 1, group = kCwMaxKeys / pl.list_len > 128 ? 128 : kCwMaxKeys / pl.list_len;
+    if ((blocks + group - 1) / group > group) return no("snapshot too large for the class-list merge");
     if (e->global_offset != 0 || e->n_global != e->n) return no("sharded snapshot");
     // work buffers: [keys | ready | ctl | classes] zeroed per run, the rest written before it is read
     CwWork w{};
-    w.n_blocks = (int)blocks;
+    w.n_blocks = (int)blocks, w.merge_group = (int)group;
     const size_t zb = sizeof(unsigned long long) * kCwSlots + sizeof(uint32_t) * kCwSlots + sizeof(uint32_t) * 16 + sizeof(CwClass) * kCwSlots;
     unsigned char *base = nullptr;
     int rc;
@@ -930,6 +934,7 @@ static int cw_make_plan(ccsim_engine *e) {
     if (getenv("CCSIM_CW_PROF") && atoi(getenv("CCSIM_CW_PROF")) && (rc = dev_alloc(e, &w.prof, (size_t)16, e->pod_allocs))) return rc; // measurement runs
     if ((rc = dev_alloc(e, &w.top, (size_t)blocks * kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs, false))) return rc;
     if ((rc = dev_alloc(e, &w.lists, (size_t)kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs))) return rc;
+    if (blocks > group && (rc = dev_alloc(e, &w.top2, (size_t)((blocks + group - 1) / group) * kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs, false))) return rc;
     if ((rc = dev_alloc(e, &w.umin, (size_t)blocks * kMaxTsc, e->pod_allocs))) return rc;
     unsigned char *argbuf = nullptr;
     if ((rc = dev_alloc(e, &argbuf, sizeof(CwDecideArgs), e->pod_allocs))) return rc;
@@ -1440,7 +1445,12 @@ static void launch_cw_window(ccsim_engine *e) {
     else hipLaunchKernelGGL((k_cw_scan<kMaxExtra, false>), g, b, 0, e->stream, sa);
     const CwTopArgs ta{e->cols, e->d_state, e->cw_work, e->cw_plan.list_len};
     hipLaunchKernelGGL(k_cw_top, g, b, 0, e->stream, ta);
-    hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses), b, 0, e->stream, ta);
+    const int G = e->cw_work.merge_group, groups = (e->cw_work.n_blocks + G - 1) / G;
+    if (groups == 1) hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, 1), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top, e->cw_work.n_blocks, G, e->cw_work.lists);
+    else {
+        hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, groups), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top, e->cw_work.n_blocks, G, e->cw_work.top2);
+        hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, 1), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top2, groups, G, e->cw_work.lists);
+    }
     // lane = candidate form first (it declines, untouched, whatever it does not cover); the general form right behind it
     if (e->cw_fast) { // (the pod's shape picks the instantiation: bit c of HU / bit k of KU = unique-per-node key)
         const int hu = (e->pts.n > 0 && e->cw_plan.h_unique[0] ? 1 : 0) | (e->pts.n > 1 && e->cw_plan.h_unique[1] ? 2 : 0);

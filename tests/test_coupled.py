@@ -124,6 +124,21 @@ def test_c5_shape_single_template_windows_do_the_work(ccref, monkeypatch, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("group", [2, 5])
+def test_class_lists_merged_in_two_levels(ccref, monkeypatch, group):
+    """Snapshots with more node blocks than one merge workgroup stages (about 100k nodes at L = 64) merge the blocks' class lists in
+    two levels (k_cw_merge: groups of blocks, then the groups).  CCSIM_CW_MERGE_GROUP forces the same on small snapshots."""
+    monkeypatch.setenv("CCSIM_CW_MERGE_GROUP", str(group))
+    n = 1024 * group * group - 300  # (kCwTile nodes per block: group^2 blocks, the last one ragged)
+    nodes, pod, prof = c5_single_template(n)
+    got, info = _run(ccref, nodes, pod, prof, 700, monkeypatch, 64, 16)
+    assert info["windows"] * 8 < got.placed, info
+    rng = np.random.default_rng(4242 + group)
+    nodes, pod, prof = coupled_case(rng, n, roomy=True)
+    _run(ccref, nodes, pod, prof, 900, monkeypatch, 64, 8, expect_plan=False)
+
+
+@pytest.mark.gpu
 def test_falls_back_exactly_when_the_classes_do_not_fit(ccref, monkeypatch):
     """More classes than the windowed mode represents (a soft hostname constraint over nodes with many different existing counts x
     zones): DevState::cw_fallback, the run continues one pass per placement -- same answer."""
