@@ -152,8 +152,11 @@ def main():
         eng.load(nodes, pod, prof)
 
         def step(mode, lim):
+            # the per-node counts are delivered into the engine's page-locked result array, reused from step to step (include/ccsim.h
+            # ccsim_host_alloc): a fresh pageable array per step costs 0.18 ms of page faults and staging at 1M nodes
+            # (profiles/r03/step_breakdown.txt), which is the caller's allocation policy and not the simulation
             eng.reset_state()
-            return eng.run(max_limit=lim, mode=mode, want_log=False)
+            return eng.run(max_limit=lim, mode=mode, want_log=False, reuse_buffers=True)
 
     for _ in range(args.warmup):
         step(args.mode, limit)
@@ -166,6 +169,8 @@ def main():
         scans += r.scans
     barrier()
     dt = time.perf_counter() - t0
+    if not distributed:
+        r.per_node_count = r.per_node_count.copy()  # (a view of the reused result array until here: later runs of the engine overwrite it)
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,8 +189,8 @@ def main():
     # Roofline.  The dominant kernel of the batched mode is the persistent level kernel k_level_persist (csrc/ccsim_persist.h:
     # one launch per simulation; it reads the narrow node columns once, keeps them in LDS, and writes the state back at
     # the end), of the sequential mode k_scan.  Duration: HIP events around the launch on the engine's stream
-    # (ccsim_report.kernel_ns of the LAST timed step; rocprofv3 --kernel-trace --stats of this command, profiles/r02/,
-    # reports the same average).  `achieved` = HBM bytes the launch really moves (rocprofv3 PMC, profiles/r02/pmc_traffic.json,
+    # (ccsim_report.kernel_ns of the LAST timed step; rocprofv3 --kernel-trace --stats of this command, profiles/r03/,
+    # reports the same average).  `achieved` = HBM bytes the launch really moves (rocprofv3 PMC, profiles/r03/pmc_traffic.json,
     # accepted only if it was collected with THIS libccsim.so) / duration: a physical rate.  The persistent kernel is not
     # HBM-bound -- it is bound by its grid-wide syncs (syncs x (barrier latency + the run-downs of the slowest workgroup)) --
     # so the fraction is small by design; `sync_bound` carries that model.  The work the reference semantics imply
@@ -196,15 +201,15 @@ def main():
     persistent = args.mode == "batched" and not distributed and os.environ.get("CCSIM_PERSIST", "1") != "0"
     kernel = "k_level_persist" if persistent else ("k_level_commit" if args.mode == "batched" else "k_scan")
     sha = lib_sha16()
-    pmc, pmc_note = {}, "no profiles/r02/pmc_traffic.json for this workload"
+    pmc, pmc_note = {}, "no profiles/r03/pmc_traffic.json for this workload"
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")))
         if hi - lo != 1_000_000:
             pmc_note = "PMC traffic was collected at 1,000,000 nodes per GPU"
         elif pj.get("lib_sha16") != sha and pj.get("src_sha16") != src_sha16():  # (the binary embeds its build path: the sources decide)
             pmc_note = f"stale: collected with libccsim.so {pj.get('lib_sha16')} / sources {pj.get('src_sha16')}, this run uses {sha} / {src_sha16()}"
         else:
-            pmc, pmc_note = pj["kernels"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so (profiles/r02/pmc_traffic.json)"
+            pmc, pmc_note = pj["kernels"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so (profiles/r03/pmc_traffic.json)"
     except (OSError, KeyError, ValueError):
         pass
     roofline = None

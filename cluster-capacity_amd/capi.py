@@ -130,6 +130,8 @@ SYMBOLS = {
     "ccsim_dist_sync_tables": (C.c_int, [C.c_void_p]),
     "ccsim_dist_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
     "ccsim_reset_state": (C.c_int, [C.c_void_p]),
+    "ccsim_host_alloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "ccsim_host_free": (None, [C.c_void_p, C.c_void_p]),
     "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ccsim_debug_persist_prof": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_multi_stops": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
@@ -358,6 +360,7 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            self._free_pinned()
             self.lib.ccsim_destroy(self.h)
             self.h = None
 
@@ -404,9 +407,28 @@ class Engine:
         self._chk(self.lib.ccsim_schedule_pod(self.h, int(pod_idx), C.byref(cyc)), "ccsim_schedule_pod")
         return int(cyc.node), int(cyc.evaluated_nodes), int(cyc.feasible_nodes)
 
-    def _report(self, want_log: bool, log_cap: int):
+    def _pinned_per_node(self):
+        """One page-locked int32[n] per engine (ccsim_host_alloc), reused by every run(reuse_buffers=True)."""
+        n = max(1, self.n)
+        buf = getattr(self, "_pin_per_node", None)
+        if buf is None or buf[1].shape[0] != n:
+            self._free_pinned()
+            ptr = self.lib.ccsim_host_alloc(self.h, n * 4)
+            if not ptr:
+                raise MemoryError("ccsim_host_alloc failed")
+            arr = np.ctypeslib.as_array((C.c_int32 * n).from_address(ptr))
+            self._pin_per_node = buf = (ptr, arr)
+        return buf[1]
+
+    def _free_pinned(self):
+        buf = getattr(self, "_pin_per_node", None)
+        if buf is not None and self.h:
+            self.lib.ccsim_host_free(self.h, buf[0])
+        self._pin_per_node = None
+
+    def _report(self, want_log: bool, log_cap: int, reuse_buffers: bool = False):
         rep = CReport()
-        per_node = np.zeros(max(1, self.n), np.int32)
+        per_node = self._pinned_per_node() if reuse_buffers else np.zeros(max(1, self.n), np.int32)
         rep.per_node_count = _ptr(per_node, _p32)
         rep.per_node_cap = per_node.shape[0]
         log = None
@@ -423,9 +445,9 @@ class Engine:
         rep.stop_spec = -1
         return rep, per_node, log, ht
 
-    def _result(self, rep, per_node, log, ht) -> M.RunResult:
+    def _result(self, rep, per_node, log, ht, reuse_buffers: bool = False) -> M.RunResult:
         return M.RunResult(
-            placed=int(rep.placed), stop=int(rep.stop), per_node_count=per_node[: self.n].copy(),
+            placed=int(rep.placed), stop=int(rep.stop), per_node_count=per_node[: self.n] if reuse_buffers else per_node[: self.n].copy(),
             log=log[: int(rep.log_len)].copy() if log is not None else None,
             hist=np.array(list(rep.hist), dtype=np.int64), hist_taintset=ht.copy(),
             n_code_unschedulable=int(rep.n_code_unschedulable), rounds=int(rep.rounds),
@@ -434,12 +456,15 @@ class Engine:
             per_spec_count=self._per_spec[: self.n_pods].copy(), stop_spec=int(rep.stop_spec),
         )
 
-    def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None) -> M.RunResult:
+    def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None,
+            reuse_buffers: bool = False) -> M.RunResult:
+        """`reuse_buffers`: the per-node counts land in the engine's page-locked result array (ccsim_host_alloc) and the result
+        holds a VIEW of it, valid until the next run -- what a caller that simulates repeatedly does with its own arrays."""
         if log_cap is None:
             log_cap = max_limit if max_limit > 0 else 1 << 22
-        rep, per_node, log, ht = self._report(want_log, log_cap)
+        rep, per_node, log, ht = self._report(want_log, log_cap, reuse_buffers)
         self._chk(self.lib.ccsim_run(self.h, int(max_limit), MODES[mode], C.byref(rep)), "ccsim_run")
-        return self._result(rep, per_node, log, ht)
+        return self._result(rep, per_node, log, ht, reuse_buffers)
 
     def schedule_one(self):
         cyc = CCycle()

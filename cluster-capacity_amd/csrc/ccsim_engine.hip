@@ -1366,7 +1366,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     return 0;
 }
 
-// The persistent form of the batched mode (ccsim_persist.h): narrow mirrors, one 1024-thread workgroup per CU with up to
+// The persistent form of the batched mode (ccsim_persist.h): narrow mirrors, one 512-thread workgroup (kPThreads) per CU with up to
 // 4096 nodes each in LDS, scores and pod counts in 16 bits.  Everything else takes the multi-kernel path.
 static int persist_k(const ccsim_engine *e) {
     if (!e->persist_allowed || !e->cols.narrow || e->pod.nx != 0 || e->n_ranks != 0 || e->n_cus <= 0 || e->n <= 0) return 0;
@@ -1745,6 +1745,18 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
     }
     e->begun = false;
     return 0;
+}
+
+extern "C" void *ccsim_host_alloc(ccsim_engine *e, size_t bytes) {
+    if (!e || bytes == 0) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(e->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    memset(p, 0, bytes);
+    return p;
+}
+extern "C" void ccsim_host_free(ccsim_engine *e, void *p) {
+    if (!e || !p) return;
+    if (hipSetDevice(e->device) == hipSuccess) (void)hipHostFree(p);
 }
 
 // measurement aid: s_memtime ticks (100 MHz) workgroup 0 of the last persistent launch spent per phase

@@ -23,6 +23,7 @@
  */
 #ifndef CCSIM_H
 #define CCSIM_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -352,6 +353,15 @@ int ccsim_dist_tables_done(ccsim_engine *e);
  * device-to-device from pristine copies kept in HBM: the next ccsim_run starts from the same cluster
  * (what a fresh framework.New + SyncWithClient would give, simulator.go:107-295) without a host upload. */
 int ccsim_reset_state(ccsim_engine *e);
+
+/* Page-locked host memory for the result arrays of ccsim_report (per_node_count, log, hist_taintset).  Optional -- any host
+ * pointer is accepted there -- but a device-to-host copy into ordinary (pageable) memory is staged by the runtime and, into pages
+ * that were never touched, takes a page fault per 4 KiB: at 1M nodes the 4 MB of per-node counts cost more than the simulation
+ * itself ("what a step costs around the kernel").  A caller that runs many simulations allocates its result
+ * arrays here once and reuses them (cgo: C memory wrapped with unsafe.Slice).  The device is the engine's.  ccsim_host_alloc
+ * returns NULL on failure; ccsim_host_free(NULL) is a no-op. */
+void *ccsim_host_alloc(ccsim_engine *e, size_t bytes);
+void ccsim_host_free(ccsim_engine *e, void *p);
 
 /* Measurement aid (bench.py roofline): time `iters` back-to-back launches of the dominant kernel of
  * `mode` (the full pods x nodes pass: k_scan or k_level_score) with HIP events on the engine's stream;

@@ -278,6 +278,8 @@ int ccsim_dist_table(ccsim_engine *e, int32_t idx, void **ptr, int64_t *len, int
 }
 int ccsim_dist_tables_done(ccsim_engine *e) { (void)e; return 0; }
 int ccsim_reset_state(ccsim_engine *e) { (void)e; return -38; }
+void *ccsim_host_alloc(ccsim_engine *e, size_t bytes) { (void)e; return calloc(1, bytes); }
+void ccsim_host_free(ccsim_engine *e, void *p) { (void)e; free(p); }
 int ccsim_time_scan(ccsim_engine *e, int32_t a, int32_t b, int64_t *c, int64_t *d) { (void)e, (void)a, (void)b, (void)c, (void)d; return -38; }
 int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }

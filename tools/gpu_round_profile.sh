@@ -1,27 +1,45 @@
 #!/bin/bash
-# round-end evidence: the bench line, rocprofv3 kernel stats of the same command, PMC traffic (separate passes), the
-# barrier micro-benchmark.  Everything lands in gpurun_out/r02/ ; copy what is to be judged into profiles/r02/.
+# round-end evidence on the FINAL library: the whole -m gpu suite, the bench line, rocprofv3 kernel stats of the same command,
+# PMC traffic (separate passes), the sequential cycle, the coupled windowed mode, config 5, the sharded protocol at one rank,
+# smoke().  Everything lands in gpurun_out/$R/ ; copy what is to be judged into profiles/$R/.
+#   tools/gpu_round_profile.sh [round tag, default r03] [skip-suite]
 exec < /dev/null
+R=${1:-r03}
 cd /root/repo
-O=/root/repo/gpurun_out/r02
+O=/root/repo/gpurun_out/$R
 mkdir -p $O
-timeout 200 python -m pytest tests/test_multi.py tests/test_golden.py tests/test_ports_images.py tests/test_dist_rccl.py -m gpu -q -rf 2>&1 | tail -5 | tee $O/quick_tests.txt
-# PMC traffic first (separate rocprofv3 passes, --kernel-trace only): bench.py accepts profiles/r02/pmc_traffic.json only if it
-# was collected with the libccsim.so it runs
-bash tools/gpu_pmc.sh r02 "FETCH_SIZE" "WRITE_SIZE" 2>&1 | tail -12
-cp gpurun_out/pmc_traffic_r02.json $O/pmc_traffic.json 2>/dev/null && cp gpurun_out/pmc_traffic_r02.json profiles/r02/pmc_traffic.json
-rm -rf gpurun_out/pmc_r02_1 gpurun_out/pmc_r02_2
+python - > $O/lib_hash.txt <<'PY'
+import hashlib, sys
+sys.path.insert(0, ".")
+import __graft_entry__ as ge
+ge.load_package()
+from cluster_capacity_amd import build as b
+print("libccsim.so sha256[:16]", hashlib.sha256(open(b.lib_path(), "rb").read()).hexdigest()[:16], "| sources + flags sha256[:16]", b.source_sha16())
+PY
+cat $O/lib_hash.txt
+if [ "$2" != "skip-suite" ]; then
+  ( cat $O/lib_hash.txt; echo "python -m pytest tests -m gpu -q -n 4 --timeout 900 (the driver's command is the same without -n)"; \
+    timeout 1500 python -m pytest tests -m gpu -q -n 4 --timeout 900 --durations=8 2>&1 | grep -v "amdgpu.ids" | tail -25 ) | tee $O/gpu_tests.txt | tail -6
+fi
+# PMC traffic (separate rocprofv3 passes, --kernel-trace only): bench.py accepts profiles/$R/pmc_traffic.json only if it was
+# collected with the sources it runs
+bash tools/gpu_pmc.sh $R "FETCH_SIZE" "WRITE_SIZE" 2>&1 | tail -14
+cp gpurun_out/pmc_traffic_$R.json $O/pmc_traffic.json 2>/dev/null && cp gpurun_out/pmc_traffic_$R.json profiles/$R/pmc_traffic.json
+rm -rf gpurun_out/pmc_${R}_1 gpurun_out/pmc_${R}_2
 cd /root/repo
-timeout 400 python bench.py > $O/bench_1M.json 2> $O/bench_1M.err; tail -c 400 $O/bench_1M.json; echo
+timeout 400 python bench.py > $O/bench_1M.json 2> $O/bench_1M.err; tail -c 300 $O/bench_1M.json; echo
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/ks
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python /root/repo/bench.py --no-cpu --no-variants --seq-rounds 0 > $O/bench_1M_under_rocprofv3.json 2> $O/ks.err
-f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_1M_kernel_stats.csv && cut -c1-200 $O/bench_1M_kernel_stats.csv | head -12
-cd /root/repo
+f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/bench_1M_kernel_stats.csv && cut -c1-200 $O/bench_1M_kernel_stats.csv | head -8
 rm -rf $O/ks
-# config 5 (1024 pod specs): throughput line + per-kernel time
+# the sequential cycle (one dispatch: k_scan_fused)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python /root/repo/bench.py --mode sequential --no-cpu --no-variants --no-roofline --steps 3 > $O/bench_seq_1M.json 2> $O/ks.err
+f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/seq_1M_kernel_stats.csv && cut -c1-200 $O/seq_1M_kernel_stats.csv | head -5
+rm -rf $O/ks
+cd /root/repo
+# config 5 (1024 pod specs): throughput line
 timeout 300 python tools/bench_c5.py 100000 1024 200000 64 2>&1 | grep -v amdgpu.ids | tee $O/bench_c5.txt | cut -c1-300
-bash tools/gpu_c5_prof.sh > /dev/null 2>&1; cp gpurun_out/c5_kernel_stats.csv $O/c5_kernel_stats.csv 2>/dev/null
-timeout 120 python tools/persist_prof.py 1000000 8 1,16,64 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-250
-CCSIM_FORCE_DIST=1 timeout 120 python bench.py --no-variants --no-cpu --seq-rounds 0 --steps 3 2>/dev/null > $O/bench_dist_world1.json; cut -c1-200 $O/bench_dist_world1.json
+timeout 120 python tools/persist_prof.py 1000000 4 384 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-250
+CCSIM_FORCE_DIST=1 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>/dev/null > $O/bench_dist_world1.json; cut -c1-200 $O/bench_dist_world1.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/smoke.txt
