@@ -18,8 +18,8 @@ print("libccsim.so sha256[:16]", hashlib.sha256(open(b.lib_path(), "rb").read())
 PY
 cat $O/lib_hash.txt
 if [ "$2" != "skip-suite" ]; then
-  ( cat $O/lib_hash.txt; echo "python -m pytest tests -m gpu -q -n 4 --timeout 900 (the driver's command is the same without -n)"; \
-    timeout 1500 python -m pytest tests -m gpu -q -n 4 --timeout 900 --durations=8 2>&1 | grep -v "amdgpu.ids" | tail -25 ) | tee $O/gpu_tests.txt | tail -6
+  ( cat $O/lib_hash.txt; echo "python -m pytest tests -m gpu -q --timeout 900"; \
+    timeout 1500 python -m pytest tests -m gpu -q --timeout 900 --durations=8 2>&1 | grep -v "amdgpu.ids" | tail -25 ) | tee $O/gpu_tests.txt | tail -6
 fi
 # PMC traffic (separate rocprofv3 passes, --kernel-trace only): bench.py accepts profiles/$R/pmc_traffic.json only if it was
 # collected with the sources it runs
