@@ -1152,9 +1152,14 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     // sampled search with K = 1 -- the first feasible node of the rotating visiting order wins, the search stops at the second
     const int64_t k_find = profile_has_scoring(e->prof) ? num_feasible_nodes_to_find(e->prof.percentage_of_nodes_to_score, e->n_global) : 1;
     const int64_t smp_K = k_find < e->n_global ? k_find : 0;
-    if (smp_K > 0 && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
+    if (smp_K > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "percentageOfNodesToScore < 100 (here: the first %lld feasible nodes of %lld) makes the outcome depend on the "
-                                "visiting order: sequential mode on one GPU only", (long long)smp_K, (long long)e->n_global);
+                                "visiting order: sequential mode only", (long long)smp_K, (long long)e->n_global);
+    // on shards the sampled search is two exchanges per cycle (counts, then the max-loc: DevState::smp_phase); pods with
+    // topology-coupled plugins would need their Filter on the selected nodes only -- not in that protocol
+    if (smp_K > 0 && e->n_ranks > 0 && (e->pts.n > 0 || e->ipa.on || e->soft.n > 0))
+        return fail(e, -ENOSYS, "percentageOfNodesToScore < 100 on several GPUs with topology spread constraints or inter-pod affinity: "
+                                "one GPU only, for now");
     if (smp_K != e->smp_K) drop_graph(e);
     e->smp_K = smp_K;
     if (mode == CCSIM_MODE_BATCHED && !e->pod.fit_enabled)
@@ -1178,6 +1183,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     }
     st.smp_K = e->smp_K;
     st.smp_start = e->smp_K > 0 ? e->smp_start_cur % (e->n_global > 0 ? e->n_global : 1) : 0;
+    st.smp_N = e->n_global, st.smp_off = 0, st.smp_phase = 0, st.smp_rank = e->n_ranks > 0 ? e->rank : 0;
     st.ipa_aff_total = e->ipa_aff_total_cur, st.ipa_exist_total = e->ipa_exist_total_cur, st.ipa_entries = e->ipa_entries_cur;
     for (int c = 0; c < kMaxTsc; c++) st.soft_size_a[c] = -1; // unknown: the first scan derives sizes and weights
     st.soft_min_a = INT64_MAX, st.soft_max_a = 0;

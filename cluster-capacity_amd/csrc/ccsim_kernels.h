@@ -207,6 +207,15 @@ struct DevState {
     int64_t smp_Ftotal;      // feasible nodes of the whole snapshot (this cycle)
     int64_t smp_stop;        // rotated position of the (K+1)-th feasible node = nodes visited; -1: all N were visited
     int64_t evaluated;       // sum of visited nodes over the cycles
+    // ... on node-range SHARDS (n_ranks > 0; tests/sharded_sampled_model.py): a cycle is two exchanges.  Phase 0: every shard
+    // counts its feasible nodes (all / those before the start index), the gathered counts give the cluster totals and the number
+    // of feasible nodes in the shards before this one -- with that offset the rank-in-visiting-order formula of the scoring pass
+    // holds unchanged.  Phase 1: the scoring pass on the selected nodes, max-loc exchange, decision (normalization maxima over
+    // the selected nodes: assumed, verified on the gathered records, the scoring pass redone if they moved).
+    int64_t smp_N;           // nodes of the whole snapshot (the visiting order wraps around at it)
+    int64_t smp_off;         // feasible nodes in the shards before this one (this cycle)
+    int32_t smp_phase;       // sharded runs: 0 = the next pass counts, 1 = the next pass scores
+    int32_t smp_rank;        // this shard's rank
     // multi-kernel batched mode: several score levels per pass, committed blindly and validated afterwards (ccsim_level.h)
     int64_t lvl_Lo;          // the pending commit takes every node scoring >= lvl_Lo down to < lvl_Lo (== lvl_M: one level)
     int64_t prev_nfeas, prev_c_mt, prev_c_ma; // this shard's counts before the pending blind batch (restored by a roll-back)
@@ -240,7 +249,8 @@ struct XRec {
     int64_t win_elig;   // PodTopologySpread eligibility bits of the node
     int32_t win_pts_v[kMaxTsc];
     int32_t win_ipa_v[4];
-    int64_t pad[2];
+    int64_t pad[2];     // sampled search on shards: counting pass [0] feasible nodes of the shard, [1] those before the start index;
+                        // scoring pass [0] visiting position of the node that cancels the search (-1: not this shard's)
 };
 static_assert(sizeof(XRec) == 32 * 8, "XRec must be CCSIM_XCHG_WORDS int64");
 
@@ -808,8 +818,9 @@ template <int NX, bool PTS, bool NARROW = false, int SMP = 0>
 __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     const DevState st = *a.st;
     if (st.done) return;
-    const int64_t smp_S = st.smp_start, smp_N = a.c.n;
-    int64_t smp_carry = SMP == 2 ? a.smp_prefix[blockIdx.x] : 0; // feasible nodes before the current tile (index order)
+    if (SMP != 0 && a.n_ranks > 0 && st.smp_phase != (SMP == 1 ? 0 : 1)) return; // sharded: this pass belongs to the other phase
+    const int64_t smp_S = st.smp_start, smp_N = st.smp_N;
+    int64_t smp_carry = SMP == 2 ? a.smp_prefix[blockIdx.x] + st.smp_off : 0; // feasible nodes before the current tile (index order, all shards)
     uint32_t smp_cnt = 0, smp_before = 0;
     int smp_par = 0;
     __shared__ uint32_t s_smp[2][kThreads / 64];
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
         }
         if (SMP == 1) { // counting pass: no scores
             smp_cnt += (uint32_t)fe[0] + (uint32_t)fe[1];
-            smp_before += (uint32_t)(fe[0] && i0 < smp_S) + (uint32_t)(fe[1] && i0 + 1 < smp_S);
+            smp_before += (uint32_t)(fe[0] && a.c.global_offset + i0 < smp_S) + (uint32_t)(fe[1] && a.c.global_offset + i0 + 1 < smp_S);
             continue;
         }
         int64_t vpos[2] = {a.c.global_offset + i0, a.c.global_offset + i0 + 1}; // tie-break position of the node
@@ -920,7 +931,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
             const int64_t f0 = fe[0];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const int64_t gi = i0 + k, F = F0 + (k ? f0 : 0);
+                const int64_t gi = a.c.global_offset + i0 + k, F = F0 + (k ? f0 : 0);
                 const int64_t rank = gi >= smp_S ? F - st.smp_Fs : F + st.smp_Ftotal - st.smp_Fs;
                 vpos[k] = gi >= smp_S ? gi - smp_S : gi + smp_N - smp_S;
                 if (fe[k] && rank == st.smp_K) a.st->smp_stop = vpos[k]; // the node that cancels the search (:655-662)
@@ -1079,6 +1090,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
 // per-block feasible counts (index order), the snapshot total and F(start).
 __global__ __launch_bounds__(kThreads) void k_smp_prefix(ScanArgs a) {
     if (a.st->done) return;
+    if (a.n_ranks > 0 && a.st->smp_phase != 0) return; // sharded: a scoring pass
     const int tid = threadIdx.x, n = a.n_partials;
     const int per = (n + kThreads - 1) / kThreads;
     const int lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
@@ -1147,14 +1159,15 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
         return;
     }
     const bool smp = st.smp_K > 0;
+    const int64_t N = smp ? st.smp_N : a.c.n; // (the sampled search wraps around at the cluster's node count; `evaluated` is only reported for it)
     // a finished sampled cycle moves nextStartNodeIndex past the nodes it visited (schedule_one.go:538-539)
     const bool smp_all = !smp || st.smp_Ftotal <= st.smp_K; // the search visited every node
     if (key == 0) {
         st.done = DONE_UNSCHEDULABLE;
         st.rounds += 1;
         st.last_feasible = 0;
-        st.last_evaluated = (int32_t)a.c.n; // no feasible node: every node was visited
-        st.evaluated += a.c.n;
+        st.last_evaluated = (int32_t)N; // no feasible node: every node was visited
+        st.evaluated += N;
     } else if ((int32_t)mt != st.mt_a || (int32_t)ma != st.ma_a) {
         st.mt_a = (int32_t)mt;
         st.ma_a = (int32_t)ma;
@@ -1177,12 +1190,12 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
         st.ipa_max_a = ipa_mx;
     } else {
         int64_t g = key_index(key);
-        const int64_t visited = smp_all ? a.c.n : st.smp_stop;
+        const int64_t visited = smp_all ? N : st.smp_stop;
         if (smp) { // the key carries the visiting position
             g += st.smp_start;
-            g = g >= a.c.n ? g - a.c.n : g;
+            g = g >= N ? g - N : g;
             st.smp_start += visited; // both terms are <= N
-            st.smp_start = st.smp_start >= a.c.n ? st.smp_start - a.c.n : st.smp_start;
+            st.smp_start = st.smp_start >= N ? st.smp_start - N : st.smp_start;
             st.evaluated += visited;
         }
         st.last_evaluated = (int32_t)visited;
@@ -1252,6 +1265,14 @@ template <class A>
 __device__ void final_body(const A &a) {
     if (a.st->done) return;
     const int tid = threadIdx.x;
+    if (a.n_ranks > 0 && a.st->smp_K > 0 && a.st->smp_phase == 0) { // sharded sampled search, counting pass: this shard's two counts
+        if (tid == 0) {
+            XRec r{};
+            r.pad[0] = a.st->smp_Ftotal, r.pad[1] = a.st->smp_Fs; // (k_smp_prefix: over this shard's nodes)
+            *a.xsend = r;
+        }
+        return;
+    }
     uint64_t key = 0;
     uint32_t mt = 0, ma = 0;
     int64_t nf = 0;
@@ -1383,6 +1404,7 @@ __device__ void final_body(const A &a) {
         for (int c = 0; c < kMaxTsc; c++) r.pts_min[c] = c < a.pts.n ? pts_min[c] : 0x7fffffff;
         r.ipa_mn = a.ipa.on ? ipa_mn : INT64_MAX;
         r.ipa_mx = a.ipa.on ? ipa_mx : INT64_MIN;
+        r.pad[0] = a.st->smp_K > 0 ? a.st->smp_stop : -1; // sampled search: the cancelling node's visiting position, if this shard owns it
         if (key && (a.pts.n || a.ipa.on)) { // topology value ids of this shard's best node
             const int64_t i = key_index(key) - a.c.global_offset;
             r.win_elig = a.pts.n ? a.pts.elig[i] : 0;
@@ -1403,6 +1425,30 @@ __global__ __launch_bounds__(kThreads) void k_final(ScanArgs a) { final_body(a);
 __global__ void k_decide(ScanArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (a.st->done) return;
+    const bool smp = a.st->smp_K > 0;
+    if (smp && a.st->smp_phase == 0) { // sampled search, after the counting pass: the cluster's totals and this shard's offset
+        int64_t total = 0, before = 0, off = 0;
+        for (int r = 0; r < a.n_ranks; r++) {
+            const XRec &q = a.xrecv[r];
+            off += r < a.st->smp_rank ? q.pad[0] : 0;
+            total += q.pad[0], before += q.pad[1];
+        }
+        DevState &st = *a.st;
+        st.scans += 1;
+        st.smp_Ftotal = total, st.smp_Fs = before, st.smp_off = off, st.smp_stop = -1;
+        if (total == 0) { // no feasible node anywhere: FitError (schedule_one.go:448-454); every node was visited
+            st.done = DONE_UNSCHEDULABLE, st.rounds += 1, st.winner = -1;
+            st.last_feasible = 0, st.last_evaluated = (int32_t)st.smp_N, st.evaluated += st.smp_N;
+        } else
+            st.smp_phase = 1;
+        return;
+    }
+    const int64_t rounds_before = a.st->rounds;
+    if (smp) { // the cancelling node's position travels with its owner's record
+        int64_t stop = -1;
+        for (int r = 0; r < a.n_ranks; r++) stop = a.xrecv[r].pad[0] > stop ? a.xrecv[r].pad[0] : stop;
+        a.st->smp_stop = stop;
+    }
     uint64_t key = 0;
     uint32_t mt = 0, ma = 0;
     int64_t nf = 0, ipa_mn = INT64_MAX, ipa_mx = INT64_MIN;
@@ -1428,6 +1474,7 @@ __global__ void k_decide(ScanArgs a) {
         for (int k = 0; k < 4; k++) wt.ipa_v[k] = q.win_ipa_v[k];
     }
     decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, nullptr, coupled ? &wt : nullptr);
+    if (smp && (a.st->rounds != rounds_before || a.st->done)) a.st->smp_phase = 0; // the cycle ended (a stale maximum repeats the scoring pass only)
 }
 
 // ------------------------------------------------------------------------------------------------

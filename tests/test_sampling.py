@@ -112,8 +112,57 @@ def test_sampled_search_continues_across_runs(ccref):
     assert np.array_equal(c.log, ref.log)
 
 
+def _check_sharded(ccref, nodes, pod, prof, limit, world):
+    """The sampled search on `world` node-range shards (two exchanges per cycle: counts, then the max-loc; DevState::smp_phase),
+    driven shard by shard on one GPU: same log, same stop, same nodes visited cycle by cycle as the oracle's visiting loop."""
+    from test_gpu_parity import _LocalShards
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    res, log = _LocalShards(nodes, pod, prof, world).run(limit, "sequential", max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res), ([(r.placed, r.stop) for r in res], ref.placed, ref.stop)
+    assert np.array_equal(log[: ref.placed], ref.log)
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    assert all(r.evaluated_total == ref.evaluated_total for r in res), ([r.evaluated_total for r in res], ref.evaluated_total)
+    assert all(r.last_feasible == ref.last_feasible for r in res)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
+    return res, ref
+
+
 @pytest.mark.gpu
-def test_sampled_search_is_sequential_single_gpu_only(ccref):
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+@pytest.mark.parametrize("cfg,n,pct,limit", [("C3", 1000, 0, 0), ("C3", 1000, 0, 300), ("C2", 5000, 10, 400), ("C3", 300, 50, 0),
+                                             ("C3", 777, 35, 0), ("C2", 2049, 0, 1000), ("C3", 100, 0, 0)])
+def test_sampled_search_on_shards_vs_oracle(ccref, world, cfg, n, pct, limit):
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
+    res, ref = _check_sharded(ccref, nodes, pod, _with_pct(prof, pct), limit, world)
+    if ccref.num_feasible_nodes_to_find(pct, n) < n:
+        assert res[0].evaluated_total < (ref.placed + 1) * n  # the search really stopped early
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_sampled_search_on_shards_random_plugin_mix(ccref, seed):
+    rng = np.random.default_rng(3300 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(100, 1500)))
+    prof = _with_pct(prof, int(rng.choice([0, 10, 35, 70, 99])))
+    _check_sharded(ccref, nodes, pod, prof, int(rng.choice([0, 0, 37, 500])), int(rng.integers(1, 6)))
+
+
+@pytest.mark.gpu
+def test_sampled_search_on_shards_k1_and_refusals(ccref):
+    # a profile without Score plugins keeps the first feasible node of the visiting order (K = 1) -- on shards too
+    nodes, pod, prof = synth.make_config("C3", n_nodes=1500, seed=31)
+    bare = dataclasses.replace(prof, w_taint=0, w_nodeaffinity=0, w_fit=0, w_balanced=0, w_imagelocality=0, w_topologyspread=0, w_interpodaffinity=0)
+    _check_sharded(ccref, nodes, pod, bare, 700, 3)
+    # topology-coupled plugins are not part of the sharded sampled protocol: refused, not approximated
+    from test_gpu_parity import _LocalShards
+    pod.spread = [synth.zone_spread(1500, max_skew=2)]
+    with pytest.raises(capi.CcsimError):
+        _LocalShards(nodes, pod, _with_pct(prof, 0), 2).run(50, "sequential", 50)
+
+
+@pytest.mark.gpu
+def test_sampled_search_is_sequential_only(ccref):
     nodes, pod, prof = synth.make_config("C3", n_nodes=500, seed=13)
     e = capi.Engine(device=0)
     e.load(nodes, pod, _with_pct(prof, 0))
