@@ -733,6 +733,8 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             e->pts = pt;
             if ((rc = dev_alloc(e, &e->d_pts_min_partials, (size_t)kMaxGrid * kMaxTsc, e->pod_allocs))) return rc;
         } else {
+            for (size_t j = 0; j < idx.size(); j++) // replicated across ranks like the hard constraints' (counts add)
+                e->dist_tables.push_back({pt.tbl[j], (int64_t)e->pts_table_len[first + j], 4, 0});
             e->soft.n = pt.n, e->soft.w = pf.w_topologyspread, e->soft.elig = elig;
             for (auto &b : e->backups)
                 if (b.first == (void *)e->cols.pod_count) e->soft.pod_count0 = (const int32_t *)b.second;
@@ -1142,9 +1144,16 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
     if (e->ipa.on && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "inter-pod affinity couples nodes through topology pairs: use CCSIM_MODE_SEQUENTIAL");
-    if (e->soft.n > 0 && (mode == CCSIM_MODE_BATCHED || e->n_ranks > 0))
+    if (e->soft.n > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "ScheduleAnyway topology spread constraints score every node against cluster-wide counts: "
-                                "sequential mode on one GPU only, for now");
+                                "sequential mode only");
+    if (e->soft.n > 0 && e->n_ranks > 0) { // the candidate-domain sets travel as bitmaps in the exchange record (XRec, kXSoftBits)
+        int bits = 0;
+        for (int c = 0; c < e->soft.n; c++) bits += e->soft.is_hostname[c] ? 0 : e->soft.n_domains[c];
+        if (bits > kXSoftBits)
+            return fail(e, -ENOSYS, "ScheduleAnyway topology spread constraints over %d domains in total: more than the %d a sharded run's "
+                                    "exchange record carries", bits, kXSoftBits);
+    }
     if (e->pts.n > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "batched mode is not valid with topology spread constraints (a placement changes the feasibility of "
                                 "other nodes): use CCSIM_MODE_SEQUENTIAL");

@@ -253,6 +253,25 @@ struct XRec {
                         // scoring pass [0] visiting position of the node that cancels the search (-1: not this shard's)
 };
 static_assert(sizeof(XRec) == 32 * 8, "XRec must be CCSIM_XCHG_WORDS int64");
+// Sequential mode with ScheduleAnyway spread constraints on shards: the nine words the batched mode uses for its level plan
+// (c_mt .. cut_ma) carry what the PodTopologySpread score needs cluster-wide (scoring.go:118-265; tests/sharded_coupled_model.py):
+//   [0] feasible nodes that have every soft key (the rest are ignored: score 0)   [1], [2] min / max raw score over them
+//   [3] eligibility bits of the shard's best node                                 [4..8] the SET of candidate domains per
+//   constraint as a bitmap (constraint c's domain v at bit soft_bit_offset(c) + v - 1; hostname constraints use [0] instead)
+// and pad[0..1] hold that node's topology value ids of the soft constraints.  The decision verifies the assumed weights
+// (log(size + 2), size = |union of the candidate sets|) and the assumed normalization range on the gathered records, exactly as
+// the unsharded mode does on its own partials, and rescans if they moved.
+constexpr int kXSoftWords = 9, kXSoftBitWords = 5, kXSoftBits = kXSoftBitWords * 64;
+static_assert(offsetof(XRec, cut_ma) - offsetof(XRec, c_mt) == (kXSoftWords - 1) * 8, "nine contiguous words");
+__host__ __device__ inline int soft_bit_offset(const DevSoft &p, int c) { // first bit of constraint c's candidate-domain set
+    int off = 0;
+    for (int q = 0; q < c; q++) off += p.is_hostname[q] ? 0 : p.n_domains[q];
+    return off;
+}
+__host__ __device__ inline int64_t *xrec_soft(XRec &r) { return &r.c_mt; }
+__host__ __device__ inline const int64_t *xrec_soft(const XRec &r) { return &r.c_mt; }
+__host__ __device__ inline int32_t *xrec_soft_ids(XRec &r) { return reinterpret_cast<int32_t *>(&r.pad[0]); }
+__host__ __device__ inline const int32_t *xrec_soft_ids(const XRec &r) { return reinterpret_cast<const int32_t *>(&r.pad[0]); }
 
 // ------------------------------------------------------------------------------------------------
 // Wave-wide reductions on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 / :31 across
@@ -1136,6 +1155,8 @@ struct WinnerTopo { // topology value ids of the winning node (from the owning r
     uint32_t elig;
     int32_t pts_v[kMaxTsc];
     int32_t ipa_v[4];
+    uint32_t soft_elig;
+    int32_t soft_v[kMaxTsc];
 };
 
 struct SoftAgg { // one scan's PodTopologySpread PreScore facts
@@ -1225,10 +1246,10 @@ __device__ __forceinline__ void decide_commit(const A &a, uint64_t key, uint32_t
                 if (v && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.pts.self_match[c]) a.pts.tbl[c][v] += 1;
             }
         }
-        if (a.soft.n && local) { // scoring.go:147-178 on the next cycle (single GPU only)
-            const uint32_t eb = a.soft.elig[i];
+        if (a.soft.n && (local || wt)) { // scoring.go:147-178 on the next cycle (replicated tables: every rank)
+            const uint32_t eb = wt ? wt->soft_elig : a.soft.elig[i];
             for (int c = 0; c < a.soft.n; c++) {
-                const int32_t v = a.soft.label[c][i];
+                const int32_t v = wt ? wt->soft_v[c] : a.soft.label[c][i];
                 if (v && !a.soft.is_hostname[c] && (eb & 1u) && ((eb >> (1 + c)) & 1u) && a.soft.self_match[c]) a.soft.tbl[c][v] += 1;
             }
         }
@@ -1356,6 +1377,18 @@ __device__ void final_body(const A &a) {
             if ((tid & 63) == 0) s_sf[3 + c][tid >> 6] = d;
         }
     }
+    __shared__ unsigned long long s_sbits[kXSoftBitWords]; // sharded: the candidate-domain SETS (the sizes are not additive across shards)
+    if (a.soft.n && a.n_ranks > 0) {
+        if (tid < kXSoftBitWords) s_sbits[tid] = 0ull;
+        __syncthreads();
+        const int32_t epoch = (int32_t)(a.st->scans + 1);
+        for (int c = 0; c < a.soft.n; c++) {
+            if (a.soft.is_hostname[c]) continue;
+            const int off = soft_bit_offset(a.soft, c);
+            for (int v = 1 + tid; v <= a.soft.n_domains[c]; v += kThreads)
+                if (a.soft.flag[c][v] == epoch) atomicOr(&s_sbits[(off + v - 1) >> 6], 1ull << ((off + v - 1) & 63));
+        }
+    }
     __syncthreads();
     if (tid != 0) return;
     key = 0, mt = 0, ma = 0, nf = 0;
@@ -1405,6 +1438,19 @@ __device__ void final_body(const A &a) {
         r.ipa_mn = a.ipa.on ? ipa_mn : INT64_MAX;
         r.ipa_mx = a.ipa.on ? ipa_mx : INT64_MIN;
         r.pad[0] = a.st->smp_K > 0 ? a.st->smp_stop : -1; // sampled search: the cancelling node's visiting position, if this shard owns it
+        if (a.soft.n) { // (never together with the sampled search on shards: begin_run)
+            int64_t *w = xrec_soft(r);
+            int64_t cn = 0;
+            for (int x = 0; x < kThreads / 64; x++) cn += s_sf[0][x];
+            w[0] = cn, w[1] = soft.mn, w[2] = soft.mx, w[3] = 0;
+            for (int q = 0; q < kXSoftBitWords; q++) w[4 + q] = (int64_t)s_sbits[q];
+            r.pad[0] = r.pad[1] = 0;
+            if (key) {
+                const int64_t i = key_index(key) - a.c.global_offset;
+                w[3] = a.soft.elig[i];
+                for (int c = 0; c < a.soft.n; c++) xrec_soft_ids(r)[c] = a.soft.label[c][i];
+            }
+        }
         if (key && (a.pts.n || a.ipa.on)) { // topology value ids of this shard's best node
             const int64_t i = key_index(key) - a.c.global_offset;
             r.win_elig = a.pts.n ? a.pts.elig[i] : 0;
@@ -1466,14 +1512,41 @@ __global__ void k_decide(ScanArgs a) {
         ipa_mx = q.ipa_mx > ipa_mx ? q.ipa_mx : ipa_mx;
     }
     WinnerTopo wt{};
-    const bool coupled = a.pts.n || a.ipa.on;
+    const bool coupled = a.pts.n || a.ipa.on || a.soft.n;
     if (coupled && win >= 0) { // the winner's domain ids travel with its record
         const XRec &q = a.xrecv[win];
         wt.elig = (uint32_t)q.win_elig;
         for (int c = 0; c < kMaxTsc; c++) wt.pts_v[c] = q.win_pts_v[c];
         for (int k = 0; k < 4; k++) wt.ipa_v[k] = q.win_ipa_v[k];
+        if (a.soft.n) {
+            wt.soft_elig = (uint32_t)xrec_soft(q)[3];
+            for (int c = 0; c < kMaxTsc; c++) wt.soft_v[c] = xrec_soft_ids(q)[c];
+        }
     }
-    decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, nullptr, coupled ? &wt : nullptr);
+    SoftAgg soft{};
+    if (a.soft.n) { // PodTopologySpread PreScore facts of the whole cluster: counts add, ranges combine, candidate sets unite
+        int64_t cn = 0;
+        unsigned long long bits[kXSoftBitWords] = {};
+        soft.mn = INT64_MAX, soft.mx = 0;
+        for (int r = 0; r < a.n_ranks; r++) {
+            const int64_t *w = xrec_soft(a.xrecv[r]);
+            cn += w[0];
+            soft.mn = w[1] < soft.mn ? w[1] : soft.mn;
+            soft.mx = w[2] > soft.mx ? w[2] : soft.mx;
+            for (int q = 0; q < kXSoftBitWords; q++) bits[q] |= (unsigned long long)w[4 + q];
+        }
+        for (int c = 0; c < a.soft.n; c++) {
+            if (a.soft.is_hostname[c]) {
+                soft.size[c] = cn;
+                continue;
+            }
+            const int off = soft_bit_offset(a.soft, c);
+            int64_t d = 0;
+            for (int v = 1; v <= a.soft.n_domains[c]; v++) d += (bits[(off + v - 1) >> 6] >> ((off + v - 1) & 63)) & 1ull;
+            soft.size[c] = d;
+        }
+    }
+    decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, a.soft.n ? &soft : nullptr, coupled ? &wt : nullptr);
     if (smp && (a.st->rounds != rounds_before || a.st->done)) a.st->smp_phase = 0; // the cycle ended (a stale maximum repeats the scoring pass only)
 }
 

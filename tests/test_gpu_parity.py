@@ -280,6 +280,61 @@ def test_sharded_protocol_with_topology_coupled_plugins(ccref, world, seed):
         assert sum(r.n_code_unschedulable for r in res) == ref.n_code_unschedulable
 
 
+def _sharded_vs_oracle(ccref, nodes, pod, prof, limit, world, cap=1500):
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    if ref.placed > cap:
+        limit = cap
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    res, log = _LocalShards(nodes, pod, prof, world).run(limit, "sequential", max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res), ([(r.placed, r.stop) for r in res], ref.placed, ref.stop)
+    n = min(len(log), len(ref.log))
+    first = next((i for i in range(n) if log[i] != ref.log[i]), None)
+    assert first is None, ("first differing placement", first, log[max(0, first - 2): first + 3].tolist(), ref.log[max(0, first - 2): first + 3].tolist())
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
+
+
+@pytest.mark.parametrize("world,seed", [(1, 0), (2, 1), (3, 2), (2, 3), (4, 4), (2, 5), (3, 6), (5, 7), (2, 8), (3, 9), (2, 10), (4, 11)])
+def test_sharded_protocol_with_schedule_anyway_constraints(ccref, world, seed):
+    """ScheduleAnyway spread constraints (and hard ones, and inter-pod terms beside them) across shards: the candidate-domain SETS
+    travel as bitmaps in the exchange record, the counts of feasible non-ignored nodes add, the raw-score ranges combine; the
+    decision verifies the assumed log(size + 2) weights and the assumed normalization range on the gathered records and rescans
+    when they moved; every rank adds the winner's clone to its replicated per-domain tables (tests/sharded_coupled_model.py)."""
+    rng = np.random.default_rng(700 + seed)  # (the cases of tests/test_spread.py::test_gpu_soft_and_hard_spread_random)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(20, 900)))
+    cons = H.random_spread(rng, nodes, n_constraints=2)
+    for k in cons:
+        k.hard = bool(rng.integers(0, 2))
+    if seed % 4 == 0:
+        cons[0].is_hostname, cons[0].hard = True, False  # scored per node instead of per domain
+    if not any(not k.hard for k in cons):
+        cons[-1].hard = False
+    pod.spread = cons
+    if seed % 3 == 2:
+        pod.ipa = H.random_ipa(rng, nodes)
+    _sharded_vs_oracle(ccref, nodes, pod, prof, int(rng.choice([0, 0, 70])), world)
+
+
+@pytest.mark.parametrize("world,n,limit,hostname", [(2, 500, 300, False), (3, 1500, 0, False), (4, 700, 400, True)])
+def test_sharded_soft_spread_synthetic(ccref, world, n, limit, hostname):
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=40 + n)  # (tests/test_spread.py::test_gpu_soft_spread_synthetic)
+    pod.spread = [M.SpreadConstraint(col=1, max_skew=2, hard=False, self_match=True, n_domains=synth.zones_for(n))]
+    if hostname:
+        nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))
+        pod.spread.append(M.SpreadConstraint(col=2, max_skew=1, hard=False, self_match=True, is_hostname=True, n_domains=n))
+    _sharded_vs_oracle(ccref, nodes, pod, prof, limit, world)
+
+
+def test_sharded_soft_spread_beyond_the_record_is_refused():
+    n = 800
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=9)
+    nodes.label_cols.append((np.arange(n, dtype=np.int32) % 400) + 1)  # 400 domains: more than the record's bitmap carries
+    pod.spread = [M.SpreadConstraint(col=2, max_skew=1, hard=False, self_match=True, n_domains=400)]
+    with pytest.raises(capi.CcsimError):
+        _LocalShards(nodes, pod, prof, 2).run(20, "sequential", 20)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("narrow", ["0", "1"])
 def test_wide_and_narrow_column_paths_agree_with_oracle(ccref, monkeypatch, mode, narrow):
