@@ -747,11 +747,14 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     if (S.done || S.cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the general kernel records the fallback)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int LL = uni32(a.plan.list_len), LS = LL + 1, W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
+    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
     const int C = uni32((int)a.w.ctl[kCwCtlClasses]);
+    // members of a class list this kernel uses: all L, or as many as the staging area holds for C classes (many classes with long
+    // lists: the window then ends where a class has used up its shorter list -- earlier, never differently)
+    const int LU = uni32(C > 0 && C * LL > kCwListLds ? kCwListLds / C : LL), LS = LU + 1;
     constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
-    bool fits = C <= kCwFastClasses && C * LL <= kCwListLds;
+    bool fits = C <= kCwFastClasses && LU >= 1;
     if (NH > 0) fits = fits && a.pts.max_skew[0] <= (1 << 29);
     if (NH > 1) fits = fits && a.pts.max_skew[1] <= (1 << 29);
     if (NH > 0 && !HU0) fits = fits && a.plan.h_len[0] <= 64;
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     for (int q = tid; q < C * LS; q += kCwThreads) {
         const int c = q / LS, m = q - c * LS;
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
-        if (m < LL) {
+        if (m < LU) {
             const unsigned long long key = a.w.lists[c * LL + m];
             if (key) {
                 const int64_t i = key_index(key) - a.c.global_offset;
@@ -856,7 +859,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         uint32_t nleft = 1u;
         if (cls) {
             nleft = 0u;
-            for (int m = 0; m < LL; m++) nleft += L.ent[lane * LS + m].y != 0u ? 1u : 0u;
+            for (int m = 0; m < LU; m++) nleft += L.ent[lane * LS + m].y != 0u ? 1u : 0u;
         }
         if (!track) cht = cha = 1u;
         // lane = domain (shared-key hard constraints): count and presence, for the minimum

@@ -75,7 +75,7 @@ def test_ipa_random(ccref, monkeypatch, seed, window, list_len):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window,list_len", [(1, 1), (5, 3), (64, 16), (64, 4)])
+@pytest.mark.parametrize("window,list_len", [(1, 1), (5, 3), (64, 16), (64, 4), (1024, 64)])  # (the last: the defaults; many classes x long lists = shortened staged lists)
 @pytest.mark.parametrize("seed", range(30))
 def test_coupled_cases_with_unique_keys(ccref, monkeypatch, seed, window, list_len):
     """tests/test_coupled_model.py's generator: hard / soft constraints and inter-pod terms over shared keys AND over a unique-per-node
