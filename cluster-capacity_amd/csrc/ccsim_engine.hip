@@ -168,6 +168,8 @@ struct ccsim_engine {
     std::vector<size_t> backup_bytes;
     bool begun = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t copy_stream = nullptr;  // the large result copies of fill_report run beside the FitError diagnosis (created on first use)
+    hipEvent_t ev_copy = nullptr;
     double kernel_ms = 0;
     int64_t limit = 0;
     int mode = 0;
@@ -311,6 +313,8 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     dist_comm_release(e);
     for (hipEvent_t ev : e->pass_events) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1347,15 +1351,32 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     out->n_code_unschedulable = 0;
     if (out->hist_taintset)
         for (int i = 0; i < out->hist_taintset_cap; i++) out->hist_taintset[i] = 0;
+    // The per-node counts (4 MB at 1M nodes: 75 us over PCIe) and the log leave on a second stream, beside the terminal round's
+    // diagnosis pass (k_hist: 33 us at 1M nodes) and its small copies -- both only read the final state.
+    hipStream_t cs = e->stream;
+    if (e->n >= (1 << 16) && st.done == DONE_UNSCHEDULABLE && (out->per_node_count || (out->log && e->d_log))) {
+        if (!e->copy_stream) {
+            if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) e->copy_stream = nullptr;
+            if (e->copy_stream && hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(e->copy_stream);
+                e->copy_stream = nullptr;
+            }
+        }
+        if (e->copy_stream) {
+            HIPCHK(e, hipEventRecord(e->ev_copy, e->stream)); // (whatever the run still has in flight: the rows' flush of the multi-kernel form)
+            HIPCHK(e, hipStreamWaitEvent(e->copy_stream, e->ev_copy, 0));
+            cs = e->copy_stream;
+        }
+    }
     if (out->per_node_count) {
         if (out->per_node_cap < e->n) return fail(e, -EINVAL, "per_node_cap too small");
-        HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, cs));
     }
     out->log_len = 0;
     if (out->log && e->d_log) {
         int64_t len = st.placed < e->log_cap ? st.placed : e->log_cap;
         if (len > out->log_cap) len = out->log_cap;
-        if (len > 0) HIPCHK(e, hipMemcpyAsync(out->log, e->d_log, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, e->stream));
+        if (len > 0) HIPCHK(e, hipMemcpyAsync(out->log, e->d_log, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, cs));
         out->log_len = len;
     }
     if (st.done == DONE_UNSCHEDULABLE && e->n > 0) {
@@ -1378,6 +1399,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
             for (int i = 0; i < e->n_taintsets && i < out->hist_taintset_cap; i++) out->hist_taintset[i] = (int64_t)ht[i];
     }
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (cs != e->stream) HIPCHK(e, hipStreamSynchronize(cs));
     return 0;
 }
 
@@ -1739,7 +1761,7 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
     HIPCHK(e, hipSetDevice(e->device));
     for (size_t i = 0; i < e->backups.size(); i++)
         HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
+    // (placed_cnt is a per-run result: begin_run zeroes it)
     for (size_t c = 0; c < e->pts_tables.size(); c++)
         HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].first, e->pts_tables[c].second, e->pts_table_len[c] * 4, hipMemcpyDeviceToDevice, e->stream));
     for (size_t c = 0; c < e->ipa_tables.size(); c++)
