@@ -319,11 +319,18 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
     bool rescore = true, ordered = want_log;
     int kb = a.level_batch; // levels the fast path resolves per sync: halved when a batch had to be rolled back, doubled after a clean one
     int64_t last_k = 1, last_xmt = 0, last_xma = 0; // the last clean pass: levels resolved, holders of the normalization maxima it exhausted
+    // A blind batch that exhausted every holder of a normalization maximum is rolled back.  Where was the event?  Every holder that
+    // filled up reports the score it had before its last clone; the lowest of them is (the scores falling along a run-down) the level at
+    // which the LAST holder went, `ev_level`: the levels above it are redone as one blind batch, that level in canonical order.
+    // Only a guess for speed -- the validation decides again, and halving remains the fallback (round 2 halved from the start:
+    // 14 of 33 iterations of a C4 run were rolled-back attempts).
+    int32_t ev_level = -1;
     unsigned long long pf[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
 #define PTICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     while (!done && (int)gc.gen_no < a.max_syncs) {
         if (rescore) {
+            ev_level = -1; // (a level of the old score scale)
             // ---- normalization maxima over the feasible set, then every node's TotalScore --------------------
             uint32_t lmt = 0, lma = 0;
 #pragma unroll 1
@@ -401,7 +408,9 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
         // A batch that exhausts the last feasible holder of a normalization maximum is rolled back: do not try one when, at
         // the rate of the last pass, the holders would run out within twice its span (a heuristic for speed only -- the
         // validation below decides)
+        if (!ordered && ev_level >= 0 && M <= ev_level) ordered = true, ev_level = -1; // the level of the located event: in canonical order
         int kcap = kb;
+        if (!ordered && ev_level >= 0 && M - ev_level < kcap) kcap = M - ev_level; // ... and the levels above it in one batch
         if (mt > 0 && last_xmt > 0) {
             const int64_t lv = c_mt * last_k / last_xmt / 2;
             kcap = lv < kcap ? (lv < 1 ? 1 : (int)lv) : kcap;
@@ -532,6 +541,7 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
 
         // (c) APPLY: rewrite the level's nodes, re-score them
         uint32_t committed = 0, x_nf = 0, x_mt = 0, x_ma = 0;
+        uint32_t xl_mt = 0, xl_ma = 0; // blind batches: 0x10000 - (score before the last clone) of the holders that filled up, maximum
         int64_t carry = prefix_b;
 #pragma unroll 1
         for (int r0 = 0; r0 < total; r0 += kPThreads) {
@@ -572,23 +582,35 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                 L.sct[li] = s | ((uint32_t)took << 16);
                 committed += (uint32_t)took;
                 if (f) mymax = s + 1 > mymax ? s + 1 : mymax;
-                else x_nf++, x_mt += n.w >> 30 & 1u, x_ma += n.w >> 29 & 1u;
+                else {
+                    x_nf++, x_mt += n.w >> 30 & 1u, x_ma += n.w >> 29 & 1u;
+                    if (!ordered && took > 0 && (n.w >> 29 & 3u)) { // a holder filled up in a blind batch: its score before the last clone
+                        NodeNarrow q = n;
+                        nd_apply(cx, q, -1);
+                        const uint32_t sp = (uint32_t)nd_score(cx, q, (int64_t)(q.w & 0xffffu), NoRcp{});
+                        if (n.w >> 30 & 1u) xl_mt = 0x10000u - sp > xl_mt ? 0x10000u - sp : xl_mt; // (max of the complement = the lowest score)
+                        if (n.w >> 29 & 1u) xl_ma = 0x10000u - sp > xl_ma ? 0x10000u - sp : xl_ma;
+                    }
+                }
             }
         }
         PTICK(2);
         // (d) block reduction -> grid reduction
         mymax = wave_max_u32(mymax);
         if (wave * 64 < total) committed = wave_sum_u32(committed), x_nf = wave_sum_u32(x_nf), x_mt = wave_sum_u32(x_mt), x_ma = wave_sum_u32(x_ma);
+        if (!ordered) xl_mt = wave_max_u32(xl_mt), xl_ma = wave_max_u32(xl_ma);
         if (lane == 0) {
             R.mx[0][wave] = mymax;
+            R.mx[1][wave] = xl_mt, R.mx[2][wave] = xl_ma;
             R.ad[0][wave] = (unsigned long long)committed | ((unsigned long long)x_nf << 32);
             R.ad[1][wave] = (unsigned long long)x_mt | ((unsigned long long)x_ma << 32);
         }
         __syncthreads();
         if (wave == 0) {
             const unsigned long long v0 = comb_max(R.mx[0]), v1 = comb_add(R.ad[0]), v2 = comb_add(R.ad[1]);
+            const unsigned long long v3 = comb_max(R.mx[1]), v4 = comb_max(R.mx[2]);
             if (lane == 0) {
-                s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
+                s_v[0] = v0, s_v[1] = v1, s_v[2] = v2, s_v[3] = v3, s_v[4] = v4;
                 s_n = 0; // next level's list (every thread read `total` before the barrier above)
             }
         }
@@ -617,8 +639,19 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                         L.sct[li] = (uint32_t)nd_score(cx, n, (int64_t)(n.w & 0xffffu), NoRcp{}); // (it was feasible: it took pods)
                     }
                 __syncthreads();
-                if (Lo < M) kb = (M - Lo + 1) >> 1; // a batch: retry with half the levels, still blind (the event is somewhere inside)
-                else ordered = true;                // one level: redo it in canonical order
+                if (Lo < M) {
+                    kb = (M - Lo + 1) >> 1; // a batch: retry with half the levels, still blind (the event is somewhere inside) ...
+                    if (cut_event && !over) { // ... unless the holders that filled up say where
+                        int32_t ev = -1;
+                        if (mt > 0 && g_xmt == c_mt && uni64(s_red[3]) != 0) ev = (int32_t)(0x10000 - (int64_t)uni64(s_red[3]));
+                        if (ma > 0 && g_xma == c_ma && uni64(s_red[4]) != 0) {
+                            const int32_t e2 = (int32_t)(0x10000 - (int64_t)uni64(s_red[4]));
+                            ev = e2 > ev ? e2 : ev; // (the event that comes first in canonical order: the higher level)
+                        }
+                        if (ev >= Lo && ev <= M) ev_level = ev, kb = a.level_batch; // (the batch is cut at ev_level + 1 where Lo is chosen)
+                    }
+                } else
+                    ordered = true; // one level: redo it in canonical order
                 continue;
             }
         }
