@@ -1203,6 +1203,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     for (auto &fl : e->soft_flags) HIPCHK(e, hipMemsetAsync(fl.first, 0, fl.second * 4, e->stream)); // epochs restart at 1
     st.limit = max_limit;
     st.lvl_full = 1; // no score cache yet
+    st.lvl_ev = -1;
     {   // several score levels per pass (blind, validated, rolled back if need be: ccsim_level.h) wherever the commit rows exist
         const int persist = (mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes) ? persist_k(e) : 0;
         const bool rows_now = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !persist;

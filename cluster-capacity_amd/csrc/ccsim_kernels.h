@@ -223,6 +223,7 @@ struct DevState {
     int32_t lvl_blind;       // the commit of this pass is a blind batch: validate it before its placements count
     int32_t lvl_rollback;    // the next pass undoes the batch of pass lvl_pass (a normalization maximum ran out of holders, or --max-limit was crossed inside it)
     int32_t lvl_pass, pad2;  // stamp of the last committing pass (commit rows carry it next to the clones they took in it)
+    int64_t lvl_ev;          // score level at which a rolled-back batch located its normalization event (-1: none): ccsim_level.h level_decide
     // windowed mode for topology-coupled plugins (ccsim_coupled.h)
     int32_t cw_fallback;     // 1 = the windowed mode gave up on this run: the one-pass-per-placement loop continues from the current state
     int32_t cw_windows;      // windows resolved so far

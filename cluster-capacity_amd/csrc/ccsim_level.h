@@ -311,10 +311,13 @@ __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v) {
     return v;
 }
 
+constexpr int64_t kEvBase = 1ll << 40; // located events travel as kEvBase - score (maximum-combined, like the plan pass's cut indices)
+
 struct __attribute__((aligned(16))) CommitPartial { // per k_level_commit block: 64 bytes
     int64_t committed;      // placements committed by this block in this pass
     int64_t T;              // plan pass: placements of the block's nodes at level st.lvl_M
-    int64_t cut_mt, cut_ma; // plan pass: highest global index among exhausted holders of st.mt_a / st.ma_a (-1 none)
+    int64_t cut_mt, cut_ma; // plan pass: highest global index among exhausted holders of st.mt_a / st.ma_a (-1 none);
+                            // blind batch: kEvBase - (lowest score a holder that filled up had before its last clone) (-1 none)
     uint32_t e_mt, e_ma;    // plan pass: how many holders their run-down exhausts
     // commit pass: the block's part of the NEXT level, from the score cache (unchanged nodes) and the re-scored level nodes
     uint64_t key;           // block max ((score+1) << 40 | (2^40-1 - global idx)); 0 = nothing feasible
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
     const int32_t M = (int32_t)(commit_on && st.lvl_blind ? st.lvl_Lo : st.lvl_M);
     const int32_t pass_stamp = st.lvl_pass + 1;
     const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const bool blind_batch = commit_on && st.lvl_blind != 0 && !plan_only;
 
     int64_t committed = 0;
     int64_t carry = ordered ? st.lvl_rank_prefix + a.blockprefix[blockIdx.x] : 0;
@@ -672,6 +676,15 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
                         x_nf++;
                         x_mt += cnt == mt ? 1u : 0u;
                         x_ma += aff == ma ? 1u : 0u;
+                        // a holder of a normalization maximum filled up in a blind batch: its score before the last clone -- should the
+                        // batch fail validation, the lowest of them is where the last holder went (level_decide, DevState::lvl_ev)
+                        if (blind_batch && took > 0 && ((mt > 0 && cnt == mt) || (ma > 0 && aff == ma))) {
+                            auto q = n;
+                            nd_apply(cx, q, -1);
+                            const int64_t sp = nd_score(cx, q, nstat, nd_rcp(q));
+                            if (mt > 0 && cnt == mt) cut_mt = kEvBase - sp > cut_mt ? kEvBase - sp : cut_mt; // (max of the complement: the lowest score)
+                            if (ma > 0 && aff == ma) cut_ma = kEvBase - sp > cut_ma ? kEvBase - sp : cut_ma;
+                        }
                     }
                 }
             }
@@ -680,6 +693,7 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
     }
 
     committed = wave_sum_i64(committed);
+    if (blind_batch) cut_mt = wave_max_i64(cut_mt), cut_ma = wave_max_i64(cut_ma); // (block-uniform; the plan pass's fields carry the located levels)
     if (plan_only) { // block-uniform
         T = wave_sum_i64(T);
         cut_mt = wave_max_i64(cut_mt);
@@ -742,8 +756,11 @@ __device__ __forceinline__ void level_issue(DevState &st, int64_t n_top, uint32_
     st.lvl_rank_prefix = 0;
     st.lvl_plan_only = 0, st.lvl_valid = 0, st.lvl_blind = 0;
     st.lvl_Lo = st.lvl_M;
-    if (st.lvl_kb > 1 && !want_log) { // several levels, blind; validated by the next level_decide (roll-back + half the levels if it fails)
-        const int64_t lo = st.lvl_M - (st.lvl_kb - 1);
+    // a rolled-back batch located its event at level lvl_ev: the levels above it in one batch, that level itself in canonical order
+    if (st.lvl_ev >= 0 && st.lvl_M <= st.lvl_ev) st.lvl_ev = -1, must_plan = true;
+    else if (st.lvl_kb > 1 && !want_log) { // several levels, blind; validated by the next level_decide (roll-back + fewer levels if it fails)
+        int64_t lo = st.lvl_M - (st.lvl_kb - 1);
+        if (st.lvl_ev >= 0 && lo <= st.lvl_ev) lo = st.lvl_ev + 1;
         st.lvl_Lo = lo > 0 ? lo : 0;
         st.lvl_blind = 1, st.lvl_valid = 1;
         st.prev_nfeas = st.cur_nfeas, st.prev_c_mt = st.cur_c_mt, st.prev_c_ma = st.cur_c_ma;
@@ -785,7 +802,13 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
         if (cut_event || over) {
             st.lvl_rollback = 1, st.lvl_valid = 0, st.lvl_blind = 0;
             const int64_t span = st.lvl_M - st.lvl_Lo + 1;
-            st.lvl_kb = span > 1 ? (int32_t)(span >> 1) : 1;
+            st.lvl_kb = span > 1 ? (int32_t)(span >> 1) : 1; // retry with half the levels ...
+            if (cut_event && !over) { // ... unless the holders that filled up say where the event was (ccsim_persist.h ev_level)
+                int64_t ev = -1;
+                if (st.mt_a > 0 && g.c_mt == 0 && g.cut_mt > 0) ev = kEvBase - g.cut_mt;
+                if (st.ma_a > 0 && g.c_ma == 0 && g.cut_ma > 0 && kEvBase - g.cut_ma > ev) ev = kEvBase - g.cut_ma; // (the first event: the higher level)
+                if (ev >= st.lvl_Lo && ev <= st.lvl_M) st.lvl_ev = ev, st.lvl_kb = st.lvl_kb_max > 1 ? st.lvl_kb_max : 2;
+            }
             st.cur_nfeas = st.prev_nfeas, st.cur_c_mt = st.prev_c_mt, st.cur_c_ma = st.prev_c_ma;
             return;
         }
@@ -808,12 +831,14 @@ __device__ __forceinline__ void level_decide(DevState &st, const LevelAgg &g, bo
     st.last_feasible = (int32_t)g.nfeas;
     if (incremental && ((st.mt_a > 0 && g.c_mt == 0) || (st.ma_a > 0 && g.c_ma == 0))) {
         st.lvl_full = 1; // the last feasible holder of a normalization maximum is gone: every cached score is stale
+        st.lvl_ev = -1;  // (a level of the old score scale)
         return;
     }
     if ((int32_t)g.mt != st.mt_a || (int32_t)g.ma != st.ma_a) { // scores above used stale constants: rescan
         st.mt_a = (int32_t)g.mt;
         st.ma_a = (int32_t)g.ma;
         st.lvl_full = 1;
+        st.lvl_ev = -1;
         return;
     }
     st.lvl_full = 0;
