@@ -256,13 +256,16 @@ class LevelModel:
         """Mirrors k_level_persist without a placement log.  Per sync: every feasible node scoring >= Lo = M - kb + 1 runs down
         until it scores < Lo (or stops fitting) -- for one node exactly the sequence of its run-downs at the levels in between,
         and without a log or a limit the interleaving across nodes is unobservable.  If that exhausted every feasible holder
-        of a normalization maximum, or crossed the limit, the whole batch is undone and retried with half the levels; a single
-        level that still trips is redone ORDERED (plan, cut, canonical commit: run()'s level step).  Returns the counters a
+        of a normalization maximum, or crossed the limit, the whole batch is undone and retried: with the levels above the one at which
+        the last holder went (every holder that filled up reports the score it had before its last clone -- a guess for speed,
+        validated like any other batch) and that level itself ORDERED, else with half the levels; a single level that still trips
+        is redone ORDERED (plan, cut, canonical commit: run()'s level step).  Returns the counters a
         log-less run reports (placed, per-node counts, stop) + how many syncs / roll-backs it took."""
         placed, syncs, rollbacks = 0, 0, 0
         per_node = np.zeros(self.N, np.int32)
         kb = level_batch
         rescore = True
+        ev_level = -1  # score level at which a rolled-back batch located its event
         mt = ma = c_mt = c_ma = 0
         while True:
             feas = [n for n in range(self.N) if self.feasible(n)]
@@ -271,6 +274,7 @@ class LevelModel:
             if rescore:  # exact maxima over the feasible set (one extra grid reduce), then every node's TotalScore
                 mt, ma = max(self.cnt[n] for n in feas), max(self.aff[n] for n in feas)
                 rescore = False
+                ev_level = -1  # (a level of the old score scale)
             c_mt = sum(1 for n in feas if self.cnt[n] == mt)
             c_ma = sum(1 for n in feas if self.aff[n] == ma)
             sc = {n: self.stat(n, mt, ma) + self.dyn(n) for n in feas}
@@ -278,7 +282,9 @@ class LevelModel:
             ordered = False
             while True:  # one sync (retried with fewer levels after a roll-back)
                 syncs += 1
-                Lo = M if ordered else max(M - (kb - 1), 0)
+                if not ordered and ev_level >= 0 and M <= ev_level:
+                    ordered, ev_level = True, -1
+                Lo = M if ordered else max(M - (kb - 1), 0, ev_level + 1)
                 work = [n for n in feas if sc[n] >= Lo]
                 if ordered:  # the level step of run(): plan, cut, canonical order, limit clamp
                     e_mt = e_ma = 0
@@ -311,12 +317,21 @@ class LevelModel:
                     rescore = cut != 1 << 62  # a maximum lost its last feasible holder: new constants
                     break
                 took, x_mt, x_ma = {}, 0, 0
+                lo_mt = lo_ma = None  # lowest score a holder that filled up had before its last clone
                 for n in work:  # blind: any order
                     j, f = self.run_down(n, self.stat(n, mt, ma), Lo, 1 << 30)
                     took[n] = j
                     if not f:
                         x_mt += self.cnt[n] == mt
                         x_ma += self.aff[n] == ma
+                        if j > 0 and ((mt > 0 and self.cnt[n] == mt) or (ma > 0 and self.aff[n] == ma)):
+                            self.apply(n, -1)
+                            sp = self.stat(n, mt, ma) + self.dyn(n)
+                            self.apply(n, +1)
+                            if mt > 0 and self.cnt[n] == mt:
+                                lo_mt = sp if lo_mt is None else min(lo_mt, sp)
+                            if ma > 0 and self.aff[n] == ma:
+                                lo_ma = sp if lo_ma is None else min(lo_ma, sp)
                 total = sum(took.values())
                 cut_event = (mt > 0 and x_mt == c_mt) or (ma > 0 and x_ma == c_ma)
                 over = limit > 0 and placed + total > limit
@@ -327,6 +342,14 @@ class LevelModel:
                             self.apply(n, -1)
                     if Lo < M:
                         kb = (M - Lo + 1) >> 1
+                        if cut_event and not over:
+                            ev = -1
+                            if mt > 0 and x_mt == c_mt and lo_mt is not None:
+                                ev = lo_mt
+                            if ma > 0 and x_ma == c_ma and lo_ma is not None:
+                                ev = max(ev, lo_ma)
+                            if Lo <= ev <= M:
+                                ev_level, kb = ev, level_batch
                     else:
                         ordered = True
                     continue
