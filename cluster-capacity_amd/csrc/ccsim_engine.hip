@@ -1442,7 +1442,9 @@ static int run_persist(ccsim_engine *e, int k) {
     // Round 3 (run_down_safe_skip: long run-downs cost a bisection): 64 -> 0.88 ms, 128 -> 0.85, 256 -> 0.96, 384 -> 0.555, 512 -> 0.77,
     // >= 640 -> 0.68 (profiles/r03/persist_batch_sweep.txt; not monotone: what a batch costs depends on where the normalization
     // maxima run out of holders inside it).  Any value gives the same results.
-    a.level_batch = 384;
+    // Round 3, second half (a rolled-back batch locates its event, the rescore phase predicts it: ccsim_persist.h ev_level): the size hardly
+    // matters any more -- 192 -> 0.314 ms, 384 -> 0.279, 1024 -> 0.266 (profiles/r03/persist_batch_sweep_predicted_events.txt).
+    a.level_batch = 1024;
     if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     if (const char *f = getenv("CCSIM_PERSIST_FAULT")) a.fault = atoi(f); // test knob: the lost-workgroup path (tests/test_persist.py)

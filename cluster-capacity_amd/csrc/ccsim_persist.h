@@ -357,6 +357,12 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             if (uni32(s_err)) break;
             mt = (uint32_t)uni64(s_red[0]), ma = (uint32_t)uni64(s_red[3]);
             uint32_t lmax = 0, lnf = 0, lcmt = 0, lcma = 0; // lmax: score + 1
+            // Where will these constants end?  When the last feasible holder of a maximum fills up -- and a node's run-down depends on
+            // nothing but the node: every holder evaluates, once, the score it will have before the clone that fills it (the Fit filter's
+            // capacity in closed form, fit.go:564-615); the lowest of them per maximum is the level of that event, the higher of the two
+            // the first one.  The batches then stop above it and take that level in canonical order without a failed attempt first (a
+            // guess for speed like `ev_level` after a roll-back: every batch is validated).
+            uint32_t pl_mt = 0, pl_ma = 0; // 0x10000 - predicted level, maximum
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int li = k * kPThreads + tid;
@@ -370,21 +376,40 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                     lmax = sc + 1 > lmax ? sc + 1 : lmax;
                     lnf++, lcmt += cnt == mt, lcma += aff == ma;
                     wsv |= (cnt == mt ? 1u << 30 : 0u) | (aff == ma ? 1u << 29 : 0u) | (uint32_t)nstat;
+                    if (!want_log && ((mt > 0 && cnt == mt) || (ma > 0 && aff == ma))) {
+                        int32_t room = n.a_pods - n.npods; // clones until the node is full (>= 1: it is feasible)
+                        if (!a.p.all_zero_req) {
+                            if (cx.q.req0 > 0) room = (n.a0 - n.r0) / cx.q.req0 < room ? (n.a0 - n.r0) / cx.q.req0 : room;
+                            if (cx.q.req1 > 0) room = (n.a1 - n.r1) / cx.q.req1 < room ? (n.a1 - n.r1) / cx.q.req1 : room;
+                        }
+                        NodeNarrow q = n;
+                        nd_apply(cx, q, (int64_t)(room - 1));
+                        const uint32_t sp = (uint32_t)(nstat + dynamic_score_narrow(a.p, cx.q, q.a0, q.a1, q.r0, q.r1, q.z0, q.z1));
+                        if (mt > 0 && cnt == mt) pl_mt = 0x10000u - sp > pl_mt ? 0x10000u - sp : pl_mt;
+                        if (ma > 0 && aff == ma) pl_ma = 0x10000u - sp > pl_ma ? 0x10000u - sp : pl_ma;
+                    }
                 } // (a node the Fit filter rejects never becomes feasible again: placements only add pods)
                 L.ws[li] = wsv;
                 L.sct[li] = sc;
             }
             lmax = wave_max_u32(lmax);
             lnf = wave_sum_u32(lnf), lcmt = wave_sum_u32(lcmt), lcma = wave_sum_u32(lcma);
-            if (lane == 0) R.mx[0][wave] = lmax, R.ad[0][wave] = (unsigned long long)lnf | ((unsigned long long)lcmt << 32), R.ad[1][wave] = lcma;
+            pl_mt = wave_max_u32(pl_mt), pl_ma = wave_max_u32(pl_ma);
+            if (lane == 0) {
+                R.mx[0][wave] = lmax, R.ad[0][wave] = (unsigned long long)lnf | ((unsigned long long)lcmt << 32), R.ad[1][wave] = lcma;
+                R.mx[1][wave] = pl_mt, R.mx[2][wave] = pl_ma;
+            }
             __syncthreads();
             if (wave == 0) {
                 const unsigned long long v0 = comb_max(R.mx[0]), v1 = comb_add(R.ad[0]), v2 = comb_add(R.ad[1]);
-                if (lane == 0) s_v[0] = v0, s_v[1] = v1, s_v[2] = v2;
+                const unsigned long long v3 = comb_max(R.mx[1]), v4 = comb_max(R.mx[2]);
+                if (lane == 0) s_v[0] = v0, s_v[1] = v1, s_v[2] = v2, s_v[3] = v3, s_v[4] = v4;
             }
             grid_reduce(gc);
             if (uni32(s_err)) break;
             scans += 1;
+            if (uni64(s_red[3]) != 0) ev_level = (int32_t)(0x10000 - (int64_t)uni64(s_red[3])); // (the first event: the higher level)
+            if (uni64(s_red[4]) != 0 && (int32_t)(0x10000 - (int64_t)uni64(s_red[4])) > ev_level) ev_level = (int32_t)(0x10000 - (int64_t)uni64(s_red[4]));
             nfeas = (int64_t)(uni64(s_red[1]) & 0xffffffffull), c_mt = (int64_t)(uni64(s_red[1]) >> 32), c_ma = (int64_t)uni64(s_red[2]);
             if (uni64(s_red[0]) == 0) { // schedule_one.go:448-454: no feasible node
                 done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0;

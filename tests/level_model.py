@@ -275,6 +275,23 @@ class LevelModel:
                 mt, ma = max(self.cnt[n] for n in feas), max(self.aff[n] for n in feas)
                 rescore = False
                 ev_level = -1  # (a level of the old score scale)
+                # where these constants will end: every holder's score before the clone that fills it (its run-down depends on nothing
+                # but the node); the lowest per maximum is the level of that event, the higher of the two the first one
+                lo = {}
+                for which, top, arr in (("mt", mt, self.cnt), ("ma", ma, self.aff)):
+                    for n in feas:
+                        if top > 0 and arr[n] == top:
+                            j = 0
+                            while self.feasible(n):
+                                self.apply(n, +1)
+                                j += 1
+                            self.apply(n, -1)
+                            sp = self.stat(n, mt, ma) + self.dyn(n)
+                            for _ in range(j - 1):
+                                self.apply(n, -1)
+                            lo[which] = sp if which not in lo else min(lo[which], sp)
+                if lo:
+                    ev_level = max(lo.values())
             c_mt = sum(1 for n in feas if self.cnt[n] == mt)
             c_ma = sum(1 for n in feas if self.aff[n] == ma)
             sc = {n: self.stat(n, mt, ma) + self.dyn(n) for n in feas}

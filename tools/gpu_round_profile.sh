@@ -40,6 +40,7 @@ rm -rf $O/ks
 cd /root/repo
 # config 5 (1024 pod specs): throughput line
 timeout 300 python tools/bench_c5.py 100000 1024 200000 64 2>&1 | grep -v amdgpu.ids | tee $O/bench_c5.txt | cut -c1-300
-timeout 120 python tools/persist_prof.py 1000000 4 384 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-250
+timeout 120 python tools/persist_prof.py 1000000 4 1024 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-250
+timeout 120 python tools/persist_prof.py 1000000 3 64,192,384,1024,4096 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/persist_batch_sweep_predicted_events.txt
 CCSIM_FORCE_DIST=1 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>/dev/null > $O/bench_dist_world1.json; cut -c1-200 $O/bench_dist_world1.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/smoke.txt
