@@ -6,7 +6,11 @@ The per-node arithmetic is tests/level_model.py's restatement.  Record layout = 
 ((score+1)<<40 | (2^40-1 - global idx)), word1 mt, word2 ma, word3 nfeas; the batched mode adds c_mt, c_ma, committed,
 n_top, T, e_mt, e_ma, cut_mt, cut_ma (words 4..12) and follows the level / plan / cut state machine of
 ccsim_level.h (level_decide, k_level_final, k_level_decide): one exchange per score level, every rank reduces the
-gathered records identically, placements of a level are ordered by rank (shards are contiguous node ranges)."""
+gathered records identically, placements of a level are ordered by rank (shards are contiguous node ranges).
+The sampled search (percentageOfNodesToScore < 100) follows the engine's two-phase form (ccsim_kernels.h DevState::smp_phase, k_decide):
+a counting pass whose record carries this shard's feasible nodes (all / before the start index; words 13, 14 here, XRec::pad in the
+engine), then the scoring pass over the nodes whose rank in the rotating visiting order is below K, with the visiting position of the
+node of rank K (it cancels the search) riding on its owner's record (word 13)."""
 import numpy as np
 
 from cluster_capacity_amd import model as M
@@ -31,6 +35,13 @@ class CpuShardEngine:
         self.limit, self.world, self.rank, self.send, self.recv = max_limit, n_ranks, rank, send, recv
         self.mt = self.ma = 0
         self.placed, self.done = 0, 0
+        # sampled search of the sequential mode (schedule_one.go:610-723)
+        p = self.m.prof
+        scoring = any((p.w_taint, p.w_nodeaffinity, p.w_fit, p.w_balanced))
+        N, pct = self.n_global, p.percentage_of_nodes_to_score
+        k = N if N < 100 else max(100, N * (pct if pct else max(5, 50 - N // 125)) // 100)
+        self.smp_K = (k if scoring else 1) if (k if scoring else 1) < N and mode == "sequential" else 0
+        self.smp_start = self.smp_phase = self.smp_off = self.smp_Ftotal = self.smp_Fs = 0
         self.per_node = np.zeros(self.n, np.int32)
         self.log = np.full(max(1, log_cap), -1, np.int32)
 
@@ -139,6 +150,8 @@ class CpuShardEngine:
         if self.mode == "batched":
             return self._scan_batched()
         m = self.m
+        if self.smp_K:
+            return self._scan_sampled()
         key = mt = ma = nf = 0
         for n in range(self.n):
             if not m.feasible(n):
@@ -155,6 +168,8 @@ class CpuShardEngine:
         if self.mode == "batched":
             return self._decide_batched()
         rec = self.recv.view(self.world, -1).numpy()
+        if self.smp_K:
+            return self._decide_sampled(rec)
         key, mt, ma, nf = int(rec[:, 0].max()), int(rec[:, 1].max()), int(rec[:, 2].max()), int(rec[:, 3].sum())
         if key == 0:
             self.done = 1
@@ -171,6 +186,58 @@ class CpuShardEngine:
             self.placed += 1
             if self.limit > 0 and self.placed >= self.limit:
                 self.done = 2
+
+    # ---- sampled search on shards: counting pass, exchange, scoring pass, exchange ------------------------------------
+    def _scan_sampled(self):
+        m, N, S = self.m, self.n_global, self.smp_start
+        feas = [n for n in range(self.n) if m.feasible(n)]
+        self.send.zero_()
+        if self.smp_phase == 0:
+            self.send[13], self.send[14] = len(feas), sum(1 for n in feas if self.off + n < S)
+            return
+        key = mt = ma = nf = 0
+        stop = -1
+        for f_local, n in enumerate(feas):  # F(i): feasible nodes before i in INDEX order, over all shards
+            g, F = self.off + n, self.smp_off + f_local
+            rank = F - self.smp_Fs if g >= S else F + self.smp_Ftotal - self.smp_Fs
+            vpos = g - S if g >= S else g + N - S
+            if rank == self.smp_K:
+                stop = vpos  # the node that cancels the search (schedule_one.go:655-662)
+            if rank >= self.smp_K:
+                continue
+            nf += 1
+            mt, ma = max(mt, m.cnt[n]), max(ma, m.aff[n])
+            key = max(key, ((m.stat(n, self.mt, self.ma) + m.dyn(n) + 1) << IDX_BITS) | (IDX_MASK - vpos))
+        self.send[:4] = self.send.new_tensor([key, mt, ma, nf])
+        self.send[13] = stop
+
+    def _decide_sampled(self, rec):
+        N = self.n_global
+        if self.smp_phase == 0:
+            tot = rec[:, 13]
+            self.smp_Ftotal, self.smp_Fs, self.smp_off = int(tot.sum()), int(rec[:, 14].sum()), int(tot[: self.rank].sum())
+            if self.smp_Ftotal == 0:
+                self.done = 1
+            else:
+                self.smp_phase = 1
+            return
+        key, mt, ma, stop = int(rec[:, 0].max()), int(rec[:, 1].max()), int(rec[:, 2].max()), int(rec[:, 13].max())
+        if (mt, ma) != (self.mt, self.ma):
+            self.mt, self.ma = mt, ma  # the maxima over the SELECTED nodes moved: the scoring pass again
+            return
+        g = (IDX_MASK - (key & IDX_MASK) + self.smp_start) % N  # the key carries the visiting position
+        i = g - self.off
+        if 0 <= i < self.n:
+            self.m.apply(i)
+            self.per_node[i] += 1
+        if self.placed < len(self.log):
+            self.log[self.placed] = g
+        self.placed += 1
+        visited = N if self.smp_Ftotal <= self.smp_K else stop
+        self.smp_start = (self.smp_start + visited) % N
+        self.smp_phase = 0
+        if self.limit > 0 and self.placed >= self.limit:
+            self.done = 2
 
     def dist_poll(self):
         return self.done, self.placed

@@ -23,6 +23,9 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n, limit = int(os.environ["CC_N"]), int(os.environ["CC_LIMIT"])
 nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=31)
+if os.environ.get("CC_PCT"):  # the sampled search (schedule_one.go:610-723): two exchanges per cycle
+    import dataclasses
+    prof = dataclasses.replace(prof, percentage_of_nodes_to_score=int(os.environ["CC_PCT"]))
 lo, hi = ccdist.shard_bounds(n, world, rank)
 eng = CpuShardEngine(nodes.slice(lo, hi), pod, prof, lo, n)
 send = torch.zeros(16, dtype=torch.int64); recv = torch.zeros(16 * world, dtype=torch.int64)
@@ -61,6 +64,23 @@ def test_sharded_runner_over_gloo(tmp_path, world, n, limit, mode, log):
     script.write_text(WORKER)
     env = dict(os.environ, CC_ROOT=ROOT, CC_N=str(n), CC_LIMIT=str(limit), CC_MODE=mode, CC_LOG=str(log), OMP_NUM_THREADS="1")
     port = 29500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line and '"ok": true' in line[0], (out.stdout[-1000:], out.stderr[-1000:])
+
+
+@pytest.mark.parametrize("world,n,limit,pct", [(2, 240, 150, 30), (3, 400, 0, 0), (2, 1000, 300, 10), (3, 130, 90, 50)])
+def test_sharded_sampled_search_over_gloo(tmp_path, world, n, limit, pct):
+    """percentageOfNodesToScore < 100 on shards: a counting pass and a scoring pass per cycle, one all-gather each (the engine's
+    two-phase form: DevState::smp_phase; the protocol is tests/sharded_sampled_model.py), the rotating start index advanced by the
+    visited count on every rank alike.  Same log as the oracle's visiting loop."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, CC_ROOT=ROOT, CC_N=str(n), CC_LIMIT=str(limit), CC_MODE="sequential", CC_LOG="1", CC_PCT=str(pct), OMP_NUM_THREADS="1")
+    port = 29500 + (os.getpid() % 2000) + 7 + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
