@@ -252,13 +252,17 @@ inline RunResult simulate_sharded(const Snapshot &s, int64_t max_limit, const st
     if (s.n_templates() != 1) throw std::runtime_error("several templates run on one GPU (ccsim_set_pods)");
     if (n_gpus < 1) throw std::runtime_error("--gpus must be >= 1");
     HostProfile prof_eff = prof;
-    prof_eff.c.percentage_of_nodes_to_score = 100; // the sampled search is single-GPU (its outcome depends on one visiting order)
+    const bool coupled = !s.spread.empty() || s.has_ipa;
+    // percentageOfNodesToScore as on one GPU (simulate() above) -- the sampled search runs on shards too (two exchanges per cycle,
+    // DESIGN.md section 5) -- except together with topology-coupled plugins, where the shards score every node
+    if (coupled) prof_eff.c.percentage_of_nodes_to_score = 100;
+    else if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = max_limit > 0 ? 0 : 100;
     Marshalled m;
     marshal(s, prof_eff, m);
     const int64_t N = (int64_t)s.n(), per = (N + n_gpus - 1) / n_gpus;
-    const bool coupled = !s.spread.empty() || s.has_ipa;
+    const bool sampled = prof_eff.c.percentage_of_nodes_to_score != 100 && s.n() >= 100;
     const int32_t mode = mode_flag == "sequential" ? CCSIM_MODE_SEQUENTIAL : mode_flag == "batched" ? CCSIM_MODE_BATCHED
-                         : (coupled ? CCSIM_MODE_SEQUENTIAL : CCSIM_MODE_BATCHED);
+                         : (coupled || sampled ? CCSIM_MODE_SEQUENTIAL : CCSIM_MODE_BATCHED);
     int64_t cap = max_limit;
     if (cap <= 0) {
         cap = 0;

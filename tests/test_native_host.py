@@ -1248,6 +1248,27 @@ def test_native_sharded_host_side_views_threads_and_merge(native, recorder, tmp_
     assert got["status"] == json.loads(json.dumps(want["status"]))
 
 
+def test_native_sharded_percentage_of_nodes_to_score(native, recorder, tmp_path):
+    """--gpus N keeps percentageOfNodesToScore as on one GPU -- unset: every node, or the reference's adaptive default when --max-limit
+    makes the order matter; set: as set -- since the sampled search runs on shards (two exchanges per cycle); except for a template
+    with topology-coupled plugins, whose shards score every node."""
+    def pcts(case, extra):
+        nodes, pods, pod, _ = CASES[case]()
+        d = tmp_path / (case + "-".join(extra).replace("/", "_"))
+        d.mkdir()
+        podspec, snaps = _write(d, "json", nodes, pods, pod)
+        env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(d / "shard.json"), CCSIM_RECORD_PER_DEVICE="1")
+        p = subprocess.run([native, "--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["-o", "json", "--gpus", "2"] + extra,
+                           capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 0, p.stderr
+        return [json.load(open(f"{d}/shard.json.{g}"))["profile"]["pct"] for g in range(2)]
+
+    assert pcts("readme", []) == [100, 100]
+    assert pcts("readme", ["--max-limit", "3"]) == [0, 0]
+    assert pcts("readme", ["--percentage-of-nodes-to-score", "30"]) == [30, 30]
+    assert pcts("rich", ["--percentage-of-nodes-to-score", "30", "--max-limit", "3"]) == [100, 100]  # (spread constraints + inter-pod affinity)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_native_sharded_host_side_views_random_clusters(native, recorder, tmp_path, seed):
     """The same slicing check over the random clusters / pod specs of the ingest fuzz (spread constraints, inter-pod affinity with
