@@ -1,6 +1,9 @@
 """Executable specification of ONE template with topology-coupled SCORES (PodTopologySpread ScheduleAnyway constraints, InterPodAffinity
-preferred terms) on node-range SHARDS -- TEST INFRASTRUCTURE, and the protocol the engine's multi-GPU path lacks today (SURVEY 8(e):
-"ScheduleAnyway scoring is single-GPU").  The per-domain tables are replicated on every rank (the engine already all-reduces them
+preferred terms) on node-range SHARDS -- TEST INFRASTRUCTURE: the protocol specification from which the engine's sharded ScheduleAnyway
+scoring was built (round 3: the candidate-domain sets as bitmaps, the counts and the raw-score range in the max-loc record, XRec /
+xrec_soft in ccsim_kernels.h; tests/test_gpu_parity.py::test_sharded_protocol_with_schedule_anyway_constraints).  The engine needs ONE
+exchange per pass instead of the three below: the scan scores under ASSUMED weights and ranges, the decision verifies them on the
+gathered records and rescans when they moved, as its unsharded mode does.  The per-domain tables are replicated on every rank (the engine already all-reduces them
 at load and every rank applies the winner's contribution); what a rank cannot know alone are the cycle-wide quantities the
 normalizations need.  One cycle = three exchanges of one small record per rank:
   A  feasible count, ignored count, the SET of candidate domains per soft constraint (a bitmap over the constraint's domains), the

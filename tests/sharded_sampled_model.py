@@ -1,5 +1,8 @@
 """Executable specification of the SAMPLED search (percentageOfNodesToScore < 100, schedule_one.go:610-723) on node-range SHARDS --
-TEST INFRASTRUCTURE, and the protocol the engine's multi-GPU path lacks today (the sampled search is single-GPU).
+TEST INFRASTRUCTURE: the protocol specification from which the engine's sharded sampled search was built (round 3: ccsim_kernels.h
+DevState::smp_phase, k_decide; tests/test_sampling.py::test_sampled_search_on_shards_*).  The engine folds exchange 2 into exchange 3 --
+the maxima over the selected nodes are ASSUMED by the scoring pass and verified on the gathered winner records, as in its unsharded
+mode, and the cancelling node's position rides on the same record -- so a cycle costs two all-gathers instead of three.
 R ranks own contiguous node ranges; every exchange below is one fixed-size record per rank, all-gathered (the engine's 256-byte
 exchange record has room for each of them), and every rank derives the same decisions from the gathered records.
 
