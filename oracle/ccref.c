@@ -523,8 +523,8 @@ void ccref_ipa_normalize(int64_t *scores, int64_t n) {
 }
 
 /* P/podtopologyspread/scoring.go:61-265 PreScore + Score + NormalizeScore over the feasible list */
-static void pts_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas,
-                       int64_t nf, int64_t *out) {
+static void pts_scores_ex(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas,
+                          int64_t nf, int64_t *out, int64_t *raw_out, double *weight_out) {
     int64_t *cnt[CCREF_MAX_TSC];
     double weight[CCREF_MAX_TSC];
     int64_t topo_size[CCREF_MAX_TSC];
@@ -591,9 +591,16 @@ static void pts_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_
         }
         out[i] = (int64_t)go_round(score);
     }
+    if (raw_out) memcpy(raw_out, out, sizeof(int64_t) * (size_t)nf);
+    if (weight_out)
+        for (int c = 0; c < pod->n_spread; c++) weight_out[c] = pod->spread[c].hard ? 0.0 : weight[c];
     ccref_pts_normalize(out, ignored, nf);
     for (int c = 0; c < pod->n_spread; c++) free(cnt[c]);
     free(ignored);
+}
+
+static void pts_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas, int64_t nf, int64_t *out) {
+    pts_scores_ex(nd, pod, placed, feas, nf, out, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -855,6 +862,15 @@ int ccref_unit_pts_prefilter(const ccref_nodes *nd, const ccref_pod *pod, const 
     memcpy(match_num, s.match_num[c], sizeof(int64_t) * (size_t)(pod->spread[c].n_domains + 1));
     *min_match = s.min_match[c], *n_dom = s.n_dom[c];
     for (int j = 0; j < CCREF_MAX_TSC; j++) free(s.match_num[j]);
+    return 0;
+}
+
+/* PodTopologySpread PreScore + Score + NormalizeScore (scoring.go:61-265) over the feasible list `feas`: raw scores (math.Round'ed), the
+ * normalized ones, the per-constraint weights -- what tests/test_reference_vectors.py holds against the reference's own functions */
+int ccref_unit_pts_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas, int64_t nf, int64_t *raw,
+                          int64_t *norm, double *weights) {
+    if (nf < 0) return -1;
+    pts_scores_ex(nd, pod, placed, feas, nf, norm, raw, weights);
     return 0;
 }
 

@@ -119,6 +119,14 @@ FUNCS += [
     ("nodeScoreHeap_Less", S + "/schedule_one.go", "func (h nodeScoreHeap) Less(i, j int) bool { return h[i].TotalScore > h[j].TotalScore }", ["h", "i", "j"], False, {"oneline": True}),
     ("selectHost", S + "/schedule_one.go", "func selectHost(nodeScoreList []framework.NodePluginScores, count int) (string, []framework.NodePluginScores, error) {", ["nodeScoreList", "count"], False),
     ("topologyNormalizingWeight", P + "/scoring.go", "func topologyNormalizingWeight(size int) float64 {", ["size"], False),
+    # PodTopologySpread's PreScore and Score (scoring.go:61-223): initPreScoreState's loop over the FILTERED nodes (ignored nodes, the candidate
+    # domains of every constraint and their number), the weights, PreScore's closure over ALL nodes (matching pods counted into the candidate
+    # domains), and Score.  *int64 map values are one-element lists here (new(int64) -> [0], atomic.AddInt64(p, n) -> p[0] += n, *p -> p[0])
+    ("ptsPreScore_initNodes", P + "/scoring.go", "\tfor _, node := range filteredNodes {", ["s", "filteredNodes", "requireAllTopologies", "topoSize"], False, {"block": True}),
+    ("ptsPreScore_weights", P + "/scoring.go", "\tfor i, c := range s.Constraints {", ["s", "filteredNodes", "topoSize"], False, {"block": True}),
+    ("ptsPreScore_processAllNode", P + "/scoring.go", "\tprocessAllNode := func(n int) {", ["n", "pl", "pod", "allNodes", "state", "requireAllTopologies", "requiredNodeAffinity"], False),
+    ("ptsScore", P + "/scoring.go", "func (pl *PodTopologySpread) Score(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) (int64, *fwk.Status) {",
+     ["s", "node", "nodeInfo", "pod"], False),
 ]
 # per-function textual substitutions applied to a Go statement before the general rules (method calls on receivers the harness models as plain
 # Python values; Go's value semantics where Python would alias)
@@ -138,6 +146,10 @@ REWRITE = {
                    (r"^return sortedNodeScoreList\[0\]\.Name, sortedNodeScoreList, nil$", "return sortedNodeScoreList[0].Name, sortedNodeScoreList, None"),
                    (r"^sortedNodeScoreList = sortedNodeScoreList\[:count\]$", "sortedNodeScoreList = sortedNodeScoreList[:count]")],
     "topologyNormalizingWeight": [(r"math\.Log\(", "go_math_log(")],
+    "ptsPreScore_initNodes": [(r"v1\.LabelHostname", "LabelHostname"), (r"= new\(int64\)$", "= [0]"), (r"^topoSize\[i\]\+\+$", "topoSize[i] += 1")],
+    "ptsPreScore_weights": [(r"v1\.LabelHostname", "LabelHostname")],
+    "ptsPreScore_processAllNode": [(r"\bc\.matchNodeInclusionPolicies\(", "matchNodeInclusionPolicies(c, "), (r"^atomic\.AddInt64\(tpCount, int64\(count\)\)$", "tpCount[0] += count")],
+    "ptsScore": [(r"v1\.LabelHostname", "LabelHostname"), (r"= \*s\.TopologyValueToPodCounts\[i\]\[tpVal\]$", "= s.TopologyValueToPodCounts[i][tpVal][0]"), (r"math\.Round\(", "go_round(")],
 }
 # statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
 JOINED = {}
@@ -145,6 +157,7 @@ DROP = {
     "ptsNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if s == nil {", "return nil", "}"],
     "ptsFilter": ["node := nodeInfo.Node()", "s, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
     "ipaFilter": ["state, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
+    "ptsScore": ["node := nodeInfo.Node()", "s, err := getPreScoreState(cycleState)", "if err != nil {", "return 0, fwk.AsStatus(err)", "}"],
     "ipaNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if len(s.topologyScore) == 0 {", "return nil", "}"],
 }
 
@@ -469,6 +482,29 @@ def gocopy(x):
     return copy.copy(x)
 
 
+class GoLabels(dict):
+    """map[string]string: a missing key reads as ""."""
+    def __missing__(self, k):
+        return ""
+
+
+class GoPtrMap(dict):
+    """map[string]*int64: a missing key reads as nil."""
+    def __missing__(self, k):
+        return None
+
+
+class GoSet(set):
+    """sets.Set[string]."""
+    def Insert(self, k): self.add(k)
+    def Has(self, k): return k in self
+
+
+def go_round(x):
+    """math.Round: half away from zero."""
+    return math.floor(x + 0.5) if x >= 0 else -math.floor(-x + 0.5)
+
+
 class GoHeap(list):
     """nodeScoreHeap: a slice behind heap.Interface -- Len / Less / Swap / Push / Pop as schedule_one.go:949-963 has them (Less is the transliterated one)."""
     less = None
@@ -576,10 +612,12 @@ def build():
            "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"],
            # round 3: the loop-level pieces
            "GoStruct": GoStruct, "gocopy": gocopy, "GoHeap": GoHeap, "heap": GoContainerHeap, "go_math_log": go_math_log, "MinNodeScore": 0, "NodeInclusionPolicyHonor": "Honor",
+           "LabelHostname": "kubernetes.io/hostname", "go_round": go_round,
            "newCriticalPaths": lambda: [GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1), GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1)]}
     iface = open(os.path.join(REF, S, "framework/interface.go")).read()
     assert re.search(r"MinNodeScore int64 = 0\b", iface) and re.search(r"MaxNodeScore int64 = %d\b" % PINS["score.max_node_score"], iface)
     assert re.search(r'NodeInclusionPolicyHonor NodeInclusionPolicy = "Honor"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read())
+    assert re.search(r'LabelHostname = "kubernetes.io/hostname"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/well_known_labels.go")).read())
     ptsf = open(os.path.join(REF, S, "framework/plugins/podtopologyspread/filtering.go")).read()
     assert "return &criticalPaths{{MatchNum: math.MaxInt32}, {MatchNum: math.MaxInt32}}" in ptsf  # newCriticalPaths, as the lambda above has it
     op_src = open(os.path.join(REF, "vendor/k8s.io/apimachinery/pkg/selection/operator.go")).read()
@@ -842,6 +880,50 @@ def vectors(env):
         env["calPreFilterState_minima"](st, constraints)
         rows.append([gate, cons, nodes, tolerations, [[list(kv) for kv in sorted(m.items())] for m in st.TpValueToMatchNum], [p[0].MatchNum for p in st.CriticalPaths]])
     v["calPreFilterState"] = rows
+    # PodTopologySpread's PreScore + Score + NormalizeScore over a FILTERED node list (scoring.go:61-265): ignored nodes, candidate domains and
+    # their number -> the log(size + 2) weights, matching pods of ALL nodes counted into the candidate domains (node inclusion policies, other
+    # namespaces, terminating pods), hostname constraints scored per node, math.Round, the normalization.  requireAllTopologies = true: the pod
+    # carries its own constraints (the system-default branch is DESIGN.md section 8 item 4)
+    rows = []
+    HOST = env["LabelHostname"]
+    for _ in range(700):
+        n_nodes = rnd.randint(1, 9)
+        gate = rnd.random() < 0.7
+        keys = rnd.choice([["zone"], [HOST], ["zone", HOST], ["zone", "rack"], ["rack", "zone", HOST], ["zone", "zone"]])
+        cons = [{"key": k, "maxSkew": rnd.randint(1, 4), "affinityPolicy": rnd.choice(["Honor", "Honor", "Ignore"]), "taintsPolicy": rnd.choice(["Honor", "Ignore", "Ignore"]),
+                 "emptySelector": rnd.random() < 0.1} for k in keys]
+        nodes = []
+        for i in range(n_nodes):
+            lb = {k: v for k, v in (("zone", rnd.choice(["a", "a", "b", "c", None])), ("rack", rnd.choice(["r1", "r2", "r2", None])), (HOST, rnd.choice([f"h{i}"] * 5 + [None]))) if v is not None}
+            taints = [{"Key": "dedicated", "Value": "infra", "Effect": rnd.choice(["NoSchedule", "PreferNoSchedule", "NoExecute"])}] if rnd.random() < 0.25 else []
+            pods = [{"ns": rnd.choice(["default", "default", "other"]), "terminating": rnd.random() < 0.15, "match": [rnd.random() < 0.6 for _ in cons]} for _ in range(rnd.choice([0, 1, 2, 3, 6]))]
+            nodes.append({"name": f"n{i}", "labels": lb, "taints": taints, "affinityMatch": rnd.random() < 0.8, "pods": pods})
+        filtered = sorted(rnd.sample(range(n_nodes), rnd.randint(1, n_nodes)))
+        tolerations = [{"Key": "dedicated", "Value": "infra", "Effect": "", "Operator": "Equal"}] if rnd.random() < 0.3 else []
+        mk = lambda d: types.SimpleNamespace(**d)
+        pod = types.SimpleNamespace(Namespace="default", Spec=types.SimpleNamespace(Tolerations=[mk(t) for t in tolerations]))
+        constraints = [GoStruct(TopologyKey=c["key"], MaxSkew=c["maxSkew"], NodeAffinityPolicy=c["affinityPolicy"], NodeTaintsPolicy=c["taintsPolicy"],
+                                Selector=types.SimpleNamespace(Empty=lambda e=c["emptySelector"]: e, Matches=lambda lbls, j=j: lbls["match"][j])) for j, c in enumerate(cons)]
+        all_nodes = []
+        for nd_ in nodes:
+            node = types.SimpleNamespace(Name=nd_["name"], Labels=GoLabels(nd_["labels"]), Spec=types.SimpleNamespace(Taints=[mk(t) for t in nd_["taints"]]), affinityMatch=nd_["affinityMatch"])
+            infos = [types.SimpleNamespace(GetPod=lambda p=p: types.SimpleNamespace(DeletionTimestamp=("t" if p["terminating"] else None), Namespace=p["ns"], Labels={"match": p["match"]})) for p in nd_["pods"]]
+            all_nodes.append(types.SimpleNamespace(Node=lambda node=node: node, GetPods=lambda infos=infos: infos))
+        require = types.SimpleNamespace(Match=lambda node: (node.affinityMatch, None))
+        pl = types.SimpleNamespace(enableNodeInclusionPolicyInPodTopologySpread=gate)
+        st = GoStruct(Constraints=constraints, IgnoredNodes=GoSet(), TopologyValueToPodCounts=[GoPtrMap() for _ in constraints], TopologyNormalizingWeight=[0.0] * len(constraints))
+        filtered_infos = [all_nodes[i] for i in filtered]
+        topo_size = [0] * len(constraints)
+        env["ptsPreScore_initNodes"](st, filtered_infos, True, topo_size)
+        env["ptsPreScore_weights"](st, filtered_infos, topo_size)
+        for n in range(len(all_nodes)):  # parallelizer.Until(ctx, len(allNodes), processAllNode, ...): atomic adds, any order
+            env["ptsPreScore_processAllNode"](n, pl, pod, all_nodes, st, True, require)
+        raw = [env["ptsScore"](st, info.Node(), info, pod)[0] for info in filtered_infos]
+        ignored = [info.Node().Name in st.IgnoredNodes for info in filtered_infos]
+        norm = list(raw)
+        env["ptsNormalizeScore"](norm, ignored)
+        rows.append([gate, cons, nodes, tolerations, filtered, [int(x) for x in ignored], [w.hex() for w in st.TopologyNormalizingWeight], raw, norm])
+    v["ptsPreScoreScore"] = rows
     # RunScorePlugins: weight x normalized score per plugin, summed per node
     rows = []
     for _ in range(600):

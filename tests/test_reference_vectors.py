@@ -38,7 +38,7 @@ def test_transliterations_are_line_by_line():
         lines = lines if opts.get("block") else lines[opts.get("header", 1):-1]  # (a block is cut with its own first and last line)
         go = [l.strip() for l in lines if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
-        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 4 if name == "ptsFilter" else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
+        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 4 if name in ("ptsFilter", "ptsScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
         two_value_lookups = sum(", ok := " in l or ":= ls.Lookup(" in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
         two_value_lookups += sum(l.startswith("if ") and ", ok := " in l and not l.startswith("if _, ok") for l in go)  # `if v, ok := m[k]; ok {`: the lookup's two lines, then the test
         two_value_lookups += sum(bool(re.match(r"if (\w+, _|_, \w+) := .*; !?\w+ \{$", l)) and ", ok := " not in l for l in go)  # `if match, _ := f(x); !match {`: the call, then the test
@@ -168,6 +168,41 @@ def test_cal_prefilter_state(ccref):
             have = {inv[vid]: cnt for vid, cnt in enumerate(match_num) if vid and cnt >= 0}
             assert have == {k: v for k, v in want_maps[j]}, (gate, cons, nodes_, j)
             assert mn == want_min[j] and ndom == len(want_maps[j]), (gate, cons, nodes_, j)
+
+
+def test_pts_prescore_and_score(ccref):
+    """podtopologyspread/scoring.go:61-265 -- initPreScoreState's loop over the filtered nodes, the weights, PreScore's closure over all nodes,
+    Score, NormalizeScore -- against the oracle's pts_scores: the same ignored nodes (score 0), the same log(size + 2) weights bit for bit, the
+    same raw (math.Round'ed) and normalized scores.  The per-node inputs the oracle takes are derived the way the ingests derive them."""
+    import numpy as np
+    import helpers as H
+    from cluster_capacity_amd import ingest, model as M
+    host = "kubernetes.io/hostname"
+    for gate, cons, nodes_, tolerations, filtered, ignored, weights_hex, raw, norm in VEC["ptsPreScoreScore"]:
+        n = len(nodes_)
+        keys = sorted({c["key"] for c in cons})
+        cols, ids = zip(*[_intern([nd["labels"].get(k) for nd in nodes_]) for k in keys])
+        nodes = _plain_nodes(n, cols)
+        low = lambda d: {k.lower(): v for k, v in d.items() if v != ""}
+        tols = [low(t) for t in tolerations]
+        spread = []
+        for j, c in enumerate(cons):
+            counts = [0 if c["emptySelector"] else sum(1 for p in nd["pods"] if p["match"][j] and p["ns"] == "default" and not p["terminating"]) for nd in nodes_]
+            inc = []
+            for nd in nodes_:
+                untolerated = not ingest.taint_verdict([low(t) for t in nd["taints"]], tols)[0]
+                ok = ((c["affinityPolicy"] != "Honor" or nd["affinityMatch"]) and (c["taintsPolicy"] != "Honor" or not untolerated)) if gate else nd["affinityMatch"]
+                inc.append(1 if ok else 0)
+            ki = keys.index(c["key"])
+            spread.append(M.SpreadConstraint(col=ki, max_skew=c["maxSkew"], min_domains=1, hard=False, self_match=True, is_hostname=c["key"] == host,
+                                             n_domains=max(len(ids[ki]), 1), node_match_count=np.array(counts, np.int32), node_included=np.array(inc, np.uint8)))
+        pod = H.simple_pod(100, 64 << 20)
+        pod.spread = spread
+        got_raw, got_norm, got_w = ccref.unit_pts_scores(nodes, pod, filtered)
+        where = (gate, cons, nodes_, filtered)
+        assert [float.fromhex(h) for h in weights_hex] == got_w, where
+        assert [r if not ig else 0 for r, ig in zip(raw, ignored)] == got_raw, (raw, got_raw, where)
+        assert norm == got_norm, (norm, got_norm, where)
 
 
 def test_weigh_and_sum(ccref):
