@@ -300,6 +300,19 @@ static void ipa_build(const ccref_nodes *nd, const ccref_pod *pod, const int32_t
     s->filter_active = !(s->exist_total == 0 && a->n_aff_terms == 0 && a->n_anti_terms == 0);
 }
 
+/* InterPodAffinity.Score (scoring.go:235-257): the sum of the score map's entries at the node's own topology values */
+static void ipa_raw_scores(const ccref_nodes *nd, const ccref_pod *pod, const ipa_state *s, const int64_t *feas, int64_t nf, int64_t *out) {
+    const ccref_ipa *a = &pod->ipa;
+    for (int64_t i = 0; i < nf; i++) {
+        int64_t v = 0;
+        for (int k = 0; k < a->n_keys; k++) {
+            int32_t d = nd->label_cols[a->key_col[k]][feas[i]];
+            if (d) v += s->score[k][d];
+        }
+        out[i] = v;
+    }
+}
+
 /* filtering.go:352-432; returns 0 ok, 1 affinity (Unresolvable), 2 anti-affinity, 3 existing pods' anti-affinity */
 static int ipa_filter(const ccref_nodes *nd, const ccref_pod *pod, const ipa_state *s, int64_t n) {
     const ccref_ipa *a = &pod->ipa;
@@ -774,15 +787,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
         }
         /* InterPodAffinity Score + NormalizeScore (scoring.go:226-290); PreScore Skip without any term hit */
         if (prof->w_interpodaffinity && ipa && ipa->entries > 0) {
-            const ccref_ipa *a = &pod->ipa;
-            for (int64_t i = 0; i < nf; i++) {
-                int64_t v = 0;
-                for (int k = 0; k < a->n_keys; k++) {
-                    int32_t d = nd->label_cols[a->key_col[k]][ws->feas[i]];
-                    if (d) v += ipa->score[k][d];
-                }
-                sc[i] = v;
-            }
+            ipa_raw_scores(nd, pod, ipa, ws->feas, nf, sc);
             ccref_ipa_normalize(sc, nf);
             ccref_weigh(ws->total, sc, prof->w_interpodaffinity, nf);
         }
@@ -887,6 +892,29 @@ int ccref_unit_ipa_build(const ccref_nodes *nd, const ccref_pod *pod, const int3
     size_t len = sizeof(int64_t) * (size_t)(pod->ipa.key_ndom[k] + 1);
     memcpy(aff, s.aff[k], len), memcpy(anti, s.anti[k], len), memcpy(exist, s.exist[k], len), memcpy(score, s.score[k], len);
     totals[0] = s.aff_total, totals[1] = s.exist_total, totals[2] = s.entries;
+    for (int j = 0; j < CCREF_MAX_IPA_KEYS; j++) free(s.aff[j]), free(s.anti[j]), free(s.exist[j]), free(s.score[j]);
+    return 0;
+}
+
+/* InterPodAffinity PreScore + Score + NormalizeScore (scoring.go:128-290) over the feasible list: raw and normalized scores, and whether
+ * PreScore skips the plugin (no term hit anywhere: *skipped = 1, the scores are then all 0) */
+int ccref_unit_ipa_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas, int64_t nf, int64_t *raw,
+                          int64_t *norm, int32_t *skipped) {
+    if (!pod->has_ipa || nf < 0) return -1;
+    ipa_state s;
+    memset(&s, 0, sizeof s);
+    for (int j = 0; j < pod->ipa.n_keys; j++) {
+        size_t len = sizeof(int64_t) * (size_t)(pod->ipa.key_ndom[j] + 1);
+        s.aff[j] = (int64_t *)malloc(len), s.anti[j] = (int64_t *)malloc(len), s.exist[j] = (int64_t *)malloc(len), s.score[j] = (int64_t *)malloc(len);
+    }
+    ipa_build(nd, pod, placed, &s);
+    *skipped = s.entries > 0 ? 0 : 1;
+    memset(raw, 0, sizeof(int64_t) * (size_t)nf), memset(norm, 0, sizeof(int64_t) * (size_t)nf);
+    if (s.entries > 0) {
+        ipa_raw_scores(nd, pod, &s, feas, nf, raw);
+        memcpy(norm, raw, sizeof(int64_t) * (size_t)nf);
+        ccref_ipa_normalize(norm, nf);
+    }
     for (int j = 0; j < CCREF_MAX_IPA_KEYS; j++) free(s.aff[j]), free(s.anti[j]), free(s.exist[j]), free(s.score[j]);
     return 0;
 }

@@ -262,6 +262,8 @@ int ccref_unit_pts_prefilter(const ccref_nodes *nd, const ccref_pod *pod, const 
                              int64_t *n_dom);
 int ccref_unit_pts_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas, int64_t nf, int64_t *raw,
                           int64_t *norm, double *weights);
+int ccref_unit_ipa_scores(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, const int64_t *feas, int64_t nf, int64_t *raw,
+                          int64_t *norm, int32_t *skipped);
 int ccref_unit_ipa_build(const ccref_nodes *nd, const ccref_pod *pod, const int32_t *placed, int k, int64_t *aff, int64_t *anti, int64_t *exist,
                          int64_t *score, int64_t *totals);
 /* the NormalizeScore steps of PodTopologySpread (scoring.go:226-265; ignored: in IgnoredNodes, NULL = none) and InterPodAffinity

@@ -520,6 +520,21 @@ def unit_pts_scores(nodes, pod, feasible, placed=None):
     return raw[:nf].tolist(), norm[:nf].tolist(), [float(x) for x in w][: len(pod.spread)]
 
 
+def unit_ipa_scores(nodes, pod, feasible, placed=None):
+    """InterPodAffinity PreScore + Score + NormalizeScore over the feasible list: (raw scores, normalized scores, PreScore skipped?)."""
+    m = _Marshal()
+    cn, cp = m.nodes(nodes), m.pod(pod)
+    pl = np.zeros(max(1, nodes.n), np.int32) if placed is None else np.ascontiguousarray(placed, dtype=np.int32)
+    feas = np.ascontiguousarray(feasible, dtype=np.int64)
+    nf = int(feas.shape[0])
+    raw, norm = np.zeros(max(1, nf), np.int64), np.zeros(max(1, nf), np.int64)
+    skipped = C.c_int32()
+    fn = lib().ccref_unit_ipa_scores
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(_Nodes), C.POINTER(_Pod), _p32, _p64, C.c_int64, _p64, _p64, C.POINTER(C.c_int32)]
+    assert fn(C.byref(cn), C.byref(cp), _ptr(pl, _p32), _ptr(feas, _p64), nf, _ptr(raw, _p64), _ptr(norm, _p64), C.byref(skipped)) == 0
+    return raw[:nf].tolist(), norm[:nf].tolist(), bool(skipped.value)
+
+
 def unit_ipa_build(nodes, pod, placed=None):
     """InterPodAffinity's PreFilter / PreScore maps of a cluster: per key (aff, anti, exist, score) per value id, and the totals."""
     m = _Marshal()

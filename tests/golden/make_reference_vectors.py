@@ -98,6 +98,7 @@ FUNCS += [
 # body, "header": lines of the function header}.  A closure handed to the parallelizer (`processNode := func(n int) {`, `Until(ctx, len(nodes),
 # func(index int) {`) is cut as a function of its index; the harness calls it for 0..n-1 in order (the pieces write disjoint slots).
 I = S + "/framework/plugins/interpodaffinity/filtering.go"
+IS = S + "/framework/plugins/interpodaffinity/scoring.go"
 P = S + "/framework/plugins/podtopologyspread"
 FUNCS += [
     ("topologyToMatchedTermCount_update", I, "func (m topologyToMatchedTermCount) update(node *v1.Node, tk string, value int64) {", ["m", "node", "tk", "value"], False),
@@ -125,6 +126,18 @@ FUNCS += [
     ("ptsPreScore_initNodes", P + "/scoring.go", "\tfor _, node := range filteredNodes {", ["s", "filteredNodes", "requireAllTopologies", "topoSize"], False, {"block": True}),
     ("ptsPreScore_weights", P + "/scoring.go", "\tfor i, c := range s.Constraints {", ["s", "filteredNodes", "topoSize"], False, {"block": True}),
     ("ptsPreScore_processAllNode", P + "/scoring.go", "\tprocessAllNode := func(n int) {", ["n", "pl", "pod", "allNodes", "state", "requireAllTopologies", "requiredNodeAffinity"], False),
+    # InterPodAffinity's PreScore and Score (interpodaffinity/scoring.go:51-257): the score map's processTerm / processTerms / append, what one
+    # existing pod contributes (processExistingPod), PreScore's closure over the nodes, Score.  (`topoScores[atomic.AddInt32(&index, 1)] = x`
+    # appends; the merge loop `for i := 0; i <= int(index); i++ { state.topologyScore.append(topoScores[i]) }` is written out by the harness)
+    ("scoreMap_processTerm", IS, "func (m scoreMap) processTerm(term *fwk.AffinityTerm, weight int32, pod *v1.Pod, nsLabels labels.Set, node *v1.Node, multiplier int32) {",
+     ["m", "term", "weight", "pod", "nsLabels", "node", "multiplier"], False),
+    ("scoreMap_processTerms", IS, "func (m scoreMap) processTerms(terms []fwk.WeightedAffinityTerm, pod *v1.Pod, nsLabels labels.Set, node *v1.Node, multiplier int32) {",
+     ["m", "terms", "pod", "nsLabels", "node", "multiplier"], False),
+    ("scoreMap_append", IS, "func (m scoreMap) append(other scoreMap) {", ["m", "other"], False),
+    ("ipa_processExistingPod", IS, "func (pl *InterPodAffinity) processExistingPod(", ["pl", "state", "existingPod", "existingPodNodeInfo", "incomingPod", "topoScore"], False, {"header": 7}),
+    ("ipaPreScore_processNode", IS, "\tprocessNode := func(i int) {", ["i", "pl", "allNodes", "hasConstraints", "state", "pod", "topoScores"], False),
+    ("ipaScore", IS, "func (pl *InterPodAffinity) Score(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) (int64, *fwk.Status) {",
+     ["s", "node"], False),
     ("ptsScore", P + "/scoring.go", "func (pl *PodTopologySpread) Score(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) (int64, *fwk.Status) {",
      ["s", "node", "nodeInfo", "pod"], False),
 ]
@@ -146,6 +159,11 @@ REWRITE = {
                    (r"^return sortedNodeScoreList\[0\]\.Name, sortedNodeScoreList, nil$", "return sortedNodeScoreList[0].Name, sortedNodeScoreList, None"),
                    (r"^sortedNodeScoreList = sortedNodeScoreList\[:count\]$", "sortedNodeScoreList = sortedNodeScoreList[:count]")],
     "topologyNormalizingWeight": [(r"math\.Log\(", "go_math_log(")],
+    "scoreMap_processTerm": [(r"= make\(map\[string\]int64\)$", "= GoMap()")],
+    "scoreMap_processTerms": [(r"^m\.processTerm\(", "scoreMap_processTerm(m, ")],
+    "ipa_processExistingPod": [(r"^topoScore\.processTerms\(", "scoreMap_processTerms(topoScore, "), (r"^topoScore\.processTerm\(", "scoreMap_processTerm(topoScore, ")],
+    "ipaPreScore_processNode": [(r"= make\(scoreMap\)$", "= GoPtrMap()"), (r"^pl\.processExistingPod\(", "ipa_processExistingPod(pl, "),
+                                (r"^topoScores\[atomic\.AddInt32\(&index, 1\)\] = topoScore$", "topoScores.append(topoScore)")],
     "ptsPreScore_initNodes": [(r"v1\.LabelHostname", "LabelHostname"), (r"= new\(int64\)$", "= [0]"), (r"^topoSize\[i\]\+\+$", "topoSize[i] += 1")],
     "ptsPreScore_weights": [(r"v1\.LabelHostname", "LabelHostname")],
     "ptsPreScore_processAllNode": [(r"\bc\.matchNodeInclusionPolicies\(", "matchNodeInclusionPolicies(c, "), (r"^atomic\.AddInt64\(tpCount, int64\(count\)\)$", "tpCount[0] += count")],
@@ -158,6 +176,7 @@ DROP = {
     "ptsFilter": ["node := nodeInfo.Node()", "s, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
     "ipaFilter": ["state, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
     "ptsScore": ["node := nodeInfo.Node()", "s, err := getPreScoreState(cycleState)", "if err != nil {", "return 0, fwk.AsStatus(err)", "}"],
+    "ipaScore": ["node := nodeInfo.Node()", "s, err := getPreScoreState(cycleState)", "if err != nil {", "return 0, fwk.AsStatus(err)", "}"],
     "ipaNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if len(s.topologyScore) == 0 {", "return nil", "}"],
 }
 
@@ -285,7 +304,9 @@ def transliterate(name, params, body, int_div, opts=None):
             m2 = re.fullmatch(r"for _, (\w+) := range ([\w.]+(?:\(\))?)", ln)
             m3 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+)", ln)
             m4 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+\.ScalarResources)", ln)
-            if m4:  # a map: Go's order is random, sorted here
+            mmap = re.fullmatch(r"for (\w+), (\w+) := range (other|oScores|s\.topologyScore)", ln)  # the score maps of InterPodAffinity
+            if m4 or mmap:  # a map: Go's order is random, sorted here
+                m4 = m4 or mmap
                 ln = f"for {m4.group(1)}, {m4.group(2)} in sorted({m4.group(3)}.items()):"
             elif m3 and m3.group(1) != "_":
                 ln = f"for {m3.group(1)}, {m3.group(2)} in enumerate({m3.group(3)}):"
@@ -293,11 +314,11 @@ def transliterate(name, params, body, int_div, opts=None):
                 ln = f"for {m.group(1)} in range(len({m.group(2)})):"
             elif m2:
                 ln = f"for {m2.group(1)} in {m2.group(2)}:"
-            elif re.fullmatch(r"if (\w+), ok := (.+)\[([\w.]+)\]; ok", ln):  # if with an init statement: the lookup, then the test
-                mi = re.fullmatch(r"if (\w+), ok := (.+)\[([\w.]+)\]; ok", ln)
-                out.append("    " * depth + f"ok = {mi.group(3)} in {mi.group(2)}")
-                out.append("    " * depth + f"{mi.group(1)} = {mi.group(2)}.get({mi.group(3)}, \"\")")
-                ln = "if ok:"
+            elif re.fullmatch(r"if (\w+), (\w+) := (.+)\[([\w.]+)\]; \2", ln):  # if with an init statement: the lookup, then the test
+                mi = re.fullmatch(r"if (\w+), (\w+) := (.+)\[([\w.]+)\]; \2", ln)
+                out.append("    " * depth + f"{mi.group(2)} = {mi.group(4)} in {mi.group(3)}")
+                out.append("    " * depth + f"{mi.group(1)} = {mi.group(3)}.get({mi.group(4)}, \"\")")
+                ln = f"if {mi.group(2)}:"
             elif re.fullmatch(r"for (\w+) := 0; \1 < len\((\w+)\); \1\+\+", ln):  # the counting loop
                 mc = re.fullmatch(r"for (\w+) := 0; \1 < len\((\w+)\); \1\+\+", ln)
                 ln = f"for {mc.group(1)} in range(len({mc.group(2)})):"
@@ -612,7 +633,7 @@ def build():
            "minFeasibleNodesToFind": PINS["search.min_feasible_nodes"], "minFeasibleNodesPercentageToFind": PINS["search.min_feasible_percentage"],
            # round 3: the loop-level pieces
            "GoStruct": GoStruct, "gocopy": gocopy, "GoHeap": GoHeap, "heap": GoContainerHeap, "go_math_log": go_math_log, "MinNodeScore": 0, "NodeInclusionPolicyHonor": "Honor",
-           "LabelHostname": "kubernetes.io/hostname", "go_round": go_round,
+           "LabelHostname": "kubernetes.io/hostname", "go_round": go_round, "GoMap": GoMap, "GoPtrMap": GoPtrMap,
            "newCriticalPaths": lambda: [GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1), GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1)]}
     iface = open(os.path.join(REF, S, "framework/interface.go")).read()
     assert re.search(r"MinNodeScore int64 = 0\b", iface) and re.search(r"MaxNodeScore int64 = %d\b" % PINS["score.max_node_score"], iface)
@@ -924,6 +945,62 @@ def vectors(env):
         env["ptsNormalizeScore"](norm, ignored)
         rows.append([gate, cons, nodes, tolerations, filtered, [int(x) for x in ignored], [w.hex() for w in st.TopologyNormalizingWeight], raw, norm])
     v["ptsPreScoreScore"] = rows
+    # InterPodAffinity's PreScore + Score + NormalizeScore (interpodaffinity/scoring.go:51-290): the incoming pod's preferred terms against every
+    # existing pod, the existing pods' required (HardPodAffinityWeight) and preferred terms against the incoming pod, nodes without labels or
+    # without the term's key, only pods with affinity when the incoming pod has no preferred terms, PreScore's Skip when nothing hit
+    rows = []
+    for _ in range(700):
+        n_nodes = rnd.randint(1, 8)
+        hard_w = rnd.choice([0, 1, 1, 7])
+        mkterm = lambda: {"key": rnd.choice(["zone", "host"]), "weight": rnd.choice([1, 5, 50, 100])}
+        inc_aff = [mkterm() for _ in range(rnd.choice([0, 0, 1, 2]))]
+        inc_anti = [mkterm() for _ in range(rnd.choice([0, 0, 1, 2]))]
+        nodes = []
+        for i in range(n_nodes):
+            lb = {k: v for k, v in (("zone", rnd.choice(["a", "a", "b", None])), ("host", rnd.choice([f"h{i}"] * 4 + [None]))) if v is not None}
+            pods = []
+            for _p in range(rnd.choice([0, 1, 2, 4])):
+                own = rnd.random() < 0.5  # the pod has affinity terms of its own
+                pods.append({"matchAff": [rnd.random() < 0.5 for _ in inc_aff], "matchAnti": [rnd.random() < 0.5 for _ in inc_anti],
+                             "required": [dict(mkterm(), matches=rnd.random() < 0.6) for _ in range(rnd.choice([0, 1, 2]) if own else 0)],
+                             "prefAff": [dict(mkterm(), matches=rnd.random() < 0.6) for _ in range(rnd.choice([0, 1]) if own else 0)],
+                             "prefAnti": [dict(mkterm(), matches=rnd.random() < 0.6) for _ in range(rnd.choice([0, 1]) if own else 0)]})
+            nodes.append({"name": f"n{i}", "labels": lb, "pods": pods})
+        filtered = sorted(rnd.sample(range(n_nodes), rnd.randint(1, n_nodes)))
+        incoming = types.SimpleNamespace(Namespace="default")
+        term_on_existing = lambda t, which, j: GoStruct(TopologyKey=t["key"], Matches=lambda pod, ns, which=which, j=j: pod.flags[which][j])
+        term_on_incoming = lambda t: GoStruct(TopologyKey=t["key"], Matches=lambda pod, ns, m=t["matches"]: m)
+        weighted = lambda term, w: GoStruct(AffinityTerm=term, Weight=w)
+        pod_info = types.SimpleNamespace(GetPreferredAffinityTerms=lambda: [weighted(term_on_existing(t, "matchAff", j), t["weight"]) for j, t in enumerate(inc_aff)],
+                                         GetPreferredAntiAffinityTerms=lambda: [weighted(term_on_existing(t, "matchAnti", j), t["weight"]) for j, t in enumerate(inc_anti)])
+        state = GoStruct(topologyScore=GoPtrMap(), podInfo=pod_info, namespaceLabels=None)
+        has_constraints = bool(inc_aff or inc_anti)
+        infos = []
+        for nd_ in nodes:
+            node = types.SimpleNamespace(Name=nd_["name"], Labels=GoLabels(nd_["labels"]))
+            pis = []
+            for p in nd_["pods"]:
+                ep = types.SimpleNamespace(flags=p)
+                pis.append(types.SimpleNamespace(GetPod=lambda ep=ep: ep, has_affinity=bool(p["required"] or p["prefAff"] or p["prefAnti"]),
+                                                 GetRequiredAffinityTerms=lambda p=p: [term_on_incoming(t) for t in p["required"]],
+                                                 GetPreferredAffinityTerms=lambda p=p: [weighted(term_on_incoming(t), t["weight"]) for t in p["prefAff"]],
+                                                 GetPreferredAntiAffinityTerms=lambda p=p: [weighted(term_on_incoming(t), t["weight"]) for t in p["prefAnti"]]))
+            infos.append(types.SimpleNamespace(Node=lambda node=node: node, GetPods=lambda pis=pis: pis, GetPodsWithAffinity=lambda pis=pis: [x for x in pis if x.has_affinity]))
+        # scoring.go:153-165: every node when the incoming pod has preferred terms, else the nodes hosting pods with affinity
+        all_nodes = infos if has_constraints else [x for x in infos if x.GetPodsWithAffinity()]
+        pl = types.SimpleNamespace(args=types.SimpleNamespace(HardPodAffinityWeight=hard_w))
+        topo_scores = []
+        for i in range(len(all_nodes)):  # parallelizer.Until(pCtx, len(allNodes), processNode, ...): the maps are merged afterwards, any order
+            env["ipaPreScore_processNode"](i, pl, all_nodes, has_constraints, state, incoming, topo_scores)
+        skipped = not topo_scores  # index == -1: fwk.Skip
+        for ts in topo_scores:     # for i := 0; i <= int(index); i++ { state.topologyScore.append(topoScores[i]) }
+            env["scoreMap_append"](state.topologyScore, ts)
+        raw = [0 if skipped else env["ipaScore"](state, infos[i].Node())[0] for i in filtered]
+        norm = list(raw)
+        if not skipped:
+            env["ipaNormalizeScore"](norm)
+        rows.append([hard_w, inc_aff, inc_anti, nodes, filtered, int(skipped), sorted([k, sorted([list(kv) for kv in m.items()])] for k, m in state.topologyScore.items()), raw, norm])
+    v["ipaPreScoreScore"] = rows
     # RunScorePlugins: weight x normalized score per plugin, summed per node
     rows = []
     for _ in range(600):

@@ -38,9 +38,10 @@ def test_transliterations_are_line_by_line():
         lines = lines if opts.get("block") else lines[opts.get("header", 1):-1]  # (a block is cut with its own first and last line)
         go = [l.strip() for l in lines if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
-        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 4 if name in ("ptsFilter", "ptsScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
+        dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 4 if name in ("ptsFilter", "ptsScore", "ipaScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
         two_value_lookups = sum(", ok := " in l or ":= ls.Lookup(" in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
         two_value_lookups += sum(l.startswith("if ") and ", ok := " in l and not l.startswith("if _, ok") for l in go)  # `if v, ok := m[k]; ok {`: the lookup's two lines, then the test
+        two_value_lookups += 2 * sum(bool(re.match(r"if (\w+), (?!ok\b)(\w+) := .+\[[\w.]+\]; \2 \{$", l)) for l in go)  # the same with another flag name (`tpValueExist`, `exist`)
         two_value_lookups += sum(bool(re.match(r"if (\w+, _|_, \w+) := .*; !?\w+ \{$", l)) and ", ok := " not in l for l in go)  # `if match, _ := f(x); !match {`: the call, then the test
         two_value_lookups += sum(bool(re.match(r"for \w+ := .+; ; \w+ = ", l)) for l in go)  # `for x := f(); ; x = f() {`: `while True:` + the call
         named_result = 1 if re.search(r"\) \(\w+ [\[\]\w.]+\) \{$", s["go"].split("\n")[0]) else 0  # `(n int)`: one line that sets its zero value
@@ -203,6 +204,50 @@ def test_pts_prescore_and_score(ccref):
         assert [float.fromhex(h) for h in weights_hex] == got_w, where
         assert [r if not ig else 0 for r, ig in zip(raw, ignored)] == got_raw, (raw, got_raw, where)
         assert norm == got_norm, (norm, got_norm, where)
+
+
+def test_ipa_prescore_and_score(ccref):
+    """interpodaffinity/scoring.go:51-290 -- processTerm / processTerms / append, processExistingPod, PreScore's closure over the nodes, Score,
+    NormalizeScore -- against the oracle's score tables (ipa_build), its Score and its Skip: the same topology-pair sums, the same raw and
+    normalized scores over a filtered node list, PreScore skipped in the same clusters.  The per-node inputs the oracle takes (the weight an
+    existing pod contributes per key, the number of term hits) are derived the way the ingests derive them."""
+    import numpy as np
+    import helpers as H
+    from cluster_capacity_amd import model as M
+    for hard_w, inc_aff, inc_anti, nodes_, filtered, skipped, want_map, raw, norm in VEC["ipaPreScoreScore"]:
+        n = len(nodes_)
+        keys = ("zone", "host")
+        cols, ids = zip(*[_intern([nd["labels"].get(k) for nd in nodes_]) for k in keys])
+        nodes = _plain_nodes(n, cols)
+        score_existing = [np.zeros(n, np.int64) for _ in keys]
+        entries = 0
+        for i, nd in enumerate(nodes_):
+            for p in nd["pods"]:
+                hits = [(t["key"], t["weight"]) for t, m in zip(inc_aff, p["matchAff"]) if m] + [(t["key"], -t["weight"]) for t, m in zip(inc_anti, p["matchAnti"]) if m]
+                if hard_w > 0:
+                    hits += [(t["key"], hard_w) for t in p["required"] if t["matches"]]
+                hits += [(t["key"], t["weight"]) for t in p["prefAff"] if t["matches"]] + [(t["key"], -t["weight"]) for t in p["prefAnti"] if t["matches"]]
+                for key, w in hits:
+                    if key in nd["labels"]:  # the node carries the term's topology key (scoring.go:53-60)
+                        score_existing[keys.index(key)][i] += w
+                        entries += 1
+        pod = H.simple_pod(100, 64 << 20)
+        pod.ipa = M.InterPodAffinity(key_cols=[0, 1], key_ndom=[max(len(ids[0]), 1), max(len(ids[1]), 1)], aff_keys=[], self_aff=False, aff_existing=None, anti_keys=[],
+                                     anti_self=[], anti_existing=[], exist_anti=[None, None], score_existing=score_existing, score_self=[0, 0], self_entries=[0, 0],
+                                     entries_existing=entries)
+        where = (hard_w, inc_aff, inc_anti, nodes_, filtered)
+        tabs, totals = ccref.unit_ipa_build(nodes, pod)
+        got = {}
+        for k, name in enumerate(keys):
+            inv = {v: s_ for s_, v in ids[k].items()}
+            for vid, w in enumerate(tabs[k][3]):
+                if vid and w:
+                    got[(name, inv[vid])] = w
+        want = {(k, val): w for k, m in want_map for val, w in m if w}  # (an entry that sums to 0 scores like no entry)
+        assert got == want, where
+        assert (totals[2] == 0) == bool(skipped), where
+        got_raw, got_norm, got_skipped = ccref.unit_ipa_scores(nodes, pod, filtered)
+        assert got_skipped == bool(skipped) and got_raw == raw and got_norm == norm, (got_raw, raw, got_norm, norm, where)
 
 
 def test_weigh_and_sum(ccref):
