@@ -14,7 +14,10 @@
  * (ccref_least_allocated, ccref_balanced_allocation, ccref_default_normalize, ccref_num_feasible_nodes_to_find,
  * ccref_image_locality_score, ccref_pts_normalize, ccref_ipa_normalize) and three filters as the loop applies them -- NodeResourcesFit's fitsRequest (reason
  * set + the Unresolvable status rule), PodTopologySpread's Filter with minMatchNum, InterPodAffinity's Filter with its satisfy* functions, each checked node by
- * node through ccref_run -- equal the output of a mechanical line-by-line transliteration of the reference's own Go functions
+ * node through ccref_run -- and, since round 3, the loop-level pieces: PodTopologySpread's calPreFilterState (ccref_unit_pts_prefilter) and its
+ * PreScore + Score (ccref_unit_pts_scores), InterPodAffinity's count maps (ccref_unit_ipa_build) and its PreScore + Score + Skip
+ * (ccref_unit_ipa_scores), RunScorePlugins' weight-and-sum (ccref_weigh), selectHost (ccref_select_host), topologyNormalizingWeight
+ * (ccref_go_log) -- equal the output of a mechanical line-by-line transliteration of the reference's own Go functions
  * (tests/golden/reference_vectors.json, tests/test_reference_vectors.py); every message string, status code, default and the
  * filter order equal what the sources say (tests/golden/reference_pins.json, tests/test_reference_pins.py).
  *
