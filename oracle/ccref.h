@@ -16,7 +16,8 @@
  * set + the Unresolvable status rule), PodTopologySpread's Filter with minMatchNum, InterPodAffinity's Filter with its satisfy* functions, each checked node by
  * node through ccref_run -- and, since round 3, the loop-level pieces: PodTopologySpread's calPreFilterState (ccref_unit_pts_prefilter) and its
  * PreScore + Score (ccref_unit_pts_scores), InterPodAffinity's count maps (ccref_unit_ipa_build) and its PreScore + Score + Skip
- * (ccref_unit_ipa_scores), RunScorePlugins' weight-and-sum (ccref_weigh), selectHost (ccref_select_host), topologyNormalizingWeight
+ * (ccref_unit_ipa_scores), the node search of a cycle from a given start index (ccref_schedule_one: nodes visited, feasible nodes kept, the next
+ * start index), RunScorePlugins' weight-and-sum (ccref_weigh), selectHost (ccref_select_host), topologyNormalizingWeight
  * (ccref_go_log) -- equal the output of a mechanical line-by-line transliteration of the reference's own Go functions
  * (tests/golden/reference_vectors.json, tests/test_reference_vectors.py); every message string, status code, default and the
  * filter order equal what the sources say (tests/golden/reference_pins.json, tests/test_reference_pins.py).

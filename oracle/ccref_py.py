@@ -380,6 +380,23 @@ def run(profile, nodes, pod, max_limit: int = 0, threads: int = 1, want_log: boo
     )
 
 
+def schedule_one(profile, nodes, pod, next_start: int = 0):
+    """ONE scheduling cycle from the visiting position `next_start` (ccref_schedule_one): (winner or -1, nodes the search visited, feasible nodes
+    kept, the next start index).  `nodes` is not modified (the marshalled copy takes the placement)."""
+    m = _Marshal()
+    cn, cp, cf = m.nodes(nodes), m.pod(pod), m.profile(profile)
+    res = _Result()
+    per_node = np.zeros(max(1, nodes.n), np.int32)
+    res.per_node_count = _ptr(per_node, _p32)
+    ht = np.zeros(max(1, len(pod.taint_filter_ok)), np.int64)
+    res.hist_taintset = _ptr(ht, _p64)
+    st = C.c_int64(int(next_start))  # ccref_sched_state { int64_t next_start_node_index; }
+    fn = lib().ccref_schedule_one
+    fn.restype, fn.argtypes = C.c_int64, [C.POINTER(_Profile), C.POINTER(_Nodes), C.POINTER(_Pod), C.POINTER(C.c_int64), C.POINTER(_Result)]
+    w = int(fn(C.byref(cf), C.byref(cn), C.byref(cp), C.byref(st), C.byref(res)))
+    return w, int(res.last_evaluated), int(res.last_feasible), int(st.value)
+
+
 class _MultiResult(C.Structure):
     _fields_ = [
         ("placed", C.c_int64),

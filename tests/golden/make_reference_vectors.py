@@ -138,6 +138,12 @@ FUNCS += [
     ("ipaPreScore_processNode", IS, "\tprocessNode := func(i int) {", ["i", "pl", "allNodes", "hasConstraints", "state", "pod", "topoScores"], False),
     ("ipaScore", IS, "func (pl *InterPodAffinity) Score(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) (int64, *fwk.Status) {",
      ["s", "node"], False),
+    # the node search (schedule_one.go:610-693): the closure the parallelizer runs per visiting position.  The canonical mode of the oracle is ONE
+    # worker taking the positions in order and stopping once the context is cancelled -- the harness's loop; feasibleNodesLen is a counter
+    # object (atomic.AddInt32(&x, n) -> x.add(n), returning the new value); the two lines that move nextStartNodeIndex (:538-539) are asserted
+    # to be in the source and written out by the harness
+    ("findNodesThatPassFilters_checkNode", S + "/schedule_one.go", "\tcheckNode := func(i int) {",
+     ["i", "sched", "nodes", "numAllNodes", "schedFramework", "ctx", "state", "pod", "errCh", "cancel", "feasibleNodesLen", "numNodesToFind", "feasibleNodes", "result"], False),
     ("ptsScore", P + "/scoring.go", "func (pl *PodTopologySpread) Score(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) (int64, *fwk.Status) {",
      ["s", "node", "nodeInfo", "pod"], False),
 ]
@@ -159,6 +165,11 @@ REWRITE = {
                    (r"^return sortedNodeScoreList\[0\]\.Name, sortedNodeScoreList, nil$", "return sortedNodeScoreList[0].Name, sortedNodeScoreList, None"),
                    (r"^sortedNodeScoreList = sortedNodeScoreList\[:count\]$", "sortedNodeScoreList = sortedNodeScoreList[:count]")],
     "topologyNormalizingWeight": [(r"math\.Log\(", "go_math_log(")],
+    "findNodesThatPassFilters_checkNode": [(r"fwk\.Error\b", '"Error"'), (r"^errCh\.SendErrorWithCancel\(status\.AsError\(\), func\(\) \{$", "if errCh.send(status) {"),
+                                           (r"errors\.New\((\"[^\"]*\")\)", r"\1"), (r"^\}\)$", "}"),
+                                           (r"^length := atomic\.AddInt32\(&feasibleNodesLen, 1\)$", "length := feasibleNodesLen.add(1)"),
+                                           (r"^atomic\.AddInt32\(&feasibleNodesLen, -1\)$", "feasibleNodesLen.add(-1)"),
+                                           (r"^result\[i\] = &nodeStatus\{node: nodeInfo\.Node\(\)\.Name, status: status\}$", "result[i] = (nodeInfo.Node().Name, status)")],
     "scoreMap_processTerm": [(r"= make\(map\[string\]int64\)$", "= GoMap()")],
     "scoreMap_processTerms": [(r"^m\.processTerm\(", "scoreMap_processTerm(m, ")],
     "ipa_processExistingPod": [(r"^topoScore\.processTerms\(", "scoreMap_processTerms(topoScore, "), (r"^topoScore\.processTerm\(", "scoreMap_processTerm(topoScore, ")],
@@ -638,6 +649,9 @@ def build():
     iface = open(os.path.join(REF, S, "framework/interface.go")).read()
     assert re.search(r"MinNodeScore int64 = 0\b", iface) and re.search(r"MaxNodeScore int64 = %d\b" % PINS["score.max_node_score"], iface)
     assert re.search(r'NodeInclusionPolicyHonor NodeInclusionPolicy = "Honor"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read())
+    so = open(os.path.join(REF, S, "schedule_one.go")).read()
+    assert "\tprocessedNodes := len(feasibleNodes) + diagnosis.NodeToStatus.Len()\n\tsched.nextStartNodeIndex = (sched.nextStartNodeIndex + processedNodes) % len(allNodes)\n" in so
+    assert "\tschedFramework.Parallelizer().Until(ctx, numAllNodes, checkNode, metrics.Filter)\n\tfeasibleNodes = feasibleNodes[:feasibleNodesLen]\n" in so
     assert re.search(r'LabelHostname = "kubernetes.io/hostname"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/well_known_labels.go")).read())
     ptsf = open(os.path.join(REF, S, "framework/plugins/podtopologyspread/filtering.go")).read()
     assert "return &criticalPaths{{MatchNum: math.MaxInt32}, {MatchNum: math.MaxInt32}}" in ptsf  # newCriticalPaths, as the lambda above has it
@@ -1001,6 +1015,38 @@ def vectors(env):
             env["ipaNormalizeScore"](norm)
         rows.append([hard_w, inc_aff, inc_anti, nodes, filtered, int(skipped), sorted([k, sorted([list(kv) for kv in m.items()])] for k, m in state.topologyScore.items()), raw, norm])
     v["ipaPreScoreScore"] = rows
+    # the node search of one cycle (schedule_one.go:610-693 + :538-539): numNodesToFind, the visiting order from nextStartNodeIndex, the search
+    # cancelled by the (K+1)-th feasible node, the nodes processed, the next start index.  ONE worker taking the positions in order (the oracle's
+    # canonical mode): parallelizer.Until with one worker checks the context before every piece
+    rows = []
+    for _ in range(1500):
+        n = rnd.choice([rnd.randint(1, 99), rnd.randint(100, 400), rnd.randint(100, 400), 100, 101, 125])
+        pct = rnd.choice([0, 0, 5, 30, 50, 99, 100])
+        scoring = rnd.random() < 0.85  # a profile without Score plugins keeps ONE feasible node (:619-621)
+        start = rnd.randrange(n)
+        p_feas = rnd.choice([0.0, 0.02, 0.3, 0.7, 1.0])
+        feas = [rnd.random() < p_feas for _ in range(n)]
+        num_to_find = env["numFeasibleNodesToFind"](types.SimpleNamespace(percentageOfNodesToScore=0), pct, n)
+        if not scoring:
+            num_to_find = 1
+        ok, bad = types.SimpleNamespace(Code=lambda: "Success", IsSuccess=lambda: True), types.SimpleNamespace(Code=lambda: "Unschedulable", IsSuccess=lambda: False)
+        infos = [types.SimpleNamespace(idx=i, Node=lambda i=i: types.SimpleNamespace(Name=f"n{i}")) for i in range(n)]
+        fw = types.SimpleNamespace(RunFilterPluginsWithNominatedPods=lambda ctx, state, pod, info: ok if feas[info.idx] else bad)
+        sched = types.SimpleNamespace(nextStartNodeIndex=start)
+        counter = types.SimpleNamespace(v=0)
+        counter.add = lambda d, c=counter: (setattr(c, "v", c.v + d), c.v)[1]
+        ctx = types.SimpleNamespace(cancelled=None)
+        cancel = lambda why, ctx=ctx: setattr(ctx, "cancelled", why)
+        feasible_nodes, result = [None] * num_to_find, [None] * n
+        for i in range(n):  # Until(ctx, numAllNodes, checkNode, ...), one worker
+            if ctx.cancelled:
+                break
+            env["findNodesThatPassFilters_checkNode"](i, sched, infos, n, fw, ctx, None, None, None, cancel, counter, num_to_find, feasible_nodes, result)
+        feasible_nodes = feasible_nodes[: counter.v]                      # feasibleNodes = feasibleNodes[:feasibleNodesLen]
+        processed = len(feasible_nodes) + sum(r is not None for r in result)  # processedNodes := len(feasibleNodes) + diagnosis.NodeToStatus.Len()
+        next_start = (start + processed) % n                               # sched.nextStartNodeIndex = (... + processedNodes) % len(allNodes)
+        rows.append([n, pct, int(scoring), start, [int(f) for f in feas], [x.idx for x in feasible_nodes], processed, next_start])
+    v["findNodesThatPassFilters"] = rows
     # RunScorePlugins: weight x normalized score per plugin, summed per node
     rows = []
     for _ in range(600):

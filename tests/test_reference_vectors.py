@@ -46,7 +46,8 @@ def test_transliterations_are_line_by_line():
         two_value_lookups += sum(bool(re.match(r"for \w+ := .+; ; \w+ = ", l)) for l in go)  # `for x := f(); ; x = f() {`: `while True:` + the call
         named_result = 1 if re.search(r"\) \(\w+ [\[\]\w.]+\) \{$", s["go"].split("\n")[0]) else 0  # `(n int)`: one line that sets its zero value
         joined = s.get("joined", 0)  # lines absorbed into the one before: a condition continued after && / ||, a composite literal's fields
-        assert len(go) - dropped + two_value_lookups + named_result - joined == len(py), name
+        closers = 1 if name == "findNodesThatPassFilters_checkNode" else 0  # the `})` that ends the func() { ... } argument of SendErrorWithCancel: a brace
+        assert len(go) - dropped + two_value_lookups + named_result - joined - closers == len(py), name
 
 
 def test_least_allocated(ccref):
@@ -248,6 +249,31 @@ def test_ipa_prescore_and_score(ccref):
         assert (totals[2] == 0) == bool(skipped), where
         got_raw, got_norm, got_skipped = ccref.unit_ipa_scores(nodes, pod, filtered)
         assert got_skipped == bool(skipped) and got_raw == raw and got_norm == norm, (got_raw, raw, got_norm, norm, where)
+
+
+def test_node_search_of_one_cycle(ccref):
+    """schedule_one.go:610-693 (findNodesThatPassFilters' per-position closure: the visiting order from nextStartNodeIndex, the search cancelled by
+    the (K+1)-th feasible node) and :538-539 (nodes processed -> the next start index), driven by one worker in order, against ONE cycle of the
+    oracle from the same start index: the same number of nodes visited, the same number of feasible nodes kept, the same next start index, a
+    winner among the nodes the reference kept (the first of them for a profile without Score plugins)."""
+    import dataclasses
+    import numpy as np
+    import helpers as H
+    from cluster_capacity_amd import model as M
+    for n, pct, scoring, start, feas, kept, processed, next_start in VEC["findNodesThatPassFilters"]:
+        # feasibility through NodeResourcesFit: an infeasible node has no pod slot left
+        nodes = H.simple_nodes([4000] * n, [8 * H.GiB] * n, [110 if f else 0 for f in feas])
+        pod = H.simple_pod(100, 64 * H.MiB)
+        prof = dataclasses.replace(M.Profile.default(), percentage_of_nodes_to_score=pct)
+        if not scoring:
+            prof = dataclasses.replace(prof, w_taint=0, w_nodeaffinity=0, w_fit=0, w_balanced=0, w_topologyspread=0, w_interpodaffinity=0, w_imagelocality=0)
+        winner, evaluated, n_feasible, nxt = ccref.schedule_one(prof, nodes, pod, start)
+        where = (n, pct, scoring, start)
+        if not kept:
+            assert winner == -1 and evaluated == n, where  # FitError: every node was visited (the start index is not read again)
+            continue
+        assert evaluated == processed and n_feasible == len(kept) and nxt == next_start, (evaluated, processed, n_feasible, len(kept), nxt, next_start, where)
+        assert winner in kept and (scoring or winner == kept[0]), (winner, kept[:5], where)
 
 
 def test_weigh_and_sum(ccref):
