@@ -99,6 +99,7 @@ FUNCS += [
 # func(index int) {`) is cut as a function of its index; the harness calls it for 0..n-1 in order (the pieces write disjoint slots).
 I = S + "/framework/plugins/interpodaffinity/filtering.go"
 IS = S + "/framework/plugins/interpodaffinity/scoring.go"
+KT = "vendor/k8s.io/kube-scheduler/framework/types.go"
 P = S + "/framework/plugins/podtopologyspread"
 FUNCS += [
     ("topologyToMatchedTermCount_update", I, "func (m topologyToMatchedTermCount) update(node *v1.Node, tk string, value int64) {", ["m", "node", "tk", "value"], False),
@@ -144,6 +145,13 @@ FUNCS += [
     # to be in the source and written out by the harness
     ("findNodesThatPassFilters_checkNode", S + "/schedule_one.go", "\tcheckNode := func(i int) {",
      ["i", "sched", "nodes", "numAllNodes", "schedFramework", "ctx", "state", "pod", "errCh", "cancel", "feasibleNodesLen", "numNodesToFind", "feasibleNodes", "result"], False),
+    # NodePorts (nodeports/node_ports.go:176-185 over HostPortInfo, kube-scheduler/framework/types.go:427-538): sanitize, NewProtocolPort,
+    # CheckConflict, fitsPorts.  *string parameters are one-element lists; the map key *pp is the (protocol, port) pair; HostPortInfo.Add's
+    # insertion is the harness's (it calls the transliterated sanitize)
+    ("HostPortInfo_sanitize", KT, "func (h HostPortInfo) sanitize(ip, protocol *string) {", ["h", "ip", "protocol"], False),
+    ("NewProtocolPort", KT, "func NewProtocolPort(protocol string, port int32) *ProtocolPort {", ["protocol", "port"], False),
+    ("HostPortInfo_CheckConflict", KT, "func (h HostPortInfo) CheckConflict(ip, protocol string, port int32) bool {", ["h", "ip", "protocol", "port"], False),
+    ("fitsPorts", S + "/framework/plugins/nodeports/node_ports.go", "func fitsPorts(wantPorts []v1.ContainerPort, nodeInfo fwk.NodeInfo) bool {", ["wantPorts", "nodeInfo"], False),
     ("ptsScore", P + "/scoring.go", "func (pl *PodTopologySpread) Score(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) (int64, *fwk.Status) {",
      ["s", "node", "nodeInfo", "pod"], False),
 ]
@@ -170,6 +178,13 @@ REWRITE = {
                                            (r"^length := atomic\.AddInt32\(&feasibleNodesLen, 1\)$", "length := feasibleNodesLen.add(1)"),
                                            (r"^atomic\.AddInt32\(&feasibleNodesLen, -1\)$", "feasibleNodesLen.add(-1)"),
                                            (r"^result\[i\] = &nodeStatus\{node: nodeInfo\.Node\(\)\.Name, status: status\}$", "result[i] = (nodeInfo.Node().Name, status)")],
+    "HostPortInfo_sanitize": [(r"\*ip\b", "ip[0]"), (r"\*protocol\b", "protocol[0]"), (r"string\(v1\.ProtocolTCP\)", "ProtocolTCP")],
+    "NewProtocolPort": [(r"string\(v1\.ProtocolTCP\)", "ProtocolTCP")],
+    "HostPortInfo_CheckConflict": [(r"^h\.sanitize\(&ip, &protocol\)$", "ipp, protop = [ip], [protocol]; HostPortInfo_sanitize(h, ipp, protop); ip, protocol = ipp[0], protop[0]"),
+                                   (r"^for _, m := range h \{$", "for _, m := range h.values() {"), (r"^if _, ok := m\[\*pp\]; ok \{$", "if (pp.Protocol, pp.Port) in m {"),
+                                   (r"^if _, ok2 := m\[\*pp\]; ok2 \{$", "if (pp.Protocol, pp.Port) in m {"),
+                                   (r"^for _, key := range \[\]string\{DefaultBindAllHostIP, ip\} \{$", "for key in [DefaultBindAllHostIP, ip] {")],
+    "fitsPorts": [(r"existingPorts\.CheckConflict\(", "HostPortInfo_CheckConflict(existingPorts, "), (r"string\(cp\.Protocol\)", "cp.Protocol")],
     "scoreMap_processTerm": [(r"= make\(map\[string\]int64\)$", "= GoMap()")],
     "scoreMap_processTerms": [(r"^m\.processTerm\(", "scoreMap_processTerm(m, ")],
     "ipa_processExistingPod": [(r"^topoScore\.processTerms\(", "scoreMap_processTerms(topoScore, "), (r"^topoScore\.processTerm\(", "scoreMap_processTerm(topoScore, ")],
@@ -359,6 +374,8 @@ def transliterate(name, params, body, int_div, opts=None):
                 ln = f"for {ml.group(1)}, {ml.group(2)} in sorted({ml.group(3)}.items()):"
             elif ln.startswith("if "):
                 ln = "if " + ln[3:] + ":"
+            elif re.fullmatch(r"for \w+ in \[[\w., ]+\]", ln):  # (a REWRITE put a Go range over a slice literal into this form)
+                ln = ln + ":"
             else:
                 raise SystemExit(f"{name}: cannot transliterate {raw!r}")
         else:
@@ -645,10 +662,13 @@ def build():
            # round 3: the loop-level pieces
            "GoStruct": GoStruct, "gocopy": gocopy, "GoHeap": GoHeap, "heap": GoContainerHeap, "go_math_log": go_math_log, "MinNodeScore": 0, "NodeInclusionPolicyHonor": "Honor",
            "LabelHostname": "kubernetes.io/hostname", "go_round": go_round, "GoMap": GoMap, "GoPtrMap": GoPtrMap,
+           "DefaultBindAllHostIP": "0.0.0.0", "ProtocolTCP": "TCP",
            "newCriticalPaths": lambda: [GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1), GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1)]}
     iface = open(os.path.join(REF, S, "framework/interface.go")).read()
     assert re.search(r"MinNodeScore int64 = 0\b", iface) and re.search(r"MaxNodeScore int64 = %d\b" % PINS["score.max_node_score"], iface)
     assert re.search(r'NodeInclusionPolicyHonor NodeInclusionPolicy = "Honor"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read())
+    kt = open(os.path.join(REF, KT)).read()
+    assert 'const DefaultBindAllHostIP = "0.0.0.0"' in kt and re.search(r'ProtocolTCP Protocol = "TCP"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read())
     so = open(os.path.join(REF, S, "schedule_one.go")).read()
     assert "\tprocessedNodes := len(feasibleNodes) + diagnosis.NodeToStatus.Len()\n\tsched.nextStartNodeIndex = (sched.nextStartNodeIndex + processedNodes) % len(allNodes)\n" in so
     assert "\tschedFramework.Parallelizer().Until(ctx, numAllNodes, checkNode, metrics.Filter)\n\tfeasibleNodes = feasibleNodes[:feasibleNodesLen]\n" in so
@@ -1047,6 +1067,24 @@ def vectors(env):
         next_start = (start + processed) % n                               # sched.nextStartNodeIndex = (... + processedNodes) % len(allNodes)
         rows.append([n, pct, int(scoring), start, [int(f) for f in feas], [x.idx for x in feasible_nodes], processed, next_start])
     v["findNodesThatPassFilters"] = rows
+    # NodePorts: the wanted host ports of a pod against the ports in use on a node -- empty ip / protocol (0.0.0.0 / TCP), the wildcard ip on either
+    # side, ports <= 0 (no host port), the same port under another protocol or another ip
+    rows = []
+    ips, protos, ports = ["", "0.0.0.0", "10.0.0.1", "10.0.0.2"], ["", "TCP", "UDP"], [0, 80, 80, 443, 8080]
+    for _ in range(2500):
+        mkp = lambda: {"hostIP": rnd.choice(ips), "protocol": rnd.choice(protos), "hostPort": rnd.choice(ports)}
+        used, want = [mkp() for _ in range(rnd.choice([0, 1, 2, 4]))], [mkp() for _ in range(rnd.choice([0, 1, 2, 3]))]
+        h = {}
+        for u in used:  # HostPortInfo.Add (types.go:458-474): port > 0, sanitize, insert
+            if u["hostPort"] <= 0:
+                continue
+            ipp, protop = [u["hostIP"]], [u["protocol"]]
+            env["HostPortInfo_sanitize"](h, ipp, protop)
+            pp = env["NewProtocolPort"](protop[0], u["hostPort"])
+            h.setdefault(ipp[0], {})[(pp.Protocol, pp.Port)] = True
+        info = types.SimpleNamespace(GetUsedPorts=lambda h=h: h)
+        rows.append([used, want, env["fitsPorts"]([types.SimpleNamespace(HostIP=w["hostIP"], Protocol=w["protocol"], HostPort=w["hostPort"]) for w in want], info)])
+    v["fitsPorts"] = rows
     # RunScorePlugins: weight x normalized score per plugin, summed per node
     rows = []
     for _ in range(600):

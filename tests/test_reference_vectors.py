@@ -47,6 +47,8 @@ def test_transliterations_are_line_by_line():
         named_result = 1 if re.search(r"\) \(\w+ [\[\]\w.]+\) \{$", s["go"].split("\n")[0]) else 0  # `(n int)`: one line that sets its zero value
         joined = s.get("joined", 0)  # lines absorbed into the one before: a condition continued after && / ||, a composite literal's fields
         closers = 1 if name == "findNodesThatPassFilters_checkNode" else 0  # the `})` that ends the func() { ... } argument of SendErrorWithCancel: a brace
+        if name == "HostPortInfo_CheckConflict":
+            two_value_lookups -= 2  # `if _, ok := m[*pp]; ok {` twice: a membership test on the (protocol, port) pair, one line each (make_reference_vectors.REWRITE)
         assert len(go) - dropped + two_value_lookups + named_result - joined - closers == len(py), name
 
 
@@ -413,6 +415,15 @@ def test_pod_topology_spread_filter(ccref):
                 assert r.n_code_unschedulable == (1 if code == "Unschedulable" else 0), (code, i)
             checked += 1
     assert checked == 3600
+
+
+def test_node_ports():
+    """nodeports/node_ports.go:176-185 over HostPortInfo (sanitize, NewProtocolPort, CheckConflict): the ingest's host_ports + ports_conflict give the
+    same verdict for every pair of (ports in use on the node, ports the pod wants)."""
+    from cluster_capacity_amd import ingest
+    spec = lambda ps: {"containers": [{"ports": [{k: v for k, v in p.items() if v != ""} for p in ps]}]}
+    for used, want, fits in VEC["fitsPorts"]:
+        assert (not ingest.ports_conflict(ingest.host_ports(spec(want)), set(ingest.host_ports(spec(used))))) == fits, (used, want, fits)
 
 
 def test_zone_key():
