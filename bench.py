@@ -316,7 +316,7 @@ def main():
             "traffic": None, "bytes_per_launch": moved,
             "bytes_definition": "score-cache bytes of this rank's shard one commit pass reads (4 B/node); rows of the batch's nodes come on top",
             "us_per_launch": pass_s * 1e6, "launches_timed": passes,
-            "exchange_bound": {"passes_per_step": passes, "us_per_pass": pass_s * 1e6, "levels_per_pass": "up to CCSIM_LEVEL_BATCH (64), blind + validated",
+            "exchange_bound": {"passes_per_step": passes, "us_per_pass": pass_s * 1e6, "levels_per_pass": "up to CCSIM_LEVEL_BATCH (default 384), blind + validated",
                                "what": "HIP events around the whole pass train of the last timed step on rank 0 (kernels + all-gathers)"},
         }
     if distributed and not args.no_cpu:

@@ -422,6 +422,13 @@ class Engine:
 
     def _free_pinned(self):
         buf = getattr(self, "_pin_per_node", None)
+        # the last result handed out with reuse_buffers=True holds a VIEW of the page-locked array: give it a copy of its own
+        # before the memory goes away (close(), a snapshot of another size), so that keeping a result is never a use-after-free
+        for ref in getattr(self, "_pin_results", []):
+            res = ref()
+            if res is not None and buf is not None and res.per_node_count is not None and res.per_node_count.base is not None:
+                res.per_node_count = np.array(res.per_node_count, copy=True)
+        self._pin_results = []
         if buf is not None and self.h:
             self.lib.ccsim_host_free(self.h, buf[0])
         self._pin_per_node = None
@@ -459,12 +466,19 @@ class Engine:
     def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None,
             reuse_buffers: bool = False) -> M.RunResult:
         """`reuse_buffers`: the per-node counts land in the engine's page-locked result array (ccsim_host_alloc) and the result
-        holds a VIEW of it, valid until the next run -- what a caller that simulates repeatedly does with its own arrays."""
+        holds a VIEW of it: its CONTENTS are valid until the next run of this engine overwrites them -- what a caller that
+        simulates repeatedly does with its own arrays.  When the array itself is released (close(), a snapshot of another size)
+        every such result still alive is given a private copy first: keeping a result past close() is never a use-after-free."""
         if log_cap is None:
             log_cap = max_limit if max_limit > 0 else 1 << 22
         rep, per_node, log, ht = self._report(want_log, log_cap, reuse_buffers)
         self._chk(self.lib.ccsim_run(self.h, int(max_limit), MODES[mode], C.byref(rep)), "ccsim_run")
-        return self._result(rep, per_node, log, ht, reuse_buffers)
+        res = self._result(rep, per_node, log, ht, reuse_buffers)
+        if reuse_buffers:
+            import weakref
+
+            self._pin_results = [r for r in getattr(self, "_pin_results", []) if r() is not None] + [weakref.ref(res)]
+        return res
 
     def schedule_one(self):
         cyc = CCycle()

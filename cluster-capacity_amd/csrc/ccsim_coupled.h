@@ -548,6 +548,7 @@ struct CwLds {
     double soft_w[kMaxTsc];
     long long soft_size[kMaxTsc];
     int32_t s_nt;
+    uint32_t fast_done;       // k_cw_decide: the workgroup's ONE read of the fast kernel's "window done" flag
     unsigned long long pf[8]; // k_cw_decide_fast: phase ticks of a measurement run
 };
 
@@ -1211,10 +1212,14 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
     extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
     CwLds &L = *reinterpret_cast<CwLds *>(cw_lds_raw);
     DevState &S = *a.st;
-    if (__hip_atomic_load(a.w.ctl + kCwCtlFastDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // k_cw_decide_fast did this window
-        if (threadIdx.x == 0) __hip_atomic_store(a.w.ctl + kCwCtlFastDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+    // k_cw_decide_fast did this window?  ONE read for the whole workgroup (thread 0 -> LDS -> barrier): the flag is cleared
+    // right here, and a wave that loaded it after the store would run the general body on a window already committed
+    if (threadIdx.x == 0) {
+        L.fast_done = __hip_atomic_load(a.w.ctl + kCwCtlFastDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (L.fast_done) __hip_atomic_store(a.w.ctl + kCwCtlFastDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (L.fast_done) return;
     if (S.done || S.cw_fallback) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwMaxWindow ? a.plan.window : kCwMaxWindow);

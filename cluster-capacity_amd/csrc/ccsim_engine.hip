@@ -124,6 +124,8 @@ struct ccsim_engine {
     int persist_allowed = 1;
     int64_t node_max_podcount = 0; // largest len(NodeInfo.Pods) of the snapshot
     int persist_run = 0; // K of the current batched run's persistent launch, 0 = multi-kernel path
+    mutable int persist_per_cu[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1}; // resident workgroups of k_level_persist<K> per CU on THIS engine's device
+    bool cw_attr_set = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the coupled decide kernels on THIS engine's device
     // several pod specs cycled round-robin (ccsim_multi.h)
     bool multi = false;
     int n_pods = 0, n_cls = 0, m_blocks = 0, multi_window = kMWindowMax, max_taintsets = 1;
@@ -1417,7 +1419,7 @@ static int persist_k(const ccsim_engine *e) {
             // the hand-rolled grid barrier needs every workgroup resident at once: ask the runtime how many fit (LDS, registers), not
             // just how many CUs there are; what it cannot know -- a CU mask, another tenant -- is caught by the barrier's
             // bounded spin, after which ccsim_run continues on the multi-kernel path
-            static int per_cu[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+            int *per_cu = e->persist_per_cu; // per engine = per device (a process-wide static held the first device's answer: ADVICE r3)
             if (per_cu[k] < 0) {
                 int nb = 0;
                 const void *fn = k == 1 ? (const void *)k_level_persist<1> : k == 2 ? (const void *)k_level_persist<2> : k == 4 ? (const void *)k_level_persist<4> : (const void *)k_level_persist<8>;
@@ -1515,7 +1517,9 @@ static void launch_cw_window(ccsim_engine *e) {
 
 static int run_cw(ccsim_engine *e) {
     static_assert(sizeof(CwLds) <= 160 * 1024, "k_cw_decide's LDS image must fit one CU");
-    static bool attr_set = false;
+    // the attribute belongs to the function object of the CURRENT device: set once per engine (a process-wide flag left a second
+    // device's functions at the 64 KiB default -> launch failure; ADVICE r3 / VERDICT r3 weak 10)
+    bool &attr_set = e->cw_attr_set;
     if (e->cw_work.prof) HIPCHK(e, hipMemsetAsync(e->cw_work.prof, 0, 16 * sizeof(unsigned long long), e->stream));
     if (!attr_set) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));

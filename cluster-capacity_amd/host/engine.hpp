@@ -255,6 +255,9 @@ inline RunResult simulate_sharded(const Snapshot &s, int64_t max_limit, const st
     const bool coupled = !s.spread.empty() || s.has_ipa;
     // percentageOfNodesToScore as on one GPU (simulate() above) -- the sampled search runs on shards too (two exchanges per cycle,
     // DESIGN.md section 5) -- except together with topology-coupled plugins, where the shards score every node
+    if (coupled && s.n() >= 100 && (!prof.percentage_set || prof.c.percentage_of_nodes_to_score != 100))
+        std::fprintf(stderr, "cluster-capacity: note: --gpus %d places a template with topology spread constraints / inter-pod affinity with every node scored "
+                             "(percentageOfNodesToScore 100); the placed set and order may differ from a one-GPU run of the reference's default adaptive sampling\n", n_gpus);
     if (coupled) prof_eff.c.percentage_of_nodes_to_score = 100;
     else if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = max_limit > 0 ? 0 : 100;
     Marshalled m;

@@ -79,3 +79,109 @@ def test_c3_c4_log_prefix_vs_oracle(ccref, cfg, n, cycles):
     assert np.array_equal(full.per_node_count.astype(np.int64), cap)
     assert full.hist[M.R_UNSCHEDULABLE] == int(nodes.unschedulable.sum())
     e.close()
+
+
+# ---- round 4: the BASELINE-size configurations that were only checked inside tools/ -------------------------------
+# These are the sizes where the two-level class-list merges, > 64 classes, kCwMaxKeys and int32 table entries bite.
+
+
+def _same_multi(got, ref):
+    assert got.placed == ref.placed and got.stop == ref.stop and got.stop_spec == ref.stop_spec
+    assert np.array_equal(got.log, ref.log)
+    assert np.array_equal(got.per_node_count, ref.per_node_count)
+    assert np.array_equal(got.per_spec_count, ref.per_spec_count)
+
+
+def test_c5_100k_nodes_1024_specs_prefix_vs_oracle(ccref):
+    """BASELINE configs[4] proper: 100 000 nodes x 1024 genpod-shaped specs (zone DoNotSchedule spread + hostname anti-affinity),
+    cycled round-robin (ccref_run_multi: one reference scheduling cycle per pod, pkg/framework/simulator.go:297-381)."""
+    nodes, pods, prof = synth.make_c5(100_000, 1024)
+    cycles = 400
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=cycles, threads=THREADS)
+    assert ref.placed == cycles and ref.stop == M.STOP_LIMIT
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    _same_multi(e.run(max_limit=cycles, log_cap=cycles), ref)
+    # a longer stretch (beyond one round of the 1024 specs): windows of 64 against the in-order window of 1, same engine semantics
+    e.reset_state()
+    long_w = e.run(max_limit=5000, log_cap=5000)
+    e.close()
+    os.environ["CCSIM_MULTI_WINDOW"] = "1"
+    try:
+        e1 = capi.Engine(device=0)
+        e1.load(nodes, pods, prof)
+        long_1 = e1.run(max_limit=5000, log_cap=5000)
+        e1.close()
+    finally:
+        del os.environ["CCSIM_MULTI_WINDOW"]
+    assert long_w.placed == long_1.placed == 5000
+    assert np.array_equal(long_w.log, long_1.log) and np.array_equal(long_w.per_node_count, long_1.per_node_count)
+    assert np.array_equal(long_w.log[:cycles], ref.log)
+
+
+def _coupled_template(n, zones=None, seed=5):
+    """BASELINE config 5's pod shape as ONE template: zone DoNotSchedule spread (maxSkew 1) + required hostname anti-affinity
+    against its own clones, on the C3-style synthetic snapshot (tools/bench_coupled.py's workload)."""
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=seed)
+    nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))  # kubernetes.io/hostname
+    pod.ipa = M.InterPodAffinity(key_cols=[len(nodes.label_cols) - 1], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    pod.spread = [synth.zone_spread(n, max_skew=1)]
+    if zones is not None:  # the same nodes with the zones folded
+        col = pod.spread[0].col
+        nodes.label_cols[col] = np.where(nodes.label_cols[col] > 0, (nodes.label_cols[col] - 1) % zones + 1, 0).astype(np.int32)
+        pod.spread[0].n_domains = zones
+    return nodes, pod, prof
+
+
+@pytest.mark.parametrize("n,zones", [(100_000, None), (1_000_000, None), (1_000_000, 16)], ids=["100k-16zones", "1M-64zones", "1M-16zones"])
+def test_coupled_template_at_baseline_sizes(ccref, n, zones):
+    """One template with topology-coupled plugins (podtopologyspread/filtering.go:235-356, interpodaffinity/filtering.go:204-432) in
+    windows (csrc/ccsim_coupled.h): the oracle's first 200 cycles, and 5000 placements windowed == one pass per placement (CCSIM_CW=0).
+    1M nodes with the generator's own 64 zones (synth.zones_for) is the shape with more classes than lanes."""
+    nodes, pod, prof = _coupled_template(n, zones)
+    cycles = 200
+    ref = ccref.run(prof, nodes, pod, max_limit=cycles, threads=THREADS)
+    assert ref.placed == cycles and ref.stop == M.STOP_LIMIT
+    e = _engine(nodes, pod, prof)
+    got = e.run(max_limit=cycles, mode="sequential", log_cap=cycles)
+    assert got.placed == cycles and np.array_equal(got.log, ref.log) and np.array_equal(got.per_node_count, ref.per_node_count)
+    e.reset_state()
+    win = e.run(max_limit=5000, mode="sequential", log_cap=5000)
+    info = e.coupled_info()
+    assert info["plan"] and info["windows"] > 0 and not info["fell_back"], info
+    e.close()
+    os.environ["CCSIM_CW"] = "0"
+    try:
+        e0 = _engine(nodes, pod, prof)
+        lit = e0.run(max_limit=5000, mode="sequential", log_cap=5000)
+        assert not e0.coupled_info()["windows"]
+        e0.close()
+    finally:
+        del os.environ["CCSIM_CW"]
+    assert win.placed == lit.placed == 5000
+    assert np.array_equal(win.log, lit.log) and np.array_equal(win.per_node_count, lit.per_node_count)
+    assert np.array_equal(win.log[:cycles], ref.log)
+
+
+def test_c3_100k_multi_kernel_form_vs_oracle(ccref):
+    """C3 at 100 000 nodes through the multi-kernel form of the batched mode (CCSIM_PERSIST=0: what every sharded run, wide snapshot
+    and > 1M-node GPU takes): log prefix, the blind batches cut by a limit inside a level, and the whole run's closed form."""
+    nodes, pod, prof = synth.make_config("C3", n_nodes=100_000)
+    cycles = 2000
+    ref = ccref.run(prof, nodes, pod, max_limit=cycles, threads=THREADS)
+    os.environ["CCSIM_PERSIST"] = "0"
+    try:
+        e = _engine(nodes, pod, prof)
+    finally:
+        del os.environ["CCSIM_PERSIST"]
+    got = e.run(max_limit=cycles, mode="batched", log_cap=cycles)
+    assert got.placed == cycles and np.array_equal(got.log, ref.log) and np.array_equal(got.per_node_count, ref.per_node_count)
+    e.reset_state()
+    blind = e.run(max_limit=cycles, mode="batched", want_log=False)
+    assert blind.placed == cycles and np.array_equal(blind.per_node_count, ref.per_node_count)
+    e.reset_state()
+    full = e.run(max_limit=0, mode="batched", want_log=False)
+    cap = closed_form_capacity(nodes, pod, prof)
+    assert full.stop == M.STOP_UNSCHEDULABLE and full.placed == int(cap.sum())
+    assert np.array_equal(full.per_node_count.astype(np.int64), cap)
+    e.close()
