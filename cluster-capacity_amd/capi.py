@@ -518,11 +518,12 @@ class Engine:
 
     def persist_prof(self):
         """Phase breakdown of the last persistent batched launch (ccsim_debug_persist_prof), in microseconds."""
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 16)()
         self._chk(self.lib.ccsim_debug_persist_prof(self.h, out), "ccsim_debug_persist_prof")
         names = ["scan_list", "plan", "apply", "block_reduce", "grid_reduce", "rescore"]
         d = {k: out[i] / 100.0 for i, k in enumerate(names)}
         d["levels"] = int(out[6])
+        d["load"], d["rescore_maxima"], d["write_back"] = out[7] / 100.0, out[8] / 100.0, out[10] / 100.0
         return d
 
     # ---- distributed stepping (collective supplied by the caller, see dist.py) ----

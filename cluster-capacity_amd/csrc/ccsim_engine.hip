@@ -119,12 +119,23 @@ struct ccsim_engine {
     int64_t *d_blockprefix = nullptr;
     int rank = 0;
     // persistent batched run (ccsim_persist.h)
-    PersistSync *d_psync = nullptr;
+    PersistSync *d_psync = nullptr; // [kPMaxRanks]: one per virtual rank of a validation run, [0] otherwise
+    // mailbox form of the persistent kernel (ccsim_persist.h): this device's box (fine-grained, peer-mapped) and every rank's box as this
+    // device addresses it.  Virtual ranks (CCSIM_PERSIST_VRANKS, validation on one GPU): kPMaxRanks boxes in one allocation.
+    PersistMailbox *d_mbox = nullptr;
+    PersistMailbox *mbox_peers[kPMaxRanks] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<void *> mbox_ipc_open;  // peers' boxes opened through IPC handles (other processes)
+    bool mbox_ready = false;            // the boxes of all comm_ranks ranks are mapped
+    uint32_t persist_seq = 0;           // launch sequence of the mailbox form (tags: nothing is zeroed between launches)
+    int persist_vranks = 0;             // CCSIM_PERSIST_VRANKS: run the single-device batched mode as that many virtual ranks
+    bool reset_pending = false;         // ccsim_reset_state deferred the restore of the node columns: the next persistent launch loads the
+                                        // pristine copies directly; everything else restores first (ensure_cols)
+    bool hist_in_kernel = false;        // the last persistent launch filled d_hist / d_hist_ts itself (no k_hist pass)
     int n_cus = 0;
     int persist_allowed = 1;
     int64_t node_max_podcount = 0; // largest len(NodeInfo.Pods) of the snapshot
     int persist_run = 0; // K of the current batched run's persistent launch, 0 = multi-kernel path
-    mutable int persist_per_cu[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1}; // resident workgroups of k_level_persist<K> per CU on THIS engine's device
+    mutable int persist_per_cu[2][9] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1}}; // resident workgroups of k_level_persist<K, MB> per CU on THIS engine's device
     bool cw_attr_set = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the coupled decide kernels on THIS engine's device
     // several pod specs cycled round-robin (ccsim_multi.h)
     bool multi = false;
@@ -215,6 +226,7 @@ static int build_narrow(ccsim_engine *e);
 static int cw_make_plan(ccsim_engine *e);
 static bool label_col_unique(const ccsim_engine *e, int col);
 static int persist_k(const ccsim_engine *e);
+static int ensure_cols(ccsim_engine *e);
 
 template <typename T>
 static int upload(ccsim_engine *e, T **out, const T *src, size_t count, size_t padded, std::vector<void *> &track) {
@@ -258,6 +270,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     if (const char *f = getenv("CCSIM_PERSIST")) e->persist_allowed = atoi(f); // A/B knob: 0 = multi-kernel batched mode
     if (const char *f = getenv("CCSIM_CW")) e->cw_allowed = atoi(f);           // A/B knob: 0 = coupled plugins one pass per placement
     if (const char *f = getenv("CCSIM_FUSED")) e->fused_allowed = atoi(f);     // A/B knob: 0 = sequential cycle as k_scan + k_final
+    if (const char *f = getenv("CCSIM_PERSIST_VRANKS")) e->persist_vranks = atoi(f) > 1 && atoi(f) <= kPMaxRanks ? atoi(f) : 0; // validation knob
     if (hipSetDevice(e->device) != hipSuccess) {
         delete e;
         return -EIO;
@@ -280,7 +293,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
         hipMalloc((void **)&e->d_smp_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_smp_prefix, sizeof(int64_t) * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess ||
-        hipMalloc((void **)&e->d_psync, sizeof(PersistSync)) != hipSuccess) {
+        hipMalloc((void **)&e->d_psync, sizeof(PersistSync) * kPMaxRanks) != hipSuccess) {
         ccsim_destroy(e);
         return -ENOMEM;
     }
@@ -335,6 +348,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     drop_graph(e);
     free_list(e->allocs);
     e->backups.clear();
+    e->reset_pending = false;
     e->backup_bytes.clear();
     e->have_nodes = e->have_pod = e->begun = false;
     e->multi = false;
@@ -622,6 +636,7 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     if (!e->have_nodes || !e->have_profile) return fail(e, -EINVAL, "load nodes and set the profile first");
     if (int vrc = validate_pod(e, pod)) return vrc;
     HIPCHK(e, hipSetDevice(e->device));
+    if (int erc = ensure_cols(e)) return erc; // (a deferred ccsim_reset_state: the columns this pod's mirrors are built from)
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->pod_allocs);
@@ -1384,14 +1399,17 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     }
     if (st.done == DONE_UNSCHEDULABLE && e->n > 0) {
         // terminal round: FitError diagnosis (types.go:787-836)
-        HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
-        HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
-        HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state, e->ipa,
-                   e->ports_on ? 1 : 0, e->d_alloc_pods_real, e->d_ports_base};
-        int64_t hb = (e->n + kThreads - 1) / kThreads;
-        if (hb > 2048) hb = 2048;
-        hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
-        HIPCHK(e, hipGetLastError());
+        if (!e->hist_in_kernel) { // (the persistent launch fills the histogram itself, from the node state it holds in LDS)
+            HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
+            HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
+            HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state, e->ipa,
+                       e->ports_on ? 1 : 0, e->d_alloc_pods_real, e->d_ports_base};
+            int64_t hb = (e->n + kThreads - 1) / kThreads;
+            if (hb > 2048) hb = 2048;
+            hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
+            HIPCHK(e, hipGetLastError());
+        }
+        e->hist_in_kernel = false;
         std::vector<unsigned long long> hh(CCSIM_NREASON + 1), ht((size_t)e->n_taintsets);
         HIPCHK(e, hipMemcpyAsync(hh.data(), e->d_hist, sizeof(unsigned long long) * hh.size(), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipMemcpyAsync(ht.data(), e->d_hist_ts, sizeof(unsigned long long) * ht.size(), hipMemcpyDeviceToHost, e->stream));
@@ -1408,8 +1426,13 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
 
 // The persistent form of the batched mode (ccsim_persist.h): narrow mirrors, one 512-thread workgroup (kPThreads) per CU with up to
 // 4096 nodes each in LDS, scores and pod counts in 16 bits.  Everything else takes the multi-kernel path.
-static int persist_k(const ccsim_engine *e) {
-    if (!e->persist_allowed || !e->cols.narrow || e->pod.nx != 0 || e->n_ranks != 0 || e->n_cus <= 0 || e->n <= 0) return 0;
+// `mb`: the mailbox form (several ranks; its own instantiation, hence its own occupancy answer); `sharded`: this engine holds one shard.
+static const void *persist_fn(int k, bool mb) {
+    if (mb) return k == 1 ? (const void *)k_level_persist<1, true> : k == 2 ? (const void *)k_level_persist<2, true> : k == 4 ? (const void *)k_level_persist<4, true> : (const void *)k_level_persist<8, true>;
+    return k == 1 ? (const void *)k_level_persist<1, false> : k == 2 ? (const void *)k_level_persist<2, false> : k == 4 ? (const void *)k_level_persist<4, false> : (const void *)k_level_persist<8, false>;
+}
+static int persist_k_impl(const ccsim_engine *e, bool mb, bool sharded) {
+    if (!e->persist_allowed || !e->cols.narrow || e->pod.nx != 0 || (!sharded && e->n_ranks != 0) || e->n_cus <= 0 || e->n <= 0) return 0;
     if (e->node_max_pods > 65535 || e->node_max_podcount > 65535) return 0;
     const int64_t max_total = 100ll * ((int64_t)e->pod.w_taint + e->pod.w_aff + e->pod.w_fit + e->pod.w_bal + e->pod.w_img);
     if (max_total >= 65535) return 0;
@@ -1419,25 +1442,58 @@ static int persist_k(const ccsim_engine *e) {
             // the hand-rolled grid barrier needs every workgroup resident at once: ask the runtime how many fit (LDS, registers), not
             // just how many CUs there are; what it cannot know -- a CU mask, another tenant -- is caught by the barrier's
             // bounded spin, after which ccsim_run continues on the multi-kernel path
-            int *per_cu = e->persist_per_cu; // per engine = per device (a process-wide static held the first device's answer: ADVICE r3)
+            int *per_cu = e->persist_per_cu[mb ? 1 : 0]; // per engine = per device (a process-wide static held the first device's answer: ADVICE r3)
             if (per_cu[k] < 0) {
                 int nb = 0;
-                const void *fn = k == 1 ? (const void *)k_level_persist<1> : k == 2 ? (const void *)k_level_persist<2> : k == 4 ? (const void *)k_level_persist<4> : (const void *)k_level_persist<8>;
-                per_cu[k] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kPThreads, 0) == hipSuccess ? nb : 0;
+                per_cu[k] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, persist_fn(k, mb), kPThreads, 0) == hipSuccess ? nb : 0;
             }
             const int64_t grid = (e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads);
             return (int64_t)per_cu[k] * e->n_cus >= grid ? k : 0;
         }
     return 0;
 }
+static int persist_k(const ccsim_engine *e) { return persist_k_impl(e, e->persist_vranks > 0, false); }
 
-static int run_persist(ccsim_engine *e, int k) {
+// the deferred half of ccsim_reset_state: the node columns back from their pristine copies, the mirrors and the NodePorts clamp after them
+static int ensure_cols(ccsim_engine *e) {
+    if (!e->reset_pending) return 0;
+    e->reset_pending = false;
+    HIPCHK(e, hipSetDevice(e->device));
+    for (size_t i = 0; i < e->backups.size(); i++)
+        HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
+    if (e->have_pod) {
+        int rc = build_narrow(e);
+        if (rc) return rc;
+        if (e->ports_on) { // the NodePorts clamp follows the restored pod counts
+            hipLaunchKernelGGL(k_ports_clamp, dim3((unsigned)((e->n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, e->d_ports_eff,
+                               e->d_ports_base, e->d_alloc_pods_real, (const int32_t *)e->cols.pod_count, e->n_pad);
+            HIPCHK(e, hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+static void launch_persist(ccsim_engine *e, int k, bool mb, int grid, const PersistArgs &a) {
+#define CCSIM_PERSIST_LAUNCH(KK, MBB) hipLaunchKernelGGL((k_level_persist<KK, MBB>), dim3(grid), dim3(kPThreads), 0, e->stream, a)
+    if (mb) {
+        if (k == 1) CCSIM_PERSIST_LAUNCH(1, true); else if (k == 2) CCSIM_PERSIST_LAUNCH(2, true); else if (k == 4) CCSIM_PERSIST_LAUNCH(4, true); else CCSIM_PERSIST_LAUNCH(8, true);
+    } else {
+        if (k == 1) CCSIM_PERSIST_LAUNCH(1, false); else if (k == 2) CCSIM_PERSIST_LAUNCH(2, false); else if (k == 4) CCSIM_PERSIST_LAUNCH(4, false); else CCSIM_PERSIST_LAUNCH(8, false);
+    }
+#undef CCSIM_PERSIST_LAUNCH
+}
+
+static PersistArgs persist_args(ccsim_engine *e) {
     PersistArgs a{};
     const DevCols &c = e->cols;
-    a.c = PersistCols{{c.a32[0], c.a32[1]}, {c.r32[0], c.r32[1]}, {c.z32[0], c.z32[1]}, c.alloc_pods, c.pod_count, c.placed_cnt, c.stat,
-                      {c.req[0], c.req[1]}, c.nz_mcpu, c.nz_mem, c.n_pad, c.global_offset, c.mem_shift};
+    a.c = PersistCols{};
+    a.c.a32[0] = c.a32[0], a.c.a32[1] = c.a32[1], a.c.r32[0] = c.r32[0], a.c.r32[1] = c.r32[1], a.c.z32[0] = c.z32[0], a.c.z32[1] = c.z32[1];
+    a.c.alloc_pods = c.alloc_pods, a.c.pod_count = c.pod_count, a.c.placed_cnt = c.placed_cnt, a.c.stat = c.stat;
+    a.c.req[0] = c.req[0], a.c.req[1] = c.req[1], a.c.nz_mcpu = c.nz_mcpu, a.c.nz_mem = c.nz_mem;
+    a.c.n_pad = c.n_pad, a.c.global_offset = c.global_offset, a.c.mem_shift = c.mem_shift, a.c.n = c.n;
+    a.c.sreason = c.sreason, a.c.taintset_id = c.taintset_id, a.c.n_taintsets = e->n_taintsets, a.c.rows = c.rows;
     a.p = e->pod, a.st = e->d_state, a.sync = e->d_psync, a.log = e->d_log, a.want_log = e->d_log ? 1 : 0;
-    a.max_syncs = 1 << 20;
+    a.max_syncs = 1 << 19;
     a.seq_steps = 8;
     if (const char *f = getenv("CCSIM_SEQ_STEPS")) a.seq_steps = atoi(f) > 0 ? atoi(f) : kSeqSteps; // tuning knob
     // levels per blind batch, measured on the C4 snapshot.  Round 2 (every state of a run-down evaluated): 16 -> 1.97 ms, 64 -> 1.57, 128 -> 1.64.
@@ -1450,14 +1506,59 @@ static int run_persist(ccsim_engine *e, int k) {
     if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     if (const char *f = getenv("CCSIM_PERSIST_FAULT")) a.fault = atoi(f); // test knob: the lost-workgroup path (tests/test_persist.py)
+    return a;
+}
+
+// this engine's mailbox(es): fine-grained device memory (coherent for peers' writes over xGMI and for system-scope polls)
+static int mbox_alloc(ccsim_engine *e) {
+    if (e->d_mbox) return 0;
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, sizeof(PersistMailbox) * kPMaxRanks, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(e, hipMalloc(&p, sizeof(PersistMailbox) * kPMaxRanks)); // (virtual ranks on one device work in ordinary memory too)
+    }
+    HIPCHK(e, hipMemset(p, 0, sizeof(PersistMailbox) * kPMaxRanks));
+    e->d_mbox = (PersistMailbox *)p;
+    return 0;
+}
+
+static int run_persist(ccsim_engine *e, int k) {
+    PersistArgs a = persist_args(e);
     const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
+    // validation of the mailbox form on ONE device: the grid's workgroups split into virtual ranks with separate sync blocks and
+    // mailboxes -- the protocol of a sharded run (ccsim_dist_run), same memory scopes, no second process
+    const bool mb = e->persist_vranks > 0;
+    int sync_blocks = 1;
+    if (mb) {
+        int rc = mbox_alloc(e);
+        if (rc) return rc;
+        int v = e->persist_vranks < grid ? e->persist_vranks : grid;
+        a.bpr = (grid + v - 1) / v;
+        a.vranks = a.n_ranks = (grid + a.bpr - 1) / a.bpr;
+        a.rank = 0;
+        for (int r = 0; r < a.n_ranks; r++) a.mbox[r] = e->d_mbox + r;
+        sync_blocks = a.n_ranks;
+    }
+    // the FitError diagnosis of the terminal cycle comes out of the launch itself (the node state is in LDS): no k_hist pass.  Not with
+    // host ports (the clamped pod capacity hides the real one) and not in the mailbox form (its state goes to the commit rows).
+    const bool diag = !mb && !e->ports_on;
     for (int launch = 0; launch < 64; launch++) {
-        HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync), e->stream));
+        a.c.from_pristine = e->reset_pending ? 1 : 0;
+        if (e->reset_pending) { // (backups: the wide columns in load order -- req[0 .. ncol), nz_mcpu, nz_mem, pod_count)
+            a.c.p_req[0] = (const int64_t *)e->backups[0].second, a.c.p_req[1] = (const int64_t *)e->backups[1].second;
+            a.c.p_nz[0] = (const int64_t *)e->backups[(size_t)e->ncol].second, a.c.p_nz[1] = (const int64_t *)e->backups[(size_t)e->ncol + 1].second;
+            a.c.p_pod_count = (const int32_t *)e->backups[(size_t)e->ncol + 2].second;
+        }
+        a.c.cnt_assign = launch == 0 ? 1 : 0; // (begin_run zeroed the per-run counts)
+        a.c.hist = diag ? e->d_hist : nullptr, a.c.hist_ts = e->d_hist_ts, a.c.hist_code = e->d_hist_code;
+        if (mb) a.tag_base = (e->persist_seq++ & 0xfffu) << 20;
+        HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync) * (size_t)sync_blocks, e->stream));
+        if (diag) {
+            HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
+            HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
+        }
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-        if (k == 1) hipLaunchKernelGGL(k_level_persist<1>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
-        else if (k == 2) hipLaunchKernelGGL(k_level_persist<2>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
-        else if (k == 4) hipLaunchKernelGGL(k_level_persist<4>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
-        else hipLaunchKernelGGL(k_level_persist<8>, dim3(grid), dim3(kPThreads), 0, e->stream, a);
+        launch_persist(e, k, mb, grid, a);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
         int rc = read_state(e);
@@ -1465,11 +1566,26 @@ static int run_persist(ccsim_engine *e, int k) {
         float ms = 0;
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->kernel_ms += ms, e->pass_kernel_ms += ms, e->pass_launches += 1;
-        if (e->h_state->done == DONE_ERROR) { // nothing was written back (ccsim_persist.h): the caller redoes the run on the multi-kernel path
+        bool failed = e->h_state->done == DONE_ERROR;
+        if (mb && !failed) { // a rank may have given up after rank 0 wrote the state: every rank's flag counts
+            std::vector<PersistSync> hs((size_t)sync_blocks);
+            HIPCHK(e, hipMemcpy(hs.data(), e->d_psync, sizeof(PersistSync) * (size_t)sync_blocks, hipMemcpyDeviceToHost));
+            for (const auto &b : hs) failed = failed || b.err[0] != 0;
+        }
+        if (failed) { // nothing was written back (ccsim_persist.h): the caller redoes the run on the multi-kernel path
             if (launch == 0) return -EAGAIN;
             return fail(e, -EIO, "persistent level kernel: grid barrier timed out (a workgroup was not resident)");
         }
-        if (e->h_state->done) return 0;
+        e->reset_pending = false; // the columns hold this launch's state now
+        if (mb) { // every (virtual) rank succeeded: the commit rows become the columns
+            const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
+            hipLaunchKernelGGL(k_rows_flush, dim3(blocks), dim3(kThreads), 0, e->stream, e->cols, e->d_state, 0);
+            HIPCHK(e, hipGetLastError());
+        }
+        if (e->h_state->done) {
+            e->hist_in_kernel = diag && e->h_state->done == DONE_UNSCHEDULABLE;
+            return 0;
+        }
     }
     return fail(e, -EIO, "persistent level kernel did not finish");
 }
@@ -1558,10 +1674,18 @@ static int run_cw(ccsim_engine *e) {
 extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
     if (!e || !out) return -EINVAL;
     out->stop_spec = -1;
-    if (e->multi) return run_multi(e, max_limit, out);
+    int rc;
+    if (e->multi) {
+        if ((rc = ensure_cols(e))) return rc;
+        return run_multi(e, max_limit, out);
+    }
     e->n_ranks = 0;
     e->d_xsend = e->d_xrecv = nullptr;
-    int rc = begin_run(e, max_limit, mode, out->log ? out->log_cap : 0);
+    e->hist_in_kernel = false;
+    // a pending ccsim_reset_state is consumed by the persistent launch itself (it loads the pristine columns); every other form
+    // restores the columns first
+    if (!(mode == CCSIM_MODE_BATCHED && !e->time_passes && e->have_pod && persist_k(e)) && (rc = ensure_cols(e))) return rc;
+    rc = begin_run(e, max_limit, mode, out->log ? out->log_cap : 0);
     if (rc) return rc;
     if (e->n == 0) { // schedule_one.go:438-440 ErrNoNodesAvailable
         e->h_state->done = DONE_UNSCHEDULABLE;
@@ -1571,6 +1695,7 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         rc = run_persist(e, e->persist_run);
         if (rc == -EAGAIN) { // its grid barrier could not be satisfied on this device right now: the multi-kernel form, from the untouched state
             e->persist_allowed = 0;
+            if ((rc = ensure_cols(e))) return rc;
             if ((rc = begin_run(e, max_limit, mode, out->log ? out->log_cap : 0))) return rc;
         } else {
             if (rc) return rc;
@@ -1615,6 +1740,7 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
 extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
     if (!e || !out) return -EINVAL;
     int rc;
+    if ((rc = ensure_cols(e))) return rc;
     if (!e->begun || e->h_state->done != DONE_RUNNING || e->mode != CCSIM_MODE_SEQUENTIAL || e->n_ranks != 0) {
         // first cycle, or a ccsim_run has finished on this engine: a fresh run state on the current columns
         e->n_ranks = 0;
@@ -1649,6 +1775,7 @@ extern "C" int ccsim_read_state(ccsim_engine *e, int64_t *req_mcpu, int64_t *req
                                 int32_t *pod_count) {
     if (!e || !e->have_nodes) return -EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
+    if (int erc = ensure_cols(e)) return erc;
     const size_t n = (size_t)e->n;
     if (req_mcpu) HIPCHK(e, hipMemcpyAsync(req_mcpu, e->cols.req[0], 8 * n, hipMemcpyDeviceToHost, e->stream));
     if (req_mem) HIPCHK(e, hipMemcpyAsync(req_mem, e->cols.req[1], 8 * n, hipMemcpyDeviceToHost, e->stream));
@@ -1665,6 +1792,7 @@ extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int
     if (!e || iters <= 0 || !total_ns) return -EINVAL;
     int rc;
     e->n_ranks = 0;
+    if ((rc = ensure_cols(e))) return rc;
     if ((rc = begin_run(e, 0, mode, 0))) return rc; // fresh state: a finished run leaves done != 0
     HIPCHK(e, hipSetDevice(e->device));
     const bool lvl = mode == CCSIM_MODE_BATCHED; // k_level_score: the batched mode's full pass
@@ -1689,6 +1817,7 @@ extern "C" int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int
 extern "C" int ccsim_dist_begin(ccsim_engine *e, int64_t max_limit, int32_t mode, int32_t n_ranks, int32_t rank,
                                 void *sendbuf, void *recvbuf, int64_t log_cap) {
     if (!e || n_ranks < 1 || rank < 0 || rank >= n_ranks || !sendbuf || !recvbuf) return -EINVAL;
+    if (int erc = ensure_cols(e)) return erc;
     e->n_ranks = n_ranks;
     e->rank = rank;
     e->d_xsend = (XRec *)sendbuf;
@@ -1766,22 +1895,21 @@ extern "C" int ccsim_dist_tables_done(ccsim_engine *e) {
 extern "C" int ccsim_reset_state(ccsim_engine *e) {
     if (!e || !e->have_nodes) return -EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
-    for (size_t i = 0; i < e->backups.size(); i++)
-        HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
+    // The node columns (~44 B per node to copy, the mirrors to rebuild: 0.05 ms at 1M nodes) are restored LAZILY when the next run can
+    // load the pristine copies itself -- the persistent batched launch does (ccsim_persist.h `from_pristine`) -- and by whichever
+    // entry point touches the columns first otherwise (ensure_cols).
+    e->n_ranks = 0;
+    const bool lazy = e->have_pod && !e->multi && !e->ports_on && !e->time_passes && persist_k(e) != 0 && !getenv("CCSIM_EAGER_RESET");
+    e->reset_pending = true;
+    if (!lazy) {
+        int rc = ensure_cols(e);
+        if (rc) return rc;
+    }
     // (placed_cnt is a per-run result: begin_run zeroes it)
     for (size_t c = 0; c < e->pts_tables.size(); c++)
         HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].first, e->pts_tables[c].second, e->pts_table_len[c] * 4, hipMemcpyDeviceToDevice, e->stream));
     for (size_t c = 0; c < e->ipa_tables.size(); c++)
         HIPCHK(e, hipMemcpyAsync(e->ipa_tables[c].first, e->ipa_tables[c].second, e->ipa_table_len[c] * 8, hipMemcpyDeviceToDevice, e->stream));
-    if (e->have_pod) {
-        int rc = build_narrow(e);
-        if (rc) return rc;
-        if (e->ports_on) { // the NodePorts clamp follows the restored pod counts
-            hipLaunchKernelGGL(k_ports_clamp, dim3((unsigned)((e->n_pad + kThreads - 1) / kThreads)), dim3(kThreads), 0, e->stream, e->d_ports_eff,
-                               e->d_ports_base, e->d_alloc_pods_real, (const int32_t *)e->cols.pod_count, e->n_pad);
-            HIPCHK(e, hipGetLastError());
-        }
-    }
     if (e->multi) { // the specs' own plugin state: spread count tables, anti-affinity bitmap, the round-robin position
         HIPCHK(e, hipMemcpyAsync(e->d_tbl_pool, e->d_tbl_pool0, e->tbl_len * 4, hipMemcpyDeviceToDevice, e->stream));
         HIPCHK(e, hipMemcpyAsync(e->d_anti_bits, e->d_anti_bits0, e->anti_words * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -1804,10 +1932,10 @@ extern "C" void ccsim_host_free(ccsim_engine *e, void *p) {
 }
 
 // measurement aid: s_memtime ticks (100 MHz) workgroup 0 of the last persistent launch spent per phase
-extern "C" int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out8) {
-    if (!e || !out8) return -EINVAL;
+extern "C" int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out16) {
+    if (!e || !out16) return -EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipMemcpy(out8, e->d_psync->prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(out16, e->d_psync->prof, sizeof(int64_t) * 16, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -2064,6 +2192,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     for (int p = 0; p < n_pods; p++)
         if ((rc = validate_pod(e, &pods[p]))) return rc;
     HIPCHK(e, hipSetDevice(e->device));
+    if (int erc = ensure_cols(e)) return erc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->pod_allocs);
@@ -2427,8 +2556,9 @@ extern "C" int ccsim_schedule_pod(ccsim_engine *e, int32_t pod_idx, ccsim_cycle 
     if (!e->multi) return pod_idx == 0 ? ccsim_schedule_one(e, out) : fail(e, -EINVAL, "one pod spec is set: pod_idx must be 0");
     if (pod_idx < 0 || pod_idx >= e->n_pods) return fail(e, -EINVAL, "pod_idx out of range");
     // (per-node / per-spec result counters restart: this is one cycle at the SchedulePod seam, not a run)
-    int rc = begin_multi(e, 0, 0, pod_idx);
+    int rc = ensure_cols(e);
     if (rc) return rc;
+    if ((rc = begin_multi(e, 0, 0, pod_idx))) return rc;
     const MultiArgs a = multi_args(e);
     out->node = -1, out->evaluated_nodes = (int32_t)e->n_global, out->feasible_nodes = 0;
     for (int tries = 0; tries < 8; tries++) {

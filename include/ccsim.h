@@ -369,9 +369,10 @@ void ccsim_host_free(ccsim_engine *e, void *p);
 int ccsim_time_scan(ccsim_engine *e, int32_t mode, int32_t iters, int64_t *total_ns, int64_t *bytes_per_scan);
 
 /* Measurement aid: where the last persistent batched launch (csrc/ccsim_persist.h) spent its time.
- * out8: 10 ns ticks of workgroup 0 in [0] level scan + work list, [1] run-down planning, [2] commit + re-score,
- * [3] block reduction, [4] grid-wide reduce + barrier, [5] full re-score phases; [6] = levels; [7] unused. */
-int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out8);
+ * out16: 10 ns ticks of workgroup 0 in [0] level scan + work list, [1] run-down planning (+ the blind batch's apply), [2] ordered commit +
+ * re-score, [3] block reduction, [4] grid-wide reduce + barrier, [5] re-score: scores + event prediction + reduce; [6] = level passes;
+ * [7] load HBM -> LDS, [8] re-score: normalization maxima (+ reduce), [9] (unused), [10] write-back + FitError diagnosis; [11..15] unused. */
+int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out16);
 /* ... and why the windows of the last multi-spec run (ccsim_set_pods, P > 1) ended: out8[r] = windows ended by reason r
  * (0 complete, 1 a normalization maximum was re-derived, 2 Unschedulable, 3 too few holders of a maximum left untouched,
  * 4 the candidate bounds could not prove the choice, 5 every candidate touched and full, 6 touched-node table full, 7 limit). */

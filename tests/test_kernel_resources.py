@@ -25,8 +25,11 @@ def test_streaming_kernels_use_no_scratch_and_do_not_spill():
         limit = 0 if ("<0," in k or "<" not in k) else (96 if "<9," in k else 64)
         assert int(rows[k]["ScratchSize"]) <= limit, (k, rows[k])
         assert rows[k]["VGPRs Spill"] == "0", (k, rows[k])  # (SGPRs may spill into VGPR lanes: no memory traffic)
-    for k in ("k_level_persist<1>", "k_level_persist<2>", "k_level_persist<4>", "k_level_persist<8>", "k_multi_scan", "k_multi_commit_par"):
+    persist = [f"k_level_persist<{k},{mb}>" for k in (1, 2, 4, 8) for mb in (0, 1)]  # (local grid reduce, mailbox form)
+    for k in persist + ["k_multi_scan", "k_multi_commit_par"]:
         assert rows[k]["VGPRs Spill"] == "0", (k, rows[k])
+    for k in persist:  # 512-thread workgroups, one per CU: 2 waves per SIMD is all the kernel is launched with
+        assert int(rows[k]["ScratchSize"]) == 0 and int(rows[k]["Occupancy"]) >= 2, (k, rows[k])
     assert rows["k_multi_scan"]["ScratchSize"] == "0" and rows["k_multi_commit_par"]["ScratchSize"] == "0"
     for k in ("k_final", "k_decide"):  # one working copy of DevState, nothing else (not the 1.7 KB argument block)
         assert int(rows[k]["ScratchSize"]) <= 768, (k, rows[k])

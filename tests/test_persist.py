@@ -131,3 +131,58 @@ def test_fallback_when_the_snapshot_does_not_qualify(ccref):
     ref = ccref.run(M.Profile.default(), nodes, pod, max_limit=0)
     got, _ = _run(nodes, pod, M.Profile.default(), 0, False)
     _same(got, ref, check_log=False)
+
+
+@pytest.mark.parametrize("vranks", ["2", "3", "4", "8"])
+@pytest.mark.parametrize("cfg,n,limit", [("C3", 4096, 0), ("C3", 4096, 700), ("C2", 5000, 300), ("C3", 20_000, 12_345), ("C3", 1500, 0)])
+def test_mailbox_form_on_virtual_ranks(ccref, monkeypatch, vranks, cfg, n, limit):
+    """The cross-GPU form of the persistent kernel (ccsim_persist.h, MB = true: per-rank local reduce, the completing workgroup
+    publishes the rank's eight words as tagged 8-byte granules into every rank's mailbox, everybody polls its own box), validated on
+    ONE device: the grid's workgroups split into virtual ranks with separate sync blocks and mailboxes -- same protocol, same
+    system-scope accesses, commit rows published only after every rank succeeded.  Blind and ordered paths."""
+    monkeypatch.setenv("CCSIM_PERSIST_VRANKS", vranks)
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=4321 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    got, st = _run(nodes, pod, prof, limit, want_log=False)
+    _same(got, ref, check_log=False)
+    cnt = ref.per_node_count.astype(np.int64)
+    assert np.array_equal(st["req_mcpu"], nodes.req[0] + cnt * int(pod.req[0]))
+    assert np.array_equal(st["req_mem"], nodes.req[1] + cnt * int(pod.req[1]))
+    assert np.array_equal(st["pod_count"], nodes.pod_count + ref.per_node_count)
+    got, _ = _run(nodes, pod, prof, limit, want_log=True)  # ordered path: positions need the lower ranks' planned placements
+    _same(got, ref, check_log=True)
+
+
+@pytest.mark.parametrize("vranks", ["2", "5"])
+@pytest.mark.parametrize("seed", range(12))
+def test_mailbox_form_random_plugin_mix(ccref, monkeypatch, vranks, seed):
+    monkeypatch.setenv("CCSIM_PERSIST_VRANKS", vranks)
+    rng = np.random.default_rng(7000 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(600, 6000)))
+    limit = int(rng.choice([0, 0, 37, 500]))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    for want_log in (False, True):
+        got, _ = _run(nodes, pod, prof, limit, want_log)
+        _same(got, ref, check_log=want_log)
+
+
+def test_mailbox_form_1m_nodes_and_continued_runs(ccref, monkeypatch):
+    """C4 at 1M nodes on 8 virtual ranks of 32 workgroups: oracle prefix with the log, the closed-form exhaustive vector without; and a
+    run continued across launches (the commit rows of one launch are the columns the next one loads)."""
+    monkeypatch.setenv("CCSIM_PERSIST_VRANKS", "8")
+    nodes, pod, prof = synth.make_config("C4", n_nodes=1_000_000)
+    ref = ccref.run(prof, nodes, pod, max_limit=300, threads=16)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    a = e.run(max_limit=300, mode="batched", log_cap=300)
+    assert a.placed == 300 and np.array_equal(a.log, ref.log) and np.array_equal(a.per_node_count, ref.per_node_count)
+    b = e.run(max_limit=0, mode="batched", want_log=False, log_cap=0)  # continues from the state the first launch left
+    free_c, free_m = nodes.alloc[0] - nodes.req[0], nodes.alloc[1] - nodes.req[1]
+    cap = np.minimum(np.minimum(free_c // 150, free_m // (100 << 20)), (nodes.alloc_pods - nodes.pod_count).astype(np.int64)).clip(0)
+    cap = np.where((nodes.unschedulable == 0), cap, 0)
+    assert a.placed + b.placed == int(cap.sum())
+    assert np.array_equal((a.per_node_count + b.per_node_count).astype(np.int64), cap)
+    e.reset_state()
+    c = e.run(max_limit=0, mode="batched", want_log=False, log_cap=0)
+    assert c.placed == int(cap.sum()) and np.array_equal(c.per_node_count.astype(np.int64), cap) and np.array_equal(c.hist, b.hist)
+    e.close()

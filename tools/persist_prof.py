@@ -35,5 +35,6 @@ for steps, batch in [(s_, b_) for b_ in batches for s_ in sweep]:
     lv = max(1, p["levels"])
     print(f"batch={batch:3d} seq_steps={steps:3d} placed={r.placed} levels={p['levels']} passes={r.scans} kernel={r0.kernel_ns/1e6:.3f} ms (stamped run {r.kernel_ns/1e6:.3f} ms) "
           f"({r.kernel_ns/1e3/lv:.2f} us/level) | per level us: " +
-          " ".join(f"{k}={v/lv:.2f}" for k, v in p.items() if k not in ("levels", "rescore")) + f" | rescore total {p['rescore']:.1f} us", flush=True)
+          " ".join(f"{k}={v/lv:.2f}" for k, v in p.items() if k in ("scan_list", "plan", "apply", "block_reduce", "grid_reduce")) +
+          f" | whole run us: load {p['load']:.1f}, rescore maxima {p['rescore_maxima']:.1f} + scores/prediction/reduce {p['rescore']:.1f}, write-back + diagnosis {p['write_back']:.1f}", flush=True)
     e.close()
