@@ -131,6 +131,12 @@ struct ccsim_engine {
     bool reset_pending = false;         // ccsim_reset_state deferred the restore of the node columns: the next persistent launch loads the
                                         // pristine copies directly; everything else restores first (ensure_cols)
     bool hist_in_kernel = false;        // the last persistent launch filled d_hist / d_hist_ts itself (no k_hist pass)
+    bool persist_hint = false;          // persist_hint_mt / _ma: the normalization maxima the last persistent launch of this pod started with
+    int32_t persist_hint_mt = 0, persist_hint_ma = 0;
+    // ... and its results left for the host right behind the kernel, before the host knew how the launch ended (one stream sync per run):
+    bool early_counts = false, early_hist = false;
+    unsigned long long *h_hist_pin = nullptr; // page-locked [CCSIM_NREASON + 1 + h_hist_ts_cap]
+    size_t h_hist_ts_cap = 0;
     int n_cus = 0;
     int persist_allowed = 1;
     int64_t node_max_podcount = 0; // largest len(NodeInfo.Pods) of the snapshot
@@ -325,6 +331,7 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->d_psync) (void)hipFree(e->d_psync);
     if (e->d_log) (void)hipFree(e->d_log);
     if (e->h_state) (void)hipHostFree(e->h_state);
+    if (e->h_hist_pin) (void)hipHostFree(e->h_hist_pin);
     dist_comm_release(e);
     for (hipEvent_t ev : e->pass_events) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -643,6 +650,7 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     free_list(e->multi_allocs);
     e->multi = false;
     e->have_pod = e->begun = false;
+    e->persist_hint = false;
     e->n_taintsets = pod->n_taintsets;
 
     const ccsim_profile &pf = e->prof;
@@ -1234,7 +1242,8 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     st.log_cap = e->log_cap;
     *e->h_state = st;
     HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
+    if (!(mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes && persist_k(e))) // (the persistent launch WRITES the per-run counts: cnt_assign)
+        HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
     if (e->d_log && e->n_ranks > 0) // shards fill disjoint positions of the global log: -1 = "not mine"
         HIPCHK(e, hipMemsetAsync(e->d_log, 0xff, sizeof(int32_t) * (size_t)e->log_cap, e->stream));
     e->kernel_ms = 0;
@@ -1372,7 +1381,7 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     // The per-node counts (4 MB at 1M nodes: 75 us over PCIe) and the log leave on a second stream, beside the terminal round's
     // diagnosis pass (k_hist: 33 us at 1M nodes) and its small copies -- both only read the final state.
     hipStream_t cs = e->stream;
-    if (e->n >= (1 << 16) && st.done == DONE_UNSCHEDULABLE && (out->per_node_count || (out->log && e->d_log))) {
+    if (e->n >= (1 << 16) && st.done == DONE_UNSCHEDULABLE && !e->early_counts && (out->per_node_count || (out->log && e->d_log))) {
         if (!e->copy_stream) {
             if (hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking) != hipSuccess) e->copy_stream = nullptr;
             if (e->copy_stream && hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming) != hipSuccess) {
@@ -1388,8 +1397,10 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     }
     if (out->per_node_count) {
         if (out->per_node_cap < e->n) return fail(e, -EINVAL, "per_node_cap too small");
-        HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, cs));
+        if (!e->early_counts) // (the persistent launch's counts are on the host already)
+            HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, cs));
     }
+    e->early_counts = false;
     out->log_len = 0;
     if (out->log && e->d_log) {
         int64_t len = st.placed < e->log_cap ? st.placed : e->log_cap;
@@ -1397,7 +1408,13 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
         if (len > 0) HIPCHK(e, hipMemcpyAsync(out->log, e->d_log, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost, cs));
         out->log_len = len;
     }
-    if (st.done == DONE_UNSCHEDULABLE && e->n > 0) {
+    if (st.done == DONE_UNSCHEDULABLE && e->n > 0 && e->hist_in_kernel && e->early_hist) { // diagnosis by the persistent launch, copied behind it
+        for (int i = 0; i < CCSIM_NREASON; i++) out->hist[i] = (int64_t)e->h_hist_pin[i];
+        out->n_code_unschedulable = (int64_t)e->h_hist_pin[CCSIM_NREASON];
+        if (out->hist_taintset)
+            for (int i = 0; i < e->n_taintsets && i < out->hist_taintset_cap; i++) out->hist_taintset[i] = (int64_t)e->h_hist_pin[CCSIM_NREASON + 1 + i];
+        e->hist_in_kernel = e->early_hist = false;
+    } else if (st.done == DONE_UNSCHEDULABLE && e->n > 0) {
         // terminal round: FitError diagnosis (types.go:787-836)
         if (!e->hist_in_kernel) { // (the persistent launch fills the histogram itself, from the node state it holds in LDS)
             HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
@@ -1506,6 +1523,8 @@ static PersistArgs persist_args(ccsim_engine *e) {
     if (const char *f = getenv("CCSIM_LEVEL_BATCH")) a.level_batch = atoi(f) > 0 ? atoi(f) : 1; // tuning knob
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     if (const char *f = getenv("CCSIM_PERSIST_FAULT")) a.fault = atoi(f); // test knob: the lost-workgroup path (tests/test_persist.py)
+    a.spec_cut = e->n_global < (1ll << 24) && !(getenv("CCSIM_PERSIST_SPEC") && atoi(getenv("CCSIM_PERSIST_SPEC")) == 0); // (A/B knob)
+    a.hint_valid = e->persist_hint ? 1 : 0, a.hint_mt = e->persist_hint_mt, a.hint_ma = e->persist_hint_ma;
     return a;
 }
 
@@ -1522,7 +1541,7 @@ static int mbox_alloc(ccsim_engine *e) {
     return 0;
 }
 
-static int run_persist(ccsim_engine *e, int k) {
+static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
     PersistArgs a = persist_args(e);
     const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
     // validation of the mailbox form on ONE device: the grid's workgroups split into virtual ranks with separate sync blocks and
@@ -1561,12 +1580,35 @@ static int run_persist(ccsim_engine *e, int k) {
         launch_persist(e, k, mb, grid, a);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
-        int rc = read_state(e);
-        if (rc) return rc;
+        // the results leave right behind the kernel, before the host knows how the launch ended: the state block, the per-node
+        // counts (4 MB at 1M nodes: the step's longest transfer starts the moment the kernel ends), the diagnosis -- ONE sync
+        HIPCHK(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        e->early_counts = e->early_hist = false;
+        if (!mb && out && out->per_node_count && out->per_node_cap >= e->n) {
+            HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+            e->early_counts = true;
+        }
+        if (diag) {
+            const size_t nts = (size_t)(e->n_taintsets > 0 ? e->n_taintsets : 1);
+            if (!e->h_hist_pin || e->h_hist_ts_cap < nts) {
+                if (e->h_hist_pin) (void)hipHostFree(e->h_hist_pin);
+                e->h_hist_pin = nullptr;
+                HIPCHK(e, hipHostMalloc((void **)&e->h_hist_pin, sizeof(unsigned long long) * (CCSIM_NREASON + 1 + nts), hipHostMallocDefault));
+                e->h_hist_ts_cap = nts;
+            }
+            HIPCHK(e, hipMemcpyAsync(e->h_hist_pin, e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->h_hist_pin + CCSIM_NREASON + 1, e->d_hist_ts, sizeof(unsigned long long) * (size_t)e->n_taintsets, hipMemcpyDeviceToHost, e->stream));
+            e->early_hist = true;
+        }
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->ipa_aff_total_cur = e->h_state->ipa_aff_total, e->ipa_exist_total_cur = e->h_state->ipa_exist_total;
+        e->ipa_entries_cur = e->h_state->ipa_entries;
+        e->smp_start_cur = e->h_state->smp_start;
         float ms = 0;
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->kernel_ms += ms, e->pass_kernel_ms += ms, e->pass_launches += 1;
         bool failed = e->h_state->done == DONE_ERROR;
+        if (failed || !e->h_state->done) e->early_counts = e->early_hist = false;
         if (mb && !failed) { // a rank may have given up after rank 0 wrote the state: every rank's flag counts
             std::vector<PersistSync> hs((size_t)sync_blocks);
             HIPCHK(e, hipMemcpy(hs.data(), e->d_psync, sizeof(PersistSync) * (size_t)sync_blocks, hipMemcpyDeviceToHost));
@@ -1577,6 +1619,7 @@ static int run_persist(ccsim_engine *e, int k) {
             return fail(e, -EIO, "persistent level kernel: grid barrier timed out (a workgroup was not resident)");
         }
         e->reset_pending = false; // the columns hold this launch's state now
+        e->persist_hint = true, e->persist_hint_mt = e->h_state->p_mt0, e->persist_hint_ma = e->h_state->p_ma0;
         if (mb) { // every (virtual) rank succeeded: the commit rows become the columns
             const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
             hipLaunchKernelGGL(k_rows_flush, dim3(blocks), dim3(kThreads), 0, e->stream, e->cols, e->d_state, 0);
@@ -1681,7 +1724,7 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
     }
     e->n_ranks = 0;
     e->d_xsend = e->d_xrecv = nullptr;
-    e->hist_in_kernel = false;
+    e->hist_in_kernel = e->early_counts = e->early_hist = false;
     // a pending ccsim_reset_state is consumed by the persistent launch itself (it loads the pristine columns); every other form
     // restores the columns first
     if (!(mode == CCSIM_MODE_BATCHED && !e->time_passes && e->have_pod && persist_k(e)) && (rc = ensure_cols(e))) return rc;
@@ -1692,7 +1735,7 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         return fill_report(e, out);
     }
     if (e->persist_run) { // begin_run chose the persistent form of the batched mode
-        rc = run_persist(e, e->persist_run);
+        rc = run_persist(e, e->persist_run, out);
         if (rc == -EAGAIN) { // its grid barrier could not be satisfied on this device right now: the multi-kernel form, from the untouched state
             e->persist_allowed = 0;
             if ((rc = ensure_cols(e))) return rc;

@@ -227,6 +227,8 @@ struct DevState {
     // windowed mode for topology-coupled plugins (ccsim_coupled.h)
     int32_t cw_fallback;     // 1 = the windowed mode gave up on this run: the one-pass-per-placement loop continues from the current state
     int32_t cw_windows;      // windows resolved so far
+    // persistent batched launch (ccsim_persist.h): the normalization maxima the launch started with (the next launch's hint)
+    int32_t p_mt0, p_ma0;
 };
 
 // per-block result of one scan: 16 bytes

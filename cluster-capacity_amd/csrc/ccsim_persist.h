@@ -43,7 +43,7 @@ constexpr unsigned kGenErr = 0xffffffffu; // PersistSync::gen: the run is abando
 constexpr int kPSpinLimit = 1 << 22;
 
 struct PersistSync { // global memory, one per rank; zeroed by the host before every launch
-    unsigned long long slot[2][kPGroups][8]; // [parity][group][word]; words 0,3,4: tagged max; 1,2,5,6,7: cumulative add
+    unsigned long long slot[2][kPGroups][8]; // [parity][group][word]; words 0,3,4,5,6: tagged max; 1,2,7: cumulative add
     unsigned int garrive[kPGroups][16];      // cumulative arrivals per group (one 64-byte line each)
     unsigned int top[16];                    // cumulative group completions
     unsigned int gen[16];                    // generations released so far; kGenErr: abandoned.  Advanced ONLY by compare-and-swap, so a
@@ -100,6 +100,8 @@ struct PersistArgs {
     int32_t level_batch; // fast path: score levels resolved per grid-wide sync (>= 1)
     int32_t prof;        // measurement runs: per-phase s_memrealtime stamps (each stamp costs a few hundred ns)
     int32_t fault;       // test knob (CCSIM_PERSIST_FAULT=1): workgroup 0 never arrives at the first barrier -- the lost-workgroup path
+    int32_t spec_cut;    // every global node index fits 24 bits: the event prediction carries the node, and a blind batch may END at the event
+    int32_t hint_valid, hint_mt, hint_ma; // the normalization maxima the last launch STARTED with (assumed, verified in the scores' reduce)
     // mailbox form
     int32_t n_ranks, rank;   // ranks of the job / this device's rank (virtual ranks: rank of workgroup b = b / bpr)
     int32_t vranks, bpr;     // virtual ranks inside this grid (0 = a real rank per device), workgroups per virtual rank
@@ -126,8 +128,8 @@ __device__ __forceinline__ unsigned long long p_ld_sys_u64(const unsigned long l
 }
 
 // Grid-wide reduction + barrier.  Thread 0 has put this workgroup's contribution into s_v[0..7] (LDS; zero = nothing to
-// add); on return s_red[0..7] (LDS) holds the result over every workgroup of every rank: words 0, 3, 4 combine with MAX
-// (payload < 2^40), the others with ADD.  One generation = one call by every workgroup.
+// add); on return s_red[0..7] (LDS) holds the result over every workgroup of every rank: words 0, 3, 4, 5, 6 combine with MAX
+// (payload < 2^40), words 1, 2, 7 with ADD.  One generation = one call by every workgroup.
 struct GridCtx {
     PersistSync *s;
     unsigned gen_no;             // generations completed
@@ -146,7 +148,7 @@ struct GridCtx {
     int *s_flag;                 // LDS: this workgroup completed its rank's local reduction
 };
 
-__device__ __forceinline__ bool is_max_word(int w) { return w == 0 || w == 3 || w == 4; }
+__device__ __forceinline__ bool is_max_word(int w) { return w == 0 || (w >= 3 && w <= 6); }
 
 // a value every lane holds identically (read from LDS): tell the compiler, so that it lives in SGPRs
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
@@ -312,6 +314,7 @@ __device__ __forceinline__ NodeNarrow nd_shfl(const NodeNarrow &n, int src) { //
     return o;
 }
 
+// M: the level the node runs down to -- PER LANE (a batch that ends inside a level takes that level only up to the cut: ev_cut)
 __device__ __forceinline__ int32_t wave_run_down_rows(const RunCtx &cx, const NodeNarrow &n, int32_t stat, int32_t M, bool mine, bool &feas_after,
                                                       int seq_steps) {
     const int lane = threadIdx.x & 63, row = lane >> 4, rl = lane & 15;
@@ -345,7 +348,7 @@ __device__ __forceinline__ int32_t wave_run_down_rows(const RunCtx &cx, const No
         }
         const bool active = src >= 0;
         const NodeNarrow base = nd_shfl(cur, active ? src : 0);
-        const int32_t bstat = __shfl(stat, active ? src : 0, 64);
+        const int32_t bstat = __shfl(stat, active ? src : 0, 64), bM = __shfl(M, active ? src : 0, 64);
         const int32_t room = (int32_t)nd_room(base); // after `room` more placements the node is full
         int32_t j = 0;
         bool f_end = true, row_done = !active;
@@ -355,7 +358,7 @@ __device__ __forceinline__ int32_t wave_run_down_rows(const RunCtx &cx, const No
             const int32_t k = k0 + rl + 1;
             nd_apply(cx, t, k < room ? k : room);
             const bool f = nd_feasible(cx, t); // (k >= room: the pod count alone makes it infeasible)
-            const bool stop = !(f && nd_score(cx, t, (int64_t)bstat, NoRcp{}) >= (int64_t)M);
+            const bool stop = !(f && nd_score(cx, t, (int64_t)bstat, NoRcp{}) >= (int64_t)bM);
             const uint64_t sm = __ballot(stop), fm = __ballot(f);
             const uint32_t seg = (uint32_t)(sm >> (row * 16)) & 0xffffu;
             if (!row_done && seg) {
@@ -402,8 +405,23 @@ __device__ __forceinline__ unsigned long long comb_add(const unsigned long long 
     return (unsigned long long)wave_sum_i64((int64_t)((threadIdx.x & 63) < kPWaves ? arr[threadIdx.x & 63] : 0ull));
 }
 
+// Event keys: (0x10000 - level) << 24 | node (0 = none).  Their maximum is the LOWEST level and, of its nodes, the LAST: where a
+// normalization maximum loses its last feasible holder.  Of the two maxima the event that comes first in canonical order counts:
+// the higher level, then the lower node.
+__device__ __forceinline__ unsigned long long event_key(int32_t level, int64_t node) { return ((unsigned long long)(0x10000 - level) << 24) | (unsigned long long)node; }
+__device__ __forceinline__ void pick_event(unsigned long long kmt, unsigned long long kma, bool with_node, int32_t &ev_level, int64_t &ev_cut) {
+    ev_level = -1, ev_cut = -1;
+    if (kmt) ev_level = 0x10000 - (int32_t)(kmt >> 24), ev_cut = (int64_t)(kmt & 0xffffffull);
+    if (kma) {
+        const int32_t lv = 0x10000 - (int32_t)(kma >> 24);
+        const int64_t ct = (int64_t)(kma & 0xffffffull);
+        if (lv > ev_level || (lv == ev_level && ct < ev_cut)) ev_level = lv, ev_cut = ct;
+    }
+    if (!with_node) ev_cut = -1;
+}
+
 struct PBlockRed { // per-wave partials of a block reduction
-    unsigned long long mx[3][kPWaves]; // max-words 0, 3, 4
+    unsigned long long mx[5][kPWaves]; // max-words 0, 3, 4, 5, 6
     unsigned long long ad[2][kPWaves]; // add-words 1, 2
 };
 
@@ -503,15 +521,24 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
     // Only a guess for speed -- the validation decides again, and halving remains the fallback (round 2 halved from the start:
     // 14 of 33 iterations of a C4 run were rolled-back attempts).
     int32_t ev_level = -1;
+    // ... and WHICH node: the prediction (and a rolled-back batch's report) carries the index of the holder that goes last, so a blind
+    // batch may END at the event -- the levels above ev_level, and of level ev_level the nodes up to ev_cut, exactly what the reference
+    // places before its normalization constants change -- instead of stopping above it and taking the level in canonical order (two
+    // more grid-wide syncs per event).  Validated like every batch: the holders that filled up report (level, index) of the last one.
+    int64_t ev_cut = -1;
+    const int64_t gbase = a.c.global_offset + base; // canonical index of this workgroup's first node
+    bool hint = a.hint_valid != 0; // the first re-score assumes the maxima the last launch started with
+    bool first_consts = true;
 
     while (!done && (int)gc.gen_no < a.max_syncs) {
         if (rescore) {
-            ev_level = -1; // (a level of the old score scale)
+            ev_level = -1, ev_cut = -1; // (a level of the old score scale)
             // ---- normalization maxima over the feasible set (P/helper/normalize_score.go:28-56).  First time: every node's raw static
             // word comes from HBM (all K loads of a thread in flight together -- one after the other they were K dependent L2 round
             // trips) and its Fit verdict from the state.  Later: the pass that found the event left the raw words in `ws`, the dynamic
             // part of every feasible node's score in `sct`, and brought the new maxima with its reduce.
-            if (!have_max) {
+            if (hint) mt = (uint32_t)a.hint_mt, ma = (uint32_t)a.hint_ma; // (verified below, with the scores' reduce)
+            else if (!have_max) {
                 uint32_t wst[K];
 #pragma unroll
                 for (int k = 0; k < K; k++) {
@@ -525,7 +552,6 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                     const uint32_t w = wst[k];
                     NodeNarrow n = p_load_node<K>(L, li);
                     n.w = w;
-                    L.ws[li] = w; // raw static word until the scores are written below
                     if (nd_feasible(cx, n)) {
                         const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
                         lmt = cnt > lmt ? cnt : lmt, lma = aff > lma ? aff : lma;
@@ -544,21 +570,32 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             }
             have_max = false;
             PTICK(8);
-            uint32_t lmax = 0, lnf = 0, lcmt = 0, lcma = 0; // lmax: score + 1
-#pragma unroll 1
+            // ---- every node's TotalScore under (mt, ma).  The first time the resource scores are evaluated (resource_allocation.go);
+            // later only the static part is swapped: TotalScore - old static part (the low half of `ws`) + new static part -- the
+            // resource scores do not move when the normalization constants do.
+            uint32_t lmax = 0, lnf = 0, lcmt = 0, lcma = 0, lbad = 0; // lmax: score + 1; lbad: feasible nodes above an ASSUMED maximum
+            uint32_t wst[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) { // the raw static words: all K loads of a thread in flight together
+                const int64_t i = base + k * kPThreads + tid;
+                wst[k] = i < a.c.n_pad ? a.c.stat[i] : 0u;
+            }
+#pragma unroll
             for (int k = 0; k < K; k++) {
                 const int li = k * kPThreads + tid;
-                const uint32_t w = L.ws[li]; // raw static word
+                const uint32_t w = wst[k];
                 uint32_t sc = kScInf, wsv = w & (1u << kStatOkBit);
                 uint32_t dyn = 0;
                 bool feas;
                 if (first_score) {
                     NodeNarrow n = p_load_node<K>(L, li);
+                    n.w = w;
                     feas = nd_feasible(cx, n);
                     if (feas) dyn = (uint32_t)dynamic_score_narrow(a.p, cx.q, n.a0, n.a1, n.r0, n.r1, n.z0, n.z1);
                 } else {
-                    dyn = L.sct[li] & 0xffffu; // (left by the pass that found the event: TotalScore minus the old static part)
-                    feas = dyn != kScInf;
+                    const uint32_t old = L.sct[li] & 0xffffu;
+                    feas = old != kScInf;
+                    dyn = old - (L.ws[li] & 0xffffu);
                 }
                 bool holder = false;
                 if (feas) {
@@ -567,6 +604,7 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                     sc = nstat + dyn;
                     lmax = sc + 1 > lmax ? sc + 1 : lmax;
                     lnf++, lcmt += cnt == mt, lcma += aff == ma;
+                    lbad += (cnt > mt || aff > ma) ? 1u : 0u;
                     wsv |= (cnt == mt ? 1u << 30 : 0u) | (aff == ma ? 1u << 29 : 0u) | nstat;
                     holder = !want_log && ((mt > 0 && cnt == mt) || (ma > 0 && aff == ma));
                 } // (a node the Fit filter rejects never becomes feasible again: placements only add pods)
@@ -581,14 +619,13 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                     if (holder) L.list[wbase + __popcll(b & lt_mask)] = (uint16_t)li;
                 }
             }
-            first_score = false;
             __syncthreads();
             // Where will these constants end?  When the last feasible holder of a maximum fills up -- and a node's run-down depends on
             // nothing but the node: every holder evaluates, once, the score it will have before the clone that fills it (the Fit filter's
             // capacity in closed form, fit.go:564-615); the lowest of them per maximum is the level of that event, the higher of the two
             // the first one.  The batches then stop above it and take that level in canonical order without a failed attempt first (a
             // guess for speed like `ev_level` after a roll-back: every batch is validated).
-            uint32_t pl_mt = 0, pl_ma = 0; // 0x10000 - predicted level, maximum
+            unsigned long long pl_mt = 0, pl_ma = 0; // max of (0x10000 - predicted level) << 24 | node: the LOWEST level, of its holders the LAST
             {
                 const int total_h = uni32(s_n);
 #pragma unroll 1
@@ -603,15 +640,17 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                     NodeNarrow q = n;
                     nd_apply(cx, q, (int64_t)(room - 1));
                     const uint32_t sp = (n.w & 0xffffu) + (uint32_t)dynamic_score_narrow(a.p, cx.q, q.a0, q.a1, q.r0, q.r1, q.z0, q.z1);
-                    if (mt > 0 && (n.w >> 30 & 1u)) pl_mt = 0x10000u - sp > pl_mt ? 0x10000u - sp : pl_mt;
-                    if (ma > 0 && (n.w >> 29 & 1u)) pl_ma = 0x10000u - sp > pl_ma ? 0x10000u - sp : pl_ma;
+                    const unsigned long long key = ((unsigned long long)(0x10000u - sp) << 24) | (unsigned long long)(a.spec_cut ? gbase + li : 0);
+                    if (mt > 0 && (n.w >> 30 & 1u)) pl_mt = key > pl_mt ? key : pl_mt;
+                    if (ma > 0 && (n.w >> 29 & 1u)) pl_ma = key > pl_ma ? key : pl_ma;
                 }
             }
             lmax = wave_max_u32(lmax);
-            lnf = wave_sum_u32(lnf), lcmt = wave_sum_u32(lcmt), lcma = wave_sum_u32(lcma);
-            pl_mt = wave_max_u32(pl_mt), pl_ma = wave_max_u32(pl_ma);
+            lnf = wave_sum_u32(lnf), lcmt = wave_sum_u32(lcmt), lcma = wave_sum_u32(lcma), lbad = wave_sum_u32(lbad);
+            pl_mt = wave_max_u64(pl_mt), pl_ma = wave_max_u64(pl_ma);
             if (lane == 0) {
-                R.mx[0][wave] = lmax, R.ad[0][wave] = (unsigned long long)lnf | ((unsigned long long)lcmt << 32), R.ad[1][wave] = lcma;
+                R.mx[0][wave] = lmax, R.ad[0][wave] = (unsigned long long)lnf | ((unsigned long long)lcmt << 32);
+                R.ad[1][wave] = (unsigned long long)lcma | ((unsigned long long)lbad << 32);
                 R.mx[1][wave] = pl_mt, R.mx[2][wave] = pl_ma;
             }
             __syncthreads();
@@ -625,10 +664,16 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             }
             grid_reduce<MB>(gc);
             if (uni32(s_err)) break;
+            nfeas = (int64_t)(uni64(s_red[1]) & 0xffffffffull), c_mt = (int64_t)(uni64(s_red[1]) >> 32), c_ma = (int64_t)(uni64(s_red[2]) & 0xffffffffull);
+            if (hint) { // the assumed maxima hold iff no feasible node lies above them and each has a feasible holder
+                hint = false;
+                if ((uni64(s_red[2]) >> 32) != 0 || (mt > 0 && c_mt == 0) || (ma > 0 && c_ma == 0)) continue; // stale: the maxima first, then the scores again
+            }
+            first_score = false;
             scans += 1;
-            if (uni64(s_red[3]) != 0) ev_level = (int32_t)(0x10000 - (int64_t)uni64(s_red[3])); // (the first event: the higher level)
-            if (uni64(s_red[4]) != 0 && (int32_t)(0x10000 - (int64_t)uni64(s_red[4])) > ev_level) ev_level = (int32_t)(0x10000 - (int64_t)uni64(s_red[4]));
-            nfeas = (int64_t)(uni64(s_red[1]) & 0xffffffffull), c_mt = (int64_t)(uni64(s_red[1]) >> 32), c_ma = (int64_t)uni64(s_red[2]);
+            if (first_consts && lb == 0 && tid == 0) a.st->p_mt0 = (int32_t)mt, a.st->p_ma0 = (int32_t)ma; // (the launch's first constants: the next launch's hint)
+            first_consts = false;
+            pick_event(uni64(s_red[3]), uni64(s_red[4]), a.spec_cut != 0, ev_level, ev_cut);
             if (uni64(s_red[0]) == 0) { // schedule_one.go:448-454: no feasible node
                 done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0;
                 break;
@@ -651,9 +696,16 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
         // A batch that exhausts the last feasible holder of a normalization maximum is rolled back: do not try one when, at
         // the rate of the last pass, the holders would run out within twice its span (a heuristic for speed only -- the
         // validation below decides)
-        if (!ordered && ev_level >= 0 && M <= ev_level) ordered = true, ev_level = -1; // the level of the located event: in canonical order
+        bool spec = false; // this batch ends AT the event: level ev_level up to node ev_cut (per-node threshold)
+        if (!ordered && ev_level >= 0 && M <= ev_level) {
+            if (ev_cut >= 0 && M == ev_level) spec = true;
+            else ordered = true, ev_level = -1, ev_cut = -1; // the level of the located event: in canonical order
+        }
         int kcap = kb;
-        if (!ordered && ev_level >= 0 && M - ev_level < kcap) kcap = M - ev_level; // ... and the levels above it in one batch
+        if (!ordered && !spec && ev_level >= 0) {
+            if (ev_cut >= 0) spec = M - ev_level + 1 <= kb;                   // the levels above the event and the event itself in one batch
+            else if (M - ev_level < kcap) kcap = M - ev_level;                // ... or only the levels above it
+        }
         if (mt > 0 && last_xmt > 0) {
             const int64_t lv = c_mt * last_k / last_xmt / 2;
             kcap = lv < kcap ? (lv < 1 ? 1 : (int)lv) : kcap;
@@ -662,13 +714,14 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             const int64_t lv = c_ma * last_k / last_xma / 2;
             kcap = lv < kcap ? (lv < 1 ? 1 : (int)lv) : kcap;
         }
-        const int32_t Lo = ordered ? M : (M - (kcap - 1) > 0 ? M - (kcap - 1) : 0);
+        const int32_t Lo = ordered ? M : spec ? ev_level : (M - (kcap - 1) > 0 ? M - (kcap - 1) : 0);
+        const int64_t bcut = spec ? ev_cut : kNoCut; // nodes beyond it stop one level higher
         uint32_t mymax = 0; // score + 1 over the nodes this pass leaves alone
         int wtot = 0;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const uint32_t sc = L.sct[k * kPThreads + tid] & 0xffffu;
-            const bool lv = sc >= (uint32_t)Lo && sc != kScInf;
+            const bool lv = sc >= (uint32_t)Lo + (gbase + k * kPThreads + tid > bcut ? 1u : 0u) && sc != kScInf;
             if (!lv && sc != kScInf) mymax = sc + 1 > mymax ? sc + 1 : mymax;
             const int c = __popcll(__ballot(lv));
             wtot += c;
@@ -681,7 +734,7 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const uint32_t sc = L.sct[k * kPThreads + tid] & 0xffffu;
-                const bool lv = sc >= (uint32_t)Lo && sc != kScInf;
+                const bool lv = sc >= (uint32_t)Lo + (gbase + k * kPThreads + tid > bcut ? 1u : 0u) && sc != kScInf;
                 const uint64_t b = __ballot(lv);
                 if (lv) L.list[wbase + __popcll(b & lt_mask)] = (uint16_t)(k * kPThreads + tid);
                 wbase += __popcll(b);
@@ -721,7 +774,7 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
         // (b) PLAN: every level node's run-down length -> the high half of its score word.  A blind batch applies it on the spot
         // (the node's new state and score: what (c) does for the ordered path after the cut is known)
         uint32_t committed = 0, x_nf = 0, x_mt = 0, x_ma = 0;
-        uint32_t xl_mt = 0, xl_ma = 0; // blind batches: 0x10000 - (score before the last clone) of the holders that filled up, maximum
+        unsigned long long xl_mt = 0, xl_ma = 0; // blind batches: event key (level = score before the last clone, node) of the holders that filled up, maximum
         {
             uint32_t T = 0, e_mt = 0, e_ma = 0;
             int64_t cmt = 0, cma = 0; // global index + 1 of the highest exhausted holder
@@ -736,7 +789,7 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                 if (mine) li = L.list[r0 + e], n = p_load_node<K>(L, li);
                 bool fend = true;
                 int32_t j = 0;
-                if (wave < nwork) j = wave_run_down_rows(cx, n, (int32_t)(n.w & 0xffffu), Lo, mine, fend, a.seq_steps);
+                if (wave < nwork) j = wave_run_down_rows(cx, n, (int32_t)(n.w & 0xffffu), Lo + (gbase + li > bcut ? 1 : 0), mine, fend, a.seq_steps);
                 if (mine) {
                     if (ordered) {
                         L.sct[li] = (L.sct[li] & 0xffffu) | ((uint32_t)j << 16);
@@ -759,8 +812,9 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                                 NodeNarrow q = n;
                                 nd_apply(cx, q, -1);
                                 const uint32_t sp = (uint32_t)nd_score(cx, q, (int64_t)(q.w & 0xffffu), NoRcp{});
-                                if (n.w >> 30 & 1u) xl_mt = 0x10000u - sp > xl_mt ? 0x10000u - sp : xl_mt; // (max of the complement = the lowest score)
-                                if (n.w >> 29 & 1u) xl_ma = 0x10000u - sp > xl_ma ? 0x10000u - sp : xl_ma;
+                                const unsigned long long key = event_key((int32_t)sp, a.spec_cut ? gbase + li : 0);
+                                if (n.w >> 30 & 1u) xl_mt = key > xl_mt ? key : xl_mt; // (the lowest level, of its nodes the last)
+                                if (n.w >> 29 & 1u) xl_ma = key > xl_ma ? key : xl_ma;
                             }
                         }
                     }
@@ -848,49 +902,44 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                     else x_nf++, x_mt += n.w >> 30 & 1u, x_ma += n.w >> 29 & 1u;
                 }
             }
-            if (cut != kNoCut) {
-                // A normalization maximum loses its last feasible holder in this level: new constants follow.  Their maxima ride on
-                // this level's reduce (words 3, 4: unused on the ordered path) instead of a reduce of their own, and every feasible
-                // node keeps the dynamic part of its score (TotalScore minus the old static part), the raw static word back in `ws`:
-                // the re-score swaps the static part without evaluating a single node (resource_allocation.go scores do not move).
-                __syncthreads();
-                uint32_t wst[K];
+        }
+        // A pass that (probably) ends at a normalization event is followed by new constants: their maxima -- over the nodes still
+        // feasible AFTER this pass -- ride on its reduce (words 5, 6) instead of a reduce of their own.
+        uint32_t nx_mt = 0, nx_ma = 0;
+        const bool with_max = spec || (ordered && cut != kNoCut);
+        if (with_max) {
+            __syncthreads(); // (the scores this pass rewrote)
+            uint32_t wst[K];
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const int64_t i = base + k * kPThreads + tid;
-                    wst[k] = i < a.c.n_pad ? a.c.stat[i] : 0u;
-                }
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const int li = k * kPThreads + tid;
-                    const uint32_t w = wst[k], sc = L.sct[li] & 0xffffu;
-                    if (sc != kScInf) {
-                        const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-                        xl_mt = cnt > xl_mt ? cnt : xl_mt, xl_ma = aff > xl_ma ? aff : xl_ma;
-                        L.sct[li] = sc - (L.ws[li] & 0xffffu);
-                    } else
-                        L.sct[li] = kScInf;
-                    L.ws[li] = w;
-                }
+            for (int k = 0; k < K; k++) {
+                const int64_t i = base + k * kPThreads + tid;
+                wst[k] = i < a.c.n_pad ? a.c.stat[i] : 0u;
             }
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if ((L.sct[k * kPThreads + tid] & 0xffffu) != kScInf) {
+                    const uint32_t cnt = (wst[k] >> kStatCntShift) & kStatCntMask, aff = wst[k] & kStatAffMask;
+                    nx_mt = cnt > nx_mt ? cnt : nx_mt, nx_ma = aff > nx_ma ? aff : nx_ma;
+                }
         }
         PTICK(2);
         // (d) block reduction -> grid reduction
         mymax = wave_max_u32(mymax);
         committed = wave_sum_u32(committed), x_nf = wave_sum_u32(x_nf), x_mt = wave_sum_u32(x_mt), x_ma = wave_sum_u32(x_ma);
-        xl_mt = wave_max_u32(xl_mt), xl_ma = wave_max_u32(xl_ma);
+        xl_mt = wave_max_u64(xl_mt), xl_ma = wave_max_u64(xl_ma);
+        if (with_max) nx_mt = wave_max_u32(nx_mt), nx_ma = wave_max_u32(nx_ma);
         if (lane == 0) {
             R.mx[0][wave] = mymax;
-            R.mx[1][wave] = xl_mt, R.mx[2][wave] = xl_ma;
+            R.mx[1][wave] = xl_mt, R.mx[2][wave] = xl_ma, R.mx[3][wave] = nx_mt, R.mx[4][wave] = nx_ma;
             R.ad[0][wave] = (unsigned long long)committed | ((unsigned long long)x_nf << 32);
             R.ad[1][wave] = (unsigned long long)x_mt | ((unsigned long long)x_ma << 32);
         }
         __syncthreads();
         if (wave == 0) {
             const unsigned long long v0 = comb_max(R.mx[0]), v1 = comb_add(R.ad[0]), v2 = comb_add(R.ad[1]);
-            const unsigned long long v3 = comb_max(R.mx[1]), v4 = comb_max(R.mx[2]);
+            const unsigned long long v3 = comb_max(R.mx[1]), v4 = comb_max(R.mx[2]), v5 = comb_max(R.mx[3]), v6 = comb_max(R.mx[4]);
             if (lane == 0) {
-                s_v[0] = v0, s_v[1] = v1, s_v[2] = v2, s_v[3] = v3, s_v[4] = v4;
+                s_v[0] = v0, s_v[1] = v1, s_v[2] = v2, s_v[3] = v3, s_v[4] = v4, s_v[5] = v5, s_v[6] = v6;
                 s_n = 0; // next level's list (every thread read `total` before the barrier above)
             }
         }
@@ -903,11 +952,19 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
         const int64_t g_xmt = (int64_t)(uni64(s_red[2]) & 0xffffffffull), g_xma = (int64_t)(uni64(s_red[2]) >> 32);
         const uint32_t g_next = (uint32_t)uni64(s_red[0]);
 
+        bool event_done = ordered && cut != kNoCut; // this pass ended exactly where a normalization maximum lost its last feasible holder
         if (!ordered) {
             // validate the blind commit: did it exhaust every holder of a normalization maximum, or cross the limit?
-            const bool cut_event = (mt > 0 && g_xmt == c_mt) || (ma > 0 && g_xma == c_ma);
+            const bool ex_mt = mt > 0 && g_xmt == c_mt, ex_ma = ma > 0 && g_xma == c_ma;
+            const bool cut_event = ex_mt || ex_ma;
             const bool over = limit > 0 && placed + g_committed > limit;
-            if (cut_event || over) { // undo the whole level, redo it in canonical order
+            if (spec && cut_event && !over) {
+                // a batch cut at the predicted event stands iff every maximum that ran out of holders did so exactly there: the
+                // holders that filled up report the (level, node) of the last one.  Anything else is rolled back like any batch.
+                const unsigned long long want = event_key(ev_level, ev_cut);
+                event_done = (!ex_mt || uni64(s_red[3]) == want) && (!ex_ma || uni64(s_red[4]) == want);
+            }
+            if ((cut_event && !event_done) || over) { // undo the whole level, redo it in canonical order
 #pragma unroll 1
                 for (int r0 = 0; r0 < total; r0 += kPThreads)
                     if (r0 + tid < total) {
@@ -919,36 +976,42 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
                         L.sct[li] = (uint32_t)nd_score(cx, n, (int64_t)(n.w & 0xffffu), NoRcp{}); // (it was feasible: it took pods)
                     }
                 __syncthreads();
-                if (Lo < M) {
+                if (Lo < M || spec) {
                     kb = (M - Lo + 1) >> 1; // a batch: retry with half the levels, still blind (the event is somewhere inside) ...
+                    kb = kb < 1 ? 1 : kb;
                     if (cut_event && !over) { // ... unless the holders that filled up say where
+                        const int32_t old_level = ev_level;
+                        const int64_t old_cut = spec ? ev_cut : -1;
+                        ev_level = -1, ev_cut = -1; // (whatever was predicted did not hold)
                         int32_t ev = -1;
-                        if (mt > 0 && g_xmt == c_mt && uni64(s_red[3]) != 0) ev = (int32_t)(0x10000 - (int64_t)uni64(s_red[3]));
-                        if (ma > 0 && g_xma == c_ma && uni64(s_red[4]) != 0) {
-                            const int32_t e2 = (int32_t)(0x10000 - (int64_t)uni64(s_red[4]));
-                            ev = e2 > ev ? e2 : ev; // (the event that comes first in canonical order: the higher level)
+                        int64_t ec = -1;
+                        pick_event(ex_mt ? uni64(s_red[3]) : 0ull, ex_ma ? uni64(s_red[4]) : 0ull, a.spec_cut != 0, ev, ec);
+                        if (ev >= Lo && ev <= M) {
+                            ev_level = ev, ev_cut = ec, kb = a.level_batch; // (the batch is cut at the event where Lo is chosen)
+                            if (spec && ev == old_level && ec == old_cut) ev_cut = -1; // the same place again: that level in canonical order
                         }
-                        if (ev >= Lo && ev <= M) ev_level = ev, kb = a.level_batch; // (the batch is cut at ev_level + 1 where Lo is chosen)
                     }
+                    if (spec && Lo == M && (ev_level < 0 || over)) ordered = true; // (one level, nothing learnt / the limit inside it: canonical order)
                 } else
                     ordered = true; // one level: redo it in canonical order
                 continue;
             }
+            if (spec) ev_level = -1, ev_cut = -1; // the prediction is spent (the event happened, or the batch ended short of it)
         }
         placed += g_committed, rounds += g_committed;
         if (!ordered) kb = 2 * kb < a.level_batch ? 2 * kb : a.level_batch;
         last_k = M - Lo + 1, last_xmt = g_xmt, last_xma = g_xma;
         nfeas -= g_xnf, c_mt -= g_xmt, c_ma -= g_xma;
         scans += 1;
-        if (ordered && cut != kNoCut) { // a normalization maximum lost its last feasible holder: new constants (their maxima came with this reduce)
-            mt = (uint32_t)uni64(s_red[3]), ma = (uint32_t)uni64(s_red[4]);
+        if (event_done) { // a normalization maximum lost its last feasible holder: new constants (their maxima came with this reduce)
+            mt = (uint32_t)uni64(s_red[5]), ma = (uint32_t)uni64(s_red[6]);
             have_max = true;
         }
         if (limit > 0 && placed >= limit) { // simulator.go:297-312: tested after the append
             done = DONE_LIMIT;
             break;
         }
-        if (ordered && cut != kNoCut) {
+        if (event_done) {
             rescore = true;
             ordered = want_log;
             continue;

@@ -252,32 +252,56 @@ class LevelModel:
 
     # ---- the persistent kernel's fast path (ccsim_persist.h): several score levels per grid-wide sync, committed blindly,
     #      validated afterwards, rolled back and redone with fewer levels (down to ONE level in canonical order) ----
-    def run_persistent(self, limit=0, level_batch=8):
+    @staticmethod
+    def _pick_event(k_mt, k_ma):
+        """Event keys are (level, node) of the holder of a maximum that fills up LAST: the lowest level, of its nodes the highest.
+        Of the two maxima the event that comes first in canonical order counts: the higher level, then the lower node."""
+        ev = None
+        for k in (k_mt, k_ma):
+            if k is not None and (ev is None or k[0] > ev[0] or (k[0] == ev[0] and k[1] < ev[1])):
+                ev = k
+        return ev if ev is not None else (-1, -1)
+
+    def run_persistent(self, limit=0, level_batch=8, spec=True):
         """Mirrors k_level_persist without a placement log.  Per sync: every feasible node scoring >= Lo = M - kb + 1 runs down
         until it scores < Lo (or stops fitting) -- for one node exactly the sequence of its run-downs at the levels in between,
         and without a log or a limit the interleaving across nodes is unobservable.  If that exhausted every feasible holder
-        of a normalization maximum, or crossed the limit, the whole batch is undone and retried: with the levels above the one at which
-        the last holder went (every holder that filled up reports the score it had before its last clone -- a guess for speed,
-        validated like any other batch) and that level itself ORDERED, else with half the levels; a single level that still trips
-        is redone ORDERED (plan, cut, canonical commit: run()'s level step).  Returns the counters a
-        log-less run reports (placed, per-node counts, stop) + how many syncs / roll-backs it took."""
-        placed, syncs, rollbacks = 0, 0, 0
+        of a normalization maximum, or crossed the limit, the whole batch is undone and retried.  Round 4: the re-score predicts
+        WHERE the constants end -- (level, node) of the holder that fills up last -- and a batch may END exactly there: the levels
+        above the event, and of the event's level the nodes up to that node (a per-node threshold), which is what the reference
+        places before its normalization constants change.  The batch stands iff every maximum that ran out of holders did so at
+        exactly that (level, node), as reported by the holders that filled up; anything else is rolled back (and the report says
+        where the event really was), else with half the levels; a single level that still trips is redone ORDERED (plan, cut,
+        canonical commit: run()'s level step).  `spec=False`: round 3's form (stop above the event, that level ordered).
+        Returns the counters a log-less run reports (placed, per-node counts, stop) + how many syncs / roll-backs it took."""
+        placed, syncs, rollbacks, spec_ok = 0, 0, 0, 0
         per_node = np.zeros(self.N, np.int32)
         kb = level_batch
         rescore = True
-        ev_level = -1  # score level at which a rolled-back batch located its event
+        ev_level, ev_cut = -1, -1  # where the current constants end: score level, node (-1: unknown)
         mt = ma = c_mt = c_ma = 0
+
+        def filled_key(n):  # the score the (full) node had before its last clone, and the node
+            self.apply(n, -1)
+            sp = self.stat(n, mt, ma) + self.dyn(n)
+            self.apply(n, +1)
+            return (sp, n)
+
+        def later(a, b):  # the later of two fill-ups in canonical order: lower level, then higher node
+            if a is None:
+                return b
+            return b if (b[0] < a[0] or (b[0] == a[0] and b[1] > a[1])) else a
+
         while True:
             feas = [n for n in range(self.N) if self.feasible(n)]
             if not feas:
-                return dict(placed=placed, stop=0, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks)
-            if rescore:  # exact maxima over the feasible set (one extra grid reduce), then every node's TotalScore
+                return dict(placed=placed, stop=0, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks, spec_ok=spec_ok)
+            if rescore:  # exact maxima over the feasible set, then every node's TotalScore
                 mt, ma = max(self.cnt[n] for n in feas), max(self.aff[n] for n in feas)
                 rescore = False
-                ev_level = -1  # (a level of the old score scale)
                 # where these constants will end: every holder's score before the clone that fills it (its run-down depends on nothing
-                # but the node); the lowest per maximum is the level of that event, the higher of the two the first one
-                lo = {}
+                # but the node); per maximum the LAST holder to go, of the two maxima the first event
+                keys = {"mt": None, "ma": None}
                 for which, top, arr in (("mt", mt, self.cnt), ("ma", ma, self.aff)):
                     for n in feas:
                         if top > 0 and arr[n] == top:
@@ -285,13 +309,13 @@ class LevelModel:
                             while self.feasible(n):
                                 self.apply(n, +1)
                                 j += 1
-                            self.apply(n, -1)
-                            sp = self.stat(n, mt, ma) + self.dyn(n)
-                            for _ in range(j - 1):
+                            key = filled_key(n)
+                            for _ in range(j):
                                 self.apply(n, -1)
-                            lo[which] = sp if which not in lo else min(lo[which], sp)
-                if lo:
-                    ev_level = max(lo.values())
+                            keys[which] = later(keys[which], key)
+                ev_level, ev_cut = self._pick_event(keys["mt"], keys["ma"])
+                if not spec:
+                    ev_cut = -1
             c_mt = sum(1 for n in feas if self.cnt[n] == mt)
             c_ma = sum(1 for n in feas if self.aff[n] == ma)
             sc = {n: self.stat(n, mt, ma) + self.dyn(n) for n in feas}
@@ -299,10 +323,21 @@ class LevelModel:
             ordered = False
             while True:  # one sync (retried with fewer levels after a roll-back)
                 syncs += 1
+                spec_batch = False
                 if not ordered and ev_level >= 0 and M <= ev_level:
-                    ordered, ev_level = True, -1
-                Lo = M if ordered else max(M - (kb - 1), 0, ev_level + 1)
-                work = [n for n in feas if sc[n] >= Lo]
+                    if ev_cut >= 0 and M == ev_level:
+                        spec_batch = True
+                    else:
+                        ordered, ev_level, ev_cut = True, -1, -1
+                kcap = kb
+                if not ordered and not spec_batch and ev_level >= 0:
+                    if ev_cut >= 0:
+                        spec_batch = M - ev_level + 1 <= kb
+                    elif M - ev_level < kcap:
+                        kcap = M - ev_level
+                Lo = M if ordered else (ev_level if spec_batch else max(M - (kcap - 1), 0))
+                thr = (lambda n: Lo + (1 if n > ev_cut else 0)) if spec_batch else (lambda n: Lo)
+                work = [n for n in feas if sc[n] >= thr(n)]
                 if ordered:  # the level step of run(): plan, cut, canonical order, limit clamp
                     e_mt = e_ma = 0
                     cut_mt = cut_ma = -1
@@ -330,50 +365,62 @@ class LevelModel:
                         placed += j
                         per_node[n] += j
                     if limit > 0 and placed >= limit:
-                        return dict(placed=placed, stop=1, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks)
+                        return dict(placed=placed, stop=1, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks, spec_ok=spec_ok)
                     rescore = cut != 1 << 62  # a maximum lost its last feasible holder: new constants
                     break
                 took, x_mt, x_ma = {}, 0, 0
-                lo_mt = lo_ma = None  # lowest score a holder that filled up had before its last clone
+                k_mt = k_ma = None  # the LAST holder that filled up, per maximum: (score before its last clone, node)
                 for n in work:  # blind: any order
-                    j, f = self.run_down(n, self.stat(n, mt, ma), Lo, 1 << 30)
+                    j, f = self.run_down(n, self.stat(n, mt, ma), thr(n), 1 << 30)
                     took[n] = j
                     if not f:
                         x_mt += self.cnt[n] == mt
                         x_ma += self.aff[n] == ma
                         if j > 0 and ((mt > 0 and self.cnt[n] == mt) or (ma > 0 and self.aff[n] == ma)):
-                            self.apply(n, -1)
-                            sp = self.stat(n, mt, ma) + self.dyn(n)
-                            self.apply(n, +1)
+                            key = filled_key(n)
                             if mt > 0 and self.cnt[n] == mt:
-                                lo_mt = sp if lo_mt is None else min(lo_mt, sp)
+                                k_mt = later(k_mt, key)
                             if ma > 0 and self.aff[n] == ma:
-                                lo_ma = sp if lo_ma is None else min(lo_ma, sp)
+                                k_ma = later(k_ma, key)
                 total = sum(took.values())
-                cut_event = (mt > 0 and x_mt == c_mt) or (ma > 0 and x_ma == c_ma)
+                ex_mt, ex_ma = mt > 0 and x_mt == c_mt, ma > 0 and x_ma == c_ma
+                cut_event = ex_mt or ex_ma
                 over = limit > 0 and placed + total > limit
-                if cut_event or over:  # undo the whole batch
+                event_done = False
+                if spec_batch and cut_event and not over:  # the batch stands iff every exhausted maximum went exactly at the predicted place
+                    want = (ev_level, ev_cut)
+                    event_done = (not ex_mt or k_mt == want) and (not ex_ma or k_ma == want)
+                if (cut_event and not event_done) or over:  # undo the whole batch
                     rollbacks += 1
                     for n, j in took.items():
                         for _ in range(j):
                             self.apply(n, -1)
-                    if Lo < M:
-                        kb = (M - Lo + 1) >> 1
+                    if Lo < M or spec_batch:
+                        kb = max(1, (M - Lo + 1) >> 1)
                         if cut_event and not over:
-                            ev = -1
-                            if mt > 0 and x_mt == c_mt and lo_mt is not None:
-                                ev = lo_mt
-                            if ma > 0 and x_ma == c_ma and lo_ma is not None:
-                                ev = max(ev, lo_ma)
+                            old = (ev_level, ev_cut if spec_batch else -1)
+                            ev_level, ev_cut = -1, -1
+                            ev, ec = self._pick_event(k_mt if ex_mt else None, k_ma if ex_ma else None)
+                            if not spec:
+                                ec = -1
                             if Lo <= ev <= M:
-                                ev_level, kb = ev, level_batch
+                                ev_level, ev_cut, kb = ev, ec, level_batch
+                                if spec_batch and (ev, ec) == old:
+                                    ev_cut = -1
+                        if spec_batch and Lo == M and (ev_level < 0 or over):
+                            ordered = True
                     else:
                         ordered = True
                     continue
+                if spec_batch:
+                    ev_level, ev_cut = -1, -1
+                    spec_ok += event_done
                 placed += total
                 for n, j in took.items():
                     per_node[n] += j
                 kb = min(2 * kb, level_batch)
                 if limit > 0 and placed >= limit:
-                    return dict(placed=placed, stop=1, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks)
+                    return dict(placed=placed, stop=1, per_node_count=per_node, syncs=syncs, rollbacks=rollbacks, spec_ok=spec_ok)
+                if event_done:
+                    rescore = True
                 break

@@ -64,23 +64,44 @@ def test_incremental_score_cache_synthetic(ccref, cfg, n, limit):
     assert got["full_passes"] < got["levels"] or got["levels"] <= 2
 
 
-def _check_persistent(ccref, nodes, pod, prof, limit, batch):
+def _check_persistent(ccref, nodes, pod, prof, limit, batch, spec=True):
     ref = ccref.run(prof, nodes, pod, max_limit=limit, want_log=False)
-    got = LevelModel(prof, nodes, pod).run_persistent(limit, batch)
+    got = LevelModel(prof, nodes, pod).run_persistent(limit, batch, spec=spec)
     assert got["placed"] == ref.placed and got["stop"] == ref.stop
     assert np.array_equal(got["per_node_count"], ref.per_node_count)
     return got
 
 
-@pytest.mark.parametrize("batch", [1, 4, 64])
+@pytest.mark.parametrize("spec", [True, False])
+@pytest.mark.parametrize("batch", [1, 4, 64, 1024])
 @pytest.mark.parametrize("seed", range(12))
-def test_persistent_level_batches_random_plugin_mix(ccref, seed, batch):
+def test_persistent_level_batches_random_plugin_mix(ccref, seed, batch, spec):
     """The persistent kernel's argument (ccsim_persist.h): several score levels per sync committed blindly + validation +
     roll-back give the sequential oracle's totals, per-node counts and stop -- incl. limits falling inside a batch and
     normalization maxima losing their last feasible holder inside one."""
     rng = np.random.default_rng(seed)
     nodes, pod, prof = H.random_case(rng, int(rng.integers(1, 400)))
-    _check_persistent(ccref, nodes, pod, prof, int(rng.choice([0, 0, 37, 500])), batch)
+    _check_persistent(ccref, nodes, pod, prof, int(rng.choice([0, 0, 37, 500])), batch, spec)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_persistent_batches_that_end_at_the_event(ccref, seed):
+    """Round 4: a blind batch ends exactly where a normalization maximum loses its last feasible holder (level + node predicted by
+    the re-score, per-node threshold, validated by the holders that filled up).  Few holders of the maxima, so that the events fall
+    inside batches; with and without a limit."""
+    rng = np.random.default_rng(900 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(20, 500)))
+    limit = int(rng.choice([0, 0, 0, 211]))
+    got = _check_persistent(ccref, nodes, pod, prof, limit, int(rng.choice([16, 64, 1024])))
+    old = _check_persistent(ccref, nodes, pod, prof, limit, 64, spec=False)
+    assert np.array_equal(got["per_node_count"], old["per_node_count"])
+
+
+def test_batches_that_end_at_the_event_save_syncs(ccref):
+    nodes, pod, prof = synth.make_config("C3", n_nodes=2000, seed=7)
+    new = _check_persistent(ccref, nodes, pod, prof, 0, 1024)
+    old = _check_persistent(ccref, nodes, pod, prof, 0, 1024, spec=False)
+    assert new["spec_ok"] >= 1 and new["syncs"] < old["syncs"], (new["syncs"], old["syncs"], new["spec_ok"])
 
 
 def test_persistent_level_batches_save_syncs_and_roll_back(ccref):
