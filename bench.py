@@ -126,6 +126,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # N > 1: the persistent level kernel ACROSS the GPUs (mailboxes over xGMI inside ONE launch per rank; csrc/ccsim_persist.h MB form,
+        # include/ccsim.h ccsim_dist_mbox_*).  The library's default is the RCCL pass protocol; the bench opts in (CCSIM_DIST_MAILBOX=0
+        # for the A/B run).  Every rank that cannot take part -- a box that cannot be mapped, a shard that does not qualify, a bounded
+        # spin that expires -- sends ALL ranks back to the pass protocol, from the untouched state; `config.multi_gpu_form` says what ran.
+        os.environ.setdefault("CCSIM_DIST_MAILBOX", "1")
         if world == 1:  # CCSIM_FORCE_DIST=1 without a launcher: a one-rank job on this GPU
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29513")):
                 os.environ.setdefault(k, v)
@@ -154,7 +159,7 @@ def main():
         def step(mode, lim):
             # the per-node counts are delivered into the engine's page-locked result array, reused from step to step (include/ccsim.h
             # ccsim_host_alloc): a fresh pageable array per step costs 0.18 ms of page faults and staging at 1M nodes
-            # (profiles/r03/step_breakdown.txt), which is the caller's allocation policy and not the simulation
+            # (profiles/r04/step_breakdown.txt), which is the caller's allocation policy and not the simulation
             eng.reset_state()
             return eng.run(max_limit=lim, mode=mode, want_log=False, reuse_buffers=True)
 
@@ -189,8 +194,8 @@ def main():
     # Roofline.  The dominant kernel of the batched mode is the persistent level kernel k_level_persist (csrc/ccsim_persist.h:
     # one launch per simulation; it reads the narrow node columns once, keeps them in LDS, and writes the state back at
     # the end), of the sequential mode k_scan.  Duration: HIP events around the launch on the engine's stream
-    # (ccsim_report.kernel_ns of the LAST timed step; rocprofv3 --kernel-trace --stats of this command, profiles/r03/,
-    # reports the same average).  `achieved` = HBM bytes the launch really moves (rocprofv3 PMC, profiles/r03/pmc_traffic.json,
+    # (ccsim_report.kernel_ns of the LAST timed step; rocprofv3 --kernel-trace --stats of this command, profiles/r04/,
+    # reports the same average).  `achieved` = HBM bytes the launch really moves (rocprofv3 PMC, profiles/r04/pmc_traffic.json,
     # accepted only if it was collected with THIS libccsim.so) / duration: a physical rate.  The persistent kernel is not
     # HBM-bound -- it is bound by its grid-wide syncs (syncs x (barrier latency + the run-downs of the slowest workgroup)) --
     # so the fraction is small by design; `sync_bound` carries that model.  The work the reference semantics imply
@@ -201,15 +206,15 @@ def main():
     persistent = args.mode == "batched" and not distributed and os.environ.get("CCSIM_PERSIST", "1") != "0"
     kernel = "k_level_persist" if persistent else ("k_level_commit" if args.mode == "batched" else "k_scan")
     sha = lib_sha16()
-    pmc, pmc_note = {}, "no profiles/r03/pmc_traffic.json for this workload"
+    pmc, pmc_note = {}, "no profiles/r04/pmc_traffic.json for this workload"
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")))
         if hi - lo != 1_000_000:
             pmc_note = "PMC traffic was collected at 1,000,000 nodes per GPU"
         elif pj.get("lib_sha16") != sha and pj.get("src_sha16") != src_sha16():  # (the binary embeds its build path: the sources decide)
             pmc_note = f"stale: collected with libccsim.so {pj.get('lib_sha16')} / sources {pj.get('src_sha16')}, this run uses {sha} / {src_sha16()}"
         else:
-            pmc, pmc_note = pj["kernels"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so (profiles/r03/pmc_traffic.json)"
+            pmc, pmc_note = pj["kernels"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so (profiles/r04/pmc_traffic.json)"
     except (OSError, KeyError, ValueError):
         pass
     roofline = None
@@ -296,6 +301,10 @@ def main():
             "passes_per_step": scans // max(1, args.steps),
             "sequential_mode_placements_per_s": seq,
             "parallelism": f"node-shard x{world}",
+            "multi_gpu_form": None if not distributed else (
+                "persistent level kernel per rank, grid reduce extended over the ranks through xGMI mailboxes (one launch per run)"
+                if r.pass_launches == 1 and r.scans < 64 and os.environ.get("CCSIM_DIST_MAILBOX") == "1"
+                else "pass protocol: commit + reduce + ncclAllGather(256 B/rank) + decide per pass"),
             "arithmetic": "exact integer results: the canonical state is int64 columns; this snapshot's values fit the engine's lossless "
                           "32-bit mirrors (validated per pod spec), which the timed kernels compute in (int32 / f32 estimates with exact "
                           "fix-ups); `wide_path_ms_per_step` is the same step on the int64 / fp64 path",
@@ -310,7 +319,21 @@ def main():
         passes = max(1, int(r.scans))
         pass_s = r.kernel_ns / 1e9 / passes
         moved = (hi - lo) * 4
-        out["roofline"] = {
+        if out["config"]["multi_gpu_form"].startswith("persistent"):
+            # one persistent launch per rank: the shard's narrow state read once (36 B/node), the commit rows written once (32 B/node);
+            # bound by its grid-wide syncs, each now a local reduce + one 128-byte store burst per peer over xGMI + a poll of the own box
+            moved = (hi - lo) * (36 + 32)
+            out["roofline"] = {
+                "bound": "sync-latency", "kernel": "k_level_persist<K, mailbox> (one launch per rank and run)",
+                "achieved": moved / (r.kernel_ns / 1e9) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": moved / (r.kernel_ns / 1e9) / 1e9 / HBM_PEAK_GBPS,
+                "traffic": None, "bytes_per_launch": moved,
+                "bytes_definition": "bytes the launch is written to move on this rank (no counters for the sharded run)",
+                "us_per_launch": r.kernel_ns / 1e3, "launches_timed": 1,
+                "sync_bound": {"syncs_per_launch": passes, "us_per_sync": r.kernel_ns / 1e3 / passes,
+                               "what": "HIP events around the launch of the last timed step on rank 0; the step adds two ncclAllReduce agreements (go / finished) around it"},
+            }
+        else:
+          out["roofline"] = {
             "bound": "sync-latency", "kernel": "k_level_commit (+ k_level_final, ncclAllGather 256 B/rank, k_level_decide) per pass",
             "achieved": moved / pass_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": moved / pass_s / 1e9 / HBM_PEAK_GBPS,
             "traffic": None, "bytes_per_launch": moved,

@@ -129,6 +129,12 @@ SYMBOLS = {
     "ccsim_dist_comm_init": (C.c_int, [C.c_void_p, _pu8, C.c_int32, C.c_int32]),
     "ccsim_dist_sync_tables": (C.c_int, [C.c_void_p]),
     "ccsim_dist_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
+    "ccsim_dist_mbox_info": (C.c_int, [C.c_void_p, _pu8]),
+    "ccsim_dist_mbox_connect": (C.c_int, [C.c_void_p, _pu8, C.c_int32, C.c_int32]),
+    "ccsim_dist_mbox_eligible": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_mbox_launch": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_mbox_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "ccsim_dist_mbox_finish": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccsim_reset_state": (C.c_int, [C.c_void_p]),
     "ccsim_host_alloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "ccsim_host_free": (None, [C.c_void_p, C.c_void_p]),
@@ -178,6 +184,7 @@ class CcsimError(RuntimeError):
 
 
 DIST_ID_BYTES = 128
+MBOX_INFO_BYTES = 96
 
 
 def dist_unique_id() -> bytes:
@@ -566,6 +573,36 @@ class Engine:
         rep, per_node, log, ht = self._report(want_log, log_cap)
         self._chk(self.lib.ccsim_dist_run(self.h, int(max_limit), MODES[mode], C.byref(rep)), "ccsim_dist_run")
         return self._result(rep, per_node, log, ht)
+
+    # ---- ... or the persistent level kernel across the GPUs: mailbox form (include/ccsim.h ccsim_dist_mbox_*) ----
+    def dist_mbox_info(self) -> bytes:
+        buf = (C.c_uint8 * MBOX_INFO_BYTES)()
+        self._chk(self.lib.ccsim_dist_mbox_info(self.h, buf), "ccsim_dist_mbox_info")
+        return bytes(buf)
+
+    def dist_mbox_connect(self, infos, rank: int):
+        """`infos`: every rank's dist_mbox_info(), in rank order."""
+        blob = b"".join(infos)
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        self._chk(self.lib.ccsim_dist_mbox_connect(self.h, buf, len(infos), int(rank)), "ccsim_dist_mbox_connect")
+
+    def dist_mbox_eligible(self) -> bool:
+        return bool(self.lib.ccsim_dist_mbox_eligible(self.h))
+
+    def dist_mbox_launch(self):
+        self._chk(self.lib.ccsim_dist_mbox_launch(self.h), "ccsim_dist_mbox_launch")
+
+    def dist_mbox_status(self) -> bool:
+        ok = C.c_int32()
+        self._chk(self.lib.ccsim_dist_mbox_status(self.h, C.byref(ok)), "ccsim_dist_mbox_status")
+        return bool(ok.value)
+
+    def dist_mbox_finish(self, all_ok: bool) -> bool:
+        """True: the result stands (dist_finish reports it).  False: fall back to the pass protocol from the untouched state."""
+        rc = self.lib.ccsim_dist_mbox_finish(self.h, 1 if all_ok else 0)
+        if rc < 0:
+            self._chk(rc, "ccsim_dist_mbox_finish")
+        return rc == 0
 
     def dist_finish(self, want_log: bool = False, log_cap: int = 0) -> M.RunResult:
         rep, per_node, log, ht = self._report(want_log, log_cap)

@@ -28,6 +28,7 @@
 #include <string>
 #include <thread>
 #include <time.h>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/ccsim.h"
@@ -125,7 +126,12 @@ struct ccsim_engine {
     PersistMailbox *d_mbox = nullptr;
     PersistMailbox *mbox_peers[kPMaxRanks] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void *> mbox_ipc_open;  // peers' boxes opened through IPC handles (other processes)
-    bool mbox_ready = false;            // the boxes of all comm_ranks ranks are mapped
+    bool mbox_ready = false;            // the boxes of all mb_ranks ranks are mapped
+    int mb_ranks = 0, mb_rank = 0;      // ranks of the mailbox job / this engine's rank
+    uint32_t mb_seq = 0;                // launches of the mailbox form so far: the same on every rank (they launch together or not at all)
+    int mb_k = 0;                       // K of the launch in flight
+    int mb_go = -1;                     // ccsim_dist_run: did every rank call this pod / snapshot eligible? (-1: not agreed yet; reset by set_pod / load_nodes / comm_init -- SPMD: on every rank alike)
+    DevState mb_state0{};               // the run state ccsim_dist_begin uploaded (restored when the ranks fall back to the pass protocol)
     uint32_t persist_seq = 0;           // launch sequence of the mailbox form (tags: nothing is zeroed between launches)
     int persist_vranks = 0;             // CCSIM_PERSIST_VRANKS: run the single-device batched mode as that many virtual ranks
     bool reset_pending = false;         // ccsim_reset_state deferred the restore of the node columns: the next persistent launch loads the
@@ -332,6 +338,8 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->d_log) (void)hipFree(e->d_log);
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_hist_pin) (void)hipHostFree(e->h_hist_pin);
+    for (void *p : e->mbox_ipc_open) (void)hipIpcCloseMemHandle(p);
+    if (e->d_mbox) (void)hipFree(e->d_mbox);
     dist_comm_release(e);
     for (hipEvent_t ev : e->pass_events) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -356,6 +364,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     free_list(e->allocs);
     e->backups.clear();
     e->reset_pending = false;
+    e->mb_go = -1;
     e->backup_bytes.clear();
     e->have_nodes = e->have_pod = e->begun = false;
     e->multi = false;
@@ -651,6 +660,7 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     e->multi = false;
     e->have_pod = e->begun = false;
     e->persist_hint = false;
+    e->mb_go = -1;
     e->n_taintsets = pod->n_taintsets;
 
     const ccsim_profile &pf = e->prof;
@@ -2000,6 +2010,148 @@ extern "C" int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out) {
     return fill_report(e, out);
 }
 
+
+// ================================================================================================================
+// The persistent level kernel across the GPUs: mailbox form (include/ccsim.h "ccsim_dist_mbox_*"; ccsim_persist.h MB = true)
+// ================================================================================================================
+namespace {
+struct MboxInfo {
+    int64_t pid;
+    int32_t device, pad;
+    uint64_t ptr;
+    hipIpcMemHandle_t handle;
+};
+static_assert(sizeof(MboxInfo) <= CCSIM_MBOX_INFO_BYTES, "mailbox addressing record");
+} // namespace
+
+static void mbox_disconnect(ccsim_engine *e) {
+    for (void *p : e->mbox_ipc_open) (void)hipIpcCloseMemHandle(p);
+    e->mbox_ipc_open.clear();
+    for (auto &p : e->mbox_peers) p = nullptr;
+    e->mbox_ready = false;
+}
+
+extern "C" int ccsim_dist_mbox_info(ccsim_engine *e, uint8_t *info_out) {
+    if (!e || !info_out) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = mbox_alloc(e);
+    if (rc) return rc;
+    MboxInfo mi{};
+    mi.pid = (int64_t)getpid(), mi.device = e->device, mi.ptr = (uint64_t)(uintptr_t)e->d_mbox;
+    if (hipIpcGetMemHandle(&mi.handle, e->d_mbox) != hipSuccess) { // (a peer in another process will not be able to map it: it says so)
+        (void)hipGetLastError();
+        memset(&mi.handle, 0, sizeof mi.handle);
+        mi.pad = 1;
+    }
+    memset(info_out, 0, CCSIM_MBOX_INFO_BYTES);
+    memcpy(info_out, &mi, sizeof mi);
+    return 0;
+}
+
+extern "C" int ccsim_dist_mbox_connect(ccsim_engine *e, const uint8_t *all_infos, int32_t n_ranks, int32_t rank) {
+    if (!e || !all_infos || n_ranks < 1 || n_ranks > kPMaxRanks || rank < 0 || rank >= n_ranks) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = mbox_alloc(e);
+    if (rc) return rc;
+    mbox_disconnect(e);
+    for (int r = 0; r < n_ranks; r++) {
+        MboxInfo mi;
+        memcpy(&mi, all_infos + (size_t)r * CCSIM_MBOX_INFO_BYTES, sizeof mi);
+        if (r == rank) {
+            e->mbox_peers[r] = e->d_mbox;
+        } else if (mi.pid == (int64_t)getpid()) { // an engine of this process: its pointer is valid here
+            if (mi.device != e->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, e->device, mi.device) != hipSuccess || !can) {
+                    mbox_disconnect(e);
+                    return fail(e, -ENOTSUP, "mailbox of rank %d: device %d cannot access device %d", r, e->device, mi.device);
+                }
+                const hipError_t pe = hipDeviceEnablePeerAccess(mi.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                    mbox_disconnect(e);
+                    return fail(e, -ENOTSUP, "mailbox of rank %d: hipDeviceEnablePeerAccess(%d) failed: %s", r, mi.device, hipGetErrorString(pe));
+                }
+                (void)hipGetLastError();
+            }
+            e->mbox_peers[r] = (PersistMailbox *)(uintptr_t)mi.ptr;
+        } else { // another process: through its IPC handle (HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf)
+            void *p = nullptr;
+            if (mi.pad != 0 || hipIpcOpenMemHandle(&p, mi.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                (void)hipGetLastError();
+                mbox_disconnect(e);
+                return fail(e, -ENOTSUP, "mailbox of rank %d could not be mapped through its IPC handle", r);
+            }
+            e->mbox_ipc_open.push_back(p);
+            e->mbox_peers[r] = (PersistMailbox *)p;
+        }
+    }
+    e->mb_ranks = n_ranks, e->mb_rank = rank, e->mb_seq = 0, e->mb_go = -1;
+    e->mbox_ready = true;
+    return 0;
+}
+
+extern "C" int ccsim_dist_mbox_eligible(ccsim_engine *e) {
+    if (!e || !e->have_nodes || !e->have_pod || !e->have_profile || !e->mbox_ready) return 0;
+    if (hipSetDevice(e->device) != hipSuccess) return 0;
+    return persist_k_impl(e, true, true) > 0 ? 1 : 0;
+}
+
+extern "C" int ccsim_dist_mbox_launch(ccsim_engine *e) {
+    if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
+    if (!e->mbox_ready || e->n_ranks != e->mb_ranks || e->rank != e->mb_rank) return fail(e, -EINVAL, "ccsim_dist_mbox_connect first (same ranks as ccsim_dist_begin)");
+    if (e->mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "the mailbox form is the batched mode's");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int k = persist_k_impl(e, true, true);
+    if (!k) return fail(e, -ENOSYS, "this shard does not qualify for the persistent form");
+    e->mb_k = k;
+    e->mb_state0 = *e->h_state; // (what ccsim_dist_begin uploaded)
+    PersistArgs a = persist_args(e);
+    a.n_ranks = e->mb_ranks, a.rank = e->mb_rank, a.vranks = 0, a.bpr = 0;
+    for (int r = 0; r < e->mb_ranks; r++) a.mbox[r] = e->mbox_peers[r];
+    a.tag_base = (e->mb_seq++ & 0xfffu) << 20;
+    a.hint_valid = 0;       // (the hint is per engine: ranks could disagree about it -- and every rank must take the same number of syncs)
+    a.c.from_pristine = 0;  // (ccsim_dist_begin restored the columns)
+    a.c.cnt_assign = 1;
+    a.c.hist = nullptr;
+    const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
+    HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync), e->stream));
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    launch_persist(e, k, true, grid, a);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    return 0;
+}
+
+extern "C" int ccsim_dist_mbox_status(ccsim_engine *e, int32_t *ok) {
+    if (!e || !ok || !e->begun) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = read_state(e);
+    if (rc) return rc;
+    PersistSync hs;
+    HIPCHK(e, hipMemcpy(&hs, e->d_psync, sizeof hs, hipMemcpyDeviceToHost));
+    float ms = 0;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->kernel_ms = ms, e->pass_kernel_ms = ms, e->pass_launches = 1;
+    *ok = (e->h_state->done != DONE_ERROR && e->h_state->done != DONE_RUNNING && hs.err[0] == 0) ? 1 : 0;
+    return 0;
+}
+
+extern "C" int ccsim_dist_mbox_finish(ccsim_engine *e, int32_t all_ok) {
+    if (!e || !e->begun) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (all_ok) return 0; // the commit rows hold the final state: ccsim_dist_finish publishes them (k_rows_flush) and reports
+    // some rank could not finish: nobody publishes.  The rows k_rows_build made are what the pass protocol starts from -- rewrite
+    // them (this rank's launch may have written its rows), restore the run state ccsim_dist_begin uploaded
+    const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(k_rows_build, dim3(blocks), dim3(kThreads), 0, e->stream, e->cols);
+    HIPCHK(e, hipGetLastError());
+    *e->h_state = e->mb_state0;
+    HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->dist_pass_in_window = 0;
+    return 1;
+}
+
 // ================================================================================================================
 // The sharded run driven from C++ over the engine's own RCCL communicator (include/ccsim.h "multi-GPU, driven by the
 // library").  RCCL is bound at run time (dlopen): libccsim.so has no link-time dependency on it and single-GPU users
@@ -2017,7 +2169,7 @@ struct RcclApi {
     const char *(*GetErrorString)(int) = nullptr;
     std::string err;
 };
-constexpr int kNcclInt32 = 2, kNcclInt64 = 4, kNcclSum = 0, kNcclMax = 2; // rccl.h:448-463
+constexpr int kNcclInt8 = 0, kNcclInt32 = 2, kNcclInt64 = 4, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3; // rccl.h:448-463
 
 static double now_s() {
     struct timespec ts;
@@ -2143,6 +2295,45 @@ extern "C" int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id_bytes, in
     HIPCHK(e, hipMalloc((void **)&e->d_own_recv, sizeof(XRec) * (size_t)n_ranks));
     HIPCHK(e, hipMemset(e->d_own_send, 0, sizeof(XRec)));
     HIPCHK(e, hipMemset(e->d_own_recv, 0, sizeof(XRec) * (size_t)n_ranks));
+    // the persistent kernel across the GPUs (CCSIM_DIST_MAILBOX=1): every rank's mailbox mapped into every rank, addressing
+    // records all-gathered over the new communicator.  Whatever fails here leaves the pass protocol as it is.
+    mbox_disconnect(e);
+    if (getenv("CCSIM_DIST_MAILBOX") && atoi(getenv("CCSIM_DIST_MAILBOX")) != 0 && n_ranks <= kPMaxRanks && sizeof(XRec) >= CCSIM_MBOX_INFO_BYTES) {
+        uint8_t mine[CCSIM_MBOX_INFO_BYTES];
+        std::vector<uint8_t> all((size_t)n_ranks * CCSIM_MBOX_INFO_BYTES);
+        int rc = ccsim_dist_mbox_info(e, mine);
+        if (rc == 0) {
+            HIPCHK(e, hipMemcpy(e->d_own_send, mine, sizeof mine, hipMemcpyHostToDevice));
+            RCCLCHK(e, r.AllGather(e->d_own_send, e->d_own_recv, CCSIM_MBOX_INFO_BYTES, kNcclInt8, e->rccl_comm, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            HIPCHK(e, hipMemcpy(all.data(), e->d_own_recv, all.size(), hipMemcpyDeviceToHost));
+            rc = ccsim_dist_mbox_connect(e, all.data(), n_ranks, rank);
+            HIPCHK(e, hipMemset(e->d_own_send, 0, sizeof(XRec)));
+            HIPCHK(e, hipMemset(e->d_own_recv, 0, sizeof(XRec) * (size_t)n_ranks));
+        }
+        {   // connected everywhere or nowhere: the ranks must agree on whether ccsim_dist_run takes the collective steps of the mailbox form
+            int32_t mine_ok = rc == 0 ? 1 : 0, all_ok = 0;
+            int32_t *buf = (int32_t *)e->d_own_send;
+            HIPCHK(e, hipMemcpy(buf, &mine_ok, sizeof mine_ok, hipMemcpyHostToDevice));
+            RCCLCHK(e, r.AllReduce(buf, buf, 1, kNcclInt32, kNcclMin, e->rccl_comm, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            HIPCHK(e, hipMemcpy(&all_ok, buf, sizeof all_ok, hipMemcpyDeviceToHost));
+            HIPCHK(e, hipMemset(e->d_own_send, 0, sizeof(XRec)));
+            if (!all_ok) mbox_disconnect(e);
+        }
+        if (dist_debug()) fprintf(stderr, "[ccsim dist] rank %d: mailboxes %s%s%s\n", rank, rc == 0 ? "connected" : "NOT connected", rc ? ": " : "", rc ? e->err.c_str() : "");
+    }
+    return 0;
+}
+
+// minimum over the ranks of a host flag, through the communicator (the mailbox form's go / no-go decisions)
+static int dist_all_min(ccsim_engine *e, int32_t mine, int32_t *out) {
+    int32_t *buf = (int32_t *)e->d_own_send; // (idle here: the pass protocol has not started / is over)
+    HIPCHK(e, hipMemcpyAsync(buf, &mine, sizeof mine, hipMemcpyHostToDevice, e->stream));
+    RCCLCHK(e, rccl().AllReduce(buf, buf, 1, kNcclInt32, kNcclMin, e->rccl_comm, e->stream));
+    HIPCHK(e, hipMemcpyAsync(out, buf, sizeof *out, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_own_send, 0, sizeof(XRec), e->stream));
     return 0;
 }
 
@@ -2163,6 +2354,26 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
     static_assert(sizeof(XRec) == CCSIM_XCHG_WORDS * 8, "exchange record size");
     int rc = ccsim_dist_begin(e, max_limit, mode, e->comm_ranks, e->comm_rank, e->d_own_send, e->d_own_recv, out->log ? out->log_cap : 0);
     if (rc) return rc;
+    // The persistent kernel across the GPUs (mailboxes connected by ccsim_dist_comm_init under CCSIM_DIST_MAILBOX=1): one launch per
+    // rank for the whole batched run, the exchange inside the kernel.  Two agreements around it -- is every rank eligible, did every
+    // rank finish -- and the pass protocol below as the fallback from the untouched state.
+    if (mode == CCSIM_MODE_BATCHED && e->mbox_ready && e->mb_ranks == e->comm_ranks) { // (connected by the same collective call on every rank)
+        int32_t go = e->mb_go, fine = 0;
+        if (go < 0) { // (once per pod spec: eligibility is a property of the snapshot and the pod)
+            if ((rc = dist_all_min(e, ccsim_dist_mbox_eligible(e), &go))) return rc;
+            e->mb_go = go;
+        }
+        if (go) {
+            int32_t ok = 0;
+            const int lrc = ccsim_dist_mbox_launch(e);
+            if (lrc == 0 && (rc = ccsim_dist_mbox_status(e, &ok))) return rc;
+            if ((rc = dist_all_min(e, lrc == 0 ? ok : 0, &fine))) return rc;
+            if (dist_debug()) fprintf(stderr, "[ccsim dist] rank %d: mailbox form %s (%.3f ms)\n", e->comm_rank, fine ? "finished on every rank" : "abandoned: pass protocol", e->kernel_ms);
+            rc = ccsim_dist_mbox_finish(e, fine);
+            if (rc < 0) return rc;
+            if (fine) return ccsim_dist_finish(e, out);
+        }
+    }
     int per_poll = 32;
     if (const char *f = getenv("CCSIM_DIST_POLL")) per_poll = atoi(f) > 0 ? atoi(f) : per_poll; // tuning knob (the SAME value on every rank)
     int64_t last_placed = -1;

@@ -41,6 +41,7 @@ constexpr int kTagShift = 40;        // max-words: generation tag above a 40-bit
 constexpr int DONE_ERROR = 3;
 constexpr unsigned kGenErr = 0xffffffffu; // PersistSync::gen: the run is abandoned
 constexpr int kPSpinLimit = 1 << 22;
+constexpr int kPMboxSpinLimit = 1 << 21; // polls of a rank's mailbox (two system-scope loads + s_sleep each: a few seconds) before the rank gives up
 
 struct PersistSync { // global memory, one per rank; zeroed by the host before every launch
     unsigned long long slot[2][kPGroups][8]; // [parity][group][word]; words 0,3,4,5,6: tagged max; 1,2,7: cumulative add
@@ -269,7 +270,7 @@ __device__ __forceinline__ void grid_reduce(GridCtx &gc) {
             }
             if (__ballot(ok) == ~0ull) break;
             ++spins;
-            if (spins > kPSpinLimit || ((spins & 255) == 0 && (__hip_atomic_load(&box->err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (gc.tag_base | 1u) ||
+            if (spins > kPMboxSpinLimit || ((spins & 255) == 0 && (__hip_atomic_load(&box->err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (gc.tag_base | 1u) ||
                                                                p_ld_u32(&s->err[0])))) {
                 bad = true;
                 break;

@@ -340,6 +340,32 @@ int ccsim_dist_sync_tables(ccsim_engine *e);
  * placements (-1 elsewhere), as ccsim_dist_finish does. */
 int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out);
 
+/* ---- multi-GPU, the persistent level kernel ACROSS the GPUs (csrc/ccsim_persist.h, mailbox form; SURVEY.md 8(e) "if RCCL latency
+ * dominates: persistent kernels + P2P-mapped flag/mailbox buffers over xGMI implementing the 8-way max-loc in-kernel") ----
+ * Every rank keeps its shard in LDS for the whole batched run; the grid-wide reduce of the one-GPU form is extended over the ranks:
+ * the workgroup that completes a rank's local reduction writes the rank's eight words as tagged 8-byte granules into a mailbox
+ * on every GPU (one 128-byte store burst per peer per sync over xGMI), every workgroup polls its own GPU's box.  No collective
+ * call, no kernel boundary per exchange.  A rank that cannot take part (snapshot not eligible, a peer's box not mappable, a
+ * bounded spin that expired) makes ALL ranks fall back to the pass protocol above: nothing is published before every rank agrees.
+ *   ccsim_dist_mbox_info     this rank's addressing record (process, device, pointer, IPC handle): allocate the box, CCSIM_MBOX_INFO_BYTES out
+ *   ccsim_dist_mbox_connect  all ranks' records, in rank order: map every peer's box (same process: directly / peer access; else IPC)
+ *   ccsim_dist_mbox_eligible 1 if this rank's shard and pod qualify for the persistent form (collect the minimum over the ranks)
+ *   -- then, after ccsim_dist_begin(mode = CCSIM_MODE_BATCHED) on every rank and only if EVERY rank is eligible:
+ *   ccsim_dist_mbox_launch   enqueue the persistent launch (asynchronous)
+ *   ccsim_dist_mbox_status   wait for it; *ok = 1 if this rank finished the run cleanly (collect the minimum over the ranks)
+ *   ccsim_dist_mbox_finish   all_ok = 1: publish the result (then ccsim_dist_finish as usual), returns 0.  all_ok = 0: restore the
+ *                            run state of ccsim_dist_begin and return 1: continue with ccsim_dist_scan / _decide from the untouched columns.
+ * ccsim_dist_comm_init + ccsim_dist_run do all of this over the engine's RCCL communicator when CCSIM_DIST_MAILBOX=1 (default 0:
+ * the form has been validated on one GPU -- virtual ranks inside one grid, two engines and two processes sharing the device --
+ * never on a multi-GPU box). */
+#define CCSIM_MBOX_INFO_BYTES 96
+int ccsim_dist_mbox_info(ccsim_engine *e, uint8_t *info_out /* [CCSIM_MBOX_INFO_BYTES] */);
+int ccsim_dist_mbox_connect(ccsim_engine *e, const uint8_t *all_infos /* [n_ranks][CCSIM_MBOX_INFO_BYTES] */, int32_t n_ranks, int32_t rank);
+int ccsim_dist_mbox_eligible(ccsim_engine *e);
+int ccsim_dist_mbox_launch(ccsim_engine *e);
+int ccsim_dist_mbox_status(ccsim_engine *e, int32_t *ok);
+int ccsim_dist_mbox_finish(ccsim_engine *e, int32_t all_ok);
+
 /* Topology-coupled plugins on several GPUs (hard PodTopologySpread constraints, InterPodAffinity): the per-domain
  * count / score tables are replicated on every rank, but ccsim_set_pod can only fill them from the rank's own nodes.
  * After ccsim_set_pod on every rank the caller all-reduces each table in place across ranks (table i:

@@ -281,6 +281,13 @@ int ccsim_reset_state(ccsim_engine *e) { (void)e; return -38; }
 void *ccsim_host_alloc(ccsim_engine *e, size_t bytes) { (void)e; return calloc(1, bytes); }
 void ccsim_host_free(ccsim_engine *e, void *p) { (void)e; free(p); }
 int ccsim_time_scan(ccsim_engine *e, int32_t a, int32_t b, int64_t *c, int64_t *d) { (void)e, (void)a, (void)b, (void)c, (void)d; return -38; }
+/* the mailbox form (ccsim_dist_mbox_*): not recorded -- "not eligible", so that a host falls back to the pass protocol */
+int ccsim_dist_mbox_info(ccsim_engine *e, uint8_t *o) { (void)e, (void)o; return -38; }
+int ccsim_dist_mbox_connect(ccsim_engine *e, const uint8_t *a, int32_t n, int32_t r) { (void)e, (void)a, (void)n, (void)r; return -38; }
+int ccsim_dist_mbox_eligible(ccsim_engine *e) { (void)e; return 0; }
+int ccsim_dist_mbox_launch(ccsim_engine *e) { (void)e; return -38; }
+int ccsim_dist_mbox_status(ccsim_engine *e, int32_t *ok) { (void)e, (void)ok; return -38; }
+int ccsim_dist_mbox_finish(ccsim_engine *e, int32_t all_ok) { (void)e, (void)all_ok; return -38; }
 int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_coupled(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }

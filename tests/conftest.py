@@ -35,7 +35,7 @@ def _have_gpu() -> bool:
 # one-rank RCCL path on a cold box).  Files not named keep their alphabetical order between the two groups.
 _ORDER_FIRST = ["test_gpu_parity.py", "test_persist.py", "test_sampling.py", "test_spread.py", "test_ipa.py", "test_coupled.py", "test_multi.py",
                 "test_ports_images.py", "test_golden.py", "test_baseline_configs.py", "test_kernel_resources.py"]
-_ORDER_LAST = ["test_dist_rccl.py", "test_abi.py", "test_preemption.py", "test_ingest_cli.py", "test_host_robustness.py", "test_native_host.py"]
+_ORDER_LAST = ["test_dist_mailbox.py", "test_dist_rccl.py", "test_abi.py", "test_preemption.py", "test_ingest_cli.py", "test_host_robustness.py", "test_native_host.py"]
 
 
 def _file_rank(item) -> int:

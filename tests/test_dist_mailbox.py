@@ -1,0 +1,251 @@
+"""The persistent level kernel ACROSS ranks (csrc/ccsim_persist.h, mailbox form; include/ccsim.h ccsim_dist_mbox_*): every rank keeps
+its shard in LDS, the grid-wide reduce is extended over the ranks through mailboxes (tagged 8-byte granules written into every
+rank's box by the workgroup that completes a rank's local reduction), nothing is published before every rank reports success.
+
+The GPU box has ONE GPU, so the ranks here are
+  * several ENGINES of one process on the same device, each with its own stream: separate persistent grids running side by side,
+    each polling its own box and writing into the others' through plain device pointers (what `cluster-capacity-native --gpus N`
+    does with peer access between devices);
+  * two PROCESSES sharing the device: the boxes mapped through hipIpcGetMemHandle / hipIpcOpenMemHandle (what one process per GPU
+    does over xGMI);
+  * one rank over the engine's RCCL communicator (CCSIM_DIST_MAILBOX=1 inside ccsim_dist_comm_init / ccsim_dist_run).
+tests/test_persist.py::test_mailbox_form_on_virtual_ranks runs the same kernel code on virtual ranks inside ONE grid."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if "cluster_capacity_amd" not in sys.modules:  # (a spawned rank imports this module without conftest.py)
+    for _p in (_ROOT, os.path.join(_ROOT, "tests")):
+        if _p not in sys.path:
+            sys.path.insert(0, _p)
+    import __graft_entry__ as _ge
+
+    _ge.load_package()
+
+import helpers as H
+from cluster_capacity_amd import capi, dist as ccdist, model as M, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Ranks:
+    """`world` engines on device 0, one stream each, mailboxes connected; exchange buffers for the pass protocol (the fallback)."""
+
+    def __init__(self, nodes, pod, prof, world):
+        import torch
+
+        self.torch, self.world = torch, world
+        self.streams = [torch.cuda.Stream(device=0) for _ in range(world)]
+        self.engines = []
+        for r in range(world):
+            lo, hi = ccdist.shard_bounds(nodes.n, world, r)
+            e = capi.Engine(device=0, stream=self.streams[r].cuda_stream, use_graph=False)
+            e.load(nodes.slice(lo, hi), ccdist.shard_pod(pod, lo, hi), prof, global_offset=lo, n_global=nodes.n)
+            self.engines.append(e)
+        self.send = [torch.zeros(capi.XCHG_WORDS, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+        self.recv = [torch.zeros(capi.XCHG_WORDS * world, dtype=torch.int64, device="cuda:0") for _ in range(world)]
+        infos = [e.dist_mbox_info() for e in self.engines]
+        for r, e in enumerate(self.engines):
+            e.dist_mbox_connect(infos, r)
+        torch.cuda.synchronize()
+
+    def run(self, limit, log_cap):
+        W = self.world
+        for r, e in enumerate(self.engines):
+            e.dist_begin(limit, "batched", W, r, self.send[r].data_ptr(), self.recv[r].data_ptr(), log_cap)
+        self.eligible = all([e.dist_mbox_eligible() for e in self.engines])  # (the agreement every rank takes part in)
+        stood = [False]
+        if self.eligible:
+            for e in self.engines:
+                e.dist_mbox_launch()  # asynchronous: the ranks' persistent grids run side by side
+            oks = [e.dist_mbox_status() for e in self.engines]
+            stood = [e.dist_mbox_finish(all(oks)) for e in self.engines]
+            assert all(stood) == all(oks) and len(set(stood)) == 1
+        if not stood[0]:  # the pass protocol from the untouched state (ccsim_dist_scan -> all-gather -> ccsim_dist_decide)
+            for _ in range(100_000):
+                for e in self.engines:
+                    e.dist_scan()
+                for s in self.streams:
+                    s.synchronize()
+                gathered = self.torch.cat(self.send)
+                for r in range(W):
+                    self.recv[r].copy_(gathered)
+                self.torch.cuda.synchronize()
+                for e in self.engines:
+                    e.dist_decide()
+                if all([e.dist_poll()[0] for e in self.engines]):
+                    break
+        res = [e.dist_finish(log_cap > 0, log_cap) for e in self.engines]
+        return stood[0], res, (ccdist.merge_logs([r.log for r in res]) if log_cap > 0 else None)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+
+def _check(res, log, ref, want_log):
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res)
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    if want_log:
+        assert np.array_equal(log[: ref.placed], ref.log)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
+
+
+@pytest.mark.parametrize("world,cfg,n,limit", [(2, "C3", 3000, 0), (3, "C3", 5000, 1234), (4, "C3", 4000, 0), (2, "C2", 2500, 700)])
+def test_mailbox_form_between_engines_of_one_process(ccref, world, cfg, n, limit):
+    # (at most 4 engines: the runtime maps the streams of a process onto 4 hardware queues by default, GPU_MAX_HW_QUEUES -- a fifth
+    # persistent grid would queue behind one that waits for it; eight ranks run as virtual ranks in tests/test_persist.py)
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=31 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    rk = _Ranks(nodes, pod, prof, world)
+    for want_log in (False, True):  # blind batches / the ordered path (positions over the ranks)
+        stood, res, log = rk.run(limit, max(1, ref.placed) if want_log else 0)
+        assert stood, "the ranks' persistent grids did not all finish (not co-resident?)"
+        _check(res, log, ref, want_log)
+        for e in rk.engines:
+            e.reset_state()
+    rk.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mailbox_form_random_plugin_mix_between_engines(ccref, seed):
+    """Few holders of the normalization maxima: events, roll-backs and batches that end at the event, across ranks."""
+    rng = np.random.default_rng(4200 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(600, 3000)))
+    prof.filter_mask |= M.F_FIT
+    world = int(rng.integers(2, 5))
+    rk = _Ranks(nodes, pod, prof, world)
+    for limit in (0, int(rng.choice([37, 500]))):
+        ref = ccref.run(prof, nodes, pod, max_limit=limit)
+        stood, res, log = rk.run(limit, 0)
+        assert stood == rk.eligible  # (a shard that does not qualify -- extended resources, odd memory units -- sends every rank to the pass protocol)
+        _check(res, log, ref, False)
+        for e in rk.engines:
+            e.reset_state()
+    rk.close()
+
+
+def test_a_rank_that_cannot_finish_makes_every_rank_fall_back(ccref, monkeypatch):
+    """Injected: workgroup 0 of every engine never arrives at its first local barrier (CCSIM_PERSIST_FAULT): the bounded spins expire,
+    every rank reports failure, nobody publishes, and the pass protocol finishes the run from the untouched state."""
+    monkeypatch.setenv("CCSIM_PERSIST_FAULT", "1")
+    nodes, pod, prof = synth.make_config("C3", n_nodes=2500, seed=8)
+    ref = ccref.run(prof, nodes, pod, max_limit=0, threads=8)
+    rk = _Ranks(nodes, pod, prof, 2)
+    stood, res, log = rk.run(0, 0)
+    assert not stood
+    _check(res, log, ref, False)
+    rk.close()
+
+
+def _child(rank, world, n, limit, conn):
+    """One rank as a process of its own (spawned): the parent relays the addressing records and the go / no-go flags."""
+    import torch
+    from cluster_capacity_amd import capi as C2, dist as D2, synth as S2
+
+    nodes, pod, prof = S2.make_config("C3", n_nodes=n, seed=31 + n)
+    lo, hi = D2.shard_bounds(n, world, rank)
+    e = C2.Engine(device=0, use_graph=False)
+    e.load(nodes.slice(lo, hi), D2.shard_pod(pod, lo, hi), prof, global_offset=lo, n_global=n)
+    conn.send(e.dist_mbox_info())
+    infos = conn.recv()
+    try:
+        e.dist_mbox_connect(infos, rank)
+    except C2.CcsimError as ex:
+        conn.send(("noconnect", str(ex)))
+        return
+    conn.send(("connected", ""))
+    if not conn.recv():
+        return
+    send = torch.zeros(C2.XCHG_WORDS, dtype=torch.int64, device="cuda:0")
+    recv = torch.zeros(C2.XCHG_WORDS * world, dtype=torch.int64, device="cuda:0")
+    e.dist_begin(limit, "batched", world, rank, send.data_ptr(), recv.data_ptr(), 0)
+    conn.send(bool(e.dist_mbox_eligible()))
+    if not conn.recv():
+        return
+    e.dist_mbox_launch()
+    conn.send(bool(e.dist_mbox_status()))
+    all_ok = conn.recv()
+    stood = e.dist_mbox_finish(all_ok)
+    if stood:
+        r = e.dist_finish(False, 0)
+        conn.send(("stood", int(r.placed), int(r.stop), r.per_node_count, r.hist))
+    else:
+        st = e.read_state()
+        conn.send(("fellback", np.array_equal(st["pod_count"], nodes.slice(lo, hi).pod_count)))
+    e.close()
+
+
+def test_mailbox_form_between_two_processes_over_ipc_handles(ccref):
+    """One process per rank, the boxes mapped through IPC handles.  Both processes share the one GPU of the box: if their persistent
+    grids do not run side by side the bounded spins expire and both fall back -- then the untouched state is what is checked."""
+    import multiprocessing as mp
+
+    world, n, limit = 2, 3000, 0
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=31 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(world)]
+    procs = [ctx.Process(target=_child, args=(r, world, n, limit, pipes[r][1])) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        par = [pp[0] for pp in pipes]
+        assert all(c.poll(H.SUBPROC_TIMEOUT) for c in par)
+        infos = [c.recv() for c in par]
+        for c in par:
+            c.send(infos)
+        conn = [c.recv() for c in par]
+        go = all(k == "connected" for k, _ in conn)
+        for c in par:
+            c.send(go)
+        if not go:
+            pytest.skip("the boxes could not be mapped across processes here: %s" % (conn,))
+        elig = [c.recv() for c in par]
+        for c in par:
+            c.send(all(elig))
+        assert all(elig)
+        oks = [c.recv() for c in par]
+        for c in par:
+            c.send(all(oks))
+        out = [c.recv() for c in par]
+    finally:
+        for p in procs:
+            p.join(H.SUBPROC_TIMEOUT)
+            if p.is_alive():
+                p.terminate()
+    print("two processes on one GPU:", [o[0] for o in out], "oks", oks)
+    if all(oks):
+        assert all(o[0] == "stood" for o in out)
+        assert all(o[1] == ref.placed and o[2] == ref.stop for o in out)
+        assert np.array_equal(np.concatenate([o[3] for o in out]), ref.per_node_count)
+        assert np.array_equal(sum(o[4] for o in out), ref.hist)
+    else:
+        assert all(o[0] == "fellback" and o[1] for o in out)
+
+
+@pytest.mark.parametrize("cfg,n,limit", [("C3", 1500, 0), ("C3", 20_000, 2_345)])
+def test_library_driven_run_takes_the_mailbox_form(ccref, monkeypatch, capfd, cfg, n, limit):
+    """ccsim_dist_comm_init / ccsim_dist_run with CCSIM_DIST_MAILBOX=1 (one rank: the box has one GPU): addressing records over the
+    communicator, the two agreements as ncclAllReduce(min), the persistent launch, the commit rows published."""
+    monkeypatch.setenv("CCSIM_DIST_MAILBOX", "1")
+    monkeypatch.setenv("CCSIM_DIST_DEBUG", "1")
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=500 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    e = capi.Engine(device=0, use_graph=False)
+    e.load(nodes, pod, prof)
+    e.dist_comm_init(capi.dist_unique_id(), 1, 0)
+    for rep in range(2):
+        e.reset_state()
+        got = e.dist_run(limit, "batched", want_log=True, log_cap=max(1, ref.placed))
+        assert got.placed == ref.placed and got.stop == ref.stop
+        assert np.array_equal(got.per_node_count, ref.per_node_count) and np.array_equal(got.log, ref.log)
+        if ref.stop == M.STOP_UNSCHEDULABLE:
+            assert np.array_equal(got.hist, ref.hist)
+    e.close()
+    err = capfd.readouterr().err
+    assert "mailboxes connected" in err and err.count("mailbox form finished on every rank") == 2, err[-2000:]
