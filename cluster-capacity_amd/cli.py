@@ -258,7 +258,14 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         # do not depend on it when nothing observes the ORDER of the placements (no --max-limit, no topology-coupled plugin): then
         # every node is scored (the fast batched mode); otherwise the reference's default applies
         # (several templates are always searched completely: the engine's windows need every node scored)
-        pct = 0 if len(pods) == 1 and (args.max_limit > 0 or snap.pod.spread or snap.pod.ipa is not None) else 100
+        # Round 4: a template with topology-coupled plugins is searched completely too (the windowed mode, csrc/ccsim_coupled.h, needs
+        # every node scored; a sampled search cannot be windowed) -- with a note, as host/engine.hpp simulate() prints it
+        coupled = bool(snap.pod.spread) or snap.pod.ipa is not None
+        pct = 0 if len(pods) == 1 and args.max_limit > 0 and not coupled else 100
+        if len(pods) == 1 and coupled and snap.nodes.n >= 100:
+            print("cluster-capacity: note: a template with topology spread constraints / inter-pod affinity is placed with every node scored "
+                  "(percentageOfNodesToScore 100); the placed set and order may differ from a run of the reference's default adaptive sampling "
+                  "(--percentage-of-nodes-to-score 0 selects it)", file=sys.stderr)
     result = simulate(snap, args.max_limit, args.mode, percentage_of_nodes_to_score=pct, profile=prof)
     review = build_review(pod, snap, result, args.max_limit, prof.filter_mask)
     if args.output == "json":

@@ -573,8 +573,10 @@ def test_native_host_marshals_the_c_abi_like_the_python_binding(native, recorder
         keep = []
         assert lib.ccsim_load_nodes(h, C.byref(capi.marshal_nodes(snap.nodes, keep))) == 0
         # --max-limit makes the run order-dependent: without an explicit percentageOfNodesToScore the host applies the reference's
-        # default (0 = adaptive sampling), see host/engine.hpp simulate()
-        assert lib.ccsim_set_profile(h, C.byref(capi.marshal_profile(dataclasses.replace(M.Profile.default(), percentage_of_nodes_to_score=0)))) == 0
+        # default (0 = adaptive sampling), see host/engine.hpp simulate() -- except for a template with topology-coupled plugins,
+        # which is searched completely (the windowed mode needs every node scored; the host says so on stderr)
+        coupled_tpl = bool(snap.pod.spread) or snap.pod.ipa is not None
+        assert lib.ccsim_set_profile(h, C.byref(capi.marshal_profile(dataclasses.replace(M.Profile.default(), percentage_of_nodes_to_score=100 if coupled_tpl else 0)))) == 0
         assert lib.ccsim_set_pod(h, C.byref(capi.marshal_pod(snap.pod, keep))) == 0
         lib.ccsim_destroy(h)
     finally:
