@@ -49,7 +49,7 @@ class CTerm(C.Structure):
 class CSpread(C.Structure):
     _fields_ = [("col", C.c_int32), ("max_skew", C.c_int32), ("min_domains", C.c_int32), ("hard", C.c_int32),
                 ("self_match", C.c_int32), ("n_domains", C.c_int32), ("node_match_count", _p32), ("node_included", _pu8),
-                ("is_hostname", C.c_int32)]
+                ("is_hostname", C.c_int32), ("missing_value", C.c_int32)]
 
 
 class CIpa(C.Structure):
@@ -275,6 +275,7 @@ def marshal_pod(pod: M.PodSpec, keep: list) -> CPod:
         c.col, c.max_skew, c.min_domains = int(k.col), int(k.max_skew), int(k.min_domains)
         c.hard, c.self_match, c.n_domains = int(bool(k.hard)), int(bool(k.self_match)), int(k.n_domains)
         c.is_hostname = int(bool(k.is_hostname))
+        c.missing_value = int(getattr(k, "missing_value", 0))
         if k.node_match_count is not None:
             a = np.ascontiguousarray(k.node_match_count, dtype=np.int32)
             keep.append(a)
@@ -381,6 +382,10 @@ class Engine:
     def load(self, nodes: M.NodesSoA, pod, profile: M.Profile, global_offset: int = 0,
              n_global: Optional[int] = None):
         """`pod`: one M.PodSpec, or a list of them (cycled round-robin: ccsim_set_pods)."""
+        if not isinstance(pod, (list, tuple)) and getattr(pod, "soft_relaxed", False):
+            if global_offset or (n_global not in (None, nodes.n)):
+                raise ValueError("a pod scored with requireAllTopologies = false: apply model.relax_soft to the WHOLE snapshot before sharding it")
+            nodes, pod = M.relax_soft(nodes, pod)  # (the engine form: one more value id for the nodes that lack a key, ccsim.h missing_value)
         keep: list = []
         self._chk(self.lib.ccsim_load_nodes(self.h, C.byref(marshal_nodes(nodes, keep, global_offset, n_global))), "ccsim_load_nodes")
         self.n = nodes.n
@@ -394,6 +399,8 @@ class Engine:
         self._chk(self.lib.ccsim_set_profile(self.h, C.byref(marshal_profile(profile))), "ccsim_set_profile")
 
     def set_pod(self, pod: M.PodSpec):
+        if getattr(pod, "soft_relaxed", False):
+            raise ValueError("a pod scored with requireAllTopologies = false needs its nodes' label columns extended: Engine.load / model.relax_soft")
         keep: list = []
         cp = marshal_pod(pod, keep)
         self._chk(self.lib.ccsim_set_pod(self.h, C.byref(cp)), "ccsim_set_pod")

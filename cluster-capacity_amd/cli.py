@@ -247,7 +247,7 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         return 1
     if snap.default_spreading_unmodelled:
         print("warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's system default "
-              "spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; some node lacks one of the two labels (or several templates run): "
+              "spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; some node lacks the kubernetes.io/hostname label (or several templates run): "
               "not modelled -- the order of the placements (and so a --max-limit result) may differ, the total does not", file=sys.stderr)
     if args.percentage_of_nodes_to_score is not None:
         pct = args.percentage_of_nodes_to_score

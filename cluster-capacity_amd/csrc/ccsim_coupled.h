@@ -566,7 +566,7 @@ template <int MH, int MS, int MK>
 struct CwP {
     int nh, ns, nk;
     int h_comp[MH], h_unique[MH], h_off[MH], h_len[MH], h_pres[MH], h_skew[MH], h_self[MH], h_usemin[MH];
-    int s_comp[MS], s_off[MS], s_len[MS], s_bm[MS], s_host[MS], s_self[MS], s_skew[MS];
+    int s_comp[MS], s_off[MS], s_len[MS], s_bm[MS], s_host[MS], s_self[MS], s_skew[MS], s_nocredit[MS];
     int k_comp[MK], k_unique[MK], k_off[MK], k_len[MK], k_aff[MK], k_anti[MK], k_daff[MK], k_danti[MK], k_dent[MK];
     long long k_dscore[MK];
     int soft_w, ipa_w, ipa_filter, ipa_any_term, self_aff;
@@ -585,6 +585,7 @@ struct CwP {
             const bool on = c < ns;
             s_comp[c] = on ? a.plan.s_comp[c] : 0, s_off[c] = on ? a.plan.s_off[c] : 0, s_len[c] = on ? a.plan.s_len[c] : 0, s_bm[c] = on ? a.plan.s_bm[c] : 0;
             s_host[c] = on ? a.soft.is_hostname[c] : 0, s_self[c] = on ? a.soft.self_match[c] : 0, s_skew[c] = on ? a.soft.max_skew[c] : 0;
+            s_nocredit[c] = on ? a.soft.nocredit[c] : 0;
         }
 #pragma unroll
         for (int k = 0; k < MK; k++) {
@@ -1419,6 +1420,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide(const CwDecideArgs *__
                             for (int c = 0; c < MS; c++)
                                 if (c < P.ns) {
                                     const int32_t tv = t[P.s_comp[c]];
+                                    if (!P.s_host[c] && tv == P.s_nocredit[c] && tv != 0) continue; // key missing under the system defaults: no credit (scoring.go:210)
                                     const int64_t ct = P.s_host[c] ? (int64_t)(tv >> 1) : (int64_t)L.i32[P.s_off[c] + tv];
                                     sc += (double)ct * L.soft_w[c] + (double)(P.s_skew[c] - 1);
                                 }

@@ -132,6 +132,8 @@ struct ccsim_engine {
     int mb_k = 0;                       // K of the launch in flight
     int mb_go = -1;                     // ccsim_dist_run: did every rank call this pod / snapshot eligible? (-1: not agreed yet; reset by set_pod / load_nodes / comm_init -- SPMD: on every rank alike)
     DevState mb_state0{};               // the run state ccsim_dist_begin uploaded (restored when the ranks fall back to the pass protocol)
+    int32_t *d_mb_ok = nullptr;         // device flag of the launch in flight: 1 = this rank finished cleanly (ccsim_persist.h ok_flag)
+    int32_t *h_mb_ok = nullptr;         // ... and the ranks' minimum, page-locked
     uint32_t persist_seq = 0;           // launch sequence of the mailbox form (tags: nothing is zeroed between launches)
     int persist_vranks = 0;             // CCSIM_PERSIST_VRANKS: run the single-device batched mode as that many virtual ranks
     bool reset_pending = false;         // ccsim_reset_state deferred the restore of the node columns: the next persistent launch loads the
@@ -340,6 +342,8 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->h_hist_pin) (void)hipHostFree(e->h_hist_pin);
     for (void *p : e->mbox_ipc_open) (void)hipIpcCloseMemHandle(p);
     if (e->d_mbox) (void)hipFree(e->d_mbox);
+    if (e->d_mb_ok) (void)hipFree(e->d_mb_ok);
+    if (e->h_mb_ok) (void)hipHostFree(e->h_mb_ok);
     dist_comm_release(e);
     for (hipEvent_t ev : e->pass_events) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -738,6 +742,9 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
                 DevSoft &so = e->soft;
                 so.max_skew[j] = k.max_skew, so.self_match[j] = k.self_match ? 1 : 0, so.is_hostname[j] = k.is_hostname ? 1 : 0;
                 so.n_domains[j] = k.n_domains;
+                if (k.missing_value < 0 || k.missing_value > k.n_domains || (k.missing_value && k.is_hostname))
+                    return fail(e, -EINVAL, "spread constraint: missing_value must name a value id of a non-hostname key");
+                so.nocredit[j] = k.missing_value;
                 so.label[j] = lc[k.col], so.tbl[j] = tbl, so.existing[j] = ex;
                 int32_t *flag = nullptr;
                 if ((rc = dev_alloc(e, &flag, len, e->pod_allocs))) return rc;
@@ -1548,6 +1555,8 @@ static int mbox_alloc(ccsim_engine *e) {
     }
     HIPCHK(e, hipMemset(p, 0, sizeof(PersistMailbox) * kPMaxRanks));
     e->d_mbox = (PersistMailbox *)p;
+    HIPCHK(e, hipMalloc((void **)&e->d_mb_ok, sizeof(int32_t) * 4));
+    HIPCHK(e, hipHostMalloc((void **)&e->h_mb_ok, sizeof(int32_t) * 4, hipHostMallocDefault));
     return 0;
 }
 
@@ -2115,6 +2124,8 @@ extern "C" int ccsim_dist_mbox_launch(ccsim_engine *e) {
     a.c.hist = nullptr;
     const int grid = (int)((e->n_pad + (int64_t)k * kPThreads - 1) / ((int64_t)k * kPThreads));
     HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync), e->stream));
+    HIPCHK(e, hipMemsetD32Async((hipDeviceptr_t)e->d_mb_ok, 1, 1, e->stream));
+    a.ok_flag = e->d_mb_ok;
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     launch_persist(e, k, true, grid, a);
     HIPCHK(e, hipGetLastError());
@@ -2364,10 +2375,18 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
             e->mb_go = go;
         }
         if (go) {
-            int32_t ok = 0;
+            // launch -> ncclAllReduce(min) of the device flag -> state + verdict to the host: ONE stream sync for the whole run
             const int lrc = ccsim_dist_mbox_launch(e);
-            if (lrc == 0 && (rc = ccsim_dist_mbox_status(e, &ok))) return rc;
-            if ((rc = dist_all_min(e, lrc == 0 ? ok : 0, &fine))) return rc;
+            if (lrc != 0) HIPCHK(e, hipMemsetAsync(e->d_mb_ok, 0, sizeof(int32_t), e->stream)); // (this rank could not launch: every rank falls back)
+            RCCLCHK(e, rccl().AllReduce(e->d_mb_ok, e->d_mb_ok, 1, kNcclInt32, kNcclMin, e->rccl_comm, e->stream));
+            HIPCHK(e, hipMemcpyAsync(e->h_mb_ok, e->d_mb_ok, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+            if ((rc = read_state(e))) return rc; // (synchronizes)
+            fine = e->h_mb_ok[0];
+            if (lrc == 0) {
+                float ms = 0;
+                HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+                e->kernel_ms = ms, e->pass_kernel_ms = ms, e->pass_launches = 1;
+            }
             if (dist_debug()) fprintf(stderr, "[ccsim dist] rank %d: mailbox form %s (%.3f ms)\n", e->comm_rank, fine ? "finished on every rank" : "abandoned: pass protocol", e->kernel_ms);
             rc = ccsim_dist_mbox_finish(e, fine);
             if (rc < 0) return rc;

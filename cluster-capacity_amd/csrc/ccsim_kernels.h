@@ -148,6 +148,8 @@ struct DevPts {
 struct DevSoft {
     int32_t n, w; // soft constraints; plugin weight (0 = Score off)
     int32_t max_skew[kMaxTsc], self_match[kMaxTsc], is_hostname[kMaxTsc], n_domains[kMaxTsc];
+    int32_t nocredit[kMaxTsc];        // value id that stands for "the node lacks the key" under requireAllTopologies = false (ccsim.h missing_value): a
+                                      // domain like any other when sizes and counts are taken, no score for this constraint (scoring.go:210); 0 = none
     const int32_t *label[kMaxTsc];
     int32_t *tbl[kMaxTsc];            // matching pods per domain, over counted nodes
     int32_t *flag[kMaxTsc];           // epoch of the last scan that saw a feasible non-ignored node in the domain
@@ -748,6 +750,7 @@ __device__ __forceinline__ int64_t soft_raw_score(const DevSoft &p, const double
         else {
             cnt = p.tbl[c][v];
             p.flag[c][v] = epoch;
+            if (p.nocredit[c] && v == p.nocredit[c]) continue; // the key is missing on this node (system default constraints): counted above, no credit (scoring.go:210)
         }
         score += (double)cnt * soft_w[c] + (double)(p.max_skew[c] - 1);
     }

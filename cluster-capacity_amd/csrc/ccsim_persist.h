@@ -108,6 +108,8 @@ struct PersistArgs {
     int32_t vranks, bpr;     // virtual ranks inside this grid (0 = a real rank per device), workgroups per virtual rank
     uint32_t tag_base;       // launch sequence << 20
     PersistMailbox *mbox[kPMaxRanks]; // every rank's box as THIS device addresses it
+    int32_t *ok_flag;        // mailbox form: preset to 1 by the host, zeroed by any workgroup that gives up or by an unfinished run -- the
+                             // ranks agree on it (ncclAllReduce min, enqueued right behind the launch) before anything is published
 };
 
 template <int K>
@@ -1035,8 +1037,10 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
     // commit rows, which nobody reads until every rank has reported success to the host.
     if (s_err || p_ld_u32(&sync->err[0])) {
         if (lb == 0 && tid == 0) a.st->done = DONE_ERROR;
+        if (MB && tid == 0 && a.ok_flag) __hip_atomic_store(a.ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    if (MB && tid == 0 && a.ok_flag && !done) __hip_atomic_store(a.ok_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (out of syncs: not a finished run)
     PTICK(9);
     const int sh = a.c.mem_shift;
     const bool diag = !MB && done == DONE_UNSCHEDULABLE && a.c.hist != nullptr;

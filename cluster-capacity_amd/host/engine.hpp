@@ -90,6 +90,7 @@ struct MarshalledPod { // one template: the struct + the arrays it points into
 struct Marshalled {
     ccsim_nodes nodes{};
     ccsim_profile profile{};
+    std::vector<std::vector<int32_t>> extra_cols; // label columns made for the engine (requireAllTopologies = false: see marshal)
     std::vector<MarshalledPod> pods; // one per template (sized before the structs are filled: they point into themselves)
     std::vector<ccsim_pod> pod_array; // contiguous copies for ccsim_set_pods
 };
@@ -107,6 +108,29 @@ inline void marshal(const Snapshot &s, const HostProfile &prof, Marshalled &m) {
     for (size_t c = 0; c < s.label_cols.size(); c++) n.label_cols[c] = s.label_cols[c].data();
     m.pods.resize(s.n_templates());
     for (size_t t = 0; t < s.n_templates(); t++) marshal_pod(s.side(t), m.pods[t]);
+    // System default spreading (PodSide::soft_relaxed; scoring.go:61-115,140): the engine form.  Per ScheduleAnyway constraint whose
+    // column has nodes without the key, a new label column in which those nodes carry one more value id, named by missing_value: a
+    // domain like any other when sizes and counts are taken (the reference's "" value), no score for that constraint, and -- every node
+    // now carrying every key -- nobody ignored (include/ccsim.h; the Python binding does the same in model.relax_soft).
+    m.extra_cols.clear();
+    m.extra_cols.reserve(CCSIM_MAX_TSC);
+    if (s.n_templates() == 1 && s.soft_relaxed) {
+        ccsim_pod &p = m.pods[0].pod;
+        for (int i = 0; i < p.n_spread; i++) {
+            ccsim_spread_constraint &c = p.spread[i];
+            if (c.hard || c.is_hostname) continue;
+            const std::vector<int32_t> &src = s.label_cols[(size_t)c.col];
+            bool missing = false;
+            for (const int32_t v : src) missing = missing || v == 0;
+            if (!missing) continue;
+            if (n.n_label_cols >= CCSIM_MAX_LABEL_COLS) throw std::runtime_error("system default spreading: no label column left for the nodes without the zone key");
+            std::vector<int32_t> col(src);
+            for (auto &v : col) v = v == 0 ? c.n_domains + 1 : v;
+            m.extra_cols.push_back(std::move(col));
+            n.label_cols[n.n_label_cols] = m.extra_cols.back().data();
+            c.col = n.n_label_cols++, c.n_domains += 1, c.missing_value = c.n_domains;
+        }
+    }
     m.pod_array.clear();
     for (const auto &mp : m.pods) m.pod_array.push_back(mp.pod); // (the pointers inside stay valid: they point into m.pods[t])
     m.profile = prof.c;

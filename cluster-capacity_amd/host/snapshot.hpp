@@ -401,6 +401,7 @@ struct PodSide {
     std::vector<Term> required;
     std::vector<std::pair<int, Term>> preferred;
     std::vector<Spread> spread;
+    bool soft_relaxed = false;     // `spread` holds the plugin's system default constraints: scored with requireAllTopologies = false
     std::vector<uint8_t> included; // RequiredNodeAffinity.Match per node (spread inclusion policy); empty = all
     bool has_ipa = false;
     Ipa ipa;
@@ -816,18 +817,19 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     if (spec["resourceClaims"].truthy()) throw std::runtime_error("spec.resourceClaims: the DynamicResources plugin is not modelled");
 
     // topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
-    // System default spreading (a Service / the controller selects the template).  The plugin scores these with requireAllTopologies =
-    // false (scoring.go:61-115: a node without the key counts under the empty value instead of being ignored); when EVERY node carries
-    // both keys the two readings coincide and the constraints are exactly two more soft constraints of the pod -- otherwise they are
-    // left out and the caller is told (Snapshot::default_spreading_unmodelled)
+    // System default spreading (a Service / the controller selects the template): two more ScheduleAnyway constraints of the pod, scored
+    // with requireAllTopologies = false (scoring.go:61-115,140: a node without a key is not ignored, the missing key counts as the value
+    // "" when the domains are sized and scores nothing) -- PodSide::soft_relaxed; marshal() derives the engine's form (include/ccsim.h
+    // missing_value).  Left out, and the caller told (Snapshot::default_spreading_unmodelled), only when a node lacks the HOSTNAME label
+    // (the per-node constraint has no column to read then) or several templates run.
     Value constraints = Value::array();
     constraints.a = spec["topologySpreadConstraints"].items(); // (null = none; any other kind than a list is refused)
     if (constraints.a.empty() && system_default_spreading) {
         const Value defaults = system_default_constraints(sim_pod, spreading_objs);
         if (!defaults.a.empty()) {
             bool all = sim_pods.size() == 1; // (several templates: the engine keeps each template's spread state apart, a shared selector would couple them)
-            for (size_t i = 0; i < N && all; i++) all = (*nodes[i])["metadata"]["labels"].has(kHostname) && (*nodes[i])["metadata"]["labels"].has(kZone);
-            if (all) constraints = defaults;
+            for (size_t i = 0; i < N && all; i++) all = (*nodes[i])["metadata"]["labels"].has(kHostname);
+            if (all) constraints = defaults, s.soft_relaxed = true;
             else S.default_spreading_unmodelled = true;
         }
     }
@@ -1062,6 +1064,7 @@ inline Value pod_side_json(const PodSide &s) {
         sp.a.push_back(e);
     }
     p.set("required", rq), p.set("preferred", pf), p.set("spread", sp);
+    p.set("soft_relaxed", Value::boolean(s.soft_relaxed));
     if (s.has_ipa) {
         const Ipa &a = s.ipa;
         Value e = Value::object();

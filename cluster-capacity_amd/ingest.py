@@ -713,15 +713,17 @@ def _template_side(ctx: dict, sim_pod: dict):
     included = np.array([node_matches_required(i) for i in range(N)], np.uint8) if affinity_active else None
     constraints = list(spec.get("topologySpreadConstraints") or [])
     if not constraints and ctx.get("default_spreading") is not None:
-        # System default spreading (a Service / the controller selects the template).  The plugin scores these with
-        # requireAllTopologies = false (scoring.go:61-115: a node without the key counts under the empty value instead of being
-        # ignored); when EVERY node carries both keys the two readings coincide and the constraints are exactly two more soft
-        # constraints of the pod -- otherwise they are left out and the caller is told (pod.default_spreading_unmodelled)
+        # System default spreading (a Service / the controller selects the template): two more ScheduleAnyway constraints of the pod,
+        # scored with requireAllTopologies = false (scoring.go:61-115,140: a node without a key is not ignored, the missing key counts
+        # as the value "" when the domains are sized and scores nothing) -- PodSpec.soft_relaxed; the binding derives the engine's form
+        # (model.relax_soft).  Left out, and the caller told (pod.default_spreading_unmodelled), only when a node lacks the HOSTNAME
+        # label (the per-node constraint has no column to read then) or several templates run.
         defaults = system_default_constraints(sim_pod, *ctx["default_spreading"])
         if defaults:
             # (several templates: the engine keeps each template's spread state apart, a shared Service selector would couple them)
-            if ctx["n_templates"] == 1 and all(HOSTNAME in (n["metadata"].get("labels") or {}) and ZONE in (n["metadata"].get("labels") or {}) for n in nodes):
+            if ctx["n_templates"] == 1 and all(HOSTNAME in (n["metadata"].get("labels") or {}) for n in nodes):
                 constraints = defaults
+                pod.soft_relaxed = True
             else:
                 ctx["default_spreading_unmodelled"] = True
     for c in constraints:

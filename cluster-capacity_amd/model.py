@@ -149,6 +149,9 @@ class SpreadConstraint:
     n_domains: int = 0
     node_match_count: Optional[np.ndarray] = None  # int32[n] existing matching pods per node
     node_included: Optional[np.ndarray] = None  # uint8[n] node inclusion policies
+    # engine form of requireAllTopologies = false (see relax_soft): this value id of `col` stands for "the node lacks the key" --
+    # counted as a domain like the reference's "" value, scores nothing for this constraint.  0 = none.
+    missing_value: int = 0
 
 
 @dataclass
@@ -218,6 +221,10 @@ class PodSpec:
     # ImageLocality (plugins/imagelocality/image_locality.go:54-115): per-node score 0..100, uint8[n]; None = 0
     image_score: Optional[np.ndarray] = None
     preempt: Optional[PreemptionSide] = None  # host only, see PreemptionSide
+    # PodTopologySpread scores with requireAllTopologies = false (scoring.go:140): the pod has no constraints of its own and
+    # `spread` holds the plugin's system defaults (plugin.go:48-59).  The oracle takes this form literally (label id 0 = key missing);
+    # the engine takes the form relax_soft() derives.
+    soft_relaxed: bool = False
 
     def __post_init__(self):
         self.req = _i64(self.req)
@@ -227,6 +234,35 @@ class PodSpec:
             self.host_ports_conflict = _u8(self.host_ports_conflict)
         if self.image_score is not None:
             self.image_score = _u8(self.image_score)
+
+
+def relax_soft(nodes: "NodesSoA", pod: "PodSpec"):
+    """The engine form of a pod whose soft spread constraints are scored with requireAllTopologies = false
+    (podtopologyspread/scoring.go:61-115,140,147-178,205-219): no node is ignored, a missing key is the value "" when the
+    candidate domains are sized and counted, and a node scores nothing for a constraint whose key it lacks.  Per constraint
+    whose column has nodes without the key a NEW label column is appended in which those nodes carry one more value id
+    (n_domains + 1), named by `missing_value`: every node then "has" every key -- nobody is ignored, the extra id is sized and
+    counted like any domain -- and the engine skips the credit where it meets that id.  Returns (nodes, pod) copies; the
+    originals (what the oracle takes) are untouched.  Must be applied to the WHOLE snapshot before it is sharded."""
+    import copy
+
+    if not pod.soft_relaxed:
+        return nodes, pod
+    nodes2, pod2 = copy.copy(nodes), copy.copy(pod)
+    nodes2.label_cols = list(nodes.label_cols)
+    pod2.spread = [copy.copy(k) for k in pod.spread]
+    pod2.soft_relaxed = False
+    for k in pod2.spread:
+        if k.hard:
+            continue
+        col = np.asarray(nodes2.label_cols[k.col])
+        if not (col == 0).any():
+            continue
+        if k.is_hostname:
+            raise NotImplementedError("system default spreading on a cluster with a node that lacks kubernetes.io/hostname")
+        nodes2.label_cols.append(np.where(col == 0, k.n_domains + 1, col).astype(np.int32))
+        k.col, k.n_domains, k.missing_value = len(nodes2.label_cols) - 1, k.n_domains + 1, k.n_domains + 1
+    return nodes2, pod2
 
 
 @dataclass

@@ -131,6 +131,12 @@ typedef struct {
     const int32_t *node_match_count; /* [n_nodes] existing pods on the node matching the selector, NULL = 0 */
     const uint8_t *node_included;    /* [n_nodes] node inclusion policies (common.go:107-122), NULL = all */
     int32_t is_hostname; /* topologyKey == kubernetes.io/hostname: scored per node, not per domain (scoring.go:214-215) */
+    /* ScheduleAnyway constraints scored with requireAllTopologies = false (scoring.go:140: the plugin's system default constraints on a
+     * pod without constraints of its own): the caller gives the nodes that lack the key ONE MORE value id of `col` (counted in
+     * n_domains) and names it here.  It is sized and counted like any domain (the reference's "" value, scoring.go:96-103,166-173) but
+     * scores nothing for this constraint (scoring.go:210), and since every node then carries every key nobody is ignored.
+     * 0 = none (the pod's own constraints: a node without the key is ignored, scoring.go:84-88).  (Occupies what was padding: v3 layout.) */
+    int32_t missing_value;
 } ccsim_spread_constraint;
 
 /* InterPodAffinity in the integer world (P/interpodaffinity/{filtering.go:204-432, scoring.go:81-290}).  The

@@ -550,10 +550,12 @@ static void pts_scores_ex(const ccref_nodes *nd, const ccref_pod *pod, const int
         cnt[c] = (int64_t *)malloc(sizeof(int64_t) * (size_t)(pod->spread[c].n_domains + 1));
         for (int64_t v = 0; v <= pod->spread[c].n_domains; v++) cnt[c][v] = -1; /* nil */
     }
-    /* initPreScoreState :61-115 (requireAllTopologies is true: the pod carries its own constraints) */
+    /* initPreScoreState :61-115.  requireAllTopologies (:140) is true when the pod carries its own constraints; with the plugin's
+     * system defaults (pod->soft_relaxed) no node is ignored and a missing key is the value "" (id 0 here) */
+    const int require_all = !pod->soft_relaxed;
     for (int64_t i = 0; i < nf; i++) {
         int64_t n = feas[i];
-        if (!node_has_all_keys(nd, pod, 0, n)) {
+        if (require_all && !node_has_all_keys(nd, pod, 0, n)) {
             ignored[i] = 1;
             n_ignored++;
             continue;
@@ -576,7 +578,7 @@ static void pts_scores_ex(const ccref_nodes *nd, const ccref_pod *pod, const int
     }
     /* PreScore :147-178: count matching pods over ALL nodes into candidate domains */
     for (int64_t n = 0; n < nd->n; n++) {
-        if (!node_has_all_keys(nd, pod, 0, n)) continue;
+        if (require_all && !node_has_all_keys(nd, pod, 0, n)) continue; /* :161-164 */
         for (int c = 0; c < pod->n_spread; c++) {
             const ccref_spread_constraint *k = &pod->spread[c];
             if (k->hard || k->is_hostname) continue;
@@ -598,7 +600,7 @@ static void pts_scores_ex(const ccref_nodes *nd, const ccref_pod *pod, const int
             const ccref_spread_constraint *k = &pod->spread[c];
             if (k->hard) continue;
             int32_t v = nd->label_cols[k->col][n];
-            if (v == 0) continue;
+            if (v == 0) continue; /* `if tpVal, ok := node.Labels[c.TopologyKey]; ok` :210 -- only reachable with soft_relaxed */
             int64_t ct = k->is_hostname ? node_match_count(k, placed, n) : cnt[c][v];
             score += (double)ct * weight[c] + (double)(k->max_skew - 1); /* scoreForCount :302-304 */
         }

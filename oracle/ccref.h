@@ -185,6 +185,11 @@ typedef struct {
     /* ImageLocality (P/imagelocality/image_locality.go:54-115): the node's score 0..100 for this pod's images -- image
      * names are strings, so the caller evaluates ccref_image_locality_score per node.  NULL = 0 everywhere. */
     const uint8_t *image_score; /* [n] */
+    /* PodTopologySpread scoring with requireAllTopologies = false (scoring.go:140: the pod has no constraints of its own and the
+     * plugin's SYSTEM DEFAULT constraints apply -- "this allows nodes that don't have a zone label to still have hostname
+     * spreading"): no node is ignored, a missing key counts as the value "" when the domains are sized and counted, and scores
+     * nothing for that constraint (scoring.go:61-115, 147-178, 205-219).  0 = the pod's own constraints: every key required. */
+    int32_t soft_relaxed;
 } ccref_pod;
 
 typedef struct {

@@ -105,6 +105,7 @@ class _Pod(C.Structure):
         ("has_host_ports", C.c_int32),
         ("host_ports_conflict", _pu8),
         ("image_score", _pu8),
+        ("soft_relaxed", C.c_int32),
     ]
 
 
@@ -273,6 +274,7 @@ class _Marshal:
         s.req_tables = self.arr(tab, np.uint8, _pu8)
         spread = list(getattr(pod, "spread", []))
         assert len(spread) <= MAX_TSC
+        s.soft_relaxed = int(bool(getattr(pod, "soft_relaxed", False)))
         s.n_spread = len(spread)
         for i, k in enumerate(spread):
             s.spread[i].col = int(k.col)

@@ -165,7 +165,7 @@ static void record_pod(ccsim_engine *e, const ccsim_pod *p) {
     fprintf(f, "], \"spread\": [");
     for (int i = 0; i < p->n_spread; i++) {
         const ccsim_spread_constraint *c = &p->spread[i];
-        fprintf(f, "%s{\"k\": [%d, %d, %d, %d, %d, %d, %d], ", i ? ", " : "", c->col, c->max_skew, c->min_domains, c->hard, c->self_match, c->n_domains, c->is_hostname);
+        fprintf(f, "%s{\"k\": [%d, %d, %d, %d, %d, %d, %d, %d], ", i ? ", " : "", c->col, c->max_skew, c->min_domains, c->hard, c->self_match, c->n_domains, c->is_hostname, c->missing_value);
         arr32(f, "node_match_count", c->node_match_count, N), fprintf(f, ", ");
         arr8(f, "node_included", c->node_included, N);
         fprintf(f, "}");

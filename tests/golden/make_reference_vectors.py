@@ -938,47 +938,51 @@ def vectors(env):
     # PodTopologySpread's PreScore + Score + NormalizeScore over a FILTERED node list (scoring.go:61-265): ignored nodes, candidate domains and
     # their number -> the log(size + 2) weights, matching pods of ALL nodes counted into the candidate domains (node inclusion policies, other
     # namespaces, terminating pods), hostname constraints scored per node, math.Round, the normalization.  requireAllTopologies = true: the pod
-    # carries its own constraints (the system-default branch is DESIGN.md section 8 item 4)
-    rows = []
+    # carries its own constraints; = false (the plugin's system defaults, scoring.go:140): the second set, at the end of this function
     HOST = env["LabelHostname"]
-    for _ in range(700):
-        n_nodes = rnd.randint(1, 9)
-        gate = rnd.random() < 0.7
-        keys = rnd.choice([["zone"], [HOST], ["zone", HOST], ["zone", "rack"], ["rack", "zone", HOST], ["zone", "zone"]])
-        cons = [{"key": k, "maxSkew": rnd.randint(1, 4), "affinityPolicy": rnd.choice(["Honor", "Honor", "Ignore"]), "taintsPolicy": rnd.choice(["Honor", "Ignore", "Ignore"]),
-                 "emptySelector": rnd.random() < 0.1} for k in keys]
-        nodes = []
-        for i in range(n_nodes):
-            lb = {k: v for k, v in (("zone", rnd.choice(["a", "a", "b", "c", None])), ("rack", rnd.choice(["r1", "r2", "r2", None])), (HOST, rnd.choice([f"h{i}"] * 5 + [None]))) if v is not None}
-            taints = [{"Key": "dedicated", "Value": "infra", "Effect": rnd.choice(["NoSchedule", "PreferNoSchedule", "NoExecute"])}] if rnd.random() < 0.25 else []
-            pods = [{"ns": rnd.choice(["default", "default", "other"]), "terminating": rnd.random() < 0.15, "match": [rnd.random() < 0.6 for _ in cons]} for _ in range(rnd.choice([0, 1, 2, 3, 6]))]
-            nodes.append({"name": f"n{i}", "labels": lb, "taints": taints, "affinityMatch": rnd.random() < 0.8, "pods": pods})
-        filtered = sorted(rnd.sample(range(n_nodes), rnd.randint(1, n_nodes)))
-        tolerations = [{"Key": "dedicated", "Value": "infra", "Effect": "", "Operator": "Equal"}] if rnd.random() < 0.3 else []
-        mk = lambda d: types.SimpleNamespace(**d)
-        pod = types.SimpleNamespace(Namespace="default", Spec=types.SimpleNamespace(Tolerations=[mk(t) for t in tolerations]))
-        constraints = [GoStruct(TopologyKey=c["key"], MaxSkew=c["maxSkew"], NodeAffinityPolicy=c["affinityPolicy"], NodeTaintsPolicy=c["taintsPolicy"],
-                                Selector=types.SimpleNamespace(Empty=lambda e=c["emptySelector"]: e, Matches=lambda lbls, j=j: lbls["match"][j])) for j, c in enumerate(cons)]
-        all_nodes = []
-        for nd_ in nodes:
-            node = types.SimpleNamespace(Name=nd_["name"], Labels=GoLabels(nd_["labels"]), Spec=types.SimpleNamespace(Taints=[mk(t) for t in nd_["taints"]]), affinityMatch=nd_["affinityMatch"])
-            infos = [types.SimpleNamespace(GetPod=lambda p=p: types.SimpleNamespace(DeletionTimestamp=("t" if p["terminating"] else None), Namespace=p["ns"], Labels={"match": p["match"]})) for p in nd_["pods"]]
-            all_nodes.append(types.SimpleNamespace(Node=lambda node=node: node, GetPods=lambda infos=infos: infos))
-        require = types.SimpleNamespace(Match=lambda node: (node.affinityMatch, None))
-        pl = types.SimpleNamespace(enableNodeInclusionPolicyInPodTopologySpread=gate)
-        st = GoStruct(Constraints=constraints, IgnoredNodes=GoSet(), TopologyValueToPodCounts=[GoPtrMap() for _ in constraints], TopologyNormalizingWeight=[0.0] * len(constraints))
-        filtered_infos = [all_nodes[i] for i in filtered]
-        topo_size = [0] * len(constraints)
-        env["ptsPreScore_initNodes"](st, filtered_infos, True, topo_size)
-        env["ptsPreScore_weights"](st, filtered_infos, topo_size)
-        for n in range(len(all_nodes)):  # parallelizer.Until(ctx, len(allNodes), processAllNode, ...): atomic adds, any order
-            env["ptsPreScore_processAllNode"](n, pl, pod, all_nodes, st, True, require)
-        raw = [env["ptsScore"](st, info.Node(), info, pod)[0] for info in filtered_infos]
-        ignored = [info.Node().Name in st.IgnoredNodes for info in filtered_infos]
-        norm = list(raw)
-        env["ptsNormalizeScore"](norm, ignored)
-        rows.append([gate, cons, nodes, tolerations, filtered, [int(x) for x in ignored], [w.hex() for w in st.TopologyNormalizingWeight], raw, norm])
-    v["ptsPreScoreScore"] = rows
+
+    def pts_prescore_rows(rnd, require_all, count):
+      rows = []
+      for _ in range(count):
+          n_nodes = rnd.randint(1, 9)
+          gate = rnd.random() < 0.7
+          keys = rnd.choice([["zone"], [HOST], ["zone", HOST], ["zone", "rack"], ["rack", "zone", HOST], ["zone", "zone"]])
+          cons = [{"key": k, "maxSkew": rnd.randint(1, 4), "affinityPolicy": rnd.choice(["Honor", "Honor", "Ignore"]), "taintsPolicy": rnd.choice(["Honor", "Ignore", "Ignore"]),
+                   "emptySelector": rnd.random() < 0.1} for k in keys]
+          nodes = []
+          for i in range(n_nodes):
+              lb = {k: v for k, v in (("zone", rnd.choice(["a", "a", "b", "c", None])), ("rack", rnd.choice(["r1", "r2", "r2", None])), (HOST, rnd.choice([f"h{i}"] * 5 + [None]))) if v is not None}
+              taints = [{"Key": "dedicated", "Value": "infra", "Effect": rnd.choice(["NoSchedule", "PreferNoSchedule", "NoExecute"])}] if rnd.random() < 0.25 else []
+              pods = [{"ns": rnd.choice(["default", "default", "other"]), "terminating": rnd.random() < 0.15, "match": [rnd.random() < 0.6 for _ in cons]} for _ in range(rnd.choice([0, 1, 2, 3, 6]))]
+              nodes.append({"name": f"n{i}", "labels": lb, "taints": taints, "affinityMatch": rnd.random() < 0.8, "pods": pods})
+          filtered = sorted(rnd.sample(range(n_nodes), rnd.randint(1, n_nodes)))
+          tolerations = [{"Key": "dedicated", "Value": "infra", "Effect": "", "Operator": "Equal"}] if rnd.random() < 0.3 else []
+          mk = lambda d: types.SimpleNamespace(**d)
+          pod = types.SimpleNamespace(Namespace="default", Spec=types.SimpleNamespace(Tolerations=[mk(t) for t in tolerations]))
+          constraints = [GoStruct(TopologyKey=c["key"], MaxSkew=c["maxSkew"], NodeAffinityPolicy=c["affinityPolicy"], NodeTaintsPolicy=c["taintsPolicy"],
+                                  Selector=types.SimpleNamespace(Empty=lambda e=c["emptySelector"]: e, Matches=lambda lbls, j=j: lbls["match"][j])) for j, c in enumerate(cons)]
+          all_nodes = []
+          for nd_ in nodes:
+              node = types.SimpleNamespace(Name=nd_["name"], Labels=GoLabels(nd_["labels"]), Spec=types.SimpleNamespace(Taints=[mk(t) for t in nd_["taints"]]), affinityMatch=nd_["affinityMatch"])
+              infos = [types.SimpleNamespace(GetPod=lambda p=p: types.SimpleNamespace(DeletionTimestamp=("t" if p["terminating"] else None), Namespace=p["ns"], Labels={"match": p["match"]})) for p in nd_["pods"]]
+              all_nodes.append(types.SimpleNamespace(Node=lambda node=node: node, GetPods=lambda infos=infos: infos))
+          require = types.SimpleNamespace(Match=lambda node: (node.affinityMatch, None))
+          pl = types.SimpleNamespace(enableNodeInclusionPolicyInPodTopologySpread=gate)
+          st = GoStruct(Constraints=constraints, IgnoredNodes=GoSet(), TopologyValueToPodCounts=[GoPtrMap() for _ in constraints], TopologyNormalizingWeight=[0.0] * len(constraints))
+          filtered_infos = [all_nodes[i] for i in filtered]
+          topo_size = [0] * len(constraints)
+          env["ptsPreScore_initNodes"](st, filtered_infos, require_all, topo_size)
+          env["ptsPreScore_weights"](st, filtered_infos, topo_size)
+          for n in range(len(all_nodes)):  # parallelizer.Until(ctx, len(allNodes), processAllNode, ...): atomic adds, any order
+              env["ptsPreScore_processAllNode"](n, pl, pod, all_nodes, st, require_all, require)
+          raw = [env["ptsScore"](st, info.Node(), info, pod)[0] for info in filtered_infos]
+          ignored = [info.Node().Name in st.IgnoredNodes for info in filtered_infos]
+          norm = list(raw)
+          env["ptsNormalizeScore"](norm, ignored)
+          rows.append([gate, cons, nodes, tolerations, filtered, [int(x) for x in ignored], [w.hex() for w in st.TopologyNormalizingWeight], raw, norm])
+      return rows
+
+    v["ptsPreScoreScore"] = pts_prescore_rows(rnd, True, 700)
     # InterPodAffinity's PreScore + Score + NormalizeScore (interpodaffinity/scoring.go:51-290): the incoming pod's preferred terms against every
     # existing pod, the existing pods' required (HardPodAffinityWeight) and preferred terms against the incoming pod, nodes without labels or
     # without the term's key, only pods with affinity when the incoming pod has no preferred terms, PreScore's Skip when nothing hit
@@ -1120,6 +1124,9 @@ def vectors(env):
     v["topologyNormalizingWeight"] = [[n, env["topologyNormalizingWeight"](n).hex()] for n in list(range(0, 4097)) + [10 ** 6, 2 ** 31 - 3]]
     names = ["busybox", "busybox:1.36", "localhost:5000/app", "localhost:5000/app:v2", "gcr.io/x/y@sha256:abc", "a/b/c", "a:b/c", "", ":", "/", "x:", "reg.io:443/ns/img:tag"]
     v["normalizedImageName"] = [[n, env["normalizedImageName"](n)] for n in names]
+    # requireAllTopologies = false (scoring.go:140: a pod without constraints of its own under the plugin's system defaults): no node is ignored,
+    # a missing key is the value "" when the domains are sized and counted, and scores nothing (a stream of its own: the sets above keep theirs)
+    v["ptsPreScoreScoreRelaxed"] = pts_prescore_rows(random.Random(20260924), False, 700)
     return v
 
 

@@ -285,7 +285,8 @@ def _sharded_vs_oracle(ccref, nodes, pod, prof, limit, world, cap=1500):
     if ref.placed > cap:
         limit = cap
         ref = ccref.run(prof, nodes, pod, max_limit=limit)
-    res, log = _LocalShards(nodes, pod, prof, world).run(limit, "sequential", max(1, ref.placed))
+    e_nodes, e_pod = M.relax_soft(nodes, pod)  # (requireAllTopologies = false: the engine form, derived on the WHOLE snapshot before it is sharded)
+    res, log = _LocalShards(e_nodes, e_pod, prof, world).run(limit, "sequential", max(1, ref.placed))
     assert all(r.placed == ref.placed and r.stop == ref.stop for r in res), ([(r.placed, r.stop) for r in res], ref.placed, ref.stop)
     n = min(len(log), len(ref.log))
     first = next((i for i in range(n) if log[i] != ref.log[i]), None)
@@ -314,6 +315,16 @@ def test_sharded_protocol_with_schedule_anyway_constraints(ccref, world, seed):
     if seed % 3 == 2:
         pod.ipa = H.random_ipa(rng, nodes)
     _sharded_vs_oracle(ccref, nodes, pod, prof, int(rng.choice([0, 0, 70])), world)
+
+
+@pytest.mark.parametrize("world,seed", [(2, 0), (3, 1), (4, 2), (2, 3)])
+def test_sharded_system_default_spreading(ccref, world, seed):
+    """The plugin's system default constraints (requireAllTopologies = false, scoring.go:140) on clusters where nodes lack the zone key,
+    across shards: the extra value id that stands for the missing key is a domain like any other in the records' bitmaps and sizes."""
+    from test_spread import _relaxed_case
+    rng = np.random.default_rng(5100 + seed)  # (the cases of tests/test_spread.py::test_gpu_system_default_spreading_random)
+    nodes, pod, prof = _relaxed_case(rng, int(rng.integers(40, 700)))
+    _sharded_vs_oracle(ccref, nodes, pod, prof, int(rng.choice([0, 0, 90])), world)
 
 
 @pytest.mark.parametrize("world,n,limit,hostname", [(2, 500, 300, False), (3, 1500, 0, False), (4, 700, 400, True)])

@@ -41,6 +41,7 @@ def _pod_dump(p):
             "spread": [{"col": int(k.col), "max_skew": int(k.max_skew), "min_domains": int(k.min_domains), "hard": bool(k.hard),
                         "self_match": bool(k.self_match), "is_hostname": bool(k.is_hostname), "n_domains": int(k.n_domains),
                         "node_match_count": lst(k.node_match_count), "node_included": lst(k.node_included)} for k in p.spread],
+            "soft_relaxed": bool(getattr(p, "soft_relaxed", False)),
             "ipa": ipa, "has_host_ports": bool(p.has_host_ports), "host_ports_conflict": lst(p.host_ports_conflict),
             "image_score": lst(p.image_score),
             "preempt": {"priority": p.preempt.priority, "never": p.preempt.never, "victim_count": lst(p.preempt.victim_count),
@@ -1540,8 +1541,86 @@ def test_system_default_spreading_becomes_two_soft_constraints_when_every_node_i
     assert not b.spread and [(c.max_skew, c.hard, c.is_hostname, c.self_match) for c in a.spread] == [(3, False, True, True), (5, False, False, True)]
     # the merged selector app=guestbook,tier=frontend: p1, p3, p5 match -> on n1, n3, n1
     assert a.spread[0].node_match_count.tolist() == [0, 2, 0, 1, 0, 0, 0, 0, 0]
+    assert a.soft_relaxed and not b.soft_relaxed
     ra, rb = ccref.run(M.Profile.default(), outs["with"].nodes, a), ccref.run(M.Profile.default(), outs["without"].nodes, b)
     assert ra.placed == rb.placed and ra.per_node_count.tolist() == rb.per_node_count.tolist() and ra.log.tolist() != rb.log.tolist()
+
+
+def test_system_default_spreading_on_nodes_without_a_zone_label(native, recorder, tmp_path, ccref):
+    """requireAllTopologies = false (scoring.go:140): nodes WITHOUT topology.kubernetes.io/zone are not ignored -- they score their
+    hostname count and nothing for the zone.  Both ingests keep the reference's form (label id 0 = key missing, PodSide::soft_relaxed);
+    both hosts hand the engine the derived form: one more label column in which the nodes without the key carry one more value id, named
+    by ccsim_spread_constraint::missing_value (the ABI recorder shows what the native host marshals)."""
+    nodes = [node(f"n{i}", cpu="2", mem="4G", labels=dict({"kubernetes.io/hostname": f"n{i}"}, **({"topology.kubernetes.io/zone": f"z{i % 2}"} if i % 3 else {}))) for i in range(9)]
+    pods = [running_pod(f"p{j}", f"n{j % 4}", cpu="100m", mem="64Mi", labels={"app": "guestbook"}) for j in range(5)]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    svcs = [{"kind": "Service", "apiVersion": "v1", "metadata": {"name": "fe", "namespace": "default"}, "spec": {"selector": {"app": "guestbook"}}}]
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    path = tmp_path / "cluster.json"
+    path.write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + [dict(p, kind="Pod") for p in pods] + svcs}))
+    p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(path), "--dump-snapshot", "-"], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
+    assert p.returncode == 0 and "system default spreading" not in p.stderr, p.stderr
+    got = json.loads(p.stdout)
+    got.pop("label_keys")
+    no, po, ns = cli.load_all([str(path)])
+    snap = ingest.build_snapshot(no, po, cli.parse_pod_spec(str(tmp_path / "pod.json")), namespace_objs=ns, service_objs=cli.load_kind([str(path)], "Service"))
+    ref = py_dump(snap)
+    for k in ref:
+        assert got[k] == ref[k], k
+    assert snap.pod.soft_relaxed and not snap.default_spreading_unmodelled and [c.is_hostname for c in snap.pod.spread] == [True, False]
+    zone = snap.pod.spread[1]
+    assert (np.asarray(snap.nodes.label_cols[zone.col]) == 0).sum() == 3 and zone.n_domains == 2
+    # the oracle on the reference's form: the first clone goes to a node without a zone label and without matching pods (hostname count 0, no
+    # zone credit) -- with requireAllTopologies = true those nodes would be ignored (score 0)
+    r = ccref.run(M.Profile.default(), snap.nodes, snap.pod, max_limit=3)
+    assert int(r.log[0]) in (6,) and snap.names[int(r.log[0])] == "n6"
+    # what the native host hands the engine: a fourth... one more label column, the zone constraint on it with the extra value id named
+    rec = tmp_path / "rec.json"
+    (tmp_path / "result.json").write_text(json.dumps({"placed": 0, "stop": M.STOP_LIMIT, "n_code_unschedulable": 0, "per_node_count": [0] * 9, "log": [],
+                                                      "hist": [0] * M.NREASON, "hist_taintset": [0]}))
+    p = subprocess.run([native, "--podspec", str(tmp_path / "pod.json"), "--snapshot", str(path), "--max-limit", "1"], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT,
+                       env=dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(rec)))
+    assert p.returncode == 0, p.stderr
+    native_rec = json.load(open(rec))
+    e_nodes, e_pod = M.relax_soft(snap.nodes, snap.pod)
+    k = native_rec["pod"]["spread"][1]["k"]
+    ez = e_pod.spread[1]
+    assert k == [ez.col, 5, 1, 0, 1, 3, 0, 3] and ez.missing_value == 3 and ez.n_domains == 3
+    col = native_rec["nodes"]["label_cols"][ez.col]
+    col = col["v"] if isinstance(col, dict) else col
+    assert col == [int(v) for v in e_nodes.label_cols[ez.col]] and col.count(3) == 3
+
+
+@pytest.mark.gpu
+def test_system_default_spreading_without_zone_labels_end_to_end(native, tmp_path, ccref):
+    """The on-premises cluster of the reference's comment (scoring.go:137-139): some nodes carry no zone label, a Service selects the
+    simulated pod.  C++ host -> C ABI -> HIP engine == Python host == the oracle's literal requireAllTopologies = false branch: the same
+    replicas per node in the same (first placement) order."""
+    import io
+    nodes = [node(f"n{i:02d}", cpu="2", mem="4G", labels=dict({"kubernetes.io/hostname": f"n{i:02d}"}, **({"topology.kubernetes.io/zone": f"z{i % 3}"} if i % 4 else {}))) for i in range(14)]
+    pods = [running_pod(f"p{j}", f"n{j % 5:02d}", cpu="100m", mem="64Mi", labels={"app": "guestbook"}) for j in range(8)]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    svc = {"kind": "Service", "apiVersion": "v1", "metadata": {"name": "fe", "namespace": "default"}, "spec": {"selector": {"app": "guestbook"}}}
+    (tmp_path / "pod.json").write_text(json.dumps(pod))
+    path = tmp_path / "cluster.json"
+    path.write_text(json.dumps({"kind": "List", "items": [dict(n, kind="Node") for n in nodes] + [dict(p, kind="Pod") for p in pods] + [svc]}))
+    flags = ["--podspec", str(tmp_path / "pod.json"), "--snapshot", str(path), "--max-limit", "40", "-o", "json", "--percentage-of-nodes-to-score", "100"]
+    got = json.loads(_run(native, flags))
+    buf = io.StringIO()
+    assert cli.main(flags, out=buf) == 0
+    ref = json.loads(buf.getvalue())
+    got["status"].pop("creationTimestamp"), ref["status"].pop("creationTimestamp")
+    assert got["status"] == ref["status"] and got["status"]["replicas"] == 40
+    no, po, ns = cli.load_all([str(path)])
+    snap = ingest.build_snapshot(no, po, cli.parse_pod_spec(str(tmp_path / "pod.json")), namespace_objs=ns, service_objs=cli.load_kind([str(path)], "Service"))
+    assert snap.pod.soft_relaxed
+    r = ccref.run(M.Profile.default(), snap.nodes, snap.pod, max_limit=40)
+    order = []
+    for i in r.log.tolist():
+        if snap.names[i] not in order:
+            order.append(snap.names[i])
+    rows = got["status"]["pods"][0]["replicasOnNodes"]
+    assert [x["nodeName"] for x in rows] == order and [x["replicas"] for x in rows] == [int(r.per_node_count[snap.names.index(nm)]) for nm in order]
 
 
 def test_genpod_prints_quantities_canonically(native, tmp_path):

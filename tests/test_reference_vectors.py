@@ -174,15 +174,20 @@ def test_cal_prefilter_state(ccref):
             assert mn == want_min[j] and ndom == len(want_maps[j]), (gate, cons, nodes_, j)
 
 
-def test_pts_prescore_and_score(ccref):
+@pytest.mark.parametrize("relaxed", [False, True], ids=["requireAllTopologies", "system-defaults"])
+def test_pts_prescore_and_score(ccref, relaxed):
     """podtopologyspread/scoring.go:61-265 -- initPreScoreState's loop over the filtered nodes, the weights, PreScore's closure over all nodes,
     Score, NormalizeScore -- against the oracle's pts_scores: the same ignored nodes (score 0), the same log(size + 2) weights bit for bit, the
-    same raw (math.Round'ed) and normalized scores.  The per-node inputs the oracle takes are derived the way the ingests derive them."""
+    same raw (math.Round'ed) and normalized scores.  The per-node inputs the oracle takes are derived the way the ingests derive them.
+    `relaxed`: the Go text driven with requireAllTopologies = false (scoring.go:140, the plugin's system default constraints) against the
+    oracle's soft_relaxed branch: nobody ignored, "" counted as a domain, no credit for a constraint whose key the node lacks."""
     import numpy as np
     import helpers as H
     from cluster_capacity_amd import ingest, model as M
     host = "kubernetes.io/hostname"
-    for gate, cons, nodes_, tolerations, filtered, ignored, weights_hex, raw, norm in VEC["ptsPreScoreScore"]:
+    assert not relaxed or not any(any(row[5]) for row in VEC["ptsPreScoreScoreRelaxed"])  # (IgnoredNodes stays empty)
+    assert relaxed or any(any(row[5]) for row in VEC["ptsPreScoreScore"])
+    for gate, cons, nodes_, tolerations, filtered, ignored, weights_hex, raw, norm in VEC["ptsPreScoreScoreRelaxed" if relaxed else "ptsPreScoreScore"]:
         n = len(nodes_)
         keys = sorted({c["key"] for c in cons})
         cols, ids = zip(*[_intern([nd["labels"].get(k) for nd in nodes_]) for k in keys])
@@ -202,6 +207,7 @@ def test_pts_prescore_and_score(ccref):
                                              n_domains=max(len(ids[ki]), 1), node_match_count=np.array(counts, np.int32), node_included=np.array(inc, np.uint8)))
         pod = H.simple_pod(100, 64 << 20)
         pod.spread = spread
+        pod.soft_relaxed = relaxed
         got_raw, got_norm, got_w = ccref.unit_pts_scores(nodes, pod, filtered)
         where = (gate, cons, nodes_, filtered)
         assert [float.fromhex(h) for h in weights_hex] == got_w, where

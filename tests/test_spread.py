@@ -151,3 +151,64 @@ def test_gpu_soft_and_hard_spread_random(ccref, seed):
         cons[0].is_hostname, cons[0].hard = True, False  # scored per node instead of per domain
     pod.spread = cons
     _gpu_check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 70])))
+
+
+# ---- the plugin's SYSTEM DEFAULT constraints: requireAllTopologies = false (scoring.go:61-115,140,147-178,205-219) -------------------------
+def _relaxed_case(rng, n):
+    """random_case() nodes (label column 1: 0 = the zone key is MISSING on some nodes) + a hostname column every node carries, and the two
+    system default constraints (plugin.go:48-59: hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) as a pod without constraints of its own
+    gets them: scored with requireAllTopologies = false."""
+    nodes, pod, prof = H.random_case(rng, n)
+    nodes.label_cols = list(nodes.label_cols) + [np.arange(1, nodes.n + 1, dtype=np.int32)]
+    host = len(nodes.label_cols) - 1
+    mc = lambda: rng.integers(0, 3, nodes.n).astype(np.int32) if rng.integers(0, 2) else None
+    pod.spread = [M.SpreadConstraint(col=host, max_skew=3, hard=False, self_match=True, is_hostname=True, n_domains=nodes.n, node_match_count=mc()),
+                  M.SpreadConstraint(col=1, max_skew=5, hard=False, self_match=True, n_domains=2, node_match_count=mc())]
+    pod.soft_relaxed = True
+    return nodes, pod, prof
+
+
+def test_ka_system_default_spreading_scores_nodes_without_the_zone_label(ccref):
+    """Three identical nodes, hostnames h1..h3, zones [a, a, -]; one matching pod already runs on node 0.  requireAllTopologies = false:
+    node 2 is NOT ignored -- it scores its hostname count only (0) and nothing for the zone it does not have; the "" value is a third
+    zone domain when the weight is sized: zone weight log(3 + 2)?  No: the domains over the FILTERED nodes are {a, ""} -> log(2 + 2).
+    Raw scores: hostname weight log(3 + 2) = 1.609; node 0: 1 * 1.609 + 2 + 1 * 1.386 + 4 = round(8.995) = 9; node 1: 0 + 2 + 1 * 1.386 + 4
+    = round(7.386) = 7; node 2: 0 + 2 = 2 (no zone credit at all, not even maxSkew - 1).  Normalized 100 * (9 + 2 - s) / 9: 22, 44, 100 ->
+    the first clone goes to the node WITHOUT a zone label.  With the pod's own constraints (requireAllTopologies = true) node 2 would be
+    ignored (score 0) and node 1 would win."""
+    nodes = H.simple_nodes([4000] * 3, [8 * H.GiB] * 3, [110] * 3, label_cols=[np.array([1, 2, 3], np.int32), np.array([1, 1, 0], np.int32)])
+    pod = H.simple_pod(100, 64 * H.MiB)
+    cnt = np.array([1, 0, 0], np.int32)
+    pod.spread = [M.SpreadConstraint(col=0, max_skew=3, hard=False, self_match=True, is_hostname=True, n_domains=3, node_match_count=cnt),
+                  M.SpreadConstraint(col=1, max_skew=5, hard=False, self_match=True, n_domains=1, node_match_count=cnt)]
+    pod.soft_relaxed = True
+    raw, norm, w = ccref.unit_pts_scores(nodes, pod, [0, 1, 2])
+    assert raw == [9, 7, 2] and norm == [22, 44, 100]
+    assert ccref.run(DEFAULT, nodes, pod, max_limit=1).log.tolist() == [2]
+    pod.soft_relaxed = False
+    assert ccref.unit_pts_scores(nodes, pod, [0, 1, 2])[1][2] == 0 and ccref.run(DEFAULT, nodes, pod, max_limit=1).log.tolist() == [1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cw", ["1", "0"])
+@pytest.mark.parametrize("seed", range(10))
+def test_gpu_system_default_spreading_random(ccref, monkeypatch, seed, cw):
+    """Engine (windows of placements / one pass per placement) against the oracle's literal requireAllTopologies = false branch, on clusters
+    where nodes lack the zone key: the engine takes the form model.relax_soft derives (include/ccsim.h missing_value)."""
+    monkeypatch.setenv("CCSIM_CW", cw)
+    rng = np.random.default_rng(5100 + seed)
+    nodes, pod, prof = _relaxed_case(rng, int(rng.integers(3, 700)))
+    assert (nodes.label_cols[1] == 0).any() or nodes.n < 6
+    _gpu_check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 90])))
+
+
+@pytest.mark.gpu
+def test_gpu_system_default_spreading_on_a_cluster_without_zone_labels(ccref):
+    """The on-premises case the reference's comment names (scoring.go:137-139): no node has a zone label, hostname spreading still works."""
+    nodes, pod, prof = synth.make_config("C3", n_nodes=900, seed=12)
+    nodes.label_cols[1] = np.zeros(nodes.n, np.int32)
+    nodes.label_cols = list(nodes.label_cols) + [np.arange(1, nodes.n + 1, dtype=np.int32)]
+    pod.spread = [M.SpreadConstraint(col=2, max_skew=3, hard=False, self_match=True, is_hostname=True, n_domains=nodes.n),
+                  M.SpreadConstraint(col=1, max_skew=5, hard=False, self_match=True, n_domains=0)]
+    pod.soft_relaxed = True
+    _gpu_check(ccref, nodes, pod, prof, 700)
