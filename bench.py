@@ -151,6 +151,8 @@ def main():
 
         def step(mode, lim):
             eng.reset_state()
+            if isinstance(runner, ccdist.LibraryRunner):  # (the shard's counts into the engine's page-locked array, as at N = 1)
+                return runner.run(max_limit=lim, mode=mode, reuse_buffers=True)
             return runner.run(max_limit=lim, mode=mode)
     else:
         eng = capi.Engine(device=local_rank)
@@ -174,8 +176,7 @@ def main():
         scans += r.scans
     barrier()
     dt = time.perf_counter() - t0
-    if not distributed:
-        r.per_node_count = r.per_node_count.copy()  # (a view of the reused result array until here: later runs of the engine overwrite it)
+    r.per_node_count = r.per_node_count.copy()  # (a view of the reused result array until here: later runs of the engine overwrite it)
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

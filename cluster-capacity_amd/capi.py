@@ -576,10 +576,17 @@ class Engine:
     def dist_sync_tables(self):
         self._chk(self.lib.ccsim_dist_sync_tables(self.h), "ccsim_dist_sync_tables")
 
-    def dist_run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0) -> M.RunResult:
-        rep, per_node, log, ht = self._report(want_log, log_cap)
+    def dist_run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0,
+                 reuse_buffers: bool = False) -> M.RunResult:
+        """`reuse_buffers`: as in run() -- the shard's per-node counts land in the engine's page-locked result array."""
+        rep, per_node, log, ht = self._report(want_log, log_cap, reuse_buffers)
         self._chk(self.lib.ccsim_dist_run(self.h, int(max_limit), MODES[mode], C.byref(rep)), "ccsim_dist_run")
-        return self._result(rep, per_node, log, ht)
+        res = self._result(rep, per_node, log, ht, reuse_buffers)
+        if reuse_buffers:
+            import weakref
+
+            self._pin_results = [r for r in getattr(self, "_pin_results", []) if r() is not None] + [weakref.ref(res)]
+        return res
 
     # ---- ... or the persistent level kernel across the GPUs: mailbox form (include/ccsim.h ccsim_dist_mbox_*) ----
     def dist_mbox_info(self) -> bytes:

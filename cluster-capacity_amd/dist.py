@@ -115,8 +115,8 @@ class LibraryRunner:
     def __init__(self, engine, world: int, rank: int):
         self.engine, self.world, self.rank = engine, world, rank
 
-    def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0) -> M.RunResult:
-        return self.engine.dist_run(max_limit, mode, want_log, log_cap)
+    def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = False, log_cap: int = 0, reuse_buffers: bool = False) -> M.RunResult:
+        return self.engine.dist_run(max_limit, mode, want_log, log_cap, reuse_buffers=reuse_buffers)
 
 
 def make_library_runner(nodes_shard: M.NodesSoA, pod: M.PodSpec, profile: M.Profile, global_offset: int, n_global: int,
