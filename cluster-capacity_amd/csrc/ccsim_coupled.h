@@ -260,6 +260,17 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
                                 tup[q + 2] = v ? cw_narrow_entry(a.ipa.anti[k][v], giveup) : 0;
                                 tup[q + 3] = v ? cw_narrow_entry(a.ipa.exist[k][v], giveup) : 0;
                                 tup[q + 4] = v ? cw_narrow_entry(a.ipa.score[k][v], giveup) : 0;
+                                // The domain of a unique key is the node itself.  If it already holds a pod that one of the incoming pod's
+                                // required anti-affinity terms on this key matches, or a pod whose own anti-affinity terms match the incoming
+                                // pod, InterPodAffinity rejects the node in this cycle and in every later one (filtering.go:352-379; the
+                                // counts only grow): it is no candidate any more and forms no class.  (Round 4: the nodes that took a clone
+                                // of a pod with hostname anti-affinity doubled the classes -- one more per zone -- and pushed the synthetic
+                                // cluster's 64 zones past what the lane-per-candidate kernel holds.)
+                                if (a.ipa.filter_on && v) {
+                                    int n_anti_k = 0;
+                                    for (int t = 0; t < a.ipa.n_anti; t++) n_anti_k += a.ipa.anti_key[t] == k;
+                                    if ((n_anti_k && tup[q + 2] > 0) || (a.st->ipa_exist_total > 0 && tup[q + 3] > 0)) feas = false;
+                                }
                             }
                         }
                 }
@@ -740,7 +751,13 @@ constexpr uint32_t kCwMetaStat = kStatAffMask | (kStatCntMask << kStatCntShift);
 // stat's count (TaintToleration) and sum (NodeAffinity) fields where they are; the node's eligibility bits in the image field
 __device__ __forceinline__ uint32_t cw_meta(uint32_t stat, uint32_t elig) { return (stat & kCwMetaStat) | ((elig & kStatImgMask) << kStatImgShift); }
 
-template <int NH, int HU, int NK, int KU, bool PROF>
+// FULL (round 4): the form for MORE classes / domains than the standard one takes -- up to 64 classes and 64 domains of a shared
+// key (the synthetic 1M-node cluster has 64 zones: one class per zone).  Every lane is a class lane, so nothing is left for touched
+// nodes and for the scratch lane the standard form writes a departing winner's record to: a winner that is gone for good (full, or
+// blocked by its own clone through a required anti-affinity term -- every winner of BASELINE config 5's pod shape) only leaves its
+// (node, clones) record; one that could still win ends the window, and the next pass sees it in its new state.  Domains sit in
+// lane value - 1.  A separate instantiation, launched behind the standard one: it takes the windows that one declined.
+template <int NH, int HU, int NK, int KU, bool PROF, bool FULL = false>
 __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArgs *__restrict__ ap) {
     const CwDecideArgs &a = *ap;
     extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
@@ -748,7 +765,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     DevState &S = *a.st;
     if (S.done || S.cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the general kernel records the fallback)
+    if (FULL && __hip_atomic_load(a.w.ctl + kCwCtlFastDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the standard form took this window)
     const int tid = threadIdx.x, lane = tid & 63;
+    const int dlane = FULL ? lane + 1 : lane; // the value id of the shared-key domain this lane stands for
     const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
     const int C = uni32((int)a.w.ctl[kCwCtlClasses]);
     // members of a class list this kernel uses: all L, or as many as the staging area holds for C classes (many classes with long
@@ -756,11 +775,11 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     const int LU = uni32(C > 0 && C * LL > kCwListLds ? kCwListLds / C : LL), LS = LU + 1;
     constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
-    bool fits = C <= kCwFastClasses && LU >= 1;
+    bool fits = C <= (FULL ? 64 : kCwFastClasses) && LU >= 1;
     if (NH > 0) fits = fits && a.pts.max_skew[0] <= (1 << 29);
     if (NH > 1) fits = fits && a.pts.max_skew[1] <= (1 << 29);
-    if (NH > 0 && !HU0) fits = fits && a.plan.h_len[0] <= 64;
-    if (NH > 1 && !HU1) fits = fits && a.plan.h_len[1] <= 64;
+    if (NH > 0 && !HU0) fits = fits && a.plan.h_len[0] <= (FULL ? 65 : 64);
+    if (NH > 1 && !HU1) fits = fits && a.plan.h_len[1] <= (FULL ? 65 : 64);
     if (NK > 0 && a.ipa.w) { // PreScore must skip for the whole window: no entries now, none added by a clone (scoring.go:199-201)
         fits = fits && S.ipa_entries == 0 && a.ipa.self_entries[0] == 0;
         if (NK > 1) fits = fits && a.ipa.self_entries[1] == 0;
@@ -867,8 +886,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         // lane = domain (shared-key hard constraints): count and presence, for the minimum
         int32_t dc0 = 0, dc1 = 0;
         bool dp0 = false, dp1 = false;
-        if (NH > 0 && !HU0 && lane >= 1 && lane < a.plan.h_len[0]) dc0 = a.pts.tbl[0][lane], dp0 = a.plan.h_present[0][lane] != 0;
-        if (NH > 1 && !HU1 && lane >= 1 && lane < a.plan.h_len[1]) dc1 = a.pts.tbl[1][lane], dp1 = a.plan.h_present[1][lane] != 0;
+        if (NH > 0 && !HU0 && dlane >= 1 && dlane < a.plan.h_len[0]) dc0 = a.pts.tbl[0][dlane], dp0 = a.plan.h_present[0][dlane] != 0;
+        if (NH > 1 && !HU1 && dlane >= 1 && dlane < a.plan.h_len[1]) dc1 = a.pts.tbl[1][dlane], dp1 = a.plan.h_present[1][dlane] != 0;
         // the minimum of a hard constraint and how many domains sit at it (filtering.go:298-305): counts only grow, so the minimum
         // moves only when the last domain at it is taken -- shared keys: recomputed then (one DPP reduction); unique keys: the
         // pass's (minimum, nodes at it), and the window ends when they run out
@@ -998,7 +1017,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                         n_hv0 += counts ? 2 : 0;
                     } else {
                         hc0 += (counts & (hv0 == w_hv0)) ? 1 : 0; // every candidate of the domain, the winner's class included
-                        dc0 += (counts & (lane == w_hv0)) ? 1 : 0;
+                        dc0 += (counts & (dlane == w_hv0)) ? 1 : 0;
                         remin0 = remin0 || (at_min && nmin0 == 0);
                     }
                     n_hc0 += counts ? 1 : 0;
@@ -1012,7 +1031,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                         n_hv1 += counts ? 2 : 0;
                     } else {
                         hc1 += (counts & (hv1 == w_hv1)) ? 1 : 0;
-                        dc1 += (counts & (lane == w_hv1)) ? 1 : 0;
+                        dc1 += (counts & (dlane == w_hv1)) ? 1 : 0;
                         remin1 = remin1 || (at_min && nmin1 == 0);
                     }
                     n_hc1 += counts ? 1 : 0;
@@ -1047,7 +1066,12 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     if (exist_pos && ((w_kv0 && n_ke0 > 0) || (NK > 1 && w_kv1 && n_ke1 > 0))) dead = true;
                 }
                 const uint64_t R = ((uint64_t)w_tk << kIdxBits) | (uint64_t)g; // its (node, clones) record for the epilogue, if it leaves
-                if (w_cls) {
+                if (FULL) { // no lane to keep it in: its record, and the window ends here unless the node is gone for good
+                    CW_PUT64(myrec, R, nrec & 63);
+                    nrec += 1;
+                    if ((nrec & 63) == 0) L.rec[nrec - 64 + lane] = myrec;
+                    end_window = end_window || !dead;
+                } else if (w_cls) {
                     // it stays: a new lane behind the candidates (it does not: lane 63)
                     const int tl = dead ? 63 : ncand;
                     if (NH > 0) { CW_PUT(hv0, n_hv0, tl); CW_PUT(hc0, n_hc0, tl); }
@@ -1093,7 +1117,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
             };
             // ---- the next cycle: does it run in this window?
             auto next_cycle = [&]() {
-                go = !end_window && cycles < Wl && ncand < 64;
+                go = !end_window && cycles < Wl && (FULL || ncand < 64);
                 if (go) {
                     ok = verdicts();
                     // nothing feasible (the next pass finds out why); a class's next head is not among the members kept; the
@@ -1145,6 +1169,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 if (NH > 0) S.pts_min_a[0] = min0; // (the terminal histogram reads them: k_hist)
                 if (NH > 1) S.pts_min_a[1] = min1;
                 S.cw_windows += 1;
+                if (FULL) S.cw_full_windows += 1; else S.cw_fast_windows += 1;
                 S.done = unsched ? DONE_UNSCHEDULABLE : (limit > 0 && placed >= limit ? DONE_LIMIT : 0);
                 L.s_nt = nrec + (ncand - C);
                 if (PROF) L.pf[7] += (unsigned long long)cycles;

@@ -1657,6 +1657,9 @@ static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out);
 // ---- one template with topology-coupled plugins, in windows (ccsim_coupled.h): pass -> class lists -> up to W cycles ----
 // shapes with a lane-per-candidate decide kernel (NH hard constraints, HU unique-key mask, NK inter-pod keys, KU unique-key mask)
 #define CW_FAST_SHAPES(X) X(1, 0, 0, 0) X(1, 1, 0, 0) X(2, 0, 0, 0) X(0, 0, 1, 1) X(1, 0, 1, 1) X(2, 0, 1, 1) X(0, 0, 1, 0) X(1, 0, 1, 0)
+// ... and of those the ones that also come in the 64-class form (a unique-per-node inter-pod key: with a required anti-affinity term on it a
+// winner never comes back, which is what that form needs to make progress)
+#define CW_FULL_SHAPES(X) X(0, 0, 1, 1) X(1, 0, 1, 1) X(2, 0, 1, 1)
 static void launch_cw_window(ccsim_engine *e) {
     const CwScanArgs sa{e->cols, e->pod, e->d_state, e->pts, e->soft, e->ipa, e->cw_plan, e->cw_work};
     const dim3 g((unsigned)e->cw_work.n_blocks), b(kCwThreads);
@@ -1687,6 +1690,16 @@ static void launch_cw_window(ccsim_engine *e) {
 #undef CW_FAST_CASE
         default: break; // no lane-per-candidate instantiation for this shape: the general kernel does every window
         }
+        // ... and the form for up to 64 classes / 64 domains (the synthetic 1M-node cluster's 64 zones), behind it: takes what it declined
+        switch (shape) {
+#define CW_FULL_CASE(NH, HU, NK, KU)                                                                                              \
+    case NH * 1000 + HU * 100 + NK * 10 + KU:                                                                                    \
+        hipLaunchKernelGGL((k_cw_decide_fast<NH, HU, NK, KU, false, true>), dim3(1), b, sizeof(CwLds), e->stream, dp);             \
+        break;
+            CW_FULL_SHAPES(CW_FULL_CASE)
+#undef CW_FULL_CASE
+        default: break;
+        }
     }
     const bool small = e->pts.n <= 2 && e->soft.n <= 2 && (!e->ipa.on || e->ipa.n_keys <= 2);
     if (small) hipLaunchKernelGGL((k_cw_decide<2, 2, 2>), dim3(1), b, sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
@@ -1706,6 +1719,9 @@ static int run_cw(ccsim_engine *e) {
     HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast<NH, HU, NK, KU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         CW_FAST_SHAPES(CW_FAST_ATTR)
 #undef CW_FAST_ATTR
+#define CW_FULL_ATTR(NH, HU, NK, KU) HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast<NH, HU, NK, KU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+        CW_FULL_SHAPES(CW_FULL_ATTR)
+#undef CW_FULL_ATTR
         HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
         attr_set = true;
     }
@@ -2811,7 +2827,7 @@ extern "C" int ccsim_debug_coupled(ccsim_engine *e, int64_t *out8) {
         HIPCHK(e, hipMemcpy(out8 + 8, e->cw_work.prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));
     }
     out8[0] = e->have_pod && e->cw_ok ? 1 : 0;
-    if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback;
+    if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback, out8[5] = e->h_state->cw_fast_windows, out8[6] = e->h_state->cw_full_windows;
     out8[3] = e->cw_ok ? e->cw_plan.window : 0, out8[4] = e->cw_ok ? e->cw_plan.list_len : 0;
     return 0;
 }

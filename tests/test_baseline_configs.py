@@ -126,9 +126,9 @@ def _coupled_template(n, zones=None, seed=5):
     nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))  # kubernetes.io/hostname
     pod.ipa = M.InterPodAffinity(key_cols=[len(nodes.label_cols) - 1], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None])
     pod.spread = [synth.zone_spread(n, max_skew=1)]
-    if zones is not None:  # the same nodes with the zones folded
+    if zones is not None:  # the same nodes dealt to `zones` zones (node i -> zone i mod zones, like the generator's own labelling)
         col = pod.spread[0].col
-        nodes.label_cols[col] = np.where(nodes.label_cols[col] > 0, (nodes.label_cols[col] - 1) % zones + 1, 0).astype(np.int32)
+        nodes.label_cols[col] = (np.arange(n) % zones + 1).astype(np.int32)
         pod.spread[0].n_domains = zones
     return nodes, pod, prof
 
@@ -149,6 +149,10 @@ def test_coupled_template_at_baseline_sizes(ccref, n, zones):
     win = e.run(max_limit=5000, mode="sequential", log_cap=5000)
     info = e.coupled_info()
     assert info["plan"] and info["windows"] > 0 and not info["fell_back"], info
+    # which decide kernel: the lane-per-candidate one up to 48 classes / 63 domains (16 zones), its 64-class form for the generator's own
+    # 64 zones at 1M nodes (round 4; round 3 ran the general LDS kernel there: 1.5e5 placements/s)
+    want = "full_windows" if synth.zones_for(n) == 64 and zones is None else "fast_windows"
+    assert info[want] >= info["windows"] - 2, info
     e.close()
     os.environ["CCSIM_CW"] = "0"
     try:
@@ -161,6 +165,23 @@ def test_coupled_template_at_baseline_sizes(ccref, n, zones):
     assert win.placed == lit.placed == 5000
     assert np.array_equal(win.log, lit.log) and np.array_equal(win.per_node_count, lit.per_node_count)
     assert np.array_equal(win.log[:cycles], ref.log)
+
+
+@pytest.mark.parametrize("n,zones,limit", [(20_000, 64, 0), (9_000, 57, 2500), (30_000, 64, 4000)])
+def test_coupled_template_with_up_to_64_zones_takes_the_64_class_form(ccref, n, zones, limit):
+    """More classes than the lane-per-candidate kernel's standard form takes (48) but no more than lanes (64): its FULL form (every lane a
+    class, domains in lane value - 1, a winner that could still win ends the window) against the oracle: whole runs and limits."""
+    nodes, pod, prof = _coupled_template(n, zones)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=THREADS)
+    e = _engine(nodes, pod, prof)
+    got = e.run(max_limit=limit, mode="sequential", log_cap=max(1, ref.placed))
+    info = e.coupled_info()
+    e.close()
+    assert got.placed == ref.placed and got.stop == ref.stop
+    assert np.array_equal(got.log, ref.log) and np.array_equal(got.per_node_count, ref.per_node_count)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist)
+    assert info["full_windows"] >= info["windows"] - 2 and not info["fell_back"], info
 
 
 def test_c3_100k_multi_kernel_form_vs_oracle(ccref):
