@@ -2,9 +2,10 @@
 # round-end evidence on the FINAL library: the whole -m gpu suite, the bench line, rocprofv3 kernel stats of the same command,
 # PMC traffic (separate passes), the sequential cycle, the coupled windowed mode, config 5, the sharded protocol at one rank,
 # smoke().  Everything lands in gpurun_out/$R/ ; copy what is to be judged into profiles/$R/.
-#   tools/gpu_round_profile.sh [round tag, default r03] [skip-suite]
+#   tools/gpu_round_profile.sh [round tag, default r04] [skip-suite]
 exec < /dev/null
-R=${1:-r03}
+R=${1:-r04}
+mkdir -p /root/repo/profiles/$R
 cd /root/repo
 O=/root/repo/gpurun_out/$R
 mkdir -p $O
@@ -23,9 +24,9 @@ if [ "$2" != "skip-suite" ]; then
 fi
 # PMC traffic (separate rocprofv3 passes, --kernel-trace only): bench.py accepts profiles/$R/pmc_traffic.json only if it was
 # collected with the sources it runs
-bash tools/gpu_pmc.sh $R "FETCH_SIZE" "WRITE_SIZE" 2>&1 | tail -14
+bash tools/gpu_pmc.sh $R "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" 2>&1 | tee $O/pmc_summary.txt | tail -24
 cp gpurun_out/pmc_traffic_$R.json $O/pmc_traffic.json 2>/dev/null && cp gpurun_out/pmc_traffic_$R.json profiles/$R/pmc_traffic.json
-rm -rf gpurun_out/pmc_${R}_1 gpurun_out/pmc_${R}_2
+rm -rf gpurun_out/pmc_${R}_1 gpurun_out/pmc_${R}_2 gpurun_out/pmc_${R}_3 gpurun_out/pmc_${R}_4
 cd /root/repo
 timeout 400 python bench.py > $O/bench_1M.json 2> $O/bench_1M.err; tail -c 300 $O/bench_1M.json; echo
 cd /tmp && export TMPDIR=/tmp
@@ -40,7 +41,12 @@ rm -rf $O/ks
 cd /root/repo
 # config 5 (1024 pod specs): throughput line
 timeout 300 python tools/bench_c5.py 100000 1024 200000 64 2>&1 | grep -v amdgpu.ids | tee $O/bench_c5.txt | cut -c1-300
-timeout 120 python tools/persist_prof.py 1000000 4 1024 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-250
-timeout 120 python tools/persist_prof.py 1000000 3 64,192,384,1024,4096 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/persist_batch_sweep_predicted_events.txt
-CCSIM_FORCE_DIST=1 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>/dev/null > $O/bench_dist_world1.json; cut -c1-200 $O/bench_dist_world1.json
+timeout 120 python tools/persist_prof.py 1000000 8 1024 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-330
+CCSIM_PERSIST_SPEC=0 timeout 120 python tools/persist_prof.py 1000000 8 1024 2>&1 | grep -v amdgpu.ids | sed "s/^/CCSIM_PERSIST_SPEC=0 (round 3 form: stop above the event, that level ordered): /" | tee -a $O/persist_phase_profile.txt | cut -c1-200
+timeout 120 python tools/persist_prof.py 1000000 8 64,192,384,1024,4096 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/persist_batch_sweep.txt
+timeout 120 python tools/step_breakdown.py 2>&1 | grep -v amdgpu.ids | tee $O/step_breakdown.txt | cut -c1-250
+CCSIM_BENCH_SKIP_SEQ=1 timeout 200 python tools/bench_coupled.py 1000000 50000 1024,64 2>&1 | grep -v amdgpu.ids | tee $O/bench_coupled_1M_64zones.txt | cut -c1-300
+timeout 200 python tools/bench_coupled.py 100000 50000 1024,64 2>&1 | grep -v amdgpu.ids | tee $O/bench_coupled_100k.txt | cut -c1-300
+CCSIM_FORCE_DIST=1 CCSIM_DIST_DEBUG=1 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>$O/bench_dist_world1.err > $O/bench_dist_world1_mailbox.json; cut -c1-200 $O/bench_dist_world1_mailbox.json; grep "ccsim dist" $O/bench_dist_world1.err | tail -3
+CCSIM_FORCE_DIST=1 CCSIM_DIST_MAILBOX=0 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>/dev/null > $O/bench_dist_world1_rccl_passes.json; cut -c1-200 $O/bench_dist_world1_rccl_passes.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/smoke.txt
