@@ -1589,7 +1589,7 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
         }
         a.c.cnt_assign = launch == 0 ? 1 : 0; // (begin_run zeroed the per-run counts)
         a.c.hist = diag ? e->d_hist : nullptr, a.c.hist_ts = e->d_hist_ts, a.c.hist_code = e->d_hist_code;
-        if (mb) a.tag_base = (e->persist_seq++ & 0xfffu) << 20;
+        if (mb) a.tag_base = 0x80000000u | ((e->persist_seq++ & 0x7ffu) << 20); // (bit 31: a virtual-rank run -- never the tag of a sharded run's launch, which shares the boxes)
         HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync) * (size_t)sync_blocks, e->stream));
         if (diag) {
             HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
@@ -2133,7 +2133,7 @@ extern "C" int ccsim_dist_mbox_launch(ccsim_engine *e) {
     PersistArgs a = persist_args(e);
     a.n_ranks = e->mb_ranks, a.rank = e->mb_rank, a.vranks = 0, a.bpr = 0;
     for (int r = 0; r < e->mb_ranks; r++) a.mbox[r] = e->mbox_peers[r];
-    a.tag_base = (e->mb_seq++ & 0xfffu) << 20;
+    a.tag_base = (e->mb_seq++ & 0x7ffu) << 20;
     a.hint_valid = 0;       // (the hint is per engine: ranks could disagree about it -- and every rank must take the same number of syncs)
     a.c.from_pristine = 0;  // (ccsim_dist_begin restored the columns)
     a.c.cnt_assign = 1;
