@@ -49,4 +49,5 @@ CCSIM_BENCH_SKIP_SEQ=1 timeout 200 python tools/bench_coupled.py 1000000 50000 1
 timeout 200 python tools/bench_coupled.py 100000 50000 1024,64 2>&1 | grep -v amdgpu.ids | tee $O/bench_coupled_100k.txt | cut -c1-300
 CCSIM_FORCE_DIST=1 CCSIM_DIST_DEBUG=1 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>$O/bench_dist_world1.err > $O/bench_dist_world1_mailbox.json; cut -c1-200 $O/bench_dist_world1_mailbox.json; grep "ccsim dist" $O/bench_dist_world1.err | tail -3
 CCSIM_FORCE_DIST=1 CCSIM_DIST_MAILBOX=0 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>/dev/null > $O/bench_dist_world1_rccl_passes.json; cut -c1-200 $O/bench_dist_world1_rccl_passes.json
+( cat $O/lib_hash.txt; timeout 600 python -m pytest tests/test_dist_mailbox.py -m gpu -q -s 2>&1 | grep -E "^\[mailbox\]|two processes|passed|failed" ) | tee $O/mailbox_forms_taken.txt | tail -8
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/smoke.txt
