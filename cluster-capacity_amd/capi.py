@@ -443,11 +443,20 @@ class Engine:
             if res is not None and buf is not None and res.per_node_count is not None and res.per_node_count.base is not None:
                 res.per_node_count = np.array(res.per_node_count, copy=True)
         self._pin_results = []
+        self._rep_cache = None
         if buf is not None and self.h:
             self.lib.ccsim_host_free(self.h, buf[0])
         self._pin_per_node = None
 
     def _report(self, want_log: bool, log_cap: int, reuse_buffers: bool = False):
+        if reuse_buffers and not want_log:
+            # a caller that simulates repeatedly: the report block and its small arrays are built once (the binding's own work was
+            # ~14 of a 290 us step at 1M nodes); the library zeroes the histograms it fills
+            key = (self.n, self.n_taintsets, self.n_pods, id(getattr(self, "_pin_per_node", None)))
+            c = getattr(self, "_rep_cache", None)
+            if c is not None and c[0] == key and c[2] is self._pinned_per_node():
+                c[1].stop_spec = -1
+                return c[1], c[2], None, c[3]
         rep = CReport()
         per_node = self._pinned_per_node() if reuse_buffers else np.zeros(max(1, self.n), np.int32)
         rep.per_node_count = _ptr(per_node, _p32)
@@ -464,13 +473,15 @@ class Engine:
         rep.per_spec_count = _ptr(self._per_spec, _p32)
         rep.per_spec_cap = self._per_spec.shape[0]
         rep.stop_spec = -1
+        if reuse_buffers and not want_log:
+            self._rep_cache = ((self.n, self.n_taintsets, self.n_pods, id(self._pin_per_node)), rep, per_node, ht)
         return rep, per_node, log, ht
 
     def _result(self, rep, per_node, log, ht, reuse_buffers: bool = False) -> M.RunResult:
         return M.RunResult(
             placed=int(rep.placed), stop=int(rep.stop), per_node_count=per_node[: self.n] if reuse_buffers else per_node[: self.n].copy(),
             log=log[: int(rep.log_len)].copy() if log is not None else None,
-            hist=np.array(list(rep.hist), dtype=np.int64), hist_taintset=ht.copy(),
+            hist=np.frombuffer(rep.hist, dtype=np.int64).copy(), hist_taintset=ht.copy(),
             n_code_unschedulable=int(rep.n_code_unschedulable), rounds=int(rep.rounds),
             evaluated_total=int(rep.evaluated_total), last_feasible=int(rep.last_feasible), scans=int(rep.scans),
             kernel_ns=int(rep.kernel_ns), pass_kernel_ns=int(rep.pass_kernel_ns), pass_launches=int(rep.pass_launches), bytes_per_scan=int(rep.bytes_per_scan),
