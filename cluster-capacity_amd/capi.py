@@ -141,6 +141,7 @@ SYMBOLS = {
     "ccsim_time_scan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ccsim_debug_persist_prof": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_multi_stops": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ccsim_debug_multi_memo": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_coupled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
@@ -529,6 +530,12 @@ class Engine:
         out = (C.c_int64 * 8)()
         self._chk(self.lib.ccsim_debug_multi_stops(self.h, out), "ccsim_debug_multi_stops")
         return [int(x) for x in out]
+
+    def multi_memo(self):
+        """The multi-spec score memo of the last run (ccsim_debug_multi_memo): on?, pod-scans read from it / computed, bytes."""
+        out = (C.c_int64 * 4)()
+        self._chk(self.lib.ccsim_debug_multi_memo(self.h, out), "ccsim_debug_multi_memo")
+        return {"on": bool(out[0]), "memo_scans": int(out[1]), "full_scans": int(out[2]), "bytes": int(out[3])}
 
     def coupled_info(self):
         """How the last run of one template with topology-coupled plugins was resolved (ccsim_debug_coupled)."""

@@ -166,6 +166,8 @@ struct ccsim_engine {
     uint32_t *d_anti_bits = nullptr, *d_anti_bits0 = nullptr;
     MPartial *d_mpartials = nullptr;
     MCand *d_mcands = nullptr;
+    uint32_t *d_memo = nullptr;     // the score memo [n_pods][n_pad] (ccsim_multi.h), nullptr = off
+    int32_t *d_memo_stamp = nullptr, *d_mtouched = nullptr;
     const int32_t *tsc_label[kMTsc] = {nullptr, nullptr};
     DevPod multi_prof{};
     int32_t multi_next = 0; // spec of the next cycle (continues across runs; ccsim_reset_state rewinds it)
@@ -2487,6 +2489,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     free_list(e->pod_allocs);
     free_list(e->multi_allocs);
     e->multi = false;
+    e->d_memo = nullptr, e->d_memo_stamp = nullptr, e->d_mtouched = nullptr;
     e->have_pod = e->begun = false;
     e->pts = DevPts{}, e->soft = DevSoft{}, e->ipa = DevIpa{};
     e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = false;
@@ -2658,6 +2661,16 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     if ((rc = dev_alloc(e, &e->d_per_spec, (size_t)n_pods, e->multi_allocs))) return rc;
     if ((rc = dev_alloc(e, &e->d_mstate, (size_t)1, e->multi_allocs))) return rc;
     if (!e->h_mstate) HIPCHK(e, hipHostMalloc((void **)&e->h_mstate, sizeof(MState), hipHostMallocDefault));
+    { // the score memo: one word per (spec, node), resident for the whole simulation -- when it fits (CCSIM_MULTI_MEMO_MB caps it, 0 = off)
+        size_t cap_mb = 65536, free_b = 0, total_b = 0;
+        if (const char *f = getenv("CCSIM_MULTI_MEMO_MB")) cap_mb = (size_t)(atoll(f) > 0 ? atoll(f) : 0);
+        const size_t bytes = NP * (size_t)n_pods * sizeof(uint32_t);
+        if (cap_mb && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= (cap_mb << 20) && bytes <= free_b / 2) {
+            if ((rc = dev_alloc(e, &e->d_memo, NP * (size_t)n_pods, e->multi_allocs, false))) return rc;
+            if ((rc = dev_alloc(e, &e->d_memo_stamp, 2 * (size_t)n_pods, e->multi_allocs, false))) return rc;
+            if ((rc = dev_alloc(e, &e->d_mtouched, (size_t)kMTouched, e->multi_allocs))) return rc;
+        }
+    }
     for (int sl = 0; sl < kMTsc; sl++) e->tsc_label[sl] = slot_col[sl] >= 0 ? e->dev_label_ptrs[(size_t)slot_col[sl]] : nullptr;
     e->multi_prof = make_devpod(e, &pods[0]); // profile-level constants; the per-pod switches come from MPod
     if (e->multi_prof.gen_score) return fail(e, -ENOSYS, "several pod specs: scoring resource lists beyond cpu / memory");
@@ -2684,6 +2697,7 @@ static MultiArgs multi_args(ccsim_engine *e) {
     a.tbl_pool = e->d_tbl_pool, a.present_pool = e->d_present_pool, a.inc_pool = e->d_inc_pool, a.anti_bits = e->d_anti_bits;
     a.partials = e->d_mpartials, a.n_blocks = e->m_blocks, a.cands = e->d_mcands, a.log = e->d_log, a.per_spec = e->d_per_spec;
     a.window = e->multi_window < e->n_pods ? e->multi_window : e->n_pods;
+    a.memo = e->d_memo, a.memo_stamp = e->d_memo_stamp, a.touched = e->d_mtouched;
     return a;
 }
 
@@ -2691,8 +2705,10 @@ static void launch_multi_window(ccsim_engine *e, const MultiArgs &a) {
     const int chunks = (a.window + kMPodChunk - 1) / kMPodChunk;
     hipLaunchKernelGGL(k_multi_scan, dim3((unsigned)e->m_blocks, (unsigned)chunks), dim3(kThreads), 0, e->stream, a);
     hipLaunchKernelGGL(k_multi_select, dim3((unsigned)a.window), dim3(64), 0, e->stream, a);
-    hipLaunchKernelGGL(k_multi_commit_par, dim3(1), dim3(kMParThreads), 0, e->stream, a); // one of the two commits has the window
-    hipLaunchKernelGGL(k_multi_commit, dim3(1), dim3(64), 0, e->stream, a);           // (MState::seq_windows)
+    hipLaunchKernelGGL(k_multi_commit_par, dim3(1), dim3(kMParThreads), 0, e->stream, a); // (or, as its wave 0, the in-order commit: MState::seq_windows)
+    if (a.memo) // the touched nodes' memo words, for every stamped spec
+        hipLaunchKernelGGL(k_multi_refresh, dim3((unsigned)((a.n_pods + kMRefreshThreads - 1) / kMRefreshThreads), (unsigned)kMTouched),
+                           dim3(kMRefreshThreads), 0, e->stream, a);
 }
 
 // begin a multi-spec run (or one cycle: single_pod >= 0) on the current columns
@@ -2719,6 +2735,9 @@ static int begin_multi(ccsim_engine *e, int64_t max_limit, int64_t log_cap, int3
     HIPCHK(e, hipMemcpyAsync(e->d_mstate, e->h_mstate, sizeof(MState), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
     HIPCHK(e, hipMemsetAsync(e->d_per_spec, 0, sizeof(int32_t) * (size_t)e->n_pods, e->stream));
+    // the memo rows describe the columns as the last window left them; between runs anything may have touched the columns
+    // (ccsim_reset_state, another pod set's run): every row starts unstamped (-1, -1) and is filled by its spec's first scan
+    if (e->d_memo_stamp) HIPCHK(e, hipMemsetAsync(e->d_memo_stamp, 0xff, sizeof(int32_t) * 2 * (size_t)e->n_pods, e->stream));
     e->kernel_ms = 0, e->pass_kernel_ms = 0, e->pass_launches = 0;
     e->begun = false; // (the single-spec run state knows nothing of this run)
     return 0;
@@ -2772,7 +2791,7 @@ static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out) {
     out->last_feasible = st.last_feasible;
     out->kernel_ns = (int64_t)(e->kernel_ms * 1e6);
     out->pass_kernel_ns = 0, out->pass_launches = st.stops; // windows that ended early (the exact validation declined to go on)
-    out->bytes_per_scan = (int64_t)(36 + 4) * e->n; // per window: the narrow columns once + one static word per (pod, node) of the window
+    out->bytes_per_scan = (int64_t)(36 + 4) * e->n; // per window: the narrow columns once + one static word per (pod, node) of the window (+ one memo word with the score memo)
     memset(out->hist, 0, sizeof(out->hist));
     out->n_code_unschedulable = 0;
     if (out->hist_taintset)
@@ -2837,6 +2856,14 @@ extern "C" int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out8) {
     for (int i = 0; i < 8; i++) out8[i] = e->h_mstate->stop_count[i];
     if (getenv("CCSIM_MULTI_PROF"))
         for (int i = 0; i < 8; i++) out8[i] = e->h_mstate->prof[i];
+    return 0;
+}
+
+extern "C" int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out4) {
+    if (!e || !out4 || !e->h_mstate) return -EINVAL;
+    out4[0] = e->multi && e->d_memo ? 1 : 0;
+    out4[1] = e->h_mstate->memo_scans, out4[2] = e->h_mstate->full_scans;
+    out4[3] = e->multi && e->d_memo ? (int64_t)e->n_pad * e->n_pods * (int64_t)sizeof(uint32_t) : 0;
     return 0;
 }
 

@@ -13,7 +13,8 @@
 //                   BalancedAllocation; per (pod, workgroup): the best TWO packed (score, index) keys, feasible count,
 //                   the true maxima and their holder counts.  All against the state S0 at the start of the window.
 //   k_multi_select  one wave per pod: top-K of the per-workgroup keys (the pod's candidate list, best first).
-//   k_multi_commit  ONE wave, pods in order.  Pod j's true argmax over the state S_j (= S0 + the placements of pods
+//   multi_commit_inorder (wave 0 of k_multi_commit_par's launch when windows keep ending early)
+//                   ONE wave, pods in order.  Pod j's true argmax over the state S_j (= S0 + the placements of pods
 //                   0..j-1 of the window) is max(best UNTOUCHED node, best TOUCHED node): a node no earlier pod of the window
 //                   was placed on has the state, feasibility and score the scan saw (the pod's own spread / anti-affinity
 //                   state only changes through its OWN clones, and it appears once per window; the normalization maxima
@@ -22,6 +23,15 @@
 //                   pod j exactly.  Whenever that argument does not cover a pod (candidate list exhausted, both recorded
 //                   keys of one workgroup touched, too few holders of a maximum left, an assumed maximum was wrong) the
 //                   window ENDS before that pod and the next window starts with it: never a guess.
+//   k_multi_refresh the SCORE MEMO (round 4).  What the scan computes per (pod spec, node) -- static verdict, NodeResourcesFit,
+//                   the spec's anti-affinity bit, the weighted score sum under the spec's assumed maxima -- depends on the node's
+//                   columns and on the spec alone, and a window changes at most 64 nodes.  With 288 GB of HBM the whole
+//                   specs x nodes matrix stays resident (one 32-bit word per pair: 0 = does not fit, else TotalScore + 1;
+//                   410 MB for config 5): a scan that finds a spec's row stamped with the maxima it assumes reads the word
+//                   instead of recomputing it (~250 -> ~40 VALU instructions per pair), applies the spec's spread filter
+//                   (the only part that moves with the spec's OWN placements) and ranks; a scan that does not, computes and
+//                   fills the row, and k_multi_select stamps it.  After the commit this kernel recomputes the words of the
+//                   window's touched nodes for every stamped spec (<= 64 x P pairs).  Rows are invalidated when a run begins.
 // Results are identical to the oracle's round-robin loop (oracle/ccref.c ccref_run_multi; tests/test_multi.py).
 #pragma once
 #include "ccsim_level.h"
@@ -58,8 +68,9 @@ struct MPod { // one pod spec (device array of P)
 
 struct MState {
     int64_t placed, limit, rounds, windows, stops;
-    int64_t stop_count[8]; // windows ended by reason (k_multi_commit): diagnostics
-    int64_t prof[8];       // k_multi_commit: 10 ns ticks in [0] prologue, [1] touched-node evaluation, [2] candidate walk, [3] new touched node, [4] commit, [5] epilogue; [6] new touched nodes, [7] third-key loads
+    int64_t memo_scans, full_scans; // pods of the windows whose scan read its score memo row / computed (and filled) it
+    int64_t stop_count[8]; // windows ended by reason (multi_commit_inorder / k_multi_commit_par): diagnostics
+    int64_t prof[8];       // multi_commit_inorder: 10 ns ticks in [0] prologue, [1] touched-node evaluation, [2] candidate walk, [3] new touched node, [4] commit, [5] epilogue; [6] new touched nodes, [7] third-key loads
     int32_t done, stop_spec;
     int32_t next_pod;   // spec of the next cycle
     int32_t win_n;      // pods the pending window covers
@@ -67,9 +78,9 @@ struct MState {
     int32_t last_feasible, last_evaluated;
     int64_t winner;
     int64_t log_cap;
-    int32_t seq_windows; // > 0: the in-order commit (k_multi_commit) handles the next windows, else the assign + verify one
+    int32_t seq_windows; // > 0: the in-order commit (multi_commit_inorder) handles the next windows, else the assign + verify one
     int32_t epoch, committed_epoch; // k_multi_select bumps epoch once per window; the commit kernel that takes the window records it
-    int32_t pad_;
+    int32_t n_touched;  // nodes the last committed window placed pods on (MultiArgs::touched): k_multi_refresh's work list
 };
 
 struct MPartial { // per (pod of the window, scan workgroup)
@@ -106,7 +117,16 @@ struct MultiArgs {
     int32_t *log;
     int32_t *per_spec;               // [n_pods]
     int32_t window;                  // pods per window (<= kMWindowMax, <= n_pods)
+    // the score memo (header comment; nullptr = off: every scan computes)
+    uint32_t *memo;                  // [n_pods][n_pad]: 0 = static verdict / NodeResourcesFit / anti-affinity reject the pair, else TotalScore + 1
+    int32_t *memo_stamp;             // [n_pods][2]: the (taint, affinity) maxima the row was computed under; -1 = no row
+    int32_t *touched;                // [kMTouched] shard-local indices
 };
+
+// is spec pi's memo row the one a scan under the spec's current assumed maxima would compute?
+__device__ __forceinline__ bool m_memo_valid(const MultiArgs &a, int pi) {
+    return a.memo && a.memo_stamp[2 * pi] == a.pods[pi].mt_a && a.memo_stamp[2 * pi + 1] == a.pods[pi].ma_a;
+}
 
 __device__ __forceinline__ DevPod m_devpod(const DevPod &prof, const MPod &q) {
     DevPod p = prof;
@@ -165,19 +185,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
     __shared__ int32_t s_min[kMPodChunk][kMTsc];
     __shared__ uint32_t s_k[kMPodChunk][3][kThreads / 64];
     __shared__ uint32_t s_u[kMPodChunk][5][kThreads / 64];
+    __shared__ int32_t s_memo[kMPodChunk]; // 1 = pod jj's memo row is valid
 
     // (1) this thread's nodes: narrow columns -> registers, once for all pods of the chunk (independent of everything below)
     int32_t a0[kMNodesPerThread], a1[kMNodesPerThread], r0[kMNodesPerThread], r1[kMNodesPerThread], z0[kMNodesPerThread], z1[kMNodesPerThread];
     int32_t room[kMNodesPerThread]; // 1 = the node still has room for one more pod (fit.go:567-576: the same test for every pod)
     uint32_t lv[kMNodesPerThread]; // the node's value ids of the two spread label columns, one byte each (ids <= kMDomMax - 1)
+    bool cols = false; // does any pod of the chunk compute (no valid memo row)?  Else the columns are not needed: the words hold the result
+    for (int jj = 0; jj < jn; jj++) cols = cols || !m_memo_valid(a, (next_pod + j0 + jj) % a.n_pods);
 #pragma unroll
     for (int k = 0; k < kMNodesPerThread; k++) {
         const int64_t i = base + k * kThreads + tid;
         const bool in = i < a.c.n_pad;
-        a0[k] = in ? a.c.a32[0][i] : 0, a1[k] = in ? a.c.a32[1][i] : 0;
-        r0[k] = in ? a.c.r32[0][i] : 0, r1[k] = in ? a.c.r32[1][i] : 0;
-        z0[k] = in ? a.c.z32[0][i] : 0, z1[k] = in ? a.c.z32[1][i] : 0;
-        room[k] = in && (int64_t)a.c.pod_count[i] + 1 <= (int64_t)a.c.alloc_pods[i] ? 1 : 0;
+        const bool inc = in && cols;
+        a0[k] = inc ? a.c.a32[0][i] : 0, a1[k] = inc ? a.c.a32[1][i] : 0;
+        r0[k] = inc ? a.c.r32[0][i] : 0, r1[k] = inc ? a.c.r32[1][i] : 0;
+        z0[k] = inc ? a.c.z32[0][i] : 0, z1[k] = inc ? a.c.z32[1][i] : 0;
+        room[k] = inc && (int64_t)a.c.pod_count[i] + 1 <= (int64_t)a.c.alloc_pods[i] ? 1 : 0;
         const uint32_t l0 = in && a.tsc_label[0] ? (uint32_t)a.tsc_label[0][i] : 0u, l1 = in && a.tsc_label[1] ? (uint32_t)a.tsc_label[1][i] : 0u;
         lv[k] = (l0 & (uint32_t)kMDomMax) | ((l1 & (uint32_t)kMDomMax) << 8);
     }
@@ -191,12 +215,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
         const int32_t cls = a.pods[pi].cls, anti = a.pods[pi].anti; // (uniform address: scalar loads)
         const uint32_t *stat = a.stat_cls + (int64_t)cls * a.n_pad;
         const uint32_t *bits = a.anti_bits + (int64_t)pi * (a.n_pad / 32);
+        const bool memo = m_memo_valid(a, pi); // (nothing writes stamps or maxima while a scan runs: the same answer in the evaluation below)
+        const uint32_t *row = a.memo + (int64_t)pi * a.n_pad;
 #pragma unroll
         for (int k = 0; k < kMNodesPerThread; k++) {
             const int64_t i = base + k * kThreads + tid;
             const bool in = on && i < a.c.n_pad;
             wv[slot][k] = in ? stat[i] : 0u;
-            bv[slot][k] = in && anti ? bits[i >> 5] : 0u;
+            bv[slot][k] = memo ? (in ? row[i] : 0u) : (in && anti ? bits[i >> 5] : 0u); // the memo word takes the anti-affinity word's register
         }
     };
 #pragma unroll
@@ -212,6 +238,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
             const int pi = (next_pod + j0 + (jj < jn ? jj : 0)) % a.n_pods;
             dst[i] = reinterpret_cast<const int32_t *>(&a.pods[pi])[w];
         }
+        if (tid < kMPodChunk) s_memo[tid] = tid < jn && m_memo_valid(a, (next_pod + j0 + tid) % a.n_pods) ? 1 : 0;
     }
     __syncthreads();
     for (int i = tid; i < kMPodChunk * kMTsc * (kMDomMax + 1); i += kThreads) {
@@ -266,22 +293,35 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
                 sl[c] = uni32(q.tsc_slot[c]) != 0;
             }
             const uint32_t my_bit = (uint32_t)(tid & 31); // (the workgroup's first node and k * kThreads are multiples of 32)
+            const bool memo = uni32(s_memo[jj]) != 0;
+            uint32_t *row = a.memo ? a.memo + (int64_t)((next_pod + j0 + jj) % a.n_pods) * a.n_pad : nullptr;
             uint32_t k1 = 0, k2 = 0, k3 = 0;
             uint32_t mtb = 0, mab = 0;
             uint32_t acc = 0; // three 10-bit counters: feasible nodes | holders of the assumed taint maximum << 10 | of the affinity one << 20
 #pragma unroll
             for (int k = 0; k < kMNodesPerThread; k++) {
                 const uint32_t w = wv[slot][k];
-                bool ok = (w >> kStatOkBit) && fits_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], room[k], 0);
-                ok = ok && !((bv[slot][k] >> my_bit) & 1u); // satisfyPodAntiAffinity / existing pods' anti-affinity (filtering.go:352-379)
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                bool ok;
+                uint32_t total;
+                if (memo) { // the pair's word: everything but the spread filter
+                    ok = bv[slot][k] != 0u;
+                    total = bv[slot][k] - 1u;
+                } else {
+                    ok = (w >> kStatOkBit) && fits_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], room[k], 0);
+                    ok = ok && !((bv[slot][k] >> my_bit) & 1u); // satisfyPodAntiAffinity / existing pods' anti-affinity (filtering.go:352-379)
+                    total = 0;
+                    if (ok || row) // (a memo row is filled for every pair that fits, whatever the spread filter says today)
+                        total = ok ? (uint32_t)(static_score(p, cnt, aff, img, mt, ma, Mt, Ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k])) : 0u;
+                    const int64_t i = base + k * kThreads + tid;
+                    if (row && i < a.c.n_pad) row[i] = ok ? total + 1u : 0u;
+                }
 #pragma unroll
                 for (int c = 0; c < kMTsc; c++) { // PodTopologySpread.Filter: one LDS read and one compare per constraint
                     const uint32_t v = (sl[c] ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax; // (ids are validated <= kMDomMax - 1)
                     ok = ok && m_count(s_tbl[jj][c][v]) <= lim[c];
                 }
                 if (!ok) continue;
-                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
-                const uint32_t total = (uint32_t)(static_score(p, cnt, aff, img, mt, ma, Mt, Ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k]));
                 const uint32_t key = ((total + 1u) << 10) | (1023u - (uint32_t)(k * kThreads + tid));
                 if (key > k1) k3 = k2, k2 = k1, k1 = key; else if (key > k2) k3 = k2, k2 = key; else if (key > k3) k3 = key;
                 // the true maxima over the feasible set, and how many nodes hold the ASSUMED ones (only read when the two agree)
@@ -376,13 +416,20 @@ __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
         out.n = n, out.nfeas = (int32_t)wnf, out.mt = wmt, out.ma = wma, out.c_mt = wcmt, out.c_ma = wcma, out.bound = rest;
         a.cands[j] = out;
         if (j == 0) a.st->epoch = st.epoch + 1; // this window's candidates exist: exactly one commit kernel may consume them
+        const int pi = (st.next_pod + j) % a.n_pods;
+        atomicAdd(reinterpret_cast<unsigned long long *>(m_memo_valid(a, pi) ? &a.st->memo_scans : &a.st->full_scans), 1ull);
+        if (a.memo) { // the scan is over: the pod's memo row now holds what a scan under these maxima computes (read or just filled)
+            a.memo_stamp[2 * pi] = a.pods[pi].mt_a, a.memo_stamp[2 * pi + 1] = a.pods[pi].ma_a;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_multi_commit: one wave; pods of the window in order (see the header comment).
+// multi_commit_inorder: one wave; pods of the window in order (see the header comment).  Runs as wave 0 of
+// k_multi_commit_par's launch when MState::seq_windows says so (a launch of its own cost ~5 us per window for a kernel
+// that returns at once in all but a few windows): the other waves have left, the barriers below are wave 0's alone.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
+__device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
     MState st = *a.st;
     if (st.done || st.seq_windows <= 0 || st.committed_epoch == st.epoch) return; // (k_multi_commit_par had this window)
     st.seq_windows -= 1, st.committed_epoch = st.epoch;
@@ -597,7 +644,9 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
         a.c.pod_count[t_idx] = tnp;
         a.c.placed_cnt[t_idx] += tplaced;
     }
+    if (lane < nt && a.touched) a.touched[lane] = (int32_t)t_idx;
     if (lane == 0) {
+        st.n_touched = nt;
         st.placed += committed, st.rounds += committed;
         st.windows += 1, st.stops += stop_reason != 0 && stop_reason != 7 && stop_reason != 2;
         st.next_pod = st.single_pod >= 0 ? st.next_pod : (int32_t)((st.next_pod + committed) % a.n_pods);
@@ -619,7 +668,7 @@ __global__ __launch_bounds__(64) void k_multi_commit(MultiArgs a) {
 // them lands on a node no other pod of the window chose -- measured: 99 879 new nodes per 100 000 pods).  ASSIGN, then
 // VERIFY, then APPLY:
 //   A  (one wave, in order, ~20 instructions per pod) pod j takes the first entry of its candidate list that no earlier
-//      pod of the window took, under the same bounds as k_multi_commit (hidden third keys, exhausted list);
+//      pod of the window took, under the same bounds as multi_commit_inorder (hidden third keys, exhausted list);
 //   B  (all threads, every pair t < j in parallel) the nodes taken by earlier pods are the only nodes whose state differs
 //      from what the scan saw -- each carries exactly one more pod -- so pod j's choice is right iff none of them, in
 //      that state, beats its candidate for pod j (exact filter + score of pod j on node w_t + pod_t), and its
@@ -645,6 +694,10 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
 #define PT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); tp[i] += t_now - t_prev; t_prev = t_now; } while (0)
     if (tid == 0) s_st = *a.st;
     __syncthreads();
+    if (!s_st.done && s_st.seq_windows > 0 && s_st.committed_epoch != s_st.epoch) { // this window is the in-order commit's
+        if (wave == 0) multi_commit_inorder(a);
+        return;
+    }
     if (s_st.done || s_st.seq_windows > 0 || s_st.committed_epoch == s_st.epoch) return;
     const int W = s_st.win_n;
     const int32_t next_pod = s_st.next_pod;
@@ -860,10 +913,12 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
         a.per_spec[pi] += 1;
         const int64_t at = s_st.placed + j;
         if (a.log && at < s_st.log_cap) a.log[at] = (int32_t)(a.c.global_offset + n);
+        if (a.touched) a.touched[j] = (int32_t)n;
     }
     if (tid == 0) {
         MState st = s_st;
         st.committed_epoch = st.epoch;
+        st.n_touched = ok_n;
         int reason = fail < wa ? 3 : s_reason; // 3: a pod preferred a taken node / a maximum may have moved
         if (ok_n > 0) st.winner = a.c.global_offset + s_win[ok_n - 1], st.last_feasible = s_cd[ok_n - 1].nfeas;
         st.placed += ok_n, st.rounds += ok_n;
@@ -886,6 +941,36 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
         PT(5);
         for (int i = 0; i < 6; i++) a.st->prof[i] += tp[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_multi_refresh: grid (spec blocks, kMTouched).  Block row t = touched node t of the window just committed; thread = pod
+// spec.  Recomputes the memo word of (spec, node) from the node's columns as the commit left them -- for every spec whose
+// row is stamped with the maxima it assumes today (any other row is recomputed as a whole by the spec's next scan).
+// Idempotent: a launch that follows a window no commit kernel took repeats the last one.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kMRefreshThreads = 256;
+__global__ __launch_bounds__(kMRefreshThreads) void k_multi_refresh(MultiArgs a) {
+    const int t = blockIdx.y;
+    if (t >= a.st->n_touched) return;
+    const int pi = blockIdx.x * kMRefreshThreads + threadIdx.x;
+    if (pi >= a.n_pods || !m_memo_valid(a, pi)) return;
+    const int64_t n = a.touched[t];
+    const MPod &q = a.pods[pi];
+    DevPod p = a.prof;
+    p.all_zero_req = q.all_zero_req, p.w_bal = q.w_bal, p.w_aff = q.w_aff;
+    const NarrowPod nq{q.req0, q.req1, q.nz0, q.nz1};
+    const uint32_t w = a.stat_cls[(int64_t)q.cls * a.n_pad + n];
+    const uint32_t anti = q.anti ? (a.anti_bits[(int64_t)pi * (a.n_pad / 32) + (n >> 5)] >> (n & 31)) & 1u : 0u;
+    const int32_t a0 = a.c.a32[0][n], a1 = a.c.a32[1][n], r0 = a.c.r32[0][n], r1 = a.c.r32[1][n], z0 = a.c.z32[0][n], z1 = a.c.z32[1][n];
+    const int32_t room = (int64_t)a.c.pod_count[n] + 1 <= (int64_t)a.c.alloc_pods[n] ? 1 : 0;
+    const bool ok = (w >> kStatOkBit) && fits_narrow(p, nq, a0, a1, r0, r1, room, 0) && !anti;
+    uint32_t word = 0;
+    if (ok) {
+        const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+        word = (uint32_t)(static_score(p, cnt, aff, img, (uint32_t)q.mt_a, (uint32_t)q.ma_a) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1)) + 1u;
+    }
+    a.memo[(int64_t)pi * a.n_pad + n] = word;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -290,4 +290,5 @@ int ccsim_dist_mbox_status(ccsim_engine *e, int32_t *ok) { (void)e, (void)ok; re
 int ccsim_dist_mbox_finish(ccsim_engine *e, int32_t all_ok) { (void)e, (void)all_ok; return -38; }
 int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
+int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_coupled(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }

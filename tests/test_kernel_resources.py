@@ -30,7 +30,9 @@ def test_streaming_kernels_use_no_scratch_and_do_not_spill():
         assert rows[k]["VGPRs Spill"] == "0", (k, rows[k])
     for k in persist:  # 512-thread workgroups, one per CU: 2 waves per SIMD is all the kernel is launched with
         assert int(rows[k]["ScratchSize"]) == 0 and int(rows[k]["Occupancy"]) >= 2, (k, rows[k])
-    assert rows["k_multi_scan"]["ScratchSize"] == "0" and rows["k_multi_commit_par"]["ScratchSize"] == "0"
+    # (k_multi_commit_par's launch also carries the in-order commit as its wave 0 -- its MState working copy is the frame)
+    assert rows["k_multi_scan"]["ScratchSize"] == "0" and int(rows["k_multi_commit_par"]["ScratchSize"]) <= 192
+    assert rows["k_multi_refresh"]["ScratchSize"] == "0" and rows["k_multi_refresh"]["VGPRs Spill"] == "0"
     for k in ("k_final", "k_decide"):  # one working copy of DevState, nothing else (not the 1.7 KB argument block)
         assert int(rows[k]["ScratchSize"]) <= 768, (k, rows[k])
         assert rows[k]["VGPRs Spill"] == "0"

@@ -117,6 +117,57 @@ def test_c5_shape_10k_nodes_1024_specs_vs_oracle(ccref):
 
 
 @pytest.mark.gpu
+def test_score_memo_on_and_off_agree_and_the_memo_serves_the_scans(ccref, monkeypatch):
+    """The resident (spec, node) score memo (csrc/ccsim_multi.h): after each spec's first scan the scans read their rows -- same log,
+    counts and stop as with every scan computing (CCSIM_MULTI_MEMO_MB=0) and as the oracle's prefix; a second run on the same engine
+    starts from unstamped rows again."""
+    nodes, pods, prof = synth.make_c5(10_000, 256)
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=1500, threads=8)
+    runs = {}
+    for memo in ("on", "off"):
+        if memo == "off":
+            monkeypatch.setenv("CCSIM_MULTI_MEMO_MB", "0")
+        e = capi.Engine(device=0)
+        e.load(nodes, pods, prof)
+        r = e.run(max_limit=20_000, log_cap=20_000)
+        mm = e.multi_memo()
+        assert mm["on"] == (memo == "on") and mm["memo_scans"] + mm["full_scans"] >= r.placed
+        if memo == "on":  # every spec computes its row once (and again after a re-derived maximum); the rest is read
+            assert 4 * 256 * nodes.n <= mm["bytes"] < 4 * 256 * (nodes.n + 1024)
+            assert mm["memo_scans"] > 10 * mm["full_scans"], mm
+            e.reset_state()
+            r2 = e.run(max_limit=20_000, log_cap=20_000)
+            assert np.array_equal(r2.log, r.log) and np.array_equal(r2.per_node_count, r.per_node_count) and e.multi_memo()["full_scans"] >= 256
+        else:
+            assert mm["memo_scans"] == 0
+        runs[memo] = r
+        e.close()
+    a, b = runs["on"], runs["off"]
+    assert a.placed == b.placed == 20_000 and a.stop == b.stop
+    assert np.array_equal(a.log, b.log) and np.array_equal(a.per_node_count, b.per_node_count) and np.array_equal(a.per_spec_count, b.per_spec_count)
+    assert np.array_equal(a.log[:1500], ref.log)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_score_memo_random_specs_long_runs_vs_oracle(ccref, monkeypatch, seed):
+    """Whole runs (every spec scanned many times, nodes filling up, maxima re-derived) with the memo against the oracle, with windows that
+    keep ending early (window 7) and the in-order commit (CCSIM_MULTI_SEQ)."""
+    rng = np.random.default_rng(9100 + seed)
+    if seed & 1:
+        monkeypatch.setenv("CCSIM_MULTI_SEQ", "1")
+    monkeypatch.setenv("CCSIM_MULTI_WINDOW", "7" if seed < 2 else "64")
+    nodes, pods, prof = random_multi_case(rng, int(rng.integers(300, 900)), int(rng.integers(3, 40)))
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=0)
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    _same(e.run(max_limit=0, log_cap=max(1, ref.placed)), ref)
+    mm = e.multi_memo()
+    assert mm["on"] and mm["memo_scans"] > 0
+    e.close()
+
+
+@pytest.mark.gpu
 def test_c5_shape_whole_run_small(ccref):
     nodes, pods, prof = synth.make_c5(3000, 96)
     ref = ccref.run_multi(prof, nodes, pods, max_limit=0, threads=8)

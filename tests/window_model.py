@@ -185,7 +185,7 @@ class WindowModel:
                 bound = max(bound, cd["third"].get(b, 0))
         return 0, max(bound, cd["bound"])  # the list ran out
 
-    # ---- the run: windows with the in-order commit (k_multi_commit) or assign + verify (k_multi_commit_par) ---------------
+    # ---- the run: windows with the in-order commit (multi_commit_inorder) or assign + verify (k_multi_commit_par) ---------------
     def run(self, limit=0, parallel=False):
         log, windows, early = [], 0, 0
         nxt = 0

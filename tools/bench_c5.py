@@ -28,8 +28,11 @@ t0 = time.perf_counter()
 ref = ccref_py.run_multi(prof, nodes, pods, max_limit=oracle_rounds, threads=min(16, os.cpu_count() or 1))
 dt = time.perf_counter() - t0
 print(f"oracle (OpenMP x{min(16, os.cpu_count() or 1)}): {ref.placed / dt:.1f} placements/s ({oracle_rounds} cycles, {dt:.1f}s)", flush=True)
-for w in windows:
+memo_modes = [None] if os.environ.get("CCSIM_MULTI_MEMO_MB") is not None else [None, "0"]  # default (score memo on), then the round-3 form
+for w, memo in [(w, m) for w in windows for m in memo_modes]:
     os.environ["CCSIM_MULTI_WINDOW"] = str(w)
+    if memo is not None:
+        os.environ["CCSIM_MULTI_MEMO_MB"] = memo
     e = capi.Engine(device=0)
     t0 = time.perf_counter()
     e.load(nodes, pods, prof)
@@ -43,6 +46,8 @@ for w in windows:
         r = e.run(max_limit=L, want_log=False, log_cap=0)
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
+    mm = e.multi_memo()
+    print(f"score memo {'on' if mm['on'] else 'OFF (CCSIM_MULTI_MEMO_MB=0: every scan computes)'}: {mm['bytes'] / 1e6:.0f} MB, pod-scans read from it {mm['memo_scans']}, computed {mm['full_scans']}")
     print(f"window={w:3d}: {r.placed} placements in {best * 1e3:.1f} ms -> {r.placed / best:.3e} placements/s | windows {r.scans} "
           f"({r.placed / max(1, r.scans):.1f} pods/window, {r.pass_launches} ended early) kernel {r.kernel_ns / 1e6:.1f} ms "
           f"({r.kernel_ns / 1e3 / max(1, r.scans):.1f} us/window) | load+set_pods {t_load:.2f}s | stop={r.stop} spec={r.stop_spec} | stop reasons {e.multi_stops()}", flush=True)
@@ -51,3 +56,5 @@ for w in windows:
     del os.environ['CCSIM_MULTI_PROF']
     print('   commit profile, us per window (assign+verify: load pods/cands, tables+min, assign, winner columns, verify, apply | in-order kernel adds to the same slots):', ['%.1f' % (x / 100.0 / max(1, r.scans)) for x in pr[:6]], flush=True)
     e.close()
+    if memo is not None:
+        del os.environ["CCSIM_MULTI_MEMO_MB"]

@@ -41,6 +41,8 @@ rm -rf $O/ks
 cd /root/repo
 # config 5 (1024 pod specs): throughput line
 timeout 300 python tools/bench_c5.py 100000 1024 200000 64 2>&1 | grep -v amdgpu.ids | tee $O/bench_c5.txt | cut -c1-300
+( cd /tmp && rm -rf $O/ks && CCSIM_MULTI_MEMO_MB=65536 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python /root/repo/tools/bench_c5.py 100000 1024 100000 64 > /dev/null 2> $O/ks.err
+  f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/c5_kernel_stats.csv && cut -c1-200 $O/c5_kernel_stats.csv | head -8; rm -rf $O/ks )
 timeout 120 python tools/persist_prof.py 1000000 8 1024 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-330
 CCSIM_PERSIST_SPEC=0 timeout 120 python tools/persist_prof.py 1000000 8 1024 2>&1 | grep -v amdgpu.ids | sed "s/^/CCSIM_PERSIST_SPEC=0 (round 3 form: stop above the event, that level ordered): /" | tee -a $O/persist_phase_profile.txt | cut -c1-200
 timeout 120 python tools/persist_prof.py 1000000 8 64,192,384,1024,4096 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/persist_batch_sweep.txt
