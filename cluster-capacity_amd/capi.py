@@ -533,9 +533,12 @@ class Engine:
 
     def multi_memo(self):
         """The multi-spec score memo of the last run (ccsim_debug_multi_memo): on?, pod-scans read from it / computed, bytes."""
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 8)()
         self._chk(self.lib.ccsim_debug_multi_memo(self.h, out), "ccsim_debug_multi_memo")
-        return {"on": bool(out[0]), "memo_scans": int(out[1]), "full_scans": int(out[2]), "bytes": int(out[3])}
+        d = {"on": bool(out[0]), "memo_scans": int(out[1]), "full_scans": int(out[2]), "bytes": int(out[3])}
+        if out[7]:  # scan workgroup (0, 0), microseconds per scan: loads + staging, evaluation, merge
+            d["scan_us"] = [round(out[4 + i] / 100.0 / out[7], 2) for i in range(3)]
+        return d
 
     def coupled_info(self):
         """How the last run of one template with topology-coupled plugins was resolved (ccsim_debug_coupled)."""

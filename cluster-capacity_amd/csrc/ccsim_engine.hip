@@ -2861,6 +2861,7 @@ extern "C" int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out8) {
 
 extern "C" int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out4) {
     if (!e || !out4 || !e->h_mstate) return -EINVAL;
+    for (int i = 0; i < 4; i++) out4[4 + i] = e->h_mstate->scan_prof[i];
     out4[0] = e->multi && e->d_memo ? 1 : 0;
     out4[1] = e->h_mstate->memo_scans, out4[2] = e->h_mstate->full_scans;
     out4[3] = e->multi && e->d_memo ? (int64_t)e->n_pad * e->n_pods * (int64_t)sizeof(uint32_t) : 0;

@@ -69,6 +69,7 @@ struct MPod { // one pod spec (device array of P)
 struct MState {
     int64_t placed, limit, rounds, windows, stops;
     int64_t memo_scans, full_scans; // pods of the windows whose scan read its score memo row / computed (and filled) it
+    int64_t scan_prof[4];           // k_multi_scan, workgroup (0, 0): 10 ns ticks in [0] loads issued + staging, [1] the pods' evaluation, [2] merge; [3] scans
     int64_t stop_count[8]; // windows ended by reason (multi_commit_inorder / k_multi_commit_par): diagnostics
     int64_t prof[8];       // multi_commit_inorder: 10 ns ticks in [0] prologue, [1] touched-node evaluation, [2] candidate walk, [3] new touched node, [4] commit, [5] epilogue; [6] new touched nodes, [7] third-key loads
     int32_t done, stop_spec;
@@ -163,6 +164,149 @@ __device__ __forceinline__ int32_t m_tbl_min(const int32_t *tbl, const uint8_t *
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// multi_scan_lean: k_multi_scan for a workgroup whose pods ALL have a valid memo row (the steady state of a run).  Measured
+// on the general form (rocprofv3 + s_memrealtime, profiles/r04/c5_pmc_summary.txt): with the memo the evaluation fell to ~40
+// VALU instructions per pair, and the kernel stayed at 48 us -- the pod loop issues a dependent scalar-load -> vector-load
+// chain per pod (its words are fetched two pods ahead, after the descriptors' scalar loads) and the waves sit in those round
+// trips, not in arithmetic.  Here nothing is fetched pod by pod: the descriptors go to LDS first, then the memo words and
+// static words of ALL the chunk's pods (2 x 8 x 4 loads per thread) are issued at once, the spread tables are staged and their
+// minima taken by whole waves while those loads fly, and the evaluation runs from registers.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int next_pod, const int j0, const int jn, const int64_t base,
+                                                const unsigned long long sp_t0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ MPod l_pod[kMPodChunk];
+    __shared__ int32_t l_tbl[kMPodChunk][kMTsc][kMDomMax + 1];
+    __shared__ int32_t l_lim[kMPodChunk][kMTsc]; // the largest domain count the skew test lets through (0x7fffffff: no such constraint)
+    __shared__ uint32_t l_k[kMPodChunk][3][kThreads / 64];
+    __shared__ uint32_t l_u[kMPodChunk][5][kThreads / 64];
+
+    uint32_t lv[kMNodesPerThread];
+#pragma unroll
+    for (int k = 0; k < kMNodesPerThread; k++) {
+        const int64_t i = base + k * kThreads + tid;
+        const bool in = i < a.c.n_pad;
+        const uint32_t l0 = in && a.tsc_label[0] ? (uint32_t)a.tsc_label[0][i] : 0u, l1 = in && a.tsc_label[1] ? (uint32_t)a.tsc_label[1][i] : 0u;
+        lv[k] = (l0 & (uint32_t)kMDomMax) | ((l1 & (uint32_t)kMDomMax) << 8);
+    }
+    {
+        constexpr int kWords = (int)(sizeof(MPod) / 4);
+        int32_t *dst = reinterpret_cast<int32_t *>(&l_pod[0]);
+        for (int i = tid; i < kMPodChunk * kWords; i += kThreads) {
+            const int jj = i / kWords, w = i % kWords;
+            const int pi = (next_pod + j0 + (jj < jn ? jj : 0)) % a.n_pods;
+            dst[i] = reinterpret_cast<const int32_t *>(&a.pods[pi])[w];
+        }
+    }
+    __syncthreads();
+    // every pod's words, all in flight together
+    uint32_t cv[kMPodChunk][kMNodesPerThread], wv[kMPodChunk][kMNodesPerThread];
+#pragma unroll
+    for (int jj = 0; jj < kMPodChunk; jj++) {
+        const bool on = jj < jn;
+        const int pi = (next_pod + j0 + (on ? jj : 0)) % a.n_pods;
+        const uint32_t *row = a.memo + (int64_t)pi * a.n_pad;
+        const uint32_t *stat = a.stat_cls + (int64_t)uni32(l_pod[jj].cls) * a.n_pad;
+#pragma unroll
+        for (int k = 0; k < kMNodesPerThread; k++) {
+            const int64_t i = base + k * kThreads + tid;
+            const bool in = on && i < a.c.n_pad;
+            cv[jj][k] = in ? row[i] : 0u;
+            wv[jj][k] = in ? stat[i] : 0u;
+        }
+    }
+    for (int i = tid; i < kMPodChunk * kMTsc * (kMDomMax + 1); i += kThreads) {
+        const int jj = i / (kMTsc * (kMDomMax + 1)), c = (i / (kMDomMax + 1)) % kMTsc, v = i % (kMDomMax + 1);
+        int32_t x = 0;
+        if (jj < jn) {
+            const MPod &q = l_pod[jj];
+            if (c < q.n_tsc && v <= q.tsc_ndom[c]) x = m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]);
+            if (c < q.n_tsc && v == 0) x = kMAbsent - 1; // value id 0 = the node lacks the topology key (filtering.go:328-332): above every limit
+        }
+        l_tbl[jj][c][v] = x;
+    }
+    __syncthreads();
+    // minimum over the present domains (a wave per (pod, constraint), a lane per domain), then the limit of the skew test:
+    // (match + self - min > maxSkew) <=> match > lim; min counts as 0 while fewer than minDomains domains exist (filtering.go:56-69, 311-356)
+    for (int pc = wave; pc < kMPodChunk * kMTsc; pc += kThreads / 64) {
+        const int jj = pc / kMTsc, c = pc % kMTsc;
+        int32_t lim = 0x7fffffff;
+        if (jj < jn) { // (uniform per wave)
+            const MPod &q = l_pod[jj];
+            if (c < q.n_tsc) {
+                const int v = lane; // domains 1 .. ndom <= kMDomMax - 1 < 64
+                const int32_t x = v >= 1 && v <= q.tsc_ndom[c] ? l_tbl[jj][c][v] : 0x7fffffff;
+                const uint32_t m = ~wave_max_u32(~(x < kMAbsent ? (uint32_t)x : 0x7fffffffu)); // (minimum over the wave; 0x7fffffff if no domain is present)
+                const int32_t mm = q.tsc_npresent[c] < q.tsc_min_dom[c] ? 0 : (int32_t)m;
+                lim = q.tsc_max_skew[c] + mm - q.tsc_self[c];
+            }
+        }
+        if (lane == 0) l_lim[jj][c] = lim;
+    }
+    __syncthreads();
+    const unsigned long long sp_t1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+    for (int jj = 0; jj < kMPodChunk; jj++) {
+        if (jj < jn) { // (uniform)
+            const MPod &q = l_pod[jj];
+            const uint32_t mt = (uint32_t)uni32(q.mt_a), ma = (uint32_t)uni32(q.ma_a);
+            const int32_t lim0 = uni32(l_lim[jj][0]), lim1 = uni32(l_lim[jj][1]);
+            const bool sl0 = uni32(q.tsc_slot[0]) != 0, sl1 = uni32(q.tsc_slot[1]) != 0;
+            uint32_t k1 = 0, k2 = 0, k3 = 0, mtb = 0, mab = 0, acc = 0;
+#pragma unroll
+            for (int k = 0; k < kMNodesPerThread; k++) {
+                const uint32_t word = cv[jj][k];
+                const uint32_t v0 = (sl0 ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax, v1 = (sl1 ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax;
+                const bool ok = word != 0u && m_count(l_tbl[jj][0][v0]) <= lim0 && m_count(l_tbl[jj][1][v1]) <= lim1;
+                if (!ok) continue;
+                const uint32_t w = wv[jj][k];
+                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                const uint32_t key = (word << 10) | (1023u - (uint32_t)(k * kThreads + tid)); // word = TotalScore + 1
+                if (key > k1) k3 = k2, k2 = k1, k1 = key; else if (key > k2) k3 = k2, k2 = key; else if (key > k3) k3 = key;
+                mtb = cnt > mtb ? cnt : mtb, mab = aff > mab ? aff : mab;
+                acc += 1u | ((uint32_t)(cnt == mt) << 10) | ((uint32_t)(aff == ma) << 20);
+            }
+            const uint32_t w1 = wave_max_u32(k1);
+            const bool h1 = k1 == w1 && w1 != 0;
+            const uint32_t x2 = h1 ? k2 : k1, y2 = h1 ? k3 : k2;
+            const uint32_t w2 = wave_max_u32(x2);
+            const bool h2 = x2 == w2 && w2 != 0;
+            const uint32_t w3 = wave_max_u32(h2 ? y2 : x2);
+            const uint32_t wmt = wave_max_u32(mtb), wma = wave_max_u32(mab);
+            const uint32_t packed = wave_sum_u32(acc);
+            if (lane == 0)
+                l_k[jj][0][wave] = w1, l_k[jj][1][wave] = w2, l_k[jj][2][wave] = w3, l_u[jj][0][wave] = packed & 1023u, l_u[jj][1][wave] = wmt,
+                l_u[jj][2][wave] = wma, l_u[jj][3][wave] = (packed >> 10) & 1023u, l_u[jj][4][wave] = packed >> 20;
+        }
+    }
+    const unsigned long long sp_t2 = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (tid < jn) {
+        const int jj = tid;
+        uint32_t b1 = 0, b2 = 0, b3 = 0;
+        MPartial o{};
+        for (int x = 0; x < kThreads / 64; x++) {
+            for (int h = 0; h < 3; h++) {
+                const uint32_t key = l_k[jj][h][x];
+                if (key > b1) b3 = b2, b2 = b1, b1 = key; else if (key > b2) b3 = b2, b2 = key; else if (key > b3) b3 = key;
+            }
+            o.nfeas += l_u[jj][0][x];
+            o.mt = l_u[jj][1][x] > o.mt ? l_u[jj][1][x] : o.mt, o.ma = l_u[jj][2][x] > o.ma ? l_u[jj][2][x] : o.ma;
+            o.c_mt += l_u[jj][3][x], o.c_ma += l_u[jj][4][x];
+        }
+        auto widen = [&](uint32_t key) -> uint64_t {
+            return key ? make_key((int64_t)(key >> 10) - 1, a.c.global_offset + base + (int64_t)(1023u - (key & 1023u))) : 0ull;
+        };
+        o.key1 = widen(b1), o.key2 = widen(b2), o.key3 = widen(b3);
+        a.partials[(int64_t)(j0 + jj) * a.n_blocks + blockIdx.x] = o;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        const unsigned long long sp_t3 = __builtin_amdgcn_s_memrealtime();
+        a.st->scan_prof[0] += (int64_t)(sp_t1 - sp_t0), a.st->scan_prof[1] += (int64_t)(sp_t2 - sp_t1), a.st->scan_prof[2] += (int64_t)(sp_t3 - sp_t2), a.st->scan_prof[3] += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // k_multi_scan: grid (node workgroups, pod chunks).
 // Measured (rocprofv3, C5 100k x 1024, profiles/r02/c5_kernel_stats.csv): the first form of this kernel -- 4 pods per
 // workgroup; tables staged, THEN node columns loaded, THEN the pods' per-node words, then per pod a descriptor load and a
@@ -177,8 +321,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j0 = blockIdx.y * kMPodChunk;
     if (j0 >= win_n) return;
+    const unsigned long long sp_t0 = __builtin_amdgcn_s_memrealtime();
     const int jn = win_n - j0 < kMPodChunk ? win_n - j0 : kMPodChunk;
     const int64_t base = (int64_t)blockIdx.x * kMBlockNodes;
+    if (a.memo) { // every pod of the chunk with a valid memo row (lane jj looks at pod jj: one round trip): the lean form
+        const bool on = lane < jn;
+        const int pi = (next_pod + j0 + (on ? lane : 0)) % a.n_pods;
+        const bool valid = a.memo_stamp[2 * pi] == a.pods[pi].mt_a && a.memo_stamp[2 * pi + 1] == a.pods[pi].ma_a;
+        if (__ballot(on && !valid) == 0) {
+            multi_scan_lean(a, next_pod, j0, jn, base, sp_t0);
+            return;
+        }
+    }
 
     __shared__ MPod s_pod[kMPodChunk];
     __shared__ int32_t s_tbl[kMPodChunk][kMTsc][kMDomMax + 1];
@@ -191,17 +345,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
     int32_t a0[kMNodesPerThread], a1[kMNodesPerThread], r0[kMNodesPerThread], r1[kMNodesPerThread], z0[kMNodesPerThread], z1[kMNodesPerThread];
     int32_t room[kMNodesPerThread]; // 1 = the node still has room for one more pod (fit.go:567-576: the same test for every pod)
     uint32_t lv[kMNodesPerThread]; // the node's value ids of the two spread label columns, one byte each (ids <= kMDomMax - 1)
-    bool cols = false; // does any pod of the chunk compute (no valid memo row)?  Else the columns are not needed: the words hold the result
-    for (int jj = 0; jj < jn; jj++) cols = cols || !m_memo_valid(a, (next_pod + j0 + jj) % a.n_pods);
 #pragma unroll
     for (int k = 0; k < kMNodesPerThread; k++) {
         const int64_t i = base + k * kThreads + tid;
         const bool in = i < a.c.n_pad;
-        const bool inc = in && cols;
-        a0[k] = inc ? a.c.a32[0][i] : 0, a1[k] = inc ? a.c.a32[1][i] : 0;
-        r0[k] = inc ? a.c.r32[0][i] : 0, r1[k] = inc ? a.c.r32[1][i] : 0;
-        z0[k] = inc ? a.c.z32[0][i] : 0, z1[k] = inc ? a.c.z32[1][i] : 0;
-        room[k] = inc && (int64_t)a.c.pod_count[i] + 1 <= (int64_t)a.c.alloc_pods[i] ? 1 : 0;
+        a0[k] = in ? a.c.a32[0][i] : 0, a1[k] = in ? a.c.a32[1][i] : 0;
+        r0[k] = in ? a.c.r32[0][i] : 0, r1[k] = in ? a.c.r32[1][i] : 0;
+        z0[k] = in ? a.c.z32[0][i] : 0, z1[k] = in ? a.c.z32[1][i] : 0;
+        room[k] = in && (int64_t)a.c.pod_count[i] + 1 <= (int64_t)a.c.alloc_pods[i] ? 1 : 0;
         const uint32_t l0 = in && a.tsc_label[0] ? (uint32_t)a.tsc_label[0][i] : 0u, l1 = in && a.tsc_label[1] ? (uint32_t)a.tsc_label[1][i] : 0u;
         lv[k] = (l0 & (uint32_t)kMDomMax) | ((l1 & (uint32_t)kMDomMax) << 8);
     }
@@ -263,6 +414,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
     }
     __syncthreads();
 
+    const unsigned long long sp_t1 = __builtin_amdgcn_s_memrealtime();
     // Inside a workgroup a node is its 10-bit local index and a TotalScore fits 21 bits (checked by ccsim_set_pods), so the
     // running top three are 32-bit keys ((score + 1) << 10 | 1023 - local index: same order as the global 64-bit keys);
     // thread jj widens pod jj's three survivors at the end.
@@ -345,6 +497,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
                 s_u[jj][2][wave] = wma, s_u[jj][3][wave] = wcmt, s_u[jj][4][wave] = wcma;
         }
     }
+    const unsigned long long sp_t2 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (tid < jn) { // thread jj merges pod jj's four wave results and widens the keys
         const int jj = tid;
@@ -364,6 +517,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
         };
         o.key1 = widen(b1), o.key2 = widen(b2), o.key3 = widen(b3);
         a.partials[(int64_t)(j0 + jj) * a.n_blocks + blockIdx.x] = o;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { // (one workgroup's view: measurement aid, ccsim_debug_multi_memo)
+        const unsigned long long sp_t3 = __builtin_amdgcn_s_memrealtime();
+        a.st->scan_prof[0] += (int64_t)(sp_t1 - sp_t0), a.st->scan_prof[1] += (int64_t)(sp_t2 - sp_t1), a.st->scan_prof[2] += (int64_t)(sp_t3 - sp_t2), a.st->scan_prof[3] += 1;
     }
 }
 

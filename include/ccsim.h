@@ -412,8 +412,9 @@ int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out8);
 /* ... and how its scans were served (csrc/ccsim_multi.h, the score memo: one resident 32-bit word per (pod spec, node) holding what the
  * scan computes from the node's columns and the spec alone; CCSIM_MULTI_MEMO_MB caps its size, 0 turns it off): out4[0] = 1 if the
  * memo exists, [1] = pods of the last run's windows whose scan READ its memo row, [2] = pods whose scan computed (and filled) it,
- * [3] = bytes of the memo. */
-int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out4);
+ * [3] = bytes of the memo; [4..6] = 10 ns ticks scan workgroup (0, 0) spent issuing its loads + staging the pods' tables, evaluating
+ * the pods, merging; [7] = scans.  `out` holds 8 values. */
+int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out8);
 /* ... and how the last run of ONE template with topology-coupled plugins (PodTopologySpread, InterPodAffinity) was resolved
  * (csrc/ccsim_coupled.h: windows of placements per node pass): out8[0] = 1 if the pod spec has a windowed plan, [1] = windows
  * of the last run, [2] = 1 if that run fell back to one pass per placement (more classes / plugin inputs than the mode

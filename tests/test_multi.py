@@ -132,6 +132,7 @@ def test_score_memo_on_and_off_agree_and_the_memo_serves_the_scans(ccref, monkey
         r = e.run(max_limit=20_000, log_cap=20_000)
         mm = e.multi_memo()
         assert mm["on"] == (memo == "on") and mm["memo_scans"] + mm["full_scans"] >= r.placed
+        assert ref.placed == 1500 and r.placed > 5000
         if memo == "on":  # every spec computes its row once (and again after a re-derived maximum); the rest is read
             assert 4 * 256 * nodes.n <= mm["bytes"] < 4 * 256 * (nodes.n + 1024)
             assert mm["memo_scans"] > 10 * mm["full_scans"], mm
@@ -143,7 +144,7 @@ def test_score_memo_on_and_off_agree_and_the_memo_serves_the_scans(ccref, monkey
         runs[memo] = r
         e.close()
     a, b = runs["on"], runs["off"]
-    assert a.placed == b.placed == 20_000 and a.stop == b.stop
+    assert a.placed == b.placed > 5000 and a.stop == b.stop and a.stop_spec == b.stop_spec
     assert np.array_equal(a.log, b.log) and np.array_equal(a.per_node_count, b.per_node_count) and np.array_equal(a.per_spec_count, b.per_spec_count)
     assert np.array_equal(a.log[:1500], ref.log)
 

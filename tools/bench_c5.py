@@ -47,7 +47,7 @@ for w, memo in [(w, m) for w in windows for m in memo_modes]:
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
     mm = e.multi_memo()
-    print(f"score memo {'on' if mm['on'] else 'OFF (CCSIM_MULTI_MEMO_MB=0: every scan computes)'}: {mm['bytes'] / 1e6:.0f} MB, pod-scans read from it {mm['memo_scans']}, computed {mm['full_scans']}")
+    print(f"score memo {'on' if mm['on'] else 'OFF (CCSIM_MULTI_MEMO_MB=0: every scan computes)'}: {mm['bytes'] / 1e6:.0f} MB, pod-scans read from it {mm['memo_scans']}, computed {mm['full_scans']} | scan workgroup (0,0), us per scan: loads+staging, evaluation, merge = {mm.get('scan_us')}")
     print(f"window={w:3d}: {r.placed} placements in {best * 1e3:.1f} ms -> {r.placed / best:.3e} placements/s | windows {r.scans} "
           f"({r.placed / max(1, r.scans):.1f} pods/window, {r.pass_launches} ended early) kernel {r.kernel_ns / 1e6:.1f} ms "
           f"({r.kernel_ns / 1e3 / max(1, r.scans):.1f} us/window) | load+set_pods {t_load:.2f}s | stop={r.stop} spec={r.stop_spec} | stop reasons {e.multi_stops()}", flush=True)
