@@ -844,7 +844,9 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     __shared__ int64_t s_win[kMWindowMax];   // shard-local node index pod j was assigned
     __shared__ uint64_t s_wkey[kMWindowMax]; // ... and its key
     __shared__ int32_t s_node[kMWindowMax][10]; // the winners' columns as the scan saw them: a0 a1 r0 r1 z0 z1 alloc_pods pods l0 l1
-    __shared__ int s_wa, s_fail, s_reason, s_unsched;
+    __shared__ int s_wa, s_fail, s_reason, s_unsched, s_moved;
+    __shared__ int64_t s_pick[kMWindowMax];
+    __shared__ int s_taken[kMWindowMax];
     __shared__ int s_th_mt[kMWindowMax], s_th_ma[kMWindowMax];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
@@ -889,14 +891,17 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     __syncthreads();
 
     PT(1);
-    // ---- A: assignment.  Pod j takes the first entry of its list that no EARLIER pod of the window took.  Lane j = pod j.
-    // Every lane checks its current candidate against the lower lanes' current picks (W v_readlane steps, no memory) and
-    // moves on if it is taken; repeated until nobody moves.  This reaches the in-order result: a lane only abandons a node
-    // that a LOWER lane holds, and the lowest holder of a node never moves, so a node once taken stays taken for every
-    // higher lane -- candidates only move forward, at most K steps each; one or two rounds when conflicts are rare.
-    if (wave == 0) {
+    // ---- A: assignment.  Pod j takes the first entry of its list that no EARLIER pod of the window took.  Lane j of wave 0 =
+    // pod j (its list position, the bounds of what it skipped); whether its current candidate is held by a lower lane is
+    // asked of the WHOLE workgroup: 16 threads per pod, 4 earlier pods each, against the picks in LDS (the first form walked
+    // the 63 lower lanes with v_readlane inside wave 0: ~400 dependent instructions per round, 8.6 us per window).  A lane
+    // that finds its candidate taken moves on; repeated until nobody moves.  This reaches the in-order result: a lane only
+    // abandons a node that a LOWER lane holds, and the lowest holder of a node never moves, so a node once taken stays taken
+    // for every higher lane -- candidates only move forward, at most K steps each; a few rounds when conflicts are rare.
+    {
+        const bool w0 = wave == 0;
         const int j = lane;
-        const bool live = j < W;
+        const bool live = w0 && j < W;
         int stop = 0; // why this pod cannot be assigned (0 = it can)
         int k = 0;
         uint64_t bound = 0;
@@ -911,12 +916,22 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
         int64_t pick = live && !stop && cd.n > 0 ? key_index(cd.key[0]) - a.c.global_offset : -1;
 #pragma unroll 1
         for (int round = 0; round < kMTopK * kMWindowMax + 2; round++) {
-            bool taken = false;
-#pragma unroll 1
-            for (int t = 0; t + 1 < W; t++) { // lane t's pick, broadcast: is my candidate held by a lower lane?
-                const int64_t pt = lane_bcast_i64(pick, t);
-                taken = taken || (t < j && pick >= 0 && pt == pick);
+            if (w0) s_pick[lane] = pick;
+            __syncthreads();
+            { // thread (pod jp, quarter tq): is pod jp's candidate one of the picks of pods tq, tq + 16, tq + 32, tq + 48 below it?
+                const int jp = tid >> 4, tq = tid & 15;
+                const int64_t mine = s_pick[jp];
+                bool hit = false;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int t = tq + 16 * i;
+                    hit = hit || (t < jp && mine >= 0 && s_pick[t] == mine);
+                }
+                const unsigned long long b = __ballot(hit);
+                if (tq == 0) s_taken[jp] = (int)((b >> (lane & 48)) & 0xffffull); // (the pod's 16 threads are 16 consecutive lanes)
             }
+            __syncthreads();
+            const bool taken = w0 && s_taken[lane] != 0;
             if (taken) { // move on: remember the scan workgroup of the entry skipped
                 const int64_t blk = pick / kMBlockNodes;
                 int cnt2 = 0;
@@ -934,27 +949,34 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
                 k++;
                 pick = k < cd.n ? key_index(cd.key[k < kMTopK ? k : 0]) - a.c.global_offset : -1;
             }
-            if (!__ballot(taken)) break;
-        }
-        uint64_t ukey = 0;
-        if (live && !stop) {
-            if (k >= cd.n) { // the list ran out
-                if (cd.bound > bound) bound = cd.bound;
-                stop = 5;
-            } else {
-                ukey = cd.key[k < kMTopK ? k : 0];
-                if (bound && ukey < bound) stop = 4; // what the list hides may beat the candidate: the next scan will know
+            if (w0) {
+                const bool any = __ballot(taken) != 0;
+                if (lane == 0) s_moved = any ? 1 : 0;
             }
+            __syncthreads();
+            if (!s_moved) break;
         }
-        const uint64_t stopped = __ballot(live && stop != 0);
-        const int wa = stopped ? __ffsll((unsigned long long)stopped) - 1 : W;
-        if (lane < wa) s_win[lane] = pick, s_wkey[lane] = ukey;
-        const int reason = stopped ? __builtin_amdgcn_readlane(stop, wa < 64 ? wa : 0) : 0;
-        if (stop == 1 && live) { // repair every wrong maximum of the window at once (one window fixes a whole cycle of specs)
-            const int pj = (next_pod + j) % a.n_pods;
-            a.pods[pj].mt_a = (int32_t)cd.mt, a.pods[pj].ma_a = (int32_t)cd.ma;
+        if (w0) {
+            uint64_t ukey = 0;
+            if (live && !stop) {
+                if (k >= cd.n) { // the list ran out
+                    if (cd.bound > bound) bound = cd.bound;
+                    stop = 5;
+                } else {
+                    ukey = cd.key[k < kMTopK ? k : 0];
+                    if (bound && ukey < bound) stop = 4; // what the list hides may beat the candidate: the next scan will know
+                }
+            }
+            const uint64_t stopped = __ballot(live && stop != 0);
+            const int wa = stopped ? __ffsll((unsigned long long)stopped) - 1 : W;
+            if (lane < wa) s_win[lane] = pick, s_wkey[lane] = ukey;
+            const int reason = stopped ? __builtin_amdgcn_readlane(stop, wa < 64 ? wa : 0) : 0;
+            if (stop == 1 && live) { // repair every wrong maximum of the window at once (one window fixes a whole cycle of specs)
+                const int pj = (next_pod + j) % a.n_pods;
+                a.pods[pj].mt_a = (int32_t)cd.mt, a.pods[pj].ma_a = (int32_t)cd.ma;
+            }
+            if (lane == 0) s_wa = wa, s_reason = reason, s_unsched = reason == 2 ? wa : -1;
         }
-        if (lane == 0) s_wa = wa, s_reason = reason, s_unsched = reason == 2 ? wa : -1;
     }
     __syncthreads();
     PT(2);
@@ -981,39 +1003,44 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     __syncthreads();
 
     PT(3);
-    // ---- B: verification, every pair (t < j) in parallel: 16 threads per pod, each 4 earlier pods; the per-pair words are
-    // loaded first, all in flight together
+    // ---- B: verification, every pair (t < j) in parallel.  The wa (wa - 1) / 2 pairs are dealt evenly -- pair p and pair
+    // p + 1024 to thread p (the first form gave pod j's pairs to 16 fixed threads: the threads of the last pods carried four
+    // evaluations, those of the first pods none, and the evaluations are the phase's time: ~300 VALU instructions each on ONE
+    // CU); the per-pair words are loaded first, all in flight together
     {
-        const int j = tid >> 4, tq = tid & 15;
-        const bool pod_on = j < wa;
+        const int npairs = wa * (wa - 1) / 2;
         DevPod p = a.prof;
-        uint32_t wv[4], bv[4];
-        const MPod &q = s_pod[pod_on ? j : 0];
-        const MCand &cd = s_cd[pod_on ? j : 0];
-        const uint32_t *stat = a.stat_cls + (int64_t)q.cls * a.n_pad;
-        const uint32_t *bits = q.anti ? a.anti_bits + (int64_t)((next_pod + j) % a.n_pods) * (a.n_pad / 32) : nullptr;
+        int pj[2], pt[2];
+        uint32_t wv[2], bv[2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int t = tq + 16 * i;
-            const bool on = pod_on && t < j;
-            const int64_t n = on ? s_win[t] : 0;
-            wv[i] = on ? stat[n] : 0u;
-            bv[i] = on && bits ? bits[n >> 5] : 0u;
+        for (int i = 0; i < 2; i++) {
+            const int pp = tid + i * kMParThreads;
+            const bool on = pp < npairs;
+            // pair index -> (j, t), t < j: j (j - 1) / 2 <= pp < (j + 1) j / 2
+            int j = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)pp)) * 0.5f);
+            while (j * (j - 1) / 2 > pp) j--;
+            while ((j + 1) * j / 2 <= pp) j++;
+            pj[i] = on ? j : -1, pt[i] = on ? pp - j * (j - 1) / 2 : 0;
+            const MPod &q = s_pod[on ? j : 0];
+            const int64_t n = on ? s_win[pt[i]] : 0;
+            wv[i] = on ? a.stat_cls[(int64_t)q.cls * a.n_pad + n] : 0u;
+            bv[i] = on && q.anti ? a.anti_bits[(int64_t)((next_pod + j) % a.n_pods) * (a.n_pad / 32) + (n >> 5)] : 0u;
         }
-        int th_mt = 0, th_ma = 0;
-        bool beaten = false;
-        p.all_zero_req = q.all_zero_req, p.w_bal = q.w_bal, p.w_aff = q.w_aff;
-        const NarrowPod nq{q.req0, q.req1, q.nz0, q.nz1};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int t = tq + 16 * i;
-            if (!(pod_on && t < j)) continue;
+        for (int i = 0; i < 2; i++) {
+            const int j = pj[i], t = pt[i];
+            if (j < 0) continue;
+            const MPod &q = s_pod[j];
+            const MCand &cd = s_cd[j];
             const int64_t n = s_win[t];
             const uint32_t w = wv[i];
             const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
-            th_mt += cnt == cd.mt, th_ma += aff == cd.ma;
+            if (cnt == cd.mt) atomicAdd(&s_th_mt[j], 1);
+            if (aff == cd.ma) atomicAdd(&s_th_ma[j], 1);
             bool ok = (w >> kStatOkBit) && !((bv[i] >> (n & 31)) & 1u);
             if (!ok) continue;
+            p.all_zero_req = q.all_zero_req, p.w_bal = q.w_bal, p.w_aff = q.w_aff;
+            const NarrowPod nq{q.req0, q.req1, q.nz0, q.nz1};
             const MPod &qt = s_pod[t];
             // node w_t after pod t's placement (NodeInfo.update, types.go:409-428)
             const int32_t a0 = s_node[t][0], a1 = s_node[t][1], r0 = s_node[t][2] + qt.req0, r1 = s_node[t][3] + qt.req1;
@@ -1027,12 +1054,7 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
                 }
             if (!ok) continue;
             const int64_t total = static_score(p, cnt, aff, img, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1);
-            beaten = beaten || make_key(total, a.c.global_offset + n) > s_wkey[j]; // pod j prefers a node an earlier pod took
-        }
-        if (pod_on) {
-            if (th_mt) atomicAdd(&s_th_mt[j], th_mt);
-            if (th_ma) atomicAdd(&s_th_ma[j], th_ma);
-            if (beaten) atomicMin(&s_fail, j);
+            if (make_key(total, a.c.global_offset + n) > s_wkey[j]) atomicMin(&s_fail, j); // pod j prefers a node an earlier pod took
         }
     }
     __syncthreads();
