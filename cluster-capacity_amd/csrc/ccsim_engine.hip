@@ -2706,7 +2706,7 @@ static void launch_multi_window(ccsim_engine *e, const MultiArgs &a) {
     hipLaunchKernelGGL(k_multi_scan, dim3((unsigned)e->m_blocks, (unsigned)chunks), dim3(kThreads), 0, e->stream, a);
     hipLaunchKernelGGL(k_multi_select, dim3((unsigned)a.window), dim3(64), 0, e->stream, a);
     hipLaunchKernelGGL(k_multi_commit_par, dim3(1), dim3(kMParThreads), 0, e->stream, a); // (or, as its wave 0, the in-order commit: MState::seq_windows)
-    if (a.memo) // the touched nodes' memo words, for every stamped spec
+    // the placed specs' spread masks; the touched nodes' memo words, for every stamped spec
         hipLaunchKernelGGL(k_multi_refresh, dim3((unsigned)((a.n_pods + kMRefreshThreads - 1) / kMRefreshThreads), (unsigned)kMTouched),
                            dim3(kMRefreshThreads), 0, e->stream, a);
 }
@@ -2738,6 +2738,7 @@ static int begin_multi(ccsim_engine *e, int64_t max_limit, int64_t log_cap, int3
     // the memo rows describe the columns as the last window left them; between runs anything may have touched the columns
     // (ccsim_reset_state, another pod set's run): every row starts unstamped (-1, -1) and is filled by its spec's first scan
     if (e->d_memo_stamp) HIPCHK(e, hipMemsetAsync(e->d_memo_stamp, 0xff, sizeof(int32_t) * 2 * (size_t)e->n_pods, e->stream));
+    hipLaunchKernelGGL(k_multi_masks, dim3((unsigned)((e->n_pods + 255) / 256)), dim3(256), 0, e->stream, multi_args(e)); // the specs' per-domain spread masks, from the tables as they stand
     e->kernel_ms = 0, e->pass_kernel_ms = 0, e->pass_launches = 0;
     e->begun = false; // (the single-spec run state knows nothing of this run)
     return 0;

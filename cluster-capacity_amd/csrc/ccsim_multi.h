@@ -64,6 +64,10 @@ struct MPod { // one pod spec (device array of P)
     int32_t anti;                 // required anti-affinity to its own clones on the one-node-per-domain key
     int32_t mt_a, ma_a;           // normalization maxima assumed by the next scan
     int64_t req_wide[2], nz_wide[2]; // the int64 columns follow the narrow ones at commit
+    // PodTopologySpread.Filter per DOMAIN, as the spec's tables stand: bit v = a node with value id v passes constraint c's skew
+    // test (bit 0 -- the node lacks the key -- is 0; an unused slot passes everything).  Derived state: k_multi_masks rebuilds
+    // it from the tables when a run begins, k_multi_refresh after a placement of the spec (the only thing that moves its tables).
+    uint64_t tsc_allow[kMTsc];
 };
 
 struct MState {
@@ -82,6 +86,7 @@ struct MState {
     int32_t seq_windows; // > 0: the in-order commit (multi_commit_inorder) handles the next windows, else the assign + verify one
     int32_t epoch, committed_epoch; // k_multi_select bumps epoch once per window; the commit kernel that takes the window records it
     int32_t n_touched;  // nodes the last committed window placed pods on (MultiArgs::touched): k_multi_refresh's work list
+    int32_t placed_first, n_placed; // ... and the specs it placed: placed_first, placed_first + 1, ... (mod P): their spread masks are due
 };
 
 struct MPartial { // per (pod of the window, scan workgroup)
@@ -124,6 +129,10 @@ struct MultiArgs {
     int32_t *touched;                // [kMTouched] shard-local indices
 };
 
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { // a wave-uniform 64-bit value, into scalar registers
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
 // is spec pi's memo row the one a scan under the spec's current assumed maxima would compute?
 __device__ __forceinline__ bool m_memo_valid(const MultiArgs &a, int pi) {
     return a.memo && a.memo_stamp[2 * pi] == a.pods[pi].mt_a && a.memo_stamp[2 * pi + 1] == a.pods[pi].ma_a;
@@ -155,6 +164,29 @@ __device__ __forceinline__ int32_t m_staged_min(const int32_t *staged, int ndom)
     return m;
 }
 
+// MPod::tsc_allow[c] from the constraint's staged table (staged(v) = count, or kMAbsent for a domain without a counted node:
+// excluded from the minimum, match count 0); `bump` = the domain whose count is one higher than the table says (the placement
+// being applied), 0 = none.  (match + self - min > maxSkew) <=> match > lim; the minimum counts as 0 while fewer than
+// minDomains domains exist (filtering.go:56-69, 311-356).
+template <class Staged>
+__device__ __forceinline__ uint64_t m_allow_mask(const MPod &q, int c, Staged staged, int bump) {
+    if (c >= q.n_tsc) return ~0ull;
+    const int ndom = q.tsc_ndom[c];
+    int32_t mn = 0x7fffffff;
+    for (int v = 1; v <= ndom; v++) {
+        const int32_t x = staged(v);
+        if (x < kMAbsent) { const int32_t y = x + (v == bump ? 1 : 0); mn = y < mn ? y : mn; }
+    }
+    const int64_t lim = (int64_t)q.tsc_max_skew[c] + (q.tsc_npresent[c] < q.tsc_min_dom[c] ? 0 : (int64_t)mn) - q.tsc_self[c];
+    uint64_t mask = ~1ull;
+    for (int v = 1; v <= ndom; v++) {
+        const int32_t x = staged(v);
+        const int64_t y = x < kMAbsent ? (int64_t)x + (v == bump ? 1 : 0) : 0;
+        if (y > lim) mask &= ~(1ull << v);
+    }
+    return mask;
+}
+
 // minimum match count over the domains holding a counted node (CriticalPaths[c][0], filtering.go:298-305)
 __device__ __forceinline__ int32_t m_tbl_min(const int32_t *tbl, const uint8_t *present, int ndom) {
     int32_t m = 0x7fffffff;
@@ -169,15 +201,13 @@ __device__ __forceinline__ int32_t m_tbl_min(const int32_t *tbl, const uint8_t *
 // VALU instructions per pair, and the kernel stayed at 48 us -- the pod loop issues a dependent scalar-load -> vector-load
 // chain per pod (its words are fetched two pods ahead, after the descriptors' scalar loads) and the waves sit in those round
 // trips, not in arithmetic.  Here nothing is fetched pod by pod: the descriptors go to LDS first, then the memo words and
-// static words of ALL the chunk's pods (2 x 8 x 4 loads per thread) are issued at once, the spread tables are staged and their
-// minima taken by whole waves while those loads fly, and the evaluation runs from registers.
+// static words of ALL the chunk's pods (2 x 8 x 4 loads per thread) are issued at once, the spread filter is a bit test against
+// the spec's per-domain masks (MPod::tsc_allow: no table, no minimum, no LDS read per pair), and the evaluation runs from registers.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int next_pod, const int j0, const int jn, const int64_t base,
                                                 const unsigned long long sp_t0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ MPod l_pod[kMPodChunk];
-    __shared__ int32_t l_tbl[kMPodChunk][kMTsc][kMDomMax + 1];
-    __shared__ int32_t l_lim[kMPodChunk][kMTsc]; // the largest domain count the skew test lets through (0x7fffffff: no such constraint)
     __shared__ uint32_t l_k[kMPodChunk][3][kThreads / 64];
     __shared__ uint32_t l_u[kMPodChunk][5][kThreads / 64];
 
@@ -215,49 +245,21 @@ __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int ne
             wv[jj][k] = in ? stat[i] : 0u;
         }
     }
-    for (int i = tid; i < kMPodChunk * kMTsc * (kMDomMax + 1); i += kThreads) {
-        const int jj = i / (kMTsc * (kMDomMax + 1)), c = (i / (kMDomMax + 1)) % kMTsc, v = i % (kMDomMax + 1);
-        int32_t x = 0;
-        if (jj < jn) {
-            const MPod &q = l_pod[jj];
-            if (c < q.n_tsc && v <= q.tsc_ndom[c]) x = m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]);
-            if (c < q.n_tsc && v == 0) x = kMAbsent - 1; // value id 0 = the node lacks the topology key (filtering.go:328-332): above every limit
-        }
-        l_tbl[jj][c][v] = x;
-    }
-    __syncthreads();
-    // minimum over the present domains (a wave per (pod, constraint), a lane per domain), then the limit of the skew test:
-    // (match + self - min > maxSkew) <=> match > lim; min counts as 0 while fewer than minDomains domains exist (filtering.go:56-69, 311-356)
-    for (int pc = wave; pc < kMPodChunk * kMTsc; pc += kThreads / 64) {
-        const int jj = pc / kMTsc, c = pc % kMTsc;
-        int32_t lim = 0x7fffffff;
-        if (jj < jn) { // (uniform per wave)
-            const MPod &q = l_pod[jj];
-            if (c < q.n_tsc) {
-                const int v = lane; // domains 1 .. ndom <= kMDomMax - 1 < 64
-                const int32_t x = v >= 1 && v <= q.tsc_ndom[c] ? l_tbl[jj][c][v] : 0x7fffffff;
-                const uint32_t m = ~wave_max_u32(~(x < kMAbsent ? (uint32_t)x : 0x7fffffffu)); // (minimum over the wave; 0x7fffffff if no domain is present)
-                const int32_t mm = q.tsc_npresent[c] < q.tsc_min_dom[c] ? 0 : (int32_t)m;
-                lim = q.tsc_max_skew[c] + mm - q.tsc_self[c];
-            }
-        }
-        if (lane == 0) l_lim[jj][c] = lim;
-    }
-    __syncthreads();
     const unsigned long long sp_t1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int jj = 0; jj < kMPodChunk; jj++) {
         if (jj < jn) { // (uniform)
             const MPod &q = l_pod[jj];
             const uint32_t mt = (uint32_t)uni32(q.mt_a), ma = (uint32_t)uni32(q.ma_a);
-            const int32_t lim0 = uni32(l_lim[jj][0]), lim1 = uni32(l_lim[jj][1]);
+            // the spread filter per domain is the spec's own state (MPod::tsc_allow): two 64-bit masks in scalar registers
+            const uint64_t allow0 = uni64(q.tsc_allow[0]), allow1 = uni64(q.tsc_allow[1]);
             const bool sl0 = uni32(q.tsc_slot[0]) != 0, sl1 = uni32(q.tsc_slot[1]) != 0;
             uint32_t k1 = 0, k2 = 0, k3 = 0, mtb = 0, mab = 0, acc = 0;
 #pragma unroll
             for (int k = 0; k < kMNodesPerThread; k++) {
                 const uint32_t word = cv[jj][k];
                 const uint32_t v0 = (sl0 ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax, v1 = (sl1 ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax;
-                const bool ok = word != 0u && m_count(l_tbl[jj][0][v0]) <= lim0 && m_count(l_tbl[jj][1][v1]) <= lim1;
+                const bool ok = word != 0u && ((allow0 >> v0) & 1ull) && ((allow1 >> v1) & 1ull);
                 if (!ok) continue;
                 const uint32_t w = wv[jj][k];
                 const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
@@ -787,8 +789,11 @@ __device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
         const int pi = (st.next_pod + lane) % a.n_pods;
         const MPod &q = s_pod[lane];
 #pragma unroll
-        for (int c = 0; c < kMTsc; c++) // filtering.go:255-296 on the next cycle of this spec
-            if (c < q.n_tsc && ((my_f >> (1 + c)) & 1u) && q.tsc_self[c]) a.tbl_pool[q.tsc_tbl[c] + (q.tsc_slot[c] ? my_l1 : my_l0)] += 1;
+        for (int c = 0; c < kMTsc; c++) { // filtering.go:255-296 on the next cycle of this spec
+            const bool counted = c < q.n_tsc && ((my_f >> (1 + c)) & 1u) && q.tsc_self[c];
+            const int dv = q.tsc_slot[c] ? my_l1 : my_l0;
+            if (counted) a.tbl_pool[q.tsc_tbl[c] + dv] += 1; // (k_multi_refresh derives the spec's new masks)
+        }
         if (q.anti) atomicOr(&a.anti_bits[(int64_t)pi * (a.n_pad / 32) + (my_node >> 5)], 1u << (my_node & 31));
         a.per_spec[pi] += 1;
     }
@@ -804,6 +809,7 @@ __device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
     if (lane < nt && a.touched) a.touched[lane] = (int32_t)t_idx;
     if (lane == 0) {
         st.n_touched = nt;
+        st.placed_first = st.next_pod, st.n_placed = committed;
         st.placed += committed, st.rounds += committed;
         st.windows += 1, st.stops += stop_reason != 0 && stop_reason != 7 && stop_reason != 2;
         st.next_pod = st.single_pod >= 0 ? st.next_pod : (int32_t)((st.next_pod + committed) % a.n_pods);
@@ -839,8 +845,6 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     __shared__ MState s_st;
     __shared__ MPod s_pod[kMWindowMax];
     __shared__ MCand s_cd[kMWindowMax];
-    __shared__ int32_t s_tbl[kMWindowMax][kMTsc][kMDomMax + 1];
-    __shared__ int32_t s_min[kMWindowMax][kMTsc];
     __shared__ int64_t s_win[kMWindowMax];   // shard-local node index pod j was assigned
     __shared__ uint64_t s_wkey[kMWindowMax]; // ... and its key
     __shared__ int32_t s_node[kMWindowMax][10]; // the winners' columns as the scan saw them: a0 a1 r0 r1 z0 z1 alloc_pods pods l0 l1
@@ -864,32 +868,8 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     if (tid == 0) s_wa = W, s_fail = W, s_reason = 0, s_unsched = -1;
     __syncthreads();
     PT(0);
-    { // the pods' spread tables: 4 threads per pod, only the entries that exist, all loads in flight together (a flat
-      // loop over 64 x 2 x 64 slots was 32 dependent memory round trips per thread: 48 us per window)
-        const int j = tid >> 2, qd = tid & 3;
-        if (j < W) {
-            const MPod &q = s_pod[j];
-#pragma unroll
-            for (int c = 0; c < kMTsc; c++) {
-                int32_t x[(kMDomMax + 1) / 4];
-#pragma unroll
-                for (int i = 0; i < (kMDomMax + 1) / 4; i++) {
-                    const int v = qd + 4 * i;
-                    x[i] = (c < q.n_tsc && v <= q.tsc_ndom[c]) ? m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]) : 0;
-                }
-#pragma unroll
-                for (int i = 0; i < (kMDomMax + 1) / 4; i++) s_tbl[j][c][qd + 4 * i] = x[i];
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < W) {
-        const MPod &q = s_pod[tid];
-        for (int c = 0; c < kMTsc; c++)
-            s_min[tid][c] = c < q.n_tsc ? m_staged_min(&s_tbl[tid][c][0], q.tsc_ndom[c]) : 0;
-    }
-    __syncthreads();
-
+    // (no spread tables here: assignment and verification test the spread filter through the specs' per-domain masks,
+    // MPod::tsc_allow, and k_multi_refresh derives the placed specs' new masks from the tables the apply step increments)
     PT(1);
     // ---- A: assignment.  Pod j takes the first entry of its list that no EARLIER pod of the window took.  Lane j of wave 0 =
     // pod j (its list position, the bounds of what it skipped); whether its current candidate is held by a lower lane is
@@ -1048,9 +1028,9 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
             ok = fits_narrow(p, nq, a0, a1, r0, r1, ap, np);
 #pragma unroll
             for (int c = 0; c < kMTsc; c++)
-                if (c < q.n_tsc && ok) {
+                if (c < q.n_tsc && ok) { // PodTopologySpread.Filter on node w_t: pod j's tables have not moved (its own clones only)
                     const int32_t v = q.tsc_slot[c] ? s_node[t][9] : s_node[t][8];
-                    ok = m_pts_check(q, c, v, m_count(s_tbl[j][c][v < 0 || v > kMDomMax ? 0 : v]), s_min[j][c]) == 0;
+                    ok = ((q.tsc_allow[c] >> (v < 0 || v > kMDomMax ? 0 : v)) & 1ull) != 0;
                 }
             if (!ok) continue;
             const int64_t total = static_score(p, cnt, aff, img, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1);
@@ -1085,9 +1065,11 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
         for (int c = 0; c < kMTsc; c++)
             if (c < q.n_tsc) all = all && (q.tsc_slot[c] ? s_node[j][9] : s_node[j][8]) != 0;
 #pragma unroll
-        for (int c = 0; c < kMTsc; c++)
-            if (c < q.n_tsc && all && q.tsc_self[c] && (q.tsc_inc[c] < 0 || a.inc_pool[(int64_t)q.tsc_inc[c] * a.n_pad + n] != 0))
-                a.tbl_pool[q.tsc_tbl[c] + (q.tsc_slot[c] ? s_node[j][9] : s_node[j][8])] += 1;
+        for (int c = 0; c < kMTsc; c++) {
+            const bool counted = c < q.n_tsc && all && q.tsc_self[c] && (q.tsc_inc[c] < 0 || a.inc_pool[(int64_t)q.tsc_inc[c] * a.n_pad + n] != 0);
+            const int dv = q.tsc_slot[c] ? s_node[j][9] : s_node[j][8];
+            if (counted) a.tbl_pool[q.tsc_tbl[c] + dv] += 1; // (k_multi_refresh derives the spec's new masks)
+        }
         if (q.anti) atomicOr(&a.anti_bits[(int64_t)pi * (a.n_pad / 32) + (n >> 5)], 1u << (n & 31));
         a.per_spec[pi] += 1;
         const int64_t at = s_st.placed + j;
@@ -1098,6 +1080,7 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
         MState st = s_st;
         st.committed_epoch = st.epoch;
         st.n_touched = ok_n;
+        st.placed_first = next_pod, st.n_placed = ok_n;
         int reason = fail < wa ? 3 : s_reason; // 3: a pod preferred a taken node / a maximum may have moved
         if (ok_n > 0) st.winner = a.c.global_offset + s_win[ok_n - 1], st.last_feasible = s_cd[ok_n - 1].nfeas;
         st.placed += ok_n, st.rounds += ok_n;
@@ -1123,7 +1106,23 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_multi_refresh: grid (spec blocks, kMTouched).  Block row t = touched node t of the window just committed; thread = pod
+// k_multi_masks: thread = pod spec.  MPod::tsc_allow from the spec's tables as they stand (when a run begins: the tables may
+// have been restored by ccsim_reset_state).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_multi_masks(MultiArgs a) {
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (pi >= a.n_pods) return;
+    const MPod q = a.pods[pi];
+    for (int c = 0; c < kMTsc; c++) {
+        const int32_t *tbl = a.tbl_pool + q.tsc_tbl[c];
+        const uint8_t *present = a.present_pool + q.tsc_tbl[c];
+        a.pods[pi].tsc_allow[c] = m_allow_mask(q, c, [&](int v) { return m_stage(tbl[v], present[v]); }, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_multi_refresh: grid (spec blocks, kMTouched), after the commit.  (1) The specs the window placed: their per-domain spread
+// masks (block (0, t), a wave per constraint).  (2) Block row t = touched node t of the window just committed; thread = pod
 // spec.  Recomputes the memo word of (spec, node) from the node's columns as the commit left them -- for every spec whose
 // row is stamped with the maxima it assumes today (any other row is recomputed as a whole by the spec's next scan).
 // Idempotent: a launch that follows a window no commit kernel took repeats the last one.
@@ -1131,7 +1130,22 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
 constexpr int kMRefreshThreads = 256;
 __global__ __launch_bounds__(kMRefreshThreads) void k_multi_refresh(MultiArgs a) {
     const int t = blockIdx.y;
-    if (t >= a.st->n_touched) return;
+    if (blockIdx.x == 0 && t < a.st->n_placed && threadIdx.x < 64 * kMTsc) {
+        // the t-th spec the window placed: its spread masks from its tables as the commit left them -- wave c = constraint c,
+        // lane v = domain v (m_allow_mask, a domain per lane: the minimum over the present domains, then the skew test)
+        const int ps = (a.st->placed_first + t) % a.n_pods, c = threadIdx.x >> 6, v = threadIdx.x & 63;
+        const MPod &q = a.pods[ps];
+        if (c < q.n_tsc) { // (uniform per wave)
+            const bool dom = v >= 1 && v <= q.tsc_ndom[c];
+            const int32_t x = dom ? m_stage(a.tbl_pool[q.tsc_tbl[c] + v], a.present_pool[q.tsc_tbl[c] + v]) : kMAbsent;
+            const uint32_t mn = ~wave_max_u32(~(x < kMAbsent ? (uint32_t)x : 0x7fffffffu));
+            const int64_t lim = (int64_t)q.tsc_max_skew[c] + (q.tsc_npresent[c] < q.tsc_min_dom[c] ? 0 : (int64_t)mn) - q.tsc_self[c];
+            const bool pass = !dom || (int64_t)m_count(x) <= lim;
+            const uint64_t mask = (uint64_t)__ballot(pass) & ~1ull;
+            if (v == 0) a.pods[ps].tsc_allow[c] = mask;
+        }
+    }
+    if (!a.memo || t >= a.st->n_touched) return;
     const int pi = blockIdx.x * kMRefreshThreads + threadIdx.x;
     if (pi >= a.n_pods || !m_memo_valid(a, pi)) return;
     const int64_t n = a.touched[t];
