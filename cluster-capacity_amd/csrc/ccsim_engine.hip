@@ -2508,7 +2508,6 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
             if (q.req[c] != 0) return fail(e, -ENOSYS, "several pod specs: requests beyond cpu / memory (spec %d)", p);
         if (q.has_scalar_entries) return fail(e, -ENOSYS, "several pod specs: scalar resource entries (spec %d)", p);
         if (q.has_host_ports && (pf.filter_mask & CCSIM_F_NODEPORTS)) return fail(e, -ENOSYS, "several pod specs: host ports (spec %d)", p);
-        if (q.image_score && pf.w_imagelocality) return fail(e, -ENOSYS, "several pod specs: ImageLocality scores (spec %d)", p);
         mem_or |= (uint64_t)q.req[1] | (uint64_t)q.nz_mem;
         const int64_t gc = q.req[0] > q.nz_mcpu ? q.req[0] : q.nz_mcpu, gm = q.req[1] > q.nz_mem ? q.req[1] : q.nz_mem;
         grow_c = gc > grow_c ? gc : grow_c, grow_m = gm > grow_m ? gm : grow_m;
@@ -2555,13 +2554,33 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     if ((rc = build_narrow(e))) return rc;
 
     // ---- static classes: one k_static run per distinct (tolerations, selectors, terms) ---------------------------
+    // (the static word also carries the node's ImageLocality score for the pod: specs share a class only with the same per-node
+    // scores -- compared by a hash of the array first, then byte by byte against the class's representative)
     std::map<std::string, int> cls_of;
     std::vector<int> pod_cls((size_t)n_pods), cls_rep;
+    bool any_img = false;
     for (int p = 0; p < n_pods; p++) {
         const bool pref = pods[p].n_preferred > 0 && pf.w_nodeaffinity;
-        auto it = cls_of.emplace(static_class_key(e, &pods[p], pref), (int)cls_of.size());
-        if (it.second) cls_rep.push_back(p);
-        pod_cls[(size_t)p] = it.first->second;
+        std::string key = static_class_key(e, &pods[p], pref);
+        const uint8_t *img = pf.w_imagelocality ? pods[p].image_score : nullptr;
+        if (img) {
+            any_img = true;
+            for (size_t i = 0; i < N; i++)
+                if (img[i] > 100) return fail(e, -EINVAL, "image_score out of [0,100] (spec %d)", p);
+            uint64_t h = 1469598103934665603ull; // FNV-1a over the scores
+            for (size_t i = 0; i < N; i++) h = (h ^ img[i]) * 1099511628211ull;
+            key.append("img", 3), key.append((const char *)&h, sizeof h);
+        }
+        for (int salt = 0;; salt++) { // (a hash collision between different arrays opens another class)
+            auto it = cls_of.emplace(key, (int)cls_of.size());
+            if (it.second) cls_rep.push_back(p);
+            const uint8_t *rep_img = pf.w_imagelocality ? pods[cls_rep[(size_t)it.first->second]].image_score : nullptr;
+            if (!img || it.second || (rep_img && memcmp(rep_img, img, N) == 0)) {
+                pod_cls[(size_t)p] = it.first->second;
+                break;
+            }
+            key.push_back((char)('0' + salt % 10));
+        }
     }
     e->n_cls = (int)cls_rep.size();
     if ((rc = dev_alloc(e, &e->d_stat_cls, NP * (size_t)e->n_cls, e->multi_allocs))) return rc;
@@ -2673,6 +2692,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     }
     for (int sl = 0; sl < kMTsc; sl++) e->tsc_label[sl] = slot_col[sl] >= 0 ? e->dev_label_ptrs[(size_t)slot_col[sl]] : nullptr;
     e->multi_prof = make_devpod(e, &pods[0]); // profile-level constants; the per-pod switches come from MPod
+    e->multi_prof.w_img = any_img ? pf.w_imagelocality : 0; // (a spec without image scores has 0 in its class's static words: the weight does nothing there)
     if (e->multi_prof.gen_score) return fail(e, -ENOSYS, "several pod specs: scoring resource lists beyond cpu / memory");
     if (100ll * ((int64_t)pf.w_taint + pf.w_nodeaffinity + pf.w_fit + pf.w_balanced + pf.w_imagelocality) >= (1ll << 21))
         return fail(e, -ENOSYS, "several pod specs: plugin weights too large for the scan's packed 32-bit keys");

@@ -289,7 +289,7 @@ int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod);
  * DoNotSchedule constraints per spec (<= 62 domains each) over at most two label columns in total; inter-pod
  * affinity only as REQUIRED ANTI-affinity of a spec to its own clones on a one-node-per-domain key (kubernetes.io/hostname);
  * no selector of one spec may match the clones of another (the caller's labels are disjoint); requests over cpu / memory
- * only; no host ports, no ImageLocality scores; percentageOfNodesToScore 100; plugin weights whose total score stays below
+ * only; no host ports; ImageLocality scores per spec (round 4); percentageOfNodesToScore 100; plugin weights whose total score stays below
  * 2^21 (the scan packs (score, node) into 32 bits).  Anything else: -ENOSYS. */
 int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_pods);
 /* Scheduler.SchedulePod + assume for one pod of spec pod_idx (the B2 seam with several templates) */

@@ -10,13 +10,14 @@ import helpers as H
 from cluster_capacity_amd import capi, model as M, synth
 
 
-def random_specs(rng, nodes, n_specs):
+def random_specs(rng, nodes, n_specs, images=False):
     """Config-5-shaped specs over random_case()-style nodes (label columns: 0 = 'type' (0..4), 1 = 'zone' (0..2, 0 = key
     absent), 2 = hostname), with per-spec variety: tolerations, selectors, preferred terms, existing matching pods."""
     n = nodes.n
     t_in = lambda size, ids: np.isin(np.arange(size), ids).astype(np.uint8)
     sel_cache = {}
     pods = []
+    img_pool = [rng.integers(0, 101, n).astype(np.uint8) for _ in range(2)] if images else []
     for j in range(n_specs):
         cpu, mem = int(rng.choice([50, 100, 250, 500, 900])), int(rng.choice([64, 128, 512, 1024])) * H.MiB
         kw = {}
@@ -44,17 +45,19 @@ def random_specs(rng, nodes, n_specs):
             ex = (rng.random(n) < 0.05).astype(np.int32) if rng.random() < 0.3 else None
             ipa = M.InterPodAffinity(key_cols=[2], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[ex], exist_anti=[None],
                                      score_existing=[None], score_self=[0], self_entries=[0])
+        if img_pool and rng.random() < 0.35:  # ImageLocality scores: some specs share an array (one static class), some bring their own
+            kw["image_score"] = img_pool[int(rng.integers(0, len(img_pool)))] if rng.random() < 0.6 else rng.integers(0, 101, n).astype(np.uint8)
         pods.append(M.PodSpec(req=np.array([cpu, mem, 0], np.int64), nz_mcpu=cpu, nz_mem=mem, taint_filter_ok=ok, taint_prefer_cnt=cnt,
                               tolerates_unschedulable=bool(rng.random() < 0.2), spread=spread, ipa=ipa, **kw))
     return pods
 
 
-def random_multi_case(rng, n, n_specs):
+def random_multi_case(rng, n, n_specs, images=False):
     nodes = H.simple_nodes(rng.choice([2000, 4000, 8000, 16000], n), rng.choice([4, 8, 16, 32], n) * H.GiB, rng.integers(3, 30, n),
                            req_mcpu=rng.integers(0, 20, n) * 50, req_mem=rng.integers(0, 8, n) * 256 * H.MiB, pod_count=rng.integers(0, 3, n),
                            taintset_id=rng.integers(0, 4, n), unschedulable=(rng.random(n) < 0.03),
                            label_cols=[rng.integers(0, 5, n), rng.integers(0, 3, n), np.arange(1, n + 1)])
-    return nodes, random_specs(rng, nodes, n_specs), M.Profile.default()
+    return nodes, random_specs(rng, nodes, n_specs, images), M.Profile.default()
 
 
 def _same(got, ref):
@@ -165,6 +168,23 @@ def test_score_memo_random_specs_long_runs_vs_oracle(ccref, monkeypatch, seed):
     _same(e.run(max_limit=0, log_cap=max(1, ref.placed)), ref)
     mm = e.multi_memo()
     assert mm["on"] and mm["memo_scans"] > 0
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", ["5", "64"])
+@pytest.mark.parametrize("seed", range(4))
+def test_random_specs_with_image_locality_scores_vs_oracle(ccref, monkeypatch, window, seed):
+    """Specs with ImageLocality scores (image_locality.go:54-66: the node's score as it is, weight 1): the score lives in the static
+    word of the spec's CLASS, so specs share a class only with equal per-node scores."""
+    monkeypatch.setenv("CCSIM_MULTI_WINDOW", window)
+    rng = np.random.default_rng(9300 + seed)
+    nodes, pods, prof = random_multi_case(rng, int(rng.integers(100, 700)), int(rng.integers(3, 50)), images=True)
+    assert any(p.image_score is not None for p in pods)
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=0)
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    _same(e.run(max_limit=0, log_cap=max(1, ref.placed)), ref)
     e.close()
 
 
