@@ -136,6 +136,8 @@ struct ccsim_engine {
     int32_t *h_mb_ok = nullptr;         // ... and the ranks' minimum, page-locked
     uint32_t persist_seq = 0;           // launch sequence of the mailbox form (tags: nothing is zeroed between launches)
     int persist_vranks = 0;             // CCSIM_PERSIST_VRANKS: run the single-device batched mode as that many virtual ranks
+    bool lazy_wide = true;              // (CCSIM_EAGER_WIDE=1: the persistent launch writes the int64 columns back itself)
+    bool wide_stale = false;            // a persistent launch left the int64 request columns behind the mirrors (PersistCols::skip_wide): ensure_cols re-derives them
     bool reset_pending = false;         // ccsim_reset_state deferred the restore of the node columns: the next persistent launch loads the
                                         // pristine copies directly; everything else restores first (ensure_cols)
     bool hist_in_kernel = false;        // the last persistent launch filled d_hist / d_hist_ts itself (no k_hist pass)
@@ -284,6 +286,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     e->time_passes = cfg->time_passes;
     if (const char *f = getenv("CCSIM_NARROW")) e->narrow_allowed = atoi(f); // A/B knob
     if (const char *f = getenv("CCSIM_PERSIST")) e->persist_allowed = atoi(f); // A/B knob: 0 = multi-kernel batched mode
+    if (const char *f = getenv("CCSIM_EAGER_WIDE")) e->lazy_wide = atoi(f) == 0;
     if (const char *f = getenv("CCSIM_CW")) e->cw_allowed = atoi(f);           // A/B knob: 0 = coupled plugins one pass per placement
     if (const char *f = getenv("CCSIM_FUSED")) e->fused_allowed = atoi(f);     // A/B knob: 0 = sequential cycle as k_scan + k_final
     if (const char *f = getenv("CCSIM_PERSIST_VRANKS")) e->persist_vranks = atoi(f) > 1 && atoi(f) <= kPMaxRanks ? atoi(f) : 0; // validation knob
@@ -369,7 +372,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     drop_graph(e);
     free_list(e->allocs);
     e->backups.clear();
-    e->reset_pending = false;
+    e->reset_pending = false, e->wide_stale = false;
     e->mb_go = -1;
     e->backup_bytes.clear();
     e->have_nodes = e->have_pod = e->begun = false;
@@ -1492,8 +1495,19 @@ static int persist_k(const ccsim_engine *e) { return persist_k_impl(e, e->persis
 
 // the deferred half of ccsim_reset_state: the node columns back from their pristine copies, the mirrors and the NodePorts clamp after them
 static int ensure_cols(ccsim_engine *e) {
-    if (!e->reset_pending) return 0;
+    if (!e->reset_pending) {
+        if (e->wide_stale) { // (the mirrors are the state: the int64 columns follow them)
+            e->wide_stale = false;
+            HIPCHK(e, hipSetDevice(e->device));
+            const DevCols &c = e->cols;
+            hipLaunchKernelGGL(k_widen, dim3((unsigned)((e->n_pad + 255) / 256)), dim3(256), 0, e->stream, (const int32_t *)c.r32[0], (const int32_t *)c.r32[1],
+                               (const int32_t *)c.z32[0], (const int32_t *)c.z32[1], c.req[0], c.req[1], c.nz_mcpu, c.nz_mem, c.mem_shift, e->n_pad);
+            HIPCHK(e, hipGetLastError());
+        }
+        return 0;
+    }
     e->reset_pending = false;
+    e->wide_stale = false; // (everything is restored from the pristine copies)
     HIPCHK(e, hipSetDevice(e->device));
     for (size_t i = 0; i < e->backups.size(); i++)
         HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
@@ -1590,6 +1604,7 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
             a.c.p_pod_count = (const int32_t *)e->backups[(size_t)e->ncol + 2].second;
         }
         a.c.cnt_assign = launch == 0 ? 1 : 0; // (begin_run zeroed the per-run counts)
+        a.c.skip_wide = !mb && e->lazy_wide ? 1 : 0;
         a.c.hist = diag ? e->d_hist : nullptr, a.c.hist_ts = e->d_hist_ts, a.c.hist_code = e->d_hist_code;
         if (mb) a.tag_base = 0x80000000u | ((e->persist_seq++ & 0x7ffu) << 20); // (bit 31: a virtual-rank run -- never the tag of a sharded run's launch, which shares the boxes)
         HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync) * (size_t)sync_blocks, e->stream));
@@ -1640,6 +1655,7 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
             return fail(e, -EIO, "persistent level kernel: grid barrier timed out (a workgroup was not resident)");
         }
         e->reset_pending = false; // the columns hold this launch's state now
+        if (a.c.skip_wide) e->wide_stale = true; // ... the mirrors do; the int64 columns are re-derived on demand (ensure_cols)
         e->persist_hint = true, e->persist_hint_mt = e->h_state->p_mt0, e->persist_hint_ma = e->h_state->p_ma0;
         if (mb) { // every (virtual) rank succeeded: the commit rows become the columns
             const int blocks = (int)((e->n_pad + kThreads - 1) / kThreads);

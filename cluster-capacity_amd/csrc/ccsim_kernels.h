@@ -704,6 +704,15 @@ __device__ __forceinline__ int64_t static_score(const DevPod &p, uint32_t c, uin
     return static_score(p, c, a, img, mt, ma, div_magic(mt), div_magic(ma));
 }
 
+// the int64 columns from the lossless 32-bit mirrors (cpu as it is, memory << the common power-of-two unit): what a persistent
+// launch that skipped their write-back (PersistCols::skip_wide) left to be done
+__global__ __launch_bounds__(256) void k_widen(const int32_t *r0, const int32_t *r1, const int32_t *z0, const int32_t *z1, int64_t *req0, int64_t *req1,
+                                               int64_t *nz_mcpu, int64_t *nz_mem, int sh, int64_t n_pad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    req0[i] = (int64_t)r0[i], req1[i] = (int64_t)r1[i] << sh, nz_mcpu[i] = (int64_t)z0[i], nz_mem[i] = (int64_t)z1[i] << sh;
+}
+
 __device__ __forceinline__ uint64_t make_key(int64_t total, int64_t gidx) {
     return ((uint64_t)(total + 1) << kIdxBits) | (kIdxMask - (uint64_t)gidx);
 }

@@ -87,6 +87,9 @@ struct PersistCols {
     unsigned long long *hist, *hist_ts, *hist_code; // the terminal cycle's diagnosis, from the state in LDS (types.go:787-836); null = not here
     int32_t n_taintsets, cnt_assign; // cnt_assign: placed_cnt is written, not added to (first launch of a run)
     int32_t *rows;                  // mailbox form: the final state goes to the commit rows (k_rows_flush publishes it once every rank agrees)
+    int32_t skip_wide;              // the int64 columns are NOT written back: they are a function of the mirrors (value << unit), and the
+                                    // engine re-derives them when an entry point that reads them comes along (ensure_cols: k_widen) --
+                                    // 32 of the write-back's 56 B per node
 };
 
 struct PersistArgs {
@@ -1066,8 +1069,10 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             continue;
         }
         a.c.r32[0][i] = r0, a.c.r32[1][i] = r1, a.c.z32[0][i] = z0, a.c.z32[1][i] = z1;
-        a.c.req[0][i] = (int64_t)r0, a.c.req[1][i] = (int64_t)r1 << sh;
-        a.c.nz_mcpu[i] = (int64_t)z0, a.c.nz_mem[i] = (int64_t)z1 << sh;
+        if (!a.c.skip_wide) {
+            a.c.req[0][i] = (int64_t)r0, a.c.req[1][i] = (int64_t)r1 << sh;
+            a.c.nz_mcpu[i] = (int64_t)z0, a.c.nz_mem[i] = (int64_t)z1 << sh;
+        }
         a.c.pod_count[i] = np;
         if (a.c.cnt_assign) a.c.placed_cnt[i] = np - np0;
         else a.c.placed_cnt[i] += np - np0;
