@@ -34,3 +34,32 @@ def test_windows_end_early_and_still_match(ccref):
     for got in (wide, tight):
         assert got["placed"] == ref.placed and np.array_equal(got["log"], ref.log)
     assert tight["windows"] >= wide["windows"]
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+@pytest.mark.parametrize("window,tile", [(1, 16), (5, 4), (64, 16)])
+@pytest.mark.parametrize("seed", range(8))
+def test_memo_masks_and_assumed_maxima_vs_oracle(ccref, seed, window, tile, parallel):
+    """Round 4's bookkeeping (score memo + refresh, per-domain spread masks, assumed maxima + repair; MemoWindowModel) reproduces the
+    oracle's loop, and its invariants -- every memo word a scan reads equals its recomputation, the masks equal the table-derived
+    verdicts -- hold at every use (asserted inside the model)."""
+    from window_model import MemoWindowModel
+    rng = np.random.default_rng(700 + seed)
+    nodes, pods, prof = random_multi_case(rng, int(rng.integers(20, 160)), int(rng.integers(2, 20)))
+    limit = int(rng.choice([0, 0, 41]))
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=limit)
+    got = MemoWindowModel(prof, nodes, pods, tile=tile, topk=8, window=window).run(limit, parallel=parallel)
+    assert got["placed"] == ref.placed and got["stop"] == ref.stop and got["stop_spec"] == ref.stop_spec
+    assert np.array_equal(got["log"], ref.log)
+    st = got["stats"]
+    if ref.placed > 3 * len(pods):
+        assert st["memo_scans"] > 0 and st["words_checked"] > 0  # (the rows were read, not only filled)
+
+
+def test_memo_without_refresh_is_caught(ccref):
+    """The model's invariant has teeth: without the refresh of the touched nodes a scan meets a stale word."""
+    from window_model import MemoWindowModel
+    rng = np.random.default_rng(4243)
+    nodes, pods, prof = random_multi_case(rng, 80, 6)
+    with pytest.raises(AssertionError, match="stale memo word"):
+        MemoWindowModel(prof, nodes, pods, window=6, refresh=False).run(0)

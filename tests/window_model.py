@@ -276,3 +276,108 @@ class WindowModel:
         self.z0[n] -= int(q.nz_mcpu); self.z1[n] -= int(q.nz_mem)
         self.npods[n] -= 1
         self.placed[s][n] -= 1
+
+
+class MemoWindowModel(WindowModel):
+    """Round 4's bookkeeping on top of the window argument (csrc/ccsim_multi.h: the score memo, the per-domain spread masks, the
+    ASSUMED normalization maxima), restated so that its invariants can be asserted on the CPU at every use:
+
+      memo      memo[s][n] = 0 if the static verdict / NodeResourcesFit / the spec's anti-affinity reject the pair, else
+                TotalScore(s, n) + 1 under the maxima the row is STAMPED with.  A scan whose spec's stamp equals the maxima it
+                assumes reads the row (here: asserts word == recomputation); any other scan fills the row; `select` stamps it.
+      refresh   after a commit, the words of the nodes the window placed pods on are recomputed for every spec whose stamp
+                equals its assumed maxima AFTER the commit's repairs (k_multi_refresh); a row whose spec's maxima were
+                re-derived keeps its old stamp and is refilled by the spec's next scan.
+      masks     allow[s][c] = the value ids a node may carry to pass constraint c's skew test; rebuilt for the specs a window
+                placed (their tables moved), asserted current at every scan.
+      maxima    scores are computed under the spec's ASSUMED maxima; a scan that finds other true maxima over its feasible set
+                ends the window before that pod and repairs the assumption of it and of every later pod of the window."""
+
+    def __init__(self, prof, nodes, pods, tile=16, topk=8, window=64, refresh=True):
+        super().__init__(prof, nodes, pods, tile, topk, window)
+        self.mt_a, self.ma_a = [0] * self.P, [0] * self.P
+        self.stamp = [None] * self.P
+        self.memo = [[0] * self.N for _ in pods]
+        self.allow = [self._masks(s) for s in range(self.P)]
+        self.refresh_on = refresh
+        self.stats = dict(memo_scans=0, full_scans=0, refreshed=0, repairs=0, words_checked=0)
+
+    def _hard(self, s):
+        return [k for k in self.pods[s].spread if k.hard] if (self.prof.filter_mask & F_TOPOLOGYSPREAD) else []
+
+    def _masks(self, s):
+        out = []
+        for k, match, mn in self.spread_state(s):
+            vals = {int(self.nd.label_cols[k.col][n]) for n in range(self.N)} - {0}
+            out.append({v for v in vals if match.get(v, 0) + (1 if k.self_match else 0) - mn <= k.max_skew})
+        return out
+
+    def _word(self, s, n):
+        return self.score(s, n, self.mt_a[s], self.ma_a[s]) + 1 if self.feasible(s, n, []) else 0  # (no spread state: everything but that filter)
+
+    def scan(self, s):
+        assumed = (self.mt_a[s], self.ma_a[s])
+        if self.stamp[s] == assumed:
+            self.stats["memo_scans"] += 1
+            for n in range(self.N):  # THE invariant: what the scan reads is what it would compute
+                assert self.memo[s][n] == self._word(s, n), ("stale memo word", s, n, self.memo[s][n], self._word(s, n))
+            self.stats["words_checked"] += self.N
+        else:
+            self.stats["full_scans"] += 1
+            self.memo[s] = [self._word(s, n) for n in range(self.N)]
+        self.stamp[s] = assumed  # (k_multi_select, after the scan)
+        sp = self.spread_state(s)
+        assert self.allow[s] == self._masks(s), ("stale spread masks", s)
+        hard = self._hard(s)
+        feas = [n for n in range(self.N)
+                if self.memo[s][n] and all(int(self.nd.label_cols[k.col][n]) in self.allow[s][c] for c, k in enumerate(hard))]
+        assert feas == [n for n in range(self.N) if self.feasible(s, n, sp)]  # (word + masks == the filters)
+        mt = max((self.cnt[s][n] for n in feas), default=0)
+        ma = max((self.aff[s][n] for n in feas), default=0)
+        cd = dict(nfeas=len(feas), mt=mt, ma=ma, wrong=(mt, ma) != assumed, sp=sp)
+        if not feas:
+            return cd
+        keys = {n: self.key(self.memo[s][n] - 1, n) for n in feas}  # scores under the ASSUMED maxima
+        tiles = {}
+        for n in feas:
+            tiles.setdefault(n // self.tile, []).append(keys[n])
+        top2, third = [], {}
+        for b, ks in tiles.items():
+            ks.sort(reverse=True)
+            top2 += ks[:2]
+            third[b] = ks[2] if len(ks) > 2 else 0
+        top2.sort(reverse=True)
+        cd.update(c_mt=sum(1 for n in feas if self.cnt[s][n] == mt), c_ma=sum(1 for n in feas if self.aff[s][n] == ma),
+                  cand=top2[: self.topk], bound=top2[self.topk] if len(top2) > self.topk else 0, third=third)
+        return cd
+
+    def run(self, limit=0, parallel=False):
+        log, windows, nxt, idle = [], 0, 0, 0
+        while True:
+            W = self.window if limit <= 0 else min(self.window, limit - len(log))
+            specs = [(nxt + j) % self.P for j in range(W)]
+            cds = [self.scan(s) for s in specs]  # all against S0
+            windows += 1
+            cut = next((j for j, cd in enumerate(cds) if cd["wrong"]), W)  # a wrong assumption ends the window before that pod ...
+            for j in range(cut, W):  # ... and one window repairs every later pod of it
+                if (self.mt_a[specs[j]], self.ma_a[specs[j]]) != (cds[j]["mt"], cds[j]["ma"]):
+                    self.stats["repairs"] += 1
+                self.mt_a[specs[j]], self.ma_a[specs[j]] = cds[j]["mt"], cds[j]["ma"]
+            before = len(log)
+            done = (self._commit_par if parallel else self._commit_seq)(specs[:cut], cds[:cut], log)
+            placed = list(zip(specs, log[before:]))
+            for s, _ in placed:  # the placed specs' tables moved: their masks (k_multi_refresh, block (0, t))
+                self.allow[s] = self._masks(s)
+            if self.refresh_on:
+                for _, n in placed:  # the touched nodes' words, for every spec whose row stands under today's maxima
+                    for s2 in range(self.P):
+                        if self.stamp[s2] == (self.mt_a[s2], self.ma_a[s2]):
+                            self.memo[s2][n] = self._word(s2, n)
+                            self.stats["refreshed"] += 1
+            nxt = (nxt + done["committed"]) % self.P
+            if done.get("stop") == "unschedulable":
+                return dict(placed=len(log), stop=0, stop_spec=done["spec"], log=np.array(log, np.int32), windows=windows, stats=self.stats)
+            if limit > 0 and len(log) >= limit:
+                return dict(placed=len(log), stop=1, stop_spec=-1, log=np.array(log, np.int32), windows=windows, stats=self.stats)
+            idle = 0 if done["committed"] else idle + 1
+            assert idle <= 1, "a window that only repaired maxima is followed by one whose pod 0 commits"
