@@ -93,8 +93,8 @@ def cpu_baseline(nodes, pod, prof, rounds: int, engine_log, blind_counts=None, c
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20 in the batched mode -- a step is ~0.3 ms -- and 3 in the sequential mode)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: 3 / 1)")
     ap.add_argument("--mode", default="batched", choices=["sequential", "batched"])
     ap.add_argument("--nodes", type=int, default=1_000_000, help="nodes per GPU (weak) / in the whole snapshot (strong)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch timing run (PMC collection runs)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.mode == "batched" else 3
+    if args.warmup is None:
+        args.warmup = 3 if args.mode == "batched" else 1
 
     # ONE JSON line on stdout: RCCL announces itself on stdout (version banner, some of it at exit) -- everything but the line goes
     # to stderr: fd 1 points at stderr for the run, the line is written to the saved descriptor
