@@ -1,0 +1,68 @@
+"""The one JSON line `bench.py` prints is a contract with the driver: its keys, the metric BASELINE.json names, the arithmetic that ties
+`value`, `ms_per_step` and the workload together, the `roofline` and `cpu_baseline` objects.  Checked on the lines committed under
+profiles/ (CPU) and on a short run of bench.py itself (GPU)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOP = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
+
+
+def _check_line(d, full):
+    for k in TOP:
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"].split(";")[0].strip() and d["unit"] == "placements/s"
+    assert d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert isinstance(d["n_gpus"], int) and d["n_gpus"] >= 1 and d["steps"] >= 1 and d["ms_per_step"] > 0
+    cfg = d["config"]
+    assert "workload" in cfg and "model" not in cfg
+    # value = whole-job placements per second: the placements of one step over the time of one step
+    assert d["value"] == pytest.approx(cfg["placements_per_step"] / (d["ms_per_step"] * 1e-3), rel=0.02)
+    if "roofline" in d and d["roofline"]:
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, k
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-6) and 0 < r["frac"] < 1
+        if r["traffic"] is not None:  # PMC bytes of one launch over the launch's duration = the achieved rate
+            assert r["achieved"] == pytest.approx(r["traffic"] / (r["us_per_launch"] * 1e-6) / 1e9, rel=0.02)
+        assert r["us_per_launch"] * 1e-3 <= d["ms_per_step"] * 1.05  # the dominant kernel fits inside the step it is part of
+    if full:
+        c = d["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c, k
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+        assert c["log_equals_engine_prefix"] is True  # (the oracle's log is the engine's: the baseline ran the same simulation)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[34]", "**", "bench_1M.json"), recursive=True)))
+def test_committed_bench_lines_keep_the_contract(path):
+    _check_line(json.load(open(path)), full=True)
+
+
+def test_round_4_line_carries_pmc_traffic_of_the_sources_in_the_tree():
+    """bench.py accepts profiles/<round>/pmc_traffic.json only when it was collected with the sources it runs: the committed file must
+    be stamped with the hash of the tree's csrc/ + include/, or the driver's line says `traffic: null`."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from cluster_capacity_amd import build as b
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")))
+    assert pmc["src_sha16"] == b.source_sha16(), "profiles/r04/pmc_traffic.json was collected with other sources: re-run tools/gpu_round_profile.sh r04 skip-suite"
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_on_stdout():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-variants", "--seq-rounds", "0",
+                          "--nodes", "100000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    _check_line(d, full=False)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
