@@ -211,17 +211,22 @@ def main():
     persistent = args.mode == "batched" and not distributed and os.environ.get("CCSIM_PERSIST", "1") != "0"
     kernel = "k_level_persist" if persistent else ("k_level_commit" if args.mode == "batched" else "k_scan")
     sha = lib_sha16()
-    pmc, pmc_note = {}, "no profiles/r04/pmc_traffic.json for this workload"
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")))
-        if hi - lo != 1_000_000:
-            pmc_note = "PMC traffic was collected at 1,000,000 nodes per GPU"
-        elif pj.get("lib_sha16") != sha and pj.get("src_sha16") != src_sha16():  # (the binary embeds its build path: the sources decide)
-            pmc_note = f"stale: collected with libccsim.so {pj.get('lib_sha16')} / sources {pj.get('src_sha16')}, this run uses {sha} / {src_sha16()}"
-        else:
-            pmc, pmc_note = pj["kernels"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so (profiles/r04/pmc_traffic.json)"
-    except (OSError, KeyError, ValueError):
-        pass
+    pmc, pmc_note = {}, "no profiles/rNN/pmc_traffic.json for this workload"
+    import glob
+    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_traffic.json")), reverse=True):  # the newest round first
+        rel = os.path.relpath(pmc_path, ROOT)
+        try:
+            pj = json.load(open(pmc_path))
+            if hi - lo != 1_000_000:
+                pmc_note = "PMC traffic was collected at 1,000,000 nodes per GPU"
+            elif pj.get("lib_sha16") != sha and pj.get("src_sha16") != src_sha16():  # (the binary embeds its build path: the sources decide)
+                pmc_note = f"stale: {rel} was collected with libccsim.so {pj.get('lib_sha16')} / sources {pj.get('src_sha16')}, this run uses {sha} / {src_sha16()}"
+                continue
+            else:
+                pmc, pmc_note = pj["kernels"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same libccsim.so ({rel})"
+        except (OSError, KeyError, ValueError):
+            continue
+        break
     roofline = None
     if not args.no_roofline and not distributed:
         eng.reset_state()

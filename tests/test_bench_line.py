@@ -45,15 +45,17 @@ def test_committed_bench_lines_keep_the_contract(path):
     _check_line(json.load(open(path)), full=True)
 
 
-def test_round_4_line_carries_pmc_traffic_of_the_sources_in_the_tree():
-    """bench.py accepts profiles/<round>/pmc_traffic.json only when it was collected with the sources it runs: the committed file must
+def test_a_committed_pmc_file_was_collected_with_the_sources_in_the_tree():
+    """bench.py accepts a profiles/<round>/pmc_traffic.json only when it was collected with the sources it runs: some committed file must
     be stamped with the hash of the tree's csrc/ + include/, or the driver's line says `traffic: null`."""
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
     ge.load_package()
     from cluster_capacity_amd import build as b
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")))
-    assert pmc["src_sha16"] == b.source_sha16(), "profiles/r04/pmc_traffic.json was collected with other sources: re-run tools/gpu_round_profile.sh r04 skip-suite"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_traffic.json")), reverse=True)  # (bench.py takes the newest that matches)
+    have = {os.path.relpath(f, ROOT): json.load(open(f)).get("src_sha16") for f in files}
+    assert b.source_sha16() in have.values(), (f"no profiles/rNN/pmc_traffic.json was collected with the tree's sources ({b.source_sha16()}; have {have}): "
+                                                "re-run tools/gpu_round_profile.sh <round> skip-suite on the GPU and commit profiles/<round>/pmc_traffic.json")
 
 
 @pytest.mark.gpu
