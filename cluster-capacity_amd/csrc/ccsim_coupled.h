@@ -45,7 +45,9 @@ constexpr int kCwSlots = 1024;      // global open-addressing class table (power
 constexpr int kCwBlockSlots = 256;  // per-block LDS class table of the scan (power of two)
 constexpr int kCwMaxList = 64;      // L
 constexpr int kCwMaxWindow = 256;   // W of the general decide kernel (a touched node keeps its whole tuple in LDS)
-constexpr int kCwFastWindow = 1024; // W of the lane-per-candidate kernel (a touched node is (index, clones))
+constexpr int kCwFastWindow = 2048; // W of the lane-per-candidate kernel (a touched node is (index, clones)): 64 classes x the 32 list members
+                                    // its staging area holds for each carry 2048 cycles per pass (round 4; 1024 before: the pass's fixed work --
+                                    // scan, top, merges: ~280 us at 1M nodes / 64 zones -- halves per placement)
 constexpr int kCwThreads = 256, kCwPerThread = 4, kCwTile = kCwThreads * kCwPerThread;
 constexpr int kCwMaxKeys = 6400;    // k_cw_merge stages blocks x L keys of one class in LDS (32 KiB)
 constexpr int kCwLdsI32 = 4096;     // k_cw_decide: int32 words of shared-key tables (hard / soft counts, presence flags, candidate bitmaps)
@@ -547,9 +549,9 @@ struct CwLds {
     // nodes that received a clone in this window.  `alive` lists the ones that may still win (a node that is full, or whose own
     // clone blocks it through a required anti-affinity term, never comes back: the counts only grow)
     int32_t t_tuple[kCwMaxWindow][kCwTuple];
-    long long t_gidx[kCwFastWindow];
+    long long t_gidx[kCwMaxWindow];
     int32_t t_A[kCwMaxWindow];
-    uint32_t t_cnt[kCwMaxWindow], t_aff[kCwMaxWindow], t_took[kCwFastWindow], t_elig[kCwMaxWindow];
+    uint32_t t_cnt[kCwMaxWindow], t_aff[kCwMaxWindow], t_took[kCwMaxWindow], t_elig[kCwMaxWindow];
     int32_t alive[kCwMaxWindow];
     long long e_rp[kCwCand], e_ri[kCwCand]; // per candidate: raw PodTopologySpread / InterPodAffinity score
     uint32_t e_fl[kCwCand];                 // bit0 feasible, bit1 has all soft keys
@@ -736,7 +738,7 @@ __device__ __forceinline__ int32_t wave_min_i32_nonneg(int32_t v) { return (int3
 //    with a load that nothing waits for before the next cycle's argmax;
 //  * no per-cycle store: the placement log and the (node, clones) records of the epilogue are kept one per lane (lane = cycle
 //    mod 64) and written 64 at a time;
-//  * no 64-bit run counters: a window is <= 1024 cycles, so the loop counts in 32 bits against bounds computed once (limit,
+//  * no 64-bit run counters: a window is <= 2048 cycles, so the loop counts in 32 bits against bounds computed once (limit,
 //    log capacity), and the inter-pod totals are (was zero, is positive) flags plus 32-bit deltas added to the state at the end;
 //  * the argmax is a 32-bit DPP maximum of the keys' high words (the score); the low words (lowest index first) are only
 //    reduced when several lanes share the score.
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         fits = fits && S.ipa_entries == 0 && a.ipa.self_entries[0] == 0;
         if (NK > 1) fits = fits && a.ipa.self_entries[1] == 0;
     }
-    for (int k = 0; k < NK; k++) // (what a clone adds per key, summed in 32 bits over <= 1024 cycles)
+    for (int k = 0; k < NK; k++) // (what a clone adds per key, summed in 32 bits over <= 2048 cycles)
         fits = fits && a.ipa.aff_terms_on_key[k] < (1 << 16) && a.ipa.anti_self_on_key[k] < (1 << 16) && a.ipa.self_entries[k] < (1 << 16);
     if (!uni32(fits)) return;
     unsigned long long t_prev = 0ull;

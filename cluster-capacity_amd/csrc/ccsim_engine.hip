@@ -955,7 +955,8 @@ static int cw_make_plan(ccsim_engine *e) {
         }
     if (i32 > kCwLdsI32 || i64 > kCwLdsI64) return no("shared-key tables exceed the decide kernel's LDS budget");
     pl.n_comp = kCwTuple, pl.i32_words = i32, pl.i64_words = i64;
-    pl.window = 1024, pl.list_len = 64; // (profiles/r03/bench_coupled.txt, C5-shaped template at 100k nodes: 512/32 -> 0.98M placements/s, 1024/64 -> 1.03M)
+    pl.window = 2048, pl.list_len = 64; // (profiles/r03/bench_coupled.txt, C5-shaped template at 100k nodes: 512/32 -> 0.98M placements/s, 1024/64 -> 1.03M;
+                                        // round 4: 2048 -- with 64 classes the lists carry that many cycles, with 16 they still end a window at ~1000)
     if (const char *f = getenv("CCSIM_CW_WINDOW")) pl.window = atoi(f); // tuning / test knobs
     if (const char *f = getenv("CCSIM_CW_LIST")) pl.list_len = atoi(f);
     pl.window = pl.window < 1 ? 1 : (pl.window > kCwFastWindow ? kCwFastWindow : pl.window); // (the general decide kernel clamps to its own kCwMaxWindow)
