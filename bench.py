@@ -431,7 +431,10 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0 and not distributed and not args.no_cpu and not args.no_secondary and args.mode == "batched":
         eng.close()  # (the headline engine's columns are not needed any more: the memory is the next engines')
-        out["secondary"] = secondary_lines(local_rank)
+        try:
+            out["secondary"] = secondary_lines(local_rank)
+        except Exception as ex:  # (the headline line above is complete: a failure here is reported, not fatal)
+            out["secondary"] = {"error": f"{type(ex).__name__}: {ex}"[:400]}
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -38,6 +38,7 @@ def _check_line(d, full):
             assert k in c, k
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
         assert c["log_equals_engine_prefix"] is True  # (the oracle's log is the engine's: the baseline ran the same simulation)
+        assert "error" not in (d.get("secondary") or {}), d["secondary"]
         for name, sec in (d.get("secondary") or {}).items():  # config 5 / the coupled template, timed in the same process, checked first
             assert sec["unit"] == "placements/s" and sec["value"] > 0 and sec["placements"] > 0, name
             assert any(k.endswith("_equal_oracle") and v is True for k, v in sec.items()), name
