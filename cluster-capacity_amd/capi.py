@@ -457,6 +457,7 @@ class Engine:
             c = getattr(self, "_rep_cache", None)
             if c is not None and c[0] == key and c[2] is self._pinned_per_node():
                 c[1].stop_spec = -1
+                self._per_spec = c[4]  # (a run with a log in between built its own block and arrays: the cached block points at THESE)
                 return c[1], c[2], None, c[3]
         rep = CReport()
         per_node = self._pinned_per_node() if reuse_buffers else np.zeros(max(1, self.n), np.int32)
@@ -475,7 +476,8 @@ class Engine:
         rep.per_spec_cap = self._per_spec.shape[0]
         rep.stop_spec = -1
         if reuse_buffers and not want_log:
-            self._rep_cache = ((self.n, self.n_taintsets, self.n_pods, id(self._pin_per_node)), rep, per_node, ht)
+            # (the tuple keeps every array the block points at alive for as long as the block can be handed out again)
+            self._rep_cache = ((self.n, self.n_taintsets, self.n_pods, id(self._pin_per_node)), rep, per_node, ht, self._per_spec)
         return rep, per_node, log, ht
 
     def _result(self, rep, per_node, log, ht, reuse_buffers: bool = False) -> M.RunResult:

@@ -127,3 +127,43 @@ def test_integration_md_go_binding_names_what_the_header_declares():
                     assert member in structs[struct], (struct, member)
                     checked += 1
     assert checked > 40
+
+
+def test_cached_report_block_keeps_its_arrays_across_other_runs(tmp_path):
+    """capi.Engine hands a caller that reuses buffers ONE report block (ccsim_report) run after run.  A run WITH a log in between builds
+    its own block and arrays: the cached block must still point at live arrays afterwards (its per-spec array used to be dropped), and
+    the result must be read from the arrays the library wrote.  Driven against tests/abi_recorder.c in a process of its own."""
+    import subprocess
+    import sys
+    import textwrap
+    here = os.path.dirname(os.path.abspath(__file__))
+    rec = tmp_path / "libabi_recorder.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", str(rec), os.path.join(here, "abi_recorder.c")])
+    code = textwrap.dedent("""
+        import ctypes, gc, sys
+        sys.path.insert(0, %r)
+        import __graft_entry__ as ge
+        ge.load_package()
+        import numpy as np
+        from cluster_capacity_amd import capi, synth
+        nodes, pod, prof = synth.make_config("C4", n_nodes=2048)
+        e = capi.Engine(device=0)
+        e.load(nodes, pod, prof)
+        e._pin_per_node = (0, np.zeros(2048, np.int32))  # (stands in for the page-locked array: no GPU here)
+        rep1, pn1, _, ht1 = e._report(False, 0, True)
+        spec1 = e._per_spec
+        addr = ctypes.addressof(rep1.per_spec_count.contents)
+        assert addr == spec1.ctypes.data
+        e._report(True, 16, False)  # a run with a log: its own block, its own arrays
+        assert e._per_spec is not spec1
+        del spec1
+        gc.collect()
+        rep2, pn2, log2, ht2 = e._report(False, 0, True)
+        assert rep2 is rep1 and pn2 is pn1 and ht2 is ht1 and log2 is None
+        assert ctypes.addressof(rep2.per_spec_count.contents) == addr == e._per_spec.ctypes.data  # the block's array is alive and is the one read
+        assert ctypes.addressof(rep2.hist_taintset.contents) == ht2.ctypes.data
+        print("ok")
+    """) % os.path.dirname(here)
+    env = dict(os.environ, CCSIM_LIB=str(rec), CCSIM_RECORD=str(tmp_path / "rec.json"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
