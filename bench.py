@@ -143,9 +143,26 @@ def secondary_lines(device: int):
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: the same command as N ranks of one node, one per GPU, the way the contract's launcher
+    would start it (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...).
+    Rank 0 prints the line; this process only passes the ranks' output and exit status on."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free port of the loopback interface (the container's hostname may not resolve)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node = ranks of the job.  Under a launcher (WORLD_SIZE set: torch.distributed.run) it must equal the world size; "
+                         "without one, N > 1 makes bench.py launch itself as N ranks (torch.distributed.run, 127.0.0.1).  Default: the launcher's world size, else 1")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20 in the batched mode -- a step is ~0.3 ms -- and 3 in the sequential mode)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: 3 / 1)")
     ap.add_argument("--mode", default="batched", choices=["sequential", "batched"])
@@ -163,6 +180,16 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip config 5 and the coupled template (`secondary` in the line; they need the oracle: also off with --no-cpu)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch timing run (PMC collection runs)")
     args = ap.parse_args()
+    # --gpus is the number of ranks, one per GPU.  Either a launcher made them (the driver: python -m torch.distributed.run --nproc-per-node N
+    # bench.py --gpus N) and the flag must agree with it, or bench.py makes them itself: a plain `python bench.py --gpus 8` is an 8-rank job too.
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus is not None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    if args.gpus is None:
+        args.gpus = int(world_env or 1)
+    if int(world_env or 1) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world_env} rank(s) (WORLD_SIZE): refusing to print a line for the wrong job\n")
+        sys.exit(2)
     if args.steps is None:
         args.steps = 20 if args.mode == "batched" else 3
     if args.warmup is None:
@@ -178,7 +205,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
-    torch.cuda.set_device(local_rank)
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not os.environ.get("CCSIM_LIB"):
+        # no CPU path exists in the product.  (tests/test_bench_line.py runs the launcher / rank plumbing of this file on the CPU with
+        # tests/abi_recorder.c named by CCSIM_LIB -- a stand-in that schedules nothing -- and gloo in place of RCCL; never a measurement.)
+        sys.stderr.write("bench.py: no GPU visible (torch.cuda.is_available() is False): the engine is HIP only\n")
+        sys.exit(3)
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
     distributed = world > 1 or os.environ.get("CCSIM_FORCE_DIST") == "1"  # world == 1 over RCCL: a plumbing self-test
     if distributed:
         import torch.distributed as dist
@@ -192,7 +226,11 @@ def main():
         if world == 1:  # CCSIM_FORCE_DIST=1 without a launcher: a one-rank job on this GPU
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29513")):
                 os.environ.setdefault(k, v)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if have_gpu:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
     limit = args.limit if args.limit >= 0 else (0 if args.mode == "batched" else 2048)
     n_global = args.nodes * world if args.scaling == "weak" else args.nodes
     lo, hi = ccdist.shard_bounds(n_global, world, rank)
@@ -201,7 +239,8 @@ def main():
     def barrier():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if have_gpu:
+            torch.cuda.synchronize()
 
     if distributed:
         runner = ccdist.make_torch_runner(nodes, pod, prof, lo, n_global, local_rank)
@@ -236,7 +275,7 @@ def main():
     dt = time.perf_counter() - t0
     r.per_node_count = r.per_node_count.copy()  # (a view of the reused result array until here: later runs of the engine overwrite it)
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if have_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -347,6 +386,8 @@ def main():
         "value": placed / dt,
         "unit": "placements/s",
         "n_gpus": world,
+        # the size of the communicator libccsim.so really built (ncclCommCount), not the flag: null on one GPU without a communicator
+        "rccl_ranks_seen": (eng.dist_comm_size()[0] if distributed and isinstance(runner, ccdist.LibraryRunner) else (dist.get_world_size() if distributed else None)),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -435,6 +476,8 @@ def main():
             out["secondary"] = secondary_lines(local_rank)
         except Exception as ex:  # (the headline line above is complete: a failure here is reported, not fatal)
             out["secondary"] = {"error": f"{type(ex).__name__}: {ex}"[:400]}
+    if not have_gpu:  # (the CPU plumbing test: nothing was scheduled, nothing was measured -- say so in the line itself)
+        out["invalid"] = f"no GPU: ABI stand-in {os.environ.get('CCSIM_LIB')} in place of libccsim.so, gloo in place of RCCL; launcher / rank plumbing only"
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

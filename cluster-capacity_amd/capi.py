@@ -128,6 +128,7 @@ SYMBOLS = {
     "ccsim_dist_unique_id": (C.c_int, [_pu8]),
     "ccsim_dist_comm_init": (C.c_int, [C.c_void_p, _pu8, C.c_int32, C.c_int32]),
     "ccsim_dist_sync_tables": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ccsim_dist_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
     "ccsim_dist_mbox_info": (C.c_int, [C.c_void_p, _pu8]),
     "ccsim_dist_mbox_connect": (C.c_int, [C.c_void_p, _pu8, C.c_int32, C.c_int32]),
@@ -596,6 +597,12 @@ class Engine:
     def dist_comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
         buf = (C.c_uint8 * DIST_ID_BYTES).from_buffer_copy(unique_id)
         self._chk(self.lib.ccsim_dist_comm_init(self.h, buf, int(n_ranks), int(rank)), "ccsim_dist_comm_init")
+
+    def dist_comm_size(self):
+        """(ranks, this rank) as the communicator reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int32(), C.c_int32()
+        self._chk(self.lib.ccsim_dist_comm_size(self.h, C.byref(n), C.byref(r)), "ccsim_dist_comm_size")
+        return int(n.value), int(r.value)
 
     def dist_sync_tables(self):
         self._chk(self.lib.ccsim_dist_sync_tables(self.h), "ccsim_dist_sync_tables")

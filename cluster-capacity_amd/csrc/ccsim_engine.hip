@@ -2213,6 +2213,8 @@ struct RcclApi {
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*CommUserRank)(void *, int *) = nullptr;
     std::string err;
 };
 constexpr int kNcclInt8 = 0, kNcclInt32 = 2, kNcclInt64 = 4, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3; // rccl.h:448-463
@@ -2260,6 +2262,8 @@ RcclApi &rccl() {
     a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
     a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+    a.CommCount = (decltype(a.CommCount))sym("ncclCommCount");
+    a.CommUserRank = (decltype(a.CommUserRank))sym("ncclCommUserRank");
     if (!a.err.empty()) a.h = nullptr;
     if (dist_debug()) fprintf(stderr, "[ccsim dist] librccl bound in %.2f s%s%s\n", now_s() - t0, a.err.empty() ? "" : ": ", a.err.c_str());
     return a;
@@ -2369,6 +2373,17 @@ extern "C" int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id_bytes, in
         }
         if (dist_debug()) fprintf(stderr, "[ccsim dist] rank %d: mailboxes %s%s%s\n", rank, rc == 0 ? "connected" : "NOT connected", rc ? ": " : "", rc ? e->err.c_str() : "");
     }
+    return 0;
+}
+
+extern "C" int ccsim_dist_comm_size(ccsim_engine *e, int32_t *n_ranks_out, int32_t *rank_out) {
+    if (!e || !n_ranks_out) return -EINVAL;
+    if (!e->rccl_comm) return fail(e, -EINVAL, "ccsim_dist_comm_init first");
+    int n = 0, r = 0;
+    RCCLCHK(e, rccl().CommCount(e->rccl_comm, &n));
+    RCCLCHK(e, rccl().CommUserRank(e->rccl_comm, &r));
+    *n_ranks_out = n;
+    if (rank_out) *rank_out = r;
     return 0;
 }
 

@@ -341,6 +341,10 @@ int ccsim_dist_finish(ccsim_engine *e, ccsim_report *out);
 int ccsim_dist_unique_id(uint8_t *id_out /* [CCSIM_DIST_ID_BYTES] */);
 int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id /* [CCSIM_DIST_ID_BYTES] */, int32_t n_ranks, int32_t rank);
 int ccsim_dist_sync_tables(ccsim_engine *e);
+/* What the communicator itself says (ncclCommCount / ncclCommUserRank), not what the caller passed: the number of ranks that really
+ * joined and this engine's rank among them.  bench.py prints it as `rccl_ranks_seen` beside `n_gpus`.  -EINVAL before
+ * ccsim_dist_comm_init. */
+int ccsim_dist_comm_size(ccsim_engine *e, int32_t *n_ranks_out, int32_t *rank_out);
 /* ClusterCapacity.Run on the sharded snapshot: every rank calls it with the same max_limit / mode; out describes THIS
  * shard (per_node_count, hist) plus the global totals (placed, stop, rounds); with a log each rank fills its own
  * placements (-1 elsewhere), as ccsim_dist_finish does. */

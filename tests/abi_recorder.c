@@ -227,6 +227,13 @@ int ccsim_dist_comm_init(ccsim_engine *e, const uint8_t *id, int32_t n_ranks, in
     return id_ok ? 0 : -22;
 }
 
+int ccsim_dist_comm_size(ccsim_engine *e, int32_t *n_ranks_out, int32_t *rank_out) {
+    if (e->world < 1) return -22;
+    *n_ranks_out = e->world;
+    if (rank_out) *rank_out = e->rank;
+    return 0;
+}
+
 int ccsim_dist_sync_tables(ccsim_engine *e) {
     sep(e);
     fprintf(e->f, "\"dist_sync_tables\": %d", e->world);
@@ -277,7 +284,7 @@ int ccsim_dist_table(ccsim_engine *e, int32_t idx, void **ptr, int64_t *len, int
     return 0;
 }
 int ccsim_dist_tables_done(ccsim_engine *e) { (void)e; return 0; }
-int ccsim_reset_state(ccsim_engine *e) { (void)e; return -38; }
+int ccsim_reset_state(ccsim_engine *e) { (void)e; return 0; } /* (nothing to restore: bench.py's step frame calls it before every run) */
 void *ccsim_host_alloc(ccsim_engine *e, size_t bytes) { (void)e; return calloc(1, bytes); }
 void ccsim_host_free(ccsim_engine *e, void *p) { (void)e; free(p); }
 int ccsim_time_scan(ccsim_engine *e, int32_t a, int32_t b, int64_t *c, int64_t *d) { (void)e, (void)a, (void)b, (void)c, (void)d; return -38; }

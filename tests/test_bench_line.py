@@ -62,6 +62,68 @@ def test_a_committed_pmc_file_was_collected_with_the_sources_in_the_tree():
                                                 "re-run tools/gpu_round_profile.sh <round> skip-suite on the GPU and commit profiles/<round>/pmc_traffic.json")
 
 
+def _recorder(tmp_path):
+    rec = tmp_path / "libabi_recorder.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", str(rec), os.path.join(ROOT, "tests", "abi_recorder.c")])
+    return dict(os.environ, CCSIM_LIB=str(rec), CCSIM_RECORD=str(tmp_path / "rec.json"), CCSIM_RECORD_PER_DEVICE="1", OMP_NUM_THREADS="1")
+
+
+def _strip_launcher_env(env):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks(tmp_path, gpus):
+    """`python bench.py --gpus N` parsed the flag and ran on one GPU.  Now it launches itself as N ranks (torch.distributed.run
+    on 127.0.0.1) and the line says how many ranks took part -- both by the job (`n_gpus`) and by the communicator the library built
+    (`rccl_ranks_seen`, ccsim_dist_comm_size).  On the CPU: tests/abi_recorder.c stands in for libccsim.so and gloo for RCCL; every rank's
+    record must show ITS shard of the one snapshot and the communicator of N ranks."""
+    env = _strip_launcher_env(_recorder(tmp_path))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--nodes", "2000", "--no-cpu", "--no-roofline", "--seq-rounds", "0",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    _check_line(d, full=False)
+    assert d["n_gpus"] == gpus and d["rccl_ranks_seen"] == gpus and d["scaling"] == "strong" and "invalid" in d
+    per = -(-2000 // gpus)
+    for g in range(gpus):
+        r = json.load(open(f"{tmp_path}/rec.json.{g}"))
+        assert r["dist_comm_init"] == {"n_ranks": gpus, "rank": g, "id_ok": 1}
+        assert r["nodes"]["n_global"] == 2000 and r["nodes"]["global_offset"] == g * per and r["nodes"]["n_nodes"] == min(2000, g * per + per) - g * per
+
+
+def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launcher(tmp_path):
+    env = _recorder(tmp_path)
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nodes", "2000", "--no-cpu"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 2 and "--gpus 2" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    env = _strip_launcher_env(dict(os.environ))
+    env.pop("CCSIM_LIB", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nodes", "2000"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 3 and "no GPU" in out.stderr and not out.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_bench_gpus_1_is_a_plain_one_gpu_run():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-variants", "--seq-rounds", "0",
+                          "--nodes", "100000"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=_strip_launcher_env(dict(os.environ)))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    _check_line(d, full=False)
+    assert d["n_gpus"] == 1 and d["rccl_ranks_seen"] is None and "invalid" not in d
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_on_stdout():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-variants", "--seq-rounds", "0",
