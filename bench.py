@@ -113,14 +113,15 @@ def secondary_lines(device: int):
 
     # config 5: windows of <= 64 different pod specs per pass (csrc/ccsim_multi.h)
     nodes, pods, prof = synth.make_c5(100_000, 1024)
-    ref = ccref_py.run_multi(prof, nodes, pods, max_limit=300, threads=threads)
+    C5_GATE = 2200  # every one of the 1024 specs at least twice, >= 34 windows incl. the ones that end early (oracle: ~5 s on 16 threads)
+    ref = ccref_py.run_multi(prof, nodes, pods, max_limit=C5_GATE, threads=threads)
     e = capi.Engine(device=device)
     e.load(nodes, pods, prof)
-    head = e.run(max_limit=300, log_cap=300)
-    assert np.array_equal(head.log, ref.log), "config 5: engine and oracle placement logs differ"
+    head = e.run(max_limit=C5_GATE, log_cap=C5_GATE)
+    assert np.array_equal(head.log, ref.log) and np.array_equal(head.per_node_count, ref.per_node_count), "config 5: engine and oracle placement logs differ"
     r, dt = best_of(e, lambda: e.run(max_limit=200_000, want_log=False, log_cap=0))
     out["c5_100k_nodes_x_1024_specs"] = {"value": r.placed / dt, "unit": "placements/s", "placements": int(r.placed), "windows": int(r.scans),
-                                          "us_per_window": dt * 1e6 / max(1, r.scans), "first_300_placements_equal_oracle": True}
+                                          "us_per_window": dt * 1e6 / max(1, r.scans), f"first_{C5_GATE}_placements_equal_oracle": True, "windows_in_checked_prefix": int(head.scans)}
     e.close()
     # config 5's pod shape as one template (zone DoNotSchedule spread + hostname anti-affinity), the generator's own 64 zones at 1M nodes:
     # windows of placements per node pass (csrc/ccsim_coupled.h)
@@ -129,16 +130,18 @@ def secondary_lines(device: int):
     nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))  # kubernetes.io/hostname
     pod.ipa = M.InterPodAffinity(key_cols=[len(nodes.label_cols) - 1], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None])
     pod.spread = [synth.zone_spread(n, max_skew=1)]
-    ref = ccref_py.run(prof, nodes, pod, max_limit=200, threads=threads)
+    CW_GATE = 4300  # two full 2048-cycle windows and the start of a third (oracle: ~90 cycles/s at 1M nodes on 16 threads, ~50 s)
+    ref = ccref_py.run(prof, nodes, pod, max_limit=CW_GATE, threads=threads)
     e = capi.Engine(device=device)
     e.load(nodes, pod, prof)
-    head = e.run(max_limit=200, mode="sequential", log_cap=200)
-    assert np.array_equal(head.log, ref.log), "coupled template: engine and oracle placement logs differ"
+    head = e.run(max_limit=CW_GATE, mode="sequential", log_cap=CW_GATE)
+    assert np.array_equal(head.log, ref.log) and np.array_equal(head.per_node_count, ref.per_node_count), "coupled template: engine and oracle placement logs differ"
+    head_windows = e.coupled_info()["windows"]
     r, dt = best_of(e, lambda: e.run(max_limit=50_000, mode="sequential", want_log=False, log_cap=0))
     info = e.coupled_info()
     out["coupled_template_1M_nodes_64_zones"] = {"value": r.placed / dt, "unit": "placements/s", "placements": int(r.placed), "node_passes": int(r.scans),
                                                   "us_per_pass": dt * 1e6 / max(1, r.scans), "windowed": bool(info["windows"] and not info["fell_back"]),
-                                                  "first_200_placements_equal_oracle": True}
+                                                  f"first_{CW_GATE}_placements_equal_oracle": True, "windows_in_checked_prefix": int(head_windows)}
     e.close()
     return out
 

@@ -96,12 +96,18 @@ def test_c5_100k_nodes_1024_specs_prefix_vs_oracle(ccref):
     """BASELINE configs[4] proper: 100 000 nodes x 1024 genpod-shaped specs (zone DoNotSchedule spread + hostname anti-affinity),
     cycled round-robin (ccref_run_multi: one reference scheduling cycle per pod, pkg/framework/simulator.go:297-381)."""
     nodes, pods, prof = synth.make_c5(100_000, 1024)
-    cycles = 400
+    # round 5 (VERDICT r4 item 2): every spec at least twice against the ORACLE -- 2 200 cycles = two rounds of the 1024 specs and a bit,
+    # >= 34 windows of <= 64 pods, the early-ended windows among them (the engine's own window-of-1 run below is a second opinion, not
+    # the checker).  The oracle does ~450 cycles/s here on 16 threads.
+    cycles = 2200
     ref = ccref.run_multi(prof, nodes, pods, max_limit=cycles, threads=THREADS)
     assert ref.placed == cycles and ref.stop == M.STOP_LIMIT
+    assert int(np.asarray(ref.per_spec_count).min()) >= 2
     e = capi.Engine(device=0)
     e.load(nodes, pods, prof)
-    _same_multi(e.run(max_limit=cycles, log_cap=cycles), ref)
+    head = e.run(max_limit=cycles, log_cap=cycles)
+    _same_multi(head, ref)
+    assert 34 <= head.scans < cycles // 8, head.scans  # (windows really were windows: <= 64 pods each, and far more than one pod on average)
     # a longer stretch (beyond one round of the 1024 specs): windows of 64 against the in-order window of 1, same engine semantics
     e.reset_state()
     long_w = e.run(max_limit=5000, log_cap=5000)
@@ -139,12 +145,17 @@ def test_coupled_template_at_baseline_sizes(ccref, n, zones):
     windows (csrc/ccsim_coupled.h): the oracle's first 200 cycles, and 5000 placements windowed == one pass per placement (CCSIM_CW=0).
     1M nodes with the generator's own 64 zones (synth.zones_for) is the shape with more classes than lanes."""
     nodes, pod, prof = _coupled_template(n, zones)
-    cycles = 200
+    # round 5 (VERDICT r4 item 2): the ORACLE checks whole windows and their boundaries, not a tenth of one: 4 300 cycles are two full
+    # 2048-cycle windows of the 64-class kernel plus the start of a third (1M nodes / 64 zones: the oracle does ~90 cycles/s there on 16
+    # threads, ~50 s), four to five 1000-cycle windows of the lane-per-candidate kernel at 16 zones
+    cycles = 4300 if zones is None else 2200
     ref = ccref.run(prof, nodes, pod, max_limit=cycles, threads=THREADS)
     assert ref.placed == cycles and ref.stop == M.STOP_LIMIT
     e = _engine(nodes, pod, prof)
     got = e.run(max_limit=cycles, mode="sequential", log_cap=cycles)
     assert got.placed == cycles and np.array_equal(got.log, ref.log) and np.array_equal(got.per_node_count, ref.per_node_count)
+    head_info = e.coupled_info()
+    assert head_info["windows"] >= 3 and not head_info["fell_back"], head_info  # (>= 2 window boundaries inside the oracle-checked stretch)
     e.reset_state()
     win = e.run(max_limit=5000, mode="sequential", log_cap=5000)
     info = e.coupled_info()
@@ -164,7 +175,7 @@ def test_coupled_template_at_baseline_sizes(ccref, n, zones):
         del os.environ["CCSIM_CW"]
     assert win.placed == lit.placed == 5000
     assert np.array_equal(win.log, lit.log) and np.array_equal(win.per_node_count, lit.per_node_count)
-    assert np.array_equal(win.log[:cycles], ref.log)
+    assert np.array_equal(win.log[:min(cycles, 5000)], ref.log[:5000])
 
 
 @pytest.mark.parametrize("n,zones,limit", [(20_000, 64, 0), (9_000, 57, 2500), (30_000, 64, 4000)])

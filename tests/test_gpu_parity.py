@@ -107,6 +107,43 @@ def test_eager_and_graph_launch_agree(ccref):
     assert np.array_equal(a.log, b.log) and a.placed == b.placed == 500
 
 
+def _numpy_total_scores(nodes, pod, prof):
+    """TotalScore of every node of the initial snapshot and the feasibility vector, in numpy, for pods without topology-coupled plugins
+    and without required node affinity (C3 / C4): NodeUnschedulable + TaintToleration + NodeResourcesFit filters (fit.go:564-615);
+    TaintToleration (reverse-normalized, taint_toleration.go:169-199), NodeAffinity preferred terms (normalized, node_affinity.go:241-290),
+    LeastAllocated (least_allocated.go:30-61), BalancedAllocation (balanced_allocation.go:146-180), weighted (framework.go:1214-1238)."""
+    assert not pod.spread and pod.ipa is None and not pod.has_required_terms and not pod.has_node_selector and pod.image_score is None
+    n = nodes.n
+    feasible = (nodes.unschedulable == 0) | bool(pod.tolerates_unschedulable)
+    feasible &= np.asarray(pod.taint_filter_ok)[nodes.taintset_id] != 0
+    feasible &= nodes.pod_count + 1 <= nodes.alloc_pods
+    for c in range(3):
+        if pod.req[c]:
+            feasible &= pod.req[c] <= nodes.alloc[c] - nodes.req[c]
+    prefer = np.asarray(pod.taint_prefer_cnt)[nodes.taintset_id].astype(np.int64)
+    mx = int(prefer[feasible].max())
+    taint = np.full(n, 100, np.int64) if mx == 0 else 100 - 100 * prefer // mx
+    aff = np.zeros(n, np.int64)
+    for w, term in pod.preferred:
+        m = np.ones(n, bool)
+        for col, table in term:
+            m &= np.asarray(table)[nodes.label_cols[col]] != 0
+        aff += w * m
+    mx = int(aff[feasible].max())
+    aff = aff if mx == 0 else 100 * aff // mx
+    nz = [nodes.nz_mcpu + pod.nz_mcpu, nodes.nz_mem + pod.nz_mem]
+    least = np.zeros(n, np.int64)
+    for c, w in zip(prof.fit_res, prof.fit_res_w):
+        assert c < 2
+        least += np.where(nz[c] > nodes.alloc[c], 0, (nodes.alloc[c] - nz[c]) * 100 // np.maximum(nodes.alloc[c], 1)) * w
+    least //= sum(prof.fit_res_w)
+    assert tuple(prof.bal_res) == (0, 1)
+    f = [np.minimum(1.0, (nodes.req[c] + pod.req[c]).astype(np.float64) / nodes.alloc[c].astype(np.float64)) for c in (0, 1)]
+    bal = ((1.0 - np.abs(f[0] - f[1]) / 2.0) * 100.0).astype(np.int64)
+    total = prof.w_taint * taint + prof.w_nodeaffinity * aff + prof.w_fit * least + prof.w_balanced * bal
+    return total, feasible
+
+
 def test_full_size_properties_1m_nodes():
     """BASELINE full size: size-independent properties instead of the (too slow) oracle."""
     nodes, pod, prof = synth.make_config("C4", n_nodes=1_000_000)
@@ -121,7 +158,14 @@ def test_full_size_properties_1m_nodes():
     free_cpu = nodes.alloc[0] - nodes.req[0]
     assert (got.per_node_count.astype(np.int64) * 150 <= free_cpu).all()
     assert (got.per_node_count + nodes.pod_count <= nodes.alloc_pods).all()
-    # greedy property of round 1: the first winner maximizes the (static) total score, lowest index on ties
+    # greedy property of cycle 1 (schedule_one.go:894-941 with the canonical tie-break): the first winner holds the maximum TotalScore
+    # over the feasible nodes of the INITIAL snapshot, and no feasible node before it in canonical order scores as much -- recomputed here
+    # in numpy from the reference's formulas (least_allocated.go:30-61, balanced_allocation.go:146-180, normalize_score.go:28-56,
+    # framework.go:1214-1238), independent of the oracle and of the kernels
+    total, feasible = _numpy_total_scores(nodes, pod, prof)
+    first = int(got.log[0])
+    assert feasible[first] and total[first] == total[feasible].max()
+    assert not (feasible[:first] & (total[:first] == total[first])).any()
     st = e.read_state()
     assert np.array_equal(st["pod_count"], nodes.pod_count + got.per_node_count)
 
