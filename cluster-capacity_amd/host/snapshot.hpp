@@ -418,6 +418,20 @@ struct PodSide {
     // a victim of the node takes part in the PreFilter state of a topology-coupled filter of the template (removing it would
     // change that state: not modelled by the dry run); empty = no such node
     std::vector<uint8_t> victim_interacts;
+    // a topology-coupled FILTER is active: a DoNotSchedule spread constraint (podtopologyspread/filtering.go:311-356), required inter-pod
+    // (anti-)affinity of the template or anti-affinity terms of existing pods that match it (interpodaffinity/filtering.go:352-432).
+    // With one, WHICH nodes a cycle saw decides not only the order of the placements but how many fit: the total depends on
+    // percentageOfNodesToScore (host/engine.hpp simulate() keeps the reference's default for such templates).
+    bool hard_coupled() const {
+        for (const auto &c : spread)
+            if (c.hard) return true;
+        if (has_ipa) {
+            if (!ipa.aff_keys.empty() || !ipa.anti_keys.empty()) return true;
+            for (const auto &v : ipa.exist_anti)
+                if (!v.empty()) return true;
+        }
+        return false;
+    }
 };
 
 // The snapshot: node columns shared by every template + the first template (as base class: the single-template code reads

@@ -574,10 +574,9 @@ def test_native_host_marshals_the_c_abi_like_the_python_binding(native, recorder
         keep = []
         assert lib.ccsim_load_nodes(h, C.byref(capi.marshal_nodes(snap.nodes, keep))) == 0
         # --max-limit makes the run order-dependent: without an explicit percentageOfNodesToScore the host applies the reference's
-        # default (0 = adaptive sampling), see host/engine.hpp simulate() -- except for a template with topology-coupled plugins,
-        # which is searched completely (the windowed mode needs every node scored; the host says so on stderr)
-        coupled_tpl = bool(snap.pod.spread) or snap.pod.ipa is not None
-        assert lib.ccsim_set_profile(h, C.byref(capi.marshal_profile(dataclasses.replace(M.Profile.default(), percentage_of_nodes_to_score=100 if coupled_tpl else 0)))) == 0
+        # default (0 = adaptive sampling), see host/engine.hpp simulate() -- round 5: also for a template with topology-coupled
+        # plugins (the windowed every-node-scored form is the caller's choice: --percentage-of-nodes-to-score 100)
+        assert lib.ccsim_set_profile(h, C.byref(capi.marshal_profile(dataclasses.replace(M.Profile.default(), percentage_of_nodes_to_score=0)))) == 0
         assert lib.ccsim_set_pod(h, C.byref(capi.marshal_pod(snap.pod, keep))) == 0
         lib.ccsim_destroy(h)
     finally:
@@ -1249,6 +1248,38 @@ def test_native_sharded_host_side_views_threads_and_merge(native, recorder, tmp_
     got = json.loads(stdout)
     got["status"].pop("creationTimestamp"), want["status"].pop("creationTimestamp", None)
     assert got["status"] == json.loads(json.dumps(want["status"]))
+
+
+def test_default_percentage_of_nodes_to_score_follows_the_reference(native, recorder, tmp_path):
+    """the reference passes ComponentConfig.PercentageOfNodesToScore through unchanged (simulator.go:424): its default is the
+    adaptive sampling.  Left unset, both hosts score every node only where total and distribution cannot depend on the order: no
+    --max-limit and no topology-coupled FILTER.  A template with a DoNotSchedule constraint / required inter-pod (anti-)affinity keeps
+    0; one whose coupled plugins only score (ScheduleAnyway, preferred inter-pod terms) is searched completely; a named value wins."""
+    nodes, pods, rich, _ = CASES["rich"]()
+    soft = rich_pod()
+    soft["spec"]["affinity"].pop("podAntiAffinity")
+    soft["spec"]["topologySpreadConstraints"] = [c for c in soft["spec"]["topologySpreadConstraints"] if c["whenUnsatisfiable"] == "ScheduleAnyway"]
+    plain = yaml.safe_load(EXAMPLES_POD)
+    k = [0]
+
+    def pct(pod, extra, existing=True):
+        k[0] += 1
+        d = tmp_path / f"run{k[0]}"
+        d.mkdir()
+        podspec, snaps = _write(d, "json", nodes, pods if existing else [], pod)
+        env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(d / "rec.json"))
+        p = subprocess.run([native, "--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["-o", "json"] + extra, capture_output=True, text=True, env=env,
+                           timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 0, p.stderr
+        # the Python host applies the same rule (cli.hard_coupled is what it branches on)
+        snap = ingest.build_snapshot(*cli.load_objects(snaps), cli.parse_pod_spec(podspec), [])
+        return json.load(open(d / "rec.json"))["profile"]["pct"], cli.hard_coupled(snap.pod)
+
+    assert pct(plain, []) == (100, False) and pct(plain, ["--max-limit", "3"]) == (0, False)
+    assert pct(rich, []) == (0, True) and pct(rich, ["--max-limit", "3"]) == (0, True)
+    assert pct(rich, ["--percentage-of-nodes-to-score", "100"]) == (100, True)
+    assert pct(soft, []) == (0, True)  # (existing pods of the rich cluster carry required anti-affinity terms that match the template: a coupled filter)
+    assert pct(soft, [], existing=False) == (100, False) and pct(soft, ["--max-limit", "3"], existing=False) == (0, False)
 
 
 def test_native_sharded_percentage_of_nodes_to_score(native, recorder, tmp_path):
