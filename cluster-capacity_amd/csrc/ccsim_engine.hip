@@ -140,6 +140,11 @@ struct ccsim_engine {
     bool wide_stale = false;            // a persistent launch left the int64 request columns behind the mirrors (PersistCols::skip_wide): ensure_cols re-derives them
     bool reset_pending = false;         // ccsim_reset_state deferred the restore of the node columns: the next persistent launch loads the
                                         // pristine copies directly; everything else restores first (ensure_cols)
+    bool mbox_coarse = false;           // the mailbox could only be allocated as ordinary (coarse-grained) device memory: usable by virtual ranks and
+                                        // engines of the same device only
+    bool extras_dirty = false;          // a run of a pod with extra resource columns (ephemeral-storage / scalar: pod.nx != 0) or of several pod specs may have
+                                        // moved req[2 .. ncol) since the last full restore: a lazy reset consumed by the persistent launch (which loads
+                                        // only cpu / memory / pod counts) copies those columns back as well
     bool hist_in_kernel = false;        // the last persistent launch filled d_hist / d_hist_ts itself (no k_hist pass)
     bool persist_hint = false;          // persist_hint_mt / _ma: the normalization maxima the last persistent launch of this pod started with
     int32_t persist_hint_mt = 0, persist_hint_ma = 0;
@@ -1194,6 +1199,7 @@ static int launch_level_final(ccsim_engine *e, bool commit_launched = true, bool
 static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_cap) {
     if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
     if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
+    if (e->pod.nx != 0 || e->multi) e->extras_dirty = true;
     if (e->ipa.on && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "inter-pod affinity couples nodes through topology pairs: use CCSIM_MODE_SEQUENTIAL");
     if (e->soft.n > 0 && mode == CCSIM_MODE_BATCHED)
@@ -1509,6 +1515,7 @@ static int ensure_cols(ccsim_engine *e) {
     }
     e->reset_pending = false;
     e->wide_stale = false; // (everything is restored from the pristine copies)
+    e->extras_dirty = false;
     HIPCHK(e, hipSetDevice(e->device));
     for (size_t i = 0; i < e->backups.size(); i++)
         HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
@@ -1569,6 +1576,8 @@ static int mbox_alloc(ccsim_engine *e) {
     if (hipExtMallocWithFlags(&p, sizeof(PersistMailbox) * kPMaxRanks, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         HIPCHK(e, hipMalloc(&p, sizeof(PersistMailbox) * kPMaxRanks)); // (virtual ranks on one device work in ordinary memory too)
+        e->mbox_coarse = true; // ... but a peer DEVICE's stores into it and this device's polls of it are not coherent: such a box is
+                               // never advertised to another device (ccsim_dist_mbox_info / _connect)
     }
     HIPCHK(e, hipMemset(p, 0, sizeof(PersistMailbox) * kPMaxRanks));
     e->d_mbox = (PersistMailbox *)p;
@@ -1603,6 +1612,11 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
             a.c.p_req[0] = (const int64_t *)e->backups[0].second, a.c.p_req[1] = (const int64_t *)e->backups[1].second;
             a.c.p_nz[0] = (const int64_t *)e->backups[(size_t)e->ncol].second, a.c.p_nz[1] = (const int64_t *)e->backups[(size_t)e->ncol + 1].second;
             a.c.p_pod_count = (const int32_t *)e->backups[(size_t)e->ncol + 2].second;
+            if (e->extras_dirty) { // this pod does not read them, the next one may: the reset that was asked for covers every column
+                for (size_t i = 2; i < (size_t)e->ncol; i++)
+                    HIPCHK(e, hipMemcpyAsync(e->backups[i].first, e->backups[i].second, e->backup_bytes[i], hipMemcpyDeviceToDevice, e->stream));
+                e->extras_dirty = false;
+            }
         }
         a.c.cnt_assign = launch == 0 ? 1 : 0; // (begin_run zeroed the per-run counts)
         a.c.skip_wide = !mb && e->lazy_wide ? 1 : 0;
@@ -2087,6 +2101,7 @@ extern "C" int ccsim_dist_mbox_info(ccsim_engine *e, uint8_t *info_out) {
         memset(&mi.handle, 0, sizeof mi.handle);
         mi.pad = 1;
     }
+    if (e->mbox_coarse) mi.pad |= 2; // (coarse-grained memory: only engines of the same device may use this box)
     memset(info_out, 0, CCSIM_MBOX_INFO_BYTES);
     memcpy(info_out, &mi, sizeof mi);
     return 0;
@@ -2101,6 +2116,12 @@ extern "C" int ccsim_dist_mbox_connect(ccsim_engine *e, const uint8_t *all_infos
     for (int r = 0; r < n_ranks; r++) {
         MboxInfo mi;
         memcpy(&mi, all_infos + (size_t)r * CCSIM_MBOX_INFO_BYTES, sizeof mi);
+        if (r != rank && (mi.device != e->device || mi.pid != (int64_t)getpid()) && ((mi.pad & 2) || e->mbox_coarse)) {
+            // stores of one device into ordinary memory of another, polled there, need not become visible: every rank sees the same
+            // records and refuses alike -- the ranks then agree on the pass protocol up front instead of spinning into the poll bound
+            mbox_disconnect(e);
+            return fail(e, -ENOTSUP, "mailbox of rank %d is ordinary (coarse-grained) device memory: not usable between devices", (mi.pad & 2) ? r : rank);
+        }
         if (r == rank) {
             e->mbox_peers[r] = e->d_mbox;
         } else if (mi.pid == (int64_t)getpid()) { // an engine of this process: its pointer is valid here
@@ -2120,7 +2141,7 @@ extern "C" int ccsim_dist_mbox_connect(ccsim_engine *e, const uint8_t *all_infos
             e->mbox_peers[r] = (PersistMailbox *)(uintptr_t)mi.ptr;
         } else { // another process: through its IPC handle (HSA_ENABLE_IPC_MODE_LEGACY=0: dmabuf)
             void *p = nullptr;
-            if (mi.pad != 0 || hipIpcOpenMemHandle(&p, mi.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            if ((mi.pad & 1) != 0 || hipIpcOpenMemHandle(&p, mi.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
                 (void)hipGetLastError();
                 mbox_disconnect(e);
                 return fail(e, -ENOTSUP, "mailbox of rank %d could not be mapped through its IPC handle", r);
@@ -2129,6 +2150,11 @@ extern "C" int ccsim_dist_mbox_connect(ccsim_engine *e, const uint8_t *all_infos
             e->mbox_peers[r] = (PersistMailbox *)p;
         }
     }
+    // a new set of peers starts its launch sequence at 0 again, so nothing of an earlier connection may be left in the box (a granule
+    // of its launch 0 carries the same tag; a stale error word would abort the first launch at once): zeroed HERE, before any peer can
+    // launch -- the callers' agreement step (ccsim_dist_comm_init: an all-reduce behind this call; in-process callers: connect every
+    // engine, then launch) orders every rank's zeroing before every rank's first store
+    HIPCHK(e, hipMemset(e->d_mbox, 0, sizeof(PersistMailbox) * kPMaxRanks));
     e->mb_ranks = n_ranks, e->mb_rank = rank, e->mb_seq = 0, e->mb_go = -1;
     e->mbox_ready = true;
     return 0;
@@ -2142,17 +2168,21 @@ extern "C" int ccsim_dist_mbox_eligible(ccsim_engine *e) {
 
 extern "C" int ccsim_dist_mbox_launch(ccsim_engine *e) {
     if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
+    // one launch attempt = one sequence number on EVERY rank, whatever becomes of it here: a rank that fails one of the checks below
+    // must not fall a launch behind its peers (their tags would never match again and every later run would spin into the poll bound);
+    // and what ccsim_dist_begin uploaded is captured before anything can fail, for the fallback of ccsim_dist_mbox_finish
+    const uint32_t seq = e->mb_seq++;
+    e->mb_state0 = *e->h_state;
     if (!e->mbox_ready || e->n_ranks != e->mb_ranks || e->rank != e->mb_rank) return fail(e, -EINVAL, "ccsim_dist_mbox_connect first (same ranks as ccsim_dist_begin)");
     if (e->mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "the mailbox form is the batched mode's");
     HIPCHK(e, hipSetDevice(e->device));
     const int k = persist_k_impl(e, true, true);
     if (!k) return fail(e, -ENOSYS, "this shard does not qualify for the persistent form");
     e->mb_k = k;
-    e->mb_state0 = *e->h_state; // (what ccsim_dist_begin uploaded)
     PersistArgs a = persist_args(e);
     a.n_ranks = e->mb_ranks, a.rank = e->mb_rank, a.vranks = 0, a.bpr = 0;
     for (int r = 0; r < e->mb_ranks; r++) a.mbox[r] = e->mbox_peers[r];
-    a.tag_base = (e->mb_seq++ & 0x7ffu) << 20;
+    a.tag_base = (seq & 0x7ffu) << 20;
     a.hint_valid = 0;       // (the hint is per engine: ranks could disagree about it -- and every rank must take the same number of syncs)
     a.c.from_pristine = 0;  // (ccsim_dist_begin restored the columns)
     a.c.cnt_assign = 1;
@@ -2766,6 +2796,7 @@ static void launch_multi_window(ccsim_engine *e, const MultiArgs &a) {
 // begin a multi-spec run (or one cycle: single_pod >= 0) on the current columns
 static int begin_multi(ccsim_engine *e, int64_t max_limit, int64_t log_cap, int32_t single_pod) {
     HIPCHK(e, hipSetDevice(e->device));
+    e->extras_dirty = true;
     if (log_cap != e->log_cap) {
         if (e->d_log) HIPCHK(e, hipFree(e->d_log));
         e->d_log = nullptr, e->log_cap = 0;

@@ -358,7 +358,10 @@ int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_repor
  * call, no kernel boundary per exchange.  A rank that cannot take part (snapshot not eligible, a peer's box not mappable, a
  * bounded spin that expired) makes ALL ranks fall back to the pass protocol above: nothing is published before every rank agrees.
  *   ccsim_dist_mbox_info     this rank's addressing record (process, device, pointer, IPC handle): allocate the box, CCSIM_MBOX_INFO_BYTES out
- *   ccsim_dist_mbox_connect  all ranks' records, in rank order: map every peer's box (same process: directly / peer access; else IPC)
+ *   ccsim_dist_mbox_connect  all ranks' records, in rank order: map every peer's box (same process: directly / peer access; else IPC);
+ *                            zeroes this rank's box and restarts its launch sequence, so NO rank may launch before EVERY rank has
+ *                            connected (any agreement step does: ccsim_dist_comm_init all-reduces "connected" behind it).  A box that
+ *                            could only be allocated as ordinary (coarse-grained) memory is refused between devices (-ENOTSUP on every rank)
  *   ccsim_dist_mbox_eligible 1 if this rank's shard and pod qualify for the persistent form (collect the minimum over the ranks)
  *   -- then, after ccsim_dist_begin(mode = CCSIM_MODE_BATCHED) on every rank and only if EVERY rank is eligible:
  *   ccsim_dist_mbox_launch   enqueue the persistent launch (asynchronous)

@@ -193,3 +193,38 @@ def test_mailbox_form_1m_nodes_and_continued_runs(ccref, monkeypatch):
     c = e.run(max_limit=0, mode="batched", want_log=False, log_cap=0)
     assert c.placed == int(cap.sum()) and np.array_equal(c.per_node_count.astype(np.int64), cap) and np.array_equal(c.hist, b.hist)
     e.close()
+
+
+def test_lazy_reset_restores_the_extra_resource_columns_too(ccref):
+    """ccsim_reset_state is lazy when the next run is a persistent launch, and that launch loads cpu / memory / pod counts
+    from the pristine copies itself -- the columns of the OTHER resources (ephemeral-storage, scalars), which a pod without such requests
+    never reads, were left as an earlier pod's run had moved them.  Sequence: pod A (asks for ephemeral storage) runs; pod B (does not)
+    is set, the state is reset, B runs a few placements on the persistent form; pod A is set again WITHOUT a reset: it must find B's
+    placements and its own column pristine -- the oracle's run of A on the snapshot with B's placements applied."""
+    import copy
+
+    n = 3000
+    nodes, pod_b, prof = synth.make_config("C3", n_nodes=n, seed=99)
+    pod_a = copy.copy(pod_b)
+    pod_a.req = pod_b.req.copy()
+    pod_a.req[2] = 30 << 30  # 30 GiB of the nodes' 100 GiB ephemeral storage: three clones per node, whatever cpu / memory allow
+    e = capi.Engine(device=0)
+    e.load(nodes, pod_a, prof)
+    first = e.run(max_limit=0, mode="batched", want_log=False)
+    assert first.hist[M.R_RES0 + 2] > 0  # (ephemeral storage really was what ran out)
+    e.set_pod(pod_b)
+    e.reset_state()
+    rb = e.run(max_limit=1000, mode="batched", want_log=False)  # the persistent launch consumes the lazy reset
+    assert rb.placed == 1000 and rb.pass_launches >= 1
+    e.set_pod(pod_a)
+    ra = e.run(max_limit=0, mode="batched", want_log=False)
+    e.close()
+    after_b = nodes.copy()
+    cnt = rb.per_node_count.astype(np.int64)
+    for c in range(3):
+        after_b.req[c] = after_b.req[c] + cnt * int(pod_b.req[c])
+    after_b.nz_mcpu, after_b.nz_mem = after_b.nz_mcpu + cnt * pod_b.nz_mcpu, after_b.nz_mem + cnt * pod_b.nz_mem
+    after_b.pod_count = (after_b.pod_count + rb.per_node_count).astype(np.int32)
+    ref = ccref.run(prof, after_b, pod_a, max_limit=0, threads=8)
+    assert ref.placed > 0
+    _same(ra, ref, check_log=False)
