@@ -548,7 +548,7 @@ class Engine:
         out = (C.c_int64 * 16)()
         self._chk(self.lib.ccsim_debug_coupled(self.h, out), "ccsim_debug_coupled")
         d = {"plan": bool(out[0]), "windows": int(out[1]), "fell_back": bool(out[2]), "window": int(out[3]), "list_len": int(out[4]),
-             "fast_windows": int(out[5]), "full_windows": int(out[6])}
+             "fast_windows": int(out[5]), "full_windows": int(out[6]), "swept": int(out[7])}
         if out[15]:  # CCSIM_CW_PROF=1: microseconds per cycle of the deciding wave, by phase
             names = ["stage", "setup", "verdicts", "raw_scores", "argmax", "commit", "write_back"]
             d["prof_us_per_cycle"] = {k: round(out[8 + i] / 100.0 / out[15], 3) for i, k in enumerate(names)}

@@ -62,6 +62,7 @@ struct CwPlan {
     int32_t k_comp[kMaxIpaKeys], k_unique[kMaxIpaKeys], k_off[kMaxIpaKeys], k_len[kMaxIpaKeys];   // InterPodAffinity key k
     int32_t i32_words, i64_words;
     int32_t window, list_len;
+    int32_t sweep; // k_cw_decide_fast resolves whole ROUNDS of placements at once where it can (CCSIM_CW_SWEEP=0: one placement per step, the A/B and test knob)
     const int32_t *h_present[kMaxTsc]; // domain-presence flags of hard constraint c (k_pts_init)
 };
 
@@ -747,6 +748,11 @@ struct CwFastLds {
     unsigned long long rec[kCwFastWindow + 64]; // nodes that received clones in this window: index | clones << kIdxBits
     int32_t s_nt;
     unsigned long long pf[8];
+    // sweeps (a round of placements at once, see `sweep` in the kernel): per value id of the shared key -- candidates of the domain /
+    // "the domain took a clone in this sweep" (both all-zero outside a sweep); the participants' facts by position; the log's current group
+    int32_t dn[72], dflag[72];
+    uint32_t byrank[64];
+    int32_t lg[64];
 };
 static_assert(sizeof(CwFastLds) <= sizeof(CwLds), "both decide kernels are launched with sizeof(CwLds) of LDS");
 constexpr uint32_t kCwMetaStat = kStatAffMask | (kStatCntMask << kStatCntShift);
@@ -809,6 +815,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     }
     if (tid == 0) L.s_nt = -1; // -1: the window was not taken
     if (tid < 8) L.pf[tid] = 0;
+    if (tid < 72) L.dn[tid] = 0, L.dflag[tid] = 0;
     __syncthreads();
 
     if (tid < 64) {
@@ -1131,6 +1138,115 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     go = !stop;
                 }
             };
+            // ---- SWEEP (round 5): a whole ROUND of placements at once.  One hard constraint over a shared key (zones) and at most a
+            // unique-per-node inter-pod key (hostname): when every candidate lane of the cycle at hand is a class whose domain sits AT THE
+            // CAP of the skew test (count + self - minimum == maxSkew: with maxSkew 1 every feasible domain does), whose head counts for
+            // the constraint, and no two of them share a domain, then the next cycles are known without running them: a clone makes its
+            // domain infeasible until the minimum moves (filtering.go:311-356), the minimum moves only when the last domain at it is
+            // taken, nothing else a verdict reads changes (a unique key's entries are the winner's own), so cycle p is won by the p-th
+            // best head of this cycle's candidates -- the candidates sorted by key -- for as long as the cycle loop's own stop tests
+            // pass.  Those are tests on the candidates that are LEFT, so they become positions in the sorted order: the cycle budget;
+            // the first head that would stay a candidate after its clone (the loop's business); the last holder of an assumed
+            // normalization maximum (DefaultNormalizeScore over the cycle's feasible nodes: cycle p runs iff a holder sits at a position
+            // >= p); the candidate that takes the last domain at the minimum (the verdicts after it read another minimum).  Ranks by
+            // all-pairs comparison (m readlane steps), facts by position through LDS, then every lane applies its own share: ~1-2 us
+            // per round of up to 64 placements instead of ~0.4-0.7 us per placement.  Exactly the cycles the loop would run, in its order.
+            constexpr bool SWEEP = NH == 1 && !HU0 && (NK == 0 || (NK == 1 && KU0));
+            const bool sweep_on = SWEEP && uni32(a.plan.sweep) != 0 && h_self0 != 0;
+            int n_sweeps = 0, n_swept = 0;
+            auto sweep = [&]() -> bool {
+                const uint64_t okm = __ballot(ok);
+                const int m = __popcll(okm);
+                if (m < 4) return false;
+                if (!FULL && (okm >> C) != 0ull) return false; // a node that already took a clone is a candidate: the loop's business
+                // the first clone of a run moves the inter-pod totals from "no matching pod anywhere" to "some": the loop's business too
+                if (NK > 0 && ((aff_zero && k_daff0 != 0) || (!exist_pos && k_danti0 != 0))) return false;
+                const uint32_t el = (hmeta >> kStatImgShift) & kStatImgMask;
+                const bool counts = (el & 1u) && ((el >> 1) & 1u) && hv0 != 0;
+                const int32_t min_eff = h_usemin0 ? (min0 < kCountCap ? min0 : kCountCap) : 0;
+                if (__ballot(ok && !(counts && hc0 - min_eff == h_rhs0)) != 0ull) return false;
+                // one candidate per domain?
+                if (ok) atomicAdd(&L.dn[hv0], 1);
+                cw_lds_sync();
+                const int32_t in_dom = ok ? L.dn[hv0] : 1;
+                cw_lds_sync();
+                if (ok) L.dn[hv0] = 0;
+                if (__ballot(in_dom != 1) != 0ull) return false;
+                // would the head stay a candidate after its clone?  (commit's `dead`, per lane)
+                bool stays = hA1 >= 0;
+                if (NK > 0 && ipa_filter && kv0 != 0) {
+                    if (k_anti0 && kn0 + k_danti0 > 0) stays = false;
+                    if ((exist_pos || k_danti0 != 0) && ke0 + k_danti0 > 0) stays = false;
+                }
+                // position of every candidate in the order the cycles would take them (keys are unique: they carry the node index)
+                uint32_t rank = 0;
+                for (uint64_t rem = okm; rem != 0ull; rem &= rem - 1ull) {
+                    const uint64_t kj = rl64(key, __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)rem) - 1));
+                    rank += kj > key ? 1u : 0u;
+                }
+                const uint32_t w_cnt = (hmeta >> kStatCntShift) & kStatCntMask, w_aff = hmeta & kStatAffMask;
+                if (ok) L.byrank[rank] = (hc0 == min0 ? 1u : 0u) | (stays ? 2u : 0u) | (cmt == mt_a ? 4u : 0u) | (cma == ma_a ? 8u : 0u);
+                cw_lds_sync();
+                const uint32_t pfl = lane < m ? L.byrank[lane] : 0u; // lane = position from here on
+                const uint64_t M_min = __ballot((pfl & 1u) != 0u), M_stay = __ballot((pfl & 2u) != 0u), M_t = __ballot((pfl & 4u) != 0u), M_a = __ballot((pfl & 8u) != 0u);
+                int T = m < Wl - cycles ? m : Wl - cycles;
+                if (M_stay != 0ull) { const int q = __ffsll((unsigned long long)M_stay) - 1; T = T < q ? T : q; }
+                if (track) {
+                    const int jt = M_t ? 64 - __clzll(M_t) : 0, ja = M_a ? 64 - __clzll(M_a) : 0;
+                    T = T < jt ? T : jt, T = T < ja ? T : ja;
+                }
+                if (nmin0 > 0u && (uint32_t)__popcll(M_min) >= nmin0) { // the candidate that takes the last domain at the minimum ends the round
+                    uint64_t mm = M_min;
+                    for (uint32_t q = 1; q < nmin0; q++) mm &= mm - 1ull;
+                    const int cut = __ffsll((unsigned long long)mm); // (1-based: positions 0 .. cut - 1 run)
+                    T = T < cut ? T : cut;
+                }
+                T = uni32(T);
+                if (T < 2) return false;
+                // ---- the T cycles, every lane its own share
+                const bool take = ok && rank < (uint32_t)T;
+                lf = (ok && rank >= (uint32_t)(T - 1)) ? nfm : 0u; // the feasible nodes of the last of them
+                const int64_t gi = key_index(key);
+                const int cycles0 = cycles, nrec0 = nrec;
+                // (node, clones) records and the log: positions cycles0 + rank; the lanes keep the current group of 64 as the loop does
+                if (lane < (nrec0 & 63)) L.rec[(nrec0 & ~63) + lane] = myrec;
+                if (lane < (cycles0 & 63)) {
+                    if ((cycles0 & ~63) + lane < log_room) a.log[placed0 + ((cycles0 & ~63) + lane)] = mylog;
+                    L.lg[lane] = mylog;
+                }
+                cw_lds_sync();
+                if (take) {
+                    L.dflag[hv0] = 1;
+                    L.rec[nrec0 + (int)rank] = (1ull << kIdxBits) | (uint64_t)gi;
+                    const int pos = cycles0 + (int)rank;
+                    if (pos < log_room) a.log[placed0 + pos] = (int32_t)gi;
+                    if (pos >= ((cycles0 + T) & ~63)) L.lg[pos & 63] = (int32_t)gi;
+                }
+                cw_lds_sync();
+                hc0 += L.dflag[hv0 <= 64 ? hv0 : 0];
+                dc0 += dlane <= 64 ? L.dflag[dlane] : 0;
+                cycles += T, nrec += T;
+                if (lane < (nrec & 63)) myrec = L.rec[(nrec & ~63) + lane];
+                if (lane < (cycles & 63)) mylog = L.lg[lane];
+                cw_lds_sync();
+                if (take) L.dflag[hv0] = 0;
+                const int dmin = __popcll(M_min & (T >= 64 ? ~0ull : ((1ull << T) - 1ull)));
+                nmin0 -= (uint32_t)dmin;
+                remin0 = remin0 || (dmin > 0 && nmin0 == 0u);
+                if (NK > 0) {
+                    const int n_on = __popcll(__ballot(take && kv0 != 0));
+                    d_aff += k_daff0 * n_on, d_exist += k_danti0 * n_on, d_ent += k_dent0 * n_on;
+                    aff_zero = aff_zero && !(n_on != 0 && k_daff0 != 0), exist_pos = exist_pos || (n_on != 0 && k_danti0 != 0);
+                }
+                if (take) { // the class loses its head (commit's class form)
+                    nfm -= 1, head += 1, nleft -= 1;
+                    if (track) cht -= w_cnt == cmt ? 1u : 0u, cha -= w_aff == cma ? 1u : 0u;
+                    const uint4 r = L.ent[lane * LS + head];
+                    key = ((uint64_t)r.y << 32) | r.x, hA1 = (int32_t)r.z, hmeta = r.w;
+                }
+                n_sweeps += 1, n_swept += T;
+                return true;
+            };
             // The hot loop runs while class heads win (every cycle of a pod whose clones exclude each other); a node winning AGAIN
             // takes a trip to its columns (cw_local_after, with loops over the extra resources): kept out of the hot loop's body,
             // whose register allocation it spoiled (SGPR spills reloaded in every cycle).
@@ -1139,6 +1255,10 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 asm volatile("" ::: "memory"); // (keeps this header apart from the hot loop's: merged, they are one loop with the slow path inside)
 #pragma unroll 1
                 while (uni32(go)) {
+                    if (SWEEP && sweep_on && uni32(sweep())) {
+                        next_cycle();
+                        continue;
+                    }
                     argmax();
                     if (wl >= C) {
                         again = true;
@@ -1171,6 +1291,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 if (NH > 0) S.pts_min_a[0] = min0; // (the terminal histogram reads them: k_hist)
                 if (NH > 1) S.pts_min_a[1] = min1;
                 S.cw_windows += 1;
+                S.cw_sweeps += n_sweeps, S.cw_swept += n_swept;
                 if (FULL) S.cw_full_windows += 1; else S.cw_fast_windows += 1;
                 S.done = unsched ? DONE_UNSCHEDULABLE : (limit > 0 && placed >= limit ? DONE_LIMIT : 0);
                 L.s_nt = nrec + (ncand - C);

@@ -964,6 +964,8 @@ static int cw_make_plan(ccsim_engine *e) {
                                         // round 4: 2048 -- with 64 classes the lists carry that many cycles, with 16 they still end a window at ~1000)
     if (const char *f = getenv("CCSIM_CW_WINDOW")) pl.window = atoi(f); // tuning / test knobs
     if (const char *f = getenv("CCSIM_CW_LIST")) pl.list_len = atoi(f);
+    pl.sweep = 1;
+    if (const char *f = getenv("CCSIM_CW_SWEEP")) pl.sweep = atoi(f) != 0; // A/B and test knob: 0 = one placement per step of the deciding wave
     pl.window = pl.window < 1 ? 1 : (pl.window > kCwFastWindow ? kCwFastWindow : pl.window); // (the general decide kernel clamps to its own kCwMaxWindow)
     pl.list_len = pl.list_len < 1 ? 1 : (pl.list_len > kCwMaxList ? kCwMaxList : pl.list_len);
     const int64_t blocks = (e->n_pad + kCwTile - 1) / kCwTile;
@@ -2930,7 +2932,7 @@ extern "C" int ccsim_debug_coupled(ccsim_engine *e, int64_t *out8) {
         HIPCHK(e, hipMemcpy(out8 + 8, e->cw_work.prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));
     }
     out8[0] = e->have_pod && e->cw_ok ? 1 : 0;
-    if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback, out8[5] = e->h_state->cw_fast_windows, out8[6] = e->h_state->cw_full_windows;
+    if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback, out8[5] = e->h_state->cw_fast_windows, out8[6] = e->h_state->cw_full_windows, out8[7] = e->h_state->cw_swept;
     out8[3] = e->cw_ok ? e->cw_plan.window : 0, out8[4] = e->cw_ok ? e->cw_plan.list_len : 0;
     return 0;
 }

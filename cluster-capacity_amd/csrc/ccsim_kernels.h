@@ -230,6 +230,7 @@ struct DevState {
     int32_t cw_fallback;     // 1 = the windowed mode gave up on this run: the one-pass-per-placement loop continues from the current state
     int32_t cw_windows;      // windows resolved so far
     int32_t cw_fast_windows, cw_full_windows; // ... of them by the lane-per-candidate kernel / by its 64-class form
+    int32_t cw_sweeps, cw_swept;              // rounds that kernel resolved at once, and the placements in them (ccsim_coupled.h `sweep`)
     // persistent batched launch (ccsim_persist.h): the normalization maxima the launch started with (the next launch's hint)
     int32_t p_mt0, p_ma0;
 };

@@ -426,7 +426,7 @@ int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out8);
  * (csrc/ccsim_coupled.h: windows of placements per node pass): out8[0] = 1 if the pod spec has a windowed plan, [1] = windows
  * of the last run, [2] = 1 if that run fell back to one pass per placement (more classes / plugin inputs than the mode
  * represents), [3] = window length W, [4] = class-list length L, [5] = windows the lane-per-candidate kernel took, [6] = windows its
- * 64-class form took (the others ran the general decide kernel); out[8..15] (with CCSIM_CW_PROF=1): 10 ns ticks the deciding
+ * 64-class form took (the others ran the general decide kernel), [7] = placements that kernel resolved in whole rounds (sweeps: CCSIM_CW_SWEEP=0 turns them off); out[8..15] (with CCSIM_CW_PROF=1): 10 ns ticks the deciding
  * wave spent in [8] staging, [9] minima set-up, [10] candidates' verdicts, [11] raw scores, [12] totals + argmax, [13] commit, [14] write-back;
  * [15] = cycles.  `out` holds 16 values.  Knobs (read by ccsim_set_pod): CCSIM_CW=0 disables the mode, CCSIM_CW_WINDOW, CCSIM_CW_LIST. */
 int ccsim_debug_coupled(ccsim_engine *e, int64_t *out16);

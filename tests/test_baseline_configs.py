@@ -156,6 +156,7 @@ def test_coupled_template_at_baseline_sizes(ccref, n, zones):
     assert got.placed == cycles and np.array_equal(got.log, ref.log) and np.array_equal(got.per_node_count, ref.per_node_count)
     head_info = e.coupled_info()
     assert head_info["windows"] >= 3 and not head_info["fell_back"], head_info  # (>= 2 window boundaries inside the oracle-checked stretch)
+    assert head_info["swept"] >= cycles - 64 * head_info["windows"], head_info  # (round 5: whole rounds at once -- what the oracle checked here IS the sweep path)
     e.reset_state()
     win = e.run(max_limit=5000, mode="sequential", log_cap=5000)
     info = e.coupled_info()

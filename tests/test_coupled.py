@@ -176,3 +176,64 @@ def test_disabled_by_knob_and_unaffected_modes(ccref, monkeypatch):
     for i in range(50, 60):
         assert e.schedule_one()[0] == ref.log[i]
     e.close()
+
+
+# ---- round 5: SWEEPS -- whole rounds of placements at once in the lane-per-candidate kernel (csrc/ccsim_coupled.h `sweep`) ------------
+def sweep_case(rng, n):
+    """The shape sweeps apply to -- ONE hard spread constraint over a shared key, at most a unique-per-node inter-pod key -- with everything
+    that cuts a round short or keeps a cycle out of one: 4 ... 40 domains with unequal numbers of existing matching pods (catch-up phases in
+    which some feasible domain is below the cap), maxSkew 1 ... 3, minDomains above the domains present, nodes the inclusion policy does
+    not count, nodes without the key, PreferNoSchedule taints / preferred affinity held by few nodes (normalization maxima that lose
+    their last feasible holder inside a round), nodes that take several clones (winners that stay candidates), hostname anti-affinity
+    (winners that leave), existing pods that block their node."""
+    nodes, pod, prof = H.random_case(rng, n)
+    ndom = int(rng.integers(4, 41))
+    zone = rng.integers(1, ndom + 1, n).astype(np.int32)
+    if rng.integers(0, 2):
+        zone[rng.random(n) < 0.03] = 0
+    host = np.arange(1, n + 1, dtype=np.int32)
+    nodes.label_cols = list(nodes.label_cols) + [zone, host]
+    zc, hc = len(nodes.label_cols) - 2, len(nodes.label_cols) - 1
+    pod.spread = [M.SpreadConstraint(col=zc, max_skew=int(rng.choice([1, 1, 1, 2, 3])), min_domains=int(rng.choice([1, 1, 1, ndom + 2])), hard=True,
+                                     self_match=bool(rng.integers(0, 8) != 0), n_domains=ndom,
+                                     node_match_count=rng.integers(0, 3, n).astype(np.int32) if rng.integers(0, 2) else None,
+                                     node_included=(rng.random(n) < 0.9).astype(np.uint8) if rng.integers(0, 3) == 0 else None)]
+    kind = int(rng.integers(0, 3))
+    if kind >= 1:  # hostname anti-affinity against the own clones: every winner leaves (BASELINE config 5's pod shape)
+        blocked = (rng.random(n) < 0.05).astype(np.int32) if kind == 2 else None  # existing pods the term matches
+        pod.ipa = M.InterPodAffinity(key_cols=[hc], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[blocked])
+    else:  # winners stay candidates while they have room: give some of them room for several clones
+        roomy = rng.random(n) < 0.3
+        nodes.alloc_pods = np.where(roomy, nodes.alloc_pods * 4, nodes.alloc_pods).astype(np.int32)
+        nodes.alloc = [np.where(roomy, a * 4, a) for a in nodes.alloc]
+    return nodes, pod, prof
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sweep", ["1", "0"])
+@pytest.mark.parametrize("seed", range(40))
+def test_sweeps_random(ccref, monkeypatch, seed, sweep):
+    """Rounds resolved at once == one placement per step == the oracle, placement by placement (log, stop, histogram)."""
+    monkeypatch.setenv("CCSIM_CW_SWEEP", sweep)
+    rng = np.random.default_rng(8800 + seed)
+    nodes, pod, prof = sweep_case(rng, int(rng.integers(40, 4000)))
+    limit = int(rng.choice([0, 0, 37, 333, 1000]))
+    window, list_len = [(2048, 64), (64, 16), (300, 5)][seed % 3]
+    got, info = _run(ccref, nodes, pod, prof, limit, monkeypatch, window, list_len)
+    assert (info["swept"] == 0) if sweep == "0" else True
+    SWEPT[sweep] = SWEPT.get(sweep, 0) + info["swept"]
+    PLACED[sweep] = PLACED.get(sweep, 0) + got.placed
+
+
+SWEPT, PLACED = {}, {}
+
+
+@pytest.mark.gpu
+def test_sweeps_did_most_of_the_work_where_they_apply(ccref, monkeypatch):
+    """Guard against a sweep path that silently never runs: on BASELINE config 5's pod shape (maxSkew 1: every feasible domain is at the
+    cap) all but the first placement of a run go through sweeps; and the random cases above (run in the same session) swept too."""
+    nodes, pod, prof = c5_single_template(20_000)
+    got, info = _run(ccref, nodes, pod, prof, 3000, monkeypatch, 2048, 64)
+    assert info["swept"] >= got.placed - 64, info
+    if PLACED.get("1"):  # (only when test_sweeps_random ran in this process)
+        assert SWEPT["1"] > 0.2 * PLACED["1"], (SWEPT, PLACED)
