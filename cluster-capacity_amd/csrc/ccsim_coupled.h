@@ -45,7 +45,7 @@ constexpr int kCwSlots = 1024;      // global open-addressing class table (power
 constexpr int kCwBlockSlots = 256;  // per-block LDS class table of the scan (power of two)
 constexpr int kCwMaxList = 64;      // L
 constexpr int kCwMaxWindow = 256;   // W of the general decide kernel (a touched node keeps its whole tuple in LDS)
-constexpr int kCwFastWindow = 2048; // W of the lane-per-candidate kernel (a touched node is (index, clones)): 64 classes x the 32 list members
+constexpr int kCwFastWindow = 4096; // W of the lane-per-candidate kernel (a touched node is (index, clones)): 64 classes x the 64 list members (round 5; 2048 = 64 x 32 in round 4)
                                     // its staging area holds for each carry 2048 cycles per pass (round 4; 1024 before: the pass's fixed work --
                                     // scan, top, merges: ~280 us at 1M nodes / 64 zones -- halves per placement)
 constexpr int kCwThreads = 256, kCwPerThread = 4, kCwTile = kCwThreads * kCwPerThread;
@@ -75,6 +75,16 @@ struct __attribute__((aligned(16))) CwClass {
     uint32_t pad[2];
 };
 
+struct __attribute__((aligned(16))) CwPart {
+    uint32_t nf, mt, ht, ma, ha, pad[3];
+};
+// (max, holders) pairs combine as: the larger maximum with its holders; equal maxima add their holders
+__device__ __forceinline__ void cw_part_add(CwPart &x, const CwPart &y) {
+    x.nf += y.nf;
+    if (y.mt > x.mt) x.mt = y.mt, x.ht = y.ht; else if (y.mt == x.mt) x.ht += y.ht;
+    if (y.ma > x.ma) x.ma = y.ma, x.ha = y.ha; else if (y.ma == x.ma) x.ha += y.ha;
+}
+
 struct CwWork {
     unsigned long long *keys; // [kCwSlots] tuple hash of the class in the slot, 0 = empty
     uint32_t *ready;          // [kCwSlots] the claimant has written the tuple
@@ -91,7 +101,13 @@ struct CwWork {
     unsigned long long *lists; // [kCwMaxClasses][L]
     unsigned long long *umin; // [blocks][kMaxTsc] unique-key hard constraints: (minimum << 32) | counted nodes at the minimum
     int32_t n_blocks;
+    // per (block, class) and per (merge group, class): members, maxima, holders of the maxima -- written by k_cw_top, reduced by k_cw_merge
+    // into CwClass.  (Round 4 accumulated them with atomics on the class record: ~4 000 same-address device-scope atomics per class and
+    // pass at 1M nodes, from every XCD -- that serialization, not the 36 MB of columns, was the scan's 130-170 us.)
+    CwPart *part;  // [blocks][kCwMaxClasses]
+    CwPart *part2; // [groups][kCwMaxClasses]
 };
+
 
 __device__ __forceinline__ uint64_t cw_hash(const int32_t *t, int n) {
     uint64_t h = 0x9e3779b97f4a7c15ull;
@@ -136,11 +152,10 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
     if (st.done || st.cw_fallback) return;
     __shared__ unsigned long long b_key[kCwBlockSlots];
     __shared__ int32_t b_tuple[kCwBlockSlots][kCwTuple];
-    __shared__ uint32_t b_nf[kCwBlockSlots], b_mt[kCwBlockSlots], b_ma[kCwBlockSlots];
     __shared__ int32_t b_gslot[kCwBlockSlots];
     __shared__ uint32_t b_um[kMaxTsc], b_uc[kMaxTsc];
     const int tid = threadIdx.x;
-    for (int s = tid; s < kCwBlockSlots; s += kCwThreads) b_key[s] = 0, b_nf[s] = 0, b_mt[s] = 0, b_ma[s] = 0, b_gslot[s] = -1;
+    for (int s = tid; s < kCwBlockSlots; s += kCwThreads) b_key[s] = 0, b_gslot[s] = -1;
     if (tid < kMaxTsc) b_um[tid] = 0x7fffffffu, b_uc[tid] = 0;
     __syncthreads();
     const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
@@ -302,7 +317,6 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
                     break;
                 }
             }
-            if (s >= 0) atomicAdd(&b_nf[s], 1u), atomicMax(&b_mt[s], cnt), atomicMax(&b_ma[s], aff);
         }
         lslot[j] = s, mine4[j] = mine;
     }
@@ -346,7 +360,10 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
         const unsigned long long h = b_key[s];
         int g = (int)(h & (kCwSlots - 1)), probes = 0;
         for (;;) {
-            const unsigned long long old = atomicCAS(&a.w.keys[g], 0ull, h);
+            // look before claiming: once a class is in the table (after the first few blocks) every later block only READS its slot --
+            // a device-scope load, served in parallel -- instead of queueing a compare-and-swap on the same address behind ~1000 others
+            unsigned long long old = __hip_atomic_load(&a.w.keys[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0ull) old = atomicCAS(&a.w.keys[g], 0ull, h);
             if (old == 0ull) {
                 const uint32_t id = atomicAdd(&a.w.ctl[kCwCtlClasses], 1u);
                 if (id >= (uint32_t)kCwMaxClasses) __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -371,12 +388,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_scan(CwScanArgs a) {
             }
         }
         gs[r] = g;
-        if (g >= 0) {
-            atomicAdd(&a.w.cls[g].nf, b_nf[s]);
-            atomicMax(&a.w.cls[g].mt, b_mt[s]);
-            atomicMax(&a.w.cls[g].ma, b_ma[s]);
-        }
-        b_gslot[s] = g;
+        b_gslot[s] = g; // (members, maxima and holders of the class: k_cw_top per block, k_cw_merge over the blocks -- no atomics on the class record)
     }
 #pragma unroll
     for (int r = 0; r < (kCwBlockSlots + kCwThreads - 1) / kCwThreads; r++) {
@@ -416,31 +428,40 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
     if (a.st->done || a.st->cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     __shared__ unsigned long long cand[2][kCwMaxClasses];
-    __shared__ uint32_t l_mt[kCwMaxClasses], l_ma[kCwMaxClasses], l_ht[kCwMaxClasses], l_ha[kCwMaxClasses];
+    __shared__ uint32_t l_nf[kCwMaxClasses], l_mt[kCwMaxClasses], l_ma[kCwMaxClasses], l_ht[kCwMaxClasses], l_ha[kCwMaxClasses];
     const int tid = threadIdx.x;
     const int C = (int)a.w.ctl[kCwCtlClasses];
-    for (int id = tid; id < C; id += kCwThreads) {
-        const CwClass &k = a.w.cls[a.w.slot_of_id[id]];
-        l_mt[id] = k.mt, l_ma[id] = k.ma, l_ht[id] = 0, l_ha[id] = 0;
-    }
+    for (int id = tid; id < C; id += kCwThreads) l_nf[id] = 0, l_mt[id] = 0, l_ma[id] = 0, l_ht[id] = 0, l_ha[id] = 0;
     __syncthreads();
     int id_[kCwPerThread];
     uint64_t key_[kCwPerThread];
+    uint32_t cnt_[kCwPerThread], aff_[kCwPerThread];
+    // this block's members of every class, their TaintToleration / NodeAffinity maxima ...
 #pragma unroll
     for (int j = 0; j < kCwPerThread; j++) {
         const int64_t i = (int64_t)blockIdx.x * kCwTile + (int64_t)j * kCwThreads + tid;
-        id_[j] = -1, key_[j] = 0;
+        id_[j] = -1, key_[j] = 0, cnt_[j] = 0, aff_[j] = 0;
         if (i < a.c.n) {
             const int32_t slot = a.w.node_slot[i];
             if (slot >= 0) {
                 id_[j] = (int)a.w.cls[slot].id;
                 key_[j] = make_key((int64_t)a.w.node_A[i], a.c.global_offset + i);
                 const uint32_t w = a.c.stat[i];
-                if (((w >> kStatCntShift) & kStatCntMask) == l_mt[id_[j]]) atomicAdd(&l_ht[id_[j]], 1u);
-                if ((w & kStatAffMask) == l_ma[id_[j]]) atomicAdd(&l_ha[id_[j]], 1u);
+                cnt_[j] = (w >> kStatCntShift) & kStatCntMask, aff_[j] = w & kStatAffMask;
+                atomicAdd(&l_nf[id_[j]], 1u);
+                if (cnt_[j]) atomicMax(&l_mt[id_[j]], cnt_[j]);
+                if (aff_[j]) atomicMax(&l_ma[id_[j]], aff_[j]);
             }
         }
     }
+    __syncthreads();
+    // ... and how many of them hold the block's maxima (k_cw_merge combines the blocks: the larger maximum with its holders)
+#pragma unroll
+    for (int j = 0; j < kCwPerThread; j++)
+        if (id_[j] >= 0) {
+            if (cnt_[j] == l_mt[id_[j]]) atomicAdd(&l_ht[id_[j]], 1u);
+            if (aff_[j] == l_ma[id_[j]]) atomicAdd(&l_ha[id_[j]], 1u);
+        }
     unsigned long long *out = a.w.top + (size_t)blockIdx.x * kCwMaxClasses * a.list_len;
     for (int id = tid; id < C; id += kCwThreads) cand[0][id] = 0ull, cand[1][id] = 0ull;
     __syncthreads();
@@ -458,9 +479,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
         __syncthreads();
     }
     for (int id = tid; id < C; id += kCwThreads) {
-        CwClass &k = a.w.cls[a.w.slot_of_id[id]];
-        if (l_ht[id]) atomicAdd(&k.ht, l_ht[id]);
-        if (l_ha[id]) atomicAdd(&k.ha, l_ha[id]);
+        CwPart q;
+        q.nf = l_nf[id], q.mt = l_mt[id], q.ht = l_ht[id], q.ma = l_ma[id], q.ha = l_ha[id], q.pad[0] = q.pad[1] = q.pad[2] = 0;
+        a.w.part[(size_t)blockIdx.x * kCwMaxClasses + id] = q;
     }
 }
 
@@ -469,7 +490,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_top(CwTopArgs a) {
 // One launch when the snapshot's blocks fit one group (dst = the class lists); else two levels: groups -> CwWork::top2 -> lists
 // (G^2 blocks: 10 M nodes at L = 64).
 constexpr int kCwMergeThreads = 64;
-__global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a, const unsigned long long *__restrict__ src, int nb_all, int G, unsigned long long *__restrict__ dst) {
+__global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a, const unsigned long long *__restrict__ src, int nb_all, int G, unsigned long long *__restrict__ dst,
+                                                          const CwPart *__restrict__ psrc, CwPart *__restrict__ pdst) {
     if (a.st->done || a.st->cw_fallback) return;
     if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const int C = (int)a.w.ctl[kCwCtlClasses], id = blockIdx.x, g = blockIdx.y, L = a.list_len;
@@ -477,11 +499,34 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a, const unsi
     const int b_first = g * G, nb = (nb_all - b_first < G ? nb_all - b_first : G);
     __shared__ unsigned long long s_k[kCwMaxKeys];
     __shared__ uint8_t s_head[kCwMaxKeys];
+    __shared__ CwPart s_part[kCwThreads / 64];
     for (int q = threadIdx.x; q < nb * L; q += kCwThreads) { // staging: all four waves
         const int b = q / L, r = q % L;
         s_k[q] = src[((size_t)(b_first + b) * kCwMaxClasses + id) * L + r];
     }
     for (int b = threadIdx.x; b < nb; b += kCwThreads) s_head[b] = 0;
+    {   // the class's members / maxima / holders over these blocks (or groups): pdst = nullptr -> the class record itself
+        CwPart acc;
+        acc.nf = acc.mt = acc.ht = acc.ma = acc.ha = 0, acc.pad[0] = acc.pad[1] = acc.pad[2] = 0;
+        for (int b = threadIdx.x; b < nb; b += kCwThreads) cw_part_add(acc, psrc[(size_t)(b_first + b) * kCwMaxClasses + id]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            CwPart o;
+            o.nf = (uint32_t)__shfl_xor((int)acc.nf, off), o.mt = (uint32_t)__shfl_xor((int)acc.mt, off), o.ht = (uint32_t)__shfl_xor((int)acc.ht, off);
+            o.ma = (uint32_t)__shfl_xor((int)acc.ma, off), o.ha = (uint32_t)__shfl_xor((int)acc.ha, off);
+            cw_part_add(acc, o);
+        }
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kCwThreads / 64; w++) cw_part_add(acc, s_part[w]);
+            if (pdst) pdst[(size_t)g * kCwMaxClasses + id] = acc;
+            else {
+                CwClass &k = a.w.cls[a.w.slot_of_id[id]];
+                k.nf = acc.nf, k.mt = acc.mt, k.ma = acc.ma, k.ht = acc.ht, k.ha = acc.ha;
+            }
+        }
+    }
     __syncthreads();
     if (threadIdx.x >= kCwMergeThreads) return; // the rounds: one wave, no block barrier
     const int lane = threadIdx.x;
@@ -743,14 +788,16 @@ __device__ __forceinline__ int32_t wave_min_i32_nonneg(int32_t v) { return (int3
 //    log capacity), and the inter-pod totals are (was zero, is positive) flags plus 32-bit deltas added to the state at the end;
 //  * the argmax is a 32-bit DPP maximum of the keys' high words (the score); the low words (lowest index first) are only
 //    reduced when several lanes share the score.
+constexpr int kCwFastListLds = 4096; // class-list entries the lane-per-candidate kernel stages (64 classes x 64 members: 64 KiB)
 struct CwFastLds {
-    uint4 ent[kCwListLds + 64];                 // class c, member m at c * (L + 1) + m: {key lo, key hi, A after one more clone, meta}; a zero key ends the list
+    uint4 ent[kCwFastListLds + 64];             // class c, member m at c * (L + 1) + m: {key lo, key hi, A after one more clone, meta}; a zero key ends the list
     unsigned long long rec[kCwFastWindow + 64]; // nodes that received clones in this window: index | clones << kIdxBits
     int32_t s_nt;
     unsigned long long pf[8];
     // sweeps (a round of placements at once, see `sweep` in the kernel): per value id of the shared key -- candidates of the domain /
     // "the domain took a clone in this sweep" (both all-zero outside a sweep); the participants' facts by position; the log's current group
-    int32_t dn[72], dflag[72];
+    int32_t dflag[72];
+    unsigned long long dbest[72], skey[64];
     uint32_t byrank[64];
     int32_t lg[64];
 };
@@ -780,7 +827,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     const int C = uni32((int)a.w.ctl[kCwCtlClasses]);
     // members of a class list this kernel uses: all L, or as many as the staging area holds for C classes (many classes with long
     // lists: the window then ends where a class has used up its shorter list -- earlier, never differently)
-    const int LU = uni32(C > 0 && C * LL > kCwListLds ? kCwListLds / C : LL), LS = LU + 1;
+    const int LU = uni32(C > 0 && C * LL > kCwFastListLds ? kCwFastListLds / C : LL), LS = LU + 1;
     constexpr bool HU0 = (HU & 1) != 0, HU1 = (HU & 2) != 0, KU0 = (KU & 1) != 0, KU1 = (KU & 2) != 0;
     // ---- does this window qualify?  (uniform; nothing has been modified yet)
     bool fits = C <= (FULL ? 64 : kCwFastClasses) && LU >= 1;
@@ -815,7 +862,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     }
     if (tid == 0) L.s_nt = -1; // -1: the window was not taken
     if (tid < 8) L.pf[tid] = 0;
-    if (tid < 72) L.dn[tid] = 0, L.dflag[tid] = 0;
+    if (tid < 72) L.dbest[tid] = 0ull, L.dflag[tid] = 0;
     __syncthreads();
 
     if (tid < 64) {
@@ -1156,8 +1203,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
             int n_sweeps = 0, n_swept = 0;
             auto sweep = [&]() -> bool {
                 const uint64_t okm = __ballot(ok);
-                const int m = __popcll(okm);
-                if (m < 4) return false;
+                if (__popcll(okm) < 4) return false;
                 if (!FULL && (okm >> C) != 0ull) return false; // a node that already took a clone is a candidate: the loop's business
                 // the first clone of a run moves the inter-pod totals from "no matching pod anywhere" to "some": the loop's business too
                 if (NK > 0 && ((aff_zero && k_daff0 != 0) || (!exist_pos && k_danti0 != 0))) return false;
@@ -1165,27 +1211,31 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 const bool counts = (el & 1u) && ((el >> 1) & 1u) && hv0 != 0;
                 const int32_t min_eff = h_usemin0 ? (min0 < kCountCap ? min0 : kCountCap) : 0;
                 if (__ballot(ok && !(counts && hc0 - min_eff == h_rhs0)) != 0ull) return false;
-                // one candidate per domain?
-                if (ok) atomicAdd(&L.dn[hv0], 1);
+                // the best head of every domain takes part (several classes may share a domain: nodes whose own entries differ); the
+                // others of the domain stay candidates until their domain's clone lands, i.e. up to the same position
+                if (ok) atomicMax(&L.dbest[hv0], (unsigned long long)key);
+                L.byrank[lane] = 0u;
                 cw_lds_sync();
-                const int32_t in_dom = ok ? L.dn[hv0] : 1;
+                const uint64_t dk = ok ? (uint64_t)L.dbest[hv0] : 0ull;
+                const bool part = ok && key == dk;
+                L.skey[lane] = part ? (unsigned long long)key : 0ull;
                 cw_lds_sync();
-                if (ok) L.dn[hv0] = 0;
-                if (__ballot(in_dom != 1) != 0ull) return false;
+                if (part) L.dbest[hv0] = 0ull;
+                const int m = __popcll(__ballot(part));
+                if (m < 4) return false;
                 // would the head stay a candidate after its clone?  (commit's `dead`, per lane)
                 bool stays = hA1 >= 0;
                 if (NK > 0 && ipa_filter && kv0 != 0) {
                     if (k_anti0 && kn0 + k_danti0 > 0) stays = false;
                     if ((exist_pos || k_danti0 != 0) && ke0 + k_danti0 > 0) stays = false;
                 }
-                // position of every candidate in the order the cycles would take them (keys are unique: they carry the node index)
+                // position of every candidate's DOMAIN in the order the cycles would take them (keys are unique: they carry the node
+                // index): how many participants lie ahead of the domain's best head -- 64 broadcast reads from LDS
                 uint32_t rank = 0;
-                for (uint64_t rem = okm; rem != 0ull; rem &= rem - 1ull) {
-                    const uint64_t kj = rl64(key, __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)rem) - 1));
-                    rank += kj > key ? 1u : 0u;
-                }
+#pragma unroll 8
+                for (int j = 0; j < 64; j++) rank += (uint64_t)L.skey[j] > dk ? 1u : 0u;
                 const uint32_t w_cnt = (hmeta >> kStatCntShift) & kStatCntMask, w_aff = hmeta & kStatAffMask;
-                if (ok) L.byrank[rank] = (hc0 == min0 ? 1u : 0u) | (stays ? 2u : 0u) | (cmt == mt_a ? 4u : 0u) | (cma == ma_a ? 8u : 0u);
+                if (ok) atomicOr(&L.byrank[rank], (part ? ((hc0 == min0 ? 1u : 0u) | (stays ? 2u : 0u)) : 0u) | (cmt == mt_a ? 4u : 0u) | (cma == ma_a ? 8u : 0u));
                 cw_lds_sync();
                 const uint32_t pfl = lane < m ? L.byrank[lane] : 0u; // lane = position from here on
                 const uint64_t M_min = __ballot((pfl & 1u) != 0u), M_stay = __ballot((pfl & 2u) != 0u), M_t = __ballot((pfl & 4u) != 0u), M_a = __ballot((pfl & 8u) != 0u);
@@ -1204,7 +1254,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 T = uni32(T);
                 if (T < 2) return false;
                 // ---- the T cycles, every lane its own share
-                const bool take = ok && rank < (uint32_t)T;
+                const bool take = part && rank < (uint32_t)T;
                 lf = (ok && rank >= (uint32_t)(T - 1)) ? nfm : 0u; // the feasible nodes of the last of them
                 const int64_t gi = key_index(key);
                 const int cycles0 = cycles, nrec0 = nrec;

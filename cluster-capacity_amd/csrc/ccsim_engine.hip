@@ -960,7 +960,7 @@ static int cw_make_plan(ccsim_engine *e) {
         }
     if (i32 > kCwLdsI32 || i64 > kCwLdsI64) return no("shared-key tables exceed the decide kernel's LDS budget");
     pl.n_comp = kCwTuple, pl.i32_words = i32, pl.i64_words = i64;
-    pl.window = 2048, pl.list_len = 64; // (profiles/r03/bench_coupled.txt, C5-shaped template at 100k nodes: 512/32 -> 0.98M placements/s, 1024/64 -> 1.03M;
+    pl.window = 4096, pl.list_len = 64; // (round 5: 4096 = 64 classes x 64 members, with the whole lists staged; profiles/r03/bench_coupled.txt, C5-shaped template at 100k nodes: 512/32 -> 0.98M placements/s, 1024/64 -> 1.03M;
                                         // round 4: 2048 -- with 64 classes the lists carry that many cycles, with 16 they still end a window at ~1000)
     if (const char *f = getenv("CCSIM_CW_WINDOW")) pl.window = atoi(f); // tuning / test knobs
     if (const char *f = getenv("CCSIM_CW_LIST")) pl.list_len = atoi(f);
@@ -997,6 +997,8 @@ static int cw_make_plan(ccsim_engine *e) {
     if ((rc = dev_alloc(e, &w.lists, (size_t)kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs))) return rc;
     if (blocks > group && (rc = dev_alloc(e, &w.top2, (size_t)((blocks + group - 1) / group) * kCwMaxClasses * (size_t)pl.list_len, e->pod_allocs, false))) return rc;
     if ((rc = dev_alloc(e, &w.umin, (size_t)blocks * kMaxTsc, e->pod_allocs))) return rc;
+    if ((rc = dev_alloc(e, &w.part, (size_t)blocks * kCwMaxClasses, e->pod_allocs, false))) return rc;
+    if (blocks > group && (rc = dev_alloc(e, &w.part2, (size_t)((blocks + group - 1) / group) * kCwMaxClasses, e->pod_allocs, false))) return rc;
     unsigned char *argbuf = nullptr;
     if ((rc = dev_alloc(e, &argbuf, sizeof(CwDecideArgs), e->pod_allocs))) return rc;
     e->d_cw_args = argbuf;
@@ -1704,10 +1706,14 @@ static void launch_cw_window(ccsim_engine *e) {
     const CwTopArgs ta{e->cols, e->d_state, e->cw_work, e->cw_plan.list_len};
     hipLaunchKernelGGL(k_cw_top, g, b, 0, e->stream, ta);
     const int G = e->cw_work.merge_group, groups = (e->cw_work.n_blocks + G - 1) / G;
-    if (groups == 1) hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, 1), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top, e->cw_work.n_blocks, G, e->cw_work.lists);
+    if (groups == 1)
+        hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, 1), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top, e->cw_work.n_blocks, G, e->cw_work.lists,
+                           (const CwPart *)e->cw_work.part, (CwPart *)nullptr);
     else {
-        hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, groups), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top, e->cw_work.n_blocks, G, e->cw_work.top2);
-        hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, 1), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top2, groups, G, e->cw_work.lists);
+        hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, groups), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top, e->cw_work.n_blocks, G, e->cw_work.top2,
+                           (const CwPart *)e->cw_work.part, e->cw_work.part2);
+        hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, 1), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top2, groups, G, e->cw_work.lists,
+                           (const CwPart *)e->cw_work.part2, (CwPart *)nullptr);
     }
     // lane = candidate form first (it declines, untouched, whatever it does not cover); the general form right behind it
     if (e->cw_fast) { // (the pod's shape picks the instantiation: bit c of HU / bit k of KU = unique-per-node key)
@@ -1715,7 +1721,11 @@ static void launch_cw_window(ccsim_engine *e) {
         const int nk = e->ipa.on ? e->ipa.n_keys : 0, ku = (nk > 0 && e->cw_plan.k_unique[0] ? 1 : 0) | (nk > 1 && e->cw_plan.k_unique[1] ? 2 : 0);
         const CwDecideArgs *dp = (const CwDecideArgs *)e->d_cw_args;
         const int shape = e->pts.n * 1000 + hu * 100 + nk * 10 + ku;
-        switch (shape) {
+        // (a shared key with more than 63 domains is beyond the standard form whatever the classes turn out to be -- the kernel's own test,
+        // k_cw_decide_fast `fits` -- so its launch, which would return at once, is not enqueued: one dispatch boundary less per pass)
+        bool std_form = true;
+        for (int c = 0; c < e->pts.n && c < 2; c++) std_form = std_form && (e->cw_plan.h_unique[c] || e->cw_plan.h_len[c] <= 64);
+        switch (std_form ? shape : -1) {
 #define CW_FAST_CASE(NH, HU, NK, KU)                                                                                             \
     case NH * 1000 + HU * 100 + NK * 10 + KU:                                                                                    \
         if (e->cw_work.prof) hipLaunchKernelGGL((k_cw_decide_fast<NH, HU, NK, KU, true>), dim3(1), b, sizeof(CwLds), e->stream, dp); \

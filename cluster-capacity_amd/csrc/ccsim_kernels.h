@@ -231,6 +231,9 @@ struct DevState {
     int32_t cw_windows;      // windows resolved so far
     int32_t cw_fast_windows, cw_full_windows; // ... of them by the lane-per-candidate kernel / by its 64-class form
     int32_t cw_sweeps, cw_swept;              // rounds that kernel resolved at once, and the placements in them (ccsim_coupled.h `sweep`)
+    // the sampled search on resident block summaries (ccsim_sampled.h)
+    int32_t sb_dirty;        // 1 = memo and summaries do not describe the columns under (mt_a, ma_a): k_sb_build runs before the next cycle
+    int32_t sb_cycles;       // launches of k_sb_cycles that ran (diagnostics: did this path take the run)
     // persistent batched launch (ccsim_persist.h): the normalization maxima the launch started with (the next launch's hint)
     int32_t p_mt0, p_ma0;
 };

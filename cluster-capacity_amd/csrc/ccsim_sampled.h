@@ -1,0 +1,356 @@
+// ccsim_sampled.h -- the SAMPLED SEARCH (percentageOfNodesToScore < 100: the reference's DEFAULT, adaptive 50 % ... 5 %) as a resident
+// structure instead of node passes (round 5; SURVEY 8(a) row a4, 8(d) "mode B").
+//
+// Reference: findNodesThatFitPod / findNodesThatPassFilters / numFeasibleNodesToFind (S/schedule_one.go:482-564, 610-693, 697-723).  A
+// cycle visits the nodes in ring order from nextStartNodeIndex, keeps the first K feasible ones, stops at the (K+1)-th, scores the K kept,
+// picks the maximum (first in visiting order on ties), and moves the start index past what it visited (:538-539).  The
+// sequential mode does that literally: a counting pass, a prefix, a scoring pass -- three dispatches over every node, 58 us per cycle at
+// 1M nodes although a cycle changes ONE node.
+//
+// For a template without topology-coupled plugins a node's verdict and TotalScore depend on the node alone plus the two normalization
+// maxima over the K kept nodes (TaintToleration / NodeAffinity, P/helper/normalize_score.go:28-56).  So what a cycle needs is resident:
+//   memo[n]        TotalScore of every node under the ASSUMED maxima (mt_a, ma_a), -1 = infeasible (k_sb_build, once; one word per cycle after)
+//   per BLOCK of 2^shift nodes (256 at 1M): feasible nodes, the best (score, lowest index) key, the maxima of the two raw scores over
+//                  the feasible nodes -- 16 bytes per block, all blocks in the LDS of ONE workgroup for the whole run
+// and a cycle is (k_sb_cycles, one persistent workgroup, no grid-wide anything):
+//   1. ring prefix of the blocks' feasible counts from the start block -> the block that holds the (K+1)-th feasible node;
+//   2. that block and the start block (both are cut by the stretch) are read node by node (memo + static word: 2 x 2 KB), every block
+//      in between contributes its summary: argmax (ties: lowest ring position) and the maxima over exactly the K kept nodes;
+//   3. maxima differ from the assumed ones -> rebuild under the true ones (as decide_commit does: "stale maxima: rescan"); else
+//   4. NodeInfo.update on the winner (S/framework/types.go:409-428), its memo word, its block's summary, the start index.
+// Three dependent trips to L2 per cycle instead of three passes over HBM.  Exactly the oracle's cycle: same nodes visited, same K
+// kept, same winner, same start index (tests/test_sampling.py compares evaluated_total / last_feasible / the log cycle by cycle).
+#pragma once
+#include "ccsim_level.h"
+
+namespace ccsim {
+
+constexpr int kSbThreads = 1024;
+constexpr int kSbWaves = kSbThreads / 64;
+constexpr int kSbMaxBlocks = 8192; // block summaries resident in LDS (128 KiB)
+constexpr int kSbMaxShift = 10;    // a block is at most 1024 nodes = one node per thread of the cycle kernel
+
+struct SbArgs {
+    DevCols c;
+    DevPod p;
+    DevState *st;
+    int32_t *memo;              // [n_pad]
+    uint32_t *sb_fc;            // [n_blocks] feasible nodes of the block
+    unsigned long long *sb_key; // [n_blocks] make_key(best TotalScore, lowest index holding it), 0 = no feasible node
+    uint32_t *sb_mx;            // [n_blocks] (max PreferNoSchedule count << 16) | max preferred-affinity sum, over the feasible nodes
+    int32_t *log;
+    int32_t shift, n_blocks, max_cycles;
+};
+
+// one node under the assumed maxima: TotalScore, or -1 (the wide path: any snapshot; the narrow mirrors give the same number by construction)
+__device__ __forceinline__ int32_t sb_node_score(const DevPod &p, const NodeRegs<kMaxExtra> &nd, uint32_t mt, uint32_t ma) {
+    if (!node_feasible<kMaxExtra>(p, nd)) return -1;
+    const uint32_t cnt = (nd.w >> kStatCntShift) & kStatCntMask, aff = nd.w & kStatAffMask, img = (nd.w >> kStatImgShift) & kStatImgMask;
+    return (int32_t)node_score<kMaxExtra>(p, nd, static_score(p, cnt, aff, img, mt, ma));
+}
+
+// k_sb_build: memo + block summaries of the whole snapshot under (mt_a, ma_a).  One workgroup per block.  Runs while DevState::sb_dirty.
+template <bool NARROW>
+__global__ __launch_bounds__(256) void k_sb_build(SbArgs a) {
+    const DevState &st = *a.st;
+    if (st.done || !st.sb_dirty) return;
+    const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
+    const int tid = threadIdx.x, B = 1 << a.shift;
+    const int64_t base = (int64_t)blockIdx.x << a.shift;
+    const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
+    uint32_t fc = 0, bmt = 0, bma = 0;
+    uint64_t best = 0;
+    for (int j = tid; j < B; j += 256) {
+        const int64_t i = base + j;
+        if (i >= a.c.n_pad) break;
+        int32_t sc = -1;
+        const uint32_t w = a.c.stat[i];
+        if (i < a.c.n) {
+            if (NARROW) {
+                const int32_t na0 = a.c.a32[0][i], na1 = a.c.a32[1][i], nr0 = a.c.r32[0][i], nr1 = a.c.r32[1][i];
+                if ((w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, a.c.alloc_pods[i], a.c.pod_count[i])) {
+                    const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
+                    sc = (int32_t)(static_score(a.p, cnt, aff, img, mt, ma) + dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, a.c.z32[0][i], a.c.z32[1][i]));
+                }
+            } else {
+                NodeRegs<kMaxExtra> nd;
+                load_one<kMaxExtra>(a.c, a.p, i, nd);
+                sc = sb_node_score(a.p, nd, mt, ma);
+            }
+        }
+        a.memo[i] = sc;
+        if (sc >= 0) {
+            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+            fc += 1, bmt = cnt > bmt ? cnt : bmt, bma = aff > bma ? aff : bma;
+            const uint64_t k = make_key((int64_t)sc, a.c.global_offset + i);
+            best = k > best ? k : best;
+        }
+    }
+    __shared__ uint32_t s_fc[4], s_mt[4], s_ma[4];
+    __shared__ uint64_t s_k[4];
+    fc = wave_sum_u32_dpp(fc), bmt = wave_max_u32(bmt), bma = wave_max_u32(bma), best = wave_max_u64(best);
+    if ((tid & 63) == 0) s_fc[tid >> 6] = fc, s_mt[tid >> 6] = bmt, s_ma[tid >> 6] = bma, s_k[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) fc += s_fc[w], bmt = s_mt[w] > bmt ? s_mt[w] : bmt, bma = s_ma[w] > bma ? s_ma[w] : bma, best = s_k[w] > best ? s_k[w] : best;
+        a.sb_fc[blockIdx.x] = fc, a.sb_key[blockIdx.x] = best, a.sb_mx[blockIdx.x] = (bmt << 16) | bma;
+    }
+}
+
+struct SbLds {
+    uint32_t fc[kSbMaxBlocks];
+    unsigned long long key[kSbMaxBlocks];
+    uint32_t mx[kSbMaxBlocks];
+    uint32_t w_a[kSbWaves], w_b[kSbWaves], w_c[kSbWaves], w_d[kSbWaves]; // per-wave partial sums (two uses per cycle: parity-free, a barrier separates them)
+    unsigned long long w_key[kSbWaves];
+    uint32_t w_mt[kSbWaves], w_ma[kSbWaves];
+    long long w_stop[kSbWaves];
+    // what one thread found and every thread needs
+    int32_t cross_r, cross_need;
+    int32_t nm, nm_feas_delta; // the winner's new memo word; -1 if it left the feasible nodes
+    long long nm_idx;
+    int32_t flag;
+};
+
+__device__ __forceinline__ int32_t ld_memo(const int32_t *p) { return (int32_t)__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// exclusive prefix of `v` over the workgroup's threads, and the total: wave scan + the waves' totals through `ws` (the caller's barrier
+// discipline: one __syncthreads inside; `ws` must not be in use)
+__device__ __forceinline__ uint32_t sb_excl_scan(uint32_t v, uint32_t *ws, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+        inc += lane >= off ? o : 0u;
+    }
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kSbWaves; w++) {
+        const uint32_t t = ws[w];
+        before += w < wave ? t : 0u, all += t;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+// k_sb_cycles: up to max_cycles scheduling cycles in ONE workgroup.
+__global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds_raw[];
+    SbLds &L = *reinterpret_cast<SbLds *>(sb_lds_raw);
+    DevState &S = *a.st;
+    if (S.done || S.sb_dirty) return; // (dirty: the maxima moved and nobody rebuilt -- the host's loop enqueues k_sb_build first)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = a.n_blocks, B = 1 << a.shift, sh = a.shift;
+    const int64_t N = a.c.n;
+    for (int b = tid; b < nb; b += kSbThreads) L.fc[b] = a.sb_fc[b], L.key[b] = a.sb_key[b], L.mx[b] = a.sb_mx[b];
+    uint32_t ft = 0;
+    for (int b = tid; b < nb; b += kSbThreads) ft += a.sb_fc[b];
+    ft = wave_sum_u32_dpp(ft);
+    if (lane == 0) L.w_a[wave] = ft;
+    if (tid == 0) L.nm_idx = -1, L.nm = -1;
+    __syncthreads();
+    int64_t Ftotal = 0;
+    for (int w = 0; w < kSbWaves; w++) Ftotal += L.w_a[w];
+    __syncthreads();
+    // the run state every thread carries (updated identically from broadcast values; thread 0 writes it back)
+    const int64_t K = S.smp_K, limit = S.limit, log_cap = S.log_cap;
+    const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
+    int64_t start = S.smp_start, placed = S.placed, rounds = S.rounds, scans = S.scans, evaluated = S.evaluated, winner = -1;
+    int32_t last_feasible = S.last_feasible, last_evaluated = S.last_evaluated, done = 0, dirty = 0;
+    uint32_t new_mt = mt_a, new_ma = ma_a;
+    int64_t pend_blk = -1; // the block of the last winner: its summary is recomputed alongside the next cycle's first reads
+    const int E = (nb - 1 + kSbThreads - 1) / kSbThreads; // full blocks per thread in the ring scan
+
+    for (int cyc = 0; cyc < a.max_cycles && !done && !dirty; cyc++) {
+        if (Ftotal == 0) { // schedule_one.go:448-454: every node was visited, none passed
+            done = DONE_UNSCHEDULABLE, rounds += 1, scans += 1, last_feasible = 0, last_evaluated = (int32_t)N, evaluated += N, winner = -1;
+            break;
+        }
+        const int sb = (int)(start >> sh), so = (int)(start & (B - 1));
+        if (tid == 0) L.cross_r = -1; // (read after the barriers of the scans below)
+        // ---- the start block, node by node (thread t = node t of the block); and the summary of the last winner's block
+        const int64_t i_s = ((int64_t)sb << sh) + tid;
+        int32_t m_s = -1;
+        uint32_t w_s = 0;
+        if (tid < B && i_s < a.c.n_pad) m_s = i_s == L.nm_idx ? L.nm : ld_memo(a.memo + i_s), w_s = a.c.stat[i_s];
+        int32_t m_p = -1;
+        uint32_t w_p = 0;
+        int64_t i_p = -1;
+        if (pend_blk >= 0) {
+            i_p = (pend_blk << sh) + tid;
+            if (tid < B && i_p < a.c.n_pad) m_p = i_p == L.nm_idx ? L.nm : ld_memo(a.memo + i_p), w_p = a.c.stat[i_p];
+        }
+        // ---- ring scan over the full blocks: entry r = 1 .. nb - 1 is block (sb + r) mod nb
+        const int r_lo = tid * E + 1, r_hi = (tid + 1) * E < nb - 1 ? (tid + 1) * E : nb - 1;
+        uint32_t ls = 0;
+        for (int r = r_lo; r <= r_hi; r++) {
+            int b = sb + r;
+            b = b >= nb ? b - nb : b;
+            ls += L.fc[b];
+        }
+        // feasible nodes of the start block behind / before the start index, and every thread's rank among them
+        const bool f_s = m_s >= 0, tail_s = tid >= so;
+        uint32_t tailF = 0, headF = 0, fullF = 0;
+        const uint32_t rk_tail = sb_excl_scan(f_s && tail_s ? 1u : 0u, L.w_a, &tailF);
+        // (the three scans share one barrier each: their wave totals live in separate arrays)
+        const uint32_t rk_head = sb_excl_scan(f_s && !tail_s ? 1u : 0u, L.w_b, &headF);
+        const uint32_t ex = sb_excl_scan(ls, L.w_c, &fullF);
+        // ---- the summary of the last winner's block (its loads have landed by now)
+        if (pend_blk >= 0) {
+            uint32_t pf = m_p >= 0 ? 1u : 0u, pmt = m_p >= 0 ? (w_p >> kStatCntShift) & kStatCntMask : 0u, pma = m_p >= 0 ? w_p & kStatAffMask : 0u;
+            uint64_t pk = m_p >= 0 ? make_key((int64_t)m_p, a.c.global_offset + i_p) : 0ull;
+            pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma), pk = wave_max_u64(pk);
+            if (lane == 0) L.w_d[wave] = pf, L.w_mt[wave] = pmt, L.w_ma[wave] = pma, L.w_key[wave] = pk;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < kSbWaves; w++) pf += L.w_d[w], pmt = L.w_mt[w] > pmt ? L.w_mt[w] : pmt, pma = L.w_ma[w] > pma ? L.w_ma[w] : pma, pk = L.w_key[w] > pk ? L.w_key[w] : pk;
+                L.fc[pend_blk] = pf, L.key[pend_blk] = pk, L.mx[pend_blk] = (pmt << 16) | pma;
+                a.sb_fc[pend_blk] = pf, a.sb_key[pend_blk] = pk, a.sb_mx[pend_blk] = (pmt << 16) | pma; // (the global copy stays current: the next launch reloads it)
+            }
+            __syncthreads();
+            pend_blk = -1;
+        }
+        // ---- where does the stretch end?  (uniform: every thread holds the same totals)
+        const bool all = Ftotal <= K; // fewer feasible nodes than wanted: the search visits every node (:538: processed = N)
+        int mode = 0; // 0 all, 1 the (K+1)-th feasible node is behind the start index in the start block, 2 in a full block, 3 before the start index in the start block
+        if (!all) mode = (int64_t)tailF >= K + 1 ? 1 : ((int64_t)tailF + fullF >= K + 1 ? 2 : 3);
+        // (fullF: every block but the start block; tailF + fullF + headF == Ftotal)
+        uint64_t best = 0;
+        uint32_t cmt = 0, cma = 0;
+        int64_t stop = -1;
+        auto ringpos = [&](int64_t i) -> int64_t { return i >= start ? i - start : i + N - start; };
+        auto take_node = [&](int32_t m, uint32_t w, int64_t i) {
+            const uint64_t k = ((uint64_t)((int64_t)m + 1) << kIdxBits) | (kIdxMask - (uint64_t)ringpos(i));
+            best = k > best ? k : best;
+            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+            cmt = cnt > cmt ? cnt : cmt, cma = aff > cma ? aff : cma;
+        };
+        // the start block's share
+        if (f_s && tail_s) {
+            if (mode != 1 || (int64_t)rk_tail < K) take_node(m_s, w_s, i_s);
+            else if ((int64_t)rk_tail == K) stop = i_s;
+        }
+        if (f_s && !tail_s && (mode == 0 || mode == 3)) {
+            const int64_t need = K - ((int64_t)tailF + fullF); // (mode 3: how many of them are among the first K)
+            if (mode == 0 || (int64_t)rk_head < need) take_node(m_s, w_s, i_s);
+            else if ((int64_t)rk_head == need) stop = i_s;
+        }
+        // the full blocks' share: whole blocks inside the stretch by their summaries; the one the stretch ends in is found here
+        if (mode != 1) {
+            int64_t run = (int64_t)tailF + ex;
+            for (int r = r_lo; r <= r_hi; r++) {
+                int b = sb + r;
+                b = b >= nb ? b - nb : b;
+                const int64_t f = L.fc[b];
+                if (mode == 0 || mode == 3 || run + f <= K) {
+                    const uint64_t k = L.key[b];
+                    if (k) {
+                        const uint64_t rk = ((uint64_t)(key_score(k) + 1) << kIdxBits) | (kIdxMask - (uint64_t)ringpos(key_index(k) - a.c.global_offset));
+                        best = rk > best ? rk : best;
+                        const uint32_t x = L.mx[b];
+                        cmt = (x >> 16) > cmt ? (x >> 16) : cmt, cma = (x & 0xffffu) > cma ? (x & 0xffffu) : cma;
+                    }
+                } else if (run <= K) { // run <= K < run + f: the (K+1)-th feasible node of the visiting order is in this block
+                    L.cross_r = r, L.cross_need = (int32_t)(K - run);
+                }
+                run += f;
+            }
+        }
+        __syncthreads();
+        if (mode == 2) { // the block the stretch ends in, node by node
+            int b = sb + L.cross_r;
+            b = b >= nb ? b - nb : b;
+            const int64_t i_e = ((int64_t)b << sh) + tid;
+            int32_t m_e = -1;
+            uint32_t w_e = 0;
+            if (tid < B && i_e < a.c.n_pad) m_e = i_e == L.nm_idx ? L.nm : ld_memo(a.memo + i_e), w_e = a.c.stat[i_e];
+            uint32_t tot = 0;
+            const uint32_t rk_e = sb_excl_scan(m_e >= 0 ? 1u : 0u, L.w_a, &tot);
+            if (m_e >= 0) {
+                if ((int32_t)rk_e < L.cross_need) take_node(m_e, w_e, i_e);
+                else if ((int32_t)rk_e == L.cross_need) stop = i_e;
+            }
+        }
+        // ---- the cycle's argmax, the maxima over the kept nodes, the node the search stopped at
+        best = wave_max_u64(best), cmt = wave_max_u32(cmt), cma = wave_max_u32(cma);
+        {
+            const uint64_t sp = wave_max_u64((uint64_t)(stop + 1));
+            if (lane == 0) L.w_key[wave] = best, L.w_mt[wave] = cmt, L.w_ma[wave] = cma, L.w_stop[wave] = (long long)sp;
+        }
+        __syncthreads();
+        uint64_t sp1 = 0;
+#pragma unroll
+        for (int w = 0; w < kSbWaves; w++) {
+            best = L.w_key[w] > best ? L.w_key[w] : best, cmt = L.w_mt[w] > cmt ? L.w_mt[w] : cmt, cma = L.w_ma[w] > cma ? L.w_ma[w] : cma;
+            sp1 = (uint64_t)L.w_stop[w] > sp1 ? (uint64_t)L.w_stop[w] : sp1;
+        }
+        stop = (int64_t)sp1 - 1;
+        scans += 1;
+        if (cmt != mt_a || cma != ma_a) { // the scores were normalized with other maxima than the kept nodes': rebuild under the true ones
+            new_mt = cmt, new_ma = cma, dirty = 1;
+            break;
+        }
+        // ---- commit (schedule_one.go:967-984 assume -> NodeInfo.update): one thread, its loads issued together
+        const int64_t g_ring = (int64_t)(kIdxMask - (best & kIdxMask));
+        int64_t g = start + g_ring;
+        g = g >= N ? g - N : g;
+        const int64_t visited = all ? N : ringpos(stop);
+        if (tid == 0) {
+            const int64_t i = g - a.c.global_offset;
+            NodeRegs<kMaxExtra> nd;
+            load_one<kMaxExtra>(a.c, a.p, i, nd);
+            node_apply<kMaxExtra>(a.p, nd, 1);
+            store_dyn<kMaxExtra>(a.c, a.p, i, nd, 1);
+#pragma unroll 1
+            for (int col = 2; col < a.p.ncol; col++) { // (columns the pod requests but that are no slot of the Fit test: kept current like decide_commit does)
+                bool slot = false;
+                for (int x = 0; x < a.p.nx; x++) slot = slot || a.p.xcol[x] == col;
+                if (!slot && a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
+            }
+            const int32_t nm = sb_node_score(a.p, nd, mt_a, ma_a);
+            __hip_atomic_store((uint32_t *)(a.memo + i), (uint32_t)nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence(); // (later cycles read the word from L2; the next one takes it from L.nm)
+            L.nm = nm, L.nm_idx = i;
+            if (a.log && placed < log_cap) a.log[placed] = (int32_t)g;
+        }
+        __syncthreads();
+        const int32_t nm = L.nm;
+        pend_blk = (g - a.c.global_offset) >> sh;
+        if (nm < 0) { // the winner is full: one feasible node less, in its block and in the cluster (the ring scan of the next cycle reads both)
+            Ftotal -= 1;
+            if (tid == 0) L.fc[pend_blk] -= 1;
+        }
+        placed += 1, rounds += 1, winner = g, evaluated += visited, last_evaluated = (int32_t)visited;
+        last_feasible = (int32_t)(all ? Ftotal + (nm < 0 ? 1 : 0) : K);
+        if (!all) start = stop;
+        if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312
+        __syncthreads();
+    }
+    // the last winner's block summary, if it is still pending
+    if (pend_blk >= 0) {
+        const int64_t i_p = (pend_blk << sh) + tid;
+        int32_t m_p = -1;
+        uint32_t w_p = 0;
+        if (tid < B && i_p < a.c.n_pad) m_p = i_p == L.nm_idx ? L.nm : ld_memo(a.memo + i_p), w_p = a.c.stat[i_p];
+        uint32_t pf = m_p >= 0 ? 1u : 0u, pmt = m_p >= 0 ? (w_p >> kStatCntShift) & kStatCntMask : 0u, pma = m_p >= 0 ? w_p & kStatAffMask : 0u;
+        uint64_t pk = m_p >= 0 ? make_key((int64_t)m_p, a.c.global_offset + i_p) : 0ull;
+        pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma), pk = wave_max_u64(pk);
+        if (lane == 0) L.w_d[wave] = pf, L.w_mt[wave] = pmt, L.w_ma[wave] = pma, L.w_key[wave] = pk;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kSbWaves; w++) pf += L.w_d[w], pmt = L.w_mt[w] > pmt ? L.w_mt[w] : pmt, pma = L.w_ma[w] > pma ? L.w_ma[w] : pma, pk = L.w_key[w] > pk ? L.w_key[w] : pk;
+            a.sb_fc[pend_blk] = pf, a.sb_key[pend_blk] = pk, a.sb_mx[pend_blk] = (pmt << 16) | pma;
+        }
+    }
+    if (tid == 0) {
+        S.smp_start = start, S.placed = placed, S.rounds = rounds, S.scans = scans, S.evaluated = evaluated, S.winner = winner;
+        S.last_feasible = last_feasible, S.last_evaluated = last_evaluated, S.done = done;
+        if (dirty) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma, S.sb_dirty = 1;
+        S.sb_cycles += 1;
+    }
+}
+
+} // namespace ccsim
