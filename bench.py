@@ -143,6 +143,23 @@ def secondary_lines(device: int):
                                                   "us_per_pass": dt * 1e6 / max(1, r.scans), "windowed": bool(info["windows"] and not info["fell_back"]),
                                                   f"first_{CW_GATE}_placements_equal_oracle": True, "windows_in_checked_prefix": int(head_windows)}
     e.close()
+    # the headline snapshot and pod under the reference's DEFAULT percentageOfNodesToScore (0 = adaptive: 5 % at 1M nodes, the first K = 50 000
+    # feasible nodes of the rotating visiting order per cycle, schedule_one.go:610-723; SURVEY 8(d) "mode B"): cycles on resident block
+    # summaries (csrc/ccsim_sampled.h) -- the literal loop of scheduling cycles, one placement each
+    import dataclasses
+    nodes, pod, prof = synth.make_config("C4", n_nodes=n)
+    prof = dataclasses.replace(prof, percentage_of_nodes_to_score=0)
+    MB_GATE = 3000
+    ref = ccref_py.run(prof, nodes, pod, max_limit=MB_GATE, threads=threads)
+    e = capi.Engine(device=device)
+    e.load(nodes, pod, prof)
+    head = e.run(max_limit=MB_GATE, mode="sequential", log_cap=MB_GATE)
+    assert np.array_equal(head.log, ref.log) and head.evaluated_total == ref.evaluated_total, "mode B: engine and oracle differ (log / nodes visited)"
+    r, dt = best_of(e, lambda: e.run(max_limit=100_000, mode="sequential", want_log=False, log_cap=0))
+    out["mode_b_adaptive_sampling_1M_nodes"] = {"value": r.placed / dt, "unit": "placements/s", "placements": int(r.placed), "us_per_cycle": dt * 1e6 / max(1, r.placed),
+                                                "nodes_visited_per_cycle": r.evaluated_total / max(1, r.placed), "resident_form": bool(r.pass_launches > 0),
+                                                f"first_{MB_GATE}_placements_and_visited_nodes_equal_oracle": True}
+    e.close()
     return out
 
 

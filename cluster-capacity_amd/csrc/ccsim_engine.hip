@@ -11,6 +11,7 @@
 #include "ccsim_persist.h"
 #include "ccsim_multi.h"
 #include "ccsim_coupled.h"
+#include "ccsim_sampled.h"
 
 #include <dlfcn.h>
 #include <errno.h>
@@ -190,6 +191,13 @@ struct ccsim_engine {
     size_t cw_zero_bytes = 0;
     int cw_allowed = 1;
     bool cw_run = false;                         // the current run takes the windowed path
+    // the sampled search on resident block summaries (ccsim_sampled.h): buffers of the node count's lifetime, made on first use
+    int32_t *d_sb_memo = nullptr;
+    uint32_t *d_sb_fc = nullptr, *d_sb_mx = nullptr;
+    unsigned long long *d_sb_key = nullptr;
+    int sb_shift = 0, sb_blocks = 0;
+    int sb_allowed = 1;                          // CCSIM_SB=0: the three-pass cycle (A/B and test knob)
+    bool sb_attr_set = false, sb_run = false;
     bool cw_fast = false;                        // ... and may use the lane-per-candidate decide kernel (k_cw_decide_fast)
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
@@ -293,6 +301,7 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
     if (const char *f = getenv("CCSIM_PERSIST")) e->persist_allowed = atoi(f); // A/B knob: 0 = multi-kernel batched mode
     if (const char *f = getenv("CCSIM_EAGER_WIDE")) e->lazy_wide = atoi(f) == 0;
     if (const char *f = getenv("CCSIM_CW")) e->cw_allowed = atoi(f);           // A/B knob: 0 = coupled plugins one pass per placement
+    if (const char *f = getenv("CCSIM_SB")) e->sb_allowed = atoi(f);           // A/B knob: 0 = the sampled search as three node passes per cycle
     if (const char *f = getenv("CCSIM_FUSED")) e->fused_allowed = atoi(f);     // A/B knob: 0 = sequential cycle as k_scan + k_final
     if (const char *f = getenv("CCSIM_PERSIST_VRANKS")) e->persist_vranks = atoi(f) > 1 && atoi(f) <= kPMaxRanks ? atoi(f) : 0; // validation knob
     if (hipSetDevice(e->device) != hipSuccess) {
@@ -376,6 +385,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->allocs);
+    e->d_sb_memo = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr; // (they lived in e->allocs)
     e->backups.clear();
     e->reset_pending = false, e->wide_stale = false;
     e->mb_go = -1;
@@ -1289,6 +1299,25 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     e->persist_run = (mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes) ? persist_k(e) : 0;
     // topology-coupled plugins of one template: windows of placements per pass when every node is scored (ccsim_coupled.h)
     e->cw_run = mode == CCSIM_MODE_SEQUENTIAL && e->cw_ok && e->n_ranks == 0 && e->smp_K == 0 && !e->time_passes && e->n > 0;
+    // the sampled search of a template without topology-coupled plugins: cycles on resident block summaries (ccsim_sampled.h)
+    e->sb_run = false;
+    if (mode == CCSIM_MODE_SEQUENTIAL && e->smp_K > 0 && e->n_ranks == 0 && !e->time_passes && e->sb_allowed && e->pts.n == 0 && e->soft.n == 0 && !e->ipa.on &&
+        e->global_offset == 0 && e->n_global == e->n) {
+        int sh = 8;
+        while (sh <= kSbMaxShift && ((e->n_pad + ((int64_t)1 << sh) - 1) >> sh) > kSbMaxBlocks) sh++;
+        if (sh <= kSbMaxShift) {
+            const int blocks = (int)((e->n_pad + ((int64_t)1 << sh) - 1) >> sh);
+            if (!e->d_sb_memo) {
+                int rc2;
+                if ((rc2 = dev_alloc(e, &e->d_sb_memo, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_fc, (size_t)kSbMaxBlocks, e->allocs)) ||
+                    (rc2 = dev_alloc(e, &e->d_sb_key, (size_t)kSbMaxBlocks, e->allocs)) || (rc2 = dev_alloc(e, &e->d_sb_mx, (size_t)kSbMaxBlocks, e->allocs)))
+                    return rc2;
+            }
+            e->sb_shift = sh, e->sb_blocks = blocks, e->sb_run = true;
+            e->h_state->sb_dirty = 1; // nothing is known about the columns under the run's maxima yet
+            HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+        }
+    }
     if (e->cw_run) HIPCHK(e, hipMemsetAsync(e->cw_zero_base, 0, e->cw_zero_bytes, e->stream));
     const bool rows = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !e->persist_run;
     if (rows != e->rows_active) drop_graph(e);
@@ -1794,6 +1823,43 @@ static int run_cw(ccsim_engine *e) {
     }
 }
 
+// ---- the sampled search of one template without topology-coupled plugins on resident block summaries (ccsim_sampled.h) ----
+static int run_sb(ccsim_engine *e) {
+    static_assert(sizeof(SbLds) <= 160 * 1024, "k_sb_cycles' LDS image must fit one CU");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!e->sb_attr_set) {
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
+        e->sb_attr_set = true;
+    }
+    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, 1024};
+    if (const char *f = getenv("CCSIM_SB_CYCLES")) a.max_cycles = atoi(f) > 0 ? atoi(f) : a.max_cycles; // tuning / test knob: cycles per launch
+    int idle = 0;
+    for (;;) {
+        const int64_t placed0 = e->h_state->placed;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        for (int rep = 0; rep < 4; rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
+            if (e->cols.narrow && e->pod.nx == 0) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            hipLaunchKernelGGL(k_sb_cycles, dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
+        }
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        int rc = read_state(e);
+        if (rc) return rc;
+        float ms = 0;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->kernel_ms += ms;
+        if (getenv("CCSIM_SB_DEBUG"))
+            fprintf(stderr, "[ccsim sb] placed %lld rounds %lld scans %lld done %d dirty %d mt_a %d ma_a %d start %lld launches %d K %lld blocks %d shift %d\n", (long long)e->h_state->placed,
+                    (long long)e->h_state->rounds, (long long)e->h_state->scans, e->h_state->done, e->h_state->sb_dirty, e->h_state->mt_a, e->h_state->ma_a,
+                    (long long)e->h_state->smp_start, e->h_state->sb_cycles, (long long)e->h_state->smp_K, e->sb_blocks, e->sb_shift);
+        e->pass_launches = e->h_state->sb_cycles; // (ccsim_report.pass_launches: launches of the cycle kernel that ran -- 0 on every other path of the sampled search)
+        if (e->h_state->done) return 0;
+        idle = e->h_state->placed == placed0 ? idle + 1 : 0;
+        if (idle >= 4) return fail(e, -EIO, "sampled search made no progress in %d launches", 16);
+    }
+}
+
 extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
     if (!e || !out) return -EINVAL;
     out->stop_spec = -1;
@@ -1829,6 +1895,10 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         if ((rc = run_cw(e))) return rc;
         if (e->h_state->done) return fill_report(e, out);
         // (cw_fallback: the windowed mode cannot represent this run -- the one-pass-per-placement loop below continues it)
+    }
+    if (e->sb_run) { // begin_run chose the resident form of the sampled search
+        if ((rc = run_sb(e))) return rc;
+        return fill_report(e, out);
     }
     int rps = e->rounds_per_sync > 0 ? e->rounds_per_sync : (mode == CCSIM_MODE_BATCHED ? 64 : 256);
     for (;;) {

@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds_raw[];
     SbLds &L = *reinterpret_cast<SbLds *>(sb_lds_raw);
     DevState &S = *a.st;
-    if (S.done || S.sb_dirty) return; // (dirty: the maxima moved and nobody rebuilt -- the host's loop enqueues k_sb_build first)
+    if (S.done) return;
+    // (DevState::sb_dirty: k_sb_build is enqueued in front of every launch of this kernel and has rebuilt memo and summaries if the flag
+    // was set -- under the maxima this launch reads below; the flag is cleared at the end of this launch unless the maxima moved again)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = a.n_blocks, B = 1 << a.shift, sh = a.shift;
     const int64_t N = a.c.n;
@@ -348,7 +350,8 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
     if (tid == 0) {
         S.smp_start = start, S.placed = placed, S.rounds = rounds, S.scans = scans, S.evaluated = evaluated, S.winner = winner;
         S.last_feasible = last_feasible, S.last_evaluated = last_evaluated, S.done = done;
-        if (dirty) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma, S.sb_dirty = 1;
+        S.sb_dirty = dirty;
+        if (dirty) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
         S.sb_cycles += 1;
     }
 }

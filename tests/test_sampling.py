@@ -21,6 +21,13 @@ def _check(ccref, nodes, pod, prof, limit):
     assert np.array_equal(got.per_node_count, ref.per_node_count)
     assert got.evaluated_total == ref.evaluated_total  # the same nodes were visited, cycle by cycle
     assert got.last_feasible == ref.last_feasible
+    # which form ran: a template without topology-coupled plugins takes the resident block summaries (csrc/ccsim_sampled.h, round 5) when
+    # the search really samples; everything else (and CCSIM_SB=0) the three node passes per cycle
+    import os
+    sampled = ccref.num_feasible_nodes_to_find(prof.percentage_of_nodes_to_score, nodes.n) < nodes.n or not (prof.w_taint or prof.w_nodeaffinity or prof.w_fit or prof.w_balanced
+                                                                                                        or prof.w_imagelocality or prof.w_topologyspread or prof.w_interpodaffinity)
+    resident = sampled and not pod.spread and pod.ipa is None and os.environ.get("CCSIM_SB", "1") != "0"
+    assert (got.pass_launches > 0) == resident, (got.pass_launches, resident)
     if ref.stop == M.STOP_UNSCHEDULABLE:
         assert np.array_equal(got.hist, ref.hist)
         assert got.n_code_unschedulable == ref.n_code_unschedulable
@@ -42,6 +49,28 @@ def test_sampled_search_vs_oracle(ccref, cfg, n, pct, limit):
     k = ccref.num_feasible_nodes_to_find(pct, n)
     if k < n:
         assert got.evaluated_total < (got.placed + 1) * n  # the search really stopped early
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{"CCSIM_SB": "0"}, {"CCSIM_SB_CYCLES": "3"}, {"CCSIM_SB_CYCLES": "1"}], ids=["three-passes", "3-cycles-per-launch", "1-cycle-per-launch"])
+@pytest.mark.parametrize("cfg,n,pct,limit", [("C3", 1000, 0, 0), ("C2", 5000, 10, 400), ("C3", 4096, 5, 0), ("C3", 777, 35, 0)])
+def test_sampled_search_forms_agree(ccref, monkeypatch, knobs, cfg, n, pct, limit):
+    """The three-pass cycle (what the SchedulePod seam, shards and coupled templates still take) and the resident form relaunched every few
+    cycles (the hand-over of the pending block summary, the start index, the assumed maxima between launches) against the oracle."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
+    _check(ccref, nodes, pod, _with_pct(prof, pct), limit)
+
+
+@pytest.mark.gpu
+def test_sampled_search_1m_nodes_adaptive_default(ccref):
+    """BASELINE's headline snapshot under the reference's DEFAULT configuration (percentageOfNodesToScore 0 -> 5 % at 1M nodes: K = 50 000
+    of the rotating visiting order per cycle, schedule_one.go:697-723): 3 000 cycles against the oracle's visiting loop."""
+    nodes, pod, prof = synth.make_config("C4", n_nodes=1_000_000)
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, 0), 3000)
+    assert got.evaluated_total < 3000 * 80_000  # (K = 50 000 kept + the infeasible nodes met on the way: far from every node)
+    e.close()
 
 
 @pytest.mark.gpu
