@@ -1828,7 +1828,8 @@ static int run_sb(ccsim_engine *e) {
     static_assert(sizeof(SbLds) <= 160 * 1024, "k_sb_cycles' LDS image must fit one CU");
     HIPCHK(e, hipSetDevice(e->device));
     if (!e->sb_attr_set) {
-        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
         e->sb_attr_set = true;
     }
     SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, 1024};
@@ -1838,9 +1839,13 @@ static int run_sb(ccsim_engine *e) {
         const int64_t placed0 = e->h_state->placed;
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         for (int rep = 0; rep < 4; rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
-            if (e->cols.narrow && e->pod.nx == 0) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
-            else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
-            hipLaunchKernelGGL(k_sb_cycles, dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
+            if (e->cols.narrow && e->pod.nx == 0) {
+                hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+                hipLaunchKernelGGL((k_sb_cycles<true>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
+            } else {
+                hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+                hipLaunchKernelGGL((k_sb_cycles<false>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
+            }
         }
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));

@@ -25,10 +25,10 @@
 
 namespace ccsim {
 
-constexpr int kSbThreads = 1024;
+constexpr int kSbThreads = 256;
 constexpr int kSbWaves = kSbThreads / 64;
 constexpr int kSbMaxBlocks = 8192; // block summaries resident in LDS (128 KiB)
-constexpr int kSbMaxShift = 10;    // a block is at most 1024 nodes = one node per thread of the cycle kernel
+constexpr int kSbMaxShift = 10;    // a block is at most 1024 nodes = four consecutive nodes per thread of the cycle kernel
 
 struct SbArgs {
     DevCols c;
@@ -101,42 +101,35 @@ struct SbLds {
     uint32_t fc[kSbMaxBlocks];
     unsigned long long key[kSbMaxBlocks];
     uint32_t mx[kSbMaxBlocks];
-    uint32_t w_a[kSbWaves], w_b[kSbWaves], w_c[kSbWaves], w_d[kSbWaves]; // per-wave partial sums (two uses per cycle: parity-free, a barrier separates them)
-    unsigned long long w_key[kSbWaves];
+    // per-wave partials (one barrier between writing and reading each group; the groups alternate by use)
+    uint32_t w_ct[kSbWaves], w_ch[kSbWaves], w_ls[kSbWaves], w_pf[kSbWaves], w_pmt[kSbWaves], w_pma[kSbWaves], w_ce[kSbWaves];
+    unsigned long long w_pk[kSbWaves], w_key[kSbWaves];
     uint32_t w_mt[kSbWaves], w_ma[kSbWaves];
     long long w_stop[kSbWaves];
     // what one thread found and every thread needs
     int32_t cross_r, cross_need;
-    int32_t nm, nm_feas_delta; // the winner's new memo word; -1 if it left the feasible nodes
-    long long nm_idx;
-    int32_t flag;
+    int32_t nm;        // the last winner's new memo word (-1: it left the feasible nodes)
+    long long nm_idx;  // ... and its index
 };
 
 __device__ __forceinline__ int32_t ld_memo(const int32_t *p) { return (int32_t)__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// exclusive prefix of `v` over the workgroup's threads, and the total: wave scan + the waves' totals through `ws` (the caller's barrier
-// discipline: one __syncthreads inside; `ws` must not be in use)
-__device__ __forceinline__ uint32_t sb_excl_scan(uint32_t v, uint32_t *ws, uint32_t *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t sb_wave_incl(uint32_t v) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
-        inc += lane >= off ? o : 0u;
+        const uint32_t o = (uint32_t)__shfl_up((int)v, off);
+        v += lane >= off ? o : 0u;
     }
-    if (lane == 63) ws[wave] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < kSbWaves; w++) {
-        const uint32_t t = ws[w];
-        before += w < wave ? t : 0u, all += t;
-    }
-    *total = all;
-    return before + inc - v;
+    return v;
 }
 
-// k_sb_cycles: up to max_cycles scheduling cycles in ONE workgroup.
+// k_sb_cycles: up to max_cycles scheduling cycles in ONE workgroup of 256 threads.  A block's nodes are dealt to the threads in
+// runs of NP = block / 256 consecutive nodes (index order = thread order, then position in the run).  Five barriers and two
+// dependent trips to L2 per cycle: the start block of the NEXT cycle and the winner's block are fetched while one thread applies
+// the placement; the block the stretch ends in is the trip that cannot be known earlier.
+template <bool NARROW>
 __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds_raw[];
     SbLds &L = *reinterpret_cast<SbLds *>(sb_lds_raw);
@@ -145,46 +138,53 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
     // (DevState::sb_dirty: k_sb_build is enqueued in front of every launch of this kernel and has rebuilt memo and summaries if the flag
     // was set -- under the maxima this launch reads below; the flag is cleared at the end of this launch unless the maxima moved again)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = a.n_blocks, B = 1 << a.shift, sh = a.shift;
+    const int nb = a.n_blocks, sh = a.shift, B = 1 << sh, NP = B / kSbThreads; // NP in {1, 2, 4}
     const int64_t N = a.c.n;
     for (int b = tid; b < nb; b += kSbThreads) L.fc[b] = a.sb_fc[b], L.key[b] = a.sb_key[b], L.mx[b] = a.sb_mx[b];
     uint32_t ft = 0;
     for (int b = tid; b < nb; b += kSbThreads) ft += a.sb_fc[b];
     ft = wave_sum_u32_dpp(ft);
-    if (lane == 0) L.w_a[wave] = ft;
+    if (lane == 0) L.w_ls[wave] = ft;
     if (tid == 0) L.nm_idx = -1, L.nm = -1;
     __syncthreads();
     int64_t Ftotal = 0;
-    for (int w = 0; w < kSbWaves; w++) Ftotal += L.w_a[w];
+    for (int w = 0; w < kSbWaves; w++) Ftotal += L.w_ls[w];
     __syncthreads();
     // the run state every thread carries (updated identically from broadcast values; thread 0 writes it back)
     const int64_t K = S.smp_K, limit = S.limit, log_cap = S.log_cap;
     const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
+    const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
     int64_t start = S.smp_start, placed = S.placed, rounds = S.rounds, scans = S.scans, evaluated = S.evaluated, winner = -1;
     int32_t last_feasible = S.last_feasible, last_evaluated = S.last_evaluated, done = 0, dirty = 0;
     uint32_t new_mt = mt_a, new_ma = ma_a;
-    int64_t pend_blk = -1; // the block of the last winner: its summary is recomputed alongside the next cycle's first reads
+    int64_t pend_blk = -1; // the block of the last winner: its summary is recomputed from the words fetched while the placement was applied
     const int E = (nb - 1 + kSbThreads - 1) / kSbThreads; // full blocks per thread in the ring scan
+    constexpr int kNP = (1 << kSbMaxShift) / kSbThreads;
+    int32_t ms[kNP], mp[kNP];
+    uint32_t ws[kNP], wp[kNP];
+    // (memo words are read past the CU's vector L1: a plain load may hit a line fetched BEFORE this workgroup's own thread 0 rewrote a word
+    // of it some cycles ago -- measured: the first form of this kernel with plain loads placed differently near the end of whole runs,
+    // where the same few blocks are read again and again)
+    auto fetch = [&](int64_t blk, int32_t *m, uint32_t *w) {
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            m[j] = -1, w[j] = 0;
+            const int64_t i = (blk << sh) + (int64_t)tid * NP + j;
+            if (j < NP && i < a.c.n_pad) m[j] = ld_memo(a.memo + i), w[j] = a.c.stat[i];
+        }
+    };
+    fetch(start >> sh, ms, ws);
+#pragma unroll
+    for (int j = 0; j < kNP; j++) mp[j] = -1, wp[j] = 0;
 
     for (int cyc = 0; cyc < a.max_cycles && !done && !dirty; cyc++) {
         if (Ftotal == 0) { // schedule_one.go:448-454: every node was visited, none passed
             done = DONE_UNSCHEDULABLE, rounds += 1, scans += 1, last_feasible = 0, last_evaluated = (int32_t)N, evaluated += N, winner = -1;
             break;
         }
-        const int sb = (int)(start >> sh), so = (int)(start & (B - 1));
-        if (tid == 0) L.cross_r = -1; // (read after the barriers of the scans below)
-        // ---- the start block, node by node (thread t = node t of the block); and the summary of the last winner's block
-        const int64_t i_s = ((int64_t)sb << sh) + tid;
-        int32_t m_s = -1;
-        uint32_t w_s = 0;
-        if (tid < B && i_s < a.c.n_pad) m_s = i_s == L.nm_idx ? L.nm : ld_memo(a.memo + i_s), w_s = a.c.stat[i_s];
-        int32_t m_p = -1;
-        uint32_t w_p = 0;
-        int64_t i_p = -1;
-        if (pend_blk >= 0) {
-            i_p = (pend_blk << sh) + tid;
-            if (tid < B && i_p < a.c.n_pad) m_p = i_p == L.nm_idx ? L.nm : ld_memo(a.memo + i_p), w_p = a.c.stat[i_p];
-        }
+        const int sb = (int)(start >> sh);
+        const int64_t i_s0 = ((int64_t)sb << sh) + (int64_t)tid * NP; // this thread's first node of the start block
+        if (tid == 0) L.cross_r = -1;
         // ---- ring scan over the full blocks: entry r = 1 .. nb - 1 is block (sb + r) mod nb
         const int r_lo = tid * E + 1, r_hi = (tid + 1) * E < nb - 1 ? (tid + 1) * E : nb - 1;
         uint32_t ls = 0;
@@ -193,33 +193,52 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             b = b >= nb ? b - nb : b;
             ls += L.fc[b];
         }
-        // feasible nodes of the start block behind / before the start index, and every thread's rank among them
-        const bool f_s = m_s >= 0, tail_s = tid >= so;
-        uint32_t tailF = 0, headF = 0, fullF = 0;
-        const uint32_t rk_tail = sb_excl_scan(f_s && tail_s ? 1u : 0u, L.w_a, &tailF);
-        // (the three scans share one barrier each: their wave totals live in separate arrays)
-        const uint32_t rk_head = sb_excl_scan(f_s && !tail_s ? 1u : 0u, L.w_b, &headF);
-        const uint32_t ex = sb_excl_scan(ls, L.w_c, &fullF);
-        // ---- the summary of the last winner's block (its loads have landed by now)
-        if (pend_blk >= 0) {
-            uint32_t pf = m_p >= 0 ? 1u : 0u, pmt = m_p >= 0 ? (w_p >> kStatCntShift) & kStatCntMask : 0u, pma = m_p >= 0 ? w_p & kStatAffMask : 0u;
-            uint64_t pk = m_p >= 0 ? make_key((int64_t)m_p, a.c.global_offset + i_p) : 0ull;
-            pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma), pk = wave_max_u64(pk);
-            if (lane == 0) L.w_d[wave] = pf, L.w_mt[wave] = pmt, L.w_ma[wave] = pma, L.w_key[wave] = pk;
-            __syncthreads();
-            if (tid == 0) {
-                for (int w = 1; w < kSbWaves; w++) pf += L.w_d[w], pmt = L.w_mt[w] > pmt ? L.w_mt[w] : pmt, pma = L.w_ma[w] > pma ? L.w_ma[w] : pma, pk = L.w_key[w] > pk ? L.w_key[w] : pk;
-                L.fc[pend_blk] = pf, L.key[pend_blk] = pk, L.mx[pend_blk] = (pmt << 16) | pma;
-                a.sb_fc[pend_blk] = pf, a.sb_key[pend_blk] = pk, a.sb_mx[pend_blk] = (pmt << 16) | pma; // (the global copy stays current: the next launch reloads it)
+        // feasible nodes of the start block behind / before the start index among this thread's run; the pending block's partial summary
+        uint32_t ct = 0, ch = 0, pf = 0, pmt = 0, pma = 0;
+        uint64_t pk = 0;
+#pragma unroll
+        for (int j = 0; j < kNP; j++) {
+            if (ms[j] >= 0) (i_s0 + j >= start ? ct : ch) += 1u;
+            if (mp[j] >= 0) {
+                const uint32_t cnt = (wp[j] >> kStatCntShift) & kStatCntMask, aff = wp[j] & kStatAffMask;
+                pf += 1, pmt = cnt > pmt ? cnt : pmt, pma = aff > pma ? aff : pma;
+                const uint64_t k = make_key((int64_t)mp[j], (pend_blk << sh) + (int64_t)tid * NP + j);
+                pk = k > pk ? k : pk;
             }
-            __syncthreads();
-            pend_blk = -1;
+        }
+        const uint32_t ict = sb_wave_incl(ct), ich = sb_wave_incl(ch), ils = sb_wave_incl(ls);
+        if (pend_blk >= 0) pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma), pk = wave_max_u64(pk);
+        if (lane == 63) L.w_ct[wave] = ict, L.w_ch[wave] = ich, L.w_ls[wave] = ils;
+        if (lane == 0 && pend_blk >= 0) L.w_pf[wave] = pf, L.w_pmt[wave] = pmt, L.w_pma[wave] = pma, L.w_pk[wave] = pk;
+        __syncthreads(); // ---- barrier 1
+        uint32_t tailF = 0, headF = 0, fullF = 0, bt = 0, bh = 0, bl = 0;
+#pragma unroll
+        for (int w = 0; w < kSbWaves; w++) {
+            const uint32_t x = L.w_ct[w], y = L.w_ch[w], z = L.w_ls[w];
+            tailF += x, headF += y, fullF += z;
+            bt += w < wave ? x : 0u, bh += w < wave ? y : 0u, bl += w < wave ? z : 0u;
+        }
+        const uint32_t rk_tail0 = bt + ict - ct, rk_head0 = bh + ich - ch, ex = bl + ils - ls; // exclusive prefixes over the threads
+        // the pending block's summary: every thread holds it (the walk below meets the block in some thread), thread 0 files it
+        uint32_t P_fc = 0, P_mx = 0;
+        uint64_t P_key = 0;
+        if (pend_blk >= 0) {
+            uint32_t qmt = 0, qma = 0;
+#pragma unroll
+            for (int w = 0; w < kSbWaves; w++) {
+                P_fc += L.w_pf[w], qmt = L.w_pmt[w] > qmt ? L.w_pmt[w] : qmt, qma = L.w_pma[w] > qma ? L.w_pma[w] : qma;
+                P_key = L.w_pk[w] > P_key ? L.w_pk[w] : P_key;
+            }
+            P_mx = (qmt << 16) | qma;
+            if (tid == 0) {
+                L.fc[pend_blk] = P_fc, L.key[pend_blk] = P_key, L.mx[pend_blk] = P_mx;
+                a.sb_fc[pend_blk] = P_fc, a.sb_key[pend_blk] = P_key, a.sb_mx[pend_blk] = P_mx; // (the global copy stays current: the next launch reloads it)
+            }
         }
         // ---- where does the stretch end?  (uniform: every thread holds the same totals)
         const bool all = Ftotal <= K; // fewer feasible nodes than wanted: the search visits every node (:538: processed = N)
         int mode = 0; // 0 all, 1 the (K+1)-th feasible node is behind the start index in the start block, 2 in a full block, 3 before the start index in the start block
         if (!all) mode = (int64_t)tailF >= K + 1 ? 1 : ((int64_t)tailF + fullF >= K + 1 ? 2 : 3);
-        // (fullF: every block but the start block; tailF + fullF + headF == Ftotal)
         uint64_t best = 0;
         uint32_t cmt = 0, cma = 0;
         int64_t stop = -1;
@@ -231,14 +250,23 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             cmt = cnt > cmt ? cnt : cmt, cma = aff > cma ? aff : cma;
         };
         // the start block's share
-        if (f_s && tail_s) {
-            if (mode != 1 || (int64_t)rk_tail < K) take_node(m_s, w_s, i_s);
-            else if ((int64_t)rk_tail == K) stop = i_s;
-        }
-        if (f_s && !tail_s && (mode == 0 || mode == 3)) {
-            const int64_t need = K - ((int64_t)tailF + fullF); // (mode 3: how many of them are among the first K)
-            if (mode == 0 || (int64_t)rk_head < need) take_node(m_s, w_s, i_s);
-            else if ((int64_t)rk_head == need) stop = i_s;
+        {
+            const int64_t need_head = K - ((int64_t)tailF + fullF); // (mode 3: how many of the nodes before the start index are among the first K)
+            uint32_t rt = rk_tail0, rh = rk_head0;
+#pragma unroll
+            for (int j = 0; j < kNP; j++)
+                if (ms[j] >= 0) {
+                    const int64_t i = i_s0 + j;
+                    if (i >= start) {
+                        if (mode != 1 || (int64_t)rt < K) take_node(ms[j], ws[j], i);
+                        else if ((int64_t)rt == K) stop = i;
+                        rt += 1;
+                    } else {
+                        if (mode == 0 || (mode == 3 && (int64_t)rh < need_head)) take_node(ms[j], ws[j], i);
+                        else if (mode == 3 && (int64_t)rh == need_head) stop = i;
+                        rh += 1;
+                    }
+                }
         }
         // the full blocks' share: whole blocks inside the stretch by their summaries; the one the stretch ends in is found here
         if (mode != 1) {
@@ -246,13 +274,14 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             for (int r = r_lo; r <= r_hi; r++) {
                 int b = sb + r;
                 b = b >= nb ? b - nb : b;
-                const int64_t f = L.fc[b];
+                const bool pend = b == pend_blk;
+                const int64_t f = pend ? P_fc : L.fc[b];
                 if (mode == 0 || mode == 3 || run + f <= K) {
-                    const uint64_t k = L.key[b];
+                    const uint64_t k = pend ? P_key : (uint64_t)L.key[b];
                     if (k) {
-                        const uint64_t rk = ((uint64_t)(key_score(k) + 1) << kIdxBits) | (kIdxMask - (uint64_t)ringpos(key_index(k) - a.c.global_offset));
+                        const uint64_t rk = ((uint64_t)(key_score(k) + 1) << kIdxBits) | (kIdxMask - (uint64_t)ringpos(key_index(k)));
                         best = rk > best ? rk : best;
-                        const uint32_t x = L.mx[b];
+                        const uint32_t x = pend ? P_mx : L.mx[b];
                         cmt = (x >> 16) > cmt ? (x >> 16) : cmt, cma = (x & 0xffffu) > cma ? (x & 0xffffu) : cma;
                     }
                 } else if (run <= K) { // run <= K < run + f: the (K+1)-th feasible node of the visiting order is in this block
@@ -261,20 +290,35 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
                 run += f;
             }
         }
-        __syncthreads();
-        if (mode == 2) { // the block the stretch ends in, node by node
+        pend_blk = -1;
+        __syncthreads(); // ---- barrier 2
+        if (mode == 2) { // the block the stretch ends in, node by node: the one trip to L2 nothing could have started earlier
             int b = sb + L.cross_r;
             b = b >= nb ? b - nb : b;
-            const int64_t i_e = ((int64_t)b << sh) + tid;
-            int32_t m_e = -1;
-            uint32_t w_e = 0;
-            if (tid < B && i_e < a.c.n_pad) m_e = i_e == L.nm_idx ? L.nm : ld_memo(a.memo + i_e), w_e = a.c.stat[i_e];
-            uint32_t tot = 0;
-            const uint32_t rk_e = sb_excl_scan(m_e >= 0 ? 1u : 0u, L.w_a, &tot);
-            if (m_e >= 0) {
-                if ((int32_t)rk_e < L.cross_need) take_node(m_e, w_e, i_e);
-                else if ((int32_t)rk_e == L.cross_need) stop = i_e;
+            int32_t me[kNP];
+            uint32_t we[kNP];
+            fetch(b, me, we);
+            const int64_t i_e0 = ((int64_t)b << sh) + (int64_t)tid * NP;
+            uint32_t ce = 0;
+#pragma unroll
+            for (int j = 0; j < kNP; j++) {
+                if (j < NP && i_e0 + j == L.nm_idx) me[j] = L.nm;
+                ce += me[j] >= 0 ? 1u : 0u;
             }
+            const uint32_t ice = sb_wave_incl(ce);
+            if (lane == 63) L.w_ce[wave] = ice;
+            __syncthreads(); // ---- barrier 3
+            uint32_t re = ice - ce;
+#pragma unroll
+            for (int w = 0; w < kSbWaves; w++) re += w < wave ? L.w_ce[w] : 0u;
+            const int32_t need = L.cross_need;
+#pragma unroll
+            for (int j = 0; j < kNP; j++)
+                if (me[j] >= 0) {
+                    if ((int32_t)re < need) take_node(me[j], we[j], i_e0 + j);
+                    else if ((int32_t)re == need) stop = i_e0 + j;
+                    re += 1;
+                }
         }
         // ---- the cycle's argmax, the maxima over the kept nodes, the node the search stopped at
         best = wave_max_u64(best), cmt = wave_max_u32(cmt), cma = wave_max_u32(cma);
@@ -282,7 +326,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             const uint64_t sp = wave_max_u64((uint64_t)(stop + 1));
             if (lane == 0) L.w_key[wave] = best, L.w_mt[wave] = cmt, L.w_ma[wave] = cma, L.w_stop[wave] = (long long)sp;
         }
-        __syncthreads();
+        __syncthreads(); // ---- barrier 4
         uint64_t sp1 = 0;
 #pragma unroll
         for (int w = 0; w < kSbWaves; w++) {
@@ -295,55 +339,78 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             new_mt = cmt, new_ma = cma, dirty = 1;
             break;
         }
-        // ---- commit (schedule_one.go:967-984 assume -> NodeInfo.update): one thread, its loads issued together
+        // ---- commit (schedule_one.go:967-984 assume -> NodeInfo.update) by one thread, while every thread fetches what the next cycle
+        // starts with: its start block, and the winner's block for the summary
         const int64_t g_ring = (int64_t)(kIdxMask - (best & kIdxMask));
         int64_t g = start + g_ring;
         g = g >= N ? g - N : g;
         const int64_t visited = all ? N : ringpos(stop);
+        if (!all) start = stop;
+        pend_blk = g >> sh;
+        fetch(start >> sh, ms, ws);
+        fetch(pend_blk, mp, wp);
         if (tid == 0) {
-            const int64_t i = g - a.c.global_offset;
+            const int64_t i = g;
             NodeRegs<kMaxExtra> nd;
+            int32_t na0 = 0, na1 = 0;
+            // The node may have won before in THIS launch: its columns were rewritten by this very thread, and the CU's vector L1 does not
+            // take a store's data -- a plain load would hit the line as it was fetched for the earlier placement and the update below
+            // would be lost (measured: with the 6 KB a cycle of this kernel reads, such lines survive; placements went astray after a
+            // node's second clone in one launch).  Acquire at agent scope = invalidate the L1 before the row is read.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (NARROW) na0 = a.c.a32[0][i], na1 = a.c.a32[1][i];
             load_one<kMaxExtra>(a.c, a.p, i, nd);
             node_apply<kMaxExtra>(a.p, nd, 1);
             store_dyn<kMaxExtra>(a.c, a.p, i, nd, 1);
-#pragma unroll 1
-            for (int col = 2; col < a.p.ncol; col++) { // (columns the pod requests but that are no slot of the Fit test: kept current like decide_commit does)
-                bool slot = false;
-                for (int x = 0; x < a.p.nx; x++) slot = slot || a.p.xcol[x] == col;
-                if (!slot && a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
-            }
-            const int32_t nm = sb_node_score(a.p, nd, mt_a, ma_a);
+            int32_t nm;
+            if (NARROW) { // (the lossless mirrors: the same number as the wide path, ccsim_kernels.h "NARROW arithmetic")
+                const int32_t nr0 = (int32_t)nd.r_cpu, nr1 = (int32_t)(nd.r_mem >> a.c.mem_shift), nz0 = (int32_t)nd.z_cpu, nz1 = (int32_t)(nd.z_mem >> a.c.mem_shift);
+                nm = -1;
+                if ((nd.w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, nd.a_pods, nd.npods)) {
+                    const uint32_t cnt = (nd.w >> kStatCntShift) & kStatCntMask, aff = nd.w & kStatAffMask, img = (nd.w >> kStatImgShift) & kStatImgMask;
+                    nm = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) + dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1));
+                }
+            } else
+                nm = sb_node_score(a.p, nd, mt_a, ma_a);
             __hip_atomic_store((uint32_t *)(a.memo + i), (uint32_t)nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence(); // (later cycles read the word from L2; the next one takes it from L.nm)
+            __threadfence(); // (the word must have reached L2 before the barrier lets other waves fetch its block again)
             L.nm = nm, L.nm_idx = i;
+            if (nm < 0) L.fc[pend_blk] -= 1; // (the ring scan of the next cycle reads it; the summary proper follows from the words fetched above)
             if (a.log && placed < log_cap) a.log[placed] = (int32_t)g;
         }
-        __syncthreads();
+        __syncthreads(); // ---- barrier 5
         const int32_t nm = L.nm;
-        pend_blk = (g - a.c.global_offset) >> sh;
-        if (nm < 0) { // the winner is full: one feasible node less, in its block and in the cluster (the ring scan of the next cycle reads both)
-            Ftotal -= 1;
-            if (tid == 0) L.fc[pend_blk] -= 1;
+        {   // the words fetched above predate the placement: the winner's own is the one thread 0 has just computed
+            const int64_t i_n0 = ((start >> sh) << sh) + (int64_t)tid * NP, i_p0 = (pend_blk << sh) + (int64_t)tid * NP;
+#pragma unroll
+            for (int j = 0; j < kNP; j++) {
+                if (j < NP && i_n0 + j == g) ms[j] = nm;
+                if (j < NP && i_p0 + j == g) mp[j] = nm;
+            }
         }
+        if (nm < 0) Ftotal -= 1;
         placed += 1, rounds += 1, winner = g, evaluated += visited, last_evaluated = (int32_t)visited;
         last_feasible = (int32_t)(all ? Ftotal + (nm < 0 ? 1 : 0) : K);
-        if (!all) start = stop;
         if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312
-        __syncthreads();
     }
     // the last winner's block summary, if it is still pending
     if (pend_blk >= 0) {
-        const int64_t i_p = (pend_blk << sh) + tid;
-        int32_t m_p = -1;
-        uint32_t w_p = 0;
-        if (tid < B && i_p < a.c.n_pad) m_p = i_p == L.nm_idx ? L.nm : ld_memo(a.memo + i_p), w_p = a.c.stat[i_p];
-        uint32_t pf = m_p >= 0 ? 1u : 0u, pmt = m_p >= 0 ? (w_p >> kStatCntShift) & kStatCntMask : 0u, pma = m_p >= 0 ? w_p & kStatAffMask : 0u;
-        uint64_t pk = m_p >= 0 ? make_key((int64_t)m_p, a.c.global_offset + i_p) : 0ull;
+        uint32_t pf = 0, pmt = 0, pma = 0;
+        uint64_t pk = 0;
+#pragma unroll
+        for (int j = 0; j < kNP; j++)
+            if (mp[j] >= 0) {
+                const uint32_t cnt = (wp[j] >> kStatCntShift) & kStatCntMask, aff = wp[j] & kStatAffMask;
+                pf += 1, pmt = cnt > pmt ? cnt : pmt, pma = aff > pma ? aff : pma;
+                const uint64_t k = make_key((int64_t)mp[j], (pend_blk << sh) + (int64_t)tid * NP + j);
+                pk = k > pk ? k : pk;
+            }
         pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma), pk = wave_max_u64(pk);
-        if (lane == 0) L.w_d[wave] = pf, L.w_mt[wave] = pmt, L.w_ma[wave] = pma, L.w_key[wave] = pk;
+        __syncthreads();
+        if (lane == 0) L.w_pf[wave] = pf, L.w_pmt[wave] = pmt, L.w_pma[wave] = pma, L.w_pk[wave] = pk;
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < kSbWaves; w++) pf += L.w_d[w], pmt = L.w_mt[w] > pmt ? L.w_mt[w] : pmt, pma = L.w_ma[w] > pma ? L.w_ma[w] : pma, pk = L.w_key[w] > pk ? L.w_key[w] : pk;
+            for (int w = 1; w < kSbWaves; w++) pf += L.w_pf[w], pmt = L.w_pmt[w] > pmt ? L.w_pmt[w] : pmt, pma = L.w_pma[w] > pma ? L.w_pma[w] : pma, pk = L.w_pk[w] > pk ? L.w_pk[w] : pk;
             a.sb_fc[pend_blk] = pf, a.sb_key[pend_blk] = pk, a.sb_mx[pend_blk] = (pmt << 16) | pma;
         }
     }
