@@ -108,8 +108,9 @@ struct SbLds {
     long long w_stop[kSbWaves];
     // what one thread found and every thread needs
     int32_t cross_r, cross_need;
-    int32_t nm;        // the last winner's new memo word (-1: it left the feasible nodes)
-    long long nm_idx;  // ... and its index
+    int32_t nm, nm2;           // the new memo words of the last winner and of the one before (-1: it left the feasible nodes)
+    long long nm_idx, nm2_idx; // ... and their indices.  (A memo store is certain to be in L2 only two barriers-5 later: the thread that
+                               // made it fences at the start of its NEXT commit, off the path every other wave waits on.)
 };
 
 __device__ __forceinline__ int32_t ld_memo(const int32_t *p) { return (int32_t)__hip_atomic_load((const uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
     for (int b = tid; b < nb; b += kSbThreads) ft += a.sb_fc[b];
     ft = wave_sum_u32_dpp(ft);
     if (lane == 0) L.w_ls[wave] = ft;
-    if (tid == 0) L.nm_idx = -1, L.nm = -1;
+    if (tid == 0) L.nm_idx = -1, L.nm = -1, L.nm2_idx = -1, L.nm2 = -1;
     __syncthreads();
     int64_t Ftotal = 0;
     for (int w = 0; w < kSbWaves; w++) Ftotal += L.w_ls[w];
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
         // the full blocks' share: whole blocks inside the stretch by their summaries; the one the stretch ends in is found here
         if (mode != 1) {
             int64_t run = (int64_t)tailF + ex;
+            uint64_t bk = 0; // the best summary key among this thread's blocks: its entries follow the ring, so on equal scores the first one stands
             for (int r = r_lo; r <= r_hi; r++) {
                 int b = sb + r;
                 b = b >= nb ? b - nb : b;
@@ -279,8 +281,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
                 if (mode == 0 || mode == 3 || run + f <= K) {
                     const uint64_t k = pend ? P_key : (uint64_t)L.key[b];
                     if (k) {
-                        const uint64_t rk = ((uint64_t)(key_score(k) + 1) << kIdxBits) | (kIdxMask - (uint64_t)ringpos(key_index(k)));
-                        best = rk > best ? rk : best;
+                        bk = (k >> kIdxBits) > (bk >> kIdxBits) ? k : bk;
                         const uint32_t x = pend ? P_mx : L.mx[b];
                         cmt = (x >> 16) > cmt ? (x >> 16) : cmt, cma = (x & 0xffffu) > cma ? (x & 0xffffu) : cma;
                     }
@@ -288,6 +289,10 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
                     L.cross_r = r, L.cross_need = (int32_t)(K - run);
                 }
                 run += f;
+            }
+            if (bk) {
+                const uint64_t rk = ((uint64_t)(key_score(bk) + 1) << kIdxBits) | (kIdxMask - (uint64_t)ringpos(key_index(bk)));
+                best = rk > best ? rk : best;
             }
         }
         pend_blk = -1;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             uint32_t ce = 0;
 #pragma unroll
             for (int j = 0; j < kNP; j++) {
-                if (j < NP && i_e0 + j == L.nm_idx) me[j] = L.nm;
+                if (j < NP && i_e0 + j == L.nm_idx) me[j] = L.nm; // (the store before that one was fenced before the last barrier)
                 ce += me[j] >= 0 ? 1u : 0u;
             }
             const uint32_t ice = sb_wave_incl(ce);
@@ -356,7 +361,9 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             // The node may have won before in THIS launch: its columns were rewritten by this very thread, and the CU's vector L1 does not
             // take a store's data -- a plain load would hit the line as it was fetched for the earlier placement and the update below
             // would be lost (measured: with the 6 KB a cycle of this kernel reads, such lines survive; placements went astray after a
-            // node's second clone in one launch).  Acquire at agent scope = invalidate the L1 before the row is read.
+            // node's second clone in one launch).  Acquire at agent scope = invalidate the L1 before the row is read.  The release in
+            // front of it waits for the LAST cycle's stores (long done by now): from the coming barrier on, that cycle's memo word is in L2.
+            __threadfence();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (NARROW) na0 = a.c.a32[0][i], na1 = a.c.a32[1][i];
             load_one<kMaxExtra>(a.c, a.p, i, nd);
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             } else
                 nm = sb_node_score(a.p, nd, mt_a, ma_a);
             __hip_atomic_store((uint32_t *)(a.memo + i), (uint32_t)nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence(); // (the word must have reached L2 before the barrier lets other waves fetch its block again)
+            L.nm2 = L.nm, L.nm2_idx = L.nm_idx;
             L.nm = nm, L.nm_idx = i;
             if (nm < 0) L.fc[pend_blk] -= 1; // (the ring scan of the next cycle reads it; the summary proper follows from the words fetched above)
             if (a.log && placed < log_cap) a.log[placed] = (int32_t)g;
@@ -382,8 +389,12 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
         const int32_t nm = L.nm;
         {   // the words fetched above predate the placement: the winner's own is the one thread 0 has just computed
             const int64_t i_n0 = ((start >> sh) << sh) + (int64_t)tid * NP, i_p0 = (pend_blk << sh) + (int64_t)tid * NP;
+            const int64_t g2 = L.nm2_idx; // (the winner before: its word may not have reached L2 when the fetches above were issued)
+            const int32_t nm2 = L.nm2;
 #pragma unroll
             for (int j = 0; j < kNP; j++) {
+                if (j < NP && i_n0 + j == g2) ms[j] = nm2;
+                if (j < NP && i_p0 + j == g2) mp[j] = nm2;
                 if (j < NP && i_n0 + j == g) ms[j] = nm;
                 if (j < NP && i_p0 + j == g) mp[j] = nm;
             }
