@@ -369,6 +369,9 @@ def main():
             "traffic": traffic, "traffic_source": pmc_note, "bytes_per_launch": moved,
             "bytes_definition": "HBM bytes one launch moves (PMC when available, else the kernel's designed traffic): a physical rate",
             "us_per_launch": dom_s * 1e6, "launches_timed": int(launches),
+            # what a timed step spends outside its dominant kernel: the per-node counts over PCIe (4 MB at 1M nodes),
+            # the state upload / read-back, launch and the one stream sync, the Python binding (profiles/r04/step_breakdown.txt)
+            "step_overhead_us": (dt / args.steps - dom_s * (launches if persistent else 1)) * 1e6 if persistent else None,
             "sync_bound": {
                 "what": "the persistent kernel is bound by grid-wide sync latency, not HBM: one reduce+barrier per resolved batch of score levels",
                 "syncs_per_launch": int(r.scans), "us_per_sync": dom_s * 1e6 / max(1, r.scans),
