@@ -342,11 +342,73 @@ class CoupledWindowModel:
     def raw_ipa(self, T, n):
         return sum(T["score"][k].get(self.kdom[k][n], 0) for k in range(len(self.ipa.key_cols)) if self.kdom[k][n])
 
+    # ---- sweeps (round 5, csrc/ccsim_coupled.h `sweep`): the next cycles of a window PREDICTED from the cycle at hand ----
+    def sweep_predict(self, T, minima, cand, mt, ma, budget):
+        """The kernel's rule, restated: one hard constraint over a shared key, at most one inter-pod key and that one unique per node,
+        no plugin score beside the node-local one; every candidate is a class head whose domain sits AT THE CAP of the skew test and
+        whose head counts for the constraint.  Then cycle p is won by the p-th best of the domains' best heads, for as long as the
+        loop's own stop tests -- as positions in that order -- allow.  Returns the predicted winners (possibly fewer than 2: no sweep).
+        run(audit_sweeps=True) holds every prediction against the cycles the loop then really runs."""
+        p = self.prof
+        if len(self.hard) != 1 or self.soft:
+            return []
+        i = self.hard[0]
+        c0 = self.spread[i]
+        if self.s_unique[i] or not c0.self_match:
+            return []
+        a = self.ipa
+        danti = 0
+        if a is not None:
+            if len(a.key_cols) != 1 or not self.k_unique[0] or (p.w_interpodaffinity and (T["entries"] > 0 or any(a.self_entries))):
+                return []
+            danti = sum(1 for t, k in enumerate(a.anti_keys) if k == 0 and a.anti_self[t])
+            if (self.fm & F_INTERPODAFFINITY) and ((T["aff_total"] == 0 and a.self_aff and a.aff_keys) or (T["exist_total"] == 0 and danti)):
+                return []  # the first clone of a run moves the totals from "none" to "some": the loop's business
+        if any(c is None for _, c in cand):
+            return []  # a node that already took a clone is a candidate
+        cnt_of = lambda n: T["hard"][i].get(self.sdom[i][n], 0)
+        for n, _ in cand:
+            if not (self.hard_keys[n] and self.sincl[i][n]) or cnt_of(n) + 1 - minima[i] != c0.max_skew:
+                return []
+        key = lambda n, c: (-c["list"][c["head"]][0], -n)
+        best = {}
+        for n, c in cand:
+            d = self.sdom[i][n]
+            if d not in best or key(n, c) > key(*best[d]):
+                best[d] = (n, c)
+        order = sorted(best.values(), key=lambda nc: key(*nc), reverse=True)
+        pos = {self.sdom[i][n]: q for q, (n, _) in enumerate(order)}
+        length = min(len(order), budget)
+
+        def stays(n):  # would the head stay a candidate after its clone?  (commit's `dead`)
+            if self.ports_on or self.npods[n] + 2 > self.apods[n]:
+                return False
+            if (self.fm & F_FIT) and not self.all_zero and any(self.preq[c] != 0 and 2 * self.preq[c] > self.alloc[c][n] - self.req[c][n] for c in range(self.ncol)):
+                return False
+            return not (a is not None and (self.fm & F_INTERPODAFFINITY) and danti and self.kdom[0][n])
+
+        for q, (n, _) in enumerate(order):
+            if stays(n):
+                length = min(length, q)
+                break
+        # the assumed maxima must be held by a candidate that is still feasible: the last position with a holder
+        length = min(length, 1 + max((pos[self.sdom[i][n]] for n, c in cand if c["mt"] == mt), default=-1),
+                     1 + max((pos[self.sdom[i][n]] for n, c in cand if c["ma"] == ma), default=-1))
+        # the candidate that takes the last domain at the minimum ends the round
+        vals = T["hard"][i]
+        mn = min(vals.values()) if vals else MAXINT32
+        n_at_min = sum(v == mn for v in vals.values())
+        at_min = [q for q, (n, _) in enumerate(order) if cnt_of(n) == mn]
+        if n_at_min and len(at_min) >= n_at_min:
+            length = min(length, at_min[n_at_min - 1] + 1)
+        return [n for n, _ in order[:length]] if length >= 2 else []
+
     # ---- the windowed loop ----
-    def run(self, limit=0):
+    def run(self, limit=0, audit_sweeps=False):
         N, p = self.N, self.prof
         log, scans = [], 0
-        stats = {"windows": 0, "classes_max": 0, "cut_by_maxima": 0}
+        stats = {"windows": 0, "classes_max": 0, "cut_by_maxima": 0, "swept": 0}
+        pred = []  # audit_sweeps: winners a sweep predicted for the coming cycles
         while True:
             # ===== scan: everything below is one pass over the nodes in the state at the start of the window =====
             scans += 1
@@ -391,6 +453,7 @@ class CoupledWindowModel:
                     assert minima[i] == (0 if self.n_dom[i] < self.spread[i].min_domains else mn)
                 if self.device_plan and done > 0 and any(c["nf"] > 0 and c["head"] >= len(c["list"]) for c in classes.values()):
                     stats["cut_by_list"] = stats.get("cut_by_list", 0) + 1
+                    pred = []  # (this model ends the window for ANY class with an exhausted list, the kernel only for a feasible one: a prediction may outlive it)
                     break  # a class's next head is not among the members the scan kept
                 cand = []  # (node, class or None)
                 for c in classes.values():
@@ -402,6 +465,7 @@ class CoupledWindowModel:
                     if self.node_feasible(n) and self.coupled_filter(T, minima, n):
                         cand.append((n, None))
                 if not cand:
+                    assert not pred, "a sweep predicted a cycle the loop does not run (nothing feasible)"
                     break  # nothing feasible among what the window knows: the next scan decides (it sees every node)
                 # the normalization maxima the scan assumed must be the maxima of THIS cycle's feasible set
                 if done > 0:
@@ -410,6 +474,7 @@ class CoupledWindowModel:
                     ma_now = max(c["ma"] if c is not None else self.aff[n] for n, c in cand)
                     if not known or mt_now != mt or ma_now != ma:
                         stats["cut_by_maxima"] += 1
+                        assert not pred, "a sweep predicted a cycle the loop does not run (the maxima moved)"
                         break
                 nf = sum(c["nf"] if c is not None else 1 for _, c in cand)
                 # PodTopologySpread score: weights from the candidate domains / feasible count, then min / max of the raw scores
@@ -446,6 +511,13 @@ class CoupledWindowModel:
                     if best is None or total > best[0] or (total == best[0] and n < best[1]):
                         best = (total, n, c)
                 _, w, c = best
+                if audit_sweeps and self.device_plan:
+                    if not pred and pts is None and ipa is None:
+                        pred = self.sweep_predict(T, minima, cand, mt, ma, min(self.W - done, (limit - len(log)) if limit else self.W))
+                        stats["swept"] += len(pred)
+                    if pred:
+                        assert pred[0] == w, ("a sweep predicted another winner", pred[:4], w, len(log))
+                        pred = pred[1:]
                 for i in umin:  # the winner leaves the minimum of a unique-key hard constraint
                     if self.hard_keys[w] and self.sincl[i][w] and self.spread[i].self_match and T["hard"][i].get(self.sdom[i][w], 0) == umin[i][0]:
                         umin[i][1] -= 1

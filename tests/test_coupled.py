@@ -201,7 +201,8 @@ def sweep_case(rng, n):
     kind = int(rng.choice([0, 1, 1, 2, 2]))
     if kind >= 1:  # hostname anti-affinity against the own clones: every winner leaves (BASELINE config 5's pod shape)
         blocked = (rng.random(n) < 0.05).astype(np.int32) if kind == 2 else None  # existing pods the term matches
-        pod.ipa = M.InterPodAffinity(key_cols=[hc], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[blocked])
+        pod.ipa = M.InterPodAffinity(key_cols=[hc], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[blocked], exist_anti=[None],
+                                     score_existing=[None], score_self=[0], self_entries=[0])
     else:  # winners stay candidates while they have room: give some of them room for several clones
         roomy = rng.random(n) < 0.3
         nodes.alloc_pods = np.where(roomy, nodes.alloc_pods * 4, nodes.alloc_pods).astype(np.int32)

@@ -117,3 +117,51 @@ def test_windows_save_scans(ccref):
         log, stop, s, stats = CoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=64).run(4000)
         placed, scans, cuts = placed + len(log), scans + s, cuts + stats["cut_by_maxima"]
     assert placed > 1000 and scans * 8 < placed, (placed, scans, cuts)
+
+
+# ---- round 5: sweeps (csrc/ccsim_coupled.h `sweep`): the rule that predicts a round of placements, audited against the cycles --------
+@pytest.mark.parametrize("seed", range(40))
+def test_sweep_predictions_are_the_cycles_the_loop_runs(ccref, seed):
+    """tests/coupled_model.py sweep_predict restates the kernel's rule; run(audit_sweeps=True) asserts, cycle by cycle, that every
+    predicted winner is the winner the loop then picks and that no stop test of the loop fires inside a predicted stretch -- on the
+    adversarial generator of tests/test_coupled.py::test_sweeps_random (unequal domain counts, maxSkew 1 ... 3, minDomains, nodes that
+    do not count, few holders of the normalization maxima, winners that stay / leave, limits inside a round), log == oracle's."""
+    from test_coupled import sweep_case
+    rng = np.random.default_rng(8800 + seed)
+    nodes, pod, prof = sweep_case(rng, int(rng.integers(40, 500)))
+    limit = int(rng.choice([0, 0, 37, 333]))
+    window, list_len = [(4096, 64), (64, 16), (300, 5)][seed % 3]
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    log, stop, scans, stats = CoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=window, device_plan=True, list_len=list_len).run(limit, audit_sweeps=True)
+    assert log == ref.log.tolist(), (seed, window, list_len)
+
+
+def test_sweep_predictions_cover_a_good_part_of_the_adversarial_cases(ccref):
+    """(Guard against a rule that never fires: over the generator's cases a third of the placements lie inside predicted stretches.)"""
+    from test_coupled import sweep_case
+    swept = placed = 0
+    for seed in range(0, 40, 3):
+        rng = np.random.default_rng(8800 + seed)
+        nodes, pod, prof = sweep_case(rng, int(rng.integers(40, 500)))
+        log, stop, scans, stats = CoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=4096, device_plan=True, list_len=64).run(int(rng.choice([0, 0, 37, 333])), audit_sweeps=True)
+        swept, placed = swept + stats["swept"], placed + len(log)
+    assert placed > 500 and swept > 0.15 * placed, (swept, placed)
+
+
+def test_sweeps_cover_the_config_5_pod_shape(ccref):
+    """On BASELINE config 5's pod shape (zone spread maxSkew 1 + hostname anti-affinity) the rule predicts all but a handful of cycles."""
+    rng = np.random.default_rng(5)
+    n, zones = 600, 16
+    nodes = H.simple_nodes(rng.choice([4000, 8000, 16000], n), rng.choice([8, 16, 32], n) * (1 << 30), np.full(n, 110),
+                           req_mcpu=rng.integers(0, 2000, n), req_mem=rng.integers(0, 4, n) * (1 << 30), pod_count=rng.integers(0, 20, n),
+                           label_cols=[rng.integers(1, zones + 1, n), np.arange(1, n + 1)])
+    nodes.nz_mcpu, nodes.nz_mem = nodes.req[0].copy(), nodes.req[1].copy()
+    pod = H.simple_pod(500, 1 << 30)
+    pod.spread = [M.SpreadConstraint(col=0, max_skew=1, min_domains=1, hard=True, self_match=True, n_domains=zones)]
+    pod.ipa = M.InterPodAffinity(key_cols=[1], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None], exist_anti=[None],
+                                 score_existing=[None], score_self=[0], self_entries=[0])
+    prof = M.Profile.default()
+    ref = ccref.run(prof, nodes, pod)
+    log, stop, scans, stats = CoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=1024, device_plan=True, list_len=64).run(0, audit_sweeps=True)
+    assert log == ref.log.tolist() and stop == "Unschedulable"
+    assert stats["swept"] >= 0.9 * len(log), (stats, len(log))
