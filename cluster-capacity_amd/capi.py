@@ -129,6 +129,11 @@ SYMBOLS = {
     "ccsim_dist_comm_init": (C.c_int, [C.c_void_p, _pu8, C.c_int32, C.c_int32]),
     "ccsim_dist_sync_tables": (C.c_int, [C.c_void_p]),
     "ccsim_dist_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ccsim_dist_cw_eligible": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_cw_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ccsim_dist_cw_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "ccsim_dist_cw_scan": (C.c_int, [C.c_void_p]),
+    "ccsim_dist_cw_decide": (C.c_int, [C.c_void_p]),
     "ccsim_dist_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(CReport)]),
     "ccsim_dist_mbox_info": (C.c_int, [C.c_void_p, _pu8]),
     "ccsim_dist_mbox_connect": (C.c_int, [C.c_void_p, _pu8, C.c_int32, C.c_int32]),
@@ -597,6 +602,24 @@ class Engine:
     def dist_comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
         buf = (C.c_uint8 * DIST_ID_BYTES).from_buffer_copy(unique_id)
         self._chk(self.lib.ccsim_dist_comm_init(self.h, buf, int(n_ranks), int(rank)), "ccsim_dist_comm_init")
+
+    # ---- windows of placements on shards (one template, zone spread + hostname anti-affinity): include/ccsim.h ccsim_dist_cw_*
+    def dist_cw_eligible(self) -> bool:
+        return bool(self.lib.ccsim_dist_cw_eligible(self.h))
+
+    def dist_cw_enable(self, all_ok: bool):
+        self._chk(self.lib.ccsim_dist_cw_enable(self.h, 1 if all_ok else 0), "ccsim_dist_cw_enable")
+
+    def dist_cw_buffers(self):
+        s, r, b = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._chk(self.lib.ccsim_dist_cw_buffers(self.h, C.byref(s), C.byref(r), C.byref(b)), "ccsim_dist_cw_buffers")
+        return int(s.value), int(r.value), int(b.value)
+
+    def dist_cw_scan(self):
+        self._chk(self.lib.ccsim_dist_cw_scan(self.h), "ccsim_dist_cw_scan")
+
+    def dist_cw_decide(self):
+        self._chk(self.lib.ccsim_dist_cw_decide(self.h), "ccsim_dist_cw_decide")
 
     def dist_comm_size(self):
         """(ranks, this rank) as the communicator reports them (ncclCommCount / ncclCommUserRank)."""

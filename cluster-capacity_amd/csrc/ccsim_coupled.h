@@ -52,7 +52,7 @@ constexpr int kCwThreads = 256, kCwPerThread = 4, kCwTile = kCwThreads * kCwPerT
 constexpr int kCwMaxKeys = 6400;    // k_cw_merge stages blocks x L keys of one class in LDS (32 KiB)
 constexpr int kCwLdsI32 = 4096;     // k_cw_decide: int32 words of shared-key tables (hard / soft counts, presence flags, candidate bitmaps)
 constexpr int kCwLdsI64 = 2048;     // ... int64 words (four InterPodAffinity tables per shared key)
-constexpr int kCwCtlClasses = 0, kCwCtlGiveUp = 1;
+constexpr int kCwCtlClasses = 0, kCwCtlGiveUp = 1, kCwCtlFastDone = 2;
 
 // Where each plugin input sits in the class tuple, and where its table lives in the decide kernel's LDS (host-built per pod spec).
 struct CwPlan {
@@ -106,6 +106,13 @@ struct CwWork {
     // pass at 1M nodes, from every XCD -- that serialization, not the 36 MB of columns, was the scan's 130-170 us.)
     CwPart *part;  // [blocks][kCwMaxClasses]
     CwPart *part2; // [groups][kCwMaxClasses]
+    // node-range shards (round 5; "windows on shards" below): this rank's window record, the gathered records of all ranks, and what
+    // k_cw_xunify makes of them -- the cluster's classes and their merged lists, identical on every rank
+    unsigned char *xsend, *xrecv;
+    uint32_t *xhdr;  // [4] classes of the cluster, give-up flag
+    CwClass *xcls;   // [kCwXClasses]
+    uint4 *xent;     // [kCwXClasses][kCwMaxList] staged list entries {key lo, key hi, A after one more clone, meta}
+    int32_t x_ranks, x_rank;
 };
 
 
@@ -564,6 +571,187 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_merge(CwTopArgs a, const unsi
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Windows on node-range shards (round 5) for the shape the 64-class kernel takes with every winner
+// leaving for good -- ONE hard constraint over a shared key + ONE unique-per-node inter-pod key (zone spread + hostname
+// anti-affinity: BASELINE config 5's pod shape).  Per window and rank: the pass over the shard as on one GPU (scan / top / merge: the
+// keys carry global indices), k_cw_xpack (the rank's classes -- tuple, statistics, the staged entries of their lists -- into a
+// fixed-size record), ONE all-gather of the records (73 KB per rank; the caller's collective or ncclAllGather in ccsim_dist_run),
+// k_cw_xunify (classes with equal tuples are one class: first occurrence in rank order names it; their lists merge by key; their
+// statistics combine like the blocks' -- the same bytes in, the same result out on every rank), then the deciding wave REPLICATED on
+// every rank on the merged lists (k_cw_decide_fast<.., SH>): identical placements everywhere.  Owners apply a placement to their
+// columns and to the unique key's table entries (a node's own entries are only ever read by its owner's scan); every rank adds it to
+// the shared key's domain counts (the domain id rides in the record) and to the replicated run state.  Whatever a rank cannot
+// represent travels as a flag in its record: every rank falls back to the one-pass-per-placement protocol alike.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kCwXClasses = 64;
+struct __attribute__((aligned(16))) CwXHdr {
+    uint32_t C, giveup, L, pad;
+};
+struct __attribute__((aligned(16))) CwXClass {
+    int32_t tuple[kCwTuple];
+    uint32_t nf, mt, ma, ht, ha, pad;
+    unsigned long long hash;
+    uint4 ent[kCwMaxList];
+};
+constexpr size_t kCwXBytes = sizeof(CwXHdr) + (size_t)kCwXClasses * sizeof(CwXClass);
+constexpr int kCwRecZoneShift = 53; // a (node, clones) record also carries the shared key's domain id of a clone that counts: idx : 40 | clones : 13 | domain : 7
+constexpr uint64_t kCwRecClonesMask = (1ull << (kCwRecZoneShift - kIdxBits)) - 1;
+
+struct CwXArgs {
+    DevCols c;
+    const DevState *st;
+    DevPts pts;
+    CwWork w;
+    int32_t list_len;
+};
+
+// one workgroup per class of this rank (grid kCwXClasses x 64 threads): thread m stages list member m
+__global__ __launch_bounds__(64) void k_cw_xpack(CwXArgs a) {
+    CwXHdr *hdr = reinterpret_cast<CwXHdr *>(a.w.xsend);
+    CwXClass *out = reinterpret_cast<CwXClass *>(a.w.xsend + sizeof(CwXHdr));
+    const int c = blockIdx.x, m = threadIdx.x, L = a.list_len;
+    const bool idle = a.st->done || a.st->cw_fallback;
+    const uint32_t giveup = idle ? 1u : __hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int C = idle ? 0 : (int)a.w.ctl[kCwCtlClasses];
+    if (c == 0 && m == 0) hdr->C = (uint32_t)(C <= kCwXClasses ? C : 0), hdr->giveup = giveup || C > kCwXClasses ? 1u : 0u, hdr->L = (uint32_t)L, hdr->pad = 0;
+    if (giveup || C > kCwXClasses || c >= C) return;
+    const CwClass &k = a.w.cls[a.w.slot_of_id[c]];
+    CwXClass &o = out[c];
+    if (m < kCwTuple) o.tuple[m] = k.tuple[m];
+    if (m == 0) o.nf = k.nf, o.mt = k.mt, o.ma = k.ma, o.ht = k.ht, o.ha = k.ha, o.pad = 0, o.hash = cw_hash(k.tuple, kCwTuple);
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (m < L) {
+        const unsigned long long key = a.w.lists[c * L + m];
+        if (key) {
+            const int64_t i = key_index(key) - a.c.global_offset;
+            r.x = (uint32_t)key, r.y = (uint32_t)(key >> 32), r.z = (uint32_t)a.w.node_A1[i];
+            r.w = (a.c.stat[i] & (kStatAffMask | (kStatCntMask << kStatCntShift))) | (((a.pts.n ? (uint32_t)a.pts.elig[i] : 0u) & kStatImgMask) << kStatImgShift);
+        }
+    }
+    o.ent[m] = r; // (kCwMaxList == 64 == the workgroup)
+}
+
+// one workgroup per class of the CLUSTER (grid kCwXClasses x 256 threads); every workgroup names the classes itself (the same few
+// kilobytes, the same answer), then merges its own
+__global__ __launch_bounds__(kCwThreads) void k_cw_xunify(CwXArgs a) {
+    if (a.st->done || a.st->cw_fallback) return;
+    const int R = a.w.x_ranks, tid = threadIdx.x, g = blockIdx.x;
+    __shared__ unsigned long long s_hash[8 * kCwXClasses];
+    __shared__ int16_t s_lead[8 * kCwXClasses], s_gid[8 * kCwXClasses];
+    __shared__ int s_G, s_bad;
+    auto hdr_of = [&](int r) { return reinterpret_cast<const CwXHdr *>(a.w.xrecv + (size_t)r * kCwXBytes); };
+    auto cls_of = [&](int r, int c) { return reinterpret_cast<const CwXClass *>(a.w.xrecv + (size_t)r * kCwXBytes + sizeof(CwXHdr)) + c; };
+    if (tid == 0) {
+        int bad = R > 8 ? 1 : 0;
+        for (int r = 0; r < R && r < 8; r++) bad |= hdr_of(r)->giveup != 0;
+        s_bad = bad, s_G = 0;
+    }
+    for (int p = tid; p < 8 * kCwXClasses; p += kCwThreads) {
+        const int r = p / kCwXClasses, c = p % kCwXClasses;
+        s_hash[p] = r < R && c < (int)hdr_of(r)->C ? cls_of(r, c)->hash : 0ull; // (cw_hash never returns 0)
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (g == 0 && tid == 0) a.w.xhdr[0] = 0, a.w.xhdr[1] = 1;
+        return;
+    }
+    // the first pair (rank, class) in rank order with the same tuple names the class
+    for (int p = tid; p < 8 * kCwXClasses; p += kCwThreads) {
+        int lead = -1;
+        const unsigned long long h = s_hash[p];
+        if (h) {
+            lead = p;
+            for (int q = 0; q < p; q++)
+                if (s_hash[q] == h) {
+                    const CwXClass *x = cls_of(q / kCwXClasses, q % kCwXClasses), *y = cls_of(p / kCwXClasses, p % kCwXClasses);
+                    bool same = true;
+                    for (int t = 0; t < kCwTuple; t++) same = same && x->tuple[t] == y->tuple[t];
+                    if (same) {
+                        lead = q;
+                        break;
+                    }
+                    atomicOr(&s_bad, 1); // two tuples, one hash: the windowed mode's give-up condition everywhere else too
+                }
+        }
+        s_lead[p] = (int16_t)lead;
+    }
+    __syncthreads();
+    for (int p = tid; p < 8 * kCwXClasses; p += kCwThreads) {
+        int gid = -1;
+        if (s_lead[p] == p) {
+            gid = 0;
+            for (int q = 0; q < p; q++) gid += s_lead[q] == q ? 1 : 0;
+            atomicMax(&s_G, gid + 1);
+        }
+        s_gid[p] = (int16_t)gid;
+    }
+    __syncthreads();
+    const int G = s_G;
+    if (s_bad || G > kCwXClasses) {
+        if (g == 0 && tid == 0) a.w.xhdr[0] = 0, a.w.xhdr[1] = 1;
+        return;
+    }
+    if (g == 0 && tid == 0) a.w.xhdr[0] = (uint32_t)G, a.w.xhdr[1] = 0, a.w.xhdr[2] = 0, a.w.xhdr[3] = 0;
+    if (g >= G || tid >= 64) return;
+    // this class: at most one list per rank (a rank's classes have distinct tuples); lane r merges rank r's
+    const int lane = tid;
+    const CwXClass *mine = nullptr;
+    if (lane < R)
+        for (int c = 0; c < (int)hdr_of(lane)->C; c++) {
+            const int p = lane * kCwXClasses + c;
+            if (s_gid[s_lead[p]] == g) mine = cls_of(lane, c);
+        }
+    CwPart acc;
+    acc.nf = mine ? mine->nf : 0, acc.mt = mine ? mine->mt : 0, acc.ht = mine ? mine->ht : 0, acc.ma = mine ? mine->ma : 0, acc.ha = mine ? mine->ha : 0;
+    acc.pad[0] = acc.pad[1] = acc.pad[2] = 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        CwPart o;
+        o.nf = (uint32_t)__shfl_xor((int)acc.nf, off), o.mt = (uint32_t)__shfl_xor((int)acc.mt, off), o.ht = (uint32_t)__shfl_xor((int)acc.ht, off);
+        o.ma = (uint32_t)__shfl_xor((int)acc.ma, off), o.ha = (uint32_t)__shfl_xor((int)acc.ha, off);
+        cw_part_add(acc, o);
+    }
+    int head = 0;
+    uint4 cur = mine ? mine->ent[0] : make_uint4(0u, 0u, 0u, 0u);
+    for (int m = 0; m < kCwMaxList; m++) {
+        const uint64_t mykey = ((uint64_t)cur.y << 32) | cur.x;
+        const uint64_t K = wave_max_u64(mykey);
+        if (K != 0ull && mykey == K) { // (keys are unique: they carry the node index)
+            a.w.xent[(size_t)g * kCwMaxList + m] = cur;
+            head += 1;
+            cur = head < kCwMaxList ? mine->ent[head] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (K == 0ull && lane == 0) a.w.xent[(size_t)g * kCwMaxList + m] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const unsigned long long has = __ballot(mine != nullptr);
+    if (lane == __ffsll(has) - 1) { // the class's first rank: its tuple is the tuple
+        CwClass &k = a.w.xcls[g];
+        for (int t = 0; t < kCwTuple; t++) k.tuple[t] = mine->tuple[t];
+        k.nf = acc.nf, k.mt = acc.mt, k.ma = acc.ma, k.ht = acc.ht, k.ha = acc.ha, k.id = (uint32_t)g, k.pad[0] = k.pad[1] = 0;
+    }
+}
+
+// behind the deciding wave of a sharded window: nobody took it (a shape or a size the 64-class form declines) -> every rank, alike,
+// continues with one pass per placement; the rank's class table is left empty either way
+__global__ __launch_bounds__(kCwThreads) void k_cw_xfallback(CwXArgs a, DevState *st) {
+    if (st->done || st->cw_fallback) return;
+    const bool took = __hip_atomic_load(a.w.ctl + kCwCtlFastDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (took) {
+        if (threadIdx.x == 0) __hip_atomic_store(a.w.ctl + kCwCtlFastDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int C = (int)a.w.ctl[kCwCtlClasses];
+    for (int id = threadIdx.x; id < C && id < kCwMaxClasses; id += kCwThreads) {
+        const int gs = a.w.slot_of_id[id];
+        a.w.keys[gs] = 0ull, a.w.ready[gs] = 0u;
+        CwClass &k = a.w.cls[gs];
+        k.nf = k.mt = k.ma = k.ht = k.ha = 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.w.ctl[kCwCtlClasses] = 0u, a.w.ctl[kCwCtlGiveUp] = 0u, st->cw_fallback = 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // k_cw_decide: the window's cycles.
 // ------------------------------------------------------------------------------------------------------------------------
 struct CwDecideArgs {
@@ -757,7 +945,6 @@ __device__ __forceinline__ int32_t cw_local_after(const CwDecideArgs &a, int64_t
 // it leaves everything untouched and the general kernel, launched right behind it, does the window.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kCwFastClasses = 48; // (the other lanes hold touched nodes that may still win)
-constexpr int kCwCtlFastDone = 2;
 
 // a value every lane holds identically but the compiler cannot know it (it came through a vector load): say so, or every
 // quantity derived from it -- loop counters, branch conditions -- is handled as divergent, with exec-mask bookkeeping
@@ -812,19 +999,24 @@ __device__ __forceinline__ uint32_t cw_meta(uint32_t stat, uint32_t elig) { retu
 // blocked by its own clone through a required anti-affinity term -- every winner of BASELINE config 5's pod shape) only leaves its
 // (node, clones) record; one that could still win ends the window, and the next pass sees it in its new state.  Domains sit in
 // lane value - 1.  A separate instantiation, launched behind the standard one: it takes the windows that one declined.
-template <int NH, int HU, int NK, int KU, bool PROF, bool FULL = false>
+// SH (round 5): the window of a node-range SHARD -- classes and staged list entries come merged over the ranks from k_cw_xunify, the wave
+// runs replicated on every rank, and the epilogue applies a placement to the columns and the unique key's entries only where the node
+// is this rank's (the shared key's domain count and the run state on every rank).
+template <int NH, int HU, int NK, int KU, bool PROF, bool FULL = false, bool SH = false>
 __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArgs *__restrict__ ap) {
     const CwDecideArgs &a = *ap;
     extern __shared__ __attribute__((aligned(16))) unsigned char cw_lds_raw[];
     CwFastLds &L = *reinterpret_cast<CwFastLds *>(cw_lds_raw);
     DevState &S = *a.st;
     if (S.done || S.cw_fallback) return;
-    if (__hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the general kernel records the fallback)
-    if (FULL && __hip_atomic_load(a.w.ctl + kCwCtlFastDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the standard form took this window)
+    if (!SH && __hip_atomic_load(a.w.ctl + kCwCtlGiveUp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the general kernel records the fallback)
+    if (SH && a.w.xhdr[1]) return; // (some rank gave up: k_cw_xfallback records it on every rank)
+    if (FULL && !SH && __hip_atomic_load(a.w.ctl + kCwCtlFastDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return; // (the standard form took this window)
     const int tid = threadIdx.x, lane = tid & 63;
     const int dlane = FULL ? lane + 1 : lane; // the value id of the shared-key domain this lane stands for
-    const int LL = uni32(a.plan.list_len), W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
-    const int C = uni32((int)a.w.ctl[kCwCtlClasses]);
+    const int LL = uni32(SH ? kCwMaxList : a.plan.list_len), W = uni32(a.plan.window < kCwFastWindow ? a.plan.window : kCwFastWindow);
+    const int C = uni32(SH ? (int)a.w.xhdr[0] : (int)a.w.ctl[kCwCtlClasses]);
+    const int64_t own_lo = a.c.global_offset, own_hi = a.c.global_offset + a.c.n; // (SH: the nodes whose columns are this rank's)
     // members of a class list this kernel uses: all L, or as many as the staging area holds for C classes (many classes with long
     // lists: the window then ends where a class has used up its shorter list -- earlier, never differently)
     const int LU = uni32(C > 0 && C * LL > kCwFastListLds ? kCwFastListLds / C : LL), LS = LU + 1;
@@ -850,7 +1042,9 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     for (int q = tid; q < C * LS; q += kCwThreads) {
         const int c = q / LS, m = q - c * LS;
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
-        if (m < LU) {
+        if (SH) { // (staged by the owners' k_cw_xpack, merged by k_cw_xunify)
+            if (m < LU) r = a.w.xent[(size_t)c * kCwMaxList + m];
+        } else if (m < LU) {
             const unsigned long long key = a.w.lists[c * LL + m];
             if (key) {
                 const int64_t i = key_index(key) - a.c.global_offset;
@@ -891,7 +1085,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         bool over = false;
         const bool cls = lane < C;
         if (cls) {
-            const CwClass &k = a.w.cls[a.w.slot_of_id[lane]];
+            const CwClass &k = SH ? a.w.xcls[lane] : a.w.cls[a.w.slot_of_id[lane]];
             nfm = k.nf, cmt = k.mt, cma = k.ma, cht = k.ht, cha = k.ha;
             const uint4 r = L.ent[lane * LS];
             key = ((uint64_t)r.y << 32) | r.x, hA1 = (int32_t)r.z, hmeta = r.w;
@@ -1064,8 +1258,10 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 }
                 // the clone is an existing pod of the next cycle (filtering.go:255-296, interpodaffinity/filtering.go:204-272)
                 int32_t n_hv0 = w_hv0, n_hc0 = w_hc0, n_hv1 = w_hv1, n_hc1 = w_hc1; // the winner's own components after the clone
+                uint64_t zbits = 0; // (a clone that counts for a shared-key constraint names its domain in its record: kCwRecZoneShift)
                 if (NH > 0) {
                     const bool counts = (w_el & 1u) && ((w_el >> 1) & 1u) && h_self0 && (HU0 ? (w_hv0 & 1) : w_hv0) != 0;
+                    if (!HU0 && counts) zbits = (uint64_t)(uint32_t)w_hv0 << kCwRecZoneShift;
                     const bool at_min = counts && w_hc0 == min0;
                     nmin0 -= at_min ? 1u : 0u;
                     if (HU0) {
@@ -1121,7 +1317,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                     if ((k_anti0 && w_kv0 && n_kn0 > 0) || (NK > 1 && k_anti1 && w_kv1 && n_kn1 > 0)) dead = true;
                     if (exist_pos && ((w_kv0 && n_ke0 > 0) || (NK > 1 && w_kv1 && n_ke1 > 0))) dead = true;
                 }
-                const uint64_t R = ((uint64_t)w_tk << kIdxBits) | (uint64_t)g; // its (node, clones) record for the epilogue, if it leaves
+                const uint64_t R = zbits | ((uint64_t)w_tk << kIdxBits) | (uint64_t)g; // its (node, clones) record for the epilogue, if it leaves
                 if (FULL) { // no lane to keep it in: its record, and the window ends here unless the node is gone for good
                     CW_PUT64(myrec, R, nrec & 63);
                     nrec += 1;
@@ -1168,7 +1364,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 }
                 CW_PUT(mylog, (int32_t)g, cycles & 63);
                 cycles += 1;
-                if ((cycles & 63) == 0 && cycles - 64 + lane < log_room) a.log[placed0 + (cycles - 64 + lane)] = mylog;
+                if ((cycles & 63) == 0 && cycles - 64 + lane < log_room && (!SH || ((int64_t)mylog >= own_lo && (int64_t)mylog < own_hi)))
+                    a.log[placed0 + (cycles - 64 + lane)] = mylog; // (SH: a rank logs its own placements; the others' positions stay -1)
                 CW_TICK(5);
             };
             // ---- the next cycle: does it run in this window?
@@ -1261,15 +1458,15 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
                 // (node, clones) records and the log: positions cycles0 + rank; the lanes keep the current group of 64 as the loop does
                 if (lane < (nrec0 & 63)) L.rec[(nrec0 & ~63) + lane] = myrec;
                 if (lane < (cycles0 & 63)) {
-                    if ((cycles0 & ~63) + lane < log_room) a.log[placed0 + ((cycles0 & ~63) + lane)] = mylog;
+                    if ((cycles0 & ~63) + lane < log_room && (!SH || ((int64_t)mylog >= own_lo && (int64_t)mylog < own_hi))) a.log[placed0 + ((cycles0 & ~63) + lane)] = mylog;
                     L.lg[lane] = mylog;
                 }
                 cw_lds_sync();
                 if (take) {
                     L.dflag[hv0] = 1;
-                    L.rec[nrec0 + (int)rank] = (1ull << kIdxBits) | (uint64_t)gi;
+                    L.rec[nrec0 + (int)rank] = ((uint64_t)(uint32_t)hv0 << kCwRecZoneShift) | (1ull << kIdxBits) | (uint64_t)gi; // (a sweep's clones all count)
                     const int pos = cycles0 + (int)rank;
-                    if (pos < log_room) a.log[placed0 + pos] = (int32_t)gi;
+                    if (pos < log_room && (!SH || (gi >= own_lo && gi < own_hi))) a.log[placed0 + pos] = (int32_t)gi;
                     if (pos >= ((cycles0 + T) & ~63)) L.lg[pos & 63] = (int32_t)gi;
                 }
                 cw_lds_sync();
@@ -1326,7 +1523,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
             cw_lds_sync();
             ncand = uni32(ncand), nrec = uni32(nrec), cycles = uni32(cycles);
             // what the lanes still hold: the log's last partial group, the records' last partial group, the touched nodes that stayed
-            if (lane < (cycles & 63) && (cycles & ~63) + lane < log_room) a.log[placed0 + ((cycles & ~63) + lane)] = mylog;
+            if (lane < (cycles & 63) && (cycles & ~63) + lane < log_room && (!SH || ((int64_t)mylog >= own_lo && (int64_t)mylog < own_hi))) a.log[placed0 + ((cycles & ~63) + lane)] = mylog;
             if (lane < (nrec & 63)) L.rec[(nrec & ~63) + lane] = myrec;
             if (lane >= C && lane < ncand) L.rec[nrec + (lane - C)] = ((uint64_t)tk << kIdxBits) | (uint64_t)key_index(key);
             const uint32_t nf_last = wave_sum_u32_dpp(lf);
@@ -1357,7 +1554,12 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
     for (int ti = tid; ti < nt; ti += kCwThreads) {
         const unsigned long long R = L.rec[ti];
         const int64_t i = (int64_t)(R & kIdxMask) - a.c.global_offset;
-        const int64_t k = (int64_t)(R >> kIdxBits);
+        const int64_t k = (int64_t)((R >> kIdxBits) & kCwRecClonesMask);
+        if (SH) { // the shared key's domain count: every rank (the table is replicated); everything else: the node's owner
+            const int32_t v = (int32_t)(R >> kCwRecZoneShift);
+            if (NH > 0 && v) atomicAdd(&a.pts.tbl[0][v], (int32_t)k);
+            if (i < 0 || i >= a.c.n) continue;
+        }
         const int64_t r0 = a.c.req[0][i] + k * a.p.req[0], r1 = a.c.req[1][i] + k * a.p.req[1];
         const int64_t z0 = a.c.nz_mcpu[i] + k * a.p.nz_mcpu, z1 = a.c.nz_mem[i] + k * a.p.nz_mem;
         a.c.req[0][i] = r0, a.c.req[1][i] = r1, a.c.nz_mcpu[i] = z0, a.c.nz_mem[i] = z1;
@@ -1366,7 +1568,7 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
 #pragma unroll 1
         for (int col = 2; col < a.p.ncol; col++)
             if (a.p.req[col] != 0) a.c.req[col][i] += k * a.p.req[col];
-        if (NH > 0) {
+        if (NH > 0 && !SH) {
             const uint32_t eb = a.pts.elig[i];
             for (int c = 0; c < NH; c++) {
                 const int32_t v = a.pts.label[c][i];
@@ -1385,7 +1587,8 @@ __global__ __launch_bounds__(kCwThreads) void k_cw_decide_fast(const CwDecideArg
         }
     }
     // ---- leave the class table empty for the next pass, and tell the general kernel that the window is done
-    for (int id = tid; id < C; id += kCwThreads) {
+    const int C_loc = SH ? (int)a.w.ctl[kCwCtlClasses] : C; // (SH: C counts the cluster's classes, the table holds this rank's)
+    for (int id = tid; id < C_loc; id += kCwThreads) {
         const int g = a.w.slot_of_id[id];
         a.w.keys[g] = 0ull, a.w.ready[g] = 0u;
         CwClass &k = a.w.cls[g];

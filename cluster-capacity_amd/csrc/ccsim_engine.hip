@@ -158,6 +158,7 @@ struct ccsim_engine {
     int64_t node_max_podcount = 0; // largest len(NodeInfo.Pods) of the snapshot
     int persist_run = 0; // K of the current batched run's persistent launch, 0 = multi-kernel path
     mutable int persist_per_cu[2][9] = {{-1, -1, -1, -1, -1, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, -1, -1}}; // resident workgroups of k_level_persist<K, MB> per CU on THIS engine's device
+    bool cw_attr_shard_set = false;
     bool cw_attr_set = false; // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for the coupled decide kernels on THIS engine's device
     // several pod specs cycled round-robin (ccsim_multi.h)
     bool multi = false;
@@ -191,6 +192,7 @@ struct ccsim_engine {
     size_t cw_zero_bytes = 0;
     int cw_allowed = 1;
     bool cw_run = false;                         // the current run takes the windowed path
+    bool cw_shard_run = false, cw_shard_args = false; // ... on node-range shards (ccsim_dist_cw_*); its argument block is uploaded
     // the sampled search on resident block summaries (ccsim_sampled.h): buffers of the node count's lifetime, made on first use
     int32_t *d_sb_memo = nullptr;
     uint32_t *d_sb_fc = nullptr, *d_sb_mx = nullptr;
@@ -944,13 +946,17 @@ static int cw_make_plan(ccsim_engine *e) {
     auto no = [&](const char *why) { e->cw_why = why; return 0; };
     if (!e->cw_allowed) return no("disabled (CCSIM_CW=0)");
     if (e->n <= 0) return no("empty snapshot");
-    auto unique = [&](int col) { return label_col_unique(e, col); };
+    // On a node-range shard "unique per node" cannot be read off the shard's own column (every zone may occur once in a small shard)
+    // and must be the same answer on every rank: a key is unique iff the caller declares as many domains as the CLUSTER has nodes
+    // (then every node carries its own value) -- the table length says it.
+    const bool sharded = e->global_offset != 0 || e->n_global != e->n;
+    auto unique = [&](int col, size_t table_len) { return sharded ? ((int64_t)table_len - 1 == e->n_global && label_col_unique(e, col)) : label_col_unique(e, col); };
     CwPlan pl{};
     int i32 = 0, i64 = 0;
     if (e->pts.n > kCwMaxCons || e->soft.n > kCwMaxCons) return no("more than four hard / four soft spread constraints");
     for (int c = 0; c < e->pts.n; c++) { // tuple positions are fixed (ccsim_coupled.h kCwTuple)
         const int len = (int)e->pts_table_len[(size_t)c];
-        pl.h_comp[c] = c, pl.h_unique[c] = unique(e->pts_col[(size_t)c]) ? 1 : 0, pl.h_len[c] = len;
+        pl.h_comp[c] = c, pl.h_unique[c] = unique(e->pts_col[(size_t)c], (size_t)len) ? 1 : 0, pl.h_len[c] = len;
         pl.h_present[c] = e->pts_present[(size_t)c];
         if (!pl.h_unique[c]) pl.h_off[c] = i32, pl.h_pres[c] = i32 + len, i32 += 2 * len;
     }
@@ -964,7 +970,7 @@ static int cw_make_plan(ccsim_engine *e) {
         for (int k = 0; k < e->ipa.n_keys; k++) {
             const int len = (int)e->ipa_table_len[(size_t)k * 4];
             const int pos[4] = {kCwKeyPos0, kCwKeyPos1, kCwKeyPos2, kCwKeyPos3};
-            pl.k_unique[k] = unique(e->ipa_col[(size_t)k]) ? 1 : 0, pl.k_len[k] = len, pl.k_comp[k] = pos[k];
+            pl.k_unique[k] = unique(e->ipa_col[(size_t)k], (size_t)len) ? 1 : 0, pl.k_len[k] = len, pl.k_comp[k] = pos[k];
             if (pl.k_unique[k] && k >= 2) return no("a unique-per-node topology key beyond the second inter-pod affinity key");
             if (!pl.k_unique[k]) pl.k_off[k] = i64, i64 += 4 * len;
         }
@@ -985,7 +991,11 @@ static int cw_make_plan(ccsim_engine *e) {
     if (const char *f = getenv("CCSIM_CW_MERGE_GROUP")) group = atoi(f) >= 2 && atoi(f) < group ? atoi(f) : group; // test knob: two levels on small snapshots
     while (pl.list_len > 1 && !getenv("CCSIM_CW_MERGE_GROUP") && (blocks + group - 1) / group > group) pl.list_len >>= 1, group = kCwMaxKeys / pl.list_len > 128 ? 128 : kCwMaxKeys / pl.list_len;
     if ((blocks + group - 1) / group > group) return no("snapshot too large for the class-list merge");
-    if (e->global_offset != 0 || e->n_global != e->n) return no("sharded snapshot");
+    // a node-range shard: windows for the one shape whose deciding wave needs nothing of a remote node but what its owner staged
+    // (ccsim_coupled.h "windows on shards": one hard constraint over a shared key + one unique-per-node inter-pod key)
+    const bool shard_shape = e->pts.n == 1 && !pl.h_unique[0] && pl.h_len[0] <= 65 && e->soft.n == 0 && e->ipa.on && e->ipa.n_keys == 1 && pl.k_unique[0];
+    if (sharded && !shard_shape) return no("sharded snapshot: windows only for one shared-key hard constraint + one unique inter-pod key");
+    if (sharded && getenv("CCSIM_CW_SHARDS") && !atoi(getenv("CCSIM_CW_SHARDS"))) return no("disabled on shards (CCSIM_CW_SHARDS=0)");
     // work buffers: [keys | ready | ctl | classes] zeroed per run, the rest written before it is read
     CwWork w{};
     w.n_blocks = (int)blocks, w.merge_group = (int)group;
@@ -1009,6 +1019,12 @@ static int cw_make_plan(ccsim_engine *e) {
     if ((rc = dev_alloc(e, &w.umin, (size_t)blocks * kMaxTsc, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &w.part, (size_t)blocks * kCwMaxClasses, e->pod_allocs, false))) return rc;
     if (blocks > group && (rc = dev_alloc(e, &w.part2, (size_t)((blocks + group - 1) / group) * kCwMaxClasses, e->pod_allocs, false))) return rc;
+    if (sharded) { // the window record of this rank, the gathered records (up to 8 ranks), the cluster's classes and merged lists
+        if ((rc = dev_alloc(e, &w.xsend, kCwXBytes, e->pod_allocs)) || (rc = dev_alloc(e, &w.xrecv, kCwXBytes * 8, e->pod_allocs)) ||
+            (rc = dev_alloc(e, &w.xhdr, (size_t)4, e->pod_allocs)) || (rc = dev_alloc(e, &w.xcls, (size_t)kCwXClasses, e->pod_allocs)) ||
+            (rc = dev_alloc(e, &w.xent, (size_t)kCwXClasses * kCwMaxList, e->pod_allocs)))
+            return rc;
+    }
     unsigned char *argbuf = nullptr;
     if ((rc = dev_alloc(e, &argbuf, sizeof(CwDecideArgs), e->pod_allocs))) return rc;
     e->d_cw_args = argbuf;
@@ -1318,7 +1334,9 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
             HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
         }
     }
-    if (e->cw_run) HIPCHK(e, hipMemsetAsync(e->cw_zero_base, 0, e->cw_zero_bytes, e->stream));
+    e->cw_shard_run = mode == CCSIM_MODE_SEQUENTIAL && e->cw_ok && e->cw_fast && e->n_ranks > 0 && e->n_ranks <= 8 && e->smp_K == 0 && !e->time_passes && e->cw_work.xsend != nullptr;
+    e->cw_shard_args = false;
+    if (e->cw_run || e->cw_shard_run) HIPCHK(e, hipMemsetAsync(e->cw_zero_base, 0, e->cw_zero_bytes, e->stream));
     const bool rows = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !e->persist_run;
     if (rows != e->rows_active) drop_graph(e);
     e->rows_active = rows;
@@ -1726,7 +1744,16 @@ static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out);
 // ... and of those the ones that also come in the 64-class form (a unique-per-node inter-pod key: with a required anti-affinity term on it a
 // winner never comes back, which is what that form needs to make progress)
 #define CW_FULL_SHAPES(X) X(0, 0, 1, 1) X(1, 0, 1, 1) X(2, 0, 1, 1)
+static void launch_cw_pass(ccsim_engine *e);
+static void launch_cw_decides(ccsim_engine *e, const dim3 b);
 static void launch_cw_window(ccsim_engine *e) {
+    launch_cw_pass(e);
+    const dim3 b(kCwThreads);
+    launch_cw_decides(e, b);
+}
+
+// the node pass of a window: local verdicts and class tuples, the L best members of every class per block, merged over the blocks
+static void launch_cw_pass(ccsim_engine *e) {
     const CwScanArgs sa{e->cols, e->pod, e->d_state, e->pts, e->soft, e->ipa, e->cw_plan, e->cw_work};
     const dim3 g((unsigned)e->cw_work.n_blocks), b(kCwThreads);
     if (e->pod.nx == 0 && e->cols.narrow) hipLaunchKernelGGL((k_cw_scan<0, true>), g, b, 0, e->stream, sa);
@@ -1744,6 +1771,9 @@ static void launch_cw_window(ccsim_engine *e) {
         hipLaunchKernelGGL(k_cw_merge, dim3(kCwMaxClasses, 1), b, 0, e->stream, ta, (const unsigned long long *)e->cw_work.top2, groups, G, e->cw_work.lists,
                            (const CwPart *)e->cw_work.part2, (CwPart *)nullptr);
     }
+}
+
+static void launch_cw_decides(ccsim_engine *e, const dim3 b) {
     // lane = candidate form first (it declines, untouched, whatever it does not cover); the general form right behind it
     if (e->cw_fast) { // (the pod's shape picks the instantiation: bit c of HU / bit k of KU = unique-per-node key)
         const int hu = (e->pts.n > 0 && e->cw_plan.h_unique[0] ? 1 : 0) | (e->pts.n > 1 && e->cw_plan.h_unique[1] ? 2 : 0);
@@ -2049,6 +2079,53 @@ extern "C" int ccsim_dist_decide(ccsim_engine *e) {
         hipLaunchKernelGGL(k_level_decide, dim3(1), dim3(64), 0, e->stream, level_final_args(e, true, e->dist_score_launched));
     else
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, e->stream, scan_args(e));
+    HIPCHK(e, hipGetLastError());
+    return 0;
+}
+
+// ---- windows of placements on node-range shards (include/ccsim.h "ccsim_dist_cw_*"; ccsim_coupled.h "windows on shards") ----
+extern "C" int ccsim_dist_cw_eligible(ccsim_engine *e) { return e && e->begun && e->n_ranks >= 1 && e->cw_shard_run ? 1 : 0; }
+
+extern "C" int ccsim_dist_cw_enable(ccsim_engine *e, int32_t all_ok) {
+    if (!e || !e->begun || e->n_ranks < 1) return -EINVAL;
+    if (all_ok && !e->cw_shard_run) return fail(e, -EINVAL, "ccsim_dist_cw_enable(1) on a rank that is not eligible");
+    e->cw_shard_run = all_ok != 0;
+    if (!e->cw_shard_run) return 0;
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!e->cw_attr_shard_set) {
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_cw_decide_fast<1, 0, 1, 1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CwLds)));
+        e->cw_attr_shard_set = true;
+    }
+    e->cw_work.x_ranks = e->n_ranks, e->cw_work.x_rank = e->rank;
+    const CwDecideArgs da{e->cols, e->pod, e->d_state, e->pts, e->soft, e->ipa, e->cw_plan, e->cw_work, e->d_log};
+    HIPCHK(e, hipMemcpyAsync(e->d_cw_args, &da, sizeof da, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream)); // (`da` is a stack object)
+    return 0;
+}
+
+extern "C" int ccsim_dist_cw_buffers(ccsim_engine *e, void **send, void **recv, int64_t *bytes_per_rank) {
+    if (!e || !send || !recv || !bytes_per_rank || !e->cw_work.xsend) return -EINVAL;
+    *send = e->cw_work.xsend, *recv = e->cw_work.xrecv, *bytes_per_rank = (int64_t)kCwXBytes;
+    return 0;
+}
+
+extern "C" int ccsim_dist_cw_scan(ccsim_engine *e) {
+    if (!e || !e->begun || e->n_ranks < 1 || !e->cw_shard_run) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    launch_cw_pass(e);
+    const CwXArgs xa{e->cols, e->d_state, e->pts, e->cw_work, e->cw_plan.list_len};
+    hipLaunchKernelGGL(k_cw_xpack, dim3(kCwXClasses), dim3(64), 0, e->stream, xa);
+    HIPCHK(e, hipGetLastError());
+    return 0;
+}
+
+extern "C" int ccsim_dist_cw_decide(ccsim_engine *e) {
+    if (!e || !e->begun || e->n_ranks < 1 || !e->cw_shard_run) return -EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    const CwXArgs xa{e->cols, e->d_state, e->pts, e->cw_work, e->cw_plan.list_len};
+    hipLaunchKernelGGL(k_cw_xunify, dim3(kCwXClasses), dim3(kCwThreads), 0, e->stream, xa);
+    hipLaunchKernelGGL((k_cw_decide_fast<1, 0, 1, 1, false, true, true>), dim3(1), dim3(kCwThreads), sizeof(CwLds), e->stream, (const CwDecideArgs *)e->d_cw_args);
+    hipLaunchKernelGGL(k_cw_xfallback, dim3(1), dim3(kCwThreads), 0, e->stream, xa, e->d_state);
     HIPCHK(e, hipGetLastError());
     return 0;
 }
@@ -2565,6 +2642,36 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
     int64_t last_placed = -1;
     int idle = 0;
     HIPCHK(e, hipEventRecord(e->ev0, e->stream)); // (kernel_ns of a sharded run: the whole pass train, exchanges included)
+    {   // one template with a shared-key hard constraint + a unique inter-pod key: WINDOWS of placements per exchange (every rank must
+        // be able to: the agreement is one all-reduce; then per window the pass over the shard, ONE all-gather of 73 KB per rank, the
+        // deciding wave replicated).  A window nobody can take sets cw_fallback on every rank alike: the pass protocol below continues.
+        int32_t go = 0;
+        if (mode == CCSIM_MODE_SEQUENTIAL && (e->pts.n > 0 || e->ipa.on)) { // (the same test on every rank: the pod is)
+            if ((rc = dist_all_min(e, ccsim_dist_cw_eligible(e), &go))) return rc;
+            if ((rc = ccsim_dist_cw_enable(e, go))) return rc;
+        }
+        int cw_idle = 0;
+        while (go) {
+            const int64_t p0 = e->h_state->placed;
+            for (int w = 0; w < 4; w++) {
+                if ((rc = ccsim_dist_cw_scan(e))) return rc;
+                RCCLCHK(e, rccl().AllGather(e->cw_work.xsend, e->cw_work.xrecv, kCwXBytes, kNcclInt8, e->rccl_comm, e->stream));
+                if ((rc = ccsim_dist_cw_decide(e))) return rc;
+            }
+            if ((rc = read_state(e))) return rc;
+            if (e->h_state->done || e->h_state->cw_fallback) break;
+            cw_idle = e->h_state->placed == p0 ? cw_idle + 1 : 0;
+            if (cw_idle >= 4) return fail(e, -EIO, "sharded windowed simulation made no progress in 16 windows");
+        }
+        if (e->h_state->done) {
+            HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+            HIPCHK(e, hipEventSynchronize(e->ev1));
+            float wms = 0;
+            HIPCHK(e, hipEventElapsedTime(&wms, e->ev0, e->ev1));
+            e->kernel_ms = wms;
+            return ccsim_dist_finish(e, out);
+        }
+    }
     for (;;) {
         for (int p = 0; p < per_poll; p++) {
             if ((rc = ccsim_dist_scan(e))) return rc;

@@ -350,6 +350,25 @@ int ccsim_dist_comm_size(ccsim_engine *e, int32_t *n_ranks_out, int32_t *rank_ou
  * placements (-1 elsewhere), as ccsim_dist_finish does. */
 int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out);
 
+/* ---- multi-GPU, one template with topology-coupled plugins: WINDOWS of placements per exchange (round 5; csrc/ccsim_coupled.h "windows
+ * on shards").  For the shape ONE hard spread constraint over a shared key + ONE unique-per-node inter-pod key (zone
+ * spread + hostname anti-affinity: BASELINE config 5's pod shape), percentageOfNodesToScore = 100, sequential mode.  After
+ * ccsim_dist_begin on every rank:
+ *   ccsim_dist_cw_eligible  1 if this rank can take part (collect the minimum over the ranks)
+ *   ccsim_dist_cw_enable    the minimum; 0 = the pass protocol only.  With 1, per window and on every rank:
+ *   ccsim_dist_cw_scan      the pass over the shard -> this rank's window record (classes: tuple, statistics, staged list entries)
+ *   -- all-gather `bytes_per_rank` bytes per rank from `send` into `recv` (ccsim_dist_cw_buffers: engine-owned device buffers) --
+ *   ccsim_dist_cw_decide    classes unified and lists merged over the ranks, up to 4096 scheduling cycles decided identically on every
+ *                           rank, owners apply.  ccsim_dist_poll as usual; a window no rank can take sets the run to one pass per
+ *                           placement on every rank alike (ccsim_dist_scan / _decide continue it from the current state).
+ * ccsim_dist_run does all of this over the engine's communicator (ncclAllGather of 73 KB per rank and window).  CCSIM_CW_SHARDS=0
+ * turns it off. */
+int ccsim_dist_cw_eligible(ccsim_engine *e);
+int ccsim_dist_cw_enable(ccsim_engine *e, int32_t all_ok);
+int ccsim_dist_cw_buffers(ccsim_engine *e, void **send, void **recv, int64_t *bytes_per_rank);
+int ccsim_dist_cw_scan(ccsim_engine *e);
+int ccsim_dist_cw_decide(ccsim_engine *e);
+
 /* ---- multi-GPU, the persistent level kernel ACROSS the GPUs (csrc/ccsim_persist.h, mailbox form; SURVEY.md 8(e) "if RCCL latency
  * dominates: persistent kernels + P2P-mapped flag/mailbox buffers over xGMI implementing the 8-way max-loc in-kernel") ----
  * Every rank keeps its shard in LDS for the whole batched run; the grid-wide reduce of the one-GPU form is extended over the ranks:

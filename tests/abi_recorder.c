@@ -234,6 +234,12 @@ int ccsim_dist_comm_size(ccsim_engine *e, int32_t *n_ranks_out, int32_t *rank_ou
     return 0;
 }
 
+int ccsim_dist_cw_eligible(ccsim_engine *e) { (void)e; return 0; }
+int ccsim_dist_cw_enable(ccsim_engine *e, int32_t all_ok) { (void)e; return all_ok ? -38 : 0; }
+int ccsim_dist_cw_buffers(ccsim_engine *e, void **s, void **r, int64_t *b) { (void)e, (void)s, (void)r, (void)b; return -38; }
+int ccsim_dist_cw_scan(ccsim_engine *e) { (void)e; return -38; }
+int ccsim_dist_cw_decide(ccsim_engine *e) { (void)e; return -38; }
+
 int ccsim_dist_sync_tables(ccsim_engine *e) {
     sep(e);
     fprintf(e->f, "\"dist_sync_tables\": %d", e->world);

@@ -238,3 +238,55 @@ def test_sweeps_did_most_of_the_work_where_they_apply(ccref, monkeypatch):
     assert info["swept"] >= got.placed - 64, info
     if PLACED.get("1", 0) > 2000:  # (only when enough of test_sweeps_random ran in this process: its cases are built to cut rounds short)
         assert SWEPT["1"] > 0, (SWEPT, PLACED)
+
+
+# ---- round 5: windows on node-range shards (csrc/ccsim_coupled.h "windows on shards", include/ccsim.h ccsim_dist_cw_*) -----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+@pytest.mark.parametrize("n,limit", [(3000, 0), (20_000, 9000), (700, 0)])
+def test_c5_pod_shape_in_windows_on_shards(ccref, monkeypatch, world, n, limit):
+    """BASELINE config 5's pod shape as one template, the snapshot cut into node-range shards (several engines on the one GPU; the
+    all-gather is a device copy): per window the pass over each shard, one exchange of the ranks' window records, the deciding wave
+    replicated -- the oracle's log, per-node counts, stop, histogram; far fewer exchanges than placements."""
+    from test_gpu_parity import _LocalShards
+    nodes, pod, prof = c5_single_template(n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    sh = _LocalShards(nodes, pod, prof, world)
+    res, log = sh.run(limit, "sequential", max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res), ([(r.placed, r.stop) for r in res], ref.placed, ref.stop)
+    assert np.array_equal(log[: ref.placed], ref.log)
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
+    for e in sh.engines:
+        e.close()
+    # as many exchanges as ONE GPU makes node passes for the same run (a window ends where it ends there: exhausted class lists, moved
+    # normalization maxima -- with few zones the maxima over the feasible zones alternate late in a run), not one or two per placement
+    one = capi.Engine(device=0)
+    one.load(nodes, pod, prof)
+    got = one.run(max_limit=limit, mode="sequential", log_cap=max(1, ref.placed))
+    one.close()
+    assert np.array_equal(got.log, ref.log)
+    assert 1 <= sh.cw_windows <= got.scans + 8, (sh.cw_windows, got.scans, ref.placed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_sweep_shapes_on_shards_random(ccref, monkeypatch, seed):
+    """The adversarial generator of test_sweeps_random on 2 ... 5 shards: whatever the windows on shards take or decline (a window nobody
+    can take sends every rank to one pass per placement alike), the result is the oracle's."""
+    from test_gpu_parity import _LocalShards
+    rng = np.random.default_rng(8800 + seed)
+    nodes, pod, prof = sweep_case(rng, int(rng.integers(200, 3000)))
+    limit = int(rng.choice([0, 0, 333, 1000]))
+    world = int(rng.integers(2, 6))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    sh = _LocalShards(nodes, pod, prof, world)
+    res, log = sh.run(limit, "sequential", max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res), ([(r.placed, r.stop) for r in res], ref.placed, ref.stop)
+    assert np.array_equal(log[: ref.placed], ref.log)
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
+    for e in sh.engines:
+        e.close()

@@ -206,6 +206,36 @@ class _LocalShards:
         W = self.world
         for r, e in enumerate(self.engines):
             e.dist_begin(limit, mode, W, r, self.send[r].data_ptr(), self.recv[r].data_ptr(), log_cap)
+        # one template, zone spread + hostname anti-affinity: windows of placements per exchange where every rank can (round 5)
+        self.cw_windows = 0
+        go = all([e.dist_cw_eligible() for e in self.engines])
+        for e in self.engines:
+            e.dist_cw_enable(go)
+        if go:
+            bufs = [e.dist_cw_buffers() for e in self.engines]
+            nbytes = bufs[0][2]
+            assert nbytes % 8 == 0 and all(b[2] == nbytes for b in bufs)
+            snd = [self.torch.as_tensor(ccdist._DevArray(b[0], nbytes // 8, 8), device="cuda:0") for b in bufs]
+            rcv = [self.torch.as_tensor(ccdist._DevArray(b[1], W * nbytes // 8, 8), device="cuda:0") for b in bufs]
+            for _ in range(1_000_000):
+                for e in self.engines:
+                    e.dist_cw_scan()
+                gathered = self.torch.cat(snd)
+                for r in range(W):
+                    rcv[r].copy_(gathered)
+                for e in self.engines:
+                    e.dist_cw_decide()
+                self.cw_windows += 1
+                done = [e.dist_poll()[0] for e in self.engines]
+                fell = [e.coupled_info()["fell_back"] for e in self.engines]
+                assert len(set(done)) == 1 and len(set(fell)) == 1  # (replicated decisions)
+                if done[0] or fell[0]:
+                    if fell[0]:
+                        self.cw_windows -= 1
+                    break
+            if all([e.dist_poll()[0] for e in self.engines]):
+                res = [e.dist_finish(log_cap > 0, log_cap) for e in self.engines]
+                return res, (ccdist.merge_logs([r.log for r in res]) if log_cap > 0 else None)
         for _ in range(1_000_000):
             for _ in range(poll_every):  # (the batched mode launches its full pass only right after a poll)
                 for e in self.engines:
