@@ -1019,7 +1019,8 @@ static int cw_make_plan(ccsim_engine *e) {
     if ((rc = dev_alloc(e, &w.umin, (size_t)blocks * kMaxTsc, e->pod_allocs))) return rc;
     if ((rc = dev_alloc(e, &w.part, (size_t)blocks * kCwMaxClasses, e->pod_allocs, false))) return rc;
     if (blocks > group && (rc = dev_alloc(e, &w.part2, (size_t)((blocks + group - 1) / group) * kCwMaxClasses, e->pod_allocs, false))) return rc;
-    if (sharded) { // the window record of this rank, the gathered records (up to 8 ranks), the cluster's classes and merged lists
+    if (shard_shape) { // (also on an unsharded snapshot: a one-rank communicator takes the same path)
+        // the window record of this rank, the gathered records (up to 8 ranks), the cluster's classes and merged lists
         if ((rc = dev_alloc(e, &w.xsend, kCwXBytes, e->pod_allocs)) || (rc = dev_alloc(e, &w.xrecv, kCwXBytes * 8, e->pod_allocs)) ||
             (rc = dev_alloc(e, &w.xhdr, (size_t)4, e->pod_allocs)) || (rc = dev_alloc(e, &w.xcls, (size_t)kCwXClasses, e->pod_allocs)) ||
             (rc = dev_alloc(e, &w.xent, (size_t)kCwXClasses * kCwMaxList, e->pod_allocs)))
@@ -1334,7 +1335,8 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
             HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
         }
     }
-    e->cw_shard_run = mode == CCSIM_MODE_SEQUENTIAL && e->cw_ok && e->cw_fast && e->n_ranks > 0 && e->n_ranks <= 8 && e->smp_K == 0 && !e->time_passes && e->cw_work.xsend != nullptr;
+    e->cw_shard_run = mode == CCSIM_MODE_SEQUENTIAL && e->cw_ok && e->cw_fast && e->n_ranks > 0 && e->n_ranks <= 8 && e->smp_K == 0 && !e->time_passes && e->cw_work.xsend != nullptr &&
+                      !(getenv("CCSIM_CW_SHARDS") && !atoi(getenv("CCSIM_CW_SHARDS")));
     e->cw_shard_args = false;
     if (e->cw_run || e->cw_shard_run) HIPCHK(e, hipMemsetAsync(e->cw_zero_base, 0, e->cw_zero_bytes, e->stream));
     const bool rows = mode == CCSIM_MODE_BATCHED && e->cols.narrow && e->n > 0 && !e->persist_run;

@@ -80,3 +80,31 @@ def test_dist_run_needs_a_communicator():
     with pytest.raises(capi.CcsimError, match="ccsim_dist_comm_init first"):
         e.dist_run(0, "batched")
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,limit", [(3000, 0), (50_000, 20_000)])
+def test_library_driven_windows_on_shards_world_1(ccref, monkeypatch, n, limit):
+    """BASELINE config 5's pod shape as one template through ccsim_dist_run: the windows of placements per exchange (round 5,
+    ccsim_dist_cw_*: the agreement all-reduce, per window an ncclAllGather of the window record on the engine's stream, the deciding
+    wave) on a one-rank communicator == the oracle; with CCSIM_CW_SHARDS=0 the same run takes one exchange per placement."""
+    from test_coupled import c5_single_template
+    nodes, pod, prof = c5_single_template(n)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    scans = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("CCSIM_CW_SHARDS", knob)
+        e = capi.Engine(device=0, use_graph=False)
+        e.load(nodes, pod, prof)
+        e.dist_comm_init(capi.dist_unique_id(), 1, 0)
+        e.dist_sync_tables()
+        got = e.dist_run(limit, "sequential", want_log=True, log_cap=max(1, ref.placed))
+        assert got.placed == ref.placed and got.stop == ref.stop and np.array_equal(got.log, ref.log), knob
+        assert np.array_equal(got.per_node_count, ref.per_node_count), knob
+        if ref.stop == M.STOP_UNSCHEDULABLE:
+            assert np.array_equal(got.hist, ref.hist), knob
+        scans[knob] = got.scans
+        info = e.coupled_info()
+        assert (info["windows"] > 0) == (knob == "1"), (knob, info)
+        e.close()
+    assert scans["1"] * 2 < scans["0"], scans  # (passes: windows against one or two per placement; with 3 zones the late phase of a run moves the maxima every cycle)
