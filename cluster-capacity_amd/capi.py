@@ -187,7 +187,7 @@ def _ptr(a, t):
 
 
 class CcsimError(RuntimeError):
-    pass
+    rc = 0  # the entry point's return code (e.g. -38 = -ENOSYS: a shape this form of the engine does not take)
 
 
 DIST_ID_BYTES = 128
@@ -384,7 +384,9 @@ class Engine:
     def _chk(self, rc: int, what: str):
         if rc != 0:
             msg = self.lib.ccsim_last_error(self.h)
-            raise CcsimError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")
+            err = CcsimError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")
+            err.rc = rc
+            raise err
 
     def load(self, nodes: M.NodesSoA, pod, profile: M.Profile, global_offset: int = 0,
              n_global: Optional[int] = None):

@@ -187,12 +187,107 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
     prof = profile or M.Profile.default()
     prof.percentage_of_nodes_to_score = percentage_of_nodes_to_score
     # several templates: ccsim_set_pods, cycled round-robin by ccsim_run (windows of pods x nodes; `mode` does not apply)
-    eng.load(snap.nodes, snap.pods if len(snap.pods) > 1 else snap.pod, prof)
     cap = max_limit if max_limit > 0 else int(min(int(snap.nodes.alloc_pods.astype(np.int64).sum()), 1 << 26))
     try:
+        try:
+            eng.load(snap.nodes, snap.pods if len(snap.pods) > 1 else snap.pod, prof)
+        except capi.CcsimError as ex:
+            if len(snap.pods) > 1 and ex.rc == -38:  # -ENOSYS: a set of pod specs the window engine does not take
+                print("cluster-capacity: note: these templates are placed one scheduling cycle at a time (the windows of several pod specs do not "
+                      f"take them: {str(ex).split(': ', 1)[-1]})", file=sys.stderr)
+                return simulate_specs_one_cycle_at_a_time(snap.nodes, snap.pods, prof, max_limit, eng)
+            raise
         return eng.run(max_limit=max_limit, mode=mode, want_log=True, log_cap=max(1, cap))
     finally:
         eng.close()
+
+
+def pod_with_clones(nodes: M.NodesSoA, pod: M.PodSpec, clones: np.ndarray) -> M.PodSpec:
+    """The pod spec as the cycle after `clones[n]` of its own clones landed on node n must see it: every clone is an existing pod of the
+    next cycle (types.go:345-350 AddPod), so it joins the per-node counts the spec's topology-coupled plugins were given for the
+    snapshot's pods -- exactly what the oracle's workspace does with its `placed` vector (oracle/ccref.c node_match_count, ipa_build) and
+    what the engine's own tables do within a run of ONE spec."""
+    import copy
+
+    if not clones.any():
+        return pod
+    p = copy.copy(pod)
+    c32 = clones.astype(np.int32)
+    p.spread = [copy.copy(k) for k in pod.spread]
+    for k in p.spread:
+        if k.self_match:
+            k.node_match_count = c32.copy() if k.node_match_count is None else (np.asarray(k.node_match_count, np.int32) + c32)
+    if pod.ipa is not None:
+        a = copy.copy(pod.ipa)
+        add = lambda arr, inc, dt: inc.astype(dt) if arr is None else np.asarray(arr, dt) + inc.astype(dt)  # noqa: E731
+        if a.self_aff:
+            a.aff_existing = add(a.aff_existing, c32, np.int32)
+        a.anti_existing = [add(arr, c32, np.int32) if a.anti_self[t] else arr for t, arr in enumerate(a.anti_existing)]
+        n_keys = len(a.key_cols)
+        exist = list(a.exist_anti) + [None] * (n_keys - len(a.exist_anti))
+        score = list(a.score_existing) + [None] * (n_keys - len(a.score_existing))
+        entries = int(a.entries_existing)
+        for k in range(n_keys):
+            terms = sum(1 for t, kk in enumerate(a.anti_keys) if kk == k and a.anti_self[t])
+            if terms:
+                exist[k] = add(exist[k], c32 * terms, np.int32)
+            w = int(a.score_self[k]) if k < len(a.score_self) else 0
+            if w:
+                score[k] = add(score[k], clones.astype(np.int64) * w, np.int64)
+            se = int(a.self_entries[k]) if k < len(a.self_entries) else 0
+            if se:
+                entries += int(clones[np.asarray(nodes.label_cols[a.key_cols[k]]) != 0].sum()) * se
+        a.exist_anti, a.score_existing, a.entries_existing = exist, score, entries
+        p.ipa = a
+    if pod.has_host_ports:  # (a node holds at most one clone of a pod with host ports: node_ports.go:164-176)
+        conflict = (clones > 0).astype(np.uint8)
+        p.host_ports_conflict = conflict if pod.host_ports_conflict is None else (np.asarray(pod.host_ports_conflict, np.uint8) | conflict)
+    return p
+
+
+def simulate_specs_one_cycle_at_a_time(nodes: M.NodesSoA, pods, prof: M.Profile, max_limit: int, eng=None, device: int = 0) -> M.RunResult:
+    """Several pod specs, cycled round-robin, WITHOUT the window engine (csrc/ccsim_multi.h takes BASELINE config 5's shape; scalar
+    resources, ScheduleAnyway constraints, more than two topology keys, values outside the narrow mirrors are -ENOSYS there): the literal
+    loop of the reference -- cycle i schedules a clone of spec i mod P (pkg/framework/simulator.go:297-381) -- with one ccsim_set_pod
+    + one scheduling cycle of the HIP engine per placement.  The node columns carry every earlier clone; what a spec's own earlier
+    clones add to ITS plugin state is folded into the per-node counts it is set with (pod_with_clones; the templates' selectors are
+    disjoint -- ingest._check_templates_disjoint -- so other specs' clones add nothing).  A slow path (an O(N) upload per cycle), exact:
+    tests/test_multi.py holds it against the oracle's round-robin loop.  Host ports: a clone excludes clones of OTHER specs with the same
+    port from its node as well, which nothing here tracks -- refused unless at most one template asks for host ports."""
+    from . import capi
+
+    P, N = len(pods), nodes.n
+    if sum(1 for q in pods if q.has_host_ports) > 1:
+        raise NotImplementedError("several templates with host ports")
+    own = eng is None
+    if own:
+        eng = capi.Engine(device=device)
+    prof = M.Profile(**{**prof.__dict__, "percentage_of_nodes_to_score": 100})  # (as the window engine: every node is scored)
+    eng.load(nodes, pods[0], prof)
+    clones = np.zeros((P, N), np.int64)
+    log, per_node, per_spec = [], np.zeros(N, np.int32), np.zeros(P, np.int32)
+    last, stop, stop_spec = None, M.STOP_LIMIT, -1
+    try:
+        while True:
+            t = len(log) % P
+            eng.set_pod(pod_with_clones(nodes, pods[t], clones[t]))
+            last = eng.run(max_limit=1, mode="sequential", want_log=True, log_cap=1)
+            if last.placed == 0:
+                stop, stop_spec = last.stop, t
+                break
+            w = int(last.log[0])
+            log.append(w)
+            clones[t, w] += 1
+            per_node[w] += 1
+            per_spec[t] += 1
+            if max_limit > 0 and len(log) >= max_limit:
+                break
+    finally:
+        if own:
+            eng.close()
+    return M.RunResult(placed=len(log), stop=stop, per_node_count=per_node, log=np.asarray(log, np.int32), hist=last.hist if stop_spec >= 0 else np.zeros(M.NREASON, np.int64),
+                       hist_taintset=last.hist_taintset if stop_spec >= 0 else np.zeros_like(last.hist_taintset), n_code_unschedulable=last.n_code_unschedulable if stop_spec >= 0 else 0,
+                       rounds=len(log) + (1 if stop_spec >= 0 else 0), per_spec_count=per_spec, stop_spec=stop_spec)
 
 
 def hard_coupled(pod) -> bool:

@@ -1231,6 +1231,11 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     if (!e->have_nodes || !e->have_profile || !e->have_pod) return fail(e, -EINVAL, "nodes, profile and pod must be set");
     if (mode != CCSIM_MODE_SEQUENTIAL && mode != CCSIM_MODE_BATCHED) return fail(e, -ENOSYS, "mode %d not implemented", mode);
     if (e->pod.nx != 0 || e->multi) e->extras_dirty = true;
+    // every placement of this run moves a node's memory columns by this pod's (non-zero) request: whatever pod spec is set NEXT must
+    // choose the narrow mirrors' memory unit among the divisors of these values too, not only of the snapshot's -- a spec with a coarser
+    // unit set after runs of a finer one read mirrors that had lost the low bits (found by the one-cycle-at-a-time loop over several pod
+    // specs, tests/test_multi.py::test_refused_spec_sets_*: alternating specs of 64 MiB and 1 GiB)
+    e->node_mem_or |= (uint64_t)e->pod.req[1] | (uint64_t)e->pod.nz_mem;
     if (e->ipa.on && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "inter-pod affinity couples nodes through topology pairs: use CCSIM_MODE_SEQUENTIAL");
     if (e->soft.n > 0 && mode == CCSIM_MODE_BATCHED)

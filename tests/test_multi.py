@@ -228,3 +228,56 @@ def test_unsupported_multi_spec_shapes_are_rejected():
         e.load(nodes, aff, prof)
     e.load(nodes, pods, M.Profile.default())  # and the supported shape loads
     e.close()
+
+
+# ---- round 5: pod-spec sets the window engine refuses take the literal loop, one scheduling cycle at a time ------
+def _refused_specs(rng, nodes, n_specs, kind):
+    """random_specs() bent out of the window engine's shape: `soft` = a ScheduleAnyway constraint (scores against cluster-wide counts),
+    `scalar` = a scalar resource request, `affinity` = required inter-pod affinity over a shared key with preferred-term scores,
+    `ports` = one template with host ports."""
+    pods = random_specs(rng, nodes, n_specs)
+    n = nodes.n
+    j = int(rng.integers(0, n_specs))
+    if kind == "soft":
+        pods[j].spread = list(pods[j].spread) + [M.SpreadConstraint(col=1, max_skew=int(rng.integers(1, 3)), hard=False, self_match=True, n_domains=2)]
+    elif kind == "scalar":
+        for q in pods[:: 2]:
+            q.req = np.array(list(q.req) + [int(rng.integers(1, 3))], np.int64)
+            q.has_scalar_entries = True
+        for q in pods[1:: 2]:
+            q.req = np.array(list(q.req) + [0], np.int64)
+    elif kind == "affinity":
+        pods[j].ipa = M.InterPodAffinity(key_cols=[1], key_ndom=[2], aff_keys=[0], self_aff=True, anti_keys=[], anti_self=[], anti_existing=[],
+                                         exist_anti=[None], score_existing=[rng.integers(-2, 3, n).astype(np.int64)], score_self=[int(rng.integers(1, 4))],
+                                         self_entries=[1], entries_existing=int(n // 3))
+    elif kind == "ports":
+        pods[j].has_host_ports = True
+        pods[j].host_ports_conflict = (rng.random(n) < 0.1).astype(np.uint8)
+    return pods
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["soft", "scalar", "affinity", "ports"])
+@pytest.mark.parametrize("seed", range(3))
+def test_refused_spec_sets_take_one_cycle_at_a_time_vs_oracle(ccref, kind, seed):
+    from cluster_capacity_amd import cli
+    rng = np.random.default_rng(4400 + seed)
+    n = int(rng.integers(60, 400))
+    nodes, _, prof = random_multi_case(rng, n, 1)
+    if kind == "scalar":  # a scalar resource column on the nodes
+        nodes.alloc.append(rng.integers(0, 9, n).astype(np.int64))
+        nodes.req.append(rng.integers(0, 2, n).astype(np.int64))
+        nodes.scalar_names = ["example.com/gpu"]
+    pods = _refused_specs(rng, nodes, int(rng.integers(2, 7)), kind)
+    limit = int(rng.choice([0, 0, 150]))
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=limit)
+    e = capi.Engine(device=0)
+    try:
+        e.load(nodes, pods, prof)
+        refused = False
+    except capi.CcsimError as ex:
+        refused = ex.rc == -38
+    e.close()
+    assert refused, "the case was meant to be outside the window engine's shape"
+    got = cli.simulate_specs_one_cycle_at_a_time(nodes, pods, prof, limit)
+    _same(got, ref)

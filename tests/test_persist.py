@@ -228,3 +228,32 @@ def test_lazy_reset_restores_the_extra_resource_columns_too(ccref):
     ref = ccref.run(prof, after_b, pod_a, max_limit=0, threads=8)
     assert ref.placed > 0
     _same(ra, ref, check_log=False)
+
+
+@pytest.mark.parametrize("mode", ["batched", "sequential"])
+def test_a_pod_spec_set_after_runs_of_a_finer_grained_one(ccref, mode):
+    """The narrow mirrors keep memory in units of the largest power of two dividing every value of the snapshot AND of the pod.  A pod
+    with a coarse unit (1 GiB) set after a run of a pod with a finer one (100 MiB = 25 x 4 MiB) meets columns that are no longer multiples
+    of 64 MiB: the unit must come down with them (round 5: found by the one-cycle-at-a-time loop over several pod specs)."""
+    import copy
+
+    n = 2000
+    nodes, pod_a, prof = synth.make_config("C3", n_nodes=n, seed=123)  # 150m / 100 MiB
+    pod_b = copy.copy(pod_a)
+    pod_b.req = pod_a.req.copy()
+    pod_b.req[0], pod_b.req[1], pod_b.nz_mcpu, pod_b.nz_mem = 500, 1 << 30, 500, 1 << 30
+    e = capi.Engine(device=0)
+    e.load(nodes, pod_a, prof)
+    ra = e.run(max_limit=3000, mode=mode, want_log=False)
+    assert ra.placed == 3000
+    e.set_pod(pod_b)
+    rb = e.run(max_limit=0, mode=mode, want_log=False)
+    e.close()
+    after_a = nodes.copy()
+    cnt = ra.per_node_count.astype(np.int64)
+    for c in range(3):
+        after_a.req[c] = after_a.req[c] + cnt * int(pod_a.req[c])
+    after_a.nz_mcpu, after_a.nz_mem = after_a.nz_mcpu + cnt * pod_a.nz_mcpu, after_a.nz_mem + cnt * pod_a.nz_mem
+    after_a.pod_count = (after_a.pod_count + ra.per_node_count).astype(np.int32)
+    ref = ccref.run(prof, after_a, pod_b, max_limit=0, threads=8)
+    _same(rb, ref, check_log=False)
