@@ -14,6 +14,7 @@ GPU through the C ABI (capi.Engine); there is no CPU fallback.
 from __future__ import annotations
 
 import argparse
+import copy
 import datetime
 import json
 import math
@@ -262,7 +263,8 @@ def simulate_specs_one_cycle_at_a_time(nodes: M.NodesSoA, pods, prof: M.Profile,
     own = eng is None
     if own:
         eng = capi.Engine(device=device)
-    prof = M.Profile(**{**prof.__dict__, "percentage_of_nodes_to_score": 100})  # (as the window engine: every node is scored)
+    prof = copy.copy(prof)  # (a shallow copy keeps the host-side notes schedconfig hangs on the object)
+    prof.percentage_of_nodes_to_score = 100  # as the window engine: every node is scored
     eng.load(nodes, pods[0], prof)
     clones = np.zeros((P, N), np.int64)
     log, per_node, per_spec = [], np.zeros(N, np.int32), np.zeros(P, np.int32)

@@ -75,6 +75,7 @@ struct ccsim_engine {
     uint64_t *d_ipa_partials = nullptr;
     DevSoft soft{};
     uint64_t *d_soft_partials = nullptr;
+    int32_t *d_soft_pc0 = nullptr; // pod_count when the pod with soft constraints was set (DevSoft::pod_count0)
     std::vector<std::pair<int32_t *, size_t>> soft_flags; // epoch flag tables, cleared at the start of every run
     struct DistTable { void *ptr; int64_t len; int32_t elem_bytes, op; };
     std::vector<DistTable> dist_tables;   // replicated tables the caller all-reduces across ranks (ccsim_dist_table)
@@ -388,6 +389,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     drop_graph(e);
     free_list(e->allocs);
     e->d_sb_memo = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr; // (they lived in e->allocs)
+    e->d_soft_pc0 = nullptr; // (sized for the previous snapshot: the pod is set again after a load)
     e->backups.clear();
     e->reset_pending = false, e->wide_stale = false;
     e->mb_go = -1;
@@ -715,6 +717,7 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     // (filtering.go:235-308), soft -> Score state (scoring.go:61-178)
     e->pts = DevPts{};
     e->soft = DevSoft{};
+    e->d_soft_pc0 = nullptr;
     e->d_pts_min_partials = nullptr;
     e->d_soft_partials = nullptr;
     e->pts_tables.clear();
@@ -804,8 +807,12 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
             for (size_t j = 0; j < idx.size(); j++) // replicated across ranks like the hard constraints' (counts add)
                 e->dist_tables.push_back({pt.tbl[j], (int64_t)e->pts_table_len[first + j], 4, 0});
             e->soft.n = pt.n, e->soft.w = pf.w_topologyspread, e->soft.elig = elig;
-            for (auto &b : e->backups)
-                if (b.first == (void *)e->cols.pod_count) e->soft.pod_count0 = (const int32_t *)b.second;
+            // "clones on the node" = pod_count - pod_count0: the column as it stands NOW (the per-node counts of this pod describe the pods
+            // behind it -- after runs of other pods on this engine that is not the loaded snapshot: the hosts' one-cycle-at-a-time loop for
+            // refused template sets); ccsim_reset_state takes it back to the loaded snapshot's with the column.
+            if ((rc = dev_alloc(e, &e->d_soft_pc0, (size_t)e->n_pad, e->pod_allocs))) return rc;
+            HIPCHK(e, hipMemcpyAsync(e->d_soft_pc0, e->cols.pod_count, (size_t)e->n_pad * 4, hipMemcpyDeviceToDevice, e->stream));
+            e->soft.pod_count0 = e->d_soft_pc0;
             if ((rc = dev_alloc(e, &e->d_soft_partials, (size_t)kMaxGrid * 3, e->pod_allocs))) return rc;
         }
     }
@@ -2188,6 +2195,9 @@ extern "C" int ccsim_reset_state(ccsim_engine *e) {
         if (rc) return rc;
     }
     // (placed_cnt is a per-run result: begin_run zeroes it)
+    if (e->d_soft_pc0)
+        for (auto &b : e->backups)
+            if (b.first == (void *)e->cols.pod_count) HIPCHK(e, hipMemcpyAsync(e->d_soft_pc0, b.second, (size_t)e->n_pad * 4, hipMemcpyDeviceToDevice, e->stream));
     for (size_t c = 0; c < e->pts_tables.size(); c++)
         HIPCHK(e, hipMemcpyAsync(e->pts_tables[c].first, e->pts_tables[c].second, e->pts_table_len[c] * 4, hipMemcpyDeviceToDevice, e->stream));
     for (size_t c = 0; c < e->ipa_tables.size(); c++)
@@ -2755,6 +2765,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     e->d_memo = nullptr, e->d_memo_stamp = nullptr, e->d_mtouched = nullptr;
     e->have_pod = e->begun = false;
     e->pts = DevPts{}, e->soft = DevSoft{}, e->ipa = DevIpa{};
+    e->d_soft_pc0 = nullptr;
     e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = false;
     e->pts_tables.clear(), e->pts_table_len.clear(), e->ipa_tables.clear(), e->ipa_table_len.clear(), e->soft_flags.clear();
     e->dist_tables.clear(), e->pts_present.clear();

@@ -201,6 +201,96 @@ inline void marshal_pod(const PodSide &s, MarshalledPod &m) {
     p.image_score = s.image_score.empty() ? nullptr : s.image_score.data();
 }
 
+// What one more clone of template `t` on node `n` adds to the per-node counts the template's topology-coupled plugins are set with:
+// every clone is an existing pod of the next cycle (types.go:345-350 AddPod).  Mirrors cli.pod_with_clones / the oracle's workspace
+// (oracle/ccref.c node_match_count, ipa_build).
+inline void add_own_clone(const Snapshot &s, PodSide &side, size_t n) {
+    const size_t N = s.n();
+    for (auto &k : side.spread)
+        if (k.self_match) {
+            if (k.node_match_count.empty()) k.node_match_count.assign(N, 0);
+            k.node_match_count[n] += 1;
+        }
+    if (side.has_ipa) {
+        Ipa &a = side.ipa;
+        if (a.self_aff) {
+            if (a.aff_existing.empty()) a.aff_existing.assign(N, 0);
+            a.aff_existing[n] += 1;
+        }
+        for (size_t t = 0; t < a.anti_keys.size(); t++)
+            if (a.anti_self[t]) {
+                if (a.anti_existing[t].empty()) a.anti_existing[t].assign(N, 0);
+                a.anti_existing[t][n] += 1;
+            }
+        for (size_t k = 0; k < a.key_cols.size(); k++) {
+            int terms = 0;
+            for (size_t t = 0; t < a.anti_keys.size(); t++) terms += a.anti_keys[t] == (int)k && a.anti_self[t] ? 1 : 0;
+            if (terms) {
+                if (a.exist_anti[k].empty()) a.exist_anti[k].assign(N, 0);
+                a.exist_anti[k][n] += terms;
+            }
+            if (a.score_self[k]) {
+                if (a.score_existing[k].empty()) a.score_existing[k].assign(N, 0);
+                a.score_existing[k][n] += a.score_self[k];
+            }
+            if (a.self_entries[k] && s.label_cols[(size_t)a.key_cols[k]][n] != 0) a.entries_existing += a.self_entries[k];
+        }
+    }
+    if (side.has_host_ports) { // (a node holds at most one clone of a pod with host ports: node_ports.go:164-176)
+        if (side.host_ports_conflict.empty()) side.host_ports_conflict.assign(N, 0);
+        side.host_ports_conflict[n] = 1;
+    }
+}
+
+// Several templates WITHOUT the window engine: the reference's literal loop -- cycle i schedules a clone of template i mod P
+// (pkg/framework/simulator.go:297-381) -- with one ccsim_set_pod + one scheduling cycle of the HIP engine per placement.  The node
+// columns carry every earlier clone; what a template's own earlier clones add to ITS plugin state is folded into the per-node counts
+// it is set with (add_own_clone; the templates' selectors are disjoint, snapshot.hpp check_templates_disjoint, so other templates'
+// clones add nothing).  A slow path, exact (tests/test_multi.py, tests/test_native_host.py).  Host ports of more than one template:
+// refused (a clone excludes clones of OTHER templates with the same port from its node, which nothing here tracks).
+inline RunResult simulate_one_cycle_at_a_time(const Api &api, ccsim_engine *e, const Snapshot &s, int64_t max_limit) {
+    const size_t P = s.n_templates(), N = s.n();
+    int with_ports = 0;
+    for (size_t t = 0; t < P; t++) with_ports += s.side(t).has_host_ports ? 1 : 0;
+    if (with_ports > 1) throw Unsupported("several templates with host ports");
+    std::vector<PodSide> sides;
+    for (size_t t = 0; t < P; t++) sides.push_back(s.side(t));
+    RunResult r;
+    r.per_node_count.assign(std::max<size_t>(N, 1), 0);
+    r.per_spec_count.assign(P, 0);
+    r.hist.assign(CCSIM_NREASON, 0);
+    r.hist_taintset.assign(std::max<size_t>(s.taint_filter_ok.size(), 1), 0);
+    r.stop = CCSIM_STOP_LIMIT, r.stop_spec = -1;
+    std::vector<int32_t> one_count(std::max<size_t>(N, 1), 0);
+    auto fail = [&](int rc, const char *what) { throw std::runtime_error(std::string(what) + " failed rc=" + std::to_string(rc) + ": " + (api.last_error(e) ? api.last_error(e) : "")); };
+    for (;;) {
+        const size_t t = (size_t)(r.placed % (int64_t)P);
+        MarshalledPod mp;
+        marshal_pod(sides[t], mp);
+        int rc = api.set_pod(e, &mp.pod);
+        if (rc) fail(rc, "ccsim_set_pod");
+        int32_t won = -1;
+        ccsim_report rep{};
+        std::vector<int64_t> ts(std::max<size_t>(sides[t].taint_filter_ok.size(), 1), 0);
+        rep.per_node_count = one_count.data(), rep.per_node_cap = (int64_t)one_count.size();
+        rep.log = &won, rep.log_cap = 1, rep.stop_spec = -1;
+        rep.hist_taintset = ts.data(), rep.hist_taintset_cap = (int32_t)ts.size();
+        if ((rc = api.run(e, 1, CCSIM_MODE_SEQUENTIAL, &rep))) fail(rc, "ccsim_run");
+        if (rep.placed == 0) {
+            r.stop = rep.stop, r.stop_spec = (int32_t)t, r.n_code_unschedulable = rep.n_code_unschedulable;
+            r.hist.assign(rep.hist, rep.hist + CCSIM_NREASON);
+            r.hist_taintset.assign(ts.begin(), ts.begin() + (std::ptrdiff_t)std::min(ts.size(), sides[t].taint_filter_ok.size()));
+            break;
+        }
+        r.log.push_back(won);
+        r.per_node_count[(size_t)won] += 1, r.per_spec_count[t] += 1, r.placed += 1;
+        add_own_clone(s, sides[t], (size_t)won);
+        if (max_limit > 0 && r.placed >= max_limit) break;
+    }
+    r.per_node_count.resize(N);
+    return r;
+}
+
 inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::string &mode_flag, const HostProfile &prof, int device) {
     const Api api = load_api();
     Marshalled m;
@@ -243,7 +333,23 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     chk(api.load_nodes(e, &m.nodes), "ccsim_load_nodes");
     chk(api.set_profile(e, &m.profile), "ccsim_set_profile");
     if (s.n_templates() == 1) chk(api.set_pod(e, &m.pod_array[0]), "ccsim_set_pod");
-    else chk(api.set_pods(e, m.pod_array.data(), (int32_t)m.pod_array.size()), "ccsim_set_pods"); // cycled round-robin by ccsim_run
+    else {
+        const int src = api.set_pods(e, m.pod_array.data(), (int32_t)m.pod_array.size()); // cycled round-robin by ccsim_run
+        if (src == -38) { // -ENOSYS: a set of pod specs the window engine does not take: the literal loop instead
+            const std::string why = api.last_error(e) ? api.last_error(e) : "";
+            std::fprintf(stderr, "cluster-capacity: note: these templates are placed one scheduling cycle at a time (the windows of several pod specs do not take them: %s)\n",
+                         why.c_str());
+            try {
+                RunResult r = simulate_one_cycle_at_a_time(api, e, s, max_limit);
+                api.destroy(e);
+                return r;
+            } catch (...) {
+                api.destroy(e);
+                throw;
+            }
+        }
+        chk(src, "ccsim_set_pods");
+    }
     // a pod that couples nodes through topology domains, or a sampled search, is order-dependent: the literal loop
     const bool coupled = !s.spread.empty() || s.has_ipa;
     const bool sampled = percentage != 100 && s.n() >= 100;

@@ -1139,6 +1139,41 @@ def test_several_templates_cli_end_to_end_both_hosts(ccref, native, tmp_path):
     assert "Termination reason: LimitReached: Maximum number of pods simulated: 7" in txt and txt.count("The cluster can schedule") == 3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["soft", "scalar"])
+def test_refused_template_sets_take_one_cycle_at_a_time_in_both_hosts(ccref, native, tmp_path, kind):
+    """A template set outside the window engine's shape (ccsim_set_pods answers -ENOSYS): both hosts then drive the loop of
+    simulator.go:186-256 one cycle at a time over the single-template path, the earlier clones of every template folded into the
+    per-node counts of the one in turn. Same review as the oracle's round-robin loop."""
+    import io
+    nodes, pods, templates = _templates_case(n_nodes=30)
+    if kind == "soft":
+        templates[2]["spec"]["topologySpreadConstraints"].append({"maxSkew": 1, "topologyKey": "kubernetes.io/hostname", "whenUnsatisfiable": "ScheduleAnyway",
+                                                                  "labelSelector": {"matchLabels": {"app": "t2"}}})
+    else:
+        for nd in nodes[::2]:
+            nd["status"]["allocatable"]["example.com/widget"] = "3"
+        templates[0]["spec"]["containers"][0]["resources"]["requests"]["example.com/widget"] = "1"
+    cluster, paths = _write_templates(tmp_path, nodes, pods, templates)
+    flags = [x for p in paths for x in ("--podspec", p)] + ["--snapshot", cluster]
+    for extra in ([], ["--max-limit", "11"]):
+        p = subprocess.run([native] + flags + extra + ["-o", "json"], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 0, p.stderr
+        assert "one scheduling cycle at a time" in p.stderr
+        got = json.loads(p.stdout)
+        buf = io.StringIO()
+        assert cli.main(flags + extra + ["-o", "json"], out=buf) == 0
+        ref = json.loads(buf.getvalue())
+        got["status"].pop("creationTimestamp"), ref["status"].pop("creationTimestamp")
+        assert got["status"] == ref["status"]
+        snap = ingest.build_snapshot(nodes, pods, [cli.parse_pod_spec(q) for q in paths])
+        r = ccref.run_multi(M.Profile.default(), snap.nodes, snap.pods, max_limit=11 if extra else 0)
+        assert got["status"]["replicas"] == r.placed
+        assert [sum(x["replicas"] for x in q["replicasOnNodes"]) for q in got["status"]["pods"]] == r.per_spec_count.tolist()
+        for t in range(3):
+            assert [x["nodeName"] for x in got["status"]["pods"][t]["replicasOnNodes"]] == list(dict.fromkeys(snap.names[i] for i in r.log[t::3]))
+
+
 # ---- --gpus N: the snapshot sharded over the GPUs of one box, the run driven inside libccsim.so over RCCL ------------------
 def test_native_sharded_run_fails_loudly_without_gpus(native, tmp_path):
     nodes, pods, pod, _ = CASES["readme"]()

@@ -153,6 +153,44 @@ def test_gpu_soft_and_hard_spread_random(ccref, seed):
     _gpu_check(ccref, nodes, pod, prof, int(rng.choice([0, 0, 70])))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("reset", [False, True])
+def test_gpu_soft_hostname_counts_after_runs_of_another_pod(ccref, reset):
+    """The clones of a pod with a self-matching ScheduleAnyway hostname constraint are counted per node as len(Pods) now minus len(Pods) when
+    the pod was SET (DevSoft::pod_count0) -- not minus the loaded snapshot's, which would count another pod's earlier clones on this
+    engine as this pod's (the hosts' one-cycle-at-a-time loop sets a different template every cycle).  After ccsim_reset_state the
+    reference point is the loaded snapshot again."""
+    import copy
+    n = 300
+    nodes, first, prof = synth.make_config("C3", n_nodes=n, seed=91)
+    nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))
+    second = copy.copy(first)
+    second.req = list(first.req)
+    second.req[0], second.nz_mcpu = first.req[0] // 2 + 1, first.req[0] // 2 + 1
+    second.spread = [M.SpreadConstraint(col=len(nodes.label_cols) - 1, max_skew=1, hard=False, self_match=True, is_hostname=True, n_domains=n)]
+    a = ccref.run(prof, nodes, first, max_limit=170)
+    after = copy.deepcopy(nodes)
+    for w in a.log.tolist():  # (types.go:409-428 AddPod, as oracle/ccref.c applies it)
+        for c in range(len(after.req)):
+            after.req[c][w] += first.req[c]
+        after.nz_mcpu[w] += first.nz_mcpu
+        after.nz_mem[w] += first.nz_mem
+        after.pod_count[w] += 1
+    e = capi.Engine(device=0)
+    try:
+        e.load(nodes, first, prof)
+        g = e.run(max_limit=170, mode="sequential", want_log=True, log_cap=170)
+        assert g.log.tolist() == a.log.tolist()
+        e.set_pod(second)
+        if reset:
+            e.reset_state()
+        ref = ccref.run(prof, nodes if reset else after, second, max_limit=260)
+        got = e.run(max_limit=260, mode="sequential", want_log=True, log_cap=260)
+        assert got.log.tolist() == ref.log.tolist()
+    finally:
+        e.close()
+
+
 # ---- the plugin's SYSTEM DEFAULT constraints: requireAllTopologies = false (scoring.go:61-115,140,147-178,205-219) -------------------------
 def _relaxed_case(rng, n):
     """random_case() nodes (label column 1: 0 = the zone key is MISSING on some nodes) + a hostname column every node carries, and the two
