@@ -73,6 +73,7 @@ class CPod(C.Structure):
         ("n_reqs", C.c_int32), ("reqs", C.POINTER(CReq)), ("req_tables_len", C.c_int64), ("req_tables", _pu8),
         ("n_spread", C.c_int32), ("spread", CSpread * M.MAX_TSC), ("has_ipa", C.c_int32), ("ipa", CIpa),
         ("has_host_ports", C.c_int32), ("host_ports_conflict", _pu8), ("image_score", _pu8),
+        ("volume_exclusive", C.c_int32), ("volume_veto", _pu8),
     ]
 
 
@@ -100,7 +101,7 @@ class CCycle(C.Structure):
     _fields_ = [("node", C.c_int64), ("evaluated_nodes", C.c_int32), ("feasible_nodes", C.c_int32)]
 
 
-ABI_VERSION = 3  # CCSIM_ABI_VERSION of include/ccsim.h
+ABI_VERSION = 4  # CCSIM_ABI_VERSION of include/ccsim.h
 
 # every symbol include/ccsim.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = {
@@ -296,7 +297,8 @@ def marshal_pod(pod: M.PodSpec, keep: list) -> CPod:
     if ipa is not None:
         _fill_ipa(s.ipa, ipa, keep)
     s.has_host_ports = int(bool(getattr(pod, "has_host_ports", False)))
-    for name in ("host_ports_conflict", "image_score"):
+    s.volume_exclusive = int(bool(getattr(pod, "volume_exclusive", False)))
+    for name in ("host_ports_conflict", "image_score", "volume_veto"):
         a = getattr(pod, name, None)
         if a is not None:
             a = np.ascontiguousarray(a, dtype=np.uint8)

@@ -64,7 +64,9 @@ struct ccsim_engine {
     uint32_t *d_stat = nullptr;
     uint8_t *d_sreason = nullptr;
     const int32_t *d_alloc_pods_real = nullptr; // Allocatable.AllowedPodNumber as loaded (cols.alloc_pods may be a pod's clamped copy)
-    bool ports_on = false;                      // NodePorts active for the current pod (ccsim_set_pod)
+    bool ports_on = false;                      // one clone per node for the current pod (ccsim_set_pod): NodePorts active, or its own disks conflict
+    bool excl_ports = false;                    // ... and which of the two reports a node that holds a clone (host ports: before NodeResourcesFit)
+    const uint8_t *d_vol_veto = nullptr;        // ccsim_pod.volume_veto on the device (k_static marks such nodes, k_hist names the plugin); NULL = none
     int32_t *d_ports_eff = nullptr, *d_ports_base = nullptr; // the clamped pod capacity and the pod counts it was built from (k_ports_clamp)
 
     // pod / profile
@@ -568,6 +570,12 @@ static int static_pass(ccsim_engine *e, const ccsim_pod *pod, bool score_preferr
         if ((rc = upload(e, &d_pc, pod->host_ports_conflict, (size_t)e->n, (size_t)e->n_pad, track))) return rc;
         s.ports_conflict = d_pc;
     }
+    if (pod->volume_veto) {
+        uint8_t *d_vv = nullptr;
+        if ((rc = upload(e, &d_vv, pod->volume_veto, (size_t)e->n, (size_t)e->n_pad, track))) return rc;
+        s.volume_veto = d_vv;
+        e->d_vol_veto = d_vv; // (lives as long as the pod: `track` is the pod's allocation list whenever a pod carries one)
+    }
     if (pf.w_imagelocality && pod->image_score) {
         uint8_t *d_img = nullptr;
         if ((rc = upload(e, &d_img, pod->image_score, (size_t)e->n, (size_t)e->n_pad, track))) return rc;
@@ -672,6 +680,11 @@ static int validate_pod(ccsim_engine *e, const ccsim_pod *pod) {
             if (pod->image_score[i] > 100) return fail(e, -EINVAL, "image_score out of [0,100]");
     if (pod->has_host_ports && (e->prof.filter_mask & CCSIM_F_NODEPORTS) && !(e->prof.filter_mask & CCSIM_F_FIT))
         return fail(e, -ENOSYS, "NodePorts needs the NodeResourcesFit filter (one clone per node is kept as a pod-capacity clamp)");
+    if (pod->volume_exclusive && !(e->prof.filter_mask & CCSIM_F_FIT))
+        return fail(e, -ENOSYS, "volume_exclusive needs the NodeResourcesFit filter (one clone per node is kept as a pod-capacity clamp)");
+    if (pod->volume_veto)
+        for (int64_t i = 0; i < e->n; i++)
+            if (pod->volume_veto[i] > CCSIM_VOL_CODES) return fail(e, -EINVAL, "volume_veto code out of range");
     return 0;
 }
 
@@ -700,7 +713,9 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
     // allocatable pod count (k_ports_clamp), which every Fit evaluation of every mode already tests
     e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = false;
     e->d_ports_eff = e->d_ports_base = nullptr;
-    if ((pf.filter_mask & CCSIM_F_NODEPORTS) && pod->has_host_ports) {
+    e->excl_ports = (pf.filter_mask & CCSIM_F_NODEPORTS) && pod->has_host_ports;
+    e->d_vol_veto = nullptr;
+    if (e->excl_ports || pod->volume_exclusive) { // (a clone's own disks, volume_restrictions.go:105-150: the same construction)
         // (against the pod counts as they are NOW -- a pod spec set after runs of other specs finds their clones on the nodes -- and
         // rebuilt by ccsim_reset_state)
         if ((rc = dev_alloc(e, &e->d_ports_eff, (size_t)e->n_pad, e->pod_allocs))) return rc;
@@ -1511,10 +1526,11 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
     } else if (st.done == DONE_UNSCHEDULABLE && e->n > 0) {
         // terminal round: FitError diagnosis (types.go:787-836)
         if (!e->hist_in_kernel) { // (the persistent launch fills the histogram itself, from the node state it holds in LDS)
+            if (int erc = ensure_cols(e)) return erc; // (k_hist reads the int64 request columns: a persistent launch may have left them behind the mirrors)
             HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
             HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
             HistArgs h{e->cols, e->pod, e->d_hist, e->d_hist_ts, e->d_hist_code, e->n_taintsets, e->pts, e->d_state, e->ipa,
-                       e->ports_on ? 1 : 0, e->d_alloc_pods_real, e->d_ports_base};
+                       e->ports_on ? 1 : 0, e->excl_ports ? 1 : 0, e->d_vol_veto, e->d_alloc_pods_real, e->d_ports_base};
             int64_t hb = (e->n + kThreads - 1) / kThreads;
             if (hb > 2048) hb = 2048;
             hipLaunchKernelGGL(k_hist, dim3((unsigned)hb), dim3(kThreads), 0, e->stream, h);
@@ -1670,7 +1686,7 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
     }
     // the FitError diagnosis of the terminal cycle comes out of the launch itself (the node state is in LDS): no k_hist pass.  Not with
     // host ports (the clamped pod capacity hides the real one) and not in the mailbox form (its state goes to the commit rows).
-    const bool diag = !mb && !e->ports_on;
+    const bool diag = !mb && !e->ports_on && !e->d_vol_veto;
     for (int launch = 0; launch < 64; launch++) {
         a.c.from_pristine = e->reset_pending ? 1 : 0;
         if (e->reset_pending) { // (backups: the wide columns in load order -- req[0 .. ncol), nz_mcpu, nz_mem, pod_count)
@@ -2261,6 +2277,7 @@ struct MboxInfo {
     hipIpcMemHandle_t handle;
 };
 static_assert(sizeof(MboxInfo) <= CCSIM_MBOX_INFO_BYTES, "mailbox addressing record");
+static_assert(kHistSlots - 1 == CCSIM_NREASON && kHistVolCodes == CCSIM_VOL_CODES && kHistVol0 == CCSIM_R_VOL0, "k_hist's bins are the ABI's reason slots");
 } // namespace
 
 static void mbox_disconnect(ccsim_engine *e) {
@@ -2766,7 +2783,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     e->have_pod = e->begun = false;
     e->pts = DevPts{}, e->soft = DevSoft{}, e->ipa = DevIpa{};
     e->d_soft_pc0 = nullptr;
-    e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = false;
+    e->cols.alloc_pods = e->d_alloc_pods_real, e->ports_on = e->excl_ports = false, e->d_vol_veto = nullptr;
     e->pts_tables.clear(), e->pts_table_len.clear(), e->ipa_tables.clear(), e->ipa_table_len.clear(), e->soft_flags.clear();
     e->dist_tables.clear(), e->pts_present.clear();
     const size_t N = (size_t)e->n, NP = (size_t)e->n_pad;
@@ -2782,6 +2799,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
             if (q.req[c] != 0) return fail(e, -ENOSYS, "several pod specs: requests beyond cpu / memory (spec %d)", p);
         if (q.has_scalar_entries) return fail(e, -ENOSYS, "several pod specs: scalar resource entries (spec %d)", p);
         if (q.has_host_ports && (pf.filter_mask & CCSIM_F_NODEPORTS)) return fail(e, -ENOSYS, "several pod specs: host ports (spec %d)", p);
+        if (q.volume_exclusive || q.volume_veto) return fail(e, -ENOSYS, "several pod specs: volume plugins (spec %d)", p);
         mem_or |= (uint64_t)q.req[1] | (uint64_t)q.nz_mem;
         const int64_t gc = q.req[0] > q.nz_mcpu ? q.req[0] : q.nz_mcpu, gm = q.req[1] > q.nz_mem ? q.req[1] : q.nz_mem;
         grow_c = gc > grow_c ? gc : grow_c, grow_m = gm > grow_m ? gm : grow_m;

@@ -52,7 +52,7 @@ struct DevCols {
     int32_t *pod_count;
     int64_t *nz_mcpu, *nz_mem;
     const uint32_t *stat;  // static word per node for the current pod spec
-    const uint8_t *sreason; // which static filter rejected the node (0 none 1 unschedulable 2 taint 3 affinity)
+    const uint8_t *sreason; // which static filter rejected the node (0 none 1 unschedulable 2 taint 3 affinity 4 host ports 5 a volume plugin)
     const int32_t *taintset_id;
     int32_t *placed_cnt;   // simulated pods per node
     int64_t n;             // real node count of this shard
@@ -1865,6 +1865,7 @@ struct StaticArgs {
     const int32_t *const *label_cols; // device array of column pointers
     const uint8_t *ports_conflict;    // NodePorts: an existing pod of the node holds a conflicting host port (NULL: plugin off / none)
     const uint8_t *image_score;       // ImageLocality score per node, 0..100 (NULL: 0)
+    const uint8_t *volume_veto;       // the volume plugins' verdict per node against the snapshot's pods (NULL: none); ccsim_pod.volume_veto
     uint32_t *stat;
     uint8_t *sreason;
 };
@@ -1903,6 +1904,9 @@ __global__ __launch_bounds__(kThreads) void k_static(StaticArgs a) {
     // NodePorts runs after NodeAffinity and before NodeResourcesFit (default_plugins.go:34-40); the ports of the clones
     // placed during the run are the engine's business (one clone per node: the clamped pod capacity, ccsim_set_pod)
     if (!reason && a.ports_conflict && a.ports_conflict[n]) reason = 4;
+    // The volume plugins run AFTER NodeResourcesFit (default_plugins.go:40-45): the node is out either way, which plugin reports it is
+    // k_hist's business (Fit first, with the node's state at the terminal cycle)
+    if (!reason && a.volume_veto && a.volume_veto[n]) reason = 5;
     uint32_t cnt = (uint32_t)a.taint_prefer_cnt[ts];
     uint32_t aff = 0;
     for (int t = 0; t < a.n_preferred; t++)
@@ -1930,13 +1934,16 @@ struct HistArgs {
     DevPts pts;
     const DevState *st;
     DevIpa ipa;
-    int32_t ports_on;               // NodePorts active for this pod: a node that took a clone has no free ports
+    int32_t ports_on;               // one clone per node (the clamped pod capacity): NodePorts active for this pod, or its own disks conflict
+    int32_t excl_ports;             // ... and which: 1 = host ports (reported before NodeResourcesFit), 0 = disks (VolumeRestrictions, after it)
+    const uint8_t *volume_veto;     // ccsim_pod.volume_veto (sreason 5: which volume plugin, once Fit has passed)
     const int32_t *alloc_pods_real; // Allocatable.AllowedPodNumber (c.alloc_pods is the clamped copy while ports_on)
     const int32_t *ports_base;      // pods on the node when the clamp was built (k_ports_clamp): more than that = it holds a clone of this pod
 };
 
-constexpr int kHistSlots = 4 + kMaxRes + 2 + 3 + 1 + 1; // + NodePorts + the status-code counter
-constexpr int kHistNodePorts = 4 + kMaxRes + 2 + 3;
+constexpr int kHistVolCodes = 7;                // CCSIM_VOL_CODES
+constexpr int kHistSlots = 4 + kMaxRes + 2 + 3 + 1 + kHistVolCodes + 1; // + NodePorts + the volume plugins + the status-code counter
+constexpr int kHistNodePorts = 4 + kMaxRes + 2 + 3, kHistVol0 = kHistNodePorts + 1;
 constexpr int kHistIpa = 4 + kMaxRes + 2;          // affinity, anti-affinity, existing pods' anti-affinity
 constexpr int kHistPtsMissing = 4 + kMaxRes, kHistPtsSkew = 4 + kMaxRes + 1;
 constexpr int kHistTsLds = 1024;                // taint sets histogrammed in LDS (more fall back to global atomics)
@@ -1958,7 +1965,8 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
             continue;
         }
         if (sr == 3) { atomicAdd(&sh[2], 1u); continue; }
-        if (sr == 4 || (a.ports_on && a.c.pod_count[n] > a.ports_base[n])) { // node_ports.go:148-162: plain Unschedulable, before NodeResourcesFit
+        const bool holds_clone = a.ports_on && a.c.pod_count[n] > a.ports_base[n];
+        if (sr == 4 || (holds_clone && a.excl_ports)) { // node_ports.go:148-162: plain Unschedulable, before NodeResourcesFit
             atomicAdd(&sh[kHistNodePorts], 1u);
             atomicAdd(&sh[kHistSlots - 1], 1u);
             continue;
@@ -1980,6 +1988,15 @@ __global__ __launch_bounds__(kThreads) void k_hist(HistArgs a) {
         }
         if (any) {
             if (!unresolvable) atomicAdd(&sh[kHistSlots - 1], 1u);
+            continue;
+        }
+        // VolumeRestrictions / NodeVolumeLimits / VolumeBinding / VolumeZone follow NodeResourcesFit (default_plugins.go:40-45): a node
+        // that holds a clone whose disks conflict with the next one's (volume_restrictions.go:310-313: the first check of the first of
+        // them), else the caller's verdict against the snapshot's pods
+        if (sr == 5 || holds_clone) {
+            const int code = holds_clone ? 1 : (int)a.volume_veto[n];
+            atomicAdd(&sh[kHistVol0 + code - 1], 1u);
+            if (code <= 3) atomicAdd(&sh[kHistSlots - 1], 1u); // (CCSIM_VOL_LAST_UNSCHEDULABLE)
             continue;
         }
         // PodTopologySpread comes after NodeResourcesFit in the filter order (first failing plugin reports)

@@ -42,7 +42,7 @@ def shard_pod(pod: M.PodSpec, lo: int, hi: int) -> M.PodSpec:
 
     p = copy.copy(pod)
     cut = lambda a: None if a is None else a[lo:hi]  # noqa: E731
-    p.host_ports_conflict, p.image_score = cut(pod.host_ports_conflict), cut(pod.image_score)
+    p.host_ports_conflict, p.image_score, p.volume_veto = cut(pod.host_ports_conflict), cut(pod.image_score), cut(pod.volume_veto)
     p.spread = [copy.copy(k) for k in pod.spread]
     for k in p.spread:
         k.node_match_count, k.node_included = cut(k.node_match_count), cut(k.node_included)

@@ -54,6 +54,14 @@ inline const char *reason_text(int slot) {
     case CCSIM_R_IPA_ANTI: return "node(s) didn't match pod anti-affinity rules";
     case CCSIM_R_IPA_EXISTING_ANTI: return "node(s) didn't satisfy existing pods anti-affinity rules";
     case CCSIM_R_NODEPORTS: return "node(s) didn't have free ports for the requested pod ports"; // nodeports/node_ports.go:39
+    // volumerestrictions/volume_restrictions.go:57-59, nodevolumelimits/csi.go:44, volumebinding/binder.go:65-71, volumezone/volume_zone.go:61
+    case CCSIM_R_VOL_DISK_CONFLICT: return "node(s) had no available disk";
+    case CCSIM_R_VOL_RWOP: return "node(s) unavailable due to PersistentVolumeClaim with ReadWriteOncePod access mode already in-use by another pod";
+    case CCSIM_R_VOL_MAX_COUNT: return "node(s) exceed max volume count";
+    case CCSIM_R_VOL_NODE_AFFINITY: return "node(s) didn't match PersistentVolume's node affinity";
+    case CCSIM_R_VOL_NO_PV: return "node(s) didn't find available persistent volumes to bind";
+    case CCSIM_R_VOL_PV_NOT_EXIST: return "node(s) unavailable due to one or more pvc(s) bound to non-existent pv(s)";
+    case CCSIM_R_VOL_ZONE: return "node(s) had no available volume zone";
     }
     return nullptr;
 }

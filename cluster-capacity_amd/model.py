@@ -42,7 +42,12 @@ R_IPA_AFFINITY = R_PTS_SKEW + 1
 R_IPA_ANTI = R_IPA_AFFINITY + 1
 R_IPA_EXISTING_ANTI = R_IPA_ANTI + 1
 R_NODEPORTS = R_IPA_EXISTING_ANTI + 1
-NREASON = R_NODEPORTS + 1
+# the volume plugins in filter order: slot = R_VOL0 + (PodSpec.volume_veto code - 1)  (include/ccsim.h CCSIM_R_VOL*)
+VOL_DISK_CONFLICT, VOL_RWOP, VOL_MAX_COUNT, VOL_NODE_AFFINITY, VOL_NO_PV, VOL_PV_NOT_EXIST, VOL_ZONE = 1, 2, 3, 4, 5, 6, 7
+VOL_CODES = 7
+VOL_LAST_UNSCHEDULABLE = 3  # codes 1..3 are plain Unschedulable, 4..7 UnschedulableAndUnresolvable
+R_VOL0 = R_NODEPORTS + 1
+NREASON = R_VOL0 + VOL_CODES
 
 STOP_UNSCHEDULABLE = 0
 STOP_LIMIT = 1
@@ -220,6 +225,11 @@ class PodSpec:
     host_ports_conflict: Optional[np.ndarray] = None
     # ImageLocality (plugins/imagelocality/image_locality.go:54-115): per-node score 0..100, uint8[n]; None = 0
     image_score: Optional[np.ndarray] = None
+    # VolumeRestrictions / NodeVolumeLimits / VolumeBinding / VolumeZone (after NodeResourcesFit, default_plugins.go:41-44): uint8[n], the
+    # code VOL_* of the first of them that rejects the node against the snapshot's pods (None = none); volume_exclusive: the pod's
+    # disks conflict with a clone's (volume_restrictions.go:105-150), a node takes at most one clone
+    volume_exclusive: bool = False
+    volume_veto: Optional[np.ndarray] = None
     preempt: Optional[PreemptionSide] = None  # host only, see PreemptionSide
     # PodTopologySpread scores with requireAllTopologies = false (scoring.go:140): the pod has no constraints of its own and
     # `spread` holds the plugin's system defaults (plugin.go:48-59).  The oracle takes this form literally (label id 0 = key missing);
@@ -234,6 +244,8 @@ class PodSpec:
             self.host_ports_conflict = _u8(self.host_ports_conflict)
         if self.image_score is not None:
             self.image_score = _u8(self.image_score)
+        if self.volume_veto is not None:
+            self.volume_veto = _u8(self.volume_veto)
 
 
 def relax_soft(nodes: "NodesSoA", pod: "PodSpec"):

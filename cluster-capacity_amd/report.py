@@ -30,6 +30,14 @@ REASON_TEXT = {
     M.R_IPA_ANTI: "node(s) didn't match pod anti-affinity rules",
     M.R_IPA_EXISTING_ANTI: "node(s) didn't satisfy existing pods anti-affinity rules",
     M.R_NODEPORTS: "node(s) didn't have free ports for the requested pod ports",  # nodeports/node_ports.go:39
+    # volumerestrictions/volume_restrictions.go:57-59, nodevolumelimits/csi.go:44, volumebinding/binder.go:65-71, volumezone/volume_zone.go:61
+    M.R_VOL0 + M.VOL_DISK_CONFLICT - 1: "node(s) had no available disk",
+    M.R_VOL0 + M.VOL_RWOP - 1: "node(s) unavailable due to PersistentVolumeClaim with ReadWriteOncePod access mode already in-use by another pod",
+    M.R_VOL0 + M.VOL_MAX_COUNT - 1: "node(s) exceed max volume count",
+    M.R_VOL0 + M.VOL_NODE_AFFINITY - 1: "node(s) didn't match PersistentVolume's node affinity",
+    M.R_VOL0 + M.VOL_NO_PV - 1: "node(s) didn't find available persistent volumes to bind",
+    M.R_VOL0 + M.VOL_PV_NOT_EXIST - 1: "node(s) unavailable due to one or more pvc(s) bound to non-existent pv(s)",
+    M.R_VOL0 + M.VOL_ZONE - 1: "node(s) had no available volume zone",
 }
 
 

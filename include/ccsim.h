@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CCSIM_ABI_VERSION 3
+#define CCSIM_ABI_VERSION 4
 #define CCSIM_MAX_SCALAR 8
 #define CCSIM_MAX_RES (3 + CCSIM_MAX_SCALAR)
 #define CCSIM_MAX_LABEL_COLS 32
@@ -63,8 +63,19 @@ enum {
     CCSIM_R_IPA_ANTI,          /* "node(s) didn't match pod anti-affinity rules" */
     CCSIM_R_IPA_EXISTING_ANTI, /* "node(s) didn't satisfy existing pods anti-affinity rules" */
     CCSIM_R_NODEPORTS,         /* "node(s) didn't have free ports for the requested pod ports" (P/nodeports/node_ports.go:39) */
+    /* the volume plugins, in their filter order (default_plugins.go:41-44): slot = CCSIM_R_VOL0 + (ccsim_pod.volume_veto code - 1) */
+    CCSIM_R_VOL0,
+    CCSIM_R_VOL_DISK_CONFLICT = CCSIM_R_VOL0, /* "node(s) had no available disk" (P/volumerestrictions/volume_restrictions.go:55), Unschedulable */
+    CCSIM_R_VOL_RWOP,          /* "node(s) unavailable due to PersistentVolumeClaim with ReadWriteOncePod access mode already in-use by another pod" (:59), Unschedulable */
+    CCSIM_R_VOL_MAX_COUNT,     /* "node(s) exceed max volume count" (P/nodevolumelimits/csi.go:44), Unschedulable */
+    CCSIM_R_VOL_NODE_AFFINITY, /* "node(s) didn't match PersistentVolume's node affinity" (P/volumebinding/binder.go:67), UnschedulableAndUnresolvable */
+    CCSIM_R_VOL_NO_PV,         /* "node(s) didn't find available persistent volumes to bind" (binder.go:65), UnschedulableAndUnresolvable */
+    CCSIM_R_VOL_PV_NOT_EXIST,  /* "node(s) unavailable due to one or more pvc(s) bound to non-existent pv(s)" (binder.go:71), UnschedulableAndUnresolvable */
+    CCSIM_R_VOL_ZONE,          /* "node(s) had no available volume zone" (P/volumezone/volume_zone.go:61), UnschedulableAndUnresolvable */
     CCSIM_NREASON
 };
+#define CCSIM_VOL_CODES 7           /* volume_veto codes 1 .. CCSIM_VOL_CODES */
+#define CCSIM_VOL_LAST_UNSCHEDULABLE 3 /* codes 1..3 are plain Unschedulable (preemption dry-run candidates), the rest UnschedulableAndUnresolvable */
 
 enum { CCSIM_STOP_UNSCHEDULABLE = 0, CCSIM_STOP_LIMIT = 1, CCSIM_STOP_NO_NODES = 2 };
 
@@ -202,6 +213,19 @@ typedef struct {
     /* ImageLocality (P/imagelocality/image_locality.go:54-115): the node's score 0..100 for the pod's container images
      * (sizes x spread over the snapshot's nodes: strings, evaluated by the caller); folded into the static word. */
     const uint8_t *image_score; /* [n_nodes], NULL = 0 */
+    /* The volume plugins -- VolumeRestrictions, NodeVolumeLimits, VolumeBinding, VolumeZone -- run after NodeResourcesFit and before
+     * PodTopologySpread (default_plugins.go:40-45).  Their verdicts are string / object-graph work (volume ids, PV labels and node
+     * affinity, CSINode limits) that does not change while clones are placed, EXCEPT a clone's own disks: the caller evaluates them.
+     * volume_veto[n] = 0, or the code 1..CCSIM_VOL_CODES of the FIRST volume plugin that rejects node n against the snapshot's pods
+     * (1 disk conflict volume_restrictions.go:310-313, 2 ReadWriteOncePod :314-318, 3 max volume count nodevolumelimits/csi.go:255-345,
+     * 4 PersistentVolume node affinity, 5 no persistent volume to bind, 6 bound to a non-existent PV volumebinding/volume_binding.go:417-445,
+     * 7 volume zone volumezone/volume_zone.go:191-240); reported in slot CCSIM_R_VOL0 + code - 1 for nodes that pass every filter up to and
+     * including NodeResourcesFit (first failing plugin reports, framework.go:897-930).
+     * volume_exclusive = 1: two clones conflict on the same node (isVolumeConflict of the pod's volumes with themselves,
+     * volume_restrictions.go:105-150: an EBS volume, a GCE PD / ISCSI / RBD mount that is not read-only), so a node takes at most
+     * one -- the NodePorts construction, with the disk-conflict reason attributed AFTER NodeResourcesFit. */
+    int32_t volume_exclusive;
+    const uint8_t *volume_veto; /* [n_nodes], NULL = no node is rejected */
 } ccsim_pod;
 
 /* Scheduler profile: which plugins run and their weights/args.  Replaces

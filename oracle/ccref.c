@@ -348,6 +348,7 @@ typedef struct {
     uint32_t fit_mask; /* bit0 Too many pods, bit 1+col Insufficient <col> */
     int pts_code;
     int ipa_code;
+    int vol_code; /* 1..CCREF_VOL_CODES */
 } fail_info;
 
 static int filter_node(const ccref_profile *prof, const ccref_nodes *nd, const ccref_pod *pod, const pts_state *pts,
@@ -400,6 +401,14 @@ static int filter_node(const ccref_profile *prof, const ccref_nodes *nd, const c
             fi->fit_mask = mask;
             return unresolvable ? -2 : -1;
         }
+    }
+    /* VolumeRestrictions, NodeVolumeLimits, VolumeBinding, VolumeZone (default_plugins.go:41-44), evaluated by the caller against the
+     * snapshot's pods (volume_veto: the first of them that rejects the node); a clone's own disks (volume_restrictions.go:105-150,
+     * 310-313: the first check of the first of the four) */
+    if ((pod->volume_exclusive && placed && placed[n] > 0) || (pod->volume_veto && pod->volume_veto[n])) {
+        fi->plugin = CCREF_F_VOLUMES;
+        fi->vol_code = (pod->volume_exclusive && placed && placed[n] > 0) ? 1 : (int)pod->volume_veto[n];
+        return fi->vol_code <= CCREF_VOL_LAST_UNSCHEDULABLE ? -1 : -2;
     }
     /* P/podtopologyspread/filtering.go:311-356 */
     if ((fm & CCREF_F_TOPOLOGYSPREAD) && pts) {
@@ -732,6 +741,7 @@ static int64_t schedule_one_ws(const ccref_profile *prof, ccref_nodes *nd, const
                     break;
                 case CCREF_F_NODEAFFINITY: res->hist[CCREF_R_NODEAFFINITY]++; break;
                 case CCREF_F_NODEPORTS: res->hist[CCREF_R_NODEPORTS]++; break;
+                case CCREF_F_VOLUMES: res->hist[CCREF_R_VOL0 + fi->vol_code - 1]++; break;
                 case CCREF_F_FIT:
                     if (fi->fit_mask & 1u) res->hist[CCREF_R_TOO_MANY_PODS]++;
                     for (int c = 0; c < CCREF_MAX_RES; c++)
@@ -1044,6 +1054,7 @@ int ccref_run_multi(const ccref_profile *prof, ccref_nodes *nodes, const ccref_p
 static void add_reasons(const fail_info *fi, int64_t *hist) {
     switch (fi->plugin) {
     case CCREF_F_NODEPORTS: hist[CCREF_R_NODEPORTS]++; break;
+    case CCREF_F_VOLUMES: hist[CCREF_R_VOL0 + fi->vol_code - 1]++; break;
     case CCREF_F_FIT:
         if (fi->fit_mask & 1u) hist[CCREF_R_TOO_MANY_PODS]++;
         for (int c = 0; c < CCREF_MAX_RES; c++)

@@ -52,7 +52,9 @@ enum {
     CCREF_F_FIT = 1u << 4,           /* P/noderesources/fit.go */
     CCREF_F_TOPOLOGYSPREAD = 1u << 5, /* P/podtopologyspread */
     CCREF_F_INTERPODAFFINITY = 1u << 6, /* P/interpodaffinity */
-    CCREF_F_NODEPORTS = 1u << 7 /* P/nodeports (runs between NodeAffinity and NodeResourcesFit, default_plugins.go:34-40) */
+    CCREF_F_NODEPORTS = 1u << 7, /* P/nodeports (runs between NodeAffinity and NodeResourcesFit, default_plugins.go:34-40) */
+    CCREF_F_VOLUMES = 1u << 8    /* (a tag for fail_info only, never part of a profile's filter_mask: which of the four volume plugins
+                                  * run is the caller's business -- it evaluates them into ccref_pod.volume_veto / volume_exclusive) */
 };
 
 /* reason slots of the terminal-round histogram (S/framework/types.go:787-836) */
@@ -68,8 +70,19 @@ enum {
     CCREF_R_IPA_ANTI,          /* "node(s) didn't match pod anti-affinity rules" */
     CCREF_R_IPA_EXISTING_ANTI, /* "node(s) didn't satisfy existing pods anti-affinity rules" */
     CCREF_R_NODEPORTS,         /* "node(s) didn't have free ports for the requested pod ports" (P/nodeports/node_ports.go:39) */
+    /* the volume plugins in filter order (default_plugins.go:41-44): slot = CCREF_R_VOL0 + (volume_veto code - 1) */
+    CCREF_R_VOL0,
+    CCREF_R_VOL_DISK_CONFLICT = CCREF_R_VOL0, /* "node(s) had no available disk" (P/volumerestrictions/volume_restrictions.go:55) */
+    CCREF_R_VOL_RWOP,          /* "node(s) unavailable due to PersistentVolumeClaim with ReadWriteOncePod access mode already in-use by another pod" (:59) */
+    CCREF_R_VOL_MAX_COUNT,     /* "node(s) exceed max volume count" (P/nodevolumelimits/csi.go:44) */
+    CCREF_R_VOL_NODE_AFFINITY, /* "node(s) didn't match PersistentVolume's node affinity" (P/volumebinding/binder.go:67, UnschedulableAndUnresolvable) */
+    CCREF_R_VOL_NO_PV,         /* "node(s) didn't find available persistent volumes to bind" (binder.go:65, UnschedulableAndUnresolvable) */
+    CCREF_R_VOL_PV_NOT_EXIST,  /* "node(s) unavailable due to one or more pvc(s) bound to non-existent pv(s)" (binder.go:71, UnschedulableAndUnresolvable) */
+    CCREF_R_VOL_ZONE,          /* "node(s) had no available volume zone" (P/volumezone/volume_zone.go:61, UnschedulableAndUnresolvable) */
     CCREF_NREASON
 };
+#define CCREF_VOL_CODES 7
+#define CCREF_VOL_LAST_UNSCHEDULABLE 3 /* codes 1..3 plain Unschedulable, 4..6 UnschedulableAndUnresolvable */
 
 enum { CCREF_STOP_UNSCHEDULABLE = 0, CCREF_STOP_LIMIT = 1, CCREF_STOP_NO_NODES = 2 };
 
@@ -185,6 +198,13 @@ typedef struct {
     /* ImageLocality (P/imagelocality/image_locality.go:54-115): the node's score 0..100 for this pod's images -- image
      * names are strings, so the caller evaluates ccref_image_locality_score per node.  NULL = 0 everywhere. */
     const uint8_t *image_score; /* [n] */
+    /* VolumeRestrictions / NodeVolumeLimits / VolumeBinding / VolumeZone: after NodeResourcesFit, before PodTopologySpread
+     * (default_plugins.go:40-45).  volume_veto[n] = 0 or the code (1..CCREF_VOL_CODES) of the first of them that rejects node n
+     * against the snapshot's pods -- string and object work, evaluated by the caller; volume_exclusive: the pod's own disks conflict
+     * with a clone's (isVolumeConflict, volume_restrictions.go:105-150), so a node that took a clone fails with the disk-conflict
+     * reason (:310-313). */
+    int32_t volume_exclusive;
+    const uint8_t *volume_veto; /* [n], NULL = none */
     /* PodTopologySpread scoring with requireAllTopologies = false (scoring.go:140: the pod has no constraints of its own and the
      * plugin's SYSTEM DEFAULT constraints apply -- "this allows nodes that don't have a zone label to still have hostname
      * spreading"): no node is ignored, a missing key counts as the value "" when the domains are sized and counted, and scores

@@ -20,8 +20,10 @@ MAX_LABEL_COLS = 32
 MAX_TSC = 8
 MAX_IPA_KEYS = 4
 MAX_IPA_TERMS = 8
-NREASON = 4 + MAX_RES + 2 + 3 + 1
-R_NODEPORTS = NREASON - 1
+VOL_CODES = 7
+R_NODEPORTS = 4 + MAX_RES + 2 + 3
+R_VOL0 = R_NODEPORTS + 1
+NREASON = R_VOL0 + VOL_CODES
 
 _p64 = C.POINTER(C.c_int64)
 _p32 = C.POINTER(C.c_int32)
@@ -105,6 +107,8 @@ class _Pod(C.Structure):
         ("has_host_ports", C.c_int32),
         ("host_ports_conflict", _pu8),
         ("image_score", _pu8),
+        ("volume_exclusive", C.c_int32),
+        ("volume_veto", _pu8),
         ("soft_relaxed", C.c_int32),
     ]
 
@@ -297,6 +301,9 @@ class _Marshal:
             s.host_ports_conflict = self.arr(pod.host_ports_conflict, np.uint8, _pu8)
         if getattr(pod, "image_score", None) is not None:
             s.image_score = self.arr(pod.image_score, np.uint8, _pu8)
+        s.volume_exclusive = int(bool(getattr(pod, "volume_exclusive", False)))
+        if getattr(pod, "volume_veto", None) is not None:
+            s.volume_veto = self.arr(pod.volume_veto, np.uint8, _pu8)
         return s
 
     def profile(self, p) -> _Profile:

@@ -38,7 +38,8 @@ def summarize(r, n_nodes, limit):
         "per_node_count_sha256": hashlib.sha256(np.asarray(r.per_node_count, np.int32).tobytes()).hexdigest(),
         "per_node_count_head": [int(x) for x in r.per_node_count[:16]],
         "log_sha256": hashlib.sha256(log.tobytes()).hexdigest(), "log_head": [int(x) for x in log[:16]],
-        "hist": [int(x) for x in r.hist] if r.stop == M.STOP_UNSCHEDULABLE else None,
+        # (the slots up to NodePorts, as the file was made; the volume plugins' slots added by ABI 4 follow them and no golden case has a volume)
+        "hist": [int(x) for x in r.hist[: M.R_NODEPORTS + 1]] if r.stop == M.STOP_UNSCHEDULABLE else None,
         "hist_taintset": [int(x) for x in r.hist_taintset] if r.stop == M.STOP_UNSCHEDULABLE else None,
         "stop_reason": R.stop_reason(r, n_nodes, limit),
     }
