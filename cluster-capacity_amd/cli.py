@@ -184,13 +184,18 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
     # a sampled search (schedule_one.go:610-723) is order-dependent: the literal one-cycle-per-pass loop
     sampled = percentage_of_nodes_to_score != 100 and snap.nodes.n >= 100
     mode = mode or ("sequential" if coupled or sampled else "batched")
-    eng = capi.Engine(device=device)
     prof = profile or M.Profile.default()
     prof.percentage_of_nodes_to_score = percentage_of_nodes_to_score
+    if len(snap.pods) == 1 and snap.pod.prefilter_reject:  # a volume plugin's PreFilter rejects the pod everywhere: the first cycle ends the run
+        return rejected_by_prefilter(snap.nodes, snap.pod, snap.pod.prefilter_reject)
+    eng = capi.Engine(device=device)
     # several templates: ccsim_set_pods, cycled round-robin by ccsim_run (windows of pods x nodes; `mode` does not apply)
     cap = max_limit if max_limit > 0 else int(min(int(snap.nodes.alloc_pods.astype(np.int64).sum()), 1 << 26))
     try:
         try:
+            if len(snap.pods) > 1 and any(q.prefilter_reject or q.rwop_capacity_one for q in snap.pods):
+                # (what these templates need is host-side: nothing ccsim_set_pods could refuse)
+                return simulate_specs_one_cycle_at_a_time(snap.nodes, snap.pods, prof, max_limit, eng)
             eng.load(snap.nodes, snap.pods if len(snap.pods) > 1 else snap.pod, prof)
         except capi.CcsimError as ex:
             if len(snap.pods) > 1 and ex.rc == -38:  # -ENOSYS: a set of pod specs the window engine does not take
@@ -198,9 +203,40 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
                       f"take them: {str(ex).split(': ', 1)[-1]})", file=sys.stderr)
                 return simulate_specs_one_cycle_at_a_time(snap.nodes, snap.pods, prof, max_limit, eng)
             raise
+        if len(snap.pods) == 1 and snap.pod.rwop_capacity_one and max_limit != 1:
+            # A ReadWriteOncePod claim nobody uses yet: the first clone takes it (volume_restrictions.go:249-264, 283-291), the second
+            # cycle then fails on every node that gets as far as VolumeRestrictions: the pod set again on the SAME state with that verdict
+            first = eng.run(max_limit=1, mode=mode, want_log=True, log_cap=1)
+            if first.placed == 0:
+                return first
+            eng.set_pod(with_rwop_in_use(snap.pod, snap.nodes.n, first.per_node_count))
+            last = eng.run(max_limit=0, mode=mode, want_log=True, log_cap=1)
+            assert last.placed == 0 and last.stop == M.STOP_UNSCHEDULABLE
+            last.placed, last.per_node_count, last.log, last.rounds = 1, first.per_node_count, first.log, first.rounds + last.rounds
+            return last
         return eng.run(max_limit=max_limit, mode=mode, want_log=True, log_cap=max(1, cap))
     finally:
         eng.close()
+
+
+def rejected_by_prefilter(nodes: M.NodesSoA, pod: M.PodSpec, msg: str, placed_before=None) -> M.RunResult:
+    """The cycle a PreFilter plugin rejects (schedule_one.go:495-508): no node is evaluated, every node carries the plugin's status."""
+    n = nodes.n
+    return M.RunResult(placed=0, stop=M.STOP_UNSCHEDULABLE, per_node_count=np.zeros(n, np.int32), log=np.zeros(0, np.int32),
+                       hist=np.zeros(M.NREASON, np.int64), hist_taintset=np.zeros(max(1, len(pod.taint_filter_ok)), np.int64),
+                       n_code_unschedulable=0, rounds=1, prefilter_msg=msg)
+
+
+def with_rwop_in_use(pod: M.PodSpec, n: int, clones=None) -> M.PodSpec:
+    """The pod once a clone holds its ReadWriteOncePod claim: VolumeRestrictions fails every node -- after its own disk check (`clones`:
+    where the pod's earlier clones sit, for a pod whose disks are exclusive: the engine counts clones from the moment a pod is set)."""
+    q = copy.copy(pod)
+    veto = np.zeros(n, np.uint8) if pod.volume_veto is None else np.asarray(pod.volume_veto, np.uint8).copy()
+    if pod.volume_exclusive and clones is not None:
+        veto[np.asarray(clones) > 0] = M.VOL_DISK_CONFLICT
+    veto[veto != M.VOL_DISK_CONFLICT] = M.VOL_RWOP
+    q.volume_veto, q.rwop_capacity_one = veto, False
+    return q
 
 
 def pod_with_clones(nodes: M.NodesSoA, pod: M.PodSpec, clones: np.ndarray) -> M.PodSpec:
@@ -240,6 +276,10 @@ def pod_with_clones(nodes: M.NodesSoA, pod: M.PodSpec, clones: np.ndarray) -> M.
                 entries += int(clones[np.asarray(nodes.label_cols[a.key_cols[k]]) != 0].sum()) * se
         a.exist_anti, a.score_existing, a.entries_existing = exist, score, entries
         p.ipa = a
+    if pod.volume_exclusive:  # (... and of a pod whose disks conflict with a clone's: volume_restrictions.go:105-150, the first volume check)
+        veto = np.zeros(len(clones), np.uint8) if pod.volume_veto is None else np.asarray(pod.volume_veto, np.uint8).copy()
+        veto[clones > 0] = M.VOL_DISK_CONFLICT
+        p.volume_veto = veto
     if pod.has_host_ports:  # (a node holds at most one clone of a pod with host ports: node_ports.go:164-176)
         conflict = (clones > 0).astype(np.uint8)
         p.host_ports_conflict = conflict if pod.host_ports_conflict is None else (np.asarray(pod.host_ports_conflict, np.uint8) | conflict)
@@ -269,9 +309,17 @@ def simulate_specs_one_cycle_at_a_time(nodes: M.NodesSoA, pods, prof: M.Profile,
     clones = np.zeros((P, N), np.int64)
     log, per_node, per_spec = [], np.zeros(N, np.int32), np.zeros(P, np.int32)
     last, stop, stop_spec = None, M.STOP_LIMIT, -1
+    pods = list(pods)
+    prefilter_msg = None
     try:
         while True:
             t = len(log) % P
+            if pods[t].prefilter_reject:  # a volume plugin's PreFilter: this template's cycle ends the run
+                last, prefilter_msg = rejected_by_prefilter(nodes, pods[t], pods[t].prefilter_reject), pods[t].prefilter_reject
+                stop, stop_spec = M.STOP_UNSCHEDULABLE, t
+                break
+            if pods[t].rwop_capacity_one and per_spec[t] == 1:  # its first clone holds the ReadWriteOncePod claim now
+                pods[t] = with_rwop_in_use(pods[t], N)  # (pod_with_clones adds the clones' own disks below)
             eng.set_pod(pod_with_clones(nodes, pods[t], clones[t]))
             last = eng.run(max_limit=1, mode="sequential", want_log=True, log_cap=1)
             if last.placed == 0:
@@ -289,7 +337,12 @@ def simulate_specs_one_cycle_at_a_time(nodes: M.NodesSoA, pods, prof: M.Profile,
             eng.close()
     return M.RunResult(placed=len(log), stop=stop, per_node_count=per_node, log=np.asarray(log, np.int32), hist=last.hist if stop_spec >= 0 else np.zeros(M.NREASON, np.int64),
                        hist_taintset=last.hist_taintset if stop_spec >= 0 else np.zeros_like(last.hist_taintset), n_code_unschedulable=last.n_code_unschedulable if stop_spec >= 0 else 0,
-                       rounds=len(log) + (1 if stop_spec >= 0 else 0), per_spec_count=per_spec, stop_spec=stop_spec)
+                       rounds=len(log) + (1 if stop_spec >= 0 else 0), per_spec_count=per_spec, stop_spec=stop_spec, prefilter_msg=prefilter_msg)
+
+
+def ingest_volume_plugins():
+    from . import volumes
+    return volumes.PLUGINS
 
 
 def hard_coupled(pod) -> bool:
@@ -315,6 +368,10 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
     ap.add_argument("-o", "--output", default="", choices=["", "json", "yaml"], help="Output format. One of: json|yaml")
     ap.add_argument("--mode", default=None, choices=["batched", "sequential"], help="engine mode (default: batched unless the pod couples nodes)")
     ap.add_argument("--default-config", default="", help="Path to JSON or YAML file containing scheduler configuration.")
+    ap.add_argument("--sync-persistent-volumes", action="store_true",
+                    help="also take the PersistentVolume objects of the snapshot: bound claims are then judged as kube-scheduler judges them on the "
+                         "live cluster (VolumeBinding's node affinity, VolumeZone's labels).  The reference's SyncWithClient does not copy volumes "
+                         "(a bound claim ends its run with 'persistentvolume \"x\" not found'): that is the default here too")
     ap.add_argument("--percentage-of-nodes-to-score", type=int, default=None,
                     help="KubeSchedulerConfiguration.percentageOfNodesToScore: 100 scores every node (the final capacity and "
                          "distribution do not depend on it for pods without topology constraints); 0 = the scheduler's adaptive default")
@@ -345,7 +402,12 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
         services = by.get("Service", [])
         snap = ingest.build_snapshot(node_objs, pod_objs, pod, [x for x in args.exclude_nodes.split(",") if x], hard_pod_affinity_weight=hard_weight,
                                      namespace_objs=ns_objs, service_objs=services, owner_objs=owners,
-                                     system_default_spreading=bool(prof.w_topologyspread) and getattr(prof, "system_default_spreading", True))
+                                     system_default_spreading=bool(prof.w_topologyspread) and getattr(prof, "system_default_spreading", True),
+                                     # SyncWithClient copies claims and classes, not the volumes (simulator.go:228-295)
+                                     pvc_objs=by.get("PersistentVolumeClaim", []), class_objs=by.get("StorageClass", []),
+                                     pv_objs=by.get("PersistentVolume", []) if args.sync_persistent_volumes else None,
+                                     volume_plugins=getattr(prof, "volume_plugins", ingest_volume_plugins()),
+                                     volume_plugins_partial=getattr(prof, "volume_plugins_partial", False))
     except (TypeError, AttributeError, KeyError, OverflowError) as e:
         # the objects are walked as plain dicts / lists: a string where a mapping belongs (a decode error in the reference, which reads
         # into typed structs) or a sum beyond int64 surfaces as one of these -- refused, like the native host refuses it

@@ -511,7 +511,10 @@ def _term_matches_pod(term: dict, term_owner_ns: str, pod: dict, ns_labels: Opti
 
 def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude_nodes: Sequence[str] = (),
                    hard_pod_affinity_weight: int = 1, namespace_objs: Sequence[dict] = (), service_objs: Sequence[dict] = (),
-                   owner_objs: Sequence[dict] = (), system_default_spreading: bool = True) -> Snapshot:
+                   owner_objs: Sequence[dict] = (), system_default_spreading: bool = True, pvc_objs: Sequence[dict] = (),
+                   class_objs: Sequence[dict] = (), pv_objs: Optional[Sequence[dict]] = None,
+                   volume_plugins: Sequence[str] = ("VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"),
+                   volume_plugins_partial: bool = False) -> Snapshot:
     """SyncWithClient (simulator.go:176-295: namespaces, nodes, pods) + every per-pod-spec precomputation, in integers.
     `sim_pod`: the template, or a list of templates (cycled round-robin by the simulation)."""
     sim_pods = list(sim_pod) if isinstance(sim_pod, (list, tuple)) else [sim_pod]
@@ -578,7 +581,9 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
 
     ctx = dict(nodes=nodes, N=N, index=index, live=live, ns_labels=ns_labels, res_names=res_names, scalars=scalars, set_taints=set_taints,
                ts_id=ts_id, it=it, hard_pod_affinity_weight=hard_pod_affinity_weight,
-               default_spreading=(service_objs, owner_objs) if system_default_spreading else None, n_templates=len(sim_pods))
+               default_spreading=(service_objs, owner_objs) if system_default_spreading else None, n_templates=len(sim_pods),
+               pvc_objs=pvc_objs, class_objs=class_objs, pv_objs=pv_objs, volume_plugins=tuple(volume_plugins),
+               volume_plugins_partial=volume_plugins_partial)
     sides = [_template_side(ctx, sp) for sp in sim_pods]
     soa = M.NodesSoA(alloc=alloc, alloc_pods=alloc_pods, req=req, nz_mcpu=nzc, nz_mem=nzm, pod_count=pcount,
                      taintset_id=ts_id, unschedulable=unsched, label_cols=[a for a in it.arrays] or [], names=names,
@@ -588,7 +593,30 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
     snap.pods, snap.taint_reasons_all = [p for p, _ in sides], [r for _, r in sides]
     if len(sides) > 1:
         _check_templates_disjoint(sim_pods)
+        _check_template_volumes_disjoint(sim_pods, pvc_objs)
     return snap
+
+
+def _check_template_volumes_disjoint(sim_pods: List[dict], pvc_objs: Sequence[dict]):
+    """Several templates: a clone's disks exclude clones of the SAME template from its node (volume_exclusive); a disk or a
+    ReadWriteOncePod claim shared by two templates would exclude the other's clones too, which nothing tracks."""
+    from . import volumes as V
+
+    rwop = {((o.get("metadata") or {}).get("namespace") or "default", (o.get("metadata") or {}).get("name", "")) for o in pvc_objs
+            if "ReadWriteOncePod" in ((o.get("spec") or {}).get("accessModes") or [])}
+
+    def claims(p):
+        ns = (p.get("metadata") or {}).get("namespace") or "default"
+        return {(ns, (v["persistentVolumeClaim"] or {}).get("claimName", "")) for v in (p.get("spec") or {}).get("volumes") or []
+                if v.get("persistentVolumeClaim") is not None}
+    for a_i, a in enumerate(sim_pods):
+        for b_i, b in enumerate(sim_pods):
+            if a_i >= b_i:
+                continue
+            if V.pod_conflicts((a.get("spec") or {}).get("volumes") or [], (b.get("spec") or {}).get("volumes") or []):
+                raise NotImplementedError(f"templates {a_i} and {b_i} mount the same disk: conflicts between clones of different templates are not modelled")
+            if claims(a) & claims(b) & rwop:
+                raise NotImplementedError(f"templates {a_i} and {b_i} share a ReadWriteOncePod claim: not modelled")
 
 
 def _check_templates_disjoint(sim_pods: List[dict]):
@@ -700,12 +728,16 @@ def _template_side(ctx: dict, sim_pod: dict):
                     rest.setdefault(index[p["spec"]["nodeName"]], set()).update(hp)
             pre.ports_conflict_rest = np.array([1 if i in rest and ports_conflict(want, rest[i]) else 0 for i in range(N)], np.uint8)
     pod.preempt = pre
-    # volume-backed plugins (VolumeBinding / VolumeZone / VolumeRestrictions / NodeVolumeLimits / DynamicResources) have no
-    # integer form here: a pod that would activate them is refused instead of silently ignoring the constraint
-    for v in spec.get("volumes") or []:
-        for kind in ("persistentVolumeClaim", "ephemeral", "gcePersistentDisk", "awsElasticBlockStore", "rbd", "iscsi", "csi"):
-            if v.get(kind) is not None:
-                raise NotImplementedError(f"pod volume {v.get('name')!r} of kind {kind}: the volume plugins are not modelled")
+    # VolumeRestrictions / NodeVolumeLimits / VolumeBinding / VolumeZone: the object side (volumes.py) -> per-node verdict codes, the
+    # clones' own disks, the PreFilter rejections.  (inline csi volumes only count against CSINode limits, which the simulated cluster
+    # does not have: nodevolumelimits/csi.go:265-290.)  DynamicResources stays refused.
+    from . import volumes as V
+    if spec.get("volumes") and ctx.get("volume_plugins_partial"):
+        raise NotImplementedError("the scheduler configuration disables only the filter point of a volume plugin: a pod with volumes is not modelled under it")
+    vs = V.volume_side(sim_pod, nodes, live, index, ctx.get("pvc_objs") or (), ctx.get("class_objs") or (), ctx.get("pv_objs"),
+                       ctx.get("volume_plugins") or V.PLUGINS)
+    pod.volume_veto, pod.volume_exclusive = vs.veto, vs.exclusive
+    pod.prefilter_reject, pod.rwop_capacity_one = vs.prefilter_reject, vs.rwop_capacity_one
     if spec.get("resourceClaims"):
         raise NotImplementedError("spec.resourceClaims: the DynamicResources plugin is not modelled")
 

@@ -230,6 +230,10 @@ class PodSpec:
     # disks conflict with a clone's (volume_restrictions.go:105-150), a node takes at most one clone
     volume_exclusive: bool = False
     volume_veto: Optional[np.ndarray] = None
+    # host only (volumes.py): a volume plugin's PreFilter rejects the pod on every node (its message); a ReadWriteOncePod claim nobody
+    # uses yet (the first clone takes it: the hosts then set the pod again with VOL_RWOP on every node)
+    prefilter_reject: Optional[str] = None
+    rwop_capacity_one: bool = False
     preempt: Optional[PreemptionSide] = None  # host only, see PreemptionSide
     # PodTopologySpread scores with requireAllTopologies = false (scoring.go:140): the pod has no constraints of its own and
     # `spread` holds the plugin's system defaults (plugin.go:48-59).  The oracle takes this form literally (label id 0 = key missing);
@@ -325,4 +329,5 @@ class RunResult:
     pass_launches: int = 0
     bytes_per_scan: int = 0
     per_spec_count: Optional[np.ndarray] = None  # several pod specs: placements per spec
+    prefilter_msg: Optional[str] = None          # host only: the terminal cycle was rejected by a PreFilter plugin (FitError.Diagnosis.PreFilterMsg)
     stop_spec: int = -1                          # ... and the spec whose pod was Unschedulable

@@ -180,6 +180,9 @@ def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedula
     if n_templates > 1:
         out.kind = "unmodelled"
         return out
+    if pod.volume_veto is not None or pod.volume_exclusive:  # (a victim's disks / claims would have to leave the verdicts with it)
+        out.kind = "unmodelled"
+        return out
     idx = np.nonzero(pre.victim_count)[0]
     cnt = np.asarray(per_node_count, np.int64)[idx]
     sok = static_ok(nodes, pod, idx, filter_mask)

@@ -81,13 +81,19 @@ def fit_error_message(
     scalar_names: Sequence[str] = (),
     with_preemption: bool = True,
     preemption=None,
+    prefilter_msg: Optional[str] = None,
 ) -> str:
     """FitError.Error() for the terminal round, including the DefaultPreemption tail.  `preemption`: the outcome of the dry
     run (preemption.Outcome); None = no node holds a pod of lower priority than the simulated one."""
     msg = f"0/{n_nodes} nodes are available:"
-    body = _histogram_message(_reason_histogram(hist, hist_taintset, taint_reasons, scalar_names))
-    if body:
-        msg += f" {body}."
+    if prefilter_msg:
+        # a PreFilter plugin rejected the pod (schedule_one.go:495-508): its message stands for every node (types.go:789-794), and every
+        # node is UnschedulableAndUnresolvable for the preemption that follows (n_code_unschedulable = 0)
+        msg += f" {prefilter_msg}."
+    else:
+        body = _histogram_message(_reason_histogram(hist, hist_taintset, taint_reasons, scalar_names))
+        if body:
+            msg += f" {body}."
     if not with_preemption or (preemption is not None and preemption.kind == "nominated"):
         return msg  # a candidate node was found: PostFilter returns Success with an empty message (preemption.go:281-303)
     if preemption is not None and preemption.kind == "never":
@@ -114,7 +120,8 @@ def stop_reason(result, n_nodes: int, max_limit: int, **kw) -> str:
         return f"LimitReached: Maximum number of pods simulated: {max_limit}"
     if result.stop == M.STOP_NO_NODES:
         return "Unschedulable: no nodes available to schedule pods"
-    return "Unschedulable: " + fit_error_message(n_nodes, result.hist, result.hist_taintset, result.n_code_unschedulable, **kw)
+    return "Unschedulable: " + fit_error_message(n_nodes, result.hist, result.hist_taintset, result.n_code_unschedulable,
+                                                 prefilter_msg=getattr(result, "prefilter_msg", None), **kw)
 
 
 def main_fail_reason(message: str):

@@ -31,6 +31,9 @@ PLUGINS = {
 FOLDED_AWAY = {"SchedulingGates", "PrioritySort", "VolumeRestrictions", "NodeVolumeLimits", "EBSLimits", "GCEPDLimits",
                "AzureDiskLimits", "VolumeBinding", "VolumeZone", "DynamicResources", "DefaultPreemption",
                "DefaultBinder", "ClusterCapacityBinder"}
+# ... of which these four are evaluated on the host for pods with volumes (volumes.py): disabling one under multiPoint takes it out;
+# with only its filter point disabled a pod with volumes is refused (the PreFilter half would still run in the scheduler)
+VOLUME_PLUGINS = ("VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone")
 
 
 class ConfigError(ValueError):
@@ -62,10 +65,14 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
     p = dataclasses.asdict(M.Profile.default())
     hard = 1
     system_default_spreading = True  # PodTopologySpreadArgs.defaultingType System (the default)
+    volume_plugins = set(VOLUME_PLUGINS)
+    volume_partial = []
 
     def done():
         out = M.Profile(**p)
         out.system_default_spreading = system_default_spreading  # host-side note (not an ABI field): see ingest.default_spreading_applies
+        out.volume_plugins = tuple(n for n in VOLUME_PLUGINS if n in volume_plugins)  # host-side note: which of them volumes.py evaluates
+        out.volume_plugins_partial = bool(volume_partial)
         return out, hard
     if not cfg:
         return done()
@@ -99,6 +106,10 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
         pset = pset or {}
         for d in pset.get("disabled") or []:
             name = d.get("name", "")
+            if do_filter and (name == "*" or name in VOLUME_PLUGINS):
+                if not multipoint:
+                    volume_partial.append(name)  # (its PreFilter would still run: refused when a pod with volumes arrives)
+                volume_plugins.difference_update(VOLUME_PLUGINS if name == "*" else (name,))
             infos = list(PLUGINS.values()) if name == "*" else [lookup(name)]
             for info in infos:
                 if info is None:
@@ -108,6 +119,8 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
                 if do_score:
                     set_score(info, 0)
         for e in pset.get("enabled") or []:
+            if multipoint and e.get("name", "") in VOLUME_PLUGINS:
+                volume_plugins.add(e["name"])
             info = lookup(e.get("name", ""))
             if info is None:
                 continue

@@ -1,0 +1,292 @@
+"""The volume plugins' object side: VolumeRestrictions, NodeVolumeLimits, VolumeBinding, VolumeZone.
+
+What they decide is string and object-graph work that does not change while clones are placed -- except a clone's own disks and a
+ReadWriteOncePod claim -- so it is evaluated here, once per template, into what the engine takes (include/ccsim.h ccsim_pod):
+`volume_veto[n]` (the code of the first of the four that rejects node n against the snapshot's pods) and `volume_exclusive`.  The
+PreFilter outcomes that reject the pod on every node (zero replicas, with the plugin's message as FitError.Diagnosis.PreFilterMsg) never
+reach the engine.  Python mirror of host/volumes.hpp.
+
+What the REFERENCE's scheduler sees: SyncWithClient copies PersistentVolumeClaims and StorageClasses into the fake cluster but NOT
+PersistentVolumes, CSINodes, CSIDrivers or CSIStorageCapacities (pkg/framework/simulator.go:228-295).  Hence, with the default plugins:
+  * a claim that does not exist                    -> VolumeRestrictions.PreFilter: `persistentvolumeclaim "x" not found`
+                                                      (volumerestrictions/volume_restrictions.go:175-181)
+  * a lost / terminating claim                     -> VolumeBinding.PreFilter (volumebinding/volume_binding.go:333-339, 356-357)
+  * an unbound claim of an Immediate class         -> VolumeBinding.PreFilter: "pod has unbound immediate PersistentVolumeClaims" (:366-372)
+  * a BOUND claim                                  -> VolumeZone.PreFilter: `persistentvolume "pv" not found` (volumezone/volume_zone.go:156-159,
+                                                      253-258) -- the volume is not in the fake cluster
+  * an unbound WaitForFirstConsumer claim          -> passes every PreFilter; VolumeBinding.Filter finds no volume to bind
+                                                      (binder.go checkVolumeProvisions): a class without a provisioner fails every node with
+                                                      "node(s) didn't find available persistent volumes to bind"; a class WITH one passes, and
+                                                      the pod then waits in PreBind for a PV controller the fake cluster does not run -- the
+                                                      reference hangs; refused here with that reason
+  * NodeVolumeLimits                               -> never rejects: no CSINode, no limits (nodevolumelimits/csi.go:265-290)
+  * GCE PD / EBS / RBD / ISCSI volumes             -> VolumeRestrictions.Filter against the node's pods and the clones (:105-150, 310-313)
+  * a ReadWriteOncePod claim                       -> in use by a pod of the snapshot: every node fails (:283-291); else the first clone
+                                                      takes it and the second cycle fails everywhere: capacity 1
+`sync_persistent_volumes` (the hosts' --sync-persistent-volumes) goes one step beyond the reference: PersistentVolume objects of the
+snapshot are taken too, so bound claims are judged as kube-scheduler judges them on the live cluster -- VolumeBinding's node affinity of the
+bound volume (binder.go checkBoundClaims) and VolumeZone's label match (volume_zone.go:191-240) -- as static per-node verdicts."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import model as M
+
+PLUGINS = ("VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone")
+ANN_BIND_COMPLETED = "pv.kubernetes.io/bind-completed"  # volume.AnnBindCompleted
+ANN_BETA_STORAGE_CLASS = "volume.beta.kubernetes.io/storage-class"  # v1.BetaStorageClassAnnotation
+NO_PROVISIONER = "kubernetes.io/no-provisioner"  # volume.NotSupportedProvisioner
+ZONE_BETA, REGION_BETA = "failure-domain.beta.kubernetes.io/zone", "failure-domain.beta.kubernetes.io/region"
+ZONE_GA, REGION_GA = "topology.kubernetes.io/zone", "topology.kubernetes.io/region"
+TOPOLOGY_LABELS = (ZONE_BETA, REGION_BETA, ZONE_GA, REGION_GA)  # volume_zone.go:84-89
+RESTRICTED_KINDS = ("gcePersistentDisk", "awsElasticBlockStore", "rbd", "iscsi")  # needsRestrictionsCheck (volume_restrictions.go:152-155)
+
+
+@dataclass
+class VolumeSide:
+    prefilter_reject: Optional[str] = None  # the pod is UnschedulableAndUnresolvable on every node: FitError.Diagnosis.PreFilterMsg
+    veto: Optional[np.ndarray] = None       # uint8[n]: model.VOL_* of the first volume plugin that rejects the node; None = none does
+    exclusive: bool = False                 # a clone's disks conflict with the next one's on the same node
+    rwop_capacity_one: bool = False         # a ReadWriteOncePod claim nobody uses yet: the first clone takes it, then every node fails
+
+
+def _read_only(src: dict) -> bool:
+    return bool(src.get("readOnly"))
+
+
+def volume_conflict(v: dict, ev: dict) -> bool:
+    """isVolumeConflict for one pair of volumes (volume_restrictions.go:105-150)."""
+    a, b = v.get("gcePersistentDisk"), ev.get("gcePersistentDisk")
+    if a is not None and b is not None and a.get("pdName", "") == b.get("pdName", "") and not (_read_only(a) and _read_only(b)):
+        return True
+    a, b = v.get("awsElasticBlockStore"), ev.get("awsElasticBlockStore")
+    if a is not None and b is not None and a.get("volumeID", "") == b.get("volumeID", ""):
+        return True
+    a, b = v.get("iscsi"), ev.get("iscsi")
+    if a is not None and b is not None and a.get("iqn", "") == b.get("iqn", "") and not (_read_only(a) and _read_only(b)):
+        return True
+    a, b = v.get("rbd"), ev.get("rbd")
+    if a is not None and b is not None:
+        mon, emon = a.get("monitors") or [], b.get("monitors") or []
+        pool, epool = a.get("pool") or "", b.get("pool") or ""  # (as written: ParseAPISpec applies no API defaults, options.go:79-147)
+        if set(mon) & set(emon) and pool == epool and a.get("image", "") == b.get("image", "") and not (_read_only(a) and _read_only(b)):
+            return True
+    return False
+
+
+def pod_conflicts(volumes: Sequence[dict], other_volumes: Sequence[dict]) -> bool:
+    """!satisfyVolumeConflicts for one existing pod (volume_restrictions.go:266-280)."""
+    return any(any(v.get(k) is not None for k in RESTRICTED_KINDS) and any(volume_conflict(v, ev) for ev in other_volumes) for v in volumes)
+
+
+def claim_class(pvc: dict) -> str:
+    """storagehelpers.GetPersistentVolumeClaimClass: the beta annotation wins over spec.storageClassName."""
+    ann = (pvc.get("metadata") or {}).get("annotations") or {}
+    if ANN_BETA_STORAGE_CLASS in ann:
+        return ann[ANN_BETA_STORAGE_CLASS] or ""
+    return (pvc.get("spec") or {}).get("storageClassName") or ""
+
+
+def _zones(value: str) -> Optional[set]:
+    """volumehelpers.LabelZonesToSet: "a__b" -> {a, b}; an empty element is an error (the label is then ignored, volume_zone.go:384-388)."""
+    out = set()
+    for z in str(value).split("__"):
+        z = z.strip()
+        if not z:
+            return None
+        out.add(z)
+    return out
+
+
+def _requirement_matches(labels: dict, r: dict) -> bool:
+    from .ingest import requirement_matches
+
+    key = r.get("key", "")
+    return requirement_matches(key in labels, labels.get(key), r.get("operator", ""), [str(x) for x in r.get("values") or []])
+
+
+def pv_node_affinity_matches(pv: dict, node_labels: dict) -> bool:
+    """storagehelpers.CheckNodeAffinity (component-helpers/storage/volume/helpers.go:68-84): the node object it builds carries the labels
+    only, so a matchFields requirement on metadata.name is compared with the empty name."""
+    req = ((pv.get("spec") or {}).get("nodeAffinity") or {}).get("required")
+    if req is None:
+        return True
+    for term in req.get("nodeSelectorTerms") or []:
+        exprs, fields = term.get("matchExpressions") or [], term.get("matchFields") or []
+        if not exprs and not fields:
+            continue  # (an empty term matches nothing: nodeaffinity.go:118-121)
+        if all(_requirement_matches(node_labels, r) for r in exprs) and all(_requirement_matches({"metadata.name": ""}, r) for r in fields):
+            return True
+    return False
+
+
+def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: Dict[str, int], pvc_objs: Sequence[dict] = (),
+                class_objs: Sequence[dict] = (), pv_objs: Optional[Sequence[dict]] = None,
+                enabled: Sequence[str] = PLUGINS) -> VolumeSide:
+    """`live`: the snapshot's non-terminal pods on kept nodes; `pv_objs` None: persistent volumes are not synced (the reference)."""
+    spec = sim_pod.get("spec") or {}
+    ns = (sim_pod.get("metadata") or {}).get("namespace") or "default"
+    volumes = list(spec.get("volumes") or [])
+    out = VolumeSide()
+    if not volumes:
+        return out
+    N = len(nodes)
+    for v in volumes:
+        if v.get("ephemeral") is not None:
+            # (the claim is named after the CLONE -- "<pod>-<volume>" -- and made by a controller the fake cluster does not run)
+            raise NotImplementedError(f"pod volume {v.get('name')!r}: generic ephemeral volumes are not modelled")
+    pvcs = {((o.get("metadata") or {}).get("namespace") or "default", (o.get("metadata") or {}).get("name", "")): o for o in pvc_objs}
+    classes = {(o.get("metadata") or {}).get("name", ""): o for o in class_objs}
+    pvs = None if pv_objs is None else {(o.get("metadata") or {}).get("name", ""): o for o in pv_objs}
+    claim_vols = [v for v in volumes if v.get("persistentVolumeClaim") is not None]
+    claim_names = [(v["persistentVolumeClaim"] or {}).get("claimName", "") for v in claim_vols]
+    not_found = lambda kind, name: f'{kind} "{name}" not found'  # noqa: E731  (apierrors.NewNotFound(...).Error())
+
+    # ---- PreFilter, in plugin order (framework.go:726-787: the first rejection ends the cycle) ------------------------------------------
+    rwop: List[str] = []
+    if "VolumeRestrictions" in enabled:  # volume_restrictions.go:166-193, 249-264
+        for name in claim_names:
+            pvc = pvcs.get((ns, name))
+            if pvc is None:
+                out.prefilter_reject = not_found("persistentvolumeclaim", name)
+                return out
+            if "ReadWriteOncePod" in ((pvc.get("spec") or {}).get("accessModes") or []):
+                rwop.append(name)
+    delayed: List[dict] = []
+    bound: List[dict] = []
+    if "VolumeBinding" in enabled and claim_names:  # volume_binding.go:306-383, binder.go:719-828
+        for name in claim_names:
+            pvc = pvcs.get((ns, name))
+            if pvc is None:
+                out.prefilter_reject = not_found("persistentvolumeclaim", name)
+                return out
+            if (pvc.get("status") or {}).get("phase") == "Lost":
+                out.prefilter_reject = f'persistentvolumeclaim "{name}" bound to non-existent persistentvolume "{(pvc.get("spec") or {}).get("volumeName") or ""}"'
+                return out
+            if (pvc.get("metadata") or {}).get("deletionTimestamp") is not None:
+                out.prefilter_reject = f'persistentvolumeclaim "{name}" is being deleted'
+                return out
+        immediate = False
+        for name in claim_names:
+            pvc = pvcs[(ns, name)]
+            vol_name = (pvc.get("spec") or {}).get("volumeName") or ""
+            if vol_name and ANN_BIND_COMPLETED in ((pvc.get("metadata") or {}).get("annotations") or {}):
+                bound.append(pvc)
+                continue
+            cname = claim_class(pvc)
+            delay = False
+            if cname:  # volume.IsDelayBindingMode (an error of the class lister is a scheduler ERROR, not a rejection)
+                cls = classes.get(cname)
+                if cls is None:
+                    raise NotImplementedError(f'persistentvolumeclaim "{name}": StorageClass "{cname}" is not in the snapshot (the reference\'s scheduler fails the cycle with an error)')
+                if cls.get("volumeBindingMode") is None:
+                    raise NotImplementedError(f'StorageClass "{cname}" has no volumeBindingMode (the reference\'s scheduler fails the cycle with an error)')
+                delay = cls["volumeBindingMode"] == "WaitForFirstConsumer"
+            if delay and not vol_name:
+                delayed.append(pvc)
+            else:
+                immediate = True
+        if immediate:
+            out.prefilter_reject = "pod has unbound immediate PersistentVolumeClaims"
+            return out
+    topologies: List[Tuple[str, set]] = []
+    if "VolumeZone" in enabled:  # volume_zone.go:111-165
+        for name in claim_names:
+            if name == "":
+                out.prefilter_reject = "PersistentVolumeClaim had no name"
+                return out
+            pvc = pvcs.get((ns, name))
+            if pvc is None:
+                out.prefilter_reject = not_found("persistentvolumeclaim", name)
+                return out
+            vol_name = (pvc.get("spec") or {}).get("volumeName") or ""
+            if not vol_name:
+                cname = claim_class(pvc)
+                if not cname:
+                    out.prefilter_reject = "PersistentVolumeClaim had no pv name and storageClass name"
+                    return out
+                cls = classes.get(cname)
+                if cls is None:
+                    out.prefilter_reject = not_found("storageclass.storage.k8s.io", cname)
+                    return out
+                if cls.get("volumeBindingMode") is None:
+                    out.prefilter_reject = f'VolumeBindingMode not set for StorageClass "{cname}"'
+                    return out
+                if cls["volumeBindingMode"] == "WaitForFirstConsumer":
+                    continue
+                out.prefilter_reject = "PersistentVolume had no name"
+                return out
+            pv = None if pvs is None else pvs.get(vol_name)
+            if pv is None:
+                out.prefilter_reject = not_found("persistentvolume", vol_name)
+                return out
+            labels = (pv.get("metadata") or {}).get("labels") or {}
+            for key in TOPOLOGY_LABELS:
+                if key in labels:
+                    zs = _zones(labels[key])
+                    if zs is not None:
+                        topologies.append((key, zs))
+
+    # ---- Filter: the first of the four that rejects the node (default_plugins.go:41-44) --------------------------------------------------
+    veto = np.zeros(N, np.uint8)
+
+    def mark(mask, code):
+        veto[(veto == 0) & mask] = code
+
+    if "VolumeRestrictions" in enabled:
+        if any(v.get(k) is not None for v in volumes for k in RESTRICTED_KINDS):
+            conflict = np.zeros(N, bool)
+            for p in live:
+                if pod_conflicts(volumes, (p.get("spec") or {}).get("volumes") or []):
+                    conflict[index[p["spec"]["nodeName"]]] = True
+            mark(conflict, M.VOL_DISK_CONFLICT)
+            out.exclusive = pod_conflicts(volumes, volumes)
+        if rwop:  # IsPVCUsedByPods (S/backend/cache/snapshot.go usedPVCSet: every pod of every node, keyed namespace/name)
+            used = set()
+            for p in live:
+                pns = (p.get("metadata") or {}).get("namespace") or "default"
+                for v in (p.get("spec") or {}).get("volumes") or []:
+                    if v.get("persistentVolumeClaim") is not None:
+                        used.add((pns, (v["persistentVolumeClaim"] or {}).get("claimName", "")))
+            if any((ns, name) in used for name in rwop):
+                mark(np.ones(N, bool), M.VOL_RWOP)
+            else:
+                out.rwop_capacity_one = True
+    # (NodeVolumeLimits: no CSINode in the fake cluster, no limits: nodevolumelimits/csi.go:265-290)
+    if "VolumeBinding" in enabled:
+        if bound:  # binder.go checkBoundClaims
+            missing = pvs is None or any(((c.get("spec") or {}).get("volumeName") or "") not in pvs for c in bound)
+            if missing:
+                mark(np.ones(N, bool), M.VOL_PV_NOT_EXIST)
+            else:
+                node_labels = [(n.get("metadata") or {}).get("labels") or {} for n in nodes]
+                bad = np.array([not all(pv_node_affinity_matches(pvs[(c["spec"]["volumeName"])], lb) for c in bound) for lb in node_labels], bool)
+                mark(bad, M.VOL_NODE_AFFINITY)
+        for pvc in delayed:  # binder.go findMatchingVolumes (no volume of the class to match) -> checkVolumeProvisions
+            cname = claim_class(pvc)
+            if pvs is not None and any(((pv.get("spec") or {}).get("storageClassName") or "") == cname for pv in pvs.values()):
+                raise NotImplementedError(f'persistentvolumeclaim "{pvc["metadata"]["name"]}": matching an unbound claim against the persistent volumes of class "{cname}" is not modelled')
+            prov = (classes[cname].get("provisioner") or "")
+            if prov == "" or prov == NO_PROVISIONER:
+                mark(np.ones(N, bool), M.VOL_NO_PV)
+            else:
+                raise NotImplementedError(f'persistentvolumeclaim "{pvc["metadata"]["name"]}" waits for its first consumer: StorageClass "{cname}" would provision the volume in '
+                                          "PreBind, which waits for a PV controller the simulated cluster does not run (the reference does not terminate)")
+    if "VolumeZone" in enabled and topologies:  # volume_zone.go:191-240
+        bad = np.zeros(N, bool)
+        for i, n in enumerate(nodes):
+            labels = (n.get("metadata") or {}).get("labels") or {}
+            if not any(k in labels for k in TOPOLOGY_LABELS):
+                continue  # (a node without any zone label is fine: a single-zone cluster)
+            for key, zs in topologies:
+                ga = {ZONE_BETA: ZONE_GA, REGION_BETA: REGION_GA}.get(key, key)
+                val = labels.get(key) if key in labels else labels.get(ga)
+                if val is None or val not in zs:
+                    bad[i] = True
+                    break
+        mark(bad, M.VOL_ZONE)
+    out.veto = veto if veto.any() else None
+    return out
