@@ -39,10 +39,12 @@ class ClusterCapacity {
         return c;
     }
     // spreading_objs: the Services and controllers of the dump (PodTopologySpread's system default constraints)
+    // volume_objs: the PersistentVolumeClaims and StorageClasses of the dump (simulator.go:228-295; volumes only with sync_volumes)
     void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods, const std::vector<Value> &namespaces = {},
-                        const std::vector<Value> &spreading_objs = {}) {
+                        const std::vector<Value> &spreading_objs = {}, VolumeObjects volume_objs = {}) {
+        volume_objs.plugins = profile_.volume_plugins, volume_objs.plugins_partial = profile_.volume_plugins_partial;
         snap_ = build_snapshot(nodes, pods, pods_, exclude_, profile_.hard_pod_affinity_weight, namespaces, spreading_objs,
-                               profile_.c.w_topologyspread != 0 && profile_.system_default_spreading);
+                               profile_.c.w_topologyspread != 0 && profile_.system_default_spreading, &volume_objs);
         synced_ = true;
     }
     void Run() {

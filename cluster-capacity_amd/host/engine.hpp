@@ -199,6 +199,8 @@ inline void marshal_pod(const PodSide &s, MarshalledPod &m) {
     p.has_host_ports = s.has_host_ports;
     p.host_ports_conflict = s.host_ports_conflict.empty() ? nullptr : s.host_ports_conflict.data();
     p.image_score = s.image_score.empty() ? nullptr : s.image_score.data();
+    p.volume_exclusive = s.volume_exclusive;
+    p.volume_veto = s.volume_veto.empty() ? nullptr : s.volume_veto.data();
 }
 
 // What one more clone of template `t` on node `n` adds to the per-node counts the template's topology-coupled plugins are set with:
@@ -240,6 +242,32 @@ inline void add_own_clone(const Snapshot &s, PodSide &side, size_t n) {
         if (side.host_ports_conflict.empty()) side.host_ports_conflict.assign(N, 0);
         side.host_ports_conflict[n] = 1;
     }
+    if (side.volume_exclusive) { // (... and of a pod whose disks conflict with a clone's: volume_restrictions.go:105-150, the first volume check)
+        if (side.volume_veto.empty()) side.volume_veto.assign(N, 0);
+        side.volume_veto[n] = 1;
+    }
+}
+
+// The cycle a PreFilter plugin rejects (schedule_one.go:495-508): no node is evaluated, every node carries the plugin's status.
+inline RunResult rejected_by_prefilter(const Snapshot &s, const PodSide &side, const std::string &msg) {
+    RunResult r;
+    r.placed = 0, r.stop = CCSIM_STOP_UNSCHEDULABLE, r.n_code_unschedulable = 0, r.prefilter_msg = msg;
+    r.per_node_count.assign(s.n(), 0);
+    r.hist.assign(CCSIM_NREASON, 0);
+    r.hist_taintset.assign(side.taint_filter_ok.size(), 0);
+    r.per_spec_count.assign(s.n_templates(), 0);
+    return r;
+}
+
+// The pod once a clone holds its ReadWriteOncePod claim: VolumeRestrictions fails every node -- after its own disk check (`clones`: where
+// the pod's earlier clones sit, for a pod whose disks are exclusive: the engine counts clones from the moment a pod is set).
+inline void rwop_now_in_use(PodSide &side, size_t N, const std::vector<int32_t> *clones = nullptr) {
+    if (side.volume_veto.empty()) side.volume_veto.assign(N, 0);
+    for (size_t i = 0; i < N; i++) {
+        if (side.volume_exclusive && clones && (*clones)[i] > 0) side.volume_veto[i] = 1;
+        if (side.volume_veto[i] != 1) side.volume_veto[i] = 2;
+    }
+    side.rwop_capacity_one = false;
 }
 
 // Several templates WITHOUT the window engine: the reference's literal loop -- cycle i schedules a clone of template i mod P
@@ -265,6 +293,12 @@ inline RunResult simulate_one_cycle_at_a_time(const Api &api, ccsim_engine *e, c
     auto fail = [&](int rc, const char *what) { throw std::runtime_error(std::string(what) + " failed rc=" + std::to_string(rc) + ": " + (api.last_error(e) ? api.last_error(e) : "")); };
     for (;;) {
         const size_t t = (size_t)(r.placed % (int64_t)P);
+        if (!sides[t].prefilter_reject.empty()) { // a volume plugin's PreFilter: this template's cycle ends the run
+            r.stop = CCSIM_STOP_UNSCHEDULABLE, r.stop_spec = (int32_t)t, r.n_code_unschedulable = 0, r.prefilter_msg = sides[t].prefilter_reject;
+            r.hist_taintset.assign(sides[t].taint_filter_ok.size(), 0);
+            break;
+        }
+        if (sides[t].rwop_capacity_one && r.per_spec_count[t] == 1) rwop_now_in_use(sides[t], N); // (add_own_clone has marked its own disks)
         MarshalledPod mp;
         marshal_pod(sides[t], mp);
         int rc = api.set_pod(e, &mp.pod);
@@ -317,6 +351,7 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
         std::fprintf(stderr, "cluster-capacity: note: several templates are placed with every node scored (percentageOfNodesToScore 100); with --max-limit the placed "
                              "set may differ from a run of the reference's default adaptive sampling\n");
     const int percentage = prof_eff.c.percentage_of_nodes_to_score;
+    if (s.n_templates() == 1 && !s.prefilter_reject.empty()) return rejected_by_prefilter(s, s, s.prefilter_reject); // (no engine, no device)
     marshal(s, prof_eff, m);
     ccsim_config cfg{};
     cfg.abi_version = CCSIM_ABI_VERSION, cfg.device = device, cfg.use_graph = 1;
@@ -332,8 +367,19 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     };
     chk(api.load_nodes(e, &m.nodes), "ccsim_load_nodes");
     chk(api.set_profile(e, &m.profile), "ccsim_set_profile");
+    bool host_side_rules = false; // (a PreFilter rejection / a ReadWriteOncePod claim of some template: nothing ccsim_set_pods could refuse)
+    for (size_t t = 0; t < s.n_templates(); t++) host_side_rules = host_side_rules || !s.side(t).prefilter_reject.empty() || s.side(t).rwop_capacity_one;
     if (s.n_templates() == 1) chk(api.set_pod(e, &m.pod_array[0]), "ccsim_set_pod");
-    else {
+    else if (host_side_rules) {
+        try {
+            RunResult r = simulate_one_cycle_at_a_time(api, e, s, max_limit);
+            api.destroy(e);
+            return r;
+        } catch (...) {
+            api.destroy(e);
+            throw;
+        }
+    } else {
         const int src = api.set_pods(e, m.pod_array.data(), (int32_t)m.pod_array.size()); // cycled round-robin by ccsim_run
         if (src == -38) { // -ENOSYS: a set of pod specs the window engine does not take: the literal loop instead
             const std::string why = api.last_error(e) ? api.last_error(e) : "";
@@ -372,7 +418,30 @@ inline RunResult simulate(const Snapshot &s, int64_t max_limit, const std::strin
     rep.per_node_count = r.per_node_count.data(), rep.per_node_cap = (int64_t)r.per_node_count.size();
     rep.log = r.log.data(), rep.log_cap = cap;
     rep.hist_taintset = r.hist_taintset.data(), rep.hist_taintset_cap = (int32_t)r.hist_taintset.size();
-    chk(api.run(e, max_limit, mode, &rep), "ccsim_run");
+    if (s.n_templates() == 1 && s.rwop_capacity_one && max_limit != 1) {
+        // A ReadWriteOncePod claim nobody uses yet: the first clone takes it (volume_restrictions.go:249-264, 283-291), the second cycle
+        // then fails on every node that gets as far as VolumeRestrictions: the pod set again on the SAME state with that verdict
+        chk(api.run(e, 1, mode, &rep), "ccsim_run");
+        if (rep.placed == 1) {
+            const std::vector<int32_t> first_counts = r.per_node_count;
+            const int32_t first_node = r.log[0];
+            PodSide side = s;
+            rwop_now_in_use(side, s.n(), &first_counts);
+            MarshalledPod mp;
+            marshal_pod(side, mp);
+            chk(api.set_pod(e, &mp.pod), "ccsim_set_pod");
+            std::vector<int32_t> none(std::max<size_t>(s.n(), 1), 0);
+            rep.per_node_count = none.data();
+            chk(api.run(e, 0, mode, &rep), "ccsim_run");
+            if (rep.placed != 0 || rep.stop != CCSIM_STOP_UNSCHEDULABLE) {
+                api.destroy(e);
+                throw std::runtime_error("a second clone of a pod with a ReadWriteOncePod claim was placed");
+            }
+            r.per_node_count = first_counts, r.log[0] = first_node;
+            rep.placed = 1, rep.log_len = 1, rep.per_node_count = r.per_node_count.data();
+        }
+    } else
+        chk(api.run(e, max_limit, mode, &rep), "ccsim_run");
     api.destroy(e);
     r.placed = rep.placed, r.stop = rep.stop, r.n_code_unschedulable = rep.n_code_unschedulable, r.stop_spec = rep.stop_spec;
     r.per_node_count.resize(s.n());

@@ -112,7 +112,12 @@ std::vector<Value> load_kind(const std::vector<std::string> &paths, const std::s
 
 // `templates`: the simulated pods -- the Nodes' status.images entries are kept only for the images their containers name
 void load_objects(const std::vector<std::string> &paths, const std::vector<Value> &templates, std::vector<Value> &nodes, std::vector<Value> &pods,
-                  std::vector<Value> &namespaces, std::vector<Value> &services) {
+                  std::vector<Value> &namespaces, std::vector<Value> &services, VolumeObjects &vol) {
+    // spec.volumes of the dump's pods are materialised only when a template has volumes the volume plugins compare them with
+    bool template_volumes = false;
+    for (const auto &t : templates)
+        for (const auto &v : t["spec"]["volumes"].items()) template_volumes = template_volumes || restricted(v) || !v["persistentVolumeClaim"].is_null();
+    prune::keep_pod_volumes() = template_volumes;
     std::vector<std::string> wanted;
     for (const auto &t : templates)
         for (const char *list : {"initContainers", "containers"})
@@ -123,6 +128,9 @@ void load_objects(const std::vector<std::string> &paths, const std::vector<Value
         else if (kind == "Pod") pods.push_back(std::move(o));
         else if (kind == "Namespace") namespaces.push_back(std::move(o));
         else if (kind == "Service" || kind == "ReplicationController" || kind == "ReplicaSet" || kind == "StatefulSet") services.push_back(std::move(o));
+        else if (kind == "PersistentVolumeClaim") vol.claims.push_back(std::move(o)); // SyncWithClient copies claims and classes (simulator.go:228-295) ...
+        else if (kind == "StorageClass") vol.classes.push_back(std::move(o));
+        else if (kind == "PersistentVolume" && vol.sync_volumes) vol.volumes.push_back(std::move(o)); // ... not the volumes (--sync-persistent-volumes)
     }, &wanted);
 }
 
@@ -165,7 +173,7 @@ RunResult result_from_json(const Value &v) {
 int usage(const char *msg) {
     std::fprintf(stderr, "%s\nusage: cluster-capacity --podspec FILE [--podspec FILE ...] --snapshot FILE [--snapshot FILE ...] [--max-limit N] [--exclude-nodes a,b]\n"
                          "                        [--default-config FILE] [--verbose] [-o json|yaml] [--mode batched|sequential]\n"
-                         "                        [--percentage-of-nodes-to-score P] [--device D] [--gpus N]\n"
+                         "                        [--percentage-of-nodes-to-score P] [--sync-persistent-volumes] [--device D] [--gpus N]\n"
                          "       cluster-capacity --genpod NAMESPACE --snapshot FILE [--snapshot FILE ...] [-o json|yaml]\n",
                  msg);
     return 2;
@@ -181,6 +189,7 @@ int main(int argc, char **argv) {
     int64_t max_limit = 0;
     int percentage = 100, device = 0, gpus = 1;
     bool force_sharded = false;
+    bool sync_volumes = false;
     bool verbose = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i], val;
@@ -208,6 +217,7 @@ int main(int argc, char **argv) {
             else if (a == "--mode") mode = need();
             else if (a == "--percentage-of-nodes-to-score") percentage = std::stoi(need()), pct_flag = true;
             else if (a == "--default-config") sched_config = need();
+            else if (a == "--sync-persistent-volumes") sync_volumes = true; // beyond the reference: PersistentVolume objects are taken too
             else if (a == "--dump-profile") dump_profile = true;
             else if (a == "--genpod") genpod_ns = need(); // cmd/genpod: the pod a namespace's LimitRanges / annotations describe
             else if (a == "--device") device = std::stoi(need());
@@ -278,9 +288,11 @@ int main(int argc, char **argv) {
         };
         auto t0 = now();
         std::vector<Value> node_objs, pod_objs, ns_objs, svc_objs;
-        load_objects(snapshots, templates, node_objs, pod_objs, ns_objs, svc_objs);
+        VolumeObjects vol;
+        vol.sync_volumes = sync_volumes;
+        load_objects(snapshots, templates, node_objs, pod_objs, ns_objs, svc_objs, vol);
         lap("read + parse objects", t0);
-        cc.SyncWithClient(node_objs, pod_objs, ns_objs, svc_objs);
+        cc.SyncWithClient(node_objs, pod_objs, ns_objs, svc_objs, std::move(vol));
         if (cc.snapshot().default_spreading_unmodelled)
             std::fprintf(stderr, "warning: a Service (or its controller) selects the simulated pod and it has no topologySpreadConstraints of its own: the scheduler's "
                                  "system default spreading (hostname maxSkew 3, zone maxSkew 5, ScheduleAnyway) would score the nodes too; some node lacks one of the "

@@ -173,6 +173,7 @@ inline PreemptionOutcome preemption_dry_run(const Snapshot &s, const PodSide &p,
     if (mixed_priorities) return out.kind = PreemptionOutcome::Unmodelled, out;
     if (p.victim_count.empty()) return out;
     if (n_templates > 1) return out.kind = PreemptionOutcome::Unmodelled, out;
+    if (!p.volume_veto.empty() || p.volume_exclusive) return out.kind = PreemptionOutcome::Unmodelled, out; // (a victim's disks / claims would have to leave the verdicts with it)
 
     bool all_zero = !p.has_scalar_entries; // fit.go:578-583
     for (size_t c = 0; c < 3 && c < R; c++) all_zero = all_zero && !(p.preq[c] > 0);

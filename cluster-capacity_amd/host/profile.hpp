@@ -20,6 +20,10 @@ struct HostProfile {
     int hard_pod_affinity_weight = 1; // InterPodAffinityArgs (defaults.go:229-231), used by the ingest
     bool percentage_set = false;      // percentageOfNodesToScore came from the config file / the command line (else: see simulate())
     bool system_default_spreading = true; // PodTopologySpreadArgs.defaultingType System (the default); List with no constraints turns it off
+    // which of VolumeRestrictions / NodeVolumeLimits / VolumeBinding / VolumeZone the host evaluates for pods with volumes (volumes.hpp):
+    // disabling one under multiPoint takes it out; with only its filter point disabled a pod with volumes is refused
+    std::vector<std::string> volume_plugins = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};
+    bool volume_plugins_partial = false;
 };
 
 inline HostProfile default_profile() {
@@ -102,6 +106,12 @@ inline HostProfile profile_from_config(const Value &cfg) {
     auto apply = [&](const Value &set, bool do_filter, bool do_score, bool multipoint) {
         for (const auto &d : set["disabled"].items()) {
             const std::string name = d["name"].text();
+            const bool volume_plugin = name == "VolumeRestrictions" || name == "NodeVolumeLimits" || name == "VolumeBinding" || name == "VolumeZone";
+            if (do_filter && (name == "*" || volume_plugin)) {
+                if (!multipoint) p.volume_plugins_partial = true; // (its PreFilter would still run: refused when a pod with volumes arrives)
+                if (name == "*") p.volume_plugins.clear();
+                else p.volume_plugins.erase(std::remove(p.volume_plugins.begin(), p.volume_plugins.end(), name), p.volume_plugins.end());
+            }
             if (name == "*") {
                 for (const auto &kv : plugin_table()) {
                     if (do_filter) set_filter(kv.second, false);
@@ -115,6 +125,12 @@ inline HostProfile profile_from_config(const Value &cfg) {
             }
         }
         for (const auto &e : set["enabled"].items()) {
+            if (multipoint) {
+                const std::string en = e["name"].text();
+                static const char *order[] = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};
+                for (const char *v : order)
+                    if (en == v && std::find(p.volume_plugins.begin(), p.volume_plugins.end(), en) == p.volume_plugins.end()) p.volume_plugins.push_back(en);
+            }
             const PluginInfo *i = lookup(e["name"].text());
             if (!i) continue;
             if (do_filter) set_filter(*i, true);

@@ -29,6 +29,7 @@ struct RunResult { // what ccsim_run hands back (host copies)
     int64_t n_code_unschedulable = 0;
     std::vector<int32_t> per_spec_count; // several templates: placements per template ...
     int32_t stop_spec = -1;              // ... and the template whose pod was Unschedulable
+    std::string prefilter_msg;           // host only: the terminal cycle was rejected by a PreFilter plugin (FitError.Diagnosis.PreFilterMsg)
 };
 
 inline std::string histogram_message(const std::map<std::string, int64_t> &reasons) {
@@ -92,8 +93,14 @@ inline std::map<std::string, int64_t> reason_histogram(const std::vector<int64_t
 inline std::string fit_error_message(int64_t n_nodes, const RunResult &r, const std::vector<std::string> &taint_reasons,
                                      const std::vector<std::string> &scalar_names, const PreemptionOutcome *pre = nullptr) {
     std::string msg = "0/" + std::to_string(n_nodes) + " nodes are available:";
-    const std::string body = histogram_message(reason_histogram(r.hist, r.hist_taintset, taint_reasons, scalar_names));
-    if (!body.empty()) msg += " " + body + ".";
+    if (!r.prefilter_msg.empty()) {
+        // a PreFilter plugin rejected the pod (schedule_one.go:495-508): its message stands for every node (types.go:789-794), and every
+        // node is UnschedulableAndUnresolvable for the preemption that follows (n_code_unschedulable = 0)
+        msg += " " + r.prefilter_msg + ".";
+    } else {
+        const std::string body = histogram_message(reason_histogram(r.hist, r.hist_taintset, taint_reasons, scalar_names));
+        if (!body.empty()) msg += " " + body + ".";
+    }
     if (pre && pre->kind == PreemptionOutcome::Nominated) return msg; // a candidate: PostFilter Success, empty message (preemption.go:281-303)
     if (pre && pre->kind == PreemptionOutcome::Never) return msg + " preemption: not eligible due to preemptionPolicy=Never."; // default_preemption.go:355-357
     // Nodes that failed with plain Unschedulable are dry-run nodes: without a lower-priority pod each reports "No preemption

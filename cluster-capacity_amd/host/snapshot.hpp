@@ -310,6 +310,9 @@ inline bool label_selector_matches(const Value &sel, const Value &labels) {
     return true;
 }
 inline bool selector_empty(const Value &sel) { return !sel.is_null() && !sel["matchLabels"].truthy() && !sel["matchExpressions"].truthy(); }
+} // namespace cchost
+#include "volumes.hpp"
+namespace cchost {
 
 struct Requirement {
     int col;
@@ -408,6 +411,12 @@ struct PodSide {
     bool has_host_ports = false;              // NodePorts: util.GetHostPorts(pod) is not empty
     std::vector<uint8_t> host_ports_conflict; // per node: an existing pod holds a conflicting port; empty = none does
     std::vector<uint8_t> image_score;         // ImageLocality score per node (0..100); empty = no image of the pod anywhere
+    // the volume plugins (volumes.hpp): per node the code of the first of them that rejects it (empty = none does); the pod's own disks
+    // conflict with a clone's; HOST ONLY: a PreFilter rejection (its message; empty = none) and the ReadWriteOncePod claim nobody uses yet
+    std::vector<uint8_t> volume_veto;
+    bool volume_exclusive = false;
+    std::string prefilter_reject;
+    bool rwop_capacity_one = false;
     // DefaultPreemption's dry run of the terminal cycle (HOST ONLY, never crosses the C ABI; preemption.hpp): a victim is an
     // existing pod of lower priority than the template (default_preemption.go:392-396)
     int64_t priority = 0;
@@ -581,8 +590,12 @@ inline bool any_nonzero(const std::vector<int32_t> &v) {
 
 inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const std::vector<Value> &sim_pods,
                                const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1,
-                               const std::vector<Value> &namespace_objs = {}, const std::vector<Value> &spreading_objs = {}, bool system_default_spreading = true) {
+                               const std::vector<Value> &namespace_objs = {}, const std::vector<Value> &spreading_objs = {}, bool system_default_spreading = true,
+                               const VolumeObjects *volume_objs = nullptr) {
     // spreading_objs: the Services and controllers (ReplicationController / ReplicaSet / StatefulSet) of the dump: helper.DefaultSelector
+    // volume_objs: the claims, classes (and, beyond the reference, volumes) of the dump + which volume plugins run; nullptr = none, all four
+    static const VolumeObjects no_volume_objs;
+    const VolumeObjects &vol = volume_objs ? *volume_objs : no_volume_objs;
     if (sim_pods.empty()) throw std::runtime_error("no pod spec");
     Snapshot S;
     NamespaceLabels ns_labels;
@@ -823,11 +836,14 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
             }
         }
     }
-    // volume-backed plugins (VolumeBinding / VolumeZone / VolumeRestrictions / NodeVolumeLimits / DynamicResources) have no
-    // integer form here: a pod that would activate them is refused instead of silently ignoring the constraint
-    for (const auto &v : spec["volumes"].items())
-        for (const char *kind : {"persistentVolumeClaim", "ephemeral", "gcePersistentDisk", "awsElasticBlockStore", "rbd", "iscsi", "csi"})
-            if (!v[kind].is_null()) throw std::runtime_error("pod volume '" + v["name"].text() + "' of kind " + kind + ": the volume plugins are not modelled");
+    // VolumeRestrictions / NodeVolumeLimits / VolumeBinding / VolumeZone: the object side (volumes.hpp) -> per-node verdict codes, the
+    // clones' own disks, the PreFilter rejections.  (inline csi volumes only count against CSINode limits, which the simulated cluster
+    // does not have: nodevolumelimits/csi.go:265-290.)  DynamicResources stays refused.
+    {
+        VolumeSide vs = volume_side(sim_pod, nodes, live, live_node, vol);
+        s.volume_veto = std::move(vs.veto), s.volume_exclusive = vs.exclusive;
+        s.prefilter_reject = vs.rejected ? vs.prefilter_reject : std::string(), s.rwop_capacity_one = vs.rwop_capacity_one;
+    }
     if (spec["resourceClaims"].truthy()) throw std::runtime_error("spec.resourceClaims: the DynamicResources plugin is not modelled");
 
     // topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
@@ -1013,6 +1029,29 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     S.label_keys = it.keys;
     S.label_cols = it.arrays;
     if ((int)S.label_cols.size() > CCSIM_MAX_LABEL_COLS) throw Unsupported("too many distinct label keys in selectors");
+    // several templates: a clone's disks exclude clones of the SAME template from its node (volume_exclusive); a disk or a
+    // ReadWriteOncePod claim shared by two templates would exclude the other's clones too, which nothing tracks
+    if (sim_pods.size() > 1) {
+        std::set<std::pair<std::string, std::string>> rwop;
+        for (const auto &o : vol.claims)
+            for (const auto &m : o["spec"]["accessModes"].items())
+                if (m.text() == "ReadWriteOncePod") rwop.insert({ns_of(o), o["metadata"]["name"].text()});
+        auto claims = [&](const Value &p) {
+            std::set<std::pair<std::string, std::string>> out;
+            for (const auto &v : p["spec"]["volumes"].items())
+                if (!v["persistentVolumeClaim"].is_null()) out.insert({ns_of(p), v["persistentVolumeClaim"]["claimName"].text()});
+            return out;
+        };
+        for (size_t a = 0; a < sim_pods.size(); a++)
+            for (size_t b = a + 1; b < sim_pods.size(); b++) {
+                if (pod_conflicts(sim_pods[a]["spec"]["volumes"], sim_pods[b]["spec"]["volumes"]))
+                    throw Unsupported("templates " + std::to_string(a) + " and " + std::to_string(b) + " mount the same disk: conflicts between clones of different templates are not modelled");
+                const auto ca = claims(sim_pods[a]), cb = claims(sim_pods[b]);
+                for (const auto &c : ca)
+                    if (cb.count(c) && rwop.count(c))
+                        throw Unsupported("templates " + std::to_string(a) + " and " + std::to_string(b) + " share a ReadWriteOncePod claim: not modelled");
+            }
+    }
     // several templates: what a clone contributes to the plugin state of later cycles is kept per template (the engine's
     // ccsim_set_pods contract): no selector of one template may match the clones of another
     if (sim_pods.size() > 1)
@@ -1035,8 +1074,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
 
 inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::vector<Value> &pod_objs, const Value &sim_pod,
                                const std::vector<std::string> &exclude_nodes, int hard_pod_affinity_weight = 1,
-                               const std::vector<Value> &namespace_objs = {}, const std::vector<Value> &spreading_objs = {}, bool system_default_spreading = true) {
-    return build_snapshot(node_objs, pod_objs, std::vector<Value>{sim_pod}, exclude_nodes, hard_pod_affinity_weight, namespace_objs, spreading_objs, system_default_spreading);
+                               const std::vector<Value> &namespace_objs = {}, const std::vector<Value> &spreading_objs = {}, bool system_default_spreading = true,
+                               const VolumeObjects *volume_objs = nullptr) {
+    return build_snapshot(node_objs, pod_objs, std::vector<Value>{sim_pod}, exclude_nodes, hard_pod_affinity_weight, namespace_objs, spreading_objs, system_default_spreading,
+                          volume_objs);
 }
 
 // ---- the dump the CPU tests compare with the Python ingest (tests/test_native_host.py) -------------------------
@@ -1097,6 +1138,10 @@ inline Value pod_side_json(const PodSide &s) {
     p.set("has_host_ports", Value::boolean(s.has_host_ports));
     p.set("host_ports_conflict", s.host_ports_conflict.empty() ? Value() : int_array(s.host_ports_conflict));
     p.set("image_score", s.image_score.empty() ? Value() : int_array(s.image_score));
+    p.set("volume_veto", s.volume_veto.empty() ? Value() : int_array(s.volume_veto));
+    p.set("volume_exclusive", Value::boolean(s.volume_exclusive));
+    p.set("prefilter_reject", s.prefilter_reject.empty() ? Value() : Value::str(s.prefilter_reject));
+    p.set("rwop_capacity_one", Value::boolean(s.rwop_capacity_one));
     Value pre = Value::object();
     pre.set("priority", Value::num(s.priority)), pre.set("never", Value::boolean(s.preempt_never));
     pre.set("victim_count", s.victim_count.empty() ? Value() : int_array(s.victim_count));

@@ -167,6 +167,11 @@ inline bool one_of(const std::string &k, std::initializer_list<const char *> nam
 }
 // `kind`: of the item being parsed ("" until its "kind" member was seen); images_filtered / images_none: status.images is filtered
 // by the template's image names / dropped altogether (no template names an image)
+// spec.volumes of the dump's Pods: read only when a template carries volumes the volume plugins compare them with (main.cpp load_objects)
+inline bool &keep_pod_volumes() {
+    static bool keep = false;
+    return keep;
+}
 inline int member_ctx(Ctx c, const std::string &k, const std::string &kind, bool images_filtered, bool images_none) {
     switch (c) {
     case Item:
@@ -177,14 +182,16 @@ inline int member_ctx(Ctx c, const std::string &k, const std::string &kind, bool
         return NoCtx;
     case Metadata:
         if (one_of(k, {"managedFields", "ownerReferences", "finalizers"})) return -1;
-        if (k == "annotations" && !kind.empty() && kind != "Namespace") return -1;
+        // (a claim's annotations say whether its binding is complete and name its class the old way: volumes.hpp)
+        if (k == "annotations" && !kind.empty() && kind != "Namespace" && kind != "PersistentVolumeClaim") return -1;
         return NoCtx;
     case Status:
         if (k == "images") return images_filtered ? (images_none ? -1 : (int)Images) : (int)NoCtx;
         return one_of(k, {"phase", "allocatable"}) ? NoCtx : -1;
     case Spec:
         if (one_of(k, {"containers", "initContainers"})) return Containers;
-        if (one_of(k, {"volumes", "securityContext", "imagePullSecrets", "dnsConfig", "hostAliases", "readinessGates", "tolerations", "ephemeralContainers"})) return -1;
+        if (k == "volumes") return keep_pod_volumes() ? (int)NoCtx : -1;
+        if (one_of(k, {"securityContext", "imagePullSecrets", "dnsConfig", "hostAliases", "readinessGates", "tolerations", "ephemeralContainers"})) return -1;
         return NoCtx;
     case Container:
         return one_of(k, {"env", "envFrom", "volumeMounts", "volumeDevices", "livenessProbe", "readinessProbe", "startupProbe", "lifecycle", "securityContext",

@@ -1,0 +1,335 @@
+// volumes.hpp -- the volume plugins' object side: VolumeRestrictions, NodeVolumeLimits, VolumeBinding, VolumeZone.
+//
+// What they decide is string and object-graph work that does not change while clones are placed -- except a clone's own disks and a
+// ReadWriteOncePod claim -- so it is evaluated here, once per template, into what the engine takes (include/ccsim.h ccsim_pod):
+// volume_veto[n] (the code of the first of the four that rejects node n against the snapshot's pods) and volume_exclusive.  The PreFilter
+// outcomes that reject the pod on every node (zero replicas, the plugin's message as FitError.Diagnosis.PreFilterMsg) never reach the
+// engine.  Same semantics as cluster_capacity_amd/volumes.py, checked against it in tests/test_volume_ingest.py.
+//
+// What the REFERENCE's scheduler sees: SyncWithClient copies PersistentVolumeClaims and StorageClasses into the fake cluster but NOT
+// PersistentVolumes, CSINodes, CSIDrivers or CSIStorageCapacities (pkg/framework/simulator.go:228-295).  With the default plugins:
+//   a claim that does not exist            VolumeRestrictions.PreFilter: persistentvolumeclaim "x" not found (volume_restrictions.go:175-181)
+//   a lost / terminating claim             VolumeBinding.PreFilter (volumebinding/volume_binding.go:333-339, 356-357)
+//   an unbound claim of an Immediate class VolumeBinding.PreFilter: "pod has unbound immediate PersistentVolumeClaims" (:366-372)
+//   a BOUND claim                          VolumeZone.PreFilter: persistentvolume "pv" not found (volumezone/volume_zone.go:156-159, 253-258)
+//   an unbound WaitForFirstConsumer claim  passes every PreFilter; VolumeBinding.Filter finds nothing to bind (binder.go
+//                                          checkVolumeProvisions): without a provisioner every node fails with "node(s) didn't find
+//                                          available persistent volumes to bind"; with one the pod passes and then waits in PreBind for
+//                                          a PV controller the fake cluster does not run -- the reference hangs; refused with that reason
+//   NodeVolumeLimits                       never rejects: no CSINode, no limits (nodevolumelimits/csi.go:265-290)
+//   GCE PD / EBS / RBD / ISCSI volumes     VolumeRestrictions.Filter against the node's pods and the clones (:105-150, 310-313)
+//   a ReadWriteOncePod claim               in use by a pod of the snapshot: every node fails (:283-291); else the first clone takes it
+//                                          and the second cycle fails everywhere: capacity 1
+// --sync-persistent-volumes goes one step beyond the reference: PersistentVolume objects of the snapshot are taken too, so bound claims
+// are judged as kube-scheduler judges them on the live cluster -- VolumeBinding's node affinity of the bound volume (binder.go
+// checkBoundClaims) and VolumeZone's label match (volume_zone.go:191-240) -- as static per-node verdicts.
+#pragma once
+#include <algorithm>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "value.hpp"
+
+namespace cchost {
+
+// (included by snapshot.hpp below its requirement_matches / string_list)
+
+static const char *const kVolumePlugins[] = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};
+static const char *const kAnnBindCompleted = "pv.kubernetes.io/bind-completed";           // volume.AnnBindCompleted
+static const char *const kAnnBetaStorageClass = "volume.beta.kubernetes.io/storage-class"; // v1.BetaStorageClassAnnotation
+static const char *const kNoProvisioner = "kubernetes.io/no-provisioner";                  // volume.NotSupportedProvisioner
+static const char *const kZoneBeta = "failure-domain.beta.kubernetes.io/zone";
+static const char *const kRegionBeta = "failure-domain.beta.kubernetes.io/region";
+static const char *const kZoneGA = "topology.kubernetes.io/zone";
+static const char *const kRegionGA = "topology.kubernetes.io/region";
+static const char *const kTopologyLabels[] = {kZoneBeta, kRegionBeta, kZoneGA, kRegionGA}; // volume_zone.go:84-89
+static const char *const kRestrictedKinds[] = {"gcePersistentDisk", "awsElasticBlockStore", "rbd", "iscsi"}; // needsRestrictionsCheck
+
+// the objects of the snapshot the volume plugins read, and which of the plugins the profile runs
+struct VolumeObjects {
+    std::vector<Value> claims, classes, volumes;
+    bool sync_volumes = false; // --sync-persistent-volumes (the reference's SyncWithClient copies none)
+    std::vector<std::string> plugins = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};
+    bool plugins_partial = false; // the configuration disables only the filter point of one: pods with volumes are refused
+    bool on(const char *name) const { return std::find(plugins.begin(), plugins.end(), name) != plugins.end(); }
+};
+
+struct VolumeSide {
+    bool rejected = false;        // a PreFilter plugin rejects the pod on every node ...
+    std::string prefilter_reject; // ... with this message
+    std::vector<uint8_t> veto;    // per node: code 1..CCSIM_VOL_CODES of the first volume plugin that rejects it; empty = none does
+    bool exclusive = false;       // a clone's disks conflict with the next one's on the same node
+    bool rwop_capacity_one = false; // a ReadWriteOncePod claim nobody uses yet
+};
+
+inline bool restricted(const Value &v) {
+    for (const char *k : kRestrictedKinds)
+        if (!v[k].is_null()) return true;
+    return false;
+}
+
+// isVolumeConflict for one pair of volumes (volume_restrictions.go:105-150)
+inline bool volume_conflict(const Value &v, const Value &ev) {
+    auto ro = [](const Value &s) { return s["readOnly"].truthy(); };
+    {
+        const Value &a = v["gcePersistentDisk"], &b = ev["gcePersistentDisk"];
+        if (!a.is_null() && !b.is_null() && a["pdName"].text() == b["pdName"].text() && !(ro(a) && ro(b))) return true;
+    }
+    {
+        const Value &a = v["awsElasticBlockStore"], &b = ev["awsElasticBlockStore"];
+        if (!a.is_null() && !b.is_null() && a["volumeID"].text() == b["volumeID"].text()) return true;
+    }
+    {
+        const Value &a = v["iscsi"], &b = ev["iscsi"];
+        if (!a.is_null() && !b.is_null() && a["iqn"].text() == b["iqn"].text() && !(ro(a) && ro(b))) return true;
+    }
+    {
+        const Value &a = v["rbd"], &b = ev["rbd"];
+        if (!a.is_null() && !b.is_null()) {
+            bool overlap = false;
+            for (const auto &m : a["monitors"].items())
+                for (const auto &e : b["monitors"].items()) overlap = overlap || m.text() == e.text();
+            // (pool as written: ParseAPISpec applies no API defaults, options.go:79-147)
+            if (overlap && a["pool"].text() == b["pool"].text() && a["image"].text() == b["image"].text() && !(ro(a) && ro(b))) return true;
+        }
+    }
+    return false;
+}
+
+// !satisfyVolumeConflicts for one existing pod (volume_restrictions.go:266-280)
+inline bool pod_conflicts(const Value &volumes, const Value &other_volumes) {
+    for (const auto &v : volumes.items()) {
+        if (!restricted(v)) continue;
+        for (const auto &ev : other_volumes.items())
+            if (volume_conflict(v, ev)) return true;
+    }
+    return false;
+}
+
+// storagehelpers.GetPersistentVolumeClaimClass: the beta annotation wins over spec.storageClassName
+inline std::string claim_class(const Value &pvc) {
+    const Value &ann = pvc["metadata"]["annotations"];
+    if (ann.has(kAnnBetaStorageClass)) return ann[kAnnBetaStorageClass].text();
+    return pvc["spec"]["storageClassName"].text();
+}
+
+// volumehelpers.LabelZonesToSet: "a__b" -> {a, b}; an empty element is an error (the label is then ignored, volume_zone.go:384-388)
+inline bool label_zones(const std::string &value, std::set<std::string> &out) {
+    size_t pos = 0;
+    for (;;) {
+        const size_t next = value.find("__", pos);
+        std::string z = value.substr(pos, next == std::string::npos ? std::string::npos : next - pos);
+        const size_t b = z.find_first_not_of(" \t\r\n\v\f"), e = z.find_last_not_of(" \t\r\n\v\f");
+        if (b == std::string::npos) return false;
+        out.insert(z.substr(b, e - b + 1));
+        if (next == std::string::npos) return true;
+        pos = next + 2;
+    }
+}
+
+// storagehelpers.CheckNodeAffinity (component-helpers/storage/volume/helpers.go:68-84): the node object it builds carries the labels only,
+// so a matchFields requirement on metadata.name is compared with the empty name
+inline bool pv_node_affinity_matches(const Value &pv, const Value &node_labels) {
+    const Value &req = pv["spec"]["nodeAffinity"]["required"];
+    if (req.is_null()) return true;
+    for (const auto &term : req["nodeSelectorTerms"].items()) {
+        const Value &exprs = term["matchExpressions"], &fields = term["matchFields"];
+        if (exprs.items().empty() && fields.items().empty()) continue; // (an empty term matches nothing: nodeaffinity.go:118-121)
+        bool ok = true;
+        for (const auto &r : exprs.items()) {
+            const std::string k = r["key"].text();
+            ok = ok && requirement_matches(node_labels.has(k), node_labels[k].text(), r["operator"].text(), string_list(r["values"]));
+        }
+        for (const auto &r : fields.items()) ok = ok && requirement_matches(r["key"].text() == "metadata.name", "", r["operator"].text(), string_list(r["values"]));
+        if (ok) return true;
+    }
+    return false;
+}
+
+struct VolumeUnsupported : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// `live`: the snapshot's non-terminal pods on kept nodes, `live_node[j]`: the node index of live[j]
+inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Value *> &nodes, const std::vector<const Value *> &live,
+                              const std::vector<size_t> &live_node, const VolumeObjects &vo) {
+    VolumeSide out;
+    const Value &spec = sim_pod["spec"];
+    const std::string ns = sim_pod["metadata"]["namespace"].truthy() ? sim_pod["metadata"]["namespace"].text() : "default";
+    const Value &volumes = spec["volumes"];
+    if (volumes.items().empty()) return out;
+    if (vo.plugins_partial)
+        throw VolumeUnsupported("the scheduler configuration disables only the filter point of a volume plugin: a pod with volumes is not modelled under it");
+    const size_t N = nodes.size();
+    for (const auto &v : volumes.items())
+        if (!v["ephemeral"].is_null()) // (the claim is named after the CLONE -- "<pod>-<volume>" -- and made by a controller the fake cluster does not run)
+            throw VolumeUnsupported("pod volume '" + v["name"].text() + "': generic ephemeral volumes are not modelled");
+    auto obj_ns = [](const Value &o) { return o["metadata"]["namespace"].truthy() ? o["metadata"]["namespace"].text() : std::string("default"); };
+    std::map<std::pair<std::string, std::string>, const Value *> pvcs;
+    for (const auto &o : vo.claims) pvcs[{obj_ns(o), o["metadata"]["name"].text()}] = &o;
+    std::map<std::string, const Value *> classes, pvs;
+    for (const auto &o : vo.classes) classes[o["metadata"]["name"].text()] = &o;
+    if (vo.sync_volumes)
+        for (const auto &o : vo.volumes) pvs[o["metadata"]["name"].text()] = &o;
+    std::vector<std::string> claim_names;
+    for (const auto &v : volumes.items())
+        if (!v["persistentVolumeClaim"].is_null()) claim_names.push_back(v["persistentVolumeClaim"]["claimName"].text());
+    auto find_pvc = [&](const std::string &name) -> const Value * {
+        auto it = pvcs.find({ns, name});
+        return it == pvcs.end() ? nullptr : it->second;
+    };
+    auto reject = [&](std::string msg) {
+        out.rejected = true, out.prefilter_reject = std::move(msg);
+        return out;
+    };
+    auto not_found = [](const char *kind, const std::string &name) { return std::string(kind) + " \"" + name + "\" not found"; }; // apierrors.NewNotFound(...).Error()
+
+    // ---- PreFilter, in plugin order (framework.go:726-787: the first rejection ends the cycle) ---------------------------------------
+    std::vector<std::string> rwop;
+    if (vo.on("VolumeRestrictions")) // volume_restrictions.go:166-193, 249-264
+        for (const auto &name : claim_names) {
+            const Value *pvc = find_pvc(name);
+            if (!pvc) return reject(not_found("persistentvolumeclaim", name));
+            for (const auto &m : (*pvc)["spec"]["accessModes"].items())
+                if (m.text() == "ReadWriteOncePod") {
+                    rwop.push_back(name);
+                    break;
+                }
+        }
+    std::vector<const Value *> delayed, bound;
+    if (vo.on("VolumeBinding") && !claim_names.empty()) { // volume_binding.go:306-383, binder.go:719-828
+        for (const auto &name : claim_names) {
+            const Value *pvc = find_pvc(name);
+            if (!pvc) return reject(not_found("persistentvolumeclaim", name));
+            if ((*pvc)["status"]["phase"].text() == "Lost")
+                return reject("persistentvolumeclaim \"" + name + "\" bound to non-existent persistentvolume \"" + (*pvc)["spec"]["volumeName"].text() + "\"");
+            if (!(*pvc)["metadata"]["deletionTimestamp"].is_null()) return reject("persistentvolumeclaim \"" + name + "\" is being deleted");
+        }
+        bool immediate = false;
+        for (const auto &name : claim_names) {
+            const Value &pvc = *find_pvc(name);
+            const std::string vol_name = pvc["spec"]["volumeName"].text();
+            if (!vol_name.empty() && pvc["metadata"]["annotations"].has(kAnnBindCompleted)) {
+                bound.push_back(&pvc);
+                continue;
+            }
+            const std::string cname = claim_class(pvc);
+            bool delay = false;
+            if (!cname.empty()) { // volume.IsDelayBindingMode (an error of the class lister is a scheduler ERROR, not a rejection)
+                auto it = classes.find(cname);
+                if (it == classes.end())
+                    throw VolumeUnsupported("persistentvolumeclaim \"" + name + "\": StorageClass \"" + cname + "\" is not in the snapshot (the reference's scheduler fails the cycle with an error)");
+                if ((*it->second)["volumeBindingMode"].is_null())
+                    throw VolumeUnsupported("StorageClass \"" + cname + "\" has no volumeBindingMode (the reference's scheduler fails the cycle with an error)");
+                delay = (*it->second)["volumeBindingMode"].text() == "WaitForFirstConsumer";
+            }
+            if (delay && vol_name.empty()) delayed.push_back(&pvc);
+            else immediate = true;
+        }
+        if (immediate) return reject("pod has unbound immediate PersistentVolumeClaims");
+    }
+    std::vector<std::pair<std::string, std::set<std::string>>> topologies;
+    if (vo.on("VolumeZone")) // volume_zone.go:111-165
+        for (const auto &name : claim_names) {
+            if (name.empty()) return reject("PersistentVolumeClaim had no name");
+            const Value *pvc = find_pvc(name);
+            if (!pvc) return reject(not_found("persistentvolumeclaim", name));
+            const std::string vol_name = (*pvc)["spec"]["volumeName"].text();
+            if (vol_name.empty()) {
+                const std::string cname = claim_class(*pvc);
+                if (cname.empty()) return reject("PersistentVolumeClaim had no pv name and storageClass name");
+                auto it = classes.find(cname);
+                if (it == classes.end()) return reject(not_found("storageclass.storage.k8s.io", cname));
+                if ((*it->second)["volumeBindingMode"].is_null()) return reject("VolumeBindingMode not set for StorageClass \"" + cname + "\"");
+                if ((*it->second)["volumeBindingMode"].text() == "WaitForFirstConsumer") continue;
+                return reject("PersistentVolume had no name");
+            }
+            auto pv = pvs.find(vol_name);
+            if (pv == pvs.end()) return reject(not_found("persistentvolume", vol_name));
+            const Value &labels = (*pv->second)["metadata"]["labels"];
+            for (const char *key : kTopologyLabels)
+                if (labels.has(key)) {
+                    std::set<std::string> zs;
+                    if (label_zones(labels[key].text(), zs)) topologies.emplace_back(key, std::move(zs));
+                }
+        }
+
+    // ---- Filter: the first of the four that rejects the node (default_plugins.go:41-44) ------------------------------------------------
+    std::vector<uint8_t> veto(N, 0);
+    bool any = false;
+    auto mark = [&](size_t i, int code) {
+        if (!veto[i]) veto[i] = (uint8_t)code, any = true;
+    };
+    auto mark_all = [&](int code) {
+        for (size_t i = 0; i < N; i++) mark(i, code);
+    };
+    if (vo.on("VolumeRestrictions")) {
+        bool needs = false;
+        for (const auto &v : volumes.items()) needs = needs || restricted(v);
+        if (needs) {
+            for (size_t j = 0; j < live.size(); j++)
+                if (pod_conflicts(volumes, (*live[j])["spec"]["volumes"])) mark(live_node[j], 1);
+            out.exclusive = pod_conflicts(volumes, volumes);
+        }
+        if (!rwop.empty()) { // IsPVCUsedByPods (the snapshot's usedPVCSet: every pod of every node, keyed namespace/name)
+            bool used = false;
+            for (size_t j = 0; j < live.size() && !used; j++) {
+                const std::string pns = obj_ns(*live[j]);
+                if (pns != ns) continue;
+                for (const auto &v : (*live[j])["spec"]["volumes"].items())
+                    if (!v["persistentVolumeClaim"].is_null() &&
+                        std::find(rwop.begin(), rwop.end(), v["persistentVolumeClaim"]["claimName"].text()) != rwop.end())
+                        used = true;
+            }
+            if (used) mark_all(2);
+            else out.rwop_capacity_one = true;
+        }
+    }
+    // (NodeVolumeLimits: no CSINode in the fake cluster, no limits: nodevolumelimits/csi.go:265-290)
+    if (vo.on("VolumeBinding")) {
+        if (!bound.empty()) { // binder.go checkBoundClaims
+            bool missing = false;
+            for (const Value *c : bound) missing = missing || !pvs.count((*c)["spec"]["volumeName"].text());
+            if (missing) mark_all(6);
+            else
+                for (size_t i = 0; i < N; i++) {
+                    bool ok = true;
+                    for (const Value *c : bound) ok = ok && pv_node_affinity_matches(*pvs[(*c)["spec"]["volumeName"].text()], (*nodes[i])["metadata"]["labels"]);
+                    if (!ok) mark(i, 4);
+                }
+        }
+        for (const Value *pvc : delayed) { // binder.go findMatchingVolumes (no volume of the class to match) -> checkVolumeProvisions
+            const std::string cname = claim_class(*pvc);
+            for (const auto &kv : pvs)
+                if ((*kv.second)["spec"]["storageClassName"].text() == cname)
+                    throw VolumeUnsupported("persistentvolumeclaim \"" + (*pvc)["metadata"]["name"].text() + "\": matching an unbound claim against the persistent volumes of class \"" +
+                                            cname + "\" is not modelled");
+            const std::string prov = (*classes[cname])["provisioner"].text();
+            if (prov.empty() || prov == kNoProvisioner) mark_all(5);
+            else
+                throw VolumeUnsupported("persistentvolumeclaim \"" + (*pvc)["metadata"]["name"].text() + "\" waits for its first consumer: StorageClass \"" + cname +
+                                        "\" would provision the volume in PreBind, which waits for a PV controller the simulated cluster does not run (the reference does not terminate)");
+        }
+    }
+    if (vo.on("VolumeZone") && !topologies.empty()) // volume_zone.go:191-240
+        for (size_t i = 0; i < N; i++) {
+            const Value &labels = (*nodes[i])["metadata"]["labels"];
+            bool constrained = false;
+            for (const char *k : kTopologyLabels) constrained = constrained || labels.has(k);
+            if (!constrained) continue; // (a node without any zone label is fine: a single-zone cluster)
+            for (const auto &t : topologies) {
+                const std::string ga = t.first == kZoneBeta ? kZoneGA : t.first == kRegionBeta ? kRegionGA : t.first;
+                const bool ok = labels.has(t.first) ? t.second.count(labels[t.first].text()) : (labels.has(ga) && t.second.count(labels[ga].text()));
+                if (!ok) {
+                    mark(i, 7);
+                    break;
+                }
+            }
+        }
+    if (any) out.veto = std::move(veto);
+    return out;
+}
+
+} // namespace cchost

@@ -44,6 +44,8 @@ def _pod_dump(p):
             "soft_relaxed": bool(getattr(p, "soft_relaxed", False)),
             "ipa": ipa, "has_host_ports": bool(p.has_host_ports), "host_ports_conflict": lst(p.host_ports_conflict),
             "image_score": lst(p.image_score),
+            "volume_veto": lst(p.volume_veto), "volume_exclusive": bool(p.volume_exclusive), "prefilter_reject": p.prefilter_reject,
+            "rwop_capacity_one": bool(p.rwop_capacity_one),
             "preempt": {"priority": p.preempt.priority, "never": p.preempt.never, "victim_count": lst(p.preempt.victim_count),
                         "victim_req": [lst(v) for v in p.preempt.victim_req], "ports_conflict_rest": lst(p.preempt.ports_conflict_rest),
                         "victim_interacts": lst(p.preempt.victim_interacts)}}

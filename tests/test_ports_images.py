@@ -95,12 +95,15 @@ def test_ingest_and_oracle_known_answer(ccref):
     assert ccref.run(M.Profile(w_imagelocality=0), snap.nodes, snap.pod).log.tolist() == [0, 1, 2, 4]
 
 
-def test_volume_backed_pods_are_refused():
+def test_pods_the_hosts_still_refuse():
+    """(volumes: round 5 evaluates the volume plugins -- tests/test_volume_ingest.py; generic ephemeral volumes and DRA stay refused)"""
     nodes, pods, pod, _ = CASES["readme"]()
     pod["spec"]["volumes"] = [{"name": "scratch", "emptyDir": {}}, {"name": "cfg", "configMap": {"name": "x"}}]
     ingest.build_snapshot(nodes, pods, pod)  # node-independent volumes are fine
     pod["spec"]["volumes"].append({"name": "data", "persistentVolumeClaim": {"claimName": "pvc-1"}})
-    with pytest.raises(NotImplementedError, match="volume plugins are not modelled"):
+    assert ingest.build_snapshot(nodes, pods, pod).pod.prefilter_reject == 'persistentvolumeclaim "pvc-1" not found'
+    pod["spec"]["volumes"][-1] = {"name": "data", "ephemeral": {"volumeClaimTemplate": {}}}
+    with pytest.raises(NotImplementedError, match="ephemeral volumes are not modelled"):
         ingest.build_snapshot(nodes, pods, pod)
     pod["spec"]["volumes"].pop()
     pod["spec"]["resourceClaims"] = [{"name": "gpu"}]

@@ -219,3 +219,168 @@ def test_snapshot_carries_the_verdicts():
     with pytest.raises(NotImplementedError, match="same disk"):
         ingest.build_snapshot(nodes, [], [_pod([{"name": "d", "awsElasticBlockStore": {"volumeID": "vol-1"}}], "a"),
                                           _pod([{"name": "e", "awsElasticBlockStore": {"volumeID": "vol-1"}}], "b")])
+
+
+# ---- the native host: same verdicts from the same objects (--dump-snapshot), same reports ---------------------------------------------
+def _write_case(tmp_path, pod, nodes, objs):
+    (tmp_path / "pod.yaml").write_text(yaml.safe_dump(json.loads(json.dumps(pod))))
+    (tmp_path / "cluster.json").write_text(json.dumps({"kind": "List", "items": nodes + objs}))
+    return ["--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "cluster.json")]
+
+
+def _both_sides(native, tmp_path, pod, nodes, objs, extra=()):
+    flags = _write_case(tmp_path, pod, nodes, objs) + list(extra)
+    got = json.loads(_run(native, flags + ["--dump-snapshot", "-"]))["pod"]
+    by = cli.load_by_kind([flags[3]])
+    snap = ingest.build_snapshot(by.get("Node", []), by.get("Pod", []), cli.parse_pod_spec(flags[1]), pvc_objs=by.get("PersistentVolumeClaim", []),
+                                 class_objs=by.get("StorageClass", []), pv_objs=by.get("PersistentVolume", []) if "--sync-persistent-volumes" in extra else None)
+    p = snap.pod
+    ref = {"volume_veto": None if p.volume_veto is None else [int(x) for x in p.volume_veto], "volume_exclusive": bool(p.volume_exclusive),
+           "prefilter_reject": p.prefilter_reject, "rwop_capacity_one": bool(p.rwop_capacity_one)}
+    assert {k: got[k] for k in ref} == ref
+    return ref
+
+
+def test_native_host_gives_the_same_verdicts(native, tmp_path):
+    nodes = _nodes()
+    old = running_pod("old", "n2", cpu="100m")
+    old["spec"]["volumes"] = [{"name": "d", "gcePersistentDisk": {"pdName": "disk-1"}}, _claim_vol("solo")]
+    ro = running_pod("ro", "n4", cpu="100m")
+    ro["spec"]["volumes"] = [{"name": "d", "rbd": {"monitors": ["m1", "m2"], "pool": "p", "image": "i", "readOnly": True}}]
+    classes = [_class("local"), _class("fast", mode="Immediate"), _class("ebs", provisioner="ebs.csi.aws.com")]
+    claims = [_pvc("solo", cls="local", modes=("ReadWriteOncePod",)), _pvc("free", cls="local", modes=("ReadWriteOncePod",)), _pvc("b", volume_name="pv-1"),
+              _pvc("imm", cls="fast"), _pvc("old-style", **{"annotations": {V.ANN_BETA_STORAGE_CLASS: "local"}})]
+    terms = [{"matchExpressions": [{"key": "kubernetes.io/hostname", "operator": "In", "values": ["n3", "n5"]}]}]
+    pvs = [_pv("pv-1", labels={V.ZONE_BETA: "z0__z2"}, terms=terms)]
+    objs = [old, ro] + classes + claims + pvs
+    cases = [
+        ([{"name": "d", "gcePersistentDisk": {"pdName": "disk-1"}}], ()),
+        ([{"name": "d", "gcePersistentDisk": {"pdName": "disk-1", "readOnly": True}}], ()),
+        ([{"name": "d", "rbd": {"monitors": ["m2"], "pool": "p", "image": "i"}}, {"name": "e", "awsElasticBlockStore": {"volumeID": "v"}}], ()),
+        ([_claim_vol("solo")], ()), ([_claim_vol("free")], ()), ([_claim_vol("ghost")], ()), ([_claim_vol("imm")], ()), ([_claim_vol("old-style")], ()),
+        ([_claim_vol("b")], ()), ([_claim_vol("b")], ("--sync-persistent-volumes",)),
+        ([{"name": "tmp", "emptyDir": {}}, {"name": "inline", "csi": {"driver": "d"}}], ()),
+    ]
+    seen = []
+    for k, (vols, extra) in enumerate(cases):
+        d = tmp_path / f"c{k}"
+        d.mkdir()
+        seen.append(_both_sides(native, d, _pod(vols), nodes, objs, extra))
+    assert seen[0]["volume_veto"] == [0, 0, 1, 0, 0, 0] and seen[0]["volume_exclusive"]
+    assert seen[2]["volume_veto"] == [0, 0, 0, 0, 1, 0] and seen[2]["volume_exclusive"]
+    assert seen[3]["volume_veto"] == [M.VOL_RWOP] * 6 and seen[4]["rwop_capacity_one"] and seen[4]["volume_veto"] == [M.VOL_NO_PV] * 6
+    assert seen[5]["prefilter_reject"] == 'persistentvolumeclaim "ghost" not found' and seen[6]["prefilter_reject"] == "pod has unbound immediate PersistentVolumeClaims"
+    assert seen[7]["volume_veto"] == [M.VOL_NO_PV] * 6  # the class named by the beta annotation
+    assert seen[8]["prefilter_reject"] == 'persistentvolume "pv-1" not found'
+    assert seen[9]["volume_veto"] == [4, 4, 4, 0, 4, 0] and seen[9]["prefilter_reject"] is None  # n3 (z0) and n5 (z2) carry the volume's node affinity and zones
+    assert seen[10] == {"volume_veto": None, "volume_exclusive": False, "prefilter_reject": None, "rwop_capacity_one": False}
+
+
+def test_native_host_refuses_what_the_python_host_refuses(native, tmp_path):
+    nodes = _nodes()
+    for vols, objs, what in (([_claim_vol("c")], [_pvc("c", cls="ebs"), _class("ebs", provisioner="ebs.csi.aws.com")], "PV controller"),
+                             ([_claim_vol("c")], [_pvc("c", cls="nowhere")], "not in the snapshot"),
+                             ([{"name": "s", "ephemeral": {"volumeClaimTemplate": {}}}], [], "ephemeral")):
+        flags = _write_case(tmp_path, _pod(vols), nodes, objs)
+        p = subprocess.run([native] + flags, capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 1 and what in p.stderr
+        with pytest.raises(NotImplementedError, match=what):
+            cli.main(flags, out=io.StringIO())
+
+
+def test_both_hosts_report_a_prefilter_rejection_without_a_device(native, tmp_path):
+    """Zero replicas, the plugin's message, "Preemption is not helpful" on every node: no scheduling cycle reaches the engine."""
+    nodes = _nodes()
+    flags = _write_case(tmp_path, _pod([_claim_vol("data")]), nodes, [_pvc("data", volume_name="pv-7")])
+    want = ('0/6 nodes are available: persistentvolume "pv-7" not found. preemption: 0/6 nodes are available: 6 Preemption is not helpful for scheduling.')
+    got = json.loads(_run(native, flags + ["-o", "json"]))
+    buf = io.StringIO()
+    assert cli.main(flags + ["-o", "json"], out=buf) == 0
+    ref = json.loads(buf.getvalue())
+    got["status"].pop("creationTimestamp"), ref["status"].pop("creationTimestamp")
+    assert got["status"] == ref["status"]
+    assert got["status"]["replicas"] == 0 and got["status"]["failReason"] == {"failType": "Unschedulable", "failMessage": want}
+    txt = _run(native, flags + ["--verbose"])
+    assert "Termination reason: Unschedulable: " + want in txt
+
+
+# ---- GPU: both CLIs end to end ------------------------------------------------------------------------------------------------------
+def _status(native, flags):
+    got = json.loads(_run(native, flags + ["-o", "json"]))
+    buf = io.StringIO()
+    assert cli.main(flags + ["-o", "json"], out=buf) == 0
+    ref = json.loads(buf.getvalue())
+    got["status"].pop("creationTimestamp"), ref["status"].pop("creationTimestamp")
+    assert got["status"] == ref["status"]
+    return got["status"]
+
+
+@pytest.mark.gpu
+def test_gpu_cli_disks_both_hosts_vs_oracle(ccref, native, tmp_path):
+    """A read-write GCE PD: nodes whose pods mount it are out, every other node takes ONE clone; the terminal message names the disk
+    conflict for the nodes that still had room."""
+    nodes = _nodes(9)
+    users = []
+    for k, n in enumerate(("n2", "n5")):
+        u = running_pod(f"user-{k}", n, cpu="100m")
+        u["spec"]["volumes"] = [{"name": "d", "gcePersistentDisk": {"pdName": "disk-1", "readOnly": True}}]
+        users.append(u)
+    pod = _pod([{"name": "d", "gcePersistentDisk": {"pdName": "disk-1"}}])
+    flags = _write_case(tmp_path, pod, nodes, users)
+    st = _status(native, flags)
+    snap = ingest.build_snapshot(nodes, users, cli.parse_pod_spec(flags[1]))
+    r = ccref.run(M.Profile.default(), snap.nodes, snap.pod)
+    assert st["replicas"] == r.placed == 7
+    assert [x["nodeName"] for x in st["pods"][0]["replicasOnNodes"]] == [snap.names[i] for i in r.log]
+    assert st["failReason"]["failMessage"] == R.stop_reason(r, 9, 0)[len("Unschedulable: "):]
+    assert "9 node(s) had no available disk" in st["failReason"]["failMessage"]
+    st = _status(native, flags + ["--max-limit", "3"])
+    assert st["replicas"] == 3 and st["failReason"]["failType"] == "LimitReached"
+
+
+@pytest.mark.gpu
+def test_gpu_cli_read_write_once_pod_claim_has_capacity_one(native, tmp_path):
+    nodes = _nodes()
+    classes = [_class("local")]
+    # (bound claims end at VolumeZone's PreFilter in the reference's fake cluster; with the volumes synced the claim is usable)
+    claim = _pvc("solo", volume_name="pv-1", modes=("ReadWriteOncePod",))
+    objs = classes + [claim, _pv("pv-1", labels={ZONE: "z1"})]
+    flags = _write_case(tmp_path, _pod([_claim_vol("solo")]), nodes, objs) + ["--sync-persistent-volumes"]
+    st = _status(native, flags)
+    assert st["replicas"] == 1 and st["pods"][0]["replicasOnNodes"][0]["nodeName"] in ("n1", "n4")
+    # VolumeRestrictions speaks before VolumeZone: all six nodes report the claim in use, none the zone
+    assert "6 node(s) unavailable due to PersistentVolumeClaim with ReadWriteOncePod" in st["failReason"]["failMessage"]
+    assert "volume zone" not in st["failReason"]["failMessage"]
+    st = _status(native, flags + ["--max-limit", "1"])
+    assert st["replicas"] == 1 and st["failReason"]["failType"] == "LimitReached"
+    user = running_pod("user", "n0", cpu="100m")
+    user["spec"]["volumes"] = [_claim_vol("solo")]
+    d = tmp_path / "used"
+    d.mkdir()
+    st = _status(native, _write_case(d, _pod([_claim_vol("solo")]), nodes, objs + [user]) + ["--sync-persistent-volumes"])
+    assert st["replicas"] == 0 and "6 node(s) unavailable due to PersistentVolumeClaim with ReadWriteOncePod" in st["failReason"]["failMessage"]
+
+
+@pytest.mark.gpu
+def test_gpu_cli_several_templates_with_volumes_vs_oracle(ccref, native, tmp_path):
+    """Templates with volumes are outside the window engine's shape (ccsim_set_pods: -ENOSYS): one cycle at a time, the clones' own disks
+    folded into the verdicts the template is set with."""
+    nodes = _nodes(8)
+    a = _pod([{"name": "d", "awsElasticBlockStore": {"volumeID": "vol-a"}}], "tmpl-a")
+    b = _pod([], "tmpl-b")
+    for t, p in enumerate((a, b)):
+        p["metadata"]["labels"] = {"app": f"t{t}"}
+        (tmp_path / f"t{t}.yaml").write_text(yaml.safe_dump(json.loads(json.dumps(p))))
+    (tmp_path / "cluster.json").write_text(json.dumps({"kind": "List", "items": nodes}))
+    flags = ["--podspec", str(tmp_path / "t0.yaml"), "--podspec", str(tmp_path / "t1.yaml"), "--snapshot", str(tmp_path / "cluster.json")]
+    st = _status(native, flags)
+    snap = ingest.build_snapshot(nodes, [], [cli.parse_pod_spec(flags[1]), cli.parse_pod_spec(flags[3])])
+    r = ccref.run_multi(M.Profile.default(), snap.nodes, snap.pods)
+    assert st["replicas"] == r.placed and r.per_spec_count.tolist() == [8, 8] and r.stop_spec == 0
+    assert [sum(x["replicas"] for x in q["replicasOnNodes"]) for q in st["pods"]] == r.per_spec_count.tolist()
+    assert "8 node(s) had no available disk" in st["failReason"]["failMessage"]
+    # a template a PreFilter plugin rejects ends the run at ITS first cycle: template 0's first clone is placed, nothing more
+    c = _pod([_claim_vol("ghost")], "tmpl-c")
+    (tmp_path / "t1.yaml").write_text(yaml.safe_dump(json.loads(json.dumps(c))))
+    st = _status(native, flags)
+    assert st["replicas"] == 1 and 'persistentvolumeclaim "ghost" not found' in st["failReason"]["failMessage"]
