@@ -462,6 +462,8 @@ inline RunResult simulate_sharded(const Snapshot &s, int64_t max_limit, const st
     if (!api.dist_unique_id || !api.dist_comm_init || !api.dist_sync_tables || !api.dist_run) throw std::runtime_error("libccsim.so lacks the ccsim_dist_* entry points");
     if (s.n_templates() != 1) throw std::runtime_error("several templates run on one GPU (ccsim_set_pods)");
     if (n_gpus < 1) throw std::runtime_error("--gpus must be >= 1");
+    if (!s.prefilter_reject.empty()) return rejected_by_prefilter(s, s, s.prefilter_reject);
+    if (s.rwop_capacity_one) throw Unsupported("a pod with a ReadWriteOncePod claim runs on one GPU (its one clone needs no shards)");
     HostProfile prof_eff = prof;
     const bool coupled = !s.spread.empty() || s.has_ipa;
     // percentageOfNodesToScore as on one GPU (simulate() above) -- the sampled search runs on shards too (two exchanges per cycle,
@@ -510,7 +512,7 @@ inline RunResult simulate_sharded(const Snapshot &s, int64_t max_limit, const st
             for (int q = 0; q < pp.ipa.n_keys; q++) off(pp.ipa.exist_anti[q]), off(pp.ipa.score_existing[q]);
             if (lo > 0) pp.ipa.entries_existing = 0; // a cluster-wide count: contributed once, then all-reduced
         }
-        off(pp.host_ports_conflict), off(pp.image_score);
+        off(pp.host_ports_conflict), off(pp.image_score), off(pp.volume_veto);
         ccsim_config cfg{};
         cfg.abi_version = CCSIM_ABI_VERSION, cfg.device = g, cfg.use_graph = 0;
         ccsim_engine *e = nullptr;

@@ -193,6 +193,8 @@ static void record_pod(ccsim_engine *e, const ccsim_pod *p) {
     fprintf(f, ", \"has_host_ports\": %d, ", p->has_host_ports);
     arr8(f, "host_ports_conflict", p->host_ports_conflict, N), fprintf(f, ", ");
     arr8(f, "image_score", p->image_score, N);
+    fprintf(f, ", \"volume_exclusive\": %d, ", p->volume_exclusive);
+    arr8(f, "volume_veto", p->volume_veto, N);
     fprintf(f, "}");
 }
 

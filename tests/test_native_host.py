@@ -159,7 +159,21 @@ def ports_images_case():
     return nodes, pods, pod, []
 
 
+def disks_case():
+    """VolumeRestrictions (round 5): w1's pod mounts the PD read-write (conflict), w3's read-only (fine next to the template's read-only
+    mount); the template's EBS volume makes its clones exclusive."""
+    nodes = [node(f"w{i}", cpu="4", mem="8Gi", pods="20", labels={"kubernetes.io/hostname": f"w{i}"}) for i in range(6)]
+    rw = running_pod("writer", "w1", cpu="100m")
+    rw["spec"]["volumes"] = [{"name": "d", "gcePersistentDisk": {"pdName": "disk-1"}}, {"name": "tmp", "emptyDir": {}}]
+    ro = running_pod("reader", "w3", cpu="100m")
+    ro["spec"]["volumes"] = [{"name": "d", "gcePersistentDisk": {"pdName": "disk-1", "readOnly": True}}]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["spec"]["volumes"] = [{"name": "d", "gcePersistentDisk": {"pdName": "disk-1", "readOnly": True}}, {"name": "e", "awsElasticBlockStore": {"volumeID": "vol-1"}}]
+    return nodes, [rw, ro], pod, []
+
+
 CASES = {
+    "disks": lambda: disks_case(),
     "readme": lambda: ([node(f"kube-node-{i}", cpu="2", mem="4G") for i in range(1, 5)], [], yaml.safe_load(EXAMPLES_POD), []),
     "taints-selectors": lambda: (
         [node("a", labels={"disk": "ssd"}), node("b", labels={"disk": "hdd"}),
@@ -1186,7 +1200,7 @@ def test_native_sharded_run_fails_loudly_without_gpus(native, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["readme", "taints-selectors", "ports-images"])
+@pytest.mark.parametrize("case", ["readme", "taints-selectors", "ports-images", "disks"])
 def test_native_sharded_path_with_one_rank_equals_the_plain_run(native, tmp_path, case):
     """--force-sharded: node-range shard [0, N), one thread, one RCCL rank: shard views of the marshalled arrays, ccsim_dist_comm_init /
     sync_tables / dist_run and the merge of the per-rank reports must give the review of the plain single-GPU run."""
@@ -1228,7 +1242,7 @@ def _slice_pod(rec, lo, hi):
             a[k] = [{"v": sl(c["v"])} for c in a[k]]
         if lo > 0:
             a["entries_existing"] = 0
-    out["host_ports_conflict"], out["image_score"] = sl(out["host_ports_conflict"]), sl(out["image_score"])
+    out["host_ports_conflict"], out["image_score"], out["volume_veto"] = sl(out["host_ports_conflict"]), sl(out["image_score"]), sl(out["volume_veto"])
     return out
 
 
@@ -1378,7 +1392,9 @@ def _decorate(obj, rng):
     st["containerStatuses"] = [{"name": "c", "ready": True, "state": {"running": {"startedAt": "2025-01-01T00:00:00Z"}}, "imageID": "sha256:" + "0" * 64}]
     sp = o.setdefault("spec", {})
     if o.get("kind") == "Pod":
-        sp["volumes"] = [{"name": "data", "persistentVolumeClaim": {"claimName": "pvc"}}, {"name": "kube-api-access", "projected": {"sources": [{"serviceAccountToken": {"path": "token"}}]}}]
+        # (kept when a template has volumes of its own to compare them with -- round 5 -- skipped otherwise)
+        sp["volumes"] = (sp.get("volumes") or []) + [{"name": "data", "persistentVolumeClaim": {"claimName": "pvc"}},
+                                                     {"name": "kube-api-access", "projected": {"sources": [{"serviceAccountToken": {"path": "token"}}]}}]
         sp["tolerations"] = [{"key": "node.kubernetes.io/not-ready", "operator": "Exists", "effect": "NoExecute", "tolerationSeconds": 300}]
         sp["securityContext"], sp["imagePullSecrets"] = {"runAsUser": 1000}, [{"name": "regcred"}]
         for c in (sp.get("containers") or []) + (sp.get("initContainers") or []):
