@@ -178,7 +178,7 @@ struct ccsim_engine {
     uint32_t *d_anti_bits = nullptr, *d_anti_bits0 = nullptr;
     MPartial *d_mpartials = nullptr;
     MCand *d_mcands = nullptr;
-    uint32_t *d_memo = nullptr;     // the score memo [n_pods][n_pad] (ccsim_multi.h), nullptr = off
+    uint16_t *d_memo = nullptr;     // the score memo [n_pods][n_pad], 16-bit words (ccsim_multi.h), nullptr = off
     int32_t *d_memo_stamp = nullptr, *d_mtouched = nullptr;
     const int32_t *tsc_label[kMTsc] = {nullptr, nullptr};
     DevPod multi_prof{};
@@ -2975,8 +2975,11 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     { // the score memo: one word per (spec, node), resident for the whole simulation -- when it fits (CCSIM_MULTI_MEMO_MB caps it, 0 = off)
         size_t cap_mb = 65536, free_b = 0, total_b = 0;
         if (const char *f = getenv("CCSIM_MULTI_MEMO_MB")) cap_mb = (size_t)(atoll(f) > 0 ? atoll(f) : 0);
-        const size_t bytes = NP * (size_t)n_pods * sizeof(uint32_t);
-        if (cap_mb && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= (cap_mb << 20) && bytes <= free_b / 2) {
+        const size_t bytes = NP * (size_t)n_pods * sizeof(uint16_t);
+        // (a word holds TotalScore + 1 in 11 bits: the profile's weights must leave it there -- the default profile's sum is 8 -- and the
+        // lean scan reads four nodes' words / labels per load: the padded length is a multiple of four -- kTile is)
+        const bool word_fits = 100ll * ((int64_t)pf.w_taint + pf.w_nodeaffinity + pf.w_fit + pf.w_balanced + pf.w_imagelocality) + 1 <= (int64_t)kMemoScoreMask;
+        if (cap_mb && word_fits && NP % 4 == 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= (cap_mb << 20) && bytes <= free_b / 2) {
             if ((rc = dev_alloc(e, &e->d_memo, NP * (size_t)n_pods, e->multi_allocs, false))) return rc;
             if ((rc = dev_alloc(e, &e->d_memo_stamp, 2 * (size_t)n_pods, e->multi_allocs, false))) return rc;
             if ((rc = dev_alloc(e, &e->d_mtouched, (size_t)kMTouched, e->multi_allocs))) return rc;
@@ -3014,7 +3017,7 @@ static MultiArgs multi_args(ccsim_engine *e) {
 }
 
 static void launch_multi_window(ccsim_engine *e, const MultiArgs &a) {
-    const int chunks = (a.window + kMPodChunk - 1) / kMPodChunk;
+    const int chunks = ((a.window + kMPodChunk - 1) / kMPodChunk) * kMLeanPer; // (grid.y: lean workgroups, ccsim_multi.h kMLeanChunk)
     hipLaunchKernelGGL(k_multi_scan, dim3((unsigned)e->m_blocks, (unsigned)chunks), dim3(kThreads), 0, e->stream, a);
     hipLaunchKernelGGL(k_multi_select, dim3((unsigned)a.window), dim3(64), 0, e->stream, a);
     hipLaunchKernelGGL(k_multi_commit_par, dim3(1), dim3(kMParThreads), 0, e->stream, a); // (or, as its wave 0, the in-order commit: MState::seq_windows)
@@ -3178,7 +3181,7 @@ extern "C" int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out4) {
     for (int i = 0; i < 4; i++) out4[4 + i] = e->h_mstate->scan_prof[i];
     out4[0] = e->multi && e->d_memo ? 1 : 0;
     out4[1] = e->h_mstate->memo_scans, out4[2] = e->h_mstate->full_scans;
-    out4[3] = e->multi && e->d_memo ? (int64_t)e->n_pad * e->n_pods * (int64_t)sizeof(uint32_t) : 0;
+    out4[3] = e->multi && e->d_memo ? (int64_t)e->n_pad * e->n_pods * (int64_t)sizeof(uint16_t) : 0;
     return 0;
 }
 

@@ -40,10 +40,20 @@ namespace ccsim {
 
 constexpr int kMWindowMax = 64;   // pods per window (= lanes of the commit wave holding per-pod rows)
 #ifndef CCSIM_MPOD_CHUNK
-#define CCSIM_MPOD_CHUNK 8 // (build-time knob for A/B runs)
+#define CCSIM_MPOD_CHUNK 2 // (build-time knob for A/B runs; round 5: 8 -> 2, see kMLeanChunk)
 #endif
 constexpr int kMPodChunk = CCSIM_MPOD_CHUNK; // pods per scan workgroup ...
 constexpr int kMPodSub = 2;                  // ... whose per-node words are held in registers at a time
+// Round 5: the LEAN form of the scan (every pod of the chunk has a valid memo row: the steady state) is not bound by bytes or by total
+// arithmetic but by how many instructions ONE wave executes back to back -- at 8 pods per workgroup ~1500 in the evaluation, 6.5 us at
+// the three waves a SIMD holds.  Fewer pods per workgroup, more workgroups: measured (profiles/r05/bench_c5_pod_chunk.txt) 8 pods per
+// workgroup 48.0 us per window, 4: 45.3, 2: 44.8.  (A chunk's pods can also be spread over kMLeanPer lean workgroups while the general
+// form keeps 8 per workgroup -- one kernel then carries the general form's registers into the lean form's occupancy: 49.9 us.  So the
+// chunk itself is 2 and the general form re-reads the node columns per 2 pods: it runs for a spec's first scan and after normalization
+// events only, and when the memo is off: 7.3e5 -> see DESIGN 4.3.)
+constexpr int kMLeanChunk = kMPodChunk;
+constexpr int kMLeanPer = kMPodChunk / kMLeanChunk;
+static_assert(kMPodChunk % kMLeanChunk == 0, "lean workgroups per pod chunk");
 static_assert(kMPodChunk % kMPodSub == 0, "pods per scan workgroup: a multiple of kMPodSub");
 constexpr int kMNodesPerThread = 4;
 constexpr int kMBlockNodes = kThreads * kMNodesPerThread; // 1024
@@ -124,10 +134,35 @@ struct MultiArgs {
     int32_t *per_spec;               // [n_pods]
     int32_t window;                  // pods per window (<= kMWindowMax, <= n_pods)
     // the score memo (header comment; nullptr = off: every scan computes)
-    uint32_t *memo;                  // [n_pods][n_pad]: 0 = static verdict / NodeResourcesFit / anti-affinity reject the pair, else TotalScore + 1
+    // [n_pods][n_pad] 16-bit words (round 5: half the bytes of the scan's dominant stream): bits 0..10 = 0 when the static verdict /
+    // NodeResourcesFit / anti-affinity reject the pair, else TotalScore + 1; bits 11..14 = how the node's taint count / affinity sum
+    // stand to the maxima the row was computed under (kMemoEqT ...): the lean scan needs no static word
+    uint16_t *memo;
     int32_t *memo_stamp;             // [n_pods][2]: the (taint, affinity) maxima the row was computed under; -1 = no row
     int32_t *touched;                // [kMTouched] shard-local indices
 };
+
+__device__ __forceinline__ uint32_t op_or_u32(uint32_t a, uint32_t b) { return a | b; }
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    CCSIM_DPP_STEP32(v, 0u, op_or_u32, 0x111, 0xf) CCSIM_DPP_STEP32(v, 0u, op_or_u32, 0x112, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_or_u32, 0x114, 0xf) CCSIM_DPP_STEP32(v, 0u, op_or_u32, 0x118, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_or_u32, 0x142, 0xa) CCSIM_DPP_STEP32(v, 0u, op_or_u32, 0x143, 0xc)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+constexpr uint32_t kMemoScoreMask = 0x7ffu; // TotalScore + 1 <= 2047 (ccsim_set_pods checks the weights; else the memo stays off)
+constexpr uint32_t kMemoEqT = 1u << 11, kMemoGtT = 1u << 12, kMemoEqA = 1u << 13, kMemoGtA = 1u << 14;
+__device__ __forceinline__ uint16_t m_memo_word(bool ok, uint32_t total, uint32_t cnt, uint32_t aff, uint32_t mt, uint32_t ma) {
+    if (!ok) return 0;
+    return (uint16_t)((total + 1u) | (cnt == mt ? kMemoEqT : 0u) | (cnt > mt ? kMemoGtT : 0u) | (aff == ma ? kMemoEqA : 0u) | (aff > ma ? kMemoGtA : 0u));
+}
+// What a scan that only sees those bits can say about a true maximum over its feasible nodes: the assumed one when a holder is
+// among them, else a value that DIFFERS from it -- above or below as the truth is.  The commit ends the window before such a pod
+// and takes the value as the next assumption; the scan that follows (the row's stamp no longer matches: the general form) reports
+// the exact maximum, and one more zero-progress window later the assumption is exact.  Never a wrong score: every score the
+// commit uses was computed under maxima it has checked against the true ones.
+__device__ __forceinline__ uint32_t m_max_from_level(uint32_t level, uint32_t assumed, uint32_t nfeas) {
+    return level >= 2u ? assumed + 1u : level == 1u ? assumed : (assumed == 0u || nfeas == 0u ? 0u : assumed - 1u);
+}
 
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { // a wave-uniform 64-bit value, into scalar registers
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -204,69 +239,83 @@ __device__ __forceinline__ int32_t m_tbl_min(const int32_t *tbl, const uint8_t *
 // static words of ALL the chunk's pods (2 x 8 x 4 loads per thread) are issued at once, the spread filter is a bit test against
 // the spec's per-domain masks (MPod::tsc_allow: no table, no minimum, no LDS read per pair), and the evaluation runs from registers.
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int next_pod, const int j0, const int jn, const int64_t base,
-                                                const unsigned long long sp_t0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ MPod l_pod[kMPodChunk];
-    __shared__ uint32_t l_k[kMPodChunk][3][kThreads / 64];
-    __shared__ uint32_t l_u[kMPodChunk][5][kThreads / 64];
-
-    uint32_t lv[kMNodesPerThread];
+// The loads of the lean form -- issued by k_multi_scan TOGETHER with the loads that decide which form runs (one round trip instead of two).
+struct MLeanLoads {
+    uint32_t lv[kMNodesPerThread]; // the thread's four consecutive nodes: value ids of the two spread label columns, one byte each
+    uint2 cv[kMLeanChunk];         // per pod: the four nodes' memo words
+    int32_t desc;                  // this thread's word of the pods' descriptors (tid < kMLeanChunk * sizeof(MPod) / 4)
+};
+__device__ __forceinline__ void multi_scan_lean_loads(const MultiArgs &a, const int next_pod, const int j0, const int jn, const int64_t base, MLeanLoads &L) {
+    const int tid = threadIdx.x;
+    // a thread owns FOUR CONSECUTIVE nodes (local indices 4 tid .. 4 tid + 3): the labels arrive as one 16-byte load per column, a
+    // pod's four 16-bit memo words as one 8-byte load (n_pad is a multiple of four: ccsim_set_pods checks)
+    const int64_t i4 = base + 4 * tid;
+    const bool in4 = i4 < a.c.n_pad;
+    const int4 z = make_int4(0, 0, 0, 0);
+    const int4 l0 = in4 && a.tsc_label[0] ? *reinterpret_cast<const int4 *>(a.tsc_label[0] + i4) : z;
+    const int4 l1 = in4 && a.tsc_label[1] ? *reinterpret_cast<const int4 *>(a.tsc_label[1] + i4) : z;
+    const int32_t x0[4] = {l0.x, l0.y, l0.z, l0.w}, x1[4] = {l1.x, l1.y, l1.z, l1.w};
 #pragma unroll
-    for (int k = 0; k < kMNodesPerThread; k++) {
-        const int64_t i = base + k * kThreads + tid;
-        const bool in = i < a.c.n_pad;
-        const uint32_t l0 = in && a.tsc_label[0] ? (uint32_t)a.tsc_label[0][i] : 0u, l1 = in && a.tsc_label[1] ? (uint32_t)a.tsc_label[1][i] : 0u;
-        lv[k] = (l0 & (uint32_t)kMDomMax) | ((l1 & (uint32_t)kMDomMax) << 8);
-    }
-    {
-        constexpr int kWords = (int)(sizeof(MPod) / 4);
-        int32_t *dst = reinterpret_cast<int32_t *>(&l_pod[0]);
-        for (int i = tid; i < kMPodChunk * kWords; i += kThreads) {
-            const int jj = i / kWords, w = i % kWords;
-            const int pi = (next_pod + j0 + (jj < jn ? jj : 0)) % a.n_pods;
-            dst[i] = reinterpret_cast<const int32_t *>(&a.pods[pi])[w];
-        }
-    }
-    __syncthreads();
-    // every pod's words, all in flight together
-    uint32_t cv[kMPodChunk][kMNodesPerThread], wv[kMPodChunk][kMNodesPerThread];
+    for (int k = 0; k < kMNodesPerThread; k++) L.lv[k] = ((uint32_t)x0[k] & (uint32_t)kMDomMax) | (((uint32_t)x1[k] & (uint32_t)kMDomMax) << 8);
 #pragma unroll
-    for (int jj = 0; jj < kMPodChunk; jj++) {
+    for (int jj = 0; jj < kMLeanChunk; jj++) {
         const bool on = jj < jn;
         const int pi = (next_pod + j0 + (on ? jj : 0)) % a.n_pods;
-        const uint32_t *row = a.memo + (int64_t)pi * a.n_pad;
-        const uint32_t *stat = a.stat_cls + (int64_t)uni32(l_pod[jj].cls) * a.n_pad;
-#pragma unroll
-        for (int k = 0; k < kMNodesPerThread; k++) {
-            const int64_t i = base + k * kThreads + tid;
-            const bool in = on && i < a.c.n_pad;
-            cv[jj][k] = in ? row[i] : 0u;
-            wv[jj][k] = in ? stat[i] : 0u;
-        }
+        L.cv[jj] = on && in4 ? *reinterpret_cast<const uint2 *>(a.memo + (int64_t)pi * a.n_pad + i4) : make_uint2(0u, 0u);
     }
+    constexpr int kWords = (int)(sizeof(MPod) / 4);
+    static_assert(kMLeanChunk * kWords <= kThreads, "one descriptor word per thread");
+    L.desc = 0;
+    if (tid < kMLeanChunk * kWords) {
+        const int jj = tid / kWords, w = tid % kWords;
+        const int pi = (next_pod + j0 + (jj < jn ? jj : 0)) % a.n_pods;
+        L.desc = reinterpret_cast<const int32_t *>(&a.pods[pi])[w];
+    }
+}
+
+__device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int next_pod, const int j0, const int jn, const int64_t base,
+                                                const unsigned long long sp_t0, const MLeanLoads &L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ MPod l_pod[kMLeanChunk];
+    __shared__ uint32_t l_k[kMLeanChunk][3][kThreads / 64];
+    __shared__ uint32_t l_u[kMLeanChunk][5][kThreads / 64];
+    const uint32_t *lv = L.lv;
+    const uint2 *cv = L.cv;
+    {
+        constexpr int kWords = (int)(sizeof(MPod) / 4);
+        if (tid < kMLeanChunk * kWords) reinterpret_cast<int32_t *>(&l_pod[0])[tid] = L.desc;
+    }
+    __syncthreads();
     const unsigned long long sp_t1 = __builtin_amdgcn_s_memrealtime();
+    // (no branch per pod: a pod beyond the window's end has all-zero words and ranks nothing -- the eight pods' reduction chains are
+    // independent and the scheduler interleaves them; with a uniform branch around each pod they ran one after the other)
 #pragma unroll
-    for (int jj = 0; jj < kMPodChunk; jj++) {
-        if (jj < jn) { // (uniform)
+    for (int jj = 0; jj < kMLeanChunk; jj++) {
+        {
             const MPod &q = l_pod[jj];
-            const uint32_t mt = (uint32_t)uni32(q.mt_a), ma = (uint32_t)uni32(q.ma_a);
             // the spread filter per domain is the spec's own state (MPod::tsc_allow): two 64-bit masks in scalar registers
             const uint64_t allow0 = uni64(q.tsc_allow[0]), allow1 = uni64(q.tsc_allow[1]);
             const bool sl0 = uni32(q.tsc_slot[0]) != 0, sl1 = uni32(q.tsc_slot[1]) != 0;
-            uint32_t k1 = 0, k2 = 0, k3 = 0, mtb = 0, mab = 0, acc = 0;
+            uint32_t k1 = 0, k2 = 0, k3 = 0, lv_bits = 0, acc = 0;
+            const uint32_t words[4] = {cv[jj].x & 0xffffu, cv[jj].x >> 16, cv[jj].y & 0xffffu, cv[jj].y >> 16};
 #pragma unroll
             for (int k = 0; k < kMNodesPerThread; k++) {
-                const uint32_t word = cv[jj][k];
+                // Branch-free (round 5): as nested `if`s this loop compiled to three exec-mask branches per pair -- 96 per workgroup pass --
+                // and the three waves a SIMD holds here cannot hide their issue bubbles (8.4 us of "evaluation" for ~1500 instructions)
+                const uint32_t word = words[k];
                 const uint32_t v0 = (sl0 ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax, v1 = (sl1 ? lv[k] >> 8 : lv[k]) & (uint32_t)kMDomMax;
-                const bool ok = word != 0u && ((allow0 >> v0) & 1ull) && ((allow1 >> v1) & 1ull);
-                if (!ok) continue;
-                const uint32_t w = wv[jj][k];
-                const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
-                const uint32_t key = (word << 10) | (1023u - (uint32_t)(k * kThreads + tid)); // word = TotalScore + 1
-                if (key > k1) k3 = k2, k2 = k1, k1 = key; else if (key > k2) k3 = k2, k2 = key; else if (key > k3) k3 = key;
-                mtb = cnt > mtb ? cnt : mtb, mab = aff > mab ? aff : mab;
-                acc += 1u | ((uint32_t)(cnt == mt) << 10) | ((uint32_t)(aff == ma) << 20);
+                const uint32_t sc = word & kMemoScoreMask; // TotalScore + 1, 0 = the pair is out
+                const uint32_t pass = (uint32_t)((allow0 >> v0) & (allow1 >> v1) & 1ull);
+                const uint32_t okm = (sc != 0u ? pass : 0u) ? 0xffffffffu : 0u; // all ones: the node is feasible for the pod today
+                uint32_t key = (((sc << 10) | (1023u - (uint32_t)(4 * tid + k))) & okm); // | the lower index wins a tie
+                // insert into the sorted triple (keys of feasible nodes are unique and non-zero)
+                uint32_t t = key > k1 ? key : k1; key = key > k1 ? k1 : key; k1 = t;
+                t = key > k2 ? key : k2; key = key > k2 ? k2 : key; k2 = t;
+                k3 = key > k3 ? key : k3;
+                // (the word's four flag bits as they are: OR over the feasible nodes, one reduction for both maxima)
+                const uint32_t wm = word & okm;
+                lv_bits |= wm;
+                acc += (okm & 1u) + ((uint32_t)((wm & (kMemoEqT | kMemoGtT)) == kMemoEqT) << 10) + ((uint32_t)((wm & (kMemoEqA | kMemoGtA)) == kMemoEqA) << 20);
             }
             const uint32_t w1 = wave_max_u32(k1);
             const bool h1 = k1 == w1 && w1 != 0;
@@ -274,18 +323,19 @@ __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int ne
             const uint32_t w2 = wave_max_u32(x2);
             const bool h2 = x2 == w2 && w2 != 0;
             const uint32_t w3 = wave_max_u32(h2 ? y2 : x2);
-            const uint32_t wmt = wave_max_u32(mtb), wma = wave_max_u32(mab);
+            const uint32_t wbits = wave_or_u32(lv_bits);
+            const uint32_t wlt = (wbits & kMemoGtT) ? 2u : (wbits & kMemoEqT) ? 1u : 0u, wla = (wbits & kMemoGtA) ? 2u : (wbits & kMemoEqA) ? 1u : 0u;
             const uint32_t packed = wave_sum_u32(acc);
-            if (lane == 0)
-                l_k[jj][0][wave] = w1, l_k[jj][1][wave] = w2, l_k[jj][2][wave] = w3, l_u[jj][0][wave] = packed & 1023u, l_u[jj][1][wave] = wmt,
-                l_u[jj][2][wave] = wma, l_u[jj][3][wave] = (packed >> 10) & 1023u, l_u[jj][4][wave] = packed >> 20;
+            if (lane == 0 && jj < jn)
+                l_k[jj][0][wave] = w1, l_k[jj][1][wave] = w2, l_k[jj][2][wave] = w3, l_u[jj][0][wave] = packed & 1023u, l_u[jj][1][wave] = wlt,
+                l_u[jj][2][wave] = wla, l_u[jj][3][wave] = (packed >> 10) & 1023u, l_u[jj][4][wave] = packed >> 20;
         }
     }
     const unsigned long long sp_t2 = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (tid < jn) {
         const int jj = tid;
-        uint32_t b1 = 0, b2 = 0, b3 = 0;
+        uint32_t b1 = 0, b2 = 0, b3 = 0, lt = 0, la = 0;
         MPartial o{};
         for (int x = 0; x < kThreads / 64; x++) {
             for (int h = 0; h < 3; h++) {
@@ -293,9 +343,10 @@ __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int ne
                 if (key > b1) b3 = b2, b2 = b1, b1 = key; else if (key > b2) b3 = b2, b2 = key; else if (key > b3) b3 = key;
             }
             o.nfeas += l_u[jj][0][x];
-            o.mt = l_u[jj][1][x] > o.mt ? l_u[jj][1][x] : o.mt, o.ma = l_u[jj][2][x] > o.ma ? l_u[jj][2][x] : o.ma;
+            lt = l_u[jj][1][x] > lt ? l_u[jj][1][x] : lt, la = l_u[jj][2][x] > la ? l_u[jj][2][x] : la;
             o.c_mt += l_u[jj][3][x], o.c_ma += l_u[jj][4][x];
         }
+        o.mt = m_max_from_level(lt, (uint32_t)l_pod[jj].mt_a, o.nfeas), o.ma = m_max_from_level(la, (uint32_t)l_pod[jj].ma_a, o.nfeas);
         auto widen = [&](uint32_t key) -> uint64_t {
             return key ? make_key((int64_t)(key >> 10) - 1, a.c.global_offset + base + (int64_t)(1023u - (key & 1023u))) : 0ull;
         };
@@ -321,20 +372,28 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
     const int32_t done = a.st->done, win_n = a.st->win_n, next_pod = a.st->next_pod; // (not the whole MState: it would sit in ~60 SGPRs)
     if (done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j0 = blockIdx.y * kMPodChunk;
+    const int sub = blockIdx.y % kMLeanPer; // this workgroup's share of the chunk in the lean form (kMLeanChunk)
+    const int j0 = (blockIdx.y / kMLeanPer) * kMPodChunk;
     if (j0 >= win_n) return;
     const unsigned long long sp_t0 = __builtin_amdgcn_s_memrealtime();
     const int jn = win_n - j0 < kMPodChunk ? win_n - j0 : kMPodChunk;
     const int64_t base = (int64_t)blockIdx.x * kMBlockNodes;
-    if (a.memo) { // every pod of the chunk with a valid memo row (lane jj looks at pod jj: one round trip): the lean form
+    if (a.memo) { // every pod of the chunk with a valid memo row (lane jj looks at pod jj): the lean form
         const bool on = lane < jn;
         const int pi = (next_pod + j0 + (on ? lane : 0)) % a.n_pods;
-        const bool valid = a.memo_stamp[2 * pi] == a.pods[pi].mt_a && a.memo_stamp[2 * pi + 1] == a.pods[pi].ma_a;
+        // ONE round trip: the words that decide the form, and with them everything the lean form loads (wasted when the general form
+        // runs: each spec's first scan and the scans after a normalization event)
+        const int32_t st0 = a.memo_stamp[2 * pi], st1 = a.memo_stamp[2 * pi + 1], as0 = a.pods[pi].mt_a, as1 = a.pods[pi].ma_a;
+        const int lj0 = j0 + sub * kMLeanChunk, ljn = jn - sub * kMLeanChunk < kMLeanChunk ? jn - sub * kMLeanChunk : kMLeanChunk;
+        MLeanLoads L;
+        multi_scan_lean_loads(a, next_pod, lj0, ljn > 0 ? ljn : 0, base, L);
+        const bool valid = st0 == as0 && st1 == as1;
         if (__ballot(on && !valid) == 0) {
-            multi_scan_lean(a, next_pod, j0, jn, base, sp_t0);
+            if (ljn > 0) multi_scan_lean(a, next_pod, lj0, ljn, base, sp_t0, L);
             return;
         }
     }
+    if (sub != 0) return; // the general form: the chunk's first workgroup does all of its pods
 
     __shared__ MPod s_pod[kMPodChunk];
     __shared__ int32_t s_tbl[kMPodChunk][kMTsc][kMDomMax + 1];
@@ -369,13 +428,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
         const uint32_t *stat = a.stat_cls + (int64_t)cls * a.n_pad;
         const uint32_t *bits = a.anti_bits + (int64_t)pi * (a.n_pad / 32);
         const bool memo = m_memo_valid(a, pi); // (nothing writes stamps or maxima while a scan runs: the same answer in the evaluation below)
-        const uint32_t *row = a.memo + (int64_t)pi * a.n_pad;
+        const uint16_t *row = a.memo + (int64_t)pi * a.n_pad;
 #pragma unroll
         for (int k = 0; k < kMNodesPerThread; k++) {
             const int64_t i = base + k * kThreads + tid;
             const bool in = on && i < a.c.n_pad;
             wv[slot][k] = in ? stat[i] : 0u;
-            bv[slot][k] = memo ? (in ? row[i] : 0u) : (in && anti ? bits[i >> 5] : 0u); // the memo word takes the anti-affinity word's register
+            bv[slot][k] = memo ? (in ? (uint32_t)row[i] & kMemoScoreMask : 0u) : (in && anti ? bits[i >> 5] : 0u); // the memo word takes the anti-affinity word's register
         }
     };
 #pragma unroll
@@ -448,7 +507,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
             }
             const uint32_t my_bit = (uint32_t)(tid & 31); // (the workgroup's first node and k * kThreads are multiples of 32)
             const bool memo = uni32(s_memo[jj]) != 0;
-            uint32_t *row = a.memo ? a.memo + (int64_t)((next_pod + j0 + jj) % a.n_pods) * a.n_pad : nullptr;
+            uint16_t *row = a.memo ? a.memo + (int64_t)((next_pod + j0 + jj) % a.n_pods) * a.n_pad : nullptr;
             uint32_t k1 = 0, k2 = 0, k3 = 0;
             uint32_t mtb = 0, mab = 0;
             uint32_t acc = 0; // three 10-bit counters: feasible nodes | holders of the assumed taint maximum << 10 | of the affinity one << 20
@@ -468,7 +527,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
                     if (ok || row) // (a memo row is filled for every pair that fits, whatever the spread filter says today)
                         total = ok ? (uint32_t)(static_score(p, cnt, aff, img, mt, ma, Mt, Ma) + dynamic_score_narrow(p, nq, a0[k], a1[k], r0[k], r1[k], z0[k], z1[k])) : 0u;
                     const int64_t i = base + k * kThreads + tid;
-                    if (row && i < a.c.n_pad) row[i] = ok ? total + 1u : 0u;
+                    if (row && i < a.c.n_pad) row[i] = m_memo_word(ok, total, cnt, aff, mt, ma);
                 }
 #pragma unroll
                 for (int c = 0; c < kMTsc; c++) { // PodTopologySpread.Filter: one LDS read and one compare per constraint
@@ -1158,10 +1217,11 @@ __global__ __launch_bounds__(kMRefreshThreads) void k_multi_refresh(MultiArgs a)
     const int32_t a0 = a.c.a32[0][n], a1 = a.c.a32[1][n], r0 = a.c.r32[0][n], r1 = a.c.r32[1][n], z0 = a.c.z32[0][n], z1 = a.c.z32[1][n];
     const int32_t room = (int64_t)a.c.pod_count[n] + 1 <= (int64_t)a.c.alloc_pods[n] ? 1 : 0;
     const bool ok = (w >> kStatOkBit) && fits_narrow(p, nq, a0, a1, r0, r1, room, 0) && !anti;
-    uint32_t word = 0;
+    uint16_t word = 0;
     if (ok) {
         const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask, img = (w >> kStatImgShift) & kStatImgMask;
-        word = (uint32_t)(static_score(p, cnt, aff, img, (uint32_t)q.mt_a, (uint32_t)q.ma_a) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1)) + 1u;
+        const uint32_t total = (uint32_t)(static_score(p, cnt, aff, img, (uint32_t)q.mt_a, (uint32_t)q.ma_a) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1));
+        word = m_memo_word(true, total, cnt, aff, (uint32_t)q.mt_a, (uint32_t)q.ma_a);
     }
     a.memo[(int64_t)pi * a.n_pad + n] = word;
 }

@@ -137,7 +137,7 @@ def test_score_memo_on_and_off_agree_and_the_memo_serves_the_scans(ccref, monkey
         assert mm["on"] == (memo == "on") and mm["memo_scans"] + mm["full_scans"] >= r.placed
         assert ref.placed == 1500 and r.placed > 5000
         if memo == "on":  # every spec computes its row once (and again after a re-derived maximum); the rest is read
-            assert 4 * 256 * nodes.n <= mm["bytes"] < 4 * 256 * (nodes.n + 1024)
+            assert 2 * 256 * nodes.n <= mm["bytes"] < 2 * 256 * (nodes.n + 1024)  # 16-bit words (round 5)
             assert mm["memo_scans"] > 10 * mm["full_scans"], mm
             e.reset_state()
             r2 = e.run(max_limit=20_000, log_cap=20_000)
