@@ -239,6 +239,63 @@ __device__ __forceinline__ int32_t m_tbl_min(const int32_t *tbl, const uint8_t *
 // static words of ALL the chunk's pods (2 x 8 x 4 loads per thread) are issued at once, the spread filter is a bit test against
 // the spec's per-domain masks (MPod::tsc_allow: no table, no minimum, no LDS read per pair), and the evaluation runs from registers.
 // ------------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------------
+// multi_select_pod: ONE WAVE -- the top-K of the scan workgroups' best-two keys for pod j of the window, sorted, + the aggregates.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void multi_select_pod(const MultiArgs &a, const int j, const int next_pod) {
+    const int lane = threadIdx.x & 63;
+    const MPartial *pp = a.partials + (int64_t)j * a.n_blocks;
+    uint64_t best[kMTopK];
+#pragma unroll
+    for (int k = 0; k < kMTopK; k++) best[k] = 0;
+    uint32_t nf = 0, mt = 0, ma = 0, cmt = 0, cma = 0;
+    uint64_t dropped = 0; // the best key this lane saw and does not keep (it may still be the wave's (K+1)-th)
+    // every lane keeps the sorted top-K of its share, then K rounds of wave max + pop
+    for (int b = lane; b < a.n_blocks; b += 64) {
+        const MPartial q = pp[b];
+        for (int h = 0; h < 2; h++) {
+            uint64_t key = h ? q.key2 : q.key1;
+#pragma unroll
+            for (int k = 0; k < kMTopK; k++)
+                if (key > best[k]) { const uint64_t t = best[k]; best[k] = key; key = t; }
+            dropped = key > dropped ? key : dropped;
+        }
+        nf += q.nfeas;
+        mt = q.mt > mt ? q.mt : mt, ma = q.ma > ma ? q.ma : ma;
+        cmt += q.c_mt, cma += q.c_ma; // holders of the pod's ASSUMED maxima (meaningful iff they are the true ones: checked by the commit)
+    }
+    const uint32_t wmt = wave_max_u32(mt), wma = wave_max_u32(ma);
+    const uint32_t wcmt = wave_sum_u32(cmt), wcma = wave_sum_u32(cma), wnf = wave_sum_u32(nf);
+    MCand &out = a.cands[j]; // (the keys go straight to memory: `out.key[n++]` on a local copy was a dynamically indexed array in scratch)
+    int n = 0;
+#pragma unroll 1
+    for (int k = 0; k < kMTopK; k++) {
+        const uint64_t m = wave_max_u64(best[0]);
+        if (!m) break;
+        if (lane == 0) out.key[n] = m;
+        n++;
+        if (best[0] == m) { // unique keys: one lane pops
+#pragma unroll
+            for (int x = 0; x + 1 < kMTopK; x++) best[x] = best[x + 1];
+            best[kMTopK - 1] = 0;
+        }
+    }
+    if (lane == 0)
+        for (int k = n; k < kMTopK; k++) out.key[k] = 0;
+    // what the list does not hold: the lanes' remaining (and dropped) candidates; the workgroups' hidden nodes are bounded
+    // per workgroup (MPartial::key3) when the commit needs them
+    const uint64_t rest = wave_max_u64(best[0] > dropped ? best[0] : dropped);
+    if (lane == 0) {
+        out.n = n, out.nfeas = (int32_t)wnf, out.mt = wmt, out.ma = wma, out.c_mt = wcmt, out.c_ma = wcma, out.bound = rest;
+        if (j == 0) a.st->epoch = a.st->epoch + 1; // this window's candidates exist: exactly one commit kernel may consume them
+        const int pi = (next_pod + j) % a.n_pods;
+        atomicAdd(reinterpret_cast<unsigned long long *>(m_memo_valid(a, pi) ? &a.st->memo_scans : &a.st->full_scans), 1ull);
+        if (a.memo) { // the scan is over: the pod's memo row now holds what a scan under these maxima computes (read or just filled)
+            a.memo_stamp[2 * pi] = a.pods[pi].mt_a, a.memo_stamp[2 * pi + 1] = a.pods[pi].ma_a;
+        }
+    }
+}
+
 // The loads of the lean form -- issued by k_multi_scan TOGETHER with the loads that decide which form runs (one round trip instead of two).
 struct MLeanLoads {
     uint32_t lv[kMNodesPerThread]; // the thread's four consecutive nodes: value ids of the two spread label columns, one byte each
@@ -251,17 +308,23 @@ __device__ __forceinline__ void multi_scan_lean_loads(const MultiArgs &a, const 
     // pod's four 16-bit memo words as one 8-byte load (n_pad is a multiple of four: ccsim_set_pods checks)
     const int64_t i4 = base + 4 * tid;
     const bool in4 = i4 < a.c.n_pad;
-    const int4 z = make_int4(0, 0, 0, 0);
-    const int4 l0 = in4 && a.tsc_label[0] ? *reinterpret_cast<const int4 *>(a.tsc_label[0] + i4) : z;
-    const int4 l1 = in4 && a.tsc_label[1] ? *reinterpret_cast<const int4 *>(a.tsc_label[1] + i4) : z;
-    const int32_t x0[4] = {l0.x, l0.y, l0.z, l0.w}, x1[4] = {l1.x, l1.y, l1.z, l1.w};
-#pragma unroll
-    for (int k = 0; k < kMNodesPerThread; k++) L.lv[k] = ((uint32_t)x0[k] & (uint32_t)kMDomMax) | (((uint32_t)x1[k] & (uint32_t)kMDomMax) << 8);
+    // (unconditional 16- / 8-byte loads from an address that is always valid, the result masked: `cond ? *p : zero` on a vector made
+    // the compiler select between p and a zero in SCRATCH and load dword by dword)
+    const int64_t i4c = in4 ? i4 : 0;
+    const bool has0 = a.tsc_label[0] != nullptr, has1 = a.tsc_label[1] != nullptr;
+    const int4 l0 = *reinterpret_cast<const int4 *>((has0 ? a.tsc_label[0] : a.c.pod_count) + i4c);
+    const int4 l1 = *reinterpret_cast<const int4 *>((has1 ? a.tsc_label[1] : a.c.pod_count) + i4c);
+    const uint32_t m0 = in4 && has0 ? (uint32_t)kMDomMax : 0u, m1 = in4 && has1 ? (uint32_t)kMDomMax : 0u;
+    L.lv[0] = ((uint32_t)l0.x & m0) | (((uint32_t)l1.x & m1) << 8), L.lv[1] = ((uint32_t)l0.y & m0) | (((uint32_t)l1.y & m1) << 8);
+    L.lv[2] = ((uint32_t)l0.z & m0) | (((uint32_t)l1.z & m1) << 8), L.lv[3] = ((uint32_t)l0.w & m0) | (((uint32_t)l1.w & m1) << 8);
+    static_assert(kMNodesPerThread == 4, "four consecutive nodes per thread");
 #pragma unroll
     for (int jj = 0; jj < kMLeanChunk; jj++) {
         const bool on = jj < jn;
         const int pi = (next_pod + j0 + (on ? jj : 0)) % a.n_pods;
-        L.cv[jj] = on && in4 ? *reinterpret_cast<const uint2 *>(a.memo + (int64_t)pi * a.n_pad + i4) : make_uint2(0u, 0u);
+        const uint2 w = *reinterpret_cast<const uint2 *>(a.memo + (int64_t)pi * a.n_pad + i4c);
+        const uint32_t mk = on && in4 ? 0xffffffffu : 0u;
+        L.cv[jj] = make_uint2(w.x & mk, w.y & mk);
     }
     constexpr int kWords = (int)(sizeof(MPod) / 4);
     static_assert(kMLeanChunk * kWords <= kThreads, "one descriptor word per thread");
@@ -279,8 +342,8 @@ __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int ne
     __shared__ MPod l_pod[kMLeanChunk];
     __shared__ uint32_t l_k[kMLeanChunk][3][kThreads / 64];
     __shared__ uint32_t l_u[kMLeanChunk][5][kThreads / 64];
-    const uint32_t *lv = L.lv;
-    const uint2 *cv = L.cv;
+    const auto &lv = L.lv; // (references, not pointers: the struct stays in registers)
+    const auto &cv = L.cv;
     {
         constexpr int kWords = (int)(sizeof(MPod) / 4);
         if (tid < kMLeanChunk * kWords) reinterpret_cast<int32_t *>(&l_pod[0])[tid] = L.desc;
@@ -586,60 +649,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_multi_select: one wave per pod of the window -- the top-K of the workgroups' best-two keys, sorted, + the aggregates.
+// k_multi_select: one wave per pod of the window (multi_select_pod).  Round 5 tried the selection in the scan's TAIL (the last workgroup
+// of a pod chunk to deliver its partials selects for the chunk: a ticket per chunk): with a release fence per workgroup the scan became a
+// 279 us kernel (3 136 L2 write-backs), with agent-scope word stores and a relaxed ticket 46 us -- 98 same-address device-scope atomics
+// per chunk from eight XCDs serialize at ~0.3 us each.  A launch of its own costs 5.8 us: it stays (profiles/r05/bench_c5_pod_chunk.txt).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
-    const MState st = *a.st;
-    const int j = blockIdx.x, lane = threadIdx.x;
-    if (st.done || j >= st.win_n) return;
-    const MPartial *pp = a.partials + (int64_t)j * a.n_blocks;
-    uint64_t best[kMTopK];
-#pragma unroll
-    for (int k = 0; k < kMTopK; k++) best[k] = 0;
-    uint32_t nf = 0, mt = 0, ma = 0, cmt = 0, cma = 0;
-    uint64_t dropped = 0; // the best key this lane saw and does not keep (it may still be the wave's (K+1)-th)
-    // every lane keeps the sorted top-K of its share, then K rounds of wave max + pop
-    for (int b = lane; b < a.n_blocks; b += 64) {
-        const MPartial q = pp[b];
-        for (int h = 0; h < 2; h++) {
-            uint64_t key = h ? q.key2 : q.key1;
-#pragma unroll
-            for (int k = 0; k < kMTopK; k++)
-                if (key > best[k]) { const uint64_t t = best[k]; best[k] = key; key = t; }
-            dropped = key > dropped ? key : dropped;
-        }
-        nf += q.nfeas;
-        mt = q.mt > mt ? q.mt : mt, ma = q.ma > ma ? q.ma : ma;
-        cmt += q.c_mt, cma += q.c_ma; // holders of the pod's ASSUMED maxima (meaningful iff they are the true ones: checked by the commit)
-    }
-    const uint32_t wmt = wave_max_u32(mt), wma = wave_max_u32(ma);
-    const uint32_t wcmt = wave_sum_u32(cmt), wcma = wave_sum_u32(cma), wnf = wave_sum_u32(nf);
-    MCand out{};
-    int n = 0;
-#pragma unroll 1
-    for (int k = 0; k < kMTopK; k++) {
-        const uint64_t m = wave_max_u64(best[0]);
-        if (!m) break;
-        out.key[n++] = m;
-        if (best[0] == m) { // unique keys: one lane pops
-#pragma unroll
-            for (int x = 0; x + 1 < kMTopK; x++) best[x] = best[x + 1];
-            best[kMTopK - 1] = 0;
-        }
-    }
-    // what the list does not hold: the lanes' remaining (and dropped) candidates; the workgroups' hidden nodes are bounded
-    // per workgroup (MPartial::key3) when the commit needs them
-    const uint64_t rest = wave_max_u64(best[0] > dropped ? best[0] : dropped);
-    if (lane == 0) {
-        out.n = n, out.nfeas = (int32_t)wnf, out.mt = wmt, out.ma = wma, out.c_mt = wcmt, out.c_ma = wcma, out.bound = rest;
-        a.cands[j] = out;
-        if (j == 0) a.st->epoch = st.epoch + 1; // this window's candidates exist: exactly one commit kernel may consume them
-        const int pi = (st.next_pod + j) % a.n_pods;
-        atomicAdd(reinterpret_cast<unsigned long long *>(m_memo_valid(a, pi) ? &a.st->memo_scans : &a.st->full_scans), 1ull);
-        if (a.memo) { // the scan is over: the pod's memo row now holds what a scan under these maxima computes (read or just filled)
-            a.memo_stamp[2 * pi] = a.pods[pi].mt_a, a.memo_stamp[2 * pi + 1] = a.pods[pi].ma_a;
-        }
-    }
+    const int32_t done = a.st->done, win_n = a.st->win_n, next_pod = a.st->next_pod;
+    if (done || (int)blockIdx.x >= win_n) return;
+    multi_select_pod(a, (int)blockIdx.x, next_pod);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
