@@ -19,6 +19,7 @@ struct ccsim_engine {
     int first;
     int64_t global_offset, n_global;
     int world, rank;
+    int64_t one_cycle_runs; /* ccsim_dist_run calls with max_limit == 1 so far (the hosts' one-cycle-at-a-time loop) */
 };
 
 static void arr64(FILE *f, const char *k, const int64_t *p, int64_t n) {
@@ -253,6 +254,25 @@ int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_repor
     fprintf(e->f, "\"dist_run\": {\"max_limit\": %lld, \"mode\": %d, \"per_node_cap\": %lld, \"log_cap\": %lld, \"hist_taintset_cap\": %d}", (long long)max_limit, mode,
             (long long)out->per_node_cap, (long long)out->log_cap, out->hist_taintset_cap);
     if (e->world <= 0 || out->per_node_cap < e->n || (out->hist_taintset && out->hist_taintset_cap < e->n_taintsets)) return -22;
+    if (max_limit == 1) { /* the one-cycle-at-a-time loop: cycle c lands on global node c (logged by its owner), cycle n_global finds nothing */
+        const int64_t c = e->one_cycle_runs++;
+        memset(out->hist, 0, sizeof out->hist);
+        for (int64_t i = 0; i < e->n; i++) out->per_node_count[i] = 0;
+        out->log_len = 0, out->n_code_unschedulable = 0;
+        if (c < e->n_global) {
+            const int mine = c >= e->global_offset && c < e->global_offset + e->n;
+            out->placed = 1, out->stop = CCSIM_STOP_LIMIT;
+            if (mine) out->per_node_count[c - e->global_offset] = 1;
+            if (out->log && out->log_cap > 0) out->log[0] = mine ? (int32_t)c : -1, out->log_len = 1;
+        } else {
+            out->placed = 0, out->stop = CCSIM_STOP_UNSCHEDULABLE;
+            out->hist[CCSIM_R_TOO_MANY_PODS] = e->n;
+            if (out->hist_taintset)
+                for (int i = 0; i < e->n_taintsets; i++) out->hist_taintset[i] = 0;
+            out->n_code_unschedulable = e->n;
+        }
+        return 0;
+    }
     out->placed = e->n_global, out->stop = CCSIM_STOP_UNSCHEDULABLE, out->log_len = 0;
     for (int64_t i = 0; i < e->n; i++) out->per_node_count[i] = 1;
     if (out->log)

@@ -1190,6 +1190,25 @@ def test_refused_template_sets_take_one_cycle_at_a_time_in_both_hosts(ccref, nat
             assert [x["nodeName"] for x in got["status"]["pods"][t]["replicasOnNodes"]] == list(dict.fromkeys(snap.names[i] for i in r.log[t::3]))
 
 
+@pytest.mark.gpu
+def test_native_sharded_templates_with_one_rank_equal_the_window_engine(ccref, native, tmp_path):
+    """--force-sharded with several templates: one rank, one thread, the one-cycle-at-a-time loop over ccsim_dist_run == the window engine
+    of the plain run == the oracle's round-robin loop."""
+    nodes, pods, templates = _templates_case(n_nodes=30)
+    cluster, paths = _write_templates(tmp_path, nodes, pods, templates)
+    flags = [x for p in paths for x in ("--podspec", p)] + ["--snapshot", cluster, "-o", "json"]
+    for extra in ([], ["--max-limit", "10"]):
+        plain = json.loads(_run(native, flags + extra))
+        p = subprocess.run([native] + flags + extra + ["--force-sharded"], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 0 and "one scheduling cycle at a time" in p.stderr, p.stderr
+        got = json.loads(p.stdout)
+        got["status"].pop("creationTimestamp"), plain["status"].pop("creationTimestamp")
+        assert got["status"] == plain["status"]
+    snap = ingest.build_snapshot(nodes, pods, [cli.parse_pod_spec(q) for q in paths])
+    r = ccref.run_multi(M.Profile.default(), snap.nodes, snap.pods)
+    assert json.loads(_run(native, flags + ["--force-sharded"]))["status"]["replicas"] == r.placed
+
+
 # ---- --gpus N: the snapshot sharded over the GPUs of one box, the run driven inside libccsim.so over RCCL ------------------
 def test_native_sharded_run_fails_loudly_without_gpus(native, tmp_path):
     nodes, pods, pod, _ = CASES["readme"]()
@@ -1299,6 +1318,41 @@ def test_native_sharded_host_side_views_threads_and_merge(native, recorder, tmp_
     got = json.loads(stdout)
     got["status"].pop("creationTimestamp"), want["status"].pop("creationTimestamp", None)
     assert got["status"] == json.loads(json.dumps(want["status"]))
+
+
+@pytest.mark.parametrize("n_gpus", [1, 2, 3])
+def test_native_sharded_templates_one_cycle_at_a_time_threads_and_merge(native, recorder, tmp_path, n_gpus):
+    """Several templates with --gpus N (round 5): the rank threads walk the cycles in lock-step -- per cycle every rank sets ITS slice of
+    template i mod P with the template's own earlier clones folded in, synchronizes the tables and runs ccsim_dist_run(max_limit = 1).
+    Against tests/abi_recorder.c, whose canned cycle c lands on global node c: 12 cycles, one pod per node, templates 0, 1, 2 by turns, the
+    13th cycle (template 0) finds nothing; the LAST pod every rank was handed is template 0 with its four clones (nodes 0, 3, 6, 9) in the
+    per-node counts of its slice."""
+    nodes, pods, templates = _templates_case(n_nodes=12)
+    cluster, paths = _write_templates(tmp_path, nodes, pods, templates)
+    flags = [x for p in paths for x in ("--podspec", p)] + ["--snapshot", cluster, "-o", "json", "--gpus", str(n_gpus)] + (["--force-sharded"] if n_gpus == 1 else [])
+    env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "shard.json"), CCSIM_RECORD_PER_DEVICE="1")
+    p = subprocess.run([native] + flags, capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
+    assert p.returncode == 0, p.stderr
+    assert "one scheduling cycle at a time" in p.stderr
+    st = json.loads(p.stdout)["status"]
+    snap = ingest.build_snapshot(nodes, pods, [cli.parse_pod_spec(q) for q in paths])
+    assert st["replicas"] == 12 and [[x["nodeName"] for x in q["replicasOnNodes"]] for q in st["pods"]] == [[snap.names[i] for i in range(t, 12, 3)] for t in range(3)]
+    assert st["failReason"]["failMessage"].startswith("0/12 nodes are available: 12 Too many pods.")
+    per = -(-12 // n_gpus)
+    for g in range(n_gpus):
+        rec = json.load(open(f"{tmp_path}/shard.json.{g}"))  # (repeated keys: the LAST set_pod / dist_run of the rank)
+        lo, hi = min(12, g * per), min(12, g * per + per)
+        assert rec["dist_comm_init"] == {"n_ranks": n_gpus, "rank": g, "id_ok": 1} and rec["dist_run"]["max_limit"] == 1 and rec["profile"]["pct"] == 100
+        anti = rec["pod"]["ipa"]["anti_existing"][0]["v"]  # template 0: its required hostname anti-affinity sees its own clones
+        base = np.asarray(snap.pods[0].ipa.anti_existing[0] if snap.pods[0].ipa.anti_existing[0] is not None else np.zeros(12), np.int64)
+        want = base.copy()
+        want[[0, 3, 6, 9]] += 1
+        assert anti == want[lo:hi].tolist()
+        cnt = rec["pod"]["spread"][0]["node_match_count"]
+        base = np.asarray(snap.pods[0].spread[0].node_match_count if snap.pods[0].spread[0].node_match_count is not None else np.zeros(12), np.int64)
+        want = base.copy()
+        want[[0, 3, 6, 9]] += 1
+        assert cnt == want[lo:hi].tolist()
 
 
 def test_default_percentage_of_nodes_to_score_follows_the_reference(native, recorder, tmp_path):
