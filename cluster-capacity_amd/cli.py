@@ -406,6 +406,8 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
                                      # SyncWithClient copies claims and classes, not the volumes (simulator.go:228-295)
                                      pvc_objs=by.get("PersistentVolumeClaim", []), class_objs=by.get("StorageClass", []),
                                      pv_objs=by.get("PersistentVolume", []) if args.sync_persistent_volumes else None,
+                                     csinode_objs=by.get("CSINode", []) if args.sync_persistent_volumes else (),
+                                     attachment_objs=by.get("VolumeAttachment", []) if args.sync_persistent_volumes else (),
                                      volume_plugins=getattr(prof, "volume_plugins", ingest_volume_plugins()),
                                      volume_plugins_partial=getattr(prof, "volume_plugins_partial", False))
     except (TypeError, AttributeError, KeyError, OverflowError) as e:

@@ -131,6 +131,8 @@ void load_objects(const std::vector<std::string> &paths, const std::vector<Value
         else if (kind == "PersistentVolumeClaim") vol.claims.push_back(std::move(o)); // SyncWithClient copies claims and classes (simulator.go:228-295) ...
         else if (kind == "StorageClass") vol.classes.push_back(std::move(o));
         else if (kind == "PersistentVolume" && vol.sync_volumes) vol.volumes.push_back(std::move(o)); // ... not the volumes (--sync-persistent-volumes)
+        else if (kind == "CSINode" && vol.sync_volumes) vol.csinodes.push_back(std::move(o));           // (... nor what NodeVolumeLimits counts against)
+        else if (kind == "VolumeAttachment" && vol.sync_volumes) vol.attachments.push_back(std::move(o));
     }, &wanted);
 }
 

@@ -20,9 +20,10 @@
 //   GCE PD / EBS / RBD / ISCSI volumes     VolumeRestrictions.Filter against the node's pods and the clones (:105-150, 310-313)
 //   a ReadWriteOncePod claim               in use by a pod of the snapshot: every node fails (:283-291); else the first clone takes it
 //                                          and the second cycle fails everywhere: capacity 1
-// --sync-persistent-volumes goes one step beyond the reference: PersistentVolume objects of the snapshot are taken too, so bound claims
-// are judged as kube-scheduler judges them on the live cluster -- VolumeBinding's node affinity of the bound volume (binder.go
-// checkBoundClaims) and VolumeZone's label match (volume_zone.go:191-240) -- as static per-node verdicts.
+// --sync-persistent-volumes goes one step beyond the reference: PersistentVolume, CSINode and VolumeAttachment objects of the snapshot are
+// taken too, so bound claims are judged as kube-scheduler judges them on the live cluster -- VolumeBinding's node affinity of the bound
+// volume (binder.go checkBoundClaims), VolumeZone's label match (volume_zone.go:191-240) and NodeVolumeLimits' per-driver counts
+// (nodevolumelimits/csi.go:255-339) -- as static per-node verdicts.
 #pragma once
 #include <algorithm>
 #include <map>
@@ -50,6 +51,7 @@ static const char *const kRestrictedKinds[] = {"gcePersistentDisk", "awsElasticB
 // the objects of the snapshot the volume plugins read, and which of the plugins the profile runs
 struct VolumeObjects {
     std::vector<Value> claims, classes, volumes;
+    std::vector<Value> csinodes, attachments; // CSINode / VolumeAttachment: taken with the volumes only (NodeVolumeLimits has no limits to check without)
     bool sync_volumes = false; // --sync-persistent-volumes (the reference's SyncWithClient copies none)
     std::vector<std::string> plugins = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};
     bool plugins_partial = false; // the configuration disables only the filter point of one: pods with volumes are refused
@@ -151,6 +153,45 @@ inline bool pv_node_affinity_matches(const Value &pv, const Value &node_labels) 
 struct VolumeUnsupported : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+
+// in-tree plugins whose volumes count against the limits of the CSI driver they were migrated to (csi-translation-lib): judging them needs the
+// translation of the volume source and the node's migrated-plugins annotation -- not modelled, refused where it would matter
+inline bool migratable_provisioner(const std::string &p) {
+    for (const char *x : {"kubernetes.io/aws-ebs", "kubernetes.io/gce-pd", "kubernetes.io/azure-disk", "kubernetes.io/azure-file", "kubernetes.io/cinder",
+                          "kubernetes.io/vsphere-volume", "kubernetes.io/portworx-volume"})
+        if (p == x) return true;
+    return false;
+}
+
+// CSILimits.getCSIDriverInfo (nodevolumelimits/csi.go:446-505, 507-541): (driver, unique volume name) of a claim's volume; false = not
+// counted.  A claim without a (known) volume counts as one volume of its class's provisioner, named after the claim.
+inline bool csi_volume(const Value &pvc, const std::map<std::string, const Value *> &pvs, const std::map<std::string, const Value *> &classes, std::string &driver,
+                       std::string &unique) {
+    const std::string vol_name = pvc["spec"]["volumeName"].text();
+    auto pv = vol_name.empty() ? pvs.end() : pvs.find(vol_name);
+    if (pv == pvs.end()) {
+        auto cls = classes.find(claim_class(pvc));
+        const std::string prov = cls == classes.end() ? std::string() : (*cls->second)["provisioner"].text();
+        if (prov.empty()) return false;
+        if (migratable_provisioner(prov)) throw VolumeUnsupported("StorageClass provisioner \"" + prov + "\": volume limits of migrated in-tree plugins are not modelled");
+        const std::string ns = pvc["metadata"]["namespace"].truthy() ? pvc["metadata"]["namespace"].text() : "default";
+        driver = prov, unique = prov + "/claim-" + ns + "/" + pvc["metadata"]["name"].text();
+        return true;
+    }
+    const Value &spec = (*pv->second)["spec"];
+    const Value &csi = spec["csi"];
+    if (csi.is_null()) {
+        for (const char *k : {"awsElasticBlockStore", "gcePersistentDisk", "azureDisk", "azureFile", "cinder", "vsphereVolume", "portworxVolume"})
+            if (!spec[k].is_null())
+                throw VolumeUnsupported("PersistentVolume \"" + (*pv->second)["metadata"]["name"].text() + "\": volume limits of migrated in-tree plugins are not modelled");
+        return false;
+    }
+    driver = csi["driver"].text();
+    const std::string handle = csi["volumeHandle"].text();
+    if (driver.empty() || handle.empty()) return false;
+    unique = driver + "/" + handle;
+    return true;
+}
 
 // `live`: the snapshot's non-terminal pods on kept nodes, `live_node[j]`: the node index of live[j]
 inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Value *> &nodes, const std::vector<const Value *> &live,
@@ -287,7 +328,66 @@ inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Valu
             else out.rwop_capacity_one = true;
         }
     }
-    // (NodeVolumeLimits: no CSINode in the fake cluster, no limits: nodevolumelimits/csi.go:265-290)
+    // NodeVolumeLimits (nodevolumelimits/csi.go:255-339): no CSINode in the reference's fake cluster, hence no limits (:265-290).  With the
+    // snapshot's volumes synced, CSINodes and VolumeAttachments are taken too: per node, the pod's NEW volumes (not attached there yet) per
+    // driver against the driver's allocatable count minus what the node's pods and attachments hold.  Static: the clones share the
+    // template's claims, so a node's first clone attaches them and every later one adds nothing.
+    if (vo.on("NodeVolumeLimits") && vo.sync_volumes && !claim_names.empty() && !vo.csinodes.empty()) {
+        std::map<std::string, size_t> node_index;
+        for (size_t i = 0; i < N; i++) node_index[(*nodes[i])["metadata"]["name"].text()] = i;
+        std::map<size_t, std::map<std::string, long long>> limits_of;
+        for (const auto &o : vo.csinodes) {
+            auto it = node_index.find(o["metadata"]["name"].text());
+            if (it == node_index.end()) continue;
+            std::map<std::string, long long> lim;
+            for (const auto &d : o["spec"]["drivers"].items())
+                if (!d["allocatable"]["count"].is_null()) lim[d["name"].text()] = d["allocatable"]["count"].as_int();
+            if (!lim.empty()) limits_of[it->second] = std::move(lim);
+        }
+        std::map<std::string, std::string> fresh_all; // unique volume name -> driver
+        for (const auto &name : claim_names) {
+            const Value *pvc = find_pvc(name);
+            if (!pvc) throw VolumeUnsupported("persistentvolumeclaim \"" + name + "\" is missing and only NodeVolumeLimits would notice: not modelled");
+            std::string drv, uniq;
+            if (csi_volume(*pvc, pvs, classes, drv, uniq)) fresh_all[uniq] = drv;
+        }
+        if (!fresh_all.empty() && !limits_of.empty()) {
+            std::map<size_t, std::map<std::string, std::string>> held, extra;
+            for (size_t j = 0; j < live.size(); j++) {
+                if (!limits_of.count(live_node[j])) continue;
+                const std::string pns = obj_ns(*live[j]);
+                for (const auto &v : (*live[j])["spec"]["volumes"].items()) {
+                    if (v["persistentVolumeClaim"].is_null()) continue;
+                    auto q = pvcs.find({pns, v["persistentVolumeClaim"]["claimName"].text()});
+                    std::string drv, uniq; // (an existing pod's unknown claim is not counted: csi.go:393-399)
+                    if (q != pvcs.end() && csi_volume(*q->second, pvs, classes, drv, uniq)) held[live_node[j]][uniq] = drv;
+                }
+            }
+            for (const auto &va : vo.attachments) { // getNodeVolumeAttachmentInfo (:572-601)
+                const Value &sp = va["spec"];
+                auto it = node_index.find(sp["nodeName"].text());
+                auto pv = pvs.find(sp["source"]["persistentVolumeName"].text());
+                if (it == node_index.end() || !limits_of.count(it->second) || !sp["attacher"].truthy() || pv == pvs.end() || (*pv->second)["spec"]["csi"].is_null()) continue;
+                extra[it->second][sp["attacher"].text() + "/" + (*pv->second)["spec"]["csi"]["volumeHandle"].text()] = sp["attacher"].text();
+            }
+            for (const auto &kv : limits_of) {
+                const size_t i = kv.first;
+                const auto &attached = held[i];
+                std::map<std::string, long long> count, fresh;
+                for (const auto &a : attached) count[a.second] += 1;
+                for (const auto &x : extra[i])
+                    if (!attached.count(x.first)) count[x.second] += 1;
+                for (const auto &f : fresh_all)
+                    if (!attached.count(f.first)) fresh[f.second] += 1;
+                bool over = false;
+                for (const auto &f : fresh) {
+                    auto lim = kv.second.find(f.first);
+                    over = over || (lim != kv.second.end() && count[f.first] + f.second > lim->second);
+                }
+                if (over) mark(i, 3);
+            }
+        }
+    }
     if (vo.on("VolumeBinding")) {
         if (!bound.empty()) { // binder.go checkBoundClaims
             bool missing = false;

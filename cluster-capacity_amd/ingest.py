@@ -514,7 +514,7 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
                    owner_objs: Sequence[dict] = (), system_default_spreading: bool = True, pvc_objs: Sequence[dict] = (),
                    class_objs: Sequence[dict] = (), pv_objs: Optional[Sequence[dict]] = None,
                    volume_plugins: Sequence[str] = ("VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"),
-                   volume_plugins_partial: bool = False) -> Snapshot:
+                   volume_plugins_partial: bool = False, csinode_objs: Sequence[dict] = (), attachment_objs: Sequence[dict] = ()) -> Snapshot:
     """SyncWithClient (simulator.go:176-295: namespaces, nodes, pods) + every per-pod-spec precomputation, in integers.
     `sim_pod`: the template, or a list of templates (cycled round-robin by the simulation)."""
     sim_pods = list(sim_pod) if isinstance(sim_pod, (list, tuple)) else [sim_pod]
@@ -583,7 +583,7 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
                ts_id=ts_id, it=it, hard_pod_affinity_weight=hard_pod_affinity_weight,
                default_spreading=(service_objs, owner_objs) if system_default_spreading else None, n_templates=len(sim_pods),
                pvc_objs=pvc_objs, class_objs=class_objs, pv_objs=pv_objs, volume_plugins=tuple(volume_plugins),
-               volume_plugins_partial=volume_plugins_partial)
+               volume_plugins_partial=volume_plugins_partial, csinode_objs=csinode_objs, attachment_objs=attachment_objs)
     sides = [_template_side(ctx, sp) for sp in sim_pods]
     soa = M.NodesSoA(alloc=alloc, alloc_pods=alloc_pods, req=req, nz_mcpu=nzc, nz_mem=nzm, pod_count=pcount,
                      taintset_id=ts_id, unschedulable=unsched, label_cols=[a for a in it.arrays] or [], names=names,
@@ -735,7 +735,7 @@ def _template_side(ctx: dict, sim_pod: dict):
     if spec.get("volumes") and ctx.get("volume_plugins_partial"):
         raise NotImplementedError("the scheduler configuration disables only the filter point of a volume plugin: a pod with volumes is not modelled under it")
     vs = V.volume_side(sim_pod, nodes, live, index, ctx.get("pvc_objs") or (), ctx.get("class_objs") or (), ctx.get("pv_objs"),
-                       ctx.get("volume_plugins") or V.PLUGINS)
+                       ctx.get("volume_plugins") or V.PLUGINS, ctx.get("csinode_objs") or (), ctx.get("attachment_objs") or ())
     pod.volume_veto, pod.volume_exclusive = vs.veto, vs.exclusive
     pod.prefilter_reject, pod.rwop_capacity_one = vs.prefilter_reject, vs.rwop_capacity_one
     if spec.get("resourceClaims"):

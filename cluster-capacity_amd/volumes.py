@@ -23,9 +23,10 @@ PersistentVolumes, CSINodes, CSIDrivers or CSIStorageCapacities (pkg/framework/s
   * GCE PD / EBS / RBD / ISCSI volumes             -> VolumeRestrictions.Filter against the node's pods and the clones (:105-150, 310-313)
   * a ReadWriteOncePod claim                       -> in use by a pod of the snapshot: every node fails (:283-291); else the first clone
                                                       takes it and the second cycle fails everywhere: capacity 1
-`sync_persistent_volumes` (the hosts' --sync-persistent-volumes) goes one step beyond the reference: PersistentVolume objects of the
-snapshot are taken too, so bound claims are judged as kube-scheduler judges them on the live cluster -- VolumeBinding's node affinity of the
-bound volume (binder.go checkBoundClaims) and VolumeZone's label match (volume_zone.go:191-240) -- as static per-node verdicts."""
+`sync_persistent_volumes` (the hosts' --sync-persistent-volumes) goes one step beyond the reference: PersistentVolume, CSINode and
+VolumeAttachment objects of the snapshot are taken too, so bound claims are judged as kube-scheduler judges them on the live cluster --
+VolumeBinding's node affinity of the bound volume (binder.go checkBoundClaims), VolumeZone's label match (volume_zone.go:191-240) and
+NodeVolumeLimits' per-driver counts (nodevolumelimits/csi.go:255-339) -- as static per-node verdicts."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -43,6 +44,11 @@ ZONE_BETA, REGION_BETA = "failure-domain.beta.kubernetes.io/zone", "failure-doma
 ZONE_GA, REGION_GA = "topology.kubernetes.io/zone", "topology.kubernetes.io/region"
 TOPOLOGY_LABELS = (ZONE_BETA, REGION_BETA, ZONE_GA, REGION_GA)  # volume_zone.go:84-89
 RESTRICTED_KINDS = ("gcePersistentDisk", "awsElasticBlockStore", "rbd", "iscsi")  # needsRestrictionsCheck (volume_restrictions.go:152-155)
+# in-tree plugins whose volumes count against the limits of the CSI driver they were migrated to (csi-translation-lib): judging them needs
+# the translation of the volume source and the node's migrated-plugins annotation -- not modelled, refused where it would matter
+MIGRATABLE_PROVISIONERS = ("kubernetes.io/aws-ebs", "kubernetes.io/gce-pd", "kubernetes.io/azure-disk", "kubernetes.io/azure-file",
+                           "kubernetes.io/cinder", "kubernetes.io/vsphere-volume", "kubernetes.io/portworx-volume")
+MIGRATABLE_PV_SOURCES = ("awsElasticBlockStore", "gcePersistentDisk", "azureDisk", "azureFile", "cinder", "vsphereVolume", "portworxVolume")
 
 
 @dataclass
@@ -123,10 +129,33 @@ def pv_node_affinity_matches(pv: dict, node_labels: dict) -> bool:
     return False
 
 
+def csi_volume(pvc: dict, pvs: Optional[dict], classes: dict) -> Optional[Tuple[str, str]]:
+    """CSILimits.getCSIDriverInfo (nodevolumelimits/csi.go:446-505, 507-541): -> (driver, unique volume name) of a claim's volume, None =
+    not counted.  A claim without a (known) volume counts as one volume of its class's provisioner, named after the claim."""
+    md, spec = pvc.get("metadata") or {}, pvc.get("spec") or {}
+    pv = pvs.get(spec.get("volumeName") or "") if pvs is not None and spec.get("volumeName") else None
+    if pv is None:
+        cls = classes.get(claim_class(pvc))
+        prov = (cls or {}).get("provisioner") or ""
+        if not prov:
+            return None
+        if prov in MIGRATABLE_PROVISIONERS:
+            raise NotImplementedError(f'StorageClass provisioner "{prov}": volume limits of migrated in-tree plugins are not modelled')
+        return prov, f'{prov}/claim-{md.get("namespace") or "default"}/{md.get("name", "")}'
+    csi = (pv.get("spec") or {}).get("csi")
+    if csi is None:
+        if any((pv.get("spec") or {}).get(k) is not None for k in MIGRATABLE_PV_SOURCES):
+            raise NotImplementedError(f'PersistentVolume "{(pv.get("metadata") or {}).get("name", "")}": volume limits of migrated in-tree plugins are not modelled')
+        return None
+    driver, handle = csi.get("driver") or "", csi.get("volumeHandle") or ""
+    return (driver, f"{driver}/{handle}") if driver and handle else None
+
+
 def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: Dict[str, int], pvc_objs: Sequence[dict] = (),
                 class_objs: Sequence[dict] = (), pv_objs: Optional[Sequence[dict]] = None,
-                enabled: Sequence[str] = PLUGINS) -> VolumeSide:
-    """`live`: the snapshot's non-terminal pods on kept nodes; `pv_objs` None: persistent volumes are not synced (the reference)."""
+                enabled: Sequence[str] = PLUGINS, csinode_objs: Sequence[dict] = (), attachment_objs: Sequence[dict] = ()) -> VolumeSide:
+    """`live`: the snapshot's non-terminal pods on kept nodes; `pv_objs` None: persistent volumes are not synced (the reference) --
+    `csinode_objs` / `attachment_objs` (CSINode, VolumeAttachment) are then ignored too: NodeVolumeLimits has no limits to check."""
     spec = sim_pod.get("spec") or {}
     ns = (sim_pod.get("metadata") or {}).get("namespace") or "default"
     volumes = list(spec.get("volumes") or [])
@@ -255,7 +284,63 @@ def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: D
                 mark(np.ones(N, bool), M.VOL_RWOP)
             else:
                 out.rwop_capacity_one = True
-    # (NodeVolumeLimits: no CSINode in the fake cluster, no limits: nodevolumelimits/csi.go:265-290)
+    # NodeVolumeLimits (nodevolumelimits/csi.go:255-339): no CSINode in the reference's fake cluster, hence no limits (:265-290).  With the
+    # snapshot's volumes synced, CSINodes and VolumeAttachments are taken too: per node, the pod's NEW volumes (not attached there yet) per
+    # driver against the driver's allocatable count minus what the node's pods and attachments hold.  Static: the clones share the
+    # template's claims, so a node's first clone attaches them and every later one adds nothing.
+    if "NodeVolumeLimits" in enabled and pvs is not None and claim_names and csinode_objs:
+        limits_of = {}
+        for o in csinode_objs:
+            lim = {d.get("name", ""): int((d.get("allocatable") or {})["count"]) for d in ((o.get("spec") or {}).get("drivers") or [])
+                   if (d.get("allocatable") or {}).get("count") is not None}
+            if lim and (o.get("metadata") or {}).get("name", "") in index:
+                limits_of[index[o["metadata"]["name"]]] = lim
+        new: Dict[str, str] = {}
+        for name in claim_names:
+            pvc = pvcs.get((ns, name))
+            if pvc is None:  # (filterAttachableVolumes for the new pod: UnschedulableAndUnresolvable on every node that has a CSINode ... with limits or not)
+                raise NotImplementedError(f'persistentvolumeclaim "{name}" is missing and only NodeVolumeLimits would notice: not modelled')
+            dv = csi_volume(pvc, pvs, classes)
+            if dv is not None:
+                new[dv[1]] = dv[0]
+        if new and limits_of:
+            held: Dict[int, Dict[str, str]] = {}
+            for p in live:
+                i = index[p["spec"]["nodeName"]]
+                if i not in limits_of:
+                    continue
+                pns = (p.get("metadata") or {}).get("namespace") or "default"
+                for v in (p.get("spec") or {}).get("volumes") or []:
+                    if v.get("persistentVolumeClaim") is None:
+                        continue
+                    q = pvcs.get((pns, (v["persistentVolumeClaim"] or {}).get("claimName", "")))
+                    dv = csi_volume(q, pvs, classes) if q is not None else None  # (an existing pod's unknown claim is not counted: :393-399)
+                    if dv is not None:
+                        held.setdefault(i, {})[dv[1]] = dv[0]
+            extra: Dict[int, Dict[str, str]] = {}
+            for va in attachment_objs:  # getNodeVolumeAttachmentInfo (:572-601)
+                sp = va.get("spec") or {}
+                i = index.get(sp.get("nodeName") or "")
+                pv = pvs.get((sp.get("source") or {}).get("persistentVolumeName") or "")
+                csi = ((pv or {}).get("spec") or {}).get("csi")
+                if i is None or i not in limits_of or not sp.get("attacher") or csi is None:
+                    continue
+                extra.setdefault(i, {})[f'{sp["attacher"]}/{csi.get("volumeHandle") or ""}'] = sp["attacher"]
+            over = np.zeros(N, bool)
+            for i, lim in limits_of.items():
+                attached = held.get(i, {})
+                count: Dict[str, int] = {}
+                for drv in attached.values():
+                    count[drv] = count.get(drv, 0) + 1
+                for uniq, drv in extra.get(i, {}).items():
+                    if uniq not in attached:
+                        count[drv] = count.get(drv, 0) + 1
+                fresh: Dict[str, int] = {}
+                for uniq, drv in new.items():
+                    if uniq not in attached:
+                        fresh[drv] = fresh.get(drv, 0) + 1
+                over[i] = any(drv in lim and count.get(drv, 0) + k > lim[drv] for drv, k in fresh.items())
+            mark(over, M.VOL_MAX_COUNT)
     if "VolumeBinding" in enabled:
         if bound:  # binder.go checkBoundClaims
             missing = pvs is None or any(((c.get("spec") or {}).get("volumeName") or "") not in pvs for c in bound)

@@ -187,6 +187,66 @@ def test_bound_claims_against_synced_volumes():
     assert _side(pod, nodes, pvc_objs=[claim], pv_objs=[_pv("pv-1")]).veto is None
 
 
+def _csi_pv(name, handle, driver="ebs.csi.aws.com"):
+    return {"apiVersion": "v1", "kind": "PersistentVolume", "metadata": {"name": name}, "spec": {"csi": {"driver": driver, "volumeHandle": handle}, "storageClassName": ""}}
+
+
+def _csinode(name, count, driver="ebs.csi.aws.com"):
+    d = {"name": driver, "nodeID": name}
+    if count is not None:
+        d["allocatable"] = {"count": count}
+    return {"apiVersion": "storage.k8s.io/v1", "kind": "CSINode", "metadata": {"name": name}, "spec": {"drivers": [d]}}
+
+
+def _csi_case():
+    """6 nodes, a driver limit of 2 volumes on n0..n4 (none declared on n5).  The template mounts claim `mine` (volume h-mine).
+    n0: two other volumes attached (pods)            -> over the limit
+    n1: one other volume + `mine` itself (a pod uses the same claim) -> nothing NEW to attach: fits
+    n2: one volume by a pod, one more by a VolumeAttachment only     -> over
+    n3: one volume by a pod that a VolumeAttachment names too        -> counted once: fits
+    n4: a pod whose claim is unknown (not counted) + one volume      -> fits
+    n5: three volumes, but its CSINode declares no count             -> no limit"""
+    nodes = _nodes()
+    claims = [_pvc("mine", volume_name="pv-mine")] + [_pvc(f"c{k}", volume_name=f"pv-{k}") for k in range(8)]
+    pvs = [_csi_pv("pv-mine", "h-mine")] + [_csi_pv(f"pv-{k}", f"h-{k}") for k in range(8)]
+    pods = []
+
+    def user(node_name, *claim_names):
+        p = running_pod(f"u{len(pods)}", node_name, cpu="100m")
+        p["spec"]["volumes"] = [_claim_vol(c, f"v{j}") for j, c in enumerate(claim_names)]
+        pods.append(p)
+    user("n0", "c0", "c1")
+    user("n1", "c2", "mine")
+    user("n2", "c3")
+    user("n3", "c4")
+    user("n4", "c5", "nowhere")
+    user("n5", "c5", "c6", "c7")
+    vas = [{"apiVersion": "storage.k8s.io/v1", "kind": "VolumeAttachment", "metadata": {"name": f"va{k}"},
+            "spec": {"attacher": "ebs.csi.aws.com", "nodeName": n, "source": {"persistentVolumeName": pv}}} for k, (n, pv) in enumerate([("n2", "pv-6"), ("n3", "pv-4")])]
+    csinodes = [_csinode(f"n{i}", 2) for i in range(5)] + [_csinode("n5", None)]
+    return nodes, pods, claims, pvs, csinodes, vas
+
+
+def test_node_volume_limits_against_synced_csinodes():
+    nodes, pods, claims, pvs, csinodes, vas = _csi_case()
+    pod = _pod([_claim_vol("mine")])
+    s = _side(pod, nodes, pods, pvc_objs=claims, pv_objs=pvs, csinode_objs=csinodes, attachment_objs=vas)
+    assert s.prefilter_reject is None and s.veto.tolist() == [M.VOL_MAX_COUNT, 0, M.VOL_MAX_COUNT, 0, 0, 0]
+    # without the volumes synced (the reference): the bound claim ends at VolumeZone's PreFilter, CSINodes are not even looked at
+    assert _side(pod, nodes, pods, pvc_objs=claims, csinode_objs=csinodes).prefilter_reject == 'persistentvolume "pv-mine" not found'
+    # the plugin out of the profile
+    assert _side(pod, nodes, pods, pvc_objs=claims, pv_objs=pvs, csinode_objs=csinodes, attachment_objs=vas,
+                 enabled=("VolumeRestrictions", "VolumeBinding", "VolumeZone")).veto is None
+    # an unbound claim counts as one volume of its class's provisioner, named after the claim (csi.go:507-541)
+    wait = _pvc("later", cls="ebs")
+    s = _side(_pod([_claim_vol("later")]), nodes, pods, pvc_objs=claims + [wait], class_objs=[_class("ebs", mode="WaitForFirstConsumer", provisioner="ebs.csi.aws.com")],
+              pv_objs=pvs, csinode_objs=csinodes, attachment_objs=vas, enabled=("VolumeRestrictions", "NodeVolumeLimits"))
+    assert s.veto.tolist() == [M.VOL_MAX_COUNT, M.VOL_MAX_COUNT, M.VOL_MAX_COUNT, 0, 0, 0]
+    with pytest.raises(NotImplementedError, match="migrated in-tree"):
+        _side(_pod([_claim_vol("later")]), nodes, pods, pvc_objs=claims + [wait], class_objs=[_class("ebs", provisioner="kubernetes.io/aws-ebs")],
+              pv_objs=pvs, csinode_objs=csinodes, enabled=("NodeVolumeLimits",))
+
+
 # ---- the report ----------------------------------------------------------------------------------------------------------------------
 def test_prefilter_rejection_message():
     r = cli.rejected_by_prefilter(ingest.build_snapshot(_nodes(), [], _pod([])).nodes, M.PodSpec(req=np.zeros(3, np.int64), nz_mcpu=0, nz_mem=0, has_scalar_entries=False,
@@ -233,7 +293,9 @@ def _both_sides(native, tmp_path, pod, nodes, objs, extra=()):
     got = json.loads(_run(native, flags + ["--dump-snapshot", "-"]))["pod"]
     by = cli.load_by_kind([flags[3]])
     snap = ingest.build_snapshot(by.get("Node", []), by.get("Pod", []), cli.parse_pod_spec(flags[1]), pvc_objs=by.get("PersistentVolumeClaim", []),
-                                 class_objs=by.get("StorageClass", []), pv_objs=by.get("PersistentVolume", []) if "--sync-persistent-volumes" in extra else None)
+                                 class_objs=by.get("StorageClass", []), pv_objs=by.get("PersistentVolume", []) if "--sync-persistent-volumes" in extra else None,
+                                 csinode_objs=by.get("CSINode", []) if "--sync-persistent-volumes" in extra else (),
+                                 attachment_objs=by.get("VolumeAttachment", []) if "--sync-persistent-volumes" in extra else ())
     p = snap.pod
     ref = {"volume_veto": None if p.volume_veto is None else [int(x) for x in p.volume_veto], "volume_exclusive": bool(p.volume_exclusive),
            "prefilter_reject": p.prefilter_reject, "rwop_capacity_one": bool(p.rwop_capacity_one)}
@@ -274,6 +336,23 @@ def test_native_host_gives_the_same_verdicts(native, tmp_path):
     assert seen[8]["prefilter_reject"] == 'persistentvolume "pv-1" not found'
     assert seen[9]["volume_veto"] == [4, 4, 4, 0, 4, 0] and seen[9]["prefilter_reject"] is None  # n3 (z0) and n5 (z2) carry the volume's node affinity and zones
     assert seen[10] == {"volume_veto": None, "volume_exclusive": False, "prefilter_reject": None, "rwop_capacity_one": False}
+
+
+def test_native_host_counts_csi_volumes_like_the_python_host(native, tmp_path):
+    nodes, pods, claims, pvs, csinodes, vas = _csi_case()
+    objs = pods + claims + pvs + csinodes + vas + [_pvc("later", cls="ebs"), _class("ebs", mode="WaitForFirstConsumer", provisioner="ebs.csi.aws.com")]
+    a = tmp_path / "a"
+    a.mkdir()
+    got = _both_sides(native, a, _pod([_claim_vol("mine")]), nodes, objs, ("--sync-persistent-volumes",))
+    assert got["volume_veto"] == [M.VOL_MAX_COUNT, 0, M.VOL_MAX_COUNT, 0, 0, 0]
+    b = tmp_path / "b"
+    b.mkdir()
+    assert _both_sides(native, b, _pod([_claim_vol("mine")]), nodes, objs)["prefilter_reject"] == 'persistentvolume "pv-mine" not found'
+    # two claims of the template: on n1 `mine` is attached already (one NEW volume, but the node sits at its limit), two new ones elsewhere
+    c = tmp_path / "c"
+    c.mkdir()
+    got = _both_sides(native, c, _pod([_claim_vol("mine"), _claim_vol("c7", "second")]), nodes, objs, ("--sync-persistent-volumes",))
+    assert got["volume_veto"] == [3, 3, 3, 3, 3, 0]
 
 
 def test_native_host_refuses_what_the_python_host_refuses(native, tmp_path):
