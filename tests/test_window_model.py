@@ -56,6 +56,34 @@ def test_memo_masks_and_assumed_maxima_vs_oracle(ccref, seed, window, tile, para
         assert st["memo_scans"] > 0 and st["words_checked"] > 0  # (the rows were read, not only filled)
 
 
+@pytest.mark.parametrize("parallel", [False, True])
+@pytest.mark.parametrize("window,tile", [(1, 16), (5, 4), (64, 16)])
+@pytest.mark.parametrize("seed", range(12))
+def test_flag_words_report_maxima_inexactly_and_still_reproduce_the_oracle(ccref, seed, window, tile, parallel):
+    """Round 5's 16-bit memo word (csrc/ccsim_multi.h): a scan that reads its row knows only whether a feasible node holds / exceeds the
+    assumed normalization maxima.  A differing maximum is reported as assumed +- 1; the self-correction (window ends, general scan, exact
+    value) must leave the placement sequence the oracle's, with at most two zero-progress windows in a row (asserted inside the model)."""
+    from window_model import MemoWindowModel
+    rng = np.random.default_rng(7700 + seed)
+    nodes, pods, prof = random_multi_case(rng, int(rng.integers(20, 160)), int(rng.integers(2, 20)))
+    limit = int(rng.choice([0, 0, 41]))
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=limit)
+    got = MemoWindowModel(prof, nodes, pods, tile=tile, topk=8, window=window, flags=True).run(limit, parallel=parallel)
+    assert got["placed"] == ref.placed and got["stop"] == ref.stop and got["stop_spec"] == ref.stop_spec
+    assert np.array_equal(got["log"], ref.log)
+
+
+def test_flag_words_do_report_inexactly_somewhere(ccref):
+    """(the cases above exercise the inexact report: summed over a few of them it happens)"""
+    from window_model import MemoWindowModel
+    inexact = 0
+    for seed in range(12):
+        rng = np.random.default_rng(7700 + seed)
+        nodes, pods, prof = random_multi_case(rng, int(rng.integers(20, 160)), int(rng.integers(2, 20)))
+        inexact += MemoWindowModel(prof, nodes, pods, window=5, tile=4, flags=True).run(0)["stats"].get("inexact", 0)
+    assert inexact > 0
+
+
 def test_memo_without_refresh_is_caught(ccref):
     """The model's invariant has teeth: without the refresh of the touched nodes a scan meets a stale word."""
     from window_model import MemoWindowModel

@@ -291,10 +291,17 @@ class MemoWindowModel(WindowModel):
       masks     allow[s][c] = the value ids a node may carry to pass constraint c's skew test; rebuilt for the specs a window
                 placed (their tables moved), asserted current at every scan.
       maxima    scores are computed under the spec's ASSUMED maxima; a scan that finds other true maxima over its feasible set
-                ends the window before that pod and repairs the assumption of it and of every later pod of the window."""
+                ends the window before that pod and repairs the assumption of it and of every later pod of the window.
+      flags     (round 5, `flags=True`: the 16-bit memo word) a scan that READS its row sees, per node, only how the node's taint count /
+                affinity sum stands to the maxima the row was computed under -- equal, above, below -- not the values.  It reports a
+                true maximum that differs from the assumed one as DIFFERENT (assumed + 1 when some feasible node lies above, assumed - 1
+                when none holds it), not exactly (csrc/ccsim_multi.h m_max_from_level).  The window still ends before such a pod; the
+                next scan of the spec computes (its stamp no longer matches) and reports the exact maxima, so at most TWO windows in a
+                row make no progress, and every score a commit uses was computed under maxima checked against the true ones."""
 
-    def __init__(self, prof, nodes, pods, tile=16, topk=8, window=64, refresh=True):
+    def __init__(self, prof, nodes, pods, tile=16, topk=8, window=64, refresh=True, flags=False):
         super().__init__(prof, nodes, pods, tile, topk, window)
+        self.flags = flags
         self.mt_a, self.ma_a = [0] * self.P, [0] * self.P
         self.stamp = [None] * self.P
         self.memo = [[0] * self.N for _ in pods]
@@ -317,7 +324,8 @@ class MemoWindowModel(WindowModel):
 
     def scan(self, s):
         assumed = (self.mt_a[s], self.ma_a[s])
-        if self.stamp[s] == assumed:
+        lean = self.stamp[s] == assumed
+        if lean:
             self.stats["memo_scans"] += 1
             for n in range(self.N):  # THE invariant: what the scan reads is what it would compute
                 assert self.memo[s][n] == self._word(s, n), ("stale memo word", s, n, self.memo[s][n], self._word(s, n))
@@ -334,6 +342,14 @@ class MemoWindowModel(WindowModel):
         assert feas == [n for n in range(self.N) if self.feasible(s, n, sp)]  # (word + masks == the filters)
         mt = max((self.cnt[s][n] for n in feas), default=0)
         ma = max((self.aff[s][n] for n in feas), default=0)
+        if lean and self.flags:  # what the flag bits of the row let the scan say (m_max_from_level)
+            def from_flags(vals, a):
+                level = 2 if any(v > a for v in vals) else 1 if any(v == a for v in vals) else 0
+                return a + 1 if level == 2 else a if level == 1 else (0 if a == 0 or not vals else a - 1)
+            rep_t, rep_a = from_flags([self.cnt[s][n] for n in feas], assumed[0]), from_flags([self.aff[s][n] for n in feas], assumed[1])
+            assert (rep_t == assumed[0]) == (mt == assumed[0]) and (rep_a == assumed[1]) == (ma == assumed[1])  # "differs" is exact, the value is not
+            self.stats["inexact"] = self.stats.get("inexact", 0) + ((rep_t, rep_a) != (mt, ma))
+            mt, ma = rep_t, rep_a
         cd = dict(nfeas=len(feas), mt=mt, ma=ma, wrong=(mt, ma) != assumed, sp=sp)
         if not feas:
             return cd
@@ -380,4 +396,4 @@ class MemoWindowModel(WindowModel):
             if limit > 0 and len(log) >= limit:
                 return dict(placed=len(log), stop=1, stop_spec=-1, log=np.array(log, np.int32), windows=windows, stats=self.stats)
             idle = 0 if done["committed"] else idle + 1
-            assert idle <= 1, "a window that only repaired maxima is followed by one whose pod 0 commits"
+            assert idle <= (2 if self.flags else 1), "a window that only repaired maxima is followed by one whose pod 0 commits (two with the flag words)"
