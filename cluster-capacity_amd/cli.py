@@ -409,7 +409,8 @@ def main(argv: Optional[List[str]] = None, out=sys.stdout) -> int:
                                      csinode_objs=by.get("CSINode", []) if args.sync_persistent_volumes else (),
                                      attachment_objs=by.get("VolumeAttachment", []) if args.sync_persistent_volumes else (),
                                      volume_plugins=getattr(prof, "volume_plugins", ingest_volume_plugins()),
-                                     volume_plugins_partial=getattr(prof, "volume_plugins_partial", False))
+                                     volume_plugins_partial=getattr(prof, "volume_plugins_partial", False),
+                                     dra_enabled=getattr(prof, "dra_enabled", True), dra_partial=getattr(prof, "dra_partial", False))
     except (TypeError, AttributeError, KeyError, OverflowError) as e:
         # the objects are walked as plain dicts / lists: a string where a mapping belongs (a decode error in the reference, which reads
         # into typed structs) or a sum beyond int64 surfaces as one of these -- refused, like the native host refuses it

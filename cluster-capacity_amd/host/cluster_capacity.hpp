@@ -43,6 +43,7 @@ class ClusterCapacity {
     void SyncWithClient(const std::vector<Value> &nodes, const std::vector<Value> &pods, const std::vector<Value> &namespaces = {},
                         const std::vector<Value> &spreading_objs = {}, VolumeObjects volume_objs = {}) {
         volume_objs.plugins = profile_.volume_plugins, volume_objs.plugins_partial = profile_.volume_plugins_partial;
+        volume_objs.dra_enabled = profile_.dra_enabled, volume_objs.dra_partial = profile_.dra_partial;
         snap_ = build_snapshot(nodes, pods, pods_, exclude_, profile_.hard_pod_affinity_weight, namespaces, spreading_objs,
                                profile_.c.w_topologyspread != 0 && profile_.system_default_spreading, &volume_objs);
         synced_ = true;

@@ -24,6 +24,7 @@ struct HostProfile {
     // disabling one under multiPoint takes it out; with only its filter point disabled a pod with volumes is refused
     std::vector<std::string> volume_plugins = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};
     bool volume_plugins_partial = false;
+    bool dra_enabled = true, dra_partial = false; // DynamicResources: in the profile; only its filter point disabled (pods with resourceClaims are refused then)
 };
 
 inline HostProfile default_profile() {
@@ -107,6 +108,10 @@ inline HostProfile profile_from_config(const Value &cfg) {
         for (const auto &d : set["disabled"].items()) {
             const std::string name = d["name"].text();
             const bool volume_plugin = name == "VolumeRestrictions" || name == "NodeVolumeLimits" || name == "VolumeBinding" || name == "VolumeZone";
+            if (do_filter && (name == "*" || name == "DynamicResources")) {
+                if (multipoint) p.dra_enabled = false;
+                else p.dra_partial = true;
+            }
             if (do_filter && (name == "*" || volume_plugin)) {
                 if (!multipoint) p.volume_plugins_partial = true; // (its PreFilter would still run: refused when a pod with volumes arrives)
                 if (name == "*") p.volume_plugins.clear();
@@ -125,6 +130,7 @@ inline HostProfile profile_from_config(const Value &cfg) {
             }
         }
         for (const auto &e : set["enabled"].items()) {
+            if (multipoint && e["name"].text() == "DynamicResources") p.dra_enabled = true;
             if (multipoint) {
                 const std::string en = e["name"].text();
                 static const char *order[] = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};

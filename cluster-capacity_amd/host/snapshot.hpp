@@ -698,7 +698,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     for (size_t i = 0; i < N; i++) S.unschedulable[i] = (*nodes[i])["spec"]["unschedulable"].truthy();
     Interner it(nodes); // shared by the templates: a label column per key any of them touches
 
-    auto template_side = [&](const Value &sim_pod, PodSide &s) {
+    auto template_side = [&](const Value &sim_pod, PodSide &s, size_t template_index) {
     const Value &spec = sim_pod["spec"];
     const std::string sim_ns = ns_of(sim_pod);
     const Value &sim_labels = sim_pod["metadata"]["labels"];
@@ -844,7 +844,12 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
         s.volume_veto = std::move(vs.veto), s.volume_exclusive = vs.exclusive;
         s.prefilter_reject = vs.rejected ? vs.prefilter_reject : std::string(), s.rwop_capacity_one = vs.rwop_capacity_one;
     }
-    if (spec["resourceClaims"].truthy()) throw std::runtime_error("spec.resourceClaims: the DynamicResources plugin is not modelled");
+    if (spec["resourceClaims"].truthy() && vol.dra_enabled) {
+        // DynamicResources' PreFilter runs after the volume plugins' (default_plugins.go:45-47); the fake cluster holds no ResourceClaim
+        if (vol.dra_partial)
+            throw Unsupported("the scheduler configuration disables only the filter point of DynamicResources: a pod with resourceClaims is not modelled under it");
+        if (s.prefilter_reject.empty()) s.prefilter_reject = dra_prefilter(sim_pod, template_index);
+    }
 
     // topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
     // System default spreading (a Service / the controller selects the template): two more ScheduleAnyway constraints of the pod, scored
@@ -1021,10 +1026,10 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     if (std::find(interacts.begin(), interacts.end(), (uint8_t)1) != interacts.end()) s.victim_interacts = interacts;
     }; // template_side
 
-    template_side(sim_pods[0], S);
+    template_side(sim_pods[0], S, 0);
     for (size_t t = 1; t < sim_pods.size(); t++) {
         S.more.emplace_back();
-        template_side(sim_pods[t], S.more.back());
+        template_side(sim_pods[t], S.more.back(), t);
     }
     S.label_keys = it.keys;
     S.label_cols = it.arrays;

@@ -55,6 +55,7 @@ struct VolumeObjects {
     bool sync_volumes = false; // --sync-persistent-volumes (the reference's SyncWithClient copies none)
     std::vector<std::string> plugins = {"VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"};
     bool plugins_partial = false; // the configuration disables only the filter point of one: pods with volumes are refused
+    bool dra_enabled = true, dra_partial = false; // DynamicResources in the profile (a pod with spec.resourceClaims: dra_prefilter)
     bool on(const char *name) const { return std::find(plugins.begin(), plugins.end(), name) != plugins.end(); }
 };
 
@@ -70,6 +71,23 @@ inline bool restricted(const Value &v) {
     for (const char *k : kRestrictedKinds)
         if (!v[k].is_null()) return true;
     return false;
+}
+
+// DynamicResources.PreFilter for a pod with spec.resourceClaims in the reference's fake cluster, which holds NO ResourceClaim (SyncWithClient
+// does not copy them, simulator.go:176-295): the first claim the plugin looks up is missing and the pod is UnschedulableAndUnresolvable on
+// every node (dynamicresources.go:397-412, 562-565, 1703-1712) -- zero replicas with that message.  "" = the pod names no claim (Skip).
+//   resourceClaimName: c          could not find ResourceClaim "ns/c"            (the scheduler's assume cache, util/assumecache NotFoundError)
+//   resourceClaimTemplateName: t  pod "ns/<name>-<k>": ResourceClaim not created yet   (the clone of cycle k is <template>-<k>, podgenerator.go:34)
+//   neither                       pod "ns/<name>-<k>", spec.resourceClaim "x": none of the supported fields are set
+inline std::string dra_prefilter(const Value &sim_pod, size_t clone_index) {
+    const std::string ns = sim_pod["metadata"]["namespace"].truthy() ? sim_pod["metadata"]["namespace"].text() : "default";
+    const std::string name = sim_pod["metadata"]["name"].text() + "-" + std::to_string(clone_index);
+    for (const auto &rc : sim_pod["spec"]["resourceClaims"].items()) {
+        if (!rc["resourceClaimName"].is_null()) return "could not find ResourceClaim \"" + ns + "/" + rc["resourceClaimName"].text() + "\"";
+        if (!rc["resourceClaimTemplateName"].is_null()) return "pod \"" + ns + "/" + name + "\": ResourceClaim not created yet";
+        return "pod \"" + ns + "/" + name + "\", spec.resourceClaim \"" + rc["name"].text() + "\": none of the supported fields are set";
+    }
+    return "";
 }
 
 // isVolumeConflict for one pair of volumes (volume_restrictions.go:105-150)

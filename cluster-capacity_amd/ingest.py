@@ -514,7 +514,8 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
                    owner_objs: Sequence[dict] = (), system_default_spreading: bool = True, pvc_objs: Sequence[dict] = (),
                    class_objs: Sequence[dict] = (), pv_objs: Optional[Sequence[dict]] = None,
                    volume_plugins: Sequence[str] = ("VolumeRestrictions", "NodeVolumeLimits", "VolumeBinding", "VolumeZone"),
-                   volume_plugins_partial: bool = False, csinode_objs: Sequence[dict] = (), attachment_objs: Sequence[dict] = ()) -> Snapshot:
+                   volume_plugins_partial: bool = False, csinode_objs: Sequence[dict] = (), attachment_objs: Sequence[dict] = (),
+                   dra_enabled: bool = True, dra_partial: bool = False) -> Snapshot:
     """SyncWithClient (simulator.go:176-295: namespaces, nodes, pods) + every per-pod-spec precomputation, in integers.
     `sim_pod`: the template, or a list of templates (cycled round-robin by the simulation)."""
     sim_pods = list(sim_pod) if isinstance(sim_pod, (list, tuple)) else [sim_pod]
@@ -583,8 +584,9 @@ def build_snapshot(node_objs: List[dict], pod_objs: List[dict], sim_pod, exclude
                ts_id=ts_id, it=it, hard_pod_affinity_weight=hard_pod_affinity_weight,
                default_spreading=(service_objs, owner_objs) if system_default_spreading else None, n_templates=len(sim_pods),
                pvc_objs=pvc_objs, class_objs=class_objs, pv_objs=pv_objs, volume_plugins=tuple(volume_plugins),
-               volume_plugins_partial=volume_plugins_partial, csinode_objs=csinode_objs, attachment_objs=attachment_objs)
-    sides = [_template_side(ctx, sp) for sp in sim_pods]
+               volume_plugins_partial=volume_plugins_partial, csinode_objs=csinode_objs, attachment_objs=attachment_objs,
+               dra_enabled=dra_enabled, dra_partial=dra_partial)
+    sides = [_template_side(dict(ctx, template_index=t), sp) for t, sp in enumerate(sim_pods)]
     soa = M.NodesSoA(alloc=alloc, alloc_pods=alloc_pods, req=req, nz_mcpu=nzc, nz_mem=nzm, pod_count=pcount,
                      taintset_id=ts_id, unschedulable=unsched, label_cols=[a for a in it.arrays] or [], names=names,
                      scalar_names=scalars)
@@ -738,8 +740,12 @@ def _template_side(ctx: dict, sim_pod: dict):
                        ctx.get("volume_plugins") or V.PLUGINS, ctx.get("csinode_objs") or (), ctx.get("attachment_objs") or ())
     pod.volume_veto, pod.volume_exclusive = vs.veto, vs.exclusive
     pod.prefilter_reject, pod.rwop_capacity_one = vs.prefilter_reject, vs.rwop_capacity_one
-    if spec.get("resourceClaims"):
-        raise NotImplementedError("spec.resourceClaims: the DynamicResources plugin is not modelled")
+    if spec.get("resourceClaims") and ctx.get("dra_enabled", True):
+        # DynamicResources' PreFilter runs after the volume plugins' (default_plugins.go:45-47); the fake cluster holds no ResourceClaim
+        if ctx.get("dra_partial"):
+            raise NotImplementedError("the scheduler configuration disables only the filter point of DynamicResources: a pod with resourceClaims is not modelled under it")
+        if pod.prefilter_reject is None:
+            pod.prefilter_reject = V.dra_prefilter(sim_pod, ctx.get("template_index", 0))
 
     # topology spread constraints (common.go:86-127); NodeAffinityPolicy defaults to Honor, NodeTaintsPolicy to Ignore
     included = np.array([node_matches_required(i) for i in range(N)], np.uint8) if affinity_active else None

@@ -67,12 +67,14 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
     system_default_spreading = True  # PodTopologySpreadArgs.defaultingType System (the default)
     volume_plugins = set(VOLUME_PLUGINS)
     volume_partial = []
+    dra = [True, False]  # DynamicResources: enabled, only its filter point disabled
 
     def done():
         out = M.Profile(**p)
         out.system_default_spreading = system_default_spreading  # host-side note (not an ABI field): see ingest.default_spreading_applies
         out.volume_plugins = tuple(n for n in VOLUME_PLUGINS if n in volume_plugins)  # host-side note: which of them volumes.py evaluates
         out.volume_plugins_partial = bool(volume_partial)
+        out.dra_enabled, out.dra_partial = dra[0], dra[1]  # host-side notes: a pod with spec.resourceClaims (volumes.dra_prefilter)
         return out, hard
     if not cfg:
         return done()
@@ -106,6 +108,11 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
         pset = pset or {}
         for d in pset.get("disabled") or []:
             name = d.get("name", "")
+            if do_filter and name in ("*", "DynamicResources"):
+                if multipoint:
+                    dra[0] = False
+                else:
+                    dra[1] = True
             if do_filter and (name == "*" or name in VOLUME_PLUGINS):
                 if not multipoint:
                     volume_partial.append(name)  # (its PreFilter would still run: refused when a pod with volumes arrives)
@@ -121,6 +128,8 @@ def profile_from_config(cfg: Optional[dict]) -> Tuple[M.Profile, int]:
         for e in pset.get("enabled") or []:
             if multipoint and e.get("name", "") in VOLUME_PLUGINS:
                 volume_plugins.add(e["name"])
+            if multipoint and e.get("name", "") == "DynamicResources":
+                dra[0] = True
             info = lookup(e.get("name", ""))
             if info is None:
                 continue

@@ -63,6 +63,26 @@ def _read_only(src: dict) -> bool:
     return bool(src.get("readOnly"))
 
 
+def dra_prefilter(sim_pod: dict, clone_index: int = 0) -> Optional[str]:
+    """DynamicResources.PreFilter for a pod with spec.resourceClaims in the reference's fake cluster, which holds NO ResourceClaim
+    (SyncWithClient does not copy them, simulator.go:176-295): the first claim the plugin looks up is missing and the pod is
+    UnschedulableAndUnresolvable on every node (dynamicresources.go:397-412, 562-565, 1703-1712) -- zero replicas with that message.
+      resourceClaimName: c          -> `could not find ResourceClaim "ns/c"` (the scheduler's assume cache, util/assumecache NotFoundError)
+      resourceClaimTemplateName: t  -> `pod "ns/<name>-<k>": ResourceClaim not created yet` (resourceclaim.Name: no status entry; the clone
+                                       of cycle k is named <template>-<k>, podgenerator.go:34)
+      neither                       -> `pod "ns/<name>-<k>", spec.resourceClaim "x": none of the supported fields are set`
+    None: the pod names no claim (PreFilter Skip)."""
+    md = sim_pod.get("metadata") or {}
+    ns, name = md.get("namespace") or "default", f'{md.get("name", "")}-{clone_index}'
+    for rc in (sim_pod.get("spec") or {}).get("resourceClaims") or []:
+        if rc.get("resourceClaimName") is not None:
+            return f'could not find ResourceClaim "{ns}/{rc["resourceClaimName"]}"'
+        if rc.get("resourceClaimTemplateName") is not None:
+            return f'pod "{ns}/{name}": ResourceClaim not created yet'
+        return f'pod "{ns}/{name}", spec.resourceClaim "{rc.get("name", "")}": none of the supported fields are set'
+    return None
+
+
 def volume_conflict(v: dict, ev: dict) -> bool:
     """isVolumeConflict for one pair of volumes (volume_restrictions.go:105-150)."""
     a, b = v.get("gcePersistentDisk"), ev.get("gcePersistentDisk")

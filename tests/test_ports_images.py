@@ -96,7 +96,7 @@ def test_ingest_and_oracle_known_answer(ccref):
 
 
 def test_pods_the_hosts_still_refuse():
-    """(volumes: round 5 evaluates the volume plugins -- tests/test_volume_ingest.py; generic ephemeral volumes and DRA stay refused)"""
+    """(volumes: round 5 evaluates the volume plugins -- tests/test_volume_ingest.py; generic ephemeral volumes stay refused)"""
     nodes, pods, pod, _ = CASES["readme"]()
     pod["spec"]["volumes"] = [{"name": "scratch", "emptyDir": {}}, {"name": "cfg", "configMap": {"name": "x"}}]
     ingest.build_snapshot(nodes, pods, pod)  # node-independent volumes are fine
@@ -106,9 +106,11 @@ def test_pods_the_hosts_still_refuse():
     with pytest.raises(NotImplementedError, match="ephemeral volumes are not modelled"):
         ingest.build_snapshot(nodes, pods, pod)
     pod["spec"]["volumes"].pop()
+    # (DRA: the fake cluster holds no ResourceClaim -- the plugin's PreFilter rejects the pod; tests/test_volume_ingest.py)
     pod["spec"]["resourceClaims"] = [{"name": "gpu"}]
-    with pytest.raises(NotImplementedError, match="DynamicResources"):
-        ingest.build_snapshot(nodes, pods, pod)
+    assert "none of the supported fields are set" in ingest.build_snapshot(nodes, pods, pod).pod.prefilter_reject
+    with pytest.raises(NotImplementedError, match="filter point of DynamicResources"):
+        ingest.build_snapshot(nodes, pods, pod, dra_partial=True)
 
 
 decorate = H.with_ports_and_images

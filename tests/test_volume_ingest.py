@@ -383,6 +383,47 @@ def test_both_hosts_report_a_prefilter_rejection_without_a_device(native, tmp_pa
     assert "Termination reason: Unschedulable: " + want in txt
 
 
+def test_resource_claims_end_at_the_dra_prefilter_in_both_hosts(native, tmp_path):
+    """DynamicResources.PreFilter in the reference's fake cluster (no ResourceClaim is copied): the first claim it looks up is missing."""
+    nodes = _nodes()
+    cases = [([{"name": "gpu", "resourceClaimName": "shared-gpu"}], 'could not find ResourceClaim "default/shared-gpu"'),
+             ([{"name": "gpu", "resourceClaimTemplateName": "gpu-template"}], 'pod "default/sim-0": ResourceClaim not created yet'),
+             ([{"name": "gpu"}], 'pod "default/sim-0", spec.resourceClaim "gpu": none of the supported fields are set')]
+    for k, (claims, msg) in enumerate(cases):
+        pod = _pod([])
+        pod["spec"]["resourceClaims"] = claims
+        d = tmp_path / f"c{k}"
+        d.mkdir()
+        assert _both_sides(native, d, pod, nodes, [])["prefilter_reject"] == msg
+    # the volume plugins' PreFilters run first (default_plugins.go:41-47)
+    pod = _pod([_claim_vol("ghost")])
+    pod["spec"]["resourceClaims"] = cases[0][0]
+    d = tmp_path / "both"
+    d.mkdir()
+    assert _both_sides(native, d, pod, nodes, [])["prefilter_reject"] == 'persistentvolumeclaim "ghost" not found'
+    # end to end, no device: zero replicas with the message
+    pod = _pod([])
+    pod["spec"]["resourceClaims"] = cases[0][0]
+    d = tmp_path / "e2e"
+    d.mkdir()
+    flags = _write_case(d, pod, nodes, [])
+    got = json.loads(_run(native, flags + ["-o", "json"]))["status"]
+    buf = io.StringIO()
+    assert cli.main(flags + ["-o", "json"], out=buf) == 0
+    ref = json.loads(buf.getvalue())["status"]
+    got.pop("creationTimestamp"), ref.pop("creationTimestamp")
+    assert got == ref and got["replicas"] == 0
+    assert got["failReason"]["failMessage"].startswith('0/6 nodes are available: could not find ResourceClaim "default/shared-gpu". preemption: 0/6 nodes are available: 6 Preemption is not helpful')
+    # the plugin taken out of the profile (multiPoint): the claims are nobody's business
+    prof, _ = schedconfig.profile_from_config({"kind": "KubeSchedulerConfiguration", "profiles": [{"plugins": {"multiPoint": {"disabled": [{"name": "DynamicResources"}]}}}]})
+    assert not prof.dra_enabled and ingest.build_snapshot(nodes, [], pod, dra_enabled=prof.dra_enabled).pod.prefilter_reject is None
+    cfg = d / "sched.yaml"
+    cfg.write_text(yaml.safe_dump({"apiVersion": "kubescheduler.config.k8s.io/v1", "kind": "KubeSchedulerConfiguration",
+                                   "profiles": [{"plugins": {"multiPoint": {"disabled": [{"name": "DynamicResources"}]}}}]}))
+    dump = json.loads(_run(native, flags + ["--default-config", str(cfg), "--dump-snapshot", "-"]))
+    assert dump["pod"]["prefilter_reject"] is None
+
+
 # ---- GPU: both CLIs end to end ------------------------------------------------------------------------------------------------------
 def _status(native, flags):
     got = json.loads(_run(native, flags + ["-o", "json"]))
