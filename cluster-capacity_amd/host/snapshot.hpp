@@ -840,7 +840,7 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     // clones' own disks, the PreFilter rejections.  (inline csi volumes only count against CSINode limits, which the simulated cluster
     // does not have: nodevolumelimits/csi.go:265-290.)  DynamicResources stays refused.
     {
-        VolumeSide vs = volume_side(sim_pod, nodes, live, live_node, vol);
+        VolumeSide vs = volume_side(sim_pod, nodes, live, live_node, vol, template_index);
         s.volume_veto = std::move(vs.veto), s.volume_exclusive = vs.exclusive;
         s.prefilter_reject = vs.rejected ? vs.prefilter_reject : std::string(), s.rwop_capacity_one = vs.rwop_capacity_one;
     }

@@ -10,6 +10,7 @@
 // PersistentVolumes, CSINodes, CSIDrivers or CSIStorageCapacities (pkg/framework/simulator.go:228-295).  With the default plugins:
 //   a claim that does not exist            VolumeRestrictions.PreFilter: persistentvolumeclaim "x" not found (volume_restrictions.go:175-181)
 //   a lost / terminating claim             VolumeBinding.PreFilter (volumebinding/volume_binding.go:333-339, 356-357)
+//   a generic ephemeral volume             VolumeBinding.PreFilter: its claim "<clone>-<volume>" is never created (:306-331)
 //   an unbound claim of an Immediate class VolumeBinding.PreFilter: "pod has unbound immediate PersistentVolumeClaims" (:366-372)
 //   a BOUND claim                          VolumeZone.PreFilter: persistentvolume "pv" not found (volumezone/volume_zone.go:156-159, 253-258)
 //   an unbound WaitForFirstConsumer claim  passes every PreFilter; VolumeBinding.Filter finds nothing to bind (binder.go
@@ -213,7 +214,7 @@ inline bool csi_volume(const Value &pvc, const std::map<std::string, const Value
 
 // `live`: the snapshot's non-terminal pods on kept nodes, `live_node[j]`: the node index of live[j]
 inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Value *> &nodes, const std::vector<const Value *> &live,
-                              const std::vector<size_t> &live_node, const VolumeObjects &vo) {
+                              const std::vector<size_t> &live_node, const VolumeObjects &vo, size_t clone_index = 0) {
     VolumeSide out;
     const Value &spec = sim_pod["spec"];
     const std::string ns = sim_pod["metadata"]["namespace"].truthy() ? sim_pod["metadata"]["namespace"].text() : "default";
@@ -222,9 +223,6 @@ inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Valu
     if (vo.plugins_partial)
         throw VolumeUnsupported("the scheduler configuration disables only the filter point of a volume plugin: a pod with volumes is not modelled under it");
     const size_t N = nodes.size();
-    for (const auto &v : volumes.items())
-        if (!v["ephemeral"].is_null()) // (the claim is named after the CLONE -- "<pod>-<volume>" -- and made by a controller the fake cluster does not run)
-            throw VolumeUnsupported("pod volume '" + v["name"].text() + "': generic ephemeral volumes are not modelled");
     auto obj_ns = [](const Value &o) { return o["metadata"]["namespace"].truthy() ? o["metadata"]["namespace"].text() : std::string("default"); };
     std::map<std::pair<std::string, std::string>, const Value *> pvcs;
     for (const auto &o : vo.claims) pvcs[{obj_ns(o), o["metadata"]["name"].text()}] = &o;
@@ -258,8 +256,22 @@ inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Valu
                 }
         }
     std::vector<const Value *> delayed, bound;
-    if (vo.on("VolumeBinding") && !claim_names.empty()) { // volume_binding.go:306-383, binder.go:719-828
-        for (const auto &name : claim_names) {
+    // Generic ephemeral volumes: the claim is named after the CLONE -- "<pod>-<volume>", ephemeral.VolumeClaimName; the clone of cycle k is
+    // <template>-<k> (podgenerator.go:34) -- and made by a controller the fake cluster does not run: VolumeBinding.PreFilter's podHasPVCs
+    // (volume_binding.go:306-331) meets it missing and rejects the pod.  The volumes are walked in their order, claims and ephemeral alike.
+    bool has_eph = false;
+    for (const auto &v : volumes.items()) has_eph = has_eph || !v["ephemeral"].is_null();
+    if (has_eph && !vo.on("VolumeBinding")) throw VolumeUnsupported("generic ephemeral volumes without the VolumeBinding plugin are not modelled");
+    if (vo.on("VolumeBinding") && (!claim_names.empty() || has_eph)) { // volume_binding.go:306-383, binder.go:719-828
+        const std::string clone = sim_pod["metadata"]["name"].text() + "-" + std::to_string(clone_index);
+        for (const auto &v : volumes.items()) {
+            if (!v["ephemeral"].is_null()) {
+                const std::string made = clone + "-" + v["name"].text();
+                if (find_pvc(made)) throw VolumeUnsupported("persistentvolumeclaim \"" + made + "\" exists: whether it was created for the simulated pod is not modelled");
+                return reject("waiting for ephemeral volume controller to create the persistentvolumeclaim \"" + made + "\"");
+            }
+            if (v["persistentVolumeClaim"].is_null()) continue;
+            const std::string name = v["persistentVolumeClaim"]["claimName"].text();
             const Value *pvc = find_pvc(name);
             if (!pvc) return reject(not_found("persistentvolumeclaim", name));
             if ((*pvc)["status"]["phase"].text() == "Lost")

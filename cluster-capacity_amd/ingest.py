@@ -737,7 +737,8 @@ def _template_side(ctx: dict, sim_pod: dict):
     if spec.get("volumes") and ctx.get("volume_plugins_partial"):
         raise NotImplementedError("the scheduler configuration disables only the filter point of a volume plugin: a pod with volumes is not modelled under it")
     vs = V.volume_side(sim_pod, nodes, live, index, ctx.get("pvc_objs") or (), ctx.get("class_objs") or (), ctx.get("pv_objs"),
-                       ctx.get("volume_plugins") or V.PLUGINS, ctx.get("csinode_objs") or (), ctx.get("attachment_objs") or ())
+                       ctx.get("volume_plugins") or V.PLUGINS, ctx.get("csinode_objs") or (), ctx.get("attachment_objs") or (),
+                       clone_index=ctx.get("template_index", 0))
     pod.volume_veto, pod.volume_exclusive = vs.veto, vs.exclusive
     pod.prefilter_reject, pod.rwop_capacity_one = vs.prefilter_reject, vs.rwop_capacity_one
     if spec.get("resourceClaims") and ctx.get("dra_enabled", True):

@@ -11,6 +11,7 @@ PersistentVolumes, CSINodes, CSIDrivers or CSIStorageCapacities (pkg/framework/s
   * a claim that does not exist                    -> VolumeRestrictions.PreFilter: `persistentvolumeclaim "x" not found`
                                                       (volumerestrictions/volume_restrictions.go:175-181)
   * a lost / terminating claim                     -> VolumeBinding.PreFilter (volumebinding/volume_binding.go:333-339, 356-357)
+  * a generic ephemeral volume                     -> VolumeBinding.PreFilter: its claim "<clone>-<volume>" is never created (:306-331)
   * an unbound claim of an Immediate class         -> VolumeBinding.PreFilter: "pod has unbound immediate PersistentVolumeClaims" (:366-372)
   * a BOUND claim                                  -> VolumeZone.PreFilter: `persistentvolume "pv" not found` (volumezone/volume_zone.go:156-159,
                                                       253-258) -- the volume is not in the fake cluster
@@ -173,7 +174,8 @@ def csi_volume(pvc: dict, pvs: Optional[dict], classes: dict) -> Optional[Tuple[
 
 def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: Dict[str, int], pvc_objs: Sequence[dict] = (),
                 class_objs: Sequence[dict] = (), pv_objs: Optional[Sequence[dict]] = None,
-                enabled: Sequence[str] = PLUGINS, csinode_objs: Sequence[dict] = (), attachment_objs: Sequence[dict] = ()) -> VolumeSide:
+                enabled: Sequence[str] = PLUGINS, csinode_objs: Sequence[dict] = (), attachment_objs: Sequence[dict] = (),
+                clone_index: int = 0) -> VolumeSide:
     """`live`: the snapshot's non-terminal pods on kept nodes; `pv_objs` None: persistent volumes are not synced (the reference) --
     `csinode_objs` / `attachment_objs` (CSINode, VolumeAttachment) are then ignored too: NodeVolumeLimits has no limits to check."""
     spec = sim_pod.get("spec") or {}
@@ -183,10 +185,6 @@ def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: D
     if not volumes:
         return out
     N = len(nodes)
-    for v in volumes:
-        if v.get("ephemeral") is not None:
-            # (the claim is named after the CLONE -- "<pod>-<volume>" -- and made by a controller the fake cluster does not run)
-            raise NotImplementedError(f"pod volume {v.get('name')!r}: generic ephemeral volumes are not modelled")
     pvcs = {((o.get("metadata") or {}).get("namespace") or "default", (o.get("metadata") or {}).get("name", "")): o for o in pvc_objs}
     classes = {(o.get("metadata") or {}).get("name", ""): o for o in class_objs}
     pvs = None if pv_objs is None else {(o.get("metadata") or {}).get("name", ""): o for o in pv_objs}
@@ -206,8 +204,24 @@ def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: D
                 rwop.append(name)
     delayed: List[dict] = []
     bound: List[dict] = []
-    if "VolumeBinding" in enabled and claim_names:  # volume_binding.go:306-383, binder.go:719-828
-        for name in claim_names:
+    # Generic ephemeral volumes: the claim is named after the CLONE -- "<pod>-<volume>", ephemeral.VolumeClaimName; the clone of cycle k is
+    # <template>-<k> (podgenerator.go:34) -- and made by a controller the fake cluster does not run: VolumeBinding.PreFilter's podHasPVCs
+    # (volume_binding.go:306-331) meets it missing and rejects the pod.  The volumes are walked in their order, claims and ephemeral alike.
+    eph = [v for v in volumes if v.get("ephemeral") is not None]
+    if eph and "VolumeBinding" not in enabled:
+        raise NotImplementedError("generic ephemeral volumes without the VolumeBinding plugin are not modelled")
+    if "VolumeBinding" in enabled and (claim_names or eph):  # volume_binding.go:306-383, binder.go:719-828
+        clone = f'{(sim_pod.get("metadata") or {}).get("name", "")}-{clone_index}'
+        for v in volumes:
+            if v.get("ephemeral") is not None:
+                made = f'{clone}-{v.get("name", "")}'
+                if (ns, made) in pvcs:
+                    raise NotImplementedError(f'persistentvolumeclaim "{made}" exists: whether it was created for the simulated pod is not modelled')
+                out.prefilter_reject = f'waiting for ephemeral volume controller to create the persistentvolumeclaim "{made}"'
+                return out
+            if v.get("persistentVolumeClaim") is None:
+                continue
+            name = (v["persistentVolumeClaim"] or {}).get("claimName", "")
             pvc = pvcs.get((ns, name))
             if pvc is None:
                 out.prefilter_reject = not_found("persistentvolumeclaim", name)

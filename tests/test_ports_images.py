@@ -96,15 +96,14 @@ def test_ingest_and_oracle_known_answer(ccref):
 
 
 def test_pods_the_hosts_still_refuse():
-    """(volumes: round 5 evaluates the volume plugins -- tests/test_volume_ingest.py; generic ephemeral volumes stay refused)"""
+    """(volumes: round 5 evaluates the volume plugins -- tests/test_volume_ingest.py; every such pod ends at a PreFilter, as in the reference)"""
     nodes, pods, pod, _ = CASES["readme"]()
     pod["spec"]["volumes"] = [{"name": "scratch", "emptyDir": {}}, {"name": "cfg", "configMap": {"name": "x"}}]
     ingest.build_snapshot(nodes, pods, pod)  # node-independent volumes are fine
     pod["spec"]["volumes"].append({"name": "data", "persistentVolumeClaim": {"claimName": "pvc-1"}})
     assert ingest.build_snapshot(nodes, pods, pod).pod.prefilter_reject == 'persistentvolumeclaim "pvc-1" not found'
     pod["spec"]["volumes"][-1] = {"name": "data", "ephemeral": {"volumeClaimTemplate": {}}}
-    with pytest.raises(NotImplementedError, match="ephemeral volumes are not modelled"):
-        ingest.build_snapshot(nodes, pods, pod)
+    assert ingest.build_snapshot(nodes, pods, pod).pod.prefilter_reject == f'waiting for ephemeral volume controller to create the persistentvolumeclaim "{pod["metadata"]["name"]}-0-data"'
     pod["spec"]["volumes"].pop()
     # (DRA: the fake cluster holds no ResourceClaim -- the plugin's PreFilter rejects the pod; tests/test_volume_ingest.py)
     pod["spec"]["resourceClaims"] = [{"name": "gpu"}]

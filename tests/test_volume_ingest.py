@@ -107,8 +107,15 @@ def test_wait_for_first_consumer_claims():
         _side(pod, pvc_objs=[_pvc("c", cls="ebs")], class_objs=[_class("ebs", provisioner="ebs.csi.aws.com")])
     with pytest.raises(NotImplementedError, match="not in the snapshot"):
         _side(pod, pvc_objs=[_pvc("c", cls="ebs")])
-    with pytest.raises(NotImplementedError, match="ephemeral"):
-        _side(_pod([{"name": "scratch", "ephemeral": {"volumeClaimTemplate": {}}}]))
+    # a generic ephemeral volume: its claim is named after the clone and nobody creates it (volume_binding.go:306-331)
+    s = _side(_pod([{"name": "tmp", "emptyDir": {}}, {"name": "scratch", "ephemeral": {"volumeClaimTemplate": {}}}, _claim_vol("ghost")]), enabled=("NodeVolumeLimits", "VolumeBinding", "VolumeZone"))
+    assert s.prefilter_reject == 'waiting for ephemeral volume controller to create the persistentvolumeclaim "sim-0-scratch"'
+    s = _side(_pod([{"name": "scratch", "ephemeral": {"volumeClaimTemplate": {}}}]), clone_index=2)
+    assert s.prefilter_reject == 'waiting for ephemeral volume controller to create the persistentvolumeclaim "sim-2-scratch"'
+    with pytest.raises(NotImplementedError, match="created for the simulated pod"):
+        _side(_pod([{"name": "scratch", "ephemeral": {"volumeClaimTemplate": {}}}]), pvc_objs=[_pvc("sim-0-scratch")])
+    with pytest.raises(NotImplementedError, match="without the VolumeBinding plugin"):
+        _side(_pod([{"name": "scratch", "ephemeral": {"volumeClaimTemplate": {}}}]), enabled=("VolumeRestrictions",))
 
 
 def test_pods_without_volume_plugins_business():
@@ -322,6 +329,7 @@ def test_native_host_gives_the_same_verdicts(native, tmp_path):
         ([_claim_vol("solo")], ()), ([_claim_vol("free")], ()), ([_claim_vol("ghost")], ()), ([_claim_vol("imm")], ()), ([_claim_vol("old-style")], ()),
         ([_claim_vol("b")], ()), ([_claim_vol("b")], ("--sync-persistent-volumes",)),
         ([{"name": "tmp", "emptyDir": {}}, {"name": "inline", "csi": {"driver": "d"}}], ()),
+        ([{"name": "scratch", "ephemeral": {"volumeClaimTemplate": {}}}], ()),
     ]
     seen = []
     for k, (vols, extra) in enumerate(cases):
@@ -336,6 +344,7 @@ def test_native_host_gives_the_same_verdicts(native, tmp_path):
     assert seen[8]["prefilter_reject"] == 'persistentvolume "pv-1" not found'
     assert seen[9]["volume_veto"] == [4, 4, 4, 0, 4, 0] and seen[9]["prefilter_reject"] is None  # n3 (z0) and n5 (z2) carry the volume's node affinity and zones
     assert seen[10] == {"volume_veto": None, "volume_exclusive": False, "prefilter_reject": None, "rwop_capacity_one": False}
+    assert seen[11]["prefilter_reject"] == 'waiting for ephemeral volume controller to create the persistentvolumeclaim "sim-0-scratch"'
 
 
 def test_native_host_counts_csi_volumes_like_the_python_host(native, tmp_path):
@@ -359,7 +368,7 @@ def test_native_host_refuses_what_the_python_host_refuses(native, tmp_path):
     nodes = _nodes()
     for vols, objs, what in (([_claim_vol("c")], [_pvc("c", cls="ebs"), _class("ebs", provisioner="ebs.csi.aws.com")], "PV controller"),
                              ([_claim_vol("c")], [_pvc("c", cls="nowhere")], "not in the snapshot"),
-                             ([{"name": "s", "ephemeral": {"volumeClaimTemplate": {}}}], [], "ephemeral")):
+                             ([{"name": "s", "ephemeral": {"volumeClaimTemplate": {}}}], [_pvc("sim-0-s")], "created for the simulated pod")):
         flags = _write_case(tmp_path, _pod(vols), nodes, objs)
         p = subprocess.run([native] + flags, capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
         assert p.returncode == 1 and what in p.stderr
