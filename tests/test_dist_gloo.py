@@ -72,7 +72,7 @@ def test_sharded_runner_over_gloo(tmp_path, world, n, limit, mode, log):
     assert line and '"ok": true' in line[0], (out.stdout[-1000:], out.stderr[-1000:])
 
 
-@pytest.mark.parametrize("world,n,limit,pct", [(2, 240, 150, 30), (3, 400, 0, 0), (2, 1000, 300, 10), (3, 130, 90, 50)])
+@pytest.mark.parametrize("world,n,limit,pct", [(2, 240, 150, 30), (3, 400, 500, 0), (2, 1000, 300, 10), (3, 130, 90, 50)])
 def test_sharded_sampled_search_over_gloo(tmp_path, world, n, limit, pct):
     """percentageOfNodesToScore < 100 on shards: a counting pass and a scoring pass per cycle, one all-gather each (the engine's
     two-phase form: DevState::smp_phase; the protocol is tests/sharded_sampled_model.py), the rotating start index advanced by the

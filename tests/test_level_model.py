@@ -98,7 +98,7 @@ def test_persistent_batches_that_end_at_the_event(ccref, seed):
 
 
 def test_batches_that_end_at_the_event_save_syncs(ccref):
-    nodes, pod, prof = synth.make_config("C3", n_nodes=2000, seed=7)
+    nodes, pod, prof = synth.make_config("C3", n_nodes=1000, seed=7)
     new = _check_persistent(ccref, nodes, pod, prof, 0, 1024)
     old = _check_persistent(ccref, nodes, pod, prof, 0, 1024, spec=False)
     assert new["spec_ok"] >= 1 and new["syncs"] < old["syncs"], (new["syncs"], old["syncs"], new["spec_ok"])

@@ -28,9 +28,9 @@ def test_resident_sampled_search_vs_oracle(ccref, seed, block):
 
 
 def test_c3_shape_adaptive_default_every_mode_of_the_stretch_end(ccref):
-    nodes, pod, prof = synth.make_config("C3", n_nodes=1200, seed=5)
-    prof = dataclasses.replace(prof, percentage_of_nodes_to_score=0)  # adaptive: 50 - 1200/125 = 41 % -> K = 492
+    nodes, pod, prof = synth.make_config("C3", n_nodes=600, seed=5)
+    prof = dataclasses.replace(prof, percentage_of_nodes_to_score=0)  # adaptive: 50 - 600/125 = 46 % -> K = 276
     ref = ccref.run(prof, nodes, pod, max_limit=0)
-    model = ResidentSampledModel(prof, nodes.copy(), pod, block=512, check=False)  # (K + 1 feasible nodes fit behind a start index: mode 1 occurs)
+    model = ResidentSampledModel(prof, nodes.copy(), pod, block=256, check=False)  # (K + 1 feasible nodes fit behind a start index: mode 1 occurs)
     log, stop, visited, starts = model.run(0)
     assert log == ref.log.tolist() and visited == ref.evaluated_total and stop == "Unschedulable"

@@ -50,6 +50,35 @@ def collect(hipcc: str = "/opt/rocm/bin/hipcc") -> dict:
     return rows
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def collect_from_library(lib_path: str) -> dict:
+    """The same table read off the BUILT library (no second compile of the engine: the first form of this check took 70 s of the CPU
+    suite): .hip_fatbin -> the gfx950 code object -> its AMDGPU metadata note (per kernel: .vgpr_count, .private_segment_fixed_size =
+    the scratch frame, .vgpr_spill_count).  Occupancy = waves per SIMD the unified 512-entry register file allows (allocation granule 8)."""
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
+        subprocess.run([f"{LLVM_BIN}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat], check=True, capture_output=True)
+        subprocess.run([f"{LLVM_BIN}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                       check=True, capture_output=True)
+        notes = subprocess.run([f"{LLVM_BIN}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    rows, cur = {}, None
+    for line in notes.splitlines():
+        if line.startswith("  - "):  # the next kernel of amdhsa.kernels
+            cur = {}
+            line = "    " + line[4:]
+        m = re.match(r"    \.(name|vgpr_count|private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count):\s+(\S+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = m.group(2)
+            if len(cur) == 5:
+                v = int(cur["vgpr_count"])
+                rows[demangle_kernel(cur["name"])] = {"VGPRs": cur["vgpr_count"], "ScratchSize": cur["private_segment_fixed_size"], "VGPRs Spill": cur["vgpr_spill_count"],
+                                                     "SGPRs Spill": cur["sgpr_spill_count"], "Occupancy": str(min(8, 512 // max(8, -(-v // 8) * 8)))}
+                cur = None
+    return rows
+
+
 if __name__ == "__main__":
     for k, v in collect().items():
         print(k.ljust(34), "VGPRs", v.get("VGPRs", "?").rjust(4), " scratch", v.get("ScratchSize", "?").rjust(5),
