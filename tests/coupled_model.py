@@ -404,7 +404,59 @@ class CoupledWindowModel:
         return [n for n, _ in order[:length]] if length >= 2 else []
 
     # ---- the windowed loop ----
+    # ---- the node pass, per node range (the whole cluster here; a rank's shard in ShardedCoupledWindowModel) ------------------------------
+    node_range = None  # (lo, hi): set in run()
+
+    def exchange(self, scan):
+        """What the pass `scan(lo, hi)` finds on every rank's node range, in rank order (one rank: its own)."""
+        return [scan(*self.node_range)]
+
+    def scan_facts(self, T, minima, lo, hi):
+        feas0 = [n for n in range(lo, hi) if self.node_feasible(n) and self.coupled_filter(T, minima, n)]
+        return (bool(feas0), max((self.cnt[n] for n in feas0), default=0), max((self.aff[n] for n in feas0), default=0))
+
+    def scan_classes(self, T, mt, ma, lo, hi):
+        """key -> dict(list = the best node-feasible members of the range by (A desc, index asc), nf, max / holders of cnt and aff)"""
+        classes = {}
+        for n in range(lo, hi):
+            if not self.node_feasible(n):
+                continue
+            c = classes.setdefault(self.class_key(T, n), {"all": [], "nf": 0})
+            c["all"].append((-self.local_score(n, mt, ma), n))
+            c["nf"] += 1
+        for c in classes.values():
+            c["all"].sort()
+            c["list"] = c["all"][: (self.L if self.device_plan else self.W)]
+            members = [n for _, n in c["all"]]
+            c["mt"], c["ma"] = max(self.cnt[n] for n in members), max(self.aff[n] for n in members)
+            c["ht"], c["ha"] = sum(self.cnt[n] == c["mt"] for n in members), sum(self.aff[n] == c["ma"] for n in members)
+            del c["all"]
+        return classes
+
+    def merge_classes(self, parts):
+        """The ranges' class records unified (csrc/ccsim_coupled.h k_cw_xunify): members add, lists merge and keep the best, a maximum is
+        the largest of the ranges' and its holders are those of the ranges that reach it."""
+        out = {}
+        for part in parts:
+            for k, c in part.items():
+                o = out.get(k)
+                if o is None:
+                    out[k] = dict(c, list=list(c["list"]))
+                    continue
+                o["nf"] += c["nf"]
+                o["list"] = sorted(o["list"] + c["list"])[: (self.L if self.device_plan else self.W)]
+                for m, h, vals in (("mt", "ht", None), ("ma", "ha", None)):
+                    if c[m] > o[m]:
+                        o[m], o[h] = c[m], c[h]
+                    elif c[m] == o[m]:
+                        o[h] += c[h]
+        for c in out.values():
+            c["head"] = 0
+        return out
+
     def run(self, limit=0, audit_sweeps=False):
+        if self.node_range is None:
+            self.node_range = (0, self.N)
         N, p = self.N, self.prof
         log, scans = [], 0
         stats = {"windows": 0, "classes_max": 0, "cut_by_maxima": 0, "swept": 0}
@@ -413,27 +465,14 @@ class CoupledWindowModel:
             # ===== scan: everything below is one pass over the nodes in the state at the start of the window =====
             scans += 1
             T = self.build_tables()
-            feas_local = [n for n in range(N) if self.node_feasible(n)]
             minima = self.hard_minima(T)
-            feas0 = [n for n in feas_local if self.coupled_filter(T, minima, n)]
-            if not feas0:
+            # the pass over the nodes, in two steps so that it can run on node-range shards (ShardedCoupledWindowModel): the global
+            # facts the local scores need (is anything feasible, the normalization maxima), then the classes of the range
+            facts = self.exchange(lambda lo, hi: self.scan_facts(T, minima, lo, hi))
+            if not any(f[0] for f in facts):
                 return log, "Unschedulable", scans, stats
-            mt = max(self.cnt[n] for n in feas0)
-            ma = max(self.aff[n] for n in feas0)
-            classes = {}  # key -> dict(list = W best node-feasible members by (A desc, index asc), nf, max / holders of cnt and aff)
-            for n in feas_local:
-                k = self.class_key(T, n)
-                c = classes.setdefault(k, {"all": [], "nf": 0})
-                c["all"].append((-self.local_score(n, mt, ma), n))
-                c["nf"] += 1
-            for c in classes.values():
-                c["all"].sort()
-                c["list"] = c["all"][: (self.L if self.device_plan else self.W)]
-                members = [n for _, n in c["all"]]
-                c["mt"], c["ma"] = max(self.cnt[n] for n in members), max(self.aff[n] for n in members)
-                c["ht"], c["ha"] = sum(self.cnt[n] == c["mt"] for n in members), sum(self.aff[n] == c["ma"] for n in members)
-                c["head"] = 0
-                del c["all"]
+            mt, ma = max(f[1] for f in facts), max(f[2] for f in facts)
+            classes = self.merge_classes(self.exchange(lambda lo, hi: self.scan_classes(T, mt, ma, lo, hi)))
             stats["windows"] += 1
             stats["classes_max"] = max(stats["classes_max"], len(classes))
             touched = []  # nodes that received a clone in this window
@@ -535,3 +574,23 @@ class CoupledWindowModel:
                 done += 1
                 if limit and len(log) >= limit:
                     return log, "LimitReached", scans, stats
+
+
+class ShardedCoupledWindowModel(CoupledWindowModel):
+    """The windowed mode on node-range shards (round 5, csrc/ccsim_coupled.h k_cw_xpack / k_cw_xunify, ccsim_dist_cw_*): every rank passes
+    over ITS nodes only, the ranks exchange what the pass found -- once for the global facts the local scores need, once for the window
+    records (classes, their statistics, their staged list entries) -- every rank unifies the records identically and runs the deciding
+    loop replicated.  (This stand-in keeps the whole cluster's state on every rank -- the real engine applies a placement on its owner and
+    keeps only the domain tables replicated -- so what it checks is the exchange and the unification, on real process groups.)"""
+
+    def __init__(self, *a, world=1, rank=0, all_gather=None, **kw):
+        super().__init__(*a, **kw)
+        per = -(-self.N // world)
+        self.ranges = [(min(self.N, r * per), min(self.N, r * per + per)) for r in range(world)]
+        self.node_range = self.ranges[rank]
+        self._all_gather = all_gather  # None: every range is passed over in THIS process (the unification alone, no process group)
+
+    def exchange(self, scan):
+        if self._all_gather is None:
+            return [scan(lo, hi) for lo, hi in self.ranges]
+        return self._all_gather(scan(*self.node_range))

@@ -8,7 +8,7 @@ import pytest
 
 import helpers as H
 from cluster_capacity_amd import model as M
-from coupled_model import CoupledWindowModel
+from coupled_model import CoupledWindowModel, ShardedCoupledWindowModel
 
 
 def coupled_case(rng, n, roomy=False):
@@ -165,3 +165,17 @@ def test_sweeps_cover_the_config_5_pod_shape(ccref):
     log, stop, scans, stats = CoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=1024, device_plan=True, list_len=64).run(0, audit_sweeps=True)
     assert log == ref.log.tolist() and stop == "Unschedulable"
     assert stats["swept"] >= 0.9 * len(log), (stats, len(log))
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("seed", range(24))
+def test_window_records_of_node_range_shards_unify_to_the_same_windows(ccref, seed, world):
+    """Round 5 (windows on shards): per-range class records -- members, list entries, maxima and their holders -- merged as
+    k_cw_xunify merges them give the windows of the unsharded pass: same log as the oracle, same number of node passes."""
+    rng = np.random.default_rng(3300 + seed)
+    nodes, pod, prof = coupled_case(rng, int(rng.integers(5, 400)), roomy=bool(seed % 2))
+    limit = int(rng.choice([0, 0, 61, 400]))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit or 3000)
+    one = CoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=64, device_plan=True, list_len=8).run(limit or 3000)
+    log, stop, scans, stats = ShardedCoupledWindowModel(prof, nodes.copy(), pod, ccref.go_log, window=64, device_plan=True, list_len=8, world=world).run(limit or 3000)
+    assert log == ref.log.tolist() and log == one[0] and stop == one[1] and scans == one[2]
