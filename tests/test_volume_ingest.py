@@ -513,3 +513,109 @@ def test_gpu_cli_several_templates_with_volumes_vs_oracle(ccref, native, tmp_pat
     (tmp_path / "t1.yaml").write_text(yaml.safe_dump(json.loads(json.dumps(c))))
     st = _status(native, flags)
     assert st["replicas"] == 1 and 'persistentvolumeclaim "ghost" not found' in st["failReason"]["failMessage"]
+
+
+# ---- random differential: the two hosts on random object graphs -----------------------------------------------------------------------
+def _random_volume_world(rng):
+    n = int(rng.integers(3, 12))
+    nodes = []
+    for i in range(n):
+        labels = {"kubernetes.io/hostname": f"n{i}"}
+        if rng.random() < 0.8:
+            labels[ZONE if rng.random() < 0.7 else V.ZONE_BETA] = f"z{int(rng.integers(0, 3))}"
+        if rng.random() < 0.3:
+            labels[V.REGION_GA] = f"r{int(rng.integers(0, 2))}"
+        nodes.append(node(f"n{i}", cpu="4", mem="8Gi", pods="10", labels=labels))
+    drivers = ["ebs.csi.aws.com", "pd.csi.storage.gke.io"]
+    classes = [_class("local"), _class("fast", mode="Immediate", provisioner=drivers[0]), _class("csi-wait", provisioner=drivers[1]),
+               _class("nomode", mode=None), _class("intree", provisioner="kubernetes.io/aws-ebs")]
+    pvs, claims = [], []
+    for k in range(int(rng.integers(2, 9))):
+        labels = {}
+        if rng.random() < 0.4:
+            labels[ZONE if rng.random() < 0.6 else V.ZONE_BETA] = "__".join(f"z{z}" for z in sorted(set(rng.integers(0, 3, int(rng.integers(1, 3))).tolist())))
+        terms = None
+        if rng.random() < 0.3:
+            terms = [{"matchExpressions": [{"key": "kubernetes.io/hostname", "operator": str(rng.choice(["In", "NotIn"])), "values": [f"n{int(x)}" for x in rng.integers(0, n, 2)]}]}]
+        pv = _csi_pv(f"pv-{k}", f"h-{k}", drivers[int(rng.integers(0, 2))]) if rng.random() < 0.7 else _pv(f"pv-{k}")
+        pv["metadata"]["labels"] = labels
+        if terms is not None:
+            pv["spec"]["nodeAffinity"] = {"required": {"nodeSelectorTerms": terms}}
+        if rng.random() < 0.1:
+            pv["spec"].pop("csi", None)
+            pv["spec"]["gcePersistentDisk"] = {"pdName": f"pd-{k}"}
+        pvs.append(pv)
+    for k in range(int(rng.integers(2, 10))):
+        kind = rng.random()
+        modes = ("ReadWriteOncePod",) if rng.random() < 0.25 else ("ReadWriteOnce",)
+        if kind < 0.45:
+            c = _pvc(f"c{k}", volume_name=f"pv-{int(rng.integers(0, len(pvs) + 1))}", modes=modes, bound=bool(rng.random() < 0.85))
+        else:
+            c = _pvc(f"c{k}", cls=str(rng.choice(["local", "fast", "csi-wait", "nomode", "intree", "gone"])) if rng.random() < 0.85 else None, modes=modes)
+        if rng.random() < 0.07:
+            c["status"]["phase"] = "Lost"
+        if rng.random() < 0.05:
+            c["metadata"]["deletionTimestamp"] = "2025-01-01T00:00:00Z"
+        if rng.random() < 0.1:
+            c["metadata"].setdefault("annotations", {})[V.ANN_BETA_STORAGE_CLASS] = "local"
+        claims.append(c)
+
+    def random_volumes(k_max, own):
+        vols = []
+        for j in range(int(rng.integers(0, k_max + 1))):
+            r = rng.random()
+            name = f"v{j}"
+            if r < 0.45:
+                vols.append(_claim_vol(f"c{int(rng.integers(0, len(claims) + (1 if own else 0)))}", name))
+            elif r < 0.6:
+                vols.append({"name": name, "gcePersistentDisk": {"pdName": f"disk-{int(rng.integers(0, 2))}", "readOnly": bool(rng.random() < 0.5)}})
+            elif r < 0.7:
+                vols.append({"name": name, "awsElasticBlockStore": {"volumeID": f"vol-{int(rng.integers(0, 2))}"}})
+            elif r < 0.78:
+                vols.append({"name": name, "rbd": {"monitors": [f"m{int(x)}" for x in rng.integers(0, 3, 2)], "pool": "p", "image": f"i{int(rng.integers(0, 2))}", "readOnly": bool(rng.random() < 0.5)}})
+            elif r < 0.85:
+                vols.append({"name": name, "iscsi": {"iqn": f"iqn-{int(rng.integers(0, 2))}", "targetPortal": "p", "lun": 0, "readOnly": bool(rng.random() < 0.5)}})
+            elif r < 0.9 and own:
+                vols.append({"name": name, "ephemeral": {"volumeClaimTemplate": {}}})
+            else:
+                vols.append({"name": name, "emptyDir": {}})
+        return vols
+    pods = []
+    for k in range(int(rng.integers(0, 10))):
+        p = running_pod(f"p{k}", f"n{int(rng.integers(0, n))}", cpu="100m")
+        p["spec"]["volumes"] = random_volumes(3, False)
+        if rng.random() < 0.2:
+            p["metadata"]["namespace"] = "other"
+        pods.append(p)
+    csinodes = [_csinode(f"n{i}", int(rng.integers(1, 4)) if rng.random() < 0.8 else None, drivers[int(rng.integers(0, 2))]) for i in range(n) if rng.random() < 0.7]
+    vas = [{"apiVersion": "storage.k8s.io/v1", "kind": "VolumeAttachment", "metadata": {"name": f"va{k}"},
+            "spec": {"attacher": drivers[int(rng.integers(0, 2))], "nodeName": f"n{int(rng.integers(0, n))}", "source": {"persistentVolumeName": f"pv-{int(rng.integers(0, len(pvs)))}"}}}
+           for k in range(int(rng.integers(0, 5)))]
+    template = _pod(random_volumes(3, True))
+    if rng.random() < 0.15:
+        template["spec"]["resourceClaims"] = [{"name": "dev", **({"resourceClaimName": "gpu"} if rng.random() < 0.5 else {"resourceClaimTemplateName": "tpl"})}]
+    return nodes, pods + classes + claims + pvs + csinodes + vas, template
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_both_hosts_agree_on_random_volume_object_graphs(native, tmp_path, seed):
+    """Random claims / classes / volumes / CSINodes / attachments / pods with volumes, with and without --sync-persistent-volumes: the native
+    host's verdicts == the Python host's; what one refuses the other refuses."""
+    rng = np.random.default_rng(52_000 + seed)
+    nodes, objs, template = _random_volume_world(rng)
+    extra = ("--sync-persistent-volumes",) if seed % 2 else ()
+    flags = _write_case(tmp_path, template, nodes, objs) + list(extra)
+    by = cli.load_by_kind([flags[3]])
+    try:
+        snap = ingest.build_snapshot(by.get("Node", []), by.get("Pod", []), cli.parse_pod_spec(flags[1]), pvc_objs=by.get("PersistentVolumeClaim", []),
+                                     class_objs=by.get("StorageClass", []), pv_objs=by.get("PersistentVolume", []) if extra else None,
+                                     csinode_objs=by.get("CSINode", []) if extra else (), attachment_objs=by.get("VolumeAttachment", []) if extra else ())
+    except NotImplementedError as e:
+        p = subprocess.run([native] + flags + ["--dump-snapshot", "-"], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 1, (str(e), p.stdout[-300:])
+        return
+    got = json.loads(_run(native, flags + ["--dump-snapshot", "-"]))["pod"]
+    p = snap.pod
+    ref = {"volume_veto": None if p.volume_veto is None else [int(x) for x in p.volume_veto], "volume_exclusive": bool(p.volume_exclusive),
+           "prefilter_reject": p.prefilter_reject, "rwop_capacity_one": bool(p.rwop_capacity_one)}
+    assert {k: got[k] for k in ref} == ref
