@@ -117,7 +117,18 @@ def build_review(pod, snap: ingest.Snapshot, result: M.RunResult, max_limit: int
     outcome = None
     if result.stop == M.STOP_UNSCHEDULABLE:  # the PostFilter of the terminal cycle: DefaultPreemption's dry run (message tail only)
         mixed = len({(p.preempt.priority if p.preempt else 0) for p in snap.pods}) > 1  # clones of one template below another's priority
-        outcome = preemption.dry_run(snap.nodes, snap.pods[failing], result.per_node_count, result.n_code_unschedulable, filter_mask, P, mixed)
+        pod_f = snap.pods[failing]
+        if pod_f.rwop_capacity_one and result.placed >= 1 and not getattr(result, "prefilter_msg", None):
+            # the terminal cycle saw the pod with its ReadWriteOncePod claim held by its own clone (with_rwop_in_use): a clone is no victim,
+            # so the claim stays in conflict on every node whatever the dry run removes (static disk conflicts may leave with a victim)
+            pod_f = with_rwop_in_use(pod_f, snap.nodes.n, result.per_node_count if P == 1 else None)
+            pre = copy.copy(pod_f.preempt or M.PreemptionSide())
+            rest = np.full(snap.nodes.n, M.VOL_RWOP, np.uint8)
+            if pre.volume_veto_rest is not None:
+                rest[np.asarray(pre.volume_veto_rest) == M.VOL_DISK_CONFLICT] = M.VOL_DISK_CONFLICT
+            pre.volume_veto_rest = rest
+            pod_f.preempt = pre
+        outcome = preemption.dry_run(snap.nodes, pod_f, result.per_node_count, result.n_code_unschedulable, filter_mask, P, mixed)
         if outcome.kind == "unmodelled":
             print("warning: a lower-priority pod takes part in a topology-coupled filter of the simulated pod (or several templates "
                   "run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims",

@@ -261,16 +261,7 @@ inline RunResult rejected_by_prefilter(const Snapshot &s, const PodSide &side, c
     return r;
 }
 
-// The pod once a clone holds its ReadWriteOncePod claim: VolumeRestrictions fails every node -- after its own disk check (`clones`: where
-// the pod's earlier clones sit, for a pod whose disks are exclusive: the engine counts clones from the moment a pod is set).
-inline void rwop_now_in_use(PodSide &side, size_t N, const std::vector<int32_t> *clones = nullptr) {
-    if (side.volume_veto.empty()) side.volume_veto.assign(N, 0);
-    for (size_t i = 0; i < N; i++) {
-        if (side.volume_exclusive && clones && (*clones)[i] > 0) side.volume_veto[i] = 1;
-        if (side.volume_veto[i] != 1) side.volume_veto[i] = 2;
-    }
-    side.rwop_capacity_one = false;
-}
+// (rwop_now_in_use: snapshot.hpp)
 
 // Several templates WITHOUT the window engine: the reference's literal loop -- cycle i schedules a clone of template i mod P
 // (pkg/framework/simulator.go:297-381) -- with one ccsim_set_pod + one scheduling cycle of the HIP engine per placement.  The node

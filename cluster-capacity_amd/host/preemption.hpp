@@ -173,7 +173,6 @@ inline PreemptionOutcome preemption_dry_run(const Snapshot &s, const PodSide &p,
     if (mixed_priorities) return out.kind = PreemptionOutcome::Unmodelled, out;
     if (p.victim_count.empty()) return out;
     if (n_templates > 1) return out.kind = PreemptionOutcome::Unmodelled, out;
-    if (!p.volume_veto.empty() || p.volume_exclusive) return out.kind = PreemptionOutcome::Unmodelled, out; // (a victim's disks / claims would have to leave the verdicts with it)
 
     bool all_zero = !p.has_scalar_entries; // fit.go:578-583
     for (size_t c = 0; c < 3 && c < R; c++) all_zero = all_zero && !(p.preq[c] > 0);
@@ -207,8 +206,12 @@ inline PreemptionOutcome preemption_dry_run(const Snapshot &s, const PodSide &p,
         bool beyond = false, c_unres = false;
         const uint32_t m0 = fit(i, used, pods, beyond);
         const int c_reason = coupled.active() ? coupled.verdict(i, c_unres) : 0;
+        // the volume plugins follow NodeResourcesFit (default_plugins.go:40-45): a node that holds a clone whose disks conflict with the next
+        // one's, else the hosts' verdict against the node's pods -- now, and with the victims gone (volumes.hpp veto_with_victims_gone)
+        const int vol_now = p.volume_exclusive && cnt > 0 ? 1 : (p.volume_veto.empty() ? 0 : (int)p.volume_veto[i]);
+        const int vol_rest = p.volume_exclusive && cnt > 0 ? 1 : (p.volume_veto_rest.empty() ? 0 : (int)p.volume_veto_rest[i]);
         // the terminal status of the node: the first failing plugin decides the code; plain Unschedulable = a dry-run node
-        const bool is_potential = conflict_now || m0 ? (conflict_now || !beyond) : (c_reason != 0 && !c_unres);
+        const bool is_potential = conflict_now || m0 ? (conflict_now || !beyond) : vol_now ? vol_now <= CCSIM_VOL_LAST_UNSCHEDULABLE : (c_reason != 0 && !c_unres);
         if (!is_potential) continue;
         if (coupled.active() && !p.victim_interacts.empty() && p.victim_interacts[i]) {
             std::fill(out.hist.begin(), out.hist.end(), 0); // (the no-victims form: nothing of the partial walk may reach the message)
@@ -222,7 +225,8 @@ inline PreemptionOutcome preemption_dry_run(const Snapshot &s, const PodSide &p,
             if (m1 & 1u) out.hist[CCSIM_R_TOO_MANY_PODS]++;
             for (size_t c = 0; c < R; c++)
                 if (m1 & (1u << (1 + c))) out.hist[CCSIM_R_RES0 + c]++;
-        } else if (c_reason) out.hist[(size_t)c_reason]++;
+        } else if (vol_rest) out.hist[(size_t)(CCSIM_R_VOL0 + vol_rest - 1)]++;
+        else if (c_reason) out.hist[(size_t)c_reason]++;
         else nominated = true;
     }
     if (nominated) return out.kind = PreemptionOutcome::Nominated, out;

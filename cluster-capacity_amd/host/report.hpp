@@ -131,7 +131,20 @@ inline std::string terminal_stop_reason(const Snapshot &snap, const RunResult &r
     if (r.stop != CCSIM_STOP_UNSCHEDULABLE) return stop_reason(r, (int64_t)snap.n(), max_limit, snap.side(failing).taint_reasons, snap.scalar_names);
     bool mixed = false; // clones of one template below another template's priority
     for (size_t t = 1; t < P; t++) mixed = mixed || snap.side(t).priority != snap.side(0).priority;
-    const PreemptionOutcome pre = preemption_dry_run(snap, snap.side(failing), r.per_node_count, r.n_code_unschedulable, filter_mask, P, mixed);
+    PodSide terminal; // (only when the terminal cycle saw another pod than the snapshot's)
+    const PodSide *pf = &snap.side(failing);
+    if (pf->rwop_capacity_one && r.placed >= 1 && r.prefilter_msg.empty()) {
+        // the terminal cycle saw the pod with its ReadWriteOncePod claim held by its own clone (rwop_now_in_use): a clone is no victim, so the
+        // claim stays in conflict on every node whatever the dry run removes (static disk conflicts may leave with a victim)
+        terminal = *pf;
+        rwop_now_in_use(terminal, snap.n(), P == 1 ? &r.per_node_count : nullptr);
+        std::vector<uint8_t> rest(snap.n(), 2);
+        for (size_t i = 0; i < rest.size() && i < pf->volume_veto_rest.size(); i++)
+            if (pf->volume_veto_rest[i] == 1) rest[i] = 1;
+        terminal.volume_veto_rest = std::move(rest);
+        pf = &terminal;
+    }
+    const PreemptionOutcome pre = preemption_dry_run(snap, *pf, r.per_node_count, r.n_code_unschedulable, filter_mask, P, mixed);
     if (warn && pre.kind == PreemptionOutcome::Unmodelled)
         std::fprintf(stderr, "warning: a lower-priority pod takes part in a topology-coupled filter of the simulated pod (or several templates "
                              "run): the preemption dry run is not modelled, the 'preemption:' part of the message assumes no victims\n");

@@ -427,6 +427,7 @@ struct PodSide {
     // a victim of the node takes part in the PreFilter state of a topology-coupled filter of the template (removing it would
     // change that state: not modelled by the dry run); empty = no such node
     std::vector<uint8_t> victim_interacts;
+    std::vector<uint8_t> volume_veto_rest; // volume_veto with the node's victims gone (volumes.hpp veto_with_victims_gone); empty = no node is rejected then
     // a topology-coupled FILTER is active: a DoNotSchedule spread constraint (podtopologyspread/filtering.go:311-356), required inter-pod
     // (anti-)affinity of the template or anti-affinity terms of existing pods that match it (interpodaffinity/filtering.go:352-432).
     // With one, WHICH nodes a cycle saw decides not only the order of the placements but how many fit: the total depends on
@@ -445,6 +446,17 @@ struct PodSide {
 
 // The snapshot: node columns shared by every template + the first template (as base class: the single-template code reads
 // s.preq, s.spread, ... as before) + the further templates of a `--podspec a --podspec b ...` run (`more`).
+// The pod once a clone holds its ReadWriteOncePod claim: VolumeRestrictions fails every node -- after its own disk check (`clones`: where
+// the pod's earlier clones sit, for a pod whose disks are exclusive: the engine counts clones from the moment a pod is set).
+inline void rwop_now_in_use(PodSide &side, size_t N, const std::vector<int32_t> *clones = nullptr) {
+    if (side.volume_veto.empty()) side.volume_veto.assign(N, 0);
+    for (size_t i = 0; i < N; i++) {
+        if (side.volume_exclusive && clones && (*clones)[i] > 0) side.volume_veto[i] = 1;
+        if (side.volume_veto[i] != 1) side.volume_veto[i] = 2;
+    }
+    side.rwop_capacity_one = false;
+}
+
 struct Snapshot : PodSide {
     // nodes (canonical order)
     std::vector<std::string> names, res_names, scalar_names;
@@ -841,6 +853,8 @@ inline Snapshot build_snapshot(const std::vector<Value> &node_objs, const std::v
     // does not have: nodevolumelimits/csi.go:265-290.)  DynamicResources stays refused.
     {
         VolumeSide vs = volume_side(sim_pod, nodes, live, live_node, vol, template_index);
+        if (!s.victim_count.empty() && !vs.veto.empty() && !vs.rejected) // (DefaultPreemption's dry run: the verdicts once a node's victims are gone)
+            s.volume_veto_rest = veto_with_victims_gone(sim_pod, nodes, live, live_node, is_victim, vol, vs, template_index);
         s.volume_veto = std::move(vs.veto), s.volume_exclusive = vs.exclusive;
         s.prefilter_reject = vs.rejected ? vs.prefilter_reject : std::string(), s.rwop_capacity_one = vs.rwop_capacity_one;
     }
@@ -1155,6 +1169,7 @@ inline Value pod_side_json(const PodSide &s) {
     pre.set("victim_req", vr);
     pre.set("ports_conflict_rest", s.ports_conflict_rest.empty() ? Value() : int_array(s.ports_conflict_rest));
     pre.set("victim_interacts", s.victim_interacts.empty() ? Value() : int_array(s.victim_interacts));
+    pre.set("volume_veto_rest", s.volume_veto_rest.empty() ? Value() : int_array(s.volume_veto_rest));
     p.set("preempt", pre);
     return p;
 }

@@ -462,4 +462,48 @@ inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Valu
     return out;
 }
 
+// The verdicts as DefaultPreemption's dry run sees them on a node once ITS lower-priority pods are removed (default_preemption.go:217-310: per
+// node; the PreFilter state follows through RemovePod, volume_restrictions.go:205-213).  Disk conflicts, volume limits and what a bound volume
+// says about the node depend on that node alone: the evaluation over the remaining pods.  A ReadWriteOncePod claim in use is a cluster-wide
+// count: it stays in conflict on node n unless EVERY pod using the claim is a victim sitting on n.  Empty = no node is rejected then.
+inline std::vector<uint8_t> veto_with_victims_gone(const Value &sim_pod, const std::vector<const Value *> &nodes, const std::vector<const Value *> &live,
+                                                   const std::vector<size_t> &live_node, const std::vector<uint8_t> &is_victim, const VolumeObjects &vo,
+                                                   const VolumeSide &full, size_t clone_index) {
+    std::vector<const Value *> rest_live;
+    std::vector<size_t> rest_node;
+    for (size_t j = 0; j < live.size(); j++)
+        if (!is_victim[j]) rest_live.push_back(live[j]), rest_node.push_back(live_node[j]);
+    VolumeSide rest = volume_side(sim_pod, nodes, rest_live, rest_node, vo, clone_index);
+    const size_t N = nodes.size();
+    std::vector<uint8_t> veto = rest.veto.empty() ? std::vector<uint8_t>(N, 0) : rest.veto;
+    if (std::find(full.veto.begin(), full.veto.end(), (uint8_t)2) != full.veto.end()) { // (the claim is in use by some pod of the snapshot)
+        const std::string ns = sim_pod["metadata"]["namespace"].truthy() ? sim_pod["metadata"]["namespace"].text() : "default";
+        std::set<std::string> rwop;
+        for (const auto &v : sim_pod["spec"]["volumes"].items()) {
+            if (v["persistentVolumeClaim"].is_null()) continue;
+            const std::string name = v["persistentVolumeClaim"]["claimName"].text();
+            for (const auto &o : vo.claims)
+                if (o["metadata"]["name"].text() == name && (o["metadata"]["namespace"].truthy() ? o["metadata"]["namespace"].text() : "default") == ns)
+                    for (const auto &m : o["spec"]["accessModes"].items())
+                        if (m.text() == "ReadWriteOncePod") rwop.insert(name);
+        }
+        std::vector<size_t> users; // (indices into live)
+        for (size_t j = 0; j < live.size(); j++) {
+            const Value &p = *live[j];
+            if ((p["metadata"]["namespace"].truthy() ? p["metadata"]["namespace"].text() : "default") != ns) continue;
+            bool uses = false;
+            for (const auto &v : p["spec"]["volumes"].items()) uses = uses || (!v["persistentVolumeClaim"].is_null() && rwop.count(v["persistentVolumeClaim"]["claimName"].text()));
+            if (uses) users.push_back(j);
+        }
+        for (size_t i = 0; i < N; i++) {
+            bool all_leave = true;
+            for (size_t j : users) all_leave = all_leave && is_victim[j] && live_node[j] == i;
+            if (!all_leave && veto[i] != 1) veto[i] = 2;
+        }
+    }
+    bool any = false;
+    for (uint8_t x : veto) any = any || x;
+    return any ? veto : std::vector<uint8_t>();
+}
+
 } // namespace cchost

@@ -741,6 +741,10 @@ def _template_side(ctx: dict, sim_pod: dict):
                        clone_index=ctx.get("template_index", 0))
     pod.volume_veto, pod.volume_exclusive = vs.veto, vs.exclusive
     pod.prefilter_reject, pod.rwop_capacity_one = vs.prefilter_reject, vs.rwop_capacity_one
+    if victims and vs.veto is not None and vs.prefilter_reject is None:  # (DefaultPreemption's dry run: the verdicts once a node's victims are gone)
+        pre.volume_veto_rest = V.veto_with_victims_gone(sim_pod, nodes, live, victims, index, vs, pvc_objs=ctx.get("pvc_objs") or (), class_objs=ctx.get("class_objs") or (),
+                                                        pv_objs=ctx.get("pv_objs"), enabled=ctx.get("volume_plugins") or V.PLUGINS, csinode_objs=ctx.get("csinode_objs") or (),
+                                                        attachment_objs=ctx.get("attachment_objs") or (), clone_index=ctx.get("template_index", 0))
     if spec.get("resourceClaims") and ctx.get("dra_enabled", True):
         # DynamicResources' PreFilter runs after the volume plugins' (default_plugins.go:45-47); the fake cluster holds no ResourceClaim
         if ctx.get("dra_partial"):

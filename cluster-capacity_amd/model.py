@@ -198,6 +198,8 @@ class PreemptionSide:
     # hard spread selector / a required (anti)affinity term, or carries an anti-affinity term that matches the template): removing
     # it would change that state (RunPreFilterExtensionRemovePod) -- such nodes are not modelled by the dry run.  None = no such node
     victim_interacts: Optional[np.ndarray] = None
+    # PodSpec.volume_veto with the node's victims gone (uint8[n], volumes.veto_with_victims_gone); None = no node is rejected then
+    volume_veto_rest: Optional[np.ndarray] = None
 
 
 @dataclass

@@ -180,9 +180,6 @@ def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedula
     if n_templates > 1:
         out.kind = "unmodelled"
         return out
-    if pod.volume_veto is not None or pod.volume_exclusive:  # (a victim's disks / claims would have to leave the verdicts with it)
-        out.kind = "unmodelled"
-        return out
     idx = np.nonzero(pre.victim_count)[0]
     cnt = np.asarray(per_node_count, np.int64)[idx]
     sok = static_ok(nodes, pod, idx, filter_mask)
@@ -225,14 +222,21 @@ def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedula
     term_req = [nodes.req[c][idx] + cnt * int(pod.req[c]) for c in range(ncol)]
     term_pods = nodes.pod_count[idx].astype(np.int64) + cnt
     m0, beyond0 = fit(term_req, term_pods)
+    # the volume plugins follow NodeResourcesFit (default_plugins.go:40-45): a node that holds a clone whose disks conflict with the next
+    # one's, else the hosts' verdict against the node's pods -- now, and with the victims gone (volumes.veto_with_victims_gone)
+    vol_now = np.zeros(len(idx), np.int64) if pod.volume_veto is None else np.asarray(pod.volume_veto, np.int64)[idx]
+    vol_rest = np.zeros(len(idx), np.int64) if pre.volume_veto_rest is None else np.asarray(pre.volume_veto_rest, np.int64)[idx]
+    if pod.volume_exclusive:
+        vol_now, vol_rest = np.where(cnt > 0, M.VOL_DISK_CONFLICT, vol_now), np.where(cnt > 0, M.VOL_DISK_CONFLICT, vol_rest)
     local_fail = conflict_now | (m0 != 0)
-    potential = sok & np.where(local_fail, conflict_now | ~beyond0, c_fail & ~c_unres)
+    vol_fail = ~local_fail & (vol_now != 0)
+    potential = sok & np.where(local_fail, conflict_now | ~beyond0, np.where(vol_fail, vol_now <= M.VOL_LAST_UNSCHEDULABLE, c_fail & ~c_unres))
     if coupled.active and pre.victim_interacts is not None and (potential & (pre.victim_interacts[idx] != 0)).any():
         out.kind = "unmodelled"
         return out
     # ... with the victims gone
     m1, _ = fit([term_req[c] - pre.victim_req[c][idx] for c in range(ncol)], term_pods - pre.victim_count[idx])
-    fits = potential & ~conflict_rest & (m1 == 0) & ~c_fail
+    fits = potential & ~conflict_rest & (m1 == 0) & (vol_rest == 0) & ~c_fail
     if fits.any():
         out.kind = "nominated"
         return out
@@ -242,6 +246,8 @@ def dry_run(nodes: M.NodesSoA, pod: M.PodSpec, per_node_count, n_code_unschedula
     out.hist[M.R_TOO_MANY_PODS] = int((still & ((m1 & 1) != 0)).sum())
     for c in range(ncol):
         out.hist[M.R_RES0 + c] = int((still & ((m1 >> (1 + c)) & 1 != 0)).sum())
-    for j in np.nonzero(still & (m1 == 0))[0]:  # node-locally fine now: the coupled filter's reason (the first failing plugin's)
+    for code in range(1, M.VOL_CODES + 1):
+        out.hist[M.R_VOL0 + code - 1] = int((still & (m1 == 0) & (vol_rest == code)).sum())
+    for j in np.nonzero(still & (m1 == 0) & (vol_rest == 0))[0]:  # node-locally fine now: the coupled filter's reason (the first failing plugin's)
         out.hist[verdicts[j][0]] += 1
     return out

@@ -150,6 +150,28 @@ def pv_node_affinity_matches(pv: dict, node_labels: dict) -> bool:
     return False
 
 
+def veto_with_victims_gone(sim_pod: dict, nodes: List[dict], live: Sequence[dict], victims: Sequence[dict], index: Dict[str, int], full: "VolumeSide",
+                           **kw) -> Optional[np.ndarray]:
+    """The verdicts as DefaultPreemption's dry run sees them on a node once ITS lower-priority pods are removed (default_preemption.go:217-310:
+    per node; the PreFilter state follows through RemovePod, volume_restrictions.go:205-213).  Disk conflicts, volume limits and what a bound
+    volume says about the node depend on that node alone: the evaluation over the remaining pods.  A ReadWriteOncePod claim in use is a
+    cluster-wide count: it stays in conflict on node n unless EVERY pod using the claim is a victim sitting on n."""
+    gone = {id(p) for p in victims}
+    rest = volume_side(sim_pod, nodes, [p for p in live if id(p) not in gone], index, **kw)
+    veto = np.zeros(len(nodes), np.uint8) if rest.veto is None else rest.veto.copy()
+    if full.veto is not None and (full.veto == M.VOL_RWOP).any():  # (the claim is in use by some pod of the snapshot)
+        ns = (sim_pod.get("metadata") or {}).get("namespace") or "default"
+        pvcs = {((o.get("metadata") or {}).get("namespace") or "default", (o.get("metadata") or {}).get("name", "")): o for o in kw.get("pvc_objs") or ()}
+        mine = {(v["persistentVolumeClaim"] or {}).get("claimName", "") for v in (sim_pod.get("spec") or {}).get("volumes") or [] if v.get("persistentVolumeClaim") is not None}
+        rwop = {c for c in mine if "ReadWriteOncePod" in (((pvcs.get((ns, c)) or {}).get("spec") or {}).get("accessModes") or [])}
+        users = [p for p in live if ((p.get("metadata") or {}).get("namespace") or "default") == ns and
+                 any(v.get("persistentVolumeClaim") is not None and (v["persistentVolumeClaim"] or {}).get("claimName", "") in rwop for v in (p.get("spec") or {}).get("volumes") or [])]
+        for i in range(len(nodes)):
+            if not all(id(u) in gone and index[u["spec"]["nodeName"]] == i for u in users) and veto[i] != M.VOL_DISK_CONFLICT:
+                veto[i] = M.VOL_RWOP
+    return veto if veto.any() else None
+
+
 def csi_volume(pvc: dict, pvs: Optional[dict], classes: dict) -> Optional[Tuple[str, str]]:
     """CSILimits.getCSIDriverInfo (nodevolumelimits/csi.go:446-505, 507-541): -> (driver, unique volume name) of a claim's volume, None =
     not counted.  A claim without a (known) volume counts as one volume of its class's provisioner, named after the claim."""

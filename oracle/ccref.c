@@ -1087,6 +1087,7 @@ int ccref_preemption_dry_run(const ccref_profile *prof, const ccref_nodes *nodes
     t.pod_count = pc;
     ccref_pod without = *pod; /* the node's used ports once the victims are gone */
     without.host_ports_conflict = victims ? victims->ports_conflict_rest : NULL;
+    without.volume_veto = victims ? victims->volume_veto_rest : NULL; /* (the clones' own disks stay: volume_exclusive + placed) */
 
     /* the cycle's PreFilter state of the topology-coupled plugins, as schedule_one_ws builds it (the second Filter run of the dry
      * run reads this state; removing a victim that takes no part in it leaves it as it is) */

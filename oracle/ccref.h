@@ -323,6 +323,8 @@ typedef struct {
     /* [n], NULL = none: a victim of the node takes part in the PreFilter state of a topology-coupled filter of the pod (matches a
      * hard spread selector / a required (anti)affinity term, or carries an anti-affinity term matching the pod) */
     const uint8_t *victim_interacts;
+    /* [n], NULL = none: ccref_pod.volume_veto evaluated against the node's REMAINING pods (a victim's disks and claims leave with it) */
+    const uint8_t *volume_veto_rest;
 } ccref_victims;
 typedef struct {
     int32_t nominated;

@@ -583,14 +583,14 @@ def image_locality_score(sizes, num_nodes, total_nodes, n_containers):
 
 
 class _Victims(C.Structure):
-    _fields_ = [("victim_count", _p32), ("victim_req", _p64 * MAX_RES), ("ports_conflict_rest", _pu8), ("victim_interacts", _pu8)]
+    _fields_ = [("victim_count", _p32), ("victim_req", _p64 * MAX_RES), ("ports_conflict_rest", _pu8), ("victim_interacts", _pu8), ("volume_veto_rest", _pu8)]
 
 
 class _Preemption(C.Structure):
     _fields_ = [("nominated", C.c_int32), ("hist", C.c_int64 * NREASON), ("no_victims", C.c_int64), ("not_helpful", C.c_int64)]
 
 
-def preemption_dry_run(profile, nodes, pod, placed, victim_count=None, victim_req=(), ports_conflict_rest=None, victim_interacts=None):
+def preemption_dry_run(profile, nodes, pod, placed, victim_count=None, victim_req=(), ports_conflict_rest=None, victim_interacts=None, volume_veto_rest=None):
     """DefaultPreemption's dry run of the terminal cycle (ccref_preemption_dry_run): `nodes` as loaded, `placed` = clones
     per node.  -> namespace(nominated, hist, no_victims, not_helpful); raises NotImplementedError for topology-coupled filters."""
     m = _Marshal()
@@ -606,6 +606,9 @@ def preemption_dry_run(profile, nodes, pod, placed, victim_count=None, victim_re
     if ports_conflict_rest is not None:
         keep.append(np.ascontiguousarray(ports_conflict_rest, dtype=np.uint8))
         v.ports_conflict_rest = _ptr(keep[-1], _pu8)
+    if volume_veto_rest is not None:
+        keep.append(np.ascontiguousarray(volume_veto_rest, dtype=np.uint8))
+        v.volume_veto_rest = _ptr(keep[-1], _pu8)
     if victim_interacts is not None:
         keep.append(np.ascontiguousarray(victim_interacts, dtype=np.uint8))
         v.victim_interacts = _ptr(keep[-1], _pu8)

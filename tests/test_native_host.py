@@ -48,7 +48,7 @@ def _pod_dump(p):
             "rwop_capacity_one": bool(p.rwop_capacity_one),
             "preempt": {"priority": p.preempt.priority, "never": p.preempt.never, "victim_count": lst(p.preempt.victim_count),
                         "victim_req": [lst(v) for v in p.preempt.victim_req], "ports_conflict_rest": lst(p.preempt.ports_conflict_rest),
-                        "victim_interacts": lst(p.preempt.victim_interacts)}}
+                        "victim_interacts": lst(p.preempt.victim_interacts), "volume_veto_rest": lst(p.preempt.volume_veto_rest)}}
 
 
 def py_dump(snap):

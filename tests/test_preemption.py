@@ -194,6 +194,35 @@ def test_host_dry_run_equals_oracle_restatement(ccref, seed):
         assert np.array_equal(got.hist, ref.hist), seed
 
 
+@pytest.mark.parametrize("seed", range(60))
+def test_host_dry_run_with_volume_verdicts_equals_oracle_restatement(ccref, seed):
+    """Round 5: the volume plugins' verdicts (after NodeResourcesFit; codes 1..3 plain Unschedulable: dry-run candidates) now and with a node's
+    victims gone, exclusive disks (a clone is no victim: its node keeps the disk conflict), with and without host ports and coupled filters."""
+    rng = np.random.default_rng(9900 + seed)
+    nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, int(rng.integers(5, 300))))
+    if seed % 3 == 0:
+        pod.spread = H.random_spread(rng, nodes)
+    n = nodes.n
+    codes = rng.integers(1, M.VOL_CODES + 1, n).astype(np.uint8)
+    pod.volume_veto = np.where(rng.random(n) < rng.choice([0.1, 0.5, 0.9]), codes, 0).astype(np.uint8)
+    pod.volume_exclusive = bool(seed % 2)
+    prof.filter_mask |= M.F_FIT
+    r = ccref.run(prof, nodes, pod)
+    assert r.stop == M.STOP_UNSCHEDULABLE
+    vc, vreq = _random_victims(rng, nodes)
+    ports_rest = (rng.random(n) < 0.3).astype(np.uint8) if pod.has_host_ports else None
+    vol_rest = np.where(rng.random(n) < 0.5, pod.volume_veto, 0).astype(np.uint8)  # some verdicts leave with the victims
+    pod.preempt = M.PreemptionSide(priority=1, victim_count=vc if vc.any() else None, victim_req=vreq, ports_conflict_rest=ports_rest,
+                                   volume_veto_rest=vol_rest if vol_rest.any() else None)
+    ref = ccref.preemption_dry_run(prof, nodes, pod, r.per_node_count, vc, vreq, ports_rest, volume_veto_rest=vol_rest)
+    assert ref.not_helpful == n - r.n_code_unschedulable
+    got = preemption.dry_run(nodes, pod, r.per_node_count, r.n_code_unschedulable, prof.filter_mask)
+    assert (got.kind == "nominated") == ref.nominated, seed
+    if not ref.nominated:
+        assert got.kind == "none" and got.no_victims == ref.no_victims and got.not_helpful == ref.not_helpful
+        assert np.array_equal(got.hist, ref.hist), seed
+
+
 @pytest.mark.parametrize("seed", range(80))
 def test_host_dry_run_with_coupled_filters_equals_oracle_restatement(ccref, seed):
     """Hard spread constraints and inter-pod (anti)affinity on the template, victims that take no part in their state (and, for some

@@ -515,6 +515,40 @@ def test_gpu_cli_several_templates_with_volumes_vs_oracle(ccref, native, tmp_pat
     assert st["replicas"] == 1 and 'persistentvolumeclaim "ghost" not found' in st["failReason"]["failMessage"]
 
 
+def test_verdicts_with_a_nodes_victims_gone_in_both_hosts(native, tmp_path):
+    """DefaultPreemption's dry run removes the lower-priority pods of ONE node and filters again: a disk conflict leaves with the victim that
+    holds the disk; a ReadWriteOncePod claim stays in use on every node but the one whose victims are ALL of its users."""
+    nodes = _nodes()
+    writer = running_pod("writer", "n1", cpu="100m")           # lower priority: a victim; holds the template's disk
+    writer["spec"]["volumes"] = [{"name": "d", "gcePersistentDisk": {"pdName": "disk-1"}}]
+    keeper = running_pod("keeper", "n2", cpu="100m")            # same priority as the template: stays; holds the disk too
+    keeper["spec"]["volumes"] = [{"name": "d", "gcePersistentDisk": {"pdName": "disk-1"}}]
+    keeper["spec"]["priority"] = 5
+    user = running_pod("user", "n4", cpu="100m")                # a victim that uses the template's ReadWriteOncePod claim
+    user["spec"]["volumes"] = [_claim_vol("solo")]
+    pod = _pod([{"name": "d", "gcePersistentDisk": {"pdName": "disk-1", "readOnly": True}}])
+    pod["spec"]["priority"] = 5
+    a = tmp_path / "a"
+    a.mkdir()
+    flags = _write_case(a, pod, nodes, [writer, keeper, user])
+    got = json.loads(_run(native, flags + ["--dump-snapshot", "-"]))["pod"]
+    snap = ingest.build_snapshot(nodes, [writer, keeper, user], cli.parse_pod_spec(flags[1]))
+    assert snap.pod.volume_veto.tolist() == [0, 1, 1, 0, 0, 0] and snap.pod.preempt.volume_veto_rest.tolist() == [0, 0, 1, 0, 0, 0]
+    assert got["volume_veto"] == [0, 1, 1, 0, 0, 0] and got["preempt"]["volume_veto_rest"] == [0, 0, 1, 0, 0, 0]
+    # the ReadWriteOncePod claim: in use (by `user` on n4) -> every node fails now; with a node's victims gone only n4 is free of it
+    pod = _pod([_claim_vol("solo")])
+    pod["spec"]["priority"] = 5
+    objs = [writer, keeper, user, _class("local"), _pvc("solo", volume_name="pv-1", modes=("ReadWriteOncePod",)), _pv("pv-1")]
+    b = tmp_path / "b"
+    b.mkdir()
+    flags = _write_case(b, pod, nodes, objs) + ["--sync-persistent-volumes"]
+    got = json.loads(_run(native, flags + ["--dump-snapshot", "-"]))["pod"]
+    by = cli.load_by_kind([flags[3]])
+    snap = ingest.build_snapshot(by["Node"], by["Pod"], cli.parse_pod_spec(flags[1]), pvc_objs=by["PersistentVolumeClaim"], class_objs=by["StorageClass"], pv_objs=by["PersistentVolume"])
+    assert snap.pod.volume_veto.tolist() == [2] * 6 and snap.pod.preempt.volume_veto_rest.tolist() == [2, 2, 2, 2, 0, 2]
+    assert got["volume_veto"] == [2] * 6 and got["preempt"]["volume_veto_rest"] == [2, 2, 2, 2, 0, 2]
+
+
 # ---- random differential: the two hosts on random object graphs -----------------------------------------------------------------------
 def _random_volume_world(rng):
     n = int(rng.integers(3, 12))
@@ -592,6 +626,11 @@ def _random_volume_world(rng):
             "spec": {"attacher": drivers[int(rng.integers(0, 2))], "nodeName": f"n{int(rng.integers(0, n))}", "source": {"persistentVolumeName": f"pv-{int(rng.integers(0, len(pvs)))}"}}}
            for k in range(int(rng.integers(0, 5)))]
     template = _pod(random_volumes(3, True))
+    if rng.random() < 0.6:  # lower-priority pods around: DefaultPreemption's dry run needs the verdicts with a node's victims gone
+        template["spec"]["priority"] = 5
+        for p in pods:
+            if rng.random() < 0.4:
+                p["spec"]["priority"] = 7
     if rng.random() < 0.15:
         template["spec"]["resourceClaims"] = [{"name": "dev", **({"resourceClaimName": "gpu"} if rng.random() < 0.5 else {"resourceClaimTemplateName": "tpl"})}]
     return nodes, pods + classes + claims + pvs + csinodes + vas, template
@@ -619,3 +658,5 @@ def test_both_hosts_agree_on_random_volume_object_graphs(native, tmp_path, seed)
     ref = {"volume_veto": None if p.volume_veto is None else [int(x) for x in p.volume_veto], "volume_exclusive": bool(p.volume_exclusive),
            "prefilter_reject": p.prefilter_reject, "rwop_capacity_one": bool(p.rwop_capacity_one)}
     assert {k: got[k] for k in ref} == ref
+    rest = p.preempt.volume_veto_rest
+    assert got["preempt"]["volume_veto_rest"] == (None if rest is None else [int(x) for x in rest])
