@@ -250,3 +250,62 @@ def test_deep_but_legal_nesting_is_read_and_skipped_members_do_not_count(native,
     p = _run(native, tmp_path, node.encode(), json.dumps(pod).encode(), "json")  # (managedFields is pruned: skipped without recursion)
     assert p.returncode == 0, p.stderr[-300:]
     assert json.loads(p.stdout)["names"] == ["n"]
+
+
+# ---- round 5: the objects the volume plugins read ---------------------------------------------------------------------------------------
+def _volume_world():
+    from test_volume_ingest import _claim_vol, _class, _csi_pv, _csinode, _nodes, _pod, _pvc
+    from test_native_host import running_pod
+    nodes = _nodes()
+    user = running_pod("user", "n1", cpu="100m")
+    user["spec"]["volumes"] = [_claim_vol("other"), {"name": "d", "gcePersistentDisk": {"pdName": "disk-1"}}]
+    objs = [user, _class("local"), _pvc("mine", volume_name="pv-1", modes=("ReadWriteOncePod",)), _pvc("other", volume_name="pv-2"), _csi_pv("pv-1", "h1"), _csi_pv("pv-2", "h2"),
+            _csinode("n1", 2), {"apiVersion": "storage.k8s.io/v1", "kind": "VolumeAttachment", "metadata": {"name": "va"},
+                                "spec": {"attacher": "ebs.csi.aws.com", "nodeName": "n2", "source": {"persistentVolumeName": "pv-2"}}}]
+    pod = _pod([_claim_vol("mine"), {"name": "d", "gcePersistentDisk": {"pdName": "disk-1", "readOnly": True}}])
+    return nodes, objs, pod
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_damaged_volume_objects_are_refused_or_read_alike(native, tmp_path, seed):
+    """A value of the wrong kind somewhere in a claim / class / volume / CSINode / attachment / a pod's volume list: the native host refuses
+    with a message (exit 1) or reads the object exactly as the Python host does -- never crashes (run under the sanitizers too)."""
+    rng = random.Random(7100 + seed)
+    nodes, objs, pod = _volume_world()
+    junk = rng.choice(["text", 7, -1, 3.5, True, None, [], {}, [1, 2], {"a": {"b": []}}, "9" * 40])
+    victim = rng.choice([o for o in objs])
+
+    def paths(o, pre=()):
+        out = []
+        if isinstance(o, dict):
+            for k, v in o.items():
+                out.append(pre + (k,))
+                out += paths(v, pre + (k,))
+        elif isinstance(o, list):
+            for i, v in enumerate(o):
+                out.append(pre + (i,))
+                out += paths(v, pre + (i,))
+        return out
+    where = rng.choice([p for p in paths(victim) if p[0] in ("spec", "metadata", "provisioner", "volumeBindingMode", "status")])
+    cur = victim
+    for k in where[:-1]:
+        cur = cur[k]
+    cur[where[-1]] = junk
+    (tmp_path / "pod.yaml").write_text(yaml.safe_dump(json.loads(json.dumps(pod))))
+    (tmp_path / "cluster.json").write_text(json.dumps({"kind": "List", "items": nodes + objs}))
+    flags = ["--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "cluster.json"), "--sync-persistent-volumes", "--dump-snapshot", "-"]
+    p = subprocess.run([native] + flags, capture_output=True, text=True, timeout=120)
+    assert p.returncode in (0, 1), (where, junk, p.returncode, p.stderr[-400:])  # (a sanitizer report or a signal is neither)
+    if p.returncode == 1:
+        assert p.stderr.strip().startswith("cluster-capacity:"), p.stderr[-300:]
+        return
+    by = cli.load_by_kind([flags[3]])
+    try:
+        snap = ingest.build_snapshot(by.get("Node", []), by.get("Pod", []), cli.parse_pod_spec(flags[1]), pvc_objs=by.get("PersistentVolumeClaim", []),
+                                     class_objs=by.get("StorageClass", []), pv_objs=by.get("PersistentVolume", []), csinode_objs=by.get("CSINode", []),
+                                     attachment_objs=by.get("VolumeAttachment", []))
+    except Exception:  # noqa: BLE001  (the Python mirror may stumble over what the native host read as harmless: only agreement on success is claimed)
+        return
+    got = json.loads(p.stdout)["pod"]
+    q = snap.pod
+    assert got["volume_veto"] == (None if q.volume_veto is None else [int(x) for x in q.volume_veto]) and got["prefilter_reject"] == q.prefilter_reject, (where, junk)
