@@ -150,6 +150,7 @@ SYMBOLS = {
     "ccsim_debug_multi_stops": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_multi_memo": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_coupled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ccsim_debug_sampled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -562,6 +563,17 @@ class Engine:
             names = ["stage", "setup", "verdicts", "raw_scores", "argmax", "commit", "write_back"]
             d["prof_us_per_cycle"] = {k: round(out[8 + i] / 100.0 / out[15], 3) for i, k in enumerate(names)}
             d["cycles"] = int(out[15])
+        return d
+
+    def sampled_info(self):
+        """Which form the last sampled search (percentageOfNodesToScore < 100) took (ccsim_debug_sampled)."""
+        out = (C.c_int64 * 16)()
+        self._chk(self.lib.ccsim_debug_sampled(self.h, out), "ccsim_debug_sampled")
+        d = {"resident": bool(out[0]), "laps_form": bool(out[1]), "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
+             "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
+        if out[3] and any(out[8:15]):  # CCSIM_SB_PROF=1: microseconds per lap, by phase
+            names = ["prefix", "whole_blocks", "cut_blocks", "decide", "wait_commit", "summaries", "commit_wave"]
+            d["prof_us_per_lap"] = {k: round(out[8 + i] / 100.0 / out[3], 3) for i, k in enumerate(names)}
         return d
 
     def persist_prof(self):

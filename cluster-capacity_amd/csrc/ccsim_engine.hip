@@ -201,8 +201,10 @@ struct ccsim_engine {
     uint32_t *d_sb_fc = nullptr, *d_sb_mx = nullptr;
     unsigned long long *d_sb_key = nullptr;
     int sb_shift = 0, sb_blocks = 0;
-    int sb_allowed = 1;                          // CCSIM_SB=0: the three-pass cycle (A/B and test knob)
+    int sb_allowed = 1;                          // CCSIM_SB=0: the three-pass cycle, 2: one cycle at a time on the summaries (A/B and test knobs)
     bool sb_attr_set = false, sb_run = false;
+    unsigned long long *d_sb_prof = nullptr;     // CCSIM_SB_PROF=1: k_sb_laps' phase ticks
+    bool sb_laps = false;                        // this run: a lap of the ring at a time (k_sb_laps) instead of a cycle at a time (k_sb_cycles)
     bool cw_fast = false;                        // ... and may use the lane-per-candidate decide kernel (k_cw_decide_fast)
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
     int32_t *d_a32[2] = {nullptr, nullptr};
@@ -390,7 +392,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->allocs);
-    e->d_sb_memo = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr; // (they lived in e->allocs)
+    e->d_sb_memo = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr, e->d_sb_prof = nullptr; // (they lived in e->allocs)
     e->d_soft_pc0 = nullptr; // (sized for the previous snapshot: the pod is set again after a load)
     e->backups.clear();
     e->reset_pending = false, e->wide_stale = false;
@@ -1347,10 +1349,20 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     e->sb_run = false;
     if (mode == CCSIM_MODE_SEQUENTIAL && e->smp_K > 0 && e->n_ranks == 0 && !e->time_passes && e->sb_allowed && e->pts.n == 0 && e->soft.n == 0 && !e->ipa.on &&
         e->global_offset == 0 && e->n_global == e->n) {
-        int sh = 8;
-        while (sh <= kSbMaxShift && ((e->n_pad + ((int64_t)1 << sh) - 1) >> sh) > kSbMaxBlocks) sh++;
+        // a lap of the ring at a time wants blocks of <= K nodes (one stretch boundary per block at most) that one wave reads: 64 ... 256
+        // nodes; K >= 100 whenever a profile with Score plugins samples (schedule_one.go:697-723), so only K = 1 (no Score plugin) and
+        // snapshots beyond 8192 x 256 nodes stay on the cycle-at-a-time form
+        int sh = kLapMinShift;
+        auto blocks_at = [&](int x) { return (e->n_pad + ((int64_t)1 << x) - 1) >> x; };
+        while (sh < kLapMaxShift && blocks_at(sh) > 2048 && ((int64_t)2 << sh) <= e->smp_K) sh++;
+        if (const char *f = getenv("CCSIM_SB_SHIFT")) sh = atoi(f); // test knob
+        e->sb_laps = e->sb_allowed == 1 && sh >= kLapMinShift && sh <= kLapMaxShift && ((int64_t)1 << sh) <= e->smp_K && blocks_at(sh) <= kSbMaxBlocks;
+        if (!e->sb_laps) {
+            sh = 8;
+            while (sh <= kSbMaxShift && blocks_at(sh) > kSbMaxBlocks) sh++;
+        }
         if (sh <= kSbMaxShift) {
-            const int blocks = (int)((e->n_pad + ((int64_t)1 << sh) - 1) >> sh);
+            const int blocks = (int)blocks_at(sh);
             if (!e->d_sb_memo) {
                 int rc2;
                 if ((rc2 = dev_alloc(e, &e->d_sb_memo, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_fc, (size_t)kSbMaxBlocks, e->allocs)) ||
@@ -1885,26 +1897,40 @@ static int run_cw(ccsim_engine *e) {
 
 // ---- the sampled search of one template without topology-coupled plugins on resident block summaries (ccsim_sampled.h) ----
 static int run_sb(ccsim_engine *e) {
-    static_assert(sizeof(SbLds) <= 160 * 1024, "k_sb_cycles' LDS image must fit one CU");
+    static_assert(sizeof(SbLds) <= 160 * 1024 && sizeof(LapLds) <= 160 * 1024, "the cycle kernels' LDS images must fit one CU");
     HIPCHK(e, hipSetDevice(e->device));
     if (!e->sb_attr_set) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
         HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
         e->sb_attr_set = true;
     }
-    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, 1024};
+    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : 1024, nullptr, 65536};
+    if (getenv("CCSIM_SB_PROF") && atoi(getenv("CCSIM_SB_PROF"))) {
+        if (!e->d_sb_prof) {
+            int rc2;
+            if ((rc2 = dev_alloc(e, &e->d_sb_prof, (size_t)8, e->allocs))) return rc2;
+        }
+        HIPCHK(e, hipMemsetAsync(e->d_sb_prof, 0, sizeof(unsigned long long) * 8, e->stream));
+        a.prof = e->d_sb_prof;
+    }
     if (const char *f = getenv("CCSIM_SB_CYCLES")) a.max_cycles = atoi(f) > 0 ? atoi(f) : a.max_cycles; // tuning / test knob: cycles per launch
+    if (const char *f = getenv("CCSIM_SB_SLOW_FLOOR")) a.slow_floor = atoll(f);                          // test knob: see SbArgs
+    const bool narrow = e->cols.narrow && e->pod.nx == 0;
     int idle = 0;
     for (;;) {
         const int64_t placed0 = e->h_state->placed;
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         for (int rep = 0; rep < 4; rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
-            if (e->cols.narrow && e->pod.nx == 0) {
-                hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
-                hipLaunchKernelGGL((k_sb_cycles<true>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
+            if (narrow) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            if (e->sb_laps) {
+                if (narrow) hipLaunchKernelGGL((k_sb_laps<true>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
+                else hipLaunchKernelGGL((k_sb_laps<false>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
             } else {
-                hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
-                hipLaunchKernelGGL((k_sb_cycles<false>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
+                if (narrow) hipLaunchKernelGGL((k_sb_cycles<true>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
+                else hipLaunchKernelGGL((k_sb_cycles<false>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
             }
         }
         HIPCHK(e, hipGetLastError());
@@ -1915,9 +1941,9 @@ static int run_sb(ccsim_engine *e) {
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->kernel_ms += ms;
         if (getenv("CCSIM_SB_DEBUG"))
-            fprintf(stderr, "[ccsim sb] placed %lld rounds %lld scans %lld done %d dirty %d mt_a %d ma_a %d start %lld launches %d K %lld blocks %d shift %d\n", (long long)e->h_state->placed,
+            fprintf(stderr, "[ccsim sb] placed %lld rounds %lld scans %lld done %d dirty %d mt_a %d ma_a %d start %lld launches %d K %lld blocks %d shift %d laps %d (%d) slow %d\n", (long long)e->h_state->placed,
                     (long long)e->h_state->rounds, (long long)e->h_state->scans, e->h_state->done, e->h_state->sb_dirty, e->h_state->mt_a, e->h_state->ma_a,
-                    (long long)e->h_state->smp_start, e->h_state->sb_cycles, (long long)e->h_state->smp_K, e->sb_blocks, e->sb_shift);
+                    (long long)e->h_state->smp_start, e->h_state->sb_cycles, (long long)e->h_state->smp_K, e->sb_blocks, e->sb_shift, (int)e->sb_laps, e->h_state->sb_laps, e->h_state->sb_slow);
         e->pass_launches = e->h_state->sb_cycles; // (ccsim_report.pass_launches: launches of the cycle kernel that ran -- 0 on every other path of the sampled search)
         if (e->h_state->done) return 0;
         idle = e->h_state->placed == placed0 ? idle + 1 : 0;
@@ -3165,6 +3191,21 @@ extern "C" int ccsim_debug_coupled(ccsim_engine *e, int64_t *out8) {
     out8[0] = e->have_pod && e->cw_ok ? 1 : 0;
     if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback, out8[5] = e->h_state->cw_fast_windows, out8[6] = e->h_state->cw_full_windows, out8[7] = e->h_state->cw_swept;
     out8[3] = e->cw_ok ? e->cw_plan.window : 0, out8[4] = e->cw_ok ? e->cw_plan.list_len : 0;
+    return 0;
+}
+
+// measurement aid: which form the last sampled search took (ccsim_sampled.h)
+extern "C" int ccsim_debug_sampled(ccsim_engine *e, int64_t *out8) {
+    if (!e || !out8) return -EINVAL;
+    for (int i = 0; i < 16; i++) out8[i] = 0;
+    if (e->d_sb_prof && e->sb_run) {
+        HIPCHK(e, hipSetDevice(e->device));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipMemcpy(out8 + 8, e->d_sb_prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));
+    }
+    if (!e->h_state || !e->begun || !e->sb_run) return 0;
+    out8[0] = 1, out8[1] = e->sb_laps ? 1 : 0, out8[2] = e->h_state->sb_cycles, out8[3] = e->h_state->sb_laps, out8[4] = e->h_state->sb_slow;
+    out8[5] = e->sb_shift, out8[6] = e->sb_blocks, out8[7] = e->smp_K;
     return 0;
 }
 

@@ -233,7 +233,8 @@ struct DevState {
     int32_t cw_sweeps, cw_swept;              // rounds that kernel resolved at once, and the placements in them (ccsim_coupled.h `sweep`)
     // the sampled search on resident block summaries (ccsim_sampled.h)
     int32_t sb_dirty;        // 1 = memo and summaries do not describe the columns under (mt_a, ma_a): k_sb_build runs before the next cycle
-    int32_t sb_cycles;       // launches of k_sb_cycles that ran (diagnostics: did this path take the run)
+    int32_t sb_cycles;       // launches of k_sb_cycles / k_sb_laps that ran (diagnostics: did this path take the run)
+    int32_t sb_laps, sb_slow; // k_sb_laps: laps of the ring evaluated, stretches re-evaluated node by node under their own maxima
     // persistent batched launch (ccsim_persist.h): the normalization maxima the launch started with (the next launch's hint)
     int32_t p_mt0, p_ma0;
 };

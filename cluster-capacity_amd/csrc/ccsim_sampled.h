@@ -23,6 +23,10 @@
 #pragma once
 #include "ccsim_level.h"
 
+#ifndef CCSIM_LAP_THREADS
+#define CCSIM_LAP_THREADS 512 // the workgroup of k_sb_laps (a build-time A/B knob: 256, 512, 1024)
+#endif
+
 namespace ccsim {
 
 constexpr int kSbThreads = 256;
@@ -40,6 +44,8 @@ struct SbArgs {
     uint32_t *sb_mx;            // [n_blocks] (max PreferNoSchedule count << 16) | max preferred-affinity sum, over the feasible nodes
     int32_t *log;
     int32_t shift, n_blocks, max_cycles;
+    unsigned long long *prof; // k_sb_laps, measurement runs (CCSIM_SB_PROF=1): 10 ns ticks per phase, summed over the run; else nullptr
+    int64_t slow_floor; // k_sb_laps: stretches whose maxima differ from the assumed ones are re-evaluated node by node while they cover <= max(this, N / 4) nodes
 };
 
 // one node under the assumed maxima: TotalScore, or -1 (the wide path: any snapshot; the narrow mirrors give the same number by construction)
@@ -95,6 +101,30 @@ __global__ __launch_bounds__(256) void k_sb_build(SbArgs a) {
         for (int w = 1; w < 4; w++) fc += s_fc[w], bmt = s_mt[w] > bmt ? s_mt[w] : bmt, bma = s_ma[w] > bma ? s_ma[w] : bma, best = s_k[w] > best ? s_k[w] : best;
         a.sb_fc[blockIdx.x] = fc, a.sb_key[blockIdx.x] = best, a.sb_mx[blockIdx.x] = (bmt << 16) | bma;
     }
+}
+
+// NodeInfo.update for one more clone on node i (S/framework/types.go:409-428; schedule_one.go:967-984 assume), and the node's memo word
+// under the assumed maxima afterwards.  The caller has invalidated its L1 if the row may have been written before in this launch.
+template <bool NARROW>
+__device__ __forceinline__ int32_t sb_place(const SbArgs &a, const NarrowPod &npod, int64_t i, uint32_t mt_a, uint32_t ma_a) {
+    NodeRegs<kMaxExtra> nd;
+    int32_t na0 = 0, na1 = 0;
+    if (NARROW) na0 = a.c.a32[0][i], na1 = a.c.a32[1][i];
+    load_one<kMaxExtra>(a.c, a.p, i, nd);
+    node_apply<kMaxExtra>(a.p, nd, 1);
+    store_dyn<kMaxExtra>(a.c, a.p, i, nd, 1);
+    int32_t nm;
+    if (NARROW) { // (the lossless mirrors: the same number as the wide path, ccsim_kernels.h "NARROW arithmetic")
+        const int32_t nr0 = (int32_t)nd.r_cpu, nr1 = (int32_t)(nd.r_mem >> a.c.mem_shift), nz0 = (int32_t)nd.z_cpu, nz1 = (int32_t)(nd.z_mem >> a.c.mem_shift);
+        nm = -1;
+        if ((nd.w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, nd.a_pods, nd.npods)) {
+            const uint32_t cnt = (nd.w >> kStatCntShift) & kStatCntMask, aff = nd.w & kStatAffMask, img = (nd.w >> kStatImgShift) & kStatImgMask;
+            nm = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) + dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1));
+        }
+    } else
+        nm = sb_node_score(a.p, nd, mt_a, ma_a);
+    __hip_atomic_store((uint32_t *)(a.memo + i), (uint32_t)nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return nm;
 }
 
 struct SbLds {
@@ -356,8 +386,6 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
         fetch(pend_blk, mp, wp);
         if (tid == 0) {
             const int64_t i = g;
-            NodeRegs<kMaxExtra> nd;
-            int32_t na0 = 0, na1 = 0;
             // The node may have won before in THIS launch: its columns were rewritten by this very thread, and the CU's vector L1 does not
             // take a store's data -- a plain load would hit the line as it was fetched for the earlier placement and the update below
             // would be lost (measured: with the 6 KB a cycle of this kernel reads, such lines survive; placements went astray after a
@@ -365,21 +393,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
             // front of it waits for the LAST cycle's stores (long done by now): from the coming barrier on, that cycle's memo word is in L2.
             __threadfence();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (NARROW) na0 = a.c.a32[0][i], na1 = a.c.a32[1][i];
-            load_one<kMaxExtra>(a.c, a.p, i, nd);
-            node_apply<kMaxExtra>(a.p, nd, 1);
-            store_dyn<kMaxExtra>(a.c, a.p, i, nd, 1);
-            int32_t nm;
-            if (NARROW) { // (the lossless mirrors: the same number as the wide path, ccsim_kernels.h "NARROW arithmetic")
-                const int32_t nr0 = (int32_t)nd.r_cpu, nr1 = (int32_t)(nd.r_mem >> a.c.mem_shift), nz0 = (int32_t)nd.z_cpu, nz1 = (int32_t)(nd.z_mem >> a.c.mem_shift);
-                nm = -1;
-                if ((nd.w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, nd.a_pods, nd.npods)) {
-                    const uint32_t cnt = (nd.w >> kStatCntShift) & kStatCntMask, aff = nd.w & kStatAffMask, img = (nd.w >> kStatImgShift) & kStatImgMask;
-                    nm = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) + dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1));
-                }
-            } else
-                nm = sb_node_score(a.p, nd, mt_a, ma_a);
-            __hip_atomic_store((uint32_t *)(a.memo + i), (uint32_t)nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t nm = sb_place<NARROW>(a, npod, i, mt_a, ma_a);
             L.nm2 = L.nm, L.nm2_idx = L.nm_idx;
             L.nm = nm, L.nm_idx = i;
             if (nm < 0) L.fc[pend_blk] -= 1; // (the ring scan of the next cycle reads it; the summary proper follows from the words fetched above)
@@ -431,6 +445,466 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
         S.sb_dirty = dirty;
         if (dirty) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
         S.sb_cycles += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_sb_laps (round 6): the same search a LAP of the ring at a time.
+//
+// The next cycle starts exactly at the node this cycle stopped at -- its (K+1)-th feasible node (:538-539 with :655-662) -- the winner
+// lies among the K kept nodes, and a placement changes that one node.  So with F feasible nodes at ring ranks 0 .. F-1 from the start
+// index, cycle j keeps ranks [jK, (j+1)K) and stops at rank (j+1)K for every j < J = (F-1) / K: the J cycles of one lap of the ring
+// read disjoint stretches that no earlier cycle of the lap has written, and their normalization maxima are over their own K nodes.
+// They are evaluated side by side from the state at the start of the lap (tests/sampled_lap_model.py is this kernel in Python, checked
+// against the oracle's visiting loop on the CPU):
+//   1. ring prefix of the blocks' feasible counts (LDS): a block that holds a rank jK is CUT by a stretch boundary, every other block
+//      lies wholly inside one stretch and contributes its summary to it (K >= block size: one boundary per segment at most);
+//   2. the cut blocks, one wave each, node by node (the one dependent trip to L2 of the evaluation): the feasible nodes before the
+//      boundary go to the stretch that ends there, the boundary node and those behind it to the next;
+//   3. a stretch whose kept nodes' maxima differ from the assumed ones is re-evaluated node by node under its own (TotalScore is
+//      static part + state part: the score under other maxima follows from the memo word and the static word) -- unless such
+//      stretches cover more than a quarter of the ring: then the first of them ends the lap and everything is rebuilt under its maxima;
+//   4. the J placements by J lanes of one wave (disjoint nodes), the winners' block summaries by the other waves meanwhile.
+// F <= K is the degenerate lap of one stretch without a boundary (every node is visited, the start index stays).  One workgroup: a lap
+// is ~40 KB of loads and two dependent trips to L2; what it needs from the rest of the chip is nothing, and a grid-wide barrier per
+// lap would cost more than the lap.
+constexpr int kLapThreads = CCSIM_LAP_THREADS, kLapWaves = kLapThreads / 64;
+constexpr int kLapCuts = 32, kLapMaxJ = kLapCuts - 1;  // stretches per lap: cuts 0 .. J
+constexpr int kLapRounds = kLapCuts / kLapWaves;       // cuts (and winners) per wave
+constexpr int kLapMinShift = 6, kLapMaxShift = 8;      // a cut block is one wave's: 1, 2 or 4 consecutive nodes per lane
+constexpr int kLapNP = (1 << kLapMaxShift) / 64;
+constexpr uint32_t kLapOver = 1u, kLapHitT = 2u, kLapHitA = 4u; // a stretch's maxima equal the assumed ones iff its flags are kLapHitT | kLapHitA
+
+struct LapLds {
+    uint32_t fc[kSbMaxBlocks];
+    unsigned long long key[kSbMaxBlocks];
+    uint32_t mx[kSbMaxBlocks];
+    // per stretch j: the best kept node, separately for the nodes at or behind the lap's start index [0] and before it [1] (the ring wraps
+    // once: inside either part visiting order = index order, so the summaries' absolute keys compare as they are; part [0] comes first);
+    // flags: a kept node above an assumed maximum / holding the assumed taint maximum / holding the assumed affinity maximum
+    unsigned long long s_key[2][kLapCuts];
+    uint32_t s_flag[kLapCuts];
+    // per cut c: cut 0 is the start index, cut j the boundary between stretch j - 1 and stretch j (its node = where cycle j - 1 stopped)
+    int32_t cut_blk[kLapCuts], cut_need[kLapCuts], cut_kind[kLapCuts]; // kind 0: a whole block, 1: the start block before the start index
+    int32_t cut_node[kLapCuts];
+    uint32_t cut_tail[kLapCuts]; // feasible nodes of the cut's block at or behind (index >=) its node, as of the lap's start
+    int32_t nm[kLapCuts], g[kLapCuts]; // the winners and their memo words after the placements
+    uint32_t w_scan[kLapWaves], w_mt[kLapWaves], w_ma[kLapWaves];
+    unsigned long long w_key[kLapWaves];
+};
+
+// inclusive prefix sum across the 64 lanes: the DPP steps of wave_sum_u32_dpp, without the final broadcast
+__device__ __forceinline__ uint32_t lap_wave_incl(uint32_t v) {
+    CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x111, 0xf) CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x112, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x114, 0xf) CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x118, 0xf)
+    CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x142, 0xa) CCSIM_DPP_STEP32(v, 0u, op_add_u32, 0x143, 0xc)
+    return v;
+}
+// the greatest key among the lanes with `in` set, lanes ordered by index within one part of the ring: highest score, then the lowest lane
+__device__ __forceinline__ unsigned long long lap_wave_best(bool in, unsigned long long k) {
+    const uint32_t sc = in ? (uint32_t)(k >> kIdxBits) : 0u, top = wave_max_u32(sc);
+    if (top == 0) return 0ull;
+    const int l = __ffsll((long long)__ballot(in && sc == top)) - 1;
+    return (unsigned long long)lane_bcast_i64((int64_t)k, l);
+}
+__device__ __forceinline__ uint32_t lap_flags(uint32_t cnt, uint32_t aff, uint32_t mt_a, uint32_t ma_a) {
+    return ((cnt > mt_a || aff > ma_a) ? kLapOver : 0u) | (cnt == mt_a ? kLapHitT : 0u) | (aff == ma_a ? kLapHitA : 0u);
+}
+__device__ __forceinline__ uint32_t lap_wave_or3(bool in, uint32_t f) { // OR of 3-bit flags over the lanes with `in` set: three ballots
+    return (__ballot(in && (f & 1u)) ? 1u : 0u) | (__ballot(in && (f & 2u)) ? 2u : 0u) | (__ballot(in && (f & 4u)) ? 4u : 0u);
+}
+
+template <bool NARROW>
+__global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds_raw[];
+    LapLds &L = *reinterpret_cast<LapLds *>(sb_lds_raw);
+    DevState &S = *a.st;
+    if (S.done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = a.n_blocks, sh = a.shift, NP = (1 << sh) / 64; // NP in {1, 2, 4}
+    const int32_t N = (int32_t)a.c.n;
+    const uint32_t K = (uint32_t)S.smp_K;
+    const int64_t limit = S.limit, log_cap = S.log_cap;
+    const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
+    const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
+    int32_t start = (int32_t)S.smp_start;
+    int64_t placed = S.placed, rounds = S.rounds, scans = S.scans, evaluated = S.evaluated, winner = S.winner;
+    int32_t last_feasible = S.last_feasible, last_evaluated = S.last_evaluated, done = 0, dirty = 0, laps = 0, slow = 0;
+    uint32_t new_mt = mt_a, new_ma = ma_a;
+    auto ringpos = [&](int32_t i) -> int32_t { return i >= start ? i - start : i + N - start; };
+    // one block, NP consecutive nodes per lane.  Plain (vector) loads: every wave invalidates its L1 at the start of a lap, and what
+    // the lap before wrote was released to L2 by the committing wave before the barrier in front of that
+    auto fetch = [&](int blk, int32_t *m, uint32_t *w) {
+        const int64_t i0 = ((int64_t)blk << sh) + (int64_t)lane * NP;
+        if (NP == 4) {
+            const int4 x = *reinterpret_cast<const int4 *>(a.memo + i0);
+            const uint4 y = *reinterpret_cast<const uint4 *>(a.c.stat + i0);
+            m[0] = x.x, m[1] = x.y, m[2] = x.z, m[3] = x.w, w[0] = y.x, w[1] = y.y, w[2] = y.z, w[3] = y.w;
+        } else if (NP == 2) {
+            const int2 x = *reinterpret_cast<const int2 *>(a.memo + i0);
+            const uint2 y = *reinterpret_cast<const uint2 *>(a.c.stat + i0);
+            m[0] = x.x, m[1] = x.y, m[2] = m[3] = -1, w[0] = y.x, w[1] = y.y, w[2] = w[3] = 0;
+        } else
+            m[0] = a.memo[i0], m[1] = m[2] = m[3] = -1, w[0] = a.c.stat[i0], w[1] = w[2] = w[3] = 0;
+    };
+    {
+        uint32_t ft = 0;
+        for (int b = tid; b < nb; b += kLapThreads) {
+            const uint32_t f = a.sb_fc[b];
+            L.fc[b] = f, L.key[b] = a.sb_key[b], L.mx[b] = a.sb_mx[b], ft += f;
+        }
+        ft = wave_sum_u32_dpp(ft);
+        if (lane == 0) L.w_scan[wave] = ft;
+        if (wave == 0) { // the start block's feasible nodes at or behind the start index
+            int32_t m[kLapNP];
+            uint32_t w[kLapNP];
+            fetch(start >> sh, m, w);
+            uint32_t t = 0;
+#pragma unroll
+            for (int k = 0; k < kLapNP; k++) t += (m[k] >= 0 && ((start >> sh) << sh) + lane * NP + k >= start) ? 1u : 0u;
+            t = wave_sum_u32_dpp(t);
+            if (lane == 0) L.cut_tail[0] = t;
+        }
+    }
+    __syncthreads();
+    uint32_t Ftotal = 0;
+    for (int w = 0; w < kLapWaves; w++) Ftotal += L.w_scan[w];
+    uint32_t tailF = L.cut_tail[0];
+    __syncthreads();
+    int64_t budget = a.max_cycles;
+    const int E = (nb - 1 + kLapThreads - 1) / kLapThreads; // ring entries per thread
+    const int64_t slow_cap = a.slow_floor > N / 4 ? a.slow_floor : N / 4;
+    unsigned long long t_prev = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull, pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LAP_TICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+
+    while (!done && !dirty && budget > 0) {
+        if (Ftotal == 0) { // schedule_one.go:448-454: every node was visited, none passed
+            done = DONE_UNSCHEDULABLE, rounds += 1, scans += 1, last_feasible = 0, last_evaluated = N, evaluated += N, winner = -1;
+            break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (see fetch)
+        const bool all = Ftotal <= K; // fewer feasible nodes than wanted: the search visits every node (:538: processed = N)
+        int J = all ? 1 : (int)((Ftotal - 1) / K < (uint32_t)kLapMaxJ ? (Ftotal - 1) / K : (uint32_t)kLapMaxJ);
+        if (limit > 0 && limit - placed < J) J = (int)(limit - placed); // (the stretches behind the limit are never looked at)
+        if (budget < J) J = (int)budget;
+        const int sb = start >> sh;
+        if (tid < kLapCuts) L.s_key[0][tid] = 0, L.s_key[1][tid] = 0, L.s_flag[tid] = 0, L.cut_blk[tid] = -1;
+        // ---- 1. ring prefix over the whole blocks: entry r = 1 .. nb - 1 is block (sb + r) mod nb
+        const int r_lo = tid * E + 1, r_hi = (tid + 1) * E < nb - 1 ? (tid + 1) * E : nb - 1;
+        uint32_t ls = 0;
+        for (int r = r_lo; r <= r_hi; r++) {
+            int b = sb + r;
+            b = b >= nb ? b - nb : b;
+            ls += L.fc[b];
+        }
+        const uint32_t ils = lap_wave_incl(ls);
+        if (lane == 63) L.w_scan[wave] = ils;
+        __syncthreads(); // ---- barrier 1
+        LAP_TICK(0);
+        uint32_t fullF = 0, before = 0;
+#pragma unroll
+        for (int w = 0; w < kLapWaves; w++) {
+            const uint32_t z = L.w_scan[w];
+            fullF += z, before += w < wave ? z : 0u;
+        }
+        if (tid == 0) { // the start block before the start index: the last segment of the ring
+            const uint32_t p_head = tailF + fullF, headF = L.fc[sb] - tailF;
+            if (all) {
+                if (headF > 0) L.cut_blk[1] = sb, L.cut_need[1] = 0x7fffffff, L.cut_kind[1] = 1; // (all of it belongs to the one stretch)
+            } else if (p_head <= (uint32_t)J * K && (uint32_t)J * K < p_head + headF)
+                L.cut_blk[J] = sb, L.cut_need[J] = (int32_t)((uint32_t)J * K - p_head), L.cut_kind[J] = 1;
+        }
+        // ---- the whole blocks: which stretch, or cut by which boundary.  Threads follow the ring: a thread's (stretch, part) slot
+        // changes rarely along its entries, and across a wave's lanes the first and the last slot cover almost every lane.
+        {
+            uint32_t run = tailF + before + ils - ls;
+            int cur = -1;
+            unsigned long long ak = 0;
+            uint32_t af = 0;
+            uint32_t j = all ? 0u : run / K, lo = j * K; // (one division per thread and lap; then by steps: a block holds at most K feasible nodes)
+            for (int r = r_lo; r <= r_hi; r++) {
+                int b = sb + r;
+                const bool wrapped = b >= nb;
+                b = wrapped ? b - nb : b;
+                const uint32_t f = L.fc[b];
+                if (f == 0) continue;
+                if (!all) {
+                    if (run >= lo + K) j += 1, lo += K;
+                    int jt = -1;
+                    if (j >= 1 && run == lo) jt = (int)j; // the boundary node is this block's first feasible node
+                    else if (lo + K < run + f) jt = (int)j + 1;
+                    if (jt >= 0) {
+                        if (jt <= J) L.cut_blk[jt] = b, L.cut_need[jt] = (int32_t)((uint32_t)jt * K - run), L.cut_kind[jt] = 0;
+                        run += f;
+                        continue;
+                    }
+                }
+                if ((int)j < J) {
+                    const int slot = (int)j + (wrapped ? kLapCuts : 0);
+                    if (slot != cur) {
+                        if (cur >= 0) atomicMax(&L.s_key[cur >> 5][cur & 31], ak), atomicOr(&L.s_flag[cur & 31], af);
+                        cur = slot, ak = 0, af = 0;
+                    }
+                    const unsigned long long k = L.key[b];
+                    ak = k > ak ? k : ak;
+                    const uint32_t x = L.mx[b];
+                    af |= lap_flags(x >> 16, x & 0xffffu, mt_a, ma_a);
+                }
+                run += f;
+            }
+            const unsigned long long have_m = __ballot(cur >= 0);
+            if (have_m) { // one LDS atomic per (wave, slot) for the first and the last slot of the wave; the lanes in between (rare) on their own
+                const int s0 = lane_bcast_i32(cur, __ffsll((long long)have_m) - 1), s1 = lane_bcast_i32(cur, 63 - __clzll((long long)have_m));
+                {
+                    const bool in = cur == s0;
+                    const unsigned long long k = lap_wave_best(in, ak);
+                    const uint32_t f = lap_wave_or3(in, af);
+                    if (lane == 0) atomicMax(&L.s_key[s0 >> 5][s0 & 31], k), atomicOr(&L.s_flag[s0 & 31], f);
+                }
+                if (s1 != s0) {
+                    const bool in = cur == s1;
+                    const unsigned long long k = lap_wave_best(in, ak);
+                    const uint32_t f = lap_wave_or3(in, af);
+                    if (lane == 0) atomicMax(&L.s_key[s1 >> 5][s1 & 31], k), atomicOr(&L.s_flag[s1 & 31], f);
+                }
+                if (cur >= 0 && cur != s0 && cur != s1) atomicMax(&L.s_key[cur >> 5][cur & 31], ak), atomicOr(&L.s_flag[cur & 31], af);
+            }
+        }
+        __syncthreads(); // ---- barrier 2: every cut is registered
+        LAP_TICK(1);
+        // ---- 2. the cut blocks node by node: cut c is wave (c mod waves)'s.  All loads first, then the ranks.
+        {
+            int32_t cm[kLapRounds][kLapNP];
+            uint32_t cw[kLapRounds][kLapNP];
+            int cb[kLapRounds];
+#pragma unroll
+            for (int rd = 0; rd < kLapRounds; rd++) {
+                const int c = wave + rd * kLapWaves;
+                cb[rd] = c == 0 ? sb : (c <= J ? L.cut_blk[c] : -1);
+                if (cb[rd] >= 0) fetch(cb[rd], cm[rd], cw[rd]);
+            }
+#pragma unroll
+            for (int rd = 0; rd < kLapRounds; rd++) {
+                const int c = wave + rd * kLapWaves;
+                if (cb[rd] < 0) continue; // (wave-uniform)
+                const int kind = c == 0 ? 2 : L.cut_kind[c];
+                const int32_t need = c == 0 ? 0 : L.cut_need[c];
+                const int32_t i0 = (cb[rd] << sh) + lane * NP;
+                const bool part1 = kind == 1 || (kind == 0 && cb[rd] < sb); // the nodes of this segment lie before the lap's start index
+                uint32_t cnt = 0, cnt_all = 0;
+#pragma unroll
+                for (int k = 0; k < kLapNP; k++) {
+                    const bool inseg = kind == 0 || (kind == 1 ? i0 + k < start : i0 + k >= start);
+                    cnt += (cm[rd][k] >= 0 && inseg) ? 1u : 0u, cnt_all += cm[rd][k] >= 0 ? 1u : 0u;
+                }
+                const uint32_t incl = lap_wave_incl(cnt);
+                int32_t rank = (int32_t)(incl - cnt);
+                unsigned long long pk = 0, nk = 0;
+                uint32_t pfl = 0, nfl = 0;
+                int32_t stop = -1;
+#pragma unroll
+                for (int k = 0; k < kLapNP; k++) {
+                    const int32_t i = i0 + k;
+                    const bool inseg = kind == 0 || (kind == 1 ? i < start : i >= start);
+                    if (cm[rd][k] >= 0 && inseg) {
+                        const unsigned long long key = make_key((int64_t)cm[rd][k], (int64_t)i);
+                        const uint32_t fl = lap_flags((cw[rd][k] >> kStatCntShift) & kStatCntMask, cw[rd][k] & kStatAffMask, mt_a, ma_a);
+                        if (rank < need) pk = key > pk ? key : pk, pfl |= fl;
+                        else {
+                            if (rank == need) stop = i;
+                            if (c < J) nk = key > nk ? key : nk, nfl |= fl;
+                        }
+                        rank += 1;
+                    }
+                }
+                if (c > 0) {
+                    const unsigned long long sm = __ballot(stop >= 0);
+                    stop = sm ? lane_bcast_i32(stop, __ffsll((long long)sm) - 1) : -1;
+                    const unsigned long long k = lap_wave_best(pk != 0, pk);
+                    const uint32_t f = lap_wave_or3(pk != 0, pfl);
+                    if (lane == 0 && k) atomicMax(&L.s_key[part1 ? 1 : 0][c - 1], k), atomicOr(&L.s_flag[c - 1], f);
+                } else
+                    stop = start;
+                if (c < J) {
+                    const unsigned long long k = lap_wave_best(nk != 0, nk);
+                    const uint32_t f = lap_wave_or3(nk != 0, nfl);
+                    if (lane == 0 && k) atomicMax(&L.s_key[part1 ? 1 : 0][c], k), atomicOr(&L.s_flag[c], f);
+                }
+                // feasible nodes of the block at or behind the cut's node: the segment's part behind the boundary, plus (a cut before
+                // the start index) the start block's nodes at or behind the start index
+                const uint32_t seg_f = (uint32_t)lane_bcast_i32((int32_t)incl, 63), blk_f = wave_sum_u32_dpp(cnt_all);
+                uint32_t t = c == 0 ? seg_f : (stop >= 0 ? seg_f - (uint32_t)need : 0u);
+                if (kind == 1) t += blk_f - seg_f;
+                if (lane == 0) L.cut_node[c] = stop, L.cut_tail[c] = t;
+            }
+        }
+        __syncthreads(); // ---- barrier 3: the stretches' keys and flags are complete
+        LAP_TICK(2);
+        // ---- 3. which stretches stand (every wave holds the lap's J stretches in its lanes 0 .. J - 1)
+        const bool have = lane < J;
+        unsigned long long key = 0;
+        if (have) {
+            const unsigned long long k0 = L.s_key[0][lane], k1 = L.s_key[1][lane];
+            key = (k1 >> kIdxBits) > (k0 >> kIdxBits) ? k1 : k0; // (on equal scores the part at or behind the start index: it is visited first)
+        }
+        const int32_t c0 = have ? L.cut_node[lane] : 0, c1 = have && !all ? L.cut_node[lane + 1] : 0;
+        const int32_t span = all ? N : ringpos(c1) - ringpos(c0);
+        const bool mism = have && L.s_flag[lane] != (kLapHitT | kLapHitA);
+        unsigned long long mm = __ballot(mism);
+        int Jc = J;
+        if (mm) {
+            // the true maxima of a stretch, node by node (all waves on one stretch at a time)
+            auto stretch_maxima = [&](int32_t first, int32_t sp, uint32_t &mt, uint32_t &ma) {
+                uint32_t x = 0, y = 0;
+                for (int32_t d = tid; d < sp; d += kLapThreads) {
+                    int32_t i = first + d;
+                    i = i >= N ? i - N : i;
+                    if (a.memo[i] >= 0) {
+                        const uint32_t w = a.c.stat[i], cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                        x = cnt > x ? cnt : x, y = aff > y ? aff : y;
+                    }
+                }
+                x = wave_max_u32(x), y = wave_max_u32(y);
+                if (lane == 0) L.w_mt[wave] = x, L.w_ma[wave] = y;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < kLapWaves; w++) x = L.w_mt[w] > x ? L.w_mt[w] : x, y = L.w_ma[w] > y ? L.w_ma[w] : y;
+                __syncthreads();
+                mt = x, ma = y;
+            };
+            const int32_t cover = (int32_t)wave_sum_u32_dpp(mism ? (uint32_t)span : 0u);
+            if (cover > slow_cap) { // rebuild under the first such stretch's maxima; the stretches before it stand
+                const int js = __ffsll((long long)mm) - 1;
+                Jc = js, dirty = 1, scans += 1;
+                stretch_maxima(lane_bcast_i32(c0, js), lane_bcast_i32(span, js), new_mt, new_ma);
+            } else {
+                while (mm) { // re-evaluated under its own maxima: TotalScore = memo word - static part under the assumed maxima + static part under its own
+                    const int js = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const int32_t first = lane_bcast_i32(c0, js), sp = lane_bcast_i32(span, js), rp0 = ringpos(first);
+                    uint32_t mtj, maj;
+                    stretch_maxima(first, sp, mtj, maj);
+                    const uint32_t g_ta = div_magic(mt_a), g_aa = div_magic(ma_a), g_tj = div_magic(mtj), g_aj = div_magic(maj);
+                    unsigned long long bk = 0; // a RING key here: the stretch may wrap
+                    for (int32_t d = tid; d < sp; d += kLapThreads) {
+                        int32_t i = first + d;
+                        i = i >= N ? i - N : i;
+                        const int32_t m = a.memo[i];
+                        if (m >= 0) {
+                            const uint32_t w = a.c.stat[i], cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+                            const int64_t sc = (int64_t)m - static_score(a.p, cnt, aff, 0u, mt_a, ma_a, g_ta, g_aa) + static_score(a.p, cnt, aff, 0u, mtj, maj, g_tj, g_aj);
+                            const unsigned long long rk = ((unsigned long long)(sc + 1) << kIdxBits) | (kIdxMask - (unsigned long long)(rp0 + d));
+                            bk = rk > bk ? rk : bk;
+                        }
+                    }
+                    bk = wave_max_u64(bk);
+                    if (lane == 0) L.w_key[wave] = bk;
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < kLapWaves; w++) bk = L.w_key[w] > bk ? L.w_key[w] : bk;
+                    __syncthreads();
+                    if (lane == js) { // back to an absolute key
+                        int32_t gi = start + (int32_t)(kIdxMask - (bk & kIdxMask));
+                        gi = gi >= N ? gi - N : gi;
+                        key = make_key((int64_t)(bk >> kIdxBits) - 1, (int64_t)gi);
+                    }
+                    slow += 1;
+                }
+            }
+        }
+        // ---- 4. the placements (schedule_one.go:967-984 assume -> NodeInfo.update) by the lanes of the last wave, one node each; the
+        // other waves fetch the winners' blocks meanwhile (winner j is wave (j mod waves)'s)
+        const int32_t g = lane < Jc ? (int32_t)key_index(key) : -1;
+        LAP_TICK(3);
+        if (wave == kLapWaves - 1) {
+            if (lane < Jc) {
+                const int32_t nm = sb_place<NARROW>(a, npod, (int64_t)g, mt_a, ma_a);
+                L.nm[lane] = nm, L.g[lane] = g;
+                if (a.log && placed + lane < log_cap) a.log[placed + lane] = g;
+            }
+            __threadfence(); // the rows and memo words are in L2 before anyone passes the barrier below
+            LAP_TICK(6);
+        }
+        {
+            int32_t pm[kLapRounds][kLapNP];
+            uint32_t pw[kLapRounds][kLapNP];
+            int pb[kLapRounds];
+#pragma unroll
+            for (int rd = 0; rd < kLapRounds; rd++) {
+                const int jw = wave + rd * kLapWaves;
+                pb[rd] = -1;
+                if (jw < Jc) pb[rd] = lane_bcast_i32(g, jw) >> sh, fetch(pb[rd], pm[rd], pw[rd]);
+            }
+            __syncthreads(); // ---- barrier 4: the winners' new memo words are in LDS (and in L2)
+            LAP_TICK(4);
+#pragma unroll
+            for (int rd = 0; rd < kLapRounds; rd++) {
+                const int jw = wave + rd * kLapWaves;
+                if (pb[rd] < 0) continue;
+                const int32_t i0 = (pb[rd] << sh) + lane * NP;
+                // the words fetched above may predate the placements: the winners' own come from LDS.  Two winners at most share a
+                // block, and they are neighbours (a stretch holds K >= block size feasible nodes)
+                for (int x = jw - 1; x <= jw + 1; x++)
+                    if (x >= 0 && x < Jc) {
+                        const int32_t gx = L.g[x], nx = L.nm[x];
+#pragma unroll
+                        for (int k = 0; k < kLapNP; k++)
+                            if (k < NP && i0 + k == gx) pm[rd][k] = nx;
+                    }
+                uint32_t pf = 0, pmt = 0, pma = 0;
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int k = 0; k < kLapNP; k++)
+                    if (pm[rd][k] >= 0) {
+                        const uint32_t cnt = (pw[rd][k] >> kStatCntShift) & kStatCntMask, aff = pw[rd][k] & kStatAffMask;
+                        pf += 1, pmt = cnt > pmt ? cnt : pmt, pma = aff > pma ? aff : pma;
+                        const unsigned long long k2 = make_key((int64_t)pm[rd][k], (int64_t)(i0 + k));
+                        pk = k2 > pk ? k2 : pk;
+                    }
+                pk = lap_wave_best(pk != 0, pk);
+                pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma);
+                if (lane == 0) {
+                    const int b = pb[rd];
+                    L.fc[b] = pf, L.key[b] = pk, L.mx[b] = (pmt << 16) | pma;
+                    a.sb_fc[b] = pf, a.sb_key[b] = pk, a.sb_mx[b] = (pmt << 16) | pma; // (the global copy stays current: the next launch reloads it)
+                }
+            }
+        }
+        // ---- the run state, identically in every thread
+        {
+            const int32_t ns = all ? start : L.cut_node[Jc]; // where the last committed cycle stopped
+            const uint32_t nt = L.cut_tail[all ? 0 : Jc];
+            const bool left = lane < Jc && L.nm[lane] < 0; // winners that are not feasible any more
+            const bool in_tail = left && (L.g[lane] >> sh) == (ns >> sh) && L.g[lane] >= ns;
+            const int n_left = __popcll(__ballot(left)), n_tail = __popcll(__ballot(in_tail));
+            if (Jc > 0) {
+                evaluated += all ? N : ringpos(ns);
+                last_evaluated = all ? N : ringpos(ns) - ringpos(L.cut_node[Jc - 1]);
+                last_feasible = (int32_t)(all ? Ftotal : K);
+                winner = lane_bcast_i32(g, Jc - 1);
+            }
+            placed += Jc, rounds += Jc, scans += Jc, budget -= Jc > 0 ? Jc : 1;
+            Ftotal -= (uint32_t)n_left;
+            tailF = nt - (uint32_t)n_tail;
+            start = ns;
+            laps += 1;
+            if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312
+        }
+        __syncthreads(); // ---- barrier 5: the summaries in LDS are the next lap's
+        LAP_TICK(5);
+    }
+#undef LAP_TICK
+    if (a.prof) {
+        if (tid == 0)
+            for (int i = 0; i < 6; i++) a.prof[i] += pf[i];
+        if (tid == kLapThreads - 64) a.prof[6] += pf[6]; // (the committing wave's own time: rows, memo words, fence)
+    }
+    if (tid == 0) {
+        S.smp_start = start, S.placed = placed, S.rounds = rounds, S.scans = scans, S.evaluated = evaluated, S.winner = winner;
+        S.last_feasible = last_feasible, S.last_evaluated = last_evaluated, S.done = done;
+        S.sb_dirty = dirty;
+        if (dirty) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
+        S.sb_cycles += 1, S.sb_laps += laps, S.sb_slow += slow;
     }
 }
 

@@ -473,6 +473,16 @@ int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out8);
  * wave spent in [8] staging, [9] minima set-up, [10] candidates' verdicts, [11] raw scores, [12] totals + argmax, [13] commit, [14] write-back;
  * [15] = cycles.  `out` holds 16 values.  Knobs (read by ccsim_set_pod): CCSIM_CW=0 disables the mode, CCSIM_CW_WINDOW, CCSIM_CW_LIST. */
 int ccsim_debug_coupled(ccsim_engine *e, int64_t *out16);
+/* ... and how the last sampled search (percentageOfNodesToScore < 100; S/schedule_one.go:610-723) of a template without topology-coupled
+ * plugins ran (csrc/ccsim_sampled.h): out8[0] = 1 if it ran on the resident block summaries, [1] = 1 if a lap of the ring at a time
+ * (k_sb_laps; 0: a cycle at a time, k_sb_cycles), [2] = launches of that kernel, [3] = laps evaluated, [4] = stretches re-evaluated node
+ * by node under their own normalization maxima, [5] = log2 of the block size, [6] = blocks, [7] = K (numFeasibleNodesToFind);
+ * out[8..14] (with CCSIM_SB_PROF=1): 10 ns ticks k_sb_laps spent in [8] the ring prefix, [9] the whole blocks, [10] the cut blocks,
+ * [11] the decision (+ stretches re-evaluated), [12] waiting for the placements, [13] the winners' block summaries; [14] the committing
+ * wave's own time inside [12].  `out` holds 16 values.
+ * Knobs (read when a run begins; every value gives the same results): CCSIM_SB=0 three node passes per cycle, =2 a cycle at a time;
+ * CCSIM_SB_CYCLES cycles per launch; CCSIM_SB_SHIFT block size; CCSIM_SB_SLOW_FLOOR nodes below which differing maxima never rebuild. */
+int ccsim_debug_sampled(ccsim_engine *e, int64_t *out16);
 
 #ifdef __cplusplus
 }

@@ -327,3 +327,4 @@ int ccsim_debug_persist_prof(ccsim_engine *e, int64_t *out) { (void)e, (void)out
 int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_coupled(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
+int ccsim_debug_sampled(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }

@@ -28,6 +28,12 @@ def _check(ccref, nodes, pod, prof, limit):
                                                                                                         or prof.w_imagelocality or prof.w_topologyspread or prof.w_interpodaffinity)
     resident = sampled and not pod.spread and pod.ipa is None and os.environ.get("CCSIM_SB", "1") != "0"
     assert (got.pass_launches > 0) == resident, (got.pass_launches, resident)
+    info = e.sampled_info()
+    assert info["resident"] == resident
+    if resident:  # ... and a lap of the ring at a time (k_sb_laps, round 6) whenever a block of >= 64 nodes holds one stretch boundary at most
+        forced = int(os.environ.get("CCSIM_SB_SHIFT", "6"))
+        assert info["laps_form"] == (info["K"] >= (1 << forced) and os.environ.get("CCSIM_SB", "1") == "1"), info
+        assert not info["laps_form"] or (info["block"] <= info["K"] and info["laps"] > 0)
     if ref.stop == M.STOP_UNSCHEDULABLE:
         assert np.array_equal(got.hist, ref.hist)
         assert got.n_code_unschedulable == ref.n_code_unschedulable
@@ -52,15 +58,54 @@ def test_sampled_search_vs_oracle(ccref, cfg, n, pct, limit):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", [{"CCSIM_SB": "0"}, {"CCSIM_SB_CYCLES": "3"}, {"CCSIM_SB_CYCLES": "1"}], ids=["three-passes", "3-cycles-per-launch", "1-cycle-per-launch"])
+@pytest.mark.parametrize("knobs", [{"CCSIM_SB": "0"}, {"CCSIM_SB_CYCLES": "3"}, {"CCSIM_SB_CYCLES": "1"}, {"CCSIM_SB": "2"}, {"CCSIM_SB": "2", "CCSIM_SB_CYCLES": "3"},
+                                   {"CCSIM_SB_SHIFT": "7"}, {"CCSIM_SB_SHIFT": "8", "CCSIM_SB_SLOW_FLOOR": "0"}, {"CCSIM_SB_SHIFT": "6", "CCSIM_SB_SLOW_FLOOR": "0", "CCSIM_SB_CYCLES": "7"}],
+                         ids=["three-passes", "3-cycles-per-launch", "1-cycle-per-launch", "cycle-at-a-time", "cycle-at-a-time-3-per-launch", "blocks-of-128", "blocks-of-256-rebuild-early",
+                              "blocks-of-64-rebuild-early-7-per-launch"])
 @pytest.mark.parametrize("cfg,n,pct,limit", [("C3", 1000, 0, 0), ("C2", 5000, 10, 400), ("C3", 4096, 5, 0), ("C3", 777, 35, 0)])
 def test_sampled_search_forms_agree(ccref, monkeypatch, knobs, cfg, n, pct, limit):
-    """The three-pass cycle (what the SchedulePod seam, shards and coupled templates still take) and the resident form relaunched every few
-    cycles (the hand-over of the pending block summary, the start index, the assumed maxima between launches) against the oracle."""
+    """The three-pass cycle (what the SchedulePod seam, shards and coupled templates still take), the resident forms -- a lap of the ring at a
+    time (the default) and a cycle at a time (round 5's, CCSIM_SB=2) -- relaunched every few cycles (the hand-over of the summaries, the start
+    index, the assumed maxima between launches; a lap cut short by the launch's cycle budget), other block sizes, and the rebuild taken
+    instead of the node-by-node re-evaluation as soon as a stretch's maxima differ, against the oracle."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
     _check(ccref, nodes, pod, _with_pct(prof, pct), limit)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,n,pct,limit,floor", [("C3", 20_000, 5, 2500, None), ("C3", 20_000, 5, 2500, 0), ("C2", 60_000, 2, 3000, None), ("C3", 3000, 5, 0, None),
+                                                   ("C3", 3000, 5, 0, 0), ("C3", 600, 0, 0, None)])
+def test_sampled_search_many_laps_and_wraps(ccref, monkeypatch, cfg, n, pct, limit, floor):
+    """Laps of ~19 (49 at 2 %) independent cycles; every lap goes once round the ring, so a run is as many wraps as laps; 3000 nodes to the
+    end: the laps shrink to one stretch and then to the degenerate lap that visits every node (F <= K).  With and without the
+    node-by-node re-evaluation of stretches whose maxima differ from the assumed ones (floor 0: N / 4 nodes of them end the lap)."""
+    if floor is not None:
+        monkeypatch.setenv("CCSIM_SB_SLOW_FLOOR", str(floor))
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=21 + n)
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, pct), limit)
+    info = e.sampled_info()
+    assert info["laps_form"] and info["laps"] >= 3
+    if n >= 20_000:
+        k = ccref.num_feasible_nodes_to_find(pct, n)
+        assert info["laps"] <= 3 * (1 + got.placed * k // n)  # the laps really held ~ N / K cycles each
+    e.close()
+
+
+@pytest.mark.gpu
+def test_sampled_search_a_node_wins_in_consecutive_laps(ccref):
+    """Few nodes far better than the rest: the same node wins the stretch it lies in lap after lap -- its row and memo word are rewritten and
+    re-read every few microseconds by different lanes (the L1 / L2 visibility the kernel's fences are there for)."""
+    n = 4000
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=9)
+    big = np.arange(0, n, 157)
+    for c in range(len(nodes.alloc)):
+        nodes.alloc[c][big] *= 40
+    nodes.alloc_pods[big] = 4000
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, 5), 6000)
+    assert np.max(got.per_node_count) >= 40
+    e.close()
 
 
 @pytest.mark.gpu
