@@ -572,7 +572,7 @@ class Engine:
         d = {"resident": bool(out[0]), "laps_form": bool(out[1]), "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
              "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
         if out[3] and any(out[8:15]):  # CCSIM_SB_PROF=1: microseconds per lap, by phase
-            names = ["prefix", "whole_blocks", "cut_blocks", "decide", "wait_commit", "summaries", "commit_wave"]
+            names = ["find_cuts_update_tree", "cut_blocks_range_queries", "decide", "wait_commit", "leaves", "-", "commit_wave"]
             d["prof_us_per_lap"] = {k: round(out[8 + i] / 100.0 / out[3], 3) for i, k in enumerate(names)}
         return d
 

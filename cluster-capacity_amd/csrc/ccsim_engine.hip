@@ -1349,14 +1349,14 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     e->sb_run = false;
     if (mode == CCSIM_MODE_SEQUENTIAL && e->smp_K > 0 && e->n_ranks == 0 && !e->time_passes && e->sb_allowed && e->pts.n == 0 && e->soft.n == 0 && !e->ipa.on &&
         e->global_offset == 0 && e->n_global == e->n) {
-        // a lap of the ring at a time wants blocks of <= K nodes (one stretch boundary per block at most) that one wave reads: 64 ... 256
-        // nodes; K >= 100 whenever a profile with Score plugins samples (schedule_one.go:697-723), so only K = 1 (no Score plugin) and
-        // snapshots beyond 8192 x 256 nodes stay on the cycle-at-a-time form
-        int sh = kLapMinShift;
+        // a lap of the ring at a time wants blocks of <= K nodes (one stretch boundary per block at most) that one wave reads -- 256 nodes,
+        // or 64 on small snapshots -- and at most 4096 of them (the tree over them lives in LDS); K >= 100 whenever a profile with Score
+        // plugins samples (schedule_one.go:697-723), so only K = 1 (no Score plugin) and snapshots beyond 2^20 nodes stay on the
+        // cycle-at-a-time form
         auto blocks_at = [&](int x) { return (e->n_pad + ((int64_t)1 << x) - 1) >> x; };
-        while (sh < kLapMaxShift && blocks_at(sh) > 2048 && ((int64_t)2 << sh) <= e->smp_K) sh++;
+        int sh = e->smp_K >= 256 ? 8 : 6;
         if (const char *f = getenv("CCSIM_SB_SHIFT")) sh = atoi(f); // test knob
-        e->sb_laps = e->sb_allowed == 1 && sh >= kLapMinShift && sh <= kLapMaxShift && ((int64_t)1 << sh) <= e->smp_K && blocks_at(sh) <= kSbMaxBlocks;
+        e->sb_laps = e->sb_allowed == 1 && (sh == 6 || sh == 8) && ((int64_t)1 << sh) <= e->smp_K && blocks_at(sh) <= kLapMaxBlocks;
         if (!e->sb_laps) {
             sh = 8;
             while (sh <= kSbMaxShift && blocks_at(sh) > kSbMaxBlocks) sh++;
@@ -1902,8 +1902,10 @@ static int run_sb(ccsim_engine *e) {
     if (!e->sb_attr_set) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
         HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_cycles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SbLds)));
-        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
-        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
+        HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
         e->sb_attr_set = true;
     }
     SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : 1024, nullptr, 65536};
@@ -1926,8 +1928,13 @@ static int run_sb(ccsim_engine *e) {
             if (narrow) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
             else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
             if (e->sb_laps) {
-                if (narrow) hipLaunchKernelGGL((k_sb_laps<true>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
-                else hipLaunchKernelGGL((k_sb_laps<false>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
+                if (e->sb_shift == 8) {
+                    if (narrow) hipLaunchKernelGGL((k_sb_laps<true, 4>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
+                    else hipLaunchKernelGGL((k_sb_laps<false, 4>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
+                } else {
+                    if (narrow) hipLaunchKernelGGL((k_sb_laps<true, 1>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
+                    else hipLaunchKernelGGL((k_sb_laps<false, 1>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
+                }
             } else {
                 if (narrow) hipLaunchKernelGGL((k_sb_cycles<true>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);
                 else hipLaunchKernelGGL((k_sb_cycles<false>), dim3(1), dim3(kSbThreads), sizeof(SbLds), e->stream, a);

@@ -456,29 +456,32 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
 // index, cycle j keeps ranks [jK, (j+1)K) and stops at rank (j+1)K for every j < J = (F-1) / K: the J cycles of one lap of the ring
 // read disjoint stretches that no earlier cycle of the lap has written, and their normalization maxima are over their own K nodes.
 // They are evaluated side by side from the state at the start of the lap (tests/sampled_lap_model.py is this kernel in Python, checked
-// against the oracle's visiting loop on the CPU):
-//   1. ring prefix of the blocks' feasible counts (LDS): a block that holds a rank jK is CUT by a stretch boundary, every other block
-//      lies wholly inside one stretch and contributes its summary to it (K >= block size: one boundary per segment at most);
+// against the oracle's visiting loop on the CPU).  The block summaries are the leaves of a binary tree in LDS -- per node the best
+// (score, lowest index) key, the two maxima, the feasible count of its subtree -- so a lap costs O(J log blocks), not O(blocks):
+//   1. the block holding ring rank jK, by descent on the counts (J lanes of one wave): it is CUT by a stretch boundary; every block
+//      between two cuts lies wholly inside one stretch (K >= block size: one boundary per block at most);
 //   2. the cut blocks, one wave each, node by node (the one dependent trip to L2 of the evaluation): the feasible nodes before the
-//      boundary go to the stretch that ends there, the boundary node and those behind it to the next;
+//      boundary go to the stretch that ends there, the boundary node and those behind it to the next; the whole blocks of a stretch
+//      by a range query on the tree (J lanes of another wave, meanwhile);
 //   3. a stretch whose kept nodes' maxima differ from the assumed ones is re-evaluated node by node under its own (TotalScore is
 //      static part + state part: the score under other maxima follows from the memo word and the static word) -- unless such
 //      stretches cover more than a quarter of the ring: then the first of them ends the lap and everything is rebuilt under its maxima;
-//   4. the J placements by J lanes of one wave (disjoint nodes), the winners' block summaries by the other waves meanwhile.
+//   4. the J placements by J lanes of one wave (disjoint nodes), the winners' blocks re-read by the other waves meanwhile; their
+//      leaves, and -- level by level in one wave, while another finds the next lap's cuts -- the tree above them.
 // F <= K is the degenerate lap of one stretch without a boundary (every node is visited, the start index stays).  One workgroup: a lap
 // is ~40 KB of loads and two dependent trips to L2; what it needs from the rest of the chip is nothing, and a grid-wide barrier per
 // lap would cost more than the lap.
 constexpr int kLapThreads = CCSIM_LAP_THREADS, kLapWaves = kLapThreads / 64;
 constexpr int kLapCuts = 32, kLapMaxJ = kLapCuts - 1;  // stretches per lap: cuts 0 .. J
 constexpr int kLapRounds = kLapCuts / kLapWaves;       // cuts (and winners) per wave
-constexpr int kLapMinShift = 6, kLapMaxShift = 8;      // a cut block is one wave's: 1, 2 or 4 consecutive nodes per lane
-constexpr int kLapNP = (1 << kLapMaxShift) / 64;
+constexpr int kLapMaxBlocks = 4096;                    // leaves of the tree (2 x 4096 nodes x 16 B = 128 KiB of LDS)
 constexpr uint32_t kLapOver = 1u, kLapHitT = 2u, kLapHitA = 4u; // a stretch's maxima equal the assumed ones iff its flags are kLapHitT | kLapHitA
+static_assert(kLapWaves >= 2 && kLapCuts % kLapWaves == 0, "k_sb_laps: wave 0 finds the cuts while wave 1 brings the tree up to date");
 
 struct LapLds {
-    uint32_t fc[kSbMaxBlocks];
-    unsigned long long key[kSbMaxBlocks];
-    uint32_t mx[kSbMaxBlocks];
+    // heap order: node p has children 2p, 2p + 1; leaf of block b = T[nbp + b].  x, y = key; z = (max PreferNoSchedule count << 16) |
+    // max preferred-affinity sum over the subtree's feasible nodes; w = its feasible nodes
+    uint4 T[2 * kLapMaxBlocks];
     // per stretch j: the best kept node, separately for the nodes at or behind the lap's start index [0] and before it [1] (the ring wraps
     // once: inside either part visiting order = index order, so the summaries' absolute keys compare as they are; part [0] comes first);
     // flags: a kept node above an assumed maximum / holding the assumed taint maximum / holding the assumed affinity maximum
@@ -489,8 +492,9 @@ struct LapLds {
     int32_t cut_node[kLapCuts];
     uint32_t cut_tail[kLapCuts]; // feasible nodes of the cut's block at or behind (index >=) its node, as of the lap's start
     int32_t nm[kLapCuts], g[kLapCuts]; // the winners and their memo words after the placements
-    uint32_t w_scan[kLapWaves], w_mt[kLapWaves], w_ma[kLapWaves];
+    uint32_t w_mt[kLapWaves], w_ma[kLapWaves];
     unsigned long long w_key[kLapWaves];
+    uint32_t bc[4];
 };
 
 // inclusive prefix sum across the 64 lanes: the DPP steps of wave_sum_u32_dpp, without the final broadcast
@@ -513,15 +517,28 @@ __device__ __forceinline__ uint32_t lap_flags(uint32_t cnt, uint32_t aff, uint32
 __device__ __forceinline__ uint32_t lap_wave_or3(bool in, uint32_t f) { // OR of 3-bit flags over the lanes with `in` set: three ballots
     return (__ballot(in && (f & 1u)) ? 1u : 0u) | (__ballot(in && (f & 2u)) ? 2u : 0u) | (__ballot(in && (f & 4u)) ? 4u : 0u);
 }
+__device__ __forceinline__ uint32_t lap_pkmax(uint32_t a, uint32_t b) { // the two 16-bit maxima at once
+    const uint32_t hi = (a & 0xffff0000u) > (b & 0xffff0000u) ? (a & 0xffff0000u) : (b & 0xffff0000u), lo = (a & 0xffffu) > (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu);
+    return hi | lo;
+}
+__device__ __forceinline__ unsigned long long lap_key(const uint4 &n) { return ((unsigned long long)n.y << 32) | n.x; }
+// lanes of ONE wave go on to read what other lanes of it have just written to LDS
+__device__ __forceinline__ void lap_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
-template <bool NARROW>
+template <bool NARROW, int NP> // NP nodes per lane of a cut block: blocks of 64 x NP nodes
 __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds_raw[];
     LapLds &L = *reinterpret_cast<LapLds *>(sb_lds_raw);
     DevState &S = *a.st;
     if (S.done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = a.n_blocks, sh = a.shift, NP = (1 << sh) / 64; // NP in {1, 2, 4}
+    const int nb = a.n_blocks, sh = a.shift; // (1 << sh == 64 * NP)
+    int nbp = 2, levels = 1;
+    while (nbp < nb) nbp <<= 1, levels++;
     const int32_t N = (int32_t)a.c.n;
     const uint32_t K = (uint32_t)S.smp_K;
     const int64_t limit = S.limit, log_cap = S.log_cap;
@@ -540,42 +557,52 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
             const int4 x = *reinterpret_cast<const int4 *>(a.memo + i0);
             const uint4 y = *reinterpret_cast<const uint4 *>(a.c.stat + i0);
             m[0] = x.x, m[1] = x.y, m[2] = x.z, m[3] = x.w, w[0] = y.x, w[1] = y.y, w[2] = y.z, w[3] = y.w;
-        } else if (NP == 2) {
-            const int2 x = *reinterpret_cast<const int2 *>(a.memo + i0);
-            const uint2 y = *reinterpret_cast<const uint2 *>(a.c.stat + i0);
-            m[0] = x.x, m[1] = x.y, m[2] = m[3] = -1, w[0] = y.x, w[1] = y.y, w[2] = w[3] = 0;
         } else
-            m[0] = a.memo[i0], m[1] = m[2] = m[3] = -1, w[0] = a.c.stat[i0], w[1] = w[2] = w[3] = 0;
+            m[0] = a.memo[i0], w[0] = a.c.stat[i0];
     };
-    {
-        uint32_t ft = 0;
-        for (int b = tid; b < nb; b += kLapThreads) {
-            const uint32_t f = a.sb_fc[b];
-            L.fc[b] = f, L.key[b] = a.sb_key[b], L.mx[b] = a.sb_mx[b], ft += f;
+    // ---- the tree: leaves from the summaries k_sb_build (or the launch before) left, then level by level
+    for (int b = tid; b < nbp; b += kLapThreads) {
+        uint4 n = make_uint4(0u, 0u, 0u, 0u);
+        if (b < nb) {
+            const unsigned long long k = a.sb_key[b];
+            n = make_uint4((uint32_t)k, (uint32_t)(k >> 32), a.sb_mx[b], a.sb_fc[b]);
         }
-        ft = wave_sum_u32_dpp(ft);
-        if (lane == 0) L.w_scan[wave] = ft;
-        if (wave == 0) { // the start block's feasible nodes at or behind the start index
-            int32_t m[kLapNP];
-            uint32_t w[kLapNP];
-            fetch(start >> sh, m, w);
-            uint32_t t = 0;
-#pragma unroll
-            for (int k = 0; k < kLapNP; k++) t += (m[k] >= 0 && ((start >> sh) << sh) + lane * NP + k >= start) ? 1u : 0u;
-            t = wave_sum_u32_dpp(t);
-            if (lane == 0) L.cut_tail[0] = t;
+        L.T[nbp + b] = n;
+    }
+    for (int w = nbp >> 1; w >= 1; w >>= 1) {
+        __syncthreads();
+        for (int p = w + tid; p < 2 * w; p += kLapThreads) {
+            const uint4 c0 = L.T[2 * p], c1 = L.T[2 * p + 1];
+            const unsigned long long k0 = lap_key(c0), k1 = lap_key(c1), k = k0 > k1 ? k0 : k1;
+            L.T[p] = make_uint4((uint32_t)k, (uint32_t)(k >> 32), lap_pkmax(c0.z, c1.z), c0.w + c1.w);
         }
     }
+    if (wave == 0) { // the start block's feasible nodes at or behind the start index
+        int32_t m[NP];
+        uint32_t w[NP];
+        fetch(start >> sh, m, w);
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) t += (m[k] >= 0 && ((start >> sh) << sh) + lane * NP + k >= start) ? 1u : 0u;
+        t = wave_sum_u32_dpp(t);
+        if (lane == 0) L.bc[0] = t;
+    }
     __syncthreads();
-    uint32_t Ftotal = 0;
-    for (int w = 0; w < kLapWaves; w++) Ftotal += L.w_scan[w];
-    uint32_t tailF = L.cut_tail[0];
+    if (tid == 0) { // feasible nodes before the start block: the counts of the left siblings on the way up
+        uint32_t s = 0;
+        for (int p = nbp + (start >> sh); p > 1; p >>= 1)
+            if (p & 1) s += L.T[p - 1].w;
+        L.bc[1] = s;
+    }
     __syncthreads();
+    uint32_t Ftotal = L.T[1].w, tailF = L.bc[0];
+    uint32_t Pst = L.bc[1] + (L.T[nbp + (start >> sh)].w - tailF); // feasible nodes with an index below the start index
+    int prev_Jc = 0;
     int64_t budget = a.max_cycles;
-    const int E = (nb - 1 + kLapThreads - 1) / kLapThreads; // ring entries per thread
     const int64_t slow_cap = a.slow_floor > N / 4 ? a.slow_floor : N / 4;
     unsigned long long t_prev = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull, pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LAP_TICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+    __syncthreads();
 
     while (!done && !dirty && budget > 0) {
         if (Ftotal == 0) { // schedule_one.go:448-454: every node was visited, none passed
@@ -588,100 +615,79 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
         if (limit > 0 && limit - placed < J) J = (int)(limit - placed); // (the stretches behind the limit are never looked at)
         if (budget < J) J = (int)budget;
         const int sb = start >> sh;
-        if (tid < kLapCuts) L.s_key[0][tid] = 0, L.s_key[1][tid] = 0, L.s_flag[tid] = 0, L.cut_blk[tid] = -1;
-        // ---- 1. ring prefix over the whole blocks: entry r = 1 .. nb - 1 is block (sb + r) mod nb
-        const int r_lo = tid * E + 1, r_hi = (tid + 1) * E < nb - 1 ? (tid + 1) * E : nb - 1;
-        uint32_t ls = 0;
-        for (int r = r_lo; r <= r_hi; r++) {
-            int b = sb + r;
-            b = b >= nb ? b - nb : b;
-            ls += L.fc[b];
+        // ---- 1. wave 0: the counts above the last lap's winners that left the feasible nodes, then the block of every ring rank jK by
+        // descent on the counts.  Wave 1 meanwhile: keys and maxima above the last lap's winners, level by level.
+        if (wave == 0) {
+            if (lane < prev_Jc && L.nm[lane] < 0)
+                for (int p = (nbp + (L.g[lane] >> sh)) >> 1; p >= 1; p >>= 1) atomicSub(&L.T[p].w, 1u);
+            if (lane < kLapCuts) L.s_key[0][lane] = 0, L.s_key[1][lane] = 0, L.s_flag[lane] = 0, L.cut_blk[lane] = -1;
+            lap_wave_sync();
+            if (!all && lane >= 1 && lane <= J) {
+                uint32_t rem = Pst + (uint32_t)lane * K; // the rank among the feasible nodes in INDEX order
+                rem = rem >= Ftotal ? rem - Ftotal : rem;
+                int p = 1;
+                while (p < nbp) {
+                    const uint32_t l = L.T[2 * p].w;
+                    p = 2 * p + (rem >= l ? 1 : 0), rem -= rem >= l ? l : 0u;
+                }
+                const int b = p - nbp;
+                L.cut_blk[lane] = b, L.cut_need[lane] = (int32_t)rem, L.cut_kind[lane] = b == sb ? 1 : 0; // (in the start block: before the start index, K >= block size)
+            }
+            if (all && lane == 1 && L.T[nbp + sb].w > tailF) L.cut_blk[1] = sb, L.cut_need[1] = 0x7fffffff, L.cut_kind[1] = 1; // (all of it belongs to the one stretch)
+        } else if (wave == 1) {
+            int p = lane < prev_Jc ? (nbp + (L.g[lane] >> sh)) >> 1 : 0;
+            for (int lv = 0; lv < levels; lv++) {
+                if (p >= 1) {
+                    const uint4 c0 = L.T[2 * p], c1 = L.T[2 * p + 1];
+                    const unsigned long long k0 = lap_key(c0), k1 = lap_key(c1), k = k0 > k1 ? k0 : k1;
+                    L.T[p].x = (uint32_t)k, L.T[p].y = (uint32_t)(k >> 32), L.T[p].z = lap_pkmax(c0.z, c1.z); // (.w is wave 0's)
+                }
+                lap_wave_sync();
+                p >>= 1;
+            }
         }
-        const uint32_t ils = lap_wave_incl(ls);
-        if (lane == 63) L.w_scan[wave] = ils;
-        __syncthreads(); // ---- barrier 1
+        __syncthreads(); // ---- barrier A: the cuts are known, the tree describes the state
         LAP_TICK(0);
-        uint32_t fullF = 0, before = 0;
-#pragma unroll
-        for (int w = 0; w < kLapWaves; w++) {
-            const uint32_t z = L.w_scan[w];
-            fullF += z, before += w < wave ? z : 0u;
-        }
-        if (tid == 0) { // the start block before the start index: the last segment of the ring
-            const uint32_t p_head = tailF + fullF, headF = L.fc[sb] - tailF;
-            if (all) {
-                if (headF > 0) L.cut_blk[1] = sb, L.cut_need[1] = 0x7fffffff, L.cut_kind[1] = 1; // (all of it belongs to the one stretch)
-            } else if (p_head <= (uint32_t)J * K && (uint32_t)J * K < p_head + headF)
-                L.cut_blk[J] = sb, L.cut_need[J] = (int32_t)((uint32_t)J * K - p_head), L.cut_kind[J] = 1;
-        }
-        // ---- the whole blocks: which stretch, or cut by which boundary.  Threads follow the ring: a thread's (stretch, part) slot
-        // changes rarely along its entries, and across a wave's lanes the first and the last slot cover almost every lane.
+        // ---- 2. the cut blocks node by node: cut c is wave (c mod waves)'s.  All loads first; the last wave answers the stretches'
+        // range queries while its loads are under way; then the ranks.
         {
-            uint32_t run = tailF + before + ils - ls;
-            int cur = -1;
-            unsigned long long ak = 0;
-            uint32_t af = 0;
-            uint32_t j = all ? 0u : run / K, lo = j * K; // (one division per thread and lap; then by steps: a block holds at most K feasible nodes)
-            for (int r = r_lo; r <= r_hi; r++) {
-                int b = sb + r;
-                const bool wrapped = b >= nb;
-                b = wrapped ? b - nb : b;
-                const uint32_t f = L.fc[b];
-                if (f == 0) continue;
-                if (!all) {
-                    if (run >= lo + K) j += 1, lo += K;
-                    int jt = -1;
-                    if (j >= 1 && run == lo) jt = (int)j; // the boundary node is this block's first feasible node
-                    else if (lo + K < run + f) jt = (int)j + 1;
-                    if (jt >= 0) {
-                        if (jt <= J) L.cut_blk[jt] = b, L.cut_need[jt] = (int32_t)((uint32_t)jt * K - run), L.cut_kind[jt] = 0;
-                        run += f;
-                        continue;
-                    }
-                }
-                if ((int)j < J) {
-                    const int slot = (int)j + (wrapped ? kLapCuts : 0);
-                    if (slot != cur) {
-                        if (cur >= 0) atomicMax(&L.s_key[cur >> 5][cur & 31], ak), atomicOr(&L.s_flag[cur & 31], af);
-                        cur = slot, ak = 0, af = 0;
-                    }
-                    const unsigned long long k = L.key[b];
-                    ak = k > ak ? k : ak;
-                    const uint32_t x = L.mx[b];
-                    af |= lap_flags(x >> 16, x & 0xffffu, mt_a, ma_a);
-                }
-                run += f;
-            }
-            const unsigned long long have_m = __ballot(cur >= 0);
-            if (have_m) { // one LDS atomic per (wave, slot) for the first and the last slot of the wave; the lanes in between (rare) on their own
-                const int s0 = lane_bcast_i32(cur, __ffsll((long long)have_m) - 1), s1 = lane_bcast_i32(cur, 63 - __clzll((long long)have_m));
-                {
-                    const bool in = cur == s0;
-                    const unsigned long long k = lap_wave_best(in, ak);
-                    const uint32_t f = lap_wave_or3(in, af);
-                    if (lane == 0) atomicMax(&L.s_key[s0 >> 5][s0 & 31], k), atomicOr(&L.s_flag[s0 & 31], f);
-                }
-                if (s1 != s0) {
-                    const bool in = cur == s1;
-                    const unsigned long long k = lap_wave_best(in, ak);
-                    const uint32_t f = lap_wave_or3(in, af);
-                    if (lane == 0) atomicMax(&L.s_key[s1 >> 5][s1 & 31], k), atomicOr(&L.s_flag[s1 & 31], f);
-                }
-                if (cur >= 0 && cur != s0 && cur != s1) atomicMax(&L.s_key[cur >> 5][cur & 31], ak), atomicOr(&L.s_flag[cur & 31], af);
-            }
-        }
-        __syncthreads(); // ---- barrier 2: every cut is registered
-        LAP_TICK(1);
-        // ---- 2. the cut blocks node by node: cut c is wave (c mod waves)'s.  All loads first, then the ranks.
-        {
-            int32_t cm[kLapRounds][kLapNP];
-            uint32_t cw[kLapRounds][kLapNP];
+            int32_t cm[kLapRounds][NP];
+            uint32_t cw[kLapRounds][NP];
             int cb[kLapRounds];
 #pragma unroll
             for (int rd = 0; rd < kLapRounds; rd++) {
                 const int c = wave + rd * kLapWaves;
                 cb[rd] = c == 0 ? sb : (c <= J ? L.cut_blk[c] : -1);
                 if (cb[rd] >= 0) fetch(cb[rd], cm[rd], cw[rd]);
+            }
+            if (wave == kLapWaves - 1 && lane < J) {
+                // the whole blocks of stretch `lane`: ring positions strictly between its two cuts (position of block b: b behind the
+                // start block, b + nb before it; the start block itself is position sb as cut 0 and sb + nb as a cut before the start index)
+                auto pos = [&](int c) -> int {
+                    if (c == 0) return sb;
+                    const int b = L.cut_blk[c];
+                    return L.cut_kind[c] == 1 ? sb + nb : (b > sb ? b : b + nb);
+                };
+                const int pl = pos(lane) + 1, pr = all ? sb + nb : pos(lane + 1);
+                for (int part = 0; part < 2; part++) {
+                    int l = part == 0 ? pl : (pl > nb ? pl : nb) - nb, r = part == 0 ? (pr < nb ? pr : nb) : pr - nb;
+                    if (l >= r) continue;
+                    unsigned long long k = 0;
+                    uint32_t mx = 0;
+                    for (l += nbp, r += nbp; l < r; l >>= 1, r >>= 1) {
+                        if (l & 1) {
+                            const uint4 n = L.T[l++];
+                            const unsigned long long kn = lap_key(n);
+                            k = kn > k ? kn : k, mx = lap_pkmax(mx, n.z);
+                        }
+                        if (r & 1) {
+                            const uint4 n = L.T[--r];
+                            const unsigned long long kn = lap_key(n);
+                            k = kn > k ? kn : k, mx = lap_pkmax(mx, n.z);
+                        }
+                    }
+                    if (k) atomicMax(&L.s_key[part][lane], k), atomicOr(&L.s_flag[lane], lap_flags(mx >> 16, mx & 0xffffu, mt_a, ma_a));
+                }
             }
 #pragma unroll
             for (int rd = 0; rd < kLapRounds; rd++) {
@@ -691,10 +697,12 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                 const int32_t need = c == 0 ? 0 : L.cut_need[c];
                 const int32_t i0 = (cb[rd] << sh) + lane * NP;
                 const bool part1 = kind == 1 || (kind == 0 && cb[rd] < sb); // the nodes of this segment lie before the lap's start index
+                // the segment: the whole block, its nodes before the start index (kind 1), or at and behind it (cut 0)
+                const int32_t seg_lo = kind == 2 ? start : (cb[rd] << sh), seg_n = (kind == 1 ? start : ((cb[rd] + 1) << sh)) - seg_lo;
                 uint32_t cnt = 0, cnt_all = 0;
 #pragma unroll
-                for (int k = 0; k < kLapNP; k++) {
-                    const bool inseg = kind == 0 || (kind == 1 ? i0 + k < start : i0 + k >= start);
+                for (int k = 0; k < NP; k++) {
+                    const bool inseg = (uint32_t)(i0 + k - seg_lo) < (uint32_t)seg_n;
                     cnt += (cm[rd][k] >= 0 && inseg) ? 1u : 0u, cnt_all += cm[rd][k] >= 0 ? 1u : 0u;
                 }
                 const uint32_t incl = lap_wave_incl(cnt);
@@ -703,10 +711,9 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                 uint32_t pfl = 0, nfl = 0;
                 int32_t stop = -1;
 #pragma unroll
-                for (int k = 0; k < kLapNP; k++) {
+                for (int k = 0; k < NP; k++) {
                     const int32_t i = i0 + k;
-                    const bool inseg = kind == 0 || (kind == 1 ? i < start : i >= start);
-                    if (cm[rd][k] >= 0 && inseg) {
+                    if (cm[rd][k] >= 0 && (uint32_t)(i - seg_lo) < (uint32_t)seg_n) {
                         const unsigned long long key = make_key((int64_t)cm[rd][k], (int64_t)i);
                         const uint32_t fl = lap_flags((cw[rd][k] >> kStatCntShift) & kStatCntMask, cw[rd][k] & kStatAffMask, mt_a, ma_a);
                         if (rank < need) pk = key > pk ? key : pk, pfl |= fl;
@@ -738,8 +745,8 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                 if (lane == 0) L.cut_node[c] = stop, L.cut_tail[c] = t;
             }
         }
-        __syncthreads(); // ---- barrier 3: the stretches' keys and flags are complete
-        LAP_TICK(2);
+        __syncthreads(); // ---- barrier B: the stretches' keys and flags are complete
+        LAP_TICK(1);
         // ---- 3. which stretches stand (every wave holds the lap's J stretches in its lanes 0 .. J - 1)
         const bool have = lane < J;
         unsigned long long key = 0;
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
         // ---- 4. the placements (schedule_one.go:967-984 assume -> NodeInfo.update) by the lanes of the last wave, one node each; the
         // other waves fetch the winners' blocks meanwhile (winner j is wave (j mod waves)'s)
         const int32_t g = lane < Jc ? (int32_t)key_index(key) : -1;
-        LAP_TICK(3);
+        LAP_TICK(2);
         if (wave == kLapWaves - 1) {
             if (lane < Jc) {
                 const int32_t nm = sb_place<NARROW>(a, npod, (int64_t)g, mt_a, ma_a);
@@ -826,8 +833,8 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
             LAP_TICK(6);
         }
         {
-            int32_t pm[kLapRounds][kLapNP];
-            uint32_t pw[kLapRounds][kLapNP];
+            int32_t pm[kLapRounds][NP];
+            uint32_t pw[kLapRounds][NP];
             int pb[kLapRounds];
 #pragma unroll
             for (int rd = 0; rd < kLapRounds; rd++) {
@@ -835,8 +842,8 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                 pb[rd] = -1;
                 if (jw < Jc) pb[rd] = lane_bcast_i32(g, jw) >> sh, fetch(pb[rd], pm[rd], pw[rd]);
             }
-            __syncthreads(); // ---- barrier 4: the winners' new memo words are in LDS (and in L2)
-            LAP_TICK(4);
+            __syncthreads(); // ---- barrier C: the winners' new memo words are in LDS (and in L2)
+            LAP_TICK(3);
 #pragma unroll
             for (int rd = 0; rd < kLapRounds; rd++) {
                 const int jw = wave + rd * kLapWaves;
@@ -848,13 +855,13 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                     if (x >= 0 && x < Jc) {
                         const int32_t gx = L.g[x], nx = L.nm[x];
 #pragma unroll
-                        for (int k = 0; k < kLapNP; k++)
-                            if (k < NP && i0 + k == gx) pm[rd][k] = nx;
+                        for (int k = 0; k < NP; k++)
+                            if (i0 + k == gx) pm[rd][k] = nx;
                     }
                 uint32_t pf = 0, pmt = 0, pma = 0;
                 unsigned long long pk = 0;
 #pragma unroll
-                for (int k = 0; k < kLapNP; k++)
+                for (int k = 0; k < NP; k++)
                     if (pm[rd][k] >= 0) {
                         const uint32_t cnt = (pw[rd][k] >> kStatCntShift) & kStatCntMask, aff = pw[rd][k] & kStatAffMask;
                         pf += 1, pmt = cnt > pmt ? cnt : pmt, pma = aff > pma ? aff : pma;
@@ -863,11 +870,7 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                     }
                 pk = lap_wave_best(pk != 0, pk);
                 pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma);
-                if (lane == 0) {
-                    const int b = pb[rd];
-                    L.fc[b] = pf, L.key[b] = pk, L.mx[b] = (pmt << 16) | pma;
-                    a.sb_fc[b] = pf, a.sb_key[b] = pk, a.sb_mx[b] = (pmt << 16) | pma; // (the global copy stays current: the next launch reloads it)
-                }
+                if (lane == 0) L.T[nbp + pb[rd]] = make_uint4((uint32_t)pk, (uint32_t)(pk >> 32), (pmt << 16) | pma, pf); // (the tree above it: the next lap's step 1)
             }
         }
         // ---- the run state, identically in every thread
@@ -876,24 +879,35 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
             const uint32_t nt = L.cut_tail[all ? 0 : Jc];
             const bool left = lane < Jc && L.nm[lane] < 0; // winners that are not feasible any more
             const bool in_tail = left && (L.g[lane] >> sh) == (ns >> sh) && L.g[lane] >= ns;
-            const int n_left = __popcll(__ballot(left)), n_tail = __popcll(__ballot(in_tail));
+            const int n_left = __popcll(__ballot(left)), n_tail = __popcll(__ballot(in_tail)), n_below = __popcll(__ballot(left && L.g[lane] < ns));
             if (Jc > 0) {
                 evaluated += all ? N : ringpos(ns);
                 last_evaluated = all ? N : ringpos(ns) - ringpos(L.cut_node[Jc - 1]);
                 last_feasible = (int32_t)(all ? Ftotal : K);
                 winner = lane_bcast_i32(g, Jc - 1);
             }
+            if (!all) { // the new start index is ring rank Jc x K of this lap: its rank in index order
+                Pst += (uint32_t)Jc * K;
+                Pst = Pst >= Ftotal ? Pst - Ftotal : Pst;
+            }
+            Pst -= (uint32_t)n_below;
             placed += Jc, rounds += Jc, scans += Jc, budget -= Jc > 0 ? Jc : 1;
             Ftotal -= (uint32_t)n_left;
             tailF = nt - (uint32_t)n_tail;
             start = ns;
+            prev_Jc = Jc;
             laps += 1;
             if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312
         }
-        __syncthreads(); // ---- barrier 5: the summaries in LDS are the next lap's
-        LAP_TICK(5);
+        __syncthreads(); // ---- barrier D: the winners' leaves are written
+        LAP_TICK(4);
     }
 #undef LAP_TICK
+    if (!dirty) // the summaries the next launch reloads (after a rebuild request k_sb_build writes them all)
+        for (int b = tid; b < nb; b += kLapThreads) {
+            const uint4 n = L.T[nbp + b];
+            a.sb_fc[b] = n.w, a.sb_key[b] = lap_key(n), a.sb_mx[b] = n.z;
+        }
     if (a.prof) {
         if (tid == 0)
             for (int i = 0; i < 6; i++) a.prof[i] += pf[i];

@@ -31,8 +31,8 @@ def _check(ccref, nodes, pod, prof, limit):
     info = e.sampled_info()
     assert info["resident"] == resident
     if resident:  # ... and a lap of the ring at a time (k_sb_laps, round 6) whenever a block of >= 64 nodes holds one stretch boundary at most
-        forced = int(os.environ.get("CCSIM_SB_SHIFT", "6"))
-        assert info["laps_form"] == (info["K"] >= (1 << forced) and os.environ.get("CCSIM_SB", "1") == "1"), info
+        forced = int(os.environ.get("CCSIM_SB_SHIFT", "6"))  # (blocks of 256 nodes when K >= 256, else of 64; forced: 64 or 256 only)
+        assert info["laps_form"] == (info["K"] >= (1 << forced) and forced in (6, 8) and os.environ.get("CCSIM_SB", "1") == "1"), info
         assert not info["laps_form"] or (info["block"] <= info["K"] and info["laps"] > 0)
     if ref.stop == M.STOP_UNSCHEDULABLE:
         assert np.array_equal(got.hist, ref.hist)
@@ -59,8 +59,8 @@ def test_sampled_search_vs_oracle(ccref, cfg, n, pct, limit):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [{"CCSIM_SB": "0"}, {"CCSIM_SB_CYCLES": "3"}, {"CCSIM_SB_CYCLES": "1"}, {"CCSIM_SB": "2"}, {"CCSIM_SB": "2", "CCSIM_SB_CYCLES": "3"},
-                                   {"CCSIM_SB_SHIFT": "7"}, {"CCSIM_SB_SHIFT": "8", "CCSIM_SB_SLOW_FLOOR": "0"}, {"CCSIM_SB_SHIFT": "6", "CCSIM_SB_SLOW_FLOOR": "0", "CCSIM_SB_CYCLES": "7"}],
-                         ids=["three-passes", "3-cycles-per-launch", "1-cycle-per-launch", "cycle-at-a-time", "cycle-at-a-time-3-per-launch", "blocks-of-128", "blocks-of-256-rebuild-early",
+                                   {"CCSIM_SB_SHIFT": "6"}, {"CCSIM_SB_SHIFT": "8", "CCSIM_SB_SLOW_FLOOR": "0"}, {"CCSIM_SB_SHIFT": "6", "CCSIM_SB_SLOW_FLOOR": "0", "CCSIM_SB_CYCLES": "7"}],
+                         ids=["three-passes", "3-cycles-per-launch", "1-cycle-per-launch", "cycle-at-a-time", "cycle-at-a-time-3-per-launch", "blocks-of-64", "blocks-of-256-rebuild-early",
                               "blocks-of-64-rebuild-early-7-per-launch"])
 @pytest.mark.parametrize("cfg,n,pct,limit", [("C3", 1000, 0, 0), ("C2", 5000, 10, 400), ("C3", 4096, 5, 0), ("C3", 777, 35, 0)])
 def test_sampled_search_forms_agree(ccref, monkeypatch, knobs, cfg, n, pct, limit):
