@@ -571,8 +571,8 @@ class Engine:
         self._chk(self.lib.ccsim_debug_sampled(self.h, out), "ccsim_debug_sampled")
         d = {"resident": bool(out[0]), "laps_form": bool(out[1]), "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
              "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
-        if out[3] and any(out[8:15]):  # CCSIM_SB_PROF=1: microseconds per lap, by phase
-            names = ["find_cuts_update_tree", "cut_blocks_range_queries", "decide", "wait_commit", "leaves", "-", "commit_wave"]
+        if out[3] and any(out[8:16]):  # CCSIM_SB_PROF=1: microseconds per lap, by phase
+            names = ["cut_blocks_tree_range_queries", "decide", "wait_commit", "leaves_next_cuts", "w1_tree", "w1_range_queries", "commit_wave", "w0_next_cuts"]
             d["prof_us_per_lap"] = {k: round(out[8 + i] / 100.0 / out[3], 3) for i, k in enumerate(names)}
         return d
 

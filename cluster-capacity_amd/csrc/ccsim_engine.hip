@@ -198,6 +198,7 @@ struct ccsim_engine {
     bool cw_shard_run = false, cw_shard_args = false; // ... on node-range shards (ccsim_dist_cw_*); its argument block is uploaded
     // the sampled search on resident block summaries (ccsim_sampled.h): buffers of the node count's lifetime, made on first use
     int32_t *d_sb_memo = nullptr;
+    uint8_t *d_sb_flag8 = nullptr;
     uint32_t *d_sb_fc = nullptr, *d_sb_mx = nullptr;
     unsigned long long *d_sb_key = nullptr;
     int sb_shift = 0, sb_blocks = 0;
@@ -392,7 +393,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->allocs);
-    e->d_sb_memo = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr, e->d_sb_prof = nullptr; // (they lived in e->allocs)
+    e->d_sb_memo = nullptr, e->d_sb_flag8 = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr, e->d_sb_prof = nullptr; // (they lived in e->allocs)
     e->d_soft_pc0 = nullptr; // (sized for the previous snapshot: the pod is set again after a load)
     e->backups.clear();
     e->reset_pending = false, e->wide_stale = false;
@@ -1365,7 +1366,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
             const int blocks = (int)blocks_at(sh);
             if (!e->d_sb_memo) {
                 int rc2;
-                if ((rc2 = dev_alloc(e, &e->d_sb_memo, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_fc, (size_t)kSbMaxBlocks, e->allocs)) ||
+                if ((rc2 = dev_alloc(e, &e->d_sb_memo, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_flag8, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_fc, (size_t)kSbMaxBlocks, e->allocs)) ||
                     (rc2 = dev_alloc(e, &e->d_sb_key, (size_t)kSbMaxBlocks, e->allocs)) || (rc2 = dev_alloc(e, &e->d_sb_mx, (size_t)kSbMaxBlocks, e->allocs)))
                     return rc2;
             }
@@ -1908,7 +1909,7 @@ static int run_sb(ccsim_engine *e) {
         HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
         e->sb_attr_set = true;
     }
-    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : 1024, nullptr, 65536};
+    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_flag8, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : 1024, nullptr, 65536};
     if (getenv("CCSIM_SB_PROF") && atoi(getenv("CCSIM_SB_PROF"))) {
         if (!e->d_sb_prof) {
             int rc2;

@@ -39,6 +39,7 @@ struct SbArgs {
     DevPod p;
     DevState *st;
     int32_t *memo;              // [n_pad]
+    uint8_t *flag8;             // [n_pad] k_sb_laps: a node's raw scores against the ASSUMED maxima (kLapOver | kLapHitT | kLapHitA), whether feasible or not
     uint32_t *sb_fc;            // [n_blocks] feasible nodes of the block
     unsigned long long *sb_key; // [n_blocks] make_key(best TotalScore, lowest index holding it), 0 = no feasible node
     uint32_t *sb_mx;            // [n_blocks] (max PreferNoSchedule count << 16) | max preferred-affinity sum, over the feasible nodes
@@ -85,6 +86,10 @@ __global__ __launch_bounds__(256) void k_sb_build(SbArgs a) {
             }
         }
         a.memo[i] = sc;
+        if (a.flag8) {
+            const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
+            a.flag8[i] = (uint8_t)(((cnt > mt || aff > ma) ? 1u : 0u) | (cnt == mt ? 2u : 0u) | (aff == ma ? 4u : 0u));
+        }
         if (sc >= 0) {
             const uint32_t cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
             fc += 1, bmt = cnt > bmt ? cnt : bmt, bma = aff > bma ? aff : bma;
@@ -107,13 +112,14 @@ __global__ __launch_bounds__(256) void k_sb_build(SbArgs a) {
 // under the assumed maxima afterwards.  The caller has invalidated its L1 if the row may have been written before in this launch.
 template <bool NARROW>
 __device__ __forceinline__ int32_t sb_place(const SbArgs &a, const NarrowPod &npod, int64_t i, uint32_t mt_a, uint32_t ma_a) {
-    NodeRegs<kMaxExtra> nd;
+    constexpr int NX = NARROW ? 0 : kMaxExtra; // (the narrow mirrors exist for pods without extra resource columns only)
+    NodeRegs<NX> nd;
     int32_t na0 = 0, na1 = 0;
     if (NARROW) na0 = a.c.a32[0][i], na1 = a.c.a32[1][i];
-    load_one<kMaxExtra>(a.c, a.p, i, nd);
-    node_apply<kMaxExtra>(a.p, nd, 1);
-    store_dyn<kMaxExtra>(a.c, a.p, i, nd, 1);
-    int32_t nm;
+    load_one<NX>(a.c, a.p, i, nd);
+    node_apply<NX>(a.p, nd, 1);
+    store_dyn<NX>(a.c, a.p, i, nd, 1);
+    int32_t nm = -1;
     if (NARROW) { // (the lossless mirrors: the same number as the wide path, ccsim_kernels.h "NARROW arithmetic")
         const int32_t nr0 = (int32_t)nd.r_cpu, nr1 = (int32_t)(nd.r_mem >> a.c.mem_shift), nz0 = (int32_t)nd.z_cpu, nz1 = (int32_t)(nd.z_mem >> a.c.mem_shift);
         nm = -1;
@@ -121,7 +127,7 @@ __device__ __forceinline__ int32_t sb_place(const SbArgs &a, const NarrowPod &np
             const uint32_t cnt = (nd.w >> kStatCntShift) & kStatCntMask, aff = nd.w & kStatAffMask, img = (nd.w >> kStatImgShift) & kStatImgMask;
             nm = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) + dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1));
         }
-    } else
+    } else if constexpr (!NARROW)
         nm = sb_node_score(a.p, nd, mt_a, ma_a);
     __hip_atomic_store((uint32_t *)(a.memo + i), (uint32_t)nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return nm;
@@ -466,17 +472,19 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
 //   3. a stretch whose kept nodes' maxima differ from the assumed ones is re-evaluated node by node under its own (TotalScore is
 //      static part + state part: the score under other maxima follows from the memo word and the static word) -- unless such
 //      stretches cover more than a quarter of the ring: then the first of them ends the lap and everything is rebuilt under its maxima;
-//   4. the J placements by J lanes of one wave (disjoint nodes), the winners' blocks re-read by the other waves meanwhile; their
-//      leaves, and -- level by level in one wave, while another finds the next lap's cuts -- the tree above them.
+//   4. the J placements by J lanes of one wave (disjoint nodes), the winners' blocks re-read by the other waves meanwhile; then their
+//      leaves, while wave 0 already finds the NEXT lap's cuts (the counts change only when a winner leaves the feasible nodes); the tree
+//      above the leaves level by level in wave 1 while the others wait for the next lap's cut blocks -- three barriers per lap.
 // F <= K is the degenerate lap of one stretch without a boundary (every node is visited, the start index stays).  One workgroup: a lap
 // is ~40 KB of loads and two dependent trips to L2; what it needs from the rest of the chip is nothing, and a grid-wide barrier per
 // lap would cost more than the lap.
 constexpr int kLapThreads = CCSIM_LAP_THREADS, kLapWaves = kLapThreads / 64;
 constexpr int kLapCuts = 32, kLapMaxJ = kLapCuts - 1;  // stretches per lap: cuts 0 .. J
-constexpr int kLapRounds = kLapCuts / kLapWaves;       // cuts (and winners) per wave
+constexpr int kLapSlots = kLapWaves - 1;               // waves that share a lap's cut blocks (all but the tree's), and its winners' blocks (all but the finder)
+constexpr int kLapRounds = (kLapCuts + kLapSlots - 1) / kLapSlots; // cuts (and winners) per wave
 constexpr int kLapMaxBlocks = 4096;                    // leaves of the tree (2 x 4096 nodes x 16 B = 128 KiB of LDS)
 constexpr uint32_t kLapOver = 1u, kLapHitT = 2u, kLapHitA = 4u; // a stretch's maxima equal the assumed ones iff its flags are kLapHitT | kLapHitA
-static_assert(kLapWaves >= 2 && kLapCuts % kLapWaves == 0, "k_sb_laps: wave 0 finds the cuts while wave 1 brings the tree up to date");
+static_assert(kLapWaves >= 4, "k_sb_laps: wave 0 finds the next lap's cuts, wave 1 keeps the tree and answers the range queries, the last wave places the pods");
 
 struct LapLds {
     // heap order: node p has children 2p, 2p + 1; leaf of block b = T[nbp + b].  x, y = key; z = (max PreferNoSchedule count << 16) |
@@ -522,11 +530,12 @@ __device__ __forceinline__ uint32_t lap_pkmax(uint32_t a, uint32_t b) { // the t
     return hi | lo;
 }
 __device__ __forceinline__ unsigned long long lap_key(const uint4 &n) { return ((unsigned long long)n.y << 32) | n.x; }
-// lanes of ONE wave go on to read what other lanes of it have just written to LDS
+// lanes of ONE wave go on to read what other lanes of it have just written to LDS: a wave's LDS instructions execute in order, so all
+// this has to stop is the compiler moving one across
 __device__ __forceinline__ void lap_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __asm__ volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __asm__ volatile("" ::: "memory");
 }
 
 template <bool NARROW, int NP> // NP nodes per lane of a cut block: blocks of 64 x NP nodes
@@ -602,41 +611,48 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
     const int64_t slow_cap = a.slow_floor > N / 4 ? a.slow_floor : N / 4;
     unsigned long long t_prev = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull, pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LAP_TICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
-    __syncthreads();
-
-    while (!done && !dirty && budget > 0) {
-        if (Ftotal == 0) { // schedule_one.go:448-454: every node was visited, none passed
-            done = DONE_UNSCHEDULABLE, rounds += 1, scans += 1, last_feasible = 0, last_evaluated = N, evaluated += N, winner = -1;
-            break;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (see fetch)
-        const bool all = Ftotal <= K; // fewer feasible nodes than wanted: the search visits every node (:538: processed = N)
-        int J = all ? 1 : (int)((Ftotal - 1) / K < (uint32_t)kLapMaxJ ? (Ftotal - 1) / K : (uint32_t)kLapMaxJ);
+    bool all = false;
+    int J = 0;
+    auto plan = [&]() { // the coming lap: how many stretches
+        all = Ftotal <= K; // fewer feasible nodes than wanted: the search visits every node (:538: processed = N)
+        J = all ? 1 : (int)((Ftotal - 1) / K < (uint32_t)kLapMaxJ ? (Ftotal - 1) / K : (uint32_t)kLapMaxJ);
         if (limit > 0 && limit - placed < J) J = (int)(limit - placed); // (the stretches behind the limit are never looked at)
         if (budget < J) J = (int)budget;
+        if (Ftotal == 0 || done || dirty) J = 0;
+    };
+    // wave 0: the block of every ring rank jK of the coming lap, by descent on the counts
+    auto find_cuts = [&]() {
+        if (lane < kLapCuts) L.s_key[0][lane] = 0, L.s_key[1][lane] = 0, L.s_flag[lane] = 0, L.cut_blk[lane] = -1;
+        lap_wave_sync();
         const int sb = start >> sh;
-        // ---- 1. wave 0: the counts above the last lap's winners that left the feasible nodes, then the block of every ring rank jK by
-        // descent on the counts.  Wave 1 meanwhile: keys and maxima above the last lap's winners, level by level.
-        if (wave == 0) {
-            if (lane < prev_Jc && L.nm[lane] < 0)
-                for (int p = (nbp + (L.g[lane] >> sh)) >> 1; p >= 1; p >>= 1) atomicSub(&L.T[p].w, 1u);
-            if (lane < kLapCuts) L.s_key[0][lane] = 0, L.s_key[1][lane] = 0, L.s_flag[lane] = 0, L.cut_blk[lane] = -1;
-            lap_wave_sync();
-            if (!all && lane >= 1 && lane <= J) {
-                uint32_t rem = Pst + (uint32_t)lane * K; // the rank among the feasible nodes in INDEX order
-                rem = rem >= Ftotal ? rem - Ftotal : rem;
-                int p = 1;
-                while (p < nbp) {
-                    const uint32_t l = L.T[2 * p].w;
-                    p = 2 * p + (rem >= l ? 1 : 0), rem -= rem >= l ? l : 0u;
-                }
-                const int b = p - nbp;
-                L.cut_blk[lane] = b, L.cut_need[lane] = (int32_t)rem, L.cut_kind[lane] = b == sb ? 1 : 0; // (in the start block: before the start index, K >= block size)
+        if (!all && lane >= 1 && lane <= J) {
+            uint32_t rem = Pst + (uint32_t)lane * K; // the rank among the feasible nodes in INDEX order
+            rem = rem >= Ftotal ? rem - Ftotal : rem;
+            int p = 1;
+            while (p < nbp) {
+                const uint32_t l = L.T[2 * p].w;
+                p = 2 * p + (rem >= l ? 1 : 0), rem -= rem >= l ? l : 0u;
             }
-            if (all && lane == 1 && L.T[nbp + sb].w > tailF) L.cut_blk[1] = sb, L.cut_need[1] = 0x7fffffff, L.cut_kind[1] = 1; // (all of it belongs to the one stretch)
-        } else if (wave == 1) {
+            const int b = p - nbp;
+            L.cut_blk[lane] = b, L.cut_need[lane] = (int32_t)rem, L.cut_kind[lane] = b == sb ? 1 : 0; // (in the start block: before the start index, K >= block size)
+        }
+        if (all && J == 1 && lane == 1 && L.T[nbp + sb].w > tailF) L.cut_blk[1] = sb, L.cut_need[1] = 0x7fffffff, L.cut_kind[1] = 1; // (all of it belongs to the one stretch)
+    };
+    plan();
+    if (wave == 0) find_cuts();
+    __syncthreads();
+    // which of the waves' slots a cut block (every wave but the tree's) / a winner's block (every wave but the finder) falls to
+    const int cslot = wave == 0 ? 0 : wave - 1, wslot = wave - 1;
+
+    while (J > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (see fetch)
+        const int sb = start >> sh;
+        // ---- 2. the cut blocks node by node, by every wave but wave 1 (all loads first, then the ranks -- stage by stage over a wave's
+        // cuts, so that their dependent chains overlap).  Wave 1 meanwhile: keys and maxima above the last lap's winners, level by level,
+        // then the stretches' range queries.
+        if (wave == 1) {
             int p = lane < prev_Jc ? (nbp + (L.g[lane] >> sh)) >> 1 : 0;
-            for (int lv = 0; lv < levels; lv++) {
+            for (int lv = 0; lv < levels && prev_Jc > 0; lv++) {
                 if (p >= 1) {
                     const uint4 c0 = L.T[2 * p], c1 = L.T[2 * p + 1];
                     const unsigned long long k0 = lap_key(c0), k1 = lap_key(c1), k = k0 > k1 ? k0 : k1;
@@ -645,33 +661,20 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                 lap_wave_sync();
                 p >>= 1;
             }
-        }
-        __syncthreads(); // ---- barrier A: the cuts are known, the tree describes the state
-        LAP_TICK(0);
-        // ---- 2. the cut blocks node by node: cut c is wave (c mod waves)'s.  All loads first; the last wave answers the stretches'
-        // range queries while its loads are under way; then the ranks.
-        {
-            int32_t cm[kLapRounds][NP];
-            uint32_t cw[kLapRounds][NP];
-            int cb[kLapRounds];
-#pragma unroll
-            for (int rd = 0; rd < kLapRounds; rd++) {
-                const int c = wave + rd * kLapWaves;
-                cb[rd] = c == 0 ? sb : (c <= J ? L.cut_blk[c] : -1);
-                if (cb[rd] >= 0) fetch(cb[rd], cm[rd], cw[rd]);
-            }
-            if (wave == kLapWaves - 1 && lane < J) {
-                // the whole blocks of stretch `lane`: ring positions strictly between its two cuts (position of block b: b behind the
-                // start block, b + nb before it; the start block itself is position sb as cut 0 and sb + nb as a cut before the start index)
+            LAP_TICK(4);
+            if ((lane & 31) < J) {
+                // the whole blocks of stretch (lane mod 32): ring positions strictly between its two cuts (position of block b: b behind
+                // the start block, b + nb before it; the start block itself is position sb as cut 0 and sb + nb as a cut before the start
+                // index).  Lanes 0 .. 31 ask for the part at or behind the start index, lanes 32 .. 63 for the part before it.
+                const int j = lane & 31, part = lane >> 5;
                 auto pos = [&](int c) -> int {
                     if (c == 0) return sb;
                     const int b = L.cut_blk[c];
                     return L.cut_kind[c] == 1 ? sb + nb : (b > sb ? b : b + nb);
                 };
-                const int pl = pos(lane) + 1, pr = all ? sb + nb : pos(lane + 1);
-                for (int part = 0; part < 2; part++) {
-                    int l = part == 0 ? pl : (pl > nb ? pl : nb) - nb, r = part == 0 ? (pr < nb ? pr : nb) : pr - nb;
-                    if (l >= r) continue;
+                const int pl = pos(j) + 1, pr = all ? sb + nb : pos(j + 1);
+                int l = part == 0 ? pl : (pl > nb ? pl : nb) - nb, r = part == 0 ? (pr < nb ? pr : nb) : pr - nb;
+                if (l < r) {
                     unsigned long long k = 0;
                     uint32_t mx = 0;
                     for (l += nbp, r += nbp; l < r; l >>= 1, r >>= 1) {
@@ -686,67 +689,96 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
                             k = kn > k ? kn : k, mx = lap_pkmax(mx, n.z);
                         }
                     }
-                    if (k) atomicMax(&L.s_key[part][lane], k), atomicOr(&L.s_flag[lane], lap_flags(mx >> 16, mx & 0xffffu, mt_a, ma_a));
+                    if (k) atomicMax(&L.s_key[part][j], k), atomicOr(&L.s_flag[j], lap_flags(mx >> 16, mx & 0xffffu, mt_a, ma_a));
+                }
+            }
+            LAP_TICK(5);
+        } else {
+            int32_t cm[kLapRounds][NP];
+            uint32_t cf[kLapRounds]; // the nodes' flag bytes
+            int cb[kLapRounds];
+#pragma unroll
+            for (int rd = 0; rd < kLapRounds; rd++) {
+                const int c = cslot + rd * kLapSlots;
+                cb[rd] = c == 0 ? sb : (c <= J ? L.cut_blk[c] : -1);
+                if (cb[rd] >= 0) {
+                    const int64_t i0 = ((int64_t)cb[rd] << sh) + (int64_t)lane * NP;
+                    if (NP == 4) {
+                        const int4 x = *reinterpret_cast<const int4 *>(a.memo + i0);
+                        cm[rd][0] = x.x, cm[rd][1] = x.y, cm[rd][2] = x.z, cm[rd][3] = x.w;
+                        cf[rd] = *reinterpret_cast<const uint32_t *>(a.flag8 + i0);
+                    } else
+                        cm[rd][0] = a.memo[i0], cf[rd] = a.flag8[i0];
                 }
             }
 #pragma unroll
             for (int rd = 0; rd < kLapRounds; rd++) {
-                const int c = wave + rd * kLapWaves;
+                const int c = cslot + rd * kLapSlots;
                 if (cb[rd] < 0) continue; // (wave-uniform)
                 const int kind = c == 0 ? 2 : L.cut_kind[c];
                 const int32_t need = c == 0 ? 0 : L.cut_need[c];
-                const int32_t i0 = (cb[rd] << sh) + lane * NP;
+                const int32_t blo = cb[rd] << sh, i0 = blo + lane * NP;
                 const bool part1 = kind == 1 || (kind == 0 && cb[rd] < sb); // the nodes of this segment lie before the lap's start index
                 // the segment: the whole block, its nodes before the start index (kind 1), or at and behind it (cut 0)
-                const int32_t seg_lo = kind == 2 ? start : (cb[rd] << sh), seg_n = (kind == 1 ? start : ((cb[rd] + 1) << sh)) - seg_lo;
-                uint32_t cnt = 0, cnt_all = 0;
+                const int32_t seg_lo = kind == 2 ? start : blo, seg_n = (kind == 1 ? start : blo + (1 << sh)) - seg_lo;
+                uint32_t fm = 0, ca = 0; // this lane's feasible nodes inside the segment (bit k), feasible nodes at all
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
-                    const bool inseg = (uint32_t)(i0 + k - seg_lo) < (uint32_t)seg_n;
-                    cnt += (cm[rd][k] >= 0 && inseg) ? 1u : 0u, cnt_all += cm[rd][k] >= 0 ? 1u : 0u;
+                    const bool fe = cm[rd][k] >= 0;
+                    ca += fe ? 1u : 0u;
+                    fm |= (fe && (uint32_t)(i0 + k - seg_lo) < (uint32_t)seg_n) ? 1u << k : 0u;
                 }
-                const uint32_t incl = lap_wave_incl(cnt);
-                int32_t rank = (int32_t)(incl - cnt);
-                unsigned long long pk = 0, nk = 0;
-                uint32_t pfl = 0, nfl = 0;
-                int32_t stop = -1;
+                const uint32_t cnt = (uint32_t)__popc(fm), incl = lap_wave_incl(cnt);
+                // the first np of them come before the boundary (the ranks below `need`), the others at or behind it
+                const int32_t d = need - (int32_t)(incl - cnt), np = d < 0 ? 0 : (d > (int32_t)cnt ? (int32_t)cnt : d);
+                int32_t pm = -1, pi = 0, xm = -1, xi = 0, seen = 0, stop = -1;
+                uint32_t pmask = 0, xmask = 0;
 #pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    const int32_t i = i0 + k;
-                    if (cm[rd][k] >= 0 && (uint32_t)(i - seg_lo) < (uint32_t)seg_n) {
-                        const unsigned long long key = make_key((int64_t)cm[rd][k], (int64_t)i);
-                        const uint32_t fl = lap_flags((cw[rd][k] >> kStatCntShift) & kStatCntMask, cw[rd][k] & kStatAffMask, mt_a, ma_a);
-                        if (rank < need) pk = key > pk ? key : pk, pfl |= fl;
-                        else {
-                            if (rank == need) stop = i;
-                            if (c < J) nk = key > nk ? key : nk, nfl |= fl;
+                for (int k = 0; k < NP; k++)
+                    if (fm >> k & 1u) {
+                        if (seen < np) {
+                            if (cm[rd][k] > pm) pm = cm[rd][k], pi = i0 + k; // (strictly greater: the lowest index stands on equal scores)
+                            pmask |= 0xffu << (8 * k);
+                        } else {
+                            if (seen == np) stop = i0 + k;
+                            if (cm[rd][k] > xm) xm = cm[rd][k], xi = i0 + k;
+                            xmask |= 0xffu << (8 * k);
                         }
-                        rank += 1;
+                        seen += 1;
+                    }
+                uint32_t pfl = cf[rd] & pmask, xfl = cf[rd] & xmask; // OR of the side's flag bytes
+                pfl |= pfl >> 16, pfl |= pfl >> 8, xfl |= xfl >> 16, xfl |= xfl >> 8;
+                int32_t st = start;
+                if (c > 0) {
+                    const unsigned long long sm = __ballot(d >= 0 && d < (int32_t)cnt); // the one lane that holds the boundary node
+                    st = sm ? lane_bcast_i32(stop, __ffsll((long long)sm) - 1) : -1;
+                    const uint32_t top = wave_max_u32((uint32_t)(pm + 1));
+                    if (top) {
+                        const int l = __ffsll((long long)__ballot((uint32_t)(pm + 1) == top)) - 1;
+                        const unsigned long long k = make_key((int64_t)top - 1, (int64_t)lane_bcast_i32(pi, l));
+                        const uint32_t f = lap_wave_or3(pm >= 0, pfl);
+                        if (lane == 0) atomicMax(&L.s_key[part1 ? 1 : 0][c - 1], k), atomicOr(&L.s_flag[c - 1], f);
                     }
                 }
-                if (c > 0) {
-                    const unsigned long long sm = __ballot(stop >= 0);
-                    stop = sm ? lane_bcast_i32(stop, __ffsll((long long)sm) - 1) : -1;
-                    const unsigned long long k = lap_wave_best(pk != 0, pk);
-                    const uint32_t f = lap_wave_or3(pk != 0, pfl);
-                    if (lane == 0 && k) atomicMax(&L.s_key[part1 ? 1 : 0][c - 1], k), atomicOr(&L.s_flag[c - 1], f);
-                } else
-                    stop = start;
                 if (c < J) {
-                    const unsigned long long k = lap_wave_best(nk != 0, nk);
-                    const uint32_t f = lap_wave_or3(nk != 0, nfl);
-                    if (lane == 0 && k) atomicMax(&L.s_key[part1 ? 1 : 0][c], k), atomicOr(&L.s_flag[c], f);
+                    const uint32_t top = wave_max_u32((uint32_t)(xm + 1));
+                    if (top) {
+                        const int l = __ffsll((long long)__ballot((uint32_t)(xm + 1) == top)) - 1;
+                        const unsigned long long k = make_key((int64_t)top - 1, (int64_t)lane_bcast_i32(xi, l));
+                        const uint32_t f = lap_wave_or3(xm >= 0, xfl);
+                        if (lane == 0) atomicMax(&L.s_key[part1 ? 1 : 0][c], k), atomicOr(&L.s_flag[c], f);
+                    }
                 }
                 // feasible nodes of the block at or behind the cut's node: the segment's part behind the boundary, plus (a cut before
                 // the start index) the start block's nodes at or behind the start index
-                const uint32_t seg_f = (uint32_t)lane_bcast_i32((int32_t)incl, 63), blk_f = wave_sum_u32_dpp(cnt_all);
-                uint32_t t = c == 0 ? seg_f : (stop >= 0 ? seg_f - (uint32_t)need : 0u);
-                if (kind == 1) t += blk_f - seg_f;
-                if (lane == 0) L.cut_node[c] = stop, L.cut_tail[c] = t;
+                const uint32_t seg_f = (uint32_t)lane_bcast_i32((int32_t)incl, 63);
+                uint32_t t = c == 0 ? seg_f : (st >= 0 ? seg_f - (uint32_t)need : 0u);
+                if (kind == 1) t += wave_sum_u32_dpp(ca) - seg_f;
+                if (lane == 0) L.cut_node[c] = st, L.cut_tail[c] = t;
             }
         }
         __syncthreads(); // ---- barrier B: the stretches' keys and flags are complete
-        LAP_TICK(1);
+        LAP_TICK(0);
         // ---- 3. which stretches stand (every wave holds the lap's J stretches in its lanes 0 .. J - 1)
         const bool have = lane < J;
         unsigned long long key = 0;
@@ -822,7 +854,7 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
         // ---- 4. the placements (schedule_one.go:967-984 assume -> NodeInfo.update) by the lanes of the last wave, one node each; the
         // other waves fetch the winners' blocks meanwhile (winner j is wave (j mod waves)'s)
         const int32_t g = lane < Jc ? (int32_t)key_index(key) : -1;
-        LAP_TICK(2);
+        LAP_TICK(1);
         if (wave == kLapWaves - 1) {
             if (lane < Jc) {
                 const int32_t nm = sb_place<NARROW>(a, npod, (int64_t)g, mt_a, ma_a);
@@ -832,47 +864,21 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
             __threadfence(); // the rows and memo words are in L2 before anyone passes the barrier below
             LAP_TICK(6);
         }
-        {
-            int32_t pm[kLapRounds][NP];
-            uint32_t pw[kLapRounds][NP];
-            int pb[kLapRounds];
+        int32_t pm[kLapRounds][NP];
+        uint32_t pw[kLapRounds][NP];
+        int pb[kLapRounds];
 #pragma unroll
-            for (int rd = 0; rd < kLapRounds; rd++) {
-                const int jw = wave + rd * kLapWaves;
-                pb[rd] = -1;
-                if (jw < Jc) pb[rd] = lane_bcast_i32(g, jw) >> sh, fetch(pb[rd], pm[rd], pw[rd]);
-            }
-            __syncthreads(); // ---- barrier C: the winners' new memo words are in LDS (and in L2)
-            LAP_TICK(3);
+        for (int rd = 0; rd < kLapRounds; rd++) { // (winner j is wave 1 + (j mod (waves - 1))'s: wave 0 will be finding the next lap's cuts)
+            const int jw = wslot + rd * kLapSlots;
+            pb[rd] = -1;
+            if (wave > 0 && jw < Jc) pb[rd] = lane_bcast_i32(g, jw) >> sh, fetch(pb[rd], pm[rd], pw[rd]);
+            else {
 #pragma unroll
-            for (int rd = 0; rd < kLapRounds; rd++) {
-                const int jw = wave + rd * kLapWaves;
-                if (pb[rd] < 0) continue;
-                const int32_t i0 = (pb[rd] << sh) + lane * NP;
-                // the words fetched above may predate the placements: the winners' own come from LDS.  Two winners at most share a
-                // block, and they are neighbours (a stretch holds K >= block size feasible nodes)
-                for (int x = jw - 1; x <= jw + 1; x++)
-                    if (x >= 0 && x < Jc) {
-                        const int32_t gx = L.g[x], nx = L.nm[x];
-#pragma unroll
-                        for (int k = 0; k < NP; k++)
-                            if (i0 + k == gx) pm[rd][k] = nx;
-                    }
-                uint32_t pf = 0, pmt = 0, pma = 0;
-                unsigned long long pk = 0;
-#pragma unroll
-                for (int k = 0; k < NP; k++)
-                    if (pm[rd][k] >= 0) {
-                        const uint32_t cnt = (pw[rd][k] >> kStatCntShift) & kStatCntMask, aff = pw[rd][k] & kStatAffMask;
-                        pf += 1, pmt = cnt > pmt ? cnt : pmt, pma = aff > pma ? aff : pma;
-                        const unsigned long long k2 = make_key((int64_t)pm[rd][k], (int64_t)(i0 + k));
-                        pk = k2 > pk ? k2 : pk;
-                    }
-                pk = lap_wave_best(pk != 0, pk);
-                pf = wave_sum_u32_dpp(pf), pmt = wave_max_u32(pmt), pma = wave_max_u32(pma);
-                if (lane == 0) L.T[nbp + pb[rd]] = make_uint4((uint32_t)pk, (uint32_t)(pk >> 32), (pmt << 16) | pma, pf); // (the tree above it: the next lap's step 1)
+                for (int k = 0; k < NP; k++) pm[rd][k] = -1, pw[rd][k] = 0;
             }
         }
+        __syncthreads(); // ---- barrier C: the winners' new memo words are in LDS (and in L2)
+        LAP_TICK(2);
         // ---- the run state, identically in every thread
         {
             const int32_t ns = all ? start : L.cut_node[Jc]; // where the last committed cycle stopped
@@ -898,10 +904,62 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
             prev_Jc = Jc;
             laps += 1;
             if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312
+            if (budget <= 0 && !done) J = 0;
+            else plan();
         }
-        __syncthreads(); // ---- barrier D: the winners' leaves are written
-        LAP_TICK(4);
+        if (wave == 0) {
+            // ---- the counts above (and in) the leaves of the winners that left the feasible nodes, then the next lap's cuts
+            if (lane < prev_Jc && L.nm[lane] < 0)
+                for (int p = nbp + (L.g[lane] >> sh); p >= 1; p >>= 1) atomicSub(&L.T[p].w, 1u);
+            if (J > 0) find_cuts();
+            LAP_TICK(7);
+        } else {
+            // ---- the winners' leaves (keys and maxima; the counts are wave 0's).  The words fetched above may predate the placements:
+            // the winners' own come from LDS.  Two winners at most share a block, and they are neighbours (a stretch holds K >= block
+            // size feasible nodes).  The maxima change only when a node left the feasible ones.
+            const int32_t nmv = lane < prev_Jc ? L.nm[lane] : 0;
+#pragma unroll
+            for (int rd = 0; rd < kLapRounds; rd++) {
+                const int jw = wslot + rd * kLapSlots;
+                if (pb[rd] < 0) continue; // (wave-uniform)
+                const int32_t i0 = (pb[rd] << sh) + lane * NP;
+                bool gone = false;
+                for (int x = jw - 1; x <= jw + 1; x++)
+                    if (x >= 0 && x < prev_Jc) {
+                        const int32_t gx = lane_bcast_i32(g, x);
+                        if ((gx >> sh) != pb[rd]) continue;
+                        const int32_t nx = lane_bcast_i32(nmv, x);
+                        gone = gone || nx < 0;
+#pragma unroll
+                        for (int k = 0; k < NP; k++)
+                            if (i0 + k == gx) pm[rd][k] = nx;
+                    }
+                int32_t bm = -1, bi = 0;
+#pragma unroll
+                for (int k = 0; k < NP; k++)
+                    if (pm[rd][k] > bm) bm = pm[rd][k], bi = i0 + k;
+                const uint32_t top = wave_max_u32((uint32_t)(bm + 1));
+                unsigned long long k = 0;
+                if (top) k = make_key((int64_t)top - 1, (int64_t)lane_bcast_i32(bi, __ffsll((long long)__ballot((uint32_t)(bm + 1) == top)) - 1));
+                if (lane == 0) L.T[nbp + pb[rd]].x = (uint32_t)k, L.T[nbp + pb[rd]].y = (uint32_t)(k >> 32); // (the tree above it: wave 1, in the next lap)
+                if (gone) {
+                    uint32_t x = 0, y = 0;
+#pragma unroll
+                    for (int k2 = 0; k2 < NP; k2++)
+                        if (pm[rd][k2] >= 0) {
+                            const uint32_t cnt = (pw[rd][k2] >> kStatCntShift) & kStatCntMask, aff = pw[rd][k2] & kStatAffMask;
+                            x = cnt > x ? cnt : x, y = aff > y ? aff : y;
+                        }
+                    x = wave_max_u32(x), y = wave_max_u32(y);
+                    if (lane == 0) L.T[nbp + pb[rd]].z = (x << 16) | y;
+                }
+            }
+        }
+        __syncthreads(); // ---- barrier D: the winners' leaves are written, the next lap's cuts are known
+        LAP_TICK(3);
     }
+    if (!done && !dirty && Ftotal == 0 && budget > 0) // schedule_one.go:448-454: every node was visited, none passed
+        done = DONE_UNSCHEDULABLE, rounds += 1, scans += 1, last_feasible = 0, last_evaluated = N, evaluated += N, winner = -1;
 #undef LAP_TICK
     if (!dirty) // the summaries the next launch reloads (after a rebuild request k_sb_build writes them all)
         for (int b = tid; b < nb; b += kLapThreads) {
@@ -910,8 +968,10 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
         }
     if (a.prof) {
         if (tid == 0)
-            for (int i = 0; i < 6; i++) a.prof[i] += pf[i];
-        if (tid == kLapThreads - 64) a.prof[6] += pf[6]; // (the committing wave's own time: rows, memo words, fence)
+            for (int i = 0; i < 4; i++) a.prof[i] += pf[i];
+        if (tid == 64) a.prof[4] += pf[4], a.prof[5] += pf[5]; // (wave 1: the tree above the last winners, the range queries: both inside [0])
+        if (tid == kLapThreads - 64) a.prof[6] += pf[6];       // (the committing wave's own time: rows, memo words, fence: inside [2])
+        if (tid == 0) a.prof[7] += pf[7];                       // (wave 0: the counts, the next lap's cuts; the rest of [3] is waiting for the leaves)
     }
     if (tid == 0) {
         S.smp_start = start, S.placed = placed, S.rounds = rounds, S.scans = scans, S.evaluated = evaluated, S.winner = winner;

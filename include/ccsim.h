@@ -477,9 +477,9 @@ int ccsim_debug_coupled(ccsim_engine *e, int64_t *out16);
  * plugins ran (csrc/ccsim_sampled.h): out8[0] = 1 if it ran on the resident block summaries, [1] = 1 if a lap of the ring at a time
  * (k_sb_laps; 0: a cycle at a time, k_sb_cycles), [2] = launches of that kernel, [3] = laps evaluated, [4] = stretches re-evaluated node
  * by node under their own normalization maxima, [5] = log2 of the block size, [6] = blocks, [7] = K (numFeasibleNodesToFind);
- * out[8..14] (with CCSIM_SB_PROF=1): 10 ns ticks k_sb_laps spent [8] finding the cut blocks (while the tree is brought up to date),
- * [9] on the cut blocks and the range queries, [10] on the decision (+ stretches re-evaluated), [11] waiting for the placements, [12] on
- * the winners' leaves; [14] the committing wave's own time inside [11].  `out` holds 16 values.
+ * out[8..14] (with CCSIM_SB_PROF=1): 10 ns ticks k_sb_laps spent [8] on the cut blocks (wave 1: the tree, the range queries), [9] on
+ * the decision (+ stretches re-evaluated), [10] waiting for the placements, [11] on the winners' leaves (wave 0: the next lap's cuts);
+ * [14] the committing wave's own time inside [10].  `out` holds 16 values.
  * Knobs (read when a run begins; every value gives the same results): CCSIM_SB=0 three node passes per cycle, =2 a cycle at a time;
  * CCSIM_SB_CYCLES cycles per launch; CCSIM_SB_SHIFT block size; CCSIM_SB_SLOW_FLOOR nodes below which differing maxima never rebuild. */
 int ccsim_debug_sampled(ccsim_engine *e, int64_t *out16);
