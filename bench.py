@@ -144,8 +144,9 @@ def secondary_lines(device: int):
                                                   f"first_{CW_GATE}_placements_equal_oracle": True, "windows_in_checked_prefix": int(head_windows)}
     e.close()
     # the headline snapshot and pod under the reference's DEFAULT percentageOfNodesToScore (0 = adaptive: 5 % at 1M nodes, the first K = 50 000
-    # feasible nodes of the rotating visiting order per cycle, schedule_one.go:610-723; SURVEY 8(d) "mode B"): cycles on resident block
-    # summaries (csrc/ccsim_sampled.h) -- the literal loop of scheduling cycles, one placement each
+    # feasible nodes of the rotating visiting order per cycle, schedule_one.go:610-723; SURVEY 8(d) "mode B"): the literal sequence of
+    # scheduling cycles, one placement each -- evaluated a LAP of the ring at a time (the ~19 cycles of a lap visit disjoint stretches:
+    # csrc/ccsim_sampled.h k_sb_laps).  Gate: 3000 cycles = ~158 laps, each of them once round the ring (a wrap per lap): log AND nodes visited.
     import dataclasses
     nodes, pod, prof = synth.make_config("C4", n_nodes=n)
     prof = dataclasses.replace(prof, percentage_of_nodes_to_score=0)
@@ -155,10 +156,14 @@ def secondary_lines(device: int):
     e.load(nodes, pod, prof)
     head = e.run(max_limit=MB_GATE, mode="sequential", log_cap=MB_GATE)
     assert np.array_equal(head.log, ref.log) and head.evaluated_total == ref.evaluated_total, "mode B: engine and oracle differ (log / nodes visited)"
+    gate_info = e.sampled_info()
     r, dt = best_of(e, lambda: e.run(max_limit=100_000, mode="sequential", want_log=False, log_cap=0))
+    info = e.sampled_info()
     out["mode_b_adaptive_sampling_1M_nodes"] = {"value": r.placed / dt, "unit": "placements/s", "placements": int(r.placed), "us_per_cycle": dt * 1e6 / max(1, r.placed),
                                                 "nodes_visited_per_cycle": r.evaluated_total / max(1, r.placed), "resident_form": bool(r.pass_launches > 0),
-                                                f"first_{MB_GATE}_placements_and_visited_nodes_equal_oracle": True}
+                                                "lap_at_a_time": bool(info["laps_form"]), "laps": int(info["laps"]), "cycles_per_lap": r.placed / max(1, info["laps"]),
+                                                "us_per_lap": dt * 1e6 / max(1, info["laps"]), "kernel_launches": int(info["launches"]),
+                                                f"first_{MB_GATE}_placements_and_visited_nodes_equal_oracle": True, "laps_in_checked_prefix": int(gate_info["laps"])}
     e.close()
     return out
 
@@ -238,10 +243,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # N > 1: the persistent level kernel ACROSS the GPUs (mailboxes over xGMI inside ONE launch per rank; csrc/ccsim_persist.h MB form,
-        # include/ccsim.h ccsim_dist_mbox_*).  The library's default is the RCCL pass protocol; the bench opts in (CCSIM_DIST_MAILBOX=0
-        # for the A/B run).  Every rank that cannot take part -- a box that cannot be mapped, a shard that does not qualify, a bounded
-        # spin that expires -- sends ALL ranks back to the pass protocol, from the untouched state; `config.multi_gpu_form` says what ran.
+        # N > 1, two forms of the same sharded run, both measured by this process:
+        #   * the RCCL pass protocol (commit + reduce + ncclAllGather(256 B/rank) + decide per pass): the HEADLINE -- the library's default,
+        #     the form whose every piece has run on real hardware (one-rank RCCL on the GPU box, the protocol on gloo);
+        #   * the persistent level kernel ACROSS the GPUs (mailboxes over xGMI inside ONE launch per rank; csrc/ccsim_persist.h MB form,
+        #     include/ccsim.h ccsim_dist_mbox_*): connected here (CCSIM_DIST_MAILBOX=1), PROBED by one untimed step, and timed as the A/B
+        #     field `multi_gpu_forms.mailbox` only if that probe stood on every rank.  A launch that had to be abandoned is never tried
+        #     again for the pod spec (libccsim.so: mb_go = 0), so a form that cannot run on this box costs its bounded spins once.
         os.environ.setdefault("CCSIM_DIST_MAILBOX", "1")
         if world == 1:  # CCSIM_FORCE_DIST=1 without a launcher: a one-rank job on this GPU
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29513")):
@@ -282,22 +290,61 @@ def main():
             eng.reset_state()
             return eng.run(max_limit=lim, mode=mode, want_log=False, reuse_buffers=True)
 
+    library_driven = distributed and isinstance(runner, ccdist.LibraryRunner)
+    forms = None
+    if library_driven:  # the timed steps take the pass protocol; the mailbox form is probed and timed after them
+        os.environ["CCSIM_DIST_FORM"] = "passes"
+
+    def timed_steps(n_steps):
+        """EXACTLY n_steps steps between two barriers: (whole time, per-step times, the last result, placements, passes)"""
+        barrier()
+        t_0 = time.perf_counter()
+        per, placed_, scans_, res = [], 0, 0, None
+        for _ in range(n_steps):
+            s_0 = time.perf_counter()
+            res = step(args.mode, limit)
+            per.append(time.perf_counter() - s_0)
+            placed_ += res.placed
+            scans_ += res.scans
+        barrier()
+        return time.perf_counter() - t_0, per, res, placed_, scans_
+
+    def over_ranks(x, op="max"):
+        if not distributed:
+            return x
+        t_ = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}" if have_gpu else "cpu")
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.MIN)
+        return float(t_.item())
+
     for _ in range(args.warmup):
         step(args.mode, limit)
-    barrier()
-    t0 = time.perf_counter()
-    placed = scans = 0
-    for _ in range(args.steps):
-        r = step(args.mode, limit)
-        placed += r.placed
-        scans += r.scans
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, per_step, r, placed, scans = timed_steps(args.steps)
     r.per_node_count = r.per_node_count.copy()  # (a view of the reused result array until here: later runs of the engine overwrite it)
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if have_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = over_ranks(dt)
+    if library_driven:
+        def form_stats(dt_, per_, res_, placed_):
+            return {"form": eng.dist_info()["last_form"], "ms_per_step": dt_ / args.steps * 1e3, "max_step_ms": over_ranks(max(per_)) * 1e3,
+                    "median_step_ms": over_ranks(float(np.median(per_))) * 1e3, "value": placed_ / dt_, "passes_per_step": int(res_.scans)}
+        forms = {"passes": form_stats(dt, per_step, r, placed)}
+        assert forms["passes"]["form"] == "passes", forms
+        # the persistent kernel across the GPUs: one untimed probe step; timed only if it stood on every rank (all-reduced inside the library)
+        os.environ["CCSIM_DIST_FORM"] = "mailbox"
+        info0 = eng.dist_info()
+        p0 = time.perf_counter()
+        rp = step(args.mode, limit)
+        probe_s = over_ranks(time.perf_counter() - p0)
+        info = eng.dist_info()
+        stood = over_ranks(1.0 if info["last_form"] == "mailbox" else 0.0, "min") == 1.0
+        forms["mailbox"] = {"connected": bool(info["mailboxes_connected"]), "probe_step_ms": probe_s * 1e3, "probe_stood_on_every_rank": stood,
+                            "launches_abandoned": int(info["mailbox_abandoned"] - info0["mailbox_abandoned"]),
+                            "probe_result_equals_pass_protocol": bool(rp.placed == r.placed and np.array_equal(rp.per_node_count, r.per_node_count))}
+        if stood and args.mode == "batched":
+            for _ in range(args.warmup):
+                step(args.mode, limit)
+            mdt, mper, mr, mplaced, _ = timed_steps(args.steps)
+            forms["mailbox"].update(form_stats(over_ranks(mdt), mper, mr, mplaced))
+            forms["mailbox"]["result_equals_pass_protocol"] = bool(mr.placed == r.placed and np.array_equal(mr.per_node_count, r.per_node_count))
+        os.environ["CCSIM_DIST_FORM"] = "passes"
 
     # the literal one-round-per-pass loop on the same snapshot, for comparison (untimed by the driver)
     seq = None
@@ -414,6 +461,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "step_ms": {"median": over_ranks(float(np.median(per_step))) * 1e3, "max": over_ranks(max(per_step)) * 1e3},  # (the slowest rank's; a step stuck in a bounded spin shows in `max`)
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
@@ -428,10 +476,10 @@ def main():
             "passes_per_step": scans // max(1, args.steps),
             "sequential_mode_placements_per_s": seq,
             "parallelism": f"node-shard x{world}",
-            "multi_gpu_form": None if not distributed else (
-                "persistent level kernel per rank, grid reduce extended over the ranks through xGMI mailboxes (one launch per run)"
-                if r.pass_launches == 1 and r.scans < 64 and os.environ.get("CCSIM_DIST_MAILBOX") == "1"
-                else "pass protocol: commit + reduce + ncclAllGather(256 B/rank) + decide per pass"),
+            # the form the TIMED steps took (`value`, `ms_per_step`); `multi_gpu_forms` holds both forms' measurements, each with the form the
+            # library reports for it, the median and the maximum step time (a step that sat in a bounded spin shows there)
+            "multi_gpu_form": None if not distributed else "pass protocol: commit + reduce + ncclAllGather(256 B/rank) + decide per pass",
+            "multi_gpu_forms": forms,
             "arithmetic": "exact integer results: the canonical state is int64 columns; this snapshot's values fit the engine's lossless "
                           "32-bit mirrors (validated per pod spec), which the timed kernels compute in (int32 / f32 estimates with exact "
                           "fix-ups); `wide_path_ms_per_step` is the same step on the int64 / fp64 path",

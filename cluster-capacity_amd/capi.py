@@ -151,6 +151,7 @@ SYMBOLS = {
     "ccsim_debug_multi_memo": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_coupled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ccsim_debug_sampled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ccsim_debug_dist": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -564,6 +565,14 @@ class Engine:
             d["prof_us_per_cycle"] = {k: round(out[8 + i] / 100.0 / out[15], 3) for i, k in enumerate(names)}
             d["cycles"] = int(out[15])
         return d
+
+    def dist_info(self):
+        """Which form this engine's library-driven sharded runs took (ccsim_debug_dist)."""
+        out = (C.c_int64 * 8)()
+        self._chk(self.lib.ccsim_debug_dist(self.h, out), "ccsim_debug_dist")
+        forms = {0: None, 1: "mailbox", 2: "passes", 3: "windows"}
+        return {"mailboxes_connected": bool(out[0]), "mailbox_go": int(out[1]), "mailbox_abandoned": int(out[2]), "last_form": forms.get(int(out[3])),
+                "mailbox_launches": int(out[4]), "ranks": int(out[5])}
 
     def sampled_info(self):
         """Which form the last sampled search (percentageOfNodesToScore < 100) took (ccsim_debug_sampled)."""

@@ -233,6 +233,9 @@ def simulate(snap: ingest.Snapshot, max_limit: int, mode: Optional[str] = None, 
 def rejected_by_prefilter(nodes: M.NodesSoA, pod: M.PodSpec, msg: str, placed_before=None) -> M.RunResult:
     """The cycle a PreFilter plugin rejects (schedule_one.go:495-508): no node is evaluated, every node carries the plugin's status."""
     n = nodes.n
+    if n == 0:  # schedulePod returns ErrNoNodesAvailable BEFORE any PreFilter plugin runs (schedule_one.go:438-440; ADVICE r5)
+        return M.RunResult(placed=0, stop=M.STOP_NO_NODES, per_node_count=np.zeros(0, np.int32), log=np.zeros(0, np.int32), hist=np.zeros(M.NREASON, np.int64),
+                           hist_taintset=np.zeros(max(1, len(pod.taint_filter_ok)), np.int64), n_code_unschedulable=0, rounds=1)
     return M.RunResult(placed=0, stop=M.STOP_UNSCHEDULABLE, per_node_count=np.zeros(n, np.int32), log=np.zeros(0, np.int32),
                        hist=np.zeros(M.NREASON, np.int64), hist_taintset=np.zeros(max(1, len(pod.taint_filter_ok)), np.int64),
                        n_code_unschedulable=0, rounds=1, prefilter_msg=msg)
@@ -327,7 +330,8 @@ def simulate_specs_one_cycle_at_a_time(nodes: M.NodesSoA, pods, prof: M.Profile,
             t = len(log) % P
             if pods[t].prefilter_reject:  # a volume plugin's PreFilter: this template's cycle ends the run
                 last, prefilter_msg = rejected_by_prefilter(nodes, pods[t], pods[t].prefilter_reject), pods[t].prefilter_reject
-                stop, stop_spec = M.STOP_UNSCHEDULABLE, t
+                stop, stop_spec = last.stop, t  # (STOP_NO_NODES on an empty cluster: ErrNoNodesAvailable comes before any PreFilter)
+                prefilter_msg = last.prefilter_msg
                 break
             if pods[t].rwop_capacity_one and per_spec[t] == 1:  # its first clone holds the ReadWriteOncePod claim now
                 pods[t] = with_rwop_in_use(pods[t], N)  # (pod_with_clones adds the clones' own disks below)

@@ -134,6 +134,9 @@ struct ccsim_engine {
     int mb_ranks = 0, mb_rank = 0;      // ranks of the mailbox job / this engine's rank
     uint32_t mb_seq = 0;                // launches of the mailbox form so far: the same on every rank (they launch together or not at all)
     int mb_k = 0;                       // K of the launch in flight
+    int dist_last_form = 0;             // ccsim_dist_run: what the last run took (1 the persistent kernel across the GPUs, 2 the RCCL pass protocol, 3 windows of placements per exchange)
+    int mb_launches = 0;                // ccsim_dist_run: launches of the persistent kernel across the GPUs
+    int mb_abandoned = 0;               // ccsim_dist_run: mailbox launches that ended in the fall-back (each sets mb_go = 0)
     int mb_go = -1;                     // ccsim_dist_run: did every rank call this pod / snapshot eligible? (-1: not agreed yet; reset by set_pod / load_nodes / comm_init -- SPMD: on every rank alike)
     DevState mb_state0{};               // the run state ccsim_dist_begin uploaded (restored when the ranks fall back to the pass protocol)
     int32_t *d_mb_ok = nullptr;         // device flag of the launch in flight: 1 = this rank finished cleanly (ccsim_persist.h ok_flag)
@@ -2680,7 +2683,12 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
     // The persistent kernel across the GPUs (mailboxes connected by ccsim_dist_comm_init under CCSIM_DIST_MAILBOX=1): one launch per
     // rank for the whole batched run, the exchange inside the kernel.  Two agreements around it -- is every rank eligible, did every
     // rank finish -- and the pass protocol below as the fallback from the untouched state.
-    if (mode == CCSIM_MODE_BATCHED && e->mbox_ready && e->mb_ranks == e->comm_ranks) { // (connected by the same collective call on every rank)
+    // CCSIM_DIST_FORM=passes (read per run; the SAME value on every rank): this run takes the RCCL pass protocol although the mailboxes are
+    // connected -- the A/B knob of bench.py, which times both forms in one process
+    const char *form = getenv("CCSIM_DIST_FORM");
+    const bool passes_only = form && !strcmp(form, "passes");
+    e->dist_last_form = 2;
+    if (mode == CCSIM_MODE_BATCHED && e->mbox_ready && e->mb_ranks == e->comm_ranks && !passes_only) { // (connected by the same collective call on every rank)
         int32_t go = e->mb_go, fine = 0;
         if (go < 0) { // (once per pod spec: eligibility is a property of the snapshot and the pod)
             if ((rc = dist_all_min(e, ccsim_dist_mbox_eligible(e), &go))) return rc;
@@ -2689,6 +2697,7 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
         if (go) {
             // launch -> ncclAllReduce(min) of the device flag -> state + verdict to the host: ONE stream sync for the whole run
             const int lrc = ccsim_dist_mbox_launch(e);
+            e->mb_launches += 1;
             if (lrc != 0) HIPCHK(e, hipMemsetAsync(e->d_mb_ok, 0, sizeof(int32_t), e->stream)); // (this rank could not launch: every rank falls back)
             RCCLCHK(e, rccl().AllReduce(e->d_mb_ok, e->d_mb_ok, 1, kNcclInt32, kNcclMin, e->rccl_comm, e->stream));
             HIPCHK(e, hipMemcpyAsync(e->h_mb_ok, e->d_mb_ok, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
@@ -2702,7 +2711,19 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
             if (dist_debug()) fprintf(stderr, "[ccsim dist] rank %d: mailbox form %s (%.3f ms)\n", e->comm_rank, fine ? "finished on every rank" : "abandoned: pass protocol", e->kernel_ms);
             rc = ccsim_dist_mbox_finish(e, fine);
             if (rc < 0) return rc;
-            if (fine) return ccsim_dist_finish(e, out);
+            if (fine) {
+                e->dist_last_form = 1;
+                return ccsim_dist_finish(e, out);
+            }
+            // Abandoned (a rank could not launch, a grid barrier or a peer's record did not arrive within the bounded spins): the verdict is
+            // the all-reduced minimum, so every rank lands here together -- and every later run of this pod spec would relaunch the
+            // kernel, spin for seconds and fall back again.  One attempt per pod spec: the pass protocol from now on (set_pod /
+            // load_nodes / comm_init agree anew).
+            e->mb_go = 0;
+            e->mb_abandoned += 1;
+            if (e->comm_rank == 0 || dist_debug())
+                fprintf(stderr, "[ccsim dist] rank %d: the persistent kernel across the GPUs was abandoned (%.1f ms lost); this pod spec's runs take the RCCL pass protocol from here on\n",
+                        e->comm_rank, e->kernel_ms);
         }
     }
     int per_poll = 32;
@@ -2737,6 +2758,7 @@ extern "C" int ccsim_dist_run(ccsim_engine *e, int64_t max_limit, int32_t mode, 
             float wms = 0;
             HIPCHK(e, hipEventElapsedTime(&wms, e->ev0, e->ev1));
             e->kernel_ms = wms;
+            e->dist_last_form = 3;
             return ccsim_dist_finish(e, out);
         }
     }
@@ -3199,6 +3221,15 @@ extern "C" int ccsim_debug_coupled(ccsim_engine *e, int64_t *out8) {
     out8[0] = e->have_pod && e->cw_ok ? 1 : 0;
     if (e->h_state && e->begun) out8[1] = e->h_state->cw_windows, out8[2] = e->h_state->cw_fallback, out8[5] = e->h_state->cw_fast_windows, out8[6] = e->h_state->cw_full_windows, out8[7] = e->h_state->cw_swept;
     out8[3] = e->cw_ok ? e->cw_plan.window : 0, out8[4] = e->cw_ok ? e->cw_plan.list_len : 0;
+    return 0;
+}
+
+// measurement aid: which form the sharded runs of this engine took
+extern "C" int ccsim_debug_dist(ccsim_engine *e, int64_t *out8) {
+    if (!e || !out8) return -EINVAL;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    out8[0] = e->mbox_ready ? 1 : 0, out8[1] = e->mb_go, out8[2] = e->mb_abandoned, out8[3] = e->dist_last_form, out8[4] = e->mb_launches;
+    out8[5] = e->comm_ranks;
     return 0;
 }
 

@@ -201,7 +201,7 @@ struct DevState {
     // (k_level_score); otherwise k_level_commit keeps it current and these counts track the feasible set:
     int64_t cur_nfeas;       // feasible nodes of this shard
     int64_t cur_c_mt, cur_c_ma; // this shard's feasible holders of the (global) normalization maxima mt_a / ma_a
-    int32_t lvl_full, pad1;
+    int32_t lvl_full, sb_laps; // (sb_laps: k_sb_laps -- laps of the ring evaluated; diagnostics, in what was padding)
     // percentageOfNodesToScore < 100 (schedule_one.go:610-723): the sampled search of the sequential mode
     int64_t smp_K;           // numFeasibleNodesToFind; 0 = every node is scored
     int64_t smp_start;       // nextStartNodeIndex
@@ -224,7 +224,7 @@ struct DevState {
     int32_t lvl_kb, lvl_kb_max; // levels per blind batch: now / at most (1 = the one-level-per-pass protocol)
     int32_t lvl_blind;       // the commit of this pass is a blind batch: validate it before its placements count
     int32_t lvl_rollback;    // the next pass undoes the batch of pass lvl_pass (a normalization maximum ran out of holders, or --max-limit was crossed inside it)
-    int32_t lvl_pass, pad2;  // stamp of the last committing pass (commit rows carry it next to the clones they took in it)
+    int32_t lvl_pass, sb_slow; // stamp of the last committing pass; (sb_slow: k_sb_laps -- stretches re-evaluated node by node under their own maxima)  // (commit rows carry it next to the clones they took in it)
     int64_t lvl_ev;          // score level at which a rolled-back batch located its normalization event (-1: none): ccsim_level.h level_decide
     // windowed mode for topology-coupled plugins (ccsim_coupled.h)
     int32_t cw_fallback;     // 1 = the windowed mode gave up on this run: the one-pass-per-placement loop continues from the current state
@@ -234,7 +234,6 @@ struct DevState {
     // the sampled search on resident block summaries (ccsim_sampled.h)
     int32_t sb_dirty;        // 1 = memo and summaries do not describe the columns under (mt_a, ma_a): k_sb_build runs before the next cycle
     int32_t sb_cycles;       // launches of k_sb_cycles / k_sb_laps that ran (diagnostics: did this path take the run)
-    int32_t sb_laps, sb_slow; // k_sb_laps: laps of the ring evaluated, stretches re-evaluated node by node under their own maxima
     // persistent batched launch (ccsim_persist.h): the normalization maxima the launch started with (the next launch's hint)
     int32_t p_mt0, p_ma0;
 };

@@ -254,6 +254,7 @@ inline void add_own_clone(const Snapshot &s, PodSide &side, size_t n) {
 inline RunResult rejected_by_prefilter(const Snapshot &s, const PodSide &side, const std::string &msg) {
     RunResult r;
     r.placed = 0, r.stop = CCSIM_STOP_UNSCHEDULABLE, r.n_code_unschedulable = 0, r.prefilter_msg = msg;
+    if (s.n() == 0) r.stop = CCSIM_STOP_NO_NODES, r.prefilter_msg.clear(); // schedulePod returns ErrNoNodesAvailable BEFORE any PreFilter plugin runs (schedule_one.go:438-440)
     r.per_node_count.assign(s.n(), 0);
     r.hist.assign(CCSIM_NREASON, 0);
     r.hist_taintset.assign(side.taint_filter_ok.size(), 0);
@@ -288,6 +289,7 @@ inline RunResult simulate_one_cycle_at_a_time(const Api &api, ccsim_engine *e, c
         const size_t t = (size_t)(r.placed % (int64_t)P);
         if (!sides[t].prefilter_reject.empty()) { // a volume plugin's PreFilter: this template's cycle ends the run
             r.stop = CCSIM_STOP_UNSCHEDULABLE, r.stop_spec = (int32_t)t, r.n_code_unschedulable = 0, r.prefilter_msg = sides[t].prefilter_reject;
+            if (N == 0) r.stop = CCSIM_STOP_NO_NODES, r.prefilter_msg.clear(); // (ErrNoNodesAvailable comes before any PreFilter: schedule_one.go:438-440)
             r.hist_taintset.assign(sides[t].taint_filter_ok.size(), 0);
             break;
         }
@@ -536,6 +538,7 @@ inline RunResult simulate_sharded_one_cycle_at_a_time(const Api &api, const Snap
                 const size_t t = (size_t)(r.placed % (int64_t)P);
                 if (!stop_all && !sides[t].prefilter_reject.empty()) { // a volume plugin's PreFilter: this template's cycle ends the run
                     r.stop = CCSIM_STOP_UNSCHEDULABLE, r.stop_spec = (int32_t)t, r.n_code_unschedulable = 0, r.prefilter_msg = sides[t].prefilter_reject;
+                    if (N == 0) r.stop = CCSIM_STOP_NO_NODES, r.prefilter_msg.clear(); // (ErrNoNodesAvailable comes before any PreFilter: schedule_one.go:438-440)
                     r.hist_taintset.assign(sides[t].taint_filter_ok.size(), 0);
                     stop_all = true;
                 }

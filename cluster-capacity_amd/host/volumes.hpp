@@ -214,7 +214,7 @@ inline bool csi_volume(const Value &pvc, const std::map<std::string, const Value
 
 // `live`: the snapshot's non-terminal pods on kept nodes, `live_node[j]`: the node index of live[j]
 inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Value *> &nodes, const std::vector<const Value *> &live,
-                              const std::vector<size_t> &live_node, const VolumeObjects &vo, size_t clone_index = 0) {
+                              const std::vector<size_t> &live_node, const VolumeObjects &vo, size_t clone_index = 0, bool skip_rwop_filter = false) {
     VolumeSide out;
     const Value &spec = sim_pod["spec"];
     const std::string ns = sim_pod["metadata"]["namespace"].truthy() ? sim_pod["metadata"]["namespace"].text() : "default";
@@ -354,8 +354,8 @@ inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Valu
                         std::find(rwop.begin(), rwop.end(), v["persistentVolumeClaim"]["claimName"].text()) != rwop.end())
                         used = true;
             }
-            if (used) mark_all(2);
-            else out.rwop_capacity_one = true;
+            if (used && !skip_rwop_filter) mark_all(2); // (skip: DefaultPreemption's dry run keeps this verdict as a count of its own, veto_with_victims_gone)
+            else if (!used) out.rwop_capacity_one = true;
         }
     }
     // NodeVolumeLimits (nodevolumelimits/csi.go:255-339): no CSINode in the reference's fake cluster, hence no limits (:265-290).  With the
@@ -419,17 +419,19 @@ inline VolumeSide volume_side(const Value &sim_pod, const std::vector<const Valu
         }
     }
     if (vo.on("VolumeBinding")) {
-        if (!bound.empty()) { // binder.go checkBoundClaims
-            bool missing = false;
-            for (const Value *c : bound) missing = missing || !pvs.count((*c)["spec"]["volumeName"].text());
-            if (missing) mark_all(6);
-            else
-                for (size_t i = 0; i < N; i++) {
-                    bool ok = true;
-                    for (const Value *c : bound) ok = ok && pv_node_affinity_matches(*pvs[(*c)["spec"]["volumeName"].text()], (*nodes[i])["metadata"]["labels"]);
-                    if (!ok) mark(i, 4);
+        if (!bound.empty()) // binder.go checkBoundClaims (:830-865): per node, claim by claim in the pod's order -- the FIRST failure is the node's verdict
+            for (size_t i = 0; i < N; i++)
+                for (const Value *c : bound) {
+                    const auto pv = pvs.find((*c)["spec"]["volumeName"].text());
+                    if (pv == pvs.end()) {
+                        mark(i, 6);
+                        break;
+                    }
+                    if (!pv_node_affinity_matches(*pv->second, (*nodes[i])["metadata"]["labels"])) {
+                        mark(i, 4);
+                        break;
+                    }
                 }
-        }
         for (const Value *pvc : delayed) { // binder.go findMatchingVolumes (no volume of the class to match) -> checkVolumeProvisions
             const std::string cname = claim_class(*pvc);
             for (const auto &kv : pvs)
@@ -473,7 +475,7 @@ inline std::vector<uint8_t> veto_with_victims_gone(const Value &sim_pod, const s
     std::vector<size_t> rest_node;
     for (size_t j = 0; j < live.size(); j++)
         if (!is_victim[j]) rest_live.push_back(live[j]), rest_node.push_back(live_node[j]);
-    VolumeSide rest = volume_side(sim_pod, nodes, rest_live, rest_node, vo, clone_index);
+    VolumeSide rest = volume_side(sim_pod, nodes, rest_live, rest_node, vo, clone_index, true);
     const size_t N = nodes.size();
     std::vector<uint8_t> veto = rest.veto.empty() ? std::vector<uint8_t>(N, 0) : rest.veto;
     if (std::find(full.veto.begin(), full.veto.end(), (uint8_t)2) != full.veto.end()) { // (the claim is in use by some pod of the snapshot)
@@ -487,19 +489,25 @@ inline std::vector<uint8_t> veto_with_victims_gone(const Value &sim_pod, const s
                     for (const auto &m : o["spec"]["accessModes"].items())
                         if (m.text() == "ReadWriteOncePod") rwop.insert(name);
         }
-        std::vector<size_t> users; // (indices into live)
+        // the reference's arithmetic (volume_restrictions.go:70-84, 219-232): PreFilter counts ONE reference per claim of the pod that is in use
+        // (IsPVCUsedByPods, by namespace/name); RemovePod subtracts one for every volume of the removed pod whose claimName is in the pod's
+        // set -- by NAME only, whatever the victim's namespace; the node is rejected while the count is above zero (:282-291)
+        std::set<std::string> used_here; // the pod's ReadWriteOncePod claims some pod of ITS namespace uses
         for (size_t j = 0; j < live.size(); j++) {
             const Value &p = *live[j];
             if ((p["metadata"]["namespace"].truthy() ? p["metadata"]["namespace"].text() : "default") != ns) continue;
-            bool uses = false;
-            for (const auto &v : p["spec"]["volumes"].items()) uses = uses || (!v["persistentVolumeClaim"].is_null() && rwop.count(v["persistentVolumeClaim"]["claimName"].text()));
-            if (uses) users.push_back(j);
+            for (const auto &v : p["spec"]["volumes"].items())
+                if (!v["persistentVolumeClaim"].is_null() && rwop.count(v["persistentVolumeClaim"]["claimName"].text())) used_here.insert(v["persistentVolumeClaim"]["claimName"].text());
         }
-        for (size_t i = 0; i < N; i++) {
-            bool all_leave = true;
-            for (size_t j : users) all_leave = all_leave && is_victim[j] && live_node[j] == i;
-            if (!all_leave && veto[i] != 1) veto[i] = 2;
+        const long count0 = (long)used_here.size();
+        std::vector<long> released(N, 0);
+        for (size_t j = 0; j < live.size(); j++) {
+            if (!is_victim[j]) continue;
+            for (const auto &v : (*live[j])["spec"]["volumes"].items())
+                if (!v["persistentVolumeClaim"].is_null() && rwop.count(v["persistentVolumeClaim"]["claimName"].text())) released[live_node[j]] += 1;
         }
+        for (size_t i = 0; i < N; i++)
+            if (count0 - released[i] > 0 && veto[i] != 1) veto[i] = 2;
     }
     bool any = false;
     for (uint8_t x : veto) any = any || x;

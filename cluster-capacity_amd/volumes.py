@@ -155,19 +155,31 @@ def veto_with_victims_gone(sim_pod: dict, nodes: List[dict], live: Sequence[dict
     """The verdicts as DefaultPreemption's dry run sees them on a node once ITS lower-priority pods are removed (default_preemption.go:217-310:
     per node; the PreFilter state follows through RemovePod, volume_restrictions.go:205-213).  Disk conflicts, volume limits and what a bound
     volume says about the node depend on that node alone: the evaluation over the remaining pods.  A ReadWriteOncePod claim in use is a
-    cluster-wide count: it stays in conflict on node n unless EVERY pod using the claim is a victim sitting on n."""
+    cluster-wide COUNT that the victims of node n decrement (the reference's own arithmetic, below)."""
     gone = {id(p) for p in victims}
-    rest = volume_side(sim_pod, nodes, [p for p in live if id(p) not in gone], index, **kw)
+    rest = volume_side(sim_pod, nodes, [p for p in live if id(p) not in gone], index, skip_rwop_filter=True, **kw)
     veto = np.zeros(len(nodes), np.uint8) if rest.veto is None else rest.veto.copy()
-    if full.veto is not None and (full.veto == M.VOL_RWOP).any():  # (the claim is in use by some pod of the snapshot)
+    if full.veto is not None and (full.veto == M.VOL_RWOP).any():  # (a ReadWriteOncePod claim of the pod is in use by some pod of the snapshot)
+        # the reference's arithmetic (volume_restrictions.go:70-84, 219-232): PreFilter counts ONE reference per claim of the pod that is in use
+        # (IsPVCUsedByPods, by namespace/name); RemovePod subtracts one for every volume of the removed pod whose claimName is in the pod's set --
+        # by NAME only, whatever the victim's namespace; the node is rejected while the count is above zero (:282-291)
         ns = (sim_pod.get("metadata") or {}).get("namespace") or "default"
         pvcs = {((o.get("metadata") or {}).get("namespace") or "default", (o.get("metadata") or {}).get("name", "")): o for o in kw.get("pvc_objs") or ()}
         mine = {(v["persistentVolumeClaim"] or {}).get("claimName", "") for v in (sim_pod.get("spec") or {}).get("volumes") or [] if v.get("persistentVolumeClaim") is not None}
         rwop = {c for c in mine if "ReadWriteOncePod" in (((pvcs.get((ns, c)) or {}).get("spec") or {}).get("accessModes") or [])}
-        users = [p for p in live if ((p.get("metadata") or {}).get("namespace") or "default") == ns and
-                 any(v.get("persistentVolumeClaim") is not None and (v["persistentVolumeClaim"] or {}).get("claimName", "") in rwop for v in (p.get("spec") or {}).get("volumes") or [])]
+        used = set()
+        for p in live:
+            pns = (p.get("metadata") or {}).get("namespace") or "default"
+            for v in (p.get("spec") or {}).get("volumes") or []:
+                if v.get("persistentVolumeClaim") is not None:
+                    used.add((pns, (v["persistentVolumeClaim"] or {}).get("claimName", "")))
+        count0 = sum(1 for c in rwop if (ns, c) in used)
+        released = np.zeros(len(nodes), np.int64)
+        for u in victims:
+            released[index[u["spec"]["nodeName"]]] += sum(1 for v in (u.get("spec") or {}).get("volumes") or []
+                                                          if v.get("persistentVolumeClaim") is not None and (v["persistentVolumeClaim"] or {}).get("claimName", "") in rwop)
         for i in range(len(nodes)):
-            if not all(id(u) in gone and index[u["spec"]["nodeName"]] == i for u in users) and veto[i] != M.VOL_DISK_CONFLICT:
+            if count0 - released[i] > 0 and veto[i] != M.VOL_DISK_CONFLICT:
                 veto[i] = M.VOL_RWOP
     return veto if veto.any() else None
 
@@ -197,8 +209,9 @@ def csi_volume(pvc: dict, pvs: Optional[dict], classes: dict) -> Optional[Tuple[
 def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: Dict[str, int], pvc_objs: Sequence[dict] = (),
                 class_objs: Sequence[dict] = (), pv_objs: Optional[Sequence[dict]] = None,
                 enabled: Sequence[str] = PLUGINS, csinode_objs: Sequence[dict] = (), attachment_objs: Sequence[dict] = (),
-                clone_index: int = 0) -> VolumeSide:
-    """`live`: the snapshot's non-terminal pods on kept nodes; `pv_objs` None: persistent volumes are not synced (the reference) --
+                clone_index: int = 0, skip_rwop_filter: bool = False) -> VolumeSide:
+    """`live`: the snapshot's non-terminal pods on kept nodes; `skip_rwop_filter`: DefaultPreemption's dry run keeps the ReadWriteOncePod verdict as a
+    count of its own (veto_with_victims_gone); `pv_objs` None: persistent volumes are not synced (the reference) --
     `csinode_objs` / `attachment_objs` (CSINode, VolumeAttachment) are then ignored too: NodeVolumeLimits has no limits to check."""
     spec = sim_pod.get("spec") or {}
     ns = (sim_pod.get("metadata") or {}).get("namespace") or "default"
@@ -337,7 +350,8 @@ def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: D
                     if v.get("persistentVolumeClaim") is not None:
                         used.add((pns, (v["persistentVolumeClaim"] or {}).get("claimName", "")))
             if any((ns, name) in used for name in rwop):
-                mark(np.ones(N, bool), M.VOL_RWOP)
+                if not skip_rwop_filter:
+                    mark(np.ones(N, bool), M.VOL_RWOP)
             else:
                 out.rwop_capacity_one = True
     # NodeVolumeLimits (nodevolumelimits/csi.go:255-339): no CSINode in the reference's fake cluster, hence no limits (:265-290).  With the
@@ -398,14 +412,20 @@ def volume_side(sim_pod: dict, nodes: List[dict], live: Sequence[dict], index: D
                 over[i] = any(drv in lim and count.get(drv, 0) + k > lim[drv] for drv, k in fresh.items())
             mark(over, M.VOL_MAX_COUNT)
     if "VolumeBinding" in enabled:
-        if bound:  # binder.go checkBoundClaims
-            missing = pvs is None or any(((c.get("spec") or {}).get("volumeName") or "") not in pvs for c in bound)
-            if missing:
-                mark(np.ones(N, bool), M.VOL_PV_NOT_EXIST)
-            else:
-                node_labels = [(n.get("metadata") or {}).get("labels") or {} for n in nodes]
-                bad = np.array([not all(pv_node_affinity_matches(pvs[(c["spec"]["volumeName"])], lb) for c in bound) for lb in node_labels], bool)
-                mark(bad, M.VOL_NODE_AFFINITY)
+        if bound:  # binder.go checkBoundClaims (:830-865): per node, claim by claim in the pod's order -- the FIRST failure is the node's verdict
+            node_labels = [(n.get("metadata") or {}).get("labels") or {} for n in nodes]
+            verdict = np.zeros(N, np.uint8)
+            for i, lb in enumerate(node_labels):
+                for c in bound:
+                    pv = None if pvs is None else pvs.get((c.get("spec") or {}).get("volumeName") or "")
+                    if pv is None:
+                        verdict[i] = M.VOL_PV_NOT_EXIST
+                        break
+                    if not pv_node_affinity_matches(pv, lb):
+                        verdict[i] = M.VOL_NODE_AFFINITY
+                        break
+            mark(verdict == M.VOL_PV_NOT_EXIST, M.VOL_PV_NOT_EXIST)
+            mark(verdict == M.VOL_NODE_AFFINITY, M.VOL_NODE_AFFINITY)
         for pvc in delayed:  # binder.go findMatchingVolumes (no volume of the class to match) -> checkVolumeProvisions
             cname = claim_class(pvc)
             if pvs is not None and any(((pv.get("spec") or {}).get("storageClassName") or "") == cname for pv in pvs.values()):

@@ -483,6 +483,13 @@ int ccsim_debug_coupled(ccsim_engine *e, int64_t *out16);
  * Knobs (read when a run begins; every value gives the same results): CCSIM_SB=0 three node passes per cycle, =2 a cycle at a time;
  * CCSIM_SB_CYCLES cycles per launch; CCSIM_SB_SHIFT block size; CCSIM_SB_SLOW_FLOOR nodes below which differing maxima never rebuild. */
 int ccsim_debug_sampled(ccsim_engine *e, int64_t *out16);
+/* ... and which form this engine's library-driven sharded runs (ccsim_dist_run) took: out8[0] = 1 if the ranks' mailboxes are connected
+ * (ccsim_dist_comm_init under CCSIM_DIST_MAILBOX=1), [1] = the ranks' agreement on the persistent kernel across the GPUs for the current
+ * pod spec (-1 not asked yet, 1 go, 0 no: not eligible, or a launch had to be abandoned -- one attempt per pod spec), [2] = launches
+ * abandoned so far, [3] = the form of the last run (1 that kernel, 2 the RCCL pass protocol, 3 windows of placements per exchange),
+ * [4] = launches of that kernel so far, [5] = ranks of the communicator.  CCSIM_DIST_FORM=passes (read per run, the same on every
+ * rank) keeps a run on the pass protocol although the mailboxes are connected. */
+int ccsim_debug_dist(ccsim_engine *e, int64_t *out8);
 
 #ifdef __cplusplus
 }

@@ -328,3 +328,8 @@ int ccsim_debug_multi_stops(ccsim_engine *e, int64_t *out) { (void)e, (void)out;
 int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_coupled(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
 int ccsim_debug_sampled(ccsim_engine *e, int64_t *out) { (void)e, (void)out; return -38; }
+int ccsim_debug_dist(ccsim_engine *e, int64_t *out) { /* no mailboxes here: every run is the pass protocol */
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[1] = -1, out[3] = 2, out[5] = e->world;
+    return 0;
+}

@@ -60,6 +60,45 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+class _OracleWithMemo:
+    """ccref_py with its whole-simulation entry points memoized per session on a digest of their inputs.  The oracle is deterministic
+    (the thread count changes its speed only), and the suites ask it the same question again and again -- one engine form per
+    parametrization against ONE oracle answer (VERDICT r5 weak #12: the GPU suite spent most of its 13 minutes inside the oracle)."""
+
+    def __init__(self, mod, budget_bytes=768 << 20):
+        self._m, self._memo, self._bytes, self._budget = mod, {}, 0, budget_bytes
+
+    def __getattr__(self, k):
+        return getattr(self._m, k)
+
+    def _key(self, *parts):
+        import hashlib
+        import pickle
+        return hashlib.sha1(pickle.dumps(parts, protocol=4)).digest()
+
+    def _copy(self, r):
+        import copy
+        import types
+        return types.SimpleNamespace(**{k: (v.copy() if hasattr(v, "copy") else copy.copy(v)) for k, v in vars(r).items()})
+
+    def _through(self, key, call):
+        hit = self._memo.get(key)
+        if hit is None:
+            hit = call()
+            size = sum(getattr(v, "nbytes", 64) for v in vars(hit).values())
+            if self._bytes + size <= self._budget:
+                self._memo[key], self._bytes = hit, self._bytes + size
+        return self._copy(hit)
+
+    def run(self, profile, nodes, pod, max_limit=0, threads=1, want_log=True, log_cap=None):
+        key = self._key("run", profile, nodes, pod, int(max_limit), bool(want_log), log_cap)
+        return self._through(key, lambda: self._m.run(profile, nodes, pod, max_limit=max_limit, threads=threads, want_log=want_log, log_cap=log_cap))
+
+    def run_multi(self, profile, nodes, pods, max_limit=0, threads=1, log_cap=None):
+        key = self._key("run_multi", profile, nodes, pods, int(max_limit), log_cap)
+        return self._through(key, lambda: self._m.run_multi(profile, nodes, pods, max_limit=max_limit, threads=threads, log_cap=log_cap))
+
+
 @pytest.fixture(scope="session")
 def ccref():
     """The CPU oracle (test infrastructure)."""
@@ -67,4 +106,4 @@ def ccref():
     import ccref_py
 
     ccref_py.build()
-    return ccref_py
+    return _OracleWithMemo(ccref_py)

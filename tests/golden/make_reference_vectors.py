@@ -155,9 +155,39 @@ FUNCS += [
     ("ptsScore", P + "/scoring.go", "func (pl *PodTopologySpread) Score(ctx context.Context, cycleState fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) (int64, *fwk.Status) {",
      ["s", "node", "nodeInfo", "pod"], False),
 ]
+# Round 6 -- the volume plugins' Filters (the object side of cluster-capacity_amd/volumes.py and host/volumes.hpp was compared
+# with itself only).  VolumeRestrictions' disk conflicts (volume_restrictions.go:103-160, 266-280), VolumeZone's label match (volume_zone.go:91-100,
+# 191-240; the lines that fetch the PreFilter state are dropped: podPVTopologies is an argument), NodeVolumeLimits' counting (csi.go:255-343, 574-586;
+# the listers behind pl.* are the harness's), VolumeBinding's bound claims (binder.go:830-865; pvCache / csiNodeLister / CheckNodeAffinity are the harness's).
+VP = S + "/framework/plugins"
+FUNCS += [
+    ("haveOverlap", VP + "/volumerestrictions/volume_restrictions.go", "func haveOverlap(a1, a2 []string) bool {", ["a1", "a2"], False),
+    ("isVolumeConflict", VP + "/volumerestrictions/volume_restrictions.go", "func isVolumeConflict(volume *v1.Volume, pod *v1.Pod) bool {", ["volume", "pod"], False),
+    ("needsRestrictionsCheck", VP + "/volumerestrictions/volume_restrictions.go", "func needsRestrictionsCheck(v v1.Volume) bool {", ["v"], False),
+    ("satisfyVolumeConflicts", VP + "/volumerestrictions/volume_restrictions.go", "func satisfyVolumeConflicts(pod *v1.Pod, nodeInfo fwk.NodeInfo) bool {", ["pod", "nodeInfo"], False),
+    ("translateToGALabel", VP + "/volumezone/volume_zone.go", "func translateToGALabel(label string) string {", ["label"], False),
+    ("volumeZoneFilter", VP + "/volumezone/volume_zone.go", "func (pl *VolumeZone) Filter(ctx context.Context, cs fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) *fwk.Status {",
+     ["podPVTopologies", "pod", "nodeInfo"], False),
+    ("getVolumeLimits", VP + "/nodevolumelimits/csi.go", "func getVolumeLimits(csiNode *storagev1.CSINode) map[string]int64 {", ["csiNode"], False),
+    ("csiLimitsFilter", VP + "/nodevolumelimits/csi.go", "func (pl *CSILimits) Filter(ctx context.Context, _ fwk.CycleState, pod *v1.Pod, nodeInfo fwk.NodeInfo) *fwk.Status {",
+     ["pl", "pod", "nodeInfo"], False),
+    ("checkBoundClaims", VP + "/volumebinding/binder.go",
+     "func (b *volumeBinder) checkBoundClaims(logger klog.Logger, claims []*v1.PersistentVolumeClaim, node *v1.Node, pod *v1.Pod) (bool, bool, error) {", ["b", "claims", "node", "pod"], False),
+]
 # per-function textual substitutions applied to a Go statement before the general rules (method calls on receivers the harness models as plain
 # Python values; Go's value semantics where Python would alias)
 REWRITE = {
+    "haveOverlap": [(r"^m := sets\.New\(a1\.\.\.\)$", "m := GoSet(a1)"), (r"^if _, ok := m\[val\]; ok \{$", "if m.Has(val) {")],
+    "volumeZoneFilter": [(r"^v, ok = node\.Labels\[translateToGALabel\(pvTopology\.key\)\]$", "v, ok := node.Labels[translateToGALabel(pvTopology.key)]")],
+    "getVolumeLimits": [(r"make\(map\[string\]int64\)", "{}"), (r"int64\(\*d\.Allocatable\.Count\)", "int64(d.Allocatable.Count)")],
+    "csiLimitsFilter": [(r"make\(map\[string\]string\)", "{}"), (r"map\[string\]int\{\}", "GoMap()"), (r" /\* (new|existing) pod \*/", ""),
+                        (r"^if err := (pl\.filterAttachableVolumes\(.*\)); err != nil \{$", r"if (err := \1) != nil {"),
+                        (r"^return fwk\.NewStatus\(fwk\.UnschedulableAndUnresolvable, err\.Error\(\)\)$", 'return ["UnschedulableAndUnresolvable", err.Error()]'),
+                        (r"^return fwk\.AsStatus\(err\)$", 'return ["Error", err]'), (r"apierrors\.IsNotFound\(err\)", "err.NotFound"),
+                        (r"^delete\(newVolumes, volumeUniqueName\)$", "newVolumes.pop(volumeUniqueName, None)"), (r"^(\w+)\[driverName\]\+\+$", r"\1[driverName] += 1"),
+                        (r"^for _, driverName := range newVolumes \{$", "for _, driverName := range newVolumes.values() {"),
+                        (r'^"(maxLimits|pod)", .*$', "logger.continued")],
+    "checkBoundClaims": [(r"^if errors\.Is\(err, assumecache\.ErrNotFound\) \{$", "if err == ErrNotFound {"), (r"volume\.CheckNodeAffinity\(", "CheckNodeAffinity(")],
     "topologyToMatchedTermCount_update": [(r"^delete\(m, pair\)$", "m.pop(pair, None)")],
     "updateWithAffinityTerms": [(r"\bm\.update\(", "topologyToMatchedTermCount_update(m, ")],
     "updateWithAntiAffinityTerms": [(r"\bm\.update\(", "topologyToMatchedTermCount_update(m, ")],
@@ -198,6 +228,9 @@ REWRITE = {
 # statements about the scheduler's cycle state, not arithmetic: removed before the transliteration (they are still in the recorded Go text)
 JOINED = {}
 DROP = {
+    "volumeZoneFilter": ["logger := klog.FromContext(ctx)", "if len(pod.Spec.Volumes) == 0 {", "return nil", "}", "var podPVTopologies []pvTopology", "state, err := getStateData(cs)",
+                         "if err != nil {", "var status *fwk.Status", "podPVTopologies, status = pl.getPVbyPod(logger, pod)", "if !status.IsSuccess() {", "return status", "}", "} else {",
+                         "podPVTopologies = state.podPVTopologies", "}"],
     "ptsNormalizeScore": ["s, err := getPreScoreState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}", "if s == nil {", "return nil", "}"],
     "ptsFilter": ["node := nodeInfo.Node()", "s, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
     "ipaFilter": ["state, err := getPreFilterState(cycleState)", "if err != nil {", "return fwk.AsStatus(err)", "}"],
@@ -330,7 +363,7 @@ def transliterate(name, params, body, int_div, opts=None):
             m2 = re.fullmatch(r"for _, (\w+) := range ([\w.]+(?:\(\))?)", ln)
             m3 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+)", ln)
             m4 = re.fullmatch(r"for (\w+), (\w+) := range ([\w.]+\.ScalarResources)", ln)
-            mmap = re.fullmatch(r"for (\w+), (\w+) := range (other|oScores|s\.topologyScore)", ln)  # the score maps of InterPodAffinity
+            mmap = re.fullmatch(r"for (\w+), (\w+) := range (other|oScores|s\.topologyScore|attachedVolumes|volumeAttachments|newVolumeCount)", ln)  # the score maps of InterPodAffinity; the CSI volume maps
             if m4 or mmap:  # a map: Go's order is random, sorted here
                 m4 = m4 or mmap
                 ln = f"for {m4.group(1)}, {m4.group(2)} in sorted({m4.group(3)}.items()):"
@@ -637,6 +670,343 @@ def parse_int(text):
     return 0, "error"
 
 
+
+# ---- round 6: the volume plugins' Filters on Kubernetes objects (dicts as `kubectl get -o json` gives them) -----------------------------------------
+class GoObj(types.SimpleNamespace):
+    """A Go struct with exactly the fields the harness sets (a pointer field that is nil is None)."""
+
+
+ErrNotFound = "assumecache: object not found"  # the sentinel checkBoundClaims compares with (errors.Is)
+
+
+class GoNotFound:
+    """apierrors.NewNotFound(resource, name): Error() as apimachinery formats it."""
+    NotFound = True
+
+    def __init__(self, kind, name):
+        self.msg = f'{kind} "{name}" not found'
+
+    def Error(self):
+        return self.msg
+
+
+def go_volume(v):
+    g, a, i, r, c = v.get("gcePersistentDisk"), v.get("awsElasticBlockStore"), v.get("iscsi"), v.get("rbd"), v.get("persistentVolumeClaim")
+    return GoObj(Name=v.get("name", ""),
+                 GCEPersistentDisk=None if g is None else GoObj(PDName=g.get("pdName", ""), ReadOnly=bool(g.get("readOnly"))),
+                 AWSElasticBlockStore=None if a is None else GoObj(VolumeID=a.get("volumeID", "")),
+                 ISCSI=None if i is None else GoObj(IQN=i.get("iqn", ""), ReadOnly=bool(i.get("readOnly"))),
+                 RBD=None if r is None else GoObj(CephMonitors=list(r.get("monitors") or []), RBDPool=r.get("pool") or "", RBDImage=r.get("image", ""), ReadOnly=bool(r.get("readOnly"))),
+                 PersistentVolumeClaim=None if c is None else GoObj(ClaimName=c.get("claimName", "")), Ephemeral=None)
+
+
+def go_pod(p):
+    md = p.get("metadata") or {}
+    return GoObj(Name=md.get("name", ""), Namespace=md.get("namespace") or "default", Spec=GoObj(Volumes=[go_volume(v) for v in (p.get("spec") or {}).get("volumes") or []]))
+
+
+class GoPodInfo:
+    def __init__(self, pod): self.pod = pod
+    def GetPod(self): return self.pod
+
+
+class GoVolNodeInfo:
+    def __init__(self, name, labels, pods):
+        self.node, self.pods = GoObj(Name=name, Labels=dict(labels)), [GoPodInfo(p) for p in pods]
+
+    def Node(self): return self.node
+    def GetPods(self): return self.pods
+
+
+def label_zones_to_set(value):
+    """volumehelpers.LabelZonesToSet (cloud-provider/volume/helpers): "a__b" -> {a, b}; an empty element is an error.  Not part of the cut: the
+    reference calls it while PreFilter collects the topologies (volume_zone.go:380-398, restated in pv_topologies below)."""
+    out = GoSet()
+    for z in value.split("__"):
+        z = z.strip()
+        if not z:
+            return None
+        out.add(z)
+    return out
+
+
+def pv_topologies(env, pv):
+    out = []
+    labels = (pv.get("metadata") or {}).get("labels") or {}
+    for key in env["topologyLabels"]:
+        if key in labels:
+            zs = label_zones_to_set(labels[key])
+            if zs is None:
+                continue
+            out.append(GoObj(pvName=pv["metadata"]["name"], key=key, values=zs))
+    return out
+
+
+NODE_SELECTOR_OPS = {"In": "in", "NotIn": "notin", "Exists": "exists", "DoesNotExist": "!", "Gt": "gt", "Lt": "lt"}  # nodeaffinity.go nodeSelectorRequirementsAsSelector
+
+
+def check_node_affinity(env, pv, node_labels):
+    """storagehelpers.CheckNodeAffinity (component-helpers/storage/volume/helpers.go:68-84) over corev1.MatchNodeSelectorTerms: the terms are ORed, a
+    term's matchExpressions ANDed (an empty term matches nothing); each expression is the transliterated labels.Requirement.Matches."""
+    req = ((pv.get("spec") or {}).get("nodeAffinity") or {}).get("required")
+    if (pv.get("spec") or {}).get("nodeAffinity") is None or req is None:
+        return None
+    for term in req.get("nodeSelectorTerms") or []:
+        exprs = term.get("matchExpressions") or []
+        if not exprs:
+            continue
+        if all(env["requirementMatches"](types.SimpleNamespace(key=r["key"], operator=NODE_SELECTOR_OPS[r["operator"]], strValues=[str(x) for x in r.get("values") or []]), node_labels)
+               for r in exprs):
+            return None
+    return "no matching NodeSelectorTerms"
+
+
+class CsiHarness:
+    """What CSILimits.Filter reaches through pl.*: the listers, filterAttachableVolumes / getCSIDriverInfo(+FromSC) (csi.go:345-412, 455-545; in-tree
+    volumes that would be migrated do not occur in the generated worlds), getNodeVolumeAttachmentInfo (:588-618)."""
+    def __init__(self, pvcs, pvs, classes, csinodes, vas):
+        self.pvcs, self.pvs, self.classes, self.csinodes, self.vas = pvcs, pvs, classes, csinodes, vas
+        self.csiNodeLister = types.SimpleNamespace(Get=self._csinode)
+
+    def _csinode(self, name):
+        o = self.csinodes.get(name)
+        if o is None:
+            return None, GoNotFound("csinode.storage.k8s.io", name)
+        drivers = [GoObj(Name=d.get("name", ""), Allocatable=None if d.get("allocatable") is None else GoObj(Count=d["allocatable"].get("count")))
+                   for d in (o.get("spec") or {}).get("drivers") or []]
+        return GoObj(Name=name, Spec=GoObj(Drivers=drivers)), None
+
+    def _driver_info(self, pvc):
+        spec, md = pvc.get("spec") or {}, pvc.get("metadata") or {}
+        pv = self.pvs.get(spec.get("volumeName") or "") if spec.get("volumeName") else None
+        if pv is None:  # getCSIDriverInfoFromSC
+            ann = md.get("annotations") or {}
+            sc = ann["volume.beta.kubernetes.io/storage-class"] if "volume.beta.kubernetes.io/storage-class" in ann else (spec.get("storageClassName") or "")
+            cls = self.classes.get(sc) if sc else None
+            if cls is None:
+                return "", ""
+            return cls.get("provisioner") or "", f'RANDOMPREFIX-{md.get("namespace") or "default"}/{md.get("name", "")}'
+        csi = (pv.get("spec") or {}).get("csi")
+        if csi is None:
+            return "", ""
+        return csi.get("driver") or "", csi.get("volumeHandle") or ""
+
+    def filterAttachableVolumes(self, logger, pod, csiNode, newPod, result):
+        for vol in pod.Spec.Volumes:
+            if vol.PersistentVolumeClaim is None:
+                continue  # (inline volumes: only migratable in-tree ones would count)
+            name = vol.PersistentVolumeClaim.ClaimName
+            if name == "":
+                return "PersistentVolumeClaim had no name"
+            pvc = self.pvcs.get((pod.Namespace, name))
+            if pvc is None:
+                if newPod:
+                    return GoNotFound("persistentvolumeclaim", name)
+                continue
+            driver, handle = self._driver_info(pvc)
+            if driver == "" or handle == "":
+                continue
+            result[f"{driver}/{handle}"] = driver
+        return None
+
+    def getNodeVolumeAttachmentInfo(self, logger, nodeName):
+        out = {}
+        for va in self.vas:
+            sp = va.get("spec") or {}
+            if sp.get("nodeName") != nodeName or not sp.get("attacher"):
+                continue
+            pvn = (sp.get("source") or {}).get("persistentVolumeName")
+            pv = self.pvs.get(pvn) if pvn is not None else None
+            csi = ((pv or {}).get("spec") or {}).get("csi")
+            if pv is None or csi is None:
+                continue
+            out[f'{sp["attacher"]}/{csi.get("volumeHandle") or ""}'] = sp["attacher"]
+        return out, None
+
+
+def volume_filter_rows(env, rnd):
+    """Four families of small worlds, one per plugin; per node what the plugin's transliterated Filter says."""
+    BIND_DONE = "pv.kubernetes.io/bind-completed"
+    zone, zone_b, region = PINS["label.zone"], PINS["label.zone_beta"], PINS["label.region"]
+    drivers = ["ebs.csi.aws.com", "pd.csi.storage.gke.io"]
+
+    def mk_nodes():
+        n = rnd.randint(2, 9)
+        out = []
+        for i in range(n):
+            labels = {"kubernetes.io/hostname": f"n{i}"}
+            if rnd.random() < 0.8:
+                labels[zone if rnd.random() < 0.6 else zone_b] = f"z{rnd.randint(0, 2)}"
+            if rnd.random() < 0.3:
+                labels[region] = f"r{rnd.randint(0, 1)}"
+            out.append({"name": f"n{i}", "labels": labels})
+        return out
+
+    def disk_volumes(k_max):
+        vols = []
+        for j in range(rnd.randint(0, k_max)):
+            r, name = rnd.random(), f"v{j}"
+            if r < 0.3:
+                vols.append({"name": name, "gcePersistentDisk": {"pdName": f"disk-{rnd.randint(0, 2)}", **({"readOnly": rnd.random() < 0.5} if rnd.random() < 0.8 else {})}})
+            elif r < 0.5:
+                vols.append({"name": name, "awsElasticBlockStore": {"volumeID": f"vol-{rnd.randint(0, 2)}"}})
+            elif r < 0.7:
+                vols.append({"name": name, "rbd": {"monitors": [f"m{rnd.randint(0, 3)}" for _ in range(rnd.randint(0, 3))], **({"pool": rnd.choice(["p", "q"])} if rnd.random() < 0.7 else {}),
+                                                   "image": f"i{rnd.randint(0, 1)}", "readOnly": rnd.random() < 0.5}})
+            elif r < 0.85:
+                vols.append({"name": name, "iscsi": {"iqn": f"iqn-{rnd.randint(0, 1)}", "targetPortal": "p", "lun": 0, "readOnly": rnd.random() < 0.5}})
+            else:
+                vols.append({"name": name, "emptyDir": {}})
+        return vols
+
+    def claim(name, pv_name="", cls=None, ns="default"):
+        md = {"name": name, "namespace": ns}
+        spec = {"accessModes": ["ReadWriteOnce"]}
+        if pv_name:
+            md["annotations"] = {BIND_DONE: "yes"}
+            spec["volumeName"] = pv_name
+        if cls is not None:
+            spec["storageClassName"] = cls
+        return {"apiVersion": "v1", "kind": "PersistentVolumeClaim", "metadata": md, "spec": spec, "status": {"phase": "Bound" if pv_name else "Pending"}}
+
+    def pod(name, node_name, volumes, ns="default"):
+        return {"apiVersion": "v1", "kind": "Pod", "metadata": {"name": name, "namespace": ns}, "spec": {"nodeName": node_name, "volumes": volumes}}
+
+    def infos(nodes, pods):
+        return [GoVolNodeInfo(nd["name"], nd["labels"], [go_pod(p) for p in pods if p["spec"]["nodeName"] == nd["name"]]) for nd in nodes]
+
+    rows = {"volumeRestrictions": [], "volumeZone": [], "csiLimits": [], "boundClaims": []}
+    for _ in range(160):
+        nodes = mk_nodes()
+        pods = [pod(f"p{k}", rnd.choice(nodes)["name"], disk_volumes(3)) for k in range(rnd.randint(0, 8))]
+        tmpl = pod("sim", "", disk_volumes(3))
+        gp = go_pod(tmpl)
+        exp = [0 if env["satisfyVolumeConflicts"](gp, ni) else 1 for ni in infos(nodes, pods)]
+        own = GoVolNodeInfo("x", {}, [gp])  # the template's clone on the same node
+        rows["volumeRestrictions"].append({"nodes": nodes, "pods": pods, "volumes": tmpl["spec"]["volumes"], "conflict": exp, "exclusive": not env["satisfyVolumeConflicts"](gp, own)})
+    for _ in range(160):
+        nodes = mk_nodes()
+        pvs = []
+        for k in range(rnd.randint(1, 5)):
+            labels = {}
+            for key in (zone, zone_b, region, PINS["label.region_beta"]):
+                if rnd.random() < 0.3:
+                    labels[key] = rnd.choice(["z0", "z1", "z0__z2", "z1__z2__z0", "r0", "r1", "z0__", " z1 ", ""])
+            pvs.append({"apiVersion": "v1", "kind": "PersistentVolume", "metadata": {"name": f"pv-{k}", "labels": labels},
+                        "spec": {"capacity": {"storage": "1Gi"}, "csi": {"driver": drivers[0], "volumeHandle": f"h-{k}"}}})
+        claims = [claim(f"c{k}", f"pv-{rnd.randint(0, len(pvs) - 1)}") for k in range(rnd.randint(1, 4))]
+        vols = [{"name": f"v{j}", "persistentVolumeClaim": {"claimName": c["metadata"]["name"]}} for j, c in enumerate(claims) if rnd.random() < 0.8] or \
+               [{"name": "v0", "persistentVolumeClaim": {"claimName": claims[0]["metadata"]["name"]}}]
+        by = {o["metadata"]["name"]: o for o in pvs}
+        cl = {c["metadata"]["name"]: c for c in claims}
+        topo = []
+        for v in vols:
+            topo += pv_topologies(env, by[cl[v["persistentVolumeClaim"]["claimName"]]["spec"]["volumeName"]])
+        gp = go_pod(pod("sim", "", vols))
+        exp = [0 if env["volumeZoneFilter"](topo, gp, ni) is None else 1 for ni in infos(nodes, [])]
+        rows["volumeZone"].append({"nodes": nodes, "objs": pvs + claims, "volumes": vols, "reject": exp})
+    for _ in range(200):
+        nodes = mk_nodes()
+        classes = [{"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "csi-wait"}, "provisioner": drivers[1], "volumeBindingMode": "WaitForFirstConsumer"},
+                   {"apiVersion": "storage.k8s.io/v1", "kind": "StorageClass", "metadata": {"name": "local"}, "provisioner": "kubernetes.io/no-provisioner", "volumeBindingMode": "WaitForFirstConsumer"}]
+        pvs = []
+        for k in range(rnd.randint(2, 8)):
+            spec = {"capacity": {"storage": "1Gi"}}
+            if rnd.random() < 0.85:
+                spec["csi"] = {"driver": rnd.choice(drivers), "volumeHandle": f"h-{rnd.randint(0, 5)}"}  # (handles repeat: one volume behind two PVs counts once)
+            else:
+                spec["local"] = {"path": "/mnt"}
+            pvs.append({"apiVersion": "v1", "kind": "PersistentVolume", "metadata": {"name": f"pv-{k}", "labels": {}}, "spec": spec})
+        claims = []
+        for k in range(rnd.randint(2, 9)):
+            r = rnd.random()
+            ns = "other" if rnd.random() < 0.15 else "default"
+            if r < 0.65:
+                claims.append(claim(f"c{k}", f"pv-{rnd.randint(0, len(pvs))}", ns=ns))  # (pv-<len> does not exist: the class decides, and there is none)
+            elif r < 0.85:
+                claims.append(claim(f"c{k}", cls=rnd.choice(["csi-wait", "local", "gone"]), ns=ns))
+            else:
+                claims.append(claim(f"c{k}", ns=ns))
+        mine = [c for c in claims if c["metadata"]["namespace"] == "default"] or [claim("c-own", "pv-0")]
+        if mine[0] not in claims:
+            claims.append(mine[0])
+
+        def claim_vols(k_max, ns, known_only):
+            out = []
+            for j in range(rnd.randint(0, k_max)):
+                pool = [c["metadata"]["name"] for c in claims if c["metadata"]["namespace"] == ns]
+                if not known_only:
+                    pool.append("missing")
+                if pool:
+                    out.append({"name": f"v{j}", "persistentVolumeClaim": {"claimName": rnd.choice(pool)}})
+            return out
+        pods = []
+        for k in range(rnd.randint(0, 10)):
+            ns = "other" if rnd.random() < 0.2 else "default"
+            pods.append(pod(f"p{k}", rnd.choice(nodes)["name"], claim_vols(3, ns, False), ns))
+        vols = claim_vols(4, "default", True) or [{"name": "v0", "persistentVolumeClaim": {"claimName": mine[0]["metadata"]["name"]}}]
+        csinodes = []
+        for nd in nodes:
+            if rnd.random() < 0.75:
+                drv = []
+                for d in drivers:
+                    if rnd.random() < 0.7:
+                        e = {"name": d, "nodeID": nd["name"]}
+                        if rnd.random() < 0.85:
+                            e["allocatable"] = {"count": rnd.randint(0, 3)} if rnd.random() < 0.9 else {}
+                        drv.append(e)
+                csinodes.append({"apiVersion": "storage.k8s.io/v1", "kind": "CSINode", "metadata": {"name": nd["name"]}, "spec": {"drivers": drv}})
+        vas = [{"apiVersion": "storage.k8s.io/v1", "kind": "VolumeAttachment", "metadata": {"name": f"va{k}"},
+                "spec": {"attacher": rnd.choice(drivers), "nodeName": rnd.choice(nodes)["name"], "source": {"persistentVolumeName": f"pv-{rnd.randint(0, len(pvs))}"}}}
+               for k in range(rnd.randint(0, 5))]
+        h = CsiHarness({(c["metadata"]["namespace"], c["metadata"]["name"]): c for c in claims}, {o["metadata"]["name"]: o for o in pvs}, {o["metadata"]["name"]: o for o in classes},
+                       {o["metadata"]["name"]: o for o in csinodes}, vas)
+        gp = go_pod(pod("sim", "", vols))
+        exp = []
+        for ni in infos(nodes, pods):
+            st = env["csiLimitsFilter"](h, gp, ni)
+            assert st is None or st[0] == "Unschedulable", st
+            exp.append(0 if st is None else 1)
+        rows["csiLimits"].append({"nodes": nodes, "pods": pods, "objs": classes + pvs + claims + csinodes + vas, "volumes": vols, "reject": exp})
+    for _ in range(160):
+        nodes = mk_nodes()
+        pvs = []
+        for k in range(rnd.randint(1, 5)):
+            spec = {"capacity": {"storage": "1Gi"}, "csi": {"driver": drivers[0], "volumeHandle": f"h-{k}"}}
+            r = rnd.random()
+            if r < 0.6:
+                terms = []
+                for _t in range(rnd.randint(0, 2)):
+                    ex = []
+                    for _e in range(rnd.randint(0, 2)):
+                        op = rnd.choice(["In", "NotIn", "Exists", "DoesNotExist"])
+                        key = rnd.choice(["kubernetes.io/hostname", zone, "absent"])
+                        e = {"key": key, "operator": op}
+                        if op in ("In", "NotIn"):
+                            e["values"] = [rnd.choice([f"n{rnd.randint(0, 8)}", f"z{rnd.randint(0, 2)}"]) for _v in range(rnd.randint(1, 3))]
+                        ex.append(e)
+                    terms.append({"matchExpressions": ex} if ex or rnd.random() < 0.5 else {})
+                spec["nodeAffinity"] = {"required": {"nodeSelectorTerms": terms}}
+            elif r < 0.7:
+                spec["nodeAffinity"] = {}
+            pvs.append({"apiVersion": "v1", "kind": "PersistentVolume", "metadata": {"name": f"pv-{k}", "labels": {}}, "spec": spec})
+        claims = [claim(f"c{k}", f"pv-{rnd.randint(0, len(pvs) - (0 if rnd.random() < 0.25 else 1))}") for k in range(rnd.randint(1, 4))]
+        vols = [{"name": f"v{j}", "persistentVolumeClaim": {"claimName": c["metadata"]["name"]}} for j, c in enumerate(claims)]
+        by = {o["metadata"]["name"]: o for o in pvs}
+        b = types.SimpleNamespace(csiNodeLister=types.SimpleNamespace(Get=lambda name: (None, GoNotFound("csinode.storage.k8s.io", name))),
+                                  pvCache=types.SimpleNamespace(GetPV=lambda name: (by[name], None) if name in by else (None, ErrNotFound)),
+                                  tryTranslatePVToCSI=lambda logger, pv, csiNode: (pv, None))
+        env["CheckNodeAffinity"] = lambda pv, labels: check_node_affinity(env, pv, labels)
+        gclaims = [GoObj(Spec=GoObj(VolumeName=c["spec"]["volumeName"])) for c in claims]
+        exp = []
+        for nd in nodes:
+            sat, found, err = env["checkBoundClaims"](b, gclaims, GoObj(Name=nd["name"], Labels=dict(nd["labels"])), None)
+            assert err is None
+            exp.append(2 if not found else (1 if not sat else 0))  # volume_binding.go:405-418: !boundPVsFound -> ErrReasonPVNotExist; !boundSatisfied -> ErrReasonNodeConflict
+        rows["boundClaims"].append({"nodes": nodes, "objs": pvs + claims, "volumes": vols, "verdict": exp})
+    return rows
+
+
 def godiv(a, b):
     q = abs(a) // abs(b)
     return q if (a >= 0) == (b >= 0) else -q
@@ -663,7 +1033,17 @@ def build():
            "GoStruct": GoStruct, "gocopy": gocopy, "GoHeap": GoHeap, "heap": GoContainerHeap, "go_math_log": go_math_log, "MinNodeScore": 0, "NodeInclusionPolicyHonor": "Honor",
            "LabelHostname": "kubernetes.io/hostname", "go_round": go_round, "GoMap": GoMap, "GoPtrMap": GoPtrMap,
            "DefaultBindAllHostIP": "0.0.0.0", "ProtocolTCP": "TCP",
-           "newCriticalPaths": lambda: [GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1), GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1)]}
+           "newCriticalPaths": lambda: [GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1), GoStruct(TopologyValue="", MatchNum=(1 << 31) - 1)],
+           # round 6: the volume plugins
+           "GoSet": GoSet, "logger": None, "ErrNotFound": ErrNotFound, "CheckNodeAffinity": None,
+           "ErrReasonConflict": "node(s) had no available volume zone", "ErrReasonMaxVolumeCountExceeded": "node(s) exceed max volume count",
+           "topologyLabels": [PINS["label.zone_beta"], PINS["label.region_beta"], PINS["label.zone"], PINS["label.region"]]}
+    vz = open(os.path.join(REF, S, "framework/plugins/volumezone/volume_zone.go")).read()
+    assert "var topologyLabels = []string{\n\tv1.LabelFailureDomainBetaZone,\n\tv1.LabelFailureDomainBetaRegion,\n\tv1.LabelTopologyZone,\n\tv1.LabelTopologyRegion,\n}" in vz
+    assert 'ErrReasonConflict = "%s"' % env["ErrReasonConflict"] in vz
+    assert 'ErrReasonMaxVolumeCountExceeded = "%s"' % env["ErrReasonMaxVolumeCountExceeded"] in open(os.path.join(REF, S, "framework/plugins/nodevolumelimits/csi.go")).read()
+    bsrc = open(os.path.join(REF, S, "framework/plugins/volumebinding/binder.go")).read()
+    assert 'ErrReasonNodeConflict ConflictReason = "node(s) didn\'t match PersistentVolume\'s node affinity"' in bsrc and "ErrReasonPVNotExist = \"node(s) unavailable due to one or more pvc(s) bound to non-existent pv(s)\"" in bsrc
     iface = open(os.path.join(REF, S, "framework/interface.go")).read()
     assert re.search(r"MinNodeScore int64 = 0\b", iface) and re.search(r"MaxNodeScore int64 = %d\b" % PINS["score.max_node_score"], iface)
     assert re.search(r'NodeInclusionPolicyHonor NodeInclusionPolicy = "Honor"', open(os.path.join(REF, "vendor/k8s.io/api/core/v1/types.go")).read())
@@ -1127,6 +1507,8 @@ def vectors(env):
     # requireAllTopologies = false (scoring.go:140: a pod without constraints of its own under the plugin's system defaults): no node is ignored,
     # a missing key is the value "" when the domains are sized and counted, and scores nothing (a stream of its own: the sets above keep theirs)
     v["ptsPreScoreScoreRelaxed"] = pts_prescore_rows(random.Random(20260924), False, 700)
+    for fam, rows in volume_filter_rows(env, random.Random(20260930)).items():  # round 6: the volume plugins' Filters on object graphs
+        v["volumeFilters_" + fam] = rows
     return v
 
 

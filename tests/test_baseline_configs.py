@@ -139,7 +139,7 @@ def _coupled_template(n, zones=None, seed=5):
     return nodes, pod, prof
 
 
-@pytest.mark.parametrize("n,zones", [(100_000, None), (1_000_000, None), (1_000_000, 16)], ids=["100k-16zones", "1M-64zones", "1M-16zones"])
+@pytest.mark.parametrize("n,zones", [(100_000, None), (1_000_000, None), (300_000, 16)], ids=["100k-16zones", "1M-64zones", "300k-16zones"])
 def test_coupled_template_at_baseline_sizes(ccref, n, zones):
     """One template with topology-coupled plugins (podtopologyspread/filtering.go:235-356, interpodaffinity/filtering.go:204-432) in
     windows (csrc/ccsim_coupled.h): the oracle's first 200 cycles, and 5000 placements windowed == one pass per placement (CCSIM_CW=0).

@@ -264,3 +264,38 @@ def test_library_driven_run_takes_the_mailbox_form(ccref, monkeypatch, capfd, cf
     e.close()
     err = capfd.readouterr().err
     assert "mailboxes connected" in err and err.count("mailbox form finished on every rank") == 2, err[-2000:]
+
+
+def test_library_driven_run_abandons_the_mailbox_form_once(ccref, monkeypatch, capfd):
+    """a launch that had to be abandoned (injected: workgroup 0 never arrives, the bounded spins expire) must not be
+    repeated by every later ccsim_dist_run of the same pod spec -- the verdict is all-reduced, every rank switches to the RCCL pass
+    protocol together, says so once, and the second run does not launch the mailbox kernel again (nor lose its seconds)."""
+    import time
+    monkeypatch.setenv("CCSIM_DIST_MAILBOX", "1")
+    monkeypatch.setenv("CCSIM_DIST_DEBUG", "1")
+    monkeypatch.setenv("CCSIM_PERSIST_FAULT", "1")
+    nodes, pod, prof = synth.make_config("C3", n_nodes=1500, seed=501)
+    ref = ccref.run(prof, nodes, pod, max_limit=0, threads=8)
+    e = capi.Engine(device=0, use_graph=False)
+    e.load(nodes, pod, prof)
+    e.dist_comm_init(capi.dist_unique_id(), 1, 0)
+    took = []
+    for rep in range(3):
+        e.reset_state()
+        t0 = time.perf_counter()
+        got = e.dist_run(0, "batched", want_log=True, log_cap=max(1, ref.placed))
+        took.append(time.perf_counter() - t0)
+        assert got.placed == ref.placed and got.stop == ref.stop
+        assert np.array_equal(got.per_node_count, ref.per_node_count) and np.array_equal(got.log, ref.log)
+    err = capfd.readouterr().err
+    assert err.count("mailbox form abandoned: pass protocol") == 1, err[-2000:]  # the first run only
+    assert err.count("the persistent kernel across the GPUs was abandoned") == 1
+    assert "mailbox form finished on every rank" not in err
+    assert max(took[1:]) < 0.5 * took[0] + 0.5, took  # (the first run lost the spins' seconds; the others did not)
+    # a new pod spec is a new agreement: the form is tried again (and, with the fault still injected, abandoned again -- once)
+    e.load(nodes, pod, prof)
+    e.reset_state()
+    got = e.dist_run(0, "batched", want_log=False, log_cap=0)
+    assert got.placed == ref.placed
+    assert capfd.readouterr().err.count("mailbox form abandoned: pass protocol") == 1
+    e.close()

@@ -39,6 +39,8 @@ def test_transliterations_are_line_by_line():
         go = [l.strip() for l in lines if l.strip() and not l.strip().startswith("//") and l.strip() != "}"]
         py = [l for l in s["python"].split("\n")[1:] if l.strip()]
         dropped = 5 if name in ("ptsNormalizeScore", "ipaNormalizeScore") else 3 if name == "ipaFilter" else 4 if name in ("ptsFilter", "ptsScore", "ipaScore") else 0  # the cycle-state preamble (make_reference_vectors.DROP), minus its braces
+        if name == "volumeZoneFilter":
+            dropped = 12  # logger, the no-volume fast path, the PreFilter state or its fallback (15 lines of DROP, 3 of them bare braces)
         two_value_lookups = sum(", ok := " in l or ":= ls.Lookup(" in l for l in go)  # `v, ok := m[k]` becomes a membership test plus a .get: one line more
         two_value_lookups += sum(l.startswith("if ") and ", ok := " in l and not l.startswith("if _, ok") for l in go)  # `if v, ok := m[k]; ok {`: the lookup's two lines, then the test
         two_value_lookups += 2 * sum(bool(re.match(r"if (\w+), (?!ok\b)(\w+) := .+\[[\w.]+\]; \2 \{$", l)) for l in go)  # the same with another flag name (`tpValueExist`, `exist`)
@@ -47,6 +49,10 @@ def test_transliterations_are_line_by_line():
         named_result = 1 if re.search(r"\) \(\w+ [\[\]\w.]+\) \{$", s["go"].split("\n")[0]) else 0  # `(n int)`: one line that sets its zero value
         joined = s.get("joined", 0)  # lines absorbed into the one before: a condition continued after && / ||, a composite literal's fields
         closers = 1 if name == "findNodesThatPassFilters_checkNode" else 0  # the `})` that ends the func() { ... } argument of SendErrorWithCancel: a brace
+        if name == "volumeZoneFilter":
+            two_value_lookups += 2  # `if _, ok := node.Labels[k]; ok {` in its three-line form; `v, ok = m[k]` (an assignment, not a declaration): lookup + .get
+        if name == "haveOverlap":
+            two_value_lookups -= 1  # `if _, ok := m[val]; ok {`: m.Has(val), one line (make_reference_vectors.REWRITE)
         if name == "HostPortInfo_CheckConflict":
             two_value_lookups -= 2  # `if _, ok := m[*pp]; ok {` twice: a membership test on the (protocol, port) pair, one line each (make_reference_vectors.REWRITE)
         assert len(go) - dropped + two_value_lookups + named_result - joined - closers == len(py), name
@@ -457,3 +463,83 @@ def test_requirement_matching():
         assert ingest.requirement_matches("k" in ls, ls.get("k"), name[op], vals) == want, (op, vals, ls)
         checked += 1
     assert checked > 1500
+
+
+# ---- round 6: the volume plugins' Filters on object graphs ---------------------------------------------------------------------
+# Every family is a set of small worlds for ONE plugin; the expected per-node verdicts come from the plugin's transliterated Filter
+# (isVolumeConflict / satisfyVolumeConflicts, VolumeZone.Filter, CSILimits.Filter + getVolumeLimits, checkBoundClaims).  Both hosts must give them:
+# cluster-capacity_amd/volumes.py here in-process, cluster-capacity-native through --dump-snapshot with the other volume plugins taken out of the profile.
+_VOL_FAMILIES = {"volumeRestrictions": "VolumeRestrictions", "volumeZone": "VolumeZone", "csiLimits": "NodeVolumeLimits", "boundClaims": "VolumeBinding"}
+
+
+def _vol_world(row):
+    from test_native_host import EXAMPLES_POD, node, running_pod
+    import yaml
+    nodes = [node(nd["name"], cpu="4", mem="8Gi", pods="10", labels=nd["labels"]) for nd in row["nodes"]]
+    pods = []
+    for p in row.get("pods", []):
+        q = running_pod(p["metadata"]["name"], p["spec"]["nodeName"], cpu="100m")
+        q["metadata"]["namespace"] = p["metadata"]["namespace"]
+        q["spec"]["volumes"] = p["spec"]["volumes"]
+        pods.append(q)
+    tmpl = yaml.safe_load(EXAMPLES_POD)
+    tmpl["metadata"]["name"], tmpl["metadata"]["namespace"] = "sim", "default"
+    tmpl["spec"]["volumes"] = row["volumes"]
+    return nodes, pods, row.get("objs", []), tmpl
+
+
+def _vol_expected(fam, row):
+    from cluster_capacity_amd import model as M
+    if fam == "volumeRestrictions":
+        return [M.VOL_DISK_CONFLICT if c else 0 for c in row["conflict"]]
+    if fam == "volumeZone":
+        return [M.VOL_ZONE if c else 0 for c in row["reject"]]
+    if fam == "csiLimits":
+        return [M.VOL_MAX_COUNT if c else 0 for c in row["reject"]]
+    return [{0: 0, 1: M.VOL_NODE_AFFINITY, 2: M.VOL_PV_NOT_EXIST}[c] for c in row["verdict"]]
+
+
+@pytest.mark.parametrize("fam", sorted(_VOL_FAMILIES))
+def test_volume_filters_python_host(fam):
+    from cluster_capacity_amd import volumes as V
+    for k, row in enumerate(VEC["volumeFilters_" + fam]):
+        nodes, pods, objs, tmpl = _vol_world(row)
+        by = {}
+        for o in objs:
+            by.setdefault(o["kind"], []).append(o)
+        index = {n["metadata"]["name"]: i for i, n in enumerate(nodes)}
+        side = V.volume_side(tmpl, nodes, pods, index, pvc_objs=by.get("PersistentVolumeClaim", []), class_objs=by.get("StorageClass", []), pv_objs=by.get("PersistentVolume", []),
+                             enabled=(_VOL_FAMILIES[fam],), csinode_objs=by.get("CSINode", []), attachment_objs=by.get("VolumeAttachment", []))
+        assert side.prefilter_reject is None, (fam, k, side.prefilter_reject)
+        got = [0] * len(nodes) if side.veto is None else [int(x) for x in side.veto]
+        assert got == _vol_expected(fam, row), (fam, k)
+        if fam == "volumeRestrictions":
+            assert bool(side.exclusive) == row["exclusive"], (fam, k)
+
+
+@pytest.mark.parametrize("fam", sorted(_VOL_FAMILIES))
+def test_volume_filters_native_host(fam, tmp_path):
+    import subprocess
+    import yaml
+    from cluster_capacity_amd import build as B
+    from helpers import SUBPROC_TIMEOUT
+    native = B.build_host()
+    others = [p for p in _VOL_FAMILIES.values() if p != _VOL_FAMILIES[fam]]
+    cfg = tmp_path / "sched.yaml"
+    cfg.write_text(yaml.safe_dump({"apiVersion": "kubescheduler.config.k8s.io/v1", "kind": "KubeSchedulerConfiguration",
+                                   "profiles": [{"plugins": {"multiPoint": {"disabled": [{"name": p} for p in others]}}}]}))
+    for k, row in enumerate(VEC["volumeFilters_" + fam]):
+        nodes, pods, objs, tmpl = _vol_world(row)
+        (tmp_path / "pod.yaml").write_text(yaml.safe_dump(json.loads(json.dumps(tmpl))))
+        (tmp_path / "cluster.json").write_text(json.dumps({"kind": "List", "items": nodes + pods + objs}))
+        p = subprocess.run([native, "--podspec", str(tmp_path / "pod.yaml"), "--snapshot", str(tmp_path / "cluster.json"), "--sync-persistent-volumes", "--default-config", str(cfg),
+                            "--dump-snapshot", "-"], capture_output=True, text=True, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 0, (fam, k, p.stderr[-500:])
+        dump = json.loads(p.stdout)
+        got = dump["pod"]
+        assert got["prefilter_reject"] is None, (fam, k, got["prefilter_reject"])
+        veto = got["volume_veto"] if got["volume_veto"] is not None else [0] * len(nodes)
+        want = dict(zip([nd["name"] for nd in row["nodes"]], _vol_expected(fam, row)))
+        assert veto == [want[name] for name in dump["names"]], (fam, k)  # (the snapshot's node order is the node tree's: zone round-robin)
+        if fam == "volumeRestrictions":
+            assert bool(got["volume_exclusive"]) == row["exclusive"], (fam, k)

@@ -202,10 +202,11 @@ def _check_sharded(ccref, nodes, pod, prof, limit, world):
     return res, ref
 
 
+# (whole runs to Unschedulable -- three node passes and two exchanges per cycle -- on two shards only; the other shard counts on bounded runs)
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [1, 2, 3, 5])
-@pytest.mark.parametrize("cfg,n,pct,limit", [("C3", 1000, 0, 0), ("C3", 1000, 0, 300), ("C2", 5000, 10, 400), ("C3", 300, 50, 0),
-                                             ("C3", 777, 35, 0), ("C2", 2049, 0, 1000), ("C3", 100, 0, 0)])
+@pytest.mark.parametrize("world,cfg,n,pct,limit",
+                         [(w, *c) for c in [("C3", 1000, 0, 300), ("C2", 5000, 10, 400), ("C3", 300, 50, 0), ("C2", 2049, 0, 1000), ("C3", 100, 0, 0)] for w in (1, 2, 3, 5)] +
+                         [(2, "C3", 1000, 0, 0), (2, "C3", 777, 35, 0), (1, "C3", 777, 35, 1500), (3, "C3", 1000, 0, 1500), (5, "C3", 777, 35, 1500), (5, "C3", 1000, 0, 1500)])
 def test_sampled_search_on_shards_vs_oracle(ccref, world, cfg, n, pct, limit):
     nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=77 + n)
     res, ref = _check_sharded(ccref, nodes, pod, _with_pct(prof, pct), limit, world)

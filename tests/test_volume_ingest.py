@@ -549,6 +549,44 @@ def test_verdicts_with_a_nodes_victims_gone_in_both_hosts(native, tmp_path):
     assert got["volume_veto"] == [2] * 6 and got["preempt"]["volume_veto_rest"] == [2, 2, 2, 2, 0, 2]
 
 
+def test_read_write_once_pod_count_as_the_reference_keeps_it(native, tmp_path):
+    """the dry run's ReadWriteOncePod state is a COUNT (volume_restrictions.go:70-84, 219-232): one reference per claim in use however
+    many pods use it, minus one per victim volume whose claimName matches -- by name only.  So with two users of the claim (one a victim on n1,
+    one staying on n2) node n1 passes the dry run, and a victim of ANOTHER namespace with a same-named claim frees its node too."""
+    nodes = _nodes()
+    u1 = running_pod("u1", "n1", cpu="100m")   # lower priority: a victim
+    u1["spec"]["volumes"] = [_claim_vol("solo")]
+    u2 = running_pod("u2", "n2", cpu="100m")   # stays (same priority as the template)
+    u2["spec"]["volumes"] = [_claim_vol("solo")]
+    u2["spec"]["priority"] = 5
+    other = running_pod("other", "n3", cpu="100m")  # a victim in another namespace whose own claim has the same name
+    other["metadata"]["namespace"] = "elsewhere"
+    other["spec"]["volumes"] = [_claim_vol("solo")]
+    pod = _pod([_claim_vol("solo")])
+    pod["spec"]["priority"] = 5
+    objs = [u1, u2, other, _class("local"), _pvc("solo", volume_name="pv-1", modes=("ReadWriteOncePod",)), _pv("pv-1")]
+    flags = _write_case(tmp_path, pod, nodes, objs) + ["--sync-persistent-volumes"]
+    got = json.loads(_run(native, flags + ["--dump-snapshot", "-"]))["pod"]
+    by = cli.load_by_kind([flags[3]])
+    snap = ingest.build_snapshot(by["Node"], by["Pod"], cli.parse_pod_spec(flags[1]), pvc_objs=by["PersistentVolumeClaim"], class_objs=by["StorageClass"], pv_objs=by["PersistentVolume"])
+    want = [2, 0, 2, 0, 2, 2]  # count 1; n1's victim and n3's victim each take one reference away, n2's user is no victim
+    assert snap.pod.volume_veto.tolist() == [2] * 6 and snap.pod.preempt.volume_veto_rest.tolist() == want
+    assert got["volume_veto"] == [2] * 6 and got["preempt"]["volume_veto_rest"] == want
+
+
+def test_an_empty_cluster_ends_before_any_prefilter_in_both_hosts(native, tmp_path):
+    """schedulePod returns ErrNoNodesAvailable before a PreFilter plugin runs (schedule_one.go:438-440): zero nodes and a pod whose claim
+    is missing is `no nodes available to schedule pods`, not the claim's message."""
+    pod = _pod([_claim_vol("missing")])
+    flags = _write_case(tmp_path, pod, [], [])
+    buf = io.StringIO()
+    assert cli.main(flags + ["-o", "json"], out=buf) == 0
+    ref = json.loads(buf.getvalue())["status"]
+    got = json.loads(_run(native, flags + ["-o", "json"]))["status"]
+    got.pop("creationTimestamp"), ref.pop("creationTimestamp")
+    assert got == ref and got["replicas"] == 0 and got["failReason"]["failMessage"] == "no nodes available to schedule pods", got
+
+
 # ---- random differential: the two hosts on random object graphs -----------------------------------------------------------------------
 def _random_volume_world(rng):
     n = int(rng.integers(3, 12))
