@@ -1408,6 +1408,26 @@ def test_native_sharded_percentage_of_nodes_to_score(native, recorder, tmp_path)
     assert pcts("rich", ["--percentage-of-nodes-to-score", "30", "--max-limit", "3"]) == [100, 100]  # (spread constraints + inter-pod affinity)
 
 
+def test_native_sharded_run_refuses_to_change_a_coupled_templates_percentage(native, recorder, tmp_path):
+    """on one GPU a template with a topology-coupled FILTER keeps the reference's default adaptive sampling; the shards score every
+    node -- another total for the same input.  --gpus N therefore wants the percentage said (100) for such a template on a cluster large
+    enough to sample (>= 100 nodes), instead of switching it silently."""
+    nodes = [node(f"n{i}", cpu="4", mem="8Gi", pods="10", labels={"topology.kubernetes.io/zone": f"z{i % 3}", "kubernetes.io/hostname": f"n{i}"}) for i in range(120)]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["metadata"]["labels"] = {"app": "sim"}
+    pod["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1, "topologyKey": "topology.kubernetes.io/zone", "whenUnsatisfiable": "DoNotSchedule",
+                                                 "labelSelector": {"matchLabels": {"app": "sim"}}}]
+    podspec, snaps = _write(tmp_path, "json", nodes, [], pod)
+    env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "shard.json"), CCSIM_RECORD_PER_DEVICE="1")
+    base = [native, "--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["-o", "json", "--gpus", "2"]
+    for extra in ([], ["--percentage-of-nodes-to-score", "30"]):
+        p = subprocess.run(base + extra, capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 1 and "--percentage-of-nodes-to-score 100" in p.stderr and not p.stdout.strip(), (p.returncode, p.stderr[-500:])
+    p = subprocess.run(base + ["--percentage-of-nodes-to-score", "100"], capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
+    assert p.returncode == 0, p.stderr
+    assert [json.load(open(f"{tmp_path}/shard.json.{g}"))["profile"]["pct"] for g in range(2)] == [100, 100]
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_native_sharded_host_side_views_random_clusters(native, recorder, tmp_path, seed):
     """The same slicing check over the random clusters / pod specs of the ingest fuzz (spread constraints, inter-pod affinity with
