@@ -578,7 +578,7 @@ class Engine:
         """Which form the last sampled search (percentageOfNodesToScore < 100) took (ccsim_debug_sampled)."""
         out = (C.c_int64 * 16)()
         self._chk(self.lib.ccsim_debug_sampled(self.h, out), "ccsim_debug_sampled")
-        d = {"resident": bool(out[0]), "laps_form": bool(out[1]), "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
+        d = {"resident": bool(out[0]), "laps_form": out[1] == 1, "zone_form": out[1] == 2, "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
              "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
         if out[3] and any(out[8:16]):  # CCSIM_SB_PROF=1: microseconds per lap, by phase
             names = ["cut_blocks_tree_range_queries", "decide", "wait_commit", "leaves_next_cuts", "w1_tree", "w1_range_queries", "commit_wave", "w0_next_cuts"]

@@ -12,6 +12,7 @@
 #include "ccsim_multi.h"
 #include "ccsim_coupled.h"
 #include "ccsim_sampled.h"
+#include "ccsim_sampled_zone.h"
 
 #include <dlfcn.h>
 #include <errno.h>
@@ -208,6 +209,12 @@ struct ccsim_engine {
     int sb_allowed = 1;                          // CCSIM_SB=0: the three-pass cycle, 2: one cycle at a time on the summaries (A/B and test knobs)
     bool sb_attr_set = false, sb_run = false;
     unsigned long long *d_sb_prof = nullptr;     // CCSIM_SB_PROF=1: k_sb_laps' phase ticks
+    // ... of one template with a hard spread constraint over <= 64 zones (+ anti-affinity over a unique-per-node key): ccsim_sampled_zone.h
+    uint8_t *d_sz_zone8 = nullptr, *d_sz_ent_flg = nullptr, *d_sz_cntz = nullptr;
+    unsigned long long *d_sz_ent_key = nullptr, *d_sz_present = nullptr;
+    uint32_t *d_sz_over = nullptr;
+    bool sz_run = false, sz_attr_set = false;
+    std::string sz_why;                          // why the last sampled run of a coupled template did not take that form
     bool sb_laps = false;                        // this run: a lap of the ring at a time (k_sb_laps) instead of a cycle at a time (k_sb_cycles)
     bool cw_fast = false;                        // ... and may use the lane-per-candidate decide kernel (k_cw_decide_fast)
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
@@ -396,7 +403,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->allocs);
-    e->d_sb_memo = nullptr, e->d_sb_flag8 = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr, e->d_sb_prof = nullptr; // (they lived in e->allocs)
+    e->d_sb_memo = nullptr, e->d_sb_flag8 = nullptr, e->d_sz_zone8 = e->d_sz_ent_flg = e->d_sz_cntz = nullptr, e->d_sz_ent_key = e->d_sz_present = nullptr, e->d_sz_over = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr, e->d_sb_prof = nullptr; // (they lived in e->allocs)
     e->d_soft_pc0 = nullptr; // (sized for the previous snapshot: the pod is set again after a load)
     e->backups.clear();
     e->reset_pending = false, e->wide_stale = false;
@@ -1378,6 +1385,50 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
             HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
         }
     }
+    // ... and of ONE template with a hard spread constraint over a shared key of <= 64 values, optionally with inter-pod terms over a key
+    // that is unique per node and without inter-pod scores: per-(block, zone) entries under the mask of eligible zones (ccsim_sampled_zone.h)
+    e->sz_run = false;
+    if (mode == CCSIM_MODE_SEQUENTIAL && e->smp_K > 0 && e->n_ranks == 0 && !e->time_passes && e->sb_allowed == 1 && (e->pts.n > 0 || e->ipa.on) && e->global_offset == 0 &&
+        e->n_global == e->n) {
+        auto no = [&](const char *why) { e->sz_why = why; };
+        const int sh = e->smp_K >= 256 ? 8 : 6;
+        const int64_t blocks = (e->n_pad + ((int64_t)1 << sh) - 1) >> sh;
+        bool ipa_fits = !e->ipa.on;
+        if (e->ipa.on) {
+            ipa_fits = e->ipa.n_keys == 1 && e->ipa.n_aff == 0 && e->ipa.self_entries[0] == 0 && e->ipa.score_self[0] == 0 && e->ipa_entries0 == 0 &&
+                       label_col_unique(e, e->ipa_col[0]);
+        }
+        if (e->pts.n != 1 || e->soft.n > 0) no("not exactly one DoNotSchedule constraint (and no ScheduleAnyway ones)");
+        else if (e->pts_table_len[0] > (size_t)kSzZones + 1) no("more than 64 topology values");
+        else if (label_col_unique(e, e->pts_col[0])) no("the constraint's key is unique per node");
+        else if (!ipa_fits) no("inter-pod terms beyond required anti-affinity over one unique-per-node key (or inter-pod scores)");
+        else if (e->smp_K < 64) no("fewer than 64 nodes kept per cycle");
+        else if (blocks > kSzMaxBlocks) no("more than 4096 blocks of nodes");
+        else if (getenv("CCSIM_SZ") && !atoi(getenv("CCSIM_SZ"))) no("disabled (CCSIM_SZ=0)");
+        else {
+            e->sz_why.clear();
+            if (!e->d_sb_memo) {
+                int rc2;
+                if ((rc2 = dev_alloc(e, &e->d_sb_memo, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_flag8, (size_t)e->n_pad, e->allocs, false)) ||
+                    (rc2 = dev_alloc(e, &e->d_sb_fc, (size_t)kSbMaxBlocks, e->allocs)) || (rc2 = dev_alloc(e, &e->d_sb_key, (size_t)kSbMaxBlocks, e->allocs)) ||
+                    (rc2 = dev_alloc(e, &e->d_sb_mx, (size_t)kSbMaxBlocks, e->allocs)))
+                    return rc2;
+            }
+            if (!e->d_sz_zone8) {
+                int rc2;
+                if ((rc2 = dev_alloc(e, &e->d_sz_zone8, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sz_ent_key, (size_t)kSzMaxBlocks * kSzZones, e->allocs)) ||
+                    (rc2 = dev_alloc(e, &e->d_sz_ent_flg, (size_t)kSzMaxBlocks * kSzZones, e->allocs)) || (rc2 = dev_alloc(e, &e->d_sz_cntz, (size_t)kSzMaxBlocks * kSzZones, e->allocs)) ||
+                    (rc2 = dev_alloc(e, &e->d_sz_present, (size_t)1, e->allocs)) || (rc2 = dev_alloc(e, &e->d_sz_over, (size_t)1, e->allocs)))
+                    return rc2;
+            }
+            HIPCHK(e, hipMemsetAsync(e->d_sz_present, 0, sizeof(unsigned long long), e->stream)); // (a new pod spec may count other nodes)
+            HIPCHK(e, hipMemsetAsync(e->d_sz_over, 0, sizeof(uint32_t), e->stream));
+            HIPCHK(e, hipMemsetAsync(e->d_sz_cntz, 0, (size_t)kSzMaxBlocks * kSzZones, e->stream));
+            e->sb_shift = sh, e->sb_blocks = (int)blocks, e->sz_run = true, e->sb_run = false, e->sb_laps = false;
+            e->h_state->sb_dirty = 1; // nothing is known about the columns under the run's maxima yet
+            HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+        }
+    }
     e->cw_shard_run = mode == CCSIM_MODE_SEQUENTIAL && e->cw_ok && e->cw_fast && e->n_ranks > 0 && e->n_ranks <= 8 && e->smp_K == 0 && !e->time_passes && e->cw_work.xsend != nullptr &&
                       !(getenv("CCSIM_CW_SHARDS") && !atoi(getenv("CCSIM_CW_SHARDS")));
     e->cw_shard_args = false;
@@ -1962,6 +2013,70 @@ static int run_sb(ccsim_engine *e) {
     }
 }
 
+// ---- the sampled search of one template with a hard spread constraint over zones (ccsim_sampled_zone.h) ----
+// returns 1 when the form does not fit after all (a (block, zone) count beyond a byte): the caller takes the three-pass cycle from the untouched state
+static int run_sz(ccsim_engine *e) {
+    static_assert(sizeof(SzLds) <= 64 * 1024, "k_sz_cycles' LDS image");
+    HIPCHK(e, hipSetDevice(e->device));
+    SzArgs a{e->cols, e->pod, e->d_state, e->pts, e->ipa, e->d_sb_memo, e->d_sz_zone8, e->d_sb_flag8, e->d_sz_ent_key, e->d_sz_ent_flg, e->d_sz_cntz, e->d_sz_over, e->d_log,
+             e->sb_shift, e->sb_blocks, 1 << 16, (int32_t)e->pts_table_len[0] - 1, e->d_sz_present, nullptr};
+    if (const char *f = getenv("CCSIM_SB_CYCLES")) a.max_cycles = atoi(f) > 0 ? atoi(f) : a.max_cycles; // tuning / test knob: cycles per launch
+    if (getenv("CCSIM_SB_PROF") && atoi(getenv("CCSIM_SB_PROF"))) {
+        if (!e->d_sb_prof) {
+            int rc2;
+            if ((rc2 = dev_alloc(e, &e->d_sb_prof, (size_t)8, e->allocs))) return rc2;
+        }
+        HIPCHK(e, hipMemsetAsync(e->d_sb_prof, 0, sizeof(unsigned long long) * 8, e->stream));
+        a.prof = e->d_sb_prof;
+    }
+    const bool narrow = e->cols.narrow && e->pod.nx == 0;
+    int idle = 0;
+    bool first = true;
+    for (;;) {
+        const int64_t placed0 = e->h_state->placed;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        for (int rep = 0; rep < (first ? 1 : 4); rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
+            if (narrow) hipLaunchKernelGGL((k_sz_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            else hipLaunchKernelGGL((k_sz_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            if (first) break; // (look at the build's verdict before the first cycle)
+            if (e->sb_shift == 8) {
+                if (narrow) hipLaunchKernelGGL((k_sz_cycles<true, 4>), dim3(1), dim3(kSzThreads), sizeof(SzLds), e->stream, a);
+                else hipLaunchKernelGGL((k_sz_cycles<false, 4>), dim3(1), dim3(kSzThreads), sizeof(SzLds), e->stream, a);
+            } else {
+                if (narrow) hipLaunchKernelGGL((k_sz_cycles<true, 1>), dim3(1), dim3(kSzThreads), sizeof(SzLds), e->stream, a);
+                else hipLaunchKernelGGL((k_sz_cycles<false, 1>), dim3(1), dim3(kSzThreads), sizeof(SzLds), e->stream, a);
+            }
+        }
+        HIPCHK(e, hipGetLastError());
+        if (first) {
+            uint32_t over = 0;
+            HIPCHK(e, hipMemcpyAsync(&over, e->d_sz_over, sizeof over, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            if (over) {
+                e->sz_why = "more than 255 nodes of one zone in a block of nodes";
+                return 1;
+            }
+            // (the build has run under the state's maxima and left sb_dirty set: the first launch of the cycle kernel behind the next build clears it)
+            first = false;
+            continue;
+        }
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        int rc = read_state(e);
+        if (rc) return rc;
+        float ms = 0;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->kernel_ms += ms;
+        if (getenv("CCSIM_SB_DEBUG"))
+            fprintf(stderr, "[ccsim sz] placed %lld rounds %lld scans %lld done %d dirty %d mt_a %d ma_a %d start %lld launches %d K %lld blocks %d shift %d cycles %d\n", (long long)e->h_state->placed,
+                    (long long)e->h_state->rounds, (long long)e->h_state->scans, e->h_state->done, e->h_state->sb_dirty, e->h_state->mt_a, e->h_state->ma_a,
+                    (long long)e->h_state->smp_start, e->h_state->sb_cycles, (long long)e->h_state->smp_K, e->sb_blocks, e->sb_shift, e->h_state->sb_laps);
+        e->pass_launches = e->h_state->sb_cycles;
+        if (e->h_state->done) return 0;
+        idle = e->h_state->placed == placed0 ? idle + 1 : 0;
+        if (idle >= 4) return fail(e, -EIO, "sampled search made no progress in %d launches", 16);
+    }
+}
+
 extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim_report *out) {
     if (!e || !out) return -EINVAL;
     out->stop_spec = -1;
@@ -2001,6 +2116,13 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
     if (e->sb_run) { // begin_run chose the resident form of the sampled search
         if ((rc = run_sb(e))) return rc;
         return fill_report(e, out);
+    }
+    if (e->sz_run) { // ... of a template with a hard spread constraint over zones
+        if ((rc = run_sz(e)) < 0) return rc;
+        if (rc == 0) return fill_report(e, out);
+        e->sz_run = false; // (nothing was placed: the three-pass cycle below continues from the untouched state)
+        e->h_state->sb_dirty = 0;
+        HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
     }
     int rps = e->rounds_per_sync > 0 ? e->rounds_per_sync : (mode == CCSIM_MODE_BATCHED ? 64 : 256);
     for (;;) {
@@ -3237,10 +3359,14 @@ extern "C" int ccsim_debug_dist(ccsim_engine *e, int64_t *out8) {
 extern "C" int ccsim_debug_sampled(ccsim_engine *e, int64_t *out8) {
     if (!e || !out8) return -EINVAL;
     for (int i = 0; i < 16; i++) out8[i] = 0;
-    if (e->d_sb_prof && e->sb_run) {
+    if (e->d_sb_prof && (e->sb_run || e->sz_run)) {
         HIPCHK(e, hipSetDevice(e->device));
         HIPCHK(e, hipStreamSynchronize(e->stream));
         HIPCHK(e, hipMemcpy(out8 + 8, e->d_sb_prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));
+    }
+    if (e->h_state && e->begun && e->sz_run) { // the form for a hard spread constraint over zones (ccsim_sampled_zone.h): [1] = 2
+        out8[0] = 1, out8[1] = 2, out8[2] = e->h_state->sb_cycles, out8[3] = e->h_state->sb_laps, out8[5] = e->sb_shift, out8[6] = e->sb_blocks, out8[7] = e->smp_K;
+        return 0;
     }
     if (!e->h_state || !e->begun || !e->sb_run) return 0;
     out8[0] = 1, out8[1] = e->sb_laps ? 1 : 0, out8[2] = e->h_state->sb_cycles, out8[3] = e->h_state->sb_laps, out8[4] = e->h_state->sb_slow;

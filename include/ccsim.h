@@ -475,7 +475,7 @@ int ccsim_debug_multi_memo(ccsim_engine *e, int64_t *out8);
 int ccsim_debug_coupled(ccsim_engine *e, int64_t *out16);
 /* ... and how the last sampled search (percentageOfNodesToScore < 100; S/schedule_one.go:610-723) of a template without topology-coupled
  * plugins ran (csrc/ccsim_sampled.h): out8[0] = 1 if it ran on the resident block summaries, [1] = 1 if a lap of the ring at a time
- * (k_sb_laps; 0: a cycle at a time, k_sb_cycles), [2] = launches of that kernel, [3] = laps evaluated, [4] = stretches re-evaluated node
+ * (k_sb_laps; 0: a cycle at a time, k_sb_cycles; 2: a template with a hard spread constraint over zones, csrc/ccsim_sampled_zone.h: [3] = cycles), [2] = launches of that kernel, [3] = laps evaluated, [4] = stretches re-evaluated node
  * by node under their own normalization maxima, [5] = log2 of the block size, [6] = blocks, [7] = K (numFeasibleNodesToFind);
  * out[8..14] (with CCSIM_SB_PROF=1): 10 ns ticks k_sb_laps spent [8] on the cut blocks (wave 1: the tree, the range queries), [9] on
  * the decision (+ stretches re-evaluated), [10] waiting for the placements, [11] on the winners' leaves (wave 0: the next lap's cuts);

@@ -26,10 +26,15 @@ def _check(ccref, nodes, pod, prof, limit):
     import os
     sampled = ccref.num_feasible_nodes_to_find(prof.percentage_of_nodes_to_score, nodes.n) < nodes.n or not (prof.w_taint or prof.w_nodeaffinity or prof.w_fit or prof.w_balanced
                                                                                                         or prof.w_imagelocality or prof.w_topologyspread or prof.w_interpodaffinity)
-    resident = sampled and not pod.spread and pod.ipa is None and os.environ.get("CCSIM_SB", "1") != "0"
-    assert (got.pass_launches > 0) == resident, (got.pass_launches, resident)
     info = e.sampled_info()
+    coupled = bool(pod.spread) or pod.ipa is not None
+    # (a coupled template takes three node passes per cycle, except the one shape csrc/ccsim_sampled_zone.h holds resident -- round 6)
+    resident = sampled and os.environ.get("CCSIM_SB", "1") != "0" and (not coupled or info["zone_form"])
+    assert (got.pass_launches > 0) == resident, (got.pass_launches, resident)
     assert info["resident"] == resident
+    if info["zone_form"]:
+        assert coupled and info["laps"] >= got.placed  # (`laps` counts this form's cycles)
+        return e, got, ref
     if resident:  # ... and a lap of the ring at a time (k_sb_laps, round 6) whenever a block of >= 64 nodes holds one stretch boundary at most
         forced = int(os.environ.get("CCSIM_SB_SHIFT", "6"))  # (blocks of 256 nodes when K >= 256, else of 64; forced: 64 or 256 only)
         assert info["laps_form"] == (info["K"] >= (1 << forced) and forced in (6, 8) and os.environ.get("CCSIM_SB", "1") == "1"), info
@@ -105,6 +110,68 @@ def test_sampled_search_a_node_wins_in_consecutive_laps(ccref):
     nodes.alloc_pods[big] = 4000
     e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, 5), 6000)
     assert np.max(got.per_node_count) >= 40
+    e.close()
+
+
+def _zone_template(n, zones=None, max_skew=1, min_domains=1, anti=True, seed=5, cfg="C3"):
+    """BASELINE config 5's pod shape as ONE template: zone DoNotSchedule spread (+ required hostname anti-affinity against its own clones)."""
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=seed)
+    pod.spread = [synth.zone_spread(n, max_skew=max_skew, min_domains=min_domains)]
+    if zones is not None:  # the same nodes dealt to `zones` zones
+        nodes.label_cols[pod.spread[0].col] = (np.arange(n) % zones + 1).astype(np.int32)
+        pod.spread[0].n_domains = zones
+    if anti:
+        nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))  # kubernetes.io/hostname
+        pod.ipa = M.InterPodAffinity(key_cols=[len(nodes.label_cols) - 1], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    return nodes, pod, prof
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,zones,pct,limit,skew,anti", [(1000, None, 0, 0, 1, True), (1000, None, 0, 0, 2, False), (5000, 7, 10, 900, 1, True), (20_000, 64, 5, 1500, 1, True),
+                                                         (4096, 3, 5, 0, 3, True), (777, 64, 35, 0, 1, True), (100_000, None, 0, 700, 1, True), (3000, 16, 5, 2500, 1, False)])
+def test_sampled_zone_form_vs_oracle(ccref, n, zones, pct, limit, skew, anti):
+    """The reference's default percentage for a template with a hard zone spread constraint (+ hostname anti-affinity): per-(block, zone) entries
+    under the mask of eligible zones (csrc/ccsim_sampled_zone.h) against the oracle's visiting loop -- log, nodes visited, feasible counts, and
+    the FitError histogram where the run ends Unschedulable."""
+    nodes, pod, prof = _zone_template(n, zones, max_skew=skew, anti=anti, seed=40 + n)
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, pct), limit)
+    assert e.sampled_info()["zone_form"], e.sampled_info()
+    e.close()
+
+
+@pytest.mark.gpu
+def test_sampled_zone_form_nodes_without_the_key_min_domains_and_existing_pods(ccref):
+    rng = np.random.default_rng(77)
+    n = 2500
+    nodes, pod, prof = _zone_template(n, 5, max_skew=1, min_domains=7, anti=True, seed=3)  # fewer zones than minDomains: the global minimum reads 0
+    col = pod.spread[0].col
+    nodes.label_cols[col][rng.random(n) < 0.1] = 0                                        # some nodes lack the key: never feasible
+    pod.spread[0].node_match_count = (rng.random(n) < 0.05).astype(np.int32) * rng.integers(1, 4, n).astype(np.int32)  # matching pods already there
+    pod.spread[0].node_included = (rng.random(n) < 0.9).astype(np.uint8)                   # node inclusion policies: some nodes are not counted
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, 5), 0)
+    assert e.sampled_info()["zone_form"]
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{"CCSIM_SZ": "0"}, {"CCSIM_SB_CYCLES": "1"}, {"CCSIM_SB_CYCLES": "5"}], ids=["three-passes", "1-cycle-per-launch", "5-cycles-per-launch"])
+def test_sampled_zone_forms_agree(ccref, monkeypatch, knobs):
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for n, zones, pct, limit in ((1500, 9, 10, 0), (6000, 64, 5, 1200)):
+        nodes, pod, prof = _zone_template(n, zones, seed=90 + n)
+        e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, pct), limit)
+        assert e.sampled_info()["zone_form"] == ("CCSIM_SZ" not in knobs)
+        e.close()
+
+
+@pytest.mark.gpu
+def test_sampled_zone_form_1m_nodes_64_zones(ccref):
+    """BASELINE's 1M-node cluster, the generator's own 64 zones, the flag left unset (what both hosts run for this template): 1300 cycles = 20 rounds
+    of the spread constraint, the search sampling 5 % while many zones are eligible and visiting every node for the last zones of a round."""
+    nodes, pod, prof = _zone_template(1_000_000, None, cfg="C3", seed=5)
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, 0), 1300)
+    assert e.sampled_info()["zone_form"]
     e.close()
 
 
