@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void k_sb_build(SbArgs a) {
 
 // NodeInfo.update for one more clone on node i (S/framework/types.go:409-428; schedule_one.go:967-984 assume), and the node's memo word
 // under the assumed maxima afterwards.  The caller has invalidated its L1 if the row may have been written before in this launch.
-template <bool NARROW>
-__device__ __forceinline__ int32_t sb_place(const SbArgs &a, const NarrowPod &npod, int64_t i, uint32_t mt_a, uint32_t ma_a) {
+template <bool NARROW, class A> // (A: SbArgs, or ccsim_sampled_zone.h's SzArgs -- c, p, memo)
+__device__ __forceinline__ int32_t sb_place(const A &a, const NarrowPod &npod, int64_t i, uint32_t mt_a, uint32_t ma_a) {
     constexpr int NX = NARROW ? 0 : kMaxExtra; // (the narrow mirrors exist for pods without extra resource columns only)
     NodeRegs<NX> nd;
     int32_t na0 = 0, na1 = 0;

@@ -174,22 +174,21 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
     unsigned long long t_prev = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull, pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define SZ_TICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     const int Eb = (nb - 1 + kSzThreads - 1) / kSzThreads; // ring entries per thread
+    auto eligible = [&](int32_t zc) -> unsigned long long { // (wave-level: lane = zone, zc = its match count)
+        const bool pres = (present >> lane) & 1ull;
+        const uint32_t mn_all = ~wave_max_u32(pres ? ~(uint32_t)zc : 0u); // min over the present zones (0xffffffff if there is none)
+        const int64_t minm = a.pts.n_present[0] < a.pts.min_domains[0] ? 0 : (int64_t)(int32_t)mn_all;
+        return __ballot(lane < a.n_values && (int64_t)zc + a.pts.self_match[0] - minm <= (int64_t)a.pts.max_skew[0]);
+    };
+    bool carried = false; // the start block's counts under E were left by the cycle before (its stop block IS this start block)
 
     while (!done && !dirty && budget > 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const int sb = start >> sh;
         // ---- 1. the eligible zones (filtering.go:311-356; every wave, lane = zone): count + selfMatch - min <= maxSkew, the minimum over the
         // zones that hold a counted node (0 when there are fewer of them than minDomains, :105-117)
-        unsigned long long E;
-        uint32_t FE;
-        {
-            const int32_t zc = L.zc[lane];
-            const bool pres = (present >> lane) & 1ull;
-            const uint32_t mn_all = ~wave_max_u32(pres ? ~(uint32_t)zc : 0u); // min over the present zones (0xffffffff if there is none)
-            const int64_t minm = a.pts.n_present[0] < a.pts.min_domains[0] ? 0 : (int64_t)(int32_t)mn_all;
-            E = __ballot(lane < a.n_values && (int64_t)zc + a.pts.self_match[0] - minm <= (int64_t)a.pts.max_skew[0]);
-            FE = wave_sum_u32_dpp(((E >> lane) & 1ull) ? (uint32_t)L.zF[lane] : 0u);
-        }
+        unsigned long long E = eligible(L.zc[lane]);
+        const uint32_t FE = wave_sum_u32_dpp(((E >> lane) & 1ull) ? (uint32_t)L.zF[lane] : 0u);
         if (FE == 0) { // schedule_one.go:448-454: every node was visited, none passed
             done = DONE_UNSCHEDULABLE, rounds += 1, scans += 1, last_feasible = 0, last_evaluated = N, evaluated += N, winner = -1;
             break;
@@ -210,21 +209,25 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             }
             E_prev = E;
         }
-        // the start block under E: its feasible nodes at or behind / before the start index (wave 0 counts; kept in registers for step 3)
+        // the start block under E: its words for step 3 (wave 0); its feasible nodes at or behind / before the start index -- counted here in
+        // the first cycle of a launch, left in LDS by the cycle before otherwise (its stop block IS this start block)
         int32_t sm[NP];
         uint32_t szw = 0, sfw = 0;
         if (wave == 0) {
             fetch(sb, sm, szw, sfw);
-            uint32_t t = 0, h = 0;
+            if (!carried) {
+                uint32_t t = 0, h = 0;
 #pragma unroll
-            for (int k = 0; k < NP; k++) {
-                const uint32_t z = (szw >> (8 * k)) & 0xffu;
-                const bool fe = sm[k] >= 0 && z && ((E >> (z - 1)) & 1ull);
-                const int32_t i = (sb << sh) + lane * NP + k;
-                t += (fe && i >= start) ? 1u : 0u, h += (fe && i < start) ? 1u : 0u;
+                for (int k = 0; k < NP; k++) {
+                    const uint32_t z = (szw >> (8 * k)) & 0xffu;
+                    const bool fe = sm[k] >= 0 && z && ((E >> (z - 1)) & 1ull);
+                    const int32_t i = (sb << sh) + lane * NP + k;
+                    t += (fe && i >= start) ? 1u : 0u, h += (fe && i < start) ? 1u : 0u;
+                }
+                t = wave_sum_u32_dpp(t), h = wave_sum_u32_dpp(h);
+                if (lane == 0) L.tailF = t, L.headF = h;
             }
-            t = wave_sum_u32_dpp(t), h = wave_sum_u32_dpp(h);
-            if (lane == 0) L.tailF = t, L.headF = h, L.s_key[0] = 0, L.s_key[1] = 0, L.s_flag = 0, L.stop_blk = -1, L.stop_kind = -1, L.stop_node = -1;
+            if (lane == 0) L.s_key[0] = 0, L.s_key[1] = 0, L.s_flag = 0, L.stop_blk = -1, L.stop_kind = -1, L.stop_node = -1;
         }
         __syncthreads(); // ---- barrier 1: fE, tailF
         SZ_TICK(0);
@@ -270,6 +273,8 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
         // start block's head when every node is visited), the blocks in between by their (block, eligible zone) entries (waves 2 ..)
         const int stop_blk = L.stop_blk, stop_kind = L.stop_kind;
         const int32_t stop_need = L.stop_need;
+        int32_t nxm[NP]; // (wave 1: the words of the block the stretch ends in)
+        uint32_t nxzw = 0, nxfw = 0;
         auto offer = [&](unsigned long long k, uint32_t fl, bool part1) { // (wave-level: lane 0 files the wave's best)
             const unsigned long long kb = lap_wave_best(k != 0, k);
             const uint32_t f = lap_wave_or3(k != 0, fl);
@@ -290,10 +295,10 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             offer(bk, bf, false);
         } else if (wave == 1) {
             const int blk = all ? sb : stop_blk;
+            fetch(blk, nxm, nxzw, nxfw); // (also the NEXT cycle's start block: kept for its counts, step 5)
             if (blk >= 0 && (!all || headF > 0)) {
-                int32_t m[NP];
-                uint32_t zw = 0, fw = 0;
-                fetch(blk, m, zw, fw);
+                int32_t *m = nxm;
+                const uint32_t zw = nxzw, fw = nxfw;
                 const int32_t i0 = (blk << sh) + lane * NP;
                 const bool head = all || stop_kind == 1; // the segment: the start block's nodes before the start index, or a whole block
                 uint32_t fm = 0;
@@ -332,18 +337,27 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             const int z = t < ne ? (int)L.elist[t] : -1;
             unsigned long long bk0 = 0, bk1 = 0;
             uint32_t bf = 0;
-#pragma unroll 4
-            for (int pb0 = (wave - 2) * bpw; pb0 < nblk; pb0 += (kSzWaves - 2) * bpw) {
-                const int pb = pb0 + lb;
-                if (pb < nblk && z >= 0) {
-                    const int p = p_lo + pb, b = p >= nb ? p - nb : p;
-                    const unsigned long long key = a.ent_key[(int64_t)b * kSzZones + z];
-                    if (key) {
-                        if (p >= nb) bk1 = key > bk1 ? key : bk1;
-                        else bk0 = key > bk0 ? key : bk0;
-                        bf |= a.ent_flg[(int64_t)b * kSzZones + z];
-                    }
+            constexpr int kU = 8; // entries in flight per lane: the loads of a round are issued before any of them is looked at
+            const int stride = (kSzWaves - 2) * bpw, zz = z >= 0 ? z : 0;
+            for (int base = (wave - 2) * bpw; base < nblk; base += kU * stride) {
+                unsigned long long kk[kU];
+                uint32_t ff[kU];
+                bool wr[kU];
+#pragma unroll
+                for (int u = 0; u < kU; u++) {
+                    const int pb = base + u * stride + lb;
+                    const bool ok = pb < nblk && z >= 0;
+                    const int p = p_lo + (ok ? pb : 0), b = p >= nb ? p - nb : p;
+                    kk[u] = a.ent_key[(int64_t)b * kSzZones + zz], ff[u] = a.ent_flg[(int64_t)b * kSzZones + zz], wr[u] = p >= nb;
+                    kk[u] = ok ? kk[u] : 0ull;
                 }
+#pragma unroll
+                for (int u = 0; u < kU; u++)
+                    if (kk[u]) {
+                        if (wr[u]) bk1 = kk[u] > bk1 ? kk[u] : bk1;
+                        else bk0 = kk[u] > bk0 ? kk[u] : bk0;
+                        bf |= ff[u];
+                    }
             }
             const unsigned long long k0 = wave_max_u64(bk0), k1 = wave_max_u64(bk1); // (lanes are zones here, not index order: the full key decides)
             const uint32_t f = lap_wave_or3((bk0 | bk1) != 0, bf);
@@ -391,19 +405,29 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
         if (tid == 0 && cycles < 8) printf("[sz] cyc %d start %d E %llx FE %u all %d tailF %u headF %u fullF %u stop_blk %d kind %d need %d stop_node %d k0 %llx k1 %llx flag %u -> g %d score %lld\n", cycles, start, E, FE, (int)all, tailF, headF, fullF, stop_blk, stop_kind, stop_need, stop_node, L.s_key[0], L.s_key[1], L.s_flag, g, (long long)key_score(key));
 #endif
         const uint32_t gz = a.zone8[g]; // (>= 1: the node was feasible)
+        const uint32_t geb = a.pts.elig[g];
+        const bool counted = (geb & 1u) && ((geb >> 1) & 1u) && a.pts.self_match[0];
+        // a clone with required anti-affinity against itself over the node's own (unique) topology value: the node is out from now on
+        const bool blocks_itself = a.ipa.on && a.ipa.filter_on && a.ipa.anti_self_on_key[0] > 0 && a.ipa.label[0][g] != 0;
+        // the zones eligible in the NEXT cycle follow from the winner's zone alone: every wave knows them now
+        const unsigned long long E_next = eligible(L.zc[lane] + ((lane == (int)gz - 1 && counted) ? 1 : 0));
         if (tid == 0) {
             const int64_t i = g;
-            const int64_t r0 = a.c.req[0][i], r1 = a.c.req[1][i], z0 = a.c.nz_mcpu[i], z1 = a.c.nz_mem[i];
-            const int32_t pc = a.c.pod_count[i], pl = a.c.placed_cnt[i];
-            a.c.req[0][i] = r0 + a.p.req[0], a.c.req[1][i] = r1 + a.p.req[1];
-            a.c.nz_mcpu[i] = z0 + a.p.nz_mcpu, a.c.nz_mem[i] = z1 + a.p.nz_mem;
-            a.c.pod_count[i] = pc + 1, a.c.placed_cnt[i] = pl + 1;
-            store_mirror(a.c, i, r0 + a.p.req[0], r1 + a.p.req[1], z0 + a.p.nz_mcpu, z1 + a.p.nz_mem);
+            int32_t nw = -1;
+            if (blocks_itself) { // (the row only: its next reader is the write-back at the end of the run)
+                const int64_t r0 = a.c.req[0][i], r1 = a.c.req[1][i], z0 = a.c.nz_mcpu[i], z1 = a.c.nz_mem[i];
+                const int32_t pc = a.c.pod_count[i], pl = a.c.placed_cnt[i];
+                a.c.req[0][i] = r0 + a.p.req[0], a.c.req[1][i] = r1 + a.p.req[1];
+                a.c.nz_mcpu[i] = z0 + a.p.nz_mcpu, a.c.nz_mem[i] = z1 + a.p.nz_mem;
+                a.c.pod_count[i] = pc + 1, a.c.placed_cnt[i] = pl + 1;
+                store_mirror(a.c, i, r0 + a.p.req[0], r1 + a.p.req[1], z0 + a.p.nz_mcpu, z1 + a.p.nz_mem);
 #pragma unroll 1
-            for (int col = 2; col < a.p.ncol; col++)
-                if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
-            const uint32_t eb = a.pts.elig[i];
-            if ((eb & 1u) && ((eb >> 1) & 1u) && a.pts.self_match[0]) a.pts.tbl[0][gz] += 1, L.zc[gz - 1] += 1;
+                for (int col = 2; col < a.p.ncol; col++)
+                    if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
+                a.memo[i] = -1;
+            } else // NodeInfo.update and the node-local word from the row in registers (the inter-pod tables at its own value do not move: no term of the clone matches itself)
+                nw = sb_place<NARROW>(a, npod, i, mt_a, ma_a);
+            if (counted) a.pts.tbl[0][gz] += 1;
             if (a.ipa.on)
                 for (int k = 0; k < a.ipa.n_keys; k++) {
                     const int32_t v = a.ipa.label[k][i];
@@ -414,22 +438,31 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
                     a.ipa.score[k][v] += a.ipa.score_self[k];
                     S.ipa_entries += a.ipa.self_entries[k];
                 }
-            __threadfence(); // (sz_node_word reads the row, the tables and the two totals back)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const int32_t nw = sz_node_word<NARROW>(a, npod, i, mt_a, ma_a);
-            a.memo[i] = nw;
             L.new_word = nw;
-#ifdef CCSIM_SZ_TRACE
-            if (cycles < 8) printf("[sz]   placed on %d zone %u new word %d\n", g, gz, nw);
-#endif
             if (a.log && placed < log_cap) a.log[placed] = g;
             __threadfence();
         }
         int32_t pm[NP];
         uint32_t pzw = 0, pfw = 0;
         if (wave == 1) fetch(gblk, pm, pzw, pfw);
-        __syncthreads(); // ---- barrier 5: the winner's new word
-        if (wave == 1) { // the (block, zone) entry of the winner
+        if (wave >= 2) { // the masked counts follow E_next: the rows of the zones that enter or leave (the winner's entry still at its old count)
+            unsigned long long diff = E_next ^ E;
+            while (diff) {
+                const int z = __ffsll((long long)diff) - 1;
+                diff &= diff - 1;
+                const bool add = (E_next >> z) & 1ull;
+                for (int b = tid - 2 * 64; b < nb; b += kSzThreads - 2 * 64) {
+                    const uint16_t c = a.cntz[(int64_t)z * kSzMaxBlocks + b];
+                    L.fE[b] = add ? (uint16_t)(L.fE[b] + c) : (uint16_t)(L.fE[b] - c);
+                }
+            }
+        }
+        E_prev = E_next;
+        __syncthreads(); // ---- barrier 5: the winner's new word; fE under E_next
+        const int32_t visited = all ? N : ringpos(stop_node);
+        const int32_t next_start = all ? start : stop_node;
+        if (wave == 1) { // the (block, zone) entry of the winner; the next cycle's start block under E_next
+            const int32_t new_word = L.new_word;
             const int32_t i0 = (gblk << sh) + lane * NP;
             unsigned long long bk = 0;
             uint32_t bf = 0, c = 0, c_old = 0;
@@ -437,7 +470,7 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             for (int k = 0; k < NP; k++) {
                 const uint32_t z = (pzw >> (8 * k)) & 0xffu;
                 if (z != gz) continue;
-                const int32_t m = i0 + k == g ? L.new_word : pm[k];
+                const int32_t m = i0 + k == g ? new_word : pm[k];
                 c_old += (i0 + k == g || pm[k] >= 0) ? 1u : 0u; // (the winner was feasible before)
                 if (m >= 0) {
                     const unsigned long long k2 = make_key((int64_t)m, (int64_t)(i0 + k));
@@ -446,28 +479,35 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             }
             bk = lap_wave_best(bk != 0, bk);
             bf = lap_wave_or3(true, bf), c = wave_sum_u32_dpp(c), c_old = wave_sum_u32_dpp(c_old);
+            // the block the stretch ended in (every node was visited: the start block) is the next start block: its counts under E_next
+            const int nblk2 = all ? sb : stop_blk;
+            const int32_t j0 = (nblk2 << sh) + lane * NP;
+            uint32_t t = 0, h = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const uint32_t z = (nxzw >> (8 * k)) & 0xffu;
+                const int32_t m = j0 + k == g ? new_word : nxm[k];
+                const bool fe = m >= 0 && z && ((E_next >> (z - 1)) & 1ull);
+                t += (fe && j0 + k >= next_start) ? 1u : 0u, h += (fe && j0 + k < next_start) ? 1u : 0u;
+            }
+            t = wave_sum_u32_dpp(t), h = wave_sum_u32_dpp(h);
             if (lane == 0) {
                 a.ent_key[(int64_t)gblk * kSzZones + (gz - 1)] = bk, a.ent_flg[(int64_t)gblk * kSzZones + (gz - 1)] = (uint8_t)bf;
                 a.cntz[(int64_t)(gz - 1) * kSzMaxBlocks + gblk] = (uint8_t)c;
-                L.ent_cnt_new = c, L.ent_cnt_old = c_old;
+                const int32_t dc = (int32_t)c - (int32_t)c_old; // 0 or -1
+                L.zF[gz - 1] += dc;
+                if ((E_next >> (gz - 1)) & 1ull) L.fE[gblk] = (uint16_t)((int32_t)L.fE[gblk] + dc);
+                if (counted) L.zc[gz - 1] += 1;
+                L.tailF = t, L.headF = h;
                 __threadfence();
             }
         }
-        __syncthreads(); // ---- barrier 6: the entry
-        {
-            const int32_t dc = (int32_t)L.ent_cnt_new - (int32_t)L.ent_cnt_old; // 0 or -1
-            if (tid == 0 && dc) {
-                L.zF[gz - 1] += dc;
-                if ((E_prev >> (gz - 1)) & 1ull) L.fE[gblk] = (uint16_t)((int32_t)L.fE[gblk] + dc);
-            }
-            const int32_t visited = all ? N : ringpos(stop_node);
-            if (!all) start = stop_node;
-            placed += 1, rounds += 1, winner = g, evaluated += visited, last_evaluated = visited;
-            last_feasible = (int32_t)(all ? FE : K);
-            budget -= 1, cycles += 1;
-            if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312
-        }
-        __syncthreads(); // ---- barrier 7
+        start = next_start, carried = true;
+        placed += 1, rounds += 1, winner = g, evaluated += visited, last_evaluated = visited;
+        last_feasible = (int32_t)(all ? FE : K);
+        budget -= 1, cycles += 1;
+        if (limit > 0 && placed >= limit) done = DONE_LIMIT; // simulator.go:297-312
+        __syncthreads(); // ---- barrier 6: the entry, the zone state, the next start block's counts
         SZ_TICK(3);
     }
 #undef SZ_TICK
