@@ -2018,7 +2018,7 @@ static int run_sb(ccsim_engine *e) {
 static int run_sz(ccsim_engine *e) {
     static_assert(sizeof(SzLds) <= 64 * 1024, "k_sz_cycles' LDS image");
     HIPCHK(e, hipSetDevice(e->device));
-    SzArgs a{e->cols, e->pod, e->d_state, e->pts, e->ipa, e->d_sb_memo, e->d_sz_zone8, e->d_sb_flag8, e->d_sz_ent_key, e->d_sz_ent_flg, e->d_sz_cntz, e->d_sz_over, e->d_log,
+    SzArgs a{e->cols, e->pod, e->d_state, e->pts, e->ipa, e->d_sb_memo, e->d_sz_zone8, e->d_sb_flag8, e->d_sz_ent_key, e->d_sz_cntz, e->d_sz_over, e->d_log,
              e->sb_shift, e->sb_blocks, 1 << 16, (int32_t)e->pts_table_len[0] - 1, e->d_sz_present, nullptr};
     if (const char *f = getenv("CCSIM_SB_CYCLES")) a.max_cycles = atoi(f) > 0 ? atoi(f) : a.max_cycles; // tuning / test knob: cycles per launch
     if (getenv("CCSIM_SB_PROF") && atoi(getenv("CCSIM_SB_PROF"))) {

@@ -12,7 +12,7 @@
 // of the global minimum (filtering.go:311-356).  The eligible zones are a 64-bit mask E, recomputed from 64 counts every cycle.  So what a
 // cycle needs is resident, as in ccsim_sampled.h, but per (block of nodes, zone):
 //   memo[n]            TotalScore of node n under the assumed maxima if its node-local part passes, else -1; zone8[n] = the node's zone
-//   ent_key[b][z]      the best (score, lowest index) key among the zone-z nodes of block b that pass node-locally; ent_flg their flags
+//   ent_key[b][z]      the best (score, lowest index) key among the zone-z nodes of block b that pass node-locally, with their flags
 //   cntz[z][b]         how many there are (zone-major: when a zone enters or leaves E, one row is added to / taken from the masked counts)
 // A cycle (k_sz_cycles, one persistent workgroup):
 //   1. E from the zone counts; the masked per-block counts fE[b] (LDS) follow E by the rows of the zones that changed;
@@ -30,6 +30,10 @@ constexpr int kSzThreads = 512, kSzWaves = kSzThreads / 64;
 constexpr int kSzMaxBlocks = 4096; // blocks of 256 (64 on small snapshots) nodes
 constexpr int kSzZones = 64;       // topology values of the hard constraint (value ids 1 .. 64)
 constexpr int kSzE = kSzMaxBlocks / kSzThreads;
+constexpr int kSzFlagShift = 37; // an entry = the best node's key with the zone's 3 flag bits XORed into bits 37 .. 39 (ones in every key: node indices stay below 2^37)
+__device__ __forceinline__ unsigned long long sz_entry(unsigned long long key, uint32_t flags) { return key ? key ^ ((unsigned long long)(flags & 7u) << kSzFlagShift) : 0ull; }
+__device__ __forceinline__ unsigned long long sz_entry_key(unsigned long long e) { return e ? e | (7ull << kSzFlagShift) : 0ull; }
+__device__ __forceinline__ uint32_t sz_entry_flags(unsigned long long e) { return (uint32_t)(~e >> kSzFlagShift) & 7u; }
 
 struct SzArgs {
     DevCols c;
@@ -39,8 +43,7 @@ struct SzArgs {
     DevIpa ipa;
     int32_t *memo;               // [n_pad]
     uint8_t *zone8, *flag8;      // [n_pad] the node's zone (value id of the constraint's key, 0 = key absent); its raw scores against the assumed maxima
-    unsigned long long *ent_key; // [blocks][64]
-    uint8_t *ent_flg;            // [blocks][64]
+    unsigned long long *ent_key; // [blocks][64] (sz_entry: key + flags)
     uint8_t *cntz;               // [64][kSzMaxBlocks] zone-major
     uint32_t *over;              // [1] set by k_sz_build when some (block, zone) count does not fit a byte: the host takes the three-pass cycle
     int32_t *log;
@@ -106,8 +109,7 @@ __global__ __launch_bounds__(256) void k_sz_build(SzArgs a) {
     }
     __syncthreads();
     if (tid < kSzZones) {
-        a.ent_key[(int64_t)blockIdx.x * kSzZones + tid] = s_key[tid];
-        a.ent_flg[(int64_t)blockIdx.x * kSzZones + tid] = (uint8_t)s_flg[tid];
+        a.ent_key[(int64_t)blockIdx.x * kSzZones + tid] = sz_entry(s_key[tid], s_flg[tid]);
         a.cntz[(int64_t)tid * kSzMaxBlocks + blockIdx.x] = (uint8_t)(s_cnt[tid] > 255u ? 255u : s_cnt[tid]);
         if (s_cnt[tid] > 255u) atomicOr(a.over, 1u);
     }
@@ -115,7 +117,6 @@ __global__ __launch_bounds__(256) void k_sz_build(SzArgs a) {
 
 struct SzLds {
     uint16_t fE[kSzMaxBlocks];   // feasible nodes of the block in the zones of E_prev
-    int32_t zc[kSzZones];        // match count per zone (TpValueToMatchNum of the one hard constraint)
     int32_t zF[kSzZones];        // feasible (node-local) nodes per zone
     unsigned long long s_key[2]; // the cycle's best kept node: at or behind the start index [0], before it [1]
     uint32_t s_flag;
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             m[0] = a.memo[i0], zw = a.zone8[i0], fw = a.flag8[i0];
     };
     // ---- the per-zone state: match counts, feasible nodes; the masked counts start empty (E_prev = no zone)
-    if (tid < kSzZones) L.zc[tid] = tid < a.n_values ? a.pts.tbl[0][tid + 1] : 0, L.zF[tid] = 0;
+    if (tid < kSzZones) L.zF[tid] = 0;
+    int32_t zc_lane = lane < a.n_values ? a.pts.tbl[0][lane + 1] : 0; // every wave: lane z holds zone z's match count (TpValueToMatchNum of the one hard constraint)
     for (int b = tid; b < kSzMaxBlocks; b += kSzThreads) L.fE[b] = 0;
     __syncthreads();
     for (int z = wave; z < kSzZones; z += kSzWaves) { // feasible nodes per zone
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
         const int sb = start >> sh;
         // ---- 1. the eligible zones (filtering.go:311-356; every wave, lane = zone): count + selfMatch - min <= maxSkew, the minimum over the
         // zones that hold a counted node (0 when there are fewer of them than minDomains, :105-117)
-        unsigned long long E = eligible(L.zc[lane]);
+        unsigned long long E = eligible(zc_lane);
         const uint32_t FE = wave_sum_u32_dpp(((E >> lane) & 1ull) ? (uint32_t)L.zF[lane] : 0u);
         if (FE == 0) { // schedule_one.go:448-454: every node was visited, none passed
             done = DONE_UNSCHEDULABLE, rounds += 1, scans += 1, last_feasible = 0, last_evaluated = N, evaluated += N, winner = -1;
@@ -337,26 +339,25 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             const int z = t < ne ? (int)L.elist[t] : -1;
             unsigned long long bk0 = 0, bk1 = 0;
             uint32_t bf = 0;
-            constexpr int kU = 8; // entries in flight per lane: the loads of a round are issued before any of them is looked at
+            constexpr int kU = 16; // entries in flight per lane: the loads of a round are issued before any of them is looked at
             const int stride = (kSzWaves - 2) * bpw, zz = z >= 0 ? z : 0;
             for (int base = (wave - 2) * bpw; base < nblk; base += kU * stride) {
                 unsigned long long kk[kU];
-                uint32_t ff[kU];
-                bool wr[kU];
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     const int pb = base + u * stride + lb;
                     const bool ok = pb < nblk && z >= 0;
                     const int p = p_lo + (ok ? pb : 0), b = p >= nb ? p - nb : p;
-                    kk[u] = a.ent_key[(int64_t)b * kSzZones + zz], ff[u] = a.ent_flg[(int64_t)b * kSzZones + zz], wr[u] = p >= nb;
+                    kk[u] = a.ent_key[(int64_t)b * kSzZones + zz];
                     kk[u] = ok ? kk[u] : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < kU; u++)
                     if (kk[u]) {
-                        if (wr[u]) bk1 = kk[u] > bk1 ? kk[u] : bk1;
-                        else bk0 = kk[u] > bk0 ? kk[u] : bk0;
-                        bf |= ff[u];
+                        const unsigned long long kq = sz_entry_key(kk[u]);
+                        if (p_lo + base + u * stride + lb >= nb) bk1 = kq > bk1 ? kq : bk1;
+                        else bk0 = kq > bk0 ? kq : bk0;
+                        bf |= sz_entry_flags(kk[u]);
                     }
             }
             const unsigned long long k0 = wave_max_u64(bk0), k1 = wave_max_u64(bk1); // (lanes are zones here, not index order: the full key decides)
@@ -410,59 +411,64 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
         // a clone with required anti-affinity against itself over the node's own (unique) topology value: the node is out from now on
         const bool blocks_itself = a.ipa.on && a.ipa.filter_on && a.ipa.anti_self_on_key[0] > 0 && a.ipa.label[0][g] != 0;
         // the zones eligible in the NEXT cycle follow from the winner's zone alone: every wave knows them now
-        const unsigned long long E_next = eligible(L.zc[lane] + ((lane == (int)gz - 1 && counted) ? 1 : 0));
+        const int32_t zc_g = lane_bcast_i32(zc_lane, (int)gz - 1);
+        zc_lane += (lane == (int)gz - 1 && counted) ? 1 : 0;
+        const unsigned long long E_next = eligible(zc_lane);
         if (tid == 0) {
             const int64_t i = g;
             int32_t nw = -1;
-            if (blocks_itself) { // (the row only: its next reader is the write-back at the end of the run)
-                const int64_t r0 = a.c.req[0][i], r1 = a.c.req[1][i], z0 = a.c.nz_mcpu[i], z1 = a.c.nz_mem[i];
-                const int32_t pc = a.c.pod_count[i], pl = a.c.placed_cnt[i];
-                a.c.req[0][i] = r0 + a.p.req[0], a.c.req[1][i] = r1 + a.p.req[1];
-                a.c.nz_mcpu[i] = z0 + a.p.nz_mcpu, a.c.nz_mem[i] = z1 + a.p.nz_mem;
-                a.c.pod_count[i] = pc + 1, a.c.placed_cnt[i] = pl + 1;
-                store_mirror(a.c, i, r0 + a.p.req[0], r1 + a.p.req[1], z0 + a.p.nz_mcpu, z1 + a.p.nz_mem);
+            if (blocks_itself) { // the row by atomics nobody waits for: its next reader is the end of the run (the node never passes again)
+                atomicAdd((unsigned long long *)&a.c.req[0][i], (unsigned long long)a.p.req[0]), atomicAdd((unsigned long long *)&a.c.req[1][i], (unsigned long long)a.p.req[1]);
+                atomicAdd((unsigned long long *)&a.c.nz_mcpu[i], (unsigned long long)a.p.nz_mcpu), atomicAdd((unsigned long long *)&a.c.nz_mem[i], (unsigned long long)a.p.nz_mem);
+                atomicAdd(&a.c.pod_count[i], 1), atomicAdd(&a.c.placed_cnt[i], 1);
+                if (a.c.narrow) {
+                    atomicAdd(&a.c.r32[0][i], (int32_t)a.p.req[0]), atomicAdd(&a.c.r32[1][i], (int32_t)(a.p.req[1] >> a.c.mem_shift));
+                    atomicAdd(&a.c.z32[0][i], (int32_t)a.p.nz_mcpu), atomicAdd(&a.c.z32[1][i], (int32_t)(a.p.nz_mem >> a.c.mem_shift));
+                }
 #pragma unroll 1
                 for (int col = 2; col < a.p.ncol; col++)
-                    if (a.p.req[col] != 0) a.c.req[col][i] += a.p.req[col];
+                    if (a.p.req[col] != 0) atomicAdd((unsigned long long *)&a.c.req[col][i], (unsigned long long)a.p.req[col]);
                 a.memo[i] = -1;
             } else // NodeInfo.update and the node-local word from the row in registers (the inter-pod tables at its own value do not move: no term of the clone matches itself)
                 nw = sb_place<NARROW>(a, npod, i, mt_a, ma_a);
-            if (counted) a.pts.tbl[0][gz] += 1;
+            if (counted) a.pts.tbl[0][gz] = zc_g + 1;
             if (a.ipa.on)
                 for (int k = 0; k < a.ipa.n_keys; k++) {
                     const int32_t v = a.ipa.label[k][i];
                     if (!v) continue;
-                    if (a.ipa.self_aff && a.ipa.aff_terms_on_key[k]) a.ipa.aff[k][v] += a.ipa.aff_terms_on_key[k], S.ipa_aff_total += a.ipa.aff_terms_on_key[k];
-                    if (a.ipa.anti_self_on_key[k])
-                        a.ipa.anti[k][v] += a.ipa.anti_self_on_key[k], a.ipa.exist[k][v] += a.ipa.anti_self_on_key[k], S.ipa_exist_total += a.ipa.anti_self_on_key[k];
-                    a.ipa.score[k][v] += a.ipa.score_self[k];
+                    if (a.ipa.self_aff && a.ipa.aff_terms_on_key[k]) atomicAdd((unsigned long long *)&a.ipa.aff[k][v], (unsigned long long)a.ipa.aff_terms_on_key[k]), S.ipa_aff_total += a.ipa.aff_terms_on_key[k];
+                    if (a.ipa.anti_self_on_key[k]) {
+                        atomicAdd((unsigned long long *)&a.ipa.anti[k][v], (unsigned long long)a.ipa.anti_self_on_key[k]), atomicAdd((unsigned long long *)&a.ipa.exist[k][v], (unsigned long long)a.ipa.anti_self_on_key[k]);
+                        S.ipa_exist_total += a.ipa.anti_self_on_key[k];
+                    }
+                    if (a.ipa.score_self[k]) atomicAdd((unsigned long long *)&a.ipa.score[k][v], (unsigned long long)a.ipa.score_self[k]);
                     S.ipa_entries += a.ipa.self_entries[k];
                 }
             L.new_word = nw;
             if (a.log && placed < log_cap) a.log[placed] = g;
-            __threadfence();
         }
         int32_t pm[NP];
         uint32_t pzw = 0, pfw = 0;
         if (wave == 1) fetch(gblk, pm, pzw, pfw);
-        if (wave >= 2) { // the masked counts follow E_next: the rows of the zones that enter or leave (the winner's entry still at its old count)
+        if (wave >= 2) { // the masked counts follow E_next: the rows of the zones that enter or leave -- every block but the winner's (wave 1 below)
             unsigned long long diff = E_next ^ E;
             while (diff) {
                 const int z = __ffsll((long long)diff) - 1;
                 diff &= diff - 1;
                 const bool add = (E_next >> z) & 1ull;
                 for (int b = tid - 2 * 64; b < nb; b += kSzThreads - 2 * 64) {
+                    if (b == gblk) continue;
                     const uint16_t c = a.cntz[(int64_t)z * kSzMaxBlocks + b];
                     L.fE[b] = add ? (uint16_t)(L.fE[b] + c) : (uint16_t)(L.fE[b] - c);
                 }
             }
         }
         E_prev = E_next;
-        __syncthreads(); // ---- barrier 5: the winner's new word; fE under E_next
+        if (!blocks_itself) __syncthreads(); // ---- barrier 5: the winner's new word (known without it when the clone blocks its own node)
         const int32_t visited = all ? N : ringpos(stop_node);
         const int32_t next_start = all ? start : stop_node;
-        if (wave == 1) { // the (block, zone) entry of the winner; the next cycle's start block under E_next
-            const int32_t new_word = L.new_word;
+        if (wave == 1) { // the (block, zone) entry of the winner; the winner's block under E_next; the next cycle's start block under E_next
+            const int32_t new_word = blocks_itself ? -1 : L.new_word;
             const int32_t i0 = (gblk << sh) + lane * NP;
             unsigned long long bk = 0;
             uint32_t bf = 0, c = 0, c_old = 0;
@@ -479,6 +485,16 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             }
             bk = lap_wave_best(bk != 0, bk);
             bf = lap_wave_or3(true, bf), c = wave_sum_u32_dpp(c), c_old = wave_sum_u32_dpp(c_old);
+            // the winner's block in the masked counts: the rows of the zones that changed (lane = zone; the winner's zone still at its old count), then its own change
+            int32_t dfe = 0;
+            {
+                const unsigned long long diff = E_next ^ E;
+                if ((diff >> lane) & 1ull) {
+                    const int32_t cz = lane == (int)gz - 1 ? (int32_t)c_old : (int32_t)a.cntz[(int64_t)lane * kSzMaxBlocks + gblk];
+                    dfe = ((E_next >> lane) & 1ull) ? cz : -cz;
+                }
+                dfe = (int32_t)wave_sum_u32_dpp((uint32_t)dfe);
+            }
             // the block the stretch ended in (every node was visited: the start block) is the next start block: its counts under E_next
             const int nblk2 = all ? sb : stop_blk;
             const int32_t j0 = (nblk2 << sh) + lane * NP;
@@ -492,16 +508,15 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             }
             t = wave_sum_u32_dpp(t), h = wave_sum_u32_dpp(h);
             if (lane == 0) {
-                a.ent_key[(int64_t)gblk * kSzZones + (gz - 1)] = bk, a.ent_flg[(int64_t)gblk * kSzZones + (gz - 1)] = (uint8_t)bf;
+                a.ent_key[(int64_t)gblk * kSzZones + (gz - 1)] = sz_entry(bk, bf);
                 a.cntz[(int64_t)(gz - 1) * kSzMaxBlocks + gblk] = (uint8_t)c;
                 const int32_t dc = (int32_t)c - (int32_t)c_old; // 0 or -1
                 L.zF[gz - 1] += dc;
-                if ((E_next >> (gz - 1)) & 1ull) L.fE[gblk] = (uint16_t)((int32_t)L.fE[gblk] + dc);
-                if (counted) L.zc[gz - 1] += 1;
+                L.fE[gblk] = (uint16_t)((int32_t)L.fE[gblk] + dfe + (((E_next >> (gz - 1)) & 1ull) ? dc : 0));
                 L.tailF = t, L.headF = h;
-                __threadfence();
             }
         }
+        if (tid == 0 || tid == 64) __threadfence(); // the row, the memo word, the entry: in L2 before the barrier below
         start = next_start, carried = true;
         placed += 1, rounds += 1, winner = g, evaluated += visited, last_evaluated = visited;
         last_feasible = (int32_t)(all ? FE : K);
@@ -513,17 +528,17 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
 #undef SZ_TICK
     if (a.prof && tid == 0)
         for (int i = 0; i < 4; i++) a.prof[i] += pf[i];
+    if (wave == 0) {
+        const uint32_t mn = ~wave_max_u32(((present >> lane) & 1ull) ? ~(uint32_t)zc_lane : 0u);
+        if (lane == 0) S.pts_min_a[0] = mn == 0xffffffffu ? 0x7fffffff : (int32_t)mn;
+    }
     if (tid == 0) {
         S.smp_start = start, S.placed = placed, S.rounds = rounds, S.scans = scans, S.evaluated = evaluated, S.winner = winner;
         S.last_feasible = last_feasible, S.last_evaluated = last_evaluated, S.done = done;
         S.sb_dirty = dirty;
         if (dirty) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
         S.sb_cycles += 1, S.sb_laps += cycles;
-        // the global minimum the FitError diagnosis pass filters with (k_hist reads DevState::pts_min_a)
-        int32_t mn = 0x7fffffff;
-        for (int z = 0; z < kSzZones; z++)
-            if ((present >> z) & 1ull) mn = L.zc[z] < mn ? L.zc[z] : mn;
-        S.pts_min_a[0] = mn;
+        // the global minimum the FitError diagnosis pass filters with (k_hist reads DevState::pts_min_a): computed below by wave 0
     }
 }
 
