@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
     LapLds &L = *reinterpret_cast<LapLds *>(sb_lds_raw);
     DevState &S = *a.st;
     if (S.done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: known to be uniform, so what follows from it stays in scalar registers)
     const int nb = a.n_blocks, sh = a.shift; // (1 << sh == 64 * NP)
     int nbp = 2, levels = 1;
     while (nbp < nb) nbp <<= 1, levels++;

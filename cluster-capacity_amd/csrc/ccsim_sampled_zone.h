@@ -30,10 +30,15 @@ constexpr int kSzThreads = 512, kSzWaves = kSzThreads / 64;
 constexpr int kSzMaxBlocks = 4096; // blocks of 256 (64 on small snapshots) nodes
 constexpr int kSzZones = 64;       // topology values of the hard constraint (value ids 1 .. 64)
 constexpr int kSzE = kSzMaxBlocks / kSzThreads;
-constexpr int kSzFlagShift = 37; // an entry = the best node's key with the zone's 3 flag bits XORed into bits 37 .. 39 (ones in every key: node indices stay below 2^37)
-__device__ __forceinline__ unsigned long long sz_entry(unsigned long long key, uint32_t flags) { return key ? key ^ ((unsigned long long)(flags & 7u) << kSzFlagShift) : 0ull; }
-__device__ __forceinline__ unsigned long long sz_entry_key(unsigned long long e) { return e ? e | (7ull << kSzFlagShift) : 0ull; }
-__device__ __forceinline__ uint32_t sz_entry_flags(unsigned long long e) { return (uint32_t)(~e >> kSzFlagShift) & 7u; }
+// This kernel's keys: (TotalScore + 1) << 40 | (2^28 - 1 - node index) << 12 | info.  Highest score first, then the lowest index; the twelve
+// info bits below the (unique) index never decide.  info = the node's flags against the assumed maxima (3 bits) | counted by the constraint << 3
+// | carries the inter-pod key << 4 | zone (value id 1 .. 64) << 5: what the placement needs to know about the winner travels with the key.  An
+// (block, zone) ENTRY is the key of the group's best node with the flag bits replaced by the OR over the group.
+constexpr unsigned long long kSzIdxMask = (1ull << 28) - 1;
+__device__ __forceinline__ unsigned long long sz_key(int32_t score, int32_t idx, uint32_t info5, uint32_t zone) {
+    return ((unsigned long long)((int64_t)score + 1) << kIdxBits) | ((kSzIdxMask - (unsigned long long)idx) << 12) | (unsigned long long)((info5 & 31u) | (zone << 5));
+}
+__device__ __forceinline__ int32_t sz_key_index(unsigned long long k) { return (int32_t)(kSzIdxMask - ((k >> 12) & kSzIdxMask)); }
 
 struct SzArgs {
     DevCols c;
@@ -42,8 +47,8 @@ struct SzArgs {
     DevPts pts;
     DevIpa ipa;
     int32_t *memo;               // [n_pad]
-    uint8_t *zone8, *flag8;      // [n_pad] the node's zone (value id of the constraint's key, 0 = key absent); its raw scores against the assumed maxima
-    unsigned long long *ent_key; // [blocks][64] (sz_entry: key + flags)
+    uint8_t *zone8, *flag8;      // [n_pad] the node's zone (value id of the constraint's key, 0 = key absent); its info bits 0 .. 4 (sz_key)
+    unsigned long long *ent_key; // [64][kSzMaxBlocks] zone-major: an eligible zone's blocks of a stretch are one run of memory
     uint8_t *cntz;               // [64][kSzMaxBlocks] zone-major
     uint32_t *over;              // [1] set by k_sz_build when some (block, zone) count does not fit a byte: the host takes the three-pass cycle
     int32_t *log;
@@ -99,17 +104,19 @@ __global__ __launch_bounds__(256) void k_sz_build(SzArgs a) {
             const uint32_t w = a.c.stat[i], cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
             fl = ((cnt > mt || aff > ma) ? 1u : 0u) | (cnt == mt ? 2u : 0u) | (aff == ma ? 4u : 0u);
             const uint32_t eb = a.pts.elig[i];
-            if (z >= 1 && z <= kSzZones && (eb & 1u) && ((eb >> 1) & 1u)) atomicOr(a.present, 1ull << (z - 1)); // (idempotent: the same bits on every rebuild)
+            const bool counted = (eb & 1u) && ((eb >> 1) & 1u);
+            if (z >= 1 && z <= kSzZones && counted) atomicOr(a.present, 1ull << (z - 1)); // (idempotent: the same bits on every rebuild)
+            fl |= (counted && a.pts.self_match[0] ? 8u : 0u) | ((a.ipa.on && a.ipa.label[0][i] != 0) ? 16u : 0u);
         }
         a.memo[i] = sc, a.zone8[i] = (uint8_t)z, a.flag8[i] = (uint8_t)fl;
         if (sc >= 0 && z >= 1 && z <= kSzZones) {
-            atomicMax(&s_key[z - 1], make_key((int64_t)sc, i));
-            atomicAdd(&s_cnt[z - 1], 1u), atomicOr(&s_flg[z - 1], fl);
+            atomicMax(&s_key[z - 1], sz_key(sc, (int32_t)i, fl, z));
+            atomicAdd(&s_cnt[z - 1], 1u), atomicOr(&s_flg[z - 1], fl & 7u);
         }
     }
     __syncthreads();
     if (tid < kSzZones) {
-        a.ent_key[(int64_t)blockIdx.x * kSzZones + tid] = sz_entry(s_key[tid], s_flg[tid]);
+        a.ent_key[(int64_t)tid * kSzMaxBlocks + blockIdx.x] = s_key[tid] ? (s_key[tid] & ~7ull) | s_flg[tid] : 0ull;
         a.cntz[(int64_t)tid * kSzMaxBlocks + blockIdx.x] = (uint8_t)(s_cnt[tid] > 255u ? 255u : s_cnt[tid]);
         if (s_cnt[tid] > 255u) atomicOr(a.over, 1u);
     }
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
     SzLds &L = *reinterpret_cast<SzLds *>(sb_lds_raw);
     DevState &S = *a.st;
     if (S.done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: known to be uniform, so what follows from it stays in scalar registers)
     const int nb = a.n_blocks, sh = a.shift;
     const int32_t N = (int32_t)a.c.n;
     const uint32_t K = (uint32_t)S.smp_K;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
                 const uint32_t z = (szw >> (8 * k)) & 0xffu;
                 const int32_t i = (sb << sh) + lane * NP + k;
                 if (sm[k] >= 0 && z && ((E >> (z - 1)) & 1ull) && i >= start) {
-                    const unsigned long long key = make_key((int64_t)sm[k], (int64_t)i);
+                    const unsigned long long key = sz_key(sm[k], i, (sfw >> (8 * k)) & 31u, z);
                     bk = key > bk ? key : bk, bf |= (sfw >> (8 * k)) & 7u;
                 }
             }
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
                 for (int k = 0; k < NP; k++)
                     if (fm >> k & 1u) {
                         if (seen < np) {
-                            const unsigned long long key = make_key((int64_t)m[k], (int64_t)(i0 + k));
+                            const unsigned long long key = sz_key(m[k], i0 + k, (fw >> (8 * k)) & 31u, (zw >> (8 * k)) & 0xffu);
                             bk = key > bk ? key : bk, bf |= (fw >> (8 * k)) & 7u;
                         } else if (seen == np)
                             stop = i0 + k;
@@ -328,39 +335,51 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
                 if (!all && lane == 0) L.stop_node = smk ? lane_bcast_i32(stop, __ffsll((long long)smk) - 1) : -1;
                 offer(bk, bf, head || blk < sb);
             }
-        } else {
-            // ring positions sb + 1 .. (the stop block's, or sb + nb): position p is block p mod nb, before the start index when p >= nb
+        }
+        {
+            // ---- every wave: its span of the (chunk of 64 ring positions, eligible zone) pairs between the two cut blocks -- zone fastest; 16
+            // entries in flight per lane.  Ring positions sb + 1 .. (the stop block's, or sb + nb): position p is block p mod nb, before the
+            // start index when p >= nb; zone-major entries: a zone's blocks of a stretch are one run of memory.
             const int p_lo = sb + 1, p_hi = all ? sb + nb : (stop_kind == 1 ? sb + nb : (stop_blk > sb ? stop_blk : stop_blk + nb));
             const int nblk = p_hi - p_lo, ne = __popcll(E);
-            // a wave's lanes: (block of the iteration, eligible zone) -- 64 / ne' blocks per iteration, ne' = ne rounded up to a power of two
-            int sh_ne = 0;
-            while ((1 << sh_ne) < ne) sh_ne++;
-            const int bpw = 64 >> sh_ne, lb = lane >> sh_ne, t = lane & ((1 << sh_ne) - 1);
-            const int z = t < ne ? (int)L.elist[t] : -1;
+            const int nchunk = (nblk + 63) >> 6, total = ne * nchunk, per = (total + kSzWaves - 1) / kSzWaves;
+            int x = wave * per;
+            const int x_end = x + per < total ? x + per : total;
             unsigned long long bk0 = 0, bk1 = 0;
             uint32_t bf = 0;
-            constexpr int kU = 16; // entries in flight per lane: the loads of a round are issued before any of them is looked at
-            const int stride = (kSzWaves - 2) * bpw, zz = z >= 0 ? z : 0;
-            for (int base = (wave - 2) * bpw; base < nblk; base += kU * stride) {
-                unsigned long long kk[kU];
+            if (x < x_end) {
+                int j = x / ne; // (one division per wave and cycle)
+                unsigned long long zm = E; // the eligible zones not yet taken at chunk j
+                for (int q = x - j * ne; q > 0; q--) zm &= zm - 1;
+                constexpr int kU = 16;
+                while (x < x_end) {
+                    unsigned long long kk[kU];
+                    bool wr[kU];
 #pragma unroll
-                for (int u = 0; u < kU; u++) {
-                    const int pb = base + u * stride + lb;
-                    const bool ok = pb < nblk && z >= 0;
-                    const int p = p_lo + (ok ? pb : 0), b = p >= nb ? p - nb : p;
-                    kk[u] = a.ent_key[(int64_t)b * kSzZones + zz];
-                    kk[u] = ok ? kk[u] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < kU; u++)
-                    if (kk[u]) {
-                        const unsigned long long kq = sz_entry_key(kk[u]);
-                        if (p_lo + base + u * stride + lb >= nb) bk1 = kq > bk1 ? kq : bk1;
-                        else bk0 = kq > bk0 ? kq : bk0;
-                        bf |= sz_entry_flags(kk[u]);
+                    for (int u = 0; u < kU; u++) {
+                        const bool okx = x + u < x_end;
+                        const int z = __ffsll((long long)zm) - 1; // (wave-uniform: scalar)
+                        const int pb = j * 64 + lane;
+                        const bool ok = okx && pb < nblk;
+                        const int p = p_lo + (ok ? pb : 0), b = p >= nb ? p - nb : p;
+                        kk[u] = a.ent_key[(okx ? z : 0) * kSzMaxBlocks + b], wr[u] = p >= nb;
+                        kk[u] = ok ? kk[u] : 0ull;
+                        if (okx) {
+                            zm &= zm - 1;
+                            if (!zm) zm = E, j += 1;
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < kU; u++)
+                        if (kk[u]) {
+                            if (wr[u]) bk1 = kk[u] > bk1 ? kk[u] : bk1;
+                            else bk0 = kk[u] > bk0 ? kk[u] : bk0;
+                            bf |= (uint32_t)kk[u] & 7u;
+                        }
+                    x += kU;
+                }
             }
-            const unsigned long long k0 = wave_max_u64(bk0), k1 = wave_max_u64(bk1); // (lanes are zones here, not index order: the full key decides)
+            const unsigned long long k0 = wave_max_u64(bk0), k1 = wave_max_u64(bk1); // (lanes are blocks of several zones here, not index order: the full key decides)
             const uint32_t f = lap_wave_or3((bk0 | bk1) != 0, bf);
             if (lane == 0) {
                 if (k0) atomicMax(&L.s_key[0], k0);
@@ -400,16 +419,12 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
         }
         // ---- 5. the placement (schedule_one.go:967-984 assume -> NodeInfo.update; the clone is an existing pod of the next cycle:
         // filtering.go:255-296, interpodaffinity/filtering.go:204-272) by one thread; wave 1 re-reads the winner's block for its entry
-        const int32_t g = (int32_t)key_index(key);
+        const int32_t g = sz_key_index(key);
         const int gblk = g >> sh;
-#ifdef CCSIM_SZ_TRACE
-        if (tid == 0 && cycles < 8) printf("[sz] cyc %d start %d E %llx FE %u all %d tailF %u headF %u fullF %u stop_blk %d kind %d need %d stop_node %d k0 %llx k1 %llx flag %u -> g %d score %lld\n", cycles, start, E, FE, (int)all, tailF, headF, fullF, stop_blk, stop_kind, stop_need, stop_node, L.s_key[0], L.s_key[1], L.s_flag, g, (long long)key_score(key));
-#endif
-        const uint32_t gz = a.zone8[g]; // (>= 1: the node was feasible)
-        const uint32_t geb = a.pts.elig[g];
-        const bool counted = (geb & 1u) && ((geb >> 1) & 1u) && a.pts.self_match[0];
+        const uint32_t gz = (uint32_t)(key >> 5) & 127u; // (>= 1: the node was feasible)
+        const bool counted = (key >> 3) & 1ull;
         // a clone with required anti-affinity against itself over the node's own (unique) topology value: the node is out from now on
-        const bool blocks_itself = a.ipa.on && a.ipa.filter_on && a.ipa.anti_self_on_key[0] > 0 && a.ipa.label[0][g] != 0;
+        const bool blocks_itself = a.ipa.on && a.ipa.filter_on && a.ipa.anti_self_on_key[0] > 0 && ((key >> 4) & 1ull);
         // the zones eligible in the NEXT cycle follow from the winner's zone alone: every wave knows them now
         const int32_t zc_g = lane_bcast_i32(zc_lane, (int)gz - 1);
         zc_lane += (lane == (int)gz - 1 && counted) ? 1 : 0;
@@ -479,22 +494,21 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
                 const int32_t m = i0 + k == g ? new_word : pm[k];
                 c_old += (i0 + k == g || pm[k] >= 0) ? 1u : 0u; // (the winner was feasible before)
                 if (m >= 0) {
-                    const unsigned long long k2 = make_key((int64_t)m, (int64_t)(i0 + k));
+                    const unsigned long long k2 = sz_key(m, i0 + k, (pfw >> (8 * k)) & 31u, z);
                     bk = k2 > bk ? k2 : bk, bf |= (pfw >> (8 * k)) & 7u, c += 1;
                 }
             }
             bk = lap_wave_best(bk != 0, bk);
             bf = lap_wave_or3(true, bf), c = wave_sum_u32_dpp(c), c_old = wave_sum_u32_dpp(c_old);
-            // the winner's block in the masked counts: the rows of the zones that changed (lane = zone; the winner's zone still at its old count), then its own change
-            int32_t dfe = 0;
-            {
-                const unsigned long long diff = E_next ^ E;
-                if ((diff >> lane) & 1ull) {
-                    const int32_t cz = lane == (int)gz - 1 ? (int32_t)c_old : (int32_t)a.cntz[(int64_t)lane * kSzMaxBlocks + gblk];
-                    dfe = ((E_next >> lane) & 1ull) ? cz : -cz;
-                }
-                dfe = (int32_t)wave_sum_u32_dpp((uint32_t)dfe);
+            // the winner's block in the masked counts: counted anew from its words under E_next
+            uint32_t fe_g = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const uint32_t z = (pzw >> (8 * k)) & 0xffu;
+                const int32_t m = i0 + k == g ? new_word : pm[k];
+                fe_g += (m >= 0 && z && ((E_next >> (z - 1)) & 1ull)) ? 1u : 0u;
             }
+            fe_g = wave_sum_u32_dpp(fe_g);
             // the block the stretch ended in (every node was visited: the start block) is the next start block: its counts under E_next
             const int nblk2 = all ? sb : stop_blk;
             const int32_t j0 = (nblk2 << sh) + lane * NP;
@@ -508,11 +522,11 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
             }
             t = wave_sum_u32_dpp(t), h = wave_sum_u32_dpp(h);
             if (lane == 0) {
-                a.ent_key[(int64_t)gblk * kSzZones + (gz - 1)] = sz_entry(bk, bf);
+                a.ent_key[(int64_t)(gz - 1) * kSzMaxBlocks + gblk] = bk ? (bk & ~7ull) | (bf & 7u) : 0ull;
                 a.cntz[(int64_t)(gz - 1) * kSzMaxBlocks + gblk] = (uint8_t)c;
                 const int32_t dc = (int32_t)c - (int32_t)c_old; // 0 or -1
                 L.zF[gz - 1] += dc;
-                L.fE[gblk] = (uint16_t)((int32_t)L.fE[gblk] + dfe + (((E_next >> (gz - 1)) & 1ull) ? dc : 0));
+                L.fE[gblk] = (uint16_t)fe_g;
                 L.tailF = t, L.headF = h;
             }
         }
