@@ -580,8 +580,11 @@ class Engine:
         self._chk(self.lib.ccsim_debug_sampled(self.h, out), "ccsim_debug_sampled")
         d = {"resident": bool(out[0]), "laps_form": out[1] == 1, "zone_form": out[1] == 2, "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
              "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
-        if out[3] and any(out[8:16]):  # CCSIM_SB_PROF=1: microseconds per lap, by phase
-            names = ["cut_blocks_tree_range_queries", "decide", "wait_commit", "leaves_next_cuts", "w1_tree", "w1_range_queries", "commit_wave", "w0_next_cuts"]
+        if out[3] and any(out[8:16]):  # CCSIM_SB_PROF=1: microseconds per lap (zone form: per cycle), by phase
+            if d["zone_form"]:
+                names = ["zone_mask_start_block", "ring_prefix_stop_block", "kept_nodes_wait", "placement_entry_next_mask", "w1_stop_block", "w1_entries", "w2_idle", "w2_entries"]
+            else:
+                names = ["cut_blocks_tree_range_queries", "decide", "wait_commit", "leaves_next_cuts", "w1_tree", "w1_range_queries", "commit_wave", "w0_next_cuts"]
             d["prof_us_per_lap"] = {k: round(out[8 + i] / 100.0 / out[3], 3) for i, k in enumerate(names)}
         return d
 

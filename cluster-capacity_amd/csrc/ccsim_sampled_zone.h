@@ -336,6 +336,7 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
                 offer(bk, bf, head || blk < sb);
             }
         }
+        SZ_TICK(4); // (per wave: its cut block)
         {
             // ---- every wave: its span of the (chunk of 64 ring positions, eligible zone) pairs between the two cut blocks -- zone fastest; 16
             // entries in flight per lane.  Ring positions sb + 1 .. (the stop block's, or sb + nb): position p is block p mod nb, before the
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
                 if (k0 | k1) atomicOr(&L.s_flag, f);
             }
         }
+        SZ_TICK(5); // (per wave: its entries)
         __syncthreads(); // ---- barrier 4: the cycle's best kept node and the kept nodes' flags
         SZ_TICK(2);
         // ---- 4. the maxima over the kept nodes against the assumed ones
@@ -542,6 +544,8 @@ __global__ __launch_bounds__(kSzThreads) void k_sz_cycles(SzArgs a) {
 #undef SZ_TICK
     if (a.prof && tid == 0)
         for (int i = 0; i < 4; i++) a.prof[i] += pf[i];
+    if (a.prof && tid == 64) a.prof[4] += pf[4], a.prof[5] += pf[5];   // (wave 1: the stop block, its entries; the rest of [2] is waiting)
+    if (a.prof && tid == 128) a.prof[6] += pf[4], a.prof[7] += pf[5];  // (wave 2: no cut block, its entries)
     if (wave == 0) {
         const uint32_t mn = ~wave_max_u32(((present >> lane) & 1ull) ? ~(uint32_t)zc_lane : 0u);
         if (lane == 0) S.pts_min_a[0] = mn == 0xffffffffu ? 0x7fffffff : (int32_t)mn;
