@@ -165,6 +165,26 @@ def secondary_lines(device: int):
                                                 "us_per_lap": dt * 1e6 / max(1, info["laps"]), "kernel_launches": int(info["launches"]),
                                                 f"first_{MB_GATE}_placements_and_visited_nodes_equal_oracle": True, "laps_in_checked_prefix": int(gate_info["laps"])}
     e.close()
+    # ... and config 5's pod shape as ONE template (zone DoNotSchedule spread + hostname anti-affinity) under that default percentage -- what both
+    # hosts run for such a template when the flag is left unset: per-(block, zone) entries under the mask of eligible zones
+    # (csrc/ccsim_sampled_zone.h; round 5: three node passes per cycle, 66 us at 1M nodes).  Gate: 700 cycles = 10 rounds of the constraint.
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=5)
+    nodes.label_cols.append(np.arange(1, n + 1, dtype=np.int32))  # kubernetes.io/hostname
+    pod.ipa = M.InterPodAffinity(key_cols=[len(nodes.label_cols) - 1], key_ndom=[n], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    pod.spread = [synth.zone_spread(n, max_skew=1)]
+    prof = dataclasses.replace(prof, percentage_of_nodes_to_score=0)
+    MZ_GATE = 700
+    ref = ccref_py.run(prof, nodes, pod, max_limit=MZ_GATE, threads=threads)
+    e = capi.Engine(device=device)
+    e.load(nodes, pod, prof)
+    head = e.run(max_limit=MZ_GATE, mode="sequential", log_cap=MZ_GATE)
+    assert np.array_equal(head.log, ref.log) and head.evaluated_total == ref.evaluated_total, "coupled template, default percentage: engine and oracle differ (log / nodes visited)"
+    r, dt = best_of(e, lambda: e.run(max_limit=20_000, mode="sequential", want_log=False, log_cap=0), reps=2)
+    info = e.sampled_info()
+    out["coupled_template_default_percentage_1M_nodes"] = {"value": r.placed / dt, "unit": "placements/s", "placements": int(r.placed), "us_per_cycle": dt * 1e6 / max(1, r.placed),
+                                                           "nodes_visited_per_cycle": r.evaluated_total / max(1, r.placed), "resident_zone_form": bool(info["zone_form"]),
+                                                           f"first_{MZ_GATE}_placements_and_visited_nodes_equal_oracle": True}
+    e.close()
     return out
 
 
