@@ -57,3 +57,7 @@ CCSIM_FORCE_DIST=1 CCSIM_DIST_DEBUG=1 timeout 120 python bench.py --no-variants 
 CCSIM_FORCE_DIST=1 CCSIM_DIST_MAILBOX=0 timeout 120 python bench.py --no-variants --seq-rounds 0 --steps 3 2>/dev/null > $O/bench_dist_world1_rccl_passes.json; cut -c1-200 $O/bench_dist_world1_rccl_passes.json
 ( cat $O/lib_hash.txt; timeout 600 python -m pytest tests/test_dist_mailbox.py -m gpu -q -s 2>&1 | grep -E "^\[mailbox\]|two processes|passed|failed" ) | tee $O/mailbox_forms_taken.txt | tail -8
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tee $O/smoke.txt
+# round 6: mode B (the reference's default percentage) -- an uncoupled template a lap of the ring at a time, a template with a hard zone constraint resident
+bash tools/gpu_mode_b_prof.sh $R/mode_b > /dev/null 2>&1; cp $O/mode_b/mode_b_1M_kernel_stats.csv $O/mode_b/pmc_mode_b.txt $O/mode_b/bench_mode_b_under_rocprofv3.txt $O/ 2>/dev/null; head -3 $O/mode_b_1M_kernel_stats.csv | cut -c1-160
+SKIP_TESTS=1 bash tools/gpu_sb6.sh $R/sb > /dev/null 2>&1; cp $O/sb/bench_mode_b.txt $O/bench_mode_b_laps_vs_cycle_at_a_time.txt; cp $O/sb/bench_mode_b_prof.txt $O/mode_b_laps_phase_profile.txt; grep "CCSIM_SB=1" $O/bench_mode_b_laps_vs_cycle_at_a_time.txt | cut -c1-140
+SKIP_TESTS=1 bash tools/gpu_sz6.sh $R/sz > /dev/null 2>&1; cp $O/sz/bench_mode_b_zone.txt $O/bench_mode_b_zone.txt; cut -c1-150 $O/bench_mode_b_zone.txt
