@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(ScanArgs a) {
     ma_b = wave_max_u32(ma_b);
     __shared__ uint64_t s_key[kThreads / 64];
     __shared__ uint32_t s_mt[kThreads / 64], s_ma[kThreads / 64], s_nf[kThreads / 64];
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // (wave: uniform, and known to the compiler as such)
     if (lane == 0) {
         s_key[wave] = best;
         s_mt[wave] = mt_b;
@@ -1626,7 +1626,7 @@ __device__ __forceinline__ void fused_store(DevState *out, const DevState *in, c
 
 template <int NX, bool NARROW>
 __global__ __launch_bounds__(kThreads) void k_scan_fused(FusedArgs a) {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // (wave: uniform, and known to the compiler as such)
     __shared__ uint64_t s_key[kThreads / 64];
     __shared__ uint32_t s_mt[kThreads / 64], s_ma[kThreads / 64], s_nf[kThreads / 64];
     __shared__ int64_t s_nf64[kThreads / 64];
@@ -1796,7 +1796,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_fused(FusedArgs a) {
 __global__ __launch_bounds__(kThreads) void k_final_fused(FusedArgs a) {
     DevState *sp = a.st[a.parity];
     if (sp->done || !sp->have_prev) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // (wave: uniform, and known to the compiler as such)
     __shared__ uint64_t s_key[kThreads / 64];
     __shared__ uint32_t s_mt[kThreads / 64], s_ma[kThreads / 64];
     __shared__ int64_t s_nf64[kThreads / 64];

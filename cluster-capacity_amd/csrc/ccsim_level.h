@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void k_level_score(LevelArgs a) {
     __shared__ uint64_t s_key[kWaves];
     __shared__ uint32_t s_u[6][kWaves];
     const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // (wave: uniform, and known to the compiler as such)
     const int64_t lo = (int64_t)blockIdx.x * a.chunk;
     int64_t hi = lo + a.chunk;
     if (hi > a.c.n_pad) hi = a.c.n_pad;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kThreads) void k_level_commit(LevelArgs a) {
     __shared__ int32_t s_cnt[kGroupTiles][kWaves];
 
     const uint32_t mt = (uint32_t)st.mt_a, ma = (uint32_t)st.ma_a;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // (wave: uniform, and known to the compiler as such)
     const int64_t lo = (int64_t)blockIdx.x * a.cchunk;
     int64_t hi = lo + a.cchunk;
     if (hi > a.c.n_pad) hi = a.c.n_pad;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(kFinalThreads) void k_level_final(LevelFinalArgs a)
     __shared__ uint32_t s_u[4][kWaves];
     __shared__ int64_t s_l[8][kWaves];
     __shared__ int64_t s_x[3][kWaves];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // (wave: uniform, and known to the compiler as such)
     const bool plan_pass = a.st->lvl_plan_only != 0;
     const bool commit_ran = plan_pass || a.st->lvl_valid != 0; // else k_level_commit exited without writing partials
     const bool full_pass = a.st->lvl_full != 0;                // k_level_score ran: the next level comes from its partials

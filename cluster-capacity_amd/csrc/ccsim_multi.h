@@ -338,7 +338,7 @@ __device__ __forceinline__ void multi_scan_lean_loads(const MultiArgs &a, const 
 
 __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int next_pod, const int j0, const int jn, const int64_t base,
                                                 const unsigned long long sp_t0, const MLeanLoads &L) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: uniform, and known to the compiler as such)
     __shared__ MPod l_pod[kMLeanChunk];
     __shared__ uint32_t l_k[kMLeanChunk][3][kThreads / 64];
     __shared__ uint32_t l_u[kMLeanChunk][5][kThreads / 64];
@@ -434,7 +434,7 @@ __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int ne
 __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
     const int32_t done = a.st->done, win_n = a.st->win_n, next_pod = a.st->next_pod; // (not the whole MState: it would sit in ~60 SGPRs)
     if (done) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: uniform, and known to the compiler as such)
     const int sub = blockIdx.y % kMLeanPer; // this workgroup's share of the chunk in the lean form (kMLeanChunk)
     const int j0 = (blockIdx.y / kMLeanPer) * kMPodChunk;
     if (j0 >= win_n) return;
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     __shared__ int64_t s_pick[kMWindowMax];
     __shared__ int s_taken[kMWindowMax];
     __shared__ int s_th_mt[kMWindowMax], s_th_ma[kMWindowMax];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: uniform, and known to the compiler as such)
     unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
 #define PT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); tp[i] += t_now - t_prev; t_prev = t_now; } while (0)
     if (tid == 0) s_st = *a.st;

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
     __shared__ long long s_scan[kPWaves];
     __shared__ unsigned int s_hist[kPHistSlots];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63; // (wave: uniform, and known to the compiler as such)
     // ranks: workgroup b of a grid with virtual ranks belongs to rank b / bpr; a real rank owns its whole grid
     int my_rank = 0, lb = (int)blockIdx.x, lgrid = (int)gridDim.x;
     if (MB) {

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kSbThreads) void k_sb_cycles(SbArgs a) {
     if (S.done) return;
     // (DevState::sb_dirty: k_sb_build is enqueued in front of every launch of this kernel and has rebuilt memo and summaries if the flag
     // was set -- under the maxima this launch reads below; the flag is cleared at the end of this launch unless the maxima moved again)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: uniform, and known to the compiler as such)
     const int nb = a.n_blocks, sh = a.shift, B = 1 << sh, NP = B / kSbThreads; // NP in {1, 2, 4}
     const int64_t N = a.c.n;
     for (int b = tid; b < nb; b += kSbThreads) L.fc[b] = a.sb_fc[b], L.key[b] = a.sb_key[b], L.mx[b] = a.sb_mx[b];
