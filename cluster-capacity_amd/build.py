@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 SOURCES = ["ccsim_engine.hip"]
-DEPS = ["ccsim_kernels.h", "ccsim_level.h", "ccsim_persist.h", "ccsim_multi.h", "ccsim_coupled.h", "ccsim_sampled.h", "ccsim_sampled_zone.h", os.path.join(ROOT, "include", "ccsim.h")]
+DEPS = ["ccsim_kernels.h", "ccsim_level.h", "ccsim_persist.h", "ccsim_multi.h", "ccsim_coupled.h", "ccsim_sampled.h", "ccsim_sampled_zone.h", "ccsim_search_full.h", os.path.join(ROOT, "include", "ccsim.h")]
 # -ffp-contract=off: the fp64 score arithmetic must match Go (no FMA fusion); no fast-math anywhere.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]

@@ -575,10 +575,11 @@ class Engine:
                 "mailbox_launches": int(out[4]), "ranks": int(out[5])}
 
     def sampled_info(self):
-        """Which form the last sampled search (percentageOfNodesToScore < 100) took (ccsim_debug_sampled)."""
+        """Which resident form the last sequential run took: the sampled search (percentageOfNodesToScore < 100) a lap / a cycle at a time, its zone form, or
+        the full search on the same summaries (ccsim_debug_sampled)."""
         out = (C.c_int64 * 16)()
         self._chk(self.lib.ccsim_debug_sampled(self.h, out), "ccsim_debug_sampled")
-        d = {"resident": bool(out[0]), "laps_form": out[1] == 1, "zone_form": out[1] == 2, "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
+        d = {"resident": bool(out[0]), "laps_form": out[1] == 1, "zone_form": out[1] == 2, "full_search_form": out[1] == 3, "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
              "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
         if out[3] and any(out[8:16]):  # CCSIM_SB_PROF=1: microseconds per lap (zone form: per cycle), by phase
             if d["zone_form"]:

@@ -13,6 +13,7 @@
 #include "ccsim_coupled.h"
 #include "ccsim_sampled.h"
 #include "ccsim_sampled_zone.h"
+#include "ccsim_search_full.h"
 
 #include <dlfcn.h>
 #include <errno.h>
@@ -215,6 +216,7 @@ struct ccsim_engine {
     uint32_t *d_sz_over = nullptr;
     bool sz_run = false, sz_attr_set = false;
     std::string sz_why;                          // why the last sampled run of a coupled template did not take that form
+    bool sf_run = false;                         // this run: the FULL search (every node scored) of an uncoupled template on the same summaries (k_sf_cycles)
     bool sb_laps = false;                        // this run: a lap of the ring at a time (k_sb_laps) instead of a cycle at a time (k_sb_cycles)
     bool cw_fast = false;                        // ... and may use the lane-per-candidate decide kernel (k_cw_decide_fast)
     // narrow mirrors (DevCols::narrow): facts about the loaded snapshot, gathered on the host at load time
@@ -1385,6 +1387,26 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
             HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
         }
     }
+    // the full search (every node scored) of such a template on the same summaries: one wave, one trip to L2 per cycle (ccsim_search_full.h)
+    e->sf_run = false;
+    if (mode == CCSIM_MODE_SEQUENTIAL && e->smp_K == 0 && e->n_ranks == 0 && !e->time_passes && e->pts.n == 0 && e->soft.n == 0 && !e->ipa.on && e->global_offset == 0 &&
+        e->n_global == e->n && e->n > 0 && !(getenv("CCSIM_SF") && !atoi(getenv("CCSIM_SF")))) {
+        int sh = 8;
+        if (((e->n_pad + 255) >> 8) > kSfMaxBlocks) sh = 10;
+        if (const char *f = getenv("CCSIM_SF_SHIFT")) sh = atoi(f) == 10 ? 10 : 8; // test knob
+        const int64_t blocks = (e->n_pad + ((int64_t)1 << sh) - 1) >> sh;
+        if (blocks <= kSfMaxBlocks) {
+            if (!e->d_sb_memo) {
+                int rc2;
+                if ((rc2 = dev_alloc(e, &e->d_sb_memo, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_flag8, (size_t)e->n_pad, e->allocs, false)) || (rc2 = dev_alloc(e, &e->d_sb_fc, (size_t)kSbMaxBlocks, e->allocs)) ||
+                    (rc2 = dev_alloc(e, &e->d_sb_key, (size_t)kSbMaxBlocks, e->allocs)) || (rc2 = dev_alloc(e, &e->d_sb_mx, (size_t)kSbMaxBlocks, e->allocs)))
+                    return rc2;
+            }
+            e->sb_shift = sh, e->sb_blocks = (int)blocks, e->sf_run = true, e->sb_laps = false;
+            e->h_state->sb_dirty = 1; // nothing is known about the columns under the run's maxima yet
+            HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+        }
+    }
     // ... and of ONE template with a hard spread constraint over a shared key of <= 64 values, optionally with inter-pod terms over a key
     // that is unique per node and without inter-pod scores: per-(block, zone) entries under the mask of eligible zones (ccsim_sampled_zone.h)
     e->sz_run = false;
@@ -1951,7 +1973,7 @@ static int run_cw(ccsim_engine *e) {
 }
 
 // ---- the sampled search of one template without topology-coupled plugins on resident block summaries (ccsim_sampled.h) ----
-static int run_sb(ccsim_engine *e) {
+static int run_sb(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_cycles > 0: ccsim_schedule_one -- that many cycles, then return)
     static_assert(sizeof(SbLds) <= 160 * 1024 && sizeof(LapLds) <= 160 * 1024, "the cycle kernels' LDS images must fit one CU");
     HIPCHK(e, hipSetDevice(e->device));
     if (!e->sb_attr_set) {
@@ -1974,15 +1996,24 @@ static int run_sb(ccsim_engine *e) {
     }
     if (const char *f = getenv("CCSIM_SB_CYCLES")) a.max_cycles = atoi(f) > 0 ? atoi(f) : a.max_cycles; // tuning / test knob: cycles per launch
     if (const char *f = getenv("CCSIM_SB_SLOW_FLOOR")) a.slow_floor = atoll(f);                          // test knob: see SbArgs
+    if (one_launch_cycles > 0) a.max_cycles = one_launch_cycles;
     const bool narrow = e->cols.narrow && e->pod.nx == 0;
     int idle = 0;
     for (;;) {
         const int64_t placed0 = e->h_state->placed;
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-        for (int rep = 0; rep < 4; rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
+        for (int rep = 0; rep < (one_launch_cycles > 0 ? 1 : 4); rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
             if (narrow) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
             else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
-            if (e->sb_laps) {
+            if (e->sf_run) {
+                if (e->sb_shift == 8) {
+                    if (narrow) hipLaunchKernelGGL((k_sf_cycles<true, 4>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
+                    else hipLaunchKernelGGL((k_sf_cycles<false, 4>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
+                } else {
+                    if (narrow) hipLaunchKernelGGL((k_sf_cycles<true, 16>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
+                    else hipLaunchKernelGGL((k_sf_cycles<false, 16>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
+                }
+            } else if (e->sb_laps) {
                 if (e->sb_shift == 8) {
                     if (narrow) hipLaunchKernelGGL((k_sb_laps<true, 4>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
                     else hipLaunchKernelGGL((k_sb_laps<false, 4>), dim3(1), dim3(kLapThreads), sizeof(LapLds), e->stream, a);
@@ -2008,6 +2039,7 @@ static int run_sb(ccsim_engine *e) {
                     (long long)e->h_state->smp_start, e->h_state->sb_cycles, (long long)e->h_state->smp_K, e->sb_blocks, e->sb_shift, (int)e->sb_laps, e->h_state->sb_laps, e->h_state->sb_slow);
         e->pass_launches = e->h_state->sb_cycles; // (ccsim_report.pass_launches: launches of the cycle kernel that ran -- 0 on every other path of the sampled search)
         if (e->h_state->done) return 0;
+        if (one_launch_cycles > 0 && e->h_state->placed - placed0 >= one_launch_cycles) return 0;
         idle = e->h_state->placed == placed0 ? idle + 1 : 0;
         if (idle >= 4) return fail(e, -EIO, "sampled search made no progress in %d launches", 16);
     }
@@ -2113,7 +2145,7 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
         if (e->h_state->done) return fill_report(e, out);
         // (cw_fallback: the windowed mode cannot represent this run -- the one-pass-per-placement loop below continues it)
     }
-    if (e->sb_run) { // begin_run chose the resident form of the sampled search
+    if (e->sb_run || e->sf_run) { // begin_run chose the resident form of the sampled search / of the full search
         if ((rc = run_sb(e))) return rc;
         return fill_report(e, out);
     }
@@ -2168,12 +2200,15 @@ extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
     out->feasible_nodes = 0;
     if (e->n == 0) return 0;
     const int64_t rounds0 = e->h_state->rounds;
-    for (int tries = 0; tries < 8; tries++) {
-        launch_cycle(e);
-        HIPCHK(e, hipGetLastError());
-        if ((rc = read_state(e))) return rc;
-        if (e->h_state->rounds != rounds0 || e->h_state->done) break;
-    }
+    if (e->sf_run || e->sb_run) { // the cycle on the resident block summaries (ccsim_search_full.h, ccsim_sampled.h): one launch, one trip per call
+        if ((rc = run_sb(e, 1))) return rc;
+    } else
+        for (int tries = 0; tries < 8; tries++) {
+            launch_cycle(e);
+            HIPCHK(e, hipGetLastError());
+            if ((rc = read_state(e))) return rc;
+            if (e->h_state->rounds != rounds0 || e->h_state->done) break;
+        }
     if (e->h_state->rounds == rounds0) return fail(e, -EIO, "scheduling cycle did not converge");
     if (e->h_state->done == DONE_UNSCHEDULABLE) {
         // allow further cycles to be attempted (each returns FitError again)
@@ -3366,6 +3401,10 @@ extern "C" int ccsim_debug_sampled(ccsim_engine *e, int64_t *out8) {
     }
     if (e->h_state && e->begun && e->sz_run) { // the form for a hard spread constraint over zones (ccsim_sampled_zone.h): [1] = 2
         out8[0] = 1, out8[1] = 2, out8[2] = e->h_state->sb_cycles, out8[3] = e->h_state->sb_laps, out8[5] = e->sb_shift, out8[6] = e->sb_blocks, out8[7] = e->smp_K;
+        return 0;
+    }
+    if (e->h_state && e->begun && e->sf_run) { // the full search on the summaries (ccsim_search_full.h): [1] = 3, [3] = cycles
+        out8[0] = 1, out8[1] = 3, out8[2] = e->h_state->sb_cycles, out8[3] = e->h_state->sb_laps, out8[5] = e->sb_shift, out8[6] = e->sb_blocks;
         return 0;
     }
     if (!e->h_state || !e->begun || !e->sb_run) return 0;
