@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the multi-kernel / wide-path comparison runs")
     ap.add_argument("--limit", type=int, default=-1, help="placements per step (0 = until Unschedulable; "
                     "-1 = mode default: 0 for batched, 2048 for sequential)")
-    ap.add_argument("--seq-rounds", type=int, default=2048, help="rounds of the sequential-mode sample (0 = skip)")
+    ap.add_argument("--seq-rounds", type=int, default=20000, help="rounds of the sequential-mode sample (0 = skip)")
     ap.add_argument("--cpu-rounds", type=int, default=1600,
                     help="placement rounds of the CPU baseline sample (the oracle scans every node per round: ~9 ms per round at 1M nodes "
                          "on 16 threads, so ~15 s); its placement log must equal the engine's first --cpu-rounds placements")
@@ -369,10 +369,11 @@ def main():
     # the literal one-round-per-pass loop on the same snapshot, for comparison (untimed by the driver)
     seq = None
     if args.mode == "batched" and args.seq_rounds > 0:
-        step("sequential", args.seq_rounds)
+        nseq = args.seq_rounds if not distributed else min(args.seq_rounds, 2048)  # (on shards a cycle is an exchange between the ranks)
+        step("sequential", nseq)
         barrier()
         s0 = time.perf_counter()
-        rs = step("sequential", args.seq_rounds)
+        rs = step("sequential", nseq)
         barrier()
         seq = rs.placed / (time.perf_counter() - s0)
 
@@ -556,6 +557,13 @@ def main():
         blind = eng.run(max_limit=args.cpu_rounds, mode=args.mode, want_log=False)
         assert blind.placed == head.placed, (blind.placed, head.placed)
         out["cpu_baseline"] = cpu_baseline(nodes_full, pod, prof, args.cpu_rounds, head.log, blind.per_node_count)
+        if args.mode == "batched" and args.seq_rounds > 0:  # the sequential sample above: the same placements, cycle by cycle
+            eng.reset_state()
+            sq = eng.run(max_limit=args.cpu_rounds, mode="sequential", want_log=True, log_cap=args.cpu_rounds)
+            assert np.array_equal(sq.log, head.log), "the sequential mode's placement log differs from the oracle's"
+            out["config"]["sequential_mode_first_placements_equal_oracle"] = int(sq.placed)
+            out["config"]["sequential_mode_form"] = ("full search on resident block summaries, one wave (k_sf_cycles)" if eng.sampled_info()["full_search_form"]
+                                                     else "one pass over the nodes per cycle (k_scan_fused)")
         out["timed_path_check"] = {
             "what": "the blind path (no log) run with --max-limit inside a score level; per-node counts equal the oracle's at the same limit",
             "limit": args.cpu_rounds, "placed": int(blind.placed), "passes": int(blind.scans), "ordered_path_passes": int(head.scans)}

@@ -1985,7 +1985,7 @@ static int run_sb(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_c
         HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
         e->sb_attr_set = true;
     }
-    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_flag8, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : 1024, nullptr, 65536};
+    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_flag8, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : (e->sf_run ? (1 << 16) : 1024), nullptr, 65536};
     if (getenv("CCSIM_SB_PROF") && atoi(getenv("CCSIM_SB_PROF"))) {
         if (!e->d_sb_prof) {
             int rc2;

@@ -78,6 +78,39 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
     unsigned long long top = wave_max_u64(gk);
     int64_t budget = a.max_cycles;
     constexpr int NX = NARROW ? 0 : kMaxExtra;
+    // What the wave holds between cycles, NOT yet in memory: the node that won last (pg), its row after its clones (nd, pc) and its memo
+    // word (cur_m) -- the emptiest node of a cluster wins again and again until its score has come down to the next one's, and costs no
+    // trip while it does; its block's memo words (bm: pg's own slot is stale until pg is evicted); the best key among the block's other
+    // nodes (ob), the group's other blocks (og), the other groups (orr) -- they stand while the winner stays where it is.
+    int32_t bm[NP], pg = -1, pb = -1, na0 = 0, na1 = 0, pc = 0, cur_m = -1;
+    NodeRegs<NX> nd;
+    nd_zero(nd);
+    unsigned long long ob = 0, og = 0, orr = 0, cur_key = 0, rest = top;
+#pragma unroll
+    for (int k = 0; k < NP; k++) bm[k] = -1;
+    auto evict = [&]() { // the held node's row and memo word to memory, its slot of the block's words
+        if (pg < 0) return;
+        if (lane == 0) {
+            a.c.req[0][pg] = nd.r_cpu, a.c.req[1][pg] = nd.r_mem, a.c.nz_mcpu[pg] = nd.z_cpu, a.c.nz_mem[pg] = nd.z_mem, a.c.pod_count[pg] = nd.npods;
+            a.c.placed_cnt[pg] = pc;
+            store_mirror(a.c, (int64_t)pg, nd.r_cpu, nd.r_mem, nd.z_cpu, nd.z_mem);
+            if (NX > 0) {
+#pragma unroll
+                for (int x = 0; x < NX; x++)
+                    if (x < a.p.nx) a.c.req[a.p.xcol[x]][pg] = nd.xr[x];
+            }
+            __hip_atomic_store((uint32_t *)(a.memo + pg), (uint32_t)cur_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; k++) bm[k] = (pb << sh) + k * 64 + lane == pg ? cur_m : bm[k];
+    };
+    auto close_block = [&]() { // the held block's key to LDS and memory, its group's key
+        if (pb < 0) return;
+        const unsigned long long leaf = cur_key > ob ? cur_key : ob, gnew = leaf > og ? leaf : og;
+        if (lane == 0) L.key[pb] = leaf, a.sb_key[pb] = leaf;
+        gk = lane == (pb >> 6) ? gnew : gk;
+        lap_wave_sync();
+    };
 
     for (;;) {
         if (limit > 0 && placed >= limit) { // simulator.go:297-312
@@ -93,81 +126,91 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
             dirty = 1, scans += 1;
             break;
         }
-        const int32_t g = (int32_t)key_index(top), b = g >> sh, grp = b >> 6;
-        // ---- the one trip: the winner's block of memo words (L1-bypassing: the launch has written some of them) and its row -- the same
-        // address in every lane, so one request; every lane then holds the row and computes the same new score
-        int32_t bm[NP];
+        const int32_t g = (int32_t)key_index(top);
+        if (g != pg) {
+            // ---- another node: the held one goes to memory; ONE trip for the winner's row (the same address in every lane, so one request:
+            // every lane then holds the row and computes the same scores) and, if it lies in another block, that block's memo words
+            // (L1-bypassing: the launch has written some of them)
+            const int32_t b = g >> sh, grp = b >> 6;
+            const bool other_block = b != pb;
+            if (other_block) close_block();
+            evict();
+            if (other_block) {
 #pragma unroll
-        for (int k = 0; k < NP; k++) {
-            const int64_t i = ((int64_t)b << sh) + k * 64 + lane;
-            bm[k] = (NP == 4 || i < n_pad) ? ld_memo(a.memo + i) : -1; // (n_pad is a multiple of 512: blocks of 256 nodes never reach beyond it)
+                for (int k = 0; k < NP; k++) {
+                    const int64_t i = ((int64_t)b << sh) + k * 64 + lane;
+                    bm[k] = (NP == 4 || i < n_pad) ? ld_memo(a.memo + i) : -1; // (n_pad is a multiple of 512: blocks of 256 nodes never reach beyond it)
+                }
+            }
+            if (NARROW) na0 = a.c.a32[0][g], na1 = a.c.a32[1][g];
+            load_one<NX>(a.c, a.p, (int64_t)g, nd);
+            pc = a.c.placed_cnt[g];
+            if (other_block) { // in the trip's shadow: the best key of the group's other blocks, of the other groups
+                const unsigned long long lv = L.key[grp * 64 + lane];
+                og = wave_max_u64(lane == (b & 63) ? 0ull : lv), orr = wave_max_u64(lane == grp ? 0ull : gk);
+            }
+            unsigned long long best = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const int32_t i = (b << sh) + k * 64 + lane;
+                const unsigned long long kk = (bm[k] >= 0 && i != g) ? make_key((int64_t)bm[k], (int64_t)i) : 0ull;
+                best = kk > best ? kk : best;
+            }
+            ob = wave_max_u64(best);
+            rest = ob > og ? ob : og;
+            rest = orr > rest ? orr : rest;
+            pg = g, pb = b;
         }
-        NodeRegs<NX> nd;
-        int32_t na0 = 0, na1 = 0;
-        if (NARROW) na0 = a.c.a32[0][g], na1 = a.c.a32[1][g];
-        load_one<NX>(a.c, a.p, (int64_t)g, nd);
-        const int32_t pc = a.c.placed_cnt[g];
-        // ---- in its shadow: the best key of the group's other blocks, of the other groups
-        const unsigned long long lv = L.key[grp * 64 + lane];
-        const unsigned long long og = wave_max_u64(lane == (b & 63) ? 0ull : lv), orr = wave_max_u64(lane == grp ? 0ull : gk);
-        // ---- NodeInfo.update (S/framework/types.go:409-428), the node's score afterwards
-        node_apply<NX>(a.p, nd, 1);
-        int32_t nm = -1;
+        // ---- NodeInfo.update (S/framework/types.go:409-428) and the node's score afterwards -- for the next 64 clones at once: lane j
+        // holds the node after j + 1 more clones.  The node wins the next cycle too while its key stays above everything else's (`rest`
+        // does not move meanwhile: nothing but this node changes), so the first lane whose key falls below it ends the streak: its state
+        // is the one the node is left in.  (Every state is evaluated with the same exact functions a cycle at a time would use.)
+        int64_t cap = budget;
+        if (limit > 0 && limit - placed < cap) cap = limit - placed;
+        NodeRegs<NX> nj = nd;
+        node_apply<NX>(a.p, nj, (int64_t)lane + 1);
+        int32_t mj = -1;
         if (NARROW) {
-            const int32_t nr0 = (int32_t)nd.r_cpu, nr1 = (int32_t)(nd.r_mem >> a.c.mem_shift), nz0 = (int32_t)nd.z_cpu, nz1 = (int32_t)(nd.z_mem >> a.c.mem_shift);
-            if ((nd.w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, nd.a_pods, nd.npods)) {
-                const uint32_t cnt = (nd.w >> kStatCntShift) & kStatCntMask, aff = nd.w & kStatAffMask, img = (nd.w >> kStatImgShift) & kStatImgMask;
-                nm = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) + dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1));
+            const int32_t nr0 = (int32_t)nj.r_cpu, nr1 = (int32_t)(nj.r_mem >> a.c.mem_shift), nz0 = (int32_t)nj.z_cpu, nz1 = (int32_t)(nj.z_mem >> a.c.mem_shift);
+            if ((nj.w >> kStatOkBit) && fits_narrow(a.p, npod, na0, na1, nr0, nr1, nj.a_pods, nj.npods)) {
+                const uint32_t cnt = (nj.w >> kStatCntShift) & kStatCntMask, aff = nj.w & kStatAffMask, img = (nj.w >> kStatImgShift) & kStatImgMask;
+                mj = (int32_t)(static_score(a.p, cnt, aff, img, mt_a, ma_a) + dynamic_score_narrow(a.p, npod, na0, na1, nr0, nr1, nz0, nz1));
             }
         } else if constexpr (!NARROW)
-            nm = sb_node_score(a.p, nd, mt_a, ma_a);
-        if (lane == 0) {
-            a.c.req[0][g] = nd.r_cpu, a.c.req[1][g] = nd.r_mem, a.c.nz_mcpu[g] = nd.z_cpu, a.c.nz_mem[g] = nd.z_mem, a.c.pod_count[g] = nd.npods;
-            a.c.placed_cnt[g] = pc + 1;
-            store_mirror(a.c, (int64_t)g, nd.r_cpu, nd.r_mem, nd.z_cpu, nd.z_mem);
-            if (NX > 0) {
-#pragma unroll
-                for (int x = 0; x < NX; x++)
-                    if (x < a.p.nx) a.c.req[a.p.xcol[x]][g] = nd.xr[x];
-            }
-            __hip_atomic_store((uint32_t *)(a.memo + g), (uint32_t)nm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.log && placed < log_cap) a.log[placed] = g;
-        }
-        // ---- the block's new key, the group's, the next winner
-        unsigned long long best = 0;
-#pragma unroll
-        for (int k = 0; k < NP; k++) {
-            const int32_t i = (b << sh) + k * 64 + lane;
-            bm[k] = i == g ? nm : bm[k];
-            const unsigned long long kk = bm[k] >= 0 ? make_key((int64_t)bm[k], (int64_t)i) : 0ull;
-            best = kk > best ? kk : best;
-        }
-        const unsigned long long leaf = wave_max_u64(best), gnew = leaf > og ? leaf : og;
-        if (lane == 0) L.key[b] = leaf, a.sb_key[b] = leaf;
-        gk = lane == grp ? gnew : gk;
-        top = gnew > orr ? gnew : orr;
+            mj = sb_node_score(a.p, nj, mt_a, ma_a);
+        const unsigned long long kj = mj >= 0 ? make_key((int64_t)mj, (int64_t)g) : 0ull;
+        const unsigned long long fail = __ballot(!(kj > rest));
+        int32_t r = fail ? __ffsll((long long)fail) : 64; // clones placed: up to and including the first state that loses
+        r = (int64_t)r > cap ? (int32_t)cap : r;
+        const int32_t nm = lane_bcast_i32(mj, r - 1);
+        node_apply<NX>(a.p, nd, (int64_t)r);
+        pc += r;
+        cur_m = nm, cur_key = nm >= 0 ? make_key((int64_t)nm, (int64_t)g) : 0ull;
+        if (lane < r && a.log && placed + lane < log_cap) a.log[placed + lane] = g;
         last_feasible = (int32_t)Ftotal;
         if (nm < 0) { // the node left the feasible ones: counts, and the maxima it may have held
             Ftotal -= 1;
             uint32_t x = 0, y = 0;
 #pragma unroll
             for (int k = 0; k < NP; k++) {
-                const int64_t i = ((int64_t)b << sh) + k * 64 + lane;
-                if (bm[k] >= 0) {
+                const int64_t i = ((int64_t)pb << sh) + k * 64 + lane;
+                if (bm[k] >= 0 && i != g) {
                     const uint32_t w = a.c.stat[i], cnt = (w >> kStatCntShift) & kStatCntMask, aff = w & kStatAffMask;
                     x = cnt > x ? cnt : x, y = aff > y ? aff : y;
                 }
             }
             const uint32_t lm = (wave_max_u32(x) << 16) | wave_max_u32(y);
-            if (lane == 0) L.mx[b] = lm, a.sb_mx[b] = lm, atomicSub(&a.sb_fc[b], 1u);
+            if (lane == 0) L.mx[pb] = lm, a.sb_mx[pb] = lm, atomicSub(&a.sb_fc[pb], 1u);
             lap_wave_sync();
-            const uint32_t gmn = sf_wave_pkmax(L.mx[grp * 64 + lane]);
-            gm = lane == grp ? gmn : gm;
+            const uint32_t gmn = sf_wave_pkmax(L.mx[(pb >> 6) * 64 + lane]);
+            gm = lane == (pb >> 6) ? gmn : gm;
             root_mx = sf_wave_pkmax(gm);
         }
-        lap_wave_sync(); // (the next cycle reads L.key)
-        placed += 1, rounds += 1, scans += 1, evaluated += N, last_evaluated = N, winner = g, budget -= 1, cycles += 1;
+        top = cur_key > rest ? cur_key : rest;
+        placed += r, rounds += r, scans += r, evaluated += (int64_t)r * N, last_evaluated = N, winner = g, budget -= r, cycles += r;
     }
+    close_block();
+    evict();
     if (dirty) { // the maxima the rebuild runs under: those of the feasible nodes
         if (lane == 0) S.mt_a = (int32_t)(root_mx >> 16), S.ma_a = (int32_t)(root_mx & 0xffffu);
     }

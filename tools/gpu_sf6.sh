@@ -6,7 +6,7 @@ O=/root/repo/gpurun_out/${1:-r06/sf}
 mkdir -p $O
 cd /root/repo
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_full_search.py -m gpu -q -x --timeout 600 2>&1 | grep -v amdgpu.ids | tail -15 | tee $O/tests.txt
+  timeout 900 python -m pytest ${SF_TESTS:-tests/test_gpu_parity.py tests/test_full_search.py} -m gpu -q -x --timeout 600 2>&1 | grep -v amdgpu.ids | tail -15 | tee $O/tests.txt
 fi
 for sf in 1 0; do
   CCSIM_SF=$sf MB_PCT=100 MB_GATE=${MB_GATE:-1200} MB_LIMIT=${MB_LIMIT:-30000} timeout 600 python tools/bench_mode_b.py 1000000 100000 2>&1 | grep -v amdgpu.ids | sed "s/^CCSIM_SB=1/CCSIM_SF=$sf/" | tee -a $O/bench_full_search.txt | cut -c1-400
