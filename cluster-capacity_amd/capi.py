@@ -582,6 +582,11 @@ class Engine:
         d = {"resident": bool(out[0]), "laps_form": out[1] == 1, "zone_form": out[1] == 2, "full_search_form": out[1] == 3, "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
              "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
         if out[3] and any(out[8:16]):  # CCSIM_SB_PROF=1: microseconds per lap (zone form: per cycle), by phase
+            if d["full_search_form"]:  # per node change: ticks of four phases; counts
+                ch = max(1, int(out[12]))
+                d["prof"] = {"node_changes": int(out[12]), "block_changes": int(out[13]), "evaluations": int(out[15]),
+                             "us_per_node_change": {k: round(out[8 + i] / 100.0 / ch, 3) for i, k in enumerate(["trip_issue_and_shadow_reductions", "wait_block_reduction", "stores", "streak_evaluations"])}}
+                return d
             if d["zone_form"]:
                 names = ["zone_mask_start_block", "ring_prefix_stop_block", "kept_nodes_wait", "placement_entry_next_mask", "w1_stop_block", "w1_entries", "w2_idle", "w2_entries"]
             else:

@@ -2003,8 +2003,12 @@ static int run_sb(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_c
         const int64_t placed0 = e->h_state->placed;
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         for (int rep = 0; rep < (one_launch_cycles > 0 ? 1 : 4); rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
-            if (narrow) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
-            else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            // (the build returns at once unless DevState::sb_dirty: the first launch of a poll is left out when the host's copy of the state,
+            // current since the last poll, says so -- at the SchedulePod seam that is one dispatch less per call)
+            if (rep > 0 || e->h_state->sb_dirty) {
+                if (narrow) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+                else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            }
             if (e->sf_run) {
                 if (e->sb_shift == 8) {
                     if (narrow) hipLaunchKernelGGL((k_sf_cycles<true, 4>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
@@ -3394,7 +3398,7 @@ extern "C" int ccsim_debug_dist(ccsim_engine *e, int64_t *out8) {
 extern "C" int ccsim_debug_sampled(ccsim_engine *e, int64_t *out8) {
     if (!e || !out8) return -EINVAL;
     for (int i = 0; i < 16; i++) out8[i] = 0;
-    if (e->d_sb_prof && (e->sb_run || e->sz_run)) {
+    if (e->d_sb_prof && (e->sb_run || e->sz_run || e->sf_run)) {
         HIPCHK(e, hipSetDevice(e->device));
         HIPCHK(e, hipStreamSynchronize(e->stream));
         HIPCHK(e, hipMemcpy(out8 + 8, e->d_sb_prof, sizeof(int64_t) * 8, hipMemcpyDeviceToHost));

@@ -88,29 +88,30 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
     unsigned long long ob = 0, og = 0, orr = 0, cur_key = 0, rest = top;
 #pragma unroll
     for (int k = 0; k < NP; k++) bm[k] = -1;
-    auto evict = [&]() { // the held node's row and memo word to memory, its slot of the block's words
-        if (pg < 0) return;
-        if (lane == 0) {
-            a.c.req[0][pg] = nd.r_cpu, a.c.req[1][pg] = nd.r_mem, a.c.nz_mcpu[pg] = nd.z_cpu, a.c.nz_mem[pg] = nd.z_mem, a.c.pod_count[pg] = nd.npods;
-            a.c.placed_cnt[pg] = pc;
-            store_mirror(a.c, (int64_t)pg, nd.r_cpu, nd.r_mem, nd.z_cpu, nd.z_mem);
-            if (NX > 0) {
+    auto store_row = [&](int32_t gx, const NodeRegs<NX> &n, int32_t cnt, int32_t m) { // a node that was held: its row and memo word to memory
+        if (gx < 0 || lane != 0) return;
+        a.c.req[0][gx] = n.r_cpu, a.c.req[1][gx] = n.r_mem, a.c.nz_mcpu[gx] = n.z_cpu, a.c.nz_mem[gx] = n.z_mem, a.c.pod_count[gx] = n.npods;
+        a.c.placed_cnt[gx] = cnt;
+        store_mirror(a.c, (int64_t)gx, n.r_cpu, n.r_mem, n.z_cpu, n.z_mem);
+        if (NX > 0) {
 #pragma unroll
-                for (int x = 0; x < NX; x++)
-                    if (x < a.p.nx) a.c.req[a.p.xcol[x]][pg] = nd.xr[x];
-            }
-            __hip_atomic_store((uint32_t *)(a.memo + pg), (uint32_t)cur_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int x = 0; x < NX; x++)
+                if (x < a.p.nx) a.c.req[a.p.xcol[x]][gx] = n.xr[x];
         }
-#pragma unroll
-        for (int k = 0; k < NP; k++) bm[k] = (pb << sh) + k * 64 + lane == pg ? cur_m : bm[k];
+        __hip_atomic_store((uint32_t *)(a.memo + gx), (uint32_t)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    auto close_block = [&]() { // the held block's key to LDS and memory, its group's key
+    int32_t ck_b = -1;
+    unsigned long long ck_leaf = 0;
+    auto close_block = [&]() { // the held block's key to LDS (to memory: with the row's stores), its group's key
         if (pb < 0) return;
         const unsigned long long leaf = cur_key > ob ? cur_key : ob, gnew = leaf > og ? leaf : og;
-        if (lane == 0) L.key[pb] = leaf, a.sb_key[pb] = leaf;
+        if (lane == 0) L.key[pb] = leaf;
+        ck_b = pb, ck_leaf = leaf;
         gk = lane == (pb >> 6) ? gnew : gk;
         lap_wave_sync();
     };
+    unsigned long long t_prev = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull, pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SF_TICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     for (;;) {
         if (limit > 0 && placed >= limit) { // simulator.go:297-312
@@ -134,7 +135,10 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
             const int32_t b = g >> sh, grp = b >> 6;
             const bool other_block = b != pb;
             if (other_block) close_block();
-            evict();
+#pragma unroll
+            for (int k = 0; k < NP; k++) bm[k] = (pb << sh) + k * 64 + lane == pg ? cur_m : bm[k]; // the held node's slot of its block's words
+            const NodeRegs<NX> od = nd; // ... and its row aside: stored BEHIND the trip below (see there)
+            const int32_t opg = pg, opc = pc, cur_m_prev = cur_m;
             if (other_block) {
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
                 const unsigned long long lv = L.key[grp * 64 + lane];
                 og = wave_max_u64(lane == (b & 63) ? 0ull : lv), orr = wave_max_u64(lane == grp ? 0ull : gk);
             }
+            SF_TICK(0);
             unsigned long long best = 0;
 #pragma unroll
             for (int k = 0; k < NP; k++) {
@@ -159,7 +164,17 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
             ob = wave_max_u64(best);
             rest = ob > og ? ob : og;
             rest = orr > rest ? orr : rest;
+            pf[4] += 1, pf[5] += other_block ? 1 : 0;
             pg = g, pb = b;
+            SF_TICK(1);
+            // ---- the node that was held and its block's key go to memory now: memory operations retire in the order they were issued, so
+            // stores in front of the loads above would have put their acknowledgements into the one trip the cycle waits for; behind them
+            // nobody waits for these (the next loads follow a streak's evaluation later)
+            __builtin_amdgcn_sched_barrier(0);
+            store_row(opg, od, opc, cur_m_prev);
+            if (ck_b >= 0 && lane == 0) a.sb_key[ck_b] = ck_leaf;
+            ck_b = -1;
+            SF_TICK(2);
         }
         // ---- NodeInfo.update (S/framework/types.go:409-428) and the node's score afterwards -- for the next 64 clones at once: lane j
         // holds the node after j + 1 more clones.  The node wins the next cycle too while its key stays above everything else's (`rest`
@@ -187,6 +202,8 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
         pc += r;
         cur_m = nm, cur_key = nm >= 0 ? make_key((int64_t)nm, (int64_t)g) : 0ull;
         if (lane < r && a.log && placed + lane < log_cap) a.log[placed + lane] = g;
+        SF_TICK(3);
+        pf[7] += 1;
         last_feasible = (int32_t)Ftotal;
         if (nm < 0) { // the node left the feasible ones: counts, and the maxima it may have held
             Ftotal -= 1;
@@ -210,7 +227,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
         placed += r, rounds += r, scans += r, evaluated += (int64_t)r * N, last_evaluated = N, winner = g, budget -= r, cycles += r;
     }
     close_block();
-    evict();
+    store_row(pg, nd, pc, cur_m);
+    if (ck_b >= 0 && lane == 0) a.sb_key[ck_b] = ck_leaf;
+#undef SF_TICK
+    if (a.prof && lane == 0)
+        for (int i = 0; i < 8; i++) a.prof[i] += pf[i];
     if (dirty) { // the maxima the rebuild runs under: those of the feasible nodes
         if (lane == 0) S.mt_a = (int32_t)(root_mx >> 16), S.ma_a = (int32_t)(root_mx & 0xffffu);
     }
