@@ -216,6 +216,7 @@ struct ccsim_engine {
     uint32_t *d_sz_over = nullptr;
     bool sz_run = false, sz_attr_set = false;
     std::string sz_why;                          // why the last sampled run of a coupled template did not take that form
+    bool sz_built = false;                       // this run's first k_sz_build has been looked at (a (block, zone) count beyond a byte: the three-pass cycle instead)
     bool sf_run = false;                         // this run: the FULL search (every node scored) of an uncoupled template on the same summaries (k_sf_cycles)
     bool sb_laps = false;                        // this run: a lap of the ring at a time (k_sb_laps) instead of a cycle at a time (k_sb_cycles)
     bool cw_fast = false;                        // ... and may use the lane-per-candidate decide kernel (k_cw_decide_fast)
@@ -1446,7 +1447,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
             HIPCHK(e, hipMemsetAsync(e->d_sz_present, 0, sizeof(unsigned long long), e->stream)); // (a new pod spec may count other nodes)
             HIPCHK(e, hipMemsetAsync(e->d_sz_over, 0, sizeof(uint32_t), e->stream));
             HIPCHK(e, hipMemsetAsync(e->d_sz_cntz, 0, (size_t)kSzMaxBlocks * kSzZones, e->stream));
-            e->sb_shift = sh, e->sb_blocks = (int)blocks, e->sz_run = true, e->sb_run = false, e->sb_laps = false;
+            e->sb_shift = sh, e->sb_blocks = (int)blocks, e->sz_run = true, e->sz_built = false, e->sb_run = false, e->sb_laps = false;
             e->h_state->sb_dirty = 1; // nothing is known about the columns under the run's maxima yet
             HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
         }
@@ -2051,12 +2052,13 @@ static int run_sb(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_c
 
 // ---- the sampled search of one template with a hard spread constraint over zones (ccsim_sampled_zone.h) ----
 // returns 1 when the form does not fit after all (a (block, zone) count beyond a byte): the caller takes the three-pass cycle from the untouched state
-static int run_sz(ccsim_engine *e) {
+static int run_sz(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_cycles > 0: ccsim_schedule_one -- that many cycles, then return)
     static_assert(sizeof(SzLds) <= 64 * 1024, "k_sz_cycles' LDS image");
     HIPCHK(e, hipSetDevice(e->device));
     SzArgs a{e->cols, e->pod, e->d_state, e->pts, e->ipa, e->d_sb_memo, e->d_sz_zone8, e->d_sb_flag8, e->d_sz_ent_key, e->d_sz_cntz, e->d_sz_over, e->d_log,
              e->sb_shift, e->sb_blocks, 1 << 16, (int32_t)e->pts_table_len[0] - 1, e->d_sz_present, nullptr};
     if (const char *f = getenv("CCSIM_SB_CYCLES")) a.max_cycles = atoi(f) > 0 ? atoi(f) : a.max_cycles; // tuning / test knob: cycles per launch
+    if (one_launch_cycles > 0) a.max_cycles = one_launch_cycles;
     if (getenv("CCSIM_SB_PROF") && atoi(getenv("CCSIM_SB_PROF"))) {
         if (!e->d_sb_prof) {
             int rc2;
@@ -2067,13 +2069,15 @@ static int run_sz(ccsim_engine *e) {
     }
     const bool narrow = e->cols.narrow && e->pod.nx == 0;
     int idle = 0;
-    bool first = true;
+    bool first = !e->sz_built; // (the build's verdict is looked at once per run: later polls of the SchedulePod seam go straight to the cycles)
     for (;;) {
         const int64_t placed0 = e->h_state->placed;
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-        for (int rep = 0; rep < (first ? 1 : 4); rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
-            if (narrow) hipLaunchKernelGGL((k_sz_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
-            else hipLaunchKernelGGL((k_sz_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+        for (int rep = 0; rep < (first || one_launch_cycles > 0 ? 1 : 4); rep++) { // (a launch ends early when the kept nodes' maxima moved: the build behind it runs then, else returns at once)
+            if (first || rep > 0 || e->h_state->sb_dirty) {
+                if (narrow) hipLaunchKernelGGL((k_sz_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+                else hipLaunchKernelGGL((k_sz_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
+            }
             if (first) break; // (look at the build's verdict before the first cycle)
             if (e->sb_shift == 8) {
                 if (narrow) hipLaunchKernelGGL((k_sz_cycles<true, 4>), dim3(1), dim3(kSzThreads), sizeof(SzLds), e->stream, a);
@@ -2093,7 +2097,7 @@ static int run_sz(ccsim_engine *e) {
                 return 1;
             }
             // (the build has run under the state's maxima and left sb_dirty set: the first launch of the cycle kernel behind the next build clears it)
-            first = false;
+            first = false, e->sz_built = true;
             continue;
         }
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -2108,6 +2112,7 @@ static int run_sz(ccsim_engine *e) {
                     (long long)e->h_state->smp_start, e->h_state->sb_cycles, (long long)e->h_state->smp_K, e->sb_blocks, e->sb_shift, e->h_state->sb_laps);
         e->pass_launches = e->h_state->sb_cycles;
         if (e->h_state->done) return 0;
+        if (one_launch_cycles > 0 && e->h_state->placed - placed0 >= one_launch_cycles) return 0;
         idle = e->h_state->placed == placed0 ? idle + 1 : 0;
         if (idle >= 4) return fail(e, -EIO, "sampled search made no progress in %d launches", 16);
     }
@@ -2204,9 +2209,19 @@ extern "C" int ccsim_schedule_one(ccsim_engine *e, ccsim_cycle *out) {
     out->feasible_nodes = 0;
     if (e->n == 0) return 0;
     const int64_t rounds0 = e->h_state->rounds;
-    if (e->sf_run || e->sb_run) { // the cycle on the resident block summaries (ccsim_search_full.h, ccsim_sampled.h): one launch, one trip per call
+    bool resident = e->sf_run || e->sb_run;
+    if (resident) { // the cycle on the resident block summaries (ccsim_search_full.h, ccsim_sampled.h): one launch, one trip per call
         if ((rc = run_sb(e, 1))) return rc;
-    } else
+    } else if (e->sz_run) { // ... on the per-(block, zone) entries of a template with a hard zone constraint (ccsim_sampled_zone.h)
+        if ((rc = run_sz(e, 1)) < 0) return rc;
+        resident = rc == 0;
+        if (rc == 1) { // (it does not fit after all; nothing was placed: the three-pass cycle from here on)
+            e->sz_run = false;
+            e->h_state->sb_dirty = 0;
+            HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+        }
+    }
+    if (!resident)
         for (int tries = 0; tries < 8; tries++) {
             launch_cycle(e);
             HIPCHK(e, hipGetLastError());

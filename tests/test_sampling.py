@@ -336,3 +336,29 @@ def test_profile_without_score_plugins_keeps_the_first_feasible_node(ccref, cfg,
     for i in range(min(200, ref.placed)):
         assert e.schedule_one()[0] == ref.log[i]
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,zones,pct,cycles,anti", [(20_000, 16, 5, 500, True), (3000, 5, 10, 0, False)])
+def test_schedule_one_takes_the_zone_form(ccref, n, zones, pct, cycles, anti):
+    """The SchedulePod seam (scheduler.go:88-91) for a template with a hard zone constraint under the default percentage: one launch on the
+    per-(block, zone) entries per call, to the FitError and past it."""
+    nodes, pod, prof = _zone_template(n, zones, anti=anti, seed=9)
+    prof = _with_pct(prof, pct)
+    ref = ccref.run(prof, nodes, pod, max_limit=cycles, threads=16)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    ev = 0
+    for r in range(ref.placed):
+        node, evaluated, feasible = e.schedule_one()
+        assert node == ref.log[r], r
+        ev += evaluated
+    info = e.sampled_info()
+    assert info["zone_form"] and info["launches"] >= ref.placed, info
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        for _ in range(3):
+            node, evaluated, feasible = e.schedule_one()
+            assert node == -1 and feasible == 0
+            ev += evaluated if _ == 0 else 0
+    assert ev == ref.evaluated_total
+    e.close()
