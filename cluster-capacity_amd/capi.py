@@ -579,7 +579,7 @@ class Engine:
         the full search on the same summaries (ccsim_debug_sampled)."""
         out = (C.c_int64 * 16)()
         self._chk(self.lib.ccsim_debug_sampled(self.h, out), "ccsim_debug_sampled")
-        d = {"resident": bool(out[0]), "laps_form": out[1] == 1, "zone_form": out[1] == 2, "full_search_form": out[1] == 3, "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
+        d = {"resident": bool(out[0]), "laps_form": out[1] in (1, 4), "handed_over_to_full_search": out[1] == 4, "zone_form": out[1] == 2, "full_search_form": out[1] == 3, "launches": int(out[2]), "laps": int(out[3]), "slow_stretches": int(out[4]),
              "block": 1 << int(out[5]), "blocks": int(out[6]), "K": int(out[7])}
         if out[3] and any(out[8:16]):  # CCSIM_SB_PROF=1: microseconds per lap (zone form: per cycle), by phase
             if d["full_search_form"]:  # per node change: ticks of four phases; counts

@@ -217,6 +217,7 @@ struct ccsim_engine {
     bool sz_run = false, sz_attr_set = false;
     std::string sz_why;                          // why the last sampled run of a coupled template did not take that form
     bool sz_built = false;                       // this run's first k_sz_build has been looked at (a (block, zone) count beyond a byte: the three-pass cycle instead)
+    bool sf_handover = false;                    // this run: k_sb_laps has handed over to k_sf_cycles (every node is visited from here on: DevState::smp_phase == 2)
     bool sf_run = false;                         // this run: the FULL search (every node scored) of an uncoupled template on the same summaries (k_sf_cycles)
     bool sb_laps = false;                        // this run: a lap of the ring at a time (k_sb_laps) instead of a cycle at a time (k_sb_cycles)
     bool cw_fast = false;                        // ... and may use the lane-per-candidate decide kernel (k_cw_decide_fast)
@@ -1360,7 +1361,7 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     // topology-coupled plugins of one template: windows of placements per pass when every node is scored (ccsim_coupled.h)
     e->cw_run = mode == CCSIM_MODE_SEQUENTIAL && e->cw_ok && e->n_ranks == 0 && e->smp_K == 0 && !e->time_passes && e->n > 0;
     // the sampled search of a template without topology-coupled plugins: cycles on resident block summaries (ccsim_sampled.h)
-    e->sb_run = false;
+    e->sb_run = false, e->sf_handover = false;
     if (mode == CCSIM_MODE_SEQUENTIAL && e->smp_K > 0 && e->n_ranks == 0 && !e->time_passes && e->sb_allowed && e->pts.n == 0 && e->soft.n == 0 && !e->ipa.on &&
         e->global_offset == 0 && e->n_global == e->n) {
         // a lap of the ring at a time wants blocks of <= K nodes (one stretch boundary per block at most) that one wave reads -- 256 nodes,
@@ -1986,7 +1987,8 @@ static int run_sb(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_c
         HIPCHK(e, hipFuncSetAttribute((const void *)k_sb_laps<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LapLds)));
         e->sb_attr_set = true;
     }
-    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_flag8, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : (e->sf_run ? (1 << 16) : 1024), nullptr, 65536};
+    SbArgs a{e->cols, e->pod, e->d_state, e->d_sb_memo, e->d_sb_flag8, e->d_sb_fc, e->d_sb_key, e->d_sb_mx, e->d_log, e->sb_shift, e->sb_blocks, e->sb_laps ? (1 << 18) : (e->sf_run ? (1 << 16) : 1024), nullptr, 65536, 0};
+    a.handover = e->sb_laps && !(getenv("CCSIM_SB_HANDOVER") && !atoi(getenv("CCSIM_SB_HANDOVER"))) ? 1 : 0; // (A/B and test knob)
     if (getenv("CCSIM_SB_PROF") && atoi(getenv("CCSIM_SB_PROF"))) {
         if (!e->d_sb_prof) {
             int rc2;
@@ -2010,10 +2012,13 @@ static int run_sb(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_c
                 if (narrow) hipLaunchKernelGGL((k_sb_build<true>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
                 else hipLaunchKernelGGL((k_sb_build<false>), dim3((unsigned)e->sb_blocks), dim3(256), 0, e->stream, a);
             }
-            if (e->sf_run) {
+            if (e->sf_run || e->sf_handover) {
                 if (e->sb_shift == 8) {
                     if (narrow) hipLaunchKernelGGL((k_sf_cycles<true, 4>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
                     else hipLaunchKernelGGL((k_sf_cycles<false, 4>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
+                } else if (e->sb_shift == 6) { // (small snapshots under the sampled search: blocks of 64)
+                    if (narrow) hipLaunchKernelGGL((k_sf_cycles<true, 1>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
+                    else hipLaunchKernelGGL((k_sf_cycles<false, 1>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
                 } else {
                     if (narrow) hipLaunchKernelGGL((k_sf_cycles<true, 16>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
                     else hipLaunchKernelGGL((k_sf_cycles<false, 16>), dim3(1), dim3(kSfThreads), 0, e->stream, a);
@@ -2043,6 +2048,7 @@ static int run_sb(ccsim_engine *e, int one_launch_cycles = 0) { // (one_launch_c
                     (long long)e->h_state->rounds, (long long)e->h_state->scans, e->h_state->done, e->h_state->sb_dirty, e->h_state->mt_a, e->h_state->ma_a,
                     (long long)e->h_state->smp_start, e->h_state->sb_cycles, (long long)e->h_state->smp_K, e->sb_blocks, e->sb_shift, (int)e->sb_laps, e->h_state->sb_laps, e->h_state->sb_slow);
         e->pass_launches = e->h_state->sb_cycles; // (ccsim_report.pass_launches: launches of the cycle kernel that ran -- 0 on every other path of the sampled search)
+        if (e->sb_laps && e->h_state->smp_phase == 2) e->sf_handover = true; // (fewer feasible nodes than the search keeps: every node is visited from here on)
         if (e->h_state->done) return 0;
         if (one_launch_cycles > 0 && e->h_state->placed - placed0 >= one_launch_cycles) return 0;
         idle = e->h_state->placed == placed0 ? idle + 1 : 0;
@@ -3427,7 +3433,7 @@ extern "C" int ccsim_debug_sampled(ccsim_engine *e, int64_t *out8) {
         return 0;
     }
     if (!e->h_state || !e->begun || !e->sb_run) return 0;
-    out8[0] = 1, out8[1] = e->sb_laps ? 1 : 0, out8[2] = e->h_state->sb_cycles, out8[3] = e->h_state->sb_laps, out8[4] = e->h_state->sb_slow;
+    out8[0] = 1, out8[1] = e->sb_laps ? (e->sf_handover ? 4 : 1) : 0, out8[2] = e->h_state->sb_cycles, out8[3] = e->h_state->sb_laps, out8[4] = e->h_state->sb_slow;
     out8[5] = e->sb_shift, out8[6] = e->sb_blocks, out8[7] = e->smp_K;
     return 0;
 }

@@ -47,6 +47,8 @@ struct SbArgs {
     int32_t shift, n_blocks, max_cycles;
     unsigned long long *prof; // k_sb_laps, measurement runs (CCSIM_SB_PROF=1): 10 ns ticks per phase, summed over the run; else nullptr
     int64_t slow_floor; // k_sb_laps: stretches whose maxima differ from the assumed ones are re-evaluated node by node while they cover <= max(this, N / 4) nodes
+    int32_t handover;   // k_sb_laps: end the launch when fewer feasible nodes are left than the search keeps (every node is visited from then on,
+                        // one cycle per lap): DevState::smp_phase = 2 tells the host to go on with k_sf_cycles (ccsim_search_full.h)
 };
 
 // one node under the assumed maxima: TotalScore, or -1 (the wide path: any snapshot; the narrow mirrors give the same number by construction)
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds_raw[];
     LapLds &L = *reinterpret_cast<LapLds *>(sb_lds_raw);
     DevState &S = *a.st;
-    if (S.done) return;
+    if (S.done || S.smp_phase == 2) return; // (2: handed over to the full search, see SbArgs::handover)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: known to be uniform, so what follows from it stays in scalar registers)
     const int nb = a.n_blocks, sh = a.shift; // (1 << sh == 64 * NP)
     int nbp = 2, levels = 1;
@@ -612,9 +614,13 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
     unsigned long long t_prev = a.prof ? __builtin_amdgcn_s_memrealtime() : 0ull, pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LAP_TICK(i) do { if (a.prof) { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); pf[i] += t_now - t_prev; t_prev = t_now; } } while (0)
     bool all = false;
-    int J = 0;
+    int J = 0, hand = 0;
     auto plan = [&]() { // the coming lap: how many stretches
         all = Ftotal <= K; // fewer feasible nodes than wanted: the search visits every node (:538: processed = N)
+        if (all && a.handover && Ftotal > 0 && !done && !dirty) { // ... from here to the end of the run: the full search's kernel takes over
+            hand = 1, J = 0;
+            return;
+        }
         J = all ? 1 : (int)((Ftotal - 1) / K < (uint32_t)kLapMaxJ ? (Ftotal - 1) / K : (uint32_t)kLapMaxJ);
         if (limit > 0 && limit - placed < J) J = (int)(limit - placed); // (the stretches behind the limit are never looked at)
         if (budget < J) J = (int)budget;
@@ -979,6 +985,7 @@ __global__ __launch_bounds__(kLapThreads) void k_sb_laps(SbArgs a) {
         S.sb_dirty = dirty;
         if (dirty) S.mt_a = (int32_t)new_mt, S.ma_a = (int32_t)new_ma;
         S.sb_cycles += 1, S.sb_laps += laps, S.sb_slow += slow;
+        if (hand) S.smp_phase = 2;
     }
 }
 

@@ -45,15 +45,38 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
     if (S.done) return; // (sb_dirty: k_sb_build in front of this launch has just rebuilt memo and summaries under S.mt_a / S.ma_a; the flag is cleared below)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = a.n_blocks, sh = a.shift; // (1 << sh == 64 * NP)
+    const int32_t N = (int32_t)a.c.n;
+    // The sampled search hands over to this kernel once fewer feasible nodes are left than it wants to keep (every node is visited from then
+    // on, schedule_one.go:538, and nextStartNodeIndex stays): the visiting order -- the tie-break -- starts at that index S0, so the keys
+    // in here carry RING positions behind the score; the summaries in memory carry indices (k_sb_build, k_sb_laps).
+    const int32_t S0 = S.smp_K > 0 ? (int32_t)S.smp_start : 0;
+    auto rpos = [&](int32_t i) -> int32_t { return i >= S0 ? i - S0 : i + N - S0; };
+    auto node_at = [&](int32_t rp) -> int32_t { return rp + S0 >= N ? rp + S0 - N : rp + S0; };
+    auto to_ring = [&](unsigned long long k) -> unsigned long long { return k ? (k & ~kIdxMask) | (kIdxMask - (unsigned long long)rpos((int32_t)key_index(k))) : 0ull; };
+    auto to_index = [&](unsigned long long k) -> unsigned long long { return k ? (k & ~kIdxMask) | (kIdxMask - (unsigned long long)node_at((int32_t)key_index(k))) : 0ull; };
     // ---- the block summaries the build (or the launch before) left; the groups' maxima
     uint32_t fc = 0;
     for (int b = tid; b < kSfMaxBlocks; b += kSfThreads) {
         const bool in = b < nb;
-        L.key[b] = in ? a.sb_key[b] : 0ull, L.mx[b] = in ? a.sb_mx[b] : 0u;
+        L.key[b] = in ? to_ring(a.sb_key[b]) : 0ull, L.mx[b] = in ? a.sb_mx[b] : 0u;
         fc += in ? a.sb_fc[b] : 0u;
     }
     fc = wave_sum_u32_dpp(fc);
     if (lane == 0) L.w_fc[wave] = fc;
+    __syncthreads();
+    if (S0 > 0 && wave == 0) { // the block the ring starts in: its best node in RING order, from its words (the summary's is the lowest index)
+        const int sb0 = S0 >> sh;
+        unsigned long long best = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int64_t i = ((int64_t)sb0 << sh) + k * 64 + lane;
+            const int32_t m = (NP == 4 || NP == 1 || i < a.c.n_pad) ? ld_memo(a.memo + i) : -1;
+            const unsigned long long kk = m >= 0 ? make_key((int64_t)m, (int64_t)rpos((int32_t)i)) : 0ull;
+            best = kk > best ? kk : best;
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) L.key[sb0] = best;
+    }
     __syncthreads();
     const int ngroups = (nb + 63) >> 6;
     for (int gq = wave; gq < kSfGroups; gq += kSfWaves) {
@@ -65,7 +88,6 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
     __syncthreads();
     if (wave != 0) return;
 
-    const int32_t N = (int32_t)a.c.n;
     const int64_t n_pad = a.c.n_pad, limit = S.limit, log_cap = S.log_cap;
     const uint32_t mt_a = (uint32_t)S.mt_a, ma_a = (uint32_t)S.ma_a;
     const NarrowPod npod = narrow_pod(a.p, a.c.mem_shift);
@@ -127,7 +149,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
             dirty = 1, scans += 1;
             break;
         }
-        const int32_t g = (int32_t)key_index(top);
+        const int32_t g = node_at((int32_t)key_index(top));
         if (g != pg) {
             // ---- another node: the held one goes to memory; ONE trip for the winner's row (the same address in every lane, so one request:
             // every lane then holds the row and computes the same scores) and, if it lies in another block, that block's memo words
@@ -143,7 +165,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
                     const int64_t i = ((int64_t)b << sh) + k * 64 + lane;
-                    bm[k] = (NP == 4 || i < n_pad) ? ld_memo(a.memo + i) : -1; // (n_pad is a multiple of 512: blocks of 256 nodes never reach beyond it)
+                    bm[k] = (NP <= 4 || i < n_pad) ? ld_memo(a.memo + i) : -1; // (n_pad is a multiple of 512: blocks of 64 or 256 nodes never reach beyond it)
                 }
             }
             if (NARROW) na0 = a.c.a32[0][g], na1 = a.c.a32[1][g];
@@ -158,7 +180,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
 #pragma unroll
             for (int k = 0; k < NP; k++) {
                 const int32_t i = (b << sh) + k * 64 + lane;
-                const unsigned long long kk = (bm[k] >= 0 && i != g) ? make_key((int64_t)bm[k], (int64_t)i) : 0ull;
+                const unsigned long long kk = (bm[k] >= 0 && i != g) ? make_key((int64_t)bm[k], (int64_t)rpos(i)) : 0ull;
                 best = kk > best ? kk : best;
             }
             ob = wave_max_u64(best);
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
             // nobody waits for these (the next loads follow a streak's evaluation later)
             __builtin_amdgcn_sched_barrier(0);
             store_row(opg, od, opc, cur_m_prev);
-            if (ck_b >= 0 && lane == 0) a.sb_key[ck_b] = ck_leaf;
+            if (ck_b >= 0 && lane == 0) a.sb_key[ck_b] = to_index(ck_leaf);
             ck_b = -1;
             SF_TICK(2);
         }
@@ -193,14 +215,14 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
             }
         } else if constexpr (!NARROW)
             mj = sb_node_score(a.p, nj, mt_a, ma_a);
-        const unsigned long long kj = mj >= 0 ? make_key((int64_t)mj, (int64_t)g) : 0ull;
+        const unsigned long long kj = mj >= 0 ? make_key((int64_t)mj, (int64_t)rpos(g)) : 0ull;
         const unsigned long long fail = __ballot(!(kj > rest));
         int32_t r = fail ? __ffsll((long long)fail) : 64; // clones placed: up to and including the first state that loses
         r = (int64_t)r > cap ? (int32_t)cap : r;
         const int32_t nm = lane_bcast_i32(mj, r - 1);
         node_apply<NX>(a.p, nd, (int64_t)r);
         pc += r;
-        cur_m = nm, cur_key = nm >= 0 ? make_key((int64_t)nm, (int64_t)g) : 0ull;
+        cur_m = nm, cur_key = nm >= 0 ? make_key((int64_t)nm, (int64_t)rpos(g)) : 0ull;
         if (lane < r && a.log && placed + lane < log_cap) a.log[placed + lane] = g;
         SF_TICK(3);
         pf[7] += 1;
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf_cycles(SbArgs a) {
     }
     close_block();
     store_row(pg, nd, pc, cur_m);
-    if (ck_b >= 0 && lane == 0) a.sb_key[ck_b] = ck_leaf;
+    if (ck_b >= 0 && lane == 0) a.sb_key[ck_b] = to_index(ck_leaf);
 #undef SF_TICK
     if (a.prof && lane == 0)
         for (int i = 0; i < 8; i++) a.prof[i] += pf[i];

@@ -479,13 +479,15 @@ int ccsim_debug_coupled(ccsim_engine *e, int64_t *out16);
 /* ... and how the last sampled search (percentageOfNodesToScore < 100; S/schedule_one.go:610-723) of a template without topology-coupled
  * plugins ran (csrc/ccsim_sampled.h): out8[0] = 1 if it ran on the resident block summaries, [1] = 1 if a lap of the ring at a time
  * (k_sb_laps; 0: a cycle at a time, k_sb_cycles; 2: a template with a hard spread constraint over zones, csrc/ccsim_sampled_zone.h: [3] = cycles;
- * 3: the FULL search, percentageOfNodesToScore = 100, on the same summaries, csrc/ccsim_search_full.h: [3] = cycles), [2] = launches of that kernel, [3] = laps evaluated, [4] = stretches re-evaluated node
+ * 3: the FULL search, percentageOfNodesToScore = 100, on the same summaries, csrc/ccsim_search_full.h: [3] = cycles; 4: laps, then -- fewer
+ * feasible nodes left than the search keeps: every node visited -- that kernel to the end of the run), [2] = launches of that kernel, [3] = laps evaluated, [4] = stretches re-evaluated node
  * by node under their own normalization maxima, [5] = log2 of the block size, [6] = blocks, [7] = K (numFeasibleNodesToFind);
  * out[8..14] (with CCSIM_SB_PROF=1): 10 ns ticks k_sb_laps spent [8] on the cut blocks (wave 1: the tree, the range queries), [9] on
  * the decision (+ stretches re-evaluated), [10] waiting for the placements, [11] on the winners' leaves (wave 0: the next lap's cuts);
  * [14] the committing wave's own time inside [10].  `out` holds 16 values.
  * Knobs (read when a run begins; every value gives the same results): CCSIM_SB=0 three node passes per cycle, =2 a cycle at a time;
  * CCSIM_SB_CYCLES cycles per launch; CCSIM_SB_SHIFT block size; CCSIM_SB_SLOW_FLOOR nodes below which differing maxima never rebuild;
+ * CCSIM_SB_HANDOVER=0 the lap kernel's one-stretch laps to the end of the run instead of handing over to k_sf_cycles;
  * CCSIM_SF=0 the full search as one pass over the nodes per cycle (k_scan_fused) instead of k_sf_cycles; CCSIM_SF_SHIFT=10 blocks of 1024. */
 int ccsim_debug_sampled(ccsim_engine *e, int64_t *out16);
 /* ... and which form this engine's library-driven sharded runs (ccsim_dist_run) took: out8[0] = 1 if the ranks' mailboxes are connected

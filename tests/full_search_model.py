@@ -37,19 +37,30 @@ def key_index(key):
 
 
 class FullSearchModel:
-    def __init__(self, prof, nodes, pod, block=64, group=8, lanes=64, check=True):
+    def __init__(self, prof, nodes, pod, block=64, group=8, lanes=64, check=True, start=0, node_model=None, assumed=(0, 0)):
+        """start / node_model / assumed: the SAMPLED search hands over to this form once fewer feasible nodes are left than it wants to keep
+        (schedule_one.go:538: every node is visited from then on and nextStartNodeIndex stays where it is): the visiting order -- and with
+        it the tie-break -- starts at that index, so every key carries the node's RING position behind it instead of its index."""
         assert not pod.spread and pod.ipa is None
-        self.m = CoupledWindowModel(prof, nodes, pod, go_log=None, every_node_scored=False)
+        self.m = node_model if node_model is not None else CoupledWindowModel(prof, nodes, pod, go_log=None, every_node_scored=False)
         self.N, self.B, self.G, self.W, self.check = nodes.n, block, group, lanes, check
+        self.S = start
         self.nb = -(-self.N // block)
         self.ng = -(-self.nb // group)
-        self.mt_a = self.ma_a = 0
+        self.mt_a, self.ma_a = assumed
         self.builds = self.node_changes = self.block_changes = self.evaluations = self.gone = 0
         self.build()
 
     # ---- k_sb_build
     def _word(self, n):
         return self.m.local_score(n, self.mt_a, self.ma_a) if self.m.node_feasible(n) else -1
+
+    def _key(self, w, n):  # greater score first, then the earlier ring position
+        return make_key(w, n - self.S if n >= self.S else n + self.N - self.S)
+
+    def _node(self, key):
+        n = key_index(key) + self.S
+        return n - self.N if n >= self.N else n
 
     def _block(self, b):
         return range(b * self.B, min(self.N, (b + 1) * self.B))
@@ -59,7 +70,7 @@ class FullSearchModel:
         for n in self._block(b):
             w = self.memo[n] if words is None else words[n - b * self.B]
             if w >= 0:
-                key = max(key, make_key(w, n))
+                key = max(key, self._key(w, n))
                 mt, ma = max(mt, self.m.cnt[n]), max(ma, self.m.aff[n])
         return key, (mt, ma)
 
@@ -118,7 +129,7 @@ class FullSearchModel:
                 if self.root_mx != (self.mt_a, self.ma_a):
                     stop = "rebuild"
                     break
-                g = key_index(top)
+                g = self._node(top)
                 if g != pg:
                     self.node_changes += 1
                     b, grp = g // B, g // B // G
@@ -133,7 +144,7 @@ class FullSearchModel:
                         bm = [self.memo[n] for n in self._block(b)]
                         og = max((self.key[x] for x in range(grp * G, min(self.nb, (grp + 1) * G)) if x != b), default=0)
                         orr = max((self.gk[x] for x in range(self.ng) if x != grp), default=0)
-                    ob = max((make_key(w, b * B + i) for i, w in enumerate(bm) if w >= 0 and b * B + i != g), default=0)
+                    ob = max((self._key(w, b * B + i) for i, w in enumerate(bm) if w >= 0 and b * B + i != g), default=0)
                     rest = max(ob, og, orr)
                     pg, pb = g, b
                     if self.check:
@@ -143,8 +154,8 @@ class FullSearchModel:
                         for x in range(self.ng):
                             if x != pb // G:
                                 assert self.gk[x] == max(self.key[x * G:(x + 1) * G]), ("stale group key", x)
-                        assert rest == max((make_key(w, n) for n, w in enumerate(self.memo) if w >= 0 and n != g), default=0), "rest"
-                        assert self.memo[g] >= 0 and make_key(self.memo[g], g) == top
+                        assert rest == max((self._key(w, n) for n, w in enumerate(self.memo) if w >= 0 and n != g), default=0), "rest"
+                        assert self.memo[g] >= 0 and self._key(self.memo[g], g) == top
                 # ---- the streak: the held node's next W states at once
                 self.evaluations += 1
                 cap = limit - len(log) if limit else 1 << 62
@@ -154,14 +165,14 @@ class FullSearchModel:
                     words.append(self._word(g))
                 r = self.W
                 for j, w in enumerate(words):
-                    if not (w >= 0 and make_key(w, g) > rest):
+                    if not (w >= 0 and self._key(w, g) > rest):
                         r = j + 1
                         break
                 r = min(r, cap)
                 for _ in range(self.W - r):
                     self._unplace(g)
                 cur_m = words[r - 1]
-                cur_key = make_key(cur_m, g) if cur_m >= 0 else 0
+                cur_key = self._key(cur_m, g) if cur_m >= 0 else 0
                 log += [g] * r
                 visited += r * N
                 if cur_m < 0:  # the node left the feasible ones

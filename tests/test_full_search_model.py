@@ -47,3 +47,30 @@ def test_one_node_and_no_feasible_node(ccref):
     ref = ccref.run(prof, nodes, big, max_limit=0)
     log, stop, visited = FullSearchModel(prof, nodes.copy(), big, block=4, group=2).run(0)
     assert log == [] and ref.placed == 0 and stop == "Unschedulable" and visited == ref.evaluated_total
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_sampled_search_hands_over_to_the_full_search(ccref, seed):
+    """percentageOfNodesToScore < 100 to the end of the run: once fewer feasible nodes are left than the search wants to keep every node is
+    visited (schedule_one.go:538: processed = N, the start index stays) -- the lap model runs until then, this model takes over on the
+    same node state with the visiting order (and the tie-break) starting at that index."""
+    from sampled_lap_model import LapSampledModel
+    rng = np.random.default_rng(8800 + seed)
+    nodes, pod, prof = H.with_ports_and_images(rng, *H.random_case(rng, int(rng.integers(300, 1500))))
+    if seed % 2:  # equal nodes: ties between the two parts of the ring decide
+        nodes, pod, prof = synth.make_config("C3", n_nodes=int(rng.integers(300, 900)), seed=seed)
+    prof = dataclasses.replace(prof, percentage_of_nodes_to_score=int(rng.choice([20, 35, 60])))
+    ref = ccref.run(prof, nodes, pod, max_limit=0)
+    lap = LapSampledModel(prof, nodes.copy(), pod, block=16, check=False)
+    log, visited = [], 0
+    while lap.Ftotal > lap.K:
+        out, flag = lap.lap(0)
+        assert flag is not None
+        for g, v in out:
+            log.append(g), (visited := visited + v)
+    assert lap.Ftotal > 0 and log == ref.log[:len(log)].tolist()
+    full = FullSearchModel(prof, nodes, pod, block=16, group=4, lanes=64, start=lap.start, node_model=lap.m, assumed=(lap.mt_a, lap.ma_a))
+    log2, stop, visited2 = full.run(0)
+    assert log + log2 == ref.log.tolist(), seed
+    assert stop == "Unschedulable" and visited + visited2 == ref.evaluated_total
+    assert lap.start > 0 or seed % 2 == 0

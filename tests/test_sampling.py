@@ -30,12 +30,16 @@ def _check(ccref, nodes, pod, prof, limit):
     coupled = bool(pod.spread) or pod.ipa is not None
     # (a coupled template takes three node passes per cycle, except the one shape csrc/ccsim_sampled_zone.h holds resident -- round 6)
     resident = sampled and os.environ.get("CCSIM_SB", "1") != "0" and (not coupled or info["zone_form"])
+    # (every node scored -- a snapshot of <= 100 nodes, or 100 % asked for: the full search on the same summaries, csrc/ccsim_search_full.h)
+    full = not sampled and not coupled and os.environ.get("CCSIM_SF", "1") != "0" and nodes.n > 0
+    assert info["full_search_form"] == full, info
+    resident = resident or full
     assert (got.pass_launches > 0) == resident, (got.pass_launches, resident)
     assert info["resident"] == resident
     if info["zone_form"]:
         assert coupled and info["laps"] >= got.placed  # (`laps` counts this form's cycles)
         return e, got, ref
-    if resident:  # ... and a lap of the ring at a time (k_sb_laps, round 6) whenever a block of >= 64 nodes holds one stretch boundary at most
+    if resident and not full:  # ... and a lap of the ring at a time (k_sb_laps, round 6) whenever a block of >= 64 nodes holds one stretch boundary at most
         forced = int(os.environ.get("CCSIM_SB_SHIFT", "6"))  # (blocks of 256 nodes when K >= 256, else of 64; forced: 64 or 256 only)
         assert info["laps_form"] == (info["K"] >= (1 << forced) and forced in (6, 8) and os.environ.get("CCSIM_SB", "1") == "1"), info
         assert not info["laps_form"] or (info["block"] <= info["K"] and info["laps"] > 0)
@@ -361,4 +365,21 @@ def test_schedule_one_takes_the_zone_form(ccref, n, zones, pct, cycles, anti):
             assert node == -1 and feasible == 0
             ev += evaluated if _ == 0 else 0
     assert ev == ref.evaluated_total
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,n,pct,handover", [("C3", 3000, 5, True), ("C3", 3000, 5, False), ("C4", 9000, 10, True), ("C2", 700, 30, True), ("C3", 40_000, 2, True)])
+def test_sampled_search_hands_over_to_the_full_search_at_the_end(ccref, monkeypatch, cfg, n, pct, handover):
+    """To the end of a run: once fewer feasible nodes are left than the search keeps, every node is visited and the start index stays
+    (schedule_one.go:538) -- a lap is one cycle then, and the full search's kernel (k_sf_cycles, ring order from that start index) takes
+    the rest of the run; CCSIM_SB_HANDOVER=0 keeps the lap kernel's one-stretch laps.  Same log, visited nodes, FitError either way."""
+    if not handover:
+        monkeypatch.setenv("CCSIM_SB_HANDOVER", "0")
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=5 + n)
+    if n >= 40_000:  # (a whole run at this size is long for the oracle: nodes nearly full from the start)
+        nodes.pod_count = np.maximum(nodes.pod_count, nodes.alloc_pods - 3).astype(nodes.pod_count.dtype)
+    e, got, ref = _check(ccref, nodes, pod, _with_pct(prof, pct), 0)
+    info = e.sampled_info()
+    assert ref.stop == M.STOP_UNSCHEDULABLE and info["laps_form"] and info["handed_over_to_full_search"] == handover, info
     e.close()

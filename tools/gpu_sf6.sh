@@ -12,3 +12,7 @@ for sf in 1 0; do
   CCSIM_SF=$sf MB_PCT=100 MB_GATE=${MB_GATE:-1200} MB_LIMIT=${MB_LIMIT:-30000} timeout 600 python tools/bench_mode_b.py 1000000 100000 2>&1 | grep -v amdgpu.ids | sed "s/^CCSIM_SB=1/CCSIM_SF=$sf/" | tee -a $O/bench_full_search.txt | cut -c1-400
 done
 CCSIM_SB_PROF=1 CCSIM_SF=1 MB_PCT=100 MB_GATE=300 MB_LIMIT=${MB_LIMIT:-30000} timeout 600 python tools/bench_mode_b.py 1000000 2>&1 | grep -v amdgpu.ids | sed "s/^CCSIM_SB=1/CCSIM_SF=1 CCSIM_SB_PROF=1/" | tee $O/bench_full_search_prof.txt | cut -c1-900
+# the end of a sampled run (fewer feasible nodes than the search keeps: every node visited): handed over to k_sf_cycles vs the lap kernel's one-stretch laps
+for ho in 1 0; do
+  CCSIM_SB_HANDOVER=$ho MB_PCT=0 MB_GATE=1000 MB_LIMIT=0 timeout 900 python tools/bench_mode_b.py 100000 2>&1 | grep -v amdgpu.ids | sed "s/^CCSIM_SB=1/whole run to Unschedulable, CCSIM_SB_HANDOVER=$ho/" | tee -a $O/bench_mode_b_whole_run.txt | cut -c1-500
+done
