@@ -61,3 +61,5 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v am
 bash tools/gpu_mode_b_prof.sh $R/mode_b > /dev/null 2>&1; cp $O/mode_b/mode_b_1M_kernel_stats.csv $O/mode_b/pmc_mode_b.txt $O/mode_b/bench_mode_b_under_rocprofv3.txt $O/ 2>/dev/null; head -3 $O/mode_b_1M_kernel_stats.csv | cut -c1-160
 SKIP_TESTS=1 bash tools/gpu_sb6.sh $R/sb > /dev/null 2>&1; cp $O/sb/bench_mode_b.txt $O/bench_mode_b_laps_vs_cycle_at_a_time.txt; cp $O/sb/bench_mode_b_prof.txt $O/mode_b_laps_phase_profile.txt; grep "CCSIM_SB=1" $O/bench_mode_b_laps_vs_cycle_at_a_time.txt | cut -c1-140
 SKIP_TESTS=1 bash tools/gpu_sz6.sh $R/sz > /dev/null 2>&1; cp $O/sz/bench_mode_b_zone.txt $O/bench_mode_b_zone.txt; cut -c1-150 $O/bench_mode_b_zone.txt
+# round 6: the full search on the block summaries by one wave (the sequential mode, the SchedulePod seam), the end of a sampled run handed over to it
+SKIP_TESTS=1 bash tools/gpu_sf6.sh $R/sf > /dev/null 2>&1; cp $O/sf/bench_full_search.txt $O/sf/bench_full_search_prof.txt $O/sf/bench_mode_b_whole_run.txt $O/sf/full_search_1M_kernel_stats.csv $O/sf/bench_seam.txt $O/ 2>/dev/null; cut -c1-170 $O/bench_full_search.txt; cut -c1-200 $O/bench_mode_b_whole_run.txt

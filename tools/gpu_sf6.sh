@@ -16,3 +16,9 @@ CCSIM_SB_PROF=1 CCSIM_SF=1 MB_PCT=100 MB_GATE=300 MB_LIMIT=${MB_LIMIT:-30000} ti
 for ho in 1 0; do
   CCSIM_SB_HANDOVER=$ho MB_PCT=0 MB_GATE=1000 MB_LIMIT=0 timeout 900 python tools/bench_mode_b.py 100000 2>&1 | grep -v amdgpu.ids | sed "s/^CCSIM_SB=1/whole run to Unschedulable, CCSIM_SB_HANDOVER=$ho/" | tee -a $O/bench_mode_b_whole_run.txt | cut -c1-500
 done
+# rocprofv3 kernel stats of the same command (the sequential mode at 1M nodes: k_sb_build once or twice, then k_sf_cycles)
+( cd /tmp && export TMPDIR=/tmp && rm -rf $O/ks && CCSIM_SF=1 MB_PCT=100 MB_GATE=200 MB_LIMIT=30000 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python /root/repo/tools/bench_mode_b.py 1000000 > $O/bench_full_search_under_rocprofv3.txt 2> $O/ks.err
+  f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/full_search_1M_kernel_stats.csv && cut -c1-160 $O/full_search_1M_kernel_stats.csv | head -5; rm -rf $O/ks )
+# the SchedulePod seam: microseconds per ccsim_schedule_one call, resident forms vs node passes
+timeout 300 python tools/bench_seam.py 1000000 2>&1 | grep -v amdgpu.ids | tee $O/bench_seam.txt | cut -c1-250
+CCSIM_SF=0 CCSIM_SB=0 SEAM_CALLS=1000 timeout 300 python tools/bench_seam.py 1000000 2>&1 | grep -v amdgpu.ids | tee -a $O/bench_seam.txt | cut -c1-250
