@@ -343,7 +343,7 @@ def test_profile_without_score_plugins_keeps_the_first_feasible_node(ccref, cfg,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,zones,pct,cycles,anti", [(20_000, 16, 5, 500, True), (3000, 5, 10, 0, False)])
+@pytest.mark.parametrize("n,zones,pct,cycles,anti", [(20_000, 16, 5, 500, True), (1500, 5, 10, 0, False)])
 def test_schedule_one_takes_the_zone_form(ccref, n, zones, pct, cycles, anti):
     """The SchedulePod seam (scheduler.go:88-91) for a template with a hard zone constraint under the default percentage: one launch on the
     per-(block, zone) entries per call, to the FitError and past it."""
@@ -369,7 +369,7 @@ def test_schedule_one_takes_the_zone_form(ccref, n, zones, pct, cycles, anti):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,n,pct,handover", [("C3", 3000, 5, True), ("C3", 3000, 5, False), ("C4", 9000, 10, True), ("C2", 700, 30, True), ("C3", 40_000, 2, True)])
+@pytest.mark.parametrize("cfg,n,pct,handover", [("C3", 3000, 5, True), ("C3", 3000, 5, False), ("C4", 5000, 10, True), ("C2", 700, 30, True), ("C3", 40_000, 2, True)])
 def test_sampled_search_hands_over_to_the_full_search_at_the_end(ccref, monkeypatch, cfg, n, pct, handover):
     """To the end of a run: once fewer feasible nodes are left than the search keeps, every node is visited and the start index stays
     (schedule_one.go:538) -- a lap is one cycle then, and the full search's kernel (k_sf_cycles, ring order from that start index) takes
