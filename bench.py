@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_000_000, help="nodes per GPU (weak) / in the whole snapshot (strong)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N > 1: strong = ONE --nodes snapshot sharded over the N GPUs (BASELINE config 4 literally); weak = N x --nodes")
+    ap.add_argument("--counts-width", type=int, default=1, choices=[0, 1, 2],
+                    help="bytes per per-node count the caller offers (ABI 5 per_node_count_narrow; 0 = int32 only)")
     ap.add_argument("--no-variants", action="store_true", help="skip the multi-kernel / wide-path comparison runs")
     ap.add_argument("--limit", type=int, default=-1, help="placements per step (0 = until Unschedulable; "
                     "-1 = mode default: 0 for batched, 2048 for sequential)")
@@ -307,8 +309,10 @@ def main():
             # the per-node counts are delivered into the engine's page-locked result array, reused from step to step (include/ccsim.h
             # ccsim_host_alloc): a fresh pageable array per step costs 0.18 ms of page faults and staging at 1M nodes
             # (profiles/r04/step_breakdown.txt), which is the caller's allocation policy and not the simulation
+            # ABI 5: the counts in ONE byte each where every count provably fits (per_node_count_narrow: no node takes more clones than its
+            # pod capacity, 110 here) -- 1 MB instead of 4 MB over PCIe; the engine answers int32 where that does not hold
             eng.reset_state()
-            return eng.run(max_limit=lim, mode=mode, want_log=False, reuse_buffers=True)
+            return eng.run(max_limit=lim, mode=mode, want_log=False, reuse_buffers=True, narrow_counts=args.counts_width)
 
     library_driven = distributed and isinstance(runner, ccdist.LibraryRunner)
     forms = None
@@ -454,6 +458,19 @@ def main():
             "full_pass": full_pass,
         }
     variants = {}
+    if not distributed:  # the same step with the per-node counts as int32 (ABI <= 4's only form): same counts
+        counts_dtype = str(r.per_node_count.dtype)
+        eng.reset_state(); r32 = eng.run(max_limit=limit, mode=args.mode, want_log=False, reuse_buffers=True)
+        assert r32.per_node_count.dtype == np.int32 and np.array_equal(r32.per_node_count, r.per_node_count) and r32.placed == r.placed
+        ts32 = []
+        for _ in range(min(args.steps, 10)):
+            torch.cuda.synchronize() if have_gpu else None
+            v0 = time.perf_counter()
+            eng.reset_state(); eng.run(max_limit=limit, mode=args.mode, want_log=False, reuse_buffers=True)
+            ts32.append(time.perf_counter() - v0)
+        variants["int32_counts_ms_per_step"] = sorted(ts32)[len(ts32) // 2] * 1e3
+        variants["per_node_counts"] = (f"{counts_dtype} ({'ccsim_report.per_node_count_narrow, ABI 5: every count <= the largest pod capacity of the snapshot' if counts_dtype != 'int32' else 'ccsim_report.per_node_count'}); "
+                                       "equal to the int32 vector of the same run (asserted)")
     if args.mode == "batched" and not distributed and not args.no_variants:
         # the same step on the other code paths of the batched mode (untimed by the driver): the multi-kernel form
         # (one commit + one decision dispatch per level) and the wide path (int64 columns, fp64 arithmetic)

@@ -94,6 +94,7 @@ class CReport(C.Structure):
         ("rounds", C.c_int64), ("scans", C.c_int64), ("evaluated_total", C.c_int64), ("last_feasible", C.c_int32),
         ("kernel_ns", C.c_int64), ("pass_kernel_ns", C.c_int64), ("pass_launches", C.c_int64), ("bytes_per_scan", C.c_int64),
         ("per_spec_count", _p32), ("per_spec_cap", C.c_int32), ("stop_spec", C.c_int32),
+        ("per_node_count_narrow", C.c_void_p), ("per_node_narrow_width", C.c_int32), ("per_node_filled_width", C.c_int32),
     ]
 
 
@@ -101,7 +102,7 @@ class CCycle(C.Structure):
     _fields_ = [("node", C.c_int64), ("evaluated_nodes", C.c_int32), ("feasible_nodes", C.c_int32)]
 
 
-ABI_VERSION = 4  # CCSIM_ABI_VERSION of include/ccsim.h
+ABI_VERSION = 5  # CCSIM_ABI_VERSION of include/ccsim.h
 
 # every symbol include/ccsim.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = {
@@ -460,6 +461,23 @@ class Engine:
         if buf is not None and self.h:
             self.lib.ccsim_host_free(self.h, buf[0])
         self._pin_per_node = None
+        nb = getattr(self, "_pin_narrow", None)
+        if nb is not None and self.h:
+            self.lib.ccsim_host_free(self.h, nb[0])
+        self._pin_narrow = None
+
+    def _pinned_narrow(self):
+        """Page-locked bytes for ccsim_report.per_node_count_narrow (ABI 5): n elements of up to two bytes."""
+        n = max(1, self.n)
+        nb = getattr(self, "_pin_narrow", None)
+        if nb is None or nb[1].shape[0] != 2 * n:
+            if nb is not None and self.h:
+                self.lib.ccsim_host_free(self.h, nb[0])
+            ptr = self.lib.ccsim_host_alloc(self.h, 2 * n)
+            if not ptr:
+                raise MemoryError("ccsim_host_alloc failed")
+            self._pin_narrow = nb = (ptr, np.ctypeslib.as_array((C.c_uint8 * (2 * n)).from_address(ptr)))
+        return nb
 
     def _report(self, want_log: bool, log_cap: int, reuse_buffers: bool = False):
         if reuse_buffers and not want_log:
@@ -504,15 +522,24 @@ class Engine:
         )
 
     def run(self, max_limit: int = 0, mode: str = "sequential", want_log: bool = True, log_cap: Optional[int] = None,
-            reuse_buffers: bool = False) -> M.RunResult:
-        """`reuse_buffers`: the per-node counts land in the engine's page-locked result array (ccsim_host_alloc) and the result
+            reuse_buffers: bool = False, narrow_counts: int = 0) -> M.RunResult:
+        """`narrow_counts` (1 or 2, with `reuse_buffers`): offer ccsim_report.per_node_count_narrow (ABI 5) -- when the run's form
+        supports it and every count fits, `per_node_count` of the result is a uint8 / uint16 view instead of int32 (same values; a
+        quarter / half of the bytes over PCIe).
+        `reuse_buffers`: the per-node counts land in the engine's page-locked result array (ccsim_host_alloc) and the result
         holds a VIEW of it: its CONTENTS are valid until the next run of this engine overwrites them -- what a caller that
         simulates repeatedly does with its own arrays.  When the array itself is released (close(), a snapshot of another size)
         every such result still alive is given a private copy first: keeping a result past close() is never a use-after-free."""
         if log_cap is None:
             log_cap = max_limit if max_limit > 0 else 1 << 22
         rep, per_node, log, ht = self._report(want_log, log_cap, reuse_buffers)
+        rep.per_node_count_narrow, rep.per_node_narrow_width, rep.per_node_filled_width = None, 0, 0
+        if narrow_counts in (1, 2) and reuse_buffers:
+            nb = self._pinned_narrow()
+            rep.per_node_count_narrow, rep.per_node_narrow_width = nb[0], int(narrow_counts)
         self._chk(self.lib.ccsim_run(self.h, int(max_limit), MODES[mode], C.byref(rep)), "ccsim_run")
+        if rep.per_node_filled_width in (1, 2):
+            per_node = self._pin_narrow[1].view(np.uint8 if rep.per_node_filled_width == 1 else np.uint16)
         res = self._result(rep, per_node, log, ht, reuse_buffers)
         if reuse_buffers:
             import weakref

@@ -38,6 +38,13 @@
 
 using namespace ccsim;
 
+// the step frame (ccsim_engine::d_frame): [DevState | hist[CCSIM_NREASON + 1] hist_ts[kFrameTs] | PersistSync[kPMaxRanks]]
+constexpr int kFrameTs = 256; // taint sets whose FitError bins live in the frame (a pod spec with more gets an array of its own)
+constexpr size_t kFrameOffHist = (sizeof(DevState) + 63) & ~(size_t)63;
+constexpr size_t kFrameOffSync = (kFrameOffHist + sizeof(unsigned long long) * (CCSIM_NREASON + 1 + kFrameTs) + 63) & ~(size_t)63;
+constexpr size_t kFrameHostBytes = kFrameOffSync + sizeof(PersistSync); // what travels: up to the first sync block
+constexpr size_t kFrameBytes = kFrameOffSync + sizeof(PersistSync) * kPMaxRanks;
+
 struct ccsim_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -115,6 +122,14 @@ struct ccsim_engine {
     int32_t *d_log = nullptr;
     int64_t log_cap = 0;
     unsigned long long *d_hist = nullptr, *d_hist_ts = nullptr, *d_hist_code = nullptr;
+    // The STEP FRAME (round 6): run state, FitError histogram (+ per-taint-set bins) and the persistent kernel's sync block are ONE device
+    // allocation -- [DevState | hist[CCSIM_NREASON + 1] hist_ts[kFrameTs] | PersistSync[kPMaxRanks]] -- so that a persistent run starts with
+    // one host-to-device copy (the state + the zeros of everything behind it; it was one copy and three fills) and ends with one copy back
+    // (state + histogram; it was three) next to the per-node counts.  d_state / d_hist / d_psync point into it.
+    unsigned char *d_frame = nullptr, *h_frame = nullptr, *h_init = nullptr; // h_frame: page-locked, what comes back (h_state = its start); h_init: page-locked, what goes out
+    unsigned long long *d_frame_ts = nullptr;
+    bool ts_in_frame = false;      // d_hist_ts is the frame's (the pod's taint sets fit kFrameTs)
+    bool frame_sent = false;       // begin_run sent the whole frame for the persistent launch that follows
     int grid = 0;
     int64_t chunk = 0;
     // batched mode (ccsim_level.h): its own launch geometry (chunk bounded by the LDS score cache)
@@ -158,7 +173,9 @@ struct ccsim_engine {
     bool persist_hint = false;          // persist_hint_mt / _ma: the normalization maxima the last persistent launch of this pod started with
     int32_t persist_hint_mt = 0, persist_hint_ma = 0;
     // ... and its results left for the host right behind the kernel, before the host knew how the launch ended (one stream sync per run):
-    bool early_counts = false, early_hist = false;
+    bool early_counts = false, early_hist = false, early_hist_framed = false;
+    int early_narrow = 0;            // the counts that left early are ccsim_report.per_node_count_narrow's, in elements of that many bytes
+    void *d_cnt_narrow = nullptr;    // [n_pad] 2-byte elements' worth (allocated on first use; goes with the snapshot)
     unsigned long long *h_hist_pin = nullptr; // page-locked [CCSIM_NREASON + 1 + h_hist_ts_cap]
     size_t h_hist_ts_cap = 0;
     int n_cus = 0;
@@ -340,17 +357,26 @@ extern "C" int ccsim_create(const ccsim_config *cfg, ccsim_engine **out) {
         e->own_stream = true;
     }
     if (hipEventCreate(&e->ev0) != hipSuccess || hipEventCreate(&e->ev1) != hipSuccess ||
-        hipHostMalloc((void **)&e->h_state, sizeof(DevState), hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void **)&e->d_state, sizeof(DevState)) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_frame, kFrameHostBytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_init, kFrameHostBytes, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&e->d_frame, kFrameBytes) != hipSuccess ||
         hipMalloc((void **)&e->d_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_state2, sizeof(DevState)) != hipSuccess ||
         hipMalloc((void **)&e->d_partials2, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
         hipMalloc((void **)&e->d_smp_partials, sizeof(uint64_t) * 2 * kMaxGrid) != hipSuccess ||
-        hipMalloc((void **)&e->d_smp_prefix, sizeof(int64_t) * kMaxGrid) != hipSuccess ||
-        hipMalloc((void **)&e->d_hist, sizeof(unsigned long long) * (CCSIM_NREASON + 1)) != hipSuccess ||
-        hipMalloc((void **)&e->d_psync, sizeof(PersistSync) * kPMaxRanks) != hipSuccess) {
+        hipMalloc((void **)&e->d_smp_prefix, sizeof(int64_t) * kMaxGrid) != hipSuccess) {
         ccsim_destroy(e);
         return -ENOMEM;
+    }
+    memset(e->h_frame, 0, kFrameHostBytes), memset(e->h_init, 0, kFrameHostBytes);
+    e->h_state = reinterpret_cast<DevState *>(e->h_frame);
+    e->d_state = reinterpret_cast<DevState *>(e->d_frame);
+    e->d_hist = reinterpret_cast<unsigned long long *>(e->d_frame + kFrameOffHist);
+    e->d_frame_ts = e->d_hist + CCSIM_NREASON + 1;
+    e->d_psync = reinterpret_cast<PersistSync *>(e->d_frame + kFrameOffSync);
+    if (hipMemset(e->d_frame, 0, kFrameBytes) != hipSuccess) {
+        ccsim_destroy(e);
+        return -EIO;
     }
     {
         hipDeviceProp_t prop;
@@ -367,19 +393,19 @@ extern "C" void ccsim_destroy(ccsim_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_graph(e);
     free_list(e->allocs);
+    e->d_cnt_narrow = nullptr;
     free_list(e->pod_allocs);
     free_list(e->multi_allocs);
     if (e->h_mstate) (void)hipHostFree(e->h_mstate);
-    if (e->d_state) (void)hipFree(e->d_state);
+    if (e->d_frame) (void)hipFree(e->d_frame); // (d_state, d_hist, d_psync)
     if (e->d_partials) (void)hipFree(e->d_partials);
     if (e->d_state2) (void)hipFree(e->d_state2);
     if (e->d_partials2) (void)hipFree(e->d_partials2);
     if (e->d_smp_partials) (void)hipFree(e->d_smp_partials);
     if (e->d_smp_prefix) (void)hipFree(e->d_smp_prefix);
-    if (e->d_hist) (void)hipFree(e->d_hist);
-    if (e->d_psync) (void)hipFree(e->d_psync);
     if (e->d_log) (void)hipFree(e->d_log);
-    if (e->h_state) (void)hipHostFree(e->h_state);
+    if (e->h_frame) (void)hipHostFree(e->h_frame); // (h_state)
+    if (e->h_init) (void)hipHostFree(e->h_init);
     if (e->h_hist_pin) (void)hipHostFree(e->h_hist_pin);
     for (void *p : e->mbox_ipc_open) (void)hipIpcCloseMemHandle(p);
     if (e->d_mbox) (void)hipFree(e->d_mbox);
@@ -407,6 +433,7 @@ extern "C" int ccsim_load_nodes(ccsim_engine *e, const ccsim_nodes *nd) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     drop_graph(e);
     free_list(e->allocs);
+    e->d_cnt_narrow = nullptr;
     e->d_sb_memo = nullptr, e->d_sb_flag8 = nullptr, e->d_sz_zone8 = e->d_sz_ent_flg = e->d_sz_cntz = nullptr, e->d_sz_ent_key = e->d_sz_present = nullptr, e->d_sz_over = nullptr, e->d_sb_fc = e->d_sb_mx = nullptr, e->d_sb_key = nullptr, e->d_sb_prof = nullptr; // (they lived in e->allocs)
     e->d_soft_pc0 = nullptr; // (sized for the previous snapshot: the pod is set again after a load)
     e->backups.clear();
@@ -743,7 +770,9 @@ extern "C" int ccsim_set_pod(ccsim_engine *e, const ccsim_pod *pod) {
         e->cols.alloc_pods = e->d_ports_eff, e->ports_on = true;
     }
     if ((rc = static_pass(e, pod, p.w_aff != 0, e->d_stat, e->d_sreason, e->pod_allocs))) return rc;
-    if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
+    e->ts_in_frame = pod->n_taintsets <= kFrameTs;
+    if (e->ts_in_frame) e->d_hist_ts = e->d_frame_ts; // (zeroed before every use)
+    else if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)pod->n_taintsets, e->pod_allocs))) return rc;
 
     // topology spread constraints: count tables + eligibility, built once.  hard -> Filter state
     // (filtering.go:235-308), soft -> Score state (scoring.go:61-178)
@@ -1345,8 +1374,16 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     st.mode = mode;
     st.log_cap = e->log_cap;
     *e->h_state = st;
-    HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
-    if (!(mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes && persist_k(e))) // (the persistent launch WRITES the per-run counts: cnt_assign)
+    const int persist_next = (mode == CCSIM_MODE_BATCHED && e->n_ranks == 0 && !e->time_passes) ? persist_k(e) : 0;
+    // a single-rank persistent launch follows: the state travels with the zeros of the histogram and of the launch's sync block behind
+    // it, in one copy (the step frame; run_persist then skips its three fills)
+    e->frame_sent = persist_next != 0 && e->persist_vranks == 0 && e->ts_in_frame && !getenv("CCSIM_FRAME_OFF");
+    if (e->frame_sent) {
+        *reinterpret_cast<DevState *>(e->h_init) = st; // (everything behind it in h_init stays zero)
+        HIPCHK(e, hipMemcpyAsync(e->d_frame, e->h_init, kFrameHostBytes, hipMemcpyHostToDevice, e->stream));
+    } else
+        HIPCHK(e, hipMemcpyAsync(e->d_state, e->h_state, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+    if (!persist_next) // (the persistent launch WRITES the per-run counts: cnt_assign)
         HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
     if (e->d_log && e->n_ranks > 0) // shards fill disjoint positions of the global log: -1 = "not mine"
         HIPCHK(e, hipMemsetAsync(e->d_log, 0xff, sizeof(int32_t) * (size_t)e->log_cap, e->stream));
@@ -1595,12 +1632,13 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
             cs = e->copy_stream;
         }
     }
+    out->per_node_filled_width = e->early_counts && e->early_narrow ? e->early_narrow : (out->per_node_count ? 4 : 0);
     if (out->per_node_count) {
         if (out->per_node_cap < e->n) return fail(e, -EINVAL, "per_node_cap too small");
         if (!e->early_counts) // (the persistent launch's counts are on the host already)
             HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, cs));
     }
-    e->early_counts = false;
+    e->early_counts = false, e->early_narrow = 0;
     out->log_len = 0;
     if (out->log && e->d_log) {
         int64_t len = st.placed < e->log_cap ? st.placed : e->log_cap;
@@ -1609,10 +1647,11 @@ static int fill_report(ccsim_engine *e, ccsim_report *out) {
         out->log_len = len;
     }
     if (st.done == DONE_UNSCHEDULABLE && e->n > 0 && e->hist_in_kernel && e->early_hist) { // diagnosis by the persistent launch, copied behind it
-        for (int i = 0; i < CCSIM_NREASON; i++) out->hist[i] = (int64_t)e->h_hist_pin[i];
-        out->n_code_unschedulable = (int64_t)e->h_hist_pin[CCSIM_NREASON];
+        const unsigned long long *hp = e->early_hist_framed ? reinterpret_cast<const unsigned long long *>(e->h_frame + kFrameOffHist) : e->h_hist_pin;
+        for (int i = 0; i < CCSIM_NREASON; i++) out->hist[i] = (int64_t)hp[i];
+        out->n_code_unschedulable = (int64_t)hp[CCSIM_NREASON];
         if (out->hist_taintset)
-            for (int i = 0; i < e->n_taintsets && i < out->hist_taintset_cap; i++) out->hist_taintset[i] = (int64_t)e->h_hist_pin[CCSIM_NREASON + 1 + i];
+            for (int i = 0; i < e->n_taintsets && i < out->hist_taintset_cap; i++) out->hist_taintset[i] = (int64_t)hp[CCSIM_NREASON + 1 + i];
         e->hist_in_kernel = e->early_hist = false;
     } else if (st.done == DONE_UNSCHEDULABLE && e->n > 0) {
         // terminal round: FitError diagnosis (types.go:787-836)
@@ -1791,13 +1830,29 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
             }
         }
         a.c.cnt_assign = launch == 0 ? 1 : 0; // (begin_run zeroed the per-run counts)
+        // ccsim_report.per_node_count_narrow: offered, and every count fits (a node takes at most its pod capacity)
+        int narrow = 0;
+        if (!mb && out && out->per_node_count_narrow && out->per_node_cap >= e->n && (out->per_node_narrow_width == 1 || out->per_node_narrow_width == 2) &&
+            e->pod.fit_enabled && e->node_max_pods < (out->per_node_narrow_width == 1 ? 256 : 65536))
+            narrow = out->per_node_narrow_width;
+        if (narrow && !e->d_cnt_narrow) {
+            uint16_t *p16 = nullptr;
+            int rc = dev_alloc(e, &p16, (size_t)e->n_pad, e->allocs);
+            if (rc) return rc;
+            e->d_cnt_narrow = p16;
+        }
+        a.c.cnt_narrow = narrow ? e->d_cnt_narrow : nullptr, a.c.cnt_narrow_width = narrow;
         a.c.skip_wide = !mb && e->lazy_wide ? 1 : 0;
         a.c.hist = diag ? e->d_hist : nullptr, a.c.hist_ts = e->d_hist_ts, a.c.hist_code = e->d_hist_code;
         if (mb) a.tag_base = 0x80000000u | ((e->persist_seq++ & 0x7ffu) << 20); // (bit 31: a virtual-rank run -- never the tag of a sharded run's launch, which shares the boxes)
-        HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync) * (size_t)sync_blocks, e->stream));
-        if (diag) {
-            HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
-            HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
+        const bool framed = e->frame_sent && launch == 0 && !mb && sync_blocks == 1; // begin_run's copy zeroed all three
+        e->frame_sent = false;
+        if (!framed) {
+            HIPCHK(e, hipMemsetAsync(e->d_psync, 0, sizeof(PersistSync) * (size_t)sync_blocks, e->stream));
+            if (diag) {
+                HIPCHK(e, hipMemsetAsync(e->d_hist, 0, sizeof(unsigned long long) * (CCSIM_NREASON + 1), e->stream));
+                HIPCHK(e, hipMemsetAsync(e->d_hist_ts, 0, sizeof(unsigned long long) * (size_t)e->n_taintsets, e->stream));
+            }
         }
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         launch_persist(e, k, mb, grid, a);
@@ -1805,13 +1860,22 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
         // the results leave right behind the kernel, before the host knows how the launch ended: the state block, the per-node
         // counts (4 MB at 1M nodes: the step's longest transfer starts the moment the kernel ends), the diagnosis -- ONE sync
-        HIPCHK(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
-        e->early_counts = e->early_hist = false;
-        if (!mb && out && out->per_node_count && out->per_node_cap >= e->n) {
+        const bool one_copy = diag && e->ts_in_frame && !getenv("CCSIM_FRAME_OFF"); // state + histogram + per-taint-set bins: contiguous in the frame
+        if (one_copy)
+            HIPCHK(e, hipMemcpyAsync(e->h_frame, e->d_frame, kFrameOffHist + sizeof(unsigned long long) * (size_t)(CCSIM_NREASON + 1 + e->n_taintsets), hipMemcpyDeviceToHost, e->stream));
+        else
+            HIPCHK(e, hipMemcpyAsync(e->h_state, e->d_state, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        e->early_counts = e->early_hist = false, e->early_narrow = 0;
+        if (narrow) {
+            HIPCHK(e, hipMemcpyAsync(out->per_node_count_narrow, e->d_cnt_narrow, (size_t)narrow * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
+            e->early_counts = true, e->early_narrow = narrow;
+        } else if (!mb && out && out->per_node_count && out->per_node_cap >= e->n) {
             HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
             e->early_counts = true;
         }
-        if (diag) {
+        e->early_hist_framed = one_copy;
+        if (one_copy) e->early_hist = true;
+        else if (diag) {
             const size_t nts = (size_t)(e->n_taintsets > 0 ? e->n_taintsets : 1);
             if (!e->h_hist_pin || e->h_hist_ts_cap < nts) {
                 if (e->h_hist_pin) (void)hipHostFree(e->h_hist_pin);
@@ -1831,7 +1895,7 @@ static int run_persist(ccsim_engine *e, int k, ccsim_report *out) {
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->kernel_ms += ms, e->pass_kernel_ms += ms, e->pass_launches += 1;
         bool failed = e->h_state->done == DONE_ERROR;
-        if (failed || !e->h_state->done) e->early_counts = e->early_hist = false;
+        if (failed || !e->h_state->done) e->early_counts = e->early_hist = false, e->early_narrow = 0;
         if (mb && !failed) { // a rank may have given up after rank 0 wrote the state: every rank's flag counts
             std::vector<PersistSync> hs((size_t)sync_blocks);
             HIPCHK(e, hipMemcpy(hs.data(), e->d_psync, sizeof(PersistSync) * (size_t)sync_blocks, hipMemcpyDeviceToHost));
@@ -2134,7 +2198,7 @@ extern "C" int ccsim_run(ccsim_engine *e, int64_t max_limit, int32_t mode, ccsim
     }
     e->n_ranks = 0;
     e->d_xsend = e->d_xrecv = nullptr;
-    e->hist_in_kernel = e->early_counts = e->early_hist = false;
+    e->hist_in_kernel = e->early_counts = e->early_hist = false, e->early_narrow = 0;
     // a pending ccsim_reset_state is consumed by the persistent launch itself (it loads the pristine columns); every other form
     // restores the columns first
     if (!(mode == CCSIM_MODE_BATCHED && !e->time_passes && e->have_pod && persist_k(e)) && (rc = ensure_cols(e))) return rc;
@@ -3124,6 +3188,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
         e->cls_taintsets[(size_t)c] = q.n_taintsets;
         e->max_taintsets = q.n_taintsets > e->max_taintsets ? q.n_taintsets : e->max_taintsets;
     }
+    e->ts_in_frame = false;
     if ((rc = dev_alloc(e, &e->d_hist_ts, (size_t)e->max_taintsets, e->multi_allocs))) return rc;
 
     // ---- per-spec plugin state: spread count tables (+ which domains hold a counted node), inclusion arrays, anti-affinity bits
@@ -3355,6 +3420,7 @@ static int run_multi(ccsim_engine *e, int64_t max_limit, ccsim_report *out) {
         if (out->per_node_cap < e->n) return fail(e, -EINVAL, "per_node_cap too small");
         HIPCHK(e, hipMemcpyAsync(out->per_node_count, e->cols.placed_cnt, sizeof(int32_t) * (size_t)e->n, hipMemcpyDeviceToHost, e->stream));
     }
+    out->per_node_filled_width = out->per_node_count ? 4 : 0;
     if (out->per_spec_count) {
         if (out->per_spec_cap < e->n_pods) return fail(e, -EINVAL, "per_spec_cap too small");
         HIPCHK(e, hipMemcpyAsync(out->per_spec_count, e->d_per_spec, sizeof(int32_t) * (size_t)e->n_pods, hipMemcpyDeviceToHost, e->stream));

@@ -86,6 +86,8 @@ struct PersistCols {
     const int32_t *taintset_id;
     unsigned long long *hist, *hist_ts, *hist_code; // the terminal cycle's diagnosis, from the state in LDS (types.go:787-836); null = not here
     int32_t n_taintsets, cnt_assign; // cnt_assign: placed_cnt is written, not added to (first launch of a run)
+    void *cnt_narrow;               // the per-run counts once more in 1- or 2-byte elements (ccsim_report.per_node_count_narrow), nullptr = not asked for
+    int32_t cnt_narrow_width;
     int32_t *rows;                  // mailbox form: the final state goes to the commit rows (k_rows_flush publishes it once every rank agrees)
     int32_t skip_wide;              // the int64 columns are NOT written back: they are a function of the mirrors (value << unit), and the
                                     // engine re-derives them when an entry point that reads them comes along (ensure_cols: k_widen) --
@@ -1074,8 +1076,12 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             a.c.nz_mcpu[i] = (int64_t)z0, a.c.nz_mem[i] = (int64_t)z1 << sh;
         }
         a.c.pod_count[i] = np;
-        if (a.c.cnt_assign) a.c.placed_cnt[i] = np - np0;
-        else a.c.placed_cnt[i] += np - np0;
+        const int32_t pc = a.c.cnt_assign ? np - np0 : a.c.placed_cnt[i] + np - np0;
+        a.c.placed_cnt[i] = pc;
+        if (a.c.cnt_narrow) { // (the host checked that every count fits the width)
+            if (a.c.cnt_narrow_width == 1) reinterpret_cast<uint8_t *>(a.c.cnt_narrow)[i] = (uint8_t)pc;
+            else reinterpret_cast<uint16_t *>(a.c.cnt_narrow)[i] = (uint16_t)pc;
+        }
         if (diag && i < a.c.n) {
             // FitError diagnosis of the terminal cycle (types.go:787-836; the same bins as k_hist): first failing plugin in filter
             // order, NodeResourcesFit keeps all its reasons (fit.go:520-531).  The persistent form runs without extra resource columns,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CCSIM_ABI_VERSION 4
+#define CCSIM_ABI_VERSION 5
 #define CCSIM_MAX_SCALAR 8
 #define CCSIM_MAX_RES (3 + CCSIM_MAX_SCALAR)
 #define CCSIM_MAX_LABEL_COLS 32
@@ -277,6 +277,15 @@ typedef struct {
     int32_t *per_spec_count; /* optional caller-allocated [per_spec_cap]: placements per pod spec */
     int32_t per_spec_cap;
     int32_t stop_spec;       /* the spec whose pod was Unschedulable (hist describes ITS FitError), -1 otherwise */
+    /* ABI 5: the per-node counts in the narrowest element that holds them.  At 1M nodes the int32 vector is 4 MB -- 72 us over PCIe, a
+     * quarter of a whole batched run -- while no node of a cluster holds more simulated pods than its pod capacity (110 by default,
+     * `Allocatable.AllowedPodNumber`).  A caller that can read 1- or 2-byte counts offers an array of per_node_cap elements of that
+     * width; when the run's form supports it (the persistent batched launch) and every count provably fits (the snapshot's largest
+     * pod capacity < 2^(8 width)) the engine fills THAT array instead of per_node_count and says so in per_node_filled_width.
+     * Otherwise per_node_count is filled as before (offer both).  Same values either way (tests/test_persist.py). */
+    void *per_node_count_narrow;    /* optional caller-allocated [per_node_cap] elements of per_node_narrow_width bytes */
+    int32_t per_node_narrow_width;  /* in: 1 (uint8_t) or 2 (uint16_t); 0 = not offered */
+    int32_t per_node_filled_width;  /* out: 4 = per_node_count was filled, 1 / 2 = per_node_count_narrow was, 0 = neither (none offered / usable) */
 } ccsim_report;
 
 /* Result of one scheduling cycle.  Replaces ScheduleResult (S/scheduler.go:154-164) as returned by

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert n in capi.SYMBOLS, f"{n} declared in ccsim.h but not bound in capi.py"
         assert getattr(lib, n) is not None
     assert set(capi.SYMBOLS) == set(names)
-    assert lib.ccsim_abi_version() == capi.ABI_VERSION == 4
+    assert lib.ccsim_abi_version() == capi.ABI_VERSION == 5
 
 
 def test_struct_layouts_match_header_sizes():

@@ -257,3 +257,50 @@ def test_a_pod_spec_set_after_runs_of_a_finer_grained_one(ccref, mode):
     after_a.pod_count = (after_a.pod_count + ra.per_node_count).astype(np.int32)
     ref = ccref.run(prof, after_a, pod_b, max_limit=0, threads=8)
     _same(rb, ref, check_log=False)
+
+
+@pytest.mark.parametrize("frame", ["on", "off"])
+@pytest.mark.parametrize("cfg,n,limit,width", [("C3", 4096, 0, 1), ("C3", 4096, 700, 2), ("C2", 3000, 0, 1), ("C3", 777, 0, 2), ("C4", 1500, 0, 1), ("C3", 1, 0, 1)])
+def test_step_frame_and_narrow_per_node_counts(ccref, monkeypatch, frame, cfg, n, limit, width):
+    """Round 6: (1) state, histogram and sync block travel as ONE frame (one copy out, one copy back: CCSIM_FRAME_OFF=1 is the form of
+    the rounds before, three fills and three copies); (2) ABI 5: ccsim_report.per_node_count_narrow -- the per-node counts in 1- or
+    2-byte elements when the caller offers that and every count fits.  Same counts, histogram and state as the oracle either way, over
+    repeated runs on one engine (reset in between: what bench.py's timed loop does)."""
+    if frame == "off":
+        monkeypatch.setenv("CCSIM_FRAME_OFF", "1")
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=4321 + n)  # (the snapshots of test_fast_path_without_log_vs_oracle: the oracle's answers are memoized per session)
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    for it in range(3):
+        e.reset_state()
+        got = e.run(max_limit=limit, mode="batched", want_log=False, reuse_buffers=True, narrow_counts=width if it != 1 else 0)
+        assert got.per_node_count.dtype == (np.int32 if it == 1 else (np.uint8 if width == 1 else np.uint16)), (it, got.per_node_count.dtype)
+        _same(got, ref, check_log=False)
+        assert np.array_equal(got.hist_taintset[: len(ref.hist_taintset)], ref.hist_taintset)
+    st = e.read_state()
+    assert np.array_equal(st["pod_count"], nodes.pod_count + ref.per_node_count)
+    e.close()
+
+
+def test_narrow_counts_are_refused_when_a_count_may_not_fit(ccref):
+    """A node whose pod capacity is 300 may take more than 255 clones: one-byte counts are not filled (per_node_count is), two-byte
+    ones are; a run that does not take the persistent form (a placement log: the ordered path still does; sequential mode does not)
+    fills per_node_count."""
+    nodes, pod, prof = synth.make_config("C2", n_nodes=2000, seed=5)
+    nodes.alloc_pods[:] = 300
+    nodes.alloc[0][:7] = nodes.alloc[0][:7] * 8  # a few nodes large enough to hold > 255 clones
+    nodes.alloc[1][:7] = nodes.alloc[1][:7] * 8
+    ref = ccref.run(prof, nodes, pod, max_limit=0, threads=8)
+    assert ref.per_node_count.max() > 255
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    for width, dt in ((1, np.int32), (2, np.uint16)):
+        e.reset_state()
+        got = e.run(max_limit=0, mode="batched", want_log=False, reuse_buffers=True, narrow_counts=width)
+        assert got.per_node_count.dtype == dt
+        _same(got, ref, check_log=False)
+    e.reset_state()
+    got = e.run(max_limit=200, mode="sequential", want_log=False, reuse_buffers=True, narrow_counts=2)
+    assert got.per_node_count.dtype == np.int32 and got.placed == 200
+    e.close()

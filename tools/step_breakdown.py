@@ -28,12 +28,13 @@ def timed(f, reps=20):
     return ts[len(ts) // 2] * 1e3, r
 
 
-def measure(n_nodes, label):
+def measure(n_nodes, label, narrow=0):
     nodes, pod, prof = synth.make_config("C4", n_nodes=n_nodes)
     e = capi.Engine(device=0)
     e.load(nodes, pod, prof)
-    e.reset_state(); e.run(mode="batched", want_log=False, reuse_buffers=True)
-    t_pin, r1 = timed(lambda: (e.reset_state(), e.run(mode="batched", want_log=False, reuse_buffers=True))[1])
+    e.reset_state(); e.run(mode="batched", want_log=False, reuse_buffers=True, narrow_counts=narrow)
+    t_pin, r1 = timed(lambda: (e.reset_state(), e.run(mode="batched", want_log=False, reuse_buffers=True, narrow_counts=narrow))[1])
+    label += f" [per-node counts as {r1.per_node_count.dtype}]"
     t_run, r0 = timed(lambda: (e.reset_state(), e.run(mode="batched", want_log=False))[1], reps=5)
     assert np.array_equal(r0.per_node_count, r1.per_node_count) and r0.placed == r1.placed
     print(f"{label}: {n_nodes} nodes C4, batched: kernel {r1.kernel_ns / 1e6:.3f} ms | step (reset + run, page-locked result array reused) {t_pin:.3f} ms "
@@ -42,7 +43,12 @@ def measure(n_nodes, label):
 
 
 print(f"libccsim sources {B.source_sha16()}")
+measure(n, "step frame + one-byte counts (ABI 5 per_node_count_narrow)", narrow=1)
+measure(n, "step frame + two-byte counts", narrow=2)
 measure(n, "lazy restore (the launch loads the pristine columns)")
+os.environ["CCSIM_FRAME_OFF"] = "1"
+measure(n, "CCSIM_FRAME_OFF=1 (rounds 4-5: state copy + three fills before the launch, three small copies behind it)")
+del os.environ["CCSIM_FRAME_OFF"]
 os.environ["CCSIM_EAGER_RESET"] = "1"
 measure(n, "eager restore (CCSIM_EAGER_RESET=1: device-to-device copy + mirror rebuild before the launch)")
 del os.environ["CCSIM_EAGER_RESET"]
