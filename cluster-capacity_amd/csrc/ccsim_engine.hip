@@ -1326,11 +1326,14 @@ static int begin_run(ccsim_engine *e, int64_t max_limit, int mode, int64_t log_c
     if (smp_K > 0 && mode == CCSIM_MODE_BATCHED)
         return fail(e, -ENOSYS, "percentageOfNodesToScore < 100 (here: the first %lld feasible nodes of %lld) makes the outcome depend on the "
                                 "visiting order: sequential mode only", (long long)smp_K, (long long)e->n_global);
-    // on shards the sampled search is two exchanges per cycle (counts, then the max-loc: DevState::smp_phase); pods with
-    // topology-coupled plugins would need their Filter on the selected nodes only -- not in that protocol
-    if (smp_K > 0 && e->n_ranks > 0 && (e->pts.n > 0 || e->ipa.on || e->soft.n > 0))
+    // on shards the sampled search is two exchanges per cycle (counts, then the max-loc: DevState::smp_phase).  Round 6: pods with
+    // topology-coupled plugins take it too -- their Filter state is the replicated tables (the same on every rank), the counting pass
+    // filters with the assumed global minimum, the scoring pass verifies it (k_decide: a stale minimum sends the cycle back to the
+    // counting pass), and the PreScore facts (candidate domains, raw-score ranges) are gathered over the SELECTED nodes only, which is
+    // what the reference's PreScore sees (filteredNodes: schedule_one.go:757-790).  CCSIM_DIST_SMP_COUPLED=0 restores the refusal.
+    if (smp_K > 0 && e->n_ranks > 0 && (e->pts.n > 0 || e->ipa.on || e->soft.n > 0) && getenv("CCSIM_DIST_SMP_COUPLED") && atoi(getenv("CCSIM_DIST_SMP_COUPLED")) == 0)
         return fail(e, -ENOSYS, "percentageOfNodesToScore < 100 on several GPUs with topology spread constraints or inter-pod affinity: "
-                                "one GPU only, for now");
+                                "switched off (CCSIM_DIST_SMP_COUPLED=0)");
     if (smp_K != e->smp_K) drop_graph(e);
     e->smp_K = smp_K;
     if (mode == CCSIM_MODE_BATCHED && !e->pod.fit_enabled)

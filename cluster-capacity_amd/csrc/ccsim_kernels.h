@@ -259,8 +259,9 @@ struct XRec {
     int64_t win_elig;   // PodTopologySpread eligibility bits of the node
     int32_t win_pts_v[kMaxTsc];
     int32_t win_ipa_v[4];
-    int64_t pad[2];     // sampled search on shards: counting pass [0] feasible nodes of the shard, [1] those before the start index;
-                        // scoring pass [0] visiting position of the node that cancels the search (-1: not this shard's)
+    int64_t pad[2];     // sampled search on shards: counting pass [0] feasible nodes of the shard, [1] those before the start index
+                        // (scoring pass: the visiting position + 1 of the node that cancels the search rides in the upper half of win_elig);
+                        // ScheduleAnyway constraints: the best node's topology value ids (xrec_soft_ids)
 };
 static_assert(sizeof(XRec) == 32 * 8, "XRec must be CCSIM_XCHG_WORDS int64");
 // Sequential mode with ScheduleAnyway spread constraints on shards: the nine words the batched mode uses for its level plan
@@ -1460,8 +1461,17 @@ __device__ void final_body(const A &a) {
         for (int c = 0; c < kMaxTsc; c++) r.pts_min[c] = c < a.pts.n ? pts_min[c] : 0x7fffffff;
         r.ipa_mn = a.ipa.on ? ipa_mn : INT64_MAX;
         r.ipa_mx = a.ipa.on ? ipa_mx : INT64_MIN;
-        r.pad[0] = a.st->smp_K > 0 ? a.st->smp_stop : -1; // sampled search: the cancelling node's visiting position, if this shard owns it
-        if (a.soft.n) { // (never together with the sampled search on shards: begin_run)
+        // the sampled search's keys carry the VISITING POSITION of a node, not its index (k_scan<SMP = 2>): back to the node for its topology ids
+        const bool smp_rec = a.st->smp_K > 0;
+        auto key_node = [&](uint64_t k) -> int64_t {
+            int64_t g = key_index(k);
+            if (smp_rec) {
+                g += a.st->smp_start;
+                g = g >= a.st->smp_N ? g - a.st->smp_N : g;
+            }
+            return g - a.c.global_offset;
+        };
+        if (a.soft.n) {
             int64_t *w = xrec_soft(r);
             int64_t cn = 0;
             for (int x = 0; x < kThreads / 64; x++) cn += s_sf[0][x];
@@ -1469,17 +1479,20 @@ __device__ void final_body(const A &a) {
             for (int q = 0; q < kXSoftBitWords; q++) w[4 + q] = (int64_t)s_sbits[q];
             r.pad[0] = r.pad[1] = 0;
             if (key) {
-                const int64_t i = key_index(key) - a.c.global_offset;
+                const int64_t i = key_node(key);
                 w[3] = a.soft.elig[i];
                 for (int c = 0; c < a.soft.n; c++) xrec_soft_ids(r)[c] = a.soft.label[c][i];
             }
         }
         if (key && (a.pts.n || a.ipa.on)) { // topology value ids of this shard's best node
-            const int64_t i = key_index(key) - a.c.global_offset;
+            const int64_t i = key_node(key);
             r.win_elig = a.pts.n ? a.pts.elig[i] : 0;
             for (int c = 0; c < a.pts.n; c++) r.win_pts_v[c] = a.pts.label[c][i];
             for (int k = 0; k < a.ipa.n_keys; k++) r.win_ipa_v[k] = a.ipa.label[k][i];
         }
+        // sampled search: the cancelling node's visiting position, if this shard owns it -- position + 1 in the upper half of the
+        // eligibility word (its lower half are the winner's 32 eligibility bits; pad[] belongs to the soft constraints' ids)
+        if (smp_rec) r.win_elig = (int64_t)(((uint64_t)r.win_elig & 0xffffffffull) | ((uint64_t)(a.st->smp_stop + 1) << 32));
         *a.xsend = r;
         return;
     }
@@ -1505,7 +1518,9 @@ __global__ void k_decide(ScanArgs a) {
         DevState &st = *a.st;
         st.scans += 1;
         st.smp_Ftotal = total, st.smp_Fs = before, st.smp_off = off, st.smp_stop = -1;
-        if (total == 0) { // no feasible node anywhere: FitError (schedule_one.go:448-454); every node was visited
+        // (with a hard spread constraint the counting pass filtered with an ASSUMED global minimum, which only the scoring pass verifies:
+        // "no feasible node" is its verdict then -- decide_commit with an empty key, after the minimum has been checked)
+        if (total == 0 && a.pts.n == 0) { // no feasible node anywhere: FitError (schedule_one.go:448-454); every node was visited
             st.done = DONE_UNSCHEDULABLE, st.rounds += 1, st.winner = -1;
             st.last_feasible = 0, st.last_evaluated = (int32_t)st.smp_N, st.evaluated += st.smp_N;
         } else
@@ -1513,9 +1528,14 @@ __global__ void k_decide(ScanArgs a) {
         return;
     }
     const int64_t rounds_before = a.st->rounds;
+    int32_t pts_min_before[kMaxTsc];
+    for (int c = 0; c < kMaxTsc; c++) pts_min_before[c] = a.st->pts_min_a[c];
     if (smp) { // the cancelling node's position travels with its owner's record
         int64_t stop = -1;
-        for (int r = 0; r < a.n_ranks; r++) stop = a.xrecv[r].pad[0] > stop ? a.xrecv[r].pad[0] : stop;
+        for (int r = 0; r < a.n_ranks; r++) {
+            const int64_t q = (int64_t)((uint64_t)a.xrecv[r].win_elig >> 32) - 1; // (final_body: position + 1 in the upper half, 0 = not this shard's)
+            stop = q > stop ? q : stop;
+        }
         a.st->smp_stop = stop;
     }
     uint64_t key = 0;
@@ -1571,6 +1591,9 @@ __global__ void k_decide(ScanArgs a) {
     }
     decide_commit(a, key, mt, ma, nf, pts_min, ipa_mn, ipa_mx, a.soft.n ? &soft : nullptr, coupled ? &wt : nullptr);
     if (smp && (a.st->rounds != rounds_before || a.st->done)) a.st->smp_phase = 0; // the cycle ended (a stale maximum repeats the scoring pass only)
+    if (smp) // ... a stale global minimum of a hard spread constraint changes which nodes PASS: the counts are void, back to the counting pass
+        for (int c = 0; c < a.pts.n; c++)
+            if (a.st->pts_min_a[c] != pts_min_before[c]) a.st->smp_phase = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -629,20 +629,15 @@ inline RunResult simulate_sharded(const Snapshot &s, int64_t max_limit, const st
     if (s.rwop_capacity_one) throw Unsupported("a pod with a ReadWriteOncePod claim runs on one GPU (its one clone needs no shards)");
     HostProfile prof_eff = prof;
     const bool coupled = !s.spread.empty() || s.has_ipa;
-    // percentageOfNodesToScore as on one GPU (simulate() above) -- the sampled search runs on shards too (two exchanges per cycle,
-    // DESIGN.md section 5) -- except together with topology-coupled plugins, where the shards score every node
-    // on one GPU a template with a topology-coupled FILTER keeps the reference's default adaptive sampling (simulate() above), and with
-    // such a filter the reported TOTAL depends on which nodes a cycle saw -- the shards would silently report another total for the same
-    // input.  Refused, with the one flag that makes both runs the same (and valid) configuration.
-    if (coupled && s.hard_coupled() && s.n() >= 100 && !(prof.percentage_set && prof.c.percentage_of_nodes_to_score == 100))
-        throw Unsupported("--gpus " + std::to_string(n_gpus) + ": a template with a DoNotSchedule spread constraint or required inter-pod (anti-)affinity is placed on shards with "
-                          "every node scored; without --gpus it keeps the reference's default adaptive node sampling (or the percentage given), and its total may differ. "
-                          "Say --percentage-of-nodes-to-score 100 (a valid reference configuration: the same result with and without --gpus), or run on one GPU");
-    if (coupled && s.n() >= 100 && !(prof.percentage_set && prof.c.percentage_of_nodes_to_score == 100) && (prof.percentage_set || max_limit > 0 || s.hard_coupled()))
-        std::fprintf(stderr, "cluster-capacity: note: --gpus %d places a template with topology spread constraints / inter-pod affinity with every node scored "
-                             "(percentageOfNodesToScore 100); the placed set and order may differ from a one-GPU run of the reference's default adaptive sampling\n", n_gpus);
-    if (coupled) prof_eff.c.percentage_of_nodes_to_score = 100;
-    else if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = max_limit > 0 ? 0 : 100;
+    // percentageOfNodesToScore exactly as on one GPU (simulate() above): the sampled search runs on shards -- two exchanges per cycle,
+    // DESIGN.md section 5 -- and since round 6 a template with topology-coupled plugins takes it too (csrc/ccsim_kernels.h k_decide:
+    // the counting pass filters with the assumed global minimum, the scoring pass verifies it), so the same input gives the same
+    // result with and without --gpus (rounds 4-5 scored every node on shards and, from ADVICE r5 on, refused to do that silently).
+    if (!prof.percentage_set) prof_eff.c.percentage_of_nodes_to_score = (max_limit > 0 || s.hard_coupled()) ? 0 : 100;
+    if (!prof.percentage_set && coupled && s.n() >= 100 && prof_eff.c.percentage_of_nodes_to_score == 0)
+        std::fprintf(stderr, "cluster-capacity: note: a template with topology spread constraints / inter-pod affinity is placed with the reference's default "
+                             "adaptive node sampling (percentageOfNodesToScore 0: on --gpus %d two exchanges per placement); --percentage-of-nodes-to-score 100 "
+                             "scores every node per cycle (also a valid reference configuration) and runs in windows of placements per exchange\n", n_gpus);
     Marshalled m;
     marshal(s, prof_eff, m);
     const int64_t N = (int64_t)s.n(), per = (N + n_gpus - 1) / n_gpus;

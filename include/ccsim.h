@@ -243,8 +243,8 @@ typedef struct {
     /* KubeSchedulerConfiguration.percentageOfNodesToScore (schedule_one.go:697-723): 100 = every node is scored;
      * 0 = adaptive (50 - N/125, at least 5 %); below 100 the search keeps the first numFeasibleNodesToFind
      * feasible nodes of a rotating visiting order (schedule_one.go:610-680).  The sampled search is order-dependent:
-     * CCSIM_MODE_SEQUENTIAL on one GPU only (ccsim_run / ccsim_schedule_one); snapshots with fewer than 100 nodes
-     * are always searched completely. */
+     * CCSIM_MODE_SEQUENTIAL only (ccsim_run / ccsim_schedule_one; on shards two exchanges per cycle, ccsim_dist_* -- since
+     * round 6 for pods with topology-coupled plugins too); snapshots with fewer than 100 nodes are always searched completely. */
     int32_t percentage_of_nodes_to_score;
     int32_t w_imagelocality; /* default 1 (default_plugins.go:49); 0 = disabled.  No NormalizeScore. */
 } ccsim_profile;

