@@ -37,7 +37,9 @@ def test_streaming_kernels_use_no_scratch_and_do_not_spill():
     assert rows["k_multi_scan"]["ScratchSize"] == "0" and int(rows["k_multi_commit_par"]["ScratchSize"]) <= 192
     assert rows["k_multi_refresh"]["ScratchSize"] == "0" and rows["k_multi_refresh"]["VGPRs Spill"] == "0"
     for k in ("k_final", "k_decide"):  # one working copy of DevState, nothing else (not the 1.7 KB argument block)
-        assert int(rows[k]["ScratchSize"]) <= 768, (k, rows[k])
+        # (k_decide, round 6: + the eight assumed spread minima it keeps to see whether the decision moved them -- the sampled search on shards
+        # goes back to its counting pass then; a one-thread kernel, the frame is not on any throughput path)
+        assert int(rows[k]["ScratchSize"]) <= (768 if k == "k_final" else 832), (k, rows[k])
         assert rows[k]["VGPRs Spill"] == "0"
     # the throughput kernels keep >= 4 waves per SIMD for the common shapes (no extended resources)
     for k in ("k_scan<0,0,1,0>", "k_scan<0,0,0,0>", "k_level_score<0,1>", "k_level_score<0,0>", "k_level_commit<0,0>"):
