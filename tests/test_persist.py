@@ -304,3 +304,25 @@ def test_narrow_counts_are_refused_when_a_count_may_not_fit(ccref):
     got = e.run(max_limit=200, mode="sequential", want_log=False, reuse_buffers=True, narrow_counts=2)
     assert got.per_node_count.dtype == np.int32 and got.placed == 200
     e.close()
+
+
+def test_more_taint_sets_than_the_step_frame_holds(ccref):
+    """The step frame carries the FitError bins of 256 taint sets; a pod spec over more of them gets an array of its own and the launch
+    its separate fills and copies (ccsim_engine::ts_in_frame).  Same histogram per taint set as the oracle -- every set rejected by the
+    TaintToleration filter shows up in its own bin."""
+    nodes, pod, prof = synth.make_config("C3", n_nodes=3000, seed=17)
+    rng = np.random.default_rng(5)
+    n_sets = 700
+    nodes.taintset_id = rng.integers(0, n_sets, nodes.n).astype(np.int32)
+    pod.taint_filter_ok = (rng.random(n_sets) < 0.6).astype(np.uint8)
+    pod.taint_prefer_cnt = rng.integers(0, 4, n_sets).astype(np.int32)
+    ref = ccref.run(prof, nodes, pod, max_limit=0, threads=8)
+    assert (ref.hist_taintset > 0).sum() > 200
+    e = capi.Engine(device=0)
+    e.load(nodes, pod, prof)
+    for narrow in (0, 1):
+        e.reset_state()
+        got = e.run(max_limit=0, mode="batched", want_log=False, reuse_buffers=True, narrow_counts=narrow)
+        _same(got, ref, check_log=False)
+        assert np.array_equal(got.hist_taintset[: n_sets], ref.hist_taintset[: n_sets])
+    e.close()
