@@ -73,6 +73,31 @@ def test_library_driven_run_with_replicated_tables(ccref, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed,pct", [(0, 0), (1, 30), (2, 10), (3, 70)])
+def test_library_driven_sampled_search_of_a_coupled_template(ccref, seed, pct):
+    """Round 6: percentageOfNodesToScore < 100 with hard spread constraints + inter-pod affinity through ccsim_dist_run (one RCCL rank: the
+    counting and the scoring pass each end in an ncclAllGather, the tables went through ccsim_dist_sync_tables) == the oracle's visiting loop."""
+    import dataclasses
+    rng = np.random.default_rng(9100 + seed)
+    nodes, pod, prof = H.random_case(rng, int(rng.integers(150, 1500)))
+    pod.spread = H.random_spread(rng, nodes, n_constraints=2)
+    pod.ipa = H.random_ipa(rng, nodes)
+    prof.filter_mask |= M.F_FIT
+    prof = dataclasses.replace(prof, percentage_of_nodes_to_score=pct)
+    ref = ccref.run(prof, nodes, pod, max_limit=300)
+    e = capi.Engine(device=0, use_graph=False)
+    e.load(nodes, pod, prof)
+    e.dist_comm_init(capi.dist_unique_id(), 1, 0)
+    e.dist_sync_tables()
+    got = e.dist_run(300, "sequential", want_log=True, log_cap=max(1, ref.placed))
+    assert got.placed == ref.placed and got.stop == ref.stop and np.array_equal(got.log, ref.log)
+    assert got.evaluated_total == ref.evaluated_total
+    if ref.stop == M.STOP_UNSCHEDULABLE:
+        assert np.array_equal(got.hist, ref.hist)
+    e.close()
+
+
+@pytest.mark.gpu
 def test_dist_run_needs_a_communicator():
     nodes, pod, prof = synth.make_config("C3", n_nodes=600, seed=1)
     e = capi.Engine(device=0)
