@@ -1779,6 +1779,7 @@ static PersistArgs persist_args(ccsim_engine *e) {
     if (const char *f = getenv("CCSIM_PERSIST_PROF")) a.prof = atoi(f);
     if (const char *f = getenv("CCSIM_PERSIST_FAULT")) a.fault = atoi(f); // test knob: the lost-workgroup path (tests/test_persist.py)
     a.spec_cut = e->n_global < (1ll << 24) && !(getenv("CCSIM_PERSIST_SPEC") && atoi(getenv("CCSIM_PERSIST_SPEC")) == 0); // (A/B knob)
+    a.end_at_empty = !(getenv("CCSIM_PERSIST_END") && atoi(getenv("CCSIM_PERSIST_END")) == 0); // (A/B knob)
     a.hint_valid = e->persist_hint ? 1 : 0, a.hint_mt = e->persist_hint_mt, a.hint_ma = e->persist_hint_ma;
     return a;
 }

@@ -107,6 +107,7 @@ struct PersistArgs {
     int32_t prof;        // measurement runs: per-phase s_memrealtime stamps (each stamp costs a few hundred ns)
     int32_t fault;       // test knob (CCSIM_PERSIST_FAULT=1): workgroup 0 never arrives at the first barrier -- the lost-workgroup path
     int32_t spec_cut;    // every global node index fits 24 bits: the event prediction carries the node, and a blind batch may END at the event
+    int32_t end_at_empty; // a batch that ends at an event and leaves no feasible node ends the launch (no re-score pass that would find none; CCSIM_PERSIST_END=0: A/B knob)
     int32_t hint_valid, hint_mt, hint_ma; // the normalization maxima the last launch STARTED with (assumed, verified in the scores' reduce)
     // mailbox form
     int32_t n_ranks, rank;   // ranks of the job / this device's rank (virtual ranks: rank of workgroup b = b / bpr)
@@ -1020,6 +1021,14 @@ __global__ __launch_bounds__(kPThreads) void k_level_persist(PersistArgs a) {
             break;
         }
         if (event_done) {
+            // The event took the last feasible node with it (the run's last holder of a maximum is the run's last node: C4 ends this way):
+            // nothing is left to re-score -- `nfeas` is exact (the scores' reduce counted the feasible nodes, every validated batch took off
+            // the ones it filled), so the launch ends here instead of after one more re-score pass and its grid-wide reduce (round 6: 7 -> 6
+            // syncs per C4 run).  schedule_one.go:448-454: no feasible node -> FitError.
+            if (nfeas == 0 && a.end_at_empty) {
+                done = DONE_UNSCHEDULABLE, rounds += 1, last_feasible = 0;
+                break;
+            }
             rescore = true;
             ordered = want_log;
             continue;

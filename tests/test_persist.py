@@ -326,3 +326,22 @@ def test_more_taint_sets_than_the_step_frame_holds(ccref):
         _same(got, ref, check_log=False)
         assert np.array_equal(got.hist_taintset[: n_sets], ref.hist_taintset[: n_sets])
     e.close()
+
+
+@pytest.mark.parametrize("cfg,n", [("C3", 4096), ("C4", 1500), ("C2", 3000)])
+def test_a_run_that_ends_at_an_event_ends_without_one_more_pass(ccref, monkeypatch, cfg, n):
+    """Round 6: when the batch that ends at a normalization event also fills the last feasible node (the run's last holder of a maximum is
+    the run's last node), the launch ends there -- the feasible count it tracks is exact -- instead of after a re-score pass that finds
+    nothing (CCSIM_PERSIST_END=0: the rounds before).  Same result either way, one sync less where the run ends that way."""
+    nodes, pod, prof = synth.make_config(cfg, n_nodes=n, seed=4321 + n)
+    ref = ccref.run(prof, nodes, pod, max_limit=0, threads=8)
+    scans = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("CCSIM_PERSIST_END", knob)
+        got, st = _run(nodes, pod, prof, 0, want_log=False)
+        _same(got, ref, check_log=False)
+        assert np.array_equal(st["pod_count"], nodes.pod_count + ref.per_node_count)
+        scans[knob] = got.scans
+        got, _ = _run(nodes, pod, prof, 0, want_log=True)  # the ordered path
+        _same(got, ref, check_log=True)
+    assert scans["0"] - 1 <= scans["1"] <= scans["0"], scans
