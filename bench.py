@@ -469,6 +469,7 @@ def main():
             eng.reset_state(); eng.run(max_limit=limit, mode=args.mode, want_log=False, reuse_buffers=True)
             ts32.append(time.perf_counter() - v0)
         variants["int32_counts_ms_per_step"] = sorted(ts32)[len(ts32) // 2] * 1e3
+        variants["int32_counts_placements_per_s"] = r32.placed / (variants["int32_counts_ms_per_step"] * 1e-3)  # the same metric with ccsim_report.per_node_count (int32)
         variants["per_node_counts"] = (f"{counts_dtype} ({'ccsim_report.per_node_count_narrow, ABI 5: every count <= the largest pod capacity of the snapshot' if counts_dtype != 'int32' else 'ccsim_report.per_node_count'}); "
                                        "equal to the int32 vector of the same run (asserted)")
     if args.mode == "batched" and not distributed and not args.no_variants:
