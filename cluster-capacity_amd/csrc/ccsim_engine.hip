@@ -201,7 +201,7 @@ struct ccsim_engine {
     MPartial *d_mpartials = nullptr;
     MCand *d_mcands = nullptr;
     uint16_t *d_memo = nullptr;     // the score memo [n_pods][n_pad], 16-bit words (ccsim_multi.h), nullptr = off
-    int32_t *d_memo_stamp = nullptr, *d_mtouched = nullptr;
+    int32_t *d_memo_stamp = nullptr, *d_mtouched = nullptr, *d_mvsync = nullptr;
     const int32_t *tsc_label[kMTsc] = {nullptr, nullptr};
     DevPod multi_prof{};
     int32_t multi_next = 0; // spec of the next cycle (continues across runs; ccsim_reset_state rewinds it)
@@ -3085,7 +3085,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     free_list(e->pod_allocs);
     free_list(e->multi_allocs);
     e->multi = false;
-    e->d_memo = nullptr, e->d_memo_stamp = nullptr, e->d_mtouched = nullptr;
+    e->d_memo = nullptr, e->d_memo_stamp = nullptr, e->d_mtouched = nullptr, e->d_mvsync = nullptr;
     e->have_pod = e->begun = false;
     e->pts = DevPts{}, e->soft = DevSoft{}, e->ipa = DevIpa{};
     e->d_soft_pc0 = nullptr;
@@ -3276,6 +3276,7 @@ extern "C" int ccsim_set_pods(ccsim_engine *e, const ccsim_pod *pods, int32_t n_
     e->m_blocks = (int)((e->n_pad + kMBlockNodes - 1) / kMBlockNodes);
     if ((rc = dev_alloc(e, &e->d_mpartials, (size_t)kMWindowMax * (size_t)e->m_blocks, e->multi_allocs))) return rc;
     if ((rc = dev_alloc(e, &e->d_mcands, (size_t)kMWindowMax, e->multi_allocs))) return rc;
+    if ((rc = dev_alloc(e, &e->d_mvsync, (size_t)kMVsyncWords, e->multi_allocs))) return rc; // (zeroed here; k_multi_commit_par leaves it zeroed)
     if ((rc = dev_alloc(e, &e->d_per_spec, (size_t)n_pods, e->multi_allocs))) return rc;
     if ((rc = dev_alloc(e, &e->d_mstate, (size_t)1, e->multi_allocs))) return rc;
     if (!e->h_mstate) HIPCHK(e, hipHostMalloc((void **)&e->h_mstate, sizeof(MState), hipHostMallocDefault));
@@ -3319,7 +3320,7 @@ static MultiArgs multi_args(ccsim_engine *e) {
     a.tbl_pool = e->d_tbl_pool, a.present_pool = e->d_present_pool, a.inc_pool = e->d_inc_pool, a.anti_bits = e->d_anti_bits;
     a.partials = e->d_mpartials, a.n_blocks = e->m_blocks, a.cands = e->d_mcands, a.log = e->d_log, a.per_spec = e->d_per_spec;
     a.window = e->multi_window < e->n_pods ? e->multi_window : e->n_pods;
-    a.memo = e->d_memo, a.memo_stamp = e->d_memo_stamp, a.touched = e->d_mtouched;
+    a.memo = e->d_memo, a.memo_stamp = e->d_memo_stamp, a.touched = e->d_mtouched, a.vsync = e->d_mvsync;
     return a;
 }
 
@@ -3327,7 +3328,7 @@ static void launch_multi_window(ccsim_engine *e, const MultiArgs &a) {
     const int chunks = ((a.window + kMPodChunk - 1) / kMPodChunk) * kMLeanPer; // (grid.y: lean workgroups, ccsim_multi.h kMLeanChunk)
     hipLaunchKernelGGL(k_multi_scan, dim3((unsigned)e->m_blocks, (unsigned)chunks), dim3(kThreads), 0, e->stream, a);
     hipLaunchKernelGGL(k_multi_select, dim3((unsigned)a.window), dim3(64), 0, e->stream, a);
-    hipLaunchKernelGGL(k_multi_commit_par, dim3(1), dim3(kMParThreads), 0, e->stream, a); // (or, as its wave 0, the in-order commit: MState::seq_windows)
+    hipLaunchKernelGGL(k_multi_commit_par, dim3(kMParGroups), dim3(kMParThreads), 0, e->stream, a); // (or, as its wave 0, the in-order commit: MState::seq_windows)
     // the placed specs' spread masks; the touched nodes' memo words, for every stamped spec
         hipLaunchKernelGGL(k_multi_refresh, dim3((unsigned)((a.n_pods + kMRefreshThreads - 1) / kMRefreshThreads), (unsigned)kMTouched),
                            dim3(kMRefreshThreads), 0, e->stream, a);
@@ -3358,6 +3359,7 @@ static int begin_multi(ccsim_engine *e, int64_t max_limit, int64_t log_cap, int3
     HIPCHK(e, hipMemcpyAsync(e->d_mstate, e->h_mstate, sizeof(MState), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemsetAsync(e->cols.placed_cnt, 0, sizeof(int32_t) * (size_t)e->n_pad, e->stream));
     HIPCHK(e, hipMemsetAsync(e->d_per_spec, 0, sizeof(int32_t) * (size_t)e->n_pods, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_mvsync, 0, sizeof(int32_t) * (size_t)kMVsyncWords, e->stream)); // (the commit's workgroups leave it zeroed; a run that was aborted may not have)
     // the memo rows describe the columns as the last window left them; between runs anything may have touched the columns
     // (ccsim_reset_state, another pod set's run): every row starts unstamped (-1, -1) and is filled by its spec's first scan
     if (e->d_memo_stamp) HIPCHK(e, hipMemsetAsync(e->d_memo_stamp, 0xff, sizeof(int32_t) * 2 * (size_t)e->n_pods, e->stream));

@@ -38,7 +38,8 @@
 
 namespace ccsim {
 
-constexpr int kMWindowMax = 64;   // pods per window (= lanes of the commit wave holding per-pod rows)
+constexpr int kMWindowMax = 128;  // pods per window (round 6: 64 -> 128; the assignment's per-pod rows live in the lanes of the commit kernel's first two waves)
+constexpr int kMSeqMax = 64;      // ... of a window the IN-ORDER commit takes (one wave: lane = pod / touched node); MState::seq_windows caps the window
 #ifndef CCSIM_MPOD_CHUNK
 #define CCSIM_MPOD_CHUNK 2 // (build-time knob for A/B runs; round 5: 8 -> 2, see kMLeanChunk)
 #endif
@@ -58,7 +59,7 @@ static_assert(kMPodChunk % kMPodSub == 0, "pods per scan workgroup: a multiple o
 constexpr int kMNodesPerThread = 4;
 constexpr int kMBlockNodes = kThreads * kMNodesPerThread; // 1024
 constexpr int kMTopK = 8;
-constexpr int kMTouched = 64;     // touched nodes a window can hold (one per lane)
+constexpr int kMTouched = kMWindowMax; // touched nodes a window can hold (the in-order commit: kMSeqMax, one per lane)
 constexpr int kMTsc = 2;          // hard spread constraints per spec
 constexpr int kMDomMax = 63;      // value ids 0..62 per spread table
 
@@ -140,6 +141,7 @@ struct MultiArgs {
     uint16_t *memo;
     int32_t *memo_stamp;             // [n_pods][2]: the (taint, affinity) maxima the row was computed under; -1 = no row
     int32_t *touched;                // [kMTouched] shard-local indices
+    int32_t *vsync;                  // [kMVsyncWords] what k_multi_commit_par's verifying workgroups hand to workgroup 0 (zero between launches)
 };
 
 __device__ __forceinline__ uint32_t op_or_u32(uint32_t a, uint32_t b) { return a | b; }
@@ -670,13 +672,13 @@ __device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
     if (st.done || st.seq_windows <= 0 || st.committed_epoch == st.epoch) return; // (k_multi_commit_par had this window)
     st.seq_windows -= 1, st.committed_epoch = st.epoch;
     const int lane = threadIdx.x;
-    const int W = st.win_n;
-    __shared__ MPod s_pod[kMWindowMax];
-    __shared__ MCand s_cd[kMWindowMax];
-    __shared__ int32_t s_tbl[kMWindowMax][kMTsc][kMDomMax + 1]; // the pods' spread tables (their own clones only: fixed until their turn)
-    __shared__ int32_t s_min[kMWindowMax][kMTsc];
-    __shared__ uint32_t s_w[kMTouched][kMWindowMax];  // static word of touched node t for pod j
-    __shared__ uint8_t s_f[kMTouched][kMWindowMax];   // bit0 anti-affinity hit, bit 1+c counted for spread constraint c
+    const int W = st.win_n < kMSeqMax ? st.win_n : kMSeqMax; // (the commit that set seq_windows capped the window; a run that starts in this mode -- CCSIM_MULTI_SEQ -- is capped here)
+    __shared__ MPod s_pod[kMSeqMax];
+    __shared__ MCand s_cd[kMSeqMax];
+    __shared__ int32_t s_tbl[kMSeqMax][kMTsc][kMDomMax + 1]; // the pods' spread tables (their own clones only: fixed until their turn)
+    __shared__ int32_t s_min[kMSeqMax][kMTsc];
+    __shared__ uint32_t s_w[kMSeqMax][kMSeqMax];  // static word of touched node t for pod j
+    __shared__ uint8_t s_f[kMSeqMax][kMSeqMax];   // bit0 anti-affinity hit, bit 1+c counted for spread constraint c
 
     unsigned long long pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0, pf5 = 0, pf6 = 0, pf7 = 0, t_prev = __builtin_amdgcn_s_memrealtime();
 #define MTICK(v) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); v += t_now - t_prev; t_prev = t_now; } while (0)
@@ -808,7 +810,7 @@ __device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
         const int64_t g = key_index(win), li = g - a.c.global_offset;
         int slot = __ffsll((unsigned long long)__ballot(lane < nt && t_idx == li)) - 1;
         if (slot < 0) { // first placement on this node in the window: it becomes a touched node
-            if (nt >= kMTouched) {
+            if (nt >= kMSeqMax) {
                 stop_reason = 6;
                 break;
             }
@@ -892,6 +894,7 @@ __device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
         st.next_pod = st.single_pod >= 0 ? st.next_pod : (int32_t)((st.next_pod + committed) % a.n_pods);
         // the next window: as many pods as fit (all different specs; not beyond the limit)
         int64_t wn = a.window < a.n_pods ? a.window : a.n_pods;
+        if (st.seq_windows > 0 && wn > kMSeqMax) wn = kMSeqMax; // (the next window is this kernel's again)
         if (st.limit > 0 && st.limit - st.placed < wn) wn = st.limit - st.placed;
         if (st.single_pod >= 0) wn = st.done || committed ? 0 : 1;
         st.win_n = (int32_t)(wn < 0 ? 0 : wn);
@@ -918,6 +921,13 @@ __device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
 //   C  (lane j = pod j) NodeInfo.update on the distinct winners, the pods' own spread tables / anti-affinity bits.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kMParThreads = 1024;
+// Round 6: the verification is VALU time on ONE CU (a wave64 instruction takes four cycles on a 16-lane SIMD: ~2.2 us per 1024 pairs,
+// 19.7 us for the 8128 pairs of a 128-pod window) -- so kMParGroups workgroups are launched.  Every one of them runs the assignment
+// (the same inputs, the same result: nothing it reads is written before the others are done), verifies its share of the pairs and hands
+// its findings to workgroup 0 through MultiArgs::vsync; workgroup 0 waits for them, then applies.
+constexpr int kMParGroups = 8;
+constexpr int kMVsMt = kMParGroups, kMVsMa = kMVsMt + kMWindowMax, kMVsyncWords = kMVsMa + kMWindowMax; // (words 0 .. kMParGroups - 1: one per workgroup)
+constexpr int kMVsSpinLimit = 1 << 24; // (polls of the arrival word: seconds; the workgroups are co-resident -- 8 of them on 256 CUs)
 __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) {
     __shared__ MState s_st;
     __shared__ MPod s_pod[kMWindowMax];
@@ -925,40 +935,49 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     __shared__ int64_t s_win[kMWindowMax];   // shard-local node index pod j was assigned
     __shared__ uint64_t s_wkey[kMWindowMax]; // ... and its key
     __shared__ int32_t s_node[kMWindowMax][10]; // the winners' columns as the scan saw them: a0 a1 r0 r1 z0 z1 alloc_pods pods l0 l1
-    __shared__ int s_wa, s_fail, s_reason, s_unsched, s_moved;
+    __shared__ int s_wa, s_fail, s_reason, s_unsched;
     __shared__ int64_t s_pick[kMWindowMax];
     __shared__ int s_taken[kMWindowMax];
     __shared__ int s_th_mt[kMWindowMax], s_th_ma[kMWindowMax];
+    __shared__ int s_stop[kMWindowMax];
+    __shared__ uint32_t s_mag[kMWindowMax][2]; // div_magic of pod j's two normalization maxima: once per pod, not once per pair (two fp64 divisions)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: uniform, and known to the compiler as such)
     unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
 #define PT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); tp[i] += t_now - t_prev; t_prev = t_now; } while (0)
     if (tid == 0) s_st = *a.st;
     __syncthreads();
+    const int grp = (int)blockIdx.x;
     if (!s_st.done && s_st.seq_windows > 0 && s_st.committed_epoch != s_st.epoch) { // this window is the in-order commit's
-        if (wave == 0) multi_commit_inorder(a);
+        if (wave == 0 && grp == 0) multi_commit_inorder(a);
         return;
     }
     if (s_st.done || s_st.seq_windows > 0 || s_st.committed_epoch == s_st.epoch) return;
     const int W = s_st.win_n;
     const int32_t next_pod = s_st.next_pod;
+    // who takes part is decided by the window's size alone (known from the state word everybody has just read): a workgroup without a
+    // share of the W (W - 1) / 2 pairs leaves before it reads anything workgroup 0 will write; the others are all awaited
+    if (grp != 0 && grp * kMParThreads >= W * (W - 1) / 2) return;
     if (tid < W) s_pod[tid] = a.pods[(next_pod + tid) % a.n_pods], s_cd[tid] = a.cands[tid], s_th_mt[tid] = 0, s_th_ma[tid] = 0;
     if (tid == 0) s_wa = W, s_fail = W, s_reason = 0, s_unsched = -1;
     __syncthreads();
+    if (tid < W) s_mag[tid][0] = div_magic(s_cd[tid].mt), s_mag[tid][1] = div_magic(s_cd[tid].ma); // (read behind the assignment's barriers)
     PT(0);
     // (no spread tables here: assignment and verification test the spread filter through the specs' per-domain masks,
     // MPod::tsc_allow, and k_multi_refresh derives the placed specs' new masks from the tables the apply step increments)
     PT(1);
-    // ---- A: assignment.  Pod j takes the first entry of its list that no EARLIER pod of the window took.  Lane j of wave 0 =
-    // pod j (its list position, the bounds of what it skipped); whether its current candidate is held by a lower lane is
-    // asked of the WHOLE workgroup: 16 threads per pod, 4 earlier pods each, against the picks in LDS (the first form walked
-    // the 63 lower lanes with v_readlane inside wave 0: ~400 dependent instructions per round, 8.6 us per window).  A lane
-    // that finds its candidate taken moves on; repeated until nobody moves.  This reaches the in-order result: a lane only
-    // abandons a node that a LOWER lane holds, and the lowest holder of a node never moves, so a node once taken stays taken
-    // for every higher lane -- candidates only move forward, at most K steps each; a few rounds when conflicts are rare.
+    // ---- A: assignment.  Pod j takes the first entry of its list that no EARLIER pod of the window took.  Thread j of the first
+    // kMWindowMax threads (two waves since round 6: windows of up to 128 pods) = pod j (its list position, the bounds of what it
+    // skipped); whether its current candidate is held by a lower pod is asked of the WHOLE workgroup: 8 threads per pod, 16 earlier
+    // pods each, against the picks in LDS (the first form walked the lower lanes with v_readlane inside one wave: ~400 dependent
+    // instructions per round, 8.6 us per window).  A pod that finds its candidate taken moves on; repeated until nobody moves.  This
+    // reaches the in-order result: a pod only abandons a node that a LOWER pod holds, and the lowest holder of a node never moves, so a
+    // node once taken stays taken for every higher pod -- candidates only move forward, at most K steps each; a few rounds when
+    // conflicts are rare.
     {
-        const bool w0 = wave == 0;
-        const int j = lane;
-        const bool live = w0 && j < W;
+        static_assert(kMParThreads == 8 * kMWindowMax, "eight checking threads per pod");
+        const bool aw = tid < kMWindowMax; // an assignment thread (waves 0 and 1)
+        const int j = tid;
+        const bool live = aw && j < W;
         int stop = 0; // why this pod cannot be assigned (0 = it can)
         int k = 0;
         uint64_t bound = 0;
@@ -973,22 +992,24 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
         int64_t pick = live && !stop && cd.n > 0 ? key_index(cd.key[0]) - a.c.global_offset : -1;
 #pragma unroll 1
         for (int round = 0; round < kMTopK * kMWindowMax + 2; round++) {
-            if (w0) s_pick[lane] = pick;
+            if (aw) s_pick[tid] = pick;
             __syncthreads();
-            { // thread (pod jp, quarter tq): is pod jp's candidate one of the picks of pods tq, tq + 16, tq + 32, tq + 48 below it?
-                const int jp = tid >> 4, tq = tid & 15;
+            bool hit = false;
+            { // thread (pod jp, eighth tq): is pod jp's candidate one of the picks of pods tq, tq + 8, ... below it?
+                const int jp = tid >> 3, tq = tid & 7;
                 const int64_t mine = s_pick[jp];
-                bool hit = false;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int t = tq + 16 * i;
+                for (int i = 0; i < kMWindowMax / 8; i++) {
+                    const int t = tq + 8 * i;
                     hit = hit || (t < jp && mine >= 0 && s_pick[t] == mine);
                 }
                 const unsigned long long b = __ballot(hit);
-                if (tq == 0) s_taken[jp] = (int)((b >> (lane & 48)) & 0xffffull); // (the pod's 16 threads are 16 consecutive lanes)
+                if (tq == 0) s_taken[jp] = (int)((b >> (lane & 56)) & 0xffull); // (the pod's 8 threads are 8 consecutive lanes)
             }
-            __syncthreads();
-            const bool taken = w0 && s_taken[lane] != 0;
+            // (the barrier behind the verdicts also says whether anybody moves: two barriers a round -- the next round's picks are
+            // written behind this one, its verdicts behind the next)
+            const bool any_moves = __syncthreads_or(hit ? 1 : 0) != 0;
+            const bool taken = aw && s_taken[tid] != 0;
             if (taken) { // move on: remember the scan workgroup of the entry skipped
                 const int64_t blk = pick / kMBlockNodes;
                 int cnt2 = 0;
@@ -1006,14 +1027,10 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
                 k++;
                 pick = k < cd.n ? key_index(cd.key[k < kMTopK ? k : 0]) - a.c.global_offset : -1;
             }
-            if (w0) {
-                const bool any = __ballot(taken) != 0;
-                if (lane == 0) s_moved = any ? 1 : 0;
-            }
-            __syncthreads();
-            if (!s_moved) break;
+            if (!any_moves) break;
         }
-        if (w0) {
+        // the first pod that cannot be assigned ends the window: its index and reason, over both assignment waves
+        if (aw) {
             uint64_t ukey = 0;
             if (live && !stop) {
                 if (k >= cd.n) { // the list ran out
@@ -1024,15 +1041,17 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
                     if (bound && ukey < bound) stop = 4; // what the list hides may beat the candidate: the next scan will know
                 }
             }
+            s_stop[tid] = live ? stop : 0;
+            s_win[tid] = pick, s_wkey[tid] = ukey; // (entries at and behind the stop are not read)
+            // (a wrong assumed maximum, stop == 1, is repaired by workgroup 0 once the other workgroups have read the pods: below)
             const uint64_t stopped = __ballot(live && stop != 0);
-            const int wa = stopped ? __ffsll((unsigned long long)stopped) - 1 : W;
-            if (lane < wa) s_win[lane] = pick, s_wkey[lane] = ukey;
-            const int reason = stopped ? __builtin_amdgcn_readlane(stop, wa < 64 ? wa : 0) : 0;
-            if (stop == 1 && live) { // repair every wrong maximum of the window at once (one window fixes a whole cycle of specs)
-                const int pj = (next_pod + j) % a.n_pods;
-                a.pods[pj].mt_a = (int32_t)cd.mt, a.pods[pj].ma_a = (int32_t)cd.ma;
-            }
-            if (lane == 0) s_wa = wa, s_reason = reason, s_unsched = reason == 2 ? wa : -1;
+            if (stopped && lane == 0) atomicMin(&s_wa, (wave << 6) + __ffsll((unsigned long long)stopped) - 1); // (s_wa starts at W)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int wa0 = s_wa;
+            const int reason = wa0 < W ? s_stop[wa0] : 0;
+            s_reason = reason, s_unsched = reason == 2 ? wa0 : -1;
         }
     }
     __syncthreads();
@@ -1067,11 +1086,13 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     {
         const int npairs = wa * (wa - 1) / 2;
         DevPod p = a.prof;
-        int pj[2], pt[2];
-        uint32_t wv[2], bv[2];
+        constexpr int kAll = kMParThreads * kMParGroups; // verifying threads of the launch
+        constexpr int kPer = (kMWindowMax * (kMWindowMax - 1) / 2 + kAll - 1) / kAll; // pairs per thread: 1 at 128 pods over 8 workgroups
+        int pj[kPer], pt[kPer];
+        uint32_t wv[kPer], bv[kPer];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int pp = tid + i * kMParThreads;
+        for (int i = 0; i < kPer; i++) {
+            const int pp = grp * kMParThreads + tid + i * kAll;
             const bool on = pp < npairs;
             // pair index -> (j, t), t < j: j (j - 1) / 2 <= pp < (j + 1) j / 2
             int j = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)pp)) * 0.5f);
@@ -1084,7 +1105,7 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
             bv[i] = on && q.anti ? a.anti_bits[(int64_t)((next_pod + j) % a.n_pods) * (a.n_pad / 32) + (n >> 5)] : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < kPer; i++) {
             const int j = pj[i], t = pt[i];
             if (j < 0) continue;
             const MPod &q = s_pod[j];
@@ -1110,11 +1131,66 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
                     ok = ((q.tsc_allow[c] >> (v < 0 || v > kMDomMax ? 0 : v)) & 1ull) != 0;
                 }
             if (!ok) continue;
-            const int64_t total = static_score(p, cnt, aff, img, cd.mt, cd.ma) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1);
+            const int64_t total = static_score(p, cnt, aff, img, cd.mt, cd.ma, s_mag[j][0], s_mag[j][1]) + dynamic_score_narrow(p, nq, a0, a1, r0, r1, z0, z1);
             if (make_key(total, a.c.global_offset + n) > s_wkey[j]) atomicMin(&s_fail, j); // pod j prefers a node an earlier pod took
         }
     }
     __syncthreads();
+    { // the other workgroups' findings -> workgroup 0.  ONE word per workgroup (arrived | it sent counts << 1 | (kMWindowMax - its first
+      // failing pod) << 8), stored with release semantics and polled by lane g of workgroup 0's first wave: the hand-over is one trip to
+      // L2 on either side (the first form -- an arrival counter, a word for the failure, the counts read behind a barrier -- was four
+      // dependent trips: 6 us of the 8.5 us phase).  The counts of taken holders of a normalization maximum travel only for a pod
+      // whose maximum is not zero (a maximum of zero cannot move: the test below does not read them).
+        const int npairs = W * (W - 1) / 2; // (of the window as it was scanned: a window the assignment cut short is awaited all the same)
+        if (grp != 0) {
+            bool sent = false;
+            if (tid < wa) {
+                const MCand &cd = s_cd[tid];
+                if (cd.mt > 0 && s_th_mt[tid]) atomicAdd(&a.vsync[kMVsMt + tid], s_th_mt[tid]), sent = true;
+                if (cd.ma > 0 && s_th_ma[tid]) atomicAdd(&a.vsync[kMVsMa + tid], s_th_ma[tid]), sent = true;
+            }
+            if (sent) __threadfence();
+            const int any = __syncthreads_or(sent ? 1 : 0);
+            if (tid == 0) {
+                const int f = s_fail;
+                __hip_atomic_store(&a.vsync[grp], 1 | (any ? 2 : 0) | ((f < wa ? kMWindowMax - f : 0) << 8), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        int expect = 0;
+        for (int g = 1; g < kMParGroups; g++) expect += g * kMParThreads < npairs ? 1 : 0;
+        if (expect) { // (workgroups 1 .. expect take part)
+            __shared__ int s_sent;
+            if (tid == 0) s_sent = 0;
+            if (wave == 0) {
+                const bool mine = lane >= 1 && lane <= expect;
+                int v = 0, spins = 0;
+                while (true) {
+                    if (mine && !v) v = __hip_atomic_load(&a.vsync[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__ballot(mine && !v) == 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kMVsSpinLimit) __builtin_trap(); // (fail loudly: the launch aborts, the engine reports -EIO)
+                }
+                if (mine) {
+                    a.vsync[lane] = 0; // (zero again for the next launch)
+                    if (v >> 8) atomicMin(&s_fail, kMWindowMax - (v >> 8));
+                    if (v & 2) s_sent = 1;
+                }
+            }
+            __syncthreads();
+            if (s_sent && tid < wa) {
+                const int m = __hip_atomic_load(&a.vsync[kMVsMt + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int f = __hip_atomic_load(&a.vsync[kMVsMa + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (m) s_th_mt[tid] += m, a.vsync[kMVsMt + tid] = 0;
+                if (f) s_th_ma[tid] += f, a.vsync[kMVsMa + tid] = 0;
+            }
+        }
+        // every workgroup has read the window's pods: a wrong assumed maximum is repaired now (one window fixes a whole cycle of specs)
+        if (tid < W && s_stop[tid] == 1) {
+            const int pj = (next_pod + tid) % a.n_pods;
+            a.pods[pj].mt_a = (int32_t)s_cd[tid].mt, a.pods[pj].ma_a = (int32_t)s_cd[tid].ma;
+        }
+    }
     if (tid < wa) { // a normalization maximum may have moved if every holder the scan counted is among the taken nodes
         const MPod &q = s_pod[tid];
         const MCand &cd = s_cd[tid];
@@ -1171,6 +1247,7 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
         // windows that keep ending early because pods prefer taken nodes: the in-order commit handles that regime
         if (reason == 3 && ok_n < 4 && W >= 16) st.seq_windows = 4;
         int64_t wn = a.window < a.n_pods ? a.window : a.n_pods;
+        if (st.seq_windows > 0 && wn > kMSeqMax) wn = kMSeqMax; // (the in-order commit holds a pod / a touched node per lane)
         if (st.limit > 0 && st.limit - st.placed < wn) wn = st.limit - st.placed;
         if (st.single_pod >= 0) wn = st.done || ok_n ? 0 : 1;
         st.win_n = (int32_t)(wn < 0 ? 0 : wn);

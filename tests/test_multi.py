@@ -91,7 +91,7 @@ def test_oracle_two_specs_hand_case(ccref):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", ["1", "7", "64"])
+@pytest.mark.parametrize("window", ["1", "7", "64", "128"])  # (128: round 6, the assignment over two waves; the in-order fallback stays at 64)
 @pytest.mark.parametrize("seed", range(10))
 def test_random_specs_vs_oracle(ccref, monkeypatch, window, seed):
     monkeypatch.setenv("CCSIM_MULTI_WINDOW", window)
@@ -281,3 +281,28 @@ def test_refused_spec_sets_take_one_cycle_at_a_time_vs_oracle(ccref, kind, seed)
     assert refused, "the case was meant to be outside the window engine's shape"
     got = cli.simulate_specs_one_cycle_at_a_time(nodes, pods, prof, limit)
     _same(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq", ["0", "1"])
+@pytest.mark.parametrize("seed", range(6))
+def test_windows_of_128_pods_vs_oracle(ccref, monkeypatch, seed, seq):
+    """Round 6: windows of up to 128 pods (the assignment's per-pod rows in the lanes of TWO waves, eight checking threads per pod,
+    up to eight pairs per thread in the verification), with more specs than a window holds; `seq`: the in-order commit forced -- it holds
+    a pod / a touched node per lane of ONE wave and takes at most 64 pods of a window the scan prepared for 128.  Whole runs (nodes
+    filling up, maxima re-derived, windows ending early) and limits inside a window == the oracle's round-robin loop."""
+    if seq == "1":
+        monkeypatch.setenv("CCSIM_MULTI_SEQ", "1")
+    rng = np.random.default_rng(9900 + seed)
+    nodes, pods, prof = random_multi_case(rng, int(rng.integers(400, 2500)), int(rng.integers(130, 400)))
+    limit = int(rng.choice([0, 0, 777, 3000]))
+    ref = ccref.run_multi(prof, nodes, pods, max_limit=limit, threads=8)
+    e = capi.Engine(device=0)
+    e.load(nodes, pods, prof)
+    got = e.run(max_limit=limit, log_cap=max(1, ref.placed))
+    _same(got, ref)
+    if seq == "0" and ref.placed > 2000:
+        assert got.scans < ref.placed / 20, (got.scans, ref.placed)  # windows really were windows
+    e.reset_state()
+    _same(e.run(max_limit=limit, log_cap=max(1, ref.placed)), ref)
+    e.close()

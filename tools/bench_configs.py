@@ -103,7 +103,7 @@ def c5(n_nodes, n_specs, limit):
     pods_per_pass = r.placed / max(1, r.scans)
     print(f"| C5: {n_specs} genpod-shaped specs round-robin (zone DoNotSchedule spread + hostname anti-affinity to their own label), "
           f"{limit:,} placements | {n_nodes:,} | oracle OMP x{threads} {ref.placed / t_cpu:,.0f}/s (first {cycles} cycles) | "
-          f"GPU windows of <= 64 pods: {r.placed:,} placements in {dt * 1e3:.1f} ms = {r.placed / dt:,.0f}/s ({r.scans} passes, "
+          f"GPU windows of <= 128 pods: {r.placed:,} placements in {dt * 1e3:.1f} ms = {r.placed / dt:,.0f}/s ({r.scans} passes, "
           f"{pods_per_pass:.1f} pods per pass, {r.pass_launches} passes ended early by the exact validation) | "
           f"algorithmic bytes per placement = N x 92 B / pods per pass = {n_nodes * 92 / pods_per_pass / 1e3:,.0f} KB "
           f"(one cycle per pass: {n_nodes * 92 / 1e6:.1f} MB) |")

@@ -40,11 +40,11 @@ f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/s
 rm -rf $O/ks
 cd /root/repo
 # config 5 (1024 pod specs): throughput line
-timeout 300 python tools/bench_c5.py 100000 1024 200000 64 2>&1 | grep -v amdgpu.ids | tee $O/bench_c5.txt | cut -c1-300
-( cd /tmp && rm -rf $O/ks && CCSIM_MULTI_MEMO_MB=65536 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python /root/repo/tools/bench_c5.py 100000 1024 100000 64 > /dev/null 2> $O/ks.err
+timeout 300 python tools/bench_c5.py 100000 1024 200000 128,64 2>&1 | grep -v amdgpu.ids | tee $O/bench_c5.txt | cut -c1-300
+( cd /tmp && rm -rf $O/ks && CCSIM_MULTI_MEMO_MB=65536 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -o ks -- python /root/repo/tools/bench_c5.py 100000 1024 100000 128 > /dev/null 2> $O/ks.err
   f=$(find $O/ks -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/c5_kernel_stats.csv && cut -c1-200 $O/c5_kernel_stats.csv | head -8; rm -rf $O/ks )
 ( cd /tmp && for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
-    rm -rf $O/pmc_c5; CCSIM_MULTI_MEMO_MB=65536 timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_c5 -o p -- python /root/repo/tools/bench_c5.py 100000 1024 20000 64 > /dev/null 2> $O/pmc_c5.err
+    rm -rf $O/pmc_c5; CCSIM_MULTI_MEMO_MB=65536 timeout 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_c5 -o p -- python /root/repo/tools/bench_c5.py 100000 1024 20000 128 > /dev/null 2> $O/pmc_c5.err
     f=$(find $O/pmc_c5 -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 /root/repo/tools/pmc_summary.py "$f" | grep multi; rm -rf $O/pmc_c5
   done ) 2>&1 | tee $O/c5_pmc_summary.txt | cut -c1-250
 timeout 120 python tools/persist_prof.py 1000000 8 1024 2>&1 | grep -v amdgpu.ids | tee $O/persist_phase_profile.txt | cut -c1-330
