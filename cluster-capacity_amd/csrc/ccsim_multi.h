@@ -650,6 +650,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
     }
 }
 
+constexpr int kMParThreads = 1024;
+// Round 6: the verification is VALU time on ONE CU (a wave64 instruction takes four cycles on a 16-lane SIMD: ~2.2 us per 1024 pairs,
+// 19.7 us for the 8128 pairs of a 128-pod window) -- so kMParGroups workgroups are launched.  Every one of them runs the assignment
+// (the same inputs, the same result: nothing it reads is written before the others are done), verifies its share of the pairs and hands
+// its findings to workgroup 0 through MultiArgs::vsync; workgroup 0 waits for them, then applies.
+constexpr int kMParGroups = 8;
+constexpr int kMVsMt = kMParGroups, kMVsMa = kMVsMt + kMWindowMax, kMVsHdr = kMVsMa + kMWindowMax, kMVsyncWords = kMVsHdr + 4; // (words 0 .. kMParGroups - 1: one per workgroup)
+// kMVsHdr: (the window is the parallel commit's, its pods, its first pod) as k_multi_select saw them.  Workgroup 0 is the only reader and
+// writer of MState in the commit's launch; the others must not look at it -- workgroup 0 rewrites it at the end (a struct store: not
+// atomic), and a workgroup dispatched late would act on a torn or a new state, find itself a share and leave a stale arrival word behind.
+constexpr int kMVsSpinLimit = 1 << 24; // (polls of the arrival word: seconds; the workgroups are co-resident -- 8 of them on 256 CUs)
+
 // ------------------------------------------------------------------------------------------------------------------
 // k_multi_select: one wave per pod of the window (multi_select_pod).  Round 5 tried the selection in the scan's TAIL (the last workgroup
 // of a pod chunk to deliver its partials selects for the chunk: a ticket per chunk): with a release fence per workgroup the scan became a
@@ -658,6 +670,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_multi_select(MultiArgs a) {
     const int32_t done = a.st->done, win_n = a.st->win_n, next_pod = a.st->next_pod;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // what k_multi_commit_par's workgroups 1 .. 7 go by (kMVsHdr): nothing in that launch writes these words
+        a.vsync[kMVsHdr + 0] = !done && a.st->seq_windows <= 0 ? 1 : 0; // the window is the parallel commit's
+        a.vsync[kMVsHdr + 1] = win_n, a.vsync[kMVsHdr + 2] = next_pod;
+    }
     if (done || (int)blockIdx.x >= win_n) return;
     multi_select_pod(a, (int)blockIdx.x, next_pod);
 }
@@ -920,14 +936,6 @@ __device__ __forceinline__ void multi_commit_inorder(const MultiArgs &a) {
 //      in-order commit takes over for a while (st.seq_windows);
 //   C  (lane j = pod j) NodeInfo.update on the distinct winners, the pods' own spread tables / anti-affinity bits.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kMParThreads = 1024;
-// Round 6: the verification is VALU time on ONE CU (a wave64 instruction takes four cycles on a 16-lane SIMD: ~2.2 us per 1024 pairs,
-// 19.7 us for the 8128 pairs of a 128-pod window) -- so kMParGroups workgroups are launched.  Every one of them runs the assignment
-// (the same inputs, the same result: nothing it reads is written before the others are done), verifies its share of the pairs and hands
-// its findings to workgroup 0 through MultiArgs::vsync; workgroup 0 waits for them, then applies.
-constexpr int kMParGroups = 8;
-constexpr int kMVsMt = kMParGroups, kMVsMa = kMVsMt + kMWindowMax, kMVsyncWords = kMVsMa + kMWindowMax; // (words 0 .. kMParGroups - 1: one per workgroup)
-constexpr int kMVsSpinLimit = 1 << 24; // (polls of the arrival word: seconds; the workgroups are co-resident -- 8 of them on 256 CUs)
 __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) {
     __shared__ MState s_st;
     __shared__ MPod s_pod[kMWindowMax];
@@ -944,19 +952,23 @@ __global__ __launch_bounds__(kMParThreads) void k_multi_commit_par(MultiArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: uniform, and known to the compiler as such)
     unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memrealtime();
 #define PT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); tp[i] += t_now - t_prev; t_prev = t_now; } while (0)
-    if (tid == 0) s_st = *a.st;
-    __syncthreads();
     const int grp = (int)blockIdx.x;
-    if (!s_st.done && s_st.seq_windows > 0 && s_st.committed_epoch != s_st.epoch) { // this window is the in-order commit's
-        if (wave == 0 && grp == 0) multi_commit_inorder(a);
-        return;
+    // Who takes part is decided by the window's size alone, and workgroups 1 .. 7 learn it from the words k_multi_select left (kMVsHdr),
+    // never from MState: a workgroup without a share of the W (W - 1) / 2 pairs leaves before it reads anything workgroup 0 will write;
+    // the others are all awaited.
+    const int32_t h_par = a.vsync[kMVsHdr + 0], h_w = a.vsync[kMVsHdr + 1], h_next = a.vsync[kMVsHdr + 2];
+    if (grp != 0 && (!h_par || grp * kMParThreads >= h_w * (h_w - 1) / 2)) return;
+    if (tid == 0 && grp == 0) s_st = *a.st;
+    __syncthreads();
+    if (grp == 0) {
+        if (!s_st.done && s_st.seq_windows > 0 && s_st.committed_epoch != s_st.epoch) { // this window is the in-order commit's
+            if (wave == 0) multi_commit_inorder(a);
+            return;
+        }
+        if (s_st.done || s_st.seq_windows > 0 || s_st.committed_epoch == s_st.epoch) return;
     }
-    if (s_st.done || s_st.seq_windows > 0 || s_st.committed_epoch == s_st.epoch) return;
-    const int W = s_st.win_n;
-    const int32_t next_pod = s_st.next_pod;
-    // who takes part is decided by the window's size alone (known from the state word everybody has just read): a workgroup without a
-    // share of the W (W - 1) / 2 pairs leaves before it reads anything workgroup 0 will write; the others are all awaited
-    if (grp != 0 && grp * kMParThreads >= W * (W - 1) / 2) return;
+    const int W = grp == 0 ? s_st.win_n : h_w; // (the same: k_multi_select wrote the header from the state workgroup 0 reads)
+    const int32_t next_pod = grp == 0 ? s_st.next_pod : h_next;
     if (tid < W) s_pod[tid] = a.pods[(next_pod + tid) % a.n_pods], s_cd[tid] = a.cands[tid], s_th_mt[tid] = 0, s_th_ma[tid] = 0;
     if (tid == 0) s_wa = W, s_fail = W, s_reason = 0, s_unsched = -1;
     __syncthreads();
