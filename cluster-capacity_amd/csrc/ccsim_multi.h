@@ -433,7 +433,10 @@ __device__ __forceinline__ void multi_scan_lean(const MultiArgs &a, const int ne
 // columns and the first pods' words are issued before the staging barriers, the pod descriptors come from LDS, the words of
 // pod j + kMPodSub are fetched into the registers pod j just released, and the per-pod reductions meet at ONE barrier.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads, 4) void k_multi_scan(MultiArgs a) {
+#ifndef CCSIM_MSCAN_OCC
+#define CCSIM_MSCAN_OCC 4 // (build-time knob for A/B runs: waves per SIMD the register allocation must leave room for)
+#endif
+__global__ __launch_bounds__(kThreads, CCSIM_MSCAN_OCC) void k_multi_scan(MultiArgs a) {
     const int32_t done = a.st->done, win_n = a.st->win_n, next_pod = a.st->next_pod; // (not the whole MState: it would sit in ~60 SGPRs)
     if (done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (wave: uniform, and known to the compiler as such)
