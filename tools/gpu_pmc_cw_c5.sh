@@ -10,7 +10,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   CCSIM_BENCH_SKIP_SEQ=1 timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p -o p -- python /root/repo/tools/bench_coupled.py 1000000 50000 4096,64 > /dev/null 2> $O/p.err
   f=$(find $O/p -name "*counter_collection.csv" | head -1); [ -n "$f" ] && { echo "== coupled 1M / 64 zones, $set"; python3 /root/repo/tools/pmc_summary.py "$f" | grep "k_cw"; }
   rm -rf $O/p
-  CCSIM_MULTI_MEMO_MB=65536 timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p -o p -- python /root/repo/tools/bench_c5.py 100000 1024 50000 64 > /dev/null 2> $O/p.err
+  CCSIM_MULTI_MEMO_MB=65536 timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p -o p -- python /root/repo/tools/bench_c5.py 100000 1024 50000 128 > /dev/null 2> $O/p.err
   f=$(find $O/p -name "*counter_collection.csv" | head -1); [ -n "$f" ] && { echo "== config 5 (100k x 1024, memo on), $set"; python3 /root/repo/tools/pmc_summary.py "$f" | grep "k_multi"; }
   rm -rf $O/p
 done 2>&1 | tee $O/pmc_cw_c5.txt
